@@ -1,0 +1,750 @@
+/*
+ * oracle/speckv_oracle.c -- CPU restatement of the FastLM/CXL-SpecKV hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see speckv_oracle.h).  Plain C99, single thread,
+ * written from the behaviour of the reference (citations are file:line under
+ * /root/reference); no reference source is copied.
+ *
+ * Build: gcc -O2 -std=c99 -ffp-contract=off -fno-fast-math (oracle/Makefile).
+ * The float paths rely on IEEE single arithmetic with one rounding per
+ * operation, which is what the reference gets from g++ -O2 on x86-64 (SSE2).
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "speckv_oracle.h"
+
+#include <fcntl.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+/* ================================================================== */
+/* fp16                                                                */
+/* ================================================================== */
+static uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static float    u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+float orc_half_to_float(uint16_t h)
+{
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp  = (h >> 10) & 0x1Fu;
+    uint32_t man  = h & 0x3FFu;
+    if (exp == 0) {
+        if (man == 0) return u2f(sign);
+        /* subnormal: man * 2^-24 */
+        float v = (float)man * (1.0f / 16777216.0f);
+        return u2f(f2u(v) | sign);
+    }
+    if (exp == 31) return u2f(sign | 0x7F800000u | (man << 13));
+    return u2f(sign | ((exp + 112u) << 23) | (man << 13));
+}
+
+uint16_t orc_float_to_half(float f)
+{
+    uint32_t u = f2u(f);
+    uint32_t sign = (u >> 16) & 0x8000u;
+    uint32_t a = u & 0x7FFFFFFFu;
+    if (a >= 0x7F800000u) {               /* inf / nan */
+        if (a == 0x7F800000u) return (uint16_t)(sign | 0x7C00u);
+        uint32_t m = (a >> 13) & 0x3FFu;
+        return (uint16_t)(sign | 0x7C00u | m | 0x200u); /* quiet */
+    }
+    if (a >= 0x477FF000u)                 /* rounds to >= 65520 -> inf */
+        return (uint16_t)(sign | 0x7C00u);
+    if (a < 0x33000001u)                  /* <= 2^-25 -> 0 (tie to even) */
+        return (uint16_t)sign;
+    int32_t e = (int32_t)(a >> 23) - 127;
+    uint32_t m = (a & 0x7FFFFFu) | 0x800000u;  /* 24-bit significand */
+    uint32_t shift, half;
+    if (e < -14) {                        /* subnormal half */
+        shift = (uint32_t)(13 + (-14 - e));
+        half = 0;
+    } else {
+        shift = 13;
+        half = (uint32_t)(e + 15) << 10;
+    }
+    uint32_t q = m >> shift;
+    uint32_t rem = m & ((1u << shift) - 1u);
+    uint32_t halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (q & 1u))) q++;
+    if (e < -14) return (uint16_t)(sign | q);          /* carry into exp is fine */
+    /* q has the implicit bit at position 10 */
+    return (uint16_t)(sign | (half + q - 0x400u));
+}
+
+/* ================================================================== */
+/* host allocator ids                                                  */
+/* ================================================================== */
+uint64_t orc_virt_page_id(uint64_t handle, uint64_t i)
+{   /* speckv_allocator.cpp:24 */
+    return (handle << 32) | (i << 12);
+}
+uint64_t orc_phys_page_id(uint64_t handle, uint64_t i)
+{   /* speckv_allocator.cpp:25 */
+    return 0x4000000000ULL + (handle << 20) + (i << 12);
+}
+uint64_t orc_num_pages(uint64_t bytes)
+{   /* speckv_allocator.cpp:18-19 */
+    return (bytes + ORC_PAGE_SIZE - 1) / ORC_PAGE_SIZE;
+}
+uint64_t orc_desc_gpu_addr(uint64_t virt_page_id)
+{   /* speckv_allocator.cpp:123 */
+    return 0x8000000000ULL + (virt_page_id & 0xFFFFFFFFFFFFULL);
+}
+uint64_t orc_encode_virt_page(uint32_t req_id, uint16_t layer, uint16_t head,
+                              uint32_t pos, uint8_t kind)
+{   /* speckv_allocator.cpp:92-103 */
+    return ((uint64_t)req_id << 32) | ((uint64_t)layer << 16) |
+           ((uint64_t)head << 8) | ((uint64_t)pos << 1) | (uint64_t)kind;
+}
+
+/* ---- C ABI model -------------------------------------------------- */
+typedef struct {
+    uint64_t handle;
+    uint64_t size_bytes;
+    uint64_t n_pages;
+    uint32_t* flags;     /* page_table_ copy flags (speckv_allocator.cpp:135) */
+    int live;
+} orc_allocation_t;
+
+struct orc_cabi {
+    int initialized;
+    uint64_t next_handle;
+    orc_allocation_t* allocs;
+    size_t n_allocs, cap_allocs;
+};
+
+orc_cabi_t* orc_cabi_new(void)
+{
+    orc_cabi_t* c = (orc_cabi_t*)calloc(1, sizeof(*c));
+    c->next_handle = 1;
+    return c;
+}
+static void cabi_drop_all(orc_cabi_t* c)
+{
+    for (size_t i = 0; i < c->n_allocs; ++i) free(c->allocs[i].flags);
+    free(c->allocs);
+    c->allocs = NULL; c->n_allocs = c->cap_allocs = 0;
+    c->next_handle = 1;   /* a new SpeckvAllocator starts at 1 (speckv_allocator.hpp:57) */
+}
+void orc_cabi_delete(orc_cabi_t* c) { if (c) { cabi_drop_all(c); free(c); } }
+
+int orc_cabi_init(orc_cabi_t* c, const char* dev_path)
+{   /* speckv_c_api.cpp:13-32, speckv_driver.cpp:11-16 */
+    if (c->initialized) return -1;
+    int fd = dev_path ? open(dev_path, O_RDWR) : -1;
+    if (fd < 0) return -1;            /* ctor throws -> catch(...) -> GENERAL */
+    close(fd);
+    c->initialized = 1;
+    return 0;
+}
+void orc_cabi_finalize(orc_cabi_t* c)
+{   /* speckv_c_api.cpp:34-39 */
+    cabi_drop_all(c);
+    c->initialized = 0;
+}
+static orc_allocation_t* cabi_find(orc_cabi_t* c, uint64_t h)
+{
+    for (size_t i = 0; i < c->n_allocs; ++i)
+        if (c->allocs[i].live && c->allocs[i].handle == h) return &c->allocs[i];
+    return NULL;
+}
+int orc_cabi_alloc(orc_cabi_t* c, uint64_t bytes, uint64_t* out)
+{   /* speckv_c_api.cpp:41-53, speckv_allocator.cpp:11-38 */
+    if (!c->initialized || !out) return -4;
+    if (c->n_allocs == c->cap_allocs) {
+        c->cap_allocs = c->cap_allocs ? 2 * c->cap_allocs : 16;
+        c->allocs = (orc_allocation_t*)realloc(c->allocs, c->cap_allocs * sizeof(orc_allocation_t));
+    }
+    orc_allocation_t* a = &c->allocs[c->n_allocs++];
+    a->handle = c->next_handle++;
+    a->size_bytes = bytes;
+    a->n_pages = orc_num_pages(bytes);
+    a->flags = (uint32_t*)calloc(a->n_pages ? a->n_pages : 1, sizeof(uint32_t));
+    a->live = 1;
+    *out = a->handle;
+    return 0;
+}
+int orc_cabi_free(orc_cabi_t* c, uint64_t h)
+{   /* speckv_c_api.cpp:55-64, speckv_allocator.cpp:40-52 : unknown -> OK */
+    if (!c->initialized) return -4;
+    orc_allocation_t* a = cabi_find(c, h);
+    if (a) { a->live = 0; free(a->flags); a->flags = NULL; }
+    return 0;
+}
+int orc_cabi_access(orc_cabi_t* c, uint64_t h, uint64_t off, uint64_t len, uint64_t* out)
+{   /* speckv_c_api.cpp:66-83, speckv_allocator.cpp:54-74 ; len ignored */
+    (void)len;
+    if (!c->initialized || !out) return -4;
+    orc_allocation_t* a = cabi_find(c, h);
+    if (!a) return -1;
+    uint64_t page_idx = off / ORC_PAGE_SIZE, page_off = off % ORC_PAGE_SIZE;
+    if (page_idx >= a->n_pages) return -1;
+    if ((a->flags[page_idx] & 0x3u) == 0) a->flags[page_idx] |= 0x2u; /* sync fetch -> L2 */
+    *out = orc_phys_page_id(h, page_idx) + page_off;
+    return 0;
+}
+int orc_cabi_prefetch(orc_cabi_t* c, uint32_t req_id, uint16_t layer, uint32_t cur_pos,
+                      uint32_t depth_k, const int32_t* tokens, uint32_t history_len)
+{   /* speckv_c_api.cpp:85-99 ; driver result ignored (speckv_allocator.cpp:89) */
+    (void)req_id; (void)layer; (void)cur_pos; (void)depth_k;
+    if (!c->initialized || !tokens || history_len == 0) return -4;
+    return 0;
+}
+int orc_cabi_set_prefetch_depth(orc_cabi_t* c, uint32_t k)
+{   /* speckv_c_api.cpp:101-110 ; ioctl on the fake device fails -> DRIVER */
+    (void)k;
+    if (!c->initialized) return -4;
+    return -2;
+}
+int orc_cabi_set_compression_scheme(orc_cabi_t* c, int scheme)
+{   /* speckv_c_api.cpp:112-121 */
+    (void)scheme;
+    if (!c->initialized) return -4;
+    return -2;
+}
+int orc_cabi_page_flags(orc_cabi_t* c, uint64_t h, uint64_t page_idx, uint32_t* out)
+{
+    orc_allocation_t* a = cabi_find(c, h);
+    if (!a || page_idx >= a->n_pages) return -1;
+    *out = a->flags[page_idx];
+    return 0;
+}
+
+uint64_t orc_calc_offset(uint64_t req_id, uint64_t layer, uint64_t head, uint64_t pos,
+                         uint64_t kind, uint64_t entry_bytes, uint64_t num_layers,
+                         uint64_t num_tokens, uint64_t num_heads)
+{   /* vllm_speckv_backend.py:95-100 */
+    return ((((req_id * num_layers + layer) * 2 + kind) * num_tokens + pos) * num_heads + head)
+           * entry_bytes;
+}
+uint64_t orc_shim_total_bytes(uint64_t T, uint64_t L, uint64_t H, uint64_t D, uint64_t bpe)
+{   /* vllm_speckv_backend.py:39-40 */
+    return T * L * H * D * bpe * 2;
+}
+
+/* ================================================================== */
+/* codec                                                               */
+/* ================================================================== */
+float orc_compute_scale(const float* x, size_t n)
+{   /* cache_engine.cpp:172-184 : NaN never wins the '>' compare */
+    float max_val = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        float a = fabsf(x[i]);
+        if (a > max_val) max_val = a;
+    }
+    return (max_val > 0.0f) ? (max_val / 127.0f) : 1.0f;
+}
+
+/* float -> int32 as x86-64 cvttss2si does it: out of range / NaN give
+ * INT32_MIN ("integer indefinite").  The reference's static_cast<int8_t>
+ * of a float compiles to that instruction followed by a byte truncation
+ * (cache_engine.cpp:191). */
+static int32_t cvttss2si(float v)
+{
+    if (!(v > -2147483904.0f && v < 2147483648.0f)) return INT32_MIN;
+    return (int32_t)v;
+}
+
+void orc_quantize(const float* x, size_t n, float scale, int mode, int8_t* q)
+{
+    if (mode == ORC_QUANT_REF_EXACT) {
+        /* cache_engine.cpp:189-192 : two rounded ops, roundf (half away),
+         * int8 wrap; the following clamp is a no-op on an int8 value. */
+        for (size_t i = 0; i < n; ++i) {
+            float scaled = x[i] / scale;
+            float r = roundf(scaled * 127.0f);
+            q[i] = (int8_t)(uint8_t)((uint32_t)cvttss2si(r) & 0xFFu);
+        }
+    } else {
+        /* intent: q = clamp(round(x / s), -127, 127)
+         * (cache_engine.cpp:182 comment, kv_compress.v:130) */
+        for (size_t i = 0; i < n; ++i) {
+            float r = roundf(x[i] / scale);
+            if (!(r == r)) r = 0.0f;
+            if (r > 127.0f) r = 127.0f;
+            if (r < -127.0f) r = -127.0f;
+            q[i] = (int8_t)(int32_t)r;
+        }
+    }
+}
+
+void orc_delta_encode(const int8_t* q, size_t n, int8_t* d)
+{   /* cache_engine.cpp:198-211 */
+    if (n == 0) return;
+    d[0] = q[0];
+    for (size_t i = 1; i < n; ++i)
+        d[i] = (int8_t)(uint8_t)((uint8_t)q[i] - (uint8_t)q[i - 1]);
+}
+
+size_t orc_rle_encode(const int8_t* d, size_t n, uint8_t* out)
+{   /* cache_engine.cpp:213-239 */
+    if (n == 0) return 0;
+    size_t w = 0;
+    int8_t cur = d[0];
+    size_t count = 1;
+    for (size_t i = 1; i < n; ++i) {
+        if (d[i] == cur && count < 255) {
+            count++;
+        } else {
+            out[w++] = (uint8_t)cur;
+            out[w++] = (uint8_t)count;
+            cur = d[i];
+            count = 1;
+        }
+    }
+    out[w++] = (uint8_t)cur;
+    out[w++] = (uint8_t)count;
+    return w;
+}
+
+size_t orc_rle_decode(const uint8_t* rle, size_t len, int8_t* out, size_t cap, size_t* total)
+{   /* cache_engine.cpp:241-258 : odd trailing byte dropped, count 0 emits nothing */
+    size_t w = 0, tot = 0;
+    for (size_t i = 0; i + 1 < len; i += 2) {
+        int8_t v = (int8_t)rle[i];
+        uint8_t c = rle[i + 1];
+        tot += c;
+        for (size_t j = 0; j < c; ++j)
+            if (w < cap) out[w++] = v;
+    }
+    if (total) *total = tot;
+    return w;
+}
+
+void orc_delta_decode(const int8_t* d, size_t n, int8_t* q)
+{   /* cache_engine.cpp:260-273 */
+    if (n == 0) return;
+    q[0] = d[0];
+    for (size_t i = 1; i < n; ++i)
+        q[i] = (int8_t)(uint8_t)((uint8_t)q[i - 1] + (uint8_t)d[i]);
+}
+
+void orc_dequantize(const int8_t* q, size_t n, float scale, int mode, float* y)
+{
+    if (mode == ORC_QUANT_REF_EXACT) {
+        /* cache_engine.cpp:278-281 : divide by 127 first, then scale */
+        for (size_t i = 0; i < n; ++i) {
+            float s = (float)q[i] / 127.0f;
+            y[i] = s * scale;
+        }
+    } else {
+        for (size_t i = 0; i < n; ++i) y[i] = (float)q[i] * scale;
+    }
+}
+
+size_t orc_compress_f32(const float* x, size_t n, int mode, float* scale, uint8_t* rle)
+{   /* cache_engine.cpp:40-82 */
+    float s = orc_compute_scale(x, n);
+    *scale = s;
+    if (n == 0) return 0;
+    int8_t* q = (int8_t*)malloc(n);
+    int8_t* d = (int8_t*)malloc(n);
+    orc_quantize(x, n, s, mode, q);
+    orc_delta_encode(q, n, d);
+    size_t len = orc_rle_encode(d, n, rle);
+    free(q); free(d);
+    return len;
+}
+
+size_t orc_decompress_f32(const uint8_t* rle, size_t len, float scale, int mode,
+                          float* y, size_t cap)
+{   /* cache_engine.cpp:84-116 */
+    int8_t* d = (int8_t*)malloc(cap ? cap : 1);
+    int8_t* q = (int8_t*)malloc(cap ? cap : 1);
+    size_t n = orc_rle_decode(rle, len, d, cap, NULL);
+    orc_delta_decode(d, n, q);
+    orc_dequantize(q, n, scale, mode, y);
+    free(d); free(q);
+    return n;
+}
+
+size_t orc_compress_block_f16(const uint16_t* x, size_t n, int scheme, int mode,
+                              float* scale, uint8_t* rec)
+{
+    if (scheme == ORC_COMP_FP16) {
+        memcpy(rec, x, 2 * n);
+        *scale = 1.0f;
+        return 2 * n;
+    }
+    float* xf = (float*)malloc((n ? n : 1) * sizeof(float));
+    for (size_t i = 0; i < n; ++i) xf[i] = orc_half_to_float(x[i]);
+    size_t len;
+    if (scheme == ORC_COMP_INT8) {
+        float s = orc_compute_scale(xf, n);
+        *scale = s;
+        orc_quantize(xf, n, s, mode, (int8_t*)rec);
+        len = n;
+    } else {
+        len = orc_compress_f32(xf, n, mode, scale, rec);
+    }
+    free(xf);
+    return len;
+}
+
+size_t orc_decompress_block_f32(const uint8_t* rec, size_t len, float scale, int scheme,
+                                int mode, float* y, size_t cap)
+{
+    if (scheme == ORC_COMP_FP16) {
+        size_t n = len / 2; if (n > cap) n = cap;
+        for (size_t i = 0; i < n; ++i) {
+            uint16_t h; memcpy(&h, rec + 2 * i, 2);
+            y[i] = orc_half_to_float(h);
+        }
+        return n;
+    }
+    if (scheme == ORC_COMP_INT8) {
+        size_t n = len < cap ? len : cap;
+        orc_dequantize((const int8_t*)rec, n, scale, mode, y);
+        return n;
+    }
+    return orc_decompress_f32(rec, len, scale, mode, y, cap);
+}
+
+size_t orc_decompress_block_f16(const uint8_t* rec, size_t len, float scale, int scheme,
+                                int mode, uint16_t* y, size_t cap)
+{
+    if (scheme == ORC_COMP_FP16) {
+        size_t n = len / 2; if (n > cap) n = cap;
+        memcpy(y, rec, 2 * n);
+        return n;
+    }
+    float* yf = (float*)malloc((cap ? cap : 1) * sizeof(float));
+    size_t n = orc_decompress_block_f32(rec, len, scale, scheme, mode, yf, cap);
+    for (size_t i = 0; i < n; ++i) y[i] = orc_float_to_half(yf[i]);
+    free(yf);
+    return n;
+}
+
+double orc_layer_compression_ratio(uint32_t layer_id)
+{   /* cache_engine.cpp:25-33,142-148 : 80/3 = 26, 2*80/3 = 53 */
+    if (layer_id >= 80) return 3.2;
+    if (layer_id < 80 / 3) return 3.5;
+    if (layer_id > 2 * 80 / 3) return 2.75;
+    return 3.2;
+}
+double orc_codec_throughput_gbps(size_t num_engines, double mhz, size_t width_bits)
+{   /* cache_engine.cpp:291-296 */
+    double per_engine = ((double)width_bits / 8.0) * (mhz / 1000.0);
+    return per_engine * (double)num_engines;
+}
+size_t orc_codec_pipeline_latency_cycles(void) { return 25; } /* cache_engine.cpp:286-289 */
+
+/* ---- TLB ----------------------------------------------------------- */
+struct orc_tlb { size_t n; uint64_t* va; uint64_t* pa; uint8_t* valid; };
+orc_tlb_t* orc_tlb_new(size_t entries)
+{
+    orc_tlb_t* t = (orc_tlb_t*)calloc(1, sizeof(*t));
+    t->n = entries;
+    t->va = (uint64_t*)calloc(entries, 8);
+    t->pa = (uint64_t*)calloc(entries, 8);
+    t->valid = (uint8_t*)calloc(entries, 1);
+    return t;
+}
+void orc_tlb_delete(orc_tlb_t* t) { if (t) { free(t->va); free(t->pa); free(t->valid); free(t); } }
+uint64_t orc_tlb_translate(orc_tlb_t* t, uint64_t va, int* was_hit)
+{   /* cache_engine.cpp:118-140 */
+    size_t idx = (size_t)((va >> 12) % t->n);
+    if (t->valid[idx] && t->va[idx] == (va & ~0xFFFULL)) {
+        if (was_hit) *was_hit = 1;
+        return t->pa[idx] + (va & 0xFFF);
+    }
+    if (was_hit) *was_hit = 0;
+    uint64_t pa = 0x4000000000ULL + (va & 0xFFFFFFFFFFFFULL);
+    t->va[idx] = va & ~0xFFFULL;
+    t->pa[idx] = pa & ~0xFFFULL;
+    t->valid[idx] = 1;
+    return pa;
+}
+
+/* ================================================================== */
+/* memory manager                                                      */
+/* ================================================================== */
+typedef struct { uint64_t* v; size_t n, cap; } u64vec;
+static void vec_push(u64vec* a, uint64_t x)
+{
+    if (a->n == a->cap) { a->cap = a->cap ? 2 * a->cap : 16; a->v = (uint64_t*)realloc(a->v, a->cap * 8); }
+    a->v[a->n++] = x;
+}
+static void vec_remove_all(u64vec* a, uint64_t x)
+{   /* erase(remove(...)) */
+    size_t w = 0;
+    for (size_t i = 0; i < a->n; ++i) if (a->v[i] != x) a->v[w++] = a->v[i];
+    a->n = w;
+}
+
+typedef struct {
+    uint64_t va, pa;
+    int tier, state;
+    uint32_t access_count;
+    int is_hot;
+    uint32_t layer_id;
+    int present;
+} orc_page_t;
+
+struct orc_mm {
+    uint64_t l1_bytes, l2_bytes, l3_bytes, page_size;
+    uint64_t next_va, next_pa_l1, next_pa_l2, next_pa_l3;
+    orc_page_t* pages; size_t n_pages, cap_pages;   /* indexed by (va - VA0)/page_size */
+    u64vec l1, l2, l3, lru;
+    orc_mm_stats_t st;
+};
+#define ORC_VA0 0x100000000ULL
+
+orc_mm_t* orc_mm_new(uint64_t l1_gb, uint64_t l2_gb, uint64_t l3_gb, uint64_t page_size)
+{   /* cxl_memory_manager.cpp:9-24 */
+    orc_mm_t* m = (orc_mm_t*)calloc(1, sizeof(*m));
+    m->l1_bytes = l1_gb << 30; m->l2_bytes = l2_gb << 30; m->l3_bytes = l3_gb << 30;
+    m->page_size = page_size;
+    m->next_va = ORC_VA0;
+    m->next_pa_l1 = 0x8000000000ULL;
+    m->next_pa_l2 = 0x10000000000ULL;
+    m->next_pa_l3 = 0x20000000000ULL;
+    return m;
+}
+void orc_mm_delete(orc_mm_t* m)
+{
+    if (!m) return;
+    free(m->pages); free(m->l1.v); free(m->l2.v); free(m->l3.v); free(m->lru.v); free(m);
+}
+static orc_page_t* mm_exact(orc_mm_t* m, uint64_t page_va)
+{
+    if (page_va < ORC_VA0) return NULL;
+    uint64_t d = page_va - ORC_VA0;
+    if (d % m->page_size) return NULL;
+    uint64_t idx = d / m->page_size;
+    if (idx >= m->n_pages || !m->pages[idx].present) return NULL;
+    return &m->pages[idx];
+}
+static orc_page_t* mm_get_page(orc_mm_t* m, uint64_t va)
+{   /* cxl_memory_manager.cpp:279-283 */
+    return mm_exact(m, (va / m->page_size) * m->page_size);
+}
+static u64vec* mm_tier_vec(orc_mm_t* m, int tier)
+{
+    return tier == ORC_TIER_L1 ? &m->l1 : tier == ORC_TIER_L2 ? &m->l2 : &m->l3;
+}
+static int mm_can_fit(orc_mm_t* m, int tier, uint64_t size)
+{   /* cxl_memory_manager.cpp:295-316 : counts list entries, not pages */
+    uint64_t used = (uint64_t)mm_tier_vec(m, tier)->n * m->page_size;
+    uint64_t avail = tier == ORC_TIER_L1 ? m->l1_bytes : tier == ORC_TIER_L2 ? m->l2_bytes : m->l3_bytes;
+    return used + size <= avail;
+}
+static void mm_update_lru(orc_mm_t* m, uint64_t va)
+{   /* cxl_memory_manager.cpp:318-323 */
+    vec_remove_all(&m->lru, va);
+    vec_push(&m->lru, va);
+}
+
+uint64_t orc_mm_allocate(orc_mm_t* m, uint64_t size_bytes, uint32_t layer_id, int tier)
+{   /* cxl_memory_manager.cpp:28-80 */
+    uint64_t n = (size_bytes + m->page_size - 1) / m->page_size;
+    uint64_t req = n * m->page_size;
+    int actual = tier;
+    if (tier == ORC_TIER_L1 && !mm_can_fit(m, ORC_TIER_L1, req)) actual = ORC_TIER_L3;
+    uint64_t va = m->next_va, pa;
+    if (actual == ORC_TIER_L1)      { pa = m->next_pa_l1; m->next_pa_l1 += req; vec_push(&m->l1, va); }
+    else if (actual == ORC_TIER_L2) { pa = m->next_pa_l2; m->next_pa_l2 += req; vec_push(&m->l2, va); }
+    else                            { pa = m->next_pa_l3; m->next_pa_l3 += req; vec_push(&m->l3, va); }
+    uint64_t first = (va - ORC_VA0) / m->page_size;
+    if (first + n > m->cap_pages) {
+        size_t nc = m->cap_pages ? m->cap_pages : 1024;
+        while (nc < first + n) nc *= 2;
+        m->pages = (orc_page_t*)realloc(m->pages, nc * sizeof(orc_page_t));
+        memset(m->pages + m->cap_pages, 0, (nc - m->cap_pages) * sizeof(orc_page_t));
+        m->cap_pages = nc;
+    }
+    for (uint64_t i = 0; i < n; ++i) {
+        orc_page_t* p = &m->pages[first + i];
+        p->va = va + i * m->page_size;
+        p->pa = pa + i * m->page_size;
+        p->tier = actual; p->state = ORC_STATE_EXCLUSIVE;
+        p->access_count = 0; p->is_hot = 0; p->layer_id = layer_id; p->present = 1;
+    }
+    if (first + n > m->n_pages) m->n_pages = first + n;
+    m->next_va += req;
+    return va;
+}
+
+void orc_mm_deallocate(orc_mm_t* m, uint64_t va)
+{   /* cxl_memory_manager.cpp:82-104 : exact-key lookup, erases ONE page */
+    orc_page_t* p = mm_exact(m, va);
+    if (!p) return;
+    if (p->tier == ORC_TIER_L1) { vec_remove_all(&m->l1, va); vec_remove_all(&m->lru, va); }
+    else vec_remove_all(mm_tier_vec(m, p->tier), va);
+    p->present = 0;
+}
+
+uint64_t orc_mm_translate(orc_mm_t* m, uint64_t va)
+{   /* cxl_memory_manager.cpp:106-117 */
+    uint64_t page_va = (va / m->page_size) * m->page_size;
+    orc_page_t* p = mm_exact(m, page_va);
+    return p ? p->pa + (va - page_va) : 0;
+}
+int orc_mm_is_in_cache(orc_mm_t* m, uint64_t va, int tier)
+{   /* cxl_memory_manager.cpp:119-128 */
+    orc_page_t* p = mm_get_page(m, va);
+    return p ? p->tier == tier : 0;
+}
+
+int orc_mm_demote_to_l3(orc_mm_t* m, uint64_t va)
+{   /* cxl_memory_manager.cpp:165-194 */
+    orc_page_t* p = mm_get_page(m, va);
+    if (!p || p->tier == ORC_TIER_L3) return 0;
+    int old = p->tier;
+    p->tier = ORC_TIER_L3;
+    if (old == ORC_TIER_L1) {
+        vec_remove_all(&m->l1, va); vec_remove_all(&m->lru, va);
+        m->st.migrations_l1_to_l3++;
+    } else if (old == ORC_TIER_L2) {
+        vec_remove_all(&m->l2, va);
+    }
+    vec_push(&m->l3, va);
+    return 1;
+}
+
+int orc_mm_promote_to_l1(orc_mm_t* m, uint64_t va)
+{   /* cxl_memory_manager.cpp:130-163.  The reference self-deadlocks when it
+     * has to evict; the restatement performs the eviction the
+     * code intends (front of the LRU list goes to L3). */
+    orc_page_t* p = mm_get_page(m, va);
+    if (!p || p->tier == ORC_TIER_L1) return 0;
+    if (!mm_can_fit(m, ORC_TIER_L1, m->page_size) && m->lru.n) {
+        uint64_t victim = m->lru.v[0];
+        memmove(m->lru.v, m->lru.v + 1, (m->lru.n - 1) * 8); m->lru.n--;
+        orc_mm_demote_to_l3(m, victim);
+    }
+    int old = p->tier;
+    p->tier = ORC_TIER_L1;
+    if (old == ORC_TIER_L2) vec_remove_all(&m->l2, va);
+    else if (old == ORC_TIER_L3) { vec_remove_all(&m->l3, va); m->st.migrations_l3_to_l1++; }
+    vec_push(&m->l1, va);
+    mm_update_lru(m, va);
+    return 1;
+}
+
+void orc_mm_invalidate_page(orc_mm_t* m, uint64_t va)
+{ orc_page_t* p = mm_get_page(m, va); if (p) p->state = ORC_STATE_INVALID; }
+void orc_mm_mark_modified(orc_mm_t* m, uint64_t va)
+{ orc_page_t* p = mm_get_page(m, va); if (p) p->state = ORC_STATE_MODIFIED; }
+int orc_mm_get_page_state(orc_mm_t* m, uint64_t va)
+{ orc_page_t* p = mm_get_page(m, va); return p ? p->state : ORC_STATE_INVALID; }
+
+void orc_mm_update_access_tracking(orc_mm_t* m, uint64_t va)
+{   /* cxl_memory_manager.cpp:223-245 */
+    orc_page_t* p = mm_get_page(m, va);
+    if (!p) return;
+    p->access_count++;
+    if (p->tier == ORC_TIER_L1) m->st.l1_hits++;
+    else if (p->tier == ORC_TIER_L2) m->st.l2_hits++;
+    else m->st.l3_accesses++;
+    mm_update_lru(m, va);
+}
+int orc_mm_is_hot_page(orc_mm_t* m, uint64_t va)
+{   /* cxl_memory_manager.cpp:247-257 */
+    orc_page_t* p = mm_get_page(m, va);
+    if (!p) return 0;
+    p->is_hot = p->access_count > 10;
+    return p->is_hot;
+}
+void orc_mm_get_statistics(orc_mm_t* m, orc_mm_stats_t* out)
+{   /* cxl_memory_manager.cpp:259-274 */
+    *out = m->st;
+    uint64_t t1 = out->l1_hits + out->l1_misses, t2 = out->l2_hits + out->l2_misses;
+    if (t1) out->l1_hit_rate = (double)out->l1_hits / (double)t1;
+    if (t2) out->l2_hit_rate = (double)out->l2_hits / (double)t2;
+}
+
+uint64_t orc_mm_cxl_access(orc_mm_t* m, uint64_t base_va, uint64_t offset)
+{   /* memory_allocator.cpp:105-143 */
+    uint64_t va = base_va + offset;
+    orc_mm_update_access_tracking(m, va);
+    if (orc_mm_is_in_cache(m, va, ORC_TIER_L1)) return va;
+    if (orc_mm_is_in_cache(m, va, ORC_TIER_L2)) {
+        if (orc_mm_is_hot_page(m, va)) orc_mm_promote_to_l1(m, va);
+        return va;
+    }
+    orc_mm_promote_to_l1(m, va);
+    return va;
+}
+
+/* ================================================================== */
+/* prefetcher                                                          */
+/* ================================================================== */
+uint64_t orc_compute_kv_address(uint32_t req_id, uint32_t layer_id, uint32_t position)
+{   /* speculative_prefetcher.cpp:153-160 */
+    return ((uint64_t)req_id << 32) | ((uint64_t)layer_id << 16) | (uint64_t)position;
+}
+
+size_t orc_prefetch_legacy(orc_mm_t* mm, uint32_t layer_id, size_t depth,
+                           size_t n_predictions, uint64_t* out_va)
+{   /* speculative_prefetcher.cpp:35-67 : req_id fixed 0, position i+1 */
+    (void)depth;
+    size_t w = 0;
+    for (size_t i = 0; i < n_predictions; ++i) {
+        uint64_t va = orc_compute_kv_address(0, layer_id, (uint32_t)(i + 1));
+        if (mm && (orc_mm_is_in_cache(mm, va, ORC_TIER_L1) ||
+                   orc_mm_is_in_cache(mm, va, ORC_TIER_L2)))
+            continue;
+        out_va[w++] = va;
+    }
+    return w;
+}
+
+struct orc_adapt { size_t depth; double hist[100]; size_t n; };
+orc_adapt_t* orc_adapt_new(size_t d)
+{ orc_adapt_t* a = (orc_adapt_t*)calloc(1, sizeof(*a)); a->depth = d; return a; }
+void orc_adapt_delete(orc_adapt_t* a) { free(a); }
+void orc_adapt_update(orc_adapt_t* a, int ok)
+{   /* speculative_prefetcher.cpp:98-120 : window 100, decision on last 10 */
+    if (a->n == 100) { memmove(a->hist, a->hist + 1, 99 * sizeof(double)); a->n = 99; }
+    a->hist[a->n++] = ok ? 1.0 : 0.0;
+    if (a->n >= 10) {
+        double acc = 0.0;
+        for (size_t i = a->n - 10; i < a->n; ++i) acc += a->hist[i];
+        acc /= 10.0;
+        if (acc > 0.95 && a->depth < 8) a->depth++;
+        else if (acc < 0.85 && a->depth > 2) a->depth--;
+    }
+}
+size_t orc_adapt_depth(const orc_adapt_t* a) { return a->depth; }
+int orc_is_misprediction(uint32_t actual, const uint32_t* predicted, size_t n)
+{   /* speculative_prefetcher.cpp:84-96 */
+    for (size_t i = 0; i < n; ++i) if (predicted[i] == actual) return 0;
+    return 1;
+}
+
+uint64_t orc_rtl_prefetch_vaddr(uint32_t req_id, uint16_t layer, uint32_t pos_plus)
+{   /* prefetch_core.v:92-98 : the 89-bit concatenation keeps its low 64 bits:
+     * bit0 kind=0, bits 1..32 pos, bits 33..40 head=0, bits 41..56 layer,
+     * bits 57..63 req[6:0]. */
+    return ((uint64_t)pos_plus << 1) | ((uint64_t)layer << 41) | ((uint64_t)req_id << 57);
+}
+
+size_t orc_prefetch_pages(uint32_t req_id, uint32_t layer, uint32_t cur_pos, uint32_t depth_k,
+                          uint64_t L, uint64_t T, uint64_t H, uint64_t D, uint64_t bpe,
+                          uint64_t alloc_pages, const uint32_t* flags,
+                          uint64_t* out, size_t cap)
+{
+    size_t w = 0;
+    uint64_t entry = D * bpe, row = H * entry;
+    if (row == 0) return 0;
+    for (uint64_t kind = 0; kind < 2; ++kind) {
+        int have_last = 0; uint64_t last = 0;
+        for (uint64_t i = 1; i <= depth_k; ++i) {
+            uint64_t p = (uint64_t)cur_pos + i;
+            if (p >= T) break;
+            uint64_t off = orc_calc_offset(req_id, layer, 0, p, kind, entry, L, T, H);
+            uint64_t pg0 = off / ORC_PAGE_SIZE, pg1 = (off + row - 1) / ORC_PAGE_SIZE;
+            for (uint64_t pg = pg0; pg <= pg1; ++pg) {
+                if (have_last && pg <= last) continue;
+                have_last = 1; last = pg;
+                if (pg >= alloc_pages) continue;
+                if (flags && (flags[pg] & 0x3u)) continue;
+                if (w < cap) out[w] = pg;
+                w++;
+            }
+        }
+    }
+    return w < cap ? w : cap;
+}

@@ -1,0 +1,208 @@
+/*
+ * oracle/speckv_oracle.h -- CPU restatement of the FastLM/CXL-SpecKV hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and there only as the checker.  The shipped path
+ * (cxl-speckv_amd/csrc -> libcxlspeckv.so) never links or calls it.
+ *
+ * Parity status: PINNED.  Every function below is validated here in the dev
+ * container against the reference compiled from /root/reference by
+ * oracle/Makefile (oracle/_ref/libspeckv_ref.so, see oracle/ref_harness.cpp)
+ * and against the golden fixtures in tests/golden/ that were generated from
+ * that reference build by tests/golden/generate_golden.py.
+ *
+ * All reference citations are relative to /root/reference.
+ */
+#ifndef SPECKV_ORACLE_H
+#define SPECKV_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* fp16 helpers (IEEE binary16 <-> binary32; RNE on narrowing)         */
+/* ------------------------------------------------------------------ */
+float    orc_half_to_float(uint16_t h);
+uint16_t orc_float_to_half(float f);
+
+/* ------------------------------------------------------------------ */
+/* Host allocator / page table ids  (host/src/speckv_allocator.cpp)    */
+/* ------------------------------------------------------------------ */
+#define ORC_PAGE_SIZE 4096u
+
+/* speckv_allocator.cpp:24-25 */
+uint64_t orc_virt_page_id(uint64_t handle, uint64_t page_idx);
+uint64_t orc_phys_page_id(uint64_t handle, uint64_t page_idx);
+/* speckv_allocator.cpp:18-19 */
+uint64_t orc_num_pages(uint64_t bytes);
+/* speckv_allocator.cpp:123 : gpu_addr of the sync-fetch descriptor */
+uint64_t orc_desc_gpu_addr(uint64_t virt_page_id);
+/* speckv_allocator.cpp:92-103 (private, never called by the reference) */
+uint64_t orc_encode_virt_page(uint32_t req_id, uint16_t layer, uint16_t head,
+                              uint32_t pos, uint8_t kind);
+
+/* A model of the 8-function C ABI on the fake device ("/dev/null"):
+ * host/src/speckv_c_api.cpp:13-121 + speckv_allocator.cpp:11-74.
+ * Status codes are those of host/include/speckv.h:12-18. */
+typedef struct orc_cabi orc_cabi_t;
+orc_cabi_t* orc_cabi_new(void);
+void        orc_cabi_delete(orc_cabi_t*);
+int      orc_cabi_init(orc_cabi_t*, const char* dev_path);
+void     orc_cabi_finalize(orc_cabi_t*);
+int      orc_cabi_alloc(orc_cabi_t*, uint64_t bytes, uint64_t* out_handle);
+int      orc_cabi_free(orc_cabi_t*, uint64_t handle);
+int      orc_cabi_access(orc_cabi_t*, uint64_t handle, uint64_t offset,
+                         uint64_t length, uint64_t* out_ptr);
+int      orc_cabi_prefetch(orc_cabi_t*, uint32_t req_id, uint16_t layer,
+                           uint32_t cur_pos, uint32_t depth_k,
+                           const int32_t* tokens, uint32_t history_len);
+int      orc_cabi_set_prefetch_depth(orc_cabi_t*, uint32_t k);
+int      orc_cabi_set_compression_scheme(orc_cabi_t*, int scheme);
+/* page flags after accesses (speckv_allocator.cpp:105-113,135): bit1 = L2 */
+int      orc_cabi_page_flags(orc_cabi_t*, uint64_t handle, uint64_t page_idx,
+                             uint32_t* out_flags);
+
+/* Python shim offset (host/python/vllm_speckv_backend.py:87-100) */
+uint64_t orc_calc_offset(uint64_t req_id, uint64_t layer, uint64_t head,
+                         uint64_t pos, uint64_t kind, uint64_t entry_bytes,
+                         uint64_t num_layers, uint64_t num_tokens,
+                         uint64_t num_heads);
+/* total bytes of one shim allocation (vllm_speckv_backend.py:39-40) */
+uint64_t orc_shim_total_bytes(uint64_t num_tokens, uint64_t num_layers,
+                              uint64_t num_heads, uint64_t head_dim,
+                              uint64_t bytes_per_element);
+
+/* ------------------------------------------------------------------ */
+/* Codec  (src/fpga_engine/cache_engine.cpp)                           */
+/* ------------------------------------------------------------------ */
+enum { ORC_QUANT_REF_EXACT = 0, ORC_QUANT_INTENT = 1 };
+enum { ORC_COMP_FP16 = 0, ORC_COMP_INT8 = 1, ORC_COMP_INT8_DELTA_RLE = 2 };
+
+/* cache_engine.cpp:172-184 */
+float  orc_compute_scale(const float* x, size_t n);
+/* cache_engine.cpp:186-196 (REF_EXACT) / header+RTL intent (INTENT) */
+void   orc_quantize(const float* x, size_t n, float scale, int mode, int8_t* q);
+/* cache_engine.cpp:198-211 */
+void   orc_delta_encode(const int8_t* q, size_t n, int8_t* d);
+/* cache_engine.cpp:213-239 ; returns bytes written (<= 2n) */
+size_t orc_rle_encode(const int8_t* d, size_t n, uint8_t* out);
+/* cache_engine.cpp:241-258 ; returns elements written (<= cap) and sets
+ * *total to the unclamped sum of counts */
+size_t orc_rle_decode(const uint8_t* rle, size_t len, int8_t* out, size_t cap,
+                      size_t* total);
+/* cache_engine.cpp:260-273 */
+void   orc_delta_decode(const int8_t* d, size_t n, int8_t* q);
+/* cache_engine.cpp:275-284 (REF_EXACT) / q*scale (INTENT) */
+void   orc_dequantize(const int8_t* q, size_t n, float scale, int mode, float* y);
+
+/* FPGACacheEngine::compress (cache_engine.cpp:40-82): full pipeline.
+ * rle must hold 2n bytes.  Returns compressed_size. */
+size_t orc_compress_f32(const float* x, size_t n, int mode, float* scale,
+                        uint8_t* rle);
+/* FPGACacheEngine::decompress (cache_engine.cpp:84-116).  Returns elements. */
+size_t orc_decompress_f32(const uint8_t* rle, size_t len, float scale, int mode,
+                          float* y, size_t cap);
+
+/* KV-block forms used by the engine: one block = n fp16 elements
+ * (n = 2048 for a 4 KiB page).  fp16 -> fp32 is exact; the reference maths
+ * runs in fp32; fp32 -> fp16 on the way out is one RNE rounding.
+ * scheme 0: raw fp16 copy (rec = 2n bytes).
+ * scheme 1: int8 quantise only (rec = n bytes).
+ * scheme 2: quantise + delta + RLE (rec <= 2n bytes).
+ * Returns record bytes. */
+size_t orc_compress_block_f16(const uint16_t* x, size_t n, int scheme, int mode,
+                              float* scale, uint8_t* rec);
+size_t orc_decompress_block_f16(const uint8_t* rec, size_t len, float scale,
+                                int scheme, int mode, uint16_t* y, size_t cap);
+size_t orc_decompress_block_f32(const uint8_t* rec, size_t len, float scale,
+                                int scheme, int mode, float* y, size_t cap);
+
+/* cache_engine.cpp:25-33,142-148 */
+double   orc_layer_compression_ratio(uint32_t layer_id);
+/* cache_engine.cpp:286-296 */
+double   orc_codec_throughput_gbps(size_t num_engines, double mhz, size_t width_bits);
+size_t   orc_codec_pipeline_latency_cycles(void);
+
+/* ATU / TLB (cache_engine.cpp:118-140) */
+typedef struct orc_tlb orc_tlb_t;
+orc_tlb_t* orc_tlb_new(size_t entries);
+void       orc_tlb_delete(orc_tlb_t*);
+uint64_t   orc_tlb_translate(orc_tlb_t*, uint64_t va, int* was_hit);
+
+/* ------------------------------------------------------------------ */
+/* 3-tier memory manager (src/cxl_memory/cxl_memory_manager.cpp)       */
+/* ------------------------------------------------------------------ */
+enum { ORC_TIER_L1 = 0, ORC_TIER_L2 = 1, ORC_TIER_L3 = 2 };
+enum { ORC_STATE_INVALID = 0, ORC_STATE_SHARED = 1, ORC_STATE_EXCLUSIVE = 2,
+       ORC_STATE_MODIFIED = 3 };
+
+typedef struct orc_mm orc_mm_t;
+typedef struct {
+    uint64_t l1_hits, l1_misses, l2_hits, l2_misses, l3_accesses;
+    uint64_t migrations_l1_to_l3, migrations_l3_to_l1;
+    double   l1_hit_rate, l2_hit_rate;
+} orc_mm_stats_t;
+
+orc_mm_t* orc_mm_new(uint64_t l1_gb, uint64_t l2_gb, uint64_t l3_gb, uint64_t page_size);
+void      orc_mm_delete(orc_mm_t*);
+uint64_t  orc_mm_allocate(orc_mm_t*, uint64_t size_bytes, uint32_t layer_id, int tier);
+void      orc_mm_deallocate(orc_mm_t*, uint64_t va);
+uint64_t  orc_mm_translate(orc_mm_t*, uint64_t va);
+int       orc_mm_is_in_cache(orc_mm_t*, uint64_t va, int tier);
+int       orc_mm_promote_to_l1(orc_mm_t*, uint64_t va);
+int       orc_mm_demote_to_l3(orc_mm_t*, uint64_t va);
+void      orc_mm_invalidate_page(orc_mm_t*, uint64_t va);
+void      orc_mm_mark_modified(orc_mm_t*, uint64_t va);
+int       orc_mm_get_page_state(orc_mm_t*, uint64_t va);
+void      orc_mm_update_access_tracking(orc_mm_t*, uint64_t va);
+int       orc_mm_is_hot_page(orc_mm_t*, uint64_t va);
+void      orc_mm_get_statistics(orc_mm_t*, orc_mm_stats_t*);
+/* memory_allocator.cpp:105-143 access policy on top of the manager */
+uint64_t  orc_mm_cxl_access(orc_mm_t*, uint64_t base_va, uint64_t offset);
+
+/* ------------------------------------------------------------------ */
+/* Speculative prefetcher (src/prefetcher/speculative_prefetcher.cpp)  */
+/* ------------------------------------------------------------------ */
+/* speculative_prefetcher.cpp:153-160 */
+uint64_t orc_compute_kv_address(uint32_t req_id, uint32_t layer_id, uint32_t position);
+/* speculative_prefetcher.cpp:25-82 : address list of one prefetch() call.
+ * mm may be NULL (nothing resident).  Returns number of requests emitted. */
+size_t   orc_prefetch_legacy(orc_mm_t* mm, uint32_t layer_id, size_t depth,
+                             size_t n_predictions, uint64_t* out_va);
+
+/* adaptive depth + misprediction stats (speculative_prefetcher.cpp:84-137) */
+typedef struct orc_adapt orc_adapt_t;
+orc_adapt_t* orc_adapt_new(size_t initial_depth);
+void         orc_adapt_delete(orc_adapt_t*);
+void         orc_adapt_update(orc_adapt_t*, int was_correct);
+size_t       orc_adapt_depth(const orc_adapt_t*);
+/* returns 1 when actual is NOT among predicted (a misprediction) */
+int          orc_is_misprediction(uint32_t actual, const uint32_t* predicted, size_t n);
+
+/* RTL intent (hardware/rtl/prefetch_core.v:92-98,158): the virtual address
+ * the prefetch FSM asks the ATU for at iteration idx. 64-bit truncation of
+ * {req[31:0], layer[15:0], 8'd0, pos[31:0], 1'b0}. */
+uint64_t orc_rtl_prefetch_vaddr(uint32_t req_id, uint16_t layer, uint32_t pos_plus);
+
+/* Engine lookup (prefetch_core.v:150-241 intent mapped through the shim
+ * layout vllm_speckv_backend.py:87-100): pages of (req, layer, kind in {K,V})
+ * covering positions cur_pos+1 .. cur_pos+k (clipped to num_tokens-1), in
+ * order kind-major, ascending page, duplicates removed.  `flags` (may be
+ * NULL) is the per-page residency array of the allocation; pages with
+ * flags&3 are filtered out (speckv_allocator.cpp:105-113).  Returns count. */
+size_t orc_prefetch_pages(uint32_t req_id, uint32_t layer, uint32_t cur_pos,
+                          uint32_t depth_k, uint64_t num_layers,
+                          uint64_t num_tokens, uint64_t num_heads,
+                          uint64_t head_dim, uint64_t bytes_per_element,
+                          uint64_t alloc_pages, const uint32_t* flags,
+                          uint64_t* out_pages, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPECKV_ORACLE_H */
