@@ -1,0 +1,325 @@
+// cxl-speckv_amd/csrc/c_api.cpp -- extern "C" surface of libcxlspeckv.so.
+//
+// Mirrors the shape of the reference's host/src/speckv_c_api.cpp:8-121: one
+// process-global engine, one mutex, every entry point validates "initialised"
+// first and no C++ exception crosses the ABI.  Status codes per call are the
+// reference's (SURVEY.md sect. 8b "Error conventions").
+#include "../../include/speckv.h"
+#include "../../include/speckv_ext.h"
+#include "engine.hpp"
+
+#include <cstdio>
+#include <memory>
+#include <mutex>
+
+using speckv::Engine;
+
+namespace {
+std::unique_ptr<Engine> g_engine;
+std::mutex g_mutex;
+
+template <typename F>
+speckv_status_t guarded(F&& f)
+{
+    try {
+        return static_cast<speckv_status_t>(f());
+    } catch (const std::bad_alloc&) {
+        return SPECKV_ERR_NOMEM;
+    } catch (...) {
+        return SPECKV_ERR_GENERAL;
+    }
+}
+#define LOCK std::lock_guard<std::mutex> lock(g_mutex)
+#define NEED_INIT if (!g_engine) return SPECKV_ERR_INVAL
+} // namespace
+
+extern "C" {
+
+speckv_status_t speckv_init(const char* dev_path)
+{
+    LOCK;
+    if (g_engine) return SPECKV_ERR_GENERAL;          // already initialised (speckv_c_api.cpp:16-18)
+    return guarded([&] {
+        int status = SPECKV_ERR_GENERAL;
+        g_engine = Engine::open(dev_path, &status);
+        return status;
+    });
+}
+
+void speckv_finalize(void)
+{
+    LOCK;
+    try { g_engine.reset(); } catch (...) {}
+}
+
+speckv_status_t speckv_alloc(size_t bytes, const speckv_alloc_hint_t* hint, speckv_handle_t* out)
+{
+    LOCK;
+    if (!g_engine || !out) return SPECKV_ERR_INVAL;
+    return guarded([&] { uint64_t h = 0; int rc = g_engine->alloc(bytes, hint, &h); if (rc == 0) *out = h; return rc; });
+}
+
+speckv_status_t speckv_free(speckv_handle_t handle)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->free(handle); });
+}
+
+speckv_status_t speckv_access(speckv_handle_t handle, uint64_t offset_bytes, size_t length_bytes,
+                              void** out_gpu_ptr)
+{
+    LOCK;
+    if (!g_engine || !out_gpu_ptr) return SPECKV_ERR_INVAL;
+    return guarded([&] { return g_engine->access(handle, offset_bytes, length_bytes, out_gpu_ptr); });
+}
+
+speckv_status_t speckv_prefetch(uint32_t req_id, uint16_t layer, uint32_t cur_pos, uint32_t depth_k,
+                                const int32_t* recent_tokens, uint32_t history_len)
+{
+    LOCK;
+    if (!g_engine || !recent_tokens || history_len == 0) return SPECKV_ERR_INVAL;
+    return guarded([&] { return g_engine->prefetch(req_id, layer, cur_pos, depth_k, recent_tokens, history_len); });
+}
+
+speckv_status_t speckv_set_prefetch_depth(uint32_t depth_k)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->set_prefetch_depth(depth_k); });
+}
+
+speckv_status_t speckv_set_compression_scheme(speckv_comp_scheme_t scheme)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->set_scheme(static_cast<int>(scheme)); });
+}
+
+// ------------------------------------------------------------------ ext
+speckv_status_t speckv_ext_set_quant_mode(speckv_quant_mode_t mode)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->set_quant_mode(static_cast<int>(mode)); });
+}
+
+speckv_status_t speckv_ext_translate(speckv_handle_t handle, uint64_t offset_bytes, speckv_ext_page_info_t* out)
+{
+    LOCK;
+    if (!g_engine || !out) return SPECKV_ERR_INVAL;
+    return guarded([&] { return g_engine->translate(handle, offset_bytes, out); });
+}
+
+speckv_status_t speckv_ext_fetch_desc(speckv_handle_t handle, uint64_t offset_bytes, speckv_dma_desc_t* out)
+{
+    LOCK;
+    if (!g_engine || !out) return SPECKV_ERR_INVAL;
+    return guarded([&] { return g_engine->fetch_desc(handle, offset_bytes, out); });
+}
+
+speckv_status_t speckv_ext_set_layout(speckv_handle_t handle, uint32_t num_tokens, uint32_t num_layers,
+                                      uint32_t num_heads, uint32_t head_dim, uint32_t bytes_per_element)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->set_layout(handle, num_tokens, num_layers, num_heads, head_dim, bytes_per_element); });
+}
+
+speckv_status_t speckv_ext_write(speckv_handle_t handle, uint64_t offset_bytes, const void* src, size_t len, int src_on_device)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->write(handle, offset_bytes, src, len, src_on_device != 0); });
+}
+
+speckv_status_t speckv_ext_read(speckv_handle_t handle, uint64_t offset_bytes, void* dst, size_t len, int dst_on_device)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->read(handle, offset_bytes, dst, len, dst_on_device != 0); });
+}
+
+speckv_status_t speckv_ext_fetch_range(speckv_handle_t handle, uint64_t first_page, uint64_t n_pages,
+                                       void* d_dst, int out_f32, void* stream)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->fetch_range(handle, first_page, n_pages, d_dst, out_f32 != 0, static_cast<hipStream_t>(stream)); });
+}
+
+speckv_status_t speckv_ext_fetch_list(speckv_handle_t handle, const uint32_t* d_pages, uint32_t n,
+                                      void* d_dst, int out_f32, void* stream)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->fetch_list(handle, d_pages, n, d_dst, out_f32 != 0, static_cast<hipStream_t>(stream)); });
+}
+
+speckv_status_t speckv_ext_access_batch(speckv_handle_t handle, const uint64_t* offsets, uint32_t n, void** out_ptrs)
+{
+    LOCK;
+    if (!g_engine || (n && (!offsets || !out_ptrs))) return SPECKV_ERR_INVAL;
+    return guarded([&] { return g_engine->access_batch(handle, offsets, n, out_ptrs); });
+}
+
+speckv_status_t speckv_ext_prefetch_batch(uint32_t n, const uint32_t* req_ids, const uint16_t* layers,
+                                          const uint32_t* cur_pos, const uint32_t* depth_k)
+{
+    LOCK;
+    if (!g_engine || (n && (!req_ids || !layers || !cur_pos))) return SPECKV_ERR_INVAL;
+    return guarded([&] { return g_engine->prefetch_batch(n, req_ids, layers, cur_pos, depth_k); });
+}
+
+speckv_status_t speckv_ext_prefetch_flush(uint32_t* n_issued)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->prefetch_flush(n_issued); });
+}
+
+speckv_status_t speckv_ext_prefetch_lookup(speckv_handle_t handle, uint32_t n, const uint32_t* d_req_ids,
+                                           const uint32_t* d_layers, const uint32_t* d_cur_pos,
+                                           const uint32_t* d_depth_k, uint32_t* d_out_pages, uint32_t cap,
+                                           uint32_t* d_out_count, void* stream)
+{
+    LOCK;
+    if (!g_engine || !d_out_count || (n && (!d_req_ids || !d_layers || !d_cur_pos || !d_depth_k || !d_out_pages)))
+        return SPECKV_ERR_INVAL;
+    return guarded([&] {
+        return g_engine->prefetch_lookup(handle, n, d_req_ids, d_layers, d_cur_pos, d_depth_k, d_out_pages, cap,
+                                         d_out_count, static_cast<hipStream_t>(stream));
+    });
+}
+
+speckv_status_t speckv_ext_prefetch_legacy_addrs(uint32_t layer, uint32_t depth_k, uint64_t* out_addrs, uint32_t* out_n)
+{   // speculative_prefetcher.cpp:48,153-160 : req_id is the constant 0, position i+1
+    if (!out_addrs || !out_n) return SPECKV_ERR_INVAL;
+    for (uint32_t i = 0; i < depth_k; ++i)
+        out_addrs[i] = (0ULL << 32) | (static_cast<uint64_t>(layer) << 16) | static_cast<uint64_t>(i + 1);
+    *out_n = depth_k;
+    return SPECKV_OK;
+}
+
+speckv_status_t speckv_ext_verify(uint32_t req_id, int32_t actual_token, const int32_t* predicted,
+                                  uint32_t n_predicted, uint32_t* was_hit, uint32_t* new_depth)
+{
+    LOCK;
+    if (!g_engine || (n_predicted && !predicted)) return SPECKV_ERR_INVAL;
+    return guarded([&] { return g_engine->verify(req_id, actual_token, predicted, n_predicted, was_hit, new_depth); });
+}
+
+speckv_status_t speckv_ext_verify_batch(uint32_t n, uint32_t k, const int32_t* d_actual, const int32_t* d_predicted,
+                                        uint8_t* d_hit, uint32_t* d_hit_count, void* stream)
+{
+    if (!d_hit_count || (n && (!d_actual || !d_predicted || !d_hit))) return SPECKV_ERR_INVAL;
+    if (n && (k == 0 || k > 64)) return SPECKV_ERR_INVAL;
+    hipError_t e = speckv::launch_verify(n, k, d_actual, d_predicted, d_hit, d_hit_count, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        fprintf(stderr, "[libcxlspeckv] speckv_ext_verify_batch: %s\n", hipGetErrorString(e));
+        return SPECKV_ERR_DRIVER;
+    }
+    return SPECKV_OK;
+}
+
+speckv_status_t speckv_ext_get_prefetch_depth(uint32_t* depth_k)
+{
+    LOCK;
+    if (!g_engine || !depth_k) return SPECKV_ERR_INVAL;
+    *depth_k = g_engine->prefetch_depth();
+    return SPECKV_OK;
+}
+
+speckv_status_t speckv_ext_poll_complete(uint32_t* done)
+{
+    LOCK;
+    if (!g_engine || !done) return SPECKV_ERR_INVAL;
+    return guarded([&] { return g_engine->poll_complete(done); });
+}
+
+speckv_status_t speckv_ext_sync(void)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->sync(); });
+}
+
+// raw codec operators: no engine state, caller-owned device buffers
+static speckv_status_t codec_launch(bool compress, const speckv::CodecArgs& a, void* stream)
+{
+    hipError_t e = compress ? speckv::launch_compress(a, static_cast<hipStream_t>(stream))
+                            : speckv::launch_decompress(a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        fprintf(stderr, "[libcxlspeckv] codec launch failed: %s\n", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return SPECKV_ERR_DRIVER;
+    }
+    return SPECKV_OK;
+}
+
+speckv_status_t speckv_ext_codec_compress(const void* d_src_f16, uint64_t n_blocks, void* d_recs, uint64_t rec_stride,
+                                          uint32_t* d_rec_bytes, float* d_scales, int scheme, int quant_mode, void* stream)
+{
+    if (scheme < 0 || scheme > 2 || quant_mode < 0 || quant_mode > 1) return SPECKV_ERR_INVAL;
+    if (n_blocks && (!d_src_f16 || !d_recs || !d_rec_bytes)) return SPECKV_ERR_INVAL;
+    if (rec_stride % 16) return SPECKV_ERR_INVAL;
+    if (rec_stride < (scheme == SPECKV_COMP_INT8 ? 2048u : 4096u)) return SPECKV_ERR_INVAL;
+    speckv::CodecArgs a{};
+    a.recs = static_cast<uint8_t*>(d_recs);
+    a.rec_stride = rec_stride;
+    a.rec_bytes = d_rec_bytes;
+    a.scales = d_scales;
+    a.data = static_cast<uint8_t*>(const_cast<void*>(d_src_f16));
+    a.data_stride = speckv::kPageSize;
+    a.n = n_blocks;
+    a.scheme = scheme;
+    a.quant_mode = quant_mode;
+    return codec_launch(true, a, stream);
+}
+
+speckv_status_t speckv_ext_codec_decompress(const void* d_recs, uint64_t rec_stride, const uint32_t* d_rec_bytes,
+                                            const float* d_scales, uint64_t n_blocks, void* d_dst, int out_f32,
+                                            int scheme, int quant_mode, void* stream)
+{
+    if (scheme < 0 || scheme > 2 || quant_mode < 0 || quant_mode > 1) return SPECKV_ERR_INVAL;
+    if (n_blocks && (!d_recs || !d_rec_bytes || !d_dst)) return SPECKV_ERR_INVAL;
+    if (rec_stride % 16) return SPECKV_ERR_INVAL;
+    speckv::CodecArgs a{};
+    a.recs = static_cast<uint8_t*>(const_cast<void*>(d_recs));
+    a.rec_stride = rec_stride;
+    a.rec_bytes = const_cast<uint32_t*>(d_rec_bytes);
+    a.scales = const_cast<float*>(d_scales);
+    a.data = static_cast<uint8_t*>(d_dst);
+    a.data_stride = out_f32 ? 2ull * speckv::kPageSize : speckv::kPageSize;
+    a.n = n_blocks;
+    a.scheme = scheme;
+    a.quant_mode = quant_mode;
+    a.out_f32 = out_f32 ? 1 : 0;
+    return codec_launch(false, a, stream);
+}
+
+speckv_status_t speckv_ext_promote_to_l1(speckv_handle_t handle, uint64_t offset_bytes)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->promote_to_l1(handle, offset_bytes); });
+}
+
+speckv_status_t speckv_ext_demote_to_l3(speckv_handle_t handle, uint64_t offset_bytes)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->demote_to_l3(handle, offset_bytes); });
+}
+
+speckv_status_t speckv_ext_stats(speckv_ext_stats_t* out)
+{
+    LOCK;
+    if (!g_engine || !out) return SPECKV_ERR_INVAL;
+    return guarded([&] { return g_engine->stats(out); });
+}
+
+double speckv_ext_layer_compression_ratio(uint32_t layer_id)
+{   // cache_engine.cpp:25-33,142-148 (80/3 = 26, 2*80/3 = 53)
+    if (layer_id >= 80) return 3.2;
+    if (layer_id < 80 / 3) return 3.5;
+    if (layer_id > 2 * 80 / 3) return 2.75;
+    return 3.2;
+}
+
+// not part of the public headers: hardware self-test of the DPP scans
+speckv_status_t speckv_debug_wave_primitives(const uint32_t* d_in, uint32_t* d_out, void* stream)
+{
+    return speckv::launch_debug_dpp(d_in, d_out, static_cast<hipStream_t>(stream)) == hipSuccess ? SPECKV_OK : SPECKV_ERR_DRIVER;
+}
+
+const char* speckv_ext_backend(void) { return "hip"; }
+
+} // extern "C"

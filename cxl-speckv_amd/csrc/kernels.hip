@@ -1,0 +1,775 @@
+// cxl-speckv_amd/csrc/kernels.hip -- hand-written CDNA4 (gfx950) kernels of the
+// KV hot path: block compress, fetch + decompress, prefetch lookup, verify.
+//
+// What they replace in the reference (paths under /root/reference):
+//   FPGACacheEngine::compress / ::decompress   src/fpga_engine/cache_engine.cpp:40-116,172-284
+//   (RTL twins hardware/rtl/kv_compress.v, kv_decompress.v)
+//   prefetch_core lookup loop                  hardware/rtl/prefetch_core.v:150-241
+//   SpeculativePrefetcher::handle_misprediction src/prefetcher/speculative_prefetcher.cpp:84-96
+//
+// Execution model.  These are HBM-bound byte kernels, not GEMMs: no MFMA.
+// One wavefront (64 lanes) owns one 2048-element block; lane l holds elements
+// [8l+512j, 8l+512j+8), j=0..3, so each global access is a coalesced 1 KiB
+// instruction (16 B per lane).  The serial recurrences of the reference
+// (run-length expand, int8 delta chain) become wave-level scans:
+//   * run start positions   = exclusive add-scan of the run counts
+//   * delta prefix at a run = exclusive add-scan (mod 256) of value*count,
+//     carried in the top byte of the same 32-bit scan word
+//   * "which run covers output p" = max-scan over a 2048-entry head table in
+//     LDS into which every run scatters one word at its start position
+// Scans are DPP (row_shr / row_bcast) inside the wave; there is no workgroup
+// barrier anywhere, so wavefronts never wait for each other.
+#include "kernels.hpp"
+
+#include <hip/hip_fp16.h>
+
+#include <cstdlib>
+
+namespace speckv {
+namespace {
+
+constexpr int kWaves = 4;                 // wavefronts per workgroup
+constexpr int kThreads = 64 * kWaves;
+constexpr int kDecLdsWords = 2048;        // per wave: head table, 8 KiB
+constexpr int kEncLdsHalves = 2056 + 2048; // per wave: run positions + pair buffer
+
+// ------------------------------------------------------------------ DPP
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp(uint32_t old, uint32_t src)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(
+        static_cast<int>(old), static_cast<int>(src), CTRL, ROW_MASK, BANK_MASK, false));
+}
+// inclusive add-scan over the 64 lanes (identity 0 flows in at row edges)
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v)
+{
+    v += dpp<0x111>(0u, v);            // row_shr:1
+    v += dpp<0x112>(0u, v);            // row_shr:2
+    v += dpp<0x114>(0u, v);            // row_shr:4
+    v += dpp<0x118>(0u, v);            // row_shr:8
+    v += dpp<0x142, 0xA>(0u, v);       // row_bcast:15 -> rows 1,3
+    v += dpp<0x143, 0xC>(0u, v);       // row_bcast:31 -> rows 2,3
+    return v;
+}
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v)
+{
+    v = umax(v, dpp<0x111>(0u, v));
+    v = umax(v, dpp<0x112>(0u, v));
+    v = umax(v, dpp<0x114>(0u, v));
+    v = umax(v, dpp<0x118>(0u, v));
+    v = umax(v, dpp<0x142, 0xA>(0u, v));
+    v = umax(v, dpp<0x143, 0xC>(0u, v));
+    return v;
+}
+// lane i receives lane i-1's value, lane 0 receives `fill`.
+// Written as an explicit v_mov_b32_dpp: when hipcc folds a wave_shr:1 update_dpp
+// into the consuming VOP2 (v_subrev_u32_dpp ... wave_shr:1 bound_ctrl:1) the
+// result is wrong on gfx950 for some lanes (found by tests/test_gpu_codec.py,
+// kept covered by test_wave_primitives); the plain move form is reliable.
+// The two wait states a DPP read needs after the VALU write of its source are
+// inside the statement (hipcc adds none for asm).
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t fill)
+{
+    uint32_t r = fill;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0"
+                 : "+v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ uint32_t lane63(uint32_t v)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+// LDS traffic of one wave is in order in hardware; this only pins the compiler.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// head-table swizzle: a wave writes/reads dword p with p = 8*lane + k; XOR with
+// bits 5..9 spreads the 32 lanes of a group over 32 distinct LDS banks.
+__device__ __forceinline__ uint32_t swz(uint32_t p) { return p ^ ((p >> 5) & 31u); }
+
+// ------------------------------------------------------------ arithmetic
+// float(q)/127.0f, correctly rounded, without a divide: one Newton step on
+// q * fl(1/127) is exact for every int8 q (checked exhaustively in
+// tests/test_host_logic.py::test_div127_identity).
+__device__ __forceinline__ float div127(float fq)
+{
+    const float rcp = 0x1.020408p-7f;           // fl(1/127)
+    float r0 = fq * rcp;
+    float e = __builtin_fmaf(-127.0f, r0, fq);
+    return __builtin_fmaf(e, rcp, r0);
+}
+template <int MODE>
+__device__ __forceinline__ float dequant(int q, float scale)
+{
+    float fq = static_cast<float>(q);
+    if (MODE == kRefExact) return div127(fq) * scale;   // cache_engine.cpp:279-280
+    return fq * scale;
+}
+// cache_engine.cpp:190-192 on x86-64: cvttss2si + byte truncation
+template <int MODE>
+__device__ __forceinline__ uint32_t quantize(float x, float scale)
+{
+    if (MODE == kRefExact) {
+        float scaled = x / scale;
+        float r = roundf(scaled * 127.0f);
+        int i = (fabsf(r) < 2147483648.0f) ? static_cast<int>(r) : static_cast<int>(0x80000000u);
+        return static_cast<uint32_t>(i) & 0xFFu;
+    } else {
+        float r = roundf(x / scale);
+        if (!(r == r)) r = 0.0f;
+        r = fminf(fmaxf(r, -127.0f), 127.0f);
+        return static_cast<uint32_t>(static_cast<int>(r)) & 0xFFu;
+    }
+}
+// The reference rounds the fp32 product to fp32 first and the result to fp16
+// second.  Without the empty asm hipcc selects v_fma_mixlo_f16 for
+// "(half)(x * scale)", which rounds the exact product once and differs from the
+// reference in ~1e-5 of the elements (caught by test_many_random_blocks).
+__device__ __forceinline__ uint32_t pack_half2(float a, float b)
+{
+    asm volatile("" : "+v"(a), "+v"(b));
+    _Float16 ha = static_cast<_Float16>(a), hb = static_cast<_Float16>(b);
+    uint16_t ua = __builtin_bit_cast(uint16_t, ha), ub = __builtin_bit_cast(uint16_t, hb);
+    return static_cast<uint32_t>(ua) | (static_cast<uint32_t>(ub) << 16);
+}
+__device__ __forceinline__ float half_bits_to_float(uint32_t h16)
+{
+    return static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(h16)));
+}
+template <bool F32>
+__device__ __forceinline__ void store8(uint8_t* dst, uint32_t p0, const float (&y)[8])
+{
+    if (F32) {
+        uint4* o = reinterpret_cast<uint4*>(dst + 4ull * p0);
+        o[0] = make_uint4(__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3]));
+        o[1] = make_uint4(__float_as_uint(y[4]), __float_as_uint(y[5]), __float_as_uint(y[6]), __float_as_uint(y[7]));
+    } else {
+        *reinterpret_cast<uint4*>(dst + 2ull * p0) =
+            make_uint4(pack_half2(y[0], y[1]), pack_half2(y[2], y[3]),
+                       pack_half2(y[4], y[5]), pack_half2(y[6], y[7]));
+    }
+}
+
+// ===================================================================
+// decode: INT8_DELTA_RLE  (cache_engine.cpp:241-284)
+// ===================================================================
+template <int MODE, bool F32>
+__device__ __forceinline__ void decode_rle(const uint8_t* __restrict__ rec, uint32_t len,
+                                           float scale, uint8_t* __restrict__ dst,
+                                           uint32_t* heads, uint32_t lane)
+{
+    // (1) clear the head table: 8 KiB per wave
+    uint4* h4 = reinterpret_cast<uint4*>(heads);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h4[j * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+
+    // (2) scan the (value,count) pairs; scatter one head word per run
+    const uint32_t npairs = len >> 1;           // odd trailing byte dropped
+    uint32_t carry = 0;                         // (sum v*c mod 256)<<24 | sum c
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t pair0 = 512u * j + 8u * lane;
+        uint4 w = make_uint4(0u, 0u, 0u, 0u);
+        if (pair0 < npairs) w = *reinterpret_cast<const uint4*>(rec + 2ull * pair0);
+        const uint32_t words[4] = {w.x, w.y, w.z, w.w};
+        uint32_t v[8], c[8], s[8];
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t word = words[k >> 1] >> ((k & 1) * 16);
+            v[k] = word & 0xFFu;
+            c[k] = (pair0 + k < npairs) ? ((word >> 8) & 0xFFu) : 0u;
+            s[k] = run;
+            run += ((v[k] * c[k]) << 24) | c[k];
+        }
+        const uint32_t incl = wave_incl_add(run);
+        const uint32_t base = carry + incl - run;
+        carry += lane63(incl);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t e = base + s[k];
+            const uint32_t start = e & 0xFFFFFFu;
+            if (c[k] != 0u && start < kBlockElems)
+                heads[swz(start)] = 0x10000u | ((e >> 24) << 8) | v[k];
+        }
+    }
+    const uint32_t total = carry & 0xFFFFFFu;
+    const uint32_t nvalid = total < kBlockElems ? total : kBlockElems;
+    wave_lds_fence();
+
+    // (3) every output finds its run by a max-scan over the head table
+    uint32_t mcarry = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t p0 = 512u * j + 8u * lane;
+        uint32_t key[8];
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t p = p0 + k;
+            const uint32_t w = heads[swz(p)];
+            const uint32_t kk = w ? w + (p << 16) : 0u;     // (p+1)<<16 | prefix<<8 | value
+            m = umax(m, kk);
+            key[k] = m;
+        }
+        const uint32_t incl = wave_incl_max(m);
+        const uint32_t excl = umax(wave_shr1(incl, 0u), mcarry);
+        mcarry = umax(mcarry, lane63(incl));
+        float y[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t p = p0 + k;
+            const uint32_t kk = umax(key[k], excl);
+            // q[p] = prefix + (p - start + 1) * value   (mod 256), start = (kk>>16)-1
+            const uint32_t q8 = (((kk >> 8) & 0xFFu) + (p + 2u - (kk >> 16)) * (kk & 0xFFu)) & 0xFFu;
+            const int q = static_cast<int>(static_cast<int8_t>(q8));
+            y[k] = (p < nvalid) ? dequant<MODE>(q, scale) : 0.0f;
+        }
+        store8<F32>(dst, p0, y);
+    }
+    wave_lds_fence();
+}
+
+// decode: INT8 (quantise only)
+template <int MODE, bool F32>
+__device__ __forceinline__ void decode_int8(const uint8_t* __restrict__ rec, uint32_t len,
+                                            float scale, uint8_t* __restrict__ dst, uint32_t lane)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t p0 = 512u * j + 8u * lane;
+        uint2 w = make_uint2(0u, 0u);
+        if (p0 < len) w = *reinterpret_cast<const uint2*>(rec + p0);
+        float y[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t b = ((k < 4 ? w.x : w.y) >> ((k & 3) * 8)) & 0xFFu;
+            const int q = static_cast<int>(static_cast<int8_t>(b));
+            y[k] = (p0 + k < len) ? dequant<MODE>(q, scale) : 0.0f;
+        }
+        store8<F32>(dst, p0, y);
+    }
+}
+
+// decode: FP16 (raw copy, optional widening)
+template <bool F32>
+__device__ __forceinline__ void decode_fp16(const uint8_t* __restrict__ rec, uint32_t len,
+                                            uint8_t* __restrict__ dst, uint32_t lane)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t p0 = 512u * j + 8u * lane;
+        uint4 w = make_uint4(0u, 0u, 0u, 0u);
+        if (2u * p0 < len) w = *reinterpret_cast<const uint4*>(rec + 2ull * p0);
+        if (!F32) {
+            // mask a ragged tail at element granularity
+            const uint32_t words[4] = {w.x, w.y, w.z, w.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint32_t lo = (2u * (p0 + 2 * t) + 1u < len) ? (words[t] & 0xFFFFu) : 0u;
+                uint32_t hi = (2u * (p0 + 2 * t + 1) + 1u < len) ? (words[t] & 0xFFFF0000u) : 0u;
+                o[t] = lo | hi;
+            }
+            *reinterpret_cast<uint4*>(dst + 2ull * p0) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+            const uint32_t words[4] = {w.x, w.y, w.z, w.w};
+            float y[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t h = (words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+                y[k] = (2u * (p0 + k) + 1u < len) ? half_bits_to_float(h) : 0.0f;
+            }
+            store8<true>(dst, p0, y);
+        }
+    }
+}
+
+template <int SCHEME, int MODE, bool F32>
+__global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[SCHEME == kInt8DeltaRle ? kWaves * kDecLdsWords : 4];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint64_t n = a.n;
+    if (a.n_dev) { const uint64_t nd = *a.n_dev; n = nd < n ? nd : n; }
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kWaves;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kWaves + wave; i < n; i += stride) {
+        const uint64_t page = a.page_list ? a.page_list[i] : a.first + i;
+        const uint8_t* rec;
+        uint32_t len;
+        float scale;
+        if (a.entries) {
+            const PageEntry e = a.entries[page];
+            rec = reinterpret_cast<const uint8_t*>(e.pool_addr);
+            len = e.rec_bytes;
+            scale = e.scale;
+        } else {
+            rec = a.recs + page * a.rec_stride;
+            len = a.rec_bytes[page];
+            scale = a.scales ? a.scales[page] : 1.0f;
+        }
+        uint8_t* dst = a.data_list ? reinterpret_cast<uint8_t*>(a.data_list[i])
+                                   : a.data + i * a.data_stride;
+        // wave-uniform values live in SGPRs
+        len = __builtin_amdgcn_readfirstlane(len);
+        scale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(scale)));
+        if (SCHEME == kInt8DeltaRle) {
+            if (len > 2u * kBlockElems) len = 2u * kBlockElems;
+            decode_rle<MODE, F32>(rec, len, scale, dst, lds + wave * kDecLdsWords, lane);
+        } else if (SCHEME == kInt8) {
+            if (len > kBlockElems) len = kBlockElems;
+            decode_int8<MODE, F32>(rec, len, scale, dst, lane);
+        } else {
+            if (len > 2u * kBlockElems) len = 2u * kBlockElems;
+            decode_fp16<F32>(rec, len, dst, lane);
+        }
+        if (a.flags && lane == 0u)
+            a.flags[page] = (a.flags[page] & ~8u) | a.set_flags;
+    }
+}
+
+// ===================================================================
+// encode  (cache_engine.cpp:40-82,172-239)
+// ===================================================================
+template <int SCHEME, int MODE>
+__global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t lds[SCHEME == kInt8DeltaRle ? kWaves * kEncLdsHalves : 8];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint64_t n = a.n;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kWaves;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kWaves + wave; i < n; i += stride) {
+        const uint64_t page = a.page_list ? a.page_list[i] : a.first + i;
+        const uint8_t* src = a.data_list ? reinterpret_cast<const uint8_t*>(a.data_list[i])
+                                         : a.data + i * a.data_stride;
+        uint8_t* rec = a.entries ? reinterpret_cast<uint8_t*>(a.entries[page].pool_addr)
+                                 : a.recs + page * a.rec_stride;
+        uint32_t out_len;
+        float scale = 1.0f;
+
+        uint4 raw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            raw[j] = *reinterpret_cast<const uint4*>(src + 2ull * (512u * j + 8u * lane));
+
+        if (SCHEME == kFp16) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<uint4*>(rec + 2ull * (512u * j + 8u * lane)) = raw[j];
+            out_len = 2u * kBlockElems;
+        } else {
+            float x[4][8];
+            float mx = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t words[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    x[j][k] = half_bits_to_float((words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
+                    const float ax = fabsf(x[j][k]);
+                    mx = (ax > mx) ? ax : mx;          // NaN never wins (cache_engine.cpp:176-180)
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float other = __shfl_xor(mx, o);
+                mx = (other > mx) ? other : mx;
+            }
+            scale = (mx > 0.0f) ? (mx / 127.0f) : 1.0f;
+
+            uint32_t q[4][8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) q[j][k] = quantize<MODE>(x[j][k], scale);
+
+            if (SCHEME == kInt8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint2 o;
+                    o.x = q[j][0] | (q[j][1] << 8) | (q[j][2] << 16) | (q[j][3] << 24);
+                    o.y = q[j][4] | (q[j][5] << 8) | (q[j][6] << 16) | (q[j][7] << 24);
+                    *reinterpret_cast<uint2*>(rec + 512u * j + 8u * lane) = o;
+                }
+                out_len = kBlockElems;
+            } else {
+                uint16_t* runpos = lds + wave * kEncLdsHalves;     // [2056]
+                uint16_t* pairbuf = runpos + 2056;                 // [2048]
+                // delta (cache_engine.cpp:198-211), with q[-1] := 0 so d[0] = q[0]
+                uint32_t d[4][8];
+                uint32_t isrun[4][8];     // run-start flag
+                uint32_t ridx[4][8];      // index of the run this element starts
+                uint32_t qtail = 0, dtail = 0, scarry = 0, rcarry = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t p0 = 512u * j + 8u * lane;
+                    uint32_t prevq = wave_shr1(q[j][7], qtail);
+                    qtail = lane63(q[j][7]);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        d[j][k] = (q[j][k] - prevq) & 0xFFu;
+                        prevq = q[j][k];
+                    }
+                    // stretch starts: element differs from its predecessor
+                    uint32_t prevd = wave_shr1(d[j][7], dtail);
+                    dtail = lane63(d[j][7]);
+                    uint32_t key[8];
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t p = p0 + k;
+                        const bool neq = (p == 0u) || (d[j][k] != prevd);
+                        prevd = d[j][k];
+                        m = umax(m, neq ? p : 0u);
+                        key[k] = m;
+                    }
+                    const uint32_t incl = wave_incl_max(m);
+                    const uint32_t excl = umax(wave_shr1(incl, 0u), scarry);
+                    scarry = umax(scarry, lane63(incl));
+                    // a run starts every 255 elements inside a stretch (count < 255 rule)
+                    uint32_t cnt = 0;
+                    uint32_t loc[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t t = (p0 + k) - umax(key[k], excl);
+                        isrun[j][k] = (t % 255u == 0u) ? 1u : 0u;
+                        loc[k] = cnt;
+                        cnt += isrun[j][k];
+                    }
+                    const uint32_t rincl = wave_incl_add(cnt);
+                    const uint32_t rbase = rcarry + rincl - cnt;
+                    rcarry += lane63(rincl);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        ridx[j][k] = rbase + loc[k];
+                        if (isrun[j][k]) runpos[ridx[j][k]] = static_cast<uint16_t>(p0 + k);
+                    }
+                }
+                const uint32_t nruns = rcarry;
+                if (lane == 0u) runpos[nruns] = static_cast<uint16_t>(kBlockElems);
+                wave_lds_fence();
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (isrun[j][k]) {
+                            const uint32_t p = 512u * j + 8u * lane + k;
+                            const uint32_t count = runpos[ridx[j][k] + 1u] - p;
+                            pairbuf[ridx[j][k]] = static_cast<uint16_t>(d[j][k] | (count << 8));
+                        }
+                // zero the tail of the last 16-byte chunk so the stored slot is deterministic
+                {
+                    const uint32_t idx = nruns + lane;
+                    if (lane < 8u && idx < ((nruns + 7u) & ~7u)) pairbuf[idx] = 0;
+                }
+                wave_lds_fence();
+                out_len = 2u * nruns;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t b = 1024u * j + 16u * lane;
+                    if (b < out_len)
+                        *reinterpret_cast<uint4*>(rec + b) =
+                            *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(pairbuf) + b);
+                }
+                wave_lds_fence();
+            }
+        }
+        if (lane == 0u) {
+            if (a.entries) {
+                a.entries[page].rec_bytes = out_len;
+                a.entries[page].scale = scale;
+            } else {
+                a.rec_bytes[page] = out_len;
+                if (a.scales) a.scales[page] = scale;
+            }
+        }
+    }
+}
+
+// ===================================================================
+// prefetch lookup  (prefetch_core.v:150-241 ; speckv_allocator.cpp:105-113)
+// ===================================================================
+// 32 lanes per request: lane c -> kind = c>>4, position cur_pos + (c&15) + 1.
+// Pages of a position = pages covering its [head 0 .. head H-1] row in the
+// shim layout; a lane emits only pages its predecessor lane did not cover.
+struct Cand { uint32_t lo, hi; };   // half-open range of NEW pages of this lane (before residency filter)
+
+__device__ __forceinline__ Cand candidate(const Layout& lay, uint32_t req, uint32_t layer,
+                                          uint32_t pos, uint32_t depth, uint32_t c)
+{
+    Cand r{0u, 0u};
+    const uint32_t kind = c >> 4, i = (c & 15u) + 1u;
+    const uint64_t p = static_cast<uint64_t>(pos) + i;
+    if (i > depth || p >= lay.num_tokens) return r;
+    const uint64_t entry = static_cast<uint64_t>(lay.head_dim) * lay.bytes_per_element;
+    const uint64_t row = entry * lay.num_heads;
+    if (row == 0) return r;
+    // vllm_speckv_backend.py:95-100 with head = 0
+    const uint64_t off = ((((static_cast<uint64_t>(req) * lay.num_layers + layer) * 2 + kind)
+                           * lay.num_tokens + p) * lay.num_heads) * entry;
+    uint64_t pg0 = off / kPageSize;
+    const uint64_t pg1 = (off + row - 1) / kPageSize;
+    if (i > 1) {                       // predecessor position p-1 covered up to:
+        const uint64_t prev_pg1 = (off - 1) / kPageSize;   // (off - row + row - 1)
+        if (pg0 <= prev_pg1) pg0 = prev_pg1 + 1;
+    }
+    uint64_t hi = pg1 + 1;
+    if (hi > lay.alloc_pages) hi = lay.alloc_pages;
+    if (pg0 >= hi) return r;
+    r.lo = static_cast<uint32_t>(pg0);
+    r.hi = static_cast<uint32_t>(hi);
+    return r;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_prefetch_lookup(Layout lay, uint32_t n,
+        const uint32_t* __restrict__ req, const uint32_t* __restrict__ layer,
+        const uint32_t* __restrict__ pos, const uint32_t* __restrict__ depth,
+        const uint32_t* __restrict__ flags, uint32_t* __restrict__ wave_tot,
+        const uint32_t* __restrict__ wave_base, uint32_t* __restrict__ out, uint32_t cap)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // global wave = 2 requests
+    const uint32_t r = 2u * gw + (lane >> 5);
+    uint32_t cnt = 0;
+    Cand cd{0u, 0u};
+    const bool live_wave = 2u * gw < n;
+    if (r < n) {
+        uint32_t dk = depth[r];
+        if (dk > 16u) dk = 16u;
+        cd = candidate(lay, req[r], layer[r], pos[r], dk, lane & 31u);
+        for (uint32_t pg = cd.lo; pg < cd.hi; ++pg)
+            cnt += (flags && (flags[pg] & 3u)) ? 0u : 1u;
+    }
+    const uint32_t incl = wave_incl_add(cnt);
+    if (!WRITE) {
+        if (lane == 63u && live_wave) wave_tot[gw] = incl;
+    } else {
+        uint32_t w = (live_wave ? wave_base[gw] : 0u) + incl - cnt;
+        for (uint32_t pg = cd.lo; pg < cd.hi; ++pg)
+            if (!(flags && (flags[pg] & 3u))) {
+                if (w < cap) out[w] = pg;
+                ++w;
+            }
+    }
+}
+
+// single-workgroup exclusive scan of the per-wave totals (n_w is small:
+// requests/2); total is clamped to cap.
+__global__ __launch_bounds__(1024) void k_scan_totals(const uint32_t* __restrict__ tot,
+        uint32_t* __restrict__ base, uint32_t n_w, uint32_t* __restrict__ count, uint32_t cap)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t running;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n_w; i0 += 1024u) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint32_t v = (i < n_w) ? tot[i] : 0u;
+        const uint32_t incl = wave_incl_add(v);
+        if (lane == 63u) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (uint32_t w = 0; w < wave; ++w) wbase += wsum[w];
+        const uint32_t run = running;
+        if (i < n_w) base[i] = run + wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023u) running = run + wbase + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = running < cap ? running : cap;
+}
+
+// ===================================================================
+// verify  (speculative_prefetcher.cpp:84-96): hit[r] = actual[r] in predicted[r][0..k)
+// ===================================================================
+__global__ __launch_bounds__(256) void k_verify(uint32_t n, uint32_t k, uint32_t kp2,
+        const int32_t* __restrict__ actual, const int32_t* __restrict__ predicted,
+        uint8_t* __restrict__ hit, uint32_t* __restrict__ hit_count)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t per_wave = 64u / kp2;
+    const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t g = lane / kp2, j = lane % kp2;
+    const uint32_t r = gw * per_wave + g;
+    bool match = false;
+    if (r < n && j < k) match = predicted[static_cast<uint64_t>(r) * k + j] == actual[r];
+    const unsigned long long mask = __ballot(match);          // 64-bit verify mask
+    const unsigned long long gmask = (kp2 == 64u) ? ~0ull : (((1ull << kp2) - 1ull) << (g * kp2));
+    const bool ghit = (mask & gmask) != 0ull;
+    const bool leader = (r < n) && (j == 0u);
+    if (leader) hit[r] = ghit ? 1 : 0;
+    const unsigned long long hits = __ballot(leader && ghit);
+    if (lane == 0u && hits) atomicAdd(hit_count, static_cast<uint32_t>(__popcll(hits)));
+}
+
+__global__ void k_update_flags(uint32_t* flags, const uint32_t* pages, uint32_t n,
+                               uint32_t and_mask, uint32_t or_mask)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const uint32_t p = pages[i]; flags[p] = (flags[p] & and_mask) | or_mask; }
+}
+
+__global__ void k_init_entries(PageEntry* e, uint64_t n, uint64_t base, uint64_t stride)
+{
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) { e[i].pool_addr = base + i * stride; e[i].rec_bytes = 0; e[i].scale = 1.0f; }
+}
+
+// self-test of the wave primitives (tests/test_gpu_codec.py::test_wave_primitives)
+__global__ void k_debug_dpp(const uint32_t* in, uint32_t* out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t v = in[threadIdx.x];
+    out[0 * 64 + lane] = wave_shr1(v, 0xABCDu);
+    out[1 * 64 + lane] = wave_incl_add(v);
+    out[2 * 64 + lane] = wave_incl_max(v);
+    out[3 * 64 + lane] = lane63(v);
+    // the dependent pattern used by the encoder: produce, shift, consume
+    const uint32_t w = (v * 2654435761u) >> 24;
+    const uint32_t prev = wave_shr1(w, 7u);
+    out[4 * 64 + lane] = (w - prev) & 0xFFu;
+}
+
+int g_cus = 0;
+int num_cus()
+{
+    if (g_cus == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            g_cus = cus;
+        else
+            g_cus = 256;
+    }
+    return g_cus;
+}
+uint32_t codec_grid(uint64_t n)
+{
+    // persistent-ish grid: enough workgroups to fill every CU several times
+    // over, grid-stride for the rest (blocks of a wave are 4 KiB apart, so
+    // neighbouring waves stream neighbouring pages).
+    static int per_cu = [] {
+        const char* e = getenv("SPECKV_WGS_PER_CU");
+        int v = e ? atoi(e) : 20;
+        return v > 0 ? v : 20;
+    }();
+    const uint64_t want = (n + kWaves - 1) / kWaves;
+    const uint64_t cap = static_cast<uint64_t>(num_cus()) * per_cu;
+    return static_cast<uint32_t>(want < cap ? (want ? want : 1) : cap);
+}
+
+template <int SCHEME, int MODE>
+hipError_t launch_dec2(const CodecArgs& a, hipStream_t s)
+{
+    const uint32_t grid = codec_grid(a.n);
+    if (a.out_f32) hipLaunchKernelGGL((k_fetch_decompress<SCHEME, MODE, true>), dim3(grid), dim3(kThreads), 0, s, a);
+    else           hipLaunchKernelGGL((k_fetch_decompress<SCHEME, MODE, false>), dim3(grid), dim3(kThreads), 0, s, a);
+    return hipGetLastError();
+}
+template <int SCHEME>
+hipError_t launch_dec1(const CodecArgs& a, hipStream_t s)
+{
+    return a.quant_mode == kIntent ? launch_dec2<SCHEME, kIntent>(a, s) : launch_dec2<SCHEME, kRefExact>(a, s);
+}
+template <int SCHEME>
+hipError_t launch_enc1(const CodecArgs& a, hipStream_t s)
+{
+    const uint32_t grid = codec_grid(a.n);
+    if (a.quant_mode == kIntent) hipLaunchKernelGGL((k_compress<SCHEME, kIntent>), dim3(grid), dim3(kThreads), 0, s, a);
+    else                         hipLaunchKernelGGL((k_compress<SCHEME, kRefExact>), dim3(grid), dim3(kThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+} // namespace
+
+hipError_t launch_decompress(const CodecArgs& a, hipStream_t s)
+{
+    if (a.n == 0) return hipSuccess;
+    switch (a.scheme) {
+    case kFp16: return launch_dec1<kFp16>(a, s);
+    case kInt8: return launch_dec1<kInt8>(a, s);
+    case kInt8DeltaRle: return launch_dec1<kInt8DeltaRle>(a, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_compress(const CodecArgs& a, hipStream_t s)
+{
+    if (a.n == 0) return hipSuccess;
+    switch (a.scheme) {
+    case kFp16: return launch_enc1<kFp16>(a, s);
+    case kInt8: return launch_enc1<kInt8>(a, s);
+    case kInt8DeltaRle: return launch_enc1<kInt8DeltaRle>(a, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_prefetch_lookup(const Layout& lay, uint32_t n, const uint32_t* d_req,
+                                  const uint32_t* d_layer, const uint32_t* d_pos,
+                                  const uint32_t* d_k, const uint32_t* d_flags, uint32_t* d_out,
+                                  uint32_t cap, uint32_t* d_count, uint32_t* d_scratch,
+                                  hipStream_t s)
+{
+    if (n == 0) return hipMemsetAsync(d_count, 0, sizeof(uint32_t), s);
+    const uint32_t n_w = (n + 1u) / 2u;                 // 2 requests per wave
+    uint32_t* tot = d_scratch;
+    uint32_t* base = d_scratch + n_w;
+    const uint32_t grid = (n_w * 64u + 255u) / 256u;
+    hipLaunchKernelGGL((k_prefetch_lookup<false>), dim3(grid), dim3(256), 0, s, lay, n, d_req, d_layer,
+                       d_pos, d_k, d_flags, tot, static_cast<const uint32_t*>(nullptr),
+                       static_cast<uint32_t*>(nullptr), cap);
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, s, tot, base, n_w, d_count, cap);
+    hipLaunchKernelGGL((k_prefetch_lookup<true>), dim3(grid), dim3(256), 0, s, lay, n, d_req, d_layer,
+                       d_pos, d_k, d_flags, static_cast<uint32_t*>(nullptr), base, d_out, cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_verify(uint32_t n, uint32_t k, const int32_t* d_actual,
+                         const int32_t* d_predicted, uint8_t* d_hit, uint32_t* d_hit_count,
+                         hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(d_hit_count, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess || n == 0) return e;
+    if (k == 0 || k > 64u) return hipErrorInvalidValue;
+    uint32_t kp2 = 1;
+    while (kp2 < k) kp2 <<= 1;
+    const uint32_t per_wave = 64u / kp2;
+    const uint32_t waves = (n + per_wave - 1u) / per_wave;
+    const uint32_t grid = (waves * 64u + 255u) / 256u;
+    hipLaunchKernelGGL(k_verify, dim3(grid), dim3(256), 0, s, n, k, kp2, d_actual, d_predicted, d_hit,
+                       d_hit_count);
+    return hipGetLastError();
+}
+
+hipError_t launch_debug_dpp(const uint32_t* d_in, uint32_t* d_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_debug_dpp, dim3(1), dim3(64), 0, s, d_in, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_update_flags(uint32_t* d_flags, const uint32_t* d_pages, uint32_t n,
+                               uint32_t and_mask, uint32_t or_mask, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_update_flags, dim3((n + 255u) / 256u), dim3(256), 0, s, d_flags, d_pages, n,
+                       and_mask, or_mask);
+    return hipGetLastError();
+}
+
+hipError_t launch_init_entries(PageEntry* d_entries, uint64_t n, uint64_t base, uint64_t stride,
+                               hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_init_entries, dim3(static_cast<uint32_t>((n + 255u) / 256u)), dim3(256), 0, s,
+                       d_entries, n, base, stride);
+    return hipGetLastError();
+}
+
+} // namespace speckv

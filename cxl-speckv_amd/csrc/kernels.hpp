@@ -1,0 +1,85 @@
+// cxl-speckv_amd/csrc/kernels.hpp -- launch interface of the CDNA4 kernels.
+//
+// One KV block = one 4 KiB page = 2048 fp16 elements.  One 64-lane wavefront
+// owns one block at a time (4 wavefronts per workgroup, no workgroup barrier):
+// lane l holds elements [8l + 512j, 8l + 512j + 8) for j = 0..3, so every
+// global load/store instruction is one fully coalesced 1 KiB access.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace speckv {
+
+constexpr uint32_t kPageSize = 4096;
+constexpr uint32_t kBlockElems = 2048;
+
+enum Scheme : int { kFp16 = 0, kInt8 = 1, kInt8DeltaRle = 2 };
+enum QuantMode : int { kRefExact = 0, kIntent = 1 };
+
+// Device-resident page-table entry (16 B).
+struct PageEntry {
+    uint64_t pool_addr;   // device address of the stored record (local or peer HBM)
+    uint32_t rec_bytes;   // record length in bytes (0 = never written)
+    float    scale;       // per-block scale factor
+};
+
+// Source / destination description of one codec launch.  Exactly one of
+// {entries, recs} is used as the record source.
+struct CodecArgs {
+    // record side
+    PageEntry*      entries;      // page table (engine form), indexed by page
+    uint8_t*        recs;         // raw form: record i at recs + i*rec_stride
+    uint64_t        rec_stride;
+    uint32_t*       rec_bytes;    // raw form
+    float*          scales;       // raw form
+    // block index mapping: page = page_list ? page_list[i] : first + i
+    const uint32_t* page_list;
+    uint64_t        first;
+    // fp16 / fp32 side: block i at data + i*data_stride_bytes, or data_list[i]
+    uint8_t*        data;
+    uint64_t        data_stride;
+    const uint64_t* data_list;
+    // count
+    uint64_t        n;
+    const uint32_t* n_dev;        // optional: n read from device memory (<= n)
+    // residency mirror update on completion (decompress only): flags[page] = (flags & ~8) | set_flags
+    uint32_t*       flags;
+    uint32_t        set_flags;
+    int             scheme;
+    int             quant_mode;
+    int             out_f32;
+};
+
+hipError_t launch_compress(const CodecArgs& a, hipStream_t s);
+hipError_t launch_decompress(const CodecArgs& a, hipStream_t s);
+
+// Shim layout (vllm_speckv_backend.py:87-100) of the allocation a lookup runs on.
+struct Layout {
+    uint32_t num_tokens, num_layers, num_heads, head_dim, bytes_per_element;
+    uint64_t alloc_pages;
+};
+
+// Prefetch lookup: 3 kernels (mask+count, scan, scatter) -> compacted page list
+// in request order.  scratch must hold (2*n + 2) uint32.
+hipError_t launch_prefetch_lookup(const Layout& lay, uint32_t n,
+                                  const uint32_t* d_req, const uint32_t* d_layer,
+                                  const uint32_t* d_pos, const uint32_t* d_k,
+                                  const uint32_t* d_flags, uint32_t* d_out, uint32_t cap,
+                                  uint32_t* d_count, uint32_t* d_scratch, hipStream_t s);
+
+hipError_t launch_verify(uint32_t n, uint32_t k, const int32_t* d_actual,
+                         const int32_t* d_predicted, uint8_t* d_hit,
+                         uint32_t* d_hit_count, hipStream_t s);
+
+// flags[pages[i]] = (flags[pages[i]] & and_mask) | or_mask
+hipError_t launch_update_flags(uint32_t* d_flags, const uint32_t* d_pages, uint32_t n,
+                               uint32_t and_mask, uint32_t or_mask, hipStream_t s);
+
+// entries[first+i].pool_addr = base + i*stride ; rec_bytes = 0 ; scale = 1
+hipError_t launch_init_entries(PageEntry* d_entries, uint64_t n, uint64_t base,
+                               uint64_t stride, hipStream_t s);
+
+// wave-primitive self test: in[64] -> out[5*64]
+hipError_t launch_debug_dpp(const uint32_t* d_in, uint32_t* d_out, hipStream_t s);
+
+} // namespace speckv

@@ -1,0 +1,105 @@
+// cxl-speckv_amd/csrc/slab_pool.cpp -- see slab_pool.hpp
+#include "slab_pool.hpp"
+
+namespace speckv {
+
+namespace {
+constexpr size_t kGranule = 4096;
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+}
+
+bool SlabPool::same_slab(uintptr_t a, uintptr_t b) const
+{
+    for (const auto& s : slabs_) {
+        const uintptr_t lo = reinterpret_cast<uintptr_t>(s.base), hi = lo + s.bytes;
+        if (a >= lo && a < hi) return b >= lo && b <= hi;
+    }
+    return false;
+}
+
+void SlabPool::insert_free(uintptr_t addr, size_t len)
+{
+    // coalesce with neighbours, but never across two hipMalloc'ed slabs
+    auto next = free_.lower_bound(addr);
+    if (next != free_.begin()) {
+        auto prev = std::prev(next);
+        if (prev->first + prev->second == addr && same_slab(prev->first, addr)) {
+            addr = prev->first;
+            len += prev->second;
+            free_.erase(prev);
+        }
+    }
+    if (next != free_.end() && addr + len == next->first && same_slab(addr, next->first)) {
+        len += next->second;
+        free_.erase(next);
+    }
+    free_[addr] = len;
+}
+
+bool SlabPool::grow(size_t min_bytes)
+{
+    size_t want = min_bytes > slab_bytes_ ? round_up(min_bytes, kGranule) : slab_bytes_;
+    if (capacity_ && reserved_ + want > capacity_) {
+        if (reserved_ + min_bytes > capacity_) return false;
+        want = round_up(min_bytes, kGranule);
+    }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(device_) != hipSuccess) return false;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess && want > min_bytes) {       // fall back to an exact-size slab
+        (void)hipGetLastError();
+        want = round_up(min_bytes, kGranule);
+        e = hipMalloc(&p, want);
+    }
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess || !p) { (void)hipGetLastError(); return false; }
+    slabs_.push_back({static_cast<uint8_t*>(p), want});
+    reserved_ += want;
+    insert_free(reinterpret_cast<uintptr_t>(p), want);
+    return true;
+}
+
+void* SlabPool::alloc(size_t bytes)
+{
+    if (bytes == 0) return nullptr;
+    bytes = round_up(bytes, kGranule);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        for (auto it = free_.begin(); it != free_.end(); ++it) {
+            if (it->second >= bytes) {
+                const uintptr_t addr = it->first;
+                const size_t rest = it->second - bytes;
+                free_.erase(it);
+                if (rest) free_[addr + bytes] = rest;
+                used_ += bytes;
+                return reinterpret_cast<void*>(addr);
+            }
+        }
+        if (!grow(bytes)) return nullptr;
+    }
+    return nullptr;
+}
+
+void SlabPool::free(void* p, size_t bytes)
+{
+    if (!p || bytes == 0) return;
+    bytes = round_up(bytes, kGranule);
+    used_ -= bytes;
+    insert_free(reinterpret_cast<uintptr_t>(p), bytes);
+}
+
+void SlabPool::release()
+{
+    if (slabs_.empty()) return;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(device_);
+    for (auto& s : slabs_) (void)hipFree(s.base);
+    (void)hipSetDevice(prev);
+    slabs_.clear();
+    free_.clear();
+    reserved_ = used_ = 0;
+}
+
+} // namespace speckv

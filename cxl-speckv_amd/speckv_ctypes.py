@@ -1,0 +1,250 @@
+"""ctypes binding of libcxlspeckv.so.
+
+Same class, constructor, attributes and methods as the reference's binding
+(reference host/python/speckv_ctypes.py:7-98) so callers written against it run
+unchanged; the ``ext_*`` methods bind the additive entry points of
+include/speckv_ext.h when the loaded library exports them.
+"""
+import ctypes
+from ctypes import (c_char_p, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint16, c_uint32, c_uint64, c_void_p)
+
+
+class SpeckvError(RuntimeError):
+    """RuntimeError carrying the speckv_status_t code."""
+
+    def __init__(self, what, status):
+        super().__init__(f"{what} failed: {status}")
+        self.status = status
+
+
+class PageInfo(ctypes.Structure):
+    """speckv_ext_page_info_t (include/speckv_ext.h)."""
+    _fields_ = [("virt_page_id", c_uint64), ("phys_page_id", c_uint64), ("page_size", c_uint32),
+                ("flags", c_uint32), ("pool_device", c_int32), ("scheme", c_uint32), ("rec_bytes", c_uint32),
+                ("scale", c_float), ("pool_addr", c_uint64), ("cache_addr", c_uint64),
+                ("access_count", c_uint32), ("reserved", c_uint32)]
+
+
+class DmaDesc(ctypes.Structure):
+    """speckv_dma_desc_t == reference SpeckvDmaDesc (host/include/speckv_driver.hpp:9-14)."""
+    _fields_ = [("fpga_addr", c_uint64), ("gpu_addr", c_uint64), ("bytes", c_uint32), ("flags", c_uint32)]
+
+
+class Stats(ctypes.Structure):
+    """speckv_ext_stats_t (include/speckv_ext.h)."""
+    _fields_ = [(n, c_uint64) for n in (
+        "l1_hits", "l1_misses", "l2_hits", "l2_misses", "l3_accesses", "migrations_l1_to_l3",
+        "migrations_l3_to_l1", "total_prefetches", "successful_prefetches", "mispredictions",
+        "total_compressions", "total_decompressions", "compressed_bytes", "original_bytes",
+        "total_allocations", "total_deallocations", "current_allocated_bytes", "peak_allocated_bytes",
+        "dma_submitted", "dma_completed", "pool_bytes_reserved", "cache_bytes_reserved")] + \
+        [(n, c_uint32) for n in ("prefetch_depth", "compression_scheme", "quant_mode", "n_pool_devices")]
+
+
+_u32p = ctypes.POINTER(c_uint32)
+_u64p = ctypes.POINTER(c_uint64)
+
+_EXT_SIGNATURES = {
+    "speckv_ext_set_quant_mode": [c_int],
+    "speckv_ext_translate": [c_uint64, c_uint64, ctypes.POINTER(PageInfo)],
+    "speckv_ext_fetch_desc": [c_uint64, c_uint64, ctypes.POINTER(DmaDesc)],
+    "speckv_ext_set_layout": [c_uint64, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32],
+    "speckv_ext_write": [c_uint64, c_uint64, c_void_p, c_size_t, c_int],
+    "speckv_ext_read": [c_uint64, c_uint64, c_void_p, c_size_t, c_int],
+    "speckv_ext_fetch_range": [c_uint64, c_uint64, c_uint64, c_void_p, c_int, c_void_p],
+    "speckv_ext_fetch_list": [c_uint64, c_void_p, c_uint32, c_void_p, c_int, c_void_p],
+    "speckv_ext_access_batch": [c_uint64, _u64p, c_uint32, ctypes.POINTER(c_void_p)],
+    "speckv_ext_prefetch_batch": [c_uint32, _u32p, ctypes.POINTER(c_uint16), _u32p, _u32p],
+    "speckv_ext_prefetch_flush": [_u32p],
+    "speckv_ext_prefetch_lookup": [c_uint64, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p],
+    "speckv_ext_prefetch_legacy_addrs": [c_uint32, c_uint32, _u64p, _u32p],
+    "speckv_ext_verify": [c_uint32, c_int32, ctypes.POINTER(c_int32), c_uint32, _u32p, _u32p],
+    "speckv_ext_verify_batch": [c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "speckv_ext_get_prefetch_depth": [_u32p],
+    "speckv_ext_poll_complete": [_u32p],
+    "speckv_ext_sync": [],
+    "speckv_ext_codec_compress": [c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "speckv_ext_codec_decompress": [c_void_p, c_uint64, c_void_p, c_void_p, c_uint64, c_void_p, c_int, c_int, c_int, c_void_p],
+    "speckv_ext_promote_to_l1": [c_uint64, c_uint64],
+    "speckv_ext_demote_to_l3": [c_uint64, c_uint64],
+    "speckv_ext_stats": [ctypes.POINTER(Stats)],
+}
+
+
+def bind_ext(lib):
+    """Attach argtypes/restype of every speckv_ext_* symbol the library exports."""
+    found = []
+    for name, args in _EXT_SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            continue
+        fn.argtypes, fn.restype = args, c_int
+        found.append(name)
+    for name, res in (("speckv_ext_layer_compression_ratio", ctypes.c_double), ("speckv_ext_backend", c_char_p)):
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            continue
+        fn.restype = res
+        fn.argtypes = [c_uint32] if res is ctypes.c_double else []
+        found.append(name)
+    return found
+
+
+class SpeckvLib:
+    def __init__(self, path: str, dev_path: str = "/dev/speckv0"):
+        from .build import load_library
+        self.lib = load_library(path)
+
+        # typedef uint64_t speckv_handle_t;
+        self.handle_t = c_uint64
+
+        self.lib.speckv_init.argtypes = [c_char_p]
+        self.lib.speckv_init.restype = c_int
+        self.lib.speckv_finalize.argtypes = []
+        self.lib.speckv_finalize.restype = None
+
+        class AllocHint(ctypes.Structure):
+            _fields_ = [("preferred_node", c_uint32), ("reserved", c_uint32)]
+        self.AllocHint = AllocHint
+
+        self.lib.speckv_alloc.argtypes = [c_size_t, ctypes.POINTER(AllocHint), ctypes.POINTER(self.handle_t)]
+        self.lib.speckv_alloc.restype = c_int
+        self.lib.speckv_free.argtypes = [self.handle_t]
+        self.lib.speckv_free.restype = c_int
+        self.lib.speckv_access.argtypes = [self.handle_t, c_uint64, c_size_t, ctypes.POINTER(c_void_p)]
+        self.lib.speckv_access.restype = c_int
+        self.lib.speckv_prefetch.argtypes = [c_uint32, c_uint16, c_uint32, c_uint32, ctypes.POINTER(c_int32), c_uint32]
+        self.lib.speckv_prefetch.restype = c_int
+        self.lib.speckv_set_prefetch_depth.argtypes = [c_uint32]
+        self.lib.speckv_set_prefetch_depth.restype = c_int
+        self.lib.speckv_set_compression_scheme.argtypes = [c_int]
+        self.lib.speckv_set_compression_scheme.restype = c_int
+        self.ext = bind_ext(self.lib)
+
+        ret = self.lib.speckv_init(dev_path.encode("ascii"))
+        if ret != 0:
+            raise SpeckvError("speckv_init", ret)
+
+    # ---- the reference surface (speckv_ctypes.py:64-98) -------------
+    def alloc(self, bytes_needed, preferred_node=0):
+        hint = self.AllocHint(preferred_node, 0)
+        handle = self.handle_t()
+        ret = self.lib.speckv_alloc(bytes_needed, ctypes.byref(hint), ctypes.byref(handle))
+        if ret != 0:
+            raise SpeckvError("speckv_alloc", ret)
+        return handle.value
+
+    def free(self, handle):
+        ret = self.lib.speckv_free(handle)
+        if ret != 0:
+            raise SpeckvError("speckv_free", ret)
+
+    def access(self, handle, offset, length):
+        gpu_ptr = c_void_p()
+        ret = self.lib.speckv_access(handle, offset, length, ctypes.byref(gpu_ptr))
+        if ret != 0:
+            raise SpeckvError("speckv_access", ret)
+        return gpu_ptr.value
+
+    def prefetch(self, req_id, layer, cur_pos, depth_k, tokens):
+        arr = (c_int32 * len(tokens))(*tokens)
+        ret = self.lib.speckv_prefetch(req_id, layer, cur_pos, depth_k, arr, len(tokens))
+        if ret != 0:
+            raise SpeckvError("speckv_prefetch", ret)
+
+    def set_prefetch_depth(self, depth_k):
+        ret = self.lib.speckv_set_prefetch_depth(depth_k)
+        if ret != 0:
+            raise SpeckvError("speckv_set_prefetch_depth", ret)
+
+    def set_compression_scheme(self, scheme):
+        ret = self.lib.speckv_set_compression_scheme(scheme)
+        if ret != 0:
+            raise SpeckvError("speckv_set_compression_scheme", ret)
+
+    # ---- additions ---------------------------------------------------
+    def finalize(self):
+        self.lib.speckv_finalize()
+
+    def _ext(self, name, *args):
+        ret = getattr(self.lib, name)(*args)
+        if ret != 0:
+            raise SpeckvError(name, ret)
+
+    def translate(self, handle, offset):
+        info = PageInfo()
+        self._ext("speckv_ext_translate", handle, offset, ctypes.byref(info))
+        return info
+
+    def fetch_desc(self, handle, offset):
+        d = DmaDesc()
+        self._ext("speckv_ext_fetch_desc", handle, offset, ctypes.byref(d))
+        return d
+
+    def set_layout(self, handle, num_tokens, num_layers, num_heads, head_dim, bytes_per_element):
+        self._ext("speckv_ext_set_layout", handle, num_tokens, num_layers, num_heads, head_dim, bytes_per_element)
+
+    def set_quant_mode(self, mode):
+        self._ext("speckv_ext_set_quant_mode", mode)
+
+    def write(self, handle, offset, src_ptr, nbytes, on_device):
+        self._ext("speckv_ext_write", handle, offset, c_void_p(src_ptr), nbytes, int(on_device))
+
+    def read(self, handle, offset, dst_ptr, nbytes, on_device):
+        self._ext("speckv_ext_read", handle, offset, c_void_p(dst_ptr), nbytes, int(on_device))
+
+    def fetch_range(self, handle, first_page, n_pages, d_dst, out_f32=False, stream=None):
+        self._ext("speckv_ext_fetch_range", handle, first_page, n_pages, c_void_p(d_dst), int(out_f32), c_void_p(stream or 0))
+
+    def fetch_list(self, handle, d_pages, n, d_dst, out_f32=False, stream=None):
+        self._ext("speckv_ext_fetch_list", handle, c_void_p(d_pages), n, c_void_p(d_dst), int(out_f32), c_void_p(stream or 0))
+
+    def access_batch(self, handle, offsets):
+        n = len(offsets)
+        offs = (c_uint64 * n)(*offsets)
+        out = (c_void_p * n)()
+        self._ext("speckv_ext_access_batch", handle, offs, n, out)
+        return [p or 0 for p in out]
+
+    def prefetch_batch(self, req_ids, layers, cur_pos, depth_k=None):
+        n = len(req_ids)
+        k = (c_uint32 * n)(*depth_k) if depth_k is not None else None
+        self._ext("speckv_ext_prefetch_batch", n, (c_uint32 * n)(*req_ids), (c_uint16 * n)(*layers),
+                  (c_uint32 * n)(*cur_pos), k)
+
+    def prefetch_flush(self):
+        n = c_uint32()
+        self._ext("speckv_ext_prefetch_flush", ctypes.byref(n))
+        return n.value
+
+    def verify(self, req_id, actual_token, predicted):
+        hit, depth = c_uint32(), c_uint32()
+        arr = (c_int32 * max(len(predicted), 1))(*predicted)
+        self._ext("speckv_ext_verify", req_id, actual_token, arr, len(predicted), ctypes.byref(hit), ctypes.byref(depth))
+        return bool(hit.value), depth.value
+
+    def prefetch_depth(self):
+        d = c_uint32()
+        self._ext("speckv_ext_get_prefetch_depth", ctypes.byref(d))
+        return d.value
+
+    def poll_complete(self):
+        d = c_uint32()
+        self._ext("speckv_ext_poll_complete", ctypes.byref(d))
+        return d.value
+
+    def sync(self):
+        self._ext("speckv_ext_sync")
+
+    def promote_to_l1(self, handle, offset):
+        return self.lib.speckv_ext_promote_to_l1(handle, offset) == 0
+
+    def demote_to_l3(self, handle, offset):
+        return self.lib.speckv_ext_demote_to_l3(handle, offset) == 0
+
+    def stats(self):
+        s = Stats()
+        self._ext("speckv_ext_stats", ctypes.byref(s))
+        return s

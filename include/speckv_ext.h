@@ -1,0 +1,181 @@
+/*
+ * include/speckv_ext.h -- additive entry points of libcxlspeckv.so.
+ *
+ * The eight functions of include/speckv.h are the drop-in surface.  The
+ * reference C ABI stops at the fake pointer returned by speckv_access: it has
+ * no write path (flags bit0 exists only in tests/test_dma.c:42), no way to
+ * observe the page table (host/include/speckv_allocator.hpp:49-55 is private),
+ * no batch form, and it never reaches its own codec
+ * (src/fpga_engine/cache_engine.h:42-56) or prefetcher
+ * (src/prefetcher/speculative_prefetcher.h:45-57).  The speckv_ext_* functions
+ * below expose exactly those pieces, with plain pointers and sizes only, so
+ * that (a) parity can be checked on logical ids and on codec bytes, (b) a
+ * serving engine can drive the path in batches.  Each one cites the reference
+ * interface it stands in for.
+ *
+ * Pointers named d_* are DEVICE pointers on the compute GPU.  `stream` is a
+ * hipStream_t passed as void* (NULL = the engine's own fetch stream); all
+ * *_async style work is ordered on it.
+ */
+#ifndef SPECKV_EXT_H
+#define SPECKV_EXT_H
+
+#include "speckv.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPECKV_PAGE_SIZE   4096u          /* speckv_allocator.cpp:18,58 */
+#define SPECKV_BLOCK_ELEMS 2048u          /* fp16 elements per page */
+
+/* ---- quantiser mode (SURVEY.md sect. 0.4) ----------------------------- */
+typedef enum {
+    SPECKV_QUANT_REF_EXACT = 0,  /* bit-for-bit cache_engine.cpp:186-196,275-284 */
+    SPECKV_QUANT_INTENT    = 1,  /* q=clamp(round(x/s),-127,127), y=q*s (cache_engine.cpp:182, kv_compress.v:130) */
+} speckv_quant_mode_t;
+speckv_status_t speckv_ext_set_quant_mode(speckv_quant_mode_t mode);
+
+/* ---- DMA descriptor: wire format of the reference (speckv_driver.hpp:9-14,
+ *      driver/uapi/speckv_ioctl.h:10-15), 24 bytes -------------------------- */
+typedef struct {
+    uint64_t fpga_addr;   /* pool-side address (HBM of the pool GPU)            */
+    uint64_t gpu_addr;    /* compute-GPU address                                */
+    uint32_t bytes;
+    uint32_t flags;       /* bit0 0=pool->GPU 1=GPU->pool, bit1 compressed, bit2 prefetch */
+} speckv_dma_desc_t;
+#define SPECKV_DMA_WRITE      0x1u
+#define SPECKV_DMA_COMPRESSED 0x2u
+#define SPECKV_DMA_PREFETCH   0x4u
+
+/* ---- page table introspection (KvPageHandle, speckv_allocator.hpp:21-26) */
+typedef struct {
+    uint64_t virt_page_id;   /* (handle<<32)|(i<<12)          speckv_allocator.cpp:24 */
+    uint64_t phys_page_id;   /* 0x4000000000+(h<<20)+(i<<12)  speckv_allocator.cpp:25 */
+    uint32_t page_size;      /* 4096 */
+    uint32_t flags;          /* bit0 L1, bit1 L2, bit2 compressed */
+    int32_t  pool_device;    /* HIP device holding the pool copy, -1 in /dev/null mode */
+    uint32_t scheme;         /* speckv_comp_scheme_t of the allocation */
+    uint32_t rec_bytes;      /* bytes of the stored record (0 = never written) */
+    float    scale;          /* per-block scale factor */
+    uint64_t pool_addr;      /* device address of the record in the pool */
+    uint64_t cache_addr;     /* device address of the decompressed copy, 0 if not resident */
+    uint32_t access_count;   /* MemoryPage::access_count, cxl_memory_manager.h:34 */
+    uint32_t reserved;
+} speckv_ext_page_info_t;
+speckv_status_t speckv_ext_translate(speckv_handle_t handle, uint64_t offset_bytes,
+                                     speckv_ext_page_info_t* out);
+
+/* descriptor the engine would submit for a synchronous fetch of that page
+ * (speckv_allocator.cpp:115-127) -- logical ids, for parity */
+speckv_status_t speckv_ext_fetch_desc(speckv_handle_t handle, uint64_t offset_bytes,
+                                      speckv_dma_desc_t* out);
+
+/* ---- layout of the shim allocation (vllm_speckv_backend.py:26-43,87-100) */
+speckv_status_t speckv_ext_set_layout(speckv_handle_t handle, uint32_t num_tokens,
+                                      uint32_t num_layers, uint32_t num_heads,
+                                      uint32_t head_dim, uint32_t bytes_per_element);
+
+/* ---- data path --------------------------------------------------------- */
+/* Populate the pool (compress with the allocation's scheme).  offset and len
+ * must be multiples of 4096 (len may run to the end of the allocation).
+ * Stands in for the DMA write direction the reference only sketches. */
+speckv_status_t speckv_ext_write(speckv_handle_t handle, uint64_t offset_bytes,
+                                 const void* src, size_t len, int src_on_device);
+/* Fetch + decompress straight into a caller buffer, bypassing the tiers. */
+speckv_status_t speckv_ext_read(speckv_handle_t handle, uint64_t offset_bytes,
+                                void* dst, size_t len, int dst_on_device);
+/* The bulk hot path: fetch + decompress pages [first_page, first_page+n) of a
+ * handle into d_dst (n * 2048 elements, fp16 if out_f32==0 else fp32).
+ * Asynchronous on `stream`.  One kernel launch. */
+speckv_status_t speckv_ext_fetch_range(speckv_handle_t handle, uint64_t first_page,
+                                       uint64_t n_pages, void* d_dst, int out_f32,
+                                       void* stream);
+/* Same for an arbitrary device-resident page list. */
+speckv_status_t speckv_ext_fetch_list(speckv_handle_t handle, const uint32_t* d_pages,
+                                      uint32_t n, void* d_dst, int out_f32, void* stream);
+/* Batched speckv_access: out_ptrs[i] = device address of offsets[i]. */
+speckv_status_t speckv_ext_access_batch(speckv_handle_t handle, const uint64_t* offsets,
+                                        uint32_t n, void** out_ptrs);
+
+/* ---- speculative prefetch (speculative_prefetcher.cpp:25-82, prefetch_core.v:150-241) */
+/* Batched speckv_prefetch: host arrays of n requests against the handle that
+ * last received speckv_ext_set_layout. */
+speckv_status_t speckv_ext_prefetch_batch(uint32_t n, const uint32_t* req_ids,
+                                          const uint16_t* layers, const uint32_t* cur_pos,
+                                          const uint32_t* depth_k);
+/* Drain queued prefetch requests now; *n_issued = pages fetched into L2. */
+speckv_status_t speckv_ext_prefetch_flush(uint32_t* n_issued);
+/* The raw lookup kernel on device buffers: for request r, candidate pages of
+ * positions cur_pos+1..cur_pos+depth_k (K then V), residency-filtered with the
+ * handle's device flag mirror, compacted in request order into d_out_pages.
+ * *d_out_count receives the total.  Deterministic. */
+speckv_status_t speckv_ext_prefetch_lookup(speckv_handle_t handle, uint32_t n,
+                                           const uint32_t* d_req_ids, const uint32_t* d_layers,
+                                           const uint32_t* d_cur_pos, const uint32_t* d_depth_k,
+                                           uint32_t* d_out_pages, uint32_t cap,
+                                           uint32_t* d_out_count, void* stream);
+/* Legacy address list of the reference's CPU prefetcher
+ * (speculative_prefetcher.cpp:48,153-160): (0<<32)|(layer<<16)|(i+1). */
+speckv_status_t speckv_ext_prefetch_legacy_addrs(uint32_t layer, uint32_t depth_k,
+                                                 uint64_t* out_addrs, uint32_t* out_n);
+
+/* Verification + adaptive depth (speculative_prefetcher.cpp:84-137). */
+speckv_status_t speckv_ext_verify(uint32_t req_id, int32_t actual_token,
+                                  const int32_t* predicted, uint32_t n_predicted,
+                                  uint32_t* was_hit, uint32_t* new_depth);
+/* Batched token-compare kernel: hit[r] = actual[r] in predicted[r*k .. r*k+k). */
+speckv_status_t speckv_ext_verify_batch(uint32_t n, uint32_t k, const int32_t* d_actual,
+                                        const int32_t* d_predicted, uint8_t* d_hit,
+                                        uint32_t* d_hit_count, void* stream);
+speckv_status_t speckv_ext_get_prefetch_depth(uint32_t* depth_k);
+
+/* ---- completion queue (SpeckvDriver::poll_complete, speckv_driver.cpp:65-72;
+ *      kernel side speckv_kernel_module.c:194-215): descriptors completed
+ *      since the previous poll. */
+speckv_status_t speckv_ext_poll_complete(uint32_t* done);
+speckv_status_t speckv_ext_sync(void);
+
+/* ---- raw codec operators on caller-owned device buffers -------------------
+ * FPGACacheEngine::compress / ::decompress (cache_engine.cpp:40-116) applied
+ * per 2048-element KV block.  Work without speckv_init (need a HIP device). */
+speckv_status_t speckv_ext_codec_compress(const void* d_src_f16, uint64_t n_blocks,
+                                          void* d_recs, uint64_t rec_stride,
+                                          uint32_t* d_rec_bytes, float* d_scales,
+                                          int scheme, int quant_mode, void* stream);
+speckv_status_t speckv_ext_codec_decompress(const void* d_recs, uint64_t rec_stride,
+                                            const uint32_t* d_rec_bytes, const float* d_scales,
+                                            uint64_t n_blocks, void* d_dst, int out_f32,
+                                            int scheme, int quant_mode, void* stream);
+
+/* ---- tier manager (CXLMemoryManager, cxl_memory_manager.h:40-90) ---------- */
+speckv_status_t speckv_ext_promote_to_l1(speckv_handle_t handle, uint64_t offset_bytes);
+speckv_status_t speckv_ext_demote_to_l3(speckv_handle_t handle, uint64_t offset_bytes);
+
+/* ---- statistics (Statistics structs: cxl_memory_manager.h:73-83,
+ *      speculative_prefetcher.h:59-66, cache_engine.h:65-72, memory_allocator.h:42-48) */
+typedef struct {
+    uint64_t l1_hits, l1_misses, l2_hits, l2_misses, l3_accesses;
+    uint64_t migrations_l1_to_l3, migrations_l3_to_l1;
+    uint64_t total_prefetches, successful_prefetches, mispredictions;
+    uint64_t total_compressions, total_decompressions;
+    uint64_t compressed_bytes, original_bytes;
+    uint64_t total_allocations, total_deallocations;
+    uint64_t current_allocated_bytes, peak_allocated_bytes;
+    uint64_t dma_submitted, dma_completed;
+    uint64_t pool_bytes_reserved, cache_bytes_reserved;
+    uint32_t prefetch_depth, compression_scheme, quant_mode, n_pool_devices;
+} speckv_ext_stats_t;
+speckv_status_t speckv_ext_stats(speckv_ext_stats_t* out);
+
+/* hard-coded per-layer ratio table and analytic throughput of the reference
+ * (cache_engine.cpp:25-33,142-148,286-296) */
+double speckv_ext_layer_compression_ratio(uint32_t layer_id);
+
+/* library identity: "hip" when built with the HIP data path */
+const char* speckv_ext_backend(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPECKV_EXT_H */

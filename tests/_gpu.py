@@ -1,0 +1,75 @@
+"""Helpers for the -m gpu tests: drive libcxlspeckv.so through its C ABI with
+torch tensors as plain device buffers (torch is plumbing only)."""
+import ctypes as C
+
+import numpy as np
+
+import cxl_speckv_amd as pkg
+from cxl_speckv_amd.speckv_ctypes import bind_ext
+
+N = 2048
+
+
+def load_raw_lib():
+    """The library without speckv_init: raw codec / verify operators only."""
+    lib = pkg.load_library()
+    bind_ext(lib)
+    return lib
+
+
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def stream_ptr():
+    torch = torch_mod()
+    return torch.cuda.current_stream().cuda_stream
+
+
+def gpu_compress(lib, x16, scheme, mode, rec_stride=4096):
+    """x16: (B, 2048) float16 numpy.  Returns scales f32[B], lens u32[B], recs u8[B, stride]."""
+    torch = torch_mod()
+    x16 = np.ascontiguousarray(x16, dtype=np.float16).reshape(-1, N)
+    B = x16.shape[0]
+    d_x = torch.from_numpy(x16.view(np.int16)).cuda()
+    d_recs = torch.full((B, rec_stride), 0xA5, dtype=torch.uint8, device="cuda")
+    d_len = torch.zeros(B, dtype=torch.int32, device="cuda")
+    d_scale = torch.zeros(B, dtype=torch.float32, device="cuda")
+    rc = lib.speckv_ext_codec_compress(d_x.data_ptr(), B, d_recs.data_ptr(), rec_stride, d_len.data_ptr(),
+                                       d_scale.data_ptr(), scheme, mode, stream_ptr())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return (d_scale.cpu().numpy(), d_len.cpu().numpy().view(np.uint32), d_recs.cpu().numpy())
+
+
+def gpu_decompress(lib, recs, lens, scales, scheme, mode, out_f32=False):
+    torch = torch_mod()
+    recs = np.ascontiguousarray(recs, dtype=np.uint8)
+    B, stride = recs.shape
+    d_recs = torch.from_numpy(recs).cuda()
+    d_len = torch.from_numpy(np.ascontiguousarray(lens, dtype=np.uint32).view(np.int32)).cuda()
+    d_scale = torch.from_numpy(np.ascontiguousarray(scales, dtype=np.float32)).cuda()
+    if out_f32:
+        d_y = torch.full((B, N), float("nan"), dtype=torch.float32, device="cuda")
+    else:
+        d_y = torch.full((B, N), 0x7E00, dtype=torch.int16, device="cuda")
+    rc = lib.speckv_ext_codec_decompress(d_recs.data_ptr(), stride, d_len.data_ptr(), d_scale.data_ptr(), B,
+                                         d_y.data_ptr(), int(out_f32), scheme, mode, stream_ptr())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    y = d_y.cpu().numpy()
+    return y if out_f32 else y.view(np.float16)
+
+
+def assert_same_float_bits(a, b, what=""):
+    """Bit-exact except that NaNs only have to be NaNs on both sides."""
+    a = np.asarray(a); b = np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    na, nb = np.isnan(a), np.isnan(b)
+    assert np.array_equal(na, nb), f"{what}: NaN positions differ"
+    ua = a.view(np.uint16 if a.dtype == np.float16 else np.uint32)
+    ub = b.view(np.uint16 if b.dtype == np.float16 else np.uint32)
+    bad = (ua != ub) & ~na
+    assert not bad.any(), f"{what}: {int(bad.sum())} elements differ, first at {np.argwhere(bad)[0]}"

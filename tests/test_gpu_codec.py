@@ -1,0 +1,203 @@
+"""-m gpu: the HIP codec kernels against the oracle, through the C ABI
+(speckv_ext_codec_compress / speckv_ext_codec_decompress).
+
+Bar: compressed bytes, record lengths and scale bits identical; decoded fp32 and
+fp16 bit-identical (NaN payloads excepted) in both quantiser modes."""
+import os
+
+import numpy as np
+import pytest
+
+from tests._gpu import N, assert_same_float_bits, gpu_compress, gpu_decompress, load_raw_lib
+
+pytestmark = pytest.mark.gpu
+
+SCHEMES = [0, 1, 2]
+MODES = [0, 1]
+
+
+def make_blocks(seed=1234):
+    rng = np.random.default_rng(seed)
+    blocks = [
+        rng.standard_normal(N),                                   # gaussian
+        rng.standard_normal(N) * 3.7,
+        np.zeros(N),                                              # all zero -> runs of 255
+        np.repeat(rng.standard_normal(N // 32), 32),              # piecewise constant
+        np.full(N, 0.37),
+        np.linspace(-3, 3, N),
+        np.where(rng.random(N) < 0.02, rng.standard_normal(N), 0),  # sparse
+        rng.standard_normal(N) * 1e-3,
+        rng.standard_normal(N) * 6e-6,                            # fp16 subnormals
+        np.resize(np.array([65504, -65504, 6.1e-5, 5.96e-8, -5.96e-8, 0, -0.0, 1, -1]), N),
+        np.concatenate([np.zeros(255), [1.0], np.zeros(510), [2.0], np.zeros(N - 767)]),   # run splits at 255
+        np.concatenate([np.full(256, 1.0), np.full(N - 256, -1.0)]),
+        np.resize(np.array([1.0, 1.0, 2.0]), N),
+        np.arange(N) % 7 - 3.0,
+    ]
+    x = np.stack(blocks)
+    with np.errstate(over="ignore"):
+        x16 = x.astype(np.float16)
+    # inf / nan edge cases (cache_engine.cpp:176-180,190-191 through cvttss2si)
+    e1 = x16[0].copy(); e1[5] = np.inf
+    e2 = x16[0].copy(); e2[7] = np.nan
+    e3 = x16[0].copy(); e3[0] = -np.inf; e3[100] = np.nan
+    return np.concatenate([x16, np.stack([e1, e2, e3])])
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return load_raw_lib()
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_compress_matches_oracle(lib, oracle, scheme, mode):
+    x16 = make_blocks()
+    scales, lens, recs = gpu_compress(lib, x16, scheme, mode)
+    o_scales, o_lens, o_recs = oracle.compress_blocks_f16(x16, scheme, mode)
+    assert np.array_equal(lens, o_lens), (lens, o_lens)
+    if scheme != 0:
+        nan = np.isnan(o_scales)
+        assert np.array_equal(np.isnan(scales), nan)
+        assert scales[~nan].tobytes() == o_scales[~nan].tobytes()
+    for b in range(x16.shape[0]):
+        assert recs[b, :lens[b]].tobytes() == o_recs[b, :lens[b]].tobytes(), f"block {b}"
+
+
+@pytest.mark.parametrize("out_f32", [False, True])
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_decompress_matches_oracle(lib, oracle, scheme, mode, out_f32):
+    x16 = make_blocks()
+    o_scales, o_lens, o_recs = oracle.compress_blocks_f16(x16, scheme, mode)
+    y = gpu_decompress(lib, o_recs, o_lens, o_scales, scheme, mode, out_f32)
+    for b in range(x16.shape[0]):
+        if out_f32:
+            want = np.zeros(N, np.float32)
+            got = oracle.decompress_block_f32(o_recs[b, :o_lens[b]], o_scales[b], scheme, mode, N)
+        else:
+            want = np.zeros(N, np.float16)
+            got = oracle.decompress_block_f16(o_recs[b, :o_lens[b]], o_scales[b], scheme, mode, N)
+        want[:got.size] = got
+        assert_same_float_bits(y[b], want, f"scheme {scheme} mode {mode} block {b}")
+
+
+def test_golden_reference_vectors(lib, golden_dir):
+    """Reference-generated vectors (tests/golden/codec_vectors.npz): the HIP path
+    reproduces the reference's bytes and fp32 outputs without the oracle in between."""
+    g = np.load(os.path.join(golden_dir, "codec_vectors.npz"))
+    names = [k[:-2] for k in g.files if k.endswith(".x") and g[k].size == N]
+    assert len(names) >= 8
+    x16 = np.stack([g[f"{n}.x"] for n in names]).astype(np.float16)
+    scales, lens, recs = gpu_compress(lib, x16, 2, 0)
+    for i, n in enumerate(names):
+        assert scales[i].tobytes() == g[f"{n}.scale"][0].tobytes(), n
+        assert recs[i, :lens[i]].tobytes() == g[f"{n}.rle"].tobytes(), n
+    y = gpu_decompress(lib, recs, lens, scales, 2, 0, out_f32=True)
+    for i, n in enumerate(names):
+        assert_same_float_bits(y[i], g[f"{n}.y"], n)
+
+
+def test_decode_malformed_and_ragged(lib, oracle):
+    """Decoder edge cases of cache_engine.cpp:241-258: odd trailing byte, zero
+    counts, counts > 127, short / empty / overlong streams."""
+    rng = np.random.default_rng(5)
+    streams = [
+        [5, 3, 7],                       # odd tail dropped
+        [5, 0, 9, 2],                    # count 0
+        [255, 200, 1, 255, 128, 1],
+        [1],
+        [],
+        [3, 255] * 8 + [4, 8],           # exactly 2048
+        [3, 255] * 9,                    # overlong: clipped at the block
+        list(rng.integers(0, 256, 4096)),  # random pairs, random counts (sum >> 2048)
+        [b for _ in range(2048) for b in (int(rng.integers(0, 256)), 1)],   # 2048 runs of 1
+        [7, 0] * 100 + [9, 5],           # many zero-count pairs before data
+    ]
+    recs = np.zeros((len(streams), 4096), np.uint8)
+    lens = np.zeros(len(streams), np.uint32)
+    for i, s in enumerate(streams):
+        recs[i, :len(s)] = s
+        lens[i] = len(s)
+    scales = np.full(len(streams), 0.5, np.float32)
+    for mode in MODES:
+        y = gpu_decompress(lib, recs, lens, scales, 2, mode, out_f32=True)
+        for i in range(len(streams)):
+            want = np.zeros(N, np.float32)
+            got = oracle.decompress_block_f32(recs[i, :lens[i]], 0.5, 2, mode, N)
+            want[:got.size] = got
+            assert_same_float_bits(y[i], want, f"stream {i} mode {mode}")
+    # ragged INT8 / FP16 records
+    for scheme, ls in ((1, [0, 1, 7, 8, 9, 2047, 2048]), (0, [0, 2, 3, 14, 16, 18, 4094, 4096])):
+        recs = rng.integers(0, 256, (len(ls), 4096)).astype(np.uint8)
+        if scheme == 0:
+            recs = (rng.standard_normal((len(ls), N)).astype(np.float16)).view(np.uint8).reshape(len(ls), 4096)
+        lens = np.array(ls, np.uint32)
+        scales = np.full(len(ls), 0.25, np.float32)
+        y = gpu_decompress(lib, recs, lens, scales, scheme, 0, out_f32=False)
+        for i in range(len(ls)):
+            want = np.zeros(N, np.float16)
+            got = oracle.decompress_block_f16(recs[i, :lens[i]], 0.25, scheme, 0, N)
+            want[:got.size] = got
+            assert_same_float_bits(y[i], want, f"scheme {scheme} len {ls[i]}")
+
+
+def test_many_random_blocks(lib, oracle):
+    """2048 seeded blocks with mixed statistics (1/4 smooth, 1/4 sparse)."""
+    rng = np.random.default_rng(2001)
+    B = 2048
+    x = rng.standard_normal((B, N))
+    x[: B // 4] = np.repeat(rng.standard_normal((B // 4, N // 16)), 16, axis=1)
+    x[B // 4: B // 2] *= rng.random((B // 4, N)) < 0.05
+    x16 = x.astype(np.float16)
+    for mode in MODES:
+        scales, lens, recs = gpu_compress(lib, x16, 2, mode)
+        o_scales, o_lens, o_recs = oracle.compress_blocks_f16(x16, 2, mode)
+        assert np.array_equal(lens, o_lens)
+        assert scales.tobytes() == o_scales.tobytes()
+        mask = np.arange(4096)[None, :] < lens[:, None]
+        assert np.array_equal(recs[mask], o_recs[mask])
+        y = gpu_decompress(lib, recs, lens, scales, 2, mode)
+        want = oracle.decompress_blocks_f16(o_recs, o_lens, o_scales, 2, mode)
+        assert_same_float_bits(y, want, f"mode {mode}")
+
+
+def test_full_size_roundtrip_properties(lib):
+    """BASELINE config 2 size (131072 blocks = 512 MiB fp16): size-independent
+    properties instead of the oracle -- decode(encode(x)) is a fixed point of a
+    second encode/decode pass (idempotence), INTENT-mode error is bounded by
+    scale/2, FP16 scheme is the identity."""
+    import torch
+    B = 131072
+    g = torch.Generator(device="cuda"); g.manual_seed(2001)
+    x = torch.randn((B, N), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+    recs = torch.empty((B, 4096), dtype=torch.uint8, device="cuda")
+    lens = torch.empty(B, dtype=torch.int32, device="cuda")
+    scales = torch.empty(B, dtype=torch.float32, device="cuda")
+    y = torch.empty_like(x); y2 = torch.empty_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    for scheme, mode in ((0, 0), (1, 1), (2, 1), (2, 0)):
+        assert lib.speckv_ext_codec_compress(x.data_ptr(), B, recs.data_ptr(), 4096, lens.data_ptr(), scales.data_ptr(), scheme, mode, s) == 0
+        assert lib.speckv_ext_codec_decompress(recs.data_ptr(), 4096, lens.data_ptr(), scales.data_ptr(), B, y.data_ptr(), 0, scheme, mode, s) == 0
+        torch.cuda.synchronize()
+        if scheme == 0:
+            assert torch.equal(y.view(torch.int16), x.view(torch.int16))
+            continue
+        if mode == 1:
+            err = (y.float() - x.float()).abs()
+            bound = scales[:, None] * 0.5 + (y.float().abs() * 2 ** -11) + 1e-7
+            assert bool((err <= bound).all())
+            # idempotence: the INTENT quantiser is a projection (scale may shrink by < 1 ulp of fp16 max)
+            lens2 = torch.empty_like(lens); scales2 = torch.empty_like(scales)
+            assert lib.speckv_ext_codec_compress(y.data_ptr(), B, recs.data_ptr(), 4096, lens2.data_ptr(), scales2.data_ptr(), scheme, mode, s) == 0
+            assert lib.speckv_ext_codec_decompress(recs.data_ptr(), 4096, lens2.data_ptr(), scales2.data_ptr(), B, y2.data_ptr(), 0, scheme, mode, s) == 0
+            torch.cuda.synchronize()
+            err2 = (y2.float() - y.float()).abs()
+            assert bool((err2 <= bound).all())
+        if scheme == 2:
+            # record length law: every pair is 2 bytes, counts sum to 2048
+            l = lens.cpu().numpy().astype(np.int64)
+            assert (l % 2 == 0).all() and (l >= 2 * 9).all() and (l <= 4096).all()
+            sample = recs[:64].cpu().numpy()
+            for b in range(64):
+                assert int(sample[b, 1:l[b]:2].astype(np.int64).sum()) == N
