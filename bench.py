@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""bench.py -- KV blocks/s fetch+decompress on MI355X, against the HBM roofline.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one batch: fetch + decompress every
+4 KiB KV block of one Llama-3-8B-shaped sequence (BASELINE.json configs[1]:
+32 layers, 8 KV heads, D=128, fp16, T=4096 -> 131 072 blocks = 512 MiB) from the
+local-HBM pool into a contiguous fp16 destination, through the drop-in library's
+C ABI (speckv_ext_fetch_range; one kernel launch).  The pool is populated (and
+compressed on the GPU) before the timed region, so inputs are resident in HBM.
+
+With N ranks the blocks shard naturally: every rank owns the pool of its own
+sequence and decodes it locally -- no data-path collective, weak scaling.  Rank 0
+prints ONE JSON line; `value` is whole-job blocks/s.
+
+`roofline`     : the dominant kernel (k_fetch_decompress), algorithmic bytes per
+                 launch / average launch duration from HIP events recorded on the
+                 launch stream inside the timed region, vs 8 TB/s HBM3E.
+`cpu_baseline` : the reference's own FPGACacheEngine::decompress (oracle/_ref,
+                 kind "reference") or our C restatement (kind "port") timed on
+                 this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PAGE = 4096
+BLOCK_ELEMS = 2048
+SCHEME_NAMES = {0: "fp16", 1: "int8", 2: "int8_delta_rle"}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scheme", type=int, default=2, help="0 fp16, 1 int8, 2 int8+delta+rle (reference codec)")
+    ap.add_argument("--quant", type=int, default=0, help="0 REF_EXACT (parity mode), 1 INTENT")
+    ap.add_argument("--tokens", type=int, default=4096)
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    return ap.parse_args()
+
+
+# --------------------------------------------------------------------------
+# CPU baseline (checker code, used here ONLY as the thing timed beside the GPU)
+# --------------------------------------------------------------------------
+def cpu_baseline(seconds, sample_blocks=8192, seed=2001):
+    import ctypes as C
+    from oracle.bindings import Oracle, Reference, have_reference, _ptr, f32p, u8p, u32p
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((sample_blocks, BLOCK_ELEMS)).astype(np.float16).astype(np.float32)
+    n_threads = os.cpu_count() or 1
+    if have_reference():
+        kind = "reference"
+        ref = Reference()
+        L = ref.lib
+        recs = np.zeros((sample_blocks, 2 * BLOCK_ELEMS), np.uint8)
+        lens = np.zeros(sample_blocks, np.uint32)
+        scales = np.zeros(sample_blocks, np.float32)
+        L.ref_engine_compress_blocks(ref.engine, _ptr(x, f32p), sample_blocks, BLOCK_ELEMS, _ptr(scales, f32p),
+                                     _ptr(recs, u8p), 2 * BLOCK_ELEMS, _ptr(lens, u32p))
+
+        def work(lo, hi, out):
+            eng = L.ref_engine_new()          # one engine per thread, disjoint blocks
+            y = np.empty((hi - lo, BLOCK_ELEMS), np.float32)
+            t0 = time.perf_counter(); done = 0
+            while time.perf_counter() - t0 < seconds:
+                L.ref_engine_decompress_blocks(eng, _ptr(recs[lo:hi], u8p), 2 * BLOCK_ELEMS, _ptr(lens[lo:hi], u32p),
+                                               _ptr(scales[lo:hi], f32p), hi - lo, _ptr(y, f32p), BLOCK_ELEMS)
+                done += hi - lo
+            out.append((done, time.perf_counter() - t0))
+            L.ref_engine_delete(eng)
+    else:
+        kind = "port"
+        orc = Oracle()
+        L = orc.lib
+        scales, lens, recs = orc.compress_blocks_f16(x.astype(np.float16), 2, 0)
+
+        def work(lo, hi, out):
+            y = np.empty(BLOCK_ELEMS, np.float32)
+            t0 = time.perf_counter(); done = 0
+            while time.perf_counter() - t0 < seconds:
+                for b in range(lo, hi):
+                    L.orc_decompress_f32(_ptr(recs[b], u8p), int(lens[b]), C.c_float(float(scales[b])), 0,
+                                         _ptr(y, f32p), BLOCK_ELEMS)
+                done += hi - lo
+            out.append((done, time.perf_counter() - t0))
+
+    # 1 thread (the reference is single-threaded behind one mutex) ...
+    one = []
+    work(0, min(1024, sample_blocks), one)
+    v1 = one[0][0] / one[0][1]
+    # ... and all host cores, one engine per thread over disjoint blocks
+    outs, threads = [], []
+    per = sample_blocks // n_threads
+    for t in range(n_threads):
+        th = threading.Thread(target=work, args=(t * per, (t + 1) * per, outs))
+        th.start(); threads.append(th)
+    for th in threads:
+        th.join()
+    vall = sum(d for d, _ in outs) / max(e for _, e in outs)
+    return {"value": round(vall, 1), "unit": "blocks/s", "cores": n_threads, "kind": kind,
+            "value_1thread": round(v1, 1),
+            "sample": f"{sample_blocks} N(0,1) fp16 blocks (seed {seed}), INT8_DELTA_RLE decompress to fp32, "
+                      f"looped ~{seconds:.0f}s per leg; 1 thread and {n_threads} threads (one engine each)"}
+
+
+# --------------------------------------------------------------------------
+def main():
+    args = parse_args()
+    import torch
+    import cxl_speckv_amd as pkg
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the data path)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    T, Lyr, H, D, bpe = args.tokens, args.layers, 8, 128, 2
+    kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), f"hip:{local_rank}")
+    lib = kv.lib
+    lib.set_compression_scheme(args.scheme)
+    lib.set_quant_mode(args.quant)
+    handle = kv.allocate(T, Lyr, H, D, bpe)
+    n_blocks = T * Lyr * H * D * bpe * 2 // PAGE
+    # a dedicated HIP stream: the kernels are launched on it and the HIP events
+    # that time them are recorded on it (the NULL stream means "engine stream"
+    # to the library)
+    stream = torch.cuda.Stream()
+    sp = stream.cuda_stream
+    assert sp != 0
+
+    # synthetic KV: N(0,1) fp16 in the shim layout [req][layer][kind][pos][head][D]
+    g = torch.Generator(device="cuda"); g.manual_seed(2001 + rank)
+    src = torch.randn((n_blocks, BLOCK_ELEMS), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lib.write(handle, 0, src.data_ptr(), src.numel() * 2, on_device=True)      # compress into the pool
+    compress_s = time.perf_counter() - t0
+    dst = torch.empty((n_blocks, BLOCK_ELEMS), dtype=torch.float16, device="cuda")
+    st = lib.stats()
+    alg_bytes = st.compressed_bytes + n_blocks * (4 + PAGE)                    # c_i + 4 + 4096 per block
+
+    def step():
+        lib.fetch_range(handle, 0, n_blocks, dst.data_ptr(), False, sp)
+
+    for _ in range(args.warmup):
+        step()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    # parity spot check on this very data (oracle = checker only)
+    parity = None
+    if rank == 0:
+        from oracle.bindings import Oracle
+        orc = Oracle()
+        idx = np.linspace(0, n_blocks - 1, 48).astype(np.int64)
+        xs = src[idx].cpu().numpy()
+        got = dst[idx].cpu().numpy()
+        scales, lens, recs = orc.compress_blocks_f16(xs, args.scheme, args.quant)
+        want = orc.decompress_blocks_f16(recs, lens, scales, args.scheme, args.quant)
+        parity = bool(got.view(np.uint16).tobytes() == want.view(np.uint16).tobytes())
+        for j, p in enumerate(idx[:8]):
+            info = lib.translate(handle, int(p) * PAGE)
+            parity = parity and info.rec_bytes == int(lens[j]) and info.phys_page_id == 0x4000000000 + (handle << 20) + (int(p) << 12)
+
+    extras = {}
+    if rank == 0 and not args.no_extras:
+        with torch.cuda.stream(stream):
+            extras = run_extras(torch, pkg, lib, src, dst, n_blocks, sp)
+
+    if rank == 0:
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "KV blocks/s fetch+decompress",
+            "value": round(world * n_blocks * args.steps / elapsed, 1),
+            "unit": "blocks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[1]: 1xMI355X local-HBM pool, Llama-3-8B-shaped KV ({Lyr} layers, 8 KV heads, "
+                            f"D=128, fp16, T={T}) = {n_blocks} x 4 KiB blocks per GPU, fetch+decompress all blocks per step",
+                "scheme": SCHEME_NAMES[args.scheme],
+                "quantiser": "REF_EXACT" if args.quant == 0 else "INTENT",
+                "blocks_per_gpu": n_blocks,
+                "parallelism": f"blocks sharded over {world} rank(s), no data-path collective",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_fetch_decompress",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": int(alg_bytes),
+                "avg_launch_ms": round(kern_ms, 4),
+                "bytes_per_block": round(alg_bytes / n_blocks, 1),
+            },
+            "parity_spot_check": parity,
+            "compress_s_untimed": round(compress_s, 4),
+            "extras": extras,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out))
+    kv.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_extras(torch, pkg, lib, src, dst, n_blocks, sp):
+    """Secondary measurements through the raw codec operators (same kernels):
+    every scheme's decode, and the compress side.  Not part of `value`."""
+    raw = lib.lib
+    ex = {}
+    recs = torch.empty((n_blocks, PAGE), dtype=torch.uint8, device="cuda")
+    lens = torch.empty(n_blocks, dtype=torch.int32, device="cuda")
+    scales = torch.empty(n_blocks, dtype=torch.float32, device="cuda")
+
+    def timed(fn, reps=10):
+        fn(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); [fn() for _ in range(reps)]; b.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    for scheme, mode, name in ((0, 0, "fp16_copy"), (1, 0, "int8_ref_exact"), (2, 0, "rle_ref_exact"), (2, 1, "rle_intent")):
+        stride = 2048 if scheme == 1 else PAGE
+        enc = lambda: raw.speckv_ext_codec_compress(src.data_ptr(), n_blocks, recs.data_ptr(), stride, lens.data_ptr(), scales.data_ptr(), scheme, mode, sp)
+        dec = lambda: raw.speckv_ext_codec_decompress(recs.data_ptr(), stride, lens.data_ptr(), scales.data_ptr(), n_blocks, dst.data_ptr(), 0, scheme, mode, sp)
+        enc_ms = timed(enc)
+        dec_ms = timed(dec)
+        comp = int(lens.to(torch.int64).sum().item())
+        dec_bytes = comp + n_blocks * (4 + PAGE)
+        enc_bytes = n_blocks * PAGE + comp + n_blocks * 8
+        ex[name] = {
+            "decompress_blocks_per_s": round(n_blocks / (dec_ms * 1e-3), 1),
+            "decompress_GBps": round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1),
+            "decompress_frac_hbm": round(dec_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "compress_blocks_per_s": round(n_blocks / (enc_ms * 1e-3), 1),
+            "compress_GBps": round(enc_bytes / (enc_ms * 1e-3) / 1e9, 1),
+            "record_bytes_per_block": round(comp / n_blocks, 1),
+        }
+    return ex
+
+
+if __name__ == "__main__":
+    main()
