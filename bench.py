@@ -40,6 +40,23 @@ BLOCK_ELEMS = 2048
 SCHEME_NAMES = {0: "fp16", 1: "int8", 2: "int8_delta_rle"}
 
 
+def pmc_traffic(scheme, quant):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3
+    --pmc passes of this same command (profiles/*_pmc.json, corrected as
+    MI355X_MICROARCH.md prescribes).  PMC cannot be read from inside the run, so
+    this is the profile's number, labelled with its source; None if absent."""
+    import glob
+    key = f"k_fetch_decompress<{scheme}, {quant}, false>"
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(fn))["pmc"].get(key)
+        except Exception:
+            d = None
+        if d and d.get("hbm_traffic_bytes_per_launch"):
+            return int(d["hbm_traffic_bytes_per_launch"]), os.path.relpath(fn, ROOT)
+    return None, None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,6 +224,8 @@ def main():
 
     if rank == 0:
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_src = (pmc_traffic(args.scheme, args.quant)
+                                if (T, Lyr) == (4096, 32) else (None, None))
         out = {
             "metric": "KV blocks/s fetch+decompress",
             "value": round(world * n_blocks * args.steps / elapsed, 1),
@@ -235,7 +254,8 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "avg_launch_ms": round(kern_ms, 4),
                 "bytes_per_block": round(alg_bytes / n_blocks, 1),

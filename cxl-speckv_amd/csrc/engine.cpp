@@ -224,32 +224,49 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
                 for (size_t i = 0; i < pools_.size(); ++i) use.push_back(static_cast<int>(i));
             const uint64_t D = use.size();
             bool ok = true;
+            bool single_run = (D == 1);
+            std::vector<PageEntry> host;
             for (uint64_t k = 0; k < D && ok; ++k) {
                 const uint64_t np = (a->n_pages + D - 1 - k) / D;     // pages with page % D == k
-                if (np == 0) { a->extents.push_back({use[k], nullptr, 0, 0}); continue; }
+                if (np == 0) continue;
                 const size_t need = np * a->rec_stride;
                 void* base = pools_[use[k]]->alloc(need);
-                if (!base) { ok = false; break; }
-                a->extents.push_back({use[k], base, need, np});
+                if (base) {
+                    a->extents.push_back({use[k], base, need, np});
+                    if (!single_run) {
+                        if (host.empty()) host.resize(a->n_pages);
+                        for (uint64_t j = 0; j < np; ++j)
+                            host[k + j * D] = PageEntry{reinterpret_cast<uint64_t>(base) + j * a->rec_stride, 0u, 1.0f};
+                    }
+                    continue;
+                }
+                // fragmented pool: place the pages of this device in several runs
+                single_run = false;
+                if (host.empty()) host.resize(a->n_pages);
+                uint64_t placed = 0;
+                while (ok && placed < np) {
+                    size_t got = 0;
+                    void* part = pools_[use[k]]->alloc_up_to((np - placed) * a->rec_stride, a->rec_stride, &got);
+                    if (!part) { ok = false; break; }
+                    const uint64_t cnt = got / a->rec_stride;
+                    a->extents.push_back({use[k], part, got, cnt});
+                    for (uint64_t j = 0; j < cnt; ++j)
+                        host[k + (placed + j) * D] = PageEntry{reinterpret_cast<uint64_t>(part) + j * a->rec_stride, 0u, 1.0f};
+                    placed += cnt;
+                }
             }
             if (ok) ok = hipMalloc(reinterpret_cast<void**>(&a->d_entries), a->n_pages * sizeof(PageEntry)) == hipSuccess;
             if (ok) ok = hipMalloc(reinterpret_cast<void**>(&a->d_flags), a->n_pages * sizeof(uint32_t)) == hipSuccess;
             if (ok) ok = hipMemsetAsync(a->d_flags, 0, a->n_pages * sizeof(uint32_t), stream_) == hipSuccess;
             if (ok) {
-                if (D == 1) {
+                if (single_run)
                     ok = launch_init_entries(a->d_entries, a->n_pages, reinterpret_cast<uint64_t>(a->extents[0].base),
                                              a->rec_stride, stream_) == hipSuccess;
-                } else {
-                    std::vector<PageEntry> host(a->n_pages);
-                    for (uint64_t i = 0; i < a->n_pages; ++i) {
-                        const auto& ex = a->extents[i % D];
-                        host[i].pool_addr = reinterpret_cast<uint64_t>(ex.base) + (i / D) * a->rec_stride;
-                        host[i].rec_bytes = 0;
-                        host[i].scale = 1.0f;
-                    }
+                else
                     ok = hipMemcpy(a->d_entries, host.data(), host.size() * sizeof(PageEntry), hipMemcpyHostToDevice) == hipSuccess;
-                }
             }
+            a->pool_of_residue.assign(D, 0);
+            for (uint64_t k = 0; k < D; ++k) a->pool_of_residue[k] = use[k];
             if (ok) ok = hipStreamSynchronize(stream_) == hipSuccess;
             (void)hipSetDevice(prev);
             if (!ok) {
@@ -716,7 +733,7 @@ int Engine::translate(uint64_t handle, uint64_t off, speckv_ext_page_info_t* o)
         PageEntry e{};
         HIP_TRY(hipMemcpy(&e, a->d_entries + p, sizeof(e), hipMemcpyDeviceToHost));
         (void)hipSetDevice(prev);
-        o->pool_device = pools_[a->extents[p % a->extents.size()].pool]->device();
+        o->pool_device = pools_[a->pool_of_residue[p % a->pool_of_residue.size()]]->device();
         o->rec_bytes = e.rec_bytes;
         o->scale = e.scale;
         o->pool_addr = e.pool_addr;
@@ -755,6 +772,9 @@ int Engine::write(uint64_t handle, uint64_t off, const void* src, size_t len, bo
     const uint64_t full = len / kPageSize, tail = len % kPageSize;
     int prev = 0; (void)hipGetDevice(&prev); HIP_TRY(hipSetDevice(device_));
     reap(true);
+    // the source may have been produced on any stream of the caller: this call is
+    // synchronous anyway, so order it after everything queued on the device
+    if (on_device) HIP_TRY(hipDeviceSynchronize());
     CodecArgs c{};
     c.entries = a->d_entries;
     c.data_stride = kPageSize;
@@ -816,6 +836,7 @@ int Engine::read(uint64_t handle, uint64_t off, void* dst, size_t len, bool on_d
     if (len == 0) return SPECKV_OK;
     const uint64_t p0 = off / kPageSize, full = len / kPageSize, tail = len % kPageSize;
     int prev = 0; (void)hipGetDevice(&prev); HIP_TRY(hipSetDevice(device_));
+    if (on_device) HIP_TRY(hipDeviceSynchronize());    // dst may still be in use on a caller stream
     CodecArgs c{};
     c.entries = a->d_entries;
     c.data_stride = kPageSize;

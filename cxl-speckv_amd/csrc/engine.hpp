@@ -58,6 +58,7 @@ struct Allocation {
     // HIP mode
     struct Extent { int pool; void* base; size_t bytes; uint64_t n_pages; };
     std::vector<Extent> extents;
+    std::vector<int> pool_of_residue;     // pool index serving pages with page % D == k
     PageEntry* d_entries = nullptr;
     uint32_t* d_flags = nullptr;
     bool has_layout = false;

@@ -81,6 +81,32 @@ void* SlabPool::alloc(size_t bytes)
     return nullptr;
 }
 
+void* SlabPool::alloc_up_to(size_t want, size_t granule, size_t* got)
+{
+    *got = 0;
+    if (want == 0 || granule == 0) return nullptr;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        auto best = free_.end();
+        size_t best_len = 0;
+        for (auto it = free_.begin(); it != free_.end(); ++it) {
+            size_t usable = it->second / granule * granule;
+            if (usable > want) usable = want;
+            if (usable > best_len) { best_len = usable; best = it; }
+        }
+        if (best != free_.end() && best_len >= granule) {
+            const uintptr_t addr = best->first;
+            const size_t rest = best->second - best_len;
+            free_.erase(best);
+            if (rest) free_[addr + best_len] = rest;
+            used_ += best_len;
+            *got = best_len;
+            return reinterpret_cast<void*>(addr);
+        }
+        if (!grow(want < slab_bytes_ ? want : slab_bytes_)) return nullptr;
+    }
+    return nullptr;
+}
+
 void SlabPool::free(void* p, size_t bytes)
 {
     if (!p || bytes == 0) return;

@@ -27,6 +27,10 @@ public:
 
     // Contiguous run of `bytes` (rounded up to 4 KiB).  nullptr = out of memory.
     void* alloc(size_t bytes);
+    // Fragmented fallback: the largest free run that is a multiple of `granule`
+    // and at most `want` bytes (grows by one slab when nothing is free).
+    // *got receives its size; nullptr = out of memory.
+    void* alloc_up_to(size_t want, size_t granule, size_t* got);
     void free(void* p, size_t bytes);
     void release();                      // hipFree every slab
 

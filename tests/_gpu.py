@@ -73,3 +73,23 @@ def assert_same_float_bits(a, b, what=""):
     ub = b.view(np.uint16 if b.dtype == np.float16 else np.uint32)
     bad = (ua != ub) & ~na
     assert not bad.any(), f"{what}: {int(bad.sum())} elements differ, first at {np.argwhere(bad)[0]}"
+
+
+def _hip_runtime():
+    """The one HIP runtime already mapped in this process (torch's bundled copy)."""
+    import os
+    torch = torch_mod()
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    rt = C.CDLL(path if os.path.exists(path) else "libamdhip64.so")
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rt.hipMemcpy.restype = C.c_int
+    return rt
+
+
+def dev_to_host(ptr, nbytes):
+    """Copy nbytes from a raw device address (as returned by speckv_access)."""
+    torch_mod().cuda.synchronize()
+    buf = np.empty(nbytes, np.uint8)
+    rc = _hip_runtime().hipMemcpy(buf.ctypes.data, C.c_void_p(ptr), nbytes, 2)   # hipMemcpyDeviceToHost
+    assert rc == 0, rc
+    return buf

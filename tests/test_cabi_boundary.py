@@ -1,0 +1,249 @@
+"""-m "not gpu": the drop-in boundary on CPU.
+
+* libcxlspeckv.so loads (RTLD_NOW: no undefined symbols) and exports every
+  function include/speckv.h and include/speckv_ext.h declare;
+* on the reference's fake device "/dev/null" (page-table emulation, no data
+  path) every status code and every logical address equals the reference's,
+  replaying the traces captured from the reference (tests/golden/);
+* ports of the reference's own tests (tests/test_allocator.cpp, test_c_api.c,
+  test_python.py scenarios);
+* a data-path call without a HIP device fails loudly instead of falling back.
+No compute is executed here."""
+import ctypes as C
+import json
+import os
+import re
+
+import pytest
+
+import cxl_speckv_amd as pkg
+from cxl_speckv_amd.speckv_ctypes import SpeckvError
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    return pkg.build_library()
+
+
+@pytest.fixture()
+def nulllib(libpath):
+    lib = pkg.SpeckvLib(libpath, "/dev/null")
+    yield lib
+    lib.finalize()
+
+
+def declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(speckv_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(libpath):
+    lib = C.CDLL(libpath, mode=os.RTLD_NOW)
+    names = declared_functions("speckv.h") + declared_functions("speckv_ext.h")
+    assert len(declared_functions("speckv.h")) == 8
+    assert len(names) > 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ but not exported"
+    assert lib.speckv_ext_backend is not None
+    lib.speckv_ext_backend.restype = C.c_char_p
+    assert lib.speckv_ext_backend() == b"hip"
+
+
+def test_abi_struct_sizes():
+    from cxl_speckv_amd.speckv_ctypes import DmaDesc, PageInfo
+    assert C.sizeof(DmaDesc) == 24            # driver/uapi/speckv_ioctl.h:10-15
+    assert C.sizeof(PageInfo) == 64
+
+
+def test_cabi_trace_replay(libpath, golden_dir):
+    """F-cabi: the reference's C ABI on /dev/null, call by call."""
+    trace = json.load(open(os.path.join(golden_dir, "cabi_trace.json")))["trace"]
+    lib = pkg.load_library(libpath)
+    lib.speckv_alloc.argtypes = [C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.speckv_free.argtypes = [C.c_uint64]
+    lib.speckv_access.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.speckv_prefetch.argtypes = [C.c_uint32, C.c_uint16, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32]
+    lib.speckv_init.argtypes = [C.c_char_p]
+    lib.speckv_finalize.restype = None
+    for e in trace:
+        op, a, st, val = e["op"], e["args"], e["status"], e["value"]
+        if op == "init":
+            if a[0] == "/dev/speckv0":
+                # no HIP device here: like the reference without its char device -> -1
+                import torch
+                if torch.cuda.is_available():
+                    continue
+            assert lib.speckv_init(a[0].encode()) == st, e
+        elif op == "finalize":
+            lib.speckv_finalize()
+        elif op == "alloc":
+            h = C.c_uint64()
+            assert lib.speckv_alloc(a[0], None, C.byref(h)) == st, e
+            if st == 0: assert h.value == val, e
+        elif op == "alloc_null_out":
+            assert lib.speckv_alloc(a[0], None, None) == st
+        elif op == "free":
+            assert lib.speckv_free(a[0]) == st, e
+        elif op == "access":
+            p = C.c_void_p()
+            assert lib.speckv_access(a[0], a[1], a[2], C.byref(p)) == st, e
+            if st == 0: assert (p.value or 0) == val, e
+        elif op == "access_null_out":
+            assert lib.speckv_access(a[0], a[1], a[2], None) == st
+        elif op == "prefetch":
+            toks = a[4]
+            arr = (C.c_int32 * 16)(*(toks if toks else [0] * 16))
+            ptr = None if toks is None else arr
+            n = 16 if toks is None else len(toks)
+            assert lib.speckv_prefetch(a[0], a[1], a[2], a[3], ptr, n) == st, e
+        elif op == "set_prefetch_depth":
+            assert lib.speckv_set_prefetch_depth(a[0]) == st, e
+        elif op == "set_compression_scheme":
+            assert lib.speckv_set_compression_scheme(a[0]) == st, e
+        else:
+            raise AssertionError(op)
+    lib.speckv_finalize()
+
+
+def test_shim_offsets_and_pointers(libpath, golden_dir):
+    """F-offset: our CxlSpeckvKVAllocator against the reference shim's outputs."""
+    g = json.load(open(os.path.join(golden_dir, "shim_offsets.json")))
+    kv = pkg.CxlSpeckvKVAllocator(libpath, "/dev/null")
+    try:
+        for cfg in g["configs"]:
+            T, L, H, D, bpe = (cfg[k] for k in ("T", "L", "H", "D", "bpe"))
+            handle = kv.allocate(T, L, H, D, bpe)
+            assert handle == cfg["handle"]
+            for e in cfg["entries"]:
+                off = kv._calc_offset(e["req"], e["layer"], e["head"], e["pos"], e["kind"], D * bpe)
+                assert off == e["offset"]
+                if e["status"] == 0:
+                    assert kv.get_kv_ptr(e["req"], e["layer"], e["head"], e["pos"], e["kind"], D * bpe) == e["ptr"]
+                else:
+                    with pytest.raises(RuntimeError, match=f"speckv_access failed: {e['status']}"):
+                        kv.get_kv_ptr(e["req"], e["layer"], e["head"], e["pos"], e["kind"], D * bpe)
+        kv.prefetch_step(0, 0, 100, list(range(1, 17)), 4)
+    finally:
+        kv.close()
+
+
+def test_translate_matches_oracle_ids(nulllib, oracle):
+    O = oracle.lib
+    h1 = nulllib.alloc(5 << 20)
+    h2 = nulllib.alloc(12345)
+    for h, size in ((h1, 5 << 20), (h2, 12345)):
+        for off in (0, 1, 4095, 4096, 8197, size - 1):
+            info = nulllib.translate(h, off)
+            p = off // 4096
+            assert info.virt_page_id == O.orc_virt_page_id(h, p)
+            assert info.phys_page_id == O.orc_phys_page_id(h, p)
+            assert info.page_size == 4096 and info.pool_device == -1
+            d = nulllib.fetch_desc(h, off)
+            assert (d.fpga_addr, d.gpu_addr, d.bytes, d.flags) == (info.phys_page_id, O.orc_desc_gpu_addr(info.virt_page_id), 4096, 0)
+    # residency flag after access (speckv_allocator.cpp:135): bit1, first page only
+    assert nulllib.translate(h1, 3 * 4096).flags == 0
+    nulllib.access(h1, 3 * 4096 + 5, 9000)
+    assert nulllib.translate(h1, 3 * 4096).flags == 2
+    assert nulllib.translate(h1, 4 * 4096).flags == 0          # length ignored by the reference
+    with pytest.raises(SpeckvError) as ei:
+        nulllib.translate(h1, 5 << 20)
+    assert ei.value.status == -1
+
+
+def test_reference_test_allocator_scenarios(nulllib):
+    """Port of reference tests/test_allocator.cpp:11-136 on the fake device."""
+    h = nulllib.alloc(1024 * 1024)
+    assert h != 0
+    nulllib.free(h)
+    hs = [nulllib.alloc(4096 * (i + 1)) for i in range(10)]
+    assert all(hs) and len(set(hs)) == 10
+    for x in hs:
+        nulllib.free(x)
+    h = nulllib.alloc(4096)
+    p = [nulllib.access(h, o, 1024) for o in (0, 1024, 2048)]
+    base = 0x4000000000 + (h << 20)
+    assert p == [base, base + 0x400, base + 0x800]            # what the reference prints for handle 1: 0x4000100000...
+    nulllib.free(h)
+    nulllib.prefetch(1, 0, 100, 4, list(range(1, 17)))
+
+
+def test_reference_test_python_scenarios(libpath):
+    """Port of reference tests/test_python.py:17-99.  The reference test re-inits
+    without finalize and fails there; ours finalizes."""
+    for _ in range(3):
+        lib = pkg.SpeckvLib(libpath, "/dev/null")
+        with pytest.raises(SpeckvError) as ei:                 # double init -> -1, as the reference
+            pkg.SpeckvLib(libpath, "/dev/null")
+        assert ei.value.status == -1
+        h = lib.alloc(1024 * 1024)
+        assert lib.access(h, 0, 4096) == 0x4000000000 + (h << 20)
+        lib.prefetch(req_id=1, layer=0, cur_pos=100, depth_k=4, tokens=list(range(1, 17)))
+        lib.free(h)
+        lib.finalize()
+
+
+def test_no_cpu_fallback_for_the_data_path(nulllib):
+    """The fake device has no data path: every data call fails with DRIVER (-2)."""
+    h = nulllib.alloc(1 << 20)
+    buf = (C.c_uint8 * 4096)()
+    for call in (lambda: nulllib.write(h, 0, C.addressof(buf), 4096, False),
+                 lambda: nulllib.read(h, 0, C.addressof(buf), 4096, False),
+                 lambda: nulllib.fetch_range(h, 0, 1, C.addressof(buf)),
+                 lambda: nulllib.poll_complete()):
+        with pytest.raises(SpeckvError) as ei:
+            call()
+        assert ei.value.status == -2
+    with pytest.raises(SpeckvError) as ei:
+        nulllib.set_compression_scheme(2)                      # reference on /dev/null: ioctl fails -> -2
+    assert ei.value.status == -2
+
+
+def test_init_without_gpu_fails_loudly(libpath, capfd):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    with pytest.raises(SpeckvError) as ei:
+        pkg.SpeckvLib(libpath, "/dev/speckv0")
+    assert ei.value.status == -1                               # reference: open() fails -> exception -> -1
+    assert "no usable HIP device" in capfd.readouterr().err
+
+
+def test_verify_and_adaptive_depth_host_logic(nulllib, golden_dir):
+    """speckv_ext_verify drives the same depth trace as the reference prefetcher."""
+    g = json.load(open(os.path.join(golden_dir, "prefetch.json")))
+    assert nulllib.prefetch_depth() == g["initial_depth"]
+    for ok, want in zip(g["outcomes"], g["depth_trace"]):
+        hit, depth = nulllib.verify(0, 5 if ok else 9, [1, 5, 7])
+        assert hit == bool(ok) and depth == want
+    st = nulllib.stats()
+    assert st.mispredictions == g["outcomes"].count(0)
+    addrs = (C.c_uint64 * 16)(); n = C.c_uint32()
+    for c in g["calls"]:
+        k = c["depth"] or 4
+        assert nulllib.lib.speckv_ext_prefetch_legacy_addrs(c["layer"], k, addrs, C.byref(n)) == 0
+        assert list(addrs[:n.value]) == c["addresses"]
+
+
+def test_layer_ratio_table(libpath, oracle):
+    lib = pkg.load_library(libpath)
+    lib.speckv_ext_layer_compression_ratio.restype = C.c_double
+    lib.speckv_ext_layer_compression_ratio.argtypes = [C.c_uint32]
+    for layer in list(range(90)) + [1000]:
+        assert lib.speckv_ext_layer_compression_ratio(layer) == oracle.lib.orc_layer_compression_ratio(layer)
+
+
+def test_div127_identity():
+    """The divide-free dequantiser in kernels.hip (div127): q*fl(1/127) plus one
+    Newton step equals float(q)/127.0f for every int8 q."""
+    import numpy as np
+    f32 = np.float32
+    q = np.arange(-128, 128).astype(f32)
+    rcp = f32(1.0) / f32(127.0)
+    assert rcp == np.float32(float.fromhex("0x1.020408p-7"))
+    r0 = (q * rcp).astype(f32)
+    e = (-127.0 * r0.astype(np.float64) + q.astype(np.float64)).astype(f32)       # exact fma, one rounding
+    r1 = (e.astype(np.float64) * np.float64(rcp) + r0.astype(np.float64)).astype(f32)
+    assert np.array_equal(r1, (q / f32(127.0)).astype(f32))

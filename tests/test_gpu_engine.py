@@ -1,0 +1,318 @@
+"""-m gpu: the engine behind the C ABI (HIP device mode) against the oracle.
+
+Indexing / residency / descriptor work must be bit-exact; decoded KV must be
+bit-exact in REF_EXACT mode (same tolerance statement as test_gpu_codec.py)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import cxl_speckv_amd as pkg
+from cxl_speckv_amd.speckv_ctypes import SpeckvError
+from tests._gpu import N, assert_same_float_bits, dev_to_host, torch_mod
+
+pytestmark = pytest.mark.gpu
+PAGE = 4096
+
+
+@pytest.fixture()
+def eng():
+    kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), "hip:0")
+    yield kv
+    kv.close()
+
+
+def synth(n_pages, seed=1234):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n_pages, N))
+    x[1::7] = 0.0
+    x[2::7] = np.repeat(rng.standard_normal((len(x[2::7]), N // 32)), 32, axis=1)
+    return x.astype(np.float16)
+
+
+@pytest.mark.parametrize("scheme", [0, 1, 2])
+def test_write_read_translate_parity(eng, oracle, scheme):
+    lib = eng.lib
+    lib.set_compression_scheme(scheme)
+    T, L, H, D, bpe = 128, 1, 8, 128, 2                      # BASELINE config 1 shape
+    h = eng.allocate(T, L, H, D, bpe)
+    n_pages = T * L * H * D * bpe * 2 // PAGE
+    x = synth(n_pages)
+    lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+    y = np.empty_like(x)
+    lib.read(h, 0, y.ctypes.data, y.nbytes, False)
+    scales, lens, recs = oracle.compress_blocks_f16(x, scheme, 0)
+    want = oracle.decompress_blocks_f16(recs, lens, scales, scheme, 0)
+    assert_same_float_bits(y, want)
+    for p in range(n_pages):
+        info = lib.translate(h, p * PAGE + 17)
+        assert info.virt_page_id == oracle.lib.orc_virt_page_id(h, p)
+        assert info.phys_page_id == oracle.lib.orc_phys_page_id(h, p)
+        assert info.rec_bytes == lens[p] and info.scheme == scheme and info.pool_device == 0
+        assert np.float32(info.scale).tobytes() == scales[p].tobytes()
+        assert info.flags == (4 if scheme else 0)            # bit2 = compressed, not resident yet
+        stored = dev_to_host(info.pool_addr, int(lens[p]))
+        assert stored.tobytes() == recs[p, :lens[p]].tobytes()
+    st = lib.stats()
+    assert st.total_compressions == n_pages and st.compressed_bytes == int(lens.sum())
+
+
+def test_access_returns_decoded_page_and_sets_l2(eng, oracle):
+    lib = eng.lib
+    lib.set_compression_scheme(2)
+    h = eng.allocate(128, 1, 8, 128, 2)
+    x = synth(128)
+    lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+    scales, lens, recs = oracle.compress_blocks_f16(x, 2, 0)
+    want = oracle.decompress_blocks_f16(recs, lens, scales, 2, 0)
+    for (layer, head, pos, kind) in ((0, 0, 0, 0), (0, 7, 127, 1), (0, 3, 64, 0), (0, 1, 5, 1)):
+        off = eng._calc_offset(0, layer, head, pos, kind, 256)
+        ptr = eng.get_kv_ptr(0, layer, head, pos, kind, 256)
+        got = dev_to_host(ptr, 256).view(np.float16)
+        flat = want.reshape(-1)
+        assert_same_float_bits(got, flat[off // 2: off // 2 + 128])
+        info = lib.translate(h, off)
+        assert info.flags & 2 and info.cache_addr == ptr - off % PAGE
+    with pytest.raises(RuntimeError, match="speckv_access failed: -1"):
+        eng.get_kv_ptr(1, 0, 0, 0, 0, 256)                    # req_id 1 overflows the allocation, like the reference
+    # hot page promotion: > 10 touches of an L2 page -> L1 (cxl_memory_manager.cpp:247-257, memory_allocator.cpp:127-134)
+    off = eng._calc_offset(0, 0, 0, 40, 0, 256)
+    for i in range(12):
+        ptr = lib.access(h, off, 256)
+    info = lib.translate(h, off)
+    assert info.flags & 1 and not info.flags & 2 and info.access_count == 12
+    assert_same_float_bits(dev_to_host(ptr, 256).view(np.float16), want.reshape(-1)[off // 2: off // 2 + 128])
+    st = lib.stats()
+    assert st.l1_hits >= 1 and st.l2_hits >= 9 and st.l3_accesses >= 5
+    # a span over three pages comes back contiguous
+    ptr = lib.access(h, 10 * PAGE + 100, 2 * PAGE + 50)
+    got = dev_to_host(ptr, 2 * PAGE + 50)
+    assert got.tobytes() == want.view(np.uint8).reshape(-1)[10 * PAGE + 100: 12 * PAGE + 150].tobytes()
+    # explicit tier moves
+    assert lib.demote_to_l3(h, off) and lib.translate(h, off).flags & 3 == 0
+    assert lib.promote_to_l1(h, off) and lib.translate(h, off).flags & 1
+    assert not lib.promote_to_l1(h, off)                      # already there -> false, as CXLMemoryManager
+
+
+def test_prefetch_through_cabi_matches_oracle_pages(eng, oracle):
+    lib = eng.lib
+    lib.set_compression_scheme(2)
+    T, L, H, D, bpe = 512, 4, 8, 128, 2
+    h = eng.allocate(T, L, H, D, bpe)
+    n_pages = T * L * H * D * bpe * 2 // PAGE
+    x = synth(n_pages, seed=7)
+    lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+    toks = list(range(1, 17))
+    pos, k = 100, 4
+    for layer in range(L):                                    # the decode-loop sketch of the reference shim
+        eng.prefetch_step(0, layer, pos, toks, k)
+    lib.sync()
+    expect = set()
+    for layer in range(L):
+        expect |= set(oracle.prefetch_pages(0, layer, pos, k, L, T, H, D, bpe, n_pages).tolist())
+    resident = {p for p in range(n_pages) if lib.translate(h, p * PAGE).flags & 3}
+    assert resident == expect
+    assert lib.stats().total_prefetches == len(expect)
+    done = lib.poll_complete()
+    assert done == len(expect) and lib.poll_complete() == 0   # cleared by the poll, speckv_kernel_module.c:194-215
+    # prefetched data is the decoded page
+    scales, lens, recs = oracle.compress_blocks_f16(x, 2, 0)
+    p = sorted(expect)[0]
+    ptr = lib.access(h, p * PAGE, 64)
+    want = oracle.decompress_block_f16(recs[p, :lens[p]], scales[p], 2, 0, N)
+    assert_same_float_bits(dev_to_host(ptr, PAGE).view(np.float16), want)
+    assert lib.stats().l2_hits >= 1
+    # a second look-ahead at the same position issues nothing new
+    assert eng.prefetch_decode_step([0], [pos], k) == 0
+    assert eng.prefetch_decode_step([0], [pos + 2], k) > 0
+
+
+def test_lookup_kernel_matches_oracle_order(eng, oracle):
+    torch = torch_mod()
+    lib = eng.lib
+    T, L, H, D, bpe = 4096, 32, 8, 128, 2                     # Llama-3-8B-shaped, BASELINE config 2/3
+    h = eng.allocate(T, L, H, D, bpe)
+    n_pages = T * L * H * D * bpe * 2 // PAGE
+    rng = np.random.default_rng(11)
+    # make some pages resident first so the residency filter has work to do
+    for p in rng.integers(0, n_pages, 300):
+        lib.access(h, int(p) * PAGE, 1)
+    flags = np.array([lib.translate(h, int(p) * PAGE).flags for p in range(0, n_pages, 1)], np.uint32) if n_pages <= 4096 else None
+    n = 3000
+    req = np.zeros(n, np.uint32); req[::97] = 1               # req 1 is out of range -> nothing
+    layer = rng.integers(0, L, n).astype(np.uint32)
+    pos = rng.integers(0, T, n).astype(np.uint32); pos[:50] = T - 3
+    k = rng.integers(1, 17, n).astype(np.uint32)
+    t = lambda a: torch.from_numpy(a.view(np.int32)).cuda()
+    d_req, d_layer, d_pos, d_k = t(req), t(layer), t(pos), t(k)
+    cap = n * 64
+    d_out = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    d_cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rc = lib.lib.speckv_ext_prefetch_lookup(h, n, d_req.data_ptr(), d_layer.data_ptr(), d_pos.data_ptr(), d_k.data_ptr(),
+                                            d_out.data_ptr(), cap, d_cnt.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    cnt = int(d_cnt.item())
+    got = d_out[:cnt].cpu().numpy().view(np.uint32)
+    fl = np.zeros(n_pages, np.uint32)
+    touched = {int(p) for p in np.random.default_rng(11).integers(0, n_pages, 300)}
+    for p in touched:
+        fl[p] = lib.translate(h, p * PAGE).flags
+    want = []
+    for i in range(n):
+        want += oracle.prefetch_pages(int(req[i]), int(layer[i]), int(pos[i]), int(k[i]), L, T, H, D, bpe, n_pages, fl).tolist()
+    assert cnt == len(want)
+    assert got.tolist() == want                                # same pages, same order: deterministic compaction
+
+
+def test_lookup_odd_geometry(eng, oracle):
+    """Rows that straddle pages (H*D*bpe not a divisor of 4096)."""
+    torch = torch_mod()
+    lib = eng.lib
+    T, L, H, D, bpe = 100, 3, 5, 96, 2
+    h = eng.allocate(T, L, H, D, bpe)
+    n_pages = (T * L * H * D * bpe * 2 + PAGE - 1) // PAGE
+    rng = np.random.default_rng(3)
+    n = 500
+    req = np.zeros(n, np.uint32)
+    layer = rng.integers(0, L, n).astype(np.uint32)
+    pos = rng.integers(0, T, n).astype(np.uint32)
+    k = rng.integers(1, 9, n).astype(np.uint32)
+    t = lambda a: torch.from_numpy(a.view(np.int32)).cuda()
+    d = [t(a) for a in (req, layer, pos, k)]
+    d_out = torch.zeros(n * 64, dtype=torch.int32, device="cuda"); d_cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert lib.lib.speckv_ext_prefetch_lookup(h, n, *[a.data_ptr() for a in d], d_out.data_ptr(), n * 64, d_cnt.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    got = d_out[:int(d_cnt.item())].cpu().numpy().view(np.uint32).tolist()
+    want = []
+    for i in range(n):
+        want += oracle.prefetch_pages(0, int(layer[i]), int(pos[i]), int(k[i]), L, T, H, D, bpe, n_pages).tolist()
+    assert got == want
+
+
+def test_verify_batch_kernel(oracle):
+    torch = torch_mod()
+    lib = pkg.load_library()
+    from cxl_speckv_amd.speckv_ctypes import bind_ext
+    bind_ext(lib)
+    rng = np.random.default_rng(5)
+    for k in (1, 3, 4, 8, 13, 64):
+        n = 5000
+        pred = rng.integers(0, 50, (n, k)).astype(np.int32)
+        actual = rng.integers(0, 50, n).astype(np.int32)
+        d_pred = torch.from_numpy(pred).cuda(); d_act = torch.from_numpy(actual).cuda()
+        d_hit = torch.full((n,), 7, dtype=torch.uint8, device="cuda"); d_cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        assert lib.speckv_ext_verify_batch(n, k, d_act.data_ptr(), d_pred.data_ptr(), d_hit.data_ptr(), d_cnt.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        want = (pred == actual[:, None]).any(axis=1)
+        assert np.array_equal(d_hit.cpu().numpy().astype(bool), want)
+        assert int(d_cnt.item()) == int(want.sum())
+        for i in range(0, n, 617):                            # and the oracle's per-call predicate
+            u = pred[i].astype(np.uint32)
+            miss = oracle.lib.orc_is_misprediction(int(actual[i]), u.ctypes.data_as(C.POINTER(C.c_uint32)), k)
+            assert bool(miss) == (not want[i])
+
+
+def test_eviction_and_refetch_small_cache():
+    """L2 ring smaller than the working set: evicted pages lose their residency
+    bit and come back correct when touched again."""
+    os.environ["SPECKV_L2_MB"] = "1"                          # 256 slots
+    os.environ["SPECKV_L1_MB"] = "1"
+    try:
+        kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), "hip:0")
+    finally:
+        del os.environ["SPECKV_L2_MB"]; del os.environ["SPECKV_L1_MB"]
+    try:
+        lib = kv.lib
+        lib.set_compression_scheme(1)
+        h = kv.allocate(1024, 1, 8, 128, 2)                   # 1024 pages
+        x = synth(1024, seed=99)
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+        y = np.empty_like(x); lib.read(h, 0, y.ctypes.data, y.nbytes, False)
+        for p in range(600):
+            lib.access(h, p * PAGE, 8)
+        res = [bool(lib.translate(h, p * PAGE).flags & 3) for p in range(600)]
+        assert sum(res) == 256 and all(res[-256:]) and not any(res[:300])
+        for p in (0, 17, 599, 300):
+            ptr = lib.access(h, p * PAGE, 8)
+            assert dev_to_host(ptr, PAGE).tobytes() == y[p].tobytes()
+        # L1 LRU eviction: 256 L1 slots, promote 300 pages
+        for p in range(300):
+            lib.promote_to_l1(h, (700 + p) * PAGE) if not lib.translate(h, (700 + p) * PAGE).flags & 1 else None
+        l1 = [bool(lib.translate(h, (700 + p) * PAGE).flags & 1) for p in range(300)]
+        assert sum(l1) == 256 and all(l1[-256:])
+        st = lib.stats()
+        assert st.migrations_l3_to_l1 == 300 and st.migrations_l1_to_l3 == 44
+    finally:
+        kv.close()
+
+
+def test_pool_exhaustion_and_reuse():
+    os.environ["SPECKV_POOL_CAP_MB"] = "64"
+    os.environ["SPECKV_SLAB_MB"] = "16"
+    try:
+        lib = pkg.SpeckvLib(pkg.library_path(), "hip:0")
+    finally:
+        del os.environ["SPECKV_POOL_CAP_MB"]; del os.environ["SPECKV_SLAB_MB"]
+    try:
+        hs = [lib.alloc(16 << 20) for _ in range(4)]
+        assert hs == [1, 2, 3, 4]
+        with pytest.raises(SpeckvError) as ei:
+            lib.alloc(16 << 20)
+        assert ei.value.status == -3                          # SPECKV_ERR_NOMEM (unused by the reference, real here)
+        lib.free(hs[1]); lib.free(hs[2])
+        h = lib.alloc(32 << 20)                               # freed runs (two 16 MiB slabs) are reused, in two extents
+        assert h == 5
+        assert lib.stats().pool_bytes_reserved == 64 << 20
+        x = synth(8192, seed=4)
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)       # data path across the extent seam
+        y = np.empty_like(x); lib.read(h, 0, y.ctypes.data, y.nbytes, False)
+        assert y.tobytes() == x.tobytes()
+        a0, a1 = lib.translate(h, 4095 * PAGE).pool_addr, lib.translate(h, 4096 * PAGE).pool_addr
+        assert a1 != a0 + PAGE                                # really two runs
+        lib.free(12345)                                       # unknown handle: OK, like the reference
+        assert lib.alloc(0) == 6
+        with pytest.raises(SpeckvError) as ei:
+            lib.access(6, 0, 1)
+        assert ei.value.status == -1
+    finally:
+        lib.finalize()
+
+
+def test_fetch_list_and_range_full_size(eng):
+    """BASELINE config 2 size through the engine: 131072 blocks written from a
+    device buffer, fetched back by range and by a permuted list; FP16 scheme is
+    the identity, INT8_DELTA_RLE must agree with the raw codec operator."""
+    torch = torch_mod()
+    lib = eng.lib
+    B = 131072
+    g = torch.Generator(device="cuda"); g.manual_seed(2001)
+    x = torch.randn((B, N), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+    out = torch.empty_like(x)
+    s = torch.cuda.Stream()
+    for scheme in (0, 2):
+        lib.set_compression_scheme(scheme)
+        h = eng.allocate(4096, 32, 8, 128, 2)
+        lib.write(h, 0, x.data_ptr(), x.numel() * 2, True)
+        lib.fetch_range(h, 0, B, out.data_ptr(), False, s.cuda_stream)
+        torch.cuda.synchronize()
+        if scheme == 0:
+            assert torch.equal(out.view(torch.int16), x.view(torch.int16))
+        else:
+            recs = torch.empty((B, PAGE), dtype=torch.uint8, device="cuda")
+            lens = torch.empty(B, dtype=torch.int32, device="cuda"); scales = torch.empty(B, dtype=torch.float32, device="cuda")
+            ref = torch.empty_like(x)
+            raw = lib.lib
+            assert raw.speckv_ext_codec_compress(x.data_ptr(), B, recs.data_ptr(), PAGE, lens.data_ptr(), scales.data_ptr(), 2, 0, None) == 0
+            assert raw.speckv_ext_codec_decompress(recs.data_ptr(), PAGE, lens.data_ptr(), scales.data_ptr(), B, ref.data_ptr(), 0, 2, 0, None) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+            assert lib.stats().compressed_bytes >= int(lens.to(torch.int64).sum().item())
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(1))[:4096].to(torch.int32).cuda()
+        sub = torch.empty((4096, N), dtype=torch.float16, device="cuda")
+        lib.fetch_list(h, perm.data_ptr(), 4096, sub.data_ptr(), False, s.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(sub.view(torch.int16), out[perm.long()].view(torch.int16))
+        lib.free(h)
