@@ -137,6 +137,36 @@ def cpu_baseline(seconds, sample_blocks=8192, seed=2001):
 
 
 # --------------------------------------------------------------------------
+# timing contract (shared with tests/test_multirank_cpu.py, which runs it under gloo)
+# --------------------------------------------------------------------------
+def run_timed(step, steps, warmup, sync, dist=None, warm=None, reduce_device="cpu"):
+    """W untimed warmup steps, then EXACTLY `steps` timed steps bracketed by a
+    barrier + device sync on both sides; returns the MAX elapsed over ranks."""
+    import torch
+    for _ in range(warmup):
+        (warm or (lambda: step(0)))()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def whole_job_rate(world, units_per_rank, steps, elapsed):
+    """Units all ranks processed / max-over-ranks time (weak scaling: per-rank work fixed)."""
+    return world * units_per_rank * steps / elapsed
+
+
 def main():
     args = parse_args()
     import torch
@@ -183,23 +213,16 @@ def main():
     def step():
         lib.fetch_range(handle, 0, n_blocks, dst.data_ptr(), False, sp)
 
-    for _ in range(args.warmup):
-        step()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if dist: dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for a, b in evs:
+
+    def timed_step(i):
+        a, b = evs[i]
         a.record(stream)
         step()
         b.record(stream)
-    torch.cuda.synchronize()
-    if dist: dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    elapsed = run_timed(timed_step, args.steps, args.warmup, torch.cuda.synchronize, dist,
+                        warm=lambda: step(), reduce_device="cuda")
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
     # parity spot check on this very data (oracle = checker only)
@@ -228,7 +251,7 @@ def main():
                                 if (T, Lyr) == (4096, 32) else (None, None))
         out = {
             "metric": "KV blocks/s fetch+decompress",
-            "value": round(world * n_blocks * args.steps / elapsed, 1),
+            "value": round(whole_job_rate(world, n_blocks, args.steps, elapsed), 1),
             "unit": "blocks/s",
             "n_gpus": world,
             "steps": args.steps,
