@@ -52,6 +52,7 @@ __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v)
     return v;
 }
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t wave_incl_max(uint32_t v)
 {
     v = umax(v, dpp<0x111>(0u, v));
@@ -156,79 +157,175 @@ __device__ __forceinline__ void store8(uint8_t* dst, uint32_t p0, const float (&
 // ===================================================================
 // decode: INT8_DELTA_RLE  (cache_engine.cpp:241-284)
 // ===================================================================
-template <int MODE, bool F32>
-__device__ __forceinline__ void decode_rle(const uint8_t* __restrict__ rec, uint32_t len,
-                                           float scale, uint8_t* __restrict__ dst,
-                                           uint32_t* heads, uint32_t lane)
+// float(q)/127.0f without a divide, 2 ops: fma(q, hi, q*lo) with hi = fl(1/127),
+// lo = fl(1/127 - hi) is correctly rounded for every int8 q (exhaustive check in
+// tests/test_cabi_boundary.py::test_div127_identity).
+template <int MODE>
+__device__ __forceinline__ float dequant_q8(uint32_t q8, float scale)
 {
-    // (1) clear the head table: 8 KiB per wave
-    uint4* h4 = reinterpret_cast<uint4*>(heads);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) h4[j * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+    const float fq = static_cast<float>(static_cast<int>(static_cast<int8_t>(q8 & 0xFFu)));
+    if (MODE == kRefExact) {
+        const float hi = 0x1.020408p-7f, lo = 0x1.020408p-35f;
+        const float r = __builtin_fmaf(fq, hi, fq * lo);
+        return r * scale;                                  // cache_engine.cpp:279-280
+    }
+    return fq * scale;
+}
 
-    // (2) scan the (value,count) pairs; scatter one head word per run
-    const uint32_t npairs = len >> 1;           // odd trailing byte dropped
-    uint32_t carry = 0;                         // (sum v*c mod 256)<<24 | sum c
+// ---- fast path: well-formed block (every count >= 1, counts sum to 2048) ----
+// The decoded int8 sequence is the SECOND-order prefix sum (mod 256) of
+//   E[start_r] = value_r - value_{r-1},  0 elsewhere,
+// because the expanded deltas are piecewise constant (first prefix sum of E)
+// and q is their running sum (second prefix sum).  So each run scatters ONE
+// byte into a 2 KiB table at its start position, and every lane then walks its
+// 8 table bytes with two adds per element; lane carries come from two DPP
+// add-scans per 512-element chunk (v_sad_u8 / v_dot4_u32_u8 give the lane totals).
+// Returns false (nothing stored) when the block is not well-formed.
+template <int MODE, bool F32>
+__device__ __forceinline__ bool decode_rle_fast(const uint8_t* __restrict__ rec, uint32_t len,
+                                                float scale, uint8_t* __restrict__ dst,
+                                                uint8_t* tab, uint32_t lane)
+{
+    const uint32_t npairs = len >> 1;                       // odd trailing byte dropped
+    uint4 w[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t pair0 = 512u * j + 8u * lane;
-        uint4 w = make_uint4(0u, 0u, 0u, 0u);
-        if (pair0 < npairs) w = *reinterpret_cast<const uint4*>(rec + 2ull * pair0);
-        const uint32_t words[4] = {w.x, w.y, w.z, w.w};
+        w[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (pair0 < npairs) w[j] = *reinterpret_cast<const uint4*>(rec + 2ull * pair0);
+    }
+    // clear the byte table (2 KiB) and the 64 dummy bytes behind it
+    uint4* t4 = reinterpret_cast<uint4*>(tab);
+    t4[lane] = make_uint4(0u, 0u, 0u, 0u);
+    t4[64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+
+    uint32_t ccarry = 0;        // running count total
+    uint32_t vtail = 0;         // value of the last pair of the previous chunk (0 before the first run)
+    uint32_t mn = 255u;         // min count over valid pairs
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (512u * j >= npairs) break;                      // wave-uniform
+        const uint32_t pair0 = 512u * j + 8u * lane;
+        const uint32_t ws[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
+        const bool full = 512u * (j + 1) <= npairs;         // wave-uniform
         uint32_t v[8], c[8], s[8];
         uint32_t run = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const uint32_t word = words[k >> 1] >> ((k & 1) * 16);
+            const uint32_t word = ws[k >> 1] >> ((k & 1) * 16);
             v[k] = word & 0xFFu;
-            c[k] = (pair0 + k < npairs) ? ((word >> 8) & 0xFFu) : 0u;
-            s[k] = run;
-            run += ((v[k] * c[k]) << 24) | c[k];
+            c[k] = (word >> 8) & 0xFFu;
         }
-        const uint32_t incl = wave_incl_add(run);
-        const uint32_t base = carry + incl - run;
-        carry += lane63(incl);
+        if (!full) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (pair0 + k >= npairs) c[k] = 0x100u;     // marks "not a pair": no count, no write
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const uint32_t e = base + s[k];
-            const uint32_t start = e & 0xFFFFFFu;
-            if (c[k] != 0u && start < kBlockElems)
-                heads[swz(start)] = 0x10000u | ((e >> 24) << 8) | v[k];
+            s[k] = run;
+            run += c[k] & 0xFFu;
+            mn = umin(mn, c[k]);                            // 0x100 never lowers it
         }
+        const uint32_t incl = wave_incl_add(run);
+        const uint32_t base = ccarry + incl - run;
+        ccarry += lane63(incl);
+        uint32_t prev = wave_shr1(v[7], vtail);
+        vtail = lane63(v[7]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t e = v[k] - prev;
+            prev = v[k];
+            uint32_t idx = (base + s[k]) & 2047u;
+            if (!full) idx = (c[k] & 0x100u) ? 2048u + lane : idx;
+            tab[idx] = static_cast<uint8_t>(e);
+        }
+        if (!full) {
+            // the last valid pair's value must seed the next chunk (there is none: all later chunks are empty)
+        }
+    }
+    const bool ok = (ccarry == kBlockElems) && (__ballot(mn == 0u) == 0ull);
+    if (!ok) return false;
+    wave_lds_fence();
+
+    uint32_t c1 = 0, c2 = 0;    // S1 / S2 at the end of the previous chunk
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t p0 = 512u * j + 8u * lane;
+        const uint2 x = *reinterpret_cast<const uint2*>(tab + p0);
+        const uint32_t t1 = __builtin_amdgcn_sad_u8(x.x, 0u, __builtin_amdgcn_sad_u8(x.y, 0u, 0u));
+        const uint32_t t2 = __builtin_amdgcn_udot4(x.x, 0x05060708u,
+                                                   __builtin_amdgcn_udot4(x.y, 0x01020304u, 0u, false), false);
+        const uint32_t i1 = wave_incl_add(t1);
+        const uint32_t x1 = c1 + i1 - t1;                   // S1 entering this lane
+        const uint32_t u = t2 + 8u * x1;                    // this lane's S2 increment
+        const uint32_t i2 = wave_incl_add(u);
+        const uint32_t x2 = c2 + i2 - u;                    // S2 entering this lane
+        c1 += lane63(i1);
+        c2 += lane63(i2);
+        uint32_t s1 = x1, s2 = x2;
+        float y[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            s1 += ((k < 4 ? x.x : x.y) >> ((k & 3) * 8)) & 0xFFu;
+            s2 += s1;
+            y[k] = dequant_q8<MODE>(s2, scale);
+        }
+        store8<F32>(dst, p0, y);
+    }
+    wave_lds_fence();
+    return true;
+}
+
+// ---- general path: any byte stream (zero counts, short or overlong streams) ----
+// One pair per lane per step; runs scatter {valid, prefix, value} words into a
+// 2048-entry head table at their start position and a max-scan of
+// (position+1)<<16 | word finds the run covering every output.  Rolled loops: this
+// is the rare path and must stay small in registers.
+template <int MODE, bool F32>
+__device__ __noinline__ void decode_rle_general(const uint8_t* __restrict__ rec, uint32_t len,
+                                                float scale, uint8_t* __restrict__ dst,
+                                                uint32_t* heads, uint32_t lane)
+{
+    uint4* h4 = reinterpret_cast<uint4*>(heads);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h4[j * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t npairs = len >> 1;
+    uint32_t carry = 0;                                     // (sum v*c mod 256)<<24 | sum c
+#pragma unroll 1
+    for (uint32_t b = 0; b < npairs; b += 64u) {
+        const uint32_t i = b + lane;
+        uint32_t bits = 0;
+        if (i < npairs) bits = *reinterpret_cast<const uint16_t*>(rec + 2ull * i);
+        const uint32_t v = bits & 0xFFu, c = bits >> 8;
+        const uint32_t packed = ((v * c) << 24) | c;
+        const uint32_t incl = wave_incl_add(packed);
+        const uint32_t e = carry + incl - packed;
+        carry += lane63(incl);
+        const uint32_t start = e & 0xFFFFFFu;
+        if (c != 0u && start < kBlockElems) heads[start] = 0x10000u | ((e >> 24) << 8) | v;
     }
     const uint32_t total = carry & 0xFFFFFFu;
     const uint32_t nvalid = total < kBlockElems ? total : kBlockElems;
     wave_lds_fence();
-
-    // (3) every output finds its run by a max-scan over the head table
     uint32_t mcarry = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t p0 = 512u * j + 8u * lane;
-        uint32_t key[8];
-        uint32_t m = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t p = p0 + k;
-            const uint32_t w = heads[swz(p)];
-            const uint32_t kk = w ? w + (p << 16) : 0u;     // (p+1)<<16 | prefix<<8 | value
-            m = umax(m, kk);
-            key[k] = m;
-        }
-        const uint32_t incl = wave_incl_max(m);
-        const uint32_t excl = umax(wave_shr1(incl, 0u), mcarry);
+#pragma unroll 1
+    for (uint32_t p0 = 0; p0 < kBlockElems; p0 += 64u) {
+        const uint32_t p = p0 + lane;
+        const uint32_t w = heads[p];
+        const uint32_t own = w ? w + (p << 16) : 0u;        // (p+1)<<16 | prefix<<8 | value
+        const uint32_t incl = wave_incl_max(own);
+        const uint32_t kk = umax(incl, mcarry);
         mcarry = umax(mcarry, lane63(incl));
-        float y[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t p = p0 + k;
-            const uint32_t kk = umax(key[k], excl);
-            // q[p] = prefix + (p - start + 1) * value   (mod 256), start = (kk>>16)-1
-            const uint32_t q8 = (((kk >> 8) & 0xFFu) + (p + 2u - (kk >> 16)) * (kk & 0xFFu)) & 0xFFu;
-            const int q = static_cast<int>(static_cast<int8_t>(q8));
-            y[k] = (p < nvalid) ? dequant<MODE>(q, scale) : 0.0f;
+        // q[p] = prefix + (p - start + 1) * value  (mod 256), start = (kk>>16)-1
+        const uint32_t q8 = ((kk >> 8) & 0xFFu) + (p + 2u - (kk >> 16)) * (kk & 0xFFu);
+        const float y = (p < nvalid) ? dequant_q8<MODE>(q8, scale) : 0.0f;
+        if (F32) {
+            reinterpret_cast<float*>(dst)[p] = y;
+        } else {
+            float a = y, z = 0.0f;
+            reinterpret_cast<uint16_t*>(dst)[p] = static_cast<uint16_t>(pack_half2(a, z) & 0xFFFFu);
         }
-        store8<F32>(dst, p0, y);
     }
     wave_lds_fence();
 }
@@ -319,7 +416,9 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
         scale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(scale)));
         if (SCHEME == kInt8DeltaRle) {
             if (len > 2u * kBlockElems) len = 2u * kBlockElems;
-            decode_rle<MODE, F32>(rec, len, scale, dst, lds + wave * kDecLdsWords, lane);
+            uint32_t* region = lds + wave * kDecLdsWords;
+            if (!decode_rle_fast<MODE, F32>(rec, len, scale, dst, reinterpret_cast<uint8_t*>(region), lane))
+                decode_rle_general<MODE, F32>(rec, len, scale, dst, region, lane);
         } else if (SCHEME == kInt8) {
             if (len > kBlockElems) len = kBlockElems;
             decode_int8<MODE, F32>(rec, len, scale, dst, lane);
