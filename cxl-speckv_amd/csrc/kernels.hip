@@ -172,6 +172,37 @@ __device__ __forceinline__ float dequant_q8(uint32_t q8, float scale)
     return fq * scale;
 }
 
+// ---- sub-dword VALU forms (SDWA): one instruction extracts a byte AND uses it ----
+// (pure register ops, no memory, no hazards beyond what the hardware interlocks)
+#define SPECKV_SDWA2(NAME, OP, S0, S1)                                                          \
+    __device__ __forceinline__ uint32_t NAME(uint32_t a, uint32_t b)                            \
+    {                                                                                           \
+        uint32_t r;                                                                             \
+        asm(OP " %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" S0 " src1_sel:" S1   \
+            : "=v"(r) : "v"(a), "v"(b));                                                        \
+        return r;                                                                               \
+    }
+SPECKV_SDWA2(add_b0, "v_add_u32_sdwa", "DWORD", "BYTE_0")
+SPECKV_SDWA2(add_b1, "v_add_u32_sdwa", "DWORD", "BYTE_1")
+SPECKV_SDWA2(add_b2, "v_add_u32_sdwa", "DWORD", "BYTE_2")
+SPECKV_SDWA2(add_b3, "v_add_u32_sdwa", "DWORD", "BYTE_3")
+SPECKV_SDWA2(min_b1, "v_min_u32_sdwa", "DWORD", "BYTE_1")
+SPECKV_SDWA2(min_b3, "v_min_u32_sdwa", "DWORD", "BYTE_3")
+SPECKV_SDWA2(sub_b0_b2, "v_sub_u32_sdwa", "BYTE_0", "BYTE_2")   // a.b0 - b.b2
+SPECKV_SDWA2(sub_b2_b0, "v_sub_u32_sdwa", "BYTE_2", "BYTE_0")   // a.b2 - b.b0
+#undef SPECKV_SDWA2
+template <int K> __device__ __forceinline__ uint32_t add_byte(uint32_t a, uint32_t lo, uint32_t hi)
+{
+    return K == 0 ? add_b0(a, lo) : K == 1 ? add_b1(a, lo) : K == 2 ? add_b2(a, lo) : K == 3 ? add_b3(a, lo)
+         : K == 4 ? add_b0(a, hi) : K == 5 ? add_b1(a, hi) : K == 6 ? add_b2(a, hi) : add_b3(a, hi);
+}
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+__device__ __forceinline__ void lds_store_b8(uint32_t addr, uint32_t v)
+{
+    *reinterpret_cast<lds_u8*>(static_cast<uintptr_t>(addr)) = static_cast<uint8_t>(v);
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // ---- fast path: well-formed block (every count >= 1, counts sum to 2048) ----
 // The decoded int8 sequence is the SECOND-order prefix sum (mod 256) of
 //   E[start_r] = value_r - value_{r-1},  0 elsewhere,
@@ -180,6 +211,53 @@ __device__ __forceinline__ float dequant_q8(uint32_t q8, float scale)
 // byte into a 2 KiB table at its start position, and every lane then walks its
 // 8 table bytes with two adds per element; lane carries come from two DPP
 // add-scans per 512-element chunk (v_sad_u8 / v_dot4_u32_u8 give the lane totals).
+// Per pair the VALU work is three SDWA instructions: next address, E, min count.
+//
+// One 512-pair chunk of the pair phase.  A pair dword is  v0 | c0<<8 | v1<<16 | c1<<24.
+// Returns false when the running count passes 2048 (caller falls back).
+template <bool FULL>
+__device__ __forceinline__ bool rle_pair_chunk(const uint4 wv, uint32_t pair0, uint32_t npairs,
+                                               uint32_t tab_addr, uint32_t& ccarry, uint32_t& wtail,
+                                               uint32_t& mn)
+{
+    uint32_t w[4] = {wv.x, wv.y, wv.z, wv.w};
+    uint32_t wm[4] = {wv.x, wv.y, wv.z, wv.w};              // count bytes as seen by the zero-count test
+    if (!FULL) {
+        // pairs at or beyond npairs are not pairs: count 0 for addressing, 0xFF for the min test
+        const int nv = static_cast<int>(npairs) - static_cast<int>(pair0);     // valid pairs of this lane
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t keep = 0x00FF00FFu | (nv > 2 * t ? 0x0000FF00u : 0u) | (nv > 2 * t + 1 ? 0xFF000000u : 0u);
+            w[t] &= keep;
+            wm[t] |= ~keep;
+        }
+    }
+    // lane total of the 8 counts (bytes 1 and 3 of each dword)
+    uint32_t run = __builtin_amdgcn_udot4(w[0], 0x01000100u, 0u, false);
+    run = __builtin_amdgcn_udot4(w[1], 0x01000100u, run, false);
+    run = __builtin_amdgcn_udot4(w[2], 0x01000100u, run, false);
+    run = __builtin_amdgcn_udot4(w[3], 0x01000100u, run, false);
+    const uint32_t incl = wave_incl_add(run);
+    const uint32_t base = ccarry + incl - run;              // start position of this lane's first pair
+    ccarry += lane63(incl);
+    if (ccarry > kBlockElems) return false;                 // wave-uniform; nothing of this chunk is scattered
+    // every start below is <= 2048; 2048 itself is a dummy byte behind the table
+    const uint32_t prevw = wave_shr1(w[3], wtail);          // previous pair's dword (value in byte 2)
+    wtail = lane63(w[3]);
+    uint32_t a = tab_addr + base;
+    lds_store_b8(a, sub_b0_b2(w[0], prevw)); a = add_b1(a, w[0]);
+    lds_store_b8(a, sub_b2_b0(w[0], w[0]));  a = add_b3(a, w[0]);
+    lds_store_b8(a, sub_b0_b2(w[1], w[0]));  a = add_b1(a, w[1]);
+    lds_store_b8(a, sub_b2_b0(w[1], w[1]));  a = add_b3(a, w[1]);
+    lds_store_b8(a, sub_b0_b2(w[2], w[1]));  a = add_b1(a, w[2]);
+    lds_store_b8(a, sub_b2_b0(w[2], w[2]));  a = add_b3(a, w[2]);
+    lds_store_b8(a, sub_b0_b2(w[3], w[2]));  a = add_b1(a, w[3]);
+    lds_store_b8(a, sub_b2_b0(w[3], w[3]));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { mn = min_b1(mn, wm[t]); mn = min_b3(mn, wm[t]); }
+    return true;
+}
+
 // Returns false (nothing stored) when the block is not well-formed.
 template <int MODE, bool F32>
 __device__ __forceinline__ bool decode_rle_fast(const uint8_t* __restrict__ rec, uint32_t len,
@@ -194,55 +272,23 @@ __device__ __forceinline__ bool decode_rle_fast(const uint8_t* __restrict__ rec,
         w[j] = make_uint4(0u, 0u, 0u, 0u);
         if (pair0 < npairs) w[j] = *reinterpret_cast<const uint4*>(rec + 2ull * pair0);
     }
-    // clear the byte table (2 KiB) and the 64 dummy bytes behind it
+    // clear the byte table (2 KiB); byte 2048 is a write-only dummy
     uint4* t4 = reinterpret_cast<uint4*>(tab);
     t4[lane] = make_uint4(0u, 0u, 0u, 0u);
     t4[64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t tab_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8*)tab));
 
     uint32_t ccarry = 0;        // running count total
-    uint32_t vtail = 0;         // value of the last pair of the previous chunk (0 before the first run)
+    uint32_t wtail = 0;         // last pair dword of the previous chunk (value 0 before the first run)
     uint32_t mn = 255u;         // min count over valid pairs
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (512u * j >= npairs) break;                      // wave-uniform
         const uint32_t pair0 = 512u * j + 8u * lane;
-        const uint32_t ws[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
-        const bool full = 512u * (j + 1) <= npairs;         // wave-uniform
-        uint32_t v[8], c[8], s[8];
-        uint32_t run = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t word = ws[k >> 1] >> ((k & 1) * 16);
-            v[k] = word & 0xFFu;
-            c[k] = (word >> 8) & 0xFFu;
-        }
-        if (!full) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (pair0 + k >= npairs) c[k] = 0x100u;     // marks "not a pair": no count, no write
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            s[k] = run;
-            run += c[k] & 0xFFu;
-            mn = umin(mn, c[k]);                            // 0x100 never lowers it
-        }
-        const uint32_t incl = wave_incl_add(run);
-        const uint32_t base = ccarry + incl - run;
-        ccarry += lane63(incl);
-        uint32_t prev = wave_shr1(v[7], vtail);
-        vtail = lane63(v[7]);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t e = v[k] - prev;
-            prev = v[k];
-            uint32_t idx = (base + s[k]) & 2047u;
-            if (!full) idx = (c[k] & 0x100u) ? 2048u + lane : idx;
-            tab[idx] = static_cast<uint8_t>(e);
-        }
-        if (!full) {
-            // the last valid pair's value must seed the next chunk (there is none: all later chunks are empty)
-        }
+        bool go;
+        if (512u * (j + 1) <= npairs) go = rle_pair_chunk<true>(w[j], pair0, npairs, tab_addr, ccarry, wtail, mn);
+        else                          go = rle_pair_chunk<false>(w[j], pair0, npairs, tab_addr, ccarry, wtail, mn);
+        if (!go) return false;
     }
     const bool ok = (ccarry == kBlockElems) && (__ballot(mn == 0u) == 0ull);
     if (!ok) return false;
@@ -264,12 +310,32 @@ __device__ __forceinline__ bool decode_rle_fast(const uint8_t* __restrict__ rec,
         c1 += lane63(i1);
         c2 += lane63(i2);
         uint32_t s1 = x1, s2 = x2;
+        uint32_t q[8];
+        s1 = add_byte<0>(s1, x.x, x.y); s2 += s1; q[0] = s2;
+        s1 = add_byte<1>(s1, x.x, x.y); s2 += s1; q[1] = s2;
+        s1 = add_byte<2>(s1, x.x, x.y); s2 += s1; q[2] = s2;
+        s1 = add_byte<3>(s1, x.x, x.y); s2 += s1; q[3] = s2;
+        s1 = add_byte<4>(s1, x.x, x.y); s2 += s1; q[4] = s2;
+        s1 = add_byte<5>(s1, x.x, x.y); s2 += s1; q[5] = s2;
+        s1 = add_byte<6>(s1, x.x, x.y); s2 += s1; q[6] = s2;
+        s1 = add_byte<7>(s1, x.x, x.y); s2 += s1; q[7] = s2;
         float y[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            s1 += ((k < 4 ? x.x : x.y) >> ((k & 3) * 8)) & 0xFFu;
-            s2 += s1;
-            y[k] = dequant_q8<MODE>(s2, scale);
+        for (int k = 0; k < 8; k += 2) {
+            f32x2 fq;
+            fq.x = static_cast<float>(static_cast<int>(static_cast<int8_t>(q[k] & 0xFFu)));
+            fq.y = static_cast<float>(static_cast<int>(static_cast<int8_t>(q[k + 1] & 0xFFu)));
+            f32x2 r;
+            if (MODE == kRefExact) {
+                const f32x2 hi = {0x1.020408p-7f, 0x1.020408p-7f}, lo = {0x1.020408p-35f, 0x1.020408p-35f};
+                r = __builtin_elementwise_fma(fq, hi, fq * lo);        // float(q)/127.0f, correctly rounded
+            } else {
+                r = fq;
+            }
+            const f32x2 sc = {scale, scale};
+            r = r * sc;
+            y[k] = r.x;
+            y[k + 1] = r.y;
         }
         store8<F32>(dst, p0, y);
     }
@@ -385,49 +451,68 @@ __device__ __forceinline__ void decode_fp16(const uint8_t* __restrict__ rec, uin
     }
 }
 
+// One block's source/destination, all wave-uniform (lives in SGPRs: the block
+// index is made provably uniform, so these are scalar loads through the K$).
+struct BlockDesc {
+    const uint8_t* rec;
+    uint8_t* dst;
+    uint64_t page;
+    uint32_t len;
+    float scale;
+};
+__device__ __forceinline__ BlockDesc load_desc(const CodecArgs& a, uint64_t i)
+{
+    BlockDesc d;
+    d.page = a.page_list ? a.page_list[i] : a.first + i;
+    if (a.entries) {
+        const PageEntry e = a.entries[d.page];
+        d.rec = reinterpret_cast<const uint8_t*>(e.pool_addr);
+        d.len = e.rec_bytes;
+        d.scale = e.scale;
+    } else {
+        d.rec = a.recs + d.page * a.rec_stride;
+        d.len = a.rec_bytes[d.page];
+        d.scale = a.scales ? a.scales[d.page] : 1.0f;
+    }
+    d.dst = a.data_list ? reinterpret_cast<uint8_t*>(a.data_list[i]) : a.data + i * a.data_stride;
+    return d;
+}
+
 template <int SCHEME, int MODE, bool F32>
 __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[SCHEME == kInt8DeltaRle ? kWaves * kDecLdsWords : 4];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint64_t n = a.n;
     if (a.n_dev) { const uint64_t nd = *a.n_dev; n = nd < n ? nd : n; }
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kWaves;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kWaves + wave; i < n; i += stride) {
-        const uint64_t page = a.page_list ? a.page_list[i] : a.first + i;
-        const uint8_t* rec;
-        uint32_t len;
-        float scale;
-        if (a.entries) {
-            const PageEntry e = a.entries[page];
-            rec = reinterpret_cast<const uint8_t*>(e.pool_addr);
-            len = e.rec_bytes;
-            scale = e.scale;
-        } else {
-            rec = a.recs + page * a.rec_stride;
-            len = a.rec_bytes[page];
-            scale = a.scales ? a.scales[page] : 1.0f;
-        }
-        uint8_t* dst = a.data_list ? reinterpret_cast<uint8_t*>(a.data_list[i])
-                                   : a.data + i * a.data_stride;
-        // wave-uniform values live in SGPRs
-        len = __builtin_amdgcn_readfirstlane(len);
-        scale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(scale)));
+    uint64_t i = static_cast<uint64_t>(blockIdx.x) * kWaves + wave;
+    if (i >= n) return;
+    BlockDesc cur = load_desc(a, i);
+    for (;;) {
+        // the next block's descriptor is fetched while this block is decoded
+        const uint64_t nx = i + stride;
+        BlockDesc nxt = cur;
+        if (nx < n) nxt = load_desc(a, nx);
+        uint32_t len = cur.len;
         if (SCHEME == kInt8DeltaRle) {
             if (len > 2u * kBlockElems) len = 2u * kBlockElems;
             uint32_t* region = lds + wave * kDecLdsWords;
-            if (!decode_rle_fast<MODE, F32>(rec, len, scale, dst, reinterpret_cast<uint8_t*>(region), lane))
-                decode_rle_general<MODE, F32>(rec, len, scale, dst, region, lane);
+            if (!decode_rle_fast<MODE, F32>(cur.rec, len, cur.scale, cur.dst, reinterpret_cast<uint8_t*>(region), lane))
+                decode_rle_general<MODE, F32>(cur.rec, len, cur.scale, cur.dst, region, lane);
         } else if (SCHEME == kInt8) {
             if (len > kBlockElems) len = kBlockElems;
-            decode_int8<MODE, F32>(rec, len, scale, dst, lane);
+            decode_int8<MODE, F32>(cur.rec, len, cur.scale, cur.dst, lane);
         } else {
             if (len > 2u * kBlockElems) len = 2u * kBlockElems;
-            decode_fp16<F32>(rec, len, dst, lane);
+            decode_fp16<F32>(cur.rec, len, cur.dst, lane);
         }
         if (a.flags && lane == 0u)
-            a.flags[page] = (a.flags[page] & ~8u) | a.set_flags;
+            atomicOr(&a.flags[cur.page], a.set_flags);       // neighbours belong to other waves / XCDs
+        if (nx >= n) break;
+        cur = nxt;
+        i = nx;
     }
 }
 
@@ -688,31 +773,38 @@ __global__ __launch_bounds__(1024) void k_scan_totals(const uint32_t* __restrict
 // ===================================================================
 // verify  (speculative_prefetcher.cpp:84-96): hit[r] = actual[r] in predicted[r][0..k)
 // ===================================================================
-__global__ __launch_bounds__(256) void k_verify(uint32_t n, uint32_t k, uint32_t kp2,
+// One request per lane; the 64-bit __ballot of the per-lane result is the
+// wave's verify mask (its popcount feeds the hit counter).  A wave owns 64
+// consecutive bytes of hit[] and a workgroup 256, so no two workgroups ever
+// write into the same 128-byte line: the earlier layout (16 lanes per request,
+// 4 result bytes per wave) let eight workgroups on eight XCDs share one line and
+// showed rare wrong bytes on MI355X (tests/test_gpu_engine.py::test_verify_batch_kernel).
+__global__ __launch_bounds__(256) void k_verify(uint32_t n, uint32_t k,
         const int32_t* __restrict__ actual, const int32_t* __restrict__ predicted,
         uint8_t* __restrict__ hit, uint32_t* __restrict__ hit_count)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t per_wave = 64u / kp2;
-    const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t g = lane / kp2, j = lane % kp2;
-    const uint32_t r = gw * per_wave + g;
-    bool match = false;
-    if (r < n && j < k) match = predicted[static_cast<uint64_t>(r) * k + j] == actual[r];
-    const unsigned long long mask = __ballot(match);          // 64-bit verify mask
-    const unsigned long long gmask = (kp2 == 64u) ? ~0ull : (((1ull << kp2) - 1ull) << (g * kp2));
-    const bool ghit = (mask & gmask) != 0ull;
-    const bool leader = (r < n) && (j == 0u);
-    if (leader) hit[r] = ghit ? 1 : 0;
-    const unsigned long long hits = __ballot(leader && ghit);
-    if (lane == 0u && hits) atomicAdd(hit_count, static_cast<uint32_t>(__popcll(hits)));
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    bool h = false;
+    if (r < n) {
+        const int32_t a = actual[r];
+        const int32_t* p = predicted + static_cast<uint64_t>(r) * k;
+        for (uint32_t j = 0; j < k; ++j) h = h || (p[j] == a);
+        hit[r] = h ? 1 : 0;
+    }
+    const unsigned long long mask = __ballot(h);              // 64-bit verify mask of this wave
+    if (lane == 0u && mask) atomicAdd(hit_count, static_cast<uint32_t>(__popcll(mask)));
 }
 
 __global__ void k_update_flags(uint32_t* flags, const uint32_t* pages, uint32_t n,
                                uint32_t and_mask, uint32_t or_mask)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const uint32_t p = pages[i]; flags[p] = (flags[p] & and_mask) | or_mask; }
+    if (i < n) {
+        const uint32_t p = pages[i];
+        if (and_mask != 0xFFFFFFFFu) atomicAnd(&flags[p], and_mask);
+        if (or_mask) atomicOr(&flags[p], or_mask);
+    }
 }
 
 __global__ void k_init_entries(PageEntry* e, uint64_t n, uint64_t base, uint64_t stride)
@@ -837,12 +929,7 @@ hipError_t launch_verify(uint32_t n, uint32_t k, const int32_t* d_actual,
     hipError_t e = hipMemsetAsync(d_hit_count, 0, sizeof(uint32_t), s);
     if (e != hipSuccess || n == 0) return e;
     if (k == 0 || k > 64u) return hipErrorInvalidValue;
-    uint32_t kp2 = 1;
-    while (kp2 < k) kp2 <<= 1;
-    const uint32_t per_wave = 64u / kp2;
-    const uint32_t waves = (n + per_wave - 1u) / per_wave;
-    const uint32_t grid = (waves * 64u + 255u) / 256u;
-    hipLaunchKernelGGL(k_verify, dim3(grid), dim3(256), 0, s, n, k, kp2, d_actual, d_predicted, d_hit,
+    hipLaunchKernelGGL(k_verify, dim3((n + 255u) / 256u), dim3(256), 0, s, n, k, d_actual, d_predicted, d_hit,
                        d_hit_count);
     return hipGetLastError();
 }

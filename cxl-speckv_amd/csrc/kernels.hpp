@@ -42,7 +42,7 @@ struct CodecArgs {
     // count
     uint64_t        n;
     const uint32_t* n_dev;        // optional: n read from device memory (<= n)
-    // residency mirror update on completion (decompress only): flags[page] = (flags & ~8) | set_flags
+    // residency mirror update on completion (decompress only): flags[page] |= set_flags (atomic)
     uint32_t*       flags;
     uint32_t        set_flags;
     int             scheme;
