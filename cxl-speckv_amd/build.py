@@ -21,7 +21,13 @@ def build_library(force=False, jobs=4):
 
 
 def library_path():
-    """Path of the built library; raises (loudly) when it has not been built."""
+    """Path of the built library; raises (loudly) when it has not been built.
+    SPECKV_LIB_PATH overrides it (A/B builds during kernel tuning)."""
+    override = os.environ.get("SPECKV_LIB_PATH")
+    if override:
+        if not os.path.exists(override):
+            raise RuntimeError(f"SPECKV_LIB_PATH={override} does not exist")
+        return override
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
