@@ -249,10 +249,12 @@ static speckv_status_t codec_launch(bool compress, const speckv::CodecArgs& a, v
 speckv_status_t speckv_ext_codec_compress(const void* d_src_f16, uint64_t n_blocks, void* d_recs, uint64_t rec_stride,
                                           uint32_t* d_rec_bytes, float* d_scales, int scheme, int quant_mode, void* stream)
 {
-    if (scheme < 0 || scheme > 2 || quant_mode < 0 || quant_mode > 1) return SPECKV_ERR_INVAL;
+    if (scheme < 0 || scheme > SPECKV_COMP_FP8_E4M3 || quant_mode < 0 || quant_mode > 1) return SPECKV_ERR_INVAL;
     if (n_blocks && (!d_src_f16 || !d_recs || !d_rec_bytes)) return SPECKV_ERR_INVAL;
     if (rec_stride % 16) return SPECKV_ERR_INVAL;
-    if (rec_stride < (scheme == SPECKV_COMP_INT8 ? 2048u : 4096u)) return SPECKV_ERR_INVAL;
+    const uint64_t need = scheme == SPECKV_COMP_INT8 || scheme == SPECKV_COMP_FP8_E4M3 ? 2048u
+                        : scheme == SPECKV_COMP_INT4_G32 ? 1152u : 4096u;
+    if (rec_stride < need) return SPECKV_ERR_INVAL;
     speckv::CodecArgs a{};
     a.recs = static_cast<uint8_t*>(d_recs);
     a.rec_stride = rec_stride;
@@ -270,7 +272,7 @@ speckv_status_t speckv_ext_codec_decompress(const void* d_recs, uint64_t rec_str
                                             const float* d_scales, uint64_t n_blocks, void* d_dst, int out_f32,
                                             int scheme, int quant_mode, void* stream)
 {
-    if (scheme < 0 || scheme > 2 || quant_mode < 0 || quant_mode > 1) return SPECKV_ERR_INVAL;
+    if (scheme < 0 || scheme > SPECKV_COMP_FP8_E4M3 || quant_mode < 0 || quant_mode > 1) return SPECKV_ERR_INVAL;
     if (n_blocks && (!d_recs || !d_rec_bytes || !d_dst)) return SPECKV_ERR_INVAL;
     if (rec_stride % 16) return SPECKV_ERR_INVAL;
     speckv::CodecArgs a{};
@@ -285,6 +287,15 @@ speckv_status_t speckv_ext_codec_decompress(const void* d_recs, uint64_t rec_str
     a.quant_mode = quant_mode;
     a.out_f32 = out_f32 ? 1 : 0;
     return codec_launch(false, a, stream);
+}
+
+speckv_status_t speckv_ext_qk_scores_fp8(speckv_handle_t handle, uint32_t layer, const void* d_q_f16, uint32_t g,
+                                         uint32_t pos_begin, uint32_t pos_end, float* d_out, void* stream)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] {
+        return g_engine->qk_scores_fp8(handle, layer, d_q_f16, g, pos_begin, pos_end, d_out, static_cast<hipStream_t>(stream));
+    });
 }
 
 speckv_status_t speckv_ext_promote_to_l1(speckv_handle_t handle, uint64_t offset_bytes)

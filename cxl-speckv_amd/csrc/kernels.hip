@@ -474,6 +474,56 @@ __device__ __forceinline__ void decode_fp16(const uint8_t* __restrict__ rec, uin
     }
 }
 
+// decode: INT4_G32 (config 5 extension; record = 64 fp16 scales + 1024 B nibbles)
+template <bool F32>
+__device__ __forceinline__ void decode_int4(const uint8_t* __restrict__ rec, uint32_t len,
+                                            uint8_t* __restrict__ dst, uint32_t lane)
+{
+    const bool ok = len >= kInt4RecBytes;                    // short record decodes to zeros
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t p0 = 512u * j + 8u * lane;
+        uint32_t nib = 0;
+        float s = 0.0f;
+        if (ok) {
+            nib = *reinterpret_cast<const uint32_t*>(rec + 128u + (p0 >> 1));
+            s = half_bits_to_float(*reinterpret_cast<const uint16_t*>(rec + 2u * (p0 >> 5)));
+        }
+        float y[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = (static_cast<int>(nib << (28 - 4 * k))) >> 28;       // sign-extended nibble
+            y[k] = ok ? static_cast<float>(q) * s : 0.0f;
+        }
+        store8<F32>(dst, p0, y);
+    }
+}
+
+// decode: FP8_E4M3 (config 5 extension; per-block scale)
+template <bool F32>
+__device__ __forceinline__ void decode_fp8(const uint8_t* __restrict__ rec, uint32_t len,
+                                           float scale, uint8_t* __restrict__ dst, uint32_t lane)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t p0 = 512u * j + 8u * lane;
+        uint2 w = make_uint2(0u, 0u);
+        if (p0 < len) w = *reinterpret_cast<const uint2*>(rec + p0);
+        float y[8];
+        y[0] = __builtin_amdgcn_cvt_f32_fp8(static_cast<int>(w.x), 0);
+        y[1] = __builtin_amdgcn_cvt_f32_fp8(static_cast<int>(w.x), 1);
+        y[2] = __builtin_amdgcn_cvt_f32_fp8(static_cast<int>(w.x), 2);
+        y[3] = __builtin_amdgcn_cvt_f32_fp8(static_cast<int>(w.x), 3);
+        y[4] = __builtin_amdgcn_cvt_f32_fp8(static_cast<int>(w.y), 0);
+        y[5] = __builtin_amdgcn_cvt_f32_fp8(static_cast<int>(w.y), 1);
+        y[6] = __builtin_amdgcn_cvt_f32_fp8(static_cast<int>(w.y), 2);
+        y[7] = __builtin_amdgcn_cvt_f32_fp8(static_cast<int>(w.y), 3);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] = (p0 + k < len) ? y[k] * scale : 0.0f;
+        store8<F32>(dst, p0, y);
+    }
+}
+
 // One block's source/destination, all wave-uniform (lives in SGPRs: the block
 // index is made provably uniform, so these are scalar loads through the K$).
 struct BlockDesc {
@@ -527,6 +577,11 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
         } else if (SCHEME == kInt8) {
             if (len > kBlockElems) len = kBlockElems;
             decode_int8<MODE, F32>(cur.rec, len, cur.scale, cur.dst, lane);
+        } else if (SCHEME == kInt4G32) {
+            decode_int4<F32>(cur.rec, len, cur.dst, lane);
+        } else if (SCHEME == kFp8E4m3) {
+            if (len > kBlockElems) len = kBlockElems;
+            decode_fp8<F32>(cur.rec, len, cur.scale, cur.dst, lane);
         } else {
             if (len > 2u * kBlockElems) len = 2u * kBlockElems;
             decode_fp16<F32>(cur.rec, len, cur.dst, lane);
@@ -569,6 +624,74 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
             for (int j = 0; j < 4; ++j)
                 *reinterpret_cast<uint4*>(rec + 2ull * (512u * j + 8u * lane)) = raw[j];
             out_len = 2u * kBlockElems;
+        } else if (SCHEME == kInt4G32) {
+            // per group of 32 elements (4 lanes x 8): s = fp16(max|x|/7), q = clamp(round(x/s), -7, 7)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t words[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+                float xv[8];
+                float mx = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    xv[k] = half_bits_to_float((words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
+                    const float ax = fabsf(xv[k]);
+                    mx = (ax > mx) ? ax : mx;
+                }
+                float o = __shfl_xor(mx, 1); mx = (o > mx) ? o : mx;
+                o = __shfl_xor(mx, 2);       mx = (o > mx) ? o : mx;
+                float sdiv = mx / 7.0f;
+                asm volatile("" : "+v"(sdiv));                      // keep the fp32 rounding of the divide
+                const _Float16 s16 = static_cast<_Float16>(sdiv);
+                const float sc = static_cast<float>(s16);
+                uint32_t nib = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float r = 0.0f;
+                    if (sc != 0.0f && sc == sc) {
+                        r = roundf(xv[k] / sc);
+                        if (!(r == r)) r = 0.0f;
+                        r = fminf(fmaxf(r, -7.0f), 7.0f);
+                    }
+                    nib |= (static_cast<uint32_t>(static_cast<int>(r)) & 0xFu) << (4 * k);
+                }
+                const uint32_t p0 = 512u * j + 8u * lane;
+                *reinterpret_cast<uint32_t*>(rec + 128u + (p0 >> 1)) = nib;
+                if ((lane & 3u) == 0u)
+                    *reinterpret_cast<uint16_t*>(rec + 2u * (p0 >> 5)) = __builtin_bit_cast(uint16_t, s16);
+            }
+            out_len = kInt4RecBytes;
+        } else if (SCHEME == kFp8E4m3) {
+            float x[4][8];
+            float mx = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t words[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    x[j][k] = half_bits_to_float((words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
+                    const float ax = fabsf(x[j][k]);
+                    mx = (ax > mx) ? ax : mx;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float other = __shfl_xor(mx, o);
+                mx = (other > mx) ? other : mx;
+            }
+            scale = (mx > 0.0f) ? (mx / 448.0f) : 1.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = fminf(fmaxf(x[j][k] / scale, -448.0f), 448.0f);
+                int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+                lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+                int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+                hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+                *reinterpret_cast<uint2*>(rec + 512u * j + 8u * lane) =
+                    make_uint2(static_cast<uint32_t>(lo), static_cast<uint32_t>(hi));
+            }
+            out_len = kBlockElems;
         } else {
             float x[4][8];
             float mx = 0.0f;
@@ -836,6 +959,90 @@ __global__ void k_init_entries(PageEntry* e, uint64_t n, uint64_t base, uint64_t
     if (i < n) { e[i].pool_addr = base + i * stride; e[i].rec_bytes = 0; e[i].scale = 1.0f; }
 }
 
+// ===================================================================
+// fused dequant-matvec (BASELINE config 5): q.K^T from FP8 records on the matrix cores
+// ===================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// per query row: scale = max|q|/448 (1 if zero), e4m3 bytes of clamp(q/scale); rows >= g are zero
+__global__ __launch_bounds__(64) void k_quantize_q_e4m3(const uint16_t* __restrict__ q16, uint32_t g,
+                                                        uint32_t d, uint8_t* __restrict__ q8,
+                                                        float* __restrict__ qs)
+{
+    const uint32_t lane = threadIdx.x, h = blockIdx.x / 16u, m = blockIdx.x % 16u;
+    uint8_t* out = q8 + (static_cast<uint64_t>(h) * 16u + m) * d;
+    if (m >= g) {
+        for (uint32_t i = lane; i < d; i += 64u) out[i] = 0;
+        if (lane == 0) qs[h * 16u + m] = 1.0f;
+        return;
+    }
+    const uint16_t* row = q16 + (static_cast<uint64_t>(h) * g + m) * d;
+    float mx = 0.0f;
+    for (uint32_t i = lane; i < d; i += 64u) { const float a = fabsf(half_bits_to_float(row[i])); mx = (a > mx) ? a : mx; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(mx, o); mx = (t > mx) ? t : mx; }
+    const float sc = (mx > 0.0f) ? (mx / 448.0f) : 1.0f;
+    for (uint32_t i = lane; i < d; i += 64u) {
+        const float v = fminf(fmaxf(half_bits_to_float(row[i]) / sc, -448.0f), 448.0f);
+        out[i] = static_cast<uint8_t>(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.0f, 0, false) & 0xFF);
+    }
+    if (lane == 0) qs[h * 16u + m] = sc;
+}
+
+// One wave = 8 pages = 16 positions, all heads.  MFMA 16x16x32 fp8: A = 16 query
+// rows x 32 k, B = 32 k x 16 positions; lane (c = l%16, kb = l/16) supplies 8
+// consecutive k of row/column c.  The k axis of the dot product is permuted so that
+// lane kb owns d in [32kb, 32kb+32): four MFMA steps consume 32 contiguous bytes of
+// a K row, i.e. every 128-byte K row is read once by 4 lanes, straight from the pool.
+__global__ __launch_bounds__(256) void k_qk_scores_fp8(const PageEntry* __restrict__ entries,
+        uint64_t first_page, uint32_t n_pages, uint32_t heads, uint32_t g,
+        const uint8_t* __restrict__ q8, const float* __restrict__ qs, float* __restrict__ out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t page0 = gw * 8u;
+    if (page0 >= n_pages) return;
+    const uint32_t c = lane & 15u, kb = lane >> 4;
+    const uint32_t n_pos = 2u * n_pages;
+    // B side: column c = position page0*2 + c  ->  page page0 + c/2, slot c%2
+    const uint32_t pg = page0 + (c >> 1);
+    const bool live = pg < n_pages;
+    PageEntry e{0, 0, 0.0f};
+    if (live) e = entries[first_page + pg];
+    const bool have = live && e.rec_bytes >= kBlockElems;
+    const uint8_t* krow = reinterpret_cast<const uint8_t*>(e.pool_addr) + (c & 1u) * (heads * 128u) + kb * 32u;
+    for (uint32_t h = 0; h < heads; ++h) {
+        uint4 b0 = make_uint4(0u, 0u, 0u, 0u), b1 = b0;
+        if (have) {
+            b0 = ld16(krow + h * 128u);
+            b1 = ld16(krow + h * 128u + 16u);
+        }
+        const uint8_t* qrow = q8 + (static_cast<uint64_t>(h) * 16u + c) * 128u + kb * 32u;
+        const uint4 a0 = *reinterpret_cast<const uint4*>(qrow);
+        const uint4 a1 = *reinterpret_cast<const uint4*>(qrow + 16);
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+            static_cast<long>(a0.x | (static_cast<uint64_t>(a0.y) << 32)), static_cast<long>(b0.x | (static_cast<uint64_t>(b0.y) << 32)), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+            static_cast<long>(a0.z | (static_cast<uint64_t>(a0.w) << 32)), static_cast<long>(b0.z | (static_cast<uint64_t>(b0.w) << 32)), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+            static_cast<long>(a1.x | (static_cast<uint64_t>(a1.y) << 32)), static_cast<long>(b1.x | (static_cast<uint64_t>(b1.y) << 32)), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+            static_cast<long>(a1.z | (static_cast<uint64_t>(a1.w) << 32)), static_cast<long>(b1.z | (static_cast<uint64_t>(b1.w) << 32)), acc, 0, 0, 0);
+        // accumulator: lane holds rows m = 4*kb + i (i = 0..3) of column c
+        const uint32_t t = page0 * 2u + c;
+        if (live) {
+            const float ks = have ? e.scale : 0.0f;
+            const float r[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t m = 4u * kb + i;
+                if (m < g) out[(static_cast<uint64_t>(h) * g + m) * n_pos + t] = r[i] * ks * qs[h * 16u + m];
+            }
+        }
+    }
+}
+
 // self-test of the wave primitives (tests/test_gpu_codec.py::test_wave_primitives)
 __global__ void k_debug_dpp(const uint32_t* in, uint32_t* out)
 {
@@ -910,6 +1117,8 @@ hipError_t launch_decompress(const CodecArgs& a, hipStream_t s)
     case kFp16: return launch_dec1<kFp16>(a, s);
     case kInt8: return launch_dec1<kInt8>(a, s);
     case kInt8DeltaRle: return launch_dec1<kInt8DeltaRle>(a, s);
+    case kInt4G32: return launch_dec2<kInt4G32, kRefExact>(a, s);      // the quantiser mode does not apply
+    case kFp8E4m3: return launch_dec2<kFp8E4m3, kRefExact>(a, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -921,6 +1130,14 @@ hipError_t launch_compress(const CodecArgs& a, hipStream_t s)
     case kFp16: return launch_enc1<kFp16>(a, s);
     case kInt8: return launch_enc1<kInt8>(a, s);
     case kInt8DeltaRle: return launch_enc1<kInt8DeltaRle>(a, s);
+    case kInt4G32: {
+        hipLaunchKernelGGL((k_compress<kInt4G32, kRefExact>), dim3(codec_grid(a.n)), dim3(kThreads), 0, s, a);
+        return hipGetLastError();
+    }
+    case kFp8E4m3: {
+        hipLaunchKernelGGL((k_compress<kFp8E4m3, kRefExact>), dim3(codec_grid(a.n)), dim3(kThreads), 0, s, a);
+        return hipGetLastError();
+    }
     default: return hipErrorInvalidValue;
     }
 }
@@ -954,6 +1171,26 @@ hipError_t launch_verify(uint32_t n, uint32_t k, const int32_t* d_actual,
     if (k == 0 || k > 64u) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_verify, dim3((n + 255u) / 256u), dim3(256), 0, s, n, k, d_actual, d_predicted, d_hit,
                        d_hit_count);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantize_q_e4m3(const void* d_q_f16, uint32_t heads, uint32_t g, uint32_t d,
+                                  uint8_t* d_q8, float* d_qs, hipStream_t s)
+{
+    if (heads == 0 || g == 0 || g > 16u || d != 128u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_quantize_q_e4m3, dim3(heads * 16u), dim3(64), 0, s,
+                       static_cast<const uint16_t*>(d_q_f16), g, d, d_q8, d_qs);
+    return hipGetLastError();
+}
+
+hipError_t launch_qk_scores_fp8(const PageEntry* d_entries, uint64_t first_page, uint32_t n_pages,
+                                uint32_t heads, uint32_t g, const uint8_t* d_q8, const float* d_qs,
+                                float* d_out, hipStream_t s)
+{
+    if (n_pages == 0) return hipSuccess;
+    const uint32_t waves = (n_pages + 7u) / 8u;
+    hipLaunchKernelGGL(k_qk_scores_fp8, dim3((waves + 3u) / 4u), dim3(256), 0, s, d_entries, first_page,
+                       n_pages, heads, g, d_q8, d_qs, d_out);
     return hipGetLastError();
 }
 

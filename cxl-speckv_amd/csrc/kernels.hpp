@@ -13,7 +13,8 @@ namespace speckv {
 constexpr uint32_t kPageSize = 4096;
 constexpr uint32_t kBlockElems = 2048;
 
-enum Scheme : int { kFp16 = 0, kInt8 = 1, kInt8DeltaRle = 2 };
+enum Scheme : int { kFp16 = 0, kInt8 = 1, kInt8DeltaRle = 2, kInt4G32 = 3, kFp8E4m3 = 4 };
+constexpr uint32_t kInt4RecBytes = 128 + 1024;   // 64 fp16 group scales + 2048 nibbles
 enum QuantMode : int { kRefExact = 0, kIntent = 1 };
 
 // Device-resident page-table entry (16 B).
@@ -78,6 +79,18 @@ hipError_t launch_update_flags(uint32_t* d_flags, const uint32_t* d_pages, uint3
 // entries[first+i].pool_addr = base + i*stride ; rec_bytes = 0 ; scale = 1
 hipError_t launch_init_entries(PageEntry* d_entries, uint64_t n, uint64_t base,
                                uint64_t stride, hipStream_t s);
+
+// Fused dequant-matvec of BASELINE config 5: q.K^T scores straight from FP8_E4M3
+// records with v_mfma_f32_16x16x32_fp8_fp8 (no fp16 K is ever materialised).
+// Layout requirement: one K row (all heads of one position) = 2048 B, i.e. two
+// positions per 4 KiB page (H*D = 1024 elements, e.g. 8 kv heads x 128).
+//   d_q8     [H][16][128] e4m3 query rows (rows >= g are zero), d_qs [H][16] their scales
+//   d_out    [H][g][n_pos] fp32, n_pos = 2 * n_pages
+hipError_t launch_quantize_q_e4m3(const void* d_q_f16, uint32_t heads, uint32_t g, uint32_t d,
+                                  uint8_t* d_q8, float* d_qs, hipStream_t s);
+hipError_t launch_qk_scores_fp8(const PageEntry* d_entries, uint64_t first_page, uint32_t n_pages,
+                                uint32_t heads, uint32_t g, const uint8_t* d_q8, const float* d_qs,
+                                float* d_out, hipStream_t s);
 
 // wave-primitive self test: in[64] -> out[5*64]
 hipError_t launch_debug_dpp(const uint32_t* d_in, uint32_t* d_out, hipStream_t s);

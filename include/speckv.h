@@ -89,6 +89,9 @@ typedef enum {
     SPECKV_COMP_FP16           = 0,
     SPECKV_COMP_INT8           = 1,
     SPECKV_COMP_INT8_DELTA_RLE = 2,
+    /* additive values (no reference counterpart; BASELINE config 5, see speckv_ext.h) */
+    SPECKV_COMP_INT4_G32       = 3,
+    SPECKV_COMP_FP8_E4M3       = 4,
 } speckv_comp_scheme_t;
 
 /* reference host/include/speckv.h:65-66 / speckv_c_api.cpp:101-121.

@@ -148,6 +148,22 @@ speckv_status_t speckv_ext_codec_decompress(const void* d_recs, uint64_t rec_str
                                             uint64_t n_blocks, void* d_dst, int out_f32,
                                             int scheme, int quant_mode, void* stream);
 
+/* ---- 4:1 / 2:1 formats + fused dequant-matvec (BASELINE config 5; SURVEY 8a row
+ *      A22: no reference counterpart, parity is against oracle/ only) -----------
+ * SPECKV_COMP_INT4_G32: record 1152 B = 64 fp16 group scales + 2048 nibbles.
+ * SPECKV_COMP_FP8_E4M3: record 2048 B of OCP e4m3fn + one f32 scale per block.
+ * speckv_ext_qk_scores_fp8: attention scores q.K^T for positions
+ * [pos_begin, pos_end) (both even) of `layer`, computed on the matrix cores
+ * directly from the FP8 records of the K region (request 0 of the shim layout;
+ * needs speckv_ext_set_layout with num_heads*head_dim == 1024, head_dim 128).
+ *   d_q_f16 : [num_heads][g][128] fp16 query rows (g <= 16 rows per kv head, GQA)
+ *   d_out   : [num_heads][g][pos_end-pos_begin] fp32
+ * The query is quantised per row to e4m3 (scale max|q|/448) on the device. */
+speckv_status_t speckv_ext_qk_scores_fp8(speckv_handle_t handle, uint32_t layer,
+                                         const void* d_q_f16, uint32_t g,
+                                         uint32_t pos_begin, uint32_t pos_end,
+                                         float* d_out, void* stream);
+
 /* ---- tier manager (CXLMemoryManager, cxl_memory_manager.h:40-90) ---------- */
 speckv_status_t speckv_ext_promote_to_l1(speckv_handle_t handle, uint64_t offset_bytes);
 speckv_status_t speckv_ext_demote_to_l3(speckv_handle_t handle, uint64_t offset_bytes);

@@ -47,7 +47,7 @@ class Oracle:
     """Thin numpy front-end over libspeckv_oracle.so."""
 
     REF_EXACT, INTENT = 0, 1
-    FP16, INT8, INT8_DELTA_RLE = 0, 1, 2
+    FP16, INT8, INT8_DELTA_RLE, INT4_G32, FP8_E4M3 = 0, 1, 2, 3, 4
 
     def __init__(self, path=None):
         path = path or ORACLE_SO
@@ -87,6 +87,10 @@ class Oracle:
             "orc_compress_block_f16": (C.c_size_t, [u16p, C.c_size_t, C.c_int, C.c_int, f32p, u8p]),
             "orc_decompress_block_f16": (C.c_size_t, [u8p, C.c_size_t, C.c_float, C.c_int, C.c_int, u16p, C.c_size_t]),
             "orc_decompress_block_f32": (C.c_size_t, [u8p, C.c_size_t, C.c_float, C.c_int, C.c_int, f32p, C.c_size_t]),
+            "orc_f32_to_e4m3": (C.c_uint8, [C.c_float]),
+            "orc_e4m3_to_f32": (C.c_float, [C.c_uint8]),
+            "orc_qk_scores_fp8": (None, [u8p, f32p, C.c_size_t, u8p, f32p, C.c_size_t, C.c_size_t, f32p]),
+            "orc_quantize_rows_e4m3": (None, [u16p, C.c_size_t, C.c_size_t, u8p, f32p]),
             "orc_layer_compression_ratio": (C.c_double, [C.c_uint32]),
             "orc_codec_throughput_gbps": (C.c_double, [C.c_size_t, C.c_double, C.c_size_t]),
             "orc_codec_pipeline_latency_cycles": (C.c_size_t, []),

@@ -359,9 +359,92 @@ size_t orc_decompress_f32(const uint8_t* rle, size_t len, float scale, int mode,
     return n;
 }
 
+/* ---- e4m3fn (OCP FP8: 1-4-3, bias 7, no inf, 0x7F/0xFF NaN, max 448) ---- */
+float orc_e4m3_to_f32(uint8_t b)
+{
+    uint32_t sign = (b & 0x80u) ? 0x80000000u : 0u;
+    uint32_t e = (b >> 3) & 0xFu, m = b & 7u;
+    if (e == 15 && m == 7) return u2f(sign | 0x7FC00000u);
+    if (e == 0) { float v = (float)m * (1.0f / 512.0f); return u2f(f2u(v) | sign); }   /* m/8 * 2^-6 */
+    return u2f(sign | ((e + 120u) << 23) | (m << 20));
+}
+uint8_t orc_f32_to_e4m3(float f)
+{
+    uint32_t u = f2u(f);
+    uint8_t sign = (uint8_t)((u >> 24) & 0x80u);
+    uint32_t a = u & 0x7FFFFFFFu;
+    if (a > 0x7F800000u) return (uint8_t)(sign | 0x7Fu);                 /* NaN */
+    if (a >= 0x43E00000u) return (uint8_t)(sign | 0x7Eu);                /* >= 448: saturate */
+    if (a < 0x3A800000u) {                                               /* < 2^-10: rounds to 0 or min subnormal */
+        /* min subnormal 2^-9; ties at 2^-10 go to even (0) */
+        return (uint8_t)(sign | ((a > 0x3A800000u) ? 1u : 0u));
+    }
+    int32_t e = (int32_t)(a >> 23) - 127;
+    uint32_t m = (a & 0x7FFFFFu) | 0x800000u;
+    uint32_t shift;
+    uint32_t base;
+    if (e < -6) { shift = (uint32_t)(20 + (-6 - e)); base = 0; }           /* subnormal target */
+    else        { shift = 20; base = (uint32_t)(e + 7) << 3; }
+    uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) q++;
+    uint32_t r = (e < -6) ? q : base + q - 8u;
+    if (r > 0x7Eu) r = 0x7Eu;
+    return (uint8_t)(sign | r);
+}
+
+static size_t compress_int4_g32(const float* xf, size_t n, uint8_t* rec)
+{
+    size_t groups = n / 32;
+    uint8_t* nib = rec + 2 * groups;
+    memset(nib, 0, n / 2);
+    for (size_t g = 0; g < groups; ++g) {
+        float mx = 0.0f;
+        for (size_t i = 0; i < 32; ++i) { float a = fabsf(xf[g * 32 + i]); if (a > mx) mx = a; }
+        uint16_t s16 = orc_float_to_half(mx / 7.0f);
+        memcpy(rec + 2 * g, &s16, 2);
+        float s = orc_half_to_float(s16);
+        for (size_t i = 0; i < 32; ++i) {
+            float r = 0.0f;
+            if (s != 0.0f && s == s) {
+                r = roundf(xf[g * 32 + i] / s);
+                if (!(r == r)) r = 0.0f;
+                if (r > 7.0f) r = 7.0f;
+                if (r < -7.0f) r = -7.0f;
+            }
+            uint8_t q = (uint8_t)((int32_t)r & 0xF);
+            size_t e = g * 32 + i;
+            nib[e >> 1] |= (uint8_t)((e & 1) ? (q << 4) : q);
+        }
+    }
+    return 2 * groups + n / 2;
+}
+
 size_t orc_compress_block_f16(const uint16_t* x, size_t n, int scheme, int mode,
                               float* scale, uint8_t* rec)
 {
+    if (scheme == ORC_COMP_INT4_G32 || scheme == ORC_COMP_FP8_E4M3) {
+        float* xf = (float*)malloc((n ? n : 1) * sizeof(float));
+        for (size_t i = 0; i < n; ++i) xf[i] = orc_half_to_float(x[i]);
+        size_t len;
+        if (scheme == ORC_COMP_INT4_G32) {
+            *scale = 1.0f;
+            len = compress_int4_g32(xf, n, rec);
+        } else {
+            float mx = 0.0f;
+            for (size_t i = 0; i < n; ++i) { float a = fabsf(xf[i]); if (a > mx) mx = a; }
+            float s = (mx > 0.0f) ? (mx / 448.0f) : 1.0f;
+            *scale = s;
+            for (size_t i = 0; i < n; ++i) {
+                float v = xf[i] / s;
+                if (v > 448.0f) v = 448.0f;
+                if (v < -448.0f) v = -448.0f;
+                rec[i] = orc_f32_to_e4m3(v);
+            }
+            len = n;
+        }
+        free(xf);
+        return len;
+    }
     if (scheme == ORC_COMP_FP16) {
         memcpy(rec, x, 2 * n);
         *scale = 1.0f;
@@ -385,6 +468,24 @@ size_t orc_compress_block_f16(const uint16_t* x, size_t n, int scheme, int mode,
 size_t orc_decompress_block_f32(const uint8_t* rec, size_t len, float scale, int scheme,
                                 int mode, float* y, size_t cap)
 {
+    if (scheme == ORC_COMP_INT4_G32) {
+        /* fixed-size record: cap/32 group scales then cap/2 nibble bytes; a short record decodes to zeros */
+        size_t groups = cap / 32;
+        if (len < 2 * groups + cap / 2) { for (size_t i = 0; i < cap; ++i) y[i] = 0.0f; return cap; }
+        const uint8_t* nib = rec + 2 * groups;
+        for (size_t i = 0; i < cap; ++i) {
+            uint16_t s16; memcpy(&s16, rec + 2 * (i / 32), 2);
+            uint8_t q4 = (uint8_t)((nib[i >> 1] >> ((i & 1) * 4)) & 0xF);
+            int q = (q4 & 8) ? (int)q4 - 16 : (int)q4;
+            y[i] = (float)q * orc_half_to_float(s16);
+        }
+        return cap;
+    }
+    if (scheme == ORC_COMP_FP8_E4M3) {
+        size_t n = len < cap ? len : cap;
+        for (size_t i = 0; i < n; ++i) y[i] = orc_e4m3_to_f32(rec[i]) * scale;
+        return n;
+    }
     if (scheme == ORC_COMP_FP16) {
         size_t n = len / 2; if (n > cap) n = cap;
         for (size_t i = 0; i < n; ++i) {
@@ -414,6 +515,34 @@ size_t orc_decompress_block_f16(const uint8_t* rec, size_t len, float scale, int
     for (size_t i = 0; i < n; ++i) y[i] = orc_float_to_half(yf[i]);
     free(yf);
     return n;
+}
+
+void orc_quantize_rows_e4m3(const uint16_t* q16, size_t rows, size_t d, uint8_t* q8, float* scale)
+{
+    for (size_t r = 0; r < rows; ++r) {
+        float mx = 0.0f;
+        for (size_t i = 0; i < d; ++i) { float a = fabsf(orc_half_to_float(q16[r * d + i])); if (a > mx) mx = a; }
+        float s = (mx > 0.0f) ? (mx / 448.0f) : 1.0f;
+        scale[r] = s;
+        for (size_t i = 0; i < d; ++i) {
+            float v = orc_half_to_float(q16[r * d + i]) / s;
+            if (v > 448.0f) v = 448.0f;
+            if (v < -448.0f) v = -448.0f;
+            q8[r * d + i] = orc_f32_to_e4m3(v);
+        }
+    }
+}
+
+void orc_qk_scores_fp8(const uint8_t* q8, const float* q_scale, size_t g, const uint8_t* k_rec,
+                       const float* k_scale, size_t n_pos, size_t d, float* out)
+{
+    for (size_t m = 0; m < g; ++m)
+        for (size_t t = 0; t < n_pos; ++t) {
+            float acc = 0.0f;
+            for (size_t i = 0; i < d; ++i)
+                acc += orc_e4m3_to_f32(q8[m * d + i]) * orc_e4m3_to_f32(k_rec[t * d + i]);
+            out[m * n_pos + t] = acc * k_scale[t] * q_scale[m];
+        }
 }
 
 double orc_layer_compression_ratio(uint32_t layer_id)

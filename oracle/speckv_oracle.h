@@ -122,6 +122,31 @@ size_t orc_decompress_block_f16(const uint8_t* rec, size_t len, float scale,
 size_t orc_decompress_block_f32(const uint8_t* rec, size_t len, float scale,
                                 int scheme, int mode, float* y, size_t cap);
 
+/* ---- 4:1 / 2:1 block formats of BASELINE config 5 --------
+ * EXTENSION WITHOUT A REFERENCE COUNTERPART: **parity unpinned** -- there is no
+ * reference code for these; this restatement is the definition the HIP kernels
+ * are held to.
+ *   scheme 3 INT4_G32 : record = 64 fp16 group scales (128 B) + 1024 B of
+ *     nibbles (element 2i low, 2i+1 high, two's complement).  Per group of 32:
+ *     s = fp16(max|x| / 7); q = clamp(roundf(x / float(s)), -7, 7) (0 when
+ *     s == 0 or x is NaN); y = q * float(s).
+ *   scheme 4 FP8_E4M3 : per-block f32 scale s = max|x| / 448 (1 when all zero),
+ *     record = 2048 OCP e4m3fn bytes of clamp(x / s, +-448) rounded to nearest
+ *     even; y = e4m3(b) * s.
+ * fp16 in, fp16 (one RNE rounding) or fp32 out, like the other schemes. */
+enum { ORC_COMP_INT4_G32 = 3, ORC_COMP_FP8_E4M3 = 4 };
+uint8_t orc_f32_to_e4m3(float f);
+float   orc_e4m3_to_f32(uint8_t b);
+/* q.K^T scores straight from FP8 records (the fused dequant-matvec of config 5):
+ * k_rec: n_pos rows of 128 e4m3 bytes (one kv head), k_scale[n_pos] the scale of
+ * the block each row came from; q8: g rows of 128 e4m3 bytes with q_scale[g].
+ * out[m*n_pos + t] = (sum_d q8[m][d]*k[t][d], fp32, d ascending) * k_scale[t] * q_scale[m]. */
+void orc_qk_scores_fp8(const uint8_t* q8, const float* q_scale, size_t g,
+                       const uint8_t* k_rec, const float* k_scale, size_t n_pos,
+                       size_t d, float* out);
+/* per-row e4m3 quantisation of the query (scale = max|q|/448, 1 if zero) */
+void orc_quantize_rows_e4m3(const uint16_t* q16, size_t rows, size_t d, uint8_t* q8, float* scale);
+
 /* cache_engine.cpp:25-33,142-148 */
 double   orc_layer_compression_ratio(uint32_t layer_id);
 /* cache_engine.cpp:286-296 */

@@ -82,6 +82,58 @@ def test_decompress_matches_oracle(lib, oracle, scheme, mode, out_f32):
         assert_same_float_bits(y[b], want, f"scheme {scheme} mode {mode} block {b}")
 
 
+@pytest.mark.parametrize("scheme", [3, 4])
+def test_extension_formats_match_oracle(lib, oracle, scheme):
+    """INT4_G32 / FP8_E4M3 (BASELINE config 5; no reference counterpart, parity is
+    against oracle/ only): record bytes and decoded fp16/fp32 bit-identical."""
+    x16 = make_blocks()
+    rng = np.random.default_rng(77)
+    extra = np.stack([rng.standard_normal(N) * 10.0 ** rng.integers(-4, 3), rng.standard_normal(N) * 300,
+                      np.where(rng.random(N) < 0.5, 0, rng.standard_normal(N)),
+                      np.repeat(rng.standard_normal(N // 32) * np.array([1e-6, 1, 100, 6e4] * (N // 128)), 32)])
+    with np.errstate(over="ignore"):
+        x16 = np.concatenate([x16, extra.astype(np.float16)])
+    finite = np.isfinite(x16.astype(np.float32)).all(axis=1)     # inf/nan blocks: covered separately below
+    scales, lens, recs = gpu_compress(lib, x16, scheme, 0)
+    o_scales, o_lens, o_recs = oracle.compress_blocks_f16(x16, scheme, 0)
+    assert np.array_equal(lens, o_lens) and (lens == (1152 if scheme == 3 else 2048)).all()
+    for b in np.flatnonzero(finite):
+        assert recs[b, :lens[b]].tobytes() == o_recs[b, :lens[b]].tobytes(), f"block {b}"
+        if scheme == 4:
+            assert scales[b].tobytes() == o_scales[b].tobytes()
+    for out_f32 in (False, True):
+        y = gpu_decompress(lib, o_recs, o_lens, o_scales, scheme, 0, out_f32)
+        for b in np.flatnonzero(finite):
+            if out_f32:
+                want = oracle.decompress_block_f32(o_recs[b, :o_lens[b]], o_scales[b], scheme, 0, N)
+            else:
+                want = oracle.decompress_block_f16(o_recs[b, :o_lens[b]], o_scales[b], scheme, 0, N)
+            assert_same_float_bits(y[b], want, f"scheme {scheme} f32={out_f32} block {b}")
+    # every e4m3 byte / every nibble decodes like the oracle
+    if scheme == 4:
+        rec = np.resize(np.arange(256, dtype=np.uint8), (1, 4096)); ln = np.array([2048], np.uint32)
+        y = gpu_decompress(lib, rec, ln, np.array([0.5], np.float32), 4, 0, True)[0]
+        want = oracle.decompress_block_f32(rec[0, :2048], 0.5, 4, 0, N)
+        assert_same_float_bits(y, want, "all e4m3 bytes")
+    # round-trip error bounds (size-independent property)
+    y = gpu_decompress(lib, recs, lens, scales, scheme, 0, True)
+    xf = x16.astype(np.float32)
+    for b in np.flatnonzero(finite):
+        if scheme == 3:
+            g = np.abs(xf[b]).reshape(-1, 32).max(axis=1)
+            bound = np.repeat(g / 7 * 0.5 * 1.01 + g * 2 ** -10, 32) + 1e-12
+        else:
+            bound = np.abs(xf[b]) * 2 ** -4 + np.abs(xf[b]).max() / 448 * 2 ** -10 + 1e-12
+        assert (np.abs(y[b] - xf[b]) <= bound).all(), f"block {b}"
+    # short records decode to zeros (INT4) / a zero tail (FP8)
+    lens2 = lens.copy(); lens2[0] = 100
+    y = gpu_decompress(lib, recs, lens2, scales, scheme, 0, True)
+    want = np.zeros(N, np.float32)
+    got = oracle.decompress_block_f32(recs[0, :100], scales[0], scheme, 0, N)
+    want[:got.size] = got
+    assert_same_float_bits(y[0], want, "short record")
+
+
 def test_golden_reference_vectors(lib, golden_dir):
     """Reference-generated vectors (tests/golden/codec_vectors.npz): the HIP path
     reproduces the reference's bytes and fp32 outputs without the oracle in between."""

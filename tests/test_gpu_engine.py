@@ -316,3 +316,55 @@ def test_fetch_list_and_range_full_size(eng):
         torch.cuda.synchronize()
         assert torch.equal(sub.view(torch.int16), out[perm.long()].view(torch.int16))
         lib.free(h)
+
+
+def test_fp8_qk_scores_fused_mfma(eng, oracle):
+    """BASELINE config 5 fused dequant-matvec: q.K^T scores computed by
+    v_mfma_f32_16x16x32_fp8_fp8 straight from the FP8 pool records, against the
+    oracle's scalar fp32 loop over the same e4m3 bytes.  The products are exact in
+    both; the fp8 MFMA's internal accumulation is NOT a correctly rounded fp32 chain
+    (measured on MI355X against an exact fp64 sum: max 1.1e-5, mean 1.3e-6 of
+    sum|terms|), so the stated tolerance is |got - want| <= 3e-5 * sum|terms|."""
+    torch = torch_mod()
+    lib = eng.lib
+    lib.set_compression_scheme(4)
+    T, L, H, D, bpe, G = 256, 3, 8, 128, 2, 8                 # GQA: 8 query rows per kv head
+    h = eng.allocate(T, L, H, D, bpe)
+    n_pages = T * L * H * D * bpe * 2 // PAGE
+    rng = np.random.default_rng(31)
+    x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.1, 4.0, (n_pages, 1))).astype(np.float16)
+    lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+    scales, lens, recs = oracle.compress_blocks_f16(x, 4, 0)
+    q = rng.standard_normal((H, G, D)).astype(np.float16)
+    d_q = torch.from_numpy(q.view(np.int16)).cuda()
+    q8 = np.zeros((H * G, D), np.uint8); qs = np.zeros(H * G, np.float32)
+    from oracle.bindings import _ptr, u8p, u16p, f32p
+    oracle.lib.orc_quantize_rows_e4m3(_ptr(q.view(np.uint16).reshape(-1), u16p), H * G, D, _ptr(q8, u8p), _ptr(qs, f32p))
+    for layer, (pb, pe) in ((0, (0, T)), (2, (64, 200)), (1, (2, 4))):
+        npos = pe - pb
+        d_out = torch.full((H, G, npos), float("nan"), dtype=torch.float32, device="cuda")
+        lib.qk_scores_fp8(h, layer, d_q.data_ptr(), G, pb, pe, d_out.data_ptr())
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        first_page = (layer * 2 * T + pb) // 2
+        for head in range(H):
+            # rows of this kv head: position t lives in page first_page + t//2, slot t%2
+            krows = np.stack([recs[first_page + t // 2, ((t % 2) * H + head) * D:((t % 2) * H + head + 1) * D] for t in range(npos)])
+            kscale = np.array([scales[first_page + t // 2] for t in range(npos)], np.float32)
+            want = np.zeros((G, npos), np.float32)
+            oracle.lib.orc_qk_scores_fp8(_ptr(np.ascontiguousarray(q8[head * G:(head + 1) * G]), u8p), _ptr(qs[head * G:(head + 1) * G].copy(), f32p), G,
+                                         _ptr(np.ascontiguousarray(krows), u8p), _ptr(kscale, f32p), npos, D, _ptr(want, f32p))
+            qf = np.array([[oracle.lib.orc_e4m3_to_f32(int(b)) for b in row] for row in q8[head * G:(head + 1) * G]], np.float32)
+            kf = np.array([[oracle.lib.orc_e4m3_to_f32(int(b)) for b in row] for row in krows], np.float32)
+            mag = (np.abs(qf) @ np.abs(kf).T) * kscale[None, :] * qs[head * G:(head + 1) * G, None]
+            assert np.all(np.abs(got[head] - want) <= 3e-5 * mag + 1e-30), (layer, head, float(np.abs(got[head] - want).max()))
+    # and the scores are close to the fp16 attention scores they stand for (quantisation error only)
+    d_out = torch.empty((H, G, T), dtype=torch.float32, device="cuda")
+    lib.qk_scores_fp8(h, 0, d_q.data_ptr(), G, 0, T, d_out.data_ptr())
+    torch.cuda.synchronize()
+    kfull = x[:T // 2].reshape(T // 2, 2, H, D).astype(np.float32).reshape(T, H, D)       # layer 0, kind K
+    ref = np.einsum("hgd,thd->hgt", q.astype(np.float32), kfull)
+    err = np.abs(d_out.cpu().numpy() - ref)
+    assert err.max() <= 0.08 * np.abs(ref).max() + 0.5
+    with pytest.raises(SpeckvError):
+        lib.qk_scores_fp8(h, 0, d_q.data_ptr(), G, 1, 5, d_out.data_ptr())     # odd positions -> INVAL
