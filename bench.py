@@ -412,6 +412,49 @@ def xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream
     return info
 
 
+def fp8_scores_extra(torch, kv, T, Lyr):
+    """BASELINE configs[4] (int4/fp8 path, 70B-shaped KV: 80 layers, 8 kv heads, D=128,
+    32k context): the fused dequant-matvec -- q.K^T scores of every layer of one
+    sequence straight from FP8 records on the fp8 matrix cores, 8 query rows per kv
+    head (GQA).  Bytes = the K records read; the fp16 K is never materialised."""
+    lib = kv.lib
+    try:
+        lib.set_compression_scheme(4)
+        h = lib.alloc(T * Lyr * 8 * 128 * 2 * 2)
+        lib.set_layout(h, T, Lyr, 8, 128, 2)
+        n_pages = T * Lyr * 8 * 128 * 2 * 2 // PAGE
+        g = torch.Generator(device="cuda"); g.manual_seed(2005)
+        chunk = 65536
+        for p0 in range(0, n_pages, chunk):
+            x = torch.randn((min(chunk, n_pages - p0), BLOCK_ELEMS), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+            lib.write(h, p0 * PAGE, x.data_ptr(), x.numel() * 2, True)
+        q = torch.randn((Lyr, 8, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+        out = torch.empty((Lyr, 8, 8, T), dtype=torch.float32, device="cuda")
+        s = torch.cuda.Stream()
+        def allayers():
+            lib.qk_scores_fp8_layers(h, 0, Lyr, q.data_ptr(), 8, 0, T, out.data_ptr(), s.cuda_stream)
+        allayers(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        a.record(s)
+        for _ in range(reps):
+            allayers()
+        b.record(s); torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        k_bytes = Lyr * (T // 2) * 2048
+        lib.free(h)
+        out_bytes = Lyr * 8 * 8 * T * 4
+        return {"fp8_qk_scores_mfma": {"layers": Lyr, "positions": T, "query_rows_per_kv_head": 8,
+                                       "pool_GiB_fp8": round(n_pages * 2048 / 2**30, 2), "scores_written_GBps": round(out_bytes / (ms * 1e-3) / 1e9, 1),
+                                       "ms_all_layers": round(ms, 4), "K_record_GBps": round(k_bytes / (ms * 1e-3) / 1e9, 1),
+                                       "frac_hbm": round(k_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                       "note": "all layers in one scores launch (+1 query-quantise launch); bytes = K records only"}}
+    except Exception as e:
+        return {"fp8_qk_scores_mfma": {"error": repr(e)}}
+    finally:
+        lib.set_compression_scheme(2)
+
+
 def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     """Latency / rate of the non-bulk entry points (C ABI calls, not kernels alone)."""
     lib = kv.lib
@@ -430,6 +473,7 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     hit_us = (time.perf_counter() - t0) / 10 * 1e6
     ex["speckv_access_us"] = {"miss_sync_fetch": round(miss_us, 2), "hit": round(hit_us, 2),
                               "reference_emulated_us": "2.2-2.8 (SURVEY 3.1, no data moved)"}
+    ex.update(fp8_scores_extra(torch, kv, 32768, 80))      # BASELINE configs[4] shape: 70B-shaped KV @ 32k context
     # one decode step of a 256-sequence batch worth of look-ahead requests (cfg4-sized call count)
     n_req = 256 * Lyr
     reqs = [0] * n_req
@@ -460,14 +504,15 @@ def run_extras(torch, pkg, lib, src, dst, n_blocks, sp):
         a.record(); [fn() for _ in range(reps)]; b.record(); torch.cuda.synchronize()
         return a.elapsed_time(b) / reps
 
-    for scheme, mode, name in ((0, 0, "fp16_copy"), (1, 0, "int8_ref_exact"), (2, 0, "rle_ref_exact"), (2, 1, "rle_intent")):
-        stride = 2048 if scheme == 1 else PAGE
+    for scheme, mode, name in ((0, 0, "fp16_copy"), (1, 0, "int8_ref_exact"), (2, 0, "rle_ref_exact"), (2, 1, "rle_intent"),
+                               (3, 0, "int4_g32"), (4, 0, "fp8_e4m3")):
+        stride = {1: 2048, 3: 1152, 4: 2048}.get(scheme, PAGE)
         enc = lambda: raw.speckv_ext_codec_compress(src.data_ptr(), n_blocks, recs.data_ptr(), stride, lens.data_ptr(), scales.data_ptr(), scheme, mode, sp)
         dec = lambda: raw.speckv_ext_codec_decompress(recs.data_ptr(), stride, lens.data_ptr(), scales.data_ptr(), n_blocks, dst.data_ptr(), 0, scheme, mode, sp)
         enc_ms = timed(enc)
         dec_ms = timed(dec)
         comp = int(lens.to(torch.int64).sum().item())
-        dec_bytes = comp + n_blocks * (4 + PAGE)
+        dec_bytes = comp + n_blocks * ((0 if scheme == 3 else 4) + PAGE)
         enc_bytes = n_blocks * PAGE + comp + n_blocks * 8
         ex[name] = {
             "decompress_blocks_per_s": round(n_blocks / (dec_ms * 1e-3), 1),

@@ -29,9 +29,14 @@ def library_path():
             raise RuntimeError(f"SPECKV_LIB_PATH={override} does not exist")
         return override
     if not os.path.exists(LIB_PATH):
-        raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(needs hipcc). There is no CPU fallback for the KV data path.")
+        # a fresh checkout: build in-tree once (hipcc cross-compiles gfx950 anywhere)
+        try:
+            build_library()
+        except Exception as e:
+            raise RuntimeError(
+                f"{LIB_PATH} is missing and could not be built ({e!r}). Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+                "There is no CPU fallback for the KV data path.") from e
     return LIB_PATH
 
 

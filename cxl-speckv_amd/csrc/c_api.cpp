@@ -294,7 +294,18 @@ speckv_status_t speckv_ext_qk_scores_fp8(speckv_handle_t handle, uint32_t layer,
 {
     LOCK; NEED_INIT;
     return guarded([&] {
-        return g_engine->qk_scores_fp8(handle, layer, d_q_f16, g, pos_begin, pos_end, d_out, static_cast<hipStream_t>(stream));
+        return g_engine->qk_scores_fp8(handle, layer, 1, d_q_f16, g, pos_begin, pos_end, d_out, static_cast<hipStream_t>(stream));
+    });
+}
+
+speckv_status_t speckv_ext_qk_scores_fp8_layers(speckv_handle_t handle, uint32_t layer_begin, uint32_t n_layers,
+                                                const void* d_q_f16, uint32_t g, uint32_t pos_begin, uint32_t pos_end,
+                                                float* d_out, void* stream)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] {
+        return g_engine->qk_scores_fp8(handle, layer_begin, n_layers, d_q_f16, g, pos_begin, pos_end, d_out,
+                                       static_cast<hipStream_t>(stream));
     });
 }
 

@@ -942,7 +942,7 @@ int Engine::fetch_list(uint64_t handle, const uint32_t* d_pages, uint32_t n, voi
     return SPECKV_OK;
 }
 
-int Engine::qk_scores_fp8(uint64_t handle, uint32_t layer, const void* d_q_f16, uint32_t g,
+int Engine::qk_scores_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
                           uint32_t pos_begin, uint32_t pos_end, float* d_out, hipStream_t s)
 {
     if (null_) return no_data_path("speckv_ext_qk_scores_fp8");
@@ -952,22 +952,25 @@ int Engine::qk_scores_fp8(uint64_t handle, uint32_t layer, const void* d_q_f16, 
     const Layout& L = a->layout;
     // one K row (all heads of a position) must be 2048 B: two positions per page
     if (L.head_dim != 128 || L.bytes_per_element != 2 || L.num_heads * L.head_dim != 1024) return SPECKV_ERR_INVAL;
-    if (layer >= L.num_layers || pos_begin % 2 || pos_begin > pos_end || pos_end > L.num_tokens || pos_end % 2)
+    if (n_layers == 0 || layer >= L.num_layers || n_layers > L.num_layers - layer || pos_begin % 2 || pos_begin > pos_end ||
+        pos_end > L.num_tokens || pos_end % 2)
         return SPECKV_ERR_INVAL;
     if (g == 0 || g > 16 || !d_q_f16 || !d_out) return SPECKV_ERR_INVAL;
     const uint32_t n_pages = (pos_end - pos_begin) / 2;
     if (n_pages == 0) return SPECKV_OK;
     // shim layout [req 0][layer][kind 0 = K][pos][head]: page of (layer, pos)
     const uint64_t first_page = (static_cast<uint64_t>(layer) * 2 * L.num_tokens + pos_begin) / 2;
-    if (first_page + n_pages > a->n_pages) return SPECKV_ERR_GENERAL;
+    const uint64_t layer_stride = static_cast<uint64_t>(L.num_tokens);      // pages per layer: K + V = 2*T/2
+    if (first_page + (n_layers - 1) * layer_stride + n_pages > a->n_pages) return SPECKV_ERR_GENERAL;
     int prev = 0; (void)hipGetDevice(&prev);
     if (prev != device_) HIP_TRY(hipSetDevice(device_));
     hipStream_t st = s ? s : stream_;
-    uint8_t* q8 = static_cast<uint8_t*>(scratch(s_req_, static_cast<size_t>(L.num_heads) * 16 * 128 + L.num_heads * 16 * sizeof(float)));
+    const size_t rows = static_cast<size_t>(n_layers) * L.num_heads * 16;
+    uint8_t* q8 = static_cast<uint8_t*>(scratch(s_req_, rows * 128 + rows * sizeof(float)));
     if (!q8) return SPECKV_ERR_NOMEM;
-    float* qs = reinterpret_cast<float*>(q8 + static_cast<size_t>(L.num_heads) * 16 * 128);
-    HIP_TRY(launch_quantize_q_e4m3(d_q_f16, L.num_heads, g, L.head_dim, q8, qs, st));
-    HIP_TRY(launch_qk_scores_fp8(a->d_entries, first_page, n_pages, L.num_heads, g, q8, qs, d_out, st));
+    float* qs = reinterpret_cast<float*>(q8 + rows * 128);
+    HIP_TRY(launch_quantize_q_e4m3(d_q_f16, n_layers * L.num_heads, g, L.head_dim, q8, qs, st));
+    HIP_TRY(launch_qk_scores_fp8(a->d_entries, first_page, layer_stride, n_layers, n_pages, L.num_heads, g, q8, qs, d_out, st));
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
     if (prev != device_) (void)hipSetDevice(prev);
     return SPECKV_OK;

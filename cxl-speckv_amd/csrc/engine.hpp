@@ -98,7 +98,7 @@ public:
                         uint32_t* d_count, hipStream_t s);
     int verify(uint32_t req, int32_t actual, const int32_t* pred, uint32_t n,
                uint32_t* was_hit, uint32_t* new_depth);
-    int qk_scores_fp8(uint64_t handle, uint32_t layer, const void* d_q_f16, uint32_t g,
+    int qk_scores_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
                       uint32_t pos_begin, uint32_t pos_end, float* d_out, hipStream_t s);
     int poll_complete(uint32_t* done);
     int sync();

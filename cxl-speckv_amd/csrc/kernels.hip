@@ -964,11 +964,17 @@ __global__ void k_init_entries(PageEntry* e, uint64_t n, uint64_t base, uint64_t
 // ===================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi)
+{
+    return static_cast<long>(static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32));
+}
+
 // per query row: scale = max|q|/448 (1 if zero), e4m3 bytes of clamp(q/scale); rows >= g are zero
 __global__ __launch_bounds__(64) void k_quantize_q_e4m3(const uint16_t* __restrict__ q16, uint32_t g,
                                                         uint32_t d, uint8_t* __restrict__ q8,
                                                         float* __restrict__ qs)
 {
+    // blockIdx.x runs over (layer, head, row): q16 is [layers][heads][g][d], q8 [layers][heads][16][d]
     const uint32_t lane = threadIdx.x, h = blockIdx.x / 16u, m = blockIdx.x % 16u;
     uint8_t* out = q8 + (static_cast<uint64_t>(h) * 16u + m) * d;
     if (m >= g) {
@@ -989,55 +995,92 @@ __global__ __launch_bounds__(64) void k_quantize_q_e4m3(const uint16_t* __restri
     if (lane == 0) qs[h * 16u + m] = sc;
 }
 
-// One wave = 8 pages = 16 positions, all heads.  MFMA 16x16x32 fp8: A = 16 query
-// rows x 32 k, B = 32 k x 16 positions; lane (c = l%16, kb = l/16) supplies 8
-// consecutive k of row/column c.  The k axis of the dot product is permuted so that
-// lane kb owns d in [32kb, 32kb+32): four MFMA steps consume 32 contiguous bytes of
-// a K row, i.e. every 128-byte K row is read once by 4 lanes, straight from the pool.
-__global__ __launch_bounds__(256) void k_qk_scores_fp8(const PageEntry* __restrict__ entries,
-        uint64_t first_page, uint32_t n_pages, uint32_t heads, uint32_t g,
+// One wave = 8 pages = 16 positions, all 8 kv heads, K tile staged in LDS.
+//   * fetch: the 16 KiB tile goes pool -> LDS with 16 global_load_lds_dwordx4 (1 KiB
+//     each, no VGPRs); instruction i brings the row block of position i (8 heads x
+//     128 B).  Whole 128-byte lines per instruction, pages read exactly once.
+//   * LDS image: row block i sits at i*1024; its 16-byte chunks are XOR-swizzled with
+//     i ON THE SOURCE SIDE (lane l fetches chunk l^i), because the MFMA reader walks
+//     16 row blocks at the same in-row offset (1 KiB stride = one bank otherwise).
+//   * MFMA 16x16x32 fp8: lane (c = l%16, kb = l/16) feeds 8 consecutive d of query
+//     row c (A) / position c (B); the d axis is permuted so lane kb owns
+//     d in [32kb, 32kb+32) -> two ds_read_b64 per 16-byte chunk.
+__global__ __launch_bounds__(128) void k_qk_scores_fp8(const PageEntry* __restrict__ entries,
+        uint64_t first_page, uint64_t layer_page_stride, uint32_t n_pages, uint32_t heads, uint32_t g,
         const uint8_t* __restrict__ q8, const float* __restrict__ qs, float* __restrict__ out)
 {
+    __shared__ __attribute__((aligned(1024))) uint8_t tiles[2][16384];
+    // blockIdx.y = layer (several layers of one sequence in one launch)
+    first_page += blockIdx.y * layer_page_stride;
+    q8 += static_cast<uint64_t>(blockIdx.y) * heads * 16u * 128u;
+    qs += static_cast<uint64_t>(blockIdx.y) * heads * 16u;
+    out += static_cast<uint64_t>(blockIdx.y) * heads * g * 2u * n_pages;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t page0 = gw * 8u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t page0 = (blockIdx.x * 2u + wave) * 8u;            // wave-uniform
     if (page0 >= n_pages) return;
-    const uint32_t c = lane & 15u, kb = lane >> 4;
+    uint8_t* tile = tiles[wave];
     const uint32_t n_pos = 2u * n_pages;
-    // B side: column c = position page0*2 + c  ->  page page0 + c/2, slot c%2
-    const uint32_t pg = page0 + (c >> 1);
-    const bool live = pg < n_pages;
-    PageEntry e{0, 0, 0.0f};
-    if (live) e = entries[first_page + pg];
-    const bool have = live && e.rec_bytes >= kBlockElems;
-    const uint8_t* krow = reinterpret_cast<const uint8_t*>(e.pool_addr) + (c & 1u) * (heads * 128u) + kb * 32u;
-    for (uint32_t h = 0; h < heads; ++h) {
-        uint4 b0 = make_uint4(0u, 0u, 0u, 0u), b1 = b0;
-        if (have) {
-            b0 = ld16(krow + h * 128u);
-            b1 = ld16(krow + h * 128u + 16u);
+    // ---- fetch: 8 pages x 2 positions, descriptors through the scalar cache
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t pg = page0 + j;
+        PageEntry e{0, 0, 0.0f};
+        if (pg < n_pages) e = entries[first_page + pg];
+        const bool ok = pg < n_pages && e.rec_bytes >= kBlockElems;       // wave-uniform
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const int i = 2 * j + sl;
+            if (ok) {
+                const uint8_t* src = reinterpret_cast<const uint8_t*>(e.pool_addr) + sl * 1024 + ((lane ^ i) * 16u);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src),
+                    (__attribute__((address_space(3))) void*)(tile + i * 1024), 16, 0, 0);
+            } else {
+                *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16u) = make_uint4(0u, 0u, 0u, 0u);
+            }
         }
+    }
+    const uint32_t c = lane & 15u, kb = lane >> 4;
+    const uint32_t pgc = page0 + (c >> 1);
+    const bool live = pgc < n_pages;
+    float ks = 0.0f;
+    if (live) {
+        const PageEntry ec = entries[first_page + pgc];
+        ks = ec.rec_bytes >= kBlockElems ? ec.scale : 0.0f;
+    }
+    // query operands and row scales of all 8 heads: requested while the tile is in flight
+    uint4 a0[8], a1[8];
+    f32x4 qsc[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
         const uint8_t* qrow = q8 + (static_cast<uint64_t>(h) * 16u + c) * 128u + kb * 32u;
-        const uint4 a0 = *reinterpret_cast<const uint4*>(qrow);
-        const uint4 a1 = *reinterpret_cast<const uint4*>(qrow + 16);
+        a0[h] = *reinterpret_cast<const uint4*>(qrow);
+        a1[h] = *reinterpret_cast<const uint4*>(qrow + 16);
+        qsc[h] = *reinterpret_cast<const f32x4*>(qs + h * 16u + 4u * kb);
+    }
+    const uint32_t t = page0 * 2u + c;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // DMA landed, operands loaded
+    wave_lds_fence();
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        // B: chunks h*8 + kb*2 (+1) of row block c, at their swizzled place
+        const uint32_t q0 = (static_cast<uint32_t>(h) * 8u + kb * 2u) ^ c, q1 = (static_cast<uint32_t>(h) * 8u + kb * 2u + 1u) ^ c;
+        const uint2 b00 = *reinterpret_cast<const uint2*>(tile + c * 1024u + q0 * 16u);
+        const uint2 b01 = *reinterpret_cast<const uint2*>(tile + c * 1024u + q0 * 16u + 8u);
+        const uint2 b10 = *reinterpret_cast<const uint2*>(tile + c * 1024u + q1 * 16u);
+        const uint2 b11 = *reinterpret_cast<const uint2*>(tile + c * 1024u + q1 * 16u + 8u);
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-            static_cast<long>(a0.x | (static_cast<uint64_t>(a0.y) << 32)), static_cast<long>(b0.x | (static_cast<uint64_t>(b0.y) << 32)), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-            static_cast<long>(a0.z | (static_cast<uint64_t>(a0.w) << 32)), static_cast<long>(b0.z | (static_cast<uint64_t>(b0.w) << 32)), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-            static_cast<long>(a1.x | (static_cast<uint64_t>(a1.y) << 32)), static_cast<long>(b1.x | (static_cast<uint64_t>(b1.y) << 32)), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-            static_cast<long>(a1.z | (static_cast<uint64_t>(a1.w) << 32)), static_cast<long>(b1.z | (static_cast<uint64_t>(b1.w) << 32)), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(a0[h].x, a0[h].y), pack64(b00.x, b00.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(a0[h].z, a0[h].w), pack64(b01.x, b01.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(a1[h].x, a1[h].y), pack64(b10.x, b10.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(a1[h].z, a1[h].w), pack64(b11.x, b11.y), acc, 0, 0, 0);
         // accumulator: lane holds rows m = 4*kb + i (i = 0..3) of column c
-        const uint32_t t = page0 * 2u + c;
         if (live) {
-            const float ks = have ? e.scale : 0.0f;
-            const float r[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint32_t m = 4u * kb + i;
-                if (m < g) out[(static_cast<uint64_t>(h) * g + m) * n_pos + t] = r[i] * ks * qs[h * 16u + m];
+                if (m < g) out[(static_cast<uint64_t>(h) * g + m) * n_pos + t] = acc[i] * ks * qsc[h][i];
             }
         }
     }
@@ -1178,19 +1221,20 @@ hipError_t launch_quantize_q_e4m3(const void* d_q_f16, uint32_t heads, uint32_t 
                                   uint8_t* d_q8, float* d_qs, hipStream_t s)
 {
     if (heads == 0 || g == 0 || g > 16u || d != 128u) return hipErrorInvalidValue;
+    // `heads` may be layers*heads: rows are independent
     hipLaunchKernelGGL(k_quantize_q_e4m3, dim3(heads * 16u), dim3(64), 0, s,
                        static_cast<const uint16_t*>(d_q_f16), g, d, d_q8, d_qs);
     return hipGetLastError();
 }
 
-hipError_t launch_qk_scores_fp8(const PageEntry* d_entries, uint64_t first_page, uint32_t n_pages,
-                                uint32_t heads, uint32_t g, const uint8_t* d_q8, const float* d_qs,
-                                float* d_out, hipStream_t s)
+hipError_t launch_qk_scores_fp8(const PageEntry* d_entries, uint64_t first_page, uint64_t layer_page_stride,
+                                uint32_t n_layers, uint32_t n_pages, uint32_t heads, uint32_t g,
+                                const uint8_t* d_q8, const float* d_qs, float* d_out, hipStream_t s)
 {
-    if (n_pages == 0) return hipSuccess;
+    if (n_pages == 0 || n_layers == 0) return hipSuccess;
     const uint32_t waves = (n_pages + 7u) / 8u;
-    hipLaunchKernelGGL(k_qk_scores_fp8, dim3((waves + 3u) / 4u), dim3(256), 0, s, d_entries, first_page,
-                       n_pages, heads, g, d_q8, d_qs, d_out);
+    hipLaunchKernelGGL(k_qk_scores_fp8, dim3((waves + 1u) / 2u, n_layers), dim3(128), 0, s, d_entries, first_page,
+                       layer_page_stride, n_pages, heads, g, d_q8, d_qs, d_out);
     return hipGetLastError();
 }
 

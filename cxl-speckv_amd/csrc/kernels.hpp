@@ -88,9 +88,9 @@ hipError_t launch_init_entries(PageEntry* d_entries, uint64_t n, uint64_t base,
 //   d_out    [H][g][n_pos] fp32, n_pos = 2 * n_pages
 hipError_t launch_quantize_q_e4m3(const void* d_q_f16, uint32_t heads, uint32_t g, uint32_t d,
                                   uint8_t* d_q8, float* d_qs, hipStream_t s);
-hipError_t launch_qk_scores_fp8(const PageEntry* d_entries, uint64_t first_page, uint32_t n_pages,
-                                uint32_t heads, uint32_t g, const uint8_t* d_q8, const float* d_qs,
-                                float* d_out, hipStream_t s);
+hipError_t launch_qk_scores_fp8(const PageEntry* d_entries, uint64_t first_page, uint64_t layer_page_stride,
+                                uint32_t n_layers, uint32_t n_pages, uint32_t heads, uint32_t g,
+                                const uint8_t* d_q8, const float* d_qs, float* d_out, hipStream_t s);
 
 // wave-primitive self test: in[64] -> out[5*64]
 hipError_t launch_debug_dpp(const uint32_t* d_in, uint32_t* d_out, hipStream_t s);

@@ -163,6 +163,12 @@ speckv_status_t speckv_ext_qk_scores_fp8(speckv_handle_t handle, uint32_t layer,
                                          const void* d_q_f16, uint32_t g,
                                          uint32_t pos_begin, uint32_t pos_end,
                                          float* d_out, void* stream);
+/* Several layers of the sequence in one launch: d_q_f16 [n_layers][num_heads][g][128],
+ * d_out [n_layers][num_heads][g][pos_end-pos_begin]. */
+speckv_status_t speckv_ext_qk_scores_fp8_layers(speckv_handle_t handle, uint32_t layer_begin,
+                                                uint32_t n_layers, const void* d_q_f16, uint32_t g,
+                                                uint32_t pos_begin, uint32_t pos_end,
+                                                float* d_out, void* stream);
 
 /* ---- tier manager (CXLMemoryManager, cxl_memory_manager.h:40-90) ---------- */
 speckv_status_t speckv_ext_promote_to_l1(speckv_handle_t handle, uint64_t offset_bytes);

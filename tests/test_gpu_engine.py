@@ -368,3 +368,13 @@ def test_fp8_qk_scores_fused_mfma(eng, oracle):
     assert err.max() <= 0.08 * np.abs(ref).max() + 0.5
     with pytest.raises(SpeckvError):
         lib.qk_scores_fp8(h, 0, d_q.data_ptr(), G, 1, 5, d_out.data_ptr())     # odd positions -> INVAL
+    # several layers in one launch == the per-layer calls
+    ql = rng.standard_normal((L, H, G, D)).astype(np.float16)
+    d_ql = torch.from_numpy(ql.view(np.int16)).cuda()
+    multi = torch.empty((L, H, G, T), dtype=torch.float32, device="cuda")
+    lib.qk_scores_fp8_layers(h, 0, L, d_ql.data_ptr(), G, 0, T, multi.data_ptr())
+    single = torch.empty((H, G, T), dtype=torch.float32, device="cuda")
+    for layer in range(L):
+        lib.qk_scores_fp8(h, layer, d_ql[layer].data_ptr(), G, 0, T, single.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(multi[layer], single)
