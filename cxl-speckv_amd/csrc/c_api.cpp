@@ -321,6 +321,12 @@ speckv_status_t speckv_ext_demote_to_l3(speckv_handle_t handle, uint64_t offset_
     return guarded([&] { return g_engine->demote_to_l3(handle, offset_bytes); });
 }
 
+speckv_status_t speckv_ext_migrate(speckv_handle_t handle, uint64_t first_page, uint64_t n_pages, uint32_t target_pool)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->migrate(handle, first_page, n_pages, target_pool); });
+}
+
 speckv_status_t speckv_ext_stats(speckv_ext_stats_t* out)
 {
     LOCK;

@@ -180,6 +180,7 @@ Engine::~Engine()
     if (d_count_) (void)hipFree(d_count_);
     if (cache_base_) (void)hipFree(cache_base_);
     pools_.clear();
+    if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     if (stream_) (void)hipStreamDestroy(stream_);
     (void)hipSetDevice(prev);
 }
@@ -275,6 +276,8 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
             }
             a->pool_of_residue.assign(D, 0);
             for (uint64_t k = 0; k < D; ++k) a->pool_of_residue[k] = use[k];
+            a->page_pool.resize(a->n_pages);
+            for (uint64_t i = 0; i < a->n_pages; ++i) a->page_pool[i] = static_cast<uint8_t>(use[i % D]);
             if (ok) ok = hipStreamSynchronize(stream_) == hipSuccess;
             (void)hipSetDevice(prev);
             if (!ok) {
@@ -426,17 +429,25 @@ int Engine::fetch_into_slots(Allocation* a, const std::vector<uint32_t>& pages,
     const uint32_t n = static_cast<uint32_t>(pages.size());
     if (n == 0) return SPECKV_OK;
     flush_mirror();
-    std::vector<uint64_t> dst(n);
-    for (uint32_t i = 0; i < n; ++i) dst[i] = reinterpret_cast<uint64_t>(slot_ptr(slots[i]));
-    uint32_t* d_pages = static_cast<uint32_t*>(scratch(s_pages_, n * sizeof(uint32_t)));
-    uint64_t* d_dst = static_cast<uint64_t*>(scratch(s_dst_, n * sizeof(uint64_t)));
-    if (!d_pages || !d_dst) return SPECKV_ERR_NOMEM;
-    HIP_TRY(hipMemcpyAsync(d_pages, pages.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
-    HIP_TRY(hipMemcpyAsync(d_dst, dst.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
+    bool run = true;                     // consecutive pages into consecutive slots: no descriptor upload
+    for (uint32_t i = 1; i < n && run; ++i) run = pages[i] == pages[0] + i && slots[i] == slots[0] + i;
     CodecArgs c{};
     c.entries = a->d_entries;
-    c.page_list = d_pages;
-    c.data_list = d_dst;
+    if (run) {
+        c.first = pages[0];
+        c.data = slot_ptr(slots[0]);
+        c.data_stride = kPageSize;
+    } else {
+        std::vector<uint64_t> dst(n);
+        for (uint32_t i = 0; i < n; ++i) dst[i] = reinterpret_cast<uint64_t>(slot_ptr(slots[i]));
+        uint32_t* d_pages = static_cast<uint32_t*>(scratch(s_pages_, n * sizeof(uint32_t)));
+        uint64_t* d_dst = static_cast<uint64_t*>(scratch(s_dst_, n * sizeof(uint64_t)));
+        if (!d_pages || !d_dst) return SPECKV_ERR_NOMEM;
+        HIP_TRY(hipMemcpyAsync(d_pages, pages.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipMemcpyAsync(d_dst, dst.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
+        c.page_list = d_pages;
+        c.data_list = d_dst;
+    }
     c.n = n;
     c.flags = a->d_flags;
     c.set_flags = 2u;
@@ -445,12 +456,16 @@ int Engine::fetch_into_slots(Allocation* a, const std::vector<uint32_t>& pages,
     HIP_TRY(launch_decompress(c, stream_));
     st_.dma_submitted += n;
     st_.total_decompressions += n;
-    hipEvent_t ev = get_event();
-    if (ev) { HIP_TRY(hipEventRecord(ev, stream_)); inflight_.push_back({ev, n}); }
-    if (wait || !ev) {
+    if (wait) {                          // sync_fetch_page: submit, then spin on completion
         HIP_TRY(hipStreamSynchronize(stream_));
         reap(true);
+        completed_unpolled_ += n;
+        st_.dma_completed += n;
+        return SPECKV_OK;
     }
+    hipEvent_t ev = get_event();
+    if (ev) { HIP_TRY(hipEventRecord(ev, stream_)); inflight_.push_back({ev, n}); }
+    else { HIP_TRY(hipStreamSynchronize(stream_)); completed_unpolled_ += n; st_.dma_completed += n; }
     return SPECKV_OK;
 }
 
@@ -741,7 +756,7 @@ int Engine::translate(uint64_t handle, uint64_t off, speckv_ext_page_info_t* o)
         PageEntry e{};
         HIP_TRY(hipMemcpy(&e, a->d_entries + p, sizeof(e), hipMemcpyDeviceToHost));
         (void)hipSetDevice(prev);
-        o->pool_device = pools_[a->pool_of_residue[p % a->pool_of_residue.size()]]->device();
+        o->pool_device = pools_[a->page_pool[p]]->device();
         o->rec_bytes = e.rec_bytes;
         o->scale = e.scale;
         o->pool_addr = e.pool_addr;
@@ -973,6 +988,64 @@ int Engine::qk_scores_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, co
     HIP_TRY(launch_qk_scores_fp8(a->d_entries, first_page, layer_stride, n_layers, n_pages, L.num_heads, g, q8, qs, d_out, st));
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
     if (prev != device_) (void)hipSetDevice(prev);
+    return SPECKV_OK;
+}
+
+// Migration of pool records between pool GPUs (the data-moving counterpart of the
+// reference's tier flips, cxl_memory_manager.cpp:130-194, which move nothing):
+// hipMemcpyPeerAsync on a dedicated copy stream, one copy per contiguous source run,
+// then the device page table is re-pointed and the old slots return to their slab.
+int Engine::migrate(uint64_t handle, uint64_t first, uint64_t n, uint32_t target_pool)
+{
+    if (null_) return no_data_path("speckv_ext_migrate");
+    Allocation* a = find(handle);
+    if (!a) return SPECKV_ERR_GENERAL;
+    if (first > a->n_pages || n > a->n_pages - first) return SPECKV_ERR_GENERAL;
+    if (target_pool >= pools_.size()) return SPECKV_ERR_INVAL;
+    if (n == 0) return SPECKV_OK;
+    int prev = 0; (void)hipGetDevice(&prev); HIP_TRY(hipSetDevice(device_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    reap(true);
+    if (!copy_stream_) HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    const size_t stride = a->rec_stride;
+    uint8_t* dst = static_cast<uint8_t*>(pools_[target_pool]->alloc(n * stride));
+    if (!dst) { (void)hipSetDevice(prev); return SPECKV_ERR_NOMEM; }
+    std::vector<PageEntry> cur(n);
+    HIP_TRY(hipMemcpy(cur.data(), a->d_entries + first, n * sizeof(PageEntry), hipMemcpyDeviceToHost));
+    const int dst_dev = pools_[target_pool]->device();
+    struct Run { uint64_t addr; size_t bytes; int pool; };
+    std::vector<Run> old;
+    for (uint64_t i = 0; i < n;) {
+        uint64_t j = i + 1;
+        while (j < n && cur[j].pool_addr == cur[j - 1].pool_addr + stride && a->page_pool[first + j] == a->page_pool[first + i]) ++j;
+        const int src_pool = a->page_pool[first + i];
+        const size_t bytes = (j - i) * stride;
+        HIP_TRY(hipMemcpyPeerAsync(dst + i * stride, dst_dev, reinterpret_cast<const void*>(cur[i].pool_addr),
+                                   pools_[src_pool]->device(), bytes, copy_stream_));
+        old.push_back({cur[i].pool_addr, bytes, src_pool});
+        i = j;
+    }
+    HIP_TRY(hipStreamSynchronize(copy_stream_));
+    HIP_TRY(launch_retarget_entries(a->d_entries + first, n, reinterpret_cast<uint64_t>(dst), stride, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    // bookkeeping: the old runs leave the allocation's extent list (split where needed)
+    for (const Run& r : old) {
+        std::vector<Allocation::Extent> next;
+        for (const auto& ex : a->extents) {
+            const uint64_t lo = reinterpret_cast<uint64_t>(ex.base), hi = lo + ex.bytes;
+            if (ex.pool != r.pool || r.addr >= hi || r.addr + r.bytes <= lo) { next.push_back(ex); continue; }
+            if (r.addr > lo) next.push_back({ex.pool, ex.base, static_cast<size_t>(r.addr - lo), (r.addr - lo) / stride});
+            if (r.addr + r.bytes < hi)
+                next.push_back({ex.pool, reinterpret_cast<void*>(r.addr + r.bytes), static_cast<size_t>(hi - r.addr - r.bytes),
+                                (hi - r.addr - r.bytes) / stride});
+        }
+        a->extents.swap(next);
+        pools_[r.pool]->free(reinterpret_cast<void*>(r.addr), r.bytes);
+    }
+    a->extents.push_back({static_cast<int>(target_pool), dst, n * stride, n});
+    for (uint64_t i = 0; i < n; ++i) a->page_pool[first + i] = static_cast<uint8_t>(target_pool);
+    st_.pool_migrated_pages += n;
+    (void)hipSetDevice(prev);
     return SPECKV_OK;
 }
 

@@ -58,7 +58,8 @@ struct Allocation {
     // HIP mode
     struct Extent { int pool; void* base; size_t bytes; uint64_t n_pages; };
     std::vector<Extent> extents;
-    std::vector<int> pool_of_residue;     // pool index serving pages with page % D == k
+    std::vector<int> pool_of_residue;     // pool index serving pages with page % D == k (at allocation)
+    std::vector<uint8_t> page_pool;       // pool index holding each page's record now
     PageEntry* d_entries = nullptr;
     uint32_t* d_flags = nullptr;
     bool has_layout = false;
@@ -100,6 +101,7 @@ public:
                uint32_t* was_hit, uint32_t* new_depth);
     int qk_scores_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
                       uint32_t pos_begin, uint32_t pos_end, float* d_out, hipStream_t s);
+    int migrate(uint64_t handle, uint64_t first_page, uint64_t n_pages, uint32_t target_pool);
     int poll_complete(uint32_t* done);
     int sync();
     int promote_to_l1(uint64_t handle, uint64_t off);
@@ -114,6 +116,7 @@ private:
     bool null_ = false;
     int device_ = 0;
     hipStream_t stream_ = nullptr;         // fetch / codec side stream
+    hipStream_t copy_stream_ = nullptr;    // peer copies (pool <-> pool migration)
     std::vector<std::unique_ptr<SlabPool>> pools_;
 
     std::unordered_map<uint64_t, std::unique_ptr<Allocation>> allocs_;

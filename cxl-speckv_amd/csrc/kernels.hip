@@ -1101,6 +1101,12 @@ __global__ void k_debug_dpp(const uint32_t* in, uint32_t* out)
     out[4 * 64 + lane] = (w - prev) & 0xFFu;
 }
 
+__global__ void k_retarget_entries(PageEntry* e, uint64_t n, uint64_t base, uint64_t stride)
+{
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) e[i].pool_addr = base + i * stride;
+}
+
 int g_cus = 0;
 int num_cus()
 {
@@ -1235,6 +1241,14 @@ hipError_t launch_qk_scores_fp8(const PageEntry* d_entries, uint64_t first_page,
     const uint32_t waves = (n_pages + 7u) / 8u;
     hipLaunchKernelGGL(k_qk_scores_fp8, dim3((waves + 1u) / 2u, n_layers), dim3(128), 0, s, d_entries, first_page,
                        layer_page_stride, n_pages, heads, g, d_q8, d_qs, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t base, uint64_t stride, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_retarget_entries, dim3(static_cast<uint32_t>((n + 255u) / 256u)), dim3(256), 0, s,
+                       d_entries, n, base, stride);
     return hipGetLastError();
 }
 

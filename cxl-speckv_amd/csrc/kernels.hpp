@@ -92,6 +92,9 @@ hipError_t launch_qk_scores_fp8(const PageEntry* d_entries, uint64_t first_page,
                                 uint32_t n_layers, uint32_t n_pages, uint32_t heads, uint32_t g,
                                 const uint8_t* d_q8, const float* d_qs, float* d_out, hipStream_t s);
 
+// entries[i].pool_addr = base + i*stride (record bytes / scale untouched): after a migration
+hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t base, uint64_t stride, hipStream_t s);
+
 // wave-primitive self test: in[64] -> out[5*64]
 hipError_t launch_debug_dpp(const uint32_t* d_in, uint32_t* d_out, hipStream_t s);
 

@@ -38,7 +38,8 @@ class Stats(ctypes.Structure):
         "total_compressions", "total_decompressions", "compressed_bytes", "original_bytes",
         "total_allocations", "total_deallocations", "current_allocated_bytes", "peak_allocated_bytes",
         "dma_submitted", "dma_completed", "pool_bytes_reserved", "cache_bytes_reserved")] + \
-        [(n, c_uint32) for n in ("prefetch_depth", "compression_scheme", "quant_mode", "n_pool_devices")]
+        [(n, c_uint32) for n in ("prefetch_depth", "compression_scheme", "quant_mode", "n_pool_devices")] + \
+        [("pool_migrated_pages", c_uint64)]
 
 
 _u32p = ctypes.POINTER(c_uint32)
@@ -69,6 +70,7 @@ _EXT_SIGNATURES = {
     "speckv_ext_qk_scores_fp8_layers": [c_uint64, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_void_p],
     "speckv_ext_promote_to_l1": [c_uint64, c_uint64],
     "speckv_ext_demote_to_l3": [c_uint64, c_uint64],
+    "speckv_ext_migrate": [c_uint64, c_uint64, c_uint64, c_uint32],
     "speckv_ext_stats": [ctypes.POINTER(Stats)],
 }
 
@@ -253,6 +255,9 @@ class SpeckvLib:
 
     def demote_to_l3(self, handle, offset):
         return self.lib.speckv_ext_demote_to_l3(handle, offset) == 0
+
+    def migrate(self, handle, first_page, n_pages, target_pool):
+        self._ext("speckv_ext_migrate", handle, first_page, n_pages, target_pool)
 
     def stats(self):
         s = Stats()

@@ -173,6 +173,12 @@ speckv_status_t speckv_ext_qk_scores_fp8_layers(speckv_handle_t handle, uint32_t
 /* ---- tier manager (CXLMemoryManager, cxl_memory_manager.h:40-90) ---------- */
 speckv_status_t speckv_ext_promote_to_l1(speckv_handle_t handle, uint64_t offset_bytes);
 speckv_status_t speckv_ext_demote_to_l3(speckv_handle_t handle, uint64_t offset_bytes);
+/* Move the pool records of pages [first_page, first_page+n) to pool GPU
+ * `target_pool` (index into SPECKV_POOL_DEVICES order): hipMemcpyPeerAsync over
+ * xGMI on a side stream, page table re-pointed, old slots freed.  The reference's
+ * promote/demote only flip a tier tag (cxl_memory_manager.cpp:130-194). */
+speckv_status_t speckv_ext_migrate(speckv_handle_t handle, uint64_t first_page,
+                                   uint64_t n_pages, uint32_t target_pool);
 
 /* ---- statistics (Statistics structs: cxl_memory_manager.h:73-83,
  *      speculative_prefetcher.h:59-66, cache_engine.h:65-72, memory_allocator.h:42-48) */
@@ -187,6 +193,7 @@ typedef struct {
     uint64_t dma_submitted, dma_completed;
     uint64_t pool_bytes_reserved, cache_bytes_reserved;
     uint32_t prefetch_depth, compression_scheme, quant_mode, n_pool_devices;
+    uint64_t pool_migrated_pages;
 } speckv_ext_stats_t;
 speckv_status_t speckv_ext_stats(speckv_ext_stats_t* out);
 

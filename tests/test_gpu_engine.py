@@ -378,3 +378,42 @@ def test_fp8_qk_scores_fused_mfma(eng, oracle):
         lib.qk_scores_fp8(h, layer, d_ql[layer].data_ptr(), G, 0, T, single.data_ptr())
         torch.cuda.synchronize()
         assert torch.equal(multi[layer], single)
+
+
+def test_migrate_records_between_pool_slabs(oracle):
+    """speckv_ext_migrate: hipMemcpyPeerAsync of record runs + page-table re-point
+    (one GPU here, so source and target pool are the same device; the copy path,
+    the extent bookkeeping and the retarget kernel are the same as across xGMI)."""
+    os.environ["SPECKV_SLAB_MB"] = "8"
+    try:
+        lib = pkg.SpeckvLib(pkg.library_path(), "hip:0")
+    finally:
+        del os.environ["SPECKV_SLAB_MB"]
+    try:
+        lib.set_compression_scheme(2)
+        h = lib.alloc(1024 * PAGE)
+        x = synth(1024, seed=12)
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+        before = np.empty_like(x); lib.read(h, 0, before.ctypes.data, before.nbytes, False)
+        addr0 = [lib.translate(h, p * PAGE).pool_addr for p in (0, 99, 100, 355, 356, 1023)]
+        info0 = [(lib.translate(h, p * PAGE).rec_bytes, lib.translate(h, p * PAGE).scale) for p in (100, 200, 355)]
+        reserved = lib.stats().pool_bytes_reserved
+        lib.migrate(h, 100, 256, 0)
+        addr1 = [lib.translate(h, p * PAGE).pool_addr for p in (0, 99, 100, 355, 356, 1023)]
+        assert addr1[0] == addr0[0] and addr1[1] == addr0[1] and addr1[4] == addr0[4] and addr1[5] == addr0[5]
+        assert addr1[2] != addr0[2] and addr1[3] == addr1[2] + 255 * PAGE          # one new contiguous run
+        assert [(lib.translate(h, p * PAGE).rec_bytes, lib.translate(h, p * PAGE).scale) for p in (100, 200, 355)] == info0
+        after = np.empty_like(x); lib.read(h, 0, after.ctypes.data, after.nbytes, False)
+        assert after.tobytes() == before.tobytes()
+        assert lib.stats().pool_migrated_pages == 256
+        # the vacated slots are reusable: a new allocation fits without growing the pool much
+        h2 = lib.alloc(256 * PAGE)
+        assert lib.stats().pool_bytes_reserved <= reserved + (8 << 20)
+        ptr = lib.access(h, 150 * PAGE, 64)                                       # tiers still work on migrated pages
+        assert dev_to_host(ptr, PAGE).tobytes() == before[150].tobytes()
+        lib.free(h); lib.free(h2)
+        with pytest.raises(SpeckvError) as ei:
+            lib.migrate(h, 0, 1, 0)
+        assert ei.value.status == -1
+    finally:
+        lib.finalize()
