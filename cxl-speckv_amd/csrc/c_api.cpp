@@ -348,6 +348,27 @@ speckv_status_t speckv_debug_wave_primitives(const uint32_t* d_in, uint32_t* d_o
     return speckv::launch_debug_dpp(d_in, d_out, static_cast<hipStream_t>(stream)) == hipSuccess ? SPECKV_OK : SPECKV_ERR_DRIVER;
 }
 
+double speckv_ext_codec_model_throughput_gbps(uint32_t num_engines, double clock_mhz, uint32_t data_width_bits)
+{   // cache_engine.cpp:291-296
+    return (static_cast<double>(data_width_bits) / 8.0) * (clock_mhz / 1000.0) * static_cast<double>(num_engines);
+}
+
+uint64_t speckv_ext_encode_virt_page(uint32_t req_id, uint16_t layer, uint16_t head, uint32_t pos, uint8_t kind)
+{   // speckv_allocator.cpp:92-103
+    return (static_cast<uint64_t>(req_id) << 32) | (static_cast<uint64_t>(layer) << 16) |
+           (static_cast<uint64_t>(head) << 8) | (static_cast<uint64_t>(pos) << 1) | static_cast<uint64_t>(kind);
+}
+
+uint64_t speckv_ext_rtl_prefetch_vaddr(uint32_t req_id, uint16_t layer, uint32_t pos)
+{   // prefetch_core.v:92-98: {req[31:0], layer[15:0], 8'd0, pos[31:0], 1'b0} truncated to 64 bits
+    return (static_cast<uint64_t>(pos) << 1) | (static_cast<uint64_t>(layer) << 41) | (static_cast<uint64_t>(req_id) << 57);
+}
+
+uint64_t speckv_ext_atu_translate(uint64_t virtual_addr)
+{   // cache_engine.cpp:131-132
+    return 0x4000000000ULL + (virtual_addr & 0xFFFFFFFFFFFFULL);
+}
+
 const char* speckv_ext_backend(void) { return "hip"; }
 
 } // extern "C"

@@ -197,9 +197,22 @@ typedef struct {
 } speckv_ext_stats_t;
 speckv_status_t speckv_ext_stats(speckv_ext_stats_t* out);
 
+/* ---- address encodings of the reference, pure functions ----
+ * speckv_ext_encode_virt_page : SpeckvAllocator::encode_virt_page, speckv_allocator.cpp:92-103
+ *                               (req<<32)|(layer<<16)|(head<<8)|(pos<<1)|kind  (fields overlap, as there)
+ * speckv_ext_rtl_prefetch_vaddr: prefetch_core.v:92-98,158  low 64 bits of {req,layer,8'd0,pos,1'b0}
+ * speckv_ext_atu_translate    : ATU/TLB miss mapping, cache_engine.cpp:131-132, address_translation.cpp:85-90:
+ *                               0x4000000000 + (va & 0xFFFFFFFFFFFF)  (the engine itself translates through
+ *                               the HBM page table; this is kept for parity of logical ids only) */
+uint64_t speckv_ext_encode_virt_page(uint32_t req_id, uint16_t layer, uint16_t head, uint32_t pos, uint8_t kind);
+uint64_t speckv_ext_rtl_prefetch_vaddr(uint32_t req_id, uint16_t layer, uint32_t pos);
+uint64_t speckv_ext_atu_translate(uint64_t virtual_addr);
+
 /* hard-coded per-layer ratio table and analytic throughput of the reference
  * (cache_engine.cpp:25-33,142-148,286-296) */
 double speckv_ext_layer_compression_ratio(uint32_t layer_id);
+/* width/8 * MHz/1000 * engines (cache_engine.cpp:291-296): 51.2 for the reference's defaults */
+double speckv_ext_codec_model_throughput_gbps(uint32_t num_engines, double clock_mhz, uint32_t data_width_bits);
 
 /* library identity: "hip" when built with the HIP data path */
 const char* speckv_ext_backend(void);

@@ -247,3 +247,33 @@ def test_div127_identity():
     e = (-127.0 * r0.astype(np.float64) + q.astype(np.float64)).astype(f32)       # exact fma, one rounding
     r1 = (e.astype(np.float64) * np.float64(rcp) + r0.astype(np.float64)).astype(f32)
     assert np.array_equal(r1, (q / f32(127.0)).astype(f32))
+
+
+def test_address_encodings(libpath, oracle, reference=None):
+    """the reference's address encodings as pure functions,
+    against the oracle (itself pinned to the reference's TLB in test_oracle_vs_ref)."""
+    import numpy as np
+    lib = pkg.load_library(libpath)
+    for f, args in (("speckv_ext_encode_virt_page", [C.c_uint32, C.c_uint16, C.c_uint16, C.c_uint32, C.c_uint8]),
+                    ("speckv_ext_rtl_prefetch_vaddr", [C.c_uint32, C.c_uint16, C.c_uint32]),
+                    ("speckv_ext_atu_translate", [C.c_uint64])):
+        getattr(lib, f).restype = C.c_uint64
+        getattr(lib, f).argtypes = args
+    lib.speckv_ext_codec_model_throughput_gbps.restype = C.c_double
+    lib.speckv_ext_codec_model_throughput_gbps.argtypes = [C.c_uint32, C.c_double, C.c_uint32]
+    O = oracle.lib
+    rng = np.random.default_rng(1)
+    for _ in range(500):
+        req, layer, head, pos, kind = (int(rng.integers(0, 2**32)), int(rng.integers(0, 2**16)), int(rng.integers(0, 2**16)),
+                                       int(rng.integers(0, 2**32)), int(rng.integers(0, 2)))
+        assert lib.speckv_ext_encode_virt_page(req, layer, head, pos, kind) == O.orc_encode_virt_page(req, layer, head, pos, kind)
+        assert lib.speckv_ext_rtl_prefetch_vaddr(req, layer, pos) == O.orc_rtl_prefetch_vaddr(req, layer, pos)
+    # known answers: encode (1,2,3,4,1) and the survey's ATU example 0x123456789 -> 0x4123456789
+    assert lib.speckv_ext_encode_virt_page(1, 2, 3, 4, 1) == (1 << 32) | (2 << 16) | (3 << 8) | (4 << 1) | 1
+    assert lib.speckv_ext_rtl_prefetch_vaddr(0, 5, 101) == (101 << 1) | (5 << 41)
+    assert lib.speckv_ext_atu_translate(0x123456789) == 0x4123456789
+    tlb = O.orc_tlb_new(1024)
+    for va in [int(v) for v in rng.integers(0, 2**63, 200, dtype=np.uint64)]:
+        assert lib.speckv_ext_atu_translate(va) == O.orc_tlb_translate(tlb, va, None)     # every first touch is a miss
+    O.orc_tlb_delete(tlb)
+    assert lib.speckv_ext_codec_model_throughput_gbps(1, 800.0, 512) == O.orc_codec_throughput_gbps(1, 800.0, 512) == 51.2
