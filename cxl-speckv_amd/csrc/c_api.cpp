@@ -342,6 +342,12 @@ double speckv_ext_layer_compression_ratio(uint32_t layer_id)
     return 3.2;
 }
 
+// not part of the public headers: exhaustive exactness check of the codec's fast divide
+speckv_status_t speckv_debug_divcheck(float den, unsigned long long* d_counters, void* stream)
+{
+    return speckv::launch_debug_divcheck(den, d_counters, static_cast<hipStream_t>(stream)) == hipSuccess ? SPECKV_OK : SPECKV_ERR_DRIVER;
+}
+
 // not part of the public headers: hardware self-test of the DPP scans
 speckv_status_t speckv_debug_wave_primitives(const uint32_t* d_in, uint32_t* d_out, void* stream)
 {

@@ -109,6 +109,19 @@ __device__ __forceinline__ float dequant(int q, float scale)
     if (MODE == kRefExact) return div127(fq) * scale;   // cache_engine.cpp:279-280
     return fq * scale;
 }
+// x / s for many x and one s: r = 1/s (one correctly rounded divide per block),
+// q0 = x*r, e = fma(-q0, s, x) (exact residual), q = fma(e, r, q0).  For the operands
+// this codec sees (x any finite fp16 value, s = fl(m/127) or fl(m/448), m a positive
+// finite fp16 value) q equals the correctly rounded x/s bit for bit: checked
+// EXHAUSTIVELY on the device (2^16 x 31743 pairs per divisor family) by
+// tests/test_gpu_codec.py::test_fast_division_is_exact via k_debug_divcheck.
+__device__ __forceinline__ float div_by_scale(float x, float s, float r)
+{
+    const float q0 = x * r;
+    const float e = __builtin_fmaf(-q0, s, x);
+    return __builtin_fmaf(e, r, q0);
+}
+
 // cache_engine.cpp:190-192 on x86-64: cvttss2si + byte truncation
 template <int MODE>
 __device__ __forceinline__ uint32_t quantize(float x, float scale)
@@ -129,6 +142,27 @@ __device__ __forceinline__ uint32_t quantize(float x, float scale)
 // second.  Without the empty asm hipcc selects v_fma_mixlo_f16 for
 // "(half)(x * scale)", which rounds the exact product once and differs from the
 // reference in ~1e-5 of the elements (caught by test_many_random_blocks).
+// the same byte as quantize<MODE> for a finite x of a finite block: the divide goes
+// through the block's reciprocal (div_by_scale) and the out-of-range test is not needed
+template <int MODE>
+__device__ __forceinline__ uint32_t quantize_finite(float x, float scale, float rcp)
+{
+    const float scaled = div_by_scale(x, scale, rcp);
+    if (MODE == kRefExact) {
+        return static_cast<uint32_t>(static_cast<int>(roundf(scaled * 127.0f))) & 0xFFu;
+    } else {
+        const float r = fminf(fmaxf(roundf(scaled), -127.0f), 127.0f);
+        return static_cast<uint32_t>(static_cast<int>(r)) & 0xFFu;
+    }
+}
+// max|x| of a block plus "every element is finite" in one pass: fmaxf ignores NaN like
+// the reference's '>' compare (cache_engine.cpp:176-180); x*0 accumulates a NaN for inf/NaN
+__device__ __forceinline__ void absmax_finite(float x, float& mx, float& nanacc)
+{
+    mx = __builtin_fmaxf(mx, fabsf(x));
+    nanacc = __builtin_fmaf(x, 0.0f, nanacc);
+}
+
 __device__ __forceinline__ uint32_t pack_half2(float a, float b)
 {
     asm volatile("" : "+v"(a), "+v"(b));
@@ -631,12 +665,13 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                 const uint32_t words[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
                 float xv[8];
                 float mx = 0.0f;
+                float nanacc = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     xv[k] = half_bits_to_float((words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
-                    const float ax = fabsf(xv[k]);
-                    mx = (ax > mx) ? ax : mx;
+                    absmax_finite(xv[k], mx, nanacc);
                 }
+                const bool finite = __ballot(!(nanacc == 0.0f)) == 0ull;   // wave-uniform
                 float o = __shfl_xor(mx, 1); mx = (o > mx) ? o : mx;
                 o = __shfl_xor(mx, 2);       mx = (o > mx) ? o : mx;
                 float sdiv = mx / 7.0f;
@@ -644,15 +679,27 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                 const _Float16 s16 = static_cast<_Float16>(sdiv);
                 const float sc = static_cast<float>(s16);
                 uint32_t nib = 0;
+                if (finite) {
+                    // |x| <= 7.5*sc in a finite group: the reciprocal divide is exact (test_fast_division_is_exact)
+                    const bool nz = sc != 0.0f;
+                    const float rcp = nz ? 1.0f / sc : 0.0f;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    float r = 0.0f;
-                    if (sc != 0.0f && sc == sc) {
-                        r = roundf(xv[k] / sc);
-                        if (!(r == r)) r = 0.0f;
+                    for (int k = 0; k < 8; ++k) {
+                        float r = nz ? roundf(div_by_scale(xv[k], sc, rcp)) : 0.0f;
                         r = fminf(fmaxf(r, -7.0f), 7.0f);
+                        nib |= (static_cast<uint32_t>(static_cast<int>(r)) & 0xFu) << (4 * k);
                     }
-                    nib |= (static_cast<uint32_t>(static_cast<int>(r)) & 0xFu) << (4 * k);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float r = 0.0f;
+                        if (sc != 0.0f && sc == sc) {
+                            r = roundf(xv[k] / sc);
+                            if (!(r == r)) r = 0.0f;
+                            r = fminf(fmaxf(r, -7.0f), 7.0f);
+                        }
+                        nib |= (static_cast<uint32_t>(static_cast<int>(r)) & 0xFu) << (4 * k);
+                    }
                 }
                 const uint32_t p0 = 512u * j + 8u * lane;
                 *reinterpret_cast<uint32_t*>(rec + 128u + (p0 >> 1)) = nib;
@@ -662,15 +709,14 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
             out_len = kInt4RecBytes;
         } else if (SCHEME == kFp8E4m3) {
             float x[4][8];
-            float mx = 0.0f;
+            float mx = 0.0f, nanacc = 0.0f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t words[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     x[j][k] = half_bits_to_float((words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
-                    const float ax = fabsf(x[j][k]);
-                    mx = (ax > mx) ? ax : mx;
+                    absmax_finite(x[j][k], mx, nanacc);
                 }
             }
 #pragma unroll
@@ -679,11 +725,19 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                 mx = (other > mx) ? other : mx;
             }
             scale = (mx > 0.0f) ? (mx / 448.0f) : 1.0f;
+            const bool finite = __ballot(!(nanacc == 0.0f)) == 0ull;       // wave-uniform
+            const float rcp = 1.0f / scale;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v[8];
+                if (finite) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = fminf(fmaxf(x[j][k] / scale, -448.0f), 448.0f);
+                    for (int k = 0; k < 8; ++k)
+                        v[k] = fminf(fmaxf(__builtin_copysignf(div_by_scale(x[j][k], scale, rcp), x[j][k]), -448.0f), 448.0f);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = fminf(fmaxf(x[j][k] / scale, -448.0f), 448.0f);
+                }
                 int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
                 lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
                 int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
@@ -694,15 +748,14 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
             out_len = kBlockElems;
         } else {
             float x[4][8];
-            float mx = 0.0f;
+            float mx = 0.0f, nanacc = 0.0f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t words[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     x[j][k] = half_bits_to_float((words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
-                    const float ax = fabsf(x[j][k]);
-                    mx = (ax > mx) ? ax : mx;          // NaN never wins (cache_engine.cpp:176-180)
+                    absmax_finite(x[j][k], mx, nanacc);        // NaN never wins (cache_engine.cpp:176-180)
                 }
             }
 #pragma unroll
@@ -711,12 +764,21 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                 mx = (other > mx) ? other : mx;
             }
             scale = (mx > 0.0f) ? (mx / 127.0f) : 1.0f;
+            const bool finite = __ballot(!(nanacc == 0.0f)) == 0ull;       // wave-uniform
 
             uint32_t q[4][8];
+            if (finite) {
+                const float rcp = 1.0f / scale;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) q[j][k] = quantize<MODE>(x[j][k], scale);
+                    for (int k = 0; k < 8; ++k) q[j][k] = quantize_finite<MODE>(x[j][k], scale, rcp);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) q[j][k] = quantize<MODE>(x[j][k], scale);
+            }
 
             if (SCHEME == kInt8) {
 #pragma unroll
@@ -1086,6 +1148,34 @@ __global__ __launch_bounds__(128) void k_qk_scores_fp8(const PageEntry* __restri
     }
 }
 
+// exhaustive check of div_by_scale: thread = one divisor (fp16 magnitude bits mbits in
+// [1, 0x7BFF] divided by `den`), loop over all 65536 fp16 dividends; counts mismatches
+// against the IEEE divide, and (second counter) mismatches of the REF_EXACT byte
+// (roundf(x/s*127) & 0xFF) which is what the codec finally stores.
+__global__ void k_debug_divcheck(float den, unsigned long long* counters)
+{
+    const uint32_t mbits = blockIdx.x * blockDim.x + threadIdx.x + 1u;
+    if (mbits > 0x7BFFu) return;
+    const float m = half_bits_to_float(mbits);
+    // den > 0: s = m/den and |x| <= m (INT8 family: den 127, FP8: den 448).
+    // den == 0: INT4 family: s = m is itself an fp16 value (the stored group scale) and |x| <= 7.5 m.
+    const float s = den > 0.0f ? m / den : m;
+    const float lim = den > 0.0f ? m : 7.5f * m;
+    const float mul = den == 127.0f ? 127.0f : 1.0f;
+    const float r = 1.0f / s;
+    unsigned long long bad = 0, badq = 0;
+    for (uint32_t xb = 0; xb < 65536u; ++xb) {
+        if ((xb & 0x7C00u) == 0x7C00u) continue;                 // inf / nan dividends take the slow path
+        const float x = half_bits_to_float(xb);
+        if (fabsf(x) > lim) continue;                            // the block / group maximum bounds every |x|
+        const float a = x / s, b = div_by_scale(x, s, r);
+        bad += (__float_as_uint(a) != __float_as_uint(__builtin_copysignf(b, x))) ? 1ull : 0ull;
+        badq += (static_cast<int>(roundf(a * mul)) != static_cast<int>(roundf(b * mul))) ? 1ull : 0ull;
+    }
+    if (bad) atomicAdd(&counters[0], bad);
+    if (badq) atomicAdd(&counters[1], badq);
+}
+
 // self-test of the wave primitives (tests/test_gpu_codec.py::test_wave_primitives)
 __global__ void k_debug_dpp(const uint32_t* in, uint32_t* out)
 {
@@ -1249,6 +1339,12 @@ hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t ba
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_retarget_entries, dim3(static_cast<uint32_t>((n + 255u) / 256u)), dim3(256), 0, s,
                        d_entries, n, base, stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_debug_divcheck(float den, unsigned long long* d_counters, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_debug_divcheck, dim3((0x7BFFu + 255u) / 256u), dim3(256), 0, s, den, d_counters);
     return hipGetLastError();
 }
 

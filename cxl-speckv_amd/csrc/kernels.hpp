@@ -95,6 +95,9 @@ hipError_t launch_qk_scores_fp8(const PageEntry* d_entries, uint64_t first_page,
 // entries[i].pool_addr = base + i*stride (record bytes / scale untouched): after a migration
 hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t base, uint64_t stride, hipStream_t s);
 
+// exhaustive exactness check of the reciprocal-based divide (counters[0] quotient bits, [1] stored byte)
+hipError_t launch_debug_divcheck(float den, unsigned long long* d_counters, hipStream_t s);
+
 // wave-primitive self test: in[64] -> out[5*64]
 hipError_t launch_debug_dpp(const uint32_t* d_in, uint32_t* d_out, hipStream_t s);
 

@@ -253,3 +253,39 @@ def test_full_size_roundtrip_properties(lib):
             sample = recs[:64].cpu().numpy()
             for b in range(64):
                 assert int(sample[b, 1:l[b]:2].astype(np.int64).sum()) == N
+
+
+def test_fast_division_is_exact(lib):
+    """The compressor divides by the block scale through one reciprocal per block
+    (kernels.hip: div_by_scale).  Exhaustive device check: every finite fp16
+    dividend against every divisor the codec can form (m/127, m/448, and fp16 group
+    scales) gives the same quotient bits as the IEEE divide (and the same stored byte)."""
+    import ctypes as C
+    import torch
+    lib.speckv_debug_divcheck.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+    for den in (127.0, 448.0, 0.0):
+        cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
+        assert lib.speckv_debug_divcheck(den, cnt.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        assert cnt.tolist() == [0, 0], (den, cnt.tolist())
+
+
+def test_wave_primitives(lib):
+    """DPP scans / shifts on the hardware (the folded wave_shr form once miscompiled)."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(0)
+    for trial in range(4):
+        v = rng.integers(0, 1000, 64).astype(np.uint32) if trial else np.arange(64, dtype=np.uint32) + 100
+        d_in = torch.from_numpy(v.view(np.int32)).cuda()
+        d_out = torch.zeros(5 * 64, dtype=torch.int32, device="cuda")
+        assert lib.speckv_debug_wave_primitives(C.c_void_p(d_in.data_ptr()), C.c_void_p(d_out.data_ptr()), None) == 0
+        torch.cuda.synchronize()
+        o = d_out.cpu().numpy().view(np.uint32).reshape(5, 64)
+        assert np.array_equal(o[0], np.concatenate([[0xABCD], v[:-1]]))
+        assert np.array_equal(o[1], np.cumsum(v).astype(np.uint32))
+        assert np.array_equal(o[2], np.maximum.accumulate(v))
+        assert (o[3] == v[63]).all()
+        w = ((v.astype(np.uint64) * 2654435761) & 0xFFFFFFFF) >> 24
+        prev = np.concatenate([[7], w[:-1]]).astype(np.int64)
+        assert np.array_equal(o[4], ((w.astype(np.int64) - prev) & 0xFF).astype(np.uint32))
