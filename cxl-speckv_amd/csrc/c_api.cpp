@@ -195,7 +195,7 @@ speckv_status_t speckv_ext_verify(uint32_t req_id, int32_t actual_token, const i
                                   uint32_t n_predicted, uint32_t* was_hit, uint32_t* new_depth)
 {
     LOCK;
-    if (!g_engine || (n_predicted && !predicted)) return SPECKV_ERR_INVAL;
+    if (!g_engine) return SPECKV_ERR_INVAL;
     return guarded([&] { return g_engine->verify(req_id, actual_token, predicted, n_predicted, was_hit, new_depth); });
 }
 
@@ -319,6 +319,19 @@ speckv_status_t speckv_ext_demote_to_l3(speckv_handle_t handle, uint64_t offset_
 {
     LOCK; NEED_INIT;
     return guarded([&] { return g_engine->demote_to_l3(handle, offset_bytes); });
+}
+
+speckv_status_t speckv_ext_predictor_load(const float* embedding, const float* out_weights, uint32_t vocab, int on_device)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->predictor_load(embedding, out_weights, vocab, on_device != 0); });
+}
+
+speckv_status_t speckv_ext_predict_batch(uint32_t n, const int32_t* d_histories, uint32_t k, int32_t* d_tokens,
+                                         float* d_conf, void* stream)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->predict_batch(n, d_histories, k, d_tokens, d_conf, static_cast<hipStream_t>(stream)); });
 }
 
 speckv_status_t speckv_ext_migrate(speckv_handle_t handle, uint64_t first_page, uint64_t n_pages, uint32_t target_pool)

@@ -175,7 +175,9 @@ Engine::~Engine()
     for (auto ev : event_pool_) (void)hipEventDestroy(ev);
     for (auto& kv : allocs_) release_allocation(kv.second.get());
     allocs_.clear();
-    for (Scratch* s : {&s_pages_, &s_dst_, &s_req_, &s_out_, &s_tmp_, &s_stage_})
+    if (d_emb_) (void)hipFree(d_emb_);
+    if (d_wout_) (void)hipFree(d_wout_);
+    for (Scratch* s : {&s_pages_, &s_dst_, &s_req_, &s_out_, &s_tmp_, &s_stage_, &s_hid_, &s_logits_, &s_hist_, &s_pred_})
         if (s->p) (void)hipFree(s->p);
     if (d_count_) (void)hipFree(d_count_);
     if (cache_base_) (void)hipFree(cache_base_);
@@ -587,8 +589,16 @@ int Engine::access_batch(uint64_t handle, const uint64_t* offs, uint32_t n, void
 int Engine::prefetch(uint32_t req, uint16_t layer, uint32_t pos, uint32_t k,
                      const int32_t* tokens, uint32_t hist)
 {
-    (void)tokens; (void)hist;   // the history feeds the token predictor, not the addressing
     if (null_) return SPECKV_OK;                            // submit_prefetch result ignored, speckv_allocator.cpp:89
+    // the history feeds the token predictor (it never influences the addressing,
+    // speculative_prefetcher.cpp:48): last 16 tokens, zero-padded at the front (lstm_predictor.cpp:44-51)
+    if (d_emb_ && tokens && hist) {
+        std::vector<int32_t> h(16, 0);
+        const uint32_t take = hist < 16 ? hist : 16;
+        for (uint32_t i = 0; i < take; ++i) h[16 - take + i] = tokens[hist - take + i];
+        auto it = hist_.find(req);
+        if (it == hist_.end() || it->second != h) { hist_[req] = h; hist_dirty_.push_back(req); }
+    }
     queue_.push_back({req, layer, pos, k ? k : adapt_.depth()});
     uint32_t thr = flush_threshold_;
     if (thr == 0) {
@@ -668,8 +678,76 @@ int Engine::prefetch_flush(uint32_t* n_issued)
             if (n_issued) *n_issued = m;
         }
     }
+    if (rc == SPECKV_OK) rc = run_predictor_for_dirty();
     (void)hipSetDevice(prev);
     return rc;
+}
+
+// ----------------------------------------------------------------- predictor
+int Engine::predictor_load(const float* emb, const float* wout, uint32_t vocab, bool on_device)
+{
+    if (null_) return no_data_path("speckv_ext_predictor_load");
+    if (!emb || !wout || vocab < 8) return SPECKV_ERR_INVAL;
+    int prev = 0; (void)hipGetDevice(&prev); HIP_TRY(hipSetDevice(device_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    if (d_emb_) { (void)hipFree(d_emb_); d_emb_ = nullptr; }
+    if (d_wout_) { (void)hipFree(d_wout_); d_wout_ = nullptr; }
+    const size_t eb = static_cast<size_t>(vocab) * 64 * sizeof(float), wb = static_cast<size_t>(vocab) * 128 * sizeof(float);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_emb_), eb));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_wout_), wb));
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (on_device) HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(d_emb_, emb, eb, kind));
+    HIP_TRY(hipMemcpy(d_wout_, wout, wb, kind));
+    vocab_ = vocab;
+    hist_.clear(); pred_.clear(); hist_dirty_.clear();
+    (void)hipSetDevice(prev);
+    return SPECKV_OK;
+}
+
+int Engine::predict_batch(uint32_t n, const int32_t* d_hist, uint32_t k, int32_t* d_tok, float* d_conf, hipStream_t s)
+{
+    if (null_) return no_data_path("speckv_ext_predict_batch");
+    if (!d_emb_) return SPECKV_ERR_INVAL;
+    if (n == 0) return SPECKV_OK;
+    if (!d_hist || !d_tok || !d_conf || k == 0 || k > 8) return SPECKV_ERR_INVAL;
+    int prev = 0; (void)hipGetDevice(&prev); HIP_TRY(hipSetDevice(device_));
+    float* hid = static_cast<float*>(scratch(s_hid_, static_cast<size_t>(n) * 128 * sizeof(float)));
+    float* logits = static_cast<float*>(scratch(s_logits_, static_cast<size_t>(n) * vocab_ * sizeof(float)));
+    if (!hid || !logits) { (void)hipSetDevice(prev); return SPECKV_ERR_NOMEM; }
+    hipStream_t st = s ? s : stream_;
+    HIP_TRY(launch_predict(n, d_hist, d_emb_, d_wout_, vocab_, 2, k, hid, logits, d_tok, d_conf, st));
+    if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+    (void)hipSetDevice(prev);
+    return SPECKV_OK;
+}
+
+int Engine::run_predictor_for_dirty()
+{
+    if (!d_emb_ || hist_dirty_.empty()) { hist_dirty_.clear(); return SPECKV_OK; }
+    std::sort(hist_dirty_.begin(), hist_dirty_.end());
+    hist_dirty_.erase(std::unique(hist_dirty_.begin(), hist_dirty_.end()), hist_dirty_.end());
+    const uint32_t n = static_cast<uint32_t>(hist_dirty_.size());
+    uint32_t k = adapt_.depth();
+    if (k > 8) k = 8;
+    if (k == 0) k = 1;
+    std::vector<int32_t> h(static_cast<size_t>(n) * 16);
+    for (uint32_t i = 0; i < n; ++i) memcpy(&h[i * 16], hist_[hist_dirty_[i]].data(), 16 * sizeof(int32_t));
+    int32_t* d_h = static_cast<int32_t*>(scratch(s_hist_, h.size() * sizeof(int32_t)));
+    uint8_t* d_p = static_cast<uint8_t*>(scratch(s_pred_, static_cast<size_t>(n) * k * (sizeof(int32_t) + sizeof(float))));
+    if (!d_h || !d_p) return SPECKV_ERR_NOMEM;
+    int32_t* d_tok = reinterpret_cast<int32_t*>(d_p);
+    float* d_conf = reinterpret_cast<float*>(d_p + static_cast<size_t>(n) * k * sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(d_h, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+    int rc = predict_batch(n, d_h, k, d_tok, d_conf, stream_);
+    if (rc != SPECKV_OK) return rc;
+    std::vector<int32_t> tok(static_cast<size_t>(n) * k);
+    HIP_TRY(hipMemcpyAsync(tok.data(), d_tok, tok.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    reap(true);
+    for (uint32_t i = 0; i < n; ++i) pred_[hist_dirty_[i]].assign(tok.begin() + static_cast<size_t>(i) * k, tok.begin() + static_cast<size_t>(i + 1) * k);
+    hist_dirty_.clear();
+    return SPECKV_OK;
 }
 
 int Engine::prefetch_lookup(uint64_t handle, uint32_t n, const uint32_t* d_req, const uint32_t* d_layer,
@@ -694,7 +772,15 @@ int Engine::prefetch_lookup(uint64_t handle, uint32_t n, const uint32_t* d_req, 
 int Engine::verify(uint32_t req, int32_t actual, const int32_t* pred, uint32_t n,
                    uint32_t* was_hit, uint32_t* new_depth)
 {
-    (void)req;
+    // no list given: verify against the prediction the engine made from the request's last history
+    std::vector<int32_t> own;
+    if (!pred || n == 0) {
+        auto it = pred_.find(req);
+        if (it == pred_.end()) return SPECKV_ERR_INVAL;
+        own = it->second;
+        pred = own.data();
+        n = static_cast<uint32_t>(own.size());
+    }
     bool hit = false;                                        // speculative_prefetcher.cpp:84-96
     for (uint32_t i = 0; i < n; ++i) if (pred[i] == actual) { hit = true; break; }
     if (!hit) st_.mispredictions++; else st_.successful_prefetches++;

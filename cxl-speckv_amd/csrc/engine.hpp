@@ -102,6 +102,8 @@ public:
     int qk_scores_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
                       uint32_t pos_begin, uint32_t pos_end, float* d_out, hipStream_t s);
     int migrate(uint64_t handle, uint64_t first_page, uint64_t n_pages, uint32_t target_pool);
+    int predictor_load(const float* emb, const float* wout, uint32_t vocab, bool on_device);
+    int predict_batch(uint32_t n, const int32_t* d_hist, uint32_t k, int32_t* d_tok, float* d_conf, hipStream_t s);
     int poll_complete(uint32_t* done);
     int sync();
     int promote_to_l1(uint64_t handle, uint64_t off);
@@ -156,6 +158,15 @@ private:
     Scratch s_pages_, s_dst_, s_req_, s_out_, s_tmp_, s_stage_;
     uint32_t* d_count_ = nullptr;
 
+    // token predictor (lstm_predictor.cpp): weights in HBM, last history / prediction per request
+    float* d_emb_ = nullptr;
+    float* d_wout_ = nullptr;
+    uint32_t vocab_ = 0;
+    Scratch s_hid_, s_logits_, s_hist_, s_pred_;
+    std::unordered_map<uint32_t, std::vector<int32_t>> hist_;
+    std::unordered_map<uint32_t, std::vector<int32_t>> pred_;
+    std::vector<uint32_t> hist_dirty_;
+
     speckv_ext_stats_t st_{};
 
     Allocation* find(uint64_t h);
@@ -175,6 +186,7 @@ private:
     int fetch_into_slots(Allocation* a, const std::vector<uint32_t>& pages,
                          const std::vector<uint32_t>& slots, bool wait);
     void reap(bool wait_all);
+    int run_predictor_for_dirty();
     hipEvent_t get_event();
 };
 

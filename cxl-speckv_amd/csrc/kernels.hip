@@ -1176,6 +1176,127 @@ __global__ void k_debug_divcheck(float den, unsigned long long* counters)
     if (badq) atomicAdd(&counters[1], badq);
 }
 
+// ===================================================================
+// token predictor  (src/prefetcher/lstm_predictor.cpp:40-188)
+// ===================================================================
+// The reference's "LSTM" is degenerate: gates fixed at 0.5, recurrent weights unused,
+// candidate g = sum_j 0.1*embedding[token][j] (lstm_predictor.cpp:117-146).  These
+// kernels compute exactly that maths for a batch of 16-token histories, then the
+// 128 x vocab output mat-vec, softmax and top-k.  fp tolerance vs the oracle: the
+// device tanhf/expf and the reduction order differ from glibc's (tests state 1e-4).
+constexpr uint32_t kPredHist = 16, kPredEmb = 64, kPredHidden = 128;
+
+// one wave per request: lane 0 walks the history; every lane stores 2 of the 128 hidden values
+__global__ __launch_bounds__(64) void k_lstm_hidden(const int32_t* __restrict__ hist, uint32_t n,
+        const float* __restrict__ emb, uint32_t vocab, uint32_t layers, float* __restrict__ hid)
+{
+    const uint32_t r = blockIdx.x, lane = threadIdx.x;
+    if (r >= n) return;
+    float h = 0.0f, c = 0.0f;
+    if (lane == 0) {
+        for (uint32_t t = 0; t < kPredHist; ++t) {
+            const uint32_t tok = static_cast<uint32_t>(hist[r * kPredHist + t]);
+            float g = 0.0f;
+            if (tok < vocab) {
+                const float* e = emb + static_cast<uint64_t>(tok) * kPredEmb;
+                for (uint32_t j = 0; j < kPredEmb; ++j) g += e[j] * 0.1f;
+            }
+            for (uint32_t l = 0; l < layers; ++l) {
+                c = 0.5f * c + 0.5f * tanhf(g);
+                h = 0.5f * tanhf(c);
+            }
+        }
+    }
+    h = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(h)));
+    hid[static_cast<uint64_t>(r) * kPredHidden + lane] = h;
+    hid[static_cast<uint64_t>(r) * kPredHidden + 64u + lane] = h;
+}
+
+// logits[b][i] = sum_j hid[b][j] * wout[i][j].  4 lanes per output row (32 weights each, held in
+// registers), 16 rows per wave -> a wave streams 8 KiB of contiguous weights once for the whole batch.
+__global__ __launch_bounds__(256) void k_lstm_logits(const float* __restrict__ hid, uint32_t n,
+        const float* __restrict__ wout, uint32_t vocab, float* __restrict__ logits)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t row = gw * 16u + (lane >> 2), part = lane & 3u;
+    float w[32];
+    const bool live = row < vocab;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) v = *reinterpret_cast<const float4*>(wout + static_cast<uint64_t>(row) * kPredHidden + part * 32u + i * 4);
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    for (uint32_t b = 0; b < n; ++b) {
+        const float* hb = hid + static_cast<uint64_t>(b) * kPredHidden + part * 32u;
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc += hb[i] * w[i];
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (live && part == 0u) logits[static_cast<uint64_t>(b) * vocab + row] = acc;
+    }
+}
+
+// softmax + top-k of one request per workgroup (k <= 8).  Ties: lower token id first.
+__global__ __launch_bounds__(256) void k_softmax_topk(const float* __restrict__ logits, uint32_t vocab,
+        uint32_t k, int32_t* __restrict__ out_tok, float* __restrict__ out_conf)
+{
+    __shared__ float red[256];
+    __shared__ uint32_t redi[256];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const float* l = logits + static_cast<uint64_t>(b) * vocab;
+    float val[8];
+    uint32_t idx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { val[i] = -INFINITY; idx[i] = 0xFFFFFFFFu; }
+    float mx = -INFINITY;
+    for (uint32_t i = tid; i < vocab; i += 256u) {
+        const float v = l[i];
+        mx = fmaxf(mx, v);
+        // sorted insertion (descending value, ascending index)
+        if (v > val[7] || (v == val[7] && i < idx[7])) {
+            val[7] = v; idx[7] = i;
+#pragma unroll
+            for (int j = 7; j > 0; --j) {
+                const bool sw = val[j] > val[j - 1] || (val[j] == val[j - 1] && idx[j] < idx[j - 1]);
+                if (sw) { const float tv = val[j]; val[j] = val[j - 1]; val[j - 1] = tv;
+                          const uint32_t ti = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = ti; }
+            }
+        }
+    }
+    red[tid] = mx; __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
+    mx = red[0]; __syncthreads();
+    float sum = 0.0f;
+    for (uint32_t i = tid; i < vocab; i += 256u) sum += expf(l[i] - mx);
+    red[tid] = sum; __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    sum = red[0]; __syncthreads();
+    uint32_t head = 0;
+    for (uint32_t r = 0; r < k; ++r) {
+        float cv = -INFINITY; uint32_t ci = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (static_cast<uint32_t>(j) == head) { cv = val[j]; ci = idx[j]; }
+        red[tid] = cv; redi[tid] = ci; __syncthreads();
+        for (uint32_t s = 128; s > 0; s >>= 1) {
+            if (tid < s) {
+                const float ov = red[tid + s]; const uint32_t oi = redi[tid + s];
+                if (ov > red[tid] || (ov == red[tid] && oi < redi[tid])) { red[tid] = ov; redi[tid] = oi; }
+            }
+            __syncthreads();
+        }
+        const float bv = red[0]; const uint32_t bi = redi[0];
+        __syncthreads();
+        if (ci == bi && ci != 0xFFFFFFFFu) ++head;                 // the owner of the winner advances
+        if (tid == 0) {
+            out_tok[b * k + r] = static_cast<int32_t>(bi);
+            out_conf[b * k + r] = expf(bv - mx) / sum;
+        }
+    }
+}
+
 // self-test of the wave primitives (tests/test_gpu_codec.py::test_wave_primitives)
 __global__ void k_debug_dpp(const uint32_t* in, uint32_t* out)
 {
@@ -1339,6 +1460,19 @@ hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t ba
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_retarget_entries, dim3(static_cast<uint32_t>((n + 255u) / 256u)), dim3(256), 0, s,
                        d_entries, n, base, stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb, const float* d_wout, uint32_t vocab,
+                          uint32_t layers, uint32_t k, float* d_hid, float* d_logits, int32_t* d_tok, float* d_conf,
+                          hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    if (k == 0 || k > 8u || vocab < k) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_lstm_hidden, dim3(n), dim3(64), 0, s, d_hist, n, d_emb, vocab, layers, d_hid);
+    const uint32_t waves = (vocab + 15u) / 16u;
+    hipLaunchKernelGGL(k_lstm_logits, dim3((waves + 3u) / 4u), dim3(256), 0, s, d_hid, n, d_wout, vocab, d_logits);
+    hipLaunchKernelGGL(k_softmax_topk, dim3(n), dim3(256), 0, s, d_logits, vocab, k, d_tok, d_conf);
     return hipGetLastError();
 }
 

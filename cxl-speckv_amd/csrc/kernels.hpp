@@ -95,6 +95,13 @@ hipError_t launch_qk_scores_fp8(const PageEntry* d_entries, uint64_t first_page,
 // entries[i].pool_addr = base + i*stride (record bytes / scale untouched): after a migration
 hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t base, uint64_t stride, hipStream_t s);
 
+// Token predictor (lstm_predictor.cpp:40-188): n histories of 16 tokens -> top-k (k <= 8) tokens and
+// confidences.  d_emb [vocab][64], d_wout [vocab][128]; d_hid (n*128 floats) and d_logits (n*vocab
+// floats) are scratch.
+hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb, const float* d_wout, uint32_t vocab,
+                          uint32_t layers, uint32_t k, float* d_hid, float* d_logits, int32_t* d_tok, float* d_conf,
+                          hipStream_t s);
+
 // exhaustive exactness check of the reciprocal-based divide (counters[0] quotient bits, [1] stored byte)
 hipError_t launch_debug_divcheck(float den, unsigned long long* d_counters, hipStream_t s);
 

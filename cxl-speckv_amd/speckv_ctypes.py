@@ -71,6 +71,8 @@ _EXT_SIGNATURES = {
     "speckv_ext_promote_to_l1": [c_uint64, c_uint64],
     "speckv_ext_demote_to_l3": [c_uint64, c_uint64],
     "speckv_ext_migrate": [c_uint64, c_uint64, c_uint64, c_uint32],
+    "speckv_ext_predictor_load": [c_void_p, c_void_p, c_uint32, c_int],
+    "speckv_ext_predict_batch": [c_uint32, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p],
     "speckv_ext_stats": [ctypes.POINTER(Stats)],
 }
 
@@ -223,11 +225,21 @@ class SpeckvLib:
         self._ext("speckv_ext_prefetch_flush", ctypes.byref(n))
         return n.value
 
-    def verify(self, req_id, actual_token, predicted):
+    def verify(self, req_id, actual_token, predicted=None):
+        """predicted=None: verify against the engine's own prediction for req_id."""
         hit, depth = c_uint32(), c_uint32()
-        arr = (c_int32 * max(len(predicted), 1))(*predicted)
-        self._ext("speckv_ext_verify", req_id, actual_token, arr, len(predicted), ctypes.byref(hit), ctypes.byref(depth))
+        if predicted is None:
+            self._ext("speckv_ext_verify", req_id, actual_token, None, 0, ctypes.byref(hit), ctypes.byref(depth))
+        else:
+            arr = (c_int32 * max(len(predicted), 1))(*predicted)
+            self._ext("speckv_ext_verify", req_id, actual_token, arr, len(predicted), ctypes.byref(hit), ctypes.byref(depth))
         return bool(hit.value), depth.value
+
+    def predictor_load(self, emb_ptr, wout_ptr, vocab, on_device):
+        self._ext("speckv_ext_predictor_load", c_void_p(emb_ptr), c_void_p(wout_ptr), vocab, int(on_device))
+
+    def predict_batch(self, n, d_hist, k, d_tok, d_conf, stream=None):
+        self._ext("speckv_ext_predict_batch", n, c_void_p(d_hist), k, c_void_p(d_tok), c_void_p(d_conf), c_void_p(stream or 0))
 
     def prefetch_depth(self):
         d = c_uint32()

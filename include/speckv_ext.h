@@ -120,7 +120,21 @@ speckv_status_t speckv_ext_prefetch_lookup(speckv_handle_t handle, uint32_t n,
 speckv_status_t speckv_ext_prefetch_legacy_addrs(uint32_t layer, uint32_t depth_k,
                                                  uint64_t* out_addrs, uint32_t* out_n);
 
-/* Verification + adaptive depth (speculative_prefetcher.cpp:84-137). */
+/* Token predictor (LSTMPredictor, src/prefetcher/lstm_predictor.cpp:40-188).
+ * The reference draws its weights from rand(); here the caller supplies them:
+ * embedding [vocab][64], out_weights [vocab][128] (fp32, host or device).  Once loaded,
+ * speckv_prefetch keeps the last 16 tokens per request, each flush predicts the next
+ * tokens of the requests whose history changed (top-depth, depth <= 8), and
+ * speckv_ext_verify(req, actual, NULL, 0) checks against that prediction.
+ * speckv_ext_predict_batch is the raw operator: n histories of 16 int32 tokens
+ * (device) -> top-k tokens / confidences (device, k <= 8). */
+speckv_status_t speckv_ext_predictor_load(const float* embedding, const float* out_weights,
+                                          uint32_t vocab, int on_device);
+speckv_status_t speckv_ext_predict_batch(uint32_t n, const int32_t* d_histories, uint32_t k,
+                                         int32_t* d_tokens, float* d_conf, void* stream);
+
+/* Verification + adaptive depth (speculative_prefetcher.cpp:84-137).  predicted == NULL
+ * verifies against the engine's own prediction for req_id (needs a loaded predictor). */
 speckv_status_t speckv_ext_verify(uint32_t req_id, int32_t actual_token,
                                   const int32_t* predicted, uint32_t n_predicted,
                                   uint32_t* was_hit, uint32_t* new_depth);

@@ -120,6 +120,8 @@ class Oracle:
             "orc_adapt_depth": (C.c_size_t, [C.c_void_p]),
             "orc_is_misprediction": (C.c_int, [C.c_uint32, u32p, C.c_size_t]),
             "orc_rtl_prefetch_vaddr": (C.c_uint64, [C.c_uint32, C.c_uint16, C.c_uint32]),
+            "orc_lstm_predict": (C.c_size_t, [f32p, f32p] + [C.c_size_t] * 5 + [u32p, C.c_size_t, C.c_size_t, u32p, f32p]),
+            "orc_lstm_reference_weights": (None, [C.c_uint, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, f32p, f32p]),
             "orc_prefetch_pages": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32] + [C.c_uint64] * 6 + [u32p, u64p, C.c_size_t]),
         }
         for name, (res, args) in sig.items():
@@ -181,6 +183,19 @@ class Oracle:
         for b in range(B):
             self.lib.orc_decompress_block_f16(_ptr(recs[b], u8p), int(lens[b]), C.c_float(float(scales[b])), scheme, mode, _ptr(y[b], u16p), n)
         return y.view(np.float16)
+
+    def lstm_predict(self, emb, wout, history, k, hist_len=16, layers=2):
+        emb = np.ascontiguousarray(emb, np.float32); wout = np.ascontiguousarray(wout, np.float32)
+        h = np.ascontiguousarray(history, np.uint32)
+        tok = np.zeros(k, np.uint32); prob = np.zeros(k, np.float32)
+        n = self.lib.orc_lstm_predict(_ptr(emb, f32p), _ptr(wout, f32p), emb.shape[0], emb.shape[1], wout.shape[1], layers,
+                                      hist_len, _ptr(h, u32p), h.size, k, _ptr(tok, u32p), _ptr(prob, f32p))
+        return tok[:n], prob[:n]
+
+    def lstm_reference_weights(self, seed=1, vocab=32000, emb_dim=64, hidden=128, layers=2):
+        emb = np.zeros((vocab, emb_dim), np.float32); wout = np.zeros((vocab, hidden), np.float32)
+        self.lib.orc_lstm_reference_weights(seed, vocab, emb_dim, hidden, layers, _ptr(emb, f32p), _ptr(wout, f32p))
+        return emb, wout
 
     def prefetch_pages(self, req, layer, cur_pos, k, L, T, H, D, bpe, alloc_pages, flags=None, cap=64):
         out = np.zeros(cap, dtype=np.uint64)

@@ -843,6 +843,60 @@ int orc_is_misprediction(uint32_t actual, const uint32_t* predicted, size_t n)
     return 1;
 }
 
+void orc_lstm_reference_weights(unsigned seed, size_t vocab, size_t emb_dim, size_t hidden,
+                                size_t layers, float* emb, float* wout)
+{   /* lstm_predictor.cpp:22-35 */
+    srand(seed);
+    for (size_t i = 0; i < vocab * emb_dim; ++i) emb[i] = ((float)rand() / RAND_MAX - 0.5f) * 0.1f;
+    for (size_t i = 0; i < layers * hidden * hidden * 4; ++i) (void)rand();
+    for (size_t i = 0; i < hidden * vocab; ++i) wout[i] = ((float)rand() / RAND_MAX - 0.5f) * 0.1f;
+}
+
+size_t orc_lstm_predict(const float* emb, const float* wout, size_t vocab, size_t emb_dim,
+                        size_t hidden, size_t layers, size_t hist_len,
+                        const uint32_t* history, size_t n_hist, size_t k,
+                        uint32_t* out_tok, float* out_prob)
+{
+    /* lstm_predictor.cpp:44-51 : last hist_len tokens, zero-padded at the front */
+    uint32_t* h = (uint32_t*)calloc(hist_len ? hist_len : 1, sizeof(uint32_t));
+    if (n_hist >= hist_len) memcpy(h, history + (n_hist - hist_len), hist_len * sizeof(uint32_t));
+    else memcpy(h + (hist_len - n_hist), history, n_hist * sizeof(uint32_t));
+    float* hid = (float*)calloc(hidden, sizeof(float));
+    float* cell = (float*)calloc(hidden, sizeof(float));
+    float* e = (float*)calloc(emb_dim, sizeof(float));
+    for (size_t t = 0; t < hist_len; ++t) {
+        /* embed_token, lstm_predictor.cpp:148-159 */
+        for (size_t j = 0; j < emb_dim; ++j) e[j] = (h[t] < vocab) ? emb[(size_t)h[t] * emb_dim + j] : 0.0f;
+        for (size_t l = 0; l < layers; ++l) {
+            /* lstm_forward, lstm_predictor.cpp:117-146 */
+            for (size_t i = 0; i < hidden; ++i) {
+                float g = 0.0f;
+                for (size_t j = 0; j < emb_dim && j < hidden; ++j) g += e[j] * 0.1f;
+                cell[i] = 0.5f * cell[i] + 0.5f * tanhf(g);
+                hid[i] = 0.5f * tanhf(cell[i]);
+            }
+        }
+    }
+    /* compute_output_probs, lstm_predictor.cpp:161-188 */
+    float* p = (float*)calloc(vocab ? vocab : 1, sizeof(float));
+    for (size_t i = 0; i < vocab; ++i)
+        for (size_t j = 0; j < hidden; ++j) p[i] += hid[j] * wout[i * hidden + j];
+    float mx = p[0];
+    for (size_t i = 1; i < vocab; ++i) if (p[i] > mx) mx = p[i];
+    float sum = 0.0f;
+    for (size_t i = 0; i < vocab; ++i) { p[i] = expf(p[i] - mx); sum += p[i]; }
+    for (size_t i = 0; i < vocab; ++i) p[i] /= sum;
+    /* top-k by probability (lstm_predictor.cpp:75-93) */
+    size_t n = k < vocab ? k : vocab;
+    for (size_t r = 0; r < n; ++r) {
+        size_t best = 0; float bp = -1.0f;
+        for (size_t i = 0; i < vocab; ++i) if (p[i] > bp) { bp = p[i]; best = i; }
+        out_tok[r] = (uint32_t)best; out_prob[r] = bp; p[best] = -2.0f;
+    }
+    free(h); free(hid); free(cell); free(e); free(p);
+    return n;
+}
+
 uint64_t orc_rtl_prefetch_vaddr(uint32_t req_id, uint16_t layer, uint32_t pos_plus)
 {   /* prefetch_core.v:92-98 : the 89-bit concatenation keeps its low 64 bits:
      * bit0 kind=0, bits 1..32 pos, bits 33..40 head=0, bits 41..56 layer,

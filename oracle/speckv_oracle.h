@@ -209,6 +209,25 @@ size_t       orc_adapt_depth(const orc_adapt_t*);
 /* returns 1 when actual is NOT among predicted (a misprediction) */
 int          orc_is_misprediction(uint32_t actual, const uint32_t* predicted, size_t n);
 
+/* Token predictor (src/prefetcher/lstm_predictor.cpp:40-188), SURVEY 8f row N1.
+ * The reference's "LSTM" is degenerate (gates fixed at 0.5, recurrent weights
+ * unused, candidate g = sum_j 0.1*embedding[j]); this restates exactly that maths,
+ * sequentially, in the reference's operation order.  emb: [vocab][emb_dim],
+ * wout: [vocab][hidden].  history is padded with zeros at the FRONT / cut to its
+ * last hist_len tokens (lstm_predictor.cpp:44-51).  Returns min(k, vocab) pairs,
+ * highest probability first (ties: lower token id first; the reference's
+ * std::sort leaves tie order unspecified). */
+size_t orc_lstm_predict(const float* emb, const float* wout, size_t vocab, size_t emb_dim,
+                        size_t hidden, size_t layers, size_t hist_len,
+                        const uint32_t* history, size_t n_hist, size_t k,
+                        uint32_t* out_tok, float* out_prob);
+/* weights as the reference's constructor draws them (lstm_predictor.cpp:27-35):
+ * srand(seed) then rand() in the order embedding, lstm (discarded here), output.
+ * With seed 1 (glibc's default state) this reproduces the first predictor
+ * constructed in a fresh process. */
+void orc_lstm_reference_weights(unsigned seed, size_t vocab, size_t emb_dim, size_t hidden,
+                                size_t layers, float* emb, float* wout);
+
 /* RTL intent (hardware/rtl/prefetch_core.v:92-98,158): the virtual address
  * the prefetch FSM asks the ATU for at iteration idx. 64-bit truncation of
  * {req[31:0], layer[15:0], 8'd0, pos[31:0], 1'b0}. */

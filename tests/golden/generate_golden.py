@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REFROOT = "/root/reference"
 
-from oracle.bindings import REF_SO, Reference, _ptr, u32p, u64p, i32p  # noqa: E402
+from oracle.bindings import REF_SO, Reference, _ptr, u32p, u64p, i32p, f32p  # noqa: E402
 
 
 def gen_cabi(ref):
@@ -212,9 +212,13 @@ def gen_prefetch(ref):
     for hist, layer, depth in (([*range(1, 17)], 5, 0), ([*range(101, 117)], 0, 8), ([7, 8, 9], 79, 2),
                                ([1], 65535, 3), ([*range(1, 17)], 31, 1)):
         h = np.array(hist, np.uint32)
-        va = np.zeros(16, np.uint64)
-        n = R.ref_pf_prefetch(pf, _ptr(h, u32p), h.size, layer, depth, _ptr(va, u64p), None, None, 16)
-        calls.append({"history": hist, "layer": layer, "depth": depth, "addresses": [int(v) for v in va[:n]]})
+        va = np.zeros(16, np.uint64); tok = np.zeros(16, np.uint32); conf = np.zeros(16, np.float32)
+        n = R.ref_pf_prefetch(pf, _ptr(h, u32p), h.size, layer, depth, _ptr(va, u64p), _ptr(tok, u32p),
+                              _ptr(conf, f32p), 16)
+        # predicted tokens / confidences of the FIRST predictor constructed in this process
+        # (weights from glibc rand() in its default state, lstm_predictor.cpp:27-35)
+        calls.append({"history": hist, "layer": layer, "depth": depth, "addresses": [int(v) for v in va[:n]],
+                      "tokens": [int(t) for t in tok[:n]], "conf_bits": [int(b) for b in conf[:n].view(np.uint32)]})
     rng = np.random.default_rng(3)
     outcomes = [1] * 9 + [1] * 6 + [0] * 12 + [int(v) for v in (rng.random(200) < 0.9)]
     depths = []

@@ -417,3 +417,43 @@ def test_migrate_records_between_pool_slabs(oracle):
         assert ei.value.status == -1
     finally:
         lib.finalize()
+
+
+def test_token_predictor_matches_oracle_and_reference(eng, oracle, golden_dir):
+    """the predictor kernels against the oracle's restatement of
+    lstm_predictor.cpp (itself bit-exact against the reference, test_oracle_golden).
+    Tokens must be identical; confidences within 5e-4 relative: the reference sums
+    32000 fp32 softmax terms sequentially (its own rounding error is ~1e-4 of the sum),
+    the device reduces them as a tree and uses its own tanhf/expf."""
+    import json
+    torch = torch_mod()
+    lib = eng.lib
+    emb, wout = oracle.lstm_reference_weights(1)               # what the reference's first predictor holds
+    lib.predictor_load(emb.ctypes.data, wout.ctypes.data, 32000, False)
+    g = json.load(open(os.path.join(golden_dir, "prefetch.json")))
+    rng = np.random.default_rng(17)
+    hists = [c["history"] for c in g["calls"]] + [list(rng.integers(0, 32000, 16)) for _ in range(40)] + [[0] * 16, [31999] * 16, [40000, 5, 7]]
+    H = np.zeros((len(hists), 16), np.int32)
+    for i, h in enumerate(hists):
+        h = list(h)[-16:]
+        H[i, 16 - len(h):] = h
+    for k in (1, 4, 8):
+        d_h = torch.from_numpy(H).cuda()
+        d_tok = torch.zeros((len(hists), k), dtype=torch.int32, device="cuda"); d_conf = torch.zeros((len(hists), k), dtype=torch.float32, device="cuda")
+        lib.predict_batch(len(hists), d_h.data_ptr(), k, d_tok.data_ptr(), d_conf.data_ptr())
+        torch.cuda.synchronize()
+        tok = d_tok.cpu().numpy(); conf = d_conf.cpu().numpy()
+        for i, h in enumerate(hists):
+            o_tok, o_conf = oracle.lstm_predict(emb, wout, np.array(h, np.uint32), k)
+            assert tok[i].tolist() == o_tok.astype(np.int32).tolist(), (i, k)
+            assert np.allclose(conf[i], o_conf, rtol=5e-4, atol=0)
+    # the reference's own golden prediction for history 1..16 (SURVEY appendix A)
+    assert tok[0][:4].tolist() == [11465, 24880, 10938, 28629]
+    # closed loop through the drop-in entry points: prefetch(history) -> flush -> verify(actual)
+    h = eng.allocate(128, 1, 8, 128, 2)
+    eng.prefetch_step(7, 0, 10, list(range(1, 17)), 4)
+    lib.sync()
+    assert lib.verify(7, 24880) == (True, 4)                   # second-ranked prediction: a hit
+    assert lib.verify(7, 123)[0] is False
+    with pytest.raises(SpeckvError):
+        lib.verify(99, 1)                                      # no history for this request

@@ -160,6 +160,15 @@ def test_prefetch_golden(oracle, golden_dir):
         n = O.orc_prefetch_legacy(None, c["layer"], eff, eff, _ptr(out, u64p))
         assert out[:n].tolist() == c["addresses"]
     assert g["calls"][0]["addresses"] == [0x50001, 0x50002, 0x50003, 0x50004]
+    # token predictor: the oracle's restatement with the reference's
+    # constructor weights reproduces the reference's predictions bit for bit
+    emb, wout = oracle.lstm_reference_weights(1)
+    for c in g["calls"]:
+        eff = c["depth"] or depth
+        tok, prob = oracle.lstm_predict(emb, wout, c["history"], eff)
+        assert tok.tolist() == c["tokens"]
+        assert prob.view(np.uint32).tolist() == c["conf_bits"]
+    assert g["calls"][0]["tokens"] == [11465, 24880, 10938, 28629]
     ad = O.orc_adapt_new(depth)
     for ok, want in zip(g["outcomes"], g["depth_trace"]):
         O.orc_adapt_update(ad, ok)
