@@ -455,6 +455,34 @@ def fp8_scores_extra(torch, kv, T, Lyr):
         lib.set_compression_scheme(2)
 
 
+def predictor_extra(torch, lib):
+    """Token predictor (reference LSTMPredictor::predict_top_k: 13.5 ms per call on one CPU
+    core; paper claim < 10 us on the FPGA): latency of one top-4 prediction
+    and of a 256-request batch, random weights of the reference's shape (32000 x 64 / x 128)."""
+    try:
+        g = torch.Generator(device="cuda"); g.manual_seed(9)
+        emb = (torch.rand((32000, 64), generator=g, device="cuda") - 0.5) * 0.1
+        wout = (torch.rand((32000, 128), generator=g, device="cuda") - 0.5) * 0.1
+        lib.predictor_load(emb.data_ptr(), wout.data_ptr(), 32000, True)
+        out = {}
+        s = torch.cuda.Stream()
+        for n in (1, 256):
+            hist = torch.randint(0, 32000, (n, 16), generator=g, device="cuda", dtype=torch.int32)
+            tok = torch.empty((n, 4), dtype=torch.int32, device="cuda"); conf = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+            lib.predict_batch(n, hist.data_ptr(), 4, tok.data_ptr(), conf.data_ptr(), s.cuda_stream); torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 20
+            a.record(s)
+            for _ in range(reps):
+                lib.predict_batch(n, hist.data_ptr(), 4, tok.data_ptr(), conf.data_ptr(), s.cuda_stream)
+            b.record(s); torch.cuda.synchronize()
+            out[f"batch_{n}_us"] = round(a.elapsed_time(b) / reps * 1e3, 2)
+        out["reference_cpu_ms_per_call"] = 13.5
+        return {"token_predictor_top4": out}
+    except Exception as e:
+        return {"token_predictor_top4": {"error": repr(e)}}
+
+
 def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     """Latency / rate of the non-bulk entry points (C ABI calls, not kernels alone)."""
     lib = kv.lib
@@ -474,6 +502,7 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     ex["speckv_access_us"] = {"miss_sync_fetch": round(miss_us, 2), "hit": round(hit_us, 2),
                               "reference_emulated_us": "2.2-2.8 (SURVEY 3.1, no data moved)"}
     ex.update(fp8_scores_extra(torch, kv, 32768, 80))      # BASELINE configs[4] shape: 70B-shaped KV @ 32k context
+    ex.update(predictor_extra(torch, lib))
     # one decode step of a 256-sequence batch worth of look-ahead requests (cfg4-sized call count)
     n_req = 256 * Lyr
     reqs = [0] * n_req

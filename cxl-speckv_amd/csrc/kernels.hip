@@ -31,7 +31,7 @@ namespace {
 constexpr int kWaves = 4;                 // wavefronts per workgroup
 constexpr int kThreads = 64 * kWaves;
 constexpr int kDecLdsWords = 528;         // per wave: 2 KiB byte table + 64 B of write-only dummies
-constexpr int kEncLdsHalves = 2056 + 2048; // per wave: run positions + pair buffer
+constexpr int kEncLdsHalves = 3200;        // per wave: 6400 B (see kEncWaveBytes)
 
 // ------------------------------------------------------------------ DPP
 template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
@@ -629,6 +629,137 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
 }
 
 // ===================================================================
+// RLE encode of the delta stream (cache_engine.cpp:198-239)
+// ===================================================================
+// Wave LDS layout (bytes): [0,16) write-only dummies / lead, [16, 16+4096) pair
+// buffer, [4128, 4128+2048) the quantised bytes in position order (for the
+// general path).  Both paths scatter, per RUN START at position p, the value
+// byte of its own pair and the count byte of the PREVIOUS pair (p - previous
+// start); the last pair is closed after the loop.  No read-back from LDS.
+constexpr uint32_t kEncPairOff = 16, kEncQOff = 4128, kEncWaveBytes = 6400;
+constexpr uint32_t kEncFail = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p)
+{
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8*)p));
+}
+
+// Fast path: no stretch of equal deltas reaches 255 elements, so every change
+// of the delta starts a run and no run has to be split (count < 255 rule).
+// Per chunk: flags -> count / last start per lane -> one add-scan (run index) and
+// one max-scan (previous start) -> 2 byte stores per element.  Returns the number
+// of runs, or kEncFail when a long stretch may exist (>= 14 lanes of a chunk
+// without any run start: a 255-stretch needs 30 such lanes in two chunks).
+// The block is quantised chunk by chunk (8 live bytes per lane instead of 32); the
+// bytes are also staged in LDS in position order in case the general path is needed.
+template <int MODE>
+__device__ __forceinline__ void quantize_chunk(const float (&x)[8], float scale, float rcp, bool finite, uint32_t (&q)[8])
+{
+    if (finite) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = quantize_finite<MODE>(x[k], scale, rcp);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = quantize<MODE>(x[k], scale);
+    }
+}
+template <int MODE>
+__device__ __forceinline__ uint32_t encode_rle_fast(const float (&x)[4][8], float scale, float rcp, bool finite,
+                                                    uint8_t* wl, uint32_t lane)
+{
+    const uint32_t pair_addr = lds_addr_of(wl + kEncPairOff);
+    const uint32_t dummy = lds_addr_of(wl);
+    uint32_t qtail = 0, dtail = 0, mcarry = 0, icarry = 0;       // mcarry: position+1 of the last run start
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t p0 = 512u * j + 8u * lane;
+        uint32_t q[8];
+        quantize_chunk<MODE>(x[j], scale, rcp, finite, q);
+        *reinterpret_cast<uint2*>(wl + kEncQOff + p0) =
+            make_uint2(q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24), q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24));
+        uint32_t prevq = wave_shr1(q[7], qtail);
+        qtail = lane63(q[7]);
+        uint32_t d[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { d[k] = (q[k] - prevq) & 0xFFu; prevq = q[k]; }
+        uint32_t prevd = wave_shr1(d[7], dtail);
+        dtail = lane63(d[7]);
+        bool nq[8];
+        uint32_t cnt = 0, lm = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            nq[k] = (p0 + k == 0u) || (d[k] != prevd);
+            prevd = d[k];
+            cnt += nq[k] ? 1u : 0u;
+            lm = nq[k] ? p0 + k + 1u : lm;
+        }
+        if (__popcll(__ballot(cnt == 0u)) >= 14) {                           // wave-uniform: long stretch possible
+            // stage the rest of the block for the general path
+            for (int jj = j + 1; jj < 4; ++jj) {
+                uint32_t qq[8];
+                quantize_chunk<MODE>(x[jj], scale, rcp, finite, qq);
+                *reinterpret_cast<uint2*>(wl + kEncQOff + 512u * jj + 8u * lane) =
+                    make_uint2(qq[0] | (qq[1] << 8) | (qq[2] << 16) | (qq[3] << 24), qq[4] | (qq[5] << 8) | (qq[6] << 16) | (qq[7] << 24));
+            }
+            return kEncFail;
+        }
+        const uint32_t ic = wave_incl_add(cnt);
+        uint32_t idx = icarry + ic - cnt;
+        icarry += lane63(ic);
+        const uint32_t im = wave_incl_max(lm);
+        uint32_t m = umax(wave_shr1(im, 0u), mcarry);
+        mcarry = umax(mcarry, lane63(im));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t p = p0 + k;
+            const uint32_t b = nq[k] ? pair_addr + 2u * idx - 1u : dummy;
+            lds_store_b8(b, p + 1u - m);             // count of the previous run
+            lds_store_b8(b + 1u, d[k]);              // value of this run
+            m = nq[k] ? p + 1u : m;
+            idx += nq[k] ? 1u : 0u;
+        }
+    }
+    lds_store_b8(pair_addr + 2u * icarry - 1u, kBlockElems + 1u - mcarry);  // close the last run
+    return icarry;
+}
+
+// General path (long stretches: zeros, constants): one element per lane per step,
+// rolled; stretch starts by max-scan, a run starts every 255 elements of a stretch.
+__device__ __noinline__ uint32_t encode_rle_general(uint8_t* wl, uint32_t lane)
+{
+    const uint32_t pair_addr = lds_addr_of(wl + kEncPairOff);
+    const uint8_t* qb = wl + kEncQOff;
+    uint32_t qtail = 0, dtail = 0, scarry = 0, mcarry = 0, icarry = 0;
+#pragma unroll 1
+    for (uint32_t step = 0; step < kBlockElems / 64u; ++step) {
+        const uint32_t p = 64u * step + lane;
+        const uint32_t qv = qb[p];
+        const uint32_t prevq = wave_shr1(qv, qtail);
+        qtail = lane63(qv);
+        const uint32_t d = (qv - prevq) & 0xFFu;
+        const uint32_t prevd = wave_shr1(d, dtail);
+        dtail = lane63(d);
+        const bool neq = (p == 0u) || (d != prevd);
+        const uint32_t is = wave_incl_max(neq ? p + 1u : 0u);
+        const uint32_t ss = umax(is, scarry);                      // stretch start, position+1
+        scarry = umax(scarry, lane63(is));
+        const bool isrun = ((p + 1u - ss) % 255u) == 0u;           // count < 255 rule (cache_engine.cpp:224)
+        const uint32_t ic = wave_incl_add(isrun ? 1u : 0u);
+        const uint32_t idx = icarry + ic - (isrun ? 1u : 0u);
+        icarry += lane63(ic);
+        const uint32_t im = wave_incl_max(isrun ? p + 1u : 0u);
+        const uint32_t prev = umax(wave_shr1(im, 0u), mcarry);
+        mcarry = umax(mcarry, lane63(im));
+        if (isrun) {
+            lds_store_b8(pair_addr + 2u * idx - 1u, p + 1u - prev);
+            lds_store_b8(pair_addr + 2u * idx, d);
+        }
+    }
+    lds_store_b8(pair_addr + 2u * icarry - 1u, kBlockElems + 1u - mcarry);
+    return icarry;
+}
+
+// ===================================================================
 // encode  (cache_engine.cpp:40-82,172-239)
 // ===================================================================
 template <int SCHEME, int MODE>
@@ -765,99 +896,32 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
             }
             scale = (mx > 0.0f) ? (mx / 127.0f) : 1.0f;
             const bool finite = __ballot(!(nanacc == 0.0f)) == 0ull;       // wave-uniform
-
-            uint32_t q[4][8];
-            if (finite) {
-                const float rcp = 1.0f / scale;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) q[j][k] = quantize_finite<MODE>(x[j][k], scale, rcp);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) q[j][k] = quantize<MODE>(x[j][k], scale);
-            }
+            const float rcp = 1.0f / scale;
 
             if (SCHEME == kInt8) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    uint32_t q[8];
+                    quantize_chunk<MODE>(x[j], scale, rcp, finite, q);
                     uint2 o;
-                    o.x = q[j][0] | (q[j][1] << 8) | (q[j][2] << 16) | (q[j][3] << 24);
-                    o.y = q[j][4] | (q[j][5] << 8) | (q[j][6] << 16) | (q[j][7] << 24);
+                    o.x = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+                    o.y = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
                     *reinterpret_cast<uint2*>(rec + 512u * j + 8u * lane) = o;
                 }
                 out_len = kBlockElems;
             } else {
-                uint16_t* runpos = lds + wave * kEncLdsHalves;     // [2056]
-                uint16_t* pairbuf = runpos + 2056;                 // [2048]
-                // delta (cache_engine.cpp:198-211), with q[-1] := 0 so d[0] = q[0]
-                uint32_t d[4][8];
-                uint32_t isrun[4][8];     // run-start flag
-                uint32_t ridx[4][8];      // index of the run this element starts
-                uint32_t qtail = 0, dtail = 0, scarry = 0, rcarry = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t p0 = 512u * j + 8u * lane;
-                    uint32_t prevq = wave_shr1(q[j][7], qtail);
-                    qtail = lane63(q[j][7]);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        d[j][k] = (q[j][k] - prevq) & 0xFFu;
-                        prevq = q[j][k];
-                    }
-                    // stretch starts: element differs from its predecessor
-                    uint32_t prevd = wave_shr1(d[j][7], dtail);
-                    dtail = lane63(d[j][7]);
-                    uint32_t key[8];
-                    uint32_t m = 0;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const uint32_t p = p0 + k;
-                        const bool neq = (p == 0u) || (d[j][k] != prevd);
-                        prevd = d[j][k];
-                        m = umax(m, neq ? p : 0u);
-                        key[k] = m;
-                    }
-                    const uint32_t incl = wave_incl_max(m);
-                    const uint32_t excl = umax(wave_shr1(incl, 0u), scarry);
-                    scarry = umax(scarry, lane63(incl));
-                    // a run starts every 255 elements inside a stretch (count < 255 rule)
-                    uint32_t cnt = 0;
-                    uint32_t loc[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const uint32_t t = (p0 + k) - umax(key[k], excl);
-                        isrun[j][k] = (t % 255u == 0u) ? 1u : 0u;
-                        loc[k] = cnt;
-                        cnt += isrun[j][k];
-                    }
-                    const uint32_t rincl = wave_incl_add(cnt);
-                    const uint32_t rbase = rcarry + rincl - cnt;
-                    rcarry += lane63(rincl);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        ridx[j][k] = rbase + loc[k];
-                        if (isrun[j][k]) runpos[ridx[j][k]] = static_cast<uint16_t>(p0 + k);
-                    }
-                }
-                const uint32_t nruns = rcarry;
-                if (lane == 0u) runpos[nruns] = static_cast<uint16_t>(kBlockElems);
+                uint8_t* wl = reinterpret_cast<uint8_t*>(lds) + wave * kEncWaveBytes;
+                uint32_t nruns = encode_rle_fast<MODE>(x, scale, rcp, finite, wl, lane);
                 wave_lds_fence();
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        if (isrun[j][k]) {
-                            const uint32_t p = 512u * j + 8u * lane + k;
-                            const uint32_t count = runpos[ridx[j][k] + 1u] - p;
-                            pairbuf[ridx[j][k]] = static_cast<uint16_t>(d[j][k] | (count << 8));
-                        }
+                if (nruns == kEncFail) {
+                    nruns = encode_rle_general(wl, lane);
+                    wave_lds_fence();
+                }
+                uint8_t* pairbuf = wl + kEncPairOff;
                 // zero the tail of the last 16-byte chunk so the stored slot is deterministic
                 {
                     const uint32_t idx = nruns + lane;
-                    if (lane < 8u && idx < ((nruns + 7u) & ~7u)) pairbuf[idx] = 0;
+                    if (lane < 8u && idx < ((nruns + 7u) & ~7u)) reinterpret_cast<uint16_t*>(pairbuf)[idx] = 0;
                 }
                 wave_lds_fence();
                 out_len = 2u * nruns;
@@ -865,8 +929,7 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t b = 1024u * j + 16u * lane;
                     if (b < out_len)
-                        *reinterpret_cast<uint4*>(rec + b) =
-                            *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(pairbuf) + b);
+                        *reinterpret_cast<uint4*>(rec + b) = *reinterpret_cast<const uint4*>(pairbuf + b);
                 }
                 wave_lds_fence();
             }
@@ -1192,21 +1255,25 @@ __global__ __launch_bounds__(64) void k_lstm_hidden(const int32_t* __restrict__ 
 {
     const uint32_t r = blockIdx.x, lane = threadIdx.x;
     if (r >= n) return;
-    float h = 0.0f, c = 0.0f;
-    if (lane == 0) {
-        for (uint32_t t = 0; t < kPredHist; ++t) {
-            const uint32_t tok = static_cast<uint32_t>(hist[r * kPredHist + t]);
-            float g = 0.0f;
-            if (tok < vocab) {
-                const float* e = emb + static_cast<uint64_t>(tok) * kPredEmb;
-                for (uint32_t j = 0; j < kPredEmb; ++j) g += e[j] * 0.1f;
-            }
-            for (uint32_t l = 0; l < layers; ++l) {
-                c = 0.5f * c + 0.5f * tanhf(g);
-                h = 0.5f * tanhf(c);
-            }
-        }
+    // candidate g_t = sum_j 0.1*embedding[token_t][j]: lane j holds entry j of every token's row
+    // (16 independent loads in flight), one wave reduction per token
+    float g[kPredHist];
+#pragma unroll
+    for (uint32_t t = 0; t < kPredHist; ++t) {
+        const uint32_t tok = static_cast<uint32_t>(hist[r * kPredHist + t]);
+        g[t] = (tok < vocab) ? emb[static_cast<uint64_t>(tok) * kPredEmb + lane] * 0.1f : 0.0f;
     }
+#pragma unroll
+    for (uint32_t t = 0; t < kPredHist; ++t)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) g[t] += __shfl_xor(g[t], o);
+    float h = 0.0f, c = 0.0f;
+#pragma unroll
+    for (uint32_t t = 0; t < kPredHist; ++t)
+        for (uint32_t l = 0; l < layers; ++l) {
+            c = 0.5f * c + 0.5f * tanhf(g[t]);
+            h = 0.5f * tanhf(c);
+        }
     h = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(h)));
     hid[static_cast<uint64_t>(r) * kPredHidden + lane] = h;
     hid[static_cast<uint64_t>(r) * kPredHidden + 64u + lane] = h;
@@ -1240,11 +1307,12 @@ __global__ __launch_bounds__(256) void k_lstm_logits(const float* __restrict__ h
 }
 
 // softmax + top-k of one request per workgroup (k <= 8).  Ties: lower token id first.
-__global__ __launch_bounds__(256) void k_softmax_topk(const float* __restrict__ logits, uint32_t vocab,
+constexpr uint32_t kSmThreads = 1024;
+__global__ __launch_bounds__(1024) void k_softmax_topk(const float* __restrict__ logits, uint32_t vocab,
         uint32_t k, int32_t* __restrict__ out_tok, float* __restrict__ out_conf)
 {
-    __shared__ float red[256];
-    __shared__ uint32_t redi[256];
+    __shared__ float red[kSmThreads];
+    __shared__ uint32_t redi[kSmThreads];
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const float* l = logits + static_cast<uint64_t>(b) * vocab;
     float val[8];
@@ -1252,7 +1320,7 @@ __global__ __launch_bounds__(256) void k_softmax_topk(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 8; ++i) { val[i] = -INFINITY; idx[i] = 0xFFFFFFFFu; }
     float mx = -INFINITY;
-    for (uint32_t i = tid; i < vocab; i += 256u) {
+    for (uint32_t i = tid; i < vocab; i += kSmThreads) {
         const float v = l[i];
         mx = fmaxf(mx, v);
         // sorted insertion (descending value, ascending index)
@@ -1267,12 +1335,12 @@ __global__ __launch_bounds__(256) void k_softmax_topk(const float* __restrict__ 
         }
     }
     red[tid] = mx; __syncthreads();
-    for (uint32_t s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
+    for (uint32_t s = kSmThreads / 2; s > 0; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
     mx = red[0]; __syncthreads();
     float sum = 0.0f;
-    for (uint32_t i = tid; i < vocab; i += 256u) sum += expf(l[i] - mx);
+    for (uint32_t i = tid; i < vocab; i += kSmThreads) sum += expf(l[i] - mx);
     red[tid] = sum; __syncthreads();
-    for (uint32_t s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    for (uint32_t s = kSmThreads / 2; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
     sum = red[0]; __syncthreads();
     uint32_t head = 0;
     for (uint32_t r = 0; r < k; ++r) {
@@ -1280,7 +1348,7 @@ __global__ __launch_bounds__(256) void k_softmax_topk(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 8; ++j) if (static_cast<uint32_t>(j) == head) { cv = val[j]; ci = idx[j]; }
         red[tid] = cv; redi[tid] = ci; __syncthreads();
-        for (uint32_t s = 128; s > 0; s >>= 1) {
+        for (uint32_t s = kSmThreads / 2; s > 0; s >>= 1) {
             if (tid < s) {
                 const float ov = red[tid + s]; const uint32_t oi = redi[tid + s];
                 if (ov > red[tid] || (ov == red[tid] && oi < redi[tid])) { red[tid] = ov; redi[tid] = oi; }
@@ -1472,7 +1540,7 @@ hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb,
     hipLaunchKernelGGL(k_lstm_hidden, dim3(n), dim3(64), 0, s, d_hist, n, d_emb, vocab, layers, d_hid);
     const uint32_t waves = (vocab + 15u) / 16u;
     hipLaunchKernelGGL(k_lstm_logits, dim3((waves + 3u) / 4u), dim3(256), 0, s, d_hid, n, d_wout, vocab, d_logits);
-    hipLaunchKernelGGL(k_softmax_topk, dim3(n), dim3(256), 0, s, d_logits, vocab, k, d_tok, d_conf);
+    hipLaunchKernelGGL(k_softmax_topk, dim3(n), dim3(1024), 0, s, d_logits, vocab, k, d_tok, d_conf);
     return hipGetLastError();
 }
 
