@@ -457,3 +457,16 @@ def test_token_predictor_matches_oracle_and_reference(eng, oracle, golden_dir):
     assert lib.verify(7, 123)[0] is False
     with pytest.raises(SpeckvError):
         lib.verify(99, 1)                                      # no history for this request
+
+
+def test_decode_loop_example_runs():
+    """The reference's decode-loop sketch (vllm_speckv_backend.py:104-129), runnable:
+    after the first step every row the loop touches was brought in by the look-ahead."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("decode_loop_example", os.path.join(os.path.dirname(__file__), "..", "examples", "decode_loop_example.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    out = mod.run(steps=12, layers=4, tokens=256, verbose=False)
+    assert out["prefetched_pages"] > 0
+    # 12 steps x 4 layers x 2 kinds accesses: only the very first step can miss
+    assert out["l3_accesses"] <= 8 and out["l2_hits"] + out["l1_hits"] >= 11 * 8
+    assert out["depth"] <= 4 and out["mispredictions"] == 12          # random tokens never match: depth decays
