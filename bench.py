@@ -501,8 +501,6 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     hit_us = (time.perf_counter() - t0) / 10 * 1e6
     ex["speckv_access_us"] = {"miss_sync_fetch": round(miss_us, 2), "hit": round(hit_us, 2),
                               "reference_emulated_us": "2.2-2.8 (SURVEY 3.1, no data moved)"}
-    ex.update(fp8_scores_extra(torch, kv, 32768, 80))      # BASELINE configs[4] shape: 70B-shaped KV @ 32k context
-    ex.update(predictor_extra(torch, lib))
     # one decode step of a 256-sequence batch worth of look-ahead requests (cfg4-sized call count)
     n_req = 256 * Lyr
     reqs = [0] * n_req
@@ -515,6 +513,8 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     dt = time.perf_counter() - t0
     ex["prefetch_flush"] = {"requests": n_req, "pages_issued": issued, "ms": round(dt * 1e3, 3),
                             "requests_per_s": round(n_req / dt, 1)}
+    ex.update(fp8_scores_extra(torch, kv, 32768, 80))      # BASELINE configs[4] shape: 70B-shaped KV @ 32k context
+    ex.update(predictor_extra(torch, lib))
     return ex
 
 
