@@ -470,3 +470,123 @@ def test_decode_loop_example_runs():
     # 12 steps x 4 layers x 2 kinds accesses: only the very first step can miss
     assert out["l3_accesses"] <= 8 and out["l2_hits"] + out["l1_hits"] >= 11 * 8
     assert out["depth"] <= 4 and out["mispredictions"] == 12          # random tokens never match: depth decays
+
+
+def test_striped_multi_pool_on_one_gpu(oracle):
+    """SPECKV_POOL_DEVICES="0,0,0": three pools (here all on GPU 0) exercise the
+    multi-GPU placement code on a one-GPU box: pages striped page % 3, host-built
+    page table, preferred_node placement, migration between pools."""
+    os.environ["SPECKV_POOL_DEVICES"] = "0,0,0"
+    try:
+        lib = pkg.SpeckvLib(pkg.library_path(), "hip:0")
+    finally:
+        del os.environ["SPECKV_POOL_DEVICES"]
+    try:
+        assert lib.stats().n_pool_devices == 3
+        lib.set_compression_scheme(2)
+        n = 1000                                                  # not a multiple of 3
+        h = lib.alloc(n * PAGE)
+        x = synth(n, seed=21)
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+        scales, lens, recs = oracle.compress_blocks_f16(x, 2, 0)
+        want = oracle.decompress_blocks_f16(recs, lens, scales, 2, 0)
+        y = np.empty_like(x); lib.read(h, 0, y.ctypes.data, y.nbytes, False)
+        assert_same_float_bits(y, want)
+        addr = [lib.translate(h, p * PAGE).pool_addr for p in range(12)]
+        for r in range(3):                                        # each residue class is one contiguous run
+            assert addr[r + 3] == addr[r] + PAGE and addr[r + 6] == addr[r] + 2 * PAGE and addr[r + 9] == addr[r] + 3 * PAGE
+        assert len({a // (1 << 20) for a in addr[:3]}) >= 1
+        for p in (0, 1, 2, 500, 999):
+            info = lib.translate(h, p * PAGE)
+            assert info.rec_bytes == lens[p] and stored_equal(info, recs[p], lens[p])
+        # an allocation pinned to one pool (preferred_node is 1-based; 0 = stripe)
+        h2 = lib.alloc(64 * PAGE, preferred_node=2)
+        a2 = [lib.translate(h2, p * PAGE).pool_addr for p in range(4)]
+        assert a2[1] == a2[0] + PAGE and a2[3] == a2[0] + 3 * PAGE
+        # migrate a striped range into pool 1: it becomes one contiguous run, data unchanged
+        lib.migrate(h, 30, 90, 1)
+        a = [lib.translate(h, p * PAGE).pool_addr for p in (30, 31, 119)]
+        assert a[1] == a[0] + PAGE and a[2] == a[0] + 89 * PAGE
+        y2 = np.empty_like(x); lib.read(h, 0, y2.ctypes.data, y2.nbytes, False)
+        assert y2.tobytes() == y.tobytes()
+        # tiers and prefetch on top of the striped pool
+        ptr = lib.access(h, 77 * PAGE + 128, 256)
+        assert dev_to_host(ptr, 256).tobytes() == y.view(np.uint8).reshape(-1)[77 * PAGE + 128: 77 * PAGE + 384].tobytes()
+        lib.free(h); lib.free(h2)
+        assert lib.stats().pool_migrated_pages == 90
+    finally:
+        lib.finalize()
+
+
+def stored_equal(info, rec, n):
+    return dev_to_host(info.pool_addr, int(n)).tobytes() == rec[:n].tobytes()
+
+
+def test_engine_random_operations_vs_model(oracle):
+    """Model-based check of the engine's bookkeeping: random alloc / write / access /
+    read / prefetch / free sequences; every byte handed back must be the oracle's
+    decode of what was written last, every status the reference's."""
+    os.environ["SPECKV_L2_MB"] = "2"; os.environ["SPECKV_L1_MB"] = "1"
+    try:
+        kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), "hip:0")
+    finally:
+        del os.environ["SPECKV_L2_MB"]; del os.environ["SPECKV_L1_MB"]
+    lib = kv.lib
+    rng = np.random.default_rng(2024)
+    model = {}                                                     # handle -> dict(pages, scheme, data (decoded fp16 or None per page))
+    next_handle = 1
+    try:
+        for step in range(400):
+            op = rng.choice(["alloc", "write", "access", "read", "free", "prefetch", "span"], p=[0.1, 0.2, 0.3, 0.15, 0.05, 0.1, 0.1])
+            if op == "alloc" or not model:
+                scheme = int(rng.integers(0, 5))
+                lib.set_compression_scheme(scheme)
+                T = int(rng.choice([16, 64, 130]))
+                L = int(rng.integers(1, 4))
+                h = kv.allocate(T, L, 8, 128, 2)
+                assert h == next_handle; next_handle += 1
+                n_pages = T * L * 8 * 128 * 2 * 2 // PAGE
+                model[h] = {"pages": n_pages, "scheme": scheme, "data": np.zeros((n_pages, N), np.float16), "geom": (T, L)}
+                continue
+            h = int(rng.choice(list(model)))
+            m = model[h]
+            if op == "write":
+                p0 = int(rng.integers(0, m["pages"])); cnt = int(rng.integers(1, min(40, m["pages"] - p0) + 1))
+                x = synth(cnt, seed=int(rng.integers(0, 1 << 30)))
+                lib.write(h, p0 * PAGE, x.ctypes.data, x.nbytes, False)
+                sc, ln, rc = oracle.compress_blocks_f16(x, m["scheme"], 0)
+                m["data"][p0:p0 + cnt] = oracle.decompress_blocks_f16(rc, ln, sc, m["scheme"], 0)
+            elif op == "access":
+                off = int(rng.integers(0, m["pages"] * PAGE + 3 * PAGE))
+                if off >= m["pages"] * PAGE:
+                    with pytest.raises(SpeckvError) as ei:
+                        lib.access(h, off, 64)
+                    assert ei.value.status == -1
+                else:
+                    ln = int(rng.integers(1, 300)); ln = min(ln, (off // PAGE + 1) * PAGE - off)
+                    ptr = lib.access(h, off, ln)
+                    assert dev_to_host(ptr, ln).tobytes() == m["data"].view(np.uint8).reshape(-1)[off:off + ln].tobytes()
+            elif op == "span":
+                p0 = int(rng.integers(0, m["pages"])); cnt = int(rng.integers(1, min(6, m["pages"] - p0) + 1))
+                ptr = lib.access(h, p0 * PAGE + 16, cnt * PAGE - 32)
+                assert dev_to_host(ptr, cnt * PAGE - 32).tobytes() == m["data"].view(np.uint8).reshape(-1)[p0 * PAGE + 16:(p0 + cnt) * PAGE - 16].tobytes()
+            elif op == "read":
+                p0 = int(rng.integers(0, m["pages"])); cnt = int(rng.integers(1, min(64, m["pages"] - p0) + 1))
+                y = np.empty((cnt, N), np.float16)
+                lib.read(h, p0 * PAGE, y.ctypes.data, y.nbytes, False)
+                assert_same_float_bits(y, m["data"][p0:p0 + cnt])
+            elif op == "prefetch":
+                T, L = m["geom"]
+                if kv.handle == h:                                   # look-ahead works on the shim's live handle
+                    kv.prefetch_decode_step([0], [int(rng.integers(0, T))], int(rng.integers(1, 9)))
+            elif op == "free":
+                lib.free(h)
+                del model[h]
+                with pytest.raises(SpeckvError) as ei:
+                    lib.access(h, 0, 1)
+                assert ei.value.status == -1
+        st = lib.stats()
+        assert st.total_allocations == next_handle - 1
+        assert st.current_allocated_bytes == sum(v["pages"] * PAGE for v in model.values())
+    finally:
+        kv.close()
