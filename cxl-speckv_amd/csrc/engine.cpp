@@ -435,6 +435,7 @@ int Engine::fetch_into_slots(Allocation* a, const std::vector<uint32_t>& pages,
     for (uint32_t i = 1; i < n && run; ++i) run = pages[i] == pages[0] + i && slots[i] == slots[0] + i;
     CodecArgs c{};
     c.entries = a->d_entries;
+    c.trusted = 1;                       // pool records only ever come from k_compress
     if (run) {
         c.first = pages[0];
         c.data = slot_ptr(slots[0]);
@@ -886,6 +887,7 @@ int Engine::write(uint64_t handle, uint64_t off, const void* src, size_t len, bo
     if (on_device) HIP_TRY(hipDeviceSynchronize());
     CodecArgs c{};
     c.entries = a->d_entries;
+    c.trusted = 1;                       // pool records only ever come from k_compress
     c.data_stride = kPageSize;
     c.scheme = a->scheme;
     c.quant_mode = quant_mode_;
@@ -948,6 +950,7 @@ int Engine::read(uint64_t handle, uint64_t off, void* dst, size_t len, bool on_d
     if (on_device) HIP_TRY(hipDeviceSynchronize());    // dst may still be in use on a caller stream
     CodecArgs c{};
     c.entries = a->d_entries;
+    c.trusted = 1;                       // pool records only ever come from k_compress
     c.data_stride = kPageSize;
     c.scheme = a->scheme;
     c.quant_mode = quant_mode_;
@@ -990,6 +993,7 @@ int Engine::fetch_range(uint64_t handle, uint64_t first, uint64_t n, void* d_dst
     if (prev != device_) HIP_TRY(hipSetDevice(device_));
     CodecArgs c{};
     c.entries = a->d_entries;
+    c.trusted = 1;                       // pool records only ever come from k_compress
     c.first = first;
     c.n = n;
     c.data = static_cast<uint8_t*>(d_dst);
@@ -1022,6 +1026,7 @@ int Engine::fetch_list(uint64_t handle, const uint32_t* d_pages, uint32_t n, voi
     if (prev != device_) HIP_TRY(hipSetDevice(device_));
     CodecArgs c{};
     c.entries = a->d_entries;
+    c.trusted = 1;                       // pool records only ever come from k_compress
     c.page_list = d_pages;
     c.n = n;
     c.data = static_cast<uint8_t*>(d_dst);

@@ -276,7 +276,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //
 // One 512-pair chunk of the pair phase.  A pair dword is  v0 | c0<<8 | v1<<16 | c1<<24.
 // Returns false when the running count passes 2048 (caller falls back).
-template <bool FULL>
+template <bool FULL, bool CHECK>
 __device__ __forceinline__ bool rle_pair_chunk(const uint4 wv, uint32_t pair0, uint32_t npairs,
                                                uint32_t tab_addr, uint32_t& ccarry, uint32_t& wtail,
                                                uint32_t& mn)
@@ -314,16 +314,21 @@ __device__ __forceinline__ bool rle_pair_chunk(const uint4 wv, uint32_t pair0, u
     lds_store_b8(a, sub_b2_b0(w[2], w[2]));  a = add_b3(a, w[2]);
     lds_store_b8(a, sub_b0_b2(w[3], w[2]));  a = add_b1(a, w[3]);
     lds_store_b8(a, sub_b2_b0(w[3], w[3]));
+    if (CHECK) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { mn = min_b1(mn, wm[t]); mn = min_b3(mn, wm[t]); }
+        for (int t = 0; t < 4; ++t) { mn = min_b1(mn, wm[t]); mn = min_b3(mn, wm[t]); }
+    }
     return true;
 }
 
 // Returns false (nothing stored) when the block is not well-formed.
+// `trusted` (wave-uniform): the stream comes from k_compress -- no zero counts, and the
+// bytes between len and the next 16-byte boundary are zero pairs, which scatter into
+// the dummy byte; every chunk then takes the unmasked, unchecked form.
 template <int MODE, bool F32>
 __device__ __forceinline__ bool decode_rle_fast(const uint8_t* __restrict__ rec, uint32_t len,
                                                 float scale, uint8_t* __restrict__ dst,
-                                                uint8_t* tab, uint32_t lane)
+                                                uint8_t* tab, uint32_t lane, bool trusted)
 {
     const uint32_t npairs = len >> 1;                       // odd trailing byte dropped
     uint4 w[4];
@@ -347,8 +352,9 @@ __device__ __forceinline__ bool decode_rle_fast(const uint8_t* __restrict__ rec,
         if (512u * j >= npairs) break;                      // wave-uniform
         const uint32_t pair0 = 512u * j + 8u * lane;
         bool go;
-        if (512u * (j + 1) <= npairs) go = rle_pair_chunk<true>(w[j], pair0, npairs, tab_addr, ccarry, wtail, mn);
-        else                          go = rle_pair_chunk<false>(w[j], pair0, npairs, tab_addr, ccarry, wtail, mn);
+        if (trusted)                       go = rle_pair_chunk<true, false>(w[j], pair0, npairs, tab_addr, ccarry, wtail, mn);
+        else if (512u * (j + 1) <= npairs) go = rle_pair_chunk<true, true>(w[j], pair0, npairs, tab_addr, ccarry, wtail, mn);
+        else                               go = rle_pair_chunk<false, true>(w[j], pair0, npairs, tab_addr, ccarry, wtail, mn);
         if (!go) return false;
     }
     const bool ok = (ccarry == kBlockElems) && (__ballot(mn == 0u) == 0ull);
@@ -606,7 +612,8 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
         if (SCHEME == kInt8DeltaRle) {
             if (len > 2u * kBlockElems) len = 2u * kBlockElems;
             uint32_t* region = lds + wave * kDecLdsWords;
-            if (!decode_rle_fast<MODE, F32>(cur.rec, len, cur.scale, cur.dst, reinterpret_cast<uint8_t*>(region), lane))
+            if (!decode_rle_fast<MODE, F32>(cur.rec, len, cur.scale, cur.dst, reinterpret_cast<uint8_t*>(region), lane,
+                                            a.trusted != 0))
                 decode_rle_general<MODE, F32>(cur.rec, len, cur.scale, cur.dst, lane);
         } else if (SCHEME == kInt8) {
             if (len > kBlockElems) len = kBlockElems;

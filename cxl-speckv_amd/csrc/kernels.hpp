@@ -49,6 +49,9 @@ struct CodecArgs {
     int             scheme;
     int             quant_mode;
     int             out_f32;
+    // records were written by k_compress (the engine's pool): INT8_DELTA_RLE streams are then known to
+    // have no zero counts and a zero-padded tail, which the decoder need not re-check per pair
+    int             trusted;
 };
 
 hipError_t launch_compress(const CodecArgs& a, hipStream_t s);
