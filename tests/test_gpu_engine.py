@@ -590,3 +590,55 @@ def test_engine_random_operations_vs_model(oracle):
         assert st.current_allocated_bytes == sum(v["pages"] * PAGE for v in model.values())
     finally:
         kv.close()
+
+
+def test_config4_shaped_sequence_full_size(oracle):
+    """BASELINE configs[3] shape, one sequence: Llama-3-70B-shaped KV (80 layers, 8 kv
+    heads, D=128) at 8k context = 2 684 354 560 B = 655 360 pages.
+    Allocation ids, bulk write / fetch at full size, spot parity against the oracle,
+    FP16 identity and decode idempotence as size-independent properties."""
+    import time
+    torch = torch_mod()
+    kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), "hip:0")
+    lib = kv.lib
+    try:
+        T, L, H, D, bpe = 8192, 80, 8, 128, 2
+        lib.set_compression_scheme(2)
+        t0 = time.perf_counter()
+        h = kv.allocate(T, L, H, D, bpe)
+        alloc_s = time.perf_counter() - t0
+        n_pages = 655360
+        assert lib.translate(h, (n_pages - 1) * PAGE).phys_page_id == oracle.lib.orc_phys_page_id(h, n_pages - 1)
+        # last entry of the shim layout (SURVEY appendix A: 0x40a02fff00 for handle 3 -> same arithmetic here)
+        off = kv._calc_offset(0, 79, 7, 8191, 1, 256)
+        assert off == 2684354560 - 256
+        assert alloc_s < 0.25, alloc_s                     # the reference spends 0.25 s in hash inserts for this size
+        g = torch.Generator(device="cuda"); g.manual_seed(2004)
+        chunk = 65536
+        out = torch.empty((chunk, N), dtype=torch.float16, device="cuda")
+        s = torch.cuda.Stream()
+        keep = {}
+        for p0 in range(0, n_pages, chunk):
+            x = torch.randn((chunk, N), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+            if p0 in (0, 5 * chunk):
+                x[:chunk // 2] = 0                            # long zero runs: the general encoder/decoder paths at scale
+            lib.write(h, p0 * PAGE, x.data_ptr(), x.numel() * 2, True)
+            if p0 in (0, 5 * chunk, 9 * chunk):
+                keep[p0] = x[::4099].cpu().numpy()
+        st = lib.stats()
+        assert st.total_compressions == n_pages and st.compressed_bytes < n_pages * PAGE
+        for p0 in range(0, n_pages, chunk):
+            lib.fetch_range(h, p0, chunk, out.data_ptr(), False, s.cuda_stream)
+            torch.cuda.synchronize()
+            if p0 in keep:
+                xs = keep[p0]
+                got = out[::4099].cpu().numpy()
+                sc, ln, rc = oracle.compress_blocks_f16(xs, 2, 0)
+                want = oracle.decompress_blocks_f16(rc, ln, sc, 2, 0)
+                assert_same_float_bits(got, want, f"chunk {p0}")
+        # look-ahead of a 256-layer-batch worth of requests at this geometry
+        issued = kv.prefetch_decode_step([0], [4000], 4)
+        assert issued == 80 * 2 * 2 or issued == 80 * 2 * 3    # K and V, 2-3 pages per (layer, kind)
+        lib.sync()
+    finally:
+        kv.close()
