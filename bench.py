@@ -75,12 +75,15 @@ def parse_args():
 # --------------------------------------------------------------------------
 # CPU baseline (checker code, used here ONLY as the thing timed beside the GPU)
 # --------------------------------------------------------------------------
-def cpu_baseline(seconds, sample_blocks=8192, seed=2001):
+def cpu_baseline(seconds, sample_blocks=None, seed=2001):
     import ctypes as C
     from oracle.bindings import Oracle, Reference, have_reference, _ptr, f32p, u8p, u32p
+    n_threads = os.cpu_count() or 1
+    if sample_blocks is None:
+        # >= 128 blocks per thread and call, so the ctypes call (GIL released) dominates the Python loop
+        sample_blocks = max(8192, 128 * n_threads)
     rng = np.random.default_rng(seed)
     x = rng.standard_normal((sample_blocks, BLOCK_ELEMS)).astype(np.float16).astype(np.float32)
-    n_threads = os.cpu_count() or 1
     if have_reference():
         kind = "reference"
         ref = Reference()

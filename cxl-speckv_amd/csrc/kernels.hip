@@ -28,7 +28,10 @@
 namespace speckv {
 namespace {
 
-constexpr int kWaves = 4;                 // wavefronts per workgroup
+#ifndef SPECKV_WAVES
+#define SPECKV_WAVES 4
+#endif
+constexpr int kWaves = SPECKV_WAVES;      // wavefronts per workgroup (independent of each other)
 constexpr int kThreads = 64 * kWaves;
 constexpr int kDecLdsWords = 528;         // per wave: 2 KiB byte table + 64 B of write-only dummies
 constexpr int kEncLdsHalves = 3200;        // per wave: 6400 B (see kEncWaveBytes)
@@ -1417,7 +1420,7 @@ uint32_t codec_grid(uint64_t n)
         return v > 0 ? v : 128;
     }();
     const uint64_t want = (n + kWaves - 1) / kWaves;
-    const uint64_t cap = static_cast<uint64_t>(num_cus()) * per_cu;
+    const uint64_t cap = static_cast<uint64_t>(num_cus()) * per_cu * (4 / kWaves);
     return static_cast<uint32_t>(want < cap ? (want ? want : 1) : cap);
 }
 
