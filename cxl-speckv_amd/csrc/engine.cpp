@@ -177,9 +177,10 @@ Engine::~Engine()
     allocs_.clear();
     if (d_emb_) (void)hipFree(d_emb_);
     if (d_wout_) (void)hipFree(d_wout_);
-    for (Scratch* s : {&s_pages_, &s_dst_, &s_req_, &s_out_, &s_tmp_, &s_stage_, &s_hid_, &s_logits_, &s_hist_, &s_pred_})
+    for (Scratch* s : {&s_pages_, &s_dst_, &s_req_, &s_out_, &s_tmp_, &s_stage_, &s_hid_, &s_logits_, &s_hist_, &s_pred_, &s_attn_})
         if (s->p) (void)hipFree(s->p);
     if (d_count_) (void)hipFree(d_count_);
+    if (d_zero_page_) (void)hipFree(d_zero_page_);
     if (cache_base_) (void)hipFree(cache_base_);
     pools_.clear();
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
@@ -1077,6 +1078,76 @@ int Engine::qk_scores_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, co
     float* qs = reinterpret_cast<float*>(q8 + rows * 128);
     HIP_TRY(launch_quantize_q_e4m3(d_q_f16, n_layers * L.num_heads, g, L.head_dim, q8, qs, st));
     HIP_TRY(launch_qk_scores_fp8(a->d_entries, first_page, layer_stride, n_layers, n_pages, L.num_heads, g, q8, qs, d_out, st));
+    if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+    if (prev != device_) (void)hipSetDevice(prev);
+    return SPECKV_OK;
+}
+
+// Fused decode attention over the FP8 K and V regions of [layer, layer+n_layers) (attend.hip).
+int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
+                       uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
+{
+    if (null_) return no_data_path("speckv_ext_attend_fp8");
+    Allocation* a = find(handle);
+    if (!a) return SPECKV_ERR_GENERAL;
+    if (!a->has_layout || a->scheme != SPECKV_COMP_FP8_E4M3) return SPECKV_ERR_INVAL;
+    const Layout& L = a->layout;
+    if (L.head_dim != 128 || L.bytes_per_element != 2 || L.num_heads * L.head_dim != 1024 || L.num_tokens % 2) return SPECKV_ERR_INVAL;
+    if (n_layers == 0 || layer >= L.num_layers || n_layers > L.num_layers - layer || pos_begin % 2 || pos_begin > pos_end ||
+        pos_end > L.num_tokens || pos_end % 2)
+        return SPECKV_ERR_INVAL;
+    if (g == 0 || g > 16 || !d_q_f16 || !d_out) return SPECKV_ERR_INVAL;
+    const uint32_t n_pages = (pos_end - pos_begin) / 2;
+    int prev = 0; (void)hipGetDevice(&prev);
+    if (prev != device_) HIP_TRY(hipSetDevice(device_));
+    hipStream_t st = s ? s : stream_;
+    const size_t out_elems = static_cast<size_t>(n_layers) * L.num_heads * g * 128;
+    if (n_pages == 0) {          // empty range: softmax over nothing -> zeros (and -inf lse is left to the caller)
+        HIP_TRY(hipMemsetAsync(d_out, 0, out_elems * sizeof(float), st));
+        if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+        if (prev != device_) (void)hipSetDevice(prev);
+        return SPECKV_OK;
+    }
+    // shim layout [req 0][layer][kind][pos][head]: K pages of a layer, then its V pages
+    const uint64_t k_first = (static_cast<uint64_t>(layer) * 2 * L.num_tokens + pos_begin) / 2;
+    const uint64_t v_first = k_first + L.num_tokens / 2;
+    const uint64_t layer_stride = static_cast<uint64_t>(L.num_tokens);
+    if (v_first + (n_layers - 1) * layer_stride + n_pages > a->n_pages) return SPECKV_ERR_GENERAL;
+    if (!d_zero_page_) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
+        HIP_TRY(hipMemset(d_zero_page_, 0, kPageSize));
+    }
+    // splits: enough waves to fill the chip (~32 per CU), never less than one 32-position tile each
+    const uint32_t n_tiles = (n_pages + 15u) / 16u;
+    const uint32_t rows = n_layers * L.num_heads;
+    uint32_t want = (8192u + rows - 1u) / rows;
+    if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));
+    uint32_t n_splits = std::max(1u, std::min(want, n_tiles));
+    const uint32_t tiles_per_split = (n_tiles + n_splits - 1u) / n_splits;
+    n_splits = (n_tiles + tiles_per_split - 1u) / tiles_per_split;
+    const size_t q_bytes = static_cast<size_t>(rows) * 16 * 128, qs_bytes = static_cast<size_t>(rows) * 16 * sizeof(float);
+    const size_t acc_bytes = static_cast<size_t>(rows) * n_splits * 16 * 128 * sizeof(float);
+    const size_t ml_bytes = static_cast<size_t>(rows) * n_splits * 32 * sizeof(float);
+    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, q_bytes + qs_bytes + acc_bytes + ml_bytes));
+    if (!buf) return SPECKV_ERR_NOMEM;
+    AttendArgs k{};
+    k.entries = a->d_entries;
+    k.k_first = k_first;
+    k.v_first = v_first;
+    k.layer_stride = layer_stride;
+    k.n_pages = n_pages;
+    k.heads = L.num_heads;
+    k.g = g;
+    k.n_splits = n_splits;
+    k.tiles_per_split = tiles_per_split;
+    k.q8 = buf;
+    k.qs = reinterpret_cast<float*>(buf + q_bytes);
+    k.scale_log2e = sm_scale * 1.4426950408889634f;
+    k.zero_page = d_zero_page_;
+    k.part_acc = reinterpret_cast<float*>(buf + q_bytes + qs_bytes);
+    k.part_ml = reinterpret_cast<float*>(buf + q_bytes + qs_bytes + acc_bytes);
+    HIP_TRY(launch_quantize_q_e4m3(d_q_f16, rows, g, L.head_dim, buf, reinterpret_cast<float*>(buf + q_bytes), st));
+    HIP_TRY(launch_attend_fp8(k, n_layers, d_out, d_lse, st));
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
     if (prev != device_) (void)hipSetDevice(prev);
     return SPECKV_OK;

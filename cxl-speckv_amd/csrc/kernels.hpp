@@ -95,6 +95,24 @@ hipError_t launch_qk_scores_fp8(const PageEntry* d_entries, uint64_t first_page,
                                 uint32_t n_layers, uint32_t n_pages, uint32_t heads, uint32_t g,
                                 const uint8_t* d_q8, const float* d_qs, float* d_out, hipStream_t s);
 
+// Decode attention straight from FP8_E4M3 records (attend.hip): softmax(q.K^T * sm_scale) . V per kv head,
+// split over the positions, partials merged by a second kernel.  Same layout requirement as the scores.
+struct AttendArgs {
+    const PageEntry* entries;
+    uint64_t k_first, v_first;        // first K / V page of layer_begin at pos_begin
+    uint64_t layer_stride;            // pages per layer (K + V)
+    uint32_t n_pages;                 // pages of the position range
+    uint32_t heads, g;
+    uint32_t n_splits, tiles_per_split;   // tile = 16 pages = 32 positions
+    const uint8_t* q8;                // [layers][heads][16][128] e4m3
+    const float* qs;                  // [layers][heads][16]
+    float scale_log2e;                // sm_scale * log2(e)
+    const uint8_t* zero_page;         // 4 KiB of zeros: stands in for pages never written
+    float* part_acc;                  // [layers][heads][splits][16][128]
+    float* part_ml;                   // [layers][heads][splits][2][16]
+};
+hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s);
+
 // entries[i].pool_addr = base + i*stride (record bytes / scale untouched): after a migration
 hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t base, uint64_t stride, hipStream_t s);
 

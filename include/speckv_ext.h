@@ -184,6 +184,19 @@ speckv_status_t speckv_ext_qk_scores_fp8_layers(speckv_handle_t handle, uint32_t
                                                 uint32_t pos_begin, uint32_t pos_end,
                                                 float* d_out, void* stream);
 
+/* speckv_ext_attend_fp8: the whole decode attention of layers [layer_begin, layer_begin+n_layers)
+ * over positions [pos_begin, pos_end) (both even), computed from the FP8 K and V records
+ * without materialising fp16 KV:  out = softmax(q.K^T * sm_scale) . V  per kv head.
+ *   d_q_f16 : [n_layers][num_heads][g][128] fp16      d_out : [n_layers][num_heads][g][128] fp32
+ *   d_lse   : optional [n_layers][num_heads][g] fp32 log-sum-exp of the scaled scores (NULL to skip)
+ * Scores on v_mfma_f32_16x16x32_fp8_fp8, weights in f16 against V widened to f16 (exact) on
+ * v_mfma_f32_16x16x32_f16, fp32 accumulation; the position range is split across the chip and
+ * merged by a second kernel.  Pages never written count as zeros.  Same layout requirement as
+ * speckv_ext_qk_scores_fp8.  (second half; oracle: orc_attend_fp8.) */
+speckv_status_t speckv_ext_attend_fp8(speckv_handle_t handle, uint32_t layer_begin, uint32_t n_layers,
+                                      const void* d_q_f16, uint32_t g, uint32_t pos_begin, uint32_t pos_end,
+                                      float sm_scale, float* d_out, float* d_lse, void* stream);
+
 /* ---- tier manager (CXLMemoryManager, cxl_memory_manager.h:40-90) ---------- */
 speckv_status_t speckv_ext_promote_to_l1(speckv_handle_t handle, uint64_t offset_bytes);
 speckv_status_t speckv_ext_demote_to_l3(speckv_handle_t handle, uint64_t offset_bytes);

@@ -144,6 +144,15 @@ float   orc_e4m3_to_f32(uint8_t b);
 void orc_qk_scores_fp8(const uint8_t* q8, const float* q_scale, size_t g,
                        const uint8_t* k_rec, const float* k_scale, size_t n_pos,
                        size_t d, float* out);
+/* Decode attention of one kv head over FP8 records (own extension, parity unpinned):
+ *   s[m][t]   = (sum_d q8[m][d]*k[t][d]) * k_scale[t] * q_scale[m] * sm_scale
+ *   out[m][:] = sum_t softmax_t(s[m][:])[t] * v[t][:] * v_scale[t]        (double precision throughout)
+ *   lse[m]    = log sum_t exp(s[m][t])   (NULL to skip);  mag[m][:] = sum_t softmax[t] * |v[t][:] * v_scale[t]|
+ * mag (NULL to skip) is the magnitude the stated tolerance of the HIP kernel is relative to. */
+void orc_attend_fp8(const uint8_t* q8, const float* q_scale, size_t g,
+                    const uint8_t* k_rec, const float* k_scale,
+                    const uint8_t* v_rec, const float* v_scale, size_t n_pos, size_t d,
+                    float sm_scale, float* out, float* lse, float* mag);
 /* per-row e4m3 quantisation of the query (scale = max|q|/448, 1 if zero) */
 void orc_quantize_rows_e4m3(const uint16_t* q16, size_t rows, size_t d, uint8_t* q8, float* scale);
 

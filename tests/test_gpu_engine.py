@@ -380,6 +380,143 @@ def test_fp8_qk_scores_fused_mfma(eng, oracle):
         assert torch.equal(multi[layer], single)
 
 
+def _fp8_head_rows(recs, scales, first_page, npos, head, H, D):
+    rows = np.stack([recs[first_page + t // 2, ((t % 2) * H + head) * D:((t % 2) * H + head + 1) * D] for t in range(npos)])
+    sc = np.array([scales[first_page + t // 2] for t in range(npos)], np.float32)
+    return np.ascontiguousarray(rows), sc
+
+
+def test_fp8_fused_attention(eng, oracle):
+    """BASELINE config 5, both halves of the fused dequant-matvec: softmax(q.K^T).V straight from
+    the FP8 K and V records (speckv_ext_attend_fp8) against the oracle's double-precision
+    attention over the same e4m3 bytes.  Error sources of the HIP path: softmax weights rounded
+    to f16 (2^-11 each), the fp8 MFMA's accumulation of the scores (test above), v_exp_f32, fp32
+    accumulation.  Stated tolerance: |got - want| <= 2e-3 * sum_t p_t |v_t| + 1e-6, lse within 2e-3."""
+    torch = torch_mod()
+    lib = eng.lib
+    lib.set_compression_scheme(4)
+    T, L, H, D, bpe, G = 512, 3, 8, 128, 2, 8
+    h = eng.allocate(T, L, H, D, bpe)
+    n_pages = T * L * H * D * bpe * 2 // PAGE
+    rng = np.random.default_rng(47)
+    x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.05, 6.0, (n_pages, 1))).astype(np.float16)
+    lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+    scales, lens, recs = oracle.compress_blocks_f16(x, 4, 0)
+    from oracle.bindings import _ptr, u8p, u16p, f32p
+    q = (rng.standard_normal((L, H, G, D)) * 2.0).astype(np.float16)
+    d_q = torch.from_numpy(q.view(np.int16)).cuda()
+    q8 = np.zeros((L * H * G, D), np.uint8); qs = np.zeros(L * H * G, np.float32)
+    oracle.lib.orc_quantize_rows_e4m3(_ptr(q.view(np.uint16).reshape(-1), u16p), L * H * G, D, _ptr(q8, u8p), _ptr(qs, f32p))
+    q8 = q8.reshape(L, H, G, D); qs = qs.reshape(L, H, G)
+    sm = 1.0 / np.sqrt(D)
+
+    def want_for(layer, pb, pe, sm_scale):
+        npos = pe - pb
+        kf = (layer * 2 * T + pb) // 2
+        vf = kf + T // 2
+        out = np.zeros((H, G, D), np.float32); lse = np.zeros((H, G), np.float32); mag = np.zeros((H, G, D), np.float32)
+        for head in range(H):
+            krows, ksc = _fp8_head_rows(recs, scales, kf, npos, head, H, D)
+            vrows, vsc = _fp8_head_rows(recs, scales, vf, npos, head, H, D)
+            o = np.zeros((G, D), np.float32); l = np.zeros(G, np.float32); m = np.zeros((G, D), np.float32)
+            oracle.lib.orc_attend_fp8(_ptr(np.ascontiguousarray(q8[layer, head]), u8p), _ptr(qs[layer, head].copy(), f32p), G,
+                                      _ptr(krows, u8p), _ptr(ksc, f32p), _ptr(vrows, u8p), _ptr(vsc, f32p), npos, D,
+                                      float(sm_scale), _ptr(o, f32p), _ptr(l, f32p), _ptr(m, f32p))
+            out[head], lse[head], mag[head] = o, l, m
+        return out, lse, mag
+
+    # (layer, range, splits): one tile, ragged last tile, many splits, one split, range not at 0
+    cases = [(0, (0, T), None), (2, (64, 200), None), (1, (2, 4), None), (1, (0, 34), "1"), (0, (0, T), "1"), (2, (30, 512), "3")]
+    for layer, (pb, pe), splits in cases:
+        if splits is None: os.environ.pop("SPECKV_ATTEND_SPLITS", None)
+        else: os.environ["SPECKV_ATTEND_SPLITS"] = splits
+        try:
+            d_out = torch.full((H, G, D), float("nan"), dtype=torch.float32, device="cuda")
+            d_lse = torch.full((H, G), float("nan"), dtype=torch.float32, device="cuda")
+            lib.attend_fp8(h, layer, 1, d_q[layer].data_ptr(), G, pb, pe, sm, d_out.data_ptr(), d_lse.data_ptr())
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("SPECKV_ATTEND_SPLITS", None)
+        want, wlse, mag = want_for(layer, pb, pe, sm)
+        got, glse = d_out.cpu().numpy(), d_lse.cpu().numpy()
+        err = np.abs(got - want)
+        assert np.all(err <= 2e-3 * mag + 1e-6), (layer, pb, pe, splits, float((err / (mag + 1e-9)).max()))
+        assert np.all(np.abs(glse - wlse) <= 2e-3), (layer, pb, pe, float(np.abs(glse - wlse).max()))
+    # sharp softmax (large scale): the running-max rescale path, still within tolerance
+    d_out = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
+    lib.attend_fp8(h, 0, 1, d_q[0].data_ptr(), G, 0, T, 1.0, d_out.data_ptr())
+    torch.cuda.synchronize()
+    want, _, mag = want_for(0, 0, T, 1.0)
+    assert np.all(np.abs(d_out.cpu().numpy() - want) <= 2e-3 * mag + 1e-6)
+    # all layers in one launch == per-layer calls, bit for bit
+    multi = torch.empty((L, H, G, D), dtype=torch.float32, device="cuda")
+    lib.attend_fp8(h, 0, L, d_q.data_ptr(), G, 0, T, sm, multi.data_ptr())
+    torch.cuda.synchronize()
+    for layer in range(L):
+        single = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
+        lib.attend_fp8(h, layer, 1, d_q[layer].data_ptr(), G, 0, T, sm, single.data_ptr())
+        torch.cuda.synchronize()
+        want, _, mag = want_for(layer, 0, T, sm)
+        assert np.all(np.abs(single.cpu().numpy() - want) <= 2e-3 * mag + 1e-6)
+        assert np.all(np.abs(multi[layer].cpu().numpy() - want) <= 2e-3 * mag + 1e-6)
+    # and it is the attention over the fp16 KV it stands for, up to the FP8 quantisation of q, K and V
+    kfull = x[:T // 2].reshape(T // 2, 2, H, D).astype(np.float32).reshape(T, H, D)
+    vfull = x[T // 2:T].reshape(T // 2, 2, H, D).astype(np.float32).reshape(T, H, D)
+    s = np.einsum("hgd,thd->hgt", q[0].astype(np.float32), kfull) * sm
+    p = np.exp(s - s.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
+    ref = np.einsum("hgt,thd->hgd", p, vfull)
+    lib.attend_fp8(h, 0, 1, d_q[0].data_ptr(), G, 0, T, sm, d_out.data_ptr())
+    torch.cuda.synchronize()
+    rel = np.abs(d_out.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert rel <= 0.15, rel
+    # empty range -> zeros; odd positions / wrong scheme -> INVAL
+    lib.attend_fp8(h, 0, 1, d_q[0].data_ptr(), G, 8, 8, sm, d_out.data_ptr())
+    torch.cuda.synchronize()
+    assert float(d_out.abs().max()) == 0.0
+    with pytest.raises(SpeckvError):
+        lib.attend_fp8(h, 0, 1, d_q[0].data_ptr(), G, 1, 5, sm, d_out.data_ptr())
+
+
+def test_fp8_fused_attention_unwritten_pages_count_as_zeros(eng, oracle):
+    """Pages never written decode to zeros in fetch+decompress; the fused attention sees the same:
+    K = 0 (score 0, still a softmax term) and V = 0."""
+    torch = torch_mod()
+    lib = eng.lib
+    lib.set_compression_scheme(4)
+    T, L, H, D, bpe, G = 64, 1, 8, 128, 2, 4
+    h = eng.allocate(T, L, H, D, bpe)
+    rng = np.random.default_rng(5)
+    # write K pages 0..15 (positions 0..31) and V pages 0..15 only; positions 32..63 stay unwritten
+    xk = rng.standard_normal((16, N)).astype(np.float16)
+    xv = rng.standard_normal((16, N)).astype(np.float16)
+    lib.write(h, 0, xk.ctypes.data, xk.nbytes, False)
+    lib.write(h, (T // 2) * PAGE, xv.ctypes.data, xv.nbytes, False)
+    sk, _, rk = oracle.compress_blocks_f16(xk, 4, 0)
+    sv, _, rv = oracle.compress_blocks_f16(xv, 4, 0)
+    recs_k = np.zeros((T // 2, rk.shape[1]), np.uint8); recs_k[:16] = rk
+    recs_v = np.zeros((T // 2, rv.shape[1]), np.uint8); recs_v[:16] = rv
+    sc_k = np.zeros(T // 2, np.float32); sc_k[:16] = sk
+    sc_v = np.zeros(T // 2, np.float32); sc_v[:16] = sv
+    from oracle.bindings import _ptr, u8p, u16p, f32p
+    q = rng.standard_normal((H, G, D)).astype(np.float16)
+    q8 = np.zeros((H * G, D), np.uint8); qs = np.zeros(H * G, np.float32)
+    oracle.lib.orc_quantize_rows_e4m3(_ptr(q.view(np.uint16).reshape(-1), u16p), H * G, D, _ptr(q8, u8p), _ptr(qs, f32p))
+    d_q = torch.from_numpy(q.view(np.int16)).cuda()
+    d_out = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
+    sm = 0.1
+    lib.attend_fp8(h, 0, 1, d_q.data_ptr(), G, 0, T, sm, d_out.data_ptr())
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    for head in range(H):
+        krows, ksc = _fp8_head_rows(recs_k, sc_k, 0, T, head, H, D)
+        vrows, vsc = _fp8_head_rows(recs_v, sc_v, 0, T, head, H, D)
+        o = np.zeros((G, D), np.float32); m = np.zeros((G, D), np.float32)
+        oracle.lib.orc_attend_fp8(_ptr(np.ascontiguousarray(q8[head * G:(head + 1) * G]), u8p), _ptr(qs[head * G:(head + 1) * G].copy(), f32p), G,
+                                  _ptr(krows, u8p), _ptr(ksc, f32p), _ptr(vrows, u8p), _ptr(vsc, f32p), T, D, sm,
+                                  _ptr(o, f32p), None, _ptr(m, f32p))
+        assert np.all(np.abs(got[head] - o) <= 2e-3 * m + 1e-6)
+
+
 def test_migrate_records_between_pool_slabs(oracle):
     """speckv_ext_migrate: hipMemcpyPeerAsync of record runs + page-table re-point
     (one GPU here, so source and target pool are the same device; the copy path,
