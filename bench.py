@@ -445,9 +445,27 @@ def fp8_scores_extra(torch, kv, T, Lyr):
         b.record(s); torch.cuda.synchronize()
         ms = a.elapsed_time(b) / reps
         k_bytes = Lyr * (T // 2) * 2048
+        # the whole decode attention (scores + softmax + p.V) of every layer from the same records
+        att = {}
+        try:
+            o = torch.empty((Lyr, 8, 8, 128), dtype=torch.float32, device="cuda")
+            def attend():
+                lib.attend_fp8(h, 0, Lyr, q.data_ptr(), 8, 0, T, 0.08838834764831845, o.data_ptr(), None, s.cuda_stream)
+            attend(); torch.cuda.synchronize()
+            a.record(s)
+            for _ in range(reps):
+                attend()
+            b.record(s); torch.cuda.synchronize()
+            ams = a.elapsed_time(b) / reps
+            att = {"fp8_fused_attention": {"layers": Lyr, "positions": T, "query_rows_per_kv_head": 8,
+                                           "ms_all_layers": round(ams, 4), "KV_record_GBps": round(2 * k_bytes / (ams * 1e-3) / 1e9, 1),
+                                           "frac_hbm": round(2 * k_bytes / (ams * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                           "note": "softmax(q.K^T).V of all layers: quantise + attend + combine launches; bytes = K and V records"}}
+        except Exception as e:
+            att = {"fp8_fused_attention": {"error": repr(e)}}
         lib.free(h)
         out_bytes = Lyr * 8 * 8 * T * 4
-        return {"fp8_qk_scores_mfma": {"layers": Lyr, "positions": T, "query_rows_per_kv_head": 8,
+        return {**att, "fp8_qk_scores_mfma": {"layers": Lyr, "positions": T, "query_rows_per_kv_head": 8,
                                        "pool_GiB_fp8": round(n_pages * 2048 / 2**30, 2), "scores_written_GBps": round(out_bytes / (ms * 1e-3) / 1e9, 1),
                                        "ms_all_layers": round(ms, 4), "K_record_GBps": round(k_bytes / (ms * 1e-3) / 1e9, 1),
                                        "frac_hbm": round(k_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),

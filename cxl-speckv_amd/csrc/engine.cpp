@@ -271,11 +271,19 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
             if (ok) ok = hipMalloc(reinterpret_cast<void**>(&a->d_flags), a->n_pages * sizeof(uint32_t)) == hipSuccess;
             if (ok) ok = hipMemsetAsync(a->d_flags, 0, a->n_pages * sizeof(uint32_t), stream_) == hipSuccess;
             if (ok) {
-                if (single_run)
+                if (single_run) {
                     ok = launch_init_entries(a->d_entries, a->n_pages, reinterpret_cast<uint64_t>(a->extents[0].base),
                                              a->rec_stride, stream_) == hipSuccess;
-                else
+                    // FP8 pools start as zero bytes (= records of zeros), which lets the fused attention address
+                    // them arithmetically without a validity test per page
+                    if (ok && a->scheme == SPECKV_COMP_FP8_E4M3 && pools_[a->extents[0].pool]->device() == device_) {
+                        ok = hipMemsetAsync(a->extents[0].base, 0, a->extents[0].bytes, stream_) == hipSuccess;
+                        if (ok) a->linear_base = static_cast<uint8_t*>(a->extents[0].base);
+                    }
+                }
+                else {
                     ok = hipMemcpy(a->d_entries, host.data(), host.size() * sizeof(PageEntry), hipMemcpyHostToDevice) == hipSuccess;
+                }
             }
             a->pool_of_residue.assign(D, 0);
             for (uint64_t k = 0; k < D; ++k) a->pool_of_residue[k] = use[k];
@@ -1144,6 +1152,7 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     k.qs = reinterpret_cast<float*>(buf + q_bytes);
     k.scale_log2e = sm_scale * 1.4426950408889634f;
     k.zero_page = d_zero_page_;
+    k.lin_base = getenv("SPECKV_ATTEND_GENERAL") ? nullptr : a->linear_base;
     k.part_acc = reinterpret_cast<float*>(buf + q_bytes + qs_bytes);
     k.part_ml = reinterpret_cast<float*>(buf + q_bytes + qs_bytes + acc_bytes);
     HIP_TRY(launch_quantize_q_e4m3(d_q_f16, rows, g, L.head_dim, buf, reinterpret_cast<float*>(buf + q_bytes), st));
@@ -1206,6 +1215,7 @@ int Engine::migrate(uint64_t handle, uint64_t first, uint64_t n, uint32_t target
     }
     a->extents.push_back({static_cast<int>(target_pool), dst, n * stride, n});
     for (uint64_t i = 0; i < n; ++i) a->page_pool[first + i] = static_cast<uint8_t>(target_pool);
+    a->linear_base = nullptr;                     // records no longer lie in one run
     st_.pool_migrated_pages += n;
     (void)hipSetDevice(prev);
     return SPECKV_OK;

@@ -62,6 +62,9 @@ struct Allocation {
     std::vector<uint8_t> page_pool;       // pool index holding each page's record now
     PageEntry* d_entries = nullptr;
     uint32_t* d_flags = nullptr;
+    // set while every record lies in ONE run of one local pool (record p at linear_base + p*rec_stride)
+    // and, for the fixed-size formats, never-written records are zero bytes; cleared by a migration
+    uint8_t* linear_base = nullptr;
     bool has_layout = false;
     Layout layout{};
 };

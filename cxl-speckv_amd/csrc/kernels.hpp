@@ -107,7 +107,9 @@ struct AttendArgs {
     const uint8_t* q8;                // [layers][heads][16][128] e4m3
     const float* qs;                  // [layers][heads][16]
     float scale_log2e;                // sm_scale * log2(e)
-    const uint8_t* zero_page;         // 4 KiB of zeros: stands in for pages never written
+    const uint8_t* zero_page;         // 4 KiB of zeros: stands in for pages never written (general form)
+    const uint8_t* lin_base;          // non-null: record p of the allocation sits at lin_base + p*2048 and
+                                      // never-written records are zero bytes (linear, pipelined form)
     float* part_acc;                  // [layers][heads][splits][16][128]
     float* part_ml;                   // [layers][heads][splits][2][16]
 };

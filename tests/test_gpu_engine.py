@@ -390,8 +390,10 @@ def test_fp8_fused_attention(eng, oracle):
     """BASELINE config 5, both halves of the fused dequant-matvec: softmax(q.K^T).V straight from
     the FP8 K and V records (speckv_ext_attend_fp8) against the oracle's double-precision
     attention over the same e4m3 bytes.  Error sources of the HIP path: softmax weights rounded
-    to f16 (2^-11 each), the fp8 MFMA's accumulation of the scores (test above), v_exp_f32, fp32
-    accumulation.  Stated tolerance: |got - want| <= 2e-3 * sum_t p_t |v_t| + 1e-6, lse within 2e-3."""
+    to f16 (2^-11 each), v_exp_f32, fp32 accumulation, and the fp8 MFMA's accumulation of the
+    scores (test above: delta <= 3e-5 * sum|q||k| * scales per score), which moves each softmax
+    weight by a relative delta.  Stated tolerance, with mag = sum_t p_t |v_t|:
+    |got - want| <= (2e-3 + 2*delta_max) * mag + 1e-6, lse within 2e-3 + delta_max."""
     torch = torch_mod()
     lib = eng.lib
     lib.set_compression_scheme(4)
@@ -409,21 +411,26 @@ def test_fp8_fused_attention(eng, oracle):
     oracle.lib.orc_quantize_rows_e4m3(_ptr(q.view(np.uint16).reshape(-1), u16p), L * H * G, D, _ptr(q8, u8p), _ptr(qs, f32p))
     q8 = q8.reshape(L, H, G, D); qs = qs.reshape(L, H, G)
     sm = 1.0 / np.sqrt(D)
+    lut = np.array([oracle.lib.orc_e4m3_to_f32(b) for b in range(256)], np.float32)
+    lut[np.isnan(lut)] = 0.0
 
     def want_for(layer, pb, pe, sm_scale):
         npos = pe - pb
         kf = (layer * 2 * T + pb) // 2
         vf = kf + T // 2
         out = np.zeros((H, G, D), np.float32); lse = np.zeros((H, G), np.float32); mag = np.zeros((H, G, D), np.float32)
+        delta = 0.0
         for head in range(H):
             krows, ksc = _fp8_head_rows(recs, scales, kf, npos, head, H, D)
             vrows, vsc = _fp8_head_rows(recs, scales, vf, npos, head, H, D)
+            smag = (np.abs(lut[q8[layer, head]]) @ np.abs(lut[krows]).T) * ksc[None, :] * qs[layer, head][:, None] * sm_scale
+            delta = max(delta, 3e-5 * float(smag.max()))
             o = np.zeros((G, D), np.float32); l = np.zeros(G, np.float32); m = np.zeros((G, D), np.float32)
             oracle.lib.orc_attend_fp8(_ptr(np.ascontiguousarray(q8[layer, head]), u8p), _ptr(qs[layer, head].copy(), f32p), G,
                                       _ptr(krows, u8p), _ptr(ksc, f32p), _ptr(vrows, u8p), _ptr(vsc, f32p), npos, D,
                                       float(sm_scale), _ptr(o, f32p), _ptr(l, f32p), _ptr(m, f32p))
             out[head], lse[head], mag[head] = o, l, m
-        return out, lse, mag
+        return out, lse, mag, delta
 
     # (layer, range, splits): one tile, ragged last tile, many splits, one split, range not at 0
     cases = [(0, (0, T), None), (2, (64, 200), None), (1, (2, 4), None), (1, (0, 34), "1"), (0, (0, T), "1"), (2, (30, 512), "3")]
@@ -437,17 +444,17 @@ def test_fp8_fused_attention(eng, oracle):
             torch.cuda.synchronize()
         finally:
             os.environ.pop("SPECKV_ATTEND_SPLITS", None)
-        want, wlse, mag = want_for(layer, pb, pe, sm)
+        want, wlse, mag, delta = want_for(layer, pb, pe, sm)
         got, glse = d_out.cpu().numpy(), d_lse.cpu().numpy()
         err = np.abs(got - want)
-        assert np.all(err <= 2e-3 * mag + 1e-6), (layer, pb, pe, splits, float((err / (mag + 1e-9)).max()))
-        assert np.all(np.abs(glse - wlse) <= 2e-3), (layer, pb, pe, float(np.abs(glse - wlse).max()))
+        assert np.all(err <= (2e-3 + 2 * delta) * mag + 1e-6), (layer, pb, pe, splits, float((err / (mag + 1e-9)).max()))
+        assert np.all(np.abs(glse - wlse) <= 2e-3 + delta), (layer, pb, pe, float(np.abs(glse - wlse).max()))
     # sharp softmax (large scale): the running-max rescale path, still within tolerance
     d_out = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
     lib.attend_fp8(h, 0, 1, d_q[0].data_ptr(), G, 0, T, 1.0, d_out.data_ptr())
     torch.cuda.synchronize()
-    want, _, mag = want_for(0, 0, T, 1.0)
-    assert np.all(np.abs(d_out.cpu().numpy() - want) <= 2e-3 * mag + 1e-6)
+    want, _, mag, delta = want_for(0, 0, T, 1.0)
+    assert np.all(np.abs(d_out.cpu().numpy() - want) <= (2e-3 + 2 * delta) * mag + 1e-6), delta
     # all layers in one launch == per-layer calls, bit for bit
     multi = torch.empty((L, H, G, D), dtype=torch.float32, device="cuda")
     lib.attend_fp8(h, 0, L, d_q.data_ptr(), G, 0, T, sm, multi.data_ptr())
@@ -456,9 +463,9 @@ def test_fp8_fused_attention(eng, oracle):
         single = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
         lib.attend_fp8(h, layer, 1, d_q[layer].data_ptr(), G, 0, T, sm, single.data_ptr())
         torch.cuda.synchronize()
-        want, _, mag = want_for(layer, 0, T, sm)
-        assert np.all(np.abs(single.cpu().numpy() - want) <= 2e-3 * mag + 1e-6)
-        assert np.all(np.abs(multi[layer].cpu().numpy() - want) <= 2e-3 * mag + 1e-6)
+        want, _, mag, delta = want_for(layer, 0, T, sm)
+        assert np.all(np.abs(single.cpu().numpy() - want) <= (2e-3 + 2 * delta) * mag + 1e-6)
+        assert np.all(np.abs(multi[layer].cpu().numpy() - want) <= (2e-3 + 2 * delta) * mag + 1e-6)
     # and it is the attention over the fp16 KV it stands for, up to the FP8 quantisation of q, K and V
     kfull = x[:T // 2].reshape(T // 2, 2, H, D).astype(np.float32).reshape(T, H, D)
     vfull = x[T // 2:T].reshape(T // 2, 2, H, D).astype(np.float32).reshape(T, H, D)
