@@ -44,6 +44,12 @@ __device__ __forceinline__ uint4 ldg16(const uint8_t* p)
     const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ uint2 ldg8(const uint8_t* p)
+{
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+    return make_uint2(v.x, v.y);
+}
 __device__ __forceinline__ uint32_t ldg4(const uint8_t* p)
 {
     return __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p));
@@ -71,16 +77,14 @@ struct AttState {
     f32x4 acc[2][4];       // out[row c][64blk + 16kb + 4i + t] in acc[blk][t][i], unnormalised
 };
 
-// scores -> online softmax -> out^T += V^T . P^T for one tile.  inr[r]: slot page r lies inside the range.
-__device__ __forceinline__ void attend_tile(const AttTile& T, const bool (&inr)[4], const uint32_t (&qd)[8], float qscale,
-                                            AttState& S)
+// Phase 1 of a tile: scores of the lane's 8 position slots (log2 domain) from the K registers.
+// inr[r]: slot page r lies inside the range.
+__device__ __forceinline__ void att_scores(const uint4 (&kx)[2][2], const float (&ks)[4], const bool (&inr)[4],
+                                           const uint32_t (&qd)[8], float qscale, float (&sc)[8])
 {
-    // ---- scores of the lane's 8 position slots (log2 domain)
-    float sc[8];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const uint32_t kd[8] = {T.kx[b][0].x, T.kx[b][0].y, T.kx[b][0].z, T.kx[b][0].w,
-                                T.kx[b][1].x, T.kx[b][1].y, T.kx[b][1].z, T.kx[b][1].w};
+        const uint32_t kd[8] = {kx[b][0].x, kx[b][0].y, kx[b][0].z, kx[b][0].w, kx[b][1].x, kx[b][1].y, kx[b][1].z, kx[b][1].w};
         f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int st = 0; st < 4; ++st)
@@ -88,10 +92,14 @@ __device__ __forceinline__ void attend_tile(const AttTile& T, const bool (&inr)[
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int j = 4 * b + i;
-            sc[j] = inr[j >> 1] ? s[i] * T.ks[j >> 1] * qscale : -INFINITY;
+            sc[j] = inr[j >> 1] ? s[i] * ks[j >> 1] * qscale : -INFINITY;
         }
     }
-    // ---- online softmax of query row c (its 32 positions sit in lanes c, c+16, c+32, c+48)
+}
+// Phase 2: online softmax of query row c (its 32 positions sit in lanes c, c+16, c+32, c+48),
+// then out^T += V^T . P^T from the V registers.
+__device__ __forceinline__ void att_softmax_pv(const float (&sc)[8], const uint32_t (&vx)[2][8], const float (&vs)[4], AttState& S)
+{
     float mx = sc[0];
 #pragma unroll
     for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc[j]);
@@ -100,7 +108,7 @@ __device__ __forceinline__ void attend_tile(const AttTile& T, const bool (&inr)[
     const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;              // a fully masked row stays at weight 0
     const float alpha = __builtin_amdgcn_exp2f(S.m_run - m_use);
     S.m_run = m_new;
-    float vmx = fmaxf(fmaxf(T.vs[0], T.vs[1]), fmaxf(T.vs[2], T.vs[3]));
+    float vmx = fmaxf(fmaxf(vs[0], vs[1]), fmaxf(vs[2], vs[3]));
     vmx = max_over_kb(vmx);                                               // the tile's largest V page scale
     const float vinv = vmx > 0.0f ? 1.0f / vmx : 0.0f;
     float psum = 0.0f;
@@ -109,18 +117,17 @@ __device__ __forceinline__ void attend_tile(const AttTile& T, const bool (&inr)[
     for (int j = 0; j < 8; ++j) {
         const float p = __builtin_amdgcn_exp2f(sc[j] - m_use);
         psum += p;
-        P[j] = static_cast<_Float16>(p * (T.vs[j >> 1] * vinv));          // V page scale rides on the weight, <= 1
+        P[j] = static_cast<_Float16>(p * (vs[j >> 1] * vinv));            // V page scale rides on the weight, <= 1
     }
     S.l_run = S.l_run * alpha + psum;
-    // ---- out^T += V^T . P^T
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
         uint32_t w01[4], w23[4];
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
             // [lo.b0, hi.b0, lo.b1, hi.b1] / [lo.b2, hi.b2, lo.b3, hi.b3]: two positions of one d column per word
-            w01[jp] = __builtin_amdgcn_perm(T.vx[blk][2 * jp + 1], T.vx[blk][2 * jp], 0x05010400u);
-            w23[jp] = __builtin_amdgcn_perm(T.vx[blk][2 * jp + 1], T.vx[blk][2 * jp], 0x07030602u);
+            w01[jp] = __builtin_amdgcn_perm(vx[blk][2 * jp + 1], vx[blk][2 * jp], 0x05010400u);
+            w23[jp] = __builtin_amdgcn_perm(vx[blk][2 * jp + 1], vx[blk][2 * jp], 0x07030602u);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -138,6 +145,13 @@ __device__ __forceinline__ void attend_tile(const AttTile& T, const bool (&inr)[
             for (int i = 0; i < 4; ++i) S.acc[blk][t][i] = S.acc[blk][t][i] * alpha + o[i] * vmx;
         }
     }
+}
+__device__ __forceinline__ void attend_tile(const AttTile& T, const bool (&inr)[4], const uint32_t (&qd)[8], float qscale,
+                                            AttState& S)
+{
+    float sc[8];
+    att_scores(T.kx, T.ks, inr, qd, qscale, sc);
+    att_softmax_pv(sc, T.vx, T.vs, S);
 }
 
 __device__ __forceinline__ void att_init(AttState& S)
@@ -175,7 +189,7 @@ __device__ __forceinline__ void att_store(const AttendArgs& a, const AttState& S
 // General form: every page goes through its page-table entry (pool address, validity, scale), so
 // records may sit anywhere (striped over pool GPUs, migrated, fragmented).  Two dependent
 // memory round trips per tile; the linear form below is the fast one.
-__global__ __launch_bounds__(256) void k_attend_fp8(AttendArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_attend_fp8(AttendArgs a)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -245,12 +259,56 @@ __global__ __launch_bounds__(256) void k_attend_fp8(AttendArgs a)
     att_store(a, S, row * a.n_splits + split, c, kb);
 }
 
-// Linear form: the allocation's records lie in one run (record p at lin_base + p*2048, the engine's
-// default placement) and never-written records are zero bytes (the engine zero-fills FP8 pools), so
-// every data address is arithmetic and only the page scales come from the page table -- nothing
-// gates the data loads.  Tiles are double-buffered in registers: the loads of tile t+1 are in
-// flight while tile t is computed.
-__global__ __launch_bounds__(256) void k_attend_fp8_linear(AttendArgs a)
+// ---- linear form ------------------------------------------------------------------------------
+// The allocation's records lie in one run (record p at lin_base + p*2048, the engine's default
+// placement) and never-written records are zero bytes (the engine zero-fills FP8 pools), so every
+// data address is arithmetic.  What the page table holds per page (scale, validity) is condensed
+// by k_attend_prepare into per-tile tables, laid out so that one 16-byte load gives a lane the
+// scales of its four slot pages; nothing gates the data loads any more.
+//
+// The texture addresser, not HBM, bounds the page-table form (28 loads per tile, TA 80 % busy at
+// 5.1 TB/s, profiles/): here a tile costs 15 loads -- K 4 x 16 B, V 8 x 8 B (whole 128-byte lines
+// per instruction), tables 3.  V as 8-byte pieces changes the d map of the output MFMAs to
+// d = 8c + t (t = 0..7), i.e. lane (c, kb) holds out[row c][32kb + 8i + t] in acc[t][i].
+//
+// The output MFMAs accumulate in place (C = acc).  acc is kept in units of the current tile's V
+// reference scale vref_t (its largest V page scale, 1 when that is 0), so the V page scales ride on
+// the f16 weights as vs/vref_t <= 1 and the only per-tile fix-up of acc is one multiply by
+// alpha * vref_{t-1}/vref_t (the ratio is tabulated, exact division, by the prepare kernel).
+
+// tables per (layer, tile): ktab/vtab 16 floats permuted as [kb][r] (r-th slot page of lane group kb:
+// pages 2kb, 2kb+1, 8+2kb, 9+2kb), vtab normalised by vref; vinfo {vref_t, vref_{t-1}/vref_t}
+__global__ __launch_bounds__(256) void k_attend_prepare(AttendArgs a, uint32_t n_tiles)
+{
+    const uint32_t layer = blockIdx.y, slot = threadIdx.x & 15u;
+    const uint32_t tile = blockIdx.x * 16u + (threadIdx.x >> 4);
+    const PageEntry* kent = a.entries + a.k_first + layer * a.layer_stride;
+    const PageEntry* vent = a.entries + a.v_first + layer * a.layer_stride;
+    auto page_of = [&](uint32_t t, uint32_t sl) { const uint32_t q = sl >> 2, r = sl & 3u; return t * 16u + (r < 2u ? 2u * q + r : 8u + 2u * q + (r - 2u)); };
+    auto vscale_of = [&](uint32_t t, uint32_t sl) {
+        const uint32_t pg = page_of(t, sl);
+        if (t >= n_tiles || pg >= a.n_pages) return 0.0f;
+        const PageEntry e = vent[pg];
+        return e.rec_bytes >= kBlockElems ? e.scale : 0.0f;
+    };
+    float ksc = 0.0f;
+    if (tile < n_tiles && page_of(tile, slot) < a.n_pages) {
+        const PageEntry e = kent[page_of(tile, slot)];
+        if (e.rec_bytes >= kBlockElems) ksc = e.scale;
+    }
+    const float vsc = vscale_of(tile, slot);
+    float vmx = vsc, pmx = (tile > 0) ? vscale_of(tile - 1u, slot) : 0.0f;     // this tile's and the previous tile's largest
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { vmx = fmaxf(vmx, __shfl_xor(vmx, o)); pmx = fmaxf(pmx, __shfl_xor(pmx, o)); }
+    if (tile >= n_tiles) return;
+    const float vref = vmx > 0.0f ? vmx : 1.0f, pref = pmx > 0.0f ? pmx : 1.0f;
+    const uint64_t at = static_cast<uint64_t>(layer) * n_tiles + tile;
+    a.ktab[at * 16u + slot] = ksc;
+    a.vtab[at * 16u + slot] = vsc / vref;
+    if (slot == 0) { a.vinfo[at * 2u] = vref; a.vinfo[at * 2u + 1u] = pref / vref; }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_attend_fp8_linear(AttendArgs a)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -259,12 +317,8 @@ __global__ __launch_bounds__(256) void k_attend_fp8_linear(AttendArgs a)
     const uint32_t hq = a.heads / 4u;
     const uint32_t layer = blockIdx.y / hq;
     const uint32_t head = (blockIdx.y % hq) * 4u + wave;
-    const uint64_t kpage0 = a.k_first + layer * a.layer_stride, vpage0 = a.v_first + layer * a.layer_stride;
-    const PageEntry* kent = a.entries + kpage0;
-    const PageEntry* vent = a.entries + vpage0;
-    const uint8_t* kbase = a.lin_base + kpage0 * 2048ull + head * 128u + kb * 32u;     // + position * 1024
-    const uint8_t* vbase = a.lin_base + vpage0 * 2048ull + head * 128u + 4u * c;
     const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;
+    const uint64_t part = row * a.n_splits + split;
 
     const uint8_t* qrow = a.q8 + (row * 16u + c) * 128u + kb * 32u;
     const uint4 qa0 = *reinterpret_cast<const uint4*>(qrow), qa1 = *reinterpret_cast<const uint4*>(qrow + 16);
@@ -274,51 +328,137 @@ __global__ __launch_bounds__(256) void k_attend_fp8_linear(AttendArgs a)
     const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
     const uint32_t t0 = split * a.tiles_per_split;
     const uint32_t t1 = min(t0 + a.tiles_per_split, n_tiles);
-    const uint32_t last_pos = 2u * a.n_pages - 1u, last_page = a.n_pages - 1u;
+    float m_run = -INFINITY, l_run = 0.0f, vref = 1.0f;
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // positions and pages beyond the range are clamped to the last valid one for the loads and masked by inr
-    auto issue = [&](uint32_t tile, AttTile& T) {
-        const uint32_t p0 = tile * 32u, pg0 = tile * 16u;
+    if (t0 < t1) {                                                       // wave-uniform
+        // running pointers of the tile being requested
+        const uint8_t* kp = a.lin_base + (a.k_first + layer * a.layer_stride) * 2048ull + head * 128u + kb * 32u
+                            + (static_cast<uint64_t>(t0) * 32u + c) * 1024u;            // block b: + b*16 KiB
+        const uint8_t* vp = a.lin_base + (a.v_first + layer * a.layer_stride) * 2048ull + head * 128u + 8u * c
+                            + (static_cast<uint64_t>(t0) * 32u + 4u * kb) * 1024u;       // slot j: + (j&3) KiB + (j>>2)*16 KiB
+        const uint64_t at0 = static_cast<uint64_t>(layer) * n_tiles + t0;
+        const float* kt = a.ktab + at0 * 16u + 4u * kb;
+        const float* vt = a.vtab + at0 * 16u + 4u * kb;
+        const float* vi = a.vinfo + at0 * 2u;
+
+        uint4 kx[2][2];
+        uint2 vx[8];
+        f32x4 ks4, vs4;
+        float vref_t, ratio_t;
+        auto issue_k = [&]() {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const uint8_t* r = kbase + static_cast<uint64_t>(min(p0 + 16u * b + c, last_pos)) * 1024u;
-            T.kx[b][0] = ldg16(r);
-            T.kx[b][1] = ldg16(r + 16);
-        }
+            for (int b = 0; b < 2; ++b) { kx[b][0] = ldg16(kp + 16384 * b); kx[b][1] = ldg16(kp + 16384 * b + 16); }
+            ks4 = *reinterpret_cast<const f32x4*>(kt);
+        };
+        auto issue_v = [&]() {
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+            for (int j = 0; j < 8; ++j) vx[j] = ldg8(vp + 1024 * (j & 3) + 16384 * (j >> 2));
+            vs4 = *reinterpret_cast<const f32x4*>(vt);
+            vref_t = vi[0];
+            ratio_t = vi[1];
+        };
+        // same request order as in the loop (K before V), pinned, so that the wait at the loop head is
+        // "everything up to K" on both paths into it
+        __builtin_amdgcn_sched_barrier(0);
+        issue_k();
+        __builtin_amdgcn_sched_barrier(0);
+        issue_v();
+        __builtin_amdgcn_sched_barrier(0);
+        const bool ragged = (a.n_pages & 15u) != 0u;
+#pragma unroll 1
+        for (uint32_t tile = t0; tile < t1; ++tile) {
+            // ONE register set, refilled as soon as its consumer has read it: K(t+1) is requested right after
+            // the score MFMAs of tile t (in flight during the softmax and p.V), V(t+1) right after p.V (in flight
+            // during the next scores).  The refills are unconditional -- the last iteration re-requests its own
+            // tile -- so the loop body is one basic block and the compiler's s_waitcnt vmcnt(N) counts are exact.
+            const uint32_t step = (tile + 1u < t1) ? 1u : 0u;            // scalar
+            // ---- scores
+            float sc[8];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const uint32_t kd[8] = {kx[b][0].x, kx[b][0].y, kx[b][0].z, kx[b][0].w, kx[b][1].x, kx[b][1].y, kx[b][1].z, kx[b][1].w};
+                f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(kd[2 * st], kd[2 * st + 1]), pack64(qd[2 * st], qd[2 * st + 1]), s, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sc[4 * b + i] = s[i] * (ks4[2 * b + (i >> 1)] * qscale);
+            }
+            if (ragged && tile + 1u == n_tiles) {                         // wave-uniform: positions beyond the range
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t pg = tile * 16u + ((j >> 1) < 2 ? 2u * kb + (j >> 1) : 8u + 2u * kb + ((j >> 1) - 2));
+                    if (pg >= a.n_pages) sc[j] = -INFINITY;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            kp += step * 32768u; kt += step * 16u;
+            issue_k();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- online softmax of query row c
+            float mx = sc[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc[j]);
+            mx = max_over_kb(mx);
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;
+            const float f = __builtin_amdgcn_exp2f(m_run - m_use);
+            m_run = m_new;
+            float psum = 0.0f;
+            f16x8 P;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const uint32_t pos = p0 + (j < 4 ? 4u * kb + j : 16u + 4u * kb + (j - 4));
-                T.vx[blk][j] = ldg4(vbase + static_cast<uint64_t>(min(pos, last_pos)) * 1024u + 64 * blk);
+                const float p = __builtin_amdgcn_exp2f(sc[j] - m_use);
+                psum += p;
+                P[j] = static_cast<_Float16>(p * vs4[j >> 1]);
+            }
+            l_run = l_run * f + psum;
+            const float fa = f * ratio_t;                                 // acc: old max -> new max, old V reference -> new
+            vref = vref_t;
+            // ---- out^T += V^T . P^T, accumulated in place
+            uint32_t w[4][4];                                             // [row pair][byte pair of the 8 d]
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                w[jp][0] = __builtin_amdgcn_perm(vx[2 * jp + 1].x, vx[2 * jp].x, 0x05010400u);
+                w[jp][1] = __builtin_amdgcn_perm(vx[2 * jp + 1].x, vx[2 * jp].x, 0x07030602u);
+                w[jp][2] = __builtin_amdgcn_perm(vx[2 * jp + 1].y, vx[2 * jp].y, 0x05010400u);
+                w[jp][3] = __builtin_amdgcn_perm(vx[2 * jp + 1].y, vx[2 * jp].y, 0x07030602u);
             }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t pg = min(pg0 + (r < 2 ? 2u * kb + r : 8u + 2u * kb + (r - 2)), last_page);
-            T.ks[r] = kent[pg].scale;
-            T.vs[r] = vent[pg].scale;
-        }
-    };
-    auto compute = [&](uint32_t tile, const AttTile& T, AttState& S) {
-        bool inr[4];
+            for (int t = 0; t < 8; ++t) {
+                f16x8 V;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) inr[r] = tile * 16u + (r < 2 ? 2u * kb + r : 8u + 2u * kb + (r - 2)) < a.n_pages;
-        attend_tile(T, inr, qd, qscale, S);
-    };
-
-    AttState S;
-    att_init(S);
-    AttTile A, B;
-    if (t0 < t1) issue(t0, A);
-#pragma unroll 1
-    for (uint32_t tile = t0; tile < t1; tile += 2) {
-        if (tile + 1 < t1) issue(tile + 1, B);
-        compute(tile, A, S);
-        if (tile + 1 >= t1) break;
-        if (tile + 2 < t1) issue(tile + 2, A);
-        compute(tile + 1, B, S);
+                for (int jp = 0; jp < 4; ++jp) {
+                    const f16x2 h = (t & 1) ? __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w[jp][t >> 1], 1.0f, true)
+                                            : __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w[jp][t >> 1], 1.0f, false);
+                    V[2 * jp] = h.x;
+                    V[2 * jp + 1] = h.y;
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t] * fa, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            vp += step * 32768u; vt += step * 16u; vi += step * 2u;
+            issue_v();
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
-    att_store(a, S, row * a.n_splits + split, c, kb);
+    // ---- partial result of this split, back in true units
+    const float l_tot = sum_over_kb(l_run);
+    if (kb == 0) {
+        a.part_ml[part * 32u + c] = m_run;
+        a.part_ml[part * 32u + 16u + c] = l_tot;
+    }
+    if (c < a.g) {
+        float* dst = a.part_acc + (part * 16u + c) * 128u + 32u * kb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(dst + 8 * i) = f32x4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]} * vref;
+            *reinterpret_cast<f32x4*>(dst + 8 * i + 4) = f32x4{acc[4][i], acc[5][i], acc[6][i], acc[7][i]} * vref;
+        }
+    }
 }
 
 // one workgroup (128 threads = the 128 d) per (layer, head, query row): merge the splits
@@ -344,8 +484,13 @@ __global__ __launch_bounds__(128) void k_attend_combine(const float* __restrict_
 hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s)
 {
     if (a.n_pages == 0 || n_layers == 0) return hipSuccess;
-    if (a.lin_base) hipLaunchKernelGGL(k_attend_fp8_linear, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
-    else            hipLaunchKernelGGL(k_attend_fp8, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
+    if (a.lin_base) {
+        const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
+        hipLaunchKernelGGL(k_attend_prepare, dim3((n_tiles + 15u) / 16u, n_layers), dim3(256), 0, s, a, n_tiles);
+        hipLaunchKernelGGL(k_attend_fp8_linear, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(k_attend_fp8, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_attend_combine, dim3(n_layers * a.heads * a.g), dim3(128), 0, s, a.part_acc, a.part_ml, a.g,

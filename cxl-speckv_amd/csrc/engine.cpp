@@ -1125,10 +1125,12 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
         HIP_TRY(hipMemset(d_zero_page_, 0, kPageSize));
     }
-    // splits: enough waves to fill the chip (~32 per CU), never less than one 32-position tile each
+    // splits: ~64 waves per CU over the launch (several rounds of the 8 resident ones), at least 8 tiles
+    // (256 positions) per split so the register pipeline fills and the partials stay small
     const uint32_t n_tiles = (n_pages + 15u) / 16u;
     const uint32_t rows = n_layers * L.num_heads;
-    uint32_t want = (8192u + rows - 1u) / rows;
+    uint32_t want = (16384u + rows - 1u) / rows;
+    want = std::min(want, std::max(1u, n_tiles / 8u));
     if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));
     uint32_t n_splits = std::max(1u, std::min(want, n_tiles));
     const uint32_t tiles_per_split = (n_tiles + n_splits - 1u) / n_splits;
@@ -1136,7 +1138,9 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     const size_t q_bytes = static_cast<size_t>(rows) * 16 * 128, qs_bytes = static_cast<size_t>(rows) * 16 * sizeof(float);
     const size_t acc_bytes = static_cast<size_t>(rows) * n_splits * 16 * 128 * sizeof(float);
     const size_t ml_bytes = static_cast<size_t>(rows) * n_splits * 32 * sizeof(float);
-    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, q_bytes + qs_bytes + acc_bytes + ml_bytes));
+    const size_t tab_bytes = static_cast<size_t>(n_layers) * n_tiles * 16 * sizeof(float);
+    const size_t vinfo_bytes = static_cast<size_t>(n_layers) * n_tiles * 2 * sizeof(float);
+    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, q_bytes + qs_bytes + acc_bytes + ml_bytes + 2 * tab_bytes + vinfo_bytes));
     if (!buf) return SPECKV_ERR_NOMEM;
     AttendArgs k{};
     k.entries = a->d_entries;
@@ -1152,7 +1156,13 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     k.qs = reinterpret_cast<float*>(buf + q_bytes);
     k.scale_log2e = sm_scale * 1.4426950408889634f;
     k.zero_page = d_zero_page_;
-    k.lin_base = getenv("SPECKV_ATTEND_GENERAL") ? nullptr : a->linear_base;
+    k.ktab = reinterpret_cast<float*>(buf + q_bytes + qs_bytes + acc_bytes + ml_bytes);
+    k.vtab = k.ktab + tab_bytes / sizeof(float);
+    k.vinfo = k.vtab + tab_bytes / sizeof(float);
+    // linear form: records in one run, and the last (possibly ragged) 32-position tile must not read past
+    // the K / V region of its layer
+    const bool fits = static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
+    k.lin_base = (getenv("SPECKV_ATTEND_GENERAL") || !fits) ? nullptr : a->linear_base;
     k.part_acc = reinterpret_cast<float*>(buf + q_bytes + qs_bytes);
     k.part_ml = reinterpret_cast<float*>(buf + q_bytes + qs_bytes + acc_bytes);
     HIP_TRY(launch_quantize_q_e4m3(d_q_f16, rows, g, L.head_dim, buf, reinterpret_cast<float*>(buf + q_bytes), st));

@@ -110,6 +110,9 @@ struct AttendArgs {
     const uint8_t* zero_page;         // 4 KiB of zeros: stands in for pages never written (general form)
     const uint8_t* lin_base;          // non-null: record p of the allocation sits at lin_base + p*2048 and
                                       // never-written records are zero bytes (linear, pipelined form)
+    float* ktab;                      // linear form: per (layer, tile) 16 K page scales, permuted (attend.hip)
+    float* vtab;                      //              16 V page scales / vref
+    float* vinfo;                     //              {vref_t, vref_{t-1}/vref_t}
     float* part_acc;                  // [layers][heads][splits][16][128]
     float* part_ml;                   // [layers][heads][splits][2][16]
 };
