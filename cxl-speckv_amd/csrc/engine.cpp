@@ -1125,11 +1125,11 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
         HIP_TRY(hipMemset(d_zero_page_, 0, kPageSize));
     }
-    // splits: ~64 waves per CU over the launch (several rounds of the 8 resident ones), at least 8 tiles
-    // (256 positions) per split so the register pipeline fills and the partials stay small
+    // splits: ~40 waves per CU over the launch (a few rounds of the 16 resident ones; measured best at
+    // 70B@32k: 16 splits/row), at least 8 tiles (256 positions) per split so the partials stay small
     const uint32_t n_tiles = (n_pages + 15u) / 16u;
     const uint32_t rows = n_layers * L.num_heads;
-    uint32_t want = (16384u + rows - 1u) / rows;
+    uint32_t want = (10240u + rows - 1u) / rows;
     want = std::min(want, std::max(1u, n_tiles / 8u));
     if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));
     uint32_t n_splits = std::max(1u, std::min(want, n_tiles));
