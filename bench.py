@@ -476,6 +476,47 @@ def fp8_scores_extra(torch, kv, T, Lyr):
         lib.set_compression_scheme(2)
 
 
+def int4_attention_extra(torch, kv, T, Lyr):
+    """BASELINE configs[4], the 4:1 format: the whole decode attention of every layer of one 70B-shaped
+    sequence at 32k context straight from INT4_G32 records (1152 B per 4 KiB page)."""
+    lib = kv.lib
+    try:
+        lib.set_compression_scheme(3)
+        h = lib.alloc(T * Lyr * 8 * 128 * 2 * 2)
+        lib.set_layout(h, T, Lyr, 8, 128, 2)
+        n_pages = T * Lyr * 8 * 128 * 2 * 2 // PAGE
+        g = torch.Generator(device="cuda"); g.manual_seed(2005)
+        chunk = 65536
+        for p0 in range(0, n_pages, chunk):
+            x = torch.randn((min(chunk, n_pages - p0), BLOCK_ELEMS), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+            lib.write(h, p0 * PAGE, x.data_ptr(), x.numel() * 2, True)
+        q = torch.randn((Lyr, 8, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+        o = torch.empty((Lyr, 8, 8, 128), dtype=torch.float32, device="cuda")
+        s = torch.cuda.Stream()
+        def attend():
+            lib.attend_int4(h, 0, Lyr, q.data_ptr(), 8, 0, T, 0.08838834764831845, o.data_ptr(), None, s.cuda_stream)
+        attend(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        a.record(s)
+        for _ in range(reps):
+            attend()
+        b.record(s); torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        rec_bytes = n_pages * 1152
+        lib.free(h)
+        return {"int4_fused_attention": {"layers": Lyr, "positions": T, "query_rows_per_kv_head": 8,
+                                         "pool_GiB_int4": round(rec_bytes / 2**30, 2), "ms_all_layers": round(ms, 4),
+                                         "KV_record_GBps": round(rec_bytes / (ms * 1e-3) / 1e9, 1),
+                                         "frac_hbm": round(rec_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                         "fp16_equivalent_GBps": round(n_pages * PAGE / (ms * 1e-3) / 1e9, 1),
+                                         "note": "softmax(q.K^T).V of all layers from INT4_G32 records: attend + combine launches"}}
+    except Exception as e:
+        return {"int4_fused_attention": {"error": repr(e)}}
+    finally:
+        lib.set_compression_scheme(2)
+
+
 def predictor_extra(torch, lib):
     """Token predictor (reference LSTMPredictor::predict_top_k: 13.5 ms per call on one CPU
     core; paper claim < 10 us on the FPGA): latency of one top-4 prediction
@@ -534,7 +575,8 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     dt = time.perf_counter() - t0
     ex["prefetch_flush"] = {"requests": n_req, "pages_issued": issued, "ms": round(dt * 1e3, 3),
                             "requests_per_s": round(n_req / dt, 1)}
-    ex.update(fp8_scores_extra(torch, kv, 32768, 80))      # BASELINE configs[4] shape: 70B-shaped KV @ 32k context
+    ex.update(fp8_scores_extra(torch, kv, 32768, 80))
+    ex.update(int4_attention_extra(torch, kv, 32768, 80))      # BASELINE configs[4] shape: 70B-shaped KV @ 32k context
     ex.update(predictor_extra(torch, lib))
     return ex
 

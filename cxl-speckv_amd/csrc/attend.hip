@@ -481,6 +481,14 @@ __global__ __launch_bounds__(128) void k_attend_combine(const float* __restrict_
     if (lse && d == 0) lse[static_cast<uint64_t>(rowq) * g + m] = L > 0.0f ? (M + log2f(L)) * 0.6931471805599453f : -INFINITY;
 }
 
+hipError_t launch_attend_combine(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s)
+{
+    if (n_layers == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_attend_combine, dim3(n_layers * a.heads * a.g), dim3(128), 0, s, a.part_acc, a.part_ml, a.g,
+                       a.n_splits, d_out, d_lse);
+    return hipGetLastError();
+}
+
 hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s)
 {
     if (a.n_pages == 0 || n_layers == 0) return hipSuccess;

@@ -1,0 +1,268 @@
+// cxl-speckv_amd/csrc/attend_int4.hip -- decode attention straight from INT4_G32 pool
+// records (the 4:1 format of BASELINE config 5; SURVEY 8a row A22, no reference counterpart,
+// parity against oracle/orc_attend_f16 over the decompressed pages).
+//
+// Record of one 4 KiB page (2 positions x 8 kv heads x 128 d, element e = (slot*8 + head)*128 + d):
+// 64 fp16 group scales (group = 32 consecutive elements) then 1024 nibble bytes, low nibble = even
+// element, two's complement.  A head's row of one position = 64 nibble bytes + 4 scales.
+//
+// Semantics: K and V are dequantised exactly as fetch+decompress does (fp16(q4 * scale), one
+// rounding: v_pk_mul_f16 of two exactly represented factors), the query stays fp16, both products
+// run on v_mfma_f32_16x16x32_f16 with fp32 accumulation, softmax weights are rounded to f16.  So
+// the result is the attention over the decompressed fp16 pages without ever writing them.
+//
+// Linear form only (records of the allocation in one run, never-written records zero bytes): one
+// wave = one kv head x one split of the positions, tiles of 32 positions.
+//   scores S^T = K . q^T: lane (c, kb) feeds row c = position 16b + c, d = 32kb + 8*step + e --
+//     exactly group kb of that row: ONE 16-byte load and one scale per lane and block.
+//   output O^T = V^T . P^T: rows c = d columns 8c + t, k-slots = the lane's 8 positions (as in
+//     attend.hip).  A wave fetches the V tile with two 16-byte loads per lane (whole rows), stages
+//     it in 4 KiB of its own LDS and reads it back as "8 nibbles of one position" dwords -- 7
+//     global loads per 4.5 KiB tile; the texture addresser bounded the dword-gather form.
+#include "kernels.hpp"
+
+namespace speckv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ uint4 ldg16(const uint8_t* p)
+{
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float max_over_kb(float v)
+{
+    v = fmaxf(v, __shfl_xor(v, 16));
+    return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float sum_over_kb(float v)
+{
+    v += __shfl_xor(v, 16);
+    return v + __shfl_xor(v, 32);
+}
+__device__ __forceinline__ f16x2 as_h2(uint32_t u) { return __builtin_bit_cast(f16x2, u); }
+
+// two nibbles (already XORed with 8: offset binary) in bits [3:0] and [19:16] -> {q_lo, q_hi} * s2, exactly
+// fp16(q * s): 0x6400 | u is the fp16 number 1024 + u, so minus 1032 leaves q = u - 8 exactly.
+__device__ __forceinline__ f16x2 deq2(uint32_t spread, f16x2 s2)
+{
+    const f16x2 k1032 = {static_cast<_Float16>(1032.0f), static_cast<_Float16>(1032.0f)};
+    return (as_h2(spread | 0x64006400u) - k1032) * s2;
+}
+// selectors of v_perm_b32(S0 = high nibbles, S1 = low nibbles): byte K of each, zero-extended to 16 bits
+// -> [S1.bK, 0, S0.bK, 0]  (selector value 0x0C yields the constant 0)
+template <int K> __device__ __forceinline__ uint32_t pair_of_byte(uint32_t hi, uint32_t lo)
+{
+    return __builtin_amdgcn_perm(hi, lo, 0x0C040C00u + 0x00010001u * K);
+}
+// 8 nibbles of one row (offset binary, low nibble = even element) -> 8 fp16 values times the row's group scale
+__device__ __forceinline__ f16x8 deq_row8(uint32_t wx, f16x2 s2)
+{
+    const uint32_t lo = wx & 0x0F0F0F0Fu, hi = (wx >> 4) & 0x0F0F0F0Fu;     // elements 0,2,4,6 / 1,3,5,7
+    const f16x2 a = deq2(pair_of_byte<0>(hi, lo), s2), b = deq2(pair_of_byte<1>(hi, lo), s2);
+    const f16x2 c = deq2(pair_of_byte<2>(hi, lo), s2), d = deq2(pair_of_byte<3>(hi, lo), s2);
+    return f16x8{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+}
+
+} // namespace
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_attend_int4_linear(AttendArgs a)
+{
+    // per wave: V nibbles 32 rows x 128 B pitch (64 used, +64 for rows with bit 2 set: bank spread), then
+    // 32 rows x 8 B of V group scales
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4][4096 + 256];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t c = lane & 15u, kb = lane >> 4;
+    const uint32_t split = blockIdx.x;
+    const uint32_t hq = a.heads / 4u;
+    const uint32_t layer = blockIdx.y / hq;
+    const uint32_t head = (blockIdx.y % hq) * 4u + wave;
+    const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;
+    const uint64_t part = row * a.n_splits + split;
+    uint8_t* vl = lds[wave];
+
+    // query operand: fp16 row c of this head, d = 32kb + 8*step + e (rows >= g are zero)
+    f16x8 qv[4];
+    {
+        const uint16_t* q16 = reinterpret_cast<const uint16_t*>(a.q8) + (row * a.g + c) * 128u + kb * 32u;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            uint4 t = make_uint4(0u, 0u, 0u, 0u);
+            if (c < a.g) t = *reinterpret_cast<const uint4*>(q16 + 8 * st);
+            qv[st] = __builtin_bit_cast(f16x8, t);
+        }
+    }
+    const float qscale = a.scale_log2e;
+
+    const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
+    const uint32_t t0 = split * a.tiles_per_split;
+    const uint32_t t1 = min(t0 + a.tiles_per_split, n_tiles);
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    if (t0 < t1) {                                                       // wave-uniform
+        const uint32_t rowoff = (c & 1u) * 8u + head;                    // (slot, head) row of the lane's K rows
+        // K: lane's rows 16b + c of the tile -> page tile*16 + 8b + c/2; per tile the pointers advance 16 pages
+        const uint8_t* kpage = a.lin_base + (a.k_first + layer * a.layer_stride + static_cast<uint64_t>(t0) * 16u + (c >> 1)) * kInt4RecBytes;
+        const uint8_t* kdat = kpage + 128u + rowoff * 64u + kb * 16u;    // block b: + 8 pages
+        const uint8_t* ksc = kpage + rowoff * 8u + kb * 2u;
+        // V staging loads: instruction n covers rows 16n + lane/4 (16-byte piece lane%4); scales: row lane/2, half lane%2
+        const uint8_t* vpage0 = a.lin_base + (a.v_first + layer * a.layer_stride + static_cast<uint64_t>(t0) * 16u) * kInt4RecBytes;
+        const uint32_t vr = lane >> 2;                                   // row 0..15 (+16 for n = 1)
+        const uint8_t* vdat = vpage0 + (vr >> 1) * kInt4RecBytes + 128u + ((vr & 1u) * 8u + head) * 64u + (lane & 3u) * 16u;
+        const uint32_t sr = lane >> 1;                                   // row 0..31
+        const uint8_t* vsc = vpage0 + (sr >> 1) * kInt4RecBytes + ((sr & 1u) * 8u + head) * 8u + (lane & 1u) * 4u;
+        const uint32_t tile_bytes = 16u * kInt4RecBytes;
+
+        uint4 kx[2];
+        uint16_t ks[2];
+        uint4 vraw[2];
+        uint32_t vsraw;
+        auto issue_k = [&]() {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                kx[b] = ldg16(kdat + 8u * kInt4RecBytes * b);
+                ks[b] = *reinterpret_cast<const uint16_t*>(ksc + 8u * kInt4RecBytes * b);
+            }
+        };
+        auto issue_v = [&]() {
+            vraw[0] = ldg16(vdat);
+            vraw[1] = ldg16(vdat + 8u * kInt4RecBytes);
+            vsraw = *reinterpret_cast<const uint32_t*>(vsc);
+        };
+        // LDS addresses: writer and reader
+        const uint32_t wr0 = vr * 128u + ((vr >> 2) & 1u) * 64u + (lane & 3u) * 16u;           // rows 16..31: + 2048, same bit 2
+        const uint32_t wrs = 4096u + sr * 8u + (lane & 1u) * 4u;
+        // reader: position slot j is row r = 4kb + j (j < 4) or 16 + 4kb + (j - 4); bit 2 of r is kb & 1 either way,
+        // so every read is one base address plus a compile-time offset
+        const uint8_t* rdb = vl + 4u * kb * 128u + (kb & 1u) * 64u + 4u * c;
+        const uint8_t* rsb = vl + 4096u + 4u * kb * 8u + 2u * (c >> 2);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_k();
+        __builtin_amdgcn_sched_barrier(0);
+        issue_v();
+        __builtin_amdgcn_sched_barrier(0);
+        const bool ragged = (a.n_pages & 15u) != 0u;
+#pragma unroll 1
+        for (uint32_t tile = t0; tile < t1; ++tile) {
+            const uint32_t step = (tile + 1u < t1) ? tile_bytes : 0u;    // the last iteration re-requests its own tile
+            // ---- scores
+            float sc[8];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const _Float16 sh = __builtin_bit_cast(_Float16, ks[b]);
+                const f16x2 s2 = {sh, sh};
+                const uint32_t w[4] = {kx[b].x ^ 0x88888888u, kx[b].y ^ 0x88888888u, kx[b].z ^ 0x88888888u, kx[b].w ^ 0x88888888u};
+                f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8(w[st], s2), qv[st], s, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sc[4 * b + i] = s[i] * qscale;
+            }
+            if (ragged && tile + 1u == n_tiles) {                         // wave-uniform: positions beyond the range
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t pg = tile * 16u + ((j >> 1) < 2 ? 2u * kb + (j >> 1) : 8u + 2u * kb + ((j >> 1) - 2));
+                    if (pg >= a.n_pages) sc[j] = -INFINITY;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            kdat += step; ksc += step;
+            issue_k();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- online softmax of query row c
+            float mx = sc[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc[j]);
+            mx = max_over_kb(mx);
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;
+            const float f = __builtin_amdgcn_exp2f(m_run - m_use);
+            m_run = m_new;
+            float psum = 0.0f;
+            f16x8 P;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float p = __builtin_amdgcn_exp2f(sc[j] - m_use);
+                psum += p;
+                P[j] = static_cast<_Float16>(p);
+            }
+            l_run = l_run * f + psum;
+            // ---- V tile: registers -> this wave's LDS -> operand order
+            *reinterpret_cast<uint4*>(vl + wr0) = vraw[0];
+            *reinterpret_cast<uint4*>(vl + wr0 + 2048u) = vraw[1];
+            *reinterpret_cast<uint32_t*>(vl + wrs) = vsraw;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t vw[8], vs16[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ro = (j < 4) ? j : 16 + (j - 4);
+                vw[j] = *reinterpret_cast<const uint32_t*>(rdb + 128 * ro) ^ 0x88888888u;     // 8 nibbles of slot j, d = 8c..8c+7
+                vs16[j] = *reinterpret_cast<const uint16_t*>(rsb + 8 * ro);                   // its group scale (group c/4)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            vdat += step; vsc += step;
+            issue_v();                                                    // the staging registers are free again
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- out^T += V^T . P^T, accumulated in place
+            // element d = 8c + t of the two positions of a pair: nibble t&1 of byte t/2 of either position's dword
+            uint32_t nl[8], nh[8];                                        // low / high nibbles of slot j, one per byte
+            f16x2 s2[4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { nl[j] = vw[j] & 0x0F0F0F0Fu; nh[j] = (vw[j] >> 4) & 0x0F0F0F0Fu; }
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) s2[jp] = as_h2(vs16[2 * jp] | (vs16[2 * jp + 1] << 16));
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                f16x8 V;
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    // [slot 2jp, 0, slot 2jp+1, 0]
+                    const uint32_t sel = 0x0C040C00u + 0x00010001u * (t >> 1);
+                    const uint32_t sp = (t & 1) ? __builtin_amdgcn_perm(nh[2 * jp + 1], nh[2 * jp], sel)
+                                                : __builtin_amdgcn_perm(nl[2 * jp + 1], nl[2 * jp], sel);
+                    const f16x2 v = deq2(sp, s2[jp]);
+                    V[2 * jp] = v.x;
+                    V[2 * jp + 1] = v.y;
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t] * f, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- partial result of this split
+    const float l_tot = sum_over_kb(l_run);
+    if (kb == 0) {
+        a.part_ml[part * 32u + c] = m_run;
+        a.part_ml[part * 32u + 16u + c] = l_tot;
+    }
+    if (c < a.g) {
+        float* dst = a.part_acc + (part * 16u + c) * 128u + 32u * kb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(dst + 8 * i) = f32x4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+            *reinterpret_cast<f32x4*>(dst + 8 * i + 4) = f32x4{acc[4][i], acc[5][i], acc[6][i], acc[7][i]};
+        }
+    }
+}
+
+hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_t s)
+{
+    if (a.n_pages == 0 || n_layers == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_attend_int4_linear, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+} // namespace speckv

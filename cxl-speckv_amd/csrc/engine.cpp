@@ -274,9 +274,10 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
                 if (single_run) {
                     ok = launch_init_entries(a->d_entries, a->n_pages, reinterpret_cast<uint64_t>(a->extents[0].base),
                                              a->rec_stride, stream_) == hipSuccess;
-                    // FP8 pools start as zero bytes (= records of zeros), which lets the fused attention address
+                    // FP8 / INT4 pools start as zero bytes (= records of zeros), which lets the fused attention address
                     // them arithmetically without a validity test per page
-                    if (ok && a->scheme == SPECKV_COMP_FP8_E4M3 && pools_[a->extents[0].pool]->device() == device_) {
+                    if (ok && (a->scheme == SPECKV_COMP_FP8_E4M3 || a->scheme == SPECKV_COMP_INT4_G32) &&
+                        pools_[a->extents[0].pool]->device() == device_) {
                         ok = hipMemsetAsync(a->extents[0].base, 0, a->extents[0].bytes, stream_) == hipSuccess;
                         if (ok) a->linear_base = static_cast<uint8_t*>(a->extents[0].base);
                     }
@@ -1167,6 +1168,77 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     k.part_ml = reinterpret_cast<float*>(buf + q_bytes + qs_bytes + acc_bytes);
     HIP_TRY(launch_quantize_q_e4m3(d_q_f16, rows, g, L.head_dim, buf, reinterpret_cast<float*>(buf + q_bytes), st));
     HIP_TRY(launch_attend_fp8(k, n_layers, d_out, d_lse, st));
+    if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+    if (prev != device_) (void)hipSetDevice(prev);
+    return SPECKV_OK;
+}
+
+// Fused decode attention over INT4_G32 K and V records (attend_int4.hip): linear placement only.
+int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
+                        uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
+{
+    if (null_) return no_data_path("speckv_ext_attend_int4");
+    Allocation* a = find(handle);
+    if (!a) return SPECKV_ERR_GENERAL;
+    if (!a->has_layout || a->scheme != SPECKV_COMP_INT4_G32) return SPECKV_ERR_INVAL;
+    const Layout& L = a->layout;
+    if (L.head_dim != 128 || L.bytes_per_element != 2 || L.num_heads * L.head_dim != 1024 || L.num_tokens % 2) return SPECKV_ERR_INVAL;
+    if (n_layers == 0 || layer >= L.num_layers || n_layers > L.num_layers - layer || pos_begin % 2 || pos_begin > pos_end ||
+        pos_end > L.num_tokens || pos_end % 2)
+        return SPECKV_ERR_INVAL;
+    if (g == 0 || g > 16 || !d_q_f16 || !d_out) return SPECKV_ERR_INVAL;
+    const uint32_t n_pages = (pos_end - pos_begin) / 2;
+    int prev = 0; (void)hipGetDevice(&prev);
+    if (prev != device_) HIP_TRY(hipSetDevice(device_));
+    hipStream_t st = s ? s : stream_;
+    const size_t out_elems = static_cast<size_t>(n_layers) * L.num_heads * g * 128;
+    if (n_pages == 0) {
+        HIP_TRY(hipMemsetAsync(d_out, 0, out_elems * sizeof(float), st));
+        if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+        if (prev != device_) (void)hipSetDevice(prev);
+        return SPECKV_OK;
+    }
+    const uint64_t k_first = (static_cast<uint64_t>(layer) * 2 * L.num_tokens + pos_begin) / 2;
+    const uint64_t v_first = k_first + L.num_tokens / 2;
+    const uint64_t layer_stride = static_cast<uint64_t>(L.num_tokens);
+    if (v_first + (n_layers - 1) * layer_stride + n_pages > a->n_pages) return SPECKV_ERR_GENERAL;
+    const uint32_t n_tiles = (n_pages + 15u) / 16u;
+    // the tile loop reads whole 32-position tiles: the last one must stay inside the layer's K / V region
+    const bool fits = static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
+    if (!a->linear_base || !fits) {
+        SPECKV_ERR("speckv_ext_attend_int4: needs the allocation's records in one local run (not striped, not migrated) "
+                   "and pos_begin + 32*ceil((pos_end-pos_begin)/32) <= num_tokens");
+        if (prev != device_) (void)hipSetDevice(prev);
+        return SPECKV_ERR_INVAL;
+    }
+    const uint32_t rows = n_layers * L.num_heads;
+    uint32_t want = (5120u + rows - 1u) / rows;      // VALU-bound kernel: fewer, longer splits measured best
+    want = std::min(want, std::max(1u, n_tiles / 8u));
+    if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));
+    uint32_t n_splits = std::max(1u, std::min(want, n_tiles));
+    const uint32_t tiles_per_split = (n_tiles + n_splits - 1u) / n_splits;
+    n_splits = (n_tiles + tiles_per_split - 1u) / tiles_per_split;
+    const size_t acc_bytes = static_cast<size_t>(rows) * n_splits * 16 * 128 * sizeof(float);
+    const size_t ml_bytes = static_cast<size_t>(rows) * n_splits * 32 * sizeof(float);
+    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes));
+    if (!buf) return SPECKV_ERR_NOMEM;
+    AttendArgs k{};
+    k.entries = a->d_entries;
+    k.k_first = k_first;
+    k.v_first = v_first;
+    k.layer_stride = layer_stride;
+    k.n_pages = n_pages;
+    k.heads = L.num_heads;
+    k.g = g;
+    k.n_splits = n_splits;
+    k.tiles_per_split = tiles_per_split;
+    k.q8 = static_cast<const uint8_t*>(d_q_f16);
+    k.scale_log2e = sm_scale * 1.4426950408889634f;
+    k.lin_base = a->linear_base;
+    k.part_acc = reinterpret_cast<float*>(buf);
+    k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
+    HIP_TRY(launch_attend_int4(k, n_layers, st));
+    HIP_TRY(launch_attend_combine(k, n_layers, d_out, d_lse, st));
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
     if (prev != device_) (void)hipSetDevice(prev);
     return SPECKV_OK;

@@ -106,6 +106,8 @@ public:
                       uint32_t pos_begin, uint32_t pos_end, float* d_out, hipStream_t s);
     int attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
                    uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
+    int attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
+                    uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
     int migrate(uint64_t handle, uint64_t first_page, uint64_t n_pages, uint32_t target_pool);
     int predictor_load(const float* emb, const float* wout, uint32_t vocab, bool on_device);
     int predict_batch(uint32_t n, const int32_t* d_hist, uint32_t k, int32_t* d_tok, float* d_conf, hipStream_t s);

@@ -117,6 +117,10 @@ struct AttendArgs {
     float* part_ml;                   // [layers][heads][splits][2][16]
 };
 hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s);
+// INT4_G32 records (attend_int4.hip; linear form only: a.lin_base must be set, a.q8 = the fp16 query rows
+// [layers][heads][g][128]); writes the split partials, launch_attend_combine merges them
+hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_t s);
+hipError_t launch_attend_combine(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s);
 
 // entries[i].pool_addr = base + i*stride (record bytes / scale untouched): after a migration
 hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t base, uint64_t stride, hipStream_t s);

@@ -91,6 +91,7 @@ class Oracle:
             "orc_e4m3_to_f32": (C.c_float, [C.c_uint8]),
             "orc_qk_scores_fp8": (None, [u8p, f32p, C.c_size_t, u8p, f32p, C.c_size_t, C.c_size_t, f32p]),
             "orc_attend_fp8": (None, [u8p, f32p, C.c_size_t, u8p, f32p, u8p, f32p, C.c_size_t, C.c_size_t, C.c_float, f32p, f32p, f32p]),
+            "orc_attend_f16": (None, [u16p, C.c_size_t, u16p, u16p, C.c_size_t, C.c_size_t, C.c_float, f32p, f32p, f32p]),
             "orc_quantize_rows_e4m3": (None, [u16p, C.c_size_t, C.c_size_t, u8p, f32p]),
             "orc_layer_compression_ratio": (C.c_double, [C.c_uint32]),
             "orc_codec_throughput_gbps": (C.c_double, [C.c_size_t, C.c_double, C.c_size_t]),

@@ -581,6 +581,41 @@ void orc_attend_fp8(const uint8_t* q8, const float* q_scale, size_t g, const uin
     free(s); free(o); free(a);
 }
 
+void orc_attend_f16(const uint16_t* q16, size_t g, const uint16_t* k16, const uint16_t* v16, size_t n_pos, size_t d,
+                    float sm_scale, float* out, float* lse, float* mag)
+{
+    double* s = (double*)malloc((n_pos ? n_pos : 1) * sizeof(double));
+    double* o = (double*)malloc(d * sizeof(double));
+    double* a = (double*)malloc(d * sizeof(double));
+    for (size_t m = 0; m < g; ++m) {
+        double mx = -INFINITY;
+        for (size_t t = 0; t < n_pos; ++t) {
+            double acc = 0.0;
+            for (size_t i = 0; i < d; ++i)
+                acc += (double)orc_half_to_float(q16[m * d + i]) * (double)orc_half_to_float(k16[t * d + i]);
+            s[t] = acc * (double)sm_scale;
+            if (s[t] > mx) mx = s[t];
+        }
+        double l = 0.0;
+        for (size_t i = 0; i < d; ++i) { o[i] = 0.0; a[i] = 0.0; }
+        for (size_t t = 0; t < n_pos; ++t) {
+            double p = exp(s[t] - mx);
+            l += p;
+            for (size_t i = 0; i < d; ++i) {
+                double v = (double)orc_half_to_float(v16[t * d + i]);
+                o[i] += p * v;
+                a[i] += p * fabs(v);
+            }
+        }
+        for (size_t i = 0; i < d; ++i) {
+            out[m * d + i] = (l > 0.0) ? (float)(o[i] / l) : 0.0f;
+            if (mag) mag[m * d + i] = (l > 0.0) ? (float)(a[i] / l) : 0.0f;
+        }
+        if (lse) lse[m] = (l > 0.0) ? (float)(mx + log(l)) : -INFINITY;
+    }
+    free(s); free(o); free(a);
+}
+
 double orc_layer_compression_ratio(uint32_t layer_id)
 {   /* cache_engine.cpp:25-33,142-148 : 80/3 = 26, 2*80/3 = 53 */
     if (layer_id >= 80) return 3.2;

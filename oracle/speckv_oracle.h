@@ -153,6 +153,11 @@ void orc_attend_fp8(const uint8_t* q8, const float* q_scale, size_t g,
                     const uint8_t* k_rec, const float* k_scale,
                     const uint8_t* v_rec, const float* v_scale, size_t n_pos, size_t d,
                     float sm_scale, float* out, float* lse, float* mag);
+/* Decode attention of one kv head over fp16 K / V rows (what fetch+decompress yields), fp16 query:
+ *   out[m][:] = sum_t softmax_t(q[m].k[t] * sm_scale) * v[t][:]   in double precision;
+ *   lse, mag as in orc_attend_fp8.  Checker of speckv_ext_attend_int4 (own extension, parity unpinned). */
+void orc_attend_f16(const uint16_t* q16, size_t g, const uint16_t* k16, const uint16_t* v16, size_t n_pos, size_t d,
+                    float sm_scale, float* out, float* lse, float* mag);
 /* per-row e4m3 quantisation of the query (scale = max|q|/448, 1 if zero) */
 void orc_quantize_rows_e4m3(const uint16_t* q16, size_t rows, size_t d, uint8_t* q8, float* scale);
 

@@ -524,6 +524,87 @@ def test_fp8_fused_attention_unwritten_pages_count_as_zeros(eng, oracle):
         assert np.all(np.abs(got[head] - o) <= 2e-3 * m + 1e-6)
 
 
+def test_int4_fused_attention(eng, oracle):
+    """The 4:1 format of BASELINE config 5: softmax(q.K^T).V straight from INT4_G32 records
+    (speckv_ext_attend_int4) against the oracle's double-precision attention over the pages as
+    fetch+decompress yields them (fp16(q4 * group scale)) -- the fused kernel must dequantise to
+    exactly those values.  Error sources: f16 rounding of the softmax weights (2^-11 each), fp32
+    accumulation of the f16 MFMAs, v_exp_f32.  Stated tolerance: |got - want| <= 2e-3 * sum_t p_t |v_t| + 1e-6,
+    lse within 2e-3."""
+    torch = torch_mod()
+    lib = eng.lib
+    lib.set_compression_scheme(3)
+    T, L, H, D, bpe, G = 512, 2, 8, 128, 2, 8
+    h = eng.allocate(T, L, H, D, bpe)
+    n_pages = T * L * H * D * bpe * 2 // PAGE
+    rng = np.random.default_rng(53)
+    x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.05, 6.0, (n_pages, 1))).astype(np.float16)
+    x[5] = 0.0                                                    # a page of zeros: zero group scales
+    lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+    # the pages as the non-fused path decodes them (bit-exact vs the oracle, checked in test_gpu_codec)
+    scales, lens, recs = oracle.compress_blocks_f16(x, 3, 0)
+    dec = oracle.decompress_blocks_f16(recs, lens, scales, 3, 0).reshape(n_pages, 2, H, D)     # [page][slot][head][d]
+    from oracle.bindings import _ptr, u16p, f32p
+    q = (rng.standard_normal((L, H, G, D)) * 2.0).astype(np.float16)
+    d_q = torch.from_numpy(q.view(np.int16)).cuda()
+    sm = 1.0 / np.sqrt(D)
+
+    def want_for(layer, pb, pe, sm_scale):
+        npos = pe - pb
+        kf = (layer * 2 * T + pb) // 2
+        vf = kf + T // 2
+        out = np.zeros((H, G, D), np.float32); lse = np.zeros((H, G), np.float32); mag = np.zeros((H, G, D), np.float32)
+        for head in range(H):
+            k16 = np.ascontiguousarray(dec[kf:kf + npos // 2, :, head, :].reshape(npos, D)).view(np.uint16)
+            v16 = np.ascontiguousarray(dec[vf:vf + npos // 2, :, head, :].reshape(npos, D)).view(np.uint16)
+            o = np.zeros((G, D), np.float32); l = np.zeros(G, np.float32); m = np.zeros((G, D), np.float32)
+            oracle.lib.orc_attend_f16(_ptr(np.ascontiguousarray(q[layer, head]).view(np.uint16).reshape(-1), u16p), G,
+                                      _ptr(k16.reshape(-1), u16p), _ptr(v16.reshape(-1), u16p), npos, D, float(sm_scale),
+                                      _ptr(o, f32p), _ptr(l, f32p), _ptr(m, f32p))
+            out[head], lse[head], mag[head] = o, l, m
+        return out, lse, mag
+
+    cases = [(0, (0, T), None), (1, (64, 200), None), (1, (2, 4), None), (0, (0, 34), "1"), (0, (0, T), "1"), (1, (32, 480), "3")]
+    for layer, (pb, pe), splits in cases:
+        if splits is None: os.environ.pop("SPECKV_ATTEND_SPLITS", None)
+        else: os.environ["SPECKV_ATTEND_SPLITS"] = splits
+        try:
+            d_out = torch.full((H, G, D), float("nan"), dtype=torch.float32, device="cuda")
+            d_lse = torch.full((H, G), float("nan"), dtype=torch.float32, device="cuda")
+            lib.attend_int4(h, layer, 1, d_q[layer].data_ptr(), G, pb, pe, sm, d_out.data_ptr(), d_lse.data_ptr())
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("SPECKV_ATTEND_SPLITS", None)
+        want, wlse, mag = want_for(layer, pb, pe, sm)
+        got, glse = d_out.cpu().numpy(), d_lse.cpu().numpy()
+        err = np.abs(got - want)
+        assert np.all(err <= 2e-3 * mag + 1e-6), (layer, pb, pe, splits, float((err / (mag + 1e-9)).max()))
+        assert np.all(np.abs(glse - wlse) <= 2e-3), (layer, pb, pe, float(np.abs(glse - wlse).max()))
+    # both layers in one launch
+    multi = torch.empty((L, H, G, D), dtype=torch.float32, device="cuda")
+    lib.attend_int4(h, 0, L, d_q.data_ptr(), G, 0, T, sm, multi.data_ptr())
+    torch.cuda.synchronize()
+    for layer in range(L):
+        want, _, mag = want_for(layer, 0, T, sm)
+        assert np.all(np.abs(multi[layer].cpu().numpy() - want) <= 2e-3 * mag + 1e-6)
+    # and it is close to the attention over the original fp16 KV (int4 quantisation error only)
+    kfull = x[:T // 2].reshape(T // 2, 2, H, D).astype(np.float32).reshape(T, H, D)
+    vfull = x[T // 2:T].reshape(T // 2, 2, H, D).astype(np.float32).reshape(T, H, D)
+    s_ = np.einsum("hgd,thd->hgt", q[0].astype(np.float32), kfull) * sm
+    p = np.exp(s_ - s_.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
+    ref = np.einsum("hgt,thd->hgd", p, vfull)
+    rel = np.linalg.norm(multi[0].cpu().numpy() - ref) / np.linalg.norm(ref)      # 4-bit KV under a peaky softmax: coarse
+    assert rel <= 0.5, rel
+    # a range whose last tile would leave the layer's region, odd positions, wrong scheme -> INVAL
+    d_out = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
+    with pytest.raises(SpeckvError):
+        lib.attend_int4(h, 0, 1, d_q[0].data_ptr(), G, 30, 512, sm, d_out.data_ptr())
+    with pytest.raises(SpeckvError):
+        lib.attend_int4(h, 0, 1, d_q[0].data_ptr(), G, 1, 5, sm, d_out.data_ptr())
+    with pytest.raises(SpeckvError):
+        lib.attend_fp8(h, 0, 1, d_q[0].data_ptr(), G, 0, T, sm, d_out.data_ptr())
+
+
 def test_migrate_records_between_pool_slabs(oracle):
     """speckv_ext_migrate: hipMemcpyPeerAsync of record runs + page-table re-point
     (one GPU here, so source and target pool are the same device; the copy path,
