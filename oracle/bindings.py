@@ -92,6 +92,21 @@ class Oracle:
             "orc_qk_scores_fp8": (None, [u8p, f32p, C.c_size_t, u8p, f32p, C.c_size_t, C.c_size_t, f32p]),
             "orc_attend_fp8": (None, [u8p, f32p, C.c_size_t, u8p, f32p, u8p, f32p, C.c_size_t, C.c_size_t, C.c_float, f32p, f32p, f32p]),
             "orc_attend_f16": (None, [u16p, C.c_size_t, u16p, u16p, C.c_size_t, C.c_size_t, C.c_float, f32p, f32p, f32p]),
+            "orc_coh_new": (C.c_void_p, [C.c_size_t, C.c_int]),
+            "orc_coh_delete": (None, [C.c_void_p]),
+            "orc_coh_request_read": (C.c_int, [C.c_void_p, C.c_uint64]),
+            "orc_coh_request_write": (C.c_int, [C.c_void_p, C.c_uint64]),
+            "orc_coh_invalidate": (C.c_int, [C.c_void_p, C.c_uint64]),
+            "orc_coh_writeback": (C.c_int, [C.c_void_p, C.c_uint64]),
+            "orc_coh_flush_all": (C.c_int, [C.c_void_p]),
+            "orc_coh_get_state": (C.c_int, [C.c_void_p, C.c_uint64]),
+            "orc_coh_get_tier": (C.c_int, [C.c_void_p, C.c_uint64]),
+            "orc_coh_promote_to_l1": (C.c_int, [C.c_void_p, C.c_uint64]),
+            "orc_coh_demote_to_l3": (C.c_int, [C.c_void_p, C.c_uint64]),
+            "orc_coh_update_tier": (None, [C.c_void_p, C.c_uint64, C.c_int]),
+            "orc_coh_batch_invalidate": (C.c_int, [C.c_void_p, u64p, C.c_size_t]),
+            "orc_coh_get_statistics": (None, [C.c_void_p, u64p]),
+            "orc_coh_reset_statistics": (None, [C.c_void_p]),
             "orc_quantize_rows_e4m3": (None, [u16p, C.c_size_t, C.c_size_t, u8p, f32p]),
             "orc_layer_compression_ratio": (C.c_double, [C.c_uint32]),
             "orc_codec_throughput_gbps": (C.c_double, [C.c_size_t, C.c_double, C.c_size_t]),
@@ -289,3 +304,87 @@ class Reference:
         y = np.empty(max(cap, 1), dtype=np.float32)
         n = self.lib.ref_engine_decompress(self.engine, _ptr(rle, u8p), rle.size, C.c_float(float(scale)), _ptr(y, f32p), cap)
         return y[:min(n, cap)].copy()
+
+
+# ---- coherence directory: one driver for the three implementations ------------------------------
+REF_COH_SO = os.path.join(_HERE, "_ref", "libspeckv_ref_coh.so")
+COH_OPS = ("read", "write", "invalidate", "writeback", "flush_all", "promote_to_l1", "demote_to_l3", "update_tier",
+           "batch_invalidate", "get_state", "get_tier", "reset_statistics")
+
+
+def have_reference_coherence():
+    return os.path.exists(REF_COH_SO)
+
+
+class _CohBase:
+    """op(name, addr_or_list, arg) -> int result; stats() -> 7 counters.  Subclasses bind a backend."""
+
+    def run(self, ops):
+        """ops: list of (name, addr | [addrs], tier).  Returns [result, ...] + final (states, stats)."""
+        return [self.op(*o) for o in ops]
+
+
+class OracleCoherence(_CohBase):
+    def __init__(self, oracle, line=64, has_driver=1):
+        self.L = oracle.lib
+        self.h = self.L.orc_coh_new(line, has_driver)
+
+    def close(self):
+        if self.h: self.L.orc_coh_delete(self.h); self.h = None
+
+    def op(self, name, a=0, t=0):
+        L, h = self.L, self.h
+        if name == "read": return L.orc_coh_request_read(h, a)
+        if name == "write": return L.orc_coh_request_write(h, a)
+        if name == "flush_all": return L.orc_coh_flush_all(h)
+        if name == "update_tier": L.orc_coh_update_tier(h, a, t); return 0
+        if name == "reset_statistics": L.orc_coh_reset_statistics(h); return 0
+        if name == "batch_invalidate":
+            arr = np.ascontiguousarray(a, np.uint64)
+            return L.orc_coh_batch_invalidate(h, _ptr(arr, u64p), arr.size)
+        return getattr(L, "orc_coh_" + name)(h, a)
+
+    def stats(self):
+        st = np.zeros(7, np.uint64)
+        self.L.orc_coh_get_statistics(self.h, _ptr(st, u64p))
+        return [int(v) for v in st]
+
+
+class ReferenceCoherence(_CohBase):
+    """The reference's CoherenceManager itself (oracle/_ref/libspeckv_ref_coh.so, oracle/coh_harness.cpp)."""
+
+    def __init__(self, line=64, has_driver=1):
+        self.L = L = C.CDLL(REF_COH_SO)
+        L.refcoh_new.restype = C.c_void_p; L.refcoh_new.argtypes = [C.c_size_t, C.c_int]
+        L.refcoh_delete.argtypes = [C.c_void_p]
+        for f in ("request_read", "request_write", "writeback"):
+            getattr(L, "refcoh_" + f).argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t]
+        for f in ("invalidate", "get_state", "get_tier", "promote_to_l1", "demote_to_l3"):
+            getattr(L, "refcoh_" + f).argtypes = [C.c_void_p, C.c_uint64]
+        L.refcoh_flush_all.argtypes = [C.c_void_p]; L.refcoh_reset_statistics.argtypes = [C.c_void_p]
+        L.refcoh_update_tier.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
+        L.refcoh_batch_invalidate.argtypes = [C.c_void_p, u64p, C.c_size_t]
+        L.refcoh_get_statistics.argtypes = [C.c_void_p, u64p]
+        self.h = L.refcoh_new(line, has_driver)
+        self.buf = C.create_string_buffer(256)
+
+    def close(self):
+        if self.h: self.L.refcoh_delete(self.h); self.h = None
+
+    def op(self, name, a=0, t=0):
+        L, h = self.L, self.h
+        if name == "read": return L.refcoh_request_read(h, a, self.buf, 64)
+        if name == "write": return L.refcoh_request_write(h, a, self.buf, 64)
+        if name == "writeback": return L.refcoh_writeback(h, a, self.buf, 64)
+        if name == "flush_all": return L.refcoh_flush_all(h)
+        if name == "update_tier": L.refcoh_update_tier(h, a, t); return 0
+        if name == "reset_statistics": L.refcoh_reset_statistics(h); return 0
+        if name == "batch_invalidate":
+            arr = np.ascontiguousarray(a, np.uint64)
+            return L.refcoh_batch_invalidate(h, _ptr(arr, u64p), arr.size)
+        return getattr(L, "refcoh_" + name)(h, a)
+
+    def stats(self):
+        st = np.zeros(7, np.uint64)
+        self.L.refcoh_get_statistics(self.h, _ptr(st, u64p))
+        return [int(v) for v in st]

@@ -1002,3 +1002,140 @@ size_t orc_prefetch_pages(uint32_t req_id, uint32_t layer, uint32_t cur_pos, uin
     }
     return w < cap ? w : cap;
 }
+
+/* ---- coherence shadow directory (coherence_manager.cpp) --------------------- */
+typedef struct { uint64_t line; uint8_t used, state, tier; uint32_t access_count; } coh_entry;
+struct orc_coh { size_t line_size; int has_driver; coh_entry* tab; size_t cap, n; uint64_t st[7]; };
+enum { COH_READS, COH_WRITES, COH_OPS, COH_INVAL, COH_WB, COH_HITS, COH_MISSES };
+enum { COH_OP_READ, COH_OP_WRITE, COH_OP_INVALIDATE, COH_OP_WRITEBACK };
+
+orc_coh_t* orc_coh_new(size_t cache_line_size, int has_driver)
+{
+    orc_coh_t* c = (orc_coh_t*)calloc(1, sizeof(*c));
+    c->line_size = cache_line_size;
+    c->has_driver = has_driver;
+    c->cap = 1024;
+    c->tab = (coh_entry*)calloc(c->cap, sizeof(coh_entry));
+    return c;
+}
+void orc_coh_delete(orc_coh_t* c) { if (c) { free(c->tab); free(c); } }
+static uint64_t coh_align(const orc_coh_t* c, uint64_t a) { return a & ~((uint64_t)c->line_size - 1u); }  /* coherence_manager.h:206-208 */
+static size_t coh_slot(const orc_coh_t* c, uint64_t line) { return (size_t)((line * 0x9E3779B97F4A7C15ull) >> 20) & (c->cap - 1); }
+static coh_entry* coh_find(const orc_coh_t* c, uint64_t line)
+{
+    for (size_t i = coh_slot(c, line);; i = (i + 1) & (c->cap - 1)) {
+        if (!c->tab[i].used) return NULL;
+        if (c->tab[i].line == line) return &c->tab[i];
+    }
+}
+static coh_entry* coh_get_or_create(orc_coh_t* c, uint64_t line)
+{   /* coherence_manager.cpp:384-396: new entries are INVALID, L3_CXL, access_count 0 */
+    coh_entry* e = coh_find(c, line);
+    if (e) return e;
+    if ((c->n + 1) * 2 > c->cap) {
+        coh_entry* old = c->tab; size_t oc = c->cap;
+        c->cap *= 2;
+        c->tab = (coh_entry*)calloc(c->cap, sizeof(coh_entry));
+        for (size_t i = 0; i < oc; ++i)
+            if (old[i].used) {
+                size_t j = coh_slot(c, old[i].line);
+                while (c->tab[j].used) j = (j + 1) & (c->cap - 1);
+                c->tab[j] = old[i];
+            }
+        free(old);
+    }
+    size_t i = coh_slot(c, line);
+    while (c->tab[i].used) i = (i + 1) & (c->cap - 1);
+    c->tab[i].used = 1; c->tab[i].line = line; c->tab[i].state = 0; c->tab[i].tier = 2; c->tab[i].access_count = 0;
+    c->n++;
+    return &c->tab[i];
+}
+static void coh_count(orc_coh_t* c, int op, int hit)
+{   /* coherence_manager.cpp:436-458 */
+    if (op == COH_OP_READ) { c->st[COH_READS]++; c->st[hit ? COH_HITS : COH_MISSES]++; }
+    else if (op == COH_OP_WRITE) { c->st[COH_WRITES]++; c->st[hit ? COH_HITS : COH_MISSES]++; }
+    else c->st[COH_OPS]++;
+}
+static int coh_send(orc_coh_t* c, int op)
+{   /* coherence_manager.cpp:398-424: no driver -> false (nothing counted); else counted as a hit, true */
+    if (!c->has_driver) return 0;
+    coh_count(c, op, 1);
+    return 1;
+}
+int orc_coh_request_read(orc_coh_t* c, uint64_t addr)
+{   /* :33-68 */
+    uint64_t line = coh_align(c, addr);
+    coh_entry* e = coh_find(c, line);
+    if (e && e->state != 0) { coh_count(c, COH_OP_READ, 1); e->access_count++; return 1; }
+    coh_count(c, COH_OP_READ, 0);
+    int ok = coh_send(c, COH_OP_READ);
+    if (ok) { e = coh_get_or_create(c, line); e->state = 1; e->tier = 0; e->access_count = 1; }
+    return ok;
+}
+int orc_coh_request_write(orc_coh_t* c, uint64_t addr)
+{   /* :70-106 */
+    uint64_t line = coh_align(c, addr);
+    coh_entry* e = coh_find(c, line);
+    if (e && e->state == 1) { coh_count(c, COH_OP_INVALIDATE, 0); c->st[COH_INVAL]++; }
+    coh_count(c, COH_OP_WRITE, e != NULL);
+    int ok = coh_send(c, COH_OP_WRITE);
+    if (ok) { e = coh_get_or_create(c, line); e->state = 3; e->tier = 0; e->access_count++; }
+    return ok;
+}
+int orc_coh_invalidate(orc_coh_t* c, uint64_t addr)
+{   /* :108-134 */
+    coh_entry* e = coh_find(c, coh_align(c, addr));
+    if (!e) return 1;
+    if (e->state == 3) c->st[COH_WB]++;
+    e->state = 0;
+    int ok = coh_send(c, COH_OP_INVALIDATE);
+    c->st[COH_INVAL]++;
+    return ok;
+}
+int orc_coh_writeback(orc_coh_t* c, uint64_t addr)
+{   /* :136-158 */
+    coh_entry* e = coh_find(c, coh_align(c, addr));
+    if (!e || e->state != 3) return 1;
+    int ok = coh_send(c, COH_OP_WRITEBACK);
+    if (ok) { e->state = 1; e->tier = 2; c->st[COH_WB]++; }
+    return ok;
+}
+int orc_coh_flush_all(orc_coh_t* c)
+{   /* :160-181 (the send result is ignored there) */
+    uint64_t flushed = 0;
+    for (size_t i = 0; i < c->cap; ++i)
+        if (c->tab[i].used && c->tab[i].state == 3) { (void)coh_send(c, COH_OP_WRITEBACK); c->tab[i].state = 1; c->tab[i].tier = 2; flushed++; }
+    c->st[COH_WB] += flushed;
+    return 1;
+}
+int orc_coh_get_state(const orc_coh_t* c, uint64_t addr) { coh_entry* e = coh_find(c, coh_align(c, addr)); return e ? e->state : 0; }
+int orc_coh_get_tier(const orc_coh_t* c, uint64_t addr) { coh_entry* e = coh_find(c, coh_align(c, addr)); return e ? e->tier : 2; }
+int orc_coh_promote_to_l1(orc_coh_t* c, uint64_t addr)
+{   /* :211-238: creates the entry (INVALID) when absent */
+    coh_entry* e = coh_get_or_create(c, coh_align(c, addr));
+    if (e->tier == 0) return 1;
+    int ok = coh_send(c, COH_OP_READ);
+    if (ok) e->tier = 0;
+    return ok;
+}
+int orc_coh_demote_to_l3(orc_coh_t* c, uint64_t addr)
+{   /* :240-261 */
+    coh_entry* e = coh_find(c, coh_align(c, addr));
+    if (!e || e->tier == 2) return 1;
+    if (e->state == 3) { (void)coh_send(c, COH_OP_WRITEBACK); e->state = 1; c->st[COH_WB]++; }
+    e->tier = 2;
+    return 1;
+}
+void orc_coh_update_tier(orc_coh_t* c, uint64_t addr, int tier) { coh_get_or_create(c, coh_align(c, addr))->tier = (uint8_t)tier; }   /* :263-270 */
+int orc_coh_batch_invalidate(orc_coh_t* c, const uint64_t* addrs, size_t n)
+{   /* :272-289: only present lines get an operation, every address counts as an invalidation */
+    int all = 1;
+    for (size_t i = 0; i < n; ++i) {
+        coh_entry* e = coh_find(c, coh_align(c, addrs[i]));
+        if (e) { e->state = 0; all &= coh_send(c, COH_OP_INVALIDATE); }
+    }
+    c->st[COH_INVAL] += n;
+    return all;
+}
+void orc_coh_get_statistics(const orc_coh_t* c, uint64_t* stats7) { memcpy(stats7, c->st, sizeof(c->st)); }
+void orc_coh_reset_statistics(orc_coh_t* c) { memset(c->st, 0, sizeof(c->st)); }

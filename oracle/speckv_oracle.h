@@ -260,6 +260,30 @@ size_t orc_prefetch_pages(uint32_t req_id, uint32_t layer, uint32_t cur_pos,
                           uint64_t alloc_pages, const uint32_t* flags,
                           uint64_t* out_pages, size_t cap);
 
+/* ---- coherence shadow directory -----------------------------
+ * CoherenceManager of the reference (src/cxl_memory/coherence_manager.cpp), restated: a per-line
+ * MESI tag + tier tag + counters; every "FPGA operation" is a stub that succeeds iff the manager
+ * has a driver (coherence_manager.cpp:398-424) and counts as a directory HIT of its kind
+ * (:436-458), which is why one missing read adds 2 to total_reads.  States: 0 I, 1 S, 2 E, 3 M;
+ * tiers: 0 L1_GPU, 1 L2_PREFETCH, 2 L3_CXL.  stats[7] = total_reads, total_writes, coherence_ops,
+ * invalidations_sent, writebacks_performed, directory_hits, directory_misses. */
+typedef struct orc_coh orc_coh_t;
+orc_coh_t* orc_coh_new(size_t cache_line_size, int has_driver);
+void orc_coh_delete(orc_coh_t* c);
+int orc_coh_request_read(orc_coh_t* c, uint64_t addr);
+int orc_coh_request_write(orc_coh_t* c, uint64_t addr);
+int orc_coh_invalidate(orc_coh_t* c, uint64_t addr);
+int orc_coh_writeback(orc_coh_t* c, uint64_t addr);
+int orc_coh_flush_all(orc_coh_t* c);
+int orc_coh_get_state(const orc_coh_t* c, uint64_t addr);
+int orc_coh_get_tier(const orc_coh_t* c, uint64_t addr);
+int orc_coh_promote_to_l1(orc_coh_t* c, uint64_t addr);
+int orc_coh_demote_to_l3(orc_coh_t* c, uint64_t addr);
+void orc_coh_update_tier(orc_coh_t* c, uint64_t addr, int tier);
+int orc_coh_batch_invalidate(orc_coh_t* c, const uint64_t* addrs, size_t n);
+void orc_coh_get_statistics(const orc_coh_t* c, uint64_t* stats7);
+void orc_coh_reset_statistics(orc_coh_t* c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -235,11 +235,64 @@ def gen_prefetch(ref):
     R.ref_pf_delete(pf); R.ref_mm_delete(mm)
 
 
+def gen_coherence():
+    """Traces of the reference's CoherenceManager (oracle/_ref/libspeckv_ref_coh.so): the scenarios of the
+    reference's own tests/test_coherence.cpp:57-398, plus one seeded random walk over every operation, with the
+    result of every call, and the per-line (state, tier) and the seven counters at the end."""
+    import numpy as np
+    from oracle.bindings import ReferenceCoherence
+    def run(line, has_driver, ops):
+        rc = ReferenceCoherence(line, has_driver)
+        results = rc.run([tuple(o) for o in ops])
+        addrs = sorted({a for o in ops if len(o) > 1 for a in (o[1] if isinstance(o[1], list) else [o[1]])})
+        final = {hex(a): [rc.op("get_state", a), rc.op("get_tier", a)] for a in addrs}
+        st = rc.stats()
+        rc.close()
+        return {"cache_line_size": line, "has_driver": has_driver, "ops": ops, "results": results, "final": final, "stats": st}
+    scen = {
+        "read_operations": [["read", 0x10000], ["get_state", 0x10000], ["get_tier", 0x10000], ["read", 0x10000]],
+        "write_operations": [["read", 0x20000], ["get_state", 0x20000], ["write", 0x20000], ["get_state", 0x20000]],
+        "invalidation": [["read", 0x30000], ["invalidate", 0x30000], ["get_state", 0x30000]],
+        "writeback": [["write", 0x40000], ["writeback", 0x40000], ["get_state", 0x40000]],
+        "tier_promotion": [["get_tier", 0x50000], ["promote_to_l1", 0x50000], ["get_tier", 0x50000], ["get_state", 0x50000]],
+        "tier_demotion": [["promote_to_l1", 0x60000], ["demote_to_l3", 0x60000], ["get_tier", 0x60000]],
+        "batch_operations": [["read", 0x70000], ["read", 0x70040], ["read", 0x70080], ["read", 0x700C0],
+                             ["batch_invalidate", [0x70000, 0x70040, 0x70080, 0x700C0]]],
+        "flush_all": [["write", 0x80000], ["write", 0x80040], ["write", 0x80080], ["flush_all"]],
+        "statistics": [["read", 0x90000], ["write", 0x90040], ["invalidate", 0x90000]],
+        "state_transitions": [["get_state", 0xA0000], ["read", 0xA0000], ["write", 0xA0000], ["writeback", 0xA0000], ["invalidate", 0xA0000]],
+        "multiple_addresses": [["read", 0xB0000 + i * 0x1000] for i in range(10)],
+        "unaligned_and_modified_paths": [["write", 0x1234], ["get_state", 0x1200], ["get_state", 0x1240], ["demote_to_l3", 0x1239],
+                                         ["write", 0x5000], ["invalidate", 0x5010], ["update_tier", 0x6000, 1], ["get_tier", 0x6000],
+                                         ["get_state", 0x6000], ["read", 0x6000], ["batch_invalidate", [0x6000, 0x7000, 0x1234]],
+                                         ["writeback", 0x9999]],
+    }
+    out = {"source": "reference src/cxl_memory/coherence_manager.cpp (CoherenceManager, opaque non-null driver)",
+           "scenarios": {k: run(64, 1, v) for k, v in scen.items()}}
+    rng = np.random.default_rng(77)
+    names = ["read", "write", "invalidate", "writeback", "promote_to_l1", "demote_to_l3", "get_state", "get_tier"]
+    walk = []
+    for _ in range(400):
+        r = rng.random()
+        a = int(rng.integers(0, 24)) * 0x40 + int(rng.integers(0, 64))
+        if r < 0.03: walk.append(["flush_all"])
+        elif r < 0.06: walk.append(["batch_invalidate", [int(rng.integers(0, 24)) * 0x40 for _ in range(int(rng.integers(0, 6)))]])
+        elif r < 0.09: walk.append(["update_tier", a, int(rng.integers(0, 3))])
+        elif r < 0.10: walk.append(["reset_statistics"])
+        else: walk.append([names[int(rng.integers(0, len(names)))], a])
+    out["random_walk"] = run(64, 1, walk)
+    out["no_driver"] = run(64, 0, [["read", 0x100], ["write", 0x100], ["promote_to_l1", 0x200], ["get_tier", 0x200],
+                                   ["invalidate", 0x100], ["update_tier", 0x300, 0], ["demote_to_l3", 0x300], ["flush_all"]])
+    out["line_128"] = run(128, 1, [["write", 0x1040], ["get_state", 0x1000], ["get_state", 0x1080], ["read", 0x10FF]])
+    json.dump(out, open(os.path.join(HERE, "coherence_trace.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     ref = Reference()
     gen_codec(ref)
     gen_mm(ref)
     gen_prefetch(ref)
     gen_shim(ref)
+    gen_coherence()
     gen_cabi(ref)   # last: leaves the reference C ABI finalized
     print("golden fixtures written to", HERE)
