@@ -277,3 +277,23 @@ def test_address_encodings(libpath, oracle, reference=None):
         assert lib.speckv_ext_atu_translate(va) == O.orc_tlb_translate(tlb, va, None)     # every first touch is a miss
     O.orc_tlb_delete(tlb)
     assert lib.speckv_ext_codec_model_throughput_gbps(1, 800.0, 512) == O.orc_codec_throughput_gbps(1, 800.0, 512) == 51.2
+
+
+def _build_c_demo():
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg.library_path()                                   # make sure the library exists
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples")])
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    return os.path.join(root, "examples", "_build", "cxlspeckv_demo"), env
+
+
+def test_headers_are_c99_and_the_c_demo_runs_on_the_fake_device():
+    """include/*.h compile as strict C99 (-Wall -Wextra -pedantic) and a plain C program drives the ABI:
+    the page-table part of examples/cxlspeckv_demo.c on the reference's /dev/null device."""
+    import subprocess
+    exe, env = _build_c_demo()
+    out = subprocess.run([exe, "/dev/null"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "0x4000102005" in out.stdout and "0x4123456789" in out.stdout      # F-cabi / ATU goldens (SURVEY Appendix A)

@@ -697,6 +697,17 @@ def test_decode_loop_example_runs():
     assert out["depth"] <= 4 and out["mispredictions"] == 12          # random tokens never match: depth decays
 
 
+def test_c_demo_runs_on_the_gpu():
+    """examples/cxlspeckv_demo.c (the reference's cxlspeckv_demo, through the C ABI) end to end on the MI355X."""
+    import subprocess
+    from tests.test_cabi_boundary import _build_c_demo
+    exe, env = _build_c_demo()
+    out = subprocess.run([exe, "hip:0", "24"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Demo completed successfully" in out.stdout
+    assert "L2 (prefetched) hits" in out.stdout
+
+
 def test_striped_multi_pool_on_one_gpu(oracle):
     """SPECKV_POOL_DEVICES="0,0,0": three pools (here all on GPU 0) exercise the
     multi-GPU placement code on a one-GPU box: pages striped page % 3, host-built
