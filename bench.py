@@ -387,6 +387,26 @@ def xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream
     steps = max(1, min(args.steps, 20))
     sp = stream.cuda_stream
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # raw link calibration: one large device-to-device copy from the next GPU, every rank at once
+    # (a ring: each link carries one copy in one direction) -- the measured peak beside the nominal one
+    raw = None
+    try:
+        peer = 0 if single_gpu_test else (local_rank + 1) % world
+        nbytes = 256 << 20
+        remote = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{peer}")
+        local = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{0 if single_gpu_test else local_rank}")
+        local.copy_(remote, non_blocking=True); torch.cuda.synchronize()
+        dist.barrier()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(4):
+            local.copy_(remote, non_blocking=True)
+        c1.record(); torch.cuda.synchronize()
+        raw = 4 * nbytes / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del remote, local
+    except Exception as e:
+        info["raw_copy_skipped"] = repr(e)
+    all_ok(True)                  # keep the ranks in step whatever happened above
 
     def step(i):
         if i == 0:
@@ -409,6 +429,10 @@ def xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream
                      "peak_nominal_GBps_per_gpu": peak,
                      "frac_of_nominal": round(gbps / peak, 4),
                      "note": "nominal = links x 153.6 GB/s; per-direction accounting of that figure is not verified here"})
+        if raw:
+            info.update({"raw_peer_copy_GBps_one_link": round(raw, 1),
+                         "frac_of_measured_copy_peak": round(gbps / (raw * min(world - 1, 7)), 4),
+                         "raw_copy_note": "256 MiB device-to-device copy from the next GPU, all ranks at once (one direction per link)"})
     except Exception as e:
         info["skipped"] = repr(e)
     kv2.close()
