@@ -32,6 +32,21 @@ size_t env_mb(const char* name, size_t def_mb)
     return static_cast<size_t>(strtoull(e, nullptr, 10));
 }
 
+// The C ABI may be called with any HIP device current (SURVEY 8b "Threading"): every entry that touches the
+// GPU makes the engine's device current for its own duration and restores the caller's on every exit path.
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceScope() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 uint32_t stride_for(int scheme)
 {
     switch (scheme) {
@@ -167,9 +182,7 @@ int Engine::init_hip(int device)
 Engine::~Engine()
 {
     if (null_) return;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
-    (void)hipSetDevice(device_);
+    DeviceScope device_scope(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (auto& b : inflight_) (void)hipEventDestroy(b.ev);
     for (auto ev : event_pool_) (void)hipEventDestroy(ev);
@@ -185,7 +198,6 @@ Engine::~Engine()
     pools_.clear();
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     if (stream_) (void)hipStreamDestroy(stream_);
-    (void)hipSetDevice(prev);
 }
 
 Allocation* Engine::find(uint64_t h)
@@ -227,7 +239,7 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
         a->slot.assign(a->n_pages, 0u);
         a->access_count.assign(a->n_pages, 0u);
         if (a->n_pages) {
-            int prev = 0; (void)hipGetDevice(&prev); (void)hipSetDevice(device_);
+            DeviceScope device_scope(device_);
             // placement: preferred_node picks one pool GPU (1-based; 0 = stripe over all)
             std::vector<int> use;
             if (hint && hint->preferred_node >= 1 && hint->preferred_node <= pools_.size())
@@ -291,7 +303,6 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
             a->page_pool.resize(a->n_pages);
             for (uint64_t i = 0; i < a->n_pages; ++i) a->page_pool[i] = static_cast<uint8_t>(use[i % D]);
             if (ok) ok = hipStreamSynchronize(stream_) == hipSuccess;
-            (void)hipSetDevice(prev);
             if (!ok) {
                 (void)hipGetLastError();
                 release_allocation(a.get());
@@ -333,11 +344,10 @@ int Engine::free(uint64_t handle)
     auto it = allocs_.find(handle);
     if (it == allocs_.end()) return SPECKV_OK;
     if (!null_) {
-        int prev = 0; (void)hipGetDevice(&prev); (void)hipSetDevice(device_);
+        DeviceScope device_scope(device_);
         reap(true);
         (void)hipStreamSynchronize(stream_);
         release_allocation(it->second.get());
-        (void)hipSetDevice(prev);
     }
     st_.total_deallocations++;
     st_.current_allocated_bytes -= it->second->size_bytes;
@@ -499,7 +509,7 @@ int Engine::access(uint64_t handle, uint64_t off, size_t len, void** out)
     uint64_t p1 = len ? (off + len - 1) / kPageSize : p0;
     if (p1 >= a->n_pages) p1 = a->n_pages - 1;
     if (p1 - p0 + 1 > n_l2_) return SPECKV_ERR_NOMEM;
-    int prev = 0; (void)hipGetDevice(&prev); HIP_TRY(hipSetDevice(device_));
+    DeviceScope device_scope(device_);
     int rc = SPECKV_OK;
     // a multi-page span must come back contiguous
     bool contiguous = true;
@@ -542,7 +552,6 @@ int Engine::access(uint64_t handle, uint64_t off, size_t len, void** out)
         reap(true);
     }
     if (rc == SPECKV_OK) *out = slot_ptr(a->slot[p0]) + poff;
-    (void)hipSetDevice(prev);
     return rc;
 }
 
@@ -560,7 +569,7 @@ int Engine::access_batch(uint64_t handle, const uint64_t* offs, uint32_t n, void
         }
         return SPECKV_OK;
     }
-    int prev = 0; (void)hipGetDevice(&prev); HIP_TRY(hipSetDevice(device_));
+    DeviceScope device_scope(device_);
     ++epoch_;
     if (a->stamp.size() != a->n_pages) a->stamp.assign(a->n_pages, 0u);
     std::vector<uint32_t> miss;
@@ -592,7 +601,6 @@ int Engine::access_batch(uint64_t handle, const uint64_t* offs, uint32_t n, void
             out[i] = (a->flags[p] & 3u) ? slot_ptr(a->slot[p]) + offs[i] % kPageSize : nullptr;
             if (!out[i]) rc = SPECKV_ERR_GENERAL;   // evicted inside this very batch (cache smaller than batch)
         }
-    (void)hipSetDevice(prev);
     return rc;
 }
 
@@ -641,7 +649,7 @@ int Engine::prefetch_flush(uint32_t* n_issued)
         queue_.clear();
         return SPECKV_OK;
     }
-    int prev = 0; (void)hipGetDevice(&prev); HIP_TRY(hipSetDevice(device_));
+    DeviceScope device_scope(device_);
     const uint32_t n = static_cast<uint32_t>(queue_.size());
     std::vector<uint32_t> soa(4ull * n);
     for (uint32_t i = 0; i < n; ++i) {
@@ -653,7 +661,7 @@ int Engine::prefetch_flush(uint32_t* n_issued)
     const uint32_t cap = static_cast<uint32_t>(std::min<uint64_t>(n * 32ull * (row / kPageSize + 2), 1ull << 30));
     uint32_t* d_req = static_cast<uint32_t*>(scratch(s_req_, soa.size() * sizeof(uint32_t)));
     uint32_t* d_out = static_cast<uint32_t*>(scratch(s_out_, (static_cast<size_t>(cap) + 2ull * n + 4) * sizeof(uint32_t)));
-    if (!d_req || !d_out) { (void)hipSetDevice(prev); return SPECKV_ERR_NOMEM; }
+    if (!d_req || !d_out) return SPECKV_ERR_NOMEM;
     uint32_t* d_scr = d_out + cap;
     flush_mirror();
     HIP_TRY(hipMemcpyAsync(d_req, soa.data(), soa.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
@@ -690,7 +698,6 @@ int Engine::prefetch_flush(uint32_t* n_issued)
         }
     }
     if (rc == SPECKV_OK) rc = run_predictor_for_dirty();
-    (void)hipSetDevice(prev);
     return rc;
 }
 
@@ -699,7 +706,7 @@ int Engine::predictor_load(const float* emb, const float* wout, uint32_t vocab, 
 {
     if (null_) return no_data_path("speckv_ext_predictor_load");
     if (!emb || !wout || vocab < 8) return SPECKV_ERR_INVAL;
-    int prev = 0; (void)hipGetDevice(&prev); HIP_TRY(hipSetDevice(device_));
+    DeviceScope device_scope(device_);
     HIP_TRY(hipStreamSynchronize(stream_));
     if (d_emb_) { (void)hipFree(d_emb_); d_emb_ = nullptr; }
     if (d_wout_) { (void)hipFree(d_wout_); d_wout_ = nullptr; }
@@ -712,7 +719,6 @@ int Engine::predictor_load(const float* emb, const float* wout, uint32_t vocab, 
     HIP_TRY(hipMemcpy(d_wout_, wout, wb, kind));
     vocab_ = vocab;
     hist_.clear(); pred_.clear(); hist_dirty_.clear();
-    (void)hipSetDevice(prev);
     return SPECKV_OK;
 }
 
@@ -722,14 +728,13 @@ int Engine::predict_batch(uint32_t n, const int32_t* d_hist, uint32_t k, int32_t
     if (!d_emb_) return SPECKV_ERR_INVAL;
     if (n == 0) return SPECKV_OK;
     if (!d_hist || !d_tok || !d_conf || k == 0 || k > 8) return SPECKV_ERR_INVAL;
-    int prev = 0; (void)hipGetDevice(&prev); HIP_TRY(hipSetDevice(device_));
+    DeviceScope device_scope(device_);
     float* hid = static_cast<float*>(scratch(s_hid_, static_cast<size_t>(n) * 128 * sizeof(float)));
     float* logits = static_cast<float*>(scratch(s_logits_, static_cast<size_t>(n) * vocab_ * sizeof(float)));
-    if (!hid || !logits) { (void)hipSetDevice(prev); return SPECKV_ERR_NOMEM; }
+    if (!hid || !logits) return SPECKV_ERR_NOMEM;
     hipStream_t st = s ? s : stream_;
     HIP_TRY(launch_predict(n, d_hist, d_emb_, d_wout_, vocab_, 2, k, hid, logits, d_tok, d_conf, st));
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
-    (void)hipSetDevice(prev);
     return SPECKV_OK;
 }
 
@@ -769,14 +774,13 @@ int Engine::prefetch_lookup(uint64_t handle, uint32_t n, const uint32_t* d_req, 
     Allocation* a = find(handle);
     if (!a) return SPECKV_ERR_GENERAL;
     if (!a->has_layout) return SPECKV_ERR_INVAL;
-    int prev = 0; (void)hipGetDevice(&prev); HIP_TRY(hipSetDevice(device_));
+    DeviceScope device_scope(device_);
     flush_mirror();
     uint32_t* scr = static_cast<uint32_t*>(scratch(s_tmp_, (2ull * n + 4) * sizeof(uint32_t)));
-    if (!scr) { (void)hipSetDevice(prev); return SPECKV_ERR_NOMEM; }
+    if (!scr) return SPECKV_ERR_NOMEM;
     hipStream_t st = s ? s : stream_;
     HIP_TRY(launch_prefetch_lookup(a->layout, n, d_req, d_layer, d_pos, d_k, a->d_flags, d_out, cap, d_count, scr, st));
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
-    (void)hipSetDevice(prev);
     return SPECKV_OK;
 }
 
@@ -849,10 +853,9 @@ int Engine::translate(uint64_t handle, uint64_t off, speckv_ext_page_info_t* o)
     o->pool_device = -1;
     o->scale = 1.0f;
     if (!null_) {
-        int prev = 0; (void)hipGetDevice(&prev); HIP_TRY(hipSetDevice(device_));
+        DeviceScope device_scope(device_);
         PageEntry e{};
         HIP_TRY(hipMemcpy(&e, a->d_entries + p, sizeof(e), hipMemcpyDeviceToHost));
-        (void)hipSetDevice(prev);
         o->pool_device = pools_[a->page_pool[p]]->device();
         o->rec_bytes = e.rec_bytes;
         o->scale = e.scale;
@@ -890,7 +893,7 @@ int Engine::write(uint64_t handle, uint64_t off, const void* src, size_t len, bo
     if (len == 0) return SPECKV_OK;
     const uint64_t p0 = off / kPageSize;
     const uint64_t full = len / kPageSize, tail = len % kPageSize;
-    int prev = 0; (void)hipGetDevice(&prev); HIP_TRY(hipSetDevice(device_));
+    DeviceScope device_scope(device_);
     reap(true);
     // the source may have been produced on any stream of the caller: this call is
     // synchronous anyway, so order it after everything queued on the device
@@ -909,7 +912,7 @@ int Engine::write(uint64_t handle, uint64_t off, const void* src, size_t len, bo
         }
         if (tail) {
             uint8_t* st = static_cast<uint8_t*>(scratch(s_stage_, kPageSize));
-            if (!st) { (void)hipSetDevice(prev); return SPECKV_ERR_NOMEM; }
+            if (!st) return SPECKV_ERR_NOMEM;
             HIP_TRY(hipMemsetAsync(st, 0, kPageSize, stream_));
             HIP_TRY(hipMemcpyAsync(st, s8 + full * kPageSize, tail, hipMemcpyDeviceToDevice, stream_));
             c.first = p0 + full; c.n = 1; c.data = st;
@@ -919,7 +922,7 @@ int Engine::write(uint64_t handle, uint64_t off, const void* src, size_t len, bo
         const uint64_t total = full + (tail ? 1 : 0);
         const uint64_t chunk_pages = std::min<uint64_t>(total, 16384);      // 64 MiB staging
         uint8_t* st = static_cast<uint8_t*>(scratch(s_stage_, chunk_pages * kPageSize));
-        if (!st) { (void)hipSetDevice(prev); return SPECKV_ERR_NOMEM; }
+        if (!st) return SPECKV_ERR_NOMEM;
         for (uint64_t done = 0; done < total; done += chunk_pages) {
             const uint64_t np = std::min(chunk_pages, total - done);
             const size_t bytes = static_cast<size_t>(std::min<uint64_t>(np * kPageSize, len - done * kPageSize));
@@ -942,7 +945,6 @@ int Engine::write(uint64_t handle, uint64_t off, const void* src, size_t len, bo
     }
     st_.total_compressions += np;
     st_.original_bytes += np * kPageSize;
-    (void)hipSetDevice(prev);
     return SPECKV_OK;
 }
 
@@ -956,7 +958,7 @@ int Engine::read(uint64_t handle, uint64_t off, void* dst, size_t len, bool on_d
     if (len % kPageSize && off + len != a->size_bytes) return SPECKV_ERR_INVAL;
     if (len == 0) return SPECKV_OK;
     const uint64_t p0 = off / kPageSize, full = len / kPageSize, tail = len % kPageSize;
-    int prev = 0; (void)hipGetDevice(&prev); HIP_TRY(hipSetDevice(device_));
+    DeviceScope device_scope(device_);
     if (on_device) HIP_TRY(hipDeviceSynchronize());    // dst may still be in use on a caller stream
     CodecArgs c{};
     c.entries = a->d_entries;
@@ -972,7 +974,7 @@ int Engine::read(uint64_t handle, uint64_t off, void* dst, size_t len, bool on_d
         const uint64_t total = full + (tail ? 1 : 0);
         const uint64_t chunk_pages = std::min<uint64_t>(total, 16384);
         uint8_t* st = static_cast<uint8_t*>(scratch(s_stage_, chunk_pages * kPageSize));
-        if (!st) { (void)hipSetDevice(prev); return SPECKV_ERR_NOMEM; }
+        if (!st) return SPECKV_ERR_NOMEM;
         for (uint64_t done = 0; done < total; done += chunk_pages) {
             const uint64_t np = std::min(chunk_pages, total - done);
             const size_t bytes = static_cast<size_t>(std::min<uint64_t>(np * kPageSize, len - done * kPageSize));
@@ -987,7 +989,6 @@ int Engine::read(uint64_t handle, uint64_t off, void* dst, size_t len, bool on_d
     const uint64_t np = full + (tail ? 1 : 0);
     st_.total_decompressions += np;
     st_.dma_submitted += np; st_.dma_completed += np; completed_unpolled_ += np;
-    (void)hipSetDevice(prev);
     return SPECKV_OK;
 }
 
@@ -999,8 +1000,7 @@ int Engine::fetch_range(uint64_t handle, uint64_t first, uint64_t n, void* d_dst
     if (first > a->n_pages || n > a->n_pages - first) return SPECKV_ERR_GENERAL;
     if (!d_dst) return SPECKV_ERR_INVAL;
     if (n == 0) return SPECKV_OK;
-    int prev = 0; (void)hipGetDevice(&prev);
-    if (prev != device_) HIP_TRY(hipSetDevice(device_));
+    DeviceScope device_scope(device_);
     CodecArgs c{};
     c.entries = a->d_entries;
     c.trusted = 1;                       // pool records only ever come from k_compress
@@ -1021,7 +1021,6 @@ int Engine::fetch_range(uint64_t handle, uint64_t first, uint64_t n, void* d_dst
     } else {
         st_.dma_completed += n;            // completion belongs to the caller's stream
     }
-    if (prev != device_) (void)hipSetDevice(prev);
     return SPECKV_OK;
 }
 
@@ -1032,8 +1031,7 @@ int Engine::fetch_list(uint64_t handle, const uint32_t* d_pages, uint32_t n, voi
     if (!a) return SPECKV_ERR_GENERAL;
     if (!d_dst || (!d_pages && n)) return SPECKV_ERR_INVAL;
     if (n == 0) return SPECKV_OK;
-    int prev = 0; (void)hipGetDevice(&prev);
-    if (prev != device_) HIP_TRY(hipSetDevice(device_));
+    DeviceScope device_scope(device_);
     CodecArgs c{};
     c.entries = a->d_entries;
     c.trusted = 1;                       // pool records only ever come from k_compress
@@ -1054,7 +1052,6 @@ int Engine::fetch_list(uint64_t handle, const uint32_t* d_pages, uint32_t n, voi
     } else {
         st_.dma_completed += n;
     }
-    if (prev != device_) (void)hipSetDevice(prev);
     return SPECKV_OK;
 }
 
@@ -1078,8 +1075,7 @@ int Engine::qk_scores_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, co
     const uint64_t first_page = (static_cast<uint64_t>(layer) * 2 * L.num_tokens + pos_begin) / 2;
     const uint64_t layer_stride = static_cast<uint64_t>(L.num_tokens);      // pages per layer: K + V = 2*T/2
     if (first_page + (n_layers - 1) * layer_stride + n_pages > a->n_pages) return SPECKV_ERR_GENERAL;
-    int prev = 0; (void)hipGetDevice(&prev);
-    if (prev != device_) HIP_TRY(hipSetDevice(device_));
+    DeviceScope device_scope(device_);
     hipStream_t st = s ? s : stream_;
     const size_t rows = static_cast<size_t>(n_layers) * L.num_heads * 16;
     uint8_t* q8 = static_cast<uint8_t*>(scratch(s_req_, rows * 128 + rows * sizeof(float)));
@@ -1088,7 +1084,6 @@ int Engine::qk_scores_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, co
     HIP_TRY(launch_quantize_q_e4m3(d_q_f16, n_layers * L.num_heads, g, L.head_dim, q8, qs, st));
     HIP_TRY(launch_qk_scores_fp8(a->d_entries, first_page, layer_stride, n_layers, n_pages, L.num_heads, g, q8, qs, d_out, st));
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
-    if (prev != device_) (void)hipSetDevice(prev);
     return SPECKV_OK;
 }
 
@@ -1107,14 +1102,12 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
         return SPECKV_ERR_INVAL;
     if (g == 0 || g > 16 || !d_q_f16 || !d_out) return SPECKV_ERR_INVAL;
     const uint32_t n_pages = (pos_end - pos_begin) / 2;
-    int prev = 0; (void)hipGetDevice(&prev);
-    if (prev != device_) HIP_TRY(hipSetDevice(device_));
+    DeviceScope device_scope(device_);
     hipStream_t st = s ? s : stream_;
     const size_t out_elems = static_cast<size_t>(n_layers) * L.num_heads * g * 128;
     if (n_pages == 0) {          // empty range: softmax over nothing -> zeros (and -inf lse is left to the caller)
         HIP_TRY(hipMemsetAsync(d_out, 0, out_elems * sizeof(float), st));
         if (!s) HIP_TRY(hipStreamSynchronize(stream_));
-        if (prev != device_) (void)hipSetDevice(prev);
         return SPECKV_OK;
     }
     // shim layout [req 0][layer][kind][pos][head]: K pages of a layer, then its V pages
@@ -1169,7 +1162,6 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     HIP_TRY(launch_quantize_q_e4m3(d_q_f16, rows, g, L.head_dim, buf, reinterpret_cast<float*>(buf + q_bytes), st));
     HIP_TRY(launch_attend_fp8(k, n_layers, d_out, d_lse, st));
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
-    if (prev != device_) (void)hipSetDevice(prev);
     return SPECKV_OK;
 }
 
@@ -1188,14 +1180,12 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
         return SPECKV_ERR_INVAL;
     if (g == 0 || g > 16 || !d_q_f16 || !d_out) return SPECKV_ERR_INVAL;
     const uint32_t n_pages = (pos_end - pos_begin) / 2;
-    int prev = 0; (void)hipGetDevice(&prev);
-    if (prev != device_) HIP_TRY(hipSetDevice(device_));
+    DeviceScope device_scope(device_);
     hipStream_t st = s ? s : stream_;
     const size_t out_elems = static_cast<size_t>(n_layers) * L.num_heads * g * 128;
     if (n_pages == 0) {
         HIP_TRY(hipMemsetAsync(d_out, 0, out_elems * sizeof(float), st));
         if (!s) HIP_TRY(hipStreamSynchronize(stream_));
-        if (prev != device_) (void)hipSetDevice(prev);
         return SPECKV_OK;
     }
     const uint64_t k_first = (static_cast<uint64_t>(layer) * 2 * L.num_tokens + pos_begin) / 2;
@@ -1208,7 +1198,6 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     if (!a->linear_base || !fits) {
         SPECKV_ERR("speckv_ext_attend_int4: needs the allocation's records in one local run (not striped, not migrated) "
                    "and pos_begin + 32*ceil((pos_end-pos_begin)/32) <= num_tokens");
-        if (prev != device_) (void)hipSetDevice(prev);
         return SPECKV_ERR_INVAL;
     }
     const uint32_t rows = n_layers * L.num_heads;
@@ -1240,7 +1229,6 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     HIP_TRY(launch_attend_int4(k, n_layers, st));
     HIP_TRY(launch_attend_combine(k, n_layers, d_out, d_lse, st));
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
-    if (prev != device_) (void)hipSetDevice(prev);
     return SPECKV_OK;
 }
 
@@ -1256,13 +1244,13 @@ int Engine::migrate(uint64_t handle, uint64_t first, uint64_t n, uint32_t target
     if (first > a->n_pages || n > a->n_pages - first) return SPECKV_ERR_GENERAL;
     if (target_pool >= pools_.size()) return SPECKV_ERR_INVAL;
     if (n == 0) return SPECKV_OK;
-    int prev = 0; (void)hipGetDevice(&prev); HIP_TRY(hipSetDevice(device_));
+    DeviceScope device_scope(device_);
     HIP_TRY(hipStreamSynchronize(stream_));
     reap(true);
     if (!copy_stream_) HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
     const size_t stride = a->rec_stride;
     uint8_t* dst = static_cast<uint8_t*>(pools_[target_pool]->alloc(n * stride));
-    if (!dst) { (void)hipSetDevice(prev); return SPECKV_ERR_NOMEM; }
+    if (!dst) return SPECKV_ERR_NOMEM;
     std::vector<PageEntry> cur(n);
     HIP_TRY(hipMemcpy(cur.data(), a->d_entries + first, n * sizeof(PageEntry), hipMemcpyDeviceToHost));
     const int dst_dev = pools_[target_pool]->device();
@@ -1299,16 +1287,14 @@ int Engine::migrate(uint64_t handle, uint64_t first, uint64_t n, uint32_t target
     for (uint64_t i = 0; i < n; ++i) a->page_pool[first + i] = static_cast<uint8_t>(target_pool);
     a->linear_base = nullptr;                     // records no longer lie in one run
     st_.pool_migrated_pages += n;
-    (void)hipSetDevice(prev);
     return SPECKV_OK;
 }
 
 int Engine::poll_complete(uint32_t* done)
 {   // SPECKV_IOCTL_POLL_DONE: completions since the previous poll, then cleared
     if (null_) return SPECKV_ERR_DRIVER;
-    int prev = 0; (void)hipGetDevice(&prev); (void)hipSetDevice(device_);
+    DeviceScope device_scope(device_);
     reap(false);
-    (void)hipSetDevice(prev);
     *done = static_cast<uint32_t>(std::min<uint64_t>(completed_unpolled_, UINT32_MAX));
     completed_unpolled_ = 0;
     return SPECKV_OK;
@@ -1317,12 +1303,11 @@ int Engine::poll_complete(uint32_t* done)
 int Engine::sync()
 {
     if (null_) return SPECKV_OK;
-    int prev = 0; (void)hipGetDevice(&prev); HIP_TRY(hipSetDevice(device_));
+    DeviceScope device_scope(device_);
     uint32_t n = 0;
     int rc = prefetch_flush(&n);
     HIP_TRY(hipStreamSynchronize(stream_));
     reap(true);
-    (void)hipSetDevice(prev);
     return rc;
 }
 
@@ -1334,7 +1319,7 @@ int Engine::promote_to_l1(uint64_t handle, uint64_t off)
     const uint64_t p = off / kPageSize;
     if (p >= a->n_pages) return SPECKV_ERR_GENERAL;
     if (a->flags[p] & 1u) return SPECKV_ERR_GENERAL;          // already there -> false (cxl_memory_manager.cpp:134-136)
-    int prev = 0; (void)hipGetDevice(&prev); HIP_TRY(hipSetDevice(device_));
+    DeviceScope device_scope(device_);
     int rc = SPECKV_OK;
     if (a->flags[p] & 2u) {
         move_to_l1(a, static_cast<uint32_t>(p));
@@ -1350,7 +1335,6 @@ int Engine::promote_to_l1(uint64_t handle, uint64_t off)
         }
     }
     HIP_TRY(hipStreamSynchronize(stream_));
-    (void)hipSetDevice(prev);
     return rc;
 }
 
@@ -1377,7 +1361,7 @@ int Engine::stats(speckv_ext_stats_t* out)
     for (auto& p : pools_) st_.pool_bytes_reserved += p->reserved_bytes();
     if (!null_) {
         // compressed bytes = sum of record lengths currently stored
-        int prev = 0; (void)hipGetDevice(&prev); (void)hipSetDevice(device_);
+        DeviceScope device_scope(device_);
         uint64_t comp = 0;
         std::vector<PageEntry> host;
         for (auto& kv : allocs_) {
@@ -1388,7 +1372,6 @@ int Engine::stats(speckv_ext_stats_t* out)
                 for (auto& e : host) comp += e.rec_bytes;
         }
         st_.compressed_bytes = comp;
-        (void)hipSetDevice(prev);
     }
     *out = st_;
     return SPECKV_OK;
