@@ -600,18 +600,22 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     hit_us = (time.perf_counter() - t0) / 10 * 1e6
     ex["speckv_access_us"] = {"miss_sync_fetch": round(miss_us, 2), "hit": round(hit_us, 2),
                               "reference_emulated_us": "2.2-2.8 (SURVEY 3.1, no data moved)"}
-    # one decode step of a 256-sequence batch worth of look-ahead requests (cfg4-sized call count)
+    # one decode step of a 256-sequence batch worth of look-ahead requests (cfg4-sized call count); the first
+    # flush of a process also pays scratch allocation and first-launch costs, so it is reported apart
     n_req = 256 * Lyr
     reqs = [0] * n_req
     layers = [i % Lyr for i in range(n_req)]
-    pos = [int(p) for p in rng.integers(0, T - 8, n_req)]
-    lib.prefetch_batch(reqs, layers, pos, [4] * n_req)
-    t0 = time.perf_counter()
-    issued = lib.prefetch_flush()
-    lib.sync()
-    dt = time.perf_counter() - t0
-    ex["prefetch_flush"] = {"requests": n_req, "pages_issued": issued, "ms": round(dt * 1e3, 3),
-                            "requests_per_s": round(n_req / dt, 1)}
+    flush_ms, issued_n = [], []
+    for rep in range(3):
+        pos = [int(p) for p in rng.integers(0, T - 8, n_req)]
+        lib.prefetch_batch(reqs, layers, pos, [4] * n_req)
+        t0 = time.perf_counter()
+        issued_n.append(lib.prefetch_flush())
+        lib.sync()
+        flush_ms.append((time.perf_counter() - t0) * 1e3)
+    ex["prefetch_flush"] = {"requests": n_req, "pages_issued": issued_n[-1], "ms": round(min(flush_ms[1:]), 3),
+                            "first_call_ms": round(flush_ms[0], 3), "requests_per_s": round(n_req / (min(flush_ms[1:]) * 1e-3), 1),
+                            "note": "lookup kernels + list read-back + ring-slot assignment + fetch launch + sync, steady state"}
     ex.update(fp8_scores_extra(torch, kv, 32768, 80))
     ex.update(int4_attention_extra(torch, kv, 32768, 80))      # BASELINE configs[4] shape: 70B-shaped KV @ 32k context
     ex.update(predictor_extra(torch, lib))

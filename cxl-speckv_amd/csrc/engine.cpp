@@ -2,6 +2,7 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -650,6 +651,9 @@ int Engine::prefetch_flush(uint32_t* n_issued)
         return SPECKV_OK;
     }
     DeviceScope device_scope(device_);
+    static const bool timing = getenv("SPECKV_TIMING") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto t_a = tnow();
     const uint32_t n = static_cast<uint32_t>(queue_.size());
     std::vector<uint32_t> soa(4ull * n);
     for (uint32_t i = 0; i < n; ++i) {
@@ -670,8 +674,10 @@ int Engine::prefetch_flush(uint32_t* n_issued)
     uint32_t count = 0;
     HIP_TRY(hipMemcpyAsync(&count, d_count_, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
+    auto t_b = tnow();
     std::vector<uint32_t> cand(count);
     if (count) HIP_TRY(hipMemcpy(cand.data(), d_out, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    auto t_c = tnow();
     // host side: dedupe across requests, assign ring slots, submit one fetch batch
     ++epoch_;
     if (a->stamp.size() != a->n_pages) a->stamp.assign(a->n_pages, 0u);
@@ -680,13 +686,16 @@ int Engine::prefetch_flush(uint32_t* n_issued)
     for (uint32_t p : cand)
         if (p < a->n_pages && !(a->flags[p] & 3u) && a->stamp[p] != epoch_) { a->stamp[p] = epoch_; pages.push_back(p); }
     if (pages.size() > n_l2_ / 2) pages.resize(n_l2_ / 2);   // never let one flush wipe the whole ring
+    auto t_d = tnow(), t_e = t_d, t_f = t_d;
     int rc = SPECKV_OK;
     if (!pages.empty()) {
         const uint32_t m = static_cast<uint32_t>(pages.size());
         const uint32_t run = take_l2_run(m);
         std::vector<uint32_t> slots(m);
         for (uint32_t i = 0; i < m; ++i) slots[i] = run + i;
+        t_e = tnow();
         rc = fetch_into_slots(a, pages, slots, false);       // asynchronous: overlaps the caller's compute
+        t_f = tnow();
         if (rc == SPECKV_OK) {
             for (uint32_t i = 0; i < m; ++i) {
                 a->slot[pages[i]] = slots[i];
@@ -696,6 +705,11 @@ int Engine::prefetch_flush(uint32_t* n_issued)
             st_.total_prefetches += m;
             if (n_issued) *n_issued = m;
         }
+    }
+    if (timing) {
+        auto us = [](auto x, auto y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
+        fprintf(stderr, "[speckv timing] flush n=%u: lookup+sync %.1f us, list d2h %.1f, dedupe %.1f, ring %.1f, submit %.1f, bookkeeping %.1f\n",
+                n, us(t_a, t_b), us(t_b, t_c), us(t_c, t_d), us(t_d, t_e), us(t_e, t_f), us(t_f, tnow()));
     }
     if (rc == SPECKV_OK) rc = run_predictor_for_dirty();
     return rc;
