@@ -587,6 +587,27 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     lib = kv.lib
     ex = {}
     rng = np.random.default_rng(7)
+    # SURVEY 8d access pattern (ii): the same blocks fetched in a seeded uniform-random page permutation
+    try:
+        perm = torch.from_numpy(np.random.default_rng(2001).permutation(n_blocks).astype(np.int32)).cuda()
+        out = torch.empty((n_blocks, BLOCK_ELEMS), dtype=torch.float16, device="cuda")
+        st_ = torch.cuda.Stream()
+        def gather():
+            lib.fetch_list(handle, perm.data_ptr(), n_blocks, out.data_ptr(), False, st_.cuda_stream)
+        gather(); torch.cuda.synchronize()
+        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a_.record(st_)
+        for _ in range(10):
+            gather()
+        b_.record(st_); torch.cuda.synchronize()
+        ms = a_.elapsed_time(b_) / 10
+        rec_total = lib.stats().compressed_bytes
+        ex["fetch_random_permutation"] = {"blocks_per_s": round(n_blocks / (ms * 1e-3), 1), "ms": round(ms, 4),
+                                          "frac_hbm": round((rec_total + n_blocks * (PAGE + 4 + 12)) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                          "note": "speckv_ext_fetch_list over a seeded permutation of all pages (page list + 8 B destination per block read too)"}
+        del out, perm
+    except Exception as e:
+        ex["fetch_random_permutation"] = {"error": repr(e)}
     # speckv_access: miss = synchronous fetch of one page; hit = page-table lookup only
     offs = [int(p) * PAGE for p in rng.integers(0, n_blocks, 200)]
     t0 = time.perf_counter()
@@ -655,6 +676,22 @@ def run_extras(torch, pkg, lib, src, dst, n_blocks, sp):
             "compress_GBps": round(enc_bytes / (enc_ms * 1e-3) / 1e9, 1),
             "record_bytes_per_block": round(comp / n_blocks, 1),
         }
+    # SURVEY 8d structured sets that exercise the RLE stage itself: all-zero blocks (one run per 255 elements) and
+    # piecewise-constant blocks (runs of 32), INT8_DELTA_RLE, reference quantiser
+    g = torch.Generator(device="cuda"); g.manual_seed(77)
+    pw = torch.randn((n_blocks, BLOCK_ELEMS // 32), generator=g, device="cuda").repeat_interleave(32, dim=1).to(torch.float16)
+    for name, data in (("rle_all_zero_blocks", torch.zeros_like(src)), ("rle_piecewise_runs_of_32", pw)):
+        enc = lambda: raw.speckv_ext_codec_compress(data.data_ptr(), n_blocks, recs.data_ptr(), PAGE, lens.data_ptr(), scales.data_ptr(), 2, 0, sp)
+        dec = lambda: raw.speckv_ext_codec_decompress(recs.data_ptr(), PAGE, lens.data_ptr(), scales.data_ptr(), n_blocks, dst.data_ptr(), 0, 2, 0, sp)
+        enc_ms = timed(enc)
+        dec_ms = timed(dec)
+        comp = int(lens.to(torch.int64).sum().item())
+        dec_bytes = comp + n_blocks * (4 + PAGE)
+        ex[name] = {"decompress_blocks_per_s": round(n_blocks / (dec_ms * 1e-3), 1),
+                    "decompress_GBps": round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1),
+                    "decompress_frac_hbm": round(dec_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    "compress_blocks_per_s": round(n_blocks / (enc_ms * 1e-3), 1),
+                    "record_bytes_per_block": round(comp / n_blocks, 1)}
     return ex
 
 

@@ -680,6 +680,7 @@ __device__ __forceinline__ uint32_t encode_rle_fast(const float (&x)[4][8], floa
     const uint32_t pair_addr = lds_addr_of(wl + kEncPairOff);
     const uint32_t dummy = lds_addr_of(wl);
     uint32_t qtail = 0, dtail = 0, mcarry = 0, icarry = 0;       // mcarry: position+1 of the last run start
+    bool prev_sparse = false, failed = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t p0 = 512u * j + 8u * lane;
@@ -703,22 +704,23 @@ __device__ __forceinline__ uint32_t encode_rle_fast(const float (&x)[4][8], floa
             cnt += nq[k] ? 1u : 0u;
             lm = nq[k] ? p0 + k + 1u : lm;
         }
-        if (__popcll(__ballot(cnt == 0u)) >= 14) {                           // wave-uniform: long stretch possible
-            // stage the rest of the block for the general path
-            for (int jj = j + 1; jj < 4; ++jj) {
-                uint32_t qq[8];
-                quantize_chunk<MODE>(x[jj], scale, rcp, finite, qq);
-                *reinterpret_cast<uint2*>(wl + kEncQOff + 512u * jj + 8u * lane) =
-                    make_uint2(qq[0] | (qq[1] << 8) | (qq[2] << 16) | (qq[3] << 24), qq[4] | (qq[5] << 8) | (qq[6] << 16) | (qq[7] << 24));
-            }
-            return kEncFail;
-        }
+        // cheap pre-filter: a run longer than 248 elements needs >= 28 start-free lanes in this chunk and the previous
+        // one together, i.e. >= 14 in one of them
+        const bool sparse = __popcll(__ballot(cnt == 0u)) >= 14;             // wave-uniform
+        const bool suspicious = sparse || prev_sparse;
+        prev_sparse = sparse;
         const uint32_t ic = wave_incl_add(cnt);
         uint32_t idx = icarry + ic - cnt;
         icarry += lane63(ic);
         const uint32_t im = wave_incl_max(lm);
         uint32_t m = umax(wave_shr1(im, 0u), mcarry);
         mcarry = umax(mcarry, lane63(im));
+        // A count is "position of this run start - previous run start"; only a lane's FIRST start of the chunk can
+        // close a long run, and that run is shorter than (end of the lane's 8 elements - previous start).  If that
+        // bound passes 255 anywhere the run may need splitting (cache_engine.cpp:224), which only the general path does.
+        // (the loop simply runs on after a failure -- every chunk stages its q bytes for the general path anyway and
+        // the scatter stays inside the pair buffer -- which keeps this rare branch out of the register budget)
+        if (suspicious && __ballot(cnt != 0u && p0 + 8u - m > 255u) != 0ull) failed = true;   // wave-uniform
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t p = p0 + k;
@@ -729,6 +731,7 @@ __device__ __forceinline__ uint32_t encode_rle_fast(const float (&x)[4][8], floa
             idx += nq[k] ? 1u : 0u;
         }
     }
+    if (failed || kBlockElems + 1u - mcarry > 255u) return kEncFail;        // a run may need splitting (q is fully staged)
     lds_store_b8(pair_addr + 2u * icarry - 1u, kBlockElems + 1u - mcarry);  // close the last run
     return icarry;
 }
@@ -919,6 +922,12 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                     *reinterpret_cast<uint2*>(rec + 512u * j + 8u * lane) = o;
                 }
                 out_len = kBlockElems;
+            } else if (mx == 0.0f) {
+                // every element is +-0 (or a NaN, which quantises to 0 as well): all deltas are 0, so the record is
+                // eight runs of 255 zeros and one of 8 (cache_engine.cpp:208-239) -- no need to encode anything
+                if (lane < 16u)
+                    reinterpret_cast<uint16_t*>(rec)[lane] = lane < 8u ? 0xFF00u : (lane == 8u ? 0x0800u : 0u);
+                out_len = 18u;
             } else {
                 uint8_t* wl = reinterpret_cast<uint8_t*>(lds) + wave * kEncWaveBytes;
                 uint32_t nruns = encode_rle_fast<MODE>(x, scale, rcp, finite, wl, lane);
