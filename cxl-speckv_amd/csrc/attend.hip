@@ -203,10 +203,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;
 
     // query operand: bytes [32kb, 32kb+32) of e4m3 row c; its scale carries sm_scale*log2(e)
-    const uint8_t* qrow = a.q8 + (row * 16u + c) * 128u + kb * 32u;
-    const uint4 qa0 = *reinterpret_cast<const uint4*>(qrow), qa1 = *reinterpret_cast<const uint4*>(qrow + 16);
-    const uint32_t qd[8] = {qa0.x, qa0.y, qa0.z, qa0.w, qa1.x, qa1.y, qa1.z, qa1.w};
-    const float qscale = a.qs[row * 16u + c] * a.scale_log2e;
+    // query operand: row c of this head, d = 32kb + 8*step + e, quantised here exactly as k_quantize_q_e4m3 does
+    // (scale = max|q|/448 over the row, 1 if zero; e4m3 of clamp(q/scale)); rows >= g are zero
+    uint32_t qd[8];
+    float qscale;
+    {
+        float xq[32];
+        float mx = 0.0f;
+        const uint16_t* qsrc = a.q16 + (row * a.g + min(c, a.g - 1u)) * 128u + kb * 32u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 w = *reinterpret_cast<const uint4*>(qsrc + 8 * i);
+            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                xq[8 * i + k] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(ws[k >> 1] >> (16 * (k & 1)))));
+                mx = fmaxf(mx, fabsf(xq[8 * i + k]));
+            }
+        }
+        mx = max_over_kb(mx);
+        const float sc = (mx > 0.0f) ? (mx / 448.0f) : 1.0f;
+        const bool live = c < a.g;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = live ? fminf(fmaxf(xq[4 * i + k] / sc, -448.0f), 448.0f) : 0.0f;
+            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+            qd[i] = static_cast<uint32_t>(pk);
+        }
+        qscale = (live ? sc : 1.0f) * a.scale_log2e;
+    }
 
     const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
     const uint32_t t0 = split * a.tiles_per_split;
@@ -262,9 +290,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // ---- linear form ------------------------------------------------------------------------------
 // The allocation's records lie in one run (record p at lin_base + p*2048, the engine's default
 // placement) and never-written records are zero bytes (the engine zero-fills FP8 pools), so every
-// data address is arithmetic.  What the page table holds per page (scale, validity) is condensed
-// by k_attend_prepare into per-tile tables, laid out so that one 16-byte load gives a lane the
-// scales of its four slot pages; nothing gates the data loads any more.
+// data address is arithmetic.  The page scales come from the allocation's scale_tab (kept in tile
+// order by k_compress: one 16-byte load gives a lane the scales of its four slot pages); nothing
+// gates the data loads any more and the call needs no helper launch: the query rows are quantised
+// in the kernel prologue (each lane converts exactly the 32 values it feeds to the score MFMAs).
 //
 // The texture addresser, not HBM, bounds the page-table form (28 loads per tile, TA 80 % busy at
 // 5.1 TB/s, profiles/): here a tile costs 15 loads -- K 4 x 16 B, V 8 x 8 B (whole 128-byte lines
@@ -272,40 +301,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // d = 8c + t (t = 0..7), i.e. lane (c, kb) holds out[row c][32kb + 8i + t] in acc[t][i].
 //
 // The output MFMAs accumulate in place (C = acc).  acc is kept in units of the current tile's V
-// reference scale vref_t (its largest V page scale, 1 when that is 0), so the V page scales ride on
-// the f16 weights as vs/vref_t <= 1 and the only per-tile fix-up of acc is one multiply by
-// alpha * vref_{t-1}/vref_t (the ratio is tabulated, exact division, by the prepare kernel).
+// reference scale vref_t (its largest V page scale; unchanged when that is 0), so the V page scales
+// ride on the f16 weights as vs/vref_t <= 1 and the only per-tile fix-up of acc is one multiply by
+// alpha * vref_{t-1}/vref_t.
 
-// tables per (layer, tile): ktab/vtab 16 floats permuted as [kb][r] (r-th slot page of lane group kb:
-// pages 2kb, 2kb+1, 8+2kb, 9+2kb), vtab normalised by vref; vinfo {vref_t, vref_{t-1}/vref_t}
-__global__ __launch_bounds__(256) void k_attend_prepare(AttendArgs a, uint32_t n_tiles)
+// scale_tab of an allocation: the block scale of every page, stored in "tile order" -- for each aligned group of 16
+// pages of a (layer, kind) region the order [kb][r] = pages 2kb, 2kb+1, 8+2kb, 9+2kb -- so that lane group kb reads the
+// scales of its four slot pages with one 16-byte load.  k_compress keeps it current (CodecArgs::scale_tab); this kernel
+// (re)builds it from the page table when the layout becomes known.  Never-written pages hold 0.
+__global__ __launch_bounds__(256) void k_build_scale_tab(const PageEntry* __restrict__ entries, uint64_t n_pages,
+                                                         uint32_t region_pages, float* __restrict__ tab)
 {
-    const uint32_t layer = blockIdx.y, slot = threadIdx.x & 15u;
-    const uint32_t tile = blockIdx.x * 16u + (threadIdx.x >> 4);
-    const PageEntry* kent = a.entries + a.k_first + layer * a.layer_stride;
-    const PageEntry* vent = a.entries + a.v_first + layer * a.layer_stride;
-    auto page_of = [&](uint32_t t, uint32_t sl) { const uint32_t q = sl >> 2, r = sl & 3u; return t * 16u + (r < 2u ? 2u * q + r : 8u + 2u * q + (r - 2u)); };
-    auto vscale_of = [&](uint32_t t, uint32_t sl) {
-        const uint32_t pg = page_of(t, sl);
-        if (t >= n_tiles || pg >= a.n_pages) return 0.0f;
-        const PageEntry e = vent[pg];
-        return e.rec_bytes >= kBlockElems ? e.scale : 0.0f;
-    };
-    float ksc = 0.0f;
-    if (tile < n_tiles && page_of(tile, slot) < a.n_pages) {
-        const PageEntry e = kent[page_of(tile, slot)];
-        if (e.rec_bytes >= kBlockElems) ksc = e.scale;
-    }
-    const float vsc = vscale_of(tile, slot);
-    float vmx = vsc, pmx = (tile > 0) ? vscale_of(tile - 1u, slot) : 0.0f;     // this tile's and the previous tile's largest
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) { vmx = fmaxf(vmx, __shfl_xor(vmx, o)); pmx = fmaxf(pmx, __shfl_xor(pmx, o)); }
-    if (tile >= n_tiles) return;
-    const float vref = vmx > 0.0f ? vmx : 1.0f, pref = pmx > 0.0f ? pmx : 1.0f;
-    const uint64_t at = static_cast<uint64_t>(layer) * n_tiles + tile;
-    a.ktab[at * 16u + slot] = ksc;
-    a.vtab[at * 16u + slot] = vsc / vref;
-    if (slot == 0) { a.vinfo[at * 2u] = vref; a.vinfo[at * 2u + 1u] = pref / vref; }
+    const uint64_t p = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    if (p >= n_pages) return;
+    const PageEntry e = entries[p];
+    const uint32_t j = static_cast<uint32_t>(p % region_pages) & 15u;
+    tab[p - j + attend_tile_slot(j)] = e.rec_bytes >= kBlockElems ? e.scale : 0.0f;
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_attend_fp8_linear(AttendArgs a)
@@ -320,10 +331,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;
     const uint64_t part = row * a.n_splits + split;
 
-    const uint8_t* qrow = a.q8 + (row * 16u + c) * 128u + kb * 32u;
-    const uint4 qa0 = *reinterpret_cast<const uint4*>(qrow), qa1 = *reinterpret_cast<const uint4*>(qrow + 16);
-    const uint32_t qd[8] = {qa0.x, qa0.y, qa0.z, qa0.w, qa1.x, qa1.y, qa1.z, qa1.w};
-    const float qscale = a.qs[row * 16u + c] * a.scale_log2e;
+    // query operand: row c of this head, d = 32kb + 8*step + e, quantised here exactly as k_quantize_q_e4m3 does
+    // (scale = max|q|/448 over the row, 1 if zero; e4m3 of clamp(q/scale)); rows >= g are zero
+    uint32_t qd[8];
+    float qscale;
+    {
+        float xq[32];
+        float mx = 0.0f;
+        const uint16_t* qsrc = a.q16 + (row * a.g + min(c, a.g - 1u)) * 128u + kb * 32u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 w = *reinterpret_cast<const uint4*>(qsrc + 8 * i);
+            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                xq[8 * i + k] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(ws[k >> 1] >> (16 * (k & 1)))));
+                mx = fmaxf(mx, fabsf(xq[8 * i + k]));
+            }
+        }
+        mx = max_over_kb(mx);
+        const float sc = (mx > 0.0f) ? (mx / 448.0f) : 1.0f;
+        const bool live = c < a.g;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = live ? fminf(fmaxf(xq[4 * i + k] / sc, -448.0f), 448.0f) : 0.0f;
+            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+            qd[i] = static_cast<uint32_t>(pk);
+        }
+        qscale = (live ? sc : 1.0f) * a.scale_log2e;
+    }
 
     const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
     const uint32_t t0 = split * a.tiles_per_split;
@@ -339,15 +378,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                             + (static_cast<uint64_t>(t0) * 32u + c) * 1024u;            // block b: + b*16 KiB
         const uint8_t* vp = a.lin_base + (a.v_first + layer * a.layer_stride) * 2048ull + head * 128u + 8u * c
                             + (static_cast<uint64_t>(t0) * 32u + 4u * kb) * 1024u;       // slot j: + (j&3) KiB + (j>>2)*16 KiB
-        const uint64_t at0 = static_cast<uint64_t>(layer) * n_tiles + t0;
-        const float* kt = a.ktab + at0 * 16u + 4u * kb;
-        const float* vt = a.vtab + at0 * 16u + 4u * kb;
-        const float* vi = a.vinfo + at0 * 2u;
+        const float* kt = a.scale_tab + (a.k_first + layer * a.layer_stride + static_cast<uint64_t>(t0) * 16u) + 4u * kb;
+        const float* vt = a.scale_tab + (a.v_first + layer * a.layer_stride + static_cast<uint64_t>(t0) * 16u) + 4u * kb;
 
         uint4 kx[2][2];
         uint2 vx[8];
         f32x4 ks4, vs4;
-        float vref_t, ratio_t;
         auto issue_k = [&]() {
 #pragma unroll
             for (int b = 0; b < 2; ++b) { kx[b][0] = ldg16(kp + 16384 * b); kx[b][1] = ldg16(kp + 16384 * b + 16); }
@@ -357,8 +393,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int j = 0; j < 8; ++j) vx[j] = ldg8(vp + 1024 * (j & 3) + 16384 * (j >> 2));
             vs4 = *reinterpret_cast<const f32x4*>(vt);
-            vref_t = vi[0];
-            ratio_t = vi[1];
         };
         // same request order as in the loop (K before V), pinned, so that the wait at the loop head is
         // "everything up to K" on both paths into it
@@ -407,16 +441,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;
             const float f = __builtin_amdgcn_exp2f(m_run - m_use);
             m_run = m_new;
+            // the tile's V reference scale (its largest V page scale) and the weights in units of it
+            const float vmx = max_over_kb(fmaxf(fmaxf(vs4[0], vs4[1]), fmaxf(vs4[2], vs4[3])));
+            const float vref_t = vmx > 0.0f ? vmx : vref;
+            const float rinv = __builtin_amdgcn_rcpf(vref_t);
             float psum = 0.0f;
             f16x8 P;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float p = __builtin_amdgcn_exp2f(sc[j] - m_use);
                 psum += p;
-                P[j] = static_cast<_Float16>(p * vs4[j >> 1]);
+                P[j] = static_cast<_Float16>(p * (vs4[j >> 1] * rinv));
             }
             l_run = l_run * f + psum;
-            const float fa = f * ratio_t;                                 // acc: old max -> new max, old V reference -> new
+            const float fa = f * (vref * rinv);                            // acc: old max -> new max, old V reference -> new
             vref = vref_t;
             // ---- out^T += V^T . P^T, accumulated in place
             uint32_t w[4][4];                                             // [row pair][byte pair of the 8 d]
@@ -440,7 +478,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t] * fa, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            vp += step * 32768u; vt += step * 16u; vi += step * 2u;
+            vp += step * 32768u; vt += step * 16u;
             issue_v();
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -461,49 +499,88 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
-// one workgroup (128 threads = the 128 d) per (layer, head, query row): merge the splits
-__global__ __launch_bounds__(128) void k_attend_combine(const float* __restrict__ part_acc, const float* __restrict__ part_ml,
+// Merge of the split partials: one workgroup of 512 threads per (layer, head, query row).  The per-layer call of a
+// decode step has few rows and many splits, so the merge must not walk the splits serially (a 128-split merge with
+// one dependent load chain per thread took 52 us, 3.5x the attention kernel itself): every thread first takes its
+// own splits for the max and the weights (kept in LDS), then four thread groups share the splits of the weighted sum.
+constexpr uint32_t kMaxSplits = 2048;
+__global__ __launch_bounds__(512) void k_attend_combine(const float* __restrict__ part_acc, const float* __restrict__ part_ml,
                                                         uint32_t g, uint32_t n_splits, float* __restrict__ out,
                                                         float* __restrict__ lse)
 {
-    const uint32_t rowq = blockIdx.x / g, m = blockIdx.x % g, d = threadIdx.x;     // rowq = layer*heads + head
-    float M = -INFINITY;
-    for (uint32_t s = 0; s < n_splits; ++s) M = fmaxf(M, part_ml[(static_cast<uint64_t>(rowq) * n_splits + s) * 32u + m]);
+    __shared__ float w[kMaxSplits];
+    __shared__ float red[8];
+    __shared__ float osum[4][128];
+    const uint32_t rowq = blockIdx.x / g, m = blockIdx.x % g, t = threadIdx.x;     // rowq = layer*heads + head
+    const uint32_t lane = t & 63u, wv = t >> 6;
+    const float* ml = part_ml + static_cast<uint64_t>(rowq) * n_splits * 32u;
+    auto block_reduce = [&](float v, bool is_max) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const float u = __shfl_xor(v, o); v = is_max ? fmaxf(v, u) : v + u; }
+        __syncthreads();
+        if (lane == 0) red[wv] = v;
+        __syncthreads();
+        float r = red[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+        return r;
+    };
+    float mloc = -INFINITY;
+    for (uint32_t s = t; s < n_splits; s += 512u) mloc = fmaxf(mloc, ml[s * 32u + m]);
+    const float M = block_reduce(mloc, true);
     const float Mu = (M == -INFINITY) ? 0.0f : M;
-    float L = 0.0f, o = 0.0f;
-    for (uint32_t s = 0; s < n_splits; ++s) {
-        const uint64_t part = static_cast<uint64_t>(rowq) * n_splits + s;
-        const float w = __builtin_amdgcn_exp2f(part_ml[part * 32u + m] - Mu);
-        L += w * part_ml[part * 32u + 16u + m];
-        o += w * part_acc[(part * 16u + m) * 128u + d];
+    float lloc = 0.0f;
+    for (uint32_t s = t; s < n_splits; s += 512u) {
+        const float ws = __builtin_amdgcn_exp2f(ml[s * 32u + m] - Mu);
+        w[s] = ws;
+        lloc += ws * ml[s * 32u + 16u + m];
     }
-    out[(static_cast<uint64_t>(rowq) * g + m) * 128u + d] = L > 0.0f ? o / L : 0.0f;
-    if (lse && d == 0) lse[static_cast<uint64_t>(rowq) * g + m] = L > 0.0f ? (M + log2f(L)) * 0.6931471805599453f : -INFINITY;
+    const float L = block_reduce(lloc, false);                     // (its barriers also publish w[])
+    const uint32_t grp = t >> 7, d = t & 127u;
+    const float* acc = part_acc + (static_cast<uint64_t>(rowq) * n_splits * 16u + m) * 128u + d;
+    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
+    uint32_t s = grp;
+    for (; s + 12u < n_splits; s += 16u) {                         // four independent loads in flight per thread
+        o0 += w[s] * acc[static_cast<uint64_t>(s) * 2048u];
+        o1 += w[s + 4u] * acc[static_cast<uint64_t>(s + 4u) * 2048u];
+        o2 += w[s + 8u] * acc[static_cast<uint64_t>(s + 8u) * 2048u];
+        o3 += w[s + 12u] * acc[static_cast<uint64_t>(s + 12u) * 2048u];
+    }
+    for (; s < n_splits; s += 4u) o0 += w[s] * acc[static_cast<uint64_t>(s) * 2048u];
+    osum[grp][d] = (o0 + o1) + (o2 + o3);
+    __syncthreads();
+    if (grp == 0) {
+        const float o = (osum[0][d] + osum[1][d]) + (osum[2][d] + osum[3][d]);
+        out[(static_cast<uint64_t>(rowq) * g + m) * 128u + d] = L > 0.0f ? o / L : 0.0f;
+        if (lse && d == 0) lse[static_cast<uint64_t>(rowq) * g + m] = L > 0.0f ? (M + log2f(L)) * 0.6931471805599453f : -INFINITY;
+    }
 }
 
 hipError_t launch_attend_combine(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s)
 {
     if (n_layers == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_attend_combine, dim3(n_layers * a.heads * a.g), dim3(128), 0, s, a.part_acc, a.part_ml, a.g,
+    if (a.n_splits > kMaxSplits) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_attend_combine, dim3(n_layers * a.heads * a.g), dim3(512), 0, s, a.part_acc, a.part_ml, a.g,
                        a.n_splits, d_out, d_lse);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_scale_tab(const PageEntry* d_entries, uint64_t n_pages, uint32_t region_pages, float* d_scale_tab, hipStream_t s)
+{
+    if (n_pages == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_build_scale_tab, dim3(static_cast<uint32_t>((n_pages + 255u) / 256u)), dim3(256), 0, s, d_entries, n_pages,
+                       region_pages, d_scale_tab);
     return hipGetLastError();
 }
 
 hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s)
 {
     if (a.n_pages == 0 || n_layers == 0) return hipSuccess;
-    if (a.lin_base) {
-        const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
-        hipLaunchKernelGGL(k_attend_prepare, dim3((n_tiles + 15u) / 16u, n_layers), dim3(256), 0, s, a, n_tiles);
-        hipLaunchKernelGGL(k_attend_fp8_linear, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
-    } else {
-        hipLaunchKernelGGL(k_attend_fp8, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
-    }
+    if (a.lin_base) hipLaunchKernelGGL(k_attend_fp8_linear, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
+    else            hipLaunchKernelGGL(k_attend_fp8, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_attend_combine, dim3(n_layers * a.heads * a.g), dim3(128), 0, s, a.part_acc, a.part_ml, a.g,
-                       a.n_splits, d_out, d_lse);
-    return hipGetLastError();
+    return launch_attend_combine(a, n_layers, d_out, d_lse, s);
 }
 
 } // namespace speckv

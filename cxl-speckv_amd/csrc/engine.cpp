@@ -336,6 +336,7 @@ void Engine::release_allocation(Allocation* a)
     a->extents.clear();
     if (a->d_entries) (void)hipFree(a->d_entries);
     if (a->d_flags) (void)hipFree(a->d_flags);
+    if (a->d_scale_tab) { (void)hipFree(a->d_scale_tab); a->d_scale_tab = nullptr; }
     a->d_entries = nullptr;
     a->d_flags = nullptr;
 }
@@ -848,6 +849,19 @@ int Engine::set_layout(uint64_t handle, uint32_t T, uint32_t L, uint32_t H, uint
     a->layout = Layout{T, L, H, D, bpe, a->n_pages};
     a->has_layout = true;
     layout_handle_ = handle;
+    // fused-attention scale table (FP8 records, 2 positions per page, regions aligned to 16-page tiles)
+    if (!null_ && a->scheme == SPECKV_COMP_FP8_E4M3 && a->n_pages && static_cast<uint64_t>(H) * D * bpe == 2048u && T % 32u == 0u) {
+        DeviceScope device_scope(device_);
+        if (!a->d_scale_tab) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&a->d_scale_tab), a->n_pages * sizeof(float)));
+        a->region_pages = T / 2u;
+        HIP_TRY(launch_build_scale_tab(a->d_entries, a->n_pages, a->region_pages, a->d_scale_tab, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+    } else if (a->d_scale_tab) {
+        DeviceScope device_scope(device_);
+        (void)hipFree(a->d_scale_tab);
+        a->d_scale_tab = nullptr;
+        a->region_pages = 0;
+    }
     return SPECKV_OK;
 }
 
@@ -914,7 +928,8 @@ int Engine::write(uint64_t handle, uint64_t off, const void* src, size_t len, bo
     if (on_device) HIP_TRY(hipDeviceSynchronize());
     CodecArgs c{};
     c.entries = a->d_entries;
-    c.trusted = 1;                       // pool records only ever come from k_compress
+    c.scale_tab = a->d_scale_tab;        // fused-attention scale table follows every write
+    c.region_pages = a->region_pages;
     c.data_stride = kPageSize;
     c.scheme = a->scheme;
     c.quant_mode = quant_mode_;
@@ -1140,15 +1155,13 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     uint32_t want = (10240u + rows - 1u) / rows;
     want = std::min(want, std::max(1u, n_tiles / 8u));
     if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));
-    uint32_t n_splits = std::max(1u, std::min(want, n_tiles));
+    uint32_t n_splits = std::max(1u, std::min(std::min(want, n_tiles), 2048u));
     const uint32_t tiles_per_split = (n_tiles + n_splits - 1u) / n_splits;
     n_splits = (n_tiles + tiles_per_split - 1u) / tiles_per_split;
     const size_t q_bytes = static_cast<size_t>(rows) * 16 * 128, qs_bytes = static_cast<size_t>(rows) * 16 * sizeof(float);
     const size_t acc_bytes = static_cast<size_t>(rows) * n_splits * 16 * 128 * sizeof(float);
     const size_t ml_bytes = static_cast<size_t>(rows) * n_splits * 32 * sizeof(float);
-    const size_t tab_bytes = static_cast<size_t>(n_layers) * n_tiles * 16 * sizeof(float);
-    const size_t vinfo_bytes = static_cast<size_t>(n_layers) * n_tiles * 2 * sizeof(float);
-    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, q_bytes + qs_bytes + acc_bytes + ml_bytes + 2 * tab_bytes + vinfo_bytes));
+    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, q_bytes + qs_bytes + acc_bytes + ml_bytes));
     if (!buf) return SPECKV_ERR_NOMEM;
     AttendArgs k{};
     k.entries = a->d_entries;
@@ -1164,16 +1177,17 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     k.qs = reinterpret_cast<float*>(buf + q_bytes);
     k.scale_log2e = sm_scale * 1.4426950408889634f;
     k.zero_page = d_zero_page_;
-    k.ktab = reinterpret_cast<float*>(buf + q_bytes + qs_bytes + acc_bytes + ml_bytes);
-    k.vtab = k.ktab + tab_bytes / sizeof(float);
-    k.vinfo = k.vtab + tab_bytes / sizeof(float);
-    // linear form: records in one run, and the last (possibly ragged) 32-position tile must not read past
-    // the K / V region of its layer
-    const bool fits = static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
+    // linear form: records in one run, scale table present, tiles aligned with the table's (pos_begin a multiple of 32),
+    // and the last (possibly ragged) 32-position tile must not read past the K / V region of its layer
+    const bool fits = pos_begin % 32u == 0u && a->d_scale_tab &&
+                      static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
+    k.scale_tab = a->d_scale_tab;
+    k.q16 = static_cast<const uint16_t*>(d_q_f16);
     k.lin_base = (getenv("SPECKV_ATTEND_GENERAL") || !fits) ? nullptr : a->linear_base;
     k.part_acc = reinterpret_cast<float*>(buf + q_bytes + qs_bytes);
     k.part_ml = reinterpret_cast<float*>(buf + q_bytes + qs_bytes + acc_bytes);
-    HIP_TRY(launch_quantize_q_e4m3(d_q_f16, rows, g, L.head_dim, buf, reinterpret_cast<float*>(buf + q_bytes), st));
+    if (!k.lin_base)                     // the linear form quantises the query in its own prologue
+        HIP_TRY(launch_quantize_q_e4m3(d_q_f16, rows, g, L.head_dim, buf, reinterpret_cast<float*>(buf + q_bytes), st));
     HIP_TRY(launch_attend_fp8(k, n_layers, d_out, d_lse, st));
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
     return SPECKV_OK;
@@ -1218,7 +1232,7 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     uint32_t want = (5120u + rows - 1u) / rows;      // VALU-bound kernel: fewer, longer splits measured best
     want = std::min(want, std::max(1u, n_tiles / 8u));
     if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));
-    uint32_t n_splits = std::max(1u, std::min(want, n_tiles));
+    uint32_t n_splits = std::max(1u, std::min(std::min(want, n_tiles), 2048u));
     const uint32_t tiles_per_split = (n_tiles + n_splits - 1u) / n_splits;
     n_splits = (n_tiles + tiles_per_split - 1u) / tiles_per_split;
     const size_t acc_bytes = static_cast<size_t>(rows) * n_splits * 16 * 128 * sizeof(float);

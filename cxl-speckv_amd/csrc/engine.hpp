@@ -65,6 +65,9 @@ struct Allocation {
     // set while every record lies in ONE run of one local pool (record p at linear_base + p*rec_stride)
     // and, for the fixed-size formats, never-written records are zero bytes; cleared by a migration
     uint8_t* linear_base = nullptr;
+    // FP8 allocations with a known layout: block scales in the fused attention's tile order (attend.hip), n_pages floats
+    float* d_scale_tab = nullptr;
+    uint32_t region_pages = 0;
     bool has_layout = false;
     Layout layout{};
 };

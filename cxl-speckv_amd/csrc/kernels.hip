@@ -957,6 +957,10 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
             if (a.entries) {
                 a.entries[page].rec_bytes = out_len;
                 a.entries[page].scale = scale;
+                if (a.scale_tab) {
+                    const uint32_t j = static_cast<uint32_t>(page % a.region_pages) & 15u;
+                    a.scale_tab[page - j + attend_tile_slot(j)] = scale;
+                }
             } else {
                 a.rec_bytes[page] = out_len;
                 if (a.scales) a.scales[page] = scale;

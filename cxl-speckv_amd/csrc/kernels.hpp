@@ -52,6 +52,11 @@ struct CodecArgs {
     // records were written by k_compress (the engine's pool): INT8_DELTA_RLE streams are then known to
     // have no zero counts and a zero-padded tail, which the decoder need not re-check per pair
     int             trusted;
+    // compress only: when set, the block scale of page p is also stored at scale_tab[tile order of p] -- the
+    // per-tile order the fused attention reads with one 16-byte load (attend.hip); region_pages = pages of one
+    // (layer, kind) region of the shim layout, a multiple of 16
+    float*          scale_tab;
+    uint32_t        region_pages;
 };
 
 hipError_t launch_compress(const CodecArgs& a, hipStream_t s);
@@ -110,13 +115,17 @@ struct AttendArgs {
     const uint8_t* zero_page;         // 4 KiB of zeros: stands in for pages never written (general form)
     const uint8_t* lin_base;          // non-null: record p of the allocation sits at lin_base + p*2048 and
                                       // never-written records are zero bytes (linear, pipelined form)
-    float* ktab;                      // linear form: per (layer, tile) 16 K page scales, permuted (attend.hip)
-    float* vtab;                      //              16 V page scales / vref
-    float* vinfo;                     //              {vref_t, vref_{t-1}/vref_t}
+    const float* scale_tab;           // linear form: page scales of the whole allocation in tile order (attend.hip)
+    const uint16_t* q16;              // linear form: the fp16 query rows [layers][heads][g][128] (quantised in the kernel)
     float* part_acc;                  // [layers][heads][splits][16][128]
     float* part_ml;                   // [layers][heads][splits][2][16]
 };
+// a.lin_base set: linear form (a.scale_tab, a.q16); else page-table form (a.q8 / a.qs from launch_quantize_q_e4m3)
 hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s);
+// scale_tab[tile order of p] = entries[p].rec_bytes >= 2048 ? entries[p].scale : 0 for every page (set_layout time)
+hipError_t launch_build_scale_tab(const PageEntry* d_entries, uint64_t n_pages, uint32_t region_pages, float* d_scale_tab, hipStream_t s);
+// position of page-in-tile j (0..15) in the tile order [kb][r]: pages 2kb, 2kb+1, 8+2kb, 9+2kb of lane group kb
+__host__ __device__ inline uint32_t attend_tile_slot(uint32_t j) { return j < 8u ? ((j >> 1) << 2) + (j & 1u) : (((j - 8u) >> 1) << 2) + 2u + (j & 1u); }
 // INT4_G32 records (attend_int4.hip; linear form only: a.lin_base must be set, a.q8 = the fp16 query rows
 // [layers][heads][g][128]); writes the split partials, launch_attend_combine merges them
 hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_t s);
