@@ -524,6 +524,54 @@ def test_fp8_fused_attention_unwritten_pages_count_as_zeros(eng, oracle):
         assert np.all(np.abs(got[head] - o) <= 2e-3 * m + 1e-6)
 
 
+def test_fp8_attention_scale_table_follows_writes(eng, oracle):
+    """The linear form reads page scales from a per-allocation table in tile order: built from the page table when
+    the layout arrives (pages written BEFORE set_layout), kept current by every later write (pages rewritten with
+    other magnitudes).  Both orders must give the oracle's attention."""
+    torch = torch_mod()
+    lib = eng.lib
+    lib.set_compression_scheme(4)
+    T, L, H, D, G = 128, 2, 8, 128, 8
+    n_pages = T * L * H * D * 2 * 2 // PAGE
+    h = lib.alloc(n_pages * PAGE)
+    rng = np.random.default_rng(61)
+    x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.1, 3.0, (n_pages, 1))).astype(np.float16)
+    lib.write(h, 0, x.ctypes.data, x.nbytes, False)               # before the layout is known
+    lib.set_layout(h, T, L, H, D, 2)
+    from oracle.bindings import _ptr, u8p, u16p, f32p
+    q = rng.standard_normal((L, H, G, D)).astype(np.float16)
+    d_q = torch.from_numpy(q.view(np.int16)).cuda()
+    q8 = np.zeros((L * H * G, D), np.uint8); qs = np.zeros(L * H * G, np.float32)
+    oracle.lib.orc_quantize_rows_e4m3(_ptr(q.view(np.uint16).reshape(-1), u16p), L * H * G, D, _ptr(q8, u8p), _ptr(qs, f32p))
+    q8 = q8.reshape(L, H, G, D); qs = qs.reshape(L, H, G)
+
+    def check(xcur):
+        scales, lens, recs = oracle.compress_blocks_f16(xcur, 4, 0)
+        d_out = torch.empty((L, H, G, D), dtype=torch.float32, device="cuda")
+        lib.attend_fp8(h, 0, L, d_q.data_ptr(), G, 0, T, 0.1, d_out.data_ptr())
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        for layer in range(L):
+            kf = layer * T
+            vf = kf + T // 2
+            for head in range(H):
+                krows, ksc = _fp8_head_rows(recs, scales, kf, T, head, H, D)
+                vrows, vsc = _fp8_head_rows(recs, scales, vf, T, head, H, D)
+                o = np.zeros((G, D), np.float32); m = np.zeros((G, D), np.float32)
+                oracle.lib.orc_attend_fp8(_ptr(np.ascontiguousarray(q8[layer, head]), u8p), _ptr(qs[layer, head].copy(), f32p), G,
+                                          _ptr(krows, u8p), _ptr(ksc, f32p), _ptr(vrows, u8p), _ptr(vsc, f32p), T, D, 0.1,
+                                          _ptr(o, f32p), None, _ptr(m, f32p))
+                assert np.all(np.abs(got[layer, head] - o) <= 2.5e-3 * m + 1e-6), (layer, head)
+
+    check(x)
+    # rewrite a few scattered pages (K and V regions of both layers) with much larger values
+    for pg in (0, 7, 33, T // 2 + 5, T + 17, T + T // 2 + 63):
+        x[pg] = (rng.standard_normal(N) * 20.0).astype(np.float16)
+        lib.write(h, pg * PAGE, x[pg].ctypes.data, PAGE, False)
+    check(x)
+    lib.free(h)
+
+
 def test_int4_fused_attention(eng, oracle):
     """The 4:1 format of BASELINE config 5: softmax(q.K^T).V straight from INT4_G32 records
     (speckv_ext_attend_int4) against the oracle's double-precision attention over the pages as
