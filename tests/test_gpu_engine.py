@@ -318,6 +318,41 @@ def test_fetch_list_and_range_full_size(eng):
         lib.free(h)
 
 
+def test_reference_driver_test_scenarios(eng):
+    """The scenarios of the reference's driver-level tests, through the C ABI that replaces its ioctl interface
+    (driver/ is gone: descriptor batches are kernel launches, SPECKV_IOCTL_POLL_DONE is speckv_ext_poll_complete):
+    tests/test_params.c:15-66 (every depth / scheme value accepted), tests/test_prefetch.c:15-83 (tokens 101..116,
+    layers 0..4, then ten requests req_id 1..10 -- requests outside the single-request shim allocation are accepted
+    and address nothing), tests/test_dma.c:15-96 (a batch of four page fetches, then poll until completions show)."""
+    lib = eng.lib
+    for depth in (1, 2, 4, 8, 16):
+        lib.set_prefetch_depth(depth)
+    for scheme in (0, 1, 2):
+        lib.set_compression_scheme(scheme)
+    T, L, H, D, bpe = 256, 5, 8, 128, 2
+    h = eng.allocate(T, L, H, D, bpe)
+    n_pages = T * L * H * D * bpe * 2 // PAGE
+    x = synth(n_pages, seed=3)
+    lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+    tokens = list(range(101, 117))
+    lib.prefetch(1, 0, 100, 4, tokens)
+    for layer in range(5):
+        lib.prefetch(1, layer, 100 + layer, 4, tokens)
+    for req_id in range(1, 11):
+        lib.prefetch(req_id, 0, req_id * 10, 4, list(range(1, 17)))
+    lib.prefetch_flush()
+    lib.sync()
+    lib.poll_complete()
+    # a "DMA batch" of four pages: synchronous fetches complete before the call returns, so one poll sees them
+    ptrs = lib.access_batch(h, [0, PAGE, 2 * PAGE, 4 * PAGE])
+    assert len(ptrs) == 4 and all(ptrs)
+    done, polls = 0, 0
+    while done == 0 and polls < 100:
+        done = lib.poll_complete(); polls += 1
+    assert done >= 1
+    assert lib.poll_complete() == 0                      # POLL_DONE clears (speckv_kernel_module.c:194-215)
+
+
 def test_fp8_qk_scores_fused_mfma(eng, oracle):
     """BASELINE config 5 fused dequant-matvec: q.K^T scores computed by
     v_mfma_f32_16x16x32_fp8_fp8 straight from the FP8 pool records, against the
