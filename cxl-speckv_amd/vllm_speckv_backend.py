@@ -111,5 +111,23 @@ class CxlSpeckvKVAllocator:
         return self._speckv.access_batch(
             self._handle, [self._calc_offset(req_id, layer, 0, p, kind, entry) for p in positions])
 
+    def kv_rows(self, req_id: int, layer: int, kind: int, pos_begin: int, pos_end: int):
+        """The [pos_begin, pos_end) rows of one layer's K (kind 0) or V (kind 1) as ONE torch fp16 tensor
+        [positions][num_heads][head_dim] that aliases the engine's cache slots (no copy): the tensor view over
+        ``out_gpu_ptr`` the reference's shim only mentions (vllm_speckv_backend.py:64).  The covering pages are made
+        resident by one ``speckv_access`` over the span, which returns them contiguous.  The view stays valid until
+        those slots are recycled (ring order) or the handle is freed -- consume it within the step."""
+        import torch
+        g = self._geom
+        row_bytes = g.num_heads * g.head_dim * g.bytes_per_element
+        off = self._calc_offset(req_id, layer, 0, pos_begin, kind, g.head_dim * g.bytes_per_element)
+        nbytes = (pos_end - pos_begin) * row_bytes
+        ptr = self._speckv.access(self._handle, off, nbytes)
+
+        class _Span:                       # minimal __cuda_array_interface__ carrier (works on ROCm builds of torch)
+            __cuda_array_interface__ = {"shape": (pos_end - pos_begin, g.num_heads, g.head_dim), "typestr": "<f2",
+                                        "data": (ptr, False), "version": 2, "strides": None}
+        return torch.as_tensor(_Span(), device="cuda")
+
     def close(self):
         self._speckv.finalize()

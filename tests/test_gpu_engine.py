@@ -688,6 +688,43 @@ def test_int4_fused_attention(eng, oracle):
         lib.attend_fp8(h, 0, 1, d_q[0].data_ptr(), G, 0, T, sm, d_out.data_ptr())
 
 
+def test_fused_attention_equals_attention_over_fetched_pages(eng):
+    """Product paths against each other, no checker in between: the decode attention computed by torch in fp32 over
+    the fp16 rows that speckv_access fetches + decompresses (viewed in place through CxlSpeckvKVAllocator.kv_rows)
+    versus the fused kernels reading the compressed records directly.  INT4: same dequantised values by construction,
+    so only the f16 rounding of the softmax weights separates them (2e-3 of sum p|v|).  FP8: the fused kernel
+    additionally quantises the query to e4m3 (per-row scale), which moves the scores by up to ~6 % of |q||k|, so only
+    closeness is asserted."""
+    torch = torch_mod()
+    lib = eng.lib
+    T, L, H, D, G = 256, 2, 8, 128, 8
+    rng = np.random.default_rng(71)
+    sm = 1.0 / np.sqrt(D)
+    for scheme, fused in ((3, lib.attend_int4), (4, lib.attend_fp8)):
+        lib.set_compression_scheme(scheme)
+        h = eng.allocate(T, L, H, D, 2)
+        n_pages = T * L * H * D * 2 * 2 // PAGE
+        x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.2, 2.0, (n_pages, 1))).astype(np.float16)
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+        q = torch.from_numpy((rng.standard_normal((L, H, G, D))).astype(np.float16)).cuda()
+        out = torch.empty((L, H, G, D), dtype=torch.float32, device="cuda")
+        fused(h, 0, L, q.data_ptr(), G, 0, T, sm, out.data_ptr())
+        torch.cuda.synchronize()
+        for layer in range(L):
+            k = eng.kv_rows(0, layer, 0, 0, T).float().clone()           # [T][H][D], decompressed by the engine
+            v = eng.kv_rows(0, layer, 1, 0, T).float().clone()
+            s_ = torch.einsum("hgd,thd->hgt", q[layer].float(), k) * sm
+            p = torch.softmax(s_, dim=-1)
+            ref = torch.einsum("hgt,thd->hgd", p, v)
+            mag = torch.einsum("hgt,thd->hgd", p, v.abs())
+            err = (out[layer] - ref).abs()
+            if scheme == 3:
+                assert bool((err <= 2e-3 * mag + 1e-6).all()), float((err / (mag + 1e-9)).max())
+            else:
+                assert float(err.max() / ref.abs().max()) < 0.1
+        lib.free(h)
+
+
 def test_migrate_records_between_pool_slabs(oracle):
     """speckv_ext_migrate: hipMemcpyPeerAsync of record runs + page-table re-point
     (one GPU here, so source and target pool are the same device; the copy path,
