@@ -326,10 +326,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint32_t c = lane & 15u, kb = lane >> 4;
     const uint32_t split = blockIdx.x;
     const uint32_t hq = a.heads / 4u;
-    const uint32_t layer = blockIdx.y / hq;
+    uint32_t layer = blockIdx.y / hq;                                    // batch form: the sequence index
     const uint32_t head = (blockIdx.y % hq) * 4u + wave;
-    const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;
-    const uint64_t part = row * a.n_splits + split;
+    const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;  // query / output row block
+    uint64_t part = row * a.n_splits + split;
+    if (a.seqs) {                                                        // wave-uniform: per-sequence geometry
+        const AttendSeq sq = a.seqs[layer];
+        if (split >= sq.n_splits) return;
+        a.lin_base = sq.lin_base;
+        a.scale_tab = sq.scale_tab;
+        a.k_first = sq.k_first;
+        a.v_first = sq.v_first;
+        a.n_pages = sq.n_pages;
+        part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
+        layer = 0;
+    }
 
     // query operand: row c of this head, d = 32kb + 8*step + e, quantised here exactly as k_quantize_q_e4m3 does
     // (scale = max|q|/448 over the row, 1 if zero; e4m3 of clamp(q/scale)); rows >= g are zero
@@ -506,14 +517,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 constexpr uint32_t kMaxSplits = 2048;
 __global__ __launch_bounds__(512) void k_attend_combine(const float* __restrict__ part_acc, const float* __restrict__ part_ml,
                                                         uint32_t g, uint32_t n_splits, float* __restrict__ out,
-                                                        float* __restrict__ lse)
+                                                        float* __restrict__ lse, const AttendSeq* __restrict__ seqs,
+                                                        uint32_t heads)
 {
     __shared__ float w[kMaxSplits];
     __shared__ float red[8];
     __shared__ float osum[4][128];
     const uint32_t rowq = blockIdx.x / g, m = blockIdx.x % g, t = threadIdx.x;     // rowq = layer*heads + head
     const uint32_t lane = t & 63u, wv = t >> 6;
-    const float* ml = part_ml + static_cast<uint64_t>(rowq) * n_splits * 32u;
+    uint64_t part0 = static_cast<uint64_t>(rowq) * n_splits;           // first partial of this (layer | sequence, head)
+    if (seqs) {
+        const AttendSeq sq = seqs[rowq / heads];
+        n_splits = sq.n_splits;
+        part0 = sq.part_base + static_cast<uint64_t>(rowq % heads) * n_splits;
+    }
+    const float* ml = part_ml + part0 * 32u;
     auto block_reduce = [&](float v, bool is_max) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const float u = __shfl_xor(v, o); v = is_max ? fmaxf(v, u) : v + u; }
@@ -537,7 +555,7 @@ __global__ __launch_bounds__(512) void k_attend_combine(const float* __restrict_
     }
     const float L = block_reduce(lloc, false);                     // (its barriers also publish w[])
     const uint32_t grp = t >> 7, d = t & 127u;
-    const float* acc = part_acc + (static_cast<uint64_t>(rowq) * n_splits * 16u + m) * 128u + d;
+    const float* acc = part_acc + (part0 * 16u + m) * 128u + d;
     float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
     uint32_t s = grp;
     for (; s + 12u < n_splits; s += 16u) {                         // four independent loads in flight per thread
@@ -561,8 +579,17 @@ hipError_t launch_attend_combine(const AttendArgs& a, uint32_t n_layers, float* 
     if (n_layers == 0) return hipSuccess;
     if (a.n_splits > kMaxSplits) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_attend_combine, dim3(n_layers * a.heads * a.g), dim3(512), 0, s, a.part_acc, a.part_ml, a.g,
-                       a.n_splits, d_out, d_lse);
+                       a.n_splits, d_out, d_lse, a.seqs, a.heads);
     return hipGetLastError();
+}
+
+hipError_t launch_attend_fp8_batch(const AttendArgs& a, uint32_t n_seq, float* d_out, float* d_lse, hipStream_t s)
+{
+    if (n_seq == 0 || a.n_splits == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_attend_fp8_linear, dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_attend_combine(a, n_seq, d_out, d_lse, s);
 }
 
 hipError_t launch_build_scale_tab(const PageEntry* d_entries, uint64_t n_pages, uint32_t region_pages, float* d_scale_tab, hipStream_t s)

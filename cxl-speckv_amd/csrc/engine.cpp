@@ -191,10 +191,12 @@ Engine::~Engine()
     allocs_.clear();
     if (d_emb_) (void)hipFree(d_emb_);
     if (d_wout_) (void)hipFree(d_wout_);
-    for (Scratch* s : {&s_pages_, &s_dst_, &s_req_, &s_out_, &s_tmp_, &s_stage_, &s_hid_, &s_logits_, &s_hist_, &s_pred_, &s_attn_})
+    for (Scratch* s : {&s_pages_, &s_dst_, &s_req_, &s_out_, &s_tmp_, &s_stage_, &s_hid_, &s_logits_, &s_hist_, &s_pred_, &s_attn_, &s_attn_seq_})
         if (s->p) (void)hipFree(s->p);
     if (d_count_) (void)hipFree(d_count_);
     if (d_zero_page_) (void)hipFree(d_zero_page_);
+    if (seq_ring_.base) (void)hipHostFree(seq_ring_.base);
+    for (auto ev : seq_ring_.ev) if (ev) (void)hipEventDestroy(ev);
     if (cache_base_) (void)hipFree(cache_base_);
     pools_.clear();
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
@@ -1189,6 +1191,98 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     if (!k.lin_base)                     // the linear form quantises the query in its own prologue
         HIP_TRY(launch_quantize_q_e4m3(d_q_f16, rows, g, L.head_dim, buf, reinterpret_cast<float*>(buf + q_bytes), st));
     HIP_TRY(launch_attend_fp8(k, n_layers, d_out, d_lse, st));
+    if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+    return SPECKV_OK;
+}
+
+// One decode step of a batch: the fused FP8 attention of ONE layer for many sequences (allocations) in one launch
+// (BASELINE configs[3] shape: 256 sequences).  Every allocation must qualify for the linear form.
+int Engine::attend_fp8_batch(uint32_t n_seq, const uint64_t* handles, uint32_t layer, const void* d_q_f16, uint32_t g,
+                             const uint32_t* pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
+{
+    if (null_) return no_data_path("speckv_ext_attend_fp8_batch");
+    if (n_seq == 0) return SPECKV_OK;
+    if (!handles || !pos_end || !d_q_f16 || !d_out || g == 0 || g > 16) return SPECKV_ERR_INVAL;
+    std::vector<AttendSeq> seqs(n_seq);
+    uint64_t total_tiles = 0;
+    uint32_t heads = 0;
+    for (uint32_t i = 0; i < n_seq; ++i) {
+        Allocation* a = find(handles[i]);
+        if (!a) return SPECKV_ERR_GENERAL;
+        if (!a->has_layout || a->scheme != SPECKV_COMP_FP8_E4M3) return SPECKV_ERR_INVAL;
+        const Layout& L = a->layout;
+        if (L.head_dim != 128 || L.bytes_per_element != 2 || L.num_heads * L.head_dim != 1024) return SPECKV_ERR_INVAL;
+        if (layer >= L.num_layers || pos_end[i] % 2 || pos_end[i] > L.num_tokens) return SPECKV_ERR_INVAL;
+        const uint32_t n_pages = pos_end[i] / 2, n_tiles = (n_pages + 15u) / 16u;
+        if (!a->linear_base || !a->d_scale_tab || static_cast<uint64_t>(n_tiles) * 32u > L.num_tokens) {
+            SPECKV_ERR("speckv_ext_attend_fp8_batch: sequence %u does not qualify for the linear form "
+                       "(records in one local run, layout with num_tokens %% 32 == 0)", i);
+            return SPECKV_ERR_INVAL;
+        }
+        heads = L.num_heads;
+        seqs[i].lin_base = a->linear_base;
+        seqs[i].scale_tab = a->d_scale_tab;
+        seqs[i].k_first = static_cast<uint64_t>(layer) * L.num_tokens;       // (layer*2*T)/2
+        seqs[i].v_first = seqs[i].k_first + L.num_tokens / 2;
+        seqs[i].n_pages = n_pages;
+        seqs[i].n_splits = n_tiles;                                           // tiles for now, splits below
+        total_tiles += n_tiles;
+    }
+    DeviceScope device_scope(device_);
+    hipStream_t st = s ? s : stream_;
+    const size_t out_elems = static_cast<size_t>(n_seq) * heads * g * 128;
+    if (total_tiles == 0) {
+        HIP_TRY(hipMemsetAsync(d_out, 0, out_elems * sizeof(float), st));
+        if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+        return SPECKV_OK;
+    }
+    // one split length for the whole batch: ~10k waves over the launch, at least 8 tiles per split
+    uint32_t tps = static_cast<uint32_t>(std::max<uint64_t>(8, (total_tiles * heads + 10239u) / 10240u));
+    if (const char* env = getenv("SPECKV_ATTEND_TILES_PER_SPLIT")) tps = std::max(1, atoi(env));
+    uint32_t max_splits = 0;
+    uint64_t parts = 0;
+    for (uint32_t i = 0; i < n_seq; ++i) {
+        const uint32_t n_tiles = seqs[i].n_splits;
+        seqs[i].n_splits = (n_tiles + tps - 1u) / tps;
+        if (seqs[i].n_splits > 2048u) return SPECKV_ERR_INVAL;
+        seqs[i].part_base = static_cast<uint32_t>(parts);
+        parts += static_cast<uint64_t>(heads) * seqs[i].n_splits;
+        max_splits = std::max(max_splits, seqs[i].n_splits);
+    }
+    const size_t acc_bytes = static_cast<size_t>(parts) * 16 * 128 * sizeof(float), ml_bytes = static_cast<size_t>(parts) * 32 * sizeof(float);
+    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes));
+    AttendSeq* d_seqs = static_cast<AttendSeq*>(scratch(s_attn_seq_, seqs.size() * sizeof(AttendSeq)));
+    if (!buf || !d_seqs) return SPECKV_ERR_NOMEM;
+    // descriptors go through a pinned slot so the call can return without waiting for the copy
+    const size_t seq_bytes = seqs.size() * sizeof(AttendSeq);
+    if (seq_ring_.slot_bytes < seq_bytes) {
+        if (seq_ring_.base) { HIP_TRY(hipDeviceSynchronize()); (void)hipHostFree(seq_ring_.base); seq_ring_.base = nullptr; }
+        seq_ring_.slot_bytes = std::max<size_t>(seq_bytes * 2, 16384);
+        HIP_TRY(hipHostMalloc(&seq_ring_.base, seq_ring_.slot_bytes * 4, hipHostMallocDefault));
+        for (auto& ev : seq_ring_.ev)
+            if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const int slot = seq_ring_.next;
+    seq_ring_.next = (slot + 1) & 3;
+    HIP_TRY(hipEventSynchronize(seq_ring_.ev[slot]));          // the copy that last used this slot has finished
+    void* staged = static_cast<uint8_t*>(seq_ring_.base) + static_cast<size_t>(slot) * seq_ring_.slot_bytes;
+    memcpy(staged, seqs.data(), seq_bytes);
+    HIP_TRY(hipMemcpyAsync(d_seqs, staged, seq_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(seq_ring_.ev[slot], st));
+    // sequences without positions have no splits: their rows are written as zeros by the merge (L == 0)
+    AttendArgs k{};
+    k.heads = heads;
+    k.g = g;
+    k.n_splits = max_splits;
+    k.tiles_per_split = tps;
+    k.layer_stride = 0;
+    k.q16 = static_cast<const uint16_t*>(d_q_f16);
+    k.scale_log2e = sm_scale * 1.4426950408889634f;
+    k.lin_base = seqs[0].lin_base;           // (overridden per sequence)
+    k.seqs = d_seqs;
+    k.part_acc = reinterpret_cast<float*>(buf);
+    k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
+    HIP_TRY(launch_attend_fp8_batch(k, n_seq, d_out, d_lse, st));
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
     return SPECKV_OK;
 }

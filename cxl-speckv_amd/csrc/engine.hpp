@@ -109,6 +109,8 @@ public:
                       uint32_t pos_begin, uint32_t pos_end, float* d_out, hipStream_t s);
     int attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
                    uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
+    int attend_fp8_batch(uint32_t n_seq, const uint64_t* handles, uint32_t layer, const void* d_q_f16, uint32_t g,
+                         const uint32_t* pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
     int attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
                     uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
     int migrate(uint64_t handle, uint64_t first_page, uint64_t n_pages, uint32_t target_pool);
@@ -173,7 +175,9 @@ private:
     float* d_wout_ = nullptr;
     uint32_t vocab_ = 0;
     Scratch s_hid_, s_logits_, s_hist_, s_pred_;
-    Scratch s_attn_;
+    Scratch s_attn_, s_attn_seq_;
+    // pinned staging for the batch descriptors: 4 slots in rotation, each guarded by an event (no stream sync per call)
+    struct PinnedRing { void* base = nullptr; size_t slot_bytes = 0; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; int next = 0; } seq_ring_;
     uint8_t* d_zero_page_ = nullptr;     // stands in for never-written pages in the fused attention
     std::unordered_map<uint32_t, std::vector<int32_t>> hist_;
     std::unordered_map<uint32_t, std::vector<int32_t>> pred_;

@@ -100,6 +100,18 @@ hipError_t launch_qk_scores_fp8(const PageEntry* d_entries, uint64_t first_page,
                                 uint32_t n_layers, uint32_t n_pages, uint32_t heads, uint32_t g,
                                 const uint8_t* d_q8, const float* d_qs, float* d_out, hipStream_t s);
 
+// Batch form of the linear fused attention: many sequences (allocations), one layer each, one launch.  The fields
+// override their AttendArgs namesakes per sequence; part_base = index of the sequence's first (head, split) partial.
+struct AttendSeq {
+    const uint8_t* lin_base;
+    const float* scale_tab;
+    uint64_t k_first, v_first;        // first K / V page of the wanted layer (position 0)
+    uint32_t n_pages;                 // pages of [0, pos_end)
+    uint32_t n_splits;                // ceil(tiles / tiles_per_split), <= gridDim.x
+    uint32_t part_base;
+    uint32_t reserved;
+};
+
 // Decode attention straight from FP8_E4M3 records (attend.hip): softmax(q.K^T * sm_scale) . V per kv head,
 // split over the positions, partials merged by a second kernel.  Same layout requirement as the scores.
 struct AttendArgs {
@@ -117,6 +129,7 @@ struct AttendArgs {
                                       // never-written records are zero bytes (linear, pipelined form)
     const float* scale_tab;           // linear form: page scales of the whole allocation in tile order (attend.hip)
     const uint16_t* q16;              // linear form: the fp16 query rows [layers][heads][g][128] (quantised in the kernel)
+    const struct AttendSeq* seqs;     // batch form: one descriptor per sequence (blockIdx.y / (heads/4)), else null
     float* part_acc;                  // [layers][heads][splits][16][128]
     float* part_ml;                   // [layers][heads][splits][2][16]
 };
@@ -130,6 +143,9 @@ __host__ __device__ inline uint32_t attend_tile_slot(uint32_t j) { return j < 8u
 // [layers][heads][g][128]); writes the split partials, launch_attend_combine merges them
 hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_t s);
 hipError_t launch_attend_combine(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s);
+// batch form: a.seqs (device) holds n_seq descriptors, a.q16 = [n_seq][heads][g][128], a.n_splits = the largest
+// per-sequence split count; d_out [n_seq][heads][g][128]
+hipError_t launch_attend_fp8_batch(const AttendArgs& a, uint32_t n_seq, float* d_out, float* d_lse, hipStream_t s);
 
 // entries[i].pool_addr = base + i*stride (record bytes / scale untouched): after a migration
 hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t base, uint64_t stride, hipStream_t s);

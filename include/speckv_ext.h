@@ -197,6 +197,17 @@ speckv_status_t speckv_ext_attend_fp8(speckv_handle_t handle, uint32_t layer_beg
                                       const void* d_q_f16, uint32_t g, uint32_t pos_begin, uint32_t pos_end,
                                       float sm_scale, float* d_out, float* d_lse, void* stream);
 
+/* speckv_ext_attend_fp8_batch: one decode step of a batch -- the fused FP8 attention of ONE layer for n_seq sequences
+ * (one allocation each, request 0 of its shim layout) over positions [0, pos_end[i]) in one launch pair.
+ *   handles, pos_end : host arrays of n_seq      d_q_f16 : [n_seq][num_heads][g][128] fp16 (device)
+ *   d_out : [n_seq][num_heads][g][128] fp32      d_lse : optional [n_seq][num_heads][g]
+ * Every allocation must hold FP8 records in one local run with a layout whose num_tokens is a multiple of 32 (the
+ * default placement; SPECKV_ERR_INVAL otherwise).  Asynchronous on `stream` (the host arrays are copied before the
+ * call returns).  Note: d_scale_tab / the scratch of consecutive calls on DIFFERENT streams is shared -- use one stream. */
+speckv_status_t speckv_ext_attend_fp8_batch(uint32_t n_seq, const speckv_handle_t* handles, uint32_t layer,
+                                            const void* d_q_f16, uint32_t g, const uint32_t* pos_end, float sm_scale,
+                                            float* d_out, float* d_lse, void* stream);
+
 /* speckv_ext_attend_int4: the same attention over SPECKV_COMP_INT4_G32 records (the 4:1 format).  K and V are
  * dequantised exactly as fetch+decompress does (fp16(q4 * group scale)), the query stays fp16, both products run
  * on v_mfma_f32_16x16x32_f16 with fp32 accumulation: the attention over the decompressed fp16 pages, without

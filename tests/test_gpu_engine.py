@@ -607,6 +607,58 @@ def test_fp8_attention_scale_table_follows_writes(eng, oracle):
     lib.free(h)
 
 
+def test_fp8_fused_attention_batch_of_sequences(eng):
+    """speckv_ext_attend_fp8_batch: one layer of many sequences (one allocation each, different lengths, one of them
+    empty) in one launch pair, against the per-sequence entry point.  Same kernel, other split boundaries, so the
+    results agree to fp32 summation order (1e-4 of sum p|v| is generous); the oracle parity of the per-sequence form
+    is test_fp8_fused_attention."""
+    torch = torch_mod()
+    lib = eng.lib
+    lib.set_compression_scheme(4)
+    T, L, H, D, G = 1024, 2, 8, 128, 8
+    rng = np.random.default_rng(83)
+    lens = [1024, 64, 0, 258, 1000, 32, 514, 2]
+    handles = []
+    for n in lens:
+        h = lib.alloc(T * L * H * D * 2 * 2)
+        lib.set_layout(h, T, L, H, D, 2)
+        n_pages = T * L * H * D * 2 * 2 // PAGE
+        x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.2, 2.0, (n_pages, 1))).astype(np.float16)
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+        handles.append(h)
+    q = torch.from_numpy(rng.standard_normal((len(lens), H, G, D)).astype(np.float16)).cuda()
+    sm = 1.0 / np.sqrt(D)
+    for layer in (0, 1):
+        for tps in (None, "1", "3"):
+            if tps is None: os.environ.pop("SPECKV_ATTEND_TILES_PER_SPLIT", None)
+            else: os.environ["SPECKV_ATTEND_TILES_PER_SPLIT"] = tps
+            try:
+                out = torch.full((len(lens), H, G, D), float("nan"), dtype=torch.float32, device="cuda")
+                lse = torch.full((len(lens), H, G), float("nan"), dtype=torch.float32, device="cuda")
+                lib.attend_fp8_batch(handles, layer, q.data_ptr(), G, lens, sm, out.data_ptr(), lse.data_ptr())
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("SPECKV_ATTEND_TILES_PER_SPLIT", None)
+            for i, (h, n) in enumerate(zip(handles, lens)):
+                one = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
+                one_lse = torch.empty((H, G), dtype=torch.float32, device="cuda")
+                lib.attend_fp8(h, layer, 1, q[i].data_ptr(), G, 0, n, sm, one.data_ptr(), one_lse.data_ptr())
+                torch.cuda.synchronize()
+                if n == 0:
+                    assert float(out[i].abs().max()) == 0.0
+                    continue
+                scale = float(one.abs().max()) + 1e-6
+                assert float((out[i] - one).abs().max()) <= 2e-4 * scale, (layer, tps, i, n)
+                assert float((lse[i] - one_lse).abs().max()) <= 1e-4, (layer, tps, i, n)
+    # a sequence that does not qualify (INT4 allocation) -> INVAL, nothing launched
+    lib.set_compression_scheme(3)
+    hx = lib.alloc(T * L * H * D * 2 * 2); lib.set_layout(hx, T, L, H, D, 2)
+    with pytest.raises(SpeckvError):
+        lib.attend_fp8_batch(handles + [hx], 0, q.data_ptr(), G, lens + [64], sm, out.data_ptr())
+    for h in handles + [hx]:
+        lib.free(h)
+
+
 def test_int4_fused_attention(eng, oracle):
     """The 4:1 format of BASELINE config 5: softmax(q.K^T).V straight from INT4_G32 records
     (speckv_ext_attend_int4) against the oracle's double-precision attention over the pages as
