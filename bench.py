@@ -554,6 +554,49 @@ def int4_attention_extra(torch, kv, T, Lyr):
         lib.set_compression_scheme(2)
 
 
+def batch_attention_extra(torch, kv, n_seq=256, T=8192):
+    """BASELINE configs[3] shape on one GPU: one decode step's attention of ONE layer for a batch of 256 sequences at
+    8k context (8 kv heads x 128, 8 query rows per kv head), FP8 records, one launch pair for the whole batch."""
+    lib = kv.lib
+    handles = []
+    try:
+        lib.set_compression_scheme(4)
+        g = torch.Generator(device="cuda"); g.manual_seed(2004)
+        n_pages = T * 8 * 128 * 2 * 2 // PAGE
+        x = torch.randn((n_pages, BLOCK_ELEMS), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+        for _ in range(n_seq):
+            h = lib.alloc(n_pages * PAGE)
+            lib.set_layout(h, T, 1, 8, 128, 2)
+            lib.write(h, 0, x.data_ptr(), x.numel() * 2, True)       # same synthetic KV in every sequence: bytes are what count
+            handles.append(h)
+        q = torch.randn((n_seq, 8, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+        o = torch.empty((n_seq, 8, 8, 128), dtype=torch.float32, device="cuda")
+        s = torch.cuda.Stream()
+        lens = [T] * n_seq
+        def step():
+            lib.attend_fp8_batch(handles, 0, q.data_ptr(), 8, lens, 0.08838834764831845, o.data_ptr(), None, s.cuda_stream)
+        step(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        a.record(s)
+        for _ in range(reps):
+            step()
+        b.record(s); torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        rec_bytes = n_seq * n_pages * 2048
+        return {"fp8_attention_batch_decode_step": {"sequences": n_seq, "context": T, "layers_per_call": 1,
+                                                    "ms_per_layer": round(ms, 4), "KV_record_GBps": round(rec_bytes / (ms * 1e-3) / 1e9, 1),
+                                                    "frac_hbm": round(rec_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                                    "note": f"speckv_ext_attend_fp8_batch: {n_seq} sequences x {T} context, one layer, one launch pair"}}
+    except Exception as e:
+        return {"fp8_attention_batch_decode_step": {"error": repr(e)}}
+    finally:
+        for h in handles:
+            try: lib.free(h)
+            except Exception: pass
+        lib.set_compression_scheme(2)
+
+
 def predictor_extra(torch, lib):
     """Token predictor (reference LSTMPredictor::predict_top_k: 13.5 ms per call on one CPU
     core; paper claim < 10 us on the FPGA): latency of one top-4 prediction
@@ -638,7 +681,8 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
                             "first_call_ms": round(flush_ms[0], 3), "requests_per_s": round(n_req / (min(flush_ms[1:]) * 1e-3), 1),
                             "note": "lookup kernels + list read-back + ring-slot assignment + fetch launch + sync, steady state"}
     ex.update(fp8_scores_extra(torch, kv, 32768, 80))
-    ex.update(int4_attention_extra(torch, kv, 32768, 80))      # BASELINE configs[4] shape: 70B-shaped KV @ 32k context
+    ex.update(int4_attention_extra(torch, kv, 32768, 80))
+    ex.update(batch_attention_extra(torch, kv))      # BASELINE configs[4] shape: 70B-shaped KV @ 32k context
     ex.update(predictor_extra(torch, lib))
     return ex
 
