@@ -184,6 +184,36 @@ __device__ __forceinline__ void att_store(const AttendArgs& a, const AttState& S
     }
 }
 
+// Query operand of the score MFMAs for lane (c, kb): the 32 values d = 32kb .. 32kb+31 of fp16 row c, quantised exactly
+// as k_quantize_q_e4m3 does (row scale = max|q|/448, 1 if zero; e4m3 of clamp(q/scale)); a dead row (c >= g) is zero.
+__device__ __forceinline__ void quantize_query_operand(const uint16_t* qsrc, bool live, uint32_t (&qd)[8], float& row_scale)
+{
+    float xq[32];
+    float mx = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint4 w = *reinterpret_cast<const uint4*>(qsrc + 8 * i);
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            xq[8 * i + k] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(ws[k >> 1] >> (16 * (k & 1)))));
+            mx = fmaxf(mx, fabsf(xq[8 * i + k]));
+        }
+    }
+    mx = max_over_kb(mx);
+    const float sc = (mx > 0.0f) ? (mx / 448.0f) : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = live ? fminf(fmaxf(xq[4 * i + k] / sc, -448.0f), 448.0f) : 0.0f;
+        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+        qd[i] = static_cast<uint32_t>(pk);
+    }
+    row_scale = live ? sc : 1.0f;
+}
+
 } // namespace
 
 // General form: every page goes through its page-table entry (pool address, validity, scale), so
@@ -203,38 +233,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;
 
     // query operand: bytes [32kb, 32kb+32) of e4m3 row c; its scale carries sm_scale*log2(e)
-    // query operand: row c of this head, d = 32kb + 8*step + e, quantised here exactly as k_quantize_q_e4m3 does
-    // (scale = max|q|/448 over the row, 1 if zero; e4m3 of clamp(q/scale)); rows >= g are zero
     uint32_t qd[8];
     float qscale;
-    {
-        float xq[32];
-        float mx = 0.0f;
-        const uint16_t* qsrc = a.q16 + (row * a.g + min(c, a.g - 1u)) * 128u + kb * 32u;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint4 w = *reinterpret_cast<const uint4*>(qsrc + 8 * i);
-            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                xq[8 * i + k] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(ws[k >> 1] >> (16 * (k & 1)))));
-                mx = fmaxf(mx, fabsf(xq[8 * i + k]));
-            }
-        }
-        mx = max_over_kb(mx);
-        const float sc = (mx > 0.0f) ? (mx / 448.0f) : 1.0f;
-        const bool live = c < a.g;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = live ? fminf(fmaxf(xq[4 * i + k] / sc, -448.0f), 448.0f) : 0.0f;
-            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
-            pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
-            qd[i] = static_cast<uint32_t>(pk);
-        }
-        qscale = (live ? sc : 1.0f) * a.scale_log2e;
-    }
+    quantize_query_operand(a.q16 + (row * a.g + min(c, a.g - 1u)) * 128u + kb * 32u, c < a.g, qd, qscale);
+    qscale *= a.scale_log2e;
 
     const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
     const uint32_t t0 = split * a.tiles_per_split;
@@ -572,6 +574,105 @@ __global__ __launch_bounds__(512) void k_attend_combine(const float* __restrict_
         out[(static_cast<uint64_t>(rowq) * g + m) * 128u + d] = L > 0.0f ? o / L : 0.0f;
         if (lse && d == 0) lse[static_cast<uint64_t>(rowq) * g + m] = L > 0.0f ? (M + log2f(L)) * 0.6931471805599453f : -INFINITY;
     }
+}
+
+// q.K^T scores only, linear form: the score half of k_attend_fp8_linear (same operand maps, same register refill
+// pipeline for K) writing out[layer][head][row][position]; V is never touched.  tiles_per_split tiles per wave.
+__global__ __launch_bounds__(256) void k_qk_scores_fp8_linear(AttendArgs a, float* __restrict__ out)
+{
+    // per wave: one tile of scores, [16 rows][32 positions] with a 36-dword row pitch (bank spread), so that the tile
+    // leaves as whole 128-byte lines: the MFMA result has 4 positions of one row per lane, a row of the tile is 128 B
+    __shared__ __attribute__((aligned(16))) float stage[4][16 * 36];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t c = lane & 15u, kb = lane >> 4;
+    const uint32_t hq = a.heads / 4u;
+    const uint32_t layer = blockIdx.y / hq;
+    const uint32_t head = (blockIdx.y % hq) * 4u + wave;
+    const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;
+    uint32_t qd[8];
+    float qscale;
+    quantize_query_operand(a.q16 + (row * a.g + min(c, a.g - 1u)) * 128u + kb * 32u, c < a.g, qd, qscale);
+    const uint32_t n_tiles = (a.n_pages + 15u) / 16u, n_pos = 2u * a.n_pages;
+    const uint32_t t0 = blockIdx.x * a.tiles_per_split;
+    const uint32_t t1 = min(t0 + a.tiles_per_split, n_tiles);
+    if (t0 >= t1) return;
+    const uint8_t* kp = a.lin_base + (a.k_first + layer * a.layer_stride) * 2048ull + head * 128u + kb * 32u
+                        + (static_cast<uint64_t>(t0) * 32u + c) * 1024u;
+    const float* kt = a.scale_tab + (a.k_first + layer * a.layer_stride + static_cast<uint64_t>(t0) * 16u) + 4u * kb;
+    float* st = stage[wave];
+    // store side: lane -> (row lane/8 [+8], 16-byte piece lane%8) of the staged tile
+    float* dst = out + (row * a.g + (lane >> 3)) * n_pos + static_cast<uint64_t>(t0) * 32u + 4u * (lane & 7u);
+    // two K register sets: the requests of tiles t+1 and t+2 are in flight while tile t is scored
+    struct KTile { uint4 kx[2][2]; f32x4 ks4; };
+    auto issue_k = [&](KTile& T) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { T.kx[b][0] = ldg16(kp + 16384 * b); T.kx[b][1] = ldg16(kp + 16384 * b + 16); }
+        T.ks4 = *reinterpret_cast<const f32x4*>(kt);
+    };
+    auto score_store = [&](uint32_t tile, const KTile& T) {
+        f32x4 sc[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const uint32_t kd[8] = {T.kx[b][0].x, T.kx[b][0].y, T.kx[b][0].z, T.kx[b][0].w, T.kx[b][1].x, T.kx[b][1].y, T.kx[b][1].z, T.kx[b][1].w};
+            f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+                s = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(kd[2 * st], kd[2 * st + 1]), pack64(qd[2 * st], qd[2 * st + 1]), s, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sc[b][i] = s[i] * T.ks4[2 * b + (i >> 1)] * qscale;    // (acc * k scale) * q scale, as the page-table form
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) *reinterpret_cast<f32x4*>(st + c * 36u + 16u * b + 4u * kb) = sc[b];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const uint32_t r = (lane >> 3) + 8u * half;                                        // query row of this lane's piece
+            if (r < a.g) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(st + r * 36u + 4u * (lane & 7u));
+                const uint32_t p = tile * 32u + 4u * (lane & 7u);
+                float* d = dst + static_cast<uint64_t>(8u * half) * n_pos;
+                if (p + 3u < n_pos) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(d));
+                else
+                    for (int i = 0; i < 4; ++i)
+                        if (p + i < n_pos) d[i] = v[i];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        dst += 32;
+    };
+    auto advance = [&](uint32_t next_tile) { const uint32_t st = next_tile < t1 ? 1u : 0u; kp += st * 32768u; kt += st * 16u; };
+    KTile A, B;
+    __builtin_amdgcn_sched_barrier(0);
+    issue_k(A);
+    __builtin_amdgcn_sched_barrier(0);
+    advance(t0 + 1u);
+    issue_k(B);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (uint32_t tile = t0; tile < t1; tile += 2) {
+        score_store(tile, A);
+        __builtin_amdgcn_sched_barrier(0);
+        advance(tile + 2u);
+        issue_k(A);                                   // (past the end: re-requests the last tile, never used)
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile + 1u >= t1) break;
+        score_store(tile + 1u, B);
+        __builtin_amdgcn_sched_barrier(0);
+        advance(tile + 3u);
+        issue_k(B);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+hipError_t launch_qk_scores_fp8_linear(const AttendArgs& a, uint32_t n_layers, float* d_out, hipStream_t s)
+{
+    if (a.n_pages == 0 || n_layers == 0) return hipSuccess;
+    const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
+    hipLaunchKernelGGL(k_qk_scores_fp8_linear, dim3((n_tiles + a.tiles_per_split - 1u) / a.tiles_per_split, n_layers * (a.heads / 4u)), dim3(256), 0, s, a, d_out);
+    return hipGetLastError();
 }
 
 hipError_t launch_attend_combine(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s)

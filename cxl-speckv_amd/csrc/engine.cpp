@@ -1108,6 +1108,27 @@ int Engine::qk_scores_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, co
     if (first_page + (n_layers - 1) * layer_stride + n_pages > a->n_pages) return SPECKV_ERR_GENERAL;
     DeviceScope device_scope(device_);
     hipStream_t st = s ? s : stream_;
+    {   // linear form (records in one run, scale table, tile-aligned range inside the layer's region): direct loads
+        const uint32_t n_tiles = (n_pages + 15u) / 16u;
+        const bool fits = pos_begin % 32u == 0u && a->d_scale_tab && a->linear_base && !getenv("SPECKV_ATTEND_GENERAL") &&
+                          static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
+        if (fits) {
+            AttendArgs k{};
+            k.k_first = first_page;
+            k.layer_stride = layer_stride;
+            k.n_pages = n_pages;
+            k.heads = L.num_heads;
+            k.g = g;
+            k.tiles_per_split = 16;
+            if (const char* env = getenv("SPECKV_QK_TILES_PER_WAVE")) k.tiles_per_split = std::max(1, atoi(env));
+            k.lin_base = a->linear_base;
+            k.scale_tab = a->d_scale_tab;
+            k.q16 = static_cast<const uint16_t*>(d_q_f16);
+            HIP_TRY(launch_qk_scores_fp8_linear(k, n_layers, d_out, st));
+            if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+            return SPECKV_OK;
+        }
+    }
     const size_t rows = static_cast<size_t>(n_layers) * L.num_heads * 16;
     uint8_t* q8 = static_cast<uint8_t*>(scratch(s_req_, rows * 128 + rows * sizeof(float)));
     if (!q8) return SPECKV_ERR_NOMEM;
