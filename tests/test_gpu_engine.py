@@ -777,6 +777,50 @@ def test_fused_attention_equals_attention_over_fetched_pages(eng):
         lib.free(h)
 
 
+def test_fused_attention_row_counts_and_odd_geometry(eng):
+    """g = 1 and g = 16 query rows per kv head, and a token count that is no multiple of 32 (FP8 falls back to the
+    page-table form; the INT4 entry point, linear only, reports INVAL for a range whose last tile leaves the region).
+    Rows are independent of one another, so a row's result must not depend on how many rows travel with it."""
+    torch = torch_mod()
+    lib = eng.lib
+    rng = np.random.default_rng(97)
+    H, D = 8, 128
+    sm = 1.0 / np.sqrt(D)
+    for scheme, fused, T in ((4, lib.attend_fp8, 256), (3, lib.attend_int4, 256), (4, lib.attend_fp8, 100)):
+        lib.set_compression_scheme(scheme)
+        h = eng.allocate(T, 1, H, D, 2)
+        n_pages = T * H * D * 2 * 2 // PAGE
+        x = rng.standard_normal((n_pages, N)).astype(np.float16)
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+        q16 = torch.from_numpy(rng.standard_normal((H, 16, D)).astype(np.float16)).cuda()
+        full = torch.empty((H, 16, D), dtype=torch.float32, device="cuda")
+        fused(h, 0, 1, q16.data_ptr(), 16, 0, T, sm, full.data_ptr())
+        torch.cuda.synchronize()
+        # against torch attention over the rows the engine fetches + decompresses
+        k = eng.kv_rows(0, 0, 0, 0, T).float().clone()
+        v = eng.kv_rows(0, 0, 1, 0, T).float().clone()
+        p = torch.softmax(torch.einsum("hgd,thd->hgt", q16.float(), k) * sm, dim=-1)
+        ref = torch.einsum("hgt,thd->hgd", p, v)
+        mag = torch.einsum("hgt,thd->hgd", p, v.abs())
+        err = (full - ref).abs()
+        if scheme == 3:
+            assert bool((err <= 2e-3 * mag + 1e-6).all())
+        else:
+            assert float(err.max() / ref.abs().max()) < 0.1
+        for g in (1, 8):
+            part = torch.empty((H, g, D), dtype=torch.float32, device="cuda")
+            qg = q16[:, :g, :].contiguous()
+            fused(h, 0, 1, qg.data_ptr(), g, 0, T, sm, part.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(part, full[:, :g, :]), (scheme, T, g)
+        lib.free(h)
+    lib.set_compression_scheme(3)
+    h = eng.allocate(100, 1, H, D, 2)
+    with pytest.raises(SpeckvError):
+        lib.attend_int4(h, 0, 1, q16.data_ptr(), 16, 0, 100, sm, full.data_ptr())
+    lib.free(h)
+
+
 def test_migrate_records_between_pool_slabs(oracle):
     """speckv_ext_migrate: hipMemcpyPeerAsync of record runs + page-table re-point
     (one GPU here, so source and target pool are the same device; the copy path,
