@@ -821,6 +821,39 @@ def test_fused_attention_row_counts_and_odd_geometry(eng):
     lib.free(h)
 
 
+def test_per_layer_attention_calls_capture_into_a_hip_graph(eng):
+    """In steady state speckv_ext_attend_fp8 on a caller stream is kernel launches only (no allocation, no
+    synchronisation), so the per-layer calls of a decode step can be captured into one HIP graph and replayed."""
+    torch = torch_mod()
+    lib = eng.lib
+    lib.set_compression_scheme(4)
+    T, L, H, D, G = 512, 4, 8, 128, 8
+    h = eng.allocate(T, L, H, D, 2)
+    n_pages = T * L * H * D * 2 * 2 // PAGE
+    x = np.random.default_rng(101).standard_normal((n_pages, N)).astype(np.float16)
+    lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+    q = torch.randn((L, H, G, D), device="cuda").to(torch.float16)
+    eager = torch.zeros((L, H, G, D), dtype=torch.float32, device="cuda")
+    replayed = torch.zeros_like(eager)
+    s = torch.cuda.Stream()
+
+    def step(out):
+        for layer in range(L):
+            lib.attend_fp8(h, layer, 1, q[layer].data_ptr(), G, 0, T, 0.1, out[layer].data_ptr(), None, s.cuda_stream)
+
+    step(eager); torch.cuda.synchronize()                      # warm: scratch buffers reach their size
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(graph, stream=s):
+            step(replayed)
+    torch.cuda.synchronize()
+    replayed.zero_()
+    with torch.cuda.stream(s):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(eager, replayed)
+
+
 def test_migrate_records_between_pool_slabs(oracle):
     """speckv_ext_migrate: hipMemcpyPeerAsync of record runs + page-table re-point
     (one GPU here, so source and target pool are the same device; the copy path,
