@@ -297,3 +297,42 @@ def test_headers_are_c99_and_the_c_demo_runs_on_the_fake_device():
     out = subprocess.run([exe, "/dev/null"], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert "0x4000102005" in out.stdout and "0x4123456789" in out.stdout      # F-cabi / ATU goldens
+
+
+def test_calls_from_many_threads(libpath):
+    """SURVEY 8b threading: the C ABI is callable from any thread (one process-global lock, speckv_c_api.cpp:10).
+    Eight threads allocate, access, translate and free at once on the fake device; every result must be the value
+    the single-threaded formulas give and every handle must be unique."""
+    import threading
+    lib = pkg.SpeckvLib(libpath, "/dev/null")
+    errors, handles = [], []
+    lock = threading.Lock()
+
+    def worker(seed):
+        try:
+            mine = []
+            for i in range(200):
+                size = 4096 * (1 + (seed * 7 + i) % 13)
+                h = lib.alloc(size)
+                mine.append(h)
+                off = ((seed + i) * 977) % size
+                assert lib.access(h, off, 16) == 0x4000000000 + (h << 20) + off
+                info = lib.translate(h, off)
+                assert info.virt_page_id == ((h << 32) | ((off // 4096) << 12)) and info.flags == 2
+                if i % 3 == 0:
+                    lib.free(mine.pop(0))
+                lib.prefetch(seed, i % 4, i, 4, list(range(1, 17)))
+            with lock:
+                handles.extend(mine)
+            for h in mine:
+                lib.free(h)
+        except Exception as e:                      # noqa: BLE001 - collected and re-raised below
+            with lock:
+                errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    lib.finalize()
+    assert not errors, errors[:3]
+    assert len(set(handles)) == len(handles)

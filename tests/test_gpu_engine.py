@@ -854,6 +854,41 @@ def test_per_layer_attention_calls_capture_into_a_hip_graph(eng):
     assert torch.equal(eager, replayed)
 
 
+def test_data_path_from_many_threads(eng, oracle):
+    """The HIP engine behind the same lock: four threads read back disjoint page ranges (fetch + decompress to host),
+    access pages and queue look-aheads concurrently; every byte must equal the single-threaded oracle result."""
+    import threading
+    lib = eng.lib
+    lib.set_compression_scheme(2)
+    T, L, H, D, bpe = 256, 4, 8, 128, 2
+    h = eng.allocate(T, L, H, D, bpe)
+    n_pages = T * L * H * D * bpe * 2 // PAGE
+    x = synth(n_pages, seed=23)
+    lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+    scales, lens, recs = oracle.compress_blocks_f16(x, 2, 0)
+    want = oracle.decompress_blocks_f16(recs, lens, scales, 2, 0)
+    errors = []
+
+    def worker(tid):
+        try:
+            lo, hi = tid * n_pages // 4, (tid + 1) * n_pages // 4
+            for rep in range(3):
+                y = np.empty((hi - lo, N), np.float16)
+                lib.read(h, lo * PAGE, y.ctypes.data, y.nbytes, False)
+                assert y.view(np.uint16).tobytes() == want[lo:hi].view(np.uint16).tobytes()
+                for pg in range(lo, hi, 37):
+                    assert lib.access(h, pg * PAGE + 64, 128)
+                lib.prefetch(0, tid % L, 10 + rep, 4, list(range(1, 17)))
+        except Exception as e:                      # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    lib.sync()
+    assert not errors, errors[:2]
+
+
 def test_migrate_records_between_pool_slabs(oracle):
     """speckv_ext_migrate: hipMemcpyPeerAsync of record runs + page-table re-point
     (one GPU here, so source and target pool are the same device; the copy path,
