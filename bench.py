@@ -449,6 +449,26 @@ def xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream
     except Exception as e:
         info["skipped"] = repr(e)
     kv2.close()
+    # the collective alternative for the symmetric layout: every rank contributes a shard of compressed
+    # records and RCCL all-gathers them over xGMI; the path uses it only if it beats the peer-load kernel above
+    if not single_gpu_test and dist.get_backend() == "nccl":
+        try:
+            shard = torch.empty(64 << 20, dtype=torch.uint8, device=f"cuda:{local_rank}")
+            gathered = torch.empty(world * shard.numel(), dtype=torch.uint8, device=f"cuda:{local_rank}")
+            dist.all_gather_into_tensor(gathered, shard); torch.cuda.synchronize()
+            dist.barrier()
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record()
+            for _ in range(5):
+                dist.all_gather_into_tensor(gathered, shard)
+            g1.record(); torch.cuda.synchronize()
+            ag_ms = g0.elapsed_time(g1) / 5
+            info["rccl_allgather"] = {"shard_MiB": 64, "ms": round(ag_ms, 3),
+                                      "inbound_GBps_per_gpu": round((world - 1) * shard.numel() / (ag_ms * 1e-3) / 1e9, 1),
+                                      "note": "torch.distributed all_gather_into_tensor (RCCL) of one 64 MiB shard per rank"}
+            del shard, gathered
+        except Exception as e:
+            info["rccl_allgather"] = {"skipped": repr(e)}
     return info
 
 
