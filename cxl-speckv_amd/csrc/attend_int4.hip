@@ -81,10 +81,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const uint32_t c = lane & 15u, kb = lane >> 4;
     const uint32_t split = blockIdx.x;
     const uint32_t hq = a.heads / 4u;
-    const uint32_t layer = blockIdx.y / hq;
+    uint32_t layer = blockIdx.y / hq;                                    // batch form: the sequence index
     const uint32_t head = (blockIdx.y % hq) * 4u + wave;
     const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;
-    const uint64_t part = row * a.n_splits + split;
+    uint64_t part = row * a.n_splits + split;
+    if (a.seqs) {                                                        // wave-uniform: per-sequence geometry
+        const AttendSeq sq = a.seqs[layer];
+        if (split >= sq.n_splits) return;
+        a.lin_base = sq.lin_base;
+        a.k_first = sq.k_first;
+        a.v_first = sq.v_first;
+        a.n_pages = sq.n_pages;
+        part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
+        layer = 0;
+    }
     uint8_t* vl = lds[wave];
 
     // query operand: fp16 row c of this head, d = 32kb + 8*step + e (rows >= g are zero)
@@ -260,7 +270,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_t s)
 {
-    if (a.n_pages == 0 || n_layers == 0) return hipSuccess;
+    if ((a.n_pages == 0 && !a.seqs) || n_layers == 0 || a.n_splits == 0) return hipSuccess;   // batch form: geometry per sequence
     hipLaunchKernelGGL(k_attend_int4_linear, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
     return hipGetLastError();
 }

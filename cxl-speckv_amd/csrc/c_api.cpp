@@ -331,6 +331,17 @@ speckv_status_t speckv_ext_attend_fp8_batch(uint32_t n_seq, const speckv_handle_
     });
 }
 
+speckv_status_t speckv_ext_attend_int4_batch(uint32_t n_seq, const speckv_handle_t* handles, uint32_t layer, const void* d_q_f16,
+                                             uint32_t g, const uint32_t* pos_end, float sm_scale, float* d_out, float* d_lse,
+                                             void* stream)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] {
+        return g_engine->attend_batch(SPECKV_COMP_INT4_G32, n_seq, handles, layer, d_q_f16, g, pos_end, sm_scale, d_out, d_lse,
+                                      static_cast<hipStream_t>(stream));
+    });
+}
+
 speckv_status_t speckv_ext_attend_int4(speckv_handle_t handle, uint32_t layer_begin, uint32_t n_layers, const void* d_q_f16,
                                        uint32_t g, uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out,
                                        float* d_lse, void* stream)

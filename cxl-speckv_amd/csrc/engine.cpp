@@ -1221,7 +1221,14 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
 int Engine::attend_fp8_batch(uint32_t n_seq, const uint64_t* handles, uint32_t layer, const void* d_q_f16, uint32_t g,
                              const uint32_t* pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
 {
-    if (null_) return no_data_path("speckv_ext_attend_fp8_batch");
+    return attend_batch(SPECKV_COMP_FP8_E4M3, n_seq, handles, layer, d_q_f16, g, pos_end, sm_scale, d_out, d_lse, s);
+}
+
+int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, uint32_t layer, const void* d_q_f16, uint32_t g,
+                         const uint32_t* pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
+{
+    const bool fp8 = scheme == SPECKV_COMP_FP8_E4M3;
+    if (null_) return no_data_path("speckv_ext_attend_*_batch");
     if (n_seq == 0) return SPECKV_OK;
     if (!handles || !pos_end || !d_q_f16 || !d_out || g == 0 || g > 16) return SPECKV_ERR_INVAL;
     std::vector<AttendSeq> seqs(n_seq);
@@ -1230,14 +1237,15 @@ int Engine::attend_fp8_batch(uint32_t n_seq, const uint64_t* handles, uint32_t l
     for (uint32_t i = 0; i < n_seq; ++i) {
         Allocation* a = find(handles[i]);
         if (!a) return SPECKV_ERR_GENERAL;
-        if (!a->has_layout || a->scheme != SPECKV_COMP_FP8_E4M3) return SPECKV_ERR_INVAL;
+        if (!a->has_layout || a->scheme != scheme) return SPECKV_ERR_INVAL;
         const Layout& L = a->layout;
-        if (L.head_dim != 128 || L.bytes_per_element != 2 || L.num_heads * L.head_dim != 1024) return SPECKV_ERR_INVAL;
+        if (L.head_dim != 128 || L.bytes_per_element != 2 || L.num_heads * L.head_dim != 1024 || L.num_tokens % 2) return SPECKV_ERR_INVAL;
         if (layer >= L.num_layers || pos_end[i] % 2 || pos_end[i] > L.num_tokens) return SPECKV_ERR_INVAL;
         const uint32_t n_pages = pos_end[i] / 2, n_tiles = (n_pages + 15u) / 16u;
-        if (!a->linear_base || !a->d_scale_tab || static_cast<uint64_t>(n_tiles) * 32u > L.num_tokens) {
-            SPECKV_ERR("speckv_ext_attend_fp8_batch: sequence %u does not qualify for the linear form "
-                       "(records in one local run, layout with num_tokens %% 32 == 0)", i);
+        if (!a->linear_base || (fp8 && !a->d_scale_tab) || static_cast<uint64_t>(n_tiles) * 32u > L.num_tokens) {
+            SPECKV_ERR("speckv_ext_attend_*_batch: sequence %u does not qualify for the linear form "
+                       "(records in one local run, pos_end rounded up to 32 inside the layer%s)", i,
+                       fp8 ? ", layout with num_tokens %% 32 == 0" : "");
             return SPECKV_ERR_INVAL;
         }
         heads = L.num_heads;
@@ -1298,12 +1306,18 @@ int Engine::attend_fp8_batch(uint32_t n_seq, const uint64_t* handles, uint32_t l
     k.tiles_per_split = tps;
     k.layer_stride = 0;
     k.q16 = static_cast<const uint16_t*>(d_q_f16);
+    k.q8 = static_cast<const uint8_t*>(d_q_f16);          // the INT4 kernel reads the fp16 query through q8
     k.scale_log2e = sm_scale * 1.4426950408889634f;
     k.lin_base = seqs[0].lin_base;           // (overridden per sequence)
     k.seqs = d_seqs;
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
-    HIP_TRY(launch_attend_fp8_batch(k, n_seq, d_out, d_lse, st));
+    if (fp8) {
+        HIP_TRY(launch_attend_fp8_batch(k, n_seq, d_out, d_lse, st));
+    } else {
+        HIP_TRY(launch_attend_int4(k, n_seq, st));        // grid y = sequences x head groups, as for layers
+        HIP_TRY(launch_attend_combine(k, n_seq, d_out, d_lse, st));
+    }
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
     return SPECKV_OK;
 }

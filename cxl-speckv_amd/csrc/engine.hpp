@@ -111,6 +111,8 @@ public:
                    uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
     int attend_fp8_batch(uint32_t n_seq, const uint64_t* handles, uint32_t layer, const void* d_q_f16, uint32_t g,
                          const uint32_t* pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
+    int attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, uint32_t layer, const void* d_q_f16, uint32_t g,
+                     const uint32_t* pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
     int attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
                     uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
     int migrate(uint64_t handle, uint64_t first_page, uint64_t n_pages, uint32_t target_pool);

@@ -70,6 +70,7 @@ _EXT_SIGNATURES = {
     "speckv_ext_qk_scores_fp8_layers": [c_uint64, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_void_p],
     "speckv_ext_attend_fp8": [c_uint64, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, c_uint32, ctypes.c_float, c_void_p, c_void_p, c_void_p],
     "speckv_ext_attend_fp8_batch": [c_uint32, ctypes.POINTER(c_uint64), c_uint32, c_void_p, c_uint32, _u32p, ctypes.c_float, c_void_p, c_void_p, c_void_p],
+    "speckv_ext_attend_int4_batch": [c_uint32, ctypes.POINTER(c_uint64), c_uint32, c_void_p, c_uint32, _u32p, ctypes.c_float, c_void_p, c_void_p, c_void_p],
     "speckv_ext_attend_int4": [c_uint64, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, c_uint32, ctypes.c_float, c_void_p, c_void_p, c_void_p],
     "speckv_ext_promote_to_l1": [c_uint64, c_uint64],
     "speckv_ext_demote_to_l3": [c_uint64, c_uint64],
@@ -275,6 +276,13 @@ class SpeckvLib:
         hs = (c_uint64 * n)(*handles)
         pe = (c_uint32 * n)(*pos_end)
         self._ext("speckv_ext_attend_fp8_batch", n, hs, layer, c_void_p(d_q_f16), g, pe, ctypes.c_float(sm_scale),
+                  c_void_p(d_out), c_void_p(d_lse or 0), c_void_p(stream or 0))
+
+    def attend_int4_batch(self, handles, layer, d_q_f16, g, pos_end, sm_scale, d_out, d_lse=None, stream=None):
+        n = len(handles)
+        hs = (c_uint64 * n)(*handles)
+        pe = (c_uint32 * n)(*pos_end)
+        self._ext("speckv_ext_attend_int4_batch", n, hs, layer, c_void_p(d_q_f16), g, pe, ctypes.c_float(sm_scale),
                   c_void_p(d_out), c_void_p(d_lse or 0), c_void_p(stream or 0))
 
     def attend_int4(self, handle, layer_begin, n_layers, d_q_f16, g, pos_begin, pos_end, sm_scale, d_out, d_lse=None,

@@ -218,6 +218,11 @@ speckv_status_t speckv_ext_attend_int4(speckv_handle_t handle, uint32_t layer_be
                                        const void* d_q_f16, uint32_t g, uint32_t pos_begin, uint32_t pos_end,
                                        float sm_scale, float* d_out, float* d_lse, void* stream);
 
+/* The batch form for INT4_G32 allocations (arguments as speckv_ext_attend_fp8_batch). */
+speckv_status_t speckv_ext_attend_int4_batch(uint32_t n_seq, const speckv_handle_t* handles, uint32_t layer,
+                                             const void* d_q_f16, uint32_t g, const uint32_t* pos_end, float sm_scale,
+                                             float* d_out, float* d_lse, void* stream);
+
 /* ---- tier manager (CXLMemoryManager, cxl_memory_manager.h:40-90) ---------- */
 speckv_status_t speckv_ext_promote_to_l1(speckv_handle_t handle, uint64_t offset_bytes);
 speckv_status_t speckv_ext_demote_to_l3(speckv_handle_t handle, uint64_t offset_bytes);

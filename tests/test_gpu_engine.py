@@ -607,14 +607,16 @@ def test_fp8_attention_scale_table_follows_writes(eng, oracle):
     lib.free(h)
 
 
-def test_fp8_fused_attention_batch_of_sequences(eng):
+@pytest.mark.parametrize("scheme", [4, 3])
+def test_fused_attention_batch_of_sequences(eng, scheme):
     """speckv_ext_attend_fp8_batch: one layer of many sequences (one allocation each, different lengths, one of them
     empty) in one launch pair, against the per-sequence entry point.  Same kernel, other split boundaries, so the
     results agree to fp32 summation order (1e-4 of sum p|v| is generous); the oracle parity of the per-sequence form
     is test_fp8_fused_attention."""
     torch = torch_mod()
     lib = eng.lib
-    lib.set_compression_scheme(4)
+    lib.set_compression_scheme(scheme)
+    batch_fn, single_fn = (lib.attend_fp8_batch, lib.attend_fp8) if scheme == 4 else (lib.attend_int4_batch, lib.attend_int4)
     T, L, H, D, G = 1024, 2, 8, 128, 8
     rng = np.random.default_rng(83)
     lens = [1024, 64, 0, 258, 1000, 32, 514, 2]
@@ -635,14 +637,14 @@ def test_fp8_fused_attention_batch_of_sequences(eng):
             try:
                 out = torch.full((len(lens), H, G, D), float("nan"), dtype=torch.float32, device="cuda")
                 lse = torch.full((len(lens), H, G), float("nan"), dtype=torch.float32, device="cuda")
-                lib.attend_fp8_batch(handles, layer, q.data_ptr(), G, lens, sm, out.data_ptr(), lse.data_ptr())
+                batch_fn(handles, layer, q.data_ptr(), G, lens, sm, out.data_ptr(), lse.data_ptr())
                 torch.cuda.synchronize()
             finally:
                 os.environ.pop("SPECKV_ATTEND_TILES_PER_SPLIT", None)
             for i, (h, n) in enumerate(zip(handles, lens)):
                 one = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
                 one_lse = torch.empty((H, G), dtype=torch.float32, device="cuda")
-                lib.attend_fp8(h, layer, 1, q[i].data_ptr(), G, 0, n, sm, one.data_ptr(), one_lse.data_ptr())
+                single_fn(h, layer, 1, q[i].data_ptr(), G, 0, n, sm, one.data_ptr(), one_lse.data_ptr())
                 torch.cuda.synchronize()
                 if n == 0:
                     assert float(out[i].abs().max()) == 0.0
@@ -650,11 +652,11 @@ def test_fp8_fused_attention_batch_of_sequences(eng):
                 scale = float(one.abs().max()) + 1e-6
                 assert float((out[i] - one).abs().max()) <= 2e-4 * scale, (layer, tps, i, n)
                 assert float((lse[i] - one_lse).abs().max()) <= 1e-4, (layer, tps, i, n)
-    # a sequence that does not qualify (INT4 allocation) -> INVAL, nothing launched
-    lib.set_compression_scheme(3)
+    # a sequence stored in the other format does not qualify -> INVAL, nothing launched
+    lib.set_compression_scheme(3 if scheme == 4 else 4)
     hx = lib.alloc(T * L * H * D * 2 * 2); lib.set_layout(hx, T, L, H, D, 2)
     with pytest.raises(SpeckvError):
-        lib.attend_fp8_batch(handles + [hx], 0, q.data_ptr(), G, lens + [64], sm, out.data_ptr())
+        batch_fn(handles + [hx], 0, q.data_ptr(), G, lens + [64], sm, out.data_ptr())
     for h in handles + [hx]:
         lib.free(h)
 
