@@ -6,11 +6,18 @@
  * load this library, and there only as the checker.  The shipped path
  * (cxl-speckv_amd/csrc -> libcxlspeckv.so) never links or calls it.
  *
- * Parity status: PINNED.  Every function below is validated here in the dev
- * container against the reference compiled from /root/reference by
- * oracle/Makefile (oracle/_ref/libspeckv_ref.so, see oracle/ref_harness.cpp)
- * and against the golden fixtures in tests/golden/ that were generated from
- * that reference build by tests/golden/generate_golden.py.
+ * Parity status: PINNED for everything that restates reference code -- ids, C ABI
+ * model, INT8 / INT8_DELTA_RLE codec, memory manager, TLB, prefetcher, adaptive
+ * depth, token predictor, coherence directory: validated here in the dev container
+ * against the reference compiled from /root/reference by oracle/Makefile
+ * (oracle/_ref/libspeckv_ref.so via oracle/ref_harness.cpp, and
+ * oracle/_ref/libspeckv_ref_coh.so via oracle/coh_harness.cpp) and against the
+ * golden fixtures in tests/golden/ generated from those builds by
+ * tests/golden/generate_golden.py.
+ * PARITY UNPINNED for the extensions that have no reference counterpart (SURVEY 8a
+ * row A22): the INT4_G32 / FP8_E4M3 block formats, orc_qk_scores_fp8,
+ * orc_attend_fp8, orc_attend_f16, orc_quantize_rows_e4m3 -- those are our own
+ * definitions and say so where they are declared.
  *
  * All reference citations are relative to /root/reference.
  */
