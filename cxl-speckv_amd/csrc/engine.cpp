@@ -1176,7 +1176,10 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     const uint32_t n_tiles = (n_pages + 15u) / 16u;
     const uint32_t rows = n_layers * L.num_heads;
     uint32_t want = (10240u + rows - 1u) / rows;
-    want = std::min(want, std::max(1u, n_tiles / 8u));
+    // per-layer calls are latency-bound: short contexts want short splits (measured best: 2 tiles per split at 2k
+    // context, 4 at 8k, 8 at 32k), long multi-layer launches are bounded by `want` above
+    const uint32_t min_tiles = std::min(8u, std::max(2u, n_tiles / 64u));
+    want = std::min(want, std::max(1u, n_tiles / min_tiles));
     if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));
     uint32_t n_splits = std::max(1u, std::min(std::min(want, n_tiles), 2048u));
     const uint32_t tiles_per_split = (n_tiles + n_splits - 1u) / n_splits;
@@ -1359,7 +1362,8 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     }
     const uint32_t rows = n_layers * L.num_heads;
     uint32_t want = (5120u + rows - 1u) / rows;      // VALU-bound kernel: fewer, longer splits measured best
-    want = std::min(want, std::max(1u, n_tiles / 8u));
+    const uint32_t min_tiles = std::min(8u, std::max(2u, n_tiles / 64u));      // per-layer calls: see attend_fp8
+    want = std::min(want, std::max(1u, n_tiles / min_tiles));
     if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));
     uint32_t n_splits = std::max(1u, std::min(std::min(want, n_tiles), 2048u));
     const uint32_t tiles_per_split = (n_tiles + n_splits - 1u) / n_splits;
