@@ -214,6 +214,41 @@ def test_many_random_blocks(lib, oracle):
         assert_same_float_bits(y, want, f"mode {mode}")
 
 
+def test_run_lengths_around_the_split_limit(lib, oracle):
+    """The RLE encoder keeps its fast path while every run stays under the 255 limit (bounded by a per-lane estimate
+    that is up to 7 elements pessimistic) and hands longer stretches to the run splitter (cache_engine.cpp:224: a run
+    closes at count 255).  Piecewise-constant blocks whose zero-delta stretches are 230..270 long, at every alignment
+    against the 8-element lanes and the 512-element chunks, plus stretches that begin in one chunk and end in the
+    next, pin that boundary byte for byte; all-zero blocks with a single spike pin the direct zero-record path."""
+    rng = np.random.default_rng(424242)
+    blocks = []
+    for seg in range(230, 271):
+        for shift in (0, 1, 3, 7, 8, 129, 255, 500):
+            levels = rng.standard_normal((N + 600) // seg + 3)
+            x = np.repeat(levels, seg)[shift:shift + N]
+            blocks.append(x)
+    for start in (0, 1, 300, 511, 512, 1000, 1790, 1800):            # one long stretch inside noise, crossing chunk borders
+        for length in (240, 247, 248, 249, 254, 255, 256, 257, 300, 520):
+            x = rng.standard_normal(N)
+            x[start:start + length] = x[start]
+            blocks.append(x)
+    for pos in (0, 1, 254, 255, 256, 1023, 2047):                    # zeros with one spike; and exact zeros
+        x = np.zeros(N); x[pos] = 1.0
+        blocks.append(x)
+    blocks.append(np.zeros(N)); blocks.append(-np.zeros(N))
+    x16 = np.stack(blocks).astype(np.float16)
+    for mode in MODES:
+        scales, lens, recs = gpu_compress(lib, x16, 2, mode)
+        o_scales, o_lens, o_recs = oracle.compress_blocks_f16(x16, 2, mode)
+        assert np.array_equal(lens, o_lens), np.nonzero(lens != o_lens)[0][:8]
+        assert scales.tobytes() == o_scales.tobytes()
+        mask = np.arange(4096)[None, :] < lens[:, None]
+        bad = np.nonzero((recs != o_recs) & mask)
+        assert bad[0].size == 0, (mode, bad[0][:5], bad[1][:5])
+        y = gpu_decompress(lib, recs, lens, scales, 2, mode)
+        assert_same_float_bits(y, oracle.decompress_blocks_f16(o_recs, o_lens, o_scales, 2, mode), f"mode {mode}")
+
+
 def test_full_size_roundtrip_properties(lib):
     """BASELINE config 2 size (131072 blocks = 512 MiB fp16): size-independent
     properties instead of the oracle -- decode(encode(x)) is a fixed point of a
