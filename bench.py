@@ -270,7 +270,7 @@ def main():
         parity = bool(parity)
 
     extras = {}
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras:      # secondary measurements: single-GPU runs only
         with torch.cuda.stream(stream):
             extras = run_extras(torch, pkg, lib, src, dst, n_blocks, sp)
         extras.update(run_engine_extras(torch, kv, handle, n_blocks, T, Lyr))
@@ -342,11 +342,13 @@ def main():
         x = xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream, red_dev, single_gpu_test)
         if rank == 0 and out is not None:
             out["xgmi"] = x
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # rank 0 at N=1 only (bench contract)
         try:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         except Exception as e:                                  # the checker must never cost the result
             out["cpu_baseline"] = {"error": repr(e)}
+    elif rank == 0 and world > 1:
+        out["cpu_baseline"] = None                              # measured by the N=1 run
     dog.cancel()
     emit()
     if dist:
