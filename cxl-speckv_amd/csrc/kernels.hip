@@ -147,15 +147,23 @@ __device__ __forceinline__ uint32_t quantize(float x, float scale)
 // reference in ~1e-5 of the elements (caught by test_many_random_blocks).
 // the same byte as quantize<MODE> for a finite x of a finite block: the divide goes
 // through the block's reciprocal (div_by_scale) and the out-of-range test is not needed
+// round-half-away-from-zero to int for the values this codec rounds: truncate(y + copysign(0.5, y)).  In general that
+// differs from roundf (y + 0.5 can round up across an integer), but not for any y the codec forms from a finite block:
+// checked EXHAUSTIVELY on the device next to the divide (k_debug_divcheck, third counter: every fp16 x against every
+// scale, y = x/s*127, y = x/s and the INT4 y = x/s16).  3 VALU (bfi, add, cvt) instead of the 7 of roundf + cvt.
+__device__ __forceinline__ int round_to_int(float y)
+{
+    return static_cast<int>(y + __builtin_copysignf(0.5f, y));
+}
 template <int MODE>
 __device__ __forceinline__ uint32_t quantize_finite(float x, float scale, float rcp)
 {
     const float scaled = div_by_scale(x, scale, rcp);
     if (MODE == kRefExact) {
-        return static_cast<uint32_t>(static_cast<int>(roundf(scaled * 127.0f))) & 0xFFu;
+        return static_cast<uint32_t>(round_to_int(scaled * 127.0f)) & 0xFFu;
     } else {
-        const float r = fminf(fmaxf(roundf(scaled), -127.0f), 127.0f);
-        return static_cast<uint32_t>(static_cast<int>(r)) & 0xFFu;
+        const int r = min(max(round_to_int(scaled), -127), 127);
+        return static_cast<uint32_t>(r) & 0xFFu;
     }
 }
 // max|x| of a block plus "every element is finite" in one pass: fmaxf ignores NaN like
@@ -829,9 +837,8 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                     const float rcp = nz ? 1.0f / sc : 0.0f;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        float r = nz ? roundf(div_by_scale(xv[k], sc, rcp)) : 0.0f;
-                        r = fminf(fmaxf(r, -7.0f), 7.0f);
-                        nib |= (static_cast<uint32_t>(static_cast<int>(r)) & 0xFu) << (4 * k);
+                        const int r = nz ? min(max(round_to_int(div_by_scale(xv[k], sc, rcp)), -7), 7) : 0;
+                        nib |= (static_cast<uint32_t>(r) & 0xFu) << (4 * k);
                     }
                 } else {
 #pragma unroll
@@ -1249,7 +1256,7 @@ __global__ void k_debug_divcheck(float den, unsigned long long* counters)
     const float lim = den > 0.0f ? m : 7.5f * m;
     const float mul = den == 127.0f ? 127.0f : 1.0f;
     const float r = 1.0f / s;
-    unsigned long long bad = 0, badq = 0;
+    unsigned long long bad = 0, badq = 0, badr = 0;
     for (uint32_t xb = 0; xb < 65536u; ++xb) {
         if ((xb & 0x7C00u) == 0x7C00u) continue;                 // inf / nan dividends take the slow path
         const float x = half_bits_to_float(xb);
@@ -1257,9 +1264,14 @@ __global__ void k_debug_divcheck(float den, unsigned long long* counters)
         const float a = x / s, b = div_by_scale(x, s, r);
         bad += (__float_as_uint(a) != __float_as_uint(__builtin_copysignf(b, x))) ? 1ull : 0ull;
         badq += (static_cast<int>(roundf(a * mul)) != static_cast<int>(roundf(b * mul))) ? 1ull : 0ull;
+        // candidate cheap rounding: truncate(y + copysign(0.5, y)) against roundf(y), for both products the codec rounds
+        const float y1 = b * mul, y2 = b;
+        badr += (static_cast<int>(roundf(y1)) != static_cast<int>(y1 + __builtin_copysignf(0.5f, y1))) ? 1ull : 0ull;
+        badr += (static_cast<int>(roundf(y2)) != static_cast<int>(y2 + __builtin_copysignf(0.5f, y2))) ? 1ull : 0ull;
     }
     if (bad) atomicAdd(&counters[0], bad);
     if (badq) atomicAdd(&counters[1], badq);
+    if (badr) atomicAdd(&counters[2], badr);
 }
 
 // ===================================================================

@@ -294,15 +294,17 @@ def test_fast_division_is_exact(lib):
     """The compressor divides by the block scale through one reciprocal per block
     (kernels.hip: div_by_scale).  Exhaustive device check: every finite fp16
     dividend against every divisor the codec can form (m/127, m/448, and fp16 group
-    scales) gives the same quotient bits as the IEEE divide (and the same stored byte)."""
+    scales) gives the same quotient bits as the IEEE divide (and the same stored byte).  Third counter: the cheap
+    rounding truncate(y + copysign(0.5, y)) equals roundf(y) for every product the codec rounds (kernels.hip:
+    round_to_int)."""
     import ctypes as C
     import torch
     lib.speckv_debug_divcheck.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
     for den in (127.0, 448.0, 0.0):
-        cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
+        cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
         assert lib.speckv_debug_divcheck(den, cnt.data_ptr(), None) == 0
         torch.cuda.synchronize()
-        assert cnt.tolist() == [0, 0], (den, cnt.tolist())
+        assert cnt.tolist() == [0, 0, 0, 0], (den, cnt.tolist())
 
 
 def test_wave_primitives(lib):
