@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+EXTRAS_RAMP_MS = 25.0           # untimed clock ramp before each secondary measurement (see ramp())
 PAGE = 4096
 BLOCK_ELEMS = 2048
 SCHEME_NAMES = {0: "fp16", 1: "int8", 2: "int8_delta_rle"}
@@ -69,6 +70,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--ramp-ms", type=float, default=60.0, help="untimed clock ramp before every timed region (0 = off)")
     return ap.parse_args()
 
 
@@ -137,6 +139,25 @@ def cpu_baseline(seconds, sample_blocks=None, seed=2001):
             "value_1thread": round(v1, 1),
             "sample": f"{sample_blocks} N(0,1) fp16 blocks (seed {seed}), INT8_DELTA_RLE decompress to fp32, "
                       f"looped ~{seconds:.0f}s per leg; 1 thread and {n_threads} threads (one engine each)"}
+
+
+# --------------------------------------------------------------------------
+# clock ramp: an idle MI355X sits at 648 MHz sclk and needs ~8 ms (about 40 launches of the 180 us kernel) of
+# continuous work before the shader clock settles: measured per-step durations 181-190 us for the first 40 steps,
+# 171 us from then on (scratch/step_trend.py).  Every timed region below is therefore preceded by an UNTIMED run of
+# the same step for ramp_ms of wall time, in addition to the W warm-up steps of the contract.
+# --------------------------------------------------------------------------
+def ramp(fn, sync, ramp_ms):
+    if ramp_ms <= 0:
+        return 0
+    t0 = time.perf_counter()
+    n = 0
+    while (time.perf_counter() - t0) * 1e3 < ramp_ms:
+        for _ in range(8):
+            fn()
+        sync()
+        n += 8
+    return n
 
 
 # --------------------------------------------------------------------------
@@ -237,6 +258,7 @@ def main():
         if i == args.steps - 1:
             ev1.record(stream)
 
+    ramp_steps = ramp(step, torch.cuda.synchronize, args.ramp_ms)
     elapsed = run_timed(timed_step, args.steps, args.warmup, torch.cuda.synchronize, dist,
                         warm=lambda: step(), reduce_device=red_dev)
     kern_ms = ev0.elapsed_time(ev1) / args.steps
@@ -287,6 +309,8 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "untimed_clock_ramp": {"ms": args.ramp_ms, "steps": ramp_steps,
+                                   "note": "same step, before the W warm-up steps: an idle MI355X needs ~8 ms of work to reach its clocks"},
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
@@ -431,6 +455,7 @@ def xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream
             ev1.record(stream)
 
     try:
+        ramp(lambda: lib.fetch_range(handle, 0, n_blocks, dst.data_ptr(), False, sp), torch.cuda.synchronize, args.ramp_ms)
         elapsed = run_timed(step, steps, 2, torch.cuda.synchronize, dist,
                             warm=lambda: lib.fetch_range(handle, 0, n_blocks, dst.data_ptr(), False, sp),
                             reduce_device=red_dev)
@@ -496,6 +521,7 @@ def fp8_scores_extra(torch, kv, T, Lyr):
         def allayers():
             lib.qk_scores_fp8_layers(h, 0, Lyr, q.data_ptr(), 8, 0, T, out.data_ptr(), s.cuda_stream)
         allayers(); torch.cuda.synchronize()
+        ramp(allayers, torch.cuda.synchronize, EXTRAS_RAMP_MS)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 5
         a.record(s)
@@ -511,6 +537,7 @@ def fp8_scores_extra(torch, kv, T, Lyr):
             def attend():
                 lib.attend_fp8(h, 0, Lyr, q.data_ptr(), 8, 0, T, 0.08838834764831845, o.data_ptr(), None, s.cuda_stream)
             attend(); torch.cuda.synchronize()
+            ramp(attend, torch.cuda.synchronize, EXTRAS_RAMP_MS)
             a.record(s)
             for _ in range(reps):
                 attend()
@@ -555,6 +582,7 @@ def int4_attention_extra(torch, kv, T, Lyr):
         def attend():
             lib.attend_int4(h, 0, Lyr, q.data_ptr(), 8, 0, T, 0.08838834764831845, o.data_ptr(), None, s.cuda_stream)
         attend(); torch.cuda.synchronize()
+        ramp(attend, torch.cuda.synchronize, EXTRAS_RAMP_MS)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 5
         a.record(s)
@@ -598,6 +626,7 @@ def batch_attention_extra(torch, kv, n_seq=256, T=8192):
         def step():
             lib.attend_fp8_batch(handles, 0, q.data_ptr(), 8, lens, 0.08838834764831845, o.data_ptr(), None, s.cuda_stream)
         step(); torch.cuda.synchronize()
+        ramp(step, torch.cuda.synchronize, EXTRAS_RAMP_MS)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 10
         a.record(s)
@@ -660,6 +689,7 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
         def gather():
             lib.fetch_list(handle, perm.data_ptr(), n_blocks, out.data_ptr(), False, st_.cuda_stream)
         gather(); torch.cuda.synchronize()
+        ramp(gather, torch.cuda.synchronize, EXTRAS_RAMP_MS)
         a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a_.record(st_)
         for _ in range(10):
@@ -720,6 +750,7 @@ def run_extras(torch, pkg, lib, src, dst, n_blocks, sp):
 
     def timed(fn, reps=10):
         fn(); torch.cuda.synchronize()
+        ramp(fn, torch.cuda.synchronize, EXTRAS_RAMP_MS)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); [fn() for _ in range(reps)]; b.record(); torch.cuda.synchronize()
         return a.elapsed_time(b) / reps
