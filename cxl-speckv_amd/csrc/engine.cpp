@@ -350,7 +350,9 @@ int Engine::free(uint64_t handle)
     if (!null_) {
         DeviceScope device_scope(device_);
         reap(true);
-        (void)hipStreamSynchronize(stream_);
+        // asynchronous entry points (fetch_range / fetch_list / attend_* on a caller stream) may still be reading this
+        // allocation's records: wait for the whole device, as hipFree would, before the pool memory is recycled
+        (void)hipDeviceSynchronize();
         release_allocation(it->second.get());
     }
     st_.total_deallocations++;
