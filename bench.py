@@ -475,6 +475,25 @@ def xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream
                          "raw_copy_note": "256 MiB device-to-device copy from the next GPU, all ranks at once (one direction per link)"})
     except Exception as e:
         info["skipped"] = repr(e)
+    # SURVEY 8d cfg3 asks for the uncompressed variant too: fp16 pages (4096 B per block over the link)
+    try:
+        if "skipped" not in info:
+            lib.set_compression_scheme(0)
+            h16 = lib.alloc(n_blocks * PAGE)
+            lib.write(h16, 0, src.data_ptr(), src.numel() * 2, on_device=True)
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            lib.fetch_range(h16, 0, n_blocks, dst.data_ptr(), False, sp); torch.cuda.synchronize()
+            dist.barrier()
+            f0.record(stream)
+            for _ in range(5):
+                lib.fetch_range(h16, 0, n_blocks, dst.data_ptr(), False, sp)
+            f1.record(stream); torch.cuda.synchronize()
+            ms16 = f0.elapsed_time(f1) / 5
+            info["fp16_pages"] = {"inbound_GBps_per_gpu": round(n_blocks * PAGE / (ms16 * 1e-3) / 1e9, 1),
+                                  "blocks_per_s_per_gpu": round(n_blocks / (ms16 * 1e-3), 1)}
+            lib.free(h16)
+    except Exception as e:
+        info["fp16_pages"] = {"skipped": repr(e)}
     kv2.close()
     # the collective alternative for the symmetric layout: every rank contributes a shard of compressed
     # records and RCCL all-gathers them over xGMI; the path uses it only if it beats the peer-load kernel above
