@@ -994,6 +994,42 @@ def test_c_demo_runs_on_the_gpu():
     assert "L2 (prefetched) hits" in out.stdout
 
 
+def test_fp8_attention_over_a_striped_and_migrated_pool():
+    """The fused attention on records that are NOT in one run: pool striped over three pools (page % 3), then part of it
+    migrated -- the page-table form must give what the linear form gives on a one-pool engine for the same data."""
+    torch = torch_mod()
+    T, L, H, D, G = 256, 2, 8, 128, 8
+    n_pages = T * L * H * D * 2 * 2 // PAGE
+    x = np.random.default_rng(131).standard_normal((n_pages, N)).astype(np.float16)
+    q = torch.from_numpy(np.random.default_rng(132).standard_normal((L, H, G, D)).astype(np.float16)).cuda()
+    outs = []
+    for pools in (None, "0,0,0"):
+        if pools: os.environ["SPECKV_POOL_DEVICES"] = pools
+        try:
+            lib = pkg.SpeckvLib(pkg.library_path(), "hip:0")
+        finally:
+            os.environ.pop("SPECKV_POOL_DEVICES", None)
+        try:
+            lib.set_compression_scheme(4)
+            h = lib.alloc(n_pages * PAGE)
+            lib.set_layout(h, T, L, H, D, 2)
+            lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+            if pools:
+                lib.migrate(h, 10, 50, 1)
+            out = torch.empty((L, H, G, D), dtype=torch.float32, device="cuda")
+            lse = torch.empty((L, H, G), dtype=torch.float32, device="cuda")
+            lib.attend_fp8(h, 0, L, q.data_ptr(), G, 0, T, 0.1, out.data_ptr(), lse.data_ptr())
+            torch.cuda.synchronize()
+            outs.append((out.cpu(), lse.cpu()))
+            lib.free(h)
+        finally:
+            lib.finalize()
+    (o_lin, l_lin), (o_pt, l_pt) = outs
+    scale = float(o_lin.abs().max())
+    assert float((o_lin - o_pt).abs().max()) <= 2e-4 * scale        # same maths, other split boundaries / tile reference scales
+    assert float((l_lin - l_pt).abs().max()) <= 1e-4
+
+
 def test_striped_multi_pool_on_one_gpu(oracle):
     """SPECKV_POOL_DEVICES="0,0,0": three pools (here all on GPU 0) exercise the
     multi-GPU placement code on a one-GPU box: pages striped page % 3, host-built
