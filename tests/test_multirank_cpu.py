@@ -61,3 +61,27 @@ def test_single_rank_needs_no_process_group():
     e = bench.run_timed(lambda i: n.append(i), steps=3, warmup=1, sync=lambda: None)
     assert n == [0, 0, 1, 2] and e > 0
     assert bench.whole_job_rate(1, 131072, 3, 0.5) == 131072 * 3 / 0.5
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """The bench line committed with the round's profile (profiles/r01f_bench.json = stdout of `python bench.py` on the
+    MI355X box) carries every field of the driver's contract, with the tier's meaning: metric and config from
+    BASELINE.json, roofline and cpu_baseline objects, no model keys."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "r01f_bench.json")))
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert d["metric"] in base["metric"] and d["unit"] == "blocks/s"
+    for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["dtype"] == "u8" and "workload" in d["config"] and "model" not in d["config"]
+    assert "configs[1]" in d["config"]["workload"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.5 < r["frac"] < 1.0
+    assert r["traffic"] is None or 0.95 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
+    assert abs(d["value"] - 131072 * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+    c = d["cpu_baseline"]
+    assert c["unit"] == "blocks/s" and c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["parity_spot_check"] is True
