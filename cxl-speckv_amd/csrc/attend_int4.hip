@@ -11,8 +11,10 @@
 // run on v_mfma_f32_16x16x32_f16 with fp32 accumulation, softmax weights are rounded to f16.  So
 // the result is the attention over the decompressed fp16 pages without ever writing them.
 //
-// Linear form only (records of the allocation in one run, never-written records zero bytes): one
-// wave = one kv head x one split of the positions, tiles of 32 positions.
+// One wave = one kv head x one split of the positions, tiles of 32 positions.  LINEAR form: records of the
+// allocation in one run (record p at lin_base + p*1152, never-written records zero bytes), addresses are
+// arithmetic.  Page-table form (striped / migrated / remote pools, ranges that are not tile aligned): the same
+// kernel takes each page's record address from its page-table entry (never-written pages read a zero page).
 //   scores S^T = K . q^T: lane (c, kb) feeds row c = position 16b + c, d = 32kb + 8*step + e --
 //     exactly group kb of that row: ONE 16-byte load and one scale per lane and block.
 //   output O^T = V^T . P^T: rows c = d columns 8c + t, k-slots = the lane's 8 positions (as in
@@ -71,7 +73,8 @@ __device__ __forceinline__ f16x8 deq_row8(uint32_t wx, f16x2 s2)
 
 } // namespace
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_attend_int4_linear(AttendArgs a)
+template <bool LINEAR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_attend_int4(AttendArgs a)
 {
     // per wave: V nibbles 32 rows x 128 B pitch (64 used, +64 for rows with bit 2 set: bank spread), then
     // 32 rows x 8 B of V group scales
@@ -136,17 +139,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         uint16_t ks[2];
         uint4 vraw[2];
         uint32_t vsraw;
+        // page-table form: record base of page pg of the K / V region (clamped into the range; never written -> zeros)
+        const PageEntry* kent = a.entries + a.k_first + layer * a.layer_stride;
+        const PageEntry* vent = a.entries + a.v_first + layer * a.layer_stride;
+        auto rec_base = [&](const PageEntry* ent, uint32_t pg) -> const uint8_t* {
+            const PageEntry e = ent[min(pg, a.n_pages - 1u)];
+            return e.rec_bytes >= kInt4RecBytes ? reinterpret_cast<const uint8_t*>(e.pool_addr) : a.zero_page;
+        };
+        uint32_t next_k = t0, next_v = t0;                                // tile the next request is for
         auto issue_k = [&]() {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                kx[b] = ldg16(kdat + 8u * kInt4RecBytes * b);
-                ks[b] = *reinterpret_cast<const uint16_t*>(ksc + 8u * kInt4RecBytes * b);
+                if (LINEAR) {
+                    kx[b] = ldg16(kdat + 8u * kInt4RecBytes * b);
+                    ks[b] = *reinterpret_cast<const uint16_t*>(ksc + 8u * kInt4RecBytes * b);
+                } else {
+                    const uint8_t* base = rec_base(kent, next_k * 16u + 8u * b + (c >> 1));
+                    kx[b] = ldg16(base + 128u + rowoff * 64u + kb * 16u);
+                    ks[b] = *reinterpret_cast<const uint16_t*>(base + rowoff * 8u + kb * 2u);
+                }
             }
         };
         auto issue_v = [&]() {
-            vraw[0] = ldg16(vdat);
-            vraw[1] = ldg16(vdat + 8u * kInt4RecBytes);
-            vsraw = *reinterpret_cast<const uint32_t*>(vsc);
+            if (LINEAR) {
+                vraw[0] = ldg16(vdat);
+                vraw[1] = ldg16(vdat + 8u * kInt4RecBytes);
+                vsraw = *reinterpret_cast<const uint32_t*>(vsc);
+            } else {
+                const uint32_t voff = 128u + ((vr & 1u) * 8u + head) * 64u + (lane & 3u) * 16u;
+                vraw[0] = ldg16(rec_base(vent, next_v * 16u + (vr >> 1)) + voff);
+                vraw[1] = ldg16(rec_base(vent, next_v * 16u + 8u + (vr >> 1)) + voff);
+                vsraw = *reinterpret_cast<const uint32_t*>(rec_base(vent, next_v * 16u + (sr >> 1)) + ((sr & 1u) * 8u + head) * 8u + (lane & 1u) * 4u);
+            }
         };
         // LDS addresses: writer and reader
         const uint32_t wr0 = vr * 128u + ((vr >> 2) & 1u) * 64u + (lane & 3u) * 16u;           // rows 16..31: + 2048, same bit 2
@@ -186,7 +210,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            kdat += step; ksc += step;
+            kdat += step; ksc += step; next_k += step ? 1u : 0u;
             issue_k();
             __builtin_amdgcn_sched_barrier(0);
             // ---- online softmax of query row c
@@ -223,7 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            vdat += step; vsc += step;
+            vdat += step; vsc += step; next_v += step ? 1u : 0u;
             issue_v();                                                    // the staging registers are free again
             __builtin_amdgcn_sched_barrier(0);
             // ---- out^T += V^T . P^T, accumulated in place
@@ -271,7 +295,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_t s)
 {
     if ((a.n_pages == 0 && !a.seqs) || n_layers == 0 || a.n_splits == 0) return hipSuccess;   // batch form: geometry per sequence
-    hipLaunchKernelGGL(k_attend_int4_linear, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
+    if (a.lin_base) hipLaunchKernelGGL(k_attend_int4<true>, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
+    else            hipLaunchKernelGGL(k_attend_int4<false>, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

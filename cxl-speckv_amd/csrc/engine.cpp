@@ -1355,12 +1355,13 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     const uint64_t layer_stride = static_cast<uint64_t>(L.num_tokens);
     if (v_first + (n_layers - 1) * layer_stride + n_pages > a->n_pages) return SPECKV_ERR_GENERAL;
     const uint32_t n_tiles = (n_pages + 15u) / 16u;
-    // the tile loop reads whole 32-position tiles: the last one must stay inside the layer's K / V region
+    // linear form: records in one local run and every 32-position tile inside the layer's K / V region; otherwise the
+    // page-table form of the same kernel
     const bool fits = static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
-    if (!a->linear_base || !fits) {
-        SPECKV_ERR("speckv_ext_attend_int4: needs the allocation's records in one local run (not striped, not migrated) "
-                   "and pos_begin + 32*ceil((pos_end-pos_begin)/32) <= num_tokens");
-        return SPECKV_ERR_INVAL;
+    const bool linear = a->linear_base && fits && !getenv("SPECKV_ATTEND_GENERAL");
+    if (!linear && !d_zero_page_) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
+        HIP_TRY(hipMemset(d_zero_page_, 0, kPageSize));
     }
     const uint32_t rows = n_layers * L.num_heads;
     uint32_t want = (5120u + rows - 1u) / rows;      // VALU-bound kernel: fewer, longer splits measured best
@@ -1386,7 +1387,8 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     k.tiles_per_split = tiles_per_split;
     k.q8 = static_cast<const uint8_t*>(d_q_f16);
     k.scale_log2e = sm_scale * 1.4426950408889634f;
-    k.lin_base = a->linear_base;
+    k.lin_base = linear ? a->linear_base : nullptr;
+    k.zero_page = d_zero_page_;
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
     HIP_TRY(launch_attend_int4(k, n_layers, st));

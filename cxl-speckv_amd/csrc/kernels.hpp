@@ -139,7 +139,8 @@ hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_ou
 hipError_t launch_build_scale_tab(const PageEntry* d_entries, uint64_t n_pages, uint32_t region_pages, float* d_scale_tab, hipStream_t s);
 // position of page-in-tile j (0..15) in the tile order [kb][r]: pages 2kb, 2kb+1, 8+2kb, 9+2kb of lane group kb
 __host__ __device__ inline uint32_t attend_tile_slot(uint32_t j) { return j < 8u ? ((j >> 1) << 2) + (j & 1u) : (((j - 8u) >> 1) << 2) + 2u + (j & 1u); }
-// INT4_G32 records (attend_int4.hip; linear form only: a.lin_base must be set, a.q8 = the fp16 query rows
+// INT4_G32 records (attend_int4.hip; a.lin_base set: linear form, else page-table form with a.entries / a.zero_page;
+// a.q8 = the fp16 query rows
 // [layers][heads][g][128]); writes the split partials, launch_attend_combine merges them
 hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_t s);
 hipError_t launch_attend_combine(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s);

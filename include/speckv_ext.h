@@ -211,9 +211,9 @@ speckv_status_t speckv_ext_attend_fp8_batch(uint32_t n_seq, const speckv_handle_
 /* speckv_ext_attend_int4: the same attention over SPECKV_COMP_INT4_G32 records (the 4:1 format).  K and V are
  * dequantised exactly as fetch+decompress does (fp16(q4 * group scale)), the query stays fp16, both products run
  * on v_mfma_f32_16x16x32_f16 with fp32 accumulation: the attention over the decompressed fp16 pages, without
- * writing them.  Needs the allocation's records in one local run (the default placement of a one-pool engine;
- * SPECKV_ERR_INVAL after a migration or on a striped pool) and
- * pos_begin + 32*ceil((pos_end-pos_begin)/32) <= num_tokens.  (oracle: orc_attend_f16 over decompressed pages.) */
+ * writing them.  Records in one local run (the default placement of a one-pool engine) take the arithmetic-address
+ * form of the kernel; striped / migrated pools and ranges whose last 32-position tile would leave the layer go
+ * through the page table.  (oracle: orc_attend_f16 over decompressed pages.) */
 speckv_status_t speckv_ext_attend_int4(speckv_handle_t handle, uint32_t layer_begin, uint32_t n_layers,
                                        const void* d_q_f16, uint32_t g, uint32_t pos_begin, uint32_t pos_end,
                                        float sm_scale, float* d_out, float* d_lse, void* stream);

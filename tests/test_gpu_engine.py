@@ -732,10 +732,13 @@ def test_int4_fused_attention(eng, oracle):
     ref = np.einsum("hgt,thd->hgd", p, vfull)
     rel = np.linalg.norm(multi[0].cpu().numpy() - ref) / np.linalg.norm(ref)      # 4-bit KV under a peaky softmax: coarse
     assert rel <= 0.5, rel
-    # a range whose last tile would leave the layer's region, odd positions, wrong scheme -> INVAL
+    # a range whose last 32-position tile would leave the layer's region goes through the page table
     d_out = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
-    with pytest.raises(SpeckvError):
-        lib.attend_int4(h, 0, 1, d_q[0].data_ptr(), G, 30, 512, sm, d_out.data_ptr())
+    lib.attend_int4(h, 1, 1, d_q[1].data_ptr(), G, 30, 512, sm, d_out.data_ptr())
+    torch.cuda.synchronize()
+    want, _, mag = want_for(1, 30, 512, sm)
+    assert np.all(np.abs(d_out.cpu().numpy() - want) <= 2e-3 * mag + 1e-6)
+    # odd positions, wrong scheme -> INVAL
     with pytest.raises(SpeckvError):
         lib.attend_int4(h, 0, 1, d_q[0].data_ptr(), G, 1, 5, sm, d_out.data_ptr())
     with pytest.raises(SpeckvError):
@@ -780,15 +783,15 @@ def test_fused_attention_equals_attention_over_fetched_pages(eng):
 
 
 def test_fused_attention_row_counts_and_odd_geometry(eng):
-    """g = 1 and g = 16 query rows per kv head, and a token count that is no multiple of 32 (FP8 falls back to the
-    page-table form; the INT4 entry point, linear only, reports INVAL for a range whose last tile leaves the region).
+    """g = 1 and g = 16 query rows per kv head, and a token count that is no multiple of 32 (both formats fall back to
+    the page-table form of their kernels).
     Rows are independent of one another, so a row's result must not depend on how many rows travel with it."""
     torch = torch_mod()
     lib = eng.lib
     rng = np.random.default_rng(97)
     H, D = 8, 128
     sm = 1.0 / np.sqrt(D)
-    for scheme, fused, T in ((4, lib.attend_fp8, 256), (3, lib.attend_int4, 256), (4, lib.attend_fp8, 100)):
+    for scheme, fused, T in ((4, lib.attend_fp8, 256), (3, lib.attend_int4, 256), (4, lib.attend_fp8, 100), (3, lib.attend_int4, 100)):
         lib.set_compression_scheme(scheme)
         h = eng.allocate(T, 1, H, D, 2)
         n_pages = T * H * D * 2 * 2 // PAGE
@@ -816,11 +819,6 @@ def test_fused_attention_row_counts_and_odd_geometry(eng):
             torch.cuda.synchronize()
             assert torch.equal(part, full[:, :g, :]), (scheme, T, g)
         lib.free(h)
-    lib.set_compression_scheme(3)
-    h = eng.allocate(100, 1, H, D, 2)
-    with pytest.raises(SpeckvError):
-        lib.attend_int4(h, 0, 1, q16.data_ptr(), 16, 0, 100, sm, full.data_ptr())
-    lib.free(h)
 
 
 def test_per_layer_attention_calls_capture_into_a_hip_graph(eng):
@@ -994,7 +992,8 @@ def test_c_demo_runs_on_the_gpu():
     assert "L2 (prefetched) hits" in out.stdout
 
 
-def test_fp8_attention_over_a_striped_and_migrated_pool():
+@pytest.mark.parametrize("scheme", [4, 3])
+def test_attention_over_a_striped_and_migrated_pool(scheme):
     """The fused attention on records that are NOT in one run: pool striped over three pools (page % 3), then part of it
     migrated -- the page-table form must give what the linear form gives on a one-pool engine for the same data."""
     torch = torch_mod()
@@ -1010,7 +1009,7 @@ def test_fp8_attention_over_a_striped_and_migrated_pool():
         finally:
             os.environ.pop("SPECKV_POOL_DEVICES", None)
         try:
-            lib.set_compression_scheme(4)
+            lib.set_compression_scheme(scheme)
             h = lib.alloc(n_pages * PAGE)
             lib.set_layout(h, T, L, H, D, 2)
             lib.write(h, 0, x.ctypes.data, x.nbytes, False)
@@ -1018,7 +1017,7 @@ def test_fp8_attention_over_a_striped_and_migrated_pool():
                 lib.migrate(h, 10, 50, 1)
             out = torch.empty((L, H, G, D), dtype=torch.float32, device="cuda")
             lse = torch.empty((L, H, G), dtype=torch.float32, device="cuda")
-            lib.attend_fp8(h, 0, L, q.data_ptr(), G, 0, T, 0.1, out.data_ptr(), lse.data_ptr())
+            (lib.attend_fp8 if scheme == 4 else lib.attend_int4)(h, 0, L, q.data_ptr(), G, 0, T, 0.1, out.data_ptr(), lse.data_ptr())
             torch.cuda.synchronize()
             outs.append((out.cpu(), lse.cpu()))
             lib.free(h)
