@@ -889,6 +889,54 @@ def test_data_path_from_many_threads(eng, oracle):
     assert not errors, errors[:2]
 
 
+def test_fused_attention_random_cases_against_fetched_pages(eng):
+    """Thirty seeded random cases per format: token count, context length (even, anywhere in the layer), query rows,
+    split count, a random subset of pages never written and a few rewritten with other magnitudes -- the fused kernels
+    against torch attention over the rows the engine fetches + decompresses.  INT4: same dequantised values, so the
+    f16 weight rounding bound (2e-3 of sum p|v|) holds case by case; FP8: the query's e4m3 quantisation is the only
+    extra term, bounded loosely."""
+    torch = torch_mod()
+    lib = eng.lib
+    rng = np.random.default_rng(20261003)
+    H, D = 8, 128
+    for scheme, fused in ((3, lib.attend_int4), (4, lib.attend_fp8)):
+        for case in range(30):
+            lib.set_compression_scheme(scheme)
+            T = int(rng.choice([64, 96, 128, 200, 256, 384]))
+            L = int(rng.integers(1, 3))
+            G = int(rng.integers(1, 17))
+            h = eng.allocate(T, L, H, D, 2)
+            n_pages = T * L * H * D * 2 * 2 // PAGE
+            x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.1, 3.0, (n_pages, 1))).astype(np.float16)
+            skip = rng.random(n_pages) < 0.15                                  # pages never written
+            for pg in np.nonzero(~skip)[0]:
+                lib.write(h, int(pg) * PAGE, x[pg].ctypes.data, PAGE, False)
+            for pg in rng.choice(np.nonzero(~skip)[0], size=3):                # rewritten later
+                x[pg] = (rng.standard_normal(N) * 8.0).astype(np.float16)
+                lib.write(h, int(pg) * PAGE, x[pg].ctypes.data, PAGE, False)
+            layer = int(rng.integers(0, L))
+            pos_end = 2 * int(rng.integers(1, T // 2 + 1))
+            q = torch.from_numpy(rng.standard_normal((H, G, D)).astype(np.float16)).cuda()
+            out = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
+            os.environ["SPECKV_ATTEND_SPLITS"] = str(int(rng.integers(1, 6)))
+            try:
+                fused(h, layer, 1, q.data_ptr(), G, 0, pos_end, 0.09, out.data_ptr())
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("SPECKV_ATTEND_SPLITS", None)
+            k = eng.kv_rows(0, layer, 0, 0, pos_end).float().clone()
+            v = eng.kv_rows(0, layer, 1, 0, pos_end).float().clone()
+            p = torch.softmax(torch.einsum("hgd,thd->hgt", q.float(), k) * 0.09, dim=-1)
+            ref = torch.einsum("hgt,thd->hgd", p, v)
+            mag = torch.einsum("hgt,thd->hgd", p, v.abs())
+            err = (out - ref).abs()
+            if scheme == 3:
+                assert bool((err <= 2e-3 * mag + 1e-6).all()), (case, T, L, G, pos_end, float((err / (mag + 1e-9)).max()))
+            else:
+                assert float(err.max()) <= 0.12 * float(ref.abs().max()) + 1e-3, (case, T, L, G, pos_end)
+            lib.free(h)
+
+
 def test_migrate_records_between_pool_slabs(oracle):
     """speckv_ext_migrate: hipMemcpyPeerAsync of record runs + page-table re-point
     (one GPU here, so source and target pool are the same device; the copy path,
