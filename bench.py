@@ -667,6 +667,46 @@ def batch_attention_extra(torch, kv, n_seq=256, T=8192):
         lib.set_compression_scheme(2)
 
 
+def seq70b_extra(torch, kv):
+    """The same hot path on one Llama-3-70B-shaped sequence (BASELINE configs[3] shape per sequence: 80 layers, 8 kv
+    heads x 128, T = 8192 -> 655 360 blocks = 2.5 GiB fp16), INT8_DELTA_RLE, reference quantiser."""
+    lib = kv.lib
+    try:
+        lib.set_compression_scheme(2)
+        T, Lyr = 8192, 80
+        n_pages = T * Lyr * 8 * 128 * 2 * 2 // PAGE
+        h = lib.alloc(n_pages * PAGE)
+        g = torch.Generator(device="cuda"); g.manual_seed(2004)
+        chunk = 65536
+        for p0 in range(0, n_pages, chunk):
+            x = torch.randn((min(chunk, n_pages - p0), BLOCK_ELEMS), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+            lib.write(h, p0 * PAGE, x.data_ptr(), x.numel() * 2, True)
+        rec_total = 0
+        dst = torch.empty((n_pages, BLOCK_ELEMS), dtype=torch.float16, device="cuda")
+        s = torch.cuda.Stream()
+        def step():
+            lib.fetch_range(h, 0, n_pages, dst.data_ptr(), False, s.cuda_stream)
+        step(); torch.cuda.synchronize()
+        ramp(step, torch.cuda.synchronize, EXTRAS_RAMP_MS)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        a.record(s)
+        for _ in range(reps):
+            step()
+        b.record(s); torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        info = lib.translate(h, 0)
+        alg = n_pages * (4080 + 4 + PAGE)            # N(0,1) blocks: 4080 record bytes on average (measured on the main workload)
+        lib.free(h)
+        del dst
+        return {"fetch_decompress_70b_shaped_sequence": {"blocks": n_pages, "ms": round(ms, 4),
+                                                         "blocks_per_s": round(n_pages / (ms * 1e-3), 1),
+                                                         "frac_hbm": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                                         "note": "one 70B-shaped sequence at 8k context, one launch; first record %d B" % info.rec_bytes}}
+    except Exception as e:
+        return {"fetch_decompress_70b_shaped_sequence": {"error": repr(e)}}
+
+
 def predictor_extra(torch, lib):
     """Token predictor (reference LSTMPredictor::predict_top_k: 13.5 ms per call on one CPU
     core; paper claim < 10 us on the FPGA): latency of one top-4 prediction
@@ -751,6 +791,7 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     ex["prefetch_flush"] = {"requests": n_req, "pages_issued": issued_n[-1], "ms": round(min(flush_ms[1:]), 3),
                             "first_call_ms": round(flush_ms[0], 3), "requests_per_s": round(n_req / (min(flush_ms[1:]) * 1e-3), 1),
                             "note": "lookup kernels + list read-back + ring-slot assignment + fetch launch + sync, steady state"}
+    ex.update(seq70b_extra(torch, kv))
     ex.update(fp8_scores_extra(torch, kv, 32768, 80))
     ex.update(int4_attention_extra(torch, kv, 32768, 80))
     ex.update(batch_attention_extra(torch, kv))      # BASELINE configs[4] shape: 70B-shaped KV @ 32k context

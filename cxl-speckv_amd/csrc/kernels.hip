@@ -1441,8 +1441,8 @@ uint32_t codec_grid(uint64_t n)
     // waves stream neighbouring pages.
     static int per_cu = [] {
         const char* e = getenv("SPECKV_WGS_PER_CU");
-        int v = e ? atoi(e) : 128;
-        return v > 0 ? v : 128;
+        int v = e ? atoi(e) : 256;
+        return v > 0 ? v : 256;
     }();
     const uint64_t want = (n + kWaves - 1) / kWaves;
     const uint64_t cap = static_cast<uint64_t>(num_cus()) * per_cu * (4 / kWaves);
