@@ -937,6 +937,43 @@ def test_fused_attention_random_cases_against_fetched_pages(eng):
             lib.free(h)
 
 
+def test_fused_attention_argument_errors(eng):
+    """Status codes of the attention entry points for bad arguments (no launch, no crash): unknown handle -> GENERAL
+    (-1, as speckv_access), everything else -> INVAL (-4)."""
+    torch = torch_mod()
+    lib = eng.lib
+    lib.set_compression_scheme(4)
+    T, L, H, D, G = 64, 2, 8, 128, 8
+    h = eng.allocate(T, L, H, D, 2)
+    q = torch.zeros((L, H, G, D), dtype=torch.float16, device="cuda")
+    out = torch.zeros((L, H, G, D), dtype=torch.float32, device="cuda")
+    def status(fn, *a):
+        try:
+            fn(*a)
+            return 0
+        except SpeckvError as e:
+            return e.status
+    ok = (h, 0, 1, q.data_ptr(), G, 0, T, 0.1, out.data_ptr())
+    assert status(lib.attend_fp8, *ok) == 0
+    assert status(lib.attend_fp8, 999, *ok[1:]) == -1
+    for bad in ((h, 0, 0) + ok[3:],                      # no layers
+                (h, L, 1) + ok[3:],                      # layer out of range
+                (h, 1, 2) + ok[3:],                      # layer range past the end
+                ok[:3] + (0,) + ok[4:],                  # q NULL
+                ok[:4] + (0,) + ok[5:],                  # g = 0
+                ok[:4] + (17,) + ok[5:],                 # g > 16
+                ok[:5] + (4, 2) + ok[7:],                # pos_begin > pos_end
+                ok[:5] + (0, T + 2) + ok[7:],            # pos_end > num_tokens
+                ok[:8] + (0,)):                          # out NULL
+        assert status(lib.attend_fp8, *bad) == -4, bad
+    assert status(lib.attend_int4, *ok) == -4            # FP8 allocation through the INT4 entry point
+    assert status(lib.attend_fp8_batch, [], 0, q.data_ptr(), G, [], 0.1, out.data_ptr()) == 0
+    assert status(lib.attend_fp8_batch, [h], L, q.data_ptr(), G, [T], 0.1, out.data_ptr()) == -4
+    assert status(lib.attend_fp8_batch, [h], 0, q.data_ptr(), G, [T + 2], 0.1, out.data_ptr()) == -4
+    assert status(lib.attend_fp8_batch, [h, 12345], 0, q.data_ptr(), G, [T, T], 0.1, out.data_ptr()) == -1
+    assert status(lib.qk_scores_fp8, 999, 0, q.data_ptr(), G, 0, T, out.data_ptr()) == -1
+
+
 def test_migrate_records_between_pool_slabs(oracle):
     """speckv_ext_migrate: hipMemcpyPeerAsync of record runs + page-table re-point
     (one GPU here, so source and target pool are the same device; the copy path,
