@@ -4,9 +4,14 @@
 // process-global engine, one mutex, every entry point validates "initialised"
 // first and no C++ exception crosses the ABI.  Status codes per call are the
 // reference's (SURVEY.md sect. 8b "Error conventions").
+// the public headers are the export list: everything declared in them gets default visibility, the rest of the
+// library is built with -fvisibility=hidden
+#pragma GCC visibility push(default)
 #include "../../include/speckv.h"
 #include "../../include/speckv_ext.h"
+#pragma GCC visibility pop
 #include "engine.hpp"
+#include "placement.hpp"
 
 #include <cstdio>
 #include <memory>
@@ -399,18 +404,6 @@ double speckv_ext_layer_compression_ratio(uint32_t layer_id)
     return 3.2;
 }
 
-// not part of the public headers: exhaustive exactness check of the codec's fast divide
-speckv_status_t speckv_debug_divcheck(float den, unsigned long long* d_counters, void* stream)
-{
-    return speckv::launch_debug_divcheck(den, d_counters, static_cast<hipStream_t>(stream)) == hipSuccess ? SPECKV_OK : SPECKV_ERR_DRIVER;
-}
-
-// not part of the public headers: hardware self-test of the DPP scans
-speckv_status_t speckv_debug_wave_primitives(const uint32_t* d_in, uint32_t* d_out, void* stream)
-{
-    return speckv::launch_debug_dpp(d_in, d_out, static_cast<hipStream_t>(stream)) == hipSuccess ? SPECKV_OK : SPECKV_ERR_DRIVER;
-}
-
 double speckv_ext_codec_model_throughput_gbps(uint32_t num_engines, double clock_mhz, uint32_t data_width_bits)
 {   // cache_engine.cpp:291-296
     return (static_cast<double>(data_width_bits) / 8.0) * (clock_mhz / 1000.0) * static_cast<double>(num_engines);
@@ -430,6 +423,19 @@ uint64_t speckv_ext_rtl_prefetch_vaddr(uint32_t req_id, uint16_t layer, uint32_t
 uint64_t speckv_ext_atu_translate(uint64_t virtual_addr)
 {   // cache_engine.cpp:131-132
     return 0x4000000000ULL + (virtual_addr & 0xFFFFFFFFFFFFULL);
+}
+
+void speckv_ext_placement(uint64_t n_pages, uint32_t n_pool, uint64_t page, uint32_t* pool_index, uint64_t* record_index)
+{
+    (void)n_pages;
+    const speckv::Placement pl = speckv::place_page(page, n_pool);
+    if (pool_index) *pool_index = pl.pool;
+    if (record_index) *record_index = pl.record;
+}
+
+uint64_t speckv_ext_pool_shard_pages(uint64_t n_pages, uint32_t n_pool, uint32_t pool_index)
+{
+    return speckv::shard_pages(n_pages, n_pool, pool_index);
 }
 
 const char* speckv_ext_backend(void) { return "hip"; }

@@ -1,0 +1,164 @@
+// cxl-speckv_amd/csrc/codec_device.hpp -- wave-level primitives and the exact arithmetic of the codec kernels
+// (device code only; included by kernels.hip and by the test-only self-check kernels in tests/csrc/).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdint>
+
+#include "kernels.hpp"
+
+namespace speckv {
+namespace {
+
+// ------------------------------------------------------------------ DPP
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp(uint32_t old, uint32_t src)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(
+        static_cast<int>(old), static_cast<int>(src), CTRL, ROW_MASK, BANK_MASK, false));
+}
+// inclusive add-scan over the 64 lanes (identity 0 flows in at row edges)
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v)
+{
+    v += dpp<0x111>(0u, v);            // row_shr:1
+    v += dpp<0x112>(0u, v);            // row_shr:2
+    v += dpp<0x114>(0u, v);            // row_shr:4
+    v += dpp<0x118>(0u, v);            // row_shr:8
+    v += dpp<0x142, 0xA>(0u, v);       // row_bcast:15 -> rows 1,3
+    v += dpp<0x143, 0xC>(0u, v);       // row_bcast:31 -> rows 2,3
+    return v;
+}
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v)
+{
+    v = umax(v, dpp<0x111>(0u, v));
+    v = umax(v, dpp<0x112>(0u, v));
+    v = umax(v, dpp<0x114>(0u, v));
+    v = umax(v, dpp<0x118>(0u, v));
+    v = umax(v, dpp<0x142, 0xA>(0u, v));
+    v = umax(v, dpp<0x143, 0xC>(0u, v));
+    return v;
+}
+// lane i receives lane i-1's value, lane 0 receives `fill`.
+// Written as an explicit v_mov_b32_dpp: when hipcc folds a wave_shr:1 update_dpp
+// into the consuming VOP2 (v_subrev_u32_dpp ... wave_shr:1 bound_ctrl:1) the
+// result is wrong on gfx950 for some lanes (found by tests/test_gpu_codec.py,
+// kept covered by test_wave_primitives); the plain move form is reliable.
+// The two wait states a DPP read needs after the VALU write of its source are
+// inside the statement (hipcc adds none for asm).
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t fill)
+{
+    uint32_t r = fill;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0"
+                 : "+v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ uint32_t lane63(uint32_t v)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+// LDS traffic of one wave is in order in hardware; this only pins the compiler.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// head-table swizzle: a wave writes/reads dword p with p = 8*lane + k; XOR with
+// bits 5..9 spreads the 32 lanes of a group over 32 distinct LDS banks.
+__device__ __forceinline__ uint32_t swz(uint32_t p) { return p ^ ((p >> 5) & 31u); }
+
+// ------------------------------------------------------------ arithmetic
+// float(q)/127.0f, correctly rounded, without a divide: one Newton step on
+// q * fl(1/127) is exact for every int8 q (checked exhaustively in
+// tests/test_host_logic.py::test_div127_identity).
+__device__ __forceinline__ float div127(float fq)
+{
+    const float rcp = 0x1.020408p-7f;           // fl(1/127)
+    float r0 = fq * rcp;
+    float e = __builtin_fmaf(-127.0f, r0, fq);
+    return __builtin_fmaf(e, rcp, r0);
+}
+template <int MODE>
+__device__ __forceinline__ float dequant(int q, float scale)
+{
+    float fq = static_cast<float>(q);
+    if (MODE == kRefExact) return div127(fq) * scale;   // cache_engine.cpp:279-280
+    return fq * scale;
+}
+// x / s for many x and one s: r = 1/s (one correctly rounded divide per block),
+// q0 = x*r, e = fma(-q0, s, x) (exact residual), q = fma(e, r, q0).  For the operands
+// this codec sees (x any finite fp16 value, s = fl(m/127) or fl(m/448), m a positive
+// finite fp16 value) q equals the correctly rounded x/s bit for bit: checked
+// EXHAUSTIVELY on the device (2^16 x 31743 pairs per divisor family) by
+// tests/test_gpu_codec.py::test_fast_division_is_exact via k_debug_divcheck.
+__device__ __forceinline__ float div_by_scale(float x, float s, float r)
+{
+    const float q0 = x * r;
+    const float e = __builtin_fmaf(-q0, s, x);
+    return __builtin_fmaf(e, r, q0);
+}
+
+// cache_engine.cpp:190-192 on x86-64: cvttss2si + byte truncation
+template <int MODE>
+__device__ __forceinline__ uint32_t quantize(float x, float scale)
+{
+    if (MODE == kRefExact) {
+        float scaled = x / scale;
+        float r = roundf(scaled * 127.0f);
+        int i = (fabsf(r) < 2147483648.0f) ? static_cast<int>(r) : static_cast<int>(0x80000000u);
+        return static_cast<uint32_t>(i) & 0xFFu;
+    } else {
+        float r = roundf(x / scale);
+        if (!(r == r)) r = 0.0f;
+        r = fminf(fmaxf(r, -127.0f), 127.0f);
+        return static_cast<uint32_t>(static_cast<int>(r)) & 0xFFu;
+    }
+}
+// The reference rounds the fp32 product to fp32 first and the result to fp16
+// second.  Without the empty asm hipcc selects v_fma_mixlo_f16 for
+// "(half)(x * scale)", which rounds the exact product once and differs from the
+// reference in ~1e-5 of the elements (caught by test_many_random_blocks).
+// the same byte as quantize<MODE> for a finite x of a finite block: the divide goes
+// through the block's reciprocal (div_by_scale) and the out-of-range test is not needed
+// round-half-away-from-zero to int for the values this codec rounds: truncate(y + copysign(0.5, y)).  In general that
+// differs from roundf (y + 0.5 can round up across an integer), but not for any y the codec forms from a finite block:
+// checked EXHAUSTIVELY on the device next to the divide (k_debug_divcheck, third counter: every fp16 x against every
+// scale, y = x/s*127, y = x/s and the INT4 y = x/s16).  3 VALU (bfi, add, cvt) instead of the 7 of roundf + cvt.
+__device__ __forceinline__ int round_to_int(float y)
+{
+    return static_cast<int>(y + __builtin_copysignf(0.5f, y));
+}
+template <int MODE>
+__device__ __forceinline__ uint32_t quantize_finite(float x, float scale, float rcp)
+{
+    const float scaled = div_by_scale(x, scale, rcp);
+    if (MODE == kRefExact) {
+        return static_cast<uint32_t>(round_to_int(scaled * 127.0f)) & 0xFFu;
+    } else {
+        const int r = min(max(round_to_int(scaled), -127), 127);
+        return static_cast<uint32_t>(r) & 0xFFu;
+    }
+}
+// max|x| of a block plus "every element is finite" in one pass: fmaxf ignores NaN like
+// the reference's '>' compare (cache_engine.cpp:176-180); x*0 accumulates a NaN for inf/NaN
+__device__ __forceinline__ void absmax_finite(float x, float& mx, float& nanacc)
+{
+    mx = __builtin_fmaxf(mx, fabsf(x));
+    nanacc = __builtin_fmaf(x, 0.0f, nanacc);
+}
+
+__device__ __forceinline__ uint32_t pack_half2(float a, float b)
+{
+    asm volatile("" : "+v"(a), "+v"(b));
+    _Float16 ha = static_cast<_Float16>(a), hb = static_cast<_Float16>(b);
+    uint16_t ua = __builtin_bit_cast(uint16_t, ha), ub = __builtin_bit_cast(uint16_t, hb);
+    return static_cast<uint32_t>(ua) | (static_cast<uint32_t>(ub) << 16);
+}
+__device__ __forceinline__ float half_bits_to_float(uint32_t h16)
+{
+    return static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(h16)));
+}
+} // namespace
+} // namespace speckv

@@ -2,7 +2,9 @@
 // coherence_manager_* C ABI (include/speckv_coherence.h; reference: coherence_c_api.cpp:33-209 over
 // CoherenceManager, coherence_manager.cpp).  Host bookkeeping only -- the reference's device operations are
 // stubs that always succeed (coherence_manager.cpp:398-434) and no call moves data.
+#pragma GCC visibility push(default)
 #include "../../include/speckv_coherence.h"
+#pragma GCC visibility pop
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <mutex>

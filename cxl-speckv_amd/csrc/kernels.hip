@@ -20,6 +20,7 @@
 // Scans are DPP (row_shr / row_bcast) inside the wave; there is no workgroup
 // barrier anywhere, so wavefronts never wait for each other.
 #include "kernels.hpp"
+#include "codec_device.hpp"
 
 #include <hip/hip_fp16.h>
 
@@ -36,155 +37,6 @@ constexpr int kThreads = 64 * kWaves;
 constexpr int kDecLdsWords = 528;         // per wave: 2 KiB byte table + 64 B of write-only dummies
 constexpr int kEncLdsHalves = 3200;        // per wave: 6400 B (see kEncWaveBytes)
 
-// ------------------------------------------------------------------ DPP
-template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
-__device__ __forceinline__ uint32_t dpp(uint32_t old, uint32_t src)
-{
-    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(
-        static_cast<int>(old), static_cast<int>(src), CTRL, ROW_MASK, BANK_MASK, false));
-}
-// inclusive add-scan over the 64 lanes (identity 0 flows in at row edges)
-__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v)
-{
-    v += dpp<0x111>(0u, v);            // row_shr:1
-    v += dpp<0x112>(0u, v);            // row_shr:2
-    v += dpp<0x114>(0u, v);            // row_shr:4
-    v += dpp<0x118>(0u, v);            // row_shr:8
-    v += dpp<0x142, 0xA>(0u, v);       // row_bcast:15 -> rows 1,3
-    v += dpp<0x143, 0xC>(0u, v);       // row_bcast:31 -> rows 2,3
-    return v;
-}
-__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
-__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
-__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v)
-{
-    v = umax(v, dpp<0x111>(0u, v));
-    v = umax(v, dpp<0x112>(0u, v));
-    v = umax(v, dpp<0x114>(0u, v));
-    v = umax(v, dpp<0x118>(0u, v));
-    v = umax(v, dpp<0x142, 0xA>(0u, v));
-    v = umax(v, dpp<0x143, 0xC>(0u, v));
-    return v;
-}
-// lane i receives lane i-1's value, lane 0 receives `fill`.
-// Written as an explicit v_mov_b32_dpp: when hipcc folds a wave_shr:1 update_dpp
-// into the consuming VOP2 (v_subrev_u32_dpp ... wave_shr:1 bound_ctrl:1) the
-// result is wrong on gfx950 for some lanes (found by tests/test_gpu_codec.py,
-// kept covered by test_wave_primitives); the plain move form is reliable.
-// The two wait states a DPP read needs after the VALU write of its source are
-// inside the statement (hipcc adds none for asm).
-__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t fill)
-{
-    uint32_t r = fill;
-    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0"
-                 : "+v"(r) : "v"(v));
-    return r;
-}
-__device__ __forceinline__ uint32_t lane63(uint32_t v)
-{
-    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
-}
-// LDS traffic of one wave is in order in hardware; this only pins the compiler.
-__device__ __forceinline__ void wave_lds_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-// head-table swizzle: a wave writes/reads dword p with p = 8*lane + k; XOR with
-// bits 5..9 spreads the 32 lanes of a group over 32 distinct LDS banks.
-__device__ __forceinline__ uint32_t swz(uint32_t p) { return p ^ ((p >> 5) & 31u); }
-
-// ------------------------------------------------------------ arithmetic
-// float(q)/127.0f, correctly rounded, without a divide: one Newton step on
-// q * fl(1/127) is exact for every int8 q (checked exhaustively in
-// tests/test_host_logic.py::test_div127_identity).
-__device__ __forceinline__ float div127(float fq)
-{
-    const float rcp = 0x1.020408p-7f;           // fl(1/127)
-    float r0 = fq * rcp;
-    float e = __builtin_fmaf(-127.0f, r0, fq);
-    return __builtin_fmaf(e, rcp, r0);
-}
-template <int MODE>
-__device__ __forceinline__ float dequant(int q, float scale)
-{
-    float fq = static_cast<float>(q);
-    if (MODE == kRefExact) return div127(fq) * scale;   // cache_engine.cpp:279-280
-    return fq * scale;
-}
-// x / s for many x and one s: r = 1/s (one correctly rounded divide per block),
-// q0 = x*r, e = fma(-q0, s, x) (exact residual), q = fma(e, r, q0).  For the operands
-// this codec sees (x any finite fp16 value, s = fl(m/127) or fl(m/448), m a positive
-// finite fp16 value) q equals the correctly rounded x/s bit for bit: checked
-// EXHAUSTIVELY on the device (2^16 x 31743 pairs per divisor family) by
-// tests/test_gpu_codec.py::test_fast_division_is_exact via k_debug_divcheck.
-__device__ __forceinline__ float div_by_scale(float x, float s, float r)
-{
-    const float q0 = x * r;
-    const float e = __builtin_fmaf(-q0, s, x);
-    return __builtin_fmaf(e, r, q0);
-}
-
-// cache_engine.cpp:190-192 on x86-64: cvttss2si + byte truncation
-template <int MODE>
-__device__ __forceinline__ uint32_t quantize(float x, float scale)
-{
-    if (MODE == kRefExact) {
-        float scaled = x / scale;
-        float r = roundf(scaled * 127.0f);
-        int i = (fabsf(r) < 2147483648.0f) ? static_cast<int>(r) : static_cast<int>(0x80000000u);
-        return static_cast<uint32_t>(i) & 0xFFu;
-    } else {
-        float r = roundf(x / scale);
-        if (!(r == r)) r = 0.0f;
-        r = fminf(fmaxf(r, -127.0f), 127.0f);
-        return static_cast<uint32_t>(static_cast<int>(r)) & 0xFFu;
-    }
-}
-// The reference rounds the fp32 product to fp32 first and the result to fp16
-// second.  Without the empty asm hipcc selects v_fma_mixlo_f16 for
-// "(half)(x * scale)", which rounds the exact product once and differs from the
-// reference in ~1e-5 of the elements (caught by test_many_random_blocks).
-// the same byte as quantize<MODE> for a finite x of a finite block: the divide goes
-// through the block's reciprocal (div_by_scale) and the out-of-range test is not needed
-// round-half-away-from-zero to int for the values this codec rounds: truncate(y + copysign(0.5, y)).  In general that
-// differs from roundf (y + 0.5 can round up across an integer), but not for any y the codec forms from a finite block:
-// checked EXHAUSTIVELY on the device next to the divide (k_debug_divcheck, third counter: every fp16 x against every
-// scale, y = x/s*127, y = x/s and the INT4 y = x/s16).  3 VALU (bfi, add, cvt) instead of the 7 of roundf + cvt.
-__device__ __forceinline__ int round_to_int(float y)
-{
-    return static_cast<int>(y + __builtin_copysignf(0.5f, y));
-}
-template <int MODE>
-__device__ __forceinline__ uint32_t quantize_finite(float x, float scale, float rcp)
-{
-    const float scaled = div_by_scale(x, scale, rcp);
-    if (MODE == kRefExact) {
-        return static_cast<uint32_t>(round_to_int(scaled * 127.0f)) & 0xFFu;
-    } else {
-        const int r = min(max(round_to_int(scaled), -127), 127);
-        return static_cast<uint32_t>(r) & 0xFFu;
-    }
-}
-// max|x| of a block plus "every element is finite" in one pass: fmaxf ignores NaN like
-// the reference's '>' compare (cache_engine.cpp:176-180); x*0 accumulates a NaN for inf/NaN
-__device__ __forceinline__ void absmax_finite(float x, float& mx, float& nanacc)
-{
-    mx = __builtin_fmaxf(mx, fabsf(x));
-    nanacc = __builtin_fmaf(x, 0.0f, nanacc);
-}
-
-__device__ __forceinline__ uint32_t pack_half2(float a, float b)
-{
-    asm volatile("" : "+v"(a), "+v"(b));
-    _Float16 ha = static_cast<_Float16>(a), hb = static_cast<_Float16>(b);
-    uint16_t ua = __builtin_bit_cast(uint16_t, ha), ub = __builtin_bit_cast(uint16_t, hb);
-    return static_cast<uint32_t>(ua) | (static_cast<uint32_t>(ub) << 16);
-}
-__device__ __forceinline__ float half_bits_to_float(uint32_t h16)
-{
-    return static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(h16)));
-}
 // Streaming accesses: every record byte is read once and every output byte
 // written once per launch, so both are marked non-temporal (measured on MI355X,
 // 131072 blocks: nt stores +4..8 %, nt loads+stores +6..10 % over plain accesses;
@@ -1241,39 +1093,6 @@ __global__ __launch_bounds__(128) void k_qk_scores_fp8(const PageEntry* __restri
     }
 }
 
-// exhaustive check of div_by_scale: thread = one divisor (fp16 magnitude bits mbits in
-// [1, 0x7BFF] divided by `den`), loop over all 65536 fp16 dividends; counts mismatches
-// against the IEEE divide, and (second counter) mismatches of the REF_EXACT byte
-// (roundf(x/s*127) & 0xFF) which is what the codec finally stores.
-__global__ void k_debug_divcheck(float den, unsigned long long* counters)
-{
-    const uint32_t mbits = blockIdx.x * blockDim.x + threadIdx.x + 1u;
-    if (mbits > 0x7BFFu) return;
-    const float m = half_bits_to_float(mbits);
-    // den > 0: s = m/den and |x| <= m (INT8 family: den 127, FP8: den 448).
-    // den == 0: INT4 family: s = m is itself an fp16 value (the stored group scale) and |x| <= 7.5 m.
-    const float s = den > 0.0f ? m / den : m;
-    const float lim = den > 0.0f ? m : 7.5f * m;
-    const float mul = den == 127.0f ? 127.0f : 1.0f;
-    const float r = 1.0f / s;
-    unsigned long long bad = 0, badq = 0, badr = 0;
-    for (uint32_t xb = 0; xb < 65536u; ++xb) {
-        if ((xb & 0x7C00u) == 0x7C00u) continue;                 // inf / nan dividends take the slow path
-        const float x = half_bits_to_float(xb);
-        if (fabsf(x) > lim) continue;                            // the block / group maximum bounds every |x|
-        const float a = x / s, b = div_by_scale(x, s, r);
-        bad += (__float_as_uint(a) != __float_as_uint(__builtin_copysignf(b, x))) ? 1ull : 0ull;
-        badq += (static_cast<int>(roundf(a * mul)) != static_cast<int>(roundf(b * mul))) ? 1ull : 0ull;
-        // candidate cheap rounding: truncate(y + copysign(0.5, y)) against roundf(y), for both products the codec rounds
-        const float y1 = b * mul, y2 = b;
-        badr += (static_cast<int>(roundf(y1)) != static_cast<int>(y1 + __builtin_copysignf(0.5f, y1))) ? 1ull : 0ull;
-        badr += (static_cast<int>(roundf(y2)) != static_cast<int>(y2 + __builtin_copysignf(0.5f, y2))) ? 1ull : 0ull;
-    }
-    if (bad) atomicAdd(&counters[0], bad);
-    if (badq) atomicAdd(&counters[1], badq);
-    if (badr) atomicAdd(&counters[2], badr);
-}
-
 // ===================================================================
 // token predictor  (src/prefetcher/lstm_predictor.cpp:40-188)
 // ===================================================================
@@ -1398,21 +1217,6 @@ __global__ __launch_bounds__(1024) void k_softmax_topk(const float* __restrict__
             out_conf[b * k + r] = expf(bv - mx) / sum;
         }
     }
-}
-
-// self-test of the wave primitives (tests/test_gpu_codec.py::test_wave_primitives)
-__global__ void k_debug_dpp(const uint32_t* in, uint32_t* out)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t v = in[threadIdx.x];
-    out[0 * 64 + lane] = wave_shr1(v, 0xABCDu);
-    out[1 * 64 + lane] = wave_incl_add(v);
-    out[2 * 64 + lane] = wave_incl_max(v);
-    out[3 * 64 + lane] = lane63(v);
-    // the dependent pattern used by the encoder: produce, shift, consume
-    const uint32_t w = (v * 2654435761u) >> 24;
-    const uint32_t prev = wave_shr1(w, 7u);
-    out[4 * 64 + lane] = (w - prev) & 0xFFu;
 }
 
 __global__ void k_retarget_entries(PageEntry* e, uint64_t n, uint64_t base, uint64_t stride)
@@ -1576,18 +1380,6 @@ hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb,
     const uint32_t waves = (vocab + 15u) / 16u;
     hipLaunchKernelGGL(k_lstm_logits, dim3((waves + 3u) / 4u), dim3(256), 0, s, d_hid, n, d_wout, vocab, d_logits);
     hipLaunchKernelGGL(k_softmax_topk, dim3(n), dim3(1024), 0, s, d_logits, vocab, k, d_tok, d_conf);
-    return hipGetLastError();
-}
-
-hipError_t launch_debug_divcheck(float den, unsigned long long* d_counters, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_debug_divcheck, dim3((0x7BFFu + 255u) / 256u), dim3(256), 0, s, den, d_counters);
-    return hipGetLastError();
-}
-
-hipError_t launch_debug_dpp(const uint32_t* d_in, uint32_t* d_out, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_debug_dpp, dim3(1), dim3(64), 0, s, d_in, d_out);
     return hipGetLastError();
 }
 

@@ -160,10 +160,4 @@ hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb,
                           uint32_t layers, uint32_t k, float* d_hid, float* d_logits, int32_t* d_tok, float* d_conf,
                           hipStream_t s);
 
-// exhaustive exactness check of the reciprocal-based divide (counters[0] quotient bits, [1] stored byte)
-hipError_t launch_debug_divcheck(float den, unsigned long long* d_counters, hipStream_t s);
-
-// wave-primitive self test: in[64] -> out[5*64]
-hipError_t launch_debug_dpp(const uint32_t* d_in, uint32_t* d_out, hipStream_t s);
-
 } // namespace speckv

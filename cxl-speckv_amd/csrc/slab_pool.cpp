@@ -1,10 +1,28 @@
 // cxl-speckv_amd/csrc/slab_pool.cpp -- see slab_pool.hpp
 #include "slab_pool.hpp"
 
+#include <cstdlib>
+
 namespace speckv {
 
 namespace {
-constexpr size_t kGranule = 4096;
+#ifdef SPECKV_SLAB_HOST_BACKING
+// test build only (tests/csrc/slab_pool_test.cpp, never libcxlspeckv.so): slabs come from the host heap so the
+// allocator's bookkeeping can be property-tested where there is no GPU
+hipError_t slab_malloc(void** p, size_t n) { *p = aligned_alloc(4096, (n + 4095) / 4096 * 4096); return *p ? hipSuccess : hipErrorOutOfMemory; }
+void slab_free(void* p) { ::free(p); }
+void use_device(int) {}
+int current_device() { return 0; }
+#else
+hipError_t slab_malloc(void** p, size_t n) { return hipMalloc(p, n); }
+void slab_free(void* p) { (void)hipFree(p); }
+void use_device(int d) { (void)hipSetDevice(d); }
+int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
+#endif
+// every record stride (4096, 2048, 1152) is a multiple of 128 B = one cache line: with this granule a run of k
+// records occupies exactly k*stride bytes, so any sub-run of records can be freed on its own (Engine::migrate)
+// without the freed range reaching into live neighbours
+constexpr size_t kGranule = 128;
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }
 
@@ -43,17 +61,16 @@ bool SlabPool::grow(size_t min_bytes)
         if (reserved_ + min_bytes > capacity_) return false;
         want = round_up(min_bytes, kGranule);
     }
-    int prev = 0;
-    (void)hipGetDevice(&prev);
-    if (hipSetDevice(device_) != hipSuccess) return false;
+    const int prev = current_device();
+    use_device(device_);
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, want);
+    hipError_t e = slab_malloc(&p, want);
     if (e != hipSuccess && want > min_bytes) {       // fall back to an exact-size slab
         (void)hipGetLastError();
         want = round_up(min_bytes, kGranule);
-        e = hipMalloc(&p, want);
+        e = slab_malloc(&p, want);
     }
-    (void)hipSetDevice(prev);
+    use_device(prev);
     if (e != hipSuccess || !p) { (void)hipGetLastError(); return false; }
     slabs_.push_back({static_cast<uint8_t*>(p), want});
     reserved_ += want;
@@ -84,7 +101,8 @@ void* SlabPool::alloc(size_t bytes)
 void* SlabPool::alloc_up_to(size_t want, size_t granule, size_t* got)
 {
     *got = 0;
-    if (want == 0 || granule == 0) return nullptr;
+    want = granule ? want / granule * granule : 0;      // whole granules only
+    if (want == 0) return nullptr;
     for (int attempt = 0; attempt < 2; ++attempt) {
         auto best = free_.end();
         size_t best_len = 0;
@@ -111,18 +129,17 @@ void SlabPool::free(void* p, size_t bytes)
 {
     if (!p || bytes == 0) return;
     bytes = round_up(bytes, kGranule);
-    used_ -= bytes;
+    used_ = used_ >= bytes ? used_ - bytes : 0;
     insert_free(reinterpret_cast<uintptr_t>(p), bytes);
 }
 
 void SlabPool::release()
 {
     if (slabs_.empty()) return;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
-    (void)hipSetDevice(device_);
-    for (auto& s : slabs_) (void)hipFree(s.base);
-    (void)hipSetDevice(prev);
+    const int prev = current_device();
+    use_device(device_);
+    for (auto& s : slabs_) slab_free(s.base);
+    use_device(prev);
     slabs_.clear();
     free_.clear();
     reserved_ = used_ = 0;

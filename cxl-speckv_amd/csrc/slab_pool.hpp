@@ -25,7 +25,8 @@ public:
     SlabPool(const SlabPool&) = delete;
     SlabPool& operator=(const SlabPool&) = delete;
 
-    // Contiguous run of `bytes` (rounded up to 4 KiB).  nullptr = out of memory.
+    // Contiguous run of `bytes` (rounded up to 128 B, one cache line).  nullptr = out of memory.
+    // free() takes any 128-B-granular sub-range of what alloc returned.
     void* alloc(size_t bytes);
     // Fragmented fallback: the largest free run that is a multiple of `granule`
     // and at most `want` bytes (grows by one slab when nothing is free).
@@ -38,6 +39,7 @@ public:
     size_t reserved_bytes() const { return reserved_; }
     size_t used_bytes() const { return used_; }
     size_t n_slabs() const { return slabs_.size(); }
+    size_t n_free_runs() const { return free_.size(); }
 
 private:
     struct Slab { uint8_t* base; size_t bytes; };

@@ -261,6 +261,42 @@ uint64_t speckv_ext_encode_virt_page(uint32_t req_id, uint16_t layer, uint16_t h
 uint64_t speckv_ext_rtl_prefetch_vaddr(uint32_t req_id, uint16_t layer, uint32_t pos);
 uint64_t speckv_ext_atu_translate(uint64_t virtual_addr);
 
+/* ---- legacy 3-tier address space (CXLMemoryManager, src/cxl_memory/cxl_memory_manager.cpp:9-322, and the
+ *      cxl_access policy of src/integration/memory_allocator.cpp:105-143) -------------
+ * Pure host arithmetic on logical addresses: bump allocation (virt from 0x100000000; phys L1 0x8000000000,
+ * L2 0x10000000000, L3 0x20000000000), translate, tier tags with LRU / hot (> 10 touches) promotion, page states,
+ * statistics -- call for call what the reference's class returns, including deallocate() forgetting only the first
+ * page.  No data moves here (none moves in the reference either); the HIP engine applies the same policy to real
+ * slots.  tier: 0 L1_GPU_LOCAL, 1 L2_PREFETCH, 2 L3_CXL_POOL; state: 0 INVALID, 1 SHARED, 2 EXCLUSIVE, 3 MODIFIED. */
+typedef struct speckv_ext_mm speckv_ext_mm_t;
+typedef struct {
+    uint64_t l1_hits, l1_misses, l2_hits, l2_misses, l3_accesses;
+    uint64_t migrations_l1_to_l3, migrations_l3_to_l1;
+    double   l1_hit_rate, l2_hit_rate;
+} speckv_ext_mm_stats_t;
+speckv_ext_mm_t* speckv_ext_mm_new(uint64_t l1_gb, uint64_t l2_gb, uint64_t l3_gb, uint64_t page_size);
+void     speckv_ext_mm_delete(speckv_ext_mm_t* m);
+uint64_t speckv_ext_mm_allocate(speckv_ext_mm_t* m, uint64_t size_bytes, uint32_t layer_id, int preferred_tier);
+void     speckv_ext_mm_deallocate(speckv_ext_mm_t* m, uint64_t virtual_addr);
+uint64_t speckv_ext_mm_translate(speckv_ext_mm_t* m, uint64_t virtual_addr);
+int      speckv_ext_mm_is_in_cache(speckv_ext_mm_t* m, uint64_t virtual_addr, int tier);
+int      speckv_ext_mm_promote_to_l1(speckv_ext_mm_t* m, uint64_t virtual_addr);
+int      speckv_ext_mm_demote_to_l3(speckv_ext_mm_t* m, uint64_t virtual_addr);
+void     speckv_ext_mm_invalidate_page(speckv_ext_mm_t* m, uint64_t virtual_addr);
+void     speckv_ext_mm_mark_modified(speckv_ext_mm_t* m, uint64_t virtual_addr);
+int      speckv_ext_mm_get_page_state(speckv_ext_mm_t* m, uint64_t virtual_addr);
+void     speckv_ext_mm_update_access_tracking(speckv_ext_mm_t* m, uint64_t virtual_addr);
+int      speckv_ext_mm_is_hot_page(speckv_ext_mm_t* m, uint64_t virtual_addr);
+void     speckv_ext_mm_get_statistics(speckv_ext_mm_t* m, speckv_ext_mm_stats_t* out);
+uint64_t speckv_ext_mm_cxl_access(speckv_ext_mm_t* m, uint64_t base_virtual_addr, uint64_t offset);
+
+/* ---- pool placement: the one rule the engine places records by, as pure functions -------------
+ * An allocation of n_pages striped over n_pool pool GPUs: page p lives on pool p % n_pool as record p / n_pool of
+ * that pool's run; pool k holds ceil((n_pages - k) / n_pool) records.  (n_pool == 0 is treated as 1.) */
+void     speckv_ext_placement(uint64_t n_pages, uint32_t n_pool, uint64_t page,
+                              uint32_t* pool_index, uint64_t* record_index);
+uint64_t speckv_ext_pool_shard_pages(uint64_t n_pages, uint32_t n_pool, uint32_t pool_index);
+
 /* hard-coded per-layer ratio table and analytic throughput of the reference
  * (cache_engine.cpp:25-33,142-148,286-296) */
 double speckv_ext_layer_compression_ratio(uint32_t layer_id);

@@ -17,6 +17,17 @@ def load_raw_lib():
     return lib
 
 
+def load_debug_lib():
+    """tests/_build/libspeckv_debug.so: TEST-ONLY self-check kernels over the product's device helpers
+    (tests/csrc/debug_kernels.hip); built on demand, never part of libcxlspeckv.so."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "csrc")])
+    pkg.load_library()                      # one HIP runtime in the process (torch's), mapped first
+    return C.CDLL(os.path.join(root, "tests", "_build", "libspeckv_debug.so"))
+
+
 def torch_mod():
     import torch
     assert torch.cuda.is_available(), "these tests need the MI355X"

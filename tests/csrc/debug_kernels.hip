@@ -1,0 +1,76 @@
+// tests/csrc/debug_kernels.hip -- TEST-ONLY self-check kernels (built into tests/_build/libspeckv_debug.so, never
+// into libcxlspeckv.so): exhaustive exactness check of the codec's reciprocal-based divide and cheap rounding, and a
+// hardware self-test of the wave primitives, run against the very same device functions the product kernels use
+// (cxl-speckv_amd/csrc/codec_device.hpp).
+#include "../../cxl-speckv_amd/csrc/codec_device.hpp"
+
+namespace speckv {
+namespace {
+
+// exhaustive check of div_by_scale: thread = one divisor (fp16 magnitude bits mbits in
+// [1, 0x7BFF] divided by `den`), loop over all 65536 fp16 dividends; counts mismatches
+// against the IEEE divide, and (second counter) mismatches of the REF_EXACT byte
+// (roundf(x/s*127) & 0xFF) which is what the codec finally stores.
+__global__ void k_debug_divcheck(float den, unsigned long long* counters)
+{
+    const uint32_t mbits = blockIdx.x * blockDim.x + threadIdx.x + 1u;
+    if (mbits > 0x7BFFu) return;
+    const float m = half_bits_to_float(mbits);
+    // den > 0: s = m/den and |x| <= m (INT8 family: den 127, FP8: den 448).
+    // den == 0: INT4 family: s = m is itself an fp16 value (the stored group scale) and |x| <= 7.5 m.
+    const float s = den > 0.0f ? m / den : m;
+    const float lim = den > 0.0f ? m : 7.5f * m;
+    const float mul = den == 127.0f ? 127.0f : 1.0f;
+    const float r = 1.0f / s;
+    unsigned long long bad = 0, badq = 0, badr = 0;
+    for (uint32_t xb = 0; xb < 65536u; ++xb) {
+        if ((xb & 0x7C00u) == 0x7C00u) continue;                 // inf / nan dividends take the slow path
+        const float x = half_bits_to_float(xb);
+        if (fabsf(x) > lim) continue;                            // the block / group maximum bounds every |x|
+        const float a = x / s, b = div_by_scale(x, s, r);
+        bad += (__float_as_uint(a) != __float_as_uint(__builtin_copysignf(b, x))) ? 1ull : 0ull;
+        badq += (static_cast<int>(roundf(a * mul)) != static_cast<int>(roundf(b * mul))) ? 1ull : 0ull;
+        // candidate cheap rounding: truncate(y + copysign(0.5, y)) against roundf(y), for both products the codec rounds
+        const float y1 = b * mul, y2 = b;
+        badr += (static_cast<int>(roundf(y1)) != static_cast<int>(y1 + __builtin_copysignf(0.5f, y1))) ? 1ull : 0ull;
+        badr += (static_cast<int>(roundf(y2)) != static_cast<int>(y2 + __builtin_copysignf(0.5f, y2))) ? 1ull : 0ull;
+    }
+    if (bad) atomicAdd(&counters[0], bad);
+    if (badq) atomicAdd(&counters[1], badq);
+    if (badr) atomicAdd(&counters[2], badr);
+}
+
+// self-test of the wave primitives (tests/test_gpu_codec.py::test_wave_primitives)
+__global__ void k_debug_dpp(const uint32_t* in, uint32_t* out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t v = in[threadIdx.x];
+    out[0 * 64 + lane] = wave_shr1(v, 0xABCDu);
+    out[1 * 64 + lane] = wave_incl_add(v);
+    out[2 * 64 + lane] = wave_incl_max(v);
+    out[3 * 64 + lane] = lane63(v);
+    // the dependent pattern used by the encoder: produce, shift, consume
+    const uint32_t w = (v * 2654435761u) >> 24;
+    const uint32_t prev = wave_shr1(w, 7u);
+    out[4 * 64 + lane] = (w - prev) & 0xFFu;
+}
+
+
+} // namespace
+} // namespace speckv
+
+extern "C" {
+
+int speckv_debug_divcheck(float den, unsigned long long* d_counters, void* stream)
+{
+    hipLaunchKernelGGL(speckv::k_debug_divcheck, dim3((0x7BFFu + 255u) / 256u), dim3(256), 0, static_cast<hipStream_t>(stream), den, d_counters);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int speckv_debug_wave_primitives(const uint32_t* d_in, uint32_t* d_out, void* stream)
+{
+    hipLaunchKernelGGL(speckv::k_debug_dpp, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), d_in, d_out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}

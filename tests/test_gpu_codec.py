@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from tests._gpu import N, assert_same_float_bits, gpu_compress, gpu_decompress, load_raw_lib
+from tests._gpu import N, assert_same_float_bits, gpu_compress, gpu_decompress, load_debug_lib, load_raw_lib
 
 pytestmark = pytest.mark.gpu
 
@@ -290,7 +290,7 @@ def test_full_size_roundtrip_properties(lib):
                 assert int(sample[b, 1:l[b]:2].astype(np.int64).sum()) == N
 
 
-def test_fast_division_is_exact(lib):
+def test_fast_division_is_exact():
     """The compressor divides by the block scale through one reciprocal per block
     (kernels.hip: div_by_scale).  Exhaustive device check: every finite fp16
     dividend against every divisor the codec can form (m/127, m/448, and fp16 group
@@ -299,6 +299,7 @@ def test_fast_division_is_exact(lib):
     round_to_int)."""
     import ctypes as C
     import torch
+    lib = load_debug_lib()
     lib.speckv_debug_divcheck.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
     for den in (127.0, 448.0, 0.0):
         cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
@@ -307,10 +308,12 @@ def test_fast_division_is_exact(lib):
         assert cnt.tolist() == [0, 0, 0, 0], (den, cnt.tolist())
 
 
-def test_wave_primitives(lib):
+def test_wave_primitives():
     """DPP scans / shifts on the hardware (the folded wave_shr form once miscompiled)."""
     import ctypes as C
     import torch
+    lib = load_debug_lib()
+    lib.speckv_debug_wave_primitives.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     rng = np.random.default_rng(0)
     for trial in range(4):
         v = rng.integers(0, 1000, 64).astype(np.uint32) if trial else np.arange(64, dtype=np.uint32) + 100

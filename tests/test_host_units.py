@@ -1,0 +1,240 @@
+"""-m "not gpu": host-side units of the product library, no GPU involved.
+
+  * speckv_ext_mm_*  (SURVEY 8a rows A10-A14 in the PRODUCT): replay of the reference's memory-manager trace
+    (tests/golden/mm_trace.json, recorded from the reference's CXLMemoryManager) and random walks against the oracle;
+  * SlabPool bookkeeping (tests/csrc/slab_pool_test.cpp: the product's slab_pool.cpp over host-heap slabs):
+    sub-range frees at record granularity never reach into live neighbours (the round-1 migrate bug);
+  * speckv_ext_placement / speckv_ext_pool_shard_pages: the striping rule;
+  * the drop-in .so exports the C ABI and nothing else.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import cxl_speckv_amd as pkg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class MMStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("l1_hits", "l1_misses", "l2_hits", "l2_misses", "l3_accesses",
+                                          "migrations_l1_to_l3", "migrations_l3_to_l1")] + \
+               [("l1_hit_rate", C.c_double), ("l2_hit_rate", C.c_double)]
+
+
+MM_SIG = {
+    "new": (C.c_void_p, [C.c_uint64] * 4), "delete": (None, [C.c_void_p]),
+    "allocate": (C.c_uint64, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int]),
+    "deallocate": (None, [C.c_void_p, C.c_uint64]), "translate": (C.c_uint64, [C.c_void_p, C.c_uint64]),
+    "is_in_cache": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int]),
+    "promote_to_l1": (C.c_int, [C.c_void_p, C.c_uint64]), "demote_to_l3": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "invalidate_page": (None, [C.c_void_p, C.c_uint64]), "mark_modified": (None, [C.c_void_p, C.c_uint64]),
+    "get_page_state": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "update_access_tracking": (None, [C.c_void_p, C.c_uint64]), "is_hot_page": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "get_statistics": (None, [C.c_void_p, C.POINTER(MMStats)]),
+    "cxl_access": (C.c_uint64, [C.c_void_p, C.c_uint64, C.c_uint64]),
+}
+
+
+@pytest.fixture(scope="module")
+def product():
+    lib = pkg.load_library()
+    for name, (res, args) in MM_SIG.items():
+        fn = getattr(lib, "speckv_ext_mm_" + name)
+        fn.restype, fn.argtypes = res, args
+    lib.speckv_ext_placement.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    lib.speckv_ext_placement.restype = None
+    lib.speckv_ext_pool_shard_pages.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+    lib.speckv_ext_pool_shard_pages.restype = C.c_uint64
+    return lib
+
+
+def _stats(lib, mm, prefix):
+    s = MMStats()
+    getattr(lib, prefix + "get_statistics")(mm, C.byref(s))
+    return [s.l1_hits, s.l1_misses, s.l2_hits, s.l2_misses, s.l3_accesses, s.migrations_l1_to_l3, s.migrations_l3_to_l1], \
+           [s.l1_hit_rate, s.l2_hit_rate]
+
+
+def test_product_memory_manager_replays_the_reference_trace(product, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "mm_trace.json")))
+    mm = product.speckv_ext_mm_new(12, 3, 128, 4096)
+    for op, a, want in g["events"]:
+        got = getattr(product, "speckv_ext_mm_" + op)(mm, *a)
+        if want is not None:
+            assert got == want, (op, a, got, want)
+    u, d = _stats(product, mm, "speckv_ext_mm_")
+    assert u == g["stats_u"] and d == g["stats_d"]
+    product.speckv_ext_mm_delete(mm)
+    # SURVEY appendix A, F-mm
+    mm = product.speckv_ext_mm_new(12, 3, 128, 4096)
+    a0 = product.speckv_ext_mm_allocate(mm, 524288, 0, 2)
+    assert a0 == 0x100000000 and product.speckv_ext_mm_translate(mm, a0) == 0x20000000000
+    assert product.speckv_ext_mm_allocate(mm, 4096, 3, 0) == 0x100080000
+    assert product.speckv_ext_mm_translate(mm, 0x100080000) == 0x8000000000
+    a2 = product.speckv_ext_mm_allocate(mm, 5000, 4, 1)
+    assert a2 == 0x100081000 and product.speckv_ext_mm_translate(mm, a2) == 0x10000000000
+    assert product.speckv_ext_mm_translate(mm, a2 + 8191) == 0x10000000000 + 8191      # 5000 B -> 2 pages
+    assert product.speckv_ext_mm_translate(mm, a2 + 8192) == 0
+    assert product.speckv_ext_mm_translate(mm, a0 + 4096 * 3 + 17) == 0x20000003011
+    product.speckv_ext_mm_delete(mm)
+
+
+@pytest.mark.parametrize("l1_gb", [12, 0])
+def test_product_memory_manager_random_walk_equals_oracle(product, oracle, l1_gb):
+    """Same call sequence into the product and into the oracle (itself pinned to the reference by
+    tests/test_oracle_vs_ref.py): every return value and the statistics agree.  l1_gb = 0 makes every promotion
+    evict the LRU entry first (cxl_memory_manager.cpp:139-142)."""
+    O = oracle.lib
+    rng = np.random.default_rng(100 + l1_gb)
+    pm = product.speckv_ext_mm_new(l1_gb, 3, 128, 4096)
+    om = O.orc_mm_new(l1_gb, 3, 128, 4096)
+    bases = []
+    for step in range(4000):
+        r = rng.random()
+        if r < 0.05 or not bases:
+            size = int(rng.integers(1, 40000)); layer = int(rng.integers(0, 80)); tier = int(rng.integers(0, 3))
+            a, b = product.speckv_ext_mm_allocate(pm, size, layer, tier), O.orc_mm_allocate(om, size, layer, tier)
+            assert a == b
+            bases.append((a, size))
+            continue
+        base, size = bases[int(rng.integers(0, len(bases)))]
+        va = base + int(rng.integers(0, size + 6000))          # sometimes past the end / into the next allocation
+        if rng.random() < 0.05:
+            va = int(rng.integers(0, 1 << 34))
+        op = rng.choice(["translate", "is_in_cache", "promote_to_l1", "demote_to_l3", "update_access_tracking",
+                         "is_hot_page", "get_page_state", "mark_modified", "invalidate_page", "cxl_access", "deallocate"],
+                        p=[.15, .1, .15, .1, .2, .08, .05, .03, .03, .1, .01])
+        if op == "is_in_cache":
+            t = int(rng.integers(0, 3))
+            assert product.speckv_ext_mm_is_in_cache(pm, va, t) == O.orc_mm_is_in_cache(om, va, t), (step, hex(va))
+        elif op == "cxl_access":
+            off = va - base
+            if off < 0:
+                continue
+            assert product.speckv_ext_mm_cxl_access(pm, base, off) == O.orc_mm_cxl_access(om, base, off)
+        elif op == "deallocate":
+            product.speckv_ext_mm_deallocate(pm, base); O.orc_mm_deallocate(om, base)
+        else:
+            a = getattr(product, "speckv_ext_mm_" + op)(pm, va)
+            b = getattr(O, "orc_mm_" + op)(om, va)
+            if op not in ("update_access_tracking", "mark_modified", "invalidate_page"):
+                assert a == b, (step, op, hex(va), a, b)
+    from tests.test_oracle_golden import MMStats as OStats
+    s = OStats(); O.orc_mm_get_statistics(om, C.byref(s))
+    u, d = _stats(product, pm, "speckv_ext_mm_")
+    assert u == [s.l1_hits, s.l1_misses, s.l2_hits, s.l2_misses, s.l3_accesses, s.migrations_l1_to_l3, s.migrations_l3_to_l1]
+    assert d == [s.l1_hit_rate, s.l2_hit_rate]
+    product.speckv_ext_mm_delete(pm); O.orc_mm_delete(om)
+
+
+# ----------------------------------------------------------------------------- slab pool
+@pytest.fixture(scope="module")
+def slab():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "csrc")])
+    lib = C.CDLL(os.path.join(ROOT, "tests", "_build", "libslabpool_test.so"))
+    lib.slabtest_new.restype = C.c_void_p; lib.slabtest_new.argtypes = [C.c_size_t, C.c_size_t]
+    lib.slabtest_delete.argtypes = [C.c_void_p]
+    lib.slabtest_alloc.restype = C.c_void_p; lib.slabtest_alloc.argtypes = [C.c_void_p, C.c_size_t]
+    lib.slabtest_alloc_up_to.restype = C.c_void_p; lib.slabtest_alloc_up_to.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.slabtest_free.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    for n in ("used", "reserved", "free_runs"):
+        getattr(lib, "slabtest_" + n).restype = C.c_size_t; getattr(lib, "slabtest_" + n).argtypes = [C.c_void_p]
+    return lib
+
+
+@pytest.mark.parametrize("stride", [2048, 1152, 4096])
+def test_slab_subrange_free_never_reaches_live_records(slab, stride):
+    """freeing record 1 of a run of 64 and allocating again must not hand out bytes of record 2."""
+    p = slab.slabtest_new(1 << 20, 0)
+    base = slab.slabtest_alloc(p, 64 * stride)
+    assert base and slab.slabtest_used(p) == 64 * stride
+    slab.slabtest_free(p, base + stride, stride)
+    assert slab.slabtest_used(p) == 63 * stride
+    again = slab.slabtest_alloc(p, min(stride, 4096))
+    assert again == base + stride                                 # first fit: exactly the hole, nothing more
+    if stride < 4096:
+        nxt = slab.slabtest_alloc(p, 4096)
+        assert nxt >= base + 64 * stride                          # a bigger request cannot fit in the hole
+    slab.slabtest_delete(p)
+
+
+def test_slab_random_alloc_free_keeps_runs_disjoint(slab):
+    rng = np.random.default_rng(5)
+    p = slab.slabtest_new(256 << 10, 0)
+    live = []            # (addr, bytes)
+    for step in range(3000):
+        if live and rng.random() < 0.45:
+            i = int(rng.integers(0, len(live)))
+            addr, n = live.pop(i)
+            stride = 128 * int(rng.integers(1, 9))
+            if n > 2 * stride and rng.random() < 0.5:             # free a middle piece first, then the two rests
+                k = (n // stride) // 2 * stride
+                slab.slabtest_free(p, addr + k, stride)
+                slab.slabtest_free(p, addr, k)
+                if n - k - stride:
+                    slab.slabtest_free(p, addr + k + stride, n - k - stride)
+            else:
+                slab.slabtest_free(p, addr, n)
+        else:
+            n = 128 * int(rng.integers(1, 600))
+            if rng.random() < 0.2:
+                got = C.c_size_t()
+                want = max(n, 1152)
+                a = slab.slabtest_alloc_up_to(p, want, 1152, C.byref(got))
+                n = got.value
+                assert a and n and n % 1152 == 0 and n <= want
+            else:
+                a = slab.slabtest_alloc(p, n)
+                assert a
+            assert a % 128 == 0
+            for b, m in live:
+                assert a + n <= b or b + m <= a, "overlapping live runs"
+            live.append((a, n))
+        assert slab.slabtest_used(p) == sum(m for _, m in live)
+        assert slab.slabtest_reserved(p) >= slab.slabtest_used(p)
+    for a, n in live:
+        slab.slabtest_free(p, a, n)
+    assert slab.slabtest_used(p) == 0
+    assert slab.slabtest_free_runs(p) <= slab.slabtest_reserved(p) // (256 << 10) + 3   # everything coalesced again, slab by slab
+    slab.slabtest_delete(p)
+
+
+def test_slab_capacity_limit(slab):
+    p = slab.slabtest_new(64 << 10, 128 << 10)
+    a = slab.slabtest_alloc(p, 100 << 10)
+    assert a and not slab.slabtest_alloc(p, 64 << 10)             # would pass the cap
+    slab.slabtest_free(p, a, 100 << 10)
+    assert slab.slabtest_alloc(p, 64 << 10)
+    slab.slabtest_delete(p)
+
+
+# ----------------------------------------------------------------------------- placement
+def test_placement_rule(product):
+    for n_pages, d in ((131072, 1), (131072, 7), (655360, 7), (10, 3), (5, 8), (0, 4), (1000, 0)):
+        dd = d or 1
+        shard = [product.speckv_ext_pool_shard_pages(n_pages, d, k) for k in range(dd)]
+        assert sum(shard) == n_pages and max(shard) - min(shard) <= 1
+        assert product.speckv_ext_pool_shard_pages(n_pages, d, dd) == 0
+        seen = [[] for _ in range(dd)]
+        for p in list(range(min(n_pages, 50))) + ([n_pages - 1] if n_pages else []):
+            pool, rec = C.c_uint32(), C.c_uint64()
+            product.speckv_ext_placement(n_pages, d, p, C.byref(pool), C.byref(rec))
+            assert pool.value == p % dd and rec.value == p // dd and rec.value < shard[pool.value]
+            seen[pool.value].append(rec.value)
+        for s in seen:
+            assert s == sorted(s)                                 # consecutive pages of a pool are consecutive records
+
+
+# ----------------------------------------------------------------------------- symbol hygiene
+def test_library_exports_only_the_c_abi():
+    out = subprocess.check_output(["nm", "-D", "--defined-only", pkg.library_path()], text=True)
+    names = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    assert len(names) >= 60
+    stray = [n for n in names if not (n.startswith("speckv_") or n.startswith("coherence_manager_"))]
+    assert stray == [], stray
+    assert not [n for n in names if n.startswith("speckv_debug")], "self-check kernels belong to tests/_build/libspeckv_debug.so"
