@@ -34,7 +34,8 @@ speckv_status_t guarded(F&& f)
         return SPECKV_ERR_GENERAL;
     }
 }
-#define LOCK std::lock_guard<std::mutex> lock(g_mutex)
+// every entry hands its lock to the engine, which releases it only while it waits for the GPU (engine.cpp: wait_event)
+#define LOCK std::unique_lock<std::mutex> lock(g_mutex); if (g_engine) g_engine->enter(&lock)
 #define NEED_INIT if (!g_engine) return SPECKV_ERR_INVAL
 } // namespace
 
@@ -42,7 +43,7 @@ extern "C" {
 
 speckv_status_t speckv_init(const char* dev_path)
 {
-    LOCK;
+    std::unique_lock<std::mutex> lock(g_mutex);
     if (g_engine) return SPECKV_ERR_GENERAL;          // already initialised (speckv_c_api.cpp:16-18)
     return guarded([&] {
         int status = SPECKV_ERR_GENERAL;
@@ -53,7 +54,7 @@ speckv_status_t speckv_init(const char* dev_path)
 
 void speckv_finalize(void)
 {
-    LOCK;
+    std::unique_lock<std::mutex> lock(g_mutex);
     try { g_engine.reset(); } catch (...) {}
 }
 
@@ -142,7 +143,20 @@ speckv_status_t speckv_ext_fetch_range(speckv_handle_t handle, uint64_t first_pa
                                        void* d_dst, int out_f32, void* stream)
 {
     LOCK; NEED_INIT;
-    return guarded([&] { return g_engine->fetch_range(handle, first_page, n_pages, d_dst, out_f32 != 0, static_cast<hipStream_t>(stream)); });
+    return guarded([&] { return g_engine->fetch_range(handle, first_page, n_pages, d_dst, out_f32 != 0, static_cast<hipStream_t>(stream), 0); });
+}
+
+speckv_status_t speckv_ext_fetch_range_engine(speckv_handle_t handle, uint64_t first_page, uint64_t n_pages,
+                                              void* d_dst, int out_f32, void* stream, int engine)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->fetch_range(handle, first_page, n_pages, d_dst, out_f32 != 0, static_cast<hipStream_t>(stream), engine); });
+}
+
+speckv_status_t speckv_ext_bind_request(uint32_t req_id, speckv_handle_t handle, uint32_t local_req)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->bind_request(req_id, handle, local_req); });
 }
 
 speckv_status_t speckv_ext_fetch_list(speckv_handle_t handle, const uint32_t* d_pages, uint32_t n,
@@ -331,8 +345,8 @@ speckv_status_t speckv_ext_attend_fp8_batch(uint32_t n_seq, const speckv_handle_
 {
     LOCK; NEED_INIT;
     return guarded([&] {
-        return g_engine->attend_fp8_batch(n_seq, handles, layer, d_q_f16, g, pos_end, sm_scale, d_out, d_lse,
-                                          static_cast<hipStream_t>(stream));
+        return g_engine->attend_batch(SPECKV_COMP_FP8_E4M3, n_seq, handles, layer, d_q_f16, g, pos_end, sm_scale, d_out, d_lse,
+                                      static_cast<hipStream_t>(stream));
     });
 }
 

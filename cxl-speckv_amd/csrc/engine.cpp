@@ -1,5 +1,6 @@
 // cxl-speckv_amd/csrc/engine.cpp -- see engine.hpp
 #include "engine.hpp"
+#include "placement.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -25,6 +26,11 @@ bool g_verbose = [] { const char* e = getenv("SPECKV_LOG"); return e && *e && *e
             return SPECKV_ERR_DRIVER;                                              \
         }                                                                          \
     } while (0)
+#define RC_TRY(expr) do { int _rc = (expr); if (_rc != SPECKV_OK) return _rc; } while (0)
+
+constexpr uint32_t kResSlots = 64;          // flush result words in rotation
+constexpr uint32_t kMaxFlights = 16;        // flushes in flight before the oldest is waited for
+constexpr uint32_t kUpdCap = 1u << 16;      // mirror-update ring entries
 
 size_t env_mb(const char* name, size_t def_mb)
 {
@@ -69,6 +75,29 @@ int no_data_path(const char* what)
     return SPECKV_ERR_DRIVER;
 }
 
+bool is_capturing(hipStream_t s)
+{
+    if (!s) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+}
+
+std::vector<int> parse_int_list(const char* env)
+{
+    std::vector<int> out;
+    if (!env) return out;
+    std::string s(env);
+    size_t i = 0;
+    while (i < s.size()) {
+        size_t j = s.find(',', i);
+        if (j == std::string::npos) j = s.size();
+        if (j > i) out.push_back(atoi(s.substr(i, j - i).c_str()));
+        i = j + 1;
+    }
+    return out;
+}
+
 } // namespace
 
 // ------------------------------------------------------------------ depth
@@ -90,6 +119,7 @@ std::unique_ptr<Engine> Engine::open(const char* dev_path, int* status)
 {
     std::unique_ptr<Engine> e(new Engine());
     const std::string path = dev_path ? dev_path : "";
+    e->pool_devs_ = parse_int_list(getenv("SPECKV_POOL_DEVICES"));
     if (path == "/dev/null") {            // the reference's fake device
         e->null_ = true;
         *status = SPECKV_OK;
@@ -128,23 +158,12 @@ int Engine::init_hip(int device)
 
     // pool devices: default = the compute GPU itself; SPECKV_POOL_DEVICES="1,2,3"
     // places the pool in peer HBM reached over xGMI.
-    std::vector<int> devs;
-    if (const char* env = getenv("SPECKV_POOL_DEVICES")) {
-        std::string s(env);
-        size_t i = 0;
-        while (i < s.size()) {
-            size_t j = s.find(',', i);
-            if (j == std::string::npos) j = s.size();
-            if (j > i) devs.push_back(atoi(s.substr(i, j - i).c_str()));
-            i = j + 1;
-        }
-    }
-    if (devs.empty()) devs.push_back(device_);
+    if (pool_devs_.empty()) pool_devs_.push_back(device_);
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     const size_t slab = env_mb("SPECKV_SLAB_MB", 1024) << 20;
     const size_t cap = env_mb("SPECKV_POOL_CAP_MB", 0) << 20;
-    for (int d : devs) {
+    for (int d : pool_devs_) {
         if (d < 0 || d >= count) { SPECKV_ERR("pool device %d does not exist", d); return SPECKV_ERR_DRIVER; }
         if (d != device_) {
             int can = 0;
@@ -159,6 +178,7 @@ int Engine::init_hip(int device)
         }
         pools_.emplace_back(new SlabPool(d, slab, cap));
     }
+    if (pools_.size() > 255) { SPECKV_ERR("at most 255 pool devices"); return SPECKV_ERR_DRIVER; }
 
     // cache arena on the compute GPU (reference defaults 12 GB L1 / 3 GB L2,
     // cxl_memory_manager.h:42-44; ours are env-tunable and allocated up front)
@@ -168,11 +188,30 @@ int Engine::init_hip(int device)
     if (n_l2_ < 64) n_l2_ = 64;
     if (n_l1_ < 16) n_l1_ = 16;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&cache_base_), static_cast<size_t>(n_l2_ + n_l1_) * kPageSize));
-    owner_.assign(n_l2_ + n_l1_, Owner{nullptr, 0});
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_owner_), static_cast<size_t>(n_l2_) * sizeof(uint64_t)));
+    HIP_TRY(hipMemsetAsync(d_owner_, 0xFF, static_cast<size_t>(n_l2_) * sizeof(uint64_t), stream_));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hand_), 64));
+    HIP_TRY(hipMemsetAsync(d_hand_, 0, 64, stream_));
+    l1_owner_.assign(n_l1_, Owner{nullptr, 0});
     lru_prev_.assign(n_l2_ + n_l1_, UINT32_MAX);
     lru_next_.assign(n_l2_ + n_l1_, UINT32_MAX);
     l1_free_.reserve(n_l1_);
     for (uint32_t i = 0; i < n_l1_; ++i) l1_free_.push_back(n_l2_ + n_l1_ - 1 - i);
+
+    // device allocation table, flush result words, mirror-update ring
+    tab_cap_ = 4096;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tab_), tab_cap_ * sizeof(DevAlloc)));
+    HIP_TRY(hipMemsetAsync(d_tab_, 0, tab_cap_ * sizeof(DevAlloc), stream_));
+    row_owner_.assign(tab_cap_, nullptr);
+    for (uint32_t i = 0; i < tab_cap_; ++i) free_rows_.push_back(tab_cap_ - 1 - i);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&res_ring_), kResSlots * sizeof(FlushResult), hipHostMallocMapped | hipHostMallocPortable));
+    memset(res_ring_, 0, kResSlots * sizeof(FlushResult));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_res_ring_), kResSlots * sizeof(FlushResult)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&upd_ring_), kUpdCap * sizeof(MirrorUpdate), hipHostMallocMapped | hipHostMallocPortable));
+    upd_cap_ = kUpdCap;
+    HIP_TRY(hipEventCreateWithFlags(&upd_event_, hipEventDisableTiming));
+    HIP_TRY(hipStreamSynchronize(stream_));
+
     st_.cache_bytes_reserved = static_cast<uint64_t>(n_l2_ + n_l1_) * kPageSize;
     st_.n_pool_devices = static_cast<uint32_t>(pools_.size());
     if (const char* env = getenv("SPECKV_PREFETCH_BATCH")) flush_threshold_ = static_cast<uint32_t>(atoi(env));
@@ -184,19 +223,40 @@ Engine::~Engine()
 {
     if (null_) return;
     DeviceScope device_scope(device_);
-    if (stream_) (void)hipStreamSynchronize(stream_);
+    (void)hipDeviceSynchronize();
+    for (auto& f : flights_) { if (f.assigned) (void)hipEventDestroy(f.assigned); }
     for (auto& b : inflight_) (void)hipEventDestroy(b.ev);
     for (auto ev : event_pool_) (void)hipEventDestroy(ev);
+    for (auto& z : zombies_) { release_allocation(z.a.get()); if (z.engine_ev) (void)hipEventDestroy(z.engine_ev); }
+    zombies_.clear();
     for (auto& kv : allocs_) release_allocation(kv.second.get());
     allocs_.clear();
     if (d_emb_) (void)hipFree(d_emb_);
     if (d_wout_) (void)hipFree(d_wout_);
-    for (Scratch* s : {&s_pages_, &s_dst_, &s_req_, &s_out_, &s_tmp_, &s_stage_, &s_hid_, &s_logits_, &s_hist_, &s_pred_, &s_attn_, &s_attn_seq_})
+    for (Scratch* s : {&s_pages_, &s_dst_, &s_req_, &s_out_, &s_tmp_, &s_stage_, &s_flush_, &s_hid_, &s_logits_, &s_hist_, &s_pred_, &s_attn_, &s_attn_seq_})
         if (s->p) (void)hipFree(s->p);
+    for (void* p : retired_) (void)hipFree(p);
+    for (auto& l : lanes_) {
+        if (l.s) (void)hipStreamDestroy(l.s);
+        for (auto ev : l.copied) if (ev) (void)hipEventDestroy(ev);
+    }
+    for (int b = 0; b < 2; ++b) {
+        if (stage_[b]) (void)hipFree(stage_[b]);
+        if (stage_free_[b]) (void)hipEventDestroy(stage_free_[b]);
+    }
     if (d_count_) (void)hipFree(d_count_);
     if (d_zero_page_) (void)hipFree(d_zero_page_);
     if (seq_ring_.base) (void)hipHostFree(seq_ring_.base);
     for (auto ev : seq_ring_.ev) if (ev) (void)hipEventDestroy(ev);
+    if (req_stage_) (void)hipHostFree(req_stage_);
+    for (auto ev : req_stage_ev_) if (ev) (void)hipEventDestroy(ev);
+    if (res_ring_) (void)hipHostFree(res_ring_);
+    if (d_res_ring_) (void)hipFree(d_res_ring_);
+    if (upd_ring_) (void)hipHostFree(upd_ring_);
+    if (upd_event_) (void)hipEventDestroy(upd_event_);
+    if (d_tab_) (void)hipFree(d_tab_);
+    if (d_owner_) (void)hipFree(d_owner_);
+    if (d_hand_) (void)hipFree(d_hand_);
     if (cache_base_) (void)hipFree(cache_base_);
     pools_.clear();
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
@@ -209,10 +269,23 @@ Allocation* Engine::find(uint64_t h)
     return it == allocs_.end() ? nullptr : it->second.get();
 }
 
-void* Engine::scratch(Scratch& s, size_t bytes)
+// Scratch buffers grow on demand.  A buffer that a stream capture has used is never freed (the captured graph
+// keeps its address): growth then retires it instead, and growth DURING a capture is refused (nullptr) -- warm the
+// call up once outside the capture, as with any graph-captured library call.
+void* Engine::scratch(Scratch& s, size_t bytes, hipStream_t user)
 {
-    if (bytes <= s.cap) return s.p;
-    if (s.p) { (void)hipStreamSynchronize(stream_); (void)hipFree(s.p); s.p = nullptr; s.cap = 0; }
+    const bool capturing = is_capturing(user);
+    if (bytes <= s.cap) { if (capturing) s.in_graph = true; return s.p; }
+    if (capturing) {
+        SPECKV_ERR("a call inside a stream capture needs %zu bytes of scratch but %zu are reserved: run it once outside the capture first",
+                   bytes, s.cap);
+        return nullptr;
+    }
+    if (s.p) {
+        if (s.in_graph) retired_.push_back(s.p);
+        else { (void)hipDeviceSynchronize(); (void)hipFree(s.p); }
+        s.p = nullptr; s.cap = 0; s.in_graph = false;
+    }
     size_t want = std::max<size_t>(bytes, 1 << 16);
     want = (want + (want >> 1) + 4095) & ~size_t(4095);
     if (hipMalloc(&s.p, want) != hipSuccess) { (void)hipGetLastError(); s.p = nullptr; return nullptr; }
@@ -228,6 +301,53 @@ hipEvent_t Engine::get_event()
     return e;
 }
 
+// The ABI lock is released while the host only waits for the GPU: other threads may enter the engine meanwhile,
+// so callers re-validate whatever they looked up before the wait.
+int Engine::wait_event(hipEvent_t ev)
+{
+    if (!ev) return SPECKV_OK;
+    if (hipEventQuery(ev) == hipSuccess) return SPECKV_OK;
+    (void)hipGetLastError();
+    std::unique_lock<std::mutex>* mine = lk_;
+    if (mine && mine->owns_lock()) mine->unlock(); else mine = nullptr;
+    const hipError_t e = hipEventSynchronize(ev);
+    if (mine) { mine->lock(); lk_ = mine; (void)hipSetDevice(device_); }
+    if (e != hipSuccess) {
+        SPECKV_ERR("hipEventSynchronize failed: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return SPECKV_ERR_DRIVER;
+    }
+    return SPECKV_OK;
+}
+
+int Engine::wait_stream()
+{
+    hipEvent_t ev = get_event();
+    if (!ev) { HIP_TRY(hipStreamSynchronize(stream_)); return SPECKV_OK; }
+    HIP_TRY(hipEventRecord(ev, stream_));
+    const int rc = wait_event(ev);
+    put_event(ev);
+    return rc;
+}
+
+// --------------------------------------------------------- allocation table
+int Engine::publish_row(Allocation* a)
+{
+    DevAlloc r{};
+    r.entries = a->d_entries;
+    r.d_flags = a->d_flags;
+    r.d_slot = a->d_slot;
+    r.stamp = a->d_stamp;
+    void* dp = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dp, a->pinned, 0));
+    r.h_flags = static_cast<uint32_t*>(dp);
+    r.h_slot = r.h_flags + a->n_pages;
+    r.layout = a->has_layout ? a->layout : Layout{0, 0, 0, 0, 0, a->n_pages};
+    // 80 bytes from the stack: HIP stages pageable sources before it returns
+    HIP_TRY(hipMemcpyAsync(d_tab_ + a->row, &r, sizeof(r), hipMemcpyHostToDevice, stream_));
+    return SPECKV_OK;
+}
+
 // ------------------------------------------------------------ alloc/free
 int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
 {
@@ -237,54 +357,78 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
     a->n_pages = (bytes + kPageSize - 1) / kPageSize;
     a->scheme = scheme_;
     a->rec_stride = stride_for(scheme_);
-    a->flags.assign(a->n_pages, 0u);
-    if (!null_) {
-        a->slot.assign(a->n_pages, 0u);
+    if (null_) {
+        a->null_flags.assign(a->n_pages, 0u);
+        a->flags = a->null_flags.data();
+    } else {
         a->access_count.assign(a->n_pages, 0u);
         if (a->n_pages) {
             DeviceScope device_scope(device_);
+            drain_zombies(false);
             // placement: preferred_node picks one pool GPU (1-based; 0 = stripe over all)
             std::vector<int> use;
             if (hint && hint->preferred_node >= 1 && hint->preferred_node <= pools_.size())
                 use.push_back(static_cast<int>(hint->preferred_node) - 1);
             else
                 for (size_t i = 0; i < pools_.size(); ++i) use.push_back(static_cast<int>(i));
-            const uint64_t D = use.size();
+            const uint32_t D = static_cast<uint32_t>(use.size());
             bool ok = true;
             bool single_run = (D == 1);
+            bool regular = true;
             std::vector<PageEntry> host;
-            for (uint64_t k = 0; k < D && ok; ++k) {
-                const uint64_t np = (a->n_pages + D - 1 - k) / D;     // pages with page % D == k
-                if (np == 0) continue;
-                const size_t need = np * a->rec_stride;
-                void* base = pools_[use[k]]->alloc(need);
-                if (base) {
-                    a->extents.push_back({use[k], base, need, np});
-                    if (!single_run) {
-                        if (host.empty()) host.resize(a->n_pages);
-                        for (uint64_t j = 0; j < np; ++j)
-                            host[k + j * D] = PageEntry{reinterpret_cast<uint64_t>(base) + j * a->rec_stride, 0u, 1.0f};
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                ok = true; regular = true; single_run = (D == 1); host.clear();
+                for (uint32_t k = 0; k < D && ok; ++k) {
+                    const uint64_t np = shard_pages(a->n_pages, D, k);    // pages with page % D == k
+                    if (np == 0) { a->extents.push_back({use[k], nullptr, 0, 0}); continue; }
+                    const size_t need = np * a->rec_stride;
+                    void* base = pools_[use[k]]->alloc(need);
+                    if (base) {
+                        a->extents.push_back({use[k], base, need, np});
+                        if (!single_run) {
+                            if (host.empty()) host.resize(a->n_pages);
+                            for (uint64_t j = 0; j < np; ++j)
+                                host[k + j * D] = PageEntry{reinterpret_cast<uint64_t>(base) + j * a->rec_stride, 0u, 1.0f};
+                        }
+                        continue;
                     }
-                    continue;
+                    // fragmented pool: place the pages of this device in several runs
+                    single_run = false; regular = false;
+                    if (host.empty()) host.resize(a->n_pages);
+                    uint64_t placed = 0;
+                    while (ok && placed < np) {
+                        size_t got = 0;
+                        void* part = pools_[use[k]]->alloc_up_to((np - placed) * a->rec_stride, a->rec_stride, &got);
+                        if (!part) { ok = false; break; }
+                        const uint64_t cnt = got / a->rec_stride;
+                        a->extents.push_back({use[k], part, got, cnt});
+                        for (uint64_t j = 0; j < cnt; ++j)
+                            host[k + (placed + j) * D] = PageEntry{reinterpret_cast<uint64_t>(part) + j * a->rec_stride, 0u, 1.0f};
+                        placed += cnt;
+                    }
                 }
-                // fragmented pool: place the pages of this device in several runs
-                single_run = false;
-                if (host.empty()) host.resize(a->n_pages);
-                uint64_t placed = 0;
-                while (ok && placed < np) {
-                    size_t got = 0;
-                    void* part = pools_[use[k]]->alloc_up_to((np - placed) * a->rec_stride, a->rec_stride, &got);
-                    if (!part) { ok = false; break; }
-                    const uint64_t cnt = got / a->rec_stride;
-                    a->extents.push_back({use[k], part, got, cnt});
-                    for (uint64_t j = 0; j < cnt; ++j)
-                        host[k + (placed + j) * D] = PageEntry{reinterpret_cast<uint64_t>(part) + j * a->rec_stride, 0u, 1.0f};
-                    placed += cnt;
-                }
+                if (ok || attempt == 1 || zombies_.empty()) break;
+                // out of pool memory with freed allocations still waiting for their streams: wait for them, retry
+                for (auto& ex : a->extents) if (ex.base) pools_[ex.pool]->free(ex.base, ex.bytes);
+                a->extents.clear();
+                drain_zombies(true);
             }
+            uint32_t* dev3 = nullptr;
             if (ok) ok = hipMalloc(reinterpret_cast<void**>(&a->d_entries), a->n_pages * sizeof(PageEntry)) == hipSuccess;
-            if (ok) ok = hipMalloc(reinterpret_cast<void**>(&a->d_flags), a->n_pages * sizeof(uint32_t)) == hipSuccess;
-            if (ok) ok = hipMemsetAsync(a->d_flags, 0, a->n_pages * sizeof(uint32_t), stream_) == hipSuccess;
+            if (ok) ok = hipMalloc(reinterpret_cast<void**>(&dev3), 3 * a->n_pages * sizeof(uint32_t)) == hipSuccess;
+            if (ok) {
+                a->d_flags = dev3; a->d_slot = dev3 + a->n_pages; a->d_stamp = dev3 + 2 * a->n_pages;
+                ok = hipMemsetAsync(a->d_flags, 0, a->n_pages * sizeof(uint32_t), stream_) == hipSuccess &&
+                     hipMemsetAsync(a->d_slot, 0xFF, a->n_pages * sizeof(uint32_t), stream_) == hipSuccess &&
+                     hipMemsetAsync(a->d_stamp, 0, a->n_pages * sizeof(uint32_t), stream_) == hipSuccess;
+            }
+            if (ok) ok = hipHostMalloc(&a->pinned, 2 * a->n_pages * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocPortable) == hipSuccess;
+            if (ok) {
+                a->flags = static_cast<uint32_t*>(a->pinned);
+                a->slot = a->flags + a->n_pages;
+                memset(a->flags, 0, a->n_pages * sizeof(uint32_t));
+                memset(a->slot, 0xFF, a->n_pages * sizeof(uint32_t));
+            }
             if (ok) {
                 if (single_run) {
                     ok = launch_init_entries(a->d_entries, a->n_pages, reinterpret_cast<uint64_t>(a->extents[0].base),
@@ -301,10 +445,16 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
                     ok = hipMemcpy(a->d_entries, host.data(), host.size() * sizeof(PageEntry), hipMemcpyHostToDevice) == hipSuccess;
                 }
             }
+            a->regular = regular;
             a->pool_of_residue.assign(D, 0);
-            for (uint64_t k = 0; k < D; ++k) a->pool_of_residue[k] = use[k];
+            for (uint32_t k = 0; k < D; ++k) a->pool_of_residue[k] = use[k];
             a->page_pool.resize(a->n_pages);
             for (uint64_t i = 0; i < a->n_pages; ++i) a->page_pool[i] = static_cast<uint8_t>(use[i % D]);
+            if (ok) {
+                if (free_rows_.empty()) { SPECKV_ERR("speckv_alloc: more than %u live allocations", tab_cap_); ok = false; }
+                else { a->row = free_rows_.back(); free_rows_.pop_back(); row_owner_[a->row] = a.get(); }
+            }
+            if (ok) ok = publish_row(a.get()) == SPECKV_OK;
             if (ok) ok = hipStreamSynchronize(stream_) == hipSuccess;
             if (!ok) {
                 (void)hipGetLastError();
@@ -319,46 +469,109 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
     st_.total_allocations++;
     st_.current_allocated_bytes += bytes;
     st_.peak_allocated_bytes = std::max(st_.peak_allocated_bytes, st_.current_allocated_bytes);
+    Allocation* raw = a.get();
     allocs_[a->handle] = std::move(a);
+    if (raw->n_pages) layout_handle_ = raw->handle;       // the shim's single live allocation is the newest one
+    // SPECKV_LAYOUT=T,L,H,D,bpe: geometry for callers that only speak the reference's 8 functions (its
+    // allocate() sends none, vllm_speckv_backend.py:26-43); applied when the size matches
+    if (const char* env = getenv("SPECKV_LAYOUT")) {
+        const std::vector<int> g = parse_int_list(env);
+        if (g.size() == 5 && g[0] > 0 && g[1] > 0 && g[2] > 0 && g[3] > 0 && g[4] > 0 &&
+            2ull * g[0] * g[1] * g[2] * g[3] * g[4] == bytes)
+            (void)set_layout(raw->handle, g[0], g[1], g[2], g[3], g[4]);
+    }
     return SPECKV_OK;
 }
 
 void Engine::release_allocation(Allocation* a)
 {
     if (null_) return;
-    for (uint64_t p = 0; p < a->n_pages && !a->slot.empty(); ++p)
-        if (a->flags[p] & 3u) {
-            const uint32_t s = a->slot[p];
-            if (s >= n_l2_) { lru_unlink(s); l1_free_.push_back(s); }
-            owner_[s] = Owner{nullptr, 0};
-        }
-    pending_clear_.erase(a);
+    if (a->l1_pages)
+        for (uint32_t i = 0; i < n_l1_; ++i)
+            if (l1_owner_[i].a == a) {
+                const uint32_t s = n_l2_ + i;
+                lru_unlink(s);
+                l1_free_.push_back(s);
+                l1_owner_[i] = Owner{nullptr, 0};
+            }
+    a->l1_pages = 0;
+    if (a->row != kNoSlot) {              // ring owners may have named the row until now
+        row_owner_[a->row] = nullptr;
+        free_rows_.push_back(a->row);
+        a->row = kNoSlot;
+    }
     for (auto& ex : a->extents)
         if (ex.base) pools_[ex.pool]->free(ex.base, ex.bytes);
     a->extents.clear();
     if (a->d_entries) (void)hipFree(a->d_entries);
-    if (a->d_flags) (void)hipFree(a->d_flags);
+    if (a->d_flags) (void)hipFree(a->d_flags);            // flags, slots and stamps are one block
     if (a->d_scale_tab) { (void)hipFree(a->d_scale_tab); a->d_scale_tab = nullptr; }
+    if (a->pinned) { (void)hipHostFree(a->pinned); a->pinned = nullptr; }
     a->d_entries = nullptr;
-    a->d_flags = nullptr;
+    a->d_flags = a->d_slot = a->d_stamp = nullptr;
+    a->flags = a->slot = nullptr;
+}
+
+void Engine::note_use(Allocation* a, hipStream_t s)
+{
+    if (!s || s == stream_) return;
+    if (std::find(a->user_streams.begin(), a->user_streams.end(), s) == a->user_streams.end()) a->user_streams.push_back(s);
+}
+
+bool Engine::quiet(const Zombie& z)
+{
+    if (z.engine_ev && hipEventQuery(z.engine_ev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    for (hipStream_t s : z.a->user_streams) {
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipErrorNotReady) { (void)hipGetLastError(); return false; }
+        if (q != hipSuccess) (void)hipGetLastError();       // a stream the caller destroyed has nothing queued
+    }
+    return true;
+}
+
+void Engine::drain_zombies(bool wait)
+{
+    for (size_t i = 0; i < zombies_.size();) {
+        Zombie& z = zombies_[i];
+        if (wait && !quiet(z)) {
+            if (z.engine_ev) (void)hipEventSynchronize(z.engine_ev);
+            for (hipStream_t s : z.a->user_streams) if (hipStreamSynchronize(s) != hipSuccess) (void)hipGetLastError();
+        }
+        if (wait || quiet(z)) {
+            release_allocation(z.a.get());
+            put_event(z.engine_ev);
+            zombies_[i] = std::move(zombies_.back());
+            zombies_.pop_back();
+        } else {
+            ++i;
+        }
+    }
 }
 
 int Engine::free(uint64_t handle)
 {   // speckv_allocator.cpp:40-52 : unknown handle is a silent no-op
     auto it = allocs_.find(handle);
     if (it == allocs_.end()) return SPECKV_OK;
-    if (!null_) {
-        DeviceScope device_scope(device_);
-        reap(true);
-        // asynchronous entry points (fetch_range / fetch_list / attend_* on a caller stream) may still be reading this
-        // allocation's records: wait for the whole device, as hipFree would, before the pool memory is recycled
-        (void)hipDeviceSynchronize();
-        release_allocation(it->second.get());
-    }
     st_.total_deallocations++;
     st_.current_allocated_bytes -= it->second->size_bytes;
     if (layout_handle_ == handle) layout_handle_ = 0;
+    for (auto b = bindings_.begin(); b != bindings_.end();)
+        b = b->second.handle == handle ? bindings_.erase(b) : std::next(b);
+    std::unique_ptr<Allocation> a = std::move(it->second);
     allocs_.erase(it);
+    if (null_ || a->n_pages == 0) return SPECKV_OK;
+    DeviceScope device_scope(device_);
+    // The table row is cleared in stream order (kernels already queued still see it); the memory itself goes back to
+    // the pool once the engine stream has passed this point and every caller stream that was handed work on the
+    // allocation has drained -- without stalling the device, and without blocking this call when they have not.
+    const DevAlloc empty{};
+    (void)hipMemcpyAsync(d_tab_ + a->row, &empty, sizeof(empty), hipMemcpyHostToDevice, stream_);
+    Zombie z{std::move(a), get_event()};
+    if (z.engine_ev) (void)hipEventRecord(z.engine_ev, stream_);
+    else (void)hipStreamSynchronize(stream_);
+    // the table row is recycled only when the allocation is really released
+    zombies_.push_back(std::move(z));
+    drain_zombies(false);
     return SPECKV_OK;
 }
 
@@ -380,21 +593,59 @@ void Engine::lru_push_mru(uint32_t s)
     if (lru_head_ == UINT32_MAX) lru_head_ = s;
 }
 
-void Engine::drop_slot(uint32_t s)
+void Engine::queue_update(Allocation* a, uint32_t page, uint32_t and_mask, uint32_t or_mask, uint32_t slot)
 {
-    Owner& o = owner_[s];
-    if (!o.a) return;
-    o.a->flags[o.page] &= ~3u;
-    pending_clear_[o.a].push_back(o.page);
-    o = Owner{nullptr, 0};
+    if (upd_pending_ == upd_cap_) (void)flush_mirror();
+    upd_ring_[upd_head_ % upd_cap_] = MirrorUpdate{a->row, page, and_mask, or_mask, slot, 0u};
+    ++upd_head_;
+    ++upd_pending_;
+}
+
+// Host-originated residency changes reach the device mirrors before any kernel that reads them.  The kernel reads
+// the pinned ring in place; the ring is not written again before that launch has finished (callers of queue_update
+// run after quiesce(), and a full ring waits here).
+int Engine::flush_mirror()
+{
+    if (upd_pending_ == 0) return SPECKV_OK;
+    void* dp = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dp, upd_ring_, 0));
+    const MirrorUpdate* d_ring = static_cast<const MirrorUpdate*>(dp);
+    uint32_t start = (upd_head_ - upd_pending_) % upd_cap_, left = upd_pending_;
+    while (left) {
+        const uint32_t seg = std::min(left, upd_cap_ - start);
+        HIP_TRY(launch_apply_updates(d_tab_, d_ring + start, seg, stream_));
+        start = (start + seg) % upd_cap_;
+        left -= seg;
+    }
+    HIP_TRY(hipEventRecord(upd_event_, stream_));
+    const bool was_full = upd_pending_ == upd_cap_;
+    upd_pending_ = 0;
+    if (was_full) RC_TRY(wait_event(upd_event_));
+    return SPECKV_OK;
+}
+
+// A page leaves the cache (host decision: invalidation by a write, demotion, LRU eviction, span re-fetch).
+// Only called with no fetch in flight (quiesce), so host and device mirrors cannot race on the page's words.
+void Engine::drop_page(Allocation* a, uint32_t page)
+{
+    const uint32_t f = a->flags[page];
+    if (!(f & 3u)) return;
+    const uint32_t s = a->slot[page];
+    if ((f & 1u) && s >= n_l2_) {
+        lru_unlink(s);
+        l1_free_.push_back(s);
+        l1_owner_[s - n_l2_] = Owner{nullptr, 0};
+        if (a->l1_pages) a->l1_pages--;
+    }
+    a->flags[page] = f & ~3u;
+    queue_update(a, page, ~3u, 0u, kKeepSlot);     // a ring slot keeps naming the page until it is reused: harmless
 }
 
 uint32_t Engine::take_l2_run(uint32_t n)
 {
-    // FIFO ring; a run never wraps so multi-page spans stay contiguous
-    uint32_t start = static_cast<uint32_t>(l2_hand_ % n_l2_);
+    // FIFO ring; a run never wraps so multi-page spans stay contiguous (k_flush_assign applies the same rule)
+    uint32_t start = l2_hand_ % n_l2_;
     if (start + n > n_l2_) start = 0;
-    for (uint32_t i = 0; i < n; ++i) drop_slot(start + i);
     l2_hand_ = start + n;
     return start;
 }
@@ -404,38 +655,97 @@ uint32_t Engine::take_l1_slot()
     if (!l1_free_.empty()) { uint32_t s = l1_free_.back(); l1_free_.pop_back(); return s; }
     // evict_l1_lru -> demote_to_l3 (cxl_memory_manager.cpp:285-293)
     const uint32_t victim = lru_head_;
-    lru_unlink(victim);
-    drop_slot(victim);
+    const Owner o = l1_owner_[victim - n_l2_];
+    if (o.a) drop_page(o.a, o.page); else { lru_unlink(victim); l1_free_.push_back(victim); }
     st_.migrations_l1_to_l3++;
-    return victim;
+    const uint32_t s = l1_free_.back();
+    l1_free_.pop_back();
+    return s;
 }
 
-void Engine::move_to_l1(Allocation* a, uint32_t page)
+int Engine::move_to_l1(Allocation* a, uint32_t page)
 {   // promote_to_l1 (cxl_memory_manager.cpp:130-163) for a page that sits in the L2 ring
     const uint32_t from = a->slot[page];
     const uint32_t to = take_l1_slot();
-    (void)hipMemcpyAsync(slot_ptr(to), slot_ptr(from), kPageSize, hipMemcpyDeviceToDevice, stream_);
-    owner_[from] = Owner{nullptr, 0};
-    owner_[to] = Owner{a, page};
+    HIP_TRY(hipMemcpyAsync(slot_ptr(to), slot_ptr(from), kPageSize, hipMemcpyDeviceToDevice, stream_));
+    l1_owner_[to - n_l2_] = Owner{a, page};
+    a->l1_pages++;
     a->slot[page] = to;
     a->flags[page] = (a->flags[page] & ~2u) | 1u;
+    queue_update(a, page, ~2u, 1u, to);
     lru_push_mru(to);
+    return SPECKV_OK;
 }
 
-void Engine::flush_mirror()
+void Engine::absorb(Flight& f)
 {
-    for (auto& kv : pending_clear_) {
-        auto& v = kv.second;
-        if (v.empty()) continue;
-        void* d = scratch(s_tmp_, v.size() * sizeof(uint32_t));
-        if (!d) continue;
-        (void)hipMemcpyAsync(d, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream_);
-        (void)launch_update_flags(kv.first->d_flags, static_cast<const uint32_t*>(d),
-                                  static_cast<uint32_t>(v.size()), ~3u, 0u, stream_);
-        (void)hipStreamSynchronize(stream_);     // scratch is reused by the next group
-        v.clear();
+    f.m = f.result->m;
+    f.base = f.result->base;
+    f.absorbed = true;
+    if (f.m) l2_hand_ = f.base + f.m;                  // the device applied take_l2_run's rule
+    st_.total_prefetches += f.m;
+    st_.dma_submitted += f.m;
+    st_.total_decompressions += f.m;
+    if (f.assigned) { put_event(f.assigned); f.assigned = nullptr; }
+}
+
+// Every flush's slot assignment is known to the host (waits for the small assign kernels only, not for the data).
+int Engine::settle()
+{
+    for (size_t i = 0; i < flights_.size(); ++i)
+        if (!flights_[i].absorbed) {
+            const hipEvent_t ev = flights_[i].assigned;
+            RC_TRY(wait_event(ev));                          // may release the ABI lock: look the flight up again
+            for (auto& f : flights_)
+                if (!f.absorbed && f.assigned == ev) absorb(f);
+            i = static_cast<size_t>(-1);
+        }
+    while (!flights_.empty() && flights_.front().absorbed) {
+        if (hipEventQuery(flights_.front().done) != hipSuccess) { (void)hipGetLastError(); break; }
+        put_event(flights_.front().done);
+        flights_.pop_front();
     }
-    pending_clear_.clear();
+    return SPECKV_OK;
+}
+
+// No fetch kernel is running or queued: the precondition of every host-side change of a page's residency words
+// (the fetch kernels update those words themselves, for the pages they bring in and for the ones they evict).
+int Engine::quiesce()
+{
+    RC_TRY(settle());
+    while (!flights_.empty() || ring_busy_ > 0) {
+        RC_TRY(wait_stream());
+        RC_TRY(settle());
+        if (ring_busy_ > 0 && flights_.empty()) break;       // another thread's synchronous fetch: its kernel has finished too
+    }
+    return SPECKV_OK;
+}
+
+// before a host-initiated ring operation: device mirrors current, ring hand current
+int Engine::prepare_ring_op()
+{
+    for (int spin = 0; spin < 8; ++spin) {
+        RC_TRY(flush_mirror());
+        RC_TRY(settle());
+        bool clean = upd_pending_ == 0;
+        for (auto& f : flights_) clean = clean && f.absorbed;
+        if (clean) break;
+    }
+    return SPECKV_OK;
+}
+
+// pages [p0, p1] that an in-flight flush is bringing in have landed
+int Engine::wait_landed(const Allocation* a, uint64_t p0, uint64_t p1)
+{
+    if (flights_.empty()) return SPECKV_OK;
+    std::vector<hipEvent_t> need;
+    for (const Flight& f : flights_) {
+        if (!f.absorbed || f.m == 0) continue;
+        for (uint64_t p = p0; p <= p1; ++p)
+            if ((a->flags[p] & 2u) && a->slot[p] >= f.base && a->slot[p] < f.base + f.m) { need.push_back(f.done); break; }
+    }
+    for (hipEvent_t ev : need) RC_TRY(wait_event(ev));
+    return need.empty() ? SPECKV_OK : settle();
 }
 
 void Engine::reap(bool wait_all)
@@ -444,57 +754,80 @@ void Engine::reap(bool wait_all)
         Batch& b = inflight_.front();
         hipError_t q = wait_all ? hipEventSynchronize(b.ev) : hipEventQuery(b.ev);
         if (q == hipErrorNotReady) { (void)hipGetLastError(); break; }
-        completed_unpolled_ += b.n;
-        st_.dma_completed += b.n;
+        const uint32_t n = b.n_from ? b.n_from->m : b.n;
+        completed_unpolled_ += n;
+        st_.dma_completed += n;
         event_pool_.push_back(b.ev);
         inflight_.pop_front();
     }
 }
 
-int Engine::fetch_into_slots(Allocation* a, const std::vector<uint32_t>& pages,
-                             const std::vector<uint32_t>& slots, bool wait)
+// Synchronous fetch of `pages` (in this order) into a fresh run of ring slots; *base_out = first slot.
+// The fetch kernel does the ring bookkeeping (eviction of the previous owners, slot / flag words on both sides).
+int Engine::fetch_into_ring(Allocation* a, const std::vector<uint32_t>& pages, uint32_t* base_out)
 {
     const uint32_t n = static_cast<uint32_t>(pages.size());
     if (n == 0) return SPECKV_OK;
-    flush_mirror();
-    bool run = true;                     // consecutive pages into consecutive slots: no descriptor upload
-    for (uint32_t i = 1; i < n && run; ++i) run = pages[i] == pages[0] + i && slots[i] == slots[0] + i;
+    if (n > n_l2_) return SPECKV_ERR_NOMEM;
+    RC_TRY(prepare_ring_op());
+    bool run = true;
+    for (uint32_t i = 1; i < n && run; ++i) run = pages[i] == pages[0] + i;
     CodecArgs c{};
     c.entries = a->d_entries;
     c.trusted = 1;                       // pool records only ever come from k_compress
     if (run) {
         c.first = pages[0];
-        c.data = slot_ptr(slots[0]);
-        c.data_stride = kPageSize;
     } else {
-        std::vector<uint64_t> dst(n);
-        for (uint32_t i = 0; i < n; ++i) dst[i] = reinterpret_cast<uint64_t>(slot_ptr(slots[i]));
         uint32_t* d_pages = static_cast<uint32_t*>(scratch(s_pages_, n * sizeof(uint32_t)));
-        uint64_t* d_dst = static_cast<uint64_t*>(scratch(s_dst_, n * sizeof(uint64_t)));
-        if (!d_pages || !d_dst) return SPECKV_ERR_NOMEM;
+        if (!d_pages) return SPECKV_ERR_NOMEM;
         HIP_TRY(hipMemcpyAsync(d_pages, pages.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
-        HIP_TRY(hipMemcpyAsync(d_dst, dst.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
         c.page_list = d_pages;
-        c.data_list = d_dst;
     }
+    const uint32_t base = take_l2_run(n);
     c.n = n;
-    c.flags = a->d_flags;
-    c.set_flags = 2u;
     c.scheme = a->scheme;
     c.quant_mode = quant_mode_;
+    c.tab = d_tab_;
+    c.alloc_idx = a->row;
+    c.ring_owner = d_owner_;
+    c.ring_base = cache_base_;
+    c.slot0 = base;
+    c.hand_ptr = d_hand_;
+    c.new_hand = l2_hand_;
     HIP_TRY(launch_decompress(c, stream_));
     st_.dma_submitted += n;
     st_.total_decompressions += n;
-    if (wait) {                          // sync_fetch_page: submit, then spin on completion
-        HIP_TRY(hipStreamSynchronize(stream_));
-        reap(true);
-        completed_unpolled_ += n;
-        st_.dma_completed += n;
-        return SPECKV_OK;
-    }
-    hipEvent_t ev = get_event();
-    if (ev) { HIP_TRY(hipEventRecord(ev, stream_)); inflight_.push_back({ev, n}); }
-    else { HIP_TRY(hipStreamSynchronize(stream_)); completed_unpolled_ += n; st_.dma_completed += n; }
+    const uint64_t handle = a->handle;
+    ++ring_busy_;
+    const int wrc = wait_stream();       // sync_fetch_page: submit, then spin on completion
+    --ring_busy_;
+    RC_TRY(wrc);
+    completed_unpolled_ += n;
+    st_.dma_completed += n;
+    if (find(handle) != a) return SPECKV_ERR_GENERAL;     // freed by another thread while we waited
+    *base_out = base;
+    return SPECKV_OK;
+}
+
+// Synchronous fetch of one page into a host-managed (L1) slot.
+int Engine::fetch_into_slot(Allocation* a, uint32_t page, uint32_t slot)
+{
+    RC_TRY(flush_mirror());
+    CodecArgs c{};
+    c.entries = a->d_entries;
+    c.trusted = 1;
+    c.first = page;
+    c.n = 1;
+    c.data = slot_ptr(slot);
+    c.data_stride = kPageSize;
+    c.scheme = a->scheme;
+    c.quant_mode = quant_mode_;
+    HIP_TRY(launch_decompress(c, stream_));
+    st_.dma_submitted += 1;
+    st_.total_decompressions += 1;
+    RC_TRY(wait_stream());
+    completed_unpolled_ += 1;
+    st_.dma_completed += 1;
     return SPECKV_OK;
 }
 
@@ -512,15 +845,25 @@ int Engine::access(uint64_t handle, uint64_t off, size_t len, void** out)
         *out = reinterpret_cast<void*>(0x4000000000ULL + (handle << 20) + (p0 << 12) + poff);
         return SPECKV_OK;
     }
+    if (!a->entry_bytes_seen && len && len <= kPageSize) a->entry_bytes_seen = static_cast<uint32_t>(len);
     uint64_t p1 = len ? (off + len - 1) / kPageSize : p0;
     if (p1 >= a->n_pages) p1 = a->n_pages - 1;
     if (p1 - p0 + 1 > n_l2_) return SPECKV_ERR_NOMEM;
     DeviceScope device_scope(device_);
-    int rc = SPECKV_OK;
-    // a multi-page span must come back contiguous
-    bool contiguous = true;
-    for (uint64_t p = p0; p <= p1; ++p)
-        if (!(a->flags[p] & 3u) || a->slot[p] != a->slot[p0] + (p - p0)) { contiguous = false; break; }
+    RC_TRY(settle());
+    auto resident_run = [&] {                                // a multi-page span must come back contiguous
+        for (uint64_t p = p0; p <= p1; ++p)
+            if (!(a->flags[p] & 3u) || a->slot[p] != a->slot[p0] + (p - p0)) return false;
+        return true;
+    };
+    bool contiguous = resident_run();
+    if (!contiguous && (!flights_.empty() || ring_busy_ > 0)) {
+        // a flush in flight may be bringing these very pages: let it land before deciding to fetch (and before the
+        // span's stale copies are dropped below)
+        RC_TRY(quiesce());
+        if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
+        contiguous = resident_run();
+    }
     std::vector<uint32_t> miss;
     for (uint64_t p = p0; p <= p1; ++p) {
         a->access_count[p]++;                                // update_access_tracking, cxl_memory_manager.cpp:223-245
@@ -530,35 +873,25 @@ int Engine::access(uint64_t handle, uint64_t off, size_t len, void** out)
         else { st_.l3_accesses++; st_.l2_misses++; }
         if (!contiguous || !(f & 3u)) miss.push_back(static_cast<uint32_t>(p));
     }
+    int rc = SPECKV_OK;
     if (!miss.empty()) {
-        if (p1 > p0) {                                       // refetch the whole span into one run
-            for (uint32_t p : miss)
-                if (a->flags[p] & 3u) {
-                    const uint32_t s = a->slot[p];
-                    if (s >= n_l2_) { lru_unlink(s); l1_free_.push_back(s); }
-                    drop_slot(s);
-                }
-        }
-        const uint32_t run = take_l2_run(static_cast<uint32_t>(miss.size()));
-        std::vector<uint32_t> slots(miss.size());
-        for (size_t i = 0; i < miss.size(); ++i) slots[i] = run + static_cast<uint32_t>(i);
-        rc = fetch_into_slots(a, miss, slots, true);         // sync_fetch_page: submit + spin on completion
-        if (rc == SPECKV_OK)
-            for (size_t i = 0; i < miss.size(); ++i) {
-                a->slot[miss[i]] = slots[i];
-                a->flags[miss[i]] |= 2u;                     // speckv_allocator.cpp:135
-                owner_[slots[i]] = Owner{a, miss[i]};
-            }
+        if (p1 > p0)                                         // refetch the whole span into one run
+            for (uint32_t p : miss) drop_page(a, p);
+        uint32_t base = 0;
+        rc = fetch_into_ring(a, miss, &base);                // sync_fetch_page: submit + spin on completion
+        if (rc != SPECKV_OK) return rc;
     } else if (p1 == p0 && (a->flags[p0] & 3u) == 2u && a->access_count[p0] > 10) {
         // L2 hit on a hot page -> promote (memory_allocator.cpp:127-134, is_hot_page: count > 10)
-        move_to_l1(a, static_cast<uint32_t>(p0));
+        RC_TRY(quiesce());
+        if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
+        if ((a->flags[p0] & 3u) == 2u) { RC_TRY(move_to_l1(a, static_cast<uint32_t>(p0))); RC_TRY(wait_stream()); }
+    } else {
+        RC_TRY(wait_landed(a, p0, p1));                      // a prefetched page may still be landing
     }
-    if (rc == SPECKV_OK && !inflight_.empty()) {             // a prefetched page may still be landing
-        HIP_TRY(hipStreamSynchronize(stream_));
-        reap(true);
-    }
-    if (rc == SPECKV_OK) *out = slot_ptr(a->slot[p0]) + poff;
-    return rc;
+    if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
+    if (!(a->flags[p0] & 3u)) return SPECKV_ERR_GENERAL;     // evicted again by a concurrent caller (cache far too small)
+    *out = slot_ptr(a->slot[p0]) + poff;
+    return SPECKV_OK;
 }
 
 int Engine::access_batch(uint64_t handle, const uint64_t* offs, uint32_t n, void** out)
@@ -576,7 +909,10 @@ int Engine::access_batch(uint64_t handle, const uint64_t* offs, uint32_t n, void
         return SPECKV_OK;
     }
     DeviceScope device_scope(device_);
-    ++epoch_;
+    // everything a flush is still bringing in has to land before the pointers are handed out
+    RC_TRY(quiesce());
+    if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
+    ++access_epoch_;
     if (a->stamp.size() != a->n_pages) a->stamp.assign(a->n_pages, 0u);
     std::vector<uint32_t> miss;
     for (uint32_t i = 0; i < n; ++i) {
@@ -584,23 +920,15 @@ int Engine::access_batch(uint64_t handle, const uint64_t* offs, uint32_t n, void
         a->access_count[p]++;
         const uint32_t f = a->flags[p];
         if (f & 1u) st_.l1_hits++; else if (f & 2u) st_.l2_hits++; else { st_.l3_accesses++; st_.l2_misses++; }
-        if (!(f & 3u) && a->stamp[p] != epoch_) { a->stamp[p] = epoch_; miss.push_back(p); }
+        if (!(f & 3u) && a->stamp[p] != access_epoch_) { a->stamp[p] = access_epoch_; miss.push_back(p); }
     }
     int rc = SPECKV_OK;
     if (miss.size() > n_l2_) rc = SPECKV_ERR_NOMEM;
     if (rc == SPECKV_OK && !miss.empty()) {
-        const uint32_t run = take_l2_run(static_cast<uint32_t>(miss.size()));
-        std::vector<uint32_t> slots(miss.size());
-        for (size_t i = 0; i < miss.size(); ++i) slots[i] = run + static_cast<uint32_t>(i);
-        rc = fetch_into_slots(a, miss, slots, true);
-        if (rc == SPECKV_OK)
-            for (size_t i = 0; i < miss.size(); ++i) {
-                a->slot[miss[i]] = slots[i];
-                a->flags[miss[i]] |= 2u;
-                owner_[slots[i]] = Owner{a, miss[i]};
-            }
+        uint32_t base = 0;
+        rc = fetch_into_ring(a, miss, &base);
+        if (rc == SPECKV_OK && (a = find(handle)) == nullptr) rc = SPECKV_ERR_GENERAL;
     }
-    if (rc == SPECKV_OK && !inflight_.empty()) { (void)hipStreamSynchronize(stream_); reap(true); }
     if (rc == SPECKV_OK)
         for (uint32_t i = 0; i < n; ++i) {
             const uint64_t p = offs[i] / kPageSize;
@@ -611,6 +939,14 @@ int Engine::access_batch(uint64_t handle, const uint64_t* offs, uint32_t n, void
 }
 
 // --------------------------------------------------------------- prefetch
+int Engine::bind_request(uint32_t req, uint64_t handle, uint32_t local_req)
+{
+    if (handle == 0) { bindings_.erase(req); return SPECKV_OK; }
+    if (!find(handle)) return SPECKV_ERR_GENERAL;
+    bindings_[req] = Binding{handle, local_req};
+    return SPECKV_OK;
+}
+
 int Engine::prefetch(uint32_t req, uint16_t layer, uint32_t pos, uint32_t k,
                      const int32_t* tokens, uint32_t hist)
 {
@@ -624,13 +960,17 @@ int Engine::prefetch(uint32_t req, uint16_t layer, uint32_t pos, uint32_t k,
         auto it = hist_.find(req);
         if (it == hist_.end() || it->second != h) { hist_[req] = h; hist_dirty_.push_back(req); }
     }
+    // Without a known geometry (a caller that speaks only the reference's 8 functions) the layer count is learnt
+    // from the calls themselves: the shim walks layers 0..L-1 per token (vllm_speckv_backend.py:116-118), so the
+    // step is complete when the layer index falls back; flush then, not after a fixed count.
+    Allocation* la = layout_handle_ ? find(layout_handle_) : nullptr;
+    const bool known = (la && la->has_layout) || !bindings_.empty();
+    if (!known && !queue_.empty() && layer <= queue_.back().layer) { uint32_t n = 0; (void)prefetch_flush(&n); }
+    max_layer_seen_ = std::max<uint32_t>(max_layer_seen_, layer);
     queue_.push_back({req, layer, pos, k ? k : adapt_.depth()});
     uint32_t thr = flush_threshold_;
-    if (thr == 0) {
-        Allocation* a = layout_handle_ ? find(layout_handle_) : nullptr;
-        thr = a && a->has_layout ? a->layout.num_layers : 32u;
-    }
-    if (queue_.size() >= thr) { uint32_t n = 0; (void)prefetch_flush(&n); }   // driver result ignored, as in the reference
+    if (thr == 0) thr = known ? (la && la->has_layout ? la->layout.num_layers : 32u) : 4096u;
+    if (queue_.size() >= thr) (void)prefetch_flush(nullptr);   // driver result ignored, as in the reference
     return SPECKV_OK;
 }
 
@@ -639,8 +979,36 @@ int Engine::prefetch_batch(uint32_t n, const uint32_t* req, const uint16_t* laye
 {
     if (null_) return SPECKV_OK;
     queue_.reserve(queue_.size() + n);
-    for (uint32_t i = 0; i < n; ++i) queue_.push_back({req[i], layer[i], pos[i], (k && k[i]) ? k[i] : adapt_.depth()});
+    for (uint32_t i = 0; i < n; ++i) {
+        max_layer_seen_ = std::max<uint32_t>(max_layer_seen_, layer[i]);
+        queue_.push_back({req[i], layer[i], pos[i], (k && k[i]) ? k[i] : adapt_.depth()});
+    }
     return SPECKV_OK;
+}
+
+// Geometry for callers that never sent one (the reference's allocate() sends none; its hardware derives addresses
+// itself, prefetch_core.v:92-98).  Prefetch is only a cache fill, so an assumed geometry can cost bandwidth but never
+// correctness: entry size from the first speckv_access (length_bytes = head_dim * bytes_per_element in the shim,
+// vllm_speckv_backend.py:57-64; 256 if none was seen), kv heads from SPECKV_KV_HEADS (8), layers from the calls.
+bool Engine::infer_layout(Allocation* a)
+{
+    if (!a || a->n_pages == 0) return false;
+    const uint64_t entry = a->entry_bytes_seen ? a->entry_bytes_seen : 256u;
+    const uint64_t H = std::max<uint64_t>(1, env_mb("SPECKV_KV_HEADS", 8));
+    const uint64_t L = static_cast<uint64_t>(max_layer_seen_) + 1;
+    const uint64_t denom = 2 * L * H * entry;
+    if (a->size_bytes == 0 || a->size_bytes % denom) return false;
+    const uint64_t T = a->size_bytes / denom;
+    const uint32_t bpe = (entry % 2 == 0) ? 2u : 1u;
+    if (set_layout(a->handle, static_cast<uint32_t>(T), static_cast<uint32_t>(L), static_cast<uint32_t>(H),
+                   static_cast<uint32_t>(entry / bpe), bpe) != SPECKV_OK)
+        return false;
+    a->layout_inferred = true;
+    SPECKV_ERR("speckv_prefetch: no geometry was given for handle %llu (speckv_ext_set_layout / SPECKV_LAYOUT); assuming "
+               "tokens=%llu layers=%llu kv_heads=%llu entry=%llu B from the calls seen so far",
+               static_cast<unsigned long long>(a->handle), static_cast<unsigned long long>(T),
+               static_cast<unsigned long long>(L), static_cast<unsigned long long>(H), static_cast<unsigned long long>(entry));
+    return true;
 }
 
 int Engine::prefetch_flush(uint32_t* n_issued)
@@ -648,76 +1016,158 @@ int Engine::prefetch_flush(uint32_t* n_issued)
     if (n_issued) *n_issued = 0;
     if (null_) return SPECKV_OK;
     if (queue_.empty()) return SPECKV_OK;
-    Allocation* a = layout_handle_ ? find(layout_handle_) : nullptr;
-    if (!a || !a->has_layout || a->n_pages == 0) {
-        // no geometry known: nothing can be addressed (the reference would have sent the
-        // request to the FPGA, whose ATU maps (req,layer,pos) itself)
-        queue_.clear();
-        return SPECKV_OK;
-    }
     DeviceScope device_scope(device_);
     static const bool timing = getenv("SPECKV_TIMING") != nullptr;
-    auto tnow = [] { return std::chrono::steady_clock::now(); };
-    auto t_a = tnow();
-    const uint32_t n = static_cast<uint32_t>(queue_.size());
-    std::vector<uint32_t> soa(4ull * n);
-    for (uint32_t i = 0; i < n; ++i) {
-        soa[i] = queue_[i].req; soa[n + i] = queue_[i].layer;
-        soa[2ull * n + i] = queue_[i].pos; soa[3ull * n + i] = queue_[i].k;
+    const auto t_a = std::chrono::steady_clock::now();
+    // resolve every request to (allocation row, request index inside it); group by scheme (one fetch kernel each)
+    Allocation* dflt = layout_handle_ ? find(layout_handle_) : nullptr;
+    if (dflt && !dflt->has_layout && bindings_.empty()) (void)infer_layout(dflt);
+    struct Group { std::vector<uint32_t> idx; uint32_t W = 0; };
+    std::unordered_map<int, Group> groups;
+    std::vector<uint32_t> rows(queue_.size(), kNoSlot), local(queue_.size(), 0);
+    uint64_t dropped = 0;
+    for (size_t i = 0; i < queue_.size(); ++i) {
+        Allocation* a = dflt;
+        uint32_t lr = queue_[i].req;
+        if (!bindings_.empty()) {
+            auto b = bindings_.find(queue_[i].req);
+            if (b != bindings_.end()) { a = find(b->second.handle); lr = b->second.local_req; }
+        }
+        if (!a || !a->has_layout || a->n_pages == 0 || a->row == kNoSlot) { ++dropped; continue; }
+        const Layout& L = a->layout;
+        const uint64_t per_req = 2ull * L.num_tokens * L.num_layers * L.num_heads * L.head_dim * L.bytes_per_element;
+        const uint64_t n_req = per_req ? (a->size_bytes + per_req - 1) / per_req : 0;
+        if (lr >= n_req || queue_[i].layer >= L.num_layers) { ++dropped; continue; }
+        rows[i] = a->row;
+        local[i] = lr;
+        Group& g = groups[a->scheme];
+        g.idx.push_back(static_cast<uint32_t>(i));
+        const uint64_t row_bytes = static_cast<uint64_t>(L.num_heads) * L.head_dim * L.bytes_per_element;
+        g.W = std::max<uint32_t>(g.W, static_cast<uint32_t>(row_bytes / kPageSize + 2));
     }
-    queue_.clear();
-    const uint64_t row = static_cast<uint64_t>(a->layout.num_heads) * a->layout.head_dim * a->layout.bytes_per_element;
-    const uint32_t cap = static_cast<uint32_t>(std::min<uint64_t>(n * 32ull * (row / kPageSize + 2), 1ull << 30));
-    uint32_t* d_req = static_cast<uint32_t*>(scratch(s_req_, soa.size() * sizeof(uint32_t)));
-    uint32_t* d_out = static_cast<uint32_t*>(scratch(s_out_, (static_cast<size_t>(cap) + 2ull * n + 4) * sizeof(uint32_t)));
-    if (!d_req || !d_out) return SPECKV_ERR_NOMEM;
-    uint32_t* d_scr = d_out + cap;
-    flush_mirror();
-    HIP_TRY(hipMemcpyAsync(d_req, soa.data(), soa.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
-    HIP_TRY(launch_prefetch_lookup(a->layout, n, d_req, d_req + n, d_req + 2ull * n, d_req + 3ull * n,
-                                   a->d_flags, d_out, cap, d_count_, d_scr, stream_));
-    uint32_t count = 0;
-    HIP_TRY(hipMemcpyAsync(&count, d_count_, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
-    auto t_b = tnow();
-    std::vector<uint32_t> cand(count);
-    if (count) HIP_TRY(hipMemcpy(cand.data(), d_out, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    auto t_c = tnow();
-    // host side: dedupe across requests, assign ring slots, submit one fetch batch
-    ++epoch_;
-    if (a->stamp.size() != a->n_pages) a->stamp.assign(a->n_pages, 0u);
-    std::vector<uint32_t> pages;
-    pages.reserve(count);
-    for (uint32_t p : cand)
-        if (p < a->n_pages && !(a->flags[p] & 3u) && a->stamp[p] != epoch_) { a->stamp[p] = epoch_; pages.push_back(p); }
-    if (pages.size() > n_l2_ / 2) pages.resize(n_l2_ / 2);   // never let one flush wipe the whole ring
-    auto t_d = tnow(), t_e = t_d, t_f = t_d;
-    int rc = SPECKV_OK;
-    if (!pages.empty()) {
-        const uint32_t m = static_cast<uint32_t>(pages.size());
-        const uint32_t run = take_l2_run(m);
-        std::vector<uint32_t> slots(m);
-        for (uint32_t i = 0; i < m; ++i) slots[i] = run + i;
-        t_e = tnow();
-        rc = fetch_into_slots(a, pages, slots, false);       // asynchronous: overlaps the caller's compute
-        t_f = tnow();
-        if (rc == SPECKV_OK) {
-            for (uint32_t i = 0; i < m; ++i) {
-                a->slot[pages[i]] = slots[i];
-                a->flags[pages[i]] |= 2u;
-                owner_[slots[i]] = Owner{a, pages[i]};
-            }
-            st_.total_prefetches += m;
-            if (n_issued) *n_issued = m;
+    if (dropped) {
+        st_.prefetch_dropped += dropped;
+        if (!warned_no_layout_) {
+            warned_no_layout_ = true;
+            SPECKV_ERR("speckv_prefetch: %llu request(s) could not be addressed (no geometry for the allocation, unknown request "
+                       "binding, or layer / request index out of range) and were dropped; see speckv_ext_set_layout, "
+                       "speckv_ext_bind_request, SPECKV_LAYOUT (reported once; counted in speckv_ext_stats.prefetch_dropped)",
+                       static_cast<unsigned long long>(dropped));
         }
     }
+    int rc = SPECKV_OK;
+    uint32_t issued_total = 0;
+    for (auto& kv : groups) {
+        Group& g = kv.second;
+        // at most 2^24 candidate words per pipeline run (dedupe key)
+        const uint32_t max_n = std::max<uint32_t>(1u, ((1u << 24) - 1u) / (32u * g.W));
+        for (size_t b = 0; b < g.idx.size() && rc == SPECKV_OK; b += max_n) {
+            const uint32_t n = static_cast<uint32_t>(std::min<size_t>(max_n, g.idx.size() - b));
+            std::vector<uint32_t> soa(5ull * n);
+            for (uint32_t j = 0; j < n; ++j) {
+                const uint32_t i = g.idx[b + j];
+                soa[j] = local[i]; soa[n + j] = queue_[i].layer; soa[2ull * n + j] = queue_[i].pos;
+                soa[3ull * n + j] = queue_[i].k; soa[4ull * n + j] = rows[i];
+            }
+            uint32_t m = 0;
+            rc = flush_group(kv.first, soa, n, g.W, n_issued ? &m : nullptr);
+            issued_total += m;
+        }
+    }
+    queue_.clear();
+    if (n_issued) *n_issued = issued_total;
     if (timing) {
-        auto us = [](auto x, auto y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
-        fprintf(stderr, "[speckv timing] flush n=%u: lookup+sync %.1f us, list d2h %.1f, dedupe %.1f, ring %.1f, submit %.1f, bookkeeping %.1f\n",
-                n, us(t_a, t_b), us(t_b, t_c), us(t_c, t_d), us(t_d, t_e), us(t_e, t_f), us(t_f, tnow()));
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_a).count();
+        fprintf(stderr, "[speckv timing] flush submit: %.1f us (host time; the GPU pipeline runs asynchronously)\n", us);
     }
     if (rc == SPECKV_OK) rc = run_predictor_for_dirty();
     return rc;
+}
+
+// One run of the device-side flush pipeline for requests of allocations that share a compression scheme:
+// upload the requests, candidates -> dedupe -> ring assignment -> compaction (kernels.hip), then ONE fetch launch
+// that reads its block count and first slot from device memory.  Nothing comes back to the host but 16 bytes
+// (FlushResult, written to pinned memory by the assign kernel), read when somebody needs them.
+int Engine::flush_group(int scheme, const std::vector<uint32_t>& soa, uint32_t n, uint32_t W, uint32_t* n_issued)
+{
+    if (flights_.size() >= kMaxFlights) { RC_TRY(settle()); if (flights_.size() >= kMaxFlights) { RC_TRY(wait_stream()); RC_TRY(settle()); } }
+    RC_TRY(flush_mirror());
+    if (++flush_epoch_ > 255u) {               // 8-bit epoch in the dedupe stamps: start over with clean stamps
+        flush_epoch_ = 1;
+        for (auto& kv : allocs_)
+            if (kv.second->d_stamp) HIP_TRY(hipMemsetAsync(kv.second->d_stamp, 0, kv.second->n_pages * sizeof(uint32_t), stream_));
+    }
+    const uint64_t words = static_cast<uint64_t>(n) * 32u * W;
+    const uint32_t n_w = static_cast<uint32_t>((words + 63u) >> 6);
+    const uint32_t max_take = static_cast<uint32_t>(std::min<uint64_t>(n_l2_ / 2, words));   // never let one flush wipe the whole ring
+    const size_t bytes = (5ull * n + words + 2ull * n_w + 8 + 2ull * max_take) * sizeof(uint32_t);
+    uint32_t* buf = static_cast<uint32_t*>(scratch(s_flush_, bytes));
+    if (!buf) return SPECKV_ERR_NOMEM;
+    // request upload through a pinned slot (4 in rotation, each guarded by an event): no stream sync
+    const size_t up = soa.size() * sizeof(uint32_t);
+    if (req_stage_bytes_ < up) {
+        if (req_stage_) { RC_TRY(wait_stream()); (void)hipHostFree(req_stage_); req_stage_ = nullptr; }
+        req_stage_bytes_ = std::max<size_t>(up * 2, 1 << 20);
+        HIP_TRY(hipHostMalloc(&req_stage_, req_stage_bytes_ * 4, hipHostMallocDefault));
+        for (auto& ev : req_stage_ev_)
+            if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const int slot = req_stage_next_;
+    req_stage_next_ = (slot + 1) & 3;
+    RC_TRY(wait_event(req_stage_ev_[slot]));
+    void* staged = static_cast<uint8_t*>(req_stage_) + static_cast<size_t>(slot) * req_stage_bytes_;
+    memcpy(staged, soa.data(), up);
+    HIP_TRY(hipMemcpyAsync(buf, staged, up, hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipEventRecord(req_stage_ev_[slot], stream_));
+
+    const uint32_t rs = res_next_++ % kResSlots;
+    void* dp = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dp, res_ring_, 0));
+    FlushArgs f{};
+    f.tab = d_tab_;
+    f.n = n;
+    f.W = W;
+    f.req = buf; f.layer = buf + n; f.pos = buf + 2ull * n; f.depth = buf + 3ull * n; f.row = buf + 4ull * n;
+    f.epoch = flush_epoch_;
+    f.cand = buf + 5ull * n;
+    f.wave_tot = f.cand + words;
+    f.final_page = f.wave_tot + 2ull * n_w + 8;
+    f.final_row = f.final_page + max_take;
+    f.max_take = max_take;
+    f.n_l2 = n_l2_;
+    f.hand = d_hand_;
+    f.result_dev = d_res_ring_ + rs;
+    f.result_host = static_cast<FlushResult*>(dp) + rs;
+    res_ring_[rs] = FlushResult{0, 0, 0, 0};
+    HIP_TRY(launch_flush_pipeline(f, stream_));
+    Flight fl;
+    fl.assigned = get_event();
+    fl.done = get_event();
+    fl.result = res_ring_ + rs;
+    if (!fl.assigned || !fl.done) return SPECKV_ERR_DRIVER;
+    HIP_TRY(hipEventRecord(fl.assigned, stream_));
+
+    CodecArgs c{};
+    c.trusted = 1;
+    c.tab = d_tab_;
+    c.alloc_list = f.final_row;
+    c.page_list = f.final_page;
+    c.n = max_take;
+    c.n_dev = &f.result_dev->m;
+    c.ring_owner = d_owner_;
+    c.ring_base = cache_base_;
+    c.slot0_dev = &f.result_dev->base;
+    c.scheme = scheme;
+    c.quant_mode = quant_mode_;
+    HIP_TRY(launch_decompress(c, stream_));
+    HIP_TRY(hipEventRecord(fl.done, stream_));
+    flights_.push_back(fl);
+    if (hipEvent_t ev = get_event()) { HIP_TRY(hipEventRecord(ev, stream_)); inflight_.push_back({ev, 0u, fl.result}); }
+    if (n_issued) {                       // the caller wants the page count now: wait for the assign kernel (not the data)
+        RC_TRY(settle());
+        *n_issued = fl.result->m;
+    }
+    return SPECKV_OK;
 }
 
 // ----------------------------------------------------------------- predictor
@@ -726,7 +1176,7 @@ int Engine::predictor_load(const float* emb, const float* wout, uint32_t vocab, 
     if (null_) return no_data_path("speckv_ext_predictor_load");
     if (!emb || !wout || vocab < 8) return SPECKV_ERR_INVAL;
     DeviceScope device_scope(device_);
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(hipDeviceSynchronize());
     if (d_emb_) { (void)hipFree(d_emb_); d_emb_ = nullptr; }
     if (d_wout_) { (void)hipFree(d_wout_); d_wout_ = nullptr; }
     const size_t eb = static_cast<size_t>(vocab) * 64 * sizeof(float), wb = static_cast<size_t>(vocab) * 128 * sizeof(float);
@@ -748,8 +1198,8 @@ int Engine::predict_batch(uint32_t n, const int32_t* d_hist, uint32_t k, int32_t
     if (n == 0) return SPECKV_OK;
     if (!d_hist || !d_tok || !d_conf || k == 0 || k > 8) return SPECKV_ERR_INVAL;
     DeviceScope device_scope(device_);
-    float* hid = static_cast<float*>(scratch(s_hid_, static_cast<size_t>(n) * 128 * sizeof(float)));
-    float* logits = static_cast<float*>(scratch(s_logits_, static_cast<size_t>(n) * vocab_ * sizeof(float)));
+    float* hid = static_cast<float*>(scratch(s_hid_, static_cast<size_t>(n) * 128 * sizeof(float), s));
+    float* logits = static_cast<float*>(scratch(s_logits_, static_cast<size_t>(n) * vocab_ * sizeof(float), s));
     if (!hid || !logits) return SPECKV_ERR_NOMEM;
     hipStream_t st = s ? s : stream_;
     HIP_TRY(launch_predict(n, d_hist, d_emb_, d_wout_, vocab_, 2, k, hid, logits, d_tok, d_conf, st));
@@ -779,7 +1229,6 @@ int Engine::run_predictor_for_dirty()
     std::vector<int32_t> tok(static_cast<size_t>(n) * k);
     HIP_TRY(hipMemcpyAsync(tok.data(), d_tok, tok.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
-    reap(true);
     for (uint32_t i = 0; i < n; ++i) pred_[hist_dirty_[i]].assign(tok.begin() + static_cast<size_t>(i) * k, tok.begin() + static_cast<size_t>(i + 1) * k);
     hist_dirty_.clear();
     return SPECKV_OK;
@@ -794,12 +1243,16 @@ int Engine::prefetch_lookup(uint64_t handle, uint32_t n, const uint32_t* d_req, 
     if (!a) return SPECKV_ERR_GENERAL;
     if (!a->has_layout) return SPECKV_ERR_INVAL;
     DeviceScope device_scope(device_);
-    flush_mirror();
-    uint32_t* scr = static_cast<uint32_t*>(scratch(s_tmp_, (2ull * n + 4) * sizeof(uint32_t)));
+    RC_TRY(quiesce());                     // the residency mirror the kernel filters with is final
+    if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
+    RC_TRY(flush_mirror());
+    uint32_t* scr = static_cast<uint32_t*>(scratch(s_tmp_, (2ull * n + 4) * sizeof(uint32_t), s));
     if (!scr) return SPECKV_ERR_NOMEM;
     hipStream_t st = s ? s : stream_;
+    if (s) RC_TRY(wait_stream());          // the mirror updates above ran on the engine stream
     HIP_TRY(launch_prefetch_lookup(a->layout, n, d_req, d_layer, d_pos, d_k, a->d_flags, d_out, cap, d_count, scr, st));
-    if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+    note_use(a, s);
+    if (!s) RC_TRY(wait_stream());
     return SPECKV_OK;
 }
 
@@ -852,16 +1305,19 @@ int Engine::set_layout(uint64_t handle, uint32_t T, uint32_t L, uint32_t H, uint
     if (!T || !L || !H || !D || !bpe) return SPECKV_ERR_INVAL;
     a->layout = Layout{T, L, H, D, bpe, a->n_pages};
     a->has_layout = true;
+    a->layout_inferred = false;
     layout_handle_ = handle;
+    if (null_ || a->n_pages == 0) return SPECKV_OK;
+    DeviceScope device_scope(device_);
+    RC_TRY(publish_row(a));
     // fused-attention scale table (FP8 records, 2 positions per page, regions aligned to 16-page tiles)
-    if (!null_ && a->scheme == SPECKV_COMP_FP8_E4M3 && a->n_pages && static_cast<uint64_t>(H) * D * bpe == 2048u && T % 32u == 0u) {
-        DeviceScope device_scope(device_);
+    if (a->scheme == SPECKV_COMP_FP8_E4M3 && static_cast<uint64_t>(H) * D * bpe == 2048u && T % 32u == 0u) {
         if (!a->d_scale_tab) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&a->d_scale_tab), a->n_pages * sizeof(float)));
         a->region_pages = T / 2u;
         HIP_TRY(launch_build_scale_tab(a->d_entries, a->n_pages, a->region_pages, a->d_scale_tab, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
     } else if (a->d_scale_tab) {
-        DeviceScope device_scope(device_);
+        HIP_TRY(hipDeviceSynchronize());
         (void)hipFree(a->d_scale_tab);
         a->d_scale_tab = nullptr;
         a->region_pages = 0;
@@ -880,21 +1336,26 @@ int Engine::translate(uint64_t handle, uint64_t off, speckv_ext_page_info_t* o)
     o->virt_page_id = (handle << 32) | (p << 12);                        // speckv_allocator.cpp:24
     o->phys_page_id = 0x4000000000ULL + (handle << 20) + (p << 12);      // speckv_allocator.cpp:25
     o->page_size = kPageSize;
-    o->flags = a->flags[p];
     o->scheme = static_cast<uint32_t>(a->scheme);
-    o->pool_device = -1;
     o->scale = 1.0f;
-    if (!null_) {
-        DeviceScope device_scope(device_);
-        PageEntry e{};
-        HIP_TRY(hipMemcpy(&e, a->d_entries + p, sizeof(e), hipMemcpyDeviceToHost));
-        o->pool_device = pools_[a->page_pool[p]]->device();
-        o->rec_bytes = e.rec_bytes;
-        o->scale = e.scale;
-        o->pool_addr = e.pool_addr;
-        o->cache_addr = (a->flags[p] & 3u) ? reinterpret_cast<uint64_t>(slot_ptr(a->slot[p])) : 0;
-        o->access_count = a->access_count[p];
+    if (null_) {
+        o->flags = a->flags[p];
+        // the pool GPU the page WOULD live on (placement rule only; nothing is stored on the fake device)
+        o->pool_device = pool_devs_.empty() ? -1 : pool_devs_[place_page(p, static_cast<uint32_t>(pool_devs_.size())).pool];
+        return SPECKV_OK;
     }
+    DeviceScope device_scope(device_);
+    RC_TRY(quiesce());                      // residency words are final (a flush in flight may be writing them)
+    if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
+    o->flags = a->flags[p];
+    PageEntry e{};
+    HIP_TRY(hipMemcpy(&e, a->d_entries + p, sizeof(e), hipMemcpyDeviceToHost));
+    o->pool_device = pools_[a->page_pool[p]]->device();
+    o->rec_bytes = e.rec_bytes;
+    o->scale = e.scale;
+    o->pool_addr = e.pool_addr;
+    o->cache_addr = (a->flags[p] & 3u) ? reinterpret_cast<uint64_t>(slot_ptr(a->slot[p])) : 0;
+    o->access_count = a->access_count[p];
     return SPECKV_OK;
 }
 
@@ -926,7 +1387,9 @@ int Engine::write(uint64_t handle, uint64_t off, const void* src, size_t len, bo
     const uint64_t p0 = off / kPageSize;
     const uint64_t full = len / kPageSize, tail = len % kPageSize;
     DeviceScope device_scope(device_);
-    reap(true);
+    RC_TRY(quiesce());
+    if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
+    reap(false);
     // the source may have been produced on any stream of the caller: this call is
     // synchronous anyway, so order it after everything queued on the device
     if (on_device) HIP_TRY(hipDeviceSynchronize());
@@ -963,17 +1426,13 @@ int Engine::write(uint64_t handle, uint64_t off, const void* src, size_t len, bo
             HIP_TRY(hipMemcpyAsync(st, s8 + done * kPageSize, bytes, hipMemcpyHostToDevice, stream_));
             c.first = p0 + done; c.n = np; c.data = st;
             HIP_TRY(launch_compress(c, stream_));
-            HIP_TRY(hipStreamSynchronize(stream_));
+            HIP_TRY(hipStreamSynchronize(stream_));       // the staging buffer is shared: keep the ABI lock
         }
     }
     HIP_TRY(hipStreamSynchronize(stream_));
     const uint64_t np = full + (tail ? 1 : 0);
     for (uint64_t p = p0; p < p0 + np; ++p) {
-        if (a->flags[p] & 3u) {                             // a cached copy is stale now
-            const uint32_t s = a->slot[p];
-            if (s >= n_l2_) { lru_unlink(s); l1_free_.push_back(s); }
-            drop_slot(s);
-        }
+        drop_page(a, static_cast<uint32_t>(p));             // a cached copy is stale now
         if (a->scheme != SPECKV_COMP_FP16) a->flags[p] |= 4u; else a->flags[p] &= ~4u;
     }
     st_.total_compressions += np;
@@ -1025,32 +1484,137 @@ int Engine::read(uint64_t handle, uint64_t off, void* dst, size_t len, bool on_d
     return SPECKV_OK;
 }
 
-int Engine::fetch_range(uint64_t handle, uint64_t first, uint64_t n, void* d_dst, bool f32, hipStream_t s)
+// Copy-engine fetch of a logical page range (the reference's DMA path: one descriptor per 4 KiB page through the
+// DMA engine, speckv_allocator.cpp:115-138, dma_engine.v:150-217 -- here one hipMemcpyPeerAsync per POOL GPU and
+// chunk, because striping makes the range one contiguous record run on every pool): the runs are copied over xGMI
+// into local staging on per-peer side streams, then decompressed locally from there.  Two staging buffers in
+// rotation: the copies of chunk c+1 overlap the decompression of chunk c.
+int Engine::fetch_range_copy_engine(Allocation* a, uint64_t first, uint64_t n, void* d_dst, bool f32, hipStream_t st)
+{
+    const uint32_t D = static_cast<uint32_t>(a->pool_of_residue.size());
+    if (D == 0 || D > 8 || !a->regular) return SPECKV_ERR_INVAL;
+    const size_t stride = a->rec_stride;
+    if (!stage_[0]) {
+        stage_bytes_ = env_mb("SPECKV_STAGE_MB", 64) << 20;
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&stage_[b]), stage_bytes_));
+            HIP_TRY(hipEventCreateWithFlags(&stage_free_[b], hipEventDisableTiming));
+        }
+    }
+    if (lanes_.size() < pools_.size()) {
+        const size_t old = lanes_.size();
+        lanes_.resize(pools_.size());
+        for (size_t i = old; i < lanes_.size(); ++i) {
+            HIP_TRY(hipStreamCreateWithFlags(&lanes_[i].s, hipStreamNonBlocking));
+            for (auto& ev : lanes_[i].copied) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
+    }
+    // records per pool and chunk: the staging buffer is cut into D equal regions
+    const uint64_t region = (stage_bytes_ / D) / stride * stride;
+    const uint64_t recs_per_region = region / stride;
+    if (recs_per_region == 0) return SPECKV_ERR_NOMEM;
+    const uint64_t chunk_pages = recs_per_region * D;     // logical pages per chunk (each pool gets <= recs_per_region of them)
+    // the source records must be in place: everything queued on the engine stream (writes are synchronous) and on
+    // the caller's stream so far is ordered before the first copy
+    hipEvent_t start = get_event();
+    if (!start) return SPECKV_ERR_DRIVER;
+    HIP_TRY(hipEventRecord(start, st));
+    uint64_t done = 0;
+    int chunk = 0;
+    while (done < n) {
+        const uint64_t f0 = first + done, nc = std::min(chunk_pages, n - done);
+        const int b = chunk & 1;
+        CodecArgs c{};
+        c.entries = a->d_entries;
+        c.trusted = 1;
+        c.first = f0;
+        c.n = nc;
+        c.data = static_cast<uint8_t*>(d_dst) + done * (f32 ? 2ull * kPageSize : kPageSize);
+        c.data_stride = f32 ? 2ull * kPageSize : kPageSize;
+        c.scheme = a->scheme;
+        c.quant_mode = quant_mode_;
+        c.out_f32 = f32 ? 1 : 0;
+        c.stripe_n = D;
+        for (uint32_t k = 0; k < D; ++k) {
+            uint64_t rb = 0, cnt = 0;
+            shard_range(f0, nc, D, k, &rb, &cnt);
+            c.stripe_delta[k] = 0;
+            if (cnt == 0) continue;
+            const int pool = a->pool_of_residue[k];
+            const uint8_t* src = static_cast<const uint8_t*>(a->extents[k].base) + rb * stride;
+            uint8_t* dstk = stage_[b] + k * region;
+            c.stripe_delta[k] = static_cast<int64_t>(reinterpret_cast<intptr_t>(dstk) - reinterpret_cast<intptr_t>(src));
+            PeerLane& lane = lanes_[pool];
+            if (chunk == 0) HIP_TRY(hipStreamWaitEvent(lane.s, start, 0));
+            HIP_TRY(hipStreamWaitEvent(lane.s, stage_free_[b], 0));        // the decompression that last read this buffer
+            HIP_TRY(hipMemcpyPeerAsync(dstk, device_, src, pools_[pool]->device(), cnt * stride, lane.s));
+            HIP_TRY(hipEventRecord(lane.copied[b], lane.s));
+            HIP_TRY(hipStreamWaitEvent(st, lane.copied[b], 0));
+            st_.copy_engine_bytes += cnt * stride;
+        }
+        HIP_TRY(launch_decompress(c, st));
+        HIP_TRY(hipEventRecord(stage_free_[b], st));
+        done += nc;
+        ++chunk;
+    }
+    put_event(start);
+    st_.copy_engine_runs += static_cast<uint64_t>(chunk) * D;
+    return SPECKV_OK;
+}
+
+int Engine::fetch_range(uint64_t handle, uint64_t first, uint64_t n, void* d_dst, bool f32, hipStream_t s, int engine_choice)
 {
     if (null_) return no_data_path("speckv_ext_fetch_range");
     Allocation* a = find(handle);
     if (!a) return SPECKV_ERR_GENERAL;
     if (first > a->n_pages || n > a->n_pages - first) return SPECKV_ERR_GENERAL;
     if (!d_dst) return SPECKV_ERR_INVAL;
+    if (engine_choice < 0 || engine_choice > 2) return SPECKV_ERR_INVAL;
     if (n == 0) return SPECKV_OK;
     DeviceScope device_scope(device_);
-    CodecArgs c{};
-    c.entries = a->d_entries;
-    c.trusted = 1;                       // pool records only ever come from k_compress
-    c.first = first;
-    c.n = n;
-    c.data = static_cast<uint8_t*>(d_dst);
-    c.data_stride = f32 ? 2ull * kPageSize : kPageSize;
-    c.scheme = a->scheme;
-    c.quant_mode = quant_mode_;
-    c.out_f32 = f32 ? 1 : 0;
     hipStream_t st = s ? s : stream_;
-    HIP_TRY(launch_decompress(c, st));
+    // which engine moves the records: the fused peer-load kernel (the wave loads the record over xGMI and
+    // decompresses in registers) or the copy engines (SDMA runs into local staging, then a local decompress).
+    // Per batch: long runs on remote pools go to the copy engines, short ones to the kernel; 1 / 2 force a choice
+    // (SPECKV_REMOTE_ENGINE=kernel|copy overrides "auto").
+    static const int env_choice = [] {
+        const char* e = getenv("SPECKV_REMOTE_ENGINE");
+        return !e ? 0 : !strcmp(e, "kernel") ? 1 : !strcmp(e, "copy") ? 2 : 0;
+    }();
+    int choice = engine_choice ? engine_choice : env_choice;
+    const uint32_t D = static_cast<uint32_t>(a->pool_of_residue.size());
+    const bool can_copy = a->regular && D >= 1 && D <= 8 && !is_capturing(st);
+    if (choice == 0) {
+        bool remote = false;
+        for (int p : a->pool_of_residue) remote = remote || pools_[p]->device() != device_;
+        static const uint64_t min_run = env_mb("SPECKV_COPY_MIN_RUN_KB", 1024) << 10;
+        choice = (remote && can_copy && (n / D) * a->rec_stride >= min_run) ? 2 : 1;
+    }
+    if (choice == 2 && !can_copy) {
+        if (engine_choice == 2) return SPECKV_ERR_INVAL;     // asked for explicitly on a placement that has no runs
+        choice = 1;
+    }
+    if (choice == 2) {
+        RC_TRY(fetch_range_copy_engine(a, first, n, d_dst, f32, st));
+    } else {
+        CodecArgs c{};
+        c.entries = a->d_entries;
+        c.trusted = 1;                       // pool records only ever come from k_compress
+        c.first = first;
+        c.n = n;
+        c.data = static_cast<uint8_t*>(d_dst);
+        c.data_stride = f32 ? 2ull * kPageSize : kPageSize;
+        c.scheme = a->scheme;
+        c.quant_mode = quant_mode_;
+        c.out_f32 = f32 ? 1 : 0;
+        HIP_TRY(launch_decompress(c, st));
+    }
+    note_use(a, s);
     st_.dma_submitted += n;
     st_.total_decompressions += n;
     if (!s) {
         hipEvent_t ev = get_event();
-        if (ev) { HIP_TRY(hipEventRecord(ev, stream_)); inflight_.push_back({ev, static_cast<uint32_t>(n)}); }
+        if (ev) { HIP_TRY(hipEventRecord(ev, stream_)); inflight_.push_back({ev, static_cast<uint32_t>(n), nullptr}); }
     } else {
         st_.dma_completed += n;            // completion belongs to the caller's stream
     }
@@ -1077,11 +1641,12 @@ int Engine::fetch_list(uint64_t handle, const uint32_t* d_pages, uint32_t n, voi
     c.out_f32 = f32 ? 1 : 0;
     hipStream_t st = s ? s : stream_;
     HIP_TRY(launch_decompress(c, st));
+    note_use(a, s);
     st_.dma_submitted += n;
     st_.total_decompressions += n;
     if (!s) {
         hipEvent_t ev = get_event();
-        if (ev) { HIP_TRY(hipEventRecord(ev, stream_)); inflight_.push_back({ev, n}); }
+        if (ev) { HIP_TRY(hipEventRecord(ev, stream_)); inflight_.push_back({ev, n, nullptr}); }
     } else {
         st_.dma_completed += n;
     }
@@ -1127,17 +1692,19 @@ int Engine::qk_scores_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, co
             k.scale_tab = a->d_scale_tab;
             k.q16 = static_cast<const uint16_t*>(d_q_f16);
             HIP_TRY(launch_qk_scores_fp8_linear(k, n_layers, d_out, st));
-            if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+            note_use(a, s);
+            if (!s) RC_TRY(wait_stream());
             return SPECKV_OK;
         }
     }
     const size_t rows = static_cast<size_t>(n_layers) * L.num_heads * 16;
-    uint8_t* q8 = static_cast<uint8_t*>(scratch(s_req_, rows * 128 + rows * sizeof(float)));
+    uint8_t* q8 = static_cast<uint8_t*>(scratch(s_req_, rows * 128 + rows * sizeof(float), s));
     if (!q8) return SPECKV_ERR_NOMEM;
     float* qs = reinterpret_cast<float*>(q8 + rows * 128);
     HIP_TRY(launch_quantize_q_e4m3(d_q_f16, n_layers * L.num_heads, g, L.head_dim, q8, qs, st));
     HIP_TRY(launch_qk_scores_fp8(a->d_entries, first_page, layer_stride, n_layers, n_pages, L.num_heads, g, q8, qs, d_out, st));
-    if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+    note_use(a, s);
+    if (!s) RC_TRY(wait_stream());
     return SPECKV_OK;
 }
 
@@ -1170,6 +1737,7 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     const uint64_t layer_stride = static_cast<uint64_t>(L.num_tokens);
     if (v_first + (n_layers - 1) * layer_stride + n_pages > a->n_pages) return SPECKV_ERR_GENERAL;
     if (!d_zero_page_) {
+        if (is_capturing(s)) return SPECKV_ERR_INVAL;        // first call must run outside a capture (see scratch())
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
         HIP_TRY(hipMemset(d_zero_page_, 0, kPageSize));
     }
@@ -1189,7 +1757,7 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     const size_t q_bytes = static_cast<size_t>(rows) * 16 * 128, qs_bytes = static_cast<size_t>(rows) * 16 * sizeof(float);
     const size_t acc_bytes = static_cast<size_t>(rows) * n_splits * 16 * 128 * sizeof(float);
     const size_t ml_bytes = static_cast<size_t>(rows) * n_splits * 32 * sizeof(float);
-    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, q_bytes + qs_bytes + acc_bytes + ml_bytes));
+    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, q_bytes + qs_bytes + acc_bytes + ml_bytes, s));
     if (!buf) return SPECKV_ERR_NOMEM;
     AttendArgs k{};
     k.entries = a->d_entries;
@@ -1217,24 +1785,27 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     if (!k.lin_base)                     // the linear form quantises the query in its own prologue
         HIP_TRY(launch_quantize_q_e4m3(d_q_f16, rows, g, L.head_dim, buf, reinterpret_cast<float*>(buf + q_bytes), st));
     HIP_TRY(launch_attend_fp8(k, n_layers, d_out, d_lse, st));
-    if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+    note_use(a, s);
+    if (!s) RC_TRY(wait_stream());
     return SPECKV_OK;
 }
 
-// One decode step of a batch: the fused FP8 attention of ONE layer for many sequences (allocations) in one launch
+// One decode step of a batch: the fused attention of ONE layer for many sequences (allocations) in one launch
 // (BASELINE configs[3] shape: 256 sequences).  Every allocation must qualify for the linear form.
-int Engine::attend_fp8_batch(uint32_t n_seq, const uint64_t* handles, uint32_t layer, const void* d_q_f16, uint32_t g,
-                             const uint32_t* pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
-{
-    return attend_batch(SPECKV_COMP_FP8_E4M3, n_seq, handles, layer, d_q_f16, g, pos_end, sm_scale, d_out, d_lse, s);
-}
-
+// Not capturable into a HIP graph: the per-call descriptors travel through a pinned slot that later calls reuse, so a
+// replay would read other calls' descriptors -- the call refuses to run on a capturing stream (the per-sequence
+// entry points speckv_ext_attend_fp8 / _int4 are capturable).
 int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, uint32_t layer, const void* d_q_f16, uint32_t g,
                          const uint32_t* pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
 {
     const bool fp8 = scheme == SPECKV_COMP_FP8_E4M3;
     if (null_) return no_data_path("speckv_ext_attend_*_batch");
     if (n_seq == 0) return SPECKV_OK;
+    if (is_capturing(s)) {
+        SPECKV_ERR("speckv_ext_attend_*_batch cannot be captured into a HIP graph (its descriptors are staged per call); "
+                   "capture the per-sequence speckv_ext_attend_fp8 / _int4 calls instead");
+        return SPECKV_ERR_INVAL;
+    }
     if (!handles || !pos_end || !d_q_f16 || !d_out || g == 0 || g > 16) return SPECKV_ERR_INVAL;
     std::vector<AttendSeq> seqs(n_seq);
     uint64_t total_tiles = 0;
@@ -1254,6 +1825,7 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
             return SPECKV_ERR_INVAL;
         }
         heads = L.num_heads;
+        note_use(a, s);
         seqs[i].lin_base = a->linear_base;
         seqs[i].scale_tab = a->d_scale_tab;
         seqs[i].k_first = static_cast<uint64_t>(layer) * L.num_tokens;       // (layer*2*T)/2
@@ -1284,8 +1856,8 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
         max_splits = std::max(max_splits, seqs[i].n_splits);
     }
     const size_t acc_bytes = static_cast<size_t>(parts) * 16 * 128 * sizeof(float), ml_bytes = static_cast<size_t>(parts) * 32 * sizeof(float);
-    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes));
-    AttendSeq* d_seqs = static_cast<AttendSeq*>(scratch(s_attn_seq_, seqs.size() * sizeof(AttendSeq)));
+    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes, s));
+    AttendSeq* d_seqs = static_cast<AttendSeq*>(scratch(s_attn_seq_, seqs.size() * sizeof(AttendSeq), s));
     if (!buf || !d_seqs) return SPECKV_ERR_NOMEM;
     // descriptors go through a pinned slot so the call can return without waiting for the copy
     const size_t seq_bytes = seqs.size() * sizeof(AttendSeq);
@@ -1360,6 +1932,7 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     const bool fits = static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
     const bool linear = a->linear_base && fits && !getenv("SPECKV_ATTEND_GENERAL");
     if (!linear && !d_zero_page_) {
+        if (is_capturing(s)) return SPECKV_ERR_INVAL;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
         HIP_TRY(hipMemset(d_zero_page_, 0, kPageSize));
     }
@@ -1373,7 +1946,7 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     n_splits = (n_tiles + tiles_per_split - 1u) / tiles_per_split;
     const size_t acc_bytes = static_cast<size_t>(rows) * n_splits * 16 * 128 * sizeof(float);
     const size_t ml_bytes = static_cast<size_t>(rows) * n_splits * 32 * sizeof(float);
-    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes));
+    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes, s));
     if (!buf) return SPECKV_ERR_NOMEM;
     AttendArgs k{};
     k.entries = a->d_entries;
@@ -1393,7 +1966,8 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
     HIP_TRY(launch_attend_int4(k, n_layers, st));
     HIP_TRY(launch_attend_combine(k, n_layers, d_out, d_lse, st));
-    if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+    note_use(a, s);
+    if (!s) RC_TRY(wait_stream());
     return SPECKV_OK;
 }
 
@@ -1410,12 +1984,23 @@ int Engine::migrate(uint64_t handle, uint64_t first, uint64_t n, uint32_t target
     if (target_pool >= pools_.size()) return SPECKV_ERR_INVAL;
     if (n == 0) return SPECKV_OK;
     DeviceScope device_scope(device_);
-    HIP_TRY(hipStreamSynchronize(stream_));
-    reap(true);
+    RC_TRY(quiesce());
+    RC_TRY(wait_stream());
+    if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
+    // asynchronous entry points on caller streams (fetch_range / fetch_list / attend_*) may still be reading the
+    // records that are about to move: wait for exactly those streams (the ABI lock stays held: the allocation's
+    // placement must not change under another caller)
+    for (hipStream_t us : a->user_streams)
+        if (hipStreamSynchronize(us) != hipSuccess) (void)hipGetLastError();
+    reap(false);
     if (!copy_stream_) HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
     const size_t stride = a->rec_stride;
     uint8_t* dst = static_cast<uint8_t*>(pools_[target_pool]->alloc(n * stride));
     if (!dst) return SPECKV_ERR_NOMEM;
+    struct PoolGuard {                      // the new run goes back to the pool on every error path
+        SlabPool* pool; void* p; size_t bytes; bool keep = false;
+        ~PoolGuard() { if (!keep) pool->free(p, bytes); }
+    } guard{pools_[target_pool].get(), dst, n * stride};
     std::vector<PageEntry> cur(n);
     HIP_TRY(hipMemcpy(cur.data(), a->d_entries + first, n * sizeof(PageEntry), hipMemcpyDeviceToHost));
     const int dst_dev = pools_[target_pool]->device();
@@ -1434,12 +2019,14 @@ int Engine::migrate(uint64_t handle, uint64_t first, uint64_t n, uint32_t target
     HIP_TRY(hipStreamSynchronize(copy_stream_));
     HIP_TRY(launch_retarget_entries(a->d_entries + first, n, reinterpret_cast<uint64_t>(dst), stride, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
-    // bookkeeping: the old runs leave the allocation's extent list (split where needed)
+    guard.keep = true;
+    // bookkeeping: the old runs leave the allocation's extent list (split where needed).  Record strides are
+    // multiples of the pool's 128-byte granule, so a sub-run is freed exactly (never reaching into live neighbours).
     for (const Run& r : old) {
         std::vector<Allocation::Extent> next;
         for (const auto& ex : a->extents) {
             const uint64_t lo = reinterpret_cast<uint64_t>(ex.base), hi = lo + ex.bytes;
-            if (ex.pool != r.pool || r.addr >= hi || r.addr + r.bytes <= lo) { next.push_back(ex); continue; }
+            if (!ex.base || ex.pool != r.pool || r.addr >= hi || r.addr + r.bytes <= lo) { next.push_back(ex); continue; }
             if (r.addr > lo) next.push_back({ex.pool, ex.base, static_cast<size_t>(r.addr - lo), (r.addr - lo) / stride});
             if (r.addr + r.bytes < hi)
                 next.push_back({ex.pool, reinterpret_cast<void*>(r.addr + r.bytes), static_cast<size_t>(hi - r.addr - r.bytes),
@@ -1451,6 +2038,7 @@ int Engine::migrate(uint64_t handle, uint64_t first, uint64_t n, uint32_t target
     a->extents.push_back({static_cast<int>(target_pool), dst, n * stride, n});
     for (uint64_t i = 0; i < n; ++i) a->page_pool[first + i] = static_cast<uint8_t>(target_pool);
     a->linear_base = nullptr;                     // records no longer lie in one run
+    a->regular = false;                           // nor in the striping order the copy engine relies on
     st_.pool_migrated_pages += n;
     return SPECKV_OK;
 }
@@ -1469,10 +2057,11 @@ int Engine::sync()
 {
     if (null_) return SPECKV_OK;
     DeviceScope device_scope(device_);
-    uint32_t n = 0;
-    int rc = prefetch_flush(&n);
-    HIP_TRY(hipStreamSynchronize(stream_));
-    reap(true);
+    int rc = prefetch_flush(nullptr);
+    RC_TRY(wait_stream());
+    RC_TRY(settle());
+    reap(false);
+    drain_zombies(false);
     return rc;
 }
 
@@ -1483,24 +2072,26 @@ int Engine::promote_to_l1(uint64_t handle, uint64_t off)
     if (!a) return SPECKV_ERR_GENERAL;
     const uint64_t p = off / kPageSize;
     if (p >= a->n_pages) return SPECKV_ERR_GENERAL;
-    if (a->flags[p] & 1u) return SPECKV_ERR_GENERAL;          // already there -> false (cxl_memory_manager.cpp:134-136)
     DeviceScope device_scope(device_);
-    int rc = SPECKV_OK;
+    RC_TRY(quiesce());
+    if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
+    if (a->flags[p] & 1u) return SPECKV_ERR_GENERAL;          // already there -> false (cxl_memory_manager.cpp:134-136)
     if (a->flags[p] & 2u) {
-        move_to_l1(a, static_cast<uint32_t>(p));
-    } else {
-        const uint32_t s = take_l1_slot();
-        rc = fetch_into_slots(a, {static_cast<uint32_t>(p)}, {s}, true);
-        if (rc == SPECKV_OK) {
-            a->slot[p] = s; a->flags[p] |= 1u; owner_[s] = Owner{a, static_cast<uint32_t>(p)};
-            lru_push_mru(s);
-            st_.migrations_l3_to_l1++;
-        } else {
-            l1_free_.push_back(s);
-        }
+        RC_TRY(move_to_l1(a, static_cast<uint32_t>(p)));
+        return wait_stream();
     }
-    HIP_TRY(hipStreamSynchronize(stream_));
-    return rc;
+    const uint32_t s = take_l1_slot();
+    const int rc = fetch_into_slot(a, static_cast<uint32_t>(p), s);
+    if ((a = find(handle)) == nullptr) { l1_free_.push_back(s); return SPECKV_ERR_GENERAL; }
+    if (rc != SPECKV_OK) { l1_free_.push_back(s); return rc; }
+    a->slot[p] = s;
+    a->flags[p] = (a->flags[p] & ~3u) | 1u;
+    l1_owner_[s - n_l2_] = Owner{a, static_cast<uint32_t>(p)};
+    a->l1_pages++;
+    queue_update(a, static_cast<uint32_t>(p), ~3u, 1u, s);
+    lru_push_mru(s);
+    st_.migrations_l3_to_l1++;
+    return SPECKV_OK;
 }
 
 int Engine::demote_to_l3(uint64_t handle, uint64_t off)
@@ -1510,10 +2101,12 @@ int Engine::demote_to_l3(uint64_t handle, uint64_t off)
     if (!a) return SPECKV_ERR_GENERAL;
     const uint64_t p = off / kPageSize;
     if (p >= a->n_pages) return SPECKV_ERR_GENERAL;
+    DeviceScope device_scope(device_);
+    RC_TRY(quiesce());
+    if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
     if (!(a->flags[p] & 3u)) return SPECKV_ERR_GENERAL;       // already in the pool only
-    const uint32_t s = a->slot[p];
-    if (a->flags[p] & 1u) { lru_unlink(s); l1_free_.push_back(s); st_.migrations_l1_to_l3++; }
-    drop_slot(s);
+    if (a->flags[p] & 1u) st_.migrations_l1_to_l3++;
+    drop_page(a, static_cast<uint32_t>(p));
     return SPECKV_OK;
 }
 
@@ -1527,6 +2120,8 @@ int Engine::stats(speckv_ext_stats_t* out)
     if (!null_) {
         // compressed bytes = sum of record lengths currently stored
         DeviceScope device_scope(device_);
+        RC_TRY(settle());                   // prefetch counters of the flushes submitted so far
+        reap(false);
         uint64_t comp = 0;
         std::vector<PageEntry> host;
         for (auto& kv : allocs_) {

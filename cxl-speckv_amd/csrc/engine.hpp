@@ -7,19 +7,22 @@
 //   CXLMemoryManager src/cxl_memory/cxl_memory_manager.cpp  L1/L2/L3 tiers, LRU, hot pages
 //   CXLMemoryAllocator::cxl_access policy            src/integration/memory_allocator.cpp:105-143
 //   SpeculativePrefetcher depth adaptation           src/prefetcher/speculative_prefetcher.cpp:84-137
+//   prefetch_core lookup/issue loop                  hardware/rtl/prefetch_core.v:150-241 (device-side flush)
+//   DMA engine, one descriptor per page              hardware/rtl/dma_engine.v:150-217 (copy-engine fetch of runs)
 //
 // HBM layout (compute GPU = device the engine was opened on):
-//   pool   (L3): SlabPool per pool GPU; every page of an allocation owns one
-//                fixed-size record slot (4096 B for FP16 / INT8_DELTA_RLE worst
-//                case, 2048 B for INT8); slots of one allocation are one
-//                contiguous run per pool GPU, pages striped page % n_pool.
-//   table      : per allocation, PageEntry[n_pages] (16 B: record address,
-//                record bytes, scale) + uint32 residency mirror, both in HBM.
-//   cache (L1+L2): one arena of 4 KiB slots on the compute GPU; slots
-//                [0, n_l2) are the prefetch ring (FIFO), [n_l2, n_l2+n_l1)
-//                the LRU-managed resident set.
-// All tier bookkeeping is host-side (as in the reference); kernels see the
-// page table and the residency mirror only.
+//   pool   (L3): SlabPool per pool GPU; every page of an allocation owns one fixed-size record slot (4096 B for
+//                FP16 / INT8_DELTA_RLE worst case, 2048 B for INT8 / FP8, 1152 B for INT4); pages striped
+//                page % n_pool, so a logical page range is ONE contiguous record run on every pool GPU.
+//   table      : per allocation PageEntry[n_pages] (16 B: record address, record bytes, scale), the residency
+//                mirror (flags, slot) and the dedupe stamps, all in HBM; one DevAlloc row per allocation in the
+//                device allocation table so kernels can work across allocations.
+//   cache (L1+L2): one arena of 4 KiB slots on the compute GPU; slots [0, n_l2) are the prefetch ring (FIFO,
+//                runs never wrap), [n_l2, n_l2+n_l1) the LRU-managed resident set.
+// Who owns what: the L2 ring is managed ON THE DEVICE (owner table, eviction, slot / flag updates are done by the
+// fetch kernel itself; the prefetch flush assigns its ring run on the device); the host keeps an exact mirror of
+// the ring hand (same deterministic rule) and reads residency from a pinned, device-written copy of flags / slots.
+// L1 (LRU) stays host-managed, as the reference's tier manager.
 #pragma once
 #include "../../include/speckv_ext.h"
 #include "kernels.hpp"
@@ -27,6 +30,7 @@
 
 #include <deque>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -51,17 +55,26 @@ struct Allocation {
     uint64_t n_pages = 0;
     int scheme = 0;
     uint32_t rec_stride = kPageSize;
-    std::vector<uint32_t> flags;          // bit0 L1, bit1 L2, bit2 compressed (KvPageHandle::flags)
-    std::vector<uint32_t> slot;           // cache slot when flags&3
+    uint32_t row = kNoSlot;               // row in the device allocation table
+    // residency as the host sees it: bit0 L1, bit1 L2, bit2 compressed (KvPageHandle::flags) and the cache slot.
+    // HIP mode: pinned host memory that the device kernels also write (fetch kernel / flush); /dev/null: plain memory.
+    uint32_t* flags = nullptr;
+    uint32_t* slot = nullptr;
+    std::vector<uint32_t> null_flags;     // backing store on the fake device
+    void* pinned = nullptr;               // backing store on a HIP device (flags then slots)
     std::vector<uint32_t> access_count;   // MemoryPage::access_count
-    std::vector<uint32_t> stamp;          // dedupe epoch for prefetch flushes
+    std::vector<uint32_t> stamp;          // dedupe epoch of access_batch
+    uint32_t l1_pages = 0;
     // HIP mode
     struct Extent { int pool; void* base; size_t bytes; uint64_t n_pages; };
     std::vector<Extent> extents;
     std::vector<int> pool_of_residue;     // pool index serving pages with page % D == k (at allocation)
     std::vector<uint8_t> page_pool;       // pool index holding each page's record now
+    bool regular = false;                 // placement still is "page p = record p/D of the run on pool p%D"
     PageEntry* d_entries = nullptr;
     uint32_t* d_flags = nullptr;
+    uint32_t* d_slot = nullptr;
+    uint32_t* d_stamp = nullptr;
     // set while every record lies in ONE run of one local pool (record p at linear_base + p*rec_stride)
     // and, for the fixed-size formats, never-written records are zero bytes; cleared by a migration
     uint8_t* linear_base = nullptr;
@@ -69,7 +82,11 @@ struct Allocation {
     float* d_scale_tab = nullptr;
     uint32_t region_pages = 0;
     bool has_layout = false;
+    bool layout_inferred = false;
     Layout layout{};
+    uint32_t entry_bytes_seen = 0;        // length_bytes of the first speckv_access (= head_dim * bytes_per_element in the shim)
+    // caller streams that have been handed asynchronous work on this allocation (speckv_free waits for those only)
+    std::vector<hipStream_t> user_streams;
 };
 
 class Engine {
@@ -79,6 +96,9 @@ public:
     ~Engine();
 
     bool null_device() const { return null_; }
+    // The C ABI serialises callers with one mutex (speckv_c_api.cpp:10).  Every entry hands its lock to the engine,
+    // which releases it only while it waits for the GPU (state is re-validated afterwards).
+    void enter(std::unique_lock<std::mutex>* lk) { lk_ = lk; }
 
     int alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out);
     int free(uint64_t handle);
@@ -92,9 +112,10 @@ public:
     int translate(uint64_t handle, uint64_t off, speckv_ext_page_info_t* out);
     int fetch_desc(uint64_t handle, uint64_t off, speckv_dma_desc_t* out);
     int set_layout(uint64_t handle, uint32_t T, uint32_t L, uint32_t H, uint32_t D, uint32_t bpe);
+    int bind_request(uint32_t req, uint64_t handle, uint32_t local_req);
     int write(uint64_t handle, uint64_t off, const void* src, size_t len, bool on_device);
     int read(uint64_t handle, uint64_t off, void* dst, size_t len, bool on_device);
-    int fetch_range(uint64_t handle, uint64_t first, uint64_t n, void* d_dst, bool f32, hipStream_t s);
+    int fetch_range(uint64_t handle, uint64_t first, uint64_t n, void* d_dst, bool f32, hipStream_t s, int engine_choice);
     int fetch_list(uint64_t handle, const uint32_t* d_pages, uint32_t n, void* d_dst, bool f32, hipStream_t s);
     int access_batch(uint64_t handle, const uint64_t* offs, uint32_t n, void** out);
     int prefetch_batch(uint32_t n, const uint32_t* req, const uint16_t* layer,
@@ -109,8 +130,6 @@ public:
                       uint32_t pos_begin, uint32_t pos_end, float* d_out, hipStream_t s);
     int attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
                    uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
-    int attend_fp8_batch(uint32_t n_seq, const uint64_t* handles, uint32_t layer, const void* d_q_f16, uint32_t g,
-                         const uint32_t* pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
     int attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, uint32_t layer, const void* d_q_f16, uint32_t g,
                      const uint32_t* pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
     int attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
@@ -131,8 +150,10 @@ private:
 
     bool null_ = false;
     int device_ = 0;
+    std::unique_lock<std::mutex>* lk_ = nullptr;
     hipStream_t stream_ = nullptr;         // fetch / codec side stream
     hipStream_t copy_stream_ = nullptr;    // peer copies (pool <-> pool migration)
+    std::vector<int> pool_devs_;           // pool GPUs in SPECKV_POOL_DEVICES order (also kept on the fake device)
     std::vector<std::unique_ptr<SlabPool>> pools_;
 
     std::unordered_map<uint64_t, std::unique_ptr<Allocation>> allocs_;
@@ -143,34 +164,82 @@ private:
     int quant_mode_ = SPECKV_QUANT_REF_EXACT;
     AdaptiveDepth adapt_{4};
 
+    // device allocation table
+    DevAlloc* d_tab_ = nullptr;
+    uint32_t tab_cap_ = 0;
+    std::vector<uint32_t> free_rows_;
+    std::vector<Allocation*> row_owner_;
+    int publish_row(Allocation* a);        // (re)write the allocation's table row on the engine stream
+
     // cache arena
     struct Owner { Allocation* a; uint32_t page; };
     uint8_t* cache_base_ = nullptr;
     uint32_t n_l2_ = 0, n_l1_ = 0;
-    uint64_t l2_hand_ = 0;
-    std::vector<Owner> owner_;
+    uint32_t l2_hand_ = 0;                 // host mirror of the device ring hand
+    uint64_t* d_owner_ = nullptr;          // [n_l2] (row << 32 | page), kNoOwner when free
+    uint32_t* d_hand_ = nullptr;
+    std::vector<Owner> l1_owner_;          // [n_l1], slot - n_l2
     std::vector<uint32_t> lru_prev_, lru_next_, l1_free_;
     uint32_t lru_head_ = UINT32_MAX, lru_tail_ = UINT32_MAX;   // head = least recent
+
+    // request -> allocation binding (speckv_ext_bind_request); unbound requests index into the last laid-out
+    // allocation, as in the reference's single-allocation shim (vllm_speckv_backend.py:95-100)
+    struct Binding { uint64_t handle; uint32_t local_req; };
+    std::unordered_map<uint32_t, Binding> bindings_;
 
     // prefetch queue
     struct Req { uint32_t req, layer, pos, k; };
     std::vector<Req> queue_;
     uint32_t flush_threshold_ = 0;
-    uint32_t epoch_ = 0;
+    uint32_t access_epoch_ = 0;
+    uint32_t flush_epoch_ = 0;             // 1..255 (dedupe stamps)
+    uint32_t max_layer_seen_ = 0;
+    bool warned_no_layout_ = false;
 
-    // residency-mirror maintenance
-    std::unordered_map<Allocation*, std::vector<uint32_t>> pending_clear_;
+    // host-originated residency changes waiting to reach the device mirrors (pinned ring read by k_apply_updates)
+    MirrorUpdate* upd_ring_ = nullptr;
+    uint32_t upd_cap_ = 0, upd_head_ = 0, upd_pending_ = 0;      // [head - pending, head) not yet launched
+    hipEvent_t upd_event_ = nullptr;       // last launch that read the ring
+
+    // flushes whose slot assignment the host has not absorbed yet
+    struct Flight {
+        hipEvent_t assigned = nullptr;     // after the assign kernel: the result words are final
+        hipEvent_t done = nullptr;         // after the fetch kernel
+        FlushResult* result = nullptr;     // pinned
+        bool absorbed = false;
+        uint32_t base = 0, m = 0;
+    };
+    std::deque<Flight> flights_;
+    FlushResult* res_ring_ = nullptr;      // pinned, kResSlots entries
+    FlushResult* d_res_ring_ = nullptr;    // device twin
+    uint32_t res_next_ = 0;
+    void* req_stage_ = nullptr;            // pinned staging for request uploads (4 slots in rotation)
+    size_t req_stage_bytes_ = 0;
+    hipEvent_t req_stage_ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+    int req_stage_next_ = 0;
 
     // completion accounting (speckv_kernel_module.c:194-215)
-    struct Batch { hipEvent_t ev; uint32_t n; };
+    struct Batch { hipEvent_t ev; uint32_t n; const FlushResult* n_from; };
     std::deque<Batch> inflight_;
     std::vector<hipEvent_t> event_pool_;
     uint64_t completed_unpolled_ = 0;
 
+    // allocations freed while a stream may still read them
+    struct Zombie { std::unique_ptr<Allocation> a; hipEvent_t engine_ev; };
+    std::vector<Zombie> zombies_;
+
     // device scratch
-    struct Scratch { void* p = nullptr; size_t cap = 0; };
-    Scratch s_pages_, s_dst_, s_req_, s_out_, s_tmp_, s_stage_;
+    struct Scratch { void* p = nullptr; size_t cap = 0; bool in_graph = false; };
+    Scratch s_pages_, s_dst_, s_req_, s_out_, s_tmp_, s_stage_, s_flush_;
+    std::vector<void*> retired_;           // scratch buffers a captured graph may still reference
     uint32_t* d_count_ = nullptr;
+
+    // copy-engine fetch: per-pool side streams, double-buffered staging on the compute GPU
+    struct PeerLane { hipStream_t s = nullptr; hipEvent_t copied[2] = {nullptr, nullptr}; };
+    std::vector<PeerLane> lanes_;
+    uint8_t* stage_[2] = {nullptr, nullptr};
+    size_t stage_bytes_ = 0;               // per buffer
+    hipEvent_t stage_free_[2] = {nullptr, nullptr};
 
     // token predictor (lstm_predictor.cpp): weights in HBM, last history / prediction per request
     float* d_emb_ = nullptr;
@@ -189,23 +258,40 @@ private:
 
     Allocation* find(uint64_t h);
     int init_hip(int device);
-    void* scratch(Scratch& s, size_t bytes);
+    void* scratch(Scratch& s, size_t bytes, hipStream_t user = nullptr);
     void release_allocation(Allocation* a);
+    void note_use(Allocation* a, hipStream_t s);
+    bool quiet(const Zombie& z);
+    void drain_zombies(bool wait);
+    // waits that give up the ABI lock (lk_) while the GPU works
+    int wait_event(hipEvent_t ev);
+    int wait_stream();                                    // everything queued on stream_ so far
     // tiers
     uint8_t* slot_ptr(uint32_t slot) const { return cache_base_ + static_cast<size_t>(slot) * kPageSize; }
-    void drop_slot(uint32_t slot);                       // forget owner (page becomes non-resident)
-    uint32_t take_l2_run(uint32_t n);                    // contiguous run of n ring slots
+    void drop_page(Allocation* a, uint32_t page);         // page leaves the cache (any tier)
+    uint32_t take_l2_run(uint32_t n);                     // host mirror of the ring rule
     uint32_t take_l1_slot();
     void lru_unlink(uint32_t slot);
     void lru_push_mru(uint32_t slot);
-    void move_to_l1(Allocation* a, uint32_t page);
-    void flush_mirror();
+    int move_to_l1(Allocation* a, uint32_t page);
+    void queue_update(Allocation* a, uint32_t page, uint32_t and_mask, uint32_t or_mask, uint32_t slot);
+    int flush_mirror();
+    int settle();                                         // absorb every flush assignment (waits for the assign kernels)
+    int quiesce();                                        // no fetch kernel running or queued
+    int prepare_ring_op();
+    uint32_t ring_busy_ = 0;                              // synchronous ring fetches in their (unlocked) wait
+    void absorb(Flight& f);
+    int wait_landed(const Allocation* a, uint64_t p0, uint64_t p1);   // pages of an in-flight flush have arrived
     // data movement
-    int fetch_into_slots(Allocation* a, const std::vector<uint32_t>& pages,
-                         const std::vector<uint32_t>& slots, bool wait);
+    int fetch_into_ring(Allocation* a, const std::vector<uint32_t>& pages, uint32_t* base_out);
+    int fetch_into_slot(Allocation* a, uint32_t page, uint32_t slot);
+    int fetch_range_copy_engine(Allocation* a, uint64_t first, uint64_t n, void* d_dst, bool f32, hipStream_t st);
+    bool infer_layout(Allocation* a);
+    int flush_group(int scheme, const std::vector<uint32_t>& soa, uint32_t n, uint32_t W, uint32_t* n_issued);
     void reap(bool wait_all);
     int run_predictor_for_dirty();
     hipEvent_t get_event();
+    void put_event(hipEvent_t e) { if (e) event_pool_.push_back(e); }
 };
 
 } // namespace speckv

@@ -435,23 +435,49 @@ struct BlockDesc {
     uint64_t page;
     uint32_t len;
     float scale;
+    uint32_t row;       // table row of the block's allocation (ring bookkeeping / multi-allocation launches)
 };
-__device__ __forceinline__ BlockDesc load_desc(const CodecArgs& a, uint64_t i)
+__device__ __forceinline__ BlockDesc load_desc(const CodecArgs& a, uint64_t i, uint32_t slot0)
 {
     BlockDesc d;
     d.page = a.page_list ? a.page_list[i] : a.first + i;
-    if (a.entries) {
-        const PageEntry e = a.entries[d.page];
+    d.row = a.alloc_list ? a.alloc_list[i] : a.alloc_idx;
+    const PageEntry* entries = a.alloc_list ? a.tab[d.row].entries : a.entries;
+    if (entries) {
+        const PageEntry e = entries[d.page];
         d.rec = reinterpret_cast<const uint8_t*>(e.pool_addr);
         d.len = e.rec_bytes;
         d.scale = e.scale;
+        if (a.stripe_n) d.rec += a.stripe_delta[d.page % a.stripe_n];     // staged copy of the record (copy-engine fetch)
     } else {
         d.rec = a.recs + d.page * a.rec_stride;
         d.len = a.rec_bytes[d.page];
         d.scale = a.scales ? a.scales[d.page] : 1.0f;
     }
-    d.dst = a.data_list ? reinterpret_cast<uint8_t*>(a.data_list[i]) : a.data + i * a.data_stride;
+    if (a.ring_owner) d.dst = a.ring_base + (static_cast<uint64_t>(slot0) + i) * kPageSize;
+    else d.dst = a.data_list ? reinterpret_cast<uint8_t*>(a.data_list[i]) : a.data + i * a.data_stride;
     return d;
+}
+
+// Ring bookkeeping of one fetched block (one lane): see CodecArgs::ring_owner.
+__device__ __forceinline__ void ring_note(const CodecArgs& a, const BlockDesc& d, uint32_t slot)
+{
+    const uint64_t prev = a.ring_owner[slot];
+    const uint64_t me = (static_cast<uint64_t>(d.row) << 32) | d.page;
+    if (prev != kNoOwner && prev != me) {
+        const DevAlloc t = a.tab[prev >> 32];
+        const uint32_t pp = static_cast<uint32_t>(prev);
+        if (t.entries && t.d_slot[pp] == slot) {                    // still pointing here: the page leaves L2
+            const uint32_t v = atomicAnd(&t.d_flags[pp], ~2u) & ~2u;
+            t.h_flags[pp] = v;
+        }
+    }
+    a.ring_owner[slot] = me;
+    const DevAlloc t = a.tab[d.row];
+    t.d_slot[d.page] = slot;
+    t.h_slot[d.page] = slot;
+    const uint32_t v = atomicOr(&t.d_flags[d.page], 2u) | 2u;
+    t.h_flags[d.page] = v;
 }
 
 template <int SCHEME, int MODE, bool F32>
@@ -462,15 +488,17 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint64_t n = a.n;
     if (a.n_dev) { const uint64_t nd = *a.n_dev; n = nd < n ? nd : n; }
+    const uint32_t slot0 = a.slot0_dev ? *a.slot0_dev : a.slot0;
+    if (a.hand_ptr && blockIdx.x == 0 && threadIdx.x == 0) *a.hand_ptr = a.new_hand;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kWaves;
     uint64_t i = static_cast<uint64_t>(blockIdx.x) * kWaves + wave;
     if (i >= n) return;
-    BlockDesc cur = load_desc(a, i);
+    BlockDesc cur = load_desc(a, i, slot0);
     for (;;) {
         // the next block's descriptor is fetched while this block is decoded
         const uint64_t nx = i + stride;
         BlockDesc nxt = cur;
-        if (nx < n) nxt = load_desc(a, nx);
+        if (nx < n) nxt = load_desc(a, nx, slot0);
         uint32_t len = cur.len;
         if (SCHEME == kInt8DeltaRle) {
             if (len > 2u * kBlockElems) len = 2u * kBlockElems;
@@ -490,8 +518,10 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
             if (len > 2u * kBlockElems) len = 2u * kBlockElems;
             decode_fp16<F32>(cur.rec, len, cur.dst, lane);
         }
-        if (a.flags && lane == 0u)
-            atomicOr(&a.flags[cur.page], a.set_flags);       // neighbours belong to other waves / XCDs
+        if (lane == 0u) {
+            if (a.ring_owner) ring_note(a, cur, slot0 + static_cast<uint32_t>(i));
+            else if (a.flags) atomicOr(&a.flags[cur.page], a.set_flags);   // neighbours belong to other waves / XCDs
+        }
         if (nx >= n) break;
         cur = nxt;
         i = nx;
@@ -924,6 +954,106 @@ __global__ __launch_bounds__(1024) void k_scan_totals(const uint32_t* __restrict
 }
 
 // ===================================================================
+// device-side prefetch flush  (prefetch_core.v:150-241: the whole loop without the host)
+// ===================================================================
+// Candidate words live at a fixed stride: request r, lane c (kind, look-ahead step), word t -> index
+// (r*32 + c)*W + t, kNoSlot when unused.  Request order = index order, so "first occurrence" of a page is the
+// smallest index naming it: every valid candidate does atomicMax(stamp[page], key(index)) with
+// key = epoch<<24 | (0xFFFFFF - index); the candidate whose key survives is the one kept.  Stamps of older
+// flushes carry an older epoch and lose against any key of this one (the host clears them when the 8-bit epoch wraps).
+__device__ __forceinline__ uint32_t flush_key(uint32_t epoch, uint32_t index) { return (epoch << 24) | (0xFFFFFFu - index); }
+
+__global__ __launch_bounds__(256) void k_flush_candidates(FlushArgs a)
+{
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (request, lane)
+    const uint32_t r = gt >> 5, c = gt & 31u;
+    if (r >= a.n) return;
+    const uint32_t row = a.row[r];
+    Cand cd{0u, 0u};
+    DevAlloc t{};
+    if (row != kNoSlot) {
+        t = a.tab[row];
+        if (t.entries) {
+            uint32_t dk = a.depth[r];
+            if (dk > 16u) dk = 16u;
+            cd = candidate(t.layout, a.req[r], a.layer[r], a.pos[r], dk, c);
+        }
+    }
+    const uint32_t base = gt * a.W;
+    for (uint32_t w = 0; w < a.W; ++w) {
+        uint32_t pg = kNoSlot;
+        if (cd.lo + w < cd.hi && !(t.d_flags[cd.lo + w] & 3u)) {
+            pg = cd.lo + w;
+            atomicMax(&t.stamp[pg], flush_key(a.epoch, base + w));
+        }
+        a.cand[base + w] = pg;
+    }
+}
+
+// keep[i] = candidate i is the first occurrence of its page; WRITE = false: per-wave totals, true: ordered scatter
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_flush_mark(FlushArgs a, const FlushResult* __restrict__ res)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total = a.n * 32u * a.W;
+    bool keep = false;
+    uint32_t pg = kNoSlot, row = kNoSlot;
+    if (i < total) {
+        pg = a.cand[i];
+        if (pg != kNoSlot) {
+            row = a.row[i / (32u * a.W)];
+            keep = a.tab[row].stamp[pg] == flush_key(a.epoch, i);
+        }
+    }
+    const unsigned long long mask = __ballot(keep);
+    const uint32_t w = i >> 6;
+    if (!WRITE) {
+        if (lane == 0u && i < total) a.wave_tot[w] = static_cast<uint32_t>(__popcll(mask));
+    } else if (keep) {
+        const uint32_t n_w = (total + 63u) >> 6;
+        const uint32_t rank = a.wave_tot[n_w + w] + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+        if (rank < res->m) { a.final_page[rank] = pg; a.final_row[rank] = row; }
+    }
+}
+
+// one workgroup: exclusive scan of the wave totals, then the ring run [base, base+m) (a run never wraps, as
+// Engine::take_l2_run on the host: same rule, so host and device agree on the hand)
+__global__ __launch_bounds__(1024) void k_flush_assign(FlushArgs a)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t running;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n_w = (a.n * 32u * a.W + 63u) >> 6;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n_w; i0 += 1024u) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint32_t v = (i < n_w) ? a.wave_tot[i] : 0u;
+        const uint32_t incl = wave_incl_add(v);
+        if (lane == 63u) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (uint32_t w = 0; w < wave; ++w) wbase += wsum[w];
+        const uint32_t run = running;
+        if (i < n_w) a.wave_tot[n_w + i] = run + wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023u) running = run + wbase + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t total = running;
+        const uint32_t m = total < a.max_take ? total : a.max_take;
+        uint32_t start = *a.hand % a.n_l2;
+        if (start + m > a.n_l2) start = 0;
+        if (m) *a.hand = start + m;
+        const FlushResult r{m, start, total, 0u};
+        *a.result_dev = r;
+        *a.result_host = r;
+    }
+}
+
+// ===================================================================
 // verify  (speculative_prefetcher.cpp:84-96): hit[r] = actual[r] in predicted[r][0..k)
 // ===================================================================
 // One request per lane; the 64-bit __ballot of the per-lane result is the
@@ -949,15 +1079,16 @@ __global__ __launch_bounds__(256) void k_verify(uint32_t n, uint32_t k,
     if (lane == 0u && mask) atomicAdd(hit_count, static_cast<uint32_t>(__popcll(mask)));
 }
 
-__global__ void k_update_flags(uint32_t* flags, const uint32_t* pages, uint32_t n,
-                               uint32_t and_mask, uint32_t or_mask)
+__global__ void k_apply_updates(const DevAlloc* __restrict__ tab, const MirrorUpdate* __restrict__ up, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const uint32_t p = pages[i];
-        if (and_mask != 0xFFFFFFFFu) atomicAnd(&flags[p], and_mask);
-        if (or_mask) atomicOr(&flags[p], or_mask);
-    }
+    if (i >= n) return;
+    const MirrorUpdate u = up[i];
+    const DevAlloc t = tab[u.alloc_idx];
+    if (!t.entries) return;
+    if (u.and_mask != 0xFFFFFFFFu) atomicAnd(&t.d_flags[u.page], u.and_mask);
+    if (u.or_mask) atomicOr(&t.d_flags[u.page], u.or_mask);
+    if (u.slot != kKeepSlot) t.d_slot[u.page] = u.slot;
 }
 
 __global__ void k_init_entries(PageEntry* e, uint64_t n, uint64_t base, uint64_t stride)
@@ -1329,6 +1460,20 @@ hipError_t launch_prefetch_lookup(const Layout& lay, uint32_t n, const uint32_t*
     return hipGetLastError();
 }
 
+hipError_t launch_flush_pipeline(const FlushArgs& a, hipStream_t s)
+{
+    if (a.n == 0 || a.W == 0) return hipErrorInvalidValue;
+    const uint64_t total = static_cast<uint64_t>(a.n) * 32u * a.W;
+    if (total >= (1ull << 24)) return hipErrorInvalidValue;        // the dedupe key carries 24 index bits
+    const uint32_t g_lane = static_cast<uint32_t>((static_cast<uint64_t>(a.n) * 32u + 255u) / 256u);
+    const uint32_t g_word = static_cast<uint32_t>((total + 255u) / 256u);
+    hipLaunchKernelGGL(k_flush_candidates, dim3(g_lane), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_flush_mark<false>), dim3(g_word), dim3(256), 0, s, a, static_cast<const FlushResult*>(nullptr));
+    hipLaunchKernelGGL(k_flush_assign, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL((k_flush_mark<true>), dim3(g_word), dim3(256), 0, s, a, static_cast<const FlushResult*>(a.result_dev));
+    return hipGetLastError();
+}
+
 hipError_t launch_verify(uint32_t n, uint32_t k, const int32_t* d_actual,
                          const int32_t* d_predicted, uint8_t* d_hit, uint32_t* d_hit_count,
                          hipStream_t s)
@@ -1383,12 +1528,10 @@ hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb,
     return hipGetLastError();
 }
 
-hipError_t launch_update_flags(uint32_t* d_flags, const uint32_t* d_pages, uint32_t n,
-                               uint32_t and_mask, uint32_t or_mask, hipStream_t s)
+hipError_t launch_apply_updates(const DevAlloc* d_tab, const MirrorUpdate* d_updates, uint32_t n, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_update_flags, dim3((n + 255u) / 256u), dim3(256), 0, s, d_flags, d_pages, n,
-                       and_mask, or_mask);
+    hipLaunchKernelGGL(k_apply_updates, dim3((n + 255u) / 256u), dim3(256), 0, s, d_tab, d_updates, n);
     return hipGetLastError();
 }
 

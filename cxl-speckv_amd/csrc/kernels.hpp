@@ -24,8 +24,32 @@ struct PageEntry {
     float    scale;       // per-block scale factor
 };
 
+// Shim layout (vllm_speckv_backend.py:87-100) of the allocation a lookup runs on.
+struct Layout {
+    uint32_t num_tokens, num_layers, num_heads, head_dim, bytes_per_element;
+    uint64_t alloc_pages;
+};
+
+// One row of the device allocation table: what kernels that work across allocations (the prefetch pipeline, the
+// ring bookkeeping of the fetch kernel) need to know about an allocation.  A freed row has entries == nullptr.
+//   d_flags / d_slot : residency mirror in HBM (bit0 L1, bit1 L2; cache slot) -- what kernels read
+//   h_flags / h_slot : the same words in pinned host memory (device-visible) -- what the host reads; kernels that
+//                      change a page's residency store the new value to both
+//   stamp            : per-page scratch word of the flush's first-occurrence dedupe
+struct DevAlloc {
+    PageEntry* entries;
+    uint32_t*  d_flags;
+    uint32_t*  d_slot;
+    uint32_t*  h_flags;
+    uint32_t*  h_slot;
+    uint32_t*  stamp;
+    Layout     layout;
+};
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+constexpr uint64_t kNoOwner = ~0ull;
+
 // Source / destination description of one codec launch.  Exactly one of
-// {entries, recs} is used as the record source.
+// {entries, recs, tab+alloc_list} is used as the record source.
 struct CodecArgs {
     // record side
     PageEntry*      entries;      // page table (engine form), indexed by page
@@ -57,16 +81,28 @@ struct CodecArgs {
     // (layer, kind) region of the shim layout, a multiple of 16
     float*          scale_tab;
     uint32_t        region_pages;
+    // blocks of several allocations in one launch (decompress only): block i belongs to row alloc_list[i] of tab
+    const DevAlloc* tab;
+    const uint32_t* alloc_list;
+    // L2-ring bookkeeping done by the fetch kernel itself (decompress only, ring_owner != nullptr): block i lands in
+    // cache slot slot0 + i (dst = ring_base + slot*4096); the wave evicts the slot's previous owner (clears its L2 bit
+    // if it still points at this slot), records the new owner, the page's slot and its L2 bit, in HBM and in the
+    // host-visible mirror.  slot0 comes from slot0_dev when set (device-side flush), else from slot0.
+    uint64_t*       ring_owner;
+    uint8_t*        ring_base;
+    const uint32_t* slot0_dev;
+    uint32_t        slot0;
+    uint32_t        alloc_idx;    // row of tab for every block when alloc_list == nullptr
+    uint32_t*       hand_ptr;     // optional: block 0 stores new_hand (host-initiated takes keep the device hand current)
+    uint32_t        new_hand;
+    // copy-engine fetch: the records of pool (page % stripe_n) were copied into local staging, to their pool address
+    // + stripe_delta[page % stripe_n]
+    uint32_t        stripe_n;
+    int64_t         stripe_delta[8];
 };
 
 hipError_t launch_compress(const CodecArgs& a, hipStream_t s);
 hipError_t launch_decompress(const CodecArgs& a, hipStream_t s);
-
-// Shim layout (vllm_speckv_backend.py:87-100) of the allocation a lookup runs on.
-struct Layout {
-    uint32_t num_tokens, num_layers, num_heads, head_dim, bytes_per_element;
-    uint64_t alloc_pages;
-};
 
 // Prefetch lookup: 3 kernels (mask+count, scan, scatter) -> compacted page list
 // in request order.  scratch must hold (2*n + 2) uint32.
@@ -80,9 +116,38 @@ hipError_t launch_verify(uint32_t n, uint32_t k, const int32_t* d_actual,
                          const int32_t* d_predicted, uint8_t* d_hit,
                          uint32_t* d_hit_count, hipStream_t s);
 
-// flags[pages[i]] = (flags[pages[i]] & and_mask) | or_mask
-hipError_t launch_update_flags(uint32_t* d_flags, const uint32_t* d_pages, uint32_t n,
-                               uint32_t and_mask, uint32_t or_mask, hipStream_t s);
+// Host-originated residency changes applied to the device mirrors: for each update,
+// d_flags[page] = (d_flags[page] & and_mask) | or_mask and, unless slot == kKeepSlot, d_slot[page] = slot.
+struct MirrorUpdate { uint32_t alloc_idx, page, and_mask, or_mask, slot, pad; };
+constexpr uint32_t kKeepSlot = 0xFFFFFFFEu;
+hipError_t launch_apply_updates(const DevAlloc* d_tab, const MirrorUpdate* d_updates, uint32_t n, hipStream_t s);
+
+// Device-side prefetch flush (prefetch_core.v:150-241: predict -> encode -> translate -> directory check -> issue,
+// without the host).  n requests (SoA: local request index inside the allocation, layer, position, depth, table row)
+// -> candidate pages in request order (fixed stride of 32*W words per request), first-occurrence dedupe through the
+// per-page stamps, ordered compaction, ring-slot assignment, and the final (page, row) lists a fetch launch consumes.
+struct FlushResult { uint32_t m, base, total, pad; };      // pages taken, first ring slot, distinct candidates found
+struct FlushArgs {
+    const DevAlloc* tab;
+    uint32_t        n;            // requests
+    uint32_t        W;            // candidate words per lane (max new pages of one position + 1)
+    const uint32_t* req;          // [n] request index inside its allocation
+    const uint32_t* layer;
+    const uint32_t* pos;
+    const uint32_t* depth;
+    const uint32_t* row;          // [n] table row (kNoSlot = unaddressable request: contributes nothing)
+    uint32_t        epoch;        // 1..255, stamps of older epochs are ignored
+    uint32_t*       cand;         // [n*32*W]
+    uint32_t*       wave_tot;     // [n*W/2 rounded up] + same again for the bases
+    uint32_t*       final_page;   // [max_take]
+    uint32_t*       final_row;    // [max_take]
+    uint32_t        max_take;     // never more than this many pages per flush
+    uint32_t        n_l2;         // ring size
+    uint32_t*       hand;         // device ring hand
+    FlushResult*    result_dev;   // read by the fetch launch (n_dev = &m, slot0_dev = &base)
+    FlushResult*    result_host;  // the same, stored to pinned host memory
+};
+hipError_t launch_flush_pipeline(const FlushArgs& a, hipStream_t s);
 
 // entries[first+i].pool_addr = base + i*stride ; rec_bytes = 0 ; scale = 1
 hipError_t launch_init_entries(PageEntry* d_entries, uint64_t n, uint64_t base,

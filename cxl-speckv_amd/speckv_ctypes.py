@@ -39,7 +39,8 @@ class Stats(ctypes.Structure):
         "total_allocations", "total_deallocations", "current_allocated_bytes", "peak_allocated_bytes",
         "dma_submitted", "dma_completed", "pool_bytes_reserved", "cache_bytes_reserved")] + \
         [(n, c_uint32) for n in ("prefetch_depth", "compression_scheme", "quant_mode", "n_pool_devices")] + \
-        [("pool_migrated_pages", c_uint64)]
+        [("pool_migrated_pages", c_uint64), ("prefetch_dropped", c_uint64), ("copy_engine_runs", c_uint64),
+         ("copy_engine_bytes", c_uint64)]
 
 
 _u32p = ctypes.POINTER(c_uint32)
@@ -53,6 +54,8 @@ _EXT_SIGNATURES = {
     "speckv_ext_write": [c_uint64, c_uint64, c_void_p, c_size_t, c_int],
     "speckv_ext_read": [c_uint64, c_uint64, c_void_p, c_size_t, c_int],
     "speckv_ext_fetch_range": [c_uint64, c_uint64, c_uint64, c_void_p, c_int, c_void_p],
+    "speckv_ext_fetch_range_engine": [c_uint64, c_uint64, c_uint64, c_void_p, c_int, c_void_p, c_int],
+    "speckv_ext_bind_request": [c_uint32, c_uint64, c_uint32],
     "speckv_ext_fetch_list": [c_uint64, c_void_p, c_uint32, c_void_p, c_int, c_void_p],
     "speckv_ext_access_batch": [c_uint64, _u64p, c_uint32, ctypes.POINTER(c_void_p)],
     "speckv_ext_prefetch_batch": [c_uint32, _u32p, ctypes.POINTER(c_uint16), _u32p, _u32p],
@@ -205,8 +208,18 @@ class SpeckvLib:
     def read(self, handle, offset, dst_ptr, nbytes, on_device):
         self._ext("speckv_ext_read", handle, offset, c_void_p(dst_ptr), nbytes, int(on_device))
 
-    def fetch_range(self, handle, first_page, n_pages, d_dst, out_f32=False, stream=None):
-        self._ext("speckv_ext_fetch_range", handle, first_page, n_pages, c_void_p(d_dst), int(out_f32), c_void_p(stream or 0))
+    ENGINE_AUTO, ENGINE_KERNEL, ENGINE_COPY = 0, 1, 2
+
+    def fetch_range(self, handle, first_page, n_pages, d_dst, out_f32=False, stream=None, engine=None):
+        """engine: None/0 = chosen per batch, 1 = fused peer-load + decompress kernel, 2 = copy engines + local decompress."""
+        if engine:
+            self._ext("speckv_ext_fetch_range_engine", handle, first_page, n_pages, c_void_p(d_dst), int(out_f32),
+                      c_void_p(stream or 0), int(engine))
+        else:
+            self._ext("speckv_ext_fetch_range", handle, first_page, n_pages, c_void_p(d_dst), int(out_f32), c_void_p(stream or 0))
+
+    def bind_request(self, req_id, handle, local_req=0):
+        self._ext("speckv_ext_bind_request", req_id, handle, local_req)
 
     def fetch_list(self, handle, d_pages, n, d_dst, out_f32=False, stream=None):
         self._ext("speckv_ext_fetch_list", handle, c_void_p(d_pages), n, c_void_p(d_dst), int(out_f32), c_void_p(stream or 0))
@@ -224,7 +237,12 @@ class SpeckvLib:
         self._ext("speckv_ext_prefetch_batch", n, (c_uint32 * n)(*req_ids), (c_uint16 * n)(*layers),
                   (c_uint32 * n)(*cur_pos), k)
 
-    def prefetch_flush(self):
+    def prefetch_flush(self, want_count=True):
+        """Submit the queued look-ahead requests (device-side pipeline).  want_count=False only submits; True also
+        waits for the page count (not for the data)."""
+        if not want_count:
+            self._ext("speckv_ext_prefetch_flush", None)
+            return None
         n = c_uint32()
         self._ext("speckv_ext_prefetch_flush", ctypes.byref(n))
         return n.value

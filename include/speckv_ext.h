@@ -91,6 +91,16 @@ speckv_status_t speckv_ext_read(speckv_handle_t handle, uint64_t offset_bytes,
 speckv_status_t speckv_ext_fetch_range(speckv_handle_t handle, uint64_t first_page,
                                        uint64_t n_pages, void* d_dst, int out_f32,
                                        void* stream);
+/* The same with the fetch engine chosen by the caller: 0 = per batch (long runs on remote pools -> copy engines,
+ * everything else -> fused kernel; SPECKV_REMOTE_ENGINE=kernel|copy overrides), 1 = fused peer-load + decompress
+ * kernel, 2 = copy engines: the range's contiguous record runs (one per pool GPU, because pages are striped) are
+ * copied with hipMemcpyPeerAsync on per-peer side streams into local staging and decompressed from there,
+ * double-buffered.  Stands in for the reference's DMA path (one descriptor per page through the DMA engine:
+ * host/src/speckv_allocator.cpp:115-138, hardware/rtl/dma_engine.v:150-217).  Engine 2 needs the default striped
+ * placement (SPECKV_ERR_INVAL after a migration or on a fragmented allocation). */
+speckv_status_t speckv_ext_fetch_range_engine(speckv_handle_t handle, uint64_t first_page,
+                                              uint64_t n_pages, void* d_dst, int out_f32,
+                                              void* stream, int engine);
 /* Same for an arbitrary device-resident page list. */
 speckv_status_t speckv_ext_fetch_list(speckv_handle_t handle, const uint32_t* d_pages,
                                       uint32_t n, void* d_dst, int out_f32, void* stream);
@@ -99,12 +109,19 @@ speckv_status_t speckv_ext_access_batch(speckv_handle_t handle, const uint64_t* 
                                         uint32_t n, void** out_ptrs);
 
 /* ---- speculative prefetch (speculative_prefetcher.cpp:25-82, prefetch_core.v:150-241) */
-/* Batched speckv_prefetch: host arrays of n requests against the handle that
- * last received speckv_ext_set_layout. */
+/* Which allocation a request id of speckv_prefetch / speckv_ext_prefetch_batch addresses: request `req_id` is
+ * request `local_req` of `handle`'s layout (one allocation per sequence: local_req 0).  handle 0 removes the binding.
+ * Unbound request ids index into the most recently laid-out (else most recently allocated) allocation, as in the
+ * reference's single-allocation shim (vllm_speckv_backend.py:95-100); requests that address nothing are counted in
+ * speckv_ext_stats_t.prefetch_dropped. */
+speckv_status_t speckv_ext_bind_request(uint32_t req_id, speckv_handle_t handle, uint32_t local_req);
+/* Batched speckv_prefetch: host arrays of n requests (see speckv_ext_bind_request). */
 speckv_status_t speckv_ext_prefetch_batch(uint32_t n, const uint32_t* req_ids,
                                           const uint16_t* layers, const uint32_t* cur_pos,
                                           const uint32_t* depth_k);
-/* Drain queued prefetch requests now; *n_issued = pages fetched into L2. */
+/* Drain queued prefetch requests now: candidates, residency filter, dedupe, ring-slot assignment and the fetch all
+ * run on the device; the call only submits (no host round trip).  n_issued may be NULL; when given, the call waits
+ * for the (small) assignment kernel and returns the number of pages being fetched into L2. */
 speckv_status_t speckv_ext_prefetch_flush(uint32_t* n_issued);
 /* The raw lookup kernel on device buffers: for request r, candidate pages of
  * positions cur_pos+1..cur_pos+depth_k (K then V), residency-filtered with the
@@ -247,6 +264,9 @@ typedef struct {
     uint64_t pool_bytes_reserved, cache_bytes_reserved;
     uint32_t prefetch_depth, compression_scheme, quant_mode, n_pool_devices;
     uint64_t pool_migrated_pages;
+    uint64_t prefetch_dropped;      /* speckv_prefetch requests that could not be addressed (no geometry / binding) */
+    uint64_t copy_engine_runs;      /* hipMemcpyPeerAsync runs issued by the copy-engine fetch */
+    uint64_t copy_engine_bytes;     /* bytes they moved into local staging */
 } speckv_ext_stats_t;
 speckv_status_t speckv_ext_stats(speckv_ext_stats_t* out);
 
