@@ -202,6 +202,8 @@ int Engine::init_hip(int device)
     tab_cap_ = 4096;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tab_), tab_cap_ * sizeof(DevAlloc)));
     HIP_TRY(hipMemsetAsync(d_tab_, 0, tab_cap_ * sizeof(DevAlloc), stream_));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_tab_), tab_cap_ * sizeof(DevAlloc), hipHostMallocDefault));
+    memset(h_tab_, 0, tab_cap_ * sizeof(DevAlloc));
     row_owner_.assign(tab_cap_, nullptr);
     for (uint32_t i = 0; i < tab_cap_; ++i) free_rows_.push_back(tab_cap_ - 1 - i);
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&res_ring_), kResSlots * sizeof(FlushResult), hipHostMallocMapped | hipHostMallocPortable));
@@ -255,6 +257,7 @@ Engine::~Engine()
     if (upd_ring_) (void)hipHostFree(upd_ring_);
     if (upd_event_) (void)hipEventDestroy(upd_event_);
     if (d_tab_) (void)hipFree(d_tab_);
+    if (h_tab_) (void)hipHostFree(h_tab_);
     if (d_owner_) (void)hipFree(d_owner_);
     if (d_hand_) (void)hipFree(d_hand_);
     if (cache_base_) (void)hipFree(cache_base_);
@@ -343,8 +346,9 @@ int Engine::publish_row(Allocation* a)
     r.h_flags = static_cast<uint32_t*>(dp);
     r.h_slot = r.h_flags + a->n_pages;
     r.layout = a->has_layout ? a->layout : Layout{0, 0, 0, 0, 0, a->n_pages};
-    // 80 bytes from the stack: HIP stages pageable sources before it returns
-    HIP_TRY(hipMemcpyAsync(d_tab_ + a->row, &r, sizeof(r), hipMemcpyHostToDevice, stream_));
+    // the copy reads its source when the stream gets to it: the source is the row's own slot in a pinned mirror
+    h_tab_[a->row] = r;
+    HIP_TRY(hipMemcpyAsync(d_tab_ + a->row, h_tab_ + a->row, sizeof(r), hipMemcpyHostToDevice, stream_));
     return SPECKV_OK;
 }
 
@@ -564,8 +568,8 @@ int Engine::free(uint64_t handle)
     // The table row is cleared in stream order (kernels already queued still see it); the memory itself goes back to
     // the pool once the engine stream has passed this point and every caller stream that was handed work on the
     // allocation has drained -- without stalling the device, and without blocking this call when they have not.
-    const DevAlloc empty{};
-    (void)hipMemcpyAsync(d_tab_ + a->row, &empty, sizeof(empty), hipMemcpyHostToDevice, stream_);
+    h_tab_[a->row] = DevAlloc{};
+    (void)hipMemcpyAsync(d_tab_ + a->row, h_tab_ + a->row, sizeof(DevAlloc), hipMemcpyHostToDevice, stream_);
     Zombie z{std::move(a), get_event()};
     if (z.engine_ev) (void)hipEventRecord(z.engine_ev, stream_);
     else (void)hipStreamSynchronize(stream_);

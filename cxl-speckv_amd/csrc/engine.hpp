@@ -166,6 +166,7 @@ private:
 
     // device allocation table
     DevAlloc* d_tab_ = nullptr;
+    DevAlloc* h_tab_ = nullptr;            // pinned mirror: the source of every (asynchronous) row update
     uint32_t tab_cap_ = 0;
     std::vector<uint32_t> free_rows_;
     std::vector<Allocation*> row_owner_;

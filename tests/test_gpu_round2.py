@@ -1,0 +1,387 @@
+"""-m gpu: what round 2 added to the engine, against the oracle / against the round-1 paths.
+
+  * device-side prefetch flush: first-occurrence order, ring slots in that order, many allocations per flush,
+    ring wrap / eviction done by the fetch kernel;
+  * copy-engine fetch (hipMemcpyPeerAsync runs + local decompress) == fused peer-load kernel, bit for bit;
+  * migration frees exact record runs;
+  * speckv_prefetch under the reference's unchanged shim (8 symbols only);
+  * speckv_free does not stall on the device; batch attention refuses stream capture.
+The "peers" are pools on the same GPU (SPECKV_POOL_DEVICES=0,0,0): placement, copies and bookkeeping are the code
+that runs across xGMI; only the link is missing on a one-GPU box.
+"""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import pytest
+
+import cxl_speckv_amd as pkg
+from cxl_speckv_amd.speckv_ctypes import SpeckvError
+from tests._gpu import N, assert_same_float_bits, dev_to_host, torch_mod
+from tests.test_gpu_engine import synth
+
+pytestmark = pytest.mark.gpu
+PAGE = 4096
+
+
+def open_lib(**env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return pkg.SpeckvLib(pkg.library_path(), "hip:0")
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def expected_flush(oracle, reqs, geom, n_pages, resident=()):
+    """Oracle: candidate pages of every request in request order, first occurrence kept, resident pages skipped."""
+    T, L, H, D, bpe = geom
+    seen, out = set(resident), []
+    fl = np.zeros(n_pages, np.uint32)
+    for p in resident:
+        fl[p] = 2
+    for (req, layer, pos, k) in reqs:
+        for p in oracle.prefetch_pages(req, layer, pos, k, L, T, H, D, bpe, n_pages, fl).tolist():
+            if p not in seen:
+                seen.add(p); out.append(p)
+    return out
+
+
+def test_flush_keeps_first_occurrence_order_and_assigns_slots_in_it(oracle):
+    lib = open_lib(SPECKV_L2_MB=64)
+    try:
+        lib.set_compression_scheme(2)
+        geom = (T, L, H, D, bpe) = (1024, 6, 8, 128, 2)
+        n_pages = 2 * T * L * H * D * bpe // PAGE
+        h = lib.alloc(n_pages * PAGE)
+        lib.set_layout(h, *geom)
+        x = synth(n_pages, seed=5)
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+        rng = np.random.default_rng(77)
+        n = 700
+        reqs = [(0, int(rng.integers(0, L)), int(rng.integers(0, 64)) * 2, int(rng.integers(1, 9))) for _ in range(n)]
+        reqs += reqs[:50]                                      # exact duplicates, overlapping look-aheads everywhere
+        pre = [3, 4, 1025]                                     # already resident: must be filtered
+        for p in pre:
+            lib.access(h, p * PAGE, 8)
+        want = expected_flush(oracle, reqs, geom, n_pages, resident=pre)
+        lib.prefetch_batch([r[0] for r in reqs], [r[1] for r in reqs], [r[2] for r in reqs], [r[3] for r in reqs])
+        issued = lib.prefetch_flush()
+        assert issued == len(want)
+        lib.sync()
+        infos = [lib.translate(h, p * PAGE) for p in want]
+        assert all(i.flags & 2 for i in infos)
+        base = infos[0].cache_addr
+        assert [i.cache_addr - base for i in infos] == [j * PAGE for j in range(len(want))]   # slot = first slot + rank
+        resident = {p for p in range(n_pages) if lib.translate(h, p * PAGE).flags & 3}
+        assert resident == set(want) | set(pre)
+        scales, lens, recs = oracle.compress_blocks_f16(x, 2, 0)
+        for j in (0, 1, len(want) // 2, len(want) - 1):
+            p = want[j]
+            dec = oracle.decompress_block_f16(recs[p, :lens[p]], scales[p], 2, 0, N)
+            assert_same_float_bits(dev_to_host(infos[j].cache_addr, PAGE).view(np.float16), dec)
+        st = lib.stats()
+        assert st.total_prefetches == len(want) and st.prefetch_dropped == 0
+        assert lib.poll_complete() >= len(want)
+        # the same requests again: everything is resident, nothing is issued
+        lib.prefetch_batch([r[0] for r in reqs], [r[1] for r in reqs], [r[2] for r in reqs], [r[3] for r in reqs])
+        assert lib.prefetch_flush() == 0
+    finally:
+        lib.finalize()
+
+
+def test_flush_over_many_allocations_with_request_bindings(oracle):
+    """One allocation per sequence (the serving layout): request ids are bound to handles, one flush serves them all."""
+    lib = open_lib()
+    try:
+        lib.set_compression_scheme(1)
+        geom = (T, L, H, D, bpe) = (256, 4, 8, 128, 2)
+        n_pages = 2 * T * L * H * D * bpe // PAGE
+        n_seq = 12
+        hs, data = [], []
+        for s in range(n_seq):
+            h = lib.alloc(n_pages * PAGE)
+            lib.set_layout(h, *geom)
+            x = synth(n_pages, seed=100 + s)
+            lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+            lib.bind_request(1000 + s, h, 0)
+            hs.append(h); data.append(x)
+        pos = [10 + 6 * s for s in range(n_seq)]
+        reqs, layers, poss = [], [], []
+        for s in range(n_seq):
+            for layer in range(L):
+                reqs.append(1000 + s); layers.append(layer); poss.append(pos[s])
+        reqs += [5, 77777]; layers += [0, 1]; poss += [4, 4]        # unbound ids address the newest allocation as req 5 / 77777: out of range
+        lib.prefetch_batch(reqs, layers, poss, [4] * len(reqs))
+        issued = lib.prefetch_flush()
+        lib.sync()
+        total = 0
+        for s in range(n_seq):
+            want = expected_flush(oracle, [(0, layer, pos[s], 4) for layer in range(L)], geom, n_pages)
+            got = {p for p in range(n_pages) if lib.translate(hs[s], p * PAGE).flags & 2}
+            assert got == set(want), s
+            total += len(want)
+            p = want[-1]
+            ptr = lib.access(hs[s], p * PAGE, 16)
+            sc, ln, rc = oracle.compress_blocks_f16(data[s][p:p + 1], 1, 0)
+            dec = oracle.decompress_block_f16(rc[0, :ln[0]], sc[0], 1, 0, N)
+            assert_same_float_bits(dev_to_host(ptr, PAGE).view(np.float16), dec)
+        assert issued == total
+        st = lib.stats()
+        assert st.prefetch_dropped == 2 and st.total_prefetches == total
+        # a freed allocation takes its binding with it; its requests are dropped, the others still work
+        lib.free(hs[0])
+        lib.prefetch_batch([1000, 1001], [0, 0], [100, 100], [2, 2])
+        assert lib.prefetch_flush() > 0
+        assert lib.stats().prefetch_dropped == 3
+    finally:
+        lib.finalize()
+
+
+def test_ring_wrap_and_eviction_by_the_fetch_kernel(oracle):
+    """A ring of 256 slots under flushes that wrap it several times: what is flagged resident really is there, evicted
+    pages lose their bit, synchronous misses interleave with flushes, the host's ring hand stays in step."""
+    lib = open_lib(SPECKV_L2_MB=1, SPECKV_L1_MB=1)
+    try:
+        lib.set_compression_scheme(1)
+        geom = (T, L, H, D, bpe) = (512, 2, 8, 128, 2)
+        n_pages = 2 * T * L * H * D * bpe // PAGE            # 2048
+        h = lib.alloc(n_pages * PAGE)
+        lib.set_layout(h, *geom)
+        x = synth(n_pages, seed=9)
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+        y = np.empty_like(x); lib.read(h, 0, y.ctypes.data, y.nbytes, False)
+        rng = np.random.default_rng(3)
+        for step in range(40):
+            n = int(rng.integers(1, 30))
+            lib.prefetch_batch([0] * n, [int(v) for v in rng.integers(0, L, n)], [int(v) * 2 for v in rng.integers(0, T // 2 - 10, n)],
+                               [int(v) for v in rng.integers(1, 9, n)])
+            issued = lib.prefetch_flush()
+            assert issued <= 128                                  # never more than half the ring per flush
+            if step % 3 == 0:                                     # a synchronous miss between flushes
+                p = int(rng.integers(0, n_pages))
+                ptr = lib.access(h, p * PAGE, 8)
+                assert dev_to_host(ptr, PAGE).tobytes() == y[p].tobytes()
+            if step % 5 == 4:
+                lib.sync()
+                infos = [(p, lib.translate(h, p * PAGE)) for p in range(n_pages)]
+                res = [(p, i) for p, i in infos if i.flags & 2]
+                assert len(res) <= 256
+                assert len({i.cache_addr for _, i in res}) == len(res)              # one page per slot
+                for p, i in res[::7]:
+                    assert dev_to_host(i.cache_addr, PAGE).tobytes() == y[p].tobytes()
+        assert lib.stats().total_prefetches > 256 * 3
+    finally:
+        lib.finalize()
+
+
+@pytest.mark.parametrize("scheme", [2, 0, 4, 3])
+def test_copy_engine_fetch_equals_kernel_fetch(scheme):
+    """speckv_ext_fetch_range_engine: engine 2 (coalesced hipMemcpyPeerAsync runs on per-peer streams into staging, local
+    decompress, double-buffered) against engine 1 (fused peer-load kernel), pool striped over three peers."""
+    torch = torch_mod()
+    lib = open_lib(SPECKV_POOL_DEVICES="0,0,0", SPECKV_STAGE_MB=1)      # 1 MiB staging: many chunks
+    try:
+        lib.set_compression_scheme(scheme)
+        n = 5000                                                      # not a multiple of 3, > several chunks
+        h = lib.alloc(n * PAGE)
+        x = synth(n, seed=33 + scheme)
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+        s = torch.cuda.Stream()
+        for first, cnt, f32 in ((0, n, False), (1, n - 1, False), (7, 1000, True), (4999, 1, False), (2, 2, False), (100, 0, False)):
+            a = torch.full((max(cnt, 1), N * (2 if f32 else 1)), -1, dtype=torch.int16, device="cuda")
+            b = torch.full_like(a, -2)
+            lib.fetch_range(h, first, cnt, a.data_ptr(), f32, s.cuda_stream, engine=1)
+            lib.fetch_range(h, first, cnt, b.data_ptr(), f32, s.cuda_stream, engine=2)
+            torch.cuda.synchronize()
+            if cnt:
+                assert torch.equal(a, b), (scheme, first, cnt, f32)
+        assert lib.stats().copy_engine_runs > 0 and lib.stats().copy_engine_bytes > 0
+        # on the engine's own stream too, and the default (auto) choice on a same-GPU pool is the kernel
+        runs = lib.stats().copy_engine_runs
+        a = torch.empty((n, N), dtype=torch.int16, device="cuda"); b = torch.empty_like(a)
+        lib.fetch_range(h, 0, n, a.data_ptr(), False, None, engine=2)
+        lib.fetch_range(h, 0, n, b.data_ptr(), False, None)
+        lib.sync()
+        assert torch.equal(a, b) and lib.stats().copy_engine_runs > runs
+        runs = lib.stats().copy_engine_runs
+        lib.fetch_range(h, 0, n, b.data_ptr(), False, s.cuda_stream)
+        torch.cuda.synchronize()
+        assert lib.stats().copy_engine_runs == runs
+        # after a migration the records are no longer in striping order: engine 2 is refused, auto still works
+        lib.migrate(h, 10, 31, 1)
+        with pytest.raises(SpeckvError) as ei:
+            lib.fetch_range(h, 0, n, b.data_ptr(), False, s.cuda_stream, engine=2)
+        assert ei.value.status == -4
+        lib.fetch_range(h, 0, n, b.data_ptr(), False, s.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+    finally:
+        lib.finalize()
+
+
+@pytest.mark.parametrize("scheme", [4, 3, 1])
+def test_migration_frees_exact_runs(scheme, oracle):
+    """records are 2048 / 1152 B; migrating an odd number of pages out of a striped pool and then
+    allocating and writing a second handle must leave every record of the first one intact."""
+    lib = open_lib(SPECKV_POOL_DEVICES="0,0,0", SPECKV_SLAB_MB=8)
+    try:
+        lib.set_compression_scheme(scheme)
+        n = 1001
+        h = lib.alloc(n * PAGE)
+        x = synth(n, seed=55)
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+        before = np.empty_like(x); lib.read(h, 0, before.ctypes.data, before.nbytes, False)
+        reserved = lib.stats().pool_bytes_reserved
+        lib.migrate(h, 3, 37, 1)                                   # 37 single-record runs leave pools 0 and 2 (and 1)
+        lib.migrate(h, 500, 1, 0)
+        h2 = lib.alloc(300 * PAGE)                                 # lands in the holes and around them
+        z = synth(300, seed=56)
+        lib.write(h2, 0, z.ctypes.data, z.nbytes, False)
+        h3 = lib.alloc(64 * PAGE, preferred_node=1)
+        lib.write(h3, 0, z.ctypes.data, 64 * PAGE, False)
+        after = np.empty_like(x); lib.read(h, 0, after.ctypes.data, after.nbytes, False)
+        assert after.tobytes() == before.tobytes()
+        got2 = np.empty_like(z); lib.read(h2, 0, got2.ctypes.data, got2.nbytes, False)
+        sc, ln, rc = oracle.compress_blocks_f16(z, scheme, 0)
+        assert_same_float_bits(got2, oracle.decompress_blocks_f16(rc, ln, sc, scheme, 0))
+        assert lib.stats().pool_bytes_reserved <= reserved + (16 << 20)
+        lib.free(h); lib.free(h2); lib.free(h3)
+        lib.sync()
+        h4 = lib.alloc(n * PAGE)                                   # everything coalesced back: fits without new slabs
+        assert lib.stats().pool_bytes_reserved <= reserved + (16 << 20)
+        lib.free(h4)
+    finally:
+        lib.finalize()
+
+
+def _raw_reference_surface():
+    """The 8 reference symbols only, bound as the reference's speckv_ctypes.py binds them."""
+    lib = pkg.load_library()
+    lib.speckv_init.argtypes = [C.c_char_p]; lib.speckv_init.restype = C.c_int
+    lib.speckv_finalize.restype = None
+    lib.speckv_alloc.argtypes = [C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64)]; lib.speckv_alloc.restype = C.c_int
+    lib.speckv_free.argtypes = [C.c_uint64]
+    lib.speckv_access.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, C.POINTER(C.c_void_p)]; lib.speckv_access.restype = C.c_int
+    lib.speckv_prefetch.argtypes = [C.c_uint32, C.c_uint16, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32]
+    lib.speckv_prefetch.restype = C.c_int
+    return lib
+
+
+@pytest.mark.parametrize("mode", ["env", "inferred"])
+def test_prefetch_under_the_reference_shim_unchanged(mode, oracle):
+    """BASELINE north_star: 'drops into the existing vLLM integration shim unchanged'.  The reference's allocate() sends
+    no geometry (vllm_speckv_backend.py:26-43).  Call order of its decode loop (:104-129) with ONLY the 8 reference
+    functions: allocate -> per token, prefetch_step per layer -> get_kv_ptr.  Pages of the look-ahead must become
+    L2-resident (observed through speckv_ext_translate, which the caller would not need)."""
+    from cxl_speckv_amd.speckv_ctypes import PageInfo
+    T, L, H, D, bpe = 256, 4, 8, 128, 2
+    total = 2 * T * L * H * D * bpe
+    n_pages = total // PAGE
+    if mode == "env":
+        os.environ["SPECKV_LAYOUT"] = f"{T},{L},{H},{D},{bpe}"
+    lib = _raw_reference_surface()
+    try:
+        assert lib.speckv_init(b"hip:0") == 0
+        h = C.c_uint64()
+        assert lib.speckv_alloc(total, None, C.byref(h)) == 0
+        toks = (C.c_int32 * 16)(*range(1, 17))
+        out = C.c_void_p()
+        entry = D * bpe
+
+        def off(layer, head, pos, kind):
+            return ((((0 * L + layer) * 2 + kind) * T + pos) * H + head) * entry
+        if mode == "inferred":
+            # the shim reads the current position first (that is how the entry size becomes known)
+            assert lib.speckv_access(h, off(0, 0, 10, 0), entry, C.byref(out)) == 0
+        for pos in (10, 11):                                   # two tokens: the layer index falling back ends a step
+            for layer in range(L):
+                assert lib.speckv_prefetch(0, layer, pos, 4, toks, 16) == 0
+        assert lib.speckv_access(h, off(1, 3, 12, 1), entry, C.byref(out)) == 0 and out.value
+        lib.speckv_ext_translate.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(PageInfo)]
+        want = set()
+        for layer in range(L):
+            want |= set(oracle.prefetch_pages(0, layer, 10, 4, L, T, H, D, bpe, n_pages).tolist())
+        info = PageInfo()
+        res = set()
+        for p in range(n_pages):
+            assert lib.speckv_ext_translate(h, p * PAGE, C.byref(info)) == 0
+            if info.flags & 2:
+                res.add(p)
+        assert want <= res, sorted(want - res)[:8]
+        assert lib.speckv_free(h) == 0
+    finally:
+        lib.speckv_finalize()
+        os.environ.pop("SPECKV_LAYOUT", None)
+
+
+def test_free_returns_without_waiting_for_the_device():
+    """speckv_free used to hipDeviceSynchronize(); now an allocation a caller stream may still read is released later,
+    and the call returns at once even while an unrelated long kernel occupies the GPU."""
+    torch = torch_mod()
+    lib = open_lib()
+    try:
+        lib.set_compression_scheme(2)
+        n = 4096
+        h = lib.alloc(n * PAGE)
+        x = synth(n, seed=2)
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+        dst = torch.empty((n, N), dtype=torch.int16, device="cuda")
+        busy, user = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(busy):
+            torch.cuda._sleep(int(2.0e9))                          # ~1 s of GPU time on another stream
+        with torch.cuda.stream(user):
+            torch.cuda._sleep(int(4.0e8))                          # the caller's own stream is busy too (~0.2 s)
+        lib.fetch_range(h, 0, n, dst.data_ptr(), False, user.cuda_stream)
+        t0 = time.perf_counter()
+        lib.free(h)
+        dt = time.perf_counter() - t0
+        assert dt < 0.05, dt
+        h2 = lib.alloc(n * PAGE)                                   # still works while the old records wait for their stream
+        lib.write(h2, 0, x.ctypes.data, x.nbytes, False)
+        torch.cuda.synchronize()
+        ref = np.empty_like(x); lib.read(h2, 0, ref.ctypes.data, ref.nbytes, False)
+        assert dst.cpu().numpy().view(np.float16).tobytes() == ref.tobytes()       # the fetch read intact records
+        lib.sync()
+        lib.free(h2)
+    finally:
+        lib.finalize()
+
+
+def test_batch_attention_refuses_stream_capture():
+    """the batch forms stage their descriptors per call and must not be captured into a graph."""
+    torch = torch_mod()
+    lib = open_lib()
+    try:
+        lib.set_compression_scheme(4)
+        T, H, D, G = 64, 8, 128, 8
+        n_pages = 2 * T * H * D * 2 // PAGE
+        h = lib.alloc(n_pages * PAGE)
+        lib.set_layout(h, T, 1, H, D, 2)
+        x = synth(n_pages, seed=4)
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+        q = torch.randn((1, H, G, D), device="cuda").to(torch.float16)
+        out = torch.empty((1, H, G, D), dtype=torch.float32, device="cuda")
+        s = torch.cuda.Stream()
+        lib.attend_fp8_batch([h], 0, q.data_ptr(), G, [T], 0.1, out.data_ptr(), None, s.cuda_stream)    # eager: fine
+        torch.cuda.synchronize()
+        eager = out.clone()
+        lib.attend_fp8(h, 0, 1, q.data_ptr(), G, 0, T, 0.1, out.data_ptr(), None, s.cuda_stream)         # warm-up sizes the scratch
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            with pytest.raises(SpeckvError) as ei:
+                lib.attend_fp8_batch([h], 0, q.data_ptr(), G, [T], 0.1, out.data_ptr(), None, s.cuda_stream)
+            assert ei.value.status == -4
+            lib.attend_fp8(h, 0, 1, q.data_ptr(), G, 0, T, 0.1, out.data_ptr(), None, s.cuda_stream)     # per-sequence form: capturable
+        out.zero_()
+        g.replay(); torch.cuda.synchronize()
+        assert torch.allclose(out, eager, rtol=1e-5, atol=1e-6)
+    finally:
+        lib.finalize()
