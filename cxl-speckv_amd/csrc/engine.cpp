@@ -475,7 +475,6 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
     st_.peak_allocated_bytes = std::max(st_.peak_allocated_bytes, st_.current_allocated_bytes);
     Allocation* raw = a.get();
     allocs_[a->handle] = std::move(a);
-    if (raw->n_pages) layout_handle_ = raw->handle;       // the shim's single live allocation is the newest one
     // SPECKV_LAYOUT=T,L,H,D,bpe: geometry for callers that only speak the reference's 8 functions (its
     // allocate() sends none, vllm_speckv_backend.py:26-43); applied when the size matches
     if (const char* env = getenv("SPECKV_LAYOUT")) {
@@ -738,18 +737,24 @@ int Engine::prepare_ring_op()
     return SPECKV_OK;
 }
 
-// pages [p0, p1] that an in-flight flush is bringing in have landed
+// The ring slots of a flush that is still in flight are changing hands: the previous owner of each slot is being
+// evicted and the new page is landing, both done by the fetch kernel.  A page of [p0, p1] whose slot lies in such a
+// run is either arriving or leaving -- wait for that flush, then its residency words are final.
 int Engine::wait_landed(const Allocation* a, uint64_t p0, uint64_t p1)
 {
-    if (flights_.empty()) return SPECKV_OK;
-    std::vector<hipEvent_t> need;
-    for (const Flight& f : flights_) {
-        if (!f.absorbed || f.m == 0) continue;
-        for (uint64_t p = p0; p <= p1; ++p)
-            if ((a->flags[p] & 2u) && a->slot[p] >= f.base && a->slot[p] < f.base + f.m) { need.push_back(f.done); break; }
+    for (int spin = 0; spin < 64 && !flights_.empty(); ++spin) {
+        hipEvent_t need = nullptr;
+        for (const Flight& f : flights_) {
+            if (!f.absorbed || f.m == 0) continue;
+            for (uint64_t p = p0; p <= p1 && !need; ++p)
+                if ((a->flags[p] & 2u) && a->slot[p] >= f.base && a->slot[p] < f.base + f.m) need = f.done;
+            if (need) break;
+        }
+        if (!need) break;
+        RC_TRY(wait_event(need));
+        RC_TRY(settle());
     }
-    for (hipEvent_t ev : need) RC_TRY(wait_event(ev));
-    return need.empty() ? SPECKV_OK : settle();
+    return SPECKV_OK;
 }
 
 void Engine::reap(bool wait_all)
@@ -855,6 +860,8 @@ int Engine::access(uint64_t handle, uint64_t off, size_t len, void** out)
     if (p1 - p0 + 1 > n_l2_) return SPECKV_ERR_NOMEM;
     DeviceScope device_scope(device_);
     RC_TRY(settle());
+    RC_TRY(wait_landed(a, p0, p1));                          // before residency is read: slots of a flush in flight are in transition
+    if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
     auto resident_run = [&] {                                // a multi-page span must come back contiguous
         for (uint64_t p = p0; p <= p1; ++p)
             if (!(a->flags[p] & 3u) || a->slot[p] != a->slot[p0] + (p - p0)) return false;
@@ -889,11 +896,14 @@ int Engine::access(uint64_t handle, uint64_t off, size_t len, void** out)
         RC_TRY(quiesce());
         if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
         if ((a->flags[p0] & 3u) == 2u) { RC_TRY(move_to_l1(a, static_cast<uint32_t>(p0))); RC_TRY(wait_stream()); }
-    } else {
-        RC_TRY(wait_landed(a, p0, p1));                      // a prefetched page may still be landing
     }
     if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
-    if (!(a->flags[p0] & 3u)) return SPECKV_ERR_GENERAL;     // evicted again by a concurrent caller (cache far too small)
+    if (!(a->flags[p0] & 3u)) {                              // evicted again by a concurrent caller (cache far too small)
+        SPECKV_ERR("speckv_access: page %llu of handle %llu is not resident after its fetch (flags %#x slot %u, %zu missed, hand %u)",
+                   static_cast<unsigned long long>(p0), static_cast<unsigned long long>(handle), a->flags[p0], a->slot[p0],
+                   miss.size(), l2_hand_);
+        return SPECKV_ERR_GENERAL;
+    }
     *out = slot_ptr(a->slot[p0]) + poff;
     return SPECKV_OK;
 }
@@ -943,6 +953,24 @@ int Engine::access_batch(uint64_t handle, const uint64_t* offs, uint32_t n, void
 }
 
 // --------------------------------------------------------------- prefetch
+// The allocation an unbound request id addresses: the one that last received a layout; failing that the newest
+// allocation that has one, else the newest allocation at all (the reference shim keeps a single live allocation and
+// sends no geometry, vllm_speckv_backend.py:26-43).
+Allocation* Engine::default_target()
+{
+    if (layout_handle_)
+        if (Allocation* a = find(layout_handle_)) return a;
+    Allocation* with_layout = nullptr;
+    Allocation* any = nullptr;
+    for (auto& kv : allocs_) {
+        Allocation* a = kv.second.get();
+        if (!a->n_pages) continue;
+        if (!any || a->handle > any->handle) any = a;
+        if (a->has_layout && (!with_layout || a->handle > with_layout->handle)) with_layout = a;
+    }
+    return with_layout ? with_layout : any;
+}
+
 int Engine::bind_request(uint32_t req, uint64_t handle, uint32_t local_req)
 {
     if (handle == 0) { bindings_.erase(req); return SPECKV_OK; }
@@ -967,7 +995,7 @@ int Engine::prefetch(uint32_t req, uint16_t layer, uint32_t pos, uint32_t k,
     // Without a known geometry (a caller that speaks only the reference's 8 functions) the layer count is learnt
     // from the calls themselves: the shim walks layers 0..L-1 per token (vllm_speckv_backend.py:116-118), so the
     // step is complete when the layer index falls back; flush then, not after a fixed count.
-    Allocation* la = layout_handle_ ? find(layout_handle_) : nullptr;
+    Allocation* la = default_target();
     const bool known = (la && la->has_layout) || !bindings_.empty();
     if (!known && !queue_.empty() && layer <= queue_.back().layer) { uint32_t n = 0; (void)prefetch_flush(&n); }
     max_layer_seen_ = std::max<uint32_t>(max_layer_seen_, layer);
@@ -1024,7 +1052,7 @@ int Engine::prefetch_flush(uint32_t* n_issued)
     static const bool timing = getenv("SPECKV_TIMING") != nullptr;
     const auto t_a = std::chrono::steady_clock::now();
     // resolve every request to (allocation row, request index inside it); group by scheme (one fetch kernel each)
-    Allocation* dflt = layout_handle_ ? find(layout_handle_) : nullptr;
+    Allocation* dflt = default_target();
     if (dflt && !dflt->has_layout && bindings_.empty()) (void)infer_layout(dflt);
     struct Group { std::vector<uint32_t> idx; uint32_t W = 0; };
     std::unordered_map<int, Group> groups;

@@ -258,6 +258,7 @@ private:
     speckv_ext_stats_t st_{};
 
     Allocation* find(uint64_t h);
+    Allocation* default_target();
     int init_hip(int device);
     void* scratch(Scratch& s, size_t bytes, hipStream_t user = nullptr);
     void release_allocation(Allocation* a);

@@ -54,6 +54,98 @@ def test_timing_protocol_world2(tmp_path):
     assert r[0]["rate"] == pytest.approx(2 * 1000 * 5 / r[0]["elapsed"])
 
 
+def _placement_worker(rank, world, port, out_dir):
+    """Each rank opens the page-table engine ("/dev/null": no GPU needed) with the pool list bench.py would give it and
+    the ranks cross-check page -> pool placement, logical ids and shard sizes."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    import cxl_speckv_amd as pkg
+    PAGE = 4096
+    res = {}
+    # --- BASELINE configs[3] shape: 8 GPUs, rank 0 computes, pool striped over GPUs 1..7.  Both gloo ranks build the
+    # same engine state and each verifies its own half of the page range.
+    pools = bench.pool_devices_for("cfg4", 0, 8)
+    assert pools == [1, 2, 3, 4, 5, 6, 7] and bench.pool_devices_for("cfg4", 3, 8) is None
+    assert bench.pool_devices_for("cfg3", 0, 8) == [1] and bench.pool_devices_for("cfg3", 1, 8) is None
+    os.environ["SPECKV_POOL_DEVICES"] = ",".join(map(str, pools))
+    lib = pkg.SpeckvLib(pkg.library_path(), "/dev/null")
+    os.environ.pop("SPECKV_POOL_DEVICES")
+    raw = lib.lib
+    raw.speckv_ext_pool_shard_pages.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+    raw.speckv_ext_pool_shard_pages.restype = C.c_uint64
+    n_pages = 655360                                    # one 70B-shaped sequence at 8k context
+    h = lib.alloc(n_pages * PAGE)
+    lo, hi = rank * n_pages // world, (rank + 1) * n_pages // world
+    count = [0] * 8
+    sample = {}
+    for p in list(range(lo, hi, 997)) + [lo, hi - 1]:
+        info = lib.translate(h, p * PAGE)
+        assert info.pool_device == pools[p % 7], (p, info.pool_device)
+        sample[p] = (info.pool_device, info.virt_page_id, info.phys_page_id)
+    for p in range(lo, hi):                             # exact per-pool page counts of this rank's half (arithmetic rule)
+        count[pools[p % 7]] += 1
+    shard = [raw.speckv_ext_pool_shard_pages(n_pages, 7, k) for k in range(7)]
+    res["cfg4"] = {"count": count, "shard": shard, "sample": sample, "handle": h}
+    lib.free(h)
+    lib.finalize()
+    # --- symmetric mode at the real world size: every rank's pool lives on its peers
+    mine = bench.pool_devices_for("symmetric", rank, world)
+    os.environ["SPECKV_POOL_DEVICES"] = ",".join(map(str, mine))
+    lib = pkg.SpeckvLib(pkg.library_path(), "/dev/null")
+    os.environ.pop("SPECKV_POOL_DEVICES")
+    h = lib.alloc(64 * PAGE)
+    res["symmetric"] = {"pools": mine, "devices": sorted({lib.translate(h, p * PAGE).pool_device for p in range(64)})}
+    lib.finalize()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, res)
+    torch.save(gathered, os.path.join(out_dir, f"p{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_page_to_pool_striping_world2(tmp_path):
+    """pages striped page % n_pool over the pool GPUs.  Fails if the striping rule, the shard sizes or the
+    rank -> pool-GPU lists of bench.py's remote modes break."""
+    world = 2
+    mp.spawn(_placement_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    views = [torch.load(os.path.join(tmp_path, f"p{i}.pt"), weights_only=False) for i in range(world)]
+    assert views[0] == views[1]                                    # every rank gathered the same picture
+    g = views[0]
+    n_pages = 655360
+    total = [g[0]["cfg4"]["count"][d] + g[1]["cfg4"]["count"][d] for d in range(8)]
+    assert total[0] == 0 and sum(total) == n_pages                 # the compute GPU holds no pool pages
+    assert g[0]["cfg4"]["shard"] == g[1]["cfg4"]["shard"] == [total[d] for d in range(1, 8)]
+    assert max(total[1:]) - min(total[1:]) <= 1                    # balanced over the 7 links
+    for r in range(world):
+        for p, (dev, virt, phys) in g[r]["cfg4"]["sample"].items():
+            h = g[r]["cfg4"]["handle"]
+            assert dev == 1 + p % 7
+            assert virt == (h << 32) | (p << 12) and phys == 0x4000000000 + (h << 20) + (p << 12)
+    # the halves are disjoint and meet
+    assert max(g[0]["cfg4"]["sample"]) + 1 == min(g[1]["cfg4"]["sample"])
+    for r in range(world):
+        assert r not in g[r]["symmetric"]["pools"] and g[r]["symmetric"]["devices"] == g[r]["symmetric"]["pools"]
+    assert sorted(g[0]["symmetric"]["pools"] + g[1]["symmetric"]["pools"]) == [0, 1]
+
+
+def test_remote_mode_pool_lists():
+    sys.path.insert(0, ROOT)
+    import bench
+    for world in (2, 4, 8):
+        sym = [bench.pool_devices_for("symmetric", r, world) for r in range(world)]
+        for r in range(world):
+            assert r not in sym[r] and len(sym[r]) == world - 1
+        # every GPU serves as a pool of every other GPU exactly once
+        assert all(sum(1 for r in range(world) if d in sym[r]) == world - 1 for d in range(world))
+        assert bench.pool_devices_for("cfg3", 0, world) == [1]
+        assert bench.pool_devices_for("cfg4", 0, world) == list(range(1, world))
+        assert all(bench.pool_devices_for(m, r, world) is None for m in ("cfg3", "cfg4") for r in range(1, world))
+
+
 def test_single_rank_needs_no_process_group():
     sys.path.insert(0, ROOT)
     import bench
