@@ -840,22 +840,30 @@ def flush_cfg4_extra(torch, pkg, n_seq=256, Lyr=80, T=128):
             hs.append(h)
         rng = np.random.default_rng(11)
         n_req = n_seq * Lyr
-        reqs = [s_ for s_ in range(n_seq) for _ in range(Lyr)]
-        layers = [l for _ in range(n_seq) for l in range(Lyr)]
-        ms, sub, pages = [], [], []
-        for rep in range(4):
-            base = int(rng.integers(0, T - 40)) // 8 * 8
-            pos = [base + 8 * rep] * n_req
-            lib.prefetch_batch(reqs, layers, pos, [4] * n_req)
+        reqs = np.repeat(np.arange(n_seq, dtype=np.uint32), Lyr)
+        layers = np.tile(np.arange(Lyr, dtype=np.uint16), n_seq)
+        depth = np.full(n_req, 4, np.uint32)
+        ms, sub, enq, pipe, pages = [], [], [], [], []
+        for rep in range(6):
+            pos = np.full(n_req, 8 * rep, np.uint32)
             before = int(lib.stats().total_prefetches)
             t0 = time.perf_counter()
-            lib.prefetch_flush(want_count=False)
-            t1 = time.perf_counter()
+            lib.prefetch_batch(reqs, layers, pos, depth)
+            enq.append((time.perf_counter() - t0) * 1e3)
+            t0 = time.perf_counter()
+            if rep % 2:
+                lib.prefetch_flush(want_count=False)            # submit only
+                t1 = time.perf_counter()
+                sub.append((t1 - t0) * 1e3)
+            else:
+                lib.prefetch_flush(want_count=True)             # waits for the lookup / dedupe / slot kernels, not for the data
+                pipe.append((time.perf_counter() - t0) * 1e3)
             lib.sync()
-            ms.append((time.perf_counter() - t0) * 1e3); sub.append((t1 - t0) * 1e3)
+            ms.append((time.perf_counter() - t0) * 1e3)
             pages.append(int(lib.stats().total_prefetches) - before)
         return {"prefetch_flush_cfg4_step": {"requests": n_req, "sequences": n_seq, "layers": Lyr, "pages_issued": pages[-1],
-                                             "ms": round(min(ms[1:]), 3), "submit_ms": round(min(sub[1:]), 3), "first_call_ms": round(ms[0], 3),
+                                             "ms": round(min(ms[1:]), 3), "submit_ms": round(min(sub), 3), "first_call_ms": round(ms[0], 3),
+                                             "enqueue_ms": round(min(enq[1:]), 3), "until_slots_assigned_ms": round(min(pipe[1:]), 3),
                                              "dropped": int(lib.stats().prefetch_dropped),
                                              "note": "one flush for the whole batch's decode step: 256 allocations, request ids bound to handles"}}
     except Exception as e:
@@ -937,12 +945,15 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     # device (candidates, dedupe, ring slots, fetch): `submit_ms` is what the caller's thread pays, `ms` includes
     # waiting for the fetched pages.
     n_req = 256 * Lyr
-    reqs = [0] * n_req
-    layers = [i % Lyr for i in range(n_req)]
-    flush_ms, submit_ms, issued_n = [], [], []
-    for rep in range(4):
-        pos = [int(p) for p in rng.integers(0, T - 8, n_req)]
-        lib.prefetch_batch(reqs, layers, pos, [4] * n_req)
+    reqs = np.zeros(n_req, np.uint32)
+    layers = (np.arange(n_req) % Lyr).astype(np.uint16)
+    depth = np.full(n_req, 4, np.uint32)
+    flush_ms, submit_ms, enq_ms, issued_n = [], [], [], []
+    for rep in range(5):
+        pos = rng.integers(0, T - 8, n_req).astype(np.uint32)
+        t0 = time.perf_counter()
+        lib.prefetch_batch(reqs, layers, pos, depth)
+        enq_ms.append((time.perf_counter() - t0) * 1e3)
         t0 = time.perf_counter()
         lib.prefetch_flush(want_count=False)
         t1 = time.perf_counter()
@@ -951,7 +962,7 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
         submit_ms.append((t1 - t0) * 1e3)
         issued_n.append(int(lib.stats().total_prefetches))
     ex["prefetch_flush"] = {"requests": n_req, "pages_issued": issued_n[-1] - issued_n[-2], "ms": round(min(flush_ms[1:]), 3),
-                            "submit_ms": round(min(submit_ms[1:]), 3),
+                            "submit_ms": round(min(submit_ms[1:]), 3), "enqueue_ms": round(min(enq_ms[1:]), 3),
                             "first_call_ms": round(flush_ms[0], 3), "requests_per_s": round(n_req / (min(flush_ms[1:]) * 1e-3), 1),
                             "note": "device-side flush (candidates + dedupe + ring slots + fetch launch) + sync, steady state; no host round trip"}
     ex.update(seq70b_extra(torch, kv))

@@ -469,6 +469,7 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
         }
     }
     a->handle = next_handle_++;
+    ++res_gen_;
     *out = a->handle;
     st_.total_allocations++;
     st_.current_allocated_bytes += bytes;
@@ -560,8 +561,11 @@ int Engine::free(uint64_t handle)
     if (layout_handle_ == handle) layout_handle_ = 0;
     for (auto b = bindings_.begin(); b != bindings_.end();)
         b = b->second.handle == handle ? bindings_.erase(b) : std::next(b);
+    ++res_gen_;
     std::unique_ptr<Allocation> a = std::move(it->second);
     allocs_.erase(it);
+    if (a->row != kNoSlot)                                  // requests already queued for it address nothing now
+        for (auto& r : q_row_) if (r == a->row) { r = kNoSlot; st_.prefetch_dropped++; }
     if (null_ || a->n_pages == 0) return SPECKV_OK;
     DeviceScope device_scope(device_);
     // The table row is cleared in stream order (kernels already queued still see it); the memory itself goes back to
@@ -973,10 +977,62 @@ Allocation* Engine::default_target()
 
 int Engine::bind_request(uint32_t req, uint64_t handle, uint32_t local_req)
 {
-    if (handle == 0) { bindings_.erase(req); return SPECKV_OK; }
+    if (handle == 0) { bindings_.erase(req); ++res_gen_; return SPECKV_OK; }
     if (!find(handle)) return SPECKV_ERR_GENERAL;
     bindings_[req] = Binding{handle, local_req};
+    ++res_gen_;
     return SPECKV_OK;
+}
+
+// Resolve a request id to (table row, request index inside the allocation, limits).  Decode loops send the requests
+// of one sequence back to back, so the last resolution is cached (res_gen_ changes whenever a binding, a layout or
+// the set of allocations does).
+bool Engine::resolve(uint32_t req)
+{
+    last_res_ = Resolved{};
+    last_res_.req = req;
+    last_res_.gen = res_gen_;
+    Allocation* a = nullptr;
+    uint32_t lr = req;
+    if (!bindings_.empty()) {
+        auto b = bindings_.find(req);
+        if (b != bindings_.end()) { a = find(b->second.handle); lr = b->second.local_req; }
+    }
+    if (!a) a = default_target();
+    if (!a || a->n_pages == 0 || a->row == kNoSlot) return false;
+    if (!a->has_layout) { last_res_.no_geometry = bindings_.empty(); return false; }
+    const Layout& L = a->layout;
+    const uint64_t per_req = 2ull * L.num_tokens * L.num_layers * L.num_heads * L.head_dim * L.bytes_per_element;
+    const uint64_t n_req = per_req ? (a->size_bytes + per_req - 1) / per_req : 0;
+    if (lr >= n_req) return false;
+    last_res_.row = a->row;
+    last_res_.local = lr;
+    last_res_.n_layers = L.num_layers;
+    last_res_.scheme = a->scheme;
+    const uint64_t row_bytes = static_cast<uint64_t>(L.num_heads) * L.head_dim * L.bytes_per_element;
+    last_res_.W = static_cast<uint32_t>(row_bytes / kPageSize + 2);
+    last_res_.ok = true;
+    return true;
+}
+
+// One request joins the queue (already resolved: the flush only uploads and launches).
+void Engine::enqueue(uint32_t req, uint32_t layer, uint32_t pos, uint32_t k)
+{
+    if (last_res_.req != req || last_res_.gen != res_gen_) (void)resolve(req);
+    if (!last_res_.ok) {
+        if (last_res_.no_geometry) q_unresolved_.push_back({req, layer, pos, k});   // geometry may still be learnt before the flush
+        else ++q_dropped_;
+        return;
+    }
+    if (layer >= last_res_.n_layers) { ++q_dropped_; return; }
+    if (!q_req_.empty() && q_scheme_ != last_res_.scheme) { (void)prefetch_flush(nullptr); (void)resolve(req); if (!last_res_.ok) { ++q_dropped_; return; } }
+    q_scheme_ = last_res_.scheme;
+    q_W_ = std::max(q_W_, last_res_.W);
+    q_req_.push_back(last_res_.local);
+    q_layer_.push_back(layer);
+    q_pos_.push_back(pos);
+    q_k_.push_back(k);
+    q_row_.push_back(last_res_.row);
 }
 
 int Engine::prefetch(uint32_t req, uint16_t layer, uint32_t pos, uint32_t k,
@@ -995,14 +1051,12 @@ int Engine::prefetch(uint32_t req, uint16_t layer, uint32_t pos, uint32_t k,
     // Without a known geometry (a caller that speaks only the reference's 8 functions) the layer count is learnt
     // from the calls themselves: the shim walks layers 0..L-1 per token (vllm_speckv_backend.py:116-118), so the
     // step is complete when the layer index falls back; flush then, not after a fixed count.
-    Allocation* la = default_target();
-    const bool known = (la && la->has_layout) || !bindings_.empty();
-    if (!known && !queue_.empty() && layer <= queue_.back().layer) { uint32_t n = 0; (void)prefetch_flush(&n); }
+    if (!q_unresolved_.empty() && layer <= q_unresolved_.back().layer) (void)prefetch_flush(nullptr);
     max_layer_seen_ = std::max<uint32_t>(max_layer_seen_, layer);
-    queue_.push_back({req, layer, pos, k ? k : adapt_.depth()});
+    enqueue(req, layer, pos, k ? k : adapt_.depth());
     uint32_t thr = flush_threshold_;
-    if (thr == 0) thr = known ? (la && la->has_layout ? la->layout.num_layers : 32u) : 4096u;
-    if (queue_.size() >= thr) (void)prefetch_flush(nullptr);   // driver result ignored, as in the reference
+    if (thr == 0) thr = last_res_.ok ? last_res_.n_layers : 4096u;
+    if (q_req_.size() + q_unresolved_.size() >= thr) (void)prefetch_flush(nullptr);   // driver result ignored, as in the reference
     return SPECKV_OK;
 }
 
@@ -1010,10 +1064,12 @@ int Engine::prefetch_batch(uint32_t n, const uint32_t* req, const uint16_t* laye
                            const uint32_t* pos, const uint32_t* k)
 {
     if (null_) return SPECKV_OK;
-    queue_.reserve(queue_.size() + n);
+    const size_t want = q_req_.size() + n;
+    q_req_.reserve(want); q_layer_.reserve(want); q_pos_.reserve(want); q_k_.reserve(want); q_row_.reserve(want);
+    const uint32_t dflt = adapt_.depth();
     for (uint32_t i = 0; i < n; ++i) {
         max_layer_seen_ = std::max<uint32_t>(max_layer_seen_, layer[i]);
-        queue_.push_back({req[i], layer[i], pos[i], (k && k[i]) ? k[i] : adapt_.depth()});
+        enqueue(req[i], layer[i], pos[i], (k && k[i]) ? k[i] : dflt);
     }
     return SPECKV_OK;
 }
@@ -1032,9 +1088,12 @@ bool Engine::infer_layout(Allocation* a)
     if (a->size_bytes == 0 || a->size_bytes % denom) return false;
     const uint64_t T = a->size_bytes / denom;
     const uint32_t bpe = (entry % 2 == 0) ? 2u : 1u;
-    if (set_layout(a->handle, static_cast<uint32_t>(T), static_cast<uint32_t>(L), static_cast<uint32_t>(H),
-                   static_cast<uint32_t>(entry / bpe), bpe) != SPECKV_OK)
-        return false;
+    std::vector<Req> keep;
+    keep.swap(q_unresolved_);                           // set_layout flushes the queue: not while we are re-resolving it
+    const int rc = set_layout(a->handle, static_cast<uint32_t>(T), static_cast<uint32_t>(L), static_cast<uint32_t>(H),
+                              static_cast<uint32_t>(entry / bpe), bpe);
+    keep.swap(q_unresolved_);
+    if (rc != SPECKV_OK) return false;
     a->layout_inferred = true;
     SPECKV_ERR("speckv_prefetch: no geometry was given for handle %llu (speckv_ext_set_layout / SPECKV_LAYOUT); assuming "
                "tokens=%llu layers=%llu kv_heads=%llu entry=%llu B from the calls seen so far",
@@ -1047,70 +1106,57 @@ int Engine::prefetch_flush(uint32_t* n_issued)
 {
     if (n_issued) *n_issued = 0;
     if (null_) return SPECKV_OK;
-    if (queue_.empty()) return SPECKV_OK;
+    if (in_flush_) return SPECKV_OK;
+    if (q_req_.empty() && q_unresolved_.empty() && q_dropped_ == 0) return SPECKV_OK;
     DeviceScope device_scope(device_);
+    in_flush_ = true;
     static const bool timing = getenv("SPECKV_TIMING") != nullptr;
     const auto t_a = std::chrono::steady_clock::now();
-    // resolve every request to (allocation row, request index inside it); group by scheme (one fetch kernel each)
-    Allocation* dflt = default_target();
-    if (dflt && !dflt->has_layout && bindings_.empty()) (void)infer_layout(dflt);
-    struct Group { std::vector<uint32_t> idx; uint32_t W = 0; };
-    std::unordered_map<int, Group> groups;
-    std::vector<uint32_t> rows(queue_.size(), kNoSlot), local(queue_.size(), 0);
-    uint64_t dropped = 0;
-    for (size_t i = 0; i < queue_.size(); ++i) {
-        Allocation* a = dflt;
-        uint32_t lr = queue_[i].req;
-        if (!bindings_.empty()) {
-            auto b = bindings_.find(queue_[i].req);
-            if (b != bindings_.end()) { a = find(b->second.handle); lr = b->second.local_req; }
+    if (!q_unresolved_.empty()) {          // requests that arrived before any geometry was known
+        Allocation* dflt = default_target();
+        if (dflt && !dflt->has_layout) (void)infer_layout(dflt);
+        std::vector<Req> again;
+        again.swap(q_unresolved_);
+        for (const Req& r : again) {
+            if (last_res_.req != r.req || last_res_.gen != res_gen_) (void)resolve(r.req);
+            if (last_res_.ok) enqueue(r.req, r.layer, r.pos, r.k); else ++q_dropped_;
         }
-        if (!a || !a->has_layout || a->n_pages == 0 || a->row == kNoSlot) { ++dropped; continue; }
-        const Layout& L = a->layout;
-        const uint64_t per_req = 2ull * L.num_tokens * L.num_layers * L.num_heads * L.head_dim * L.bytes_per_element;
-        const uint64_t n_req = per_req ? (a->size_bytes + per_req - 1) / per_req : 0;
-        if (lr >= n_req || queue_[i].layer >= L.num_layers) { ++dropped; continue; }
-        rows[i] = a->row;
-        local[i] = lr;
-        Group& g = groups[a->scheme];
-        g.idx.push_back(static_cast<uint32_t>(i));
-        const uint64_t row_bytes = static_cast<uint64_t>(L.num_heads) * L.head_dim * L.bytes_per_element;
-        g.W = std::max<uint32_t>(g.W, static_cast<uint32_t>(row_bytes / kPageSize + 2));
+        q_dropped_ += q_unresolved_.size();
+        q_unresolved_.clear();
     }
-    if (dropped) {
-        st_.prefetch_dropped += dropped;
+    if (q_dropped_) {
+        st_.prefetch_dropped += q_dropped_;
         if (!warned_no_layout_) {
             warned_no_layout_ = true;
             SPECKV_ERR("speckv_prefetch: %llu request(s) could not be addressed (no geometry for the allocation, unknown request "
                        "binding, or layer / request index out of range) and were dropped; see speckv_ext_set_layout, "
                        "speckv_ext_bind_request, SPECKV_LAYOUT (reported once; counted in speckv_ext_stats.prefetch_dropped)",
-                       static_cast<unsigned long long>(dropped));
+                       static_cast<unsigned long long>(q_dropped_));
         }
+        q_dropped_ = 0;
     }
     int rc = SPECKV_OK;
     uint32_t issued_total = 0;
-    for (auto& kv : groups) {
-        Group& g = kv.second;
+    const size_t total = q_req_.size();
+    if (total) {
         // at most 2^24 candidate words per pipeline run (dedupe key)
-        const uint32_t max_n = std::max<uint32_t>(1u, ((1u << 24) - 1u) / (32u * g.W));
-        for (size_t b = 0; b < g.idx.size() && rc == SPECKV_OK; b += max_n) {
-            const uint32_t n = static_cast<uint32_t>(std::min<size_t>(max_n, g.idx.size() - b));
-            std::vector<uint32_t> soa(5ull * n);
-            for (uint32_t j = 0; j < n; ++j) {
-                const uint32_t i = g.idx[b + j];
-                soa[j] = local[i]; soa[n + j] = queue_[i].layer; soa[2ull * n + j] = queue_[i].pos;
-                soa[3ull * n + j] = queue_[i].k; soa[4ull * n + j] = rows[i];
-            }
+        const uint32_t W = std::max<uint32_t>(q_W_, 2u);
+        const uint32_t max_n = std::max<uint32_t>(1u, ((1u << 24) - 1u) / (32u * W));
+        for (size_t b = 0; b < total && rc == SPECKV_OK; b += max_n) {
+            const uint32_t n = static_cast<uint32_t>(std::min<size_t>(max_n, total - b));
+            const uint32_t* cols[5] = {q_req_.data() + b, q_layer_.data() + b, q_pos_.data() + b, q_k_.data() + b, q_row_.data() + b};
             uint32_t m = 0;
-            rc = flush_group(kv.first, soa, n, g.W, n_issued ? &m : nullptr);
+            rc = flush_group(q_scheme_, cols, n, W, n_issued ? &m : nullptr);
             issued_total += m;
         }
     }
-    queue_.clear();
+    q_req_.clear(); q_layer_.clear(); q_pos_.clear(); q_k_.clear(); q_row_.clear();
+    q_W_ = 0;
+    in_flush_ = false;
     if (n_issued) *n_issued = issued_total;
     if (timing) {
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_a).count();
-        fprintf(stderr, "[speckv timing] flush submit: %.1f us (host time; the GPU pipeline runs asynchronously)\n", us);
+        fprintf(stderr, "[speckv timing] flush submit: %zu requests, %.1f us (host time; the GPU pipeline runs asynchronously)\n", total, us);
     }
     if (rc == SPECKV_OK) rc = run_predictor_for_dirty();
     return rc;
@@ -1120,7 +1166,7 @@ int Engine::prefetch_flush(uint32_t* n_issued)
 // upload the requests, candidates -> dedupe -> ring assignment -> compaction (kernels.hip), then ONE fetch launch
 // that reads its block count and first slot from device memory.  Nothing comes back to the host but 16 bytes
 // (FlushResult, written to pinned memory by the assign kernel), read when somebody needs them.
-int Engine::flush_group(int scheme, const std::vector<uint32_t>& soa, uint32_t n, uint32_t W, uint32_t* n_issued)
+int Engine::flush_group(int scheme, const uint32_t* const cols[5], uint32_t n, uint32_t W, uint32_t* n_issued)
 {
     if (flights_.size() >= kMaxFlights) { RC_TRY(settle()); if (flights_.size() >= kMaxFlights) { RC_TRY(wait_stream()); RC_TRY(settle()); } }
     RC_TRY(flush_mirror());
@@ -1136,7 +1182,7 @@ int Engine::flush_group(int scheme, const std::vector<uint32_t>& soa, uint32_t n
     uint32_t* buf = static_cast<uint32_t*>(scratch(s_flush_, bytes));
     if (!buf) return SPECKV_ERR_NOMEM;
     // request upload through a pinned slot (4 in rotation, each guarded by an event): no stream sync
-    const size_t up = soa.size() * sizeof(uint32_t);
+    const size_t up = 5ull * n * sizeof(uint32_t);
     if (req_stage_bytes_ < up) {
         if (req_stage_) { RC_TRY(wait_stream()); (void)hipHostFree(req_stage_); req_stage_ = nullptr; }
         req_stage_bytes_ = std::max<size_t>(up * 2, 1 << 20);
@@ -1148,7 +1194,7 @@ int Engine::flush_group(int scheme, const std::vector<uint32_t>& soa, uint32_t n
     req_stage_next_ = (slot + 1) & 3;
     RC_TRY(wait_event(req_stage_ev_[slot]));
     void* staged = static_cast<uint8_t*>(req_stage_) + static_cast<size_t>(slot) * req_stage_bytes_;
-    memcpy(staged, soa.data(), up);
+    for (int c = 0; c < 5; ++c) memcpy(static_cast<uint32_t*>(staged) + static_cast<size_t>(c) * n, cols[c], n * sizeof(uint32_t));
     HIP_TRY(hipMemcpyAsync(buf, staged, up, hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipEventRecord(req_stage_ev_[slot], stream_));
 
@@ -1335,6 +1381,8 @@ int Engine::set_layout(uint64_t handle, uint32_t T, uint32_t L, uint32_t H, uint
     Allocation* a = find(handle);
     if (!a) return SPECKV_ERR_GENERAL;
     if (!T || !L || !H || !D || !bpe) return SPECKV_ERR_INVAL;
+    if (!q_req_.empty()) (void)prefetch_flush(nullptr);       // queued requests were resolved against the old geometry
+    ++res_gen_;
     a->layout = Layout{T, L, H, D, bpe, a->n_pages};
     a->has_layout = true;
     a->layout_inferred = false;
@@ -1567,6 +1615,7 @@ int Engine::fetch_range_copy_engine(Allocation* a, uint64_t first, uint64_t n, v
         c.quant_mode = quant_mode_;
         c.out_f32 = f32 ? 1 : 0;
         c.stripe_n = D;
+        c.stripe_magic = (1ull << 35) / D + 1;
         for (uint32_t k = 0; k < D; ++k) {
             uint64_t rb = 0, cnt = 0;
             shard_range(f0, nc, D, k, &rb, &cnt);
@@ -1615,7 +1664,7 @@ int Engine::fetch_range(uint64_t handle, uint64_t first, uint64_t n, void* d_dst
     }();
     int choice = engine_choice ? engine_choice : env_choice;
     const uint32_t D = static_cast<uint32_t>(a->pool_of_residue.size());
-    const bool can_copy = a->regular && D >= 1 && D <= 8 && !is_capturing(st);
+    const bool can_copy = a->regular && D >= 1 && D <= 8 && a->n_pages < (1ull << 28) && !is_capturing(st);
     if (choice == 0) {
         bool remote = false;
         for (int p : a->pool_of_residue) remote = remote || pools_[p]->device() != device_;

@@ -188,9 +188,21 @@ private:
     struct Binding { uint64_t handle; uint32_t local_req; };
     std::unordered_map<uint32_t, Binding> bindings_;
 
-    // prefetch queue
+    // prefetch queue: requests are resolved when they arrive (columns ready for upload); the ones that arrive
+    // before any geometry is known wait in q_unresolved_
     struct Req { uint32_t req, layer, pos, k; };
-    std::vector<Req> queue_;
+    struct Resolved { uint32_t req = kNoSlot, row = kNoSlot, local = 0, n_layers = 0, W = 0; int scheme = -1; uint64_t gen = 0;
+                      bool ok = false, no_geometry = false; };
+    Resolved last_res_;
+    uint64_t res_gen_ = 1;
+    std::vector<uint32_t> q_req_, q_layer_, q_pos_, q_k_, q_row_;
+    std::vector<Req> q_unresolved_;
+    int q_scheme_ = 0;
+    uint32_t q_W_ = 0;
+    uint64_t q_dropped_ = 0;
+    bool in_flush_ = false;
+    bool resolve(uint32_t req);
+    void enqueue(uint32_t req, uint32_t layer, uint32_t pos, uint32_t k);
     uint32_t flush_threshold_ = 0;
     uint32_t access_epoch_ = 0;
     uint32_t flush_epoch_ = 0;             // 1..255 (dedupe stamps)
@@ -289,7 +301,7 @@ private:
     int fetch_into_slot(Allocation* a, uint32_t page, uint32_t slot);
     int fetch_range_copy_engine(Allocation* a, uint64_t first, uint64_t n, void* d_dst, bool f32, hipStream_t st);
     bool infer_layout(Allocation* a);
-    int flush_group(int scheme, const std::vector<uint32_t>& soa, uint32_t n, uint32_t W, uint32_t* n_issued);
+    int flush_group(int scheme, const uint32_t* const cols[5], uint32_t n, uint32_t W, uint32_t* n_issued);
     void reap(bool wait_all);
     int run_predictor_for_dirty();
     hipEvent_t get_event();

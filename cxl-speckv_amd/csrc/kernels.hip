@@ -435,26 +435,40 @@ struct BlockDesc {
     uint64_t page;
     uint32_t len;
     float scale;
-    uint32_t row;       // table row of the block's allocation (ring bookkeeping / multi-allocation launches)
+    uint32_t row;       // table row of the block's allocation (EXT 2: ring bookkeeping / multi-allocation launches)
 };
+// EXT selects what a launch needs beyond the plain forms, so that the bulk path keeps its register budget
+// (62 VGPRs, no SGPR spills, 8 waves per SIMD):
+//   0  page table / raw records, range or list            (speckv_ext_fetch_range / _list, codec operators)
+//   1  + records staged by the copy engines               (stripe_delta)
+//   2  + blocks of several allocations, L2-ring bookkeeping (synchronous misses, device-side flush)
+template <int EXT>
 __device__ __forceinline__ BlockDesc load_desc(const CodecArgs& a, uint64_t i, uint32_t slot0)
 {
     BlockDesc d;
     d.page = a.page_list ? a.page_list[i] : a.first + i;
-    d.row = a.alloc_list ? a.alloc_list[i] : a.alloc_idx;
-    const PageEntry* entries = a.alloc_list ? a.tab[d.row].entries : a.entries;
-    if (entries) {
-        const PageEntry e = entries[d.page];
+    d.row = 0;
+    const PageEntry* entries = a.entries;
+    if (EXT == 2) {
+        d.row = a.alloc_list ? a.alloc_list[i] : a.alloc_idx;
+        if (a.alloc_list) entries = a.tab[d.row].entries;
+    }
+    if (EXT == 2 || entries) {
+        PageEntry e{0, 0, 1.0f};
+        if (entries) e = entries[d.page];                  // a row freed meanwhile decodes as a never-written page
         d.rec = reinterpret_cast<const uint8_t*>(e.pool_addr);
         d.len = e.rec_bytes;
         d.scale = e.scale;
-        if (a.stripe_n) d.rec += a.stripe_delta[d.page % a.stripe_n];     // staged copy of the record (copy-engine fetch)
+        if (EXT == 1) {                                    // staged copy of the record (copy-engine fetch)
+            const uint64_t q = (d.page * a.stripe_magic) >> 35;        // page / stripe_n without a divide (page < 2^28)
+            d.rec += a.stripe_delta[d.page - q * a.stripe_n];
+        }
     } else {
         d.rec = a.recs + d.page * a.rec_stride;
         d.len = a.rec_bytes[d.page];
         d.scale = a.scales ? a.scales[d.page] : 1.0f;
     }
-    if (a.ring_owner) d.dst = a.ring_base + (static_cast<uint64_t>(slot0) + i) * kPageSize;
+    if (EXT == 2 && a.ring_owner) d.dst = a.ring_base + (static_cast<uint64_t>(slot0) + i) * kPageSize;
     else d.dst = a.data_list ? reinterpret_cast<uint8_t*>(a.data_list[i]) : a.data + i * a.data_stride;
     return d;
 }
@@ -467,20 +481,22 @@ __device__ __forceinline__ void ring_note(const CodecArgs& a, const BlockDesc& d
     if (prev != kNoOwner && prev != me) {
         const DevAlloc t = a.tab[prev >> 32];
         const uint32_t pp = static_cast<uint32_t>(prev);
-        if (t.entries && t.d_slot[pp] == slot) {                    // still pointing here: the page leaves L2
+        // the row may have been recycled for a smaller allocation since the slot was filled
+        if (t.entries && pp < t.layout.alloc_pages && t.d_slot[pp] == slot) {     // still pointing here: the page leaves L2
             const uint32_t v = atomicAnd(&t.d_flags[pp], ~2u) & ~2u;
             t.h_flags[pp] = v;
         }
     }
     a.ring_owner[slot] = me;
     const DevAlloc t = a.tab[d.row];
+    if (!t.entries) return;
     t.d_slot[d.page] = slot;
     t.h_slot[d.page] = slot;
     const uint32_t v = atomicOr(&t.d_flags[d.page], 2u) | 2u;
     t.h_flags[d.page] = v;
 }
 
-template <int SCHEME, int MODE, bool F32>
+template <int SCHEME, int MODE, bool F32, int EXT>
 __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[SCHEME == kInt8DeltaRle ? kWaves * kDecLdsWords : 4];
@@ -488,17 +504,20 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint64_t n = a.n;
     if (a.n_dev) { const uint64_t nd = *a.n_dev; n = nd < n ? nd : n; }
-    const uint32_t slot0 = a.slot0_dev ? *a.slot0_dev : a.slot0;
-    if (a.hand_ptr && blockIdx.x == 0 && threadIdx.x == 0) *a.hand_ptr = a.new_hand;
+    uint32_t slot0 = 0;
+    if (EXT == 2) {
+        slot0 = a.slot0_dev ? *a.slot0_dev : a.slot0;
+        if (a.hand_ptr && blockIdx.x == 0 && threadIdx.x == 0) *a.hand_ptr = a.new_hand;
+    }
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kWaves;
     uint64_t i = static_cast<uint64_t>(blockIdx.x) * kWaves + wave;
     if (i >= n) return;
-    BlockDesc cur = load_desc(a, i, slot0);
+    BlockDesc cur = load_desc<EXT>(a, i, slot0);
     for (;;) {
         // the next block's descriptor is fetched while this block is decoded
         const uint64_t nx = i + stride;
         BlockDesc nxt = cur;
-        if (nx < n) nxt = load_desc(a, nx, slot0);
+        if (nx < n) nxt = load_desc<EXT>(a, nx, slot0);
         uint32_t len = cur.len;
         if (SCHEME == kInt8DeltaRle) {
             if (len > 2u * kBlockElems) len = 2u * kBlockElems;
@@ -519,7 +538,7 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
             decode_fp16<F32>(cur.rec, len, cur.dst, lane);
         }
         if (lane == 0u) {
-            if (a.ring_owner) ring_note(a, cur, slot0 + static_cast<uint32_t>(i));
+            if (EXT == 2 && a.ring_owner) ring_note(a, cur, slot0 + static_cast<uint32_t>(i));
             else if (a.flags) atomicOr(&a.flags[cur.page], a.set_flags);   // neighbours belong to other waves / XCDs
         }
         if (nx >= n) break;
@@ -1388,8 +1407,13 @@ template <int SCHEME, int MODE>
 hipError_t launch_dec2(const CodecArgs& a, hipStream_t s)
 {
     const uint32_t grid = codec_grid(a.n);
-    if (a.out_f32) hipLaunchKernelGGL((k_fetch_decompress<SCHEME, MODE, true>), dim3(grid), dim3(kThreads), 0, s, a);
-    else           hipLaunchKernelGGL((k_fetch_decompress<SCHEME, MODE, false>), dim3(grid), dim3(kThreads), 0, s, a);
+    const int ext = (a.alloc_list || a.ring_owner) ? 2 : a.stripe_n ? 1 : 0;
+    if (ext == 2 && a.stripe_n) return hipErrorInvalidValue;
+#define SPECKV_LAUNCH_DEC(F32, EXT) \
+    hipLaunchKernelGGL((k_fetch_decompress<SCHEME, MODE, F32, EXT>), dim3(grid), dim3(kThreads), 0, s, a)
+    if (a.out_f32) { if (ext == 2) SPECKV_LAUNCH_DEC(true, 2); else if (ext == 1) SPECKV_LAUNCH_DEC(true, 1); else SPECKV_LAUNCH_DEC(true, 0); }
+    else           { if (ext == 2) SPECKV_LAUNCH_DEC(false, 2); else if (ext == 1) SPECKV_LAUNCH_DEC(false, 1); else SPECKV_LAUNCH_DEC(false, 0); }
+#undef SPECKV_LAUNCH_DEC
     return hipGetLastError();
 }
 template <int SCHEME>

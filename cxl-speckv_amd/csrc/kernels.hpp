@@ -98,6 +98,7 @@ struct CodecArgs {
     // copy-engine fetch: the records of pool (page % stripe_n) were copied into local staging, to their pool address
     // + stripe_delta[page % stripe_n]
     uint32_t        stripe_n;
+    uint64_t        stripe_magic; // floor(2^35 / stripe_n) + 1: (page * magic) >> 35 == page / stripe_n for page < 2^28
     int64_t         stripe_delta[8];
 };
 

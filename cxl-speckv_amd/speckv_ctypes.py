@@ -232,7 +232,13 @@ class SpeckvLib:
         return [p or 0 for p in out]
 
     def prefetch_batch(self, req_ids, layers, cur_pos, depth_k=None):
+        """Sequences of ints, or contiguous numpy arrays (uint32 / uint16 / uint32 / uint32) passed without a copy."""
         n = len(req_ids)
+        if hasattr(req_ids, "ctypes"):
+            as_p = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t))
+            self._ext("speckv_ext_prefetch_batch", n, as_p(req_ids, c_uint32), as_p(layers, c_uint16), as_p(cur_pos, c_uint32),
+                      as_p(depth_k, c_uint32) if depth_k is not None else None)
+            return
         k = (c_uint32 * n)(*depth_k) if depth_k is not None else None
         self._ext("speckv_ext_prefetch_batch", n, (c_uint32 * n)(*req_ids), (c_uint16 * n)(*layers),
                   (c_uint32 * n)(*cur_pos), k)
