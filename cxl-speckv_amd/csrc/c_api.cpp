@@ -133,6 +133,13 @@ speckv_status_t speckv_ext_write(speckv_handle_t handle, uint64_t offset_bytes, 
     return guarded([&] { return g_engine->write(handle, offset_bytes, src, len, src_on_device != 0); });
 }
 
+speckv_status_t speckv_ext_write_strided(speckv_handle_t handle, uint64_t first_page, uint64_t page_step, uint64_t n_pages,
+                                         const void* d_src, void* stream)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->write_strided(handle, first_page, page_step, n_pages, d_src, static_cast<hipStream_t>(stream)); });
+}
+
 speckv_status_t speckv_ext_read(speckv_handle_t handle, uint64_t offset_bytes, void* dst, size_t len, int dst_on_device)
 {
     LOCK; NEED_INIT;

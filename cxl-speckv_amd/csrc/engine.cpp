@@ -1520,6 +1520,56 @@ int Engine::write(uint64_t handle, uint64_t off, const void* src, size_t len, bo
     return SPECKV_OK;
 }
 
+// Asynchronous page writes for a decode loop: n pages first, first+step, first+2*step, ... (the pages of one position
+// pair in every (layer, kind) region of the shim layout are `num_tokens/2` pages apart) compressed from a contiguous
+// device buffer on the caller's stream.  Pages that are cached right now would go stale: that case takes the
+// synchronous path (a decode loop appends positions nobody has fetched yet).
+int Engine::write_strided(uint64_t handle, uint64_t first, uint64_t step, uint64_t n, const void* d_src, hipStream_t s)
+{
+    if (null_) return no_data_path("speckv_ext_write_strided");
+    Allocation* a = find(handle);
+    if (!a) return SPECKV_ERR_GENERAL;
+    if (!d_src || step == 0) return SPECKV_ERR_INVAL;
+    if (n == 0) return SPECKV_OK;
+    if (first >= a->n_pages || (n - 1) > (a->n_pages - 1 - first) / step) return SPECKV_ERR_GENERAL;
+    // a last page that is only partly inside the allocation would need zero padding of the source: not here
+    if (a->size_bytes % kPageSize && first + (n - 1) * step == a->n_pages - 1) return SPECKV_ERR_INVAL;
+    DeviceScope device_scope(device_);
+    // NULL = the engine's stream: the source may have been produced on any stream of the caller, order after all of them
+    if (!s) HIP_TRY(hipDeviceSynchronize());
+    bool cached = false;
+    for (uint64_t i = 0; i < n && !cached; ++i) cached = (a->flags[first + i * step] & 3u) != 0;
+    if (cached || !flights_.empty() || ring_busy_ > 0) {
+        RC_TRY(quiesce());
+        if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
+        for (uint64_t i = 0; i < n; ++i) drop_page(a, static_cast<uint32_t>(first + i * step));
+        RC_TRY(flush_mirror());
+        if (s) RC_TRY(wait_stream());
+    }
+    CodecArgs c{};
+    c.entries = a->d_entries;
+    c.scale_tab = a->d_scale_tab;
+    c.region_pages = a->region_pages;
+    c.data_stride = kPageSize;
+    c.scheme = a->scheme;
+    c.quant_mode = quant_mode_;
+    c.first = first;
+    c.page_step = step;
+    c.n = n;
+    c.data = static_cast<uint8_t*>(const_cast<void*>(d_src));
+    hipStream_t st = s ? s : stream_;
+    HIP_TRY(launch_compress(c, st));
+    note_use(a, s);
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t& f = a->flags[first + i * step];
+        if (a->scheme != SPECKV_COMP_FP16) f |= 4u; else f &= ~4u;
+    }
+    st_.total_compressions += n;
+    st_.original_bytes += n * kPageSize;
+    if (!s) RC_TRY(wait_stream());
+    return SPECKV_OK;
+}
+
 int Engine::read(uint64_t handle, uint64_t off, void* dst, size_t len, bool on_device)
 {
     if (null_) return no_data_path("speckv_ext_read");

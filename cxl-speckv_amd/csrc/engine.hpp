@@ -114,6 +114,7 @@ public:
     int set_layout(uint64_t handle, uint32_t T, uint32_t L, uint32_t H, uint32_t D, uint32_t bpe);
     int bind_request(uint32_t req, uint64_t handle, uint32_t local_req);
     int write(uint64_t handle, uint64_t off, const void* src, size_t len, bool on_device);
+    int write_strided(uint64_t handle, uint64_t first, uint64_t step, uint64_t n, const void* d_src, hipStream_t s);
     int read(uint64_t handle, uint64_t off, void* dst, size_t len, bool on_device);
     int fetch_range(uint64_t handle, uint64_t first, uint64_t n, void* d_dst, bool f32, hipStream_t s, int engine_choice);
     int fetch_list(uint64_t handle, const uint32_t* d_pages, uint32_t n, void* d_dst, bool f32, hipStream_t s);

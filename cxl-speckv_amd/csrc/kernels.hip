@@ -693,7 +693,7 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
     const uint64_t n = a.n;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kWaves;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kWaves + wave; i < n; i += stride) {
-        const uint64_t page = a.page_list ? a.page_list[i] : a.first + i;
+        const uint64_t page = a.page_list ? a.page_list[i] : a.first + i * (a.page_step ? a.page_step : 1);
         const uint8_t* src = a.data_list ? reinterpret_cast<const uint8_t*>(a.data_list[i])
                                          : a.data + i * a.data_stride;
         uint8_t* rec = a.entries ? reinterpret_cast<uint8_t*>(a.entries[page].pool_addr)

@@ -57,9 +57,10 @@ struct CodecArgs {
     uint64_t        rec_stride;
     uint32_t*       rec_bytes;    // raw form
     float*          scales;       // raw form
-    // block index mapping: page = page_list ? page_list[i] : first + i
+    // block index mapping: page = page_list ? page_list[i] : first + i  (compress only: first + i*page_step when page_step != 0)
     const uint32_t* page_list;
     uint64_t        first;
+    uint64_t        page_step;
     // fp16 / fp32 side: block i at data + i*data_stride_bytes, or data_list[i]
     uint8_t*        data;
     uint64_t        data_stride;

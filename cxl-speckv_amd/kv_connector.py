@@ -1,0 +1,206 @@
+"""A vLLM-shaped KV connector on top of libcxlspeckv.so.
+
+The reference stops at a sketch of the decode loop (reference host/python/vllm_speckv_backend.py:104-129: per token,
+``prefetch_step`` per layer, ``get_kv_ptr`` per entry) around a single-request allocator.  This class is the piece a
+paged-attention layer would talk to for a BATCH of requests:
+
+  add_request / free_request   one allocation per request (the shim layout of ``CxlSpeckvKVAllocator.allocate``:
+                               ``[layer][kind][pos][head]``), its geometry and its request id bound in the engine
+  write_prefill                the prompt's K / V of every layer, compressed into the pool
+  append                       one decode step's new K / V rows of every layer for every request of the batch; rows
+                               are stored page-wise (one 4 KiB page = 2 positions x 8 kv heads x 128), so an odd last
+                               position lives in a small fp16 tail on the compute GPU until its partner arrives
+  begin_step                   one batched speculative look-ahead for the whole batch (one device-side flush)
+  block_table                  device addresses of the decompressed pages of a request (paged-attention consumers)
+  attend                       the attention of one layer for the whole batch straight from the compressed records
+                               (FP8 / INT4 pools: ``speckv_ext_attend_*_batch``), the tail position folded in with
+                               the returned log-sum-exp
+
+Only plain device pointers cross into the library; torch is used for device buffers and the tail fold.
+"""
+from typing import Dict, List, Optional, Sequence
+
+from .speckv_ctypes import SpeckvLib
+
+PAGE = 4096
+SCHEMES = {"fp16": 0, "int8": 1, "int8_delta_rle": 2, "int4": 3, "fp8": 4}
+
+
+class _Request:
+    __slots__ = ("handle", "length", "tail_k", "tail_v")
+
+    def __init__(self, handle):
+        self.handle = handle
+        self.length = 0            # positions stored or held in the tail
+        self.tail_k = None         # [layers][heads][dim] fp16 of an odd last position
+        self.tail_v = None
+
+
+class SpeckvKVConnector:
+    def __init__(self, lib: SpeckvLib, num_layers: int, num_kv_heads: int = 8, head_dim: int = 128, max_tokens: int = 4096,
+                 scheme: str = "fp8"):
+        if num_kv_heads * head_dim * 2 != 2048:
+            raise ValueError("the page-wise layout needs num_kv_heads * head_dim == 1024 fp16 elements per position "
+                             "(8 kv heads x 128: Llama-3 8B / 70B)")
+        if max_tokens % 32:
+            raise ValueError("max_tokens must be a multiple of 32 (tile size of the fused attention)")
+        self.lib = lib
+        self.L, self.H, self.D, self.T = num_layers, num_kv_heads, head_dim, max_tokens
+        self.scheme = SCHEMES[scheme] if isinstance(scheme, str) else int(scheme)
+        self.requests: Dict[int, _Request] = {}
+        self.region_pages = max_tokens // 2                   # pages of one (layer, kind) region
+        self._side = None
+
+    # The library takes a hipStream_t and reads NULL as "the engine's own stream".  torch's default stream IS the NULL
+    # stream, so work issued from it goes through a side stream that is ordered after it and that it then waits for.
+    class _On:
+        def __init__(self, conn, stream):
+            import torch
+            self.cur = stream if stream is not None else torch.cuda.current_stream()
+            self.side = None
+            if self.cur.cuda_stream == 0:
+                if conn._side is None:
+                    conn._side = torch.cuda.Stream()
+                self.side = conn._side
+
+        def __enter__(self):
+            if self.side is not None:
+                self.side.wait_stream(self.cur)
+                return self.side
+            return self.cur
+
+        def __exit__(self, *exc):
+            if self.side is not None:
+                self.cur.wait_stream(self.side)
+            return False
+
+    # ------------------------------------------------------------------ requests
+    def add_request(self, req_id: int) -> int:
+        if req_id in self.requests:
+            raise KeyError(f"request {req_id} already exists")
+        self.lib.set_compression_scheme(self.scheme)
+        h = self.lib.alloc(2 * self.T * self.L * self.H * self.D * 2)
+        self.lib.set_layout(h, self.T, self.L, self.H, self.D, 2)
+        self.lib.bind_request(req_id, h, 0)
+        self.requests[req_id] = _Request(h)
+        return h
+
+    def free_request(self, req_id: int):
+        r = self.requests.pop(req_id)
+        self.lib.free(r.handle)                               # the binding goes with the handle
+
+    def length(self, req_id: int) -> int:
+        return self.requests[req_id].length
+
+    def _page(self, layer: int, kind: int, pos: int) -> int:
+        return ((layer * 2 + kind) * self.T + pos) // 2
+
+    # ------------------------------------------------------------------ writes
+    def write_prefill(self, req_id: int, k, v):
+        """k, v: [layers][tokens][heads][dim] fp16 CUDA tensors of the prompt."""
+        import torch
+        r = self.requests[req_id]
+        n = k.shape[1]
+        if r.length:
+            raise ValueError("write_prefill on a request that already has positions")
+        even = n & ~1
+        for kind, t in ((0, k), (1, v)):
+            t = t.contiguous()
+            for layer in range(self.L):
+                if even:
+                    off = self._page(layer, kind, 0) * PAGE
+                    rows = t[layer, :even].contiguous()
+                    self.lib.write(r.handle, off, rows.data_ptr(), rows.numel() * 2, True)
+        if n & 1:
+            r.tail_k = k[:, n - 1].contiguous().clone()
+            r.tail_v = v[:, n - 1].contiguous().clone()
+        r.length = n
+        torch.cuda.synchronize()
+
+    def append(self, req_ids: Sequence[int], k_new, v_new, stream=None):
+        """One decode step: k_new, v_new [batch][layers][heads][dim] fp16.  A position that completes a pair is written
+        together with its partner (2 * layers pages per request, one asynchronous call); an odd one waits in the tail."""
+        import torch
+        keep, todo = [], []
+        for b, rid in enumerate(req_ids):
+            r = self.requests[rid]
+            if r.length >= self.T:
+                raise ValueError(f"request {rid} is full")
+            if r.length % 2 == 0:
+                r.tail_k, r.tail_v = k_new[b].contiguous().clone(), v_new[b].contiguous().clone()
+            else:
+                # page image of the pair for every (layer, kind): [layer][kind][2 positions][heads][dim]
+                pair = torch.stack((torch.stack((r.tail_k, k_new[b]), dim=1), torch.stack((r.tail_v, v_new[b]), dim=1)), dim=1).contiguous()
+                todo.append((r.handle, self._page(0, 0, r.length - 1), pair))
+                keep.append(pair)
+                r.tail_k = r.tail_v = None
+            r.length += 1
+        if todo:
+            with self._On(self, stream) as st:
+                for handle, first, pair in todo:
+                    self.lib.write_strided(handle, first, self.region_pages, 2 * self.L, pair.data_ptr(), st.cuda_stream)
+        return keep                                            # sources of the asynchronous writes: hold until the stream passed them
+
+    # ------------------------------------------------------------------ reads
+    def begin_step(self, req_ids: Sequence[int], depth_k: int = 0) -> Optional[int]:
+        """Speculative look-ahead of the next positions of every (request, layer): one prefetch batch, one flush.
+        Meaningful for pools whose pages are consumed decompressed (fp16 / int8 schemes); the fused attention of the
+        FP8 / INT4 pools reads the records themselves."""
+        import numpy as np
+        n = len(req_ids) * self.L
+        reqs = np.repeat(np.asarray(req_ids, dtype=np.uint32), self.L)
+        layers = np.tile(np.arange(self.L, dtype=np.uint16), len(req_ids))
+        pos = np.repeat(np.asarray([max(self.requests[r].length - 1, 0) for r in req_ids], dtype=np.uint32), self.L)
+        depth = np.full(n, depth_k, np.uint32)
+        self.lib.prefetch_batch(reqs, layers, pos, depth)
+        return self.lib.prefetch_flush(want_count=False)
+
+    def block_table(self, req_id: int, layer: int, kind: int, pos_begin: int, pos_end: int) -> List[int]:
+        """Device addresses of the decompressed rows [pos_begin, pos_end) (stored positions only)."""
+        r = self.requests[req_id]
+        row = self.H * self.D * 2
+        base = ((layer * 2 + kind) * self.T) * row
+        return self.lib.access_batch(r.handle, [base + p * row for p in range(pos_begin, min(pos_end, r.length & ~1))])
+
+    def kv_rows(self, req_id: int, layer: int, kind: int):
+        """All stored rows of one layer as an fp16 tensor [positions][heads][dim] (fetch + decompress), tail included."""
+        import torch
+        r = self.requests[req_id]
+        even = r.length & ~1
+        out = torch.empty((r.length, self.H, self.D), dtype=torch.float16, device="cuda")
+        if even:
+            with self._On(self, None) as st:
+                self.lib.fetch_range(r.handle, self._page(layer, kind, 0), even // 2, out.data_ptr(), False, st.cuda_stream)
+        if r.length & 1:
+            out[even] = (r.tail_k if kind == 0 else r.tail_v)[layer]
+        return out
+
+    def attend(self, layer: int, req_ids: Sequence[int], q, sm_scale: float, stream=None):
+        """softmax(q.K^T * sm_scale).V of one layer for the batch.  q: [batch][heads][g][dim] fp16 (g query rows per kv
+        head, GQA); returns [batch][heads][g][dim] fp32.  Stored positions come straight from the compressed records
+        (one launch pair for the batch), the tail position is folded in with the log-sum-exp."""
+        import torch
+        if self.scheme not in (3, 4):
+            raise ValueError("attend() needs an FP8 or INT4 pool; use block_table() / kv_rows() with the other schemes")
+        B, H, G, D = q.shape
+        reqs = [self.requests[r] for r in req_ids]
+        q = q.contiguous()
+        out = torch.empty((B, H, G, D), dtype=torch.float32, device="cuda")
+        lse = torch.empty((B, H, G), dtype=torch.float32, device="cuda")
+        fn = self.lib.attend_fp8_batch if self.scheme == 4 else self.lib.attend_int4_batch
+        with self._On(self, stream) as st:
+            fn([r.handle for r in reqs], layer, q.data_ptr(), G, [r.length & ~1 for r in reqs], sm_scale, out.data_ptr(), lse.data_ptr(),
+               st.cuda_stream)
+        odd = [b for b, r in enumerate(reqs) if r.length & 1]
+        if odd:
+            idx = torch.tensor(odd, device="cuda")
+            kt = torch.stack([reqs[b].tail_k[layer] for b in odd]).float()        # [n][heads][dim]
+            vt = torch.stack([reqs[b].tail_v[layer] for b in odd]).float()
+            s = torch.einsum("bhgd,bhd->bhg", q[idx].float(), kt) * sm_scale
+            empty = torch.tensor([reqs[b].length < 2 for b in odd], device="cuda")[:, None, None]
+            old = torch.where(empty, torch.full_like(s, float("-inf")), lse[idx])
+            new = torch.logaddexp(old, s)
+            w_old = torch.exp(old - new)[..., None]
+            w_new = torch.exp(s - new)[..., None]
+            out[idx] = torch.where(empty[..., None], torch.zeros_like(out[idx]), out[idx]) * w_old + vt[:, :, None, :] * w_new
+        return out

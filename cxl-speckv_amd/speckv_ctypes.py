@@ -53,6 +53,7 @@ _EXT_SIGNATURES = {
     "speckv_ext_set_layout": [c_uint64, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32],
     "speckv_ext_write": [c_uint64, c_uint64, c_void_p, c_size_t, c_int],
     "speckv_ext_read": [c_uint64, c_uint64, c_void_p, c_size_t, c_int],
+    "speckv_ext_write_strided": [c_uint64, c_uint64, c_uint64, c_uint64, c_void_p, c_void_p],
     "speckv_ext_fetch_range": [c_uint64, c_uint64, c_uint64, c_void_p, c_int, c_void_p],
     "speckv_ext_fetch_range_engine": [c_uint64, c_uint64, c_uint64, c_void_p, c_int, c_void_p, c_int],
     "speckv_ext_bind_request": [c_uint32, c_uint64, c_uint32],
@@ -204,6 +205,9 @@ class SpeckvLib:
 
     def write(self, handle, offset, src_ptr, nbytes, on_device):
         self._ext("speckv_ext_write", handle, offset, c_void_p(src_ptr), nbytes, int(on_device))
+
+    def write_strided(self, handle, first_page, page_step, n_pages, d_src, stream=None):
+        self._ext("speckv_ext_write_strided", handle, first_page, page_step, n_pages, c_void_p(d_src), c_void_p(stream or 0))
 
     def read(self, handle, offset, dst_ptr, nbytes, on_device):
         self._ext("speckv_ext_read", handle, offset, c_void_p(dst_ptr), nbytes, int(on_device))

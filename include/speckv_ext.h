@@ -82,6 +82,13 @@ speckv_status_t speckv_ext_set_layout(speckv_handle_t handle, uint32_t num_token
  * Stands in for the DMA write direction the reference only sketches. */
 speckv_status_t speckv_ext_write(speckv_handle_t handle, uint64_t offset_bytes,
                                  const void* src, size_t len, int src_on_device);
+/* The append path of a decode loop: compress n pages first_page, first_page + page_step, ... from a contiguous device
+ * buffer (n * 4096 bytes), ASYNCHRONOUSLY on `stream` (the source must stay valid until the stream gets there).  In
+ * the shim layout the pages of one position pair in all (layer, kind) regions are num_tokens/2 pages apart, so one
+ * call stores a sequence's new K and V rows of every layer.  Pages that are cached at the time of the call are
+ * invalidated first (that case waits for the engine). */
+speckv_status_t speckv_ext_write_strided(speckv_handle_t handle, uint64_t first_page, uint64_t page_step,
+                                         uint64_t n_pages, const void* d_src, void* stream);
 /* Fetch + decompress straight into a caller buffer, bypassing the tiers. */
 speckv_status_t speckv_ext_read(speckv_handle_t handle, uint64_t offset_bytes,
                                 void* dst, size_t len, int dst_on_device);

@@ -385,3 +385,105 @@ def test_batch_attention_refuses_stream_capture():
         assert torch.allclose(out, eager, rtol=1e-5, atol=1e-6)
     finally:
         lib.finalize()
+
+
+@pytest.mark.parametrize("scheme", ["fp8", "int4"])
+def test_kv_connector_toy_decode_loop(scheme):
+    """a vLLM-shaped connector (one allocation per request, batched append / look-ahead / attention).
+    A 2-layer toy decode loop over a batch of three requests: at every step the attention the connector computes
+    straight from the compressed records (+ the fp16 tail position) equals torch attention over the pages fetched and
+    decompressed from the same pool.  Tolerances as the per-sequence tests: INT4 2e-3 * sum p|v| (same arithmetic on
+    both sides up to summation order), FP8 10 % of the largest output (its query is quantised to e4m3 in the kernel)."""
+    torch = torch_mod()
+    from cxl_speckv_amd.kv_connector import SpeckvKVConnector
+    lib = open_lib()
+    try:
+        L, H, D, G, T = 2, 8, 128, 4, 256
+        conn = SpeckvKVConnector(lib, num_layers=L, num_kv_heads=H, head_dim=D, max_tokens=T, scheme=scheme)
+        gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+        rnd = lambda *s: torch.randn(s, generator=gen, device="cuda", dtype=torch.float32).to(torch.float16)
+        rids, prompt = [11, 12, 13], [37, 64, 1]
+        for rid, n in zip(rids, prompt):
+            conn.add_request(rid)
+            conn.write_prefill(rid, rnd(L, n, H, D), rnd(L, n, H, D))
+        sm = 1.0 / np.sqrt(D)
+        keep = []
+        for step in range(9):
+            keep += conn.append(rids, rnd(len(rids), L, H, D), rnd(len(rids), L, H, D))
+            for layer in range(L):
+                q = rnd(len(rids), H, G, D)
+                out = conn.attend(layer, rids, q, sm)
+                torch.cuda.synchronize()
+                for b, rid in enumerate(rids):
+                    k = conn.kv_rows(rid, layer, 0).float()
+                    v = conn.kv_rows(rid, layer, 1).float()
+                    assert k.shape[0] == prompt[b] + step + 1 == conn.length(rid)
+                    p = torch.softmax(torch.einsum("hgd,thd->hgt", q[b].float(), k) * sm, dim=-1)
+                    ref = torch.einsum("hgt,thd->hgd", p, v)
+                    err = (out[b] - ref).abs()
+                    if scheme == "int4":
+                        mag = torch.einsum("hgt,thd->hgd", p, v.abs())
+                        assert bool((err <= 2e-3 * mag + 1e-5).all()), (step, layer, rid, float(err.max()))
+                    else:
+                        # e4m3 keeps 3 mantissa bits: every V element is off by <= 2^-4 of itself (0.0625 * sum p|v|), the
+                        # e4m3 query / K perturb the weights of a short context by a few per cent of max|v| on top
+                        mag = torch.einsum("hgt,thd->hgd", p, v.abs())
+                        assert bool((err <= 0.07 * mag + 0.08 * v.abs().max()).all()), (step, layer, rid, float(err.max()))
+        # a request leaves, another joins with the same id: the binding follows
+        conn.free_request(12)
+        conn.add_request(12)
+        conn.write_prefill(12, rnd(L, 8, H, D), rnd(L, 8, H, D))
+        out = conn.attend(0, [12], rnd(1, H, G, D), sm)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(out).all())
+        for rid in (11, 12, 13):
+            conn.free_request(rid)
+    finally:
+        lib.finalize()
+
+
+def test_kv_connector_block_tables_and_lookahead(oracle):
+    """The same connector over a pool whose pages are consumed decompressed (INT8_DELTA_RLE, the reference's codec):
+    one batched look-ahead per step, block tables of device addresses for a paged-attention consumer."""
+    torch = torch_mod()
+    from cxl_speckv_amd.kv_connector import SpeckvKVConnector
+    lib = open_lib()
+    try:
+        L, H, D, T = 3, 8, 128, 128
+        conn = SpeckvKVConnector(lib, num_layers=L, num_kv_heads=H, head_dim=D, max_tokens=T, scheme="int8_delta_rle")
+        gen = torch.Generator(device="cuda"); gen.manual_seed(6)
+        rnd = lambda *s: torch.randn(s, generator=gen, device="cuda", dtype=torch.float32).to(torch.float16)
+        data = {}
+        for rid, n in ((1, 40), (2, 64)):
+            conn.add_request(rid)
+            k, v = rnd(L, n, H, D), rnd(L, n, H, D)
+            conn.write_prefill(rid, k, v)
+            data[rid] = (k, v)
+        # the look-ahead of position len-1 brings the rows after it; ask at an earlier position so that stored rows are hit
+        for rid in (1, 2):
+            conn.requests[rid].length -= 10
+        conn.begin_step([1, 2], depth_k=4)
+        lib.sync()
+        for rid in (1, 2):
+            conn.requests[rid].length += 10
+        assert lib.stats().total_prefetches > 0 and lib.stats().prefetch_dropped == 0
+        hits0 = lib.stats().l2_hits
+        for rid in (1, 2):
+            n = conn.length(rid)
+            for layer in range(L):
+                for kind in (0, 1):
+                    addrs = conn.block_table(rid, layer, kind, n - 10, n - 6)
+                    assert len(addrs) == 4 and all(addrs)
+                    rows = conn.kv_rows(rid, layer, kind)
+                    torch.cuda.synchronize()
+                    for j, a in enumerate(addrs):
+                        got = dev_to_host(a, H * D * 2)
+                        assert got.tobytes() == rows[n - 10 + j].cpu().numpy().tobytes()
+                    # and those rows are what the reference codec makes of the data (oracle, bit for bit)
+                    src = data[rid][kind][layer, n - 10 - (n - 10) % 2: n - 10 - (n - 10) % 2 + 2].cpu().numpy().reshape(1, N)
+                    sc, ln, rc = oracle.compress_blocks_f16(src, 2, 0)
+                    want = oracle.decompress_blocks_f16(rc, ln, sc, 2, 0).reshape(2, H, D)
+                    assert_same_float_bits(rows[n - 10 - (n - 10) % 2: n - 10 - (n - 10) % 2 + 2].cpu().numpy(), want)
+        assert lib.stats().l2_hits > hits0                            # the block tables were served from prefetched pages
+    finally:
+        lib.finalize()
