@@ -25,6 +25,7 @@
 #include <hip/hip_fp16.h>
 
 #include <cstdlib>
+#include <cstring>
 
 namespace speckv {
 namespace {
@@ -509,15 +510,21 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
         slot0 = a.slot0_dev ? *a.slot0_dev : a.slot0;
         if (a.hand_ptr && blockIdx.x == 0 && threadIdx.x == 0) *a.hand_ptr = a.new_hand;
     }
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kWaves;
-    uint64_t i = static_cast<uint64_t>(blockIdx.x) * kWaves + wave;
+    // a wave's blocks: one, or (launches beyond the grid cap) `per_wave` CONSECUTIVE ones -- neighbouring waves then
+    // stream neighbouring pages in every round and no two rounds sit a power of two apart (a grid-stride loop over a
+    // 65 536-workgroup grid puts a wave's blocks exactly 1 GiB apart: 0.74 of peak at 2 rounds, 0.67 at 10)
+    const uint64_t per_wave = a.per_wave ? a.per_wave : 1;
+    const uint64_t gw = static_cast<uint64_t>(blockIdx.x) * kWaves + wave;
+    const uint64_t step = a.wave_step ? a.wave_step : 1;                  // 1: consecutive blocks, else one per round
+    uint64_t i = a.wave_step ? gw : gw * per_wave;
+    uint64_t end = a.wave_step ? n : ((i + per_wave < n) ? i + per_wave : n);
     if (i >= n) return;
     BlockDesc cur = load_desc<EXT>(a, i, slot0);
     for (;;) {
         // the next block's descriptor is fetched while this block is decoded
-        const uint64_t nx = i + stride;
+        const uint64_t nx = i + step;
         BlockDesc nxt = cur;
-        if (nx < n) nxt = load_desc<EXT>(a, nx, slot0);
+        if (nx < end) nxt = load_desc<EXT>(a, nx, slot0);
         uint32_t len = cur.len;
         if (SCHEME == kInt8DeltaRle) {
             if (len > 2u * kBlockElems) len = 2u * kBlockElems;
@@ -541,7 +548,7 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
             if (EXT == 2 && a.ring_owner) ring_note(a, cur, slot0 + static_cast<uint32_t>(i));
             else if (a.flags) atomicOr(&a.flags[cur.page], a.set_flags);   // neighbours belong to other waves / XCDs
         }
-        if (nx >= n) break;
+        if (nx >= end) break;
         cur = nxt;
         i = nx;
     }
@@ -691,8 +698,10 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint64_t n = a.n;
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kWaves;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kWaves + wave; i < n; i += stride) {
+    const uint64_t per_wave = a.per_wave ? a.per_wave : 1;       // consecutive blocks per wave (see k_fetch_decompress)
+    const uint64_t i0 = (static_cast<uint64_t>(blockIdx.x) * kWaves + wave) * per_wave;
+    const uint64_t i1 = (i0 + per_wave < n) ? i0 + per_wave : n;
+    for (uint64_t i = i0; i < i1; ++i) {
         const uint64_t page = a.page_list ? a.page_list[i] : a.first + i * (a.page_step ? a.page_step : 1);
         const uint8_t* src = a.data_list ? reinterpret_cast<const uint8_t*>(a.data_list[i])
                                          : a.data + i * a.data_stride;
@@ -1388,11 +1397,12 @@ int num_cus()
     }
     return g_cus;
 }
-uint32_t codec_grid(uint64_t n)
+// Launch shape: one block per wave up to per_cu workgroups per CU (short-lived waves even out the tail); beyond that
+// every wave takes the same number of consecutive blocks (*per_wave) so that no round runs half empty.
+// (A capped grid-stride loop: 655 360 blocks over 65 536 workgroups = 2.5 rounds, last one half empty: 0.73 of HBM
+// peak; balanced 0.77-0.80.  Measured with scratch/footprint.py, profiles/r02_footprint.md.)
+uint32_t codec_grid(uint64_t n, uint64_t* per_wave)
 {
-    // one block per wave up to 128 workgroups per CU (measured best on MI355X:
-    // short-lived waves even out the tail), grid-stride beyond that; neighbouring
-    // waves stream neighbouring pages.
     static int per_cu = [] {
         const char* e = getenv("SPECKV_WGS_PER_CU");
         int v = e ? atoi(e) : 256;
@@ -1400,13 +1410,27 @@ uint32_t codec_grid(uint64_t n)
     }();
     const uint64_t want = (n + kWaves - 1) / kWaves;
     const uint64_t cap = static_cast<uint64_t>(num_cus()) * per_cu * (4 / kWaves);
-    return static_cast<uint32_t>(want < cap ? (want ? want : 1) : cap);
+    *per_wave = 1;
+    if (want <= cap) return static_cast<uint32_t>(want ? want : 1);
+    const uint64_t rounds = (want + cap - 1) / cap;
+    *per_wave = rounds;
+    return static_cast<uint32_t>((want + rounds - 1) / rounds);
+}
+// Multi-round launches: a wave's blocks are one grid apart (round r covers blocks [r*G, (r+1)*G) like a launch of its
+// own).  Measured against `per_wave` consecutive blocks per wave on the same device (SPECKV_ROUNDS=consecutive):
+// 0.775 / 0.772 / 0.770 of HBM peak vs 0.753 / 0.69 / 0.657 at 4 / 5 / 20 GiB of pool + destination.
+bool round_strided()
+{
+    static const bool v = [] { const char* e = getenv("SPECKV_ROUNDS"); return !(e && !strcmp(e, "consecutive")); }();
+    return v;
 }
 
 template <int SCHEME, int MODE>
-hipError_t launch_dec2(const CodecArgs& a, hipStream_t s)
+hipError_t launch_dec2(const CodecArgs& a_in, hipStream_t s)
 {
-    const uint32_t grid = codec_grid(a.n);
+    CodecArgs a = a_in;
+    const uint32_t grid = codec_grid(a.n, &a.per_wave);
+    a.wave_step = (round_strided() && a.per_wave > 1) ? static_cast<uint64_t>(grid) * kWaves : 0;
     const int ext = (a.alloc_list || a.ring_owner) ? 2 : a.stripe_n ? 1 : 0;
     if (ext == 2 && a.stripe_n) return hipErrorInvalidValue;
 #define SPECKV_LAUNCH_DEC(F32, EXT) \
@@ -1422,9 +1446,10 @@ hipError_t launch_dec1(const CodecArgs& a, hipStream_t s)
     return a.quant_mode == kIntent ? launch_dec2<SCHEME, kIntent>(a, s) : launch_dec2<SCHEME, kRefExact>(a, s);
 }
 template <int SCHEME>
-hipError_t launch_enc1(const CodecArgs& a, hipStream_t s)
+hipError_t launch_enc1(const CodecArgs& a_in, hipStream_t s)
 {
-    const uint32_t grid = codec_grid(a.n);
+    CodecArgs a = a_in;
+    const uint32_t grid = codec_grid(a.n, &a.per_wave);
     if (a.quant_mode == kIntent) hipLaunchKernelGGL((k_compress<SCHEME, kIntent>), dim3(grid), dim3(kThreads), 0, s, a);
     else                         hipLaunchKernelGGL((k_compress<SCHEME, kRefExact>), dim3(grid), dim3(kThreads), 0, s, a);
     return hipGetLastError();
@@ -1453,11 +1478,15 @@ hipError_t launch_compress(const CodecArgs& a, hipStream_t s)
     case kInt8: return launch_enc1<kInt8>(a, s);
     case kInt8DeltaRle: return launch_enc1<kInt8DeltaRle>(a, s);
     case kInt4G32: {
-        hipLaunchKernelGGL((k_compress<kInt4G32, kRefExact>), dim3(codec_grid(a.n)), dim3(kThreads), 0, s, a);
+        CodecArgs b = a;
+        const uint32_t grid = codec_grid(b.n, &b.per_wave);
+        hipLaunchKernelGGL((k_compress<kInt4G32, kRefExact>), dim3(grid), dim3(kThreads), 0, s, b);
         return hipGetLastError();
     }
     case kFp8E4m3: {
-        hipLaunchKernelGGL((k_compress<kFp8E4m3, kRefExact>), dim3(codec_grid(a.n)), dim3(kThreads), 0, s, a);
+        CodecArgs b = a;
+        const uint32_t grid = codec_grid(b.n, &b.per_wave);
+        hipLaunchKernelGGL((k_compress<kFp8E4m3, kRefExact>), dim3(grid), dim3(kThreads), 0, s, b);
         return hipGetLastError();
     }
     default: return hipErrorInvalidValue;

@@ -68,6 +68,8 @@ struct CodecArgs {
     // count
     uint64_t        n;
     const uint32_t* n_dev;        // optional: n read from device memory (<= n)
+    uint64_t        per_wave;     // set by the launcher: blocks per wave (0 = 1) ...
+    uint64_t        wave_step;    // ... consecutive (0) or this many blocks apart (one per round of the grid)
     // residency mirror update on completion (decompress only): flags[page] |= set_flags (atomic)
     uint32_t*       flags;
     uint32_t        set_flags;
