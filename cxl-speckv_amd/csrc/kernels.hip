@@ -36,7 +36,7 @@ namespace {
 constexpr int kWaves = SPECKV_WAVES;      // wavefronts per workgroup (independent of each other)
 constexpr int kThreads = 64 * kWaves;
 constexpr int kDecLdsWords = 528;         // per wave: 2 KiB byte table + 64 B of write-only dummies
-constexpr int kEncLdsHalves = 3200;        // per wave: 6400 B (see kEncWaveBytes)
+constexpr int kEncLdsHalves = 2064;        // per wave: 4128 B (see kEncWaveBytes)
 
 // Streaming accesses: every record byte is read once and every output byte
 // written once per launch, so both are marked non-temporal (measured on MI355X,
@@ -510,9 +510,8 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
         slot0 = a.slot0_dev ? *a.slot0_dev : a.slot0;
         if (a.hand_ptr && blockIdx.x == 0 && threadIdx.x == 0) *a.hand_ptr = a.new_hand;
     }
-    // a wave's blocks: one, or (launches beyond the grid cap) `per_wave` CONSECUTIVE ones -- neighbouring waves then
-    // stream neighbouring pages in every round and no two rounds sit a power of two apart (a grid-stride loop over a
-    // 65 536-workgroup grid puts a wave's blocks exactly 1 GiB apart: 0.74 of peak at 2 rounds, 0.67 at 10)
+    // a wave's blocks: one, or (launches beyond the grid cap) `per_wave` of them, one grid apart (wave_step) or
+    // consecutive (SPECKV_ROUNDS=consecutive); see codec_grid / round_strided
     const uint64_t per_wave = a.per_wave ? a.per_wave : 1;
     const uint64_t gw = static_cast<uint64_t>(blockIdx.x) * kWaves + wave;
     const uint64_t step = a.wave_step ? a.wave_step : 1;                  // 1: consecutive blocks, else one per round
@@ -557,12 +556,10 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
 // ===================================================================
 // RLE encode of the delta stream (cache_engine.cpp:198-239)
 // ===================================================================
-// Wave LDS layout (bytes): [0,16) write-only dummies / lead, [16, 16+4096) pair
-// buffer, [4128, 4128+2048) the quantised bytes in position order (for the
-// general path).  Both paths scatter, per RUN START at position p, the value
-// byte of its own pair and the count byte of the PREVIOUS pair (p - previous
-// start); the last pair is closed after the loop.  No read-back from LDS.
-constexpr uint32_t kEncPairOff = 16, kEncQOff = 4128, kEncWaveBytes = 6400;
+// Wave LDS layout (bytes): [0,16) lead (the count byte "before the first pair" lands here), [16, 16+4096) pair
+// buffer.  Both paths scatter, per RUN START at position p, the value byte of its own pair and the count byte of the
+// PREVIOUS pair (p - previous start); the last pair is closed after the loop.  No read-back from LDS.
+constexpr uint32_t kEncPairOff = 16, kEncWaveBytes = 4128;
 constexpr uint32_t kEncFail = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p)
@@ -570,99 +567,152 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p)
     return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8*)p));
 }
 
-// Fast path: no stretch of equal deltas reaches 255 elements, so every change
-// of the delta starts a run and no run has to be split (count < 255 rule).
-// Per chunk: flags -> count / last start per lane -> one add-scan (run index) and
-// one max-scan (previous start) -> 2 byte stores per element.  Returns the number
-// of runs, or kEncFail when a long stretch may exist (>= 14 lanes of a chunk
-// without any run start: a 255-stretch needs 30 such lanes in two chunks).
-// The block is quantised chunk by chunk (8 live bytes per lane instead of 32); the
-// bytes are also staged in LDS in position order in case the general path is needed.
+// The encoder is VALU-bound (rocprofv3, 131072 N(0,1) blocks: VALU issue 93 % busy at 923 instructions per block-wave,
+// profiles/r02_compress_pmc.json), so this path is written for instruction count:
+//   * quantisation in packed fp32 (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two elements per instruction); the byte
+//     is never masked out -- every consumer selects byte 0 (SDWA);
+//   * delta = (q.b0 - prev.b0) as one SDWA subtract that writes a zero-padded byte;
+//   * the eight "starts a run" predicates of a lane stay in SGPR pairs (v_cmp results); a carry chain
+//     (v_addc: mask = 2*mask + predicate) turns them into an 8-bit mask -> run count by v_bcnt, last start by v_ffbl;
+//   * the scatter is predicated by EXEC (scalar) instead of selecting a dummy address per element, the run index
+//     advances by v_addc of the same predicate, count = k - (last start relative to the lane) with k an inline constant.
+// 8 quantised elements of one lane (low byte of each q[k] is the int8; upper bits are the rest of the int32)
 template <int MODE>
-__device__ __forceinline__ void quantize_chunk(const float (&x)[8], float scale, float rcp, bool finite, uint32_t (&q)[8])
+__device__ __forceinline__ void quantize8(const uint4 raw, float scale, float rcp, uint32_t (&q)[8])
 {
-    if (finite) {
+    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+    const f32x2 ss = {scale, scale}, rr = {rcp, rcp};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) q[k] = quantize_finite<MODE>(x[k], scale, rcp);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) q[k] = quantize<MODE>(x[k], scale);
+    for (int t = 0; t < 4; ++t) {
+        f32x2 x;
+        x.x = half_bits_to_float(w[t] & 0xFFFFu);
+        x.y = half_bits_to_float(w[t] >> 16);
+        // x / scale through the block's reciprocal (div_by_scale: exact for every operand the codec sees)
+        const f32x2 q0 = x * rr;
+        const f32x2 e = __builtin_elementwise_fma(-q0, ss, x);
+        f32x2 y = __builtin_elementwise_fma(e, rr, q0);
+        if (MODE == kRefExact) { const f32x2 k127 = {127.0f, 127.0f}; y = y * k127; }      // cache_engine.cpp:190-191
+        f32x2 h;
+        h.x = __builtin_copysignf(0.5f, y.x);
+        h.y = __builtin_copysignf(0.5f, y.y);
+        const f32x2 r = y + h;                              // round half away from zero = truncate(y + copysign(0.5, y))
+        int i0 = static_cast<int>(r.x), i1 = static_cast<int>(r.y);
+        if (MODE != kRefExact) { i0 = min(max(i0, -127), 127); i1 = min(max(i1, -127), 127); }
+        q[2 * t] = static_cast<uint32_t>(i0);
+        q[2 * t + 1] = static_cast<uint32_t>(i1);
     }
 }
-template <int MODE>
-__device__ __forceinline__ uint32_t encode_rle_fast(const float (&x)[4][8], float scale, float rcp, bool finite,
-                                                    uint8_t* wl, uint32_t lane)
+// (a.b0 - b.b0) & 0xFF in one instruction
+__device__ __forceinline__ uint32_t sub_bytes(uint32_t a, uint32_t b)
 {
-    const uint32_t pair_addr = lds_addr_of(wl + kEncPairOff);
-    const uint32_t dummy = lds_addr_of(wl);
-    uint32_t qtail = 0, dtail = 0, mcarry = 0, icarry = 0;       // mcarry: position+1 of the last run start
-    bool prev_sparse = false, failed = false;
+    uint32_t r;
+    asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// v = 2*v + predicate / v += predicate, the predicate being a v_cmp result (lane mask in an SGPR pair)
+__device__ __forceinline__ void shift_in(uint32_t& v, unsigned long long pred)
+{
+    asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(v) : "s"(pred) : "vcc");
+}
+__device__ __forceinline__ void add_pred(uint32_t& v, unsigned long long pred)
+{
+    asm("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(v) : "s"(pred) : "vcc");
+}
+// the two byte stores of a run start, executed by the lanes of `pred` only (EXEC is narrowed and restored here: no
+// branch, no dummy address)
+__device__ __forceinline__ void store_pair_if(unsigned long long pred, uint32_t addr, uint32_t count_prev, uint32_t value)
+{
+    unsigned long long saved;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b8 %2, %3\n\tds_write_b8 %2, %4 offset:1\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved) : "s"(pred), "v"(addr), "v"(count_prev), "v"(value) : "memory");
+}
+__device__ __forceinline__ uint32_t lshl1_add(uint32_t a, uint32_t b)      // 2*a + b
+{
+    uint32_t r;
+    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Fast path: no stretch of equal deltas reaches 255 elements, so every change of the delta starts a run and no run
+// has to be split (count < 255 rule).  Returns the number of runs, or kEncFail when a long stretch may exist (>= 14
+// lanes of a chunk without any run start: a 255-stretch needs 30 such lanes in two chunks) -- the caller then runs
+// the general path, which starts over.  The block must be finite (quantize8).
+template <int MODE>
+__device__ __forceinline__ uint32_t encode_rle_fast(const uint4 (&raw)[4], float scale, float rcp, uint8_t* wl, uint32_t lane)
+{
+    const uint32_t pair_m1 = lds_addr_of(wl + kEncPairOff) - 1u;
+    uint32_t qtail = 0, dtail = 0x100u, mcarry = 0, icarry = 0;  // dtail 0x100: no delta precedes element 0 (it starts a run)
+    bool prev_sparse = false, failed = false;                    // mcarry: position+1 of the last run start
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t p0 = 512u * j + 8u * lane;
         uint32_t q[8];
-        quantize_chunk<MODE>(x[j], scale, rcp, finite, q);
-        *reinterpret_cast<uint2*>(wl + kEncQOff + p0) =
-            make_uint2(q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24), q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24));
-        uint32_t prevq = wave_shr1(q[7], qtail);
+        quantize8<MODE>(raw[j], scale, rcp, q);
+        const uint32_t prevq = wave_shr1(q[7], qtail);
         qtail = lane63(q[7]);
         uint32_t d[8];
+        d[0] = sub_bytes(q[0], prevq);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { d[k] = (q[k] - prevq) & 0xFFu; prevq = q[k]; }
-        uint32_t prevd = wave_shr1(d[7], dtail);
+        for (int k = 1; k < 8; ++k) d[k] = sub_bytes(q[k], q[k - 1]);
+        const uint32_t prevd = wave_shr1(d[7], dtail);
         dtail = lane63(d[7]);
-        bool nq[8];
-        uint32_t cnt = 0, lm = 0;
+        bool st[8];                                              // element k starts a run (a v_cmp result: an SGPR pair)
+        uint32_t mask = 0;                                       // bit 7-k = element k starts a run
+        unsigned long long sm[8];                                // the same as lane masks
+        st[0] = d[0] != prevd;
+        sm[0] = __builtin_amdgcn_ballot_w64(st[0]);
+        shift_in(mask, sm[0]);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            nq[k] = (p0 + k == 0u) || (d[k] != prevd);
-            prevd = d[k];
-            cnt += nq[k] ? 1u : 0u;
-            lm = nq[k] ? p0 + k + 1u : lm;
-        }
+        for (int k = 1; k < 8; ++k) { st[k] = d[k] != d[k - 1]; sm[k] = __builtin_amdgcn_ballot_w64(st[k]); shift_in(mask, sm[k]); }
+        const uint32_t cnt = static_cast<uint32_t>(__builtin_popcount(mask));
+        // last start of the lane, as position+1 (0 = none): element 7 - ctz(mask)
+        const uint32_t lm = mask ? p0 + 8u - static_cast<uint32_t>(__builtin_ctz(mask)) : 0u;
         // cheap pre-filter: a run longer than 248 elements needs >= 28 start-free lanes in this chunk and the previous
         // one together, i.e. >= 14 in one of them
-        const bool sparse = __popcll(__ballot(cnt == 0u)) >= 14;             // wave-uniform
+        const bool sparse = __popcll(__ballot(mask == 0u)) >= 14;            // wave-uniform
         const bool suspicious = sparse || prev_sparse;
         prev_sparse = sparse;
         const uint32_t ic = wave_incl_add(cnt);
         uint32_t idx = icarry + ic - cnt;
         icarry += lane63(ic);
         const uint32_t im = wave_incl_max(lm);
-        uint32_t m = umax(wave_shr1(im, 0u), mcarry);
+        const uint32_t m = umax(wave_shr1(im, 0u), mcarry);      // last start before this lane, position+1
         mcarry = umax(mcarry, lane63(im));
         // A count is "position of this run start - previous run start"; only a lane's FIRST start of the chunk can
         // close a long run, and that run is shorter than (end of the lane's 8 elements - previous start).  If that
         // bound passes 255 anywhere the run may need splitting (cache_engine.cpp:224), which only the general path does.
-        // (the loop simply runs on after a failure -- every chunk stages its q bytes for the general path anyway and
-        // the scatter stays inside the pair buffer -- which keeps this rare branch out of the register budget)
-        if (suspicious && __ballot(cnt != 0u && p0 + 8u - m > 255u) != 0ull) failed = true;   // wave-uniform
+        // (the loop simply runs on after a failure: the scatter stays inside the wave's buffer)
+        if (suspicious && __ballot(mask != 0u && p0 + 8u - m > 255u) != 0ull) failed = true;   // wave-uniform
+        // rel = (last start, position+1) - (p0 + 1): count of the run closed by a start at element k is k - rel
+        uint32_t rel = m - p0 - 1u;
+        uint32_t addr[8], cntv[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const uint32_t p = p0 + k;
-            const uint32_t b = nq[k] ? pair_addr + 2u * idx - 1u : dummy;
-            lds_store_b8(b, p + 1u - m);             // count of the previous run
-            lds_store_b8(b + 1u, d[k]);              // value of this run
-            m = nq[k] ? p + 1u : m;
-            idx += nq[k] ? 1u : 0u;
+            addr[k] = lshl1_add(idx, pair_m1);                   // count byte of the previous pair; +1 = value byte of this one
+            cntv[k] = static_cast<uint32_t>(k) - rel;
+            rel = st[k] ? static_cast<uint32_t>(k) : rel;
+            add_pred(idx, sm[k]);
         }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) store_pair_if(sm[k], addr[k], cntv[k], d[k]);
     }
-    if (failed || kBlockElems + 1u - mcarry > 255u) return kEncFail;        // a run may need splitting (q is fully staged)
-    lds_store_b8(pair_addr + 2u * icarry - 1u, kBlockElems + 1u - mcarry);  // close the last run
+    if (failed || kBlockElems + 1u - mcarry > 255u) return kEncFail;        // a run may need splitting
+    lds_store_b8(pair_m1 + 2u * icarry, kBlockElems + 1u - mcarry);         // close the last run
     return icarry;
 }
 
-// General path (long stretches: zeros, constants): one element per lane per step,
-// rolled; stretch starts by max-scan, a run starts every 255 elements of a stretch.
-__device__ __noinline__ uint32_t encode_rle_general(uint8_t* wl, uint32_t lane)
+// General path (long stretches: zeros, constants; blocks with inf / NaN): one element per lane per step, rolled,
+// quantised with the exact scalar form straight from the source; stretch starts by max-scan, a run starts every 255
+// elements of a stretch.
+template <int MODE>
+__device__ __noinline__ uint32_t encode_rle_general(const uint8_t* __restrict__ src, float scale, uint8_t* wl, uint32_t lane)
 {
     const uint32_t pair_addr = lds_addr_of(wl + kEncPairOff);
-    const uint8_t* qb = wl + kEncQOff;
     uint32_t qtail = 0, dtail = 0, scarry = 0, mcarry = 0, icarry = 0;
 #pragma unroll 1
     for (uint32_t step = 0; step < kBlockElems / 64u; ++step) {
         const uint32_t p = 64u * step + lane;
-        const uint32_t qv = qb[p];
+        const uint32_t qv = quantize<MODE>(half_bits_to_float(reinterpret_cast<const uint16_t*>(src)[p]), scale);
         const uint32_t prevq = wave_shr1(qv, qtail);
         qtail = lane63(qv);
         const uint32_t d = (qv - prevq) & 0xFFu;
@@ -688,6 +738,38 @@ __device__ __noinline__ uint32_t encode_rle_general(uint8_t* wl, uint32_t lane)
     return icarry;
 }
 
+// max|x| of a block and "every element is finite" from the fp16 bit patterns: the largest |bits| of the 32 elements
+// a lane holds (integer order = magnitude order for finite values), two elements per instruction.
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t absmax_bits(const uint4 (&raw)[4])
+{
+    u16x2 m = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t w[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2, w[t] & 0x7FFF7FFFu));
+    }
+    const uint32_t lanemax = m.x > m.y ? m.x : m.y;
+    return lane63(wave_incl_max(lanemax));
+}
+// the reference's own rule for blocks that hold inf / NaN: a NaN never wins the '>' compare (cache_engine.cpp:176-180).
+// Rare, out of line, and fed from memory again (a register array passed by reference would move to scratch).
+__device__ __noinline__ float absmax_with_nonfinite(const uint8_t* __restrict__ src, uint32_t lane)
+{
+    float mx = 0.0f;
+#pragma unroll 1
+    for (uint32_t p = lane; p < kBlockElems; p += 64u)
+        mx = __builtin_fmaxf(mx, fabsf(half_bits_to_float(reinterpret_cast<const uint16_t*>(src)[p])));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float other = __shfl_xor(mx, o);
+        mx = (other > mx) ? other : mx;
+    }
+    return mx;
+}
+
 // ===================================================================
 // encode  (cache_engine.cpp:40-82,172-239)
 // ===================================================================
@@ -698,10 +780,12 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint64_t n = a.n;
-    const uint64_t per_wave = a.per_wave ? a.per_wave : 1;       // consecutive blocks per wave (see k_fetch_decompress)
-    const uint64_t i0 = (static_cast<uint64_t>(blockIdx.x) * kWaves + wave) * per_wave;
-    const uint64_t i1 = (i0 + per_wave < n) ? i0 + per_wave : n;
-    for (uint64_t i = i0; i < i1; ++i) {
+    const uint64_t per_wave = a.per_wave ? a.per_wave : 1;       // blocks per wave: see k_fetch_decompress
+    const uint64_t gw = static_cast<uint64_t>(blockIdx.x) * kWaves + wave;
+    const uint64_t step = a.wave_step ? a.wave_step : 1;
+    const uint64_t i0 = a.wave_step ? gw : gw * per_wave;
+    const uint64_t i1 = a.wave_step ? n : ((i0 + per_wave < n) ? i0 + per_wave : n);
+    for (uint64_t i = i0; i < i1; i += step) {
         const uint64_t page = a.page_list ? a.page_list[i] : a.first + i * (a.page_step ? a.page_step : 1);
         const uint8_t* src = a.data_list ? reinterpret_cast<const uint8_t*>(a.data_list[i])
                                          : a.data + i * a.data_stride;
@@ -808,34 +892,27 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
             }
             out_len = kBlockElems;
         } else {
-            float x[4][8];
-            float mx = 0.0f, nanacc = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t words[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    x[j][k] = half_bits_to_float((words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
-                    absmax_finite(x[j][k], mx, nanacc);        // NaN never wins (cache_engine.cpp:176-180)
-                }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float other = __shfl_xor(mx, o);
-                mx = (other > mx) ? other : mx;
-            }
-            scale = (mx > 0.0f) ? (mx / 127.0f) : 1.0f;
-            const bool finite = __ballot(!(nanacc == 0.0f)) == 0ull;       // wave-uniform
+            const uint32_t mbits = absmax_bits(raw);                       // wave-uniform
+            const bool finite = mbits < 0x7C00u;
+            const float mx = finite ? half_bits_to_float(mbits) : absmax_with_nonfinite(src, lane);
+            scale = (mx > 0.0f) ? (mx / 127.0f) : 1.0f;                    // cache_engine.cpp:172-183
             const float rcp = 1.0f / scale;
 
             if (SCHEME == kInt8) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     uint32_t q[8];
-                    quantize_chunk<MODE>(x[j], scale, rcp, finite, q);
+                    if (finite) {
+                        quantize8<MODE>(raw[j], scale, rcp, q);
+                    } else {
+                        const uint32_t words[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            q[k] = quantize<MODE>(half_bits_to_float((words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu), scale);
+                    }
                     uint2 o;
-                    o.x = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
-                    o.y = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
+                    o.x = (q[0] & 0xFFu) | ((q[1] & 0xFFu) << 8) | ((q[2] & 0xFFu) << 16) | (q[3] << 24);
+                    o.y = (q[4] & 0xFFu) | ((q[5] & 0xFFu) << 8) | ((q[6] & 0xFFu) << 16) | (q[7] << 24);
                     *reinterpret_cast<uint2*>(rec + 512u * j + 8u * lane) = o;
                 }
                 out_len = kBlockElems;
@@ -847,10 +924,10 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                 out_len = 18u;
             } else {
                 uint8_t* wl = reinterpret_cast<uint8_t*>(lds) + wave * kEncWaveBytes;
-                uint32_t nruns = encode_rle_fast<MODE>(x, scale, rcp, finite, wl, lane);
+                uint32_t nruns = finite ? encode_rle_fast<MODE>(raw, scale, rcp, wl, lane) : kEncFail;
                 wave_lds_fence();
                 if (nruns == kEncFail) {
-                    nruns = encode_rle_general(wl, lane);
+                    nruns = encode_rle_general<MODE>(src, scale, wl, lane);
                     wave_lds_fence();
                 }
                 uint8_t* pairbuf = wl + kEncPairOff;
@@ -1450,6 +1527,7 @@ hipError_t launch_enc1(const CodecArgs& a_in, hipStream_t s)
 {
     CodecArgs a = a_in;
     const uint32_t grid = codec_grid(a.n, &a.per_wave);
+    a.wave_step = (round_strided() && a.per_wave > 1) ? static_cast<uint64_t>(grid) * kWaves : 0;
     if (a.quant_mode == kIntent) hipLaunchKernelGGL((k_compress<SCHEME, kIntent>), dim3(grid), dim3(kThreads), 0, s, a);
     else                         hipLaunchKernelGGL((k_compress<SCHEME, kRefExact>), dim3(grid), dim3(kThreads), 0, s, a);
     return hipGetLastError();
@@ -1480,12 +1558,14 @@ hipError_t launch_compress(const CodecArgs& a, hipStream_t s)
     case kInt4G32: {
         CodecArgs b = a;
         const uint32_t grid = codec_grid(b.n, &b.per_wave);
+        b.wave_step = (round_strided() && b.per_wave > 1) ? static_cast<uint64_t>(grid) * kWaves : 0;
         hipLaunchKernelGGL((k_compress<kInt4G32, kRefExact>), dim3(grid), dim3(kThreads), 0, s, b);
         return hipGetLastError();
     }
     case kFp8E4m3: {
         CodecArgs b = a;
         const uint32_t grid = codec_grid(b.n, &b.per_wave);
+        b.wave_step = (round_strided() && b.per_wave > 1) ? static_cast<uint64_t>(grid) * kWaves : 0;
         hipLaunchKernelGGL((k_compress<kFp8E4m3, kRefExact>), dim3(grid), dim3(kThreads), 0, s, b);
         return hipGetLastError();
     }
