@@ -32,10 +32,18 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// Plain (temporal) loads on purpose: a head's row of one position is 64 B, HALF a 128-byte line, and the other half
+// belongs to the neighbouring head = the neighbouring wave of this workgroup.  With non-temporal loads the line did not
+// stay in L2 for the partner: PMC showed 19.1 M L2 misses for 11.8 M distinct lines (1.6x the record bytes from HBM,
+// which then ran at 0.70 of its peak while the kernel delivered 0.43).  profiles/r02_int4_mem_pmc.json
 __device__ __forceinline__ uint4 ldg16(const uint8_t* p)
 {
+#ifdef SPECKV_INT4_NT_LOADS
     const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
 }
 __device__ __forceinline__ float max_over_kb(float v)
 {
@@ -49,43 +57,74 @@ __device__ __forceinline__ float sum_over_kb(float v)
 }
 __device__ __forceinline__ f16x2 as_h2(uint32_t u) { return __builtin_bit_cast(f16x2, u); }
 
-// two nibbles (already XORed with 8: offset binary) in bits [3:0] and [19:16] -> {q_lo, q_hi} * s2, exactly
-// fp16(q * s): 0x6400 | u is the fp16 number 1024 + u, so minus 1032 leaves q = u - 8 exactly.
-__device__ __forceinline__ f16x2 deq2(uint32_t spread, f16x2 s2)
+// The kernel is VALU-bound on the nibble -> f16 conversion (rocprofv3: 426 VALU per 32-position tile and wave, VALU
+// issue 63 % busy, MFMA 9 %; profiles/r02_int4_pmc_before.json), so the conversion is written for instruction count:
+// per PAIR of values two SDWA converts (byte k of a nibble dword -> f16, the second into the upper half of the same
+// register) and one packed FMA:  fp16(u) * s + (-8 s)  =  fp16((u - 8) * s)  with ONE rounding -- u = q + 8 (offset
+// binary, 0..15) and -8 s are exact in fp16 -- i.e. bit for bit the value fetch + decompress stores.
+// (-8 s overflows fp16 for s > 8188, a group whose largest |x| is beyond 57 000; the caller detects that per tile,
+// wave-uniformly, and takes the subtract-then-multiply form.)
+// (K is a compile-time constant at every call site after unrolling: the chain folds to one pair of instructions)
+__device__ __forceinline__ uint32_t cvt_pair(const int K, uint32_t lo_src, uint32_t hi_src)
 {
-    const f16x2 k1032 = {static_cast<_Float16>(1032.0f), static_cast<_Float16>(1032.0f)};
-    return (as_h2(spread | 0x64006400u) - k1032) * s2;
+    uint32_t r;
+    if (K == 0) {
+        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(r) : "v"(lo_src));
+        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(r) : "v"(hi_src));
+    } else if (K == 1) {
+        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(r) : "v"(lo_src));
+        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(r) : "v"(hi_src));
+    } else if (K == 2) {
+        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(r) : "v"(lo_src));
+        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(r) : "v"(hi_src));
+    } else {
+        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(r) : "v"(lo_src));
+        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(r) : "v"(hi_src));
+    }
+    return r;
 }
-// selectors of v_perm_b32(S0 = high nibbles, S1 = low nibbles): byte K of each, zero-extended to 16 bits
-// -> [S1.bK, 0, S0.bK, 0]  (selector value 0x0C yields the constant 0)
-template <int K> __device__ __forceinline__ uint32_t pair_of_byte(uint32_t hi, uint32_t lo)
+// {u_lo, u_hi} (exact fp16 integers 0..15) -> {(u_lo - 8) s_lo, (u_hi - 8) s_hi}, one rounding each
+template <bool BIG> __device__ __forceinline__ f16x2 deq_pair(uint32_t upair, f16x2 s2, f16x2 m8s2)
 {
-    return __builtin_amdgcn_perm(hi, lo, 0x0C040C00u + 0x00010001u * K);
+    if (BIG) {
+        const f16x2 k8 = {static_cast<_Float16>(8.0f), static_cast<_Float16>(8.0f)};
+        return (as_h2(upair) - k8) * s2;
+    }
+    return __builtin_elementwise_fma(as_h2(upair), s2, m8s2);
 }
 // 8 nibbles of one row (offset binary, low nibble = even element) -> 8 fp16 values times the row's group scale
-__device__ __forceinline__ f16x8 deq_row8(uint32_t wx, f16x2 s2)
+template <bool BIG> __device__ __forceinline__ f16x8 deq_row8(uint32_t wx, f16x2 s2, f16x2 m8s2)
 {
     const uint32_t lo = wx & 0x0F0F0F0Fu, hi = (wx >> 4) & 0x0F0F0F0Fu;     // elements 0,2,4,6 / 1,3,5,7
-    const f16x2 a = deq2(pair_of_byte<0>(hi, lo), s2), b = deq2(pair_of_byte<1>(hi, lo), s2);
-    const f16x2 c = deq2(pair_of_byte<2>(hi, lo), s2), d = deq2(pair_of_byte<3>(hi, lo), s2);
+    const f16x2 a = deq_pair<BIG>(cvt_pair(0, lo, hi), s2, m8s2), b = deq_pair<BIG>(cvt_pair(1, lo, hi), s2, m8s2);
+    const f16x2 c = deq_pair<BIG>(cvt_pair(2, lo, hi), s2, m8s2), d = deq_pair<BIG>(cvt_pair(3, lo, hi), s2, m8s2);
     return f16x8{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
 }
+// a group scale beyond 8188 (0x6FFF): -8 s is not a finite fp16
+__device__ __forceinline__ bool scale_is_big(uint32_t ored_bits16) { return (ored_bits16 & 0x7FFFu) > 0x6FFFu; }
 
 } // namespace
 
+#ifndef SPECKV_INT4_WAVES
+#define SPECKV_INT4_WAVES 3
+#endif
+#ifndef SPECKV_INT4_WG_HEADS
+#define SPECKV_INT4_WG_HEADS 4
+#endif
+constexpr uint32_t kWgHeads = SPECKV_INT4_WG_HEADS;     // kv heads (= waves) per workgroup
 template <bool LINEAR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_attend_int4(AttendArgs a)
+__global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4_WAVES, SPECKV_INT4_WAVES))) void k_attend_int4(AttendArgs a)
 {
     // per wave: V nibbles 32 rows x 128 B pitch (64 used, +64 for rows with bit 2 set: bank spread), then
     // 32 rows x 8 B of V group scales
-    __shared__ __attribute__((aligned(16))) uint8_t lds[4][4096 + 256];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWgHeads][4096 + 256];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t c = lane & 15u, kb = lane >> 4;
     const uint32_t split = blockIdx.x;
-    const uint32_t hq = a.heads / 4u;
+    const uint32_t hq = a.heads / kWgHeads;
     uint32_t layer = blockIdx.y / hq;                                    // batch form: the sequence index
-    const uint32_t head = (blockIdx.y % hq) * 4u + wave;
+    const uint32_t head = (blockIdx.y % hq) * kWgHeads + wave;
     const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;
     uint64_t part = row * a.n_splits + split;
     if (a.seqs) {                                                        // wave-uniform: per-sequence geometry
@@ -117,6 +156,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const uint32_t t0 = split * a.tiles_per_split;
     const uint32_t t1 = min(t0 + a.tiles_per_split, n_tiles);
     float m_run = -INFINITY, l_run = 0.0f;
+    constexpr float kLazy = 8.0f;                                        // see the softmax below
     f32x4 acc[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -188,19 +228,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll 1
         for (uint32_t tile = t0; tile < t1; ++tile) {
             const uint32_t step = (tile + 1u < t1) ? tile_bytes : 0u;    // the last iteration re-requests its own tile
-            // ---- scores
+            // ---- scores (raw dot products: sm_scale * log2(e) joins in the exponent below)
             float sc[8];
+            const bool kbig = __builtin_amdgcn_ballot_w64(scale_is_big(static_cast<uint32_t>(ks[0]) | ks[1])) != 0ull;   // wave-uniform
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 const _Float16 sh = __builtin_bit_cast(_Float16, ks[b]);
                 const f16x2 s2 = {sh, sh};
+                const f16x2 km8 = {static_cast<_Float16>(-8.0f), static_cast<_Float16>(-8.0f)};
+                const f16x2 m8s2 = s2 * km8;
                 const uint32_t w[4] = {kx[b].x ^ 0x88888888u, kx[b].y ^ 0x88888888u, kx[b].z ^ 0x88888888u, kx[b].w ^ 0x88888888u};
                 f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+#ifdef SPECKV_ABL_NO_QK
+                s[0] = __uint_as_float((w[0] ^ w[1] ^ w[2] ^ w[3]) & 0x3F000000u) + static_cast<float>(s2.x);
+                if (false) {
+#else
+                if (!kbig) {
+#endif
+#ifdef SPECKV_INT4_SPLIT_CHAIN
+                    f32x4 s1 = {0.0f, 0.0f, 0.0f, 0.0f};
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8<false>(w[0], s2, m8s2), qv[0], s, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8<false>(w[1], s2, m8s2), qv[1], s1, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8<false>(w[2], s2, m8s2), qv[2], s, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8<false>(w[3], s2, m8s2), qv[3], s1, 0, 0, 0);
+                    s = s + s1;
+#else
 #pragma unroll
-                for (int st = 0; st < 4; ++st)
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8(w[st], s2), qv[st], s, 0, 0, 0);
+                    for (int st = 0; st < 4; ++st)
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8<false>(w[st], s2, m8s2), qv[st], s, 0, 0, 0);
+#endif
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) sc[4 * b + i] = s[i] * qscale;
+                    for (int st = 0; st < 4; ++st)
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8<true>(w[st], s2, m8s2), qv[st], s, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sc[4 * b + i] = s[i];
             }
             if (ragged && tile + 1u == n_tiles) {                         // wave-uniform: positions beyond the range
 #pragma unroll
@@ -213,24 +276,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             kdat += step; ksc += step; next_k += step ? 1u : 0u;
             issue_k();
             __builtin_amdgcn_sched_barrier(0);
-            // ---- online softmax of query row c
+            // ---- online softmax of query row c.  The running reference m_run only moves when the tile's maximum
+            // passes it by more than 2^kLazy: until then the weights are exp2(x - m_run) <= 2^kLazy (fine for f16, the
+            // sums are fp32) and the accumulators need no rescaling -- the result is the same after normalisation.
             float mx = sc[0];
 #pragma unroll
             for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc[j]);
-            mx = max_over_kb(mx);
-            const float m_new = fmaxf(m_run, mx);
-            const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;
-            const float f = __builtin_amdgcn_exp2f(m_run - m_use);
-            m_run = m_new;
+            mx = max_over_kb(mx) * qscale;                                 // qscale > 0
+            const bool grow = mx > m_run + kLazy;                         // also true for the first tile (m_run = -inf)
+            if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {              // wave-uniform: rare after the first tiles
+                const float m_new = grow ? mx : m_run;
+                const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;
+                const float f = __builtin_amdgcn_exp2f(m_run - m_use);    // 0 for the first tile, 1 for rows that keep theirs
+                m_run = m_new;
+                l_run *= f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] = acc[t] * f;
+            }
+            const float m_sub = (m_run == -INFINITY) ? 0.0f : -m_run;
             float psum = 0.0f;
             f16x8 P;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float p = __builtin_amdgcn_exp2f(sc[j] - m_use);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[j], qscale, m_sub));
                 psum += p;
                 P[j] = static_cast<_Float16>(p);
             }
-            l_run = l_run * f + psum;
+            l_run += psum;
             // ---- V tile: registers -> this wave's LDS -> operand order
             *reinterpret_cast<uint4*>(vl + wr0) = vraw[0];
             *reinterpret_cast<uint4*>(vl + wr0 + 2048u) = vraw[1];
@@ -253,25 +325,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             // ---- out^T += V^T . P^T, accumulated in place
             // element d = 8c + t of the two positions of a pair: nibble t&1 of byte t/2 of either position's dword
             uint32_t nl[8], nh[8];                                        // low / high nibbles of slot j, one per byte
-            f16x2 s2[4];
+            f16x2 s2[4], m8s2[4];
+            uint32_t sor = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { nl[j] = vw[j] & 0x0F0F0F0Fu; nh[j] = (vw[j] >> 4) & 0x0F0F0F0Fu; }
+            for (int j = 0; j < 8; ++j) { nl[j] = vw[j] & 0x0F0F0F0Fu; nh[j] = (vw[j] >> 4) & 0x0F0F0F0Fu; sor |= vs16[j]; }
+            const bool vbig = __builtin_amdgcn_ballot_w64(scale_is_big(sor)) != 0ull;        // wave-uniform
 #pragma unroll
-            for (int jp = 0; jp < 4; ++jp) s2[jp] = as_h2(vs16[2 * jp] | (vs16[2 * jp + 1] << 16));
+            for (int jp = 0; jp < 4; ++jp) {
+                const f16x2 km8 = {static_cast<_Float16>(-8.0f), static_cast<_Float16>(-8.0f)};
+                s2[jp] = as_h2(vs16[2 * jp] | (vs16[2 * jp + 1] << 16));
+                m8s2[jp] = s2[jp] * km8;
+            }
+#ifdef SPECKV_ABL_NO_PV
+            asm volatile("" :: "v"(nl[0]), "v"(nh[7]), "v"(P[0]), "v"(s2[0]));
+            if (false) {
+#else
+            if (!vbig) {
+#endif
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                f16x8 V;
+                for (int t = 0; t < 8; ++t) {
+                    f16x8 V;
 #pragma unroll
-                for (int jp = 0; jp < 4; ++jp) {
-                    // [slot 2jp, 0, slot 2jp+1, 0]
-                    const uint32_t sel = 0x0C040C00u + 0x00010001u * (t >> 1);
-                    const uint32_t sp = (t & 1) ? __builtin_amdgcn_perm(nh[2 * jp + 1], nh[2 * jp], sel)
-                                                : __builtin_amdgcn_perm(nl[2 * jp + 1], nl[2 * jp], sel);
-                    const f16x2 v = deq2(sp, s2[jp]);
-                    V[2 * jp] = v.x;
-                    V[2 * jp + 1] = v.y;
+                    for (int jp = 0; jp < 4; ++jp) {
+                        const uint32_t up = (t & 1) ? cvt_pair(t >> 1, nh[2 * jp], nh[2 * jp + 1]) : cvt_pair(t >> 1, nl[2 * jp], nl[2 * jp + 1]);
+                        const f16x2 v = deq_pair<false>(up, s2[jp], m8s2[jp]);
+                        V[2 * jp] = v.x;
+                        V[2 * jp + 1] = v.y;
+                    }
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t], 0, 0, 0);
                 }
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t] * f, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    f16x8 V;
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp) {
+                        const uint32_t up = (t & 1) ? cvt_pair(t >> 1, nh[2 * jp], nh[2 * jp + 1]) : cvt_pair(t >> 1, nl[2 * jp], nl[2 * jp + 1]);
+                        const f16x2 v = deq_pair<true>(up, s2[jp], m8s2[jp]);
+                        V[2 * jp] = v.x;
+                        V[2 * jp + 1] = v.y;
+                    }
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -295,8 +390,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_t s)
 {
     if ((a.n_pages == 0 && !a.seqs) || n_layers == 0 || a.n_splits == 0) return hipSuccess;   // batch form: geometry per sequence
-    if (a.lin_base) hipLaunchKernelGGL(k_attend_int4<true>, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
-    else            hipLaunchKernelGGL(k_attend_int4<false>, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
+    if (a.lin_base) hipLaunchKernelGGL(k_attend_int4<true>, dim3(a.n_splits, n_layers * (a.heads / kWgHeads)), dim3(64 * kWgHeads), 0, s, a);
+    else            hipLaunchKernelGGL(k_attend_int4<false>, dim3(a.n_splits, n_layers * (a.heads / kWgHeads)), dim3(64 * kWgHeads), 0, s, a);
     return hipGetLastError();
 }
 

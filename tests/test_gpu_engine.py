@@ -610,9 +610,10 @@ def test_fp8_attention_scale_table_follows_writes(eng, oracle):
 @pytest.mark.parametrize("scheme", [4, 3])
 def test_fused_attention_batch_of_sequences(eng, scheme):
     """speckv_ext_attend_fp8_batch: one layer of many sequences (one allocation each, different lengths, one of them
-    empty) in one launch pair, against the per-sequence entry point.  Same kernel, other split boundaries, so the
-    results agree to fp32 summation order (1e-4 of sum p|v| is generous); the oracle parity of the per-sequence form
-    is test_fp8_fused_attention."""
+    empty) in one launch pair, against the per-sequence entry point.  Same kernel, other split boundaries: each split
+    rounds its softmax weights to f16 relative to its own running reference (the INT4 kernel moves that reference
+    lazily), so two split arrangements agree to the f16 rounding of the weights (2^-11 = 4.9e-4 relative), not to fp32
+    summation order; the oracle parity of the per-sequence forms is test_fp8_fused_attention / test_int4_fused_attention."""
     torch = torch_mod()
     lib = eng.lib
     lib.set_compression_scheme(scheme)
@@ -650,7 +651,7 @@ def test_fused_attention_batch_of_sequences(eng, scheme):
                     assert float(out[i].abs().max()) == 0.0
                     continue
                 scale = float(one.abs().max()) + 1e-6
-                assert float((out[i] - one).abs().max()) <= 2e-4 * scale, (layer, tps, i, n)
+                assert float((out[i] - one).abs().max()) <= 1e-3 * scale, (layer, tps, i, n)
                 assert float((lse[i] - one_lse).abs().max()) <= 1e-4, (layer, tps, i, n)
     # a sequence stored in the other format does not qualify -> INVAL, nothing launched
     lib.set_compression_scheme(3 if scheme == 4 else 4)
