@@ -1025,6 +1025,11 @@ void Engine::enqueue(uint32_t req, uint32_t layer, uint32_t pos, uint32_t k)
         return;
     }
     if (layer >= last_res_.n_layers) { ++q_dropped_; return; }
+    if (k > 16u) {                       // the candidate kernel walks at most 16 look-ahead positions per request
+        static bool warned = false;
+        if (!warned) { warned = true; SPECKV_ERR("speckv_prefetch: look-ahead depth %u clamped to 16 (reported once)", k); }
+        k = 16u;
+    }
     if (!q_req_.empty() && q_scheme_ != last_res_.scheme) { (void)prefetch_flush(nullptr); (void)resolve(req); if (!last_res_.ok) { ++q_dropped_; return; } }
     q_scheme_ = last_res_.scheme;
     q_W_ = std::max(q_W_, last_res_.W);

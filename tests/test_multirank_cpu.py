@@ -156,12 +156,13 @@ def test_single_rank_needs_no_process_group():
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    """The bench line committed with the round's profile (profiles/r01f_bench.json = stdout of `python bench.py` on the
+    """The bench line committed with the round's profile (profiles/r02f_bench.json = stdout of `python bench.py` on the
     MI355X box) carries every field of the driver's contract, with the tier's meaning: metric and config from
-    BASELINE.json, roofline and cpu_baseline objects, no model keys."""
+    BASELINE.json, roofline and cpu_baseline objects, no model keys; `value` is the as-called figure and the ramped and
+    sustained ones stand beside it."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r01f_bench.json")))
+    d = json.load(open(os.path.join(root, "profiles", "r02f_bench.json")))
     base = json.load(open(os.path.join(root, "BASELINE.json")))
     assert d["metric"] in base["metric"] and d["unit"] == "blocks/s"
     for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
@@ -174,6 +175,18 @@ def test_committed_bench_line_has_the_contract_fields():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.5 < r["frac"] < 1.0
     assert r["traffic"] is None or 0.95 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
     assert abs(d["value"] - 131072 * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+    v = d["variants"]
+    assert set(v) == {"as_called", "ramped", "sustained"}
+    assert v["as_called"]["blocks_per_s"] == d["value"] and v["as_called"]["frac_hbm"] == r["frac"]
+    assert v["sustained"]["seconds"] >= 1.0 and v["sustained"]["steps"] > 1000
+    assert "watchdog_fired" not in d
     c = d["cpu_baseline"]
     assert c["unit"] == "blocks/s" and c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["parity_spot_check"] is True
+    f = d["extras"]["prefetch_flush"]
+    assert f["requests"] == 8192 and f["pages_issued"] > 10000 and f["submit_ms"] < 0.1 and f["ms"] < 0.2
+    # the 2-rank run on one GPU shows the three remote shapes with both engines
+    x = json.load(open(os.path.join(root, "profiles", "r02f_bench_2ranks_one_gpu.json")))["xgmi"]
+    assert set(x) >= {"cfg3", "cfg4", "symmetric", "accounting"}
+    for mode in ("cfg3", "symmetric"):
+        assert {"fused_peer_load_kernel", "copy_engines_then_local_decompress", "raw_peer_copy_GBps"} <= set(x[mode])
