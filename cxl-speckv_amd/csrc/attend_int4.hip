@@ -324,11 +324,10 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
             __builtin_amdgcn_sched_barrier(0);
             // ---- out^T += V^T . P^T, accumulated in place
             // element d = 8c + t of the two positions of a pair: nibble t&1 of byte t/2 of either position's dword
-            uint32_t nl[8], nh[8];                                        // low / high nibbles of slot j, one per byte
             f16x2 s2[4], m8s2[4];
             uint32_t sor = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { nl[j] = vw[j] & 0x0F0F0F0Fu; nh[j] = (vw[j] >> 4) & 0x0F0F0F0Fu; sor |= vs16[j]; }
+            for (int j = 0; j < 8; ++j) sor |= vs16[j];
             const bool vbig = __builtin_amdgcn_ballot_w64(scale_is_big(sor)) != 0ull;        // wave-uniform
 #pragma unroll
             for (int jp = 0; jp < 4; ++jp) {
@@ -336,36 +335,39 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
                 s2[jp] = as_h2(vs16[2 * jp] | (vs16[2 * jp + 1] << 16));
                 m8s2[jp] = s2[jp] * km8;
             }
-#ifdef SPECKV_ABL_NO_PV
-            asm volatile("" :: "v"(nl[0]), "v"(nh[7]), "v"(P[0]), "v"(s2[0]));
-            if (false) {
-#else
-            if (!vbig) {
-#endif
+            // even d columns (t = 0, 2, 4, 6) come from the low nibbles, odd ones from the high nibbles: one nibble plane
+            // is live at a time (the plane replaces the dwords it came from)
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    f16x8 V;
+            for (int half = 0; half < 2; ++half) {
+                uint32_t nb[8];
 #pragma unroll
-                    for (int jp = 0; jp < 4; ++jp) {
-                        const uint32_t up = (t & 1) ? cvt_pair(t >> 1, nh[2 * jp], nh[2 * jp + 1]) : cvt_pair(t >> 1, nl[2 * jp], nl[2 * jp + 1]);
-                        const f16x2 v = deq_pair<false>(up, s2[jp], m8s2[jp]);
-                        V[2 * jp] = v.x;
-                        V[2 * jp + 1] = v.y;
+                for (int j = 0; j < 8; ++j) nb[j] = (half ? (vw[j] >> 4) : vw[j]) & 0x0F0F0F0Fu;
+                if (!vbig) {
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const int t = 2 * tt + half;
+                        f16x8 V;
+#pragma unroll
+                        for (int jp = 0; jp < 4; ++jp) {
+                            const f16x2 v = deq_pair<false>(cvt_pair(tt, nb[2 * jp], nb[2 * jp + 1]), s2[jp], m8s2[jp]);
+                            V[2 * jp] = v.x;
+                            V[2 * jp + 1] = v.y;
+                        }
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t], 0, 0, 0);
                     }
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t], 0, 0, 0);
-                }
-            } else {
+                } else {
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    f16x8 V;
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const int t = 2 * tt + half;
+                        f16x8 V;
 #pragma unroll
-                    for (int jp = 0; jp < 4; ++jp) {
-                        const uint32_t up = (t & 1) ? cvt_pair(t >> 1, nh[2 * jp], nh[2 * jp + 1]) : cvt_pair(t >> 1, nl[2 * jp], nl[2 * jp + 1]);
-                        const f16x2 v = deq_pair<true>(up, s2[jp], m8s2[jp]);
-                        V[2 * jp] = v.x;
-                        V[2 * jp + 1] = v.y;
+                        for (int jp = 0; jp < 4; ++jp) {
+                            const f16x2 v = deq_pair<true>(cvt_pair(tt, nb[2 * jp], nb[2 * jp + 1]), s2[jp], m8s2[jp]);
+                            V[2 * jp] = v.x;
+                            V[2 * jp + 1] = v.y;
+                        }
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t], 0, 0, 0);
                     }
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
