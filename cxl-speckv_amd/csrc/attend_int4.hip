@@ -192,7 +192,11 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
             for (int b = 0; b < 2; ++b) {
                 if (LINEAR) {
                     kx[b] = ldg16(kdat + 8u * kInt4RecBytes * b);
+#ifdef SPECKV_ABL_NO_SCALE_LOADS
+                    ks[b] = 0x3800;
+#else
                     ks[b] = *reinterpret_cast<const uint16_t*>(ksc + 8u * kInt4RecBytes * b);
+#endif
                 } else {
                     const uint8_t* base = rec_base(kent, next_k * 16u + 8u * b + (c >> 1));
                     kx[b] = ldg16(base + 128u + rowoff * 64u + kb * 16u);
@@ -204,7 +208,11 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
             if (LINEAR) {
                 vraw[0] = ldg16(vdat);
                 vraw[1] = ldg16(vdat + 8u * kInt4RecBytes);
+#ifdef SPECKV_ABL_NO_SCALE_LOADS
+                vsraw = 0x38003800u;
+#else
                 vsraw = *reinterpret_cast<const uint32_t*>(vsc);
+#endif
             } else {
                 const uint32_t voff = 128u + ((vr & 1u) * 8u + head) * 64u + (lane & 3u) * 16u;
                 vraw[0] = ldg16(rec_base(vent, next_v * 16u + (vr >> 1)) + voff);
@@ -310,12 +318,20 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
             uint32_t vw[8], vs16[8];
+#ifdef SPECKV_ABL_NO_LDS_READ
+            {
+                const uint32_t t8[8] = {vraw[0].x, vraw[0].y, vraw[0].z, vraw[0].w, vraw[1].x, vraw[1].y, vraw[1].z, vraw[1].w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { vw[j] = t8[j] ^ 0x88888888u; vs16[j] = (vsraw >> (16 * (j & 1))) & 0xFFFFu; }
+            }
+#else
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int ro = (j < 4) ? j : 16 + (j - 4);
                 vw[j] = *reinterpret_cast<const uint32_t*>(rdb + 128 * ro) ^ 0x88888888u;     // 8 nibbles of slot j, d = 8c..8c+7
                 vs16[j] = *reinterpret_cast<const uint16_t*>(rsb + 8 * ro);                   // its group scale (group c/4)
             }
+#endif
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_sched_barrier(0);

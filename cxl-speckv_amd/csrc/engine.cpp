@@ -235,7 +235,7 @@ Engine::~Engine()
     allocs_.clear();
     if (d_emb_) (void)hipFree(d_emb_);
     if (d_wout_) (void)hipFree(d_wout_);
-    for (Scratch* s : {&s_pages_, &s_dst_, &s_req_, &s_out_, &s_tmp_, &s_stage_, &s_flush_, &s_hid_, &s_logits_, &s_hist_, &s_pred_, &s_attn_, &s_attn_seq_})
+    for (Scratch* s : {&s_pages_, &s_req_, &s_tmp_, &s_stage_, &s_flush_, &s_hid_, &s_logits_, &s_hist_, &s_pred_, &s_attn_, &s_attn_seq_})
         if (s->p) (void)hipFree(s->p);
     for (void* p : retired_) (void)hipFree(p);
     for (auto& l : lanes_) {

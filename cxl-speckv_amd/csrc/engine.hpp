@@ -244,7 +244,7 @@ private:
 
     // device scratch
     struct Scratch { void* p = nullptr; size_t cap = 0; bool in_graph = false; };
-    Scratch s_pages_, s_dst_, s_req_, s_out_, s_tmp_, s_stage_, s_flush_;
+    Scratch s_pages_, s_req_, s_tmp_, s_stage_, s_flush_;
     std::vector<void*> retired_;           // scratch buffers a captured graph may still reference
     uint32_t* d_count_ = nullptr;
 

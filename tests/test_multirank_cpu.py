@@ -158,8 +158,8 @@ def test_single_rank_needs_no_process_group():
 def test_committed_bench_line_has_the_contract_fields():
     """The bench line committed with the round's profile (profiles/r02f_bench.json = stdout of `python bench.py` on the
     MI355X box) carries every field of the driver's contract, with the tier's meaning: metric and config from
-    BASELINE.json, roofline and cpu_baseline objects, no model keys; `value` is the as-called figure and the ramped and
-    sustained ones stand beside it."""
+    BASELINE.json, roofline and cpu_baseline objects, no model keys; `value` is the W + K region at steady clocks (ramped), the cold
+    as-called figure and a sustained one stand beside it."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     d = json.load(open(os.path.join(root, "profiles", "r02f_bench.json")))
@@ -177,7 +177,8 @@ def test_committed_bench_line_has_the_contract_fields():
     assert abs(d["value"] - 131072 * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
     v = d["variants"]
     assert set(v) == {"as_called", "ramped", "sustained"}
-    assert v["as_called"]["blocks_per_s"] == d["value"] and v["as_called"]["frac_hbm"] == r["frac"]
+    assert v["ramped"]["blocks_per_s"] == d["value"] and v["ramped"]["frac_hbm"] == r["frac"]
+    assert v["as_called"]["frac_hbm"] <= v["ramped"]["frac_hbm"] + 0.02          # cold clocks never beat steady ones by much
     assert v["sustained"]["seconds"] >= 1.0 and v["sustained"]["steps"] > 1000
     assert "watchdog_fired" not in d
     c = d["cpu_baseline"]
