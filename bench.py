@@ -73,6 +73,7 @@ def parse_args():
     ap.add_argument("--ramp-ms", type=float, default=60.0, help="untimed clock ramp before the 'ramped' variant and the extras")
     ap.add_argument("--sustain-s", type=float, default=1.0, help="length of the 'sustained' variant")
     ap.add_argument("--no-variants", action="store_true", help="only the as-called figure (profiling runs)")
+    ap.add_argument("--xgmi-child", action="store_true", help=argparse.SUPPRESS)   # internal: see run_xgmi_children()
     return ap.parse_args()
 
 
@@ -195,6 +196,8 @@ def whole_job_rate(world, units_per_rank, steps, elapsed):
 
 def main():
     args = parse_args()
+    if args.xgmi_child:
+        return xgmi_child_main(args)
     import torch
     import cxl_speckv_amd as pkg
 
@@ -407,7 +410,9 @@ def main():
         out["extras"].update(flush_cfg4_extra(torch, pkg))
     if world > 1 and os.environ.get("SPECKV_BENCH_XGMI", "1") != "0":
         state["phase"] = "xgmi"
-        x = xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream, red_dev, single_gpu_test, state)
+        del src, dst
+        torch.cuda.empty_cache()
+        x = run_xgmi_children(args, torch, dist, rank, world, red_dev)
         if rank == 0 and out is not None:
             out["xgmi"] = x
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # rank 0 at N=1 only (bench contract)
@@ -423,6 +428,88 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------
+# Remote-pool (xGMI) phase.  It runs on hardware the development pool does not have, so it is isolated: every rank starts
+# a CHILD process (a fresh interpreter, never an exec of this one) that does the whole phase with its own process group
+# (file-store rendezvous) and the rank-0 child prints the `xgmi` object on its stdout.  A crash or hang there costs the
+# `xgmi` object -- reported as {"failed": ...} with the child's last stderr lines -- and never the scaling line.
+# --------------------------------------------------------------------------
+def run_xgmi_children(args, torch, dist, rank, world, red_dev):
+    import subprocess
+    import tempfile
+    t = torch.tensor([os.getpid() if rank == 0 else 0], dtype=torch.int64, device=red_dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    store = os.path.join(tempfile.gettempdir(), f"speckv_xgmi_{os.environ.get('MASTER_PORT', '0')}_{int(t.item())}")
+    limit = float(os.environ.get("SPECKV_XGMI_TIMEOUT_S", "240"))
+    env = dict(os.environ, SPECKV_XGMI_STORE=store)
+    cmd = [sys.executable, os.path.abspath(__file__), "--xgmi-child", "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--scheme", str(args.scheme), "--quant", str(args.quant), "--tokens", str(args.tokens),
+           "--layers", str(args.layers), "--ramp-ms", str(args.ramp_ms)]
+    errf = tempfile.TemporaryFile(mode="w+")
+    res = None
+    try:
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=errf, text=True)
+        try:
+            so, _ = proc.communicate(timeout=limit)
+            rc = proc.returncode
+        except subprocess.TimeoutExpired:
+            proc.kill()                                          # exactly the child this rank started
+            so, _ = proc.communicate()
+            rc = "timeout"
+        if rank == 0:
+            for line in reversed((so or "").splitlines()):
+                at = line.find('{"')
+                if at >= 0:
+                    try:
+                        res = json.loads(line[at:])
+                        break
+                    except ValueError:
+                        pass
+            if res is None or rc != 0:
+                errf.seek(0)
+                tail = errf.read()[-1500:]
+                res = dict(res or {}, failed=f"child of rank 0 ended with {rc!r} after at most {limit:.0f} s", stderr_tail=tail)
+    except Exception as e:
+        res = {"failed": repr(e)}
+    finally:
+        errf.close()
+    dist.barrier()
+    if rank == 0:
+        try:
+            os.remove(store)
+        except OSError:
+            pass
+    return res
+
+
+def xgmi_child_main(args):
+    import torch
+    import torch.distributed as dist
+    import cxl_speckv_amd as pkg
+    world, rank, local_rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    single_gpu_test = os.environ.get("SPECKV_BENCH_SINGLE_GPU_TEST") == "1"
+    if single_gpu_test:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    init = "file://" + os.environ["SPECKV_XGMI_STORE"]
+    if single_gpu_test:
+        dist.init_process_group(backend="gloo", init_method=init, rank=rank, world_size=world)
+        red_dev = "cpu"
+    else:
+        dist.init_process_group(backend="nccl", init_method=init, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        red_dev = "cuda"
+    n_blocks = args.tokens * args.layers * 8 * 128 * 2 * 2 // PAGE
+    g = torch.Generator(device="cuda"); g.manual_seed(2001 + rank)
+    src = torch.randn((n_blocks, BLOCK_ELEMS), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+    dst = torch.empty((n_blocks, BLOCK_ELEMS), dtype=torch.float16, device="cuda")
+    stream = torch.cuda.Stream()
+    x = xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream, red_dev, single_gpu_test, None)
+    if rank == 0:
+        print(json.dumps(x), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 XGMI_LINK_GBPS = 153.6          # nominal per link (task statement: 7 links x ~153 GB/s per GPU)

@@ -11,16 +11,20 @@
 // run on v_mfma_f32_16x16x32_f16 with fp32 accumulation, softmax weights are rounded to f16.  So
 // the result is the attention over the decompressed fp16 pages without ever writing them.
 //
-// One wave = one kv head x one split of the positions, tiles of 32 positions.  LINEAR form: records of the
-// allocation in one run (record p at lin_base + p*1152, never-written records zero bytes), addresses are
-// arithmetic.  Page-table form (striped / migrated / remote pools, ranges that are not tile aligned): the same
-// kernel takes each page's record address from its page-table entry (never-written pages read a zero page).
+// One wave = one kv head x one split of the positions, tiles of 32 positions; the four waves of a workgroup are four
+// neighbouring heads.  Two kernels:
+//   k_attend_int4_wg    LINEAR form (records of the allocation in one run: record p at lin_base + p*1152, never-written
+//                       records zero bytes, addresses are arithmetic): the workgroup fetches a tile for its four heads
+//                       together, whole 128-byte lines, global -> LDS by LDS-DMA, two tiles deep (see below)
+//   k_attend_int4<..>   page-table form (striped / migrated / remote pools, ranges that are not tile aligned): each
+//                       page's record address comes from its page-table entry (never-written pages read a zero page);
+//                       register-staged loads per wave.  <true> is the same loop on linear addresses, kept as the A/B
+//                       baseline of the LDS-DMA kernel (build with -DSPECKV_INT4_REGSTAGE)
+// Operand mapping (both kernels):
 //   scores S^T = K . q^T: lane (c, kb) feeds row c = position 16b + c, d = 32kb + 8*step + e --
-//     exactly group kb of that row: ONE 16-byte load and one scale per lane and block.
+//     exactly group kb of that row: 16 nibble bytes and one scale per lane and block.
 //   output O^T = V^T . P^T: rows c = d columns 8c + t, k-slots = the lane's 8 positions (as in
-//     attend.hip).  A wave fetches the V tile with two 16-byte loads per lane (whole rows), stages
-//     it in 4 KiB of its own LDS and reads it back as "8 nibbles of one position" dwords -- 7
-//     global loads per 4.5 KiB tile; the texture addresser bounded the dword-gather form.
+//     attend.hip): the V tile goes through LDS and is read back as "8 nibbles of one position" dwords.
 #include "kernels.hpp"
 
 namespace speckv {
@@ -103,6 +107,149 @@ template <bool BIG> __device__ __forceinline__ f16x8 deq_row8(uint32_t wx, f16x2
 // a group scale beyond 8188 (0x6FFF): -8 s is not a finite fp16
 __device__ __forceinline__ bool scale_is_big(uint32_t ored_bits16) { return (ored_bits16 & 0x7FFFu) > 0x6FFFu; }
 
+// ---- the arithmetic of one 32-position tile, shared by the two kernels below ----------------------------------------
+// scores of one block of 16 positions: S^T = K . q^T (raw dot products)
+__device__ __forceinline__ f32x4 score_block(const uint4& kx, uint32_t ks16, bool kbig, const f16x8 (&qv)[4])
+{
+    const _Float16 sh = __builtin_bit_cast(_Float16, static_cast<uint16_t>(ks16));
+    const f16x2 s2 = {sh, sh};
+    const f16x2 km8 = {static_cast<_Float16>(-8.0f), static_cast<_Float16>(-8.0f)};
+    const f16x2 m8s2 = s2 * km8;
+    const uint32_t w[4] = {kx.x ^ 0x88888888u, kx.y ^ 0x88888888u, kx.z ^ 0x88888888u, kx.w ^ 0x88888888u};
+    f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+#ifdef SPECKV_ABL_NO_QK
+    s[0] = __uint_as_float((w[0] ^ w[1] ^ w[2] ^ w[3]) & 0x3F000000u) + static_cast<float>(s2.x);
+    if (false) {
+#else
+    if (!kbig) {
+#endif
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+            s = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8<false>(w[st], s2, m8s2), qv[st], s, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+            s = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8<true>(w[st], s2, m8s2), qv[st], s, 0, 0, 0);
+    }
+    return s;
+}
+
+// online softmax of query row c over the tile's 8 scores of this lane.  The running reference m_run only moves when the
+// tile's maximum passes it by more than 2^kLazy: until then the weights are exp2(x - m_run) <= 2^kLazy (fine for f16,
+// the sums are fp32) and the accumulators need no rescaling -- the result is the same after normalisation.
+constexpr float kLazy = 8.0f;
+__device__ __forceinline__ f16x8 softmax_tile(const float (&sc)[8], float qscale, float& m_run, float& l_run, f32x4 (&acc)[8])
+{
+    float mx = sc[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc[j]);
+    mx = max_over_kb(mx) * qscale;                                 // qscale > 0
+    const bool grow = mx > m_run + kLazy;                         // also true for the first tile (m_run = -inf)
+    if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {              // wave-uniform: rare after the first tiles
+        const float m_new = grow ? mx : m_run;
+        const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;
+        const float f = __builtin_amdgcn_exp2f(m_run - m_use);    // 0 for the first tile, 1 for rows that keep theirs
+        m_run = m_new;
+        l_run *= f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = acc[t] * f;
+    }
+    const float m_sub = (m_run == -INFINITY) ? 0.0f : -m_run;
+    float psum = 0.0f;
+    f16x8 P;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[j], qscale, m_sub));
+        psum += p;
+        P[j] = static_cast<_Float16>(p);
+    }
+    l_run += psum;
+    return P;
+}
+
+// out^T += V^T . P^T, accumulated in place.  vw[j] = 8 nibbles (offset binary) of position slot j at d = 8c..8c+7,
+// vs16[j] = that slot's group scale (group c/4).  Element d = 8c + t of the two positions of a pair: nibble t&1 of byte
+// t/2 of either position's dword.
+__device__ __forceinline__ void pv_tile(const uint32_t (&vw)[8], const uint32_t (&vs16)[8], const f16x8& P, f32x4 (&acc)[8])
+{
+#ifdef SPECKV_ABL_NO_PV
+    {
+        uint32_t x = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x ^= vw[j] ^ vs16[j];
+        acc[0][0] += __uint_as_float(x & 0x3F000000u) + static_cast<float>(P[0]);
+        return;
+    }
+#endif
+    f16x2 s2[4], m8s2[4];
+    uint32_t sor = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sor |= vs16[j];
+    const bool vbig = __builtin_amdgcn_ballot_w64(scale_is_big(sor)) != 0ull;        // wave-uniform
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+        const f16x2 km8 = {static_cast<_Float16>(-8.0f), static_cast<_Float16>(-8.0f)};
+        s2[jp] = as_h2(vs16[2 * jp] | (vs16[2 * jp + 1] << 16));
+        m8s2[jp] = s2[jp] * km8;
+    }
+    // even d columns (t = 0, 2, 4, 6) come from the low nibbles, odd ones from the high nibbles: one nibble plane
+    // is live at a time (the plane replaces the dwords it came from)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        uint32_t nb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) nb[j] = (half ? (vw[j] >> 4) : vw[j]) & 0x0F0F0F0Fu;
+        if (!vbig) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int t = 2 * tt + half;
+                f16x8 V;
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    const f16x2 v = deq_pair<false>(cvt_pair(tt, nb[2 * jp], nb[2 * jp + 1]), s2[jp], m8s2[jp]);
+                    V[2 * jp] = v.x;
+                    V[2 * jp + 1] = v.y;
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t], 0, 0, 0);
+                // V stays live past the MFMA: otherwise the register allocator writes the result over V, away from
+                // acc[t], and moves all 32 accumulators back at the end of every iteration
+                asm volatile("" :: "v"(V));
+            }
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int t = 2 * tt + half;
+                f16x8 V;
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    const f16x2 v = deq_pair<true>(cvt_pair(tt, nb[2 * jp], nb[2 * jp + 1]), s2[jp], m8s2[jp]);
+                    V[2 * jp] = v.x;
+                    V[2 * jp + 1] = v.y;
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// the split's partial result: running maximum, sum and the un-normalised accumulators
+__device__ __forceinline__ void store_partial(const AttendArgs& a, uint64_t part, uint32_t c, uint32_t kb, float m_run, float l_run, const f32x4 (&acc)[8])
+{
+    const float l_tot = sum_over_kb(l_run);
+    if (kb == 0) {
+        a.part_ml[part * 32u + c] = m_run;
+        a.part_ml[part * 32u + 16u + c] = l_tot;
+    }
+    if (c < a.g) {
+        float* dst = a.part_acc + (part * 16u + c) * 128u + 32u * kb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(dst + 8 * i) = f32x4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+            *reinterpret_cast<f32x4*>(dst + 8 * i + 4) = f32x4{acc[4][i], acc[5][i], acc[6][i], acc[7][i]};
+        }
+    }
+}
+
 } // namespace
 
 #ifndef SPECKV_INT4_WAVES
@@ -156,7 +303,6 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
     const uint32_t t0 = split * a.tiles_per_split;
     const uint32_t t1 = min(t0 + a.tiles_per_split, n_tiles);
     float m_run = -INFINITY, l_run = 0.0f;
-    constexpr float kLazy = 8.0f;                                        // see the softmax below
     f32x4 acc[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -192,11 +338,7 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
             for (int b = 0; b < 2; ++b) {
                 if (LINEAR) {
                     kx[b] = ldg16(kdat + 8u * kInt4RecBytes * b);
-#ifdef SPECKV_ABL_NO_SCALE_LOADS
-                    ks[b] = 0x3800;
-#else
                     ks[b] = *reinterpret_cast<const uint16_t*>(ksc + 8u * kInt4RecBytes * b);
-#endif
                 } else {
                     const uint8_t* base = rec_base(kent, next_k * 16u + 8u * b + (c >> 1));
                     kx[b] = ldg16(base + 128u + rowoff * 64u + kb * 16u);
@@ -208,11 +350,7 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
             if (LINEAR) {
                 vraw[0] = ldg16(vdat);
                 vraw[1] = ldg16(vdat + 8u * kInt4RecBytes);
-#ifdef SPECKV_ABL_NO_SCALE_LOADS
-                vsraw = 0x38003800u;
-#else
                 vsraw = *reinterpret_cast<const uint32_t*>(vsc);
-#endif
             } else {
                 const uint32_t voff = 128u + ((vr & 1u) * 8u + head) * 64u + (lane & 3u) * 16u;
                 vraw[0] = ldg16(rec_base(vent, next_v * 16u + (vr >> 1)) + voff);
@@ -241,35 +379,7 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
             const bool kbig = __builtin_amdgcn_ballot_w64(scale_is_big(static_cast<uint32_t>(ks[0]) | ks[1])) != 0ull;   // wave-uniform
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const _Float16 sh = __builtin_bit_cast(_Float16, ks[b]);
-                const f16x2 s2 = {sh, sh};
-                const f16x2 km8 = {static_cast<_Float16>(-8.0f), static_cast<_Float16>(-8.0f)};
-                const f16x2 m8s2 = s2 * km8;
-                const uint32_t w[4] = {kx[b].x ^ 0x88888888u, kx[b].y ^ 0x88888888u, kx[b].z ^ 0x88888888u, kx[b].w ^ 0x88888888u};
-                f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
-#ifdef SPECKV_ABL_NO_QK
-                s[0] = __uint_as_float((w[0] ^ w[1] ^ w[2] ^ w[3]) & 0x3F000000u) + static_cast<float>(s2.x);
-                if (false) {
-#else
-                if (!kbig) {
-#endif
-#ifdef SPECKV_INT4_SPLIT_CHAIN
-                    f32x4 s1 = {0.0f, 0.0f, 0.0f, 0.0f};
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8<false>(w[0], s2, m8s2), qv[0], s, 0, 0, 0);
-                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8<false>(w[1], s2, m8s2), qv[1], s1, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8<false>(w[2], s2, m8s2), qv[2], s, 0, 0, 0);
-                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8<false>(w[3], s2, m8s2), qv[3], s1, 0, 0, 0);
-                    s = s + s1;
-#else
-#pragma unroll
-                    for (int st = 0; st < 4; ++st)
-                        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8<false>(w[st], s2, m8s2), qv[st], s, 0, 0, 0);
-#endif
-                } else {
-#pragma unroll
-                    for (int st = 0; st < 4; ++st)
-                        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8<true>(w[st], s2, m8s2), qv[st], s, 0, 0, 0);
-                }
+                const f32x4 s = score_block(kx[b], ks[b], kbig, qv);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sc[4 * b + i] = s[i];
             }
@@ -284,33 +394,7 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
             kdat += step; ksc += step; next_k += step ? 1u : 0u;
             issue_k();
             __builtin_amdgcn_sched_barrier(0);
-            // ---- online softmax of query row c.  The running reference m_run only moves when the tile's maximum
-            // passes it by more than 2^kLazy: until then the weights are exp2(x - m_run) <= 2^kLazy (fine for f16, the
-            // sums are fp32) and the accumulators need no rescaling -- the result is the same after normalisation.
-            float mx = sc[0];
-#pragma unroll
-            for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc[j]);
-            mx = max_over_kb(mx) * qscale;                                 // qscale > 0
-            const bool grow = mx > m_run + kLazy;                         // also true for the first tile (m_run = -inf)
-            if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {              // wave-uniform: rare after the first tiles
-                const float m_new = grow ? mx : m_run;
-                const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;
-                const float f = __builtin_amdgcn_exp2f(m_run - m_use);    // 0 for the first tile, 1 for rows that keep theirs
-                m_run = m_new;
-                l_run *= f;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) acc[t] = acc[t] * f;
-            }
-            const float m_sub = (m_run == -INFINITY) ? 0.0f : -m_run;
-            float psum = 0.0f;
-            f16x8 P;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[j], qscale, m_sub));
-                psum += p;
-                P[j] = static_cast<_Float16>(p);
-            }
-            l_run += psum;
+            const f16x8 P = softmax_tile(sc, qscale, m_run, l_run, acc);
             // ---- V tile: registers -> this wave's LDS -> operand order
             *reinterpret_cast<uint4*>(vl + wr0) = vraw[0];
             *reinterpret_cast<uint4*>(vl + wr0 + 2048u) = vraw[1];
@@ -318,97 +402,207 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
             uint32_t vw[8], vs16[8];
-#ifdef SPECKV_ABL_NO_LDS_READ
-            {
-                const uint32_t t8[8] = {vraw[0].x, vraw[0].y, vraw[0].z, vraw[0].w, vraw[1].x, vraw[1].y, vraw[1].z, vraw[1].w};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { vw[j] = t8[j] ^ 0x88888888u; vs16[j] = (vsraw >> (16 * (j & 1))) & 0xFFFFu; }
-            }
-#else
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int ro = (j < 4) ? j : 16 + (j - 4);
                 vw[j] = *reinterpret_cast<const uint32_t*>(rdb + 128 * ro) ^ 0x88888888u;     // 8 nibbles of slot j, d = 8c..8c+7
                 vs16[j] = *reinterpret_cast<const uint16_t*>(rsb + 8 * ro);                   // its group scale (group c/4)
             }
-#endif
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_sched_barrier(0);
             vdat += step; vsc += step; next_v += step ? 1u : 0u;
             issue_v();                                                    // the staging registers are free again
             __builtin_amdgcn_sched_barrier(0);
-            // ---- out^T += V^T . P^T, accumulated in place
-            // element d = 8c + t of the two positions of a pair: nibble t&1 of byte t/2 of either position's dword
-            f16x2 s2[4], m8s2[4];
-            uint32_t sor = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sor |= vs16[j];
-            const bool vbig = __builtin_amdgcn_ballot_w64(scale_is_big(sor)) != 0ull;        // wave-uniform
-#pragma unroll
-            for (int jp = 0; jp < 4; ++jp) {
-                const f16x2 km8 = {static_cast<_Float16>(-8.0f), static_cast<_Float16>(-8.0f)};
-                s2[jp] = as_h2(vs16[2 * jp] | (vs16[2 * jp + 1] << 16));
-                m8s2[jp] = s2[jp] * km8;
-            }
-            // even d columns (t = 0, 2, 4, 6) come from the low nibbles, odd ones from the high nibbles: one nibble plane
-            // is live at a time (the plane replaces the dwords it came from)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                uint32_t nb[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) nb[j] = (half ? (vw[j] >> 4) : vw[j]) & 0x0F0F0F0Fu;
-                if (!vbig) {
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) {
-                        const int t = 2 * tt + half;
-                        f16x8 V;
-#pragma unroll
-                        for (int jp = 0; jp < 4; ++jp) {
-                            const f16x2 v = deq_pair<false>(cvt_pair(tt, nb[2 * jp], nb[2 * jp + 1]), s2[jp], m8s2[jp]);
-                            V[2 * jp] = v.x;
-                            V[2 * jp + 1] = v.y;
-                        }
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t], 0, 0, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) {
-                        const int t = 2 * tt + half;
-                        f16x8 V;
-#pragma unroll
-                        for (int jp = 0; jp < 4; ++jp) {
-                            const f16x2 v = deq_pair<true>(cvt_pair(tt, nb[2 * jp], nb[2 * jp + 1]), s2[jp], m8s2[jp]);
-                            V[2 * jp] = v.x;
-                            V[2 * jp + 1] = v.y;
-                        }
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t], 0, 0, 0);
-                    }
-                }
-            }
+            pv_tile(vw, vs16, P, acc);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // ---- partial result of this split
-    const float l_tot = sum_over_kb(l_run);
-    if (kb == 0) {
-        a.part_ml[part * 32u + c] = m_run;
-        a.part_ml[part * 32u + 16u + c] = l_tot;
+    store_partial(a, part, c, kb, m_run, l_run, acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Linear form, workgroup-cooperative LDS-DMA.  Measured on the per-wave kernels: with all arithmetic removed they ran no
+// faster (0.55 -> 0.57 of HBM peak), with two tiles in flight per wave instead of one no faster either -- but with every
+// wave instruction covering WHOLE 128-byte lines the same loop ran at 0.665.  A head's row is 64 B, half a line, and the
+// other half belongs to the neighbouring wave: fetched per head, every line is requested twice, by different waves at
+// different times.  Here the four waves of a workgroup fetch the tile for their four heads together: per position row
+// one 256-byte span (2 lines), per page one 128-byte line of scales, 5 DMA instructions of 1 KiB per wave and tile.
+//   LDS, per buffer (two buffers):  K rows [32][256 B] | V rows [32][256 B] | K scale lines [16][128 B] | V scale lines
+//   rows are stored with their sixteen 16-byte pieces XOR-ed by (row & 15) (chosen on the SOURCE side: lane l fetches
+//   piece (l & 15) ^ row): the K operand reads (ds_read_b128, 16 rows x one piece) and the V reads (ds_read_b32, rows
+//   4 kb + j) are then conflict-free; K scale lines likewise by (page & 7).
+//   iteration t:  own DMAs of tile t landed (vmcnt) + barrier -> K operand, scores, softmax, V dwords
+//                 -> barrier (everybody is done with the buffer) -> DMAs of tile t+2 into it -> PV
+namespace {
+constexpr uint32_t kWgBuf = 20480u, kWgV = 8192u, kWgKs = 16384u, kWgVs = 18432u;
+
+// one LDS-DMA: lane l's 16 bytes at base + voff land at lds_dst + 16 l.  M0 (the destination) belongs to the compiler:
+// saved and restored inside the statement.
+__device__ __forceinline__ void dma16(uint32_t lds_dst, const uint8_t* base, uint32_t voff)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(base) : "memory");
+}
+
+// this wave's 5 DMAs of the current tile have landed (the 5 of the next tile may still be in flight); then everybody's
+__device__ __forceinline__ void wg_landed(bool is_last)
+{
+    if (is_last) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else         asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ void wg_take_k(uint32_t rd, uint32_t rs, u32x4& k0, u32x4& k1, uint32_t& s0, uint32_t& s1)
+{
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:4096\n\t"
+                 "ds_read_u16 %2, %5\n\tds_read_u16 %3, %5 offset:1024\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(k0), "=&v"(k1), "=&v"(s0), "=&v"(s1) : "v"(rd), "v"(rs) : "memory");
+}
+// rd[j] = address of the dword of row 4 kb + j; rows 16 + 4 kb + j are 4096 B further.  Scales: page 2 kb + j/2 (+ 8),
+// slot j % 2 = 64 B further
+__device__ __forceinline__ void wg_take_v(const uint32_t (&rd)[4], uint32_t rs, uint32_t (&w)[8], uint32_t (&sc)[8])
+{
+    asm volatile("ds_read_b32 %0, %16\n\tds_read_b32 %1, %17\n\tds_read_b32 %2, %18\n\tds_read_b32 %3, %19\n\t"
+                 "ds_read_b32 %4, %16 offset:4096\n\tds_read_b32 %5, %17 offset:4096\n\tds_read_b32 %6, %18 offset:4096\n\tds_read_b32 %7, %19 offset:4096\n\t"
+                 "ds_read_u16 %8, %20\n\tds_read_u16 %9, %20 offset:64\n\tds_read_u16 %10, %20 offset:128\n\tds_read_u16 %11, %20 offset:192\n\t"
+                 "ds_read_u16 %12, %20 offset:1024\n\tds_read_u16 %13, %20 offset:1088\n\tds_read_u16 %14, %20 offset:1152\n\tds_read_u16 %15, %20 offset:1216\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]),
+                   "=&v"(sc[0]), "=&v"(sc[1]), "=&v"(sc[2]), "=&v"(sc[3]), "=&v"(sc[4]), "=&v"(sc[5]), "=&v"(sc[6]), "=&v"(sc[7])
+                 : "v"(rd[0]), "v"(rd[1]), "v"(rd[2]), "v"(rd[3]), "v"(rs) : "memory");
+}
+} // namespace
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_attend_int4_wg(AttendArgs a)
+{
+    static_assert(kWgHeads == 4, "the cooperative kernel is laid out for 4 heads per workgroup");
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kWgBuf];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t c = lane & 15u, kb = lane >> 4;
+    const uint32_t split = blockIdx.x;
+    const uint32_t hq = a.heads / 4u;
+    uint32_t layer = blockIdx.y / hq;                                    // batch form: the sequence index
+    const uint32_t head0 = (blockIdx.y % hq) * 4u;                       // first head of the workgroup
+    const uint32_t head = head0 + wave;
+    const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;
+    uint64_t part = row * a.n_splits + split;
+    if (a.seqs) {                                                        // workgroup-uniform: per-sequence geometry
+        const AttendSeq sq = a.seqs[layer];
+        if (split >= sq.n_splits) return;
+        a.lin_base = sq.lin_base;
+        a.k_first = sq.k_first;
+        a.v_first = sq.v_first;
+        a.n_pages = sq.n_pages;
+        part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
+        layer = 0;
     }
-    if (c < a.g) {
-        float* dst = a.part_acc + (part * 16u + c) * 128u + 32u * kb;
+
+    f16x8 qv[4];
+    {
+        const uint16_t* q16 = reinterpret_cast<const uint16_t*>(a.q8) + (row * a.g + c) * 128u + kb * 32u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(dst + 8 * i) = f32x4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
-            *reinterpret_cast<f32x4*>(dst + 8 * i + 4) = f32x4{acc[4][i], acc[5][i], acc[6][i], acc[7][i]};
+        for (int st = 0; st < 4; ++st) {
+            uint4 t = make_uint4(0u, 0u, 0u, 0u);
+            if (c < a.g) t = *reinterpret_cast<const uint4*>(q16 + 8 * st);
+            qv[st] = __builtin_bit_cast(f16x8, t);
         }
     }
+    const float qscale = a.scale_log2e;
+    const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
+    const uint32_t t0 = split * a.tiles_per_split;
+    const uint32_t t1 = min(t0 + a.tiles_per_split, n_tiles);
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    if (t0 < t1) {                                                       // workgroup-uniform
+        const uint32_t tile_bytes = 16u * kInt4RecBytes;
+        const uint8_t* kreg = a.lin_base + (a.k_first + layer * a.layer_stride) * kInt4RecBytes;      // tile tt: + tt * tile_bytes
+        const uint8_t* vreg = a.lin_base + (a.v_first + layer * a.layer_stride) * kInt4RecBytes;
+        // ---- this wave's share of the fetch: rows 8w .. 8w+7 of K and of V (two instructions of 4 rows each), and the
+        // scale lines of 8 pages of K (waves 0, 1) or V (waves 2, 3)
+        auto row_src = [&](uint32_t r, uint32_t piece) { return (r >> 1) * kInt4RecBytes + 128u + ((r & 1u) * 8u + head0) * 64u + piece * 16u; };
+        const uint32_t r0 = 8u * wave + (lane >> 4), r1 = r0 + 4u;
+        const uint32_t gr0 = row_src(r0, (lane & 15u) ^ (r0 & 15u)), gr1 = row_src(r1, (lane & 15u) ^ (r1 & 15u));
+        const uint32_t spage = 8u * (wave & 1u) + (lane >> 3);
+        const uint32_t gs = spage * kInt4RecBytes + (((lane & 7u) ^ ((wave < 2u) ? (spage & 7u) : 0u)) * 16u);
+        const uint32_t lbase = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&lds[0])));
+        const uint32_t dr0 = 8u * wave * 256u, ds_ = ((wave < 2u) ? kWgKs : kWgVs) + (wave & 1u) * 1024u;   // destinations inside a buffer
+        const uint8_t* sreg = (wave < 2u) ? kreg : vreg;
+        const uint32_t last = t1 - 1u;
+        auto issue = [&](uint32_t tt, uint32_t buf) {
+            const uint64_t to = static_cast<uint64_t>(tt) * tile_bytes;
+            const uint32_t dst = lbase + buf * kWgBuf;
+            dma16(dst + dr0, kreg + to, gr0);
+            dma16(dst + dr0 + 1024u, kreg + to, gr1);
+            dma16(dst + kWgV + dr0, vreg + to, gr0);
+            dma16(dst + kWgV + dr0 + 1024u, vreg + to, gr1);
+            dma16(dst + ds_, sreg + to, gs);
+        };
+        // ---- reader addresses inside buffer 0
+        const uint32_t rdk = lbase + c * 256u + (((wave * 4u + kb) ^ c) * 16u);                       // row 16 b + c: + 4096 b
+        const uint32_t h1 = head >> 1;
+        const uint32_t rsk = lbase + kWgKs + (c >> 1) * 128u + ((((c & 1u) * 4u + h1) ^ (c >> 1)) * 16u) + (head & 1u) * 8u + kb * 2u;
+        uint32_t rdv[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j)
+            rdv[j] = lbase + kWgV + (4u * kb + j) * 256u + ((((wave ^ kb) * 4u) + ((c >> 2) ^ j)) * 16u) + (c & 3u) * 4u;
+        const uint32_t rsv = lbase + kWgVs + 2u * kb * 128u + head * 8u + 2u * (c >> 2);
+        // the query rows must have arrived before the first DMA is issued: the compiler would otherwise place its own
+        // vmcnt(0) for them at their first use, inside the loop, and drain the pipeline there in every iteration
+        asm volatile("" :: "v"(qv[0]), "v"(qv[1]), "v"(qv[2]), "v"(qv[3]));
+        issue(t0, 0u);
+        if (t0 < last) issue(t0 + 1u, 1u);
+        const bool ragged = (a.n_pages & 15u) != 0u;
+#pragma unroll 1
+        for (uint32_t tile = t0; tile < t1; ++tile) {
+            const uint32_t buf = (tile - t0) & 1u;
+            const uint32_t bo = buf * kWgBuf;
+            wg_landed(tile == last);
+            u32x4 k0, k1;
+            uint32_t ks0, ks1;
+            wg_take_k(rdk + bo, rsk + bo, k0, k1, ks0, ks1);
+            float sc[8];
+            const bool kbig = __builtin_amdgcn_ballot_w64(scale_is_big(ks0 | ks1)) != 0ull;   // wave-uniform
+            {
+                const f32x4 s0 = score_block(make_uint4(k0.x, k0.y, k0.z, k0.w), ks0, kbig, qv);
+                const f32x4 s1 = score_block(make_uint4(k1.x, k1.y, k1.z, k1.w), ks1, kbig, qv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { sc[i] = s0[i]; sc[4 + i] = s1[i]; }
+            }
+            if (ragged && tile + 1u == n_tiles) {                         // workgroup-uniform: positions beyond the range
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t pg = tile * 16u + ((j >> 1) < 2 ? 2u * kb + (j >> 1) : 8u + 2u * kb + ((j >> 1) - 2));
+                    if (pg >= a.n_pages) sc[j] = -INFINITY;
+                }
+            }
+            const f16x8 P = softmax_tile(sc, qscale, m_run, l_run, acc);
+            uint32_t vw[8], vs16[8];
+            const uint32_t rdvb[4] = {rdv[0] + bo, rdv[1] + bo, rdv[2] + bo, rdv[3] + bo};
+            wg_take_v(rdvb, rsv + bo, vw, vs16);
+            asm volatile("s_barrier" ::: "memory");                       // every wave has taken what it needs from this buffer
+            if (tile + 2u <= last) issue(tile + 2u, buf);                 // (taking V earlier, to issue earlier, measured the same)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vw[j] ^= 0x88888888u;
+            pv_tile(vw, vs16, P, acc);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the re-requested tail tiles: nothing may land after the wave ends
+    }
+    store_partial(a, part, c, kb, m_run, l_run, acc);
 }
 
 hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_t s)
 {
     if ((a.n_pages == 0 && !a.seqs) || n_layers == 0 || a.n_splits == 0) return hipSuccess;   // batch form: geometry per sequence
+#ifdef SPECKV_INT4_REGSTAGE
     if (a.lin_base) hipLaunchKernelGGL(k_attend_int4<true>, dim3(a.n_splits, n_layers * (a.heads / kWgHeads)), dim3(64 * kWgHeads), 0, s, a);
+#else
+    if (a.lin_base) hipLaunchKernelGGL(k_attend_int4_wg, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
+#endif
     else            hipLaunchKernelGGL(k_attend_int4<false>, dim3(a.n_splits, n_layers * (a.heads / kWgHeads)), dim3(64 * kWgHeads), 0, s, a);
     return hipGetLastError();
 }
