@@ -26,6 +26,7 @@
 //   output O^T = V^T . P^T: rows c = d columns 8c + t, k-slots = the lane's 8 positions (as in
 //     attend.hip): the V tile goes through LDS and is read back as "8 nibbles of one position" dwords.
 #include "kernels.hpp"
+#include <type_traits>
 
 namespace speckv {
 
@@ -170,6 +171,8 @@ __device__ __forceinline__ f16x8 softmax_tile(const float (&sc)[8], float qscale
 // out^T += V^T . P^T, accumulated in place.  vw[j] = 8 nibbles (offset binary) of position slot j at d = 8c..8c+7,
 // vs16[j] = that slot's group scale (group c/4).  Element d = 8c + t of the two positions of a pair: nibble t&1 of byte
 // t/2 of either position's dword.
+// (CHECK_BIG false: the caller knows that no group scale of the allocation is beyond 8188)
+template <bool CHECK_BIG>
 __device__ __forceinline__ void pv_tile(const uint32_t (&vw)[8], const uint32_t (&vs16)[8], const f16x8& P, f32x4 (&acc)[8])
 {
 #ifdef SPECKV_ABL_NO_PV
@@ -182,10 +185,13 @@ __device__ __forceinline__ void pv_tile(const uint32_t (&vw)[8], const uint32_t 
     }
 #endif
     f16x2 s2[4], m8s2[4];
-    uint32_t sor = 0;
+    bool vbig = false;
+    if (CHECK_BIG) {
+        uint32_t sor = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sor |= vs16[j];
-    const bool vbig = __builtin_amdgcn_ballot_w64(scale_is_big(sor)) != 0ull;        // wave-uniform
+        for (int j = 0; j < 8; ++j) sor |= vs16[j];
+        vbig = __builtin_amdgcn_ballot_w64(scale_is_big(sor)) != 0ull;               // wave-uniform
+    }
 #pragma unroll
     for (int jp = 0; jp < 4; ++jp) {
         const f16x2 km8 = {static_cast<_Float16>(-8.0f), static_cast<_Float16>(-8.0f)};
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
             vdat += step; vsc += step; next_v += step ? 1u : 0u;
             issue_v();                                                    // the staging registers are free again
             __builtin_amdgcn_sched_barrier(0);
-            pv_tile(vw, vs16, P, acc);
+            pv_tile<true>(vw, vs16, P, acc);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -474,7 +480,10 @@ __device__ __forceinline__ void wg_take_v(const uint32_t (&rd)[4], uint32_t rs, 
 }
 } // namespace
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_attend_int4_wg(AttendArgs a)
+#ifndef SPECKV_INT4_WG_WAVES
+#define SPECKV_INT4_WG_WAVES 3
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4_WG_WAVES, SPECKV_INT4_WG_WAVES))) void k_attend_int4_wg(AttendArgs a)
 {
     static_assert(kWgHeads == 4, "the cooperative kernel is laid out for 4 heads per workgroup");
     __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kWgBuf];
@@ -497,7 +506,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         a.n_pages = sq.n_pages;
         part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
         layer = 0;
+        a.big_flag = sq.big_flag;
     }
+    // workgroup-uniform: has a group scale beyond 8188 (or a non-finite one) ever been stored in this allocation?
+    const bool big_any = a.big_flag == nullptr || __builtin_amdgcn_readfirstlane(*a.big_flag) != 0u;
 
     f16x8 qv[4];
     {
@@ -557,6 +569,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         issue(t0, 0u);
         if (t0 < last) issue(t0 + 1u, 1u);
         const bool ragged = (a.n_pages & 15u) != 0u;
+        // one loop, compiled twice: with the per-tile "is a scale of this tile beyond 8188" checks and the subtract-first
+        // dequantisation behind them, and without (a second arithmetic path in the loop costs ~60 of its ~390 vector
+        // instructions per tile -- the checks, and 32 accumulator moves where the two paths merge)
+        auto tiles = [&](auto checked) {
+        constexpr bool kCheck = decltype(checked)::value;
 #pragma unroll 1
         for (uint32_t tile = t0; tile < t1; ++tile) {
             const uint32_t buf = (tile - t0) & 1u;
@@ -566,7 +583,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             uint32_t ks0, ks1;
             wg_take_k(rdk + bo, rsk + bo, k0, k1, ks0, ks1);
             float sc[8];
-            const bool kbig = __builtin_amdgcn_ballot_w64(scale_is_big(ks0 | ks1)) != 0ull;   // wave-uniform
+            const bool kbig = kCheck && __builtin_amdgcn_ballot_w64(scale_is_big(ks0 | ks1)) != 0ull;   // wave-uniform
             {
                 const f32x4 s0 = score_block(make_uint4(k0.x, k0.y, k0.z, k0.w), ks0, kbig, qv);
                 const f32x4 s1 = score_block(make_uint4(k1.x, k1.y, k1.z, k1.w), ks1, kbig, qv);
@@ -588,9 +605,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             if (tile + 2u <= last) issue(tile + 2u, buf);                 // (taking V earlier, to issue earlier, measured the same)
 #pragma unroll
             for (int j = 0; j < 8; ++j) vw[j] ^= 0x88888888u;
-            pv_tile(vw, vs16, P, acc);
+            pv_tile<kCheck>(vw, vs16, P, acc);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the re-requested tail tiles: nothing may land after the wave ends
+        };
+#ifdef SPECKV_EXPERIMENT_NO_CHECKED_LOOP
+        tiles(std::false_type{});
+#else
+        if (big_any) tiles(std::true_type{});
+        else         tiles(std::false_type{});
+#endif
     }
     store_partial(a, part, c, kb, m_run, l_run, acc);
 }

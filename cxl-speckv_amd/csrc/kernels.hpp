@@ -84,6 +84,9 @@ struct CodecArgs {
     // (layer, kind) region of the shim layout, a multiple of 16
     float*          scale_tab;
     uint32_t        region_pages;
+    // compress only, INT4_G32: set to 1 (atomically, never cleared) when a group scale beyond 8188 or a non-finite one is
+    // stored -- the fused attention then takes its checked path for this allocation (attend_int4.hip, scale_is_big)
+    uint32_t*       big_flag;
     // blocks of several allocations in one launch (decompress only): block i belongs to row alloc_list[i] of tab
     const DevAlloc* tab;
     const uint32_t* alloc_list;
@@ -179,6 +182,7 @@ struct AttendSeq {
     uint32_t n_splits;                // ceil(tiles / tiles_per_split), <= gridDim.x
     uint32_t part_base;
     uint32_t reserved;
+    const uint32_t* big_flag;         // INT4: see AttendArgs::big_flag
 };
 
 // Decode attention straight from FP8_E4M3 records (attend.hip): softmax(q.K^T * sm_scale) . V per kv head,
@@ -199,6 +203,9 @@ struct AttendArgs {
     const float* scale_tab;           // linear form: page scales of the whole allocation in tile order (attend.hip)
     const uint16_t* q16;              // linear form: the fp16 query rows [layers][heads][g][128] (quantised in the kernel)
     const struct AttendSeq* seqs;     // batch form: one descriptor per sequence (blockIdx.y / (heads/4)), else null
+    // INT4: the allocation's "a group scale beyond 8188 was stored" word (CodecArgs::big_flag); null = unknown, check
+    // every tile.  While it reads 0 the kernel runs without the per-tile checks and without the subtract-first path.
+    const uint32_t* big_flag;
     float* part_acc;                  // [layers][heads][splits][16][128]
     float* part_ml;                   // [layers][heads][splits][2][16]
 };

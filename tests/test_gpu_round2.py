@@ -487,3 +487,70 @@ def test_kv_connector_block_tables_and_lookahead(oracle):
         assert lib.stats().l2_hits > hits0                            # the block tables were served from prefetched pages
     finally:
         lib.finalize()
+
+
+def test_int4_attention_with_group_scales_near_the_fp16_limit(oracle):
+    """INT4_G32 groups whose largest |x| is beyond 57 000 get a scale above 8188: -8 s is then no finite fp16 and the
+    fused attention must dequantise subtract-first.  The compress kernel marks such an allocation (one sticky word), the
+    linear-form kernel runs its checked loop for it and its unchecked loop for every other allocation; the page-table
+    form always checks.  Expected values: the oracle's attention over the oracle's decompressed pages, tolerance as in
+    test_int4_fused_attention.  A group that took the unchecked path would produce -inf * 0 = NaN."""
+    torch = torch_mod()
+    from oracle.bindings import _ptr, u16p, f32p
+    lib = open_lib()
+    try:
+        lib.set_compression_scheme(3)
+        T, L, H, D, bpe, G = 256, 1, 8, 128, 2, 8
+        n_pages = T * L * H * D * bpe * 2 // PAGE
+        rng = np.random.default_rng(97)
+        sm = 1.0 / np.sqrt(D)
+        q = (rng.standard_normal((H, G, D)) * 0.5).astype(np.float16)
+        d_q = torch.from_numpy(q.view(np.int16)).cuda()
+
+        def run_case(x, ranges):
+            h = lib.alloc(n_pages * PAGE)
+            lib.set_layout(h, T, L, H, D, bpe)
+            lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+            scales, lens, recs = oracle.compress_blocks_f16(x, 3, 0)
+            dec = oracle.decompress_blocks_f16(recs, lens, scales, 3, 0).reshape(n_pages, 2, H, D)
+            for pb, pe in ranges:
+                npos = pe - pb
+                d_out = torch.full((H, G, D), float("nan"), dtype=torch.float32, device="cuda")
+                lib.attend_int4(h, 0, 1, d_q.data_ptr(), G, pb, pe, sm, d_out.data_ptr())
+                torch.cuda.synchronize()
+                got = d_out.cpu().numpy()
+                assert np.isfinite(got).all(), (pb, pe)
+                kf, vf = pb // 2, T // 2 + pb // 2
+                for head in range(H):
+                    k16 = np.ascontiguousarray(dec[kf:kf + npos // 2, :, head, :].reshape(npos, D)).view(np.uint16)
+                    v16 = np.ascontiguousarray(dec[vf:vf + npos // 2, :, head, :].reshape(npos, D)).view(np.uint16)
+                    o = np.zeros((G, D), np.float32); l = np.zeros(G, np.float32); m = np.zeros((G, D), np.float32)
+                    oracle.lib.orc_attend_f16(_ptr(np.ascontiguousarray(q[head]).view(np.uint16).reshape(-1), u16p), G,
+                                              _ptr(k16.reshape(-1), u16p), _ptr(v16.reshape(-1), u16p), npos, D, float(sm),
+                                              _ptr(o, f32p), _ptr(l, f32p), _ptr(m, f32p))
+                    err = np.abs(got[head] - o)
+                    assert np.all(err <= 2e-3 * m + 1e-6), (pb, pe, head, float((err / (m + 1e-9)).max()))
+            return h
+
+        plain = rng.standard_normal((n_pages, N)).astype(np.float16)
+        big = plain.copy()
+        # K pages (0 .. T/2) and V pages (T/2 .. T): a few groups of 32 elements with one value near the fp16 limit
+        for page, elem, val in ((3, 40, 60000.0), (3, 1500, -64000.0), (70, 7, 58000.0), (T // 2 + 9, 300, -61000.0),
+                                (T // 2 + 64, 2047, 65000.0), (T // 2 + 127, 0, 57400.0)):
+            big[page, elem] = np.float16(val)
+        assert np.abs(big.astype(np.float32)).max() / 7.0 > 8188.0
+        ranges = [(0, T), (0, 64), (64, 192), (30, T)]            # linear form, and (30, T) through the page table
+        h_big = run_case(big, ranges)
+        h_plain = run_case(plain, ranges)                         # its own flag word: unchecked loop, same answers as ever
+        # the mark is sticky: overwriting the large groups with ordinary data keeps the (still correct) checked loop
+        lib.write(h_big, 0, plain.ctypes.data, plain.nbytes, False)
+        d_out = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
+        d_ref = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
+        lib.attend_int4(h_big, 0, 1, d_q.data_ptr(), G, 0, T, sm, d_out.data_ptr())
+        lib.attend_int4(h_plain, 0, 1, d_q.data_ptr(), G, 0, T, sm, d_ref.data_ptr())
+        torch.cuda.synchronize()
+        # same records, same split geometry: checked and unchecked loop differ only in code path, not in arithmetic
+        assert torch.equal(d_out, d_ref)
+        lib.free(h_big); lib.free(h_plain)
+    finally:
+        lib.finalize()
