@@ -183,6 +183,7 @@ int Engine::init_hip(int device)
     // cache arena on the compute GPU (reference defaults 12 GB L1 / 3 GB L2,
     // cxl_memory_manager.h:42-44; ours are env-tunable and allocated up front)
     const size_t l2_mb = env_mb("SPECKV_L2_MB", 256), l1_mb = env_mb("SPECKV_L1_MB", 256);
+    if (const char* e = getenv("SPECKV_RING_SEQ_LIMIT")) ring_seq_limit_ = static_cast<uint32_t>(strtoul(e, nullptr, 0));   // tests
     n_l2_ = static_cast<uint32_t>((l2_mb << 20) / kPageSize);
     n_l1_ = static_cast<uint32_t>((l1_mb << 20) / kPageSize);
     if (n_l2_ < 64) n_l2_ = 64;
@@ -636,7 +637,8 @@ int Engine::flush_mirror()
 // Only called with no fetch in flight (quiesce), so host and device mirrors cannot race on the page's words.
 void Engine::drop_page(Allocation* a, uint32_t page)
 {
-    const uint32_t f = a->flags[page];
+    if (null_) { a->flags[page] &= ~3u; return; }
+    const uint32_t f = res_flags(a, page);
     if (!(f & 3u)) return;
     const uint32_t s = a->slot[page];
     if ((f & 1u) && s >= n_l2_) {
@@ -645,17 +647,45 @@ void Engine::drop_page(Allocation* a, uint32_t page)
         l1_owner_[s - n_l2_] = Owner{nullptr, 0};
         if (a->l1_pages) a->l1_pages--;
     }
-    a->flags[page] = f & ~3u;
+    a->flags[page] &= ~3u;
+    a->slot[page] = kNoSlot;
     queue_update(a, page, ~3u, 0u, kKeepSlot);     // a ring slot keeps naming the page until it is reused: harmless
 }
 
 uint32_t Engine::take_l2_run(uint32_t n)
 {
-    // FIFO ring; a run never wraps so multi-page spans stay contiguous (k_flush_assign applies the same rule)
-    uint32_t start = l2_hand_ % n_l2_;
-    if (start + n > n_l2_) start = 0;
-    l2_hand_ = start + n;
-    return start;
+    // FIFO ring; a run never wraps so multi-page spans stay contiguous (k_flush_assign applies the same rule).
+    // ring_seq_ counts every slot the hand has passed, skipped ones included: slot = sequence number % n_l2_.
+    const uint32_t start = ring_seq_ % n_l2_;
+    if (start + n > n_l2_) ring_seq_ += n_l2_ - start;
+    const uint32_t first = ring_seq_;
+    ring_seq_ += n;
+    return first;
+}
+
+// Sequence numbers are 32 bits: long before they wrap, every live one is moved down by a multiple of the ring size
+// (slots unchanged) and every dead one cleared.  O(all pages), once per ~3 * 10^9 fetched pages.
+int Engine::renumber_ring_if_due()
+{
+    if (ring_seq_ < ring_seq_limit_ || n_l2_ == 0) return SPECKV_OK;
+    RC_TRY(quiesce());
+    RC_TRY(flush_mirror());
+    RC_TRY(wait_stream());
+    const uint32_t shift = (ring_seq_ - std::min(ring_seq_, n_l2_)) / n_l2_ * n_l2_;
+    if (!shift) return SPECKV_OK;
+    for (auto& kv : allocs_) {
+        Allocation* a = kv.second.get();
+        if (!a->slot) continue;
+        for (uint64_t p = 0; p < a->n_pages; ++p) {
+            if (a->flags[p] & 1u) continue;                                  // L1 slot index
+            const uint32_t q = a->slot[p];
+            a->slot[p] = l2_live(q) ? q - shift : kNoSlot;
+        }
+    }
+    ring_seq_ -= shift;
+    HIP_TRY(hipMemcpyAsync(d_hand_, &ring_seq_, sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+    RC_TRY(wait_stream());
+    return SPECKV_OK;
 }
 
 uint32_t Engine::take_l1_slot()
@@ -673,7 +703,7 @@ uint32_t Engine::take_l1_slot()
 
 int Engine::move_to_l1(Allocation* a, uint32_t page)
 {   // promote_to_l1 (cxl_memory_manager.cpp:130-163) for a page that sits in the L2 ring
-    const uint32_t from = a->slot[page];
+    const uint32_t from = res_slot(a, page);
     const uint32_t to = take_l1_slot();
     HIP_TRY(hipMemcpyAsync(slot_ptr(to), slot_ptr(from), kPageSize, hipMemcpyDeviceToDevice, stream_));
     l1_owner_[to - n_l2_] = Owner{a, page};
@@ -690,7 +720,7 @@ void Engine::absorb(Flight& f)
     f.m = f.result->m;
     f.base = f.result->base;
     f.absorbed = true;
-    if (f.m) l2_hand_ = f.base + f.m;                  // the device applied take_l2_run's rule
+    if (f.m) ring_seq_ = f.result->seq + f.m;          // the device applied take_l2_run's rule
     st_.total_prefetches += f.m;
     st_.dma_submitted += f.m;
     st_.total_decompressions += f.m;
@@ -752,7 +782,7 @@ int Engine::wait_landed(const Allocation* a, uint64_t p0, uint64_t p1)
         for (const Flight& f : flights_) {
             if (!f.absorbed || f.m == 0) continue;
             for (uint64_t p = p0; p <= p1 && !need; ++p)
-                if ((a->flags[p] & 2u) && a->slot[p] >= f.base && a->slot[p] < f.base + f.m) need = f.done;
+                if ((res_flags(a, p) & 2u) && res_slot(a, p) >= f.base && res_slot(a, p) < f.base + f.m) need = f.done;
             if (need) break;
         }
         if (!need) break;
@@ -797,7 +827,9 @@ int Engine::fetch_into_ring(Allocation* a, const std::vector<uint32_t>& pages, u
         HIP_TRY(hipMemcpyAsync(d_pages, pages.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
         c.page_list = d_pages;
     }
-    const uint32_t base = take_l2_run(n);
+    RC_TRY(renumber_ring_if_due());
+    const uint32_t seq = take_l2_run(n);
+    const uint32_t base = seq % n_l2_;
     c.n = n;
     c.scheme = a->scheme;
     c.quant_mode = quant_mode_;
@@ -806,8 +838,9 @@ int Engine::fetch_into_ring(Allocation* a, const std::vector<uint32_t>& pages, u
     c.ring_owner = d_owner_;
     c.ring_base = cache_base_;
     c.slot0 = base;
+    c.seq0 = seq;
     c.hand_ptr = d_hand_;
-    c.new_hand = l2_hand_;
+    c.new_hand = ring_seq_;
     HIP_TRY(launch_decompress(c, stream_));
     st_.dma_submitted += n;
     st_.total_decompressions += n;
@@ -869,7 +902,7 @@ int Engine::access(uint64_t handle, uint64_t off, size_t len, void** out)
     if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
     auto resident_run = [&] {                                // a multi-page span must come back contiguous
         for (uint64_t p = p0; p <= p1; ++p)
-            if (!(a->flags[p] & 3u) || a->slot[p] != a->slot[p0] + (p - p0)) return false;
+            if (!(res_flags(a, p) & 3u) || res_slot(a, p) != res_slot(a, p0) + (p - p0)) return false;
         return true;
     };
     bool contiguous = resident_run();
@@ -883,7 +916,7 @@ int Engine::access(uint64_t handle, uint64_t off, size_t len, void** out)
     std::vector<uint32_t> miss;
     for (uint64_t p = p0; p <= p1; ++p) {
         a->access_count[p]++;                                // update_access_tracking, cxl_memory_manager.cpp:223-245
-        const uint32_t f = a->flags[p];
+        const uint32_t f = res_flags(a, p);
         if (f & 1u) { st_.l1_hits++; if (contiguous) { lru_unlink(a->slot[p]); lru_push_mru(a->slot[p]); } }
         else if (f & 2u) st_.l2_hits++;
         else { st_.l3_accesses++; st_.l2_misses++; }
@@ -896,20 +929,20 @@ int Engine::access(uint64_t handle, uint64_t off, size_t len, void** out)
         uint32_t base = 0;
         rc = fetch_into_ring(a, miss, &base);                // sync_fetch_page: submit + spin on completion
         if (rc != SPECKV_OK) return rc;
-    } else if (p1 == p0 && (a->flags[p0] & 3u) == 2u && a->access_count[p0] > 10) {
+    } else if (p1 == p0 && (res_flags(a, p0) & 3u) == 2u && a->access_count[p0] > 10) {
         // L2 hit on a hot page -> promote (memory_allocator.cpp:127-134, is_hot_page: count > 10)
         RC_TRY(quiesce());
         if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
-        if ((a->flags[p0] & 3u) == 2u) { RC_TRY(move_to_l1(a, static_cast<uint32_t>(p0))); RC_TRY(wait_stream()); }
+        if ((res_flags(a, p0) & 3u) == 2u) { RC_TRY(move_to_l1(a, static_cast<uint32_t>(p0))); RC_TRY(wait_stream()); }
     }
     if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
-    if (!(a->flags[p0] & 3u)) {                              // evicted again by a concurrent caller (cache far too small)
+    if (!(res_flags(a, p0) & 3u)) {                          // evicted again by a concurrent caller (cache far too small)
         SPECKV_ERR("speckv_access: page %llu of handle %llu is not resident after its fetch (flags %#x slot %u, %zu missed, hand %u)",
                    static_cast<unsigned long long>(p0), static_cast<unsigned long long>(handle), a->flags[p0], a->slot[p0],
-                   miss.size(), l2_hand_);
+                   miss.size(), ring_seq_);
         return SPECKV_ERR_GENERAL;
     }
-    *out = slot_ptr(a->slot[p0]) + poff;
+    *out = slot_ptr(res_slot(a, p0)) + poff;
     return SPECKV_OK;
 }
 
@@ -937,7 +970,7 @@ int Engine::access_batch(uint64_t handle, const uint64_t* offs, uint32_t n, void
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t p = static_cast<uint32_t>(offs[i] / kPageSize);
         a->access_count[p]++;
-        const uint32_t f = a->flags[p];
+        const uint32_t f = res_flags(a, p);
         if (f & 1u) st_.l1_hits++; else if (f & 2u) st_.l2_hits++; else { st_.l3_accesses++; st_.l2_misses++; }
         if (!(f & 3u) && a->stamp[p] != access_epoch_) { a->stamp[p] = access_epoch_; miss.push_back(p); }
     }
@@ -951,7 +984,7 @@ int Engine::access_batch(uint64_t handle, const uint64_t* offs, uint32_t n, void
     if (rc == SPECKV_OK)
         for (uint32_t i = 0; i < n; ++i) {
             const uint64_t p = offs[i] / kPageSize;
-            out[i] = (a->flags[p] & 3u) ? slot_ptr(a->slot[p]) + offs[i] % kPageSize : nullptr;
+            out[i] = (res_flags(a, p) & 3u) ? slot_ptr(res_slot(a, p)) + offs[i] % kPageSize : nullptr;
             if (!out[i]) rc = SPECKV_ERR_GENERAL;   // evicted inside this very batch (cache smaller than batch)
         }
     return rc;
@@ -1115,6 +1148,7 @@ int Engine::prefetch_flush(uint32_t* n_issued)
     if (in_flush_) return SPECKV_OK;
     if (q_req_.empty() && q_unresolved_.empty() && q_dropped_ == 0) return SPECKV_OK;
     DeviceScope device_scope(device_);
+    RC_TRY(renumber_ring_if_due());
     in_flush_ = true;
     static const bool timing = getenv("SPECKV_TIMING") != nullptr;
     const auto t_a = std::chrono::steady_clock::now();
@@ -1241,6 +1275,7 @@ int Engine::flush_group(int scheme, const uint32_t* const cols[5], uint32_t n, u
     c.ring_owner = d_owner_;
     c.ring_base = cache_base_;
     c.slot0_dev = &f.result_dev->base;
+    c.seq0_dev = &f.result_dev->seq;
     c.scheme = scheme;
     c.quant_mode = quant_mode_;
     HIP_TRY(launch_decompress(c, stream_));
@@ -1433,14 +1468,14 @@ int Engine::translate(uint64_t handle, uint64_t off, speckv_ext_page_info_t* o)
     DeviceScope device_scope(device_);
     RC_TRY(quiesce());                      // residency words are final (a flush in flight may be writing them)
     if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
-    o->flags = a->flags[p];
+    o->flags = res_flags(a, p);
     PageEntry e{};
     HIP_TRY(hipMemcpy(&e, a->d_entries + p, sizeof(e), hipMemcpyDeviceToHost));
     o->pool_device = pools_[a->page_pool[p]]->device();
     o->rec_bytes = e.rec_bytes;
     o->scale = e.scale;
     o->pool_addr = e.pool_addr;
-    o->cache_addr = (a->flags[p] & 3u) ? reinterpret_cast<uint64_t>(slot_ptr(a->slot[p])) : 0;
+    o->cache_addr = (res_flags(a, p) & 3u) ? reinterpret_cast<uint64_t>(slot_ptr(res_slot(a, p))) : 0;
     o->access_count = a->access_count[p];
     return SPECKV_OK;
 }
@@ -1545,7 +1580,7 @@ int Engine::write_strided(uint64_t handle, uint64_t first, uint64_t step, uint64
     // NULL = the engine's stream: the source may have been produced on any stream of the caller, order after all of them
     if (!s) HIP_TRY(hipDeviceSynchronize());
     bool cached = false;
-    for (uint64_t i = 0; i < n && !cached; ++i) cached = (a->flags[first + i * step] & 3u) != 0;
+    for (uint64_t i = 0; i < n && !cached; ++i) cached = (res_flags(a, first + i * step) & 3u) != 0;
     if (cached || !flights_.empty() || ring_busy_ > 0) {
         RC_TRY(quiesce());
         if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
@@ -2226,7 +2261,7 @@ int Engine::promote_to_l1(uint64_t handle, uint64_t off)
     RC_TRY(quiesce());
     if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
     if (a->flags[p] & 1u) return SPECKV_ERR_GENERAL;          // already there -> false (cxl_memory_manager.cpp:134-136)
-    if (a->flags[p] & 2u) {
+    if (res_flags(a, p) & 2u) {
         RC_TRY(move_to_l1(a, static_cast<uint32_t>(p)));
         return wait_stream();
     }
@@ -2254,7 +2289,7 @@ int Engine::demote_to_l3(uint64_t handle, uint64_t off)
     DeviceScope device_scope(device_);
     RC_TRY(quiesce());
     if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
-    if (!(a->flags[p] & 3u)) return SPECKV_ERR_GENERAL;       // already in the pool only
+    if (!(res_flags(a, p) & 3u)) return SPECKV_ERR_GENERAL;   // already in the pool only
     if (a->flags[p] & 1u) st_.migrations_l1_to_l3++;
     drop_page(a, static_cast<uint32_t>(p));
     return SPECKV_OK;

@@ -178,7 +178,11 @@ private:
     struct Owner { Allocation* a; uint32_t page; };
     uint8_t* cache_base_ = nullptr;
     uint32_t n_l2_ = 0, n_l1_ = 0;
-    uint32_t l2_hand_ = 0;                 // host mirror of the device ring hand
+    // Ring sequence number: every slot the L2 ring's hand has passed (slots skipped at the end of a lap included), so
+    // slot = seq % n_l2_.  The device keeps the same number (d_hand_) and stores, as a fetched page's ONLY host-visible
+    // word, the sequence number of its slot (Allocation::slot); the host derives residency from it (l2_live).
+    uint32_t ring_seq_ = 0;
+    uint32_t ring_seq_limit_ = 0xC0000000u;   // renumber_ring_if_due: keeps sequence numbers clear of the 32-bit wrap
     uint64_t* d_owner_ = nullptr;          // [n_l2] (row << 32 | page), kNoOwner when free
     uint32_t* d_hand_ = nullptr;
     std::vector<Owner> l1_owner_;          // [n_l1], slot - n_l2
@@ -285,7 +289,19 @@ private:
     // tiers
     uint8_t* slot_ptr(uint32_t slot) const { return cache_base_ + static_cast<size_t>(slot) * kPageSize; }
     void drop_page(Allocation* a, uint32_t page);         // page leaves the cache (any tier)
-    uint32_t take_l2_run(uint32_t n);                     // host mirror of the ring rule
+    uint32_t take_l2_run(uint32_t n);                     // host mirror of the ring rule: sequence number of the run's first slot
+    // a page fetched into the ring with sequence number q is intact until the hand has passed q + n_l2_
+    bool l2_live(uint32_t q) const { return q != kNoSlot && static_cast<uint32_t>(ring_seq_ - q) - 1u < n_l2_; }
+    // residency as the API reports it: bit0 L1 (host-managed), bit1 L2 (derived, see above), bit2 compressed
+    uint32_t res_flags(const Allocation* a, uint64_t p) const
+    {
+        const uint32_t f = a->flags[p];
+        if (null_) return f;
+        return (f & ~2u) | ((!(f & 1u) && l2_live(a->slot[p])) ? 2u : 0u);
+    }
+    // cache slot of a resident page (L1 slots are numbered after the ring)
+    uint32_t res_slot(const Allocation* a, uint64_t p) const { return (a->flags[p] & 1u) ? a->slot[p] : a->slot[p] % n_l2_; }
+    int renumber_ring_if_due();
     uint32_t take_l1_slot();
     void lru_unlink(uint32_t slot);
     void lru_push_mru(uint32_t slot);

@@ -474,8 +474,12 @@ __device__ __forceinline__ BlockDesc load_desc(const CodecArgs& a, uint64_t i, u
     return d;
 }
 
-// Ring bookkeeping of one fetched block (one lane): see CodecArgs::ring_owner.
-__device__ __forceinline__ void ring_note(const CodecArgs& a, const BlockDesc& d, uint32_t slot)
+// Ring bookkeeping of one fetched block (one lane): see CodecArgs::ring_owner.  Device side: the slot's previous owner
+// loses its L2 bit, the new owner is recorded.  Host side: ONE store, the page's ring sequence number -- the host derives
+// "still in the ring" from it (Engine::l2_live), so evictions need no host-visible store.  (Every 4-byte store to pinned
+// memory is a PCIe transaction of its own: with slot, flags and the evicted page's flags stored per block, a flush of
+// 19 000 blocks ran at the link's transaction rate -- 70 us against 42 us without the stores, 47 us with one.)
+__device__ __forceinline__ void ring_note(const CodecArgs& a, const BlockDesc& d, uint32_t slot, uint32_t seq)
 {
     const uint64_t prev = a.ring_owner[slot];
     const uint64_t me = (static_cast<uint64_t>(d.row) << 32) | d.page;
@@ -483,18 +487,15 @@ __device__ __forceinline__ void ring_note(const CodecArgs& a, const BlockDesc& d
         const DevAlloc t = a.tab[prev >> 32];
         const uint32_t pp = static_cast<uint32_t>(prev);
         // the row may have been recycled for a smaller allocation since the slot was filled
-        if (t.entries && pp < t.layout.alloc_pages && t.d_slot[pp] == slot) {     // still pointing here: the page leaves L2
-            const uint32_t v = atomicAnd(&t.d_flags[pp], ~2u) & ~2u;
-            t.h_flags[pp] = v;
-        }
+        if (t.entries && pp < t.layout.alloc_pages && t.d_slot[pp] == slot)      // still pointing here: the page leaves L2
+            atomicAnd(&t.d_flags[pp], ~2u);
     }
     a.ring_owner[slot] = me;
     const DevAlloc t = a.tab[d.row];
     if (!t.entries) return;
     t.d_slot[d.page] = slot;
-    t.h_slot[d.page] = slot;
-    const uint32_t v = atomicOr(&t.d_flags[d.page], 2u) | 2u;
-    t.h_flags[d.page] = v;
+    t.h_slot[d.page] = seq;
+    atomicOr(&t.d_flags[d.page], 2u);
 }
 
 template <int SCHEME, int MODE, bool F32, int EXT>
@@ -505,9 +506,10 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint64_t n = a.n;
     if (a.n_dev) { const uint64_t nd = *a.n_dev; n = nd < n ? nd : n; }
-    uint32_t slot0 = 0;
+    uint32_t slot0 = 0, seq0 = 0;
     if (EXT == 2) {
         slot0 = a.slot0_dev ? *a.slot0_dev : a.slot0;
+        seq0 = a.seq0_dev ? *a.seq0_dev : a.seq0;
         if (a.hand_ptr && blockIdx.x == 0 && threadIdx.x == 0) *a.hand_ptr = a.new_hand;
     }
     // a wave's blocks: one, or (launches beyond the grid cap) `per_wave` of them, one grid apart (wave_step) or
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
             decode_fp16<F32>(cur.rec, len, cur.dst, lane);
         }
         if (lane == 0u) {
-            if (EXT == 2 && a.ring_owner) ring_note(a, cur, slot0 + static_cast<uint32_t>(i));
+            if (EXT == 2 && a.ring_owner) ring_note(a, cur, slot0 + static_cast<uint32_t>(i), seq0 + static_cast<uint32_t>(i));
             else if (a.flags) atomicOr(&a.flags[cur.page], a.set_flags);   // neighbours belong to other waves / XCDs
         }
         if (nx >= end) break;
@@ -1152,10 +1154,13 @@ __global__ __launch_bounds__(1024) void k_flush_assign(FlushArgs a)
     if (threadIdx.x == 0) {
         const uint32_t total = running;
         const uint32_t m = total < a.max_take ? total : a.max_take;
-        uint32_t start = *a.hand % a.n_l2;
-        if (start + m > a.n_l2) start = 0;
-        if (m) *a.hand = start + m;
-        const FlushResult r{m, start, total, 0u};
+        // *a.hand is the ring's sequence number: slot = seq % n_l2; a run never wraps, the slots it skips at the end of
+        // a lap count (Engine::take_l2_run applies the same rule)
+        uint32_t seq = *a.hand;
+        uint32_t start = seq % a.n_l2;
+        if (start + m > a.n_l2) { seq += a.n_l2 - start; start = 0; }
+        if (m) *a.hand = seq + m;
+        const FlushResult r{m, start, total, seq};
         *a.result_dev = r;
         *a.result_host = r;
     }

@@ -98,8 +98,10 @@ struct CodecArgs {
     uint8_t*        ring_base;
     const uint32_t* slot0_dev;
     uint32_t        slot0;
+    const uint32_t* seq0_dev;     // ring sequence number of slot0 (block i: seq0 + i), stored as the page's host-visible word
+    uint32_t        seq0;
     uint32_t        alloc_idx;    // row of tab for every block when alloc_list == nullptr
-    uint32_t*       hand_ptr;     // optional: block 0 stores new_hand (host-initiated takes keep the device hand current)
+    uint32_t*       hand_ptr;     // optional: block 0 stores new_hand = the ring sequence number after this take (host-initiated takes keep the device's current)
     uint32_t        new_hand;
     // copy-engine fetch: the records of pool (page % stripe_n) were copied into local staging, to their pool address
     // + stripe_delta[page % stripe_n]
@@ -133,7 +135,7 @@ hipError_t launch_apply_updates(const DevAlloc* d_tab, const MirrorUpdate* d_upd
 // without the host).  n requests (SoA: local request index inside the allocation, layer, position, depth, table row)
 // -> candidate pages in request order (fixed stride of 32*W words per request), first-occurrence dedupe through the
 // per-page stamps, ordered compaction, ring-slot assignment, and the final (page, row) lists a fetch launch consumes.
-struct FlushResult { uint32_t m, base, total, pad; };      // pages taken, first ring slot, distinct candidates found
+struct FlushResult { uint32_t m, base, total, seq; };      // pages taken, first ring slot, distinct candidates found, ring sequence number of the first slot
 struct FlushArgs {
     const DevAlloc* tab;
     uint32_t        n;            // requests

@@ -143,10 +143,17 @@ def test_flush_over_many_allocations_with_request_bindings(oracle):
         lib.finalize()
 
 
-def test_ring_wrap_and_eviction_by_the_fetch_kernel(oracle):
+@pytest.mark.parametrize("seq_limit", [None, 700])
+def test_ring_wrap_and_eviction_by_the_fetch_kernel(oracle, seq_limit):
     """A ring of 256 slots under flushes that wrap it several times: what is flagged resident really is there, evicted
-    pages lose their bit, synchronous misses interleave with flushes, the host's ring hand stays in step."""
-    lib = open_lib(SPECKV_L2_MB=1, SPECKV_L1_MB=1)
+    pages lose their bit, synchronous misses interleave with flushes, the host's ring hand stays in step.  The host derives
+    "still in the ring" from the sequence number the fetch kernel stores for a page (its only host-visible store): with
+    seq_limit the 32-bit sequence numbers are renumbered every few hundred slots instead of every 3 * 10^9, so the run
+    crosses that code several times with live pages on both sides."""
+    env = {"SPECKV_L2_MB": 1, "SPECKV_L1_MB": 1}
+    if seq_limit:
+        env["SPECKV_RING_SEQ_LIMIT"] = seq_limit
+    lib = open_lib(**env)
     try:
         lib.set_compression_scheme(1)
         geom = (T, L, H, D, bpe) = (512, 2, 8, 128, 2)
