@@ -1218,7 +1218,7 @@ int Engine::flush_group(int scheme, const uint32_t* const cols[5], uint32_t n, u
     const uint64_t words = static_cast<uint64_t>(n) * 32u * W;
     const uint32_t n_w = static_cast<uint32_t>((words + 63u) >> 6);
     const uint32_t max_take = static_cast<uint32_t>(std::min<uint64_t>(n_l2_ / 2, words));   // never let one flush wipe the whole ring
-    const size_t bytes = (5ull * n + words + 2ull * n_w + 8 + 2ull * max_take) * sizeof(uint32_t);
+    const size_t bytes = (5ull * n + words + 2ull * n_w + 8 + 6ull * max_take + 4) * sizeof(uint32_t);     // + descriptors (16 B) and destinations (8 B)
     uint32_t* buf = static_cast<uint32_t*>(scratch(s_flush_, bytes));
     if (!buf) return SPECKV_ERR_NOMEM;
     // request upload through a pinned slot (4 in rotation, each guarded by an event): no stream sync
@@ -1249,8 +1249,10 @@ int Engine::flush_group(int scheme, const uint32_t* const cols[5], uint32_t n, u
     f.epoch = flush_epoch_;
     f.cand = buf + 5ull * n;
     f.wave_tot = f.cand + words;
-    f.final_page = f.wave_tot + 2ull * n_w + 8;
-    f.final_row = f.final_page + max_take;
+    f.final_entry = reinterpret_cast<PageEntry*>((reinterpret_cast<uintptr_t>(f.wave_tot + 2ull * n_w + 8) + 15u) & ~uintptr_t(15));
+    f.final_dst = reinterpret_cast<uint64_t*>(f.final_entry + max_take);
+    f.ring_owner = d_owner_;
+    f.ring_base = cache_base_;
     f.max_take = max_take;
     f.n_l2 = n_l2_;
     f.hand = d_hand_;
@@ -1265,17 +1267,13 @@ int Engine::flush_group(int scheme, const uint32_t* const cols[5], uint32_t n, u
     if (!fl.assigned || !fl.done) return SPECKV_ERR_DRIVER;
     HIP_TRY(hipEventRecord(fl.assigned, stream_));
 
+    // the fetch itself: plain list form (the scatter kernel left a record descriptor and a destination per block)
     CodecArgs c{};
     c.trusted = 1;
-    c.tab = d_tab_;
-    c.alloc_list = f.final_row;
-    c.page_list = f.final_page;
+    c.entries = f.final_entry;
+    c.data_list = f.final_dst;
     c.n = max_take;
     c.n_dev = &f.result_dev->m;
-    c.ring_owner = d_owner_;
-    c.ring_base = cache_base_;
-    c.slot0_dev = &f.result_dev->base;
-    c.seq0_dev = &f.result_dev->seq;
     c.scheme = scheme;
     c.quant_mode = quant_mode_;
     HIP_TRY(launch_decompress(c, stream_));

@@ -1123,7 +1123,33 @@ __global__ __launch_bounds__(256) void k_flush_mark(FlushArgs a, const FlushResu
     } else if (keep) {
         const uint32_t n_w = (total + 63u) >> 6;
         const uint32_t rank = a.wave_tot[n_w + w] + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
-        if (rank < res->m) { a.final_page[rank] = pg; a.final_row[rank] = row; }
+        if (rank < res->m) {
+            // Entry `rank` of the flush lands in ring slot base + rank.  Everything about it that is pointer chasing --
+            // its record descriptor, the slot's previous owner and that owner's residency words, the new owner, the
+            // page's slot words on both sides -- is done here, one THREAD per page, so that the fetch launch is the plain
+            // list form (descriptor + destination per block) at the bulk kernel's occupancy.  Done by the fetch kernel
+            // itself, one WAVE per page with a chain of ~8 dependent loads each, the 122 880-page flush of a 256-sequence
+            // decode step spent 210 us in the fetch; the chain now runs 64 pages per wave.
+            // (The words are final before the data has landed: the host waits for the flight's `done` event before it
+            // trusts a page whose slot lies in the flight's run, Engine::wait_landed.)
+            const uint32_t slot = res->base + rank;
+            const DevAlloc t = a.tab[row];
+            a.final_entry[rank] = t.entries[pg];
+            a.final_dst[rank] = reinterpret_cast<uint64_t>(a.ring_base + static_cast<uint64_t>(slot) * kPageSize);
+            const uint64_t prev = a.ring_owner[slot];
+            const uint64_t me = (static_cast<uint64_t>(row) << 32) | pg;
+            if (prev != kNoOwner && prev != me) {
+                const DevAlloc tp = a.tab[prev >> 32];
+                const uint32_t pp = static_cast<uint32_t>(prev);
+                // the row may have been recycled for a smaller allocation since the slot was filled
+                if (tp.entries && pp < tp.layout.alloc_pages && tp.d_slot[pp] == slot)    // still pointing here: the page leaves L2
+                    atomicAnd(&tp.d_flags[pp], ~2u);
+            }
+            a.ring_owner[slot] = me;
+            t.d_slot[pg] = slot;
+            t.h_slot[pg] = res->seq + rank;      // the page's only host-visible word (Engine::l2_live)
+            atomicOr(&t.d_flags[pg], 2u);
+        }
     }
 }
 

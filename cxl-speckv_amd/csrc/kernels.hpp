@@ -148,12 +148,15 @@ struct FlushArgs {
     uint32_t        epoch;        // 1..255, stamps of older epochs are ignored
     uint32_t*       cand;         // [n*32*W]
     uint32_t*       wave_tot;     // [n*W/2 rounded up] + same again for the bases
-    uint32_t*       final_page;   // [max_take]
-    uint32_t*       final_row;    // [max_take]
+    // what the fetch launch reads, in list order (block i): the page's record descriptor and its ring slot's address
+    PageEntry*      final_entry;  // [max_take]
+    uint64_t*       final_dst;    // [max_take]
+    uint64_t*       ring_owner;   // L2 ring bookkeeping, done by the scatter kernel with one THREAD per page (see there)
+    uint8_t*        ring_base;
     uint32_t        max_take;     // never more than this many pages per flush
     uint32_t        n_l2;         // ring size
     uint32_t*       hand;         // device ring hand
-    FlushResult*    result_dev;   // read by the fetch launch (n_dev = &m, slot0_dev = &base)
+    FlushResult*    result_dev;   // m is read by the fetch launch (n_dev)
     FlushResult*    result_host;  // the same, stored to pinned host memory
 };
 hipError_t launch_flush_pipeline(const FlushArgs& a, hipStream_t s);
