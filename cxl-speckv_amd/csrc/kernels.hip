@@ -1100,12 +1100,15 @@ __global__ __launch_bounds__(256) void k_flush_candidates(FlushArgs a)
     }
 }
 
-// keep[i] = candidate i is the first occurrence of its page; WRITE = false: per-wave totals, true: ordered scatter
+// keep[i] = candidate i is the first occurrence of its page; WRITE = false: totals per workgroup (256 candidates: the
+// single-workgroup scan of k_flush_assign is 4x shorter than over per-wave totals), true: ordered scatter (rank = the
+// workgroup's base from k_flush_assign + the kept candidates before this one in it)
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_flush_mark(FlushArgs a, const FlushResult* __restrict__ res)
 {
+    __shared__ uint32_t wcount[4];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t total = a.n * 32u * a.W;
     bool keep = false;
     uint32_t pg = kNoSlot, row = kNoSlot;
@@ -1117,12 +1120,15 @@ __global__ __launch_bounds__(256) void k_flush_mark(FlushArgs a, const FlushResu
         }
     }
     const unsigned long long mask = __ballot(keep);
-    const uint32_t w = i >> 6;
+    if (lane == 0u) wcount[wave] = static_cast<uint32_t>(__popcll(mask));
+    __syncthreads();
     if (!WRITE) {
-        if (lane == 0u && i < total) a.wave_tot[w] = static_cast<uint32_t>(__popcll(mask));
+        if (threadIdx.x == 0u) a.wave_tot[blockIdx.x] = wcount[0] + wcount[1] + wcount[2] + wcount[3];
     } else if (keep) {
-        const uint32_t n_w = (total + 63u) >> 6;
-        const uint32_t rank = a.wave_tot[n_w + w] + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; ++w) before += wcount[w];
+        const uint32_t n_b = (total + 255u) >> 8;
+        const uint32_t rank = a.wave_tot[n_b + blockIdx.x] + before + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
         if (rank < res->m) {
             // Entry `rank` of the flush lands in ring slot base + rank.  Everything about it that is pointer chasing --
             // its record descriptor, the slot's previous owner and that owner's residency words, the new owner, the
@@ -1160,7 +1166,7 @@ __global__ __launch_bounds__(1024) void k_flush_assign(FlushArgs a)
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t running;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t n_w = (a.n * 32u * a.W + 63u) >> 6;
+    const uint32_t n_w = (a.n * 32u * a.W + 255u) >> 8;       // totals per workgroup of k_flush_mark
     if (threadIdx.x == 0) running = 0;
     __syncthreads();
     for (uint32_t i0 = 0; i0 < n_w; i0 += 1024u) {
