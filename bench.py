@@ -865,6 +865,52 @@ def batch_attention_extra(torch, kv, n_seq=256, T=8192):
         lib.set_compression_scheme(2)
 
 
+def connector_append_extra(torch, kv, n_seq=256, Lyr=80, T=64):
+    """SURVEY 8f row N2 at the BASELINE configs[3] batch: one decode step's append for 256 sequences x 80 layers through
+    the vLLM-shaped connector.  Every other step completes a position pair per sequence: 160 pages per sequence, ONE
+    compress launch for the batch (speckv_ext_write_strided_batch); the other steps only park the rows in the tail."""
+    from cxl_speckv_amd.kv_connector import SpeckvKVConnector
+    conn = None
+    try:
+        conn = SpeckvKVConnector(kv.lib, num_layers=Lyr, max_tokens=T, scheme="fp8")
+        ids = list(range(n_seq))
+        for r in ids:
+            conn.add_request(r)
+        g = torch.Generator(device="cuda"); g.manual_seed(2005)
+        k = torch.randn((n_seq, Lyr, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+        v = torch.randn((n_seq, Lyr, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            t_pair, t_tail, dev_pair = [], [], []
+            for step in range(12):
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter()
+                a.record(s)
+                keep = conn.append(ids, k, v, stream=s)
+                b.record(s)
+                host = (time.perf_counter() - t0) * 1e3
+                torch.cuda.synchronize()
+                if step >= 2:
+                    (t_pair if step % 2 else t_tail).append(host)
+                    if step % 2: dev_pair.append(a.elapsed_time(b))
+                del keep
+        pages = n_seq * 2 * Lyr
+        return {"connector_append_step": {"sequences": n_seq, "layers": Lyr, "pages_per_pair_step": pages,
+                                          "host_ms_pair_step": round(min(t_pair), 3), "host_ms_tail_step": round(min(t_tail), 3),
+                                          "device_ms_pair_step": round(min(dev_pair), 3),
+                                          "note": "append of one decode step for the whole batch: gather + one speckv_ext_write_strided_batch launch "
+                                                  "(fp8 pool); device time includes the torch gathers that build the page images"}}
+    except Exception as e:
+        return {"connector_append_step": {"error": repr(e)}}
+    finally:
+        if conn is not None:
+            for r in list(conn.requests):
+                try: conn.free_request(r)
+                except Exception: pass
+        kv.lib.set_compression_scheme(2)
+
+
 def footprint_extra(torch, kv, T, Lyr, seed, seconds=0.4):
     """The hot path at another footprint: one sequence of T positions x Lyr layers (8 kv heads x 128), INT8_DELTA_RLE,
     reference quantiser, one launch per pass, timed over >= `seconds` of back-to-back passes after a clock ramp."""
@@ -1067,6 +1113,7 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     ex.update(fp8_scores_extra(torch, kv, 32768, 80))
     ex.update(int4_attention_extra(torch, kv, 32768, 80))
     ex.update(batch_attention_extra(torch, kv))      # BASELINE configs[4] shape: 70B-shaped KV @ 32k context
+    ex.update(connector_append_extra(torch, kv))
     ex.update(predictor_extra(torch, lib))
     return ex
 

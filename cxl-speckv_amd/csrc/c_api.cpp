@@ -140,6 +140,14 @@ speckv_status_t speckv_ext_write_strided(speckv_handle_t handle, uint64_t first_
     return guarded([&] { return g_engine->write_strided(handle, first_page, page_step, n_pages, d_src, static_cast<hipStream_t>(stream)); });
 }
 
+speckv_status_t speckv_ext_write_strided_batch(const speckv_handle_t* handles, const uint64_t* first_pages, const void* const* d_srcs,
+                                               uint32_t n_allocations, uint64_t page_step, uint64_t n_pages_each, void* stream)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->write_strided_batch(handles, first_pages, d_srcs, n_allocations, page_step, n_pages_each,
+                                                              static_cast<hipStream_t>(stream)); });
+}
+
 speckv_status_t speckv_ext_read(speckv_handle_t handle, uint64_t offset_bytes, void* dst, size_t len, int dst_on_device)
 {
     LOCK; NEED_INIT;

@@ -251,6 +251,9 @@ Engine::~Engine()
     if (d_zero_page_) (void)hipFree(d_zero_page_);
     if (seq_ring_.base) (void)hipHostFree(seq_ring_.base);
     for (auto ev : seq_ring_.ev) if (ev) (void)hipEventDestroy(ev);
+    if (grp_ring_.base) (void)hipHostFree(grp_ring_.base);
+    for (auto ev : grp_ring_.ev) if (ev) (void)hipEventDestroy(ev);
+    if (d_groups_) (void)hipFree(d_groups_);
     if (req_stage_) (void)hipHostFree(req_stage_);
     for (auto ev : req_stage_ev_) if (ev) (void)hipEventDestroy(ev);
     if (res_ring_) (void)hipHostFree(res_ring_);
@@ -1608,6 +1611,85 @@ int Engine::write_strided(uint64_t handle, uint64_t first, uint64_t step, uint64
     st_.total_compressions += n;
     st_.original_bytes += n * kPageSize;
     if (!s) RC_TRY(wait_stream());
+    return SPECKV_OK;
+}
+
+// write_strided for a batch of allocations in one launch (the append of a decode step: SURVEY 8f row N2).  Host side as
+// in write_strided per allocation (cached pages are invalidated first); the kernel takes one descriptor per allocation.
+int Engine::write_strided_batch(const uint64_t* handles, const uint64_t* firsts, const void* const* d_srcs, uint32_t n_alloc,
+                                uint64_t step, uint64_t n_each, hipStream_t s)
+{
+    if (null_) return no_data_path("speckv_ext_write_strided_batch");
+    if (!handles || !firsts || !d_srcs || step == 0 || !s) return SPECKV_ERR_INVAL;
+    if (n_alloc == 0 || n_each == 0) return SPECKV_OK;
+    std::vector<Allocation*> as(n_alloc);
+    bool cached = false;
+    for (uint32_t i = 0; i < n_alloc; ++i) {
+        Allocation* a = find(handles[i]);
+        if (!a) return SPECKV_ERR_GENERAL;
+        if (!d_srcs[i]) return SPECKV_ERR_INVAL;
+        if (a->scheme != find(handles[0])->scheme) return SPECKV_ERR_INVAL;
+        if (firsts[i] >= a->n_pages || (n_each - 1) > (a->n_pages - 1 - firsts[i]) / step) return SPECKV_ERR_GENERAL;
+        if (a->size_bytes % kPageSize && firsts[i] + (n_each - 1) * step == a->n_pages - 1) return SPECKV_ERR_INVAL;
+        for (uint32_t k = 0; k < i; ++k) if (as[k] == a) return SPECKV_ERR_INVAL;       // one descriptor per allocation
+        as[i] = a;
+        for (uint64_t j = 0; j < n_each && !cached; ++j) cached = (res_flags(a, firsts[i] + j * step) & 3u) != 0;
+    }
+    DeviceScope device_scope(device_);
+    if (cached || !flights_.empty() || ring_busy_ > 0) {
+        RC_TRY(quiesce());
+        for (uint32_t i = 0; i < n_alloc; ++i) {
+            if ((as[i] = find(handles[i])) == nullptr) return SPECKV_ERR_GENERAL;
+            for (uint64_t j = 0; j < n_each; ++j) drop_page(as[i], static_cast<uint32_t>(firsts[i] + j * step));
+        }
+        RC_TRY(flush_mirror());
+        RC_TRY(wait_stream());
+    }
+    // descriptors: pinned slot -> device slot (4 of each in rotation, guarded by an event on the caller's stream)
+    const size_t bytes = static_cast<size_t>(n_alloc) * sizeof(CompressGroup);
+    if (grp_ring_.slot_bytes < bytes) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (grp_ring_.base) { (void)hipHostFree(grp_ring_.base); grp_ring_.base = nullptr; }
+        if (d_groups_) { (void)hipFree(d_groups_); d_groups_ = nullptr; }
+        grp_ring_.slot_bytes = std::max<size_t>(bytes * 2, 16384);
+        HIP_TRY(hipHostMalloc(&grp_ring_.base, grp_ring_.slot_bytes * 4, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_groups_), grp_ring_.slot_bytes * 4));
+        for (auto& ev : grp_ring_.ev)
+            if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const int slot = grp_ring_.next;
+    grp_ring_.next = (slot + 1) & 3;
+    RC_TRY(wait_event(grp_ring_.ev[slot]));                   // may release the ABI lock
+    for (uint32_t i = 0; i < n_alloc; ++i)
+        if ((as[i] = find(handles[i])) == nullptr) return SPECKV_ERR_GENERAL;
+    CompressGroup* staged = reinterpret_cast<CompressGroup*>(static_cast<uint8_t*>(grp_ring_.base) + static_cast<size_t>(slot) * grp_ring_.slot_bytes);
+    CompressGroup* d_slot = reinterpret_cast<CompressGroup*>(reinterpret_cast<uint8_t*>(d_groups_) + static_cast<size_t>(slot) * grp_ring_.slot_bytes);
+    for (uint32_t i = 0; i < n_alloc; ++i) {
+        const Allocation* a = as[i];
+        staged[i] = CompressGroup{a->d_entries, a->d_scale_tab, a->d_int4_big, a->region_pages, 0u, firsts[i],
+                                  static_cast<const uint8_t*>(d_srcs[i])};
+    }
+    HIP_TRY(hipMemcpyAsync(d_slot, staged, bytes, hipMemcpyHostToDevice, s));
+    CodecArgs c{};
+    c.groups = d_slot;
+    c.group_n = n_each;
+    c.page_step = step;
+    c.data_stride = kPageSize;
+    c.scheme = as[0]->scheme;
+    c.quant_mode = quant_mode_;
+    c.n = static_cast<uint64_t>(n_alloc) * n_each;
+    HIP_TRY(launch_compress(c, s));
+    HIP_TRY(hipEventRecord(grp_ring_.ev[slot], s));
+    for (uint32_t i = 0; i < n_alloc; ++i) {
+        Allocation* a = as[i];
+        note_use(a, s);
+        for (uint64_t j = 0; j < n_each; ++j) {
+            uint32_t& f = a->flags[firsts[i] + j * step];
+            if (a->scheme != SPECKV_COMP_FP16) f |= 4u; else f &= ~4u;
+        }
+    }
+    st_.total_compressions += c.n;
+    st_.original_bytes += c.n * kPageSize;
     return SPECKV_OK;
 }
 

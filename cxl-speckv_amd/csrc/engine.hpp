@@ -116,6 +116,8 @@ public:
     int bind_request(uint32_t req, uint64_t handle, uint32_t local_req);
     int write(uint64_t handle, uint64_t off, const void* src, size_t len, bool on_device);
     int write_strided(uint64_t handle, uint64_t first, uint64_t step, uint64_t n, const void* d_src, hipStream_t s);
+    int write_strided_batch(const uint64_t* handles, const uint64_t* firsts, const void* const* d_srcs, uint32_t n_alloc, uint64_t step,
+                            uint64_t n_each, hipStream_t s);
     int read(uint64_t handle, uint64_t off, void* dst, size_t len, bool on_device);
     int fetch_range(uint64_t handle, uint64_t first, uint64_t n, void* d_dst, bool f32, hipStream_t s, int engine_choice);
     int fetch_list(uint64_t handle, const uint32_t* d_pages, uint32_t n, void* d_dst, bool f32, hipStream_t s);
@@ -267,7 +269,8 @@ private:
     Scratch s_hid_, s_logits_, s_hist_, s_pred_;
     Scratch s_attn_, s_attn_seq_;
     // pinned staging for the batch descriptors: 4 slots in rotation, each guarded by an event (no stream sync per call)
-    struct PinnedRing { void* base = nullptr; size_t slot_bytes = 0; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; int next = 0; } seq_ring_;
+    struct PinnedRing { void* base = nullptr; size_t slot_bytes = 0; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; int next = 0; } seq_ring_, grp_ring_;
+    CompressGroup* d_groups_ = nullptr;    // device twin of grp_ring_ (4 slots): descriptors of a grouped compress launch
     uint8_t* d_zero_page_ = nullptr;     // stands in for never-written pages in the fused attention
     std::unordered_map<uint32_t, std::vector<int32_t>> hist_;
     std::unordered_map<uint32_t, std::vector<int32_t>> pred_;

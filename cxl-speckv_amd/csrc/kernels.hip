@@ -788,11 +788,22 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
     const uint64_t i0 = a.wave_step ? gw : gw * per_wave;
     const uint64_t i1 = a.wave_step ? n : ((i0 + per_wave < n) ? i0 + per_wave : n);
     for (uint64_t i = i0; i < i1; i += step) {
-        const uint64_t page = a.page_list ? a.page_list[i] : a.first + i * (a.page_step ? a.page_step : 1);
+        uint64_t page = a.page_list ? a.page_list[i] : a.first + i * (a.page_step ? a.page_step : 1);
         const uint8_t* src = a.data_list ? reinterpret_cast<const uint8_t*>(a.data_list[i])
                                          : a.data + i * a.data_stride;
-        uint8_t* rec = a.entries ? reinterpret_cast<uint8_t*>(a.entries[page].pool_addr)
-                                 : a.recs + page * a.rec_stride;
+        PageEntry* entries = a.entries;
+        float* scale_tab = a.scale_tab;
+        uint32_t* big_flag = a.big_flag;
+        uint32_t region_pages = a.region_pages;
+        if (a.groups) {                                              // wave-uniform: this block's allocation
+            const uint64_t gi = i / a.group_n, j = i - gi * a.group_n;
+            const CompressGroup g = a.groups[gi];
+            entries = g.entries; scale_tab = g.scale_tab; big_flag = g.big_flag; region_pages = g.region_pages;
+            page = g.first + j * (a.page_step ? a.page_step : 1);
+            src = g.data + j * a.data_stride;
+        }
+        uint8_t* rec = entries ? reinterpret_cast<uint8_t*>(entries[page].pool_addr)
+                               : a.recs + page * a.rec_stride;
         uint32_t out_len;
         float scale = 1.0f;
 
@@ -856,7 +867,7 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                     *reinterpret_cast<uint16_t*>(rec + 2u * (p0 >> 5)) = __builtin_bit_cast(uint16_t, s16);
             }
             out_len = kInt4RecBytes;
-            if (a.big_flag && __builtin_amdgcn_ballot_w64(big_scale) != 0ull && lane == 0) atomicOr(a.big_flag, 1u);
+            if (big_flag && __builtin_amdgcn_ballot_w64(big_scale) != 0ull && lane == 0) atomicOr(big_flag, 1u);
         } else if (SCHEME == kFp8E4m3) {
             float x[4][8];
             float mx = 0.0f, nanacc = 0.0f;
@@ -953,12 +964,12 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
             }
         }
         if (lane == 0u) {
-            if (a.entries) {
-                a.entries[page].rec_bytes = out_len;
-                a.entries[page].scale = scale;
-                if (a.scale_tab) {
-                    const uint32_t j = static_cast<uint32_t>(page % a.region_pages) & 15u;
-                    a.scale_tab[page - j + attend_tile_slot(j)] = scale;
+            if (entries) {
+                entries[page].rec_bytes = out_len;
+                entries[page].scale = scale;
+                if (scale_tab) {
+                    const uint32_t j = static_cast<uint32_t>(page % region_pages) & 15u;
+                    scale_tab[page - j + attend_tile_slot(j)] = scale;
                 }
             } else {
                 a.rec_bytes[page] = out_len;

@@ -48,6 +48,18 @@ struct DevAlloc {
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr uint64_t kNoOwner = ~0ull;
 
+// One allocation's share of a grouped compress launch (CodecArgs::groups): pages first + j*page_step, j < group_n, from
+// data + j*data_stride.
+struct CompressGroup {
+    PageEntry*     entries;
+    float*         scale_tab;
+    uint32_t*      big_flag;
+    uint32_t       region_pages;
+    uint32_t       pad;
+    uint64_t       first;
+    const uint8_t* data;
+};
+
 // Source / destination description of one codec launch.  Exactly one of
 // {entries, recs, tab+alloc_list} is used as the record source.
 struct CodecArgs {
@@ -87,6 +99,10 @@ struct CodecArgs {
     // compress only, INT4_G32: set to 1 (atomically, never cleared) when a group scale beyond 8188 or a non-finite one is
     // stored -- the fused attention then takes its checked path for this allocation (attend_int4.hip, scale_is_big)
     uint32_t*       big_flag;
+    // compress only: blocks of several allocations in one launch -- block i belongs to groups[i / group_n] (device array)
+    // as its page i % group_n; entries / scale_tab / region_pages / big_flag / first / data above are then unused
+    const CompressGroup* groups;
+    uint64_t        group_n;
     // blocks of several allocations in one launch (decompress only): block i belongs to row alloc_list[i] of tab
     const DevAlloc* tab;
     const uint32_t* alloc_list;

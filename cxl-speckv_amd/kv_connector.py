@@ -119,26 +119,44 @@ class SpeckvKVConnector:
 
     def append(self, req_ids: Sequence[int], k_new, v_new, stream=None):
         """One decode step: k_new, v_new [batch][layers][heads][dim] fp16.  A position that completes a pair is written
-        together with its partner (2 * layers pages per request, one asynchronous call); an odd one waits in the tail."""
+        together with its partner -- 2 * layers pages per request, ONE asynchronous launch for the whole batch
+        (speckv_ext_write_strided_batch); an odd one waits in the tail.  A handful of torch kernels per call, whatever
+        the batch size: the tails of a step are kept as views of one gathered tensor."""
         import torch
-        keep, todo = [], []
+        pair_b, tail_b = [], []
         for b, rid in enumerate(req_ids):
             r = self.requests[rid]
             if r.length >= self.T:
                 raise ValueError(f"request {rid} is full")
-            if r.length % 2 == 0:
-                r.tail_k, r.tail_v = k_new[b].contiguous().clone(), v_new[b].contiguous().clone()
-            else:
-                # page image of the pair for every (layer, kind): [layer][kind][2 positions][heads][dim]
-                pair = torch.stack((torch.stack((r.tail_k, k_new[b]), dim=1), torch.stack((r.tail_v, v_new[b]), dim=1)), dim=1).contiguous()
-                todo.append((r.handle, self._page(0, 0, r.length - 1), pair))
-                keep.append(pair)
-                r.tail_k = r.tail_v = None
-            r.length += 1
-        if todo:
+            (pair_b if r.length % 2 else tail_b).append(b)
+        keep = []
+        if pair_b:
+            reqs = [self.requests[req_ids[b]] for b in pair_b]
+            idx = torch.tensor(pair_b, device=k_new.device)
+            kt = torch.stack([r.tail_k for r in reqs]); vt = torch.stack([r.tail_v for r in reqs])        # [n][layers][heads][dim]
+            kn = k_new.index_select(0, idx); vn = v_new.index_select(0, idx)
+            # page image of the pair for every (layer, kind): [n][layer][kind][2 positions][heads][dim]
+            pair = torch.stack((torch.stack((kt, kn), dim=2), torch.stack((vt, vn), dim=2)), dim=2).contiguous()
+            keep.append(pair)
+            step_bytes = pair[0].numel() * 2
             with self._On(self, stream) as st:
-                for handle, first, pair in todo:
-                    self.lib.write_strided(handle, first, self.region_pages, 2 * self.L, pair.data_ptr(), st.cuda_stream)
+                if len(reqs) == 1:
+                    self.lib.write_strided(reqs[0].handle, self._page(0, 0, reqs[0].length - 1), self.region_pages, 2 * self.L,
+                                           pair.data_ptr(), st.cuda_stream)
+                else:
+                    self.lib.write_strided_batch([r.handle for r in reqs], [self._page(0, 0, r.length - 1) for r in reqs],
+                                                 [pair.data_ptr() + i * step_bytes for i in range(len(reqs))],
+                                                 self.region_pages, 2 * self.L, st.cuda_stream)
+            for r in reqs:
+                r.tail_k = r.tail_v = None
+        if tail_b:
+            idx = torch.tensor(tail_b, device=k_new.device)
+            tk = k_new.index_select(0, idx); tv = v_new.index_select(0, idx)                               # copies: the caller may reuse k_new
+            for i, b in enumerate(tail_b):
+                r = self.requests[req_ids[b]]
+                r.tail_k, r.tail_v = tk[i], tv[i]
+        for rid in req_ids:
+            self.requests[rid].length += 1
         return keep                                            # sources of the asynchronous writes: hold until the stream passed them
 
     # ------------------------------------------------------------------ reads

@@ -54,6 +54,7 @@ _EXT_SIGNATURES = {
     "speckv_ext_write": [c_uint64, c_uint64, c_void_p, c_size_t, c_int],
     "speckv_ext_read": [c_uint64, c_uint64, c_void_p, c_size_t, c_int],
     "speckv_ext_write_strided": [c_uint64, c_uint64, c_uint64, c_uint64, c_void_p, c_void_p],
+    "speckv_ext_write_strided_batch": [c_void_p, c_void_p, c_void_p, c_uint32, c_uint64, c_uint64, c_void_p],
     "speckv_ext_fetch_range": [c_uint64, c_uint64, c_uint64, c_void_p, c_int, c_void_p],
     "speckv_ext_fetch_range_engine": [c_uint64, c_uint64, c_uint64, c_void_p, c_int, c_void_p, c_int],
     "speckv_ext_bind_request": [c_uint32, c_uint64, c_uint32],
@@ -208,6 +209,14 @@ class SpeckvLib:
 
     def write_strided(self, handle, first_page, page_step, n_pages, d_src, stream=None):
         self._ext("speckv_ext_write_strided", handle, first_page, page_step, n_pages, c_void_p(d_src), c_void_p(stream or 0))
+
+    def write_strided_batch(self, handles, first_pages, d_srcs, page_step, n_pages_each, stream):
+        """One launch for a batch of allocations: handles[i] gets pages first_pages[i] + j*page_step from d_srcs[i] + j*4096."""
+        n = len(handles)
+        hs = (c_uint64 * n)(*handles)
+        fs = (c_uint64 * n)(*first_pages)
+        ps = (c_void_p * n)(*d_srcs)
+        self._ext("speckv_ext_write_strided_batch", hs, fs, ps, n, page_step, n_pages_each, c_void_p(stream))
 
     def read(self, handle, offset, dst_ptr, nbytes, on_device):
         self._ext("speckv_ext_read", handle, offset, c_void_p(dst_ptr), nbytes, int(on_device))

@@ -89,6 +89,12 @@ speckv_status_t speckv_ext_write(speckv_handle_t handle, uint64_t offset_bytes,
  * invalidated first (that case waits for the engine). */
 speckv_status_t speckv_ext_write_strided(speckv_handle_t handle, uint64_t first_page, uint64_t page_step,
                                          uint64_t n_pages, const void* d_src, void* stream);
+/* The same for a batch of sequences in ONE launch: allocation handles[i] gets pages first_pages[i] + j * page_step
+ * (j < n_pages_each) from d_srcs[i] + j * 4096.  All allocations must use the same compression scheme and the stream
+ * must not be NULL.  (A decode step of 256 sequences appends with one call instead of 256 launches.) */
+speckv_status_t speckv_ext_write_strided_batch(const speckv_handle_t* handles, const uint64_t* first_pages,
+                                               const void* const* d_srcs, uint32_t n_allocations, uint64_t page_step,
+                                               uint64_t n_pages_each, void* stream);
 /* Fetch + decompress straight into a caller buffer, bypassing the tiers. */
 speckv_status_t speckv_ext_read(speckv_handle_t handle, uint64_t offset_bytes,
                                 void* dst, size_t len, int dst_on_device);

@@ -561,3 +561,61 @@ def test_int4_attention_with_group_scales_near_the_fp16_limit(oracle):
         lib.free(h_big); lib.free(h_plain)
     finally:
         lib.finalize()
+
+
+@pytest.mark.parametrize("scheme", [2, 3, 4])
+def test_write_strided_batch_equals_per_allocation_writes(scheme):
+    """speckv_ext_write_strided_batch (one launch for a batch of allocations: the append of a decode step) stores exactly
+    what one speckv_ext_write_strided per allocation stores: record lengths, scales and decoded pages are identical; a page
+    that was cached is invalidated; bad batches are refused."""
+    torch = torch_mod()
+    lib = open_lib()
+    try:
+        lib.set_compression_scheme(scheme)
+        T, L, H, D, bpe = 64, 3, 8, 128, 2
+        n_pages = 2 * T * L * H * D * bpe // PAGE
+        region = T // 2
+        n_alloc, n_each = 5, 2 * L
+        st = torch.cuda.Stream()
+        rng = np.random.default_rng(123 + scheme)
+        batch, single = [], []
+        for _ in range(n_alloc):
+            for lst in (batch, single):
+                h = lib.alloc(n_pages * PAGE); lib.set_layout(h, T, L, H, D, bpe); lst.append(h)
+        firsts = [int(v) for v in rng.integers(0, region, n_alloc)]
+        src = torch.from_numpy((rng.standard_normal((n_alloc, n_each, N)) * 3).astype(np.float16).view(np.int16)).cuda()
+        # one of the target pages is resident before the write: the batch write has to invalidate it
+        lib.access(batch[1], firsts[1] * PAGE, 8)
+        assert lib.translate(batch[1], firsts[1] * PAGE).flags & 3
+        torch.cuda.synchronize()
+        lib.write_strided_batch(batch, firsts, [src[i].data_ptr() for i in range(n_alloc)], region, n_each, st.cuda_stream)
+        for i in range(n_alloc):
+            lib.write_strided(single[i], firsts[i], region, n_each, src[i].data_ptr(), st.cuda_stream)
+        st.synchronize()
+        assert not (lib.translate(batch[1], firsts[1] * PAGE).flags & 3)
+        got = torch.empty((n_pages, N), dtype=torch.float16, device="cuda")
+        want = torch.empty((n_pages, N), dtype=torch.float16, device="cuda")
+        for i in range(n_alloc):
+            lib.fetch_range(batch[i], 0, n_pages, got.data_ptr(), False, st.cuda_stream)
+            lib.fetch_range(single[i], 0, n_pages, want.data_ptr(), False, st.cuda_stream)
+            st.synchronize()
+            assert torch.equal(got.view(torch.int16), want.view(torch.int16)), i
+            for j in range(n_each):
+                a, b = lib.translate(batch[i], (firsts[i] + j * region) * PAGE), lib.translate(single[i], (firsts[i] + j * region) * PAGE)
+                assert (a.rec_bytes, np.float32(a.scale).tobytes()) == (b.rec_bytes, np.float32(b.scale).tobytes())
+                assert a.rec_bytes > 0
+        ptrs = [src[i].data_ptr() for i in range(n_alloc)]
+        with pytest.raises(SpeckvError):
+            lib.write_strided_batch(batch, firsts, ptrs, region, n_each, 0)                      # NULL stream
+        with pytest.raises(SpeckvError):
+            lib.write_strided_batch(batch[:2] + batch[:1], firsts[:3], ptrs[:3], region, n_each, st.cuda_stream)   # same allocation twice
+        with pytest.raises(SpeckvError):
+            lib.write_strided_batch(batch[:2], [region * 2 * L - 1, 0], ptrs[:2], region, n_each, st.cuda_stream)  # runs off the end
+        lib.set_compression_scheme(1)
+        other = lib.alloc(n_pages * PAGE)
+        with pytest.raises(SpeckvError):
+            lib.write_strided_batch(batch[:1] + [other], firsts[:2], ptrs[:2], region, n_each, st.cuda_stream)     # mixed schemes
+        for h in batch + single + [other]:
+            lib.free(h)
+    finally:
+        lib.finalize()
