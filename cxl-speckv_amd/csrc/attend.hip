@@ -516,6 +516,244 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// ---- linear form, LDS-DMA pipeline ------------------------------------------------------------------------------------
+// Same arithmetic as k_attend_fp8_linear; the tile travels global -> LDS without passing through registers
+// (global_load_lds_dwordx4, 1 KiB per wave instruction), two tiles deep per wave.  PMC on the register-staged kernel:
+// texture addresser 80 % busy at 0.70 of HBM peak with 14 load instructions per tile and wave (V as 8-byte pieces), waves
+// waiting 83 % of their cycles, VALU 23 % busy.  A head's row of one position is exactly one 128-byte line, so a wave
+// fetches whole lines by itself: per tile 4 DMA instructions for K (8 rows each), 4 for V, 1 for the 32 page scales.
+//   per wave two buffers of  [K 32 rows x 128 B | V 32 rows x 128 B | 16 K scales, 16 V scales]
+//   iteration t:  K(t) landed -> K operand + scales to registers -> issue K(t+2) -> scores, softmax
+//                 V(t) landed -> V pieces to registers           -> issue V(t+2) -> PV
+// The destination of an LDS-DMA is lane-linear, the source per lane: row r is stored in row slot r ^ ((r >> 2) & 1) with
+// its eight 16-byte pieces XOR-ed by (r >> 1) & 7 -- chosen on the source side -- which makes the K reads (ds_read_b128,
+// lane (c, kb): pieces kb and 4 + kb of row c) and the V reads (ds_read_b64, rows 4 kb + j, bytes 8c..8c+7) conflict-free
+// under the bank rules of MI355X_MICROARCH.md.  All vector-memory and LDS traffic of the loop is inline assembly with
+// explicit counters (the tail re-requests the last tile, so the counts are the same in every iteration).
+namespace {
+constexpr uint32_t kFdBuf = 8320u, kFdV = 4096u, kFdS = 8192u;
+
+__device__ __forceinline__ void fd_dma16(uint32_t lds_dst, const uint8_t* base, uint32_t voff)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void fd_dma4(uint32_t lds_dst, const uint8_t* base, uint32_t voff)      // active lanes only
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(base) : "memory");
+}
+// all but the 13 youngest DMAs have landed (V of this tile: 4, the next tile: 9): K operand of both blocks + the scales
+__device__ __forceinline__ void fd_take_k(uint32_t rd0, uint32_t rd1, uint32_t rs, u32x4 (&k)[4], f32x4& ks, f32x4& vs)
+{
+    asm volatile("s_waitcnt vmcnt(13)\n\t"
+                 "ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %6 offset:2048\n\tds_read_b128 %3, %7 offset:2048\n\t"
+                 "ds_read_b128 %4, %8\n\tds_read_b128 %5, %8 offset:64\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(k[0]), "=&v"(k[1]), "=&v"(k[2]), "=&v"(k[3]), "=&v"(ks), "=&v"(vs) : "v"(rd0), "v"(rd1), "v"(rs) : "memory");
+}
+// V of this tile has landed (younger: the next tile 9, K + scales of the one after 5)
+typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fd_take_v(const uint32_t (&rd)[4], u32x2v (&v)[8])
+{
+    asm volatile("s_waitcnt vmcnt(14)\n\t"
+                 "ds_read_b64 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %10\n\tds_read_b64 %3, %11\n\t"
+                 "ds_read_b64 %4, %8 offset:2048\n\tds_read_b64 %5, %9 offset:2048\n\tds_read_b64 %6, %10 offset:2048\n\tds_read_b64 %7, %11 offset:2048\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(rd[0]), "v"(rd[1]), "v"(rd[2]), "v"(rd[3]) : "memory");
+}
+__device__ __forceinline__ uint32_t fd_row_slot(uint32_t r) { return r ^ ((r >> 2) & 1u); }
+__device__ __forceinline__ uint32_t fd_piece_xor(uint32_t r) { return (r >> 1) & 7u; }
+} // namespace
+
+#ifndef SPECKV_FP8_WG_HEADS
+#define SPECKV_FP8_WG_HEADS 4
+#endif
+constexpr uint32_t kFdHeads = SPECKV_FP8_WG_HEADS;          // kv heads (= waves) per workgroup
+__global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_attend_fp8_dma(AttendArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kFdHeads][2 * kFdBuf];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t c = lane & 15u, kb = lane >> 4;
+    const uint32_t split = blockIdx.x;
+    const uint32_t hq = a.heads / kFdHeads;
+    uint32_t layer = blockIdx.y / hq;                                    // batch form: the sequence index
+    const uint32_t head = (blockIdx.y % hq) * kFdHeads + wave;
+    const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;  // query / output row block
+    uint64_t part = row * a.n_splits + split;
+    if (a.seqs) {                                                        // wave-uniform: per-sequence geometry
+        const AttendSeq sq = a.seqs[layer];
+        if (split >= sq.n_splits) return;
+        a.lin_base = sq.lin_base;
+        a.scale_tab = sq.scale_tab;
+        a.k_first = sq.k_first;
+        a.v_first = sq.v_first;
+        a.n_pages = sq.n_pages;
+        part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
+        layer = 0;
+    }
+    uint32_t qd[8];
+    float qscale;
+    quantize_query_operand(a.q16 + (row * a.g + min(c, a.g - 1u)) * 128u + kb * 16u, c < a.g, qd, qscale);
+    qscale *= a.scale_log2e;
+
+    const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
+    const uint32_t t0 = split * a.tiles_per_split;
+    const uint32_t t1 = min(t0 + a.tiles_per_split, n_tiles);
+    float m_run = -INFINITY, l_run = 0.0f, vref = 1.0f;
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    if (t0 < t1) {                                                       // wave-uniform
+        // tile tt: rows at + tt * 32 KiB (32 positions x 1 KiB), scales at + tt * 16 floats
+        const uint8_t* kreg = a.lin_base + (a.k_first + layer * a.layer_stride) * 2048ull + head * 128u;
+        const uint8_t* vreg = a.lin_base + (a.v_first + layer * a.layer_stride) * 2048ull + head * 128u;
+        // scale_tab byte offset of the lane's page scale in tile 0: lanes 0..15 K pages, 16..31 V pages (tile tt: + 64 tt)
+        const uint32_t gsc = static_cast<uint32_t>(((lane < 16u ? a.k_first : a.v_first) + layer * a.layer_stride + (lane & 15u)) * 4u);
+        // DMA instruction i (0..3) fills row slots 8i .. 8i+7: lane l -> row slot 8i + l/8, piece slot l%8
+        uint32_t g[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            const uint32_t r = fd_row_slot(8u * i + (lane >> 3));        // the row that lives in this row slot (involution)
+            g[i] = r * 1024u + (((lane & 7u) ^ fd_piece_xor(r)) * 16u);
+        }
+        const uint32_t lbase = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&lds[wave][0])));
+        const uint32_t last = t1 - 1u;
+        auto issue_k = [&](uint32_t tt, uint32_t buf) {
+            const uint32_t tc = min(tt, last);
+            const uint8_t* src = kreg + static_cast<uint64_t>(tc) * 32768u;
+            const uint32_t dst = lbase + buf * kFdBuf;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) fd_dma16(dst + 1024u * i, src, g[i]);
+            // one instruction for the 32 page scales of the tile: lanes 0..15 from the K table, 16..31 from the V table
+            if (lane < 32u)
+                fd_dma4(dst + kFdS, reinterpret_cast<const uint8_t*>(a.scale_tab), gsc + tc * 64u);
+        };
+        auto issue_v = [&](uint32_t tt, uint32_t buf) {
+            const uint8_t* src = vreg + static_cast<uint64_t>(min(tt, last)) * 32768u;
+            const uint32_t dst = lbase + buf * kFdBuf + kFdV;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) fd_dma16(dst + 1024u * i, src, g[i]);
+        };
+        // reader addresses inside buffer 0
+        const uint32_t kslot = fd_row_slot(c), kx_ = fd_piece_xor(c);
+        const uint32_t rdk0 = lbase + kslot * 128u + ((kb ^ kx_) * 16u);
+        const uint32_t rdk1 = lbase + kslot * 128u + (((4u + kb) ^ kx_) * 16u);
+        const uint32_t rsc = lbase + kFdS + kb * 16u;
+        uint32_t rdv[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t r = 4u * kb + j;
+            rdv[j] = lbase + kFdV + fd_row_slot(r) * 128u + (((c >> 1) ^ fd_piece_xor(r)) * 16u) + (c & 1u) * 8u;
+        }
+        // the query operand must be complete before the first DMA (the compiler would otherwise drain the DMAs with its
+        // own vmcnt(0) at the first use inside the loop)
+        asm volatile("" :: "v"(qd[0]), "v"(qd[1]), "v"(qd[2]), "v"(qd[3]), "v"(qd[4]), "v"(qd[5]), "v"(qd[6]), "v"(qd[7]), "v"(qscale));
+        issue_k(t0, 0u);
+        issue_v(t0, 0u);
+        issue_k(t0 + 1u, 1u);
+        issue_v(t0 + 1u, 1u);
+        const bool ragged = (a.n_pages & 15u) != 0u;
+#pragma unroll 1
+        for (uint32_t tile = t0; tile < t1; ++tile) {
+            const uint32_t buf = (tile - t0) & 1u;
+            const uint32_t bo = buf * kFdBuf;
+            u32x4 kx[4];
+            f32x4 ks4, vs4;
+            fd_take_k(rdk0 + bo, rdk1 + bo, rsc + bo, kx, ks4, vs4);
+            issue_k(tile + 2u, buf);
+            // ---- scores
+            float sc[8];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const uint32_t kd[8] = {kx[2 * b].x, kx[2 * b].y, kx[2 * b].z, kx[2 * b].w, kx[2 * b + 1].x, kx[2 * b + 1].y, kx[2 * b + 1].z, kx[2 * b + 1].w};
+                f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(kd[2 * st], kd[2 * st + 1]), pack64(qd[2 * st], qd[2 * st + 1]), s, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sc[4 * b + i] = s[i] * (ks4[2 * b + (i >> 1)] * qscale);
+            }
+            if (ragged && tile + 1u == n_tiles) {                         // wave-uniform: positions beyond the range
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t pg = tile * 16u + ((j >> 1) < 2 ? 2u * kb + (j >> 1) : 8u + 2u * kb + ((j >> 1) - 2));
+                    if (pg >= a.n_pages) sc[j] = -INFINITY;
+                }
+            }
+            // ---- online softmax of query row c
+            float mx = sc[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc[j]);
+            mx = max_over_kb(mx);
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;
+            const float f = __builtin_amdgcn_exp2f(m_run - m_use);
+            m_run = m_new;
+            const float vmx = max_over_kb(fmaxf(fmaxf(vs4[0], vs4[1]), fmaxf(vs4[2], vs4[3])));
+            const float vref_t = vmx > 0.0f ? vmx : vref;
+            const float rinv = __builtin_amdgcn_rcpf(vref_t);
+            float psum = 0.0f;
+            f16x8 P;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float p = __builtin_amdgcn_exp2f(sc[j] - m_use);
+                psum += p;
+                P[j] = static_cast<_Float16>(p * (vs4[j >> 1] * rinv));
+            }
+            l_run = l_run * f + psum;
+            const float fa = f * (vref * rinv);                            // acc: old max -> new max, old V reference -> new
+            vref = vref_t;
+            // ---- V pieces, then the next-but-one tile's V is requested into the buffer they came from
+            u32x2v vx[8];
+            const uint32_t rdvb[4] = {rdv[0] + bo, rdv[1] + bo, rdv[2] + bo, rdv[3] + bo};
+            fd_take_v(rdvb, vx);
+            issue_v(tile + 2u, buf);
+            // ---- out^T += V^T . P^T, accumulated in place
+            uint32_t w[4][4];                                             // [row pair][byte pair of the 8 d]
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                w[jp][0] = __builtin_amdgcn_perm(vx[2 * jp + 1].x, vx[2 * jp].x, 0x05010400u);
+                w[jp][1] = __builtin_amdgcn_perm(vx[2 * jp + 1].x, vx[2 * jp].x, 0x07030602u);
+                w[jp][2] = __builtin_amdgcn_perm(vx[2 * jp + 1].y, vx[2 * jp].y, 0x05010400u);
+                w[jp][3] = __builtin_amdgcn_perm(vx[2 * jp + 1].y, vx[2 * jp].y, 0x07030602u);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                f16x8 V;
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    const f16x2 h = (t & 1) ? __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w[jp][t >> 1], 1.0f, true)
+                                            : __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w[jp][t >> 1], 1.0f, false);
+                    V[2 * jp] = h.x;
+                    V[2 * jp + 1] = h.y;
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t] * fa, 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the re-requested tail tiles: nothing may land after the wave ends
+    }
+    // ---- partial result of this split, back in true units
+    const float l_tot = sum_over_kb(l_run);
+    if (kb == 0) {
+        a.part_ml[part * 32u + c] = m_run;
+        a.part_ml[part * 32u + 16u + c] = l_tot;
+    }
+    if (c < a.g) {
+        float* dst = a.part_acc + (part * 16u + c) * 128u + 32u * kb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(dst + 8 * i) = f32x4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]} * vref;
+            *reinterpret_cast<f32x4*>(dst + 8 * i + 4) = f32x4{acc[4][i], acc[5][i], acc[6][i], acc[7][i]} * vref;
+        }
+    }
+}
+
 // Merge of the split partials: one workgroup of 512 threads per (layer, head, query row).  The per-layer call of a
 // decode step has few rows and many splits, so the merge must not walk the splits serially (a 128-split merge with
 // one dependent load chain per thread took 52 us, 3.5x the attention kernel itself): every thread first takes its
@@ -691,7 +929,14 @@ hipError_t launch_attend_combine(const AttendArgs& a, uint32_t n_layers, float* 
 hipError_t launch_attend_fp8_batch(const AttendArgs& a, uint32_t n_seq, float* d_out, float* d_lse, hipStream_t s)
 {
     if (n_seq == 0 || a.n_splits == 0) return hipSuccess;
+    // the batch form keeps the register-staged kernel: 256 sequences x 8k context, one layer: 0.69 of HBM peak against 0.67
+    // with the LDS-DMA kernel (many short splits: 4 waves/SIMD hide more than two tiles per wave at 2 waves/SIMD); the
+    // single-sequence form below is the other way round (8k x 80 layers: 0.61 against 0.55; 32k x 80: 0.70 both)
+#ifdef SPECKV_FP8_BATCH_DMA
+    hipLaunchKernelGGL(k_attend_fp8_dma, dim3(a.n_splits, n_seq * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
+#else
     hipLaunchKernelGGL(k_attend_fp8_linear, dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
+#endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_attend_combine(a, n_seq, d_out, d_lse, s);
@@ -708,7 +953,11 @@ hipError_t launch_build_scale_tab(const PageEntry* d_entries, uint64_t n_pages, 
 hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s)
 {
     if (a.n_pages == 0 || n_layers == 0) return hipSuccess;
+#ifdef SPECKV_FP8_REGSTAGE
     if (a.lin_base) hipLaunchKernelGGL(k_attend_fp8_linear, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
+#else
+    if (a.lin_base) hipLaunchKernelGGL(k_attend_fp8_dma, dim3(a.n_splits, n_layers * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
+#endif
     else            hipLaunchKernelGGL(k_attend_fp8, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
