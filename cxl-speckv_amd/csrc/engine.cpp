@@ -347,8 +347,7 @@ int Engine::publish_row(Allocation* a)
     r.stamp = a->d_stamp;
     void* dp = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&dp, a->pinned, 0));
-    r.h_flags = static_cast<uint32_t*>(dp);
-    r.h_slot = r.h_flags + a->n_pages;
+    r.h_slot = static_cast<uint32_t*>(dp);
     r.layout = a->has_layout ? a->layout : Layout{0, 0, 0, 0, 0, a->n_pages};
     // the copy reads its source when the stream gets to it: the source is the row's own slot in a pinned mirror
     h_tab_[a->row] = r;
@@ -366,8 +365,8 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
     a->scheme = scheme_;
     a->rec_stride = stride_for(scheme_);
     if (null_) {
-        a->null_flags.assign(a->n_pages, 0u);
-        a->flags = a->null_flags.data();
+        a->host_flags.assign(a->n_pages, 0u);
+        a->flags = a->host_flags.data();
     } else {
         a->access_count.assign(a->n_pages, 0u);
         if (a->n_pages) {
@@ -431,11 +430,11 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
                      hipMemsetAsync(a->d_slot, 0xFF, a->n_pages * sizeof(uint32_t), stream_) == hipSuccess &&
                      hipMemsetAsync(a->d_stamp, 0, (a->n_pages + 1) * sizeof(uint32_t), stream_) == hipSuccess;
             }
-            if (ok) ok = hipHostMalloc(&a->pinned, 2 * a->n_pages * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocPortable) == hipSuccess;
+            if (ok) ok = hipHostMalloc(&a->pinned, a->n_pages * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocPortable) == hipSuccess;
             if (ok) {
-                a->flags = static_cast<uint32_t*>(a->pinned);
-                a->slot = a->flags + a->n_pages;
-                memset(a->flags, 0, a->n_pages * sizeof(uint32_t));
+                a->host_flags.assign(a->n_pages, 0u);
+                a->flags = a->host_flags.data();
+                a->slot = static_cast<uint32_t*>(a->pinned);
                 memset(a->slot, 0xFF, a->n_pages * sizeof(uint32_t));
             }
             if (ok) {

@@ -56,12 +56,13 @@ struct Allocation {
     int scheme = 0;
     uint32_t rec_stride = kPageSize;
     uint32_t row = kNoSlot;               // row in the device allocation table
-    // residency as the host sees it: bit0 L1, bit1 L2, bit2 compressed (KvPageHandle::flags) and the cache slot.
-    // HIP mode: pinned host memory that the device kernels also write (fetch kernel / flush); /dev/null: plain memory.
+    // residency as the host sees it.  flags: bit0 L1, bit2 compressed (host-managed; bit1 L2 is stored on the fake device
+    // only -- on a HIP device it is derived, Engine::res_flags).  slot (HIP device only): pinned host memory that the
+    // kernels also write -- the ring sequence number of a page fetched into L2, or the L1 slot of a promoted page.
     uint32_t* flags = nullptr;
     uint32_t* slot = nullptr;
-    std::vector<uint32_t> null_flags;     // backing store on the fake device
-    void* pinned = nullptr;               // backing store on a HIP device (flags then slots)
+    std::vector<uint32_t> host_flags;     // backing store of flags
+    void* pinned = nullptr;               // backing store of slot
     std::vector<uint32_t> access_count;   // MemoryPage::access_count
     std::vector<uint32_t> stamp;          // dedupe epoch of access_batch
     uint32_t l1_pages = 0;

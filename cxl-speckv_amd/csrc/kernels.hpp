@@ -32,15 +32,15 @@ struct Layout {
 
 // One row of the device allocation table: what kernels that work across allocations (the prefetch pipeline, the
 // ring bookkeeping of the fetch kernel) need to know about an allocation.  A freed row has entries == nullptr.
-//   d_flags / d_slot : residency mirror in HBM (bit0 L1, bit1 L2; cache slot) -- what kernels read
-//   h_flags / h_slot : the same words in pinned host memory (device-visible) -- what the host reads; kernels that
-//                      change a page's residency store the new value to both
+//   d_flags / d_slot : residency in HBM (bit0 L1, bit1 L2; cache slot) -- what kernels read and keep
+//   h_slot           : one word per page in pinned host memory (device-visible) -- what the host reads: the ring
+//                      sequence number under which a kernel fetched the page (its only host-visible store; the host
+//                      derives the L2 bit from it, Engine::l2_live), or the L1 slot of a host-promoted page
 //   stamp            : per-page scratch word of the flush's first-occurrence dedupe
 struct DevAlloc {
     PageEntry* entries;
     uint32_t*  d_flags;
     uint32_t*  d_slot;
-    uint32_t*  h_flags;
     uint32_t*  h_slot;
     uint32_t*  stamp;
     Layout     layout;
