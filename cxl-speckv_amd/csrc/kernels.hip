@@ -202,6 +202,20 @@ __device__ __forceinline__ bool decode_rle_fast(const uint8_t* __restrict__ rec,
         w[j] = make_uint4(0u, 0u, 0u, 0u);
         if (pair0 < npairs) w[j] = ld16(rec + 2ull * pair0);
     }
+    // A stream whose value bytes are all zero (a block of zeros, a never-written page: len 0) decodes to +0 whatever its
+    // counts are -- 0/127 * scale with a finite scale >= 0 -- and needs neither table nor scans: plain vector stores.
+    // (Otherwise such blocks take the full constant-work path below, or, with len 0, the element-wise general path.)
+    {
+        uint32_t anyv = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) anyv |= (w[j].x | w[j].y | w[j].z | w[j].w) & 0x00FF00FFu;
+        if (__builtin_amdgcn_ballot_w64(anyv != 0u) == 0ull && scale >= 0.0f && scale < __builtin_inff()) {
+            const float z[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) store8<F32>(dst, 512u * j + 8u * lane, z);
+            return true;
+        }
+    }
     // clear the byte table (2 KiB); byte 2048 is a write-only dummy
     uint4* t4 = reinterpret_cast<uint4*>(tab);
     t4[lane] = make_uint4(0u, 0u, 0u, 0u);
