@@ -203,13 +203,13 @@ __device__ __forceinline__ bool decode_rle_fast(const uint8_t* __restrict__ rec,
         if (pair0 < npairs) w[j] = ld16(rec + 2ull * pair0);
     }
     // A stream whose value bytes are all zero (a block of zeros, a never-written page: len 0) decodes to +0 whatever its
-    // counts are -- 0/127 * scale with a finite scale >= 0 -- and needs neither table nor scans: plain vector stores.
+    // counts are -- 0/127 * scale with a finite scale of positive sign -- and needs neither table nor scans: plain vector stores.
     // (Otherwise such blocks take the full constant-work path below, or, with len 0, the element-wise general path.)
     {
         uint32_t anyv = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) anyv |= (w[j].x | w[j].y | w[j].z | w[j].w) & 0x00FF00FFu;
-        if (__builtin_amdgcn_ballot_w64(anyv != 0u) == 0ull && scale >= 0.0f && scale < __builtin_inff()) {
+        if (__builtin_amdgcn_ballot_w64(anyv != 0u) == 0ull && __float_as_uint(scale) < 0x7F800000u) {    // sign clear (not -0 either), finite
             const float z[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) store8<F32>(dst, 512u * j + 8u * lane, z);

@@ -179,6 +179,27 @@ def test_decode_malformed_and_ragged(lib, oracle):
             got = oracle.decompress_block_f32(recs[i, :lens[i]], 0.5, 2, mode, N)
             want[:got.size] = got
             assert_same_float_bits(y[i], want, f"stream {i} mode {mode}")
+    # streams whose value bytes are all zero take a shortcut (plain stores of +0) when the scale is finite and >= 0:
+    # short, exact, overlong, empty, with zero counts -- and the scales for which 0/127 * scale is NOT +0 (negative: -0,
+    # infinite or NaN: NaN) must still come out as the reference computes them
+    zstreams = [[0, 255] * 8 + [0, 8], [0, 100], [], [0, 255] * 12, [0, 0, 0, 7, 0, 0], [0, 1] * 2048, [0, 255] * 8 + [0, 8, 3]]
+    zscales = [0.5, 0.0, -0.5, float("inf"), float("nan"), -0.0, 3.0e38]
+    recs = np.zeros((len(zstreams) * len(zscales), 4096), np.uint8)
+    lens = np.zeros(recs.shape[0], np.uint32)
+    scales = np.zeros(recs.shape[0], np.float32)
+    for i, st in enumerate(zstreams):
+        for j, sc in enumerate(zscales):
+            k = i * len(zscales) + j
+            recs[k, :len(st)] = st; lens[k] = len(st); scales[k] = sc
+    for mode in MODES:
+        for f32 in (True, False):
+            y = gpu_decompress(lib, recs, lens, scales, 2, mode, out_f32=f32)
+            for k in range(recs.shape[0]):
+                dec = oracle.decompress_block_f32 if f32 else oracle.decompress_block_f16
+                want = np.zeros(N, np.float32 if f32 else np.float16)
+                got = dec(recs[k, :lens[k]], float(scales[k]), 2, mode, N)
+                want[:got.size] = got
+                assert_same_float_bits(y[k], want, f"zero-value stream {k // len(zscales)} scale {scales[k]!r} mode {mode} f32 {f32}")
     # ragged INT8 / FP16 records
     for scheme, ls in ((1, [0, 1, 7, 8, 9, 2047, 2048]), (0, [0, 2, 3, 14, 16, 18, 4094, 4096])):
         recs = rng.integers(0, 256, (len(ls), 4096)).astype(np.uint8)
