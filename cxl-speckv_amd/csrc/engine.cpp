@@ -809,7 +809,8 @@ void Engine::reap(bool wait_all)
 }
 
 // Synchronous fetch of `pages` (in this order) into a fresh run of ring slots; *base_out = first slot.
-// The fetch kernel does the ring bookkeeping (eviction of the previous owners, slot / flag words on both sides).
+// The fetch kernel does the ring bookkeeping (eviction of the previous owners in HBM, the new owner, the page's slot word
+// in HBM and its sequence number in the host-visible word).
 int Engine::fetch_into_ring(Allocation* a, const std::vector<uint32_t>& pages, uint32_t* base_out)
 {
     const uint32_t n = static_cast<uint32_t>(pages.size());

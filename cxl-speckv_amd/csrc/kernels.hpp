@@ -108,8 +108,9 @@ struct CodecArgs {
     const uint32_t* alloc_list;
     // L2-ring bookkeeping done by the fetch kernel itself (decompress only, ring_owner != nullptr): block i lands in
     // cache slot slot0 + i (dst = ring_base + slot*4096); the wave evicts the slot's previous owner (clears its L2 bit
-    // if it still points at this slot), records the new owner, the page's slot and its L2 bit, in HBM and in the
-    // host-visible mirror.  slot0 comes from slot0_dev when set (device-side flush), else from slot0.
+    // if it still points at this slot), records the new owner, the page's slot and its L2 bit in HBM and the slot's ring
+    // sequence number in the page's host-visible word.  slot0 / seq0 come from the *_dev pointers when set, else from
+    // the values.  (Synchronous misses; the device-side flush does this in its scatter kernel, one thread per page.)
     uint64_t*       ring_owner;
     uint8_t*        ring_base;
     const uint32_t* slot0_dev;
