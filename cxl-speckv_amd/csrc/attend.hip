@@ -344,6 +344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         a.k_first = sq.k_first;
         a.v_first = sq.v_first;
         a.n_pages = sq.n_pages;
+        a.tiles_per_split = sq.tiles_per_split;
         part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
         layer = 0;
     }
@@ -593,6 +594,7 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
         a.k_first = sq.k_first;
         a.v_first = sq.v_first;
         a.n_pages = sq.n_pages;
+        a.tiles_per_split = sq.tiles_per_split;
         part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
         layer = 0;
     }

@@ -287,6 +287,7 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
         a.k_first = sq.k_first;
         a.v_first = sq.v_first;
         a.n_pages = sq.n_pages;
+        a.tiles_per_split = sq.tiles_per_split;
         part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
         layer = 0;
     }
@@ -504,6 +505,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
         a.k_first = sq.k_first;
         a.v_first = sq.v_first;
         a.n_pages = sq.n_pages;
+        a.tiles_per_split = sq.tiles_per_split;
         part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
         layer = 0;
         a.big_flag = sq.big_flag;

@@ -1995,11 +1995,11 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
         HIP_TRY(hipMemset(d_zero_page_, 0, kPageSize));
     }
-    // splits: ~40 waves per CU over the launch (a few rounds of the 16 resident ones; measured best at
-    // 70B@32k: 16 splits/row), at least 8 tiles (256 positions) per split so the partials stay small
+    // splits: ~20 waves per CU over the launch (the LDS-DMA kernel keeps 8 resident; measured at 70B-shaped, 80 layers:
+    // 8 splits/row 0.72 of HBM peak at 32k and 0.63 at 8k, 16 splits 0.705 / 0.61, 4 splits 0.71 / 0.63, 2: 0.63 / 0.58)
     const uint32_t n_tiles = (n_pages + 15u) / 16u;
     const uint32_t rows = n_layers * L.num_heads;
-    uint32_t want = (10240u + rows - 1u) / rows;
+    uint32_t want = (5120u + rows - 1u) / rows;
     // per-layer calls are latency-bound: short contexts want short splits (measured best: 2 tiles per split at 2k
     // context, 4 at 8k, 8 at 32k), long multi-layer launches are bounded by `want` above
     const uint32_t min_tiles = std::min(8u, std::max(2u, n_tiles / 64u));
@@ -2097,8 +2097,12 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
         if (!s) HIP_TRY(hipStreamSynchronize(stream_));
         return SPECKV_OK;
     }
-    // one split length for the whole batch: ~10k waves over the launch, at least 8 tiles per split
-    uint32_t tps = static_cast<uint32_t>(std::max<uint64_t>(8, (total_tiles * heads + 10239u) / 10240u));
+    // one split length for the whole batch.  A batch brings its own parallelism: the fewer, longer splits the better, down
+    // to about one round of resident workgroups (256 sequences x 8k context, one layer, FP8: 8 tiles per split 0.50 of
+    // HBM peak, 32: 0.59, 64: 0.67, 128: 0.72, 256 = no split: 0.74; INT4: 64..128 best, 0.59; at 2k context both
+    // formats want no split at all).  Target: 512 workgroups (FP8) / 768 (INT4), never under 8 tiles per split.
+    const uint64_t wg_target = fp8 ? 512u : 768u;
+    uint32_t tps = static_cast<uint32_t>(std::max<uint64_t>(8, (total_tiles * (heads / 4u) + wg_target - 1u) / wg_target));
     if (const char* env = getenv("SPECKV_ATTEND_TILES_PER_SPLIT")) tps = std::max(1, atoi(env));
     uint32_t max_splits = 0;
     uint64_t parts = 0;
@@ -2106,6 +2110,9 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
         const uint32_t n_tiles = seqs[i].n_splits;
         seqs[i].n_splits = (n_tiles + tps - 1u) / tps;
         if (seqs[i].n_splits > 2048u) return SPECKV_ERR_INVAL;
+        // the sequence's tiles divided evenly over its splits (171 + 85 tiles instead of 128 + 128 cost 15 %)
+        seqs[i].tiles_per_split = seqs[i].n_splits ? (n_tiles + seqs[i].n_splits - 1u) / seqs[i].n_splits : tps;
+        seqs[i].n_splits = seqs[i].tiles_per_split ? (n_tiles + seqs[i].tiles_per_split - 1u) / seqs[i].tiles_per_split : 0u;
         seqs[i].part_base = static_cast<uint32_t>(parts);
         parts += static_cast<uint64_t>(heads) * seqs[i].n_splits;
         max_splits = std::max(max_splits, seqs[i].n_splits);

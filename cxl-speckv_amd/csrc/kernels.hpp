@@ -203,7 +203,7 @@ struct AttendSeq {
     uint32_t n_pages;                 // pages of [0, pos_end)
     uint32_t n_splits;                // ceil(tiles / tiles_per_split), <= gridDim.x
     uint32_t part_base;
-    uint32_t reserved;
+    uint32_t tiles_per_split;         // this sequence's own split length (its tiles divided evenly over n_splits)
     const uint32_t* big_flag;         // INT4: see AttendArgs::big_flag
 };
 
