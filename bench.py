@@ -821,13 +821,16 @@ def int4_attention_extra(torch, kv, T, Lyr):
         lib.set_compression_scheme(2)
 
 
-def batch_attention_extra(torch, kv, n_seq=256, T=8192):
+def batch_attention_extra(torch, kv, n_seq=256, T=8192, scheme=4):
     """BASELINE configs[3] shape on one GPU: one decode step's attention of ONE layer for a batch of 256 sequences at
-    8k context (8 kv heads x 128, 8 query rows per kv head), FP8 records, one launch pair for the whole batch."""
+    8k context (8 kv heads x 128, 8 query rows per kv head), FP8 (scheme 4) or INT4 (3) records, one launch pair for the
+    whole batch."""
     lib = kv.lib
     handles = []
+    name = "fp8_attention_batch_decode_step" if scheme == 4 else "int4_attention_batch_decode_step"
+    rec = 2048 if scheme == 4 else 1152
     try:
-        lib.set_compression_scheme(4)
+        lib.set_compression_scheme(scheme)
         g = torch.Generator(device="cuda"); g.manual_seed(2004)
         n_pages = T * 8 * 128 * 2 * 2 // PAGE
         x = torch.randn((n_pages, BLOCK_ELEMS), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
@@ -840,8 +843,9 @@ def batch_attention_extra(torch, kv, n_seq=256, T=8192):
         o = torch.empty((n_seq, 8, 8, 128), dtype=torch.float32, device="cuda")
         s = torch.cuda.Stream()
         lens = [T] * n_seq
+        fn = lib.attend_fp8_batch if scheme == 4 else lib.attend_int4_batch
         def step():
-            lib.attend_fp8_batch(handles, 0, q.data_ptr(), 8, lens, 0.08838834764831845, o.data_ptr(), None, s.cuda_stream)
+            fn(handles, 0, q.data_ptr(), 8, lens, 0.08838834764831845, o.data_ptr(), None, s.cuda_stream)
         step(); torch.cuda.synchronize()
         ramp(step, torch.cuda.synchronize, EXTRAS_RAMP_MS)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -851,13 +855,13 @@ def batch_attention_extra(torch, kv, n_seq=256, T=8192):
             step()
         b.record(s); torch.cuda.synchronize()
         ms = a.elapsed_time(b) / reps
-        rec_bytes = n_seq * n_pages * 2048
-        return {"fp8_attention_batch_decode_step": {"sequences": n_seq, "context": T, "layers_per_call": 1,
-                                                    "ms_per_layer": round(ms, 4), "KV_record_GBps": round(rec_bytes / (ms * 1e-3) / 1e9, 1),
-                                                    "frac_hbm": round(rec_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                                    "note": f"speckv_ext_attend_fp8_batch: {n_seq} sequences x {T} context, one layer, one launch pair"}}
+        rec_bytes = n_seq * n_pages * rec
+        return {name: {"sequences": n_seq, "context": T, "layers_per_call": 1,
+                       "ms_per_layer": round(ms, 4), "KV_record_GBps": round(rec_bytes / (ms * 1e-3) / 1e9, 1),
+                       "frac_hbm": round(rec_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                       "note": f"speckv_ext_attend_{'fp8' if scheme == 4 else 'int4'}_batch: {n_seq} sequences x {T} context, one layer, one launch pair"}}
     except Exception as e:
-        return {"fp8_attention_batch_decode_step": {"error": repr(e)}}
+        return {name: {"error": repr(e)}}
     finally:
         for h in handles:
             try: lib.free(h)
@@ -1113,6 +1117,7 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     ex.update(fp8_scores_extra(torch, kv, 32768, 80))
     ex.update(int4_attention_extra(torch, kv, 32768, 80))
     ex.update(batch_attention_extra(torch, kv))      # BASELINE configs[4] shape: 70B-shaped KV @ 32k context
+    ex.update(batch_attention_extra(torch, kv, scheme=3))
     ex.update(connector_append_extra(torch, kv))
     ex.update(predictor_extra(torch, lib))
     return ex
