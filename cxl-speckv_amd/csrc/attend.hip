@@ -501,8 +501,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // ---- partial result of this split, back in true units
+    // ---- partial result of this split, back in true units (or, single split: the final result)
     const float l_tot = sum_over_kb(l_run);
+    if (a.direct_out) {
+        if (c < a.g) {
+            const float w = l_tot > 0.0f ? vref / l_tot : 0.0f;
+            float* dst = a.direct_out + (row * a.g + c) * 128u + 32u * kb;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<f32x4*>(dst + 8 * i) = f32x4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]} * w;
+                *reinterpret_cast<f32x4*>(dst + 8 * i + 4) = f32x4{acc[4][i], acc[5][i], acc[6][i], acc[7][i]} * w;
+            }
+            if (a.direct_lse && kb == 0)
+                a.direct_lse[row * a.g + c] = l_tot > 0.0f ? (m_run + log2f(l_tot)) * 0.6931471805599453f : -INFINITY;
+        }
+        return;
+    }
     if (kb == 0) {
         a.part_ml[part * 32u + c] = m_run;
         a.part_ml[part * 32u + 16u + c] = l_tot;
@@ -740,8 +754,22 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the re-requested tail tiles: nothing may land after the wave ends
     }
-    // ---- partial result of this split, back in true units
+    // ---- partial result of this split, back in true units (or, single split: the final result)
     const float l_tot = sum_over_kb(l_run);
+    if (a.direct_out) {
+        if (c < a.g) {
+            const float w = l_tot > 0.0f ? vref / l_tot : 0.0f;
+            float* dst = a.direct_out + (row * a.g + c) * 128u + 32u * kb;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<f32x4*>(dst + 8 * i) = f32x4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]} * w;
+                *reinterpret_cast<f32x4*>(dst + 8 * i + 4) = f32x4{acc[4][i], acc[5][i], acc[6][i], acc[7][i]} * w;
+            }
+            if (a.direct_lse && kb == 0)
+                a.direct_lse[row * a.g + c] = l_tot > 0.0f ? (m_run + log2f(l_tot)) * 0.6931471805599453f : -INFINITY;
+        }
+        return;
+    }
     if (kb == 0) {
         a.part_ml[part * 32u + c] = m_run;
         a.part_ml[part * 32u + 16u + c] = l_tot;
@@ -940,7 +968,7 @@ hipError_t launch_attend_fp8_batch(const AttendArgs& a, uint32_t n_seq, float* d
     hipLaunchKernelGGL(k_attend_fp8_linear, dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
 #endif
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || a.direct_out) return e;
     return launch_attend_combine(a, n_seq, d_out, d_lse, s);
 }
 
@@ -962,7 +990,7 @@ hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_ou
 #endif
     else            hipLaunchKernelGGL(k_attend_fp8, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || (a.direct_out && a.lin_base)) return e;      // (the page-table form always writes partials)
     return launch_attend_combine(a, n_layers, d_out, d_lse, s);
 }
 

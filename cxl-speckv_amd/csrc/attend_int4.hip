@@ -239,9 +239,23 @@ __device__ __forceinline__ void pv_tile(const uint32_t (&vw)[8], const uint32_t 
 }
 
 // the split's partial result: running maximum, sum and the un-normalised accumulators
-__device__ __forceinline__ void store_partial(const AttendArgs& a, uint64_t part, uint32_t c, uint32_t kb, float m_run, float l_run, const f32x4 (&acc)[8])
+__device__ __forceinline__ void store_partial(const AttendArgs& a, uint64_t part, uint64_t row, uint32_t c, uint32_t kb, float m_run, float l_run, const f32x4 (&acc)[8])
 {
     const float l_tot = sum_over_kb(l_run);
+    if (a.direct_out) {                               // single split per row: the final result (AttendArgs::direct_out)
+        if (c < a.g) {
+            const float w = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+            float* dst = a.direct_out + (row * a.g + c) * 128u + 32u * kb;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<f32x4*>(dst + 8 * i) = f32x4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]} * w;
+                *reinterpret_cast<f32x4*>(dst + 8 * i + 4) = f32x4{acc[4][i], acc[5][i], acc[6][i], acc[7][i]} * w;
+            }
+            if (a.direct_lse && kb == 0)
+                a.direct_lse[row * a.g + c] = l_tot > 0.0f ? (m_run + log2f(l_tot)) * 0.6931471805599453f : -INFINITY;
+        }
+        return;
+    }
     if (kb == 0) {
         a.part_ml[part * 32u + c] = m_run;
         a.part_ml[part * 32u + 16u + c] = l_tot;
@@ -425,7 +439,7 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    store_partial(a, part, c, kb, m_run, l_run, acc);
+    store_partial(a, part, row, c, kb, m_run, l_run, acc);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -617,7 +631,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
         else         tiles(std::false_type{});
 #endif
     }
-    store_partial(a, part, c, kb, m_run, l_run, acc);
+    store_partial(a, part, row, c, kb, m_run, l_run, acc);
 }
 
 hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_t s)

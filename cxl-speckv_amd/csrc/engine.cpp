@@ -2038,6 +2038,7 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     k.part_ml = reinterpret_cast<float*>(buf + q_bytes + qs_bytes + acc_bytes);
     if (!k.lin_base)                     // the linear form quantises the query in its own prologue
         HIP_TRY(launch_quantize_q_e4m3(d_q_f16, rows, g, L.head_dim, buf, reinterpret_cast<float*>(buf + q_bytes), st));
+    if (n_splits == 1u) { k.direct_out = d_out; k.direct_lse = d_lse; }      // no merge launch (linear form)
     HIP_TRY(launch_attend_fp8(k, n_layers, d_out, d_lse, st));
     note_use(a, s);
     if (!s) RC_TRY(wait_stream());
@@ -2151,11 +2152,14 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     k.seqs = d_seqs;
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
+    bool one_split_each = true;                           // then the attention kernel writes the final rows itself
+    for (uint32_t i = 0; i < n_seq; ++i) one_split_each = one_split_each && seqs[i].n_splits == 1u;
+    if (one_split_each) { k.direct_out = d_out; k.direct_lse = d_lse; }
     if (fp8) {
         HIP_TRY(launch_attend_fp8_batch(k, n_seq, d_out, d_lse, st));
     } else {
         HIP_TRY(launch_attend_int4(k, n_seq, st));        // grid y = sequences x head groups, as for layers
-        HIP_TRY(launch_attend_combine(k, n_seq, d_out, d_lse, st));
+        if (!k.direct_out) HIP_TRY(launch_attend_combine(k, n_seq, d_out, d_lse, st));
     }
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
     return SPECKV_OK;
@@ -2236,8 +2240,9 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     k.zero_page = d_zero_page_;
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
+    if (n_splits == 1u) { k.direct_out = d_out; k.direct_lse = d_lse; }      // no merge launch
     HIP_TRY(launch_attend_int4(k, n_layers, st));
-    HIP_TRY(launch_attend_combine(k, n_layers, d_out, d_lse, st));
+    if (!k.direct_out) HIP_TRY(launch_attend_combine(k, n_layers, d_out, d_lse, st));
     note_use(a, s);
     if (!s) RC_TRY(wait_stream());
     return SPECKV_OK;

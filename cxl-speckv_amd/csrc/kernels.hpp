@@ -230,6 +230,10 @@ struct AttendArgs {
     const uint32_t* big_flag;
     float* part_acc;                  // [layers][heads][splits][16][128]
     float* part_ml;                   // [layers][heads][splits][2][16]
+    // every row has exactly ONE split (set by the engine then): the attention kernel normalises and writes the final
+    // [row][g][128] output and the log-sum-exp (may be null) itself, and no merge launch follows
+    float* direct_out;
+    float* direct_lse;
 };
 // a.lin_base set: linear form (a.scale_tab, a.q16); else page-table form (a.q8 / a.qs from launch_quantize_q_e4m3)
 hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s);
