@@ -1826,6 +1826,7 @@ int Engine::fetch_range(uint64_t handle, uint64_t first, uint64_t n, void* d_dst
     if (engine_choice < 0 || engine_choice > 2) return SPECKV_ERR_INVAL;
     if (n == 0) return SPECKV_OK;
     DeviceScope device_scope(device_);
+    if (!s) HIP_TRY(hipDeviceSynchronize());      // NULL = synchronous call on the engine's stream: d_dst may be in use on any stream
     hipStream_t st = s ? s : stream_;
     // which engine moves the records: the fused peer-load kernel (the wave loads the record over xGMI and
     // decompresses in registers) or the copy engines (SDMA runs into local staging, then a local decompress).
@@ -1883,6 +1884,7 @@ int Engine::fetch_list(uint64_t handle, const uint32_t* d_pages, uint32_t n, voi
     if (!d_dst || (!d_pages && n)) return SPECKV_ERR_INVAL;
     if (n == 0) return SPECKV_OK;
     DeviceScope device_scope(device_);
+    if (!s) HIP_TRY(hipDeviceSynchronize());      // as in fetch_range
     CodecArgs c{};
     c.entries = a->d_entries;
     c.trusted = 1;                       // pool records only ever come from k_compress
@@ -1928,6 +1930,8 @@ int Engine::qk_scores_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, co
     const uint64_t layer_stride = static_cast<uint64_t>(L.num_tokens);      // pages per layer: K + V = 2*T/2
     if (first_page + (n_layers - 1) * layer_stride + n_pages > a->n_pages) return SPECKV_ERR_GENERAL;
     DeviceScope device_scope(device_);
+    // NULL = the engine's stream and a synchronous call: the query may have been produced on any stream of the caller
+    if (!s) HIP_TRY(hipDeviceSynchronize());
     hipStream_t st = s ? s : stream_;
     {   // linear form (records in one run, scale table, tile-aligned range inside the layer's region): direct loads
         const uint32_t n_tiles = (n_pages + 15u) / 16u;
@@ -1978,6 +1982,8 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     if (g == 0 || g > 16 || !d_q_f16 || !d_out) return SPECKV_ERR_INVAL;
     const uint32_t n_pages = (pos_end - pos_begin) / 2;
     DeviceScope device_scope(device_);
+    // NULL = the engine's stream and a synchronous call: the query may have been produced on any stream of the caller
+    if (!s) HIP_TRY(hipDeviceSynchronize());
     hipStream_t st = s ? s : stream_;
     const size_t out_elems = static_cast<size_t>(n_layers) * L.num_heads * g * 128;
     if (n_pages == 0) {          // empty range: softmax over nothing -> zeros (and -inf lse is left to the caller)
@@ -1997,9 +2003,12 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     }
     // splits: ~20 waves per CU over the launch (the LDS-DMA kernel keeps 8 resident; measured at 70B-shaped, 80 layers:
     // 8 splits/row 0.72 of HBM peak at 32k and 0.63 at 8k, 16 splits 0.705 / 0.61, 4 splits 0.71 / 0.63, 2: 0.63 / 0.58)
+    // A launch that already has 128+ workgroup columns (layers x head quads) is best left unsplit: each workgroup then
+    // streams one long run, the rows are final (no partials, no merge launch) -- 80 layers: 1 split 0.73 / 0.70 / 0.64 of
+    // HBM peak at 32k / 8k / 2k context against 0.71 / 0.62 / 0.48 with 8 splits.
     const uint32_t n_tiles = (n_pages + 15u) / 16u;
     const uint32_t rows = n_layers * L.num_heads;
-    uint32_t want = (5120u + rows - 1u) / rows;
+    uint32_t want = (rows / 4u >= 128u) ? 1u : (5120u + rows - 1u) / rows;
     // per-layer calls are latency-bound: short contexts want short splits (measured best: 2 tiles per split at 2k
     // context, 4 at 8k, 8 at 32k), long multi-layer launches are bounded by `want` above
     const uint32_t min_tiles = std::min(8u, std::max(2u, n_tiles / 64u));
@@ -2091,6 +2100,8 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
         total_tiles += n_tiles;
     }
     DeviceScope device_scope(device_);
+    // NULL = the engine's stream and a synchronous call: the query may have been produced on any stream of the caller
+    if (!s) HIP_TRY(hipDeviceSynchronize());
     hipStream_t st = s ? s : stream_;
     const size_t out_elems = static_cast<size_t>(n_seq) * heads * g * 128;
     if (total_tiles == 0) {
@@ -2181,6 +2192,8 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     if (g == 0 || g > 16 || !d_q_f16 || !d_out) return SPECKV_ERR_INVAL;
     const uint32_t n_pages = (pos_end - pos_begin) / 2;
     DeviceScope device_scope(device_);
+    // NULL = the engine's stream and a synchronous call: the query may have been produced on any stream of the caller
+    if (!s) HIP_TRY(hipDeviceSynchronize());
     hipStream_t st = s ? s : stream_;
     const size_t out_elems = static_cast<size_t>(n_layers) * L.num_heads * g * 128;
     if (n_pages == 0) {

@@ -14,8 +14,10 @@
  * interface it stands in for.
  *
  * Pointers named d_* are DEVICE pointers on the compute GPU.  `stream` is a
- * hipStream_t passed as void* (NULL = the engine's own fetch stream); all
- * *_async style work is ordered on it.
+ * hipStream_t passed as void*: the work is ordered on it and the call returns
+ * without waiting.  NULL = the engine's own stream and a SYNCHRONOUS call: it
+ * first waits for the device (the caller's buffers may have been produced on
+ * any stream) and returns when the result is complete.
  */
 #ifndef SPECKV_EXT_H
 #define SPECKV_EXT_H
