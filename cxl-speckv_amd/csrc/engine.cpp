@@ -2113,8 +2113,12 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     // to about one round of resident workgroups (256 sequences x 8k context, one layer, FP8: 8 tiles per split 0.50 of
     // HBM peak, 32: 0.59, 64: 0.67, 128: 0.72, 256 = no split: 0.74; INT4: 64..128 best, 0.59; at 2k context both
     // formats want no split at all).  Target: 512 workgroups (FP8) / 768 (INT4), never under 8 tiles per split.
+    // INT4 (arithmetic-bound kernel): splits longer than 256 tiles stop paying (256 sequences x 32k: 256 tiles per split
+    // 0.67, 512: 0.65, 1024 = no split: 0.60), shorter sequences are best left whole (8k 0.63 against 0.59 in two
+    // splits, 4k 0.60 / 0.52, 2k 0.58 / 0.43: single-split rows are final, no partials and no merge).
     const uint64_t wg_target = fp8 ? 512u : 768u;
     uint32_t tps = static_cast<uint32_t>(std::max<uint64_t>(8, (total_tiles * (heads / 4u) + wg_target - 1u) / wg_target));
+    if (!fp8) tps = (static_cast<uint64_t>(n_seq) * (heads / 4u) >= 384u) ? 256u : std::min(tps, 256u);   // enough columns: whole sequences
     if (const char* env = getenv("SPECKV_ATTEND_TILES_PER_SPLIT")) tps = std::max(1, atoi(env));
     uint32_t max_splits = 0;
     uint64_t parts = 0;
