@@ -495,10 +495,7 @@ __device__ __forceinline__ void wg_take_v(const uint32_t (&rd)[4], uint32_t rs, 
 }
 } // namespace
 
-#ifndef SPECKV_INT4_WG_WAVES
-#define SPECKV_INT4_WG_WAVES 3
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4_WG_WAVES, SPECKV_INT4_WG_WAVES))) void k_attend_int4_wg(AttendArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_attend_int4_wg(AttendArgs a)
 {
     static_assert(kWgHeads == 4, "the cooperative kernel is laid out for 4 heads per workgroup");
     __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kWgBuf];
@@ -624,12 +621,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
             pv_tile<kCheck>(vw, vs16, P, acc);
         }
         };
-#ifdef SPECKV_EXPERIMENT_NO_CHECKED_LOOP
-        tiles(std::false_type{});
-#else
         if (big_any) tiles(std::true_type{});
         else         tiles(std::false_type{});
-#endif
     }
     store_partial(a, part, row, c, kb, m_run, l_run, acc);
 }
