@@ -192,6 +192,10 @@ def test_no_cpu_fallback_for_the_data_path(nulllib):
     for call in (lambda: nulllib.write(h, 0, C.addressof(buf), 4096, False),
                  lambda: nulllib.read(h, 0, C.addressof(buf), 4096, False),
                  lambda: nulllib.fetch_range(h, 0, 1, C.addressof(buf)),
+                 lambda: nulllib.write_strided(h, 0, 1, 1, C.addressof(buf), 1),
+                 lambda: nulllib.write_strided_batch([h], [0], [C.addressof(buf)], 1, 1, 1),
+                 lambda: nulllib.attend_fp8(h, 0, 1, C.addressof(buf), 8, 0, 32, 0.1, C.addressof(buf)),
+                 lambda: nulllib.attend_int4(h, 0, 1, C.addressof(buf), 8, 0, 32, 0.1, C.addressof(buf)),
                  lambda: nulllib.poll_complete()):
         with pytest.raises(SpeckvError) as ei:
             call()
