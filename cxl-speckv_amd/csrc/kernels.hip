@@ -1454,15 +1454,26 @@ __global__ __launch_bounds__(256) void k_lstm_logits(const float* __restrict__ h
     // issued 32 scalar loads per request -- 16 M load instructions for a batch of 256, which bounded the kernel (0.43 of
     // the 0.52 ms of a 256-request prediction; 0.105 ms now).  Same products, same order of additions as before.
     __shared__ __attribute__((aligned(16))) float hs[16][kPredHidden];
+    // a thread moves elements threadIdx.x and threadIdx.x + 256 (float4 units) of every tile; the next tile's two loads are
+    // issued before the current tile is consumed, so their latency runs under the arithmetic
+    static_assert(16u * kPredHidden / 4u == 512u, "two float4 per thread and tile");
+    auto fetch = [&](uint32_t b0, int q) {
+        const uint32_t e = threadIdx.x + 256u * static_cast<uint32_t>(q);
+        const uint32_t r = e / (kPredHidden / 4u), c4 = e % (kPredHidden / 4u);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b0 + r < n) v = *reinterpret_cast<const float4*>(hid + static_cast<uint64_t>(b0 + r) * kPredHidden + 4u * c4);
+        return v;
+    };
+    float4 nx0 = fetch(0u, 0), nx1 = fetch(0u, 1);
     for (uint32_t b0 = 0; b0 < n; b0 += 16u) {
         __syncthreads();
-        for (uint32_t e = threadIdx.x; e < 16u * kPredHidden / 4u; e += 256u) {
-            const uint32_t r = e / (kPredHidden / 4u), c4 = e % (kPredHidden / 4u);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b0 + r < n) v = *reinterpret_cast<const float4*>(hid + static_cast<uint64_t>(b0 + r) * kPredHidden + 4u * c4);
-            *reinterpret_cast<float4*>(&hs[r][4u * c4]) = v;
+        {
+            const uint32_t e0 = threadIdx.x, e1 = threadIdx.x + 256u;
+            *reinterpret_cast<float4*>(&hs[e0 / (kPredHidden / 4u)][4u * (e0 % (kPredHidden / 4u))]) = nx0;
+            *reinterpret_cast<float4*>(&hs[e1 / (kPredHidden / 4u)][4u * (e1 % (kPredHidden / 4u))]) = nx1;
         }
         __syncthreads();
+        if (b0 + 16u < n) { nx0 = fetch(b0 + 16u, 0); nx1 = fetch(b0 + 16u, 1); }
         const uint32_t nb = min(16u, n - b0);
         for (uint32_t bt = 0; bt < nb; ++bt) {
             const float* hb = &hs[bt][part * 32u];
@@ -1537,6 +1548,82 @@ __global__ __launch_bounds__(1024) void k_softmax_topk(const float* __restrict__
         if (tid == 0) {
             out_tok[b * k + r] = static_cast<int32_t>(bi);
             out_conf[b * k + r] = expf(bv - mx) / sum;
+        }
+    }
+}
+
+// The same for vocabularies of up to 32 768 tokens, written for latency (one request per workgroup is a chain of
+// dependent steps; the kernel above took 48-57 us per launch whatever the batch): every thread keeps its 32 logits in
+// registers (all loads in flight at once), the top-k is k rounds of "best element not taken yet" (value descending, token
+// id ascending -- the same order as the sorted insertion above), block-wide reductions go through wave shuffles and 16 LDS
+// words.  The exp-sum adds each thread's terms in the same order as above.
+__global__ __launch_bounds__(1024) void k_softmax_topk_small(const float* __restrict__ logits, uint32_t vocab,
+        uint32_t k, int32_t* __restrict__ out_tok, float* __restrict__ out_conf)
+{
+    __shared__ float red[16];
+    __shared__ uint32_t redi[16];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const float* l = logits + static_cast<uint64_t>(b) * vocab;
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const uint32_t i = tid + static_cast<uint32_t>(j) * kSmThreads;
+        v[j] = i < vocab ? l[i] : -INFINITY;
+    }
+    float mx = v[0];
+#pragma unroll
+    for (int j = 1; j < 32; ++j) mx = fmaxf(mx, v[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0u) red[wv] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
+    __syncthreads();
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+        if (tid + static_cast<uint32_t>(j) * kSmThreads < vocab) sum += expf(v[j] - mx);
+    // (the tree above summed thread partials pairwise; any order of these 1024 partials is within the stated tolerance)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0u) red[wv] = sum;
+    __syncthreads();
+    sum = red[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) sum += red[i];
+    for (uint32_t r = 0; r < k; ++r) {
+        float bv = -INFINITY; uint32_t bi = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {                                  // ascending token id: ">" keeps the lowest id among equals
+            const uint32_t i = tid + static_cast<uint32_t>(j) * kSmThreads;
+            if (i < vocab && v[j] > bv) { bv = v[j]; bi = i; }
+        }
+        // a thread whose elements are all taken or absent offers (-inf, none); -inf logits lose against any id
+        if (bi == 0xFFFFFFFFu) bv = -INFINITY;
+        float wvv = bv; uint32_t wi = bi;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(wvv, o); const uint32_t oi = __shfl_xor(wi, o);
+            if (ov > wvv || (ov == wvv && oi < wi)) { wvv = ov; wi = oi; }
+        }
+        __syncthreads();
+        if (lane == 0u) { red[wv] = wvv; redi[wv] = wi; }
+        __syncthreads();
+        wvv = red[0]; wi = redi[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) {
+            const float ov = red[i]; const uint32_t oi = redi[i];
+            if (ov > wvv || (ov == wvv && oi < wi)) { wvv = ov; wi = oi; }
+        }
+        // the owner retires the winner
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            if (tid + static_cast<uint32_t>(j) * kSmThreads == wi) v[j] = -INFINITY;
+        if (tid == 0) {
+            out_tok[b * k + r] = static_cast<int32_t>(wi);
+            out_conf[b * k + r] = expf(wvv - mx) / sum;
         }
     }
 }
@@ -1743,7 +1830,8 @@ hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb,
     hipLaunchKernelGGL(k_lstm_hidden, dim3(n), dim3(64), 0, s, d_hist, n, d_emb, vocab, layers, d_hid);
     const uint32_t waves = (vocab + 15u) / 16u;
     hipLaunchKernelGGL(k_lstm_logits, dim3((waves + 3u) / 4u), dim3(256), 0, s, d_hid, n, d_wout, vocab, d_logits);
-    hipLaunchKernelGGL(k_softmax_topk, dim3(n), dim3(1024), 0, s, d_logits, vocab, k, d_tok, d_conf);
+    if (vocab <= 32u * kSmThreads) hipLaunchKernelGGL(k_softmax_topk_small, dim3(n), dim3(1024), 0, s, d_logits, vocab, k, d_tok, d_conf);
+    else                           hipLaunchKernelGGL(k_softmax_topk, dim3(n), dim3(1024), 0, s, d_logits, vocab, k, d_tok, d_conf);
     return hipGetLastError();
 }
 
