@@ -816,7 +816,10 @@ int Engine::fetch_into_ring(Allocation* a, const std::vector<uint32_t>& pages, u
     const uint32_t n = static_cast<uint32_t>(pages.size());
     if (n == 0) return SPECKV_OK;
     if (n > n_l2_) return SPECKV_ERR_NOMEM;
+    const uint64_t handle = a->handle;
     RC_TRY(prepare_ring_op());
+    RC_TRY(renumber_ring_if_due());
+    if (find(handle) != a) return SPECKV_ERR_GENERAL;     // both may wait (and let go of the ABI lock): freed meanwhile
     bool run = true;
     for (uint32_t i = 1; i < n && run; ++i) run = pages[i] == pages[0] + i;
     CodecArgs c{};
@@ -830,7 +833,6 @@ int Engine::fetch_into_ring(Allocation* a, const std::vector<uint32_t>& pages, u
         HIP_TRY(hipMemcpyAsync(d_pages, pages.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
         c.page_list = d_pages;
     }
-    RC_TRY(renumber_ring_if_due());
     const uint32_t seq = take_l2_run(n);
     const uint32_t base = seq % n_l2_;
     c.n = n;
@@ -847,7 +849,6 @@ int Engine::fetch_into_ring(Allocation* a, const std::vector<uint32_t>& pages, u
     HIP_TRY(launch_decompress(c, stream_));
     st_.dma_submitted += n;
     st_.total_decompressions += n;
-    const uint64_t handle = a->handle;
     ++ring_busy_;
     const int wrc = wait_stream();       // sync_fetch_page: submit, then spin on completion
     --ring_busy_;
