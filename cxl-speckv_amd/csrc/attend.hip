@@ -983,11 +983,15 @@ hipError_t launch_build_scale_tab(const PageEntry* d_entries, uint64_t n_pages, 
 hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s)
 {
     if (a.n_pages == 0 || n_layers == 0) return hipSuccess;
-#ifdef SPECKV_FP8_REGSTAGE
-    if (a.lin_base) hipLaunchKernelGGL(k_attend_fp8_linear, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
-#else
-    if (a.lin_base) hipLaunchKernelGGL(k_attend_fp8_dma, dim3(a.n_splits, n_layers * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
-#endif
+    // one long split per row: the LDS-DMA kernel (two tiles deep per wave, 8 waves per CU); several shorter splits: the
+    // register-staged one (16 waves per CU hide more) -- 80 layers x 32k: 8 splits 0.756 (register-staged) / 0.72 (DMA),
+    // 1 split 0.58 / 0.73; 8k: 1 split DMA 0.69, 8 splits 0.63 / 0.62
+    // (launches with few workgroup columns -- the per-layer calls of one sequence -- are latency-bound either way: DMA kernel,
+    // 13.8 against 15.5 us at 8k context)
+    if (a.lin_base && (a.n_splits == 1u || n_layers * (a.heads / 4u) < 128u))
+        hipLaunchKernelGGL(k_attend_fp8_dma, dim3(a.n_splits, n_layers * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
+    else if (a.lin_base)
+        hipLaunchKernelGGL(k_attend_fp8_linear, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
     else            hipLaunchKernelGGL(k_attend_fp8, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || (a.direct_out && a.lin_base)) return e;      // (the page-table form always writes partials)

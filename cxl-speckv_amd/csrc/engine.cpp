@@ -2009,7 +2009,7 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     // HBM peak at 32k / 8k / 2k context against 0.71 / 0.62 / 0.48 with 8 splits.
     const uint32_t n_tiles = (n_pages + 15u) / 16u;
     const uint32_t rows = n_layers * L.num_heads;
-    uint32_t want = (rows / 4u >= 128u) ? 1u : (5120u + rows - 1u) / rows;
+    uint32_t want = (rows / 4u >= 128u && n_tiles < 768u) ? 1u : (5120u + rows - 1u) / rows;     // (32k and beyond: 8 splits, below)
     // per-layer calls are latency-bound: short contexts want short splits (measured best: 2 tiles per split at 2k
     // context, 4 at 8k, 8 at 32k), long multi-layer launches are bounded by `want` above
     const uint32_t min_tiles = std::min(8u, std::max(2u, n_tiles / 64u));
