@@ -147,7 +147,7 @@ def cpu_baseline(seconds, sample_blocks=None, seed=2001):
 # --------------------------------------------------------------------------
 # clock ramp: an idle MI355X sits at 648 MHz sclk and needs ~8 ms (about 40 launches of the 180 us kernel) of
 # continuous work before the shader clock settles: measured per-step durations 181-190 us for the first 40 steps,
-# 171 us from then on (scratch/step_trend.py).  Every timed region below is therefore preceded by an UNTIMED run of
+# 171 us from then on (profiles/tools/step_trend.py).  Every timed region below is therefore preceded by an UNTIMED run of
 # the same step for ramp_ms of wall time, in addition to the W warm-up steps of the contract.
 # --------------------------------------------------------------------------
 def ramp(fn, sync, ramp_ms):

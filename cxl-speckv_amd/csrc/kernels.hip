@@ -1650,7 +1650,7 @@ int num_cus()
 // Launch shape: one block per wave up to per_cu workgroups per CU (short-lived waves even out the tail); beyond that
 // every wave takes the same number of consecutive blocks (*per_wave) so that no round runs half empty.
 // (A capped grid-stride loop: 655 360 blocks over 65 536 workgroups = 2.5 rounds, last one half empty: 0.73 of HBM
-// peak; balanced 0.77-0.80.  Measured with scratch/footprint.py, profiles/r02_footprint.md.)
+// peak; balanced 0.77-0.80.  Measured with profiles/tools/footprint.py, profiles/r02_footprint.md.)
 uint32_t codec_grid(uint64_t n, uint64_t* per_wave)
 {
     static int per_cu = [] {

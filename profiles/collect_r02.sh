@@ -14,7 +14,7 @@ for cfg in "4096 32" "16384 32" "8192 80"; do
   tag=$(echo $cfg | tr ' ' x)
   for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
     name=$(echo $pmc | tr ' ' '+')
-    rocprofv3 --pmc $pmc --output-format csv -d $OUT/pmc_${tag}_${name} -- python3 $R/scratch/footprint.py $cfg 6 > $OUT/pmc_${tag}_${name}.log 2>&1
+    rocprofv3 --pmc $pmc --output-format csv -d $OUT/pmc_${tag}_${name} -- python3 $R/profiles/tools/footprint.py $cfg 6 > $OUT/pmc_${tag}_${name}.log 2>&1
   done
 done
 python3 $R/profiles/summarize_r02.py $OUT > $OUT/summary.json

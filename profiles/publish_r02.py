@@ -38,7 +38,7 @@ for t, name in (("4096x32", "cfg1 (131072 blocks)"), ("16384x32", "4 x cfg1 (524
                 "TCC_MISS": m(t, "TCC_MISS_sum"), "TCC_EA0_RDREQ": m(t, "TCC_EA0_RDREQ_sum"), "TCC_EA0_WRREQ": m(t, "TCC_EA0_WRREQ_sum")}
 c = fp["cfg1 (131072 blocks)"]
 rd, wr = int(c["FETCH_SIZE_KiB"] * 1024 * 2), int(c["WRITE_SIZE_KiB"] * 1024)
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on scratch/footprint.py 4096 32 (the bench's cfg1 launch), profiles/collect_r02.sh",
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on profiles/tools/footprint.py 4096 32 (the bench's cfg1 launch), profiles/collect_r02.sh",
        "units": "FETCH_SIZE and WRITE_SIZE in KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B)",
        "pmc": {"k_fetch_decompress<2, 0, false>": {"FETCH_SIZE_KiB": c["FETCH_SIZE_KiB"], "WRITE_SIZE_KiB": c["WRITE_SIZE_KiB"],
                                                     "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condense a gpurun_out/prof_* directory (rocprofv3 --kernel-trace --stats and
-separate --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, see scratch/prof.sh /
+separate --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, see profiles/tools/prof.sh /
 profiles/README.md) into small tracked files:
 
     profiles/<tag>_kernel_stats.csv   per-kernel Calls / Avg / Min / Max ns
