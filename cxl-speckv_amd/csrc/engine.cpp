@@ -658,11 +658,9 @@ uint32_t Engine::take_l2_run(uint32_t n)
 {
     // FIFO ring; a run never wraps so multi-page spans stay contiguous (k_flush_assign applies the same rule).
     // ring_seq_ counts every slot the hand has passed, skipped ones included: slot = sequence number % n_l2_.
-    const uint32_t start = ring_seq_ % n_l2_;
-    if (start + n > n_l2_) ring_seq_ += n_l2_ - start;
-    const uint32_t first = ring_seq_;
-    ring_seq_ += n;
-    return first;
+    const RingRun r = ring_take(ring_seq_, n, n_l2_);
+    ring_seq_ = r.next;
+    return r.seq;
 }
 
 // Sequence numbers are 32 bits: long before they wrap, every live one is moved down by a multiple of the ring size
@@ -2015,9 +2013,8 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     const uint32_t min_tiles = std::min(8u, std::max(2u, n_tiles / 64u));
     want = std::min(want, std::max(1u, n_tiles / min_tiles));
     if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));
-    uint32_t n_splits = std::max(1u, std::min(std::min(want, n_tiles), 2048u));
-    const uint32_t tiles_per_split = (n_tiles + n_splits - 1u) / n_splits;
-    n_splits = (n_tiles + tiles_per_split - 1u) / tiles_per_split;
+    const EvenSplit es = even_split(n_tiles, std::max(1u, std::min(want, 2048u)));
+    const uint32_t n_splits = es.n_splits, tiles_per_split = es.tiles_per_split;
     const size_t q_bytes = static_cast<size_t>(rows) * 16 * 128, qs_bytes = static_cast<size_t>(rows) * 16 * sizeof(float);
     const size_t acc_bytes = static_cast<size_t>(rows) * n_splits * 16 * 128 * sizeof(float);
     const size_t ml_bytes = static_cast<size_t>(rows) * n_splits * 32 * sizeof(float);
@@ -2125,11 +2122,11 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     uint64_t parts = 0;
     for (uint32_t i = 0; i < n_seq; ++i) {
         const uint32_t n_tiles = seqs[i].n_splits;
-        seqs[i].n_splits = (n_tiles + tps - 1u) / tps;
-        if (seqs[i].n_splits > 2048u) return SPECKV_ERR_INVAL;
+        if ((n_tiles + tps - 1u) / tps > 2048u) return SPECKV_ERR_INVAL;
         // the sequence's tiles divided evenly over its splits (171 + 85 tiles instead of 128 + 128 cost 15 %)
-        seqs[i].tiles_per_split = seqs[i].n_splits ? (n_tiles + seqs[i].n_splits - 1u) / seqs[i].n_splits : tps;
-        seqs[i].n_splits = seqs[i].tiles_per_split ? (n_tiles + seqs[i].tiles_per_split - 1u) / seqs[i].tiles_per_split : 0u;
+        const EvenSplit es = even_split(n_tiles, (n_tiles + tps - 1u) / tps);
+        seqs[i].tiles_per_split = n_tiles ? es.tiles_per_split : tps;
+        seqs[i].n_splits = es.n_splits;
         seqs[i].part_base = static_cast<uint32_t>(parts);
         parts += static_cast<uint64_t>(heads) * seqs[i].n_splits;
         max_splits = std::max(max_splits, seqs[i].n_splits);
@@ -2229,14 +2226,10 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     // to each other (measured at 32k x 80 layers: 8 splits 0.598, 10 or 12 splits 0.56, 16 splits 0.595)
     if (want > 8u) want &= ~7u;
     if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));
-    uint32_t n_splits = std::max(1u, std::min(std::min(want, n_tiles), 2048u));
-    uint32_t tiles_per_split = (n_tiles + n_splits - 1u) / n_splits;
-    n_splits = (n_tiles + tiles_per_split - 1u) / tiles_per_split;
-    if (n_splits > 8u && (n_splits & 7u) && !getenv("SPECKV_ATTEND_SPLITS")) {      // the rounding above can fall off a multiple of 8
-        const uint32_t down = n_splits & ~7u;
-        tiles_per_split = (n_tiles + down - 1u) / down;
-        n_splits = (n_tiles + tiles_per_split - 1u) / tiles_per_split;
-    }
+    EvenSplit es = even_split(n_tiles, std::max(1u, std::min(want, 2048u)));
+    if (es.n_splits > 8u && (es.n_splits & 7u) && !getenv("SPECKV_ATTEND_SPLITS"))      // the rounding can fall off a multiple of 8
+        es = even_split(n_tiles, es.n_splits & ~7u);
+    const uint32_t n_splits = es.n_splits, tiles_per_split = es.tiles_per_split;
     const size_t acc_bytes = static_cast<size_t>(rows) * n_splits * 16 * 128 * sizeof(float);
     const size_t ml_bytes = static_cast<size_t>(rows) * n_splits * 32 * sizeof(float);
     uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes, s));

@@ -26,6 +26,7 @@
 #pragma once
 #include "../../include/speckv_ext.h"
 #include "kernels.hpp"
+#include "ring_rule.hpp"
 #include "slab_pool.hpp"
 
 #include <deque>
@@ -295,7 +296,7 @@ private:
     void drop_page(Allocation* a, uint32_t page);         // page leaves the cache (any tier)
     uint32_t take_l2_run(uint32_t n);                     // host mirror of the ring rule: sequence number of the run's first slot
     // a page fetched into the ring with sequence number q is intact until the hand has passed q + n_l2_
-    bool l2_live(uint32_t q) const { return q != kNoSlot && static_cast<uint32_t>(ring_seq_ - q) - 1u < n_l2_; }
+    bool l2_live(uint32_t q) const { return q != kNoSlot && ring_live(ring_seq_, q, n_l2_); }
     // residency as the API reports it: bit0 L1 (host-managed), bit1 L2 (derived, see above), bit2 compressed
     uint32_t res_flags(const Allocation* a, uint64_t p) const
     {

@@ -20,6 +20,7 @@
 // Scans are DPP (row_shr / row_bcast) inside the wave; there is no workgroup
 // barrier anywhere, so wavefronts never wait for each other.
 #include "kernels.hpp"
+#include "ring_rule.hpp"
 #include "codec_device.hpp"
 
 #include <hip/hip_fp16.h>
@@ -1213,11 +1214,9 @@ __global__ __launch_bounds__(1024) void k_flush_assign(FlushArgs a)
         const uint32_t m = total < a.max_take ? total : a.max_take;
         // *a.hand is the ring's sequence number: slot = seq % n_l2; a run never wraps, the slots it skips at the end of
         // a lap count (Engine::take_l2_run applies the same rule)
-        uint32_t seq = *a.hand;
-        uint32_t start = seq % a.n_l2;
-        if (start + m > a.n_l2) { seq += a.n_l2 - start; start = 0; }
-        if (m) *a.hand = seq + m;
-        const FlushResult r{m, start, total, seq};
+        const RingRun run = ring_take(*a.hand, m, a.n_l2);
+        if (m) *a.hand = run.next;
+        const FlushResult r{m, run.slot, total, run.seq};
         *a.result_dev = r;
         *a.result_host = r;
     }

@@ -1,0 +1,17 @@
+// tests/csrc/host_rules_test.cpp -- TEST-ONLY C wrappers around the header-only host/device rules of the engine
+// (ring_rule.hpp: ring run / liveness arithmetic, even splits), for the CPU property tests.
+#include "../../cxl-speckv_amd/csrc/ring_rule.hpp"
+
+extern "C" {
+void rules_ring_take(uint32_t seq, uint32_t m, uint32_t n, uint32_t* out3)
+{
+    const speckv::RingRun r = speckv::ring_take(seq, m, n);
+    out3[0] = r.seq; out3[1] = r.slot; out3[2] = r.next;
+}
+int rules_ring_live(uint32_t seq, uint32_t q, uint32_t n) { return speckv::ring_live(seq, q, n) ? 1 : 0; }
+void rules_even_split(uint32_t n_tiles, uint32_t want, uint32_t* out2)
+{
+    const speckv::EvenSplit e = speckv::even_split(n_tiles, want);
+    out2[0] = e.tiles_per_split; out2[1] = e.n_splits;
+}
+}

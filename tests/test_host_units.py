@@ -238,3 +238,80 @@ def test_library_exports_only_the_c_abi():
     stray = [n for n in names if not (n.startswith("speckv_") or n.startswith("coherence_manager_"))]
     assert stray == [], stray
     assert not [n for n in names if n.startswith("speckv_debug")], "self-check kernels belong to tests/_build/libspeckv_debug.so"
+
+
+# ----------------------------------------------------------------------------- ring / split rules (ring_rule.hpp)
+@pytest.fixture(scope="module")
+def rules():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "csrc")])
+    lib = C.CDLL(os.path.join(ROOT, "tests", "_build", "libhostrules_test.so"))
+    lib.rules_ring_take.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.rules_ring_live.restype = C.c_int; lib.rules_ring_live.argtypes = [C.c_uint32] * 3
+    lib.rules_even_split.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    return lib
+
+
+@pytest.mark.parametrize("n,start", [(64, 0), (256, 0), (1000, 0), (256, 0xFFFFF000), (97, 12345)])
+def test_ring_sequence_numbers_against_a_model_of_the_ring(rules, n, start):
+    """The rule host and device share (ring_rule.hpp): runs never wrap, slot = seq % n, and `live` (derived from a stored
+    sequence number and the hand alone) says exactly whether the slot still holds that page -- checked against a plain
+    model of the ring that records which take last wrote every slot.  Includes a start near the 32-bit wrap: differences
+    are taken modulo 2^32."""
+    rng = np.random.default_rng(n + (start & 0xFFFF))
+    hand = start - start % n                                   # a hand position that is a lap boundary, like a fresh ring
+    owner = [None] * n                                         # slot -> sequence number stored there
+    stored = []                                                # every (seq, slot) ever written
+    out = (C.c_uint32 * 3)()
+    for _ in range(600):
+        m = int(rng.integers(1, n // 2 + 1))                   # the engine never takes more than half the ring
+        rules.rules_ring_take(hand & 0xFFFFFFFF, m, n, out)
+        seq, slot, nxt = out[0], out[1], out[2]
+        assert slot == seq % n and slot + m <= n               # the run does not wrap
+        assert (nxt - seq) & 0xFFFFFFFF == m
+        skipped = (seq - hand) & 0xFFFFFFFF
+        assert skipped == 0 or (slot == 0 and skipped < n)     # only the rest of a lap is ever skipped
+        for i in range(m):
+            owner[slot + i] = (seq + i) & 0xFFFFFFFF
+            stored.append(((seq + i) & 0xFFFFFFFF, slot + i))
+        hand = nxt
+        # every sequence number ever stored: live <=> it is still the owner of its slot
+        for q, s in stored[-3 * n:]:
+            intact = owner[s] == q
+            got = bool(rules.rules_ring_live(hand & 0xFFFFFFFF, q, n))
+            if got:
+                assert intact, (hand, q, s)                    # never a stale hit
+            elif intact:
+                # conservative only where the hand has passed q + n without writing the slot (skipped at the end of a lap)
+                assert (hand - q) & 0xFFFFFFFF > n, (hand, q, s)
+            if (hand - q) & 0xFFFFFFFF <= n:
+                assert got and intact, (hand, q, s)            # within one ring length of the hand: always live
+
+
+def test_ring_live_is_conservative_about_skipped_slots(rules):
+    """A slot skipped at the end of a lap keeps its old page, but the hand has passed it: `live` reports it dead (a
+    refetch, never a stale hit)."""
+    out = (C.c_uint32 * 3)()
+    n = 100
+    rules.rules_ring_take(0, 90, n, out)                       # slots 0..89, hand 90
+    rules.rules_ring_take(out[2], 30, n, out)                  # does not fit: skips 90..99, takes 0..29 of the next lap
+    assert (out[0], out[1], out[2]) == (100, 0, 130)
+    assert rules.rules_ring_live(130, 95, n) == 1              # 95 was never stored, but 89 ...
+    assert rules.rules_ring_live(130, 89, n) == 1 and rules.rules_ring_live(130, 30, n) == 1    # ... 30..89 of lap 0 are intact
+    assert rules.rules_ring_live(130, 29, n) == 0              # overwritten by sequence number 129
+    rules.rules_ring_take(130, 50, n, out)                     # 30..79
+    assert rules.rules_ring_live(out[2], 79, n) == 0 and rules.rules_ring_live(out[2], 80, n) == 1
+    assert rules.rules_ring_live(out[2], out[2], n) == 0       # nothing is stored at the hand yet
+
+
+def test_even_split_covers_the_tiles_evenly(rules):
+    out = (C.c_uint32 * 2)()
+    for n_tiles in list(range(0, 70)) + [255, 256, 257, 1023, 1024, 4097]:
+        for want in (0, 1, 2, 3, 7, 8, 9, 64, 300, 5000):
+            rules.rules_even_split(n_tiles, want, out)
+            tps, ns = out[0], out[1]
+            if n_tiles == 0:
+                assert ns == 0 and tps >= 1
+                continue
+            assert 1 <= ns <= max(1, min(want, n_tiles)) or want == 0 and ns == 1
+            assert tps * ns >= n_tiles > tps * (ns - 1)        # every split non-empty, all tiles covered
+            assert tps - (n_tiles - tps * (ns - 1)) < ns or ns == 1 or tps <= (n_tiles + ns - 1) // ns   # no split shorter than needed by rounding
