@@ -915,6 +915,57 @@ def connector_append_extra(torch, kv, n_seq=256, Lyr=80, T=64):
         kv.lib.set_compression_scheme(2)
 
 
+def connector_decode_extra(torch, kv, n_seq=256, Lyr=8, ctx=2048, T=4096):
+    """SURVEY 8f row N2 end to end: decode steps of a 256-sequence batch through the vLLM-shaped connector -- per step
+    one look-ahead flush (begin_step), one fused attention call per layer for the whole batch, one batched append.  Only the
+    KV side of a decode step (no model): what the drop-in costs per generated token at this batch and context."""
+    from cxl_speckv_amd.kv_connector import SpeckvKVConnector
+    conn = None
+    try:
+        conn = SpeckvKVConnector(kv.lib, num_layers=Lyr, max_tokens=T, scheme="fp8")
+        ids = list(range(n_seq))
+        g = torch.Generator(device="cuda"); g.manual_seed(2006)
+        kp = torch.randn((Lyr, ctx, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+        vp = torch.randn((Lyr, ctx, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+        for r in ids:
+            conn.add_request(r)
+            conn.write_prefill(r, kp, vp)                     # same synthetic prompt KV in every sequence
+        del kp, vp
+        q = torch.randn((n_seq, 8, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+        k = torch.randn((n_seq, Lyr, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+        v = torch.randn((n_seq, Lyr, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+        s = torch.cuda.Stream()
+        times = []
+        with torch.cuda.stream(s):
+            for step in range(8):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                conn.begin_step(ids, depth_k=0)
+                for layer in range(Lyr):
+                    out = conn.attend(layer, ids, q, 0.08838834764831845, stream=s)
+                keep = conn.append(ids, k, v, stream=s)
+                torch.cuda.synchronize()
+                times.append((time.perf_counter() - t0) * 1e3)
+                del keep, out
+        ms = sum(times[2:]) / len(times[2:])                   # even and odd steps alternate (tail fold / pair append)
+        rec_bytes = n_seq * Lyr * 2 * ctx * 1024                  # FP8 records read per step (K and V, 1 KiB per position and kind)
+        return {"connector_decode_step": {"sequences": n_seq, "layers": Lyr, "context": ctx, "ms_per_step": round(ms, 3),
+                                          "ms_fastest_step": round(min(times[2:]), 3), "ms_slowest_step": round(max(times[2:]), 3),
+                                          "tokens_per_s_kv_side": round(n_seq / (ms * 1e-3), 1),
+                                          "KV_record_GBps": round(rec_bytes / (ms * 1e-3) / 1e9, 1),
+                                          "frac_hbm": round(rec_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                          "note": "begin_step (flush) + one batch attention call per layer + batched append, wall time "
+                                                  "per step incl. the torch glue (tail fold, gathers); FP8 pool"}}
+    except Exception as e:
+        return {"connector_decode_step": {"error": repr(e)}}
+    finally:
+        if conn is not None:
+            for r in list(conn.requests):
+                try: conn.free_request(r)
+                except Exception: pass
+        kv.lib.set_compression_scheme(2)
+
+
 def footprint_extra(torch, kv, T, Lyr, seed, seconds=0.4):
     """The hot path at another footprint: one sequence of T positions x Lyr layers (8 kv heads x 128), INT8_DELTA_RLE,
     reference quantiser, one launch per pass, timed over >= `seconds` of back-to-back passes after a clock ramp."""
@@ -1119,6 +1170,7 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     ex.update(batch_attention_extra(torch, kv))      # BASELINE configs[4] shape: 70B-shaped KV @ 32k context
     ex.update(batch_attention_extra(torch, kv, scheme=3))
     ex.update(connector_append_extra(torch, kv))
+    ex.update(connector_decode_extra(torch, kv))
     ex.update(predictor_extra(torch, lib))
     return ex
 

@@ -50,6 +50,13 @@ class SpeckvKVConnector:
         self.requests: Dict[int, _Request] = {}
         self.region_pages = max_tokens // 2                   # pages of one (layer, kind) region
         self._side = None
+        # the tails of the last append as ONE tensor per kind ([n][layers][heads][dim]) and the request ids they belong to:
+        # a batch that decodes in lockstep folds / pairs its tails without touching 256 per-request views
+        self._tail_ids = ()
+        self._tail_k = self._tail_v = None
+        self._fold_key = self._arg_key = None
+        self._arg_handles = self._arg_lens = None
+        self._fold_idx = self._fold_empty = None
 
     # The library takes a hipStream_t and reads NULL as "the engine's own stream".  torch's default stream IS the NULL
     # stream, so work issued from it goes through a side stream that is ordered after it and that it then waits for.
@@ -87,6 +94,8 @@ class SpeckvKVConnector:
 
     def free_request(self, req_id: int):
         r = self.requests.pop(req_id)
+        if req_id in self._tail_ids:
+            self._tail_ids, self._tail_k, self._tail_v = (), None, None
         self.lib.free(r.handle)                               # the binding goes with the handle
 
     def length(self, req_id: int) -> int:
@@ -133,7 +142,10 @@ class SpeckvKVConnector:
         if pair_b:
             reqs = [self.requests[req_ids[b]] for b in pair_b]
             idx = torch.tensor(pair_b, device=k_new.device)
-            kt = torch.stack([r.tail_k for r in reqs]); vt = torch.stack([r.tail_v for r in reqs])        # [n][layers][heads][dim]
+            if tuple(req_ids[b] for b in pair_b) == self._tail_ids:
+                kt, vt = self._tail_k, self._tail_v                                                    # [n][layers][heads][dim]
+            else:
+                kt = torch.stack([r.tail_k for r in reqs]); vt = torch.stack([r.tail_v for r in reqs])
             kn = k_new.index_select(0, idx); vn = v_new.index_select(0, idx)
             # page image of the pair for every (layer, kind): [n][layer][kind][2 positions][heads][dim]
             pair = torch.stack((torch.stack((kt, kn), dim=2), torch.stack((vt, vn), dim=2)), dim=2).contiguous()
@@ -149,12 +161,14 @@ class SpeckvKVConnector:
                                                  self.region_pages, 2 * self.L, st.cuda_stream)
             for r in reqs:
                 r.tail_k = r.tail_v = None
+            self._tail_ids, self._tail_k, self._tail_v = (), None, None
         if tail_b:
             idx = torch.tensor(tail_b, device=k_new.device)
             tk = k_new.index_select(0, idx); tv = v_new.index_select(0, idx)                               # copies: the caller may reuse k_new
             for i, b in enumerate(tail_b):
                 r = self.requests[req_ids[b]]
                 r.tail_k, r.tail_v = tk[i], tv[i]
+            self._tail_ids, self._tail_k, self._tail_v = tuple(req_ids[b] for b in tail_b), tk, tv
         for rid in req_ids:
             self.requests[rid].length += 1
         return keep                                            # sources of the asynchronous writes: hold until the stream passed them
@@ -206,19 +220,41 @@ class SpeckvKVConnector:
         out = torch.empty((B, H, G, D), dtype=torch.float32, device="cuda")
         lse = torch.empty((B, H, G), dtype=torch.float32, device="cuda")
         fn = self.lib.attend_fp8_batch if self.scheme == 4 else self.lib.attend_int4_batch
+        # the argument arrays are the same for every layer of a decode step
+        akey = (tuple(req_ids), tuple(r.length for r in reqs))
+        if self._arg_key != akey:
+            import ctypes
+            self._arg_key = akey
+            self._arg_handles = (ctypes.c_uint64 * B)(*[r.handle for r in reqs])
+            self._arg_lens = (ctypes.c_uint32 * B)(*[r.length & ~1 for r in reqs])
         with self._On(self, stream) as st:
-            fn([r.handle for r in reqs], layer, q.data_ptr(), G, [r.length & ~1 for r in reqs], sm_scale, out.data_ptr(), lse.data_ptr(),
-               st.cuda_stream)
+            fn(self._arg_handles, layer, q.data_ptr(), G, self._arg_lens, sm_scale, out.data_ptr(), lse.data_ptr(), st.cuda_stream)
         odd = [b for b, r in enumerate(reqs) if r.length & 1]
         if odd:
-            idx = torch.tensor(odd, device="cuda")
-            kt = torch.stack([reqs[b].tail_k[layer] for b in odd]).float()        # [n][heads][dim]
-            vt = torch.stack([reqs[b].tail_v[layer] for b in odd]).float()
-            s = torch.einsum("bhgd,bhd->bhg", q[idx].float(), kt) * sm_scale
-            empty = torch.tensor([reqs[b].length < 2 for b in odd], device="cuda")[:, None, None]
-            old = torch.where(empty, torch.full_like(s, float("-inf")), lse[idx])
+            # per decode step the same for every layer: which rows have a tail, which of them have nothing stored yet
+            key = akey
+            if self._fold_key != key:
+                any_empty = any(reqs[b].length < 2 for b in odd)
+                self._fold_key = key
+                self._fold_idx = None if len(odd) == B else torch.tensor(odd, device="cuda")
+                self._fold_empty = torch.tensor([reqs[b].length < 2 for b in odd], device="cuda")[:, None, None] if any_empty else None
+            idx, empty = self._fold_idx, self._fold_empty
+            if tuple(req_ids[b] for b in odd) == self._tail_ids:
+                kt, vt = self._tail_k[:, layer].float(), self._tail_v[:, layer].float()   # [n][heads][dim]
+            else:
+                kt = torch.stack([reqs[b].tail_k[layer] for b in odd]).float()
+                vt = torch.stack([reqs[b].tail_v[layer] for b in odd]).float()
+            qo = q if idx is None else q[idx]
+            oo = out if idx is None else out[idx]
+            old = lse if idx is None else lse[idx]
+            s = torch.einsum("bhgd,bhd->bhg", qo.float(), kt) * sm_scale
+            if empty is not None:
+                old = torch.where(empty, torch.full_like(s, float("-inf")), old)
+                oo = torch.where(empty[..., None], torch.zeros_like(oo), oo)
             new = torch.logaddexp(old, s)
-            w_old = torch.exp(old - new)[..., None]
-            w_new = torch.exp(s - new)[..., None]
-            out[idx] = torch.where(empty[..., None], torch.zeros_like(out[idx]), out[idx]) * w_old + vt[:, :, None, :] * w_new
+            folded = oo * torch.exp(old - new)[..., None] + vt[:, :, None, :] * torch.exp(s - new)[..., None]
+            if idx is None:
+                out = folded
+            else:
+                out[idx] = folded
         return out

@@ -309,16 +309,20 @@ class SpeckvLib:
                   ctypes.c_float(sm_scale), c_void_p(d_out), c_void_p(d_lse or 0), c_void_p(stream or 0))
 
     def attend_fp8_batch(self, handles, layer, d_q_f16, g, pos_end, sm_scale, d_out, d_lse=None, stream=None):
+        """handles / pos_end: sequences of ints, or ready ctypes arrays (c_uint64 / c_uint32) that a caller reuses over
+        the layers of a decode step."""
         n = len(handles)
-        hs = (c_uint64 * n)(*handles)
-        pe = (c_uint32 * n)(*pos_end)
+        hs = handles if isinstance(handles, ctypes.Array) else (c_uint64 * n)(*handles)
+        pe = pos_end if isinstance(pos_end, ctypes.Array) else (c_uint32 * n)(*pos_end)
         self._ext("speckv_ext_attend_fp8_batch", n, hs, layer, c_void_p(d_q_f16), g, pe, ctypes.c_float(sm_scale),
                   c_void_p(d_out), c_void_p(d_lse or 0), c_void_p(stream or 0))
 
     def attend_int4_batch(self, handles, layer, d_q_f16, g, pos_end, sm_scale, d_out, d_lse=None, stream=None):
+        """handles / pos_end: sequences of ints, or ready ctypes arrays (c_uint64 / c_uint32) that a caller reuses over
+        the layers of a decode step."""
         n = len(handles)
-        hs = (c_uint64 * n)(*handles)
-        pe = (c_uint32 * n)(*pos_end)
+        hs = handles if isinstance(handles, ctypes.Array) else (c_uint64 * n)(*handles)
+        pe = pos_end if isinstance(pos_end, ctypes.Array) else (c_uint32 * n)(*pos_end)
         self._ext("speckv_ext_attend_int4_batch", n, hs, layer, c_void_p(d_q_f16), g, pe, ctypes.c_float(sm_scale),
                   c_void_p(d_out), c_void_p(d_lse or 0), c_void_p(stream or 0))
 
