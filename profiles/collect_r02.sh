@@ -5,6 +5,7 @@ R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 cd /tmp
 OUT=$R/gpurun_out/${1:-prof_r02}
+rm -rf $OUT
 mkdir -p $OUT
 # 1. the bench as the driver calls it (as-called figure only: W warm-ups + K steps) and the full default bench
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_ascalled -- python3 $R/bench.py --steps 20 --warmup 5 --no-variants --no-extras --no-cpu-baseline > $OUT/bench_ascalled.json 2> $OUT/trace_ascalled.log

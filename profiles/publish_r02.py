@@ -53,6 +53,6 @@ one_line(os.path.join(g, bench2), os.path.join(P, f"{tag}_bench_2ranks_one_gpu.j
 if drv:
     one_line(os.path.join(g, drv), os.path.join(P, f"{tag}_bench_driver_cmd.json"))
 for t in ("ascalled", "full"):
-    f = glob.glob(os.path.join(g, prof, f"trace_{t}", "**", "*kernel_stats.csv"), recursive=True)
-    shutil.copy(f[0], os.path.join(P, f"{tag}_kernel_stats_{t}.csv"))
+    f = sorted(glob.glob(os.path.join(g, prof, f"trace_{t}", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    shutil.copy(f[-1], os.path.join(P, f"{tag}_kernel_stats_{t}.csv"))      # the newest, should an older run's output remain
 print("published", tag)
