@@ -336,6 +336,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint32_t head = (blockIdx.y % hq) * 4u + wave;
     const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;  // query / output row block
     uint64_t part = row * a.n_splits + split;
+    uint32_t my_splits = a.n_splits;
     if (a.seqs) {                                                        // wave-uniform: per-sequence geometry
         const AttendSeq sq = a.seqs[layer];
         if (split >= sq.n_splits) return;
@@ -345,6 +346,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         a.v_first = sq.v_first;
         a.n_pages = sq.n_pages;
         a.tiles_per_split = sq.tiles_per_split;
+        a.k_first += static_cast<uint64_t>(a.batch_layer) * sq.layer_pages;
+        a.v_first += static_cast<uint64_t>(a.batch_layer) * sq.layer_pages;
+        my_splits = sq.n_splits;
         part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
         layer = 0;
     }
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     // ---- partial result of this split, back in true units (or, single split: the final result)
     const float l_tot = sum_over_kb(l_run);
-    if (a.direct_out) {
+    if (a.direct_out && (!a.direct_per_seq || my_splits == 1u)) {
         if (c < a.g) {
             const float w = l_tot > 0.0f ? vref / l_tot : 0.0f;
             float* dst = a.direct_out + (row * a.g + c) * 128u + 32u * kb;
@@ -600,6 +604,7 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
     const uint32_t head = (blockIdx.y % hq) * kFdHeads + wave;
     const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;  // query / output row block
     uint64_t part = row * a.n_splits + split;
+    uint32_t my_splits = a.n_splits;
     if (a.seqs) {                                                        // wave-uniform: per-sequence geometry
         const AttendSeq sq = a.seqs[layer];
         if (split >= sq.n_splits) return;
@@ -609,6 +614,9 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
         a.v_first = sq.v_first;
         a.n_pages = sq.n_pages;
         a.tiles_per_split = sq.tiles_per_split;
+        a.k_first += static_cast<uint64_t>(a.batch_layer) * sq.layer_pages;
+        a.v_first += static_cast<uint64_t>(a.batch_layer) * sq.layer_pages;
+        my_splits = sq.n_splits;
         part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
         layer = 0;
     }
@@ -756,7 +764,7 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
     }
     // ---- partial result of this split, back in true units (or, single split: the final result)
     const float l_tot = sum_over_kb(l_run);
-    if (a.direct_out) {
+    if (a.direct_out && (!a.direct_per_seq || my_splits == 1u)) {
         if (c < a.g) {
             const float w = l_tot > 0.0f ? vref / l_tot : 0.0f;
             float* dst = a.direct_out + (row * a.g + c) * 128u + 32u * kb;
@@ -792,7 +800,7 @@ constexpr uint32_t kMaxSplits = 2048;
 __global__ __launch_bounds__(512) void k_attend_combine(const float* __restrict__ part_acc, const float* __restrict__ part_ml,
                                                         uint32_t g, uint32_t n_splits, float* __restrict__ out,
                                                         float* __restrict__ lse, const AttendSeq* __restrict__ seqs,
-                                                        uint32_t heads)
+                                                        uint32_t heads, uint32_t skip_single)
 {
     __shared__ float w[kMaxSplits];
     __shared__ float red[8];
@@ -802,6 +810,7 @@ __global__ __launch_bounds__(512) void k_attend_combine(const float* __restrict_
     uint64_t part0 = static_cast<uint64_t>(rowq) * n_splits;           // first partial of this (layer | sequence, head)
     if (seqs) {
         const AttendSeq sq = seqs[rowq / heads];
+        if (skip_single && sq.n_splits == 1u) return;        // written by the attention kernel itself (workgroup-uniform)
         n_splits = sq.n_splits;
         part0 = sq.part_base + static_cast<uint64_t>(rowq % heads) * n_splits;
     }
@@ -952,7 +961,53 @@ hipError_t launch_attend_combine(const AttendArgs& a, uint32_t n_layers, float* 
     if (n_layers == 0) return hipSuccess;
     if (a.n_splits > kMaxSplits) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_attend_combine, dim3(n_layers * a.heads * a.g), dim3(512), 0, s, a.part_acc, a.part_ml, a.g,
-                       a.n_splits, d_out, d_lse, a.seqs, a.heads);
+                       a.n_splits, d_out, d_lse, a.seqs, a.heads, (a.direct_out && a.direct_per_seq) ? 1u : 0u);
+    return hipGetLastError();
+}
+
+// One more position for rows that already hold softmax(q.K^T).V and its log-sum-exp: the fp16 K / V row a decode step
+// has produced but not yet stored (a connector keeps the odd position of a pair until its partner arrives).
+//   s = q.k * sm_scale;  new = logaddexp(lse, s);  out = out * exp(lse - new) + v * exp(s - new);  lse = new
+// One wave per (row, kv head, query row), a lane holds two of the 128 dimensions.  A row without stored positions comes
+// in as out = 0, lse = -inf and leaves as out = v, lse = s.
+__global__ __launch_bounds__(256) void k_attend_fold_tail(uint32_t n_waves, const uint32_t* __restrict__ rows, uint32_t heads, uint32_t g,
+                                                          const f16x2* __restrict__ q, const f16x2* __restrict__ k_tail,
+                                                          const f16x2* __restrict__ v_tail, uint64_t tail_stride_h2, float sm_scale,
+                                                          float2* __restrict__ out, float* __restrict__ lse)
+{
+    const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (w >= n_waves) return;
+    const uint32_t m = w % g, head = (w / g) % heads, i = w / (g * heads);
+    const uint32_t b = rows ? rows[i] : i;
+    const uint64_t row = (static_cast<uint64_t>(b) * heads + head) * g + m;
+    const f16x2 qh = q[row * 64u + lane], kh = k_tail[i * tail_stride_h2 + head * 64u + lane], vh = v_tail[i * tail_stride_h2 + head * 64u + lane];
+    const float2 qv = make_float2(static_cast<float>(qh.x), static_cast<float>(qh.y));
+    const float2 kv = make_float2(static_cast<float>(kh.x), static_cast<float>(kh.y));
+    const float2 vv = make_float2(static_cast<float>(vh.x), static_cast<float>(vh.y));
+    float dot = qv.x * kv.x + qv.y * kv.y;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    const float sc = dot * sm_scale, old = lse[row];
+    const float hi = fmaxf(old, sc);
+    const float e_old = __expf(old - hi), e_new = __expf(sc - hi);          // old = -inf: e_old = 0
+    const float inv = 1.0f / (e_old + e_new);
+    float2 o = out[row * 64u + lane];
+    o.x = (o.x * e_old + vv.x * e_new) * inv;
+    o.y = (o.y * e_old + vv.y * e_new) * inv;
+    out[row * 64u + lane] = o;
+    if (lane == 0) lse[row] = hi + __logf(e_old + e_new);
+}
+
+hipError_t launch_attend_fold_tail(uint32_t n_rows, const uint32_t* d_rows, uint32_t heads, uint32_t g, const void* d_q_f16,
+                                   const void* d_k_tail, const void* d_v_tail, uint64_t tail_stride_elems, float sm_scale,
+                                   float* d_out, float* d_lse, hipStream_t s)
+{
+    const uint64_t n_waves = static_cast<uint64_t>(n_rows) * heads * g;
+    if (n_waves == 0) return hipSuccess;
+    if (n_waves > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_attend_fold_tail, dim3(static_cast<uint32_t>((n_waves + 3u) / 4u)), dim3(256), 0, s, static_cast<uint32_t>(n_waves),
+                       d_rows, heads, g, static_cast<const f16x2*>(d_q_f16), static_cast<const f16x2*>(d_k_tail),
+                       static_cast<const f16x2*>(d_v_tail), tail_stride_elems / 2u, sm_scale, reinterpret_cast<float2*>(d_out), d_lse);
     return hipGetLastError();
 }
 
@@ -968,7 +1023,7 @@ hipError_t launch_attend_fp8_batch(const AttendArgs& a, uint32_t n_seq, float* d
     hipLaunchKernelGGL(k_attend_fp8_linear, dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
 #endif
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || a.direct_out) return e;
+    if (e != hipSuccess || (a.direct_out && !a.direct_per_seq)) return e;
     return launch_attend_combine(a, n_seq, d_out, d_lse, s);
 }
 

@@ -239,10 +239,10 @@ __device__ __forceinline__ void pv_tile(const uint32_t (&vw)[8], const uint32_t 
 }
 
 // the split's partial result: running maximum, sum and the un-normalised accumulators
-__device__ __forceinline__ void store_partial(const AttendArgs& a, uint64_t part, uint64_t row, uint32_t c, uint32_t kb, float m_run, float l_run, const f32x4 (&acc)[8])
+__device__ __forceinline__ void store_partial(const AttendArgs& a, uint64_t part, uint64_t row, uint32_t my_splits, uint32_t c, uint32_t kb, float m_run, float l_run, const f32x4 (&acc)[8])
 {
     const float l_tot = sum_over_kb(l_run);
-    if (a.direct_out) {                               // single split per row: the final result (AttendArgs::direct_out)
+    if (a.direct_out && (!a.direct_per_seq || my_splits == 1u)) {                               // single split per row: the final result (AttendArgs::direct_out)
         if (c < a.g) {
             const float w = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
             float* dst = a.direct_out + (row * a.g + c) * 128u + 32u * kb;
@@ -294,6 +294,7 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
     const uint32_t head = (blockIdx.y % hq) * kWgHeads + wave;
     const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;
     uint64_t part = row * a.n_splits + split;
+    uint32_t my_splits = a.n_splits;
     if (a.seqs) {                                                        // wave-uniform: per-sequence geometry
         const AttendSeq sq = a.seqs[layer];
         if (split >= sq.n_splits) return;
@@ -302,6 +303,9 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
         a.v_first = sq.v_first;
         a.n_pages = sq.n_pages;
         a.tiles_per_split = sq.tiles_per_split;
+        a.k_first += static_cast<uint64_t>(a.batch_layer) * sq.layer_pages;
+        a.v_first += static_cast<uint64_t>(a.batch_layer) * sq.layer_pages;
+        my_splits = sq.n_splits;
         part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
         layer = 0;
     }
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    store_partial(a, part, row, c, kb, m_run, l_run, acc);
+    store_partial(a, part, row, my_splits, c, kb, m_run, l_run, acc);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -509,6 +513,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const uint32_t head = head0 + wave;
     const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;
     uint64_t part = row * a.n_splits + split;
+    uint32_t my_splits = a.n_splits;
     if (a.seqs) {                                                        // workgroup-uniform: per-sequence geometry
         const AttendSeq sq = a.seqs[layer];
         if (split >= sq.n_splits) return;
@@ -517,6 +522,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         a.v_first = sq.v_first;
         a.n_pages = sq.n_pages;
         a.tiles_per_split = sq.tiles_per_split;
+        a.k_first += static_cast<uint64_t>(a.batch_layer) * sq.layer_pages;
+        a.v_first += static_cast<uint64_t>(a.batch_layer) * sq.layer_pages;
+        my_splits = sq.n_splits;
         part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
         layer = 0;
         a.big_flag = sq.big_flag;
@@ -624,7 +632,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (big_any) tiles(std::true_type{});
         else         tiles(std::false_type{});
     }
-    store_partial(a, part, row, c, kb, m_run, l_run, acc);
+    store_partial(a, part, row, my_splits, c, kb, m_run, l_run, acc);
 }
 
 hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_t s)

@@ -376,6 +376,48 @@ speckv_status_t speckv_ext_attend_int4_batch(uint32_t n_seq, const speckv_handle
     });
 }
 
+speckv_status_t speckv_ext_attend_batch_plan(uint32_t n_seq, const speckv_handle_t* handles, const uint32_t* pos_end,
+                                             uint32_t max_pos_end, void* d_plan, size_t plan_bytes, void* stream)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] {
+        return g_engine->attend_batch_plan(n_seq, handles, pos_end, max_pos_end, d_plan, plan_bytes, static_cast<hipStream_t>(stream));
+    });
+}
+
+size_t speckv_ext_attend_plan_bytes(uint32_t n_seq) { return static_cast<size_t>(n_seq) * sizeof(speckv::AttendSeq); }
+
+speckv_status_t speckv_ext_attend_fp8_planned(const void* d_plan, uint32_t n_seq, uint32_t layer, const void* d_q_f16, uint32_t g,
+                                              uint32_t max_pos_end, float sm_scale, float* d_out, float* d_lse, void* stream)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] {
+        return g_engine->attend_planned(SPECKV_COMP_FP8_E4M3, d_plan, n_seq, layer, d_q_f16, g, max_pos_end, sm_scale, d_out, d_lse,
+                                        static_cast<hipStream_t>(stream));
+    });
+}
+
+speckv_status_t speckv_ext_attend_int4_planned(const void* d_plan, uint32_t n_seq, uint32_t layer, const void* d_q_f16, uint32_t g,
+                                               uint32_t max_pos_end, float sm_scale, float* d_out, float* d_lse, void* stream)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] {
+        return g_engine->attend_planned(SPECKV_COMP_INT4_G32, d_plan, n_seq, layer, d_q_f16, g, max_pos_end, sm_scale, d_out, d_lse,
+                                        static_cast<hipStream_t>(stream));
+    });
+}
+
+speckv_status_t speckv_ext_attend_fold_tail(uint32_t n_rows, const uint32_t* d_rows, uint32_t heads, uint32_t g, const void* d_q_f16,
+                                            const void* d_k_tail, const void* d_v_tail, uint64_t tail_stride_elems, float sm_scale,
+                                            float* d_out, float* d_lse, void* stream)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] {
+        return g_engine->attend_fold_tail(n_rows, d_rows, heads, g, d_q_f16, d_k_tail, d_v_tail, tail_stride_elems, sm_scale, d_out, d_lse,
+                                          static_cast<hipStream_t>(stream));
+    });
+}
+
 speckv_status_t speckv_ext_attend_int4(speckv_handle_t handle, uint32_t layer_begin, uint32_t n_layers, const void* d_q_f16,
                                        uint32_t g, uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out,
                                        float* d_lse, void* stream)

@@ -2057,6 +2057,16 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
 // Not capturable into a HIP graph: the per-call descriptors travel through a pinned slot that later calls reuse, so a
 // replay would read other calls' descriptors -- the call refuses to run on a capturing stream (the per-sequence
 // entry points speckv_ext_attend_fp8 / _int4 are capturable).
+// Split length of a batch launch (see the measurements quoted in attend_batch).
+static uint32_t batch_tiles_per_split(bool fp8, uint32_t n_seq, uint32_t heads, uint64_t total_tiles)
+{
+    const uint64_t wg_target = fp8 ? 512u : 768u;
+    uint32_t tps = static_cast<uint32_t>(std::max<uint64_t>(8, (total_tiles * (heads / 4u) + wg_target - 1u) / wg_target));
+    if (!fp8) tps = (static_cast<uint64_t>(n_seq) * (heads / 4u) >= 384u) ? 256u : std::min(tps, 256u);   // enough columns: whole sequences
+    if (const char* env = getenv("SPECKV_ATTEND_TILES_PER_SPLIT")) tps = std::max(1, atoi(env));
+    return tps;
+}
+
 int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, uint32_t layer, const void* d_q_f16, uint32_t g,
                          const uint32_t* pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
 {
@@ -2094,6 +2104,7 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
         seqs[i].k_first = static_cast<uint64_t>(layer) * L.num_tokens;       // (layer*2*T)/2
         seqs[i].v_first = seqs[i].k_first + L.num_tokens / 2;
         seqs[i].n_pages = n_pages;
+        seqs[i].layer_pages = L.num_tokens;                                   // K + V pages of one layer
         seqs[i].n_splits = n_tiles;                                           // tiles for now, splits below
         total_tiles += n_tiles;
     }
@@ -2114,10 +2125,7 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     // INT4 (arithmetic-bound kernel): splits longer than 256 tiles stop paying (256 sequences x 32k: 256 tiles per split
     // 0.67, 512: 0.65, 1024 = no split: 0.60), shorter sequences are best left whole (8k 0.63 against 0.59 in two
     // splits, 4k 0.60 / 0.52, 2k 0.58 / 0.43: single-split rows are final, no partials and no merge).
-    const uint64_t wg_target = fp8 ? 512u : 768u;
-    uint32_t tps = static_cast<uint32_t>(std::max<uint64_t>(8, (total_tiles * (heads / 4u) + wg_target - 1u) / wg_target));
-    if (!fp8) tps = (static_cast<uint64_t>(n_seq) * (heads / 4u) >= 384u) ? 256u : std::min(tps, 256u);   // enough columns: whole sequences
-    if (const char* env = getenv("SPECKV_ATTEND_TILES_PER_SPLIT")) tps = std::max(1, atoi(env));
+    const uint32_t tps = batch_tiles_per_split(fp8, n_seq, heads, total_tiles);
     uint32_t max_splits = 0;
     uint64_t parts = 0;
     for (uint32_t i = 0; i < n_seq; ++i) {
@@ -2174,6 +2182,148 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
         HIP_TRY(launch_attend_int4(k, n_seq, st));        // grid y = sequences x head groups, as for layers
         if (!k.direct_out) HIP_TRY(launch_attend_combine(k, n_seq, d_out, d_lse, st));
     }
+    if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+    return SPECKV_OK;
+}
+
+// ---- planned batches: descriptors resident on the device, the launches capturable ---------------------------------------
+// A decode step under a HIP graph replays the same launches with new sequence lengths.  speckv_ext_attend_batch_plan
+// (outside the graph, once per step) writes one descriptor per sequence -- valid for every layer -- into a device buffer
+// of the caller; speckv_ext_attend_*_planned is kernel launches only: no handle look-ups, no staging, grid and scratch
+// sized from max_pos_end alone, so a captured launch stays valid for as long as the lengths stay within that bound.
+struct PlanGeometry { uint32_t tps, max_splits; uint64_t parts_bound; };
+static PlanGeometry plan_geometry(bool fp8, uint32_t n_seq, uint32_t heads, uint32_t max_pos_end)
+{
+    const uint32_t tiles_max = (max_pos_end / 2u + 15u) / 16u;
+    PlanGeometry g{};
+    g.tps = batch_tiles_per_split(fp8, n_seq, heads, static_cast<uint64_t>(tiles_max) * n_seq);
+    g.max_splits = std::max(1u, (tiles_max + g.tps - 1u) / g.tps);
+    g.parts_bound = static_cast<uint64_t>(n_seq) * heads * g.max_splits;
+    return g;
+}
+
+int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uint32_t* pos_end, uint32_t max_pos_end,
+                              void* d_plan, size_t plan_bytes, hipStream_t s)
+{
+    if (null_) return no_data_path("speckv_ext_attend_batch_plan");
+    if (n_seq == 0) return SPECKV_OK;
+    if (!handles || !pos_end || !d_plan || !s || max_pos_end % 2 || plan_bytes < n_seq * sizeof(AttendSeq)) return SPECKV_ERR_INVAL;
+    if (is_capturing(s)) return SPECKV_ERR_INVAL;            // the plan is what changes between replays: it stays outside the graph
+    std::vector<AttendSeq> seqs(n_seq);
+    int scheme = -1;
+    uint32_t heads = 0, min_layers = UINT32_MAX;
+    for (uint32_t i = 0; i < n_seq; ++i) {
+        Allocation* a = find(handles[i]);
+        if (!a) return SPECKV_ERR_GENERAL;
+        if (scheme < 0) scheme = a->scheme;
+        if (!a->has_layout || a->scheme != scheme || (scheme != SPECKV_COMP_FP8_E4M3 && scheme != SPECKV_COMP_INT4_G32)) return SPECKV_ERR_INVAL;
+        const Layout& L = a->layout;
+        if (L.head_dim != 128 || L.bytes_per_element != 2 || L.num_heads * L.head_dim != 1024 || L.num_tokens % 2) return SPECKV_ERR_INVAL;
+        if (pos_end[i] % 2 || pos_end[i] > L.num_tokens || pos_end[i] > max_pos_end) return SPECKV_ERR_INVAL;
+        const uint32_t n_pages = pos_end[i] / 2, n_tiles = (n_pages + 15u) / 16u;
+        const bool fp8 = scheme == SPECKV_COMP_FP8_E4M3;
+        if (!a->linear_base || (fp8 && !a->d_scale_tab) || static_cast<uint64_t>(n_tiles) * 32u > L.num_tokens) return SPECKV_ERR_INVAL;
+        min_layers = std::min(min_layers, L.num_layers);
+        heads = L.num_heads;
+        note_use(a, s);
+        seqs[i].lin_base = a->linear_base;
+        seqs[i].big_flag = a->d_int4_big;
+        seqs[i].scale_tab = a->d_scale_tab;
+        seqs[i].k_first = 0;                                   // layer 0; the launch adds layer * layer_pages
+        seqs[i].v_first = L.num_tokens / 2;
+        seqs[i].layer_pages = L.num_tokens;
+        seqs[i].n_pages = n_pages;
+        seqs[i].n_splits = n_tiles;
+    }
+    const PlanGeometry g = plan_geometry(scheme == SPECKV_COMP_FP8_E4M3, n_seq, heads, max_pos_end);
+    if (g.max_splits > 2048u) return SPECKV_ERR_INVAL;
+    if (plans_.size() >= 64 && !plans_.count(d_plan)) plans_.clear();        // (buffers of long-gone steps)
+    plans_[d_plan] = PlanInfo{n_seq, scheme, min_layers, max_pos_end};
+    uint64_t parts = 0;
+    for (uint32_t i = 0; i < n_seq; ++i) {
+        const uint32_t n_tiles = seqs[i].n_splits;
+        const EvenSplit es = even_split(n_tiles, (n_tiles + g.tps - 1u) / g.tps);
+        seqs[i].tiles_per_split = n_tiles ? es.tiles_per_split : g.tps;
+        seqs[i].n_splits = es.n_splits;
+        seqs[i].part_base = static_cast<uint32_t>(parts);
+        parts += static_cast<uint64_t>(heads) * seqs[i].n_splits;
+    }
+    DeviceScope device_scope(device_);
+    const size_t seq_bytes = seqs.size() * sizeof(AttendSeq);
+    if (seq_ring_.slot_bytes < seq_bytes) {
+        if (seq_ring_.base) { HIP_TRY(hipDeviceSynchronize()); (void)hipHostFree(seq_ring_.base); seq_ring_.base = nullptr; }
+        seq_ring_.slot_bytes = std::max<size_t>(seq_bytes * 2, 16384);
+        HIP_TRY(hipHostMalloc(&seq_ring_.base, seq_ring_.slot_bytes * 4, hipHostMallocDefault));
+        for (auto& ev : seq_ring_.ev)
+            if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const int slot = seq_ring_.next;
+    seq_ring_.next = (slot + 1) & 3;
+    HIP_TRY(hipEventSynchronize(seq_ring_.ev[slot]));
+    void* staged = static_cast<uint8_t*>(seq_ring_.base) + static_cast<size_t>(slot) * seq_ring_.slot_bytes;
+    memcpy(staged, seqs.data(), seq_bytes);
+    HIP_TRY(hipMemcpyAsync(d_plan, staged, seq_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(seq_ring_.ev[slot], s));
+    return SPECKV_OK;
+}
+
+int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint32_t layer, const void* d_q_f16, uint32_t g,
+                           uint32_t max_pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
+{
+    const bool fp8 = scheme == SPECKV_COMP_FP8_E4M3;
+    if (null_) return no_data_path("speckv_ext_attend_*_planned");
+    if (n_seq == 0) return SPECKV_OK;
+    if (!d_plan || !d_q_f16 || !d_out || !s || g == 0 || g > 16 || max_pos_end % 2 || max_pos_end == 0) return SPECKV_ERR_INVAL;
+    const uint32_t heads = 8;                                  // the page-wise layout: 8 kv heads x 128
+    const auto plan = plans_.find(d_plan);                     // what speckv_ext_attend_batch_plan last wrote there
+    if (plan == plans_.end() || plan->second.n_seq != n_seq || plan->second.scheme != scheme || plan->second.max_pos_end != max_pos_end ||
+        layer >= plan->second.n_layers) {
+        SPECKV_ERR("speckv_ext_attend_*_planned: no plan of this shape at %p (n_seq, format and max_pos_end as planned, layer inside every layout)", d_plan);
+        return SPECKV_ERR_INVAL;
+    }
+    const PlanGeometry pg = plan_geometry(fp8, n_seq, heads, max_pos_end);
+    DeviceScope device_scope(device_);
+    const size_t acc_bytes = static_cast<size_t>(pg.parts_bound) * 16 * 128 * sizeof(float), ml_bytes = static_cast<size_t>(pg.parts_bound) * 32 * sizeof(float);
+    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes, s));      // (growth during a capture is refused: warm up once)
+    if (!buf) return is_capturing(s) ? SPECKV_ERR_INVAL : SPECKV_ERR_NOMEM;
+    AttendArgs k{};
+    k.heads = heads;
+    k.g = g;
+    k.n_splits = pg.max_splits;
+    k.tiles_per_split = pg.tps;
+    k.layer_stride = 0;
+    k.q16 = static_cast<const uint16_t*>(d_q_f16);
+    k.q8 = static_cast<const uint8_t*>(d_q_f16);
+    k.scale_log2e = sm_scale * 1.4426950408889634f;
+    k.lin_base = reinterpret_cast<const uint8_t*>(1);          // non-null: linear form (the real base comes from the descriptor)
+    k.seqs = static_cast<const AttendSeq*>(d_plan);
+    k.part_acc = reinterpret_cast<float*>(buf);
+    k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
+    k.batch_layer = layer;
+    k.direct_out = d_out;                                      // sequences with a single split are written directly ...
+    k.direct_lse = d_lse;
+    k.direct_per_seq = 1;                                      // ... decided per sequence on the device; the merge skips those
+    if (fp8) {
+        HIP_TRY(launch_attend_fp8_batch(k, n_seq, d_out, d_lse, s));
+    } else {
+        HIP_TRY(launch_attend_int4(k, n_seq, s));
+        HIP_TRY(launch_attend_combine(k, n_seq, d_out, d_lse, s));
+    }
+    return SPECKV_OK;
+}
+
+int Engine::attend_fold_tail(uint32_t n_rows, const uint32_t* d_rows, uint32_t heads, uint32_t g, const void* d_q_f16, const void* d_k_tail,
+                             const void* d_v_tail, uint64_t tail_stride_elems, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
+{
+    if (null_) return no_data_path("speckv_ext_attend_fold_tail");
+    if (n_rows == 0) return SPECKV_OK;
+    if (!d_q_f16 || !d_k_tail || !d_v_tail || !d_out || !d_lse || heads == 0 || g == 0 || g > 16 || tail_stride_elems % 2 ||
+        tail_stride_elems < static_cast<uint64_t>(heads) * 128u)
+        return SPECKV_ERR_INVAL;
+    DeviceScope device_scope(device_);
+    if (!s) HIP_TRY(hipDeviceSynchronize());                   // NULL: the engine's stream, synchronous (include/speckv_ext.h)
+    HIP_TRY(launch_attend_fold_tail(n_rows, d_rows, heads, g, d_q_f16, d_k_tail, d_v_tail, tail_stride_elems, sm_scale, d_out, d_lse,
+                                    s ? s : stream_));
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
     return SPECKV_OK;
 }

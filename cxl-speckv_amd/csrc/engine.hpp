@@ -118,6 +118,12 @@ public:
     int bind_request(uint32_t req, uint64_t handle, uint32_t local_req);
     int write(uint64_t handle, uint64_t off, const void* src, size_t len, bool on_device);
     int write_strided(uint64_t handle, uint64_t first, uint64_t step, uint64_t n, const void* d_src, hipStream_t s);
+    int attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uint32_t* pos_end, uint32_t max_pos_end, void* d_plan,
+                          size_t plan_bytes, hipStream_t s);
+    int attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint32_t layer, const void* d_q_f16, uint32_t g,
+                       uint32_t max_pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
+    int attend_fold_tail(uint32_t n_rows, const uint32_t* d_rows, uint32_t heads, uint32_t g, const void* d_q_f16, const void* d_k_tail,
+                         const void* d_v_tail, uint64_t tail_stride_elems, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
     int write_strided_batch(const uint64_t* handles, const uint64_t* firsts, const void* const* d_srcs, uint32_t n_alloc, uint64_t step,
                             uint64_t n_each, hipStream_t s);
     int read(uint64_t handle, uint64_t off, void* dst, size_t len, bool on_device);
@@ -272,6 +278,8 @@ private:
     Scratch s_attn_, s_attn_seq_;
     // pinned staging for the batch descriptors: 4 slots in rotation, each guarded by an event (no stream sync per call)
     struct PinnedRing { void* base = nullptr; size_t slot_bytes = 0; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; int next = 0; } seq_ring_, grp_ring_;
+    struct PlanInfo { uint32_t n_seq; int scheme; uint32_t n_layers, max_pos_end; };
+    std::unordered_map<const void*, PlanInfo> plans_;      // device plan buffer -> what attend_batch_plan last wrote there
     CompressGroup* d_groups_ = nullptr;    // device twin of grp_ring_ (4 slots): descriptors of a grouped compress launch
     uint8_t* d_zero_page_ = nullptr;     // stands in for never-written pages in the fused attention
     std::unordered_map<uint32_t, std::vector<int32_t>> hist_;

@@ -205,6 +205,8 @@ struct AttendSeq {
     uint32_t part_base;
     uint32_t tiles_per_split;         // this sequence's own split length (its tiles divided evenly over n_splits)
     const uint32_t* big_flag;         // INT4: see AttendArgs::big_flag
+    uint32_t layer_pages;             // pages of one layer (K + V): layer l of a planned batch starts at k_first + l * layer_pages
+    uint32_t pad;
 };
 
 // Decode attention straight from FP8_E4M3 records (attend.hip): softmax(q.K^T * sm_scale) . V per kv head,
@@ -234,7 +236,16 @@ struct AttendArgs {
     // [row][g][128] output and the log-sum-exp (may be null) itself, and no merge launch follows
     float* direct_out;
     float* direct_lse;
+    // planned batches (descriptors resident on the device, one set for all layers of a decode step): the layer of this
+    // launch, and "decide per sequence": a sequence with one split is written directly, the others through the merge
+    uint32_t batch_layer;
+    uint32_t direct_per_seq;
 };
+// out / lse of rows d_rows[i] (null: i) += the position whose fp16 K / V rows are d_k_tail / d_v_tail [i][heads][128]
+// (consecutive i tail_stride_elems apart); see k_attend_fold_tail
+hipError_t launch_attend_fold_tail(uint32_t n_rows, const uint32_t* d_rows, uint32_t heads, uint32_t g, const void* d_q_f16,
+                                   const void* d_k_tail, const void* d_v_tail, uint64_t tail_stride_elems, float sm_scale,
+                                   float* d_out, float* d_lse, hipStream_t s);
 // a.lin_base set: linear form (a.scale_tab, a.q16); else page-table form (a.q8 / a.qs from launch_quantize_q_e4m3)
 hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s);
 // scale_tab[tile order of p] = entries[p].rec_bytes >= 2048 ? entries[p].scale : 0 for every page (set_layout time)

@@ -36,6 +36,12 @@ class _Request:
         self.tail_v = None
 
 
+def _device_index(values):
+    """int32 index tensor on the device without a blocking copy (torch.tensor(list, device="cuda") waits for the stream)."""
+    import torch
+    return torch.tensor(values, dtype=torch.int32).pin_memory().to("cuda", non_blocking=True)
+
+
 class SpeckvKVConnector:
     def __init__(self, lib: SpeckvLib, num_layers: int, num_kv_heads: int = 8, head_dim: int = 128, max_tokens: int = 4096,
                  scheme: str = "fp8"):
@@ -55,8 +61,10 @@ class SpeckvKVConnector:
         self._tail_ids = ()
         self._tail_k = self._tail_v = None
         self._fold_key = self._arg_key = None
-        self._arg_handles = self._arg_lens = None
-        self._fold_idx = self._fold_empty = None
+        self._plan = None                                     # device buffer of the step's attention plan
+        self._plan_bound = 0
+        self._fold_rows = self._fold_k = self._fold_v = None
+        self._fold_n = 0
 
     # The library takes a hipStream_t and reads NULL as "the engine's own stream".  torch's default stream IS the NULL
     # stream, so work issued from it goes through a side stream that is ordered after it and that it then waits for.
@@ -96,6 +104,7 @@ class SpeckvKVConnector:
         r = self.requests.pop(req_id)
         if req_id in self._tail_ids:
             self._tail_ids, self._tail_k, self._tail_v = (), None, None
+        self._arg_key = self._fold_key = None                 # a plan names record addresses: plan again
         self.lib.free(r.handle)                               # the binding goes with the handle
 
     def length(self, req_id: int) -> int:
@@ -141,12 +150,13 @@ class SpeckvKVConnector:
         keep = []
         if pair_b:
             reqs = [self.requests[req_ids[b]] for b in pair_b]
-            idx = torch.tensor(pair_b, device=k_new.device)
+            whole = len(pair_b) == len(req_ids)
+            idx = None if whole else _device_index(pair_b)
             if tuple(req_ids[b] for b in pair_b) == self._tail_ids:
                 kt, vt = self._tail_k, self._tail_v                                                    # [n][layers][heads][dim]
             else:
                 kt = torch.stack([r.tail_k for r in reqs]); vt = torch.stack([r.tail_v for r in reqs])
-            kn = k_new.index_select(0, idx); vn = v_new.index_select(0, idx)
+            kn, vn = (k_new, v_new) if whole else (k_new.index_select(0, idx), v_new.index_select(0, idx))
             # page image of the pair for every (layer, kind): [n][layer][kind][2 positions][heads][dim]
             pair = torch.stack((torch.stack((kt, kn), dim=2), torch.stack((vt, vn), dim=2)), dim=2).contiguous()
             keep.append(pair)
@@ -163,8 +173,11 @@ class SpeckvKVConnector:
                 r.tail_k = r.tail_v = None
             self._tail_ids, self._tail_k, self._tail_v = (), None, None
         if tail_b:
-            idx = torch.tensor(tail_b, device=k_new.device)
-            tk = k_new.index_select(0, idx); tv = v_new.index_select(0, idx)                               # copies: the caller may reuse k_new
+            if len(tail_b) == len(req_ids):                                                             # copies: the caller may reuse k_new
+                tk, tv = k_new.clone(memory_format=torch.contiguous_format), v_new.clone(memory_format=torch.contiguous_format)
+            else:
+                idx = _device_index(tail_b)
+                tk = k_new.index_select(0, idx); tv = v_new.index_select(0, idx)
             for i, b in enumerate(tail_b):
                 r = self.requests[req_ids[b]]
                 r.tail_k, r.tail_v = tk[i], tv[i]
@@ -207,6 +220,27 @@ class SpeckvKVConnector:
             out[even] = (r.tail_k if kind == 0 else r.tail_v)[layer]
         return out
 
+    PLAN_BUCKET = 512
+
+    def plan_step(self, req_ids: Sequence[int], stream):
+        """The attention plan of this decode step for the batch `req_ids` at their current lengths, on `stream` (a torch
+        stream, not the default one).  attend() calls it by itself when the batch or the lengths changed; a caller that
+        replays captured per-layer calls runs it before every replay.  Returns the length bound the launches are sized for."""
+        import ctypes
+        import torch
+        reqs = [self.requests[r] for r in req_ids]
+        B = len(reqs)
+        lens = [r.length & ~1 for r in reqs]
+        bound = min(self.T, max(self.PLAN_BUCKET, (max(lens) + self.PLAN_BUCKET - 1) // self.PLAN_BUCKET * self.PLAN_BUCKET))
+        need = self.lib.attend_plan_bytes(B)
+        if self._plan is None or self._plan.numel() < need:
+            self._plan = torch.zeros(need, dtype=torch.uint8, device="cuda")
+        handles = (ctypes.c_uint64 * B)(*[r.handle for r in reqs])
+        self.lib.attend_batch_plan(handles, (ctypes.c_uint32 * B)(*lens), bound, self._plan.data_ptr(), need, stream.cuda_stream)
+        self._arg_key = ((tuple(req_ids), tuple(r.length for r in reqs)), stream.cuda_stream)
+        self._plan_bound = bound
+        return bound
+
     def attend(self, layer: int, req_ids: Sequence[int], q, sm_scale: float, stream=None):
         """softmax(q.K^T * sm_scale).V of one layer for the batch.  q: [batch][heads][g][dim] fp16 (g query rows per kv
         head, GQA); returns [batch][heads][g][dim] fp32.  Stored positions come straight from the compressed records
@@ -219,42 +253,34 @@ class SpeckvKVConnector:
         q = q.contiguous()
         out = torch.empty((B, H, G, D), dtype=torch.float32, device="cuda")
         lse = torch.empty((B, H, G), dtype=torch.float32, device="cuda")
-        fn = self.lib.attend_fp8_batch if self.scheme == 4 else self.lib.attend_int4_batch
-        # the argument arrays are the same for every layer of a decode step
+        # One plan per decode step (speckv_ext_attend_batch_plan: handle look-ups and descriptors once, resident on the
+        # device), then one launch-only call per layer (speckv_ext_attend_*_planned).  The length bound moves in steps of
+        # PLAN_BUCKET positions, so a caller that captures its per-layer calls into a HIP graph can replay that graph for
+        # PLAN_BUCKET decode steps (plan_step() outside the graph, then the replay).
         akey = (tuple(req_ids), tuple(r.length for r in reqs))
-        if self._arg_key != akey:
-            import ctypes
-            self._arg_key = akey
-            self._arg_handles = (ctypes.c_uint64 * B)(*[r.handle for r in reqs])
-            self._arg_lens = (ctypes.c_uint32 * B)(*[r.length & ~1 for r in reqs])
         with self._On(self, stream) as st:
-            fn(self._arg_handles, layer, q.data_ptr(), G, self._arg_lens, sm_scale, out.data_ptr(), lse.data_ptr(), st.cuda_stream)
-        odd = [b for b, r in enumerate(reqs) if r.length & 1]
-        if odd:
-            # per decode step the same for every layer: which rows have a tail, which of them have nothing stored yet
-            key = akey
-            if self._fold_key != key:
-                any_empty = any(reqs[b].length < 2 for b in odd)
-                self._fold_key = key
-                self._fold_idx = None if len(odd) == B else torch.tensor(odd, device="cuda")
-                self._fold_empty = torch.tensor([reqs[b].length < 2 for b in odd], device="cuda")[:, None, None] if any_empty else None
-            idx, empty = self._fold_idx, self._fold_empty
-            if tuple(req_ids[b] for b in odd) == self._tail_ids:
-                kt, vt = self._tail_k[:, layer].float(), self._tail_v[:, layer].float()   # [n][heads][dim]
-            else:
-                kt = torch.stack([reqs[b].tail_k[layer] for b in odd]).float()
-                vt = torch.stack([reqs[b].tail_v[layer] for b in odd]).float()
-            qo = q if idx is None else q[idx]
-            oo = out if idx is None else out[idx]
-            old = lse if idx is None else lse[idx]
-            s = torch.einsum("bhgd,bhd->bhg", qo.float(), kt) * sm_scale
-            if empty is not None:
-                old = torch.where(empty, torch.full_like(s, float("-inf")), old)
-                oo = torch.where(empty[..., None], torch.zeros_like(oo), oo)
-            new = torch.logaddexp(old, s)
-            folded = oo * torch.exp(old - new)[..., None] + vt[:, :, None, :] * torch.exp(s - new)[..., None]
-            if idx is None:
-                out = folded
-            else:
-                out[idx] = folded
+            if self._arg_key != (akey, st.cuda_stream):
+                self.plan_step(req_ids, st)
+            self.lib.attend_planned(self.scheme, self._plan.data_ptr(), B, layer, q.data_ptr(), G, self._plan_bound, sm_scale,
+                                    out.data_ptr(), lse.data_ptr(), st.cuda_stream)
+            # the position still waiting for its partner: folded into out / lse by one launch for the batch
+            # (speckv_ext_attend_fold_tail).  Which rows have a tail is the same for every layer of the step.
+            if self._fold_key != akey:
+                odd = [b for b, r in enumerate(reqs) if r.length & 1]
+                self._fold_key, self._fold_n = akey, len(odd)
+                self._fold_rows = self._fold_k = self._fold_v = None
+                if odd:
+                    with torch.cuda.stream(st):
+                        self._fold_rows = None if len(odd) == B else _device_index(odd)
+                        if tuple(req_ids[b] for b in odd) == self._tail_ids:
+                            self._fold_k, self._fold_v = self._tail_k, self._tail_v                 # [n][layers][heads][dim]
+                        else:
+                            self._fold_k = torch.stack([reqs[b].tail_k for b in odd]).contiguous()
+                            self._fold_v = torch.stack([reqs[b].tail_v for b in odd]).contiguous()
+            if self._fold_n:
+                row_bytes = self.H * self.D * 2
+                self.lib.attend_fold_tail(self._fold_n, self._fold_rows.data_ptr() if self._fold_rows is not None else 0, H, G,
+                                          q.data_ptr(), self._fold_k.data_ptr() + layer * row_bytes,
+                                          self._fold_v.data_ptr() + layer * row_bytes, self.L * self.H * self.D, sm_scale,
+                                          out.data_ptr(), lse.data_ptr(), st.cuda_stream)
         return out

@@ -76,6 +76,10 @@ _EXT_SIGNATURES = {
     "speckv_ext_attend_fp8": [c_uint64, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, c_uint32, ctypes.c_float, c_void_p, c_void_p, c_void_p],
     "speckv_ext_attend_fp8_batch": [c_uint32, ctypes.POINTER(c_uint64), c_uint32, c_void_p, c_uint32, _u32p, ctypes.c_float, c_void_p, c_void_p, c_void_p],
     "speckv_ext_attend_int4_batch": [c_uint32, ctypes.POINTER(c_uint64), c_uint32, c_void_p, c_uint32, _u32p, ctypes.c_float, c_void_p, c_void_p, c_void_p],
+    "speckv_ext_attend_batch_plan": [c_uint32, ctypes.POINTER(c_uint64), _u32p, c_uint32, c_void_p, c_size_t, c_void_p],
+    "speckv_ext_attend_fp8_planned": [c_void_p, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, ctypes.c_float, c_void_p, c_void_p, c_void_p],
+    "speckv_ext_attend_int4_planned": [c_void_p, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, ctypes.c_float, c_void_p, c_void_p, c_void_p],
+    "speckv_ext_attend_fold_tail": [c_uint32, c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_uint64, ctypes.c_float, c_void_p, c_void_p, c_void_p],
     "speckv_ext_attend_int4": [c_uint64, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, c_uint32, ctypes.c_float, c_void_p, c_void_p, c_void_p],
     "speckv_ext_promote_to_l1": [c_uint64, c_uint64],
     "speckv_ext_demote_to_l3": [c_uint64, c_uint64],
@@ -96,13 +100,14 @@ def bind_ext(lib):
             continue
         fn.argtypes, fn.restype = args, c_int
         found.append(name)
-    for name, res in (("speckv_ext_layer_compression_ratio", ctypes.c_double), ("speckv_ext_backend", c_char_p)):
+    for name, res, args in (("speckv_ext_layer_compression_ratio", ctypes.c_double, [c_uint32]), ("speckv_ext_backend", c_char_p, []),
+                            ("speckv_ext_attend_plan_bytes", c_size_t, [c_uint32])):
         try:
             fn = getattr(lib, name)
         except AttributeError:
             continue
         fn.restype = res
-        fn.argtypes = [c_uint32] if res is ctypes.c_double else []
+        fn.argtypes = args
         found.append(name)
     return found
 
@@ -325,6 +330,29 @@ class SpeckvLib:
         pe = pos_end if isinstance(pos_end, ctypes.Array) else (c_uint32 * n)(*pos_end)
         self._ext("speckv_ext_attend_int4_batch", n, hs, layer, c_void_p(d_q_f16), g, pe, ctypes.c_float(sm_scale),
                   c_void_p(d_out), c_void_p(d_lse or 0), c_void_p(stream or 0))
+
+    def attend_fold_tail(self, n_rows, d_rows, heads, g, d_q_f16, d_k_tail, d_v_tail, tail_stride_elems, sm_scale, d_out, d_lse,
+                         stream=None):
+        """Fold the not-yet-stored position (fp16 K / V tails) into out / lse of rows d_rows (0 / None: all, in order)."""
+        self._ext("speckv_ext_attend_fold_tail", n_rows, c_void_p(d_rows or 0), heads, g, c_void_p(d_q_f16), c_void_p(d_k_tail),
+                  c_void_p(d_v_tail), tail_stride_elems, ctypes.c_float(sm_scale), c_void_p(d_out), c_void_p(d_lse), c_void_p(stream or 0))
+
+    def attend_plan_bytes(self, n_seq):
+        return int(self.lib.speckv_ext_attend_plan_bytes(n_seq))
+
+    def attend_batch_plan(self, handles, pos_end, max_pos_end, d_plan, plan_bytes, stream):
+        """Once per decode step, outside any graph capture: the per-sequence descriptors of the step (valid for every
+        layer) written to the device buffer d_plan."""
+        n = len(handles)
+        hs = handles if isinstance(handles, ctypes.Array) else (c_uint64 * n)(*handles)
+        pe = pos_end if isinstance(pos_end, ctypes.Array) else (c_uint32 * n)(*pos_end)
+        self._ext("speckv_ext_attend_batch_plan", n, hs, pe, max_pos_end, c_void_p(d_plan), plan_bytes, c_void_p(stream))
+
+    def attend_planned(self, scheme, d_plan, n_seq, layer, d_q_f16, g, max_pos_end, sm_scale, d_out, d_lse, stream):
+        """One layer of a planned batch: kernel launches only (capturable).  scheme: 4 (FP8_E4M3) or 3 (INT4_G32)."""
+        name = "speckv_ext_attend_fp8_planned" if scheme == 4 else "speckv_ext_attend_int4_planned"
+        self._ext(name, c_void_p(d_plan), n_seq, layer, c_void_p(d_q_f16), g, max_pos_end, ctypes.c_float(sm_scale),
+                  c_void_p(d_out), c_void_p(d_lse or 0), c_void_p(stream))
 
     def attend_int4(self, handle, layer_begin, n_layers, d_q_f16, g, pos_begin, pos_end, sm_scale, d_out, d_lse=None,
                     stream=None):

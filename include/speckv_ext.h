@@ -255,6 +255,43 @@ speckv_status_t speckv_ext_attend_int4_batch(uint32_t n_seq, const speckv_handle
                                              const void* d_q_f16, uint32_t g, const uint32_t* pos_end, float sm_scale,
                                              float* d_out, float* d_lse, void* stream);
 
+/* ---- planned batches: the batch attention of a decode step under a HIP graph -------------------------------------
+ * The batch calls above stage their per-sequence descriptors on every call and cannot be captured.  The planned form
+ * splits them in two:
+ *   speckv_ext_attend_batch_plan   once per decode step, OUTSIDE any capture: looks the n_seq allocations up and writes
+ *       one descriptor per sequence -- valid for every layer -- into the caller's device buffer d_plan
+ *       (speckv_ext_attend_plan_bytes(n_seq) bytes; the copy is ordered on `stream`).
+ *   speckv_ext_attend_{fp8,int4}_planned   one layer of the batch: kernel launches only (no look-ups, no staging,
+ *       nothing allocated once the scratch is warm), so the per-layer calls of a step can be captured once and replayed
+ *       for as long as every pos_end stays <= max_pos_end: grid, split length and scratch are functions of
+ *       (n_seq, max_pos_end) alone; the lengths themselves are read from the plan on the device.
+ * Arguments as for the batch calls; max_pos_end (even) must be the value given to the plan.  `stream` must not be NULL.
+ * Run each shape once outside the capture first (scratch growth during a capture is refused with SPECKV_ERR_INVAL).
+ * A plan names record addresses: plan again after an allocation of the batch was freed, re-created or migrated. */
+size_t speckv_ext_attend_plan_bytes(uint32_t n_seq);
+speckv_status_t speckv_ext_attend_batch_plan(uint32_t n_seq, const speckv_handle_t* handles, const uint32_t* pos_end,
+                                             uint32_t max_pos_end, void* d_plan, size_t plan_bytes, void* stream);
+speckv_status_t speckv_ext_attend_fp8_planned(const void* d_plan, uint32_t n_seq, uint32_t layer, const void* d_q_f16,
+                                              uint32_t g, uint32_t max_pos_end, float sm_scale, float* d_out,
+                                              float* d_lse, void* stream);
+speckv_status_t speckv_ext_attend_int4_planned(const void* d_plan, uint32_t n_seq, uint32_t layer, const void* d_q_f16,
+                                               uint32_t g, uint32_t max_pos_end, float sm_scale, float* d_out,
+                                               float* d_lse, void* stream);
+
+/* speckv_ext_attend_fold_tail: one more position for rows that already hold an attention result and its log-sum-exp
+ * (speckv_ext_attend_* with d_lse) -- the fp16 K / V row a decode step produced but has not stored yet (pages hold
+ * position PAIRS; a connector keeps the odd position until its partner arrives):
+ *     s = q.k * sm_scale;  new = logaddexp(lse, s);  out = out * exp(lse - new) + v * exp(s - new);  lse = new
+ *   d_rows   : device array of n_rows sequence indices into d_q_f16 / d_out / d_lse, or NULL for 0..n_rows-1
+ *   d_q_f16  : [n_seq][heads][g][128] fp16      d_out : [n_seq][heads][g][128] fp32      d_lse : [n_seq][heads][g] fp32
+ *   d_k_tail, d_v_tail : fp16 [n_rows][heads][128], consecutive rows tail_stride_elems (>= heads*128, even) apart
+ * A sequence without stored positions (out = 0, lse = -inf from the batch call) ends as out = v, lse = s.
+ * One launch, in place, capturable. */
+speckv_status_t speckv_ext_attend_fold_tail(uint32_t n_rows, const uint32_t* d_rows, uint32_t heads, uint32_t g,
+                                            const void* d_q_f16, const void* d_k_tail, const void* d_v_tail,
+                                            uint64_t tail_stride_elems, float sm_scale, float* d_out, float* d_lse,
+                                            void* stream);
+
 /* ---- tier manager (CXLMemoryManager, cxl_memory_manager.h:40-90) ---------- */
 speckv_status_t speckv_ext_promote_to_l1(speckv_handle_t handle, uint64_t offset_bytes);
 speckv_status_t speckv_ext_demote_to_l3(speckv_handle_t handle, uint64_t offset_bytes);

@@ -1,6 +1,8 @@
 """Helpers for the -m gpu tests: drive libcxlspeckv.so through its C ABI with
 torch tensors as plain device buffers (torch is plumbing only)."""
+import contextlib
 import ctypes as C
+import gc
 
 import numpy as np
 
@@ -32,6 +34,23 @@ def torch_mod():
     import torch
     assert torch.cuda.is_available(), "these tests need the MI355X"
     return torch
+
+
+@contextlib.contextmanager
+def graph_capture(graph, stream):
+    """torch.cuda.graph with the cyclic garbage collector held off: a collection that runs inside the capture may
+    destroy a graph or stream left in a reference cycle by an EARLIER test (pytest.raises keeps frames alive), and HIP
+    calls of that kind abort a global-mode capture."""
+    torch = torch_mod()
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, stream=stream):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def stream_ptr():

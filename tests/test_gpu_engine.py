@@ -10,7 +10,7 @@ import pytest
 
 import cxl_speckv_amd as pkg
 from cxl_speckv_amd.speckv_ctypes import SpeckvError
-from tests._gpu import N, assert_same_float_bits, dev_to_host, torch_mod
+from tests._gpu import N, assert_same_float_bits, dev_to_host, graph_capture, torch_mod
 
 pytestmark = pytest.mark.gpu
 PAGE = 4096
@@ -845,7 +845,7 @@ def test_per_layer_attention_calls_capture_into_a_hip_graph(eng):
     step(eager); torch.cuda.synchronize()                      # warm: scratch buffers reach their size
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.stream(s):
-        with torch.cuda.graph(graph, stream=s):
+        with graph_capture(graph, s):
             step(replayed)
     torch.cuda.synchronize()
     replayed.zero_()

@@ -18,7 +18,7 @@ import pytest
 
 import cxl_speckv_amd as pkg
 from cxl_speckv_amd.speckv_ctypes import SpeckvError
-from tests._gpu import N, assert_same_float_bits, dev_to_host, torch_mod
+from tests._gpu import N, assert_same_float_bits, dev_to_host, graph_capture, torch_mod
 from tests.test_gpu_engine import synth
 
 pytestmark = pytest.mark.gpu
@@ -382,7 +382,7 @@ def test_batch_attention_refuses_stream_capture():
         lib.attend_fp8(h, 0, 1, q.data_ptr(), G, 0, T, 0.1, out.data_ptr(), None, s.cuda_stream)         # warm-up sizes the scratch
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s):
+        with graph_capture(g, s):
             with pytest.raises(SpeckvError) as ei:
                 lib.attend_fp8_batch([h], 0, q.data_ptr(), G, [T], 0.1, out.data_ptr(), None, s.cuda_stream)
             assert ei.value.status == -4
@@ -390,6 +390,144 @@ def test_batch_attention_refuses_stream_capture():
         out.zero_()
         g.replay(); torch.cuda.synchronize()
         assert torch.allclose(out, eager, rtol=1e-5, atol=1e-6)
+    finally:
+        lib.finalize()
+
+
+@pytest.mark.parametrize("scheme", [4, 3])
+def test_planned_batch_attention_replays_under_a_graph(scheme):
+    """The planned form of the batch attention: speckv_ext_attend_batch_plan once per step outside the graph, the
+    per-layer speckv_ext_attend_*_planned calls captured ONCE and replayed while the sequences grow.  Every replay must
+    equal the per-sequence entry point at the lengths of that step (the tolerance of two split arrangements, see
+    test_fused_attention_batch_of_sequences); sequences that finish in one split are written by the attention kernel,
+    the others by the merge, in the same launch."""
+    torch = torch_mod()
+    lib = open_lib()
+    try:
+        lib.set_compression_scheme(scheme)
+        single_fn = lib.attend_fp8 if scheme == 4 else lib.attend_int4
+        T, L, H, D, G = 2048, 3, 8, 128, 4
+        rng = np.random.default_rng(97)
+        steps = [[64, 1024, 2, 600, 0], [66, 1026, 4, 602, 0], [512, 2048, 34, 1600, 2], [2048, 2048, 2048, 2048, 2048]]
+        n_seq = len(steps[0])
+        handles = []
+        for _ in range(n_seq):
+            h = lib.alloc(T * L * H * D * 2 * 2)
+            lib.set_layout(h, T, L, H, D, 2)
+            n_pages = T * L * H * D * 2 * 2 // PAGE
+            x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.2, 2.0, (n_pages, 1))).astype(np.float16)
+            lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+            handles.append(h)
+        sm = 1.0 / np.sqrt(D)
+        q = torch.from_numpy(rng.standard_normal((L, n_seq, H, G, D)).astype(np.float16)).cuda()
+        out = torch.zeros((L, n_seq, H, G, D), dtype=torch.float32, device="cuda")
+        lse = torch.zeros((L, n_seq, H, G), dtype=torch.float32, device="cuda")
+        plan_bytes = lib.attend_plan_bytes(n_seq)
+        assert plan_bytes == n_seq * 64
+        plan = torch.zeros(plan_bytes, dtype=torch.uint8, device="cuda")
+        s = torch.cuda.Stream()
+        for tps in (None, "8"):                       # default geometry (whole sequences) and one with real splits
+            if tps is None: os.environ.pop("SPECKV_ATTEND_TILES_PER_SPLIT", None)
+            else: os.environ["SPECKV_ATTEND_TILES_PER_SPLIT"] = tps
+            try:
+                def run_layers():
+                    for layer in range(L):
+                        lib.attend_planned(scheme, plan.data_ptr(), n_seq, layer, q[layer].data_ptr(), G, T, sm,
+                                           out[layer].data_ptr(), lse[layer].data_ptr(), s.cuda_stream)
+                # no plan at that address yet / wrong shape -> refused, nothing launched
+                other = torch.zeros(plan_bytes, dtype=torch.uint8, device="cuda")
+                with pytest.raises(SpeckvError):
+                    lib.attend_planned(scheme, other.data_ptr(), n_seq, 0, q[0].data_ptr(), G, T, sm, out[0].data_ptr(), None, s.cuda_stream)
+                lib.attend_batch_plan(handles, steps[0], T, plan.data_ptr(), plan_bytes, s.cuda_stream)
+                with pytest.raises(SpeckvError):
+                    lib.attend_planned(scheme, plan.data_ptr(), n_seq, L, q[0].data_ptr(), G, T, sm, out[0].data_ptr(), None, s.cuda_stream)
+                with pytest.raises(SpeckvError):
+                    lib.attend_planned(scheme, plan.data_ptr(), n_seq, 0, q[0].data_ptr(), G, T - 2, sm, out[0].data_ptr(), None, s.cuda_stream)
+                with pytest.raises(SpeckvError):
+                    lib.attend_planned(7 - scheme, plan.data_ptr(), n_seq, 0, q[0].data_ptr(), G, T, sm, out[0].data_ptr(), None, s.cuda_stream)
+                run_layers()                              # warm-up: sizes the scratch
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with graph_capture(g, s):
+                    with pytest.raises(SpeckvError):      # the plan itself stays outside
+                        lib.attend_batch_plan(handles, steps[0], T, plan.data_ptr(), plan_bytes, s.cuda_stream)
+                    run_layers()
+                for lens in steps:
+                    lib.attend_batch_plan(handles, lens, T, plan.data_ptr(), plan_bytes, s.cuda_stream)
+                    s.synchronize()
+                    out.fill_(float("nan")); lse.fill_(float("nan"))
+                    torch.cuda.synchronize()
+                    g.replay()
+                    torch.cuda.synchronize()
+                    for layer in range(L):
+                        for i, (h, n) in enumerate(zip(handles, lens)):
+                            if n == 0:
+                                assert float(out[layer, i].abs().max()) == 0.0
+                                continue
+                            one = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
+                            one_lse = torch.empty((H, G), dtype=torch.float32, device="cuda")
+                            single_fn(h, layer, 1, q[layer, i].data_ptr(), G, 0, n, sm, one.data_ptr(), one_lse.data_ptr())
+                            torch.cuda.synchronize()
+                            scale = float(one.abs().max()) + 1e-6
+                            assert float((out[layer, i] - one).abs().max()) <= 1e-3 * scale, (tps, lens, layer, i)
+                            assert float((lse[layer, i] - one_lse).abs().max()) <= 1e-4, (tps, lens, layer, i)
+                # a length beyond the planned bound is refused by the plan
+                with pytest.raises(SpeckvError):
+                    lib.attend_batch_plan(handles, [T] * n_seq, T - 2, plan.data_ptr(), plan_bytes, s.cuda_stream)
+                del g
+            finally:
+                os.environ.pop("SPECKV_ATTEND_TILES_PER_SPLIT", None)
+        for h in handles:
+            lib.free(h)
+    finally:
+        lib.finalize()
+
+
+@pytest.mark.parametrize("subset", [False, True])
+def test_fold_tail_adds_one_position(subset):
+    """speckv_ext_attend_fold_tail against the same three lines in float64: rows chosen by an index list or all of them,
+    a strided tail tensor ([rows][layers][heads][dim], one layer taken), rows with nothing stored (out 0, lse -inf) and
+    scores far above / below the stored log-sum-exp.  Tolerance: fp32 dot product of 128 terms and v_exp / v_log, 2e-5
+    relative on out, 1e-5 absolute on lse."""
+    torch = torch_mod()
+    lib = open_lib()
+    try:
+        rng = np.random.default_rng(131)
+        n_seq, H, G, D, Lyr, layer = 9, 8, 5, 128, 3, 1
+        rows = [7, 0, 3, 8] if subset else list(range(n_seq))
+        q = rng.standard_normal((n_seq, H, G, D)).astype(np.float16)
+        q[3] *= 40.0                                               # score far above the stored lse
+        q[8] *= -40.0                                              # ... and far below (sign flips with k, both occur)
+        out = rng.standard_normal((n_seq, H, G, D)).astype(np.float32)
+        lse = rng.uniform(-3, 9, (n_seq, H, G)).astype(np.float32)
+        out[0] = 0.0; lse[0] = -np.inf                              # a sequence without stored positions
+        kt = rng.standard_normal((len(rows), Lyr, H, D)).astype(np.float16)
+        vt = rng.standard_normal((len(rows), Lyr, H, D)).astype(np.float16)
+        sm = 0.0884
+        want_out, want_lse = out.astype(np.float64), lse.astype(np.float64)
+        for i, b in enumerate(rows):
+            sc = np.einsum("hgd,hd->hg", q[b].astype(np.float64), kt[i, layer].astype(np.float64)) * sm
+            new = np.logaddexp(want_lse[b], sc)
+            want_out[b] = want_out[b] * np.exp(want_lse[b] - new)[..., None] + vt[i, layer].astype(np.float64)[:, None, :] * np.exp(sc - new)[..., None]
+            want_lse[b] = new
+        d_q, d_out, d_lse = torch.from_numpy(q).cuda(), torch.from_numpy(out).cuda(), torch.from_numpy(lse).cuda()
+        d_k, d_v = torch.from_numpy(kt).cuda(), torch.from_numpy(vt).cuda()
+        d_rows = torch.tensor(rows, dtype=torch.int32).cuda() if subset else None
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        lib.attend_fold_tail(len(rows), d_rows.data_ptr() if subset else 0, H, G, d_q.data_ptr(), d_k.data_ptr() + layer * H * D * 2,
+                             d_v.data_ptr() + layer * H * D * 2, Lyr * H * D, sm, d_out.data_ptr(), d_lse.data_ptr(), s.cuda_stream)
+        torch.cuda.synchronize()
+        got_out, got_lse = d_out.cpu().numpy(), d_lse.cpu().numpy()
+        assert np.all(np.abs(got_out - want_out) <= 2e-5 * np.abs(want_out) + 2e-6)
+        assert np.all(np.abs(got_lse - want_lse) <= 1e-5 * np.maximum(1.0, np.abs(want_lse)))
+        untouched = [b for b in range(n_seq) if b not in rows]
+        assert np.array_equal(got_out[untouched], out[untouched]) and np.array_equal(got_lse[untouched], lse[untouched])
+        with pytest.raises(SpeckvError):                            # tails overlapping: stride below one row
+            lib.attend_fold_tail(len(rows), 0, H, G, d_q.data_ptr(), d_k.data_ptr(), d_v.data_ptr(), H * D - 2, sm, d_out.data_ptr(),
+                                 d_lse.data_ptr(), s.cuda_stream)
+        with pytest.raises(SpeckvError):                            # the log-sum-exp is not optional here
+            lib.attend_fold_tail(len(rows), 0, H, G, d_q.data_ptr(), d_k.data_ptr(), d_v.data_ptr(), H * D, sm, d_out.data_ptr(), 0, s.cuda_stream)
     finally:
         lib.finalize()
 
