@@ -2057,13 +2057,47 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
 // Not capturable into a HIP graph: the per-call descriptors travel through a pinned slot that later calls reuse, so a
 // replay would read other calls' descriptors -- the call refuses to run on a capturing stream (the per-sequence
 // entry points speckv_ext_attend_fp8 / _int4 are capturable).
-// Split length of a batch launch (see the measurements quoted in attend_batch).
-static uint32_t batch_tiles_per_split(bool fp8, uint32_t n_seq, uint32_t heads, uint64_t total_tiles)
+// Split length of a batch launch (see the measurements quoted in attend_batch).  seqs[i].n_splits holds the tile count of
+// sequence i (null: n_seq sequences of uniform_tiles each, the bound a plan is sized for).
+static uint32_t batch_tiles_per_split(bool fp8, uint32_t n_seq, uint32_t heads, uint64_t total_tiles, const AttendSeq* seqs,
+                                      uint32_t uniform_tiles)
 {
-    const uint64_t wg_target = fp8 ? 512u : 768u;
-    uint32_t tps = static_cast<uint32_t>(std::max<uint64_t>(8, (total_tiles * (heads / 4u) + wg_target - 1u) / wg_target));
-    if (!fp8) tps = (static_cast<uint64_t>(n_seq) * (heads / 4u) >= 384u) ? 256u : std::min(tps, 256u);   // enough columns: whole sequences
-    if (const char* env = getenv("SPECKV_ATTEND_TILES_PER_SPLIT")) tps = std::max(1, atoi(env));
+    if (const char* env = getenv("SPECKV_ATTEND_TILES_PER_SPLIT")) return std::max(1, atoi(env));
+    const char* target_env = getenv("SPECKV_ATTEND_WG_TARGET");                // (measurement runs: the plain workgroup target)
+    const uint32_t hq = heads / 4u;
+    if (fp8 && !target_env) {
+        // FP8 (bandwidth-bound kernel, 4 workgroups of a CU share its rate): a launch takes about
+        //     ceil(workgroups / 256) x (tiles per split + 3)  [+ 16 for the merge launch if anything is split]
+        // tile times -- what counts is the most loaded CU, so workgroup counts just above a multiple of 256 are the ones to
+        // avoid (48 sequences x 16k: 288 workgroups 0.50 of HBM peak, 192: 0.64, 768: 0.71; 32 x 32k: 256 workgroups 0.79,
+        // 512: 0.76, 384: 0.63; 128 x 2k: unsplit 0.73, two splits 0.56).  The rule takes the cheapest split count.
+        uint32_t n_max = seqs ? 0u : uniform_tiles;
+        if (seqs) for (uint32_t i = 0; i < n_seq; ++i) n_max = std::max(n_max, seqs[i].n_splits);
+        if (n_max == 0) return 8;
+        uint64_t best_cost = UINT64_MAX;
+        uint32_t best = n_max;
+        const uint64_t columns = static_cast<uint64_t>(n_seq) * hq;
+        // candidates: whole sequences, and the split counts that just fill 1..4 workgroups per CU (4 are resident at a time;
+        // beyond that the launch runs in waves of 1024 and its last, partly filled wave is what costs)
+        for (uint32_t r = 0; r <= 4u; ++r) {
+            const uint32_t sp = r == 0 ? 1u : static_cast<uint32_t>(std::min<uint64_t>(2048u, 256u * r / columns));
+            if (sp == 0 || (r > 0 && sp == 1u)) continue;
+            const uint32_t tps = (n_max + sp - 1u) / sp;
+            if (sp > 1u && tps < 8u) continue;
+            uint64_t wgs = 0;
+            if (seqs) for (uint32_t i = 0; i < n_seq; ++i) wgs += (seqs[i].n_splits + tps - 1u) / tps;
+            else wgs = static_cast<uint64_t>(n_seq) * ((uniform_tiles + tps - 1u) / tps);
+            wgs *= hq;
+            const uint64_t slots = wgs <= 1024u ? (wgs + 255u) / 256u : 4u * ((wgs + 1023u) / 1024u);
+            const uint64_t cost = slots * (tps + (sp > 1u ? 3u : 0u)) + (sp > 1u ? 16u : 0u);
+            if (cost < best_cost) { best_cost = cost; best = tps; }
+        }
+        return best;
+    }
+    uint64_t wg_target = fp8 ? 512u : 768u;
+    if (target_env) wg_target = std::max(1, atoi(target_env));
+    uint32_t tps = static_cast<uint32_t>(std::max<uint64_t>(8, (total_tiles * hq + wg_target - 1u) / wg_target));
+    if (!fp8) tps = (static_cast<uint64_t>(n_seq) * hq >= 384u) ? 256u : std::min(tps, 256u);   // enough columns: whole sequences
     return tps;
 }
 
@@ -2121,11 +2155,12 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     // one split length for the whole batch.  A batch brings its own parallelism: the fewer, longer splits the better, down
     // to about one round of resident workgroups (256 sequences x 8k context, one layer, FP8: 8 tiles per split 0.50 of
     // HBM peak, 32: 0.59, 64: 0.67, 128: 0.72, 256 = no split: 0.74; INT4: 64..128 best, 0.59; at 2k context both
-    // formats want no split at all).  Target: 512 workgroups (FP8) / 768 (INT4), never under 8 tiles per split.
+    // formats want no split at all).  INT4 target: 768 workgroups, never under 8 tiles per split; FP8: the cost rule of
+    // batch_tiles_per_split.
     // INT4 (arithmetic-bound kernel): splits longer than 256 tiles stop paying (256 sequences x 32k: 256 tiles per split
     // 0.67, 512: 0.65, 1024 = no split: 0.60), shorter sequences are best left whole (8k 0.63 against 0.59 in two
     // splits, 4k 0.60 / 0.52, 2k 0.58 / 0.43: single-split rows are final, no partials and no merge).
-    const uint32_t tps = batch_tiles_per_split(fp8, n_seq, heads, total_tiles);
+    const uint32_t tps = batch_tiles_per_split(fp8, n_seq, heads, total_tiles, seqs.data(), 0);
     uint32_t max_splits = 0;
     uint64_t parts = 0;
     for (uint32_t i = 0; i < n_seq; ++i) {
@@ -2196,7 +2231,7 @@ static PlanGeometry plan_geometry(bool fp8, uint32_t n_seq, uint32_t heads, uint
 {
     const uint32_t tiles_max = (max_pos_end / 2u + 15u) / 16u;
     PlanGeometry g{};
-    g.tps = batch_tiles_per_split(fp8, n_seq, heads, static_cast<uint64_t>(tiles_max) * n_seq);
+    g.tps = batch_tiles_per_split(fp8, n_seq, heads, static_cast<uint64_t>(tiles_max) * n_seq, nullptr, tiles_max);
     g.max_splits = std::max(1u, (tiles_max + g.tps - 1u) / g.tps);
     g.parts_bound = static_cast<uint64_t>(n_seq) * heads * g.max_splits;
     return g;

@@ -10,5 +10,7 @@ SPECKV_BENCH_SINGLE_GPU_TEST=1 timeout 600 python -m torch.distributed.run --nno
 echo "n2fake rc=$?"
 for i in 1 2 3; do timeout 600 python -m pytest tests -x -q -m gpu -p no:cacheprovider > gpurun_out/soak_r2h_$i.log 2>&1; echo "soak $i rc=$?"; tail -1 gpurun_out/soak_r2h_$i.log; done
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+timeout 300 python profiles/tools/conn_step.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r2h_conn_step.txt
+timeout 600 python profiles/tools/batch_rule_ab.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r2h_batch_rule_ab.txt
 bash profiles/collect_r02.sh prof_r02h > /dev/null 2>&1
 echo "collect rc=$?"
