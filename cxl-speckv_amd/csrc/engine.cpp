@@ -2066,33 +2066,11 @@ static uint32_t batch_tiles_per_split(bool fp8, uint32_t n_seq, uint32_t heads, 
     const char* target_env = getenv("SPECKV_ATTEND_WG_TARGET");                // (measurement runs: the plain workgroup target)
     const uint32_t hq = heads / 4u;
     if (fp8 && !target_env) {
-        // FP8 (bandwidth-bound kernel, 4 workgroups of a CU share its rate): a launch takes about
-        //     ceil(workgroups / 256) x (tiles per split + 3)  [+ 16 for the merge launch if anything is split]
-        // tile times -- what counts is the most loaded CU, so workgroup counts just above a multiple of 256 are the ones to
-        // avoid (48 sequences x 16k: 288 workgroups 0.50 of HBM peak, 192: 0.64, 768: 0.71; 32 x 32k: 256 workgroups 0.79,
-        // 512: 0.76, 384: 0.63; 128 x 2k: unsplit 0.73, two splits 0.56).  The rule takes the cheapest split count.
-        uint32_t n_max = seqs ? 0u : uniform_tiles;
-        if (seqs) for (uint32_t i = 0; i < n_seq; ++i) n_max = std::max(n_max, seqs[i].n_splits);
-        if (n_max == 0) return 8;
-        uint64_t best_cost = UINT64_MAX;
-        uint32_t best = n_max;
-        const uint64_t columns = static_cast<uint64_t>(n_seq) * hq;
-        // candidates: whole sequences, and the split counts that just fill 1..4 workgroups per CU (4 are resident at a time;
-        // beyond that the launch runs in waves of 1024 and its last, partly filled wave is what costs)
-        for (uint32_t r = 0; r <= 4u; ++r) {
-            const uint32_t sp = r == 0 ? 1u : static_cast<uint32_t>(std::min<uint64_t>(2048u, 256u * r / columns));
-            if (sp == 0 || (r > 0 && sp == 1u)) continue;
-            const uint32_t tps = (n_max + sp - 1u) / sp;
-            if (sp > 1u && tps < 8u) continue;
-            uint64_t wgs = 0;
-            if (seqs) for (uint32_t i = 0; i < n_seq; ++i) wgs += (seqs[i].n_splits + tps - 1u) / tps;
-            else wgs = static_cast<uint64_t>(n_seq) * ((uniform_tiles + tps - 1u) / tps);
-            wgs *= hq;
-            const uint64_t slots = wgs <= 1024u ? (wgs + 255u) / 256u : 4u * ((wgs + 1023u) / 1024u);
-            const uint64_t cost = slots * (tps + (sp > 1u ? 3u : 0u)) + (sp > 1u ? 16u : 0u);
-            if (cost < best_cost) { best_cost = cost; best = tps; }
-        }
-        return best;
+        // FP8: the busiest-CU cost rule of ring_rule.hpp (48 sequences x 16k: 288 workgroups 0.50 of HBM peak, 192: 0.64,
+        // 768: 0.71; 32 x 32k: 256 workgroups 0.79, 512: 0.76, 384: 0.63; 128 x 2k: unsplit 0.73, two splits 0.56)
+        std::vector<uint32_t> tiles;
+        if (seqs) { tiles.resize(n_seq); for (uint32_t i = 0; i < n_seq; ++i) tiles[i] = seqs[i].n_splits; }
+        return fp8_batch_tiles_per_split(seqs ? tiles.data() : nullptr, n_seq, uniform_tiles, hq);
     }
     uint64_t wg_target = fp8 ? 512u : 768u;
     if (target_env) wg_target = std::max(1, atoi(target_env));

@@ -43,4 +43,36 @@ __host__ __device__ inline EvenSplit even_split(uint32_t n_tiles, uint32_t want)
     return EvenSplit{tps, (n_tiles + tps - 1u) / tps};
 }
 
+// Split length (tiles) of an FP8 batch attention launch.  tiles[i] = tiles of sequence i (null: n_seq sequences of
+// uniform_tiles each); columns_per_seq = workgroup columns one sequence contributes (kv heads / 4).  The four workgroups a
+// CU can hold share its rate, so a launch takes about  ceil(workgroups / 256) x (tiles per split + 3)  tile times, plus
+// about 16 for the merge launch if anything is split: the rule prices whole sequences and the split counts that just fill
+// 1 .. 4 workgroups per CU, and takes the cheapest.  Beyond 1024 workgroups the launch runs in waves of 1024.
+inline uint32_t fp8_batch_tiles_per_split(const uint32_t* tiles, uint32_t n_seq, uint32_t uniform_tiles, uint32_t columns_per_seq,
+                                          uint32_t n_cus = 256u)
+{
+    uint32_t n_max = tiles ? 0u : uniform_tiles;
+    if (tiles) for (uint32_t i = 0; i < n_seq; ++i) n_max = tiles[i] > n_max ? tiles[i] : n_max;
+    if (n_max == 0 || n_seq == 0 || columns_per_seq == 0) return 8u;
+    const uint64_t columns = static_cast<uint64_t>(n_seq) * columns_per_seq;
+    uint64_t best_cost = UINT64_MAX;
+    uint32_t best = n_max;
+    for (uint32_t r = 0; r <= 4u; ++r) {
+        uint64_t sp = r == 0 ? 1u : static_cast<uint64_t>(n_cus) * r / columns;
+        if (sp > 2048u) sp = 2048u;
+        if (sp == 0 || (r > 0 && sp == 1u)) continue;
+        const uint32_t tps = static_cast<uint32_t>((n_max + sp - 1u) / sp);
+        if (sp > 1u && tps < 8u) continue;                     // splits under 8 tiles cost more than they spread
+        uint64_t wgs = 0;
+        if (tiles) for (uint32_t i = 0; i < n_seq; ++i) wgs += (tiles[i] + tps - 1u) / tps;
+        else wgs = static_cast<uint64_t>(n_seq) * ((uniform_tiles + tps - 1u) / tps);
+        wgs *= columns_per_seq;
+        const uint64_t resident = 4ull * n_cus;
+        const uint64_t slots = wgs <= resident ? (wgs + n_cus - 1u) / n_cus : 4u * ((wgs + resident - 1u) / resident);
+        const uint64_t cost = slots * (tps + (sp > 1u ? 3u : 0u)) + (sp > 1u ? 16u : 0u);
+        if (cost < best_cost) { best_cost = cost; best = tps; }
+    }
+    return best;
+}
+
 } // namespace speckv

@@ -14,4 +14,8 @@ void rules_even_split(uint32_t n_tiles, uint32_t want, uint32_t* out2)
     const speckv::EvenSplit e = speckv::even_split(n_tiles, want);
     out2[0] = e.tiles_per_split; out2[1] = e.n_splits;
 }
+uint32_t rules_fp8_batch_tiles_per_split(const uint32_t* tiles, uint32_t n_seq, uint32_t uniform_tiles, uint32_t columns_per_seq)
+{
+    return speckv::fp8_batch_tiles_per_split(tiles, n_seq, uniform_tiles, columns_per_seq);
+}
 }

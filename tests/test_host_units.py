@@ -248,6 +248,8 @@ def rules():
     lib.rules_ring_take.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.rules_ring_live.restype = C.c_int; lib.rules_ring_live.argtypes = [C.c_uint32] * 3
     lib.rules_even_split.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.rules_fp8_batch_tiles_per_split.restype = C.c_uint32
+    lib.rules_fp8_batch_tiles_per_split.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32]
     return lib
 
 
@@ -315,3 +317,51 @@ def test_even_split_covers_the_tiles_evenly(rules):
             assert 1 <= ns <= max(1, min(want, n_tiles)) or want == 0 and ns == 1
             assert tps * ns >= n_tiles > tps * (ns - 1)        # every split non-empty, all tiles covered
             assert tps - (n_tiles - tps * (ns - 1)) < ns or ns == 1 or tps <= (n_tiles + ns - 1) // ns   # no split shorter than needed by rounding
+
+
+def test_fp8_batch_split_rule(rules):
+    """The split rule of the FP8 batch attention (ring_rule.hpp::fp8_batch_tiles_per_split, measured in
+    profiles/*_fp8_batch_split_rule_ab.txt): the shapes whose best split length was measured on the MI355X, and the
+    properties every answer must have -- a split is never shorter than 8 tiles, batches that fill the chip on their own stay
+    whole, a split launch stays within one residency (1024 workgroups) and is cheaper than whole sequences by the rule's
+    own busiest-CU cost, and the rule
+    for a uniform batch is the same whether the tiles come as a list or as a bound."""
+    f = rules.rules_fp8_batch_tiles_per_split
+    hq = 2                                                        # 8 kv heads: two workgroup columns per sequence
+
+    def uniform(n_seq, tiles):
+        a = f(None, n_seq, tiles, hq)
+        b = f((C.c_uint32 * n_seq)(*([tiles] * n_seq)), n_seq, 0, hq)
+        assert a == b
+        return a
+
+    def cost_whole(columns, tiles):
+        return (-(-columns // 256) if columns <= 1024 else 4 * -(-columns // 1024)) * tiles
+
+    # measured best split lengths (sequences, context / 32 tiles) -> tiles per split
+    assert uniform(128, 64) == 64 and uniform(256, 64) == 64 and uniform(256, 256) == 256 and uniform(512, 32) == 32      # whole sequences
+    assert uniform(64, 256) == 128                                # two splits: 256 workgroups
+    assert uniform(32, 128) == 32 and uniform(16, 256) == 32      # 256 workgroups
+    assert uniform(32, 1024) == 256 and uniform(4, 4096) == 128   # 256 workgroups
+    assert uniform(48, 512) == 64                                 # 8 splits: 768 workgroups = three per CU (288 would be 0.50 of peak)
+    assert uniform(100, 128) == 128 and uniform(300, 128) == 128  # 200 / 600 columns: splitting only unbalances them
+    rng = np.random.default_rng(5)
+    for _ in range(400):
+        n_seq = int(rng.integers(1, 700))
+        tiles = int(rng.integers(1, 5000))
+        tps = uniform(n_seq, tiles)
+        splits = -(-tiles // tps)
+        wgs = n_seq * hq * splits
+        assert 1 <= tps <= tiles and (splits == 1 or tps >= 8) and splits <= 2048
+        if n_seq * hq >= 256:
+            assert splits == 1 or wgs <= 1024                     # a batch that covers the chip is split only inside one residency
+        if splits > 1:                                            # priced below whole sequences by the rule's own cost
+            assert wgs <= 1024 and -(-wgs // 256) * (tps + 3) + 16 < cost_whole(n_seq * hq, tiles), (n_seq, tiles, tps, wgs)
+    # ragged batches: priced on their real workgroup count, and every sequence's own split count stays within the merge's limit
+    for _ in range(200):
+        n_seq = int(rng.integers(1, 300))
+        t = rng.integers(0, 3000, n_seq).astype(np.uint32)
+        tps = f(t.ctypes.data_as(C.POINTER(C.c_uint32)), n_seq, 0, hq)
+        assert tps >= 1 and (t.max() == 0 or tps <= max(int(t.max()), 8))
+        assert int(np.max(-(-t.astype(np.int64) // tps))) <= 2048
+    assert f(None, 0, 100, hq) == 8 and f(None, 10, 0, hq) == 8  # nothing to do: any legal length
