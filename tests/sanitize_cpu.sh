@@ -20,3 +20,4 @@ SPECKV_LIB_PATH="$ROOT/tests/_build/tsan/libcxlspeckv.so" LD_PRELOAD="$RT/libcla
   python -m pytest tests/test_cabi_boundary.py -q -s -k many_threads -p no:cacheprovider > "$log" 2>&1 || { tail -40 "$log"; exit 1; }
 if grep -q "WARNING: ThreadSanitizer" "$log"; then grep -A30 "WARNING: ThreadSanitizer" "$log" | head -80; exit 1; fi
 echo "tsan: $(tail -1 "$log")"
+rm -rf "$ROOT/tests/_build/asan" "$ROOT/tests/_build/tsan"      # 20 MB that would otherwise travel with every gpurun snapshot
