@@ -62,76 +62,54 @@ __device__ __forceinline__ float sum_over_kb(float v)
 }
 __device__ __forceinline__ f16x2 as_h2(uint32_t u) { return __builtin_bit_cast(f16x2, u); }
 
-// The kernel is VALU-bound on the nibble -> f16 conversion (rocprofv3: 426 VALU per 32-position tile and wave, VALU
-// issue 63 % busy, MFMA 9 %; profiles/r02_int4_pmc_before.json), so the conversion is written for instruction count:
-// per PAIR of values two SDWA converts (byte k of a nibble dword -> f16, the second into the upper half of the same
-// register) and one packed FMA:  fp16(u) * s + (-8 s)  =  fp16((u - 8) * s)  with ONE rounding -- u = q + 8 (offset
-// binary, 0..15) and -8 s are exact in fp16 -- i.e. bit for bit the value fetch + decompress stores.
-// (-8 s overflows fp16 for s > 8188, a group whose largest |x| is beyond 57 000; the caller detects that per tile,
-// wave-uniformly, and takes the subtract-then-multiply form.)
-// (K is a compile-time constant at every call site after unrolling: the chain folds to one pair of instructions)
-__device__ __forceinline__ uint32_t cvt_pair(const int K, uint32_t lo_src, uint32_t hi_src)
+// The kernel is VALU-bound on the nibble -> f16 conversion (rocprofv3: 426 VALU per 32-position tile and wave at first,
+// VALU issue 63 % busy, MFMA 9 %; profiles/r02_int4_pmc_before.json), so the conversion is written for instruction count.
+// A two's-complement nibble t, xor 8, is q + 8 (0..15); placed in the low mantissa bits of fp16 1024.0 (ulp 1) it reads
+// as the exact fp16 integer 1032 + q, and a nibble four bits higher, in the mantissa of 64.0 (that bit weighs 1), as
+// 72 + q.  So ONE v_bitop3_b32 -- (w & mask) ^ magic, the xor-8 folded into the magic -- turns a dword into a PAIR of fp16
+// integers, nibbles 16 bits apart; subtracting the bias is exact and the product with the group scale rounds once:
+//     fp16(q) * s  =  fp16(q * s),   bit for bit the value fetch + decompress stores,
+// for every scale (no -8 s term that could overflow: groups with scales beyond 8188 need no path of their own).
+// Per dword of 8 nibbles: 1 shift + 4 bitop3 + 4 packed subtracts + 4 packed multiplies = 13 instructions, against 16
+// with byte-selecting converts (v_cvt_f16_u16_sdwa per value) and a packed FMA per pair.
+template <int HI> __device__ __forceinline__ f16x2 deq_pair(uint32_t w, f16x2 s2)
 {
-    uint32_t r;
-    if (K == 0) {
-        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(r) : "v"(lo_src));
-        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(r) : "v"(hi_src));
-    } else if (K == 1) {
-        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(r) : "v"(lo_src));
-        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(r) : "v"(hi_src));
-    } else if (K == 2) {
-        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(r) : "v"(lo_src));
-        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(r) : "v"(hi_src));
-    } else {
-        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(r) : "v"(lo_src));
-        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(r) : "v"(hi_src));
-    }
-    return r;
+    const uint32_t u = HI ? ((w & 0x00F000F0u) ^ 0x54805480u) : ((w & 0x000F000Fu) ^ 0x64086408u);
+    const f16x2 bias = HI ? f16x2{static_cast<_Float16>(72.0f), static_cast<_Float16>(72.0f)}
+                          : f16x2{static_cast<_Float16>(1032.0f), static_cast<_Float16>(1032.0f)};
+    return (as_h2(u) - bias) * s2;
 }
-// {u_lo, u_hi} (exact fp16 integers 0..15) -> {(u_lo - 8) s_lo, (u_hi - 8) s_hi}, one rounding each
-template <bool BIG> __device__ __forceinline__ f16x2 deq_pair(uint32_t upair, f16x2 s2, f16x2 m8s2)
+// 8 nibbles of one row (two's complement, nibble p = element p) times the row's group scale, in the order
+// e0 e4 e1 e5 e2 e6 e3 e7 (pairs are 16 bits apart); the query operand is loaded in the same order (q_operand)
+__device__ __forceinline__ f16x8 deq_row8(uint32_t w, f16x2 s2)
 {
-    if (BIG) {
-        const f16x2 k8 = {static_cast<_Float16>(8.0f), static_cast<_Float16>(8.0f)};
-        return (as_h2(upair) - k8) * s2;
-    }
-    return __builtin_elementwise_fma(as_h2(upair), s2, m8s2);
-}
-// 8 nibbles of one row (offset binary, low nibble = even element) -> 8 fp16 values times the row's group scale
-template <bool BIG> __device__ __forceinline__ f16x8 deq_row8(uint32_t wx, f16x2 s2, f16x2 m8s2)
-{
-    const uint32_t lo = wx & 0x0F0F0F0Fu, hi = (wx >> 4) & 0x0F0F0F0Fu;     // elements 0,2,4,6 / 1,3,5,7
-    const f16x2 a = deq_pair<BIG>(cvt_pair(0, lo, hi), s2, m8s2), b = deq_pair<BIG>(cvt_pair(1, lo, hi), s2, m8s2);
-    const f16x2 c = deq_pair<BIG>(cvt_pair(2, lo, hi), s2, m8s2), d = deq_pair<BIG>(cvt_pair(3, lo, hi), s2, m8s2);
+    const uint32_t w8 = w >> 8;
+    const f16x2 a = deq_pair<0>(w, s2), b = deq_pair<1>(w, s2), c = deq_pair<0>(w8, s2), d = deq_pair<1>(w8, s2);
     return f16x8{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
 }
-// a group scale beyond 8188 (0x6FFF): -8 s is not a finite fp16
-__device__ __forceinline__ bool scale_is_big(uint32_t ored_bits16) { return (ored_bits16 & 0x7FFFu) > 0x6FFFu; }
+// 8 consecutive fp16 query elements q0..q7 -> the operand order of deq_row8
+__device__ __forceinline__ f16x8 q_operand(uint4 t)
+{
+    const uint32_t w0 = __builtin_amdgcn_perm(t.z, t.x, 0x05040100u), w1 = __builtin_amdgcn_perm(t.z, t.x, 0x07060302u);   // q0 q4 | q1 q5
+    const uint32_t w2 = __builtin_amdgcn_perm(t.w, t.y, 0x05040100u), w3 = __builtin_amdgcn_perm(t.w, t.y, 0x07060302u);   // q2 q6 | q3 q7
+    return __builtin_bit_cast(f16x8, make_uint4(w0, w1, w2, w3));
+}
 
 // ---- the arithmetic of one 32-position tile, shared by the two kernels below ----------------------------------------
 // scores of one block of 16 positions: S^T = K . q^T (raw dot products)
-__device__ __forceinline__ f32x4 score_block(const uint4& kx, uint32_t ks16, bool kbig, const f16x8 (&qv)[4])
+__device__ __forceinline__ f32x4 score_block(const uint4& kx, uint32_t ks16, const f16x8 (&qv)[4])
 {
     const _Float16 sh = __builtin_bit_cast(_Float16, static_cast<uint16_t>(ks16));
     const f16x2 s2 = {sh, sh};
-    const f16x2 km8 = {static_cast<_Float16>(-8.0f), static_cast<_Float16>(-8.0f)};
-    const f16x2 m8s2 = s2 * km8;
-    const uint32_t w[4] = {kx.x ^ 0x88888888u, kx.y ^ 0x88888888u, kx.z ^ 0x88888888u, kx.w ^ 0x88888888u};
+    const uint32_t w[4] = {kx.x, kx.y, kx.z, kx.w};
     f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
 #ifdef SPECKV_ABL_NO_QK
     s[0] = __uint_as_float((w[0] ^ w[1] ^ w[2] ^ w[3]) & 0x3F000000u) + static_cast<float>(s2.x);
-    if (false) {
 #else
-    if (!kbig) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8(w[st], s2), qv[st], s, 0, 0, 0);
 #endif
-#pragma unroll
-        for (int st = 0; st < 4; ++st)
-            s = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8<false>(w[st], s2, m8s2), qv[st], s, 0, 0, 0);
-    } else {
-#pragma unroll
-        for (int st = 0; st < 4; ++st)
-            s = __builtin_amdgcn_mfma_f32_16x16x32_f16(deq_row8<true>(w[st], s2, m8s2), qv[st], s, 0, 0, 0);
-    }
     return s;
 }
 
@@ -168,11 +146,10 @@ __device__ __forceinline__ f16x8 softmax_tile(const float (&sc)[8], float qscale
     return P;
 }
 
-// out^T += V^T . P^T, accumulated in place.  vw[j] = 8 nibbles (offset binary) of position slot j at d = 8c..8c+7,
-// vs16[j] = that slot's group scale (group c/4).  Element d = 8c + t of the two positions of a pair: nibble t&1 of byte
-// t/2 of either position's dword.
-// (CHECK_BIG false: the caller knows that no group scale of the allocation is beyond 8188)
-template <bool CHECK_BIG>
+// out^T += V^T . P^T, accumulated in place.  vw[j] = 8 nibbles (two's complement) of position slot j at d = 8c..8c+7,
+// vs16[j] = that slot's group scale (group c/4).  The MFMA of column d = 8c + t wants nibble t of all 8 slots, as pairs
+// (slot 2jp, slot 2jp+1): two byte permutes per slot pair put the low halves of both dwords (nibbles 0..3) into one
+// register and the high halves into another, nibbles of the two slots 16 bits apart, as deq_pair wants them.
 __device__ __forceinline__ void pv_tile(const uint32_t (&vw)[8], const uint32_t (&vs16)[8], const f16x8& P, f32x4 (&acc)[8])
 {
 #ifdef SPECKV_ABL_NO_PV
@@ -184,35 +161,29 @@ __device__ __forceinline__ void pv_tile(const uint32_t (&vw)[8], const uint32_t 
         return;
     }
 #endif
-    f16x2 s2[4], m8s2[4];
-    bool vbig = false;
-    if (CHECK_BIG) {
-        uint32_t sor = 0;
+    f16x2 s2[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sor |= vs16[j];
-        vbig = __builtin_amdgcn_ballot_w64(scale_is_big(sor)) != 0ull;               // wave-uniform
-    }
-#pragma unroll
-    for (int jp = 0; jp < 4; ++jp) {
-        const f16x2 km8 = {static_cast<_Float16>(-8.0f), static_cast<_Float16>(-8.0f)};
-        s2[jp] = as_h2(vs16[2 * jp] | (vs16[2 * jp + 1] << 16));
-        m8s2[jp] = s2[jp] * km8;
-    }
-    // even d columns (t = 0, 2, 4, 6) come from the low nibbles, odd ones from the high nibbles: one nibble plane
-    // is live at a time (the plane replaces the dwords it came from)
+    for (int jp = 0; jp < 4; ++jp) s2[jp] = as_h2(vs16[2 * jp] | (vs16[2 * jp + 1] << 16));
+    // one nibble plane pair is live at a time: t = 0, 1 from the low halves, 2, 3 from the same shifted by 8, then the
+    // high halves (the planes replace the dwords they came from)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        uint32_t nb[8];
+        uint32_t x[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) nb[j] = (half ? (vw[j] >> 4) : vw[j]) & 0x0F0F0F0Fu;
-        if (!vbig) {
+        for (int jp = 0; jp < 4; ++jp) x[jp] = __builtin_amdgcn_perm(vw[2 * jp + 1], vw[2 * jp], half ? 0x07060302u : 0x05040100u);
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const int t = 2 * tt + half;
+        for (int sh = 0; sh < 2; ++sh) {
+            if (sh) {
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) x[jp] >>= 8;
+            }
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                const int t = 4 * half + 2 * sh + hi;
                 f16x8 V;
 #pragma unroll
                 for (int jp = 0; jp < 4; ++jp) {
-                    const f16x2 v = deq_pair<false>(cvt_pair(tt, nb[2 * jp], nb[2 * jp + 1]), s2[jp], m8s2[jp]);
+                    const f16x2 v = hi ? deq_pair<1>(x[jp], s2[jp]) : deq_pair<0>(x[jp], s2[jp]);
                     V[2 * jp] = v.x;
                     V[2 * jp + 1] = v.y;
                 }
@@ -220,19 +191,6 @@ __device__ __forceinline__ void pv_tile(const uint32_t (&vw)[8], const uint32_t 
                 // V stays live past the MFMA: otherwise the register allocator writes the result over V, away from
                 // acc[t], and moves all 32 accumulators back at the end of every iteration
                 asm volatile("" :: "v"(V));
-            }
-        } else {
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const int t = 2 * tt + half;
-                f16x8 V;
-#pragma unroll
-                for (int jp = 0; jp < 4; ++jp) {
-                    const f16x2 v = deq_pair<true>(cvt_pair(tt, nb[2 * jp], nb[2 * jp + 1]), s2[jp], m8s2[jp]);
-                    V[2 * jp] = v.x;
-                    V[2 * jp + 1] = v.y;
-                }
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t], 0, 0, 0);
             }
         }
     }
@@ -311,7 +269,7 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
     }
     uint8_t* vl = lds[wave];
 
-    // query operand: fp16 row c of this head, d = 32kb + 8*step + e (rows >= g are zero)
+    // query operand: fp16 row c of this head, d = 32kb + 8*step + e in deq_row8's element order (rows >= g are zero)
     f16x8 qv[4];
     {
         const uint16_t* q16 = reinterpret_cast<const uint16_t*>(a.q8) + (row * a.g + c) * 128u + kb * 32u;
@@ -319,7 +277,7 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
         for (int st = 0; st < 4; ++st) {
             uint4 t = make_uint4(0u, 0u, 0u, 0u);
             if (c < a.g) t = *reinterpret_cast<const uint4*>(q16 + 8 * st);
-            qv[st] = __builtin_bit_cast(f16x8, t);
+            qv[st] = q_operand(t);
         }
     }
     const float qscale = a.scale_log2e;
@@ -401,10 +359,9 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
             const uint32_t step = (tile + 1u < t1) ? tile_bytes : 0u;    // the last iteration re-requests its own tile
             // ---- scores (raw dot products: sm_scale * log2(e) joins in the exponent below)
             float sc[8];
-            const bool kbig = __builtin_amdgcn_ballot_w64(scale_is_big(static_cast<uint32_t>(ks[0]) | ks[1])) != 0ull;   // wave-uniform
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const f32x4 s = score_block(kx[b], ks[b], kbig, qv);
+                const f32x4 s = score_block(kx[b], ks[b], qv);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sc[4 * b + i] = s[i];
             }
@@ -430,7 +387,7 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int ro = (j < 4) ? j : 16 + (j - 4);
-                vw[j] = *reinterpret_cast<const uint32_t*>(rdb + 128 * ro) ^ 0x88888888u;     // 8 nibbles of slot j, d = 8c..8c+7
+                vw[j] = *reinterpret_cast<const uint32_t*>(rdb + 128 * ro);                   // 8 nibbles of slot j, d = 8c..8c+7
                 vs16[j] = *reinterpret_cast<const uint16_t*>(rsb + 8 * ro);                   // its group scale (group c/4)
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -439,7 +396,7 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
             vdat += step; vsc += step; next_v += step ? 1u : 0u;
             issue_v();                                                    // the staging registers are free again
             __builtin_amdgcn_sched_barrier(0);
-            pv_tile<true>(vw, vs16, P, acc);
+            pv_tile(vw, vs16, P, acc);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -499,7 +456,10 @@ __device__ __forceinline__ void wg_take_v(const uint32_t (&rd)[4], uint32_t rs, 
 }
 } // namespace
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_attend_int4_wg(AttendArgs a)
+#ifndef SPECKV_INT4_WG_WAVES
+#define SPECKV_INT4_WG_WAVES 3
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4_WG_WAVES, SPECKV_INT4_WG_WAVES))) void k_attend_int4_wg(AttendArgs a)
 {
     static_assert(kWgHeads == 4, "the cooperative kernel is laid out for 4 heads per workgroup");
     __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kWgBuf];
@@ -527,10 +487,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         my_splits = sq.n_splits;
         part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
         layer = 0;
-        a.big_flag = sq.big_flag;
     }
-    // workgroup-uniform: has a group scale beyond 8188 (or a non-finite one) ever been stored in this allocation?
-    const bool big_any = a.big_flag == nullptr || __builtin_amdgcn_readfirstlane(*a.big_flag) != 0u;
 
     f16x8 qv[4];
     {
@@ -539,7 +496,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int st = 0; st < 4; ++st) {
             uint4 t = make_uint4(0u, 0u, 0u, 0u);
             if (c < a.g) t = *reinterpret_cast<const uint4*>(q16 + 8 * st);
-            qv[st] = __builtin_bit_cast(f16x8, t);
+            qv[st] = q_operand(t);
         }
     }
     const float qscale = a.scale_log2e;
@@ -590,11 +547,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         issue(t0, 0u);
         if (t0 < last) issue(t0 + 1u, 1u);
         const bool ragged = (a.n_pages & 15u) != 0u;
-        // one loop, compiled twice: with the per-tile "is a scale of this tile beyond 8188" checks and the subtract-first
-        // dequantisation behind them, and without (a second arithmetic path in the loop costs ~60 of its ~390 vector
-        // instructions per tile -- the checks, and 32 accumulator moves where the two paths merge)
-        auto tiles = [&](auto checked) {
-        constexpr bool kCheck = decltype(checked)::value;
 #pragma unroll 1
         for (uint32_t tile = t0; tile < t1; ++tile) {
             const uint32_t buf = (tile - t0) & 1u;
@@ -604,10 +556,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             uint32_t ks0, ks1;
             wg_take_k(rdk + bo, rsk + bo, k0, k1, ks0, ks1);
             float sc[8];
-            const bool kbig = kCheck && __builtin_amdgcn_ballot_w64(scale_is_big(ks0 | ks1)) != 0ull;   // wave-uniform
             {
-                const f32x4 s0 = score_block(make_uint4(k0.x, k0.y, k0.z, k0.w), ks0, kbig, qv);
-                const f32x4 s1 = score_block(make_uint4(k1.x, k1.y, k1.z, k1.w), ks1, kbig, qv);
+                const f32x4 s0 = score_block(make_uint4(k0.x, k0.y, k0.z, k0.w), ks0, qv);
+                const f32x4 s1 = score_block(make_uint4(k1.x, k1.y, k1.z, k1.w), ks1, qv);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { sc[i] = s0[i]; sc[4 + i] = s1[i]; }
             }
@@ -624,13 +575,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             wg_take_v(rdvb, rsv + bo, vw, vs16);
             asm volatile("s_barrier" ::: "memory");                       // every wave has taken what it needs from this buffer
             if (tile + 2u <= last) issue(tile + 2u, buf);                 // (taking V earlier, to issue earlier, measured the same)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) vw[j] ^= 0x88888888u;
-            pv_tile<kCheck>(vw, vs16, P, acc);
+            pv_tile(vw, vs16, P, acc);
         }
-        };
-        if (big_any) tiles(std::true_type{});
-        else         tiles(std::false_type{});
     }
     store_partial(a, part, row, my_splits, c, kb, m_run, l_run, acc);
 }

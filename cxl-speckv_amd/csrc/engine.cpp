@@ -422,13 +422,12 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
             }
             uint32_t* dev3 = nullptr;
             if (ok) ok = hipMalloc(reinterpret_cast<void**>(&a->d_entries), a->n_pages * sizeof(PageEntry)) == hipSuccess;
-            if (ok) ok = hipMalloc(reinterpret_cast<void**>(&dev3), (3 * a->n_pages + 1) * sizeof(uint32_t)) == hipSuccess;
+            if (ok) ok = hipMalloc(reinterpret_cast<void**>(&dev3), 3 * a->n_pages * sizeof(uint32_t)) == hipSuccess;
             if (ok) {
                 a->d_flags = dev3; a->d_slot = dev3 + a->n_pages; a->d_stamp = dev3 + 2 * a->n_pages;
-                a->d_int4_big = dev3 + 3 * a->n_pages;
                 ok = hipMemsetAsync(a->d_flags, 0, a->n_pages * sizeof(uint32_t), stream_) == hipSuccess &&
                      hipMemsetAsync(a->d_slot, 0xFF, a->n_pages * sizeof(uint32_t), stream_) == hipSuccess &&
-                     hipMemsetAsync(a->d_stamp, 0, (a->n_pages + 1) * sizeof(uint32_t), stream_) == hipSuccess;
+                     hipMemsetAsync(a->d_stamp, 0, a->n_pages * sizeof(uint32_t), stream_) == hipSuccess;
             }
             if (ok) ok = hipHostMalloc(&a->pinned, a->n_pages * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocPortable) == hipSuccess;
             if (ok) {
@@ -516,7 +515,7 @@ void Engine::release_allocation(Allocation* a)
     if (a->d_scale_tab) { (void)hipFree(a->d_scale_tab); a->d_scale_tab = nullptr; }
     if (a->pinned) { (void)hipHostFree(a->pinned); a->pinned = nullptr; }
     a->d_entries = nullptr;
-    a->d_flags = a->d_slot = a->d_stamp = a->d_int4_big = nullptr;
+    a->d_flags = a->d_slot = a->d_stamp = nullptr;
     a->flags = a->slot = nullptr;
 }
 
@@ -1517,7 +1516,6 @@ int Engine::write(uint64_t handle, uint64_t off, const void* src, size_t len, bo
     CodecArgs c{};
     c.entries = a->d_entries;
     c.scale_tab = a->d_scale_tab;        // fused-attention scale table follows every write
-    c.big_flag = a->d_int4_big;
     c.region_pages = a->region_pages;
     c.data_stride = kPageSize;
     c.scheme = a->scheme;
@@ -1591,7 +1589,6 @@ int Engine::write_strided(uint64_t handle, uint64_t first, uint64_t step, uint64
     CodecArgs c{};
     c.entries = a->d_entries;
     c.scale_tab = a->d_scale_tab;
-    c.big_flag = a->d_int4_big;
     c.region_pages = a->region_pages;
     c.data_stride = kPageSize;
     c.scheme = a->scheme;
@@ -1665,7 +1662,7 @@ int Engine::write_strided_batch(const uint64_t* handles, const uint64_t* firsts,
     CompressGroup* d_slot = reinterpret_cast<CompressGroup*>(reinterpret_cast<uint8_t*>(d_groups_) + static_cast<size_t>(slot) * grp_ring_.slot_bytes);
     for (uint32_t i = 0; i < n_alloc; ++i) {
         const Allocation* a = as[i];
-        staged[i] = CompressGroup{a->d_entries, a->d_scale_tab, a->d_int4_big, a->region_pages, 0u, firsts[i],
+        staged[i] = CompressGroup{a->d_entries, a->d_scale_tab, a->region_pages, 0u, firsts[i],
                                   static_cast<const uint8_t*>(d_srcs[i])};
     }
     HIP_TRY(hipMemcpyAsync(d_slot, staged, bytes, hipMemcpyHostToDevice, s));
@@ -2111,7 +2108,6 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
         heads = L.num_heads;
         note_use(a, s);
         seqs[i].lin_base = a->linear_base;
-        seqs[i].big_flag = a->d_int4_big;
         seqs[i].scale_tab = a->d_scale_tab;
         seqs[i].k_first = static_cast<uint64_t>(layer) * L.num_tokens;       // (layer*2*T)/2
         seqs[i].v_first = seqs[i].k_first + L.num_tokens / 2;
@@ -2240,7 +2236,6 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
         heads = L.num_heads;
         note_use(a, s);
         seqs[i].lin_base = a->linear_base;
-        seqs[i].big_flag = a->d_int4_big;
         seqs[i].scale_tab = a->d_scale_tab;
         seqs[i].k_first = 0;                                   // layer 0; the launch adds layer * layer_pages
         seqs[i].v_first = L.num_tokens / 2;
@@ -2410,7 +2405,6 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     k.q8 = static_cast<const uint8_t*>(d_q_f16);
     k.scale_log2e = sm_scale * 1.4426950408889634f;
     k.lin_base = linear ? a->linear_base : nullptr;
-    k.big_flag = a->d_int4_big;
     k.zero_page = d_zero_page_;
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);

@@ -77,7 +77,6 @@ struct Allocation {
     uint32_t* d_flags = nullptr;
     uint32_t* d_slot = nullptr;
     uint32_t* d_stamp = nullptr;
-    uint32_t* d_int4_big = nullptr;       // one word: an INT4 group scale beyond 8188 was ever stored here (CodecArgs::big_flag)
     // set while every record lies in ONE run of one local pool (record p at linear_base + p*rec_stride)
     // and, for the fixed-size formats, never-written records are zero bytes; cleared by a migration
     uint8_t* linear_base = nullptr;

@@ -808,12 +808,11 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                                          : a.data + i * a.data_stride;
         PageEntry* entries = a.entries;
         float* scale_tab = a.scale_tab;
-        uint32_t* big_flag = a.big_flag;
         uint32_t region_pages = a.region_pages;
         if (a.groups) {                                              // wave-uniform: this block's allocation
             const uint64_t gi = i / a.group_n, j = i - gi * a.group_n;
             const CompressGroup g = a.groups[gi];
-            entries = g.entries; scale_tab = g.scale_tab; big_flag = g.big_flag; region_pages = g.region_pages;
+            entries = g.entries; scale_tab = g.scale_tab; region_pages = g.region_pages;
             page = g.first + j * (a.page_step ? a.page_step : 1);
             src = g.data + j * a.data_stride;
         }
@@ -834,7 +833,6 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
             out_len = 2u * kBlockElems;
         } else if (SCHEME == kInt4G32) {
             // per group of 32 elements (4 lanes x 8): s = fp16(max|x|/7), q = clamp(round(x/s), -7, 7)
-            bool big_scale = false;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t words[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
@@ -853,7 +851,6 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                 asm volatile("" : "+v"(sdiv));                      // keep the fp32 rounding of the divide
                 const _Float16 s16 = static_cast<_Float16>(sdiv);
                 const float sc = static_cast<float>(s16);
-                big_scale |= (__builtin_bit_cast(uint16_t, s16) & 0x7FFFu) > 0x6FFFu;
                 uint32_t nib = 0;
                 if (finite) {
                     // |x| <= 7.5*sc in a finite group: the reciprocal divide is exact (test_fast_division_is_exact)
@@ -882,7 +879,6 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                     *reinterpret_cast<uint16_t*>(rec + 2u * (p0 >> 5)) = __builtin_bit_cast(uint16_t, s16);
             }
             out_len = kInt4RecBytes;
-            if (big_flag && __builtin_amdgcn_ballot_w64(big_scale) != 0ull && lane == 0) atomicOr(big_flag, 1u);
         } else if (SCHEME == kFp8E4m3) {
             float x[4][8];
             float mx = 0.0f, nanacc = 0.0f;

@@ -53,7 +53,6 @@ constexpr uint64_t kNoOwner = ~0ull;
 struct CompressGroup {
     PageEntry*     entries;
     float*         scale_tab;
-    uint32_t*      big_flag;
     uint32_t       region_pages;
     uint32_t       pad;
     uint64_t       first;
@@ -96,11 +95,8 @@ struct CodecArgs {
     // (layer, kind) region of the shim layout, a multiple of 16
     float*          scale_tab;
     uint32_t        region_pages;
-    // compress only, INT4_G32: set to 1 (atomically, never cleared) when a group scale beyond 8188 or a non-finite one is
-    // stored -- the fused attention then takes its checked path for this allocation (attend_int4.hip, scale_is_big)
-    uint32_t*       big_flag;
     // compress only: blocks of several allocations in one launch -- block i belongs to groups[i / group_n] (device array)
-    // as its page i % group_n; entries / scale_tab / region_pages / big_flag / first / data above are then unused
+    // as its page i % group_n; entries / scale_tab / region_pages / first / data above are then unused
     const CompressGroup* groups;
     uint64_t        group_n;
     // blocks of several allocations in one launch (decompress only): block i belongs to row alloc_list[i] of tab
@@ -204,7 +200,7 @@ struct AttendSeq {
     uint32_t n_splits;                // ceil(tiles / tiles_per_split), <= gridDim.x
     uint32_t part_base;
     uint32_t tiles_per_split;         // this sequence's own split length (its tiles divided evenly over n_splits)
-    const uint32_t* big_flag;         // INT4: see AttendArgs::big_flag
+    uint64_t reserved;
     uint32_t layer_pages;             // pages of one layer (K + V): layer l of a planned batch starts at k_first + l * layer_pages
     uint32_t pad;
 };
@@ -227,9 +223,6 @@ struct AttendArgs {
     const float* scale_tab;           // linear form: page scales of the whole allocation in tile order (attend.hip)
     const uint16_t* q16;              // linear form: the fp16 query rows [layers][heads][g][128] (quantised in the kernel)
     const struct AttendSeq* seqs;     // batch form: one descriptor per sequence (blockIdx.y / (heads/4)), else null
-    // INT4: the allocation's "a group scale beyond 8188 was stored" word (CodecArgs::big_flag); null = unknown, check
-    // every tile.  While it reads 0 the kernel runs without the per-tile checks and without the subtract-first path.
-    const uint32_t* big_flag;
     float* part_acc;                  // [layers][heads][splits][16][128]
     float* part_ml;                   // [layers][heads][splits][2][16]
     // every row has exactly ONE split (set by the engine then): the attention kernel normalises and writes the final
