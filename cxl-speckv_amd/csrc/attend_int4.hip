@@ -26,7 +26,6 @@
 //   output O^T = V^T . P^T: rows c = d columns 8c + t, k-slots = the lane's 8 positions (as in
 //     attend.hip): the V tile goes through LDS and is read back as "8 nibbles of one position" dwords.
 #include "kernels.hpp"
-#include <type_traits>
 
 namespace speckv {
 
@@ -456,6 +455,7 @@ __device__ __forceinline__ void wg_take_v(const uint32_t (&rd)[4], uint32_t rs, 
 }
 } // namespace
 
+// 3 waves per SIMD: 4 fit (109 VGPRs, 4 x 40 KiB of LDS) and measure the same (-DSPECKV_INT4_WG_WAVES=4)
 #ifndef SPECKV_INT4_WG_WAVES
 #define SPECKV_INT4_WG_WAVES 3
 #endif
