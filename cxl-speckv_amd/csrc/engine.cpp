@@ -184,6 +184,7 @@ int Engine::init_hip(int device)
     // cxl_memory_manager.h:42-44; ours are env-tunable and allocated up front)
     const size_t l2_mb = env_mb("SPECKV_L2_MB", 256), l1_mb = env_mb("SPECKV_L1_MB", 256);
     if (const char* e = getenv("SPECKV_RING_SEQ_LIMIT")) ring_seq_limit_ = static_cast<uint32_t>(strtoul(e, nullptr, 0));   // tests
+    if (const char* e = getenv("SPECKV_FLUSH_HOST_WORDS")) flush_words_mode_ = e[0] == 's' ? 1 : 2;                          // scatter / fetch (tests, A/B)
     n_l2_ = static_cast<uint32_t>((l2_mb << 20) / kPageSize);
     n_l1_ = static_cast<uint32_t>((l1_mb << 20) / kPageSize);
     if (n_l2_ < 64) n_l2_ = 64;
@@ -1219,7 +1220,11 @@ int Engine::flush_group(int scheme, const uint32_t* const cols[5], uint32_t n, u
     const uint64_t words = static_cast<uint64_t>(n) * 32u * W;
     const uint32_t n_w = static_cast<uint32_t>((words + 63u) >> 6);
     const uint32_t max_take = static_cast<uint32_t>(std::min<uint64_t>(n_l2_ / 2, words));   // never let one flush wipe the whole ring
-    const size_t bytes = (5ull * n + words + 2ull * n_w + 8 + 6ull * max_take + 4) * sizeof(uint32_t);     // + descriptors (16 B) and destinations (8 B)
+    // The pages' host-visible words (one PCIe transaction each) are stored by the scatter kernel, in front of the fetch,
+    // or -- large flushes -- by the fetch launch itself, spread over it: 20 480 requests -> 122 880 pages 0.213 -> 0.198 ms
+    // until landed; at 8 192 requests -> 19 095 pages the fetch is too short to hide them (0.102 -> 0.104).
+    const bool words_by_fetch = flush_words_mode_ == 2 || (flush_words_mode_ == 0 && words > (1u << 19));
+    const size_t bytes = (5ull * n + words + 2ull * n_w + 8 + 6ull * max_take + 4 + (words_by_fetch ? 2ull * max_take + 2 : 0)) * sizeof(uint32_t);     // + descriptors (16 B), destinations (8 B), word addresses (8 B)
     uint32_t* buf = static_cast<uint32_t*>(scratch(s_flush_, bytes));
     if (!buf) return SPECKV_ERR_NOMEM;
     // request upload through a pinned slot (4 in rotation, each guarded by an event): no stream sync
@@ -1252,6 +1257,7 @@ int Engine::flush_group(int scheme, const uint32_t* const cols[5], uint32_t n, u
     f.wave_tot = f.cand + words;
     f.final_entry = reinterpret_cast<PageEntry*>((reinterpret_cast<uintptr_t>(f.wave_tot + 2ull * n_w + 8) + 15u) & ~uintptr_t(15));
     f.final_dst = reinterpret_cast<uint64_t*>(f.final_entry + max_take);
+    if (words_by_fetch) f.final_host = reinterpret_cast<uint32_t**>(f.final_dst + max_take);
     f.ring_owner = d_owner_;
     f.ring_base = cache_base_;
     f.max_take = max_take;
@@ -1275,6 +1281,7 @@ int Engine::flush_group(int scheme, const uint32_t* const cols[5], uint32_t n, u
     c.data_list = f.final_dst;
     c.n = max_take;
     c.n_dev = &f.result_dev->m;
+    if (words_by_fetch) { c.host_words = f.final_host; c.seq0_dev = &f.result_dev->seq; }
     c.scheme = scheme;
     c.quant_mode = quant_mode_;
     HIP_TRY(launch_decompress(c, stream_));

@@ -164,6 +164,7 @@ private:
     std::unique_lock<std::mutex>* lk_ = nullptr;
     hipStream_t stream_ = nullptr;         // fetch / codec side stream
     hipStream_t copy_stream_ = nullptr;    // peer copies (pool <-> pool migration)
+    int flush_words_mode_ = 0;             // who stores a flush's host-visible words: 0 by size, 1 scatter kernel, 2 fetch launch
     std::vector<int> pool_devs_;           // pool GPUs in SPECKV_POOL_DEVICES order (also kept on the fake device)
     std::vector<std::unique_ptr<SlabPool>> pools_;
 

@@ -458,6 +458,7 @@ struct BlockDesc {
 //   0  page table / raw records, range or list            (speckv_ext_fetch_range / _list, codec operators)
 //   1  + records staged by the copy engines               (stripe_delta)
 //   2  + blocks of several allocations, L2-ring bookkeeping (synchronous misses, device-side flush)
+//   3  form 0 + one host-visible word per block (the fetch launch of a device-side flush)
 template <int EXT>
 __device__ __forceinline__ BlockDesc load_desc(const CodecArgs& a, uint64_t i, uint32_t slot0)
 {
@@ -527,6 +528,7 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
         seq0 = a.seq0_dev ? *a.seq0_dev : a.seq0;
         if (a.hand_ptr && blockIdx.x == 0 && threadIdx.x == 0) *a.hand_ptr = a.new_hand;
     }
+    if (EXT == 3) seq0 = *a.seq0_dev;
     // a wave's blocks: one, or (launches beyond the grid cap) `per_wave` of them, one grid apart (wave_step) or
     // consecutive (SPECKV_ROUNDS=consecutive); see codec_grid / round_strided
     const uint64_t per_wave = a.per_wave ? a.per_wave : 1;
@@ -562,6 +564,7 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
         }
         if (lane == 0u) {
             if (EXT == 2 && a.ring_owner) ring_note(a, cur, slot0 + static_cast<uint32_t>(i), seq0 + static_cast<uint32_t>(i));
+            else if (EXT == 3) *a.host_words[i] = seq0 + static_cast<uint32_t>(i);
             else if (a.flags) atomicOr(&a.flags[cur.page], a.set_flags);   // neighbours belong to other waves / XCDs
         }
         if (nx >= end) break;
@@ -1175,7 +1178,8 @@ __global__ __launch_bounds__(256) void k_flush_mark(FlushArgs a, const FlushResu
             }
             a.ring_owner[slot] = me;
             t.d_slot[pg] = slot;
-            t.h_slot[pg] = res->seq + rank;      // the page's only host-visible word (Engine::l2_live)
+            if (a.final_host) a.final_host[rank] = &t.h_slot[pg];     // stored by the fetch launch (CodecArgs::host_words)
+            else t.h_slot[pg] = res->seq + rank;                      // the page's only host-visible word (Engine::l2_live)
             atomicOr(&t.d_flags[pg], 2u);
         }
     }
@@ -1676,12 +1680,13 @@ hipError_t launch_dec2(const CodecArgs& a_in, hipStream_t s)
     CodecArgs a = a_in;
     const uint32_t grid = codec_grid(a.n, &a.per_wave);
     a.wave_step = (round_strided() && a.per_wave > 1) ? static_cast<uint64_t>(grid) * kWaves : 0;
-    const int ext = (a.alloc_list || a.ring_owner) ? 2 : a.stripe_n ? 1 : 0;
+    const int ext = a.host_words ? 3 : (a.alloc_list || a.ring_owner) ? 2 : a.stripe_n ? 1 : 0;
     if (ext == 2 && a.stripe_n) return hipErrorInvalidValue;
+    if (ext == 3 && (a.out_f32 || a.alloc_list || a.ring_owner || a.stripe_n || !a.seq0_dev || !a.data_list)) return hipErrorInvalidValue;
 #define SPECKV_LAUNCH_DEC(F32, EXT) \
     hipLaunchKernelGGL((k_fetch_decompress<SCHEME, MODE, F32, EXT>), dim3(grid), dim3(kThreads), 0, s, a)
     if (a.out_f32) { if (ext == 2) SPECKV_LAUNCH_DEC(true, 2); else if (ext == 1) SPECKV_LAUNCH_DEC(true, 1); else SPECKV_LAUNCH_DEC(true, 0); }
-    else           { if (ext == 2) SPECKV_LAUNCH_DEC(false, 2); else if (ext == 1) SPECKV_LAUNCH_DEC(false, 1); else SPECKV_LAUNCH_DEC(false, 0); }
+    else           { if (ext == 3) SPECKV_LAUNCH_DEC(false, 3); else if (ext == 2) SPECKV_LAUNCH_DEC(false, 2); else if (ext == 1) SPECKV_LAUNCH_DEC(false, 1); else SPECKV_LAUNCH_DEC(false, 0); }
 #undef SPECKV_LAUNCH_DEC
     return hipGetLastError();
 }

@@ -112,6 +112,9 @@ struct CodecArgs {
     const uint32_t* slot0_dev;
     uint32_t        slot0;
     const uint32_t* seq0_dev;     // ring sequence number of slot0 (block i: seq0 + i), stored as the page's host-visible word
+    // device-side flush (list form): block i's host-visible word *host_words[i] = *seq0_dev + i is stored by the fetch
+    // itself, spread over the launch, instead of by the scatter kernel in front of it (FlushArgs::final_host)
+    uint32_t* const* host_words;
     uint32_t        seq0;
     uint32_t        alloc_idx;    // row of tab for every block when alloc_list == nullptr
     uint32_t*       hand_ptr;     // optional: block 0 stores new_hand = the ring sequence number after this take (host-initiated takes keep the device's current)
@@ -171,6 +174,9 @@ struct FlushArgs {
     uint32_t*       hand;         // device ring hand
     FlushResult*    result_dev;   // m is read by the fetch launch (n_dev)
     FlushResult*    result_host;  // the same, stored to pinned host memory
+    // null: the scatter kernel stores every page's host-visible word itself (one PCIe transaction per page, all of them in
+    // front of the fetch); else it lists the words' addresses and the fetch launch stores them (CodecArgs::host_words)
+    uint32_t**      final_host;   // [max_take]
 };
 hipError_t launch_flush_pipeline(const FlushArgs& a, hipStream_t s);
 

@@ -52,8 +52,11 @@ def expected_flush(oracle, reqs, geom, n_pages, resident=()):
     return out
 
 
-def test_flush_keeps_first_occurrence_order_and_assigns_slots_in_it(oracle):
-    lib = open_lib(SPECKV_L2_MB=64)
+@pytest.mark.parametrize("host_words", ["scatter", "fetch"])
+def test_flush_keeps_first_occurrence_order_and_assigns_slots_in_it(oracle, host_words):
+    """host_words: the pages' host-visible residency words stored by the scatter kernel (small flushes) or by the fetch
+    launch itself (large ones) -- both forced here; translate() derives the L2 bit from exactly those words."""
+    lib = open_lib(SPECKV_L2_MB=64, SPECKV_FLUSH_HOST_WORDS=host_words)
     try:
         lib.set_compression_scheme(2)
         geom = (T, L, H, D, bpe) = (1024, 6, 8, 128, 2)
@@ -95,9 +98,10 @@ def test_flush_keeps_first_occurrence_order_and_assigns_slots_in_it(oracle):
         lib.finalize()
 
 
-def test_flush_over_many_allocations_with_request_bindings(oracle):
+@pytest.mark.parametrize("host_words", ["scatter", "fetch"])
+def test_flush_over_many_allocations_with_request_bindings(oracle, host_words):
     """One allocation per sequence (the serving layout): request ids are bound to handles, one flush serves them all."""
-    lib = open_lib()
+    lib = open_lib(SPECKV_FLUSH_HOST_WORDS=host_words)
     try:
         lib.set_compression_scheme(1)
         geom = (T, L, H, D, bpe) = (256, 4, 8, 128, 2)
@@ -143,14 +147,14 @@ def test_flush_over_many_allocations_with_request_bindings(oracle):
         lib.finalize()
 
 
-@pytest.mark.parametrize("seq_limit", [None, 700])
-def test_ring_wrap_and_eviction_by_the_fetch_kernel(oracle, seq_limit):
+@pytest.mark.parametrize("seq_limit,host_words", [(None, "scatter"), (700, "scatter"), (None, "fetch"), (700, "fetch")])
+def test_ring_wrap_and_eviction_by_the_fetch_kernel(oracle, seq_limit, host_words):
     """A ring of 256 slots under flushes that wrap it several times: what is flagged resident really is there, evicted
     pages lose their bit, synchronous misses interleave with flushes, the host's ring hand stays in step.  The host derives
     "still in the ring" from the sequence number the fetch kernel stores for a page (its only host-visible store): with
     seq_limit the 32-bit sequence numbers are renumbered every few hundred slots instead of every 3 * 10^9, so the run
     crosses that code several times with live pages on both sides."""
-    env = {"SPECKV_L2_MB": 1, "SPECKV_L1_MB": 1}
+    env = {"SPECKV_L2_MB": 1, "SPECKV_L1_MB": 1, "SPECKV_FLUSH_HOST_WORDS": host_words}
     if seq_limit:
         env["SPECKV_RING_SEQ_LIMIT"] = seq_limit
     lib = open_lib(**env)
