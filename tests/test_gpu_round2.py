@@ -639,11 +639,12 @@ def test_kv_connector_block_tables_and_lookahead(oracle):
 
 
 def test_int4_attention_with_group_scales_near_the_fp16_limit(oracle):
-    """INT4_G32 groups whose largest |x| is beyond 57 000 get a scale above 8188: -8 s is then no finite fp16 and the
-    fused attention must dequantise subtract-first.  The compress kernel marks such an allocation (one sticky word), the
-    linear-form kernel runs its checked loop for it and its unchecked loop for every other allocation; the page-table
-    form always checks.  Expected values: the oracle's attention over the oracle's decompressed pages, tolerance as in
-    test_int4_fused_attention.  A group that took the unchecked path would produce -inf * 0 = NaN."""
+    """INT4_G32 groups whose largest |x| is beyond 57 000 get a scale above 8188: a dequantisation of the form
+    fp16(u) * s + (-8 s) has no finite -8 s there (the first fast path of this kernel needed a checked second path for
+    such groups).  The conversion now subtracts first for every group -- (1032 + q) - 1032, then one rounding in the
+    product with the scale -- so these pages are ordinary; this test keeps them covered: the oracle's attention over the
+    oracle's decompressed pages, tolerance as in test_int4_fused_attention, through the linear form and ((30, T)) through
+    the page table, and an allocation that once held such groups answers exactly like one that never did."""
     torch = torch_mod()
     from oracle.bindings import _ptr, u16p, f32p
     lib = open_lib()
@@ -690,15 +691,15 @@ def test_int4_attention_with_group_scales_near_the_fp16_limit(oracle):
         assert np.abs(big.astype(np.float32)).max() / 7.0 > 8188.0
         ranges = [(0, T), (0, 64), (64, 192), (30, T)]            # linear form, and (30, T) through the page table
         h_big = run_case(big, ranges)
-        h_plain = run_case(plain, ranges)                         # its own flag word: unchecked loop, same answers as ever
-        # the mark is sticky: overwriting the large groups with ordinary data keeps the (still correct) checked loop
+        h_plain = run_case(plain, ranges)
+        # overwrite the large groups with ordinary data: nothing of them may linger
         lib.write(h_big, 0, plain.ctypes.data, plain.nbytes, False)
         d_out = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
         d_ref = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
         lib.attend_int4(h_big, 0, 1, d_q.data_ptr(), G, 0, T, sm, d_out.data_ptr())
         lib.attend_int4(h_plain, 0, 1, d_q.data_ptr(), G, 0, T, sm, d_ref.data_ptr())
         torch.cuda.synchronize()
-        # same records, same split geometry: checked and unchecked loop differ only in code path, not in arithmetic
+        # same records, same split geometry: the same bits
         assert torch.equal(d_out, d_ref)
         lib.free(h_big); lib.free(h_plain)
     finally:
