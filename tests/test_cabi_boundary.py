@@ -196,6 +196,12 @@ def test_no_cpu_fallback_for_the_data_path(nulllib):
                  lambda: nulllib.write_strided_batch([h], [0], [C.addressof(buf)], 1, 1, 1),
                  lambda: nulllib.attend_fp8(h, 0, 1, C.addressof(buf), 8, 0, 32, 0.1, C.addressof(buf)),
                  lambda: nulllib.attend_int4(h, 0, 1, C.addressof(buf), 8, 0, 32, 0.1, C.addressof(buf)),
+                 lambda: nulllib.attend_fp8_batch([h], 0, C.addressof(buf), 8, [32], 0.1, C.addressof(buf), None, 1),
+                 lambda: nulllib.attend_batch_plan([h], [32], 32, C.addressof(buf), 64, 1),
+                 lambda: nulllib.attend_planned(4, C.addressof(buf), 1, 0, C.addressof(buf), 8, 32, 0.1, C.addressof(buf), None, 1),
+                 lambda: nulllib.attend_planned(3, C.addressof(buf), 1, 0, C.addressof(buf), 8, 32, 0.1, C.addressof(buf), None, 1),
+                 lambda: nulllib.attend_fold_tail(1, 0, 8, 8, C.addressof(buf), C.addressof(buf), C.addressof(buf), 1024, 0.1,
+                                                  C.addressof(buf), C.addressof(buf), 1),
                  lambda: nulllib.poll_complete()):
         with pytest.raises(SpeckvError) as ei:
             call()
