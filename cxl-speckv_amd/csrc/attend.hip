@@ -339,7 +339,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     uint32_t my_splits = a.n_splits;
     if (a.seqs) {                                                        // wave-uniform: per-sequence geometry
         const AttendSeq sq = a.seqs[layer];
-        if (split >= sq.n_splits) return;
+        if (split >= sq.n_splits) {
+            if (sq.n_splits == 0u && split == 0u && a.direct_out && a.direct_per_seq == 2u) attend_zero_rows(a, row, lane);
+            return;
+        }
         a.lin_base = sq.lin_base;
         a.scale_tab = sq.scale_tab;
         a.k_first = sq.k_first;
@@ -607,7 +610,10 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
     uint32_t my_splits = a.n_splits;
     if (a.seqs) {                                                        // wave-uniform: per-sequence geometry
         const AttendSeq sq = a.seqs[layer];
-        if (split >= sq.n_splits) return;
+        if (split >= sq.n_splits) {
+            if (sq.n_splits == 0u && split == 0u && a.direct_out && a.direct_per_seq == 2u) attend_zero_rows(a, row, lane);
+            return;
+        }
         a.lin_base = sq.lin_base;
         a.scale_tab = sq.scale_tab;
         a.k_first = sq.k_first;
@@ -1022,7 +1028,7 @@ hipError_t launch_attend_fp8_batch(const AttendArgs& a, uint32_t n_seq, float* d
     if (dma) hipLaunchKernelGGL(k_attend_fp8_dma, dim3(a.n_splits, n_seq * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
     else     hipLaunchKernelGGL(k_attend_fp8_linear, dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || (a.direct_out && !a.direct_per_seq)) return e;
+    if (e != hipSuccess || (a.direct_out && a.direct_per_seq != 1u)) return e;      // every row final: no merge
     return launch_attend_combine(a, n_seq, d_out, d_lse, s);
 }
 

@@ -254,7 +254,10 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
     uint32_t my_splits = a.n_splits;
     if (a.seqs) {                                                        // wave-uniform: per-sequence geometry
         const AttendSeq sq = a.seqs[layer];
-        if (split >= sq.n_splits) return;
+        if (split >= sq.n_splits) {
+            if (sq.n_splits == 0u && split == 0u && a.direct_out && a.direct_per_seq == 2u) attend_zero_rows(a, row, lane);
+            return;
+        }
         a.lin_base = sq.lin_base;
         a.k_first = sq.k_first;
         a.v_first = sq.v_first;
@@ -476,7 +479,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
     uint32_t my_splits = a.n_splits;
     if (a.seqs) {                                                        // workgroup-uniform: per-sequence geometry
         const AttendSeq sq = a.seqs[layer];
-        if (split >= sq.n_splits) return;
+        if (split >= sq.n_splits) {
+            if (sq.n_splits == 0u && split == 0u && a.direct_out && a.direct_per_seq == 2u) attend_zero_rows(a, row, lane);
+            return;
+        }
         a.lin_base = sq.lin_base;
         a.k_first = sq.k_first;
         a.v_first = sq.v_first;

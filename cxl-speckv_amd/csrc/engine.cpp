@@ -2317,12 +2317,13 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
     k.batch_layer = layer;
     k.direct_out = d_out;                                      // sequences with a single split are written directly ...
     k.direct_lse = d_lse;
-    k.direct_per_seq = 1;                                      // ... decided per sequence on the device; the merge skips those
+    // ... decided per sequence on the device, the merge skips those; a geometry of one split at most needs no merge at all
+    k.direct_per_seq = pg.max_splits == 1u ? 2u : 1u;
     if (fp8) {
         HIP_TRY(launch_attend_fp8_batch(k, n_seq, d_out, d_lse, s));
     } else {
         HIP_TRY(launch_attend_int4(k, n_seq, s));
-        HIP_TRY(launch_attend_combine(k, n_seq, d_out, d_lse, s));
+        if (k.direct_per_seq != 2u) HIP_TRY(launch_attend_combine(k, n_seq, d_out, d_lse, s));
     }
     return SPECKV_OK;
 }

@@ -236,10 +236,21 @@ struct AttendArgs {
     float* direct_out;
     float* direct_lse;
     // planned batches (descriptors resident on the device, one set for all layers of a decode step): the layer of this
-    // launch, and "decide per sequence": a sequence with one split is written directly, the others through the merge
+    // launch, and "decide per sequence": 1 = a sequence with one split is written directly, the others through the merge
+    // launch that follows; 2 = the launch geometry allows one split at most, NO merge follows: sequences without
+    // positions are zeroed by the attention kernel itself (attend_zero_rows)
     uint32_t batch_layer;
     uint32_t direct_per_seq;
 };
+#if defined(__HIPCC__)
+// rows of a sequence without positions in a batch launch that has no merge behind it (one wave per kv head)
+__device__ __forceinline__ void attend_zero_rows(const AttendArgs& a, uint64_t row, uint32_t lane)
+{
+    float* dst = a.direct_out + row * a.g * 128u;
+    for (uint32_t i = lane; i < a.g * 128u; i += 64u) dst[i] = 0.0f;
+    if (a.direct_lse && lane < a.g) a.direct_lse[row * a.g + lane] = -__builtin_inff();
+}
+#endif
 // out / lse of rows d_rows[i] (null: i) += the position whose fp16 K / V rows are d_k_tail / d_v_tail [i][heads][128]
 // (consecutive i tail_stride_elems apart); see k_attend_fold_tail
 hipError_t launch_attend_fold_tail(uint32_t n_rows, const uint32_t* d_rows, uint32_t heads, uint32_t g, const void* d_q_f16,

@@ -430,7 +430,7 @@ def test_planned_batch_attention_replays_under_a_graph(scheme):
         assert plan_bytes == n_seq * 64
         plan = torch.zeros(plan_bytes, dtype=torch.uint8, device="cuda")
         s = torch.cuda.Stream()
-        for tps in (None, "8"):                       # default geometry (whole sequences) and one with real splits
+        for tps in (None, "8", "64"):                 # the rule's geometry, one with real splits, one without any (no merge launch)
             if tps is None: os.environ.pop("SPECKV_ATTEND_TILES_PER_SPLIT", None)
             else: os.environ["SPECKV_ATTEND_TILES_PER_SPLIT"] = tps
             try:
