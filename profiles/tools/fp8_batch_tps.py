@@ -5,9 +5,12 @@ import torch, bench
 import cxl_speckv_amd as pkg
 scheme = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), "hip:0")
-for n_seq, T in ((128, 2048), (64, 8192), (512, 1024), (32, 4096), (16, 8192), (256, 2048)):
+shapes = ((128, 2048), (64, 8192), (512, 1024), (32, 4096), (16, 8192), (256, 2048))
+if os.environ.get("SHAPES") == "odd":
+    shapes = ((100, 4096), (48, 16384), (24, 8192), (7, 16384), (96, 8192), (200, 8192), (32, 32768))
+for n_seq, T in shapes:
     row = []
-    for tps in (None, 8, 16, 32, 64, 128, 256):
+    for tps in (None, 8, 12, 16, 24, 32, 43, 48, 64, 86, 96, 128, 171, 256):
         if tps is None: os.environ.pop("SPECKV_ATTEND_TILES_PER_SPLIT", None)
         else: os.environ["SPECKV_ATTEND_TILES_PER_SPLIT"] = str(tps)
         if tps is not None and tps > T // 32: continue
