@@ -774,3 +774,67 @@ def test_batch_decode_graph_example_runs(scheme):
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     res = mod.run(seqs=6, layers=2, prompt=70, steps=7, scheme=scheme, max_tokens=256, verbose=False)
     assert res["final_length"] == 77 and res["max_rel_diff_graph_vs_eager"] <= 1e-3
+
+
+def test_flush_of_a_256_sequence_decode_step_at_full_size(oracle):
+    """BASELINE configs[3] call count at full size: 256 sequences x 80 layers = 20 480 look-ahead requests (depth 4),
+    one allocation per sequence, ONE device-side flush -> 122 880 pages.  At this size the pages' host-visible words are
+    stored by the fetch launch itself.  Checked: the page count, that exactly the expected pages of sampled sequences
+    are L2-resident by the host's view (translate) with slots in first-occurrence order, decoded contents of sampled
+    pages bit for bit against the oracle, and that a second flush of the same requests issues nothing."""
+    torch = torch_mod()
+    lib = open_lib(SPECKV_L2_MB=2048)
+    try:
+        lib.set_compression_scheme(2)
+        n_seq, Lyr, T, H, D = 256, 80, 128, 8, 128
+        n_pages = 2 * T * Lyr * H * D * 2 // PAGE
+        hs = []
+        for s_ in range(n_seq):
+            h = lib.alloc(n_pages * PAGE)
+            lib.set_layout(h, T, Lyr, H, D, 2)
+            lib.bind_request(s_, h, 0)
+            hs.append(h)
+        pos0 = 16
+        # real data where the flush will look (positions pos0+1 .. pos0+4 of every layer and kind) for three sequences
+        region = T // 2                                               # pages of one (layer, kind) region
+        want_pages = sorted({(layer * 2 + kind) * region + p // 2 for layer in range(Lyr) for kind in (0, 1) for p in range(pos0 + 1, pos0 + 5)})
+        assert len(want_pages) == 6 * Lyr                             # positions 17..20 touch pages 8, 9, 10 of each region
+        sampled = (0, 101, 255)
+        data = {}
+        for sq in sampled:
+            x = synth(len(want_pages), seed=300 + sq)
+            for i, pg in enumerate(want_pages):
+                lib.write(hs[sq], pg * PAGE, x[i].ctypes.data, PAGE, False)
+            data[sq] = x
+        n_req = n_seq * Lyr
+        reqs = np.repeat(np.arange(n_seq, dtype=np.uint32), Lyr)
+        layers = np.tile(np.arange(Lyr, dtype=np.uint16), n_seq)
+        lib.prefetch_batch(reqs, layers, np.full(n_req, pos0, np.uint32), np.full(n_req, 4, np.uint32))
+        issued = lib.prefetch_flush()
+        assert issued == n_seq * len(want_pages) == 122880
+        lib.sync()
+        for sq in sampled:
+            infos = {pg: lib.translate(hs[sq], pg * PAGE) for pg in want_pages}
+            assert all(i.flags & 2 for i in infos.values()), sq
+            # first-occurrence order inside a sequence: layer by layer, K pages then V pages, ascending positions
+            order = []
+            for layer in range(Lyr):
+                for kind in (0, 1):
+                    for p in range(pos0 + 1, pos0 + 5):
+                        pg = (layer * 2 + kind) * region + p // 2
+                        if pg not in order:
+                            order.append(pg)
+            addrs = [infos[pg].cache_addr for pg in order]
+            assert all(b - a == PAGE for a, b in zip(addrs, addrs[1:])), sq          # one run of ring slots per sequence
+            others = [pg for pg in range(0, n_pages, 97) if pg not in infos]
+            assert not any(lib.translate(hs[sq], pg * PAGE).flags & 3 for pg in others)
+            scales, lens, recs = oracle.compress_blocks_f16(data[sq], 2, 0)
+            for i in (0, 1, len(want_pages) // 2, len(want_pages) - 1):
+                dec = oracle.decompress_block_f16(recs[i, :lens[i]], scales[i], 2, 0, N)
+                assert_same_float_bits(dev_to_host(infos[want_pages[i]].cache_addr, PAGE).view(np.float16), dec)
+        st = lib.stats()
+        assert st.prefetch_dropped == 0
+        lib.prefetch_batch(reqs, layers, np.full(n_req, pos0, np.uint32), np.full(n_req, 4, np.uint32))
+        assert lib.prefetch_flush() == 0
+    finally:
+        lib.finalize()
