@@ -318,6 +318,20 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
             return e.rec_bytes >= kInt4RecBytes ? reinterpret_cast<const uint8_t*>(e.pool_addr) : a.zero_page;
         };
         uint32_t next_k = t0, next_v = t0;                                // tile the next request is for
+        // page-table form: the record addresses of a tile are looked up ONE REQUEST AHEAD (kbase / vbase hold those of
+        // tile next_k / next_v), so a request is one round trip, not a page-table entry and then the record behind it
+        const uint8_t* kbase[2] = {nullptr, nullptr};
+        const uint8_t* vbase[3] = {nullptr, nullptr, nullptr};
+        auto lookup_k = [&](uint32_t tile) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) kbase[b] = rec_base(kent, tile * 16u + 8u * b + (c >> 1));
+        };
+        auto lookup_v = [&](uint32_t tile) {
+            vbase[0] = rec_base(vent, tile * 16u + (vr >> 1));
+            vbase[1] = rec_base(vent, tile * 16u + 8u + (vr >> 1));
+            vbase[2] = rec_base(vent, tile * 16u + (sr >> 1));
+        };
+        if (!LINEAR) { lookup_k(t0); lookup_v(t0); }
         auto issue_k = [&]() {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
@@ -325,11 +339,11 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
                     kx[b] = ldg16(kdat + 8u * kInt4RecBytes * b);
                     ks[b] = *reinterpret_cast<const uint16_t*>(ksc + 8u * kInt4RecBytes * b);
                 } else {
-                    const uint8_t* base = rec_base(kent, next_k * 16u + 8u * b + (c >> 1));
-                    kx[b] = ldg16(base + 128u + rowoff * 64u + kb * 16u);
-                    ks[b] = *reinterpret_cast<const uint16_t*>(base + rowoff * 8u + kb * 2u);
+                    kx[b] = ldg16(kbase[b] + 128u + rowoff * 64u + kb * 16u);
+                    ks[b] = *reinterpret_cast<const uint16_t*>(kbase[b] + rowoff * 8u + kb * 2u);
                 }
             }
+            if (!LINEAR) lookup_k(next_k + 1u);                          // (clamped into the range by rec_base)
         };
         auto issue_v = [&]() {
             if (LINEAR) {
@@ -338,9 +352,10 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
                 vsraw = *reinterpret_cast<const uint32_t*>(vsc);
             } else {
                 const uint32_t voff = 128u + ((vr & 1u) * 8u + head) * 64u + (lane & 3u) * 16u;
-                vraw[0] = ldg16(rec_base(vent, next_v * 16u + (vr >> 1)) + voff);
-                vraw[1] = ldg16(rec_base(vent, next_v * 16u + 8u + (vr >> 1)) + voff);
-                vsraw = *reinterpret_cast<const uint32_t*>(rec_base(vent, next_v * 16u + (sr >> 1)) + ((sr & 1u) * 8u + head) * 8u + (lane & 1u) * 4u);
+                vraw[0] = ldg16(vbase[0] + voff);
+                vraw[1] = ldg16(vbase[1] + voff);
+                vsraw = *reinterpret_cast<const uint32_t*>(vbase[2] + ((sr & 1u) * 8u + head) * 8u + (lane & 1u) * 4u);
+                lookup_v(next_v + 1u);
             }
         };
         // LDS addresses: writer and reader
