@@ -247,47 +247,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint32_t t1 = min(t0 + a.tiles_per_split, n_tiles);
     AttState S;
     att_init(S);
-#pragma unroll 1
-    for (uint32_t tile = t0; tile < t1; ++tile) {
+    // page descriptors of one tile: the two K rows this lane feeds, and its four position-slot pages.  They are looked up
+    // ONE TILE AHEAD (after the current tile's data loads have been issued), so a tile costs one memory round trip, not a
+    // page-table entry and then the record behind it.
+    struct Desc { const uint8_t* kaddr[2]; const uint8_t* vaddr[4]; float ks[4], vs[4]; };
+    auto lookup = [&](uint32_t tile) {
+        Desc d;
         const uint32_t pg0 = tile * 16u;
-        // ---- page descriptors: the two K rows this lane feeds, and its four position-slot pages
-        const uint8_t* kaddr[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const uint32_t pg = pg0 + 8u * b + (c >> 1);
-            kaddr[b] = a.zero_page + kb * 16u;
+            d.kaddr[b] = a.zero_page + kb * 16u;
             if (pg < a.n_pages) {
                 const PageEntry e = kent[pg];
                 if (e.rec_bytes >= kBlockElems)
-                    kaddr[b] = reinterpret_cast<const uint8_t*>(e.pool_addr) + (c & 1u) * 1024u + head * 128u + kb * 16u;
+                    d.kaddr[b] = reinterpret_cast<const uint8_t*>(e.pool_addr) + (c & 1u) * 1024u + head * 128u + kb * 16u;
             }
         }
-        AttTile T;
-        const uint8_t* vaddr[4];
-        bool inr[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const uint32_t pg = pg0 + (r < 2 ? 2u * kb + r : 8u + 2u * kb + (r - 2));
-            inr[r] = pg < a.n_pages;
-            vaddr[r] = a.zero_page + 4u * c;
-            T.ks[r] = 0.0f;
-            T.vs[r] = 0.0f;
-            if (inr[r]) {
+            d.vaddr[r] = a.zero_page + 4u * c;
+            d.ks[r] = 0.0f;
+            d.vs[r] = 0.0f;
+            if (pg < a.n_pages) {
                 const PageEntry ke = kent[pg], ve = vent[pg];
-                if (ke.rec_bytes >= kBlockElems) T.ks[r] = ke.scale;
+                if (ke.rec_bytes >= kBlockElems) d.ks[r] = ke.scale;
                 if (ve.rec_bytes >= kBlockElems) {
-                    T.vs[r] = ve.scale;
-                    vaddr[r] = reinterpret_cast<const uint8_t*>(ve.pool_addr) + head * 128u + 4u * c;
+                    d.vs[r] = ve.scale;
+                    d.vaddr[r] = reinterpret_cast<const uint8_t*>(ve.pool_addr) + head * 128u + 4u * c;
                 }
             }
         }
+        return d;
+    };
+    Desc cur = lookup(t0);                                               // (t0 >= t1: nothing below runs)
+#pragma unroll 1
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+        const uint32_t pg0 = tile * 16u;
+        AttTile T;
+        bool inr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            inr[r] = pg0 + (r < 2 ? 2u * kb + r : 8u + 2u * kb + (r - 2)) < a.n_pages;
+            T.ks[r] = cur.ks[r];
+            T.vs[r] = cur.vs[r];
+        }
         // ---- data: K 2 x 32 B per lane, V 16 dwords per lane
 #pragma unroll
-        for (int b = 0; b < 2; ++b) { T.kx[b][0] = ldg16(kaddr[b]); T.kx[b][1] = ldg16(kaddr[b] + 64); }
+        for (int b = 0; b < 2; ++b) { T.kx[b][0] = ldg16(cur.kaddr[b]); T.kx[b][1] = ldg16(cur.kaddr[b] + 64); }
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) T.vx[blk][j] = ldg4(vaddr[j >> 1] + (j & 1) * 1024 + 64 * blk);
+            for (int j = 0; j < 8; ++j) T.vx[blk][j] = ldg4(cur.vaddr[j >> 1] + (j & 1) * 1024 + 64 * blk);
+        cur = lookup(tile + 1u);                                          // pages beyond the range resolve to the zero page
         attend_tile(T, inr, qd, qscale, S);
     }
     att_store(a, S, row * a.n_splits + split, c, kb);
@@ -340,7 +353,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (a.seqs) {                                                        // wave-uniform: per-sequence geometry
         const AttendSeq sq = a.seqs[layer];
         if (split >= sq.n_splits) {
-            if (sq.n_splits == 0u && split == 0u && a.direct_out && a.direct_per_seq == 2u) attend_zero_rows(a, row, lane);
+            if (sq.n_splits == 0u && split == 0u && a.direct_out && a.direct_per_seq == 2u) attend_zero_rows(a.direct_out, a.direct_lse, a.g, row, lane);
             return;
         }
         a.lin_base = sq.lin_base;
@@ -555,6 +568,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 namespace {
 constexpr uint32_t kFdBuf = 8320u, kFdV = 4096u, kFdS = 8192u;
 
+// a pointer that is the same in every lane, pinned to scalar registers (the LDS-DMA statements below take their base
+// address as an SGPR pair; a value loaded from a per-sequence descriptor is wave-uniform, but the compiler only proves
+// that while no store of the kernel could alias the descriptor)
+template <typename T> __device__ __forceinline__ T* uniform_ptr(T* p)
+{
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+    return reinterpret_cast<T*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
 __device__ __forceinline__ void fd_dma16(uint32_t lds_dst, const uint8_t* base, uint32_t voff)
 {
     uint32_t keep;
@@ -611,11 +633,11 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
     if (a.seqs) {                                                        // wave-uniform: per-sequence geometry
         const AttendSeq sq = a.seqs[layer];
         if (split >= sq.n_splits) {
-            if (sq.n_splits == 0u && split == 0u && a.direct_out && a.direct_per_seq == 2u) attend_zero_rows(a, row, lane);
+            if (sq.n_splits == 0u && split == 0u && a.direct_out && a.direct_per_seq == 2u) attend_zero_rows(a.direct_out, a.direct_lse, a.g, row, lane);
             return;
         }
-        a.lin_base = sq.lin_base;
-        a.scale_tab = sq.scale_tab;
+        a.lin_base = uniform_ptr(sq.lin_base);
+        a.scale_tab = uniform_ptr(sq.scale_tab);
         a.k_first = sq.k_first;
         a.v_first = sq.v_first;
         a.n_pages = sq.n_pages;

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
     if (a.seqs) {                                                        // wave-uniform: per-sequence geometry
         const AttendSeq sq = a.seqs[layer];
         if (split >= sq.n_splits) {
-            if (sq.n_splits == 0u && split == 0u && a.direct_out && a.direct_per_seq == 2u) attend_zero_rows(a, row, lane);
+            if (sq.n_splits == 0u && split == 0u && a.direct_out && a.direct_per_seq == 2u) attend_zero_rows(a.direct_out, a.direct_lse, a.g, row, lane);
             return;
         }
         a.lin_base = sq.lin_base;
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
     if (a.seqs) {                                                        // workgroup-uniform: per-sequence geometry
         const AttendSeq sq = a.seqs[layer];
         if (split >= sq.n_splits) {
-            if (sq.n_splits == 0u && split == 0u && a.direct_out && a.direct_per_seq == 2u) attend_zero_rows(a, row, lane);
+            if (sq.n_splits == 0u && split == 0u && a.direct_out && a.direct_per_seq == 2u) attend_zero_rows(a.direct_out, a.direct_lse, a.g, row, lane);
             return;
         }
         a.lin_base = sq.lin_base;

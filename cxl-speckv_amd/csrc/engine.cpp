@@ -2011,7 +2011,14 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     // HBM peak at 32k / 8k / 2k context against 0.71 / 0.62 / 0.48 with 8 splits.
     const uint32_t n_tiles = (n_pages + 15u) / 16u;
     const uint32_t rows = n_layers * L.num_heads;
-    uint32_t want = (rows / 4u >= 128u && n_tiles < 768u) ? 1u : (5120u + rows - 1u) / rows;     // (32k and beyond: 8 splits, below)
+    // linear form: records in one run, scale table present, tiles aligned with the table's (pos_begin a multiple of 32),
+    // and the last (possibly ragged) 32-position tile must not read past the K / V region of its layer
+    const bool fits = pos_begin % 32u == 0u && a->d_scale_tab &&
+                      static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
+    const uint8_t* lin_base = (getenv("SPECKV_ATTEND_GENERAL") || !fits) ? nullptr : a->linear_base;
+    // (the page-table form has nothing to gain from whole rows: it hides its look-ups behind other waves and always
+    // goes through the merge -- 80 layers x 8k: one split 0.13 of HBM peak, eight 0.18+)
+    uint32_t want = (lin_base && rows / 4u >= 128u && n_tiles < 768u) ? 1u : (5120u + rows - 1u) / rows;     // (32k and beyond: 8 splits, below)
     // per-layer calls are latency-bound: short contexts want short splits (measured best: 2 tiles per split at 2k
     // context, 4 at 8k, 8 at 32k), long multi-layer launches are bounded by `want` above
     const uint32_t min_tiles = std::min(8u, std::max(2u, n_tiles / 64u));
@@ -2038,13 +2045,9 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     k.qs = reinterpret_cast<float*>(buf + q_bytes);
     k.scale_log2e = sm_scale * 1.4426950408889634f;
     k.zero_page = d_zero_page_;
-    // linear form: records in one run, scale table present, tiles aligned with the table's (pos_begin a multiple of 32),
-    // and the last (possibly ragged) 32-position tile must not read past the K / V region of its layer
-    const bool fits = pos_begin % 32u == 0u && a->d_scale_tab &&
-                      static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
     k.scale_tab = a->d_scale_tab;
     k.q16 = static_cast<const uint16_t*>(d_q_f16);
-    k.lin_base = (getenv("SPECKV_ATTEND_GENERAL") || !fits) ? nullptr : a->linear_base;
+    k.lin_base = lin_base;
     k.part_acc = reinterpret_cast<float*>(buf + q_bytes + qs_bytes);
     k.part_ml = reinterpret_cast<float*>(buf + q_bytes + qs_bytes + acc_bytes);
     if (!k.lin_base)                     // the linear form quantises the query in its own prologue

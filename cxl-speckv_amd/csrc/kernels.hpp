@@ -243,12 +243,14 @@ struct AttendArgs {
     uint32_t direct_per_seq;
 };
 #if defined(__HIPCC__)
-// rows of a sequence without positions in a batch launch that has no merge behind it (one wave per kv head)
-__device__ __forceinline__ void attend_zero_rows(const AttendArgs& a, uint64_t row, uint32_t lane)
+// rows of a sequence without positions in a batch launch that has no merge behind it (one wave per kv head).
+// (Plain values, not the AttendArgs: a reference to the kernel's argument block makes the compiler keep it in memory,
+// and the LDS-DMA kernels need its pointers in scalar registers.)
+__device__ __forceinline__ void attend_zero_rows(float* direct_out, float* direct_lse, uint32_t g, uint64_t row, uint32_t lane)
 {
-    float* dst = a.direct_out + row * a.g * 128u;
-    for (uint32_t i = lane; i < a.g * 128u; i += 64u) dst[i] = 0.0f;
-    if (a.direct_lse && lane < a.g) a.direct_lse[row * a.g + lane] = -__builtin_inff();
+    float* dst = direct_out + row * g * 128u;
+    for (uint32_t i = lane; i < g * 128u; i += 64u) dst[i] = 0.0f;
+    if (direct_lse && lane < g) direct_lse[row * g + lane] = -__builtin_inff();
 }
 #endif
 // out / lse of rows d_rows[i] (null: i) += the position whose fp16 K / V rows are d_k_tail / d_v_tail [i][heads][128]
