@@ -40,6 +40,19 @@ def declared_functions(header):
     return sorted(set(re.findall(r"\b(speckv_[a-z0-9_]+)\s*\(", src)))
 
 
+def test_the_tree_builds():
+    """`make` over cxl-speckv_amd/csrc succeeds and leaves the library newer than every source: a compile error in one
+    translation unit must not hide behind a library built from an older tree (it did once: the object rule sends the
+    compiler's remarks to a file, and a stale libcxlspeckv.so kept every test green)."""
+    import subprocess
+    src = os.path.join(ROOT, "cxl-speckv_amd", "csrc")
+    r = subprocess.run(["make", "-s", "-j8", "-C", src], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    lib = os.path.join(ROOT, "cxl-speckv_amd", "lib", "libcxlspeckv.so")
+    newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src) if f.endswith((".hip", ".cpp", ".hpp", ".map")))
+    assert os.path.getmtime(lib) >= newest
+
+
 def test_library_exports_every_declared_symbol(libpath):
     lib = C.CDLL(libpath, mode=os.RTLD_NOW)
     names = declared_functions("speckv.h") + declared_functions("speckv_ext.h")
