@@ -1842,6 +1842,21 @@ hipError_t launch_apply_updates(const DevAlloc* d_tab, const MirrorUpdate* d_upd
     return hipGetLastError();
 }
 
+// 16-byte-per-lane copy (pinned host memory -> device): the request columns of a flush.  As a kernel on the flush's own
+// stream it needs no copy engine and no cross-engine dependency in front of the first flush kernel.
+__global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+hipError_t launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t s)
+{
+    const uint32_t n16 = static_cast<uint32_t>((bytes + 15u) / 16u);
+    if (n16 == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_copy16, dim3((n16 + 255u) / 256u), dim3(256), 0, s, static_cast<const uint4*>(src), static_cast<uint4*>(dst), n16);
+    return hipGetLastError();
+}
+
 hipError_t launch_init_entries(PageEntry* d_entries, uint64_t n, uint64_t base, uint64_t stride,
                                hipStream_t s)
 {

@@ -179,6 +179,8 @@ struct FlushArgs {
     uint32_t**      final_host;   // [max_take]
 };
 hipError_t launch_flush_pipeline(const FlushArgs& a, hipStream_t s);
+// bytes rounded up to 16: both buffers must be 16-byte aligned and padded to a multiple of 16
+hipError_t launch_copy16(const void* src_host_mapped, void* dst, size_t bytes, hipStream_t s);
 
 // entries[first+i].pool_addr = base + i*stride ; rec_bytes = 0 ; scale = 1
 hipError_t launch_init_entries(PageEntry* d_entries, uint64_t n, uint64_t base,
