@@ -1208,6 +1208,20 @@ int Engine::prefetch_flush(uint32_t* n_issued)
 // upload the requests, candidates -> dedupe -> ring assignment -> compaction (kernels.hip), then ONE fetch launch
 // that reads its block count and first slot from device memory.  Nothing comes back to the host but 16 bytes
 // (FlushResult, written to pinned memory by the assign kernel), read when somebody needs them.
+// The request columns of a flush go to the device through a copy KERNEL on the flush's stream: on an idle stream a copy
+// engine's transfer is followed by a cross-engine dependency of about 12 us in front of the first flush kernel.  (For the
+// descriptors of the batch attention, between back-to-back launches, the two measured the same: they stay with the engine.)
+// `staged` is pinned (hipHostMalloc) and padded to a multiple of 16 bytes, as is `dst`.
+hipError_t Engine::upload_pinned(void* dst, const void* staged, size_t bytes, hipStream_t s)
+{
+    static const bool by_kernel = [] { const char* e = getenv("SPECKV_FLUSH_UPLOAD"); return !(e && e[0] == 'c'); }();
+    if (!by_kernel) return hipMemcpyAsync(dst, staged, bytes, hipMemcpyHostToDevice, s);
+    void* staged_dev = nullptr;
+    const hipError_t e = hipHostGetDevicePointer(&staged_dev, const_cast<void*>(staged), 0);
+    if (e != hipSuccess) return e;
+    return launch_copy16(staged_dev, dst, bytes, s);
+}
+
 int Engine::flush_group(int scheme, const uint32_t* const cols[5], uint32_t n, uint32_t W, uint32_t* n_issued)
 {
     if (flights_.size() >= kMaxFlights) { RC_TRY(settle()); if (flights_.size() >= kMaxFlights) { RC_TRY(wait_stream()); RC_TRY(settle()); } }
@@ -1244,14 +1258,7 @@ int Engine::flush_group(int scheme, const uint32_t* const cols[5], uint32_t n, u
     // The columns are pulled over by a copy KERNEL on the flush's stream (16 bytes per lane from the pinned slot): a copy
     // engine's upload cost 9 us plus a 12 us cross-engine dependency in front of the first flush kernel -- 8 192 requests
     // 0.102 -> 0.094 ms until landed, 20 480 requests unchanged (SPECKV_FLUSH_UPLOAD=copy for the A/B).
-    static const bool upload_by_kernel = [] { const char* e = getenv("SPECKV_FLUSH_UPLOAD"); return !(e && e[0] == 'c'); }();
-    if (upload_by_kernel) {
-        void* staged_dev = nullptr;
-        HIP_TRY(hipHostGetDevicePointer(&staged_dev, staged, 0));
-        HIP_TRY(launch_copy16(staged_dev, buf, up, stream_));
-    } else {
-        HIP_TRY(hipMemcpyAsync(buf, staged, up, hipMemcpyHostToDevice, stream_));
-    }
+    HIP_TRY(upload_pinned(buf, staged, up, stream_));
     HIP_TRY(hipEventRecord(req_stage_ev_[slot], stream_));
 
     const uint32_t rs = res_next_++ % kResSlots;

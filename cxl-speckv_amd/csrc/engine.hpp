@@ -117,6 +117,7 @@ public:
     int bind_request(uint32_t req, uint64_t handle, uint32_t local_req);
     int write(uint64_t handle, uint64_t off, const void* src, size_t len, bool on_device);
     int write_strided(uint64_t handle, uint64_t first, uint64_t step, uint64_t n, const void* d_src, hipStream_t s);
+    hipError_t upload_pinned(void* dst, const void* staged, size_t bytes, hipStream_t s);
     int attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uint32_t* pos_end, uint32_t max_pos_end, void* d_plan,
                           size_t plan_bytes, hipStream_t s);
     int attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint32_t layer, const void* d_q_f16, uint32_t g,
