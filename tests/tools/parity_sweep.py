@@ -1,9 +1,9 @@
 """A long randomised parity sweep of the codec kernels against the CPU oracle (test infrastructure): many seeds and block
 statistics (Gaussian at several magnitudes, smooth, sparse, heavy-tailed, values at the fp16 limits, denormals), every
 scheme and quantiser mode, compress bytes / lengths / scale bits and decoded bits compared exactly.
-    python profiles/tools/parity_sweep.py [rounds=8] [blocks_per_round=16384]"""
+    python tests/tools/parity_sweep.py [rounds=8] [blocks_per_round=16384]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # tests/tools -> repo root
 sys.path.insert(0, ROOT)
 import numpy as np
 from tests._gpu import N, load_raw_lib, gpu_compress, gpu_decompress
