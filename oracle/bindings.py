@@ -87,6 +87,8 @@ class Oracle:
             "orc_compress_block_f16": (C.c_size_t, [u16p, C.c_size_t, C.c_int, C.c_int, f32p, u8p]),
             "orc_decompress_block_f16": (C.c_size_t, [u8p, C.c_size_t, C.c_float, C.c_int, C.c_int, u16p, C.c_size_t]),
             "orc_decompress_block_f32": (C.c_size_t, [u8p, C.c_size_t, C.c_float, C.c_int, C.c_int, f32p, C.c_size_t]),
+            "orc_compress_blocks_f16": (None, [u16p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, f32p, u32p, u8p, C.c_size_t, C.c_int]),
+            "orc_decompress_blocks_f16": (None, [u8p, C.c_size_t, u32p, f32p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, u16p, C.c_int]),
             "orc_f32_to_e4m3": (C.c_uint8, [C.c_float]),
             "orc_e4m3_to_f32": (C.c_float, [C.c_uint8]),
             "orc_qk_scores_fp8": (None, [u8p, f32p, C.c_size_t, u8p, f32p, C.c_size_t, C.c_size_t, f32p]),
@@ -181,25 +183,35 @@ class Oracle:
         n = self.lib.orc_decompress_block_f32(_ptr(rec, u8p), rec.size, C.c_float(float(scale)), scheme, mode, _ptr(y, f32p), cap)
         return y[:n].copy()
 
-    def compress_blocks_f16(self, x, scheme=2, mode=0, n=2048):
-        """x: (B, n) fp16.  Returns (scales f32[B], lens u32[B], recs u8[B, 2n])."""
+    def compress_blocks_f16(self, x, scheme=2, mode=0, n=2048, threads=None):
+        """x: (B, n) fp16.  Returns (scales f32[B], lens u32[B], recs u8[B, 2n]).  Blocks are independent: the C
+        batch driver spreads them over `threads` threads (default: the host's cores, at most 32)."""
         x = np.ascontiguousarray(x).view(np.uint16).reshape(-1, n)
         B = x.shape[0]
         recs = np.zeros((B, 2 * n), dtype=np.uint8)
         scales = np.zeros(B, dtype=np.float32)
         lens = np.zeros(B, dtype=np.uint32)
-        sc = C.c_float()
-        for b in range(B):
-            lens[b] = self.lib.orc_compress_block_f16(_ptr(x[b], u16p), n, scheme, mode, C.byref(sc), _ptr(recs[b], u8p))
-            scales[b] = sc.value
+        if B:
+            self.lib.orc_compress_blocks_f16(_ptr(x, u16p), B, n, scheme, mode, _ptr(scales, f32p), _ptr(lens, u32p),
+                                             _ptr(recs, u8p), 2 * n, self._threads(threads, B))
         return scales, lens, recs
 
-    def decompress_blocks_f16(self, recs, lens, scales, scheme=2, mode=0, n=2048):
+    def decompress_blocks_f16(self, recs, lens, scales, scheme=2, mode=0, n=2048, threads=None):
+        recs = np.ascontiguousarray(recs, dtype=np.uint8)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        scales = np.ascontiguousarray(scales, dtype=np.float32)
         B = len(lens)
         y = np.zeros((B, n), dtype=np.uint16)
-        for b in range(B):
-            self.lib.orc_decompress_block_f16(_ptr(recs[b], u8p), int(lens[b]), C.c_float(float(scales[b])), scheme, mode, _ptr(y[b], u16p), n)
+        if B:
+            self.lib.orc_decompress_blocks_f16(_ptr(recs, u8p), recs.shape[1], _ptr(lens, u32p), _ptr(scales, f32p), B, n,
+                                               scheme, mode, _ptr(y, u16p), self._threads(threads, B))
         return y.view(np.float16)
+
+    @staticmethod
+    def _threads(threads, n_blocks):
+        if threads is None:
+            threads = min(32, os.cpu_count() or 1)
+        return max(1, min(int(threads), (n_blocks + 63) // 64))
 
     def lstm_predict(self, emb, wout, history, k, hist_len=16, layers=2):
         emb = np.ascontiguousarray(emb, np.float32); wout = np.ascontiguousarray(wout, np.float32)

@@ -1,7 +1,8 @@
 /*
  * oracle/speckv_oracle.c -- CPU restatement of the FastLM/CXL-SpecKV hot path.
  *
- * TEST INFRASTRUCTURE ONLY (see speckv_oracle.h).  Plain C99, single thread,
+ * TEST INFRASTRUCTURE ONLY (see speckv_oracle.h).  Plain C99 (single thread; the batch drivers at the
+ * end run the per-block functions on several),
  * written from the behaviour of the reference (citations are file:line under
  * /root/reference); no reference source is copied.
  *
@@ -1139,3 +1140,72 @@ int orc_coh_batch_invalidate(orc_coh_t* c, const uint64_t* addrs, size_t n)
 }
 void orc_coh_get_statistics(const orc_coh_t* c, uint64_t* stats7) { memcpy(stats7, c->st, sizeof(c->st)); }
 void orc_coh_reset_statistics(orc_coh_t* c) { memset(c->st, 0, sizeof(c->st)); }
+
+/* ================================================================== */
+/* batch drivers: the per-block functions above over many blocks, on   */
+/* several threads (blocks are independent).  Test convenience only:   */
+/* the arithmetic is orc_compress_block_f16 / orc_decompress_block_f16 */
+/* ================================================================== */
+#include <pthread.h>
+
+typedef struct {
+    const uint16_t* x; uint8_t* recs; size_t rec_stride; uint32_t* lens; float* scales; uint16_t* y;
+    size_t n, b0, b1; int scheme, mode, compress;
+} blocks_job;
+
+static void* blocks_worker(void* arg)
+{
+    blocks_job* j = (blocks_job*)arg;
+    for (size_t b = j->b0; b < j->b1; ++b) {
+        if (j->compress) {
+            float s = 1.0f;
+            j->lens[b] = (uint32_t)orc_compress_block_f16(j->x + b * j->n, j->n, j->scheme, j->mode, &s, j->recs + b * j->rec_stride);
+            j->scales[b] = s;
+        } else {
+            size_t got = orc_decompress_block_f16(j->recs + b * j->rec_stride, j->lens[b], j->scales[b], j->scheme, j->mode,
+                                                  j->y + b * j->n, j->n);
+            for (size_t i = got; i < j->n; ++i) j->y[b * j->n + i] = 0;
+        }
+    }
+    return NULL;
+}
+
+static void blocks_run(blocks_job proto, size_t n_blocks, int threads)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    pthread_t tid[64];
+    int joinable[64];
+    blocks_job jobs[64];
+    const size_t per = (n_blocks + (size_t)threads - 1) / (size_t)threads;
+    for (int t = 0; t < threads; ++t) {
+        joinable[t] = 0;
+        jobs[t] = proto;
+        jobs[t].b0 = (size_t)t * per < n_blocks ? (size_t)t * per : n_blocks;
+        jobs[t].b1 = jobs[t].b0 + per < n_blocks ? jobs[t].b0 + per : n_blocks;
+        if (jobs[t].b0 >= jobs[t].b1) continue;
+        /* the last share runs on the calling thread; so does any share whose thread cannot be created */
+        if (t + 1 < threads && pthread_create(&tid[t], NULL, blocks_worker, &jobs[t]) == 0) joinable[t] = 1;
+        else blocks_worker(&jobs[t]);
+    }
+    for (int t = 0; t < threads; ++t)
+        if (joinable[t]) pthread_join(tid[t], NULL);
+}
+
+void orc_compress_blocks_f16(const uint16_t* x, size_t n_blocks, size_t n, int scheme, int mode,
+                             float* scales, uint32_t* lens, uint8_t* recs, size_t rec_stride, int threads)
+{
+    blocks_job j; memset(&j, 0, sizeof(j));
+    j.x = x; j.recs = recs; j.rec_stride = rec_stride; j.lens = lens; j.scales = scales; j.n = n;
+    j.scheme = scheme; j.mode = mode; j.compress = 1;
+    blocks_run(j, n_blocks, threads);
+}
+
+void orc_decompress_blocks_f16(const uint8_t* recs, size_t rec_stride, const uint32_t* lens, const float* scales,
+                               size_t n_blocks, size_t n, int scheme, int mode, uint16_t* y, int threads)
+{
+    blocks_job j; memset(&j, 0, sizeof(j));
+    j.recs = (uint8_t*)recs; j.rec_stride = rec_stride; j.lens = (uint32_t*)lens; j.scales = (float*)scales; j.y = y; j.n = n;
+    j.scheme = scheme; j.mode = mode; j.compress = 0;
+    blocks_run(j, n_blocks, threads);
+}

@@ -129,6 +129,13 @@ size_t orc_decompress_block_f16(const uint8_t* rec, size_t len, float scale,
 size_t orc_decompress_block_f32(const uint8_t* rec, size_t len, float scale,
                                 int scheme, int mode, float* y, size_t cap);
 
+/* The two block functions over n_blocks independent blocks on `threads` threads (test convenience: same
+ * arithmetic, block b at x + b*n, recs + b*rec_stride, y + b*n; decoded blocks are zero-filled behind a short stream). */
+void orc_compress_blocks_f16(const uint16_t* x, size_t n_blocks, size_t n, int scheme, int mode,
+                             float* scales, uint32_t* lens, uint8_t* recs, size_t rec_stride, int threads);
+void orc_decompress_blocks_f16(const uint8_t* recs, size_t rec_stride, const uint32_t* lens, const float* scales,
+                               size_t n_blocks, size_t n, int scheme, int mode, uint16_t* y, int threads);
+
 /* ---- 4:1 / 2:1 block formats of BASELINE config 5 --------
  * EXTENSION WITHOUT A REFERENCE COUNTERPART: **parity unpinned** -- there is no
  * reference code for these; this restatement is the definition the HIP kernels

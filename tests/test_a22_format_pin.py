@@ -11,6 +11,9 @@ Conventions pinned here (and stated in DESIGN.md):
   * saturation: beyond 448 the oracle SATURATES to +-448 (0x7E / 0xFE), which is what the gfx950 conversion
     instruction does with its clamp and what the block codec relies on; torch's cast turns those into NaN
     instead, so that range is pinned to the stated convention, not to torch.
+
+The INT4_G32 block format and both attention checkers (orc_attend_f16, orc_attend_fp8) are pinned further down against a
+numpy float64 restatement written from the format description alone (it never calls the oracle).
 """
 import numpy as np
 import pytest
@@ -77,3 +80,117 @@ def test_fp8_block_format_against_torch(oracle):
     for i in range(x.shape[0]):
         dec = torch.from_numpy(recs[i, :2048].copy()).view(torch.float8_e4m3fn).to(torch.float32).numpy() * np.float32(scales[i])
         assert np.array_equal(y[i].view(np.uint16), dec.astype(np.float16).view(np.uint16))
+
+
+# ---- INT4_G32 and the attention arithmetic: restated here from the format description alone -------------------------
+# include/speckv_ext.h ("SPECKV_COMP_INT4_G32: record 1152 B = 64 fp16 group scales + 2048 nibbles") and
+# oracle/speckv_oracle.h (per group of 32: s = fp16(max|x| / 7); q = clamp(round-half-away(x / s), -7, 7), 0 when s == 0
+# or x is NaN; nibble of element 2i in the low half of byte i, two's complement; y = fp16(q * s)).  Written in numpy
+# float64 WITHOUT calling the oracle; float64 is exact enough to reproduce the fp32 arithmetic of the definition: max|x|/7
+# and x/s of 11-bit operands never come within 2^-24 of a rounding boundary they do not sit on exactly.
+def int4_g32_encode_numpy(x16):
+    x = np.asarray(x16, np.float16).astype(np.float64).reshape(-1, 32)
+    mx = np.max(np.where(np.isnan(x), 0.0, np.abs(x)), axis=1)
+    with np.errstate(over="ignore"):
+        s16 = (mx / 7.0).astype(np.float16)
+    s = s16.astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        v = x / s[:, None]
+    r = np.sign(v) * np.floor(np.abs(v) + 0.5)
+    r = np.where(np.isnan(r), 0.0, r)
+    r = np.clip(r, -7.0, 7.0)
+    r = np.where((s[:, None] == 0.0) | np.isnan(s[:, None]), 0.0, r)
+    q = r.astype(np.int64).reshape(-1) & 0xF
+    nib = (q[0::2] | (q[1::2] << 4)).astype(np.uint8)
+    return np.concatenate([s16.view(np.uint8), nib])
+
+
+def int4_g32_decode_numpy(rec):
+    rec = np.asarray(rec, np.uint8)
+    groups = (rec.size * 2) // (32 + 4)                      # 2 B of scale + 16 B of nibbles per group
+    s = rec[:2 * groups].view(np.float16).astype(np.float64)
+    nib = rec[2 * groups:]
+    q = np.empty(2 * nib.size, np.int64)
+    q[0::2] = nib & 0xF
+    q[1::2] = nib >> 4
+    q = np.where(q >= 8, q - 16, q)
+    with np.errstate(invalid="ignore", over="ignore"):
+        return (q.astype(np.float64) * np.repeat(s, 32)).astype(np.float16)
+
+
+def attention_numpy(q, k, v, sm_scale):
+    """softmax(q.k^T * sm_scale).v in float64: q [g][d], k / v [n][d] -> out [g][d], lse [g], mag [g][d]."""
+    q = np.asarray(q, np.float64); k = np.asarray(k, np.float64); v = np.asarray(v, np.float64)
+    s = (q @ k.T) * float(sm_scale)
+    m = s.max(axis=1, keepdims=True)
+    p = np.exp(s - m)
+    l = p.sum(axis=1, keepdims=True)
+    return (p @ v) / l, (m + np.log(l))[:, 0], (p @ np.abs(v)) / l
+
+
+def _int4_test_blocks():
+    rng = np.random.default_rng(45)
+    x = (rng.standard_normal((24, 2048)) * rng.uniform(0.01, 40.0, (24, 1))).astype(np.float16)
+    x[3] = 0
+    x[4, :32] = 0                                             # one zero group inside a block
+    x[5, ::5] *= 50
+    x[6] = np.float16(65504.0)                                # group scale = fp16(65504 / 7)
+    x[7] = (rng.standard_normal(2048) * 6e-8).astype(np.float16)    # fp16 subnormals: scales underflow to 0 or denormals
+    x[8] = np.repeat(np.arange(-7, 8, dtype=np.float16), 137)[:2048]   # values that sit exactly on the grid and on ties
+    x[9] = (np.arange(2048) % 15 - 7) * np.float16(0.5) + np.float16(0.25)
+    return x
+
+
+def test_int4_g32_block_format_against_the_numpy_restatement(oracle):
+    x = _int4_test_blocks()
+    scales, lens, recs = oracle.compress_blocks_f16(x, 3, 0)
+    y = oracle.decompress_blocks_f16(recs, lens, scales, 3, 0)
+    for i in range(x.shape[0]):
+        want = int4_g32_encode_numpy(x[i])
+        assert lens[i] == 1152 and want.size == 1152
+        assert np.array_equal(recs[i, :1152], want), i
+        assert np.array_equal(y[i].view(np.uint16), int4_g32_decode_numpy(want).view(np.uint16)), i
+    # every nibble value x a spread of scales decodes as the description says (incl. -8, which the encoder never emits)
+    rec = np.zeros(1152, np.uint8)
+    rec[:128] = np.array([0.0, 1.0, 0.333, 65504.0 / 7, 6e-8, 9360.0, 1e-3, 2.5] * 8, np.float16).view(np.uint8)
+    rec[128:] = (np.arange(1024) * 37 + 11).astype(np.uint8)
+    got = oracle.decompress_blocks_f16(rec[None, :].repeat(2, 0), np.array([1152, 1151], np.uint32), np.ones(2, np.float32), 3, 0)
+    assert np.array_equal(got[0].view(np.uint16), int4_g32_decode_numpy(rec).view(np.uint16))
+    assert not got[1].any()                                    # a short record decodes to zeros
+
+
+def test_attention_oracles_against_the_numpy_restatement(oracle):
+    """orc_attend_f16 (checker of the INT4 fused attention) and orc_attend_fp8 against the float64 numpy attention over
+    the values the format descriptions give (INT4 pages through int4_g32_decode_numpy; e4m3 bytes through torch)."""
+    from oracle.bindings import _ptr, u8p, u16p, f32p
+    L = oracle.lib
+    rng = np.random.default_rng(46)
+    G, D, NPOS = 8, 128, 300
+    qh = (rng.standard_normal((G, D)) * 2).astype(np.float16)
+    sm = 1.0 / np.sqrt(D)
+    # fp16 K / V rows as the INT4 format decodes them
+    pages = (rng.standard_normal((2 * NPOS * D // 2048 + 1, 2048)) * 3).astype(np.float16)
+    dec = np.stack([int4_g32_decode_numpy(int4_g32_encode_numpy(p)) for p in pages]).reshape(-1, D)
+    k16 = np.ascontiguousarray(dec[:NPOS]); v16 = np.ascontiguousarray(dec[NPOS:2 * NPOS])
+    o = np.zeros((G, D), np.float32); l = np.zeros(G, np.float32); m = np.zeros((G, D), np.float32)
+    L.orc_attend_f16(_ptr(qh.view(np.uint16).reshape(-1), u16p), G, _ptr(k16.view(np.uint16).reshape(-1), u16p),
+                     _ptr(v16.view(np.uint16).reshape(-1), u16p), NPOS, D, float(sm), _ptr(o, f32p), _ptr(l, f32p), _ptr(m, f32p))
+    wo, wl, wm = attention_numpy(qh, k16, v16, np.float32(sm))
+    assert np.allclose(o, wo, rtol=2e-6, atol=1e-7) and np.allclose(l, wl, rtol=2e-6, atol=2e-6) and np.allclose(m, wm, rtol=2e-6, atol=1e-7)
+    # FP8: e4m3 bytes with per-row scales, query rows quantised per row (scale max|q|/448)
+    kb = rng.integers(0, 256, (NPOS, D)).astype(np.uint8); vb = rng.integers(0, 256, (NPOS, D)).astype(np.uint8)
+    kb[(kb & 0x7F) == 0x7F] = 0x3C; vb[(vb & 0x7F) == 0x7F] = 0x3C           # no NaN bytes
+    ks = rng.uniform(0.001, 0.05, NPOS).astype(np.float32); vs = rng.uniform(0.001, 0.05, NPOS).astype(np.float32)
+    q8 = np.zeros((G, D), np.uint8); qs = np.zeros(G, np.float32)
+    L.orc_quantize_rows_e4m3(_ptr(qh.view(np.uint16).reshape(-1), u16p), G, D, _ptr(q8, u8p), _ptr(qs, f32p))
+    f8 = lambda b: torch.from_numpy(np.ascontiguousarray(b)).view(torch.float8_e4m3fn).to(torch.float32).numpy().astype(np.float64)
+    # the query quantisation itself, restated with torch's cast
+    for r in range(G):
+        qf = qh[r].astype(np.float32); s = np.float32(np.abs(qf).max()) / np.float32(448.0)
+        assert np.float32(qs[r]).tobytes() == np.float32(s).tobytes()
+        assert np.array_equal(q8[r], torch.from_numpy(np.clip(qf / s, -448, 448).astype(np.float32)).to(torch.float8_e4m3fn).view(torch.uint8).numpy())
+    L.orc_attend_fp8(_ptr(q8, u8p), _ptr(qs, f32p), G, _ptr(kb, u8p), _ptr(ks, f32p), _ptr(vb, u8p), _ptr(vs, f32p), NPOS, D,
+                     float(sm), _ptr(o, f32p), _ptr(l, f32p), _ptr(m, f32p))
+    wo, wl, wm = attention_numpy(f8(q8) * qs[:, None].astype(np.float64), f8(kb) * ks[:, None].astype(np.float64),
+                                 f8(vb) * vs[:, None].astype(np.float64), np.float32(sm))
+    assert np.allclose(o, wo, rtol=2e-6, atol=1e-7) and np.allclose(l, wl, rtol=2e-6, atol=2e-6) and np.allclose(m, wm, rtol=2e-6, atol=1e-7)

@@ -281,10 +281,11 @@ def test_pool_exhaustion_and_reuse():
         lib.finalize()
 
 
-def test_fetch_list_and_range_full_size(eng):
+def test_fetch_list_and_range_full_size(eng, oracle):
     """BASELINE config 2 size through the engine: 131072 blocks written from a
     device buffer, fetched back by range and by a permuted list; FP16 scheme is
-    the identity, INT8_DELTA_RLE must agree with the raw codec operator."""
+    the identity, INT8_DELTA_RLE is checked against the C oracle, every block
+    (see also tests/test_gpu_full_size.py::test_config2_all_131072_blocks_against_the_oracle)."""
     torch = torch_mod()
     lib = eng.lib
     B = 131072
@@ -301,15 +302,10 @@ def test_fetch_list_and_range_full_size(eng):
         if scheme == 0:
             assert torch.equal(out.view(torch.int16), x.view(torch.int16))
         else:
-            recs = torch.empty((B, PAGE), dtype=torch.uint8, device="cuda")
-            lens = torch.empty(B, dtype=torch.int32, device="cuda"); scales = torch.empty(B, dtype=torch.float32, device="cuda")
-            ref = torch.empty_like(x)
-            raw = lib.lib
-            assert raw.speckv_ext_codec_compress(x.data_ptr(), B, recs.data_ptr(), PAGE, lens.data_ptr(), scales.data_ptr(), 2, 0, None) == 0
-            assert raw.speckv_ext_codec_decompress(recs.data_ptr(), PAGE, lens.data_ptr(), scales.data_ptr(), B, ref.data_ptr(), 0, 2, 0, None) == 0
-            torch.cuda.synchronize()
-            assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
-            assert lib.stats().compressed_bytes >= int(lens.to(torch.int64).sum().item())
+            scales, lens, recs = oracle.compress_blocks_f16(x.cpu().numpy(), 2, 0)
+            want = oracle.decompress_blocks_f16(recs, lens, scales, 2, 0)
+            assert_same_float_bits(out.cpu().numpy(), want, "fetch_range vs oracle")
+            assert lib.stats().compressed_bytes == int(lens.astype(np.int64).sum())
         perm = torch.randperm(B, generator=torch.Generator().manual_seed(1))[:4096].to(torch.int32).cuda()
         sub = torch.empty((4096, N), dtype=torch.float16, device="cuda")
         lib.fetch_list(h, perm.data_ptr(), 4096, sub.data_ptr(), False, s.cuda_stream)

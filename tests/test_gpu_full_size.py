@@ -1,0 +1,244 @@
+"""-m gpu: BASELINE.json configs at their OWN size against the oracle.
+
+  configs[4]  int4 / fp8 KV, 70B-shaped (80 layers, 8 kv heads x 128) @ 32k context: the fused attention of all 80
+              layers (arithmetic-address form and the page-table form, default split counts) against the oracle's
+              float64 attention on sampled (layer, head) rows; fetch + decompress of sampled pages bit-exact.
+  configs[3]  shape of a decode step: 256 sequences @ 8k context, batch and planned (graph-capturable) forms of the
+              fused attention against the oracle on sampled sequences.
+  configs[1]  all 131 072 blocks of the 8B-shaped round trip against the (threaded) C oracle, bit for bit.
+
+The oracle's checkers are themselves pinned: the codec half to the reference (tests/test_oracle_vs_ref.py), INT4_G32
+and both attention checkers to a numpy float64 restatement of the format description (tests/test_a22_format_pin.py).
+Stated tolerances are those of tests/test_gpu_engine.py (test_int4_fused_attention, test_fp8_fused_attention)."""
+import os
+
+import numpy as np
+import pytest
+
+import cxl_speckv_amd as pkg
+from tests._gpu import N, assert_same_float_bits, torch_mod
+
+pytestmark = pytest.mark.gpu
+PAGE = 4096
+H, D, G = 8, 128, 8                        # 70B-shaped: 8 kv heads x 128, 8 query heads per kv head
+
+
+@pytest.fixture()
+def eng():
+    kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), "hip:0")
+    yield kv
+    kv.close()
+
+
+def synth_pages(torch, seed, n_pages):
+    """N(0,1) values with a per-page magnitude in [0.2, 3): generated on the GPU, identical for a given seed."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    x = torch.randn((n_pages, N), generator=g, device="cuda", dtype=torch.float32)
+    mag = torch.rand((n_pages, 1), generator=g, device="cuda", dtype=torch.float32) * 2.8 + 0.2
+    return (x * mag).to(torch.float16)
+
+
+class HeadChecker:
+    """The oracle's attention of one kv head over the K / V regions of one layer, from the HOST copy of that layer's
+    pages (region = T/2 pages of K followed by T/2 pages of V), through the oracle's own compress -> records."""
+
+    def __init__(self, oracle, scheme, region_pages16, T):
+        self.oracle, self.scheme, self.T = oracle, scheme, T
+        self.scales, self.lens, self.recs = oracle.compress_blocks_f16(region_pages16, scheme, 0)
+        if scheme == 3:
+            self.dec = oracle.decompress_blocks_f16(self.recs, self.lens, self.scales, 3, 0).reshape(-1, 2, H, D)
+        else:
+            self.lut = np.array([oracle.lib.orc_e4m3_to_f32(b) for b in range(256)], np.float32)
+            self.lut[np.isnan(self.lut)] = 0.0
+
+    def want(self, q_head, head, npos, sm):
+        """q_head [G][D] fp16 -> out [G][D], lse [G], mag [G][D], delta (FP8: score error bound of the fp8 MFMA)."""
+        from oracle.bindings import _ptr, u8p, u16p, f32p
+        L = self.oracle.lib
+        hp = self.T // 2                                               # pages per K / V region
+        o = np.zeros((G, D), np.float32); l = np.zeros(G, np.float32); m = np.zeros((G, D), np.float32)
+        if npos == 0:
+            return o, np.full(G, -np.inf, np.float32), m, 0.0
+        if self.scheme == 3:
+            k16 = np.ascontiguousarray(self.dec[:hp, :, head, :].reshape(-1, D)[:npos]).view(np.uint16)
+            v16 = np.ascontiguousarray(self.dec[hp:2 * hp, :, head, :].reshape(-1, D)[:npos]).view(np.uint16)
+            L.orc_attend_f16(_ptr(np.ascontiguousarray(q_head).view(np.uint16).reshape(-1), u16p), G, _ptr(k16.reshape(-1), u16p),
+                             _ptr(v16.reshape(-1), u16p), npos, D, float(sm), _ptr(o, f32p), _ptr(l, f32p), _ptr(m, f32p))
+            return o, l, m, 0.0
+        r4 = self.recs[:, :N].reshape(-1, 2, H, D)
+        krows = np.ascontiguousarray(r4[:hp, :, head, :].reshape(-1, D)[:npos])
+        vrows = np.ascontiguousarray(r4[hp:2 * hp, :, head, :].reshape(-1, D)[:npos])
+        ksc = np.ascontiguousarray(np.repeat(self.scales[:hp], 2)[:npos]); vsc = np.ascontiguousarray(np.repeat(self.scales[hp:2 * hp], 2)[:npos])
+        q8 = np.zeros((G, D), np.uint8); qs = np.zeros(G, np.float32)
+        L.orc_quantize_rows_e4m3(_ptr(np.ascontiguousarray(q_head).view(np.uint16).reshape(-1), u16p), G, D, _ptr(q8, u8p), _ptr(qs, f32p))
+        smag = (np.abs(self.lut[q8]) @ np.abs(self.lut[krows]).T) * ksc[None, :] * qs[:, None] * sm
+        delta = 3e-5 * float(smag.max())
+        L.orc_attend_fp8(_ptr(q8, u8p), _ptr(qs, f32p), G, _ptr(krows, u8p), _ptr(ksc, f32p), _ptr(vrows, u8p), _ptr(vsc, f32p),
+                         npos, D, float(sm), _ptr(o, f32p), _ptr(l, f32p), _ptr(m, f32p))
+        return o, l, m, delta
+
+    def check(self, got, got_lse, q_head, head, npos, sm, what):
+        want, wlse, mag, delta = self.want(q_head, head, npos, sm)
+        err = np.abs(np.asarray(got, np.float32) - want)
+        tol = (2e-3 + 2 * delta) * mag + 1e-6
+        assert np.all(err <= tol), (what, float((err / (mag + 1e-9)).max()), delta)
+        if got_lse is not None and npos:
+            assert np.all(np.abs(np.asarray(got_lse, np.float32) - wlse) <= 2e-3 + delta), (what, float(np.abs(got_lse - wlse).max()))
+
+
+@pytest.mark.parametrize("scheme", [3, 4])
+def test_config5_70b_shaped_32k_context_at_full_size(eng, oracle, scheme):
+    """BASELINE configs[4]: 80 layers x 32 768 positions x 8 kv heads x 128 in INT4_G32 (3.0 GB of records) or
+    FP8_E4M3 (5.4 GB): one launch over all layers in the default geometry (the code that only runs at this size: 256-tile
+    splits, split counts rounded to a multiple of 8, the merge over many splits), the page-table form of the same, a
+    per-layer call, and sampled pages through fetch + decompress."""
+    torch = torch_mod()
+    lib = eng.lib
+    T, L = 32768, 80
+    lib.set_compression_scheme(scheme)
+    h = eng.allocate(T, L, H, D, 2)
+    layer_pages = T                                               # K + V pages of one layer
+    sampled = {0: None, 41: None, 79: None}
+    for layer in range(L):
+        x = synth_pages(torch, 2005_000 + layer, layer_pages)
+        lib.write(h, layer * layer_pages * PAGE, x.data_ptr(), x.numel() * 2, True)
+        if layer in sampled:
+            sampled[layer] = x.cpu().numpy()
+        del x
+    gq = torch.Generator(device="cuda"); gq.manual_seed(2005)
+    q = (torch.randn((L, H, G, D), generator=gq, device="cuda") * 1.5).to(torch.float16)
+    qh = q.cpu().numpy()
+    sm = 1.0 / np.sqrt(D)
+    attend = lib.attend_int4 if scheme == 3 else lib.attend_fp8
+    checkers = {layer: HeadChecker(oracle, scheme, pages, T) for layer, pages in sampled.items()}
+    heads = {0: (0, 5), 41: (3,), 79: (7, 2)}
+
+    def run(general, layer0=0, n_layers=L, pos_end=T):
+        if general: os.environ["SPECKV_ATTEND_GENERAL"] = "1"
+        try:
+            out = torch.full((n_layers, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
+            lse = torch.full((n_layers, H, G), float("nan"), dtype=torch.float32, device="cuda")
+            attend(h, layer0, n_layers, q[layer0:layer0 + n_layers].data_ptr(), G, 0, pos_end, sm, out.data_ptr(), lse.data_ptr())
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("SPECKV_ATTEND_GENERAL", None)
+        return out.cpu().numpy(), lse.cpu().numpy()
+
+    for general in (False, True):
+        out, lse = run(general)
+        assert np.isfinite(out).all() and np.isfinite(lse).all()
+        for layer, hs in heads.items():
+            for head in hs:
+                checkers[layer].check(out[layer, head], lse[layer, head], qh[layer, head], head, T, sm,
+                                      ("all layers", "page table" if general else "linear", layer, head))
+    # one layer by itself (a per-layer decode call: other split geometry), and a context that ends inside a tile
+    out, lse = run(False, 41, 1)
+    checkers[41].check(out[0, 3], lse[0, 3], qh[41, 3], 3, T, sm, "layer 41 alone")
+    out, lse = run(False, 79, 1, 32768 - 30)
+    checkers[79].check(out[0, 7], lse[0, 7], qh[79, 7], 7, T - 30, sm, "layer 79, 32738 positions")
+    # fetch + decompress of sampled pages of the same allocation, bit for bit
+    rng = np.random.default_rng(2005)
+    for layer, pages16 in sampled.items():
+        idx = np.sort(rng.choice(layer_pages, 1536, replace=False)).astype(np.uint32)
+        d_idx = torch.from_numpy((idx + layer * layer_pages).astype(np.int64)).to(torch.int32).cuda()
+        got = torch.empty((idx.size, N), dtype=torch.float16, device="cuda")
+        lib.fetch_list(h, d_idx.data_ptr(), idx.size, got.data_ptr(), False)
+        torch.cuda.synchronize()
+        c = checkers[layer]
+        want = oracle.decompress_blocks_f16(c.recs[idx], c.lens[idx], c.scales[idx], scheme, 0)
+        assert_same_float_bits(got.cpu().numpy(), want, f"layer {layer} pages")
+        info = lib.translate(h, (layer * layer_pages + int(idx[7])) * PAGE)
+        assert info.rec_bytes == c.lens[idx[7]] and np.float32(info.scale).tobytes() == c.scales[idx[7]].tobytes()
+    lib.free(h)
+
+
+@pytest.mark.parametrize("scheme", [3, 4])
+def test_config4_decode_step_256_sequences_8k_context(eng, oracle, scheme):
+    """BASELINE configs[3]'s decode step on the config-5 formats: 256 sequences (one allocation each, 8 192 positions
+    of two layers), lengths from empty to full, the batch form and the planned form of the fused attention against the
+    oracle on sampled sequences."""
+    torch = torch_mod()
+    lib = eng.lib
+    T, L, NSEQ = 8192, 2, 256
+    lib.set_compression_scheme(scheme)
+    rng = np.random.default_rng(2004)
+    lens = [8192] * NSEQ
+    for i, n in ((3, 0), (9, 2), (17, 8190), (40, 4098), (77, 6144), (130, 32), (200, 1000), (255, 8192 - 34)):
+        lens[i] = n
+    for i in range(100, 120):
+        lens[i] = int(rng.integers(1, 4096)) * 2
+    sampled = {0: None, 17: None, 40: None, 77: None, 111: None, 255: None}
+    handles = []
+    n_pages = T * L * H * D * 2 * 2 // PAGE
+    for i in range(NSEQ):
+        hnd = lib.alloc(n_pages * PAGE)
+        lib.set_layout(hnd, T, L, H, D, 2)
+        x = synth_pages(torch, 2004_000 + i, n_pages)
+        lib.write(hnd, 0, x.data_ptr(), x.numel() * 2, True)
+        if i in sampled:
+            sampled[i] = x[T:2 * T].cpu().numpy()               # layer 1: its K region then its V region
+        handles.append(hnd)
+        del x
+    gq = torch.Generator(device="cuda"); gq.manual_seed(2004)
+    q = (torch.randn((NSEQ, H, G, D), generator=gq, device="cuda") * 1.5).to(torch.float16)
+    qh = q.cpu().numpy()
+    sm = 1.0 / np.sqrt(D)
+    checkers = {i: HeadChecker(oracle, scheme, pages, T) for i, pages in sampled.items()}
+    layer = 1
+
+    def check(out, lse, what):
+        assert float(np.abs(out[3]).max()) == 0.0                # the empty sequence
+        for i, c in checkers.items():
+            for head in (1, 6):
+                c.check(out[i, head], lse[i, head], qh[i, head], head, lens[i], sm, (what, i, head))
+
+    batch = lib.attend_int4_batch if scheme == 3 else lib.attend_fp8_batch
+    out = torch.full((NSEQ, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
+    lse = torch.full((NSEQ, H, G), float("nan"), dtype=torch.float32, device="cuda")
+    batch(handles, layer, q.data_ptr(), G, lens, sm, out.data_ptr(), lse.data_ptr())
+    torch.cuda.synchronize()
+    o1, l1 = out.cpu().numpy(), lse.cpu().numpy()
+    check(o1, l1, "batch")
+    # planned form: descriptors on the device, kernel launches only
+    st = torch.cuda.Stream()
+    plan_bytes = lib.attend_plan_bytes(NSEQ)
+    d_plan = torch.empty(plan_bytes, dtype=torch.uint8, device="cuda")
+    out.fill_(float("nan")); lse.fill_(float("nan"))
+    torch.cuda.synchronize()
+    lib.attend_batch_plan(handles, lens, T, d_plan.data_ptr(), plan_bytes, st.cuda_stream)
+    lib.attend_planned(scheme, d_plan.data_ptr(), NSEQ, layer, q.data_ptr(), G, T, sm, out.data_ptr(), lse.data_ptr(), st.cuda_stream)
+    torch.cuda.synchronize()
+    check(out.cpu().numpy(), lse.cpu().numpy(), "planned")
+    for hnd in handles:
+        lib.free(hnd)
+
+
+def test_config2_all_131072_blocks_against_the_oracle(eng, oracle):
+    """BASELINE configs[1]: the 8B-shaped round trip, every one of its 131 072 blocks checked against the C oracle
+    (record lengths, scale bits through the page table on a sample, decoded bits of ALL blocks) -- INT8_DELTA_RLE in
+    both quantiser modes, with structured blocks mixed in."""
+    torch = torch_mod()
+    lib = eng.lib
+    B = 131072
+    x = synth_pages(torch, 2001, B)
+    x[5::97] = 0
+    x[7::101] = x[7::101, :64].repeat_interleave(32, dim=1)
+    xh = x.cpu().numpy()
+    out = torch.empty_like(x)
+    for mode in (0, 1):
+        lib.set_quant_mode(mode)
+        lib.set_compression_scheme(2)
+        h = eng.allocate(4096, 32, H, D, 2)
+        lib.write(h, 0, x.data_ptr(), x.numel() * 2, True)
+        lib.fetch_range(h, 0, B, out.data_ptr(), False)
+        torch.cuda.synchronize()
+        scales, lens, recs = oracle.compress_blocks_f16(xh, 2, mode)
+        want = oracle.decompress_blocks_f16(recs, lens, scales, 2, mode)
+        assert_same_float_bits(out.cpu().numpy(), want, f"mode {mode}")
+        assert lib.stats().compressed_bytes == int(lens.astype(np.int64).sum())
+        for p in (0, 5, 7, 4097, B - 1):
+            info = lib.translate(h, p * PAGE)
+            assert info.rec_bytes == lens[p] and np.float32(info.scale).tobytes() == scales[p].tobytes()
+        lib.free(h)
+    lib.set_quant_mode(0)
