@@ -22,6 +22,10 @@ using speckv::Engine;
 namespace {
 std::unique_ptr<Engine> g_engine;
 std::mutex g_mutex;
+// speckv_finalize in progress: it waits until no thread is parked inside the engine with the lock released (a thread
+// that waits for the GPU lets go of the mutex, Engine::wait_event) and keeps new entries out meanwhile -- they see the
+// library as not initialised, which is what it is about to be.
+bool g_closing = false;
 
 template <typename F>
 speckv_status_t guarded(F&& f)
@@ -35,8 +39,8 @@ speckv_status_t guarded(F&& f)
     }
 }
 // every entry hands its lock to the engine, which releases it only while it waits for the GPU (engine.cpp: wait_event)
-#define LOCK std::unique_lock<std::mutex> lock(g_mutex); if (g_engine) g_engine->enter(&lock)
-#define NEED_INIT if (!g_engine) return SPECKV_ERR_INVAL
+#define LOCK std::unique_lock<std::mutex> lock(g_mutex); if (g_engine && !g_closing) g_engine->enter(&lock)
+#define NEED_INIT if (!g_engine || g_closing) return SPECKV_ERR_INVAL
 } // namespace
 
 extern "C" {
@@ -44,7 +48,7 @@ extern "C" {
 speckv_status_t speckv_init(const char* dev_path)
 {
     std::unique_lock<std::mutex> lock(g_mutex);
-    if (g_engine) return SPECKV_ERR_GENERAL;          // already initialised (speckv_c_api.cpp:16-18)
+    if (g_engine) return SPECKV_ERR_GENERAL;          // already initialised (speckv_c_api.cpp:16-18), also while a finalize is still draining
     return guarded([&] {
         int status = SPECKV_ERR_GENERAL;
         g_engine = Engine::open(dev_path, &status);
@@ -55,13 +59,17 @@ speckv_status_t speckv_init(const char* dev_path)
 void speckv_finalize(void)
 {
     std::unique_lock<std::mutex> lock(g_mutex);
+    if (!g_engine || g_closing) return;                // not initialised, or another thread is already finalizing
+    g_closing = true;
+    g_engine->wait_idle(lock);                         // releases the mutex while it waits
     try { g_engine.reset(); } catch (...) {}
+    g_closing = false;
 }
 
 speckv_status_t speckv_alloc(size_t bytes, const speckv_alloc_hint_t* hint, speckv_handle_t* out)
 {
     LOCK;
-    if (!g_engine || !out) return SPECKV_ERR_INVAL;
+    if (!g_engine || g_closing || !out) return SPECKV_ERR_INVAL;
     return guarded([&] { uint64_t h = 0; int rc = g_engine->alloc(bytes, hint, &h); if (rc == 0) *out = h; return rc; });
 }
 
@@ -75,7 +83,7 @@ speckv_status_t speckv_access(speckv_handle_t handle, uint64_t offset_bytes, siz
                               void** out_gpu_ptr)
 {
     LOCK;
-    if (!g_engine || !out_gpu_ptr) return SPECKV_ERR_INVAL;
+    if (!g_engine || g_closing || !out_gpu_ptr) return SPECKV_ERR_INVAL;
     return guarded([&] { return g_engine->access(handle, offset_bytes, length_bytes, out_gpu_ptr); });
 }
 
@@ -83,7 +91,7 @@ speckv_status_t speckv_prefetch(uint32_t req_id, uint16_t layer, uint32_t cur_po
                                 const int32_t* recent_tokens, uint32_t history_len)
 {
     LOCK;
-    if (!g_engine || !recent_tokens || history_len == 0) return SPECKV_ERR_INVAL;
+    if (!g_engine || g_closing || !recent_tokens || history_len == 0) return SPECKV_ERR_INVAL;
     return guarded([&] { return g_engine->prefetch(req_id, layer, cur_pos, depth_k, recent_tokens, history_len); });
 }
 
@@ -109,14 +117,14 @@ speckv_status_t speckv_ext_set_quant_mode(speckv_quant_mode_t mode)
 speckv_status_t speckv_ext_translate(speckv_handle_t handle, uint64_t offset_bytes, speckv_ext_page_info_t* out)
 {
     LOCK;
-    if (!g_engine || !out) return SPECKV_ERR_INVAL;
+    if (!g_engine || g_closing || !out) return SPECKV_ERR_INVAL;
     return guarded([&] { return g_engine->translate(handle, offset_bytes, out); });
 }
 
 speckv_status_t speckv_ext_fetch_desc(speckv_handle_t handle, uint64_t offset_bytes, speckv_dma_desc_t* out)
 {
     LOCK;
-    if (!g_engine || !out) return SPECKV_ERR_INVAL;
+    if (!g_engine || g_closing || !out) return SPECKV_ERR_INVAL;
     return guarded([&] { return g_engine->fetch_desc(handle, offset_bytes, out); });
 }
 
@@ -140,12 +148,25 @@ speckv_status_t speckv_ext_write_strided(speckv_handle_t handle, uint64_t first_
     return guarded([&] { return g_engine->write_strided(handle, first_page, page_step, n_pages, d_src, static_cast<hipStream_t>(stream)); });
 }
 
+speckv_status_t speckv_ext_write_async(speckv_handle_t handle, uint64_t offset_bytes, const void* d_src, size_t len, void* stream)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->write_async(handle, offset_bytes, d_src, len, static_cast<hipStream_t>(stream)); });
+}
+
 speckv_status_t speckv_ext_write_strided_batch(const speckv_handle_t* handles, const uint64_t* first_pages, const void* const* d_srcs,
                                                uint32_t n_allocations, uint64_t page_step, uint64_t n_pages_each, void* stream)
 {
     LOCK; NEED_INIT;
     return guarded([&] { return g_engine->write_strided_batch(handles, first_pages, d_srcs, n_allocations, page_step, n_pages_each,
                                                               static_cast<hipStream_t>(stream)); });
+}
+
+speckv_status_t speckv_ext_write_runs(speckv_handle_t handle, const uint64_t* first_pages, const void* const* d_srcs, uint32_t n_runs,
+                                      uint64_t n_pages_each, void* stream)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->write_runs(handle, first_pages, d_srcs, n_runs, n_pages_each, static_cast<hipStream_t>(stream)); });
 }
 
 speckv_status_t speckv_ext_read(speckv_handle_t handle, uint64_t offset_bytes, void* dst, size_t len, int dst_on_device)
@@ -184,7 +205,7 @@ speckv_status_t speckv_ext_fetch_list(speckv_handle_t handle, const uint32_t* d_
 speckv_status_t speckv_ext_access_batch(speckv_handle_t handle, const uint64_t* offsets, uint32_t n, void** out_ptrs)
 {
     LOCK;
-    if (!g_engine || (n && (!offsets || !out_ptrs))) return SPECKV_ERR_INVAL;
+    if (!g_engine || g_closing || (n && (!offsets || !out_ptrs))) return SPECKV_ERR_INVAL;
     return guarded([&] { return g_engine->access_batch(handle, offsets, n, out_ptrs); });
 }
 
@@ -192,7 +213,7 @@ speckv_status_t speckv_ext_prefetch_batch(uint32_t n, const uint32_t* req_ids, c
                                           const uint32_t* cur_pos, const uint32_t* depth_k)
 {
     LOCK;
-    if (!g_engine || (n && (!req_ids || !layers || !cur_pos))) return SPECKV_ERR_INVAL;
+    if (!g_engine || g_closing || (n && (!req_ids || !layers || !cur_pos))) return SPECKV_ERR_INVAL;
     return guarded([&] { return g_engine->prefetch_batch(n, req_ids, layers, cur_pos, depth_k); });
 }
 
@@ -208,7 +229,7 @@ speckv_status_t speckv_ext_prefetch_lookup(speckv_handle_t handle, uint32_t n, c
                                            uint32_t* d_out_count, void* stream)
 {
     LOCK;
-    if (!g_engine || !d_out_count || (n && (!d_req_ids || !d_layers || !d_cur_pos || !d_depth_k || !d_out_pages)))
+    if (!g_engine || g_closing || !d_out_count || (n && (!d_req_ids || !d_layers || !d_cur_pos || !d_depth_k || !d_out_pages)))
         return SPECKV_ERR_INVAL;
     return guarded([&] {
         return g_engine->prefetch_lookup(handle, n, d_req_ids, d_layers, d_cur_pos, d_depth_k, d_out_pages, cap,
@@ -228,8 +249,7 @@ speckv_status_t speckv_ext_prefetch_legacy_addrs(uint32_t layer, uint32_t depth_
 speckv_status_t speckv_ext_verify(uint32_t req_id, int32_t actual_token, const int32_t* predicted,
                                   uint32_t n_predicted, uint32_t* was_hit, uint32_t* new_depth)
 {
-    LOCK;
-    if (!g_engine) return SPECKV_ERR_INVAL;
+    LOCK; NEED_INIT;
     return guarded([&] { return g_engine->verify(req_id, actual_token, predicted, n_predicted, was_hit, new_depth); });
 }
 
@@ -249,7 +269,7 @@ speckv_status_t speckv_ext_verify_batch(uint32_t n, uint32_t k, const int32_t* d
 speckv_status_t speckv_ext_get_prefetch_depth(uint32_t* depth_k)
 {
     LOCK;
-    if (!g_engine || !depth_k) return SPECKV_ERR_INVAL;
+    if (!g_engine || g_closing || !depth_k) return SPECKV_ERR_INVAL;
     *depth_k = g_engine->prefetch_depth();
     return SPECKV_OK;
 }
@@ -257,7 +277,7 @@ speckv_status_t speckv_ext_get_prefetch_depth(uint32_t* depth_k)
 speckv_status_t speckv_ext_poll_complete(uint32_t* done)
 {
     LOCK;
-    if (!g_engine || !done) return SPECKV_ERR_INVAL;
+    if (!g_engine || g_closing || !done) return SPECKV_ERR_INVAL;
     return guarded([&] { return g_engine->poll_complete(done); });
 }
 
@@ -463,7 +483,7 @@ speckv_status_t speckv_ext_migrate(speckv_handle_t handle, uint64_t first_page, 
 speckv_status_t speckv_ext_stats(speckv_ext_stats_t* out)
 {
     LOCK;
-    if (!g_engine || !out) return SPECKV_ERR_INVAL;
+    if (!g_engine || g_closing || !out) return SPECKV_ERR_INVAL;
     return guarded([&] { return g_engine->stats(out); });
 }
 

@@ -228,8 +228,9 @@ Engine::~Engine()
     if (null_) return;
     DeviceScope device_scope(device_);
     (void)hipDeviceSynchronize();
-    for (auto& f : flights_) { if (f.assigned) (void)hipEventDestroy(f.assigned); }
+    for (auto& f : flights_) { if (f.assigned) (void)hipEventDestroy(f.assigned); if (f.done) (void)hipEventDestroy(f.done); }
     for (auto& b : inflight_) (void)hipEventDestroy(b.ev);
+    for (auto& w : write_evs_) if (w.ev) (void)hipEventDestroy(w.ev);
     for (auto ev : event_pool_) (void)hipEventDestroy(ev);
     for (auto& z : zombies_) { release_allocation(z.a.get()); if (z.engine_ev) (void)hipEventDestroy(z.engine_ev); }
     zombies_.clear();
@@ -317,9 +318,12 @@ int Engine::wait_event(hipEvent_t ev)
     if (hipEventQuery(ev) == hipSuccess) return SPECKV_OK;
     (void)hipGetLastError();
     std::unique_lock<std::mutex>* mine = lk_;
-    if (mine && mine->owns_lock()) mine->unlock(); else mine = nullptr;
+    if (mine && mine->owns_lock()) { ++waiting_; mine->unlock(); } else mine = nullptr;
     const hipError_t e = hipEventSynchronize(ev);
-    if (mine) { mine->lock(); lk_ = mine; (void)hipSetDevice(device_); }
+    if (mine) {
+        mine->lock(); lk_ = mine; (void)hipSetDevice(device_);
+        if (--waiting_ == 0) idle_cv_.notify_all();      // speckv_finalize may be waiting for the engine to empty
+    }
     if (e != hipSuccess) {
         SPECKV_ERR("hipEventSynchronize failed: %s", hipGetErrorString(e));
         (void)hipGetLastError();
@@ -727,6 +731,24 @@ void Engine::absorb(Flight& f)
     if (f.assigned) { put_event(f.assigned); f.assigned = nullptr; }
 }
 
+// Non-blocking: flights whose assign kernel has finished are absorbed (in order), finished flights are retired and
+// their pages counted as completed descriptors (speckv_kernel_module.c:194-215).
+void Engine::harvest_flights()
+{
+    for (auto& f : flights_) {
+        if (f.absorbed) continue;
+        if (hipEventQuery(f.assigned) != hipSuccess) { (void)hipGetLastError(); break; }
+        absorb(f);
+    }
+    while (!flights_.empty() && flights_.front().absorbed) {
+        if (hipEventQuery(flights_.front().done) != hipSuccess) { (void)hipGetLastError(); break; }
+        completed_unpolled_ += flights_.front().m;
+        st_.dma_completed += flights_.front().m;
+        put_event(flights_.front().done);
+        flights_.pop_front();
+    }
+}
+
 // Every flush's slot assignment is known to the host (waits for the small assign kernels only, not for the data).
 int Engine::settle()
 {
@@ -738,11 +760,7 @@ int Engine::settle()
                 if (!f.absorbed && f.assigned == ev) absorb(f);
             i = static_cast<size_t>(-1);
         }
-    while (!flights_.empty() && flights_.front().absorbed) {
-        if (hipEventQuery(flights_.front().done) != hipSuccess) { (void)hipGetLastError(); break; }
-        put_event(flights_.front().done);
-        flights_.pop_front();
-    }
+    harvest_flights();
     return SPECKV_OK;
 }
 
@@ -798,12 +816,37 @@ void Engine::reap(bool wait_all)
         Batch& b = inflight_.front();
         hipError_t q = wait_all ? hipEventSynchronize(b.ev) : hipEventQuery(b.ev);
         if (q == hipErrorNotReady) { (void)hipGetLastError(); break; }
-        const uint32_t n = b.n_from ? b.n_from->m : b.n;
-        completed_unpolled_ += n;
-        st_.dma_completed += n;
+        completed_unpolled_ += b.n;
+        st_.dma_completed += b.n;
         event_pool_.push_back(b.ev);
         inflight_.pop_front();
     }
+    harvest_flights();
+}
+
+// ---- ordering of the engine stream behind asynchronous writes on caller streams (see WriterEv) -----------------------
+int Engine::note_async_write(hipStream_t s)
+{
+    if (!s || s == stream_ || is_capturing(s)) return SPECKV_OK;       // (a captured write is ordered by its graph's launch stream)
+    for (auto& w : write_evs_)
+        if (w.s == s) { HIP_TRY(hipEventRecord(w.ev, s)); w.dirty = true; return SPECKV_OK; }
+    if (write_evs_.size() >= 64) {               // streams long gone: everything they were handed has to be over first
+        RC_TRY(order_after_writes());
+        for (auto& w : write_evs_) put_event(w.ev);
+        write_evs_.clear();
+    }
+    hipEvent_t ev = get_event();
+    if (!ev) { HIP_TRY(hipStreamSynchronize(s)); return SPECKV_OK; }
+    HIP_TRY(hipEventRecord(ev, s));
+    write_evs_.push_back({s, ev, true});
+    return SPECKV_OK;
+}
+
+int Engine::order_after_writes()
+{
+    for (auto& w : write_evs_)
+        if (w.dirty) { HIP_TRY(hipStreamWaitEvent(stream_, w.ev, 0)); w.dirty = false; }
+    return SPECKV_OK;
 }
 
 // Synchronous fetch of `pages` (in this order) into a fresh run of ring slots; *base_out = first slot.
@@ -817,6 +860,7 @@ int Engine::fetch_into_ring(Allocation* a, const std::vector<uint32_t>& pages, u
     const uint64_t handle = a->handle;
     RC_TRY(prepare_ring_op());
     RC_TRY(renumber_ring_if_due());
+    RC_TRY(order_after_writes());
     if (find(handle) != a) return SPECKV_ERR_GENERAL;     // both may wait (and let go of the ABI lock): freed meanwhile
     bool run = true;
     for (uint32_t i = 1; i < n && run; ++i) run = pages[i] == pages[0] + i;
@@ -862,6 +906,7 @@ int Engine::fetch_into_ring(Allocation* a, const std::vector<uint32_t>& pages, u
 int Engine::fetch_into_slot(Allocation* a, uint32_t page, uint32_t slot)
 {
     RC_TRY(flush_mirror());
+    RC_TRY(order_after_writes());
     CodecArgs c{};
     c.entries = a->d_entries;
     c.trusted = 1;
@@ -1066,7 +1111,12 @@ void Engine::enqueue(uint32_t req, uint32_t layer, uint32_t pos, uint32_t k)
         if (!warned) { warned = true; SPECKV_ERR("speckv_prefetch: look-ahead depth %u clamped to 16 (reported once)", k); }
         k = 16u;
     }
-    if (!q_req_.empty() && q_scheme_ != last_res_.scheme) { (void)prefetch_flush(nullptr); (void)resolve(req); if (!last_res_.ok) { ++q_dropped_; return; } }
+    if (!q_req_.empty() && q_scheme_ != last_res_.scheme) {
+        (void)prefetch_flush(nullptr);
+        (void)resolve(req);
+        // (a flush in progress on another thread makes this one a no-op: a request of another format cannot join its queue)
+        if (!last_res_.ok || (!q_req_.empty() && q_scheme_ != last_res_.scheme)) { ++q_dropped_; return; }
+    }
     q_scheme_ = last_res_.scheme;
     q_W_ = std::max(q_W_, last_res_.W);
     q_req_.push_back(last_res_.local);
@@ -1179,22 +1229,32 @@ int Engine::prefetch_flush(uint32_t* n_issued)
     }
     int rc = SPECKV_OK;
     uint32_t issued_total = 0;
-    const size_t total = q_req_.size();
+    // The queue moves into locals first: flush_group may let go of the ABI lock while it waits for the GPU, and a thread
+    // that calls speckv_prefetch meanwhile appends to the live (now empty) queue -- its requests wait for the next flush
+    // (in_flush_ makes a nested flush a no-op) instead of reallocating the columns under this one or being cleared by it.
+    std::vector<uint32_t> c_req, c_layer, c_pos, c_k, c_row;
+    c_req.swap(q_req_); c_layer.swap(q_layer_); c_pos.swap(q_pos_); c_k.swap(q_k_); c_row.swap(q_row_);
+    const int scheme = q_scheme_;
+    const uint32_t q_w = q_W_;
+    q_W_ = 0;
+    const size_t total = c_req.size();
     if (total) {
         // at most 2^24 candidate words per pipeline run (dedupe key)
-        const uint32_t W = std::max<uint32_t>(q_W_, 2u);
+        const uint32_t W = std::max<uint32_t>(q_w, 2u);
         const uint32_t max_n = std::max<uint32_t>(1u, ((1u << 24) - 1u) / (32u * W));
         for (size_t b = 0; b < total && rc == SPECKV_OK; b += max_n) {
             const uint32_t n = static_cast<uint32_t>(std::min<size_t>(max_n, total - b));
-            const uint32_t* cols[5] = {q_req_.data() + b, q_layer_.data() + b, q_pos_.data() + b, q_k_.data() + b, q_row_.data() + b};
+            const uint32_t* cols[5] = {c_req.data() + b, c_layer.data() + b, c_pos.data() + b, c_k.data() + b, c_row.data() + b};
             uint32_t m = 0;
-            rc = flush_group(q_scheme_, cols, n, W, n_issued ? &m : nullptr);
+            rc = flush_group(scheme, cols, n, W, n_issued ? &m : nullptr);
             issued_total += m;
         }
     }
-    q_req_.clear(); q_layer_.clear(); q_pos_.clear(); q_k_.clear(); q_row_.clear();
-    q_W_ = 0;
     in_flush_ = false;
+    if (q_req_.empty() && q_req_.capacity() < c_req.capacity()) {      // keep the columns' capacity for the next step
+        c_req.clear(); c_layer.clear(); c_pos.clear(); c_k.clear(); c_row.clear();
+        c_req.swap(q_req_); c_layer.swap(q_layer_); c_pos.swap(q_pos_); c_k.swap(q_k_); c_row.swap(q_row_);
+    }
     if (n_issued) *n_issued = issued_total;
     if (timing) {
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_a).count();
@@ -1224,8 +1284,10 @@ hipError_t Engine::upload_pinned(void* dst, const void* staged, size_t bytes, hi
 
 int Engine::flush_group(int scheme, const uint32_t* const cols[5], uint32_t n, uint32_t W, uint32_t* n_issued)
 {
+    reap(false);                               // a decode loop calls nothing else that retires finished flights and their events
     if (flights_.size() >= kMaxFlights) { RC_TRY(settle()); if (flights_.size() >= kMaxFlights) { RC_TRY(wait_stream()); RC_TRY(settle()); } }
     RC_TRY(flush_mirror());
+    RC_TRY(order_after_writes());              // records appended on caller streams are in place before they are fetched
     if (++flush_epoch_ > 255u) {               // 8-bit epoch in the dedupe stamps: start over with clean stamps
         flush_epoch_ = 1;
         for (auto& kv : allocs_)
@@ -1288,6 +1350,10 @@ int Engine::flush_group(int scheme, const uint32_t* const cols[5], uint32_t n, u
     fl.assigned = get_event();
     fl.done = get_event();
     fl.result = res_ring_ + rs;
+    struct EventGuard {                        // the flight's events go back to the pool on every error path
+        Engine* e; Flight* f; bool keep = false;
+        ~EventGuard() { if (!keep) { e->put_event(f->assigned); e->put_event(f->done); } }
+    } guard{this, &fl};
     if (!fl.assigned || !fl.done) return SPECKV_ERR_DRIVER;
     HIP_TRY(hipEventRecord(fl.assigned, stream_));
 
@@ -1303,8 +1369,8 @@ int Engine::flush_group(int scheme, const uint32_t* const cols[5], uint32_t n, u
     c.quant_mode = quant_mode_;
     HIP_TRY(launch_decompress(c, stream_));
     HIP_TRY(hipEventRecord(fl.done, stream_));
+    guard.keep = true;
     flights_.push_back(fl);
-    if (hipEvent_t ev = get_event()) { HIP_TRY(hipEventRecord(ev, stream_)); inflight_.push_back({ev, 0u, fl.result}); }
     if (n_issued) {                       // the caller wants the page count now: wait for the assign kernel (not the data)
         RC_TRY(settle());
         *n_issued = fl.result->m;
@@ -1445,7 +1511,10 @@ int Engine::set_layout(uint64_t handle, uint32_t T, uint32_t L, uint32_t H, uint
     Allocation* a = find(handle);
     if (!a) return SPECKV_ERR_GENERAL;
     if (!T || !L || !H || !D || !bpe) return SPECKV_ERR_INVAL;
-    if (!q_req_.empty()) (void)prefetch_flush(nullptr);       // queued requests were resolved against the old geometry
+    if (!q_req_.empty()) {                                    // queued requests were resolved against the old geometry
+        (void)prefetch_flush(nullptr);
+        if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;       // the flush may have let go of the ABI lock
+    }
     ++res_gen_;
     a->layout = Layout{T, L, H, D, bpe, a->n_pages};
     a->has_layout = true;
@@ -1624,6 +1693,7 @@ int Engine::write_strided(uint64_t handle, uint64_t first, uint64_t step, uint64
     hipStream_t st = s ? s : stream_;
     HIP_TRY(launch_compress(c, st));
     note_use(a, s);
+    RC_TRY(note_async_write(s));
     for (uint64_t i = 0; i < n; ++i) {
         uint32_t& f = a->flags[first + i * step];
         if (a->scheme != SPECKV_COMP_FP16) f |= 4u; else f &= ~4u;
@@ -1634,39 +1704,60 @@ int Engine::write_strided(uint64_t handle, uint64_t first, uint64_t step, uint64
     return SPECKV_OK;
 }
 
-// write_strided for a batch of allocations in one launch (the append of a decode step: SURVEY 8f row N2).  Host side as
-// in write_strided per allocation (cached pages are invalidated first); the kernel takes one descriptor per allocation.
-int Engine::write_strided_batch(const uint64_t* handles, const uint64_t* firsts, const void* const* d_srcs, uint32_t n_alloc,
-                                uint64_t step, uint64_t n_each, hipStream_t s)
+// speckv_ext_write_async: a contiguous page range from a device buffer, on the caller's stream, no device-wide wait.
+int Engine::write_async(uint64_t handle, uint64_t off, const void* d_src, size_t len, hipStream_t s)
 {
-    if (null_) return no_data_path("speckv_ext_write_strided_batch");
+    if (null_) return no_data_path("speckv_ext_write_async");
+    if (off % kPageSize || len % kPageSize) return SPECKV_ERR_INVAL;
+    if (len == 0) return find(handle) ? SPECKV_OK : SPECKV_ERR_GENERAL;
+    return write_strided(handle, off / kPageSize, 1, len / kPageSize, d_src, s);
+}
+
+// write_strided for a batch of allocations in one launch (the append of a decode step: SURVEY 8f row N2), and several
+// page runs of ONE allocation in one launch (a prompt's K / V regions: speckv_ext_write_runs).  Host side as in
+// write_strided per group (cached pages are invalidated first); the kernel takes one descriptor per group.
+int Engine::write_groups(const uint64_t* handles, const uint64_t* firsts, const void* const* d_srcs, uint32_t n_groups,
+                         uint64_t step, uint64_t n_each, hipStream_t s, bool same_allocation)
+{
     if (!handles || !firsts || !d_srcs || step == 0 || !s) return SPECKV_ERR_INVAL;
-    if (n_alloc == 0 || n_each == 0) return SPECKV_OK;
-    std::vector<Allocation*> as(n_alloc);
+    if (n_groups == 0 || n_each == 0) return SPECKV_OK;
+    std::vector<Allocation*> as(n_groups);
     bool cached = false;
-    for (uint32_t i = 0; i < n_alloc; ++i) {
-        Allocation* a = find(handles[i]);
+    for (uint32_t i = 0; i < n_groups; ++i) {
+        Allocation* a = find(handles[same_allocation ? 0 : i]);
         if (!a) return SPECKV_ERR_GENERAL;
         if (!d_srcs[i]) return SPECKV_ERR_INVAL;
         if (a->scheme != find(handles[0])->scheme) return SPECKV_ERR_INVAL;
         if (firsts[i] >= a->n_pages || (n_each - 1) > (a->n_pages - 1 - firsts[i]) / step) return SPECKV_ERR_GENERAL;
         if (a->size_bytes % kPageSize && firsts[i] + (n_each - 1) * step == a->n_pages - 1) return SPECKV_ERR_INVAL;
-        for (uint32_t k = 0; k < i; ++k) if (as[k] == a) return SPECKV_ERR_INVAL;       // one descriptor per allocation
+        if (!same_allocation)
+            for (uint32_t k = 0; k < i; ++k) if (as[k] == a) return SPECKV_ERR_INVAL;   // one descriptor per allocation
         as[i] = a;
         for (uint64_t j = 0; j < n_each && !cached; ++j) cached = (res_flags(a, firsts[i] + j * step) & 3u) != 0;
+    }
+    if (same_allocation && n_groups > 1) {                      // the runs of one allocation must not overlap (racing writers)
+        std::vector<uint64_t> order(firsts, firsts + n_groups);
+        std::sort(order.begin(), order.end());
+        const uint64_t span = (n_each - 1) * step;
+        for (uint32_t i = 1; i < n_groups; ++i)
+            if (step == 1 ? order[i] <= order[i - 1] + span : order[i] == order[i - 1]) return SPECKV_ERR_INVAL;
+        // (strided groups that start on different pages interleave without touching: page = first + j * step)
+        if (step != 1)
+            for (uint32_t i = 1; i < n_groups; ++i)
+                if ((order[i] - order[0]) % step == 0 && order[i] - order[0] <= span) return SPECKV_ERR_INVAL;
     }
     DeviceScope device_scope(device_);
     if (cached || !flights_.empty() || ring_busy_ > 0) {
         RC_TRY(quiesce());
-        for (uint32_t i = 0; i < n_alloc; ++i) {
-            if ((as[i] = find(handles[i])) == nullptr) return SPECKV_ERR_GENERAL;
+        for (uint32_t i = 0; i < n_groups; ++i) {
+            if ((as[i] = find(handles[same_allocation ? 0 : i])) == nullptr) return SPECKV_ERR_GENERAL;
             for (uint64_t j = 0; j < n_each; ++j) drop_page(as[i], static_cast<uint32_t>(firsts[i] + j * step));
         }
         RC_TRY(flush_mirror());
         RC_TRY(wait_stream());
     }
     // descriptors: pinned slot -> device slot (4 of each in rotation, guarded by an event on the caller's stream)
-    const size_t bytes = static_cast<size_t>(n_alloc) * sizeof(CompressGroup);
+    const size_t bytes = static_cast<size_t>(n_groups) * sizeof(CompressGroup);
     if (grp_ring_.slot_bytes < bytes) {
         HIP_TRY(hipDeviceSynchronize());
         if (grp_ring_.base) { (void)hipHostFree(grp_ring_.base); grp_ring_.base = nullptr; }
@@ -1680,11 +1771,11 @@ int Engine::write_strided_batch(const uint64_t* handles, const uint64_t* firsts,
     const int slot = grp_ring_.next;
     grp_ring_.next = (slot + 1) & 3;
     RC_TRY(wait_event(grp_ring_.ev[slot]));                   // may release the ABI lock
-    for (uint32_t i = 0; i < n_alloc; ++i)
-        if ((as[i] = find(handles[i])) == nullptr) return SPECKV_ERR_GENERAL;
+    for (uint32_t i = 0; i < n_groups; ++i)
+        if ((as[i] = find(handles[same_allocation ? 0 : i])) == nullptr) return SPECKV_ERR_GENERAL;
     CompressGroup* staged = reinterpret_cast<CompressGroup*>(static_cast<uint8_t*>(grp_ring_.base) + static_cast<size_t>(slot) * grp_ring_.slot_bytes);
     CompressGroup* d_slot = reinterpret_cast<CompressGroup*>(reinterpret_cast<uint8_t*>(d_groups_) + static_cast<size_t>(slot) * grp_ring_.slot_bytes);
-    for (uint32_t i = 0; i < n_alloc; ++i) {
+    for (uint32_t i = 0; i < n_groups; ++i) {
         const Allocation* a = as[i];
         staged[i] = CompressGroup{a->d_entries, a->d_scale_tab, a->region_pages, 0u, firsts[i],
                                   static_cast<const uint8_t*>(d_srcs[i])};
@@ -1697,10 +1788,11 @@ int Engine::write_strided_batch(const uint64_t* handles, const uint64_t* firsts,
     c.data_stride = kPageSize;
     c.scheme = as[0]->scheme;
     c.quant_mode = quant_mode_;
-    c.n = static_cast<uint64_t>(n_alloc) * n_each;
+    c.n = static_cast<uint64_t>(n_groups) * n_each;
     HIP_TRY(launch_compress(c, s));
     HIP_TRY(hipEventRecord(grp_ring_.ev[slot], s));
-    for (uint32_t i = 0; i < n_alloc; ++i) {
+    RC_TRY(note_async_write(s));
+    for (uint32_t i = 0; i < n_groups; ++i) {
         Allocation* a = as[i];
         note_use(a, s);
         for (uint64_t j = 0; j < n_each; ++j) {
@@ -1711,6 +1803,19 @@ int Engine::write_strided_batch(const uint64_t* handles, const uint64_t* firsts,
     st_.total_compressions += c.n;
     st_.original_bytes += c.n * kPageSize;
     return SPECKV_OK;
+}
+
+int Engine::write_strided_batch(const uint64_t* handles, const uint64_t* firsts, const void* const* d_srcs, uint32_t n_alloc,
+                                uint64_t step, uint64_t n_each, hipStream_t s)
+{
+    if (null_) return no_data_path("speckv_ext_write_strided_batch");
+    return write_groups(handles, firsts, d_srcs, n_alloc, step, n_each, s, false);
+}
+
+int Engine::write_runs(uint64_t handle, const uint64_t* firsts, const void* const* d_srcs, uint32_t n_runs, uint64_t n_each, hipStream_t s)
+{
+    if (null_) return no_data_path("speckv_ext_write_runs");
+    return write_groups(&handle, firsts, d_srcs, n_runs, 1, n_each, s, true);
 }
 
 int Engine::read(uint64_t handle, uint64_t off, void* dst, size_t len, bool on_device)
@@ -1725,6 +1830,7 @@ int Engine::read(uint64_t handle, uint64_t off, void* dst, size_t len, bool on_d
     const uint64_t p0 = off / kPageSize, full = len / kPageSize, tail = len % kPageSize;
     DeviceScope device_scope(device_);
     if (on_device) HIP_TRY(hipDeviceSynchronize());    // dst may still be in use on a caller stream
+    else RC_TRY(order_after_writes());                 // records being written asynchronously on a caller stream
     CodecArgs c{};
     c.entries = a->d_entries;
     c.trusted = 1;                       // pool records only ever come from k_compress
@@ -1889,7 +1995,7 @@ int Engine::fetch_range(uint64_t handle, uint64_t first, uint64_t n, void* d_dst
     st_.total_decompressions += n;
     if (!s) {
         hipEvent_t ev = get_event();
-        if (ev) { HIP_TRY(hipEventRecord(ev, stream_)); inflight_.push_back({ev, static_cast<uint32_t>(n), nullptr}); }
+        if (ev) { HIP_TRY(hipEventRecord(ev, stream_)); inflight_.push_back({ev, static_cast<uint32_t>(n)}); }
     } else {
         st_.dma_completed += n;            // completion belongs to the caller's stream
     }
@@ -1922,7 +2028,7 @@ int Engine::fetch_list(uint64_t handle, const uint32_t* d_pages, uint32_t n, voi
     st_.total_decompressions += n;
     if (!s) {
         hipEvent_t ev = get_event();
-        if (ev) { HIP_TRY(hipEventRecord(ev, stream_)); inflight_.push_back({ev, n, nullptr}); }
+        if (ev) { HIP_TRY(hipEventRecord(ev, stream_)); inflight_.push_back({ev, n}); }
     } else {
         st_.dma_completed += n;
     }

@@ -29,6 +29,7 @@
 #include "ring_rule.hpp"
 #include "slab_pool.hpp"
 
+#include <condition_variable>
 #include <deque>
 #include <memory>
 #include <mutex>
@@ -101,6 +102,9 @@ public:
     // The C ABI serialises callers with one mutex (speckv_c_api.cpp:10).  Every entry hands its lock to the engine,
     // which releases it only while it waits for the GPU (state is re-validated afterwards).
     void enter(std::unique_lock<std::mutex>* lk) { lk_ = lk; }
+    // speckv_finalize: returns (with `lk` held) once no thread is parked inside the engine with the lock released
+    // (wait_event); the caller keeps new entries out meanwhile
+    void wait_idle(std::unique_lock<std::mutex>& lk) { idle_cv_.wait(lk, [this] { return waiting_ == 0; }); }
 
     int alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out);
     int free(uint64_t handle);
@@ -117,6 +121,7 @@ public:
     int bind_request(uint32_t req, uint64_t handle, uint32_t local_req);
     int write(uint64_t handle, uint64_t off, const void* src, size_t len, bool on_device);
     int write_strided(uint64_t handle, uint64_t first, uint64_t step, uint64_t n, const void* d_src, hipStream_t s);
+    int write_async(uint64_t handle, uint64_t off, const void* d_src, size_t len, hipStream_t s);
     hipError_t upload_pinned(void* dst, const void* staged, size_t bytes, hipStream_t s);
     int attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uint32_t* pos_end, uint32_t max_pos_end, void* d_plan,
                           size_t plan_bytes, hipStream_t s);
@@ -126,6 +131,7 @@ public:
                          const void* d_v_tail, uint64_t tail_stride_elems, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
     int write_strided_batch(const uint64_t* handles, const uint64_t* firsts, const void* const* d_srcs, uint32_t n_alloc, uint64_t step,
                             uint64_t n_each, hipStream_t s);
+    int write_runs(uint64_t handle, const uint64_t* firsts, const void* const* d_srcs, uint32_t n_runs, uint64_t n_each, hipStream_t s);
     int read(uint64_t handle, uint64_t off, void* dst, size_t len, bool on_device);
     int fetch_range(uint64_t handle, uint64_t first, uint64_t n, void* d_dst, bool f32, hipStream_t s, int engine_choice);
     int fetch_list(uint64_t handle, const uint32_t* d_pages, uint32_t n, void* d_dst, bool f32, hipStream_t s);
@@ -163,6 +169,8 @@ private:
     bool null_ = false;
     int device_ = 0;
     std::unique_lock<std::mutex>* lk_ = nullptr;
+    uint32_t waiting_ = 0;                 // threads inside wait_event with the ABI lock released
+    std::condition_variable idle_cv_;
     hipStream_t stream_ = nullptr;         // fetch / codec side stream
     hipStream_t copy_stream_ = nullptr;    // peer copies (pool <-> pool migration)
     int flush_words_mode_ = 0;             // who stores a flush's host-visible words: 0 by size, 1 scatter kernel, 2 fetch launch
@@ -248,8 +256,18 @@ private:
     hipEvent_t req_stage_ev_[4] = {nullptr, nullptr, nullptr, nullptr};
     int req_stage_next_ = 0;
 
-    // completion accounting (speckv_kernel_module.c:194-215)
-    struct Batch { hipEvent_t ev; uint32_t n; const FlushResult* n_from; };
+    // Asynchronous writes run on the CALLER's stream (write_strided / _batch / write_async); everything the engine reads
+    // on its own stream afterwards (synchronous misses, speckv_ext_read, the prefetch flush, L1 promotion) must be
+    // ordered behind them.  One event per caller stream, re-recorded by each write; `dirty` = the engine stream has not
+    // waited for the latest record yet (order_after_writes, called in front of every engine-stream read of pool records).
+    struct WriterEv { hipStream_t s; hipEvent_t ev; bool dirty; };
+    std::vector<WriterEv> write_evs_;
+    int note_async_write(hipStream_t s);
+    int order_after_writes();
+
+    // completion accounting (speckv_kernel_module.c:194-215): launches on the engine stream whose size is known when
+    // they are submitted; a flush's pages are counted when its flight completes (harvest_flights)
+    struct Batch { hipEvent_t ev; uint32_t n; };
     std::deque<Batch> inflight_;
     std::vector<hipEvent_t> event_pool_;
     uint64_t completed_unpolled_ = 0;
@@ -327,12 +345,15 @@ private:
     int prepare_ring_op();
     uint32_t ring_busy_ = 0;                              // synchronous ring fetches in their (unlocked) wait
     void absorb(Flight& f);
+    void harvest_flights();                               // non-blocking: absorb assigned flights, retire and count finished ones
     int wait_landed(const Allocation* a, uint64_t p0, uint64_t p1);   // pages of an in-flight flush have arrived
     // data movement
     int fetch_into_ring(Allocation* a, const std::vector<uint32_t>& pages, uint32_t* base_out);
     int fetch_into_slot(Allocation* a, uint32_t page, uint32_t slot);
     int fetch_range_copy_engine(Allocation* a, uint64_t first, uint64_t n, void* d_dst, bool f32, hipStream_t st);
     bool infer_layout(Allocation* a);
+    int write_groups(const uint64_t* handles, const uint64_t* firsts, const void* const* d_srcs, uint32_t n_groups, uint64_t step,
+                     uint64_t n_each, hipStream_t s, bool same_allocation);
     int flush_group(int scheme, const uint32_t* const cols[5], uint32_t n, uint32_t W, uint32_t* n_issued);
     void reap(bool wait_all);
     int run_predictor_for_dirty();

@@ -97,9 +97,15 @@ class SpeckvKVConnector:
                 self.side = conn._side
 
         def __enter__(self):
+            import torch
             if self.side is not None:
                 self.side.wait_stream(self.cur)
                 return self.side
+            # an explicit stream that is not torch's current one: tensors the caller (or this class) produced on the
+            # current stream -- q.contiguous(), the gathered page images -- must be complete before the library reads them
+            now = torch.cuda.current_stream()
+            if now.cuda_stream != self.cur.cuda_stream:
+                self.cur.wait_stream(now)
             return self.cur
 
         def __exit__(self, *exc):
@@ -132,25 +138,26 @@ class SpeckvKVConnector:
         return ((layer * 2 + kind) * self.T + pos) // 2
 
     # ------------------------------------------------------------------ writes
-    def write_prefill(self, req_id: int, k, v):
-        """k, v: [layers][tokens][heads][dim] fp16 CUDA tensors of the prompt."""
-        import torch
+    def write_prefill(self, req_id: int, k, v, stream=None):
+        """k, v: [layers][tokens][heads][dim] fp16 CUDA tensors of the prompt.  ONE asynchronous launch for the request
+        (speckv_ext_write_runs: the 2 * layers K / V regions are page runs of the allocation, read in place from k and v);
+        returns the tensors the launch reads -- hold them until the stream has passed it."""
         r = self.requests[req_id]
         n = k.shape[1]
         if r.length:
             raise ValueError("write_prefill on a request that already has positions")
         even = n & ~1
-        for kind, t in ((0, k), (1, v)):
-            t = t.contiguous()
-            for layer in range(self.L):
-                if even:
-                    off = self._page(layer, kind, 0) * PAGE
-                    rows = t[layer, :even].contiguous()
-                    self.lib.write(r.handle, off, rows.data_ptr(), rows.numel() * 2, True)
+        k = k.contiguous(); v = v.contiguous()
+        if even:
+            layer_bytes = n * self.H * self.D * 2
+            firsts = [self._page(layer, kind, 0) for kind in (0, 1) for layer in range(self.L)]
+            srcs = [t.data_ptr() + layer * layer_bytes for t in (k, v) for layer in range(self.L)]
+            with self._On(self, stream) as st:
+                self.lib.write_runs(r.handle, firsts, srcs, even // 2, st.cuda_stream)
         if n & 1:
             r.set_tail(k[:, n - 1].contiguous().clone(), v[:, n - 1].contiguous().clone())
         r.length = n
-        torch.cuda.synchronize()
+        return [k, v]
 
     def append(self, req_ids: Sequence[int], k_new, v_new, stream=None):
         """One decode step: k_new, v_new [batch][layers][heads][dim] fp16.  A position that completes a pair is written
@@ -173,12 +180,15 @@ class SpeckvKVConnector:
                 kt, vt = self._tail_k, self._tail_v                                                    # [n][layers][heads][dim]
             else:
                 kt = torch.stack([r.tail_k for r in reqs]); vt = torch.stack([r.tail_v for r in reqs])
-            kn, vn = (k_new, v_new) if whole else (k_new.index_select(0, idx), v_new.index_select(0, idx))
-            # page image of the pair for every (layer, kind): [n][layer][kind][2 positions][heads][dim]
-            pair = torch.stack((torch.stack((kt, kn), dim=2), torch.stack((vt, vn), dim=2)), dim=2).contiguous()
-            keep.append(pair)
-            step_bytes = pair[0].numel() * 2
             with self._On(self, stream) as st:
+                # the page images are built ON the stream the write runs on (ordered after the producers of k_new / the
+                # tails by _On): a compress kernel must never see a half-built image
+                with torch.cuda.stream(st):
+                    kn, vn = (k_new, v_new) if whole else (k_new.index_select(0, idx), v_new.index_select(0, idx))
+                    # page image of the pair for every (layer, kind): [n][layer][kind][2 positions][heads][dim]
+                    pair = torch.stack((torch.stack((kt, kn), dim=2), torch.stack((vt, vn), dim=2)), dim=2).contiguous()
+                keep.append(pair)
+                step_bytes = pair[0].numel() * 2
                 if len(reqs) == 1:
                     self.lib.write_strided(reqs[0].handle, self._page(0, 0, reqs[0].length - 1), self.region_pages, 2 * self.L,
                                            pair.data_ptr(), st.cuda_stream)

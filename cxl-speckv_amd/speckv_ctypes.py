@@ -55,6 +55,8 @@ _EXT_SIGNATURES = {
     "speckv_ext_read": [c_uint64, c_uint64, c_void_p, c_size_t, c_int],
     "speckv_ext_write_strided": [c_uint64, c_uint64, c_uint64, c_uint64, c_void_p, c_void_p],
     "speckv_ext_write_strided_batch": [c_void_p, c_void_p, c_void_p, c_uint32, c_uint64, c_uint64, c_void_p],
+    "speckv_ext_write_async": [c_uint64, c_uint64, c_void_p, c_size_t, c_void_p],
+    "speckv_ext_write_runs": [c_uint64, c_void_p, c_void_p, c_uint32, c_uint64, c_void_p],
     "speckv_ext_fetch_range": [c_uint64, c_uint64, c_uint64, c_void_p, c_int, c_void_p],
     "speckv_ext_fetch_range_engine": [c_uint64, c_uint64, c_uint64, c_void_p, c_int, c_void_p, c_int],
     "speckv_ext_bind_request": [c_uint32, c_uint64, c_uint32],
@@ -222,6 +224,16 @@ class SpeckvLib:
         fs = (c_uint64 * n)(*first_pages)
         ps = (c_void_p * n)(*d_srcs)
         self._ext("speckv_ext_write_strided_batch", hs, fs, ps, n, page_step, n_pages_each, c_void_p(stream))
+
+    def write_async(self, handle, offset, d_src, nbytes, stream):
+        """A contiguous page range from a device buffer, asynchronously on `stream` (no device-wide wait)."""
+        self._ext("speckv_ext_write_async", handle, offset, c_void_p(d_src), nbytes, c_void_p(stream or 0))
+
+    def write_runs(self, handle, first_pages, d_srcs, n_pages_each, stream):
+        """Several page runs of one allocation in ONE launch: run r = n_pages_each pages from first_pages[r], read from d_srcs[r]."""
+        n = len(first_pages)
+        self._ext("speckv_ext_write_runs", handle, (c_uint64 * n)(*first_pages), (c_void_p * n)(*d_srcs), n, n_pages_each,
+                  c_void_p(stream))
 
     def read(self, handle, offset, dst_ptr, nbytes, on_device):
         self._ext("speckv_ext_read", handle, offset, c_void_p(dst_ptr), nbytes, int(on_device))

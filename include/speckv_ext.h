@@ -91,12 +91,24 @@ speckv_status_t speckv_ext_write(speckv_handle_t handle, uint64_t offset_bytes,
  * invalidated first (that case waits for the engine). */
 speckv_status_t speckv_ext_write_strided(speckv_handle_t handle, uint64_t first_page, uint64_t page_step,
                                          uint64_t n_pages, const void* d_src, void* stream);
+/* A contiguous page range from a device buffer, ASYNCHRONOUSLY on `stream` and without a device-wide wait (speckv_ext_write
+ * with src_on_device waits for the whole device first: its source may come from any stream).  offset and len are
+ * multiples of 4096.  Ordering: work the engine later does on its own stream for speckv_access / speckv_ext_read /
+ * speckv_prefetch is ordered behind the write by the library; reads the caller issues on OTHER streams of its own
+ * (speckv_ext_fetch_range, speckv_ext_attend_*) are the caller's to order, as with any stream. */
+speckv_status_t speckv_ext_write_async(speckv_handle_t handle, uint64_t offset_bytes, const void* d_src, size_t len,
+                                       void* stream);
 /* The same for a batch of sequences in ONE launch: allocation handles[i] gets pages first_pages[i] + j * page_step
  * (j < n_pages_each) from d_srcs[i] + j * 4096.  All allocations must use the same compression scheme and the stream
  * must not be NULL.  (A decode step of 256 sequences appends with one call instead of 256 launches.) */
 speckv_status_t speckv_ext_write_strided_batch(const speckv_handle_t* handles, const uint64_t* first_pages,
                                                const void* const* d_srcs, uint32_t n_allocations, uint64_t page_step,
                                                uint64_t n_pages_each, void* stream);
+/* Several page runs of ONE allocation in one launch: run r = pages [first_pages[r], first_pages[r] + n_pages_each) from
+ * d_srcs[r] (n_pages_each * 4096 contiguous bytes).  A prompt's K and V of every layer (2 * num_layers regions of the shim
+ * layout) are stored with one call.  The runs must not overlap; the stream must not be NULL. */
+speckv_status_t speckv_ext_write_runs(speckv_handle_t handle, const uint64_t* first_pages, const void* const* d_srcs,
+                                      uint32_t n_runs, uint64_t n_pages_each, void* stream);
 /* Fetch + decompress straight into a caller buffer, bypassing the tiers. */
 speckv_status_t speckv_ext_read(speckv_handle_t handle, uint64_t offset_bytes,
                                 void* dst, size_t len, int dst_on_device);

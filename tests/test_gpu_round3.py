@@ -1,0 +1,280 @@
+"""-m gpu: round-3 engine work through the C ABI -- ordering of the engine stream behind asynchronous writes, finalize
+against a thread parked inside the engine, the prefetch queue under concurrent callers, the asynchronous write entry
+points (speckv_ext_write_async / _write_runs)."""
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import cxl_speckv_amd as pkg
+from cxl_speckv_amd.speckv_ctypes import SpeckvError, SpeckvLib
+from tests._gpu import N, assert_same_float_bits, dev_to_host, torch_mod
+
+pytestmark = pytest.mark.gpu
+PAGE = 4096
+
+
+def open_lib(**env):
+    for k, v in env.items():
+        os.environ[k] = str(v)
+    try:
+        return SpeckvLib(pkg.library_path(), "hip:0")
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+
+
+def synth(n_pages, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n_pages, N))
+    x[1::7] = 0.0
+    return x.astype(np.float16)
+
+
+@pytest.mark.parametrize("scheme", [2, 0])
+def test_engine_reads_are_ordered_behind_asynchronous_writes(oracle, scheme):
+    """a write on the CALLER's stream (write_strided / write_async / write_runs) followed, without any
+    host synchronisation, by reads the engine does on its OWN stream -- speckv_access (synchronous miss), speckv_ext_read to
+    a host buffer, a prefetch flush -- must see the new records, not the old ones and not half-written ones.  The caller's
+    stream is kept busy in front of the write so that an unordered engine stream would win the race every time."""
+    torch = torch_mod()
+    lib = open_lib()
+    try:
+        lib.set_compression_scheme(scheme)
+        T, L, H, D = 256, 2, 8, 128
+        n_pages = T * L * H * D * 2 * 2 // PAGE
+        h = lib.alloc(n_pages * PAGE)
+        lib.set_layout(h, T, L, H, D, 2)
+        old = synth(n_pages, 1)
+        lib.write(h, 0, old.ctypes.data, old.nbytes, False)
+        new = synth(n_pages, 2)
+        d_new = torch.from_numpy(new.view(np.int16)).cuda()
+        sc, ln, rc = oracle.compress_blocks_f16(new, scheme, 0)
+        want = oracle.decompress_blocks_f16(rc, ln, sc, scheme, 0)
+        user = torch.cuda.Stream()
+        torch.cuda.synchronize()
+
+        def busy():
+            with torch.cuda.stream(user):
+                torch.cuda._sleep(int(2.0e8))                      # ~0.1 s in front of the write
+
+        # 1. write_async, then a synchronous miss through the drop-in entry point
+        busy()
+        lib.write_async(h, 16 * PAGE, d_new[16:48].data_ptr(), 32 * PAGE, user.cuda_stream)
+        ptr = lib.access(h, 20 * PAGE, PAGE)
+        assert dev_to_host(ptr, PAGE).tobytes() == want[20].tobytes()
+        # 2. write_strided, then speckv_ext_read into a HOST buffer (no device-wide wait on that path)
+        busy()
+        lib.write_strided(h, 64, 3, 8, d_new[64:72].data_ptr(), user.cuda_stream)      # pages 64, 67, .. <- new[64..71]
+        got = np.empty((32, N), np.float16)
+        lib.read(h, 64 * PAGE, got.ctypes.data, got.nbytes, False)
+        for j in range(8):
+            assert got[3 * j].tobytes() == want[64 + j].tobytes(), j
+        # 3. write_runs (two regions in one launch), then a look-ahead flush that fetches those very pages into L2
+        busy()
+        lib.write_runs(h, [128, 160], [d_new[128:136].data_ptr(), d_new[160:168].data_ptr()], 8, user.cuda_stream)
+        lib.prefetch_batch([0], [0], [1], [12])                     # layer 0, positions 2..13: K pages 1..6, V pages 129..134
+        assert lib.prefetch_flush() >= 12
+        lib.sync()
+        ptr = lib.access(h, 130 * PAGE, PAGE)
+        assert dev_to_host(ptr, PAGE).tobytes() == want[130].tobytes()
+        assert lib.stats().l2_hits >= 1
+        lib.free(h)
+    finally:
+        lib.finalize()
+
+
+def test_connector_append_then_block_table_without_a_sync(oracle):
+    """The concrete case of the advice: SpeckvKVConnector.append() (asynchronous, side stream) directly followed by
+    block_table() (engine stream), and write_prefill as ONE asynchronous launch (speckv_ext_write_runs)."""
+    torch = torch_mod()
+    from cxl_speckv_amd.kv_connector import SpeckvKVConnector
+    lib = open_lib()
+    try:
+        L, H, D, T = 3, 8, 128, 128
+        conn = SpeckvKVConnector(lib, num_layers=L, num_kv_heads=H, head_dim=D, max_tokens=T, scheme="int8_delta_rle")
+        gen = torch.Generator(device="cuda"); gen.manual_seed(9)
+        rnd = lambda *s: torch.randn(s, generator=gen, device="cuda", dtype=torch.float32).to(torch.float16)
+        conn.add_request(1)
+        k0, v0 = rnd(L, 21, H, D), rnd(L, 21, H, D)                # odd prompt: position 20 waits in the tail
+        held = conn.write_prefill(1, k0, v0)
+        rows = {0: [k0[:, p] for p in range(21)], 1: [v0[:, p] for p in range(21)]}
+        for step in range(6):
+            kn, vn = rnd(1, L, H, D), rnd(1, L, H, D)
+            held += conn.append([1], kn, vn)
+            rows[0].append(kn[0]); rows[1].append(vn[0])
+            n = conn.length(1)
+            if n % 2 == 0:                                          # the pair that was just written, read back at once
+                for layer in range(L):
+                    for kind in (0, 1):
+                        addrs = conn.block_table(1, layer, kind, n - 2, n)
+                        assert len(addrs) == 2 and all(addrs)
+                        src = torch.stack((rows[kind][n - 2][layer], rows[kind][n - 1][layer])).cpu().numpy().reshape(1, N)
+                        sc, ln, rc = oracle.compress_blocks_f16(src, 2, 0)
+                        want = oracle.decompress_blocks_f16(rc, ln, sc, 2, 0).reshape(2, H * D)
+                        for j, a in enumerate(addrs):
+                            assert dev_to_host(a, H * D * 2).tobytes() == want[j].tobytes(), (step, layer, kind, j)
+        # and the prompt itself, written by one launch
+        torch.cuda.synchronize()
+        for layer in range(L):
+            for kind, t in ((0, k0), (1, v0)):
+                got = conn.kv_rows(1, layer, kind)
+                torch.cuda.synchronize()
+                src = t[layer, :20].cpu().numpy().reshape(10, N)
+                sc, ln, rc = oracle.compress_blocks_f16(src, 2, 0)
+                want = oracle.decompress_blocks_f16(rc, ln, sc, 2, 0).reshape(20, H, D)
+                assert_same_float_bits(got[:20].cpu().numpy(), want)
+    finally:
+        lib.finalize()
+
+
+def test_write_entry_point_argument_errors():
+    torch = torch_mod()
+    lib = open_lib()
+    try:
+        lib.set_compression_scheme(2)
+        h = lib.alloc(64 * PAGE)
+        buf = torch.zeros((64, N), dtype=torch.float16, device="cuda")
+        st = torch.cuda.Stream()
+        with pytest.raises(SpeckvError):
+            lib.write_async(h, 100, buf.data_ptr(), PAGE, st.cuda_stream)                 # offset not page aligned
+        with pytest.raises(SpeckvError):
+            lib.write_async(h, 0, buf.data_ptr(), 65 * PAGE, st.cuda_stream)              # past the end
+        with pytest.raises(SpeckvError):
+            lib.write_runs(h, [0, 4], [buf.data_ptr(), buf.data_ptr()], 8, st.cuda_stream)   # overlapping runs
+        with pytest.raises(SpeckvError):
+            lib.write_runs(h, [0, 60], [buf.data_ptr(), buf.data_ptr()], 8, st.cuda_stream)  # second run leaves the allocation
+        with pytest.raises(SpeckvError):
+            lib.write_runs(h, [0], [buf.data_ptr()], 8, None)                               # needs a stream
+        lib.write_async(h, 0, buf.data_ptr(), 0, st.cuda_stream)                            # empty: fine
+        lib.write_runs(h, [0, 8, 56], [buf.data_ptr()] * 3, 8, st.cuda_stream)
+        torch.cuda.synchronize()
+        assert lib.stats().total_compressions == 24
+    finally:
+        lib.finalize()
+
+
+def test_finalize_waits_for_a_thread_parked_inside_the_engine():
+    """a thread inside speckv_ext_sync has released the ABI mutex while it waits for the GPU; a
+    concurrent speckv_finalize must not destroy the engine under it.  It waits until the engine is empty, entries that
+    arrive meanwhile see the library as not initialised, and the parked call returns normally."""
+    torch = torch_mod()
+    lib = open_lib()
+    lib.set_compression_scheme(2)
+    n = 64
+    h = lib.alloc(n * PAGE)
+    x = synth(n, 3)
+    d_x = torch.from_numpy(x.view(np.int16)).cuda()
+    user = torch.cuda.Stream()
+    results = {}
+
+    def parked():
+        try:
+            # a synchronous miss: its fetch is ordered behind the asynchronous write below, which sits behind ~0.5 s of
+            # work on the caller's stream -- the thread waits for the GPU inside the engine with the ABI lock released
+            ptr = lib.access(h, 5 * PAGE, PAGE)
+            results["parked"] = "ok" if ptr else "null pointer"      # (the pointer dies with the engine: not read here)
+        except Exception as e:          # noqa: BLE001
+            results["parked"] = repr(e)
+
+    torch.cuda.synchronize()
+    with torch.cuda.stream(user):
+        torch.cuda._sleep(int(1.0e9))                              # ~0.5 s
+    lib.write_async(h, 0, d_x.data_ptr(), n * PAGE, user.cuda_stream)
+    t = threading.Thread(target=parked)
+    t.start()
+    time.sleep(0.15)                                               # the thread is inside the engine, waiting for the GPU
+    t0 = time.perf_counter()
+    lib.finalize()                                                 # must wait for it, not free the engine under it
+    t.join(timeout=30)
+    assert not t.is_alive()
+    assert results.get("parked") == "ok", results
+    assert time.perf_counter() - t0 < 20
+    # the library is really finalized and can be opened again
+    with pytest.raises(SpeckvError):
+        lib.alloc(PAGE)
+    lib2 = open_lib()
+    try:
+        assert lib2.alloc(PAGE) == 1
+    finally:
+        lib2.finalize()
+
+
+def test_prefetch_from_two_threads_while_flushes_run(oracle):
+    """speckv_prefetch from one thread while another thread's flush has let go of the ABI lock used to
+    append to the very vectors that flush was copying from, and the flush then cleared them.  Two threads enqueue and
+    flush concurrently for a while: no request may be lost (every page either fetched or already resident or counted as
+    dropped), and nothing crashes."""
+    torch = torch_mod()
+    lib = open_lib(SPECKV_L2_MB=64)
+    try:
+        lib.set_compression_scheme(2)
+        T, L, H, D = 2048, 4, 8, 128
+        n_pages = T * L * H * D * 2 * 2 // PAGE
+        handles = []
+        for r in range(2):
+            h = lib.alloc(n_pages * PAGE)
+            lib.set_layout(h, T, L, H, D, 2)
+            lib.bind_request(100 + r, h, 0)
+            handles.append(h)
+        errors = []
+
+        def worker(r):
+            try:
+                rng = np.random.default_rng(r)
+                for it in range(300):
+                    pos = int(rng.integers(0, T - 40))
+                    for layer in range(L):
+                        lib.prefetch(100 + r, layer, pos, 4, list(range(1, 17)))
+                    if it % 3 == 0:
+                        lib.prefetch_flush(want_count=(it % 2 == 0))
+            except Exception as e:      # noqa: BLE001
+                errors.append(repr(e))
+
+        ts = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+        for t in ts: t.start()
+        for t in ts: t.join(timeout=120)
+        assert not any(t.is_alive() for t in ts) and not errors, errors
+        lib.prefetch_flush()
+        lib.sync()
+        st = lib.stats()
+        assert st.prefetch_dropped == 0
+        assert st.total_prefetches > 0 and st.dma_completed >= st.total_prefetches
+        # the look-ahead of a fresh position still lands and is served from L2
+        lib.prefetch(100, 2, 1000, 4, list(range(1, 17)))
+        lib.prefetch_flush()
+        lib.sync()
+        hits0 = lib.stats().l2_hits
+        row = H * D * 2
+        off = ((2 * 2 + 0) * T + 1002) * row
+        assert lib.access(handles[0], off, 256)
+        assert lib.stats().l2_hits == hits0 + 1
+    finally:
+        lib.finalize()
+
+
+def test_decode_loop_does_not_accumulate_flights_or_events(oracle):
+    """a decode loop that only appends, flushes and attends never called anything that retired finished
+    flushes; completions are now harvested by the flush itself and counted when a flight finishes."""
+    torch = torch_mod()
+    lib = open_lib()
+    try:
+        lib.set_compression_scheme(2)
+        T, L, H, D = 1024, 2, 8, 128
+        h = lib.alloc(T * L * H * D * 2 * 2)
+        lib.set_layout(h, T, L, H, D, 2)
+        total = 0
+        for it in range(200):
+            lib.prefetch_batch([0, 0], [0, 1], [4 * it % (T - 16)] * 2, [4, 4])
+            n = lib.prefetch_flush()
+            total += n
+        lib.sync()
+        st = lib.stats()
+        assert st.total_prefetches == total and total > 0
+        assert lib.poll_complete() == total                        # descriptors completed since the last poll, then cleared
+        assert lib.poll_complete() == 0
+        assert st.dma_completed == total
+    finally:
+        lib.finalize()
