@@ -343,6 +343,48 @@ speckv_status_t speckv_ext_codec_decompress(const void* d_recs, uint64_t rec_str
     return codec_launch(false, a, stream);
 }
 
+// FPGACacheEngine::compress / ::decompress with the reference's own call shape: a tensor of any length, one scale, one
+// delta chain, one run-length stream (cache_engine.cpp:40-116)
+size_t speckv_ext_codec_tensor_workspace_bytes(uint64_t n_elems) { return speckv::tensor_compress_workspace_bytes(n_elems); }
+size_t speckv_ext_codec_tensor_decode_workspace_bytes(uint64_t rle_bytes) { return speckv::tensor_decompress_workspace_bytes(rle_bytes); }
+
+speckv_status_t speckv_ext_codec_compress_tensor(const void* d_src, uint64_t n_elems, int src_f32, void* d_rle, uint64_t* d_rle_bytes,
+                                                 float* d_scale, void* d_workspace, size_t workspace_bytes, int quant_mode, void* stream)
+{
+    if (quant_mode < 0 || quant_mode > 1 || !d_rle_bytes || !d_scale || !d_workspace) return SPECKV_ERR_INVAL;
+    if (n_elems && (!d_src || !d_rle)) return SPECKV_ERR_INVAL;
+    if ((reinterpret_cast<uintptr_t>(d_rle) & 15u) || (reinterpret_cast<uintptr_t>(d_workspace) & 255u)) return SPECKV_ERR_INVAL;
+    if (workspace_bytes < speckv::tensor_compress_workspace_bytes(n_elems)) return SPECKV_ERR_INVAL;
+    const hipError_t e = speckv::launch_tensor_compress(d_src, n_elems, src_f32 != 0, static_cast<uint8_t*>(d_rle), d_rle_bytes, d_scale,
+                                                        d_workspace, workspace_bytes, quant_mode, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        fprintf(stderr, "[libcxlspeckv] speckv_ext_codec_compress_tensor: %s\n", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return SPECKV_ERR_DRIVER;
+    }
+    return SPECKV_OK;
+}
+
+speckv_status_t speckv_ext_codec_decompress_tensor(const void* d_rle, uint64_t rle_bytes, float scale, void* d_dst, uint64_t dst_cap_elems,
+                                                   int out_f32, uint64_t* d_n_out, void* d_workspace, size_t workspace_bytes,
+                                                   int quant_mode, void* stream)
+{
+    if (quant_mode < 0 || quant_mode > 1 || !d_workspace) return SPECKV_ERR_INVAL;
+    if (rle_bytes && !d_rle) return SPECKV_ERR_INVAL;
+    if (dst_cap_elems && !d_dst) return SPECKV_ERR_INVAL;
+    if ((reinterpret_cast<uintptr_t>(d_dst) & 15u) || (reinterpret_cast<uintptr_t>(d_rle) & 1u) || (reinterpret_cast<uintptr_t>(d_workspace) & 255u))
+        return SPECKV_ERR_INVAL;
+    if (workspace_bytes < speckv::tensor_decompress_workspace_bytes(rle_bytes)) return SPECKV_ERR_INVAL;
+    const hipError_t e = speckv::launch_tensor_decompress(static_cast<const uint8_t*>(d_rle), rle_bytes, scale, d_dst, dst_cap_elems, out_f32 != 0,
+                                                          d_n_out, d_workspace, workspace_bytes, quant_mode, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        fprintf(stderr, "[libcxlspeckv] speckv_ext_codec_decompress_tensor: %s\n", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return SPECKV_ERR_DRIVER;
+    }
+    return SPECKV_OK;
+}
+
 speckv_status_t speckv_ext_qk_scores_fp8(speckv_handle_t handle, uint32_t layer, const void* d_q_f16, uint32_t g,
                                          uint32_t pos_begin, uint32_t pos_end, float* d_out, void* stream)
 {

@@ -129,6 +129,16 @@ struct CodecArgs {
 hipError_t launch_compress(const CodecArgs& a, hipStream_t s);
 hipError_t launch_decompress(const CodecArgs& a, hipStream_t s);
 
+// FPGACacheEngine::compress / ::decompress over a tensor of any length (tensor_codec.hip): one scale, one delta chain and
+// one run-length stream across the whole tensor.  d_rle: 16-byte aligned, room for 2n bytes rounded up to 16; d_ws:
+// 256-byte aligned scratch of tensor_*_workspace_bytes; d_n_out may be null.
+size_t tensor_compress_workspace_bytes(uint64_t n);
+size_t tensor_decompress_workspace_bytes(uint64_t rle_bytes);
+hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, uint8_t* d_rle, uint64_t* d_rle_bytes, float* d_scale,
+                                  void* d_ws, size_t ws_bytes, int quant_mode, hipStream_t s);
+hipError_t launch_tensor_decompress(const uint8_t* d_rle, uint64_t rle_bytes, float scale, void* d_dst, uint64_t dst_cap, bool out_f32,
+                                    uint64_t* d_n_out, void* d_ws, size_t ws_bytes, int quant_mode, hipStream_t s);
+
 // Prefetch lookup: 3 kernels (mask+count, scan, scatter) -> compacted page list
 // in request order.  scratch must hold (2*n + 2) uint32.
 hipError_t launch_prefetch_lookup(const Layout& lay, uint32_t n,

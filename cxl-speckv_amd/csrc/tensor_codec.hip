@@ -1,0 +1,458 @@
+// cxl-speckv_amd/csrc/tensor_codec.hip -- FPGACacheEngine::compress / ::decompress over a tensor of ANY length, as the
+// reference defines them (src/fpga_engine/cache_engine.cpp:40-116): ONE scale over the n elements (compute_scale_factor,
+// :172-184), ONE int8 delta chain (:198-211, :260-273) and ONE run-length stream (:213-258) -- runs, 255-element splits and
+// the delta chain all cross the 2048-element tiles the work is cut into.  (The pool itself stores KV per 4 KiB block,
+// kernels.hip: each compress() call of the engine is one block.  This file is the reference's own call shape: n = 11 in the
+// survey's known-answer test, the RTL tile of 1024 x 128 = 131 072 elements, ...)
+//
+// The serial recurrences become scans at two levels: inside a tile they are the wave scans of the block encoder's general
+// path (one element per lane and step, DPP add / max scans with carries); across tiles a single wave walks the per-tile
+// summaries 64 tiles per step.
+//   compress:   k_tc_absmax -> k_tc_tiles<summary> -> k_tc_scan -> k_tc_tiles<emit> -> k_tc_pack
+//   decompress: k_td_summary -> k_td_scan -> k_td_expand
+// Positions p = 0..n-1; d[p] = q[p] - q[p-1] (q[-1] = 0); a STRETCH starts at p == 0 or d[p] != d[p-1]; a RUN starts every
+// 255 elements of a stretch (cache_engine.cpp:224: `count < 255`); pair = (d[p], distance to the next run start).
+// Every wave writes whole 128-byte lines of its own (tile-local pair buffers, then an output-centric pack pass): byte
+// stores of different workgroups into one line are avoided throughout this library (DESIGN.md sect. 2).
+#include "kernels.hpp"
+#include "codec_device.hpp"
+
+#include <algorithm>
+
+namespace speckv {
+namespace {
+
+constexpr uint32_t kTile = 2048;            // elements per tile (one wave)
+constexpr uint32_t kTcWaves = 4;
+constexpr uint32_t kTcLead = 16;            // bytes in front of a wave's pair buffer: "count of the pair before the first" lands here
+
+struct TcSummary {                          // what a tile knows without its left neighbours (positions tile-relative, +1; 0 = none)
+    uint32_t first_ss, last_ss;             // first / last stretch start
+    uint32_t cnt_b, last_b;                 // run starts at or behind the first stretch start: how many, the last one
+};
+struct TcCarry {                            // what the scan hands back to a tile
+    uint32_t lead_phase;                    // (tile start - stretch start entering the tile) % 255
+    uint32_t runs;                          // run starts in the tile
+    uint64_t run_base;                      // run starts before the tile
+    uint64_t next_run;                      // position of the first run start behind the tile (n if none)
+};
+
+template <bool F32>
+__device__ __forceinline__ float tc_load(const void* src, uint64_t p)
+{
+    return F32 ? static_cast<const float*>(src)[p] : half_bits_to_float(static_cast<const uint16_t*>(src)[p]);
+}
+
+// max|x| over the tensor as fp32 bits (non-negative floats order like their bit patterns); a NaN never wins
+// (cache_engine.cpp:176-180: `if (abs > max_val)`)
+template <bool F32>
+__global__ __launch_bounds__(256) void k_tc_absmax(const void* __restrict__ src, uint64_t n, uint32_t* __restrict__ out_bits)
+{
+    uint32_t m = 0;
+    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < n; p += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const float a = fabsf(tc_load<F32>(src, p));
+        if (a == a) m = umax(m, __float_as_uint(a));
+    }
+    m = lane63(wave_incl_max(m));
+    if ((threadIdx.x & 63u) == 0u && m) atomicMax(out_bits, m);
+}
+
+__device__ __forceinline__ float tc_scale(uint32_t absmax_bits)
+{
+    const float mx = __uint_as_float(absmax_bits);
+    return (mx > 0.0f) ? (mx / 127.0f) : 1.0f;                      // cache_engine.cpp:183
+}
+
+// One tile, one wave: the loop of the block encoder's general path with carries that may come from other tiles.
+// EMIT = false: the tile's summary.  EMIT = true: the tile's pairs into its 4 KiB slot of the pair scratch.
+template <int MODE, bool F32, bool EMIT>
+__global__ __launch_bounds__(64 * kTcWaves) void k_tc_tiles(const void* __restrict__ src, uint64_t n, const uint32_t* __restrict__ absmax_bits,
+                                                            TcSummary* __restrict__ summ, const TcCarry* __restrict__ carry,
+                                                            uint8_t* __restrict__ pair_scratch)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[EMIT ? kTcWaves * (kTcLead + 2 * kTile) : 16];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t tile = static_cast<uint64_t>(blockIdx.x) * kTcWaves + wave;
+    const uint64_t t0 = tile * kTile;
+    if (t0 >= n) return;
+    const uint32_t len = static_cast<uint32_t>((n - t0 < kTile) ? (n - t0) : kTile);
+    const float scale = tc_scale(*absmax_bits);
+    // the two elements in front of the tile give q[t0-1] and d[t0-1]
+    uint32_t qtail = 0, dtail = 0;
+    if (t0 >= 1) {
+        qtail = quantize<MODE>(tc_load<F32>(src, t0 - 1), scale);
+        const uint32_t q2 = (t0 >= 2) ? quantize<MODE>(tc_load<F32>(src, t0 - 2), scale) : 0u;
+        dtail = (qtail - q2) & 0xFFu;
+    }
+    TcCarry cy{};
+    uint8_t* wl = nullptr;
+    uint32_t pair_addr = 0;
+    if (EMIT) {
+        cy = carry[tile];
+        wl = lds + wave * (kTcLead + 2 * kTile);
+        pair_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)(wl + kTcLead)));
+    }
+    uint32_t scarry = 0;        // last stretch start inside the tile so far (rel + 1)
+    uint32_t mcarry = 0;        // last run start inside the tile so far (rel + 1)
+    uint32_t icarry = 0;        // run starts so far
+    uint32_t first_ss = 0;
+#pragma unroll 1
+    for (uint32_t step = 0; step < kTile / 64u; ++step) {
+        const uint32_t rel = 64u * step + lane;
+        if (64u * step >= len) break;                               // wave-uniform
+        const bool live = rel < len;
+        const uint32_t qv = live ? quantize<MODE>(tc_load<F32>(src, t0 + rel), scale) : 0u;
+        const uint32_t prevq = wave_shr1(qv, qtail);
+        qtail = lane63(qv);
+        const uint32_t d = (qv - prevq) & 0xFFu;
+        const uint32_t prevd = wave_shr1(d, dtail);
+        dtail = lane63(d);
+        const bool neq = live && ((t0 + rel == 0u) || (d != prevd));
+        const unsigned long long nb = __ballot(neq);
+        if (!first_ss && nb) first_ss = 64u * step + static_cast<uint32_t>(__builtin_ctzll(nb)) + 1u;
+        const uint32_t is = wave_incl_max(neq ? rel + 1u : 0u);
+        const uint32_t ss = umax(is, scarry);                       // this element's stretch start, rel + 1 (0: before the tile)
+        scarry = umax(scarry, lane63(is));
+        bool isrun;
+        if (ss) isrun = live && ((rel + 1u - ss) % 255u) == 0u;
+        else    isrun = EMIT && live && ((cy.lead_phase + rel) % 255u) == 0u;      // continuation of a stretch of earlier tiles
+        const uint32_t ic = wave_incl_add(isrun ? 1u : 0u);
+        const uint32_t idx = icarry + ic - (isrun ? 1u : 0u);
+        icarry += lane63(ic);
+        const uint32_t im = wave_incl_max(isrun ? rel + 1u : 0u);
+        const uint32_t prev = umax(wave_shr1(im, 0u), mcarry);      // previous run start inside the tile (rel + 1, 0 = none)
+        mcarry = umax(mcarry, lane63(im));
+        if (EMIT && isrun) {
+            // value byte of this pair, count byte of the previous one (the first pair of the tile writes into the lead bytes)
+            *reinterpret_cast<__attribute__((address_space(3))) uint8_t*>(static_cast<uintptr_t>(pair_addr + 2u * idx - 1u)) = static_cast<uint8_t>(rel + 1u - prev);
+            *reinterpret_cast<__attribute__((address_space(3))) uint8_t*>(static_cast<uintptr_t>(pair_addr + 2u * idx)) = static_cast<uint8_t>(d);
+        }
+    }
+    if (!EMIT) {
+        if (lane == 0u) summ[tile] = TcSummary{first_ss, scarry, icarry, mcarry};
+        return;
+    }
+    // close the tile's last pair: it ends where the next run starts (in a later tile, or at n)
+    if (icarry && lane == 0u) {
+        const uint64_t last_abs = t0 + mcarry - 1u;
+        *reinterpret_cast<__attribute__((address_space(3))) uint8_t*>(static_cast<uintptr_t>(pair_addr + 2u * icarry - 1u)) =
+            static_cast<uint8_t>(cy.next_run - last_abs);
+    }
+    wave_lds_fence();
+    uint8_t* dst = pair_scratch + tile * (2ull * kTile);
+    const uint32_t bytes = 2u * icarry;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t b = 1024u * j + 16u * lane;
+        if (b < bytes) *reinterpret_cast<uint4*>(dst + b) = *reinterpret_cast<const uint4*>(wl + kTcLead + b);
+    }
+}
+
+// One wave over all tiles, 64 per step: what enters each tile from the left (stretch start, run count) and from the
+// right (next run start).  Also the tensor's scale and its stream length.
+__global__ __launch_bounds__(64) void k_tc_scan(const TcSummary* __restrict__ summ, TcCarry* __restrict__ carry, uint64_t n_tiles, uint64_t n,
+                                               const uint32_t* __restrict__ absmax_bits, float* __restrict__ out_scale,
+                                               uint64_t* __restrict__ out_bytes, uint64_t* __restrict__ first_run_tmp)
+{
+    const uint32_t lane = threadIdx.x;
+    uint64_t ss_carry = 0;              // last stretch start before the step (absolute position + 1)
+    uint64_t run_carry = 0;
+    for (uint64_t base = 0; base < n_tiles; base += 64u) {
+        const uint64_t t = base + lane;
+        const bool live = t < n_tiles;
+        TcSummary s{0u, 0u, 0u, 0u};
+        if (live) s = summ[t];
+        const uint64_t t0 = t * kTile;
+        const uint32_t len = live ? static_cast<uint32_t>((n - t0 < kTile) ? (n - t0) : kTile) : 0u;
+        // stretch start entering the tile: the last one of an earlier tile of this step, else of earlier steps
+        const uint32_t enc = s.last_ss ? lane * kTile + s.last_ss : 0u;
+        const uint32_t inc = wave_incl_max(enc);
+        const uint32_t exc = wave_shr1(inc, 0u);
+        const uint64_t ss_in = exc ? base * kTile + exc : ss_carry;             // absolute position + 1 (0 only for tile 0)
+        const uint32_t tot = lane63(inc);
+        if (tot) ss_carry = base * kTile + tot;
+        // run starts in front of the tile's first stretch start: every 255 elements of the entering stretch
+        uint32_t lead_phase = 0, cnt_a = 0, first_a = 0;
+        const uint32_t f_end = s.first_ss ? s.first_ss - 1u : len;
+        if (live && ss_in && f_end) {
+            lead_phase = static_cast<uint32_t>((t0 - (ss_in - 1u)) % 255u);
+            first_a = (255u - lead_phase) % 255u;
+            if (first_a < f_end) cnt_a = (f_end - 1u - first_a) / 255u + 1u;
+        }
+        const uint32_t runs = cnt_a + s.cnt_b;
+        const uint32_t rinc = wave_incl_add(runs);
+        if (live) {
+            TcCarry c;
+            c.lead_phase = lead_phase;
+            c.runs = runs;
+            c.run_base = run_carry + rinc - runs;
+            c.next_run = n;
+            carry[t] = c;
+            first_run_tmp[t] = cnt_a ? t0 + first_a + 1u : (s.cnt_b ? t0 + s.first_ss : 0u);   // absolute position + 1
+        }
+        run_carry += lane63(rinc);
+    }
+    if (lane == 0u) {
+        carry[n_tiles].run_base = run_carry;                         // sentinel for the pack pass
+        carry[n_tiles].runs = 0; carry[n_tiles].lead_phase = 0; carry[n_tiles].next_run = n;
+        *out_bytes = 2ull * run_carry;
+        *out_scale = tc_scale(*absmax_bits);
+    }
+    __threadfence();
+    // right to left: the first run start behind each tile.  Lane l takes tile base + 63 - l, so "nearest later tile" is
+    // "nearest earlier lane" and the forward max-scan applies (encoding: larger = nearer).
+    uint64_t next_carry = n;
+    const uint64_t steps = (n_tiles + 63u) / 64u;
+    for (uint64_t sidx = steps; sidx-- > 0;) {
+        const uint64_t base = sidx * 64u;
+        const uint64_t t = base + 63u - lane;
+        const bool live = t < n_tiles;
+        const uint64_t fr = live ? first_run_tmp[t] : 0u;           // absolute position + 1
+        const uint32_t span = 64u * kTile;
+        const uint32_t enc = fr ? span - static_cast<uint32_t>(fr - 1u - base * kTile) : 0u;    // position relative to the step, reversed
+        const uint32_t inc = wave_incl_max(enc);
+        const uint32_t exc = wave_shr1(inc, 0u);
+        if (live) carry[t].next_run = exc ? base * kTile + (span - exc) : next_carry;
+        const uint32_t tot = lane63(inc);
+        if (tot) next_carry = base * kTile + (span - tot);
+    }
+}
+
+// Output-centric pack: a wave owns 2048 consecutive pairs (4 KiB, line-aligned) of the stream and gathers them from the
+// tiles' slots.  Lane piece = 8 pairs: one binary search over run_base, then a walk.
+__global__ __launch_bounds__(256) void k_tc_pack(const TcCarry* __restrict__ carry, uint64_t n_tiles, const uint8_t* __restrict__ pair_scratch,
+                                                uint8_t* __restrict__ rle)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t total = carry[n_tiles].run_base;
+    const uint64_t chunk = (static_cast<uint64_t>(blockIdx.x) * 4u + wave) * kTile;
+    if (chunk >= total) return;
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+        const uint64_t r0 = chunk + 512u * j + 8u * lane;
+        if (r0 >= total) continue;
+        // last tile whose run_base <= r0 (tiles without runs share their successor's base and are skipped by the search)
+        uint64_t lo = 0, hi = n_tiles;                              // carry[hi].run_base > r0 holds for hi = n_tiles (total > r0)
+        while (hi - lo > 1u) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (carry[mid].run_base <= r0) lo = mid; else hi = mid;
+        }
+        uint64_t t = lo;
+        uint64_t tb = carry[t].run_base, te = carry[t + 1].run_base;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint64_t r = r0 + k;
+            if (r < total) {
+                while (r >= te) { ++t; tb = te; te = carry[t + 1].run_base; }
+                const uint32_t pr = *reinterpret_cast<const uint16_t*>(pair_scratch + t * (2ull * kTile) + 2ull * (r - tb));
+                w[k >> 1] |= pr << ((k & 1) * 16);
+            }
+        }
+        *reinterpret_cast<uint4*>(rle + 2ull * r0) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// ---------------------------------------------------------------- decompress
+struct TdSummary { uint32_t sum_c, sum_v; };           // of one chunk of 2048 pairs: elements it emits, sum of value*count mod 256
+struct TdCarry { uint64_t start; uint32_t q_pre, pad; }; // elements / int8 prefix in front of the chunk
+
+__global__ __launch_bounds__(256) void k_td_summary(const uint8_t* __restrict__ rle, uint64_t n_pairs, TdSummary* __restrict__ summ)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t chunk = static_cast<uint64_t>(blockIdx.x) * 4u + wave;
+    const uint64_t p0 = chunk * kTile;
+    if (p0 >= n_pairs) return;
+    uint32_t sc = 0, sv = 0;
+#pragma unroll 1
+    for (uint32_t step = 0; step < kTile / 64u; ++step) {
+        const uint64_t i = p0 + 64u * step + lane;
+        uint32_t bits = 0;
+        if (i < n_pairs) bits = *reinterpret_cast<const uint16_t*>(rle + 2ull * i);
+        const uint32_t v = bits & 0xFFu, c = bits >> 8;
+        sc += c;
+        sv += v * c;
+    }
+    sc = lane63(wave_incl_add(sc));
+    sv = lane63(wave_incl_add(sv & 0xFFu));
+    if (lane == 0u) summ[chunk] = TdSummary{sc, sv & 0xFFu};
+}
+
+__global__ __launch_bounds__(64) void k_td_scan(const TdSummary* __restrict__ summ, TdCarry* __restrict__ carry, uint64_t n_chunks,
+                                               uint64_t cap, uint64_t* __restrict__ out_n)
+{
+    const uint32_t lane = threadIdx.x;
+    uint64_t start = 0;
+    uint32_t qpre = 0;
+    for (uint64_t base = 0; base < n_chunks; base += 64u) {
+        const uint64_t c = base + lane;
+        TdSummary s{0u, 0u};
+        if (c < n_chunks) s = summ[c];
+        // 64 x 2048 x 255 elements per step do not fit 32 bits: scan the two halves of the count separately
+        const uint32_t lo = wave_incl_add(s.sum_c & 0xFFFFu), hi = wave_incl_add(s.sum_c >> 16);
+        const uint64_t inc = static_cast<uint64_t>(lo) + (static_cast<uint64_t>(hi) << 16);
+        const uint32_t vinc = wave_incl_add(s.sum_v);
+        if (c < n_chunks) carry[c] = TdCarry{start + inc - s.sum_c, (qpre + vinc - s.sum_v) & 0xFFu, 0u};
+        start += static_cast<uint64_t>(lane63(lo)) + (static_cast<uint64_t>(lane63(hi)) << 16);
+        qpre = (qpre + lane63(vinc)) & 0xFFu;
+    }
+    if (lane == 0u) {
+        carry[n_chunks] = TdCarry{start, qpre, 0u};
+        *out_n = start < cap ? start : cap;                          // elements written (the stream's total, clipped at the buffer)
+    }
+}
+
+// Output-centric expand: a wave owns 2048 consecutive output elements.  It finds the chunk of pairs its first element
+// lies in, walks the pairs 64 per step (add-scan of (value*count mod 256) << 24 | count gives each run its start and the
+// int8 prefix of all earlier deltas), and every lane writes the part of its run that falls into the tile:
+//     q[start + m] = prefix + (m + 1) * value  (mod 256)        (cache_engine.cpp:241-273)
+// into a 2 KiB byte table; dequantisation and the stores are then one coalesced pass.
+template <int MODE, bool F32>
+__global__ __launch_bounds__(256) void k_td_expand(const uint8_t* __restrict__ rle, uint64_t n_pairs, const TdCarry* __restrict__ carry,
+                                                  uint64_t n_chunks, const uint64_t* __restrict__ n_out_p, float scale, uint8_t* __restrict__ dst)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tabs[4][kTile];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t n_out = *n_out_p;
+    const uint64_t o0 = (static_cast<uint64_t>(blockIdx.x) * 4u + wave) * kTile;
+    if (o0 >= n_out) return;
+    const uint64_t o1 = (n_out - o0 < kTile) ? n_out : o0 + kTile;
+    uint8_t* tab = tabs[wave];
+    // last chunk whose first element is at or before o0 (chunks that emit nothing share their successor's start)
+    uint64_t lo = 0, hi = n_chunks;                                 // carry[n_chunks].start = total > o0
+    while (hi - lo > 1u) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (carry[mid].start <= o0) lo = mid; else hi = mid;
+    }
+    uint64_t tot = carry[lo].start;                                 // elements in front of pair `i0`
+    uint32_t qp = carry[lo].q_pre;
+#pragma unroll 1
+    for (uint64_t i0 = lo * kTile; i0 < n_pairs && tot < o1; i0 += 64u) {
+        const uint64_t i = i0 + lane;
+        uint32_t bits = 0;
+        if (i < n_pairs) bits = *reinterpret_cast<const uint16_t*>(rle + 2ull * i);
+        const uint32_t v = bits & 0xFFu, c = bits >> 8;
+        const uint32_t packed = ((v * c) << 24) | c;
+        const uint32_t incl = wave_incl_add(packed);
+        const uint32_t e = incl - packed;
+        const uint64_t start = tot + (e & 0xFFFFFFu);
+        uint32_t q = qp + (e >> 24);
+        // the part of [start, start + c) inside [o0, o1)
+        const uint64_t a = start > o0 ? start : o0, b = (start + c < o1) ? start + c : o1;
+        if (a < b) {
+            q += static_cast<uint32_t>(a - start) * v;
+#pragma unroll 1
+            for (uint64_t p = a; p < b; ++p) { q += v; tab[p - o0] = static_cast<uint8_t>(q); }
+        }
+        const uint32_t step_tot = lane63(incl);
+        tot += step_tot & 0xFFFFFFu;
+        qp = (qp + (step_tot >> 24)) & 0xFFu;
+    }
+    wave_lds_fence();
+    const uint32_t valid = static_cast<uint32_t>(o1 - o0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t p0 = 512u * j + 8u * lane;
+        if (p0 >= valid) continue;
+        const uint2 x = *reinterpret_cast<const uint2*>(tab + p0);
+        float y[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t b = ((k < 4 ? x.x : x.y) >> ((k & 3) * 8)) & 0xFFu;
+            y[k] = dequant<MODE>(static_cast<int>(static_cast<int8_t>(b)), scale);
+        }
+        if (p0 + 8u <= valid) {
+            if (F32) {
+                float* o = reinterpret_cast<float*>(dst) + o0 + p0;
+                *reinterpret_cast<float4*>(o) = make_float4(y[0], y[1], y[2], y[3]);
+                *reinterpret_cast<float4*>(o + 4) = make_float4(y[4], y[5], y[6], y[7]);
+            } else {
+                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(dst) + o0 + p0) =
+                    make_uint4(pack_half2(y[0], y[1]), pack_half2(y[2], y[3]), pack_half2(y[4], y[5]), pack_half2(y[6], y[7]));
+            }
+        } else {
+            for (uint32_t k = 0; k < 8u && p0 + k < valid; ++k) {
+                if (F32) reinterpret_cast<float*>(dst)[o0 + p0 + k] = y[k];
+                else { float a = y[k], z = 0.0f; reinterpret_cast<uint16_t*>(dst)[o0 + p0 + k] = static_cast<uint16_t>(pack_half2(a, z) & 0xFFFFu); }
+            }
+        }
+    }
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+} // namespace
+
+// workspace layout (compress): absmax word (256 B) | TcSummary[tiles] | TcCarry[tiles + 1] | first_run u64[tiles] | pair scratch
+size_t tensor_compress_workspace_bytes(uint64_t n)
+{
+    const uint64_t tiles = (n + kTile - 1) / kTile;
+    return 256 + align_up(tiles * sizeof(TcSummary), 256) + align_up((tiles + 1) * sizeof(TcCarry), 256) + align_up(tiles * 8, 256) +
+           tiles * (2ull * kTile);
+}
+size_t tensor_decompress_workspace_bytes(uint64_t rle_bytes)
+{
+    const uint64_t chunks = ((rle_bytes >> 1) + kTile - 1) / kTile;
+    return align_up(chunks * sizeof(TdSummary), 256) + align_up((chunks + 1) * sizeof(TdCarry), 256) + 256;
+}
+
+hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, uint8_t* d_rle, uint64_t* d_rle_bytes, float* d_scale,
+                                  void* d_ws, size_t ws_bytes, int quant_mode, hipStream_t s)
+{
+    if (ws_bytes < tensor_compress_workspace_bytes(n) || (reinterpret_cast<uintptr_t>(d_ws) & 255u)) return hipErrorInvalidValue;
+    const uint64_t tiles = (n + kTile - 1) / kTile;
+    uint8_t* w = static_cast<uint8_t*>(d_ws);
+    uint32_t* absmax = reinterpret_cast<uint32_t*>(w); w += 256;
+    TcSummary* summ = reinterpret_cast<TcSummary*>(w); w += align_up(tiles * sizeof(TcSummary), 256);
+    TcCarry* carry = reinterpret_cast<TcCarry*>(w); w += align_up((tiles + 1) * sizeof(TcCarry), 256);
+    uint64_t* first_run = reinterpret_cast<uint64_t*>(w); w += align_up(tiles * 8, 256);
+    uint8_t* scratch = w;
+    hipError_t e = hipMemsetAsync(absmax, 0, 256, s);
+    if (e != hipSuccess) return e;
+    if (n) {
+        const uint32_t g = static_cast<uint32_t>(std::min<uint64_t>((n + 255) / 256, 4096));
+        if (src_f32) hipLaunchKernelGGL(k_tc_absmax<true>, dim3(g), dim3(256), 0, s, d_src, n, absmax);
+        else         hipLaunchKernelGGL(k_tc_absmax<false>, dim3(g), dim3(256), 0, s, d_src, n, absmax);
+    }
+    const uint32_t tg = static_cast<uint32_t>((tiles + kTcWaves - 1) / kTcWaves);
+#define SPECKV_TC(MODE, F32, EMIT) hipLaunchKernelGGL((k_tc_tiles<MODE, F32, EMIT>), dim3(tg), dim3(64 * kTcWaves), 0, s, d_src, n, absmax, summ, carry, scratch)
+#define SPECKV_TC2(EMIT) do { if (quant_mode == kIntent) { if (src_f32) SPECKV_TC(kIntent, true, EMIT); else SPECKV_TC(kIntent, false, EMIT); } \
+                              else { if (src_f32) SPECKV_TC(kRefExact, true, EMIT); else SPECKV_TC(kRefExact, false, EMIT); } } while (0)
+    if (tiles) SPECKV_TC2(false);
+    hipLaunchKernelGGL(k_tc_scan, dim3(1), dim3(64), 0, s, summ, carry, tiles, n, absmax, d_scale, d_rle_bytes, first_run);
+    if (tiles) {
+        SPECKV_TC2(true);
+        // the pack grid covers the worst case (one pair per element); waves beyond the stream's end return at once
+        const uint64_t chunks = (n + kTile - 1) / kTile;
+        hipLaunchKernelGGL(k_tc_pack, dim3(static_cast<uint32_t>((chunks + 3) / 4)), dim3(256), 0, s, carry, tiles, scratch, d_rle);
+    }
+#undef SPECKV_TC2
+#undef SPECKV_TC
+    return hipGetLastError();
+}
+
+hipError_t launch_tensor_decompress(const uint8_t* d_rle, uint64_t rle_bytes, float scale, void* d_dst, uint64_t dst_cap, bool out_f32,
+                                    uint64_t* d_n_out, void* d_ws, size_t ws_bytes, int quant_mode, hipStream_t s)
+{
+    if (ws_bytes < tensor_decompress_workspace_bytes(rle_bytes) || (reinterpret_cast<uintptr_t>(d_ws) & 255u)) return hipErrorInvalidValue;
+    const uint64_t n_pairs = rle_bytes >> 1;                         // an odd trailing byte is dropped (cache_engine.cpp:245)
+    const uint64_t chunks = (n_pairs + kTile - 1) / kTile;
+    uint8_t* w = static_cast<uint8_t*>(d_ws);
+    TdSummary* summ = reinterpret_cast<TdSummary*>(w); w += align_up(chunks * sizeof(TdSummary), 256);
+    TdCarry* carry = reinterpret_cast<TdCarry*>(w); w += align_up((chunks + 1) * sizeof(TdCarry), 256);
+    uint64_t* n_out = d_n_out ? d_n_out : reinterpret_cast<uint64_t*>(w);
+    if (chunks) hipLaunchKernelGGL(k_td_summary, dim3(static_cast<uint32_t>((chunks + 3) / 4)), dim3(256), 0, s, d_rle, n_pairs, summ);
+    hipLaunchKernelGGL(k_td_scan, dim3(1), dim3(64), 0, s, summ, carry, chunks, dst_cap, n_out);
+    if (chunks && dst_cap) {
+        // grid: the output can hold at most min(dst_cap, 255 * n_pairs) elements; waves behind the stream's total return at once
+        const uint64_t max_out = std::min<uint64_t>(dst_cap, n_pairs * 255u);
+        const uint32_t g = static_cast<uint32_t>(((max_out + kTile - 1) / kTile + 3) / 4);
+#define SPECKV_TD(MODE, F32) hipLaunchKernelGGL((k_td_expand<MODE, F32>), dim3(g), dim3(256), 0, s, d_rle, n_pairs, carry, chunks, n_out, scale, static_cast<uint8_t*>(d_dst))
+        if (quant_mode == kIntent) { if (out_f32) SPECKV_TD(kIntent, true); else SPECKV_TD(kIntent, false); }
+        else                       { if (out_f32) SPECKV_TD(kRefExact, true); else SPECKV_TD(kRefExact, false); }
+#undef SPECKV_TD
+    }
+    return hipGetLastError();
+}
+
+} // namespace speckv

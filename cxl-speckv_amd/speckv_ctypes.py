@@ -73,6 +73,8 @@ _EXT_SIGNATURES = {
     "speckv_ext_sync": [],
     "speckv_ext_codec_compress": [c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "speckv_ext_codec_decompress": [c_void_p, c_uint64, c_void_p, c_void_p, c_uint64, c_void_p, c_int, c_int, c_int, c_void_p],
+    "speckv_ext_codec_compress_tensor": [c_void_p, c_uint64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p],
+    "speckv_ext_codec_decompress_tensor": [c_void_p, c_uint64, ctypes.c_float, c_void_p, c_uint64, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p],
     "speckv_ext_qk_scores_fp8": [c_uint64, c_uint32, c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_void_p],
     "speckv_ext_qk_scores_fp8_layers": [c_uint64, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_void_p],
     "speckv_ext_attend_fp8": [c_uint64, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, c_uint32, ctypes.c_float, c_void_p, c_void_p, c_void_p],
@@ -103,7 +105,9 @@ def bind_ext(lib):
         fn.argtypes, fn.restype = args, c_int
         found.append(name)
     for name, res, args in (("speckv_ext_layer_compression_ratio", ctypes.c_double, [c_uint32]), ("speckv_ext_backend", c_char_p, []),
-                            ("speckv_ext_attend_plan_bytes", c_size_t, [c_uint32])):
+                            ("speckv_ext_attend_plan_bytes", c_size_t, [c_uint32]),
+                            ("speckv_ext_codec_tensor_workspace_bytes", c_size_t, [c_uint64]),
+                            ("speckv_ext_codec_tensor_decode_workspace_bytes", c_size_t, [c_uint64])):
         try:
             fn = getattr(lib, name)
         except AttributeError:

@@ -206,6 +206,27 @@ speckv_status_t speckv_ext_codec_decompress(const void* d_recs, uint64_t rec_str
                                             uint64_t n_blocks, void* d_dst, int out_f32,
                                             int scheme, int quant_mode, void* stream);
 
+/* The same two operators with the reference's own call shape -- a tensor of ANY length (cache_engine.cpp:40-116: n = 11
+ * in the survey's known-answer vector, the RTL tile of 1024 x 128 = 131 072 elements): ONE scale over the n elements, ONE
+ * int8 delta chain and ONE run-length stream; runs and their 255-element splits cross the 2048-element tiles the work is
+ * cut into on the device.
+ *   d_src        n_elems values, fp32 (src_f32 != 0: the reference's std::vector<float>) or fp16
+ *   d_rle        the stream [value u8][count u8]...; 16-byte aligned, room for 2 * n_elems bytes rounded up to 16
+ *   d_rle_bytes  (device) compressed_size;   d_scale (device) scale_factor
+ *   d_workspace  256-byte aligned device scratch of speckv_ext_codec_tensor_workspace_bytes(n_elems) /
+ *                speckv_ext_codec_tensor_decode_workspace_bytes(rle_bytes) bytes
+ * Decompress: dst gets min(sum of counts, dst_cap_elems) elements (fp32 or fp16; 16-byte aligned), *d_n_out (device,
+ * optional) that number; an odd trailing byte is dropped and a zero count emits nothing, as in the reference.
+ * Asynchronous on `stream`; no engine needed. */
+size_t speckv_ext_codec_tensor_workspace_bytes(uint64_t n_elems);
+size_t speckv_ext_codec_tensor_decode_workspace_bytes(uint64_t rle_bytes);
+speckv_status_t speckv_ext_codec_compress_tensor(const void* d_src, uint64_t n_elems, int src_f32, void* d_rle,
+                                                 uint64_t* d_rle_bytes, float* d_scale, void* d_workspace,
+                                                 size_t workspace_bytes, int quant_mode, void* stream);
+speckv_status_t speckv_ext_codec_decompress_tensor(const void* d_rle, uint64_t rle_bytes, float scale, void* d_dst,
+                                                   uint64_t dst_cap_elems, int out_f32, uint64_t* d_n_out,
+                                                   void* d_workspace, size_t workspace_bytes, int quant_mode, void* stream);
+
 /* ---- 4:1 / 2:1 formats + fused dequant-matvec (BASELINE config 5; SURVEY 8a row
  *      A22: no reference counterpart, parity is against oracle/ only) -----------
  * SPECKV_COMP_INT4_G32: record 1152 B = 64 fp16 group scales + 2048 nibbles.

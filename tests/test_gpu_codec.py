@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from tests._gpu import N, assert_same_float_bits, gpu_compress, gpu_decompress, load_debug_lib, load_raw_lib
+from tests._gpu import N, assert_same_float_bits, gpu_compress, gpu_decompress, load_debug_lib, load_raw_lib, stream_ptr, torch_mod
 
 pytestmark = pytest.mark.gpu
 
@@ -350,3 +350,137 @@ def test_wave_primitives():
         w = ((v.astype(np.uint64) * 2654435761) & 0xFFFFFFFF) >> 24
         prev = np.concatenate([[7], w[:-1]]).astype(np.int64)
         assert np.array_equal(o[4], ((w.astype(np.int64) - prev) & 0xFF).astype(np.uint32))
+
+
+# ---- the reference's own call shape: a tensor of any length (speckv_ext_codec_compress_tensor / _decompress_tensor) ----
+def gpu_compress_tensor(lib, x, mode=0):
+    """x: 1-d float32 or float16 numpy.  Returns (scale f32, rle u8[compressed_size])."""
+    torch = torch_mod()
+    x = np.ascontiguousarray(x)
+    f32 = x.dtype == np.float32
+    assert f32 or x.dtype == np.float16
+    n = x.size
+    d_x = torch.from_numpy(x if f32 else x.view(np.int16)).cuda() if n else torch.zeros(1, device="cuda")
+    ws_bytes = lib.speckv_ext_codec_tensor_workspace_bytes(n)
+    d_ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device="cuda")
+    ws_ptr = (d_ws.data_ptr() + 255) & ~255
+    d_rle = torch.full(((2 * n + 15) // 16 * 16 + 16,), 0xA5, dtype=torch.uint8, device="cuda")
+    d_meta = torch.zeros(4, dtype=torch.int64, device="cuda")             # [0] compressed_size, [1] scale bits
+    rc = lib.speckv_ext_codec_compress_tensor(d_x.data_ptr(), n, int(f32), d_rle.data_ptr(), d_meta.data_ptr(), d_meta.data_ptr() + 8,
+                                              ws_ptr, ws_bytes, mode, stream_ptr())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    meta = d_meta.cpu().numpy()
+    size = int(meta[0])
+    scale = np.array([meta[1]], np.int64).view(np.float32)[0]
+    rle = d_rle.cpu().numpy()
+    assert size <= 2 * n
+    return np.float32(scale), rle[:size].copy()
+
+
+def gpu_decompress_tensor(lib, rle, scale, cap, mode=0, out_f32=True):
+    torch = torch_mod()
+    rle = np.ascontiguousarray(rle, dtype=np.uint8)
+    d_rle = torch.from_numpy(np.concatenate([rle, np.zeros(16, np.uint8)])).cuda()
+    ws_bytes = lib.speckv_ext_codec_tensor_decode_workspace_bytes(rle.size)
+    d_ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device="cuda")
+    ws_ptr = (d_ws.data_ptr() + 255) & ~255
+    d_y = torch.full((cap + 16,), float("nan"), dtype=torch.float32 if out_f32 else torch.float16, device="cuda")
+    d_n = torch.zeros(1, dtype=torch.int64, device="cuda")
+    rc = lib.speckv_ext_codec_decompress_tensor(d_rle.data_ptr(), rle.size, float(scale), d_y.data_ptr(), cap, int(out_f32), d_n.data_ptr(),
+                                                ws_ptr, ws_bytes, mode, stream_ptr())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    n = int(d_n.cpu().numpy()[0])
+    y = d_y.cpu().numpy()
+    assert np.isnan(y[max(n, cap):].astype(np.float32)).all()             # nothing written behind the buffer
+    return y[:n].copy()
+
+
+def test_tensor_codec_golden_reference_vectors(lib, golden_dir):
+    """Every reference-generated vector of tests/golden/codec_vectors.npz through the tensor form -- including the ones the
+    2048-element block form cannot take: `kat` (n = 11, the survey's known-answer test), `short_257`, and the 131 072-element
+    `big` vector, whose stream is pinned by its length, a position-weighted checksum and the bit sum
+    of its decoded output.  Bytes of the stream, bits of the scale, bits of every decoded fp32."""
+    g = np.load(os.path.join(golden_dir, "codec_vectors.npz"))
+    names = [k[:-2] for k in g.files if k.endswith(".x")]
+    assert "kat" in names and "short_257" in names and len(names) >= 11
+    for name in names:
+        x = g[f"{name}.x"].astype(np.float32)
+        scale, rle = gpu_compress_tensor(lib, x, 0)
+        assert scale.tobytes() == g[f"{name}.scale"][0].tobytes(), name
+        assert rle.tobytes() == g[f"{name}.rle"].tobytes(), name
+        y = gpu_decompress_tensor(lib, g[f"{name}.rle"], g[f"{name}.scale"][0], x.size, 0, True)
+        assert_same_float_bits(y, g[f"{name}.y"], name)
+    # the known-answer stream itself (SURVEY Appendix A, F-codec-KAT)
+    scale, rle = gpu_compress_tensor(lib, g["kat.x"].astype(np.float32), 0)
+    assert scale == np.float32(1.0)
+    assert rle.view(np.int8).tolist() == [0, 1, 127, 1, 2, 1, -65, 1, 0, 2, -32, 1, -31, 1, 0, 1, -1, 1, 0, 1]
+    # big: regenerate the input exactly as the generator did
+    n = int(g["big.n"][0])
+    x = np.random.default_rng(int(g["big.seed"][0])).standard_normal(n).astype(np.float32)
+    scale, rle = gpu_compress_tensor(lib, x, 0)
+    assert scale.tobytes() == g["big.scale"][0].tobytes()
+    assert rle.size == int(g["big.compressed_size"][0])
+    crc = int(np.bitwise_xor.reduce(rle.astype(np.uint64) * (np.arange(rle.size, dtype=np.uint64) % 251 + 1)))
+    assert crc == int(g["big.rle_crc"][0])
+    y = gpu_decompress_tensor(lib, rle, scale, n, 0, True)
+    assert y.size == n and int(y.view(np.uint32).astype(np.uint64).sum()) == int(g["big.y_sum_bits"][0])
+    # malformed streams (odd tail, zero counts, counts > 127, one byte, empty)
+    for i in range(5):
+        rle = g[f"malformed{i}.rle"]
+        want = g[f"malformed{i}.y"]
+        y = gpu_decompress_tensor(lib, rle, 0.5, max(want.size, 1) + 40, 0, True)
+        assert_same_float_bits(y, want, f"malformed{i}")
+
+
+def test_tensor_codec_matches_oracle_over_sizes_and_structures(lib, oracle):
+    """Lengths around the tile size and far beyond it, data whose runs, 255-splits and delta chain cross tile boundaries
+    (constant tensors, long piecewise-constant stretches, ramps), fp32 and fp16 sources, both quantiser modes, and the
+    decoder clipped by a short output buffer."""
+    rng = np.random.default_rng(77)
+    cases = []
+    for n in (0, 1, 2, 11, 63, 64, 65, 254, 255, 256, 257, 2047, 2048, 2049, 4095, 4097, 6000, 131072, 300001):
+        cases.append((f"gauss{n}", rng.standard_normal(n).astype(np.float32)))
+    cases.append(("const600k", np.full(600001, np.float32(0.37))))
+    cases.append(("zeros70k", np.zeros(70000, np.float32)))
+    cases.append(("ramp", np.linspace(-3, 3, 50000).astype(np.float32)))                  # constant deltas: long stretches
+    pw = np.repeat(rng.standard_normal(400).astype(np.float32), rng.integers(1, 3000, 400))
+    cases.append(("piecewise", pw))
+    sp = np.where(rng.random(200000) < 0.001, rng.standard_normal(200000), 0).astype(np.float32)
+    cases.append(("sparse", sp))
+    wide = rng.standard_normal(5000).astype(np.float32); wide[17] = np.inf; wide[99] = np.nan; wide[4000] = -3e38
+    cases.append(("nonfinite", wide))
+    for name, x in cases:
+        for mode in MODES:
+            o_scale, o_rle = oracle.compress_f32(x, mode)
+            scale, rle = gpu_compress_tensor(lib, x, mode)
+            assert np.float32(scale).tobytes() == np.float32(o_scale).tobytes(), (name, mode)
+            assert rle.tobytes() == o_rle.tobytes(), (name, mode, rle.size, o_rle.size)
+            want = oracle.decompress_f32(o_rle, o_scale, mode)
+            y = gpu_decompress_tensor(lib, o_rle, o_scale, x.size + 5, mode, True)
+            assert_same_float_bits(y, want, f"{name} mode {mode}")
+            if x.size > 100:                                                              # a buffer shorter than the stream's total
+                y = gpu_decompress_tensor(lib, o_rle, o_scale, x.size - 37, mode, True)
+                assert_same_float_bits(y, want[:x.size - 37], f"{name} clipped")
+    # fp16 source and fp16 output: the same maths on exactly converted inputs, one RNE rounding on the way out
+    for n in (11, 2049, 100000):
+        x16 = (rng.standard_normal(n) * 3).astype(np.float16)
+        o_scale, o_rle = oracle.compress_f32(x16.astype(np.float32), 0)
+        scale, rle = gpu_compress_tensor(lib, x16, 0)
+        assert np.float32(scale).tobytes() == np.float32(o_scale).tobytes() and rle.tobytes() == o_rle.tobytes()
+        y16 = gpu_decompress_tensor(lib, o_rle, o_scale, n, 0, False)
+        assert_same_float_bits(y16, oracle.decompress_f32(o_rle, o_scale, 0).astype(np.float16), f"fp16 {n}")
+    # a tensor of one 2048-element block is the block codec's record, byte for byte
+    xb = rng.standard_normal(2048).astype(np.float16)
+    scales, lens, recs = gpu_compress(lib, xb[None, :], 2, 0)
+    scale, rle = gpu_compress_tensor(lib, xb, 0)
+    assert scale.tobytes() == scales[0].tobytes() and rle.tobytes() == recs[0, :lens[0]].tobytes()
+    # random byte streams (zero counts, long counts) through the tensor decoder
+    for n_pairs in (1, 100, 2048, 2049, 10000):
+        stream = rng.integers(0, 256, 2 * n_pairs + 1).astype(np.uint8)
+        counts = stream[1::2]
+        counts[rng.random(counts.size) < 0.2] = 0
+        want = oracle.decompress_f32(stream, 0.25, 0)
+        y = gpu_decompress_tensor(lib, stream, 0.25, want.size + 3, 0, True)
+        assert_same_float_bits(y, want, f"random stream {n_pairs}")
