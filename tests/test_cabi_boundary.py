@@ -359,3 +359,30 @@ def test_calls_from_many_threads(libpath):
     lib.finalize()
     assert not errors, errors[:3]
     assert len(set(handles)) == len(handles)
+
+
+def test_reference_callers_drive_the_product_library_unchanged():
+    """The drop-in proof, kept permanent (dev container only; skipped wherever /root/reference is absent, i.e. on the GPU
+    box): the reference's own speckv_ctypes.SpeckvLib and the class body of its vLLM shim, imported from where they lie,
+    run on the PRODUCT library on "/dev/null" and produce the F-cabi trace and every F-offset pointer the reference
+    library produces; then a seeded random walk over the 8 C-ABI functions, product against the compiled reference
+    (oracle/_ref/libspeckv_ref.so), call for call.  tests/golden/dropin_check.py holds the driver."""
+    import importlib.util
+    path = os.path.join(ROOT, "tests", "golden", "dropin_check.py")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/dropin_check.py does not travel to the GPU box")
+    spec = importlib.util.spec_from_file_location("dropin_check", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not mod.available():
+        pytest.skip("needs /root/reference, oracle/_ref/libspeckv_ref.so and the built product library")
+    rep = mod.run(ops_per_seed=3000, seeds=3)
+    assert rep["cabi_product"] == rep["cabi_reference"] and len(rep["cabi_product"]) >= 35
+    assert rep["shim_product"] == rep["shim_reference"] and len(rep["shim_product"]) >= 250
+    # SURVEY Appendix A pointers, spelled out (cfg1, 8B@4k, 70B@8k; req_id 1 overflows the single-request allocation)
+    by_key = {(r[0],) + tuple(r[1:6]): r for r in rep["shim_product"]}
+    assert by_key[(1, 0, 0, 7, 127, 1)][8] == 0x400017ff00
+    assert by_key[(2, 0, 31, 7, 4095, 1)][8] == 0x40201fff00
+    assert by_key[(3, 0, 79, 7, 8191, 1)][8] == 0x40a02fff00
+    assert by_key[(1, 1, 0, 0, 0, 0)][7] == -1
+    assert rep["fuzz_ops"] == 9000 and rep["fuzz_diffs"] == [], rep["fuzz_diffs"][:5]
