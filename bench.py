@@ -415,6 +415,7 @@ def main():
         x = run_xgmi_children(args, torch, dist, rank, world, red_dev)
         if rank == 0 and out is not None:
             out["xgmi"] = x
+            out["roofline_xgmi"] = roofline_xgmi_from(x, world)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # rank 0 at N=1 only (bench contract)
         state["phase"] = "cpu_baseline"
         try:
@@ -534,13 +535,28 @@ def pool_devices_for(mode, rank, world):
     raise ValueError(mode)
 
 
+MALL_BYTES = 256 << 20           # Infinity Cache per GPU (MI355X_MICROARCH.md): SURVEY 8(d) wants the remote set >= 10x this per pool GPU
+
+
+def xgmi_sets_for(n_pool_gpus, set_bytes, single_gpu_test):
+    """How many copies of the 8B-shaped set (one allocation each) the remote working set holds, so that every pool GPU
+    keeps at least 10 x MALL of records.  SPECKV_XGMI_SETS overrides; the one-GPU dry run keeps 2."""
+    env = os.environ.get("SPECKV_XGMI_SETS")
+    if env:
+        return max(1, int(env))
+    if single_gpu_test:
+        return 2
+    return max(1, -(-21 * MALL_BYTES * n_pool_gpus // (2 * max(set_bytes, 1))))      # 10.5x: records are a little smaller than their 4 KiB pages
+
+
 def xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream, red_dev="cuda", single_gpu_test=False, state=None):
     """Remote fetch over xGMI in the three shapes of pool_devices_for(), each with both fetch engines: the fused
     peer-load + decompress kernel (engine 1) and the copy engines (engine 2: one hipMemcpyPeerAsync per pool GPU and
-    chunk on per-peer streams into local staging, local decompress), plus a raw peer-copy calibration of the same
-    links.  Inbound GB/s is per compute GPU; fractions are given against the nominal link figure under BOTH readings
-    of it (153.6 GB/s per link counted per direction, or as the sum of both directions = 76.8 inbound) and against
-    the raw copy measured here."""
+    chunk on per-peer streams into local staging, local decompress), a speculative-prefetch leg (BASELINE configs[2]
+    verbatim: look-ahead depth 4 per (sequence, layer), device-side flush, pages fetched into the L2 ring over the
+    link), plus a raw peer-copy calibration of the same links.  Inbound GB/s is per compute GPU; fractions are given
+    against the nominal link figure under BOTH readings of it (153.6 GB/s per link counted per direction, or as the
+    sum of both directions = 76.8 inbound) and against the raw copy measured here."""
     def all_ok(flag):
         t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -557,7 +573,9 @@ def xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream
     result = {"link_nominal_GBps": XGMI_LINK_GBPS,
               "accounting": "frac_nominal_per_direction = inbound / (links x 153.6); frac_nominal_bidirectional = inbound / "
                             "(links x 76.8) if 153.6 is the sum of both directions; frac_of_raw_copy = inbound / the raw "
-                            "hipMemcpy rate measured on the same links in the same phase"}
+                            "hipMemcpy rate measured on the same links in the same phase.  inbound = record bytes (what the "
+                            "decoder needs) per second; the copy engines move whole record SLOTS: their actual link bytes are "
+                            "reported beside it (copy_engine_link_bytes_per_pass, link_GBps_actual)"}
     for mode in XGMI_MODES:
         if state is not None:
             state["phase"] = f"xgmi:{mode}"
@@ -566,8 +584,10 @@ def xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream
             continue
         pools = pool_devices_for(mode, rank, world)
         active = pools is not None
-        info = {"compute_ranks": world if mode == "symmetric" else 1, "pool_gpus_per_compute_gpu": len(pool_devices_for(mode, 0, world))}
-        kv2, err, rec_bytes, handle = None, None, 0, None
+        links = len(pool_devices_for(mode, 0, world))
+        info = {"compute_ranks": world if mode == "symmetric" else 1, "pool_gpus_per_compute_gpu": links, "links": links}
+        kv2, err, rec_bytes, handles = None, None, 0, []
+        n_sets = xgmi_sets_for(links, n_blocks * PAGE, single_gpu_test)
         try:
             if active:
                 dev_list = [0] * len(pools) if single_gpu_test else pools
@@ -578,8 +598,12 @@ def xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream
                 lib = kv2.lib
                 lib.set_compression_scheme(args.scheme)
                 lib.set_quant_mode(args.quant)
-                handle = kv2.allocate(args.tokens, args.layers, 8, 128, 2)
-                lib.write(handle, 0, src.data_ptr(), src.numel() * 2, on_device=True)   # compress straight into peer HBM
+                # the remote working set: n_sets allocations of the 8B-shaped set (same synthetic KV in each: bytes are what
+                # count), sized so that every pool GPU holds >= 10 x its Infinity Cache
+                for i in range(n_sets):
+                    h = kv2.allocate(args.tokens, args.layers, 8, 128, 2)
+                    lib.write(h, 0, src.data_ptr(), src.numel() * 2, on_device=True)   # compress straight into peer HBM
+                    handles.append(h)
                 rec_bytes = lib.stats().compressed_bytes
         except Exception as e:
             err = repr(e)
@@ -591,7 +615,12 @@ def xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream
             info["skipped"] = err or "another rank could not open its peer pool"
             result[mode] = info
             continue
-        links = len(pool_devices_for(mode, 0, world))
+        per_pool = max_over_ranks(rec_bytes) / max(links, 1)
+        info["working_set"] = {"allocations": n_sets, "record_bytes_per_compute_gpu": int(max_over_ranks(rec_bytes)),
+                               "record_MiB_per_pool_gpu": round(per_pool / 2**20, 1), "x_infinity_cache": round(per_pool / MALL_BYTES, 2),
+                               "meets_10x_infinity_cache": bool(per_pool >= 10 * MALL_BYTES),
+                               "note": "SURVEY 8(d): the remote set should exceed the pool GPU's 256 MiB Infinity Cache by >= 10x"
+                                       + ("; the one-GPU dry run keeps it small on purpose" if single_gpu_test else "")}
         # raw calibration: one large device-to-device copy from EVERY pool GPU of this rank at once, each on its own stream
         raw, raw_err = None, None
         try:
@@ -622,12 +651,22 @@ def xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream
         if not ok:
             info["raw_copy_skipped"] = raw_err or "failed on another rank"
         all_ok(True)
+        rawm = max_over_ranks(raw or 0.0)
+
+        def rates(gbps):
+            e = {"frac_nominal_per_direction": round(gbps / (XGMI_LINK_GBPS * links), 4),
+                 "frac_nominal_bidirectional": round(gbps / (XGMI_LINK_GBPS / 2 * links), 4)}
+            if rawm > 0:
+                e["frac_of_raw_copy"] = round(gbps / rawm, 4)
+            return e
+
         for engine, ename in ((1, "fused_peer_load_kernel"), (2, "copy_engines_then_local_decompress")):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             eerr = None
 
             def fetch():
-                lib.fetch_range(handle, 0, n_blocks, dst.data_ptr(), False, sp, engine=engine)
+                for h in handles:                       # one pass = every allocation of the working set
+                    lib.fetch_range(h, 0, n_blocks, dst.data_ptr(), False, sp, engine=engine)
 
             def tstep(i):
                 if not active:
@@ -637,10 +676,12 @@ def xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream
                 fetch()
                 if i == steps - 1:
                     ev1.record(stream)
+            ce0 = 0
             try:
                 if active:
                     fetch(); torch.cuda.synchronize()
                     ramp(fetch, torch.cuda.synchronize, min(args.ramp_ms, 30.0))
+                    ce0 = lib.stats().copy_engine_bytes
             except Exception as e:
                 eerr = repr(e)
             if not all_ok(eerr is None):
@@ -653,18 +694,67 @@ def xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream
             rb = max_over_ranks(rec_bytes)
             gbps = rb / (ms * 1e-3) / 1e9
             e = {"inbound_GBps_per_compute_gpu": round(gbps, 1), "ms_per_pass": round(ms, 4),
-                 "blocks_per_s_whole_job": round(info["compute_ranks"] * n_blocks * steps / elapsed, 1),
-                 "link_bytes_per_pass": int(rb),
-                 "frac_nominal_per_direction": round(gbps / (XGMI_LINK_GBPS * links), 4),
-                 "frac_nominal_bidirectional": round(gbps / (XGMI_LINK_GBPS / 2 * links), 4)}
-            rawm = max_over_ranks(raw or 0.0)
-            if rawm > 0:
-                e["frac_of_raw_copy"] = round(gbps / rawm, 4)
+                 "blocks_per_s_whole_job": round(info["compute_ranks"] * n_blocks * len(handles or [0] * n_sets) * steps / elapsed, 1),
+                 "link_bytes_per_pass": int(rb)}
+            e.update(rates(gbps))
+            if engine == 2:
+                # what the copy engines really moved (whole record slots, speckv_ext_stats.copy_engine_bytes); warm-up pass included in the count
+                moved = max_over_ranks((lib.stats().copy_engine_bytes - ce0) / (steps + 1) if active else 0.0)
+                e["copy_engine_link_bytes_per_pass"] = int(moved)
+                e["link_GBps_actual"] = round(moved / (ms * 1e-3) / 1e9, 1)
+                e["slot_overhead"] = round(moved / rb, 4) if rb else None
             info[ename] = e
-        rawm = max_over_ranks(raw or 0.0)
         if rawm > 0:
             info["raw_peer_copy_GBps"] = round(rawm, 1)
             info["raw_copy_note"] = f"{links} concurrent 128 MiB device-to-device copies, one per pool GPU, into the compute GPU"
+        # BASELINE configs[2] verbatim: speculative prefetch, look-ahead depth 4 per (sequence, layer), over the link.  One
+        # decode step = one request per layer of every allocation of the working set; the device-side flush resolves them,
+        # dedupes, assigns ring slots and fetches the pages (fused peer-load + decompress, list form) into the L2 ring.
+        pf, pferr = None, None
+        try:
+            if active:
+                L_ = args.layers
+                reqs = np.repeat(np.arange(len(handles), dtype=np.uint32), L_)
+                layers = np.tile(np.arange(L_, dtype=np.uint16), len(handles))
+                depth = np.full(reqs.size, 4, np.uint32)
+                for i, h in enumerate(handles):
+                    lib.bind_request(i, h, 0)
+                n_steps = 64
+                stride_pos = max(8, (args.tokens - 16) // n_steps // 2 * 2)       # fresh pages every step
+
+                def decode_step(j, count):
+                    pos = np.full(reqs.size, (j * stride_pos) % (args.tokens - 8), np.uint32)
+                    lib.prefetch_batch(reqs, layers, pos, depth)
+                    return lib.prefetch_flush(want_count=count)
+                pages0 = decode_step(0, True); lib.sync()
+                # latency: submit -> every page of the step landed
+                lat, pages = [], 0
+                for j in range(1, 17):
+                    t0 = time.perf_counter()
+                    pages += decode_step(j, True)
+                    lib.sync()
+                    lat.append(time.perf_counter() - t0)
+                # throughput: the steps submitted back to back (the queue of flushes the engine keeps in flight)
+                torch.cuda.synchronize()
+                st0 = lib.stats().total_prefetches
+                t0 = time.perf_counter()
+                for j in range(17, 17 + n_steps - 17):
+                    decode_step(j, False)
+                lib.sync()
+                dt = time.perf_counter() - t0
+                moved_pages = lib.stats().total_prefetches - st0
+                page_rec = rec_bytes / max(n_blocks * len(handles), 1)
+                gb = moved_pages * page_rec / dt / 1e9
+                pf = {"depth_k": 4, "requests_per_step": int(reqs.size), "pages_per_step": round(pages / 16, 1), "first_step_pages": int(pages0),
+                      "ms_submit_to_landed": round(float(np.median(lat)) * 1e3, 4),
+                      "pipelined": {"steps": n_steps - 17, "pages": int(moved_pages), "ms_per_step": round(dt / max(n_steps - 17, 1) * 1e3, 4),
+                                    "inbound_GBps_per_compute_gpu": round(gb, 2), **rates(gb)},
+                      "note": "speckv_ext_prefetch_batch + device-side flush; pages decoded into the compute GPU's L2 ring"}
+        except Exception as e:
+            pferr = repr(e)
+        all_ok(True)
+        if rank == 0:
+            info["speculative_prefetch_depth4"] = pf if pf is not None else {"skipped": pferr or "rank 0 idle"}
         # the uncompressed variant (fp16 pages: 4096 B per block over the link), fused kernel
         f16 = None
         ferr = None
@@ -714,6 +804,38 @@ def xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream
         except Exception as e:
             result["rccl_allgather"] = {"skipped": repr(e)}
     return result
+
+
+def roofline_xgmi_from(x, world):
+    """The remote-fetch roofline of the rank-0 line: BASELINE.json's "achieved xGMI GB/s vs roofline" -- the 1 + (N-1) pool
+    layout (cfg4; cfg3 at N = 2), best of the two fetch engines, with the link count and BOTH accountings of the nominal
+    figure, the raw-copy ratio and the speculative-prefetch leg.  None when the phase produced nothing usable."""
+    if not isinstance(x, dict):
+        return None
+    mode = "cfg4" if isinstance(x.get("cfg4"), dict) and "same_as" not in x["cfg4"] else "cfg3"
+    m = x.get(mode)
+    if not isinstance(m, dict):
+        return None
+    best, best_name = None, None
+    for name in ("fused_peer_load_kernel", "copy_engines_then_local_decompress"):
+        e = m.get(name)
+        if isinstance(e, dict) and "inbound_GBps_per_compute_gpu" in e and (best is None or e["inbound_GBps_per_compute_gpu"] > best["inbound_GBps_per_compute_gpu"]):
+            best, best_name = e, name
+    if best is None:
+        return {"bound": "xgmi", "layout": mode, "skipped": m.get("skipped") or "no engine produced a figure"}
+    links = m.get("links", m.get("pool_gpus_per_compute_gpu"))
+    out = {"bound": "xgmi", "layout": f"{mode}: 1 compute GPU + {links} pool GPU(s)", "engine": best_name, "links": links,
+           "achieved": best["inbound_GBps_per_compute_gpu"], "unit": "GB/s",
+           "peak_nominal_per_direction": round(XGMI_LINK_GBPS * links, 1), "frac": best.get("frac_nominal_per_direction"),
+           "peak_nominal_bidirectional": round(XGMI_LINK_GBPS / 2 * links, 1), "frac_bidirectional_reading": best.get("frac_nominal_bidirectional"),
+           "raw_peer_copy_GBps": m.get("raw_peer_copy_GBps"), "frac_of_raw_copy": best.get("frac_of_raw_copy"),
+           "link_bytes_per_pass": best.get("link_bytes_per_pass"), "copy_engine_link_bytes_per_pass": (m.get("copy_engines_then_local_decompress") or {}).get("copy_engine_link_bytes_per_pass"),
+           "working_set": m.get("working_set"), "speculative_prefetch_depth4": m.get("speculative_prefetch_depth4"),
+           "engines": {n: (m.get(n) or {}).get("inbound_GBps_per_compute_gpu") for n in ("fused_peer_load_kernel", "copy_engines_then_local_decompress")},
+           "note": "frac = achieved / (links x 153.6 GB/s); north_star target >= 0.60 at 8 GPUs"}
+    if world > 1 and os.environ.get("SPECKV_BENCH_SINGLE_GPU_TEST") == "1":
+        out["note"] += "; ONE-GPU DRY RUN: every 'peer' is the same GPU, no link was crossed -- control flow only"
+    return out
 
 
 def fp8_scores_extra(torch, kv, T, Lyr):

@@ -338,8 +338,17 @@ __global__ __launch_bounds__(256) void k_build_scale_tab(const PageEntry* __rest
     tab[p - j + attend_tile_slot(j)] = e.rec_bytes >= kBlockElems ? e.scale : 0.0f;
 }
 
+// STRIPED: the same loop for an allocation striped regularly over several pools (AttendArgs::stripe_bases): the six record
+// addresses a lane needs per tile (2 K pages, 4 V pages) are recomputed from the page number -- one multiply-high, one
+// LDS read of the run base, one 64-bit multiply-add each -- instead of advancing one pointer.  Single-sequence form only.
+template <bool STRIPED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_attend_fp8_linear(AttendArgs a)
 {
+    __shared__ uint64_t s_bases[8];
+    if (STRIPED) {
+        if (threadIdx.x < 8u) s_bases[threadIdx.x] = a.stripe_bases[threadIdx.x];
+        __syncthreads();
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t c = lane & 15u, kb = lane >> 4;
@@ -412,24 +421,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     if (t0 < t1) {                                                       // wave-uniform
         // running pointers of the tile being requested
-        const uint8_t* kp = a.lin_base + (a.k_first + layer * a.layer_stride) * 2048ull + head * 128u + kb * 16u
-                            + (static_cast<uint64_t>(t0) * 32u + c) * 1024u;            // block b: + b*16 KiB; second half of the row: + 64
-        const uint8_t* vp = a.lin_base + (a.v_first + layer * a.layer_stride) * 2048ull + head * 128u + 8u * c
-                            + (static_cast<uint64_t>(t0) * 32u + 4u * kb) * 1024u;       // slot j: + (j&3) KiB + (j>>2)*16 KiB
+        const uint8_t* kp = nullptr;
+        const uint8_t* vp = nullptr;
+        if (!STRIPED) {
+            kp = a.lin_base + (a.k_first + layer * a.layer_stride) * 2048ull + head * 128u + kb * 16u
+                 + (static_cast<uint64_t>(t0) * 32u + c) * 1024u;            // block b: + b*16 KiB; second half of the row: + 64
+            vp = a.lin_base + (a.v_first + layer * a.layer_stride) * 2048ull + head * 128u + 8u * c
+                 + (static_cast<uint64_t>(t0) * 32u + 4u * kb) * 1024u;       // slot j: + (j&3) KiB + (j>>2)*16 KiB
+        }
         const float* kt = a.scale_tab + (a.k_first + layer * a.layer_stride + static_cast<uint64_t>(t0) * 16u) + 4u * kb;
         const float* vt = a.scale_tab + (a.v_first + layer * a.layer_stride + static_cast<uint64_t>(t0) * 16u) + 4u * kb;
+        // striped form: first page of the lane's K rows / V slots in tile 0 of the region, and the offsets inside a record
+        const uint32_t kpage0 = static_cast<uint32_t>(a.k_first + layer * a.layer_stride) + (c >> 1);        // block b: + 8b
+        const uint32_t vpage0 = static_cast<uint32_t>(a.v_first + layer * a.layer_stride) + 2u * kb;         // slot pair jj: + (jj & 1) + 8 (jj >> 1)
+        const uint32_t koff = (c & 1u) * 1024u + head * 128u + kb * 16u, voff = head * 128u + 8u * c;
+        uint32_t tile_k = t0, tile_v = t0;                                   // tile the next request is for
+        auto rec = [&](uint32_t page) { return attend_stripe_rec(s_bases, page, a.stripe_n, a.stripe_magic, 2048u); };
 
         uint4 kx[2][2];
         uint2 vx[8];
         f32x4 ks4, vs4;
         auto issue_k = [&]() {
 #pragma unroll
-            for (int b = 0; b < 2; ++b) { kx[b][0] = ldg16(kp + 16384 * b); kx[b][1] = ldg16(kp + 16384 * b + 64); }
+            for (int b = 0; b < 2; ++b) {
+                const uint8_t* src = STRIPED ? rec(kpage0 + tile_k * 16u + 8u * b) + koff : kp + 16384 * b;
+                kx[b][0] = ldg16(src); kx[b][1] = ldg16(src + 64);
+            }
             ks4 = *reinterpret_cast<const f32x4*>(kt);
         };
         auto issue_v = [&]() {
+            if (STRIPED) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) vx[j] = ldg8(vp + 1024 * (j & 3) + 16384 * (j >> 2));
+                for (int jj = 0; jj < 4; ++jj) {
+                    const uint8_t* src = rec(vpage0 + tile_v * 16u + (jj & 1) + 8u * (jj >> 1)) + voff;
+                    vx[(jj & 1) * 2 + (jj >> 1) * 4] = ldg8(src);               // slot j = 2 (jj & 1) + 4 (jj >> 1): position slot 0 of the page
+                    vx[(jj & 1) * 2 + (jj >> 1) * 4 + 1] = ldg8(src + 1024);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vx[j] = ldg8(vp + 1024 * (j & 3) + 16384 * (j >> 2));
+            }
             vs4 = *reinterpret_cast<const f32x4*>(vt);
         };
         // same request order as in the loop (K before V), pinned, so that the wait at the loop head is
@@ -467,7 +498,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            kp += step * 32768u; kt += step * 16u;
+            kp += step * 32768u; kt += step * 16u; tile_k += step;
             issue_k();
             __builtin_amdgcn_sched_barrier(0);
             // ---- online softmax of query row c
@@ -516,7 +547,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t] * fa, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            vp += step * 32768u; vt += step * 16u;
+            vp += step * 32768u; vt += step * 16u; tile_v += step;
             issue_v();
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1048,7 +1079,7 @@ hipError_t launch_attend_fp8_batch(const AttendArgs& a, uint32_t n_seq, float* d
     static const int forced = [] { const char* e = getenv("SPECKV_FP8_BATCH_KERNEL"); return e ? (e[0] == 'd' ? 1 : 2) : 0; }();
     const bool dma = forced ? forced == 1 : false;
     if (dma) hipLaunchKernelGGL(k_attend_fp8_dma, dim3(a.n_splits, n_seq * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
-    else     hipLaunchKernelGGL(k_attend_fp8_linear, dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
+    else     hipLaunchKernelGGL(k_attend_fp8_linear<false>, dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || (a.direct_out && a.direct_per_seq != 1u)) return e;      // every row final: no merge
     return launch_attend_combine(a, n_seq, d_out, d_lse, s);
@@ -1073,10 +1104,12 @@ hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_ou
     if (a.lin_base && (a.n_splits == 1u || n_layers * (a.heads / 4u) < 128u))
         hipLaunchKernelGGL(k_attend_fp8_dma, dim3(a.n_splits, n_layers * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
     else if (a.lin_base)
-        hipLaunchKernelGGL(k_attend_fp8_linear, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_attend_fp8_linear<false>, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
+    else if (a.stripe_bases)
+        hipLaunchKernelGGL(k_attend_fp8_linear<true>, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
     else            hipLaunchKernelGGL(k_attend_fp8, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || (a.direct_out && a.lin_base)) return e;      // (the page-table form always writes partials)
+    if (e != hipSuccess || (a.direct_out && (a.lin_base || a.stripe_bases))) return e;      // (the page-table form always writes partials)
     return launch_attend_combine(a, n_layers, d_out, d_lse, s);
 }
 

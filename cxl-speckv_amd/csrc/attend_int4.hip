@@ -445,6 +445,14 @@ __device__ __forceinline__ void dma16(uint32_t lds_dst, const uint8_t* base, uin
                  : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(base) : "memory");
 }
 
+// the same with a full 64-bit address per lane (striped form: a lane's rows may sit in any pool's run)
+__device__ __forceinline__ void dma16v(uint32_t lds_dst, const uint8_t* addr)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(addr) : "memory");
+}
+
 // this wave's 5 DMAs of the current tile have landed (the 5 of the next tile may still be in flight); then everybody's
 __device__ __forceinline__ void wg_landed(bool is_last)
 {
@@ -477,10 +485,19 @@ __device__ __forceinline__ void wg_take_v(const uint32_t (&rd)[4], uint32_t rs, 
 #ifndef SPECKV_INT4_WG_WAVES
 #define SPECKV_INT4_WG_WAVES 3
 #endif
+// STRIPED: the allocation is striped regularly over several pools (AttendArgs::stripe_bases): the five DMA addresses of a
+// wave and tile are computed per lane from the page number (multiply-high, LDS read of the run base, 64-bit multiply-add)
+// and the DMAs take a full address per lane.  Single-sequence form only.
+template <bool STRIPED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4_WG_WAVES, SPECKV_INT4_WG_WAVES))) void k_attend_int4_wg(AttendArgs a)
 {
     static_assert(kWgHeads == 4, "the cooperative kernel is laid out for 4 heads per workgroup");
     __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kWgBuf];
+    __shared__ uint64_t s_bases[8];
+    if (STRIPED) {
+        if (threadIdx.x < 8u) s_bases[threadIdx.x] = a.stripe_bases[threadIdx.x];
+        __syncthreads();
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t c = lane & 15u, kb = lane >> 4;
@@ -531,27 +548,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
 
     if (t0 < t1) {                                                       // workgroup-uniform
         const uint32_t tile_bytes = 16u * kInt4RecBytes;
-        const uint8_t* kreg = a.lin_base + (a.k_first + layer * a.layer_stride) * kInt4RecBytes;      // tile tt: + tt * tile_bytes
-        const uint8_t* vreg = a.lin_base + (a.v_first + layer * a.layer_stride) * kInt4RecBytes;
+        const uint8_t* kreg = nullptr;
+        const uint8_t* vreg = nullptr;
+        if (!STRIPED) {
+            kreg = a.lin_base + (a.k_first + layer * a.layer_stride) * kInt4RecBytes;      // tile tt: + tt * tile_bytes
+            vreg = a.lin_base + (a.v_first + layer * a.layer_stride) * kInt4RecBytes;
+        }
         // ---- this wave's share of the fetch: rows 8w .. 8w+7 of K and of V (two instructions of 4 rows each), and the
         // scale lines of 8 pages of K (waves 0, 1) or V (waves 2, 3)
-        auto row_src = [&](uint32_t r, uint32_t piece) { return (r >> 1) * kInt4RecBytes + 128u + ((r & 1u) * 8u + head0) * 64u + piece * 16u; };
+        auto row_in = [&](uint32_t r, uint32_t piece) { return 128u + ((r & 1u) * 8u + head0) * 64u + piece * 16u; };   // offset inside the record
         const uint32_t r0 = 8u * wave + (lane >> 4), r1 = r0 + 4u;
-        const uint32_t gr0 = row_src(r0, (lane & 15u) ^ (r0 & 15u)), gr1 = row_src(r1, (lane & 15u) ^ (r1 & 15u));
+        const uint32_t in0 = row_in(r0, (lane & 15u) ^ (r0 & 15u)), in1 = row_in(r1, (lane & 15u) ^ (r1 & 15u));
+        const uint32_t gr0 = (r0 >> 1) * kInt4RecBytes + in0, gr1 = (r1 >> 1) * kInt4RecBytes + in1;
         const uint32_t spage = 8u * (wave & 1u) + (lane >> 3);
-        const uint32_t gs = spage * kInt4RecBytes + (((lane & 7u) ^ ((wave < 2u) ? (spage & 7u) : 0u)) * 16u);
+        const uint32_t sin = ((lane & 7u) ^ ((wave < 2u) ? (spage & 7u) : 0u)) * 16u;
+        const uint32_t gs = spage * kInt4RecBytes + sin;
         const uint32_t lbase = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&lds[0])));
         const uint32_t dr0 = 8u * wave * 256u, ds_ = ((wave < 2u) ? kWgKs : kWgVs) + (wave & 1u) * 1024u;   // destinations inside a buffer
         const uint8_t* sreg = (wave < 2u) ? kreg : vreg;
         const uint32_t last = t1 - 1u;
+        // striped form: first page of the K / V region of this layer; the lane's pages of tile tt are + 16 tt + ...
+        const uint32_t kpage0 = static_cast<uint32_t>(a.k_first + layer * a.layer_stride), vpage0 = static_cast<uint32_t>(a.v_first + layer * a.layer_stride);
+        const uint32_t spage0 = ((wave < 2u) ? kpage0 : vpage0) + spage;
+        auto rec = [&](uint32_t page) { return attend_stripe_rec(s_bases, page, a.stripe_n, a.stripe_magic, kInt4RecBytes); };
         auto issue = [&](uint32_t tt, uint32_t buf) {
-            const uint64_t to = static_cast<uint64_t>(tt) * tile_bytes;
             const uint32_t dst = lbase + buf * kWgBuf;
-            dma16(dst + dr0, kreg + to, gr0);
-            dma16(dst + dr0 + 1024u, kreg + to, gr1);
-            dma16(dst + kWgV + dr0, vreg + to, gr0);
-            dma16(dst + kWgV + dr0 + 1024u, vreg + to, gr1);
-            dma16(dst + ds_, sreg + to, gs);
+            if (STRIPED) {
+                const uint32_t pg = tt * 16u + (r0 >> 1);                 // rows r0 and r0 + 4: pages pg and pg + 2
+                dma16v(dst + dr0, rec(kpage0 + pg) + in0);
+                dma16v(dst + dr0 + 1024u, rec(kpage0 + pg + 2u) + in1);
+                dma16v(dst + kWgV + dr0, rec(vpage0 + pg) + in0);
+                dma16v(dst + kWgV + dr0 + 1024u, rec(vpage0 + pg + 2u) + in1);
+                dma16v(dst + ds_, rec(spage0 + tt * 16u) + sin);
+            } else {
+                const uint64_t to = static_cast<uint64_t>(tt) * tile_bytes;
+                dma16(dst + dr0, kreg + to, gr0);
+                dma16(dst + dr0 + 1024u, kreg + to, gr1);
+                dma16(dst + kWgV + dr0, vreg + to, gr0);
+                dma16(dst + kWgV + dr0 + 1024u, vreg + to, gr1);
+                dma16(dst + ds_, sreg + to, gs);
+            }
         };
         // ---- reader addresses inside buffer 0
         const uint32_t rdk = lbase + c * 256u + (((wave * 4u + kb) ^ c) * 16u);                       // row 16 b + c: + 4096 b
@@ -608,8 +644,9 @@ hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_
 #ifdef SPECKV_INT4_REGSTAGE
     if (a.lin_base) hipLaunchKernelGGL(k_attend_int4<true>, dim3(a.n_splits, n_layers * (a.heads / kWgHeads)), dim3(64 * kWgHeads), 0, s, a);
 #else
-    if (a.lin_base) hipLaunchKernelGGL(k_attend_int4_wg, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
+    if (a.lin_base) hipLaunchKernelGGL(k_attend_int4_wg<false>, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
 #endif
+    else if (a.stripe_bases) hipLaunchKernelGGL(k_attend_int4_wg<true>, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
     else            hipLaunchKernelGGL(k_attend_int4<false>, dim3(a.n_splits, n_layers * (a.heads / kWgHeads)), dim3(64 * kWgHeads), 0, s, a);
     return hipGetLastError();
 }

@@ -442,19 +442,34 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
                 memset(a->slot, 0xFF, a->n_pages * sizeof(uint32_t));
             }
             if (ok) {
-                if (single_run) {
+                if (single_run)
                     ok = launch_init_entries(a->d_entries, a->n_pages, reinterpret_cast<uint64_t>(a->extents[0].base),
                                              a->rec_stride, stream_) == hipSuccess;
-                    // FP8 / INT4 pools start as zero bytes (= records of zeros), which lets the fused attention address
-                    // them arithmetically without a validity test per page
-                    if (ok && (a->scheme == SPECKV_COMP_FP8_E4M3 || a->scheme == SPECKV_COMP_INT4_G32) &&
-                        pools_[a->extents[0].pool]->device() == device_) {
-                        ok = hipMemsetAsync(a->extents[0].base, 0, a->extents[0].bytes, stream_) == hipSuccess;
-                        if (ok) a->linear_base = static_cast<uint8_t*>(a->extents[0].base);
+                else
+                    ok = hipMemcpy(a->d_entries, host.data(), host.size() * sizeof(PageEntry), hipMemcpyHostToDevice) == hipSuccess;
+            }
+            // FP8 / INT4 pools start as zero bytes (= records of zeros), which lets the fused attention address them
+            // arithmetically without a validity test per page: one run (linear form) or the regular striping over up to 8
+            // pools (striped form).  Each run is cleared on the GPU that holds it.
+            const bool fixed_fmt = a->scheme == SPECKV_COMP_FP8_E4M3 || a->scheme == SPECKV_COMP_INT4_G32;
+            if (ok && fixed_fmt && regular && D <= 8 && a->n_pages < (1ull << 28)) {
+                for (const auto& ex : a->extents) {
+                    if (!ex.base || !ok) continue;
+                    if (pools_[ex.pool]->device() == device_) {
+                        ok = hipMemsetAsync(ex.base, 0, ex.bytes, stream_) == hipSuccess;
+                    } else {
+                        DeviceScope owner(pools_[ex.pool]->device());
+                        ok = hipMemset(ex.base, 0, ex.bytes) == hipSuccess;
                     }
                 }
-                else {
-                    ok = hipMemcpy(a->d_entries, host.data(), host.size() * sizeof(PageEntry), hipMemcpyHostToDevice) == hipSuccess;
+                if (ok && single_run) {
+                    a->linear_base = static_cast<uint8_t*>(a->extents[0].base);
+                } else if (ok && D >= 2) {
+                    uint64_t bases[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (uint32_t k = 0; k < D; ++k) bases[k] = reinterpret_cast<uint64_t>(a->extents[k].base);   // extents[k] = the run of residue k
+                    ok = hipMalloc(reinterpret_cast<void**>(&a->d_stripe), sizeof(bases)) == hipSuccess &&
+                         hipMemcpy(a->d_stripe, bases, sizeof(bases), hipMemcpyHostToDevice) == hipSuccess;
+                    if (ok) a->stripe_n = D;
                 }
             }
             a->regular = regular;
@@ -518,6 +533,7 @@ void Engine::release_allocation(Allocation* a)
     if (a->d_entries) (void)hipFree(a->d_entries);
     if (a->d_flags) (void)hipFree(a->d_flags);            // flags, slots and stamps are one block
     if (a->d_scale_tab) { (void)hipFree(a->d_scale_tab); a->d_scale_tab = nullptr; }
+    if (a->d_stripe) { (void)hipFree(a->d_stripe); a->d_stripe = nullptr; a->stripe_n = 0; }
     if (a->pinned) { (void)hipHostFree(a->pinned); a->pinned = nullptr; }
     a->d_entries = nullptr;
     a->d_flags = a->d_slot = a->d_stamp = nullptr;
@@ -2139,6 +2155,8 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     const bool fits = pos_begin % 32u == 0u && a->d_scale_tab &&
                       static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
     const uint8_t* lin_base = (getenv("SPECKV_ATTEND_GENERAL") || !fits) ? nullptr : a->linear_base;
+    // regular striping over several pools: the same kernel with computed record addresses (no page-table chase)
+    const bool striped = !lin_base && fits && a->stripe_n && !getenv("SPECKV_ATTEND_GENERAL");
     // (the page-table form has nothing to gain from whole rows: it hides its look-ups behind other waves and always
     // goes through the merge -- 80 layers x 8k: one split 0.13 of HBM peak, eight 0.18+)
     uint32_t want = (lin_base && rows / 4u >= 128u && n_tiles < 768u) ? 1u : (5120u + rows - 1u) / rows;     // (32k and beyond: 8 splits, below)
@@ -2171,11 +2189,16 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     k.scale_tab = a->d_scale_tab;
     k.q16 = static_cast<const uint16_t*>(d_q_f16);
     k.lin_base = lin_base;
+    if (striped) {
+        k.stripe_bases = a->d_stripe;
+        k.stripe_n = a->stripe_n;
+        k.stripe_magic = static_cast<uint32_t>((1ull << 32) / a->stripe_n + 1u);
+    }
     k.part_acc = reinterpret_cast<float*>(buf + q_bytes + qs_bytes);
     k.part_ml = reinterpret_cast<float*>(buf + q_bytes + qs_bytes + acc_bytes);
-    if (!k.lin_base)                     // the linear form quantises the query in its own prologue
+    if (!k.lin_base && !striped)         // the linear / striped forms quantise the query in their own prologue
         HIP_TRY(launch_quantize_q_e4m3(d_q_f16, rows, g, L.head_dim, buf, reinterpret_cast<float*>(buf + q_bytes), st));
-    if (n_splits == 1u) { k.direct_out = d_out; k.direct_lse = d_lse; }      // no merge launch (linear form)
+    if (n_splits == 1u) { k.direct_out = d_out; k.direct_lse = d_lse; }      // no merge launch (linear / striped form)
     HIP_TRY(launch_attend_fp8(k, n_layers, d_out, d_lse, st));
     note_use(a, s);
     if (!s) RC_TRY(wait_stream());
@@ -2504,6 +2527,7 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     // page-table form of the same kernel
     const bool fits = static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
     const bool linear = a->linear_base && fits && !getenv("SPECKV_ATTEND_GENERAL");
+    const bool striped = !linear && a->stripe_n && fits && !getenv("SPECKV_ATTEND_GENERAL");
     if (!linear && !d_zero_page_) {
         if (is_capturing(s)) return SPECKV_ERR_INVAL;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
@@ -2539,6 +2563,11 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     k.q8 = static_cast<const uint8_t*>(d_q_f16);
     k.scale_log2e = sm_scale * 1.4426950408889634f;
     k.lin_base = linear ? a->linear_base : nullptr;
+    if (striped) {
+        k.stripe_bases = a->d_stripe;
+        k.stripe_n = a->stripe_n;
+        k.stripe_magic = static_cast<uint32_t>((1ull << 32) / a->stripe_n + 1u);
+    }
     k.zero_page = d_zero_page_;
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
@@ -2618,6 +2647,7 @@ int Engine::migrate(uint64_t handle, uint64_t first, uint64_t n, uint32_t target
     for (uint64_t i = 0; i < n; ++i) a->page_pool[first + i] = static_cast<uint8_t>(target_pool);
     a->linear_base = nullptr;                     // records no longer lie in one run
     a->regular = false;                           // nor in the striping order the copy engine relies on
+    a->stripe_n = 0;                              // (nor the fused attention's striped form; its table goes with the allocation)
     st_.pool_migrated_pages += n;
     return SPECKV_OK;
 }

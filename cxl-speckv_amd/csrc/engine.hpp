@@ -81,6 +81,11 @@ struct Allocation {
     // set while every record lies in ONE run of one local pool (record p at linear_base + p*rec_stride)
     // and, for the fixed-size formats, never-written records are zero bytes; cleared by a migration
     uint8_t* linear_base = nullptr;
+    // set while the placement is regular over 2..8 pools (and, for the fixed-size formats, never-written records are zero
+    // bytes): device array of the 8 run bases, record of page p = d_stripe[p % stripe_n] + (p / stripe_n) * rec_stride --
+    // the fused attention then computes addresses instead of chasing the page table; cleared by a migration
+    uint64_t* d_stripe = nullptr;
+    uint32_t stripe_n = 0;
     // FP8 allocations with a known layout: block scales in the fused attention's tile order (attend.hip), n_pages floats
     float* d_scale_tab = nullptr;
     uint32_t region_pages = 0;

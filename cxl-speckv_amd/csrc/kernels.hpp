@@ -253,7 +253,21 @@ struct AttendArgs {
     // positions are zeroed by the attention kernel itself (attend_zero_rows)
     uint32_t batch_layer;
     uint32_t direct_per_seq;
+    // striped form (lin_base == nullptr, stripe_bases != nullptr): the allocation still has the regular placement over
+    // 2..8 pools -- the record of page p is stripe_bases[p % stripe_n] + (p / stripe_n) * record stride (placement.hpp),
+    // never-written records zero bytes -- so every address is arithmetic here too; stripe_magic = floor(2^32 / n) + 1:
+    // __umulhi(p, magic) == p / n for every p < 2^28.  The 8 run bases live in a small device array of the allocation.
+    const uint64_t* stripe_bases;
+    uint32_t stripe_n, stripe_magic;
 };
+#if defined(__HIPCC__)
+// record address of page p in the striped form; `bases` = the allocation's run bases copied to LDS
+__device__ __forceinline__ const uint8_t* attend_stripe_rec(const uint64_t* bases, uint32_t p, uint32_t n, uint32_t magic, uint32_t stride)
+{
+    const uint32_t q = __umulhi(p, magic);
+    return reinterpret_cast<const uint8_t*>(bases[p - q * n]) + static_cast<uint64_t>(q) * stride;
+}
+#endif
 #if defined(__HIPCC__)
 // rows of a sequence without positions in a batch launch that has no merge behind it (one wave per kv head).
 // (Plain values, not the AttendArgs: a reference to the kernel's argument block makes the compiler keep it in memory,

@@ -278,3 +278,68 @@ def test_decode_loop_does_not_accumulate_flights_or_events(oracle):
         assert st.dma_completed == total
     finally:
         lib.finalize()
+
+
+@pytest.mark.parametrize("pools", ["0,0,0", "0,0,0,0,0,0,0"])
+@pytest.mark.parametrize("scheme", [3, 4])
+def test_fused_attention_over_a_regularly_striped_pool_computes_its_addresses(oracle, scheme, pools):
+    """an allocation striped `page % D` over several pools (every multi-GPU layout of configs[3] / [4])
+    used to take the page-table form of the fused attention.  While the placement is regular the record of page p is
+    base[p % D] + (p / D) * stride, and the fast kernels now compute exactly that: their result must be the oracle's (same
+    tolerance as the linear form), and identical to what the page-table form (SPECKV_ATTEND_GENERAL=1) and a one-pool
+    engine give up to split boundaries.  D = 3 and D = 7 (the 1 + 7 layout), ranges that start inside the region and end in
+    a ragged tile, several layers per launch; after a migration the placement is no longer regular and the page table
+    takes over again."""
+    torch = torch_mod()
+    from tests.test_gpu_full_size import HeadChecker, H, D, G
+    T, L = 2048, 3
+    n_pages = T * L * H * D * 2 * 2 // PAGE
+    rng = np.random.default_rng(300 + scheme)
+    x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.2, 3.0, (n_pages, 1))).astype(np.float16)
+    q = (rng.standard_normal((L, H, G, D)) * 1.5).astype(np.float16)
+    sm = 1.0 / np.sqrt(D)
+    results = {}
+    for name, env in (("one pool", {}), ("striped", {"SPECKV_POOL_DEVICES": pools})):
+        lib = open_lib(**env)
+        try:
+            lib.set_compression_scheme(scheme)
+            h = lib.alloc(n_pages * PAGE)
+            lib.set_layout(h, T, L, H, D, 2)
+            lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+            d_q = torch.from_numpy(q.view(np.int16)).cuda()
+            attend = lib.attend_int4 if scheme == 3 else lib.attend_fp8
+
+            def run(pb, pe, general=False, layer0=0, nl=L):
+                if general: os.environ["SPECKV_ATTEND_GENERAL"] = "1"
+                try:
+                    out = torch.full((nl, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
+                    lse = torch.full((nl, H, G), float("nan"), dtype=torch.float32, device="cuda")
+                    attend(h, layer0, nl, d_q[layer0:layer0 + nl].data_ptr(), G, pb, pe, sm, out.data_ptr(), lse.data_ptr())
+                    torch.cuda.synchronize()
+                finally:
+                    os.environ.pop("SPECKV_ATTEND_GENERAL", None)
+                return out.cpu().numpy(), lse.cpu().numpy()
+
+            results[name] = {"full": run(0, T), "part": run(64, T - 26, layer0=1, nl=2)}
+            if name == "striped":
+                results["page table"] = {"full": run(0, T, True), "part": run(64, T - 26, True, 1, 2)}
+                info = [lib.translate(h, p * PAGE).pool_addr for p in range(2 * len(pools.split(",")))]
+                assert len(set(info)) == len(info)
+                # after a migration the placement is irregular: the page-table form must take over (same numbers)
+                lib.migrate(h, 100, 300, 1)
+                results["migrated"] = {"full": run(0, T), "part": run(64, T - 26, layer0=1, nl=2)}
+        finally:
+            lib.finalize()
+    # the striped form against the oracle (layer 1, two heads, full range)
+    checker = HeadChecker(oracle, scheme, x[T:2 * T], T)
+    out, lse = results["striped"]["full"]
+    for head in (0, 6):
+        checker.check(out[1, head], lse[1, head], q[1, head], head, T, sm, ("striped vs oracle", head))
+    # and against the other forms of the same computation
+    for other in ("one pool", "page table", "migrated"):
+        for case in ("full", "part"):
+            o_s, l_s = results["striped"][case]
+            o_o, l_o = results[other][case]
+            scale = float(np.abs(o_o).max())
+            assert float(np.abs(o_s - o_o).max()) <= 1e-3 * scale, (other, case)
+            assert float(np.abs(l_s - l_o).max()) <= 2e-4, (other, case)
