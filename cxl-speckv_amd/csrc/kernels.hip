@@ -825,7 +825,7 @@ __device__ __noinline__ float absmax_with_nonfinite(const uint8_t* __restrict__ 
 template <int SCHEME, int MODE>
 __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t lds[SCHEME == kInt8DeltaRle ? kWaves * kEncLdsHalves : 8];
+    __shared__ __attribute__((aligned(16))) uint16_t lds[SCHEME == kInt8DeltaRle ? kWaves * kEncLdsHalves : SCHEME == kInt4G32 ? kWaves * (kInt4RecBytes / 2) : 8];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint64_t n = a.n;
@@ -905,10 +905,20 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                         nib |= (static_cast<uint32_t>(static_cast<int>(r)) & 0xFu) << (4 * k);
                     }
                 }
+                // The record is assembled in LDS and leaves as whole 16-byte pieces per lane: written straight from the
+                // registers it took eight store instructions of 4 / 2 bytes per lane (0.63-0.65 of HBM peak).
                 const uint32_t p0 = 512u * j + 8u * lane;
-                *reinterpret_cast<uint32_t*>(rec + 128u + (p0 >> 1)) = nib;
+                uint8_t* wl = reinterpret_cast<uint8_t*>(lds) + wave * kInt4RecBytes;
+                *reinterpret_cast<uint32_t*>(wl + 128u + (p0 >> 1)) = nib;
                 if ((lane & 3u) == 0u)
-                    *reinterpret_cast<uint16_t*>(rec + 2u * (p0 >> 5)) = __builtin_bit_cast(uint16_t, s16);
+                    *reinterpret_cast<uint16_t*>(wl + 2u * (p0 >> 5)) = __builtin_bit_cast(uint16_t, s16);
+            }
+            {
+                uint8_t* wl = reinterpret_cast<uint8_t*>(lds) + wave * kInt4RecBytes;
+                wave_lds_fence();
+                enc_st16(rec + 128u + 16u * lane, *reinterpret_cast<const uint4*>(wl + 128u + 16u * lane));
+                if (lane < 8u) enc_st16(rec + 16u * lane, *reinterpret_cast<const uint4*>(wl + 16u * lane));
+                wave_lds_fence();
             }
             out_len = kInt4RecBytes;
         } else if (SCHEME == kFp8E4m3) {
