@@ -509,6 +509,14 @@ speckv_status_t speckv_ext_predictor_load(const float* embedding, const float* o
     return guarded([&] { return g_engine->predictor_load(embedding, out_weights, vocab, on_device != 0); });
 }
 
+speckv_status_t speckv_ext_predictor_load_lstm(const float* embedding, uint32_t vocab, uint32_t n_layers, const float* const* w_ih,
+                                               const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
+                                               const float* out_weights, const float* out_bias, int on_device)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->predictor_load_lstm(embedding, vocab, n_layers, w_ih, w_hh, b_ih, b_hh, out_weights, out_bias, on_device != 0); });
+}
+
 speckv_status_t speckv_ext_predict_batch(uint32_t n, const int32_t* d_histories, uint32_t k, int32_t* d_tokens,
                                          float* d_conf, void* stream)
 {

@@ -238,6 +238,7 @@ Engine::~Engine()
     allocs_.clear();
     if (d_emb_) (void)hipFree(d_emb_);
     if (d_wout_) (void)hipFree(d_wout_);
+    for (float* p : lstm_bufs_) (void)hipFree(p);
     for (Scratch* s : {&s_pages_, &s_req_, &s_tmp_, &s_stage_, &s_flush_, &s_hid_, &s_logits_, &s_hist_, &s_pred_, &s_attn_, &s_attn_seq_})
         if (s->p) (void)hipFree(s->p);
     for (void* p : retired_) (void)hipFree(p);
@@ -1412,6 +1413,50 @@ int Engine::predictor_load(const float* emb, const float* wout, uint32_t vocab, 
     HIP_TRY(hipMemcpy(d_wout_, wout, wb, kind));
     vocab_ = vocab;
     hist_.clear(); pred_.clear(); hist_dirty_.clear();
+    for (float* p : lstm_bufs_) (void)hipFree(p);       // back to the reference's cell
+    lstm_bufs_.clear();
+    lstm_ = LstmParams{};
+    return SPECKV_OK;
+}
+
+// A real LSTM cell for the predictor (the reference's cell ignores its weights).  PyTorch nn.LSTM layout.
+int Engine::predictor_load_lstm(const float* emb, uint32_t vocab, uint32_t n_layers, const float* const* w_ih, const float* const* w_hh,
+                                const float* const* b_ih, const float* const* b_hh, const float* wout, const float* out_bias, bool on_device)
+{
+    if (null_) return no_data_path("speckv_ext_predictor_load_lstm");
+    if (!emb || !wout || vocab < 8 || n_layers == 0 || n_layers > 4 || !w_ih || !w_hh || !b_ih || !b_hh) return SPECKV_ERR_INVAL;
+    for (uint32_t l = 0; l < n_layers; ++l)
+        if (!w_ih[l] || !w_hh[l] || !b_ih[l] || !b_hh[l]) return SPECKV_ERR_INVAL;
+    RC_TRY(predictor_load(emb, wout, vocab, on_device));       // embedding + output layer, and the old cell's buffers released
+    DeviceScope device_scope(device_);
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    auto upload = [&](const float* src, size_t n, float** out) -> int {
+        float* d = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), n * sizeof(float)));
+        lstm_bufs_.push_back(d);
+        HIP_TRY(hipMemcpy(d, src, n * sizeof(float), kind));
+        *out = d;
+        return SPECKV_OK;
+    };
+    LstmParams p{};
+    for (uint32_t l = 0; l < n_layers; ++l) {
+        const size_t in_dim = l == 0 ? 64 : 128;
+        float *wi = nullptr, *wh = nullptr, *bi = nullptr, *bh = nullptr;
+        RC_TRY(upload(w_ih[l], 512 * in_dim, &wi));
+        RC_TRY(upload(w_hh[l], 512 * 128, &wh));
+        RC_TRY(upload(b_ih[l], 512, &bi));
+        RC_TRY(upload(b_hh[l], 512, &bh));
+        // bias = b_ih + b_hh, summed once on the host side of the copy (exact: one fp32 addition, as the cell would do)
+        std::vector<float> a(512), b(512);
+        HIP_TRY(hipMemcpy(a.data(), bi, 512 * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(b.data(), bh, 512 * sizeof(float), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 512; ++i) a[i] += b[i];
+        HIP_TRY(hipMemcpy(bi, a.data(), 512 * sizeof(float), hipMemcpyHostToDevice));
+        p.w_ih[l] = wi; p.w_hh[l] = wh; p.bias[l] = bi;
+    }
+    if (out_bias) { float* ob = nullptr; RC_TRY(upload(out_bias, vocab, &ob)); p.out_bias = ob; }
+    p.layers = n_layers;
+    lstm_ = p;
     return SPECKV_OK;
 }
 
@@ -1426,7 +1471,7 @@ int Engine::predict_batch(uint32_t n, const int32_t* d_hist, uint32_t k, int32_t
     float* logits = static_cast<float*>(scratch(s_logits_, static_cast<size_t>(n) * vocab_ * sizeof(float), s));
     if (!hid || !logits) return SPECKV_ERR_NOMEM;
     hipStream_t st = s ? s : stream_;
-    HIP_TRY(launch_predict(n, d_hist, d_emb_, d_wout_, vocab_, 2, k, hid, logits, d_tok, d_conf, st));
+    HIP_TRY(launch_predict(n, d_hist, d_emb_, d_wout_, vocab_, 2, k, hid, logits, d_tok, d_conf, st, &lstm_));
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
     return SPECKV_OK;
 }

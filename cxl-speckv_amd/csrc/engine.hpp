@@ -159,6 +159,8 @@ public:
                     uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
     int migrate(uint64_t handle, uint64_t first_page, uint64_t n_pages, uint32_t target_pool);
     int predictor_load(const float* emb, const float* wout, uint32_t vocab, bool on_device);
+    int predictor_load_lstm(const float* emb, uint32_t vocab, uint32_t n_layers, const float* const* w_ih, const float* const* w_hh,
+                            const float* const* b_ih, const float* const* b_hh, const float* wout, const float* out_bias, bool on_device);
     int predict_batch(uint32_t n, const int32_t* d_hist, uint32_t k, int32_t* d_tok, float* d_conf, hipStream_t s);
     int poll_complete(uint32_t* done);
     int sync();
@@ -298,6 +300,8 @@ private:
     float* d_emb_ = nullptr;
     float* d_wout_ = nullptr;
     uint32_t vocab_ = 0;
+    LstmParams lstm_{};                    // device copies of a real cell's weights (layers == 0: the reference's degenerate cell)
+    std::vector<float*> lstm_bufs_;
     Scratch s_hid_, s_logits_, s_hist_, s_pred_;
     Scratch s_attn_, s_attn_seq_;
     // pinned staging for the batch descriptors: 4 slots in rotation, each guarded by an event (no stream sync per call)

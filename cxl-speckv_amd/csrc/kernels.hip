@@ -1471,10 +1471,91 @@ __global__ __launch_bounds__(64) void k_lstm_hidden(const int32_t* __restrict__ 
     hid[static_cast<uint64_t>(r) * kPredHidden + 64u + lane] = h;
 }
 
-// logits[b][i] = sum_j hid[b][j] * wout[i][j].  4 lanes per output row (32 weights each, held in
+// A REAL LSTM cell (the reference's is degenerate, above; SURVEY 8f N1: "semantics must be defined by us"): the standard
+// cell with PyTorch's nn.LSTM conventions -- per layer  gates = W_ih x + W_hh h + b  (4 x 128 rows, order i, f, g, o),
+// c = sigmoid(f) c + sigmoid(i) tanh(g),  h = sigmoid(o) tanh(c),  h_0 = c_0 = 0, layer l > 0 fed with layer l-1's h of the
+// same time step; 16-token history, embedding width 64, hidden width 128.  Output: the top layer's last h.
+//   One workgroup = kLstmReq requests: a thread owns two of the 512 gate rows and computes them for all requests of the
+//   workgroup, so a weight row is read once per step for the whole group (weights: 0.9 MB for two layers, L2-resident).
+//   The cell state and the layer inputs live in LDS.
+struct LstmWeights { const float* w_ih[4]; const float* w_hh[4]; const float* bias[4]; uint32_t layers; };   // bias = b_ih + b_hh
+constexpr uint32_t kLstmReq = 8;
+__device__ __forceinline__ float sigmoidf_dev(float x) { return 1.0f / (1.0f + expf(-x)); }
+__global__ __launch_bounds__(256) void k_lstm_cell(const int32_t* __restrict__ hist, uint32_t n, const float* __restrict__ emb, uint32_t vocab,
+                                                  LstmWeights w, float* __restrict__ hid)
+{
+    __shared__ float xin[kLstmReq][kPredHidden + kPredHidden];           // [request][input of the layer | its own h]
+    __shared__ float hs[4][kLstmReq][kPredHidden], cs[4][kLstmReq][kPredHidden];
+    __shared__ float gates[kLstmReq][4 * kPredHidden];
+    const uint32_t tid = threadIdx.x, r0 = blockIdx.x * kLstmReq;
+    for (uint32_t i = tid; i < 4u * kLstmReq * kPredHidden; i += 256u) { (&hs[0][0][0])[i] = 0.0f; (&cs[0][0][0])[i] = 0.0f; }
+    __syncthreads();
+    for (uint32_t t = 0; t < kPredHist; ++t) {
+        for (uint32_t l = 0; l < w.layers; ++l) {
+            const uint32_t in_dim = l == 0 ? kPredEmb : kPredHidden, cols = in_dim + kPredHidden;
+            // stage [x | h_{t-1}] of every request
+            for (uint32_t i = tid; i < kLstmReq * cols; i += 256u) {
+                const uint32_t r = i / cols, j = i % cols;
+                float v;
+                if (j >= in_dim) v = hs[l][r][j - in_dim];
+                else if (l > 0) v = hs[l - 1][r][j];
+                else {
+                    const uint32_t tok = (r0 + r < n) ? static_cast<uint32_t>(hist[(r0 + r) * kPredHist + t]) : vocab;
+                    v = tok < vocab ? emb[static_cast<uint64_t>(tok) * kPredEmb + j] : 0.0f;
+                }
+                xin[r][j] = v;
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (uint32_t half = 0; half < 2u; ++half) {
+                const uint32_t row = tid + 256u * half;
+                const float* wi = w.w_ih[l] + static_cast<uint64_t>(row) * in_dim;
+                const float* wh = w.w_hh[l] + static_cast<uint64_t>(row) * kPredHidden;
+                float acc[kLstmReq];
+                const float b = w.bias[l][row];
+#pragma unroll
+                for (uint32_t r = 0; r < kLstmReq; ++r) acc[r] = b;
+                for (uint32_t j = 0; j < in_dim; j += 4u) {
+                    const float4 wv = *reinterpret_cast<const float4*>(wi + j);
+#pragma unroll
+                    for (uint32_t r = 0; r < kLstmReq; ++r) {
+                        const float4 xv = *reinterpret_cast<const float4*>(&xin[r][j]);
+                        acc[r] += wv.x * xv.x; acc[r] += wv.y * xv.y; acc[r] += wv.z * xv.z; acc[r] += wv.w * xv.w;
+                    }
+                }
+                for (uint32_t j = 0; j < kPredHidden; j += 4u) {
+                    const float4 wv = *reinterpret_cast<const float4*>(wh + j);
+#pragma unroll
+                    for (uint32_t r = 0; r < kLstmReq; ++r) {
+                        const float4 xv = *reinterpret_cast<const float4*>(&xin[r][in_dim + j]);
+                        acc[r] += wv.x * xv.x; acc[r] += wv.y * xv.y; acc[r] += wv.z * xv.z; acc[r] += wv.w * xv.w;
+                    }
+                }
+#pragma unroll
+                for (uint32_t r = 0; r < kLstmReq; ++r) gates[r][row] = acc[r];
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < kLstmReq * kPredHidden; i += 256u) {
+                const uint32_t r = i / kPredHidden, u = i % kPredHidden;
+                const float gi = sigmoidf_dev(gates[r][u]), gf = sigmoidf_dev(gates[r][kPredHidden + u]);
+                const float gg = tanhf(gates[r][2u * kPredHidden + u]), go = sigmoidf_dev(gates[r][3u * kPredHidden + u]);
+                const float c = gf * cs[l][r][u] + gi * gg;
+                cs[l][r][u] = c;
+                hs[l][r][u] = go * tanhf(c);
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < kLstmReq * kPredHidden; i += 256u) {
+        const uint32_t r = i / kPredHidden, u = i % kPredHidden;
+        if (r0 + r < n) hid[static_cast<uint64_t>(r0 + r) * kPredHidden + u] = hs[w.layers - 1u][r][u];
+    }
+}
+
+// logits[b][i] = sum_j hid[b][j] * wout[i][j] (+ bias[i]).  4 lanes per output row (32 weights each, held in
 // registers), 16 rows per wave -> a wave streams 8 KiB of contiguous weights once for the whole batch.
 __global__ __launch_bounds__(256) void k_lstm_logits(const float* __restrict__ hid, uint32_t n,
-        const float* __restrict__ wout, uint32_t vocab, float* __restrict__ logits)
+        const float* __restrict__ wout, const float* __restrict__ out_bias, uint32_t vocab, float* __restrict__ logits)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1525,7 +1606,7 @@ __global__ __launch_bounds__(256) void k_lstm_logits(const float* __restrict__ h
             }
             acc += __shfl_xor(acc, 1);
             acc += __shfl_xor(acc, 2);
-            if (live && part == 0u) logits[static_cast<uint64_t>(b0 + bt) * vocab + row] = acc;
+            if (live && part == 0u) logits[static_cast<uint64_t>(b0 + bt) * vocab + row] = out_bias ? acc + out_bias[row] : acc;
         }
     }
 }
@@ -1861,13 +1942,21 @@ hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t ba
 
 hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb, const float* d_wout, uint32_t vocab,
                           uint32_t layers, uint32_t k, float* d_hid, float* d_logits, int32_t* d_tok, float* d_conf,
-                          hipStream_t s)
+                          hipStream_t s, const LstmParams* lstm)
 {
     if (n == 0) return hipSuccess;
     if (k == 0 || k > 8u || vocab < k) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_lstm_hidden, dim3(n), dim3(64), 0, s, d_hist, n, d_emb, vocab, layers, d_hid);
+    if (lstm && lstm->layers) {                       // the real cell (speckv_ext_predictor_load_lstm)
+        if (lstm->layers > 4u) return hipErrorInvalidValue;
+        LstmWeights w{};
+        w.layers = lstm->layers;
+        for (uint32_t l = 0; l < lstm->layers; ++l) { w.w_ih[l] = lstm->w_ih[l]; w.w_hh[l] = lstm->w_hh[l]; w.bias[l] = lstm->bias[l]; }
+        hipLaunchKernelGGL(k_lstm_cell, dim3((n + kLstmReq - 1u) / kLstmReq), dim3(256), 0, s, d_hist, n, d_emb, vocab, w, d_hid);
+    } else {
+        hipLaunchKernelGGL(k_lstm_hidden, dim3(n), dim3(64), 0, s, d_hist, n, d_emb, vocab, layers, d_hid);
+    }
     const uint32_t waves = (vocab + 15u) / 16u;
-    hipLaunchKernelGGL(k_lstm_logits, dim3((waves + 3u) / 4u), dim3(256), 0, s, d_hid, n, d_wout, vocab, d_logits);
+    hipLaunchKernelGGL(k_lstm_logits, dim3((waves + 3u) / 4u), dim3(256), 0, s, d_hid, n, d_wout, lstm ? lstm->out_bias : nullptr, vocab, d_logits);
     if (vocab <= 32u * kSmThreads) hipLaunchKernelGGL(k_softmax_topk_small, dim3(n), dim3(1024), 0, s, d_logits, vocab, k, d_tok, d_conf);
     else                           hipLaunchKernelGGL(k_softmax_topk, dim3(n), dim3(1024), 0, s, d_logits, vocab, k, d_tok, d_conf);
     return hipGetLastError();

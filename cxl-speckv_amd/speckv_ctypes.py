@@ -90,6 +90,7 @@ _EXT_SIGNATURES = {
     "speckv_ext_migrate": [c_uint64, c_uint64, c_uint64, c_uint32],
     "speckv_ext_predictor_load": [c_void_p, c_void_p, c_uint32, c_int],
     "speckv_ext_predict_batch": [c_uint32, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p],
+    "speckv_ext_predictor_load_lstm": [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int],
     "speckv_ext_stats": [ctypes.POINTER(Stats)],
 }
 
@@ -299,6 +300,13 @@ class SpeckvLib:
 
     def predictor_load(self, emb_ptr, wout_ptr, vocab, on_device):
         self._ext("speckv_ext_predictor_load", c_void_p(emb_ptr), c_void_p(wout_ptr), vocab, int(on_device))
+
+    def predictor_load_lstm(self, emb_ptr, vocab, w_ih, w_hh, b_ih, b_hh, wout_ptr, out_bias_ptr, on_device):
+        """A real LSTM cell (PyTorch nn.LSTM layout): w_ih / w_hh / b_ih / b_hh are lists of pointers, one per layer."""
+        n = len(w_ih)
+        arr = lambda ps: (c_void_p * n)(*ps)
+        self._ext("speckv_ext_predictor_load_lstm", c_void_p(emb_ptr), vocab, n, arr(w_ih), arr(w_hh), arr(b_ih), arr(b_hh),
+                  c_void_p(wout_ptr), c_void_p(out_bias_ptr or 0), int(on_device))
 
     def predict_batch(self, n, d_hist, k, d_tok, d_conf, stream=None):
         self._ext("speckv_ext_predict_batch", n, c_void_p(d_hist), k, c_void_p(d_tok), c_void_p(d_conf), c_void_p(stream or 0))

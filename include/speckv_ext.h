@@ -174,6 +174,19 @@ speckv_status_t speckv_ext_prefetch_legacy_addrs(uint32_t layer, uint32_t depth_
  * (device) -> top-k tokens / confidences (device, k <= 8). */
 speckv_status_t speckv_ext_predictor_load(const float* embedding, const float* out_weights,
                                           uint32_t vocab, int on_device);
+/* A REAL LSTM cell for the same predictor.  The reference's cell is degenerate (gates fixed at 0.5, recurrent weights never
+ * read: lstm_predictor.cpp:117-146), which speckv_ext_predictor_load reproduces for parity; its semantics as a model are
+ * therefore defined here: the standard LSTM with PyTorch's nn.LSTM conventions --
+ *     gates = w_ih[l] x + b_ih[l] + w_hh[l] h + b_hh[l]   (rows [i | f | g | o], 4 x 128 each)
+ *     c' = sigmoid(f) c + sigmoid(i) tanh(g),   h' = sigmoid(o) tanh(c'),   h_0 = c_0 = 0
+ * n_layers <= 4 stacked layers (layer l > 0 is fed layer l-1's h of the same step), input = the 64-wide embedding of each of
+ * the last 16 tokens, output layer logits = out_weights [vocab][128] . h_top + out_bias (may be NULL), softmax, top-k.
+ * w_ih[0] is [512][64], w_ih[l > 0] and every w_hh[l] [512][128], biases [512]; fp32, host or device.  Replaces any earlier
+ * predictor; speckv_ext_predictor_load switches back to the reference's cell. */
+speckv_status_t speckv_ext_predictor_load_lstm(const float* embedding, uint32_t vocab, uint32_t n_layers,
+                                               const float* const* w_ih, const float* const* w_hh,
+                                               const float* const* b_ih, const float* const* b_hh,
+                                               const float* out_weights, const float* out_bias, int on_device);
 speckv_status_t speckv_ext_predict_batch(uint32_t n, const int32_t* d_histories, uint32_t k,
                                          int32_t* d_tokens, float* d_conf, void* stream);
 

@@ -343,3 +343,65 @@ def test_fused_attention_over_a_regularly_striped_pool_computes_its_addresses(or
             scale = float(np.abs(o_o).max())
             assert float(np.abs(o_s - o_o).max()) <= 1e-3 * scale, (other, case)
             assert float(np.abs(l_s - l_o).max()) <= 2e-4, (other, case)
+
+
+def test_real_lstm_cell_predictor_matches_torch_nn_lstm():
+    """VERDICT r2 missing #3 / SURVEY 8f N1: the reference's cell ignores its weights, so the predictor's semantics as a MODEL
+    are ours to define -- the standard LSTM in PyTorch's nn.LSTM conventions (speckv_ext_predictor_load_lstm).  Checked
+    against an implementation that is not ours: torch.nn.LSTM on the CPU (2 layers, 64 -> 128, 16-token histories), then
+    the output layer with bias, softmax and top-k.  Tolerance 2e-5 on the probabilities (device expf / tanhf against glibc,
+    accumulated over 16 steps); the token ranking must agree wherever two probabilities are further apart than that.
+    Loading the degenerate weights again switches back to the reference's cell."""
+    torch = torch_mod()
+    lib = open_lib()
+    try:
+        vocab, E, Hd, L, n, k = 4096, 64, 128, 2, 37, 8
+        gen = torch.Generator().manual_seed(11)
+        emb = torch.randn((vocab, E), generator=gen) * 0.7
+        lstm = torch.nn.LSTM(E, Hd, num_layers=L, batch_first=True)
+        with torch.no_grad():
+            for p in lstm.parameters():
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.15)
+        wout = torch.randn((vocab, Hd), generator=gen) * 0.5
+        bout = torch.randn(vocab, generator=gen) * 0.3
+        hist = torch.randint(0, vocab, (n, 16), generator=gen, dtype=torch.int32)
+        hist[3, :5] = vocab + 7                                   # out-of-vocabulary ids embed as zeros (as the reference does)
+        with torch.no_grad():
+            x = torch.where((hist < vocab).unsqueeze(-1), emb[hist.clamp(max=vocab - 1).long()], torch.zeros(1))
+            out, _ = lstm(x)
+            probs = torch.softmax(out[:, -1] @ wout.T + bout, dim=-1)
+        want_p, want_t = probs.topk(k, dim=-1)
+        par = {name: p.detach().contiguous() for name, p in lstm.named_parameters()}
+        ptr = lambda t: t.data_ptr()
+        lib.predictor_load_lstm(ptr(emb), vocab, [ptr(par[f"weight_ih_l{l}"]) for l in range(L)], [ptr(par[f"weight_hh_l{l}"]) for l in range(L)],
+                                [ptr(par[f"bias_ih_l{l}"]) for l in range(L)], [ptr(par[f"bias_hh_l{l}"]) for l in range(L)],
+                                ptr(wout), ptr(bout), False)
+        d_hist = hist.cuda()
+        d_tok = torch.zeros((n, k), dtype=torch.int32, device="cuda")
+        d_conf = torch.zeros((n, k), dtype=torch.float32, device="cuda")
+        lib.predict_batch(n, d_hist.data_ptr(), k, d_tok.data_ptr(), d_conf.data_ptr())
+        torch.cuda.synchronize()
+        got_t, got_p = d_tok.cpu(), d_conf.cpu()
+        assert float((got_p - want_p).abs().max()) <= 2e-5, float((got_p - want_p).abs().max())
+        for r in range(n):
+            for j in range(k):
+                if int(got_t[r, j]) != int(want_t[r, j]):           # only a near-tie may swap places
+                    assert abs(float(probs[r, got_t[r, j]]) - float(want_p[r, j])) <= 4e-5, (r, j)
+        assert float(got_p.sum(-1).max()) <= 1.0 + 1e-5
+        # through the engine's own path: histories arrive with speckv_prefetch, the flush predicts, verify() checks
+        lib.set_compression_scheme(2)
+        h = lib.alloc(64 * 2 * 2 * 8 * 128 * 2)
+        lib.set_layout(h, 64, 2, 8, 128, 2)
+        lib.prefetch(0, 0, 3, 4, [int(v) for v in hist[5]])
+        lib.prefetch_flush()
+        hit, _ = lib.verify(0, int(want_t[5, 0]))
+        assert hit
+        hit, _ = lib.verify(0, int(probs[5].argmin()))
+        assert not hit
+        # back to the reference's degenerate cell: the weights above are ignored again
+        lib.predictor_load(ptr(emb), ptr(wout), vocab, False)
+        lib.predict_batch(n, d_hist.data_ptr(), k, d_tok.data_ptr(), d_conf.data_ptr())
+        torch.cuda.synchronize()
+        assert not torch.equal(d_tok.cpu(), got_t)
+    finally:
+        lib.finalize()
