@@ -530,6 +530,12 @@ speckv_status_t speckv_ext_migrate(speckv_handle_t handle, uint64_t first_page, 
     return guarded([&] { return g_engine->migrate(handle, first_page, n_pages, target_pool); });
 }
 
+speckv_status_t speckv_ext_compact(speckv_handle_t handle, uint64_t* bytes_before, uint64_t* bytes_after)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] { return g_engine->compact(handle, bytes_before, bytes_after); });
+}
+
 speckv_status_t speckv_ext_stats(speckv_ext_stats_t* out)
 {
     LOCK;

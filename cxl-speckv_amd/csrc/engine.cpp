@@ -1661,6 +1661,7 @@ int Engine::write(uint64_t handle, uint64_t off, const void* src, size_t len, bo
     const uint64_t p0 = off / kPageSize;
     const uint64_t full = len / kPageSize, tail = len % kPageSize;
     DeviceScope device_scope(device_);
+    if (a->packed) { RC_TRY(unpack(a)); if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL; }   // a sealed allocation goes back into slots first
     RC_TRY(quiesce());
     if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
     reap(false);
@@ -1729,6 +1730,7 @@ int Engine::write_strided(uint64_t handle, uint64_t first, uint64_t step, uint64
     // a last page that is only partly inside the allocation would need zero padding of the source: not here
     if (a->size_bytes % kPageSize && first + (n - 1) * step == a->n_pages - 1) return SPECKV_ERR_INVAL;
     DeviceScope device_scope(device_);
+    if (a->packed) { RC_TRY(unpack(a)); if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL; }
     // NULL = the engine's stream: the source may have been produced on any stream of the caller, order after all of them
     if (!s) HIP_TRY(hipDeviceSynchronize());
     bool cached = false;
@@ -1796,6 +1798,13 @@ int Engine::write_groups(const uint64_t* handles, const uint64_t* firsts, const 
         as[i] = a;
         for (uint64_t j = 0; j < n_each && !cached; ++j) cached = (res_flags(a, firsts[i] + j * step) & 3u) != 0;
     }
+    for (uint32_t i = 0; i < n_groups; ++i)
+        if (as[i]->packed) {                                    // sealed allocations go back into slots first
+            DeviceScope scope(device_);
+            RC_TRY(unpack(as[i]));
+            for (uint32_t j = 0; j < n_groups; ++j)
+                if ((as[j] = find(handles[same_allocation ? 0 : j])) == nullptr) return SPECKV_ERR_GENERAL;
+        }
     if (same_allocation && n_groups > 1) {                      // the runs of one allocation must not overlap (racing writers)
         std::vector<uint64_t> order(firsts, firsts + n_groups);
         std::sort(order.begin(), order.end());
@@ -1932,7 +1941,8 @@ int Engine::read(uint64_t handle, uint64_t off, void* dst, size_t len, bool on_d
 int Engine::fetch_range_copy_engine(Allocation* a, uint64_t first, uint64_t n, void* d_dst, bool f32, hipStream_t st)
 {
     const uint32_t D = static_cast<uint32_t>(a->pool_of_residue.size());
-    if (D == 0 || D > 8 || !a->regular) return SPECKV_ERR_INVAL;
+    const bool packed = a->packed && a->packed_regular;
+    if (D == 0 || D > 8 || !(a->regular || packed)) return SPECKV_ERR_INVAL;
     const size_t stride = a->rec_stride;
     if (!stage_[0]) {
         stage_bytes_ = env_mb("SPECKV_STAGE_MB", 64) << 20;
@@ -1982,16 +1992,30 @@ int Engine::fetch_range_copy_engine(Allocation* a, uint64_t first, uint64_t n, v
             c.stripe_delta[k] = 0;
             if (cnt == 0) continue;
             const int pool = a->pool_of_residue[k];
-            const uint8_t* src = static_cast<const uint8_t*>(a->extents[k].base) + rb * stride;
+            // the byte run of this pool's records of the chunk: fixed slots, or -- sealed allocation -- the packed records
+            // themselves (record rb of residue k is page rb * D + k; the run ends where the next record of the pool starts)
+            const uint8_t* src;
+            size_t run_bytes;
+            if (packed) {
+                const uint64_t p_first = rb * D + k, p_next = (rb + cnt) * D + k;
+                const uint64_t lo = static_cast<uint64_t>(a->packed_off128[p_first]) << 7;
+                const uint64_t hi = p_next < a->n_pages ? static_cast<uint64_t>(a->packed_off128[p_next]) << 7 : a->packed_bytes[k];
+                src = static_cast<const uint8_t*>(a->extents[k].base) + lo;
+                run_bytes = static_cast<size_t>(hi - lo);
+            } else {
+                src = static_cast<const uint8_t*>(a->extents[k].base) + rb * stride;
+                run_bytes = cnt * stride;
+            }
             uint8_t* dstk = stage_[b] + k * region;
             c.stripe_delta[k] = static_cast<int64_t>(reinterpret_cast<intptr_t>(dstk) - reinterpret_cast<intptr_t>(src));
+            if (run_bytes == 0) continue;                                   // (records of zero length: nothing to move)
             PeerLane& lane = lanes_[pool];
             if (chunk == 0) HIP_TRY(hipStreamWaitEvent(lane.s, start, 0));
             HIP_TRY(hipStreamWaitEvent(lane.s, stage_free_[b], 0));        // the decompression that last read this buffer
-            HIP_TRY(hipMemcpyPeerAsync(dstk, device_, src, pools_[pool]->device(), cnt * stride, lane.s));
+            HIP_TRY(hipMemcpyPeerAsync(dstk, device_, src, pools_[pool]->device(), run_bytes, lane.s));
             HIP_TRY(hipEventRecord(lane.copied[b], lane.s));
             HIP_TRY(hipStreamWaitEvent(st, lane.copied[b], 0));
-            st_.copy_engine_bytes += cnt * stride;
+            st_.copy_engine_bytes += run_bytes;
         }
         HIP_TRY(launch_decompress(c, st));
         HIP_TRY(hipEventRecord(stage_free_[b], st));
@@ -2025,7 +2049,7 @@ int Engine::fetch_range(uint64_t handle, uint64_t first, uint64_t n, void* d_dst
     }();
     int choice = engine_choice ? engine_choice : env_choice;
     const uint32_t D = static_cast<uint32_t>(a->pool_of_residue.size());
-    const bool can_copy = a->regular && D >= 1 && D <= 8 && a->n_pages < (1ull << 28) && !is_capturing(st);
+    const bool can_copy = (a->regular || (a->packed && a->packed_regular)) && D >= 1 && D <= 8 && a->n_pages < (1ull << 28) && !is_capturing(st);
     if (choice == 0) {
         bool remote = false;
         for (int p : a->pool_of_residue) remote = remote || pools_[p]->device() != device_;
@@ -2637,6 +2661,7 @@ int Engine::migrate(uint64_t handle, uint64_t first, uint64_t n, uint32_t target
     if (target_pool >= pools_.size()) return SPECKV_ERR_INVAL;
     if (n == 0) return SPECKV_OK;
     DeviceScope device_scope(device_);
+    if (a->packed) { RC_TRY(unpack(a)); if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL; }
     RC_TRY(quiesce());
     RC_TRY(wait_stream());
     if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
@@ -2696,6 +2721,146 @@ int Engine::migrate(uint64_t handle, uint64_t first, uint64_t n, uint32_t target
     st_.pool_migrated_pages += n;
     return SPECKV_OK;
 }
+
+// ---------------------------------------------------------------- compaction (packed INT8_DELTA_RLE records)
+// The pool gives every page a worst-case 4 KiB slot, so on its own the reference's variable-length scheme buys no capacity
+// (cache_engine.cpp:62-78 only COUNTS compressed_size).  speckv_ext_compact packs the records of an allocation back to back
+// (128-byte aligned, page order, one extent per pool GPU) and hands the slot runs back to the slab pool: the allocation is
+// "sealed".  Everything that reads goes through the page table and does not care; the copy-engine fetch then moves record
+// bytes, not slots.  A write (or a migration) to a sealed allocation first unpacks it into slots again -- sealing is meant
+// for sequences that are parked in the pool, not for ones a decode loop appends to.
+int Engine::settle_for_relocation(Allocation*& a, uint64_t handle)
+{
+    RC_TRY(quiesce());
+    RC_TRY(order_after_writes());
+    RC_TRY(wait_stream());
+    if ((a = find(handle)) == nullptr) return SPECKV_ERR_GENERAL;
+    for (hipStream_t us : a->user_streams)            // asynchronous readers / writers on caller streams (ABI lock stays held)
+        if (hipStreamSynchronize(us) != hipSuccess) (void)hipGetLastError();
+    reap(false);
+    return SPECKV_OK;
+}
+
+int Engine::compact(uint64_t handle, uint64_t* bytes_before, uint64_t* bytes_after)
+{
+    if (null_) return no_data_path("speckv_ext_compact");
+    Allocation* a = find(handle);
+    if (!a) return SPECKV_ERR_GENERAL;
+    uint64_t before = 0;
+    for (const auto& ex : a->extents) before += ex.bytes;
+    if (bytes_before) *bytes_before = before;
+    if (bytes_after) *bytes_after = before;
+    if (a->scheme != SPECKV_COMP_INT8_DELTA_RLE || a->packed || a->n_pages == 0) return SPECKV_OK;   // fixed-size formats: slot == record
+    DeviceScope device_scope(device_);
+    RC_TRY(settle_for_relocation(a, handle));
+    const uint32_t D = static_cast<uint32_t>(a->pool_of_residue.size());
+    if (D == 0 || D > 255) return SPECKV_ERR_INVAL;
+    std::vector<PageEntry> cur(a->n_pages);
+    HIP_TRY(hipMemcpy(cur.data(), a->d_entries, a->n_pages * sizeof(PageEntry), hipMemcpyDeviceToHost));
+    // packed offsets per pool (the pool a page lives on NOW: a migration may have moved it), page order, 128-byte aligned
+    std::vector<uint64_t> total(pools_.size(), 0), new_addr(a->n_pages);
+    std::vector<uint32_t> off128(a->n_pages);
+    for (uint64_t p = 0; p < a->n_pages; ++p) {
+        const uint32_t k = a->page_pool[p];
+        off128[p] = static_cast<uint32_t>(total[k] >> 7);
+        total[k] += (static_cast<uint64_t>(cur[p].rec_bytes) + 127u) & ~127ull;
+        if ((total[k] >> 7) > 0xFFFFFFFFull) return SPECKV_ERR_NOMEM;
+    }
+    std::vector<Allocation::Extent> fresh;
+    auto undo = [&] { for (auto& ex : fresh) if (ex.base) pools_[ex.pool]->free(ex.base, ex.bytes); };
+    std::vector<uint8_t*> base(pools_.size(), nullptr);
+    // extents in residue order first (fetch_range_copy_engine reads extents[k] as "the run of residue k"), then any other pool
+    std::vector<int> order;
+    for (uint32_t k = 0; k < D; ++k) order.push_back(a->pool_of_residue[k]);
+    for (size_t k = 0; k < pools_.size(); ++k) if (std::find(order.begin(), order.end(), static_cast<int>(k)) == order.end()) order.push_back(static_cast<int>(k));
+    bool regular_pools = true;
+    for (uint32_t k = 0; k < D; ++k) for (uint32_t j = 0; j < k; ++j) regular_pools = regular_pools && a->pool_of_residue[k] != a->pool_of_residue[j];
+    std::vector<uint64_t> pbytes;
+    for (int k : order) {
+        const uint64_t need = total[k];
+        uint8_t* b = need ? static_cast<uint8_t*>(pools_[k]->alloc(need)) : nullptr;
+        if (need && !b) { undo(); return SPECKV_ERR_NOMEM; }
+        base[k] = b;
+        fresh.push_back({k, b, static_cast<size_t>(need), 0});
+        pbytes.push_back(need);
+    }
+    for (uint64_t p = 0; p < a->n_pages; ++p)
+        new_addr[p] = reinterpret_cast<uint64_t>(base[a->page_pool[p]]) + (static_cast<uint64_t>(off128[p]) << 7);
+    uint64_t* d_new = static_cast<uint64_t*>(scratch(s_pages_, a->n_pages * sizeof(uint64_t)));
+    if (!d_new) { undo(); return SPECKV_ERR_NOMEM; }
+    if (hipMemcpy(d_new, new_addr.data(), a->n_pages * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess ||
+        launch_repack(a->d_entries, d_new, a->n_pages, stream_) != hipSuccess || hipStreamSynchronize(stream_) != hipSuccess) {
+        (void)hipGetLastError();
+        undo();
+        return SPECKV_ERR_DRIVER;
+    }
+    for (auto& ex : a->extents) if (ex.base) pools_[ex.pool]->free(ex.base, ex.bytes);
+    // the copy engine's condition: pages still striped page % D over D distinct pools (no migration since the allocation)
+    bool striped = regular_pools;
+    for (uint64_t p = 0; p < a->n_pages && striped; ++p) striped = a->page_pool[p] == static_cast<uint8_t>(a->pool_of_residue[p % D]);
+    a->extents.swap(fresh);
+    a->packed = true;
+    a->packed_regular = striped;
+    a->packed_off128.swap(off128);
+    a->packed_bytes.swap(pbytes);
+    a->regular = false;
+    a->linear_base = nullptr;
+    a->stripe_n = 0;
+    uint64_t after = 0;
+    for (const auto& ex : a->extents) after += ex.bytes;
+    if (bytes_after) *bytes_after = after;
+    st_.compactions++;
+    return SPECKV_OK;
+}
+
+// A sealed allocation back into fixed slots (the placement of a fresh allocation: page p -> record p / D of the run on pool
+// residue p % D when it was striped that way, else one run per pool in page order).
+int Engine::unpack(Allocation* a)
+{
+    if (!a->packed) return SPECKV_OK;
+    const uint64_t handle = a->handle;
+    RC_TRY(settle_for_relocation(a, handle));
+    if (!a->packed) return SPECKV_OK;                   // another thread got here first while we waited
+    const uint32_t D = static_cast<uint32_t>(a->pool_of_residue.size());
+    const size_t stride = a->rec_stride;
+    std::vector<uint64_t> count(pools_.size(), 0), new_addr(a->n_pages);
+    for (uint64_t p = 0; p < a->n_pages; ++p) count[a->page_pool[p]]++;
+    std::vector<Allocation::Extent> fresh;
+    auto undo = [&] { for (auto& ex : fresh) if (ex.base) pools_[ex.pool]->free(ex.base, ex.bytes); };
+    std::vector<uint8_t*> base(pools_.size(), nullptr);
+    std::vector<int> order;
+    for (uint32_t k = 0; k < D; ++k) order.push_back(a->pool_of_residue[k]);
+    for (size_t k = 0; k < pools_.size(); ++k) if (std::find(order.begin(), order.end(), static_cast<int>(k)) == order.end()) order.push_back(static_cast<int>(k));
+    for (int k : order) {
+        const size_t need = count[k] * stride;
+        uint8_t* b = need ? static_cast<uint8_t*>(pools_[k]->alloc(need)) : nullptr;
+        if (need && !b) { undo(); SPECKV_ERR("a write to a compacted allocation needs %zu bytes of slots again: out of pool memory", need); return SPECKV_ERR_NOMEM; }
+        base[k] = b;
+        fresh.push_back({k, b, need, count[k]});
+    }
+    std::vector<uint64_t> next(pools_.size(), 0);
+    for (uint64_t p = 0; p < a->n_pages; ++p) {
+        const uint32_t k = a->page_pool[p];
+        const uint64_t rec = a->packed_regular ? p / D : next[k]++;
+        new_addr[p] = reinterpret_cast<uint64_t>(base[k]) + rec * stride;
+    }
+    uint64_t* d_new = static_cast<uint64_t*>(scratch(s_pages_, a->n_pages * sizeof(uint64_t)));
+    if (!d_new) { undo(); return SPECKV_ERR_NOMEM; }
+    if (hipMemcpy(d_new, new_addr.data(), a->n_pages * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess ||
+        launch_repack(a->d_entries, d_new, a->n_pages, stream_) != hipSuccess || hipStreamSynchronize(stream_) != hipSuccess) {
+        (void)hipGetLastError();
+        undo();
+        return SPECKV_ERR_DRIVER;
+    }
+    for (auto& ex : a->extents) if (ex.base) pools_[ex.pool]->free(ex.base, ex.bytes);
+    a->extents.swap(fresh);
+    a->regular = a->packed_regular;
+    a->packed = a->packed_regular = false;
+    a->packed_off128.clear(); a->packed_off128.shrink_to_fit();
+    a->packed_bytes.clear();
+    return SPECKV_OK;
+}
+
 
 int Engine::poll_complete(uint32_t* done)
 {   // SPECKV_IOCTL_POLL_DONE: completions since the previous poll, then cleared
@@ -2776,16 +2941,21 @@ int Engine::stats(speckv_ext_stats_t* out)
         DeviceScope device_scope(device_);
         RC_TRY(settle());                   // prefetch counters of the flushes submitted so far
         reap(false);
-        uint64_t comp = 0;
+        uint64_t comp = 0, in_use = 0, written = 0, sealed = 0;
         std::vector<PageEntry> host;
         for (auto& kv : allocs_) {
             Allocation* a = kv.second.get();
             if (!a->n_pages) continue;
+            for (const auto& ex : a->extents) in_use += ex.bytes;
+            sealed += a->packed ? 1u : 0u;
             host.resize(a->n_pages);
             if (hipMemcpy(host.data(), a->d_entries, a->n_pages * sizeof(PageEntry), hipMemcpyDeviceToHost) == hipSuccess)
-                for (auto& e : host) comp += e.rec_bytes;
+                for (auto& e : host) { comp += e.rec_bytes; written += e.rec_bytes ? 1u : 0u; }
         }
         st_.compressed_bytes = comp;
+        st_.pool_bytes_in_use = in_use;
+        st_.written_pages = written;
+        st_.sealed_allocations = sealed;
     }
     *out = st_;
     return SPECKV_OK;

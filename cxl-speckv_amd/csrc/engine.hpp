@@ -74,6 +74,12 @@ struct Allocation {
     std::vector<int> pool_of_residue;     // pool index serving pages with page % D == k (at allocation)
     std::vector<uint8_t> page_pool;       // pool index holding each page's record now
     bool regular = false;                 // placement still is "page p = record p/D of the run on pool p%D"
+    // compacted (speckv_ext_compact): the records lie back to back (128-byte aligned) in ONE packed extent per pool, in page
+    // order; packed_off128[p] = offset of page p's record inside its pool's extent in units of 128 B, packed_bytes[k] = size of
+    // pool residue k's extent (extents[k]); packed_regular: the pages still go to pool p % D (the copy engine's condition)
+    bool packed = false, packed_regular = false;
+    std::vector<uint32_t> packed_off128;
+    std::vector<uint64_t> packed_bytes;
     PageEntry* d_entries = nullptr;
     uint32_t* d_flags = nullptr;
     uint32_t* d_slot = nullptr;
@@ -158,6 +164,7 @@ public:
     int attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
                     uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
     int migrate(uint64_t handle, uint64_t first_page, uint64_t n_pages, uint32_t target_pool);
+    int compact(uint64_t handle, uint64_t* bytes_before, uint64_t* bytes_after);
     int predictor_load(const float* emb, const float* wout, uint32_t vocab, bool on_device);
     int predictor_load_lstm(const float* emb, uint32_t vocab, uint32_t n_layers, const float* const* w_ih, const float* const* w_hh,
                             const float* const* b_ih, const float* const* b_hh, const float* wout, const float* out_bias, bool on_device);
@@ -361,6 +368,8 @@ private:
     int fetch_into_slot(Allocation* a, uint32_t page, uint32_t slot);
     int fetch_range_copy_engine(Allocation* a, uint64_t first, uint64_t n, void* d_dst, bool f32, hipStream_t st);
     bool infer_layout(Allocation* a);
+    int unpack(Allocation* a);                            // a compacted allocation back into fixed slots (before any write / migration)
+    int settle_for_relocation(Allocation*& a, uint64_t handle);
     int write_groups(const uint64_t* handles, const uint64_t* firsts, const void* const* d_srcs, uint32_t n_groups, uint64_t step,
                      uint64_t n_each, hipStream_t s, bool same_allocation);
     int flush_group(int scheme, const uint32_t* const cols[5], uint32_t n, uint32_t W, uint32_t* n_issued);

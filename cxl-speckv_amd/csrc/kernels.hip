@@ -1746,6 +1746,21 @@ __global__ __launch_bounds__(1024) void k_softmax_topk_small(const float* __rest
     }
 }
 
+// Records move to new places (compaction into packed extents and back): one wave per page copies the record's bytes, rounded up
+// to 16 (k_compress zero-pads a record's last 16-byte piece), then re-points the page's table entry.
+__global__ __launch_bounds__(256) void k_repack(PageEntry* __restrict__ entries, const uint64_t* __restrict__ new_addr, uint64_t n)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t p = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    if (p >= n) return;
+    const PageEntry e = entries[p];
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(e.pool_addr);
+    uint8_t* dst = reinterpret_cast<uint8_t*>(new_addr[p]);
+    const uint32_t bytes = (e.rec_bytes + 15u) & ~15u;
+    for (uint32_t b = 16u * lane; b < bytes; b += 1024u) st16(dst + b, ld16(src + b));
+    if (lane == 0u) entries[p].pool_addr = new_addr[p];
+}
+
 __global__ void k_retarget_entries(PageEntry* e, uint64_t n, uint64_t base, uint64_t stride)
 {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1929,6 +1944,13 @@ hipError_t launch_qk_scores_fp8(const PageEntry* d_entries, uint64_t first_page,
     const uint32_t waves = (n_pages + 7u) / 8u;
     hipLaunchKernelGGL(k_qk_scores_fp8, dim3((waves + 1u) / 2u, n_layers), dim3(128), 0, s, d_entries, first_page,
                        layer_page_stride, n_pages, heads, g, d_q8, d_qs, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_repack(PageEntry* d_entries, const uint64_t* d_new_addr, uint64_t n, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_repack, dim3(static_cast<uint32_t>((n + 3u) / 4u)), dim3(256), 0, s, d_entries, d_new_addr, n);
     return hipGetLastError();
 }
 

@@ -301,6 +301,8 @@ hipError_t launch_qk_scores_fp8_linear(const AttendArgs& a, uint32_t n_layers, f
 // per-sequence split count; d_out [n_seq][heads][g][128]
 hipError_t launch_attend_fp8_batch(const AttendArgs& a, uint32_t n_seq, float* d_out, float* d_lse, hipStream_t s);
 
+// every page's record (rec_bytes rounded up to 16) copied to d_new_addr[page], then entries[page].pool_addr = d_new_addr[page]
+hipError_t launch_repack(PageEntry* d_entries, const uint64_t* d_new_addr, uint64_t n, hipStream_t s);
 // entries[i].pool_addr = base + i*stride (record bytes / scale untouched): after a migration
 hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t base, uint64_t stride, hipStream_t s);
 

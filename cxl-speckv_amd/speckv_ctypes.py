@@ -40,7 +40,8 @@ class Stats(ctypes.Structure):
         "dma_submitted", "dma_completed", "pool_bytes_reserved", "cache_bytes_reserved")] + \
         [(n, c_uint32) for n in ("prefetch_depth", "compression_scheme", "quant_mode", "n_pool_devices")] + \
         [("pool_migrated_pages", c_uint64), ("prefetch_dropped", c_uint64), ("copy_engine_runs", c_uint64),
-         ("copy_engine_bytes", c_uint64)]
+         ("copy_engine_bytes", c_uint64), ("pool_bytes_in_use", c_uint64), ("written_pages", c_uint64),
+         ("sealed_allocations", c_uint64), ("compactions", c_uint64)]
 
 
 _u32p = ctypes.POINTER(c_uint32)
@@ -88,6 +89,7 @@ _EXT_SIGNATURES = {
     "speckv_ext_promote_to_l1": [c_uint64, c_uint64],
     "speckv_ext_demote_to_l3": [c_uint64, c_uint64],
     "speckv_ext_migrate": [c_uint64, c_uint64, c_uint64, c_uint32],
+    "speckv_ext_compact": [c_uint64, _u64p, _u64p],
     "speckv_ext_predictor_load": [c_void_p, c_void_p, c_uint32, c_int],
     "speckv_ext_predict_batch": [c_uint32, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p],
     "speckv_ext_predictor_load_lstm": [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int],
@@ -391,6 +393,12 @@ class SpeckvLib:
 
     def migrate(self, handle, first_page, n_pages, target_pool):
         self._ext("speckv_ext_migrate", handle, first_page, n_pages, target_pool)
+
+    def compact(self, handle):
+        """Seal an allocation (pack its INT8_DELTA_RLE records, free the slots).  Returns (pool bytes before, after)."""
+        before, after = c_uint64(), c_uint64()
+        self._ext("speckv_ext_compact", handle, ctypes.byref(before), ctypes.byref(after))
+        return before.value, after.value
 
     def stats(self):
         s = Stats()

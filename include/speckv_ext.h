@@ -348,6 +348,15 @@ speckv_status_t speckv_ext_demote_to_l3(speckv_handle_t handle, uint64_t offset_
 speckv_status_t speckv_ext_migrate(speckv_handle_t handle, uint64_t first_page,
                                    uint64_t n_pages, uint32_t target_pool);
 
+/* Seal an allocation: pack its records back to back (128-byte aligned, page order, one extent per pool GPU) and return the
+ * worst-case 4 KiB slots to the pool.  Only the variable-length scheme gains (SPECKV_COMP_INT8_DELTA_RLE; for the others the
+ * call is a no-op): the pool then holds what the reference only counts (CompressedData::compressed_size, the ratio statistics
+ * of cache_engine.cpp:62-78), and the copy-engine fetch moves record bytes instead of slots.  Reads are unaffected (they go
+ * through the page table); a later write or migration first unpacks the allocation into slots again, so seal sequences that
+ * are parked in the pool, not ones a decode loop appends to.  *bytes_before / *bytes_after (optional): pool bytes the
+ * allocation holds.  Synchronous. */
+speckv_status_t speckv_ext_compact(speckv_handle_t handle, uint64_t* bytes_before, uint64_t* bytes_after);
+
 /* ---- statistics (Statistics structs: cxl_memory_manager.h:73-83,
  *      speculative_prefetcher.h:59-66, cache_engine.h:65-72, memory_allocator.h:42-48) */
 typedef struct {
@@ -365,6 +374,12 @@ typedef struct {
     uint64_t prefetch_dropped;      /* speckv_prefetch requests that could not be addressed (no geometry / binding) */
     uint64_t copy_engine_runs;      /* hipMemcpyPeerAsync runs issued by the copy-engine fetch */
     uint64_t copy_engine_bytes;     /* bytes they moved into local staging */
+    /* pool occupancy (cache_engine.cpp:62-78 keeps compressed_size / ratio statistics; here they are bytes of HBM):
+     * capacity ratio of the live data = written_pages * 4096 / pool_bytes_in_use */
+    uint64_t pool_bytes_in_use;     /* record storage held by live allocations (slots, or packed extents once sealed) */
+    uint64_t written_pages;         /* pages of live allocations that hold a record */
+    uint64_t sealed_allocations;    /* live allocations packed by speckv_ext_compact */
+    uint64_t compactions;           /* speckv_ext_compact calls that packed an allocation */
 } speckv_ext_stats_t;
 speckv_status_t speckv_ext_stats(speckv_ext_stats_t* out);
 

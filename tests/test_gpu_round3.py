@@ -405,3 +405,103 @@ def test_real_lstm_cell_predictor_matches_torch_nn_lstm():
         assert not torch.equal(d_tok.cpu(), got_t)
     finally:
         lib.finalize()
+
+
+@pytest.mark.parametrize("pools", [None, "0,0,0"])
+def test_compaction_packs_rle_records_and_frees_the_slots(oracle, pools):
+    """INT8_DELTA_RLE records used to live in worst-case 4 KiB slots for good, so the
+    reference's own scheme bought no pool capacity and the copy engine shipped slots.  speckv_ext_compact seals an
+    allocation: records packed back to back (128-byte aligned), slots returned to the pool.  Checked: the pool really
+    shrinks to the packed size (stats.pool_bytes_in_use, and a second allocation fits into what was freed), every read
+    path still returns the oracle's bits (bulk fetch by both engines, random list, speckv_access through the ring), the
+    copy engine now moves record bytes, a write unseals transparently, and Gaussian data (incompressible for this
+    scheme) gains nothing."""
+    torch = torch_mod()
+    env = {"SPECKV_POOL_DEVICES": pools} if pools else {}
+    lib = open_lib(SPECKV_STAGE_MB=2, **env)
+    try:
+        lib.set_compression_scheme(2)
+        n = 6144
+        rng = np.random.default_rng(17)
+        x = np.zeros((n, N), np.float16)
+        x[0::3] = np.repeat(rng.standard_normal((len(x[0::3]), N // 32)), 32, axis=1).astype(np.float16)   # runs of 32
+        x[1::3] = 0                                                                                         # zeros
+        x[2::3] = rng.standard_normal((len(x[2::3]), N)).astype(np.float16)                                 # incompressible
+        x[5] = 0; x[4095] = 0
+        sc, ln, rc = oracle.compress_blocks_f16(x, 2, 0)
+        want = oracle.decompress_blocks_f16(rc, ln, sc, 2, 0)
+        h = lib.alloc(n * PAGE)
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+        st0 = lib.stats()
+        assert st0.pool_bytes_in_use == n * PAGE and st0.written_pages == n and st0.sealed_allocations == 0
+        before, after = lib.compact(h)
+        packed = int(((ln.astype(np.int64) + 127) // 128 * 128).sum())
+        assert before == n * PAGE and after == packed and after < 0.45 * before
+        st1 = lib.stats()
+        assert st1.pool_bytes_in_use == packed and st1.sealed_allocations == 1 and st1.compactions == 1
+        assert st1.compressed_bytes == int(ln.astype(np.int64).sum())
+        assert lib.compact(h) == (packed, packed)                       # idempotent
+        # reads: bulk (both engines), list, single pages through the ring
+        out = torch.empty((n, N), dtype=torch.float16, device="cuda")
+        s = torch.cuda.Stream()
+        for engine in (1, 2):
+            out.fill_(float("nan"))
+            ce0 = lib.stats().copy_engine_bytes
+            lib.fetch_range(h, 0, n, out.data_ptr(), False, s.cuda_stream, engine=engine)
+            torch.cuda.synchronize()
+            assert_same_float_bits(out.cpu().numpy(), want, f"engine {engine}")
+            if engine == 2:
+                assert lib.stats().copy_engine_bytes - ce0 == packed    # record bytes crossed, not 4 KiB slots
+        out.fill_(float("nan"))
+        lib.fetch_range(h, 1001, 777, out.data_ptr(), False, s.cuda_stream, engine=2)      # a range that starts inside the stripes
+        torch.cuda.synchronize()
+        assert_same_float_bits(out[:777].cpu().numpy(), want[1001:1778], "partial range, copy engine")
+        perm = torch.from_numpy(rng.permutation(n)[:500].astype(np.int32)).cuda()
+        sub = torch.empty((500, N), dtype=torch.float16, device="cuda")
+        lib.fetch_list(h, perm.data_ptr(), 500, sub.data_ptr(), False)
+        torch.cuda.synchronize()
+        assert_same_float_bits(sub.cpu().numpy(), want[perm.cpu().numpy()], "list")
+        for p in (0, 1, 2, 5, 4095, n - 1):
+            assert dev_to_host(lib.access(h, p * PAGE, PAGE), PAGE).tobytes() == want[p].tobytes(), p
+            info = lib.translate(h, p * PAGE)
+            assert info.rec_bytes == ln[p] and dev_to_host(info.pool_addr, int(ln[p])).tobytes() == rc[p, :ln[p]].tobytes()
+        # the freed slots are really back in the pool: a second allocation of the same size fits without growing it
+        reserved = lib.stats().pool_bytes_reserved
+        h2 = lib.alloc((n * PAGE - packed) // PAGE // 4 * PAGE)
+        assert lib.stats().pool_bytes_reserved == reserved
+        lib.free(h2)
+        # a write unseals (back into slots), the rest of the data survives, and sealing again works
+        y = rng.standard_normal((16, N)).astype(np.float16)
+        lib.write(h, 300 * PAGE, y.ctypes.data, y.nbytes, False)
+        st2 = lib.stats()
+        assert st2.sealed_allocations == 0 and st2.pool_bytes_in_use == n * PAGE
+        x2 = x.copy(); x2[300:316] = y
+        sc2, ln2, rc2 = oracle.compress_blocks_f16(x2, 2, 0)
+        want2 = oracle.decompress_blocks_f16(rc2, ln2, sc2, 2, 0)
+        lib.fetch_range(h, 0, n, out.data_ptr(), False, s.cuda_stream)
+        torch.cuda.synchronize()
+        assert_same_float_bits(out.cpu().numpy(), want2, "after the write")
+        d_y = torch.from_numpy(y.view(np.int16)).cuda()
+        b2, a2 = lib.compact(h)
+        assert b2 == n * PAGE and a2 == int(((ln2.astype(np.int64) + 127) // 128 * 128).sum())
+        lib.write_async(h, 900 * PAGE, d_y.data_ptr(), y.nbytes, s.cuda_stream)             # asynchronous writes unseal too
+        torch.cuda.synchronize()
+        assert lib.stats().sealed_allocations == 0
+        lib.compact(h)
+        lib.migrate(h, 0, 64, 0)                                                             # and so does a migration
+        assert lib.stats().sealed_allocations == 0
+        lib.free(h)
+        assert lib.stats().pool_bytes_in_use == 0
+        # incompressible data: nothing to gain, nothing breaks; other schemes: a no-op
+        g = rng.standard_normal((512, N)).astype(np.float16)
+        hg = lib.alloc(512 * PAGE)
+        lib.write(hg, 0, g.ctypes.data, g.nbytes, False)
+        bg, ag = lib.compact(hg)
+        assert 0.99 * bg <= ag <= bg
+        lib.free(hg)
+        lib.set_compression_scheme(4)
+        hf = lib.alloc(64 * PAGE)
+        lib.write(hf, 0, g.ctypes.data, 64 * PAGE, False)
+        assert lib.compact(hf) == (64 * 2048, 64 * 2048) and lib.stats().sealed_allocations == 0
+    finally:
+        lib.finalize()
