@@ -408,6 +408,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         state["phase"] = "extras:flush_cfg4"
         out["extras"].update(flush_cfg4_extra(torch, pkg))
+        state["phase"] = "extras:striped_attention"
+        out["extras"].update(striped_attention_extra(torch, pkg))
     if world > 1 and os.environ.get("SPECKV_BENCH_XGMI", "1") != "0":
         state["phase"] = "xgmi"
         del src, dst
@@ -1221,6 +1223,127 @@ def predictor_extra(torch, lib):
         return {"token_predictor_top4": {"error": repr(e)}}
 
 
+def tensor_codec_extra(torch, lib, n=131072 * 256):
+    """FPGACacheEngine::compress / ::decompress with the reference's own call shape (cache_engine.cpp:40-116): ONE tensor of n
+    elements, one scale, one delta chain, one run-length stream (speckv_ext_codec_compress_tensor / _decompress_tensor).
+    n = 32 Mi fp16 elements (256 RTL tiles of 1024 x 128), N(0,1)."""
+    raw = lib.lib
+    try:
+        g = torch.Generator(device="cuda"); g.manual_seed(2001)
+        x = torch.randn(n, generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+        ws_bytes = int(raw.speckv_ext_codec_tensor_workspace_bytes(n))
+        ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device="cuda")
+        wsp = (ws.data_ptr() + 255) & ~255
+        rle = torch.empty(2 * n + 32, dtype=torch.uint8, device="cuda")
+        meta = torch.zeros(4, dtype=torch.int64, device="cuda")
+        y = torch.empty(n, dtype=torch.float16, device="cuda")
+        s = torch.cuda.Stream()
+
+        def enc():
+            assert raw.speckv_ext_codec_compress_tensor(x.data_ptr(), n, 0, rle.data_ptr(), meta.data_ptr(), meta.data_ptr() + 8, wsp, ws_bytes, 0, s.cuda_stream) == 0
+        enc(); torch.cuda.synchronize()
+        size = int(meta[0].item())
+        scale = float(meta[1:2].view(torch.float32)[0].item())
+        dws_bytes = int(raw.speckv_ext_codec_tensor_decode_workspace_bytes(size))
+        dws = torch.empty(dws_bytes + 256, dtype=torch.uint8, device="cuda")
+        dwsp = (dws.data_ptr() + 255) & ~255
+
+        def dec():
+            assert raw.speckv_ext_codec_decompress_tensor(rle.data_ptr(), size, scale, y.data_ptr(), n, 0, meta.data_ptr() + 16, dwsp, dws_bytes, 0, s.cuda_stream) == 0
+        out = {"elements": n, "compressed_bytes": size}
+        for name, fn, byt in (("compress", enc, 2 * n + size), ("decompress", dec, size + 2 * n)):
+            fn(); torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(s)
+            for _ in range(5):
+                fn()
+            b.record(s); torch.cuda.synchronize()
+            ms = a.elapsed_time(b) / 5
+            out[name] = {"ms": round(ms, 4), "algorithmic_GBps": round(byt / (ms * 1e-3) / 1e9, 1), "frac_hbm": round(byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        out["note"] = ("written for exactness and for any n, not tuned: three passes over the source (abs-max, tile summaries, emit) + a pack "
+                       "pass; the pool itself stores KV per 4 KiB block (the headline path)")
+        return {"tensor_codec_whole_tensor": out}
+    except Exception as e:
+        return {"tensor_codec_whole_tensor": {"error": repr(e)}}
+
+
+def compaction_extra(torch, kv, n_pages=131072):
+    """speckv_ext_compact on the structured data SURVEY 8(d) names (a third runs of 32, a third zeros, a third N(0,1)):
+    pool bytes before / after, i.e. the capacity the reference's scheme really buys once records are packed."""
+    lib = kv.lib
+    try:
+        lib.set_compression_scheme(2)
+        g = torch.Generator(device="cuda"); g.manual_seed(2006)
+        x = torch.randn((n_pages, BLOCK_ELEMS), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+        x[0::3] = x[0::3, :64].repeat_interleave(32, dim=1)
+        x[1::3] = 0
+        h = lib.alloc(n_pages * PAGE)
+        lib.write(h, 0, x.data_ptr(), x.numel() * 2, True)
+        t0 = time.perf_counter()
+        before, after = lib.compact(h)
+        ms = (time.perf_counter() - t0) * 1e3
+        lib.free(h)
+        return {"compaction_structured_third_each": {"pages": n_pages, "pool_bytes_before": before, "pool_bytes_after": after,
+                                                     "capacity_ratio_vs_slots": round(before / max(after, 1), 3),
+                                                     "capacity_ratio_vs_fp16": round(n_pages * PAGE / max(after, 1), 3), "ms": round(ms, 2),
+                                                     "note": "records packed back to back (128-byte aligned), slots returned to the pool"}}
+    except Exception as e:
+        return {"compaction_structured_third_each": {"error": repr(e)}}
+    finally:
+        lib.set_compression_scheme(2)
+
+
+def lstm_cell_extra(torch, lib):
+    """The real LSTM cell of the predictor (speckv_ext_predictor_load_lstm, 2 layers, 64 -> 128, vocab 32000)."""
+    try:
+        g = torch.Generator(device="cuda"); g.manual_seed(10)
+        rnd = lambda *s_: (torch.rand(s_, generator=g, device="cuda") - 0.5) * 0.2
+        emb, wout, bout = rnd(32000, 64), rnd(32000, 128), rnd(32000)
+        w_ih, w_hh, b_ih, b_hh = [rnd(512, 64), rnd(512, 128)], [rnd(512, 128), rnd(512, 128)], [rnd(512), rnd(512)], [rnd(512), rnd(512)]
+        lib.predictor_load_lstm(emb.data_ptr(), 32000, [t.data_ptr() for t in w_ih], [t.data_ptr() for t in w_hh],
+                                [t.data_ptr() for t in b_ih], [t.data_ptr() for t in b_hh], wout.data_ptr(), bout.data_ptr(), True)
+        out = {}
+        s = torch.cuda.Stream()
+        for n in (1, 256):
+            hist = torch.randint(0, 32000, (n, 16), generator=g, device="cuda", dtype=torch.int32)
+            tok = torch.empty((n, 4), dtype=torch.int32, device="cuda"); conf = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+            lib.predict_batch(n, hist.data_ptr(), 4, tok.data_ptr(), conf.data_ptr(), s.cuda_stream); torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(s)
+            for _ in range(20):
+                lib.predict_batch(n, hist.data_ptr(), 4, tok.data_ptr(), conf.data_ptr(), s.cuda_stream)
+            b.record(s); torch.cuda.synchronize()
+            out[f"batch_{n}_us"] = round(a.elapsed_time(b) / 20 * 1e3, 2)
+        return {"token_predictor_real_lstm_top4": out}
+    except Exception as e:
+        return {"token_predictor_real_lstm_top4": {"error": repr(e)}}
+
+
+def striped_attention_extra(torch, pkg, T=32768, Lyr=80):
+    """The fused attention over a pool striped across 7 pools (the 1 + 7 layout of BASELINE configs[3], here 7 same-GPU
+    pools): the striped form computes its record addresses; the page-table form is what every striped pool took before."""
+    out = {}
+    for scheme, name, fn in ((3, "int4", int4_attention_extra), (4, "fp8", fp8_scores_extra)):
+        for label, general in (("computed_addresses", False), ("page_table", True)):
+            os.environ["SPECKV_POOL_DEVICES"] = "0,0,0,0,0,0,0"
+            if general:
+                os.environ["SPECKV_ATTEND_GENERAL"] = "1"
+            try:
+                kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), f"hip:{torch.cuda.current_device()}")
+                try:
+                    r = fn(torch, kv, T, Lyr)
+                    r = r.get("int4_fused_attention") or r.get("fp8_fused_attention") or r
+                    out[f"{name}_{label}"] = {k: r.get(k) for k in ("ms_all_layers", "frac_hbm", "error") if k in r}
+                finally:
+                    kv.close()
+            except Exception as e:
+                out[f"{name}_{label}"] = {"error": repr(e)}
+            finally:
+                os.environ.pop("SPECKV_POOL_DEVICES", None)
+                os.environ.pop("SPECKV_ATTEND_GENERAL", None)
+    return {"fused_attention_striped_x7": out}
+
+
 def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     """Latency / rate of the non-bulk entry points (C ABI calls, not kernels alone)."""
     lib = kv.lib
@@ -1294,6 +1417,9 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     ex.update(connector_append_extra(torch, kv))
     ex.update(connector_decode_extra(torch, kv))
     ex.update(predictor_extra(torch, lib))
+    ex.update(lstm_cell_extra(torch, lib))
+    ex.update(compaction_extra(torch, kv))
+    ex.update(tensor_codec_extra(torch, lib))
     return ex
 
 

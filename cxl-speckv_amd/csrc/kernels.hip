@@ -1475,26 +1475,26 @@ __global__ __launch_bounds__(64) void k_lstm_hidden(const int32_t* __restrict__ 
 // cell with PyTorch's nn.LSTM conventions -- per layer  gates = W_ih x + W_hh h + b  (4 x 128 rows, order i, f, g, o),
 // c = sigmoid(f) c + sigmoid(i) tanh(g),  h = sigmoid(o) tanh(c),  h_0 = c_0 = 0, layer l > 0 fed with layer l-1's h of the
 // same time step; 16-token history, embedding width 64, hidden width 128.  Output: the top layer's last h.
-//   One workgroup = kLstmReq requests: a thread owns two of the 512 gate rows and computes them for all requests of the
+//   One workgroup = kLstmReq requests: a thread owns one of the 512 gate rows and computes it for all requests of the
 //   workgroup, so a weight row is read once per step for the whole group (weights: 0.9 MB for two layers, L2-resident).
 //   The cell state and the layer inputs live in LDS.
 struct LstmWeights { const float* w_ih[4]; const float* w_hh[4]; const float* bias[4]; uint32_t layers; };   // bias = b_ih + b_hh
 constexpr uint32_t kLstmReq = 8;
 __device__ __forceinline__ float sigmoidf_dev(float x) { return 1.0f / (1.0f + expf(-x)); }
-__global__ __launch_bounds__(256) void k_lstm_cell(const int32_t* __restrict__ hist, uint32_t n, const float* __restrict__ emb, uint32_t vocab,
+__global__ __launch_bounds__(512) void k_lstm_cell(const int32_t* __restrict__ hist, uint32_t n, const float* __restrict__ emb, uint32_t vocab,
                                                   LstmWeights w, float* __restrict__ hid)
 {
-    __shared__ float xin[kLstmReq][kPredHidden + kPredHidden];           // [request][input of the layer | its own h]
+    __shared__ __attribute__((aligned(16))) float xin[kLstmReq][kPredHidden + kPredHidden];   // [request][input of the layer | its own h]
     __shared__ float hs[4][kLstmReq][kPredHidden], cs[4][kLstmReq][kPredHidden];
     __shared__ float gates[kLstmReq][4 * kPredHidden];
-    const uint32_t tid = threadIdx.x, r0 = blockIdx.x * kLstmReq;
-    for (uint32_t i = tid; i < 4u * kLstmReq * kPredHidden; i += 256u) { (&hs[0][0][0])[i] = 0.0f; (&cs[0][0][0])[i] = 0.0f; }
+    const uint32_t tid = threadIdx.x, r0 = blockIdx.x * kLstmReq;     // thread = one of the 512 gate rows
+    for (uint32_t i = tid; i < 4u * kLstmReq * kPredHidden; i += 512u) { (&hs[0][0][0])[i] = 0.0f; (&cs[0][0][0])[i] = 0.0f; }
     __syncthreads();
     for (uint32_t t = 0; t < kPredHist; ++t) {
         for (uint32_t l = 0; l < w.layers; ++l) {
             const uint32_t in_dim = l == 0 ? kPredEmb : kPredHidden, cols = in_dim + kPredHidden;
             // stage [x | h_{t-1}] of every request
-            for (uint32_t i = tid; i < kLstmReq * cols; i += 256u) {
+            for (uint32_t i = tid; i < kLstmReq * cols; i += 512u) {
                 const uint32_t r = i / cols, j = i % cols;
                 float v;
                 if (j >= in_dim) v = hs[l][r][j - in_dim];
@@ -1506,36 +1506,34 @@ __global__ __launch_bounds__(256) void k_lstm_cell(const int32_t* __restrict__ h
                 xin[r][j] = v;
             }
             __syncthreads();
-#pragma unroll 1
-            for (uint32_t half = 0; half < 2u; ++half) {
-                const uint32_t row = tid + 256u * half;
+            {
+                const uint32_t row = tid;
                 const float* wi = w.w_ih[l] + static_cast<uint64_t>(row) * in_dim;
                 const float* wh = w.w_hh[l] + static_cast<uint64_t>(row) * kPredHidden;
                 float acc[kLstmReq];
                 const float b = w.bias[l][row];
 #pragma unroll
                 for (uint32_t r = 0; r < kLstmReq; ++r) acc[r] = b;
-                for (uint32_t j = 0; j < in_dim; j += 4u) {
-                    const float4 wv = *reinterpret_cast<const float4*>(wi + j);
+                // the row's weights, 16 floats (four independent 16-byte loads) per step; the additions keep the order j ascending
+                auto dot16 = [&](const float* wrow, uint32_t xoff, uint32_t j) {
+                    float4 wv[4];
 #pragma unroll
-                    for (uint32_t r = 0; r < kLstmReq; ++r) {
-                        const float4 xv = *reinterpret_cast<const float4*>(&xin[r][j]);
-                        acc[r] += wv.x * xv.x; acc[r] += wv.y * xv.y; acc[r] += wv.z * xv.z; acc[r] += wv.w * xv.w;
-                    }
-                }
-                for (uint32_t j = 0; j < kPredHidden; j += 4u) {
-                    const float4 wv = *reinterpret_cast<const float4*>(wh + j);
+                    for (int q = 0; q < 4; ++q) wv[q] = *reinterpret_cast<const float4*>(wrow + j + 4 * q);
 #pragma unroll
-                    for (uint32_t r = 0; r < kLstmReq; ++r) {
-                        const float4 xv = *reinterpret_cast<const float4*>(&xin[r][in_dim + j]);
-                        acc[r] += wv.x * xv.x; acc[r] += wv.y * xv.y; acc[r] += wv.z * xv.z; acc[r] += wv.w * xv.w;
-                    }
-                }
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (uint32_t r = 0; r < kLstmReq; ++r) {
+                            const float4 xv = *reinterpret_cast<const float4*>(&xin[r][xoff + j + 4 * q]);
+                            acc[r] += wv[q].x * xv.x; acc[r] += wv[q].y * xv.y; acc[r] += wv[q].z * xv.z; acc[r] += wv[q].w * xv.w;
+                        }
+                };
+                for (uint32_t j = 0; j < in_dim; j += 16u) dot16(wi, 0u, j);
+                for (uint32_t j = 0; j < kPredHidden; j += 16u) dot16(wh, in_dim, j);
 #pragma unroll
                 for (uint32_t r = 0; r < kLstmReq; ++r) gates[r][row] = acc[r];
             }
             __syncthreads();
-            for (uint32_t i = tid; i < kLstmReq * kPredHidden; i += 256u) {
+            for (uint32_t i = tid; i < kLstmReq * kPredHidden; i += 512u) {
                 const uint32_t r = i / kPredHidden, u = i % kPredHidden;
                 const float gi = sigmoidf_dev(gates[r][u]), gf = sigmoidf_dev(gates[r][kPredHidden + u]);
                 const float gg = tanhf(gates[r][2u * kPredHidden + u]), go = sigmoidf_dev(gates[r][3u * kPredHidden + u]);
@@ -1546,7 +1544,7 @@ __global__ __launch_bounds__(256) void k_lstm_cell(const int32_t* __restrict__ h
             __syncthreads();
         }
     }
-    for (uint32_t i = tid; i < kLstmReq * kPredHidden; i += 256u) {
+    for (uint32_t i = tid; i < kLstmReq * kPredHidden; i += 512u) {
         const uint32_t r = i / kPredHidden, u = i % kPredHidden;
         if (r0 + r < n) hid[static_cast<uint64_t>(r0 + r) * kPredHidden + u] = hs[w.layers - 1u][r][u];
     }
@@ -1973,7 +1971,7 @@ hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb,
         LstmWeights w{};
         w.layers = lstm->layers;
         for (uint32_t l = 0; l < lstm->layers; ++l) { w.w_ih[l] = lstm->w_ih[l]; w.w_hh[l] = lstm->w_hh[l]; w.bias[l] = lstm->bias[l]; }
-        hipLaunchKernelGGL(k_lstm_cell, dim3((n + kLstmReq - 1u) / kLstmReq), dim3(256), 0, s, d_hist, n, d_emb, vocab, w, d_hid);
+        hipLaunchKernelGGL(k_lstm_cell, dim3((n + kLstmReq - 1u) / kLstmReq), dim3(512), 0, s, d_hist, n, d_emb, vocab, w, d_hid);
     } else {
         hipLaunchKernelGGL(k_lstm_hidden, dim3(n), dim3(64), 0, s, d_hist, n, d_emb, vocab, layers, d_hid);
     }

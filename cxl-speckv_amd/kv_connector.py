@@ -83,6 +83,12 @@ class SpeckvKVConnector:
         self._plan_bound = 0
         self._fold_rows = self._fold_k = self._fold_v = None
         self._fold_n = 0
+        # host-side bookkeeping of a decode loop is per STEP, not per layer: `_epoch` moves whenever a length or the set of
+        # requests changes, and everything derived from (batch, lengths) -- the attention plan, the fold rows, the ctypes
+        # arrays of a batched append -- is keyed by (the caller's id sequence, epoch) instead of rebuilding 256-element tuples
+        # for every layer (that alone was ~20 us per attend() call)
+        self._epoch = 0
+        self._batch_cache = {}
 
     # The library takes a hipStream_t and reads NULL as "the engine's own stream".  torch's default stream IS the NULL
     # stream, so work issued from it goes through a side stream that is ordered after it and that it then waits for.
@@ -122,10 +128,14 @@ class SpeckvKVConnector:
         self.lib.set_layout(h, self.T, self.L, self.H, self.D, 2)
         self.lib.bind_request(req_id, h, 0)
         self.requests[req_id] = _Request(h)
+        self._epoch += 1
+        self._batch_cache.clear()
         return h
 
     def free_request(self, req_id: int):
         r = self.requests.pop(req_id)
+        self._epoch += 1
+        self._batch_cache.clear()
         if req_id in self._tail_ids:
             self._tail_ids, self._tail_k, self._tail_v = (), None, None
         self._arg_key = self._fold_key = None                 # a plan names record addresses: plan again
@@ -136,6 +146,18 @@ class SpeckvKVConnector:
 
     def _page(self, layer: int, kind: int, pos: int) -> int:
         return ((layer * 2 + kind) * self.T + pos) // 2
+
+    def _batch(self, req_ids):
+        """Per-batch constants (the request objects, their handles as a ctypes array), cached by the id sequence."""
+        import ctypes
+        key = tuple(req_ids)
+        b = self._batch_cache.get(key)
+        if b is None:
+            if len(self._batch_cache) > 16:
+                self._batch_cache.clear()
+            reqs = [self.requests[r] for r in req_ids]
+            b = self._batch_cache[key] = (key, reqs, (ctypes.c_uint64 * len(reqs))(*[r.handle for r in reqs]))
+        return b
 
     # ------------------------------------------------------------------ writes
     def write_prefill(self, req_id: int, k, v, stream=None):
@@ -157,6 +179,7 @@ class SpeckvKVConnector:
         if n & 1:
             r.set_tail(k[:, n - 1].contiguous().clone(), v[:, n - 1].contiguous().clone())
         r.length = n
+        self._epoch += 1
         return [k, v]
 
     def append(self, req_ids: Sequence[int], k_new, v_new, stream=None):
@@ -193,9 +216,13 @@ class SpeckvKVConnector:
                     self.lib.write_strided(reqs[0].handle, self._page(0, 0, reqs[0].length - 1), self.region_pages, 2 * self.L,
                                            pair.data_ptr(), st.cuda_stream)
                 else:
-                    self.lib.write_strided_batch([r.handle for r in reqs], [self._page(0, 0, r.length - 1) for r in reqs],
-                                                 [pair.data_ptr() + i * step_bytes for i in range(len(reqs))],
-                                                 self.region_pages, 2 * self.L, st.cuda_stream)
+                    import ctypes
+                    import numpy as np
+                    n_ = len(reqs)
+                    handles = self._batch(req_ids)[2] if whole else [r.handle for r in reqs]
+                    firsts = np.fromiter((r.length - 1 for r in reqs), dtype=np.uint64, count=n_) // 2       # _page(0, 0, pos) = pos // 2
+                    srcs = np.arange(n_, dtype=np.uint64) * np.uint64(step_bytes) + np.uint64(pair.data_ptr())
+                    self.lib.write_strided_batch(handles, firsts, srcs, self.region_pages, 2 * self.L, st.cuda_stream)
             for r in reqs:
                 r.clear_tail()
             self._tail_ids, self._tail_k, self._tail_v = (), None, None
@@ -211,6 +238,7 @@ class SpeckvKVConnector:
             self._tail_ids, self._tail_k, self._tail_v = tuple(req_ids[b] for b in tail_b), tk, tv
         for rid in req_ids:
             self.requests[rid].length += 1
+        self._epoch += 1
         return keep                                            # sources of the asynchronous writes: hold until the stream passed them
 
     # ------------------------------------------------------------------ reads
@@ -255,16 +283,15 @@ class SpeckvKVConnector:
         replays captured per-layer calls runs it before every replay.  Returns the length bound the launches are sized for."""
         import ctypes
         import torch
-        reqs = [self.requests[r] for r in req_ids]
+        key, reqs, handles = self._batch(req_ids)
         B = len(reqs)
         lens = [r.length & ~1 for r in reqs]
         bound = min(self.T, max(self.PLAN_BUCKET, (max(lens) + self.PLAN_BUCKET - 1) // self.PLAN_BUCKET * self.PLAN_BUCKET))
         need = self.lib.attend_plan_bytes(B)
         if self._plan is None or self._plan.numel() < need:
             self._plan = torch.zeros(need, dtype=torch.uint8, device="cuda")
-        handles = (ctypes.c_uint64 * B)(*[r.handle for r in reqs])
         self.lib.attend_batch_plan(handles, (ctypes.c_uint32 * B)(*lens), bound, self._plan.data_ptr(), need, stream.cuda_stream)
-        self._arg_key = ((tuple(req_ids), tuple(r.length for r in reqs)), stream.cuda_stream)
+        self._arg_key = ((key, self._epoch), stream.cuda_stream)
         self._plan_bound = bound
         return bound
 
@@ -276,7 +303,7 @@ class SpeckvKVConnector:
         if self.scheme not in (3, 4):
             raise ValueError("attend() needs an FP8 or INT4 pool; use block_table() / kv_rows() with the other schemes")
         B, H, G, D = q.shape
-        reqs = [self.requests[r] for r in req_ids]
+        key, reqs, _ = self._batch(req_ids)
         q = q.contiguous()
         out = torch.empty((B, H, G, D), dtype=torch.float32, device="cuda")
         lse = torch.empty((B, H, G), dtype=torch.float32, device="cuda")
@@ -284,7 +311,7 @@ class SpeckvKVConnector:
         # device), then one launch-only call per layer (speckv_ext_attend_*_planned).  The length bound moves in steps of
         # PLAN_BUCKET positions, so a caller that captures its per-layer calls into a HIP graph can replay that graph for
         # PLAN_BUCKET decode steps (plan_step() outside the graph, then the replay).
-        akey = (tuple(req_ids), tuple(r.length for r in reqs))
+        akey = (key, self._epoch)
         with self._On(self, stream) as st:
             if self._arg_key != (akey, st.cuda_stream):
                 self.plan_step(req_ids, st)

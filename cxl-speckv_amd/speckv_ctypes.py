@@ -227,9 +227,8 @@ class SpeckvLib:
     def write_strided_batch(self, handles, first_pages, d_srcs, page_step, n_pages_each, stream):
         """One launch for a batch of allocations: handles[i] gets pages first_pages[i] + j*page_step from d_srcs[i] + j*4096."""
         n = len(handles)
-        hs = (c_uint64 * n)(*handles)
-        fs = (c_uint64 * n)(*first_pages)
-        ps = (c_void_p * n)(*d_srcs)
+        as_arr = lambda v, t: v if isinstance(v, ctypes.Array) else (c_void_p(v.ctypes.data) if hasattr(v, "ctypes") else (t * n)(*v))
+        hs, fs, ps = as_arr(handles, c_uint64), as_arr(first_pages, c_uint64), as_arr(d_srcs, c_void_p)     # numpy uint64 arrays pass as they are
         self._ext("speckv_ext_write_strided_batch", hs, fs, ps, n, page_step, n_pages_each, c_void_p(stream))
 
     def write_async(self, handle, offset, d_src, nbytes, stream):
