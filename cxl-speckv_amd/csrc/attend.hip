@@ -345,10 +345,6 @@ template <bool STRIPED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_attend_fp8_linear(AttendArgs a)
 {
     __shared__ uint64_t s_bases[8];
-    if (STRIPED) {
-        if (threadIdx.x < 8u) s_bases[threadIdx.x] = a.stripe_bases[threadIdx.x];
-        __syncthreads();
-    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t c = lane & 15u, kb = lane >> 4;
@@ -359,7 +355,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;  // query / output row block
     uint64_t part = row * a.n_splits + split;
     uint32_t my_splits = a.n_splits;
-    if (a.seqs) {                                                        // wave-uniform: per-sequence geometry
+    if (a.seqs) {                                                        // workgroup-uniform: per-sequence geometry
         const AttendSeq sq = a.seqs[layer];
         if (split >= sq.n_splits) {
             if (sq.n_splits == 0u && split == 0u && a.direct_out && a.direct_per_seq == 2u) attend_zero_rows(a.direct_out, a.direct_lse, a.g, row, lane);
@@ -376,6 +372,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         my_splits = sq.n_splits;
         part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
         layer = 0;
+        if (STRIPED) {                                                   // the sequence's own placement
+            a.stripe_bases = sq.stripe_bases;
+            a.stripe_n = sq.stripe_n;
+            a.stripe_magic = sq.stripe_n > 1u ? static_cast<uint32_t>((1ull << 32) / sq.stripe_n + 1u) : 0u;
+        }
+    }
+    if (STRIPED) {
+        if (threadIdx.x < 8u) s_bases[threadIdx.x] = a.stripe_bases[threadIdx.x];
+        __syncthreads();
     }
 
     // query operand: row c of this head, d = 32kb + 8*step + e, quantised here exactly as k_quantize_q_e4m3 does
@@ -1077,8 +1082,9 @@ hipError_t launch_attend_fp8_batch(const AttendArgs& a, uint32_t n_seq, float* d
     // with the LDS-DMA kernel (many short splits: 4 waves/SIMD hide more than two tiles per wave at 2 waves/SIMD); the
     // single-sequence form below is the other way round (8k x 80 layers: 0.61 against 0.55; 32k x 80: 0.70 both)
     static const int forced = [] { const char* e = getenv("SPECKV_FP8_BATCH_KERNEL"); return e ? (e[0] == 'd' ? 1 : 2) : 0; }();
-    const bool dma = forced ? forced == 1 : false;
+    const bool dma = (forced ? forced == 1 : false) && !a.stripe_bases;
     if (dma) hipLaunchKernelGGL(k_attend_fp8_dma, dim3(a.n_splits, n_seq * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
+    else if (a.stripe_bases) hipLaunchKernelGGL(k_attend_fp8_linear<true>, dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
     else     hipLaunchKernelGGL(k_attend_fp8_linear<false>, dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || (a.direct_out && a.direct_per_seq != 1u)) return e;      // every row final: no merge

@@ -494,10 +494,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
     static_assert(kWgHeads == 4, "the cooperative kernel is laid out for 4 heads per workgroup");
     __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kWgBuf];
     __shared__ uint64_t s_bases[8];
-    if (STRIPED) {
-        if (threadIdx.x < 8u) s_bases[threadIdx.x] = a.stripe_bases[threadIdx.x];
-        __syncthreads();
-    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t c = lane & 15u, kb = lane >> 4;
@@ -525,6 +521,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
         my_splits = sq.n_splits;
         part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
         layer = 0;
+        if (STRIPED) {                                                   // the sequence's own placement
+            a.stripe_bases = sq.stripe_bases;
+            a.stripe_n = sq.stripe_n;
+            a.stripe_magic = sq.stripe_n > 1u ? static_cast<uint32_t>((1ull << 32) / sq.stripe_n + 1u) : 0u;
+        }
+    }
+    if (STRIPED) {
+        if (threadIdx.x < 8u) s_bases[threadIdx.x] = a.stripe_bases[threadIdx.x];
+        __syncthreads();
     }
 
     f16x8 qv[4];

@@ -463,9 +463,8 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
                         ok = hipMemset(ex.base, 0, ex.bytes) == hipSuccess;
                     }
                 }
-                if (ok && single_run) {
-                    a->linear_base = static_cast<uint8_t*>(a->extents[0].base);
-                } else if (ok && D >= 2) {
+                if (ok && single_run) a->linear_base = static_cast<uint8_t*>(a->extents[0].base);
+                if (ok) {                          // run bases for the striped form (D = 1: the single run, so that a batch may mix both)
                     uint64_t bases[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                     for (uint32_t k = 0; k < D; ++k) bases[k] = reinterpret_cast<uint64_t>(a->extents[k].base);   // extents[k] = the run of residue k
                     ok = hipMalloc(reinterpret_cast<void**>(&a->d_stripe), sizeof(bases)) == hipSuccess &&
@@ -2225,7 +2224,7 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
                       static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
     const uint8_t* lin_base = (getenv("SPECKV_ATTEND_GENERAL") || !fits) ? nullptr : a->linear_base;
     // regular striping over several pools: the same kernel with computed record addresses (no page-table chase)
-    const bool striped = !lin_base && fits && a->stripe_n && !getenv("SPECKV_ATTEND_GENERAL");
+    const bool striped = !lin_base && fits && a->stripe_n >= 2 && !getenv("SPECKV_ATTEND_GENERAL");
     // (the page-table form has nothing to gain from whole rows: it hides its look-ups behind other waves and always
     // goes through the merge -- 80 layers x 8k: one split 0.13 of HBM peak, eight 0.18+)
     uint32_t want = (lin_base && rows / 4u >= 128u && n_tiles < 768u) ? 1u : (5120u + rows - 1u) / rows;     // (32k and beyond: 8 splits, below)
@@ -2316,6 +2315,7 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     std::vector<AttendSeq> seqs(n_seq);
     uint64_t total_tiles = 0;
     uint32_t heads = 0;
+    bool any_striped = false;                 // then the whole launch takes the striped kernels (a single run is "striped over 1")
     for (uint32_t i = 0; i < n_seq; ++i) {
         Allocation* a = find(handles[i]);
         if (!a) return SPECKV_ERR_GENERAL;
@@ -2324,14 +2324,17 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
         if (L.head_dim != 128 || L.bytes_per_element != 2 || L.num_heads * L.head_dim != 1024 || L.num_tokens % 2) return SPECKV_ERR_INVAL;
         if (layer >= L.num_layers || pos_end[i] % 2 || pos_end[i] > L.num_tokens) return SPECKV_ERR_INVAL;
         const uint32_t n_pages = pos_end[i] / 2, n_tiles = (n_pages + 15u) / 16u;
-        if (!a->linear_base || (fp8 && !a->d_scale_tab) || static_cast<uint64_t>(n_tiles) * 32u > L.num_tokens) {
-            SPECKV_ERR("speckv_ext_attend_*_batch: sequence %u does not qualify for the linear form "
-                       "(records in one local run, pos_end rounded up to 32 inside the layer%s)", i,
-                       fp8 ? ", layout with num_tokens %% 32 == 0" : "");
+        if (!a->stripe_n || (fp8 && !a->d_scale_tab) || static_cast<uint64_t>(n_tiles) * 32u > L.num_tokens) {
+            SPECKV_ERR("speckv_ext_attend_*_batch: sequence %u does not qualify for the arithmetic-address forms "
+                       "(records in one run or striped regularly over up to 8 pools -- not after a migration --, pos_end rounded up "
+                       "to 32 inside the layer%s)", i, fp8 ? ", layout with num_tokens %% 32 == 0" : "");
             return SPECKV_ERR_INVAL;
         }
         heads = L.num_heads;
         note_use(a, s);
+        any_striped = any_striped || !a->linear_base;
+        seqs[i].stripe_bases = a->d_stripe;
+        seqs[i].stripe_n = a->stripe_n;
         seqs[i].lin_base = a->linear_base;
         seqs[i].scale_tab = a->d_scale_tab;
         seqs[i].k_first = static_cast<uint64_t>(layer) * L.num_tokens;       // (layer*2*T)/2
@@ -2403,7 +2406,8 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     k.q16 = static_cast<const uint16_t*>(d_q_f16);
     k.q8 = static_cast<const uint8_t*>(d_q_f16);          // the INT4 kernel reads the fp16 query through q8
     k.scale_log2e = sm_scale * 1.4426950408889634f;
-    k.lin_base = seqs[0].lin_base;           // (overridden per sequence)
+    k.lin_base = any_striped ? nullptr : seqs[0].lin_base;           // (overridden per sequence)
+    if (any_striped) k.stripe_bases = seqs[0].stripe_bases;          // marks a striped launch (each sequence brings its own table)
     k.seqs = d_seqs;
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
@@ -2445,6 +2449,7 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
     if (is_capturing(s)) return SPECKV_ERR_INVAL;            // the plan is what changes between replays: it stays outside the graph
     std::vector<AttendSeq> seqs(n_seq);
     int scheme = -1;
+    bool any_striped = false;
     uint32_t heads = 0, min_layers = UINT32_MAX;
     for (uint32_t i = 0; i < n_seq; ++i) {
         Allocation* a = find(handles[i]);
@@ -2456,10 +2461,13 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
         if (pos_end[i] % 2 || pos_end[i] > L.num_tokens || pos_end[i] > max_pos_end) return SPECKV_ERR_INVAL;
         const uint32_t n_pages = pos_end[i] / 2, n_tiles = (n_pages + 15u) / 16u;
         const bool fp8 = scheme == SPECKV_COMP_FP8_E4M3;
-        if (!a->linear_base || (fp8 && !a->d_scale_tab) || static_cast<uint64_t>(n_tiles) * 32u > L.num_tokens) return SPECKV_ERR_INVAL;
+        if (!a->stripe_n || (fp8 && !a->d_scale_tab) || static_cast<uint64_t>(n_tiles) * 32u > L.num_tokens) return SPECKV_ERR_INVAL;
         min_layers = std::min(min_layers, L.num_layers);
         heads = L.num_heads;
         note_use(a, s);
+        any_striped = any_striped || !a->linear_base;
+        seqs[i].stripe_bases = a->d_stripe;
+        seqs[i].stripe_n = a->stripe_n;
         seqs[i].lin_base = a->linear_base;
         seqs[i].scale_tab = a->d_scale_tab;
         seqs[i].k_first = 0;                                   // layer 0; the launch adds layer * layer_pages
@@ -2471,7 +2479,7 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
     const PlanGeometry g = plan_geometry(scheme == SPECKV_COMP_FP8_E4M3, n_seq, heads, max_pos_end);
     if (g.max_splits > 2048u) return SPECKV_ERR_INVAL;
     if (plans_.size() >= 64 && !plans_.count(d_plan)) plans_.clear();        // (buffers of long-gone steps)
-    plans_[d_plan] = PlanInfo{n_seq, scheme, min_layers, max_pos_end};
+    plans_[d_plan] = PlanInfo{n_seq, scheme, min_layers, max_pos_end, any_striped};
     uint64_t parts = 0;
     for (uint32_t i = 0; i < n_seq; ++i) {
         const uint32_t n_tiles = seqs[i].n_splits;
@@ -2528,7 +2536,8 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
     k.q16 = static_cast<const uint16_t*>(d_q_f16);
     k.q8 = static_cast<const uint8_t*>(d_q_f16);
     k.scale_log2e = sm_scale * 1.4426950408889634f;
-    k.lin_base = reinterpret_cast<const uint8_t*>(1);          // non-null: linear form (the real base comes from the descriptor)
+    if (plan->second.striped) k.stripe_bases = reinterpret_cast<const uint64_t*>(1);     // striped launch: every descriptor brings its table
+    else k.lin_base = reinterpret_cast<const uint8_t*>(1);     // non-null: linear form (the real base comes from the descriptor)
     k.seqs = static_cast<const AttendSeq*>(d_plan);
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
@@ -2596,7 +2605,7 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     // page-table form of the same kernel
     const bool fits = static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
     const bool linear = a->linear_base && fits && !getenv("SPECKV_ATTEND_GENERAL");
-    const bool striped = !linear && a->stripe_n && fits && !getenv("SPECKV_ATTEND_GENERAL");
+    const bool striped = !linear && a->stripe_n >= 2 && fits && !getenv("SPECKV_ATTEND_GENERAL");
     if (!linear && !d_zero_page_) {
         if (is_capturing(s)) return SPECKV_ERR_INVAL;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));

@@ -218,9 +218,9 @@ struct AttendSeq {
     uint32_t n_splits;                // ceil(tiles / tiles_per_split), <= gridDim.x
     uint32_t part_base;
     uint32_t tiles_per_split;         // this sequence's own split length (its tiles divided evenly over n_splits)
-    uint64_t reserved;
+    const uint64_t* stripe_bases;     // striped launches (AttendArgs::stripe_bases set): the sequence's own run bases ...
     uint32_t layer_pages;             // pages of one layer (K + V): layer l of a planned batch starts at k_first + l * layer_pages
-    uint32_t pad;
+    uint32_t stripe_n;                // ... and pool count (1 = a single run: lin_base is bases[0])
 };
 
 // Decode attention straight from FP8_E4M3 records (attend.hip): softmax(q.K^T * sm_scale) . V per kv head,
@@ -257,6 +257,7 @@ struct AttendArgs {
     // 2..8 pools -- the record of page p is stripe_bases[p % stripe_n] + (p / stripe_n) * record stride (placement.hpp),
     // never-written records zero bytes -- so every address is arithmetic here too; stripe_magic = floor(2^32 / n) + 1:
     // __umulhi(p, magic) == p / n for every p < 2^28.  The 8 run bases live in a small device array of the allocation.
+    // Batch form: non-null marks a striped launch, every AttendSeq then carries its own stripe_bases / stripe_n.
     const uint64_t* stripe_bases;
     uint32_t stripe_n, stripe_magic;
 };
@@ -264,7 +265,7 @@ struct AttendArgs {
 // record address of page p in the striped form; `bases` = the allocation's run bases copied to LDS
 __device__ __forceinline__ const uint8_t* attend_stripe_rec(const uint64_t* bases, uint32_t p, uint32_t n, uint32_t magic, uint32_t stride)
 {
-    const uint32_t q = __umulhi(p, magic);
+    const uint32_t q = n == 1u ? p : __umulhi(p, magic);              // (n is uniform: batches may mix single-run and striped sequences)
     return reinterpret_cast<const uint8_t*>(bases[p - q * n]) + static_cast<uint64_t>(q) * stride;
 }
 #endif

@@ -505,3 +505,64 @@ def test_compaction_packs_rle_records_and_frees_the_slots(oracle, pools):
         assert lib.compact(hf) == (64 * 2048, 64 * 2048) and lib.stats().sealed_allocations == 0
     finally:
         lib.finalize()
+
+
+@pytest.mark.parametrize("scheme", [3, 4])
+def test_batch_and_planned_attention_over_striped_pools(scheme):
+    """A decode step of a batch whose sequences live in striped pools (the 1 + 7 layout of configs[3]): the batch and the
+    planned forms used to refuse anything but single-run allocations.  Each sequence descriptor now carries its own run
+    bases, so one launch serves striped sequences and single-run ones (placed on one pool with preferred_node) alike;
+    results against the per-sequence entry point (same kernel family, other split boundaries: 1e-3 of the row scale)."""
+    torch = torch_mod()
+    lib = open_lib(SPECKV_POOL_DEVICES="0,0,0,0,0,0,0")
+    try:
+        lib.set_compression_scheme(scheme)
+        T, L, H, D, G = 1024, 2, 8, 128, 8
+        n_pages = T * L * H * D * 2 * 2 // PAGE
+        rng = np.random.default_rng(600 + scheme)
+        lens = [1024, 514, 0, 66, 1000, 32]
+        handles = []
+        for i, n in enumerate(lens):
+            h = lib.alloc(n_pages * PAGE, preferred_node=(3 if i % 3 == 1 else 0))       # every third sequence: one run on pool 3
+            lib.set_layout(h, T, L, H, D, 2)
+            x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.3, 2.0, (n_pages, 1))).astype(np.float16)
+            lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+            handles.append(h)
+        assert lib.translate(handles[0], 0).pool_addr != lib.translate(handles[0], PAGE).pool_addr - (2048 if scheme == 4 else 1152)
+        q = torch.from_numpy(rng.standard_normal((len(lens), H, G, D)).astype(np.float16)).cuda()
+        sm = 1.0 / np.sqrt(D)
+        single = lib.attend_int4 if scheme == 3 else lib.attend_fp8
+        batch = lib.attend_int4_batch if scheme == 3 else lib.attend_fp8_batch
+        st = torch.cuda.Stream()
+        for layer in (0, 1):
+            ref = torch.zeros((len(lens), H, G, D), dtype=torch.float32, device="cuda")
+            ref_lse = torch.full((len(lens), H, G), float("-inf"), dtype=torch.float32, device="cuda")
+            for i, (h, n) in enumerate(zip(handles, lens)):
+                if n:
+                    single(h, layer, 1, q[i].data_ptr(), G, 0, n, sm, ref[i].data_ptr(), ref_lse[i].data_ptr())
+            torch.cuda.synchronize()
+            out = torch.full((len(lens), H, G, D), float("nan"), dtype=torch.float32, device="cuda")
+            lse = torch.full((len(lens), H, G), float("nan"), dtype=torch.float32, device="cuda")
+            batch(handles, layer, q.data_ptr(), G, lens, sm, out.data_ptr(), lse.data_ptr())
+            torch.cuda.synchronize()
+            plan_bytes = lib.attend_plan_bytes(len(lens))
+            d_plan = torch.empty(plan_bytes, dtype=torch.uint8, device="cuda")
+            out2 = torch.full_like(out, float("nan")); lse2 = torch.full_like(lse, float("nan"))
+            torch.cuda.synchronize()
+            lib.attend_batch_plan(handles, lens, T, d_plan.data_ptr(), plan_bytes, st.cuda_stream)
+            lib.attend_planned(scheme, d_plan.data_ptr(), len(lens), layer, q.data_ptr(), G, T, sm, out2.data_ptr(), lse2.data_ptr(), st.cuda_stream)
+            torch.cuda.synchronize()
+            for got, got_lse, what in ((out, lse, "batch"), (out2, lse2, "planned")):
+                for i, n in enumerate(lens):
+                    if n == 0:
+                        assert float(got[i].abs().max()) == 0.0
+                        continue
+                    scale = float(ref[i].abs().max()) + 1e-6
+                    assert float((got[i] - ref[i]).abs().max()) <= 1e-3 * scale, (what, layer, i)
+                    assert float((got_lse[i] - ref_lse[i]).abs().max()) <= 2e-4, (what, layer, i)
+        # a migrated sequence no longer has an arithmetic placement: the batch call says so instead of reading wrong records
+        lib.migrate(handles[0], 4, 8, 2)
+        with pytest.raises(SpeckvError):
+            batch(handles, 0, q.data_ptr(), G, lens, sm, out.data_ptr(), lse.data_ptr())
+    finally:
+        lib.finalize()
