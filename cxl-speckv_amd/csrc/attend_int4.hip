@@ -454,10 +454,16 @@ __device__ __forceinline__ void dma16v(uint32_t lds_dst, const uint8_t* addr)
 }
 
 // this wave's 5 DMAs of the current tile have landed (the 5 of the next tile may still be in flight); then everybody's
+// (SPECKV_ABL_* macros: timing-only ablation builds, results are garbage -- profiles/tools/int4_ablate.sh)
+#ifdef SPECKV_ABL_NO_BARRIER
+#define SPECKV_WG_BARRIER ""
+#else
+#define SPECKV_WG_BARRIER "\n\ts_barrier"
+#endif
 __device__ __forceinline__ void wg_landed(bool is_last)
 {
-    if (is_last) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    else         asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+    if (is_last) asm volatile("s_waitcnt vmcnt(0)" SPECKV_WG_BARRIER ::: "memory");
+    else         asm volatile("s_waitcnt vmcnt(5)" SPECKV_WG_BARRIER ::: "memory");
 }
 __device__ __forceinline__ void wg_take_k(uint32_t rd, uint32_t rs, u32x4& k0, u32x4& k1, uint32_t& s0, uint32_t& s1)
 {
@@ -616,7 +622,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
             wg_landed(tile == last);
             u32x4 k0, k1;
             uint32_t ks0, ks1;
+#ifdef SPECKV_ABL_NO_LDSREAD
+            k0 = u32x4{tile, lane, 3u, 4u}; k1 = u32x4{lane, tile, 7u, 8u}; ks0 = 0x3C00u; ks1 = 0x3C00u;
+#else
             wg_take_k(rdk + bo, rsk + bo, k0, k1, ks0, ks1);
+#endif
             float sc[8];
             {
                 const f32x4 s0 = score_block(make_uint4(k0.x, k0.y, k0.z, k0.w), ks0, qv);
@@ -634,8 +644,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
             const f16x8 P = softmax_tile(sc, qscale, m_run, l_run, acc);
             uint32_t vw[8], vs16[8];
             const uint32_t rdvb[4] = {rdv[0] + bo, rdv[1] + bo, rdv[2] + bo, rdv[3] + bo};
+#ifdef SPECKV_ABL_NO_LDSREAD
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { vw[j] = tile + j + lane; vs16[j] = 0x3C00u; }
+            (void)rdvb;
+#else
             wg_take_v(rdvb, rsv + bo, vw, vs16);
+#endif
+#ifndef SPECKV_ABL_NO_BARRIER
             asm volatile("s_barrier" ::: "memory");                       // every wave has taken what it needs from this buffer
+#endif
             if (tile + 2u <= last) issue(tile + 2u, buf);                 // (taking V earlier, to issue earlier, measured the same)
             pv_tile(vw, vs16, P, acc);
         }
