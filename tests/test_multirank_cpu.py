@@ -146,6 +146,34 @@ def test_remote_mode_pool_lists():
         assert all(bench.pool_devices_for(m, r, world) is None for m in ("cfg3", "cfg4") for r in range(1, world))
 
 
+def test_remote_working_set_rule_and_roofline_object():
+    """the remote working set must exceed the pool GPU's 256 MiB Infinity Cache by >= 10x, and the rank-0 line
+    carries the remote roofline as a first-class object (pure functions of bench.py, no GPU needed)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    set_bytes = 131072 * 4096                                   # the 8B-shaped set, 512 MiB of fp16
+    for links in (1, 3, 7):
+        n = bench.xgmi_sets_for(links, set_bytes, False)
+        per_pool = n * set_bytes * (4080 / 4096) / links        # INT8_DELTA_RLE records of N(0,1) data
+        assert per_pool >= 10 * bench.MALL_BYTES and (n - 1) * set_bytes / links < 10.6 * bench.MALL_BYTES
+    assert bench.xgmi_sets_for(7, set_bytes, True) == 2         # the one-GPU dry run stays small
+    eng = lambda g: {"inbound_GBps_per_compute_gpu": g, "link_bytes_per_pass": 10, "frac_nominal_per_direction": g / (7 * 153.6),
+                     "frac_nominal_bidirectional": g / (7 * 76.8), "frac_of_raw_copy": 0.9}
+    x = {"cfg3": {"links": 1, "fused_peer_load_kernel": eng(50.0), "copy_engines_then_local_decompress": eng(60.0)},
+         "cfg4": {"links": 7, "fused_peer_load_kernel": eng(700.0), "raw_peer_copy_GBps": 800.0,
+                  "copy_engines_then_local_decompress": dict(eng(650.0), copy_engine_link_bytes_per_pass=11),
+                  "working_set": {"meets_10x_infinity_cache": True}, "speculative_prefetch_depth4": {"depth_k": 4}}}
+    r = bench.roofline_xgmi_from(x, 8)
+    assert r["layout"].startswith("cfg4") and r["engine"] == "fused_peer_load_kernel" and r["achieved"] == 700.0 and r["links"] == 7
+    assert abs(r["frac"] - 700.0 / (7 * 153.6)) < 1e-9 and r["peak_nominal_per_direction"] == round(7 * 153.6, 1)
+    assert r["copy_engine_link_bytes_per_pass"] == 11 and r["speculative_prefetch_depth4"]["depth_k"] == 4
+    # two GPUs: cfg4 collapses into cfg3 and the object reports that layout; a failed phase yields no object
+    r2 = bench.roofline_xgmi_from({"cfg3": x["cfg3"], "cfg4": {"same_as": "cfg3"}}, 2)
+    assert r2["layout"].startswith("cfg3") and r2["engine"] == "copy_engines_then_local_decompress" and r2["links"] == 1
+    assert bench.roofline_xgmi_from({"failed": "child died"}, 8) is None
+    assert bench.roofline_xgmi_from({"cfg4": {"links": 7, "skipped": "no peer access"}}, 8)["skipped"] == "no peer access"
+
+
 def test_single_rank_needs_no_process_group():
     sys.path.insert(0, ROOT)
     import bench
