@@ -612,6 +612,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
         // the query rows must have arrived before the first DMA is issued: the compiler would otherwise place its own
         // vmcnt(0) for them at their first use, inside the loop, and drain the pipeline there in every iteration
         asm volatile("" :: "v"(qv[0]), "v"(qv[1]), "v"(qv[2]), "v"(qv[3]));
+#ifdef SPECKV_ABL_PLAIN_LOADS
+        // timing only: the same bytes at the same addresses by plain 16-byte loads into registers, two tiles in flight, nothing else
+        if (!STRIPED) {
+            uint4 A[5], B[5], sink = make_uint4(0u, 0u, 0u, 0u);
+            auto ld = [&](uint4 (&r)[5], uint32_t tt) {
+                const uint64_t to = static_cast<uint64_t>(tt < last ? tt : last) * tile_bytes;
+                r[0] = ldg16(kreg + to + gr0); r[1] = ldg16(kreg + to + gr1); r[2] = ldg16(vreg + to + gr0);
+                r[3] = ldg16(vreg + to + gr1); r[4] = ldg16(sreg + to + gs);
+            };
+            auto eat = [&](const uint4 (&r)[5]) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) { sink.x ^= r[i].x; sink.y ^= r[i].y; sink.z ^= r[i].z; sink.w ^= r[i].w; }
+            };
+            ld(A, t0); ld(B, t0 + 1u);
+#pragma unroll 1
+            for (uint32_t tile = t0; tile < t1; tile += 2u) { eat(A); ld(A, tile + 2u); eat(B); ld(B, tile + 3u); }
+            eat(A); eat(B);
+            l_run += __uint_as_float((sink.x ^ sink.y ^ sink.z ^ sink.w) & 1u);
+            store_partial(a, part, row, my_splits, c, kb, m_run, l_run, acc);
+            return;
+        }
+#endif
         issue(t0, 0u);
         if (t0 < last) issue(t0 + 1u, 1u);
         const bool ragged = (a.n_pages & 15u) != 0u;
