@@ -2728,6 +2728,23 @@ int Engine::migrate(uint64_t handle, uint64_t first, uint64_t n, uint32_t target
     a->regular = false;                           // nor in the striping order the copy engine relies on
     a->stripe_n = 0;                              // (nor the fused attention's striped form; its table goes with the allocation)
     st_.pool_migrated_pages += n;
+    if (first == 0 && n == a->n_pages) {
+        // The WHOLE allocation moved (a hot sequence pulled onto one pool GPU, typically the compute GPU itself): its records
+        // are one run again -- page p at dst + p * stride, never-written slots copied along as the zero bytes they were -- so
+        // the placement is regular "over one pool" and every arithmetic-address path applies again: the linear form of the
+        // fused attention, the copy engine, the batch descriptors.
+        a->extents.clear();
+        a->extents.push_back({static_cast<int>(target_pool), dst, n * stride, n});
+        a->pool_of_residue.assign(1, static_cast<int>(target_pool));
+        a->regular = true;
+        const bool fixed_fmt = a->scheme == SPECKV_COMP_FP8_E4M3 || a->scheme == SPECKV_COMP_INT4_G32;
+        if (fixed_fmt && a->d_stripe) {
+            uint64_t bases[8] = {reinterpret_cast<uint64_t>(dst), 0, 0, 0, 0, 0, 0, 0};
+            HIP_TRY(hipMemcpy(a->d_stripe, bases, sizeof(bases), hipMemcpyHostToDevice));
+            a->linear_base = dst;
+            a->stripe_n = 1;
+        }
+    }
     return SPECKV_OK;
 }
 

@@ -560,9 +560,22 @@ def test_batch_and_planned_attention_over_striped_pools(scheme):
                     scale = float(ref[i].abs().max()) + 1e-6
                     assert float((got[i] - ref[i]).abs().max()) <= 1e-3 * scale, (what, layer, i)
                     assert float((got_lse[i] - ref_lse[i]).abs().max()) <= 2e-4, (what, layer, i)
-        # a migrated sequence no longer has an arithmetic placement: the batch call says so instead of reading wrong records
+        # a partly migrated sequence no longer has an arithmetic placement: the batch call says so instead of reading wrong records
         lib.migrate(handles[0], 4, 8, 2)
         with pytest.raises(SpeckvError):
             batch(handles, 0, q.data_ptr(), G, lens, sm, out.data_ptr(), lse.data_ptr())
+        # ... but a sequence migrated AS A WHOLE (a hot one pulled onto one pool GPU) is one run again and qualifies for every
+        # arithmetic-address path: same results, records at base + page * stride
+        lib.migrate(handles[0], 0, n_pages, 5)
+        stride = 2048 if scheme == 4 else 1152
+        base = lib.translate(handles[0], 0).pool_addr
+        assert [lib.translate(handles[0], p * PAGE).pool_addr - base for p in (1, 2, 77, n_pages - 1)] == [stride * p for p in (1, 2, 77, n_pages - 1)]
+        out3 = torch.full_like(out, float("nan")); lse3 = torch.full_like(lse, float("nan"))
+        batch(handles, 1, q.data_ptr(), G, lens, sm, out3.data_ptr(), lse3.data_ptr())
+        torch.cuda.synchronize()
+        for i, n in enumerate(lens):
+            if n:
+                scale = float(ref[i].abs().max()) + 1e-6
+                assert float((out3[i] - ref[i]).abs().max()) <= 1e-3 * scale and float((lse3[i] - ref_lse[i]).abs().max()) <= 2e-4, i
     finally:
         lib.finalize()
