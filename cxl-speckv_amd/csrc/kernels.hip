@@ -864,36 +864,61 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                 enc_st16(rec + 2ull * (512u * j + 8u * lane), raw[j]);
             out_len = 2u * kBlockElems;
         } else if (SCHEME == kInt4G32) {
-            // per group of 32 elements (4 lanes x 8): s = fp16(max|x|/7), q = clamp(round(x/s), -7, 7)
+            // per group of 32 elements (4 lanes x 8): s = fp16(max|x|/7), q = clamp(round(x/s), -7, 7).  The group's max|x| and
+            // its "all finite" test come from the fp16 bit patterns (v_pk_max_u16, two elements per instruction), the
+            // quantisation runs in packed fp32 (the same multiply / fma / fma / add / truncate per element as the scalar form,
+            // so the same bits).  (It bought 3 %: the fixed-size compress kernels all sit on one floor of ~128 us per 131 072
+            // blocks -- reads of the source at ~4.2 TB/s -- whatever they compute or write; DESIGN.md sect. 4.)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t words[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
-                float xv[8];
-                float mx = 0.0f;
-                float nanacc = 0.0f;
+                u16x2 m2 = {0, 0};
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    xv[k] = half_bits_to_float((words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
-                    absmax_finite(xv[k], mx, nanacc);
-                }
-                const bool finite = __ballot(!(nanacc == 0.0f)) == 0ull;   // wave-uniform
-                float o = __shfl_xor(mx, 1); mx = (o > mx) ? o : mx;
-                o = __shfl_xor(mx, 2);       mx = (o > mx) ? o : mx;
-                float sdiv = mx / 7.0f;
-                asm volatile("" : "+v"(sdiv));                      // keep the fp32 rounding of the divide
-                const _Float16 s16 = static_cast<_Float16>(sdiv);
-                const float sc = static_cast<float>(s16);
+                for (int t = 0; t < 4; ++t) m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(u16x2, words[t] & 0x7FFF7FFFu));
+                uint32_t mbits = m2.x > m2.y ? m2.x : m2.y;                 // largest |bits| of the lane's 8 elements
+                mbits = umax(mbits, static_cast<uint32_t>(__shfl_xor(static_cast<int>(mbits), 1)));
+                mbits = umax(mbits, static_cast<uint32_t>(__shfl_xor(static_cast<int>(mbits), 2)));   // ... of the group of 32
+                const bool finite = __ballot(mbits >= 0x7C00u) == 0ull;     // wave-uniform: no inf / NaN in any group of this chunk
                 uint32_t nib = 0;
+                _Float16 s16;
                 if (finite) {
-                    // |x| <= 7.5*sc in a finite group: the reciprocal divide is exact (test_fast_division_is_exact)
-                    const bool nz = sc != 0.0f;
-                    const float rcp = nz ? 1.0f / sc : 0.0f;
+                    float sdiv = half_bits_to_float(mbits) / 7.0f;
+                    asm volatile("" : "+v"(sdiv));                      // keep the fp32 rounding of the divide
+                    s16 = static_cast<_Float16>(sdiv);
+                    const float sc = static_cast<float>(s16);
+                    // |x| <= 7.5*sc in a finite group: the reciprocal divide is exact (test_fast_division_is_exact); a scale that
+                    // rounds to zero (subnormal groups) gives rcp = 0 and every quotient 0, as the definition says
+                    const float rcp = sc != 0.0f ? 1.0f / sc : 0.0f;
+                    const f32x2 ss = {sc, sc}, rr = {rcp, rcp};
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int r = nz ? min(max(round_to_int(div_by_scale(xv[k], sc, rcp)), -7), 7) : 0;
-                        nib |= (static_cast<uint32_t>(r) & 0xFu) << (4 * k);
+                    for (int t = 0; t < 4; ++t) {
+                        f32x2 x;
+                        x.x = half_bits_to_float(words[t] & 0xFFFFu);
+                        x.y = half_bits_to_float(words[t] >> 16);
+                        const f32x2 q0 = x * rr;
+                        const f32x2 e = __builtin_elementwise_fma(-q0, ss, x);
+                        const f32x2 y = __builtin_elementwise_fma(e, rr, q0);
+                        f32x2 h;
+                        h.x = __builtin_copysignf(0.5f, y.x);
+                        h.y = __builtin_copysignf(0.5f, y.y);
+                        const f32x2 r = y + h;                          // round half away from zero = truncate(y + copysign(0.5, y))
+                        const int i0 = min(max(static_cast<int>(r.x), -7), 7), i1 = min(max(static_cast<int>(r.y), -7), 7);
+                        nib |= ((static_cast<uint32_t>(i0) & 0xFu) | ((static_cast<uint32_t>(i1) & 0xFu) << 4)) << (8 * t);
                     }
                 } else {
+                    float xv[8];
+                    float mx = 0.0f, nanacc = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        xv[k] = half_bits_to_float((words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
+                        absmax_finite(xv[k], mx, nanacc);
+                    }
+                    float o = __shfl_xor(mx, 1); mx = (o > mx) ? o : mx;
+                    o = __shfl_xor(mx, 2);       mx = (o > mx) ? o : mx;
+                    float sdiv = mx / 7.0f;
+                    asm volatile("" : "+v"(sdiv));
+                    s16 = static_cast<_Float16>(sdiv);
+                    const float sc = static_cast<float>(s16);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         float r = 0.0f;
