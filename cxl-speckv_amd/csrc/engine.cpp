@@ -282,9 +282,25 @@ Allocation* Engine::find(uint64_t h)
 // Scratch buffers grow on demand.  A buffer that a stream capture has used is never freed (the captured graph
 // keeps its address): growth then retires it instead, and growth DURING a capture is refused (nullptr) -- warm the
 // call up once outside the capture, as with any graph-captured library call.
+// A scratch buffer is ONE buffer: a call that uses it on another stream than the previous user's is ordered behind
+// that user (an event recorded at the old stream's tail; nothing when callers stay on one stream).  Captures are left
+// alone: a captured call is ordered by whatever launches its graph.
 void* Engine::scratch(Scratch& s, size_t bytes, hipStream_t user)
 {
     const bool capturing = is_capturing(user);
+    hipStream_t now = user ? user : stream_;
+    if (s.last && s.last != now && s.p && !capturing && !is_capturing(s.last)) {
+        if (hipEvent_t ev = get_event()) {
+            if (hipEventRecord(ev, s.last) != hipSuccess || hipStreamWaitEvent(now, ev, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipDeviceSynchronize();
+            }
+            event_pool_.push_back(ev);
+        } else {
+            (void)hipDeviceSynchronize();
+        }
+    }
+    if (!capturing) s.last = now;
     if (bytes <= s.cap) { if (capturing) s.in_graph = true; return s.p; }
     if (capturing) {
         SPECKV_ERR("a call inside a stream capture needs %zu bytes of scratch but %zu are reserved: run it once outside the capture first",

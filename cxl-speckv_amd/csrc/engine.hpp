@@ -291,7 +291,7 @@ private:
     std::vector<Zombie> zombies_;
 
     // device scratch
-    struct Scratch { void* p = nullptr; size_t cap = 0; bool in_graph = false; };
+    struct Scratch { void* p = nullptr; size_t cap = 0; bool in_graph = false; hipStream_t last = nullptr; };   // last: the stream of the latest user
     Scratch s_pages_, s_req_, s_tmp_, s_stage_, s_flush_;
     std::vector<void*> retired_;           // scratch buffers a captured graph may still reference
     uint32_t* d_count_ = nullptr;
