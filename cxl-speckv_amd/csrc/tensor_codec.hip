@@ -18,9 +18,12 @@
 #include "codec_device.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace speckv {
 namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t kTile = 2048;            // elements per tile (one wave)
 constexpr uint32_t kTcWaves = 4;
@@ -44,17 +47,48 @@ __device__ __forceinline__ float tc_load(const void* src, uint64_t p)
 }
 
 // max|x| over the tensor as fp32 bits (non-negative floats order like their bit patterns); a NaN never wins
-// (cache_engine.cpp:176-180: `if (abs > max_val)`)
+// (cache_engine.cpp:176-180: `if (abs > max_val)`).  16 bytes per lane and step where the source allows it (the elements in
+// front of the first 16-byte boundary and behind the last one are taken one by one).
 template <bool F32>
 __global__ __launch_bounds__(256) void k_tc_absmax(const void* __restrict__ src, uint64_t n, uint32_t* __restrict__ out_bits)
 {
-    uint32_t m = 0;
-    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < n; p += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
-        const float a = fabsf(tc_load<F32>(src, p));
-        if (a == a) m = umax(m, __float_as_uint(a));
+    constexpr uint32_t kPer = F32 ? 4u : 8u, kEsz = F32 ? 4u : 2u;
+    const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x, nthr = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(src);
+    uint64_t head = ((16u - (addr & 15u)) & 15u) / kEsz;
+    if ((addr & (kEsz - 1u)) != 0u || head > n) head = n;            // (a source that is not even element-aligned: all scalar)
+    const uint64_t nvec = (n - head) / kPer;
+    uint32_t m = 0;                                                  // fp32: |x| bits; fp16: |x| half bits (converted at the end)
+    auto one = [&](uint64_t p) {
+        if (F32) { const uint32_t a = static_cast<const uint32_t*>(src)[p] & 0x7FFFFFFFu; if (a <= 0x7F800000u) m = umax(m, a); }
+        else     { const uint32_t a = static_cast<const uint16_t*>(src)[p] & 0x7FFFu;     if (a <= 0x7C00u) m = umax(m, a); }
+    };
+    for (uint64_t p = tid; p < head; p += nthr) one(p);
+    const u32x4* vsrc = reinterpret_cast<const u32x4*>(static_cast<const uint8_t*>(src) + head * kEsz);
+    for (uint64_t v = tid; v < nvec; v += nthr) {
+        const u32x4 x = __builtin_nontemporal_load(vsrc + v);
+        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (F32) { const uint32_t a = w[i] & 0x7FFFFFFFu; if (a <= 0x7F800000u) m = umax(m, a); }
+            else {
+                const uint32_t a = w[i] & 0x7FFFu, b = (w[i] >> 16) & 0x7FFFu;
+                if (a <= 0x7C00u) m = umax(m, a);
+                if (b <= 0x7C00u) m = umax(m, b);
+            }
+        }
     }
+    for (uint64_t p = head + nvec * kPer + tid; p < n; p += nthr) one(p);
+    // one atomic per workgroup: 16 384 same-address atomics (one per wave of a 4096-block grid) took 190 us by themselves
+    __shared__ uint32_t s_m[4];
     m = lane63(wave_incl_max(m));
-    if ((threadIdx.x & 63u) == 0u && m) atomicMax(out_bits, m);
+    if ((threadIdx.x & 63u) == 0u) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        m = umax(umax(s_m[0], s_m[1]), umax(s_m[2], s_m[3]));
+        if (!F32) m = __float_as_uint(half_bits_to_float(m));
+        if (m) atomicMax(out_bits, m);
+    }
 }
 
 __device__ __forceinline__ float tc_scale(uint32_t absmax_bits)
@@ -218,6 +252,124 @@ __global__ __launch_bounds__(64) void k_tc_scan(const TcSummary* __restrict__ su
     }
 }
 
+// The same scan by ONE workgroup of 16 waves (the single wave above walks 16 384 tiles -- 32 Mi elements -- in 2 x 256
+// dependent steps: 227 us, a third of the whole compress).  A step (64 tiles) is scanned locally by whichever wave it falls
+// to; what crosses steps -- the stretch start entering a step, the run count before it, the first run start behind it --
+// is a scan over per-step totals in LDS, done by wave 0 between the phases.  Up to kScanMaxSteps steps (256 Mi elements);
+// longer tensors take the single-wave kernel.
+constexpr uint32_t kScanWaves = 16, kScanMaxSteps = 2048;
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, uint32_t src)
+{
+    const uint32_t lo = __shfl(static_cast<uint32_t>(v), static_cast<int>(src)), hi = __shfl(static_cast<uint32_t>(v >> 32), static_cast<int>(src));
+    return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long lanes_above(uint32_t lane) { return lane == 63u ? 0ull : ~((2ull << lane) - 1ull); }
+
+__global__ __launch_bounds__(64 * kScanWaves) void k_tc_scan_wg(const TcSummary* __restrict__ summ, TcCarry* __restrict__ carry, uint64_t n_tiles, uint64_t n,
+                                                                const uint32_t* __restrict__ absmax_bits, float* __restrict__ out_scale,
+                                                                uint64_t* __restrict__ out_bytes)
+{
+    __shared__ uint64_t s_ss[kScanMaxSteps];        // last stretch start of the step (absolute + 1) -> stretch start entering the step
+    __shared__ uint64_t s_runs[kScanMaxSteps];      // run starts in the step -> run starts before the step
+    __shared__ uint64_t s_first[kScanMaxSteps];     // first run start of the step (absolute + 1, 0 none) -> first run start behind the step (absolute, n if none)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n_steps = static_cast<uint32_t>((n_tiles + 63u) / 64u);
+    constexpr uint64_t kOpen = ~0ull;
+    // phase 1: the last stretch start of every step
+    for (uint32_t st = wave; st < n_steps; st += kScanWaves) {
+        const uint64_t t = static_cast<uint64_t>(st) * 64u + lane;
+        const uint32_t last_ss = t < n_tiles ? summ[t].last_ss : 0u;
+        const uint32_t tot = lane63(wave_incl_max(last_ss ? lane * kTile + last_ss : 0u));
+        if (lane == 0u) s_ss[st] = tot ? static_cast<uint64_t>(st) * 64u * kTile + tot : 0ull;
+    }
+    __syncthreads();
+    if (wave == 0u) {                               // phase 2: "last non-zero before" over the steps
+        uint64_t cy = 0;
+        for (uint32_t j = 0; j < n_steps; j += 64u) {
+            const uint32_t i = j + lane;
+            const uint64_t v = i < n_steps ? s_ss[i] : 0ull;
+            const uint32_t idx = wave_incl_max(v ? lane + 1u : 0u);
+            const uint32_t ex = wave_shr1(idx, 0u), last = lane63(idx);
+            const uint64_t got = shfl64(v, ex ? ex - 1u : 0u), top = shfl64(v, last ? last - 1u : 0u);
+            if (i < n_steps) s_ss[i] = ex ? got : cy;
+            if (last) cy = top;
+        }
+    }
+    __syncthreads();
+    // phase 3: per tile what depends on the entering stretch start; local scans of the run counts and of the first run starts
+    for (uint32_t st = wave; st < n_steps; st += kScanWaves) {
+        const uint64_t base = static_cast<uint64_t>(st) * 64u, t = base + lane;
+        const bool live = t < n_tiles;
+        TcSummary s{0u, 0u, 0u, 0u};
+        if (live) s = summ[t];
+        const uint64_t t0 = t * kTile;
+        const uint32_t len = live ? static_cast<uint32_t>((n - t0 < kTile) ? (n - t0) : kTile) : 0u;
+        const uint32_t inc = wave_incl_max(s.last_ss ? lane * kTile + s.last_ss : 0u);
+        const uint32_t exc = wave_shr1(inc, 0u);
+        const uint64_t ss_in = exc ? base * kTile + exc : s_ss[st];
+        uint32_t lead_phase = 0, cnt_a = 0, first_a = 0;
+        const uint32_t f_end = s.first_ss ? s.first_ss - 1u : len;
+        if (live && ss_in && f_end) {
+            lead_phase = static_cast<uint32_t>((t0 - (ss_in - 1u)) % 255u);
+            first_a = (255u - lead_phase) % 255u;
+            if (first_a < f_end) cnt_a = (f_end - 1u - first_a) / 255u + 1u;
+        }
+        const uint32_t runs = cnt_a + s.cnt_b;
+        const uint32_t rinc = wave_incl_add(runs);
+        const uint64_t fr = !live ? 0ull : (cnt_a ? t0 + first_a + 1u : (s.cnt_b ? t0 + s.first_ss : 0ull));     // absolute + 1
+        const unsigned long long have = __ballot(fr != 0ull);
+        const unsigned long long later = have & lanes_above(lane);
+        const uint64_t nxt = shfl64(fr, later ? static_cast<uint32_t>(__builtin_ctzll(later)) : 0u);
+        if (live) {
+            TcCarry c;
+            c.lead_phase = lead_phase;
+            c.runs = runs;
+            c.run_base = rinc - runs;                               // + the step's base in phase 5
+            c.next_run = later ? nxt - 1u : kOpen;                  // open: the first run start behind the step (phase 5)
+            carry[t] = c;
+        }
+        const uint64_t first = shfl64(fr, have ? static_cast<uint32_t>(__builtin_ctzll(have)) : 0u);
+        if (lane == 0u) { s_runs[st] = lane63(rinc); s_first[st] = have ? first : 0ull; }
+    }
+    __syncthreads();
+    if (wave == 0u) {                               // phase 4: run counts before every step, first run start behind every step
+        uint64_t cy = 0;
+        for (uint32_t j = 0; j < n_steps; j += 64u) {
+            const uint32_t i = j + lane;
+            const uint32_t v = i < n_steps ? static_cast<uint32_t>(s_runs[i]) : 0u;      // <= 64 * 2048
+            const uint32_t inc = wave_incl_add(v);
+            if (i < n_steps) s_runs[i] = cy + inc - v;
+            cy += lane63(inc);
+        }
+        uint64_t behind = n;
+        for (uint32_t j = (n_steps + 63u) / 64u; j-- > 0u;) {
+            const uint32_t i = j * 64u + lane;
+            const uint64_t v = i < n_steps ? s_first[i] : 0ull;
+            const unsigned long long have = __ballot(v != 0ull);
+            const unsigned long long later = have & lanes_above(lane);
+            const uint64_t nxt = shfl64(v, later ? static_cast<uint32_t>(__builtin_ctzll(later)) : 0u);
+            const uint64_t first = shfl64(v, have ? static_cast<uint32_t>(__builtin_ctzll(have)) : 0u);
+            if (i < n_steps) s_first[i] = later ? nxt - 1u : behind;
+            if (have) behind = first - 1u;
+        }
+        if (lane == 0u) {
+            carry[n_tiles].run_base = cy;                            // sentinel for the pack pass
+            carry[n_tiles].runs = 0; carry[n_tiles].lead_phase = 0; carry[n_tiles].next_run = n;
+            *out_bytes = 2ull * cy;
+            *out_scale = tc_scale(*absmax_bits);
+        }
+    }
+    __syncthreads();
+    // phase 5: every lane finishes the entry it wrote in phase 3
+    for (uint32_t st = wave; st < n_steps; st += kScanWaves) {
+        const uint64_t t = static_cast<uint64_t>(st) * 64u + lane;
+        if (t < n_tiles) {
+            carry[t].run_base += s_runs[st];
+            if (carry[t].next_run == kOpen) carry[t].next_run = s_first[st];
+        }
+    }
+}
+
 // Output-centric pack: a wave owns 2048 consecutive pairs (4 KiB, line-aligned) of the stream and gathers them from the
 // tiles' slots.  Lane piece = 8 pairs: one binary search over run_base, then a walk.
 __global__ __launch_bounds__(256) void k_tc_pack(const TcCarry* __restrict__ carry, uint64_t n_tiles, const uint8_t* __restrict__ pair_scratch,
@@ -299,6 +451,57 @@ __global__ __launch_bounds__(64) void k_td_scan(const TdSummary* __restrict__ su
     if (lane == 0u) {
         carry[n_chunks] = TdCarry{start, qpre, 0u};
         *out_n = start < cap ? start : cap;                          // elements written (the stream's total, clipped at the buffer)
+    }
+}
+
+// The decode scan by one workgroup of 16 waves (see k_tc_scan_wg; up to kScanMaxSteps x 64 chunks of 2048 pairs).
+__global__ __launch_bounds__(64 * kScanWaves) void k_td_scan_wg(const TdSummary* __restrict__ summ, TdCarry* __restrict__ carry, uint64_t n_chunks,
+                                                                uint64_t cap, uint64_t* __restrict__ out_n)
+{
+    __shared__ uint64_t s_cnt[kScanMaxSteps];
+    __shared__ uint32_t s_val[kScanMaxSteps];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n_steps = static_cast<uint32_t>((n_chunks + 63u) / 64u);
+    for (uint32_t st = wave; st < n_steps; st += kScanWaves) {
+        const uint64_t c = static_cast<uint64_t>(st) * 64u + lane;
+        TdSummary s{0u, 0u};
+        if (c < n_chunks) s = summ[c];
+        const uint32_t lo = wave_incl_add(s.sum_c & 0xFFFFu), hi = wave_incl_add(s.sum_c >> 16);
+        const uint64_t inc = static_cast<uint64_t>(lo) + (static_cast<uint64_t>(hi) << 16);
+        const uint32_t vinc = wave_incl_add(s.sum_v);
+        if (c < n_chunks) carry[c] = TdCarry{inc - s.sum_c, (vinc - s.sum_v) & 0xFFu, 0u};
+        if (lane == 0u) {
+            s_cnt[st] = static_cast<uint64_t>(lane63(lo)) + (static_cast<uint64_t>(lane63(hi)) << 16);
+            s_val[st] = lane63(vinc) & 0xFFu;
+        }
+    }
+    __syncthreads();
+    if (wave == 0u) {
+        uint64_t start = 0;
+        uint32_t qpre = 0;
+        for (uint32_t j = 0; j < n_steps; j += 64u) {
+            const uint32_t i = j + lane;
+            const uint64_t v = i < n_steps ? s_cnt[i] : 0ull;          // <= 64 * 2048 * 255 < 2^25
+            const uint32_t q = i < n_steps ? s_val[i] : 0u;
+            const uint32_t lo = wave_incl_add(static_cast<uint32_t>(v) & 0xFFFFu), hi = wave_incl_add(static_cast<uint32_t>(v >> 16));
+            const uint64_t inc = static_cast<uint64_t>(lo) + (static_cast<uint64_t>(hi) << 16);
+            const uint32_t qinc = wave_incl_add(q);
+            if (i < n_steps) { s_cnt[i] = start + inc - v; s_val[i] = (qpre + qinc - q) & 0xFFu; }
+            start += static_cast<uint64_t>(lane63(lo)) + (static_cast<uint64_t>(lane63(hi)) << 16);
+            qpre = (qpre + lane63(qinc)) & 0xFFu;
+        }
+        if (lane == 0u) {
+            carry[n_chunks] = TdCarry{start, qpre, 0u};
+            *out_n = start < cap ? start : cap;
+        }
+    }
+    __syncthreads();
+    for (uint32_t st = wave; st < n_steps; st += kScanWaves) {
+        const uint64_t c = static_cast<uint64_t>(st) * 64u + lane;
+        if (c < n_chunks) {
+            carry[c].start += s_cnt[st];
+            carry[c].q_pre = (carry[c].q_pre + s_val[st]) & 0xFFu;
+        }
     }
 }
 
@@ -410,7 +613,7 @@ hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, u
     hipError_t e = hipMemsetAsync(absmax, 0, 256, s);
     if (e != hipSuccess) return e;
     if (n) {
-        const uint32_t g = static_cast<uint32_t>(std::min<uint64_t>((n + 255) / 256, 4096));
+        const uint32_t g = static_cast<uint32_t>(std::min<uint64_t>((n + 2047) / 2048, 1024));     // 16 bytes per lane and step, 4 workgroups per CU
         if (src_f32) hipLaunchKernelGGL(k_tc_absmax<true>, dim3(g), dim3(256), 0, s, d_src, n, absmax);
         else         hipLaunchKernelGGL(k_tc_absmax<false>, dim3(g), dim3(256), 0, s, d_src, n, absmax);
     }
@@ -419,7 +622,10 @@ hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, u
 #define SPECKV_TC2(EMIT) do { if (quant_mode == kIntent) { if (src_f32) SPECKV_TC(kIntent, true, EMIT); else SPECKV_TC(kIntent, false, EMIT); } \
                               else { if (src_f32) SPECKV_TC(kRefExact, true, EMIT); else SPECKV_TC(kRefExact, false, EMIT); } } while (0)
     if (tiles) SPECKV_TC2(false);
-    hipLaunchKernelGGL(k_tc_scan, dim3(1), dim3(64), 0, s, summ, carry, tiles, n, absmax, d_scale, d_rle_bytes, first_run);
+    if ((tiles + 63) / 64 <= kScanMaxSteps && !getenv("SPECKV_TC_SERIAL_SCAN"))
+        hipLaunchKernelGGL(k_tc_scan_wg, dim3(1), dim3(64 * kScanWaves), 0, s, summ, carry, tiles, n, absmax, d_scale, d_rle_bytes);
+    else
+        hipLaunchKernelGGL(k_tc_scan, dim3(1), dim3(64), 0, s, summ, carry, tiles, n, absmax, d_scale, d_rle_bytes, first_run);
     if (tiles) {
         SPECKV_TC2(true);
         // the pack grid covers the worst case (one pair per element); waves beyond the stream's end return at once
@@ -442,7 +648,10 @@ hipError_t launch_tensor_decompress(const uint8_t* d_rle, uint64_t rle_bytes, fl
     TdCarry* carry = reinterpret_cast<TdCarry*>(w); w += align_up((chunks + 1) * sizeof(TdCarry), 256);
     uint64_t* n_out = d_n_out ? d_n_out : reinterpret_cast<uint64_t*>(w);
     if (chunks) hipLaunchKernelGGL(k_td_summary, dim3(static_cast<uint32_t>((chunks + 3) / 4)), dim3(256), 0, s, d_rle, n_pairs, summ);
-    hipLaunchKernelGGL(k_td_scan, dim3(1), dim3(64), 0, s, summ, carry, chunks, dst_cap, n_out);
+    if ((chunks + 63) / 64 <= kScanMaxSteps && !getenv("SPECKV_TC_SERIAL_SCAN"))
+        hipLaunchKernelGGL(k_td_scan_wg, dim3(1), dim3(64 * kScanWaves), 0, s, summ, carry, chunks, dst_cap, n_out);
+    else
+        hipLaunchKernelGGL(k_td_scan, dim3(1), dim3(64), 0, s, summ, carry, chunks, dst_cap, n_out);
     if (chunks && dst_cap) {
         // grid: the output can hold at most min(dst_cap, 255 * n_pairs) elements; waves behind the stream's total return at once
         const uint64_t max_out = std::min<uint64_t>(dst_cap, n_pairs * 255u);
