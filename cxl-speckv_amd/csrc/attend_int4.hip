@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
 //   LDS, per buffer (two buffers):  K rows [32][256 B] | V rows [32][256 B] | K scale lines [16][128 B] | V scale lines
 //   rows are stored with their sixteen 16-byte pieces XOR-ed by (row & 15) (chosen on the SOURCE side: lane l fetches
 //   piece (l & 15) ^ row): the K operand reads (ds_read_b128, 16 rows x one piece) and the V reads (ds_read_b32, rows
-//   4 kb + j) are then conflict-free; K scale lines likewise by (page & 7).
+//   4 kb + j) are then conflict-free; K scale lines likewise by (page & 7), V scale lines by (page / 2) & 3.
 //   iteration t:  own DMAs of tile t landed (vmcnt) + barrier -> K operand, scores, softmax, V dwords
 //                 -> barrier (everybody is done with the buffer) -> DMAs of tile t+2 into it -> PV
 namespace {
@@ -572,7 +572,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
         const uint32_t in0 = row_in(r0, (lane & 15u) ^ (r0 & 15u)), in1 = row_in(r1, (lane & 15u) ^ (r1 & 15u));
         const uint32_t gr0 = (r0 >> 1) * kInt4RecBytes + in0, gr1 = (r1 >> 1) * kInt4RecBytes + in1;
         const uint32_t spage = 8u * (wave & 1u) + (lane >> 3);
-        const uint32_t sin = ((lane & 7u) ^ ((wave < 2u) ? (spage & 7u) : 0u)) * 16u;
+        // (V scale lines: pieces xor-ed by (page / 2) & 3 -- the reader's four position groups kb read pages 2 kb + j / 2, 256 B
+        // apart, i.e. the same banks: PMC showed 13.1 M LDS conflict cycles per launch, 20 per tile and wave, all from these 8 reads)
+        const uint32_t sin = ((lane & 7u) ^ ((wave < 2u) ? (spage & 7u) : ((spage >> 1) & 3u))) * 16u;
         const uint32_t gs = spage * kInt4RecBytes + sin;
         const uint32_t lbase = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&lds[0])));
         const uint32_t dr0 = 8u * wave * 256u, ds_ = ((wave < 2u) ? kWgKs : kWgVs) + (wave & 1u) * 1024u;   // destinations inside a buffer
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j)
             rdv[j] = lbase + kWgV + (4u * kb + j) * 256u + ((((wave ^ kb) * 4u) + ((c >> 2) ^ j)) * 16u) + (c & 3u) * 4u;
-        const uint32_t rsv = lbase + kWgVs + 2u * kb * 128u + head * 8u + 2u * (c >> 2);
+        const uint32_t rsv = lbase + kWgVs + 2u * kb * 128u + ((h1 ^ kb) * 16u) + (head & 1u) * 8u + 2u * (c >> 2);   // pages 2 kb + j / 2 (+ 8): (page / 2) & 3 = kb
         // the query rows must have arrived before the first DMA is issued: the compiler would otherwise place its own
         // vmcnt(0) for them at their first use, inside the loop, and drain the pipeline there in every iteration
         asm volatile("" :: "v"(qv[0]), "v"(qv[1]), "v"(qv[2]), "v"(qv[3]));
