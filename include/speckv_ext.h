@@ -281,7 +281,9 @@ speckv_status_t speckv_ext_attend_fp8(speckv_handle_t handle, uint32_t layer_beg
  *   d_out : [n_seq][num_heads][g][128] fp32      d_lse : optional [n_seq][num_heads][g]
  * Every allocation must hold FP8 records in one local run with a layout whose num_tokens is a multiple of 32 (the
  * default placement; SPECKV_ERR_INVAL otherwise).  Asynchronous on `stream` (the host arrays are copied before the
- * call returns).  Note: d_scale_tab / the scratch of consecutive calls on DIFFERENT streams is shared -- use one stream. */
+ * call returns).  The split partials of all attention calls live in one scratch buffer of the engine: a call on another
+ * stream than the previous one is ordered behind it by the library (an event at the old stream's tail), so callers may
+ * use several streams, but such calls do not overlap on the device. */
 speckv_status_t speckv_ext_attend_fp8_batch(uint32_t n_seq, const speckv_handle_t* handles, uint32_t layer,
                                             const void* d_q_f16, uint32_t g, const uint32_t* pos_end, float sm_scale,
                                             float* d_out, float* d_lse, void* stream);

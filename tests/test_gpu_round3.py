@@ -662,3 +662,58 @@ def test_vllm_shaped_connector_round_trip(oracle, scheme):
         assert c.get_num_new_matched_tokens(NS(request_id="req-a", num_tokens=40), 0) == (0, False)
     finally:
         lib.finalize()
+
+
+@pytest.mark.parametrize("scheme", [3, 4])
+def test_attention_calls_on_different_streams_share_the_scratch_safely(scheme):
+    """The split partials of every fused-attention call live in ONE scratch buffer of the engine.  Calls issued back to back on
+    different caller streams (no host synchronisation in between) used to be the caller's problem ("use one stream"); the
+    library now orders a call behind the previous user of the buffer when the stream changes.  Two sequences with different
+    data, attended alternately on two streams that are each kept busy in front of their call, must give exactly what the
+    same calls give one at a time."""
+    torch = torch_mod()
+    from tests.test_gpu_full_size import H, D, G
+    T, L = 4096, 4
+    n_pages = T * L * H * D * 2 * 2 // PAGE
+    lib = open_lib()
+    try:
+        lib.set_compression_scheme(scheme)
+        attend = lib.attend_int4 if scheme == 3 else lib.attend_fp8
+        rng = np.random.default_rng(900 + scheme)
+        hs, qs = [], []
+        for i in range(2):
+            x = (rng.standard_normal((n_pages, N)) * (1.0 + i)).astype(np.float16)
+            h = lib.alloc(n_pages * PAGE)
+            lib.set_layout(h, T, L, H, D, 2)
+            lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+            hs.append(h)
+            qs.append(torch.from_numpy((rng.standard_normal((L, H, G, D)) * 1.5).astype(np.float16).view(np.int16)).cuda())
+        sm = 1.0 / np.sqrt(D)
+
+        def call(i, out, lse, stream):
+            attend(hs[i], 0, L, qs[i].data_ptr(), G, 0, T, sm, out.data_ptr(), lse.data_ptr(), stream)
+
+        want = []
+        for i in range(2):
+            out = torch.empty((L, H, G, D), dtype=torch.float32, device="cuda")
+            lse = torch.empty((L, H, G), dtype=torch.float32, device="cuda")
+            call(i, out, lse, None)
+            torch.cuda.synchronize()
+            want.append((out.clone(), lse.clone()))
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        ballast = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+        for rep in range(6):
+            outs = [(k & 1, torch.full((L, H, G, D), float("nan"), dtype=torch.float32, device="cuda"),
+                     torch.full((L, H, G), float("nan"), dtype=torch.float32, device="cuda")) for k in range(8)]
+            torch.cuda.synchronize()
+            for k, (i, out, lse) in enumerate(outs):          # back to back, no host synchronisation in between
+                if (k + rep) % 3 == 0:
+                    with torch.cuda.stream(streams[i]):
+                        ballast.fill_(k)                      # this stream's call starts late: the other one overtakes it
+                call(i, out, lse, streams[i].cuda_stream)
+            torch.cuda.synchronize()
+            for i, out, lse in outs:
+                assert torch.equal(out, want[i][0]), (rep, i)
+                assert torch.equal(lse, want[i][1]), (rep, i)
+    finally:
+        lib.finalize()
