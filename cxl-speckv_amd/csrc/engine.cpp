@@ -1455,20 +1455,34 @@ int Engine::predictor_load_lstm(const float* emb, uint32_t vocab, uint32_t n_lay
         return SPECKV_OK;
     };
     LstmParams p{};
+    // the cell kernel reads weights as [column][gate row] (coalesced over its 512 threads): transposed here, once, through
+    // the host (under 1 MB per layer)
+    auto upload_transposed = [&](const float* src, size_t rows, size_t cols, float** out) -> int {
+        std::vector<float> a(rows * cols), t(rows * cols);
+        HIP_TRY(hipMemcpy(a.data(), src, a.size() * sizeof(float), on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+        for (size_t r = 0; r < rows; ++r)
+            for (size_t c = 0; c < cols; ++c) t[c * rows + r] = a[r * cols + c];
+        float* d = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), t.size() * sizeof(float)));
+        lstm_bufs_.push_back(d);
+        HIP_TRY(hipMemcpy(d, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+        *out = d;
+        return SPECKV_OK;
+    };
     for (uint32_t l = 0; l < n_layers; ++l) {
         const size_t in_dim = l == 0 ? 64 : 128;
-        float *wi = nullptr, *wh = nullptr, *bi = nullptr, *bh = nullptr;
-        RC_TRY(upload(w_ih[l], 512 * in_dim, &wi));
-        RC_TRY(upload(w_hh[l], 512 * 128, &wh));
-        RC_TRY(upload(b_ih[l], 512, &bi));
-        RC_TRY(upload(b_hh[l], 512, &bh));
+        float *wi = nullptr, *wh = nullptr, *bi = nullptr;
+        RC_TRY(upload_transposed(w_ih[l], 512, in_dim, &wi));
+        RC_TRY(upload_transposed(w_hh[l], 512, 128, &wh));
         // bias = b_ih + b_hh, summed once on the host side of the copy (exact: one fp32 addition, as the cell would do)
         std::vector<float> a(512), b(512);
-        HIP_TRY(hipMemcpy(a.data(), bi, 512 * sizeof(float), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(b.data(), bh, 512 * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(a.data(), b_ih[l], 512 * sizeof(float), on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+        HIP_TRY(hipMemcpy(b.data(), b_hh[l], 512 * sizeof(float), on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
         for (int i = 0; i < 512; ++i) a[i] += b[i];
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&bi), 512 * sizeof(float)));
+        lstm_bufs_.push_back(bi);
         HIP_TRY(hipMemcpy(bi, a.data(), 512 * sizeof(float), hipMemcpyHostToDevice));
-        p.w_ih[l] = wi; p.w_hh[l] = wh; p.bias[l] = bi;
+        p.w_ih_t[l] = wi; p.w_hh_t[l] = wh; p.bias[l] = bi;
     }
     if (out_bias) { float* ob = nullptr; RC_TRY(upload(out_bias, vocab, &ob)); p.out_bias = ob; }
     p.layers = n_layers;

@@ -1500,78 +1500,98 @@ __global__ __launch_bounds__(64) void k_lstm_hidden(const int32_t* __restrict__ 
 // cell with PyTorch's nn.LSTM conventions -- per layer  gates = W_ih x + W_hh h + b  (4 x 128 rows, order i, f, g, o),
 // c = sigmoid(f) c + sigmoid(i) tanh(g),  h = sigmoid(o) tanh(c),  h_0 = c_0 = 0, layer l > 0 fed with layer l-1's h of the
 // same time step; 16-token history, embedding width 64, hidden width 128.  Output: the top layer's last h.
-//   One workgroup = kLstmReq requests: a thread owns one of the 512 gate rows and computes it for all requests of the
-//   workgroup, so a weight row is read once per step for the whole group (weights: 0.9 MB for two layers, L2-resident).
-//   The cell state and the layer inputs live in LDS.
-struct LstmWeights { const float* w_ih[4]; const float* w_hh[4]; const float* bias[4]; uint32_t layers; };   // bias = b_ih + b_hh
-constexpr uint32_t kLstmReq = 8;
+//   A prediction is a chain of 16 x layers dependent steps, so the kernel is written for the length of a step, layer by layer:
+//   * one workgroup = kLstmReq requests, a thread = one of the 512 gate rows;
+//   * the layer's input projections W_ih x_t + b of ALL 16 steps have no dependency: computed first, into LDS;
+//   * the row of W_hh stays in 128 registers for the 16 recurrent steps (weights arrive TRANSPOSED, [column][row], so that
+//     the 512 threads of a workgroup read them coalesced -- Engine::predictor_load_lstm);
+//   * a step is then 128 x kLstmReq fused multiply-adds per thread against h in LDS (broadcast reads), a barrier, the
+//     gate non-linearities on 128 x kLstmReq threads, a barrier.
+//   First version (weights streamed from L2 in every step, 8 requests per workgroup): 0.7-0.8 ms per prediction of 256 requests.
+struct LstmWeights { const float* w_ih_t[4]; const float* w_hh_t[4]; const float* bias[4]; uint32_t layers; };   // bias = b_ih + b_hh
+constexpr uint32_t kLstmReq = 2;
 __device__ __forceinline__ float sigmoidf_dev(float x) { return 1.0f / (1.0f + expf(-x)); }
 __global__ __launch_bounds__(512) void k_lstm_cell(const int32_t* __restrict__ hist, uint32_t n, const float* __restrict__ emb, uint32_t vocab,
                                                   LstmWeights w, float* __restrict__ hid)
 {
-    __shared__ __attribute__((aligned(16))) float xin[kLstmReq][kPredHidden + kPredHidden];   // [request][input of the layer | its own h]
-    __shared__ float hs[4][kLstmReq][kPredHidden], cs[4][kLstmReq][kPredHidden];
+    __shared__ __attribute__((aligned(16))) float seq[kPredHist][kLstmReq][kPredHidden];       // the layer's input sequence, then its own output
+    __shared__ __attribute__((aligned(16))) float xp[kPredHist][kLstmReq][4 * kPredHidden];    // W_ih x_t + b of the current layer
+    __shared__ __attribute__((aligned(16))) float hcur[kLstmReq][kPredHidden];
+    __shared__ float ccur[kLstmReq][kPredHidden];
     __shared__ float gates[kLstmReq][4 * kPredHidden];
-    const uint32_t tid = threadIdx.x, r0 = blockIdx.x * kLstmReq;     // thread = one of the 512 gate rows
-    for (uint32_t i = tid; i < 4u * kLstmReq * kPredHidden; i += 512u) { (&hs[0][0][0])[i] = 0.0f; (&cs[0][0][0])[i] = 0.0f; }
+    const uint32_t row = threadIdx.x, r0 = blockIdx.x * kLstmReq;
+    for (uint32_t i = row; i < kPredHist * kLstmReq * kPredEmb; i += 512u) {
+        const uint32_t t = i / (kLstmReq * kPredEmb), r = (i / kPredEmb) % kLstmReq, j = i % kPredEmb;
+        const uint32_t tok = (r0 + r < n) ? static_cast<uint32_t>(hist[(r0 + r) * kPredHist + t]) : vocab;
+        seq[t][r][j] = tok < vocab ? emb[static_cast<uint64_t>(tok) * kPredEmb + j] : 0.0f;
+    }
     __syncthreads();
-    for (uint32_t t = 0; t < kPredHist; ++t) {
-        for (uint32_t l = 0; l < w.layers; ++l) {
-            const uint32_t in_dim = l == 0 ? kPredEmb : kPredHidden, cols = in_dim + kPredHidden;
-            // stage [x | h_{t-1}] of every request
-            for (uint32_t i = tid; i < kLstmReq * cols; i += 512u) {
-                const uint32_t r = i / cols, j = i % cols;
-                float v;
-                if (j >= in_dim) v = hs[l][r][j - in_dim];
-                else if (l > 0) v = hs[l - 1][r][j];
-                else {
-                    const uint32_t tok = (r0 + r < n) ? static_cast<uint32_t>(hist[(r0 + r) * kPredHist + t]) : vocab;
-                    v = tok < vocab ? emb[static_cast<uint64_t>(tok) * kPredEmb + j] : 0.0f;
+    for (uint32_t l = 0; l < w.layers; ++l) {
+        const uint32_t in_dim = l == 0 ? kPredEmb : kPredHidden;
+        const float* wi = w.w_ih_t[l] + row;                              // column j of this row: wi[j * 512]
+        const float b = w.bias[l][row];
+#pragma unroll 1
+        for (uint32_t t0 = 0; t0 < kPredHist; t0 += 8u) {                 // input projections, 8 steps at a time
+            float acc[8][kLstmReq];
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+                for (uint32_t r = 0; r < kLstmReq; ++r) acc[tt][r] = b;
+#pragma unroll 1
+            for (uint32_t j = 0; j < in_dim; j += 4u) {
+                const float w0 = wi[(j + 0u) * 512u], w1 = wi[(j + 1u) * 512u], w2 = wi[(j + 2u) * 512u], w3 = wi[(j + 3u) * 512u];
+#pragma unroll
+                for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+                    for (uint32_t r = 0; r < kLstmReq; ++r) {
+                        const float4 xv = *reinterpret_cast<const float4*>(&seq[t0 + tt][r][j]);
+                        acc[tt][r] += w0 * xv.x; acc[tt][r] += w1 * xv.y; acc[tt][r] += w2 * xv.z; acc[tt][r] += w3 * xv.w;
+                    }
+            }
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+                for (uint32_t r = 0; r < kLstmReq; ++r) xp[t0 + tt][r][row] = acc[tt][r];
+        }
+        float wh[kPredHidden];                                            // this row of W_hh
+        {
+            const float* whp = w.w_hh_t[l] + row;
+#pragma unroll
+            for (uint32_t j = 0; j < kPredHidden; ++j) wh[j] = whp[j * 512u];
+        }
+        if (row < kLstmReq * kPredHidden) { (&hcur[0][0])[row] = 0.0f; (&ccur[0][0])[row] = 0.0f; }
+        __syncthreads();                                                  // (everybody is also done with seq as this layer's input)
+#pragma unroll 1
+        for (uint32_t t = 0; t < kPredHist; ++t) {
+            float acc[kLstmReq];
+#pragma unroll
+            for (uint32_t r = 0; r < kLstmReq; ++r) acc[r] = xp[t][r][row];
+#pragma unroll
+            for (uint32_t j = 0; j < kPredHidden; j += 4u)
+#pragma unroll
+                for (uint32_t r = 0; r < kLstmReq; ++r) {
+                    const float4 hv = *reinterpret_cast<const float4*>(&hcur[r][j]);
+                    acc[r] += wh[j] * hv.x; acc[r] += wh[j + 1] * hv.y; acc[r] += wh[j + 2] * hv.z; acc[r] += wh[j + 3] * hv.w;
                 }
-                xin[r][j] = v;
-            }
+#pragma unroll
+            for (uint32_t r = 0; r < kLstmReq; ++r) gates[r][row] = acc[r];
             __syncthreads();
-            {
-                const uint32_t row = tid;
-                const float* wi = w.w_ih[l] + static_cast<uint64_t>(row) * in_dim;
-                const float* wh = w.w_hh[l] + static_cast<uint64_t>(row) * kPredHidden;
-                float acc[kLstmReq];
-                const float b = w.bias[l][row];
-#pragma unroll
-                for (uint32_t r = 0; r < kLstmReq; ++r) acc[r] = b;
-                // the row's weights, 16 floats (four independent 16-byte loads) per step; the additions keep the order j ascending
-                auto dot16 = [&](const float* wrow, uint32_t xoff, uint32_t j) {
-                    float4 wv[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) wv[q] = *reinterpret_cast<const float4*>(wrow + j + 4 * q);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (uint32_t r = 0; r < kLstmReq; ++r) {
-                            const float4 xv = *reinterpret_cast<const float4*>(&xin[r][xoff + j + 4 * q]);
-                            acc[r] += wv[q].x * xv.x; acc[r] += wv[q].y * xv.y; acc[r] += wv[q].z * xv.z; acc[r] += wv[q].w * xv.w;
-                        }
-                };
-                for (uint32_t j = 0; j < in_dim; j += 16u) dot16(wi, 0u, j);
-                for (uint32_t j = 0; j < kPredHidden; j += 16u) dot16(wh, in_dim, j);
-#pragma unroll
-                for (uint32_t r = 0; r < kLstmReq; ++r) gates[r][row] = acc[r];
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < kLstmReq * kPredHidden; i += 512u) {
-                const uint32_t r = i / kPredHidden, u = i % kPredHidden;
+            if (row < kLstmReq * kPredHidden) {
+                const uint32_t r = row / kPredHidden, u = row % kPredHidden;
                 const float gi = sigmoidf_dev(gates[r][u]), gf = sigmoidf_dev(gates[r][kPredHidden + u]);
                 const float gg = tanhf(gates[r][2u * kPredHidden + u]), go = sigmoidf_dev(gates[r][3u * kPredHidden + u]);
-                const float c = gf * cs[l][r][u] + gi * gg;
-                cs[l][r][u] = c;
-                hs[l][r][u] = go * tanhf(c);
+                const float c = gf * ccur[r][u] + gi * gg;
+                const float h = go * tanhf(c);
+                ccur[r][u] = c;
+                hcur[r][u] = h;
+                seq[t][r][u] = h;
             }
             __syncthreads();
         }
     }
-    for (uint32_t i = tid; i < kLstmReq * kPredHidden; i += 512u) {
-        const uint32_t r = i / kPredHidden, u = i % kPredHidden;
-        if (r0 + r < n) hid[static_cast<uint64_t>(r0 + r) * kPredHidden + u] = hs[w.layers - 1u][r][u];
+    if (row < kLstmReq * kPredHidden) {
+        const uint32_t r = row / kPredHidden, u = row % kPredHidden;
+        if (r0 + r < n) hid[static_cast<uint64_t>(r0 + r) * kPredHidden + u] = hcur[r][u];
     }
 }
 
@@ -1995,7 +2015,7 @@ hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb,
         if (lstm->layers > 4u) return hipErrorInvalidValue;
         LstmWeights w{};
         w.layers = lstm->layers;
-        for (uint32_t l = 0; l < lstm->layers; ++l) { w.w_ih[l] = lstm->w_ih[l]; w.w_hh[l] = lstm->w_hh[l]; w.bias[l] = lstm->bias[l]; }
+        for (uint32_t l = 0; l < lstm->layers; ++l) { w.w_ih_t[l] = lstm->w_ih_t[l]; w.w_hh_t[l] = lstm->w_hh_t[l]; w.bias[l] = lstm->bias[l]; }
         hipLaunchKernelGGL(k_lstm_cell, dim3((n + kLstmReq - 1u) / kLstmReq), dim3(512), 0, s, d_hist, n, d_emb, vocab, w, d_hid);
     } else {
         hipLaunchKernelGGL(k_lstm_hidden, dim3(n), dim3(64), 0, s, d_hist, n, d_emb, vocab, layers, d_hid);

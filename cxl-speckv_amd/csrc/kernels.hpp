@@ -312,7 +312,7 @@ hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t ba
 // floats) are scratch.
 // lstm != nullptr && lstm->layers > 0: a real LSTM cell (PyTorch nn.LSTM conventions, k_lstm_cell) instead of the reference's
 // degenerate one; bias[l] = b_ih[l] + b_hh[l]; out_bias may be null
-struct LstmParams { const float* w_ih[4]; const float* w_hh[4]; const float* bias[4]; const float* out_bias; uint32_t layers; };
+struct LstmParams { const float* w_ih_t[4]; const float* w_hh_t[4]; const float* bias[4]; const float* out_bias; uint32_t layers; };   // weights transposed: [column][512 gate rows]
 hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb, const float* d_wout, uint32_t vocab,
                           uint32_t layers, uint32_t k, float* d_hid, float* d_logits, int32_t* d_tok, float* d_conf,
                           hipStream_t s, const LstmParams* lstm = nullptr);
