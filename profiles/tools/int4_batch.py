@@ -6,7 +6,7 @@ from bench import ramp, PAGE, BLOCK_ELEMS, HBM_PEAK_GBPS, EXTRAS_RAMP_MS
 kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), "hip:0")
 lib = kv.lib
 scheme = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-n_seq, T = 256, int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+n_seq, T = int(os.environ.get("NSEQ", "256")), int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 lib.set_compression_scheme(scheme)
 g = torch.Generator(device="cuda"); g.manual_seed(2004)
 n_pages = T * 8 * 128 * 2 * 2 // PAGE
