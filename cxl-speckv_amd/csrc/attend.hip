@@ -25,6 +25,7 @@
 //           (4 consecutive d of one position) and splits them with v_perm_b32.
 //           -> lane (c, kb) holds out[query row c][64blk + 16kb + 4i + t].
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace speckv {
 
@@ -921,6 +922,60 @@ __global__ __launch_bounds__(512) void k_attend_combine(const float* __restrict_
     }
 }
 
+// The merge for rows with at most 4 splits (batch launches split two or three ways): one WAVE per (layer | sequence, head),
+// lane (c, kb) = query row c, dimensions 32 kb .. 32 kb + 31 -- the layout the partials are stored in, so every access is a
+// 16-byte one.  (The general kernel above spends a 512-thread workgroup per query row: 16 384 workgroups for a batch of 256
+// sequences, more than the merge is worth when there are two partials to add.)
+__global__ __launch_bounds__(256) void k_attend_combine_small(const float* __restrict__ part_acc, const float* __restrict__ part_ml,
+                                                              uint32_t g, uint32_t n_splits, float* __restrict__ out,
+                                                              float* __restrict__ lse, const AttendSeq* __restrict__ seqs,
+                                                              uint32_t heads, uint32_t skip_single, uint32_t n_rows)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const uint32_t lane = threadIdx.x & 63u, c = lane & 15u, kb = lane >> 4;
+    const uint32_t rowq = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (rowq >= n_rows) return;
+    uint64_t part0 = static_cast<uint64_t>(rowq) * n_splits;
+    if (seqs) {
+        const AttendSeq sq = seqs[rowq / heads];
+        if (skip_single && sq.n_splits == 1u) return;
+        n_splits = sq.n_splits;
+        part0 = sq.part_base + static_cast<uint64_t>(rowq % heads) * n_splits;
+    }
+    const float* ml = part_ml + part0 * 32u + c;
+    float m[4], l[4];
+    float M = -INFINITY;
+#pragma unroll
+    for (uint32_t s = 0; s < 4u; ++s) {
+        m[s] = s < n_splits ? ml[s * 32u] : -INFINITY;
+        l[s] = s < n_splits ? ml[s * 32u + 16u] : 0.0f;
+        M = fmaxf(M, m[s]);
+    }
+    const float Mu = (M == -INFINITY) ? 0.0f : M;
+    float L = 0.0f;
+    v4f o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    const float* src = part_acc + (part0 * 16u + c) * 128u + 32u * kb;
+#pragma unroll
+    for (uint32_t s = 0; s < 4u; ++s) {
+        if (s < n_splits) {                                          // wave-uniform
+            const float w = __builtin_amdgcn_exp2f(m[s] - Mu);
+            L += w * l[s];
+            if (c < g) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] += *reinterpret_cast<const v4f*>(src + static_cast<uint64_t>(s) * 2048u + 4 * i) * w;
+            }
+        }
+    }
+    if (c < g) {
+        float* dst = out + (static_cast<uint64_t>(rowq) * g + c) * 128u + 32u * kb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<v4f*>(dst + 4 * i) = L > 0.0f ? o[i] / L : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        if (lse && kb == 0u) lse[static_cast<uint64_t>(rowq) * g + c] = L > 0.0f ? (M + log2f(L)) * 0.6931471805599453f : -INFINITY;
+    }
+}
+
 // q.K^T scores only, linear form: the score half of k_attend_fp8_linear (same operand maps, same register refill
 // pipeline for K) writing out[layer][head][row][position]; V is never touched.  tiles_per_split tiles per wave.
 __global__ __launch_bounds__(256) void k_qk_scores_fp8_linear(AttendArgs a, float* __restrict__ out)
@@ -1024,6 +1079,12 @@ hipError_t launch_attend_combine(const AttendArgs& a, uint32_t n_layers, float* 
 {
     if (n_layers == 0) return hipSuccess;
     if (a.n_splits > kMaxSplits) return hipErrorInvalidValue;
+    if (a.n_splits <= 4u && !getenv("SPECKV_ATTEND_BIG_COMBINE")) {
+        const uint32_t n_rows = n_layers * a.heads;
+        hipLaunchKernelGGL(k_attend_combine_small, dim3((n_rows + 3u) / 4u), dim3(256), 0, s, a.part_acc, a.part_ml, a.g,
+                           a.n_splits, d_out, d_lse, a.seqs, a.heads, (a.direct_out && a.direct_per_seq) ? 1u : 0u, n_rows);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_attend_combine, dim3(n_layers * a.heads * a.g), dim3(512), 0, s, a.part_acc, a.part_ml, a.g,
                        a.n_splits, d_out, d_lse, a.seqs, a.heads, (a.direct_out && a.direct_per_seq) ? 1u : 0u);
     return hipGetLastError();

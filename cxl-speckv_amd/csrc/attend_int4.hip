@@ -503,10 +503,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t c = lane & 15u, kb = lane >> 4;
-    const uint32_t split = blockIdx.x;
+    const uint32_t split = a.rows_first ? blockIdx.y : blockIdx.x, by = a.rows_first ? blockIdx.x : blockIdx.y;
     const uint32_t hq = a.heads / 4u;
-    uint32_t layer = blockIdx.y / hq;                                    // batch form: the sequence index
-    const uint32_t head0 = (blockIdx.y % hq) * 4u;                       // first head of the workgroup
+    uint32_t layer = by / hq;                                            // batch form: the sequence index
+    const uint32_t head0 = (by % hq) * 4u;                               // first head of the workgroup
     const uint32_t head = head0 + wave;
     const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;
     uint64_t part = row * a.n_splits + split;
@@ -691,9 +691,10 @@ hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_
 #ifdef SPECKV_INT4_REGSTAGE
     if (a.lin_base) hipLaunchKernelGGL(k_attend_int4<true>, dim3(a.n_splits, n_layers * (a.heads / kWgHeads)), dim3(64 * kWgHeads), 0, s, a);
 #else
-    if (a.lin_base) hipLaunchKernelGGL(k_attend_int4_wg<false>, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
+    const dim3 wg_grid = a.rows_first ? dim3(n_layers * (a.heads / 4u), a.n_splits) : dim3(a.n_splits, n_layers * (a.heads / 4u));
+    if (a.lin_base) hipLaunchKernelGGL(k_attend_int4_wg<false>, wg_grid, dim3(256), 0, s, a);
 #endif
-    else if (a.stripe_bases) hipLaunchKernelGGL(k_attend_int4_wg<true>, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
+    else if (a.stripe_bases) hipLaunchKernelGGL(k_attend_int4_wg<true>, wg_grid, dim3(256), 0, s, a);
     else            hipLaunchKernelGGL(k_attend_int4<false>, dim3(a.n_splits, n_layers * (a.heads / kWgHeads)), dim3(64 * kWgHeads), 0, s, a);
     return hipGetLastError();
 }

@@ -2311,6 +2311,34 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
 // entry points speckv_ext_attend_fp8 / _int4 are capturable).
 // Split length of a batch launch (see the measurements quoted in attend_batch).  seqs[i].n_splits holds the tile count of
 // sequence i (null: n_seq sequences of uniform_tiles each, the bound a plan is sized for).
+// INT4 batch launches with between half a machine and a whole one of workgroup columns (sequences x head groups in
+// [384, 672]; 768 workgroups are resident, three per CU -- profiles/tools/probe/occupancy_lds.hip): unsplit they leave the
+// CUs a third or more empty for the whole launch, and the kernel is bound by instruction issue, so occupancy is speed (256 x 8k: 512 columns 0.64 of HBM
+// peak; the same columns at 384 / 768 sequences 0.664 / 0.692).  Every long sequence then goes in TWO pieces, a long one
+// (fraction a of its tiles) and a short one, dispatched rows-first (AttendArgs::rows_first): the long pieces all start at
+// once, the short ones take the remaining slots in turns.  a from a sweep on the MI355X (8k context, gpurun_out r3t_uneq3: a = 0.5 .. 0.85):
+//   384 columns: 0.545 whole, 0.63-0.64 for a <= 0.65;   448: 0.594 whole, 0.645 at a = 0.75, 0.62 at 0.8, no gain below 0.7;
+//   512: 0.638 whole, 0.656 at 0.65, 0.669 at 0.8;         640: 0.607 whole, 0.64 at 0.5 and at 0.8
+// -> near-equal halves up to 416 columns (the split launch is then about one round of workgroups), 0.8 beyond.  (171 + 85 tiles in the
+// splits-first order of the other launches measured 0.52: the order is what makes it work; the merge is k_attend_combine_small.)
+constexpr uint32_t kUnequalMinTiles = 192;      // 6k positions (256 x 4k: the split costs 4 %)
+struct UnequalSplit { bool on; double a; };
+static UnequalSplit int4_unequal_split(uint32_t n_seq, uint32_t hq, uint32_t tiles_max)
+{
+    const uint32_t rows = n_seq * hq;
+    if (getenv("SPECKV_ATTEND_TILES_PER_SPLIT") || getenv("SPECKV_ATTEND_WG_TARGET") || getenv("SPECKV_ATTEND_WHOLE_SEQUENCES")) return {false, 1.0};
+    if (rows < 384u || rows > 672u || tiles_max < kUnequalMinTiles) return {false, 1.0};
+    if (const char* env = getenv("SPECKV_ATTEND_UNEQUAL_A")) return {true, atof(env)};      // (measurement runs)
+    return {true, rows <= 416u ? 0.55 : 0.8};
+}
+// the two pieces of one sequence (sequences shorter than kUnequalMinTiles tiles stay whole)
+static EvenSplit unequal_pieces(const UnequalSplit& u, uint32_t n_tiles)
+{
+    if (n_tiles < kUnequalMinTiles) return EvenSplit{std::max(1u, n_tiles), n_tiles ? 1u : 0u};
+    const uint32_t first = std::min(n_tiles - 1u, static_cast<uint32_t>(u.a * n_tiles + 0.999));
+    return EvenSplit{first, 2u};
+}
+
 static uint32_t batch_tiles_per_split(bool fp8, uint32_t n_seq, uint32_t heads, uint64_t total_tiles, const AttendSeq* seqs,
                                       uint32_t uniform_tiles)
 {
@@ -2394,13 +2422,17 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     // 0.67, 512: 0.65, 1024 = no split: 0.60), shorter sequences are best left whole (8k 0.63 against 0.59 in two
     // splits, 4k 0.60 / 0.52, 2k 0.58 / 0.43: single-split rows are final, no partials and no merge).
     const uint32_t tps = batch_tiles_per_split(fp8, n_seq, heads, total_tiles, seqs.data(), 0);
+    uint32_t tiles_max = 0;
+    for (uint32_t i = 0; i < n_seq; ++i) tiles_max = std::max(tiles_max, seqs[i].n_splits);
+    const UnequalSplit unequal = fp8 ? UnequalSplit{false, 1.0} : int4_unequal_split(n_seq, heads / 4u, tiles_max);
     uint32_t max_splits = 0;
     uint64_t parts = 0;
     for (uint32_t i = 0; i < n_seq; ++i) {
         const uint32_t n_tiles = seqs[i].n_splits;
         if ((n_tiles + tps - 1u) / tps > 2048u) return SPECKV_ERR_INVAL;
         // the sequence's tiles divided evenly over its splits (171 + 85 tiles instead of 128 + 128 cost 15 %)
-        const EvenSplit es = even_split(n_tiles, (n_tiles + tps - 1u) / tps);
+        EvenSplit es = even_split(n_tiles, (n_tiles + tps - 1u) / tps);
+        if (unequal.on) es = unequal_pieces(unequal, n_tiles);
         seqs[i].tiles_per_split = n_tiles ? es.tiles_per_split : tps;
         seqs[i].n_splits = es.n_splits;
         seqs[i].part_base = static_cast<uint32_t>(parts);
@@ -2445,6 +2477,7 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     bool one_split_each = true;                           // then the attention kernel writes the final rows itself
     for (uint32_t i = 0; i < n_seq; ++i) one_split_each = one_split_each && seqs[i].n_splits == 1u;
     if (one_split_each) { k.direct_out = d_out; k.direct_lse = d_lse; }
+    if (unequal.on) k.rows_first = 1u;
     if (fp8) {
         HIP_TRY(launch_attend_fp8_batch(k, n_seq, d_out, d_lse, st));
     } else {
@@ -2460,11 +2493,18 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
 // (outside the graph, once per step) writes one descriptor per sequence -- valid for every layer -- into a device buffer
 // of the caller; speckv_ext_attend_*_planned is kernel launches only: no handle look-ups, no staging, grid and scratch
 // sized from max_pos_end alone, so a captured launch stays valid for as long as the lengths stay within that bound.
-struct PlanGeometry { uint32_t tps, max_splits; uint64_t parts_bound; };
+struct PlanGeometry { uint32_t tps, max_splits; uint64_t parts_bound; UnequalSplit unequal; };
 static PlanGeometry plan_geometry(bool fp8, uint32_t n_seq, uint32_t heads, uint32_t max_pos_end)
 {
     const uint32_t tiles_max = (max_pos_end / 2u + 15u) / 16u;
     PlanGeometry g{};
+    g.unequal = fp8 ? UnequalSplit{false, 1.0} : int4_unequal_split(n_seq, heads / 4u, tiles_max);
+    if (g.unequal.on) {                                       // (the rule depends on the plan's bound only: plan and launch agree)
+        g.tps = tiles_max;
+        g.max_splits = 2u;
+        g.parts_bound = static_cast<uint64_t>(n_seq) * heads * 2u;
+        return g;
+    }
     g.tps = batch_tiles_per_split(fp8, n_seq, heads, static_cast<uint64_t>(tiles_max) * n_seq, nullptr, tiles_max);
     g.max_splits = std::max(1u, (tiles_max + g.tps - 1u) / g.tps);
     g.parts_bound = static_cast<uint64_t>(n_seq) * heads * g.max_splits;
@@ -2514,7 +2554,7 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
     uint64_t parts = 0;
     for (uint32_t i = 0; i < n_seq; ++i) {
         const uint32_t n_tiles = seqs[i].n_splits;
-        const EvenSplit es = even_split(n_tiles, (n_tiles + g.tps - 1u) / g.tps);
+        const EvenSplit es = g.unequal.on ? unequal_pieces(g.unequal, n_tiles) : even_split(n_tiles, (n_tiles + g.tps - 1u) / g.tps);
         seqs[i].tiles_per_split = n_tiles ? es.tiles_per_split : g.tps;
         seqs[i].n_splits = es.n_splits;
         seqs[i].part_base = static_cast<uint32_t>(parts);
@@ -2577,6 +2617,7 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
     k.direct_lse = d_lse;
     // ... decided per sequence on the device, the merge skips those; a geometry of one split at most needs no merge at all
     k.direct_per_seq = pg.max_splits == 1u ? 2u : 1u;
+    if (pg.unequal.on) k.rows_first = 1u;
     if (fp8) {
         HIP_TRY(launch_attend_fp8_batch(k, n_seq, d_out, d_lse, s));
     } else {

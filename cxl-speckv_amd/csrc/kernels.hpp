@@ -260,6 +260,10 @@ struct AttendArgs {
     // Batch form: non-null marks a striped launch, every AttendSeq then carries its own stripe_bases / stripe_n.
     const uint64_t* stripe_bases;
     uint32_t stripe_n, stripe_magic;
+    // rows-first launches: grid (rows, splits) instead of (splits, rows), so that the workgroups are dispatched split by
+    // split -- split 0 of every row first.  With a long split 0 and a short split 1 per row the long pieces all start at
+    // once and the short ones fill the remaining workgroup slots in turns (engine.cpp: batch_unequal_split)
+    uint32_t rows_first;
 };
 #if defined(__HIPCC__)
 // record address of page p in the striped form; `bases` = the allocation's run bases copied to LDS
