@@ -922,10 +922,12 @@ __global__ __launch_bounds__(512) void k_attend_combine(const float* __restrict_
     }
 }
 
-// The merge for rows with at most 4 splits (batch launches split two or three ways): one WAVE per (layer | sequence, head),
+// The merge for rows with at most kSmallCombineSplits splits (batch launches split two or three ways, the many-layers form with
+// its 8): one WAVE per (layer | sequence, head),
 // lane (c, kb) = query row c, dimensions 32 kb .. 32 kb + 31 -- the layout the partials are stored in, so every access is a
 // 16-byte one.  (The general kernel above spends a 512-thread workgroup per query row: 16 384 workgroups for a batch of 256
 // sequences, more than the merge is worth when there are two partials to add.)
+constexpr uint32_t kSmallCombineSplits = 8;
 __global__ __launch_bounds__(256) void k_attend_combine_small(const float* __restrict__ part_acc, const float* __restrict__ part_ml,
                                                               uint32_t g, uint32_t n_splits, float* __restrict__ out,
                                                               float* __restrict__ lse, const AttendSeq* __restrict__ seqs,
@@ -943,10 +945,10 @@ __global__ __launch_bounds__(256) void k_attend_combine_small(const float* __res
         part0 = sq.part_base + static_cast<uint64_t>(rowq % heads) * n_splits;
     }
     const float* ml = part_ml + part0 * 32u + c;
-    float m[4], l[4];
+    float m[kSmallCombineSplits], l[kSmallCombineSplits];
     float M = -INFINITY;
 #pragma unroll
-    for (uint32_t s = 0; s < 4u; ++s) {
+    for (uint32_t s = 0; s < kSmallCombineSplits; ++s) {
         m[s] = s < n_splits ? ml[s * 32u] : -INFINITY;
         l[s] = s < n_splits ? ml[s * 32u + 16u] : 0.0f;
         M = fmaxf(M, m[s]);
@@ -958,7 +960,7 @@ __global__ __launch_bounds__(256) void k_attend_combine_small(const float* __res
     for (int i = 0; i < 8; ++i) o[i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
     const float* src = part_acc + (part0 * 16u + c) * 128u + 32u * kb;
 #pragma unroll
-    for (uint32_t s = 0; s < 4u; ++s) {
+    for (uint32_t s = 0; s < kSmallCombineSplits; ++s) {
         if (s < n_splits) {                                          // wave-uniform
             const float w = __builtin_amdgcn_exp2f(m[s] - Mu);
             L += w * l[s];
@@ -1079,7 +1081,7 @@ hipError_t launch_attend_combine(const AttendArgs& a, uint32_t n_layers, float* 
 {
     if (n_layers == 0) return hipSuccess;
     if (a.n_splits > kMaxSplits) return hipErrorInvalidValue;
-    if (a.n_splits <= 4u && !getenv("SPECKV_ATTEND_BIG_COMBINE")) {
+    if (a.n_splits <= kSmallCombineSplits && !getenv("SPECKV_ATTEND_BIG_COMBINE")) {
         const uint32_t n_rows = n_layers * a.heads;
         hipLaunchKernelGGL(k_attend_combine_small, dim3((n_rows + 3u) / 4u), dim3(256), 0, s, a.part_acc, a.part_ml, a.g,
                            a.n_splits, d_out, d_lse, a.seqs, a.heads, (a.direct_out && a.direct_per_seq) ? 1u : 0u, n_rows);
