@@ -40,20 +40,34 @@ __device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi)
 {
     return static_cast<long>(static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32));
 }
+// Record loads go through an explicit GLOBAL-address-space pointer.  A pointer the compiler cannot trace back to a kernel argument
+// (one that is assigned under a template condition, or read from a page-table entry) otherwise becomes a FLAT load: flat loads
+// count in lgkmcnt as well as vmcnt, the waits in front of the loop's scalar and LDS reads then drain every record load in
+// flight, and the compiler's own vmcnt(N) bookkeeping collapses to vmcnt(0) -- the linear FP8 kernel lost 15 % that way when
+// its pointers were initialised as nullptr for the striped instantiation (128 x 2k batch: 0.73 -> 0.62 of HBM peak).
 __device__ __forceinline__ uint4 ldg16(const uint8_t* p)
 {
-    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    typedef const u32x4 __attribute__((address_space(1)))* gp;
+    const u32x4 v = __builtin_nontemporal_load((gp)(reinterpret_cast<uintptr_t>(p)));
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ uint2 ldg8(const uint8_t* p)
 {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+    typedef const u32x2 __attribute__((address_space(1)))* gp;
+    const u32x2 v = __builtin_nontemporal_load((gp)(reinterpret_cast<uintptr_t>(p)));
     return make_uint2(v.x, v.y);
 }
 __device__ __forceinline__ uint32_t ldg4(const uint8_t* p)
 {
-    return __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p));
+    typedef const uint32_t __attribute__((address_space(1)))* gp;
+    return __builtin_nontemporal_load((gp)(reinterpret_cast<uintptr_t>(p)));
+}
+// four floats of a scale table (temporal: the table is small and every workgroup of a layer reads it), global address space as above
+__device__ __forceinline__ f32x4 ldg_f4(const float* p)
+{
+    typedef const f32x4 __attribute__((address_space(1)))* gp;
+    return *(gp)(reinterpret_cast<uintptr_t>(p));
 }
 // max over the four lanes {c, c+16, c+32, c+48}
 __device__ __forceinline__ float max_over_kb(float v)
@@ -453,7 +467,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 const uint8_t* src = STRIPED ? rec(kpage0 + tile_k * 16u + 8u * b) + koff : kp + 16384 * b;
                 kx[b][0] = ldg16(src); kx[b][1] = ldg16(src + 64);
             }
-            ks4 = *reinterpret_cast<const f32x4*>(kt);
+            ks4 = ldg_f4(kt);
         };
         auto issue_v = [&]() {
             if (STRIPED) {
@@ -467,7 +481,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
                 for (int j = 0; j < 8; ++j) vx[j] = ldg8(vp + 1024 * (j & 3) + 16384 * (j >> 2));
             }
-            vs4 = *reinterpret_cast<const f32x4*>(vt);
+            vs4 = ldg_f4(vt);
         };
         // same request order as in the loop (K before V), pinned, so that the wait at the loop head is
         // "everything up to K" on both paths into it
@@ -1010,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_qk_scores_fp8_linear(AttendArgs a, floa
     auto issue_k = [&](KTile& T) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) { T.kx[b][0] = ldg16(kp + 16384 * b); T.kx[b][1] = ldg16(kp + 16384 * b + 64); }
-        T.ks4 = *reinterpret_cast<const f32x4*>(kt);
+        T.ks4 = ldg_f4(kt);
     };
     auto score_store = [&](uint32_t tile, const KTile& T) {
         f32x4 sc[2];

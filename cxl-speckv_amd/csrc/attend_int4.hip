@@ -42,12 +42,20 @@ namespace {
 // which then ran at 0.70 of its peak while the kernel delivered 0.43).  profiles/r02_int4_mem_pmc.json
 __device__ __forceinline__ uint4 ldg16(const uint8_t* p)
 {
+    // (explicit global address space: record pointers read from page-table entries would otherwise make FLAT loads, which
+    // count in lgkmcnt as well and serialise against every LDS wait -- attend.hip)
+    typedef const u32x4 __attribute__((address_space(1)))* gp;
 #ifdef SPECKV_INT4_NT_LOADS
-    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
+    const u32x4 v = __builtin_nontemporal_load((gp)(reinterpret_cast<uintptr_t>(p)));
 #else
-    return *reinterpret_cast<const uint4*>(p);
+    const u32x4 v = *(gp)(reinterpret_cast<uintptr_t>(p));
 #endif
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+template <typename T> __device__ __forceinline__ T ldg_small(const uint8_t* p)
+{
+    typedef const T __attribute__((address_space(1)))* gp;
+    return *(gp)(reinterpret_cast<uintptr_t>(p));
 }
 __device__ __forceinline__ float max_over_kb(float v)
 {
@@ -337,10 +345,10 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
             for (int b = 0; b < 2; ++b) {
                 if (LINEAR) {
                     kx[b] = ldg16(kdat + 8u * kInt4RecBytes * b);
-                    ks[b] = *reinterpret_cast<const uint16_t*>(ksc + 8u * kInt4RecBytes * b);
+                    ks[b] = ldg_small<uint16_t>(ksc + 8u * kInt4RecBytes * b);
                 } else {
                     kx[b] = ldg16(kbase[b] + 128u + rowoff * 64u + kb * 16u);
-                    ks[b] = *reinterpret_cast<const uint16_t*>(kbase[b] + rowoff * 8u + kb * 2u);
+                    ks[b] = ldg_small<uint16_t>(kbase[b] + rowoff * 8u + kb * 2u);
                 }
             }
             if (!LINEAR) lookup_k(next_k + 1u);                          // (clamped into the range by rec_base)
@@ -349,12 +357,12 @@ __global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_wa
             if (LINEAR) {
                 vraw[0] = ldg16(vdat);
                 vraw[1] = ldg16(vdat + 8u * kInt4RecBytes);
-                vsraw = *reinterpret_cast<const uint32_t*>(vsc);
+                vsraw = ldg_small<uint32_t>(vsc);
             } else {
                 const uint32_t voff = 128u + ((vr & 1u) * 8u + head) * 64u + (lane & 3u) * 16u;
                 vraw[0] = ldg16(vbase[0] + voff);
                 vraw[1] = ldg16(vbase[1] + voff);
-                vsraw = *reinterpret_cast<const uint32_t*>(vbase[2] + ((sr & 1u) * 8u + head) * 8u + (lane & 1u) * 4u);
+                vsraw = ldg_small<uint32_t>(vbase[2] + ((sr & 1u) * 8u + head) * 8u + (lane & 1u) * 4u);
                 lookup_v(next_v + 1u);
             }
         };

@@ -2350,7 +2350,8 @@ static uint32_t batch_tiles_per_split(bool fp8, uint32_t n_seq, uint32_t heads, 
         // 768: 0.71; 32 x 32k: 256 workgroups 0.79, 512: 0.76, 384: 0.63; 128 x 2k: unsplit 0.73, two splits 0.56)
         std::vector<uint32_t> tiles;
         if (seqs) { tiles.resize(n_seq); for (uint32_t i = 0; i < n_seq; ++i) tiles[i] = seqs[i].n_splits; }
-        return fp8_batch_tiles_per_split(seqs ? tiles.data() : nullptr, n_seq, uniform_tiles, hq);
+        const char* mc = getenv("SPECKV_FP8_MERGE_COST");                     // (measurement runs)
+        return fp8_batch_tiles_per_split(seqs ? tiles.data() : nullptr, n_seq, uniform_tiles, hq, 256u, mc ? static_cast<uint32_t>(atoi(mc)) : 8u);
     }
     uint64_t wg_target = fp8 ? 512u : 768u;
     if (target_env) wg_target = std::max(1, atoi(target_env));

@@ -50,22 +50,46 @@ constexpr int kEncLdsHalves = 2064;        // per wave: 4128 B (see kEncWaveByte
 #define SPECKV_NT_STORE 1
 #endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// Records and block images are reached through pointers read from page-table entries / pointer lists, which the compiler cannot
+// trace back to a kernel argument: plain C++ dereferences of them become FLAT loads and stores (an address-space check per
+// access, and every one counts in lgkmcnt as well as vmcnt, so the waits in front of LDS and scalar reads wait for them too).
+// The codec's accesses therefore go through explicit global-address-space pointers (attend.hip: the same hazard cost the
+// linear FP8 attention kernel 15 %).
+typedef u32x4 __attribute__((address_space(1))) g_u32x4;
+template <typename T> __device__ __forceinline__ T gload(const void* p)
+{
+    typedef T __attribute__((address_space(1))) G;
+    return *(const G*)(reinterpret_cast<uintptr_t>(p));
+}
+template <typename T> __device__ __forceinline__ void gstore(void* p, T v)
+{
+    typedef T __attribute__((address_space(1))) G;
+    *(G*)(reinterpret_cast<uintptr_t>(p)) = v;
+}
+__device__ __forceinline__ uint2 gload_u2(const void* p)
+{
+    typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+    const v2 v = gload<v2>(p);
+    return make_uint2(v.x, v.y);
+}
 __device__ __forceinline__ uint4 ld16(const uint8_t* p)
 {
+    const g_u32x4* gp = (const g_u32x4*)(reinterpret_cast<uintptr_t>(p));
 #if defined(SPECKV_NT_LOAD)
-    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
+    const u32x4 v = __builtin_nontemporal_load(gp);
 #else
-    return *reinterpret_cast<const uint4*>(p);
+    const u32x4 v = *gp;
 #endif
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void st16(uint8_t* p, uint4 v)
 {
+    g_u32x4* gp = (g_u32x4*)(reinterpret_cast<uintptr_t>(p));
+    const u32x4 t = {v.x, v.y, v.z, v.w};
 #if defined(SPECKV_NT_STORE)
-    u32x4 t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
+    __builtin_nontemporal_store(t, gp);
 #else
-    *reinterpret_cast<uint4*>(p) = v;
+    *gp = t;
 #endif
 }
 // The compress direction streams too: every source byte is read once, every record byte written once (the fp16 "compress"
@@ -75,7 +99,8 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint4 enc_ld16(const uint8_t* p)
 {
 #if defined(SPECKV_ENC_PLAIN)
-    return *reinterpret_cast<const uint4*>(p);
+    const u32x4 v = *(const g_u32x4*)(reinterpret_cast<uintptr_t>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
 #else
     return ld16(p);
 #endif
@@ -83,18 +108,20 @@ __device__ __forceinline__ uint4 enc_ld16(const uint8_t* p)
 __device__ __forceinline__ void enc_st16(uint8_t* p, uint4 v)
 {
 #if defined(SPECKV_ENC_PLAIN)
-    *reinterpret_cast<uint4*>(p) = v;
+    *(g_u32x4*)(reinterpret_cast<uintptr_t>(p)) = u32x4{v.x, v.y, v.z, v.w};
 #else
     st16(p, v);
 #endif
 }
 __device__ __forceinline__ void enc_st8(uint8_t* p, uint2 v)
 {
+    typedef u32x2 __attribute__((address_space(1))) g_u32x2;
+    g_u32x2* gp = (g_u32x2*)(reinterpret_cast<uintptr_t>(p));
+    const u32x2 t = {v.x, v.y};
 #if defined(SPECKV_ENC_PLAIN)
-    *reinterpret_cast<uint2*>(p) = v;
+    *gp = t;
 #else
-    u32x2 t = {v.x, v.y};
-    __builtin_nontemporal_store(t, reinterpret_cast<u32x2*>(p));
+    __builtin_nontemporal_store(t, gp);
 #endif
 }
 template <bool F32>
@@ -329,10 +356,10 @@ template <bool F32>
 __device__ __forceinline__ void store_elem(uint8_t* dst, uint32_t p, float y)
 {
     if (F32) {
-        reinterpret_cast<float*>(dst)[p] = y;
+        gstore<float>(dst + 4ull * p, y);
     } else {
         float a = y, z = 0.0f;
-        reinterpret_cast<uint16_t*>(dst)[p] = static_cast<uint16_t>(pack_half2(a, z) & 0xFFFFu);
+        gstore<uint16_t>(dst + 2ull * p, static_cast<uint16_t>(pack_half2(a, z) & 0xFFFFu));
     }
 }
 template <int MODE, bool F32>
@@ -345,7 +372,7 @@ __device__ __noinline__ void decode_rle_general(const uint8_t* __restrict__ rec,
     for (uint32_t b = 0; b < npairs; b += 64u) {
         const uint32_t i = b + lane;
         uint32_t bits = 0;
-        if (i < npairs) bits = *reinterpret_cast<const uint16_t*>(rec + 2ull * i);
+        if (i < npairs) bits = gload<uint16_t>(rec + 2ull * i);
         const uint32_t v = bits & 0xFFu, c = bits >> 8;
         const uint32_t packed = ((v * c) << 24) | c;
         const uint32_t incl = wave_incl_add(packed);
@@ -376,7 +403,7 @@ __device__ __forceinline__ void decode_int8(const uint8_t* __restrict__ rec, uin
     for (int j = 0; j < 4; ++j) {
         const uint32_t p0 = 512u * j + 8u * lane;
         uint2 w = make_uint2(0u, 0u);
-        if (p0 < len) w = *reinterpret_cast<const uint2*>(rec + p0);
+        if (p0 < len) w = gload_u2(rec + p0);
         float y[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -434,8 +461,8 @@ __device__ __forceinline__ void decode_int4(const uint8_t* __restrict__ rec, uin
         uint32_t nib = 0;
         float s = 0.0f;
         if (ok) {
-            nib = *reinterpret_cast<const uint32_t*>(rec + 128u + (p0 >> 1));
-            s = half_bits_to_float(*reinterpret_cast<const uint16_t*>(rec + 2u * (p0 >> 5)));
+            nib = gload<uint32_t>(rec + 128u + (p0 >> 1));
+            s = half_bits_to_float(gload<uint16_t>(rec + 2u * (p0 >> 5)));
         }
         float y[8];
 #pragma unroll
@@ -456,7 +483,7 @@ __device__ __forceinline__ void decode_fp8(const uint8_t* __restrict__ rec, uint
     for (int j = 0; j < 4; ++j) {
         const uint32_t p0 = 512u * j + 8u * lane;
         uint2 w = make_uint2(0u, 0u);
-        if (p0 < len) w = *reinterpret_cast<const uint2*>(rec + p0);
+        if (p0 < len) w = gload_u2(rec + p0);
         float y[8];
         y[0] = __builtin_amdgcn_cvt_f32_fp8(static_cast<int>(w.x), 0);
         y[1] = __builtin_amdgcn_cvt_f32_fp8(static_cast<int>(w.x), 1);
@@ -761,7 +788,7 @@ __device__ __noinline__ uint32_t encode_rle_general(const uint8_t* __restrict__ 
 #pragma unroll 1
     for (uint32_t step = 0; step < kBlockElems / 64u; ++step) {
         const uint32_t p = 64u * step + lane;
-        const uint32_t qv = quantize<MODE>(half_bits_to_float(reinterpret_cast<const uint16_t*>(src)[p]), scale);
+        const uint32_t qv = quantize<MODE>(half_bits_to_float(gload<uint16_t>(src + 2ull * p)), scale);
         const uint32_t prevq = wave_shr1(qv, qtail);
         qtail = lane63(qv);
         const uint32_t d = (qv - prevq) & 0xFFu;
@@ -810,7 +837,7 @@ __device__ __noinline__ float absmax_with_nonfinite(const uint8_t* __restrict__ 
     float mx = 0.0f;
 #pragma unroll 1
     for (uint32_t p = lane; p < kBlockElems; p += 64u)
-        mx = __builtin_fmaxf(mx, fabsf(half_bits_to_float(reinterpret_cast<const uint16_t*>(src)[p])));
+        mx = __builtin_fmaxf(mx, fabsf(half_bits_to_float(gload<uint16_t>(src + 2ull * p))));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float other = __shfl_xor(mx, o);
@@ -848,7 +875,7 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
             page = g.first + j * (a.page_step ? a.page_step : 1);
             src = g.data + j * a.data_stride;
         }
-        uint8_t* rec = entries ? reinterpret_cast<uint8_t*>(entries[page].pool_addr)
+        uint8_t* rec = entries ? reinterpret_cast<uint8_t*>(gload<uint64_t>(&entries[page].pool_addr))
                                : a.recs + page * a.rec_stride;
         uint32_t out_len;
         float scale = 1.0f;
@@ -1042,11 +1069,11 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
         }
         if (lane == 0u) {
             if (entries) {
-                entries[page].rec_bytes = out_len;
-                entries[page].scale = scale;
+                gstore<uint32_t>(&entries[page].rec_bytes, out_len);
+                gstore<float>(&entries[page].scale, scale);
                 if (scale_tab) {
                     const uint32_t j = static_cast<uint32_t>(page % region_pages) & 15u;
-                    scale_tab[page - j + attend_tile_slot(j)] = scale;
+                    gstore<float>(&scale_tab[page - j + attend_tile_slot(j)], scale);
                 }
             } else {
                 a.rec_bytes[page] = out_len;

@@ -46,10 +46,11 @@ __host__ __device__ inline EvenSplit even_split(uint32_t n_tiles, uint32_t want)
 // Split length (tiles) of an FP8 batch attention launch.  tiles[i] = tiles of sequence i (null: n_seq sequences of
 // uniform_tiles each); columns_per_seq = workgroup columns one sequence contributes (kv heads / 4).  The four workgroups a
 // CU can hold share its rate, so a launch takes about  ceil(workgroups / 256) x (tiles per split + 3)  tile times, plus
-// about 16 for the merge launch if anything is split: the rule prices whole sequences and the split counts that just fill
+// about 16 for the merge launch if anything is split (8 with at most 8 splits per row: the one-wave merge kernel; measured
+// 100 x 4k: whole 0.54 of HBM peak, two splits 0.61): the rule prices whole sequences and the split counts that just fill
 // 1 .. 4 workgroups per CU, and takes the cheapest.  Beyond 1024 workgroups the launch runs in waves of 1024.
 inline uint32_t fp8_batch_tiles_per_split(const uint32_t* tiles, uint32_t n_seq, uint32_t uniform_tiles, uint32_t columns_per_seq,
-                                          uint32_t n_cus = 256u)
+                                          uint32_t n_cus = 256u, uint32_t merge_cost_small = 8u)
 {
     uint32_t n_max = tiles ? 0u : uniform_tiles;
     if (tiles) for (uint32_t i = 0; i < n_seq; ++i) n_max = tiles[i] > n_max ? tiles[i] : n_max;
@@ -69,7 +70,7 @@ inline uint32_t fp8_batch_tiles_per_split(const uint32_t* tiles, uint32_t n_seq,
         wgs *= columns_per_seq;
         const uint64_t resident = 4ull * n_cus;
         const uint64_t slots = wgs <= resident ? (wgs + n_cus - 1u) / n_cus : 4u * ((wgs + resident - 1u) / resident);
-        const uint64_t cost = slots * (tps + (sp > 1u ? 3u : 0u)) + (sp > 1u ? 16u : 0u);
+        const uint64_t cost = slots * (tps + (sp > 1u ? 3u : 0u)) + (sp > 1u ? (sp <= 8u ? merge_cost_small : 16u) : 0u);
         if (cost < best_cost) { best_cost = cost; best = tps; }
     }
     return best;

@@ -55,7 +55,8 @@ if drv:
 for t in ("ascalled", "full"):
     f = sorted(glob.glob(os.path.join(g, prof, f"trace_{t}", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     shutil.copy(f[-1], os.path.join(P, f"{tag}_kernel_stats_{t}.csv"))      # the newest, should an older run's output remain
-for extra, name in (("r2h_conn_step.txt", "connector_step.txt"), ("r2h_batch_rule_ab.txt", "fp8_batch_split_rule_ab.txt")):
-    if os.path.exists(os.path.join(g, extra)):
-        shutil.copy(os.path.join(g, extra), os.path.join(P, f"{tag}_{name}"))
+if tag.startswith("r02"):                                            # (round-2 side files; later rounds publish their own)
+    for extra, name in (("r2h_conn_step.txt", "connector_step.txt"), ("r2h_batch_rule_ab.txt", "fp8_batch_split_rule_ab.txt")):
+        if os.path.exists(os.path.join(g, extra)):
+            shutil.copy(os.path.join(g, extra), os.path.join(P, f"{tag}_{name}"))
 print("published", tag)

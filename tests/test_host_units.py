@@ -344,7 +344,8 @@ def test_fp8_batch_split_rule(rules):
     assert uniform(32, 128) == 32 and uniform(16, 256) == 32      # 256 workgroups
     assert uniform(32, 1024) == 256 and uniform(4, 4096) == 128   # 256 workgroups
     assert uniform(48, 512) == 64                                 # 8 splits: 768 workgroups = three per CU (288 would be 0.50 of peak)
-    assert uniform(100, 128) == 128 and uniform(300, 128) == 128  # 200 / 600 columns: splitting only unbalances them
+    assert uniform(300, 128) == 128                               # 600 columns: splitting only unbalances them
+    assert uniform(100, 128) == 26                                # 200 columns x 5 splits = 1000 workgroups (measured 0.61 of HBM peak, whole 0.54) since the merge is one wave per row
     rng = np.random.default_rng(5)
     for _ in range(400):
         n_seq = int(rng.integers(1, 700))
@@ -356,7 +357,7 @@ def test_fp8_batch_split_rule(rules):
         if n_seq * hq >= 256:
             assert splits == 1 or wgs <= 1024                     # a batch that covers the chip is split only inside one residency
         if splits > 1:                                            # priced below whole sequences by the rule's own cost
-            assert wgs <= 1024 and -(-wgs // 256) * (tps + 3) + 16 < cost_whole(n_seq * hq, tiles), (n_seq, tiles, tps, wgs)
+            assert wgs <= 1024 and -(-wgs // 256) * (tps + 3) + (8 if splits <= 8 else 16) < cost_whole(n_seq * hq, tiles), (n_seq, tiles, tps, wgs)
     # ragged batches: priced on their real workgroup count, and every sequence's own split count stays within the merge's limit
     for _ in range(200):
         n_seq = int(rng.integers(1, 300))
