@@ -45,23 +45,27 @@ __device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi)
 // count in lgkmcnt as well as vmcnt, the waits in front of the loop's scalar and LDS reads then drain every record load in
 // flight, and the compiler's own vmcnt(N) bookkeeping collapses to vmcnt(0) -- the linear FP8 kernel lost 15 % that way when
 // its pointers were initialised as nullptr for the striped instantiation (128 x 2k batch: 0.73 -> 0.62 of HBM peak).
+#ifdef SPECKV_ABL_FLAT_LDG      // (A/B only: the loads as they were, flat wherever the pointer's origin is not visible)
+#define SPECKV_GP(T, p) reinterpret_cast<const T*>(p)
+#else
+#define SPECKV_GP(T, p) ((const T __attribute__((address_space(1)))*)(reinterpret_cast<uintptr_t>(p)))
+#endif
 __device__ __forceinline__ uint4 ldg16(const uint8_t* p)
 {
     typedef const u32x4 __attribute__((address_space(1)))* gp;
-    const u32x4 v = __builtin_nontemporal_load((gp)(reinterpret_cast<uintptr_t>(p)));
+    (void)sizeof(gp);
+    const u32x4 v = __builtin_nontemporal_load(SPECKV_GP(u32x4, p));
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ uint2 ldg8(const uint8_t* p)
 {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    typedef const u32x2 __attribute__((address_space(1)))* gp;
-    const u32x2 v = __builtin_nontemporal_load((gp)(reinterpret_cast<uintptr_t>(p)));
+    const u32x2 v = __builtin_nontemporal_load(SPECKV_GP(u32x2, p));
     return make_uint2(v.x, v.y);
 }
 __device__ __forceinline__ uint32_t ldg4(const uint8_t* p)
 {
-    typedef const uint32_t __attribute__((address_space(1)))* gp;
-    return __builtin_nontemporal_load((gp)(reinterpret_cast<uintptr_t>(p)));
+    return __builtin_nontemporal_load(SPECKV_GP(uint32_t, p));
 }
 // four floats of a scale table (temporal: the table is small and every workgroup of a layer reads it), global address space as above
 __device__ __forceinline__ f32x4 ldg_f4(const float* p)
