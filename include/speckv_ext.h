@@ -17,7 +17,11 @@
  * hipStream_t passed as void*: the work is ordered on it and the call returns
  * without waiting.  NULL = the engine's own stream and a SYNCHRONOUS call: it
  * first waits for the device (the caller's buffers may have been produced on
- * any stream) and returns when the result is complete.
+ * any stream) and returns when the result is complete.  A stream handed to the
+ * library must stay alive until speckv_finalize or until the library has been
+ * called on another stream after it: the engine orders later work behind the
+ * stream that last wrote an allocation or last used one of its scratch buffers
+ * by recording an event on that stream.
  */
 #ifndef SPECKV_EXT_H
 #define SPECKV_EXT_H
