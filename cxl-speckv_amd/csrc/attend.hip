@@ -360,8 +360,11 @@ __global__ __launch_bounds__(256) void k_build_scale_tab(const PageEntry* __rest
 // STRIPED: the same loop for an allocation striped regularly over several pools (AttendArgs::stripe_bases): the six record
 // addresses a lane needs per tile (2 K pages, 4 V pages) are recomputed from the page number -- one multiply-high, one
 // LDS read of the run base, one 64-bit multiply-add each -- instead of advancing one pointer.  Single-sequence form only.
-template <bool STRIPED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_attend_fp8_linear(AttendArgs a)
+// TABLE: the same loop for an allocation without a regular placement (AttendArgs::table_form): the six record addresses come
+// from the page-table entries, looked up ONE REQUEST AHEAD (a request is then one round trip, not an entry and the record
+// behind it); never-written pages read the zero page.  Single-sequence form only.
+template <bool STRIPED, bool TABLE = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 : 4, TABLE ? 3 : 4))) void k_attend_fp8_linear(AttendArgs a)
 {
     __shared__ uint64_t s_bases[8];
     const uint32_t lane = threadIdx.x & 63u;
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // running pointers of the tile being requested
         const uint8_t* kp = nullptr;
         const uint8_t* vp = nullptr;
-        if (!STRIPED) {
+        if (!STRIPED && !TABLE) {
             kp = a.lin_base + (a.k_first + layer * a.layer_stride) * 2048ull + head * 128u + kb * 16u
                  + (static_cast<uint64_t>(t0) * 32u + c) * 1024u;            // block b: + b*16 KiB; second half of the row: + 64
             vp = a.lin_base + (a.v_first + layer * a.layer_stride) * 2048ull + head * 128u + 8u * c
@@ -461,6 +464,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const uint32_t koff = (c & 1u) * 1024u + head * 128u + kb * 16u, voff = head * 128u + 8u * c;
         uint32_t tile_k = t0, tile_v = t0;                                   // tile the next request is for
         auto rec = [&](uint32_t page) { return attend_stripe_rec(s_bases, page, a.stripe_n, a.stripe_magic, 2048u); };
+        // table form: record base of an absolute page of the allocation (clamped to the end of the region; a page that
+        // was never written reads zeros), and the bases of the tile the NEXT request is for
+        const uint32_t k_end = static_cast<uint32_t>(a.k_first + layer * a.layer_stride) + a.n_pages - 1u;
+        const uint32_t v_end = static_cast<uint32_t>(a.v_first + layer * a.layer_stride) + a.n_pages - 1u;
+        auto lookup = [&](uint32_t page, uint32_t end) -> const uint8_t* {
+            typedef const u32x4 __attribute__((address_space(1)))* gp;
+            const u32x4 e = *(gp)(reinterpret_cast<uintptr_t>(a.entries + min(page, end)));      // {address lo, hi, record bytes, scale}
+            const uint8_t* r = reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(e.x) | (static_cast<uint64_t>(e.y) << 32));
+            return e.z >= 2048u ? r : a.zero_page;
+        };
+        const uint8_t* kbase[2] = {nullptr, nullptr};
+        const uint8_t* vbase[4] = {nullptr, nullptr, nullptr, nullptr};
+        auto lookup_k = [&](uint32_t tile) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) kbase[b] = lookup(kpage0 + tile * 16u + 8u * b, k_end);
+        };
+        auto lookup_v = [&](uint32_t tile) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) vbase[jj] = lookup(vpage0 + tile * 16u + (jj & 1) + 8u * (jj >> 1), v_end);
+        };
+        if (TABLE) { lookup_k(t0); lookup_v(t0); }
 
         uint4 kx[2][2];
         uint2 vx[8];
@@ -468,19 +492,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         auto issue_k = [&]() {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const uint8_t* src = STRIPED ? rec(kpage0 + tile_k * 16u + 8u * b) + koff : kp + 16384 * b;
+                const uint8_t* src = TABLE ? kbase[b] + koff : STRIPED ? rec(kpage0 + tile_k * 16u + 8u * b) + koff : kp + 16384 * b;
                 kx[b][0] = ldg16(src); kx[b][1] = ldg16(src + 64);
             }
             ks4 = ldg_f4(kt);
+            if (TABLE) lookup_k(tile_k + 1u);
         };
         auto issue_v = [&]() {
-            if (STRIPED) {
+            if (STRIPED || TABLE) {
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const uint8_t* src = rec(vpage0 + tile_v * 16u + (jj & 1) + 8u * (jj >> 1)) + voff;
+                    const uint8_t* src = (TABLE ? vbase[jj] : rec(vpage0 + tile_v * 16u + (jj & 1) + 8u * (jj >> 1))) + voff;
                     vx[(jj & 1) * 2 + (jj >> 1) * 4] = ldg8(src);               // slot j = 2 (jj & 1) + 4 (jj >> 1): position slot 0 of the page
                     vx[(jj & 1) * 2 + (jj >> 1) * 4 + 1] = ldg8(src + 1024);
                 }
+                if (TABLE) lookup_v(tile_v + 1u);
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) vx[j] = ldg8(vp + 1024 * (j & 3) + 16384 * (j >> 2));
@@ -1194,9 +1220,11 @@ hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_ou
         hipLaunchKernelGGL(k_attend_fp8_linear<false>, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
     else if (a.stripe_bases)
         hipLaunchKernelGGL(k_attend_fp8_linear<true>, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
+    else if (a.table_form)
+        hipLaunchKernelGGL((k_attend_fp8_linear<false, true>), dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
     else            hipLaunchKernelGGL(k_attend_fp8, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || (a.direct_out && (a.lin_base || a.stripe_bases))) return e;      // (the page-table form always writes partials)
+    if (e != hipSuccess || (a.direct_out && (a.lin_base || a.stripe_bases || a.table_form))) return e;      // (the page-table kernel always writes partials)
     return launch_attend_combine(a, n_layers, d_out, d_lse, s);
 }
 

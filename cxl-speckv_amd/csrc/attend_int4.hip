@@ -502,7 +502,15 @@ __device__ __forceinline__ void wg_take_v(const uint32_t (&rd)[4], uint32_t rs, 
 // STRIPED: the allocation is striped regularly over several pools (AttendArgs::stripe_bases): the five DMA addresses of a
 // wave and tile are computed per lane from the page number (multiply-high, LDS read of the run base, 64-bit multiply-add)
 // and the DMAs take a full address per lane.  Single-sequence form only.
-template <bool STRIPED>
+// TABLE: an allocation without a regular placement (pages migrated one by one; AttendArgs::table_form), tile-aligned range:
+// the five record addresses of a wave and tile come from page-table entries.  The entries are fetched by hand-counted loads
+// one tile ahead of the DMAs that need them, so that neither waits for the other:
+//     after tile t is consumed:  s_waitcnt vmcnt(5)  (entries of t+2 are here; the 5 DMAs of t+1 may fly)
+//                                entry loads of t+3, DMAs of t+2
+//     top of iteration t+1:      s_waitcnt vmcnt(10) (DMAs of t+1 have landed; entries of t+3 and DMAs of t+2 may fly)
+// The schedule is uniform -- tile numbers beyond the split are clamped (their DMAs land in a buffer nobody reads again), an
+// odd split gets one extra step whose scores are -inf -- because the counts are constants.  Single-sequence form only.
+template <bool STRIPED, bool TABLE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4_WG_WAVES, SPECKV_INT4_WG_WAVES))) void k_attend_int4_wg(AttendArgs a)
 {
     static_assert(kWgHeads == 4, "the cooperative kernel is laid out for 4 heads per workgroup");
@@ -569,7 +577,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
         const uint32_t tile_bytes = 16u * kInt4RecBytes;
         const uint8_t* kreg = nullptr;
         const uint8_t* vreg = nullptr;
-        if (!STRIPED) {
+        if (!STRIPED && !TABLE) {
             kreg = a.lin_base + (a.k_first + layer * a.layer_stride) * kInt4RecBytes;      // tile tt: + tt * tile_bytes
             vreg = a.lin_base + (a.v_first + layer * a.layer_stride) * kInt4RecBytes;
         }
@@ -644,9 +652,86 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
             return;
         }
 #endif
+        const bool ragged = (a.n_pages & 15u) != 0u;
+        if (TABLE) {
+            // the lane's five page-table entries of tile tt: K pages of its rows r0 / r1, the same of V, the scale line's page
+            const uint32_t k_end = kpage0 + a.n_pages - 1u, v_end = vpage0 + a.n_pages - 1u;
+            auto entry_load = [&](u32x4& e, uint32_t page, uint32_t end) {
+                const PageEntry* p = a.entries + min(page, end);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(e) : "v"(p) : "memory");
+            };
+            auto lookups = [&](u32x4 (&e)[5], uint32_t tt) {
+                const uint32_t t_ = min(tt, last), pg = t_ * 16u + (r0 >> 1);
+                entry_load(e[0], kpage0 + pg, k_end);
+                entry_load(e[1], kpage0 + pg + 2u, k_end);
+                entry_load(e[2], vpage0 + pg, v_end);
+                entry_load(e[3], vpage0 + pg + 2u, v_end);
+                entry_load(e[4], spage0 + t_ * 16u, (wave < 2u) ? k_end : v_end);
+            };
+            auto base_of = [&](const u32x4& e) -> const uint8_t* {       // {address lo, hi, record bytes, scale}; never written: zeros
+                const uint8_t* r = reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(e.x) | (static_cast<uint64_t>(e.y) << 32));
+                return e.z >= kInt4RecBytes ? r : a.zero_page;
+            };
+            auto dmas = [&](const u32x4 (&e)[5], uint32_t buf) {
+                const uint32_t dst = lbase + buf * kWgBuf;
+                dma16v(dst + dr0, base_of(e[0]) + in0);
+                dma16v(dst + dr0 + 1024u, base_of(e[1]) + in1);
+                dma16v(dst + kWgV + dr0, base_of(e[2]) + in0);
+                dma16v(dst + kWgV + dr0 + 1024u, base_of(e[3]) + in1);
+                dma16v(dst + ds_, base_of(e[4]) + sin);
+            };
+            // one tile: `mine` holds the entries of tile + 2 (landing), `other` takes those of tile + 3
+            auto step = [&](uint32_t tile, uint32_t buf, u32x4 (&mine)[5], u32x4 (&other)[5]) {
+                const uint32_t bo = buf * kWgBuf;
+                asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
+                u32x4 k0, k1;
+                uint32_t ks0, ks1;
+                wg_take_k(rdk + bo, rsk + bo, k0, k1, ks0, ks1);
+                float sc[8];
+                {
+                    const f32x4 s0 = score_block(make_uint4(k0.x, k0.y, k0.z, k0.w), ks0, qv);
+                    const f32x4 s1 = score_block(make_uint4(k1.x, k1.y, k1.z, k1.w), ks1, qv);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { sc[i] = s0[i]; sc[4 + i] = s1[i]; }
+                }
+                if ((ragged && tile + 1u == n_tiles) || tile > last) {      // workgroup-uniform: positions beyond the range / the extra step
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t pg = tile * 16u + ((j >> 1) < 2 ? 2u * kb + (j >> 1) : 8u + 2u * kb + ((j >> 1) - 2));
+                        if (pg >= a.n_pages || tile > last) sc[j] = -INFINITY;
+                    }
+                }
+                const f16x8 P = softmax_tile(sc, qscale, m_run, l_run, acc);
+                uint32_t vw[8], vs16[8];
+                const uint32_t rdvb[4] = {rdv[0] + bo, rdv[1] + bo, rdv[2] + bo, rdv[3] + bo};
+                wg_take_v(rdvb, rsv + bo, vw, vs16);
+                // buffer free; the entries of tile + 2 are here.  (They are operands of the wait: their uses below must not be
+                // scheduled in front of it -- to the compiler the loads that produced them were complete when issued.)
+                asm volatile("s_barrier\n\ts_waitcnt vmcnt(5)" : "+v"(mine[0]), "+v"(mine[1]), "+v"(mine[2]), "+v"(mine[3]), "+v"(mine[4]) :: "memory");
+                lookups(other, tile + 3u);
+                dmas(mine, buf);
+                pv_tile(vw, vs16, P, acc);
+            };
+            u32x4 A[5], B[5];
+            lookups(A, t0);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]) :: "memory");
+            lookups(B, t0 + 1u);
+            dmas(A, 0u);                                                  // tile t0
+            asm volatile("s_waitcnt vmcnt(5)" : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]), "+v"(B[4]) :: "memory");   // entries of t0 + 1 (the DMAs of t0 may fly)
+            lookups(A, t0 + 2u);
+            dmas(B, 1u);                                                  // tile t0 + 1
+            const uint32_t t_end = t0 + ((t1 - t0 + 1u) & ~1u);
+#pragma unroll 1
+            for (uint32_t tile = t0; tile < t_end; tile += 2u) {
+                step(tile, 0u, A, B);                                     // A: entries of tile + 2; B <- tile + 3
+                step(tile + 1u, 1u, B, A);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the clamped DMAs of the last two steps)
+            store_partial(a, part, row, my_splits, c, kb, m_run, l_run, acc);
+            return;
+        }
         issue(t0, 0u);
         if (t0 < last) issue(t0 + 1u, 1u);
-        const bool ragged = (a.n_pages & 15u) != 0u;
 #pragma unroll 1
         for (uint32_t tile = t0; tile < t1; ++tile) {
             const uint32_t buf = (tile - t0) & 1u;
@@ -703,6 +788,7 @@ hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_
     if (a.lin_base) hipLaunchKernelGGL(k_attend_int4_wg<false>, wg_grid, dim3(256), 0, s, a);
 #endif
     else if (a.stripe_bases) hipLaunchKernelGGL(k_attend_int4_wg<true>, wg_grid, dim3(256), 0, s, a);
+    else if (a.table_form)   hipLaunchKernelGGL((k_attend_int4_wg<false, true>), wg_grid, dim3(256), 0, s, a);
     else            hipLaunchKernelGGL(k_attend_int4<false>, dim3(a.n_splits, n_layers * (a.heads / kWgHeads)), dim3(64 * kWgHeads), 0, s, a);
     return hipGetLastError();
 }

@@ -2256,6 +2256,10 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     const uint8_t* lin_base = (getenv("SPECKV_ATTEND_GENERAL") || !fits) ? nullptr : a->linear_base;
     // regular striping over several pools: the same kernel with computed record addresses (no page-table chase)
     const bool striped = !lin_base && fits && a->stripe_n >= 2 && !getenv("SPECKV_ATTEND_GENERAL");
+    // no regular placement (pages migrated one by one) but a tile-aligned range: the fast kernel with its record addresses
+    // from the page table, looked up one request ahead (SPECKV_ATTEND_GENERAL=2 forces it for measurements)
+    const char* general_env = getenv("SPECKV_ATTEND_GENERAL");
+    const bool table = fits && ((!lin_base && !striped && !general_env) || (general_env && general_env[0] == '2'));
     // (the page-table form has nothing to gain from whole rows: it hides its look-ups behind other waves and always
     // goes through the merge -- 80 layers x 8k: one split 0.13 of HBM peak, eight 0.18+)
     uint32_t want = (lin_base && rows / 4u >= 128u && n_tiles < 768u) ? 1u : (5120u + rows - 1u) / rows;     // (32k and beyond: 8 splits, below)
@@ -2295,7 +2299,8 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     }
     k.part_acc = reinterpret_cast<float*>(buf + q_bytes + qs_bytes);
     k.part_ml = reinterpret_cast<float*>(buf + q_bytes + qs_bytes + acc_bytes);
-    if (!k.lin_base && !striped)         // the linear / striped forms quantise the query in their own prologue
+    if (table) { k.table_form = 1u; k.lin_base = nullptr; k.stripe_bases = nullptr; }
+    if (!k.lin_base && !striped && !table)         // the linear / striped / table forms quantise the query in their own prologue
         HIP_TRY(launch_quantize_q_e4m3(d_q_f16, rows, g, L.head_dim, buf, reinterpret_cast<float*>(buf + q_bytes), st));
     if (n_splits == 1u) { k.direct_out = d_out; k.direct_lse = d_lse; }      // no merge launch (linear / striped form)
     HIP_TRY(launch_attend_fp8(k, n_layers, d_out, d_lse, st));
@@ -2677,8 +2682,12 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     // linear form: records in one local run and every 32-position tile inside the layer's K / V region; otherwise the
     // page-table form of the same kernel
     const bool fits = static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
-    const bool linear = a->linear_base && fits && !getenv("SPECKV_ATTEND_GENERAL");
-    const bool striped = !linear && a->stripe_n >= 2 && fits && !getenv("SPECKV_ATTEND_GENERAL");
+    const char* general_env = getenv("SPECKV_ATTEND_GENERAL");
+    const bool linear = a->linear_base && fits && !general_env;
+    const bool striped = !linear && a->stripe_n >= 2 && fits && !general_env;
+    // no regular placement but a range inside the layer's tiles: the workgroup kernel with its record addresses from the
+    // page table (SPECKV_ATTEND_GENERAL=2 forces it for measurements; =1: the per-wave page-table kernel)
+    const bool table = fits && ((!linear && !striped && !general_env) || (general_env && general_env[0] == '2'));
     if (!linear && !d_zero_page_) {
         if (is_capturing(s)) return SPECKV_ERR_INVAL;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
@@ -2714,6 +2723,7 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     k.q8 = static_cast<const uint8_t*>(d_q_f16);
     k.scale_log2e = sm_scale * 1.4426950408889634f;
     k.lin_base = linear ? a->linear_base : nullptr;
+    if (table) k.table_form = 1u;
     if (striped) {
         k.stripe_bases = a->d_stripe;
         k.stripe_n = a->stripe_n;

@@ -264,6 +264,10 @@ struct AttendArgs {
     // split -- split 0 of every row first.  With a long split 0 and a short split 1 per row the long pieces all start at
     // once and the short ones fill the remaining workgroup slots in turns (engine.cpp: batch_unequal_split)
     uint32_t rows_first;
+    // table form of the fast kernels (single-sequence form; lin_base and stripe_bases null): an allocation whose placement
+    // is no longer regular (pages migrated one by one) but whose range is tile-aligned -- every record address comes
+    // from the page-table entry, looked up one tile ahead of its request; never-written pages read zero_page
+    uint32_t table_form;
 };
 #if defined(__HIPCC__)
 // record address of page p in the striped form; `bases` = the allocation's run bases copied to LDS

@@ -115,7 +115,7 @@ def test_config5_70b_shaped_32k_context_at_full_size(eng, oracle, scheme):
     heads = {0: (0, 5), 41: (3,), 79: (7, 2)}
 
     def run(general, layer0=0, n_layers=L, pos_end=T):
-        if general: os.environ["SPECKV_ATTEND_GENERAL"] = "1"
+        if general: os.environ["SPECKV_ATTEND_GENERAL"] = str(int(general))      # 1: the page-table kernel, 2: the table form of the fast kernel
         try:
             out = torch.full((n_layers, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
             lse = torch.full((n_layers, H, G), float("nan"), dtype=torch.float32, device="cuda")
@@ -125,18 +125,23 @@ def test_config5_70b_shaped_32k_context_at_full_size(eng, oracle, scheme):
             os.environ.pop("SPECKV_ATTEND_GENERAL", None)
         return out.cpu().numpy(), lse.cpu().numpy()
 
-    for general in (False, True):
+    for general in (0, 1, 2):
         out, lse = run(general)
         assert np.isfinite(out).all() and np.isfinite(lse).all()
         for layer, hs in heads.items():
             for head in hs:
                 checkers[layer].check(out[layer, head], lse[layer, head], qh[layer, head], head, T, sm,
-                                      ("all layers", "page table" if general else "linear", layer, head))
+                                      ("all layers", ("linear", "page table", "table form")[general], layer, head))
     # one layer by itself (a per-layer decode call: other split geometry), and a context that ends inside a tile
     out, lse = run(False, 41, 1)
     checkers[41].check(out[0, 3], lse[0, 3], qh[41, 3], 3, T, sm, "layer 41 alone")
     out, lse = run(False, 79, 1, 32768 - 30)
     checkers[79].check(out[0, 7], lse[0, 7], qh[79, 7], 7, T - 30, sm, "layer 79, 32738 positions")
+    # the table form on a ragged range, an odd number of tiles per split and a single layer
+    out, lse = run(2, 79, 1, 32768 - 30)
+    checkers[79].check(out[0, 7], lse[0, 7], qh[79, 7], 7, T - 30, sm, "layer 79, 32738 positions, table form")
+    out, lse = run(2, 41, 1, 32768 - 96)
+    checkers[41].check(out[0, 3], lse[0, 3], qh[41, 3], 3, T - 96, sm, "layer 41, 32672 positions (1021 tiles), table form")
     # fetch + decompress of sampled pages of the same allocation, bit for bit
     rng = np.random.default_rng(2005)
     for layer, pages16 in sampled.items():
