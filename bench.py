@@ -1321,13 +1321,14 @@ def lstm_cell_extra(torch, lib):
 
 def striped_attention_extra(torch, pkg, T=32768, Lyr=80):
     """The fused attention over a pool striped across 7 pools (the 1 + 7 layout of BASELINE configs[3], here 7 same-GPU
-    pools): the striped form computes its record addresses; the page-table form is what every striped pool took before."""
+    pools): the striped form computes its record addresses; the table form (what an allocation with migrated pages takes) reads
+    them from the page table one tile ahead; the per-wave page-table kernel is what every striped pool took before."""
     out = {}
     for scheme, name, fn in ((3, "int4", int4_attention_extra), (4, "fp8", fp8_scores_extra)):
-        for label, general in (("computed_addresses", False), ("page_table", True)):
+        for label, general in (("computed_addresses", 0), ("page_table_kernel", 1), ("table_form", 2)):
             os.environ["SPECKV_POOL_DEVICES"] = "0,0,0,0,0,0,0"
             if general:
-                os.environ["SPECKV_ATTEND_GENERAL"] = "1"
+                os.environ["SPECKV_ATTEND_GENERAL"] = str(general)
             try:
                 kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), f"hip:{torch.cuda.current_device()}")
                 try:
