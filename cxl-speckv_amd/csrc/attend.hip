@@ -394,6 +394,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
         my_splits = sq.n_splits;
         part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
         layer = 0;
+        if (TABLE) a.entries = reinterpret_cast<const PageEntry*>(sq.lin_base);
         if (STRIPED) {                                                   // the sequence's own placement
             a.stripe_bases = sq.stripe_bases;
             a.stripe_n = sq.stripe_n;
@@ -1189,8 +1190,9 @@ hipError_t launch_attend_fp8_batch(const AttendArgs& a, uint32_t n_seq, float* d
     // with the LDS-DMA kernel (many short splits: 4 waves/SIMD hide more than two tiles per wave at 2 waves/SIMD); the
     // single-sequence form below is the other way round (8k x 80 layers: 0.61 against 0.55; 32k x 80: 0.70 both)
     static const int forced = [] { const char* e = getenv("SPECKV_FP8_BATCH_KERNEL"); return e ? (e[0] == 'd' ? 1 : 2) : 0; }();
-    const bool dma = (forced ? forced == 1 : false) && !a.stripe_bases;
+    const bool dma = (forced ? forced == 1 : false) && !a.stripe_bases && !a.table_form;
     if (dma) hipLaunchKernelGGL(k_attend_fp8_dma, dim3(a.n_splits, n_seq * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
+    else if (a.table_form) hipLaunchKernelGGL((k_attend_fp8_linear<false, true>), dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
     else if (a.stripe_bases) hipLaunchKernelGGL(k_attend_fp8_linear<true>, dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
     else     hipLaunchKernelGGL(k_attend_fp8_linear<false>, dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();

@@ -543,6 +543,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
         my_splits = sq.n_splits;
         part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
         layer = 0;
+        if (TABLE) a.entries = reinterpret_cast<const PageEntry*>(sq.lin_base);
         if (STRIPED) {                                                   // the sequence's own placement
             a.stripe_bases = sq.stripe_bases;
             a.stripe_n = sq.stripe_n;
@@ -785,10 +786,10 @@ hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_
     if (a.lin_base) hipLaunchKernelGGL(k_attend_int4<true>, dim3(a.n_splits, n_layers * (a.heads / kWgHeads)), dim3(64 * kWgHeads), 0, s, a);
 #else
     const dim3 wg_grid = a.rows_first ? dim3(n_layers * (a.heads / 4u), a.n_splits) : dim3(a.n_splits, n_layers * (a.heads / 4u));
+    if (a.table_form) { hipLaunchKernelGGL((k_attend_int4_wg<false, true>), wg_grid, dim3(256), 0, s, a); return hipGetLastError(); }
     if (a.lin_base) hipLaunchKernelGGL(k_attend_int4_wg<false>, wg_grid, dim3(256), 0, s, a);
 #endif
     else if (a.stripe_bases) hipLaunchKernelGGL(k_attend_int4_wg<true>, wg_grid, dim3(256), 0, s, a);
-    else if (a.table_form)   hipLaunchKernelGGL((k_attend_int4_wg<false, true>), wg_grid, dim3(256), 0, s, a);
     else            hipLaunchKernelGGL(k_attend_int4<false>, dim3(a.n_splits, n_layers * (a.heads / kWgHeads)), dim3(64 * kWgHeads), 0, s, a);
     return hipGetLastError();
 }

@@ -2381,6 +2381,8 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     uint64_t total_tiles = 0;
     uint32_t heads = 0;
     bool any_striped = false;                 // then the whole launch takes the striped kernels (a single run is "striped over 1")
+    bool any_table = false;                   // ... or, with a member that has no regular placement, the table forms
+    std::vector<const PageEntry*> ents(n_seq);
     for (uint32_t i = 0; i < n_seq; ++i) {
         Allocation* a = find(handles[i]);
         if (!a) return SPECKV_ERR_GENERAL;
@@ -2389,14 +2391,15 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
         if (L.head_dim != 128 || L.bytes_per_element != 2 || L.num_heads * L.head_dim != 1024 || L.num_tokens % 2) return SPECKV_ERR_INVAL;
         if (layer >= L.num_layers || pos_end[i] % 2 || pos_end[i] > L.num_tokens) return SPECKV_ERR_INVAL;
         const uint32_t n_pages = pos_end[i] / 2, n_tiles = (n_pages + 15u) / 16u;
-        if (!a->stripe_n || (fp8 && !a->d_scale_tab) || static_cast<uint64_t>(n_tiles) * 32u > L.num_tokens) {
-            SPECKV_ERR("speckv_ext_attend_*_batch: sequence %u does not qualify for the arithmetic-address forms "
-                       "(records in one run or striped regularly over up to 8 pools -- not after a migration --, pos_end rounded up "
+        if ((fp8 && !a->d_scale_tab) || static_cast<uint64_t>(n_tiles) * 32u > L.num_tokens) {
+            SPECKV_ERR("speckv_ext_attend_*_batch: sequence %u does not qualify for the tile-aligned forms (pos_end rounded up "
                        "to 32 inside the layer%s)", i, fp8 ? ", layout with num_tokens %% 32 == 0" : "");
             return SPECKV_ERR_INVAL;
         }
         heads = L.num_heads;
         note_use(a, s);
+        any_table = any_table || !a->stripe_n;                 // no regular placement (migrated pages): the launch reads addresses from the page tables
+        ents[i] = a->d_entries;
         any_striped = any_striped || !a->linear_base;
         seqs[i].stripe_bases = a->d_stripe;
         seqs[i].stripe_n = a->stripe_n;
@@ -2427,6 +2430,8 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     // INT4 (arithmetic-bound kernel): splits longer than 256 tiles stop paying (256 sequences x 32k: 256 tiles per split
     // 0.67, 512: 0.65, 1024 = no split: 0.60), shorter sequences are best left whole (8k 0.63 against 0.59 in two
     // splits, 4k 0.60 / 0.52, 2k 0.58 / 0.43: single-split rows are final, no partials and no merge).
+    if (any_table)                                           // (AttendSeq::lin_base carries the page table in table launches)
+        for (uint32_t i = 0; i < n_seq; ++i) seqs[i].lin_base = reinterpret_cast<const uint8_t*>(ents[i]);
     const uint32_t tps = batch_tiles_per_split(fp8, n_seq, heads, total_tiles, seqs.data(), 0);
     uint32_t tiles_max = 0;
     for (uint32_t i = 0; i < n_seq; ++i) tiles_max = std::max(tiles_max, seqs[i].n_splits);
@@ -2475,8 +2480,16 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     k.q16 = static_cast<const uint16_t*>(d_q_f16);
     k.q8 = static_cast<const uint8_t*>(d_q_f16);          // the INT4 kernel reads the fp16 query through q8
     k.scale_log2e = sm_scale * 1.4426950408889634f;
-    k.lin_base = any_striped ? nullptr : seqs[0].lin_base;           // (overridden per sequence)
+    k.lin_base = (any_striped || any_table) ? nullptr : seqs[0].lin_base;           // (overridden per sequence)
     if (any_striped) k.stripe_bases = seqs[0].stripe_bases;          // marks a striped launch (each sequence brings its own table)
+    if (any_table) {
+        k.table_form = 1u; k.lin_base = nullptr; k.stripe_bases = nullptr;
+        if (!d_zero_page_) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
+            HIP_TRY(hipMemset(d_zero_page_, 0, kPageSize));
+        }
+        k.zero_page = d_zero_page_;
+    }
     k.seqs = d_seqs;
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
@@ -2526,7 +2539,8 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
     if (is_capturing(s)) return SPECKV_ERR_INVAL;            // the plan is what changes between replays: it stays outside the graph
     std::vector<AttendSeq> seqs(n_seq);
     int scheme = -1;
-    bool any_striped = false;
+    bool any_striped = false, any_table = false;
+    std::vector<const PageEntry*> ents(n_seq);
     uint32_t heads = 0, min_layers = UINT32_MAX;
     for (uint32_t i = 0; i < n_seq; ++i) {
         Allocation* a = find(handles[i]);
@@ -2538,10 +2552,12 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
         if (pos_end[i] % 2 || pos_end[i] > L.num_tokens || pos_end[i] > max_pos_end) return SPECKV_ERR_INVAL;
         const uint32_t n_pages = pos_end[i] / 2, n_tiles = (n_pages + 15u) / 16u;
         const bool fp8 = scheme == SPECKV_COMP_FP8_E4M3;
-        if (!a->stripe_n || (fp8 && !a->d_scale_tab) || static_cast<uint64_t>(n_tiles) * 32u > L.num_tokens) return SPECKV_ERR_INVAL;
+        if ((fp8 && !a->d_scale_tab) || static_cast<uint64_t>(n_tiles) * 32u > L.num_tokens) return SPECKV_ERR_INVAL;
         min_layers = std::min(min_layers, L.num_layers);
         heads = L.num_heads;
         note_use(a, s);
+        any_table = any_table || !a->stripe_n;
+        ents[i] = a->d_entries;
         any_striped = any_striped || !a->linear_base;
         seqs[i].stripe_bases = a->d_stripe;
         seqs[i].stripe_n = a->stripe_n;
@@ -2556,7 +2572,14 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
     const PlanGeometry g = plan_geometry(scheme == SPECKV_COMP_FP8_E4M3, n_seq, heads, max_pos_end);
     if (g.max_splits > 2048u) return SPECKV_ERR_INVAL;
     if (plans_.size() >= 64 && !plans_.count(d_plan)) plans_.clear();        // (buffers of long-gone steps)
-    plans_[d_plan] = PlanInfo{n_seq, scheme, min_layers, max_pos_end, any_striped};
+    if (any_table)
+        for (uint32_t i = 0; i < n_seq; ++i) seqs[i].lin_base = reinterpret_cast<const uint8_t*>(ents[i]);
+    if (any_table && !d_zero_page_) {
+        DeviceScope zero_scope(device_);
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
+        HIP_TRY(hipMemset(d_zero_page_, 0, kPageSize));
+    }
+    plans_[d_plan] = PlanInfo{n_seq, scheme, min_layers, max_pos_end, any_striped, any_table};
     uint64_t parts = 0;
     for (uint32_t i = 0; i < n_seq; ++i) {
         const uint32_t n_tiles = seqs[i].n_splits;
@@ -2613,7 +2636,8 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
     k.q16 = static_cast<const uint16_t*>(d_q_f16);
     k.q8 = static_cast<const uint8_t*>(d_q_f16);
     k.scale_log2e = sm_scale * 1.4426950408889634f;
-    if (plan->second.striped) k.stripe_bases = reinterpret_cast<const uint64_t*>(1);     // striped launch: every descriptor brings its table
+    if (plan->second.table) { k.table_form = 1u; k.zero_page = d_zero_page_; }           // a member without a regular placement: addresses from the page tables
+    else if (plan->second.striped) k.stripe_bases = reinterpret_cast<const uint64_t*>(1);     // striped launch: every descriptor brings its table
     else k.lin_base = reinterpret_cast<const uint8_t*>(1);     // non-null: linear form (the real base comes from the descriptor)
     k.seqs = static_cast<const AttendSeq*>(d_plan);
     k.part_acc = reinterpret_cast<float*>(buf);

@@ -211,7 +211,8 @@ hipError_t launch_qk_scores_fp8(const PageEntry* d_entries, uint64_t first_page,
 // Batch form of the linear fused attention: many sequences (allocations), one layer each, one launch.  The fields
 // override their AttendArgs namesakes per sequence; part_base = index of the sequence's first (head, split) partial.
 struct AttendSeq {
-    const uint8_t* lin_base;
+    const uint8_t* lin_base;          // table launches (AttendArgs::table_form: a batch member without a regular placement makes the whole
+                                      // launch read its addresses from the page tables): the sequence's PageEntry array instead
     const float* scale_tab;
     uint64_t k_first, v_first;        // first K / V page of the wanted layer (position 0)
     uint32_t n_pages;                 // pages of [0, pos_end)
@@ -221,7 +222,7 @@ struct AttendSeq {
     const uint64_t* stripe_bases;     // striped launches (AttendArgs::stripe_bases set): the sequence's own run bases ...
     uint32_t layer_pages;             // pages of one layer (K + V): layer l of a planned batch starts at k_first + l * layer_pages
     uint32_t stripe_n;                // ... and pool count (1 = a single run: lin_base is bases[0])
-};
+};                                    // (64 bytes: speckv_ext_attend_plan_bytes)
 
 // Decode attention straight from FP8_E4M3 records (attend.hip): softmax(q.K^T * sm_scale) . V per kv head,
 // split over the positions, partials merged by a second kernel.  Same layout requirement as the scores.

@@ -283,8 +283,10 @@ speckv_status_t speckv_ext_attend_fp8(speckv_handle_t handle, uint32_t layer_beg
  * (one allocation each, request 0 of its shim layout) over positions [0, pos_end[i]) in one launch pair.
  *   handles, pos_end : host arrays of n_seq      d_q_f16 : [n_seq][num_heads][g][128] fp16 (device)
  *   d_out : [n_seq][num_heads][g][128] fp32      d_lse : optional [n_seq][num_heads][g]
- * Every allocation must hold FP8 records in one local run with a layout whose num_tokens is a multiple of 32 (the
- * default placement; SPECKV_ERR_INVAL otherwise).  Asynchronous on `stream` (the host arrays are copied before the
+ * Every allocation must hold FP8 records with a layout whose num_tokens is a multiple of 32 (SPECKV_ERR_INVAL otherwise).
+ * Any placement is served: records in one run or striped regularly over the pools take arithmetic addresses; if a member
+ * of the batch has lost its regular placement (pages migrated one by one), the whole launch reads its record addresses
+ * from the page tables instead (a few percent slower).  Asynchronous on `stream` (the host arrays are copied before the
  * call returns).  The split partials of all attention calls live in one scratch buffer of the engine: a call on another
  * stream than the previous one is ordered behind it by the library (an event at the old stream's tail), so callers may
  * use several streams, but such calls do not overlap on the device. */
@@ -295,9 +297,11 @@ speckv_status_t speckv_ext_attend_fp8_batch(uint32_t n_seq, const speckv_handle_
 /* speckv_ext_attend_int4: the same attention over SPECKV_COMP_INT4_G32 records (the 4:1 format).  K and V are
  * dequantised exactly as fetch+decompress does (fp16(q4 * group scale)), the query stays fp16, both products run
  * on v_mfma_f32_16x16x32_f16 with fp32 accumulation: the attention over the decompressed fp16 pages, without
- * writing them.  Records in one local run (the default placement of a one-pool engine) take the arithmetic-address
- * form of the kernel; striped / migrated pools and ranges whose last 32-position tile would leave the layer go
- * through the page table.  (oracle: orc_attend_f16 over decompressed pages.) */
+ * writing them.  Records in one local run (the default placement of a one-pool engine) or striped regularly over the
+ * pools take the arithmetic-address forms of the kernel; an allocation whose pages were migrated one by one takes the
+ * same kernel with its record addresses read from the page table one tile ahead; only ranges that do not start on a
+ * 32-position tile, or whose last tile would leave the layer, go through the per-wave page-table kernel.
+ * (oracle: orc_attend_f16 over decompressed pages.) */
 speckv_status_t speckv_ext_attend_int4(speckv_handle_t handle, uint32_t layer_begin, uint32_t n_layers,
                                        const void* d_q_f16, uint32_t g, uint32_t pos_begin, uint32_t pos_end,
                                        float sm_scale, float* d_out, float* d_lse, void* stream);

@@ -560,10 +560,25 @@ def test_batch_and_planned_attention_over_striped_pools(scheme):
                     scale = float(ref[i].abs().max()) + 1e-6
                     assert float((got[i] - ref[i]).abs().max()) <= 1e-3 * scale, (what, layer, i)
                     assert float((got_lse[i] - ref_lse[i]).abs().max()) <= 2e-4, (what, layer, i)
-        # a partly migrated sequence no longer has an arithmetic placement: the batch call says so instead of reading wrong records
+        # a partly migrated sequence no longer has an arithmetic placement: the whole launch then reads its record addresses from
+        # the page tables (the table forms of the kernels) -- batch and planned, same numbers as before the migration (layer 1: `ref`)
         lib.migrate(handles[0], 4, 8, 2)
-        with pytest.raises(SpeckvError):
-            batch(handles, 0, q.data_ptr(), G, lens, sm, out.data_ptr(), lse.data_ptr())
+        lib.migrate(handles[4], 300, 5, 6)
+        out4 = torch.full_like(out, float("nan")); lse4 = torch.full_like(lse, float("nan"))
+        batch(handles, 1, q.data_ptr(), G, lens, sm, out4.data_ptr(), lse4.data_ptr())
+        out5 = torch.full_like(out, float("nan")); lse5 = torch.full_like(lse, float("nan"))
+        torch.cuda.synchronize()
+        lib.attend_batch_plan(handles, lens, T, d_plan.data_ptr(), plan_bytes, st.cuda_stream)
+        lib.attend_planned(scheme, d_plan.data_ptr(), len(lens), 1, q.data_ptr(), G, T, sm, out5.data_ptr(), lse5.data_ptr(), st.cuda_stream)
+        torch.cuda.synchronize()
+        for got, got_lse, what in ((out4, lse4, "batch, table form"), (out5, lse5, "planned, table form")):
+            for i, n in enumerate(lens):
+                if n == 0:
+                    assert float(got[i].abs().max()) == 0.0
+                    continue
+                scale = float(ref[i].abs().max()) + 1e-6
+                assert float((got[i] - ref[i]).abs().max()) <= 1e-3 * scale, (what, i)
+                assert float((got_lse[i] - ref_lse[i]).abs().max()) <= 2e-4, (what, i)
         # ... but a sequence migrated AS A WHOLE (a hot one pulled onto one pool GPU) is one run again and qualifies for every
         # arithmetic-address path: same results, records at base + page * stride
         lib.migrate(handles[0], 0, n_pages, 5)
