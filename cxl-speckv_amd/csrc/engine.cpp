@@ -2316,32 +2316,16 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
 // entry points speckv_ext_attend_fp8 / _int4 are capturable).
 // Split length of a batch launch (see the measurements quoted in attend_batch).  seqs[i].n_splits holds the tile count of
 // sequence i (null: n_seq sequences of uniform_tiles each, the bound a plan is sized for).
-// INT4 batch launches with between half a machine and a whole one of workgroup columns (sequences x head groups in
-// [384, 672]; 768 workgroups are resident, three per CU -- profiles/tools/probe/occupancy_lds.hip): unsplit they leave the
-// CUs a third or more empty for the whole launch, and the kernel is bound by instruction issue, so occupancy is speed (256 x 8k: 512 columns 0.64 of HBM
-// peak; the same columns at 384 / 768 sequences 0.664 / 0.692).  Every long sequence then goes in TWO pieces, a long one
-// (fraction a of its tiles) and a short one, dispatched rows-first (AttendArgs::rows_first): the long pieces all start at
-// once, the short ones take the remaining slots in turns.  a from a sweep on the MI355X (8k context, gpurun_out r3t_uneq3: a = 0.5 .. 0.85):
-//   384 columns: 0.545 whole, 0.63-0.64 for a <= 0.65;   448: 0.594 whole, 0.645 at a = 0.75, 0.62 at 0.8, no gain below 0.7;
-//   512: 0.638 whole, 0.656 at 0.65, 0.669 at 0.8;         640: 0.607 whole, 0.64 at 0.5 and at 0.8
-// -> near-equal halves up to 416 columns (the split launch is then about one round of workgroups), 0.8 beyond.  (171 + 85 tiles in the
-// splits-first order of the other launches measured 0.52: the order is what makes it work; the merge is k_attend_combine_small.)
-constexpr uint32_t kUnequalMinTiles = 192;      // 6k positions (256 x 4k: the split costs 4 %)
-struct UnequalSplit { bool on; double a; };
+// INT4 batch launches between half a machine and a whole one of workgroup columns: every long sequence in a long and a short
+// piece, dispatched rows-first (ring_rule.hpp: int4_unequal_fraction / unequal_pieces).  The environment switches are for
+// measurement runs.
+using UnequalSplit = UnequalFraction;
 static UnequalSplit int4_unequal_split(uint32_t n_seq, uint32_t hq, uint32_t tiles_max)
 {
-    const uint32_t rows = n_seq * hq;
     if (getenv("SPECKV_ATTEND_TILES_PER_SPLIT") || getenv("SPECKV_ATTEND_WG_TARGET") || getenv("SPECKV_ATTEND_WHOLE_SEQUENCES")) return {false, 1.0};
-    if (rows < 384u || rows > 672u || tiles_max < kUnequalMinTiles) return {false, 1.0};
-    if (const char* env = getenv("SPECKV_ATTEND_UNEQUAL_A")) return {true, atof(env)};      // (measurement runs)
-    return {true, rows <= 416u ? 0.55 : 0.8};
-}
-// the two pieces of one sequence (sequences shorter than kUnequalMinTiles tiles stay whole)
-static EvenSplit unequal_pieces(const UnequalSplit& u, uint32_t n_tiles)
-{
-    if (n_tiles < kUnequalMinTiles) return EvenSplit{std::max(1u, n_tiles), n_tiles ? 1u : 0u};
-    const uint32_t first = std::min(n_tiles - 1u, static_cast<uint32_t>(u.a * n_tiles + 0.999));
-    return EvenSplit{first, 2u};
+    UnequalSplit u = int4_unequal_fraction(n_seq * hq, tiles_max);
+    if (u.on) if (const char* env = getenv("SPECKV_ATTEND_UNEQUAL_A")) u.a = atof(env);
+    return u;
 }
 
 static uint32_t batch_tiles_per_split(bool fp8, uint32_t n_seq, uint32_t heads, uint64_t total_tiles, const AttendSeq* seqs,

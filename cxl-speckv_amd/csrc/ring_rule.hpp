@@ -43,6 +43,34 @@ __host__ __device__ inline EvenSplit even_split(uint32_t n_tiles, uint32_t want)
     return EvenSplit{tps, (n_tiles + tps - 1u) / tps};
 }
 
+// INT4 batch attention launches with between half a machine and a whole one of workgroup columns (sequences x head groups in
+// [384, 672]; 768 workgroups are resident, three per CU -- profiles/tools/probe/occupancy_lds.hip): unsplit they leave the
+// CUs a third or more empty for the whole launch, and the kernel is bound by instruction issue, so occupancy is speed (256 x 8k:
+// 512 columns 0.64 of HBM peak; the same columns at 384 / 768 sequences 0.664 / 0.692).  Every long sequence then goes in TWO
+// pieces, a long one (fraction a of its tiles) and a short one, dispatched rows-first (AttendArgs::rows_first): the long pieces
+// all start at once, the short ones take the remaining slots in turns.  a from a sweep on the MI355X (8k context,
+// profiles/r03_int4_batch_split_sweep.txt: a = 0.5 .. 0.85):
+//   384 columns: 0.545 whole, 0.63-0.64 for a <= 0.65;   448: 0.594 whole, 0.645 at a = 0.75, 0.62 at 0.8, no gain below 0.7;
+//   512: 0.638 whole, 0.656 at 0.65, 0.669 at 0.8;         640: 0.607 whole, 0.64 at 0.5 and at 0.8
+// -> near-equal halves up to 416 columns (the split launch is then about one round of workgroups), 0.8 beyond.  (171 + 85 tiles in
+// the splits-first order of the other launches measured 0.52: the order is what makes it work; the merge is k_attend_combine_small.)
+constexpr uint32_t kUnequalMinTiles = 192;      // 6k positions (256 x 4k: the split costs 4 %)
+struct UnequalFraction { bool on; double a; };
+inline UnequalFraction int4_unequal_fraction(uint32_t columns, uint32_t tiles_max)
+{
+    if (columns < 384u || columns > 672u || tiles_max < kUnequalMinTiles) return {false, 1.0};
+    return {true, columns <= 416u ? 0.55 : 0.8};
+}
+// the two pieces of one sequence: {tiles of the first piece, number of pieces}; sequences shorter than kUnequalMinTiles stay whole
+inline EvenSplit unequal_pieces(const UnequalFraction& u, uint32_t n_tiles)
+{
+    if (n_tiles < kUnequalMinTiles) return EvenSplit{n_tiles ? n_tiles : 1u, n_tiles ? 1u : 0u};
+    uint32_t first = static_cast<uint32_t>(u.a * n_tiles + 0.999);
+    if (first > n_tiles - 1u) first = n_tiles - 1u;
+    if (first < (n_tiles + 1u) / 2u) first = (n_tiles + 1u) / 2u;     // the first piece is the long one
+    return EvenSplit{first, 2u};
+}
+
 // Split length (tiles) of an FP8 batch attention launch.  tiles[i] = tiles of sequence i (null: n_seq sequences of
 // uniform_tiles each); columns_per_seq = workgroup columns one sequence contributes (kv heads / 4).  The four workgroups a
 // CU can hold share its rate, so a launch takes about  ceil(workgroups / 256) x (tiles per split + 3)  tile times, plus

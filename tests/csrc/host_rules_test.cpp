@@ -18,4 +18,11 @@ uint32_t rules_fp8_batch_tiles_per_split(const uint32_t* tiles, uint32_t n_seq, 
 {
     return speckv::fp8_batch_tiles_per_split(tiles, n_seq, uniform_tiles, columns_per_seq);
 }
+// {on, first piece, pieces} of a sequence of n_tiles in an INT4 batch of `columns` workgroup columns whose longest member has tiles_max
+void rules_int4_unequal(uint32_t columns, uint32_t tiles_max, uint32_t n_tiles, uint32_t* out3)
+{
+    const speckv::UnequalFraction u = speckv::int4_unequal_fraction(columns, tiles_max);
+    const speckv::EvenSplit e = u.on ? speckv::unequal_pieces(u, n_tiles) : speckv::EvenSplit{n_tiles ? n_tiles : 1u, n_tiles ? 1u : 0u};
+    out3[0] = u.on ? 1u : 0u; out3[1] = e.tiles_per_split; out3[2] = e.n_splits;
+}
 }

@@ -248,6 +248,7 @@ def rules():
     lib.rules_ring_take.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.rules_ring_live.restype = C.c_int; lib.rules_ring_live.argtypes = [C.c_uint32] * 3
     lib.rules_even_split.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.rules_int4_unequal.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.rules_fp8_batch_tiles_per_split.restype = C.c_uint32
     lib.rules_fp8_batch_tiles_per_split.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32]
     return lib
@@ -366,3 +367,35 @@ def test_fp8_batch_split_rule(rules):
         assert tps >= 1 and (t.max() == 0 or tps <= max(int(t.max()), 8))
         assert int(np.max(-(-t.astype(np.int64) // tps))) <= 2048
     assert f(None, 0, 100, hq) == 8 and f(None, 10, 0, hq) == 8  # nothing to do: any legal length
+
+
+def test_int4_batch_unequal_split_rule(rules):
+    """The INT4 batch attention's two-pieces rule (ring_rule.hpp::int4_unequal_fraction / unequal_pieces, measured in
+    profiles/r03_int4_batch_split_sweep.txt): only batches that fill between half and the whole machine with workgroup columns,
+    only sequences of 6k positions or more; the first piece is the long one, both are non-empty and cover the sequence; the
+    measured shapes get the measured fractions."""
+    out = (C.c_uint32 * 3)()
+
+    def rule(columns, tiles_max, n_tiles):
+        rules.rules_int4_unequal(columns, tiles_max, n_tiles, out)
+        return bool(out[0]), int(out[1]), int(out[2])
+
+    assert rule(512, 256, 256) == (True, 205, 2)                  # 256 sequences x 8k: 0.8 of 256 tiles first
+    assert rule(384, 256, 256) == (True, 141, 2)                  # 192 sequences: near-equal halves
+    assert rule(512, 128, 128)[0] is False                        # 4k context: whole sequences
+    assert rule(256, 256, 256)[0] is False and rule(768, 256, 256)[0] is False      # too few / enough columns
+    rng = np.random.default_rng(17)
+    for _ in range(2000):
+        columns = int(rng.integers(1, 1200)); tiles_max = int(rng.integers(1, 5000)); n_tiles = int(rng.integers(0, tiles_max + 1))
+        on, first, pieces = rule(columns, tiles_max, n_tiles)
+        if not on:
+            assert pieces == (1 if n_tiles else 0)
+            continue
+        assert 384 <= columns <= 672 and tiles_max >= 192
+        if n_tiles < 192:
+            assert pieces == (1 if n_tiles else 0) and (first == n_tiles or n_tiles == 0)      # short members of the batch stay whole
+        else:
+            assert pieces == 2 and n_tiles / 2 <= first < n_tiles
+            second = n_tiles - first
+            assert 1 <= second <= first and -(-n_tiles // first) == 2      # what the kernel computes from tiles_per_split = first
+
