@@ -1260,8 +1260,9 @@ def tensor_codec_extra(torch, lib, n=131072 * 256):
             b.record(s); torch.cuda.synchronize()
             ms = a.elapsed_time(b) / 5
             out[name] = {"ms": round(ms, 4), "algorithmic_GBps": round(byt / (ms * 1e-3) / 1e9, 1), "frac_hbm": round(byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
-        out["note"] = ("any n, exact: three passes over the source (abs-max, tile summaries, emit: one element per lane and step) + a "
-                       "one-workgroup scan across tiles + a pack pass; the pool itself stores KV per 4 KiB block (the headline path)")
+        out["note"] = ("any n, exact: three passes over the source (abs-max, tile summaries, emit: whole fp16 tiles by the block encoder's "
+                       "8-elements-per-lane path) + a one-workgroup scan across tiles + a pack pass; the pool itself stores KV per 4 KiB "
+                       "block (the headline path)")
         return {"tensor_codec_whole_tensor": out}
     except Exception as e:
         return {"tensor_codec_whole_tensor": {"error": repr(e)}}

@@ -16,6 +16,7 @@
 // stores of different workgroups into one line are avoided throughout this library (DESIGN.md sect. 2).
 #include "kernels.hpp"
 #include "codec_device.hpp"
+#include "encode_device.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -27,6 +28,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t kTile = 2048;            // elements per tile (one wave)
 constexpr uint32_t kTcWaves = 4;
+#ifdef SPECKV_TC_NO_FAST
+constexpr bool kTcNoFast = true;             // (A/B builds: the element-wise tile loop only)
+#else
+constexpr bool kTcNoFast = false;
+#endif
 constexpr uint32_t kTcLead = 16;            // bytes in front of a wave's pair buffer: "count of the pair before the first" lands here
 
 struct TcSummary {                          // what a tile knows without its left neighbours (positions tile-relative, +1; 0 = none)
@@ -97,6 +103,85 @@ __device__ __forceinline__ float tc_scale(uint32_t absmax_bits)
     return (mx > 0.0f) ? (mx / 127.0f) : 1.0f;                      // cache_engine.cpp:183
 }
 
+// A whole tile of fp16 elements by the block encoder's FAST path (kernels.hip: encode_rle_fast -- 8 elements per lane and step,
+// packed-fp32 quantisation, SDWA deltas, run-start predicates in SGPR pairs, EXEC-predicated pair scatter), started from the
+// two elements in front of the tile instead of from zero.  Valid while every change of the delta starts a run and no run has
+// to be split: it gives up (false; nothing of its LDS output is used) when the tile holds inf / NaN, when a stretch between
+// two starts of the tile, or behind its last start, may reach 255 elements -- the caller then walks the tile element by
+// element.  Stretches that ENTER the tile are the scan's business (TcCarry::lead_phase); the caller checks that they start no
+// run inside the tile before it trusts the pairs of the emit pass.
+//   first_ss / last_ss: first / last run start of the tile (tile-relative + 1, 0 = none), n_starts: how many.
+template <int MODE, bool EMIT>
+__device__ __forceinline__ bool tc_tile_fast(const uint8_t* tsrc, float scale, float rcp, uint32_t qtail, uint32_t dtail, uint32_t pair_m1,
+                                             uint32_t lane, uint32_t& first_ss, uint32_t& last_ss, uint32_t& n_starts)
+{
+    uint4 raw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32x4 v = __builtin_nontemporal_load((const u32x4 __attribute__((address_space(1)))*)(reinterpret_cast<uintptr_t>(tsrc + 2ull * (512u * j + 8u * lane))));
+        raw[j] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+    if (absmax_bits(raw) >= 0x7C00u) return false;                  // wave-uniform
+    uint32_t mcarry = 0, icarry = 0, first = 0;
+    bool prev_sparse = false, failed = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t p0 = 512u * j + 8u * lane;
+        uint32_t q[8];
+        quantize8<MODE>(raw[j], scale, rcp, q);
+        const uint32_t prevq = wave_shr1(q[7], qtail);
+        qtail = lane63(q[7]);
+        uint32_t d[8];
+        d[0] = sub_bytes(q[0], prevq);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) d[k] = sub_bytes(q[k], q[k - 1]);
+        const uint32_t prevd = wave_shr1(d[7], dtail);
+        dtail = lane63(d[7]);
+        bool st[8];
+        uint32_t mask = 0;                                          // bit 7-k = element k starts a run
+        unsigned long long sm[8];
+        st[0] = d[0] != prevd;
+        sm[0] = __builtin_amdgcn_ballot_w64(st[0]);
+        shift_in(mask, sm[0]);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { st[k] = d[k] != d[k - 1]; sm[k] = __builtin_amdgcn_ballot_w64(st[k]); shift_in(mask, sm[k]); }
+        const uint32_t cnt = static_cast<uint32_t>(__builtin_popcount(mask));
+        const uint32_t lm = mask ? p0 + 8u - static_cast<uint32_t>(__builtin_ctz(mask)) : 0u;          // last start of the lane, position + 1
+        const unsigned long long have = __ballot(mask != 0u);
+        if (!first && have) {                                       // wave-uniform: the tile's first start
+            const uint32_t fl = static_cast<uint32_t>(__builtin_ctzll(have));
+            const uint32_t lane_first = mask ? p0 + 8u - (31u - static_cast<uint32_t>(__builtin_clz(mask))) : 0u;     // first start of the lane, position + 1
+            first = static_cast<uint32_t>(__shfl(static_cast<int>(lane_first), static_cast<int>(fl)));
+        }
+        const bool sparse = __popcll(~have) >= 14;                  // wave-uniform (see encode_rle_fast)
+        const bool suspicious = sparse || prev_sparse;
+        prev_sparse = sparse;
+        const uint32_t ic = wave_incl_add(cnt);
+        uint32_t idx = icarry + ic - cnt;
+        icarry += lane63(ic);
+        const uint32_t im = wave_incl_max(lm);
+        const uint32_t m = umax(wave_shr1(im, 0u), mcarry);         // last start before this lane, position + 1 (0: none in the tile yet)
+        mcarry = umax(mcarry, lane63(im));
+        if (suspicious && __ballot(mask != 0u && m != 0u && p0 + 8u - m > 255u) != 0ull) failed = true;
+        if (EMIT) {
+            uint32_t rel = m - p0 - 1u;
+            uint32_t addr[8], cntv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                addr[k] = lshl1_add(idx, pair_m1);
+                cntv[k] = static_cast<uint32_t>(k) - rel;
+                rel = st[k] ? static_cast<uint32_t>(k) : rel;
+                add_pred(idx, sm[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) store_pair_if(sm[k], addr[k], cntv[k], d[k]);
+        }
+    }
+    if (failed || (mcarry != 0u && kTile + 1u - mcarry > 255u)) return false;     // a run inside the tile may need splitting
+    first_ss = first; last_ss = mcarry; n_starts = icarry;
+    return true;
+}
+
 // One tile, one wave: the loop of the block encoder's general path with carries that may come from other tiles.
 // EMIT = false: the tile's summary.  EMIT = true: the tile's pairs into its 4 KiB slot of the pair scratch.
 template <int MODE, bool F32, bool EMIT>
@@ -130,8 +215,20 @@ __global__ __launch_bounds__(64 * kTcWaves) void k_tc_tiles(const void* __restri
     uint32_t mcarry = 0;        // last run start inside the tile so far (rel + 1)
     uint32_t icarry = 0;        // run starts so far
     uint32_t first_ss = 0;
+    bool fast = false;
+    if (!F32 && len == kTile && ((reinterpret_cast<uintptr_t>(src) + 2ull * t0) & 15u) == 0u && !kTcNoFast) {
+        // whole fp16 tiles: eight elements per lane and step (tc_tile_fast); everything else, and whatever it declines, element-wise below
+        uint32_t f_first = 0, f_last = 0, f_n = 0;
+        const uint32_t pair_m1 = EMIT ? pair_addr - 1u : 0u;
+        if (tc_tile_fast<MODE, EMIT>(static_cast<const uint8_t*>(src) + 2ull * t0, scale, 1.0f / scale, qtail, t0 == 0u ? 0x100u : dtail, pair_m1, lane,
+                                     f_first, f_last, f_n) &&
+            (!EMIT || cy.runs == f_n)) {                            // (emit: no run start of an entering stretch inside the tile)
+            first_ss = f_first; scarry = f_last; mcarry = f_last; icarry = f_n;
+            fast = true;
+        }
+    }
 #pragma unroll 1
-    for (uint32_t step = 0; step < kTile / 64u; ++step) {
+    for (uint32_t step = 0; step < kTile / 64u && !fast; ++step) {
         const uint32_t rel = 64u * step + lane;
         if (64u * step >= len) break;                               // wave-uniform
         const bool live = rel < len;
@@ -371,7 +468,25 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_tc_scan_wg(const TcSummary*
 }
 
 // Output-centric pack: a wave owns 2048 consecutive pairs (4 KiB, line-aligned) of the stream and gathers them from the
-// tiles' slots.  Lane piece = 8 pairs: one binary search over run_base, then a walk.
+// tiles' slots.  The tiles that hold the wave's first and last pair are found by the whole wave at once (64 probes per step of
+// a 64-ary search over run_base: 3 steps for 16 384 tiles, where a binary search per lane took 14 dependent loads, four
+// times per lane); a lane piece of 8 pairs then searches only between those two tiles -- they are neighbours unless the data
+// is sparse -- and walks.
+__device__ __forceinline__ uint64_t tc_wave_find_tile(const TcCarry* __restrict__ carry, uint64_t n_tiles, uint64_t target, uint32_t lane)
+{
+    // last tile whose run_base <= target (carry[n_tiles].run_base = total > target); run_base is non-decreasing
+    uint64_t lo = 0, hi = n_tiles;
+    while (hi - lo > 1u) {
+        const uint64_t span = hi - lo, step = (span + 63u) / 64u;
+        const uint64_t c = lo + static_cast<uint64_t>(lane + 1u) * step;
+        const bool le = c < hi && carry[c].run_base <= target;
+        const uint32_t k = static_cast<uint32_t>(__popcll(__ballot(le)));
+        const uint64_t nlo = lo + static_cast<uint64_t>(k) * step, nhi = lo + static_cast<uint64_t>(k + 1u) * step;
+        lo = nlo;
+        hi = nhi < hi ? nhi : hi;
+    }
+    return lo;
+}
 __global__ __launch_bounds__(256) void k_tc_pack(const TcCarry* __restrict__ carry, uint64_t n_tiles, const uint8_t* __restrict__ pair_scratch,
                                                 uint8_t* __restrict__ rle)
 {
@@ -379,12 +494,15 @@ __global__ __launch_bounds__(256) void k_tc_pack(const TcCarry* __restrict__ car
     const uint64_t total = carry[n_tiles].run_base;
     const uint64_t chunk = (static_cast<uint64_t>(blockIdx.x) * 4u + wave) * kTile;
     if (chunk >= total) return;
+    const uint64_t last_pair = (chunk + kTile - 1u < total) ? chunk + kTile - 1u : total - 1u;
+    const uint64_t t_first = tc_wave_find_tile(carry, n_tiles, chunk, lane);
+    const uint64_t t_last = tc_wave_find_tile(carry, n_tiles, last_pair, lane);
 #pragma unroll 1
     for (int j = 0; j < 4; ++j) {
         const uint64_t r0 = chunk + 512u * j + 8u * lane;
         if (r0 >= total) continue;
-        // last tile whose run_base <= r0 (tiles without runs share their successor's base and are skipped by the search)
-        uint64_t lo = 0, hi = n_tiles;                              // carry[hi].run_base > r0 holds for hi = n_tiles (total > r0)
+        // last tile in [t_first, t_last] whose run_base <= r0 (tiles without runs share their successor's base and are skipped)
+        uint64_t lo = t_first, hi = t_last + 1u;                    // carry[hi].run_base > last_pair >= r0
         while (hi - lo > 1u) {
             const uint64_t mid = (lo + hi) >> 1;
             if (carry[mid].run_base <= r0) lo = mid; else hi = mid;
@@ -416,14 +534,28 @@ __global__ __launch_bounds__(256) void k_td_summary(const uint8_t* __restrict__ 
     const uint64_t p0 = chunk * kTile;
     if (p0 >= n_pairs) return;
     uint32_t sc = 0, sv = 0;
+    // 8 pairs (16 bytes) per lane and step where the stream allows it (the chunk starts 4 KiB into the stream: aligned with it)
+    const bool wide = (reinterpret_cast<uintptr_t>(rle) & 15u) == 0u;
 #pragma unroll 1
-    for (uint32_t step = 0; step < kTile / 64u; ++step) {
-        const uint64_t i = p0 + 64u * step + lane;
-        uint32_t bits = 0;
-        if (i < n_pairs) bits = *reinterpret_cast<const uint16_t*>(rle + 2ull * i);
-        const uint32_t v = bits & 0xFFu, c = bits >> 8;
-        sc += c;
-        sv += v * c;
+    for (uint32_t step = 0; step < kTile / 512u; ++step) {
+        const uint64_t i = p0 + 512u * step + 8u * lane;
+        if (wide && i + 8u <= n_pairs) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(rle + 2ull * i);      // (temporal: the expand pass reads the stream again)
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {                               // dword = v0 | c0 << 8 | v1 << 16 | c1 << 24
+                const uint32_t counts = (w[t] >> 8) & 0x00FF00FFu;
+                sc = __builtin_amdgcn_udot4(counts, 0x00010001u, sc, false);
+                sv = __builtin_amdgcn_udot4(w[t], counts, sv, false);  // v0 c0 + v1 c1
+            }
+        } else {
+            for (uint32_t k = 0; k < 8u; ++k) {
+                uint32_t bits = 0;
+                if (i + k < n_pairs) bits = *reinterpret_cast<const uint16_t*>(rle + 2ull * (i + k));
+                sc += bits >> 8;
+                sv += (bits & 0xFFu) * (bits >> 8);
+            }
+        }
     }
     sc = lane63(wave_incl_add(sc));
     sv = lane63(wave_incl_add(sv & 0xFFu));
@@ -529,23 +661,48 @@ __global__ __launch_bounds__(256) void k_td_expand(const uint8_t* __restrict__ r
     }
     uint64_t tot = carry[lo].start;                                 // elements in front of pair `i0`
     uint32_t qp = carry[lo].q_pre;
+    // four pairs per lane and step (one 8-byte load where the stream is aligned): a lane sums its own four, one add-scan over
+    // the lane totals places them
+    const bool wide = (reinterpret_cast<uintptr_t>(rle) & 7u) == 0u;
 #pragma unroll 1
-    for (uint64_t i0 = lo * kTile; i0 < n_pairs && tot < o1; i0 += 64u) {
-        const uint64_t i = i0 + lane;
-        uint32_t bits = 0;
-        if (i < n_pairs) bits = *reinterpret_cast<const uint16_t*>(rle + 2ull * i);
-        const uint32_t v = bits & 0xFFu, c = bits >> 8;
-        const uint32_t packed = ((v * c) << 24) | c;
-        const uint32_t incl = wave_incl_add(packed);
-        const uint32_t e = incl - packed;
-        const uint64_t start = tot + (e & 0xFFFFFFu);
-        uint32_t q = qp + (e >> 24);
-        // the part of [start, start + c) inside [o0, o1)
-        const uint64_t a = start > o0 ? start : o0, b = (start + c < o1) ? start + c : o1;
-        if (a < b) {
-            q += static_cast<uint32_t>(a - start) * v;
+    for (uint64_t i0 = lo * kTile; i0 < n_pairs && tot < o1; i0 += 256u) {
+        const uint64_t i = i0 + 4u * lane;
+        uint32_t w0 = 0, w1 = 0;                                       // pairs i, i+1 | i+2, i+3
+        if (wide && i + 4u <= n_pairs) {
+            const uint2 x = *reinterpret_cast<const uint2*>(rle + 2ull * i);
+            w0 = x.x; w1 = x.y;
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k)
+                if (i + k < n_pairs) {
+                    const uint32_t b = *reinterpret_cast<const uint16_t*>(rle + 2ull * (i + k));
+                    if (k < 2u) w0 |= b << (16u * k); else w1 |= b << (16u * (k - 2u));
+                }
+        }
+        uint32_t pk[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t b = ((k < 2u ? w0 : w1) >> (16u * (k & 1u))) & 0xFFFFu;
+            const uint32_t v = b & 0xFFu, c = b >> 8;
+            pk[k] = ((v * c) << 24) | c;
+        }
+        const uint32_t lane_total = pk[0] + pk[1] + pk[2] + pk[3];     // counts: < 2^24 per step, the value sums wrap mod 256
+        const uint32_t incl = wave_incl_add(lane_total);
+        uint32_t e = incl - lane_total;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t b = ((k < 2u ? w0 : w1) >> (16u * (k & 1u))) & 0xFFFFu;
+            const uint32_t v = b & 0xFFu, c = b >> 8;
+            const uint64_t start = tot + (e & 0xFFFFFFu);
+            uint32_t q = qp + (e >> 24);
+            // the part of [start, start + c) inside [o0, o1)
+            const uint64_t a = start > o0 ? start : o0, bnd = (start + c < o1) ? start + c : o1;
+            if (a < bnd) {
+                q += static_cast<uint32_t>(a - start) * v;
 #pragma unroll 1
-            for (uint64_t p = a; p < b; ++p) { q += v; tab[p - o0] = static_cast<uint8_t>(q); }
+                for (uint64_t p = a; p < bnd; ++p) { q += v; tab[p - o0] = static_cast<uint8_t>(q); }
+            }
+            e += pk[k];
         }
         const uint32_t step_tot = lane63(incl);
         tot += step_tot & 0xFFFFFFu;
