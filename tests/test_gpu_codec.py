@@ -353,14 +353,20 @@ def test_wave_primitives():
 
 
 # ---- the reference's own call shape: a tensor of any length (speckv_ext_codec_compress_tensor / _decompress_tensor) ----
-def gpu_compress_tensor(lib, x, mode=0):
-    """x: 1-d float32 or float16 numpy.  Returns (scale f32, rle u8[compressed_size])."""
+def gpu_compress_tensor(lib, x, mode=0, misalign=0):
+    """x: 1-d float32 or float16 numpy.  Returns (scale f32, rle u8[compressed_size]).  misalign: elements the source is
+    shifted off its 256-byte aligned allocation by."""
     torch = torch_mod()
     x = np.ascontiguousarray(x)
     f32 = x.dtype == np.float32
     assert f32 or x.dtype == np.float16
     n = x.size
-    d_x = torch.from_numpy(x if f32 else x.view(np.int16)).cuda() if n else torch.zeros(1, device="cuda")
+    if misalign:
+        pad = np.zeros(misalign, x.dtype)
+        d_full = torch.from_numpy(np.concatenate([pad, x]) if f32 else np.concatenate([pad, x]).view(np.int16)).cuda()
+        d_x = d_full[misalign:]
+    else:
+        d_x = torch.from_numpy(x if f32 else x.view(np.int16)).cuda() if n else torch.zeros(1, device="cuda")
     ws_bytes = lib.speckv_ext_codec_tensor_workspace_bytes(n)
     d_ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device="cuda")
     ws_ptr = (d_ws.data_ptr() + 255) & ~255
@@ -463,6 +469,23 @@ def test_tensor_codec_matches_oracle_over_sizes_and_structures(lib, oracle):
             if x.size > 100:                                                              # a buffer shorter than the stream's total
                 y = gpu_decompress_tensor(lib, o_rle, o_scale, x.size - 37, mode, True)
                 assert_same_float_bits(y, want[:x.size - 37], f"{name} clipped")
+    # the same structures as fp16 sources: whole tiles take the block encoder's 8-elements-per-lane path, which must hand the
+    # tiles it cannot take (inf / NaN, stretches that may reach 255 elements, run starts of a stretch entering the tile) to the
+    # element-wise loop, tile by tile; also sources that are not 16-byte aligned (element-wise throughout)
+    noisy_then_flat = np.concatenate([rng.standard_normal(5000), np.full(9000, 0.5), rng.standard_normal(3000), np.zeros(300),
+                                      rng.standard_normal(7), np.full(254, -1.25), rng.standard_normal(2000), np.full(255, 2.0),
+                                      rng.standard_normal(1793), np.full(256, 0.75), rng.standard_normal(4000)]).astype(np.float32)
+    for name, x in cases + [("noisy_then_flat", noisy_then_flat)]:
+        if x.size < 2048:
+            continue
+        with np.errstate(over="ignore"):
+            x16 = np.clip(x, -60000.0, 60000.0).astype(np.float16) if name != "nonfinite" else x.astype(np.float16)
+        for mode in MODES:
+            o_scale, o_rle = oracle.compress_f32(x16.astype(np.float32), mode)
+            for misalign in (0, 3):
+                scale, rle = gpu_compress_tensor(lib, x16, mode, misalign)
+                assert np.float32(scale).tobytes() == np.float32(o_scale).tobytes(), (name, mode, misalign, "fp16 source")
+                assert rle.tobytes() == o_rle.tobytes(), (name, mode, misalign, "fp16 source", rle.size, o_rle.size)
     # fp16 source and fp16 output: the same maths on exactly converted inputs, one RNE rounding on the way out
     for n in (11, 2049, 100000):
         x16 = (rng.standard_normal(n) * 3).astype(np.float16)
