@@ -206,6 +206,9 @@ __device__ __forceinline__ void pv_tile(const uint32_t (&vw)[8], const uint32_t 
 // the split's partial result: running maximum, sum and the un-normalised accumulators
 __device__ __forceinline__ void store_partial(const AttendArgs& a, uint64_t part, uint64_t row, uint32_t my_splits, uint32_t c, uint32_t kb, float m_run, float l_run, const f32x4 (&acc)[8])
 {
+#ifdef SPECKV_ABL_NO_STORE
+    if (l_run != 12345.0f) return;                                         // timing only (profiles/tools/int4_where.sh)
+#endif
     const float l_tot = sum_over_kb(l_run);
     if (a.direct_out && (!a.direct_per_seq || my_splits == 1u)) {                               // single split per row: the final result (AttendArgs::direct_out)
         if (c < a.g) {
