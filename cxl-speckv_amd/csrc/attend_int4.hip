@@ -785,13 +785,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
 hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_t s)
 {
     if ((a.n_pages == 0 && !a.seqs) || n_layers == 0 || a.n_splits == 0) return hipSuccess;   // batch form: geometry per sequence
-#ifdef SPECKV_INT4_REGSTAGE
-    if (a.lin_base) hipLaunchKernelGGL(k_attend_int4<true>, dim3(a.n_splits, n_layers * (a.heads / kWgHeads)), dim3(64 * kWgHeads), 0, s, a);
-#else
     const dim3 wg_grid = a.rows_first ? dim3(n_layers * (a.heads / 4u), a.n_splits) : dim3(a.n_splits, n_layers * (a.heads / 4u));
     if (a.table_form) { hipLaunchKernelGGL((k_attend_int4_wg<false, true>), wg_grid, dim3(256), 0, s, a); return hipGetLastError(); }
-    if (a.lin_base) hipLaunchKernelGGL(k_attend_int4_wg<false>, wg_grid, dim3(256), 0, s, a);
+#ifdef SPECKV_INT4_REGSTAGE
+    if (a.lin_base && !a.rows_first) hipLaunchKernelGGL(k_attend_int4<true>, dim3(a.n_splits, n_layers * (a.heads / kWgHeads)), dim3(64 * kWgHeads), 0, s, a);
+    else
 #endif
+    if (a.lin_base) hipLaunchKernelGGL(k_attend_int4_wg<false>, wg_grid, dim3(256), 0, s, a);
     else if (a.stripe_bases) hipLaunchKernelGGL(k_attend_int4_wg<true>, wg_grid, dim3(256), 0, s, a);
     else            hipLaunchKernelGGL(k_attend_int4<false>, dim3(a.n_splits, n_layers * (a.heads / kWgHeads)), dim3(64 * kWgHeads), 0, s, a);
     return hipGetLastError();
