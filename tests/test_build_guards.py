@@ -68,3 +68,67 @@ def test_hot_kernels_use_no_flat_memory_instructions():
         assert hits, f"no kernel matching {pattern} in {obj}"
         for name, n in hits.items():
             assert n <= allowed, f"{name}: {n} flat memory instructions (allowed {allowed}) -- a record pointer is dereferenced without the global-address-space helpers"
+
+
+def _function_text(obj, pattern):
+    tmp = tempfile.mkdtemp(prefix="speckv_objx_")
+    try:
+        shutil.copy(os.path.join(OBJ, obj), tmp)
+        subprocess.run([OBJDUMP, "--offloading", obj], cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        co = [f for f in os.listdir(tmp) if "amdgcn" in f and "gfx950" in f]
+        text = subprocess.run([OBJDUMP, "-d", co[0]], cwd=tmp, check=True, capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out, cur = {}, None
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+        if m:
+            cur = m.group(1) if re.search(pattern, m.group(1)) else None
+            if cur:
+                out[cur] = []
+        elif cur:
+            ins = line.split("//")[0].strip()
+            if ins:
+                out[cur].append(ins)
+    return out
+
+
+def _vregs(s):
+    regs = set()
+    for m in re.finditer(r"v\[(\d+):(\d+)\]", s):
+        regs |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bv(\d+)\b", s):
+        regs.add(int(m.group(1)))
+    return regs
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump of the ROCm toolchain not found")
+def test_table_form_int4_kernel_reads_its_page_table_entries_only_behind_their_wait():
+    """k_attend_int4_wg<false, true> fetches page-table entries with hand-counted inline-assembly loads; to the compiler those
+    loads are complete the moment they are issued, so nothing but the operand list of the following s_waitcnt keeps it from
+    scheduling a use in front of the wait (the first version of the kernel computed addresses from entries that had not
+    arrived).  In the compiled kernel no instruction may read a register of an entry load before a vmcnt wait that covers it
+    (vmcnt(5) or less: everything older than the five newest DMAs)."""
+    funcs = _function_text("attend_int4.o", r"k_attend_int4_wgILb0ELb1E")
+    assert len(funcs) == 1
+    (name, lines), = funcs.items()
+    pending, loads = [], 0
+    for ins in lines:
+        m = re.match(r"global_load_dwordx4 (v\[\d+:\d+\])", ins)
+        if m and "lds" not in ins:
+            pending.append(_vregs(m.group(1)))
+            loads += 1
+            continue
+        w = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", ins)
+        if w:
+            if int(w.group(1)) <= 5:
+                pending = []
+            continue
+        parts = ins.split(None, 1)
+        if len(parts) < 2 or not pending:
+            continue
+        ops = parts[1].split(",")
+        srcs = parts[1] if parts[0].startswith(("global_store", "ds_write", "global_load_lds")) else ",".join(ops[1:])
+        bad = _vregs(srcs) & set().union(*pending)
+        assert not bad, f"{name}: `{ins}` reads v{sorted(bad)} while its entry load is in flight"
+    assert loads >= 20, loads                              # the prologue's and the loop's entry loads were found
