@@ -1444,12 +1444,18 @@ __global__ __launch_bounds__(64) void k_lstm_hidden(const int32_t* __restrict__ 
 //   * the layer's input projections W_ih x_t + b of ALL 16 steps have no dependency: computed first, into LDS;
 //   * the row of W_hh stays in 128 registers for the 16 recurrent steps (weights arrive TRANSPOSED, [column][row], so that
 //     the 512 threads of a workgroup read them coalesced -- Engine::predictor_load_lstm);
-//   * a step is then 128 x kLstmReq fused multiply-adds per thread against h in LDS (broadcast reads), a barrier, the
-//     gate non-linearities on 128 x kLstmReq threads, a barrier.
-//   First version (weights streamed from L2 in every step, 8 requests per workgroup): 0.7-0.8 ms per prediction of 256 requests.
+//   * a step is then 64 x kLstmReq PACKED fused multiply-adds per thread (v_pk_fma_f32 over two neighbouring columns: the
+//     weight pair is two neighbouring registers, the h pair half of a 16-byte LDS read, so no register moves) against h in LDS
+//     (broadcast reads), a barrier, the gate non-linearities on 128 x kLstmReq threads, a barrier.
+//   First version (weights streamed from L2 in every step, 8 requests per workgroup): 0.7-0.8 ms per prediction of 256
+//   requests; separate multiply and add per weight and request (-ffp-contract=off, as the reference's cell needs):
+//   0.110-0.117 ms -- the kernel is a chain of dependent vector instructions, 4 cycles each on a 16-lane SIMD, so their
+//   number is its length.  (Pairing the two REQUESTS instead needs the weight in both halves: 220 register moves and
+//   39 spilled registers, 0.163 ms.)
 struct LstmWeights { const float* w_ih_t[4]; const float* w_hh_t[4]; const float* bias[4]; uint32_t layers; };   // bias = b_ih + b_hh
 constexpr uint32_t kLstmReq = 2;
 __device__ __forceinline__ float sigmoidf_dev(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __global__ __launch_bounds__(512) void k_lstm_cell(const int32_t* __restrict__ hist, uint32_t n, const float* __restrict__ emb, uint32_t vocab,
                                                   LstmWeights w, float* __restrict__ hid)
 {
@@ -1471,11 +1477,11 @@ __global__ __launch_bounds__(512) void k_lstm_cell(const int32_t* __restrict__ h
         const float b = w.bias[l][row];
 #pragma unroll 1
         for (uint32_t t0 = 0; t0 < kPredHist; t0 += 8u) {                 // input projections, 8 steps at a time
-            float acc[8][kLstmReq];
+            f32x2 acc[8][kLstmReq];                                       // even and odd columns
 #pragma unroll
             for (int tt = 0; tt < 8; ++tt)
 #pragma unroll
-                for (uint32_t r = 0; r < kLstmReq; ++r) acc[tt][r] = b;
+                for (uint32_t r = 0; r < kLstmReq; ++r) acc[tt][r] = f32x2{b, 0.0f};
 #pragma unroll 1
             for (uint32_t j = 0; j < in_dim; j += 4u) {
                 const float w0 = wi[(j + 0u) * 512u], w1 = wi[(j + 1u) * 512u], w2 = wi[(j + 2u) * 512u], w3 = wi[(j + 3u) * 512u];
@@ -1484,13 +1490,14 @@ __global__ __launch_bounds__(512) void k_lstm_cell(const int32_t* __restrict__ h
 #pragma unroll
                     for (uint32_t r = 0; r < kLstmReq; ++r) {
                         const float4 xv = *reinterpret_cast<const float4*>(&seq[t0 + tt][r][j]);
-                        acc[tt][r] += w0 * xv.x; acc[tt][r] += w1 * xv.y; acc[tt][r] += w2 * xv.z; acc[tt][r] += w3 * xv.w;
+                        acc[tt][r] = pk_fma(f32x2{w0, w1}, f32x2{xv.x, xv.y}, acc[tt][r]);
+                        acc[tt][r] = pk_fma(f32x2{w2, w3}, f32x2{xv.z, xv.w}, acc[tt][r]);
                     }
             }
 #pragma unroll
             for (int tt = 0; tt < 8; ++tt)
 #pragma unroll
-                for (uint32_t r = 0; r < kLstmReq; ++r) xp[t0 + tt][r][row] = acc[tt][r];
+                for (uint32_t r = 0; r < kLstmReq; ++r) xp[t0 + tt][r][row] = acc[tt][r].x + acc[tt][r].y;
         }
         float wh[kPredHidden];                                            // this row of W_hh
         {
@@ -1502,18 +1509,19 @@ __global__ __launch_bounds__(512) void k_lstm_cell(const int32_t* __restrict__ h
         __syncthreads();                                                  // (everybody is also done with seq as this layer's input)
 #pragma unroll 1
         for (uint32_t t = 0; t < kPredHist; ++t) {
-            float acc[kLstmReq];
+            f32x2 acc[kLstmReq];
 #pragma unroll
-            for (uint32_t r = 0; r < kLstmReq; ++r) acc[r] = xp[t][r][row];
+            for (uint32_t r = 0; r < kLstmReq; ++r) acc[r] = f32x2{xp[t][r][row], 0.0f};
 #pragma unroll
             for (uint32_t j = 0; j < kPredHidden; j += 4u)
 #pragma unroll
                 for (uint32_t r = 0; r < kLstmReq; ++r) {
                     const float4 hv = *reinterpret_cast<const float4*>(&hcur[r][j]);
-                    acc[r] += wh[j] * hv.x; acc[r] += wh[j + 1] * hv.y; acc[r] += wh[j + 2] * hv.z; acc[r] += wh[j + 3] * hv.w;
+                    acc[r] = pk_fma(f32x2{wh[j], wh[j + 1]}, f32x2{hv.x, hv.y}, acc[r]);
+                    acc[r] = pk_fma(f32x2{wh[j + 2], wh[j + 3]}, f32x2{hv.z, hv.w}, acc[r]);
                 }
 #pragma unroll
-            for (uint32_t r = 0; r < kLstmReq; ++r) gates[r][row] = acc[r];
+            for (uint32_t r = 0; r < kLstmReq; ++r) gates[r][row] = acc[r].x + acc[r].y;
             __syncthreads();
             if (row < kLstmReq * kPredHidden) {
                 const uint32_t r = row / kPredHidden, u = row % kPredHidden;
@@ -1534,61 +1542,77 @@ __global__ __launch_bounds__(512) void k_lstm_cell(const int32_t* __restrict__ h
     }
 }
 
-// logits[b][i] = sum_j hid[b][j] * wout[i][j] (+ bias[i]).  4 lanes per output row (32 weights each, held in
-// registers), 16 rows per wave -> a wave streams 8 KiB of contiguous weights once for the whole batch.
+// logits[b][i] = sum_j hid[b][j] * wout[i][j] (+ bias[i]) on the fp32 matrix cores: a wave owns 32 output rows (16 KiB of
+// weights, read once and kept in 64 registers) and walks the requests in tiles of 32 with v_mfma_f32_32x32x2_f32 -- the hidden
+// vectors are the A operand (M = request), the weights the B operand (N = output row), so that an accumulator register holds
+// 32 consecutive logits of one request per half-wave and every store instruction writes two whole 128-byte lines.
+// The vector-ALU form this replaces (one quarter-row per lane, multiply and add per weight and request) needed ~80 VALU
+// instructions per request and wave, 4 cycles each on a 16-lane SIMD: 0.115 ms for 256 requests against ~0.014 ms of matrix time.
+// The order of the 128 additions of one logit: k = 8j + 4*(lane/32) + e for j = 0..15, e = 0..3, the lower half-wave's k first
+// inside each instruction (fused, unlike the oracle's mul + add: covered by the confidence tolerance of the parity tests).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr uint32_t kLogitsTile = 32;        // requests per matrix tile
+constexpr uint32_t kLogitsChunk = 128;      // requests per workgroup column (blockIdx.y): 2 waves per SIMD at 256 requests x 32 000 rows
+constexpr uint32_t kLogitsPitch = kPredHidden + 4u;     // floats; 16 lanes x 16 B of one ds_read_b128 fall in 64 different banks
 __global__ __launch_bounds__(256) void k_lstm_logits(const float* __restrict__ hid, uint32_t n,
         const float* __restrict__ wout, const float* __restrict__ out_bias, uint32_t vocab, float* __restrict__ logits)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t row = gw * 16u + (lane >> 2), part = lane & 3u;
-    float w[32];
+    static_assert(kPredHidden == 128u, "16 float4 per lane and operand");
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t c = lane & 31u, kh = lane >> 5;
+    const uint32_t row = (blockIdx.x * 4u + wave) * 32u + c;
     const bool live = row < vocab;
+    float4 wq[16];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live) v = *reinterpret_cast<const float4*>(wout + static_cast<uint64_t>(row) * kPredHidden + part * 32u + i * 4);
-        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    for (int j = 0; j < 16; ++j) {
+        wq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) wq[j] = *reinterpret_cast<const float4*>(wout + static_cast<uint64_t>(row) * kPredHidden + 8u * j + 4u * kh);
     }
-    // The hidden vectors go through LDS in tiles of 16 requests (8 KiB): read straight from global memory every lane
-    // issued 32 scalar loads per request -- 16 M load instructions for a batch of 256, which bounded the kernel (0.43 of
-    // the 0.52 ms of a 256-request prediction; 0.105 ms now).  Same products, same order of additions as before.
-    __shared__ __attribute__((aligned(16))) float hs[16][kPredHidden];
-    // a thread moves elements threadIdx.x and threadIdx.x + 256 (float4 units) of every tile; the next tile's two loads are
-    // issued before the current tile is consumed, so their latency runs under the arithmetic
-    static_assert(16u * kPredHidden / 4u == 512u, "two float4 per thread and tile");
-    auto fetch = [&](uint32_t b0, int q) {
-        const uint32_t e = threadIdx.x + 256u * static_cast<uint32_t>(q);
-        const uint32_t r = e / (kPredHidden / 4u), c4 = e % (kPredHidden / 4u);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (b0 + r < n) v = *reinterpret_cast<const float4*>(hid + static_cast<uint64_t>(b0 + r) * kPredHidden + 4u * c4);
-        return v;
+    const float bias = (out_bias && live) ? out_bias[row] : 0.0f;
+    const uint32_t b_begin = blockIdx.y * kLogitsChunk, b_end = min(n, b_begin + kLogitsChunk);
+    // A tile of hidden vectors (32 requests, 16 KiB) goes through LDS, shared by the four waves; two buffers, so one barrier
+    // per tile: a buffer is rewritten two tiles later, behind the barrier of the tile in between.
+    __shared__ __attribute__((aligned(16))) float hs[2][kLogitsTile][kLogitsPitch];
+    static_assert(kLogitsTile * kPredHidden / 4u == 4u * 256u, "four float4 per thread and tile");
+    float4 nx[4];
+    auto fetch = [&](uint32_t b0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t e = threadIdx.x + 256u * static_cast<uint32_t>(q);
+            const uint32_t r = e / (kPredHidden / 4u), c4 = e % (kPredHidden / 4u);
+            nx[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b0 + r < b_end) nx[q] = *reinterpret_cast<const float4*>(hid + static_cast<uint64_t>(b0 + r) * kPredHidden + 4u * c4);
+        }
     };
-    float4 nx0 = fetch(0u, 0), nx1 = fetch(0u, 1);
-    for (uint32_t b0 = 0; b0 < n; b0 += 16u) {
-        __syncthreads();
-        {
-            const uint32_t e0 = threadIdx.x, e1 = threadIdx.x + 256u;
-            *reinterpret_cast<float4*>(&hs[e0 / (kPredHidden / 4u)][4u * (e0 % (kPredHidden / 4u))]) = nx0;
-            *reinterpret_cast<float4*>(&hs[e1 / (kPredHidden / 4u)][4u * (e1 % (kPredHidden / 4u))]) = nx1;
+    fetch(b_begin);
+    uint32_t buf = 0;
+    for (uint32_t b0 = b_begin; b0 < b_end; b0 += kLogitsTile, buf ^= 1u) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t e = threadIdx.x + 256u * static_cast<uint32_t>(q);
+            *reinterpret_cast<float4*>(&hs[buf][e / (kPredHidden / 4u)][4u * (e % (kPredHidden / 4u))]) = nx[q];
         }
         __syncthreads();
-        if (b0 + 16u < n) { nx0 = fetch(b0 + 16u, 0); nx1 = fetch(b0 + 16u, 1); }
-        const uint32_t nb = min(16u, n - b0);
-        for (uint32_t bt = 0; bt < nb; ++bt) {
-            const float* hb = &hs[bt][part * 32u];
-            float acc = 0.0f;
+        if (b0 + kLogitsTile < b_end) fetch(b0 + kLogitsTile);
+        f32x16 acc;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float4 h4 = *reinterpret_cast<const float4*>(hb + 4 * i);
-                acc += h4.x * w[4 * i];
-                acc += h4.y * w[4 * i + 1];
-                acc += h4.z * w[4 * i + 2];
-                acc += h4.w * w[4 * i + 3];
+        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 h4 = *reinterpret_cast<const float4*>(&hs[buf][c][8u * j + 4u * kh]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h4.x, wq[j].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h4.y, wq[j].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h4.z, wq[j].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h4.w, wq[j].w, acc, 0, 0, 0);
+        }
+        // acc[v]: request b0 + 8*(v/4) + 4*(lane/32) + v%4, output row `row`
+        if (live) {
+            float* o = logits + static_cast<uint64_t>(b0 + 4u * kh) * vocab + row;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const uint32_t m = 8u * (v >> 2) + (v & 3);
+                if (b0 + 4u * kh + m < b_end) o[static_cast<uint64_t>(m) * vocab] = out_bias ? acc[v] + bias : acc[v];
             }
-            acc += __shfl_xor(acc, 1);
-            acc += __shfl_xor(acc, 2);
-            if (live && part == 0u) logits[static_cast<uint64_t>(b0 + bt) * vocab + row] = out_bias ? acc + out_bias[row] : acc;
         }
     }
 }
@@ -1959,8 +1983,8 @@ hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb,
     } else {
         hipLaunchKernelGGL(k_lstm_hidden, dim3(n), dim3(64), 0, s, d_hist, n, d_emb, vocab, layers, d_hid);
     }
-    const uint32_t waves = (vocab + 15u) / 16u;
-    hipLaunchKernelGGL(k_lstm_logits, dim3((waves + 3u) / 4u), dim3(256), 0, s, d_hid, n, d_wout, lstm ? lstm->out_bias : nullptr, vocab, d_logits);
+    const uint32_t waves = (vocab + 31u) / 32u;              // 32 output rows per wave (k_lstm_logits)
+    hipLaunchKernelGGL(k_lstm_logits, dim3((waves + 3u) / 4u, (n + kLogitsChunk - 1u) / kLogitsChunk), dim3(256), 0, s, d_hid, n, d_wout, lstm ? lstm->out_bias : nullptr, vocab, d_logits);
     if (vocab <= 32u * kSmThreads) hipLaunchKernelGGL(k_softmax_topk_small, dim3(n), dim3(1024), 0, s, d_logits, vocab, k, d_tok, d_conf);
     else                           hipLaunchKernelGGL(k_softmax_topk, dim3(n), dim3(1024), 0, s, d_logits, vocab, k, d_tok, d_conf);
     return hipGetLastError();
