@@ -1455,13 +1455,14 @@ int Engine::predictor_load_lstm(const float* emb, uint32_t vocab, uint32_t n_lay
         return SPECKV_OK;
     };
     LstmParams p{};
-    // the cell kernel reads weights as [column][gate row] (coalesced over its 512 threads): transposed here, once, through
-    // the host (under 1 MB per layer)
+    // the cell kernel reads weights as [register][thread] (coalesced over its 512 threads, lstm_arranged_index): arranged
+    // here, once, through the host (under 1 MB per layer)
     auto upload_transposed = [&](const float* src, size_t rows, size_t cols, float** out) -> int {
         std::vector<float> a(rows * cols), t(rows * cols);
         HIP_TRY(hipMemcpy(a.data(), src, a.size() * sizeof(float), on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
         for (size_t r = 0; r < rows; ++r)
-            for (size_t c = 0; c < cols; ++c) t[c * rows + r] = a[r * cols + c];
+            for (size_t c = 0; c < cols; ++c)
+                t[lstm_arranged_index(static_cast<uint32_t>(r), static_cast<uint32_t>(c), static_cast<uint32_t>(cols))] = a[r * cols + c];
         float* d = nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), t.size() * sizeof(float)));
         lstm_bufs_.push_back(d);

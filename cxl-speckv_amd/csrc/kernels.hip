@@ -1440,106 +1440,116 @@ __global__ __launch_bounds__(64) void k_lstm_hidden(const int32_t* __restrict__ 
 // c = sigmoid(f) c + sigmoid(i) tanh(g),  h = sigmoid(o) tanh(c),  h_0 = c_0 = 0, layer l > 0 fed with layer l-1's h of the
 // same time step; 16-token history, embedding width 64, hidden width 128.  Output: the top layer's last h.
 //   A prediction is a chain of 16 x layers dependent steps, so the kernel is written for the length of a step, layer by layer:
-//   * one workgroup = kLstmReq requests, a thread = one of the 512 gate rows;
+//   * one workgroup = one request, 512 threads (256 requests = one workgroup per CU);
 //   * the layer's input projections W_ih x_t + b of ALL 16 steps have no dependency: computed first, into LDS;
-//   * the row of W_hh stays in 128 registers for the 16 recurrent steps (weights arrive TRANSPOSED, [column][row], so that
-//     the 512 threads of a workgroup read them coalesced -- Engine::predictor_load_lstm);
-//   * a step is then 64 x kLstmReq PACKED fused multiply-adds per thread (v_pk_fma_f32 over two neighbouring columns: the
-//     weight pair is two neighbouring registers, the h pair half of a 16-byte LDS read, so no register moves) against h in LDS
-//     (broadcast reads), a barrier, the gate non-linearities on 128 x kLstmReq threads, a barrier.
-//   First version (weights streamed from L2 in every step, 8 requests per workgroup): 0.7-0.8 ms per prediction of 256
-//   requests; separate multiply and add per weight and request (-ffp-contract=off, as the reference's cell needs):
-//   0.110-0.117 ms -- the kernel is a chain of dependent vector instructions, 4 cycles each on a 16-lane SIMD, so their
-//   number is its length.  (Pairing the two REQUESTS instead needs the weight in both halves: 220 register moves and
-//   39 spilled registers, 0.163 ms.)
+//   * a thread keeps, in 128 registers for the 16 recurrent steps, the weights of EIGHT gate rows over an eighth of the
+//     columns (lstm_arranged_index; the host arranged them so that the 512 threads read coalesced).  A step is 64
+//     packed fused multiply-adds per thread (v_pk_fma_f32 over two neighbouring columns) against its 16 values of h -- four
+//     16-byte LDS reads -- then a reduction over the eight threads that share the rows (7 exchanges: DPP inside a quad,
+//     ds_swizzle across, after which thread tid owns gate row tid);
+//   * the kernel numbers gate rows 4 * unit + gate, so the four gates of a hidden unit end in the four lanes of a quad: each
+//     lane applies its gate's non-linearity (tanh as 2 sigmoid(2x) - 1: one code path), the quad exchanges the four results
+//     with DPP, and all four lanes carry c (in a register) and h; lane 0 writes h -- to the layer's output sequence, which
+//     is also where the next step reads it, so a step has ONE barrier and no buffer is ever rewritten while it is read.
+//   The forms before this one: a thread owning ONE whole gate row read all of h, 64 16-byte LDS reads per step and wave; the
+//   LDS returns 128 bytes per clock however many lanes ask for the same word, so a step was 8 waves x 64 reads x 8 clocks =
+//   1.7 us of LDS time against 0.4 us of arithmetic (0.083 ms per prediction; with separate multiply and add,
+//   -ffp-contract=off as the reference's cell needs, 0.110-0.117 ms).  Sliced rows with the non-linearities on 256 threads
+//   between two barriers (libm tanhf, IEEE division): 0.070 ms.  First version (weights streamed from L2 in every step,
+//   8 requests per workgroup): 0.7-0.8 ms per prediction of 256 requests.
 struct LstmWeights { const float* w_ih_t[4]; const float* w_hh_t[4]; const float* bias[4]; uint32_t layers; };   // bias = b_ih + b_hh
-constexpr uint32_t kLstmReq = 2;
-__device__ __forceinline__ float sigmoidf_dev(float x) { return 1.0f / (1.0f + expf(-x)); }
+constexpr uint32_t kLstmPitch = kPredHidden + 4u * (kPredHidden / 16u);      // a 16-column slice starts 20 floats after the one before: the eight slices a wave reads fall in different banks
+__device__ __forceinline__ constexpr uint32_t lstm_pad(uint32_t j) { return j + 4u * (j >> 4); }
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)); }
+__device__ __forceinline__ float lane_xor4(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101F)); }   // bit mode: and 0x1f, or 0, xor 4
+__device__ __forceinline__ float lane_xor2(float v) { return dpp_mov<0x4E>(v); }     // quad_perm [2,3,0,1]
+__device__ __forceinline__ float lane_xor1(float v) { return dpp_mov<0xB1>(v); }     // quad_perm [1,0,3,2]
+// v[i] of slice-thread s holds a partial sum of gate row 8 * group + (i ^ s): after three exchanges with the threads s ^ 4,
+// s ^ 2, s ^ 1 the return value is the whole sum of row 8 * group + s, i.e. of row threadIdx.x
+__device__ __forceinline__ float lstm_reduce8(float (&v)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += lane_xor4(v[i + 4]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) v[i] += lane_xor2(v[i + 2]);
+    return v[0] + lane_xor1(v[1]);
+}
+// sum over this thread's CS columns of  w[i][c] * x[c]  for its eight rows i; x: the thread's slice of the input vector
+template <uint32_t CS>
+__device__ __forceinline__ float lstm_slice_dot(const float (&w)[8u * CS], const float* x)
+{
+    f32x2 xv[CS / 2u];
+#pragma unroll
+    for (uint32_t k = 0; k < CS / 4u; ++k) {
+        const float4 a = *reinterpret_cast<const float4*>(x + 4u * k);
+        xv[2u * k] = f32x2{a.x, a.y}; xv[2u * k + 1u] = f32x2{a.z, a.w};
+    }
+    float red[8];
+#pragma unroll
+    for (uint32_t i = 0; i < 8u; ++i) {
+        f32x2 a = {0.0f, 0.0f};                                         // (even columns, odd columns)
+#pragma unroll
+        for (uint32_t k = 0; k < CS / 2u; ++k) a = pk_fma(f32x2{w[i * CS + 2u * k], w[i * CS + 2u * k + 1u]}, xv[k], a);
+        red[i] = a.x + a.y;
+    }
+    return lstm_reduce8(red);
+}
+template <uint32_t CS>
+__device__ __forceinline__ void lstm_project(const float* __restrict__ wsrc, float b, const float (&seq)[kPredHist][kLstmPitch],
+                                             float (&xp)[kPredHist][4 * kPredHidden])
+{
+    const uint32_t tid = threadIdx.x, s = tid & 7u;
+    float w[8u * CS];
+#pragma unroll
+    for (uint32_t q = 0; q < 8u * CS; ++q) w[q] = wsrc[q * 512u + tid];
+#pragma unroll 2
+    for (uint32_t t = 0; t < kPredHist; ++t) xp[t][tid] = lstm_slice_dot<CS>(w, &seq[t][lstm_pad(CS * s)]) + b;
+}
+__device__ __forceinline__ float sigmoid_rcp(float x) { return __builtin_amdgcn_rcpf(1.0f + expf(-x)); }     // expf of libm, the hardware's reciprocal (1 ulp)
 __global__ __launch_bounds__(512) void k_lstm_cell(const int32_t* __restrict__ hist, uint32_t n, const float* __restrict__ emb, uint32_t vocab,
                                                   LstmWeights w, float* __restrict__ hid)
 {
-    __shared__ __attribute__((aligned(16))) float seq[kPredHist][kLstmReq][kPredHidden];       // the layer's input sequence, then its own output
-    __shared__ __attribute__((aligned(16))) float xp[kPredHist][kLstmReq][4 * kPredHidden];    // W_ih x_t + b of the current layer
-    __shared__ __attribute__((aligned(16))) float hcur[kLstmReq][kPredHidden];
-    __shared__ float ccur[kLstmReq][kPredHidden];
-    __shared__ float gates[kLstmReq][4 * kPredHidden];
-    const uint32_t row = threadIdx.x, r0 = blockIdx.x * kLstmReq;
-    for (uint32_t i = row; i < kPredHist * kLstmReq * kPredEmb; i += 512u) {
-        const uint32_t t = i / (kLstmReq * kPredEmb), r = (i / kPredEmb) % kLstmReq, j = i % kPredEmb;
-        const uint32_t tok = (r0 + r < n) ? static_cast<uint32_t>(hist[(r0 + r) * kPredHist + t]) : vocab;
-        seq[t][r][j] = tok < vocab ? emb[static_cast<uint64_t>(tok) * kPredEmb + j] : 0.0f;
+    __shared__ __attribute__((aligned(16))) float seq[kPredHist][kLstmPitch];        // the layer's input sequence, then its own output (columns at lstm_pad)
+    __shared__ float xp[kPredHist][4 * kPredHidden];                                // W_ih x_t + b of the current layer; [.][tid] is written and read by thread tid only
+    const uint32_t tid = threadIdx.x, req = blockIdx.x, s = tid & 7u;
+    const uint32_t unit = tid >> 2, gate = tid & 3u;                      // the gate row this thread owns after a reduction
+    for (uint32_t i = tid; i < kPredHist * kPredEmb; i += 512u) {
+        const uint32_t t = i / kPredEmb, j = i % kPredEmb;
+        const uint32_t tok = static_cast<uint32_t>(hist[req * kPredHist + t]);
+        seq[t][lstm_pad(j)] = tok < vocab ? emb[static_cast<uint64_t>(tok) * kPredEmb + j] : 0.0f;
     }
     __syncthreads();
+    float h = 0.0f;
     for (uint32_t l = 0; l < w.layers; ++l) {
-        const uint32_t in_dim = l == 0 ? kPredEmb : kPredHidden;
-        const float* wi = w.w_ih_t[l] + row;                              // column j of this row: wi[j * 512]
-        const float b = w.bias[l][row];
-#pragma unroll 1
-        for (uint32_t t0 = 0; t0 < kPredHist; t0 += 8u) {                 // input projections, 8 steps at a time
-            f32x2 acc[8][kLstmReq];                                       // even and odd columns
-#pragma unroll
-            for (int tt = 0; tt < 8; ++tt)
-#pragma unroll
-                for (uint32_t r = 0; r < kLstmReq; ++r) acc[tt][r] = f32x2{b, 0.0f};
-#pragma unroll 1
-            for (uint32_t j = 0; j < in_dim; j += 4u) {
-                const float w0 = wi[(j + 0u) * 512u], w1 = wi[(j + 1u) * 512u], w2 = wi[(j + 2u) * 512u], w3 = wi[(j + 3u) * 512u];
-#pragma unroll
-                for (int tt = 0; tt < 8; ++tt)
-#pragma unroll
-                    for (uint32_t r = 0; r < kLstmReq; ++r) {
-                        const float4 xv = *reinterpret_cast<const float4*>(&seq[t0 + tt][r][j]);
-                        acc[tt][r] = pk_fma(f32x2{w0, w1}, f32x2{xv.x, xv.y}, acc[tt][r]);
-                        acc[tt][r] = pk_fma(f32x2{w2, w3}, f32x2{xv.z, xv.w}, acc[tt][r]);
-                    }
-            }
-#pragma unroll
-            for (int tt = 0; tt < 8; ++tt)
-#pragma unroll
-                for (uint32_t r = 0; r < kLstmReq; ++r) xp[t0 + tt][r][row] = acc[tt][r].x + acc[tt][r].y;
-        }
-        float wh[kPredHidden];                                            // this row of W_hh
+        const float b = w.bias[l][gate * kPredHidden + unit];
+        if (l == 0) lstm_project<kPredEmb / 8u>(w.w_ih_t[l], b, seq, xp);
+        else        lstm_project<kPredHidden / 8u>(w.w_ih_t[l], b, seq, xp);
+        float wh[kPredHidden];                                            // eight rows x sixteen columns of W_hh
         {
-            const float* whp = w.w_hh_t[l] + row;
+            const float* whp = w.w_hh_t[l] + tid;
 #pragma unroll
-            for (uint32_t j = 0; j < kPredHidden; ++j) wh[j] = whp[j * 512u];
+            for (uint32_t q = 0; q < kPredHidden; ++q) wh[q] = whp[q * 512u];
         }
-        if (row < kLstmReq * kPredHidden) { (&hcur[0][0])[row] = 0.0f; (&ccur[0][0])[row] = 0.0f; }
-        __syncthreads();                                                  // (everybody is also done with seq as this layer's input)
+        float c = 0.0f;
+        __syncthreads();                                                  // everybody is done with seq as this layer's input
 #pragma unroll 1
         for (uint32_t t = 0; t < kPredHist; ++t) {
-            f32x2 acc[kLstmReq];
-#pragma unroll
-            for (uint32_t r = 0; r < kLstmReq; ++r) acc[r] = f32x2{xp[t][r][row], 0.0f};
-#pragma unroll
-            for (uint32_t j = 0; j < kPredHidden; j += 4u)
-#pragma unroll
-                for (uint32_t r = 0; r < kLstmReq; ++r) {
-                    const float4 hv = *reinterpret_cast<const float4*>(&hcur[r][j]);
-                    acc[r] = pk_fma(f32x2{wh[j], wh[j + 1]}, f32x2{hv.x, hv.y}, acc[r]);
-                    acc[r] = pk_fma(f32x2{wh[j + 2], wh[j + 3]}, f32x2{hv.z, hv.w}, acc[r]);
-                }
-#pragma unroll
-            for (uint32_t r = 0; r < kLstmReq; ++r) gates[r][row] = acc[r].x + acc[r].y;
-            __syncthreads();
-            if (row < kLstmReq * kPredHidden) {
-                const uint32_t r = row / kPredHidden, u = row % kPredHidden;
-                const float gi = sigmoidf_dev(gates[r][u]), gf = sigmoidf_dev(gates[r][kPredHidden + u]);
-                const float gg = tanhf(gates[r][2u * kPredHidden + u]), go = sigmoidf_dev(gates[r][3u * kPredHidden + u]);
-                const float c = gf * ccur[r][u] + gi * gg;
-                const float h = go * tanhf(c);
-                ccur[r][u] = c;
-                hcur[r][u] = h;
-                seq[t][r][u] = h;
-            }
+            float g = xp[t][tid];
+            if (t) g += lstm_slice_dot<kPredHidden / 8u>(wh, &seq[t - 1u][lstm_pad(16u * s)]);      // h_{-1} = 0
+            const bool is_g = gate == 2u;
+            const float sg = sigmoid_rcp(is_g ? g + g : g);
+            const float act = is_g ? sg + sg - 1.0f : sg;                 // tanh(x) = 2 sigmoid(2x) - 1
+            const float ai = dpp_mov<0x00>(act), af = dpp_mov<0x55>(act), ag = dpp_mov<0xAA>(act), ao = dpp_mov<0xFF>(act);   // quad_perm [k,k,k,k]
+            c = af * c + ai * ag;
+            const float sc = sigmoid_rcp(c + c);
+            h = ao * (sc + sc - 1.0f);
+            if (gate == 0u) seq[t][lstm_pad(unit)] = h;
             __syncthreads();
         }
     }
-    if (row < kLstmReq * kPredHidden) {
-        const uint32_t r = row / kPredHidden, u = row % kPredHidden;
-        if (r0 + r < n) hid[static_cast<uint64_t>(r0 + r) * kPredHidden + u] = hcur[r][u];
-    }
+    if (gate == 0u) hid[static_cast<uint64_t>(req) * kPredHidden + unit] = h;
 }
 
 // logits[b][i] = sum_j hid[b][j] * wout[i][j] (+ bias[i]) on the fp32 matrix cores: a wave owns 32 output rows (16 KiB of
@@ -1979,7 +1989,7 @@ hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb,
         LstmWeights w{};
         w.layers = lstm->layers;
         for (uint32_t l = 0; l < lstm->layers; ++l) { w.w_ih_t[l] = lstm->w_ih_t[l]; w.w_hh_t[l] = lstm->w_hh_t[l]; w.bias[l] = lstm->bias[l]; }
-        hipLaunchKernelGGL(k_lstm_cell, dim3((n + kLstmReq - 1u) / kLstmReq), dim3(512), 0, s, d_hist, n, d_emb, vocab, w, d_hid);
+        hipLaunchKernelGGL(k_lstm_cell, dim3(n), dim3(512), 0, s, d_hist, n, d_emb, vocab, w, d_hid);
     } else {
         hipLaunchKernelGGL(k_lstm_hidden, dim3(n), dim3(64), 0, s, d_hist, n, d_emb, vocab, layers, d_hid);
     }

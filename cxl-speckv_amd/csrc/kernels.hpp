@@ -321,7 +321,18 @@ hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t ba
 // floats) are scratch.
 // lstm != nullptr && lstm->layers > 0: a real LSTM cell (PyTorch nn.LSTM conventions, k_lstm_cell) instead of the reference's
 // degenerate one; bias[l] = b_ih[l] + b_hh[l]; out_bias may be null
-struct LstmParams { const float* w_ih_t[4]; const float* w_hh_t[4]; const float* bias[4]; const float* out_bias; uint32_t layers; };   // weights transposed: [column][512 gate rows]
+struct LstmParams { const float* w_ih_t[4]; const float* w_hh_t[4]; const float* bias[4]; const float* out_bias; uint32_t layers; };   // weights arranged: lstm_arranged_index
+// Where k_lstm_cell wants the weight (gate row, column) of a 512 x cols matrix.  The kernel numbers the gate rows
+// v = 4 * unit + gate (the four gates of a hidden unit next to each other; nn.LSTM's row is 128 * gate + unit).  Thread
+// tid = 8 * (v / 8) + s keeps the column slice s = col / (cols / 8) of the eight rows v / 8 * 8 + 0..7, as register
+// q = i * (cols / 8) + col % (cols / 8) with i = (v % 8) ^ s (the xor makes the reduction over the eight slices free of
+// selects); the array is [q][512 threads], read coalesced.
+inline uint32_t lstm_cell_row(uint32_t row) { return 4u * (row % 128u) + row / 128u; }
+inline size_t lstm_arranged_index(uint32_t row, uint32_t col, uint32_t cols)
+{
+    const uint32_t v = lstm_cell_row(row), cs = cols / 8u, s = col / cs, c = col % cs, i = (v & 7u) ^ s, tid = (v & ~7u) + s;
+    return static_cast<size_t>(i * cs + c) * 512u + tid;
+}
 hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb, const float* d_wout, uint32_t vocab,
                           uint32_t layers, uint32_t k, float* d_hid, float* d_logits, int32_t* d_tok, float* d_conf,
                           hipStream_t s, const LstmParams* lstm = nullptr);
