@@ -239,7 +239,7 @@ Engine::~Engine()
     if (d_emb_) (void)hipFree(d_emb_);
     if (d_wout_) (void)hipFree(d_wout_);
     for (float* p : lstm_bufs_) (void)hipFree(p);
-    for (Scratch* s : {&s_pages_, &s_req_, &s_tmp_, &s_stage_, &s_flush_, &s_hid_, &s_logits_, &s_hist_, &s_pred_, &s_attn_, &s_attn_seq_})
+    for (Scratch* s : {&s_pages_, &s_req_, &s_tmp_, &s_stage_, &s_flush_, &s_hid_, &s_logits_, &s_predict_ws_, &s_hist_, &s_pred_, &s_attn_, &s_attn_seq_})
         if (s->p) (void)hipFree(s->p);
     for (void* p : retired_) (void)hipFree(p);
     for (auto& l : lanes_) {
@@ -1500,9 +1500,10 @@ int Engine::predict_batch(uint32_t n, const int32_t* d_hist, uint32_t k, int32_t
     DeviceScope device_scope(device_);
     float* hid = static_cast<float*>(scratch(s_hid_, static_cast<size_t>(n) * 128 * sizeof(float), s));
     float* logits = static_cast<float*>(scratch(s_logits_, static_cast<size_t>(n) * vocab_ * sizeof(float), s));
-    if (!hid || !logits) return SPECKV_ERR_NOMEM;
+    void* ws = scratch(s_predict_ws_, predict_ws_bytes(n), s);
+    if (!hid || !logits || !ws) return SPECKV_ERR_NOMEM;
     hipStream_t st = s ? s : stream_;
-    HIP_TRY(launch_predict(n, d_hist, d_emb_, d_wout_, vocab_, 2, k, hid, logits, d_tok, d_conf, st, &lstm_));
+    HIP_TRY(launch_predict(n, d_hist, d_emb_, d_wout_, vocab_, 2, k, hid, logits, ws, d_tok, d_conf, st, &lstm_));
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
     return SPECKV_OK;
 }

@@ -309,7 +309,7 @@ private:
     uint32_t vocab_ = 0;
     LstmParams lstm_{};                    // device copies of a real cell's weights (layers == 0: the reference's degenerate cell)
     std::vector<float*> lstm_bufs_;
-    Scratch s_hid_, s_logits_, s_hist_, s_pred_;
+    Scratch s_hid_, s_logits_, s_predict_ws_, s_hist_, s_pred_;
     Scratch s_attn_, s_attn_seq_;
     // pinned staging for the batch descriptors: 4 slots in rotation, each guarded by an event (no stream sync per call)
     struct PinnedRing { void* base = nullptr; size_t slot_bytes = 0; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; int next = 0; } seq_ring_, grp_ring_;

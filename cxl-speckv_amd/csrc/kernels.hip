@@ -1557,7 +1557,9 @@ __global__ __launch_bounds__(512) void k_lstm_cell(const int32_t* __restrict__ h
 // vectors are the A operand (M = request), the weights the B operand (N = output row), so that an accumulator register holds
 // 32 consecutive logits of one request per half-wave and every store instruction writes two whole 128-byte lines.
 // The vector-ALU form this replaces (one quarter-row per lane, multiply and add per weight and request) needed ~80 VALU
-// instructions per request and wave, 4 cycles each on a 16-lane SIMD: 0.115 ms for 256 requests against ~0.014 ms of matrix time.
+// instructions per request and wave, 4 cycles each on a 16-lane SIMD: 0.115 ms for 256 requests against ~0.014 ms of matrix
+// time (the instruction runs at 64 cycles back to back also on one accumulator: profiles/tools/probe/mfma_f32_rate.hip, 143-156
+// TFLOP/s).  This kernel: 0.030 ms, of which 0.004 the stores and ~0.005 the weights' first read (one request: 0.0066 ms).
 // The order of the 128 additions of one logit: k = 8j + 4*(lane/32) + e for j = 0..15, e = 0..3, the lower half-wave's k first
 // inside each instruction (fused, unlike the oracle's mul + add: covered by the confidence tolerance of the parity tests).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1686,80 +1688,137 @@ __global__ __launch_bounds__(1024) void k_softmax_topk(const float* __restrict__
     }
 }
 
-// The same for vocabularies of up to 32 768 tokens, written for latency (one request per workgroup is a chain of
-// dependent steps; the kernel above took 48-57 us per launch whatever the batch): every thread keeps its 32 logits in
-// registers (all loads in flight at once), the top-k is k rounds of "best element not taken yet" (value descending, token
-// id ascending -- the same order as the sorted insertion above), block-wide reductions go through wave shuffles and 16 LDS
-// words.  The exp-sum adds each thread's terms in the same order as above.
-__global__ __launch_bounds__(1024) void k_softmax_topk_small(const float* __restrict__ logits, uint32_t vocab,
-        uint32_t k, int32_t* __restrict__ out_tok, float* __restrict__ out_conf)
+// The same for vocabularies of up to 32 768 tokens, written for latency (one request per workgroup is a chain of dependent
+// steps: the kernel above took 48-57 us per launch whatever the batch, a 1024-thread workgroup with 32 logits per thread in
+// registers 21-26 us).  A request is cut into kTkParts workgroups of 256 threads, 16 logits per thread:
+//   * a wave finds ITS maximum, exp-sum (relative to its own maximum) and top k with shuffles only -- a candidate is one
+//     64-bit key, the logit's bits made order-preserving above ~token id, so "value descending, token id ascending" (the
+//     order of the sorted insertion above) is an unsigned maximum and a round is six exchange steps;
+//   * one barrier, then wave 0 merges the four waves (maxima, rescaled sums, 4 k keys) and writes the part's result;
+//   * a second kernel, one wave per request, merges the parts the same way and writes tokens and confidences
+//     exp(logit - max) / sum.  (One kernel whose last-arriving workgroup merges was tried: 10 us for one request, but the
+//     agent-scope release/acquire it needs writes back and invalidates the XCD's L2 once per workgroup -- 48 us for 256
+//     requests against 26 us before.)
+// A logit that is -inf or NaN is never chosen (as above: "v > best" is false for it); a rank without a candidate reports
+// token -1 and confidence 0.
+constexpr uint32_t kTkParts = 8, kTkThreads = 256, kTkPer = 16, kTkSpan = kTkThreads * kTkPer;
+constexpr uint32_t kTkWsStride = kPredictWsStride;      // bytes of workspace per request: 8 x (max, sum) | 8 x 8 keys
+static_assert(kTkParts * kTkSpan == 32u * kSmThreads, "covers the vocabularies launch_predict sends here");
+static_assert(kTkParts * 8u + kTkParts * 8u * 8u <= kTkWsStride, "workspace layout");
+__device__ __forceinline__ uint64_t tk_key(float v, uint32_t i)
 {
-    __shared__ float red[16];
-    __shared__ uint32_t redi[16];
-    const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const float* l = logits + static_cast<uint64_t>(b) * vocab;
-    float v[32];
+    if (!(v > -INFINITY)) return 0;
+    uint32_t bits = __float_as_uint(v);
+    bits ^= (bits >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+    return (static_cast<uint64_t>(bits) << 32) | (0xFFFFFFFFu - i);
+}
+__device__ __forceinline__ float tk_value(uint64_t key)
+{
+    uint32_t bits = static_cast<uint32_t>(key >> 32);
+    bits ^= (bits >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+    return __uint_as_float(bits);
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t k)
+{
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const uint32_t i = tid + static_cast<uint32_t>(j) * kSmThreads;
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t lo = __shfl_xor(static_cast<uint32_t>(k), o), hi = __shfl_xor(static_cast<uint32_t>(k >> 32), o);
+        const uint64_t other = (static_cast<uint64_t>(hi) << 32) | lo;
+        k = other > k ? other : k;
+    }
+    return k;
+}
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// merge of up to 64 (max, sum) pairs and 64 keys held one per lane; k rounds; lane 0 hands every round's winner to `put`
+template <typename Put>
+__device__ __forceinline__ void tk_merge(float m, float s, uint64_t key, uint32_t k, float& m_all, float& s_all, Put put)
+{
+    m_all = wave_max_f32(m);
+    s_all = wave_sum_f32(m > -INFINITY ? s * expf(m - m_all) : 0.0f);
+    for (uint32_t r = 0; r < k; ++r) {
+        const uint64_t w = wave_max_u64(key);
+        if (w == key) key = 0;                                          // keys are distinct (token ids are): one owner
+        put(r, w);
+    }
+}
+__global__ __launch_bounds__(256) void k_softmax_topk_small(const float* __restrict__ logits, uint32_t vocab,
+        uint32_t k, uint8_t* __restrict__ ws)
+{
+    __shared__ float wm[4], wsum[4];
+    __shared__ uint64_t wkey[4][8];
+    const uint32_t b = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const float* l = logits + static_cast<uint64_t>(b) * vocab;
+    const uint32_t base = part * kTkSpan + tid;
+    float v[kTkPer];
+#pragma unroll
+    for (uint32_t j = 0; j < kTkPer; ++j) {
+        const uint32_t i = base + j * kTkThreads;
         v[j] = i < vocab ? l[i] : -INFINITY;
     }
-    float mx = v[0];
+    float m = v[0];
 #pragma unroll
-    for (int j = 1; j < 32; ++j) mx = fmaxf(mx, v[j]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if (lane == 0u) red[wv] = mx;
-    __syncthreads();
-    mx = red[0];
-#pragma unroll
-    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
-    __syncthreads();
+    for (uint32_t j = 1; j < kTkPer; ++j) m = fmaxf(m, v[j]);
+    m = wave_max_f32(m);
     float sum = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 32; ++j)
-        if (tid + static_cast<uint32_t>(j) * kSmThreads < vocab) sum += expf(v[j] - mx);
-    // (the tree above summed thread partials pairwise; any order of these 1024 partials is within the stated tolerance)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if (lane == 0u) red[wv] = sum;
-    __syncthreads();
-    sum = red[0];
-#pragma unroll
-    for (int i = 1; i < 16; ++i) sum += red[i];
+    for (uint32_t j = 0; j < kTkPer; ++j)
+        if (base + j * kTkThreads < vocab && m > -INFINITY) sum += expf(v[j] - m);
+    sum = wave_sum_f32(sum);
     for (uint32_t r = 0; r < k; ++r) {
-        float bv = -INFINITY; uint32_t bi = 0xFFFFFFFFu;
+        float bv = -INFINITY; int bj = -1;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {                                  // ascending token id: ">" keeps the lowest id among equals
-            const uint32_t i = tid + static_cast<uint32_t>(j) * kSmThreads;
-            if (i < vocab && v[j] > bv) { bv = v[j]; bi = i; }
-        }
-        // a thread whose elements are all taken or absent offers (-inf, none); -inf logits lose against any id
-        if (bi == 0xFFFFFFFFu) bv = -INFINITY;
-        float wvv = bv; uint32_t wi = bi;
+        for (int j = 0; j < static_cast<int>(kTkPer); ++j)                // ascending token id: ">" keeps the lowest id among equals
+            if (v[j] > bv) { bv = v[j]; bj = j; }
+        const uint64_t key = bj >= 0 ? tk_key(bv, base + static_cast<uint32_t>(bj) * kTkThreads) : 0;
+        const uint64_t w = wave_max_u64(key);
+        if (w != 0 && w == key) {                                       // the owner retires the winner
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(wvv, o); const uint32_t oi = __shfl_xor(wi, o);
-            if (ov > wvv || (ov == wvv && oi < wi)) { wvv = ov; wi = oi; }
+            for (int j = 0; j < static_cast<int>(kTkPer); ++j) if (j == bj) v[j] = -INFINITY;
         }
-        __syncthreads();
-        if (lane == 0u) { red[wv] = wvv; redi[wv] = wi; }
-        __syncthreads();
-        wvv = red[0]; wi = redi[0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) {
-            const float ov = red[i]; const uint32_t oi = redi[i];
-            if (ov > wvv || (ov == wvv && oi < wi)) { wvv = ov; wi = oi; }
-        }
-        // the owner retires the winner
-#pragma unroll
-        for (int j = 0; j < 32; ++j)
-            if (tid + static_cast<uint32_t>(j) * kSmThreads == wi) v[j] = -INFINITY;
-        if (tid == 0) {
-            out_tok[b * k + r] = static_cast<int32_t>(wi);
-            out_conf[b * k + r] = expf(wvv - mx) / sum;
-        }
+        if (lane == 0u) wkey[wv][r] = w;
     }
+    if (lane == 0u) { wm[wv] = m; wsum[wv] = sum; }
+    __syncthreads();
+    if (wv != 0u) return;
+    uint8_t* mine = ws + static_cast<uint64_t>(b) * kTkWsStride;
+    float* part_ms = reinterpret_cast<float*>(mine);                     // [part] (max, sum)
+    uint64_t* part_key = reinterpret_cast<uint64_t*>(mine + kTkParts * 8u);          // [part][8]
+    float pm, ps;
+    tk_merge(lane < 4u ? wm[lane] : -INFINITY, lane < 4u ? wsum[lane] : 0.0f, lane < 4u * k ? wkey[lane / k][lane % k] : 0, k, pm, ps,
+             [&](uint32_t r, uint64_t w) { if (lane == 0u) part_key[part * 8u + r] = w; });
+    if (lane == 0u) { part_ms[2u * part] = pm; part_ms[2u * part + 1u] = ps; }
+}
+__global__ __launch_bounds__(256) void k_softmax_topk_merge(const uint8_t* __restrict__ ws, uint32_t n, uint32_t k,
+        int32_t* __restrict__ out_tok, float* __restrict__ out_conf)
+{
+    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (b >= n) return;
+    const uint8_t* mine = ws + static_cast<uint64_t>(b) * kTkWsStride;
+    const float* part_ms = reinterpret_cast<const float*>(mine);
+    const uint64_t* part_key = reinterpret_cast<const uint64_t*>(mine + kTkParts * 8u);
+    const float qm = lane < kTkParts ? part_ms[2u * lane] : -INFINITY, qs = lane < kTkParts ? part_ms[2u * lane + 1u] : 0.0f;
+    const uint64_t qk = lane < kTkParts * k ? part_key[(lane / k) * 8u + lane % k] : 0;
+    float mx, total;
+    const float* mxp = &mx; const float* totp = &total;
+    float* conf = out_conf + static_cast<uint64_t>(b) * k;
+    int32_t* tok = out_tok + static_cast<uint64_t>(b) * k;
+    tk_merge(qm, qs, qk, k, mx, total, [&](uint32_t r, uint64_t w) {
+        if (lane == 0u) {
+            tok[r] = w ? static_cast<int32_t>(0xFFFFFFFFu - static_cast<uint32_t>(w)) : -1;
+            conf[r] = w ? expf(tk_value(w) - *mxp) / *totp : 0.0f;
+        }
+    });
 }
 
 // Records move to new places (compaction into packed extents and back): one wave per page copies the record's bytes, rounded up
@@ -1979,7 +2038,7 @@ hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t ba
 }
 
 hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb, const float* d_wout, uint32_t vocab,
-                          uint32_t layers, uint32_t k, float* d_hid, float* d_logits, int32_t* d_tok, float* d_conf,
+                          uint32_t layers, uint32_t k, float* d_hid, float* d_logits, void* d_ws, int32_t* d_tok, float* d_conf,
                           hipStream_t s, const LstmParams* lstm)
 {
     if (n == 0) return hipSuccess;
@@ -1995,7 +2054,10 @@ hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb,
     }
     const uint32_t waves = (vocab + 31u) / 32u;              // 32 output rows per wave (k_lstm_logits)
     hipLaunchKernelGGL(k_lstm_logits, dim3((waves + 3u) / 4u, (n + kLogitsChunk - 1u) / kLogitsChunk), dim3(256), 0, s, d_hid, n, d_wout, lstm ? lstm->out_bias : nullptr, vocab, d_logits);
-    if (vocab <= 32u * kSmThreads) hipLaunchKernelGGL(k_softmax_topk_small, dim3(n), dim3(1024), 0, s, d_logits, vocab, k, d_tok, d_conf);
+    if (vocab <= 32u * kSmThreads) {
+        hipLaunchKernelGGL(k_softmax_topk_small, dim3(kTkParts, n), dim3(kTkThreads), 0, s, d_logits, vocab, k, static_cast<uint8_t*>(d_ws));
+        hipLaunchKernelGGL(k_softmax_topk_merge, dim3((n + 3u) / 4u), dim3(256), 0, s, static_cast<const uint8_t*>(d_ws), n, k, d_tok, d_conf);
+    }
     else                           hipLaunchKernelGGL(k_softmax_topk, dim3(n), dim3(1024), 0, s, d_logits, vocab, k, d_tok, d_conf);
     return hipGetLastError();
 }

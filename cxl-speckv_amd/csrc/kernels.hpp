@@ -334,7 +334,10 @@ inline size_t lstm_arranged_index(uint32_t row, uint32_t col, uint32_t cols)
     return static_cast<size_t>(i * cs + c) * 512u + tid;
 }
 hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb, const float* d_wout, uint32_t vocab,
-                          uint32_t layers, uint32_t k, float* d_hid, float* d_logits, int32_t* d_tok, float* d_conf,
+                          uint32_t layers, uint32_t k, float* d_hid, float* d_logits, void* d_ws, int32_t* d_tok, float* d_conf,
                           hipStream_t s, const LstmParams* lstm = nullptr);
+// d_ws: predict_ws_bytes(n) bytes of scratch (the parts of the split top-k)
+constexpr uint32_t kPredictWsStride = 640;
+inline size_t predict_ws_bytes(uint32_t n) { return static_cast<size_t>(n) * kPredictWsStride; }
 
 } // namespace speckv
