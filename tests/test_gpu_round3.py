@@ -407,6 +407,35 @@ def test_real_lstm_cell_predictor_matches_torch_nn_lstm():
         lib.finalize()
 
 
+@pytest.mark.parametrize("vocab,n,k", [(8, 1, 8), (33, 31, 8), (1007, 33, 5), (4097, 70, 8), (32768, 3, 1), (32769, 2, 8)])
+def test_predictor_shapes_off_the_tile_sizes(oracle, vocab, n, k):
+    """The predictor's kernels cut their work into fixed tiles -- 32 output rows and 32 requests per matrix tile, 4096 logits per
+    top-k workgroup, eight of those per request (beyond 32 768 tokens the one-workgroup kernel takes over) -- so: vocabularies
+    and batch sizes that are not multiples of any of them, k = 8 = the whole vocabulary, against the oracle's
+    restatement of the reference's predictor (tokens identical, confidences within 5e-4 relative, as in
+    test_token_predictor_matches_oracle_and_reference)."""
+    torch = torch_mod()
+    lib = open_lib()
+    try:
+        rng = np.random.default_rng(vocab * 131 + n)
+        emb = rng.standard_normal((vocab, 64)).astype(np.float32) * 0.5
+        wout = rng.standard_normal((vocab, 128)).astype(np.float32) * 0.5
+        lib.predictor_load(emb.ctypes.data, wout.ctypes.data, vocab, False)
+        H = rng.integers(0, vocab, (n, 16)).astype(np.int32)
+        H[0, :3] = vocab + 1                                        # out-of-vocabulary ids embed as zeros
+        d_h = torch.from_numpy(H).cuda()
+        d_tok = torch.full((n, k), -7, dtype=torch.int32, device="cuda"); d_conf = torch.zeros((n, k), dtype=torch.float32, device="cuda")
+        lib.predict_batch(n, d_h.data_ptr(), k, d_tok.data_ptr(), d_conf.data_ptr())
+        torch.cuda.synchronize()
+        tok, conf = d_tok.cpu().numpy(), d_conf.cpu().numpy()
+        for i in range(n):
+            o_tok, o_conf = oracle.lstm_predict(emb, wout, H[i].astype(np.uint32), k)
+            assert tok[i].tolist() == o_tok.astype(np.int32).tolist(), (i, tok[i], o_tok)
+            assert np.allclose(conf[i], o_conf, rtol=5e-4, atol=1e-12), (i, conf[i], o_conf)
+    finally:
+        lib.finalize()
+
+
 @pytest.mark.parametrize("pools", [None, "0,0,0"])
 def test_compaction_packs_rle_records_and_frees_the_slots(oracle, pools):
     """INT8_DELTA_RLE records used to live in worst-case 4 KiB slots for good, so the
