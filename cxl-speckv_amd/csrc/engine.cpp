@@ -1422,11 +1422,23 @@ int Engine::predictor_load(const float* emb, const float* wout, uint32_t vocab, 
     if (d_wout_) { (void)hipFree(d_wout_); d_wout_ = nullptr; }
     const size_t eb = static_cast<size_t>(vocab) * 64 * sizeof(float), wb = static_cast<size_t>(vocab) * 128 * sizeof(float);
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_emb_), eb));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_wout_), wb));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_wout_), arranged_wout_bytes(vocab)));
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     if (on_device) HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(d_emb_, emb, eb, kind));
-    HIP_TRY(hipMemcpy(d_wout_, wout, wb, kind));
+    {
+        // the output layer is kept in the order its kernel reads it (k_arrange_wout); a caller's device copy is read in place
+        float* staged = nullptr;
+        if (!on_device) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&staged), wb));
+            const hipError_t ce = hipMemcpy(staged, wout, wb, hipMemcpyHostToDevice);
+            if (ce != hipSuccess) { (void)hipFree(staged); HIP_TRY(ce); }
+        }
+        hipError_t e = launch_arrange_wout(on_device ? wout : staged, d_wout_, vocab, stream_);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+        if (staged) (void)hipFree(staged);
+        HIP_TRY(e);
+    }
     vocab_ = vocab;
     hist_.clear(); pred_.clear(); hist_dirty_.clear();
     for (float* p : lstm_bufs_) (void)hipFree(p);       // back to the reference's cell

@@ -1563,6 +1563,21 @@ __global__ __launch_bounds__(512) void k_lstm_cell(const int32_t* __restrict__ h
 // The order of the 128 additions of one logit: k = 8j + 4*(lane/32) + e for j = 0..15, e = 0..3, the lower half-wave's k first
 // inside each instruction (fused, unlike the oracle's mul + add: covered by the confidence tolerance of the parity tests).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// The output layer's weights in the order k_lstm_logits reads them: per 32 rows, float4 [j][lane] = row (lane % 32),
+// columns 8j + 4 (lane / 32) .. + 3 -- a wave's load instruction is then one contiguous KiB (row-major, its 64 lanes touched
+// 64 different lines 16 bytes at a time).  Once per predictor_load.
+__global__ __launch_bounds__(256) void k_arrange_wout(const float* __restrict__ src, float4* __restrict__ dst, uint32_t vocab)
+{
+    const uint32_t lane = threadIdx.x & 63u, tile = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t row = tile * 32u + (lane & 31u), kh = lane >> 5;
+    if (tile * 32u >= vocab) return;
+#pragma unroll
+    for (uint32_t j = 0; j < 16u; ++j) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < vocab) v = *reinterpret_cast<const float4*>(src + static_cast<uint64_t>(row) * kPredHidden + 8u * j + 4u * kh);
+        dst[(static_cast<uint64_t>(tile) * 16u + j) * 64u + lane] = v;
+    }
+}
 constexpr uint32_t kLogitsTile = 32;        // requests per matrix tile
 constexpr uint32_t kLogitsChunk = 128;      // requests per workgroup column (blockIdx.y): 2 waves per SIMD at 256 requests x 32 000 rows
 constexpr uint32_t kLogitsPitch = kPredHidden + 4u;     // floats; 16 lanes x 16 B of one ds_read_b128 fall in 64 different banks
@@ -1574,12 +1589,11 @@ __global__ __launch_bounds__(256) void k_lstm_logits(const float* __restrict__ h
     const uint32_t c = lane & 31u, kh = lane >> 5;
     const uint32_t row = (blockIdx.x * 4u + wave) * 32u + c;
     const bool live = row < vocab;
+    // the weights arrive arranged (k_arrange_wout): the wave's 32 rows are 16 KiB in a row, [j][lane] float4, rows past the vocabulary zero
     float4 wq[16];
+    const float4* wt = reinterpret_cast<const float4*>(wout) + static_cast<uint64_t>(blockIdx.x * 4u + wave) * (16u * 64u) + lane;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        wq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live) wq[j] = *reinterpret_cast<const float4*>(wout + static_cast<uint64_t>(row) * kPredHidden + 8u * j + 4u * kh);
-    }
+    for (int j = 0; j < 16; ++j) wq[j] = wt[j * 64];
     const float bias = (out_bias && live) ? out_bias[row] : 0.0f;
     const uint32_t b_begin = blockIdx.y * kLogitsChunk, b_end = min(n, b_begin + kLogitsChunk);
     // A tile of hidden vectors (32 requests, 16 KiB) goes through LDS, shared by the four waves; two buffers, so one barrier
@@ -1757,7 +1771,7 @@ __global__ __launch_bounds__(256) void k_softmax_topk_small(const float* __restr
 {
     __shared__ float wm[4], wsum[4];
     __shared__ uint64_t wkey[4][8];
-    const uint32_t b = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t b = blockIdx.x, part = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;      // (requests on x: no 65 535 limit)
     const float* l = logits + static_cast<uint64_t>(b) * vocab;
     const uint32_t base = part * kTkSpan + tid;
     float v[kTkPer];
@@ -2037,6 +2051,14 @@ hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t ba
     return hipGetLastError();
 }
 
+size_t arranged_wout_bytes(uint32_t vocab) { return static_cast<size_t>((vocab + 31u) / 32u) * 32u * kPredHidden * sizeof(float); }
+hipError_t launch_arrange_wout(const float* d_src, float* d_dst, uint32_t vocab, hipStream_t s)
+{
+    const uint32_t tiles = (vocab + 31u) / 32u;
+    hipLaunchKernelGGL(k_arrange_wout, dim3((tiles + 3u) / 4u), dim3(256), 0, s, d_src, reinterpret_cast<float4*>(d_dst), vocab);
+    return hipGetLastError();
+}
+
 hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb, const float* d_wout, uint32_t vocab,
                           uint32_t layers, uint32_t k, float* d_hid, float* d_logits, void* d_ws, int32_t* d_tok, float* d_conf,
                           hipStream_t s, const LstmParams* lstm)
@@ -2055,7 +2077,7 @@ hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb,
     const uint32_t waves = (vocab + 31u) / 32u;              // 32 output rows per wave (k_lstm_logits)
     hipLaunchKernelGGL(k_lstm_logits, dim3((waves + 3u) / 4u, (n + kLogitsChunk - 1u) / kLogitsChunk), dim3(256), 0, s, d_hid, n, d_wout, lstm ? lstm->out_bias : nullptr, vocab, d_logits);
     if (vocab <= 32u * kSmThreads) {
-        hipLaunchKernelGGL(k_softmax_topk_small, dim3(kTkParts, n), dim3(kTkThreads), 0, s, d_logits, vocab, k, static_cast<uint8_t*>(d_ws));
+        hipLaunchKernelGGL(k_softmax_topk_small, dim3(n, kTkParts), dim3(kTkThreads), 0, s, d_logits, vocab, k, static_cast<uint8_t*>(d_ws));
         hipLaunchKernelGGL(k_softmax_topk_merge, dim3((n + 3u) / 4u), dim3(256), 0, s, static_cast<const uint8_t*>(d_ws), n, k, d_tok, d_conf);
     }
     else                           hipLaunchKernelGGL(k_softmax_topk, dim3(n), dim3(1024), 0, s, d_logits, vocab, k, d_tok, d_conf);

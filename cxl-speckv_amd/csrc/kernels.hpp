@@ -336,6 +336,9 @@ inline size_t lstm_arranged_index(uint32_t row, uint32_t col, uint32_t cols)
 hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb, const float* d_wout, uint32_t vocab,
                           uint32_t layers, uint32_t k, float* d_hid, float* d_logits, void* d_ws, int32_t* d_tok, float* d_conf,
                           hipStream_t s, const LstmParams* lstm = nullptr);
+// d_wout: the output layer's weights ARRANGED by launch_arrange_wout (arranged_wout_bytes(vocab) bytes) from the row-major [vocab][128]
+size_t arranged_wout_bytes(uint32_t vocab);
+hipError_t launch_arrange_wout(const float* d_src, float* d_dst, uint32_t vocab, hipStream_t s);
 // d_ws: predict_ws_bytes(n) bytes of scratch (the parts of the split top-k)
 constexpr uint32_t kPredictWsStride = 640;
 inline size_t predict_ws_bytes(uint32_t n) { return static_cast<size_t>(n) * kPredictWsStride; }
