@@ -1732,27 +1732,36 @@ __device__ __forceinline__ float tk_value(uint64_t key)
     bits ^= (bits >> 31) ? 0x80000000u : 0xFFFFFFFFu;
     return __uint_as_float(bits);
 }
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t k)
+// All-lanes reductions over the wave for the top-k rounds, written for latency (a round is a chain of six exchanges): the
+// four steps inside a row of 16 lanes are DPP moves (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: a few clocks each),
+// rows 16 apart exchange through ds_swizzle, the two halves of the wave through ds_bpermute -- two trips through the LDS crossbar
+// instead of six.
+template <int CTRL> __device__ __forceinline__ uint32_t tk_dpp(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xf, 0xf, false)); }
+template <int STEP> __device__ __forceinline__ uint32_t tk_exchange(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t lo = __shfl_xor(static_cast<uint32_t>(k), o), hi = __shfl_xor(static_cast<uint32_t>(k >> 32), o);
-        const uint64_t other = (static_cast<uint64_t>(hi) << 32) | lo;
-        k = other > k ? other : k;
-    }
-    return k;
+    if constexpr (STEP == 0) return tk_dpp<0xB1>(v);                 // quad_perm [1,0,3,2]
+    else if constexpr (STEP == 1) return tk_dpp<0x4E>(v);            // quad_perm [2,3,0,1]
+    else if constexpr (STEP == 2) return tk_dpp<0x141>(v);           // row_half_mirror: the other quad of each 8
+    else if constexpr (STEP == 3) return tk_dpp<0x140>(v);           // row_mirror: the other 8 of each 16
+    else if constexpr (STEP == 4) return static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(v), 0x401F));    // lane ^ 16
+    else return static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), 32));
 }
-__device__ __forceinline__ float wave_max_f32(float v)
+template <int STEP = 0> __device__ __forceinline__ uint64_t wave_max_u64(uint64_t k)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    if constexpr (STEP < 6) {
+        const uint64_t other = (static_cast<uint64_t>(tk_exchange<STEP>(static_cast<uint32_t>(k >> 32))) << 32) | tk_exchange<STEP>(static_cast<uint32_t>(k));
+        return wave_max_u64<STEP + 1>(other > k ? other : k);
+    } else return k;
 }
-__device__ __forceinline__ float wave_sum_f32(float v)
+template <int STEP = 0> __device__ __forceinline__ float wave_max_f32(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    if constexpr (STEP < 6) return wave_max_f32<STEP + 1>(fmaxf(v, __uint_as_float(tk_exchange<STEP>(__float_as_uint(v)))));
+    else return v;
+}
+template <int STEP = 0> __device__ __forceinline__ float wave_sum_f32(float v)
+{
+    if constexpr (STEP < 6) return wave_sum_f32<STEP + 1>(v + __uint_as_float(tk_exchange<STEP>(__float_as_uint(v))));
+    else return v;
 }
 // merge of up to 64 (max, sum) pairs and 64 keys held one per lane; k rounds; lane 0 hands every round's winner to `put`
 template <typename Put>
