@@ -194,6 +194,10 @@ int Engine::init_hip(int device)
     HIP_TRY(hipMemsetAsync(d_owner_, 0xFF, static_cast<size_t>(n_l2_) * sizeof(uint64_t), stream_));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hand_), 64));
     HIP_TRY(hipMemsetAsync(d_hand_, 0, 64, stream_));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_done_count_), 64));
+    HIP_TRY(hipMemsetAsync(d_done_count_, 0, 64, stream_));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_done_), 64, hipHostMallocMapped | hipHostMallocPortable));
+    *h_done_ = 0;
     l1_owner_.assign(n_l1_, Owner{nullptr, 0});
     lru_prev_.assign(n_l2_ + n_l1_, UINT32_MAX);
     lru_next_.assign(n_l2_ + n_l1_, UINT32_MAX);
@@ -267,6 +271,8 @@ Engine::~Engine()
     if (h_tab_) (void)hipHostFree(h_tab_);
     if (d_owner_) (void)hipFree(d_owner_);
     if (d_hand_) (void)hipFree(d_hand_);
+    if (d_done_count_) (void)hipFree(d_done_count_);
+    if (h_done_) (void)hipHostFree(h_done_);
     if (cache_base_) (void)hipFree(cache_base_);
     pools_.clear();
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
@@ -921,11 +927,32 @@ int Engine::fetch_into_ring(Allocation* a, const std::vector<uint32_t>& pages, u
     c.seq0 = seq;
     c.hand_ptr = d_hand_;
     c.new_hand = ring_seq_;
+    // A miss of a page or a few: the kernel's last wave stores a token to a pinned host word and the host spins on it -- the
+    // runtime's own completion path costs 4 us more for a launch this short (DESIGN.md sect. 5).  A spin that runs out
+    // (a preempted GPU, a debugger) falls back to it.
+    static const bool spin_ok = getenv("SPECKV_ACCESS_NO_SPIN") == nullptr;
+    const bool spin = spin_ok && n <= 8u && h_done_ && d_done_count_;
+    if (spin) {
+        void* dp = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dp, h_done_, 0));
+        c.done_flag = static_cast<uint32_t*>(dp);
+        c.done_count = d_done_count_;
+        c.done_token = ++done_token_ ? done_token_ : ++done_token_;      // never 0: the word's initial value
+    }
     HIP_TRY(launch_decompress(c, stream_));
     st_.dma_submitted += n;
     st_.total_decompressions += n;
     ++ring_busy_;
-    const int wrc = wait_stream();       // sync_fetch_page: submit, then spin on completion
+    int wrc = SPECKV_OK;
+    bool seen = false;
+    if (spin) {
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+        for (uint32_t it = 0; !seen; ++it) {
+            seen = __atomic_load_n(h_done_, __ATOMIC_ACQUIRE) == c.done_token;
+            if (!seen && (it & 63u) == 63u && std::chrono::steady_clock::now() > t_end) break;
+        }
+    }
+    if (!seen) wrc = wait_stream();      // sync_fetch_page: submit, then spin on completion
     --ring_busy_;
     RC_TRY(wrc);
     completed_unpolled_ += n;

@@ -218,6 +218,10 @@ private:
     uint32_t ring_seq_limit_ = 0xC0000000u;   // renumber_ring_if_due: keeps sequence numbers clear of the 32-bit wrap
     uint64_t* d_owner_ = nullptr;          // [n_l2] (row << 32 | page), kNoOwner when free
     uint32_t* d_hand_ = nullptr;
+    // completion word of small synchronous fetches (CodecArgs::done_flag): pinned host word, device counter, last token handed out
+    uint32_t* h_done_ = nullptr;
+    uint32_t* d_done_count_ = nullptr;
+    uint32_t done_token_ = 0;
     std::vector<Owner> l1_owner_;          // [n_l1], slot - n_l2
     std::vector<uint32_t> lru_prev_, lru_next_, l1_free_;
     uint32_t lru_head_ = UINT32_MAX, lru_tail_ = UINT32_MAX;   // head = least recent

@@ -626,6 +626,13 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
         cur = nxt;
         i = nx;
     }
+    if (EXT == 2 && a.done_flag) {                                      // (launch-uniform; one block per wave: n waves had work)
+        __threadfence_system();                                          // the page, its residency words and the host-visible word are out
+        if (lane == 0u && atomicAdd(a.done_count, 1u) + 1u == static_cast<uint32_t>(n)) {
+            *a.done_count = 0u;
+            __hip_atomic_store(a.done_flag, a.done_token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ===================================================================
@@ -1914,6 +1921,7 @@ hipError_t launch_dec2(const CodecArgs& a_in, hipStream_t s)
     a.wave_step = (round_strided() && a.per_wave > 1) ? static_cast<uint64_t>(grid) * kWaves : 0;
     const int ext = a.host_words ? 3 : (a.alloc_list || a.ring_owner) ? 2 : a.stripe_n ? 1 : 0;
     if (ext == 2 && a.stripe_n) return hipErrorInvalidValue;
+    if (a.done_flag && (ext != 2 || a.per_wave > 1 || a.n_dev || !a.done_count)) return hipErrorInvalidValue;
     if (ext == 3 && (a.out_f32 || a.alloc_list || a.ring_owner || a.stripe_n || !a.seq0_dev || !a.data_list)) return hipErrorInvalidValue;
 #define SPECKV_LAUNCH_DEC(F32, EXT) \
     hipLaunchKernelGGL((k_fetch_decompress<SCHEME, MODE, F32, EXT>), dim3(grid), dim3(kThreads), 0, s, a)

@@ -407,6 +407,48 @@ def test_real_lstm_cell_predictor_matches_torch_nn_lstm():
         lib.finalize()
 
 
+class _RawDevice:
+    """A device buffer by address, for torch.as_tensor (CUDA array interface)."""
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+@pytest.mark.parametrize("spin", [True, False])
+def test_access_miss_completion_word_orders_the_page_for_other_streams(spin):
+    """speckv_access on a miss returns when the fetch kernel's last wave has stored a token to a pinned host word (the
+    runtime's completion path costs 4 us more; SPECKV_ACCESS_NO_SPIN=1 keeps it).  The kernel is then still retiring, so
+    what the caller does next must already see the page: 600 random misses (the ring of the default cache is recycled
+    many times over), each read at once by a kernel on ANOTHER stream, and spans of 1..8 pages; against the source (FP16
+    scheme: the stored page is the source page)."""
+    torch = torch_mod()
+    lib = open_lib(**({} if spin else {"SPECKV_ACCESS_NO_SPIN": 1}))
+    try:
+        lib.set_compression_scheme(0)
+        n_pages = 4096
+        h = lib.alloc(n_pages * PAGE)
+        rng = np.random.default_rng(3)
+        x = rng.integers(0, 2 ** 16, (n_pages, PAGE // 2), dtype=np.uint16)
+        x &= 0x7BFF                                                  # finite fp16 bit patterns
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+        side = torch.cuda.Stream()
+        held = []
+        for i in range(600):
+            p = int(rng.integers(0, n_pages - 8))
+            span = 1 + (i % 8 if i % 5 == 0 else 0)
+            ptr = lib.access(h, p * PAGE, span * PAGE)
+            with torch.cuda.stream(side):
+                held.append((p, span, torch.as_tensor(_RawDevice(ptr, span * PAGE), device="cuda").clone()))
+            if len(held) == 50:                                      # (the copies are checked in batches: no host sync per miss)
+                side.synchronize()
+                for q, sp, t in held:
+                    assert t.cpu().numpy().tobytes() == x[q:q + sp].tobytes(), (i, q, sp)
+                held.clear()
+        st = lib.stats()
+        assert st.l3_accesses >= 500
+    finally:
+        lib.finalize()
+
+
 @pytest.mark.parametrize("vocab,n,k", [(8, 1, 8), (33, 31, 8), (1007, 33, 5), (4097, 70, 8), (32768, 3, 1), (32769, 2, 8)])
 def test_predictor_shapes_off_the_tile_sizes(oracle, vocab, n, k):
     """The predictor's kernels cut their work into fixed tiles -- 32 output rows and 32 requests per matrix tile, 4096 logits per
