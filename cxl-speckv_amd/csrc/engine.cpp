@@ -273,6 +273,9 @@ Engine::~Engine()
     if (d_hand_) (void)hipFree(d_hand_);
     if (d_done_count_) (void)hipFree(d_done_count_);
     if (h_done_) (void)hipHostFree(h_done_);
+    if (pred_stream_) (void)hipStreamDestroy(pred_stream_);
+    if (pred_ev_) (void)hipEventDestroy(pred_ev_);
+    if (h_pred_io_) (void)hipHostFree(h_pred_io_);
     if (cache_base_) (void)hipFree(cache_base_);
     pools_.clear();
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
@@ -1467,6 +1470,7 @@ int Engine::predictor_load(const float* emb, const float* wout, uint32_t vocab, 
         HIP_TRY(e);
     }
     vocab_ = vocab;
+    pending_pred_.active = false;                            // (the device was synchronised above: nothing is in flight)
     hist_.clear(); pred_.clear(); hist_dirty_.clear();
     for (float* p : lstm_bufs_) (void)hipFree(p);       // back to the reference's cell
     lstm_bufs_.clear();
@@ -1547,29 +1551,54 @@ int Engine::predict_batch(uint32_t n, const int32_t* d_hist, uint32_t k, int32_t
     return SPECKV_OK;
 }
 
+int Engine::harvest_predictions()
+{
+    if (!pending_pred_.active) return SPECKV_OK;
+    const uint64_t gen = pending_pred_.gen;
+    RC_TRY(wait_event(pred_ev_));                            // may let go of the ABI lock: another thread may have harvested, or started the next one
+    if (!pending_pred_.active || pending_pred_.gen != gen) return SPECKV_OK;
+    const uint32_t n = static_cast<uint32_t>(pending_pred_.reqs.size()), k = pending_pred_.k;
+    const int32_t* tok = h_pred_io_ + static_cast<size_t>(n) * 16;
+    for (uint32_t i = 0; i < n; ++i) pred_[pending_pred_.reqs[i]].assign(tok + static_cast<size_t>(i) * k, tok + static_cast<size_t>(i + 1) * k);
+    pending_pred_.active = false;
+    return SPECKV_OK;
+}
+
 int Engine::run_predictor_for_dirty()
 {
     if (!d_emb_ || hist_dirty_.empty()) { hist_dirty_.clear(); return SPECKV_OK; }
+    RC_TRY(harvest_predictions());                           // the one before (long finished as a rule): its staging is reused
+    if (hist_dirty_.empty()) return SPECKV_OK;               // (another thread's flush took them while we waited)
     std::sort(hist_dirty_.begin(), hist_dirty_.end());
     hist_dirty_.erase(std::unique(hist_dirty_.begin(), hist_dirty_.end()), hist_dirty_.end());
     const uint32_t n = static_cast<uint32_t>(hist_dirty_.size());
     uint32_t k = adapt_.depth();
     if (k > 8) k = 8;
     if (k == 0) k = 1;
-    std::vector<int32_t> h(static_cast<size_t>(n) * 16);
-    for (uint32_t i = 0; i < n; ++i) memcpy(&h[i * 16], hist_[hist_dirty_[i]].data(), 16 * sizeof(int32_t));
-    int32_t* d_h = static_cast<int32_t*>(scratch(s_hist_, h.size() * sizeof(int32_t)));
-    uint8_t* d_p = static_cast<uint8_t*>(scratch(s_pred_, static_cast<size_t>(n) * k * (sizeof(int32_t) + sizeof(float))));
+    if (!pred_stream_) HIP_TRY(hipStreamCreateWithFlags(&pred_stream_, hipStreamNonBlocking));
+    if (!pred_ev_) HIP_TRY(hipEventCreateWithFlags(&pred_ev_, hipEventDisableTiming));
+    const size_t hist_words = static_cast<size_t>(n) * 16, io_bytes = (hist_words + static_cast<size_t>(n) * k) * sizeof(int32_t);
+    if (io_bytes > h_pred_cap_) {
+        if (h_pred_io_) { (void)hipHostFree(h_pred_io_); h_pred_io_ = nullptr; h_pred_cap_ = 0; }
+        const size_t want = std::max<size_t>(io_bytes + (io_bytes >> 1), 1 << 16);
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_pred_io_), want, hipHostMallocDefault));
+        h_pred_cap_ = want;
+    }
+    for (uint32_t i = 0; i < n; ++i) memcpy(h_pred_io_ + static_cast<size_t>(i) * 16, hist_[hist_dirty_[i]].data(), 16 * sizeof(int32_t));
+    int32_t* d_h = static_cast<int32_t*>(scratch(s_hist_, hist_words * sizeof(int32_t), pred_stream_));
+    uint8_t* d_p = static_cast<uint8_t*>(scratch(s_pred_, static_cast<size_t>(n) * k * (sizeof(int32_t) + sizeof(float)), pred_stream_));
     if (!d_h || !d_p) return SPECKV_ERR_NOMEM;
     int32_t* d_tok = reinterpret_cast<int32_t*>(d_p);
     float* d_conf = reinterpret_cast<float*>(d_p + static_cast<size_t>(n) * k * sizeof(int32_t));
-    HIP_TRY(hipMemcpyAsync(d_h, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-    int rc = predict_batch(n, d_h, k, d_tok, d_conf, stream_);
+    HIP_TRY(hipMemcpyAsync(d_h, h_pred_io_, hist_words * sizeof(int32_t), hipMemcpyHostToDevice, pred_stream_));
+    int rc = predict_batch(n, d_h, k, d_tok, d_conf, pred_stream_);
     if (rc != SPECKV_OK) return rc;
-    std::vector<int32_t> tok(static_cast<size_t>(n) * k);
-    HIP_TRY(hipMemcpyAsync(tok.data(), d_tok, tok.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
-    for (uint32_t i = 0; i < n; ++i) pred_[hist_dirty_[i]].assign(tok.begin() + static_cast<size_t>(i) * k, tok.begin() + static_cast<size_t>(i + 1) * k);
+    HIP_TRY(hipMemcpyAsync(h_pred_io_ + hist_words, d_tok, static_cast<size_t>(n) * k * sizeof(int32_t), hipMemcpyDeviceToHost, pred_stream_));
+    HIP_TRY(hipEventRecord(pred_ev_, pred_stream_));
+    pending_pred_.reqs.swap(hist_dirty_);
+    pending_pred_.k = k;
+    ++pending_pred_.gen;
+    pending_pred_.active = true;
     hist_dirty_.clear();
     return SPECKV_OK;
 }
@@ -1602,6 +1631,7 @@ int Engine::verify(uint32_t req, int32_t actual, const int32_t* pred, uint32_t n
     // no list given: verify against the prediction the engine made from the request's last history
     std::vector<int32_t> own;
     if (!pred || n == 0) {
+        RC_TRY(harvest_predictions());                       // the last flush's prediction may still be on its way
         auto it = pred_.find(req);
         if (it == pred_.end()) return SPECKV_ERR_INVAL;
         own = it->second;

@@ -324,6 +324,15 @@ private:
     std::unordered_map<uint32_t, std::vector<int32_t>> hist_;
     std::unordered_map<uint32_t, std::vector<int32_t>> pred_;
     std::vector<uint32_t> hist_dirty_;
+    // The predictions of a flush run on a stream of their own and come back through pinned memory: nobody needs the tokens
+    // before the next speckv_ext_verify (the pages a flush fetches are addressed by position, lstm_predictor's tokens only
+    // feed the hit statistics -- speculative_prefetcher.cpp:84-96), so the flush does not wait for them.
+    hipStream_t pred_stream_ = nullptr;
+    hipEvent_t pred_ev_ = nullptr;
+    int32_t* h_pred_io_ = nullptr;         // pinned: n x 16 history tokens in, n x k predicted tokens out
+    size_t h_pred_cap_ = 0;                // bytes
+    struct PendingPred { std::vector<uint32_t> reqs; uint32_t k = 0; uint64_t gen = 0; bool active = false; } pending_pred_;
+    int harvest_predictions();             // waits for the prediction in flight (if any) and files its tokens under pred_
 
     speckv_ext_stats_t st_{};
 

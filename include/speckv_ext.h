@@ -172,8 +172,11 @@ speckv_status_t speckv_ext_prefetch_legacy_addrs(uint32_t layer, uint32_t depth_
  * The reference draws its weights from rand(); here the caller supplies them:
  * embedding [vocab][64], out_weights [vocab][128] (fp32, host or device).  Once loaded,
  * speckv_prefetch keeps the last 16 tokens per request, each flush predicts the next
- * tokens of the requests whose history changed (top-depth, depth <= 8), and
- * speckv_ext_verify(req, actual, NULL, 0) checks against that prediction.
+ * tokens of the requests whose history changed (top-depth, depth <= 8) -- on a stream of the
+ * engine's own, without holding the flush up: the pages a flush fetches are addressed by
+ * position, the tokens only feed the hit statistics -- and
+ * speckv_ext_verify(req, actual, NULL, 0) checks against that prediction (waiting for it
+ * if it is still on its way).
  * speckv_ext_predict_batch is the raw operator: n histories of 16 int32 tokens
  * (device) -> top-k tokens / confidences (device, k <= 8). */
 speckv_status_t speckv_ext_predictor_load(const float* embedding, const float* out_weights,
