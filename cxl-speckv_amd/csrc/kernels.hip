@@ -1107,9 +1107,8 @@ __global__ __launch_bounds__(1024) void k_scan_totals(const uint32_t* __restrict
 // flushes carry an older epoch and lose against any key of this one (the host clears them when the 8-bit epoch wraps).
 __device__ __forceinline__ uint32_t flush_key(uint32_t epoch, uint32_t index) { return (epoch << 24) | (0xFFFFFFu - index); }
 
-__global__ __launch_bounds__(256) void k_flush_candidates(FlushArgs a)
+__device__ __forceinline__ void flush_candidates_of(const FlushArgs& a, uint32_t gt)      // gt: one thread per (request, lane)
 {
-    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (request, lane)
     const uint32_t r = gt >> 5, c = gt & 31u;
     if (r >= a.n) return;
     const uint32_t row = a.row[r];
@@ -1133,6 +1132,60 @@ __global__ __launch_bounds__(256) void k_flush_candidates(FlushArgs a)
         a.cand[base + w] = pg;
     }
 }
+__global__ __launch_bounds__(256) void k_flush_candidates(FlushArgs a) { flush_candidates_of(a, blockIdx.x * blockDim.x + threadIdx.x); }
+
+// candidate word i names page `pg` of allocation row `row` and is the first occurrence of that page in the flush
+__device__ __forceinline__ bool flush_keeps(const FlushArgs& a, uint32_t i, uint32_t total, uint32_t& pg, uint32_t& row)
+{
+    pg = kNoSlot; row = kNoSlot;
+    if (i >= total) return false;
+    pg = a.cand[i];
+    if (pg == kNoSlot) return false;
+    row = a.row[i / (32u * a.W)];
+    return a.tab[row].stamp[pg] == flush_key(a.epoch, i);
+}
+// Entry `rank` of the flush lands in ring slot base + rank.  Everything about it that is pointer chasing --
+// its record descriptor, the slot's previous owner and that owner's residency words, the new owner, the
+// page's slot words on both sides -- is done here, one THREAD per page, so that the fetch launch is the plain
+// list form (descriptor + destination per block) at the bulk kernel's occupancy.  Done by the fetch kernel
+// itself, one WAVE per page with a chain of ~8 dependent loads each, the 122 880-page flush of a 256-sequence
+// decode step spent 210 us in the fetch; the chain now runs 64 pages per wave.
+// (The words are final before the data has landed: the host waits for the flight's `done` event before it
+// trusts a page whose slot lies in the flight's run, Engine::wait_landed.)
+__device__ __forceinline__ void flush_place(const FlushArgs& a, const FlushResult& res, uint32_t rank, uint32_t row, uint32_t pg)
+{
+    const uint32_t slot = res.base + rank;
+    const DevAlloc t = a.tab[row];
+    a.final_entry[rank] = t.entries[pg];
+    a.final_dst[rank] = reinterpret_cast<uint64_t>(a.ring_base + static_cast<uint64_t>(slot) * kPageSize);
+    const uint64_t prev = a.ring_owner[slot];
+    const uint64_t me = (static_cast<uint64_t>(row) << 32) | pg;
+    if (prev != kNoOwner && prev != me) {
+        const DevAlloc tp = a.tab[prev >> 32];
+        const uint32_t pp = static_cast<uint32_t>(prev);
+        // the row may have been recycled for a smaller allocation since the slot was filled
+        if (tp.entries && pp < tp.layout.alloc_pages && tp.d_slot[pp] == slot)    // still pointing here: the page leaves L2
+            atomicAnd(&tp.d_flags[pp], ~2u);
+    }
+    a.ring_owner[slot] = me;
+    t.d_slot[pg] = slot;
+    if (a.final_host) a.final_host[rank] = &t.h_slot[pg];     // stored by the fetch launch (CodecArgs::host_words)
+    else t.h_slot[pg] = res.seq + rank;                       // the page's only host-visible word (Engine::l2_live)
+    atomicOr(&t.d_flags[pg], 2u);
+}
+// the ring run of a flush that keeps `total` candidates: [base, base+m), a run never wraps (as Engine::take_l2_run on the
+// host: same rule, so host and device agree on the hand).  *a.hand is the ring's sequence number: slot = seq % n_l2; the
+// slots a run skips at the end of a lap count.
+__device__ __forceinline__ FlushResult flush_take(const FlushArgs& a, uint32_t total)
+{
+    const uint32_t m = total < a.max_take ? total : a.max_take;
+    const RingRun run = ring_take(*a.hand, m, a.n_l2);
+    if (m) *a.hand = run.next;
+    const FlushResult r{m, run.slot, total, run.seq};
+    *a.result_dev = r;
+    *a.result_host = r;
+    return r;
+}
 
 // keep[i] = candidate i is the first occurrence of its page; WRITE = false: totals per workgroup (256 candidates: the
 // single-workgroup scan of k_flush_assign is 4x shorter than over per-wave totals), true: ordered scatter (rank = the
@@ -1144,15 +1197,8 @@ __global__ __launch_bounds__(256) void k_flush_mark(FlushArgs a, const FlushResu
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t total = a.n * 32u * a.W;
-    bool keep = false;
-    uint32_t pg = kNoSlot, row = kNoSlot;
-    if (i < total) {
-        pg = a.cand[i];
-        if (pg != kNoSlot) {
-            row = a.row[i / (32u * a.W)];
-            keep = a.tab[row].stamp[pg] == flush_key(a.epoch, i);
-        }
-    }
+    uint32_t pg, row;
+    const bool keep = flush_keeps(a, i, total, pg, row);
     const unsigned long long mask = __ballot(keep);
     if (lane == 0u) wcount[wave] = static_cast<uint32_t>(__popcll(mask));
     __syncthreads();
@@ -1163,34 +1209,7 @@ __global__ __launch_bounds__(256) void k_flush_mark(FlushArgs a, const FlushResu
         for (uint32_t w = 0; w < wave; ++w) before += wcount[w];
         const uint32_t n_b = (total + 255u) >> 8;
         const uint32_t rank = a.wave_tot[n_b + blockIdx.x] + before + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
-        if (rank < res->m) {
-            // Entry `rank` of the flush lands in ring slot base + rank.  Everything about it that is pointer chasing --
-            // its record descriptor, the slot's previous owner and that owner's residency words, the new owner, the
-            // page's slot words on both sides -- is done here, one THREAD per page, so that the fetch launch is the plain
-            // list form (descriptor + destination per block) at the bulk kernel's occupancy.  Done by the fetch kernel
-            // itself, one WAVE per page with a chain of ~8 dependent loads each, the 122 880-page flush of a 256-sequence
-            // decode step spent 210 us in the fetch; the chain now runs 64 pages per wave.
-            // (The words are final before the data has landed: the host waits for the flight's `done` event before it
-            // trusts a page whose slot lies in the flight's run, Engine::wait_landed.)
-            const uint32_t slot = res->base + rank;
-            const DevAlloc t = a.tab[row];
-            a.final_entry[rank] = t.entries[pg];
-            a.final_dst[rank] = reinterpret_cast<uint64_t>(a.ring_base + static_cast<uint64_t>(slot) * kPageSize);
-            const uint64_t prev = a.ring_owner[slot];
-            const uint64_t me = (static_cast<uint64_t>(row) << 32) | pg;
-            if (prev != kNoOwner && prev != me) {
-                const DevAlloc tp = a.tab[prev >> 32];
-                const uint32_t pp = static_cast<uint32_t>(prev);
-                // the row may have been recycled for a smaller allocation since the slot was filled
-                if (tp.entries && pp < tp.layout.alloc_pages && tp.d_slot[pp] == slot)    // still pointing here: the page leaves L2
-                    atomicAnd(&tp.d_flags[pp], ~2u);
-            }
-            a.ring_owner[slot] = me;
-            t.d_slot[pg] = slot;
-            if (a.final_host) a.final_host[rank] = &t.h_slot[pg];     // stored by the fetch launch (CodecArgs::host_words)
-            else t.h_slot[pg] = res->seq + rank;                      // the page's only host-visible word (Engine::l2_live)
-            atomicOr(&t.d_flags[pg], 2u);
-        }
+        if (rank < res->m) flush_place(a, *res, rank, row, pg);
     }
 }
 
@@ -1218,16 +1237,59 @@ __global__ __launch_bounds__(1024) void k_flush_assign(FlushArgs a)
         if (threadIdx.x == 1023u) running = run + wbase + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const uint32_t total = running;
-        const uint32_t m = total < a.max_take ? total : a.max_take;
-        // *a.hand is the ring's sequence number: slot = seq % n_l2; a run never wraps, the slots it skips at the end of
-        // a lap count (Engine::take_l2_run applies the same rule)
-        const RingRun run = ring_take(*a.hand, m, a.n_l2);
-        if (m) *a.hand = run.next;
-        const FlushResult r{m, run.slot, total, run.seq};
-        *a.result_dev = r;
-        *a.result_host = r;
+    if (threadIdx.x == 0) (void)flush_take(a, running);
+}
+
+// The whole pipeline in ONE workgroup for small flushes (the reference's own call pattern: speckv_prefetch per request and
+// layer, flushed every num_layers requests -- 32 requests x 32 lanes x 2 words for an 8B-shaped model):
+// four launches and their three hand-overs become phases between barriers; the kept flags stay in a register (one bit per
+// pass of 1024 words), the counts per (pass, wave) in LDS.  Same arithmetic, same order of entries.
+constexpr uint32_t kFlushSmallPasses = 16, kFlushSmallWords = kFlushSmallPasses * 1024u;
+// measured on the MI355X (time until the pages have landed, W = 2): 4 .. 64 requests 38-42 us against 42-43 us for the four
+// launches, 80 requests 54 against 45 (one workgroup then chases the pointers of ~500 pages alone); the host's submit time is
+// 11-14 us against 19-23.  SPECKV_FLUSH_SMALL_WORDS moves the limit, SPECKV_FLUSH_NO_SMALL=1 removes the path.
+constexpr uint64_t kFlushSmallDefault = 4096;
+__global__ __launch_bounds__(1024) void k_flush_small(FlushArgs a)
+{
+    __shared__ uint32_t wcnt[kFlushSmallPasses * 16u];      // kept candidates of (pass, wave) -> kept candidates before it
+    __shared__ uint32_t s_part[4];
+    __shared__ FlushResult s_res;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t total = a.n * 32u * a.W, passes = (total + 1023u) >> 10;
+    for (uint32_t gt = tid; gt < a.n * 32u; gt += 1024u) flush_candidates_of(a, gt);
+    __threadfence();                                        // the stamps' atomicMax and the candidate words are out
+    __syncthreads();
+    uint32_t keepbits = 0;
+    for (uint32_t j = 0; j < passes; ++j) {
+        uint32_t pg, row;
+        const bool keep = flush_keeps(a, j * 1024u + tid, total, pg, row);
+        const unsigned long long mask = __ballot(keep);
+        if (lane == 0u) wcnt[j * 16u + wave] = static_cast<uint32_t>(__popcll(mask));
+        keepbits |= (keep ? 1u : 0u) << j;
+    }
+    for (uint32_t e = passes * 16u + tid; e < kFlushSmallPasses * 16u; e += 1024u) wcnt[e] = 0u;
+    __syncthreads();
+    {   // exclusive scan of the 256 counts (entry order = candidate order) by the first four waves
+        uint32_t v = 0, incl = 0;
+        if (tid < 256u) { v = wcnt[tid]; incl = wave_incl_add(v); if (lane == 63u) s_part[wave] = incl; }
+        __syncthreads();
+        if (tid < 256u) {
+            uint32_t before = 0;
+            for (uint32_t w = 0; w < wave; ++w) before += s_part[w];
+            wcnt[tid] = before + incl - v;
+        }
+        if (tid == 0u) s_res = flush_take(a, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+        __syncthreads();
+    }
+    const FlushResult res = s_res;
+    for (uint32_t j = 0; j < passes; ++j) {
+        const bool keep = (keepbits >> j) & 1u;
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {
+            const uint32_t i = j * 1024u + tid;
+            const uint32_t rank = wcnt[j * 16u + wave] + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+            if (rank < res.m) flush_place(a, res, rank, a.row[i / (32u * a.W)], a.cand[i]);
+        }
     }
 }
 
@@ -2011,6 +2073,14 @@ hipError_t launch_flush_pipeline(const FlushArgs& a, hipStream_t s)
     if (a.n == 0 || a.W == 0) return hipErrorInvalidValue;
     const uint64_t total = static_cast<uint64_t>(a.n) * 32u * a.W;
     if (total >= (1ull << 24)) return hipErrorInvalidValue;        // the dedupe key carries 24 index bits
+    // (A/B and test switches, read at every flush: the four-launch pipeline for every size / another limit for the one-workgroup form)
+    const bool no_small = getenv("SPECKV_FLUSH_NO_SMALL") != nullptr;
+    const char* sw = getenv("SPECKV_FLUSH_SMALL_WORDS");
+    const uint64_t small_words = sw ? std::min<uint64_t>(strtoull(sw, nullptr, 10), kFlushSmallWords) : kFlushSmallDefault;
+    if (total <= small_words && !no_small) {
+        hipLaunchKernelGGL(k_flush_small, dim3(1), dim3(1024), 0, s, a);
+        return hipGetLastError();
+    }
     const uint32_t g_lane = static_cast<uint32_t>((static_cast<uint64_t>(a.n) * 32u + 255u) / 256u);
     const uint32_t g_word = static_cast<uint32_t>((total + 255u) / 256u);
     hipLaunchKernelGGL(k_flush_candidates, dim3(g_lane), dim3(256), 0, s, a);

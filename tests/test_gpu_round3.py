@@ -407,6 +407,58 @@ def test_real_lstm_cell_predictor_matches_torch_nn_lstm():
         lib.finalize()
 
 
+@pytest.mark.parametrize("n_req", [5, 64, 200])
+def test_one_workgroup_flush_equals_the_four_launch_pipeline(oracle, n_req):
+    """Small flushes run the device-side pipeline (candidates, first-occurrence dedupe, ring run, ordered placement) as phases
+    of one workgroup (k_flush_small) instead of four launches.  Same requests through both forms (SPECKV_FLUSH_NO_SMALL /
+    SPECKV_FLUSH_SMALL_WORDS, read at every flush), each in a fresh engine: the same pages become resident, in the SAME ring
+    slots (entry order is part of the contract: the host derives residency from the slot's sequence number), with the same
+    bytes; and the set of pages is the oracle's.  Requests repeat pages (dedupe) and some name pages already resident."""
+    T, L, H, D, bpe = 512, 4, 8, 128, 2
+    n_pages = T * L * H * D * bpe * 2 // PAGE
+    rng = np.random.default_rng(n_req)
+    layers = rng.integers(0, L, n_req).astype(np.uint16)
+    pos = rng.integers(0, T - 8, n_req).astype(np.uint32)
+    pos[n_req // 2:] = pos[: n_req - n_req // 2]                      # repeated positions: the same pages named again
+    reqs = np.zeros(n_req, np.uint32)
+    depth = np.full(n_req, 4, np.uint32)
+    x = (rng.standard_normal((n_pages, N)) * 0.5).astype(np.float16)
+    seen = {}
+    for form, env in (("one workgroup", {"SPECKV_FLUSH_SMALL_WORDS": 16384}), ("four launches", {"SPECKV_FLUSH_NO_SMALL": 1})):
+        for k_, v_ in env.items():
+            os.environ[k_] = str(v_)
+        try:
+            lib = SpeckvLib(pkg.library_path(), "hip:0")
+            try:
+                lib.set_compression_scheme(2)
+                h = lib.alloc(n_pages * PAGE)
+                lib.set_layout(h, T, L, H, D, bpe)
+                lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+                for p in (3, 40, 41):
+                    lib.access(h, p * PAGE, 1)                        # resident before the flush: filtered out
+                lib.prefetch_batch(reqs, layers, pos, depth)
+                lib.prefetch_flush()
+                lib.sync()
+                info = [lib.translate(h, p * PAGE) for p in range(n_pages)]
+                res = {p: (i.cache_addr, i.flags & 3) for p, i in enumerate(info) if i.flags & 3}
+                data = {p: dev_to_host(res[p][0], PAGE).tobytes() for p in sorted(res)[:40]}
+                seen[form] = (res, data, int(lib.stats().total_prefetches))
+            finally:
+                lib.finalize()
+        finally:
+            for k_ in env:
+                os.environ.pop(k_, None)
+    a, b = seen["one workgroup"], seen["four launches"]
+    base = lambda res: min(addr for addr, _ in res.values())
+    rel = lambda res: {p: (addr - base(res), f) for p, (addr, f) in res.items()}
+    assert rel(a[0]) == rel(b[0])                                    # same pages, same slots (relative to the cache base), same tier bits
+    assert a[1] == b[1] and a[2] == b[2]
+    expect = {3, 40, 41}
+    for i in range(n_req):
+        expect |= set(oracle.prefetch_pages(0, int(layers[i]), int(pos[i]), 4, L, T, H, D, bpe, n_pages).tolist())
+    assert set(a[0]) == expect
+
+
 class _RawDevice:
     """A device buffer by address, for torch.as_tensor (CUDA array interface)."""
     def __init__(self, ptr, nbytes):
