@@ -1248,6 +1248,8 @@ constexpr uint32_t kFlushSmallPasses = 16, kFlushSmallWords = kFlushSmallPasses 
 // measured on the MI355X (time until the pages have landed, W = 2): 4 .. 64 requests 38-42 us against 42-43 us for the four
 // launches, 80 requests 54 against 45 (one workgroup then chases the pointers of ~500 pages alone); the host's submit time is
 // 11-14 us against 19-23.  SPECKV_FLUSH_SMALL_WORDS moves the limit, SPECKV_FLUSH_NO_SMALL=1 removes the path.
+// (Letting this kernel pull the request columns from the host's pinned slot itself, instead of the upload launch in front of
+// it, saved the host another 2.5 us per flush and cost 4-5 us until landed, same box: 41.5-47 against 37.2-41.9.  Not kept.)
 constexpr uint64_t kFlushSmallDefault = 4096;
 __global__ __launch_bounds__(1024) void k_flush_small(FlushArgs a)
 {
