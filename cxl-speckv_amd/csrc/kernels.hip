@@ -1634,6 +1634,8 @@ __global__ __launch_bounds__(512) void k_lstm_cell(const int32_t* __restrict__ h
 // The order of the 128 additions of one logit: k = 8j + 4*(lane/32) + e for j = 0..15, e = 0..3, the lower half-wave's k first
 // inside each instruction (fused, unlike the oracle's mul + add: covered by the confidence tolerance of the parity tests).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// tiles of 32 output rows, rounded up to the four waves of a workgroup of k_lstm_logits (every wave loads its tile unconditionally)
+__host__ __device__ constexpr uint32_t logits_tiles_padded(uint32_t vocab) { return ((vocab + 31u) / 32u + 3u) & ~3u; }
 // The output layer's weights in the order k_lstm_logits reads them: per 32 rows, float4 [j][lane] = row (lane % 32),
 // columns 8j + 4 (lane / 32) .. + 3 -- a wave's load instruction is then one contiguous KiB (row-major, its 64 lanes touched
 // 64 different lines 16 bytes at a time).  Once per predictor_load.
@@ -1641,7 +1643,7 @@ __global__ __launch_bounds__(256) void k_arrange_wout(const float* __restrict__ 
 {
     const uint32_t lane = threadIdx.x & 63u, tile = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t row = tile * 32u + (lane & 31u), kh = lane >> 5;
-    if (tile * 32u >= vocab) return;
+    if (tile >= logits_tiles_padded(vocab)) return;         // (tiles past the vocabulary, up to a whole workgroup of k_lstm_logits: zeros)
 #pragma unroll
     for (uint32_t j = 0; j < 16u; ++j) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2140,11 +2142,11 @@ hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t ba
     return hipGetLastError();
 }
 
-size_t arranged_wout_bytes(uint32_t vocab) { return static_cast<size_t>((vocab + 31u) / 32u) * 32u * kPredHidden * sizeof(float); }
+size_t arranged_wout_bytes(uint32_t vocab) { return static_cast<size_t>(logits_tiles_padded(vocab)) * 32u * kPredHidden * sizeof(float); }
 hipError_t launch_arrange_wout(const float* d_src, float* d_dst, uint32_t vocab, hipStream_t s)
 {
-    const uint32_t tiles = (vocab + 31u) / 32u;
-    hipLaunchKernelGGL(k_arrange_wout, dim3((tiles + 3u) / 4u), dim3(256), 0, s, d_src, reinterpret_cast<float4*>(d_dst), vocab);
+    const uint32_t tiles = logits_tiles_padded(vocab);
+    hipLaunchKernelGGL(k_arrange_wout, dim3(tiles / 4u), dim3(256), 0, s, d_src, reinterpret_cast<float4*>(d_dst), vocab);
     return hipGetLastError();
 }
 
