@@ -1543,7 +1543,7 @@ int Engine::predict_batch(uint32_t n, const int32_t* d_hist, uint32_t k, int32_t
     DeviceScope device_scope(device_);
     float* hid = static_cast<float*>(scratch(s_hid_, static_cast<size_t>(n) * 128 * sizeof(float), s));
     float* logits = static_cast<float*>(scratch(s_logits_, static_cast<size_t>(n) * vocab_ * sizeof(float), s));
-    void* ws = scratch(s_predict_ws_, predict_ws_bytes(n), s);
+    void* ws = scratch(s_predict_ws_, predict_ws_bytes(n, vocab_), s);
     if (!hid || !logits || !ws) return SPECKV_ERR_NOMEM;
     hipStream_t st = s ? s : stream_;
     HIP_TRY(launch_predict(n, d_hist, d_emb_, d_wout_, vocab_, 2, k, hid, logits, ws, d_tok, d_conf, st, &lstm_));

@@ -1775,23 +1775,24 @@ __global__ __launch_bounds__(1024) void k_softmax_topk(const float* __restrict__
     }
 }
 
-// The same for vocabularies of up to 32 768 tokens, written for latency (one request per workgroup is a chain of dependent
-// steps: the kernel above took 48-57 us per launch whatever the batch, a 1024-thread workgroup with 32 logits per thread in
-// registers 21-26 us).  A request is cut into kTkParts workgroups of 256 threads, 16 logits per thread:
+// The same for vocabularies of up to 262 144 tokens (kTkMaxParts parts), written for latency (one request per workgroup is a
+// chain of dependent steps: the kernel above took 48-57 us per launch whatever the batch, a 1024-thread workgroup with 32
+// logits per thread in registers 21-26 us).  A request is cut into parts of 4096 logits, one workgroup of 256 threads each, 16
+// logits per thread:
 //   * a wave finds ITS maximum, exp-sum (relative to its own maximum) and top k with shuffles only -- a candidate is one
 //     64-bit key, the logit's bits made order-preserving above ~token id, so "value descending, token id ascending" (the
 //     order of the sorted insertion above) is an unsigned maximum and a round is six exchange steps;
 //   * one barrier, then wave 0 merges the four waves (maxima, rescaled sums, 4 k keys) and writes the part's result;
-//   * a second kernel, one wave per request, merges the parts the same way and writes tokens and confidences
-//     exp(logit - max) / sum.  (One kernel whose last-arriving workgroup merges was tried: 10 us for one request, but the
+//   * a second kernel, one wave per request, merges the parts -- a lane holds one part's maximum, sum and k keys (already in
+//     order: a round offers the lane's best key not yet taken) -- and writes tokens and confidences exp(logit - max) / sum.  (One kernel whose last-arriving workgroup merges was tried: 10 us for one request, but the
 //     agent-scope release/acquire it needs writes back and invalidates the XCD's L2 once per workgroup -- 48 us for 256
 //     requests against 26 us before.)
 // A logit that is -inf or NaN is never chosen (as above: "v > best" is false for it); a rank without a candidate reports
 // token -1 and confidence 0.
-constexpr uint32_t kTkParts = 8, kTkThreads = 256, kTkPer = 16, kTkSpan = kTkThreads * kTkPer;
-constexpr uint32_t kTkWsStride = kPredictWsStride;      // bytes of workspace per request: 8 x (max, sum) | 8 x 8 keys
-static_assert(kTkParts * kTkSpan == 32u * kSmThreads, "covers the vocabularies launch_predict sends here");
-static_assert(kTkParts * 8u + kTkParts * 8u * 8u <= kTkWsStride, "workspace layout");
+constexpr uint32_t kTkMaxParts = 64, kTkThreads = 256, kTkPer = 16, kTkSpan = kTkThreads * kTkPer;
+static_assert(kTkSpan == kPredictTopkSpan && kTkMaxParts == kPredictTopkMaxParts, "predict_ws_bytes");
+// workspace of one request: parts x (max, sum) | parts x 8 keys
+__device__ __forceinline__ uint32_t tk_ws_stride(uint32_t parts) { return parts * kPredictWsPerPart; }
 __device__ __forceinline__ uint64_t tk_key(float v, uint32_t i)
 {
     if (!(v > -INFINITY)) return 0;
@@ -1887,34 +1888,44 @@ __global__ __launch_bounds__(256) void k_softmax_topk_small(const float* __restr
     if (lane == 0u) { wm[wv] = m; wsum[wv] = sum; }
     __syncthreads();
     if (wv != 0u) return;
-    uint8_t* mine = ws + static_cast<uint64_t>(b) * kTkWsStride;
+    const uint32_t parts = gridDim.y;
+    uint8_t* mine = ws + static_cast<uint64_t>(b) * tk_ws_stride(parts);
     float* part_ms = reinterpret_cast<float*>(mine);                     // [part] (max, sum)
-    uint64_t* part_key = reinterpret_cast<uint64_t*>(mine + kTkParts * 8u);          // [part][8]
+    uint64_t* part_key = reinterpret_cast<uint64_t*>(mine + parts * 8u);             // [part][8]
     float pm, ps;
     tk_merge(lane < 4u ? wm[lane] : -INFINITY, lane < 4u ? wsum[lane] : 0.0f, lane < 4u * k ? wkey[lane / k][lane % k] : 0, k, pm, ps,
              [&](uint32_t r, uint64_t w) { if (lane == 0u) part_key[part * 8u + r] = w; });
     if (lane == 0u) { part_ms[2u * part] = pm; part_ms[2u * part + 1u] = ps; }
 }
-__global__ __launch_bounds__(256) void k_softmax_topk_merge(const uint8_t* __restrict__ ws, uint32_t n, uint32_t k,
+__global__ __launch_bounds__(256) void k_softmax_topk_merge(const uint8_t* __restrict__ ws, uint32_t n, uint32_t k, uint32_t parts,
         int32_t* __restrict__ out_tok, float* __restrict__ out_conf)
 {
     const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (b >= n) return;
-    const uint8_t* mine = ws + static_cast<uint64_t>(b) * kTkWsStride;
+    const uint8_t* mine = ws + static_cast<uint64_t>(b) * tk_ws_stride(parts);
     const float* part_ms = reinterpret_cast<const float*>(mine);
-    const uint64_t* part_key = reinterpret_cast<const uint64_t*>(mine + kTkParts * 8u);
-    const float qm = lane < kTkParts ? part_ms[2u * lane] : -INFINITY, qs = lane < kTkParts ? part_ms[2u * lane + 1u] : 0.0f;
-    const uint64_t qk = lane < kTkParts * k ? part_key[(lane / k) * 8u + lane % k] : 0;
-    float mx, total;
-    const float* mxp = &mx; const float* totp = &total;
+    const uint64_t* part_key = reinterpret_cast<const uint64_t*>(mine + parts * 8u);
+    const bool have = lane < parts;                                      // lane = part
+    const float qm = have ? part_ms[2u * lane] : -INFINITY, qs = have ? part_ms[2u * lane + 1u] : 0.0f;
+    uint64_t key[8];
+#pragma unroll
+    for (uint32_t r = 0; r < 8u; ++r) key[r] = (have && r < k) ? part_key[lane * 8u + r] : 0;       // descending: key[0] is the part's best not yet taken
+    const float mx = wave_max_f32(qm);
+    const float total = wave_sum_f32(qm > -INFINITY ? qs * expf(qm - mx) : 0.0f);
     float* conf = out_conf + static_cast<uint64_t>(b) * k;
     int32_t* tok = out_tok + static_cast<uint64_t>(b) * k;
-    tk_merge(qm, qs, qk, k, mx, total, [&](uint32_t r, uint64_t w) {
+    for (uint32_t r = 0; r < k; ++r) {
+        const uint64_t w = wave_max_u64(key[0]);
+        if (w != 0 && w == key[0]) {                                     // keys are distinct (token ids are): one owner, whose next key moves up
+#pragma unroll
+            for (uint32_t j = 0; j < 7u; ++j) key[j] = key[j + 1u];
+            key[7] = 0;
+        }
         if (lane == 0u) {
             tok[r] = w ? static_cast<int32_t>(0xFFFFFFFFu - static_cast<uint32_t>(w)) : -1;
-            conf[r] = w ? expf(tk_value(w) - *mxp) / *totp : 0.0f;
+            conf[r] = w ? expf(tk_value(w) - mx) / total : 0.0f;
         }
-    });
+    }
 }
 
 // Records move to new places (compaction into packed extents and back): one wave per page copies the record's bytes, rounded up
@@ -2167,9 +2178,10 @@ hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb,
     }
     const uint32_t waves = (vocab + 31u) / 32u;              // 32 output rows per wave (k_lstm_logits)
     hipLaunchKernelGGL(k_lstm_logits, dim3((waves + 3u) / 4u, (n + kLogitsChunk - 1u) / kLogitsChunk), dim3(256), 0, s, d_hid, n, d_wout, lstm ? lstm->out_bias : nullptr, vocab, d_logits);
-    if (vocab <= 32u * kSmThreads) {
-        hipLaunchKernelGGL(k_softmax_topk_small, dim3(n, kTkParts), dim3(kTkThreads), 0, s, d_logits, vocab, k, static_cast<uint8_t*>(d_ws));
-        hipLaunchKernelGGL(k_softmax_topk_merge, dim3((n + 3u) / 4u), dim3(256), 0, s, static_cast<const uint8_t*>(d_ws), n, k, d_tok, d_conf);
+    const uint32_t parts = predict_topk_parts(vocab);
+    if (parts) {
+        hipLaunchKernelGGL(k_softmax_topk_small, dim3(n, parts), dim3(kTkThreads), 0, s, d_logits, vocab, k, static_cast<uint8_t*>(d_ws));
+        hipLaunchKernelGGL(k_softmax_topk_merge, dim3((n + 3u) / 4u), dim3(256), 0, s, static_cast<const uint8_t*>(d_ws), n, k, parts, d_tok, d_conf);
     }
     else                           hipLaunchKernelGGL(k_softmax_topk, dim3(n), dim3(1024), 0, s, d_logits, vocab, k, d_tok, d_conf);
     return hipGetLastError();

@@ -346,8 +346,14 @@ hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb,
 // d_wout: the output layer's weights ARRANGED by launch_arrange_wout (arranged_wout_bytes(vocab) bytes) from the row-major [vocab][128]
 size_t arranged_wout_bytes(uint32_t vocab);
 hipError_t launch_arrange_wout(const float* d_src, float* d_dst, uint32_t vocab, hipStream_t s);
-// d_ws: predict_ws_bytes(n) bytes of scratch (the parts of the split top-k)
-constexpr uint32_t kPredictWsStride = 640;
-inline size_t predict_ws_bytes(uint32_t n) { return static_cast<size_t>(n) * kPredictWsStride; }
+// d_ws: predict_ws_bytes(n, vocab) bytes of scratch (the parts of the split top-k: 4096 logits each, at most 64 -- larger
+// vocabularies take the one-workgroup kernel and need none)
+constexpr uint32_t kPredictTopkSpan = 4096, kPredictTopkMaxParts = 64, kPredictWsPerPart = 8 + 8 * 8;
+inline uint32_t predict_topk_parts(uint32_t vocab)
+{
+    const uint32_t parts = (vocab + kPredictTopkSpan - 1u) / kPredictTopkSpan;
+    return parts <= kPredictTopkMaxParts ? parts : 0u;
+}
+inline size_t predict_ws_bytes(uint32_t n, uint32_t vocab) { return static_cast<size_t>(n) * predict_topk_parts(vocab) * kPredictWsPerPart + 64; }
 
 } // namespace speckv

@@ -501,10 +501,12 @@ def test_access_miss_completion_word_orders_the_page_for_other_streams(spin):
         lib.finalize()
 
 
-@pytest.mark.parametrize("vocab,n,k", [(8, 1, 8), (33, 31, 8), (1007, 33, 5), (4097, 70, 8), (32768, 3, 1), (32769, 2, 8)])
+@pytest.mark.parametrize("vocab,n,k", [(8, 1, 8), (33, 31, 8), (1007, 33, 5), (4097, 70, 8), (32768, 3, 1), (32769, 2, 8), (128256, 5, 8),
+                                       (262144, 2, 4), (262145, 2, 8)])
 def test_predictor_shapes_off_the_tile_sizes(oracle, vocab, n, k):
     """The predictor's kernels cut their work into fixed tiles -- 32 output rows and 32 requests per matrix tile, 4096 logits per
-    top-k workgroup, eight of those per request (beyond 32 768 tokens the one-workgroup kernel takes over) -- so: vocabularies
+    top-k workgroup, up to 64 of those per request (128 256 tokens, Llama-3's vocabulary: 32; beyond 262 144 the one-workgroup kernel
+    takes over) -- so: vocabularies
     and batch sizes that are not multiples of any of them, k = 8 = the whole vocabulary, against the oracle's
     restatement of the reference's predictor (tokens identical, confidences within 5e-4 relative, as in
     test_token_predictor_matches_oracle_and_reference)."""
