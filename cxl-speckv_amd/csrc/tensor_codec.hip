@@ -56,7 +56,7 @@ __device__ __forceinline__ float tc_load(const void* src, uint64_t p)
 // (cache_engine.cpp:176-180: `if (abs > max_val)`).  16 bytes per lane and step where the source allows it (the elements in
 // front of the first 16-byte boundary and behind the last one are taken one by one).
 template <bool F32>
-__global__ __launch_bounds__(256) void k_tc_absmax(const void* __restrict__ src, uint64_t n, uint32_t* __restrict__ out_bits)
+__global__ __launch_bounds__(1024) void k_tc_absmax(const void* __restrict__ src, uint64_t n, uint32_t* __restrict__ out_bits)
 {
     constexpr uint32_t kPer = F32 ? 4u : 8u, kEsz = F32 ? 4u : 2u;
     const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x, nthr = static_cast<uint64_t>(gridDim.x) * blockDim.x;
@@ -85,13 +85,16 @@ __global__ __launch_bounds__(256) void k_tc_absmax(const void* __restrict__ src,
         }
     }
     for (uint64_t p = head + nvec * kPer + tid; p < n; p += nthr) one(p);
-    // one atomic per workgroup: 16 384 same-address atomics (one per wave of a 4096-block grid) took 190 us by themselves
-    __shared__ uint32_t s_m[4];
+    // one atomic per workgroup of 1024 threads, one workgroup per CU: same-address atomics take ~12 ns each one after the other
+    // (16 384 of them, one per wave of a 4096-block grid, 190 us by themselves; 1024, one per 256-thread workgroup, still 12 of
+    // the kernel's 22 us)
+    __shared__ uint32_t s_m[16];
     m = lane63(wave_incl_max(m));
     if ((threadIdx.x & 63u) == 0u) s_m[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0u) {
-        m = umax(umax(s_m[0], s_m[1]), umax(s_m[2], s_m[3]));
+        m = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) m = umax(m, s_m[w]);
         if (!F32) m = __float_as_uint(half_bits_to_float(m));
         if (m) atomicMax(out_bits, m);
     }
@@ -770,9 +773,9 @@ hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, u
     hipError_t e = hipMemsetAsync(absmax, 0, 256, s);
     if (e != hipSuccess) return e;
     if (n) {
-        const uint32_t g = static_cast<uint32_t>(std::min<uint64_t>((n + 2047) / 2048, 1024));     // 16 bytes per lane and step, 4 workgroups per CU
-        if (src_f32) hipLaunchKernelGGL(k_tc_absmax<true>, dim3(g), dim3(256), 0, s, d_src, n, absmax);
-        else         hipLaunchKernelGGL(k_tc_absmax<false>, dim3(g), dim3(256), 0, s, d_src, n, absmax);
+        const uint32_t g = static_cast<uint32_t>(std::min<uint64_t>((n + 8191) / 8192, 256));     // 16 bytes per lane and step, one workgroup of 16 waves per CU
+        if (src_f32) hipLaunchKernelGGL(k_tc_absmax<true>, dim3(g), dim3(1024), 0, s, d_src, n, absmax);
+        else         hipLaunchKernelGGL(k_tc_absmax<false>, dim3(g), dim3(1024), 0, s, d_src, n, absmax);
     }
     const uint32_t tg = static_cast<uint32_t>((tiles + kTcWaves - 1) / kTcWaves);
 #define SPECKV_TC(MODE, F32, EMIT) hipLaunchKernelGGL((k_tc_tiles<MODE, F32, EMIT>), dim3(tg), dim3(64 * kTcWaves), 0, s, d_src, n, absmax, summ, carry, scratch)
