@@ -459,6 +459,65 @@ def test_one_workgroup_flush_equals_the_four_launch_pipeline(oracle, n_req):
     assert set(a[0]) == expect
 
 
+def test_flush_time_predictions_under_concurrent_prefetch_and_verify(oracle):
+    """A flush's predictions run on a stream of their own and are collected by the next speckv_ext_verify; collecting waits on
+    an event with the ABI lock released, so another thread's flush may start the NEXT prediction meanwhile (generation
+    counter in Engine::harvest_predictions).  Two threads for a second: one keeps sending speckv_prefetch calls with
+    histories (a flush every 4 calls), one keeps verifying; then, quiet again, every request's prediction is the oracle's
+    for its LAST history."""
+    lib = open_lib()
+    try:
+        emb, wout = oracle.lstm_reference_weights(1)
+        lib.predictor_load(emb.ctypes.data, wout.ctypes.data, 32000, False)
+        lib.set_compression_scheme(2)
+        T, L, H, D, bpe = 256, 4, 8, 128, 2
+        h = lib.alloc(8 * T * L * H * D * bpe * 2)
+        lib.set_layout(h, T, L, H, D, bpe)
+        rng = np.random.default_rng(9)
+        last, errors, stop = {}, [], threading.Event()
+
+        def sender():
+            try:
+                step = 0
+                while not stop.is_set():
+                    r = step % 8
+                    hist = [int(v) for v in rng.integers(0, 32000, 16)]
+                    lib.prefetch(r, step % L, 8 + (step // 8) % 200, 4, hist)
+                    last[r] = hist
+                    step += 1
+            except Exception as e:                                    # noqa: BLE001
+                errors.append(repr(e))
+
+        def checker():
+            try:
+                while not stop.is_set():
+                    for r in range(8):
+                        try:
+                            lib.verify(r, 1)
+                        except SpeckvError as e:                      # no prediction for this request yet
+                            assert e.status == -4
+            except Exception as e:                                    # noqa: BLE001
+                errors.append(repr(e))
+
+        ts = [threading.Thread(target=sender), threading.Thread(target=checker)]
+        for t in ts:
+            t.start()
+        time.sleep(1.0)
+        stop.set()
+        for t in ts:
+            t.join(timeout=30)
+        assert not any(t.is_alive() for t in ts) and not errors, errors
+        lib.prefetch_flush()
+        for r, hist in last.items():
+            o_tok, _ = oracle.lstm_predict(emb, wout, np.array(hist, np.uint32), 4)
+            hit, _ = lib.verify(r, int(o_tok[0]))
+            assert hit, r
+        st = lib.stats()
+        assert st.successful_prefetches >= len(last)
+    finally:
+        lib.finalize()
+
+
 class _RawDevice:
     """A device buffer by address, for torch.as_tensor (CUDA array interface)."""
     def __init__(self, ptr, nbytes):
