@@ -669,53 +669,54 @@ __global__ __launch_bounds__(256) void k_td_expand(const uint8_t* __restrict__ r
         lo = nlo;
         hi = nhi < hi ? nhi : hi;
     }
-    uint64_t tot = carry[lo].start;                                 // elements in front of pair `i0`
+    // positions relative to the tile from here on (32-bit): the chunk starts at or before o0, by less than 2048 x 255 elements
+    const int32_t valid_i = static_cast<int32_t>(o1 - o0);
+    int32_t tot = -static_cast<int32_t>(o0 - carry[lo].start);       // elements in front of pair `i0`, relative to o0
     uint32_t qp = carry[lo].q_pre;
-    // four pairs per lane and step (one 8-byte load where the stream is aligned): a lane sums its own four, one add-scan over
+    // eight pairs per lane and step (one 16-byte load where the stream is aligned): a lane sums its own eight, one add-scan over
     // the lane totals places them
-    const bool wide = (reinterpret_cast<uintptr_t>(rle) & 7u) == 0u;
+    const bool wide = (reinterpret_cast<uintptr_t>(rle) & 15u) == 0u;
 #pragma unroll 1
-    for (uint64_t i0 = lo * kTile; i0 < n_pairs && tot < o1; i0 += 256u) {
-        const uint64_t i = i0 + 4u * lane;
-        uint32_t w0 = 0, w1 = 0;                                       // pairs i, i+1 | i+2, i+3
-        if (wide && i + 4u <= n_pairs) {
-            const uint2 x = *reinterpret_cast<const uint2*>(rle + 2ull * i);
-            w0 = x.x; w1 = x.y;
+    for (uint64_t i0 = lo * kTile; i0 < n_pairs && tot < valid_i; i0 += 512u) {
+        const uint64_t i = i0 + 8u * lane;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};                              // pairs i, i+1 | i+2, i+3 | ...
+        if (wide && i + 8u <= n_pairs) {
+            const u32x4 x = *reinterpret_cast<const u32x4*>(rle + 2ull * i);
+            w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w;
         } else {
 #pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k)
-                if (i + k < n_pairs) {
-                    const uint32_t b = *reinterpret_cast<const uint16_t*>(rle + 2ull * (i + k));
-                    if (k < 2u) w0 |= b << (16u * k); else w1 |= b << (16u * (k - 2u));
-                }
+            for (uint32_t k = 0; k < 8u; ++k)
+                if (i + k < n_pairs) w[k >> 1] |= static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(rle + 2ull * (i + k))) << (16u * (k & 1u));
         }
-        uint32_t pk[4];
+        uint32_t sc = 0, sv = 0;                                       // the lane's counts and value x count sums (dword = v0 | c0 << 8 | v1 << 16 | c1 << 24)
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            const uint32_t b = ((k < 2u ? w0 : w1) >> (16u * (k & 1u))) & 0xFFFFu;
-            const uint32_t v = b & 0xFFu, c = b >> 8;
-            pk[k] = ((v * c) << 24) | c;
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t counts = (w[t] >> 8) & 0x00FF00FFu;
+            sc = __builtin_amdgcn_udot4(counts, 0x00010001u, sc, false);
+            sv = __builtin_amdgcn_udot4(w[t], counts, sv, false);
         }
-        const uint32_t lane_total = pk[0] + pk[1] + pk[2] + pk[3];     // counts: < 2^24 per step, the value sums wrap mod 256
+        const uint32_t lane_total = (sv << 24) | sc;                   // counts: < 2^24 per step, the value sums wrap mod 256
         const uint32_t incl = wave_incl_add(lane_total);
-        uint32_t e = incl - lane_total;
+        const uint32_t e = incl - lane_total;
+        int32_t start = tot + static_cast<int32_t>(e & 0xFFFFFFu);
+        uint32_t q = qp + (e >> 24);
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            const uint32_t b = ((k < 2u ? w0 : w1) >> (16u * (k & 1u))) & 0xFFFFu;
-            const uint32_t v = b & 0xFFu, c = b >> 8;
-            const uint64_t start = tot + (e & 0xFFFFFFu);
-            uint32_t q = qp + (e >> 24);
-            // the part of [start, start + c) inside [o0, o1)
-            const uint64_t a = start > o0 ? start : o0, bnd = (start + c < o1) ? start + c : o1;
-            if (a < bnd) {
-                q += static_cast<uint32_t>(a - start) * v;
+        for (uint32_t k = 0; k < 8u; ++k) {
+            const uint32_t bits = (w[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
+            const uint32_t v = bits & 0xFFu;
+            const int32_t c = static_cast<int32_t>(bits >> 8);
+            // the part of [start, start + c) inside [0, valid)
+            const int32_t a0 = start > 0 ? start : 0, bnd = (start + c < valid_i) ? start + c : valid_i;
+            if (a0 < bnd) {
+                uint32_t qq = q + static_cast<uint32_t>(a0 - start) * v;
 #pragma unroll 1
-                for (uint64_t p = a; p < bnd; ++p) { q += v; tab[p - o0] = static_cast<uint8_t>(q); }
+                for (int32_t p = a0; p < bnd; ++p) { qq += v; tab[p] = static_cast<uint8_t>(qq); }
             }
-            e += pk[k];
+            start += c;
+            q += v * static_cast<uint32_t>(c);
         }
         const uint32_t step_tot = lane63(incl);
-        tot += step_tot & 0xFFFFFFu;
+        tot += static_cast<int32_t>(step_tot & 0xFFFFFFu);
         qp = (qp + (step_tot >> 24)) & 0xFFu;
     }
     wave_lds_fence();
