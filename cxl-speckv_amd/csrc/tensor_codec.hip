@@ -512,6 +512,14 @@ __global__ __launch_bounds__(256) void k_tc_pack(const TcCarry* __restrict__ car
         }
         uint64_t t = lo;
         uint64_t tb = carry[t].run_base, te = carry[t + 1].run_base;
+        if (r0 + 8u <= te && r0 + 8u <= total) {
+            // all eight pairs in one tile's slot (all but the piece that straddles a tile boundary, in data that does not
+            // compress): one 16-byte load at a 2-byte-aligned address -- the eight 2-byte loads below were most of this pass
+            struct __attribute__((packed, aligned(2))) Unaligned16 { u32x4 v; };
+            const u32x4 x = reinterpret_cast<const Unaligned16*>(pair_scratch + t * (2ull * kTile) + 2ull * (r0 - tb))->v;
+            *reinterpret_cast<uint4*>(rle + 2ull * r0) = make_uint4(x.x, x.y, x.z, x.w);
+            continue;
+        }
         uint32_t w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
