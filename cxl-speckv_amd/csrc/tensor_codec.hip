@@ -376,11 +376,22 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_tc_scan_wg(const TcSummary*
     const uint32_t n_steps = static_cast<uint32_t>((n_tiles + 63u) / 64u);
     constexpr uint64_t kOpen = ~0ull;
     // phase 1: the last stretch start of every step
-    for (uint32_t st = wave; st < n_steps; st += kScanWaves) {
-        const uint64_t t = static_cast<uint64_t>(st) * 64u + lane;
-        const uint32_t last_ss = t < n_tiles ? summ[t].last_ss : 0u;
-        const uint32_t tot = lane63(wave_incl_max(last_ss ? lane * kTile + last_ss : 0u));
-        if (lane == 0u) s_ss[st] = tot ? static_cast<uint64_t>(st) * 64u * kTile + tot : 0ull;
+    // (in every phase a wave takes its steps eight at a time and issues their loads together: step after step the kernel was a
+    // chain of load latencies)
+    for (uint32_t st0 = wave; st0 < n_steps; st0 += 8u * kScanWaves) {
+        uint32_t lb[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) {
+            const uint64_t t = static_cast<uint64_t>(st0 + u * kScanWaves) * 64u + lane;
+            lb[u] = (st0 + u * kScanWaves < n_steps && t < n_tiles) ? summ[t].last_ss : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) {
+            const uint32_t st = st0 + u * kScanWaves;
+            if (st >= n_steps) break;
+            const uint32_t tot = lane63(wave_incl_max(lb[u] ? lane * kTile + lb[u] : 0u));
+            if (lane == 0u) s_ss[st] = tot ? static_cast<uint64_t>(st) * 64u * kTile + tot : 0ull;
+        }
     }
     __syncthreads();
     if (wave == 0u) {                               // phase 2: "last non-zero before" over the steps
@@ -397,11 +408,21 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_tc_scan_wg(const TcSummary*
     }
     __syncthreads();
     // phase 3: per tile what depends on the entering stretch start; local scans of the run counts and of the first run starts
-    for (uint32_t st = wave; st < n_steps; st += kScanWaves) {
+    for (uint32_t st0 = wave; st0 < n_steps; st0 += 8u * kScanWaves) {
+      TcSummary sbuf[8];
+#pragma unroll
+      for (uint32_t u = 0; u < 8u; ++u) {
+          const uint64_t t = static_cast<uint64_t>(st0 + u * kScanWaves) * 64u + lane;
+          sbuf[u] = TcSummary{0u, 0u, 0u, 0u};
+          if (st0 + u * kScanWaves < n_steps && t < n_tiles) sbuf[u] = summ[t];
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 8u; ++u) {
+        const uint32_t st = st0 + u * kScanWaves;
+        if (st >= n_steps) break;
         const uint64_t base = static_cast<uint64_t>(st) * 64u, t = base + lane;
         const bool live = t < n_tiles;
-        TcSummary s{0u, 0u, 0u, 0u};
-        if (live) s = summ[t];
+        const TcSummary s = sbuf[u];
         const uint64_t t0 = t * kTile;
         const uint32_t len = live ? static_cast<uint32_t>((n - t0 < kTile) ? (n - t0) : kTile) : 0u;
         const uint32_t inc = wave_incl_max(s.last_ss ? lane * kTile + s.last_ss : 0u);
@@ -430,6 +451,7 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_tc_scan_wg(const TcSummary*
         }
         const uint64_t first = shfl64(fr, have ? static_cast<uint32_t>(__builtin_ctzll(have)) : 0u);
         if (lane == 0u) { s_runs[st] = lane63(rinc); s_first[st] = have ? first : 0ull; }
+      }
     }
     __syncthreads();
     if (wave == 0u) {                               // phase 4: run counts before every step, first run start behind every step
@@ -461,11 +483,22 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_tc_scan_wg(const TcSummary*
     }
     __syncthreads();
     // phase 5: every lane finishes the entry it wrote in phase 3
-    for (uint32_t st = wave; st < n_steps; st += kScanWaves) {
-        const uint64_t t = static_cast<uint64_t>(st) * 64u + lane;
-        if (t < n_tiles) {
-            carry[t].run_base += s_runs[st];
-            if (carry[t].next_run == kOpen) carry[t].next_run = s_first[st];
+    for (uint32_t st0 = wave; st0 < n_steps; st0 += 8u * kScanWaves) {
+        uint64_t rb[8], nr[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) {
+            const uint64_t t = static_cast<uint64_t>(st0 + u * kScanWaves) * 64u + lane;
+            rb[u] = 0; nr[u] = 0;
+            if (st0 + u * kScanWaves < n_steps && t < n_tiles) { rb[u] = carry[t].run_base; nr[u] = carry[t].next_run; }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) {
+            const uint32_t st = st0 + u * kScanWaves;
+            const uint64_t t = static_cast<uint64_t>(st) * 64u + lane;
+            if (st < n_steps && t < n_tiles) {
+                carry[t].run_base = rb[u] + s_runs[st];
+                if (nr[u] == kOpen) carry[t].next_run = s_first[st];
+            }
         }
     }
 }
