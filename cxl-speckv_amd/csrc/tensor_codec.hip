@@ -357,6 +357,11 @@ __global__ __launch_bounds__(64) void k_tc_scan(const TcSummary* __restrict__ su
 // to; what crosses steps -- the stretch start entering a step, the run count before it, the first run start behind it --
 // is a scan over per-step totals in LDS, done by wave 0 between the phases.  Up to kScanMaxSteps steps (256 Mi elements);
 // longer tensors take the single-wave kernel.
+// What bounds it now (27 us for 16 384 tiles) is the instruction issue of the ONE CU it runs on: phase 3 is ~250 instructions
+// per step (six wave scans, four 64-bit shuffles), 16 steps per wave, four waves per SIMD at 4 clocks per instruction = 64 k
+// clocks.  Its three per-tile phases are independent across steps and could run as grids of their own (every workgroup
+// redoing the short scan over the step totals): three launches of a few microseconds instead of one of 27; not built --
+// this operator exists for parity with the reference's call shape, the pool's own path is per block.
 constexpr uint32_t kScanWaves = 16, kScanMaxSteps = 2048;
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, uint32_t src)
 {
