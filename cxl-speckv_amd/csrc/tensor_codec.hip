@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 namespace speckv {
 namespace {
@@ -707,6 +708,54 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_td_scan_wg(const TdSummary*
     }
 }
 
+// The decode scan as two grids (a wave per step of 64 chunks): the one-workgroup form is bound by the instruction issue of
+// the single CU it runs on (14 us for 16 384 chunks); the scan over the step totals is short enough for every wave to redo.
+struct TdStepTotal { uint64_t cnt; uint32_t val, pad; };
+__global__ __launch_bounds__(256) void k_td_scan_local(const TdSummary* __restrict__ summ, TdCarry* __restrict__ carry, uint64_t n_chunks,
+                                                      TdStepTotal* __restrict__ step_tot)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t st = static_cast<uint64_t>(blockIdx.x) * 4u + (threadIdx.x >> 6);
+    const uint64_t c = st * 64u + lane;
+    if (st * 64u >= n_chunks) return;
+    TdSummary s{0u, 0u};
+    if (c < n_chunks) s = summ[c];
+    const uint32_t lo = wave_incl_add(s.sum_c & 0xFFFFu), hi = wave_incl_add(s.sum_c >> 16);
+    const uint64_t inc = static_cast<uint64_t>(lo) + (static_cast<uint64_t>(hi) << 16);
+    const uint32_t vinc = wave_incl_add(s.sum_v);
+    if (c < n_chunks) carry[c] = TdCarry{inc - s.sum_c, (vinc - s.sum_v) & 0xFFu, 0u};
+    if (lane == 0u) step_tot[st] = TdStepTotal{static_cast<uint64_t>(lane63(lo)) + (static_cast<uint64_t>(lane63(hi)) << 16), lane63(vinc) & 0xFFu, 0u};
+}
+__global__ __launch_bounds__(256) void k_td_scan_apply(TdCarry* __restrict__ carry, uint64_t n_chunks, const TdStepTotal* __restrict__ step_tot,
+                                                      uint64_t cap, uint64_t* __restrict__ out_n)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t st = static_cast<uint64_t>(blockIdx.x) * 4u + (threadIdx.x >> 6);
+    const uint64_t n_steps = (n_chunks + 63u) / 64u;
+    if (st >= n_steps) return;
+    uint64_t cnt = 0;                                               // totals of the steps in front of this one (< 2^25 each)
+    uint32_t val = 0;
+    for (uint64_t j0 = 0; j0 < st; j0 += 64u) {
+        const uint64_t j = j0 + lane;
+        if (j < st) { const TdStepTotal t = step_tot[j]; cnt += t.cnt; val += t.val; }
+    }
+    const uint32_t lo = lane63(wave_incl_add(static_cast<uint32_t>(cnt) & 0xFFFFu)), mid = lane63(wave_incl_add(static_cast<uint32_t>(cnt >> 16) & 0xFFFFu));
+    const uint32_t hi = lane63(wave_incl_add(static_cast<uint32_t>(cnt >> 32)));
+    const uint64_t before = static_cast<uint64_t>(lo) + (static_cast<uint64_t>(mid) << 16) + (static_cast<uint64_t>(hi) << 32);
+    const uint32_t qbefore = lane63(wave_incl_add(val)) & 0xFFu;
+    const uint64_t c = st * 64u + lane;
+    if (c < n_chunks) {
+        const TdCarry mine = carry[c];
+        carry[c] = TdCarry{mine.start + before, (mine.q_pre + qbefore) & 0xFFu, 0u};
+    }
+    if (st + 1u == n_steps && lane == 0u) {
+        const TdStepTotal t = step_tot[st];
+        const uint64_t total = before + t.cnt;
+        carry[n_chunks] = TdCarry{total, (qbefore + t.val) & 0xFFu, 0u};
+        *out_n = total < cap ? total : cap;                          // elements written (the stream's total, clipped at the buffer)
+    }
+}
+
 // Output-centric expand: a wave owns 2048 consecutive output elements.  It finds the chunk of pairs its first element
 // lies in, walks the pairs 64 per step (add-scan of (value*count mod 256) << 24 | count gives each run its start and the
 // int8 prefix of all earlier deltas), and every lane writes the part of its run that falls into the tile:
@@ -831,7 +880,8 @@ size_t tensor_compress_workspace_bytes(uint64_t n)
 size_t tensor_decompress_workspace_bytes(uint64_t rle_bytes)
 {
     const uint64_t chunks = ((rle_bytes >> 1) + kTile - 1) / kTile;
-    return align_up(chunks * sizeof(TdSummary), 256) + align_up((chunks + 1) * sizeof(TdCarry), 256) + 256;
+    return align_up(chunks * sizeof(TdSummary), 256) + align_up((chunks + 1) * sizeof(TdCarry), 256) + 256 +
+           align_up(((chunks + 63) / 64) * 16, 256);                 // + the step totals of the two-grid scan
 }
 
 hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, uint8_t* d_rle, uint64_t* d_rle_bytes, float* d_scale,
@@ -883,10 +933,18 @@ hipError_t launch_tensor_decompress(const uint8_t* d_rle, uint64_t rle_bytes, fl
     TdCarry* carry = reinterpret_cast<TdCarry*>(w); w += align_up((chunks + 1) * sizeof(TdCarry), 256);
     uint64_t* n_out = d_n_out ? d_n_out : reinterpret_cast<uint64_t*>(w);
     if (chunks) hipLaunchKernelGGL(k_td_summary, dim3(static_cast<uint32_t>((chunks + 3) / 4)), dim3(256), 0, s, d_rle, n_pairs, summ);
-    if ((chunks + 63) / 64 <= kScanMaxSteps && !getenv("SPECKV_TC_SERIAL_SCAN"))
-        hipLaunchKernelGGL(k_td_scan_wg, dim3(1), dim3(64 * kScanWaves), 0, s, summ, carry, chunks, dst_cap, n_out);
-    else
+    const uint64_t n_steps = (chunks + 63) / 64;
+    const char* scan_env = getenv("SPECKV_TC_SCAN");                // (A/B and test switch: wg = one workgroup, serial = one wave)
+    if (chunks == 0 || (scan_env && !strcmp(scan_env, "serial")) || getenv("SPECKV_TC_SERIAL_SCAN"))
         hipLaunchKernelGGL(k_td_scan, dim3(1), dim3(64), 0, s, summ, carry, chunks, dst_cap, n_out);
+    else if (scan_env && !strcmp(scan_env, "wg") && n_steps <= kScanMaxSteps)
+        hipLaunchKernelGGL(k_td_scan_wg, dim3(1), dim3(64 * kScanWaves), 0, s, summ, carry, chunks, dst_cap, n_out);
+    else {
+        TdStepTotal* step_tot = reinterpret_cast<TdStepTotal*>(w + 256);
+        const uint32_t g = static_cast<uint32_t>((n_steps + 3) / 4);
+        hipLaunchKernelGGL(k_td_scan_local, dim3(g), dim3(256), 0, s, summ, carry, chunks, step_tot);
+        hipLaunchKernelGGL(k_td_scan_apply, dim3(g), dim3(256), 0, s, carry, chunks, step_tot, dst_cap, n_out);
+    }
     if (chunks && dst_cap) {
         // grid: the output can hold at most min(dst_cap, 255 * n_pairs) elements; waves behind the stream's total return at once
         const uint64_t max_out = std::min<uint64_t>(dst_cap, n_pairs * 255u);
