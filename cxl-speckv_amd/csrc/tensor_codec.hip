@@ -8,8 +8,8 @@
 // The serial recurrences become scans at two levels: inside a tile they are the wave scans of the block encoder's general
 // path (one element per lane and step, DPP add / max scans with carries); across tiles a single wave walks the per-tile
 // summaries 64 tiles per step.
-//   compress:   k_tc_absmax -> k_tc_tiles<summary> -> k_tc_scan -> k_tc_tiles<emit> -> k_tc_pack
-//   decompress: k_td_summary -> k_td_scan -> k_td_expand
+//   compress:   k_tc_absmax -> k_tc_tiles<summary> -> k_tc_scan_a/_b/_c -> k_tc_tiles<emit> -> k_tc_pack
+//   decompress: k_td_summary -> k_td_scan_local/_apply -> k_td_expand
 // Positions p = 0..n-1; d[p] = q[p] - q[p-1] (q[-1] = 0); a STRETCH starts at p == 0 or d[p] != d[p-1]; a RUN starts every
 // 255 elements of a stretch (cache_engine.cpp:224: `count < 255`); pair = (d[p], distance to the next run start).
 // Every wave writes whole 128-byte lines of its own (tile-local pair buffers, then an output-centric pack pass): byte
@@ -360,9 +360,8 @@ __global__ __launch_bounds__(64) void k_tc_scan(const TcSummary* __restrict__ su
 // longer tensors take the single-wave kernel.
 // What bounds it now (27 us for 16 384 tiles) is the instruction issue of the ONE CU it runs on: phase 3 is ~250 instructions
 // per step (six wave scans, four 64-bit shuffles), 16 steps per wave, four waves per SIMD at 4 clocks per instruction = 64 k
-// clocks.  Its three per-tile phases are independent across steps and could run as grids of their own (every workgroup
-// redoing the short scan over the step totals): three launches of a few microseconds instead of one of 27; not built --
-// this operator exists for parity with the reference's call shape, the pool's own path is per block.
+// clocks.  Its three per-tile phases are independent across steps: k_tc_scan_a / _b / _c below run them as grids of their own
+// (three launches, ~8 us together); this kernel stays as the SPECKV_TC_SCAN=wg form (tests run all three).
 constexpr uint32_t kScanWaves = 16, kScanMaxSteps = 2048;
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, uint32_t src)
 {
@@ -506,6 +505,110 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_tc_scan_wg(const TcSummary*
                 if (nr[u] == kOpen) carry[t].next_run = s_first[st];
             }
         }
+    }
+}
+
+// The same scan as three grids, a wave per step of 64 tiles (the one-workgroup form above is bound by the instruction issue of
+// the single CU it runs on: 27 us for 16 384 tiles): what crosses steps is short enough for every wave to look up itself --
+// the last stretch start in front of its step (A -> B), the run starts in front of it and the first run start behind it
+// (B -> C).  Step arrays in global memory: step_ss / step_runs / step_first, n_steps entries each.
+__global__ __launch_bounds__(256) void k_tc_scan_a(const TcSummary* __restrict__ summ, uint64_t n_tiles, uint64_t* __restrict__ step_ss)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t st = static_cast<uint64_t>(blockIdx.x) * 4u + (threadIdx.x >> 6);
+    if (st * 64u >= n_tiles) return;
+    const uint64_t t = st * 64u + lane;
+    const uint32_t last_ss = t < n_tiles ? summ[t].last_ss : 0u;
+    const uint32_t tot = lane63(wave_incl_max(last_ss ? lane * kTile + last_ss : 0u));
+    if (lane == 0u) step_ss[st] = tot ? st * 64u * kTile + tot : 0ull;      // last stretch start of the step (absolute + 1), 0: none
+}
+__global__ __launch_bounds__(256) void k_tc_scan_b(const TcSummary* __restrict__ summ, TcCarry* __restrict__ carry, uint64_t n_tiles, uint64_t n,
+                                                  const uint64_t* __restrict__ step_ss, uint64_t* __restrict__ step_runs, uint64_t* __restrict__ step_first)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t st = static_cast<uint64_t>(blockIdx.x) * 4u + (threadIdx.x >> 6);
+    if (st * 64u >= n_tiles) return;
+    constexpr uint64_t kOpen = ~0ull;
+    // the stretch start entering the step: the last non-zero step_ss in front of it (as a rule the step before)
+    uint64_t ss_step = 0;
+    for (uint64_t j1 = st; j1 > 0u && ss_step == 0u;) {
+        const uint64_t j0 = j1 > 64u ? j1 - 64u : 0u;                 // steps [j0, j1)
+        const uint64_t j = j0 + lane;
+        const uint64_t v = j < j1 ? step_ss[j] : 0ull;
+        const unsigned long long have = __ballot(v != 0ull);
+        if (have) ss_step = shfl64(v, 63u - static_cast<uint32_t>(__builtin_clzll(have)));
+        j1 = j0;
+    }
+    const uint64_t base = st * 64u, t = base + lane;
+    const bool live = t < n_tiles;
+    TcSummary s{0u, 0u, 0u, 0u};
+    if (live) s = summ[t];
+    const uint64_t t0 = t * kTile;
+    const uint32_t len = live ? static_cast<uint32_t>((n - t0 < kTile) ? (n - t0) : kTile) : 0u;
+    const uint32_t inc = wave_incl_max(s.last_ss ? lane * kTile + s.last_ss : 0u);
+    const uint32_t exc = wave_shr1(inc, 0u);
+    const uint64_t ss_in = exc ? base * kTile + exc : ss_step;
+    uint32_t lead_phase = 0, cnt_a = 0, first_a = 0;
+    const uint32_t f_end = s.first_ss ? s.first_ss - 1u : len;
+    if (live && ss_in && f_end) {
+        lead_phase = static_cast<uint32_t>((t0 - (ss_in - 1u)) % 255u);
+        first_a = (255u - lead_phase) % 255u;
+        if (first_a < f_end) cnt_a = (f_end - 1u - first_a) / 255u + 1u;
+    }
+    const uint32_t runs = cnt_a + s.cnt_b;
+    const uint32_t rinc = wave_incl_add(runs);
+    const uint64_t fr = !live ? 0ull : (cnt_a ? t0 + first_a + 1u : (s.cnt_b ? t0 + s.first_ss : 0ull));     // absolute + 1
+    const unsigned long long have = __ballot(fr != 0ull);
+    const unsigned long long later = have & lanes_above(lane);
+    const uint64_t nxt = shfl64(fr, later ? static_cast<uint32_t>(__builtin_ctzll(later)) : 0u);
+    if (live) {
+        TcCarry c;
+        c.lead_phase = lead_phase;
+        c.runs = runs;
+        c.run_base = rinc - runs;                                   // + the step's base in k_tc_scan_c
+        c.next_run = later ? nxt - 1u : kOpen;                      // open: the first run start behind the step (k_tc_scan_c)
+        carry[t] = c;
+    }
+    const uint64_t first = shfl64(fr, have ? static_cast<uint32_t>(__builtin_ctzll(have)) : 0u);
+    if (lane == 0u) { step_runs[st] = lane63(rinc); step_first[st] = have ? first : 0ull; }
+}
+__global__ __launch_bounds__(256) void k_tc_scan_c(TcCarry* __restrict__ carry, uint64_t n_tiles, uint64_t n, const uint64_t* __restrict__ step_runs,
+                                                  const uint64_t* __restrict__ step_first, const uint32_t* __restrict__ absmax_bits,
+                                                  float* __restrict__ out_scale, uint64_t* __restrict__ out_bytes)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t st = static_cast<uint64_t>(blockIdx.x) * 4u + (threadIdx.x >> 6);
+    const uint64_t n_steps = (n_tiles + 63u) / 64u;
+    if (st >= n_steps) return;
+    constexpr uint64_t kOpen = ~0ull;
+    uint32_t part = 0;                                               // run starts in front of the step (each step <= 64 * 2048; a lane sums <= 32 steps)
+    uint64_t wide = 0;
+    for (uint64_t j0 = 0; j0 < st; j0 += 64u) {
+        const uint64_t j = j0 + lane;
+        if (j < st) wide += step_runs[j];
+    }
+    part = static_cast<uint32_t>(wide & 0xFFFFu);
+    const uint64_t before = static_cast<uint64_t>(lane63(wave_incl_add(part))) + (static_cast<uint64_t>(lane63(wave_incl_add(static_cast<uint32_t>(wide >> 16)))) << 16);
+    // the first run start behind the step: the first non-zero step_first after it (as a rule the step after), n if none
+    uint64_t behind = n;
+    bool found = false;
+    for (uint64_t j0 = st + 1u; j0 < n_steps && !found; j0 += 64u) {
+        const uint64_t j = j0 + lane;
+        const uint64_t v = j < n_steps ? step_first[j] : 0ull;
+        const unsigned long long have = __ballot(v != 0ull);
+        if (have) { behind = shfl64(v, static_cast<uint32_t>(__builtin_ctzll(have))) - 1u; found = true; }
+    }
+    const uint64_t t = st * 64u + lane;
+    if (t < n_tiles) {
+        carry[t].run_base += before;
+        if (carry[t].next_run == kOpen) carry[t].next_run = behind;
+    }
+    if (st + 1u == n_steps && lane == 0u) {
+        const uint64_t total = before + step_runs[st];
+        carry[n_tiles].run_base = total;                             // sentinel for the pack pass
+        carry[n_tiles].runs = 0; carry[n_tiles].lead_phase = 0; carry[n_tiles].next_run = n;
+        *out_bytes = 2ull * total;
+        *out_scale = tc_scale(*absmax_bits);
     }
 }
 
@@ -907,10 +1010,24 @@ hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, u
 #define SPECKV_TC2(EMIT) do { if (quant_mode == kIntent) { if (src_f32) SPECKV_TC(kIntent, true, EMIT); else SPECKV_TC(kIntent, false, EMIT); } \
                               else { if (src_f32) SPECKV_TC(kRefExact, true, EMIT); else SPECKV_TC(kRefExact, false, EMIT); } } while (0)
     if (tiles) SPECKV_TC2(false);
-    if ((tiles + 63) / 64 <= kScanMaxSteps && !getenv("SPECKV_TC_SERIAL_SCAN"))
-        hipLaunchKernelGGL(k_tc_scan_wg, dim3(1), dim3(64 * kScanWaves), 0, s, summ, carry, tiles, n, absmax, d_scale, d_rle_bytes);
-    else
-        hipLaunchKernelGGL(k_tc_scan, dim3(1), dim3(64), 0, s, summ, carry, tiles, n, absmax, d_scale, d_rle_bytes, first_run);
+    {
+        const uint64_t n_steps = (tiles + 63) / 64;
+        const char* scan_env = getenv("SPECKV_TC_SCAN");            // (A/B and test switch: wg = one workgroup, serial = one wave)
+        if (tiles < 64 || (scan_env && !strcmp(scan_env, "serial")) || getenv("SPECKV_TC_SERIAL_SCAN"))
+            hipLaunchKernelGGL(k_tc_scan, dim3(1), dim3(64), 0, s, summ, carry, tiles, n, absmax, d_scale, d_rle_bytes, first_run);
+        else if (scan_env && !strcmp(scan_env, "wg") && n_steps <= kScanMaxSteps)
+            hipLaunchKernelGGL(k_tc_scan_wg, dim3(1), dim3(64 * kScanWaves), 0, s, summ, carry, tiles, n, absmax, d_scale, d_rle_bytes);
+        else {
+            // the step arrays live where the one-wave scan keeps its first-run starts (tiles x 8 bytes >= 3 x n_steps x 8)
+            uint64_t* step_ss = first_run;
+            uint64_t* step_runs = first_run + n_steps;
+            uint64_t* step_first = first_run + 2 * n_steps;
+            const uint32_t g = static_cast<uint32_t>((n_steps + 3) / 4);
+            hipLaunchKernelGGL(k_tc_scan_a, dim3(g), dim3(256), 0, s, summ, tiles, step_ss);
+            hipLaunchKernelGGL(k_tc_scan_b, dim3(g), dim3(256), 0, s, summ, carry, tiles, n, step_ss, step_runs, step_first);
+            hipLaunchKernelGGL(k_tc_scan_c, dim3(g), dim3(256), 0, s, carry, tiles, n, step_runs, step_first, absmax, d_scale, d_rle_bytes);
+        }
+    }
     if (tiles) {
         SPECKV_TC2(true);
         // the pack grid covers the worst case (one pair per element); waves beyond the stream's end return at once

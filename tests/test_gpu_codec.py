@@ -440,6 +440,30 @@ def test_tensor_codec_golden_reference_vectors(lib, golden_dir):
         assert_same_float_bits(y, want, f"malformed{i}")
 
 
+@pytest.mark.parametrize("form", ["grids", "wg", "serial"])
+def test_tensor_codec_scan_forms(lib, oracle, form):
+    """The scans across tiles exist in three forms -- grids of one wave per step (the default), one workgroup, one wave
+    (SPECKV_TC_SCAN, read at every call) -- which must all produce the oracle's stream and output: noise with long flat
+    stretches (runs, 255-splits and the delta chain cross tiles and steps of 64 tiles), 70 to 900 000 elements."""
+    rng = np.random.default_rng(5)
+    if form != "grids":
+        os.environ["SPECKV_TC_SCAN"] = form
+    try:
+        for n in (70, 2048 * 63 + 5, 2048 * 64, 2048 * 65 + 1, 900000):
+            x = rng.standard_normal(n).astype(np.float32)
+            for _ in range(6):                                       # flat stretches at random places, some longer than a step
+                a = int(rng.integers(0, n)); b = min(n, a + int(rng.integers(1, 200000)))
+                x[a:b] = np.float32(rng.standard_normal())
+            for mode in MODES:
+                o_scale, o_rle = oracle.compress_f32(x, mode)
+                scale, rle = gpu_compress_tensor(lib, x, mode)
+                assert np.float32(scale).tobytes() == np.float32(o_scale).tobytes() and rle.tobytes() == o_rle.tobytes(), (form, n, mode)
+                y = gpu_decompress_tensor(lib, o_rle, o_scale, n + 3, mode, True)
+                assert_same_float_bits(y, oracle.decompress_f32(o_rle, o_scale, mode), f"{form} {n} {mode}")
+    finally:
+        os.environ.pop("SPECKV_TC_SCAN", None)
+
+
 def test_tensor_codec_matches_oracle_over_sizes_and_structures(lib, oracle):
     """Lengths around the tile size and far beyond it, data whose runs, 255-splits and delta chain cross tile boundaries
     (constant tensors, long piecewise-constant stretches, ramps), fp32 and fp16 sources, both quantiser modes, and the
