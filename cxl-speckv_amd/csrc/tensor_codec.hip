@@ -188,17 +188,32 @@ __device__ __forceinline__ bool tc_tile_fast(const uint8_t* tsrc, float scale, f
 
 // One tile, one wave: the loop of the block encoder's general path with carries that may come from other tiles.
 // EMIT = false: the tile's summary.  EMIT = true: the tile's pairs into its 4 KiB slot of the pair scratch.
-template <int MODE, bool F32, bool EMIT>
+// PRE (summary pass of fp16 sources): a tile the fast path takes is EMITTED already here -- its pairs depend on nothing outside
+// the tile and the two elements in front of it, except the count of its last pair (it ends at the next run start, which the
+// scan finds) -- and flagged in pre_flags; the emit pass then only stores that one byte for it, unless a stretch entering the
+// tile starts a run inside it (TcCarry::runs != the tile's own starts), which is the emit pass's business as before.  For data
+// that does not compress the second pass over the source disappears: summary 19 + emit 28 us -> 29 + 4 for 32 Mi elements.
+template <int MODE, bool F32, bool EMIT, bool PRE = false>
 __global__ __launch_bounds__(64 * kTcWaves) void k_tc_tiles(const void* __restrict__ src, uint64_t n, const uint32_t* __restrict__ absmax_bits,
                                                             TcSummary* __restrict__ summ, const TcCarry* __restrict__ carry,
-                                                            uint8_t* __restrict__ pair_scratch)
+                                                            uint8_t* __restrict__ pair_scratch, uint8_t* __restrict__ pre_flags)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[EMIT ? kTcWaves * (kTcLead + 2 * kTile) : 16];
+    static_assert(!(EMIT && PRE) && !(PRE && F32), "PRE is the summary pass of fp16 sources");
+    __shared__ __attribute__((aligned(16))) uint8_t lds[(EMIT || PRE) ? kTcWaves * (kTcLead + 2 * kTile) : 16];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t tile = static_cast<uint64_t>(blockIdx.x) * kTcWaves + wave;
     const uint64_t t0 = tile * kTile;
     if (t0 >= n) return;
     const uint32_t len = static_cast<uint32_t>((n - t0 < kTile) ? (n - t0) : kTile);
+    if (EMIT && pre_flags && pre_flags[tile]) {                      // wave-uniform: emitted by the summary pass
+        const TcCarry c0 = carry[tile];
+        const TcSummary s0 = summ[tile];
+        if (c0.runs == s0.cnt_b) {
+            if (s0.cnt_b && lane == 0u)                             // the last pair ends where the next run starts
+                pair_scratch[tile * (2ull * kTile) + 2ull * s0.cnt_b - 1u] = static_cast<uint8_t>(c0.next_run - (t0 + s0.last_b - 1u));
+            return;
+        }
+    }
     const float scale = tc_scale(*absmax_bits);
     // the two elements in front of the tile give q[t0-1] and d[t0-1]
     uint32_t qtail = 0, dtail = 0;
@@ -210,8 +225,8 @@ __global__ __launch_bounds__(64 * kTcWaves) void k_tc_tiles(const void* __restri
     TcCarry cy{};
     uint8_t* wl = nullptr;
     uint32_t pair_addr = 0;
-    if (EMIT) {
-        cy = carry[tile];
+    if (EMIT) cy = carry[tile];
+    if (EMIT || PRE) {
         wl = lds + wave * (kTcLead + 2 * kTile);
         pair_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)(wl + kTcLead)));
     }
@@ -223,13 +238,26 @@ __global__ __launch_bounds__(64 * kTcWaves) void k_tc_tiles(const void* __restri
     if (!F32 && len == kTile && ((reinterpret_cast<uintptr_t>(src) + 2ull * t0) & 15u) == 0u && !kTcNoFast) {
         // whole fp16 tiles: eight elements per lane and step (tc_tile_fast); everything else, and whatever it declines, element-wise below
         uint32_t f_first = 0, f_last = 0, f_n = 0;
-        const uint32_t pair_m1 = EMIT ? pair_addr - 1u : 0u;
-        if (tc_tile_fast<MODE, EMIT>(static_cast<const uint8_t*>(src) + 2ull * t0, scale, 1.0f / scale, qtail, t0 == 0u ? 0x100u : dtail, pair_m1, lane,
-                                     f_first, f_last, f_n) &&
+        const uint32_t pair_m1 = (EMIT || PRE) ? pair_addr - 1u : 0u;
+        if (tc_tile_fast<MODE, EMIT || PRE>(static_cast<const uint8_t*>(src) + 2ull * t0, scale, 1.0f / scale, qtail, t0 == 0u ? 0x100u : dtail, pair_m1, lane,
+                                            f_first, f_last, f_n) &&
             (!EMIT || cy.runs == f_n)) {                            // (emit: no run start of an entering stretch inside the tile)
             first_ss = f_first; scarry = f_last; mcarry = f_last; icarry = f_n;
             fast = true;
         }
+    }
+    if (PRE) {
+        if (fast) {                                                 // the tile's pairs, all but the count of the last one
+            wave_lds_fence();
+            uint8_t* dst = pair_scratch + tile * (2ull * kTile);
+            const uint32_t bytes = 2u * icarry;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t b = 1024u * j + 16u * lane;
+                if (b < bytes) *reinterpret_cast<uint4*>(dst + b) = *reinterpret_cast<const uint4*>(wl + kTcLead + b);
+            }
+        }
+        if (lane == 0u) pre_flags[tile] = fast ? 1u : 0u;
     }
 #pragma unroll 1
     for (uint32_t step = 0; step < kTile / 64u && !fast; ++step) {
@@ -1006,10 +1034,19 @@ hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, u
         else         hipLaunchKernelGGL(k_tc_absmax<false>, dim3(g), dim3(1024), 0, s, d_src, n, absmax);
     }
     const uint32_t tg = static_cast<uint32_t>((tiles + kTcWaves - 1) / kTcWaves);
-#define SPECKV_TC(MODE, F32, EMIT) hipLaunchKernelGGL((k_tc_tiles<MODE, F32, EMIT>), dim3(tg), dim3(64 * kTcWaves), 0, s, d_src, n, absmax, summ, carry, scratch)
+    // fp16 sources: the summary pass emits the tiles its fast path takes (k_tc_tiles, PRE); the flags live behind the step
+    // arrays of the three-grid scan, so only with that scan (SPECKV_TC_NO_PRE=1: the two plain passes, A/B and test switch)
+    const char* scan_env0 = getenv("SPECKV_TC_SCAN");
+    const bool grids = tiles >= 64 && !scan_env0 && !getenv("SPECKV_TC_SERIAL_SCAN");
+    const bool pre = grids && !src_f32 && !kTcNoFast && !getenv("SPECKV_TC_NO_PRE");
+    uint8_t* pre_flags = pre ? reinterpret_cast<uint8_t*>(first_run + 3 * ((tiles + 63) / 64)) : nullptr;
+#define SPECKV_TC(MODE, F32, EMIT) hipLaunchKernelGGL((k_tc_tiles<MODE, F32, EMIT>), dim3(tg), dim3(64 * kTcWaves), 0, s, d_src, n, absmax, summ, carry, scratch, pre_flags)
 #define SPECKV_TC2(EMIT) do { if (quant_mode == kIntent) { if (src_f32) SPECKV_TC(kIntent, true, EMIT); else SPECKV_TC(kIntent, false, EMIT); } \
                               else { if (src_f32) SPECKV_TC(kRefExact, true, EMIT); else SPECKV_TC(kRefExact, false, EMIT); } } while (0)
-    if (tiles) SPECKV_TC2(false);
+    if (tiles && pre) {
+        if (quant_mode == kIntent) hipLaunchKernelGGL((k_tc_tiles<kIntent, false, false, true>), dim3(tg), dim3(64 * kTcWaves), 0, s, d_src, n, absmax, summ, carry, scratch, pre_flags);
+        else                       hipLaunchKernelGGL((k_tc_tiles<kRefExact, false, false, true>), dim3(tg), dim3(64 * kTcWaves), 0, s, d_src, n, absmax, summ, carry, scratch, pre_flags);
+    } else if (tiles) SPECKV_TC2(false);
     {
         const uint64_t n_steps = (tiles + 63) / 64;
         const char* scan_env = getenv("SPECKV_TC_SCAN");            // (A/B and test switch: wg = one workgroup, serial = one wave)

@@ -440,13 +440,15 @@ def test_tensor_codec_golden_reference_vectors(lib, golden_dir):
         assert_same_float_bits(y, want, f"malformed{i}")
 
 
-@pytest.mark.parametrize("form", ["grids", "wg", "serial"])
+@pytest.mark.parametrize("form", ["grids", "wg", "serial", "no_pre"])
 def test_tensor_codec_scan_forms(lib, oracle, form):
     """The scans across tiles exist in three forms -- grids of one wave per step (the default), one workgroup, one wave
-    (SPECKV_TC_SCAN, read at every call) -- which must all produce the oracle's stream and output: noise with long flat
+    (SPECKV_TC_SCAN, read at every call; fp16 sources: with and without the summary pass emitting, SPECKV_TC_NO_PRE) -- which must all produce the oracle's stream and output: noise with long flat
     stretches (runs, 255-splits and the delta chain cross tiles and steps of 64 tiles), 70 to 900 000 elements."""
     rng = np.random.default_rng(5)
-    if form != "grids":
+    if form == "no_pre":
+        os.environ["SPECKV_TC_NO_PRE"] = "1"                         # fp16 sources: summary and emit as two plain passes
+    elif form != "grids":
         os.environ["SPECKV_TC_SCAN"] = form
     try:
         for n in (70, 2048 * 63 + 5, 2048 * 64, 2048 * 65 + 1, 900000):
@@ -460,8 +462,14 @@ def test_tensor_codec_scan_forms(lib, oracle, form):
                 assert np.float32(scale).tobytes() == np.float32(o_scale).tobytes() and rle.tobytes() == o_rle.tobytes(), (form, n, mode)
                 y = gpu_decompress_tensor(lib, o_rle, o_scale, n + 3, mode, True)
                 assert_same_float_bits(y, oracle.decompress_f32(o_rle, o_scale, mode), f"{form} {n} {mode}")
+                if n >= 2048:                                        # the same as an fp16 source (tiles emitted by the summary pass unless no_pre)
+                    x16 = x.astype(np.float16)
+                    o_scale, o_rle = oracle.compress_f32(x16.astype(np.float32), mode)
+                    scale, rle = gpu_compress_tensor(lib, x16, mode)
+                    assert np.float32(scale).tobytes() == np.float32(o_scale).tobytes() and rle.tobytes() == o_rle.tobytes(), (form, n, mode, "fp16")
     finally:
         os.environ.pop("SPECKV_TC_SCAN", None)
+        os.environ.pop("SPECKV_TC_NO_PRE", None)
 
 
 def test_tensor_codec_matches_oracle_over_sizes_and_structures(lib, oracle):
