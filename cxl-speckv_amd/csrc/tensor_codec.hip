@@ -670,6 +670,52 @@ __global__ __launch_bounds__(256) void k_tc_pack(const TcCarry* __restrict__ car
     const uint64_t last_pair = (chunk + kTile - 1u < total) ? chunk + kTile - 1u : total - 1u;
     const uint64_t t_first = tc_wave_find_tile(carry, n_tiles, chunk, lane);
     const uint64_t t_last = tc_wave_find_tile(carry, n_tiles, last_pair, lane);
+    if (t_last - t_first <= 3u) {
+        // the chunk lies in at most four tiles (data that does not compress: three): their bases once per wave, then every
+        // lane piece places itself by comparisons -- the four pieces of a lane are independent loads instead of four chains
+        // of dependent ones
+        uint64_t rb[5];
+#pragma unroll
+        for (uint32_t q = 0; q < 5u; ++q) rb[q] = carry[(t_first + q <= n_tiles) ? t_first + q : n_tiles].run_base;
+        struct __attribute__((packed, aligned(2))) Unaligned16 { u32x4 v; };
+        bool slow[4];
+        u32x4 x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t r0 = chunk + 512u * j + 8u * lane;
+            slow[j] = false;
+            x[j] = u32x4{0u, 0u, 0u, 0u};
+            if (r0 >= total) continue;
+            uint32_t q = 0;                                           // last of the four tiles whose base is <= r0 (tiles without runs share their successor's base and are skipped)
+#pragma unroll
+            for (uint32_t k = 1; k < 4u; ++k) if (t_first + k <= t_last && rb[k] <= r0) q = k;
+            if (r0 + 8u <= rb[q + 1u] && r0 + 8u <= total)
+                x[j] = reinterpret_cast<const Unaligned16*>(pair_scratch + (t_first + q) * (2ull * kTile) + 2ull * (r0 - rb[q]))->v;
+            else slow[j] = true;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t r0 = chunk + 512u * j + 8u * lane;
+            if (r0 >= total) continue;
+            if (slow[j]) {                                            // the piece straddles tiles (or the stream's end): pair by pair
+                uint64_t t = t_first;
+                while (t < t_last && carry[t + 1].run_base <= r0) ++t;
+                uint64_t tb = carry[t].run_base, te = carry[t + 1].run_base;
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+                for (int k = 0; k < 8; ++k) {
+                    const uint64_t r = r0 + k;
+                    if (r < total) {
+                        while (r >= te) { ++t; tb = te; te = carry[t + 1].run_base; }
+                        const uint32_t pr = *reinterpret_cast<const uint16_t*>(pair_scratch + t * (2ull * kTile) + 2ull * (r - tb));
+                        w[k >> 1] |= pr << ((k & 1) * 16);
+                    }
+                }
+                x[j] = u32x4{w[0], w[1], w[2], w[3]};
+            }
+            *reinterpret_cast<uint4*>(rle + 2ull * r0) = make_uint4(x[j].x, x[j].y, x[j].z, x[j].w);
+        }
+        return;
+    }
 #pragma unroll 1
     for (int j = 0; j < 4; ++j) {
         const uint64_t r0 = chunk + 512u * j + 8u * lane;
