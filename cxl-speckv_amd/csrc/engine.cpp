@@ -198,6 +198,11 @@ int Engine::init_hip(int device)
     HIP_TRY(hipMemsetAsync(d_done_count_, 0, 64, stream_));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_done_), 64, hipHostMallocMapped | hipHostMallocPortable));
     *h_done_ = 0;
+    {
+        void* dp = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dp, h_done_, 0));
+        h_done_dev_ = static_cast<uint32_t*>(dp);
+    }
     l1_owner_.assign(n_l1_, Owner{nullptr, 0});
     lru_prev_.assign(n_l2_ + n_l1_, UINT32_MAX);
     lru_next_.assign(n_l2_ + n_l1_, UINT32_MAX);
@@ -934,11 +939,9 @@ int Engine::fetch_into_ring(Allocation* a, const std::vector<uint32_t>& pages, u
     // runtime's own completion path costs 4 us more for a launch this short (DESIGN.md sect. 5).  A spin that runs out
     // (a preempted GPU, a debugger) falls back to it.
     static const bool spin_ok = getenv("SPECKV_ACCESS_NO_SPIN") == nullptr;
-    const bool spin = spin_ok && n <= 8u && h_done_ && d_done_count_;
+    const bool spin = spin_ok && n <= 8u && h_done_dev_ && d_done_count_;
     if (spin) {
-        void* dp = nullptr;
-        HIP_TRY(hipHostGetDevicePointer(&dp, h_done_, 0));
-        c.done_flag = static_cast<uint32_t*>(dp);
+        c.done_flag = h_done_dev_;
         c.done_count = d_done_count_;
         c.done_token = ++done_token_ ? done_token_ : ++done_token_;      // never 0: the word's initial value
     }

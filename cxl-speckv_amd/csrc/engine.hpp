@@ -220,6 +220,7 @@ private:
     uint32_t* d_hand_ = nullptr;
     // completion word of small synchronous fetches (CodecArgs::done_flag): pinned host word, device counter, last token handed out
     uint32_t* h_done_ = nullptr;
+    uint32_t* h_done_dev_ = nullptr;       // the same word as the device addresses it
     uint32_t* d_done_count_ = nullptr;
     uint32_t done_token_ = 0;
     std::vector<Owner> l1_owner_;          // [n_l1], slot - n_l2
