@@ -998,12 +998,16 @@ __global__ __launch_bounds__(256) void k_td_expand(const uint8_t* __restrict__ r
             const uint32_t bits = (w[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
             const uint32_t v = bits & 0xFFu;
             const int32_t c = static_cast<int32_t>(bits >> 8);
-            // the part of [start, start + c) inside [0, valid)
-            const int32_t a0 = start > 0 ? start : 0, bnd = (start + c < valid_i) ? start + c : valid_i;
-            if (a0 < bnd) {
-                uint32_t qq = q + static_cast<uint32_t>(a0 - start) * v;
+            // the part of [start, start + c) inside [0, valid): the run's first element by itself (data that does not compress
+            // is runs of one: no loop, no bounds arithmetic), the rest of a longer run in a loop
+            if (c != 0) {
+                if (static_cast<uint32_t>(start) < static_cast<uint32_t>(valid_i)) tab[start] = static_cast<uint8_t>(q + v);
+                if (c > 1) {
+                    const int32_t a0 = start + 1 > 0 ? start + 1 : 0, bnd = (start + c < valid_i) ? start + c : valid_i;
+                    uint32_t qq = q + static_cast<uint32_t>(a0 - start) * v;
 #pragma unroll 1
-                for (int32_t p = a0; p < bnd; ++p) { qq += v; tab[p] = static_cast<uint8_t>(qq); }
+                    for (int32_t p = a0; p < bnd; ++p) { qq += v; tab[p] = static_cast<uint8_t>(qq); }
+                }
             }
             start += c;
             q += v * static_cast<uint32_t>(c);
