@@ -1411,6 +1411,23 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
                             "submit_ms": round(min(submit_ms[1:]), 3), "enqueue_ms": round(min(enq_ms[1:]), 3),
                             "first_call_ms": round(flush_ms[0], 3), "requests_per_s": round(n_req / (min(flush_ms[1:]) * 1e-3), 1),
                             "note": "device-side flush (candidates + dedupe + ring slots + fetch launch) + sync, steady state; no host round trip"}
+    # the reference's own call pattern: a flush every num_layers requests -- 32 requests, one workgroup runs the whole pipeline
+    try:
+        n_small = min(32, int(Lyr))
+        s_req = np.zeros(n_small, np.uint32); s_lay = (np.arange(n_small) % Lyr).astype(np.uint16); s_dep = np.full(n_small, 4, np.uint32)
+        sub_us, land_us = [], []
+        for rep in range(24):
+            pos = np.full(n_small, int(rng.integers(0, T - 8)), np.uint32)
+            lib.prefetch_batch(s_req, s_lay, pos, s_dep)
+            t0 = time.perf_counter()
+            lib.prefetch_flush(want_count=False)
+            t1 = time.perf_counter()
+            lib.sync()
+            land_us.append((time.perf_counter() - t0) * 1e6); sub_us.append((t1 - t0) * 1e6)
+        ex["prefetch_flush_small"] = {"requests": n_small, "submit_us": round(float(np.median(sub_us[4:])), 1), "until_landed_us": round(float(np.median(land_us[4:])), 1),
+                                      "note": "one speckv_prefetch-sized flush (requests = layers of the shape, look-ahead 4): upload, k_flush_small, fetch launch, sync"}
+    except Exception as e:                                               # noqa: BLE001
+        ex["prefetch_flush_small"] = {"error": repr(e)}
     ex.update(seq70b_extra(torch, kv))
     ex.update(fp8_scores_extra(torch, kv, 32768, 80))
     ex.update(int4_attention_extra(torch, kv, 32768, 80))
