@@ -184,13 +184,13 @@ def test_single_rank_needs_no_process_group():
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    """The bench line committed with the round's profile (profiles/r03k_bench.json = stdout of `python bench.py` on the
+    """The bench line committed with the round's profile (profiles/r03l_bench.json = stdout of `python bench.py` on the
     MI355X box) carries every field of the driver's contract, with the tier's meaning: metric and config from
     BASELINE.json, roofline and cpu_baseline objects, no model keys; `value` is the W + K region at steady clocks (ramped), the cold
     as-called figure and a sustained one stand beside it."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r03k_bench.json")))
+    d = json.load(open(os.path.join(root, "profiles", "r03l_bench.json")))
     base = json.load(open(os.path.join(root, "BASELINE.json")))
     assert d["metric"] in base["metric"] and d["unit"] == "blocks/s"
     for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
@@ -215,14 +215,14 @@ def test_committed_bench_line_has_the_contract_fields():
     f = d["extras"]["prefetch_flush"]
     assert f["requests"] == 8192 and f["pages_issued"] > 10000 and f["submit_ms"] < 0.1 and f["ms"] < 0.2
     # the 2-rank run on one GPU shows the three remote shapes with both engines
-    x = json.load(open(os.path.join(root, "profiles", "r03k_bench_2ranks_one_gpu.json")))["xgmi"]
+    x = json.load(open(os.path.join(root, "profiles", "r03l_bench_2ranks_one_gpu.json")))["xgmi"]
     assert set(x) >= {"cfg3", "cfg4", "symmetric", "accounting"}
     for mode in ("cfg3", "symmetric"):
         assert {"fused_peer_load_kernel", "copy_engines_then_local_decompress", "raw_peer_copy_GBps"} <= set(x[mode])
     # ... and the 8-rank run on one GPU executes the 1 + 7 layout for real (7-way striping, D = 7 in the fetch kernel), with
     # the prefetch-flush leg of configs[2], the working-set statement, the copy engines' actual link bytes, and the top-level
     # remote roofline object of the rank-0 line
-    d8 = json.load(open(os.path.join(root, "profiles", "r03k_bench_8ranks_one_gpu.json")))
+    d8 = json.load(open(os.path.join(root, "profiles", "r03l_bench_8ranks_one_gpu.json")))
     assert d8["n_gpus"] == 8 and "watchdog_fired" not in d8
     x8 = d8["xgmi"]
     for mode in ("cfg3", "cfg4", "symmetric"):
