@@ -39,6 +39,9 @@ EXTRAS_RAMP_MS = 25.0           # untimed clock ramp before each secondary measu
 PAGE = 4096
 BLOCK_ELEMS = 2048
 SCHEME_NAMES = {0: "fp16", 1: "int8", 2: "int8_delta_rle"}
+# the arithmetic type of the path: int8 RLE records are expanded, prefix-summed in int8, dequantised in fp32
+# (float(q) / 127.0f * scale, cache_engine.cpp:272-284) and rounded ONCE to the fp16 destination
+DTYPE_LABEL = "fp32 (int8 records -> fp16)"
 
 
 def pmc_traffic(scheme, quant):
@@ -47,10 +50,10 @@ def pmc_traffic(scheme, quant):
     MI355X_MICROARCH.md prescribes).  PMC cannot be read from inside the run, so
     this is the profile's number, labelled with its source; None if absent."""
     import glob
-    key = f"k_fetch_decompress<{scheme}, {quant}, false>"
-    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+    key = f"k_fetch_decompress<{scheme}, {quant}, false"
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_pmc.json")), reverse=True):
         try:
-            d = json.load(open(fn))["pmc"].get(key)
+            d = next((v for k, v in json.load(open(fn))["pmc"].items() if k.startswith(key)), None)
         except Exception:
             d = None
         if d and d.get("hbm_traffic_bytes_per_launch"):
@@ -81,67 +84,77 @@ def parse_args():
 # CPU baseline (checker code, used here ONLY as the thing timed beside the GPU)
 # --------------------------------------------------------------------------
 def cpu_baseline(seconds, sample_blocks=None, seed=2001):
+    """The CPU path timed beside the GPU figure, on this host's cores, on a bounded sample of the same workload.
+    `kind: "reference"`: the reference's own FPGACacheEngine::decompress (oracle/_ref, compiled from /root/reference in the
+    development container; present on the GPU box as a prebuilt .so).  `port`: our C restatement of it (oracle/), always
+    timed and printed beside the reference figure (the restatement is what is guaranteed to travel)."""
     import ctypes as C
-    from oracle.bindings import Oracle, Reference, have_reference, _ptr, f32p, u8p, u32p
+    from oracle.bindings import Oracle, Reference, have_reference, _ptr, f32p, u8p, u16p, u32p
     n_threads = os.cpu_count() or 1
     if sample_blocks is None:
         # >= 128 blocks per thread and call, so the ctypes call (GIL released) dominates the Python loop
         sample_blocks = max(8192, 128 * n_threads)
     rng = np.random.default_rng(seed)
-    x = rng.standard_normal((sample_blocks, BLOCK_ELEMS)).astype(np.float16).astype(np.float32)
-    if have_reference():
-        kind = "reference"
-        ref = Reference()
-        L = ref.lib
-        recs = np.zeros((sample_blocks, 2 * BLOCK_ELEMS), np.uint8)
-        lens = np.zeros(sample_blocks, np.uint32)
-        scales = np.zeros(sample_blocks, np.float32)
-        L.ref_engine_compress_blocks(ref.engine, _ptr(x, f32p), sample_blocks, BLOCK_ELEMS, _ptr(scales, f32p),
-                                     _ptr(recs, u8p), 2 * BLOCK_ELEMS, _ptr(lens, u32p))
+    x = rng.standard_normal((sample_blocks, BLOCK_ELEMS)).astype(np.float16)
+    orc = Oracle()
+    scales, lens, recs = orc.compress_blocks_f16(x, 2, 0)
+    legs = 4 if have_reference() else 2
+    leg_s = max(1.0, 2.0 * seconds / legs)           # the whole baseline stays at ~2 x seconds of wall time
 
-        def work(lo, hi, out):
-            eng = L.ref_engine_new()          # one engine per thread, disjoint blocks
-            y = np.empty((hi - lo, BLOCK_ELEMS), np.float32)
-            t0 = time.perf_counter(); done = 0
-            while time.perf_counter() - t0 < seconds:
-                L.ref_engine_decompress_blocks(eng, _ptr(recs[lo:hi], u8p), 2 * BLOCK_ELEMS, _ptr(lens[lo:hi], u32p),
-                                               _ptr(scales[lo:hi], f32p), hi - lo, _ptr(y, f32p), BLOCK_ELEMS)
-                done += hi - lo
-            out.append((done, time.perf_counter() - t0))
-            L.ref_engine_delete(eng)
-    else:
-        kind = "port"
-        orc = Oracle()
-        L = orc.lib
-        scales, lens, recs = orc.compress_blocks_f16(x.astype(np.float16), 2, 0)
+    def port_work(lo, hi, out):
+        y = np.empty((hi - lo, BLOCK_ELEMS), np.uint16)
+        t0 = time.perf_counter(); done = 0
+        while time.perf_counter() - t0 < leg_s:
+            orc.lib.orc_decompress_blocks_f16(_ptr(recs[lo:hi], u8p), recs.shape[1], _ptr(lens[lo:hi], u32p), _ptr(scales[lo:hi], f32p),
+                                              hi - lo, BLOCK_ELEMS, 2, 0, _ptr(y, u16p), 1)
+            done += hi - lo
+        out.append((done, time.perf_counter() - t0))
 
-        def work(lo, hi, out):
-            y = np.empty(BLOCK_ELEMS, np.float32)
-            t0 = time.perf_counter(); done = 0
-            while time.perf_counter() - t0 < seconds:
-                for b in range(lo, hi):
-                    L.orc_decompress_f32(_ptr(recs[b], u8p), int(lens[b]), C.c_float(float(scales[b])), 0,
-                                         _ptr(y, f32p), BLOCK_ELEMS)
-                done += hi - lo
-            out.append((done, time.perf_counter() - t0))
+    def timed(work):
+        # 1 thread (the reference is single-threaded behind one mutex) ...
+        one = []
+        work(0, min(1024, sample_blocks), one)
+        v1 = one[0][0] / one[0][1]
+        # ... and all host cores, one engine per thread over disjoint blocks
+        outs, threads = [], []
+        per = sample_blocks // n_threads
+        for t in range(n_threads):
+            th = threading.Thread(target=work, args=(t * per, (t + 1) * per, outs))
+            th.start(); threads.append(th)
+        for th in threads:
+            th.join()
+        return round(sum(d for d, _ in outs) / max(e for _, e in outs), 1), round(v1, 1)
 
-    # 1 thread (the reference is single-threaded behind one mutex) ...
-    one = []
-    work(0, min(1024, sample_blocks), one)
-    v1 = one[0][0] / one[0][1]
-    # ... and all host cores, one engine per thread over disjoint blocks
-    outs, threads = [], []
-    per = sample_blocks // n_threads
-    for t in range(n_threads):
-        th = threading.Thread(target=work, args=(t * per, (t + 1) * per, outs))
-        th.start(); threads.append(th)
-    for th in threads:
-        th.join()
-    vall = sum(d for d, _ in outs) / max(e for _, e in outs)
-    return {"value": round(vall, 1), "unit": "blocks/s", "cores": n_threads, "kind": kind,
-            "value_1thread": round(v1, 1),
-            "sample": f"{sample_blocks} N(0,1) fp16 blocks (seed {seed}), INT8_DELTA_RLE decompress to fp32, "
-                      f"looped ~{seconds:.0f}s per leg; 1 thread and {n_threads} threads (one engine each)"}
+    pv, pv1 = timed(port_work)
+    port = {"value": pv, "value_1thread": pv1, "unit": "blocks/s", "cores": n_threads,
+            "what": "oracle/speckv_oracle.c (C restatement), INT8_DELTA_RLE decompress to fp16"}
+    sample = (f"{sample_blocks} N(0,1) fp16 blocks (seed {seed}), INT8_DELTA_RLE decompress, looped ~{leg_s:.0f}s per leg; "
+              f"1 thread and {n_threads} threads (one engine each)")
+    if not have_reference():
+        return {"value": pv, "unit": "blocks/s", "cores": n_threads, "kind": "port", "value_1thread": pv1, "sample": sample, "port": port}
+    ref = Reference()
+    L = ref.lib
+    x32 = x.astype(np.float32)
+    rrecs = np.zeros((sample_blocks, 2 * BLOCK_ELEMS), np.uint8)
+    rlens = np.zeros(sample_blocks, np.uint32)
+    rscales = np.zeros(sample_blocks, np.float32)
+    L.ref_engine_compress_blocks(ref.engine, _ptr(x32, f32p), sample_blocks, BLOCK_ELEMS, _ptr(rscales, f32p),
+                                 _ptr(rrecs, u8p), 2 * BLOCK_ELEMS, _ptr(rlens, u32p))
+
+    def ref_work(lo, hi, out):
+        eng = L.ref_engine_new()          # one engine per thread, disjoint blocks
+        y = np.empty((hi - lo, BLOCK_ELEMS), np.float32)
+        t0 = time.perf_counter(); done = 0
+        while time.perf_counter() - t0 < leg_s:
+            L.ref_engine_decompress_blocks(eng, _ptr(rrecs[lo:hi], u8p), 2 * BLOCK_ELEMS, _ptr(rlens[lo:hi], u32p),
+                                           _ptr(rscales[lo:hi], f32p), hi - lo, _ptr(y, f32p), BLOCK_ELEMS)
+            done += hi - lo
+        out.append((done, time.perf_counter() - t0))
+        L.ref_engine_delete(eng)
+
+    rv, rv1 = timed(ref_work)
+    return {"value": rv, "unit": "blocks/s", "cores": n_threads, "kind": "reference", "value_1thread": rv1,
+            "sample": sample + "; reference = FPGACacheEngine::decompress to fp32", "port": port}
 
 
 # --------------------------------------------------------------------------
@@ -194,18 +207,59 @@ def whole_job_rate(world, units_per_rank, steps, elapsed):
     return world * units_per_rank * steps / elapsed
 
 
+def spawn_own_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, one per GPU, as a
+    CHILD `python -m torch.distributed.run` of this same script with the same arguments, pass its output through (rank 0
+    prints the one JSON line) and leave with its exit code.  Called before torch is imported or anything touches the
+    GPU: this process never initialises HIP, and nothing is exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL / peer mappings across processes
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def host_dry_run(args, world, rank):
+    """SPECKV_BENCH_HOST_DRY_RUN=1 (tests/test_multirank_cpu.py, no GPU in the container): the ranks go through the same
+    launcher, rendezvous, timing contract and rank-0 line as a real run, with a host-side sleep in place of the step.  The
+    line says so (`dry_run`); it is never a measurement."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    elapsed = run_timed(lambda i: time.sleep(0.002), args.steps, args.warmup, lambda: None, dist)
+    n_blocks = args.tokens * args.layers * 8 * 128 * 2 * 2 // PAGE
+    if rank == 0:
+        print(json.dumps({"metric": "KV blocks/s fetch+decompress", "value": round(whole_job_rate(world, n_blocks, args.steps, elapsed), 1),
+                          "unit": "blocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "dry_run": "host sleep in place of the step: not a measurement"}),
+              flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     args = parse_args()
     if args.xgmi_child:
         return xgmi_child_main(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_own_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:                                   # never a 1-GPU line labelled as N, or the reverse
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("SPECKV_BENCH_HOST_DRY_RUN") == "1":
+        return host_dry_run(args, world, rank)
     import torch
     import cxl_speckv_amd as pkg
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the data path)"
     # test hook (one-GPU boxes): SPECKV_BENCH_SINGLE_GPU_TEST=1 runs every rank on GPU 0
     # with gloo so the N>1 control flow can be exercised without a second GPU
@@ -272,8 +326,14 @@ def main():
     compress_s = time.perf_counter() - t0
     dst = torch.empty((n_blocks, BLOCK_ELEMS), dtype=torch.float16, device="cuda")
 
+    # every step is ONE launch of the dominant kernel; the count lets profiles/summarize_r04.py find the timed launches
+    # of each variant in the rocprofv3 per-dispatch trace of this same process (0-based, in dispatch order, counted over
+    # the launches of this template instance only)
+    launches = [0]
+
     def step():
         lib.fetch_range(handle, 0, n_blocks, dst.data_ptr(), False, sp)
+        launches[0] += 1
 
     # HIP events on the launch stream bracket the timed region; the dominant
     # kernel's average launch duration is that interval / K (one launch per step)
@@ -286,18 +346,20 @@ def main():
             step()
             if i == steps - 1:
                 ev1.record(stream)
+        first = launches[0] + warmup
         elapsed = run_timed(timed_step, steps, warmup, torch.cuda.synchronize, dist, warm=lambda: step(), reduce_device=red_dev)
-        return elapsed, ev0.elapsed_time(ev1) / steps
+        assert launches[0] == first + steps
+        return elapsed, ev0.elapsed_time(ev1) / steps, [first, first + steps - 1]
 
     def alg():
         # c_i + 4 + 4096 per block; the record lengths are read back after the timed regions (it is a
         # device-to-host copy of the page table: not something to put between pool setup and the first timed step)
         return lib.stats().compressed_bytes + n_blocks * (4 + PAGE)
 
-    def figure(elapsed, kern_ms, steps):
+    def figure(elapsed, kern_ms, steps, span):
         return {"blocks_per_s": round(whole_job_rate(world, n_blocks, steps, elapsed), 1),
                 "ms_per_step": round(elapsed / steps * 1e3, 4), "avg_launch_ms": round(kern_ms, 4), "steps": steps,
-                "frac_hbm": round(alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+                "frac_hbm": round(alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "launches": span}
 
     # Three figures of the same step ("harden the headline"):
     #   as_called  W warm-up steps, then exactly K timed steps, first thing after pool setup (an idle MI355X sits at
@@ -307,20 +369,20 @@ def main():
     #   sustained  at least sustain_s seconds of back-to-back launches
     state["phase"] = "main"
     torch.cuda.synchronize()
-    e1, k1 = timed_region(args.steps, args.warmup)
+    e1, k1, s1 = timed_region(args.steps, args.warmup)
     alg_bytes = alg()
-    variants = {"as_called": dict(figure(e1, k1, args.steps), note="--warmup steps only, straight after pool setup (cold clocks)")}
+    variants = {"as_called": dict(figure(e1, k1, args.steps, s1), note="--warmup steps only, straight after pool setup (cold clocks)")}
     if args.no_variants:
         elapsed, kern_ms = e1, k1
         variants["as_called"]["note"] += "; this is `value` (--no-variants)"
     else:
         ramp_steps = ramp(step, torch.cuda.synchronize, args.ramp_ms)
-        elapsed, kern_ms = timed_region(args.steps, args.warmup)
-        variants["ramped"] = dict(figure(elapsed, kern_ms, args.steps), untimed_ramp_ms=args.ramp_ms, untimed_ramp_steps=ramp_steps,
+        elapsed, kern_ms, s2 = timed_region(args.steps, args.warmup)
+        variants["ramped"] = dict(figure(elapsed, kern_ms, args.steps, s2), untimed_ramp_ms=args.ramp_ms, untimed_ramp_steps=ramp_steps,
                                   note="same W + K steps after an untimed clock ramp; this is `value`")
         n_sus = max(args.steps, int(1.03 * args.sustain_s / max(kern_ms * 1e-3, 1e-6)) + 1)    # a little over: steps may run faster than the ramped figure
-        e3, k3 = timed_region(n_sus, 0)
-        variants["sustained"] = dict(figure(e3, k3, n_sus), seconds=round(e3, 3), note=f">= {args.sustain_s} s of back-to-back launches")
+        e3, k3, s3 = timed_region(n_sus, 0)
+        variants["sustained"] = dict(figure(e3, k3, n_sus, s3), seconds=round(e3, 3), note=f">= {args.sustain_s} s of back-to-back launches")
 
     # parity spot check without any checker code in the loop: the reference's own vectors (tests/golden/
     # codec_vectors.npz: inputs, RLE bytes, scale bits and fp32 outputs recorded from the reference) go through
@@ -365,7 +427,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8",
+            "dtype": DTYPE_LABEL,
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE configs[1]: 1xMI355X local-HBM pool, Llama-3-8B-shaped KV ({Lyr} layers, 8 KV heads, "
@@ -386,6 +448,12 @@ def main():
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "avg_launch_ms": round(kern_ms, 4),
+                "frac_as_called": variants["as_called"]["frac_hbm"],
+                "avg_launch_ms_as_called": variants["as_called"]["avg_launch_ms"],
+                "launches": {"kernel_instance": f"k_fetch_decompress<{args.scheme}, {args.quant}, false, 0>",
+                             **{k: v["launches"] for k, v in variants.items()},
+                             "note": "0-based indices of this instance's dispatches in this process, in dispatch order: "
+                                     "profiles/summarize_r04.py averages the same dispatches in the rocprofv3 kernel trace"},
                 "bytes_per_block": round(alg_bytes / n_blocks, 1),
                 "timed_region": "W warm-up steps then exactly K steps, preceded by an untimed clock ramp (variants.ramped); "
                                 "the cold as-called figure and a >= 1 s sustained one are in `variants`",
@@ -417,7 +485,12 @@ def main():
         x = run_xgmi_children(args, torch, dist, rank, world, red_dev)
         if rank == 0 and out is not None:
             out["xgmi"] = x
-            out["roofline_xgmi"] = roofline_xgmi_from(x, world)
+            rx = roofline_xgmi_from(x, world)
+            out["roofline_xgmi"] = rx
+            if rx and rx.get("frac") is not None and "skipped" not in rx:
+                # north_star's second fraction, beside the HBM one, in the object the driver reads
+                out["roofline"]["xgmi"] = {"frac": rx["frac"], "achieved": rx["achieved"], "peak": rx["peak_nominal_per_direction"],
+                                           "unit": "GB/s", "links": rx["links"], "layout": rx["layout"], "engine": rx["engine"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # rank 0 at N=1 only (bench contract)
         state["phase"] = "cpu_baseline"
         try:

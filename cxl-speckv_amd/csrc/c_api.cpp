@@ -13,6 +13,7 @@
 #include "engine.hpp"
 #include "placement.hpp"
 
+#include <cstring>
 #include <cstdio>
 #include <memory>
 #include <mutex>
@@ -541,6 +542,23 @@ speckv_status_t speckv_ext_stats(speckv_ext_stats_t* out)
     LOCK;
     if (!g_engine || g_closing || !out) return SPECKV_ERR_INVAL;
     return guarded([&] { return g_engine->stats(out); });
+}
+
+uint32_t speckv_ext_abi_version(void) { return SPECKV_EXT_ABI_VERSION; }
+
+speckv_status_t speckv_ext_stats_sized(void* out, size_t out_size, size_t* written)
+{
+    LOCK;
+    if (!g_engine || g_closing || !out) return SPECKV_ERR_INVAL;
+    return guarded([&] {
+        speckv_ext_stats_t st;
+        const int rc = g_engine->stats(&st);
+        if (rc != SPECKV_OK) return rc;
+        const size_t n = out_size < sizeof(st) ? out_size : sizeof(st);
+        std::memcpy(out, &st, n);
+        if (written) *written = n;
+        return static_cast<int>(SPECKV_OK);
+    });
 }
 
 double speckv_ext_layer_compression_ratio(uint32_t layer_id)

@@ -889,6 +889,18 @@ int Engine::note_async_write(hipStream_t s)
     return SPECKV_OK;
 }
 
+// After a write kernel has been queued on `s`: note the ordering, and if that cannot be done (no event, a failed record,
+// the 64-stream overflow path failing) wait for the stream instead -- the engine stream is then trivially ordered behind
+// the write.  Fails only if the wait itself fails.
+int Engine::note_async_write_or_wait(hipStream_t s)
+{
+    if (note_async_write(s) == SPECKV_OK) return SPECKV_OK;
+    (void)hipGetLastError();
+    if (is_capturing(s)) return SPECKV_OK;
+    HIP_TRY(hipStreamSynchronize(s));
+    return SPECKV_OK;
+}
+
 int Engine::order_after_writes()
 {
     for (auto& w : write_evs_)
@@ -1859,14 +1871,16 @@ int Engine::write_strided(uint64_t handle, uint64_t first, uint64_t step, uint64
     c.data = static_cast<uint8_t*>(const_cast<void*>(d_src));
     hipStream_t st = s ? s : stream_;
     HIP_TRY(launch_compress(c, st));
+    // The kernel is queued: from here on the host mirror follows it whatever else fails (an early return between
+    // the launch and these lines left the device table and the host flags disagreeing).
     note_use(a, s);
-    RC_TRY(note_async_write(s));
     for (uint64_t i = 0; i < n; ++i) {
         uint32_t& f = a->flags[first + i * step];
         if (a->scheme != SPECKV_COMP_FP16) f |= 4u; else f &= ~4u;
     }
     st_.total_compressions += n;
     st_.original_bytes += n * kPageSize;
+    RC_TRY(note_async_write_or_wait(s));
     if (!s) RC_TRY(wait_stream());
     return SPECKV_OK;
 }
@@ -1964,9 +1978,7 @@ int Engine::write_groups(const uint64_t* handles, const uint64_t* firsts, const 
     c.quant_mode = quant_mode_;
     c.n = static_cast<uint64_t>(n_groups) * n_each;
     HIP_TRY(launch_compress(c, s));
-    HIP_TRY(hipEventRecord(grp_ring_.ev[slot], s));
-    RC_TRY(note_async_write(s));
-    for (uint32_t i = 0; i < n_groups; ++i) {
+    for (uint32_t i = 0; i < n_groups; ++i) {           // the kernel is queued: host mirror first, then the orderings
         Allocation* a = as[i];
         note_use(a, s);
         for (uint64_t j = 0; j < n_each; ++j) {
@@ -1976,6 +1988,11 @@ int Engine::write_groups(const uint64_t* handles, const uint64_t* firsts, const 
     }
     st_.total_compressions += c.n;
     st_.original_bytes += c.n * kPageSize;
+    if (hipEventRecord(grp_ring_.ev[slot], s) != hipSuccess) {      // the staging slot must not be reused under the kernel
+        (void)hipGetLastError();
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    RC_TRY(note_async_write_or_wait(s));
     return SPECKV_OK;
 }
 
@@ -2967,11 +2984,16 @@ int Engine::compact(uint64_t handle, uint64_t* bytes_before, uint64_t* bytes_aft
     bool regular_pools = true;
     for (uint32_t k = 0; k < D; ++k) for (uint32_t j = 0; j < k; ++j) regular_pools = regular_pools && a->pool_of_residue[k] != a->pool_of_residue[j];
     std::vector<uint64_t> pbytes;
+    std::vector<bool> have(pools_.size(), false);
     for (int k : order) {
-        const uint64_t need = total[k];
+        // ONE extent per distinct pool.  A pool that stands for several residues (pool_of_residue may repeat one) keeps its
+        // place in the list with an empty extent, so that extents[j] / packed_bytes[j] still belong to order[j]; the
+        // residue-indexed reader (fetch_range_copy_engine) only runs when the residues' pools are distinct (packed_regular).
+        const uint64_t need = have[k] ? 0 : total[k];
+        have[k] = true;
         uint8_t* b = need ? static_cast<uint8_t*>(pools_[k]->alloc(need)) : nullptr;
         if (need && !b) { undo(); return SPECKV_ERR_NOMEM; }
-        base[k] = b;
+        if (need) base[k] = b;
         fresh.push_back({k, b, static_cast<size_t>(need), 0});
         pbytes.push_back(need);
     }
@@ -3022,12 +3044,15 @@ int Engine::unpack(Allocation* a)
     std::vector<int> order;
     for (uint32_t k = 0; k < D; ++k) order.push_back(a->pool_of_residue[k]);
     for (size_t k = 0; k < pools_.size(); ++k) if (std::find(order.begin(), order.end(), static_cast<int>(k)) == order.end()) order.push_back(static_cast<int>(k));
+    std::vector<bool> have(pools_.size(), false);
     for (int k : order) {
-        const size_t need = count[k] * stride;
+        const size_t need = have[k] ? 0 : count[k] * stride;            // one extent per distinct pool (see compact())
+        const uint64_t recs = have[k] ? 0 : count[k];
+        have[k] = true;
         uint8_t* b = need ? static_cast<uint8_t*>(pools_[k]->alloc(need)) : nullptr;
         if (need && !b) { undo(); SPECKV_ERR("a write to a compacted allocation needs %zu bytes of slots again: out of pool memory", need); return SPECKV_ERR_NOMEM; }
-        base[k] = b;
-        fresh.push_back({k, b, need, count[k]});
+        if (need) base[k] = b;
+        fresh.push_back({k, b, need, recs});
     }
     std::vector<uint64_t> next(pools_.size(), 0);
     for (uint64_t p = 0; p < a->n_pages; ++p) {

@@ -282,6 +282,7 @@ private:
     struct WriterEv { hipStream_t s; hipEvent_t ev; bool dirty; };
     std::vector<WriterEv> write_evs_;
     int note_async_write(hipStream_t s);
+    int note_async_write_or_wait(hipStream_t s);
     int order_after_writes();
 
     // completion accounting (speckv_kernel_module.c:194-215): launches on the engine stream whose size is known when

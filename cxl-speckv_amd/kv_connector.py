@@ -262,18 +262,23 @@ class SpeckvKVConnector:
         base = ((layer * 2 + kind) * self.T) * row
         return self.lib.access_batch(r.handle, [base + p * row for p in range(pos_begin, min(pos_end, r.length & ~1))])
 
-    def kv_rows(self, req_id: int, layer: int, kind: int):
-        """All stored rows of one layer as an fp16 tensor [positions][heads][dim] (fetch + decompress), tail included."""
+    def kv_rows(self, req_id: int, layer: int, kind: int, pos_begin: int = 0, pos_end: Optional[int] = None):
+        """The stored rows [pos_begin, pos_end) of one layer (default: all of them) as an fp16 tensor [positions][heads][dim]
+        (fetch + decompress of the pages that hold them), tail included.  Only those pages are read."""
         import torch
         r = self.requests[req_id]
+        pos_end = r.length if pos_end is None else pos_end
+        if not 0 <= pos_begin <= pos_end <= r.length:
+            raise ValueError(f"rows [{pos_begin}, {pos_end}) of a request with {r.length} positions")
         even = r.length & ~1
-        out = torch.empty((r.length, self.H, self.D), dtype=torch.float16, device="cuda")
-        if even:
+        lo, hi = pos_begin & ~1, min((pos_end + 1) & ~1, even)          # whole pages (2 positions each) of the stored part
+        out = torch.empty((max(hi, pos_end) - lo, self.H, self.D), dtype=torch.float16, device="cuda")
+        if hi > lo:
             with self._On(self, None) as st:
-                self.lib.fetch_range(r.handle, self._page(layer, kind, 0), even // 2, out.data_ptr(), False, st.cuda_stream)
-        if r.length & 1:
-            out[even] = (r.tail_k if kind == 0 else r.tail_v)[layer]
-        return out
+                self.lib.fetch_range(r.handle, self._page(layer, kind, lo), (hi - lo) // 2, out.data_ptr(), False, st.cuda_stream)
+        if pos_end > even:                                               # the odd last position lives in the tail
+            out[even - lo] = (r.tail_k if kind == 0 else r.tail_v)[layer]
+        return out[pos_begin - lo:pos_end - lo]
 
     PLAN_BUCKET = 512
 

@@ -94,7 +94,11 @@ _EXT_SIGNATURES = {
     "speckv_ext_predict_batch": [c_uint32, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p],
     "speckv_ext_predictor_load_lstm": [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int],
     "speckv_ext_stats": [ctypes.POINTER(Stats)],
+    "speckv_ext_stats_sized": [c_void_p, c_size_t, ctypes.POINTER(c_size_t)],
 }
+
+
+EXT_ABI_VERSION = 4        # SPECKV_EXT_ABI_VERSION of include/speckv_ext.h
 
 
 def bind_ext(lib):
@@ -118,6 +122,17 @@ def bind_ext(lib):
         fn.restype = res
         fn.argtypes = args
         found.append(name)
+    # the structs of include/speckv_ext.h are mirrored by hand in this file: a library built from another header revision
+    # would write past (or short of) them
+    try:
+        ver = lib.speckv_ext_abi_version
+    except AttributeError:
+        ver = None
+    if ver is not None:
+        ver.restype, ver.argtypes = c_uint32, []
+        if ver() != EXT_ABI_VERSION:
+            raise RuntimeError(f"libcxlspeckv.so speaks speckv_ext ABI {ver()}, this binding {EXT_ABI_VERSION}: rebuild the library")
+        found.append("speckv_ext_abi_version")
     return found
 
 
@@ -401,5 +416,8 @@ class SpeckvLib:
 
     def stats(self):
         s = Stats()
-        self._ext("speckv_ext_stats", ctypes.byref(s))
+        n = c_size_t()
+        self._ext("speckv_ext_stats_sized", ctypes.byref(s), ctypes.sizeof(s), ctypes.byref(n))
+        if n.value != ctypes.sizeof(s):
+            raise RuntimeError(f"speckv_ext_stats_sized wrote {n.value} bytes, the binding's struct has {ctypes.sizeof(s)}")
         return s

@@ -367,7 +367,9 @@ speckv_status_t speckv_ext_migrate(speckv_handle_t handle, uint64_t first_page,
  * of cache_engine.cpp:62-78), and the copy-engine fetch moves record bytes instead of slots.  Reads are unaffected (they go
  * through the page table); a later write or migration first unpacks the allocation into slots again, so seal sequences that
  * are parked in the pool, not ones a decode loop appends to.  *bytes_before / *bytes_after (optional): pool bytes the
- * allocation holds.  Synchronous. */
+ * allocation holds.  Synchronous.  The packed extents are allocated before the slots are released (the records move in one
+ * pass), so the pool needs room for the packed size on top of the slots for the duration of the call: SPECKV_ERR_NOMEM
+ * leaves the allocation as it was. */
 speckv_status_t speckv_ext_compact(speckv_handle_t handle, uint64_t* bytes_before, uint64_t* bytes_after);
 
 /* ---- statistics (Statistics structs: cxl_memory_manager.h:73-83,
@@ -394,7 +396,15 @@ typedef struct {
     uint64_t sealed_allocations;    /* live allocations packed by speckv_ext_compact */
     uint64_t compactions;           /* speckv_ext_compact calls that packed an allocation */
 } speckv_ext_stats_t;
+/* The struct only ever grows at its end.  speckv_ext_stats() writes sizeof(speckv_ext_stats_t) of THIS header: a caller
+ * compiled against an older header must use the sized form, which writes min(out_size, the library's size) bytes (fields
+ * are never reordered, so a prefix is a valid older struct); *written (optional) = bytes written.
+ * SPECKV_EXT_ABI_VERSION is bumped whenever a struct of this header grows or an entry point changes meaning;
+ * speckv_ext_abi_version() returns the library's value (the Python binding refuses a mismatch). */
+#define SPECKV_EXT_ABI_VERSION 4u
+uint32_t        speckv_ext_abi_version(void);
 speckv_status_t speckv_ext_stats(speckv_ext_stats_t* out);
+speckv_status_t speckv_ext_stats_sized(void* out, size_t out_size, size_t* written);
 
 /* ---- address encodings of the reference, pure functions ----
  * speckv_ext_encode_virt_page : SpeckvAllocator::encode_virt_page, speckv_allocator.cpp:92-103

@@ -13,6 +13,8 @@
 #define _POSIX_C_SOURCE 200809L
 #include "speckv_oracle.h"
 
+#define ORC_STACK_ELEMS 4096   /* one KV block is 2048 elements */
+
 #include <fcntl.h>
 #include <math.h>
 #include <stdlib.h>
@@ -351,12 +353,15 @@ size_t orc_compress_f32(const float* x, size_t n, int mode, float* scale, uint8_
 size_t orc_decompress_f32(const uint8_t* rle, size_t len, float scale, int mode,
                           float* y, size_t cap)
 {   /* cache_engine.cpp:84-116 */
-    int8_t* d = (int8_t*)malloc(cap ? cap : 1);
-    int8_t* q = (int8_t*)malloc(cap ? cap : 1);
+    /* block-sized outputs use the stack: a malloc/free pair per block serialises the threaded batch driver */
+    int8_t sd[ORC_STACK_ELEMS], sq[ORC_STACK_ELEMS];
+    int8_t* d = cap <= ORC_STACK_ELEMS ? sd : (int8_t*)malloc(cap);
+    int8_t* q = cap <= ORC_STACK_ELEMS ? sq : (int8_t*)malloc(cap);
     size_t n = orc_rle_decode(rle, len, d, cap, NULL);
     orc_delta_decode(d, n, q);
     orc_dequantize(q, n, scale, mode, y);
-    free(d); free(q);
+    if (d != sd) free(d);
+    if (q != sq) free(q);
     return n;
 }
 
@@ -511,10 +516,11 @@ size_t orc_decompress_block_f16(const uint8_t* rec, size_t len, float scale, int
         memcpy(y, rec, 2 * n);
         return n;
     }
-    float* yf = (float*)malloc((cap ? cap : 1) * sizeof(float));
+    float sy[ORC_STACK_ELEMS];
+    float* yf = cap <= ORC_STACK_ELEMS ? sy : (float*)malloc(cap * sizeof(float));
     size_t n = orc_decompress_block_f32(rec, len, scale, scheme, mode, yf, cap);
     for (size_t i = 0; i < n; ++i) y[i] = orc_float_to_half(yf[i]);
-    free(yf);
+    if (yf != sy) free(yf);
     return n;
 }
 

@@ -863,6 +863,115 @@ def test_vllm_shaped_connector_round_trip(oracle, scheme):
         lib.finalize()
 
 
+def test_vllm_connector_prefix_hit_chunked_prefill_and_separate_roles():
+    """ADVICE r3 (both medium findings).  (1) A request whose first `num_computed_tokens` tokens already sit in vLLM's own
+    prefix cache loads the tokens [computed, computed + matched) -- not [0, matched): the slots of the prefix stay untouched,
+    the slots behind it receive the right rows.  (2) A prompt prefilled in chunks is stored once, in the step whose chunk
+    completes it, from all of its slots.  (3) The scheduler-role and worker-role connectors are SEPARATE objects here (vLLM
+    runs them in different processes); only the metadata object passes between them, and the scheduler-role one is built
+    without a library."""
+    torch = torch_mod()
+    from types import SimpleNamespace as NS
+    from cxl_speckv_amd.vllm_connector import SpeckvVllmConnector, slot_mapping_for
+    lib = open_lib()
+    try:
+        L, H, D, BS, NB = 2, 8, 128, 16, 64
+        sched = SpeckvVllmConnector(None, num_layers=L, num_kv_heads=H, head_dim=D, block_size=BS, max_tokens=256, scheme="fp16")
+        work = SpeckvVllmConnector(lib, num_layers=L, num_kv_heads=H, head_dim=D, block_size=BS, max_tokens=256, scheme="fp16")
+        with pytest.raises(RuntimeError, match="scheduler role"):
+            sched.register_kv_caches({})
+        gen = torch.Generator(device="cuda"); gen.manual_seed(77)
+        names = [f"model.layers.{i}.self_attn.attn" for i in range(L)]
+        caches = {n: torch.zeros((2, NB, BS, H, D), dtype=torch.float16, device="cuda") for n in names}
+        work.register_kv_caches(caches)
+        n, blk = 75, [5, 9, 2, 40, 41]                     # 75 tokens: an odd length (tail row), 5 blocks of 16
+        truth = {li: torch.randn((2, n, H, D), generator=gen, device="cuda").to(torch.float16) for li in range(L)}
+
+        def model_writes(lo, hi):                           # the forward pass of one chunk fills its slots
+            slots = torch.tensor(slot_mapping_for(blk, BS, hi - lo, lo), device="cuda")
+            for li, name in enumerate(names):
+                caches[name].reshape(2, NB * BS, H, D)[:, slots] = truth[li][:, lo:hi]
+
+        def worker_step(meta, lo, hi):
+            work.bind_connector_metadata(meta)
+            work.start_load_kv(None)
+            model_writes(lo, hi)
+            for name in names:
+                work.save_kv_layer(name, caches[name], None)
+            work.wait_for_save()
+            work.clear_connector_metadata()
+
+        # ---- chunked prefill: 32 + 32 + 11 tokens over three steps; only the last step stores
+        req = NS(request_id="r1", num_tokens=n)
+        assert sched.get_num_new_matched_tokens(req, 0) == (0, False)
+        m1 = sched.build_connector_meta(NS(scheduled_new_reqs=[NS(req_id="r1", prompt_token_ids=list(range(n)), block_ids=[blk[:2]], num_computed_tokens=0)],
+                                           num_scheduled_tokens={"r1": 32}))
+        assert m1.requests == []
+        worker_step(m1, 0, 32)
+        assert work.conn.requests == {}                    # nothing reaches the pool before the prompt is complete
+        m2 = sched.build_connector_meta(NS(scheduled_new_reqs=[], num_scheduled_tokens={"r1": 32},
+                                           scheduled_cached_reqs=NS(req_ids=["r1"], new_block_ids=[[blk[2:4]]], num_computed_tokens=[32])))
+        assert m2.requests == []
+        worker_step(m2, 32, 64)
+        m3 = sched.build_connector_meta(NS(scheduled_new_reqs=[], num_scheduled_tokens={"r1": 11},
+                                           scheduled_cached_reqs=[NS(req_id="r1", new_block_ids=[blk[4:]], num_computed_tokens=64)]))
+        assert [(r.is_store, r.first_token, r.num_tokens) for r in m3.requests] == [(True, 0, n)]
+        assert m3.requests[0].slot_mapping == slot_mapping_for(blk, BS, n)
+        worker_step(m3, 64, n)
+        torch.cuda.synchronize()
+        eid = m3.requests[0].engine_id
+        for li in range(L):
+            for kind in (0, 1):
+                assert torch.equal(work.conn.kv_rows(eid, li, kind), truth[li][kind]), (li, kind)       # all 75 rows, tail included
+                assert torch.equal(work.conn.kv_rows(eid, li, kind, 33, 70), truth[li][kind][33:70])    # a range that starts on an odd row
+
+        # ---- the request comes back with a 32-token hit in vLLM's own prefix cache: external tokens are [32, 64)
+        for t in caches.values():
+            t.zero_()
+        new_blk = [30, 31, 17, 18, 19]
+        prefix = {li: caches[names[li]].reshape(2, NB * BS, H, D) for li in range(L)}
+        pre_slots = torch.tensor(slot_mapping_for(new_blk, BS, 32), device="cuda")
+        for li in range(L):
+            prefix[li][:, pre_slots] = 7.0                  # what vLLM's own cache holds for the prefix: must not be rewritten
+        req = NS(request_id="r1", num_tokens=n)
+        matched, is_async = sched.get_num_new_matched_tokens(req, 32)
+        assert (matched, is_async) == ((n - 1) // BS * BS - 32, False)      # 64 usable - 32 computed
+        sched.update_state_after_alloc(req, NS(get_block_ids=lambda: [new_blk]), matched)
+        m4 = sched.build_connector_meta(NS(scheduled_new_reqs=[NS(req_id="r1", prompt_token_ids=list(range(n)), block_ids=[new_blk], num_computed_tokens=64)],
+                                           num_scheduled_tokens={"r1": n - 64}))
+        assert [(r.is_store, r.first_token, r.num_tokens) for r in m4.requests] == [(False, 32, 32)]
+        assert m4.requests[0].slot_mapping == slot_mapping_for(new_blk, BS, 32, 32)
+        work.bind_connector_metadata(m4)
+        work.start_load_kv(None)
+        work.clear_connector_metadata()
+        torch.cuda.synchronize()
+        ext_slots = torch.tensor(slot_mapping_for(new_blk, BS, 32, 32), device="cuda")
+        for li in range(L):
+            assert torch.equal(prefix[li][:, ext_slots], truth[li][:, 32:64]), li
+            assert bool((prefix[li][:, pre_slots] == 7.0).all())                                       # the prefix was left alone
+            rest = torch.tensor(slot_mapping_for(new_blk, BS, n - 64, 64), device="cuda")
+            assert float(prefix[li][:, rest].abs().max()) == 0.0                                       # nothing beyond the match
+
+        # ---- a load for a request this worker never saved fails with a clear error, not a KeyError
+        bad = sched.build_connector_meta(NS(scheduled_new_reqs=[]))
+        from cxl_speckv_amd.vllm_connector import ReqMeta
+        bad.requests.append(ReqMeta("ghost", 999, [0], 0, 1, False))
+        work.bind_connector_metadata(bad)
+        with pytest.raises(RuntimeError, match="not in this worker's pool"):
+            work.start_load_kv(None)
+        work.clear_connector_metadata()
+
+        # ---- free travels with the next step's metadata
+        sched.free_request("r1")
+        assert sched.get_num_new_matched_tokens(NS(request_id="r1", num_tokens=n), 0) == (0, False)
+        m5 = sched.build_connector_meta(NS(scheduled_new_reqs=[]))
+        assert m5.free_engine_ids == [eid]
+        work.bind_connector_metadata(m5)
+        assert eid not in work.conn.requests
+    finally:
+        lib.finalize()
+
+
 @pytest.mark.parametrize("scheme", [3, 4])
 def test_attention_calls_on_different_streams_share_the_scratch_safely(scheme):
     """The split partials of every fused-attention call live in ONE scratch buffer of the engine.  Calls issued back to back on

@@ -183,6 +183,32 @@ def test_single_rank_needs_no_process_group():
     assert bench.whole_job_rate(1, 131072, 3, 0.5) == 131072 * 3 / 0.5
 
 
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must come back with ONE line that says
+    n_gpus == 2.  bench.py starts `python -m torch.distributed.run` as a child BEFORE importing torch or touching the GPU;
+    SPECKV_BENCH_HOST_DRY_RUN=1 replaces the step with a host sleep (no GPU in this container), everything else -- launcher,
+    rendezvous on 127.0.0.1, barrier + MAX-over-ranks timing, rank-0 line, exit code -- is the real control flow."""
+    import json
+    import subprocess
+    env = dict(os.environ, SPECKV_BENCH_HOST_DRY_RUN="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout                              # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and "dry_run" in d
+    assert d["ms_per_step"] >= 2.0                                # six 2 ms host steps were really timed
+    assert abs(d["value"] - 2 * 131072 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01     # whole-job: both ranks' units
+    # a launcher that disagrees with --gpus is an error, not a silently relabelled 1-GPU line
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                        env=env2, capture_output=True, text=True, timeout=300)
+    assert p2.returncode != 0 and "WORLD_SIZE" in (p2.stderr + p2.stdout)
+
+
 def test_committed_bench_line_has_the_contract_fields():
     """The bench line committed with the round's profile (profiles/r03l_bench.json = stdout of `python bench.py` on the
     MI355X box) carries every field of the driver's contract, with the tier's meaning: metric and config from
