@@ -910,7 +910,7 @@ constexpr uint32_t kMaxSplits = 2048;
 __global__ __launch_bounds__(512) void k_attend_combine(const float* __restrict__ part_acc, const float* __restrict__ part_ml,
                                                         uint32_t g, uint32_t n_splits, float* __restrict__ out,
                                                         float* __restrict__ lse, const AttendSeq* __restrict__ seqs,
-                                                        uint32_t heads, uint32_t skip_single)
+                                                        uint32_t heads, uint32_t skip_single, AttendArgs::Stream sk, uint32_t n_tiles)
 {
     __shared__ float w[kMaxSplits];
     __shared__ float red[8];
@@ -923,6 +923,10 @@ __global__ __launch_bounds__(512) void k_attend_combine(const float* __restrict_
         if (skip_single && sq.n_splits == 1u) return;        // written by the attention kernel itself (workgroup-uniform)
         n_splits = sq.n_splits;
         part0 = sq.part_base + static_cast<uint64_t>(rowq % heads) * n_splits;
+    }
+    if (sk.n_wgs) {                                                    // stream form: the row's own count, slots max_slots apart
+        part0 = static_cast<uint64_t>(rowq) * sk.max_slots;
+        n_splits = attend_stream_count(rowq / heads, n_tiles, sk.len, sk.rem);
     }
     const float* ml = part_ml + part0 * 32u;
     auto block_reduce = [&](float v, bool is_max) {
@@ -976,7 +980,7 @@ constexpr uint32_t kSmallCombineSplits = 8;
 __global__ __launch_bounds__(256) void k_attend_combine_small(const float* __restrict__ part_acc, const float* __restrict__ part_ml,
                                                               uint32_t g, uint32_t n_splits, float* __restrict__ out,
                                                               float* __restrict__ lse, const AttendSeq* __restrict__ seqs,
-                                                              uint32_t heads, uint32_t skip_single, uint32_t n_rows)
+                                                              uint32_t heads, uint32_t skip_single, uint32_t n_rows, AttendArgs::Stream sk, uint32_t n_tiles)
 {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const uint32_t lane = threadIdx.x & 63u, c = lane & 15u, kb = lane >> 4;
@@ -988,6 +992,10 @@ __global__ __launch_bounds__(256) void k_attend_combine_small(const float* __res
         if (skip_single && sq.n_splits == 1u) return;
         n_splits = sq.n_splits;
         part0 = sq.part_base + static_cast<uint64_t>(rowq % heads) * n_splits;
+    }
+    if (sk.n_wgs) {                                                    // stream form (wave-uniform)
+        part0 = static_cast<uint64_t>(rowq) * sk.max_slots;
+        n_splits = attend_stream_count(rowq / heads, n_tiles, sk.len, sk.rem);
     }
     const float* ml = part_ml + part0 * 32u + c;
     float m[kSmallCombineSplits], l[kSmallCombineSplits];
@@ -1125,15 +1133,17 @@ hipError_t launch_qk_scores_fp8_linear(const AttendArgs& a, uint32_t n_layers, f
 hipError_t launch_attend_combine(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s)
 {
     if (n_layers == 0) return hipSuccess;
-    if (a.n_splits > kMaxSplits) return hipErrorInvalidValue;
-    if (a.n_splits <= kSmallCombineSplits && !getenv("SPECKV_ATTEND_BIG_COMBINE")) {
+    const uint32_t splits = a.stream.n_wgs ? a.stream.max_slots : a.n_splits;      // most partials a row can have
+    const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
+    if (splits > kMaxSplits) return hipErrorInvalidValue;
+    if (splits <= kSmallCombineSplits && !getenv("SPECKV_ATTEND_BIG_COMBINE")) {
         const uint32_t n_rows = n_layers * a.heads;
         hipLaunchKernelGGL(k_attend_combine_small, dim3((n_rows + 3u) / 4u), dim3(256), 0, s, a.part_acc, a.part_ml, a.g,
-                           a.n_splits, d_out, d_lse, a.seqs, a.heads, (a.direct_out && a.direct_per_seq) ? 1u : 0u, n_rows);
+                           a.n_splits, d_out, d_lse, a.seqs, a.heads, (a.direct_out && a.direct_per_seq) ? 1u : 0u, n_rows, a.stream, n_tiles);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_attend_combine, dim3(n_layers * a.heads * a.g), dim3(512), 0, s, a.part_acc, a.part_ml, a.g,
-                       a.n_splits, d_out, d_lse, a.seqs, a.heads, (a.direct_out && a.direct_per_seq) ? 1u : 0u);
+                       a.n_splits, d_out, d_lse, a.seqs, a.heads, (a.direct_out && a.direct_per_seq) ? 1u : 0u, a.stream, n_tiles);
     return hipGetLastError();
 }
 

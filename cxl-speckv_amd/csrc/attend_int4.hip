@@ -782,11 +782,278 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
     store_partial(a, part, row, my_splits, c, kb, m_run, l_run, acc);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Linear form, WHOLE RECORDS per workgroup: 8 waves = the 8 kv heads.  The 4-head kernel above asks memory for 256-byte
+// segments of 1152-byte records (the other four heads' segments are fetched by another workgroup at another time): a
+// read probe of that address pattern tops out at 0.80 of HBM peak, whole records at 0.85-0.88
+// (profiles/r03_int4_ablation.txt, third series).  Here a tile's K records (16 x 1152 B) and V records are consumed
+// inside ONE workgroup: every 128-byte line is requested once, a page's 1 KiB of nibbles by one DMA instruction (lines
+// 1..8 of its record), its scale line together with 3 others'.
+//   per wave and tile: 4 full DMAs (K and V nibbles of pages 2w, 2w+1) and one with 32 active lanes (4 scale lines) = 5
+//   vector-memory operations, the same in every wave, so the vmcnt arithmetic is uniform;
+//   two LDS stages of 36 KiB per workgroup, two workgroups (16 waves) per CU: the workgroups of a CU run out of phase, so
+//   while one consumes a tile the other's DMAs (and its own next tile's) are in flight.  (Three stages in one workgroup
+//   per CU -- DMAs of tile t+2 issued before tile t is consumed, one barrier per tile -- measured 0.64 against 0.68 for
+//   the 4-head kernel: with two waves per SIMD the arithmetic of a tile, ~350 instructions per wave in one dependent
+//   chain, takes longer than the tile's bytes take to arrive.  profiles/r04_int4_wg8.txt)
+// LDS stage:  K rows [32][512 B] | V rows [32][512 B] | K scale lines [16][128 B] | V scale lines [16][128 B]
+//   a position row = 8 heads x 64 B; its thirty-two 16-byte pieces are stored XOR-ed by (row & 15) (chosen on the SOURCE
+//   side of the DMA), K scale lines by (page & 7), V scale lines by (page / 2) & 3: the operand reads of the arithmetic
+//   above (ds_read_b128 of 16 rows x one piece, ds_read_b32 of rows 4 kb + j, ds_read_u16 of scales) stay conflict-free.
+// STREAM form (AttendArgs::stream.n_wgs != 0; many layers of one sequence): the launch's tiles in layer-major order are cut
+// into n_wgs contiguous pieces of equal length, one per workgroup, n_wgs = what is resident at once.  A workgroup streams
+// through its piece -- across a layer boundary the DMA pipeline just goes on; the finished layer's partial is stored, the
+// next layer's query rows are loaded -- so the launch has ONE pipeline fill per workgroup, no partial last round, and a
+// layer gets ceil(n_tiles / len) + 1 partials at most instead of one per split of a fixed grid (the partial stores and the
+// merge launch cost 9 % of the fixed-grid launch at 16 splits x 80 layers).  The merge derives each row's partial count
+// from the same arithmetic (attend_stream_wg_of).
+// The arithmetic of a tile is the one of the other kernels (score_block, softmax_tile, pv_tile): one wave = one head.
+namespace {
+constexpr uint32_t kW8V = 16384u, kW8Ks = 32768u, kW8Vs = 34816u, kW8Stage = 36864u;
+
+__device__ __forceinline__ void w8_take_k(uint32_t rd, uint32_t rs, u32x4& k0, u32x4& k1, uint32_t& s0, uint32_t& s1)
+{
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:8192\n\t"
+                 "ds_read_u16 %2, %5\n\tds_read_u16 %3, %5 offset:1024\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(k0), "=&v"(k1), "=&v"(s0), "=&v"(s1) : "v"(rd), "v"(rs) : "memory");
+}
+__device__ __forceinline__ void w8_take_v(const uint32_t (&rd)[4], uint32_t rs, uint32_t (&w)[8], uint32_t (&sc)[8])
+{
+    asm volatile("ds_read_b32 %0, %16\n\tds_read_b32 %1, %17\n\tds_read_b32 %2, %18\n\tds_read_b32 %3, %19\n\t"
+                 "ds_read_b32 %4, %16 offset:8192\n\tds_read_b32 %5, %17 offset:8192\n\tds_read_b32 %6, %18 offset:8192\n\tds_read_b32 %7, %19 offset:8192\n\t"
+                 "ds_read_u16 %8, %20\n\tds_read_u16 %9, %20 offset:64\n\tds_read_u16 %10, %20 offset:128\n\tds_read_u16 %11, %20 offset:192\n\t"
+                 "ds_read_u16 %12, %20 offset:1024\n\tds_read_u16 %13, %20 offset:1088\n\tds_read_u16 %14, %20 offset:1152\n\tds_read_u16 %15, %20 offset:1216\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]),
+                   "=&v"(sc[0]), "=&v"(sc[1]), "=&v"(sc[2]), "=&v"(sc[3]), "=&v"(sc[4]), "=&v"(sc[5]), "=&v"(sc[6]), "=&v"(sc[7])
+                 : "v"(rd[0]), "v"(rd[1]), "v"(rd[2]), "v"(rd[3]), "v"(rs) : "memory");
+}
+} // namespace
+
+#ifndef SPECKV_INT4_W8_WAVES
+#define SPECKV_INT4_W8_WAVES 4
+#endif
+// HALVES = 2 (fixed-grid and batch launches): 16 waves, the workgroup's run of tiles cut in two, waves 8..15 take the second
+// half with LDS stages of their own; at the end their (m, l, accumulators) cross over through LDS and waves 0..7 store the
+// merged result -- a row that fits one workgroup needs no partials and no merge launch, and a batch of 256 sequences fills
+// 256 CUs with 16 waves each.  One workgroup per CU then (144 KiB of LDS).  The stream form keeps HALVES = 1, two per CU.
+template <int HALVES>
+__global__ __launch_bounds__(512 * HALVES) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4_W8_WAVES, SPECKV_INT4_W8_WAVES))) void k_attend_int4_wg8(AttendArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[HALVES * 2 * kW8Stage];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t head = wave & 7u, half = wave >> 3;                   // wave = kv head (x half of the run)
+    const uint32_t c = lane & 15u, kb = lane >> 4;
+    const uint32_t n_tiles = (a.n_pages + 15u) / 16u;                    // (batch form: set per sequence below)
+    // ---- this workgroup's run of tiles: `count` tiles from tile `ct` of layer `cl` on, in layer-major order
+    uint32_t cl, ct, count, slot = 0u, my_splits = a.n_splits;
+    uint64_t part = 0u;
+    const bool stream = a.stream.n_wgs != 0u;
+    uint32_t tiles_in_layer = n_tiles;
+    if (stream) {
+        const uint64_t g0 = attend_stream_begin(blockIdx.x, a.stream.len, a.stream.rem), g1 = attend_stream_begin(blockIdx.x + 1u, a.stream.len, a.stream.rem);
+        cl = static_cast<uint32_t>(g0 / n_tiles);
+        ct = static_cast<uint32_t>(g0 - static_cast<uint64_t>(cl) * n_tiles);
+        count = static_cast<uint32_t>(g1 - g0);
+        slot = blockIdx.x - attend_stream_wg_of(static_cast<uint64_t>(cl) * n_tiles, a.stream.len, a.stream.rem);
+        my_splits = 0u;                                                   // (never the direct output: a layer has several pieces)
+    } else {
+        const uint32_t split = a.rows_first ? blockIdx.y : blockIdx.x;
+        cl = a.rows_first ? blockIdx.x : blockIdx.y;                      // batch form: the sequence index
+        part = (static_cast<uint64_t>(cl) * 8u + head) * a.n_splits + split;
+        if (a.seqs) {                                                    // workgroup-uniform: per-sequence geometry
+            const AttendSeq sq = a.seqs[cl];
+            if (split >= sq.n_splits) {
+                if (sq.n_splits == 0u && split == 0u && a.direct_out && a.direct_per_seq == 2u)
+                    attend_zero_rows(a.direct_out, a.direct_lse, a.g, static_cast<uint64_t>(cl) * 8u + head, lane);
+                return;
+            }
+            a.lin_base = sq.lin_base;
+            a.k_first = sq.k_first + static_cast<uint64_t>(a.batch_layer) * sq.layer_pages;
+            a.v_first = sq.v_first + static_cast<uint64_t>(a.batch_layer) * sq.layer_pages;
+            a.n_pages = sq.n_pages;
+            a.tiles_per_split = sq.tiles_per_split;
+            a.layer_stride = 0u;                                         // the sequence's own region: no layer offset
+            my_splits = sq.n_splits;
+            part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
+            tiles_in_layer = (sq.n_pages + 15u) / 16u;
+        }
+        ct = split * a.tiles_per_split;
+        count = ct < tiles_in_layer ? min(a.tiles_per_split, tiles_in_layer - ct) : 0u;
+    }
+    const uint32_t out_row0 = cl;                                        // (batch form: the row index is the sequence, the addresses use layer 0)
+    // every wave runs `iters` iterations (the barriers are the workgroup's); this half's own tiles are the first `count` of them
+    uint32_t iters = count;
+    if (HALVES == 2) {
+        iters = (count + 1u) / 2u;
+        ct += half * iters;
+        count = half ? count - iters : iters;
+    }
+    const float qscale = a.scale_log2e;
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    f16x8 qv[4];
+    auto load_q = [&](uint32_t row_layer) {
+        const uint16_t* q16 = reinterpret_cast<const uint16_t*>(a.q8) + ((static_cast<uint64_t>(row_layer) * 8u + head) * a.g + c) * 128u + kb * 32u;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            uint4 t = make_uint4(0u, 0u, 0u, 0u);
+            if (c < a.g) t = *reinterpret_cast<const uint4*>(q16 + 8 * st);
+            qv[st] = q_operand(t);
+        }
+        // the rows must have arrived before the next DMA is issued: the compiler would otherwise place its own vmcnt(0)
+        // for them at their first use, inside the loop, and drain the pipeline there in every iteration
+        asm volatile("" :: "v"(qv[0]), "v"(qv[1]), "v"(qv[2]), "v"(qv[3]));
+    };
+    load_q(cl);
+
+    if (iters != 0u) {                                                   // workgroup-uniform
+        const uint32_t tile_bytes = 16u * kInt4RecBytes;
+        const uint32_t addr_layer = a.seqs ? 0u : cl;
+        const uint64_t layer_bytes = a.layer_stride * kInt4RecBytes;
+        // issue cursor (scalar): K / V record pointers of the next tile to request, and that tile's index in its layer
+        const uint8_t* kptr = a.lin_base + (a.k_first + addr_layer * a.layer_stride) * kInt4RecBytes + static_cast<uint64_t>(ct) * tile_bytes;
+        const uint8_t* vptr = a.lin_base + (a.v_first + addr_layer * a.layer_stride) * kInt4RecBytes + static_cast<uint64_t>(ct) * tile_bytes;
+        uint32_t itile = ct;
+        // ---- this wave's share of the fetch.  Nibbles: pages 2w and 2w+1 of K and of V, one instruction per page: lanes
+        // 0..31 -> the page's slot 0 (row 4w or 4w+2), lanes 32..63 -> slot 1; LDS piece y of row r holds source piece y ^ (r & 15)
+        const uint32_t pslot = lane >> 5, y = lane & 31u;
+        const uint32_t ra = 4u * head + pslot, rb = ra + 2u;
+        const uint32_t ga = (2u * head) * kInt4RecBytes + 128u + pslot * 512u + ((y ^ (ra & 15u)) * 16u);
+        const uint32_t gb = (2u * head + 1u) * kInt4RecBytes + 128u + pslot * 512u + ((y ^ (rb & 15u)) * 16u);
+        // scale lines (lanes 0..31 only): waves 0..3 the K lines of pages 4w .. 4w+3, waves 4..7 the V lines of pages 4(w-4) ..
+        const uint32_t spage = 4u * (head & 3u) + ((lane & 31u) >> 3);
+        const uint32_t gs = spage * kInt4RecBytes + (((lane & 7u) ^ ((head < 4u) ? (spage & 7u) : ((spage >> 1) & 3u))) * 16u);
+        const uint32_t lbase = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&lds[0]))) + half * 2u * kW8Stage;
+        const uint32_t dn = 4u * head * 512u, dsl = ((head < 4u) ? kW8Ks : kW8Vs) + 4u * (head & 3u) * 128u;    // destinations inside a stage
+        auto issue = [&](uint32_t stage_off) {
+            const uint32_t dst = lbase + stage_off;
+            dma16(dst + dn, kptr, ga);
+            dma16(dst + dn + 1024u, kptr, gb);
+            dma16(dst + kW8V + dn, vptr, ga);
+            dma16(dst + kW8V + dn + 1024u, vptr, gb);
+            if (lane < 32u) dma16(dst + dsl, (head < 4u) ? kptr : vptr, gs);
+            kptr += tile_bytes; vptr += tile_bytes;
+            if (++itile == tiles_in_layer) {                             // (stream form: on into the next layer's regions)
+                itile = 0u;
+                kptr += layer_bytes - static_cast<uint64_t>(tiles_in_layer) * tile_bytes;
+                vptr += layer_bytes - static_cast<uint64_t>(tiles_in_layer) * tile_bytes;
+            }
+        };
+        // ---- reader addresses inside stage 0 (see the 4-head kernel: the same maps with 512-byte rows and heads 0..7)
+        const uint32_t h1 = head >> 1;
+        const uint32_t rdk = lbase + c * 512u + (((head * 4u + kb) ^ c) * 16u);                              // row 16 b + c: + 8192 b
+        const uint32_t rsk = lbase + kW8Ks + (c >> 1) * 128u + ((((c & 1u) * 4u + h1) ^ (c >> 1)) * 16u) + (head & 1u) * 8u + kb * 2u;
+        uint32_t rdv[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j)
+            rdv[j] = lbase + kW8V + (4u * kb + j) * 512u + (((head * 4u + (c >> 2)) ^ (4u * kb + j)) * 16u) + (c & 3u) * 4u;
+        const uint32_t rsv = lbase + kW8Vs + 2u * kb * 128u + ((h1 ^ kb) * 16u) + (head & 1u) * 8u + 2u * (c >> 2);
+        const bool ragged = (a.n_pages & 15u) != 0u;
+        if (count != 0u) issue(0u);
+        if (count > 1u) issue(kW8Stage);
+#pragma unroll 1
+        for (uint32_t i = 0; i < iters; ++i) {
+            const uint32_t bo = (i & 1u) * kW8Stage;
+            // this wave's 5 DMAs of the tile have landed (the 5 of the next tile may still be in flight); then everybody's
+            if (i + 1u >= count) asm volatile("s_waitcnt vmcnt(0)" SPECKV_WG_BARRIER ::: "memory");
+            else                 asm volatile("s_waitcnt vmcnt(5)" SPECKV_WG_BARRIER ::: "memory");
+            if (HALVES == 2 && i >= count) {                              // the shorter half's spare iteration: the barriers only
+#ifndef SPECKV_ABL_NO_BARRIER
+                asm volatile("s_barrier" ::: "memory");
+#endif
+                continue;
+            }
+            u32x4 k0, k1;
+            uint32_t ks0, ks1;
+#ifdef SPECKV_ABL_NO_LDSREAD
+            k0 = u32x4{i, lane, 3u, 4u}; k1 = u32x4{lane, i, 7u, 8u}; ks0 = 0x3C00u; ks1 = 0x3C00u;
+#else
+            w8_take_k(rdk + bo, rsk + bo, k0, k1, ks0, ks1);
+#endif
+            float sc[8];
+            {
+                const f32x4 s0 = score_block(make_uint4(k0.x, k0.y, k0.z, k0.w), ks0, qv);
+                const f32x4 s1 = score_block(make_uint4(k1.x, k1.y, k1.z, k1.w), ks1, qv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { sc[j] = s0[j]; sc[4 + j] = s1[j]; }
+            }
+            if (ragged && ct + 1u == tiles_in_layer) {                    // workgroup-uniform: positions beyond the range
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t pg = ct * 16u + ((j >> 1) < 2 ? 2u * kb + (j >> 1) : 8u + 2u * kb + ((j >> 1) - 2));
+                    if (pg >= a.n_pages) sc[j] = -INFINITY;
+                }
+            }
+            const f16x8 P = softmax_tile(sc, qscale, m_run, l_run, acc);
+            uint32_t vw[8], vs16[8];
+            const uint32_t rdvb[4] = {rdv[0] + bo, rdv[1] + bo, rdv[2] + bo, rdv[3] + bo};
+#ifdef SPECKV_ABL_NO_LDSREAD
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { vw[j] = i + j + lane; vs16[j] = 0x3C00u; }
+            (void)rdvb;
+#else
+            w8_take_v(rdvb, rsv + bo, vw, vs16);
+#endif
+#ifndef SPECKV_ABL_NO_BARRIER
+            asm volatile("s_barrier" ::: "memory");                       // every wave has taken what it needs from this stage
+#endif
+            if (i + 2u < count) issue(bo);
+            pv_tile(vw, vs16, P, acc);
+            if (++ct == tiles_in_layer && i + 1u < count) {               // stream form: the layer is finished, the piece goes on
+                store_partial(a, (static_cast<uint64_t>(cl) * 8u + head) * a.stream.max_slots + slot, static_cast<uint64_t>(cl) * 8u + head, 0u, c, kb, m_run, l_run, acc);
+                ct = 0u; ++cl; slot = 0u;                                 // (this workgroup is the first of the next layer)
+                m_run = -INFINITY; l_run = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                load_q(cl);
+            }
+        }
+    }
+    if (stream) part = (static_cast<uint64_t>(cl) * 8u + head) * a.stream.max_slots + slot;
+    if (HALVES == 2) {
+        // waves 8..15 hand their state to waves 0..7 of the same head: [head][8 accumulators x 64 lanes x 16 B | 64 lanes x 8 B]
+        // in the second half's stages (every DMA has landed and been consumed: nobody reads them any more)
+        const uint32_t xb = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&lds[0]))) + 2u * kW8Stage + head * 8704u + lane * 16u;
+        const uint32_t xm = xb - lane * 16u + 8192u + lane * 8u;
+        if (half == 1u) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(xb), "v"(acc[t]), "n"(t * 1024) : "memory");
+            asm volatile("ds_write_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(xm), "v"(make_float2(m_run, l_run)) : "memory");
+        }
+        __syncthreads();
+        if (half == 1u) return;
+        f32x4 o[8];
+        float2 ml;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(o[t]) : "v"(xb), "n"(t * 1024) : "memory");
+        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(ml) : "v"(xm) : "memory");
+        asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]));     // (used behind the wait)
+        const float m_new = fmaxf(m_run, ml.x), m_use = (m_new == -INFINITY) ? 0.0f : m_new;
+        const float f0 = __builtin_amdgcn_exp2f(m_run - m_use), f1 = __builtin_amdgcn_exp2f(ml.x - m_use);      // 0 for an empty half
+        m_run = m_new;
+        l_run = l_run * f0 + ml.y * f1;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = acc[t] * f0 + o[t] * f1;
+    }
+    store_partial(a, part, static_cast<uint64_t>(stream ? cl : out_row0) * 8u + head, my_splits, c, kb, m_run, l_run, acc);
+}
+
 hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_t s)
 {
     if ((a.n_pages == 0 && !a.seqs) || n_layers == 0 || a.n_splits == 0) return hipSuccess;   // batch form: geometry per sequence
     const dim3 wg_grid = a.rows_first ? dim3(n_layers * (a.heads / 4u), a.n_splits) : dim3(a.n_splits, n_layers * (a.heads / 4u));
     if (a.table_form) { hipLaunchKernelGGL((k_attend_int4_wg<false, true>), wg_grid, dim3(256), 0, s, a); return hipGetLastError(); }
+    if (a.wg8 && a.lin_base && a.heads == 8u) {                          // whole records per workgroup: one workgroup per (layer | sequence, split)
+        const dim3 grid8 = a.stream.n_wgs ? dim3(a.stream.n_wgs) : a.rows_first ? dim3(n_layers, a.n_splits) : dim3(a.n_splits, n_layers);
+        if (a.stream.n_wgs || getenv("SPECKV_INT4_W8_ONE_HALF")) hipLaunchKernelGGL(k_attend_int4_wg8<1>, grid8, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL(k_attend_int4_wg8<2>, grid8, dim3(1024), 0, s, a);
+        return hipGetLastError();
+    }
 #ifdef SPECKV_INT4_REGSTAGE
     if (a.lin_base && !a.rows_first) hipLaunchKernelGGL(k_attend_int4<true>, dim3(a.n_splits, n_layers * (a.heads / kWgHeads)), dim3(64 * kWgHeads), 0, s, a);
     else

@@ -2440,6 +2440,18 @@ static uint32_t batch_tiles_per_split(bool fp8, uint32_t n_seq, uint32_t heads, 
     return tps;
 }
 
+// INT4 batches on the whole-record kernel (k_attend_int4_wg8<2>: workgroups = sequences x splits, one 16-wave workgroup per
+// CU resident, its two halves merged in LDS): one round of resident workgroups when the batch is smaller than that, whole
+// sequences otherwise (a whole sequence is final: no partials, no merge launch); never under 32 tiles a split.
+static bool int4_batch_wg8() { static const bool on = !getenv("SPECKV_INT4_WG4"); return on; }
+static uint32_t int4_wg8_batch_tps(uint32_t n_seq, uint32_t tiles_max)
+{
+    if (const char* env = getenv("SPECKV_ATTEND_TILES_PER_SPLIT")) return std::max(1, atoi(env));      // (measurement runs)
+    const uint32_t resident = 256u;                                       // 16-wave workgroups (two halves each), one per CU
+    const uint32_t splits = std::max(1u, resident / std::max(1u, n_seq));
+    return std::max(32u, (tiles_max + splits - 1u) / splits);
+}
+
 int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, uint32_t layer, const void* d_q_f16, uint32_t g,
                          const uint32_t* pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
 {
@@ -2507,10 +2519,11 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     // splits, 4k 0.60 / 0.52, 2k 0.58 / 0.43: single-split rows are final, no partials and no merge).
     if (any_table)                                           // (AttendSeq::lin_base carries the page table in table launches)
         for (uint32_t i = 0; i < n_seq; ++i) seqs[i].lin_base = reinterpret_cast<const uint8_t*>(ents[i]);
-    const uint32_t tps = batch_tiles_per_split(fp8, n_seq, heads, total_tiles, seqs.data(), 0);
     uint32_t tiles_max = 0;
     for (uint32_t i = 0; i < n_seq; ++i) tiles_max = std::max(tiles_max, seqs[i].n_splits);
-    const UnequalSplit unequal = fp8 ? UnequalSplit{false, 1.0} : int4_unequal_split(n_seq, heads / 4u, tiles_max);
+    const bool wg8 = !fp8 && !any_striped && !any_table && heads == 8u && int4_batch_wg8();
+    const uint32_t tps = wg8 ? int4_wg8_batch_tps(n_seq, tiles_max) : batch_tiles_per_split(fp8, n_seq, heads, total_tiles, seqs.data(), 0);
+    const UnequalSplit unequal = (fp8 || wg8) ? UnequalSplit{false, 1.0} : int4_unequal_split(n_seq, heads / 4u, tiles_max);
     uint32_t max_splits = 0;
     uint64_t parts = 0;
     for (uint32_t i = 0; i < n_seq; ++i) {
@@ -2572,6 +2585,7 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     for (uint32_t i = 0; i < n_seq; ++i) one_split_each = one_split_each && seqs[i].n_splits == 1u;
     if (one_split_each) { k.direct_out = d_out; k.direct_lse = d_lse; }
     if (unequal.on) k.rows_first = 1u;
+    if (wg8) k.wg8 = 1u;
     if (fp8) {
         HIP_TRY(launch_attend_fp8_batch(k, n_seq, d_out, d_lse, st));
     } else {
@@ -2592,6 +2606,13 @@ static PlanGeometry plan_geometry(bool fp8, uint32_t n_seq, uint32_t heads, uint
 {
     const uint32_t tiles_max = (max_pos_end / 2u + 15u) / 16u;
     PlanGeometry g{};
+    if (!fp8 && heads == 8u && int4_batch_wg8()) {            // the whole-record kernel's geometry (a striped / table launch runs it on the 4-head kernels)
+        g.unequal = UnequalSplit{false, 1.0};
+        g.tps = int4_wg8_batch_tps(n_seq, tiles_max);
+        g.max_splits = std::max(1u, (tiles_max + g.tps - 1u) / g.tps);
+        g.parts_bound = static_cast<uint64_t>(n_seq) * heads * g.max_splits;
+        return g;
+    }
     g.unequal = fp8 ? UnequalSplit{false, 1.0} : int4_unequal_split(n_seq, heads / 4u, tiles_max);
     if (g.unequal.on) {                                       // (the rule depends on the plan's bound only: plan and launch agree)
         g.tps = tiles_max;
@@ -2713,7 +2734,7 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
     k.scale_log2e = sm_scale * 1.4426950408889634f;
     if (plan->second.table) { k.table_form = 1u; k.zero_page = d_zero_page_; }           // a member without a regular placement: addresses from the page tables
     else if (plan->second.striped) k.stripe_bases = reinterpret_cast<const uint64_t*>(1);     // striped launch: every descriptor brings its table
-    else k.lin_base = reinterpret_cast<const uint8_t*>(1);     // non-null: linear form (the real base comes from the descriptor)
+    else { k.lin_base = reinterpret_cast<const uint8_t*>(1); if (!fp8 && int4_batch_wg8()) k.wg8 = 1u; }     // non-null: linear form (the real base comes from the descriptor)
     k.seqs = static_cast<const AttendSeq*>(d_plan);
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
@@ -2746,6 +2767,45 @@ int Engine::attend_fold_tail(uint32_t n_rows, const uint32_t* d_rows, uint32_t h
                                     s ? s : stream_));
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
     return SPECKV_OK;
+}
+
+// Launch geometry of the whole-record INT4 kernel (k_attend_int4_wg8; 512-thread workgroups, two resident per CU).
+static int device_cus()
+{
+    static const int n_cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 256; }
+        return v;
+    }();
+    return n_cus;
+}
+// Stream form (many layers of one sequence): the launch's n_layers x n_tiles tiles, layer-major, in as many equal pieces as
+// workgroups are resident at once -- one pipeline fill per workgroup, no partial last round, few partials per layer.  Worth
+// it when a piece is long enough to amortise its fill (>= 16 tiles); *max_slots = most pieces any layer is cut into.
+static bool int4_wg8_stream(uint32_t n_layers, uint32_t n_tiles, AttendArgs::Stream* out)
+{
+    const uint64_t total = static_cast<uint64_t>(n_layers) * n_tiles;
+    uint64_t wgs = 2ull * static_cast<uint64_t>(device_cus());
+    if (const char* env = getenv("SPECKV_INT4_STREAM_WGS")) wgs = std::max(1, atoi(env));
+    if (n_layers < 2 || total < 16u * wgs || getenv("SPECKV_INT4_NO_STREAM")) return false;
+    out->n_wgs = static_cast<uint32_t>(wgs);
+    out->len = static_cast<uint32_t>(total / wgs);
+    out->rem = static_cast<uint32_t>(total % wgs);
+    out->max_slots = 1;
+    for (uint32_t l = 0; l < n_layers; ++l) out->max_slots = std::max(out->max_slots, attend_stream_count(l, n_tiles, out->len, out->rem));
+    return true;
+}
+// Fixed grid (per-layer calls, short launches): splits x layers workgroups, in whole rounds of the resident set when the
+// launch is that long, else as many 8-tile pieces as there are.
+static uint32_t int4_wg8_splits(uint32_t n_layers, uint32_t n_tiles)
+{
+    const uint64_t resident = static_cast<uint64_t>(device_cus());                 // (16-wave workgroups, two halves each: one per CU)
+    const uint64_t total = static_cast<uint64_t>(n_layers) * n_tiles;
+    uint64_t wgs = std::max<uint64_t>(1, total / 64u);
+    if (wgs >= resident) wgs = (wgs + resident / 2u) / resident * resident;       // whole rounds
+    else wgs = std::min<uint64_t>(resident, std::max<uint64_t>(wgs, total / 8u));
+    const uint64_t per_layer = std::max<uint64_t>(1, (wgs + n_layers / 2u) / n_layers);
+    return static_cast<uint32_t>(std::min<uint64_t>(per_layer, std::max<uint32_t>(1u, n_tiles / 4u)));
 }
 
 // Fused decode attention over INT4_G32 K and V records (attend_int4.hip): linear placement only.
@@ -2800,16 +2860,20 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     // is a multiple of 8 the two workgroups that share a page's scale line (head quads 0 and 1) run on the same XCD, next
     // to each other (measured at 32k x 80 layers: 8 splits 0.598, 10 or 12 splits 0.56, 16 splits 0.595)
     if (want > 8u) want &= ~7u;
+    // whole-record kernel (8 waves = 8 heads, one workgroup per CU): workgroups = splits x layers, in whole rounds of the CUs
+    const bool wg8 = linear && L.num_heads == 8 && !getenv("SPECKV_INT4_WG4");
+    if (wg8) want = int4_wg8_splits(n_layers, n_tiles);
     if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));
     EvenSplit es = even_split(n_tiles, std::max(1u, std::min(want, 2048u)));
-    if (es.n_splits > 8u && (es.n_splits & 7u) && !getenv("SPECKV_ATTEND_SPLITS"))      // the rounding can fall off a multiple of 8
+    if (!wg8 && es.n_splits > 8u && (es.n_splits & 7u) && !getenv("SPECKV_ATTEND_SPLITS"))      // the rounding can fall off a multiple of 8
         es = even_split(n_tiles, es.n_splits & ~7u);
-    const uint32_t n_splits = es.n_splits, tiles_per_split = es.tiles_per_split;
+    AttendArgs k{};
+    const bool stream = wg8 && !getenv("SPECKV_ATTEND_SPLITS") && int4_wg8_stream(n_layers, n_tiles, &k.stream);
+    const uint32_t n_splits = stream ? k.stream.max_slots : es.n_splits, tiles_per_split = es.tiles_per_split;      // (stream: slots per row)
     const size_t acc_bytes = static_cast<size_t>(rows) * n_splits * 16 * 128 * sizeof(float);
     const size_t ml_bytes = static_cast<size_t>(rows) * n_splits * 32 * sizeof(float);
     uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes, s));
     if (!buf) return SPECKV_ERR_NOMEM;
-    AttendArgs k{};
     k.entries = a->d_entries;
     k.k_first = k_first;
     k.v_first = v_first;
@@ -2823,6 +2887,7 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     k.scale_log2e = sm_scale * 1.4426950408889634f;
     k.lin_base = linear ? a->linear_base : nullptr;
     if (table) k.table_form = 1u;
+    if (wg8) k.wg8 = 1u;
     if (striped) {
         k.stripe_bases = a->d_stripe;
         k.stripe_n = a->stripe_n;
@@ -2831,7 +2896,7 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     k.zero_page = d_zero_page_;
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
-    if (n_splits == 1u) { k.direct_out = d_out; k.direct_lse = d_lse; }      // no merge launch
+    if (n_splits == 1u && !stream) { k.direct_out = d_out; k.direct_lse = d_lse; }      // no merge launch
     HIP_TRY(launch_attend_int4(k, n_layers, st));
     if (!k.direct_out) HIP_TRY(launch_attend_combine(k, n_layers, d_out, d_lse, st));
     note_use(a, s);

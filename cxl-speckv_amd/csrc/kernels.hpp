@@ -276,7 +276,29 @@ struct AttendArgs {
     // is no longer regular (pages migrated one by one) but whose range is tile-aligned -- every record address comes
     // from the page-table entry, looked up one tile ahead of its request; never-written pages read zero_page
     uint32_t table_form;
+    // INT4, linear form, 8 kv heads: the whole-record kernel (k_attend_int4_wg8: 8 waves = 8 heads, grid (splits, layers))
+    uint32_t wg8;
+    // ... and its STREAM form for many layers of one sequence (see k_attend_int4_wg8): n_wgs != 0 turns it on.  The rows'
+    // partials then sit at (row * max_slots + slot) and the merge takes each row's count from attend_stream_count().
+    struct Stream { uint32_t len, rem, n_wgs, max_slots; } stream;
 };
+// The stream partition: `total` tiles in layer-major order cut into n_wgs contiguous pieces, the first `rem` one longer
+// (len = total / n_wgs >= 1, rem = total % n_wgs).  begin(w) = first tile of piece w; wg_of(G) = the piece tile G is in.
+__host__ __device__ inline uint64_t attend_stream_begin(uint32_t w, uint32_t len, uint32_t rem)
+{
+    return static_cast<uint64_t>(w) * len + (w < rem ? w : rem);
+}
+__host__ __device__ inline uint32_t attend_stream_wg_of(uint64_t G, uint32_t len, uint32_t rem)
+{
+    const uint64_t cut = static_cast<uint64_t>(rem) * (len + 1u);
+    return G < cut ? static_cast<uint32_t>(G / (len + 1u)) : rem + static_cast<uint32_t>((G - cut) / len);
+}
+// partials of layer `layer` (n_tiles tiles per layer): pieces wg_of(first tile) .. wg_of(last tile)
+__host__ __device__ inline uint32_t attend_stream_count(uint32_t layer, uint32_t n_tiles, uint32_t len, uint32_t rem)
+{
+    const uint64_t g0 = static_cast<uint64_t>(layer) * n_tiles;
+    return attend_stream_wg_of(g0 + n_tiles - 1u, len, rem) - attend_stream_wg_of(g0, len, rem) + 1u;
+}
 #if defined(__HIPCC__)
 // record address of page p in the striped form; `bases` = the allocation's run bases copied to LDS
 __device__ __forceinline__ const uint8_t* attend_stripe_rec(const uint64_t* bases, uint32_t p, uint32_t n, uint32_t magic, uint32_t stride)

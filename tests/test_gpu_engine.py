@@ -1107,7 +1107,9 @@ def test_attention_over_a_striped_and_migrated_pool(scheme):
             lib.finalize()
     (o_lin, l_lin), (o_pt, l_pt) = outs
     scale = float(o_lin.abs().max())
-    assert float((o_lin - o_pt).abs().max()) <= 2e-4 * scale        # same maths, other split boundaries / tile reference scales
+    # same maths, other split boundaries: the softmax weights are rounded to f16 (2^-11 relative) against each split's own
+    # running reference, so two partitions of the same 256 positions differ by a few 1e-4 of the largest output
+    assert float((o_lin - o_pt).abs().max()) <= 4e-4 * scale
     assert float((l_lin - l_pt).abs().max()) <= 1e-4
 
 
