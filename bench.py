@@ -1556,13 +1556,17 @@ def run_extras(torch, pkg, lib, src, dst, n_blocks, sp):
     for name, data in (("rle_all_zero_blocks", torch.zeros_like(src)), ("rle_piecewise_runs_of_32", pw)):
         enc = lambda: raw.speckv_ext_codec_compress(data.data_ptr(), n_blocks, recs.data_ptr(), PAGE, lens.data_ptr(), scales.data_ptr(), 2, 0, sp)
         dec = lambda: raw.speckv_ext_codec_decompress(recs.data_ptr(), PAGE, lens.data_ptr(), scales.data_ptr(), n_blocks, dst.data_ptr(), 0, 2, 0, sp)
+        # the same with SPECKV_CODEC_HINT_STRUCTURED (0x100): the decoder instantiation for data known to compress
+        dec_hint = lambda: raw.speckv_ext_codec_decompress(recs.data_ptr(), PAGE, lens.data_ptr(), scales.data_ptr(), n_blocks, dst.data_ptr(), 0, 2, 0x100, sp)
         enc_ms = timed(enc)
         dec_ms = timed(dec)
+        hint_ms = timed(dec_hint)
         comp = int(lens.to(torch.int64).sum().item())
         dec_bytes = comp + n_blocks * (4 + PAGE)
         ex[name] = {"decompress_blocks_per_s": round(n_blocks / (dec_ms * 1e-3), 1),
                     "decompress_GBps": round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1),
                     "decompress_frac_hbm": round(dec_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    "decompress_frac_hbm_structured_hint": round(dec_bytes / (hint_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                     "compress_blocks_per_s": round(n_blocks / (enc_ms * 1e-3), 1),
                     "record_bytes_per_block": round(comp / n_blocks, 1)}
     return ex

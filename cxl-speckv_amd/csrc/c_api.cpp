@@ -327,6 +327,8 @@ speckv_status_t speckv_ext_codec_decompress(const void* d_recs, uint64_t rec_str
                                             const float* d_scales, uint64_t n_blocks, void* d_dst, int out_f32,
                                             int scheme, int quant_mode, void* stream)
 {
+    const int structured = quant_mode & SPECKV_CODEC_HINT_STRUCTURED;
+    quant_mode &= ~SPECKV_CODEC_HINT_STRUCTURED;
     if (scheme < 0 || scheme > SPECKV_COMP_FP8_E4M3 || quant_mode < 0 || quant_mode > 1) return SPECKV_ERR_INVAL;
     if (n_blocks && (!d_recs || !d_rec_bytes || !d_dst)) return SPECKV_ERR_INVAL;
     if (rec_stride % 16) return SPECKV_ERR_INVAL;
@@ -341,6 +343,7 @@ speckv_status_t speckv_ext_codec_decompress(const void* d_recs, uint64_t rec_str
     a.scheme = scheme;
     a.quant_mode = quant_mode;
     a.out_f32 = out_f32 ? 1 : 0;
+    a.structured_hint = structured ? 1 : 0;
     return codec_launch(false, a, stream);
 }
 

@@ -2194,6 +2194,11 @@ int Engine::fetch_range(uint64_t handle, uint64_t first, uint64_t n, void* d_dst
         c.scheme = a->scheme;
         c.quant_mode = quant_mode_;
         c.out_f32 = f32 ? 1 : 0;
+        if (a->packed && a->n_pages) {                       // sealed: the packed size is known -- short records take the flat-run decoder
+            uint64_t packed = 0;
+            for (uint64_t b : a->packed_bytes) packed += b;
+            c.structured_hint = packed / a->n_pages < 512u ? 1 : 0;
+        }
         HIP_TRY(launch_decompress(c, st));
     }
     note_use(a, s);

@@ -245,7 +245,10 @@ __device__ __forceinline__ bool rle_pair_chunk(const uint4 wv, uint32_t pair0, u
 // `trusted` (wave-uniform): the stream comes from k_compress -- no zero counts, and the
 // bytes between len and the next 16-byte boundary are zero pairs, which scatter into
 // the dummy byte; every chunk then takes the unmasked, unchecked form.
-template <int MODE, bool F32>
+// FLAT (a separate instantiation, chosen per LAUNCH for data that is known to compress: CodecArgs::structured_hint; the
+// instantiation the headline fetch runs is not touched): piecewise-constant blocks whose runs sit on 8-element boundaries
+// skip the eight recurrences and conversions of a lane -- see the second loop.
+template <int MODE, bool F32, bool FLAT = false>
 __device__ __forceinline__ bool decode_rle_fast(const uint8_t* __restrict__ rec, uint32_t len,
                                                 float scale, uint8_t* __restrict__ dst,
                                                 uint8_t* tab, uint32_t lane, bool trusted)
@@ -310,6 +313,18 @@ __device__ __forceinline__ bool decode_rle_fast(const uint8_t* __restrict__ rec,
         const uint32_t x2 = c2 + i2 - u;                    // S2 entering this lane
         c1 += lane63(i1);
         c2 += lane63(i2);
+        if (FLAT && npairs <= 256u) {                        // (wave-uniform)
+            // Piecewise-constant data on 8-element boundaries (a constant run enters the table as +d at its first element and
+            // -d at the next): every lane's eight elements are ONE value -- entering slope 0, bytes 2..7 empty, byte 1 = -byte 0
+            // -- so one conversion and plain 16-byte stores of it instead of eight recurrences and conversions.
+            const bool flat = (x1 & 0xFFu) == 0u && (x.x & 0xFFFF0000u) == 0u && x.y == 0u && ((x.x + (x.x >> 8)) & 0xFFu) == 0u;
+            if (__builtin_amdgcn_ballot_w64(!flat) == 0ull) {
+                const float v = dequant<MODE>(static_cast<int>(static_cast<int8_t>((x2 + x1 + (x.x & 0xFFu)) & 0xFFu)), scale);
+                const float y8[8] = {v, v, v, v, v, v, v, v};
+                store8<F32>(dst, p0, y8);
+                continue;
+            }
+        }
         uint32_t s1 = x1, s2 = x2;
         uint32_t q[8];
         s1 = add_byte<0>(s1, x.x, x.y); s2 += s1; q[0] = s2;
@@ -569,7 +584,7 @@ __device__ __forceinline__ void ring_note(const CodecArgs& a, const BlockDesc& d
     atomicOr(&t.d_flags[d.page], 2u);
 }
 
-template <int SCHEME, int MODE, bool F32, int EXT>
+template <int SCHEME, int MODE, bool F32, int EXT, bool FLAT = false>
 __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[SCHEME == kInt8DeltaRle ? kWaves * kDecLdsWords : 4];
@@ -602,8 +617,8 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
         if (SCHEME == kInt8DeltaRle) {
             if (len > 2u * kBlockElems) len = 2u * kBlockElems;
             uint32_t* region = lds + wave * kDecLdsWords;
-            if (!decode_rle_fast<MODE, F32>(cur.rec, len, cur.scale, cur.dst, reinterpret_cast<uint8_t*>(region), lane,
-                                            a.trusted != 0))
+            if (!decode_rle_fast<MODE, F32, FLAT>(cur.rec, len, cur.scale, cur.dst, reinterpret_cast<uint8_t*>(region), lane,
+                                                  a.trusted != 0))
                 decode_rle_general<MODE, F32>(cur.rec, len, cur.scale, cur.dst, lane);
         } else if (SCHEME == kInt8) {
             if (len > kBlockElems) len = kBlockElems;
@@ -2002,6 +2017,11 @@ hipError_t launch_dec2(const CodecArgs& a_in, hipStream_t s)
     if (ext == 3 && (a.out_f32 || a.alloc_list || a.ring_owner || a.stripe_n || !a.seq0_dev || !a.data_list)) return hipErrorInvalidValue;
 #define SPECKV_LAUNCH_DEC(F32, EXT) \
     hipLaunchKernelGGL((k_fetch_decompress<SCHEME, MODE, F32, EXT>), dim3(grid), dim3(kThreads), 0, s, a)
+    if (SCHEME == kInt8DeltaRle && a.structured_hint && ext == 0) {      // data known to compress: the FLAT instantiation (plain form only)
+        if (a.out_f32) hipLaunchKernelGGL((k_fetch_decompress<SCHEME, MODE, true, 0, SCHEME == kInt8DeltaRle>), dim3(grid), dim3(kThreads), 0, s, a);
+        else           hipLaunchKernelGGL((k_fetch_decompress<SCHEME, MODE, false, 0, SCHEME == kInt8DeltaRle>), dim3(grid), dim3(kThreads), 0, s, a);
+        return hipGetLastError();
+    }
     if (a.out_f32) { if (ext == 2) SPECKV_LAUNCH_DEC(true, 2); else if (ext == 1) SPECKV_LAUNCH_DEC(true, 1); else SPECKV_LAUNCH_DEC(true, 0); }
     else           { if (ext == 3) SPECKV_LAUNCH_DEC(false, 3); else if (ext == 2) SPECKV_LAUNCH_DEC(false, 2); else if (ext == 1) SPECKV_LAUNCH_DEC(false, 1); else SPECKV_LAUNCH_DEC(false, 0); }
 #undef SPECKV_LAUNCH_DEC

@@ -90,6 +90,9 @@ struct CodecArgs {
     // records were written by k_compress (the engine's pool): INT8_DELTA_RLE streams are then known to
     // have no zero counts and a zero-padded tail, which the decoder need not re-check per pair
     int             trusted;
+    // decompress, INT8_DELTA_RLE: the caller knows the records to be short (structured data: mean record well under 512 B) --
+    // the launch takes the instantiation with the flat-run fast path (decode_rle_fast<.., FLAT>); results are identical
+    int             structured_hint;
     // compress only: when set, the block scale of page p is also stored at scale_tab[tile order of p] -- the
     // per-tile order the fused attention reads with one 16-byte load (attend.hip); region_pages = pages of one
     // (layer, kind) region of the shim layout, a multiple of 16

@@ -221,6 +221,11 @@ speckv_status_t speckv_ext_codec_compress(const void* d_src_f16, uint64_t n_bloc
                                           void* d_recs, uint64_t rec_stride,
                                           uint32_t* d_rec_bytes, float* d_scales,
                                           int scheme, int quant_mode, void* stream);
+/* quant_mode of speckv_ext_codec_decompress may carry this flag: the records are known to be short (structured data, mean
+ * record well under 512 bytes).  The launch then takes a decoder instantiation with a fast path for constant runs on
+ * 8-element boundaries; the output is bit for bit the same with or without it.  (The engine sets it by itself for
+ * allocations sealed by speckv_ext_compact whose packed records average under 512 bytes.) */
+#define SPECKV_CODEC_HINT_STRUCTURED 0x100
 speckv_status_t speckv_ext_codec_decompress(const void* d_recs, uint64_t rec_stride,
                                             const uint32_t* d_rec_bytes, const float* d_scales,
                                             uint64_t n_blocks, void* d_dst, int out_f32,

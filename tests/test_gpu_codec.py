@@ -270,6 +270,38 @@ def test_run_lengths_around_the_split_limit(lib, oracle):
         assert_same_float_bits(y, oracle.decompress_blocks_f16(o_recs, o_lens, o_scales, 2, mode), f"mode {mode}")
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_structured_hint_decoder_is_bit_identical(lib, oracle, mode):
+    """SPECKV_CODEC_HINT_STRUCTURED selects a separate instantiation of the fetch kernel (decode_rle_fast<.., FLAT>: constant
+    runs on 8-element boundaries skip the per-element recurrences).  Its output must be the oracle's, bit for bit, on the data
+    it is meant for (runs of 32, of 8, of 64; zeros) AND on everything else a caller may wrongly hint: runs off the 8-element
+    grid, runs of 7, noise, short malformed records -- fp16 and fp32 outputs."""
+    rng = np.random.default_rng(404)
+    blocks = []
+    for run in (32, 8, 64, 256, 2048):
+        blocks.append(np.repeat(rng.standard_normal(N // run), run))
+    blocks.append(np.zeros(N))
+    off = np.repeat(rng.standard_normal(N // 32 + 1), 32)[5:5 + N]            # runs of 32 that start 5 elements late
+    blocks.append(off)
+    blocks.append(np.repeat(rng.standard_normal(N // 7 + 1), 7)[:N])           # runs of 7: never on the grid
+    mixed = np.repeat(rng.standard_normal(N // 32), 32); mixed[700:760] = rng.standard_normal(60)   # mostly flat, one noisy stretch
+    blocks.append(mixed)
+    blocks.append(rng.standard_normal(N))                                      # does not compress: the hint is simply wrong
+    x = np.stack(blocks).astype(np.float16)
+    scales, lens, recs = oracle.compress_blocks_f16(x, 2, mode)
+    want16 = oracle.decompress_blocks_f16(recs, lens, scales, 2, mode)
+    HINT = 0x100
+    for out_f32 in (False, True):
+        plain = gpu_decompress(lib, recs, lens, scales, 2, mode, out_f32)
+        hinted = gpu_decompress(lib, recs, lens, scales, 2, mode | HINT, out_f32)
+        assert_same_float_bits(hinted, plain, f"hint vs plain, f32={out_f32}")
+        if not out_f32:
+            assert_same_float_bits(hinted, want16, "hint vs oracle")
+    # the hint on other schemes is ignored, not an error
+    s1, l1, r1 = oracle.compress_blocks_f16(x, 1, mode)
+    assert_same_float_bits(gpu_decompress(lib, r1[:, :2048], l1, s1, 1, mode | HINT), gpu_decompress(lib, r1[:, :2048], l1, s1, 1, mode), "int8")
+
+
 def test_full_size_roundtrip_properties(lib):
     """BASELINE config 2 size (131072 blocks = 512 MiB fp16): size-independent
     properties instead of the oracle -- decode(encode(x)) is a fixed point of a

@@ -863,6 +863,42 @@ def test_vllm_shaped_connector_round_trip(oracle, scheme):
         lib.finalize()
 
 
+def test_sealed_structured_allocation_takes_the_flat_run_decoder(oracle):
+    """A sealed allocation whose packed records average under 512 bytes is fetched by the decoder instantiation with the
+    flat-run fast path (Engine::fetch_range sets CodecArgs::structured_hint from the packed size): same bits as the oracle,
+    fp16 and fp32, before and after the seal; a mostly-noise allocation (mean record ~4 KiB) keeps the plain decoder."""
+    torch = torch_mod()
+    lib = open_lib()
+    try:
+        lib.set_compression_scheme(2)
+        n = 1024
+        rng = np.random.default_rng(29)
+        x = np.repeat(rng.standard_normal((n, N // 32)), 32, axis=1).astype(np.float16)     # runs of 32
+        x[::5] = 0
+        x[7, 100:140] = rng.standard_normal(40).astype(np.float16)                          # one block with a noisy stretch
+        sc, ln, rc = oracle.compress_blocks_f16(x, 2, 0)
+        want = oracle.decompress_blocks_f16(rc, ln, sc, 2, 0)
+        h = lib.alloc(n * PAGE)
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+        s = torch.cuda.Stream()
+        out = torch.empty((n, N), dtype=torch.float16, device="cuda")
+        for sealed in (False, True):
+            if sealed:
+                before, after = lib.compact(h)
+                assert after / n < 512 and after < before
+            out.fill_(float("nan"))
+            lib.fetch_range(h, 0, n, out.data_ptr(), False, s.cuda_stream)
+            torch.cuda.synchronize()
+            assert_same_float_bits(out.cpu().numpy(), want, f"sealed={sealed}")
+        out32 = torch.full((n, N), float("nan"), dtype=torch.float32, device="cuda")
+        lib.fetch_range(h, 3, n - 3, out32.data_ptr(), True, s.cuda_stream)
+        torch.cuda.synchronize()
+        sc2 = oracle.decompress_blocks_f16(rc, ln, sc, 2, 0)             # (fp16 of the fp32 result is the fp16 result)
+        assert_same_float_bits(out32[:n - 3].cpu().numpy().astype(np.float16), sc2[3:], "fp32 output of the sealed allocation")
+    finally:
+        lib.finalize()
+
+
 def test_vllm_connector_prefix_hit_chunked_prefill_and_separate_roles():
     """ADVICE r3 (both medium findings).  (1) A request whose first `num_computed_tokens` tokens already sit in vLLM's own
     prefix cache loads the tokens [computed, computed + matched) -- not [0, matched): the slots of the prefix stay untouched,
