@@ -1943,6 +1943,151 @@ __global__ __launch_bounds__(256) void k_softmax_topk_merge(const uint8_t* __res
     }
 }
 
+// ---- a handful of requests (n <= kPredictSmallN): written for the length of the chain, not for throughput ----------------
+// The batch path above is four launches (hidden state | logits on the matrix cores, 32 requests per tile | top-k of 4096-logit
+// parts | merge) and writes n x vocab logits to memory in between: for ONE request that is four launch gaps around 16 MB of
+// weights (23.7 us per prediction back to back, README's "< 10 us" claim of the reference's FPGA).  Here two launches:
+//   k_predict_small:  a wave takes 32 output rows (its 16 KiB of arranged weights: the same k_arrange_wout layout), forms
+//     their logits for every request with plain fused multiply-adds against the hidden vector in LDS -- which the workgroup
+//     computes itself for the reference's degenerate cell (one wave per request: the loop of k_lstm_hidden) or reads from
+//     k_lstm_cell's output for the real one -- and reduces them at once: maximum, exp-sum, top k of its 32 rows by wave
+//     exchanges, then the four waves' results to one (max, sum, k keys) of the workgroup's 128 rows.  Logits never leave
+//     the CU.
+//   k_predict_small_merge:  one workgroup per request merges the workgroups' results (a lane per part, 64 parts per wave,
+//     as k_softmax_topk_merge) and writes tokens and confidences.  (Merged by the workgroup that finishes last instead -- one
+//     launch, write-through stores, arrival counter: 17.1 us per prediction against 15.7 with the second launch; the lone
+//     workgroup's chain of counter, agent-scope loads and exchanges is longer than a launch gap.
+//     profiles/experiments/r04_predict_small_last_arriver_merge.patch)
+// Same arithmetic as the batch path up to the order of the dot product's additions (tests state 1e-4 on confidences, as for
+// the batch path against the oracle); vocabularies up to kPredictSmallMaxParts x 128 rows, larger ones take the batch path.
+__global__ __launch_bounds__(256) void k_predict_small(const int32_t* __restrict__ hist, uint32_t n, const float* __restrict__ emb,
+        const float* __restrict__ hid_in, uint32_t layers, const float* __restrict__ wout, const float* __restrict__ out_bias,
+        uint32_t vocab, uint32_t k, uint8_t* __restrict__ ws)
+{
+    __shared__ __attribute__((aligned(16))) float hs[kPredictSmallN][kPredHidden];
+    __shared__ float wm[kPredictSmallN][4], wsum[kPredictSmallN][4];
+    __shared__ uint64_t wkey[kPredictSmallN][4][8];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t c = lane & 31u, kh = lane >> 5;
+    const uint32_t tile = blockIdx.x * 4u + wave;
+    const uint32_t row = tile * 32u + c;
+    const bool live = row < vocab && kh == 0u;                          // the two halves of the wave end with the same logit: one counts
+    // the wave's weights first (they are the long pole: 16 KiB per wave from memory), then the hidden vectors under their flight
+    float4 wq[16];
+    const float4* wt = reinterpret_cast<const float4*>(wout) + static_cast<uint64_t>(tile) * (16u * 64u) + lane;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) wq[j] = wt[j * 64];
+    const float bias = (out_bias && row < vocab) ? out_bias[row] : 0.0f;
+    if (hid_in) {                                                       // the real cell's output (k_lstm_cell)
+        for (uint32_t e = threadIdx.x; e < n * kPredHidden; e += 256u) hs[e / kPredHidden][e % kPredHidden] = hid_in[e];
+    } else if (wave < n) {                                              // the reference's degenerate cell: k_lstm_hidden's loop, request = wave
+        float g[kPredHist];
+#pragma unroll
+        for (uint32_t t = 0; t < kPredHist; ++t) {
+            const uint32_t tok = static_cast<uint32_t>(hist[wave * kPredHist + t]);
+            g[t] = (tok < vocab) ? emb[static_cast<uint64_t>(tok) * kPredEmb + lane] * 0.1f : 0.0f;
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < kPredHist; ++t)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) g[t] += __shfl_xor(g[t], o);
+        // the recurrence is a chain of 16 x layers dependent tanh: libm's tanhf (~100 instructions each) made it 9 of the
+        // kernel's 13.7 us.  tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exponential and reciprocal: absolute error
+        // ~1e-7, i.e. 1e-5 relative at the |x| ~ 0.01 these states have (tests: confidences within 5e-4 of the oracle).
+        auto fast_tanh = [](float x) {
+            x = fminf(fmaxf(x, -15.0f), 15.0f);
+            const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);         // exp(2x)
+            return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+        };
+        float tg[kPredHist];
+#pragma unroll
+        for (uint32_t t = 0; t < kPredHist; ++t) tg[t] = 0.5f * fast_tanh(g[t]);      // (independent of the chain)
+        float h = 0.0f, cc = 0.0f;
+#pragma unroll
+        for (uint32_t t = 0; t < kPredHist; ++t)
+            for (uint32_t l = 0; l < layers; ++l) {
+                cc = 0.5f * cc + tg[t];
+                h = 0.5f * fast_tanh(cc);
+            }
+        h = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(h)));
+        hs[wave][lane] = h;
+        hs[wave][64u + lane] = h;
+    }
+    __syncthreads();
+    for (uint32_t b = 0; b < n; ++b) {                                  // (n <= 4: the weights stay in registers)
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 h4 = *reinterpret_cast<const float4*>(&hs[b][8u * j + 4u * kh]);
+            acc = __builtin_fmaf(h4.x, wq[j].x, acc);
+            acc = __builtin_fmaf(h4.y, wq[j].y, acc);
+            acc = __builtin_fmaf(h4.z, wq[j].z, acc);
+            acc = __builtin_fmaf(h4.w, wq[j].w, acc);
+        }
+        acc += __shfl_xor(acc, 32);                                     // the other half of the columns
+        const float v = live ? (out_bias ? acc + bias : acc) : -INFINITY;
+        const float m = wave_max_f32(v);
+        const float sum = wave_sum_f32((live && m > -INFINITY) ? expf(v - m) : 0.0f);
+        uint64_t key = live ? tk_key(v, row) : 0;
+        for (uint32_t r = 0; r < k; ++r) {
+            const uint64_t w = wave_max_u64(key);
+            if (w == key) key = 0;                                      // one row per lane: the owner retires it
+            if (lane == 0u) wkey[b][wave][r] = w;
+        }
+        if (lane == 0u) { wm[b][wave] = m; wsum[b][wave] = sum; }
+    }
+    __syncthreads();
+    if (wave >= n) return;                                              // wave b merges request b's four results
+    const uint32_t b = wave, parts = gridDim.x, part = blockIdx.x;
+    uint8_t* mine = ws + static_cast<uint64_t>(b) * tk_ws_stride(parts);
+    float* part_ms = reinterpret_cast<float*>(mine);                     // [part] (max, sum)
+    uint64_t* part_key = reinterpret_cast<uint64_t*>(mine + parts * 8u);             // [part][8]
+    float pm, ps;
+    tk_merge(lane < 4u ? wm[b][lane] : -INFINITY, lane < 4u ? wsum[b][lane] : 0.0f, lane < 4u * k ? wkey[b][lane / k][lane % k] : 0, k, pm, ps,
+             [&](uint32_t r, uint64_t w) { if (lane == 0u) part_key[part * 8u + r] = w; });
+    if (lane == 0u) { part_ms[2u * part] = pm; part_ms[2u * part + 1u] = ps; }
+}
+__global__ __launch_bounds__(256) void k_predict_small_merge(const uint8_t* __restrict__ ws, uint32_t k, uint32_t parts,
+        int32_t* __restrict__ out_tok, float* __restrict__ out_conf)
+{
+    __shared__ float wm[4], wsum[4];
+    __shared__ uint64_t wkey[4][8];
+    const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint8_t* mine = ws + static_cast<uint64_t>(b) * tk_ws_stride(parts);
+    const float* part_ms = reinterpret_cast<const float*>(mine);
+    const uint64_t* part_key = reinterpret_cast<const uint64_t*>(mine + parts * 8u);
+    const uint32_t part = wave * 64u + lane;                             // lane = part (up to 256 of them)
+    const bool have = part < parts;
+    const float qm = have ? part_ms[2u * part] : -INFINITY, qs = have ? part_ms[2u * part + 1u] : 0.0f;
+    uint64_t key[8];
+#pragma unroll
+    for (uint32_t r = 0; r < 8u; ++r) key[r] = (have && r < k) ? part_key[part * 8u + r] : 0;       // descending: key[0] is the part's best not yet taken
+    const float mx = wave_max_f32(qm);
+    const float total = wave_sum_f32(qm > -INFINITY ? qs * expf(qm - mx) : 0.0f);
+    for (uint32_t r = 0; r < k; ++r) {
+        const uint64_t w = wave_max_u64(key[0]);
+        if (w != 0 && w == key[0]) {                                     // keys are distinct (token ids are): one owner, whose next key moves up
+#pragma unroll
+            for (uint32_t j = 0; j < 7u; ++j) key[j] = key[j + 1u];
+            key[7] = 0;
+        }
+        if (lane == 0u) wkey[wave][r] = w;
+    }
+    if (lane == 0u) { wm[wave] = mx; wsum[wave] = total; }
+    __syncthreads();
+    if (wave != 0u) return;
+    float M, S;
+    float* conf = out_conf + static_cast<uint64_t>(b) * k;
+    int32_t* tok = out_tok + static_cast<uint64_t>(b) * k;
+    tk_merge(lane < 4u ? wm[lane] : -INFINITY, lane < 4u ? wsum[lane] : 0.0f, lane < 4u * k ? wkey[lane / k][lane % k] : 0, k, M, S,
+             [&](uint32_t r, uint64_t w) {
+                 if (lane == 0u) {
+                     tok[r] = w ? static_cast<int32_t>(0xFFFFFFFFu - static_cast<uint32_t>(w)) : -1;
+                     conf[r] = w ? expf(tk_value(w) - M) / S : 0.0f;
+                 }
+             });
+}
+
 // Records move to new places (compaction into packed extents and back): one wave per page copies the record's bytes, rounded up
 // to 16 (k_compress zero-pads a record's last 16-byte piece), then re-points the page's table entry.
 __global__ __launch_bounds__(256) void k_repack(PageEntry* __restrict__ entries, const uint64_t* __restrict__ new_addr, uint64_t n)
@@ -2187,6 +2332,22 @@ hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb,
 {
     if (n == 0) return hipSuccess;
     if (k == 0 || k > 8u || vocab < k) return hipErrorInvalidValue;
+    const uint32_t small_parts = logits_tiles_padded(vocab) / 4u;       // workgroups of 128 rows
+    if (n <= kPredictSmallN && small_parts <= kPredictSmallMaxParts && !getenv("SPECKV_PREDICT_BATCH_PATH")) {
+        // a handful of requests: two launches (three with the real cell), no logits in memory (k_predict_small)
+        const bool real = lstm && lstm->layers;
+        if (real) {
+            if (lstm->layers > 4u) return hipErrorInvalidValue;
+            LstmWeights w{};
+            w.layers = lstm->layers;
+            for (uint32_t l = 0; l < lstm->layers; ++l) { w.w_ih_t[l] = lstm->w_ih_t[l]; w.w_hh_t[l] = lstm->w_hh_t[l]; w.bias[l] = lstm->bias[l]; }
+            hipLaunchKernelGGL(k_lstm_cell, dim3(n), dim3(512), 0, s, d_hist, n, d_emb, vocab, w, d_hid);
+        }
+        hipLaunchKernelGGL(k_predict_small, dim3(small_parts), dim3(256), 0, s, d_hist, n, d_emb, real ? d_hid : nullptr, layers, d_wout,
+                           lstm ? lstm->out_bias : nullptr, vocab, k, static_cast<uint8_t*>(d_ws));
+        hipLaunchKernelGGL(k_predict_small_merge, dim3(n), dim3(256), 0, s, static_cast<const uint8_t*>(d_ws), k, small_parts, d_tok, d_conf);
+        return hipGetLastError();
+    }
     if (lstm && lstm->layers) {                       // the real cell (speckv_ext_predictor_load_lstm)
         if (lstm->layers > 4u) return hipErrorInvalidValue;
         LstmWeights w{};

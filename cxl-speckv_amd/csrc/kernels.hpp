@@ -379,6 +379,13 @@ inline uint32_t predict_topk_parts(uint32_t vocab)
     const uint32_t parts = (vocab + kPredictTopkSpan - 1u) / kPredictTopkSpan;
     return parts <= kPredictTopkMaxParts ? parts : 0u;
 }
-inline size_t predict_ws_bytes(uint32_t n, uint32_t vocab) { return static_cast<size_t>(n) * predict_topk_parts(vocab) * kPredictWsPerPart + 64; }
+// a handful of requests take k_predict_small: parts of 128 rows, at most kPredictSmallMaxParts of them (vocabularies up to 32 768)
+constexpr uint32_t kPredictSmallN = 4, kPredictSmallMaxParts = 256;
+inline size_t predict_ws_bytes(uint32_t n, uint32_t vocab)
+{
+    const size_t batch = static_cast<size_t>(n) * predict_topk_parts(vocab) * kPredictWsPerPart;
+    const size_t small = static_cast<size_t>(kPredictSmallN) * kPredictSmallMaxParts * kPredictWsPerPart;
+    return (batch > small ? batch : small) + 64;
+}
 
 } // namespace speckv

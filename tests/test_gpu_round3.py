@@ -407,6 +407,67 @@ def test_real_lstm_cell_predictor_matches_torch_nn_lstm():
         lib.finalize()
 
 
+@pytest.mark.parametrize("vocab", [1000, 32000])
+def test_small_prediction_path_equals_the_batch_path(oracle, vocab):
+    """One to four requests take two launches (k_predict_small: the logits of a workgroup's 128 rows reduced on the spot, no
+    logits in memory; k_predict_small_merge) instead of the batch path's four.  Both paths on the same weights and histories
+    (SPECKV_PREDICT_BATCH_PATH, read at every call): the same tokens, confidences within 2e-5 (the dot products add in a
+    different order), for the reference's degenerate cell -- also against the oracle -- and for the real LSTM cell with an
+    output bias."""
+    torch = torch_mod()
+    lib = open_lib()
+    try:
+        rng = np.random.default_rng(vocab + 5)
+        emb = rng.standard_normal((vocab, 64)).astype(np.float32) * 0.5
+        wout = rng.standard_normal((vocab, 128)).astype(np.float32) * 0.5
+
+        def run(n, k, H):
+            d_h = torch.from_numpy(H).cuda()
+            d_tok = torch.full((n, k), -7, dtype=torch.int32, device="cuda"); d_conf = torch.zeros((n, k), dtype=torch.float32, device="cuda")
+            lib.predict_batch(n, d_h.data_ptr(), k, d_tok.data_ptr(), d_conf.data_ptr())
+            torch.cuda.synchronize()
+            return d_tok.cpu().numpy(), d_conf.cpu().numpy()
+
+        def both(n, k, H):
+            small = run(n, k, H)
+            os.environ["SPECKV_PREDICT_BATCH_PATH"] = "1"
+            try:
+                batch = run(n, k, H)
+            finally:
+                os.environ.pop("SPECKV_PREDICT_BATCH_PATH")
+            return small, batch
+
+        lib.predictor_load(emb.ctypes.data, wout.ctypes.data, vocab, False)
+        for n in (1, 2, 3, 4):
+            for k in (1, 4, 8):
+                H = rng.integers(0, vocab, (n, 16)).astype(np.int32)
+                H[0, :2] = vocab + 3                                 # out-of-vocabulary ids embed as zeros
+                (tok, conf), (btok, bconf) = both(n, k, H)
+                assert tok.tolist() == btok.tolist(), (n, k)
+                assert np.allclose(conf, bconf, rtol=2e-5, atol=1e-12), (n, k, np.abs(conf - bconf).max())
+                for i in range(n):
+                    o_tok, o_conf = oracle.lstm_predict(emb, wout, H[i].astype(np.uint32), k)
+                    assert tok[i].tolist() == o_tok.astype(np.int32).tolist(), (n, k, i)
+                    assert np.allclose(conf[i], o_conf, rtol=5e-4, atol=1e-12)
+        # the real cell: k_lstm_cell's hidden vectors feed k_predict_small
+        gen = torch.Generator().manual_seed(3)
+        rnd = lambda *shape: (torch.rand(shape, generator=gen) - 0.5) * 0.4
+        w_ih, w_hh = [rnd(512, 64), rnd(512, 128)], [rnd(512, 128), rnd(512, 128)]
+        b_ih, b_hh = [rnd(512), rnd(512)], [rnd(512), rnd(512)]
+        bout = rnd(vocab)
+        t_emb, t_wout = torch.from_numpy(emb), torch.from_numpy(wout)
+        lib.predictor_load_lstm(t_emb.data_ptr(), vocab, [t.data_ptr() for t in w_ih], [t.data_ptr() for t in w_hh],
+                                [t.data_ptr() for t in b_ih], [t.data_ptr() for t in b_hh], t_wout.data_ptr(), bout.data_ptr(), False)
+        for n in (1, 4):
+            H = rng.integers(0, vocab, (n, 16)).astype(np.int32)
+            (tok, conf), (btok, bconf) = both(n, 8, H)
+            assert tok.tolist() == btok.tolist(), n
+            assert np.allclose(conf, bconf, rtol=2e-5, atol=1e-12), (n, np.abs(conf - bconf).max())
+            assert conf[0, 0] > conf[0, 7] > 0.0
+    finally:
+        lib.finalize()
+
+
 @pytest.mark.parametrize("n_req", [5, 64, 200])
 def test_one_workgroup_flush_equals_the_four_launch_pipeline(oracle, n_req):
     """Small flushes run the device-side pipeline (candidates, first-occurrence dedupe, ring run, ordered placement) as phases
