@@ -1395,11 +1395,13 @@ def lstm_cell_extra(torch, lib):
 
 def striped_attention_extra(torch, pkg, T=32768, Lyr=80):
     """The fused attention over a pool striped across 7 pools (the 1 + 7 layout of BASELINE configs[3], here 7 same-GPU
-    pools): the striped form computes its record addresses; the table form (what an allocation with migrated pages takes) reads
-    them from the page table one tile ahead; the per-wave page-table kernel is what every striped pool took before."""
+    pools): the striped form computes its record addresses; the table form (what an allocation with migrated pages, or a
+    range whose last tile would leave its region, takes; SPECKV_ATTEND_GENERAL forces it) reads them from the page table one
+    tile ahead.  (The per-wave page-table kernels of rounds 1-3 are retired: INT4 has none left, FP8 keeps one for layouts
+    without a scale table.)"""
     out = {}
     for scheme, name, fn in ((3, "int4", int4_attention_extra), (4, "fp8", fp8_scores_extra)):
-        for label, general in (("computed_addresses", 0), ("page_table_kernel", 1), ("table_form", 2)):
+        for label, general in (("computed_addresses", 0), ("table_form", 1)):
             os.environ["SPECKV_POOL_DEVICES"] = "0,0,0,0,0,0,0"
             if general:
                 os.environ["SPECKV_ATTEND_GENERAL"] = str(general)

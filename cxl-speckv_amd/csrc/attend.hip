@@ -541,11 +541,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sc[4 * b + i] = s[i] * (ks4[2 * b + (i >> 1)] * qscale);
             }
-            if (ragged && tile + 1u == n_tiles) {                         // wave-uniform: positions beyond the range
+            if ((ragged && tile + 1u == n_tiles) || (a.skip_pages && tile == 0u)) {     // wave-uniform: positions beyond / in front of the range
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const uint32_t pg = tile * 16u + ((j >> 1) < 2 ? 2u * kb + (j >> 1) : 8u + 2u * kb + ((j >> 1) - 2));
-                    if (pg >= a.n_pages) sc[j] = -INFINITY;
+                    if (pg >= a.n_pages || pg < a.skip_pages) sc[j] = -INFINITY;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -813,11 +813,11 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sc[4 * b + i] = s[i] * (ks4[2 * b + (i >> 1)] * qscale);
             }
-            if (ragged && tile + 1u == n_tiles) {                         // wave-uniform: positions beyond the range
+            if ((ragged && tile + 1u == n_tiles) || (a.skip_pages && tile == 0u)) {     // wave-uniform: positions beyond / in front of the range
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const uint32_t pg = tile * 16u + ((j >> 1) < 2 ? 2u * kb + (j >> 1) : 8u + 2u * kb + ((j >> 1) - 2));
-                    if (pg >= a.n_pages) sc[j] = -INFINITY;
+                    if (pg >= a.n_pages || pg < a.skip_pages) sc[j] = -INFINITY;
                 }
             }
             // ---- online softmax of query row c

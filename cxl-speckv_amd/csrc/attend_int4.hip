@@ -11,15 +11,15 @@
 // run on v_mfma_f32_16x16x32_f16 with fp32 accumulation, softmax weights are rounded to f16.  So
 // the result is the attention over the decompressed fp16 pages without ever writing them.
 //
-// One wave = one kv head x one split of the positions, tiles of 32 positions; the four waves of a workgroup are four
-// neighbouring heads.  Two kernels:
-//   k_attend_int4_wg    LINEAR form (records of the allocation in one run: record p at lin_base + p*1152, never-written
-//                       records zero bytes, addresses are arithmetic): the workgroup fetches a tile for its four heads
-//                       together, whole 128-byte lines, global -> LDS by LDS-DMA, two tiles deep (see below)
-//   k_attend_int4<..>   page-table form (striped / migrated / remote pools, ranges that are not tile aligned): each
-//                       page's record address comes from its page-table entry (never-written pages read a zero page);
-//                       register-staged loads per wave.  <true> is the same loop on linear addresses, kept as the A/B
-//                       baseline of the LDS-DMA kernel (build with -DSPECKV_INT4_REGSTAGE)
+// One wave = one kv head x one split of the positions, tiles of 32 positions.  Two kernels:
+//   k_attend_int4_wg8   LINEAR form with 8 kv heads (records of the allocation in one run: record p at lin_base + p*1152,
+//                       never-written records zero bytes, addresses are arithmetic): 8 waves = the 8 heads of a tile, whole
+//                       records per workgroup, global -> LDS by LDS-DMA (see there)
+//   k_attend_int4_wg    four neighbouring heads per workgroup, whole 128-byte lines by LDS-DMA, two tiles deep: the LINEAR
+//                       form for other head counts, the STRIPED form (computed addresses over 2..8 pools) and the TABLE form
+//                       (record addresses from the page-table entries, never-written pages read a zero page, look-ups
+//                       clamped to the range: migrated pools, ranges whose last tile would leave the region)
+// (Rounds 1-3 also had a per-wave page-table kernel with register-staged loads, 0.37 of HBM peak; the table form replaced it.)
 // Operand mapping (both kernels):
 //   scores S^T = K . q^T: lane (c, kb) feeds row c = position 16b + c, d = 32kb + 8*step + e --
 //     exactly group kb of that row: 16 nibble bytes and one scale per lane and block.
@@ -240,196 +240,7 @@ __device__ __forceinline__ void store_partial(const AttendArgs& a, uint64_t part
 
 } // namespace
 
-#ifndef SPECKV_INT4_WAVES
-#define SPECKV_INT4_WAVES 3
-#endif
-#ifndef SPECKV_INT4_WG_HEADS
-#define SPECKV_INT4_WG_HEADS 4
-#endif
-constexpr uint32_t kWgHeads = SPECKV_INT4_WG_HEADS;     // kv heads (= waves) per workgroup
-template <bool LINEAR>
-__global__ __launch_bounds__(64 * SPECKV_INT4_WG_HEADS) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4_WAVES, SPECKV_INT4_WAVES))) void k_attend_int4(AttendArgs a)
-{
-    // per wave: V nibbles 32 rows x 128 B pitch (64 used, +64 for rows with bit 2 set: bank spread), then
-    // 32 rows x 8 B of V group scales
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kWgHeads][4096 + 256];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t c = lane & 15u, kb = lane >> 4;
-    const uint32_t split = blockIdx.x;
-    const uint32_t hq = a.heads / kWgHeads;
-    uint32_t layer = blockIdx.y / hq;                                    // batch form: the sequence index
-    const uint32_t head = (blockIdx.y % hq) * kWgHeads + wave;
-    const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;
-    uint64_t part = row * a.n_splits + split;
-    uint32_t my_splits = a.n_splits;
-    if (a.seqs) {                                                        // wave-uniform: per-sequence geometry
-        const AttendSeq sq = a.seqs[layer];
-        if (split >= sq.n_splits) {
-            if (sq.n_splits == 0u && split == 0u && a.direct_out && a.direct_per_seq == 2u) attend_zero_rows(a.direct_out, a.direct_lse, a.g, row, lane);
-            return;
-        }
-        a.lin_base = sq.lin_base;
-        a.k_first = sq.k_first;
-        a.v_first = sq.v_first;
-        a.n_pages = sq.n_pages;
-        a.tiles_per_split = sq.tiles_per_split;
-        a.k_first += static_cast<uint64_t>(a.batch_layer) * sq.layer_pages;
-        a.v_first += static_cast<uint64_t>(a.batch_layer) * sq.layer_pages;
-        my_splits = sq.n_splits;
-        part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
-        layer = 0;
-    }
-    uint8_t* vl = lds[wave];
-
-    // query operand: fp16 row c of this head, d = 32kb + 8*step + e in deq_row8's element order (rows >= g are zero)
-    f16x8 qv[4];
-    {
-        const uint16_t* q16 = reinterpret_cast<const uint16_t*>(a.q8) + (row * a.g + c) * 128u + kb * 32u;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            uint4 t = make_uint4(0u, 0u, 0u, 0u);
-            if (c < a.g) t = *reinterpret_cast<const uint4*>(q16 + 8 * st);
-            qv[st] = q_operand(t);
-        }
-    }
-    const float qscale = a.scale_log2e;
-
-    const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
-    const uint32_t t0 = split * a.tiles_per_split;
-    const uint32_t t1 = min(t0 + a.tiles_per_split, n_tiles);
-    float m_run = -INFINITY, l_run = 0.0f;
-    f32x4 acc[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-    if (t0 < t1) {                                                       // wave-uniform
-        const uint32_t rowoff = (c & 1u) * 8u + head;                    // (slot, head) row of the lane's K rows
-        // K: lane's rows 16b + c of the tile -> page tile*16 + 8b + c/2; per tile the pointers advance 16 pages
-        const uint8_t* kpage = a.lin_base + (a.k_first + layer * a.layer_stride + static_cast<uint64_t>(t0) * 16u + (c >> 1)) * kInt4RecBytes;
-        const uint8_t* kdat = kpage + 128u + rowoff * 64u + kb * 16u;    // block b: + 8 pages
-        const uint8_t* ksc = kpage + rowoff * 8u + kb * 2u;
-        // V staging loads: instruction n covers rows 16n + lane/4 (16-byte piece lane%4); scales: row lane/2, half lane%2
-        const uint8_t* vpage0 = a.lin_base + (a.v_first + layer * a.layer_stride + static_cast<uint64_t>(t0) * 16u) * kInt4RecBytes;
-        const uint32_t vr = lane >> 2;                                   // row 0..15 (+16 for n = 1)
-        const uint8_t* vdat = vpage0 + (vr >> 1) * kInt4RecBytes + 128u + ((vr & 1u) * 8u + head) * 64u + (lane & 3u) * 16u;
-        const uint32_t sr = lane >> 1;                                   // row 0..31
-        const uint8_t* vsc = vpage0 + (sr >> 1) * kInt4RecBytes + ((sr & 1u) * 8u + head) * 8u + (lane & 1u) * 4u;
-        const uint32_t tile_bytes = 16u * kInt4RecBytes;
-
-        uint4 kx[2];
-        uint16_t ks[2];
-        uint4 vraw[2];
-        uint32_t vsraw;
-        // page-table form: record base of page pg of the K / V region (clamped into the range; never written -> zeros)
-        const PageEntry* kent = a.entries + a.k_first + layer * a.layer_stride;
-        const PageEntry* vent = a.entries + a.v_first + layer * a.layer_stride;
-        auto rec_base = [&](const PageEntry* ent, uint32_t pg) -> const uint8_t* {
-            const PageEntry e = ent[min(pg, a.n_pages - 1u)];
-            return e.rec_bytes >= kInt4RecBytes ? reinterpret_cast<const uint8_t*>(e.pool_addr) : a.zero_page;
-        };
-        uint32_t next_k = t0, next_v = t0;                                // tile the next request is for
-        // page-table form: the record addresses of a tile are looked up ONE REQUEST AHEAD (kbase / vbase hold those of
-        // tile next_k / next_v), so a request is one round trip, not a page-table entry and then the record behind it
-        const uint8_t* kbase[2] = {nullptr, nullptr};
-        const uint8_t* vbase[3] = {nullptr, nullptr, nullptr};
-        auto lookup_k = [&](uint32_t tile) {
-#pragma unroll
-            for (int b = 0; b < 2; ++b) kbase[b] = rec_base(kent, tile * 16u + 8u * b + (c >> 1));
-        };
-        auto lookup_v = [&](uint32_t tile) {
-            vbase[0] = rec_base(vent, tile * 16u + (vr >> 1));
-            vbase[1] = rec_base(vent, tile * 16u + 8u + (vr >> 1));
-            vbase[2] = rec_base(vent, tile * 16u + (sr >> 1));
-        };
-        if (!LINEAR) { lookup_k(t0); lookup_v(t0); }
-        auto issue_k = [&]() {
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                if (LINEAR) {
-                    kx[b] = ldg16(kdat + 8u * kInt4RecBytes * b);
-                    ks[b] = ldg_small<uint16_t>(ksc + 8u * kInt4RecBytes * b);
-                } else {
-                    kx[b] = ldg16(kbase[b] + 128u + rowoff * 64u + kb * 16u);
-                    ks[b] = ldg_small<uint16_t>(kbase[b] + rowoff * 8u + kb * 2u);
-                }
-            }
-            if (!LINEAR) lookup_k(next_k + 1u);                          // (clamped into the range by rec_base)
-        };
-        auto issue_v = [&]() {
-            if (LINEAR) {
-                vraw[0] = ldg16(vdat);
-                vraw[1] = ldg16(vdat + 8u * kInt4RecBytes);
-                vsraw = ldg_small<uint32_t>(vsc);
-            } else {
-                const uint32_t voff = 128u + ((vr & 1u) * 8u + head) * 64u + (lane & 3u) * 16u;
-                vraw[0] = ldg16(vbase[0] + voff);
-                vraw[1] = ldg16(vbase[1] + voff);
-                vsraw = ldg_small<uint32_t>(vbase[2] + ((sr & 1u) * 8u + head) * 8u + (lane & 1u) * 4u);
-                lookup_v(next_v + 1u);
-            }
-        };
-        // LDS addresses: writer and reader
-        const uint32_t wr0 = vr * 128u + ((vr >> 2) & 1u) * 64u + (lane & 3u) * 16u;           // rows 16..31: + 2048, same bit 2
-        const uint32_t wrs = 4096u + sr * 8u + (lane & 1u) * 4u;
-        // reader: position slot j is row r = 4kb + j (j < 4) or 16 + 4kb + (j - 4); bit 2 of r is kb & 1 either way,
-        // so every read is one base address plus a compile-time offset
-        const uint8_t* rdb = vl + 4u * kb * 128u + (kb & 1u) * 64u + 4u * c;
-        const uint8_t* rsb = vl + 4096u + 4u * kb * 8u + 2u * (c >> 2);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_k();
-        __builtin_amdgcn_sched_barrier(0);
-        issue_v();
-        __builtin_amdgcn_sched_barrier(0);
-        const bool ragged = (a.n_pages & 15u) != 0u;
-#pragma unroll 1
-        for (uint32_t tile = t0; tile < t1; ++tile) {
-            const uint32_t step = (tile + 1u < t1) ? tile_bytes : 0u;    // the last iteration re-requests its own tile
-            // ---- scores (raw dot products: sm_scale * log2(e) joins in the exponent below)
-            float sc[8];
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const f32x4 s = score_block(kx[b], ks[b], qv);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sc[4 * b + i] = s[i];
-            }
-            if (ragged && tile + 1u == n_tiles) {                         // wave-uniform: positions beyond the range
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t pg = tile * 16u + ((j >> 1) < 2 ? 2u * kb + (j >> 1) : 8u + 2u * kb + ((j >> 1) - 2));
-                    if (pg >= a.n_pages) sc[j] = -INFINITY;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            kdat += step; ksc += step; next_k += step ? 1u : 0u;
-            issue_k();
-            __builtin_amdgcn_sched_barrier(0);
-            const f16x8 P = softmax_tile(sc, qscale, m_run, l_run, acc);
-            // ---- V tile: registers -> this wave's LDS -> operand order
-            *reinterpret_cast<uint4*>(vl + wr0) = vraw[0];
-            *reinterpret_cast<uint4*>(vl + wr0 + 2048u) = vraw[1];
-            *reinterpret_cast<uint32_t*>(vl + wrs) = vsraw;
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            uint32_t vw[8], vs16[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int ro = (j < 4) ? j : 16 + (j - 4);
-                vw[j] = *reinterpret_cast<const uint32_t*>(rdb + 128 * ro);                   // 8 nibbles of slot j, d = 8c..8c+7
-                vs16[j] = *reinterpret_cast<const uint16_t*>(rsb + 8 * ro);                   // its group scale (group c/4)
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            vdat += step; vsc += step; next_v += step ? 1u : 0u;
-            issue_v();                                                    // the staging registers are free again
-            __builtin_amdgcn_sched_barrier(0);
-            pv_tile(vw, vs16, P, acc);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    store_partial(a, part, row, my_splits, c, kb, m_run, l_run, acc);
-}
+constexpr uint32_t kWgHeads = 4;     // kv heads (= waves) per workgroup of k_attend_int4_wg
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Linear form, workgroup-cooperative LDS-DMA.  Measured on the per-wave kernels: with all arithmetic removed they ran no
@@ -1054,13 +865,9 @@ hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_
         else hipLaunchKernelGGL(k_attend_int4_wg8<2>, grid8, dim3(1024), 0, s, a);
         return hipGetLastError();
     }
-#ifdef SPECKV_INT4_REGSTAGE
-    if (a.lin_base && !a.rows_first) hipLaunchKernelGGL(k_attend_int4<true>, dim3(a.n_splits, n_layers * (a.heads / kWgHeads)), dim3(64 * kWgHeads), 0, s, a);
-    else
-#endif
     if (a.lin_base) hipLaunchKernelGGL(k_attend_int4_wg<false>, wg_grid, dim3(256), 0, s, a);
     else if (a.stripe_bases) hipLaunchKernelGGL(k_attend_int4_wg<true>, wg_grid, dim3(256), 0, s, a);
-    else            hipLaunchKernelGGL(k_attend_int4<false>, dim3(a.n_splits, n_layers * (a.heads / kWgHeads)), dim3(64 * kWgHeads), 0, s, a);
+    else return hipErrorInvalidValue;                                    // (the engine always names a form: linear, striped or table)
     return hipGetLastError();
 }
 

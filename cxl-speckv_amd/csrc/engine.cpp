@@ -2317,17 +2317,25 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
         pos_end > L.num_tokens || pos_end % 2)
         return SPECKV_ERR_INVAL;
     if (g == 0 || g > 16 || !d_q_f16 || !d_out) return SPECKV_ERR_INVAL;
-    const uint32_t n_pages = (pos_end - pos_begin) / 2;
     DeviceScope device_scope(device_);
     // NULL = the engine's stream and a synchronous call: the query may have been produced on any stream of the caller
     if (!s) HIP_TRY(hipDeviceSynchronize());
     hipStream_t st = s ? s : stream_;
     const size_t out_elems = static_cast<size_t>(n_layers) * L.num_heads * g * 128;
-    if (n_pages == 0) {          // empty range: softmax over nothing -> zeros (and -inf lse is left to the caller)
+    if (pos_end == pos_begin) {  // empty range: softmax over nothing -> zeros (and -inf lse is left to the caller)
         HIP_TRY(hipMemsetAsync(d_out, 0, out_elems * sizeof(float), st));
         if (!s) HIP_TRY(hipStreamSynchronize(stream_));
         return SPECKV_OK;
     }
+    // The scale table is laid out in tiles of 32 positions from the start of a region: a range that starts inside a tile is
+    // attended from the tile's start with its leading positions masked (AttendArgs::skip_pages), so every range of a layout
+    // with a scale table takes the tile forms (linear / striped / table) -- the per-wave page-table kernel is left with the
+    // layouts that have none (num_tokens not a multiple of 32).
+    const bool has_tab = a->d_scale_tab != nullptr;
+    const uint32_t begin_al = has_tab ? (pos_begin & ~31u) : pos_begin;
+    const uint32_t skip_pages = (pos_begin - begin_al) / 2;
+    const uint32_t n_pages = (pos_end - begin_al) / 2;
+    pos_begin = begin_al;
     // shim layout [req 0][layer][kind][pos][head]: K pages of a layer, then its V pages
     const uint64_t k_first = (static_cast<uint64_t>(layer) * 2 * L.num_tokens + pos_begin) / 2;
     const uint64_t v_first = k_first + L.num_tokens / 2;
@@ -2347,15 +2355,15 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     const uint32_t rows = n_layers * L.num_heads;
     // linear form: records in one run, scale table present, tiles aligned with the table's (pos_begin a multiple of 32),
     // and the last (possibly ragged) 32-position tile must not read past the K / V region of its layer
-    const bool fits = pos_begin % 32u == 0u && a->d_scale_tab &&
-                      static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
-    const uint8_t* lin_base = (getenv("SPECKV_ATTEND_GENERAL") || !fits) ? nullptr : a->linear_base;
-    // regular striping over several pools: the same kernel with computed record addresses (no page-table chase)
-    const bool striped = !lin_base && fits && a->stripe_n >= 2 && !getenv("SPECKV_ATTEND_GENERAL");
-    // no regular placement (pages migrated one by one) but a tile-aligned range: the fast kernel with its record addresses
-    // from the page table, looked up one request ahead (SPECKV_ATTEND_GENERAL=2 forces it for measurements)
+    // (with the range aligned as above and num_tokens a multiple of 32 the tiles never leave the region)
+    const bool fits = has_tab && static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
     const char* general_env = getenv("SPECKV_ATTEND_GENERAL");
-    const bool table = fits && ((!lin_base && !striped && !general_env) || (general_env && general_env[0] == '2'));
+    const uint8_t* lin_base = (general_env || !fits) ? nullptr : a->linear_base;
+    // regular striping over several pools: the same kernel with computed record addresses (no page-table chase)
+    const bool striped = !lin_base && fits && a->stripe_n >= 2 && !general_env;
+    // no regular placement (pages migrated one by one), or SPECKV_ATTEND_GENERAL set (measurements, tests): the fast kernel
+    // with its record addresses from the page table, looked up one request ahead
+    const bool table = fits && !lin_base && !striped;
     // (the page-table form has nothing to gain from whole rows: it hides its look-ups behind other waves and always
     // goes through the merge -- 80 layers x 8k: one split 0.13 of HBM peak, eight 0.18+)
     uint32_t want = (lin_base && rows / 4u >= 128u && n_tiles < 768u) ? 1u : (5120u + rows - 1u) / rows;     // (32k and beyond: 8 splits, below)
@@ -2377,6 +2385,7 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     k.v_first = v_first;
     k.layer_stride = layer_stride;
     k.n_pages = n_pages;
+    k.skip_pages = skip_pages;
     k.heads = L.num_heads;
     k.g = g;
     k.n_splits = n_splits;
@@ -2849,9 +2858,11 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     const char* general_env = getenv("SPECKV_ATTEND_GENERAL");
     const bool linear = a->linear_base && fits && !general_env;
     const bool striped = !linear && a->stripe_n >= 2 && fits && !general_env;
-    // no regular placement but a range inside the layer's tiles: the workgroup kernel with its record addresses from the
-    // page table (SPECKV_ATTEND_GENERAL=2 forces it for measurements; =1: the per-wave page-table kernel)
-    const bool table = fits && ((!linear && !striped && !general_env) || (general_env && general_env[0] == '2'));
+    // everything else -- no regular placement, a last tile that would leave the region, SPECKV_ATTEND_GENERAL (measurements,
+    // tests) -- takes the workgroup kernel with its record addresses from the page table: its look-ups are clamped to the
+    // range, so a ragged last tile never reads a record it has no business with.  (The per-wave page-table kernel of rounds
+    // 1-3, 0.37 of HBM peak, is gone.)
+    const bool table = !linear && !striped;
     if (!linear && !d_zero_page_) {
         if (is_capturing(s)) return SPECKV_ERR_INVAL;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));

@@ -241,6 +241,7 @@ struct AttendArgs {
     uint64_t k_first, v_first;        // first K / V page of layer_begin at pos_begin
     uint64_t layer_stride;            // pages per layer (K + V)
     uint32_t n_pages;                 // pages of the position range
+    uint32_t skip_pages;              // FP8 tile forms: the first skip_pages pages of the range are masked (a range that starts inside a 32-position tile)
     uint32_t heads, g;
     uint32_t n_splits, tiles_per_split;   // tile = 16 pages = 32 positions
     const uint8_t* q8;                // [layers][heads][16][128] e4m3

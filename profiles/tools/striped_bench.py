@@ -8,7 +8,7 @@ L = sys.argv[2] if len(sys.argv) > 2 else "80"
 rows = []
 for tool in ("int4_bench.py", "fp8_bench.py"):
     for label, env in (("linear (one pool)", {}), ("striped x7, computed addresses", {"SPECKV_POOL_DEVICES": "0,0,0,0,0,0,0"}),
-                       ("striped x7, page table", {"SPECKV_POOL_DEVICES": "0,0,0,0,0,0,0", "SPECKV_ATTEND_GENERAL": "1"})):
+                       ("striped x7, table form", {"SPECKV_POOL_DEVICES": "0,0,0,0,0,0,0", "SPECKV_ATTEND_GENERAL": "1"})):
         e = dict(os.environ); e.update(env)
         out = subprocess.run([sys.executable, os.path.join(HERE, tool), T, L], env=e, capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith(("int4", "fp8"))]

@@ -934,6 +934,63 @@ def test_fused_attention_random_cases_against_fetched_pages(eng):
             lib.free(h)
 
 
+@pytest.mark.parametrize("pools,general", [(None, False), ("0,0,0", False), (None, True)])
+def test_attention_ranges_that_start_inside_a_tile_or_end_outside_the_region(pools, general):
+    """the per-wave page-table kernels are retired.  FP8: a range that starts inside a 32-position tile is
+    attended from the tile's start with the leading positions masked (AttendArgs::skip_pages) by the linear / striped / table
+    forms; INT4: a range whose last tile would leave the layer's region takes the table form, whose look-ups are clamped.
+    Against torch attention over the rows the engine fetches + decompresses, on one pool (linear), three pools (striped) and
+    with SPECKV_ATTEND_GENERAL set (table form); layouts of 256 tokens (scale table) and 200 tokens (none: the FP8 general
+    kernel is still what runs there)."""
+    torch = torch_mod()
+    rng = np.random.default_rng(77)
+    H, D, G = 8, 128, 8
+    if pools: os.environ["SPECKV_POOL_DEVICES"] = pools
+    try:
+        kvx = pkg.CxlSpeckvKVAllocator(pkg.library_path(), "hip:0")
+    finally:
+        os.environ.pop("SPECKV_POOL_DEVICES", None)
+    lib = kvx.lib
+    try:
+        for scheme, fused in ((4, lib.attend_fp8), (3, lib.attend_int4)):
+            for T in (256, 200):
+                lib.set_compression_scheme(scheme)
+                L = 2
+                h = kvx.allocate(T, L, H, D, 2)
+                n_pages = T * L * H * D * 2 * 2 // PAGE
+                x = (rng.standard_normal((n_pages, N)) * 1.5).astype(np.float16)
+                lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+                q = torch.from_numpy(rng.standard_normal((L, H, G, D)).astype(np.float16)).cuda()
+                for pos_begin, pos_end in ((6, T), (34, 100), (62, 66), (30, 32), (0, T), (T - 2, T)):
+                    out = torch.full((L, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
+                    lse = torch.full((L, H, G), float("nan"), dtype=torch.float32, device="cuda")
+                    if general: os.environ["SPECKV_ATTEND_GENERAL"] = "1"
+                    try:
+                        fused(h, 0, L, q.data_ptr(), G, pos_begin, pos_end, 0.09, out.data_ptr(), lse.data_ptr())
+                        torch.cuda.synchronize()
+                    finally:
+                        os.environ.pop("SPECKV_ATTEND_GENERAL", None)
+                    for layer in range(L):
+                        k = kvx.kv_rows(0, layer, 0, pos_begin, pos_end).float().clone()
+                        v = kvx.kv_rows(0, layer, 1, pos_begin, pos_end).float().clone()
+                        sc = torch.einsum("hgd,thd->hgt", q[layer].float(), k) * 0.09
+                        p = torch.softmax(sc, dim=-1)
+                        ref = torch.einsum("hgt,thd->hgd", p, v)
+                        mag = torch.einsum("hgt,thd->hgd", p, v.abs())
+                        err = (out[layer] - ref).abs()
+                        what = (scheme, T, pos_begin, pos_end, layer)
+                        if scheme == 3:
+                            assert bool((err <= 2e-3 * mag + 1e-6).all()), (what, float((err / (mag + 1e-9)).max()))
+                        else:
+                            assert float(err.max()) <= 0.12 * float(ref.abs().max()) + 1e-3, what
+                        # (FP8: the query is quantised to e4m3 per row -- scores of |s| ~ 2 move by up to ~0.1, and a range of
+                        # four positions averages nothing away)
+                        assert float((lse[layer] - torch.logsumexp(sc, dim=-1)).abs().max()) <= (2e-3 if scheme == 3 else 0.15), what
+                lib.free(h)
+    finally:
+        kvx.close()
+
+
 def test_fused_attention_argument_errors(eng):
     """Status codes of the attention entry points for bad arguments (no launch, no crash): unknown handle -> GENERAL
     (-1, as speckv_access), everything else -> INVAL (-4)."""

@@ -115,7 +115,7 @@ def test_config5_70b_shaped_32k_context_at_full_size(eng, oracle, scheme):
     heads = {0: (0, 5), 41: (3,), 79: (7, 2)}
 
     def run(general, layer0=0, n_layers=L, pos_end=T):
-        if general: os.environ["SPECKV_ATTEND_GENERAL"] = str(int(general))      # 1: the page-table kernel, 2: the table form of the fast kernel
+        if general: os.environ["SPECKV_ATTEND_GENERAL"] = str(int(general))      # 1, 2: the table form of the fast kernel (record addresses from the page table)
         try:
             out = torch.full((n_layers, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
             lse = torch.full((n_layers, H, G), float("nan"), dtype=torch.float32, device="cuda")
