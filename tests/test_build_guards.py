@@ -31,7 +31,8 @@ HOT = [
     ("attend.o", r"k_qk_scores_fp8_linear", 0),
     ("attend_int4.o", r"k_attend_int4_wgILb0E", 0),
     ("attend_int4.o", r"k_attend_int4_wgILb1E", 1),
-    ("attend_int4.o", r"k_attend_int4ILb0E", 0),
+    ("attend_int4.o", r"k_attend_int4_wg8ILi1E", 0),
+    ("attend_int4.o", r"k_attend_int4_wg8ILi2E", 0),
 ]
 
 
