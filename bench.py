@@ -1333,10 +1333,10 @@ def tensor_codec_extra(torch, lib, n=131072 * 256):
             b.record(s); torch.cuda.synchronize()
             ms = a.elapsed_time(b) / 5
             out[name] = {"ms": round(ms, 4), "algorithmic_GBps": round(byt / (ms * 1e-3) / 1e9, 1), "frac_hbm": round(byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
-        out["note"] = ("any n, exact: three passes over the source (abs-max, tile summaries, emit: whole fp16 tiles by the block encoder's "
-                       "8-elements-per-lane path) + a one-workgroup scan across tiles + a pack pass; the pool itself stores KV per 4 KiB "
-                       "block (the headline path)")
-        return {"tensor_codec_whole_tensor": out}
+        out["note"] = ("any n, exact.  Compress: an abs-max pass, then ONE pass that encodes whole fp16 tiles by the block encoder's "
+                       "8-elements-per-lane path and places them in the stream by look-back across workgroups (two reads of the source, one "
+                       "write of the stream); decompress: summary, scans, expand.  The pool itself stores KV per 4 KiB block (the headline path)")
+        return {"tensor_codec_whole_tensor" if n == 131072 * 256 else f"tensor_codec_whole_tensor_{n * 2 // 2**20}MiB": out}
     except Exception as e:
         return {"tensor_codec_whole_tensor": {"error": repr(e)}}
 
@@ -1514,6 +1514,7 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     ex.update(lstm_cell_extra(torch, lib))
     ex.update(compaction_extra(torch, kv))
     ex.update(tensor_codec_extra(torch, lib))
+    ex.update(tensor_codec_extra(torch, lib, n=1280 * 2**20))          # a 2.5 GiB source: ten times the Infinity Cache
     return ex
 
 

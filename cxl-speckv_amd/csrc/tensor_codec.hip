@@ -1047,6 +1047,256 @@ __global__ __launch_bounds__(256) void k_td_expand(const uint8_t* __restrict__ r
     }
 }
 
+// ---------------------------------------------------------------- compress in ONE pass over the source (after the abs-max pass)
+// The multi-launch form above reads the source for the tile summaries, scans them in three grids, reads the source again for
+// the tiles its fast path declined, and then GATHERS the tiles' pair slots into the stream (k_tc_pack): 92 us for 32 Mi
+// elements of which the gather alone is 29 and the scans 15.  Here a tile learns what it needs from its left neighbours while
+// it still holds its pairs in LDS, and writes them where they belong.
+//   A workgroup takes kTfWaves consecutive tiles (one per wave; ticket counter: ascending order, so a workgroup's predecessors are
+//   finished or resident).  What crosses tiles INSIDE the workgroup goes through LDS; what crosses workgroups through status
+//   words, one 8-byte agent-scope word per workgroup and chain (state << 62 | value: 0 not yet, 1 own aggregate, 2 inclusive
+//   prefix; the value IS the word, nothing to fence), looked back over 64 at a time by wave 0 alone:
+//     chain 1  last stretch start at or before the workgroup's last tile (absolute position + 1): a workgroup that has a stretch
+//              start of its own publishes its inclusive prefix at once -- it is its own last start; only a workgroup inside one
+//              long stretch publishes "nothing here" and copies the prefix it finds on its left.  From the stretch start
+//              entering a tile follow the phase of the 255-splits in its head and the last run start in front of it.
+//     chain 2  run starts up to the workgroup's end (a plain sum): aggregate = runs of its tiles, known once chain 1 has answered.
+//   Every resident workgroup publishes its words without waiting for anyone (the chain-2 aggregate waits for chain 1 of workgroups
+//   that are resident), so no look-back waits for a workgroup that has not started.  (Per-TILE words were the first form: 8192
+//   waves polling 64 words each slowed the whole chip and the first tiles walked back through 128 windows -- 97 us for the pass
+//   at 32 Mi elements against 60 for the launches it replaces.  profiles/r04_tensor_codec.txt)
+//   A pair's count byte belongs to the run that ENDS it: the tile whose first run start follows writes it (one byte in front
+//   of its own pairs); the last tile closes the stream.  A tile's bytes go out as whole aligned 16-byte pieces, re-aligned
+//   from LDS with v_alignbyte (the stream position of a tile is even, not aligned), single bytes at the two ragged ends.
+#ifndef SPECKV_TF_WAVES
+#define SPECKV_TF_WAVES 16
+#endif
+constexpr uint32_t kTfWaves = SPECKV_TF_WAVES;
+typedef unsigned long long __attribute__((address_space(1))) tc_gu64;
+__device__ __forceinline__ void tc_lb_store(uint64_t* w, uint64_t state, uint64_t value)
+{
+    __hip_atomic_store(reinterpret_cast<tc_gu64*>(reinterpret_cast<uintptr_t>(w)), (state << 62) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t tc_lb_load(const uint64_t* w)
+{
+    return __hip_atomic_load(reinterpret_cast<const tc_gu64*>(reinterpret_cast<uintptr_t>(w)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr uint64_t kTcLbMask = (1ull << 62) - 1ull;
+// words [.., t) of `status`, 64 per step from the right (one wave): SUM = true adds the aggregates in front of the nearest
+// inclusive prefix to it (an aggregate is < 2^16, a prefix < 2^62); SUM = false returns that prefix alone (chain 1: the words
+// in between say "nothing here").  Waits only for words of workgroups that are running (see above); backs off while it waits.
+template <bool SUM>
+__device__ __forceinline__ uint64_t tc_look_back(const uint64_t* status, uint64_t t, uint32_t lane)
+{
+    uint64_t acc = 0, end = t;
+    for (;;) {
+        const bool have = lane < end;
+        uint64_t w;
+        unsigned long long ready, incl;
+        uint32_t first_incl;
+        for (;;) {
+            w = have ? tc_lb_load(status + (end - 1u - lane)) : (2ull << 62);        // (in front of workgroup 0: a prefix of nothing)
+            ready = __ballot((w >> 62) != 0ull);
+            incl = __ballot((w >> 62) == 2ull);
+            first_incl = incl ? static_cast<uint32_t>(__builtin_ctzll(incl)) : 64u;
+            const unsigned long long need = first_incl >= 63u ? ~0ull : ((2ull << first_incl) - 1ull);
+            if ((ready & need) == need) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        const uint64_t v = w & kTcLbMask;
+        if (SUM) acc += lane63(wave_incl_add(lane < first_incl ? static_cast<uint32_t>(v) : 0u));
+        if (first_incl < 64u) {
+            const uint32_t pl = static_cast<uint32_t>(__shfl(static_cast<int>(v & 0xFFFFFFFFull), static_cast<int>(first_incl)));
+            const uint32_t ph = static_cast<uint32_t>(__shfl(static_cast<int>(v >> 32), static_cast<int>(first_incl)));
+            return acc + ((static_cast<uint64_t>(ph) << 32) | pl);
+        }
+        end -= 64u;
+    }
+}
+
+template <int MODE, bool F32>
+__global__ __launch_bounds__(64 * kTfWaves) void k_tc_fused(const void* __restrict__ src, uint64_t n, const uint32_t* __restrict__ absmax_bits,
+                                                            uint64_t n_tiles, uint64_t* __restrict__ w1, uint64_t* __restrict__ w2,
+                                                            uint32_t* __restrict__ ticket, uint8_t* __restrict__ out,
+                                                            float* __restrict__ out_scale, uint64_t* __restrict__ out_bytes)
+{
+    constexpr uint32_t kSlot = kTcLead + 2 * kTile + 16;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kTfWaves * kSlot];
+    __shared__ uint32_t s_ticket;
+    __shared__ uint64_t s_ss[kTfWaves];                                  // last stretch start of the tile (absolute + 1, 0 = none)
+    __shared__ uint32_t s_runs[kTfWaves];
+    __shared__ uint64_t s_ss_in, s_run_base;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0u) s_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint64_t wg = s_ticket;
+    const uint64_t tile = wg * kTfWaves + wave;
+    const bool valid = tile < n_tiles;                                  // (waves behind the last tile only keep the barriers company)
+    const uint64_t t0 = tile * kTile;
+    const uint32_t len = valid ? static_cast<uint32_t>((n - t0 < kTile) ? (n - t0) : kTile) : 0u;
+    const float scale = tc_scale(*absmax_bits);
+    if (tile == 0u && lane == 0u) *out_scale = scale;
+    // the two elements in front of the tile give q[t0-1] and d[t0-1]
+    uint32_t qtail0 = 0, dtail0 = 0;
+    if (valid && t0 >= 1) {
+        qtail0 = quantize<MODE>(tc_load<F32>(src, t0 - 1), scale);
+        const uint32_t q2 = (t0 >= 2) ? quantize<MODE>(tc_load<F32>(src, t0 - 2), scale) : 0u;
+        dtail0 = (qtail0 - q2) & 0xFFu;
+    }
+    uint8_t* wl = lds + wave * kSlot;
+    const uint32_t pair_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)(wl + kTcLead)));
+    // ---- the element-wise tile loop (k_tc_tiles' general path): summary, or pairs into LDS once the entering phase is known
+    uint32_t first_ss = 0, scarry = 0, mcarry = 0, icarry = 0;
+    auto general = [&](bool emit, uint32_t lead_phase) {
+        uint32_t qtail = qtail0, dtail = dtail0;
+        first_ss = 0; scarry = 0; mcarry = 0; icarry = 0;
+#pragma unroll 1
+        for (uint32_t step = 0; step < kTile / 64u; ++step) {
+            const uint32_t rel = 64u * step + lane;
+            if (64u * step >= len) break;                               // wave-uniform
+            const bool live = rel < len;
+            const uint32_t qv = live ? quantize<MODE>(tc_load<F32>(src, t0 + rel), scale) : 0u;
+            const uint32_t prevq = wave_shr1(qv, qtail);
+            qtail = lane63(qv);
+            const uint32_t d = (qv - prevq) & 0xFFu;
+            const uint32_t prevd = wave_shr1(d, dtail);
+            dtail = lane63(d);
+            const bool neq = live && ((t0 + rel == 0u) || (d != prevd));
+            const unsigned long long nb = __ballot(neq);
+            if (!first_ss && nb) first_ss = 64u * step + static_cast<uint32_t>(__builtin_ctzll(nb)) + 1u;
+            const uint32_t is = wave_incl_max(neq ? rel + 1u : 0u);
+            const uint32_t ss = umax(is, scarry);                       // this element's stretch start, rel + 1 (0: before the tile)
+            scarry = umax(scarry, lane63(is));
+            bool isrun;
+            if (ss) isrun = live && ((rel + 1u - ss) % 255u) == 0u;
+            else    isrun = emit && live && ((lead_phase + rel) % 255u) == 0u;       // continuation of a stretch of earlier tiles
+            const uint32_t ic = wave_incl_add(isrun ? 1u : 0u);
+            const uint32_t idx = icarry + ic - (isrun ? 1u : 0u);
+            icarry += lane63(ic);
+            const uint32_t im = wave_incl_max(isrun ? rel + 1u : 0u);
+            const uint32_t prev = umax(wave_shr1(im, 0u), mcarry);      // previous run start inside the tile (rel + 1, 0 = none)
+            mcarry = umax(mcarry, lane63(im));
+            if (emit && isrun) {
+                // value byte of this pair, count byte of the previous one (the first pair of the tile writes into the lead bytes)
+                *reinterpret_cast<__attribute__((address_space(3))) uint8_t*>(static_cast<uintptr_t>(pair_addr + 2u * idx - 1u)) = static_cast<uint8_t>(rel + 1u - prev);
+                *reinterpret_cast<__attribute__((address_space(3))) uint8_t*>(static_cast<uintptr_t>(pair_addr + 2u * idx)) = static_cast<uint8_t>(d);
+            }
+        }
+    };
+    // ---- local pass: whole aligned fp16 tiles by the 8-elements-per-lane path (its pairs land in LDS), the rest element-wise
+    bool fast = false;
+    uint32_t own_runs = 0;                                              // run starts at or behind the tile's first stretch start
+    if (valid) {
+        if (!F32 && len == kTile && ((reinterpret_cast<uintptr_t>(src) + 2ull * t0) & 15u) == 0u && !kTcNoFast) {
+            uint32_t f_first = 0, f_last = 0, f_n = 0;
+            if (tc_tile_fast<MODE, true>(static_cast<const uint8_t*>(src) + 2ull * t0, scale, 1.0f / scale, qtail0, t0 == 0u ? 0x100u : dtail0, pair_addr - 1u, lane,
+                                         f_first, f_last, f_n)) {
+                first_ss = f_first; scarry = f_last; mcarry = f_last; own_runs = f_n;
+                fast = true;
+            }
+        }
+        if (!fast) { general(false, 0u); own_runs = icarry; }
+    }
+    const uint32_t last_ss = scarry;                                    // last stretch start of the tile (rel + 1, 0 = none)
+    // ---- chain 1: the stretch start entering each tile
+    if (lane == 0u) s_ss[wave] = (valid && last_ss) ? t0 + last_ss : 0ull;
+    __syncthreads();
+    if (wave == 0u) {
+        uint64_t mine = 0;
+        for (uint32_t i = 0; i < kTfWaves; ++i) mine = s_ss[i] ? s_ss[i] : mine;       // (ascending positions: the last one that has any)
+        if (lane == 0u && wg != 0u) tc_lb_store(w1 + wg, mine ? 2ull : 1ull, mine);
+        uint64_t in = 0;
+        if (wg != 0u) in = tc_look_back<false>(w1, wg, lane);
+        if (lane == 0u) {
+            if (wg == 0u) tc_lb_store(w1, 2ull, mine);                   // (tile 0 always has position 0)
+            else if (!mine) tc_lb_store(w1 + wg, 2ull, in);
+            s_ss_in = in;
+        }
+    }
+    __syncthreads();
+    uint64_t ss_in = s_ss_in;                                           // absolute position + 1 of the stretch start entering this tile
+    for (uint32_t i = 0; i < wave; ++i) ss_in = s_ss[i] ? s_ss[i] : ss_in;
+    // phase of the entering stretch at t0, its run starts in the head of the tile (in front of the first stretch start)
+    const uint32_t lead_phase = (valid && tile) ? static_cast<uint32_t>((t0 - (ss_in - 1u)) % 255u) : 0u;
+    const uint32_t head_len = first_ss ? first_ss - 1u : len;
+    uint32_t head_runs = 0;
+    if (valid && tile && head_len) head_runs = (lead_phase + head_len - 1u) / 255u - (lead_phase ? (lead_phase - 1u) / 255u : 0u) + (lead_phase ? 0u : 1u);
+    uint32_t n_runs = head_runs + own_runs;
+    if (valid && (!fast || head_runs)) {                                // the pairs of this tile by the element-wise loop
+        general(true, lead_phase);
+        n_runs = icarry;
+    }
+    // ---- chain 2: run starts in front of each tile
+    if (lane == 0u) s_runs[wave] = valid ? n_runs : 0u;
+    __syncthreads();
+    if (wave == 0u) {
+        uint32_t total = 0;
+        for (uint32_t i = 0; i < kTfWaves; ++i) total += s_runs[i];
+        uint64_t base = 0;
+        if (wg == 0u) { if (lane == 0u) tc_lb_store(w2, 2ull, total); }
+        else {
+            if (lane == 0u) tc_lb_store(w2 + wg, 1ull, total);
+            base = tc_look_back<true>(w2, wg, lane);
+            if (lane == 0u) tc_lb_store(w2 + wg, 2ull, base + total);
+        }
+        if (lane == 0u) s_run_base = base;
+    }
+    __syncthreads();
+    if (!valid) return;                                                 // (no barrier behind this point)
+    uint64_t run_base = s_run_base;
+    for (uint32_t i = 0; i < wave; ++i) run_base += s_runs[i];
+    // ---- count bytes at the seams.  The byte in front of this tile's pairs closes the last pair of its left neighbours: it ends
+    // at this tile's first run start (or, in the last tile without a run of its own, at n); the run it belongs to started at
+    // ss_in + 255 m, so the elements in front of t0 that still belong to it are ((lead_phase + 254) % 255) + 1.
+    const bool is_last = tile + 1u == n_tiles;
+    const uint32_t back = tile ? ((lead_phase + 254u) % 255u) + 1u : 0u;
+    wave_lds_fence();
+    if (lane == 0u) {
+        uint8_t* lead = wl + kTcLead - 1u;
+        if (n_runs) {
+            const uint32_t first_rel_p1 = *lead;                        // both loops store (position of the first run start + 1) here
+            *lead = static_cast<uint8_t>(first_rel_p1 - 1u + back);
+            if (is_last) wl[kTcLead + 2u * n_runs - 1u] = static_cast<uint8_t>(len - (mcarry - 1u));      // the stream's last pair ends at n
+        } else {
+            *lead = static_cast<uint8_t>(back + (is_last ? len : 0u));   // (only a short last tile has no run start: it closes the stream)
+        }
+    }
+    wave_lds_fence();
+    if (is_last && lane == 0u) *out_bytes = 2u * (run_base + n_runs);
+    // ---- this tile's bytes: [2 run_base - 1, 2 (run_base + n_runs) - 1), plus the stream's last byte in the last tile; the
+    // byte in front only if there is a pair in front (run_base > 0) that this tile has to close (it has a run, or is the last)
+    const bool lead_out = run_base != 0u && (n_runs != 0u || is_last);
+    const uint64_t g_begin = 2u * run_base - (lead_out ? 1u : 0u);
+    const uint64_t g_end = 2u * (run_base + n_runs) - ((is_last || n_runs == 0u) ? 0u : 1u);
+    if (g_end <= g_begin) return;
+    const uint32_t l_begin = kTcLead - (lead_out ? 1u : 0u);             // LDS offset (in wl) of the byte that goes to g_begin
+    const uintptr_t gaddr = reinterpret_cast<uintptr_t>(out) + g_begin, gend = reinterpret_cast<uintptr_t>(out) + g_end;
+    const uintptr_t a0 = gaddr & ~static_cast<uintptr_t>(15);
+    // LDS byte offset of global address a: l_begin + (a - gaddr).  For 16-byte aligned a the offset modulo 4 is one value (sh).
+    const uint32_t wl_addr = pair_addr - kTcLead;
+    const int32_t delta = static_cast<int32_t>(l_begin) - static_cast<int32_t>(gaddr - a0);       // LDS offset of a0 (>= 0: the lead is 16 bytes)
+    const uint32_t sh = static_cast<uint32_t>(delta) & 3u;
+#pragma unroll 1
+    for (uintptr_t a = a0 + 16u * lane; a < gend; a += 1024u) {
+        const int32_t lo = delta + static_cast<int32_t>(a - a0);          // LDS offset of the chunk's first byte
+        if (a >= gaddr && a + 16u <= gend) {
+            const uint32_t base = wl_addr + static_cast<uint32_t>(lo & ~3);
+            uint32_t d[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) d[i] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(static_cast<uintptr_t>(base + 4u * i));
+            u32x4 v;
+            v.x = __builtin_amdgcn_alignbyte(d[1], d[0], sh); v.y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+            v.z = __builtin_amdgcn_alignbyte(d[3], d[2], sh); v.w = __builtin_amdgcn_alignbyte(d[4], d[3], sh);
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a));
+        } else {                                                        // a ragged piece at one end of the tile's stretch of the stream
+            for (uint32_t b = 0; b < 16u; ++b) {
+                const uintptr_t g = a + b;
+                if (g >= gaddr && g < gend) *reinterpret_cast<uint8_t*>(g) = wl[lo + static_cast<int32_t>(b)];
+            }
+        }
+    }
+}
+
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 } // namespace
@@ -1076,12 +1326,27 @@ hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, u
     TcCarry* carry = reinterpret_cast<TcCarry*>(w); w += align_up((tiles + 1) * sizeof(TcCarry), 256);
     uint64_t* first_run = reinterpret_cast<uint64_t*>(w); w += align_up(tiles * 8, 256);
     uint8_t* scratch = w;
-    hipError_t e = hipMemsetAsync(absmax, 0, 256, s);
+    // single pass (k_tc_fused) unless a multi-launch form is asked for (SPECKV_TC_MULTIPASS, or one of the scan / pre-emit
+    // switches of the tests): its status words and ticket sit where the summaries of the multi-launch form would be
+    const bool fused = n != 0 && !getenv("SPECKV_TC_MULTIPASS") && !getenv("SPECKV_TC_SCAN") && !getenv("SPECKV_TC_SERIAL_SCAN") && !getenv("SPECKV_TC_NO_PRE");
+    const uint64_t tf_wgs = (tiles + kTfWaves - 1) / kTfWaves;
+    hipError_t e = hipMemsetAsync(absmax, 0, fused ? 512 + 16 * tf_wgs : 256, s);
     if (e != hipSuccess) return e;
     if (n) {
         const uint32_t g = static_cast<uint32_t>(std::min<uint64_t>((n + 8191) / 8192, 256));     // 16 bytes per lane and step, one workgroup of 16 waves per CU
         if (src_f32) hipLaunchKernelGGL(k_tc_absmax<true>, dim3(g), dim3(1024), 0, s, d_src, n, absmax);
         else         hipLaunchKernelGGL(k_tc_absmax<false>, dim3(g), dim3(1024), 0, s, d_src, n, absmax);
+    }
+    if (fused) {
+        uint32_t* ticket = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_ws) + 256);
+        uint64_t* w1 = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(d_ws) + 512);
+        uint64_t* w2 = w1 + tf_wgs;
+        const uint32_t g = static_cast<uint32_t>(tf_wgs);
+#define SPECKV_TF(MODE, F32) hipLaunchKernelGGL((k_tc_fused<MODE, F32>), dim3(g), dim3(64 * kTfWaves), 0, s, d_src, n, absmax, tiles, w1, w2, ticket, d_rle, d_scale, d_rle_bytes)
+        if (quant_mode == kIntent) { if (src_f32) SPECKV_TF(kIntent, true); else SPECKV_TF(kIntent, false); }
+        else                       { if (src_f32) SPECKV_TF(kRefExact, true); else SPECKV_TF(kRefExact, false); }
+#undef SPECKV_TF
+        return hipGetLastError();
     }
     const uint32_t tg = static_cast<uint32_t>((tiles + kTcWaves - 1) / kTcWaves);
     // fp16 sources: the summary pass emits the tiles its fast path takes (k_tc_tiles, PRE); the flags live behind the step

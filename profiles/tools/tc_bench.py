@@ -5,5 +5,5 @@ import torch, bench
 import cxl_speckv_amd as pkg
 kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), "hip:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 131072 * 256
-r = bench.tensor_codec_extra(torch, kv.lib, n)["tensor_codec_whole_tensor"]
+r = list(bench.tensor_codec_extra(torch, kv.lib, n).values())[0]
 print("tensor codec n", n, json.dumps({k: r[k] for k in r if k != "note"}))

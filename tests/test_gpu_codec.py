@@ -472,15 +472,19 @@ def test_tensor_codec_golden_reference_vectors(lib, golden_dir):
         assert_same_float_bits(y, want, f"malformed{i}")
 
 
-@pytest.mark.parametrize("form", ["grids", "wg", "serial", "no_pre"])
+@pytest.mark.parametrize("form", ["single_pass", "grids", "wg", "serial", "no_pre"])
 def test_tensor_codec_scan_forms(lib, oracle, form):
-    """The scans across tiles exist in three forms -- grids of one wave per step (the default), one workgroup, one wave
-    (SPECKV_TC_SCAN, read at every call; fp16 sources: with and without the summary pass emitting, SPECKV_TC_NO_PRE) -- which must all produce the oracle's stream and output: noise with long flat
-    stretches (runs, 255-splits and the delta chain cross tiles and steps of 64 tiles), 70 to 900 000 elements."""
+    """Compress exists as ONE pass with look-back across workgroups (k_tc_fused, the default since round 4) and as the
+    multi-launch form (SPECKV_TC_MULTIPASS) whose scans across tiles come in three shapes -- grids of one wave per step, one
+    workgroup, one wave (SPECKV_TC_SCAN, read at every call; fp16 sources: with and without the summary pass emitting,
+    SPECKV_TC_NO_PRE) -- which must all produce the oracle's stream and output: noise with long flat stretches (runs,
+    255-splits and the delta chain cross tiles, workgroups and steps of 64 tiles), 70 to 900 000 elements."""
     rng = np.random.default_rng(5)
     if form == "no_pre":
         os.environ["SPECKV_TC_NO_PRE"] = "1"                         # fp16 sources: summary and emit as two plain passes
-    elif form != "grids":
+    elif form == "grids":
+        os.environ["SPECKV_TC_MULTIPASS"] = "1"
+    elif form != "single_pass":
         os.environ["SPECKV_TC_SCAN"] = form
     try:
         for n in (70, 2048 * 63 + 5, 2048 * 64, 2048 * 65 + 1, 900000):
@@ -502,6 +506,7 @@ def test_tensor_codec_scan_forms(lib, oracle, form):
     finally:
         os.environ.pop("SPECKV_TC_SCAN", None)
         os.environ.pop("SPECKV_TC_NO_PRE", None)
+        os.environ.pop("SPECKV_TC_MULTIPASS", None)
 
 
 def test_tensor_codec_matches_oracle_over_sizes_and_structures(lib, oracle):
