@@ -1,0 +1,680 @@
+// cxl-speckv_amd/csrc/engine_attend.cpp -- fused decode attention: launch planning for the FP8 / INT4 kernels, single sequences and batches (Engine members)
+#include "engine_internal.hpp"
+
+namespace speckv {
+
+int Engine::qk_scores_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
+                          uint32_t pos_begin, uint32_t pos_end, float* d_out, hipStream_t s)
+{
+    if (null_) return no_data_path("speckv_ext_qk_scores_fp8");
+    Allocation* a = find(handle);
+    if (!a) return SPECKV_ERR_GENERAL;
+    if (!a->has_layout || a->scheme != SPECKV_COMP_FP8_E4M3) return SPECKV_ERR_INVAL;
+    const Layout& L = a->layout;
+    // one K row (all heads of a position) must be 2048 B: two positions per page
+    if (L.head_dim != 128 || L.bytes_per_element != 2 || L.num_heads * L.head_dim != 1024) return SPECKV_ERR_INVAL;
+    if (n_layers == 0 || layer >= L.num_layers || n_layers > L.num_layers - layer || pos_begin % 2 || pos_begin > pos_end ||
+        pos_end > L.num_tokens || pos_end % 2)
+        return SPECKV_ERR_INVAL;
+    if (g == 0 || g > 16 || !d_q_f16 || !d_out) return SPECKV_ERR_INVAL;
+    const uint32_t n_pages = (pos_end - pos_begin) / 2;
+    if (n_pages == 0) return SPECKV_OK;
+    // shim layout [req 0][layer][kind 0 = K][pos][head]: page of (layer, pos)
+    const uint64_t first_page = (static_cast<uint64_t>(layer) * 2 * L.num_tokens + pos_begin) / 2;
+    const uint64_t layer_stride = static_cast<uint64_t>(L.num_tokens);      // pages per layer: K + V = 2*T/2
+    if (first_page + (n_layers - 1) * layer_stride + n_pages > a->n_pages) return SPECKV_ERR_GENERAL;
+    DeviceScope device_scope(device_);
+    // NULL = the engine's stream and a synchronous call: the query may have been produced on any stream of the caller
+    if (!s) HIP_TRY(hipDeviceSynchronize());
+    hipStream_t st = s ? s : stream_;
+    {   // linear form (records in one run, scale table, tile-aligned range inside the layer's region): direct loads
+        const uint32_t n_tiles = (n_pages + 15u) / 16u;
+        const bool fits = pos_begin % 32u == 0u && a->d_scale_tab && a->linear_base && !getenv("SPECKV_ATTEND_GENERAL") &&
+                          static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
+        if (fits) {
+            AttendArgs k{};
+            k.k_first = first_page;
+            k.layer_stride = layer_stride;
+            k.n_pages = n_pages;
+            k.heads = L.num_heads;
+            k.g = g;
+            k.tiles_per_split = 16;
+            if (const char* env = getenv("SPECKV_QK_TILES_PER_WAVE")) k.tiles_per_split = std::max(1, atoi(env));
+            k.lin_base = a->linear_base;
+            k.scale_tab = a->d_scale_tab;
+            k.q16 = static_cast<const uint16_t*>(d_q_f16);
+            HIP_TRY(launch_qk_scores_fp8_linear(k, n_layers, d_out, st));
+            note_use(a, s);
+            if (!s) RC_TRY(wait_stream());
+            return SPECKV_OK;
+        }
+    }
+    const size_t rows = static_cast<size_t>(n_layers) * L.num_heads * 16;
+    uint8_t* q8 = static_cast<uint8_t*>(scratch(s_req_, rows * 128 + rows * sizeof(float), s));
+    if (!q8) return SPECKV_ERR_NOMEM;
+    float* qs = reinterpret_cast<float*>(q8 + rows * 128);
+    HIP_TRY(launch_quantize_q_e4m3(d_q_f16, n_layers * L.num_heads, g, L.head_dim, q8, qs, st));
+    HIP_TRY(launch_qk_scores_fp8(a->d_entries, first_page, layer_stride, n_layers, n_pages, L.num_heads, g, q8, qs, d_out, st));
+    note_use(a, s);
+    if (!s) RC_TRY(wait_stream());
+    return SPECKV_OK;
+}
+
+// Fused decode attention over the FP8 K and V regions of [layer, layer+n_layers) (attend.hip).
+int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
+                       uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
+{
+    if (null_) return no_data_path("speckv_ext_attend_fp8");
+    Allocation* a = find(handle);
+    if (!a) return SPECKV_ERR_GENERAL;
+    if (!a->has_layout || a->scheme != SPECKV_COMP_FP8_E4M3) return SPECKV_ERR_INVAL;
+    const Layout& L = a->layout;
+    if (L.head_dim != 128 || L.bytes_per_element != 2 || L.num_heads * L.head_dim != 1024 || L.num_tokens % 2) return SPECKV_ERR_INVAL;
+    if (n_layers == 0 || layer >= L.num_layers || n_layers > L.num_layers - layer || pos_begin % 2 || pos_begin > pos_end ||
+        pos_end > L.num_tokens || pos_end % 2)
+        return SPECKV_ERR_INVAL;
+    if (g == 0 || g > 16 || !d_q_f16 || !d_out) return SPECKV_ERR_INVAL;
+    DeviceScope device_scope(device_);
+    // NULL = the engine's stream and a synchronous call: the query may have been produced on any stream of the caller
+    if (!s) HIP_TRY(hipDeviceSynchronize());
+    hipStream_t st = s ? s : stream_;
+    const size_t out_elems = static_cast<size_t>(n_layers) * L.num_heads * g * 128;
+    if (pos_end == pos_begin) {  // empty range: softmax over nothing -> zeros (and -inf lse is left to the caller)
+        HIP_TRY(hipMemsetAsync(d_out, 0, out_elems * sizeof(float), st));
+        if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+        return SPECKV_OK;
+    }
+    // The scale table is laid out in tiles of 32 positions from the start of a region: a range that starts inside a tile is
+    // attended from the tile's start with its leading positions masked (AttendArgs::skip_pages), so every range of a layout
+    // with a scale table takes the tile forms (linear / striped / table) -- the per-wave page-table kernel is left with the
+    // layouts that have none (num_tokens not a multiple of 32).
+    const bool has_tab = a->d_scale_tab != nullptr;
+    const uint32_t begin_al = has_tab ? (pos_begin & ~31u) : pos_begin;
+    const uint32_t skip_pages = (pos_begin - begin_al) / 2;
+    const uint32_t n_pages = (pos_end - begin_al) / 2;
+    pos_begin = begin_al;
+    // shim layout [req 0][layer][kind][pos][head]: K pages of a layer, then its V pages
+    const uint64_t k_first = (static_cast<uint64_t>(layer) * 2 * L.num_tokens + pos_begin) / 2;
+    const uint64_t v_first = k_first + L.num_tokens / 2;
+    const uint64_t layer_stride = static_cast<uint64_t>(L.num_tokens);
+    if (v_first + (n_layers - 1) * layer_stride + n_pages > a->n_pages) return SPECKV_ERR_GENERAL;
+    if (!d_zero_page_) {
+        if (is_capturing(s)) return SPECKV_ERR_INVAL;        // first call must run outside a capture (see scratch())
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
+        HIP_TRY(hipMemset(d_zero_page_, 0, kPageSize));
+    }
+    // splits: ~20 waves per CU over the launch (the LDS-DMA kernel keeps 8 resident; measured at 70B-shaped, 80 layers:
+    // 8 splits/row 0.72 of HBM peak at 32k and 0.63 at 8k, 16 splits 0.705 / 0.61, 4 splits 0.71 / 0.63, 2: 0.63 / 0.58)
+    // A launch that already has 128+ workgroup columns (layers x head quads) is best left unsplit: each workgroup then
+    // streams one long run, the rows are final (no partials, no merge launch) -- 80 layers: 1 split 0.73 / 0.70 / 0.64 of
+    // HBM peak at 32k / 8k / 2k context against 0.71 / 0.62 / 0.48 with 8 splits.
+    const uint32_t n_tiles = (n_pages + 15u) / 16u;
+    const uint32_t rows = n_layers * L.num_heads;
+    // linear form: records in one run, scale table present, tiles aligned with the table's (pos_begin a multiple of 32),
+    // and the last (possibly ragged) 32-position tile must not read past the K / V region of its layer
+    // (with the range aligned as above and num_tokens a multiple of 32 the tiles never leave the region)
+    const bool fits = has_tab && static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
+    const char* general_env = getenv("SPECKV_ATTEND_GENERAL");
+    const uint8_t* lin_base = (general_env || !fits) ? nullptr : a->linear_base;
+    // regular striping over several pools: the same kernel with computed record addresses (no page-table chase)
+    const bool striped = !lin_base && fits && a->stripe_n >= 2 && !general_env;
+    // no regular placement (pages migrated one by one), or SPECKV_ATTEND_GENERAL set (measurements, tests): the fast kernel
+    // with its record addresses from the page table, looked up one request ahead
+    const bool table = fits && !lin_base && !striped;
+    // (the page-table form has nothing to gain from whole rows: it hides its look-ups behind other waves and always
+    // goes through the merge -- 80 layers x 8k: one split 0.13 of HBM peak, eight 0.18+)
+    uint32_t want = (lin_base && rows / 4u >= 128u && n_tiles < 768u) ? 1u : (5120u + rows - 1u) / rows;     // (32k and beyond: 8 splits, below)
+    // per-layer calls are latency-bound: short contexts want short splits (measured best: 2 tiles per split at 2k
+    // context, 4 at 8k, 8 at 32k), long multi-layer launches are bounded by `want` above
+    const uint32_t min_tiles = std::min(8u, std::max(2u, n_tiles / 64u));
+    want = std::min(want, std::max(1u, n_tiles / min_tiles));
+    if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));
+    const EvenSplit es = even_split(n_tiles, std::max(1u, std::min(want, 2048u)));
+    const uint32_t n_splits = es.n_splits, tiles_per_split = es.tiles_per_split;
+    const size_t q_bytes = static_cast<size_t>(rows) * 16 * 128, qs_bytes = static_cast<size_t>(rows) * 16 * sizeof(float);
+    const size_t acc_bytes = static_cast<size_t>(rows) * n_splits * 16 * 128 * sizeof(float);
+    const size_t ml_bytes = static_cast<size_t>(rows) * n_splits * 32 * sizeof(float);
+    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, q_bytes + qs_bytes + acc_bytes + ml_bytes, s));
+    if (!buf) return SPECKV_ERR_NOMEM;
+    AttendArgs k{};
+    k.entries = a->d_entries;
+    k.k_first = k_first;
+    k.v_first = v_first;
+    k.layer_stride = layer_stride;
+    k.n_pages = n_pages;
+    k.skip_pages = skip_pages;
+    k.heads = L.num_heads;
+    k.g = g;
+    k.n_splits = n_splits;
+    k.tiles_per_split = tiles_per_split;
+    k.q8 = buf;
+    k.qs = reinterpret_cast<float*>(buf + q_bytes);
+    k.scale_log2e = sm_scale * 1.4426950408889634f;
+    k.zero_page = d_zero_page_;
+    k.scale_tab = a->d_scale_tab;
+    k.q16 = static_cast<const uint16_t*>(d_q_f16);
+    k.lin_base = lin_base;
+    if (striped) {
+        k.stripe_bases = a->d_stripe;
+        k.stripe_n = a->stripe_n;
+        k.stripe_magic = static_cast<uint32_t>((1ull << 32) / a->stripe_n + 1u);
+    }
+    k.part_acc = reinterpret_cast<float*>(buf + q_bytes + qs_bytes);
+    k.part_ml = reinterpret_cast<float*>(buf + q_bytes + qs_bytes + acc_bytes);
+    if (table) { k.table_form = 1u; k.lin_base = nullptr; k.stripe_bases = nullptr; }
+    if (!k.lin_base && !striped && !table)         // the linear / striped / table forms quantise the query in their own prologue
+        HIP_TRY(launch_quantize_q_e4m3(d_q_f16, rows, g, L.head_dim, buf, reinterpret_cast<float*>(buf + q_bytes), st));
+    if (n_splits == 1u) { k.direct_out = d_out; k.direct_lse = d_lse; }      // no merge launch (linear / striped form)
+    HIP_TRY(launch_attend_fp8(k, n_layers, d_out, d_lse, st));
+    note_use(a, s);
+    if (!s) RC_TRY(wait_stream());
+    return SPECKV_OK;
+}
+
+// One decode step of a batch: the fused attention of ONE layer for many sequences (allocations) in one launch
+// (BASELINE configs[3] shape: 256 sequences).  Every allocation must qualify for the linear form.
+// Not capturable into a HIP graph: the per-call descriptors travel through a pinned slot that later calls reuse, so a
+// replay would read other calls' descriptors -- the call refuses to run on a capturing stream (the per-sequence
+// entry points speckv_ext_attend_fp8 / _int4 are capturable).
+// Split length of a batch launch (see the measurements quoted in attend_batch).  seqs[i].n_splits holds the tile count of
+// sequence i (null: n_seq sequences of uniform_tiles each, the bound a plan is sized for).
+// INT4 batch launches between half a machine and a whole one of workgroup columns: every long sequence in a long and a short
+// piece, dispatched rows-first (ring_rule.hpp: int4_unequal_fraction / unequal_pieces).  The environment switches are for
+// measurement runs.
+using UnequalSplit = UnequalFraction;
+static UnequalSplit int4_unequal_split(uint32_t n_seq, uint32_t hq, uint32_t tiles_max)
+{
+    if (getenv("SPECKV_ATTEND_TILES_PER_SPLIT") || getenv("SPECKV_ATTEND_WG_TARGET") || getenv("SPECKV_ATTEND_WHOLE_SEQUENCES")) return {false, 1.0};
+    UnequalSplit u = int4_unequal_fraction(n_seq * hq, tiles_max);
+    if (u.on) if (const char* env = getenv("SPECKV_ATTEND_UNEQUAL_A")) u.a = atof(env);
+    return u;
+}
+
+static uint32_t batch_tiles_per_split(bool fp8, uint32_t n_seq, uint32_t heads, uint64_t total_tiles, const AttendSeq* seqs,
+                                      uint32_t uniform_tiles)
+{
+    if (const char* env = getenv("SPECKV_ATTEND_TILES_PER_SPLIT")) return std::max(1, atoi(env));
+    const char* target_env = getenv("SPECKV_ATTEND_WG_TARGET");                // (measurement runs: the plain workgroup target)
+    const uint32_t hq = heads / 4u;
+    if (fp8 && !target_env) {
+        // FP8: the busiest-CU cost rule of ring_rule.hpp (48 sequences x 16k: 288 workgroups 0.50 of HBM peak, 192: 0.64,
+        // 768: 0.71; 32 x 32k: 256 workgroups 0.79, 512: 0.76, 384: 0.63; 128 x 2k: unsplit 0.73, two splits 0.56)
+        std::vector<uint32_t> tiles;
+        if (seqs) { tiles.resize(n_seq); for (uint32_t i = 0; i < n_seq; ++i) tiles[i] = seqs[i].n_splits; }
+        const char* mc = getenv("SPECKV_FP8_MERGE_COST");                     // (measurement runs)
+        return fp8_batch_tiles_per_split(seqs ? tiles.data() : nullptr, n_seq, uniform_tiles, hq, 256u, mc ? static_cast<uint32_t>(atoi(mc)) : 8u);
+    }
+    uint64_t wg_target = fp8 ? 512u : 768u;
+    if (target_env) wg_target = std::max(1, atoi(target_env));
+    uint32_t tps = static_cast<uint32_t>(std::max<uint64_t>(8, (total_tiles * hq + wg_target - 1u) / wg_target));
+    if (!fp8) tps = (static_cast<uint64_t>(n_seq) * hq >= 384u) ? 256u : std::min(tps, 256u);   // enough columns: whole sequences
+    return tps;
+}
+
+// INT4 batches on the whole-record kernel (k_attend_int4_wg8<2>: workgroups = sequences x splits, one 16-wave workgroup per
+// CU resident, its two halves merged in LDS): one round of resident workgroups when the batch is smaller than that, whole
+// sequences otherwise (a whole sequence is final: no partials, no merge launch); never under 32 tiles a split.
+static bool int4_batch_wg8() { static const bool on = !getenv("SPECKV_INT4_WG4"); return on; }
+static uint32_t int4_wg8_batch_tps(uint32_t n_seq, uint32_t tiles_max)
+{
+    if (const char* env = getenv("SPECKV_ATTEND_TILES_PER_SPLIT")) return std::max(1, atoi(env));      // (measurement runs)
+    const uint32_t resident = 256u;                                       // 16-wave workgroups (two halves each), one per CU
+    const uint32_t splits = std::max(1u, resident / std::max(1u, n_seq));
+    return std::max(32u, (tiles_max + splits - 1u) / splits);
+}
+
+int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, uint32_t layer, const void* d_q_f16, uint32_t g,
+                         const uint32_t* pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
+{
+    const bool fp8 = scheme == SPECKV_COMP_FP8_E4M3;
+    if (null_) return no_data_path("speckv_ext_attend_*_batch");
+    if (n_seq == 0) return SPECKV_OK;
+    if (is_capturing(s)) {
+        SPECKV_ERR("speckv_ext_attend_*_batch cannot be captured into a HIP graph (its descriptors are staged per call); "
+                   "capture the per-sequence speckv_ext_attend_fp8 / _int4 calls instead");
+        return SPECKV_ERR_INVAL;
+    }
+    if (!handles || !pos_end || !d_q_f16 || !d_out || g == 0 || g > 16) return SPECKV_ERR_INVAL;
+    std::vector<AttendSeq> seqs(n_seq);
+    uint64_t total_tiles = 0;
+    uint32_t heads = 0;
+    bool any_striped = false;                 // then the whole launch takes the striped kernels (a single run is "striped over 1")
+    bool any_table = false;                   // ... or, with a member that has no regular placement, the table forms
+    std::vector<const PageEntry*> ents(n_seq);
+    for (uint32_t i = 0; i < n_seq; ++i) {
+        Allocation* a = find(handles[i]);
+        if (!a) return SPECKV_ERR_GENERAL;
+        if (!a->has_layout || a->scheme != scheme) return SPECKV_ERR_INVAL;
+        const Layout& L = a->layout;
+        if (L.head_dim != 128 || L.bytes_per_element != 2 || L.num_heads * L.head_dim != 1024 || L.num_tokens % 2) return SPECKV_ERR_INVAL;
+        if (layer >= L.num_layers || pos_end[i] % 2 || pos_end[i] > L.num_tokens) return SPECKV_ERR_INVAL;
+        const uint32_t n_pages = pos_end[i] / 2, n_tiles = (n_pages + 15u) / 16u;
+        if ((fp8 && !a->d_scale_tab) || static_cast<uint64_t>(n_tiles) * 32u > L.num_tokens) {
+            SPECKV_ERR("speckv_ext_attend_*_batch: sequence %u does not qualify for the tile-aligned forms (pos_end rounded up "
+                       "to 32 inside the layer%s)", i, fp8 ? ", layout with num_tokens %% 32 == 0" : "");
+            return SPECKV_ERR_INVAL;
+        }
+        heads = L.num_heads;
+        note_use(a, s);
+        any_table = any_table || !a->stripe_n;                 // no regular placement (migrated pages): the launch reads addresses from the page tables
+        ents[i] = a->d_entries;
+        any_striped = any_striped || !a->linear_base;
+        seqs[i].stripe_bases = a->d_stripe;
+        seqs[i].stripe_n = a->stripe_n;
+        seqs[i].lin_base = a->linear_base;
+        seqs[i].scale_tab = a->d_scale_tab;
+        seqs[i].k_first = static_cast<uint64_t>(layer) * L.num_tokens;       // (layer*2*T)/2
+        seqs[i].v_first = seqs[i].k_first + L.num_tokens / 2;
+        seqs[i].n_pages = n_pages;
+        seqs[i].layer_pages = L.num_tokens;                                   // K + V pages of one layer
+        seqs[i].n_splits = n_tiles;                                           // tiles for now, splits below
+        total_tiles += n_tiles;
+    }
+    DeviceScope device_scope(device_);
+    // NULL = the engine's stream and a synchronous call: the query may have been produced on any stream of the caller
+    if (!s) HIP_TRY(hipDeviceSynchronize());
+    hipStream_t st = s ? s : stream_;
+    const size_t out_elems = static_cast<size_t>(n_seq) * heads * g * 128;
+    if (total_tiles == 0) {
+        HIP_TRY(hipMemsetAsync(d_out, 0, out_elems * sizeof(float), st));
+        if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+        return SPECKV_OK;
+    }
+    // one split length for the whole batch.  A batch brings its own parallelism: the fewer, longer splits the better, down
+    // to about one round of resident workgroups (256 sequences x 8k context, one layer, FP8: 8 tiles per split 0.50 of
+    // HBM peak, 32: 0.59, 64: 0.67, 128: 0.72, 256 = no split: 0.74; INT4: 64..128 best, 0.59; at 2k context both
+    // formats want no split at all).  INT4 target: 768 workgroups, never under 8 tiles per split; FP8: the cost rule of
+    // batch_tiles_per_split.
+    // INT4 (arithmetic-bound kernel): splits longer than 256 tiles stop paying (256 sequences x 32k: 256 tiles per split
+    // 0.67, 512: 0.65, 1024 = no split: 0.60), shorter sequences are best left whole (8k 0.63 against 0.59 in two
+    // splits, 4k 0.60 / 0.52, 2k 0.58 / 0.43: single-split rows are final, no partials and no merge).
+    if (any_table)                                           // (AttendSeq::lin_base carries the page table in table launches)
+        for (uint32_t i = 0; i < n_seq; ++i) seqs[i].lin_base = reinterpret_cast<const uint8_t*>(ents[i]);
+    uint32_t tiles_max = 0;
+    for (uint32_t i = 0; i < n_seq; ++i) tiles_max = std::max(tiles_max, seqs[i].n_splits);
+    const bool wg8 = !fp8 && !any_striped && !any_table && heads == 8u && int4_batch_wg8();
+    const uint32_t tps = wg8 ? int4_wg8_batch_tps(n_seq, tiles_max) : batch_tiles_per_split(fp8, n_seq, heads, total_tiles, seqs.data(), 0);
+    const UnequalSplit unequal = (fp8 || wg8) ? UnequalSplit{false, 1.0} : int4_unequal_split(n_seq, heads / 4u, tiles_max);
+    uint32_t max_splits = 0;
+    uint64_t parts = 0;
+    for (uint32_t i = 0; i < n_seq; ++i) {
+        const uint32_t n_tiles = seqs[i].n_splits;
+        if ((n_tiles + tps - 1u) / tps > 2048u) return SPECKV_ERR_INVAL;
+        // the sequence's tiles divided evenly over its splits (171 + 85 tiles instead of 128 + 128 cost 15 %)
+        EvenSplit es = even_split(n_tiles, (n_tiles + tps - 1u) / tps);
+        if (unequal.on) es = unequal_pieces(unequal, n_tiles);
+        seqs[i].tiles_per_split = n_tiles ? es.tiles_per_split : tps;
+        seqs[i].n_splits = es.n_splits;
+        seqs[i].part_base = static_cast<uint32_t>(parts);
+        parts += static_cast<uint64_t>(heads) * seqs[i].n_splits;
+        max_splits = std::max(max_splits, seqs[i].n_splits);
+    }
+    const size_t acc_bytes = static_cast<size_t>(parts) * 16 * 128 * sizeof(float), ml_bytes = static_cast<size_t>(parts) * 32 * sizeof(float);
+    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes, s));
+    AttendSeq* d_seqs = static_cast<AttendSeq*>(scratch(s_attn_seq_, seqs.size() * sizeof(AttendSeq), s));
+    if (!buf || !d_seqs) return SPECKV_ERR_NOMEM;
+    // descriptors go through a pinned slot so the call can return without waiting for the copy
+    const size_t seq_bytes = seqs.size() * sizeof(AttendSeq);
+    if (seq_ring_.slot_bytes < seq_bytes) {
+        if (seq_ring_.base) { HIP_TRY(hipDeviceSynchronize()); (void)hipHostFree(seq_ring_.base); seq_ring_.base = nullptr; }
+        seq_ring_.slot_bytes = std::max<size_t>(seq_bytes * 2, 16384);
+        HIP_TRY(hipHostMalloc(&seq_ring_.base, seq_ring_.slot_bytes * 4, hipHostMallocDefault));
+        for (auto& ev : seq_ring_.ev)
+            if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const int slot = seq_ring_.next;
+    seq_ring_.next = (slot + 1) & 3;
+    HIP_TRY(hipEventSynchronize(seq_ring_.ev[slot]));          // the copy that last used this slot has finished
+    void* staged = static_cast<uint8_t*>(seq_ring_.base) + static_cast<size_t>(slot) * seq_ring_.slot_bytes;
+    memcpy(staged, seqs.data(), seq_bytes);
+    HIP_TRY(hipMemcpyAsync(d_seqs, staged, seq_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(seq_ring_.ev[slot], st));
+    // sequences without positions have no splits: their rows are written as zeros by the merge (L == 0)
+    AttendArgs k{};
+    k.heads = heads;
+    k.g = g;
+    k.n_splits = max_splits;
+    k.tiles_per_split = tps;
+    k.layer_stride = 0;
+    k.q16 = static_cast<const uint16_t*>(d_q_f16);
+    k.q8 = static_cast<const uint8_t*>(d_q_f16);          // the INT4 kernel reads the fp16 query through q8
+    k.scale_log2e = sm_scale * 1.4426950408889634f;
+    k.lin_base = (any_striped || any_table) ? nullptr : seqs[0].lin_base;           // (overridden per sequence)
+    if (any_striped) k.stripe_bases = seqs[0].stripe_bases;          // marks a striped launch (each sequence brings its own table)
+    if (any_table) {
+        k.table_form = 1u; k.lin_base = nullptr; k.stripe_bases = nullptr;
+        if (!d_zero_page_) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
+            HIP_TRY(hipMemset(d_zero_page_, 0, kPageSize));
+        }
+        k.zero_page = d_zero_page_;
+    }
+    k.seqs = d_seqs;
+    k.part_acc = reinterpret_cast<float*>(buf);
+    k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
+    bool one_split_each = true;                           // then the attention kernel writes the final rows itself
+    for (uint32_t i = 0; i < n_seq; ++i) one_split_each = one_split_each && seqs[i].n_splits == 1u;
+    if (one_split_each) { k.direct_out = d_out; k.direct_lse = d_lse; }
+    if (unequal.on) k.rows_first = 1u;
+    if (wg8) k.wg8 = 1u;
+    if (fp8) {
+        HIP_TRY(launch_attend_fp8_batch(k, n_seq, d_out, d_lse, st));
+    } else {
+        HIP_TRY(launch_attend_int4(k, n_seq, st));        // grid y = sequences x head groups, as for layers
+        if (!k.direct_out) HIP_TRY(launch_attend_combine(k, n_seq, d_out, d_lse, st));
+    }
+    if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+    return SPECKV_OK;
+}
+
+// ---- planned batches: descriptors resident on the device, the launches capturable ---------------------------------------
+// A decode step under a HIP graph replays the same launches with new sequence lengths.  speckv_ext_attend_batch_plan
+// (outside the graph, once per step) writes one descriptor per sequence -- valid for every layer -- into a device buffer
+// of the caller; speckv_ext_attend_*_planned is kernel launches only: no handle look-ups, no staging, grid and scratch
+// sized from max_pos_end alone, so a captured launch stays valid for as long as the lengths stay within that bound.
+struct PlanGeometry { uint32_t tps, max_splits; uint64_t parts_bound; UnequalSplit unequal; };
+static PlanGeometry plan_geometry(bool fp8, uint32_t n_seq, uint32_t heads, uint32_t max_pos_end)
+{
+    const uint32_t tiles_max = (max_pos_end / 2u + 15u) / 16u;
+    PlanGeometry g{};
+    if (!fp8 && heads == 8u && int4_batch_wg8()) {            // the whole-record kernel's geometry (a striped / table launch runs it on the 4-head kernels)
+        g.unequal = UnequalSplit{false, 1.0};
+        g.tps = int4_wg8_batch_tps(n_seq, tiles_max);
+        g.max_splits = std::max(1u, (tiles_max + g.tps - 1u) / g.tps);
+        g.parts_bound = static_cast<uint64_t>(n_seq) * heads * g.max_splits;
+        return g;
+    }
+    g.unequal = fp8 ? UnequalSplit{false, 1.0} : int4_unequal_split(n_seq, heads / 4u, tiles_max);
+    if (g.unequal.on) {                                       // (the rule depends on the plan's bound only: plan and launch agree)
+        g.tps = tiles_max;
+        g.max_splits = 2u;
+        g.parts_bound = static_cast<uint64_t>(n_seq) * heads * 2u;
+        return g;
+    }
+    g.tps = batch_tiles_per_split(fp8, n_seq, heads, static_cast<uint64_t>(tiles_max) * n_seq, nullptr, tiles_max);
+    g.max_splits = std::max(1u, (tiles_max + g.tps - 1u) / g.tps);
+    g.parts_bound = static_cast<uint64_t>(n_seq) * heads * g.max_splits;
+    return g;
+}
+
+int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uint32_t* pos_end, uint32_t max_pos_end,
+                              void* d_plan, size_t plan_bytes, hipStream_t s)
+{
+    if (null_) return no_data_path("speckv_ext_attend_batch_plan");
+    if (n_seq == 0) return SPECKV_OK;
+    if (!handles || !pos_end || !d_plan || !s || max_pos_end % 2 || plan_bytes < n_seq * sizeof(AttendSeq)) return SPECKV_ERR_INVAL;
+    if (is_capturing(s)) return SPECKV_ERR_INVAL;            // the plan is what changes between replays: it stays outside the graph
+    std::vector<AttendSeq> seqs(n_seq);
+    int scheme = -1;
+    bool any_striped = false, any_table = false;
+    std::vector<const PageEntry*> ents(n_seq);
+    uint32_t heads = 0, min_layers = UINT32_MAX;
+    for (uint32_t i = 0; i < n_seq; ++i) {
+        Allocation* a = find(handles[i]);
+        if (!a) return SPECKV_ERR_GENERAL;
+        if (scheme < 0) scheme = a->scheme;
+        if (!a->has_layout || a->scheme != scheme || (scheme != SPECKV_COMP_FP8_E4M3 && scheme != SPECKV_COMP_INT4_G32)) return SPECKV_ERR_INVAL;
+        const Layout& L = a->layout;
+        if (L.head_dim != 128 || L.bytes_per_element != 2 || L.num_heads * L.head_dim != 1024 || L.num_tokens % 2) return SPECKV_ERR_INVAL;
+        if (pos_end[i] % 2 || pos_end[i] > L.num_tokens || pos_end[i] > max_pos_end) return SPECKV_ERR_INVAL;
+        const uint32_t n_pages = pos_end[i] / 2, n_tiles = (n_pages + 15u) / 16u;
+        const bool fp8 = scheme == SPECKV_COMP_FP8_E4M3;
+        if ((fp8 && !a->d_scale_tab) || static_cast<uint64_t>(n_tiles) * 32u > L.num_tokens) return SPECKV_ERR_INVAL;
+        min_layers = std::min(min_layers, L.num_layers);
+        heads = L.num_heads;
+        note_use(a, s);
+        any_table = any_table || !a->stripe_n;
+        ents[i] = a->d_entries;
+        any_striped = any_striped || !a->linear_base;
+        seqs[i].stripe_bases = a->d_stripe;
+        seqs[i].stripe_n = a->stripe_n;
+        seqs[i].lin_base = a->linear_base;
+        seqs[i].scale_tab = a->d_scale_tab;
+        seqs[i].k_first = 0;                                   // layer 0; the launch adds layer * layer_pages
+        seqs[i].v_first = L.num_tokens / 2;
+        seqs[i].layer_pages = L.num_tokens;
+        seqs[i].n_pages = n_pages;
+        seqs[i].n_splits = n_tiles;
+    }
+    const PlanGeometry g = plan_geometry(scheme == SPECKV_COMP_FP8_E4M3, n_seq, heads, max_pos_end);
+    if (g.max_splits > 2048u) return SPECKV_ERR_INVAL;
+    if (plans_.size() >= 64 && !plans_.count(d_plan)) plans_.clear();        // (buffers of long-gone steps)
+    if (any_table)
+        for (uint32_t i = 0; i < n_seq; ++i) seqs[i].lin_base = reinterpret_cast<const uint8_t*>(ents[i]);
+    if (any_table && !d_zero_page_) {
+        DeviceScope zero_scope(device_);
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
+        HIP_TRY(hipMemset(d_zero_page_, 0, kPageSize));
+    }
+    plans_[d_plan] = PlanInfo{n_seq, scheme, min_layers, max_pos_end, any_striped, any_table};
+    uint64_t parts = 0;
+    for (uint32_t i = 0; i < n_seq; ++i) {
+        const uint32_t n_tiles = seqs[i].n_splits;
+        const EvenSplit es = g.unequal.on ? unequal_pieces(g.unequal, n_tiles) : even_split(n_tiles, (n_tiles + g.tps - 1u) / g.tps);
+        seqs[i].tiles_per_split = n_tiles ? es.tiles_per_split : g.tps;
+        seqs[i].n_splits = es.n_splits;
+        seqs[i].part_base = static_cast<uint32_t>(parts);
+        parts += static_cast<uint64_t>(heads) * seqs[i].n_splits;
+    }
+    DeviceScope device_scope(device_);
+    const size_t seq_bytes = seqs.size() * sizeof(AttendSeq);
+    if (seq_ring_.slot_bytes < seq_bytes) {
+        if (seq_ring_.base) { HIP_TRY(hipDeviceSynchronize()); (void)hipHostFree(seq_ring_.base); seq_ring_.base = nullptr; }
+        seq_ring_.slot_bytes = std::max<size_t>(seq_bytes * 2, 16384);
+        HIP_TRY(hipHostMalloc(&seq_ring_.base, seq_ring_.slot_bytes * 4, hipHostMallocDefault));
+        for (auto& ev : seq_ring_.ev)
+            if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const int slot = seq_ring_.next;
+    seq_ring_.next = (slot + 1) & 3;
+    HIP_TRY(hipEventSynchronize(seq_ring_.ev[slot]));
+    void* staged = static_cast<uint8_t*>(seq_ring_.base) + static_cast<size_t>(slot) * seq_ring_.slot_bytes;
+    memcpy(staged, seqs.data(), seq_bytes);
+    HIP_TRY(hipMemcpyAsync(d_plan, staged, seq_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(seq_ring_.ev[slot], s));
+    return SPECKV_OK;
+}
+
+int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint32_t layer, const void* d_q_f16, uint32_t g,
+                           uint32_t max_pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
+{
+    const bool fp8 = scheme == SPECKV_COMP_FP8_E4M3;
+    if (null_) return no_data_path("speckv_ext_attend_*_planned");
+    if (n_seq == 0) return SPECKV_OK;
+    if (!d_plan || !d_q_f16 || !d_out || !s || g == 0 || g > 16 || max_pos_end % 2 || max_pos_end == 0) return SPECKV_ERR_INVAL;
+    const uint32_t heads = 8;                                  // the page-wise layout: 8 kv heads x 128
+    const auto plan = plans_.find(d_plan);                     // what speckv_ext_attend_batch_plan last wrote there
+    if (plan == plans_.end() || plan->second.n_seq != n_seq || plan->second.scheme != scheme || plan->second.max_pos_end != max_pos_end ||
+        layer >= plan->second.n_layers) {
+        SPECKV_ERR("speckv_ext_attend_*_planned: no plan of this shape at %p (n_seq, format and max_pos_end as planned, layer inside every layout)", d_plan);
+        return SPECKV_ERR_INVAL;
+    }
+    const PlanGeometry pg = plan_geometry(fp8, n_seq, heads, max_pos_end);
+    DeviceScope device_scope(device_);
+    const size_t acc_bytes = static_cast<size_t>(pg.parts_bound) * 16 * 128 * sizeof(float), ml_bytes = static_cast<size_t>(pg.parts_bound) * 32 * sizeof(float);
+    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes, s));      // (growth during a capture is refused: warm up once)
+    if (!buf) return is_capturing(s) ? SPECKV_ERR_INVAL : SPECKV_ERR_NOMEM;
+    AttendArgs k{};
+    k.heads = heads;
+    k.g = g;
+    k.n_splits = pg.max_splits;
+    k.tiles_per_split = pg.tps;
+    k.layer_stride = 0;
+    k.q16 = static_cast<const uint16_t*>(d_q_f16);
+    k.q8 = static_cast<const uint8_t*>(d_q_f16);
+    k.scale_log2e = sm_scale * 1.4426950408889634f;
+    if (plan->second.table) { k.table_form = 1u; k.zero_page = d_zero_page_; }           // a member without a regular placement: addresses from the page tables
+    else if (plan->second.striped) k.stripe_bases = reinterpret_cast<const uint64_t*>(1);     // striped launch: every descriptor brings its table
+    else { k.lin_base = reinterpret_cast<const uint8_t*>(1); if (!fp8 && int4_batch_wg8()) k.wg8 = 1u; }     // non-null: linear form (the real base comes from the descriptor)
+    k.seqs = static_cast<const AttendSeq*>(d_plan);
+    k.part_acc = reinterpret_cast<float*>(buf);
+    k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
+    k.batch_layer = layer;
+    k.direct_out = d_out;                                      // sequences with a single split are written directly ...
+    k.direct_lse = d_lse;
+    // ... decided per sequence on the device, the merge skips those; a geometry of one split at most needs no merge at all
+    k.direct_per_seq = pg.max_splits == 1u ? 2u : 1u;
+    if (pg.unequal.on) k.rows_first = 1u;
+    if (fp8) {
+        HIP_TRY(launch_attend_fp8_batch(k, n_seq, d_out, d_lse, s));
+    } else {
+        HIP_TRY(launch_attend_int4(k, n_seq, s));
+        if (k.direct_per_seq != 2u) HIP_TRY(launch_attend_combine(k, n_seq, d_out, d_lse, s));
+    }
+    return SPECKV_OK;
+}
+
+int Engine::attend_fold_tail(uint32_t n_rows, const uint32_t* d_rows, uint32_t heads, uint32_t g, const void* d_q_f16, const void* d_k_tail,
+                             const void* d_v_tail, uint64_t tail_stride_elems, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
+{
+    if (null_) return no_data_path("speckv_ext_attend_fold_tail");
+    if (n_rows == 0) return SPECKV_OK;
+    if (!d_q_f16 || !d_k_tail || !d_v_tail || !d_out || !d_lse || heads == 0 || g == 0 || g > 16 || tail_stride_elems % 2 ||
+        tail_stride_elems < static_cast<uint64_t>(heads) * 128u)
+        return SPECKV_ERR_INVAL;
+    DeviceScope device_scope(device_);
+    if (!s) HIP_TRY(hipDeviceSynchronize());                   // NULL: the engine's stream, synchronous (include/speckv_ext.h)
+    HIP_TRY(launch_attend_fold_tail(n_rows, d_rows, heads, g, d_q_f16, d_k_tail, d_v_tail, tail_stride_elems, sm_scale, d_out, d_lse,
+                                    s ? s : stream_));
+    if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+    return SPECKV_OK;
+}
+
+// Launch geometry of the whole-record INT4 kernel (k_attend_int4_wg8; 512-thread workgroups, two resident per CU).
+static int device_cus()
+{
+    static const int n_cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 256; }
+        return v;
+    }();
+    return n_cus;
+}
+// Stream form (many layers of one sequence): the launch's n_layers x n_tiles tiles, layer-major, in as many equal pieces as
+// workgroups are resident at once -- one pipeline fill per workgroup, no partial last round, few partials per layer.  Worth
+// it when a piece is long enough to amortise its fill (>= 16 tiles); *max_slots = most pieces any layer is cut into.
+static bool int4_wg8_stream(uint32_t n_layers, uint32_t n_tiles, AttendArgs::Stream* out)
+{
+    const uint64_t total = static_cast<uint64_t>(n_layers) * n_tiles;
+    uint64_t wgs = 2ull * static_cast<uint64_t>(device_cus());
+    if (const char* env = getenv("SPECKV_INT4_STREAM_WGS")) wgs = std::max(1, atoi(env));
+    if (n_layers < 2 || total < 16u * wgs || getenv("SPECKV_INT4_NO_STREAM")) return false;
+    out->n_wgs = static_cast<uint32_t>(wgs);
+    out->len = static_cast<uint32_t>(total / wgs);
+    out->rem = static_cast<uint32_t>(total % wgs);
+    out->max_slots = 1;
+    for (uint32_t l = 0; l < n_layers; ++l) out->max_slots = std::max(out->max_slots, attend_stream_count(l, n_tiles, out->len, out->rem));
+    return true;
+}
+// Fixed grid (per-layer calls, short launches): splits x layers workgroups, in whole rounds of the resident set when the
+// launch is that long, else as many 8-tile pieces as there are.
+static uint32_t int4_wg8_splits(uint32_t n_layers, uint32_t n_tiles)
+{
+    const uint64_t resident = static_cast<uint64_t>(device_cus());                 // (16-wave workgroups, two halves each: one per CU)
+    const uint64_t total = static_cast<uint64_t>(n_layers) * n_tiles;
+    uint64_t wgs = std::max<uint64_t>(1, total / 64u);
+    if (wgs >= resident) wgs = (wgs + resident / 2u) / resident * resident;       // whole rounds
+    else wgs = std::min<uint64_t>(resident, std::max<uint64_t>(wgs, total / 8u));
+    const uint64_t per_layer = std::max<uint64_t>(1, (wgs + n_layers / 2u) / n_layers);
+    return static_cast<uint32_t>(std::min<uint64_t>(per_layer, std::max<uint32_t>(1u, n_tiles / 4u)));
+}
+
+// Fused decode attention over INT4_G32 K and V records (attend_int4.hip): linear placement only.
+int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
+                        uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
+{
+    if (null_) return no_data_path("speckv_ext_attend_int4");
+    Allocation* a = find(handle);
+    if (!a) return SPECKV_ERR_GENERAL;
+    if (!a->has_layout || a->scheme != SPECKV_COMP_INT4_G32) return SPECKV_ERR_INVAL;
+    const Layout& L = a->layout;
+    if (L.head_dim != 128 || L.bytes_per_element != 2 || L.num_heads * L.head_dim != 1024 || L.num_tokens % 2) return SPECKV_ERR_INVAL;
+    if (n_layers == 0 || layer >= L.num_layers || n_layers > L.num_layers - layer || pos_begin % 2 || pos_begin > pos_end ||
+        pos_end > L.num_tokens || pos_end % 2)
+        return SPECKV_ERR_INVAL;
+    if (g == 0 || g > 16 || !d_q_f16 || !d_out) return SPECKV_ERR_INVAL;
+    const uint32_t n_pages = (pos_end - pos_begin) / 2;
+    DeviceScope device_scope(device_);
+    // NULL = the engine's stream and a synchronous call: the query may have been produced on any stream of the caller
+    if (!s) HIP_TRY(hipDeviceSynchronize());
+    hipStream_t st = s ? s : stream_;
+    const size_t out_elems = static_cast<size_t>(n_layers) * L.num_heads * g * 128;
+    if (n_pages == 0) {
+        HIP_TRY(hipMemsetAsync(d_out, 0, out_elems * sizeof(float), st));
+        if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+        return SPECKV_OK;
+    }
+    const uint64_t k_first = (static_cast<uint64_t>(layer) * 2 * L.num_tokens + pos_begin) / 2;
+    const uint64_t v_first = k_first + L.num_tokens / 2;
+    const uint64_t layer_stride = static_cast<uint64_t>(L.num_tokens);
+    if (v_first + (n_layers - 1) * layer_stride + n_pages > a->n_pages) return SPECKV_ERR_GENERAL;
+    const uint32_t n_tiles = (n_pages + 15u) / 16u;
+    // linear form: records in one local run and every 32-position tile inside the layer's K / V region; otherwise the
+    // page-table form of the same kernel
+    const bool fits = static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
+    const char* general_env = getenv("SPECKV_ATTEND_GENERAL");
+    const bool linear = a->linear_base && fits && !general_env;
+    const bool striped = !linear && a->stripe_n >= 2 && fits && !general_env;
+    // everything else -- no regular placement, a last tile that would leave the region, SPECKV_ATTEND_GENERAL (measurements,
+    // tests) -- takes the workgroup kernel with its record addresses from the page table: its look-ups are clamped to the
+    // range, so a ragged last tile never reads a record it has no business with.  (The per-wave page-table kernel of rounds
+    // 1-3, 0.37 of HBM peak, is gone.)
+    const bool table = !linear && !striped;
+    if (!linear && !d_zero_page_) {
+        if (is_capturing(s)) return SPECKV_ERR_INVAL;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
+        HIP_TRY(hipMemset(d_zero_page_, 0, kPageSize));
+    }
+    const uint32_t rows = n_layers * L.num_heads;
+    uint32_t want = (5120u + rows - 1u) / rows;      // VALU-bound kernel: fewer, longer splits measured best
+    const uint32_t min_tiles = std::min(8u, std::max(2u, n_tiles / 64u));      // per-layer calls: see attend_fp8
+    want = std::min(want, std::max(1u, n_tiles / min_tiles));
+    // Workgroups go to the 8 XCDs round-robin by linear id = split + n_splits * (layer, head quad): with a split count that
+    // is a multiple of 8 the two workgroups that share a page's scale line (head quads 0 and 1) run on the same XCD, next
+    // to each other (measured at 32k x 80 layers: 8 splits 0.598, 10 or 12 splits 0.56, 16 splits 0.595)
+    if (want > 8u) want &= ~7u;
+    // whole-record kernel (8 waves = 8 heads, one workgroup per CU): workgroups = splits x layers, in whole rounds of the CUs
+    const bool wg8 = linear && L.num_heads == 8 && !getenv("SPECKV_INT4_WG4");
+    if (wg8) want = int4_wg8_splits(n_layers, n_tiles);
+    if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));
+    EvenSplit es = even_split(n_tiles, std::max(1u, std::min(want, 2048u)));
+    if (!wg8 && es.n_splits > 8u && (es.n_splits & 7u) && !getenv("SPECKV_ATTEND_SPLITS"))      // the rounding can fall off a multiple of 8
+        es = even_split(n_tiles, es.n_splits & ~7u);
+    AttendArgs k{};
+    const bool stream = wg8 && !getenv("SPECKV_ATTEND_SPLITS") && int4_wg8_stream(n_layers, n_tiles, &k.stream);
+    const uint32_t n_splits = stream ? k.stream.max_slots : es.n_splits, tiles_per_split = es.tiles_per_split;      // (stream: slots per row)
+    const size_t acc_bytes = static_cast<size_t>(rows) * n_splits * 16 * 128 * sizeof(float);
+    const size_t ml_bytes = static_cast<size_t>(rows) * n_splits * 32 * sizeof(float);
+    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes, s));
+    if (!buf) return SPECKV_ERR_NOMEM;
+    k.entries = a->d_entries;
+    k.k_first = k_first;
+    k.v_first = v_first;
+    k.layer_stride = layer_stride;
+    k.n_pages = n_pages;
+    k.heads = L.num_heads;
+    k.g = g;
+    k.n_splits = n_splits;
+    k.tiles_per_split = tiles_per_split;
+    k.q8 = static_cast<const uint8_t*>(d_q_f16);
+    k.scale_log2e = sm_scale * 1.4426950408889634f;
+    k.lin_base = linear ? a->linear_base : nullptr;
+    if (table) k.table_form = 1u;
+    if (wg8) k.wg8 = 1u;
+    if (striped) {
+        k.stripe_bases = a->d_stripe;
+        k.stripe_n = a->stripe_n;
+        k.stripe_magic = static_cast<uint32_t>((1ull << 32) / a->stripe_n + 1u);
+    }
+    k.zero_page = d_zero_page_;
+    k.part_acc = reinterpret_cast<float*>(buf);
+    k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
+    if (n_splits == 1u && !stream) { k.direct_out = d_out; k.direct_lse = d_lse; }      // no merge launch
+    HIP_TRY(launch_attend_int4(k, n_layers, st));
+    if (!k.direct_out) HIP_TRY(launch_attend_combine(k, n_layers, d_out, d_lse, st));
+    note_use(a, s);
+    if (!s) RC_TRY(wait_stream());
+    return SPECKV_OK;
+}
+
+} // namespace speckv

@@ -274,7 +274,7 @@ struct AttendArgs {
     uint32_t stripe_n, stripe_magic;
     // rows-first launches: grid (rows, splits) instead of (splits, rows), so that the workgroups are dispatched split by
     // split -- split 0 of every row first.  With a long split 0 and a short split 1 per row the long pieces all start at
-    // once and the short ones fill the remaining workgroup slots in turns (engine.cpp: batch_unequal_split)
+    // once and the short ones fill the remaining workgroup slots in turns (engine_attend.cpp: int4_unequal_split)
     uint32_t rows_first;
     // table form of the fast kernels (single-sequence form; lin_base and stripe_bases null): an allocation whose placement
     // is no longer regular (pages migrated one by one) but whose range is tile-aligned -- every record address comes

@@ -1,5 +1,5 @@
 // cxl-speckv_amd/csrc/placement.hpp -- where the records of an allocation go.
-// One rule, used by Engine::alloc, the copy-engine fetch (engine.cpp) and exported as speckv_ext_placement so the
+// One rule, used by Engine::alloc, the copy-engine fetch (engine_io.cpp) and exported as speckv_ext_placement so the
 // multi-rank tests can cross-check it without a GPU: page p of an allocation striped over D pool GPUs is record
 // p / D of the run on pool p % D.  A logical page range [first, first+n) therefore maps, on every pool, to ONE
 // contiguous run of records -- which is what lets the copy engine move it with one hipMemcpyPeerAsync per pool.
