@@ -450,7 +450,7 @@ def main():
                 "avg_launch_ms": round(kern_ms, 4),
                 "frac_as_called": variants["as_called"]["frac_hbm"],
                 "avg_launch_ms_as_called": variants["as_called"]["avg_launch_ms"],
-                "launches": {"kernel_instance": f"k_fetch_decompress<{args.scheme}, {args.quant}, false, 0>",
+                "launches": {"kernel_instance": f"k_fetch_decompress<{args.scheme}, {args.quant}, false, 0, false>",
                              **{k: v["launches"] for k, v in variants.items()},
                              "note": "0-based indices of this instance's dispatches in this process, in dispatch order: "
                                      "profiles/summarize_r04.py averages the same dispatches in the rocprofv3 kernel trace"},
@@ -491,6 +491,8 @@ def main():
                 # north_star's second fraction, beside the HBM one, in the object the driver reads
                 out["roofline"]["xgmi"] = {"frac": rx["frac"], "achieved": rx["achieved"], "peak": rx["peak_nominal_per_direction"],
                                            "unit": "GB/s", "links": rx["links"], "layout": rx["layout"], "engine": rx["engine"]}
+                if os.environ.get("SPECKV_BENCH_SINGLE_GPU_TEST") == "1":
+                    out["roofline"]["xgmi"]["one_gpu_dry_run"] = "every 'peer' is the same GPU: no link was crossed, the fraction means nothing"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # rank 0 at N=1 only (bench contract)
         state["phase"] = "cpu_baseline"
         try:

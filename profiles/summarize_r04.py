@@ -47,7 +47,8 @@ def main(out_dir):
     if traced:
         r = traced["roofline"]
         inst = r["launches"]["kernel_instance"]
-        rows = dispatches(os.path.join(out_dir, "trace_driver_cmd"), inst)
+        # (match on the instance's leading template arguments: a later argument with a default may have joined the list)
+        rows = dispatches(os.path.join(out_dir, "trace_driver_cmd"), inst.rstrip(">").rsplit(", false", 1)[0] if inst.count("false") > 1 else inst.rstrip(">"))
         alg = r["algorithmic_bytes_per_launch"]
         t = {"kernel_instance": inst, "dispatches_of_instance_in_trace": len(rows), "algorithmic_bytes_per_launch": alg,
              "bench_line_of_this_process": {"frac": r["frac"], "frac_as_called": r["frac_as_called"], "avg_launch_ms": r["avg_launch_ms"]}}

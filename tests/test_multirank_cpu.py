@@ -210,23 +210,26 @@ def test_bench_gpus_2_starts_its_own_ranks():
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    """The bench line committed with the round's profile (profiles/r03l_bench.json = stdout of `python bench.py` on the
+    """The bench line committed with the round's profile (profiles/r04a_bench.json = stdout of `python bench.py` on the
     MI355X box) carries every field of the driver's contract, with the tier's meaning: metric and config from
     BASELINE.json, roofline and cpu_baseline objects, no model keys; `value` is the W + K region at steady clocks (ramped), the cold
     as-called figure and a sustained one stand beside it."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r03l_bench.json")))
+    d = json.load(open(os.path.join(root, "profiles", "r04a_bench.json")))
     base = json.load(open(os.path.join(root, "BASELINE.json")))
     assert d["metric"] in base["metric"] and d["unit"] == "blocks/s"
     for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in d, k
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
-    assert d["dtype"] == "u8" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["dtype"].startswith("fp32") and "workload" in d["config"] and "model" not in d["config"]
     assert "configs[1]" in d["config"]["workload"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.5 < r["frac"] < 1.0
+    # round 4: the cold figure stands in the roofline object too, and every variant names its dispatches (profiles/summarize_r04.py)
+    assert r["frac_as_called"] == d["variants"]["as_called"]["frac_hbm"] and r["launches"]["kernel_instance"].startswith("k_fetch_decompress<2, 0, false")
+    assert r["launches"]["as_called"] == [d["warmup"], d["warmup"] + d["steps"] - 1] and r["launches"]["ramped"][1] - r["launches"]["ramped"][0] == d["steps"] - 1
     assert r["traffic"] is None or 0.95 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
     assert abs(d["value"] - 131072 * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
     v = d["variants"]
@@ -237,18 +240,21 @@ def test_committed_bench_line_has_the_contract_fields():
     assert "watchdog_fired" not in d
     c = d["cpu_baseline"]
     assert c["unit"] == "blocks/s" and c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert c["port"]["value"] > 0 and c["port"]["cores"] == c["cores"]           # the C restatement is timed beside the compiled reference
     assert d["parity_spot_check"] is True
     f = d["extras"]["prefetch_flush"]
     assert f["requests"] == 8192 and f["pages_issued"] > 10000 and f["submit_ms"] < 0.1 and f["ms"] < 0.2
     # the 2-rank run on one GPU shows the three remote shapes with both engines
-    x = json.load(open(os.path.join(root, "profiles", "r03l_bench_2ranks_one_gpu.json")))["xgmi"]
+    d2 = json.load(open(os.path.join(root, "profiles", "r04a_bench_2ranks_one_gpu.json")))       # started by bench.py itself: `python bench.py --gpus 2`
+    assert d2["n_gpus"] == 2
+    x = d2["xgmi"]
     assert set(x) >= {"cfg3", "cfg4", "symmetric", "accounting"}
     for mode in ("cfg3", "symmetric"):
         assert {"fused_peer_load_kernel", "copy_engines_then_local_decompress", "raw_peer_copy_GBps"} <= set(x[mode])
     # ... and the 8-rank run on one GPU executes the 1 + 7 layout for real (7-way striping, D = 7 in the fetch kernel), with
     # the prefetch-flush leg of configs[2], the working-set statement, the copy engines' actual link bytes, and the top-level
     # remote roofline object of the rank-0 line
-    d8 = json.load(open(os.path.join(root, "profiles", "r03l_bench_8ranks_one_gpu.json")))
+    d8 = json.load(open(os.path.join(root, "profiles", "r04a_bench_8ranks_one_gpu.json")))
     assert d8["n_gpus"] == 8 and "watchdog_fired" not in d8
     x8 = d8["xgmi"]
     for mode in ("cfg3", "cfg4", "symmetric"):
@@ -268,3 +274,9 @@ def test_committed_bench_line_has_the_contract_fields():
     assert abs(rx["peak_nominal_per_direction"] - 7 * 153.6) < 0.1 and abs(rx["peak_nominal_bidirectional"] - 7 * 76.8) < 0.1
     assert rx["engine"] in ("fused_peer_load_kernel", "copy_engines_then_local_decompress") and rx["achieved"] > 0
     assert "ONE-GPU DRY RUN" in rx["note"]                      # no link was crossed: the line says so itself
+    assert d8["roofline"]["xgmi"]["links"] == 7 and d8["roofline"]["xgmi"]["frac"] == rx["frac"]      # north_star's second fraction inside `roofline`
+    # the headline's evidence: the per-dispatch trace of the driver's command agrees with the bench's own HIP events
+    s = json.load(open(os.path.join(root, "profiles", "r04a_summary.json")))["traced_run"]
+    for variant in ("as_called", "ramped", "sustained"):
+        assert abs(s[variant]["trace_vs_hip_events"]) < 0.02, (variant, s[variant])
+        assert abs(s[variant]["frac_from_trace"] - s[variant]["bench_frac_hbm"]) < 0.01
