@@ -916,10 +916,11 @@ def roofline_xgmi_from(x, world):
 
 
 def fp8_scores_extra(torch, kv, T, Lyr):
-    """BASELINE configs[4] (int4/fp8 path, 70B-shaped KV: 80 layers, 8 kv heads, D=128,
-    32k context): the fused dequant-matvec -- q.K^T scores of every layer of one
-    sequence straight from FP8 records on the fp8 matrix cores, 8 query rows per kv
-    head (GQA).  Bytes = the K records read; the fp16 K is never materialised."""
+    """BASELINE configs[4] (int4/fp8 path, 70B-shaped KV: 80 layers, 8 kv heads, D=128, 32k context): the fused
+    dequant-matvec -- softmax(q.K^T).V of every layer of one sequence straight from FP8 records on the fp8 matrix cores,
+    8 query rows per kv head (GQA).  Bytes = the K and V records read; fp16 K / V are never materialised.
+    (The scores-only operator speckv_ext_qk_scores_fp8 is a diagnostic -- its fp32 score stores bound it -- and is no longer
+    benched here: VERDICT r3 weak #12.)"""
     lib = kv.lib
     try:
         lib.set_compression_scheme(4)
@@ -932,48 +933,28 @@ def fp8_scores_extra(torch, kv, T, Lyr):
             x = torch.randn((min(chunk, n_pages - p0), BLOCK_ELEMS), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
             lib.write(h, p0 * PAGE, x.data_ptr(), x.numel() * 2, True)
         q = torch.randn((Lyr, 8, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
-        out = torch.empty((Lyr, 8, 8, T), dtype=torch.float32, device="cuda")
         s = torch.cuda.Stream()
-        def allayers():
-            lib.qk_scores_fp8_layers(h, 0, Lyr, q.data_ptr(), 8, 0, T, out.data_ptr(), s.cuda_stream)
-        allayers(); torch.cuda.synchronize()
-        ramp(allayers, torch.cuda.synchronize, EXTRAS_RAMP_MS)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 5
+        k_bytes = Lyr * (T // 2) * 2048
+        o = torch.empty((Lyr, 8, 8, 128), dtype=torch.float32, device="cuda")
+
+        def attend():
+            lib.attend_fp8(h, 0, Lyr, q.data_ptr(), 8, 0, T, 0.08838834764831845, o.data_ptr(), None, s.cuda_stream)
+        attend(); torch.cuda.synchronize()
+        ramp(attend, torch.cuda.synchronize, EXTRAS_RAMP_MS)
         a.record(s)
         for _ in range(reps):
-            allayers()
+            attend()
         b.record(s); torch.cuda.synchronize()
-        ms = a.elapsed_time(b) / reps
-        k_bytes = Lyr * (T // 2) * 2048
-        # the whole decode attention (scores + softmax + p.V) of every layer from the same records
-        att = {}
-        try:
-            o = torch.empty((Lyr, 8, 8, 128), dtype=torch.float32, device="cuda")
-            def attend():
-                lib.attend_fp8(h, 0, Lyr, q.data_ptr(), 8, 0, T, 0.08838834764831845, o.data_ptr(), None, s.cuda_stream)
-            attend(); torch.cuda.synchronize()
-            ramp(attend, torch.cuda.synchronize, EXTRAS_RAMP_MS)
-            a.record(s)
-            for _ in range(reps):
-                attend()
-            b.record(s); torch.cuda.synchronize()
-            ams = a.elapsed_time(b) / reps
-            att = {"fp8_fused_attention": {"layers": Lyr, "positions": T, "query_rows_per_kv_head": 8,
-                                           "ms_all_layers": round(ams, 4), "KV_record_GBps": round(2 * k_bytes / (ams * 1e-3) / 1e9, 1),
-                                           "frac_hbm": round(2 * k_bytes / (ams * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                           "note": "softmax(q.K^T).V of all layers: quantise + attend + combine launches; bytes = K and V records"}}
-        except Exception as e:
-            att = {"fp8_fused_attention": {"error": repr(e)}}
+        ams = a.elapsed_time(b) / reps
         lib.free(h)
-        out_bytes = Lyr * 8 * 8 * T * 4
-        return {**att, "fp8_qk_scores_mfma": {"layers": Lyr, "positions": T, "query_rows_per_kv_head": 8,
-                                       "pool_GiB_fp8": round(n_pages * 2048 / 2**30, 2), "scores_written_GBps": round(out_bytes / (ms * 1e-3) / 1e9, 1),
-                                       "ms_all_layers": round(ms, 4), "K_record_GBps": round(k_bytes / (ms * 1e-3) / 1e9, 1),
-                                       "frac_hbm": round(k_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                       "note": "all layers in one scores launch (+1 query-quantise launch); bytes = K records only"}}
+        return {"fp8_fused_attention": {"layers": Lyr, "positions": T, "query_rows_per_kv_head": 8, "pool_GiB_fp8": round(n_pages * 2048 / 2**30, 2),
+                                        "ms_all_layers": round(ams, 4), "KV_record_GBps": round(2 * k_bytes / (ams * 1e-3) / 1e9, 1),
+                                        "frac_hbm": round(2 * k_bytes / (ams * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                        "note": "softmax(q.K^T).V of all layers: quantise + attend + combine launches; bytes = K and V records"}}
     except Exception as e:
-        return {"fp8_qk_scores_mfma": {"error": repr(e)}}
+        return {"fp8_fused_attention": {"error": repr(e)}}
     finally:
         lib.set_compression_scheme(2)
 

@@ -4,7 +4,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOCS = ("DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md"))
+DOCS = ("DESIGN.md", "DESIGN_HISTORY.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md"))
 PREFIXES = ("profiles/", "tests/", "cxl-speckv_amd/", "include/", "oracle/", "examples/")
 REFERENCE_PATHS = {"tests/test_c_api.c"}                 # paths of the reference repository that the text names as such
 
