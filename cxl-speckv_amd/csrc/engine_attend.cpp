@@ -215,6 +215,10 @@ static uint32_t batch_tiles_per_split(bool fp8, uint32_t n_seq, uint32_t heads, 
 // CU resident, its two halves merged in LDS): one round of resident workgroups when the batch is smaller than that, whole
 // sequences otherwise (a whole sequence is final: no partials, no merge launch); never under 32 tiles a split.
 static bool int4_batch_wg8() { static const bool on = !getenv("SPECKV_INT4_WG4"); return on; }
+// More sequences than CUs: workgroups of one run (8 waves, two resident per CU) -- a finishing workgroup's successor starts
+// under its neighbour's stream, where a second round of 16-wave workgroups would wait for the whole CU (512 x 1k 0.52 -> 0.54,
+// 1024 x 1k 0.56 -> 0.595: profiles/r04_batch_short.txt); AttendArgs::wg8 = 2.
+static uint32_t int4_wg8_form(uint32_t n_seq) { return n_seq > 256u ? 2u : 1u; }
 static uint32_t int4_wg8_batch_tps(uint32_t n_seq, uint32_t tiles_max)
 {
     if (const char* env = getenv("SPECKV_ATTEND_TILES_PER_SPLIT")) return std::max(1, atoi(env));      // (measurement runs)
@@ -356,7 +360,7 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     for (uint32_t i = 0; i < n_seq; ++i) one_split_each = one_split_each && seqs[i].n_splits == 1u;
     if (one_split_each) { k.direct_out = d_out; k.direct_lse = d_lse; }
     if (unequal.on) k.rows_first = 1u;
-    if (wg8) k.wg8 = 1u;
+    if (wg8) k.wg8 = int4_wg8_form(n_seq);
     if (fp8) {
         HIP_TRY(launch_attend_fp8_batch(k, n_seq, d_out, d_lse, st));
     } else {
@@ -505,7 +509,7 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
     k.scale_log2e = sm_scale * 1.4426950408889634f;
     if (plan->second.table) { k.table_form = 1u; k.zero_page = d_zero_page_; }           // a member without a regular placement: addresses from the page tables
     else if (plan->second.striped) k.stripe_bases = reinterpret_cast<const uint64_t*>(1);     // striped launch: every descriptor brings its table
-    else { k.lin_base = reinterpret_cast<const uint8_t*>(1); if (!fp8 && int4_batch_wg8()) k.wg8 = 1u; }     // non-null: linear form (the real base comes from the descriptor)
+    else { k.lin_base = reinterpret_cast<const uint8_t*>(1); if (!fp8 && int4_batch_wg8()) k.wg8 = int4_wg8_form(n_seq); }     // non-null: linear form (the real base comes from the descriptor)
     k.seqs = static_cast<const AttendSeq*>(d_plan);
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);

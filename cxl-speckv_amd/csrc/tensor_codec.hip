@@ -1297,6 +1297,390 @@ __global__ __launch_bounds__(64 * kTfWaves) void k_tc_fused(const void* __restri
     }
 }
 
+// ---------------------------------------------------------------- decompress in ONE pass over the stream
+// The three launches above read the stream twice (summary, expand), and their expand loop takes a lane's 8 pairs one after the
+// other with a byte store per ELEMENT.  This form reads the stream once and expands the way the block decoder of the pool does
+// (kernels.hip: decode_rle_fast) -- one byte scattered per RUN, everything else constant work:
+//   the expanded deltas are piecewise constant, so the decoded int8 sequence is the SECOND prefix sum (mod 256) of
+//       E[start of run r] = value_r - value_{r-1},   0 elsewhere        (cache_engine.cpp:241-273)
+//   a wave owns a chunk of 2048 pairs (4 KiB of the stream: four 16-byte loads per lane, kept in registers) and sums its counts and
+//   value x count products; a workgroup of kTdfWaves waves takes that many consecutive chunks (ticket counter: ascending order, so
+//   a workgroup's predecessors are finished or resident) and publishes ONE 8-byte status word (state << 62 | int8 prefix << 54 |
+//   elements; the value is the word -- agent-scope relaxed store / load, nothing to fence); wave 0 looks back over the
+//   predecessors' words 64 at a time; every wave then knows where its stretch of the output starts and what q was in front of it.
+//   The stretch goes out window by window (4096 elements, aligned to 8 elements of the OUTPUT so that whole groups are 16-byte
+//   stores; a chunk of data that does not compress is one window): clear the window's byte table, scatter E for the pairs that
+//   start in it, then 512 elements per step: two packed wave scans + eight byte recurrences per lane, dequantise, store.  The
+//   groups at the two ragged ends of the stretch are stored element by element (their neighbours belong to the next chunk's wave).
+// A chunk that holds a ZERO count (nothing our encoders or the reference's emit; cache_engine.cpp:262 just skips it) would put two
+// runs on one table byte: such a chunk is expanded pair by pair, straight to memory (td_chunk_general).
+#ifndef SPECKV_TDF_WAVES
+#define SPECKV_TDF_WAVES 16
+#endif
+constexpr uint32_t kTdfWaves = SPECKV_TDF_WAVES;
+constexpr uint32_t kTdfWin = 4096;           // elements per window
+#define SPECKV_TD_SDWA2(NAME, OP, S0, S1)                                                       \
+    __device__ __forceinline__ uint32_t NAME(uint32_t a, uint32_t b)                            \
+    {                                                                                           \
+        uint32_t r;                                                                             \
+        asm(OP " %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" S0 " src1_sel:" S1   \
+            : "=v"(r) : "v"(a), "v"(b));                                                        \
+        return r;                                                                               \
+    }
+SPECKV_TD_SDWA2(td_add_b0, "v_add_u32_sdwa", "DWORD", "BYTE_0")
+SPECKV_TD_SDWA2(td_add_b1, "v_add_u32_sdwa", "DWORD", "BYTE_1")
+SPECKV_TD_SDWA2(td_add_b2, "v_add_u32_sdwa", "DWORD", "BYTE_2")
+SPECKV_TD_SDWA2(td_add_b3, "v_add_u32_sdwa", "DWORD", "BYTE_3")
+SPECKV_TD_SDWA2(td_sub_b0_b2, "v_sub_u32_sdwa", "BYTE_0", "BYTE_2")   // a.b0 - b.b2
+SPECKV_TD_SDWA2(td_sub_b2_b0, "v_sub_u32_sdwa", "BYTE_2", "BYTE_0")   // a.b2 - b.b0
+#undef SPECKV_TD_SDWA2
+template <int K> __device__ __forceinline__ uint32_t td_add_byte(uint32_t a, uint32_t lo, uint32_t hi)
+{
+    return K == 0 ? td_add_b0(a, lo) : K == 1 ? td_add_b1(a, lo) : K == 2 ? td_add_b2(a, lo) : K == 3 ? td_add_b3(a, lo)
+         : K == 4 ? td_add_b0(a, hi) : K == 5 ? td_add_b1(a, hi) : K == 6 ? td_add_b2(a, hi) : td_add_b3(a, hi);
+}
+__device__ __forceinline__ void td_lds_b8(uint32_t addr, uint32_t v) { *reinterpret_cast<lds_u8*>(static_cast<uintptr_t>(addr)) = static_cast<uint8_t>(v); }
+
+// Exclusive prefix in front of workgroup `t` (t > 0): elements (low 54 bits of the words) and the int8 prefix (the 8 bits above,
+// summed modulo 256 by the caller).  An aggregate's element count is < 2^24 x kTdfWaves.
+__device__ __forceinline__ void td_look_back(const uint64_t* status, uint64_t t, uint32_t lane, uint64_t& elems, uint32_t& qsum)
+{
+    constexpr uint64_t kLo = (1ull << 54) - 1ull;
+    elems = 0; qsum = 0;
+    uint64_t end = t;                                                    // words [.., end) are still to be looked at
+    for (;;) {
+        const bool have = lane < end;
+        uint64_t w;
+        unsigned long long ready, incl;
+        uint32_t first_incl;
+        for (;;) {                                                       // this window: every word in front of the nearest prefix must be there
+            w = have ? tc_lb_load(status + (end - 1u - lane)) : (2ull << 62);        // (in front of workgroup 0: a prefix of nothing)
+            ready = __ballot((w >> 62) != 0ull);
+            incl = __ballot((w >> 62) == 2ull);
+            first_incl = incl ? static_cast<uint32_t>(__builtin_ctzll(incl)) : 64u;
+            const unsigned long long need = first_incl >= 63u ? ~0ull : ((2ull << first_incl) - 1ull);
+            if ((ready & need) == need) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        const uint64_t v = w & kTcLbMask;
+        const bool mine = lane < first_incl;                            // aggregates in front of the prefix
+        const uint32_t lo_lo = lane63(wave_incl_add(mine ? static_cast<uint32_t>(v & 0xFFFFu) : 0u));
+        const uint32_t lo_hi = lane63(wave_incl_add(mine ? static_cast<uint32_t>((v & kLo) >> 16) : 0u));
+        elems += (static_cast<uint64_t>(lo_hi) << 16) + lo_lo;
+        qsum += lane63(wave_incl_add(mine ? static_cast<uint32_t>(v >> 54) : 0u));
+        if (first_incl < 64u) {
+            const uint32_t pl = static_cast<uint32_t>(__shfl(static_cast<int>(v & 0xFFFFFFFFull), static_cast<int>(first_incl)));
+            const uint32_t ph = static_cast<uint32_t>(__shfl(static_cast<int>(v >> 32), static_cast<int>(first_incl)));
+            const uint64_t pv = (static_cast<uint64_t>(ph) << 32) | pl;
+            elems += pv & kLo; qsum += static_cast<uint32_t>(pv >> 54);
+            return;
+        }
+        end -= 64u;
+    }
+}
+
+// A chunk with zero counts in it: pair by pair, 64 pairs per step (an add-scan of (value x count mod 256) << 24 | count gives each
+// run its start and the int8 prefix of all earlier deltas; the lane writes its run element by element), clipped at `end`.
+template <int MODE, bool F32>
+__device__ __noinline__ void td_chunk_general(const uint8_t* __restrict__ rle, uint64_t p0, uint64_t n_pairs, uint64_t start, uint64_t end,
+                                              uint32_t qp, float scale, uint8_t* __restrict__ dst, uint32_t lane)
+{
+    uint64_t pos = start;
+    uint32_t q0 = qp;
+#pragma unroll 1
+    for (uint32_t b = 0; b < kTile && pos < end; b += 64u) {
+        const uint64_t i = p0 + b + lane;
+        uint32_t bits = 0;
+        if (i < n_pairs) bits = *reinterpret_cast<const uint16_t*>(rle + 2ull * i);
+        const uint32_t v = bits & 0xFFu, c = bits >> 8;
+        const uint32_t packed = ((v * c) << 24) | c;
+        const uint32_t incl = wave_incl_add(packed);
+        const uint32_t e = incl - packed;
+        uint64_t p = pos + (e & 0xFFFFFFu);
+        uint32_t q = q0 + (e >> 24);
+#pragma unroll 1
+        for (uint32_t m = 0; m < c && p < end; ++m, ++p) {
+            q += v;
+            const float y = dequant<MODE>(static_cast<int>(static_cast<int8_t>(q & 0xFFu)), scale);
+            if (F32) reinterpret_cast<float*>(dst)[p] = y;
+            else { float a = y, z = 0.0f; reinterpret_cast<uint16_t*>(dst)[p] = static_cast<uint16_t>(pack_half2(a, z) & 0xFFFFu); }
+        }
+        const uint32_t tot = lane63(incl);
+        pos += tot & 0xFFFFFFu;
+        q0 = (q0 + (tot >> 24)) & 0xFFu;
+    }
+}
+
+// The pairs of chunk `p0 / 2048`: dword = v0 | c0 << 8 | v1 << 16 | c1 << 24, pairs p0 + 512 j + 8 lane .. + 7 in w[j]; pairs behind
+// the stream's end read as (0, 0).  mn: the smallest count among the lane's pairs that exist.
+__device__ __forceinline__ void td_load_pairs(const uint8_t* __restrict__ rle, uint64_t p0, uint64_t n_pairs, bool live, uint32_t lane,
+                                              uint32_t (&w)[4][4], uint32_t& mn)
+{
+    const bool wide = (reinterpret_cast<uintptr_t>(rle) & 15u) == 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+        const uint64_t i = p0 + 512u * j + 8u * lane;
+        w[j][0] = w[j][1] = w[j][2] = w[j][3] = 0u;
+        if (live && i < n_pairs) {
+            if (wide && i + 8u <= n_pairs) {
+                const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rle + 2ull * i));
+                w[j][0] = x.x; w[j][1] = x.y; w[j][2] = x.z; w[j][3] = x.w;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) mn = umin(mn, umin((w[j][t] >> 8) & 0xFFu, w[j][t] >> 24));
+            } else {
+#pragma unroll
+                for (uint32_t e = 0; e < 8u; ++e)
+                    if (i + e < n_pairs) {
+                        const uint32_t bits = *reinterpret_cast<const uint16_t*>(rle + 2ull * (i + e));
+                        w[j][e >> 1] |= bits << (16u * (e & 1u));
+                        mn = umin(mn, bits >> 8);
+                    }
+            }
+        }
+    }
+}
+// Per step of 512 pairs: the lane's count and value x count sums scanned across the wave.  ex: exclusive prefix of the lane in its
+// step, st: the step's total; both (sum v c mod 256) << 24 | sum c (counts < 2^24 per step).
+__device__ __forceinline__ void td_scan_pairs(const uint32_t (&w)[4][4], uint32_t (&ex)[4], uint32_t (&st)[4])
+{
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+        uint32_t sc = 0, sv = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t counts = (w[j][t] >> 8) & 0x00FF00FFu;
+            sc = __builtin_amdgcn_udot4(counts, 0x00010001u, sc, false);
+            sv = __builtin_amdgcn_udot4(w[j][t], counts, sv, false);
+        }
+        const uint32_t lt = (sv << 24) | sc;
+        const uint32_t incl = wave_incl_add(lt);
+        ex[j] = incl - lt;
+        st[j] = lane63(incl);
+    }
+}
+// One window of a chunk: elements [wo, wo + 4096) counted from the chunk's OWN first element, as int8 values relative to the q in
+// front of the chunk, into the wave's table (byte p = element wo + p).  Needs nothing from outside the chunk.
+// c1 / c2: S1 (the delta) / S2 (q - q in front of the chunk) at the end of the previous window.
+__device__ __forceinline__ void td_window_values(const uint32_t (&w)[4][4], const uint32_t (&ex)[4], const uint32_t (&st)[4], uint32_t wo,
+                                                 uint32_t tot_c, uint8_t* tab, uint32_t lane, uint32_t& c1, uint32_t& c2)
+{
+    const uint32_t tab_addr = lds_addr_of(tab);
+    const uint32_t cnt = tot_c - wo < kTdfWin ? tot_c - wo : kTdfWin;      // elements of the chunk in this window
+    {
+        u32x4* t4 = reinterpret_cast<u32x4*>(tab);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (uint32_t k = 0; k < kTdfWin / 1024u; ++k) t4[64u * k + lane] = z;
+    }
+    int32_t tot = -static_cast<int32_t>(wo);                             // first element of step 0, relative to the window (> -2^24)
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+        const int32_t step_c = static_cast<int32_t>(st[j] & 0xFFFFFFu);
+        if (tot + step_c > 0 && tot < static_cast<int32_t>(kTdfWin)) {      // (wave-uniform) the step has pairs that start in the window
+            const int32_t base = tot + static_cast<int32_t>(ex[j] & 0xFFFFFFu);
+            // value of the pair in front of the lane's first (0 in front of the chunk: E of the first run is its value)
+            const uint32_t pwj = wave_shr1(w[j][3], j == 0u ? 0u : lane63(w[j == 0u ? 0u : j - 1u][3]));
+            const uint32_t d0 = td_sub_b0_b2(w[j][0], pwj), d1 = td_sub_b2_b0(w[j][0], w[j][0]);
+            const uint32_t d2 = td_sub_b0_b2(w[j][1], w[j][0]), d3 = td_sub_b2_b0(w[j][1], w[j][1]);
+            const uint32_t d4 = td_sub_b0_b2(w[j][2], w[j][1]), d5 = td_sub_b2_b0(w[j][2], w[j][2]);
+            const uint32_t d6 = td_sub_b0_b2(w[j][3], w[j][2]), d7 = td_sub_b2_b0(w[j][3], w[j][3]);
+            if (tot >= 0 && tot + step_c <= static_cast<int32_t>(kTdfWin)) {    // all of them do: plain addresses
+                uint32_t a = tab_addr + static_cast<uint32_t>(base);
+                td_lds_b8(a, d0); a = td_add_b1(a, w[j][0]);
+                td_lds_b8(a, d1); a = td_add_b3(a, w[j][0]);
+                td_lds_b8(a, d2); a = td_add_b1(a, w[j][1]);
+                td_lds_b8(a, d3); a = td_add_b3(a, w[j][1]);
+                td_lds_b8(a, d4); a = td_add_b1(a, w[j][2]);
+                td_lds_b8(a, d5); a = td_add_b3(a, w[j][2]);
+                td_lds_b8(a, d6); a = td_add_b1(a, w[j][3]);
+                td_lds_b8(a, d7);                                       // (pairs behind the stream's end have count 0: they land on the byte behind
+                                                                        //  the chunk's last element -- nobody's, or the spare byte at the window's end)
+            } else {                                                    // a run may start in front of the window or behind it: those go to the spare bytes
+                int32_t a = base;
+                const uint32_t dd[8] = {d0, d1, d2, d3, d4, d5, d6, d7};
+#pragma unroll
+                for (uint32_t e = 0; e < 8u; ++e) {
+                    const uint32_t off = static_cast<uint32_t>(a) < kTdfWin ? static_cast<uint32_t>(a) : kTdfWin;
+                    td_lds_b8(tab_addr + off, dd[e]);
+                    a += static_cast<int32_t>((w[j][e >> 1] >> (8u + 16u * (e & 1u))) & 0xFFu);
+                }
+            }
+        }
+        tot += step_c;
+    }
+    wave_lds_fence();
+    // E -> q (relative), in place: 512 elements per step, two packed wave scans + eight byte recurrences per lane
+#pragma unroll 1
+    for (uint32_t g0 = 0; g0 < kTdfWin; g0 += 512u) {
+        if (g0 >= cnt) break;                                            // (wave-uniform) nothing of this chunk behind here
+        uint2* cell = reinterpret_cast<uint2*>(tab + g0 + 8u * lane);
+        const uint2 x = *cell;
+        const uint32_t t1 = __builtin_amdgcn_sad_u8(x.x, 0u, __builtin_amdgcn_sad_u8(x.y, 0u, 0u));
+        const uint32_t t2 = __builtin_amdgcn_udot4(x.x, 0x05060708u, __builtin_amdgcn_udot4(x.y, 0x01020304u, 0u, false), false);
+        const uint32_t i1 = wave_incl_add(t1);
+        const uint32_t x1 = c1 + i1 - t1;                                // S1 entering this lane
+        const uint32_t u = t2 + 8u * x1;                                 // this lane's S2 increment
+        const uint32_t i2 = wave_incl_add(u);
+        const uint32_t x2 = c2 + i2 - u;                                 // S2 entering this lane
+        c1 += lane63(i1);
+        c2 += lane63(i2);
+        uint32_t s1 = x1, s2 = x2;
+        uint32_t q[8];
+        s1 = td_add_byte<0>(s1, x.x, x.y); s2 += s1; q[0] = s2;
+        s1 = td_add_byte<1>(s1, x.x, x.y); s2 += s1; q[1] = s2;
+        s1 = td_add_byte<2>(s1, x.x, x.y); s2 += s1; q[2] = s2;
+        s1 = td_add_byte<3>(s1, x.x, x.y); s2 += s1; q[3] = s2;
+        s1 = td_add_byte<4>(s1, x.x, x.y); s2 += s1; q[4] = s2;
+        s1 = td_add_byte<5>(s1, x.x, x.y); s2 += s1; q[5] = s2;
+        s1 = td_add_byte<6>(s1, x.x, x.y); s2 += s1; q[6] = s2;
+        s1 = td_add_byte<7>(s1, x.x, x.y); s2 += s1; q[7] = s2;
+        uint2 o;                                                         // byte k = q[k] & 0xFF (v_perm: two low bytes, then two halves)
+        o.x = __builtin_amdgcn_perm(__builtin_amdgcn_perm(q[3], q[2], 0x0c0c0400u), __builtin_amdgcn_perm(q[1], q[0], 0x0c0c0400u), 0x05040100u);
+        o.y = __builtin_amdgcn_perm(__builtin_amdgcn_perm(q[7], q[6], 0x0c0c0400u), __builtin_amdgcn_perm(q[5], q[4], 0x0c0c0400u), 0x05040100u);
+        *cell = o;
+    }
+    wave_lds_fence();
+}
+// ... and out: groups of 8 elements aligned in the OUTPUT (16-byte stores) from a table that is aligned to the chunk: bytes
+// re-aligned with v_alignbyte from three aligned dwords; group G of the window covers table bytes [8 G - al, 8 G - al + 8), al =
+// start mod 8.  The groups at the window's two ends that hold fewer than 8 of its elements go element by element (the others
+// belong to the neighbouring chunk's wave, or to the window before / behind).
+template <int MODE, bool F32>
+__device__ __forceinline__ void td_window_store(const uint8_t* tab, uint32_t wo, uint64_t start, uint64_t end, uint32_t qp, float scale,
+                                                uint8_t* __restrict__ dst, uint32_t lane)
+{
+#ifdef SPECKV_TD_UNALIGNED
+    const uint32_t al = 0u;
+    const uint64_t obase = start + wo;
+#else
+    const uint32_t al = static_cast<uint32_t>(start) & 7u;
+    const uint64_t obase = (start & ~7ull) + wo;                        // output position of group 0's first element
+#endif
+    const int32_t lo_i = static_cast<int32_t>(al);                      // group-relative bounds of what this window stores
+    const uint64_t wend = start + wo + kTdfWin < end ? start + wo + kTdfWin : end;
+    const int32_t hi_i = static_cast<int32_t>(wend - obase);
+#pragma unroll 1
+    for (uint32_t g0 = 0; static_cast<int32_t>(g0) < hi_i; g0 += 512u) {
+        const int32_t q0 = static_cast<int32_t>(g0 + 8u * lane);         // group-relative element index of the lane's group
+        if (q0 + 8 <= lo_i || q0 >= hi_i) continue;
+        const int32_t tb = q0 - static_cast<int32_t>(al);                // table byte of its first element (>= -7)
+        const uint32_t* dw = reinterpret_cast<const uint32_t*>(tab + ((tb >> 2) << 2));           // (arithmetic shift: -1 -> the dword in front)
+        const uint32_t a0 = dw[0], a1 = dw[1], a2 = dw[2];
+        const uint32_t sh = static_cast<uint32_t>(tb) & 3u;
+        const uint32_t lo4 = __builtin_amdgcn_alignbyte(a1, a0, sh), hi4 = __builtin_amdgcn_alignbyte(a2, a1, sh);
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t b = (((e < 4 ? lo4 : hi4) >> ((e & 3) * 8)) + qp) & 0xFFu;
+            y[e] = dequant<MODE>(static_cast<int>(static_cast<int8_t>(b)), scale);
+        }
+        const uint64_t o = obase + static_cast<uint64_t>(q0);
+        if (q0 >= lo_i && q0 + 8 <= hi_i) {
+            if (F32) {
+                float* op = reinterpret_cast<float*>(dst) + o;
+                typedef float f32x4v __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(f32x4v{y[0], y[1], y[2], y[3]}, reinterpret_cast<f32x4v*>(op));
+                __builtin_nontemporal_store(f32x4v{y[4], y[5], y[6], y[7]}, reinterpret_cast<f32x4v*>(op + 4));
+            } else {
+                const u32x4 pk = {pack_half2(y[0], y[1]), pack_half2(y[2], y[3]), pack_half2(y[4], y[5]), pack_half2(y[6], y[7])};
+                __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(dst) + o));
+            }
+        } else {
+            for (int e = 0; e < 8; ++e) {
+                if (q0 + e < lo_i || q0 + e >= hi_i) continue;
+                if (F32) reinterpret_cast<float*>(dst)[o + e] = y[e];
+                else { float a = y[e], z = 0.0f; reinterpret_cast<uint16_t*>(dst)[o + e] = static_cast<uint16_t>(pack_half2(a, z) & 0xFFFFu); }
+            }
+        }
+    }
+    wave_lds_fence();
+}
+// A chunk of long runs: its windows behind the first, with the pairs read again (kept in registers over the first store pass
+// they would cost the kernel a workgroup per CU).  Out of line: data that does not compress never gets here.
+template <int MODE, bool F32>
+__device__ __noinline__ void td_windows_behind_the_first(const uint8_t* __restrict__ rle, uint64_t p0, uint64_t n_pairs, uint64_t start,
+                                                         uint64_t end, uint32_t qp, uint32_t tot_c, uint32_t c1, uint32_t c2, uint8_t* tab,
+                                                         float scale, uint8_t* __restrict__ dst, uint32_t lane)
+{
+    uint32_t w[4][4], ex[4], st[4], mn = 255u;
+    td_load_pairs(rle, p0, n_pairs, true, lane, w, mn);
+    td_scan_pairs(w, ex, st);
+#pragma unroll 1
+    for (uint32_t wo = kTdfWin; start + wo < end; wo += kTdfWin) {
+        td_window_values(w, ex, st, wo, tot_c, tab, lane, c1, c2);
+        td_window_store<MODE, F32>(tab, wo, start, end, qp, scale, dst, lane);
+    }
+}
+
+template <int MODE, bool F32>
+__global__ __launch_bounds__(64 * kTdfWaves) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_td_fused(const uint8_t* __restrict__ rle, uint64_t n_pairs, uint64_t n_chunks, uint64_t* __restrict__ status, uint32_t* __restrict__ ticket,
+                uint64_t cap, uint64_t* __restrict__ out_n, float scale, uint8_t* __restrict__ dst)
+{
+    constexpr uint32_t kFront = 16;           // bytes in front of a wave's table (the store pass may read up to 7 of them: never used)
+    __shared__ __attribute__((aligned(16))) uint8_t tabs[kTdfWaves][kFront + kTdfWin + 16];      // (+16 behind: written, never used)
+    __shared__ uint32_t s_ticket;
+    __shared__ uint32_t s_tot[kTdfWaves];
+    __shared__ uint64_t s_start[kTdfWaves];
+    __shared__ uint32_t s_qp[kTdfWaves];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0u) s_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint64_t wg = s_ticket;
+    const uint64_t chunk = wg * kTdfWaves + wave;
+    const bool live = chunk < n_chunks;                                 // (waves behind the last chunk only keep the barriers company)
+    const uint64_t p0 = chunk * kTile;
+    uint32_t w[4][4], ex[4], st[4], mn = 255u;
+    td_load_pairs(rle, p0, n_pairs, live, lane, w, mn);
+    td_scan_pairs(w, ex, st);
+    const uint32_t tot_c = (st[0] & 0xFFFFFFu) + (st[1] & 0xFFFFFFu) + (st[2] & 0xFFFFFFu) + (st[3] & 0xFFFFFFu);     // < 2^24 (2048 x 255)
+    const uint32_t tot_v = ((st[0] >> 24) + (st[1] >> 24) + (st[2] >> 24) + (st[3] >> 24)) & 0xFFu;
+    const bool has_zero = __ballot(mn == 0u) != 0ull;
+    if (lane == 0u) s_tot[wave] = (tot_v << 24) | tot_c;
+    __syncthreads();
+    // ---- wave 0: the workgroup's aggregate goes out at once (nobody in front of it is needed for that)
+    if (wave == 0u) {
+        const uint32_t wt = lane < kTdfWaves ? s_tot[lane] : 0u;
+        const uint32_t agg_c = lane63(wave_incl_add(wt & 0xFFFFFFu)), agg_v = lane63(wave_incl_add(wt >> 24)) & 0xFFu;      // < 2^24 x 16
+        if (lane == 0u) tc_lb_store(status + wg, wg == 0u ? 2ull : 1ull, (static_cast<uint64_t>(agg_v) << 54) | agg_c);
+    }
+    // ---- the first window's values: nothing in them needs the look-back, which they therefore hide
+    uint8_t* tab = tabs[wave] + kFront;
+    uint32_t c1 = 0u, c2 = 0u;
+    if (live && tot_c != 0u && !has_zero) td_window_values(w, ex, st, 0u, tot_c, tab, lane, c1, c2);
+    // ---- wave 0: the prefix in front of the workgroup by look-back, every wave's own start; then everybody knows where it writes
+    if (wave == 0u) {
+        const uint32_t wt = lane < kTdfWaves ? s_tot[lane] : 0u;         // (again: cheaper than keeping them over the window)
+        const uint32_t wic = wave_incl_add(wt & 0xFFFFFFu), wiv = wave_incl_add(wt >> 24);
+        const uint32_t agg_c = lane63(wic), agg_v = lane63(wiv) & 0xFFu;
+        uint64_t before = 0;
+        uint32_t qb = 0;
+        if (wg != 0u) {
+#ifdef SPECKV_TD_NO_LB
+            before = wg * kTdfWaves * 2048ull;                          // (timing builds only: wrong output)
+#else
+            td_look_back(status, wg, lane, before, qb);
+#endif
+            qb &= 0xFFu;
+            if (lane == 0u) tc_lb_store(status + wg, 2ull, (static_cast<uint64_t>((qb + agg_v) & 0xFFu) << 54) | (before + agg_c));
+        }
+        if (lane < kTdfWaves) {
+            s_start[lane] = before + (wic - (wt & 0xFFFFFFu));
+            s_qp[lane] = (qb + wiv - (wt >> 24)) & 0xFFu;
+        }
+        if (lane == 0u && (wg + 1u) * kTdfWaves >= n_chunks) { const uint64_t total = before + agg_c; *out_n = total < cap ? total : cap; }
+    }
+    __syncthreads();
+    if (!live) return;
+    const uint64_t start = s_start[wave];
+    const uint32_t qp = s_qp[wave];
+    const uint64_t end = (start + tot_c < cap) ? start + tot_c : cap;
+    if (start >= end) return;
+    if (has_zero) { td_chunk_general<MODE, F32>(rle, p0, n_pairs, start, end, qp, scale, dst, lane); return; }
+    td_window_store<MODE, F32>(tab, 0u, start, end, qp, scale, dst, lane);
+    if (start + kTdfWin < end) td_windows_behind_the_first<MODE, F32>(rle, p0, n_pairs, start, end, qp, tot_c, c1, c2, tab, scale, dst, lane);
+}
+
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 } // namespace
@@ -1401,6 +1785,20 @@ hipError_t launch_tensor_decompress(const uint8_t* d_rle, uint64_t rle_bytes, fl
     TdSummary* summ = reinterpret_cast<TdSummary*>(w); w += align_up(chunks * sizeof(TdSummary), 256);
     TdCarry* carry = reinterpret_cast<TdCarry*>(w); w += align_up((chunks + 1) * sizeof(TdCarry), 256);
     uint64_t* n_out = d_n_out ? d_n_out : reinterpret_cast<uint64_t*>(w);
+    if (chunks && dst_cap && !getenv("SPECKV_TC_MULTIPASS")) {
+        // single pass: a memset node (ticket, element count, one status word per workgroup), then ONE kernel
+        const uint64_t wgs = (chunks + kTdfWaves - 1) / kTdfWaves;
+        uint32_t* ticket = reinterpret_cast<uint32_t*>(d_ws);
+        uint64_t* n_out1 = d_n_out ? d_n_out : reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(d_ws) + 128);
+        uint64_t* status = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(d_ws) + 256);
+        const hipError_t e = hipMemsetAsync(d_ws, 0, 256 + wgs * 8, s);
+        if (e != hipSuccess) return e;
+#define SPECKV_TDF(MODE, F32) hipLaunchKernelGGL((k_td_fused<MODE, F32>), dim3(static_cast<uint32_t>(wgs)), dim3(64 * kTdfWaves), 0, s, d_rle, n_pairs, chunks, status, ticket, dst_cap, n_out1, scale, static_cast<uint8_t*>(d_dst))
+        if (quant_mode == kIntent) { if (out_f32) SPECKV_TDF(kIntent, true); else SPECKV_TDF(kIntent, false); }
+        else                       { if (out_f32) SPECKV_TDF(kRefExact, true); else SPECKV_TDF(kRefExact, false); }
+#undef SPECKV_TDF
+        return hipGetLastError();
+    }
     if (chunks) hipLaunchKernelGGL(k_td_summary, dim3(static_cast<uint32_t>((chunks + 3) / 4)), dim3(256), 0, s, d_rle, n_pairs, summ);
     const uint64_t n_steps = (chunks + 63) / 64;
     const char* scan_env = getenv("SPECKV_TC_SCAN");                // (A/B and test switch: wg = one workgroup, serial = one wave)

@@ -658,6 +658,48 @@ def test_fused_attention_batch_of_sequences(eng, scheme):
         lib.free(h)
 
 
+@pytest.mark.parametrize("scheme", [4, 3])
+def test_fused_attention_batch_larger_than_the_machine(eng, scheme):
+    """More sequences than the GPU has CUs (INT4: the batch then runs on workgroups of one run each, two resident per CU,
+    instead of the two-halves form): 272 short ragged sequences against the per-sequence entry point, batch and planned."""
+    torch = torch_mod()
+    lib = eng.lib
+    lib.set_compression_scheme(scheme)
+    batch_fn, single_fn = (lib.attend_fp8_batch, lib.attend_fp8) if scheme == 4 else (lib.attend_int4_batch, lib.attend_int4)
+    T, L, H, D, G = 128, 1, 8, 128, 8
+    rng = np.random.default_rng(97)
+    n_seq = 272
+    lens = [int(v) * 2 for v in rng.integers(0, T // 2 + 1, n_seq)]
+    lens[0], lens[1], lens[2] = T, 0, 2
+    n_pages = T * L * H * D * 2 * 2 // PAGE
+    xs = [(rng.standard_normal((n_pages, N)) * rng.uniform(0.2, 2.0, (n_pages, 1))).astype(np.float16) for _ in range(4)]
+    handles = []
+    for i in range(n_seq):
+        h = lib.alloc(T * L * H * D * 2 * 2)
+        lib.set_layout(h, T, L, H, D, 2)
+        lib.write(h, 0, xs[i % 4].ctypes.data, xs[i % 4].nbytes, False)
+        handles.append(h)
+    q = torch.from_numpy(rng.standard_normal((n_seq, H, G, D)).astype(np.float16)).cuda()
+    sm = 1.0 / np.sqrt(D)
+    out = torch.full((n_seq, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
+    lse = torch.full((n_seq, H, G), float("nan"), dtype=torch.float32, device="cuda")
+    batch_fn(handles, 0, q.data_ptr(), G, lens, sm, out.data_ptr(), lse.data_ptr())
+    torch.cuda.synchronize()
+    one = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
+    one_lse = torch.empty((H, G), dtype=torch.float32, device="cuda")
+    for i in list(range(8)) + list(range(250, n_seq)):
+        if lens[i] == 0:
+            assert float(out[i].abs().max()) == 0.0
+            continue
+        single_fn(handles[i], 0, 1, q[i].data_ptr(), G, 0, lens[i], sm, one.data_ptr(), one_lse.data_ptr())
+        torch.cuda.synchronize()
+        scale = float(one.abs().max()) + 1e-6
+        assert float((out[i] - one).abs().max()) <= 1e-3 * scale, (i, lens[i])
+        assert float((lse[i] - one_lse).abs().max()) <= 1e-4, (i, lens[i])
+    for h in handles:
+        lib.free(h)
+
+
 def test_int4_fused_attention(eng, oracle):
     """The 4:1 format of BASELINE config 5: softmax(q.K^T).V straight from INT4_G32 records
     (speckv_ext_attend_int4) against the oracle's double-precision attention over the pages as
