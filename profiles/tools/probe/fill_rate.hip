@@ -27,6 +27,24 @@ __global__ __launch_bounds__(256) void k_move(const u32x4* __restrict__ src, u32
         if (i < n16) { if (NT) __builtin_nontemporal_store(x[j], dst + i); else dst[i] = x[j]; }
     }
 }
+// the same with workgroups of WAVES waves (a wave owns PER consecutive KiB)
+template <int PER, int WAVES, bool COPY>
+__global__ __launch_bounds__(64 * WAVES) void k_move_wg(const u32x4* __restrict__ src, u32x4* __restrict__ dst, uint64_t n16, uint32_t v)
+{
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    u32x4 x[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const uint64_t i = ((static_cast<uint64_t>(blockIdx.x) * WAVES + w) * PER + j) * 64u + lane;
+        x[j] = u32x4{v, v, v, v};
+        if (COPY && i < n16) x[j] = __builtin_nontemporal_load(src + i);
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const uint64_t i = ((static_cast<uint64_t>(blockIdx.x) * WAVES + w) * PER + j) * 64u + lane;
+        if (i < n16) __builtin_nontemporal_store(x[j], dst + i);
+    }
+}
 int main()
 {
     const uint64_t bytes = 1ull << 30, n16 = bytes / 16;
@@ -56,6 +74,17 @@ int main()
     RUN("copy nt, 4 KiB per wave, swept", true, 4, 1, true);
     RUN("copy plain, 4 KiB per wave", false, 4, 0, true);
     RUN("copy nt, 2 KiB per wave", true, 2, 0, true);
+#define RUNW(NAME, PER, WAVES, COPY) time(NAME, (COPY ? 2.0 : 1.0) * bytes, [&] { hipLaunchKernelGGL((k_move_wg<PER, WAVES, COPY>), dim3(kib / WAVES / PER), dim3(64 * WAVES), 0, 0, (const u32x4*)s2, (u32x4*)d, n16, 0u); })
+    RUNW("fill nt, 4 KiB per wave, 1-wave workgroups", 4, 1, false);
+    RUNW("fill nt, 4 KiB per wave, 2-wave workgroups", 4, 2, false);
+    RUNW("fill nt, 4 KiB per wave, 16-wave workgroups", 4, 16, false);
+    RUNW("fill nt, 1 KiB per wave, 1-wave workgroups", 1, 1, false);
+    RUNW("fill nt, 1 KiB per wave, 16-wave workgroups", 1, 16, false);
+    RUNW("copy nt, 4 KiB per wave, 1-wave workgroups", 4, 1, true);
+    RUNW("copy nt, 4 KiB per wave, 2-wave workgroups", 4, 2, true);
+    RUNW("copy nt, 4 KiB per wave, 16-wave workgroups", 4, 16, true);
+    RUNW("copy nt, 1 KiB per wave, 1-wave workgroups", 1, 1, true);
+    RUNW("copy nt, 1 KiB per wave, 16-wave workgroups", 1, 16, true);
     time("hipMemcpyAsync d2d", 2.0 * bytes, [&] { (void)hipMemcpyAsync(d, s2, bytes, hipMemcpyDeviceToDevice, 0); });
     return 0;
 }
