@@ -89,6 +89,8 @@ class SpeckvKVConnector:
         # for every layer (that alone was ~20 us per attend() call)
         self._epoch = 0
         self._batch_cache = {}
+        self._step_cols = {}
+        self._plan_stream = None
 
     # The library takes a hipStream_t and reads NULL as "the engine's own stream".  torch's default stream IS the NULL
     # stream, so work issued from it goes through a side stream that is ordered after it and that it then waits for.
@@ -130,12 +132,14 @@ class SpeckvKVConnector:
         self.requests[req_id] = _Request(h)
         self._epoch += 1
         self._batch_cache.clear()
+        self._step_cols.clear()
         return h
 
     def free_request(self, req_id: int):
         r = self.requests.pop(req_id)
         self._epoch += 1
         self._batch_cache.clear()
+        self._step_cols.clear()
         if req_id in self._tail_ids:
             self._tail_ids, self._tail_k, self._tail_v = (), None, None
         self._arg_key = self._fold_key = None                 # a plan names record addresses: plan again
@@ -239,6 +243,12 @@ class SpeckvKVConnector:
         for rid in req_ids:
             self.requests[rid].length += 1
         self._epoch += 1
+        # The next step's attention plan, now: the host is ahead of the GPU here (the step's attention launches are still
+        # running), so its handle look-ups and the upload of its descriptors cost the next step nothing.  On the stream the
+        # step's attention ran on: the upload is ordered behind the launches that still read the current plan.
+        st = self._plan_stream
+        if st is not None and self._arg_key is not None and self._arg_key[0][0] == tuple(req_ids) and self.scheme in (3, 4):
+            self.plan_step(req_ids, st)
         return keep                                            # sources of the asynchronous writes: hold until the stream passed them
 
     # ------------------------------------------------------------------ reads
@@ -247,11 +257,17 @@ class SpeckvKVConnector:
         Meaningful for pools whose pages are consumed decompressed (fp16 / int8 schemes); the fused attention of the
         FP8 / INT4 pools reads the records themselves."""
         import numpy as np
-        n = len(req_ids) * self.L
-        reqs = np.repeat(np.asarray(req_ids, dtype=np.uint32), self.L)
-        layers = np.tile(np.arange(self.L, dtype=np.uint16), len(req_ids))
-        pos = np.repeat(np.asarray([max(self.requests[r].length - 1, 0) for r in req_ids], dtype=np.uint32), self.L)
-        depth = np.full(n, depth_k, np.uint32)
+        key, robjs, _ = self._batch(req_ids)
+        cols = self._step_cols.get((key, depth_k))            # request / layer / depth columns: constants of the batch
+        if cols is None:
+            if len(self._step_cols) > 16:
+                self._step_cols.clear()
+            n = len(req_ids) * self.L
+            cols = self._step_cols[(key, depth_k)] = (np.repeat(np.asarray(req_ids, dtype=np.uint32), self.L),
+                                                      np.tile(np.arange(self.L, dtype=np.uint16), len(req_ids)),
+                                                      np.full(n, depth_k, np.uint32))
+        reqs, layers, depth = cols
+        pos = np.repeat(np.fromiter((max(r.length - 1, 0) for r in robjs), dtype=np.uint32, count=len(robjs)), self.L)
         self.lib.prefetch_batch(reqs, layers, pos, depth)
         return self.lib.prefetch_flush(want_count=False)
 
@@ -320,6 +336,7 @@ class SpeckvKVConnector:
         with self._On(self, stream) as st:
             if self._arg_key != (akey, st.cuda_stream):
                 self.plan_step(req_ids, st)
+            self._plan_stream = st
             self.lib.attend_planned(self.scheme, self._plan.data_ptr(), B, layer, q.data_ptr(), G, self._plan_bound, sm_scale,
                                     out.data_ptr(), lse.data_ptr(), st.cuda_stream)
             # the position still waiting for its partner: folded into out / lse by one launch for the batch
