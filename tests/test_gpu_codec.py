@@ -509,6 +509,37 @@ def test_tensor_codec_scan_forms(lib, oracle, form):
         os.environ.pop("SPECKV_TC_MULTIPASS", None)
 
 
+def test_tensor_codec_look_back_over_many_workgroups(lib, oracle):
+    """Both single-pass kernels hand their prefixes from workgroup to workgroup through status words that are looked back over
+    64 at a time: a tensor of 6 Mi elements is 3072 tiles / chunks = 192 workgroups, three look-back windows deep, with flat
+    stretches longer than a workgroup's 16 tiles (chain 1 of the compressor walks past workgroups that have no stretch start)
+    and runs that cross many chunks of the decoder (several 4096-element windows per chunk, output clipped inside one)."""
+    rng = np.random.default_rng(4242)
+    n = 6 * 1024 * 1024 + 77
+    x = rng.standard_normal(n).astype(np.float32)
+    for a, m in ((100000, 70000), (1500000, 400000), (3000001, 33000), (5200000, 2049), (6000000, 255 * 40)):
+        x[a:a + m] = np.float32(rng.standard_normal())
+    x[4000000:4300000] = np.linspace(-2, 2, 300000, dtype=np.float32)       # constant deltas between quantisation steps
+    for mode in MODES:
+        o_scale, o_rle = oracle.compress_f32(x, mode)
+        scale, rle = gpu_compress_tensor(lib, x, mode)
+        assert np.float32(scale).tobytes() == np.float32(o_scale).tobytes(), mode
+        assert rle.size == o_rle.size and rle.tobytes() == o_rle.tobytes(), (mode, rle.size, o_rle.size)
+        want = oracle.decompress_f32(o_rle, o_scale, mode)
+        y = gpu_decompress_tensor(lib, o_rle, o_scale, n + 9, mode, True)
+        assert_same_float_bits(y, want, f"6Mi mode {mode}")
+        y = gpu_decompress_tensor(lib, o_rle, o_scale, 1500000 + 123457, mode, False)       # clipped inside the long flat stretch, fp16 out
+        assert_same_float_bits(y, want[:1500000 + 123457].astype(np.float16), f"6Mi clipped mode {mode}")
+    # a hand-made stream: long counts everywhere (every chunk spans many windows) and a zero count in some chunks
+    pairs = 300000
+    stream = rng.integers(0, 256, 2 * pairs).astype(np.uint8)
+    stream[1::2] = rng.integers(200, 256, pairs).astype(np.uint8)
+    stream[1 + 2 * 5000] = 0; stream[1 + 2 * 123456] = 0
+    want = oracle.decompress_f32(stream, 0.125, 0)
+    y = gpu_decompress_tensor(lib, stream, 0.125, want.size + 5, 0, True)
+    assert_same_float_bits(y, want, "long counts")
+
+
 def test_tensor_codec_matches_oracle_over_sizes_and_structures(lib, oracle):
     """Lengths around the tile size and far beyond it, data whose runs, 255-splits and delta chain cross tile boundaries
     (constant tensors, long piecewise-constant stretches, ramps), fp32 and fp16 sources, both quantiser modes, and the
