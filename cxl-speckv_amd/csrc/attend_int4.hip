@@ -59,13 +59,21 @@ template <typename T> __device__ __forceinline__ T ldg_small(const uint8_t* p)
 }
 __device__ __forceinline__ float max_over_kb(float v)
 {
-    v = fmaxf(v, __shfl_xor(v, 16));
-    return fmaxf(v, __shfl_xor(v, 32));
+    // lane ^ 16 and lane ^ 32 through gfx950's row / half swaps (v_permlane16_swap / v_permlane32_swap: both operands the same
+    // register -> the two rows, then the two halves, side by side), not through the LDS crossbar (ds_bpermute)
+    const uint32_t u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const uint32_t m = __float_as_uint(fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])));
+    const auto b = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 __device__ __forceinline__ float sum_over_kb(float v)
 {
-    v += __shfl_xor(v, 16);
-    return v + __shfl_xor(v, 32);
+    const uint32_t u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const uint32_t m = __float_as_uint(__uint_as_float(a[0]) + __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 __device__ __forceinline__ f16x2 as_h2(uint32_t u) { return __builtin_bit_cast(f16x2, u); }
 

@@ -100,6 +100,33 @@ __device__ __forceinline__ float div_by_scale(float x, float s, float r)
     return __builtin_fmaf(e, r, q0);
 }
 
+// m / 7.0f for a non-negative finite fp16 VALUE m (the INT4_G32 group scale before its rounding to fp16), correctly rounded, in two
+// operations instead of the IEEE divide's ten: fma(m, hi, m*lo) with hi = fl(1/7), lo = fl(1/7 - hi).  m has 11 significant bits and
+// m/7 never comes within 2^-27 (relative) of a rounding boundary of fp32, the pair (hi, lo) carries 1/7 to 2^-50.  Checked
+// exhaustively on the device (k_debug_divcheck, fourth counter) and on the host (tests/test_host_logic.py).
+__device__ __forceinline__ float div7_of_f16_value(float m)
+{
+    const float hi = 0x1.24924ap-3f, lo = -0x1.b6db6ep-28f;
+    return __builtin_fmaf(m, hi, m * lo);
+}
+// The block scales of the INT8 family and of FP8 the same way: m / 127.0f and m / 448.0f (= m / 7 / 64, the last step exact).
+__device__ __forceinline__ float div127_of_f16_value(float m)
+{
+    const float hi = 0x1.020408p-7f, lo = 0x1.020408p-35f;
+    return __builtin_fmaf(m, hi, m * lo);
+}
+__device__ __forceinline__ float div448_of_f16_value(float m) { return div7_of_f16_value(m) * 0.015625f; }
+// 1.0f / s for a positive normal-or-subnormal fp16 VALUE s (a stored INT4_G32 group scale), correctly rounded: the hardware's
+// reciprocal approximation (1 ulp) and one Newton step, instead of the IEEE divide.  Exhaustively checked next to div7 (all 31 743
+// positive finite fp16 values), and for the block scales s = fl(m / 127), fl(m / 448) of every such m as well (rcp_of_scale).
+__device__ __forceinline__ float rcp_of_f16_value(float s)
+{
+    const float r0 = __builtin_amdgcn_rcpf(s);
+    const float e = __builtin_fmaf(-s, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+__device__ __forceinline__ float rcp_of_scale(float s) { return rcp_of_f16_value(s); }
+
 // cache_engine.cpp:190-192 on x86-64: cvttss2si + byte truncation
 template <int MODE>
 __device__ __forceinline__ uint32_t quantize(float x, float scale)

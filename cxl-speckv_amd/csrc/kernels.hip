@@ -828,8 +828,10 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
             // per group of 32 elements (4 lanes x 8): s = fp16(max|x|/7), q = clamp(round(x/s), -7, 7).  The group's max|x| and
             // its "all finite" test come from the fp16 bit patterns (v_pk_max_u16, two elements per instruction), the
             // quantisation runs in packed fp32 (the same multiply / fma / fma / add / truncate per element as the scalar form,
-            // so the same bits).  (It bought 3 %: the fixed-size compress kernels all sit on one floor of ~128 us per 131 072
-            // blocks -- reads of the source at ~4.2 TB/s -- whatever they compute or write; DESIGN.md sect. 4.)
+            // so the same bits).  Round 4, instruction count (the kernel ran 18 % over what the chip moves at its read : write
+            // mix, profiles/r04_store_shape.txt): max|x| / 7 and 1 / s without the IEEE divide (codec_device.hpp: two and three
+            // operations, bit-identical for fp16-valued operands); no clamp when every scale of the chunk is a normal fp16
+            // (then no quotient reaches 7.5); the nibbles summed as signed i << 4k and un-biased once per dword.
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t words[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
@@ -837,20 +839,24 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(u16x2, words[t] & 0x7FFF7FFFu));
                 uint32_t mbits = m2.x > m2.y ? m2.x : m2.y;                 // largest |bits| of the lane's 8 elements
-                mbits = umax(mbits, static_cast<uint32_t>(__shfl_xor(static_cast<int>(mbits), 1)));
-                mbits = umax(mbits, static_cast<uint32_t>(__shfl_xor(static_cast<int>(mbits), 2)));   // ... of the group of 32
+                mbits = umax(mbits, dpp<0xB1>(0u, mbits));                  // quad_perm [1,0,3,2]: lane ^ 1
+                mbits = umax(mbits, dpp<0x4E>(0u, mbits));                  // quad_perm [2,3,0,1]: lane ^ 2 -> the group of 32
                 const bool finite = __ballot(mbits >= 0x7C00u) == 0ull;     // wave-uniform: no inf / NaN in any group of this chunk
                 uint32_t nib = 0;
                 _Float16 s16;
                 if (finite) {
-                    float sdiv = half_bits_to_float(mbits) / 7.0f;
+                    float sdiv = div7_of_f16_value(half_bits_to_float(mbits));
                     asm volatile("" : "+v"(sdiv));                      // keep the fp32 rounding of the divide
                     s16 = static_cast<_Float16>(sdiv);
                     const float sc = static_cast<float>(s16);
                     // |x| <= 7.5*sc in a finite group: the reciprocal divide is exact (test_fast_division_is_exact); a scale that
                     // rounds to zero (subnormal groups) gives rcp = 0 and every quotient 0, as the definition says
-                    const float rcp = sc != 0.0f ? 1.0f / sc : 0.0f;
+                    const float rcp = sc != 0.0f ? rcp_of_f16_value(sc) : 0.0f;
                     const f32x2 ss = {sc, sc}, rr = {rcp, rcp};
+                    // a subnormal scale may be off by more than half a step: only then can a quotient leave [-7.5, 7.5]
+                    const uint32_t sbits = __builtin_bit_cast(uint16_t, s16);
+                    const bool clamp = __ballot(sbits - 1u < 0x3FFu) != 0ull;                   // (wave-uniform)
+                    int iq[8];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         f32x2 x;
@@ -863,9 +869,18 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                         h.x = __builtin_copysignf(0.5f, y.x);
                         h.y = __builtin_copysignf(0.5f, y.y);
                         const f32x2 r = y + h;                          // round half away from zero = truncate(y + copysign(0.5, y))
-                        const int i0 = min(max(static_cast<int>(r.x), -7), 7), i1 = min(max(static_cast<int>(r.y), -7), 7);
-                        nib |= ((static_cast<uint32_t>(i0) & 0xFu) | ((static_cast<uint32_t>(i1) & 0xFu) << 4)) << (8 * t);
+                        iq[2 * t] = static_cast<int>(r.x);
+                        iq[2 * t + 1] = static_cast<int>(r.y);
                     }
+                    if (clamp) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) iq[k] = min(max(iq[k], -7), 7);
+                    }
+                    // nibble k = iq[k] & 0xF:  sum of iq[k] << 4k  =  sum of (iq[k] + 8) << 4k  -  0x88888888, and (i + 8) ^ 8 = i & 0xF
+                    uint32_t acc = 0x88888888u;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc += static_cast<uint32_t>(iq[k]) << (4 * k);
+                    nib = acc ^ 0x88888888u;
                 } else {
                     float xv[8];
                     float mx = 0.0f, nanacc = 0.0f;
@@ -919,14 +934,14 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                     absmax_finite(x[j][k], mx, nanacc);
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float other = __shfl_xor(mx, o);
-                mx = (other > mx) ? other : mx;
-            }
-            scale = (mx > 0.0f) ? (mx / 448.0f) : 1.0f;
+            // (mx is never a NaN and never negative: its bit pattern orders like its value -- the DPP max scan of the encoders
+            // instead of six trips through the LDS crossbar)
+            mx = __uint_as_float(lane63(wave_incl_max(__float_as_uint(mx))));
             const bool finite = __ballot(!(nanacc == 0.0f)) == 0ull;       // wave-uniform
-            const float rcp = 1.0f / scale;
+            // a finite block's max|x| is an fp16 value: its scale and the reciprocal without the IEEE divide, bit-identical
+            // (codec_device.hpp; exhaustive: test_fast_division_is_exact)
+            scale = (mx > 0.0f) ? (finite ? div448_of_f16_value(mx) : mx / 448.0f) : 1.0f;
+            const float rcp = finite ? rcp_of_scale(scale) : 1.0f / scale;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v[8];
@@ -949,8 +964,8 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
             const uint32_t mbits = absmax_bits(raw);                       // wave-uniform
             const bool finite = mbits < 0x7C00u;
             const float mx = finite ? half_bits_to_float(mbits) : absmax_with_nonfinite(src, lane);
-            scale = (mx > 0.0f) ? (mx / 127.0f) : 1.0f;                    // cache_engine.cpp:172-183
-            const float rcp = 1.0f / scale;
+            scale = (mx > 0.0f) ? (finite ? div127_of_f16_value(mx) : mx / 127.0f) : 1.0f;     // cache_engine.cpp:172-183 (finite: an fp16 value
+            const float rcp = finite ? rcp_of_scale(scale) : 1.0f / scale;                      //  over 127 without the IEEE divide, same bits)
 
             if (SCHEME == kInt8) {
 #pragma unroll

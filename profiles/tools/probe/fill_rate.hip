@@ -45,6 +45,25 @@ __global__ __launch_bounds__(64 * WAVES) void k_move_wg(const u32x4* __restrict_
         if (i < n16) __builtin_nontemporal_store(x[j], dst + i);
     }
 }
+// read 4 KiB per wave, write 4 / DIV KiB of it (the compress kernels' mixes: INT4 4096 -> 1152, INT8 / FP8 4096 -> 2052): what
+// does the chip deliver in TOTAL when most of the traffic is reads?
+template <int DIV>
+__global__ __launch_bounds__(256) void k_shrink(const u32x4* __restrict__ src, u32x4* __restrict__ dst, uint64_t n16)
+{
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint64_t wave = static_cast<uint64_t>(blockIdx.x) * 4u + w;
+    u32x4 x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = __builtin_nontemporal_load(src + (wave * 4u + j) * 64u + lane);
+    if (DIV == 0) {                                   // read only: keep the loads alive
+        const u32x4 t = x[0] ^ x[1] ^ x[2] ^ x[3];
+        if ((t.x ^ t.y ^ t.z ^ t.w) == 0x12345678u) dst[0] = t;
+        return;
+    }
+    // 4 / DIV KiB out: lanes [0, 64 * 4 / DIV) of the wave's four pieces, folded
+    if (DIV == 4) { const u32x4 t = x[0] ^ x[1] ^ x[2] ^ x[3]; __builtin_nontemporal_store(t, dst + wave * 64u + lane); }
+    if (DIV == 2) { __builtin_nontemporal_store(x[0] ^ x[1], dst + (wave * 2u) * 64u + lane); __builtin_nontemporal_store(x[2] ^ x[3], dst + (wave * 2u + 1u) * 64u + lane); }
+}
 int main()
 {
     const uint64_t bytes = 1ull << 30, n16 = bytes / 16;
@@ -85,6 +104,9 @@ int main()
     RUNW("copy nt, 4 KiB per wave, 16-wave workgroups", 4, 16, true);
     RUNW("copy nt, 1 KiB per wave, 1-wave workgroups", 1, 1, true);
     RUNW("copy nt, 1 KiB per wave, 16-wave workgroups", 1, 16, true);
+    time("read 4 KiB per wave, write nothing", 1.0 * bytes, [&] { hipLaunchKernelGGL(k_shrink<0>, dim3(kib / 16), dim3(256), 0, 0, (const u32x4*)s2, (u32x4*)d, n16); });
+    time("read 4 KiB per wave, write 1 KiB (INT4 mix)", 1.25 * bytes, [&] { hipLaunchKernelGGL(k_shrink<4>, dim3(kib / 16), dim3(256), 0, 0, (const u32x4*)s2, (u32x4*)d, n16); });
+    time("read 4 KiB per wave, write 2 KiB (INT8 mix)", 1.5 * bytes, [&] { hipLaunchKernelGGL(k_shrink<2>, dim3(kib / 16), dim3(256), 0, 0, (const u32x4*)s2, (u32x4*)d, n16); });
     time("hipMemcpyAsync d2d", 2.0 * bytes, [&] { (void)hipMemcpyAsync(d, s2, bytes, hipMemcpyDeviceToDevice, 0); });
     return 0;
 }

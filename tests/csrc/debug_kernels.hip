@@ -23,6 +23,18 @@ __global__ void k_debug_divcheck(float den, unsigned long long* counters)
     const float mul = den == 127.0f ? 127.0f : 1.0f;
     const float r = 1.0f / s;
     unsigned long long bad = 0, badq = 0, badr = 0;
+    {                                                            // the encoders' short cuts, bit for bit against the IEEE divide
+        unsigned long long badf = 0;
+        if (den == 0.0f) {
+            badf += (__float_as_uint(rcp_of_f16_value(m)) != __float_as_uint(1.0f / m)) ? 1ull : 0ull;
+            badf += (__float_as_uint(div7_of_f16_value(m)) != __float_as_uint(m / 7.0f)) ? 1ull : 0ull;
+        } else {
+            const float fast = den == 127.0f ? div127_of_f16_value(m) : div448_of_f16_value(m);
+            badf += (__float_as_uint(fast) != __float_as_uint(s)) ? 1ull : 0ull;
+            badf += (__float_as_uint(rcp_of_scale(s)) != __float_as_uint(r)) ? 1ull : 0ull;
+        }
+        if (badf) atomicAdd(&counters[3], badf);
+    }
     for (uint32_t xb = 0; xb < 65536u; ++xb) {
         if ((xb & 0x7C00u) == 0x7C00u) continue;                 // inf / nan dividends take the slow path
         const float x = half_bits_to_float(xb);

@@ -272,6 +272,38 @@ def test_div127_identity():
     assert np.array_equal(r1, (q / f32(127.0)).astype(f32))
 
 
+def test_int4_encoder_short_cuts():
+    """The INT4_G32 encoder (kernels.hip, k_compress<3>) forms a group scale as fp16(max|x| / 7) and quantises by it.  Three
+    facts it relies on, exhaustively over all positive finite fp16 values on the host (the device repeats the first and the
+    reciprocal in test_fast_division_is_exact):  m/7 as fma(m, hi, m*lo) is the correctly rounded quotient;  with a NORMAL
+    stored scale no quotient reaches 7.5, so the clamp to [-7, 7] is only needed under subnormal scales;  the nibbles of a
+    dword can be summed as signed i << 4k, biased by 0x88888888 and flipped back."""
+    import numpy as np
+    f32 = np.float32
+    m = np.arange(1, 0x7C00, dtype=np.uint16).view(np.float16).astype(f32)
+    hi, lo = f32(float.fromhex("0x1.24924ap-3")), f32(float.fromhex("-0x1.b6db6ep-28"))
+    assert hi == f32(1.0 / 7.0) and lo == f32(1.0 / 7.0 - float(hi))
+    t = (m * lo).astype(f32)
+    got = (m.astype(np.float64) * float(hi) + t.astype(np.float64)).astype(f32)               # the fma: one rounding
+    assert np.array_equal(got.view(np.uint32), (m / f32(7.0)).astype(f32).view(np.uint32))
+    s16 = (m / f32(7.0)).astype(np.float16)
+    normal = (s16.view(np.uint16) & 0x7C00) != 0
+    y = m[normal] / s16[normal].astype(f32)
+    assert float(np.trunc(y + f32(0.5)).max()) == 7.0 and float(y.max()) < 7.01
+    sub = ~normal & (s16.view(np.uint16) != 0)
+    assert float((m[sub] / s16[sub].astype(f32)).max()) > 7.5                                  # ... and there it is needed
+    rng = np.random.default_rng(1)
+    i = rng.integers(-7, 8, (100000, 8)).astype(np.int64)
+    n = np.zeros(100000, np.int64)
+    for k in range(8):
+        n = (n + (i[:, k] << (4 * k))) & 0xFFFFFFFF
+    packed = ((n + 0x88888888) & 0xFFFFFFFF) ^ 0x88888888
+    want = np.zeros(100000, np.int64)
+    for k in range(8):
+        want |= (i[:, k] & 0xF) << (4 * k)
+    assert np.array_equal(packed, want)
+
+
 def test_address_encodings(libpath, oracle, reference=None):
     """the reference's address encodings as pure functions,
     against the oracle (itself pinned to the reference's TLB in test_oracle_vs_ref)."""
