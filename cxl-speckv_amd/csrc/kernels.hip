@@ -1837,35 +1837,60 @@ __device__ __forceinline__ float tk_value(uint64_t key)
     return __uint_as_float(bits);
 }
 // All-lanes reductions over the wave for the top-k rounds, written for latency (a round is a chain of six exchanges): the
-// four steps inside a row of 16 lanes are DPP moves (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: a few clocks each),
-// rows 16 apart exchange through ds_swizzle, the two halves of the wave through ds_bpermute -- two trips through the LDS crossbar
-// instead of six.
+// four steps inside a row of 16 lanes are DPP moves (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: a few clocks each);
+// rows 16 apart and the two halves of the wave meet through gfx950's v_permlane16_swap / v_permlane32_swap -- with both operands
+// the same register they return the two rows (halves) side by side in every lane, still in the vector ALU.  (ds_swizzle and
+// ds_bpermute, two trips through the LDS crossbar per reduction, were most of a one-request prediction: 15.7 us with them.)
 template <int CTRL> __device__ __forceinline__ uint32_t tk_dpp(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xf, 0xf, false)); }
 template <int STEP> __device__ __forceinline__ uint32_t tk_exchange(uint32_t v)
 {
+    static_assert(STEP < 4, "rows and halves: tk_rows / tk_halves");
     if constexpr (STEP == 0) return tk_dpp<0xB1>(v);                 // quad_perm [1,0,3,2]
     else if constexpr (STEP == 1) return tk_dpp<0x4E>(v);            // quad_perm [2,3,0,1]
     else if constexpr (STEP == 2) return tk_dpp<0x141>(v);           // row_half_mirror: the other quad of each 8
-    else if constexpr (STEP == 3) return tk_dpp<0x140>(v);           // row_mirror: the other 8 of each 16
-    else if constexpr (STEP == 4) return static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(v), 0x401F));    // lane ^ 16
-    else return static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), 32));
+    else return tk_dpp<0x140>(v);                                    // row_mirror: the other 8 of each 16
 }
-template <int STEP = 0> __device__ __forceinline__ uint64_t wave_max_u64(uint64_t k)
+struct TkPair { uint32_t a, b; };                                    // a lane's own value and its partner's (in no particular order)
+__device__ __forceinline__ TkPair tk_rows(uint32_t v) { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return TkPair{r[0], r[1]}; }      // lane ^ 16
+__device__ __forceinline__ TkPair tk_halves(uint32_t v) { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return TkPair{r[0], r[1]}; }    // lane ^ 32
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t k)
 {
-    if constexpr (STEP < 6) {
-        const uint64_t other = (static_cast<uint64_t>(tk_exchange<STEP>(static_cast<uint32_t>(k >> 32))) << 32) | tk_exchange<STEP>(static_cast<uint32_t>(k));
-        return wave_max_u64<STEP + 1>(other > k ? other : k);
-    } else return k;
+#define SPECKV_TK_STEP(S) { const uint64_t other = (static_cast<uint64_t>(tk_exchange<S>(static_cast<uint32_t>(k >> 32))) << 32) | tk_exchange<S>(static_cast<uint32_t>(k)); k = other > k ? other : k; }
+    SPECKV_TK_STEP(0) SPECKV_TK_STEP(1) SPECKV_TK_STEP(2) SPECKV_TK_STEP(3)
+#undef SPECKV_TK_STEP
+    {
+        const TkPair hi = tk_rows(static_cast<uint32_t>(k >> 32)), lo = tk_rows(static_cast<uint32_t>(k));
+        const uint64_t x = (static_cast<uint64_t>(hi.a) << 32) | lo.a, y = (static_cast<uint64_t>(hi.b) << 32) | lo.b;
+        k = x > y ? x : y;
+    }
+    {
+        const TkPair hi = tk_halves(static_cast<uint32_t>(k >> 32)), lo = tk_halves(static_cast<uint32_t>(k));
+        const uint64_t x = (static_cast<uint64_t>(hi.a) << 32) | lo.a, y = (static_cast<uint64_t>(hi.b) << 32) | lo.b;
+        k = x > y ? x : y;
+    }
+    return k;
 }
-template <int STEP = 0> __device__ __forceinline__ float wave_max_f32(float v)
+__device__ __forceinline__ float wave_max_f32(float v)
 {
-    if constexpr (STEP < 6) return wave_max_f32<STEP + 1>(fmaxf(v, __uint_as_float(tk_exchange<STEP>(__float_as_uint(v)))));
-    else return v;
+    v = fmaxf(v, __uint_as_float(tk_exchange<0>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(tk_exchange<1>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(tk_exchange<2>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(tk_exchange<3>(__float_as_uint(v))));
+    const TkPair r = tk_rows(__float_as_uint(v));
+    v = fmaxf(__uint_as_float(r.a), __uint_as_float(r.b));
+    const TkPair h = tk_halves(__float_as_uint(v));
+    return fmaxf(__uint_as_float(h.a), __uint_as_float(h.b));
 }
-template <int STEP = 0> __device__ __forceinline__ float wave_sum_f32(float v)
+__device__ __forceinline__ float wave_sum_f32(float v)
 {
-    if constexpr (STEP < 6) return wave_sum_f32<STEP + 1>(v + __uint_as_float(tk_exchange<STEP>(__float_as_uint(v))));
-    else return v;
+    v += __uint_as_float(tk_exchange<0>(__float_as_uint(v)));
+    v += __uint_as_float(tk_exchange<1>(__float_as_uint(v)));
+    v += __uint_as_float(tk_exchange<2>(__float_as_uint(v)));
+    v += __uint_as_float(tk_exchange<3>(__float_as_uint(v)));
+    const TkPair r = tk_rows(__float_as_uint(v));
+    v = __uint_as_float(r.a) + __uint_as_float(r.b);
+    const TkPair h = tk_halves(__float_as_uint(v));
+    return __uint_as_float(h.a) + __uint_as_float(h.b);
 }
 // merge of up to 64 (max, sum) pairs and 64 keys held one per lane; k rounds; lane 0 hands every round's winner to `put`
 template <typename Put>
@@ -2003,9 +2028,7 @@ __global__ __launch_bounds__(256) void k_predict_small(const int32_t* __restrict
             g[t] = (tok < vocab) ? emb[static_cast<uint64_t>(tok) * kPredEmb + lane] * 0.1f : 0.0f;
         }
 #pragma unroll
-        for (uint32_t t = 0; t < kPredHist; ++t)
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) g[t] += __shfl_xor(g[t], o);
+        for (uint32_t t = 0; t < kPredHist; ++t) g[t] = wave_sum_f32(g[t]);
         // the recurrence is a chain of 16 x layers dependent tanh: libm's tanhf (~100 instructions each) made it 9 of the
         // kernel's 13.7 us.  tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exponential and reciprocal: absolute error
         // ~1e-7, i.e. 1e-5 relative at the |x| ~ 0.01 these states have (tests: confidences within 5e-4 of the oracle).
@@ -2039,7 +2062,7 @@ __global__ __launch_bounds__(256) void k_predict_small(const int32_t* __restrict
             acc = __builtin_fmaf(h4.z, wq[j].z, acc);
             acc = __builtin_fmaf(h4.w, wq[j].w, acc);
         }
-        acc += __shfl_xor(acc, 32);                                     // the other half of the columns
+        { const TkPair h2 = tk_halves(__float_as_uint(acc)); acc = __uint_as_float(h2.a) + __uint_as_float(h2.b); }   // the other half of the columns
         const float v = live ? (out_bias ? acc + bias : acc) : -INFINITY;
         const float m = wave_max_f32(v);
         const float sum = wave_sum_f32((live && m > -INFINITY) ? expf(v - m) : 0.0f);

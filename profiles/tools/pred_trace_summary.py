@@ -1,0 +1,13 @@
+"""Durations and gaps of the prediction kernels in a rocprofv3 --kernel-trace CSV of profiles/tools/pred_trace.py."""
+import csv, sys
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+ks = [r for r in rows if "k_predict_small" in r["Kernel_Name"]]
+# the 20 timed back-to-back single predictions: the last 40 k_predict_small* dispatches before the batch kernels
+pairs = [(a, b) for a, b in zip(ks, ks[1:]) if "merge" not in a["Kernel_Name"] and "merge" in b["Kernel_Name"]]
+pairs = pairs[-20:]
+d0 = [int(a["End_Timestamp"]) - int(a["Start_Timestamp"]) for a, b in pairs]
+d1 = [int(b["End_Timestamp"]) - int(b["Start_Timestamp"]) for a, b in pairs]
+g = [int(b["Start_Timestamp"]) - int(a["End_Timestamp"]) for a, b in pairs]
+gn = [int(n[0]["Start_Timestamp"]) - int(p[1]["End_Timestamp"]) for p, n in zip(pairs, pairs[1:])]
+avg = lambda v: sum(v) / max(1, len(v)) / 1e3
+print("k_predict_small %.2f us | gap %.2f | k_predict_small_merge %.2f | gap to the next prediction %.2f | period %.2f" % (avg(d0), avg(g), avg(d1), avg(gn), avg(d0) + avg(g) + avg(d1) + avg(gn)))
