@@ -1505,6 +1505,74 @@ __global__ __launch_bounds__(128) void k_qk_scores_fp8(const PageEntry* __restri
 // 128 x vocab output mat-vec, softmax and top-k.  fp tolerance vs the oracle: the
 // device tanhf/expf and the reduction order differ from glibc's (tests state 1e-4).
 constexpr uint32_t kPredHist = 16, kPredEmb = 64, kPredHidden = 128;
+// All-lanes reductions over the wave for the top-k rounds, written for latency (a round is a chain of six exchanges): the
+// four steps inside a row of 16 lanes are DPP moves (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: a few clocks each);
+// rows 16 apart and the two halves of the wave meet through gfx950's v_permlane16_swap / v_permlane32_swap -- with both operands
+// the same register they return the two rows (halves) side by side in every lane, still in the vector ALU.  (ds_swizzle and
+// ds_bpermute, two trips through the LDS crossbar per reduction, were most of a one-request prediction: 15.7 us with them.)
+template <int CTRL> __device__ __forceinline__ uint32_t tk_dpp(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xf, 0xf, false)); }
+template <int STEP> __device__ __forceinline__ uint32_t tk_exchange(uint32_t v)
+{
+    static_assert(STEP < 4, "rows and halves: tk_rows / tk_halves");
+    if constexpr (STEP == 0) return tk_dpp<0xB1>(v);                 // quad_perm [1,0,3,2]
+    else if constexpr (STEP == 1) return tk_dpp<0x4E>(v);            // quad_perm [2,3,0,1]
+    else if constexpr (STEP == 2) return tk_dpp<0x141>(v);           // row_half_mirror: the other quad of each 8
+    else return tk_dpp<0x140>(v);                                    // row_mirror: the other 8 of each 16
+}
+struct TkPair { uint32_t a, b; };                                    // a lane's own value and its partner's (in no particular order)
+__device__ __forceinline__ TkPair tk_rows(uint32_t v) { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return TkPair{r[0], r[1]}; }      // lane ^ 16
+__device__ __forceinline__ TkPair tk_halves(uint32_t v) { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return TkPair{r[0], r[1]}; }    // lane ^ 32
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t k)
+{
+#define SPECKV_TK_STEP(S) { const uint64_t other = (static_cast<uint64_t>(tk_exchange<S>(static_cast<uint32_t>(k >> 32))) << 32) | tk_exchange<S>(static_cast<uint32_t>(k)); k = other > k ? other : k; }
+    SPECKV_TK_STEP(0) SPECKV_TK_STEP(1) SPECKV_TK_STEP(2) SPECKV_TK_STEP(3)
+#undef SPECKV_TK_STEP
+    {
+        const TkPair hi = tk_rows(static_cast<uint32_t>(k >> 32)), lo = tk_rows(static_cast<uint32_t>(k));
+        const uint64_t x = (static_cast<uint64_t>(hi.a) << 32) | lo.a, y = (static_cast<uint64_t>(hi.b) << 32) | lo.b;
+        k = x > y ? x : y;
+    }
+    {
+        const TkPair hi = tk_halves(static_cast<uint32_t>(k >> 32)), lo = tk_halves(static_cast<uint32_t>(k));
+        const uint64_t x = (static_cast<uint64_t>(hi.a) << 32) | lo.a, y = (static_cast<uint64_t>(hi.b) << 32) | lo.b;
+        k = x > y ? x : y;
+    }
+    return k;
+}
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+    v = fmaxf(v, __uint_as_float(tk_exchange<0>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(tk_exchange<1>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(tk_exchange<2>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(tk_exchange<3>(__float_as_uint(v))));
+    const TkPair r = tk_rows(__float_as_uint(v));
+    v = fmaxf(__uint_as_float(r.a), __uint_as_float(r.b));
+    const TkPair h = tk_halves(__float_as_uint(v));
+    return fmaxf(__uint_as_float(h.a), __uint_as_float(h.b));
+}
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+    v += __uint_as_float(tk_exchange<0>(__float_as_uint(v)));
+    v += __uint_as_float(tk_exchange<1>(__float_as_uint(v)));
+    v += __uint_as_float(tk_exchange<2>(__float_as_uint(v)));
+    v += __uint_as_float(tk_exchange<3>(__float_as_uint(v)));
+    const TkPair r = tk_rows(__float_as_uint(v));
+    v = __uint_as_float(r.a) + __uint_as_float(r.b);
+    const TkPair h = tk_halves(__float_as_uint(v));
+    return __uint_as_float(h.a) + __uint_as_float(h.b);
+}
+// tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exponential and reciprocal: absolute error ~1e-7, i.e. 1e-5 relative at the
+// |x| ~ 0.01 the reference's cell states have (tests: confidences within 5e-4 of the oracle).  libm's tanhf is ~100 instructions,
+// and the recurrence is a chain of 16 x layers x 2 of them.
+// exp(x) for the softmax terms (x <= 0): the hardware's exp2 on x log2(e), relative error ~1e-6 at |x| ~ 20 (libm's expf is ~20
+// instructions and every logit of every request takes one; tests state 5e-4 on the confidences against the oracle).
+__device__ __forceinline__ float pred_fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float pred_fast_tanh(float x)
+{
+    x = fminf(fmaxf(x, -15.0f), 15.0f);
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);         // exp(2x)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
 
 // one wave per request: lane 0 walks the history; every lane stores 2 of the 128 hidden values
 __global__ __launch_bounds__(64) void k_lstm_hidden(const int32_t* __restrict__ hist, uint32_t n,
@@ -1520,16 +1588,15 @@ __global__ __launch_bounds__(64) void k_lstm_hidden(const int32_t* __restrict__ 
         const uint32_t tok = static_cast<uint32_t>(hist[r * kPredHist + t]);
         g[t] = (tok < vocab) ? emb[static_cast<uint64_t>(tok) * kPredEmb + lane] * 0.1f : 0.0f;
     }
+    float tg[kPredHist];
 #pragma unroll
-    for (uint32_t t = 0; t < kPredHist; ++t)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) g[t] += __shfl_xor(g[t], o);
+    for (uint32_t t = 0; t < kPredHist; ++t) tg[t] = 0.5f * pred_fast_tanh(wave_sum_f32(g[t]));      // (independent of the chain)
     float h = 0.0f, c = 0.0f;
 #pragma unroll
     for (uint32_t t = 0; t < kPredHist; ++t)
         for (uint32_t l = 0; l < layers; ++l) {
-            c = 0.5f * c + 0.5f * tanhf(g[t]);
-            h = 0.5f * tanhf(c);
+            c = 0.5f * c + tg[t];
+            h = 0.5f * pred_fast_tanh(c);
         }
     h = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(h)));
     hid[static_cast<uint64_t>(r) * kPredHidden + lane] = h;
@@ -1836,68 +1903,12 @@ __device__ __forceinline__ float tk_value(uint64_t key)
     bits ^= (bits >> 31) ? 0x80000000u : 0xFFFFFFFFu;
     return __uint_as_float(bits);
 }
-// All-lanes reductions over the wave for the top-k rounds, written for latency (a round is a chain of six exchanges): the
-// four steps inside a row of 16 lanes are DPP moves (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: a few clocks each);
-// rows 16 apart and the two halves of the wave meet through gfx950's v_permlane16_swap / v_permlane32_swap -- with both operands
-// the same register they return the two rows (halves) side by side in every lane, still in the vector ALU.  (ds_swizzle and
-// ds_bpermute, two trips through the LDS crossbar per reduction, were most of a one-request prediction: 15.7 us with them.)
-template <int CTRL> __device__ __forceinline__ uint32_t tk_dpp(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xf, 0xf, false)); }
-template <int STEP> __device__ __forceinline__ uint32_t tk_exchange(uint32_t v)
-{
-    static_assert(STEP < 4, "rows and halves: tk_rows / tk_halves");
-    if constexpr (STEP == 0) return tk_dpp<0xB1>(v);                 // quad_perm [1,0,3,2]
-    else if constexpr (STEP == 1) return tk_dpp<0x4E>(v);            // quad_perm [2,3,0,1]
-    else if constexpr (STEP == 2) return tk_dpp<0x141>(v);           // row_half_mirror: the other quad of each 8
-    else return tk_dpp<0x140>(v);                                    // row_mirror: the other 8 of each 16
-}
-struct TkPair { uint32_t a, b; };                                    // a lane's own value and its partner's (in no particular order)
-__device__ __forceinline__ TkPair tk_rows(uint32_t v) { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return TkPair{r[0], r[1]}; }      // lane ^ 16
-__device__ __forceinline__ TkPair tk_halves(uint32_t v) { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return TkPair{r[0], r[1]}; }    // lane ^ 32
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t k)
-{
-#define SPECKV_TK_STEP(S) { const uint64_t other = (static_cast<uint64_t>(tk_exchange<S>(static_cast<uint32_t>(k >> 32))) << 32) | tk_exchange<S>(static_cast<uint32_t>(k)); k = other > k ? other : k; }
-    SPECKV_TK_STEP(0) SPECKV_TK_STEP(1) SPECKV_TK_STEP(2) SPECKV_TK_STEP(3)
-#undef SPECKV_TK_STEP
-    {
-        const TkPair hi = tk_rows(static_cast<uint32_t>(k >> 32)), lo = tk_rows(static_cast<uint32_t>(k));
-        const uint64_t x = (static_cast<uint64_t>(hi.a) << 32) | lo.a, y = (static_cast<uint64_t>(hi.b) << 32) | lo.b;
-        k = x > y ? x : y;
-    }
-    {
-        const TkPair hi = tk_halves(static_cast<uint32_t>(k >> 32)), lo = tk_halves(static_cast<uint32_t>(k));
-        const uint64_t x = (static_cast<uint64_t>(hi.a) << 32) | lo.a, y = (static_cast<uint64_t>(hi.b) << 32) | lo.b;
-        k = x > y ? x : y;
-    }
-    return k;
-}
-__device__ __forceinline__ float wave_max_f32(float v)
-{
-    v = fmaxf(v, __uint_as_float(tk_exchange<0>(__float_as_uint(v))));
-    v = fmaxf(v, __uint_as_float(tk_exchange<1>(__float_as_uint(v))));
-    v = fmaxf(v, __uint_as_float(tk_exchange<2>(__float_as_uint(v))));
-    v = fmaxf(v, __uint_as_float(tk_exchange<3>(__float_as_uint(v))));
-    const TkPair r = tk_rows(__float_as_uint(v));
-    v = fmaxf(__uint_as_float(r.a), __uint_as_float(r.b));
-    const TkPair h = tk_halves(__float_as_uint(v));
-    return fmaxf(__uint_as_float(h.a), __uint_as_float(h.b));
-}
-__device__ __forceinline__ float wave_sum_f32(float v)
-{
-    v += __uint_as_float(tk_exchange<0>(__float_as_uint(v)));
-    v += __uint_as_float(tk_exchange<1>(__float_as_uint(v)));
-    v += __uint_as_float(tk_exchange<2>(__float_as_uint(v)));
-    v += __uint_as_float(tk_exchange<3>(__float_as_uint(v)));
-    const TkPair r = tk_rows(__float_as_uint(v));
-    v = __uint_as_float(r.a) + __uint_as_float(r.b);
-    const TkPair h = tk_halves(__float_as_uint(v));
-    return __uint_as_float(h.a) + __uint_as_float(h.b);
-}
 // merge of up to 64 (max, sum) pairs and 64 keys held one per lane; k rounds; lane 0 hands every round's winner to `put`
 template <typename Put>
 __device__ __forceinline__ void tk_merge(float m, float s, uint64_t key, uint32_t k, float& m_all, float& s_all, Put put)
 {
     m_all = wave_max_f32(m);
-    s_all = wave_sum_f32(m > -INFINITY ? s * expf(m - m_all) : 0.0f);
+    s_all = wave_sum_f32(m > -INFINITY ? s * pred_fast_exp(m - m_all) : 0.0f);
     for (uint32_t r = 0; r < k; ++r) {
         const uint64_t w = wave_max_u64(key);
         if (w == key) key = 0;                                          // keys are distinct (token ids are): one owner
@@ -1925,7 +1936,7 @@ __global__ __launch_bounds__(256) void k_softmax_topk_small(const float* __restr
     float sum = 0.0f;
 #pragma unroll
     for (uint32_t j = 0; j < kTkPer; ++j)
-        if (base + j * kTkThreads < vocab && m > -INFINITY) sum += expf(v[j] - m);
+        if (base + j * kTkThreads < vocab && m > -INFINITY) sum += pred_fast_exp(v[j] - m);
     sum = wave_sum_f32(sum);
     for (uint32_t r = 0; r < k; ++r) {
         float bv = -INFINITY; int bj = -1;
@@ -1966,7 +1977,7 @@ __global__ __launch_bounds__(256) void k_softmax_topk_merge(const uint8_t* __res
 #pragma unroll
     for (uint32_t r = 0; r < 8u; ++r) key[r] = (have && r < k) ? part_key[lane * 8u + r] : 0;       // descending: key[0] is the part's best not yet taken
     const float mx = wave_max_f32(qm);
-    const float total = wave_sum_f32(qm > -INFINITY ? qs * expf(qm - mx) : 0.0f);
+    const float total = wave_sum_f32(qm > -INFINITY ? qs * pred_fast_exp(qm - mx) : 0.0f);
     float* conf = out_conf + static_cast<uint64_t>(b) * k;
     int32_t* tok = out_tok + static_cast<uint64_t>(b) * k;
     for (uint32_t r = 0; r < k; ++r) {
@@ -1978,7 +1989,7 @@ __global__ __launch_bounds__(256) void k_softmax_topk_merge(const uint8_t* __res
         }
         if (lane == 0u) {
             tok[r] = w ? static_cast<int32_t>(0xFFFFFFFFu - static_cast<uint32_t>(w)) : -1;
-            conf[r] = w ? expf(tk_value(w) - mx) / total : 0.0f;
+            conf[r] = w ? pred_fast_exp(tk_value(w) - mx) / total : 0.0f;
         }
     }
 }
@@ -2029,23 +2040,16 @@ __global__ __launch_bounds__(256) void k_predict_small(const int32_t* __restrict
         }
 #pragma unroll
         for (uint32_t t = 0; t < kPredHist; ++t) g[t] = wave_sum_f32(g[t]);
-        // the recurrence is a chain of 16 x layers dependent tanh: libm's tanhf (~100 instructions each) made it 9 of the
-        // kernel's 13.7 us.  tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exponential and reciprocal: absolute error
-        // ~1e-7, i.e. 1e-5 relative at the |x| ~ 0.01 these states have (tests: confidences within 5e-4 of the oracle).
-        auto fast_tanh = [](float x) {
-            x = fminf(fmaxf(x, -15.0f), 15.0f);
-            const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);         // exp(2x)
-            return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-        };
+        // (the recurrence: pred_fast_tanh, as k_lstm_hidden)
         float tg[kPredHist];
 #pragma unroll
-        for (uint32_t t = 0; t < kPredHist; ++t) tg[t] = 0.5f * fast_tanh(g[t]);      // (independent of the chain)
+        for (uint32_t t = 0; t < kPredHist; ++t) tg[t] = 0.5f * pred_fast_tanh(g[t]);      // (independent of the chain)
         float h = 0.0f, cc = 0.0f;
 #pragma unroll
         for (uint32_t t = 0; t < kPredHist; ++t)
             for (uint32_t l = 0; l < layers; ++l) {
                 cc = 0.5f * cc + tg[t];
-                h = 0.5f * fast_tanh(cc);
+                h = 0.5f * pred_fast_tanh(cc);
             }
         h = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(h)));
         hs[wave][lane] = h;
@@ -2065,7 +2069,7 @@ __global__ __launch_bounds__(256) void k_predict_small(const int32_t* __restrict
         { const TkPair h2 = tk_halves(__float_as_uint(acc)); acc = __uint_as_float(h2.a) + __uint_as_float(h2.b); }   // the other half of the columns
         const float v = live ? (out_bias ? acc + bias : acc) : -INFINITY;
         const float m = wave_max_f32(v);
-        const float sum = wave_sum_f32((live && m > -INFINITY) ? expf(v - m) : 0.0f);
+        const float sum = wave_sum_f32((live && m > -INFINITY) ? pred_fast_exp(v - m) : 0.0f);
         uint64_t key = live ? tk_key(v, row) : 0;
         for (uint32_t r = 0; r < k; ++r) {
             const uint64_t w = wave_max_u64(key);
@@ -2101,7 +2105,7 @@ __global__ __launch_bounds__(256) void k_predict_small_merge(const uint8_t* __re
 #pragma unroll
     for (uint32_t r = 0; r < 8u; ++r) key[r] = (have && r < k) ? part_key[part * 8u + r] : 0;       // descending: key[0] is the part's best not yet taken
     const float mx = wave_max_f32(qm);
-    const float total = wave_sum_f32(qm > -INFINITY ? qs * expf(qm - mx) : 0.0f);
+    const float total = wave_sum_f32(qm > -INFINITY ? qs * pred_fast_exp(qm - mx) : 0.0f);
     for (uint32_t r = 0; r < k; ++r) {
         const uint64_t w = wave_max_u64(key[0]);
         if (w != 0 && w == key[0]) {                                     // keys are distinct (token ids are): one owner, whose next key moves up
@@ -2121,7 +2125,7 @@ __global__ __launch_bounds__(256) void k_predict_small_merge(const uint8_t* __re
              [&](uint32_t r, uint64_t w) {
                  if (lane == 0u) {
                      tok[r] = w ? static_cast<int32_t>(0xFFFFFFFFu - static_cast<uint32_t>(w)) : -1;
-                     conf[r] = w ? expf(tk_value(w) - M) / S : 0.0f;
+                     conf[r] = w ? pred_fast_exp(tk_value(w) - M) / S : 0.0f;
                  }
              });
 }
