@@ -1631,15 +1631,17 @@ __device__ __forceinline__ constexpr uint32_t lstm_pad(uint32_t j) { return j + 
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)); }
-__device__ __forceinline__ float lane_xor4(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101F)); }   // bit mode: and 0x1f, or 0, xor 4
+__device__ __forceinline__ float lane_xor7(float v) { return dpp_mov<0x141>(v); }    // row_half_mirror: lane 7 - s of each 8 (a DPP move; lane ^ 4 would be a ds_swizzle)
 __device__ __forceinline__ float lane_xor2(float v) { return dpp_mov<0x4E>(v); }     // quad_perm [2,3,0,1]
 __device__ __forceinline__ float lane_xor1(float v) { return dpp_mov<0xB1>(v); }     // quad_perm [1,0,3,2]
-// v[i] of slice-thread s holds a partial sum of gate row 8 * group + (i ^ s): after three exchanges with the threads s ^ 4,
-// s ^ 2, s ^ 1 the return value is the whole sum of row 8 * group + s, i.e. of row threadIdx.x
+// v[i] of slice-thread s holds a partial sum of gate row 8 * group + (i ^ s): after three exchanges with the threads s ^ 7,
+// s ^ 2, s ^ 1 the return value is the whole sum of row 8 * group + s, i.e. of row threadIdx.x.  (First exchange: thread s keeps
+// the rows (i ^ s), i < 4; its partner 7 - s = s ^ 7 holds its share of row i ^ s in v[(i ^ s) ^ (s ^ 7)] = v[7 - i].  All three are
+// DPP moves: the step of the recurrence has no trip through the LDS crossbar left.)
 __device__ __forceinline__ float lstm_reduce8(float (&v)[8])
 {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] += lane_xor4(v[i + 4]);
+    for (int i = 0; i < 4; ++i) v[i] += lane_xor7(v[7 - i]);
 #pragma unroll
     for (int i = 0; i < 2; ++i) v[i] += lane_xor2(v[i + 2]);
     return v[0] + lane_xor1(v[1]);
@@ -1675,7 +1677,7 @@ __device__ __forceinline__ void lstm_project(const float* __restrict__ wsrc, flo
 #pragma unroll 2
     for (uint32_t t = 0; t < kPredHist; ++t) xp[t][tid] = lstm_slice_dot<CS>(w, &seq[t][lstm_pad(CS * s)]) + b;
 }
-__device__ __forceinline__ float sigmoid_rcp(float x) { return __builtin_amdgcn_rcpf(1.0f + expf(-x)); }     // expf of libm, the hardware's reciprocal (1 ulp)
+__device__ __forceinline__ float sigmoid_rcp(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }     // the hardware's exp2 and reciprocal (1 ulp each; two of them on every step of the chain)
 __global__ __launch_bounds__(512) void k_lstm_cell(const int32_t* __restrict__ hist, uint32_t n, const float* __restrict__ emb, uint32_t vocab,
                                                   LstmWeights w, float* __restrict__ hid)
 {
