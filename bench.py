@@ -1134,7 +1134,7 @@ def connector_decode_extra(torch, kv, n_seq=256, Lyr=8, ctx=2048, T=4096):
                                           "tokens_per_s_kv_side": round(n_seq / (ms * 1e-3), 1),
                                           "KV_record_GBps": round(rec_bytes / (ms * 1e-3) / 1e9, 1),
                                           "frac_hbm": round(rec_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                          "note": "begin_step (flush) + one batch attention call per layer + batched append, wall time "
+                                          "note": "begin_step (flush) + one batch attention call per layer + batched append (which plans the next step), wall time "
                                                   "per step incl. the torch glue (tail fold, gathers); FP8 pool"}}
     except Exception as e:
         return {"connector_decode_step": {"error": repr(e)}}
@@ -1318,7 +1318,8 @@ def tensor_codec_extra(torch, lib, n=131072 * 256):
             out[name] = {"ms": round(ms, 4), "algorithmic_GBps": round(byt / (ms * 1e-3) / 1e9, 1), "frac_hbm": round(byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
         out["note"] = ("any n, exact.  Compress: an abs-max pass, then ONE pass that encodes whole fp16 tiles by the block encoder's "
                        "8-elements-per-lane path and places them in the stream by look-back across workgroups (two reads of the source, one "
-                       "write of the stream); decompress: summary, scans, expand.  The pool itself stores KV per 4 KiB block (the headline path)")
+                       "write of the stream); decompress: ONE pass (a chunk of 2048 pairs per wave, one byte scattered per run, look-back across "
+                       "workgroups hidden behind the values).  The pool itself stores KV per 4 KiB block (the headline path)")
         return {"tensor_codec_whole_tensor" if n == 131072 * 256 else f"tensor_codec_whole_tensor_{n * 2 // 2**20}MiB": out}
     except Exception as e:
         return {"tensor_codec_whole_tensor": {"error": repr(e)}}
