@@ -1325,6 +1325,11 @@ __global__ __launch_bounds__(64 * kTfWaves) void k_tc_fused(const void* __restri
 #define SPECKV_TDF_WAVES 16
 #endif
 constexpr uint32_t kTdfWaves = SPECKV_TDF_WAVES;
+#ifndef SPECKV_TDF_LB_WAVE
+#define SPECKV_TDF_LB_WAVE 0
+#endif
+constexpr uint32_t kTdfLbWave = SPECKV_TDF_LB_WAVE;   // 1: wave 0 of a workgroup takes no chunk, it only looks back (kTdfWaves - 1 chunks per workgroup)
+constexpr uint32_t kTdfChunks = kTdfWaves - kTdfLbWave;
 constexpr uint32_t kTdfWin = 4096;           // elements per window
 #define SPECKV_TD_SDWA2(NAME, OP, S0, S1)                                                       \
     __device__ __forceinline__ uint32_t NAME(uint32_t a, uint32_t b)                            \
@@ -1634,8 +1639,8 @@ void k_td_fused(const uint8_t* __restrict__ rle, uint64_t n_pairs, uint64_t n_ch
     if (threadIdx.x == 0u) s_ticket = atomicAdd(ticket, 1u);
     __syncthreads();
     const uint64_t wg = s_ticket;
-    const uint64_t chunk = wg * kTdfWaves + wave;
-    const bool live = chunk < n_chunks;                                 // (waves behind the last chunk only keep the barriers company)
+    const uint64_t chunk = wg * kTdfChunks + wave - kTdfLbWave;
+    const bool live = wave >= kTdfLbWave && chunk < n_chunks;           // (waves behind the last chunk only keep the barriers company)
     const uint64_t p0 = chunk * kTile;
     uint32_t w[4][4], ex[4], st[4], mn = 255u;
     td_load_pairs(rle, p0, n_pairs, live, lane, w, mn);
@@ -1664,7 +1669,7 @@ void k_td_fused(const uint8_t* __restrict__ rle, uint64_t n_pairs, uint64_t n_ch
         uint32_t qb = 0;
         if (wg != 0u) {
 #ifdef SPECKV_TD_NO_LB
-            before = wg * kTdfWaves * 2048ull;                          // (timing builds only: wrong output)
+            before = wg * kTdfChunks * 2048ull;                         // (timing builds only: wrong output)
 #else
             td_look_back(status, wg, lane, before, qb);
 #endif
@@ -1675,7 +1680,7 @@ void k_td_fused(const uint8_t* __restrict__ rle, uint64_t n_pairs, uint64_t n_ch
             s_start[lane] = before + (wic - (wt & 0xFFFFFFu));
             s_qp[lane] = (qb + wiv - (wt >> 24)) & 0xFFu;
         }
-        if (lane == 0u && (wg + 1u) * kTdfWaves >= n_chunks) { const uint64_t total = before + agg_c; *out_n = total < cap ? total : cap; }
+        if (lane == 0u && (wg + 1u) * kTdfChunks >= n_chunks) { const uint64_t total = before + agg_c; *out_n = total < cap ? total : cap; }
     }
     __syncthreads();
     if (!live) return;
@@ -1794,7 +1799,7 @@ hipError_t launch_tensor_decompress(const uint8_t* d_rle, uint64_t rle_bytes, fl
     uint64_t* n_out = d_n_out ? d_n_out : reinterpret_cast<uint64_t*>(w);
     if (chunks && dst_cap && !getenv("SPECKV_TC_MULTIPASS")) {
         // single pass: a memset node (ticket, element count, one status word per workgroup), then ONE kernel
-        const uint64_t wgs = (chunks + kTdfWaves - 1) / kTdfWaves;
+        const uint64_t wgs = (chunks + kTdfChunks - 1) / kTdfChunks;
         uint32_t* ticket = reinterpret_cast<uint32_t*>(d_ws);
         uint64_t* n_out1 = d_n_out ? d_n_out : reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(d_ws) + 128);
         uint64_t* status = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(d_ws) + 256);
