@@ -728,8 +728,6 @@ __global__ __launch_bounds__(512 * HALVES) __attribute__((amdgpu_waves_per_eu(SP
         // for them at their first use, inside the loop, and drain the pipeline there in every iteration
         asm volatile("" :: "v"(qv[0]), "v"(qv[1]), "v"(qv[2]), "v"(qv[3]));
     };
-    load_q(cl);
-
     if (iters != 0u) {                                                   // workgroup-uniform
         const uint32_t tile_bytes = 16u * kInt4RecBytes;
         const uint32_t addr_layer = a.seqs ? 0u : cl;
@@ -773,8 +771,33 @@ __global__ __launch_bounds__(512 * HALVES) __attribute__((amdgpu_waves_per_eu(SP
             rdv[j] = lbase + kW8V + (4u * kb + j) * 512u + (((head * 4u + (c >> 2)) ^ (4u * kb + j)) * 16u) + (c & 3u) * 4u;
         const uint32_t rsv = lbase + kW8Vs + 2u * kb * 128u + ((h1 ^ kb) * 16u) + (head & 1u) * 8u + 2u * (c >> 2);
         const bool ragged = (a.n_pages & 15u) != 0u;
-        if (count != 0u) issue(0u);
-        if (count > 1u) issue(kW8Stage);
+        // The first tile's requests go out BEFORE the query rows are asked for, the second tile's right behind them: descriptor ->
+        // {tile 0, query, tile 1} -> first scores is two round trips where descriptor -> query -> tiles -> scores was three (a
+        // launch of 256 x 1k spends 70 us, its fixed part 8).  The query loads are inline assembly like the DMAs, so that the
+        // compiler neither counts them nor waits for them by itself; ONE wait statement follows, with the query registers as its
+        // operands (nothing that reads them can be placed in front of it): at most the five requests of the second tile stay in
+        // flight behind it.  A run of a single tile requests that tile twice (the second copy is never read) so that the same
+        // count holds; a half without tiles asks for nothing.
+        if (count != 0u) {
+            const uint8_t* const k0p = kptr;
+            const uint8_t* const v0p = vptr;
+            const uint32_t t0i = itile;
+            issue(0u);
+            u32x4 tq0, tq1, tq2, tq3;
+            const uint32_t cq = c < a.g ? c : a.g - 1u;                   // (lanes behind the last query row: any row, zeroed below)
+            const uint16_t* q16 = reinterpret_cast<const uint16_t*>(a.q8) + ((static_cast<uint64_t>(cl) * 8u + head) * a.g + cq) * 128u + kb * 32u;
+            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
+                         : "=&v"(tq0), "=&v"(tq1), "=&v"(tq2), "=&v"(tq3) : "v"(q16) : "memory");
+            if (count == 1u) { kptr = k0p; vptr = v0p; itile = t0i; }
+            issue(kW8Stage);
+            asm volatile("s_waitcnt vmcnt(5)" : "+v"(tq0), "+v"(tq1), "+v"(tq2), "+v"(tq3) :: "memory");
+            const bool qlive = c < a.g;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            tq0 = qlive ? tq0 : z; tq1 = qlive ? tq1 : z; tq2 = qlive ? tq2 : z; tq3 = qlive ? tq3 : z;
+            qv[0] = q_operand(make_uint4(tq0.x, tq0.y, tq0.z, tq0.w)); qv[1] = q_operand(make_uint4(tq1.x, tq1.y, tq1.z, tq1.w));
+            qv[2] = q_operand(make_uint4(tq2.x, tq2.y, tq2.z, tq2.w)); qv[3] = q_operand(make_uint4(tq3.x, tq3.y, tq3.z, tq3.w));
+        }
 #pragma unroll 1
         for (uint32_t i = 0; i < iters; ++i) {
             const uint32_t bo = (i & 1u) * kW8Stage;
