@@ -25,6 +25,7 @@
 //           (4 consecutive d of one position) and splits them with v_perm_b32.
 //           -> lane (c, kb) holds out[query row c][64blk + 16kb + 4i + t].
 #include "kernels.hpp"
+#include "codec_device.hpp"          // the exact reciprocal divide of the codecs (div_by_scale and friends)
 #include <cstdlib>
 
 namespace speckv {
@@ -244,6 +245,41 @@ __device__ __forceinline__ void quantize_query_operand(const uint16_t* qsrc, boo
     }
     row_scale = live ? sc : 1.0f;
 }
+// The same from the four 16-byte pieces of the row already in registers (the fast kernels ask for them behind their first tile's
+// requests), with the 32 quotients through the row's reciprocal: div_by_scale is bit-identical to the IEEE divide for an fp16
+// dividend and a scale m / 448 (exhaustive device check: test_fast_division_is_exact); rows with inf / NaN keep the divide.
+__device__ __forceinline__ void quantize_query_rows(const u32x4 (&w4)[4], bool live, uint32_t (&qd)[8], float& row_scale)
+{
+    float xq[32];
+    float mx = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t ws[4] = {w4[i].x, w4[i].y, w4[i].z, w4[i].w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            xq[8 * i + k] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(ws[k >> 1] >> (16 * (k & 1)))));
+            mx = fmaxf(mx, fabsf(xq[8 * i + k]));
+        }
+    }
+    mx = max_over_kb(mx);
+    const bool finite = mx < INFINITY;
+    const float sc = (mx > 0.0f) ? (finite ? div448_of_f16_value(mx) : mx / 448.0f) : 1.0f;
+    const float rcp = finite ? rcp_of_scale(sc) : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float x = xq[4 * i + k];
+            const float qt = finite ? __builtin_copysignf(div_by_scale(x, sc, rcp), x) : x / sc;
+            v[k] = live ? fminf(fmaxf(qt, -448.0f), 448.0f) : 0.0f;
+        }
+        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+        qd[i] = static_cast<uint32_t>(pk);
+    }
+    row_scale = live ? sc : 1.0f;
+}
 
 } // namespace
 
@@ -415,10 +451,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
     }
 
     // query operand: row c of this head, d = 32kb + 8*step + e, quantised here exactly as k_quantize_q_e4m3 does
-    // (scale = max|q|/448 over the row, 1 if zero; e4m3 of clamp(q/scale)); rows >= g are zero
+    // (scale = max|q|/448 over the row, 1 if zero; e4m3 of clamp(q/scale)); rows >= g are zero.  Called BEHIND the first tile's
+    // requests: descriptor -> {tile, query} -> scores instead of descriptor -> query -> tile -> scores, and the 32 quotients through
+    // the row's reciprocal (div_by_scale: bit-identical for these operands, exhaustive check in test_fast_division_is_exact)
+    // instead of 32 IEEE divides -- a launch of 256 x 1k lasts 100 us and this stood in front of every workgroup's first load.
     uint32_t qd[8];
-    float qscale;
-    {
+    float qscale = 1.0f;
+    auto quantise_query = [&]() {
         float xq[32];
         float mx = 0.0f;
         const uint16_t* qsrc = a.q16 + (row * a.g + min(c, a.g - 1u)) * 128u + kb * 16u;     // d split: see quantize_query_operand
@@ -433,19 +472,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
             }
         }
         mx = max_over_kb(mx);
-        const float sc = (mx > 0.0f) ? (mx / 448.0f) : 1.0f;
+        const bool finite = mx < INFINITY;                                // (inf / NaN rows: the IEEE divide, as before)
+        const float sc = (mx > 0.0f) ? (finite ? div448_of_f16_value(mx) : mx / 448.0f) : 1.0f;
+        const float rcp = finite ? rcp_of_scale(sc) : 0.0f;
         const bool live = c < a.g;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = live ? fminf(fmaxf(xq[4 * i + k] / sc, -448.0f), 448.0f) : 0.0f;
+            for (int k = 0; k < 4; ++k) {
+                const float x = xq[4 * i + k];
+                const float qt = finite ? __builtin_copysignf(div_by_scale(x, sc, rcp), x) : x / sc;
+                v[k] = live ? fminf(fmaxf(qt, -448.0f), 448.0f) : 0.0f;
+            }
             int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
             pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
             qd[i] = static_cast<uint32_t>(pk);
         }
         qscale = (live ? sc : 1.0f) * a.scale_log2e;
-    }
+    };
 
     const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
     const uint32_t t0 = split * a.tiles_per_split;
@@ -528,6 +573,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
         issue_k();
         __builtin_amdgcn_sched_barrier(0);
         issue_v();
+        __builtin_amdgcn_sched_barrier(0);
+        quantise_query();                                                // (its loads are the youngest: they and the tile arrive together)
         __builtin_amdgcn_sched_barrier(0);
         const bool ragged = (a.n_pages & 15u) != 0u;
 #pragma unroll 1
@@ -739,9 +786,7 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
         layer = 0;
     }
     uint32_t qd[8];
-    float qscale;
-    quantize_query_operand(a.q16 + (row * a.g + min(c, a.g - 1u)) * 128u + kb * 16u, c < a.g, qd, qscale);
-    qscale *= a.scale_log2e;
+    float qscale = 1.0f;
 
     const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
     const uint32_t t0 = split * a.tiles_per_split;
@@ -793,13 +838,24 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
             const uint32_t r = 4u * kb + j;
             rdv[j] = lbase + kFdV + fd_row_slot(r) * 128u + (((c >> 1) ^ fd_piece_xor(r)) * 16u) + (c & 1u) * 8u;
         }
-        // the query operand must be complete before the first DMA (the compiler would otherwise drain the DMAs with its
-        // own vmcnt(0) at the first use inside the loop)
-        asm volatile("" :: "v"(qd[0]), "v"(qd[1]), "v"(qd[2]), "v"(qd[3]), "v"(qd[4]), "v"(qd[5]), "v"(qd[6]), "v"(qd[7]), "v"(qscale));
+        // The query row is asked for BEHIND the first tile's K requests and in front of the rest (descriptor -> {tiles, query} ->
+        // scores: two round trips, not three), by inline assembly like the DMAs: the compiler neither counts these loads nor waits
+        // for them.  One wait with the row's registers as operands: all but the 13 youngest requests (V of tile 0, tile 1) have
+        // landed -- the count fd_take_k uses at the head of every iteration.
         issue_k(t0, 0u);
+        u32x4 qw[4];
+        {
+            const uint16_t* qsrc = a.q16 + (row * a.g + min(c, a.g - 1u)) * 128u + kb * 16u;
+            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:144"
+                         : "=&v"(qw[0]), "=&v"(qw[1]), "=&v"(qw[2]), "=&v"(qw[3]) : "v"(qsrc) : "memory");
+        }
         issue_v(t0, 0u);
         issue_k(t0 + 1u, 1u);
         issue_v(t0 + 1u, 1u);
+        asm volatile("s_waitcnt vmcnt(13)" : "+v"(qw[0]), "+v"(qw[1]), "+v"(qw[2]), "+v"(qw[3]) :: "memory");
+        quantize_query_rows(qw, c < a.g, qd, qscale);
+        qscale *= a.scale_log2e;
         const bool ragged = (a.n_pages & 15u) != 0u;
 #pragma unroll 1
         for (uint32_t tile = t0; tile < t1; ++tile) {
