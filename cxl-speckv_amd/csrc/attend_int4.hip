@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
     }
 
     f16x8 qv[4];
-    {
+    if (TABLE) {                                                         // (the table form asks for its query rows first: its entry look-ups are counted by hand)
         const uint16_t* q16 = reinterpret_cast<const uint16_t*>(a.q8) + (row * a.g + c) * 128u + kb * 32u;
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
@@ -450,9 +450,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
         for (uint32_t j = 0; j < 4; ++j)
             rdv[j] = lbase + kWgV + (4u * kb + j) * 256u + ((((wave ^ kb) * 4u) + ((c >> 2) ^ j)) * 16u) + (c & 3u) * 4u;
         const uint32_t rsv = lbase + kWgVs + 2u * kb * 128u + ((h1 ^ kb) * 16u) + (head & 1u) * 8u + 2u * (c >> 2);   // pages 2 kb + j / 2 (+ 8): (page / 2) & 3 = kb
-        // the query rows must have arrived before the first DMA is issued: the compiler would otherwise place its own
+        // table form: the query rows must have arrived before the first DMA is issued: the compiler would otherwise place its own
         // vmcnt(0) for them at their first use, inside the loop, and drain the pipeline there in every iteration
-        asm volatile("" :: "v"(qv[0]), "v"(qv[1]), "v"(qv[2]), "v"(qv[3]));
+        if (TABLE) asm volatile("" :: "v"(qv[0]), "v"(qv[1]), "v"(qv[2]), "v"(qv[3]));
 #ifdef SPECKV_ABL_PLAIN_LOADS
         // timing only: the same bytes at the same addresses by plain 16-byte loads into registers, two tiles in flight, nothing else
         if (!STRIPED) {
@@ -553,8 +553,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
             store_partial(a, part, row, my_splits, c, kb, m_run, l_run, acc);
             return;
         }
+        // first tile, THEN the query rows (inline assembly: not the compiler's to count), then the second tile -- or the first once
+        // more, so that the wait's count holds for a run of one tile: descriptor -> {tile, query, tile} -> scores (see k_attend_int4_wg8)
         issue(t0, 0u);
-        if (t0 < last) issue(t0 + 1u, 1u);
+        {
+            u32x4 tq0, tq1, tq2, tq3;
+            const uint32_t cq = c < a.g ? c : a.g - 1u;
+            const uint16_t* q16 = reinterpret_cast<const uint16_t*>(a.q8) + (row * a.g + cq) * 128u + kb * 32u;
+            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
+                         : "=&v"(tq0), "=&v"(tq1), "=&v"(tq2), "=&v"(tq3) : "v"(q16) : "memory");
+            issue(t0 < last ? t0 + 1u : t0, 1u);
+            asm volatile("s_waitcnt vmcnt(5)" : "+v"(tq0), "+v"(tq1), "+v"(tq2), "+v"(tq3) :: "memory");
+            const bool qlive = c < a.g;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            tq0 = qlive ? tq0 : z; tq1 = qlive ? tq1 : z; tq2 = qlive ? tq2 : z; tq3 = qlive ? tq3 : z;
+            qv[0] = q_operand(make_uint4(tq0.x, tq0.y, tq0.z, tq0.w)); qv[1] = q_operand(make_uint4(tq1.x, tq1.y, tq1.z, tq1.w));
+            qv[2] = q_operand(make_uint4(tq2.x, tq2.y, tq2.z, tq2.w)); qv[3] = q_operand(make_uint4(tq3.x, tq3.y, tq3.z, tq3.w));
+        }
 #pragma unroll 1
         for (uint32_t tile = t0; tile < t1; ++tile) {
             const uint32_t buf = (tile - t0) & 1u;
