@@ -5,15 +5,17 @@
 // kernels.hip: each compress() call of the engine is one block.  This file is the reference's own call shape: n = 11 in the
 // survey's known-answer test, the RTL tile of 1024 x 128 = 131 072 elements, ...)
 //
-// The serial recurrences become scans at two levels: inside a tile they are the wave scans of the block encoder's general
-// path (one element per lane and step, DPP add / max scans with carries); across tiles a single wave walks the per-tile
-// summaries 64 tiles per step.
+// The serial recurrences become scans at two levels: inside a tile they are the wave scans of the block codec (DPP add / max
+// scans with carries); across tiles, since round 4, a decoupled look-back over one 8-byte status word per WORKGROUP of 16 tiles:
+//   compress:   k_tc_absmax -> k_tc_fused    (one pass over the source behind the abs-max pass; pairs written where they belong)
+//   decompress: k_td_fused                   (one pass over the stream; a byte scattered per run, as the block decoder does)
+// The multi-launch forms of rounds 2-3 stay as SPECKV_TC_MULTIPASS=1 (tests run both; A/B):
 //   compress:   k_tc_absmax -> k_tc_tiles<summary> -> k_tc_scan_a/_b/_c -> k_tc_tiles<emit> -> k_tc_pack
 //   decompress: k_td_summary -> k_td_scan_local/_apply -> k_td_expand
 // Positions p = 0..n-1; d[p] = q[p] - q[p-1] (q[-1] = 0); a STRETCH starts at p == 0 or d[p] != d[p-1]; a RUN starts every
 // 255 elements of a stretch (cache_engine.cpp:224: `count < 255`); pair = (d[p], distance to the next run start).
-// Every wave writes whole 128-byte lines of its own (tile-local pair buffers, then an output-centric pack pass): byte
-// stores of different workgroups into one line are avoided throughout this library (DESIGN.md sect. 2).
+// The multi-launch forms write whole 128-byte lines per wave (tile-local pair buffers, then an output-centric pack pass); the
+// one-pass kernels store whole aligned 16-byte pieces and single bytes / elements only at the two ragged ends of a tile's stretch.
 #include "kernels.hpp"
 #include "codec_device.hpp"
 #include "encode_device.hpp"
