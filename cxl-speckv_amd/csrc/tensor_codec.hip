@@ -1296,11 +1296,15 @@ __global__ __launch_bounds__(64 * kTfWaves) void k_tc_fused(const void* __restri
             u32x4 v;
             v.x = __builtin_amdgcn_alignbyte(d[1], d[0], sh); v.y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
             v.z = __builtin_amdgcn_alignbyte(d[3], d[2], sh); v.w = __builtin_amdgcn_alignbyte(d[4], d[3], sh);
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a));
+            // (global address space spelled out: a pointer made from an integer is a FLAT pointer to the compiler, and flat stores
+            //  count in lgkmcnt beside the LDS reads of the next piece)
+            typedef u32x4 __attribute__((address_space(1)))* g_u32x4_p;
+            __builtin_nontemporal_store(v, (g_u32x4_p)(a));
         } else {                                                        // a ragged piece at one end of the tile's stretch of the stream
+            typedef uint8_t __attribute__((address_space(1)))* g_u8_p;
             for (uint32_t b = 0; b < 16u; ++b) {
                 const uintptr_t g = a + b;
-                if (g >= gaddr && g < gend) *reinterpret_cast<uint8_t*>(g) = wl[lo + static_cast<int32_t>(b)];
+                if (g >= gaddr && g < gend) *(g_u8_p)(g) = wl[lo + static_cast<int32_t>(b)];
             }
         }
     }
