@@ -662,13 +662,22 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
 // Fast path: no stretch of equal deltas reaches 255 elements, so every change of the delta starts a run and no run
 // has to be split (count < 255 rule).  Returns the number of runs, or kEncFail when a long stretch may exist (>= 14
 // lanes of a chunk without any run start: a 255-stretch needs 30 such lanes in two chunks) -- the caller then runs
-// the general path, which starts over.  The block must be finite (quantize8).
-template <int MODE>
+// the SPLIT form, which starts over.  The block must be finite (quantize8).
+// SPLIT (round 4; its own instantiation, the plain one is untouched): stretches of any length.  A run also starts at every
+// 255th element of a stretch (cache_engine.cpp:224).  A lane holds 8 consecutive elements, so at most one such element falls
+// into the part of the lane in front of its first change of the delta -- the part that belongs to the stretch ENTERING the lane,
+// whose start is the last change in front of the lane (a second max-scan, over change positions only): if the entering
+// stretch has offset o0 at the lane's element 0, the split start is element (255 - o0 % 255) % 255 when that is one of the
+// lane's.  Everything behind that -- run indices, "count = distance to the previous start" -- is the plain path's, with the
+// split start as one more start.  (Blocks of long runs took the element-wise path before: 745 us per 131 072 blocks, four
+// times a block of noise, for the data that compresses 100 : 1.  profiles/r04_long_runs.txt)
+template <int MODE, bool SPLIT = false>
 __device__ __forceinline__ uint32_t encode_rle_fast(const uint4 (&raw)[4], float scale, float rcp, uint8_t* wl, uint32_t lane)
 {
     const uint32_t pair_m1 = lds_addr_of(wl + kEncPairOff) - 1u;
     uint32_t qtail = 0, dtail = 0x100u, mcarry = 0, icarry = 0;  // dtail 0x100: no delta precedes element 0 (it starts a run)
     bool prev_sparse = false, failed = false;                    // mcarry: position+1 of the last run start
+    uint32_t ccarry = 0;                                         // SPLIT: position+1 of the last CHANGE of the delta
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t p0 = 512u * j + 8u * lane;
@@ -686,16 +695,32 @@ __device__ __forceinline__ uint32_t encode_rle_fast(const uint4 (&raw)[4], float
         uint32_t mask = 0;                                       // bit 7-k = element k starts a run
         unsigned long long sm[8];                                // the same as lane masks
         st[0] = d[0] != prevd;
-        sm[0] = __builtin_amdgcn_ballot_w64(st[0]);
-        shift_in(mask, sm[0]);
 #pragma unroll
-        for (int k = 1; k < 8; ++k) { st[k] = d[k] != d[k - 1]; sm[k] = __builtin_amdgcn_ballot_w64(st[k]); shift_in(mask, sm[k]); }
+        for (int k = 1; k < 8; ++k) st[k] = d[k] != d[k - 1];
+        if (SPLIT) {
+            uint32_t cmask = 0;                                  // the changes alone
+#pragma unroll
+            for (int k = 0; k < 8; ++k) shift_in(cmask, __builtin_amdgcn_ballot_w64(st[k]));
+            const uint32_t lmc = cmask ? p0 + 8u - static_cast<uint32_t>(__builtin_ctz(cmask)) : 0u;
+            const uint32_t imc = wave_incl_max(lmc);
+            const uint32_t mc = umax(wave_shr1(imc, 0u), ccarry);                // last change in front of the lane, position+1 (0: none)
+            ccarry = umax(ccarry, lane63(imc));
+            const uint32_t o0 = p0 + 1u - mc;                                    // offset of element 0 in the entering stretch (>= 1)
+            const uint32_t r = o0 - 255u * ((o0 * 0x8081u) >> 23);                // o0 % 255 (exact below 4096)
+            uint32_t ks = r ? 255u - r : 0u;                                      // the lane's element at a multiple of 255, if < 8
+            const uint32_t kfirst = cmask ? static_cast<uint32_t>(__builtin_clz(cmask)) - 24u : 8u;     // the lane's first change
+            if (mc == 0u || ks >= kfirst) ks = 8u;                               // (behind a change the offsets are < 8: never a split)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) st[k] = st[k] || ks == static_cast<uint32_t>(k);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sm[k] = __builtin_amdgcn_ballot_w64(st[k]); shift_in(mask, sm[k]); }
         const uint32_t cnt = static_cast<uint32_t>(__builtin_popcount(mask));
         // last start of the lane, as position+1 (0 = none): element 7 - ctz(mask)
         const uint32_t lm = mask ? p0 + 8u - static_cast<uint32_t>(__builtin_ctz(mask)) : 0u;
         // cheap pre-filter: a run longer than 248 elements needs >= 28 start-free lanes in this chunk and the previous
         // one together, i.e. >= 14 in one of them
-        const bool sparse = __popcll(__ballot(mask == 0u)) >= 14;            // wave-uniform
+        const bool sparse = !SPLIT && __popcll(__ballot(mask == 0u)) >= 14;            // wave-uniform
         const bool suspicious = sparse || prev_sparse;
         prev_sparse = sparse;
         const uint32_t ic = wave_incl_add(cnt);
@@ -706,9 +731,9 @@ __device__ __forceinline__ uint32_t encode_rle_fast(const uint4 (&raw)[4], float
         mcarry = umax(mcarry, lane63(im));
         // A count is "position of this run start - previous run start"; only a lane's FIRST start of the chunk can
         // close a long run, and that run is shorter than (end of the lane's 8 elements - previous start).  If that
-        // bound passes 255 anywhere the run may need splitting (cache_engine.cpp:224), which only the general path does.
+        // bound passes 255 anywhere the run may need splitting (cache_engine.cpp:224), which the SPLIT form does.
         // (the loop simply runs on after a failure: the scatter stays inside the wave's buffer)
-        if (suspicious && __ballot(mask != 0u && p0 + 8u - m > 255u) != 0ull) failed = true;   // wave-uniform
+        if (!SPLIT && suspicious && __ballot(mask != 0u && p0 + 8u - m > 255u) != 0ull) failed = true;   // wave-uniform
         // rel = (last start, position+1) - (p0 + 1): count of the run closed by a start at element k is k - rel
         uint32_t rel = m - p0 - 1u;
         uint32_t addr[8], cntv[8];
@@ -722,7 +747,7 @@ __device__ __forceinline__ uint32_t encode_rle_fast(const uint4 (&raw)[4], float
 #pragma unroll
         for (int k = 0; k < 8; ++k) store_pair_if(sm[k], addr[k], cntv[k], d[k]);
     }
-    if (failed || kBlockElems + 1u - mcarry > 255u) return kEncFail;        // a run may need splitting
+    if (!SPLIT && (failed || kBlockElems + 1u - mcarry > 255u)) return kEncFail;        // a run may need splitting
     lds_store_b8(pair_m1 + 2u * icarry, kBlockElems + 1u - mcarry);         // close the last run
     return icarry;
 }
@@ -996,7 +1021,14 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                 uint32_t nruns = finite ? encode_rle_fast<MODE>(raw, scale, rcp, wl, lane) : kEncFail;
                 wave_lds_fence();
                 if (nruns == kEncFail) {
-                    nruns = encode_rle_general<MODE>(src, scale, wl, lane);
+                    if (finite) {                                        // long stretches: the fast path's SPLIT form, from the source again
+                        uint4 again[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) again[j] = enc_ld16(src + 2ull * (512u * j + 8u * lane));
+                        nruns = encode_rle_fast<MODE, true>(again, scale, rcp, wl, lane);
+                    } else {
+                        nruns = encode_rle_general<MODE>(src, scale, wl, lane);
+                    }
                     wave_lds_fence();
                 }
                 uint8_t* pairbuf = wl + kEncPairOff;

@@ -270,6 +270,61 @@ def test_run_lengths_around_the_split_limit(lib, oracle):
         assert_same_float_bits(y, oracle.decompress_blocks_f16(o_recs, o_lens, o_scales, 2, mode), f"mode {mode}")
 
 
+def test_long_stretches_take_the_split_form_of_the_fast_encoder(lib, oracle):
+    """Blocks made of LONG stretches of equal deltas (the data the scheme compresses 100 : 1): the fast encoder's SPLIT form
+    starts a run at every 255th element of a stretch, across lanes and 512-element chunks.  Random piecewise-constant blocks
+    with stretch lengths around every multiple of 255 and up to the whole block, at random phases; stretches of a constant
+    NON-ZERO delta (ramps whose quantised steps are equal); whole-block constants; long stretches between bursts of noise --
+    3 000 blocks, both quantiser modes, records byte for byte against the oracle, then decoded."""
+    rng = np.random.default_rng(20250404)
+    blocks = []
+    special = [254, 255, 256, 509, 510, 511, 764, 765, 766, 1019, 1020, 1021, 1275, 1530, 1785, 2040, 2047, 2048]
+    for i in range(2000):
+        x = np.empty(N + 4096)
+        pos = 0
+        while pos < x.size:
+            kind = rng.integers(0, 4)
+            if kind == 0: m = int(rng.choice(special)) + int(rng.integers(-1, 2))
+            elif kind == 1: m = int(rng.integers(256, 2300))
+            elif kind == 2: m = int(rng.integers(1, 40))
+            else: m = int(rng.integers(40, 256))
+            x[pos:pos + m] = rng.standard_normal()
+            pos += m
+        ph = int(rng.integers(0, 4096))
+        blocks.append(x[ph:ph + N])
+    for i in range(500):                                             # ramps: equal quantised steps over hundreds of elements
+        step = rng.choice([1.0, 2.0, 3.0, -1.0, -2.0]) / 127.0
+        x = np.zeros(N)
+        a = int(rng.integers(0, 600)); b = int(rng.integers(a + 60, a + 127))
+        x[a:b] = np.arange(b - a) * step                              # |x| < 1
+        x[0] = 1.0                                                    # pins the scale: max|x| = 1 -> q = round(127 x)
+        x[b:] = x[b - 1] if i % 2 else 0.0
+        blocks.append(x)
+    for i in range(250):                                             # constants, and long stretches between noise
+        x = np.full(N, rng.standard_normal())
+        if i % 3 == 0:
+            k = int(rng.integers(1, 6))
+            for _ in range(k):
+                a = int(rng.integers(0, N - 8)); x[a:a + int(rng.integers(1, 8))] = rng.standard_normal(1)
+        blocks.append(x)
+    for i in range(250):
+        x = rng.standard_normal(N)
+        a = int(rng.integers(0, N - 300)); m = int(rng.integers(250, N - a))
+        x[a:a + m] = x[a]
+        blocks.append(x)
+    x16 = np.stack(blocks).astype(np.float16)
+    for mode in MODES:
+        scales, lens, recs = gpu_compress(lib, x16, 2, mode)
+        o_scales, o_lens, o_recs = oracle.compress_blocks_f16(x16, 2, mode)
+        assert np.array_equal(lens, o_lens), np.nonzero(lens != o_lens)[0][:8]
+        assert scales.tobytes() == o_scales.tobytes()
+        mask = np.arange(4096)[None, :] < lens[:, None]
+        bad = np.nonzero((recs != o_recs) & mask)
+        assert bad[0].size == 0, (mode, bad[0][:5], bad[1][:5])
+        y = gpu_decompress(lib, recs, lens, scales, 2, mode)
+        assert_same_float_bits(y, oracle.decompress_blocks_f16(o_recs, o_lens, o_scales, 2, mode), f"mode {mode}")
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_structured_hint_decoder_is_bit_identical(lib, oracle, mode):
     """SPECKV_CODEC_HINT_STRUCTURED selects a separate instantiation of the fetch kernel (decode_rle_fast<.., FLAT>: constant
