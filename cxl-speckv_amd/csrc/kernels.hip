@@ -676,7 +676,7 @@ __device__ __forceinline__ uint32_t encode_rle_fast(const uint4 (&raw)[4], float
 {
     const uint32_t pair_m1 = lds_addr_of(wl + kEncPairOff) - 1u;
     uint32_t qtail = 0, dtail = 0x100u, mcarry = 0, icarry = 0;  // dtail 0x100: no delta precedes element 0 (it starts a run)
-    bool prev_sparse = false, failed = false;                    // mcarry: position+1 of the last run start
+    bool prev_sparse = false;                                    // mcarry: position+1 of the last run start
     uint32_t ccarry = 0;                                         // SPLIT: position+1 of the last CHANGE of the delta
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -732,8 +732,12 @@ __device__ __forceinline__ uint32_t encode_rle_fast(const uint4 (&raw)[4], float
         // A count is "position of this run start - previous run start"; only a lane's FIRST start of the chunk can
         // close a long run, and that run is shorter than (end of the lane's 8 elements - previous start).  If that
         // bound passes 255 anywhere the run may need splitting (cache_engine.cpp:224), which the SPLIT form does.
-        // (the loop simply runs on after a failure: the scatter stays inside the wave's buffer)
-        if (!SPLIT && suspicious && __ballot(mask != 0u && p0 + 8u - m > 255u) != 0ull) failed = true;   // wave-uniform
+        // (wave-uniform: the SPLIT form starts over, nothing of this attempt is used)
+        if (!SPLIT && suspicious) {
+            if (__ballot(mask != 0u && p0 + 8u - m > 255u) != 0ull) return kEncFail;
+            // ... or the run that is open at the end of the chunk is too long already (then its last 31 lanes hold no start: sparse)
+            if (512u * static_cast<uint32_t>(j + 1) + 1u - mcarry > 255u) return kEncFail;
+        }
         // rel = (last start, position+1) - (p0 + 1): count of the run closed by a start at element k is k - rel
         uint32_t rel = m - p0 - 1u;
         uint32_t addr[8], cntv[8];
@@ -747,7 +751,6 @@ __device__ __forceinline__ uint32_t encode_rle_fast(const uint4 (&raw)[4], float
 #pragma unroll
         for (int k = 0; k < 8; ++k) store_pair_if(sm[k], addr[k], cntv[k], d[k]);
     }
-    if (!SPLIT && (failed || kBlockElems + 1u - mcarry > 255u)) return kEncFail;        // a run may need splitting
     lds_store_b8(pair_m1 + 2u * icarry, kBlockElems + 1u - mcarry);         // close the last run
     return icarry;
 }

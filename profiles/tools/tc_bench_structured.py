@@ -8,14 +8,18 @@ import cxl_speckv_amd as pkg
 kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), "hip:0")
 raw = kv.lib.lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256 * 2**20
+lo = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+hi = int(sys.argv[3]) if len(sys.argv) > 3 else 4000
+noise_third = len(sys.argv) <= 4 or sys.argv[4] != "0"
 g = torch.Generator(device="cuda"); g.manual_seed(7)
-m = n // 512 + 1
-lens = torch.randint(16, 4000, (m,), generator=g, device="cuda")
+m = n // max(1, (lo + hi) // 4) + 1
+lens = torch.randint(lo, hi, (m,), generator=g, device="cuda")
 vals = torch.randn(m, generator=g, device="cuda")
 x = torch.repeat_interleave(vals, lens)[:n]
 if x.numel() < n: x = torch.cat([x, torch.zeros(n - x.numel(), device="cuda")])
-noise = torch.randn(n // 3, generator=g, device="cuda")
-x[n // 3: n // 3 + noise.numel()] = noise
+if noise_third:
+    noise = torch.randn(n // 3, generator=g, device="cuda")
+    x[n // 3: n // 3 + noise.numel()] = noise
 x = x.to(torch.float16).contiguous()
 ws_bytes = int(raw.speckv_ext_codec_tensor_workspace_bytes(n))
 ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device="cuda"); wsp = (ws.data_ptr() + 255) & ~255
@@ -38,4 +42,4 @@ for name, fn, byt in (("compress", enc, 2 * n + size), ("decompress", dec, size 
     for _ in range(5): fn()
     b.record(s); torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 5
-    print(f"structured n={n} stream={size} ({2*n/size:.2f}x) {name} {ms:.4f} ms  {byt/ms/1e6:.0f} GB/s  frac {byt/ms/1e6/8000:.3f}  form={'multipass' if os.environ.get('SPECKV_TC_MULTIPASS') else 'one pass'}  roundtrip_ok={ok}", flush=True)
+    print(f"structured runs {lo}..{hi} n={n} stream={size} ({2*n/size:.2f}x) {name} {ms:.4f} ms  {byt/ms/1e6:.0f} GB/s  frac {byt/ms/1e6/8000:.3f}  form={'multipass' if os.environ.get('SPECKV_TC_MULTIPASS') else 'one pass'}  roundtrip_ok={ok}", flush=True)
