@@ -1699,6 +1699,207 @@ void k_td_fused(const uint8_t* __restrict__ rle, uint64_t n_pairs, uint64_t n_ch
     if (start + kTdfWin < end) td_windows_behind_the_first<MODE, F32>(rle, p0, n_pairs, start, end, qp, tot_c, c1, c2, tab, scale, dst, lane);
 }
 
+// ---------------------------------------------------------------- output-centric expand with the run scatter (multi-launch form)
+// k_td_expand above lets a lane write the part of its run that falls into the tile element by element: a tile covered by three
+// runs of 700 elements is three lanes storing 700 bytes each.  On tensors that compress (long runs, few pairs) BOTH decoders
+// collapse -- the one-pass kernel because its work is cut by PAIRS (a chunk of 2048 pairs is a megabyte of output walked by one
+// wave), this one because of that loop: 128 Mi elements at 155 : 1 took 0.67-0.71 ms, 5 % of the roofline.  Here a wave owns 2048
+// OUTPUT elements as before, but fills its table the block decoder's way: E[start of run] = value - previous value for the runs
+// that start inside the tile (one byte per run), the state in front of the tile (q and the delta of element -1) from the packed
+// sums of the pairs in front of it, then two wave scans + eight byte recurrences per 512 elements.  Constant work per tile
+// whatever the run lengths.  A tile that meets a zero count (hand-made streams) takes td_tile_general.
+template <int MODE, bool F32>
+__device__ __noinline__ void td_tile_general(const uint8_t* __restrict__ rle, uint64_t n_pairs, uint64_t i0, uint64_t pos0, uint32_t q0,
+                                             uint64_t o0, uint64_t o1, float scale, uint8_t* __restrict__ dst, uint32_t lane)
+{
+    uint64_t pos = pos0;                                                 // element index of pair i0's first element
+    uint32_t qa = q0;
+#pragma unroll 1
+    for (uint64_t b = i0; b < n_pairs && pos < o1; b += 64u) {
+        const uint64_t i = b + lane;
+        uint32_t bits = 0;
+        if (i < n_pairs) bits = *reinterpret_cast<const uint16_t*>(rle + 2ull * i);
+        const uint32_t v = bits & 0xFFu, c = bits >> 8;
+        const uint32_t packed = ((v * c) << 24) | c;
+        const uint32_t incl = wave_incl_add(packed);
+        const uint32_t e = incl - packed;
+        uint64_t p = pos + (e & 0xFFFFFFu);
+        uint32_t q = qa + (e >> 24);
+#pragma unroll 1
+        for (uint32_t m = 0; m < c && p < o1; ++m, ++p) {
+            q += v;
+            if (p < o0) continue;
+            const float y = dequant<MODE>(static_cast<int>(static_cast<int8_t>(q & 0xFFu)), scale);
+            if (F32) reinterpret_cast<float*>(dst)[p] = y;
+            else { float a = y, z = 0.0f; reinterpret_cast<uint16_t*>(dst)[p] = static_cast<uint16_t>(pack_half2(a, z) & 0xFFFFu); }
+        }
+        const uint32_t tot = lane63(incl);
+        pos += tot & 0xFFFFFFu;
+        qa = (qa + (tot >> 24)) & 0xFFu;
+    }
+}
+template <int MODE, bool F32>
+__global__ __launch_bounds__(256) void k_td_expand_scatter(const uint8_t* __restrict__ rle, uint64_t n_pairs, const TdCarry* __restrict__ carry,
+                                                          uint64_t n_chunks, const uint64_t* __restrict__ n_out_p, float scale, uint8_t* __restrict__ dst)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tabs[4][kTile + 16];      // (+16: bytes that may be written and are never read)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t n_out = *n_out_p;
+    const uint64_t o0 = (static_cast<uint64_t>(blockIdx.x) * 4u + wave) * kTile;
+    if (o0 >= n_out) return;
+    const uint64_t o1 = (n_out - o0 < kTile) ? n_out : o0 + kTile;
+    uint8_t* tab = tabs[wave];
+    const uint32_t tab_addr = lds_addr_of(tab);
+    uint64_t lo = 0, hi = n_chunks;                                      // last chunk whose first element is at or before o0 (64-ary search)
+    while (hi - lo > 1u) {
+        const uint64_t span = hi - lo, step = (span + 63u) / 64u;
+        const uint64_t c = lo + static_cast<uint64_t>(lane + 1u) * step;
+        const bool le = c < hi && carry[c].start <= o0;
+        const uint32_t kk = static_cast<uint32_t>(__popcll(__ballot(le)));
+        const uint64_t nlo = lo + static_cast<uint64_t>(kk) * step, nhi = lo + static_cast<uint64_t>(kk + 1u) * step;
+        lo = nlo;
+        hi = nhi < hi ? nhi : hi;
+    }
+    const uint32_t valid = static_cast<uint32_t>(o1 - o0);
+    const uint64_t chunk_start = carry[lo].start;
+    const uint32_t chunk_q = carry[lo].q_pre;
+    int32_t tot = -static_cast<int32_t>(o0 - chunk_start);               // first element of the step's first pair, relative to o0
+    uint32_t qm1 = chunk_q;                                               // becomes q[-1]: everything in front of the tile
+    uint32_t dm1 = 0u;                                                   // the delta of element -1 (value of the pair that covers it)
+    uint32_t tail = 0u;                                                  // the dword of the pair in front of the step's first (value in byte 2)
+    if (lo != 0u) {                                                      // (the last pair of the chunk before: it exists and has been read by the summary pass)
+        const uint32_t b = *reinterpret_cast<const uint16_t*>(rle + 2ull * (lo * kTile - 1u));
+        tail = (b & 0xFFu) << 16;
+        dm1 = b & 0xFFu;
+        if ((b >> 8) == 0u) { td_tile_general<MODE, F32>(rle, n_pairs, lo * kTile, chunk_start, chunk_q, o0, o1, scale, dst, lane); return; }
+    }
+    {
+        u32x4* t4 = reinterpret_cast<u32x4*>(tab);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        t4[lane] = z; t4[64u + lane] = z;
+    }
+    const bool wide = (reinterpret_cast<uintptr_t>(rle) & 15u) == 0u;
+    bool zero_seen = false;
+#pragma unroll 1
+    for (uint64_t i0 = lo * kTile; i0 < n_pairs && tot < static_cast<int32_t>(valid); i0 += 512u) {
+        const uint64_t i = i0 + 8u * lane;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};                                // pairs i, i+1 | i+2, i+3 | ... (v | c << 8 | v << 16 | c << 24)
+        uint32_t mn = 255u;
+        if (wide && i + 8u <= n_pairs) {
+            const u32x4 x = *reinterpret_cast<const u32x4*>(rle + 2ull * i);
+            w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) mn = umin(mn, umin((w[t] >> 8) & 0xFFu, w[t] >> 24));
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k)
+                if (i + k < n_pairs) {
+                    const uint32_t bits = *reinterpret_cast<const uint16_t*>(rle + 2ull * (i + k));
+                    w[k >> 1] |= bits << (16u * (k & 1u));
+                    mn = umin(mn, bits >> 8);
+                }
+        }
+        if (__ballot(mn == 0u) != 0ull) { zero_seen = true; break; }
+        uint32_t sc = 0, sv = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t counts = (w[t] >> 8) & 0x00FF00FFu;
+            sc = __builtin_amdgcn_udot4(counts, 0x00010001u, sc, false);
+            sv = __builtin_amdgcn_udot4(w[t], counts, sv, false);
+        }
+        const uint32_t lt = (sv << 24) | sc;
+        const uint32_t incl = wave_incl_add(lt);
+        const uint32_t stp = lane63(incl);
+        const int32_t step_c = static_cast<int32_t>(stp & 0xFFFFFFu);
+        const uint32_t last_dw = lane63(w[3]);
+        if (tot + step_c <= 0) {                                         // (wave-uniform) every element of the step lies in front of the tile
+            qm1 += stp >> 24;
+            if (step_c != 0) dm1 = (last_dw >> 16) & 0xFFu;              // (a full step: its last pair exists and covers the last element so far)
+            tot += step_c;
+            tail = last_dw;
+            continue;
+        }
+        const uint32_t ex = incl - lt;
+        int32_t a = tot + static_cast<int32_t>(ex & 0xFFFFFFu);           // first element of the lane's first pair
+        const uint32_t pwj = wave_shr1(w[3], tail);
+        const uint32_t dd[8] = {td_sub_b0_b2(w[0], pwj), td_sub_b2_b0(w[0], w[0]), td_sub_b0_b2(w[1], w[0]), td_sub_b2_b0(w[1], w[1]),
+                                td_sub_b0_b2(w[2], w[1]), td_sub_b2_b0(w[2], w[2]), td_sub_b0_b2(w[3], w[2]), td_sub_b2_b0(w[3], w[3])};
+        if (tot < 0) {
+            // the step straddles the tile's first element: what its pairs put IN FRONT of the tile goes into q[-1], and the last
+            // pair that starts in front of the tile is the one that covers element -1
+            uint32_t qb = 0u, cov = 0u, has = 0u;
+            int32_t st_e = a;
+#pragma unroll
+            for (uint32_t e = 0; e < 8u; ++e) {
+                const uint32_t v = (w[e >> 1] >> (16u * (e & 1u))) & 0xFFu, c = (w[e >> 1] >> (8u + 16u * (e & 1u))) & 0xFFu;
+                const int32_t nb = st_e < 0 ? ((-st_e) < static_cast<int32_t>(c) ? -st_e : static_cast<int32_t>(c)) : 0;
+                qb += v * static_cast<uint32_t>(nb);
+                if (st_e < 0 && c != 0u) { cov = v; has = 1u; }
+                st_e += static_cast<int32_t>(c);
+            }
+            qm1 += lane63(wave_incl_add(qb & 0xFFu));
+            const unsigned long long hm = __ballot(has != 0u);
+            if (hm) dm1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cov), 63 - __builtin_clzll(hm)));
+        }
+#pragma unroll
+        for (uint32_t e = 0; e < 8u; ++e) {
+            const uint32_t off = static_cast<uint32_t>(a) < valid ? static_cast<uint32_t>(a) : kTile;      // in front of / behind the tile: the spare byte
+            td_lds_b8(tab_addr + off, dd[e]);
+            a += static_cast<int32_t>((w[e >> 1] >> (8u + 16u * (e & 1u))) & 0xFFu);
+        }
+        tot += step_c;
+        tail = last_dw;
+    }
+    if (zero_seen) { td_tile_general<MODE, F32>(rle, n_pairs, lo * kTile, chunk_start, chunk_q, o0, o1, scale, dst, lane); return; }
+    wave_lds_fence();
+    uint32_t c1 = dm1, c2 = qm1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t p0 = 512u * j + 8u * lane;
+        if (512u * j >= valid) break;                                    // (wave-uniform)
+        const uint2 x = *reinterpret_cast<const uint2*>(tab + p0);
+        const uint32_t t1 = __builtin_amdgcn_sad_u8(x.x, 0u, __builtin_amdgcn_sad_u8(x.y, 0u, 0u));
+        const uint32_t t2 = __builtin_amdgcn_udot4(x.x, 0x05060708u, __builtin_amdgcn_udot4(x.y, 0x01020304u, 0u, false), false);
+        const uint32_t i1 = wave_incl_add(t1);
+        const uint32_t x1 = c1 + i1 - t1;
+        const uint32_t u = t2 + 8u * x1;
+        const uint32_t i2 = wave_incl_add(u);
+        const uint32_t x2 = c2 + i2 - u;
+        c1 += lane63(i1);
+        c2 += lane63(i2);
+        if (p0 >= valid) continue;
+        uint32_t s1 = x1, s2 = x2;
+        uint32_t q[8];
+        s1 = td_add_byte<0>(s1, x.x, x.y); s2 += s1; q[0] = s2;
+        s1 = td_add_byte<1>(s1, x.x, x.y); s2 += s1; q[1] = s2;
+        s1 = td_add_byte<2>(s1, x.x, x.y); s2 += s1; q[2] = s2;
+        s1 = td_add_byte<3>(s1, x.x, x.y); s2 += s1; q[3] = s2;
+        s1 = td_add_byte<4>(s1, x.x, x.y); s2 += s1; q[4] = s2;
+        s1 = td_add_byte<5>(s1, x.x, x.y); s2 += s1; q[5] = s2;
+        s1 = td_add_byte<6>(s1, x.x, x.y); s2 += s1; q[6] = s2;
+        s1 = td_add_byte<7>(s1, x.x, x.y); s2 += s1; q[7] = s2;
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = dequant<MODE>(static_cast<int>(static_cast<int8_t>(q[e] & 0xFFu)), scale);
+        if (p0 + 8u <= valid) {
+            if (F32) {
+                float* op = reinterpret_cast<float*>(dst) + o0 + p0;
+                typedef float f32x4v __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(f32x4v{y[0], y[1], y[2], y[3]}, reinterpret_cast<f32x4v*>(op));
+                __builtin_nontemporal_store(f32x4v{y[4], y[5], y[6], y[7]}, reinterpret_cast<f32x4v*>(op + 4));
+            } else {
+                const u32x4 pk = {pack_half2(y[0], y[1]), pack_half2(y[2], y[3]), pack_half2(y[4], y[5]), pack_half2(y[6], y[7])};
+                __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(dst) + o0 + p0));
+            }
+        } else {
+            for (uint32_t e = 0; e < 8u && p0 + e < valid; ++e) {
+                if (F32) reinterpret_cast<float*>(dst)[o0 + p0 + e] = y[e];
+                else { float a2 = y[e], z = 0.0f; reinterpret_cast<uint16_t*>(dst)[o0 + p0 + e] = static_cast<uint16_t>(pack_half2(a2, z) & 0xFFFFu); }
+            }
+        }
+    }
+}
+
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 } // namespace
@@ -1803,7 +2004,15 @@ hipError_t launch_tensor_decompress(const uint8_t* d_rle, uint64_t rle_bytes, fl
     TdSummary* summ = reinterpret_cast<TdSummary*>(w); w += align_up(chunks * sizeof(TdSummary), 256);
     TdCarry* carry = reinterpret_cast<TdCarry*>(w); w += align_up((chunks + 1) * sizeof(TdCarry), 256);
     uint64_t* n_out = d_n_out ? d_n_out : reinterpret_cast<uint64_t*>(w);
-    if (chunks && dst_cap && !getenv("SPECKV_TC_MULTIPASS")) {
+    // Which form: the one-pass kernel cuts the work by PAIRS (a chunk of 2048 pairs per wave) -- right for data that does not
+    // compress, but ONE wave per megabyte of output wherever the data does: a stream that is noise with a tail of zero padding
+    // leaves a few dozen waves walking hundreds of windows each.  The multi-launch form cuts the work by OUTPUT (2048 elements per
+    // wave, constant work per tile whatever the run lengths: k_td_expand_scatter) and pays a summary pass over the stream for it:
+    // 20 % behind the one-pass kernel on runs of 4, five times ahead of it on a tensor that is one third noise and two thirds long
+    // runs (profiles/r04_long_runs.txt).  So: one pass only for streams that are practically incompressible (at most 1.02 elements
+    // per pair), by output otherwise.  SPECKV_TC_MULTIPASS=1 / SPECKV_TD_ONE_PASS=1 force a form (tests, A/B).
+    const bool few_pairs = n_pairs * 51u < std::min<uint64_t>(dst_cap, n_pairs * 255u) * 50u;
+    if (chunks && dst_cap && !getenv("SPECKV_TC_MULTIPASS") && (!few_pairs || getenv("SPECKV_TD_ONE_PASS"))) {
         // single pass: a memset node (ticket, element count, one status word per workgroup), then ONE kernel
         const uint64_t wgs = (chunks + kTdfChunks - 1) / kTdfChunks;
         uint32_t* ticket = reinterpret_cast<uint32_t*>(d_ws);
@@ -1834,7 +2043,9 @@ hipError_t launch_tensor_decompress(const uint8_t* d_rle, uint64_t rle_bytes, fl
         // grid: the output can hold at most min(dst_cap, 255 * n_pairs) elements; waves behind the stream's total return at once
         const uint64_t max_out = std::min<uint64_t>(dst_cap, n_pairs * 255u);
         const uint32_t g = static_cast<uint32_t>(((max_out + kTile - 1) / kTile + 3) / 4);
-#define SPECKV_TD(MODE, F32) hipLaunchKernelGGL((k_td_expand<MODE, F32>), dim3(g), dim3(256), 0, s, d_rle, n_pairs, carry, chunks, n_out, scale, static_cast<uint8_t*>(d_dst))
+        const bool old_expand = getenv("SPECKV_TD_EXPAND_PER_ELEMENT") != nullptr;             // (A/B, tests: the expand loop of rounds 2-3; read at every call)
+#define SPECKV_TD(MODE, F32) do { if (old_expand) hipLaunchKernelGGL((k_td_expand<MODE, F32>), dim3(g), dim3(256), 0, s, d_rle, n_pairs, carry, chunks, n_out, scale, static_cast<uint8_t*>(d_dst)); \
+                                  else hipLaunchKernelGGL((k_td_expand_scatter<MODE, F32>), dim3(g), dim3(256), 0, s, d_rle, n_pairs, carry, chunks, n_out, scale, static_cast<uint8_t*>(d_dst)); } while (0)
         if (quant_mode == kIntent) { if (out_f32) SPECKV_TD(kIntent, true); else SPECKV_TD(kIntent, false); }
         else                       { if (out_f32) SPECKV_TD(kRefExact, true); else SPECKV_TD(kRefExact, false); }
 #undef SPECKV_TD

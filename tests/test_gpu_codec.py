@@ -527,7 +527,7 @@ def test_tensor_codec_golden_reference_vectors(lib, golden_dir):
         assert_same_float_bits(y, want, f"malformed{i}")
 
 
-@pytest.mark.parametrize("form", ["single_pass", "grids", "wg", "serial", "no_pre"])
+@pytest.mark.parametrize("form", ["single_pass", "one_pass_decoder", "grids", "per_element_expand", "wg", "serial", "no_pre"])
 def test_tensor_codec_scan_forms(lib, oracle, form):
     """Compress exists as ONE pass with look-back across workgroups (k_tc_fused, the default since round 4) and as the
     multi-launch form (SPECKV_TC_MULTIPASS) whose scans across tiles come in three shapes -- grids of one wave per step, one
@@ -539,6 +539,10 @@ def test_tensor_codec_scan_forms(lib, oracle, form):
         os.environ["SPECKV_TC_NO_PRE"] = "1"                         # fp16 sources: summary and emit as two plain passes
     elif form == "grids":
         os.environ["SPECKV_TC_MULTIPASS"] = "1"
+    elif form == "per_element_expand":                               # the multi-launch decoder with the expand loop of rounds 2-3
+        os.environ["SPECKV_TC_MULTIPASS"] = "1"; os.environ["SPECKV_TD_EXPAND_PER_ELEMENT"] = "1"
+    elif form == "one_pass_decoder":                                 # the one-pass decoder also for streams of few pairs
+        os.environ["SPECKV_TD_ONE_PASS"] = "1"
     elif form != "single_pass":
         os.environ["SPECKV_TC_SCAN"] = form
     try:
@@ -562,6 +566,8 @@ def test_tensor_codec_scan_forms(lib, oracle, form):
         os.environ.pop("SPECKV_TC_SCAN", None)
         os.environ.pop("SPECKV_TC_NO_PRE", None)
         os.environ.pop("SPECKV_TC_MULTIPASS", None)
+        os.environ.pop("SPECKV_TD_EXPAND_PER_ELEMENT", None)
+        os.environ.pop("SPECKV_TD_ONE_PASS", None)
 
 
 def test_tensor_codec_look_back_over_many_workgroups(lib, oracle):
