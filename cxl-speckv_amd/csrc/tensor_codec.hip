@@ -195,6 +195,112 @@ __device__ __forceinline__ bool tc_tile_fast(const uint8_t* tsrc, float scale, f
     return true;
 }
 
+// The same for tiles with stretches of ANY length (round 4): the SPLIT form of the block encoder (kernels.hip, encode_rle_fast<.., true>
+// -- a run also starts at every 255th element of a stretch; at most one such element falls into the part of a lane in front of its
+// first change of the delta) with the stretch that ENTERS the tile: `lead_phase` = offset of the tile's element 0 in it (mod 255),
+// known once chain 1 has answered.  Used twice on a tile the plain form declines: EMIT = false, has_lead = false for the summary
+// (first / last change of the delta, run starts at or behind the first change -- the head in front of it belongs to the entering
+// stretch and is counted by arithmetic), then EMIT = true with the phase for the pairs (the tile is read again, from L2).  Tiles
+// inside long stretches took the element-wise loop for both: a tensor of long runs compressed 4 x slower than noise.
+//   first_change / last_change: tile-relative + 1, 0 = none; n_starts: run starts found; last_start: the last of them (+ 1).
+// Out of line: inlined three times into k_tc_fused it made the kernel a quarter slower on tensors that never get here.
+template <int MODE, bool EMIT>
+__device__ __noinline__ bool tc_tile_split(const uint8_t* tsrc, float scale, float rcp, uint32_t qtail, uint32_t dtail, uint32_t pair_m1,
+                                              uint32_t lane, bool has_lead, uint32_t lead_phase, uint32_t& first_change, uint32_t& last_change,
+                                              uint32_t& n_starts, uint32_t& last_start)
+{
+    // (registers: the kernel this is called from must stay at 64 VGPRs -- two 16-wave workgroups per CU -- and a callee's
+    // count is the kernel's: the tile is read chunk by chunk, a first time for the finiteness test alone)
+    auto load_chunk = [&](int j) {
+        const u32x4 v = __builtin_nontemporal_load((const u32x4 __attribute__((address_space(1)))*)(reinterpret_cast<uintptr_t>(tsrc + 2ull * (512u * j + 8u * lane))));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    {
+        u16x2 m2 = {0, 0};
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            const uint4 r = load_chunk(j);
+            const uint32_t w4[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(u16x2, w4[t] & 0x7FFF7FFFu));
+        }
+        const uint32_t lanemax = m2.x > m2.y ? m2.x : m2.y;
+        if (lane63(wave_incl_max(lanemax)) >= 0x7C00u) return false;    // wave-uniform
+    }
+    constexpr uint32_t kBias = 256u;                                 // change positions are kept as position + 1 + kBias: the entering
+    uint32_t ccarry = has_lead ? 1u + kBias - lead_phase : 0u;       // stretch starts at 1 - lead_phase (<= 1); 0 = no stretch yet
+    uint32_t mcarry = 0, icarry = 0, first = 0, lcarry = 0;        // lcarry: the tile's own last change (biased; 0: none)
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t p0 = 512u * j + 8u * lane;
+        uint32_t q[8];
+        quantize8<MODE>(load_chunk(j), scale, rcp, q);
+        const uint32_t prevq = wave_shr1(q[7], qtail);
+        qtail = lane63(q[7]);
+        uint32_t d[8];
+        d[0] = sub_bytes(q[0], prevq);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) d[k] = sub_bytes(q[k], q[k - 1]);
+        const uint32_t prevd = wave_shr1(d[7], dtail);
+        dtail = lane63(d[7]);
+        bool st[8];
+        st[0] = d[0] != prevd;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) st[k] = d[k] != d[k - 1];
+        uint32_t cmask = 0;                                          // the changes alone (bit 7-k = element k)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) shift_in(cmask, __builtin_amdgcn_ballot_w64(st[k]));
+        const unsigned long long have_c = __ballot(cmask != 0u);
+        if (!first && have_c) {                                      // wave-uniform: the tile's first change
+            const uint32_t fl = static_cast<uint32_t>(__builtin_ctzll(have_c));
+            const uint32_t lane_first = cmask ? p0 + 8u - (31u - static_cast<uint32_t>(__builtin_clz(cmask))) : 0u;
+            first = static_cast<uint32_t>(__shfl(static_cast<int>(lane_first), static_cast<int>(fl)));
+        }
+        const uint32_t lmc = cmask ? p0 + 8u - static_cast<uint32_t>(__builtin_ctz(cmask)) + kBias : 0u;
+        const uint32_t imc = wave_incl_max(lmc);
+        const uint32_t mc = umax(wave_shr1(imc, 0u), ccarry);        // start of the stretch entering the lane (biased; 0: none)
+        ccarry = umax(ccarry, lane63(imc));
+        lcarry = umax(lcarry, lane63(imc));
+        const uint32_t o0 = p0 + 1u + kBias - mc;                    // offset of the lane's element 0 in that stretch (< 4096)
+        const uint32_t r = o0 - 255u * ((o0 * 0x8081u) >> 23);
+        uint32_t ks = r ? 255u - r : 0u;
+        const uint32_t kfirst = cmask ? static_cast<uint32_t>(__builtin_clz(cmask)) - 24u : 8u;
+        if (mc == 0u || ks >= kfirst) ks = 8u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) st[k] = st[k] || ks == static_cast<uint32_t>(k);
+        uint32_t mask = 0;
+        unsigned long long sm[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sm[k] = __builtin_amdgcn_ballot_w64(st[k]); shift_in(mask, sm[k]); }
+        const uint32_t cnt = static_cast<uint32_t>(__builtin_popcount(mask));
+        const uint32_t lm = mask ? p0 + 8u - static_cast<uint32_t>(__builtin_ctz(mask)) : 0u;
+        const uint32_t ic = wave_incl_add(cnt);
+        uint32_t idx = icarry + ic - cnt;
+        icarry += lane63(ic);
+        const uint32_t im = wave_incl_max(lm);
+        const uint32_t m = umax(wave_shr1(im, 0u), mcarry);         // last start before this lane, position + 1 (0: none in the tile yet)
+        mcarry = umax(mcarry, lane63(im));
+        if (EMIT) {
+            uint32_t rel = m - p0 - 1u;
+            uint32_t addr[8], cntv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                addr[k] = lshl1_add(idx, pair_m1);
+                cntv[k] = static_cast<uint32_t>(k) - rel;
+                rel = st[k] ? static_cast<uint32_t>(k) : rel;
+                add_pred(idx, sm[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) store_pair_if(sm[k], addr[k], cntv[k], d[k]);
+        }
+    }
+    first_change = first;
+    last_change = lcarry ? lcarry - kBias : 0u;
+    n_starts = icarry;
+    last_start = mcarry;
+    return true;
+}
+
 // One tile, one wave: the loop of the block encoder's general path with carries that may come from other tiles.
 // EMIT = false: the tile's summary.  EMIT = true: the tile's pairs into its 4 KiB slot of the pair scratch.
 // PRE (summary pass of fp16 sources): a tile the fast path takes is EMITTED already here -- its pairs depend on nothing outside
@@ -1123,11 +1229,13 @@ __device__ __forceinline__ uint64_t tc_look_back(const uint64_t* status, uint64_
     }
 }
 
+// (amdgpu_waves_per_eu: with the out-of-line SPLIT tile path in it the kernel ran a quarter slower on tensors that never call it
+//  -- same instructions, other registers -- until the compiler was told to aim at 8 waves per SIMD: two workgroups per CU)
 template <int MODE, bool F32>
-__global__ __launch_bounds__(64 * kTfWaves) void k_tc_fused(const void* __restrict__ src, uint64_t n, const uint32_t* __restrict__ absmax_bits,
+__global__ __launch_bounds__(64 * kTfWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tc_fused(const void* __restrict__ src, uint64_t n, const uint32_t* __restrict__ absmax_bits,
                                                             uint64_t n_tiles, uint64_t* __restrict__ w1, uint64_t* __restrict__ w2,
                                                             uint32_t* __restrict__ ticket, uint8_t* __restrict__ out,
-                                                            float* __restrict__ out_scale, uint64_t* __restrict__ out_bytes)
+                                                            float* __restrict__ out_scale, uint64_t* __restrict__ out_bytes, uint32_t no_split)
 {
     constexpr uint32_t kSlot = kTcLead + 2 * kTile + 16;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kTfWaves * kSlot];
@@ -1193,10 +1301,12 @@ __global__ __launch_bounds__(64 * kTfWaves) void k_tc_fused(const void* __restri
         }
     };
     // ---- local pass: whole aligned fp16 tiles by the 8-elements-per-lane path (its pairs land in LDS), the rest element-wise
-    bool fast = false;
+    bool fast = false, split = false;
     uint32_t own_runs = 0;                                              // run starts at or behind the tile's first stretch start
+    const bool tile_fast_ok = !F32 && len == kTile && ((reinterpret_cast<uintptr_t>(src) + 2ull * t0) & 15u) == 0u && !kTcNoFast;
+    const bool getenv_no_split = no_split != 0u;                        // (SPECKV_TC_NO_SPLIT_TILES: the element-wise loop for long stretches, A/B and tests)
     if (valid) {
-        if (!F32 && len == kTile && ((reinterpret_cast<uintptr_t>(src) + 2ull * t0) & 15u) == 0u && !kTcNoFast) {
+        if (tile_fast_ok) {
             uint32_t f_first = 0, f_last = 0, f_n = 0;
             if (tc_tile_fast<MODE, true>(static_cast<const uint8_t*>(src) + 2ull * t0, scale, 1.0f / scale, qtail0, t0 == 0u ? 0x100u : dtail0, pair_addr - 1u, lane,
                                          f_first, f_last, f_n)) {
@@ -1204,7 +1314,16 @@ __global__ __launch_bounds__(64 * kTfWaves) void k_tc_fused(const void* __restri
                 fast = true;
             }
         }
-        if (!fast) { general(false, 0u); own_runs = icarry; }
+        // long stretches: the SPLIT form's summary (the head in front of the first change is counted by arithmetic below)
+        if (!fast && tile_fast_ok && !getenv_no_split) {
+            uint32_t f_first = 0, f_last = 0, f_n = 0, f_m = 0;
+            if (tc_tile_split<MODE, false>(static_cast<const uint8_t*>(src) + 2ull * t0, scale, 1.0f / scale, qtail0, t0 == 0u ? 0x100u : dtail0, pair_addr - 1u, lane,
+                                           false, 0u, f_first, f_last, f_n, f_m)) {
+                first_ss = f_first; scarry = f_last; mcarry = f_m; own_runs = f_n;
+                split = true;
+            }
+        }
+        if (!fast && !split) { general(false, 0u); own_runs = icarry; }
     }
     const uint32_t last_ss = scarry;                                    // last stretch start of the tile (rel + 1, 0 = none)
     // ---- chain 1: the stretch start entering each tile
@@ -1231,9 +1350,18 @@ __global__ __launch_bounds__(64 * kTfWaves) void k_tc_fused(const void* __restri
     uint32_t head_runs = 0;
     if (valid && tile && head_len) head_runs = (lead_phase + head_len - 1u) / 255u - (lead_phase ? (lead_phase - 1u) / 255u : 0u) + (lead_phase ? 0u : 1u);
     uint32_t n_runs = head_runs + own_runs;
-    if (valid && (!fast || head_runs)) {                                // the pairs of this tile by the element-wise loop
-        general(true, lead_phase);
-        n_runs = icarry;
+    if (valid && (!fast || head_runs)) {                                // the pairs of this tile once more, now that the entering phase is known
+        bool done = false;
+        if (tile_fast_ok && (fast || split) && !getenv_no_split) {       // ... by the SPLIT form (head and own runs in one pass)
+            uint32_t f_first = 0, f_last = 0, f_n = 0, f_m = 0;
+            done = tc_tile_split<MODE, true>(static_cast<const uint8_t*>(src) + 2ull * t0, scale, 1.0f / scale, qtail0, t0 == 0u ? 0x100u : dtail0, pair_addr - 1u, lane,
+                                             tile != 0u, lead_phase, f_first, f_last, f_n, f_m);
+            if (done) { n_runs = f_n; mcarry = f_m; }
+        }
+        if (!done) {                                                     // ... or element by element
+            general(true, lead_phase);
+            n_runs = icarry;
+        }
     }
     // ---- chain 2: run starts in front of each tile
     if (lane == 0u) s_runs[wave] = valid ? n_runs : 0u;
@@ -1945,7 +2073,8 @@ hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, u
         uint64_t* w1 = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(d_ws) + 512);
         uint64_t* w2 = w1 + tf_wgs;
         const uint32_t g = static_cast<uint32_t>(tf_wgs);
-#define SPECKV_TF(MODE, F32) hipLaunchKernelGGL((k_tc_fused<MODE, F32>), dim3(g), dim3(64 * kTfWaves), 0, s, d_src, n, absmax, tiles, w1, w2, ticket, d_rle, d_scale, d_rle_bytes)
+        const uint32_t no_split = getenv("SPECKV_TC_NO_SPLIT_TILES") ? 1u : 0u;
+#define SPECKV_TF(MODE, F32) hipLaunchKernelGGL((k_tc_fused<MODE, F32>), dim3(g), dim3(64 * kTfWaves), 0, s, d_src, n, absmax, tiles, w1, w2, ticket, d_rle, d_scale, d_rle_bytes, no_split)
         if (quant_mode == kIntent) { if (src_f32) SPECKV_TF(kIntent, true); else SPECKV_TF(kIntent, false); }
         else                       { if (src_f32) SPECKV_TF(kRefExact, true); else SPECKV_TF(kRefExact, false); }
 #undef SPECKV_TF

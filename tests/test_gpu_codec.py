@@ -527,7 +527,7 @@ def test_tensor_codec_golden_reference_vectors(lib, golden_dir):
         assert_same_float_bits(y, want, f"malformed{i}")
 
 
-@pytest.mark.parametrize("form", ["single_pass", "one_pass_decoder", "grids", "per_element_expand", "wg", "serial", "no_pre"])
+@pytest.mark.parametrize("form", ["single_pass", "no_split_tiles", "one_pass_decoder", "grids", "per_element_expand", "wg", "serial", "no_pre"])
 def test_tensor_codec_scan_forms(lib, oracle, form):
     """Compress exists as ONE pass with look-back across workgroups (k_tc_fused, the default since round 4) and as the
     multi-launch form (SPECKV_TC_MULTIPASS) whose scans across tiles come in three shapes -- grids of one wave per step, one
@@ -541,6 +541,8 @@ def test_tensor_codec_scan_forms(lib, oracle, form):
         os.environ["SPECKV_TC_MULTIPASS"] = "1"
     elif form == "per_element_expand":                               # the multi-launch decoder with the expand loop of rounds 2-3
         os.environ["SPECKV_TC_MULTIPASS"] = "1"; os.environ["SPECKV_TD_EXPAND_PER_ELEMENT"] = "1"
+    elif form == "no_split_tiles":                                   # the one-pass compressor with the element-wise loop for long stretches
+        os.environ["SPECKV_TC_NO_SPLIT_TILES"] = "1"
     elif form == "one_pass_decoder":                                 # the one-pass decoder also for streams of few pairs
         os.environ["SPECKV_TD_ONE_PASS"] = "1"
     elif form != "single_pass":
@@ -568,6 +570,7 @@ def test_tensor_codec_scan_forms(lib, oracle, form):
         os.environ.pop("SPECKV_TC_MULTIPASS", None)
         os.environ.pop("SPECKV_TD_EXPAND_PER_ELEMENT", None)
         os.environ.pop("SPECKV_TD_ONE_PASS", None)
+        os.environ.pop("SPECKV_TC_NO_SPLIT_TILES", None)
 
 
 def test_tensor_codec_look_back_over_many_workgroups(lib, oracle):
