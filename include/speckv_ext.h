@@ -242,6 +242,9 @@ speckv_status_t speckv_ext_codec_decompress(const void* d_recs, uint64_t rec_str
  *                speckv_ext_codec_tensor_decode_workspace_bytes(rle_bytes) bytes
  * Decompress: dst gets min(sum of counts, dst_cap_elems) elements (fp32 or fp16; 16-byte aligned), *d_n_out (device,
  * optional) that number; an odd trailing byte is dropped and a zero count emits nothing, as in the reference.
+ * Pass the tensor's element count as dst_cap_elems when it is known: the library picks its decoder from rle_bytes / 2 pairs
+ * against dst_cap_elems (a stream of one pair per element is decoded in one pass over the pairs, one that compresses tile by
+ * tile of the output); a capacity far above the real count only costs speed, never correctness.
  * Asynchronous on `stream`; no engine needed. */
 size_t speckv_ext_codec_tensor_workspace_bytes(uint64_t n_elems);
 size_t speckv_ext_codec_tensor_decode_workspace_bytes(uint64_t rle_bytes);
