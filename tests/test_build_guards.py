@@ -33,6 +33,9 @@ HOT = [
     ("attend_int4.o", r"k_attend_int4_wgILb1E", 1),
     ("attend_int4.o", r"k_attend_int4_wg8ILi1E", 0),
     ("attend_int4.o", r"k_attend_int4_wg8ILi2E", 0),
+    ("tensor_codec.o", r"k_td_fusedILi\dELb[01]E", 0),                    # the one-pass tensor kernels (their out-of-line fall-backs are not listed)
+    ("tensor_codec.o", r"k_tc_fusedILi\dELb[01]E", 0),
+    ("tensor_codec.o", r"k_td_expand_scatter", 0),
 ]
 
 
