@@ -235,6 +235,69 @@ def test_config4_decode_step_256_sequences_8k_context(eng, oracle, scheme):
         lib.free(hnd)
 
 
+@pytest.mark.parametrize("T", [1024, 2048])
+@pytest.mark.parametrize("scheme", [3, 4])
+def test_short_context_decode_step_256_sequences(eng, oracle, scheme, T):
+    """The same decode step at SHORT contexts (256 sequences x 1k / 2k positions, one layer each): the shapes where a launch's
+    fixed part weighs most and the batch forms differ most from the long-context ones (INT4: the two-halves workgroups with 16- and
+    32-tile halves; FP8: whole sequences per workgroup, the first tile requested in front of the query).  Lengths from empty to
+    full with ragged ends; batch and planned forms against the oracle on sampled sequences (rotating sample)."""
+    torch = torch_mod()
+    lib = eng.lib
+    L, NSEQ = 1, 256
+    lib.set_compression_scheme(scheme)
+    seed = sample_seed()
+    srng = np.random.default_rng(seed)
+    rng = np.random.default_rng(3000 + T)
+    lens = [T] * NSEQ
+    for i, n in ((3, 0), (9, 2), (17, T - 2), (40, T // 2 + 2), (77, 34), (130, 32), (200, 30), (255, T - 34)):
+        lens[i] = n
+    for i in range(100, 120):
+        lens[i] = int(rng.integers(1, T // 2)) * 2
+    sampled = {i: None for i in [17, 40, 77, 111, 255] + [int(v) for v in srng.choice([j for j in range(NSEQ) if j not in (3, 9, 17, 40, 77, 111, 255)], 3, replace=False)]}
+    check_heads = tuple(int(v) for v in srng.choice(H, 2, replace=False))
+    handles = []
+    n_pages = T * L * H * D * 2 * 2 // PAGE
+    for i in range(NSEQ):
+        hnd = lib.alloc(n_pages * PAGE)
+        lib.set_layout(hnd, T, L, H, D, 2)
+        x = synth_pages(torch, 3000_000 + 7 * T + i, n_pages)
+        lib.write(hnd, 0, x.data_ptr(), x.numel() * 2, True)
+        if i in sampled:
+            sampled[i] = x.cpu().numpy()                         # layer 0: its K region then its V region
+        handles.append(hnd)
+        del x
+    gq = torch.Generator(device="cuda"); gq.manual_seed(3000 + T)
+    q = (torch.randn((NSEQ, H, G, D), generator=gq, device="cuda") * 1.5).to(torch.float16)
+    qh = q.cpu().numpy()
+    sm = 1.0 / np.sqrt(D)
+    checkers = {i: HeadChecker(oracle, scheme, pages, T) for i, pages in sampled.items()}
+
+    def check(out, lse, what):
+        assert float(np.abs(out[3]).max()) == 0.0                # the empty sequence
+        for i, c in checkers.items():
+            for head in check_heads:
+                c.check(out[i, head], lse[i, head], qh[i, head], head, lens[i], sm, (what, T, i, head, "sample seed", seed))
+
+    batch = lib.attend_int4_batch if scheme == 3 else lib.attend_fp8_batch
+    out = torch.full((NSEQ, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
+    lse = torch.full((NSEQ, H, G), float("nan"), dtype=torch.float32, device="cuda")
+    batch(handles, 0, q.data_ptr(), G, lens, sm, out.data_ptr(), lse.data_ptr())
+    torch.cuda.synchronize()
+    check(out.cpu().numpy(), lse.cpu().numpy(), "batch")
+    st = torch.cuda.Stream()
+    plan_bytes = lib.attend_plan_bytes(NSEQ)
+    d_plan = torch.empty(plan_bytes, dtype=torch.uint8, device="cuda")
+    out.fill_(float("nan")); lse.fill_(float("nan"))
+    torch.cuda.synchronize()
+    lib.attend_batch_plan(handles, lens, T, d_plan.data_ptr(), plan_bytes, st.cuda_stream)
+    lib.attend_planned(scheme, d_plan.data_ptr(), NSEQ, 0, q.data_ptr(), G, T, sm, out.data_ptr(), lse.data_ptr(), st.cuda_stream)
+    torch.cuda.synchronize()
+    check(out.cpu().numpy(), lse.cpu().numpy(), "planned")
+    for hnd in handles:
+        lib.free(hnd)
+
+
 def test_config2_all_131072_blocks_against_the_oracle(eng, oracle):
     """BASELINE configs[1]: the 8B-shaped round trip, every one of its 131 072 blocks checked against the C oracle
     (record lengths, scale bits through the page table on a sample, decoded bits of ALL blocks) -- INT8_DELTA_RLE in
