@@ -1969,11 +1969,23 @@ __global__ __launch_bounds__(256) void k_td_expand_scatter(const uint8_t* __rest
             const unsigned long long hm = __ballot(has != 0u);
             if (hm) dm1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cov), 63 - __builtin_clzll(hm)));
         }
+        if (tot >= 0 && tot + step_c <= static_cast<int32_t>(valid)) {      // (wave-uniform) every pair of the step starts inside the tile: plain addresses
+            uint32_t ad = tab_addr + static_cast<uint32_t>(a);
+            td_lds_b8(ad, dd[0]); ad = td_add_b1(ad, w[0]);
+            td_lds_b8(ad, dd[1]); ad = td_add_b3(ad, w[0]);
+            td_lds_b8(ad, dd[2]); ad = td_add_b1(ad, w[1]);
+            td_lds_b8(ad, dd[3]); ad = td_add_b3(ad, w[1]);
+            td_lds_b8(ad, dd[4]); ad = td_add_b1(ad, w[2]);
+            td_lds_b8(ad, dd[5]); ad = td_add_b3(ad, w[2]);
+            td_lds_b8(ad, dd[6]); ad = td_add_b1(ad, w[3]);
+            td_lds_b8(ad, dd[7]);                                         // (pairs behind the stream's end: count 0, they land on the byte behind the last element)
+        } else {
 #pragma unroll
-        for (uint32_t e = 0; e < 8u; ++e) {
-            const uint32_t off = static_cast<uint32_t>(a) < valid ? static_cast<uint32_t>(a) : kTile;      // in front of / behind the tile: the spare byte
-            td_lds_b8(tab_addr + off, dd[e]);
-            a += static_cast<int32_t>((w[e >> 1] >> (8u + 16u * (e & 1u))) & 0xFFu);
+            for (uint32_t e = 0; e < 8u; ++e) {
+                const uint32_t off = static_cast<uint32_t>(a) < valid ? static_cast<uint32_t>(a) : kTile;  // in front of / behind the tile: the spare byte
+                td_lds_b8(tab_addr + off, dd[e]);
+                a += static_cast<int32_t>((w[e >> 1] >> (8u + 16u * (e & 1u))) & 0xFFu);
+            }
         }
         tot += step_c;
         tail = last_dw;
