@@ -450,7 +450,7 @@ def main():
                 "avg_launch_ms": round(kern_ms, 4),
                 "frac_as_called": variants["as_called"]["frac_hbm"],
                 "avg_launch_ms_as_called": variants["as_called"]["avg_launch_ms"],
-                "launches": {"kernel_instance": f"k_fetch_decompress<{args.scheme}, {args.quant}, false, 0, false>",
+                "launches": {"kernel_instance": f"k_fetch_decompress<{args.scheme}, {args.quant}, false, 0>",
                              **{k: v["launches"] for k, v in variants.items()},
                              "note": "0-based indices of this instance's dispatches in this process, in dispatch order: "
                                      "profiles/summarize_r04.py averages the same dispatches in the rocprofv3 kernel trace"},

@@ -298,6 +298,34 @@ __device__ __forceinline__ bool decode_rle_fast(const uint8_t* __restrict__ rec,
     if (!ok) return false;
     wave_lds_fence();
 
+    if (FLAT && npairs <= 256u) {                            // (wave-uniform)
+        // The whole block piecewise constant on 8-element boundaries: every lane's table bytes are (+d, -d, 0 x 6) in all four
+        // chunks.  Then no slope enters any lane (each lane's bytes sum to 0), a lane's eight elements are ONE value, and that
+        // value is the inclusive prefix sum of the +d bytes: one packed scan per two chunks (fields of 16 bits: 64 x 255 fits),
+        // one conversion and plain 16-byte stores per chunk -- instead of two scans, eight recurrences and eight conversions.
+        // A block that breaks the pattern in any lane takes the loop below (which still tests chunk by chunk).
+        uint2 xs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xs[j] = *reinterpret_cast<const uint2*>(tab + 512u * j + 8u * lane);
+        uint32_t bad = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bad |= (xs[j].x & 0xFFFF0000u) | xs[j].y | ((xs[j].x + (xs[j].x >> 8)) & 0xFFu);
+        if (__builtin_amdgcn_ballot_w64(bad != 0u) == 0ull) {
+            const uint32_t ia = wave_incl_add(__builtin_amdgcn_perm(xs[1].x, xs[0].x, 0x0C040C00u));     // chunk 0 | chunk 1 << 16
+            const uint32_t ib = wave_incl_add(__builtin_amdgcn_perm(xs[3].x, xs[2].x, 0x0C040C00u));     // chunk 2 | chunk 3 << 16
+            const uint32_t ta = lane63(ia), tb = lane63(ib);
+            const uint32_t carry1 = ta & 0xFFFFu, carry2 = carry1 + (ta >> 16), carry3 = carry2 + (tb & 0xFFFFu);
+            const uint32_t qv[4] = {ia, (ia >> 16) + carry1, ib + carry2, (ib >> 16) + carry3};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = dequant<MODE>(static_cast<int>(static_cast<int8_t>(qv[j] & 0xFFu)), scale);
+                const float y8[8] = {v, v, v, v, v, v, v, v};
+                store8<F32>(dst, 512u * j + 8u * lane, y8);
+            }
+            wave_lds_fence();
+            return true;
+        }
+    }
     uint32_t c1 = 0, c2 = 0;    // S1 / S2 at the end of the previous chunk
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -313,18 +341,6 @@ __device__ __forceinline__ bool decode_rle_fast(const uint8_t* __restrict__ rec,
         const uint32_t x2 = c2 + i2 - u;                    // S2 entering this lane
         c1 += lane63(i1);
         c2 += lane63(i2);
-        if (FLAT && npairs <= 256u) {                        // (wave-uniform)
-            // Piecewise-constant data on 8-element boundaries (a constant run enters the table as +d at its first element and
-            // -d at the next): every lane's eight elements are ONE value -- entering slope 0, bytes 2..7 empty, byte 1 = -byte 0
-            // -- so one conversion and plain 16-byte stores of it instead of eight recurrences and conversions.
-            const bool flat = (x1 & 0xFFu) == 0u && (x.x & 0xFFFF0000u) == 0u && x.y == 0u && ((x.x + (x.x >> 8)) & 0xFFu) == 0u;
-            if (__builtin_amdgcn_ballot_w64(!flat) == 0ull) {
-                const float v = dequant<MODE>(static_cast<int>(static_cast<int8_t>((x2 + x1 + (x.x & 0xFFu)) & 0xFFu)), scale);
-                const float y8[8] = {v, v, v, v, v, v, v, v};
-                store8<F32>(dst, p0, y8);
-                continue;
-            }
-        }
         uint32_t s1 = x1, s2 = x2;
         uint32_t q[8];
         s1 = add_byte<0>(s1, x.x, x.y); s2 += s1; q[0] = s2;
@@ -584,8 +600,8 @@ __device__ __forceinline__ void ring_note(const CodecArgs& a, const BlockDesc& d
     atomicOr(&t.d_flags[d.page], 2u);
 }
 
-template <int SCHEME, int MODE, bool F32, int EXT, bool FLAT = false>
-__global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
+template <int SCHEME, int MODE, bool F32, int EXT, bool FLAT>
+__device__ __forceinline__ void fetch_decompress_body(const CodecArgs& a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[SCHEME == kInt8DeltaRle ? kWaves * kDecLdsWords : 4];
     const uint32_t lane = threadIdx.x & 63u;
@@ -649,6 +665,17 @@ __global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a)
         }
     }
 }
+template <int SCHEME, int MODE, bool F32, int EXT>
+__global__ __launch_bounds__(kThreads) void k_fetch_decompress(CodecArgs a) { fetch_decompress_body<SCHEME, MODE, F32, EXT, false>(a); }
+// the FLAT instantiation (data known to compress) as a kernel of its own: these launches are store-bound with short waves, and
+// a wave slot more or less per SIMD shows (all-zero blocks 86 us at 8 waves per SIMD, 93 us at 7: the compiler is told to stay at 8)
+template <int MODE>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fetch_decompress_flat(CodecArgs a)
+{
+    fetch_decompress_body<kInt8DeltaRle, MODE, false, 0, true>(a);
+}
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void k_fetch_decompress_flat_f32(CodecArgs a) { fetch_decompress_body<kInt8DeltaRle, MODE, true, 0, true>(a); }
 
 // ===================================================================
 // RLE encode of the delta stream (cache_engine.cpp:198-239)
@@ -2242,8 +2269,8 @@ hipError_t launch_dec2(const CodecArgs& a_in, hipStream_t s)
 #define SPECKV_LAUNCH_DEC(F32, EXT) \
     hipLaunchKernelGGL((k_fetch_decompress<SCHEME, MODE, F32, EXT>), dim3(grid), dim3(kThreads), 0, s, a)
     if (SCHEME == kInt8DeltaRle && a.structured_hint && ext == 0) {      // data known to compress: the FLAT instantiation (plain form only)
-        if (a.out_f32) hipLaunchKernelGGL((k_fetch_decompress<SCHEME, MODE, true, 0, SCHEME == kInt8DeltaRle>), dim3(grid), dim3(kThreads), 0, s, a);
-        else           hipLaunchKernelGGL((k_fetch_decompress<SCHEME, MODE, false, 0, SCHEME == kInt8DeltaRle>), dim3(grid), dim3(kThreads), 0, s, a);
+        if (a.out_f32) hipLaunchKernelGGL((k_fetch_decompress_flat_f32<MODE>), dim3(grid), dim3(kThreads), 0, s, a);
+        else           hipLaunchKernelGGL((k_fetch_decompress_flat<MODE>), dim3(grid), dim3(kThreads), 0, s, a);
         return hipGetLastError();
     }
     if (a.out_f32) { if (ext == 2) SPECKV_LAUNCH_DEC(true, 2); else if (ext == 1) SPECKV_LAUNCH_DEC(true, 1); else SPECKV_LAUNCH_DEC(true, 0); }

@@ -22,6 +22,7 @@ OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 # (object, kernel name pattern, flat instructions allowed)
 HOT = [
     ("kernels.o", r"k_fetch_decompressILi\dELi\dELb[01]ELi[01]E", 0),      # plain and extension-1 forms of every scheme (EXT 2 / 3: the flush forms keep two bookkeeping accesses)
+    ("kernels.o", r"k_fetch_decompress_flat", 0),                           # the kernel of launches hinted "structured" (fp16 and fp32 outputs)
     ("kernels.o", r"k_compressILi[0134]ELi\dE", 0),
     ("kernels.o", r"k_compressILi2ELi\dE", 1),                              # (one tail store of the RLE record)
     ("attend.o", r"k_attend_fp8_linearILb0E", 0),

@@ -333,8 +333,13 @@ def test_structured_hint_decoder_is_bit_identical(lib, oracle, mode):
     grid, runs of 7, noise, short malformed records -- fp16 and fp32 outputs."""
     rng = np.random.default_rng(404)
     blocks = []
-    for run in (32, 8, 64, 256, 2048):
+    for run in (32, 8, 16, 64, 128, 256, 2048):
         blocks.append(np.repeat(rng.standard_normal(N // run), run))
+    for run in (16, 32):                                                       # large jumps: the int8 prefix wraps many times inside a chunk
+        blocks.append(np.repeat(rng.choice([-3.0, 3.0, -2.5, 2.9], N // run) + 0.01 * rng.standard_normal(N // run), run))
+    for chunk in range(4):                                                     # flat everywhere but in one 512-element chunk
+        b = np.repeat(rng.standard_normal(N // 32), 32); b[512 * chunk + 100:512 * chunk + 103] = (0.7, -0.4, 0.2)
+        blocks.append(b)
     blocks.append(np.zeros(N))
     off = np.repeat(rng.standard_normal(N // 32 + 1), 32)[5:5 + N]            # runs of 32 that start 5 elements late
     blocks.append(off)
