@@ -245,9 +245,9 @@ __device__ __forceinline__ bool rle_pair_chunk(const uint4 wv, uint32_t pair0, u
 // `trusted` (wave-uniform): the stream comes from k_compress -- no zero counts, and the
 // bytes between len and the next 16-byte boundary are zero pairs, which scatter into
 // the dummy byte; every chunk then takes the unmasked, unchecked form.
-// FLAT (a separate instantiation, chosen per LAUNCH for data that is known to compress: CodecArgs::structured_hint; the
-// instantiation the headline fetch runs is not touched): piecewise-constant blocks whose runs sit on 8-element boundaries
-// skip the eight recurrences and conversions of a lane -- see the second loop.
+// FLAT (the kernel of its own that launches hinted "structured" run, k_fetch_decompress_flat: CodecArgs::structured_hint; the
+// kernels the headline fetch runs are instantiated without it): blocks that are piecewise constant on 8-element boundaries
+// skip the scans, recurrences and conversions of the general loop -- see the whole-block path in front of it.
 template <int MODE, bool F32, bool FLAT = false>
 __device__ __forceinline__ bool decode_rle_fast(const uint8_t* __restrict__ rec, uint32_t len,
                                                 float scale, uint8_t* __restrict__ dst,
@@ -303,7 +303,7 @@ __device__ __forceinline__ bool decode_rle_fast(const uint8_t* __restrict__ rec,
         // chunks.  Then no slope enters any lane (each lane's bytes sum to 0), a lane's eight elements are ONE value, and that
         // value is the inclusive prefix sum of the +d bytes: one packed scan per two chunks (fields of 16 bits: 64 x 255 fits),
         // one conversion and plain 16-byte stores per chunk -- instead of two scans, eight recurrences and eight conversions.
-        // A block that breaks the pattern in any lane takes the loop below (which still tests chunk by chunk).
+        // A block that breaks the pattern in any lane takes the general loop below.
         uint2 xs[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) xs[j] = *reinterpret_cast<const uint2*>(tab + 512u * j + 8u * lane);
