@@ -1510,6 +1510,10 @@ def run_extras(torch, pkg, lib, src, dst, n_blocks, sp):
     recs = torch.empty((n_blocks, PAGE), dtype=torch.uint8, device="cuda")
     lens = torch.empty(n_blocks, dtype=torch.int32, device="cuda")
     scales = torch.empty(n_blocks, dtype=torch.float32, device="cuda")
+    try:
+        dst32 = torch.empty((n_blocks, BLOCK_ELEMS), dtype=torch.float32, device="cuda")
+    except Exception:                                                    # noqa: BLE001  (no room beside the other buffers: the figure is skipped)
+        dst32 = None
 
     def timed(fn, reps=10):
         fn(); torch.cuda.synchronize()
@@ -1528,6 +1532,10 @@ def run_extras(torch, pkg, lib, src, dst, n_blocks, sp):
         comp = int(lens.to(torch.int64).sum().item())
         dec_bytes = comp + n_blocks * ((0 if scheme == 3 else 4) + PAGE)
         enc_bytes = n_blocks * PAGE + comp + n_blocks * 8
+        # the same blocks decoded to fp32, the reference's own output type (FPGACacheEngine::decompress returns floats): 8 KiB written per block
+        if dst32 is not None:
+            dec32 = lambda: raw.speckv_ext_codec_decompress(recs.data_ptr(), stride, lens.data_ptr(), scales.data_ptr(), n_blocks, dst32.data_ptr(), 1, scheme, mode, sp)
+            dec32_ms = timed(dec32)
         ex[name] = {
             "decompress_blocks_per_s": round(n_blocks / (dec_ms * 1e-3), 1),
             "decompress_GBps": round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1),
@@ -1536,6 +1544,9 @@ def run_extras(torch, pkg, lib, src, dst, n_blocks, sp):
             "compress_GBps": round(enc_bytes / (enc_ms * 1e-3) / 1e9, 1),
             "record_bytes_per_block": round(comp / n_blocks, 1),
         }
+        if dst32 is not None:
+            ex[name]["decompress_fp32_out_frac_hbm"] = round((dec_bytes + n_blocks * PAGE) / (dec32_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+    del dst32
     # SURVEY 8d structured sets that exercise the RLE stage itself: all-zero blocks (one run per 255 elements) and
     # piecewise-constant blocks (runs of 32), INT8_DELTA_RLE, reference quantiser
     g = torch.Generator(device="cuda"); g.manual_seed(77)
