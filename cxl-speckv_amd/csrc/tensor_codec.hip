@@ -1871,6 +1871,7 @@ __global__ __launch_bounds__(256) void k_td_expand_scatter(const uint8_t* __rest
                                                           uint64_t n_chunks, const uint64_t* __restrict__ n_out_p, float scale, uint8_t* __restrict__ dst)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tabs[4][kTile + 16];      // (+16: bytes that may be written and are never read)
+    __shared__ __attribute__((aligned(16))) uint8_t stage[4][F32 ? 2048 : 16];   // fp32 output: the step's values on their way to whole-KiB stores
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t n_out = *n_out_p;
     const uint64_t o0 = (static_cast<uint64_t>(blockIdx.x) * 4u + wave) * kTile;
@@ -2007,7 +2008,7 @@ __global__ __launch_bounds__(256) void k_td_expand_scatter(const uint8_t* __rest
         const uint32_t x2 = c2 + i2 - u;
         c1 += lane63(i1);
         c2 += lane63(i2);
-        if (p0 >= valid) continue;
+        if (!F32 && p0 >= valid) continue;                               // (fp32: the lane may have to store a neighbour's values, below)
         uint32_t s1 = x1, s2 = x2;
         uint32_t q[8];
         s1 = td_add_byte<0>(s1, x.x, x.y); s2 += s1; q[0] = s2;
@@ -2021,13 +2022,28 @@ __global__ __launch_bounds__(256) void k_td_expand_scatter(const uint8_t* __rest
         float y[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) y[e] = dequant<MODE>(static_cast<int>(static_cast<int8_t>(q[e] & 0xFFu)), scale);
+        if (F32) {
+            // fp32: a lane's eight values are 32 bytes; stored from the lane, every instruction of the wave would write half of each
+            // 64-byte sector (the block decoders lost two thirds of their rate that way: kernels.hip store8_f32).  Through 2 KiB of
+            // LDS instead: written per lane, read back 16 bytes x 64 lanes in a row -- one contiguous KiB per store instruction.
+            // Piece t of the step (16 bytes) holds half of lane t / 2's group and goes out only if that group is whole.
+            typedef float f32x4v __attribute__((ext_vector_type(4)));
+            f32x4v* stg = reinterpret_cast<f32x4v*>(stage[wave]);
+            wave_lds_fence();
+            stg[2u * lane] = f32x4v{y[0], y[1], y[2], y[3]};
+            stg[2u * lane + 1u] = f32x4v{y[4], y[5], y[6], y[7]};
+            wave_lds_fence();
+            const f32x4v a4 = stg[lane], b4 = stg[64u + lane];
+            float* ob = reinterpret_cast<float*>(dst) + o0 + 512u * j;
+            const uint32_t g0 = 512u * j + 8u * (lane >> 1), g1 = g0 + 256u;       // first element of the groups the two pieces belong to
+            if (g0 + 8u <= valid) __builtin_nontemporal_store(a4, reinterpret_cast<f32x4v*>(ob + 4u * lane));
+            if (g1 + 8u <= valid) __builtin_nontemporal_store(b4, reinterpret_cast<f32x4v*>(ob + 256u + 4u * lane));
+            if (p0 < valid && p0 + 8u > valid)
+                for (uint32_t e = 0; e < 8u && p0 + e < valid; ++e) reinterpret_cast<float*>(dst)[o0 + p0 + e] = y[e];
+            continue;
+        }
         if (p0 + 8u <= valid) {
-            if (F32) {
-                float* op = reinterpret_cast<float*>(dst) + o0 + p0;
-                typedef float f32x4v __attribute__((ext_vector_type(4)));
-                __builtin_nontemporal_store(f32x4v{y[0], y[1], y[2], y[3]}, reinterpret_cast<f32x4v*>(op));
-                __builtin_nontemporal_store(f32x4v{y[4], y[5], y[6], y[7]}, reinterpret_cast<f32x4v*>(op + 4));
-            } else {
+            {
                 const u32x4 pk = {pack_half2(y[0], y[1]), pack_half2(y[2], y[3]), pack_half2(y[4], y[5]), pack_half2(y[6], y[7])};
                 __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(dst) + o0 + p0));
             }
