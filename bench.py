@@ -1316,6 +1316,24 @@ def tensor_codec_extra(torch, lib, n=131072 * 256):
             b.record(s); torch.cuda.synchronize()
             ms = a.elapsed_time(b) / 5
             out[name] = {"ms": round(ms, 4), "algorithmic_GBps": round(byt / (ms * 1e-3) / 1e9, 1), "frac_hbm": round(byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        if n <= 64 * 2**20:                                              # the reference's own types at the boundary: float in, float out
+            x32 = x.to(torch.float32); y32 = torch.empty(n, dtype=torch.float32, device="cuda")
+
+            def enc32():
+                assert raw.speckv_ext_codec_compress_tensor(x32.data_ptr(), n, 1, rle.data_ptr(), meta.data_ptr(), meta.data_ptr() + 8, wsp, ws_bytes, 0, s.cuda_stream) == 0
+
+            def dec32():
+                assert raw.speckv_ext_codec_decompress_tensor(rle.data_ptr(), size, scale, y32.data_ptr(), n, 1, meta.data_ptr() + 16, dwsp, dws_bytes, 0, s.cuda_stream) == 0
+            for name, fn, byt in (("compress_fp32_source", enc32, 4 * n + size), ("decompress_fp32_output", dec32, size + 4 * n)):
+                fn(); torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(s)
+                for _ in range(5):
+                    fn()
+                b.record(s); torch.cuda.synchronize()
+                ms = a.elapsed_time(b) / 5
+                out[name] = {"ms": round(ms, 4), "frac_hbm": round(byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+            del x32, y32
         out["note"] = ("any n, exact.  Compress: an abs-max pass, then ONE pass that encodes whole fp16 tiles by the block encoder's "
                        "8-elements-per-lane path and places them in the stream by look-back across workgroups (two reads of the source, one "
                        "write of the stream); decompress: ONE pass (a chunk of 2048 pairs per wave, one byte scattered per run, look-back across "
