@@ -1757,6 +1757,31 @@ __device__ __forceinline__ void td_window_store(const uint8_t* tab, uint32_t wo,
             y[e] = dequant<MODE>(static_cast<int>(static_cast<int8_t>(b)), scale);
         }
         const uint64_t o = obase + static_cast<uint64_t>(q0);
+#ifndef SPECKV_TD_F32_PER_LANE
+        if (F32) {
+            // fp32: a lane's group is 32 bytes, so stores from the lane write half of every 64-byte sector per instruction
+            // (kernels.hip store8_f32).  The four lanes of a quad hold 128 contiguous bytes: exchanged inside the quad (DPP
+            // quad_perm, no LDS -- this kernel has none to spare) so that each of the two store instructions writes a whole sector.
+            const int32_t qb = static_cast<int32_t>(g0 + 8u * (lane & ~3u));     // the quad's first element, group-relative
+            if (qb >= lo_i && qb + 32 <= hi_i) {                            // (uniform within the quad: all four groups are whole)
+                const bool odd = (lane & 1u) != 0u;
+                typedef float f32x4v __attribute__((ext_vector_type(4)));
+                f32x4v s1, s2;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t lo_b = __float_as_uint(y[k]), hi_b = __float_as_uint(y[4 + k]);
+                    const uint32_t a1 = dpp<0x50>(0u, lo_b), b1 = dpp<0x50>(0u, hi_b);          // quad_perm [0,0,1,1]
+                    const uint32_t a2 = dpp<0xFA>(0u, lo_b), b2 = dpp<0xFA>(0u, hi_b);          // quad_perm [2,2,3,3]
+                    s1[k] = __uint_as_float(odd ? b1 : a1);
+                    s2[k] = __uint_as_float(odd ? b2 : a2);
+                }
+                float* qa = reinterpret_cast<float*>(dst) + obase + static_cast<uint64_t>(qb) + 4u * (lane & 3u);
+                __builtin_nontemporal_store(s1, reinterpret_cast<f32x4v*>(qa));
+                __builtin_nontemporal_store(s2, reinterpret_cast<f32x4v*>(qa + 16));
+                continue;
+            }
+        }
+#endif
         if (q0 >= lo_i && q0 + 8 <= hi_i) {
             if (F32) {
                 float* op = reinterpret_cast<float*>(dst) + o;
