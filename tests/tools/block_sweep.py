@@ -1,7 +1,7 @@
 """A randomised sweep of the BLOCK codec's RLE scheme against the CPU oracle (test infrastructure): blocks made of random pieces --
 noise, constants, ramps with equal quantised steps, zeros, sparse noise, runs of every length from 1 to 2048 at random phases -- so
 that stretches of equal deltas end, begin and split (every 255 elements) at random places against the 8-element lanes and the
-512-element chunks of the encoder; both quantiser modes; records byte for byte, lengths, scales, decoded bits.
+512-element chunks of the encoder; both quantiser modes; records byte for byte, lengths, scales, decoded bits (fp16; the flat-run kernel; fp32 outputs, sampled against the oracle).
     python tests/tools/block_sweep.py [rounds=20] [blocks_per_round=4096]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -44,5 +44,14 @@ for r in range(rounds):
         assert bad[0].size == 0, (r, mode, bad[0][:5], bad[1][:5])
         y = gpu_decompress(lib, recs, lens, scales, 2, mode)
         assert_same_float_bits(y, oracle.decompress_blocks_f16(o_recs, o_lens, o_scales, 2, mode), f"round {r} mode {mode}")
+        # the flat-run kernel (SPECKV_CODEC_HINT_STRUCTURED) and the fp32 outputs: the same values
+        assert_same_float_bits(gpu_decompress(lib, recs, lens, scales, 2, mode | 0x100), y, f"round {r} mode {mode} hinted")
+        y32 = gpu_decompress(lib, recs, lens, scales, 2, mode, True)
+        assert_same_float_bits(gpu_decompress(lib, recs, lens, scales, 2, mode | 0x100, True), y32, f"round {r} mode {mode} hinted fp32")
+        for b in rng.integers(0, B, 24):
+            want = np.zeros(N, np.float32)
+            got = oracle.decompress_block_f32(o_recs[b, :o_lens[b]], o_scales[b], 2, mode, N)
+            want[:got.size] = got
+            assert_same_float_bits(y32[b], want, f"round {r} mode {mode} block {b} fp32")
     if r % 5 == 4: print(f"round {r} ok, {(r + 1) * B} blocks, {time.time() - t0:.1f} s", flush=True)
 print(f"block sweep clean: {rounds} rounds, {rounds * B} blocks")
