@@ -47,7 +47,7 @@ class Oracle:
     """Thin numpy front-end over libspeckv_oracle.so."""
 
     REF_EXACT, INTENT = 0, 1
-    FP16, INT8, INT8_DELTA_RLE, INT4_G32, FP8_E4M3 = 0, 1, 2, 3, 4
+    FP16, INT8, INT8_DELTA_RLE, INT4_G32, FP8_E4M3, MXFP4 = 0, 1, 2, 3, 4, 5
 
     def __init__(self, path=None):
         path = path or ORACLE_SO
@@ -110,6 +110,12 @@ class Oracle:
             "orc_coh_get_statistics": (None, [C.c_void_p, u64p]),
             "orc_coh_reset_statistics": (None, [C.c_void_p]),
             "orc_quantize_rows_e4m3": (None, [u16p, C.c_size_t, C.c_size_t, u8p, f32p]),
+            "orc_f32_to_e2m1": (C.c_uint8, [C.c_float]),
+            "orc_e2m1_to_f32": (C.c_float, [C.c_uint8]),
+            "orc_mx_scale_code": (C.c_uint8, [C.c_float, C.c_int]),
+            "orc_e8m0_to_f32": (C.c_float, [C.c_uint8]),
+            "orc_quantize_rows_mxfp8": (None, [u16p, C.c_size_t, C.c_size_t, u8p, u8p]),
+            "orc_attend_mx4": (None, [u8p, u8p, C.c_size_t, u8p, u8p, u8p, u8p, C.c_size_t, C.c_size_t, C.c_float, f32p, f32p, f32p]),
             "orc_layer_compression_ratio": (C.c_double, [C.c_uint32]),
             "orc_codec_throughput_gbps": (C.c_double, [C.c_size_t, C.c_double, C.c_size_t]),
             "orc_codec_pipeline_latency_cycles": (C.c_size_t, []),

@@ -398,6 +398,145 @@ uint8_t orc_f32_to_e4m3(float f)
     return (uint8_t)(sign | r);
 }
 
+/* ---- MXFP4 (OCP MX v1.0): E2M1 elements, E8M0 block scales ---------------------------------------------------- */
+float orc_e2m1_to_f32(uint8_t nibble)
+{
+    static const float mag[8] = {0.0f, 0.5f, 1.0f, 1.5f, 2.0f, 3.0f, 4.0f, 6.0f};
+    float v = mag[nibble & 7u];
+    return (nibble & 8u) ? -v : v;
+}
+uint8_t orc_f32_to_e2m1(float v)
+{
+    /* representable magnitudes 0, .5, 1, 1.5, 2, 3, 4, 6; a value half way between two goes to the one with the even code
+     * (0.25 -> 0, 0.75 -> 1, 1.25 -> 1, 1.75 -> 2, 2.5 -> 2, 3.5 -> 4, 5 -> 4); beyond 6: 6 */
+    static const float mag[8] = {0.0f, 0.5f, 1.0f, 1.5f, 2.0f, 3.0f, 4.0f, 6.0f};
+    if (v != v) return 0;
+    uint8_t sign = (f2u(v) & 0x80000000u) ? 8u : 0u;
+    float a = fabsf(v);
+    if (a >= 6.0f) return (uint8_t)(sign | 7u);
+    uint8_t c = 0;
+    for (uint8_t i = 0; i < 7; ++i) {
+        if (a >= mag[i] && a <= mag[i + 1]) {
+            float mid = 0.5f * (mag[i] + mag[i + 1]);                 /* exact */
+            if (a < mid) c = i; else if (a > mid) c = (uint8_t)(i + 1); else c = (i & 1u) ? (uint8_t)(i + 1) : i;
+            break;
+        }
+    }
+    return (uint8_t)(sign | c);
+}
+uint8_t orc_mx_scale_code(float amax, int emax_elem)
+{
+    if (!(amax > 0.0f)) return 0;
+    if (amax > 65504.0f) amax = 65504.0f;
+    int ex;
+    (void)frexpf(amax, &ex);                                          /* amax = m * 2^ex, m in [0.5, 1): floor(log2) = ex - 1 */
+    int code = ex - 1 - emax_elem + 127;
+    if (code < 0) code = 0;
+    if (code > 254) code = 254;
+    return (uint8_t)code;
+}
+float orc_e8m0_to_f32(uint8_t code)
+{
+    if (code == 255) return u2f(0x7FC00000u);
+    return ldexpf(1.0f, (int)code - 127);
+}
+static float finite_amax(const float* x, size_t n)
+{
+    float mx = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        float a = fabsf(x[i]);
+        if (a != a) continue;                                          /* NaN elements are skipped */
+        if (a > 65504.0f) a = 65504.0f;
+        if (a > mx) mx = a;
+    }
+    return mx;
+}
+static size_t compress_mxfp4(const float* xf, size_t n, uint8_t* rec)
+{
+    size_t groups = n / 32;
+    uint8_t* codes = rec + n / 2;
+    memset(rec, 0, n / 2 + groups);
+    for (size_t g = 0; g < groups; ++g) {
+        uint8_t code = orc_mx_scale_code(finite_amax(xf + g * 32, 32), 2);
+        codes[g] = code;
+        for (size_t i = 0; i < 32; ++i) {
+            size_t e = g * 32 + i;
+            float x = xf[e];
+            uint8_t q = 0;
+            if (x == x) {
+                if (x > 65504.0f) x = 65504.0f;
+                if (x < -65504.0f) x = -65504.0f;
+                q = orc_f32_to_e2m1(ldexpf(x, 127 - (int)code));       /* exact scaling by a power of two */
+            }
+            rec[e >> 1] |= (uint8_t)((e & 1) ? (q << 4) : q);
+        }
+    }
+    return n / 2 + groups;
+}
+void orc_quantize_rows_mxfp8(const uint16_t* q16, size_t rows, size_t d, uint8_t* q8, uint8_t* q_codes)
+{
+    size_t blocks = d / 32;
+    for (size_t r = 0; r < rows; ++r)
+        for (size_t b = 0; b < blocks; ++b) {
+            float x[32];
+            for (size_t i = 0; i < 32; ++i) x[i] = orc_half_to_float(q16[r * d + b * 32 + i]);
+            uint8_t code = orc_mx_scale_code(finite_amax(x, 32), 8);
+            q_codes[r * blocks + b] = code;
+            for (size_t i = 0; i < 32; ++i) {
+                float v = x[i];
+                uint8_t c = 0;
+                if (v == v) {
+                    if (v > 65504.0f) v = 65504.0f;
+                    if (v < -65504.0f) v = -65504.0f;
+                    c = orc_f32_to_e4m3(ldexpf(v, 127 - (int)code));   /* nearest even, saturating at 448 */
+                }
+                q8[r * d + b * 32 + i] = c;
+            }
+        }
+}
+void orc_attend_mx4(const uint8_t* q8, const uint8_t* q_codes, size_t g, const uint8_t* k_nib, const uint8_t* k_codes,
+                    const uint8_t* v_nib, const uint8_t* v_codes, size_t n_pos, size_t d, float sm_scale,
+                    float* out, float* lse, float* mag)
+{
+    size_t blocks = d / 32;
+    double* s = (double*)malloc((n_pos ? n_pos : 1) * sizeof(double));
+    double* o = (double*)malloc(d * sizeof(double));
+    double* a = (double*)malloc(d * sizeof(double));
+    double* qd = (double*)malloc(d * sizeof(double));
+    for (size_t m = 0; m < g; ++m) {
+        for (size_t i = 0; i < d; ++i)
+            qd[i] = (double)orc_e4m3_to_f32(q8[m * d + i]) * (double)orc_e8m0_to_f32(q_codes[m * blocks + i / 32]);
+        double mx = -INFINITY;
+        for (size_t t = 0; t < n_pos; ++t) {
+            double acc = 0.0;
+            for (size_t i = 0; i < d; ++i) {
+                uint8_t nb = (uint8_t)((k_nib[t * (d / 2) + (i >> 1)] >> ((i & 1) * 4)) & 0xF);
+                acc += qd[i] * (double)orc_e2m1_to_f32(nb) * (double)orc_e8m0_to_f32(k_codes[t * blocks + i / 32]);
+            }
+            s[t] = acc * (double)sm_scale;
+            if (s[t] > mx) mx = s[t];
+        }
+        double l = 0.0;
+        for (size_t i = 0; i < d; ++i) { o[i] = 0.0; a[i] = 0.0; }
+        for (size_t t = 0; t < n_pos; ++t) {
+            double p = exp(s[t] - mx);
+            l += p;
+            for (size_t i = 0; i < d; ++i) {
+                uint8_t nb = (uint8_t)((v_nib[t * (d / 2) + (i >> 1)] >> ((i & 1) * 4)) & 0xF);
+                double v = (double)orc_e2m1_to_f32(nb) * (double)orc_e8m0_to_f32(v_codes[t * blocks + i / 32]);
+                o[i] += p * v;
+                a[i] += p * fabs(v);
+            }
+        }
+        for (size_t i = 0; i < d; ++i) {
+            out[m * d + i] = (l > 0.0) ? (float)(o[i] / l) : 0.0f;
+            if (mag) mag[m * d + i] = (l > 0.0) ? (float)(a[i] / l) : 0.0f;
+        }
+        if (lse) lse[m] = (l > 0.0) ? (float)(mx + log(l)) : -INFINITY;
+    }
+    free(s); free(o); free(a); free(qd);
+}
+
 static size_t compress_int4_g32(const float* xf, size_t n, uint8_t* rec)
 {
     size_t groups = n / 32;
@@ -428,13 +567,16 @@ static size_t compress_int4_g32(const float* xf, size_t n, uint8_t* rec)
 size_t orc_compress_block_f16(const uint16_t* x, size_t n, int scheme, int mode,
                               float* scale, uint8_t* rec)
 {
-    if (scheme == ORC_COMP_INT4_G32 || scheme == ORC_COMP_FP8_E4M3) {
+    if (scheme == ORC_COMP_INT4_G32 || scheme == ORC_COMP_FP8_E4M3 || scheme == ORC_COMP_MXFP4) {
         float* xf = (float*)malloc((n ? n : 1) * sizeof(float));
         for (size_t i = 0; i < n; ++i) xf[i] = orc_half_to_float(x[i]);
         size_t len;
         if (scheme == ORC_COMP_INT4_G32) {
             *scale = 1.0f;
             len = compress_int4_g32(xf, n, rec);
+        } else if (scheme == ORC_COMP_MXFP4) {
+            *scale = 1.0f;
+            len = compress_mxfp4(xf, n, rec);
         } else {
             float mx = 0.0f;
             for (size_t i = 0; i < n; ++i) { float a = fabsf(xf[i]); if (a > mx) mx = a; }
@@ -484,6 +626,17 @@ size_t orc_decompress_block_f32(const uint8_t* rec, size_t len, float scale, int
             uint8_t q4 = (uint8_t)((nib[i >> 1] >> ((i & 1) * 4)) & 0xF);
             int q = (q4 & 8) ? (int)q4 - 16 : (int)q4;
             y[i] = (float)q * orc_half_to_float(s16);
+        }
+        return cap;
+    }
+    if (scheme == ORC_COMP_MXFP4) {
+        /* fixed-size record: cap/2 nibble bytes then cap/32 E8M0 codes; a short record decodes to zeros */
+        size_t groups = cap / 32;
+        if (len < cap / 2 + groups) { for (size_t i = 0; i < cap; ++i) y[i] = 0.0f; return cap; }
+        const uint8_t* codes = rec + cap / 2;
+        for (size_t i = 0; i < cap; ++i) {
+            uint8_t nb = (uint8_t)((rec[i >> 1] >> ((i & 1) * 4)) & 0xF);
+            y[i] = orc_e2m1_to_f32(nb) * orc_e8m0_to_f32(codes[i / 32]);      /* exact: two significant bits times a power of two */
         }
         return cap;
     }

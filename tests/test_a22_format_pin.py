@@ -194,3 +194,164 @@ def test_attention_oracles_against_the_numpy_restatement(oracle):
     wo, wl, wm = attention_numpy(f8(q8) * qs[:, None].astype(np.float64), f8(kb) * ks[:, None].astype(np.float64),
                                  f8(vb) * vs[:, None].astype(np.float64), np.float32(sm))
     assert np.allclose(o, wo, rtol=2e-6, atol=1e-7) and np.allclose(l, wl, rtol=2e-6, atol=2e-6) and np.allclose(m, wm, rtol=2e-6, atol=1e-7)
+
+
+# ---- MXFP4 (scheme 5): restated from the OCP Microscaling Formats (MX) v1.0 text alone --------------------------------
+# Block of 32 elements, one E8M0 scale X = 2^(code - 127); elements FP4 E2M1 = {0, 0.5, 1, 1.5, 2, 3, 4, 6} with a sign bit.
+# Conversion (spec section 6.3): shared exponent = floor(log2(max|x|)) - emax_elem (2 for E2M1, 8 for E4M3); elements are
+# x / X rounded to nearest (ties to even), clamped to the largest magnitude.  Stated conventions beyond the spec's text
+# (oracle/speckv_oracle.h): NaN inputs are skipped in the maximum and stored as +0, inf counts as 65504, an all-zero block
+# gets code 0; record = 1024 nibble bytes (element 2i in the low half) then 64 codes.
+E2M1_GRID = np.array([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+
+
+def e2m1_rne_numpy(v):
+    """codes of float64 values, nearest grid point, ties to the even code, saturating; written as a search over the grid"""
+    v = np.asarray(v, np.float64)
+    a = np.minimum(np.abs(v), 6.0)
+    d = np.abs(a[..., None] - E2M1_GRID)                       # distance to each of the 8 magnitudes
+    best = d.min(axis=-1, keepdims=True)
+    cand = d == best                                           # one candidate, or two on a tie (neighbouring codes)
+    even = cand & (np.arange(8) % 2 == 0)
+    code = np.where(cand.sum(-1) == 2, np.argmax(even, -1), np.argmax(cand, -1))
+    return (code | np.where(np.signbit(v), 8, 0)).astype(np.uint8)
+
+
+def mx_code_numpy(amax, emax_elem):
+    amax = np.asarray(amax, np.float64)
+    with np.errstate(divide="ignore"):
+        e = np.floor(np.log2(np.where(amax > 0, amax, 1.0))).astype(np.int64)       # exact for these magnitudes (checked below)
+    return np.where(amax > 0, np.clip(e - emax_elem + 127, 0, 254), 0).astype(np.uint8)
+
+
+def mxfp4_encode_numpy(x16):
+    x = np.asarray(x16, np.float16).astype(np.float64).reshape(-1, 32)
+    fin = np.where(np.isnan(x), 0.0, np.clip(x, -65504.0, 65504.0))
+    code = mx_code_numpy(np.abs(fin).max(axis=1), 2)
+    q = e2m1_rne_numpy(fin / np.exp2(code.astype(np.float64) - 127.0)[:, None])
+    q = np.where(np.isnan(x), 0, q).reshape(-1).astype(np.uint8)
+    return np.concatenate([(q[0::2] | (q[1::2] << 4)).astype(np.uint8), code])
+
+
+def mxfp4_decode_numpy(rec):
+    """float64 values of a record (not yet rounded to fp16)"""
+    rec = np.asarray(rec, np.uint8)
+    n = rec.size * 32 // 17                                     # 16 nibble bytes + 1 code per 32 elements
+    nib = rec[:n // 2]
+    q = np.empty(n, np.int64); q[0::2] = nib & 0xF; q[1::2] = nib >> 4
+    val = E2M1_GRID[q & 7] * np.where(q & 8, -1.0, 1.0)
+    codes = rec[n // 2:].astype(np.float64)
+    scale = np.where(codes == 255, np.nan, np.exp2(codes - 127.0))
+    return val * np.repeat(scale, 32)
+
+
+def _mx_test_blocks():
+    rng = np.random.default_rng(51)
+    x = (rng.standard_normal((32, 2048)) * rng.uniform(0.01, 40.0, (32, 1))).astype(np.float16)
+    x[3] = 0
+    x[4, :32] = 0
+    x[5, ::5] *= 50
+    x[6] = np.float16(65504.0)
+    x[7] = (rng.standard_normal(2048) * 6e-8).astype(np.float16)                    # fp16 subnormals
+    x[8] = np.tile(np.array([0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5.0, 6.0, 7.0, 7.99, -0.25, -0.75, -1.25, -1.75, -2.5, -3.5,
+                             -5.0, -7.0, 4.0, 0.5, 0.1, 0.24, 0.26, 0.74, 0.76, 1.24, 1.26, 2.49, 2.51, 4.99, 5.01, 0.0], np.float16), 64)   # every tie, with 7.99 fixing the scale at 1
+    x[9] = x[8] * np.float16(2.0 ** -9)
+    x[10, 7] = np.float16(np.inf); x[10, 40] = np.float16(-np.inf)
+    x[11, 3] = np.float16(np.nan); x[11, 64:96] = np.float16(np.nan)               # a NaN among values, a group of NaNs only
+    x[12] = np.float16(2.0 ** -24)                                                   # the smallest fp16 subnormal everywhere
+    x[13] = (np.exp2(rng.integers(-20, 15, 2048)) * rng.choice([-1, 1], 2048) * rng.choice([1.0, 1.5, 1.25, 1.75], 2048)).astype(np.float16)
+    return x
+
+
+def test_mx_scalar_conversions_against_the_spec_text(oracle):
+    L = oracle.lib
+    # E2M1: every code decodes to the grid; every fp16 value rounds as the grid search says (ties to even, saturating)
+    for c in range(16):
+        assert L.orc_e2m1_to_f32(c) == E2M1_GRID[c & 7] * (-1 if c & 8 else 1)
+    h = np.arange(65536, dtype=np.uint32).astype(np.uint16).view(np.float16)
+    f = h.astype(np.float32)
+    ok = ~np.isnan(f)
+    got = np.array([L.orc_f32_to_e2m1(float(v)) for v in f[ok]], np.uint8)
+    assert np.array_equal(got, e2m1_rne_numpy(f[ok].astype(np.float64)))
+    assert L.orc_f32_to_e2m1(float("nan")) == 0
+    assert [L.orc_f32_to_e2m1(v) for v in (0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5.0)] == [0, 2, 2, 4, 4, 6, 6]      # the seven ties
+    # E8M0: 2^(code-127) bit for bit as torch's float8_e8m0fnu decodes it; 255 is NaN on both sides
+    codes = np.arange(256, dtype=np.uint8)
+    want = torch.from_numpy(codes).view(torch.float8_e8m0fnu).to(torch.float32).numpy()
+    got = np.array([L.orc_e8m0_to_f32(int(c)) for c in codes], np.float32)
+    assert np.isnan(got[255]) and np.isnan(want[255]) and np.array_equal(got[:255].view(np.uint32), want[:255].view(np.uint32))
+    # shared exponent: floor(log2(amax)) - emax + 127 for every positive fp16 magnitude, both element types
+    pos = f[(f > 0) & np.isfinite(f)]
+    man, ex = np.frexp(pos.astype(np.float64))                 # independent of log2: amax = man * 2^ex, man in [0.5, 1)
+    for emax in (2, 8):
+        got = np.array([L.orc_mx_scale_code(float(v), emax) for v in pos], np.int64)
+        assert np.array_equal(got, ex - 1 - emax + 127)
+        assert np.array_equal(got, mx_code_numpy(pos, emax))
+    assert L.orc_mx_scale_code(0.0, 2) == 0 and L.orc_mx_scale_code(float("inf"), 2) == 15 - 2 + 127
+
+
+def test_mxfp4_block_format_against_the_numpy_restatement(oracle):
+    x = _mx_test_blocks()
+    scales, lens, recs = oracle.compress_blocks_f16(x, 5, 0)
+    y = oracle.decompress_blocks_f16(recs, lens, scales, 5, 0)
+    for i in range(x.shape[0]):
+        want = mxfp4_encode_numpy(x[i])
+        assert lens[i] == 1088 and want.size == 1088 and scales[i] == 1.0
+        assert np.array_equal(recs[i, :1088], want), i
+        with np.errstate(over="ignore", invalid="ignore"):
+            assert np.array_equal(y[i].view(np.uint16), mxfp4_decode_numpy(want).astype(np.float16).view(np.uint16)), i
+    # the largest element of every non-zero group lands on 4 or 6 (floor-type shared exponent: amax / X in [4, 8))
+    dec = mxfp4_decode_numpy(recs[0, :1088]).reshape(-1, 32)
+    top = np.abs(dec).max(axis=1) / np.exp2(recs[0, 1024:1088].astype(np.float64) - 127)
+    assert set(np.unique(top)) <= {4.0, 6.0}
+    # quantisation error bound of the format: |x - y| <= X/2 * (grid step at |x|/X) and <= amax/4 when clamped (|x|/X in (6, 8))
+    x0 = x[0].astype(np.float64).reshape(-1, 32); X = np.exp2(recs[0, 1024:1088].astype(np.float64) - 127)[:, None]
+    assert np.all(np.abs(x0 - dec) <= np.where(np.abs(x0) / X > 6, 2.0, 1.0) * X + 1e-12)
+    # every nibble value x a spread of codes decodes as described; a short record decodes to zeros, code 255 to NaN
+    rec = np.zeros(1088, np.uint8)
+    rec[:1024] = (np.arange(1024) * 37 + 11).astype(np.uint8)
+    rec[1024:] = np.array([0, 1, 100, 101, 126, 127, 128, 140, 141, 150, 254, 255, 103, 110, 120, 130] * 4, np.uint8)
+    got32 = np.stack([oracle.decompress_block_f32(rec, 1.0, 5, 0), oracle.decompress_block_f32(rec[:1087], 1.0, 5, 0)])
+    want = mxfp4_decode_numpy(rec)
+    nan = np.isnan(want)
+    assert nan.sum() == 4 * 32 and np.array_equal(np.isnan(got32[0]), nan)
+    with np.errstate(over="ignore"):
+        w32 = want[~nan].astype(np.float32)                     # (6 x 2^127 overflows to inf on both sides)
+    assert np.array_equal(got32[0][~nan].view(np.uint32), w32.view(np.uint32))      # fp32 output is exact
+    assert not got32[1].any()
+    got16 = oracle.decompress_block_f16(rec, 1.0, 5, 0)
+    with np.errstate(over="ignore", invalid="ignore"):
+        w16 = want.astype(np.float16)
+    assert np.array_equal(got16[~nan].view(np.uint16), w16[~nan].view(np.uint16)) and np.isnan(got16[nan]).all()
+
+
+def test_mxfp8_query_rows_and_the_mx4_attention_oracle_against_numpy(oracle):
+    from oracle.bindings import _ptr, u8p, u16p, f32p
+    L = oracle.lib
+    rng = np.random.default_rng(52)
+    G, D, NPOS = 8, 128, 300
+    qh = (rng.standard_normal((G, D)) * rng.uniform(0.05, 30.0, (G, 1))).astype(np.float16)
+    qh[1, :32] = 0; qh[2, 5] = np.float16(480.0); qh[3, 64:96] *= np.float16(2.0 ** -12)
+    q8 = np.zeros((G, D), np.uint8); qc = np.zeros((G, D // 32), np.uint8)
+    L.orc_quantize_rows_mxfp8(_ptr(qh.view(np.uint16).reshape(-1), u16p), G, D, _ptr(q8, u8p), _ptr(qc, u8p))
+    # restated with torch's e4m3 cast: code = floor(log2 amax) - 8 + 127, bytes = e4m3(clip(x / 2^(code-127), +-448))
+    xb = qh.astype(np.float64).reshape(G, D // 32, 32)
+    code = mx_code_numpy(np.abs(xb).max(axis=2), 8)
+    assert np.array_equal(qc, code)
+    v = np.clip(xb / np.exp2(code.astype(np.float64) - 127)[..., None], -448.0, 448.0).astype(np.float32).reshape(G, D)
+    assert np.array_equal(q8, torch.from_numpy(v).to(torch.float8_e4m3fn).view(torch.uint8).numpy())
+    assert (np.abs(xb / np.exp2(code.astype(np.float64) - 127)[..., None]).max() > 448)        # the clamp was exercised (values in (448, 512))
+    f8 = lambda b: torch.from_numpy(np.ascontiguousarray(b)).view(torch.float8_e4m3fn).to(torch.float32).numpy().astype(np.float64)
+    qd = f8(q8) * np.repeat(np.exp2(qc.astype(np.float64) - 127), 32, axis=1)
+    # K / V rows of one head: MXFP4 pages, rows of 128 elements
+    pages = (rng.standard_normal((2 * NPOS * D // 2048 + 1, 2048)) * rng.uniform(0.2, 4.0, (2 * NPOS * D // 2048 + 1, 1))).astype(np.float16)
+    recs = np.stack([mxfp4_encode_numpy(p) for p in pages])
+    nib = recs[:, :1024].reshape(-1, D // 2); codes = recs[:, 1024:].reshape(-1, D // 32)
+    dec = np.concatenate([mxfp4_decode_numpy(r) for r in recs]).reshape(-1, D)
+    kn, kc, vn, vc = (np.ascontiguousarray(a) for a in (nib[:NPOS], codes[:NPOS], nib[NPOS:2 * NPOS], codes[NPOS:2 * NPOS]))
+    o = np.zeros((G, D), np.float32); l = np.zeros(G, np.float32); m = np.zeros((G, D), np.float32)
+    sm = 1.0 / np.sqrt(D)
+    L.orc_attend_mx4(_ptr(q8, u8p), _ptr(qc, u8p), G, _ptr(kn, u8p), _ptr(kc, u8p), _ptr(vn, u8p), _ptr(vc, u8p), NPOS, D, float(sm),
+                     _ptr(o, f32p), _ptr(l, f32p), _ptr(m, f32p))
+    wo, wl, wm = attention_numpy(qd, dec[:NPOS], dec[NPOS:2 * NPOS], np.float32(sm))
+    assert np.allclose(o, wo, rtol=2e-6, atol=1e-7) and np.allclose(l, wl, rtol=2e-6, atol=2e-6) and np.allclose(m, wm, rtol=2e-6, atol=1e-7)
