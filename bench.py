@@ -794,14 +794,14 @@ def xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream
         try:
             if active and handles:
                 h = handles[-1]
-                dst.zero_()
+                dst.zero_(); torch.cuda.synchronize()          # (the fill runs on torch's stream, the fetch on ours)
                 lib.fetch_range(h, 0, n_blocks, dst.data_ptr(), False, sp, engine=2); torch.cuda.synchronize()
                 step_b = min(n_blocks, 16384)
                 first = torch.empty((step_b, BLOCK_ELEMS), dtype=torch.float16, device=dst.device)
                 cmp_ok = True
                 for b0 in range(0, n_blocks, step_b):
                     nb = min(step_b, n_blocks - b0)
-                    first.zero_()
+                    first.zero_(); torch.cuda.synchronize()
                     lib.fetch_range(h, b0, nb, first.data_ptr(), False, sp, engine=1); torch.cuda.synchronize()
                     cmp_ok = cmp_ok and torch.equal(first[:nb].view(torch.int16), dst[b0:b0 + nb].view(torch.int16))
                 cmp_ok = bool(cmp_ok and dst.view(torch.int16).count_nonzero().item() > dst.numel() // 2)     # and it is data, not two zeroed buffers

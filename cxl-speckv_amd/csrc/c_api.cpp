@@ -304,11 +304,11 @@ static speckv_status_t codec_launch(bool compress, const speckv::CodecArgs& a, v
 speckv_status_t speckv_ext_codec_compress(const void* d_src_f16, uint64_t n_blocks, void* d_recs, uint64_t rec_stride,
                                           uint32_t* d_rec_bytes, float* d_scales, int scheme, int quant_mode, void* stream)
 {
-    if (scheme < 0 || scheme > SPECKV_COMP_FP8_E4M3 || quant_mode < 0 || quant_mode > 1) return SPECKV_ERR_INVAL;
+    if (scheme < 0 || scheme > SPECKV_COMP_MXFP4 || quant_mode < 0 || quant_mode > 1) return SPECKV_ERR_INVAL;
     if (n_blocks && (!d_src_f16 || !d_recs || !d_rec_bytes)) return SPECKV_ERR_INVAL;
     if (rec_stride % 16) return SPECKV_ERR_INVAL;
     const uint64_t need = scheme == SPECKV_COMP_INT8 || scheme == SPECKV_COMP_FP8_E4M3 ? 2048u
-                        : scheme == SPECKV_COMP_INT4_G32 ? 1152u : 4096u;
+                        : scheme == SPECKV_COMP_INT4_G32 ? 1152u : scheme == SPECKV_COMP_MXFP4 ? 1088u : 4096u;
     if (rec_stride < need) return SPECKV_ERR_INVAL;
     speckv::CodecArgs a{};
     a.recs = static_cast<uint8_t*>(d_recs);
@@ -329,7 +329,7 @@ speckv_status_t speckv_ext_codec_decompress(const void* d_recs, uint64_t rec_str
 {
     const int structured = quant_mode & SPECKV_CODEC_HINT_STRUCTURED;
     quant_mode &= ~SPECKV_CODEC_HINT_STRUCTURED;
-    if (scheme < 0 || scheme > SPECKV_COMP_FP8_E4M3 || quant_mode < 0 || quant_mode > 1) return SPECKV_ERR_INVAL;
+    if (scheme < 0 || scheme > SPECKV_COMP_MXFP4 || quant_mode < 0 || quant_mode > 1) return SPECKV_ERR_INVAL;
     if (n_blocks && (!d_recs || !d_rec_bytes || !d_dst)) return SPECKV_ERR_INVAL;
     if (rec_stride % 16) return SPECKV_ERR_INVAL;
     speckv::CodecArgs a{};

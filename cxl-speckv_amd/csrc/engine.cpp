@@ -387,7 +387,7 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
             // FP8 / INT4 pools start as zero bytes (= records of zeros), which lets the fused attention address them
             // arithmetically without a validity test per page: one run (linear form) or the regular striping over up to 8
             // pools (striped form).  Each run is cleared on the GPU that holds it.
-            const bool fixed_fmt = a->scheme == SPECKV_COMP_FP8_E4M3 || a->scheme == SPECKV_COMP_INT4_G32;
+            const bool fixed_fmt = a->scheme == SPECKV_COMP_FP8_E4M3 || a->scheme == SPECKV_COMP_INT4_G32 || a->scheme == SPECKV_COMP_MXFP4;
             if (ok && fixed_fmt && regular && D <= 8 && a->n_pages < (1ull << 28)) {
                 for (const auto& ex : a->extents) {
                     if (!ex.base || !ok) continue;
@@ -1029,7 +1029,7 @@ int Engine::set_prefetch_depth(uint32_t k)
 int Engine::set_scheme(int scheme)
 {
     if (null_) return SPECKV_ERR_DRIVER;
-    if (scheme < 0 || scheme > SPECKV_COMP_FP8_E4M3) return SPECKV_ERR_INVAL;
+    if (scheme < 0 || scheme > SPECKV_COMP_MXFP4) return SPECKV_ERR_INVAL;
     scheme_ = scheme;
     return SPECKV_OK;
 }

@@ -54,7 +54,7 @@ int Engine::migrate(uint64_t handle, uint64_t first, uint64_t n, uint32_t target
     HIP_TRY(hipStreamSynchronize(stream_));
     guard.keep = true;
     // bookkeeping: the old runs leave the allocation's extent list (split where needed).  Record strides are
-    // multiples of the pool's 128-byte granule, so a sub-run is freed exactly (never reaching into live neighbours).
+    // multiples of the pool's 64-byte granule, so a sub-run is freed exactly (never reaching into live neighbours).
     for (const Run& r : old) {
         std::vector<Allocation::Extent> next;
         for (const auto& ex : a->extents) {
@@ -83,7 +83,7 @@ int Engine::migrate(uint64_t handle, uint64_t first, uint64_t n, uint32_t target
         a->extents.push_back({static_cast<int>(target_pool), dst, n * stride, n});
         a->pool_of_residue.assign(1, static_cast<int>(target_pool));
         a->regular = true;
-        const bool fixed_fmt = a->scheme == SPECKV_COMP_FP8_E4M3 || a->scheme == SPECKV_COMP_INT4_G32;
+        const bool fixed_fmt = a->scheme == SPECKV_COMP_FP8_E4M3 || a->scheme == SPECKV_COMP_INT4_G32 || a->scheme == SPECKV_COMP_MXFP4;
         if (fixed_fmt && a->d_stripe) {
             uint64_t bases[8] = {reinterpret_cast<uint64_t>(dst), 0, 0, 0, 0, 0, 0, 0};
             HIP_TRY(hipMemcpy(a->d_stripe, bases, sizeof(bases), hipMemcpyHostToDevice));

@@ -522,6 +522,35 @@ __device__ __forceinline__ void decode_int4(const uint8_t* __restrict__ rec, uin
     }
 }
 
+// decode: MXFP4 (OCP MX v1.0: record = 1024 B of E2M1 nibbles + 64 E8M0 group codes; oracle: compress_mxfp4 / ORC_COMP_MXFP4)
+// y = e2m1(nibble) * 2^(code - 127): the nibble pairs widen through v_cvt_scalef32_pk_f32_fp4 (exact), the scale is a float
+// whose exponent field is the code (a subnormal for code 0, NaN for 255) -- the product is exact in fp32.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+template <bool F32>
+__device__ __forceinline__ void decode_mx4(const uint8_t* __restrict__ rec, uint32_t len,
+                                           uint8_t* __restrict__ dst, uint32_t lane)
+{
+    const bool ok = len >= kMx4RecBytes;                     // short record decodes to zeros
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t p0 = 512u * j + 8u * lane;
+        uint32_t nib = 0, code = 127u;
+        if (ok) {
+            nib = gload<uint32_t>(rec + (p0 >> 1));
+            code = gload<uint8_t>(rec + 1024u + (p0 >> 5));
+        }
+        const float s = __uint_as_float(code == 0u ? 0x00400000u : code == 255u ? 0x7FC00000u : code << 23);
+        float y[8];
+        const f32x2v f0 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(nib, 1.0f, 0);
+        const f32x2v f1 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(nib, 1.0f, 1);
+        const f32x2v f2 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(nib, 1.0f, 2);
+        const f32x2v f3 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(nib, 1.0f, 3);
+        y[0] = f0.x * s; y[1] = f0.y * s; y[2] = f1.x * s; y[3] = f1.y * s;
+        y[4] = f2.x * s; y[5] = f2.y * s; y[6] = f3.x * s; y[7] = f3.y * s;
+        store8<F32>(dst, p0, y);
+    }
+}
+
 // decode: FP8_E4M3 (config 5 extension; per-block scale)
 template <bool F32>
 __device__ __forceinline__ void decode_fp8(const uint8_t* __restrict__ rec, uint32_t len,
@@ -659,6 +688,8 @@ __device__ __forceinline__ void fetch_decompress_body(const CodecArgs& a)
             decode_int8<MODE, F32>(cur.rec, len, cur.scale, cur.dst, lane);
         } else if (SCHEME == kInt4G32) {
             decode_int4<F32>(cur.rec, len, cur.dst, lane);
+        } else if (SCHEME == kMxFp4) {
+            decode_mx4<F32>(cur.rec, len, cur.dst, lane);
         } else if (SCHEME == kFp8E4m3) {
             if (len > kBlockElems) len = kBlockElems;
             decode_fp8<F32>(cur.rec, len, cur.scale, cur.dst, lane);
@@ -859,7 +890,8 @@ __device__ __noinline__ float absmax_with_nonfinite(const uint8_t* __restrict__ 
 template <int SCHEME, int MODE>
 __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t lds[SCHEME == kInt8DeltaRle ? kWaves * kEncLdsHalves : SCHEME == kInt4G32 ? kWaves * (kInt4RecBytes / 2) : 8];
+    __shared__ __attribute__((aligned(16))) uint16_t lds[SCHEME == kInt8DeltaRle ? kWaves * kEncLdsHalves : SCHEME == kInt4G32 ? kWaves * (kInt4RecBytes / 2)
+                                                         : SCHEME == kMxFp4 ? kWaves * (kMx4RecBytes / 2) : 8];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint64_t n = a.n;
@@ -995,6 +1027,76 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                 wave_lds_fence();
             }
             out_len = kInt4RecBytes;
+        } else if (SCHEME == kMxFp4) {
+            // OCP MX v1.0 (oracle: compress_mxfp4): per group of 32 elements (4 lanes x 8) code = floor(log2 max|x|) - 2 + 127 -- the
+            // exponent field of max|x| as a float, minus 2 -- and q = E2M1 of x / 2^(code-127), nearest even, saturating: one
+            // v_cvt_scalef32_pk_fp4_f16 per element pair straight from the fp16 words (it divides by the power of two its scale
+            // operand's exponent names, rounds to nearest even and saturates: profiles/probes/mxprobe.hip).
+            typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t words[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+                u16x2 m2 = {0, 0};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(u16x2, words[t] & 0x7FFF7FFFu));
+                uint32_t mbits = m2.x > m2.y ? m2.x : m2.y;                 // largest |bits| of the lane's 8 elements
+                mbits = umax(mbits, dpp<0xB1>(0u, mbits));                  // lane ^ 1
+                mbits = umax(mbits, dpp<0x4E>(0u, mbits));                  // lane ^ 2 -> the group of 32
+                const bool finite = __ballot(mbits >= 0x7C00u) == 0ull;     // wave-uniform: no inf / NaN in any group of this chunk
+                uint32_t nib = 0, code = 0;
+                if (finite) {
+                    code = mbits ? (__float_as_uint(half_bits_to_float(mbits)) >> 23) - 2u : 0u;
+                    const float sc = mbits ? __uint_as_float(code << 23) : 1.0f;      // (code >= 101 for any non-zero fp16: a normal float)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const f16x2v h = __builtin_bit_cast(f16x2v, words[t]);
+                        switch (t) {
+                        case 0: nib = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(nib, h, sc, 0); break;
+                        case 1: nib = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(nib, h, sc, 1); break;
+                        case 2: nib = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(nib, h, sc, 2); break;
+                        default: nib = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(nib, h, sc, 3); break;
+                        }
+                    }
+                } else {
+                    // a chunk with inf / NaN somewhere: NaN elements are skipped in the maximum and store +0, inf counts as 65504
+                    float xv[8];
+                    float mx = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float x = half_bits_to_float((words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
+                        x = (x == x) ? fminf(fmaxf(x, -65504.0f), 65504.0f) : 0.0f;
+                        xv[k] = x;
+                        mx = fmaxf(mx, fabsf(x));
+                    }
+                    float o = __shfl_xor(mx, 1); mx = (o > mx) ? o : mx;
+                    o = __shfl_xor(mx, 2);       mx = (o > mx) ? o : mx;
+                    code = mx > 0.0f ? (__float_as_uint(mx) >> 23) - 2u : 0u;
+                    const float sc = mx > 0.0f ? __uint_as_float(code << 23) : 1.0f;
+                    nib = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(nib, xv[0], xv[1], sc, 0);
+                    nib = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(nib, xv[2], xv[3], sc, 1);
+                    nib = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(nib, xv[4], xv[5], sc, 2);
+                    nib = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(nib, xv[6], xv[7], sc, 3);
+                    // a NaN element keeps no sign: +0
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t hb = (words[k >> 1] >> ((k & 1) * 16)) & 0x7FFFu;
+                        if (hb > 0x7C00u) nib &= ~(0xFu << (4 * k));
+                    }
+                }
+                // the record is assembled in LDS and leaves as whole 16-byte pieces per lane (as the INT4 record does)
+                const uint32_t p0 = 512u * j + 8u * lane;
+                uint8_t* wl = reinterpret_cast<uint8_t*>(lds) + wave * kMx4RecBytes;
+                *reinterpret_cast<uint32_t*>(wl + (p0 >> 1)) = nib;
+                if ((lane & 3u) == 0u) wl[1024u + (p0 >> 5)] = static_cast<uint8_t>(code);
+            }
+            {
+                uint8_t* wl = reinterpret_cast<uint8_t*>(lds) + wave * kMx4RecBytes;
+                wave_lds_fence();
+                enc_st16(rec + 16u * lane, *reinterpret_cast<const uint4*>(wl + 16u * lane));
+                if (lane < 4u) enc_st16(rec + 1024u + 16u * lane, *reinterpret_cast<const uint4*>(wl + 1024u + 16u * lane));
+                wave_lds_fence();
+            }
+            out_len = kMx4RecBytes;
         } else if (SCHEME == kFp8E4m3) {
             float x[4][8];
             float mx = 0.0f, nanacc = 0.0f;
@@ -2323,6 +2425,7 @@ hipError_t launch_decompress(const CodecArgs& a, hipStream_t s)
     case kInt8DeltaRle: return launch_dec1<kInt8DeltaRle>(a, s);
     case kInt4G32: return launch_dec2<kInt4G32, kRefExact>(a, s);      // the quantiser mode does not apply
     case kFp8E4m3: return launch_dec2<kFp8E4m3, kRefExact>(a, s);
+    case kMxFp4: return launch_dec2<kMxFp4, kRefExact>(a, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -2346,6 +2449,13 @@ hipError_t launch_compress(const CodecArgs& a, hipStream_t s)
         const uint32_t grid = codec_grid(b.n, &b.per_wave);
         b.wave_step = (round_strided() && b.per_wave > 1) ? static_cast<uint64_t>(grid) * kWaves : 0;
         hipLaunchKernelGGL((k_compress<kFp8E4m3, kRefExact>), dim3(grid), dim3(kThreads), 0, s, b);
+        return hipGetLastError();
+    }
+    case kMxFp4: {
+        CodecArgs b = a;
+        const uint32_t grid = codec_grid(b.n, &b.per_wave);
+        b.wave_step = (round_strided() && b.per_wave > 1) ? static_cast<uint64_t>(grid) * kWaves : 0;
+        hipLaunchKernelGGL((k_compress<kMxFp4, kRefExact>), dim3(grid), dim3(kThreads), 0, s, b);
         return hipGetLastError();
     }
     default: return hipErrorInvalidValue;

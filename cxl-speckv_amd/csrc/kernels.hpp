@@ -13,8 +13,9 @@ namespace speckv {
 constexpr uint32_t kPageSize = 4096;
 constexpr uint32_t kBlockElems = 2048;
 
-enum Scheme : int { kFp16 = 0, kInt8 = 1, kInt8DeltaRle = 2, kInt4G32 = 3, kFp8E4m3 = 4 };
+enum Scheme : int { kFp16 = 0, kInt8 = 1, kInt8DeltaRle = 2, kInt4G32 = 3, kFp8E4m3 = 4, kMxFp4 = 5 };
 constexpr uint32_t kInt4RecBytes = 128 + 1024;   // 64 fp16 group scales + 2048 nibbles
+constexpr uint32_t kMx4RecBytes = 1024 + 64;     // 2048 E2M1 nibbles + 64 E8M0 group scales (OCP MX v1.0 blocks of 32)
 enum QuantMode : int { kRefExact = 0, kIntent = 1 };
 
 // Device-resident page-table entry (16 B).

@@ -19,10 +19,12 @@ void slab_free(void* p) { (void)hipFree(p); }
 void use_device(int d) { (void)hipSetDevice(d); }
 int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 #endif
-// every record stride (4096, 2048, 1152) is a multiple of 128 B = one cache line: with this granule a run of k
-// records occupies exactly k*stride bytes, so any sub-run of records can be freed on its own (Engine::migrate)
-// without the freed range reaching into live neighbours
-constexpr size_t kGranule = 128;
+// every record stride (4096, 2048, 1152, 1088) is a multiple of 64 B = half a cache line, one HBM burst: with this granule
+// a run of k records occupies exactly k*stride bytes, so any sub-run of records can be freed on its own (Engine::migrate)
+// without the freed range reaching into live neighbours.  (128 until the 1088-byte MXFP4 record arrived; runs still start
+// on 128-byte lines whenever their size is a multiple of 128, and a 16-byte load never straddles a 64-byte piece.)
+constexpr size_t kGranule = 64;
+constexpr size_t kLine = 128;
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }
 
@@ -82,12 +84,17 @@ void* SlabPool::alloc(size_t bytes)
 {
     if (bytes == 0) return nullptr;
     bytes = round_up(bytes, kGranule);
+    // runs of whole cache lines start on a line (a free block may begin 64 bytes into one behind a run of 1088-byte records)
+    const size_t align = bytes % kLine == 0 ? kLine : kGranule;
     for (int attempt = 0; attempt < 2; ++attempt) {
         for (auto it = free_.begin(); it != free_.end(); ++it) {
-            if (it->second >= bytes) {
-                const uintptr_t addr = it->first;
-                const size_t rest = it->second - bytes;
+            const uintptr_t addr = round_up(it->first, align);
+            const size_t head = addr - it->first;
+            if (it->second >= head + bytes) {
+                const uintptr_t start = it->first;
+                const size_t rest = it->second - head - bytes;
                 free_.erase(it);
+                if (head) free_[start] = head;
                 if (rest) free_[addr + bytes] = rest;
                 used_ += bytes;
                 return reinterpret_cast<void*>(addr);
@@ -106,15 +113,19 @@ void* SlabPool::alloc_up_to(size_t want, size_t granule, size_t* got)
     for (int attempt = 0; attempt < 2; ++attempt) {
         auto best = free_.end();
         size_t best_len = 0;
+        const size_t align = granule % kLine == 0 ? kLine : kGranule;
         for (auto it = free_.begin(); it != free_.end(); ++it) {
-            size_t usable = it->second / granule * granule;
+            const size_t head = round_up(it->first, align) - it->first;
+            if (it->second <= head) continue;
+            size_t usable = (it->second - head) / granule * granule;
             if (usable > want) usable = want;
             if (usable > best_len) { best_len = usable; best = it; }
         }
         if (best != free_.end() && best_len >= granule) {
-            const uintptr_t addr = best->first;
-            const size_t rest = best->second - best_len;
+            const uintptr_t start = best->first, addr = round_up(start, align);
+            const size_t head = addr - start, rest = best->second - head - best_len;
             free_.erase(best);
+            if (head) free_[start] = head;
             if (rest) free_[addr + best_len] = rest;
             used_ += best_len;
             *got = best_len;

@@ -92,6 +92,7 @@ typedef enum {
     /* additive values (no reference counterpart; BASELINE config 5, see speckv_ext.h) */
     SPECKV_COMP_INT4_G32       = 3,
     SPECKV_COMP_FP8_E4M3       = 4,
+    SPECKV_COMP_MXFP4          = 5,   /* OCP MX v1.0: E2M1 elements, one E8M0 scale per 32 (the format gfx950's matrix cores read) */
 } speckv_comp_scheme_t;
 
 /* reference host/include/speckv.h:65-66 / speckv_c_api.cpp:101-121.

@@ -134,6 +134,60 @@ def test_extension_formats_match_oracle(lib, oracle, scheme):
     assert_same_float_bits(y[0], want, "short record")
 
 
+def test_mxfp4_block_format_matches_oracle(lib, oracle):
+    """Scheme 5, MXFP4 (OCP MX v1.0: E2M1 elements, one E8M0 scale per 32; BASELINE configs[4] "4:1 ratio"; no reference
+    counterpart: the oracle is pinned to a numpy restatement of the spec text by tests/test_a22_format_pin.py): record bytes
+    and decoded fp16 / fp32 bit-identical, INCLUDING blocks with inf / NaN (NaN -> +0, inf -> 65504 in the maximum)."""
+    x16 = make_blocks()
+    rng = np.random.default_rng(78)
+    ties = np.tile(np.array([0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5.0, 6.0, 7.0, 7.99, -0.25, -0.75, -1.25, -1.75, -2.5, -3.5,
+                             -5.0, -7.0, 4.0, 0.5, 0.1, 0.24, 0.26, 0.74, 0.76, 1.24, 1.26, 2.49, 2.51, 4.99, 5.01, -0.0]), N // 32)
+    extra = np.stack([rng.standard_normal(N) * 10.0 ** rng.integers(-4, 3), rng.standard_normal(N) * 300,
+                      np.where(rng.random(N) < 0.5, 0, rng.standard_normal(N)),
+                      np.repeat(rng.standard_normal(N // 32) * np.array([1e-6, 1, 100, 6e4] * (N // 128)), 32),
+                      ties, ties * 2.0 ** -9, ties * 2.0 ** 12, ties * 2.0 ** -22,
+                      np.exp2(rng.integers(-24, 16, N)) * rng.choice([-1.0, 1.0], N) * rng.choice([1.0, 1.25, 1.5, 1.75], N),
+                      np.full(N, 2.0 ** -24), np.full(N, -65504.0)])
+    with np.errstate(over="ignore"):
+        x16 = np.concatenate([x16, extra.astype(np.float16)])
+    e = x16[0].copy(); e[64:96] = np.nan; e[200] = np.inf; e[201] = -np.inf; e[300:332] = np.inf       # a group of NaNs only, a group of infs only
+    x16 = np.concatenate([x16, e[None]])
+    scales, lens, recs = gpu_compress(lib, x16, 5, 0)
+    o_scales, o_lens, o_recs = oracle.compress_blocks_f16(x16, 5, 0)
+    assert np.array_equal(lens, o_lens) and (lens == 1088).all() and (scales == 1.0).all()
+    for b in range(x16.shape[0]):
+        assert recs[b, :1088].tobytes() == o_recs[b, :1088].tobytes(), f"block {b}: first byte {np.flatnonzero(recs[b, :1088] != o_recs[b, :1088])[:4]}"
+    for out_f32 in (False, True):
+        y = gpu_decompress(lib, o_recs, o_lens, o_scales, 5, 0, out_f32)
+        for b in range(x16.shape[0]):
+            want = (oracle.decompress_block_f32 if out_f32 else oracle.decompress_block_f16)(o_recs[b, :1088], 1.0, 5, 0, N)
+            assert_same_float_bits(y[b], want, f"mxfp4 f32={out_f32} block {b}")
+    # every nibble under a spread of codes (0, 1: subnormal floats; 254: overflow of 6 x 2^127 to inf; 255: NaN)
+    rec = np.zeros((4, 4096), np.uint8)
+    rec[:, :1024] = (np.arange(1024) * 37 + 11).astype(np.uint8)
+    rec[0, 1024:1088] = np.array([0, 1, 100, 101, 126, 127, 128, 140, 141, 150, 254, 255, 103, 110, 120, 130] * 4, np.uint8)
+    rec[1, 1024:1088] = np.arange(64) + 96
+    rec[2, 1024:1088] = np.arange(64) * 4
+    rec[3, 1024:1088] = 255 - np.arange(64)
+    ln = np.full(4, 1088, np.uint32)
+    for out_f32 in (False, True):
+        y = gpu_decompress(lib, rec, ln, np.ones(4, np.float32), 5, 0, out_f32)
+        for b in range(4):
+            want = (oracle.decompress_block_f32 if out_f32 else oracle.decompress_block_f16)(rec[b, :1088], 1.0, 5, 0, N)
+            assert_same_float_bits(y[b], want, f"all nibbles f32={out_f32} row {b}")
+    # round trip (size-independent): |x - y| <= half a grid step of the group, a whole one where the format clamps (|x| / X in (6, 8))
+    y = gpu_decompress(lib, recs, lens, scales, 5, 0, True)
+    xf = x16.astype(np.float32)
+    for b in np.flatnonzero(np.isfinite(xf).all(axis=1)):
+        X = np.exp2(recs[b, 1024:1088].astype(np.float64) - 127)
+        bound = np.repeat(X, 32) * np.where(np.abs(xf[b]) / np.repeat(X, 32) > 6, 2.0, 1.0)
+        assert (np.abs(y[b] - xf[b]) <= bound + 1e-30).all(), f"block {b}"
+    # a short record decodes to zeros
+    lens2 = lens.copy(); lens2[0] = 1087
+    y = gpu_decompress(lib, recs, lens2, scales, 5, 0, True)
+    assert not y[0].any() and y[1].any()
+
+
 def test_golden_reference_vectors(lib, golden_dir):
     """Reference-generated vectors (tests/golden/codec_vectors.npz): the HIP path
     reproduces the reference's bytes and fp32 outputs without the oracle in between."""

@@ -147,7 +147,7 @@ def slab():
     return lib
 
 
-@pytest.mark.parametrize("stride", [2048, 1152, 4096])
+@pytest.mark.parametrize("stride", [2048, 1152, 4096, 1088])
 def test_slab_subrange_free_never_reaches_live_records(slab, stride):
     """freeing record 1 of a run of 64 and allocating again must not hand out bytes of record 2."""
     p = slab.slabtest_new(1 << 20, 0)
@@ -171,7 +171,7 @@ def test_slab_random_alloc_free_keeps_runs_disjoint(slab):
         if live and rng.random() < 0.45:
             i = int(rng.integers(0, len(live)))
             addr, n = live.pop(i)
-            stride = 128 * int(rng.integers(1, 9))
+            stride = 128 * int(rng.integers(1, 9)) if n % 128 == 0 else 1088
             if n > 2 * stride and rng.random() < 0.5:             # free a middle piece first, then the two rests
                 k = (n // stride) // 2 * stride
                 slab.slabtest_free(p, addr + k, stride)
@@ -182,16 +182,29 @@ def test_slab_random_alloc_free_keeps_runs_disjoint(slab):
                 slab.slabtest_free(p, addr, n)
         else:
             n = 128 * int(rng.integers(1, 600))
-            if rng.random() < 0.2:
+            kind = rng.random()
+            got = C.c_size_t()
+            if kind < 0.2:
                 got = C.c_size_t()
                 want = max(n, 1152)
                 a = slab.slabtest_alloc_up_to(p, want, 1152, C.byref(got))
                 n = got.value
                 assert a and n and n % 1152 == 0 and n <= want
+            elif kind < 0.4:                                       # runs of 1088-byte MXFP4 records: 64-byte granule
+                n = 1088 * int(rng.integers(1, 70))
+                if rng.random() < 0.5:
+                    got = C.c_size_t()
+                    a = slab.slabtest_alloc_up_to(p, n, 1088, C.byref(got))
+                    n = got.value
+                    assert a and n and n % 1088 == 0
+                else:
+                    a = slab.slabtest_alloc(p, n)
+                    assert a
             else:
                 a = slab.slabtest_alloc(p, n)
                 assert a
-            assert a % 128 == 0
+            by_record_1088 = 0.2 <= kind < 0.4 and got.value == n if 0.2 <= kind < 0.4 else False
+            assert a % 64 == 0 and (n % 128 or by_record_1088 or a % 128 == 0)      # runs of whole cache lines start on a line
             for b, m in live:
                 assert a + n <= b or b + m <= a, "overlapping live runs"
             live.append((a, n))
