@@ -495,6 +495,38 @@ speckv_status_t speckv_ext_attend_int4(speckv_handle_t handle, uint32_t layer_be
     });
 }
 
+speckv_status_t speckv_ext_attend_mx4(speckv_handle_t handle, uint32_t layer_begin, uint32_t n_layers, const void* d_q_f16,
+                                      uint32_t g, uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out,
+                                      float* d_lse, void* stream)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] {
+        return g_engine->attend_mx4(handle, layer_begin, n_layers, d_q_f16, g, pos_begin, pos_end, sm_scale, d_out, d_lse,
+                                    static_cast<hipStream_t>(stream));
+    });
+}
+
+speckv_status_t speckv_ext_attend_mx4_batch(uint32_t n_seq, const speckv_handle_t* handles, uint32_t layer, const void* d_q_f16,
+                                            uint32_t g, const uint32_t* pos_end, float sm_scale, float* d_out, float* d_lse,
+                                            void* stream)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] {
+        return g_engine->attend_batch(SPECKV_COMP_MXFP4, n_seq, handles, layer, d_q_f16, g, pos_end, sm_scale, d_out, d_lse,
+                                      static_cast<hipStream_t>(stream));
+    });
+}
+
+speckv_status_t speckv_ext_attend_mx4_planned(const void* d_plan, uint32_t n_seq, uint32_t layer, const void* d_q_f16, uint32_t g,
+                                              uint32_t max_pos_end, float sm_scale, float* d_out, float* d_lse, void* stream)
+{
+    LOCK; NEED_INIT;
+    return guarded([&] {
+        return g_engine->attend_planned(SPECKV_COMP_MXFP4, d_plan, n_seq, layer, d_q_f16, g, max_pos_end, sm_scale, d_out, d_lse,
+                                        static_cast<hipStream_t>(stream));
+    });
+}
+
 speckv_status_t speckv_ext_promote_to_l1(speckv_handle_t handle, uint64_t offset_bytes)
 {
     LOCK; NEED_INIT;

@@ -163,6 +163,8 @@ public:
                      const uint32_t* pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
     int attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
                     uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
+    int attend_mx4(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
+                   uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
     int migrate(uint64_t handle, uint64_t first_page, uint64_t n_pages, uint32_t target_pool);
     int compact(uint64_t handle, uint64_t* bytes_before, uint64_t* bytes_after);
     int predictor_load(const float* emb, const float* wout, uint32_t vocab, bool on_device);

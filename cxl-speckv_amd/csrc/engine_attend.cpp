@@ -227,10 +227,21 @@ static uint32_t int4_wg8_batch_tps(uint32_t n_seq, uint32_t tiles_max)
     return std::max(32u, (tiles_max + splits - 1u) / splits);
 }
 
+// MXFP4 batches (k_attend_mx4: one workgroup of 8 / HPW waves per (sequence, split), all 8 kv heads; four 4-wave workgroups
+// resident per CU): about one round of resident workgroups, never under 8 tiles a split; a whole sequence is final (no
+// partials, no merge launch).
+static uint32_t mx4_batch_tps(uint32_t n_seq, uint32_t tiles_max)
+{
+    if (const char* env = getenv("SPECKV_ATTEND_TILES_PER_SPLIT")) return std::max(1, atoi(env));      // (measurement runs)
+    const uint32_t resident = 1024u;
+    const uint32_t splits = std::max(1u, resident / std::max(1u, n_seq));
+    return std::max(8u, (tiles_max + splits - 1u) / splits);
+}
+
 int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, uint32_t layer, const void* d_q_f16, uint32_t g,
                          const uint32_t* pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
 {
-    const bool fp8 = scheme == SPECKV_COMP_FP8_E4M3;
+    const bool fp8 = scheme == SPECKV_COMP_FP8_E4M3, mx4 = scheme == SPECKV_COMP_MXFP4;
     if (null_) return no_data_path("speckv_ext_attend_*_batch");
     if (n_seq == 0) return SPECKV_OK;
     if (is_capturing(s)) {
@@ -296,9 +307,9 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
         for (uint32_t i = 0; i < n_seq; ++i) seqs[i].lin_base = reinterpret_cast<const uint8_t*>(ents[i]);
     uint32_t tiles_max = 0;
     for (uint32_t i = 0; i < n_seq; ++i) tiles_max = std::max(tiles_max, seqs[i].n_splits);
-    const bool wg8 = !fp8 && !any_striped && !any_table && heads == 8u && int4_batch_wg8();
-    const uint32_t tps = wg8 ? int4_wg8_batch_tps(n_seq, tiles_max) : batch_tiles_per_split(fp8, n_seq, heads, total_tiles, seqs.data(), 0);
-    const UnequalSplit unequal = (fp8 || wg8) ? UnequalSplit{false, 1.0} : int4_unequal_split(n_seq, heads / 4u, tiles_max);
+    const bool wg8 = !fp8 && !mx4 && !any_striped && !any_table && heads == 8u && int4_batch_wg8();
+    const uint32_t tps = mx4 ? mx4_batch_tps(n_seq, tiles_max) : wg8 ? int4_wg8_batch_tps(n_seq, tiles_max) : batch_tiles_per_split(fp8, n_seq, heads, total_tiles, seqs.data(), 0);
+    const UnequalSplit unequal = (fp8 || mx4 || wg8) ? UnequalSplit{false, 1.0} : int4_unequal_split(n_seq, heads / 4u, tiles_max);
     uint32_t max_splits = 0;
     uint64_t parts = 0;
     for (uint32_t i = 0; i < n_seq; ++i) {
@@ -363,6 +374,8 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     if (wg8) k.wg8 = int4_wg8_form(n_seq);
     if (fp8) {
         HIP_TRY(launch_attend_fp8_batch(k, n_seq, d_out, d_lse, st));
+    } else if (mx4) {
+        HIP_TRY(launch_attend_mx4(k, n_seq, d_out, d_lse, st));
     } else {
         HIP_TRY(launch_attend_int4(k, n_seq, st));        // grid y = sequences x head groups, as for layers
         if (!k.direct_out) HIP_TRY(launch_attend_combine(k, n_seq, d_out, d_lse, st));
@@ -377,10 +390,17 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
 // of the caller; speckv_ext_attend_*_planned is kernel launches only: no handle look-ups, no staging, grid and scratch
 // sized from max_pos_end alone, so a captured launch stays valid for as long as the lengths stay within that bound.
 struct PlanGeometry { uint32_t tps, max_splits; uint64_t parts_bound; UnequalSplit unequal; };
-static PlanGeometry plan_geometry(bool fp8, uint32_t n_seq, uint32_t heads, uint32_t max_pos_end)
+static PlanGeometry plan_geometry(bool fp8, uint32_t n_seq, uint32_t heads, uint32_t max_pos_end, bool mx4 = false)
 {
     const uint32_t tiles_max = (max_pos_end / 2u + 15u) / 16u;
     PlanGeometry g{};
+    if (mx4) {
+        g.unequal = UnequalSplit{false, 1.0};
+        g.tps = mx4_batch_tps(n_seq, tiles_max);
+        g.max_splits = std::max(1u, (tiles_max + g.tps - 1u) / g.tps);
+        g.parts_bound = static_cast<uint64_t>(n_seq) * heads * g.max_splits;
+        return g;
+    }
     if (!fp8 && heads == 8u && int4_batch_wg8()) {            // the whole-record kernel's geometry (a striped / table launch runs it on the 4-head kernels)
         g.unequal = UnequalSplit{false, 1.0};
         g.tps = int4_wg8_batch_tps(n_seq, tiles_max);
@@ -417,7 +437,7 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
         Allocation* a = find(handles[i]);
         if (!a) return SPECKV_ERR_GENERAL;
         if (scheme < 0) scheme = a->scheme;
-        if (!a->has_layout || a->scheme != scheme || (scheme != SPECKV_COMP_FP8_E4M3 && scheme != SPECKV_COMP_INT4_G32)) return SPECKV_ERR_INVAL;
+        if (!a->has_layout || a->scheme != scheme || (scheme != SPECKV_COMP_FP8_E4M3 && scheme != SPECKV_COMP_INT4_G32 && scheme != SPECKV_COMP_MXFP4)) return SPECKV_ERR_INVAL;
         const Layout& L = a->layout;
         if (L.head_dim != 128 || L.bytes_per_element != 2 || L.num_heads * L.head_dim != 1024 || L.num_tokens % 2) return SPECKV_ERR_INVAL;
         if (pos_end[i] % 2 || pos_end[i] > L.num_tokens || pos_end[i] > max_pos_end) return SPECKV_ERR_INVAL;
@@ -440,7 +460,7 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
         seqs[i].n_pages = n_pages;
         seqs[i].n_splits = n_tiles;
     }
-    const PlanGeometry g = plan_geometry(scheme == SPECKV_COMP_FP8_E4M3, n_seq, heads, max_pos_end);
+    const PlanGeometry g = plan_geometry(scheme == SPECKV_COMP_FP8_E4M3, n_seq, heads, max_pos_end, scheme == SPECKV_COMP_MXFP4);
     if (g.max_splits > 2048u) return SPECKV_ERR_INVAL;
     if (plans_.size() >= 64 && !plans_.count(d_plan)) plans_.clear();        // (buffers of long-gone steps)
     if (any_table)
@@ -482,7 +502,7 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
 int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint32_t layer, const void* d_q_f16, uint32_t g,
                            uint32_t max_pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
 {
-    const bool fp8 = scheme == SPECKV_COMP_FP8_E4M3;
+    const bool fp8 = scheme == SPECKV_COMP_FP8_E4M3, mx4 = scheme == SPECKV_COMP_MXFP4;
     if (null_) return no_data_path("speckv_ext_attend_*_planned");
     if (n_seq == 0) return SPECKV_OK;
     if (!d_plan || !d_q_f16 || !d_out || !s || g == 0 || g > 16 || max_pos_end % 2 || max_pos_end == 0) return SPECKV_ERR_INVAL;
@@ -493,7 +513,7 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
         SPECKV_ERR("speckv_ext_attend_*_planned: no plan of this shape at %p (n_seq, format and max_pos_end as planned, layer inside every layout)", d_plan);
         return SPECKV_ERR_INVAL;
     }
-    const PlanGeometry pg = plan_geometry(fp8, n_seq, heads, max_pos_end);
+    const PlanGeometry pg = plan_geometry(fp8, n_seq, heads, max_pos_end, mx4);
     DeviceScope device_scope(device_);
     const size_t acc_bytes = static_cast<size_t>(pg.parts_bound) * 16 * 128 * sizeof(float), ml_bytes = static_cast<size_t>(pg.parts_bound) * 32 * sizeof(float);
     uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes, s));      // (growth during a capture is refused: warm up once)
@@ -509,7 +529,7 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
     k.scale_log2e = sm_scale * 1.4426950408889634f;
     if (plan->second.table) { k.table_form = 1u; k.zero_page = d_zero_page_; }           // a member without a regular placement: addresses from the page tables
     else if (plan->second.striped) k.stripe_bases = reinterpret_cast<const uint64_t*>(1);     // striped launch: every descriptor brings its table
-    else { k.lin_base = reinterpret_cast<const uint8_t*>(1); if (!fp8 && int4_batch_wg8()) k.wg8 = int4_wg8_form(n_seq); }     // non-null: linear form (the real base comes from the descriptor)
+    else { k.lin_base = reinterpret_cast<const uint8_t*>(1); if (!fp8 && !mx4 && int4_batch_wg8()) k.wg8 = int4_wg8_form(n_seq); }     // non-null: linear form (the real base comes from the descriptor)
     k.seqs = static_cast<const AttendSeq*>(d_plan);
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
@@ -521,6 +541,8 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
     if (pg.unequal.on) k.rows_first = 1u;
     if (fp8) {
         HIP_TRY(launch_attend_fp8_batch(k, n_seq, d_out, d_lse, s));
+    } else if (mx4) {
+        HIP_TRY(launch_attend_mx4(k, n_seq, d_out, d_lse, s));
     } else {
         HIP_TRY(launch_attend_int4(k, n_seq, s));
         if (k.direct_per_seq != 2u) HIP_TRY(launch_attend_combine(k, n_seq, d_out, d_lse, s));
@@ -676,6 +698,90 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     if (n_splits == 1u && !stream) { k.direct_out = d_out; k.direct_lse = d_lse; }      // no merge launch
     HIP_TRY(launch_attend_int4(k, n_layers, st));
     if (!k.direct_out) HIP_TRY(launch_attend_combine(k, n_layers, d_out, d_lse, st));
+    note_use(a, s);
+    if (!s) RC_TRY(wait_stream());
+    return SPECKV_OK;
+}
+
+// Fused decode attention over MXFP4 K and V records (attend_mx4.hip): any placement.
+int Engine::attend_mx4(uint64_t handle, uint32_t layer, uint32_t n_layers, const void* d_q_f16, uint32_t g,
+                       uint32_t pos_begin, uint32_t pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
+{
+    if (null_) return no_data_path("speckv_ext_attend_mx4");
+    Allocation* a = find(handle);
+    if (!a) return SPECKV_ERR_GENERAL;
+    if (!a->has_layout || a->scheme != SPECKV_COMP_MXFP4) return SPECKV_ERR_INVAL;
+    const Layout& L = a->layout;
+    if (L.head_dim != 128 || L.bytes_per_element != 2 || L.num_heads * L.head_dim != 1024 || L.num_tokens % 2) return SPECKV_ERR_INVAL;
+    if (n_layers == 0 || layer >= L.num_layers || n_layers > L.num_layers - layer || pos_begin % 2 || pos_begin > pos_end ||
+        pos_end > L.num_tokens || pos_end % 2)
+        return SPECKV_ERR_INVAL;
+    if (g == 0 || g > 16 || !d_q_f16 || !d_out) return SPECKV_ERR_INVAL;
+    const uint32_t n_pages = (pos_end - pos_begin) / 2;
+    DeviceScope device_scope(device_);
+    // NULL = the engine's stream and a synchronous call: the query may have been produced on any stream of the caller
+    if (!s) HIP_TRY(hipDeviceSynchronize());
+    hipStream_t st = s ? s : stream_;
+    const size_t out_elems = static_cast<size_t>(n_layers) * L.num_heads * g * 128;
+    if (n_pages == 0) {
+        HIP_TRY(hipMemsetAsync(d_out, 0, out_elems * sizeof(float), st));
+        if (!s) HIP_TRY(hipStreamSynchronize(stream_));
+        return SPECKV_OK;
+    }
+    // tiles of 32 positions count from pos_begin (the scales travel inside the records: no table to stay aligned with)
+    const uint64_t k_first = (static_cast<uint64_t>(layer) * 2 * L.num_tokens + pos_begin) / 2;
+    const uint64_t v_first = k_first + L.num_tokens / 2;
+    const uint64_t layer_stride = static_cast<uint64_t>(L.num_tokens);
+    if (v_first + (n_layers - 1) * layer_stride + n_pages > a->n_pages) return SPECKV_ERR_GENERAL;
+    const uint32_t n_tiles = (n_pages + 15u) / 16u;
+    // arithmetic addresses need every 32-position tile inside the layer's K / V region (the last one may be ragged); otherwise,
+    // or without a regular placement, the page-table form: its look-ups are clamped to the range
+    const bool fits = static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
+    const char* general_env = getenv("SPECKV_ATTEND_GENERAL");
+    const bool linear = a->linear_base && fits && !general_env;
+    const bool striped = !linear && a->stripe_n >= 2 && fits && !general_env;
+    const bool table = !linear && !striped;
+    if (table && !d_zero_page_) {
+        if (is_capturing(s)) return SPECKV_ERR_INVAL;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
+        HIP_TRY(hipMemset(d_zero_page_, 0, kPageSize));
+    }
+    // workgroups = splits x layers (each covers the 8 kv heads), about two rounds of the resident set (four 4-wave workgroups per CU)
+    const uint32_t rows = n_layers * L.num_heads;
+    uint32_t want = std::max(1u, (2048u + n_layers - 1u) / n_layers);
+    const uint32_t min_tiles = std::min(8u, std::max(2u, n_tiles / 64u));      // per-layer calls: see attend_fp8
+    want = std::min(want, std::max(1u, n_tiles / min_tiles));
+    if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));
+    const EvenSplit es = even_split(n_tiles, std::max(1u, std::min(want, 2048u)));
+    const uint32_t n_splits = es.n_splits, tiles_per_split = es.tiles_per_split;
+    const size_t acc_bytes = static_cast<size_t>(rows) * n_splits * 16 * 128 * sizeof(float);
+    const size_t ml_bytes = static_cast<size_t>(rows) * n_splits * 32 * sizeof(float);
+    uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes, s));
+    if (!buf) return SPECKV_ERR_NOMEM;
+    AttendArgs k{};
+    k.entries = a->d_entries;
+    k.k_first = k_first;
+    k.v_first = v_first;
+    k.layer_stride = layer_stride;
+    k.n_pages = n_pages;
+    k.heads = L.num_heads;
+    k.g = g;
+    k.n_splits = n_splits;
+    k.tiles_per_split = tiles_per_split;
+    k.q16 = static_cast<const uint16_t*>(d_q_f16);
+    k.scale_log2e = sm_scale * 1.4426950408889634f;
+    k.lin_base = linear ? a->linear_base : nullptr;
+    if (table) k.table_form = 1u;
+    if (striped) {
+        k.stripe_bases = a->d_stripe;
+        k.stripe_n = a->stripe_n;
+        k.stripe_magic = static_cast<uint32_t>((1ull << 32) / a->stripe_n + 1u);
+    }
+    k.zero_page = d_zero_page_;
+    k.part_acc = reinterpret_cast<float*>(buf);
+    k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
+    if (n_splits == 1u) { k.direct_out = d_out; k.direct_lse = d_lse; }      // no merge launch
+    HIP_TRY(launch_attend_mx4(k, n_layers, d_out, d_lse, st));
     note_use(a, s);
     if (!s) RC_TRY(wait_stream());
     return SPECKV_OK;

@@ -339,6 +339,9 @@ __host__ __device__ inline uint32_t attend_tile_slot(uint32_t j) { return j < 8u
 // [layers][heads][g][128]); writes the split partials, launch_attend_combine merges them
 hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_t s);
 hipError_t launch_attend_combine(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s);
+// MXFP4 records (attend_mx4.hip): a.lin_base | a.stripe_bases | a.table_form choose the address form, a.q16 = the fp16 query rows,
+// a.seqs the batch descriptors; n_rows = layers or sequences.  Launches the merge itself when the rows are not final.
+hipError_t launch_attend_mx4(const AttendArgs& a, uint32_t n_rows, float* d_out, float* d_lse, hipStream_t s);
 // scores only, linear form (a.lin_base, a.scale_tab, a.q16, a.tiles_per_split): d_out [layers][heads][g][2*n_pages]
 hipError_t launch_qk_scores_fp8_linear(const AttendArgs& a, uint32_t n_layers, float* d_out, hipStream_t s);
 // batch form: a.seqs (device) holds n_seq descriptors, a.q16 = [n_seq][heads][g][128], a.n_splits = the largest

@@ -86,6 +86,9 @@ _EXT_SIGNATURES = {
     "speckv_ext_attend_int4_planned": [c_void_p, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, ctypes.c_float, c_void_p, c_void_p, c_void_p],
     "speckv_ext_attend_fold_tail": [c_uint32, c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_uint64, ctypes.c_float, c_void_p, c_void_p, c_void_p],
     "speckv_ext_attend_int4": [c_uint64, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, c_uint32, ctypes.c_float, c_void_p, c_void_p, c_void_p],
+    "speckv_ext_attend_mx4": [c_uint64, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, c_uint32, ctypes.c_float, c_void_p, c_void_p, c_void_p],
+    "speckv_ext_attend_mx4_batch": [c_uint32, ctypes.POINTER(c_uint64), c_uint32, c_void_p, c_uint32, _u32p, ctypes.c_float, c_void_p, c_void_p, c_void_p],
+    "speckv_ext_attend_mx4_planned": [c_void_p, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, ctypes.c_float, c_void_p, c_void_p, c_void_p],
     "speckv_ext_promote_to_l1": [c_uint64, c_uint64],
     "speckv_ext_demote_to_l3": [c_uint64, c_uint64],
     "speckv_ext_migrate": [c_uint64, c_uint64, c_uint64, c_uint32],
@@ -390,7 +393,7 @@ class SpeckvLib:
 
     def attend_planned(self, scheme, d_plan, n_seq, layer, d_q_f16, g, max_pos_end, sm_scale, d_out, d_lse, stream):
         """One layer of a planned batch: kernel launches only (capturable).  scheme: 4 (FP8_E4M3) or 3 (INT4_G32)."""
-        name = "speckv_ext_attend_fp8_planned" if scheme == 4 else "speckv_ext_attend_int4_planned"
+        name = {4: "speckv_ext_attend_fp8_planned", 3: "speckv_ext_attend_int4_planned", 5: "speckv_ext_attend_mx4_planned"}[scheme]
         self._ext(name, c_void_p(d_plan), n_seq, layer, c_void_p(d_q_f16), g, max_pos_end, ctypes.c_float(sm_scale),
                   c_void_p(d_out), c_void_p(d_lse or 0), c_void_p(stream))
 
@@ -398,6 +401,18 @@ class SpeckvLib:
                     stream=None):
         self._ext("speckv_ext_attend_int4", handle, layer_begin, n_layers, c_void_p(d_q_f16), g, pos_begin, pos_end,
                   ctypes.c_float(sm_scale), c_void_p(d_out), c_void_p(d_lse or 0), c_void_p(stream or 0))
+
+    def attend_mx4(self, handle, layer_begin, n_layers, d_q_f16, g, pos_begin, pos_end, sm_scale, d_out, d_lse=None,
+                   stream=None):
+        self._ext("speckv_ext_attend_mx4", handle, layer_begin, n_layers, c_void_p(d_q_f16), g, pos_begin, pos_end,
+                  ctypes.c_float(sm_scale), c_void_p(d_out), c_void_p(d_lse or 0), c_void_p(stream or 0))
+
+    def attend_mx4_batch(self, handles, layer, d_q_f16, g, pos_end, sm_scale, d_out, d_lse=None, stream=None):
+        n = len(handles)
+        hs = handles if isinstance(handles, ctypes.Array) else (c_uint64 * n)(*handles)
+        pe = pos_end if isinstance(pos_end, ctypes.Array) else (c_uint32 * n)(*pos_end)
+        self._ext("speckv_ext_attend_mx4_batch", n, hs, layer, c_void_p(d_q_f16), g, pe, ctypes.c_float(sm_scale),
+                  c_void_p(d_out), c_void_p(d_lse or 0), c_void_p(stream or 0))
 
     def promote_to_l1(self, handle, offset):
         return self.lib.speckv_ext_promote_to_l1(handle, offset) == 0

@@ -259,6 +259,7 @@ speckv_status_t speckv_ext_codec_decompress_tensor(const void* d_rle, uint64_t r
  *      A22: no reference counterpart, parity is against oracle/ only) -----------
  * SPECKV_COMP_INT4_G32: record 1152 B = 64 fp16 group scales + 2048 nibbles.
  * SPECKV_COMP_FP8_E4M3: record 2048 B of OCP e4m3fn + one f32 scale per block.
+ * SPECKV_COMP_MXFP4:    record 1088 B = 2048 E2M1 nibbles + 64 E8M0 block scales (OCP MX v1.0; speckv_ext_attend_mx4).
  * speckv_ext_qk_scores_fp8: attention scores q.K^T for positions
  * [pos_begin, pos_end) (both even) of `layer`, computed on the matrix cores
  * directly from the FP8 records of the K region (request 0 of the shim layout;
@@ -321,6 +322,27 @@ speckv_status_t speckv_ext_attend_int4(speckv_handle_t handle, uint32_t layer_be
 speckv_status_t speckv_ext_attend_int4_batch(uint32_t n_seq, const speckv_handle_t* handles, uint32_t layer,
                                              const void* d_q_f16, uint32_t g, const uint32_t* pos_end, float sm_scale,
                                              float* d_out, float* d_lse, void* stream);
+
+/* speckv_ext_attend_mx4: the same attention over SPECKV_COMP_MXFP4 records -- the 4:1 format gfx950's matrix cores read
+ * natively (OCP Microscaling Formats v1.0: FP4 E2M1 elements, one E8M0 power-of-two scale per 32 elements; record = 1024 B of
+ * nibbles, element 2i in the low half of byte i, then the 64 scale codes: 1088 B per 4 KiB block, 3.76 : 1).
+ * q.K^T runs on v_mfma_scale_f32_16x16x128_f8f6f4: one instruction contracts the whole head dimension, K nibbles and scale
+ * codes go in as they lie in the record, the block scales are applied by the hardware; the query is quantised to MXFP8
+ * (e4m3 elements, E8M0 per 32: emax 8, saturating) on the device.  V is widened to f16 WITH its block scale by one
+ * v_cvt_scalef32_pk_f16_fp4 per element pair and meets the f16 softmax weights on v_mfma_f32_16x16x32_f16, fp32 accumulation.
+ * Any placement is served (one run, regular striping, page-table addresses).  g <= 16 query rows per kv head; waves take
+ * 16 / g' heads at once (g' = g rounded up to 4, 8 or 16) so that every column of the score MFMA is a live query row.
+ * (oracle: orc_attend_mx4; arguments as speckv_ext_attend_int4.) */
+speckv_status_t speckv_ext_attend_mx4(speckv_handle_t handle, uint32_t layer_begin, uint32_t n_layers,
+                                      const void* d_q_f16, uint32_t g, uint32_t pos_begin, uint32_t pos_end,
+                                      float sm_scale, float* d_out, float* d_lse, void* stream);
+/* The batch and planned forms for MXFP4 allocations (arguments as speckv_ext_attend_fp8_batch / _planned). */
+speckv_status_t speckv_ext_attend_mx4_batch(uint32_t n_seq, const speckv_handle_t* handles, uint32_t layer,
+                                            const void* d_q_f16, uint32_t g, const uint32_t* pos_end, float sm_scale,
+                                            float* d_out, float* d_lse, void* stream);
+speckv_status_t speckv_ext_attend_mx4_planned(const void* d_plan, uint32_t n_seq, uint32_t layer, const void* d_q_f16,
+                                              uint32_t g, uint32_t max_pos_end, float sm_scale, float* d_out,
+                                              float* d_lse, void* stream);
 
 /* ---- planned batches: the batch attention of a decode step under a HIP graph -------------------------------------
  * The batch calls above stage their per-sequence descriptors on every call and cannot be captured.  The planned form

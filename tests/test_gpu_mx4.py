@@ -1,0 +1,338 @@
+"""-m gpu: scheme 5, MXFP4 (OCP MX v1.0: E2M1 elements, one E8M0 scale per 32) through the engine and the fused attention on the
+block-scaled matrix instruction (BASELINE configs[4] "int4/fp8 KV compression path (CDNA4 fp8 MFMA dequant), 4:1 ratio"; SURVEY 8a row
+A22: no reference counterpart -- the oracle's MX functions are pinned to a numpy restatement of the spec text by
+tests/test_a22_format_pin.py, the block codec kernels to the oracle by tests/test_gpu_codec.py::test_mxfp4_block_format_matches_oracle).
+
+Attention checker: orc_attend_mx4 -- double-precision attention over the dequantised K / V values with the query quantised to MXFP8
+exactly as the kernel does (orc_quantize_rows_mxfp8).  Error sources of the HIP path: the softmax weights rounded to f16 (2^-11
+each), v_exp_f32, fp32 accumulation, and the scaled MFMA's fp32 accumulation of a score (delta <= 3e-5 * sum|q||k| per score, as for
+the FP8 path), which moves each weight by a relative delta.  Stated tolerance, with mag = sum_t p_t |v_t|:
+    |got - want| <= (2e-3 + 2 * delta_max) * mag + 1e-6,   lse within 2e-3 + delta_max."""
+import os
+
+import numpy as np
+import pytest
+
+import cxl_speckv_amd as pkg
+from tests._gpu import N, assert_same_float_bits, torch_mod
+
+pytestmark = pytest.mark.gpu
+PAGE = 4096
+REC = 1088
+H, D = 8, 128
+E2M1 = np.array([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0, -0.0, -0.5, -1.0, -1.5, -2.0, -3.0, -4.0, -6.0], np.float64)
+E4M3 = None
+
+
+def e4m3_lut(oracle):
+    global E4M3
+    if E4M3 is None:
+        E4M3 = np.array([oracle.lib.orc_e4m3_to_f32(b) for b in range(256)], np.float64)
+        E4M3[np.isnan(E4M3)] = 0.0
+    return E4M3
+
+
+@pytest.fixture()
+def eng():
+    kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), "hip:0")
+    yield kv
+    kv.close()
+
+
+def head_rows(recs, first_page, n_pos, head):
+    """nibble rows [n_pos][64] and code rows [n_pos][4] of one kv head from MXFP4 records of pages first_page ..."""
+    r = recs[first_page:first_page + n_pos // 2, :REC]
+    nib = r[:, :1024].reshape(-1, 2, H, 64)[:, :, head, :].reshape(n_pos, 64)
+    codes = r[:, 1024:].reshape(-1, 2, H, 4)[:, :, head, :].reshape(n_pos, 4)
+    return np.ascontiguousarray(nib), np.ascontiguousarray(codes)
+
+
+def dequant_rows(nib, codes):
+    q = np.empty((nib.shape[0], 128), np.int64)
+    q[:, 0::2] = nib & 0xF
+    q[:, 1::2] = nib >> 4
+    return E2M1[q] * np.repeat(np.exp2(codes.astype(np.float64) - 127.0), 32, axis=1)
+
+
+def oracle_attention(oracle, recs, q16, T, layer, pb, pe, sm_scale, g):
+    """orc_attend_mx4 for every head of `layer` over positions [pb, pe): (out, lse, mag, delta)"""
+    from oracle.bindings import _ptr, u8p, u16p, f32p
+    L = oracle.lib
+    npos = pe - pb
+    kf = (layer * 2 * T + pb) // 2
+    vf = kf + T // 2
+    out = np.zeros((H, g, D), np.float32); lse = np.zeros((H, g), np.float32); mag = np.zeros((H, g, D), np.float32)
+    delta = 0.0
+    lut = e4m3_lut(oracle)
+    for head in range(H):
+        kn, kc = head_rows(recs, kf, npos, head)
+        vn, vc = head_rows(recs, vf, npos, head)
+        qh = np.ascontiguousarray(q16[head]).view(np.uint16).reshape(-1)
+        q8 = np.zeros((g, D), np.uint8); qc = np.zeros((g, D // 32), np.uint8)
+        L.orc_quantize_rows_mxfp8(_ptr(qh, u16p), g, D, _ptr(q8, u8p), _ptr(qc, u8p))
+        qd = lut[q8] * np.repeat(np.exp2(qc.astype(np.float64) - 127.0), 32, axis=1)
+        smag = (np.abs(qd) @ np.abs(dequant_rows(kn, kc)).T) * sm_scale
+        delta = max(delta, 3e-5 * float(smag.max()))
+        o = np.zeros((g, D), np.float32); l = np.zeros(g, np.float32); m = np.zeros((g, D), np.float32)
+        L.orc_attend_mx4(_ptr(q8, u8p), _ptr(qc, u8p), g, _ptr(kn, u8p), _ptr(kc, u8p), _ptr(vn, u8p), _ptr(vc, u8p), npos, D,
+                         float(sm_scale), _ptr(o, f32p), _ptr(l, f32p), _ptr(m, f32p))
+        out[head], lse[head], mag[head] = o, l, m
+    return out, lse, mag, delta
+
+
+def check(got, glse, want, wlse, mag, delta, what):
+    err = np.abs(got - want)
+    assert np.all(err <= (2e-3 + 2 * delta) * mag + 1e-6), (what, float((err / (mag + 1e-9)).max()), delta)
+    if glse is not None:
+        assert np.all(np.abs(glse - wlse) <= 2e-3 + delta), (what, float(np.abs(glse - wlse).max()))
+
+
+def test_mxfp4_pool_write_fetch_translate(eng, oracle):
+    """Scheme 5 through the drop-in surface: set_compression_scheme(5), write, fetch+decompress bit for bit as the oracle
+    decodes the oracle's records; 1088 B per block in the page table; never-written pages are zeros."""
+    torch = torch_mod()
+    lib = eng.lib
+    lib.set_compression_scheme(5)
+    T, L = 128, 2
+    h = eng.allocate(T, L, H, D, 2)
+    n_pages = T * L * H * D * 2 * 2 // PAGE
+    rng = np.random.default_rng(71)
+    x = (rng.standard_normal((n_pages - 4, N)) * rng.uniform(0.01, 30.0, (n_pages - 4, 1))).astype(np.float16)
+    x[3] = 0; x[5] = np.repeat(x[5, :64], 32)
+    lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+    scales, lens, recs = oracle.compress_blocks_f16(x, 5, 0)
+    want = oracle.decompress_blocks_f16(recs, lens, scales, 5, 0)
+    for f32 in (False, True):
+        out = torch.full((n_pages, N), float("nan"), dtype=torch.float32 if f32 else torch.float16, device="cuda")
+        lib.fetch_range(h, 0, n_pages, out.data_ptr(), f32, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        if f32:
+            w32 = np.stack([oracle.decompress_block_f32(recs[i, :REC], 1.0, 5, 0, N) for i in range(n_pages - 4)])
+            assert_same_float_bits(got[:n_pages - 4], w32, "fp32 out")
+        else:
+            assert_same_float_bits(got[:n_pages - 4], want, "fp16 out")
+        assert not got[n_pages - 4:].any()                     # never written: zeros
+    for p in (0, 3, 5, n_pages - 5):
+        info = lib.translate(h, p * PAGE)
+        assert info.rec_bytes == REC and info.scheme == 5 and info.scale == 1.0
+        assert info.phys_page_id == oracle.lib.orc_phys_page_id(h, p)
+    assert lib.translate(h, (n_pages - 1) * PAGE).rec_bytes == 0
+    st = lib.stats()
+    assert st.compressed_bytes == (n_pages - 4) * REC and st.pool_bytes_in_use >= n_pages * REC
+    # speckv_access on a page: decoded copy in the cache tier
+    ptr = eng.get_kv_ptr(0, 0, 0, 6, 0, D * 2)
+    assert ptr
+    from tests._gpu import dev_to_host
+    page = (0 * 2 * T + 6) // 2
+    assert dev_to_host(ptr & ~0xFFF, PAGE).tobytes() == want[page].tobytes()
+
+
+@pytest.mark.parametrize("g", [8, 4, 16, 3, 11])
+def test_mx4_fused_attention(eng, oracle, g):
+    """speckv_ext_attend_mx4 against orc_attend_mx4 for every way a wave packs heads (g <= 4: four heads per wave, <= 8: two,
+    else one): whole range, ragged last tile, many / one split, a range not at 0, a sharp softmax, all layers at once."""
+    torch = torch_mod()
+    lib = eng.lib
+    lib.set_compression_scheme(5)
+    T, L, bpe = 512, 3, 2
+    h = eng.allocate(T, L, H, D, bpe)
+    n_pages = T * L * H * D * bpe * 2 // PAGE
+    rng = np.random.default_rng(47 + g)
+    x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.05, 6.0, (n_pages, 1))).astype(np.float16)
+    x[5] = 0.0                                                    # a page of zeros: scale code 0
+    x[9, ::3] *= np.float16(40.0)                                 # wide spread inside the groups
+    lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+    scales, lens, recs = oracle.compress_blocks_f16(x, 5, 0)
+    q = (rng.standard_normal((L, H, g, D)) * 2.0).astype(np.float16)
+    q[0, 1, 0, :32] = 0                                           # a zero scale block in a query row
+    q[0, 2, g - 1, 7] = np.float16(470.0)                         # lands in (448, 512) after the MX scaling: the e4m3 clamp
+    d_q = torch.from_numpy(q.view(np.int16)).cuda()
+    sm = 1.0 / np.sqrt(D)
+    cases = [(0, (0, T), None), (2, (64, 200), None), (1, (2, 4), None), (1, (0, 34), "1"), (0, (0, T), "1"), (2, (30, 512), "3"),
+             (1, (96, 480), "5"), (0, (0, 2), None)]
+    for layer, (pb, pe), splits in cases:
+        if splits is None: os.environ.pop("SPECKV_ATTEND_SPLITS", None)
+        else: os.environ["SPECKV_ATTEND_SPLITS"] = splits
+        try:
+            d_out = torch.full((H, g, D), float("nan"), dtype=torch.float32, device="cuda")
+            d_lse = torch.full((H, g), float("nan"), dtype=torch.float32, device="cuda")
+            lib.attend_mx4(h, layer, 1, d_q[layer].data_ptr(), g, pb, pe, sm, d_out.data_ptr(), d_lse.data_ptr())
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("SPECKV_ATTEND_SPLITS", None)
+        want, wlse, mag, delta = oracle_attention(oracle, recs, q[layer], T, layer, pb, pe, sm, g)
+        check(d_out.cpu().numpy(), d_lse.cpu().numpy(), want, wlse, mag, delta, (g, layer, pb, pe, splits))
+    # sharp softmax (large scale): the running-max rescale path
+    d_out = torch.empty((H, g, D), dtype=torch.float32, device="cuda")
+    lib.attend_mx4(h, 0, 1, d_q[0].data_ptr(), g, 0, T, 1.0, d_out.data_ptr())
+    torch.cuda.synchronize()
+    want, _, mag, delta = oracle_attention(oracle, recs, q[0], T, 0, 0, T, 1.0, g)
+    check(d_out.cpu().numpy(), None, want, None, mag, delta, (g, "sharp"))
+    # all layers in one launch == per-layer calls, bit for bit
+    multi = torch.empty((L, H, g, D), dtype=torch.float32, device="cuda")
+    mlse = torch.empty((L, H, g), dtype=torch.float32, device="cuda")
+    lib.attend_mx4(h, 0, L, d_q.data_ptr(), g, 0, T, sm, multi.data_ptr(), mlse.data_ptr())
+    torch.cuda.synchronize()
+    for layer in range(L):
+        want, wlse, mag, delta = oracle_attention(oracle, recs, q[layer], T, layer, 0, T, sm, g)
+        check(multi[layer].cpu().numpy(), mlse[layer].cpu().numpy(), want, wlse, mag, delta, (g, "multi", layer))
+    # a range whose last 32-position tile would leave the layer's region takes the page-table form
+    d_out = torch.empty((H, g, D), dtype=torch.float32, device="cuda")
+    lib.attend_mx4(h, 1, 1, d_q[1].data_ptr(), g, 30, 512, sm, d_out.data_ptr())
+    torch.cuda.synchronize()
+    want, _, mag, delta = oracle_attention(oracle, recs, q[1], T, 1, 30, 512, sm, g)
+    check(d_out.cpu().numpy(), None, want, None, mag, delta, (g, "table tail"))
+    # ... and SPECKV_ATTEND_GENERAL forces it for a whole range
+    os.environ["SPECKV_ATTEND_GENERAL"] = "1"
+    try:
+        lib.attend_mx4(h, 2, 1, d_q[2].data_ptr(), g, 0, T, sm, d_out.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("SPECKV_ATTEND_GENERAL", None)
+    want, _, mag, delta = oracle_attention(oracle, recs, q[2], T, 2, 0, T, sm, g)
+    check(d_out.cpu().numpy(), None, want, None, mag, delta, (g, "table whole"))
+    # empty range: zeros
+    lib.attend_mx4(h, 0, 1, d_q[0].data_ptr(), g, 64, 64, sm, d_out.data_ptr())
+    torch.cuda.synchronize()
+    assert not d_out.cpu().numpy().any()
+    if g == 8:
+        # close to the attention over the original fp16 KV (4-bit quantisation error only)
+        kfull = x[:T // 2].reshape(T // 2, 2, H, D).astype(np.float32).reshape(T, H, D)
+        vfull = x[T // 2:T].reshape(T // 2, 2, H, D).astype(np.float32).reshape(T, H, D)
+        s_ = np.einsum("hgd,thd->hgt", q[0].astype(np.float32), kfull) * sm
+        p = np.exp(s_ - s_.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
+        ref = np.einsum("hgt,thd->hgd", p, vfull)
+        rel = np.linalg.norm(multi[0].cpu().numpy() - ref) / np.linalg.norm(ref)
+        assert rel <= 0.6, rel
+
+
+def test_mx4_attention_unwritten_pages_count_as_zeros(eng, oracle):
+    torch = torch_mod()
+    lib = eng.lib
+    lib.set_compression_scheme(5)
+    T, g = 64, 8
+    h = eng.allocate(T, 1, H, D, 2)
+    rng = np.random.default_rng(5)
+    xk = rng.standard_normal((16, N)).astype(np.float16)
+    xv = rng.standard_normal((16, N)).astype(np.float16)
+    lib.write(h, 0, xk.ctypes.data, xk.nbytes, False)                       # K positions 0..31
+    lib.write(h, (T // 2) * PAGE, xv.ctypes.data, xv.nbytes, False)         # V positions 0..31; 32..63 stay unwritten
+    recs = np.zeros((T, 2 * N), np.uint8)
+    recs[:16] = oracle.compress_blocks_f16(xk, 5, 0)[2]
+    recs[T // 2:T // 2 + 16] = oracle.compress_blocks_f16(xv, 5, 0)[2]
+    q = rng.standard_normal((1, H, g, D)).astype(np.float16)
+    d_q = torch.from_numpy(q.view(np.int16)).cuda()
+    d_out = torch.empty((H, g, D), dtype=torch.float32, device="cuda")
+    lib.attend_mx4(h, 0, 1, d_q.data_ptr(), g, 0, T, 0.1, d_out.data_ptr())
+    torch.cuda.synchronize()
+    want, _, mag, delta = oracle_attention(oracle, recs, q[0], T, 0, 0, T, 0.1, g)
+    check(d_out.cpu().numpy(), None, want, None, mag, delta, "unwritten")
+
+
+@pytest.mark.parametrize("g", [8, 4])
+def test_mx4_batch_and_planned_forms(eng, oracle, g):
+    """speckv_ext_attend_mx4_batch / _planned (one decode step of many sequences) against the single-sequence call and the oracle;
+    ragged lengths, empty sequences, split and unsplit geometries."""
+    torch = torch_mod()
+    lib = eng.lib
+    lib.set_compression_scheme(5)
+    T, L = 1024, 2
+    n_seq = 40
+    rng = np.random.default_rng(91)
+    lens = (rng.integers(1, T // 2, n_seq) * 2).astype(np.uint32)
+    lens[0], lens[1], lens[2], lens[3] = T, 0, 2, 34
+    n_pages = T * L * H * D * 2 * 2 // PAGE
+    xs = [(rng.standard_normal((n_pages, N)) * rng.uniform(0.2, 2.0, (n_pages, 1))).astype(np.float16) for _ in range(3)]
+    recs = [oracle.compress_blocks_f16(x, 5, 0)[2] for x in xs]
+    handles = []
+    for i in range(n_seq):
+        h = lib.alloc(T * L * H * D * 2 * 2)
+        lib.set_layout(h, T, L, H, D, 2)
+        lib.write(h, 0, xs[i % 3].ctypes.data, xs[i % 3].nbytes, False)
+        handles.append(h)
+    qn = rng.standard_normal((n_seq, H, g, D)).astype(np.float16)
+    q = torch.from_numpy(qn).cuda()
+    sm = 1.0 / np.sqrt(D)
+    st = torch.cuda.Stream()
+    for layer, tps in ((1, None), (0, "4")):
+        if tps: os.environ["SPECKV_ATTEND_TILES_PER_SPLIT"] = tps
+        try:
+            out = torch.full((n_seq, H, g, D), float("nan"), dtype=torch.float32, device="cuda")
+            lse = torch.full((n_seq, H, g), float("nan"), dtype=torch.float32, device="cuda")
+            lib.attend_mx4_batch(handles, layer, q.data_ptr(), g, lens, sm, out.data_ptr(), lse.data_ptr())
+            torch.cuda.synchronize()
+            # planned form: same numbers
+            plan = torch.empty(lib.attend_plan_bytes(n_seq), dtype=torch.uint8, device="cuda")
+            out2 = torch.full((n_seq, H, g, D), float("nan"), dtype=torch.float32, device="cuda")
+            lse2 = torch.full((n_seq, H, g), float("nan"), dtype=torch.float32, device="cuda")
+            lib.attend_batch_plan(handles, lens, T, plan.data_ptr(), plan.numel(), st.cuda_stream)
+            lib.attend_planned(5, plan.data_ptr(), n_seq, layer, q.data_ptr(), g, T, sm, out2.data_ptr(), lse2.data_ptr(), st.cuda_stream)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("SPECKV_ATTEND_TILES_PER_SPLIT", None)
+        one = torch.empty((H, g, D), dtype=torch.float32, device="cuda")
+        one_lse = torch.empty((H, g), dtype=torch.float32, device="cuda")
+        for i in range(n_seq):
+            if lens[i] == 0:
+                assert float(out[i].abs().max()) == 0.0 and float(out2[i].abs().max()) == 0.0
+                continue
+            lib.attend_mx4(handles[i], layer, 1, q[i].data_ptr(), g, 0, int(lens[i]), sm, one.data_ptr(), one_lse.data_ptr())
+            torch.cuda.synchronize()
+            scale = float(one.abs().max()) + 1e-6
+            for o, l, nm in ((out, lse, "batch"), (out2, lse2, "planned")):
+                assert float((o[i] - one).abs().max()) <= 1e-3 * scale, (nm, i, lens[i])
+                assert float((l[i] - one_lse).abs().max()) <= 1e-4, (nm, i, lens[i])
+            if i < 6:
+                want, wlse, mag, delta = oracle_attention(oracle, recs[i % 3], qn[i], T, layer, 0, int(lens[i]), sm, g)
+                check(out[i].cpu().numpy(), lse[i].cpu().numpy(), want, wlse, mag, delta, ("batch vs oracle", i))
+    for h in handles:
+        lib.free(h)
+
+
+def test_mx4_striped_and_migrated_placements(oracle):
+    """Records striped over three pools (every 'peer' on this GPU) take the striped form; after a migration of single pages the
+    page-table form; both equal the oracle."""
+    torch = torch_mod()
+    os.environ["SPECKV_POOL_DEVICES"] = "0,0,0"
+    try:
+        kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), "hip:0")
+    finally:
+        os.environ.pop("SPECKV_POOL_DEVICES", None)
+    try:
+        lib = kv.lib
+        lib.set_compression_scheme(5)
+        T, L, g = 256, 2, 8
+        h = kv.allocate(T, L, H, D, 2)
+        n_pages = T * L * H * D * 2 * 2 // PAGE
+        rng = np.random.default_rng(17)
+        x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.1, 4.0, (n_pages, 1))).astype(np.float16)
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+        recs = oracle.compress_blocks_f16(x, 5, 0)[2]
+        assert {lib.translate(h, p * PAGE).pool_device for p in range(6)} == {0}
+        qn = rng.standard_normal((L, H, g, D)).astype(np.float16)
+        q = torch.from_numpy(qn).cuda()
+        sm = 1.0 / np.sqrt(D)
+        out = torch.empty((H, g, D), dtype=torch.float32, device="cuda")
+        lse = torch.empty((H, g), dtype=torch.float32, device="cuda")
+        for what in ("striped", "migrated"):
+            for layer, (pb, pe) in ((0, (0, T)), (1, (32, 200))):
+                lib.attend_mx4(h, layer, 1, q[layer].data_ptr(), g, pb, pe, sm, out.data_ptr(), lse.data_ptr())
+                torch.cuda.synchronize()
+                want, wlse, mag, delta = oracle_attention(oracle, recs, qn[layer], T, layer, pb, pe, sm, g)
+                check(out.cpu().numpy(), lse.cpu().numpy(), want, wlse, mag, delta, (what, layer, pb, pe))
+            # batch form over the same allocation
+            lib.attend_mx4_batch([h], 1, q[1].data_ptr(), g, np.array([T], np.uint32), sm, out.data_ptr(), lse.data_ptr())
+            torch.cuda.synchronize()
+            want, wlse, mag, delta = oracle_attention(oracle, recs, qn[1], T, 1, 0, T, sm, g)
+            check(out.cpu().numpy(), lse.cpu().numpy(), want, wlse, mag, delta, (what, "batch"))
+            if what == "striped":
+                lib.migrate(h, 5, 3, 1)                            # three single pages to pool 1: the regular placement is gone
+        # fetch + decompress after the migration: still the oracle's bytes
+        dst = torch.empty((n_pages, N), dtype=torch.float16, device="cuda")
+        lib.fetch_range(h, 0, n_pages, dst.data_ptr(), False, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        want = oracle.decompress_blocks_f16(recs, np.full(n_pages, REC, np.uint32), np.ones(n_pages, np.float32), 5, 0)
+        assert_same_float_bits(dst.cpu().numpy(), want, "after migration")
+    finally:
+        kv.close()
