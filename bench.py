@@ -990,12 +990,15 @@ def fp8_scores_extra(torch, kv, T, Lyr):
         lib.set_compression_scheme(2)
 
 
-def int4_attention_extra(torch, kv, T, Lyr):
-    """BASELINE configs[4], the 4:1 format: the whole decode attention of every layer of one 70B-shaped
-    sequence at 32k context straight from INT4_G32 records (1152 B per 4 KiB page)."""
+def int4_attention_extra(torch, kv, T, Lyr, scheme=3):
+    """BASELINE configs[4], the 4:1 formats: the whole decode attention of every layer of one 70B-shaped
+    sequence at 32k context straight from INT4_G32 records (scheme 3: 1152 B per 4 KiB page, dequantised on the vector ALUs)
+    or MXFP4 records (scheme 5: 1088 B, q.K^T on the block-scaled matrix instruction)."""
     lib = kv.lib
+    name = "int4_fused_attention" if scheme == 3 else "mxfp4_fused_attention"
+    rec = 1152 if scheme == 3 else 1088
     try:
-        lib.set_compression_scheme(3)
+        lib.set_compression_scheme(scheme)
         h = lib.alloc(T * Lyr * 8 * 128 * 2 * 2)
         lib.set_layout(h, T, Lyr, 8, 128, 2)
         n_pages = T * Lyr * 8 * 128 * 2 * 2 // PAGE
@@ -1007,8 +1010,9 @@ def int4_attention_extra(torch, kv, T, Lyr):
         q = torch.randn((Lyr, 8, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
         o = torch.empty((Lyr, 8, 8, 128), dtype=torch.float32, device="cuda")
         s = torch.cuda.Stream()
+        fn = lib.attend_int4 if scheme == 3 else lib.attend_mx4
         def attend():
-            lib.attend_int4(h, 0, Lyr, q.data_ptr(), 8, 0, T, 0.08838834764831845, o.data_ptr(), None, s.cuda_stream)
+            fn(h, 0, Lyr, q.data_ptr(), 8, 0, T, 0.08838834764831845, o.data_ptr(), None, s.cuda_stream)
         attend(); torch.cuda.synchronize()
         ramp(attend, torch.cuda.synchronize, EXTRAS_RAMP_MS)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1018,16 +1022,16 @@ def int4_attention_extra(torch, kv, T, Lyr):
             attend()
         b.record(s); torch.cuda.synchronize()
         ms = a.elapsed_time(b) / reps
-        rec_bytes = n_pages * 1152
+        rec_bytes = n_pages * rec
         lib.free(h)
-        return {"int4_fused_attention": {"layers": Lyr, "positions": T, "query_rows_per_kv_head": 8,
-                                         "pool_GiB_int4": round(rec_bytes / 2**30, 2), "ms_all_layers": round(ms, 4),
-                                         "KV_record_GBps": round(rec_bytes / (ms * 1e-3) / 1e9, 1),
-                                         "frac_hbm": round(rec_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                         "fp16_equivalent_GBps": round(n_pages * PAGE / (ms * 1e-3) / 1e9, 1),
-                                         "note": "softmax(q.K^T).V of all layers from INT4_G32 records: attend + combine launches"}}
+        return {name: {"layers": Lyr, "positions": T, "query_rows_per_kv_head": 8, "record_bytes": rec, "ratio_to_fp16": round(PAGE / rec, 2),
+                       "pool_GiB": round(rec_bytes / 2**30, 2), "ms_all_layers": round(ms, 4),
+                       "KV_record_GBps": round(rec_bytes / (ms * 1e-3) / 1e9, 1),
+                       "frac_hbm": round(rec_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                       "fp16_equivalent_GBps": round(n_pages * PAGE / (ms * 1e-3) / 1e9, 1),
+                       "note": "softmax(q.K^T).V of all layers from " + ("INT4_G32" if scheme == 3 else "MXFP4") + " records: attend + combine launches"}}
     except Exception as e:
-        return {"int4_fused_attention": {"error": repr(e)}}
+        return {name: {"error": repr(e)}}
     finally:
         lib.set_compression_scheme(2)
 
@@ -1038,8 +1042,8 @@ def batch_attention_extra(torch, kv, n_seq=256, T=8192, scheme=4):
     whole batch."""
     lib = kv.lib
     handles = []
-    name = "fp8_attention_batch_decode_step" if scheme == 4 else "int4_attention_batch_decode_step"
-    rec = 2048 if scheme == 4 else 1152
+    name = {4: "fp8_attention_batch_decode_step", 3: "int4_attention_batch_decode_step", 5: "mxfp4_attention_batch_decode_step"}[scheme]
+    rec = {4: 2048, 3: 1152, 5: 1088}[scheme]
     try:
         lib.set_compression_scheme(scheme)
         g = torch.Generator(device="cuda"); g.manual_seed(2004)
@@ -1054,7 +1058,7 @@ def batch_attention_extra(torch, kv, n_seq=256, T=8192, scheme=4):
         o = torch.empty((n_seq, 8, 8, 128), dtype=torch.float32, device="cuda")
         s = torch.cuda.Stream()
         lens = [T] * n_seq
-        fn = lib.attend_fp8_batch if scheme == 4 else lib.attend_int4_batch
+        fn = {4: lib.attend_fp8_batch, 3: lib.attend_int4_batch, 5: lib.attend_mx4_batch}[scheme]
         def step():
             fn(handles, 0, q.data_ptr(), 8, lens, 0.08838834764831845, o.data_ptr(), None, s.cuda_stream)
         step(); torch.cuda.synchronize()
@@ -1070,7 +1074,7 @@ def batch_attention_extra(torch, kv, n_seq=256, T=8192, scheme=4):
         return {name: {"sequences": n_seq, "context": T, "layers_per_call": 1,
                        "ms_per_layer": round(ms, 4), "KV_record_GBps": round(rec_bytes / (ms * 1e-3) / 1e9, 1),
                        "frac_hbm": round(rec_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                       "note": f"speckv_ext_attend_{'fp8' if scheme == 4 else 'int4'}_batch: {n_seq} sequences x {T} context, one layer, one launch pair"}}
+                       "note": f"speckv_ext_attend_{ {4: 'fp8', 3: 'int4', 5: 'mx4'}[scheme] }_batch: {n_seq} sequences x {T} context, one layer, one launch pair"}}
     except Exception as e:
         return {name: {"error": repr(e)}}
     finally:
@@ -1539,8 +1543,10 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     ex.update(seq70b_extra(torch, kv))
     ex.update(fp8_scores_extra(torch, kv, 32768, 80))
     ex.update(int4_attention_extra(torch, kv, 32768, 80))
+    ex.update(int4_attention_extra(torch, kv, 32768, 80, scheme=5))      # the same on MXFP4 records (block-scaled matrix instruction)
     ex.update(batch_attention_extra(torch, kv))      # BASELINE configs[4] shape: 70B-shaped KV @ 32k context
     ex.update(batch_attention_extra(torch, kv, scheme=3))
+    ex.update(batch_attention_extra(torch, kv, scheme=5))
     ex.update(connector_append_extra(torch, kv))
     ex.update(connector_decode_extra(torch, kv))
     ex.update(predictor_extra(torch, lib))

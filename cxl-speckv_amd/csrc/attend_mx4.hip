@@ -1,15 +1,27 @@
-// cxl-speckv_amd/csrc/attend_mx4.hip -- decode attention straight from MXFP4 pool records (scheme 5: OCP MX v1.0, E2M1
-// elements with one E8M0 scale per 32; BASELINE configs[4] "int4/fp8 KV compression path (CDNA4 fp8 MFMA dequant), 4:1 ratio";
+// cxl-speckv_amd/csrc/attend_mx4.hip -- decode attention straight from MXFP4 pool records (scheme 5: OCP MX v1.0 elements and
+// scales, E2M1 with one E8M0 scale per 32; BASELINE configs[4] "int4/fp8 KV compression path (CDNA4 fp8 MFMA dequant), 4:1 ratio";
 // no reference counterpart, parity is against oracle/orc_attend_mx4).
 //
-// The K half runs on the instruction the format was made for: v_mfma_scale_f32_16x16x128_f8f6f4 contracts the WHOLE head
-// dimension (K = 128 = 4 blocks of 32) in one instruction and applies both operands' block scales in hardware -- K nibbles and
-// E8M0 codes feed it exactly as they lie in the record, the query is quantised to MXFP8 (e4m3 + E8M0 per 32) in the prologue.
-// No vector instruction touches a K element.  The V half cannot use it: p.V contracts over POSITIONS, and the instruction wants
-// 32 consecutive k of one row in a lane (a nibble transpose: ds_read_b64_tr_b4 does it out of LDS, profiles/probes/mxprobe.hip,
-// but the softmax weights would have to be e4m3).  V is widened to f16 by v_cvt_scalef32_pk_f16_fp4 -- ONE instruction per element
-// pair, and it applies the group's E8M0 scale itself (the pair = two d of one position = one scale group) -- and meets the f16
-// weights on v_mfma_f32_16x16x32_f16: the attention over the decompressed fp16 pages, as the INT4 path defines it.
+// The record (oracle/speckv_oracle.h): a 4 KiB page is two positions x 8 kv heads x 128 channels; byte i of the 1024 nibble bytes
+// holds channel i of position 0 (low nibble) and of position 1 (high), one E8M0 code per 16 bytes.  A head's row of a page is
+// therefore 128 contiguous bytes [channel][position] + 8 codes, and an MX block = 16 channels of both positions = 16 bytes.
+//
+// q.K^T runs on the instruction the format was made for: v_mfma_scale_f32_16x16x128_f8f6f4 takes 32 k values per lane and one
+// E8M0 scale per lane and operand -- one 16-byte block of the record and its code, exactly as they lie there.  Its k index
+// therefore runs over (channel, position) pairs; the query operand meets it interleaved with zeros:
+//     A row  = page r of the tile's 16,  k = 2 * channel + position          (two instructions: channels 0..63, 64..127)
+//     B col  = (query row q, which position w),  B[k] = q[channel] if position == w else 0     (e4m3, MXFP8 blocks of 16 channels)
+//     D[r][(q, w)] = score of query row q against position 2r + w
+// With 8 query rows per kv head (GQA 8) all 16 columns are live and every lane ends up with the scores of its OWN query row:
+// lane (c = 8w + q, kb = lane / 16) holds pages 4kb .. 4kb+3 -- the softmax never crosses lanes except for its row maximum / sum.
+//
+// p.V contracts over positions, which the block-scaled instruction cannot do from this layout; it runs on v_mfma_f32_16x16x32_f16.
+// V is widened by v_cvt_scalef32_pk_f16_fp4: ONE instruction turns a byte -- channel d of both positions of a page -- into the
+// f16 pair (d @ position 0, d @ position 1) times the block's scale, which IS an operand register of that MFMA (two consecutive
+// k slots of one row).  No shuffles, no separate scaling.  The weights meet it zero-padded the same way as the query:
+//     A row  = channel 8c + s of MFMA s (lane c takes bytes 8c .. 8c+7 of the head's row), k slot (2i, 2i+1) = page 4kb + i, position 0 | 1
+//     B col  = (q, w): slot pair (p, 0) for w = 0, (0, p) for w = 1 -- the lane's own four weights
+//     D      = the sum over the positions of parity w; the two parities are added once, in the epilogue.
 //
 // Operand maps as measured on the hardware (profiles/probes/mxprobe.hip, mxprobe2.hip; lane = (c = lane%16, kb = lane/16)):
 //   e2m1 operand  row/col c, k = 32 kb + nibble (low nibble of byte 0 first), registers 0..3
@@ -17,17 +29,11 @@
 //   scale operand byte 0 of lane (c, kb) scales (row/col c, k block kb), factor 2^(code-127)
 //   D             lane (c, kb) register r = D[row 4 kb + r][col c]
 //
-// A wave takes HPW kv heads at once (HPW = 16 / (query rows per head rounded up to 4, 8, 16)), so that all 16 columns of the
-// score MFMA are live query rows -- with GQA 8 a one-head wave would run its softmax with half its lanes dead:
-//   scores  S^T = K . q^T : A row i = (position i / HPW of the MFMA's 16 / HPW positions, head i % HPW)
-//                           B col c = (query row c % QG, head c / QG),  QG = 16 / HPW
-//           lane (c, kb) finds its own head's rows among D rows 4 kb .. 4 kb + 3: 4 / HPW position slots per MFMA, 8 per
-//           32-position tile: slot j = position PPM (j / SPM) + 4 kb / HPW + j % SPM   (PPM = 16 / HPW, SPM = 4 / HPW)
-//   output  O^T = V^T . P^T, one MFMA per (head a, t): A row c = d column 8 c + t of head a, k-slot j = the lane group's
-//           position slot j; B = P with the columns of the other heads zeroed, so all heads of the wave accumulate into ONE
-//           set of 32 accumulator registers: lane (c, kb) ends with out[query row][32 kb + 8 r + t] in acc[t][r].
-// Memory shape: the 8 / HPW waves of a workgroup read whole 1088-byte records between them; a K request is 16 bytes per lane,
-// HPW x 64 contiguous bytes per position; V is requested as dwords (8 nibbles = 8 d of one position).
+// Memory: the texture path of a CU handles one wave-level load instruction per ~25-30 cycles whatever its width (measured on the
+// first version of this kernel, which kept its tiles in registers: 33 narrow loads per 8.7 KB tile, texture addresser 75 % busy
+// at 0.47 of the HBM roofline, profiles/r05_mx4.txt).  So every byte arrives by LDS-DMA in full 1 KiB instructions: per wave and
+// 32-position tile of its two heads 4 for K, 4 for V, 1 + 1 for the codes -- 10 instructions for 8704 bytes -- two tiles deep per
+// wave; the operands are then read from LDS.  All vector-memory traffic of the loop is inline assembly with explicit counters.
 #include "kernels.hpp"
 
 namespace speckv {
@@ -42,18 +48,42 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 namespace {
 
 #define MX_GP(T, p) ((const T __attribute__((address_space(1)))*)(reinterpret_cast<uintptr_t>(p)))
-__device__ __forceinline__ u32x4 ldg16(const uint8_t* p) { return __builtin_nontemporal_load(MX_GP(u32x4, p)); }
-__device__ __forceinline__ uint32_t ldg4(const uint8_t* p) { return __builtin_nontemporal_load(MX_GP(uint32_t, p)); }
-__device__ __forceinline__ uint32_t ldg1(const uint8_t* p) { return __builtin_nontemporal_load(MX_GP(uint8_t, p)); }
-// the E8M0 codes of HPW heads of one position (HPW x 4 bytes)
-template <int HPW> struct Codes { uint32_t w[HPW]; };
-template <int HPW> __device__ __forceinline__ Codes<HPW> ldg_codes(const uint8_t* p)
+constexpr uint32_t kRec = kMx4RecBytes;                      // 1088
+constexpr uint32_t kWavesPerWg = 2;                          // two heads per wave: a workgroup covers 4 kv heads
+// per wave and stage: K rows [16 pages][256 B] | V rows [16 pages][256 B] | K codes [16][16 B] | V codes [16][16 B]
+constexpr uint32_t kStK = 0, kStV = 4096, kStKC = 8192, kStVC = 8448, kStage = 8704;
+
+template <typename T> __device__ __forceinline__ T* uniform_ptr(T* p)
 {
-    Codes<HPW> r;
-    if constexpr (HPW == 1) { r.w[0] = ldg4(p); }
-    else if constexpr (HPW == 2) { const u32x2 v = __builtin_nontemporal_load(MX_GP(u32x2, p)); r.w[0] = v.x; r.w[1] = v.y; }
-    else { const u32x4 v = ldg16(p); r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w; }
-    return r;
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+    return reinterpret_cast<T*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+// LDS-DMA: 16 (4) bytes per lane from base + voff to LDS address lds_dst + 16 (4) * lane
+__device__ __forceinline__ void dma16(uint32_t lds_dst, const uint8_t* base, uint32_t voff)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void dma4(uint32_t lds_dst, const uint8_t* base, uint32_t voff)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(base) : "memory");
+}
+// the same with a full per-lane address (striped placements: the pages of one instruction sit in different runs)
+__device__ __forceinline__ void dma16_flat(uint32_t lds_dst, const uint8_t* addr)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(addr) : "memory");
+}
+__device__ __forceinline__ void dma4_flat(uint32_t lds_dst, const uint8_t* addr)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(addr) : "memory");
 }
 __device__ __forceinline__ float max_over_kb(float v)
 {
@@ -71,55 +101,58 @@ __device__ __forceinline__ float sum_over_kb(float v)
     const auto b = __builtin_amdgcn_permlane32_swap(m, m, false, false);
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
+// the lane 8 further on in its row of 16 (the other parity of the same query row): DPP row_ror:8
+__device__ __forceinline__ float other_parity(float v)
+{
+    return __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(__float_as_uint(v)), 0x128, 0xF, 0xF, false)));
+}
 // an fp16 query element as the MX conversion sees it: NaN counts as 0, inf as 65504 (oracle: orc_quantize_rows_mxfp8)
 __device__ __forceinline__ float q_clean(uint32_t half_bits)
 {
     const float x = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(half_bits)));
     return (x == x) ? fminf(fmaxf(x, -65504.0f), 65504.0f) : 0.0f;
 }
-constexpr uint32_t kRec = kMx4RecBytes;          // 1088
 
 } // namespace
 
 // FORM 0: records in one run (record p at lin_base + p * 1088; never-written records are zero bytes = zeros with code 0)
 // FORM 1: striped regularly over 2..8 pools (AttendArgs::stripe_bases)
-// FORM 2: no regular placement: every record address from its page-table entry (never-written pages read the zero page)
-template <int HPW, int FORM>
-__global__ __launch_bounds__(64 * (8 / HPW)) void k_attend_mx4(AttendArgs a)
+// FORM 2: no regular placement, or a last tile that would leave the layer's region: every record address from its page-table
+//         entry, clamped to the range (never-written pages read the zero page); staged through registers, one tile at a time
+// grid (splits, rows x 2 head quads [, query-row groups of 8]); a workgroup = 2 waves = 4 kv heads.
+template <int FORM>
+__global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_attend_mx4(AttendArgs a)
 {
-    constexpr int PPM = 16 / HPW;        // positions per score MFMA
-    constexpr int NM = 2 * HPW;          // score MFMAs per 32-position tile
-    constexpr int SPM = 4 / HPW;         // position slots of a lane per score MFMA
-    constexpr int QG = 16 / HPW;         // query-row columns per head
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerWg][2 * kStage];
     __shared__ uint64_t s_bases[8];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t c = lane & 15u, kb = lane >> 4;
+    const uint32_t w = c >> 3, ql = c & 7u;                              // this lane's column: position parity w, query row ql of the group
+    const uint32_t q = blockIdx.z * 8u + ql;                             // query row inside the kv head's g rows
     const uint32_t split = blockIdx.x;
-    uint32_t layer = blockIdx.y;                                         // batch form: the sequence index
-    const uint32_t h0 = wave * HPW;                                      // first kv head of this wave
-    const uint32_t b = c / QG, q = c % QG;                               // this lane's column: query row q of head h0 + b
-    const uint32_t head = h0 + b;
-    uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;        // query / output row block of the lane's column
-    uint64_t part = row * a.n_splits + split;
+    uint32_t layer = blockIdx.y >> 1;                                    // batch form: the sequence index
+    const uint32_t h0 = ((blockIdx.y & 1u) * kWavesPerWg + wave) * 2u;   // first of this wave's two kv heads
+    const uint64_t row0 = static_cast<uint64_t>(layer) * a.heads + h0;   // query / output row block of head 0 (head 1: + 1)
+    uint64_t part0 = row0 * a.n_splits + split, part_step = a.n_splits;  // partials of head 0 | head 1: part0, part0 + part_step
     uint32_t my_splits = a.n_splits;
     if (a.seqs) {                                                        // workgroup-uniform: per-sequence geometry
         const AttendSeq sq = a.seqs[layer];
         if (split >= sq.n_splits) {
-            if (sq.n_splits == 0u && split == 0u && a.direct_out && a.direct_per_seq == 2u) {
-#pragma unroll
-                for (int hh = 0; hh < HPW; ++hh)
-                    attend_zero_rows(a.direct_out, a.direct_lse, a.g, static_cast<uint64_t>(layer) * a.heads + h0 + hh, lane);
+            if (sq.n_splits == 0u && split == 0u && blockIdx.z == 0u && a.direct_out && a.direct_per_seq == 2u) {
+                attend_zero_rows(a.direct_out, a.direct_lse, a.g, row0, lane);
+                attend_zero_rows(a.direct_out, a.direct_lse, a.g, row0 + 1u, lane);
             }
             return;
         }
-        a.lin_base = sq.lin_base;
+        a.lin_base = uniform_ptr(sq.lin_base);
         a.k_first = sq.k_first + static_cast<uint64_t>(a.batch_layer) * sq.layer_pages;
         a.v_first = sq.v_first + static_cast<uint64_t>(a.batch_layer) * sq.layer_pages;
         a.n_pages = sq.n_pages;
         a.tiles_per_split = sq.tiles_per_split;
         my_splits = sq.n_splits;
-        part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
+        part0 = sq.part_base + static_cast<uint64_t>(h0) * sq.n_splits + split;
+        part_step = sq.n_splits;
         if (FORM == 2) a.entries = reinterpret_cast<const PageEntry*>(sq.lin_base);
         if (FORM == 1) {
             a.stripe_bases = sq.stripe_bases;
@@ -138,247 +171,277 @@ __global__ __launch_bounds__(64 * (8 / HPW)) void k_attend_mx4(AttendArgs a)
     const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
     const uint32_t t0 = split * a.tiles_per_split;
     const uint32_t t1 = min(t0 + a.tiles_per_split, n_tiles);
-    float m_run = -INFINITY, l_run = 0.0f;
-    f32x4 acc[8];
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
+    f32x4 acc[2][8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc[hh][s] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     if (t0 < t1) {                                                       // wave-uniform
-        // ---- where the lane's pieces of a tile sit, relative to the tile's first K / V record (linear form: bytes)
-        const uint32_t kpos0 = c / HPW, khead = h0 + c % HPW;            // K row of score MFMA 0: position kpos0 of the tile, head khead
-        const uint32_t koff = (kpos0 & 1u) * 512u + khead * 64u + kb * 16u;                     // inside the record (MFMA m: page + m * PPM / 2)
-        const uint32_t ksoff = 1024u + ((kpos0 & 1u) * 8u + khead) * 4u + kb;
-        const uint32_t vpos0 = 4u * kb / HPW;                            // position slot 0
-        const uint32_t voff = (vpos0 & 1u) * 512u + h0 * 64u + 4u * c;  // head a: + 64 a; slot j: + slot_bytes(j)
-        const uint32_t vsoff = 1024u + ((vpos0 & 1u) * 8u + h0) * 4u;
-        // slot j relative to slot 0: positions dpos = PPM (j / SPM) + j % SPM further on (vpos0 is even unless HPW == 4, where dpos is)
-        auto slot_page = [](int j) { return static_cast<uint32_t>((PPM * (j / SPM) + j % SPM) >> 1); };
-        auto slot_half = [](int j) { return static_cast<uint32_t>((PPM * (j / SPM) + j % SPM) & 1); };
-        const uint32_t kpage0 = static_cast<uint32_t>(a.k_first) + (kpos0 >> 1);               // + 16 tile + m * PPM / 2
-        const uint32_t vpage0 = static_cast<uint32_t>(a.v_first) + (vpos0 >> 1);               // + 16 tile + slot_page(j)
-        const uint32_t k_end = static_cast<uint32_t>(a.k_first) + a.n_pages - 1u, v_end = static_cast<uint32_t>(a.v_first) + a.n_pages - 1u;
-        auto rec = [&](uint32_t page, uint32_t end) -> const uint8_t* {
-            if (FORM == 0) return a.lin_base + static_cast<uint64_t>(page) * kRec;
-            if (FORM == 1) return attend_stripe_rec(s_bases, page, a.stripe_n, a.stripe_magic, kRec);
-            const u32x4 e = *MX_GP(u32x4, a.entries + min(page, end));                         // {address lo, hi, record bytes, scale}
+        const uint32_t lbase = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&lds[wave][0])));
+        const uint8_t* const lptr = &lds[wave][0];
+        // ---- staging: DMA instruction i (0..3) of a region fills page rows 4i .. 4i+3: lane l -> row 4i + l/16, 16-byte slot l%16,
+        // which holds piece (slot ^ row) of the two heads' 256 bytes -- the XOR spreads the operand reads below over the banks
+        const uint32_t srow = lane >> 4, sslot = lane & 15u;
+        uint32_t goff[4];                                                // byte offset of the lane's piece from the tile's first record
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) goff[i] = (4u * i + srow) * kRec + h0 * 128u + ((sslot ^ ((4u * i + srow) & 15u)) * 16u);
+        const uint32_t goffc = (lane >> 2) * kRec + 1024u + h0 * 8u + (lane & 3u) * 4u;      // codes: lane l -> page l/4, dword l%4 of the two heads' 16
+        const uint32_t kfirst = static_cast<uint32_t>(a.k_first), vfirst = static_cast<uint32_t>(a.v_first), last_pg = a.n_pages - 1u;
+        const uint32_t last = t1 - 1u;
+        auto rec_of = [&](uint32_t first, uint32_t page_in_range) -> const uint8_t* {        // FORM 1 / 2: record of a page of the range
+            if (FORM == 1) return attend_stripe_rec(s_bases, first + page_in_range, a.stripe_n, a.stripe_magic, kRec);
+            const u32x4 e = *MX_GP(u32x4, a.entries + (first + min(page_in_range, last_pg)));      // {address lo, hi, record bytes, scale}
             const uint8_t* r = reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(e.x) | (static_cast<uint64_t>(e.y) << 32));
             return e.z >= kRec ? r : a.zero_page;
         };
+        auto stage = [&](uint32_t tt, uint32_t buf) {
+            const uint32_t tc = min(tt, last);
+            const uint32_t dst = lbase + buf * kStage;
+            if (FORM == 0) {
+                const uint8_t* kt = a.lin_base + (static_cast<uint64_t>(kfirst) + 16ull * tc) * kRec;      // (scalar)
+                const uint8_t* vt = a.lin_base + (static_cast<uint64_t>(vfirst) + 16ull * tc) * kRec;
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) dma16(dst + kStK + 1024u * i, kt, goff[i]);
+                dma4(dst + kStKC, kt, goffc);
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) dma16(dst + kStV + 1024u * i, vt, goff[i]);
+                dma4(dst + kStVC, vt, goffc);
+            } else if (FORM == 1) {
+                const uint32_t inrec = h0 * 128u;
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i)
+                    dma16_flat(dst + kStK + 1024u * i, rec_of(kfirst, 16u * tc + 4u * i + srow) + inrec + ((sslot ^ ((4u * i + srow) & 15u)) * 16u));
+                dma4_flat(dst + kStKC, rec_of(kfirst, 16u * tc + (lane >> 2)) + 1024u + h0 * 8u + (lane & 3u) * 4u);
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i)
+                    dma16_flat(dst + kStV + 1024u * i, rec_of(vfirst, 16u * tc + 4u * i + srow) + inrec + ((sslot ^ ((4u * i + srow) & 15u)) * 16u));
+                dma4_flat(dst + kStVC, rec_of(vfirst, 16u * tc + (lane >> 2)) + 1024u + h0 * 8u + (lane & 3u) * 4u);
+            } else {
+                // page-table form: through registers, synchronously (the slow path of odd ranges and migrated allocations)
+                uint8_t* d = const_cast<uint8_t*>(lptr) + buf * kStage;
+#pragma unroll
+                for (uint32_t rg = 0; rg < 2; ++rg) {
+                    const uint32_t first = rg ? vfirst : kfirst;
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) {
+                        const uint8_t* r = rec_of(first, 16u * tc + 4u * i + srow);
+                        *reinterpret_cast<u32x4*>(d + (rg ? kStV : kStK) + 1024u * i + 16u * lane) =
+                            *MX_GP(u32x4, r + h0 * 128u + ((sslot ^ ((4u * i + srow) & 15u)) * 16u));
+                    }
+                    const uint8_t* r = rec_of(first, 16u * tc + (lane >> 2));
+                    *reinterpret_cast<uint32_t*>(d + (rg ? kStVC : kStKC) + 4u * lane) = *MX_GP(uint32_t, r + 1024u + h0 * 8u + (lane & 3u) * 4u);
+                }
+            }
+        };
+        stage(t0, 0u);
+        if (FORM != 2) stage(t0 + 1u, 1u);
 
-        // ---- query operand: MXFP8 rows of this lane's column (query row q of head h0 + b), quantised here
-        v8i QB;
-        int q_code;
+        // ---- query operands (MXFP8, blocks of 16 channels, zero-interleaved): lane (c = 8w + q, kb) takes channels 8kb + 32 gq + 0..7
+        // (gq = 0..3) of query row q of both heads; operand [head][half hf] bytes 0..15 <- gq = 2 hf, bytes 16..31 <- gq = 2 hf + 1
+        v8i QB[2][2];
+        int q_code[2][2];
         {
             const bool live = q < a.g;
-            const uint16_t* qrow = a.q16 + (row * a.g + min(q, a.g - 1u)) * 128u;
-            // the lane's own scale block kb (d = 32 kb .. 32 kb + 31): its E8M0 code is this lane's scale operand
-            float amax = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const u32x4 w = *MX_GP(u32x4, qrow + 32u * kb + 8u * i);
-                const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+            for (int hh = 0; hh < 2; ++hh) {
+                const uint16_t* qrow = a.q16 + ((row0 + hh) * a.g + min(q, a.g - 1u)) * 128u;
+                float x[4][8];
+                uint32_t code[4];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(q_clean((ws[k >> 1] >> (16 * (k & 1))) & 0xFFFFu)));
-            }
-            const uint32_t code = (live && amax > 0.0f) ? (__float_as_uint(amax) >> 23) - 8u : 0u;       // floor(log2 amax) - 8 + 127
-            q_code = static_cast<int>(code);
-            // the lane's data bytes belong to two other blocks: d = 16 kb .. 16 kb + 15 (block kb / 2) and 64 + 16 kb .. (block 2 + kb / 2)
-            const uint32_t code_lo = __shfl(code, c + 16u * (kb >> 1)), code_hi = __shfl(code, c + 16u * (2u + (kb >> 1)));
-            uint32_t qd[8];
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const float mul = __uint_as_float((254u - (half ? code_hi : code_lo)) << 23);           // 2^(127 - code), exact
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const u32x4 w = *MX_GP(u32x4, qrow + 64u * half + 16u * kb + 8u * i);
-                    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-                    float v[8];
+                for (int gq = 0; gq < 4; ++gq) {
+                    const u32x4 wv = *MX_GP(u32x4, qrow + 8u * kb + 32u * gq);
+                    const uint32_t ws[4] = {wv.x, wv.y, wv.z, wv.w};
+                    float amax = 0.0f;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        const float x = q_clean((ws[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) * mul;
-                        v[k] = live ? fminf(fmaxf(x, -448.0f), 448.0f) : 0.0f;
+                        x[gq][k] = q_clean((ws[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+                        amax = fmaxf(amax, fabsf(x[gq][k]));
                     }
-                    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
-                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
-                    qd[4 * half + 2 * i] = static_cast<uint32_t>(pk);
-                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
-                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], pk, true);
-                    qd[4 * half + 2 * i + 1] = static_cast<uint32_t>(pk);
+                    // the block of 16 channels = this lane's 8 and lane ^ 16's 8 (kb ^ 1)
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
+                    amax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+                    code[gq] = (live && amax > 0.0f) ? (__float_as_uint(amax) >> 23) - 8u : 0u;            // floor(log2 amax) - 8 + 127
+                }
+                uint32_t qd[16];
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float mul = __uint_as_float((254u - code[gq]) << 23);                             // 2^(127 - code), exact
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = live ? fminf(fmaxf(x[gq][k] * mul, -448.0f), 448.0f) : 0.0f;
+                    int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+                    p0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], p0, true);
+                    int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+                    p1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], p1, true);
+                    // bytes b0..b7 -> (b0, 0, b1, 0, ...) for parity 0, (0, b0, 0, b1, ...) for parity 1   (selector 0x0c = a zero byte)
+                    const uint32_t sl = w ? 0x010C000Cu : 0x0C010C00u, sh = w ? 0x030C020Cu : 0x0C030C02u;
+                    qd[4 * gq + 0] = __builtin_amdgcn_perm(0u, static_cast<uint32_t>(p0), sl);
+                    qd[4 * gq + 1] = __builtin_amdgcn_perm(0u, static_cast<uint32_t>(p0), sh);
+                    qd[4 * gq + 2] = __builtin_amdgcn_perm(0u, static_cast<uint32_t>(p1), sl);
+                    qd[4 * gq + 3] = __builtin_amdgcn_perm(0u, static_cast<uint32_t>(p1), sh);
+                }
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    QB[hh][hf] = v8i{static_cast<int>(qd[8 * hf + 0]), static_cast<int>(qd[8 * hf + 1]), static_cast<int>(qd[8 * hf + 2]), static_cast<int>(qd[8 * hf + 3]),
+                                     static_cast<int>(qd[8 * hf + 4]), static_cast<int>(qd[8 * hf + 5]), static_cast<int>(qd[8 * hf + 6]), static_cast<int>(qd[8 * hf + 7])};
+                    // the lane's scale operand: hardware block kb of this instruction = channels 64 hf + 16 kb .. + 15 = the block lanes
+                    // (kb' = 2 (kb & 1), 2 (kb & 1) + 1) computed as their group gq = 2 hf + (kb >> 1)
+                    const uint32_t src = c + 32u * (kb & 1u);
+                    const uint32_t s0 = __shfl(code[2 * hf], src), s1 = __shfl(code[2 * hf + 1], src);
+                    q_code[hh][hf] = static_cast<int>((kb >> 1) ? s1 : s0);
                 }
             }
-            QB = v8i{static_cast<int>(qd[0]), static_cast<int>(qd[1]), static_cast<int>(qd[2]), static_cast<int>(qd[3]),
-                     static_cast<int>(qd[4]), static_cast<int>(qd[5]), static_cast<int>(qd[6]), static_cast<int>(qd[7])};
         }
-
-        u32x4 kx[NM];
-        uint32_t ks[NM];
-        uint32_t vx[HPW][8];
-        Codes<HPW> vs[8];
-        auto issue_k = [&](uint32_t tile) {
+        // ---- where the lane reads its operands in a stage
+        uint32_t rk[2][2], rkc[2][2], rv[2][4], rvc[2][4];
 #pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                const uint8_t* r = rec(kpage0 + tile * 16u + static_cast<uint32_t>(m * PPM / 2), k_end);
-                kx[m] = ldg16(r + koff);
-                ks[m] = ldg1(r + ksoff);
+        for (uint32_t hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (uint32_t hf = 0; hf < 2; ++hf) {
+                rk[hh][hf] = kStK + c * 256u + (((hh * 8u + hf * 4u + kb) ^ c) * 16u);                  // row = page c: one 16-byte MX block
+                rkc[hh][hf] = kStKC + c * 16u + hh * 8u + hf * 4u + kb;
             }
-        };
-        auto issue_v = [&](uint32_t tile) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (HPW != 4 && (j & 1)) continue;                      // (slots 2i, 2i+1 share a page unless HPW == 4)
-                const uint8_t* r = rec(vpage0 + tile * 16u + slot_page(j), v_end);
-#pragma unroll
-                for (int jj = j; jj < (HPW != 4 ? j + 2 : j + 1); ++jj) {
-                    const uint32_t hb = (HPW != 4 ? slot_half(jj) : 0u) * 512u;
-#pragma unroll
-                    for (int hh = 0; hh < HPW; ++hh) vx[hh][jj] = ldg4(r + voff + hb + 64u * hh);
-                    vs[jj] = ldg_codes<HPW>(r + vsoff + (HPW != 4 ? slot_half(jj) : 0u) * 32u);
-                }
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t pg = 4u * kb + i;
+                rv[hh][i] = kStV + pg * 256u + (((hh * 8u + (c >> 1)) ^ pg) * 16u) + (c & 1u) * 8u;      // bytes 8c .. 8c+7 of the head's row
+                rvc[hh][i] = kStVC + pg * 16u + hh * 8u + (c >> 1);
             }
-        };
-        __builtin_amdgcn_sched_barrier(0);
-        issue_k(t0);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_v(t0);
-        __builtin_amdgcn_sched_barrier(0);
+        }
         const bool ragged = (a.n_pages & 15u) != 0u;
         const uint32_t n_pos = 2u * a.n_pages, skip_pos = 2u * a.skip_pages;
-        const uint32_t gsel = 8u * (c >> 2);                             // bit offset of the lane's V scale group (d = 8c .. 8c+7 -> group c / 4) in a head's code word
 #pragma unroll 1
         for (uint32_t tile = t0; tile < t1; ++tile) {
-            const uint32_t nxt = (tile + 1u < t1) ? tile + 1u : tile;    // the last iteration re-requests its own tile: one basic block
-            // ---- scores: one block-scaled MFMA per 16 / HPW positions, the whole head dimension at once
-            float sc[8];
+            const uint32_t buf = FORM == 2 ? 0u : (tile - t0) & 1u;
+            // tile `tile` has landed: only the 10 requests of the next one may still be on their way
+            if (FORM != 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            const uint8_t* st = lptr + buf * kStage;
 #pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                const v8i A = {static_cast<int>(kx[m].x), static_cast<int>(kx[m].y), static_cast<int>(kx[m].z), static_cast<int>(kx[m].w), 0, 0, 0, 0};
-                const f32x4 s = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, QB, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 4 /* A: e2m1 */, 0 /* B: e4m3 */,
-                                                                                  0, static_cast<int>(ks[m]), 0, q_code);
+            for (int hh = 0; hh < 2; ++hh) {
+                // ---- scores: two block-scaled MFMAs (channels 0..63, 64..127) over the tile's 16 pages
+                f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int u = 0; u < SPM; ++u) {
-                    float v;
-                    if (HPW == 1) v = s[u];
-                    else if (HPW == 2) v = b ? s[2 * u + 1] : s[2 * u];
-                    else v = b == 0u ? s[0] : b == 1u ? s[1] : b == 2u ? s[2] : s[3];
-                    sc[m * SPM + u] = v * a.scale_log2e;
+                for (int hf = 0; hf < 2; ++hf) {
+                    const u32x4 kx = *reinterpret_cast<const u32x4*>(st + rk[hh][hf]);
+                    const uint32_t kc = st[rkc[hh][hf]];
+                    const v8i A = {static_cast<int>(kx.x), static_cast<int>(kx.y), static_cast<int>(kx.z), static_cast<int>(kx.w), 0, 0, 0, 0};
+                    s = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, QB[hh][hf], s, 4 /* A: e2m1 */, 0 /* B: e4m3 */, 0, static_cast<int>(kc), 0, q_code[hh][hf]);
                 }
-            }
-            if ((ragged && tile + 1u == n_tiles) || (a.skip_pages && tile == 0u)) {             // wave-uniform: positions beyond / in front of the range
+                float sc[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t pos = tile * 32u + static_cast<uint32_t>(PPM * (j / SPM) + j % SPM) + vpos0;
-                    if (pos >= n_pos || pos < skip_pos) sc[j] = -INFINITY;
+                for (int r = 0; r < 4; ++r) sc[r] = s[r] * a.scale_log2e;
+                if ((ragged && tile + 1u == n_tiles) || (a.skip_pages && tile == 0u)) {         // wave-uniform: positions beyond / in front of the range
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t pos = tile * 32u + 2u * (4u * kb + r) + w;
+                        if (pos >= n_pos || pos < skip_pos) sc[r] = -INFINITY;
+                    }
                 }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            issue_k(nxt);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- online softmax of the lane's column (its 32 positions sit in the four lanes {c, c+16, c+32, c+48})
-            float mx = sc[0];
+                // ---- online softmax of the lane's query row (its positions sit in the 8 lanes {c, c ^ 8} x kb).  The reference
+                // maximum only moves when a tile's maximum passes it by more than 2^8 (weights <= 256: no concern in f16, the
+                // accumulators are fp32): the running maximum of a decode step settles within the first tiles of a split, and the
+                // 32 accumulator registers per head are then left alone.
+                float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+                mx = max_over_kb(mx);
+                mx = fmaxf(mx, other_parity(mx));
+                if (__builtin_expect(__ballot(mx > m_run[hh] + 8.0f) != 0ull, 0)) {         // (wave-uniform; -inf + 8 = -inf: the first tile comes here)
+                    const float m_new = (mx > m_run[hh] + 8.0f) ? mx : m_run[hh];
+                    const float f = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run[hh] - m_new);
+                    m_run[hh] = m_new;
+                    l_run[hh] *= f;
 #pragma unroll
-            for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc[j]);
-            mx = max_over_kb(mx);
-            const float m_new = fmaxf(m_run, mx);
-            const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;
-            const float f = __builtin_amdgcn_exp2f(m_run - m_use);
-            m_run = m_new;
-            float psum = 0.0f;
-            f16x8 P;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float p = __builtin_amdgcn_exp2f(sc[j] - m_use);
-                psum += p;
-                P[j] = static_cast<_Float16>(p);
-            }
-            l_run = l_run * f + psum;
-            // ---- out^T += V^T . P^T: V widened to f16 with its group scale by the conversion instruction itself
-#pragma unroll
-            for (int hh = 0; hh < HPW; ++hh) {
-                f16x8 Pa = P;
-                if (HPW > 1) {
-                    const u32x4 pw = __builtin_bit_cast(u32x4, P);
-                    const bool mine = b == static_cast<uint32_t>(hh);
-                    Pa = __builtin_bit_cast(f16x8, u32x4{mine ? pw.x : 0u, mine ? pw.y : 0u, mine ? pw.z : 0u, mine ? pw.w : 0u});
+                    for (int t = 0; t < 8; ++t) acc[hh][t] *= f;
                 }
-                uint32_t lo[4][4], hi[4][4];                            // [slot pair][byte of the dword = d pair]: the pair's even / odd d, positions 2jp | 2jp+1
+                const float m_use = (m_run[hh] == -INFINITY) ? 0.0f : m_run[hh];
+                float p[4];
 #pragma unroll
-                for (int jp = 0; jp < 4; ++jp) {
-                    // scale operand of the conversion: a float whose exponent field is the group's E8M0 code
-                    const float s0 = __uint_as_float(((vs[2 * jp].w[hh] >> gsel) & 0xFFu) << 23);
-                    const float s1 = __uint_as_float(((vs[2 * jp + 1].w[hh] >> gsel) & 0xFFu) << 23);
-                    const uint32_t w0 = vx[hh][2 * jp], w1 = vx[hh][2 * jp + 1];
-#define MX_PAIR(SEL)                                                                                                   \
-    {                                                                                                                  \
-        const uint32_t e0 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w0, s0, SEL));        \
-        const uint32_t e1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w1, s1, SEL));        \
-        lo[jp][SEL] = __builtin_amdgcn_perm(e1, e0, 0x05040100u);                                                       \
-        hi[jp][SEL] = __builtin_amdgcn_perm(e1, e0, 0x07060302u);                                                       \
+                for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sc[r] - m_use); l_run[hh] += p[r]; }
+                // weights as the B operand: slot pair i = (p_i, 0) for parity 0, (0, p_i) for parity 1
+                u32x4 pw;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t h = __builtin_bit_cast(uint16_t, static_cast<_Float16>(p[r]));
+                    pw[r] = w ? (h << 16) : h;
+                }
+                const f16x8 P = __builtin_bit_cast(f16x8, pw);
+                // ---- out^T += V^T . P^T: a byte of the record = channel d of both positions of a page -> one operand register
+                u32x2 vx[4];
+                float vsc[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    vx[i] = *reinterpret_cast<const u32x2*>(st + rv[hh][i]);
+                    vsc[i] = __uint_as_float(static_cast<uint32_t>(st[rvc[hh][i]]) << 23);          // the block's E8M0 code as a float's exponent field
+                }
+#define MX_PV(S, WORD, SEL)                                                                                                      \
+    {                                                                                                                            \
+        const u32x4 vw = {__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(vx[0].WORD, vsc[0], SEL)),        \
+                          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(vx[1].WORD, vsc[1], SEL)),        \
+                          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(vx[2].WORD, vsc[2], SEL)),        \
+                          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(vx[3].WORD, vsc[3], SEL))};       \
+        acc[hh][S] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vw), P, acc[hh][S], 0, 0, 0);               \
     }
-                    MX_PAIR(0) MX_PAIR(1) MX_PAIR(2) MX_PAIR(3)
-#undef MX_PAIR
-                }
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const u32x4 vw = (t & 1) ? u32x4{hi[0][t >> 1], hi[1][t >> 1], hi[2][t >> 1], hi[3][t >> 1]}
-                                             : u32x4{lo[0][t >> 1], lo[1][t >> 1], lo[2][t >> 1], lo[3][t >> 1]};
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vw), Pa, hh == 0 ? acc[t] * f : acc[t], 0, 0, 0);
-                }
+                MX_PV(0, x, 0) MX_PV(1, x, 1) MX_PV(2, x, 2) MX_PV(3, x, 3) MX_PV(4, y, 0) MX_PV(5, y, 1) MX_PV(6, y, 2) MX_PV(7, y, 3)
+#undef MX_PV
             }
-            __builtin_amdgcn_sched_barrier(0);
-            issue_v(nxt);
-            __builtin_amdgcn_sched_barrier(0);
+            // every read of this stage has returned: the next-but-one tile may overwrite it
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (FORM != 2) stage(tile + 2u, buf);
+            else if (tile + 1u < t1) stage(tile + 1u, 0u);
         }
+        if (FORM != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-requested tail tiles: nothing may land after the wave ends
     }
-    // ---- partial result of this split (or, single split: the final result)
-    const float l_tot = sum_over_kb(l_run);
-    if (a.direct_out && (!a.direct_per_seq || my_splits == 1u)) {
-        if (q < a.g) {
-            const float w = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+    // ---- the two parities of a query row are added; the lanes of parity 0 write the partial (or, single split: the final) result
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const float l_half = sum_over_kb(l_run[hh]);
+        const float l_tot = l_half + other_parity(l_half);
+        f32x4 o[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[s][r] = acc[hh][s][r] + other_parity(acc[hh][s][r]);
+        if (w != 0u || q >= a.g) continue;
+        const uint64_t row = row0 + hh;
+        if (a.direct_out && (!a.direct_per_seq || my_splits == 1u)) {
+            const float ws = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
             float* dst = a.direct_out + (row * a.g + q) * 128u + 32u * kb;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<f32x4*>(dst + 8 * i) = f32x4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]} * w;
-                *reinterpret_cast<f32x4*>(dst + 8 * i + 4) = f32x4{acc[4][i], acc[5][i], acc[6][i], acc[7][i]} * w;
+            for (int r = 0; r < 4; ++r) {
+                *reinterpret_cast<f32x4*>(dst + 8 * r) = f32x4{o[0][r], o[1][r], o[2][r], o[3][r]} * ws;
+                *reinterpret_cast<f32x4*>(dst + 8 * r + 4) = f32x4{o[4][r], o[5][r], o[6][r], o[7][r]} * ws;
             }
             if (a.direct_lse && kb == 0)
-                a.direct_lse[row * a.g + q] = l_tot > 0.0f ? (m_run + log2f(l_tot)) * 0.6931471805599453f : -INFINITY;
+                a.direct_lse[row * a.g + q] = l_tot > 0.0f ? (m_run[hh] + log2f(l_tot)) * 0.6931471805599453f : -INFINITY;
+            continue;
         }
-        return;
-    }
-    if (kb == 0) {
-        a.part_ml[part * 32u + q] = m_run;
-        a.part_ml[part * 32u + 16u + q] = l_tot;
-    }
-    if (q < a.g) {
+        const uint64_t part = part0 + hh * part_step;
+        if (kb == 0) {
+            a.part_ml[part * 32u + q] = m_run[hh];
+            a.part_ml[part * 32u + 16u + q] = l_tot;
+        }
         float* dst = a.part_acc + (part * 16u + q) * 128u + 32u * kb;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(dst + 8 * i) = f32x4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
-            *reinterpret_cast<f32x4*>(dst + 8 * i + 4) = f32x4{acc[4][i], acc[5][i], acc[6][i], acc[7][i]};
+        for (int r = 0; r < 4; ++r) {
+            *reinterpret_cast<f32x4*>(dst + 8 * r) = f32x4{o[0][r], o[1][r], o[2][r], o[3][r]};
+            *reinterpret_cast<f32x4*>(dst + 8 * r + 4) = f32x4{o[4][r], o[5][r], o[6][r], o[7][r]};
         }
     }
 }
 
-// a.lin_base set: linear form; else a.stripe_bases: striped; else a.table_form: page-table form.  Grid (splits, layers | sequences),
-// workgroup = 8 / HPW waves covering the 8 kv heads.  Writes the final rows itself when a.direct_out allows it, else the split
-// partials followed by launch_attend_combine.
+// a.lin_base set: linear form; else a.stripe_bases: striped; else a.table_form: page-table form.  Writes the final rows itself
+// when a.direct_out allows it, else the split partials followed by launch_attend_combine.
 hipError_t launch_attend_mx4(const AttendArgs& a, uint32_t n_rows, float* d_out, float* d_lse, hipStream_t s)
 {
     if (n_rows == 0 || a.n_splits == 0 || a.heads != 8u) return a.heads != 8u ? hipErrorInvalidValue : hipSuccess;
     if (!a.seqs && a.n_pages == 0) return hipSuccess;
     const int form = a.lin_base ? 0 : a.stripe_bases ? 1 : a.table_form ? 2 : -1;
     if (form < 0) return hipErrorInvalidValue;
-    const dim3 grid(a.n_splits, n_rows);
-#define MX_LAUNCH(HPW)                                                                                                             \
-    do {                                                                                                                           \
-        if (form == 0) hipLaunchKernelGGL((k_attend_mx4<HPW, 0>), grid, dim3(64 * (8 / HPW)), 0, s, a);                             \
-        else if (form == 1) hipLaunchKernelGGL((k_attend_mx4<HPW, 1>), grid, dim3(64 * (8 / HPW)), 0, s, a);                        \
-        else hipLaunchKernelGGL((k_attend_mx4<HPW, 2>), grid, dim3(64 * (8 / HPW)), 0, s, a);                                       \
-    } while (0)
-    if (a.g <= 4u) MX_LAUNCH(4);
-    else if (a.g <= 8u) MX_LAUNCH(2);
-    else MX_LAUNCH(1);
-#undef MX_LAUNCH
+    const dim3 grid(a.n_splits, n_rows * 2u, (a.g + 7u) / 8u), block(64 * kWavesPerWg);
+    if (form == 0) hipLaunchKernelGGL(k_attend_mx4<0>, grid, block, 0, s, a);
+    else if (form == 1) hipLaunchKernelGGL(k_attend_mx4<1>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(k_attend_mx4<2>, grid, block, 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const bool all_final = a.direct_out && (!a.direct_per_seq || a.direct_per_seq == 2u);

@@ -522,9 +522,12 @@ __device__ __forceinline__ void decode_int4(const uint8_t* __restrict__ rec, uin
     }
 }
 
-// decode: MXFP4 (OCP MX v1.0: record = 1024 B of E2M1 nibbles + 64 E8M0 group codes; oracle: compress_mxfp4 / ORC_COMP_MXFP4)
-// y = e2m1(nibble) * 2^(code - 127): the nibble pairs widen through v_cvt_scalef32_pk_f32_fp4 (exact), the scale is a float
-// whose exponent field is the code (a subnormal for code 0, NaN for 255) -- the product is exact in fp32.
+// decode: MXFP4 (OCP MX v1.0 elements and scales; record = 1024 nibble bytes + 64 E8M0 codes; oracle: compress_mxfp4 / ORC_COMP_MXFP4)
+// The two halves of the block are interleaved element by element: byte i = element i (low nibble) and element 1024 + i (high),
+// code j scales bytes 16j .. 16j+15.  y = e2m1(nibble) * 2^(code - 127): the nibble pairs widen through
+// v_cvt_scalef32_pk_f32_fp4 (exact), the scale is a float whose exponent field is the code (a subnormal for code 0, NaN for
+// 255) -- the product is exact in fp32.  A lane takes bytes 8l .. 8l+7 of both 512-byte halves of the nibble area: elements
+// [512 j + 8 l, + 8) for j = 0, 1 and their partners 1024 further on (j = 2, 3 of every other decoder's lane map).
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 template <bool F32>
 __device__ __forceinline__ void decode_mx4(const uint8_t* __restrict__ rec, uint32_t len,
@@ -532,22 +535,22 @@ __device__ __forceinline__ void decode_mx4(const uint8_t* __restrict__ rec, uint
 {
     const bool ok = len >= kMx4RecBytes;                     // short record decodes to zeros
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2; ++j) {
         const uint32_t p0 = 512u * j + 8u * lane;
-        uint32_t nib = 0, code = 127u;
+        uint2 nib = make_uint2(0u, 0u);
+        uint32_t code = 127u;
         if (ok) {
-            nib = gload<uint32_t>(rec + (p0 >> 1));
-            code = gload<uint8_t>(rec + 1024u + (p0 >> 5));
+            nib = gload_u2(rec + p0);
+            code = gload<uint8_t>(rec + 1024u + (p0 >> 4));
         }
         const float s = __uint_as_float(code == 0u ? 0x00400000u : code == 255u ? 0x7FC00000u : code << 23);
-        float y[8];
-        const f32x2v f0 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(nib, 1.0f, 0);
-        const f32x2v f1 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(nib, 1.0f, 1);
-        const f32x2v f2 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(nib, 1.0f, 2);
-        const f32x2v f3 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(nib, 1.0f, 3);
-        y[0] = f0.x * s; y[1] = f0.y * s; y[2] = f1.x * s; y[3] = f1.y * s;
-        y[4] = f2.x * s; y[5] = f2.y * s; y[6] = f3.x * s; y[7] = f3.y * s;
-        store8<F32>(dst, p0, y);
+        float y0[8], y1[8];
+#define MX_DEC(K, W, SEL) { const f32x2v f = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(W, 1.0f, SEL); y0[K] = f.x * s; y1[K] = f.y * s; }
+        MX_DEC(0, nib.x, 0) MX_DEC(1, nib.x, 1) MX_DEC(2, nib.x, 2) MX_DEC(3, nib.x, 3)
+        MX_DEC(4, nib.y, 0) MX_DEC(5, nib.y, 1) MX_DEC(6, nib.y, 2) MX_DEC(7, nib.y, 3)
+#undef MX_DEC
+        store8<F32>(dst, p0, y0);
+        store8<F32>(dst, p0 + 1024u, y1);
     }
 }
 
@@ -1028,66 +1031,75 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
             }
             out_len = kInt4RecBytes;
         } else if (SCHEME == kMxFp4) {
-            // OCP MX v1.0 (oracle: compress_mxfp4): per group of 32 elements (4 lanes x 8) code = floor(log2 max|x|) - 2 + 127 -- the
-            // exponent field of max|x| as a float, minus 2 -- and q = E2M1 of x / 2^(code-127), nearest even, saturating: one
-            // v_cvt_scalef32_pk_fp4_f16 per element pair straight from the fp16 words (it divides by the power of two its scale
-            // operand's exponent names, rounds to nearest even and saturates: profiles/probes/mxprobe.hip).
+            // OCP MX v1.0 conversion (oracle: compress_mxfp4) over the block's two halves interleaved element by element: byte i of the
+            // record = element i (low nibble) and element 1024 + i (high), one E8M0 code per 16 bytes.  This lane's raw[j] and
+            // raw[j + 2] (j = 0, 1) are exactly such partners -- elements [512 j + 8 l, + 8) and the same 1024 further on -- so the
+            // interleave never leaves the lane; a block of 32 = this lane's and lane ^ 1's 8 + 8 elements of both halves.
+            //   code = floor(log2 max|x|) - 2 + 127 = the exponent field of max|x| as a float, minus 2
+            //   q    = E2M1 of x / 2^(code-127), nearest even, saturating: one v_cvt_scalef32_pk_fp4_f16 per element pair (it divides
+            //          by the power of two its scale operand's exponent names: profiles/probes/mxprobe.hip)
             typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t words[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t w0[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};                    // first half: elements 2t, 2t+1 per word
+                const uint32_t w1[4] = {raw[j + 2].x, raw[j + 2].y, raw[j + 2].z, raw[j + 2].w};    // their partners in the second half
                 u16x2 m2 = {0, 0};
 #pragma unroll
-                for (int t = 0; t < 4; ++t) m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(u16x2, words[t] & 0x7FFF7FFFu));
-                uint32_t mbits = m2.x > m2.y ? m2.x : m2.y;                 // largest |bits| of the lane's 8 elements
-                mbits = umax(mbits, dpp<0xB1>(0u, mbits));                  // lane ^ 1
-                mbits = umax(mbits, dpp<0x4E>(0u, mbits));                  // lane ^ 2 -> the group of 32
-                const bool finite = __ballot(mbits >= 0x7C00u) == 0ull;     // wave-uniform: no inf / NaN in any group of this chunk
-                uint32_t nib = 0, code = 0;
+                for (int t = 0; t < 4; ++t) {
+                    m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(u16x2, w0[t] & 0x7FFF7FFFu));
+                    m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(u16x2, w1[t] & 0x7FFF7FFFu));
+                }
+                uint32_t mbits = m2.x > m2.y ? m2.x : m2.y;                 // largest |bits| of the lane's 16 elements
+                mbits = umax(mbits, dpp<0xB1>(0u, mbits));                  // lane ^ 1 -> the block of 32
+                const bool finite = __ballot(mbits >= 0x7C00u) == 0ull;     // wave-uniform: no inf / NaN in any block of this chunk
+                uint32_t nib[2] = {0u, 0u}, code = 0;
                 if (finite) {
                     code = mbits ? (__float_as_uint(half_bits_to_float(mbits)) >> 23) - 2u : 0u;
                     const float sc = mbits ? __uint_as_float(code << 23) : 1.0f;      // (code >= 101 for any non-zero fp16: a normal float)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const f16x2v h = __builtin_bit_cast(f16x2v, words[t]);
-                        switch (t) {
-                        case 0: nib = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(nib, h, sc, 0); break;
-                        case 1: nib = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(nib, h, sc, 1); break;
-                        case 2: nib = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(nib, h, sc, 2); break;
-                        default: nib = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(nib, h, sc, 3); break;
-                        }
+                        // (element 2t of both halves), (element 2t+1 of both halves) -> bytes 2t, 2t+1
+                        const f16x2v ea = __builtin_bit_cast(f16x2v, __builtin_amdgcn_perm(w1[t], w0[t], 0x05040100u));
+                        const f16x2v eb = __builtin_bit_cast(f16x2v, __builtin_amdgcn_perm(w1[t], w0[t], 0x07060302u));
+                        uint32_t& o = nib[t >> 1];
+                        if (t & 1) { o = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(o, ea, sc, 2); o = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(o, eb, sc, 3); }
+                        else       { o = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(o, ea, sc, 0); o = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(o, eb, sc, 1); }
                     }
                 } else {
                     // a chunk with inf / NaN somewhere: NaN elements are skipped in the maximum and store +0, inf counts as 65504
-                    float xv[8];
+                    float x0[8], x1[8];
                     float mx = 0.0f;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        float x = half_bits_to_float((words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
-                        x = (x == x) ? fminf(fmaxf(x, -65504.0f), 65504.0f) : 0.0f;
-                        xv[k] = x;
-                        mx = fmaxf(mx, fabsf(x));
+                        float a0 = half_bits_to_float((w0[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu), a1 = half_bits_to_float((w1[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
+                        a0 = (a0 == a0) ? fminf(fmaxf(a0, -65504.0f), 65504.0f) : 0.0f;
+                        a1 = (a1 == a1) ? fminf(fmaxf(a1, -65504.0f), 65504.0f) : 0.0f;
+                        x0[k] = a0; x1[k] = a1;
+                        mx = fmaxf(mx, fmaxf(fabsf(a0), fabsf(a1)));
                     }
-                    float o = __shfl_xor(mx, 1); mx = (o > mx) ? o : mx;
-                    o = __shfl_xor(mx, 2);       mx = (o > mx) ? o : mx;
+                    const float o = __shfl_xor(mx, 1);
+                    mx = (o > mx) ? o : mx;
                     code = mx > 0.0f ? (__float_as_uint(mx) >> 23) - 2u : 0u;
                     const float sc = mx > 0.0f ? __uint_as_float(code << 23) : 1.0f;
-                    nib = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(nib, xv[0], xv[1], sc, 0);
-                    nib = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(nib, xv[2], xv[3], sc, 1);
-                    nib = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(nib, xv[4], xv[5], sc, 2);
-                    nib = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(nib, xv[6], xv[7], sc, 3);
-                    // a NaN element keeps no sign: +0
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        const uint32_t hb = (words[k >> 1] >> ((k & 1) * 16)) & 0x7FFFu;
-                        if (hb > 0x7C00u) nib &= ~(0xFu << (4 * k));
+                        uint32_t& ob = nib[k >> 2];
+                        switch (k & 3) {
+                        case 0: ob = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ob, x0[k], x1[k], sc, 0); break;
+                        case 1: ob = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ob, x0[k], x1[k], sc, 1); break;
+                        case 2: ob = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ob, x0[k], x1[k], sc, 2); break;
+                        default: ob = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ob, x0[k], x1[k], sc, 3); break;
+                        }
+                        // a NaN element keeps no sign: +0
+                        if (((w0[k >> 1] >> ((k & 1) * 16)) & 0x7FFFu) > 0x7C00u) ob &= ~(0x0Fu << (8 * (k & 3)));
+                        if (((w1[k >> 1] >> ((k & 1) * 16)) & 0x7FFFu) > 0x7C00u) ob &= ~(0xF0u << (8 * (k & 3)));
                     }
                 }
                 // the record is assembled in LDS and leaves as whole 16-byte pieces per lane (as the INT4 record does)
                 const uint32_t p0 = 512u * j + 8u * lane;
                 uint8_t* wl = reinterpret_cast<uint8_t*>(lds) + wave * kMx4RecBytes;
-                *reinterpret_cast<uint32_t*>(wl + (p0 >> 1)) = nib;
-                if ((lane & 3u) == 0u) wl[1024u + (p0 >> 5)] = static_cast<uint8_t>(code);
+                *reinterpret_cast<uint2*>(wl + p0) = make_uint2(nib[0], nib[1]);
+                if ((lane & 1u) == 0u) wl[1024u + (p0 >> 4)] = static_cast<uint8_t>(code);
             }
             {
                 uint8_t* wl = reinterpret_cast<uint8_t*>(lds) + wave * kMx4RecBytes;

@@ -114,8 +114,8 @@ class Oracle:
             "orc_e2m1_to_f32": (C.c_float, [C.c_uint8]),
             "orc_mx_scale_code": (C.c_uint8, [C.c_float, C.c_int]),
             "orc_e8m0_to_f32": (C.c_float, [C.c_uint8]),
-            "orc_quantize_rows_mxfp8": (None, [u16p, C.c_size_t, C.c_size_t, u8p, u8p]),
-            "orc_attend_mx4": (None, [u8p, u8p, C.c_size_t, u8p, u8p, u8p, u8p, C.c_size_t, C.c_size_t, C.c_float, f32p, f32p, f32p]),
+            "orc_quantize_rows_mxfp8": (None, [u16p, C.c_size_t, C.c_size_t, C.c_size_t, u8p, u8p]),
+            "orc_attend_mx4": (None, [u8p, u8p, C.c_size_t, C.c_size_t, u8p, u8p, u8p, u8p, C.c_size_t, C.c_size_t, C.c_float, f32p, f32p, f32p]),
             "orc_layer_compression_ratio": (C.c_double, [C.c_uint32]),
             "orc_codec_throughput_gbps": (C.c_double, [C.c_size_t, C.c_double, C.c_size_t]),
             "orc_codec_pipeline_latency_cycles": (C.c_size_t, []),

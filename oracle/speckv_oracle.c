@@ -451,38 +451,45 @@ static float finite_amax(const float* x, size_t n)
     }
     return mx;
 }
+/* The two halves of a block are interleaved element by element before the MX conversion: nibble 2i of the stream is element i,
+ * nibble 2i+1 element n/2 + i, so byte i = (element i low, element n/2 + i high) and one MX block of 32 consecutive nibbles =
+ * 16 elements of the first half + the 16 matching elements of the second (for a page of two positions x 1024 channels: 16
+ * channels of both positions -- what one lane of the block-scaled matrix instruction takes as its 32 k values). */
+static size_t mx4_elem_of_nibble(size_t nib, size_t n) { return (nib & 1) ? n / 2 + (nib >> 1) : (nib >> 1); }
 static size_t compress_mxfp4(const float* xf, size_t n, uint8_t* rec)
 {
     size_t groups = n / 32;
     uint8_t* codes = rec + n / 2;
     memset(rec, 0, n / 2 + groups);
     for (size_t g = 0; g < groups; ++g) {
-        uint8_t code = orc_mx_scale_code(finite_amax(xf + g * 32, 32), 2);
+        float blk[32];
+        for (size_t i = 0; i < 32; ++i) blk[i] = xf[mx4_elem_of_nibble(g * 32 + i, n)];
+        uint8_t code = orc_mx_scale_code(finite_amax(blk, 32), 2);
         codes[g] = code;
         for (size_t i = 0; i < 32; ++i) {
-            size_t e = g * 32 + i;
-            float x = xf[e];
+            size_t nib = g * 32 + i;
+            float x = blk[i];
             uint8_t q = 0;
             if (x == x) {
                 if (x > 65504.0f) x = 65504.0f;
                 if (x < -65504.0f) x = -65504.0f;
                 q = orc_f32_to_e2m1(ldexpf(x, 127 - (int)code));       /* exact scaling by a power of two */
             }
-            rec[e >> 1] |= (uint8_t)((e & 1) ? (q << 4) : q);
+            rec[nib >> 1] |= (uint8_t)((nib & 1) ? (q << 4) : q);
         }
     }
     return n / 2 + groups;
 }
-void orc_quantize_rows_mxfp8(const uint16_t* q16, size_t rows, size_t d, uint8_t* q8, uint8_t* q_codes)
+void orc_quantize_rows_mxfp8(const uint16_t* q16, size_t rows, size_t d, size_t block, uint8_t* q8, uint8_t* q_codes)
 {
-    size_t blocks = d / 32;
+    size_t blocks = d / block;
     for (size_t r = 0; r < rows; ++r)
         for (size_t b = 0; b < blocks; ++b) {
-            float x[32];
-            for (size_t i = 0; i < 32; ++i) x[i] = orc_half_to_float(q16[r * d + b * 32 + i]);
-            uint8_t code = orc_mx_scale_code(finite_amax(x, 32), 8);
+            float x[64];
+            for (size_t i = 0; i < block; ++i) x[i] = orc_half_to_float(q16[r * d + b * block + i]);
+            uint8_t code = orc_mx_scale_code(finite_amax(x, block), 8);
             q_codes[r * blocks + b] = code;
-            for (size_t i = 0; i < 32; ++i) {
+            for (size_t i = 0; i < block; ++i) {
                 float v = x[i];
                 uint8_t c = 0;
                 if (v == v) {
@@ -490,29 +497,33 @@ void orc_quantize_rows_mxfp8(const uint16_t* q16, size_t rows, size_t d, uint8_t
                     if (v < -65504.0f) v = -65504.0f;
                     c = orc_f32_to_e4m3(ldexpf(v, 127 - (int)code));   /* nearest even, saturating at 448 */
                 }
-                q8[r * d + b * 32 + i] = c;
+                q8[r * d + b * block + i] = c;
             }
         }
 }
-void orc_attend_mx4(const uint8_t* q8, const uint8_t* q_codes, size_t g, const uint8_t* k_nib, const uint8_t* k_codes,
-                    const uint8_t* v_nib, const uint8_t* v_codes, size_t n_pos, size_t d, float sm_scale,
+/* value of channel i of position (2 * page + half) in a page row of d nibble BYTES (byte i = position 2*page low, 2*page+1 high) with d/16 codes */
+static double mx4_row_value(const uint8_t* rows, const uint8_t* codes, size_t d, size_t t, size_t i)
+{
+    size_t page = t >> 1, half = t & 1;
+    uint8_t nb = (uint8_t)((rows[page * d + i] >> (half * 4)) & 0xF);
+    return (double)orc_e2m1_to_f32(nb) * (double)orc_e8m0_to_f32(codes[page * (d / 16) + i / 16]);
+}
+void orc_attend_mx4(const uint8_t* q8, const uint8_t* q_codes, size_t q_block, size_t g, const uint8_t* k_rows, const uint8_t* k_codes,
+                    const uint8_t* v_rows, const uint8_t* v_codes, size_t n_pos, size_t d, float sm_scale,
                     float* out, float* lse, float* mag)
 {
-    size_t blocks = d / 32;
+    size_t qblocks = d / q_block;
     double* s = (double*)malloc((n_pos ? n_pos : 1) * sizeof(double));
     double* o = (double*)malloc(d * sizeof(double));
     double* a = (double*)malloc(d * sizeof(double));
     double* qd = (double*)malloc(d * sizeof(double));
     for (size_t m = 0; m < g; ++m) {
         for (size_t i = 0; i < d; ++i)
-            qd[i] = (double)orc_e4m3_to_f32(q8[m * d + i]) * (double)orc_e8m0_to_f32(q_codes[m * blocks + i / 32]);
+            qd[i] = (double)orc_e4m3_to_f32(q8[m * d + i]) * (double)orc_e8m0_to_f32(q_codes[m * qblocks + i / q_block]);
         double mx = -INFINITY;
         for (size_t t = 0; t < n_pos; ++t) {
             double acc = 0.0;
-            for (size_t i = 0; i < d; ++i) {
-                uint8_t nb = (uint8_t)((k_nib[t * (d / 2) + (i >> 1)] >> ((i & 1) * 4)) & 0xF);
-                acc += qd[i] * (double)orc_e2m1_to_f32(nb) * (double)orc_e8m0_to_f32(k_codes[t * blocks + i / 32]);
-            }
+            for (size_t i = 0; i < d; ++i) acc += qd[i] * mx4_row_value(k_rows, k_codes, d, t, i);
             s[t] = acc * (double)sm_scale;
             if (s[t] > mx) mx = s[t];
         }
@@ -522,8 +533,7 @@ void orc_attend_mx4(const uint8_t* q8, const uint8_t* q_codes, size_t g, const u
             double p = exp(s[t] - mx);
             l += p;
             for (size_t i = 0; i < d; ++i) {
-                uint8_t nb = (uint8_t)((v_nib[t * (d / 2) + (i >> 1)] >> ((i & 1) * 4)) & 0xF);
-                double v = (double)orc_e2m1_to_f32(nb) * (double)orc_e8m0_to_f32(v_codes[t * blocks + i / 32]);
+                double v = mx4_row_value(v_rows, v_codes, d, t, i);
                 o[i] += p * v;
                 a[i] += p * fabs(v);
             }
@@ -634,9 +644,9 @@ size_t orc_decompress_block_f32(const uint8_t* rec, size_t len, float scale, int
         size_t groups = cap / 32;
         if (len < cap / 2 + groups) { for (size_t i = 0; i < cap; ++i) y[i] = 0.0f; return cap; }
         const uint8_t* codes = rec + cap / 2;
-        for (size_t i = 0; i < cap; ++i) {
-            uint8_t nb = (uint8_t)((rec[i >> 1] >> ((i & 1) * 4)) & 0xF);
-            y[i] = orc_e2m1_to_f32(nb) * orc_e8m0_to_f32(codes[i / 32]);      /* exact: two significant bits times a power of two */
+        for (size_t nib = 0; nib < cap; ++nib) {
+            uint8_t nb = (uint8_t)((rec[nib >> 1] >> ((nib & 1) * 4)) & 0xF);
+            y[mx4_elem_of_nibble(nib, cap)] = orc_e2m1_to_f32(nb) * orc_e8m0_to_f32(codes[nib / 32]);   /* exact: two significant bits times a power of two */
         }
         return cap;
     }

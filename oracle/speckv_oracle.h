@@ -177,33 +177,43 @@ void orc_quantize_rows_e4m3(const uint16_t* q16, size_t rows, size_t d, uint8_t*
 
 /* ---- scheme 5 MXFP4: the 4:1 format gfx950's matrix cores read natively (BASELINE configs[4] "int4/fp8 KV compression
  * path (CDNA4 fp8 MFMA dequant), 4:1 ratio") ------------------------------------------------------------
- * EXTENSION WITHOUT A REFERENCE COUNTERPART: **parity unpinned** by the reference.  The format is the OCP Microscaling
- * Formats (MX) specification v1.0: blocks of 32 elements share one E8M0 scale X = 2^(code - 127), elements are FP4 E2M1
- * (1-2-1, bias 1: 0, 0.5, 1, 1.5, 2, 3, 4, 6 and their negatives; no inf, no NaN).  Conversion as in the spec's section 6.3:
+ * EXTENSION WITHOUT A REFERENCE COUNTERPART: **parity unpinned** by the reference.  Element and scale formats and the
+ * conversion are the OCP Microscaling Formats (MX) specification v1.0: blocks of 32 elements share one E8M0 scale
+ * X = 2^(code - 127), elements are FP4 E2M1 (1-2-1, bias 1: 0, 0.5, 1, 1.5, 2, 3, 4, 6 and their negatives; no inf, no NaN):
  *     code = floor(log2(max|x|)) - emax_elem + 127      (emax_elem = 2 for E2M1, 8 for E4M3; max|x| over the finite part:
  *                                                        NaN elements are skipped, inf counts as 65504; 0 when max|x| == 0)
  *     q    = E2M1 of x / 2^(code - 127), rounded to nearest even, magnitudes beyond 6 clamp to 6 (NaN elements store +0)
  *     y    = e2m1(q) * 2^(code - 127)                   (exact in fp32; one RNE rounding on the way to fp16)
- * Record of a 2048-element block (1088 B, 3.76 : 1): 1024 B of nibbles (element 2i low, 2i+1 high) then the 64 E8M0 codes
- * of the 64 groups.  A short record decodes to zeros; code 255 (the spec's NaN) decodes to NaN.
+ * WHICH 32 elements share a scale is this format's own choice: the two halves of a block of n elements are interleaved element
+ * by element first -- nibble 2i of the stream is element i, nibble 2i+1 element n/2 + i -- and the MX blocks are 32 consecutive
+ * nibbles of that stream: 16 elements of the first half with the 16 matching elements of the second.  A 4 KiB KV page is two
+ * positions x 1024 channels, so a block is 16 channels of BOTH positions and byte i of the record holds channel i of position 0
+ * (low) and of position 1 (high) -- the 32 k values one lane feeds the block-scaled matrix instruction, and the pair of
+ * positions one v_cvt_scalef32_pk_f16_fp4 widens into one f16 MFMA operand register (csrc/attend_mx4.hip).
+ * Record of a 2048-element block (1088 B, 3.76 : 1): 1024 nibble bytes, then the 64 E8M0 codes (code j: bytes 16j .. 16j+15).
+ * A short record decodes to zeros; code 255 (the spec's NaN) decodes to NaN.
  * Pinned independently of this file by tests/test_a22_format_pin.py (numpy float64 restatement of the spec text and torch's
- * float8_e8m0fnu / float4_e2m1fn_x2 bit layouts where the wheel has them). */
+ * float8_e8m0fnu bit layout). */
 enum { ORC_COMP_MXFP4 = 5 };
 #define ORC_MXFP4_REC_BYTES 1088u
 uint8_t orc_f32_to_e2m1(float v);            /* nearest even, saturating, NaN -> 0 */
 float   orc_e2m1_to_f32(uint8_t nibble);
 uint8_t orc_mx_scale_code(float amax, int emax_elem);     /* E8M0 code of a block whose finite max|x| is amax */
 float   orc_e8m0_to_f32(uint8_t code);                    /* 2^(code-127) (a subnormal float for code 0), NaN for 255 */
-/* MXFP8 rows (the query operand of the block-scaled matrix instruction): per row, d/32 blocks of 32 e4m3 codes with one E8M0
- * code each (emax_elem = 8; elements = e4m3 of x / 2^(code-127), nearest even, saturating at 448) */
-void orc_quantize_rows_mxfp8(const uint16_t* q16, size_t rows, size_t d, uint8_t* q8, uint8_t* q_codes);
-/* Decode attention of one kv head over MXFP4 rows (own extension, parity unpinned):
- *   k_nib / v_nib : n_pos rows of d/2 nibble bytes;  k_codes / v_codes : n_pos rows of d/32 E8M0 codes
- *   q8 / q_codes  : g MXFP8 rows (orc_quantize_rows_mxfp8)
+/* MXFP8 rows (the query operand of the block-scaled matrix instruction): per row, d/block blocks of `block` (<= 64) e4m3 codes
+ * with one E8M0 code each (emax_elem = 8; elements = e4m3 of x / 2^(code-127), nearest even, saturating at 448).  The attention
+ * kernel uses block = 16: its query operand is interleaved with zeros to meet the position-interleaved K bytes, so one
+ * hardware scale block of 32 k covers 16 channels. */
+void orc_quantize_rows_mxfp8(const uint16_t* q16, size_t rows, size_t d, size_t block, uint8_t* q8, uint8_t* q_codes);
+/* Decode attention of one kv head over MXFP4 page rows (own extension, parity unpinned):
+ *   k_rows / v_rows   : n_pos/2 page rows of d bytes (byte i = channel i of position 2r low, 2r+1 high)
+ *   k_codes / v_codes : n_pos/2 rows of d/16 E8M0 codes (code j: channels 16j .. 16j+15 of both positions)
+ *   q8 / q_codes      : g MXFP8 rows with blocks of q_block (orc_quantize_rows_mxfp8)
  *   s[m][t]   = (sum_d q[m][d] * k[t][d]) * sm_scale          with q, k the dequantised values
- *   out[m][:] = sum_t softmax_t(s[m][:])[t] * v[t][:]          (double precision throughout); lse, mag as in orc_attend_fp8 */
-void orc_attend_mx4(const uint8_t* q8, const uint8_t* q_codes, size_t g,
-                    const uint8_t* k_nib, const uint8_t* k_codes, const uint8_t* v_nib, const uint8_t* v_codes,
+ *   out[m][:] = sum_t softmax_t(s[m][:])[t] * v[t][:]          (double precision throughout); lse, mag as in orc_attend_fp8
+ * n_pos may be odd (the last page's second position is then not attended). */
+void orc_attend_mx4(const uint8_t* q8, const uint8_t* q_codes, size_t q_block, size_t g,
+                    const uint8_t* k_rows, const uint8_t* k_codes, const uint8_t* v_rows, const uint8_t* v_codes,
                     size_t n_pos, size_t d, float sm_scale, float* out, float* lse, float* mag);
 
 /* cache_engine.cpp:25-33,142-148 */

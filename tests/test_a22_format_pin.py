@@ -201,7 +201,9 @@ def test_attention_oracles_against_the_numpy_restatement(oracle):
 # Conversion (spec section 6.3): shared exponent = floor(log2(max|x|)) - emax_elem (2 for E2M1, 8 for E4M3); elements are
 # x / X rounded to nearest (ties to even), clamped to the largest magnitude.  Stated conventions beyond the spec's text
 # (oracle/speckv_oracle.h): NaN inputs are skipped in the maximum and stored as +0, inf counts as 65504, an all-zero block
-# gets code 0; record = 1024 nibble bytes (element 2i in the low half) then 64 codes.
+# gets code 0.  Which elements form a block is the format's own choice: the two 1024-element halves of a page are interleaved
+# element by element (stream = e0, e1024, e1, e1025, ...) and the MX blocks are 32 consecutive elements of THAT stream; record =
+# 1024 nibble bytes (stream element 2i in the low half of byte i, i.e. byte i = element i low, element 1024 + i high) then 64 codes.
 E2M1_GRID = np.array([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
 
 
@@ -224,8 +226,18 @@ def mx_code_numpy(amax, emax_elem):
     return np.where(amax > 0, np.clip(e - emax_elem + 127, 0, 254), 0).astype(np.uint8)
 
 
+def mx_interleave(x):
+    x = np.asarray(x).reshape(-1)
+    return np.stack([x[:x.size // 2], x[x.size // 2:]], axis=1).reshape(-1)
+
+
+def mx_deinterleave(s):
+    s = np.asarray(s).reshape(-1, 2)
+    return np.concatenate([s[:, 0], s[:, 1]])
+
+
 def mxfp4_encode_numpy(x16):
-    x = np.asarray(x16, np.float16).astype(np.float64).reshape(-1, 32)
+    x = mx_interleave(np.asarray(x16, np.float16)).astype(np.float64).reshape(-1, 32)
     fin = np.where(np.isnan(x), 0.0, np.clip(x, -65504.0, 65504.0))
     code = mx_code_numpy(np.abs(fin).max(axis=1), 2)
     q = e2m1_rne_numpy(fin / np.exp2(code.astype(np.float64) - 127.0)[:, None])
@@ -234,7 +246,12 @@ def mxfp4_encode_numpy(x16):
 
 
 def mxfp4_decode_numpy(rec):
-    """float64 values of a record (not yet rounded to fp16)"""
+    """float64 values of a record in ELEMENT order (not yet rounded to fp16)"""
+    return mx_deinterleave(mxfp4_decode_stream_numpy(rec))
+
+
+def mxfp4_decode_stream_numpy(rec):
+    """float64 values of a record in stream (interleaved) order"""
     rec = np.asarray(rec, np.uint8)
     n = rec.size * 32 // 17                                     # 16 nibble bytes + 1 code per 32 elements
     nib = rec[:n // 2]
@@ -301,11 +318,13 @@ def test_mxfp4_block_format_against_the_numpy_restatement(oracle):
         with np.errstate(over="ignore", invalid="ignore"):
             assert np.array_equal(y[i].view(np.uint16), mxfp4_decode_numpy(want).astype(np.float16).view(np.uint16)), i
     # the largest element of every non-zero group lands on 4 or 6 (floor-type shared exponent: amax / X in [4, 8))
-    dec = mxfp4_decode_numpy(recs[0, :1088]).reshape(-1, 32)
+    dec = mxfp4_decode_stream_numpy(recs[0, :1088]).reshape(-1, 32)
     top = np.abs(dec).max(axis=1) / np.exp2(recs[0, 1024:1088].astype(np.float64) - 127)
     assert set(np.unique(top)) <= {4.0, 6.0}
+    # a block really is 16 elements of the first half with the 16 matching elements of the second
+    assert np.array_equal(mx_interleave(np.arange(2048)).reshape(-1, 32)[3], np.stack([np.arange(48, 64), np.arange(1072, 1088)], 1).reshape(-1))
     # quantisation error bound of the format: |x - y| <= X/2 * (grid step at |x|/X) and <= amax/4 when clamped (|x|/X in (6, 8))
-    x0 = x[0].astype(np.float64).reshape(-1, 32); X = np.exp2(recs[0, 1024:1088].astype(np.float64) - 127)[:, None]
+    x0 = mx_interleave(x[0]).astype(np.float64).reshape(-1, 32); X = np.exp2(recs[0, 1024:1088].astype(np.float64) - 127)[:, None]
     assert np.all(np.abs(x0 - dec) <= np.where(np.abs(x0) / X > 6, 2.0, 1.0) * X + 1e-12)
     # every nibble value x a spread of codes decodes as described; a short record decodes to zeros, code 255 to NaN
     rec = np.zeros(1088, np.uint8)
@@ -332,26 +351,38 @@ def test_mxfp8_query_rows_and_the_mx4_attention_oracle_against_numpy(oracle):
     G, D, NPOS = 8, 128, 300
     qh = (rng.standard_normal((G, D)) * rng.uniform(0.05, 30.0, (G, 1))).astype(np.float16)
     qh[1, :32] = 0; qh[2, 5] = np.float16(480.0); qh[3, 64:96] *= np.float16(2.0 ** -12)
-    q8 = np.zeros((G, D), np.uint8); qc = np.zeros((G, D // 32), np.uint8)
-    L.orc_quantize_rows_mxfp8(_ptr(qh.view(np.uint16).reshape(-1), u16p), G, D, _ptr(q8, u8p), _ptr(qc, u8p))
-    # restated with torch's e4m3 cast: code = floor(log2 amax) - 8 + 127, bytes = e4m3(clip(x / 2^(code-127), +-448))
-    xb = qh.astype(np.float64).reshape(G, D // 32, 32)
-    code = mx_code_numpy(np.abs(xb).max(axis=2), 8)
-    assert np.array_equal(qc, code)
-    v = np.clip(xb / np.exp2(code.astype(np.float64) - 127)[..., None], -448.0, 448.0).astype(np.float32).reshape(G, D)
-    assert np.array_equal(q8, torch.from_numpy(v).to(torch.float8_e4m3fn).view(torch.uint8).numpy())
-    assert (np.abs(xb / np.exp2(code.astype(np.float64) - 127)[..., None]).max() > 448)        # the clamp was exercised (values in (448, 512))
     f8 = lambda b: torch.from_numpy(np.ascontiguousarray(b)).view(torch.float8_e4m3fn).to(torch.float32).numpy().astype(np.float64)
-    qd = f8(q8) * np.repeat(np.exp2(qc.astype(np.float64) - 127), 32, axis=1)
-    # K / V rows of one head: MXFP4 pages, rows of 128 elements
-    pages = (rng.standard_normal((2 * NPOS * D // 2048 + 1, 2048)) * rng.uniform(0.2, 4.0, (2 * NPOS * D // 2048 + 1, 1))).astype(np.float16)
-    recs = np.stack([mxfp4_encode_numpy(p) for p in pages])
-    nib = recs[:, :1024].reshape(-1, D // 2); codes = recs[:, 1024:].reshape(-1, D // 32)
-    dec = np.concatenate([mxfp4_decode_numpy(r) for r in recs]).reshape(-1, D)
-    kn, kc, vn, vc = (np.ascontiguousarray(a) for a in (nib[:NPOS], codes[:NPOS], nib[NPOS:2 * NPOS], codes[NPOS:2 * NPOS]))
+    for QB in (16, 32):
+        q8 = np.zeros((G, D), np.uint8); qc = np.zeros((G, D // QB), np.uint8)
+        L.orc_quantize_rows_mxfp8(_ptr(qh.view(np.uint16).reshape(-1), u16p), G, D, QB, _ptr(q8, u8p), _ptr(qc, u8p))
+        # restated with torch's e4m3 cast: code = floor(log2 amax) - 8 + 127, bytes = e4m3(clip(x / 2^(code-127), +-448))
+        xb = qh.astype(np.float64).reshape(G, D // QB, QB)
+        code = mx_code_numpy(np.abs(xb).max(axis=2), 8)
+        assert np.array_equal(qc, code)
+        v = np.clip(xb / np.exp2(code.astype(np.float64) - 127)[..., None], -448.0, 448.0).astype(np.float32).reshape(G, D)
+        assert np.array_equal(q8, torch.from_numpy(v).to(torch.float8_e4m3fn).view(torch.uint8).numpy())
+        assert (np.abs(xb / np.exp2(code.astype(np.float64) - 127)[..., None]).max() > 448)        # the clamp was exercised (values in (448, 512))
+    QB = 16
+    qd = f8(q8) * 0                                              # (recomputed for the block size the attention uses)
+    q8 = np.zeros((G, D), np.uint8); qc = np.zeros((G, D // QB), np.uint8)
+    L.orc_quantize_rows_mxfp8(_ptr(qh.view(np.uint16).reshape(-1), u16p), G, D, QB, _ptr(q8, u8p), _ptr(qc, u8p))
+    qd = f8(q8) * np.repeat(np.exp2(qc.astype(np.float64) - 127), QB, axis=1)
+    # K / V page rows of ONE kv head out of 8: a page = [2 positions][8 heads][128]; the record's bytes 128 h .. 128 h + 127 and
+    # codes 8 h .. 8 h + 7 belong to head h
+    n_pages = NPOS // 2
+    kp = (rng.standard_normal((n_pages, 2048)) * rng.uniform(0.2, 4.0, (n_pages, 1))).astype(np.float16)
+    vp = (rng.standard_normal((n_pages, 2048)) * rng.uniform(0.2, 4.0, (n_pages, 1))).astype(np.float16)
+    head = 5
+    def rows_of(pages):
+        recs = np.stack([mxfp4_encode_numpy(p) for p in pages])
+        dec = np.stack([mxfp4_decode_numpy(r) for r in recs]).reshape(n_pages, 2, 8, D)[:, :, head, :].reshape(NPOS, D)
+        return np.ascontiguousarray(recs[:, 128 * head:128 * head + 128]), np.ascontiguousarray(recs[:, 1024 + 8 * head:1024 + 8 * head + 8]), dec
+    kr, kc, kdec = rows_of(kp)
+    vr, vc, vdec = rows_of(vp)
     o = np.zeros((G, D), np.float32); l = np.zeros(G, np.float32); m = np.zeros((G, D), np.float32)
     sm = 1.0 / np.sqrt(D)
-    L.orc_attend_mx4(_ptr(q8, u8p), _ptr(qc, u8p), G, _ptr(kn, u8p), _ptr(kc, u8p), _ptr(vn, u8p), _ptr(vc, u8p), NPOS, D, float(sm),
-                     _ptr(o, f32p), _ptr(l, f32p), _ptr(m, f32p))
-    wo, wl, wm = attention_numpy(qd, dec[:NPOS], dec[NPOS:2 * NPOS], np.float32(sm))
-    assert np.allclose(o, wo, rtol=2e-6, atol=1e-7) and np.allclose(l, wl, rtol=2e-6, atol=2e-6) and np.allclose(m, wm, rtol=2e-6, atol=1e-7)
+    for npos in (NPOS, NPOS - 1, 2, 1):
+        L.orc_attend_mx4(_ptr(q8, u8p), _ptr(qc, u8p), QB, G, _ptr(kr, u8p), _ptr(kc, u8p), _ptr(vr, u8p), _ptr(vc, u8p), npos, D, float(sm),
+                         _ptr(o, f32p), _ptr(l, f32p), _ptr(m, f32p))
+        wo, wl, wm = attention_numpy(qd, kdec[:npos], vdec[:npos], np.float32(sm))
+        assert np.allclose(o, wo, rtol=2e-6, atol=1e-7) and np.allclose(l, wl, rtol=2e-6, atol=2e-6) and np.allclose(m, wm, rtol=2e-6, atol=1e-7)

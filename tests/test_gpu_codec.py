@@ -178,10 +178,12 @@ def test_mxfp4_block_format_matches_oracle(lib, oracle):
     # round trip (size-independent): |x - y| <= half a grid step of the group, a whole one where the format clamps (|x| / X in (6, 8))
     y = gpu_decompress(lib, recs, lens, scales, 5, 0, True)
     xf = x16.astype(np.float32)
+    ilv = lambda v: np.stack([v[:N // 2], v[N // 2:]], axis=1).reshape(-1)      # the format's stream order: halves interleaved, blocks of 32
     for b in np.flatnonzero(np.isfinite(xf).all(axis=1)):
-        X = np.exp2(recs[b, 1024:1088].astype(np.float64) - 127)
-        bound = np.repeat(X, 32) * np.where(np.abs(xf[b]) / np.repeat(X, 32) > 6, 2.0, 1.0)
-        assert (np.abs(y[b] - xf[b]) <= bound + 1e-30).all(), f"block {b}"
+        X = np.repeat(np.exp2(recs[b, 1024:1088].astype(np.float64) - 127), 32)
+        xs, ys = ilv(xf[b]), ilv(y[b])
+        bound = X * np.where(np.abs(xs) / X > 6, 2.0, 1.0)
+        assert (np.abs(ys - xs) <= bound + 1e-30).all(), f"block {b}"
     # a short record decodes to zeros
     lens2 = lens.copy(); lens2[0] = 1087
     y = gpu_decompress(lib, recs, lens2, scales, 5, 0, True)

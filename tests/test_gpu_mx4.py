@@ -4,7 +4,7 @@ A22: no reference counterpart -- the oracle's MX functions are pinned to a numpy
 tests/test_a22_format_pin.py, the block codec kernels to the oracle by tests/test_gpu_codec.py::test_mxfp4_block_format_matches_oracle).
 
 Attention checker: orc_attend_mx4 -- double-precision attention over the dequantised K / V values with the query quantised to MXFP8
-exactly as the kernel does (orc_quantize_rows_mxfp8).  Error sources of the HIP path: the softmax weights rounded to f16 (2^-11
+(blocks of 16 channels) exactly as the kernel does (orc_quantize_rows_mxfp8).  Error sources of the HIP path: the softmax weights rounded to f16 (2^-11
 each), v_exp_f32, fp32 accumulation, and the scaled MFMA's fp32 accumulation of a score (delta <= 3e-5 * sum|q||k| per score, as for
 the FP8 path), which moves each weight by a relative delta.  Stated tolerance, with mag = sum_t p_t |v_t|:
     |got - want| <= (2e-3 + 2 * delta_max) * mag + 1e-6,   lse within 2e-3 + delta_max."""
@@ -40,18 +40,17 @@ def eng():
 
 
 def head_rows(recs, first_page, n_pos, head):
-    """nibble rows [n_pos][64] and code rows [n_pos][4] of one kv head from MXFP4 records of pages first_page ..."""
-    r = recs[first_page:first_page + n_pos // 2, :REC]
-    nib = r[:, :1024].reshape(-1, 2, H, 64)[:, :, head, :].reshape(n_pos, 64)
-    codes = r[:, 1024:].reshape(-1, 2, H, 4)[:, :, head, :].reshape(n_pos, 4)
-    return np.ascontiguousarray(nib), np.ascontiguousarray(codes)
+    """page rows [n_pos/2][128 B] (byte i = channel i of the page's position 0 low, position 1 high) and code rows [n_pos/2][8]
+    of one kv head from the MXFP4 records of pages first_page ..."""
+    r = recs[first_page:first_page + (n_pos + 1) // 2, :REC]
+    return np.ascontiguousarray(r[:, 128 * head:128 * head + 128]), np.ascontiguousarray(r[:, 1024 + 8 * head:1024 + 8 * head + 8])
 
 
-def dequant_rows(nib, codes):
-    q = np.empty((nib.shape[0], 128), np.int64)
-    q[:, 0::2] = nib & 0xF
-    q[:, 1::2] = nib >> 4
-    return E2M1[q] * np.repeat(np.exp2(codes.astype(np.float64) - 127.0), 32, axis=1)
+def dequant_rows(rows, codes, n_pos):
+    """[n_pos][128] float64 values of the positions of page rows"""
+    sc = np.repeat(np.exp2(codes.astype(np.float64) - 127.0), 16, axis=1)
+    v = np.stack([E2M1[rows & 0xF] * sc, E2M1[rows >> 4] * sc], axis=1).reshape(-1, 128)
+    return v[:n_pos]
 
 
 def oracle_attention(oracle, recs, q16, T, layer, pb, pe, sm_scale, g):
@@ -65,16 +64,16 @@ def oracle_attention(oracle, recs, q16, T, layer, pb, pe, sm_scale, g):
     delta = 0.0
     lut = e4m3_lut(oracle)
     for head in range(H):
-        kn, kc = head_rows(recs, kf, npos, head)
-        vn, vc = head_rows(recs, vf, npos, head)
+        kr, kc = head_rows(recs, kf, npos, head)
+        vr, vc = head_rows(recs, vf, npos, head)
         qh = np.ascontiguousarray(q16[head]).view(np.uint16).reshape(-1)
-        q8 = np.zeros((g, D), np.uint8); qc = np.zeros((g, D // 32), np.uint8)
-        L.orc_quantize_rows_mxfp8(_ptr(qh, u16p), g, D, _ptr(q8, u8p), _ptr(qc, u8p))
-        qd = lut[q8] * np.repeat(np.exp2(qc.astype(np.float64) - 127.0), 32, axis=1)
-        smag = (np.abs(qd) @ np.abs(dequant_rows(kn, kc)).T) * sm_scale
+        q8 = np.zeros((g, D), np.uint8); qc = np.zeros((g, D // 16), np.uint8)
+        L.orc_quantize_rows_mxfp8(_ptr(qh, u16p), g, D, 16, _ptr(q8, u8p), _ptr(qc, u8p))
+        qd = lut[q8] * np.repeat(np.exp2(qc.astype(np.float64) - 127.0), 16, axis=1)
+        smag = (np.abs(qd) @ np.abs(dequant_rows(kr, kc, npos)).T) * sm_scale
         delta = max(delta, 3e-5 * float(smag.max()))
         o = np.zeros((g, D), np.float32); l = np.zeros(g, np.float32); m = np.zeros((g, D), np.float32)
-        L.orc_attend_mx4(_ptr(q8, u8p), _ptr(qc, u8p), g, _ptr(kn, u8p), _ptr(kc, u8p), _ptr(vn, u8p), _ptr(vc, u8p), npos, D,
+        L.orc_attend_mx4(_ptr(q8, u8p), _ptr(qc, u8p), 16, g, _ptr(kr, u8p), _ptr(kc, u8p), _ptr(vr, u8p), _ptr(vc, u8p), npos, D,
                          float(sm_scale), _ptr(o, f32p), _ptr(l, f32p), _ptr(m, f32p))
         out[head], lse[head], mag[head] = o, l, m
     return out, lse, mag, delta
@@ -130,8 +129,8 @@ def test_mxfp4_pool_write_fetch_translate(eng, oracle):
 
 @pytest.mark.parametrize("g", [8, 4, 16, 3, 11])
 def test_mx4_fused_attention(eng, oracle, g):
-    """speckv_ext_attend_mx4 against orc_attend_mx4 for every way a wave packs heads (g <= 4: four heads per wave, <= 8: two,
-    else one): whole range, ragged last tile, many / one split, a range not at 0, a sharp softmax, all layers at once."""
+    """speckv_ext_attend_mx4 against orc_attend_mx4 for live and dead query-row columns (g <= 8: one pass, else two groups of
+    eight rows): whole range, ragged last tile, many / one split, a range not at 0, a sharp softmax, all layers at once."""
     torch = torch_mod()
     lib = eng.lib
     lib.set_compression_scheme(5)
