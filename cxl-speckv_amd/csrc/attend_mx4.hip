@@ -35,6 +35,11 @@
 // 32-position tile of its two heads 4 for K, 4 for V, 1 + 1 for the codes -- 10 instructions for 8704 bytes -- two tiles deep per
 // wave; the operands are then read from LDS.  All vector-memory traffic of the loop is inline assembly with explicit counters.
 #include "kernels.hpp"
+#include <type_traits>
+
+#ifndef MX4_CODES_POLICY
+#define MX4_CODES_POLICY ""        // the 64 bytes of codes of a record are read by all four waves of the workgroup: default cache policy (the rows: nt)
+#endif
 
 namespace speckv {
 
@@ -48,10 +53,16 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 namespace {
 
 #define MX_GP(T, p) ((const T __attribute__((address_space(1)))*)(reinterpret_cast<uintptr_t>(p)))
-constexpr uint32_t kRec = kMx4RecBytes;                      // 1088
-constexpr uint32_t kWavesPerWg = 2;                          // two heads per wave: a workgroup covers 4 kv heads
+constexpr uint32_t kRec = kMx4SlotBytes;                     // record stride: 1088 bytes of record in a slot of 9 lines
+constexpr uint32_t kWavesPerWg = 4;                          // two heads per wave: a workgroup covers the 8 kv heads -- the four waves that read a
+                                                             // record's 64 bytes of codes then sit on one CU (one L2): measured with two workgroups per
+                                                             // record, each code line came from HBM up to four times (profiles/r05_mx4.txt)
 // per wave and stage: K rows [16 pages][256 B] | V rows [16 pages][256 B] | K codes [16][16 B] | V codes [16][16 B]
 constexpr uint32_t kStK = 0, kStV = 4096, kStKC = 8192, kStVC = 8448, kStage = 8704;
+#ifndef MX4_STAGES
+#define MX4_STAGES 3          // (2: two workgroups per CU fit; measured 0.71-0.75 of the HBM roofline against 0.73-0.77 with 3 and one workgroup per CU)
+#endif
+constexpr uint32_t kStages = MX4_STAGES;                     // tiles a wave keeps in LDS: the one it works on and kStages - 1 on their way
 
 template <typename T> __device__ __forceinline__ T* uniform_ptr(T* p)
 {
@@ -63,26 +74,39 @@ template <typename T> __device__ __forceinline__ T* uniform_ptr(T* p)
 __device__ __forceinline__ void dma16(uint32_t lds_dst, const uint8_t* base, uint32_t voff)
 {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(base) : "memory");
 }
 __device__ __forceinline__ void dma4(uint32_t lds_dst, const uint8_t* base, uint32_t voff)
 {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3 nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(base) : "memory");
+}
+// a region's share of a tile in one statement: four 1 KiB pieces of rows + the codes; M0 saved and restored once
+__device__ __forceinline__ void dma_region(uint32_t lds_rows, uint32_t lds_codes, const uint8_t* base, const uint32_t (&goff)[4], uint32_t goffc)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %8 nt\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %8 nt\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %8 nt\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %8 nt\n\t"
+                 "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %7, %8" MX4_CODES_POLICY "\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_rows), "s"(lds_codes), "v"(goff[0]), "v"(goff[1]), "v"(goff[2]), "v"(goff[3]), "v"(goffc), "s"(base) : "memory", "scc");
 }
 // the same with a full per-lane address (striped placements: the pages of one instruction sit in different runs)
 __device__ __forceinline__ void dma16_flat(uint32_t lds_dst, const uint8_t* addr)
 {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_dst), "v"(addr) : "memory");
 }
 __device__ __forceinline__ void dma4_flat(uint32_t lds_dst, const uint8_t* addr)
 {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_dst), "v"(addr) : "memory");
 }
 __device__ __forceinline__ float max_over_kb(float v)
@@ -100,6 +124,12 @@ __device__ __forceinline__ float sum_over_kb(float v)
     const uint32_t m = __float_as_uint(__uint_as_float(a[0]) + __uint_as_float(a[1]));
     const auto b = __builtin_amdgcn_permlane32_swap(m, m, false, false);
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+template <uint32_t N> __device__ __forceinline__ void wait_all_but()
+{
+    static_assert(N == 15u || N == 25u, "vmcnt immediate");
+    if (N == 15u) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
 }
 // the lane 8 further on in its row of 16 (the other parity of the same query row): DPP row_ror:8
 __device__ __forceinline__ float other_parity(float v)
@@ -119,11 +149,12 @@ __device__ __forceinline__ float q_clean(uint32_t half_bits)
 // FORM 1: striped regularly over 2..8 pools (AttendArgs::stripe_bases)
 // FORM 2: no regular placement, or a last tile that would leave the layer's region: every record address from its page-table
 //         entry, clamped to the range (never-written pages read the zero page); staged through registers, one tile at a time
-// grid (splits, rows x 2 head quads [, query-row groups of 8]); a workgroup = 2 waves = 4 kv heads.
+// grid (splits, rows [, query-row groups of 8]); a workgroup = 4 waves = the 8 kv heads.
 template <int FORM>
-__global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_attend_mx4(AttendArgs a)
+__global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_eu(kStages > 2u ? 1 : 2, kStages > 2u ? 1 : 2))) void k_attend_mx4(AttendArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerWg][2 * kStage];
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];                  // kWavesPerWg x 2 stages (68 KiB: beyond the static limit)
+    uint8_t (*lds)[kStages * kStage] = reinterpret_cast<uint8_t (*)[kStages * kStage]>(lds_dyn);
     __shared__ uint64_t s_bases[8];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -131,8 +162,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
     const uint32_t w = c >> 3, ql = c & 7u;                              // this lane's column: position parity w, query row ql of the group
     const uint32_t q = blockIdx.z * 8u + ql;                             // query row inside the kv head's g rows
     const uint32_t split = blockIdx.x;
-    uint32_t layer = blockIdx.y >> 1;                                    // batch form: the sequence index
-    const uint32_t h0 = ((blockIdx.y & 1u) * kWavesPerWg + wave) * 2u;   // first of this wave's two kv heads
+    uint32_t layer = blockIdx.y;                                         // batch form: the sequence index
+    const uint32_t h0 = wave * 2u;                                       // first of this wave's two kv heads
     const uint64_t row0 = static_cast<uint64_t>(layer) * a.heads + h0;   // query / output row block of head 0 (head 1: + 1)
     uint64_t part0 = row0 * a.n_splits + split, part_step = a.n_splits;  // partials of head 0 | head 1: part0, part0 + part_step
     uint32_t my_splits = a.n_splits;
@@ -194,49 +225,42 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
             if (FORM == 1) return attend_stripe_rec(s_bases, first + page_in_range, a.stripe_n, a.stripe_magic, kRec);
             const u32x4 e = *MX_GP(u32x4, a.entries + (first + min(page_in_range, last_pg)));      // {address lo, hi, record bytes, scale}
             const uint8_t* r = reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(e.x) | (static_cast<uint64_t>(e.y) << 32));
-            return e.z >= kRec ? r : a.zero_page;
+            return e.z >= kMx4RecBytes ? r : a.zero_page;
         };
-        auto stage = [&](uint32_t tt, uint32_t buf) {
+        // one region's share of a tile (rg = 0: K rows + K codes, 1: V rows + V codes) into stage `buf`: 5 DMA instructions
+        auto stage = [&](uint32_t tt, uint32_t buf, uint32_t rg) {
             const uint32_t tc = min(tt, last);
             const uint32_t dst = lbase + buf * kStage;
+            const uint32_t first = rg ? vfirst : kfirst;
+            const uint32_t drows = dst + (rg ? kStV : kStK), dcodes = dst + (rg ? kStVC : kStKC);
             if (FORM == 0) {
-                const uint8_t* kt = a.lin_base + (static_cast<uint64_t>(kfirst) + 16ull * tc) * kRec;      // (scalar)
-                const uint8_t* vt = a.lin_base + (static_cast<uint64_t>(vfirst) + 16ull * tc) * kRec;
-#pragma unroll
-                for (uint32_t i = 0; i < 4; ++i) dma16(dst + kStK + 1024u * i, kt, goff[i]);
-                dma4(dst + kStKC, kt, goffc);
-#pragma unroll
-                for (uint32_t i = 0; i < 4; ++i) dma16(dst + kStV + 1024u * i, vt, goff[i]);
-                dma4(dst + kStVC, vt, goffc);
+                const uint8_t* rt = a.lin_base + (static_cast<uint64_t>(first) + 16ull * tc) * kRec;      // (scalar)
+                dma_region(drows, dcodes, rt, goff, goffc);
             } else if (FORM == 1) {
-                const uint32_t inrec = h0 * 128u;
 #pragma unroll
                 for (uint32_t i = 0; i < 4; ++i)
-                    dma16_flat(dst + kStK + 1024u * i, rec_of(kfirst, 16u * tc + 4u * i + srow) + inrec + ((sslot ^ ((4u * i + srow) & 15u)) * 16u));
-                dma4_flat(dst + kStKC, rec_of(kfirst, 16u * tc + (lane >> 2)) + 1024u + h0 * 8u + (lane & 3u) * 4u);
-#pragma unroll
-                for (uint32_t i = 0; i < 4; ++i)
-                    dma16_flat(dst + kStV + 1024u * i, rec_of(vfirst, 16u * tc + 4u * i + srow) + inrec + ((sslot ^ ((4u * i + srow) & 15u)) * 16u));
-                dma4_flat(dst + kStVC, rec_of(vfirst, 16u * tc + (lane >> 2)) + 1024u + h0 * 8u + (lane & 3u) * 4u);
+                    dma16_flat(drows + 1024u * i, rec_of(first, 16u * tc + 4u * i + srow) + h0 * 128u + ((sslot ^ ((4u * i + srow) & 15u)) * 16u));
+                dma4_flat(dcodes, rec_of(first, 16u * tc + (lane >> 2)) + 1024u + h0 * 8u + (lane & 3u) * 4u);
             } else {
                 // page-table form: through registers, synchronously (the slow path of odd ranges and migrated allocations)
                 uint8_t* d = const_cast<uint8_t*>(lptr) + buf * kStage;
 #pragma unroll
-                for (uint32_t rg = 0; rg < 2; ++rg) {
-                    const uint32_t first = rg ? vfirst : kfirst;
-#pragma unroll
-                    for (uint32_t i = 0; i < 4; ++i) {
-                        const uint8_t* r = rec_of(first, 16u * tc + 4u * i + srow);
-                        *reinterpret_cast<u32x4*>(d + (rg ? kStV : kStK) + 1024u * i + 16u * lane) =
-                            *MX_GP(u32x4, r + h0 * 128u + ((sslot ^ ((4u * i + srow) & 15u)) * 16u));
-                    }
-                    const uint8_t* r = rec_of(first, 16u * tc + (lane >> 2));
-                    *reinterpret_cast<uint32_t*>(d + (rg ? kStVC : kStKC) + 4u * lane) = *MX_GP(uint32_t, r + 1024u + h0 * 8u + (lane & 3u) * 4u);
+                for (uint32_t i = 0; i < 4; ++i) {
+                    const uint8_t* r = rec_of(first, 16u * tc + 4u * i + srow);
+                    *reinterpret_cast<u32x4*>(d + (rg ? kStV : kStK) + 1024u * i + 16u * lane) =
+                        *MX_GP(u32x4, r + h0 * 128u + ((sslot ^ ((4u * i + srow) & 15u)) * 16u));
                 }
+                const uint8_t* r = rec_of(first, 16u * tc + (lane >> 2));
+                *reinterpret_cast<uint32_t*>(d + (rg ? kStVC : kStKC) + 4u * lane) = *MX_GP(uint32_t, r + 1024u + h0 * 8u + (lane & 3u) * 4u);
             }
         };
-        stage(t0, 0u);
-        if (FORM != 2) stage(t0 + 1u, 1u);
+        // request order K(t), V(t), K(t+1), V(t+1), ...: five instructions each, so "all but the 15 youngest" is "this region has landed"
+        stage(t0, 0u, 0u);
+        stage(t0, 0u, 1u);
+        if (FORM != 2) {
+#pragma unroll
+            for (uint32_t sg = 1; sg < kStages; ++sg) { stage(t0 + sg, sg, 0u); stage(t0 + sg, sg, 1u); }
+        }
 
         // ---- query operands (MXFP8, blocks of 16 channels, zero-interleaved): lane (c = 8w + q, kb) takes channels 8kb + 32 gq + 0..7
         // (gq = 0..3) of query row q of both heads; operand [head][half hf] bytes 0..15 <- gq = 2 hf, bytes 16..31 <- gq = 2 hf + 1
@@ -312,22 +336,39 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
         }
         const bool ragged = (a.n_pages & 15u) != 0u;
         const uint32_t n_pos = 2u * a.n_pages, skip_pos = 2u * a.skip_pages;
-#pragma unroll 1
-        for (uint32_t tile = t0; tile < t1; ++tile) {
-            const uint32_t buf = FORM == 2 ? 0u : (tile - t0) & 1u;
-            // tile `tile` has landed: only the 10 requests of the next one may still be on their way
-            if (FORM != 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        const uint32_t wshift = 16u * w;
+        // one tile out of stage BUF (a compile-time constant: the LDS reads then carry the stage as an immediate offset)
+        auto tile_body = [&](uint32_t tile, auto buf_c) {
+            constexpr uint32_t buf = decltype(buf_c)::value;
             const uint8_t* st = lptr + buf * kStage;
+#ifdef MX4_LOCKSTEP
+            __builtin_amdgcn_s_barrier();           // (experiment: the four waves of a workgroup ask for the same tile's pieces at the same time)
+#endif
+            // ---- K of this tile has landed (younger requests: V of this tile, K and V of the next): both heads' blocks and codes
+            // to registers, and the region goes straight back to the DMA for the next-but-one tile
+            if (FORM != 2) wait_all_but<10u * kStages - 5u>();
+            u32x4 kx[2][2];
+            uint32_t kc[2][2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    kx[hh][hf] = *reinterpret_cast<const u32x4*>(st + rk[hh][hf]);
+                    kc[hh][hf] = st[rkc[hh][hf]];
+                }
+            if (FORM != 2) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kx[0][0]), "+v"(kx[0][1]), "+v"(kx[1][0]), "+v"(kx[1][1]), "+v"(kc[0][0]), "+v"(kc[0][1]), "+v"(kc[1][0]), "+v"(kc[1][1]) :: "memory");
+                stage(tile + kStages, buf, 0u);
+            }
+            f16x8 P[2];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 // ---- scores: two block-scaled MFMAs (channels 0..63, 64..127) over the tile's 16 pages
                 f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    const u32x4 kx = *reinterpret_cast<const u32x4*>(st + rk[hh][hf]);
-                    const uint32_t kc = st[rkc[hh][hf]];
-                    const v8i A = {static_cast<int>(kx.x), static_cast<int>(kx.y), static_cast<int>(kx.z), static_cast<int>(kx.w), 0, 0, 0, 0};
-                    s = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, QB[hh][hf], s, 4 /* A: e2m1 */, 0 /* B: e4m3 */, 0, static_cast<int>(kc), 0, q_code[hh][hf]);
+                    const v8i A = {static_cast<int>(kx[hh][hf].x), static_cast<int>(kx[hh][hf].y), static_cast<int>(kx[hh][hf].z), static_cast<int>(kx[hh][hf].w), 0, 0, 0, 0};
+                    s = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, QB[hh][hf], s, 4 /* A: e2m1 */, 0 /* B: e4m3 */, 0, static_cast<int>(kc[hh][hf]), 0, q_code[hh][hf]);
                 }
                 float sc[4];
 #pragma unroll
@@ -361,34 +402,62 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
                 // weights as the B operand: slot pair i = (p_i, 0) for parity 0, (0, p_i) for parity 1
                 u32x4 pw;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const uint32_t h = __builtin_bit_cast(uint16_t, static_cast<_Float16>(p[r]));
-                    pw[r] = w ? (h << 16) : h;
-                }
-                const f16x8 P = __builtin_bit_cast(f16x8, pw);
-                // ---- out^T += V^T . P^T: a byte of the record = channel d of both positions of a page -> one operand register
-                u32x2 vx[4];
-                float vsc[4];
+                for (int r = 0; r < 4; ++r) pw[r] = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, static_cast<_Float16>(p[r]))) << wshift;
+                P[hh] = __builtin_bit_cast(f16x8, pw);
+            }
+            // ---- V of this tile has landed (younger: K and V of the next tile, K of the one after): both heads' pieces and codes
+            if (FORM != 2) wait_all_but<10u * kStages - 5u>();
+            u32x2 vx[2][4];
+            uint32_t vcode[2][4];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    vx[i] = *reinterpret_cast<const u32x2*>(st + rv[hh][i]);
-                    vsc[i] = __uint_as_float(static_cast<uint32_t>(st[rvc[hh][i]]) << 23);          // the block's E8M0 code as a float's exponent field
+                    vx[hh][i] = *reinterpret_cast<const u32x2*>(st + rv[hh][i]);
+                    vcode[hh][i] = st[rvc[hh][i]];
                 }
-#define MX_PV(S, WORD, SEL)                                                                                                      \
-    {                                                                                                                            \
-        const u32x4 vw = {__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(vx[0].WORD, vsc[0], SEL)),        \
-                          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(vx[1].WORD, vsc[1], SEL)),        \
-                          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(vx[2].WORD, vsc[2], SEL)),        \
-                          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(vx[3].WORD, vsc[3], SEL))};       \
-        acc[hh][S] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vw), P, acc[hh][S], 0, 0, 0);               \
+            if (FORM != 2) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vx[0][0]), "+v"(vx[0][1]), "+v"(vx[0][2]), "+v"(vx[0][3]), "+v"(vx[1][0]), "+v"(vx[1][1]), "+v"(vx[1][2]), "+v"(vx[1][3]),
+                             "+v"(vcode[0][0]), "+v"(vcode[0][1]), "+v"(vcode[0][2]), "+v"(vcode[0][3]), "+v"(vcode[1][0]), "+v"(vcode[1][1]), "+v"(vcode[1][2]), "+v"(vcode[1][3]) :: "memory");
+                stage(tile + kStages, buf, 1u);
+            }
+            // ---- out^T += V^T . P^T: a byte of the record = channel d of both positions of a page -> one operand register
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                float vsc[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vsc[i] = __uint_as_float(vcode[hh][i] << 23);          // the block's E8M0 code as a float's exponent field
+#define MX_PV(S, WORD, SEL)                                                                                                          \
+    {                                                                                                                                \
+        const u32x4 vw = {__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(vx[hh][0].WORD, vsc[0], SEL)),        \
+                          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(vx[hh][1].WORD, vsc[1], SEL)),        \
+                          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(vx[hh][2].WORD, vsc[2], SEL)),        \
+                          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(vx[hh][3].WORD, vsc[3], SEL))};       \
+        acc[hh][S] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vw), P[hh], acc[hh][S], 0, 0, 0);               \
     }
                 MX_PV(0, x, 0) MX_PV(1, x, 1) MX_PV(2, x, 2) MX_PV(3, x, 3) MX_PV(4, y, 0) MX_PV(5, y, 1) MX_PV(6, y, 2) MX_PV(7, y, 3)
 #undef MX_PV
             }
-            // every read of this stage has returned: the next-but-one tile may overwrite it
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (FORM != 2) stage(tile + 2u, buf);
-            else if (tile + 1u < t1) stage(tile + 1u, 0u);
+            if (FORM == 2 && tile + 1u < t1) {                                    // synchronous staging of the next tile
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                stage(tile + 1u, 0u, 0u);
+                stage(tile + 1u, 0u, 1u);
+            }
+        };
+        if (FORM == 2) {
+#pragma unroll 1
+            for (uint32_t tile = t0; tile < t1; ++tile) tile_body(tile, std::integral_constant<uint32_t, 0u>{});
+        } else {
+#pragma unroll 1
+            for (uint32_t tile = t0; tile < t1; tile += kStages) {
+                tile_body(tile, std::integral_constant<uint32_t, 0u>{});
+                if (tile + 1u >= t1) break;
+                tile_body(tile + 1u, std::integral_constant<uint32_t, 1u>{});
+                if (kStages > 2u) {
+                    if (tile + 2u >= t1) break;
+                    tile_body(tile + 2u, std::integral_constant<uint32_t, (kStages > 2u ? 2u : 0u)>{});
+                }
+            }
         }
         if (FORM != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-requested tail tiles: nothing may land after the wave ends
     }
@@ -438,10 +507,18 @@ hipError_t launch_attend_mx4(const AttendArgs& a, uint32_t n_rows, float* d_out,
     if (!a.seqs && a.n_pages == 0) return hipSuccess;
     const int form = a.lin_base ? 0 : a.stripe_bases ? 1 : a.table_form ? 2 : -1;
     if (form < 0) return hipErrorInvalidValue;
-    const dim3 grid(a.n_splits, n_rows * 2u, (a.g + 7u) / 8u), block(64 * kWavesPerWg);
-    if (form == 0) hipLaunchKernelGGL(k_attend_mx4<0>, grid, block, 0, s, a);
-    else if (form == 1) hipLaunchKernelGGL(k_attend_mx4<1>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(k_attend_mx4<2>, grid, block, 0, s, a);
+    const dim3 grid(a.n_splits, n_rows, (a.g + 7u) / 8u), block(64 * kWavesPerWg);
+    constexpr size_t lds_bytes = static_cast<size_t>(kWavesPerWg) * kStages * kStage;
+    static const hipError_t attr = [] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        return e;
+    }();
+    if (attr != hipSuccess) return attr;
+    if (form == 0) hipLaunchKernelGGL(k_attend_mx4<0>, grid, block, lds_bytes, s, a);
+    else if (form == 1) hipLaunchKernelGGL(k_attend_mx4<1>, grid, block, lds_bytes, s, a);
+    else hipLaunchKernelGGL(k_attend_mx4<2>, grid, block, lds_bytes, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const bool all_final = a.direct_out && (!a.direct_per_seq || a.direct_per_seq == 2u);

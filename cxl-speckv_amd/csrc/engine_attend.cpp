@@ -227,13 +227,14 @@ static uint32_t int4_wg8_batch_tps(uint32_t n_seq, uint32_t tiles_max)
     return std::max(32u, (tiles_max + splits - 1u) / splits);
 }
 
-// MXFP4 batches (k_attend_mx4: one workgroup of 8 / HPW waves per (sequence, split), all 8 kv heads; four 4-wave workgroups
-// resident per CU): about one round of resident workgroups, never under 8 tiles a split; a whole sequence is final (no
-// partials, no merge launch).
+// MXFP4 batches (k_attend_mx4: one workgroup of 4 waves = the 8 kv heads per (sequence, split), three tiles deep in LDS: ONE
+// workgroup resident per CU): one round of resident workgroups -- measured at 256 sequences x 8k: whole sequences (256
+// workgroups) 0.77 of the HBM roofline, two splits each 0.73 (profiles/r05_mx4.txt) -- never under 8 tiles a split; a whole
+// sequence is final (no partials, no merge launch).
 static uint32_t mx4_batch_tps(uint32_t n_seq, uint32_t tiles_max)
 {
     if (const char* env = getenv("SPECKV_ATTEND_TILES_PER_SPLIT")) return std::max(1, atoi(env));      // (measurement runs)
-    const uint32_t resident = 1024u;
+    const uint32_t resident = 256u;
     const uint32_t splits = std::max(1u, resident / std::max(1u, n_seq));
     return std::max(8u, (tiles_max + splits - 1u) / splits);
 }
@@ -746,9 +747,11 @@ int Engine::attend_mx4(uint64_t handle, uint32_t layer, uint32_t n_layers, const
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
         HIP_TRY(hipMemset(d_zero_page_, 0, kPageSize));
     }
-    // workgroups = splits x layers (each covers the 8 kv heads), about two rounds of the resident set (four 4-wave workgroups per CU)
+    // workgroups = splits x layers x query-row groups (each covers the 8 kv heads; one resident per CU): one round of the CUs,
+    // rounded down -- 80 layers at 32k: 3 splits (240 workgroups) 0.765 of the HBM roofline, 6 splits 0.72-0.75 (profiles/r05_mx4.txt)
     const uint32_t rows = n_layers * L.num_heads;
-    uint32_t want = std::max(1u, (2048u + n_layers - 1u) / n_layers);
+    const uint32_t columns = n_layers * ((g + 7u) / 8u);
+    uint32_t want = std::max(1u, 256u / columns);
     const uint32_t min_tiles = std::min(8u, std::max(2u, n_tiles / 64u));      // per-layer calls: see attend_fp8
     want = std::min(want, std::max(1u, n_tiles / min_tiles));
     if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));

@@ -64,7 +64,7 @@ uint32_t stride_for(int scheme)
     case SPECKV_COMP_INT8: return 2048u;
     case SPECKV_COMP_FP8_E4M3: return 2048u;
     case SPECKV_COMP_INT4_G32: return kInt4RecBytes;      // 1152 B: the 4:1 format (3.56:1 with scales)
-    case SPECKV_COMP_MXFP4: return kMx4RecBytes;          // 1088 B: 3.76:1 with scales
+    case SPECKV_COMP_MXFP4: return kMx4SlotBytes;         // 1088-byte records (3.76:1 of traffic) in line-aligned 1152-byte slots (3.56:1 of capacity)
     default: return kPageSize;
     }
 }
