@@ -589,8 +589,11 @@ speckv_status_t speckv_ext_stats_sized(void* out, size_t out_size, size_t* writt
         speckv_ext_stats_t st;
         const int rc = g_engine->stats(&st);
         if (rc != SPECKV_OK) return rc;
+        if (out_size < sizeof(uint64_t)) return static_cast<int>(SPECKV_ERR_INVAL);      // not even the first field
         const size_t n = out_size < sizeof(st) ? out_size : sizeof(st);
         std::memcpy(out, &st, n);
+        // a caller built against a NEWER header (a larger struct) must not read uninitialised tail fields: they are zero
+        if (out_size > n) std::memset(static_cast<uint8_t*>(out) + n, 0, out_size - n);
         if (written) *written = n;
         return static_cast<int>(SPECKV_OK);
     });

@@ -800,7 +800,13 @@ int Engine::note_async_write_or_wait(hipStream_t s)
 {
     if (note_async_write(s) == SPECKV_OK) return SPECKV_OK;
     (void)hipGetLastError();
-    if (is_capturing(s)) return SPECKV_OK;
+    // (note_async_write itself returns OK for a capturing stream: a captured write is ordered by its graph's launch stream.
+    // Getting here while capturing means the bookkeeping failed in a state where the stream cannot be waited for either:
+    // the ordering is NOT established, and the caller is told so.)
+    if (is_capturing(s)) {
+        SPECKV_ERR("a pool write on a capturing stream could not be ordered in front of the engine's own stream");
+        return SPECKV_ERR_DRIVER;
+    }
     HIP_TRY(hipStreamSynchronize(s));
     return SPECKV_OK;
 }

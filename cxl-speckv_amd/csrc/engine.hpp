@@ -178,12 +178,23 @@ public:
     int stats(speckv_ext_stats_t* out);
     uint32_t prefetch_depth() const { return adapt_.depth(); }
     int compute_device() const { return device_; }
+    // compute units of THIS engine's device (launch geometry of the attention kernels; ADVICE r4: not a process-wide guess)
+    uint32_t cus()
+    {
+        if (!n_cus_) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device_) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 256; }
+            n_cus_ = static_cast<uint32_t>(v);
+        }
+        return n_cus_;
+    }
 
 private:
     Engine() = default;
 
     bool null_ = false;
     int device_ = 0;
+    uint32_t n_cus_ = 0;
     std::unique_lock<std::mutex>* lk_ = nullptr;
     uint32_t waiting_ = 0;                 // threads inside wait_event with the ABI lock released
     std::condition_variable idle_cv_;

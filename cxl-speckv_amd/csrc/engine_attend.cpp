@@ -218,11 +218,11 @@ static bool int4_batch_wg8() { static const bool on = !getenv("SPECKV_INT4_WG4")
 // More sequences than CUs: workgroups of one run (8 waves, two resident per CU) -- a finishing workgroup's successor starts
 // under its neighbour's stream, where a second round of 16-wave workgroups would wait for the whole CU (512 x 1k 0.52 -> 0.54,
 // 1024 x 1k 0.56 -> 0.595: profiles/r04_batch_short.txt); AttendArgs::wg8 = 2.
-static uint32_t int4_wg8_form(uint32_t n_seq) { return n_seq > 256u ? 2u : 1u; }
-static uint32_t int4_wg8_batch_tps(uint32_t n_seq, uint32_t tiles_max)
+static uint32_t int4_wg8_form(uint32_t n_seq, uint32_t cus) { return n_seq > cus ? 2u : 1u; }
+static uint32_t int4_wg8_batch_tps(uint32_t n_seq, uint32_t tiles_max, uint32_t cus)
 {
     if (const char* env = getenv("SPECKV_ATTEND_TILES_PER_SPLIT")) return std::max(1, atoi(env));      // (measurement runs)
-    const uint32_t resident = 256u;                                       // 16-wave workgroups (two halves each), one per CU
+    const uint32_t resident = cus;                                        // 16-wave workgroups (two halves each), one per CU
     const uint32_t splits = std::max(1u, resident / std::max(1u, n_seq));
     return std::max(32u, (tiles_max + splits - 1u) / splits);
 }
@@ -231,10 +231,10 @@ static uint32_t int4_wg8_batch_tps(uint32_t n_seq, uint32_t tiles_max)
 // workgroup resident per CU): one round of resident workgroups -- measured at 256 sequences x 8k: whole sequences (256
 // workgroups) 0.77 of the HBM roofline, two splits each 0.73 (profiles/r05_mx4.txt) -- never under 8 tiles a split; a whole
 // sequence is final (no partials, no merge launch).
-static uint32_t mx4_batch_tps(uint32_t n_seq, uint32_t tiles_max)
+static uint32_t mx4_batch_tps(uint32_t n_seq, uint32_t tiles_max, uint32_t cus)
 {
     if (const char* env = getenv("SPECKV_ATTEND_TILES_PER_SPLIT")) return std::max(1, atoi(env));      // (measurement runs)
-    const uint32_t resident = 256u;
+    const uint32_t resident = cus;
     const uint32_t splits = std::max(1u, resident / std::max(1u, n_seq));
     return std::max(8u, (tiles_max + splits - 1u) / splits);
 }
@@ -309,7 +309,7 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     uint32_t tiles_max = 0;
     for (uint32_t i = 0; i < n_seq; ++i) tiles_max = std::max(tiles_max, seqs[i].n_splits);
     const bool wg8 = !fp8 && !mx4 && !any_striped && !any_table && heads == 8u && int4_batch_wg8();
-    const uint32_t tps = mx4 ? mx4_batch_tps(n_seq, tiles_max) : wg8 ? int4_wg8_batch_tps(n_seq, tiles_max) : batch_tiles_per_split(fp8, n_seq, heads, total_tiles, seqs.data(), 0);
+    const uint32_t tps = mx4 ? mx4_batch_tps(n_seq, tiles_max, cus()) : wg8 ? int4_wg8_batch_tps(n_seq, tiles_max, cus()) : batch_tiles_per_split(fp8, n_seq, heads, total_tiles, seqs.data(), 0);
     const UnequalSplit unequal = (fp8 || mx4 || wg8) ? UnequalSplit{false, 1.0} : int4_unequal_split(n_seq, heads / 4u, tiles_max);
     uint32_t max_splits = 0;
     uint64_t parts = 0;
@@ -372,7 +372,7 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     for (uint32_t i = 0; i < n_seq; ++i) one_split_each = one_split_each && seqs[i].n_splits == 1u;
     if (one_split_each) { k.direct_out = d_out; k.direct_lse = d_lse; }
     if (unequal.on) k.rows_first = 1u;
-    if (wg8) k.wg8 = int4_wg8_form(n_seq);
+    if (wg8) k.wg8 = int4_wg8_form(n_seq, cus());
     if (fp8) {
         HIP_TRY(launch_attend_fp8_batch(k, n_seq, d_out, d_lse, st));
     } else if (mx4) {
@@ -391,20 +391,20 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
 // of the caller; speckv_ext_attend_*_planned is kernel launches only: no handle look-ups, no staging, grid and scratch
 // sized from max_pos_end alone, so a captured launch stays valid for as long as the lengths stay within that bound.
 struct PlanGeometry { uint32_t tps, max_splits; uint64_t parts_bound; UnequalSplit unequal; };
-static PlanGeometry plan_geometry(bool fp8, uint32_t n_seq, uint32_t heads, uint32_t max_pos_end, bool mx4 = false)
+static PlanGeometry plan_geometry(bool fp8, uint32_t n_seq, uint32_t heads, uint32_t max_pos_end, uint32_t cus, bool mx4 = false)
 {
     const uint32_t tiles_max = (max_pos_end / 2u + 15u) / 16u;
     PlanGeometry g{};
     if (mx4) {
         g.unequal = UnequalSplit{false, 1.0};
-        g.tps = mx4_batch_tps(n_seq, tiles_max);
+        g.tps = mx4_batch_tps(n_seq, tiles_max, cus);
         g.max_splits = std::max(1u, (tiles_max + g.tps - 1u) / g.tps);
         g.parts_bound = static_cast<uint64_t>(n_seq) * heads * g.max_splits;
         return g;
     }
     if (!fp8 && heads == 8u && int4_batch_wg8()) {            // the whole-record kernel's geometry (a striped / table launch runs it on the 4-head kernels)
         g.unequal = UnequalSplit{false, 1.0};
-        g.tps = int4_wg8_batch_tps(n_seq, tiles_max);
+        g.tps = int4_wg8_batch_tps(n_seq, tiles_max, cus);
         g.max_splits = std::max(1u, (tiles_max + g.tps - 1u) / g.tps);
         g.parts_bound = static_cast<uint64_t>(n_seq) * heads * g.max_splits;
         return g;
@@ -461,7 +461,7 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
         seqs[i].n_pages = n_pages;
         seqs[i].n_splits = n_tiles;
     }
-    const PlanGeometry g = plan_geometry(scheme == SPECKV_COMP_FP8_E4M3, n_seq, heads, max_pos_end, scheme == SPECKV_COMP_MXFP4);
+    const PlanGeometry g = plan_geometry(scheme == SPECKV_COMP_FP8_E4M3, n_seq, heads, max_pos_end, cus(), scheme == SPECKV_COMP_MXFP4);
     if (g.max_splits > 2048u) return SPECKV_ERR_INVAL;
     if (plans_.size() >= 64 && !plans_.count(d_plan)) plans_.clear();        // (buffers of long-gone steps)
     if (any_table)
@@ -514,7 +514,7 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
         SPECKV_ERR("speckv_ext_attend_*_planned: no plan of this shape at %p (n_seq, format and max_pos_end as planned, layer inside every layout)", d_plan);
         return SPECKV_ERR_INVAL;
     }
-    const PlanGeometry pg = plan_geometry(fp8, n_seq, heads, max_pos_end, mx4);
+    const PlanGeometry pg = plan_geometry(fp8, n_seq, heads, max_pos_end, cus(), mx4);
     DeviceScope device_scope(device_);
     const size_t acc_bytes = static_cast<size_t>(pg.parts_bound) * 16 * 128 * sizeof(float), ml_bytes = static_cast<size_t>(pg.parts_bound) * 32 * sizeof(float);
     uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes, s));      // (growth during a capture is refused: warm up once)
@@ -530,7 +530,7 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
     k.scale_log2e = sm_scale * 1.4426950408889634f;
     if (plan->second.table) { k.table_form = 1u; k.zero_page = d_zero_page_; }           // a member without a regular placement: addresses from the page tables
     else if (plan->second.striped) k.stripe_bases = reinterpret_cast<const uint64_t*>(1);     // striped launch: every descriptor brings its table
-    else { k.lin_base = reinterpret_cast<const uint8_t*>(1); if (!fp8 && !mx4 && int4_batch_wg8()) k.wg8 = int4_wg8_form(n_seq); }     // non-null: linear form (the real base comes from the descriptor)
+    else { k.lin_base = reinterpret_cast<const uint8_t*>(1); if (!fp8 && !mx4 && int4_batch_wg8()) k.wg8 = int4_wg8_form(n_seq, cus()); }     // non-null: linear form (the real base comes from the descriptor)
     k.seqs = static_cast<const AttendSeq*>(d_plan);
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
@@ -567,23 +567,15 @@ int Engine::attend_fold_tail(uint32_t n_rows, const uint32_t* d_rows, uint32_t h
     return SPECKV_OK;
 }
 
-// Launch geometry of the whole-record INT4 kernel (k_attend_int4_wg8; 512-thread workgroups, two resident per CU).
-static int device_cus()
-{
-    static const int n_cus = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 256; }
-        return v;
-    }();
-    return n_cus;
-}
+// Launch geometry of the whole-record INT4 kernel (k_attend_int4_wg8; 512-thread workgroups, two resident per CU); `cus` = the
+// compute units of the ENGINE's device (Engine::cus()).
 // Stream form (many layers of one sequence): the launch's n_layers x n_tiles tiles, layer-major, in as many equal pieces as
 // workgroups are resident at once -- one pipeline fill per workgroup, no partial last round, few partials per layer.  Worth
 // it when a piece is long enough to amortise its fill (>= 16 tiles); *max_slots = most pieces any layer is cut into.
-static bool int4_wg8_stream(uint32_t n_layers, uint32_t n_tiles, AttendArgs::Stream* out)
+static bool int4_wg8_stream(uint32_t n_layers, uint32_t n_tiles, uint32_t cus, AttendArgs::Stream* out)
 {
     const uint64_t total = static_cast<uint64_t>(n_layers) * n_tiles;
-    uint64_t wgs = 2ull * static_cast<uint64_t>(device_cus());
+    uint64_t wgs = 2ull * static_cast<uint64_t>(cus);
     if (const char* env = getenv("SPECKV_INT4_STREAM_WGS")) wgs = std::max(1, atoi(env));
     if (n_layers < 2 || total < 16u * wgs || getenv("SPECKV_INT4_NO_STREAM")) return false;
     out->n_wgs = static_cast<uint32_t>(wgs);
@@ -595,9 +587,9 @@ static bool int4_wg8_stream(uint32_t n_layers, uint32_t n_tiles, AttendArgs::Str
 }
 // Fixed grid (per-layer calls, short launches): splits x layers workgroups, in whole rounds of the resident set when the
 // launch is that long, else as many 8-tile pieces as there are.
-static uint32_t int4_wg8_splits(uint32_t n_layers, uint32_t n_tiles)
+static uint32_t int4_wg8_splits(uint32_t n_layers, uint32_t n_tiles, uint32_t cus)
 {
-    const uint64_t resident = static_cast<uint64_t>(device_cus());                 // (16-wave workgroups, two halves each: one per CU)
+    const uint64_t resident = static_cast<uint64_t>(cus);                 // (16-wave workgroups, two halves each: one per CU)
     const uint64_t total = static_cast<uint64_t>(n_layers) * n_tiles;
     uint64_t wgs = std::max<uint64_t>(1, total / 64u);
     if (wgs >= resident) wgs = (wgs + resident / 2u) / resident * resident;       // whole rounds
@@ -662,13 +654,13 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     if (want > 8u) want &= ~7u;
     // whole-record kernel (8 waves = 8 heads, one workgroup per CU): workgroups = splits x layers, in whole rounds of the CUs
     const bool wg8 = linear && L.num_heads == 8 && !getenv("SPECKV_INT4_WG4");
-    if (wg8) want = int4_wg8_splits(n_layers, n_tiles);
+    if (wg8) want = int4_wg8_splits(n_layers, n_tiles, cus());
     if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));
     EvenSplit es = even_split(n_tiles, std::max(1u, std::min(want, 2048u)));
     if (!wg8 && es.n_splits > 8u && (es.n_splits & 7u) && !getenv("SPECKV_ATTEND_SPLITS"))      // the rounding can fall off a multiple of 8
         es = even_split(n_tiles, es.n_splits & ~7u);
     AttendArgs k{};
-    const bool stream = wg8 && !getenv("SPECKV_ATTEND_SPLITS") && int4_wg8_stream(n_layers, n_tiles, &k.stream);
+    const bool stream = wg8 && !getenv("SPECKV_ATTEND_SPLITS") && int4_wg8_stream(n_layers, n_tiles, cus(), &k.stream);
     const uint32_t n_splits = stream ? k.stream.max_slots : es.n_splits, tiles_per_split = es.tiles_per_split;      // (stream: slots per row)
     const size_t acc_bytes = static_cast<size_t>(rows) * n_splits * 16 * 128 * sizeof(float);
     const size_t ml_bytes = static_cast<size_t>(rows) * n_splits * 32 * sizeof(float);
@@ -751,7 +743,7 @@ int Engine::attend_mx4(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     // rounded down -- 80 layers at 32k: 3 splits (240 workgroups) 0.765 of the HBM roofline, 6 splits 0.72-0.75 (profiles/r05_mx4.txt)
     const uint32_t rows = n_layers * L.num_heads;
     const uint32_t columns = n_layers * ((g + 7u) / 8u);
-    uint32_t want = std::max(1u, 256u / columns);
+    uint32_t want = std::max(1u, cus() / columns);
     const uint32_t min_tiles = std::min(8u, std::max(2u, n_tiles / 64u));      // per-layer calls: see attend_fp8
     want = std::min(want, std::max(1u, n_tiles / min_tiles));
     if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));

@@ -143,6 +143,7 @@ class SpeckvKVConnector:
         if req_id in self._tail_ids:
             self._tail_ids, self._tail_k, self._tail_v = (), None, None
         self._arg_key = self._fold_key = None                 # a plan names record addresses: plan again
+        self._plan_stream = None                              # (and no early plan on a stream the caller may be done with)
         self.lib.free(r.handle)                               # the binding goes with the handle
 
     def length(self, req_id: int) -> int:
@@ -248,7 +249,16 @@ class SpeckvKVConnector:
         # step's attention ran on: the upload is ordered behind the launches that still read the current plan.
         st = self._plan_stream
         if st is not None and self._arg_key is not None and self._arg_key[0][0] == tuple(req_ids) and self.scheme in (3, 4):
-            self.plan_step(req_ids, st)
+            # best effort: the append itself has taken effect (lengths, tails, pool write) -- a plan that cannot be made now (the
+            # stream is capturing, or was destroyed by its owner) must not make the caller retry it; attend() plans again instead
+            try:
+                import torch
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("capturing: no early plan")
+                self.plan_step(req_ids, st)
+            except Exception:
+                self._arg_key = None
+                self._plan_stream = None
         return keep                                            # sources of the asynchronous writes: hold until the stream passed them
 
     # ------------------------------------------------------------------ reads

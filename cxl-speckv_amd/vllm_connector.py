@@ -63,17 +63,21 @@ def slot_mapping_for(block_ids: Sequence[int], block_size: int, num_tokens: int,
 
 
 def _cached_requests(scheduler_output):
-    """(request id, new block ids, num_computed_tokens) of the already-running requests of a step.  vLLM has shipped this
-    both as a list of per-request objects and as ONE object of parallel lists (``req_ids``, ``new_block_ids``,
-    ``num_computed_tokens``)."""
+    """(request id, new block ids, num_computed_tokens, resumed_from_preemption) of the already-known requests of a step.
+    vLLM has shipped this both as a list of per-request objects and as ONE object of parallel lists (``req_ids``,
+    ``new_block_ids``, ``num_computed_tokens``, ``resumed_from_preemption``).  A request that was preempted and is scheduled
+    again arrives HERE, not in ``scheduled_new_reqs``, with ``resumed_from_preemption`` set and ALL of its (new) block ids."""
     c = getattr(scheduler_output, "scheduled_cached_reqs", None)
     if c is None:
         return []
     if hasattr(c, "req_ids"):
-        nb = getattr(c, "new_block_ids", None) or [None] * len(c.req_ids)
-        nc = getattr(c, "num_computed_tokens", None) or [None] * len(c.req_ids)
-        return [(rid, _flat_block_ids(b) if b else [], n) for rid, b, n in zip(c.req_ids, nb, nc)]
-    return [(_req_id(r), _flat_block_ids(getattr(r, "new_block_ids", None) or []), getattr(r, "num_computed_tokens", None)) for r in c]
+        k = len(c.req_ids)
+        nb = getattr(c, "new_block_ids", None) or [None] * k
+        nc = getattr(c, "num_computed_tokens", None) or [None] * k
+        rs = getattr(c, "resumed_from_preemption", None) or [False] * k
+        return [(rid, _flat_block_ids(b) if b else [], n, bool(r)) for rid, b, n, r in zip(c.req_ids, nb, nc, rs)]
+    return [(_req_id(r), _flat_block_ids(getattr(r, "new_block_ids", None) or []), getattr(r, "num_computed_tokens", None),
+             bool(getattr(r, "resumed_from_preemption", False))) for r in c]
 
 
 class SpeckvVllmConnector:
@@ -143,17 +147,33 @@ class SpeckvVllmConnector:
                     self._emit_store(meta, rid, blocks, n)
                 else:
                     self._prompt[rid] = (n, blocks)
-        for rid, new_blocks, computed in _cached_requests(scheduler_output):
+        for rid, new_blocks, computed, resumed in _cached_requests(scheduler_output):
+            if rid in self._to_load:
+                # a preempted request scheduled again (vLLM reports it among the cached requests, `resumed_from_preemption`, with
+                # all of its new block ids): its pool hit is loaded exactly like a new request's.  The blocks recorded at
+                # update_state_after_alloc are the request's whole table; a release that only passes them here is served too.
+                blk, first, n = self._to_load.pop(rid)
+                use = blk or list(new_blocks)
+                if len(use) * self.block_size < first + n:
+                    raise RuntimeError(f"request {rid!r}: a pool hit of tokens [{first}, {first + n}) but only {len(use)} blocks to load it into")
+                meta.requests.append(ReqMeta(rid, self._engine_id(rid), slot_mapping_for(use, self.block_size, n, first), first, n, is_store=False))
+                continue
             if rid not in self._prompt:
                 continue
             n, blocks = self._prompt[rid]
-            blocks = blocks + list(new_blocks)
+            blocks = list(new_blocks) if resumed else blocks + list(new_blocks)      # (a resumed request brings its whole table again)
             if computed is not None and computed + scheduled.get(rid, 0) >= n:
                 del self._prompt[rid]
                 self._emit_store(meta, rid, blocks, n)
             else:
                 self._prompt[rid] = (n, blocks)
-        self._to_load.clear()
+        if self._to_load:
+            # a hit that update_state_after_alloc recorded but no entry of this step's output carries: vLLM would treat those
+            # tokens as computed although nothing fills their blocks -- never drop that silently
+            lost = sorted(self._to_load)
+            self._to_load.clear()
+            raise RuntimeError(f"pool hits recorded for {lost} but the scheduler output schedules none of them (neither as a new nor "
+                               "as a cached / resumed request): their blocks would be attended without ever being filled")
         return meta
 
     def _emit_store(self, meta, rid, blocks, n):

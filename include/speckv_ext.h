@@ -428,7 +428,9 @@ typedef struct {
 } speckv_ext_stats_t;
 /* The struct only ever grows at its end.  speckv_ext_stats() writes sizeof(speckv_ext_stats_t) of THIS header: a caller
  * compiled against an older header must use the sized form, which writes min(out_size, the library's size) bytes (fields
- * are never reordered, so a prefix is a valid older struct); *written (optional) = bytes written.
+ * are never reordered, so a prefix is a valid older struct); bytes of the caller's buffer beyond the library's struct are
+ * zero-filled (a caller built against a NEWER header reads zeros there); *written (optional) = bytes of real data; out_size < 8
+ * is SPECKV_ERR_INVAL.
  * SPECKV_EXT_ABI_VERSION is bumped whenever a struct of this header grows or an entry point changes meaning;
  * speckv_ext_abi_version() returns the library's value (the Python binding refuses a mismatch). */
 #define SPECKV_EXT_ABI_VERSION 4u

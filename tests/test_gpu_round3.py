@@ -1049,6 +1049,33 @@ def test_vllm_connector_prefix_hit_chunked_prefill_and_separate_roles():
             rest = torch.tensor(slot_mapping_for(new_blk, BS, n - 64, 64), device="cuda")
             assert float(prefix[li][:, rest].abs().max()) == 0.0                                       # nothing beyond the match
 
+        # ---- the same request PREEMPTED and resumed -- vLLM lists it among the cached requests (parallel-list shape,
+        # resumed_from_preemption) with a fresh block table, never in scheduled_new_reqs; its pool hit must still be loaded
+        for t in caches.values():
+            t.zero_()
+        res_blk = [50, 51, 52, 53, 54]
+        req = NS(request_id="r1", num_tokens=n)
+        matched, _ = sched.get_num_new_matched_tokens(req, 0)
+        assert matched == (n - 1) // BS * BS                                  # 64 of the 75 tokens
+        sched.update_state_after_alloc(req, NS(get_block_ids=lambda: [res_blk]), matched)
+        m_res = sched.build_connector_meta(NS(scheduled_new_reqs=[], num_scheduled_tokens={"r1": n - matched},
+                                              scheduled_cached_reqs=NS(req_ids=["r1"], new_block_ids=[[res_blk]], num_computed_tokens=[matched],
+                                                                       resumed_from_preemption=[True])))
+        assert [(r.is_store, r.first_token, r.num_tokens) for r in m_res.requests] == [(False, 0, matched)]
+        assert m_res.requests[0].slot_mapping == slot_mapping_for(res_blk, BS, matched, 0)
+        work.bind_connector_metadata(m_res)
+        work.start_load_kv(None)
+        work.clear_connector_metadata()
+        torch.cuda.synchronize()
+        res_slots = torch.tensor(slot_mapping_for(res_blk, BS, matched, 0), device="cuda")
+        for li in range(L):
+            assert torch.equal(prefix[li][:, res_slots], truth[li][:, :matched]), li
+        # ... and a hit that no entry of the step's output carries is an error, not a silent drop
+        sched.update_state_after_alloc(req, NS(get_block_ids=lambda: [res_blk]), matched)
+        with pytest.raises(RuntimeError, match="never being filled"):
+            sched.build_connector_meta(NS(scheduled_new_reqs=[], num_scheduled_tokens={}))
+        assert sched.build_connector_meta(NS(scheduled_new_reqs=[])).requests == []         # (the state was reset)
+
         # ---- a load for a request this worker never saved fails with a clear error, not a KeyError
         bad = sched.build_connector_meta(NS(scheduled_new_reqs=[]))
         from cxl_speckv_amd.vllm_connector import ReqMeta
