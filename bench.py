@@ -44,6 +44,16 @@ SCHEME_NAMES = {0: "fp16", 1: "int8", 2: "int8_delta_rle"}
 DTYPE_LABEL = "fp32 (int8 records -> fp16)"
 
 
+def set_tuning(key, value):
+    """speckv_ext_set_tuning on the loaded library (the library reads its environment only once)."""
+    import ctypes as C
+    import cxl_speckv_amd as pkg
+    lib = pkg.load_library()
+    lib.speckv_ext_set_tuning.argtypes = [C.c_char_p, C.c_longlong]
+    lib.speckv_ext_set_tuning.restype = C.c_int
+    lib.speckv_ext_set_tuning(key.encode(), int(value))
+
+
 def pmc_traffic(scheme, quant):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3
     --pmc passes of this same command (profiles/*_pmc.json, corrected as
@@ -1441,7 +1451,7 @@ def striped_attention_extra(torch, pkg, T=32768, Lyr=80):
         for label, general in (("computed_addresses", 0), ("table_form", 1)):
             os.environ["SPECKV_POOL_DEVICES"] = "0,0,0,0,0,0,0"
             if general:
-                os.environ["SPECKV_ATTEND_GENERAL"] = str(general)
+                set_tuning("attend_general", str(general))
             try:
                 kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), f"hip:{torch.cuda.current_device()}")
                 try:
@@ -1454,7 +1464,7 @@ def striped_attention_extra(torch, pkg, T=32768, Lyr=80):
                 out[f"{name}_{label}"] = {"error": repr(e)}
             finally:
                 os.environ.pop("SPECKV_POOL_DEVICES", None)
-                os.environ.pop("SPECKV_ATTEND_GENERAL", None)
+                set_tuning("attend_general", 0)
     return {"fused_attention_striped_x7": out}
 
 

@@ -1200,7 +1200,7 @@ hipError_t launch_attend_combine(const AttendArgs& a, uint32_t n_layers, float* 
     const uint32_t splits = a.stream.n_wgs ? a.stream.max_slots : a.n_splits;      // most partials a row can have
     const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
     if (splits > kMaxSplits) return hipErrorInvalidValue;
-    if (splits <= kSmallCombineSplits && !getenv("SPECKV_ATTEND_BIG_COMBINE")) {
+    if (splits <= kSmallCombineSplits) {
         const uint32_t n_rows = n_layers * a.heads;
         hipLaunchKernelGGL(k_attend_combine_small, dim3((n_rows + 3u) / 4u), dim3(256), 0, s, a.part_acc, a.part_ml, a.g,
                            a.n_splits, d_out, d_lse, a.seqs, a.heads, (a.direct_out && a.direct_per_seq) ? 1u : 0u, n_rows, a.stream, n_tiles);
@@ -1263,10 +1263,7 @@ hipError_t launch_attend_fp8_batch(const AttendArgs& a, uint32_t n_seq, float* d
     // the batch form keeps the register-staged kernel: 256 sequences x 8k context, one layer: 0.69 of HBM peak against 0.67
     // with the LDS-DMA kernel (many short splits: 4 waves/SIMD hide more than two tiles per wave at 2 waves/SIMD); the
     // single-sequence form below is the other way round (8k x 80 layers: 0.61 against 0.55; 32k x 80: 0.70 both)
-    static const int forced = [] { const char* e = getenv("SPECKV_FP8_BATCH_KERNEL"); return e ? (e[0] == 'd' ? 1 : 2) : 0; }();
-    const bool dma = (forced ? forced == 1 : false) && !a.stripe_bases && !a.table_form;
-    if (dma) hipLaunchKernelGGL(k_attend_fp8_dma, dim3(a.n_splits, n_seq * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
-    else if (a.table_form) hipLaunchKernelGGL((k_attend_fp8_linear<false, true>), dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
+    if (a.table_form) hipLaunchKernelGGL((k_attend_fp8_linear<false, true>), dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
     else if (a.stripe_bases) hipLaunchKernelGGL(k_attend_fp8_linear<true>, dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
     else     hipLaunchKernelGGL(k_attend_fp8_linear<false>, dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();

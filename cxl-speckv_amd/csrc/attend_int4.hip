@@ -908,7 +908,7 @@ hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_
     if (a.table_form) { hipLaunchKernelGGL((k_attend_int4_wg<false, true>), wg_grid, dim3(256), 0, s, a); return hipGetLastError(); }
     if (a.wg8 && a.lin_base && a.heads == 8u) {                          // whole records per workgroup: one workgroup per (layer | sequence, split)
         const dim3 grid8 = a.stream.n_wgs ? dim3(a.stream.n_wgs) : a.rows_first ? dim3(n_layers, a.n_splits) : dim3(a.n_splits, n_layers);
-        if (a.stream.n_wgs || a.wg8 == 2u || getenv("SPECKV_INT4_W8_ONE_HALF")) hipLaunchKernelGGL(k_attend_int4_wg8<1>, grid8, dim3(512), 0, s, a);
+        if (a.stream.n_wgs || a.wg8 == 2u) hipLaunchKernelGGL(k_attend_int4_wg8<1>, grid8, dim3(512), 0, s, a);
         else hipLaunchKernelGGL(k_attend_int4_wg8<2>, grid8, dim3(1024), 0, s, a);
         return hipGetLastError();
     }

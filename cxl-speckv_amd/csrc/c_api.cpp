@@ -7,6 +7,7 @@
 // the public headers are the export list: everything declared in them gets default visibility, the rest of the
 // library is built with -fvisibility=hidden
 #pragma GCC visibility push(default)
+#include "tuning.hpp"
 #include "../../include/speckv.h"
 #include "../../include/speckv_ext.h"
 #pragma GCC visibility pop
@@ -580,6 +581,12 @@ speckv_status_t speckv_ext_stats(speckv_ext_stats_t* out)
 }
 
 uint32_t speckv_ext_abi_version(void) { return SPECKV_EXT_ABI_VERSION; }
+
+speckv_status_t speckv_ext_set_tuning(const char* key, long long value)
+{
+    LOCK;
+    return speckv::tuning_set(key, value) == 0 ? SPECKV_OK : SPECKV_ERR_INVAL;
+}
 
 speckv_status_t speckv_ext_stats_sized(void* out, size_t out_size, size_t* written)
 {

@@ -1,5 +1,6 @@
 // cxl-speckv_amd/csrc/engine.cpp -- see engine.hpp
 #include "engine_internal.hpp"
+#include "tuning.hpp"
 
 namespace speckv {
 
@@ -89,6 +90,11 @@ int Engine::init_hip(int device)
     const size_t l2_mb = env_mb("SPECKV_L2_MB", 256), l1_mb = env_mb("SPECKV_L1_MB", 256);
     if (const char* e = getenv("SPECKV_RING_SEQ_LIMIT")) ring_seq_limit_ = static_cast<uint32_t>(strtoul(e, nullptr, 0));   // tests
     if (const char* e = getenv("SPECKV_FLUSH_HOST_WORDS")) flush_words_mode_ = e[0] == 's' ? 1 : 2;                          // scatter / fetch (tests, A/B)
+    // the remaining switches of this file, read here once (nothing behind an entry point walks the environment)
+    dbg_unordered_scratch_ = getenv("SPECKV_DEBUG_UNORDERED_SCRATCH") != nullptr;        // test hook: shows that the ordering test can fail
+    access_spin_ok_ = getenv("SPECKV_ACCESS_NO_SPIN") == nullptr;
+    if (const char* e = getenv("SPECKV_LAYOUT")) default_layout_ = parse_int_list(e);     // T,L,H,D,bpe for callers of the reference's 8 functions
+    (void)tuning();                                                                       // (and the launch-form switches: tuning.hpp)
     n_l2_ = static_cast<uint32_t>((l2_mb << 20) / kPageSize);
     n_l1_ = static_cast<uint32_t>((l1_mb << 20) / kPageSize);
     if (n_l2_ < 64) n_l2_ = 64;
@@ -207,7 +213,7 @@ void* Engine::scratch(Scratch& s, size_t bytes, hipStream_t user)
 {
     const bool capturing = is_capturing(user);
     hipStream_t now = user ? user : stream_;
-    static const bool unordered = getenv("SPECKV_DEBUG_UNORDERED_SCRATCH") != nullptr;      // test hook: shows that the test can fail
+    const bool unordered = dbg_unordered_scratch_;
     if (s.last && s.last != now && s.p && !capturing && !unordered && !is_capturing(s.last)) {
         if (hipEvent_t ev = get_event()) {
             if (hipEventRecord(ev, s.last) != hipSuccess || hipStreamWaitEvent(now, ev, 0) != hipSuccess) {
@@ -436,8 +442,8 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
     allocs_[a->handle] = std::move(a);
     // SPECKV_LAYOUT=T,L,H,D,bpe: geometry for callers that only speak the reference's 8 functions (its
     // allocate() sends none, vllm_speckv_backend.py:26-43); applied when the size matches
-    if (const char* env = getenv("SPECKV_LAYOUT")) {
-        const std::vector<int> g = parse_int_list(env);
+    {
+        const std::vector<int>& g = default_layout_;
         if (g.size() == 5 && g[0] > 0 && g[1] > 0 && g[2] > 0 && g[3] > 0 && g[4] > 0 &&
             2ull * g[0] * g[1] * g[2] * g[3] * g[4] == bytes)
             (void)set_layout(raw->handle, g[0], g[1], g[2], g[3], g[4]);
@@ -860,7 +866,7 @@ int Engine::fetch_into_ring(Allocation* a, const std::vector<uint32_t>& pages, u
     // A miss of a page or a few: the kernel's last wave stores a token to a pinned host word and the host spins on it -- the
     // runtime's own completion path costs 4 us more for a launch this short (DESIGN.md sect. 5).  A spin that runs out
     // (a preempted GPU, a debugger) falls back to it.
-    static const bool spin_ok = getenv("SPECKV_ACCESS_NO_SPIN") == nullptr;
+    const bool spin_ok = access_spin_ok_;
     const bool spin = spin_ok && n <= 8u && h_done_dev_ && d_done_count_;
     if (spin) {
         c.done_flag = h_done_dev_;

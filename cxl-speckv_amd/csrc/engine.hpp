@@ -195,6 +195,8 @@ private:
     bool null_ = false;
     int device_ = 0;
     uint32_t n_cus_ = 0;
+    bool dbg_unordered_scratch_ = false, access_spin_ok_ = true;      // SPECKV_DEBUG_UNORDERED_SCRATCH / SPECKV_ACCESS_NO_SPIN, read at open
+    std::vector<int> default_layout_;                                 // SPECKV_LAYOUT, read at open
     std::unique_lock<std::mutex>* lk_ = nullptr;
     uint32_t waiting_ = 0;                 // threads inside wait_event with the ABI lock released
     std::condition_variable idle_cv_;

@@ -1,5 +1,6 @@
 // cxl-speckv_amd/csrc/engine_attend.cpp -- fused decode attention: launch planning for the FP8 / INT4 kernels, single sequences and batches (Engine members)
 #include "engine_internal.hpp"
+#include "tuning.hpp"
 
 namespace speckv {
 
@@ -29,7 +30,7 @@ int Engine::qk_scores_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, co
     hipStream_t st = s ? s : stream_;
     {   // linear form (records in one run, scale table, tile-aligned range inside the layer's region): direct loads
         const uint32_t n_tiles = (n_pages + 15u) / 16u;
-        const bool fits = pos_begin % 32u == 0u && a->d_scale_tab && a->linear_base && !getenv("SPECKV_ATTEND_GENERAL") &&
+        const bool fits = pos_begin % 32u == 0u && a->d_scale_tab && a->linear_base && !tuning().attend_general &&
                           static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
         if (fits) {
             AttendArgs k{};
@@ -39,7 +40,6 @@ int Engine::qk_scores_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, co
             k.heads = L.num_heads;
             k.g = g;
             k.tiles_per_split = 16;
-            if (const char* env = getenv("SPECKV_QK_TILES_PER_WAVE")) k.tiles_per_split = std::max(1, atoi(env));
             k.lin_base = a->linear_base;
             k.scale_tab = a->d_scale_tab;
             k.q16 = static_cast<const uint16_t*>(d_q_f16);
@@ -114,7 +114,7 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     // and the last (possibly ragged) 32-position tile must not read past the K / V region of its layer
     // (with the range aligned as above and num_tokens a multiple of 32 the tiles never leave the region)
     const bool fits = has_tab && static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
-    const char* general_env = getenv("SPECKV_ATTEND_GENERAL");
+    const bool general_env = tuning().attend_general != 0;
     const uint8_t* lin_base = (general_env || !fits) ? nullptr : a->linear_base;
     // regular striping over several pools: the same kernel with computed record addresses (no page-table chase)
     const bool striped = !lin_base && fits && a->stripe_n >= 2 && !general_env;
@@ -128,7 +128,7 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     // context, 4 at 8k, 8 at 32k), long multi-layer launches are bounded by `want` above
     const uint32_t min_tiles = std::min(8u, std::max(2u, n_tiles / 64u));
     want = std::min(want, std::max(1u, n_tiles / min_tiles));
-    if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));
+    if (tuning().attend_splits > 0) want = static_cast<uint32_t>(tuning().attend_splits);
     const EvenSplit es = even_split(n_tiles, std::max(1u, std::min(want, 2048u)));
     const uint32_t n_splits = es.n_splits, tiles_per_split = es.tiles_per_split;
     const size_t q_bytes = static_cast<size_t>(rows) * 16 * 128, qs_bytes = static_cast<size_t>(rows) * 16 * sizeof(float);
@@ -184,44 +184,38 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
 using UnequalSplit = UnequalFraction;
 static UnequalSplit int4_unequal_split(uint32_t n_seq, uint32_t hq, uint32_t tiles_max)
 {
-    if (getenv("SPECKV_ATTEND_TILES_PER_SPLIT") || getenv("SPECKV_ATTEND_WG_TARGET") || getenv("SPECKV_ATTEND_WHOLE_SEQUENCES")) return {false, 1.0};
-    UnequalSplit u = int4_unequal_fraction(n_seq * hq, tiles_max);
-    if (u.on) if (const char* env = getenv("SPECKV_ATTEND_UNEQUAL_A")) u.a = atof(env);
-    return u;
+    if (tuning().attend_tiles_per_split > 0) return {false, 1.0};          // (a forced split length: plain even splits)
+    return int4_unequal_fraction(n_seq * hq, tiles_max);
 }
 
 static uint32_t batch_tiles_per_split(bool fp8, uint32_t n_seq, uint32_t heads, uint64_t total_tiles, const AttendSeq* seqs,
                                       uint32_t uniform_tiles)
 {
-    if (const char* env = getenv("SPECKV_ATTEND_TILES_PER_SPLIT")) return std::max(1, atoi(env));
-    const char* target_env = getenv("SPECKV_ATTEND_WG_TARGET");                // (measurement runs: the plain workgroup target)
+    if (tuning().attend_tiles_per_split > 0) return static_cast<uint32_t>(tuning().attend_tiles_per_split);
     const uint32_t hq = heads / 4u;
-    if (fp8 && !target_env) {
+    if (fp8) {
         // FP8: the busiest-CU cost rule of ring_rule.hpp (48 sequences x 16k: 288 workgroups 0.50 of HBM peak, 192: 0.64,
         // 768: 0.71; 32 x 32k: 256 workgroups 0.79, 512: 0.76, 384: 0.63; 128 x 2k: unsplit 0.73, two splits 0.56)
         std::vector<uint32_t> tiles;
         if (seqs) { tiles.resize(n_seq); for (uint32_t i = 0; i < n_seq; ++i) tiles[i] = seqs[i].n_splits; }
-        const char* mc = getenv("SPECKV_FP8_MERGE_COST");                     // (measurement runs)
-        return fp8_batch_tiles_per_split(seqs ? tiles.data() : nullptr, n_seq, uniform_tiles, hq, 256u, mc ? static_cast<uint32_t>(atoi(mc)) : 8u);
+        return fp8_batch_tiles_per_split(seqs ? tiles.data() : nullptr, n_seq, uniform_tiles, hq, 256u, 8u);
     }
-    uint64_t wg_target = fp8 ? 512u : 768u;
-    if (target_env) wg_target = std::max(1, atoi(target_env));
+    const uint64_t wg_target = 768u;
     uint32_t tps = static_cast<uint32_t>(std::max<uint64_t>(8, (total_tiles * hq + wg_target - 1u) / wg_target));
-    if (!fp8) tps = (static_cast<uint64_t>(n_seq) * hq >= 384u) ? 256u : std::min(tps, 256u);   // enough columns: whole sequences
+    tps = (static_cast<uint64_t>(n_seq) * hq >= 384u) ? 256u : std::min(tps, 256u);   // enough columns: whole sequences
     return tps;
 }
 
 // INT4 batches on the whole-record kernel (k_attend_int4_wg8<2>: workgroups = sequences x splits, one 16-wave workgroup per
 // CU resident, its two halves merged in LDS): one round of resident workgroups when the batch is smaller than that, whole
 // sequences otherwise (a whole sequence is final: no partials, no merge launch); never under 32 tiles a split.
-static bool int4_batch_wg8() { static const bool on = !getenv("SPECKV_INT4_WG4"); return on; }
 // More sequences than CUs: workgroups of one run (8 waves, two resident per CU) -- a finishing workgroup's successor starts
 // under its neighbour's stream, where a second round of 16-wave workgroups would wait for the whole CU (512 x 1k 0.52 -> 0.54,
 // 1024 x 1k 0.56 -> 0.595: profiles/r04_batch_short.txt); AttendArgs::wg8 = 2.
 static uint32_t int4_wg8_form(uint32_t n_seq, uint32_t cus) { return n_seq > cus ? 2u : 1u; }
 static uint32_t int4_wg8_batch_tps(uint32_t n_seq, uint32_t tiles_max, uint32_t cus)
 {
-    if (const char* env = getenv("SPECKV_ATTEND_TILES_PER_SPLIT")) return std::max(1, atoi(env));      // (measurement runs)
+    if (tuning().attend_tiles_per_split > 0) return static_cast<uint32_t>(tuning().attend_tiles_per_split);      // (tests, measurement runs)
     const uint32_t resident = cus;                                        // 16-wave workgroups (two halves each), one per CU
     const uint32_t splits = std::max(1u, resident / std::max(1u, n_seq));
     return std::max(32u, (tiles_max + splits - 1u) / splits);
@@ -233,7 +227,7 @@ static uint32_t int4_wg8_batch_tps(uint32_t n_seq, uint32_t tiles_max, uint32_t 
 // sequence is final (no partials, no merge launch).
 static uint32_t mx4_batch_tps(uint32_t n_seq, uint32_t tiles_max, uint32_t cus)
 {
-    if (const char* env = getenv("SPECKV_ATTEND_TILES_PER_SPLIT")) return std::max(1, atoi(env));      // (measurement runs)
+    if (tuning().attend_tiles_per_split > 0) return static_cast<uint32_t>(tuning().attend_tiles_per_split);      // (tests, measurement runs)
     const uint32_t resident = cus;
     const uint32_t splits = std::max(1u, resident / std::max(1u, n_seq));
     return std::max(8u, (tiles_max + splits - 1u) / splits);
@@ -308,7 +302,7 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
         for (uint32_t i = 0; i < n_seq; ++i) seqs[i].lin_base = reinterpret_cast<const uint8_t*>(ents[i]);
     uint32_t tiles_max = 0;
     for (uint32_t i = 0; i < n_seq; ++i) tiles_max = std::max(tiles_max, seqs[i].n_splits);
-    const bool wg8 = !fp8 && !mx4 && !any_striped && !any_table && heads == 8u && int4_batch_wg8();
+    const bool wg8 = !fp8 && !mx4 && !any_striped && !any_table && heads == 8u && true;
     const uint32_t tps = mx4 ? mx4_batch_tps(n_seq, tiles_max, cus()) : wg8 ? int4_wg8_batch_tps(n_seq, tiles_max, cus()) : batch_tiles_per_split(fp8, n_seq, heads, total_tiles, seqs.data(), 0);
     const UnequalSplit unequal = (fp8 || mx4 || wg8) ? UnequalSplit{false, 1.0} : int4_unequal_split(n_seq, heads / 4u, tiles_max);
     uint32_t max_splits = 0;
@@ -402,7 +396,7 @@ static PlanGeometry plan_geometry(bool fp8, uint32_t n_seq, uint32_t heads, uint
         g.parts_bound = static_cast<uint64_t>(n_seq) * heads * g.max_splits;
         return g;
     }
-    if (!fp8 && heads == 8u && int4_batch_wg8()) {            // the whole-record kernel's geometry (a striped / table launch runs it on the 4-head kernels)
+    if (!fp8 && heads == 8u && true) {            // the whole-record kernel's geometry (a striped / table launch runs it on the 4-head kernels)
         g.unequal = UnequalSplit{false, 1.0};
         g.tps = int4_wg8_batch_tps(n_seq, tiles_max, cus);
         g.max_splits = std::max(1u, (tiles_max + g.tps - 1u) / g.tps);
@@ -530,7 +524,7 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
     k.scale_log2e = sm_scale * 1.4426950408889634f;
     if (plan->second.table) { k.table_form = 1u; k.zero_page = d_zero_page_; }           // a member without a regular placement: addresses from the page tables
     else if (plan->second.striped) k.stripe_bases = reinterpret_cast<const uint64_t*>(1);     // striped launch: every descriptor brings its table
-    else { k.lin_base = reinterpret_cast<const uint8_t*>(1); if (!fp8 && !mx4 && int4_batch_wg8()) k.wg8 = int4_wg8_form(n_seq, cus()); }     // non-null: linear form (the real base comes from the descriptor)
+    else { k.lin_base = reinterpret_cast<const uint8_t*>(1); if (!fp8 && !mx4 && true) k.wg8 = int4_wg8_form(n_seq, cus()); }     // non-null: linear form (the real base comes from the descriptor)
     k.seqs = static_cast<const AttendSeq*>(d_plan);
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
@@ -576,8 +570,7 @@ static bool int4_wg8_stream(uint32_t n_layers, uint32_t n_tiles, uint32_t cus, A
 {
     const uint64_t total = static_cast<uint64_t>(n_layers) * n_tiles;
     uint64_t wgs = 2ull * static_cast<uint64_t>(cus);
-    if (const char* env = getenv("SPECKV_INT4_STREAM_WGS")) wgs = std::max(1, atoi(env));
-    if (n_layers < 2 || total < 16u * wgs || getenv("SPECKV_INT4_NO_STREAM")) return false;
+    if (n_layers < 2 || total < 16u * wgs) return false;
     out->n_wgs = static_cast<uint32_t>(wgs);
     out->len = static_cast<uint32_t>(total / wgs);
     out->rem = static_cast<uint32_t>(total % wgs);
@@ -631,7 +624,7 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     // linear form: records in one local run and every 32-position tile inside the layer's K / V region; otherwise the
     // page-table form of the same kernel
     const bool fits = static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
-    const char* general_env = getenv("SPECKV_ATTEND_GENERAL");
+    const bool general_env = tuning().attend_general != 0;
     const bool linear = a->linear_base && fits && !general_env;
     const bool striped = !linear && a->stripe_n >= 2 && fits && !general_env;
     // everything else -- no regular placement, a last tile that would leave the region, SPECKV_ATTEND_GENERAL (measurements,
@@ -653,14 +646,15 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     // to each other (measured at 32k x 80 layers: 8 splits 0.598, 10 or 12 splits 0.56, 16 splits 0.595)
     if (want > 8u) want &= ~7u;
     // whole-record kernel (8 waves = 8 heads, one workgroup per CU): workgroups = splits x layers, in whole rounds of the CUs
-    const bool wg8 = linear && L.num_heads == 8 && !getenv("SPECKV_INT4_WG4");
+    const bool wg8 = linear && L.num_heads == 8;
     if (wg8) want = int4_wg8_splits(n_layers, n_tiles, cus());
-    if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));
+    const bool forced_splits = tuning().attend_splits > 0;
+    if (forced_splits) want = static_cast<uint32_t>(tuning().attend_splits);
     EvenSplit es = even_split(n_tiles, std::max(1u, std::min(want, 2048u)));
-    if (!wg8 && es.n_splits > 8u && (es.n_splits & 7u) && !getenv("SPECKV_ATTEND_SPLITS"))      // the rounding can fall off a multiple of 8
+    if (!wg8 && es.n_splits > 8u && (es.n_splits & 7u) && !forced_splits)      // the rounding can fall off a multiple of 8
         es = even_split(n_tiles, es.n_splits & ~7u);
     AttendArgs k{};
-    const bool stream = wg8 && !getenv("SPECKV_ATTEND_SPLITS") && int4_wg8_stream(n_layers, n_tiles, cus(), &k.stream);
+    const bool stream = wg8 && !forced_splits && int4_wg8_stream(n_layers, n_tiles, cus(), &k.stream);
     const uint32_t n_splits = stream ? k.stream.max_slots : es.n_splits, tiles_per_split = es.tiles_per_split;      // (stream: slots per row)
     const size_t acc_bytes = static_cast<size_t>(rows) * n_splits * 16 * 128 * sizeof(float);
     const size_t ml_bytes = static_cast<size_t>(rows) * n_splits * 32 * sizeof(float);
@@ -730,7 +724,7 @@ int Engine::attend_mx4(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     // arithmetic addresses need every 32-position tile inside the layer's K / V region (the last one may be ragged); otherwise,
     // or without a regular placement, the page-table form: its look-ups are clamped to the range
     const bool fits = static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
-    const char* general_env = getenv("SPECKV_ATTEND_GENERAL");
+    const bool general_env = tuning().attend_general != 0;
     const bool linear = a->linear_base && fits && !general_env;
     const bool striped = !linear && a->stripe_n >= 2 && fits && !general_env;
     const bool table = !linear && !striped;
@@ -746,7 +740,7 @@ int Engine::attend_mx4(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     uint32_t want = std::max(1u, cus() / columns);
     const uint32_t min_tiles = std::min(8u, std::max(2u, n_tiles / 64u));      // per-layer calls: see attend_fp8
     want = std::min(want, std::max(1u, n_tiles / min_tiles));
-    if (const char* env = getenv("SPECKV_ATTEND_SPLITS")) want = static_cast<uint32_t>(atoi(env));
+    if (tuning().attend_splits > 0) want = static_cast<uint32_t>(tuning().attend_splits);
     const EvenSplit es = even_split(n_tiles, std::max(1u, std::min(want, 2048u)));
     const uint32_t n_splits = es.n_splits, tiles_per_split = es.tiles_per_split;
     const size_t acc_bytes = static_cast<size_t>(rows) * n_splits * 16 * 128 * sizeof(float);

@@ -168,7 +168,7 @@ int Engine::prefetch_flush(uint32_t* n_issued)
     DeviceScope device_scope(device_);
     RC_TRY(renumber_ring_if_due());
     in_flush_ = true;
-    static const bool timing = getenv("SPECKV_TIMING") != nullptr;
+    const bool timing = g_verbose;                     // (SPECKV_LOG=1)
     const auto t_a = std::chrono::steady_clock::now();
     if (!q_unresolved_.empty()) {          // requests that arrived before any geometry was known
         Allocation* dflt = default_target();
@@ -240,8 +240,6 @@ int Engine::prefetch_flush(uint32_t* n_issued)
 // `staged` is pinned (hipHostMalloc) and padded to a multiple of 16 bytes, as is `dst`.
 hipError_t Engine::upload_pinned(void* dst, const void* staged, size_t bytes, hipStream_t s)
 {
-    static const bool by_kernel = [] { const char* e = getenv("SPECKV_FLUSH_UPLOAD"); return !(e && e[0] == 'c'); }();
-    if (!by_kernel) return hipMemcpyAsync(dst, staged, bytes, hipMemcpyHostToDevice, s);
     void* staged_dev = nullptr;
     const hipError_t e = hipHostGetDevicePointer(&staged_dev, const_cast<void*>(staged), 0);
     if (e != hipSuccess) return e;

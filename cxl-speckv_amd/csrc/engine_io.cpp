@@ -1,5 +1,6 @@
 // cxl-speckv_amd/csrc/engine_io.cpp -- the data path: writes (compress into the pool), reads, bulk fetch + decompress (Engine members)
 #include "engine_internal.hpp"
+#include "tuning.hpp"
 
 namespace speckv {
 
@@ -404,17 +405,13 @@ int Engine::fetch_range(uint64_t handle, uint64_t first, uint64_t n, void* d_dst
     // decompresses in registers) or the copy engines (SDMA runs into local staging, then a local decompress).
     // Per batch: long runs on remote pools go to the copy engines, short ones to the kernel; 1 / 2 force a choice
     // (SPECKV_REMOTE_ENGINE=kernel|copy overrides "auto").
-    static const int env_choice = [] {
-        const char* e = getenv("SPECKV_REMOTE_ENGINE");
-        return !e ? 0 : !strcmp(e, "kernel") ? 1 : !strcmp(e, "copy") ? 2 : 0;
-    }();
-    int choice = engine_choice ? engine_choice : env_choice;
+    int choice = engine_choice ? engine_choice : tuning().remote_engine;
     const uint32_t D = static_cast<uint32_t>(a->pool_of_residue.size());
     const bool can_copy = (a->regular || (a->packed && a->packed_regular)) && D >= 1 && D <= 8 && a->n_pages < (1ull << 28) && !is_capturing(st);
     if (choice == 0) {
         bool remote = false;
         for (int p : a->pool_of_residue) remote = remote || pools_[p]->device() != device_;
-        static const uint64_t min_run = env_mb("SPECKV_COPY_MIN_RUN_KB", 1024) << 10;
+        const uint64_t min_run = static_cast<uint64_t>(tuning().copy_min_run_kb > 0 ? tuning().copy_min_run_kb : 1024) << 10;
         choice = (remote && can_copy && (n / D) * a->rec_stride >= min_run) ? 2 : 1;
     }
     if (choice == 2 && !can_copy) {

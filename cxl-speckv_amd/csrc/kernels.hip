@@ -20,6 +20,7 @@
 // Scans are DPP (row_shr / row_bcast) inside the wave; there is no workgroup
 // barrier anywhere, so wavefronts never wait for each other.
 #include "kernels.hpp"
+#include "tuning.hpp"
 #include "ring_rule.hpp"
 #include "codec_device.hpp"
 #include "encode_device.hpp"
@@ -2366,11 +2367,7 @@ int num_cus()
 // peak; balanced 0.77-0.80.  Measured with profiles/tools/footprint.py, profiles/r02_footprint.md.)
 uint32_t codec_grid(uint64_t n, uint64_t* per_wave)
 {
-    static int per_cu = [] {
-        const char* e = getenv("SPECKV_WGS_PER_CU");
-        int v = e ? atoi(e) : 256;
-        return v > 0 ? v : 256;
-    }();
+    const int per_cu = tuning().wgs_per_cu > 0 ? tuning().wgs_per_cu : 256;
     const uint64_t want = (n + kWaves - 1) / kWaves;
     const uint64_t cap = static_cast<uint64_t>(num_cus()) * per_cu * (4 / kWaves);
     *per_wave = 1;
@@ -2384,8 +2381,7 @@ uint32_t codec_grid(uint64_t n, uint64_t* per_wave)
 // 0.775 / 0.772 / 0.770 of HBM peak vs 0.753 / 0.69 / 0.657 at 4 / 5 / 20 GiB of pool + destination.
 bool round_strided()
 {
-    static const bool v = [] { const char* e = getenv("SPECKV_ROUNDS"); return !(e && !strcmp(e, "consecutive")); }();
-    return v;
+    return tuning().rounds_consecutive == 0;
 }
 
 template <int SCHEME, int MODE>
@@ -2499,10 +2495,9 @@ hipError_t launch_flush_pipeline(const FlushArgs& a, hipStream_t s)
     if (a.n == 0 || a.W == 0) return hipErrorInvalidValue;
     const uint64_t total = static_cast<uint64_t>(a.n) * 32u * a.W;
     if (total >= (1ull << 24)) return hipErrorInvalidValue;        // the dedupe key carries 24 index bits
-    // (A/B and test switches, read at every flush: the four-launch pipeline for every size / another limit for the one-workgroup form)
-    const bool no_small = getenv("SPECKV_FLUSH_NO_SMALL") != nullptr;
-    const char* sw = getenv("SPECKV_FLUSH_SMALL_WORDS");
-    const uint64_t small_words = sw ? std::min<uint64_t>(strtoull(sw, nullptr, 10), kFlushSmallWords) : kFlushSmallDefault;
+    // (test switches, tuning.hpp: the four-launch pipeline for every size / another limit for the one-workgroup form)
+    const bool no_small = tuning().flush_no_small != 0;
+    const uint64_t small_words = tuning().flush_small_words > 0 ? std::min<uint64_t>(static_cast<uint64_t>(tuning().flush_small_words), kFlushSmallWords) : kFlushSmallDefault;
     if (total <= small_words && !no_small) {
         hipLaunchKernelGGL(k_flush_small, dim3(1), dim3(1024), 0, s, a);
         return hipGetLastError();
@@ -2579,7 +2574,7 @@ hipError_t launch_predict(uint32_t n, const int32_t* d_hist, const float* d_emb,
     if (n == 0) return hipSuccess;
     if (k == 0 || k > 8u || vocab < k) return hipErrorInvalidValue;
     const uint32_t small_parts = logits_tiles_padded(vocab) / 4u;       // workgroups of 128 rows
-    if (n <= kPredictSmallN && small_parts <= kPredictSmallMaxParts && !getenv("SPECKV_PREDICT_BATCH_PATH")) {
+    if (n <= kPredictSmallN && small_parts <= kPredictSmallMaxParts && !tuning().predict_batch_path) {
         // a handful of requests: two launches (three with the real cell), no logits in memory (k_predict_small)
         const bool real = lstm && lstm->layers;
         if (real) {

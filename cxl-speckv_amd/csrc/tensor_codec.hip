@@ -17,6 +17,7 @@
 // The multi-launch forms write whole 128-byte lines per wave (tile-local pair buffers, then an output-centric pack pass); the
 // one-pass kernels store whole aligned 16-byte pieces and single bytes / elements only at the two ragged ends of a tile's stretch.
 #include "kernels.hpp"
+#include "tuning.hpp"
 #include "codec_device.hpp"
 #include "encode_device.hpp"
 
@@ -1340,7 +1341,7 @@ __global__ __launch_bounds__(64 * kTfWaves) __attribute__((amdgpu_waves_per_eu(8
     bool fast = false, split = false;
     uint32_t own_runs = 0;                                              // run starts at or behind the tile's first stretch start
     const bool tile_fast_ok = len == kTile && ((reinterpret_cast<uintptr_t>(src) + (F32 ? 4ull : 2ull) * t0) & 15u) == 0u && !kTcNoFast;
-    const bool getenv_no_split = no_split != 0u;                        // (SPECKV_TC_NO_SPLIT_TILES: the element-wise loop for long stretches, A/B and tests)
+    const bool getenv_no_split = no_split != 0u;                        // (tuning.hpp tc_no_split_tiles: the element-wise loop for long stretches, tests)
     if (valid) {
         if (tile_fast_ok) {
             uint32_t f_first = 0, f_last = 0, f_n = 0;
@@ -2148,7 +2149,8 @@ hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, u
     uint8_t* scratch = w;
     // single pass (k_tc_fused) unless a multi-launch form is asked for (SPECKV_TC_MULTIPASS, or one of the scan / pre-emit
     // switches of the tests): its status words and ticket sit where the summaries of the multi-launch form would be
-    const bool fused = n != 0 && !getenv("SPECKV_TC_MULTIPASS") && !getenv("SPECKV_TC_SCAN") && !getenv("SPECKV_TC_SERIAL_SCAN") && !getenv("SPECKV_TC_NO_PRE");
+    const Tuning& tn = tuning();
+    const bool fused = n != 0 && !tn.tc_multipass && !tn.tc_scan && !tn.tc_no_pre;
     const uint64_t tf_wgs = (tiles + kTfWaves - 1) / kTfWaves;
     hipError_t e = hipMemsetAsync(absmax, 0, fused ? 512 + 16 * tf_wgs : 256, s);
     if (e != hipSuccess) return e;
@@ -2162,7 +2164,7 @@ hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, u
         uint64_t* w1 = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(d_ws) + 512);
         uint64_t* w2 = w1 + tf_wgs;
         const uint32_t g = static_cast<uint32_t>(tf_wgs);
-        const uint32_t no_split = getenv("SPECKV_TC_NO_SPLIT_TILES") ? 1u : 0u;
+        const uint32_t no_split = tn.tc_no_split_tiles ? 1u : 0u;
 #define SPECKV_TF(MODE, F32) hipLaunchKernelGGL((k_tc_fused<MODE, F32>), dim3(g), dim3(64 * kTfWaves), 0, s, d_src, n, absmax, tiles, w1, w2, ticket, d_rle, d_scale, d_rle_bytes, no_split)
         if (quant_mode == kIntent) { if (src_f32) SPECKV_TF(kIntent, true); else SPECKV_TF(kIntent, false); }
         else                       { if (src_f32) SPECKV_TF(kRefExact, true); else SPECKV_TF(kRefExact, false); }
@@ -2172,9 +2174,8 @@ hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, u
     const uint32_t tg = static_cast<uint32_t>((tiles + kTcWaves - 1) / kTcWaves);
     // fp16 sources: the summary pass emits the tiles its fast path takes (k_tc_tiles, PRE); the flags live behind the step
     // arrays of the three-grid scan, so only with that scan (SPECKV_TC_NO_PRE=1: the two plain passes, A/B and test switch)
-    const char* scan_env0 = getenv("SPECKV_TC_SCAN");
-    const bool grids = tiles >= 64 && !scan_env0 && !getenv("SPECKV_TC_SERIAL_SCAN");
-    const bool pre = grids && !src_f32 && !kTcNoFast && !getenv("SPECKV_TC_NO_PRE");
+    const bool grids = tiles >= 64 && !tn.tc_scan;
+    const bool pre = grids && !src_f32 && !kTcNoFast && !tn.tc_no_pre;
     uint8_t* pre_flags = pre ? reinterpret_cast<uint8_t*>(first_run + 3 * ((tiles + 63) / 64)) : nullptr;
 #define SPECKV_TC(MODE, F32, EMIT) hipLaunchKernelGGL((k_tc_tiles<MODE, F32, EMIT>), dim3(tg), dim3(64 * kTcWaves), 0, s, d_src, n, absmax, summ, carry, scratch, pre_flags)
 #define SPECKV_TC2(EMIT) do { if (quant_mode == kIntent) { if (src_f32) SPECKV_TC(kIntent, true, EMIT); else SPECKV_TC(kIntent, false, EMIT); } \
@@ -2185,10 +2186,9 @@ hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, u
     } else if (tiles) SPECKV_TC2(false);
     {
         const uint64_t n_steps = (tiles + 63) / 64;
-        const char* scan_env = getenv("SPECKV_TC_SCAN");            // (A/B and test switch: wg = one workgroup, serial = one wave)
-        if (tiles < 64 || (scan_env && !strcmp(scan_env, "serial")) || getenv("SPECKV_TC_SERIAL_SCAN"))
+        if (tiles < 64 || tn.tc_scan == 2)            // (tuning.hpp tc_scan: 1 = one workgroup, 2 = one wave)
             hipLaunchKernelGGL(k_tc_scan, dim3(1), dim3(64), 0, s, summ, carry, tiles, n, absmax, d_scale, d_rle_bytes, first_run);
-        else if (scan_env && !strcmp(scan_env, "wg") && n_steps <= kScanMaxSteps)
+        else if (tn.tc_scan == 1 && n_steps <= kScanMaxSteps)
             hipLaunchKernelGGL(k_tc_scan_wg, dim3(1), dim3(64 * kScanWaves), 0, s, summ, carry, tiles, n, absmax, d_scale, d_rle_bytes);
         else {
             // the step arrays live where the one-wave scan keeps its first-run starts (tiles x 8 bytes >= 3 x n_steps x 8)
@@ -2230,7 +2230,8 @@ hipError_t launch_tensor_decompress(const uint8_t* d_rle, uint64_t rle_bytes, fl
     // runs (profiles/r04_long_runs.txt).  So: one pass only for streams that are practically incompressible (at most 1.02 elements
     // per pair), by output otherwise.  SPECKV_TC_MULTIPASS=1 / SPECKV_TD_ONE_PASS=1 force a form (tests, A/B).
     const bool few_pairs = n_pairs * 51u < std::min<uint64_t>(dst_cap, n_pairs * 255u) * 50u;
-    if (chunks && dst_cap && !getenv("SPECKV_TC_MULTIPASS") && (!few_pairs || getenv("SPECKV_TD_ONE_PASS"))) {
+    const Tuning& tn = tuning();
+    if (chunks && dst_cap && !tn.tc_multipass && (!few_pairs || tn.td_one_pass)) {
         // single pass: a memset node (ticket, element count, one status word per workgroup), then ONE kernel
         const uint64_t wgs = (chunks + kTdfChunks - 1) / kTdfChunks;
         uint32_t* ticket = reinterpret_cast<uint32_t*>(d_ws);
@@ -2246,10 +2247,9 @@ hipError_t launch_tensor_decompress(const uint8_t* d_rle, uint64_t rle_bytes, fl
     }
     if (chunks) hipLaunchKernelGGL(k_td_summary, dim3(static_cast<uint32_t>((chunks + 3) / 4)), dim3(256), 0, s, d_rle, n_pairs, summ);
     const uint64_t n_steps = (chunks + 63) / 64;
-    const char* scan_env = getenv("SPECKV_TC_SCAN");                // (A/B and test switch: wg = one workgroup, serial = one wave)
-    if (chunks == 0 || (scan_env && !strcmp(scan_env, "serial")) || getenv("SPECKV_TC_SERIAL_SCAN"))
+    if (chunks == 0 || tn.tc_scan == 2)
         hipLaunchKernelGGL(k_td_scan, dim3(1), dim3(64), 0, s, summ, carry, chunks, dst_cap, n_out);
-    else if (scan_env && !strcmp(scan_env, "wg") && n_steps <= kScanMaxSteps)
+    else if (tn.tc_scan == 1 && n_steps <= kScanMaxSteps)
         hipLaunchKernelGGL(k_td_scan_wg, dim3(1), dim3(64 * kScanWaves), 0, s, summ, carry, chunks, dst_cap, n_out);
     else {
         TdStepTotal* step_tot = reinterpret_cast<TdStepTotal*>(w + 256);
@@ -2261,7 +2261,7 @@ hipError_t launch_tensor_decompress(const uint8_t* d_rle, uint64_t rle_bytes, fl
         // grid: the output can hold at most min(dst_cap, 255 * n_pairs) elements; waves behind the stream's total return at once
         const uint64_t max_out = std::min<uint64_t>(dst_cap, n_pairs * 255u);
         const uint32_t g = static_cast<uint32_t>(((max_out + kTile - 1) / kTile + 3) / 4);
-        const bool old_expand = getenv("SPECKV_TD_EXPAND_PER_ELEMENT") != nullptr;             // (A/B, tests: the expand loop of rounds 2-3; read at every call)
+        const bool old_expand = tn.td_expand_per_element != 0;             // (tests: the expand loop of rounds 2-3)
 #define SPECKV_TD(MODE, F32) do { if (old_expand) hipLaunchKernelGGL((k_td_expand<MODE, F32>), dim3(g), dim3(256), 0, s, d_rle, n_pairs, carry, chunks, n_out, scale, static_cast<uint8_t*>(d_dst)); \
                                   else hipLaunchKernelGGL((k_td_expand_scatter<MODE, F32>), dim3(g), dim3(256), 0, s, d_rle, n_pairs, carry, chunks, n_out, scale, static_cast<uint8_t*>(d_dst)); } while (0)
         if (quant_mode == kIntent) { if (out_f32) SPECKV_TD(kIntent, true); else SPECKV_TD(kIntent, false); }

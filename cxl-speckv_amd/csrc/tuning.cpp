@@ -1,0 +1,62 @@
+// cxl-speckv_amd/csrc/tuning.cpp -- see tuning.hpp
+#include "tuning.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace speckv {
+
+namespace {
+struct Key { const char* name; const char* env; int32_t Tuning::* field; };
+const Key kKeys[] = {
+    {"attend_splits", "SPECKV_ATTEND_SPLITS", &Tuning::attend_splits},
+    {"attend_tiles_per_split", "SPECKV_ATTEND_TILES_PER_SPLIT", &Tuning::attend_tiles_per_split},
+    {"attend_general", "SPECKV_ATTEND_GENERAL", &Tuning::attend_general},
+    {"tc_multipass", "SPECKV_TC_MULTIPASS", &Tuning::tc_multipass},
+    {"tc_scan", "SPECKV_TC_SCAN", &Tuning::tc_scan},
+    {"tc_no_pre", "SPECKV_TC_NO_PRE", &Tuning::tc_no_pre},
+    {"tc_no_split_tiles", "SPECKV_TC_NO_SPLIT_TILES", &Tuning::tc_no_split_tiles},
+    {"td_one_pass", "SPECKV_TD_ONE_PASS", &Tuning::td_one_pass},
+    {"td_expand_per_element", "SPECKV_TD_EXPAND_PER_ELEMENT", &Tuning::td_expand_per_element},
+    {"flush_no_small", "SPECKV_FLUSH_NO_SMALL", &Tuning::flush_no_small},
+    {"flush_small_words", "SPECKV_FLUSH_SMALL_WORDS", &Tuning::flush_small_words},
+    {"predict_batch_path", "SPECKV_PREDICT_BATCH_PATH", &Tuning::predict_batch_path},
+    {"wgs_per_cu", "SPECKV_WGS_PER_CU", &Tuning::wgs_per_cu},
+    {"rounds_consecutive", "SPECKV_ROUNDS", &Tuning::rounds_consecutive},
+    {"remote_engine", "SPECKV_REMOTE_ENGINE", &Tuning::remote_engine},
+    {"copy_min_run_kb", "SPECKV_COPY_MIN_RUN_KB", &Tuning::copy_min_run_kb},
+};
+// a few of the environment's values are words, as they always were
+int32_t parse(const char* env_name, const char* v)
+{
+    if (!strcmp(env_name, "SPECKV_TC_SCAN")) return !strcmp(v, "wg") ? 1 : !strcmp(v, "serial") ? 2 : atoi(v);
+    if (!strcmp(env_name, "SPECKV_REMOTE_ENGINE")) return !strcmp(v, "kernel") ? 1 : !strcmp(v, "copy") ? 2 : atoi(v);
+    if (!strcmp(env_name, "SPECKV_ROUNDS")) return !strcmp(v, "consecutive") ? 1 : atoi(v);
+    if (!*v) return 1;                                   // set but empty: "on"
+    const int32_t n = static_cast<int32_t>(atoi(v));
+    return (n == 0 && v[0] != '0') ? 1 : n;              // a non-numeric word: "on"
+}
+Tuning g_tuning;
+std::once_flag g_once;
+} // namespace
+
+Tuning& tuning()
+{
+    std::call_once(g_once, [] {
+        for (const Key& k : kKeys)
+            if (const char* v = getenv(k.env)) g_tuning.*(k.field) = parse(k.env, v);
+    });
+    return g_tuning;
+}
+
+int tuning_set(const char* key, long long value)
+{
+    if (!key) return -1;
+    Tuning& t = tuning();
+    for (const Key& k : kKeys)
+        if (!strcmp(k.name, key)) { t.*(k.field) = static_cast<int32_t>(value); return 0; }
+    return -1;
+}
+
+} // namespace speckv

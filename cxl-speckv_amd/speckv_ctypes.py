@@ -414,6 +414,13 @@ class SpeckvLib:
         self._ext("speckv_ext_attend_mx4_batch", n, hs, layer, c_void_p(d_q_f16), g, pe, ctypes.c_float(sm_scale),
                   c_void_p(d_out), c_void_p(d_lse or 0), c_void_p(stream or 0))
 
+    def set_tuning(self, key, value):
+        """A launch-form switch of the library (speckv_ext_set_tuning: the environment is read once per process)."""
+        self.lib.speckv_ext_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
+        self.lib.speckv_ext_set_tuning.restype = ctypes.c_int
+        if self.lib.speckv_ext_set_tuning(key.encode(), int(value)) != 0:
+            raise ValueError(f"speckv_ext_set_tuning: no such key {key!r}")
+
     def promote_to_l1(self, handle, offset):
         return self.lib.speckv_ext_promote_to_l1(handle, offset) == 0
 

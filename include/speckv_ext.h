@@ -491,6 +491,14 @@ double speckv_ext_layer_compression_ratio(uint32_t layer_id);
 /* width/8 * MHz/1000 * engines (cache_engine.cpp:291-296): 51.2 for the reference's defaults */
 double speckv_ext_codec_model_throughput_gbps(uint32_t num_engines, double clock_mhz, uint32_t data_width_bits);
 
+/* Launch-form switches (tests, measurement runs): the library reads its environment ONCE, at the first speckv_init / raw codec
+ * call of the process; after that a form is changed by this call only.  Keys (= the SPECKV_<KEY> environment names, lower case):
+ * attend_splits, attend_tiles_per_split, attend_general, tc_multipass, tc_scan (1 one workgroup, 2 one wave), tc_no_pre,
+ * tc_no_split_tiles, td_one_pass, td_expand_per_element, flush_no_small, flush_small_words, predict_batch_path, wgs_per_cu,
+ * rounds_consecutive, remote_engine (1 kernel, 2 copy engines), copy_min_run_kb.  0 restores the library's own rule.
+ * SPECKV_ERR_INVAL for an unknown key.  Works without speckv_init.  (INTEGRATION.md lists what each one does.) */
+speckv_status_t speckv_ext_set_tuning(const char* key, long long value);
+
 /* library identity: "hip" when built with the HIP data path */
 const char* speckv_ext_backend(void);
 

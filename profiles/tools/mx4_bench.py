@@ -11,14 +11,14 @@ kv = pkg.CxlSpeckvKVAllocator(os.environ.get("SPECKV_LIB_PATH", pkg.library_path
 tag = os.environ.get("TAG", "base")
 if what in ("single", "both"):
     for splits in os.environ.get("SPLITS", "0").split(","):
-        if splits != "0": os.environ["SPECKV_ATTEND_SPLITS"] = splits
+        bench.set_tuning("attend_splits", int(splits))
         r = bench.int4_attention_extra(torch, kv, 32768, 80, scheme=5)["mxfp4_fused_attention"]
-        os.environ.pop("SPECKV_ATTEND_SPLITS", None)
+        bench.set_tuning("attend_splits", 0)
         print(tag, "single 32k x 80 splits", splits, r.get("ms_all_layers"), r.get("frac_hbm"), r.get("error"), flush=True)
 if what in ("batch", "both"):
     for tps in os.environ.get("TPS", "0").split(","):
-        if tps != "0": os.environ["SPECKV_ATTEND_TILES_PER_SPLIT"] = tps
+        bench.set_tuning("attend_tiles_per_split", int(tps))
         r = bench.batch_attention_extra(torch, kv, n_seq=n_seq, T=T, scheme=5)["mxfp4_attention_batch_decode_step"]
-        os.environ.pop("SPECKV_ATTEND_TILES_PER_SPLIT", None)
+        bench.set_tuning("attend_tiles_per_split", 0)
         print(tag, f"batch {n_seq} x {T} tps", tps, r.get("ms_per_layer"), r.get("frac_hbm"), r.get("error"), flush=True)
 kv.close()

@@ -30,6 +30,19 @@ def load_debug_lib():
     return C.CDLL(os.path.join(root, "tests", "_build", "libspeckv_debug.so"))
 
 
+_TUNE_WORDS = {"wg": 1, "serial": 2, "kernel": 1, "copy": 2}
+
+
+def set_tuning(key, value):
+    """speckv_ext_set_tuning: the library reads its environment once; tests that flip a launch form between two calls say so
+    through the C ABI (include/speckv_ext.h).  Words of the old environment values ("wg", "serial", ...) are accepted."""
+    lib = pkg.load_library()
+    lib.speckv_ext_set_tuning.argtypes = [C.c_char_p, C.c_longlong]
+    lib.speckv_ext_set_tuning.restype = C.c_int
+    rc = lib.speckv_ext_set_tuning(key.encode(), int(_TUNE_WORDS.get(value, value)))
+    assert rc == 0, (key, value, rc)
+
+
 def torch_mod():
     import torch
     assert torch.cuda.is_available(), "these tests need the MI355X"

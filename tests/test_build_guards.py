@@ -137,3 +137,23 @@ def test_table_form_int4_kernel_reads_its_page_table_entries_only_behind_their_w
         bad = _vregs(srcs) & set().union(*pending)
         assert not bad, f"{name}: `{ins}` reads v{sorted(bad)} while its entry load is in flight"
     assert loads >= 20, loads                              # the prologue's and the loop's entry loads were found
+
+
+def test_no_environment_walks_behind_the_entry_points():
+    """the library reads its environment at open / first use only.  getenv may appear in csrc/tuning.cpp (the
+    one-time table), csrc/engine_internal.hpp (helpers of Engine::open and the log switch, a static initialiser) and in
+    Engine::open / Engine::init_hip of csrc/engine.cpp -- nowhere behind speckv_ext_attend_*, fetch_range or the codec
+    operators: their translation units contain no getenv at all."""
+    csrc = os.path.join(ROOT, "cxl-speckv_amd", "csrc")
+    allowed = {"tuning.cpp", "engine_internal.hpp", "engine.cpp", "tuning.hpp"}
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith((".cpp", ".hip", ".hpp")) or fn in allowed:
+            continue
+        text = open(os.path.join(csrc, fn)).read()
+        assert not re.search(r"\bgetenv\s*\(", text), f"{fn} reads the environment"
+    # engine.cpp: only inside open() / init_hip() (everything in front of the first function that is neither)
+    text = open(os.path.join(csrc, "engine.cpp")).read()
+    end_of_open = text.index("int Engine::wait_event")
+    assert "getenv" not in text[end_of_open:], "engine.cpp reads the environment outside Engine::open / Engine::init_hip"
+    # the header documents the entry point tests use instead
+    assert "speckv_ext_set_tuning" in open(os.path.join(ROOT, "include", "speckv_ext.h")).read()

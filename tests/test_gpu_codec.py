@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from tests._gpu import N, assert_same_float_bits, gpu_compress, gpu_decompress, load_debug_lib, load_raw_lib, stream_ptr, torch_mod
+from tests._gpu import N, assert_same_float_bits, gpu_compress, gpu_decompress, load_debug_lib, load_raw_lib, stream_ptr, torch_mod, set_tuning
 
 pytestmark = pytest.mark.gpu
 
@@ -591,23 +591,23 @@ def test_tensor_codec_golden_reference_vectors(lib, golden_dir):
 @pytest.mark.parametrize("form", ["single_pass", "no_split_tiles", "one_pass_decoder", "grids", "per_element_expand", "wg", "serial", "no_pre"])
 def test_tensor_codec_scan_forms(lib, oracle, form):
     """Compress exists as ONE pass with look-back across workgroups (k_tc_fused, the default since round 4) and as the
-    multi-launch form (SPECKV_TC_MULTIPASS) whose scans across tiles come in three shapes -- grids of one wave per step, one
-    workgroup, one wave (SPECKV_TC_SCAN, read at every call; fp16 sources: with and without the summary pass emitting,
-    SPECKV_TC_NO_PRE) -- which must all produce the oracle's stream and output: noise with long flat stretches (runs,
+    multi-launch form (speckv_ext_set_tuning: tc_multipass) whose scans across tiles come in three shapes -- grids of one wave per step, one
+    workgroup, one wave (tc_scan; fp16 sources: with and without the summary pass emitting,
+    tc_no_pre) -- which must all produce the oracle's stream and output: noise with long flat stretches (runs,
     255-splits and the delta chain cross tiles, workgroups and steps of 64 tiles), 70 to 900 000 elements."""
     rng = np.random.default_rng(5)
     if form == "no_pre":
-        os.environ["SPECKV_TC_NO_PRE"] = "1"                         # fp16 sources: summary and emit as two plain passes
+        set_tuning("tc_no_pre", "1")                         # fp16 sources: summary and emit as two plain passes
     elif form == "grids":
-        os.environ["SPECKV_TC_MULTIPASS"] = "1"
+        set_tuning("tc_multipass", "1")
     elif form == "per_element_expand":                               # the multi-launch decoder with the expand loop of rounds 2-3
-        os.environ["SPECKV_TC_MULTIPASS"] = "1"; os.environ["SPECKV_TD_EXPAND_PER_ELEMENT"] = "1"
+        set_tuning("tc_multipass", "1"); set_tuning("td_expand_per_element", "1")
     elif form == "no_split_tiles":                                   # the one-pass compressor with the element-wise loop for long stretches
-        os.environ["SPECKV_TC_NO_SPLIT_TILES"] = "1"
+        set_tuning("tc_no_split_tiles", "1")
     elif form == "one_pass_decoder":                                 # the one-pass decoder also for streams of few pairs
-        os.environ["SPECKV_TD_ONE_PASS"] = "1"
+        set_tuning("td_one_pass", "1")
     elif form != "single_pass":
-        os.environ["SPECKV_TC_SCAN"] = form
+        set_tuning("tc_scan", form)
     try:
         for n in (70, 2048 * 63 + 5, 2048 * 64, 2048 * 65 + 1, 900000):
             x = rng.standard_normal(n).astype(np.float32)
@@ -626,12 +626,12 @@ def test_tensor_codec_scan_forms(lib, oracle, form):
                     scale, rle = gpu_compress_tensor(lib, x16, mode)
                     assert np.float32(scale).tobytes() == np.float32(o_scale).tobytes() and rle.tobytes() == o_rle.tobytes(), (form, n, mode, "fp16")
     finally:
-        os.environ.pop("SPECKV_TC_SCAN", None)
-        os.environ.pop("SPECKV_TC_NO_PRE", None)
-        os.environ.pop("SPECKV_TC_MULTIPASS", None)
-        os.environ.pop("SPECKV_TD_EXPAND_PER_ELEMENT", None)
-        os.environ.pop("SPECKV_TD_ONE_PASS", None)
-        os.environ.pop("SPECKV_TC_NO_SPLIT_TILES", None)
+        set_tuning("tc_scan", 0)
+        set_tuning("tc_no_pre", 0)
+        set_tuning("tc_multipass", 0)
+        set_tuning("td_expand_per_element", 0)
+        set_tuning("td_one_pass", 0)
+        set_tuning("tc_no_split_tiles", 0)
 
 
 def test_tensor_codec_look_back_over_many_workgroups(lib, oracle):

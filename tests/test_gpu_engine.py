@@ -10,7 +10,7 @@ import pytest
 
 import cxl_speckv_amd as pkg
 from cxl_speckv_amd.speckv_ctypes import SpeckvError
-from tests._gpu import N, assert_same_float_bits, dev_to_host, graph_capture, torch_mod
+from tests._gpu import N, assert_same_float_bits, dev_to_host, graph_capture, torch_mod, set_tuning
 
 pytestmark = pytest.mark.gpu
 PAGE = 4096
@@ -466,15 +466,15 @@ def test_fp8_fused_attention(eng, oracle):
     # (layer, range, splits): one tile, ragged last tile, many splits, one split, range not at 0
     cases = [(0, (0, T), None), (2, (64, 200), None), (1, (2, 4), None), (1, (0, 34), "1"), (0, (0, T), "1"), (2, (30, 512), "3")]
     for layer, (pb, pe), splits in cases:
-        if splits is None: os.environ.pop("SPECKV_ATTEND_SPLITS", None)
-        else: os.environ["SPECKV_ATTEND_SPLITS"] = splits
+        if splits is None: set_tuning("attend_splits", 0)
+        else: set_tuning("attend_splits", splits)
         try:
             d_out = torch.full((H, G, D), float("nan"), dtype=torch.float32, device="cuda")
             d_lse = torch.full((H, G), float("nan"), dtype=torch.float32, device="cuda")
             lib.attend_fp8(h, layer, 1, d_q[layer].data_ptr(), G, pb, pe, sm, d_out.data_ptr(), d_lse.data_ptr())
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("SPECKV_ATTEND_SPLITS", None)
+            set_tuning("attend_splits", 0)
         want, wlse, mag, delta = want_for(layer, pb, pe, sm)
         got, glse = d_out.cpu().numpy(), d_lse.cpu().numpy()
         err = np.abs(got - want)
@@ -629,15 +629,15 @@ def test_fused_attention_batch_of_sequences(eng, scheme):
     sm = 1.0 / np.sqrt(D)
     for layer in (0, 1):
         for tps in (None, "1", "3"):
-            if tps is None: os.environ.pop("SPECKV_ATTEND_TILES_PER_SPLIT", None)
-            else: os.environ["SPECKV_ATTEND_TILES_PER_SPLIT"] = tps
+            if tps is None: set_tuning("attend_tiles_per_split", 0)
+            else: set_tuning("attend_tiles_per_split", tps)
             try:
                 out = torch.full((len(lens), H, G, D), float("nan"), dtype=torch.float32, device="cuda")
                 lse = torch.full((len(lens), H, G), float("nan"), dtype=torch.float32, device="cuda")
                 batch_fn(handles, layer, q.data_ptr(), G, lens, sm, out.data_ptr(), lse.data_ptr())
                 torch.cuda.synchronize()
             finally:
-                os.environ.pop("SPECKV_ATTEND_TILES_PER_SPLIT", None)
+                set_tuning("attend_tiles_per_split", 0)
             for i, (h, n) in enumerate(zip(handles, lens)):
                 one = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
                 one_lse = torch.empty((H, G), dtype=torch.float32, device="cuda")
@@ -742,15 +742,15 @@ def test_int4_fused_attention(eng, oracle):
 
     cases = [(0, (0, T), None), (1, (64, 200), None), (1, (2, 4), None), (0, (0, 34), "1"), (0, (0, T), "1"), (1, (32, 480), "3")]
     for layer, (pb, pe), splits in cases:
-        if splits is None: os.environ.pop("SPECKV_ATTEND_SPLITS", None)
-        else: os.environ["SPECKV_ATTEND_SPLITS"] = splits
+        if splits is None: set_tuning("attend_splits", 0)
+        else: set_tuning("attend_splits", splits)
         try:
             d_out = torch.full((H, G, D), float("nan"), dtype=torch.float32, device="cuda")
             d_lse = torch.full((H, G), float("nan"), dtype=torch.float32, device="cuda")
             lib.attend_int4(h, layer, 1, d_q[layer].data_ptr(), G, pb, pe, sm, d_out.data_ptr(), d_lse.data_ptr())
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("SPECKV_ATTEND_SPLITS", None)
+            set_tuning("attend_splits", 0)
         want, wlse, mag = want_for(layer, pb, pe, sm)
         got, glse = d_out.cpu().numpy(), d_lse.cpu().numpy()
         err = np.abs(got - want)
@@ -957,12 +957,12 @@ def test_fused_attention_random_cases_against_fetched_pages(eng):
             pos_end = 2 * int(rng.integers(1, T // 2 + 1))
             q = torch.from_numpy(rng.standard_normal((H, G, D)).astype(np.float16)).cuda()
             out = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
-            os.environ["SPECKV_ATTEND_SPLITS"] = str(int(rng.integers(1, 6)))
+            set_tuning("attend_splits", str(int(rng.integers(1, 6))))
             try:
                 fused(h, layer, 1, q.data_ptr(), G, 0, pos_end, 0.09, out.data_ptr())
                 torch.cuda.synchronize()
             finally:
-                os.environ.pop("SPECKV_ATTEND_SPLITS", None)
+                set_tuning("attend_splits", 0)
             k = eng.kv_rows(0, layer, 0, 0, pos_end).float().clone()
             v = eng.kv_rows(0, layer, 1, 0, pos_end).float().clone()
             p = torch.softmax(torch.einsum("hgd,thd->hgt", q.float(), k) * 0.09, dim=-1)
@@ -1006,12 +1006,12 @@ def test_attention_ranges_that_start_inside_a_tile_or_end_outside_the_region(poo
                 for pos_begin, pos_end in ((6, T), (34, 100), (62, 66), (30, 32), (0, T), (T - 2, T)):
                     out = torch.full((L, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
                     lse = torch.full((L, H, G), float("nan"), dtype=torch.float32, device="cuda")
-                    if general: os.environ["SPECKV_ATTEND_GENERAL"] = "1"
+                    if general: set_tuning("attend_general", "1")
                     try:
                         fused(h, 0, L, q.data_ptr(), G, pos_begin, pos_end, 0.09, out.data_ptr(), lse.data_ptr())
                         torch.cuda.synchronize()
                     finally:
-                        os.environ.pop("SPECKV_ATTEND_GENERAL", None)
+                        set_tuning("attend_general", 0)
                     for layer in range(L):
                         k = kvx.kv_rows(0, layer, 0, pos_begin, pos_end).float().clone()
                         v = kvx.kv_rows(0, layer, 1, pos_begin, pos_end).float().clone()

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 import cxl_speckv_amd as pkg
-from tests._gpu import N, assert_same_float_bits, torch_mod
+from tests._gpu import N, assert_same_float_bits, torch_mod, set_tuning
 
 pytestmark = pytest.mark.gpu
 PAGE = 4096
@@ -127,14 +127,14 @@ def test_config5_70b_shaped_32k_context_at_full_size(eng, oracle, scheme):
     heads = {0: tuple(int(v) for v in srng.choice(H, 2, replace=False)), mid: (mh,), 79: (7, int(srng.integers(0, 7)))}
 
     def run(general, layer0=0, n_layers=L, pos_end=T):
-        if general: os.environ["SPECKV_ATTEND_GENERAL"] = str(int(general))      # 1, 2: the table form of the fast kernel (record addresses from the page table)
+        if general: set_tuning("attend_general", str(int(general)))      # 1, 2: the table form of the fast kernel (record addresses from the page table)
         try:
             out = torch.full((n_layers, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
             lse = torch.full((n_layers, H, G), float("nan"), dtype=torch.float32, device="cuda")
             attend(h, layer0, n_layers, q[layer0:layer0 + n_layers].data_ptr(), G, 0, pos_end, sm, out.data_ptr(), lse.data_ptr())
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("SPECKV_ATTEND_GENERAL", None)
+            set_tuning("attend_general", 0)
         return out.cpu().numpy(), lse.cpu().numpy()
 
     for general in (0, 1, 2):

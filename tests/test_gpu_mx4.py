@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import cxl_speckv_amd as pkg
-from tests._gpu import N, assert_same_float_bits, torch_mod
+from tests._gpu import N, assert_same_float_bits, torch_mod, set_tuning
 
 pytestmark = pytest.mark.gpu
 PAGE = 4096
@@ -151,15 +151,15 @@ def test_mx4_fused_attention(eng, oracle, g):
     cases = [(0, (0, T), None), (2, (64, 200), None), (1, (2, 4), None), (1, (0, 34), "1"), (0, (0, T), "1"), (2, (30, 512), "3"),
              (1, (96, 480), "5"), (0, (0, 2), None)]
     for layer, (pb, pe), splits in cases:
-        if splits is None: os.environ.pop("SPECKV_ATTEND_SPLITS", None)
-        else: os.environ["SPECKV_ATTEND_SPLITS"] = splits
+        if splits is None: set_tuning("attend_splits", 0)
+        else: set_tuning("attend_splits", splits)
         try:
             d_out = torch.full((H, g, D), float("nan"), dtype=torch.float32, device="cuda")
             d_lse = torch.full((H, g), float("nan"), dtype=torch.float32, device="cuda")
             lib.attend_mx4(h, layer, 1, d_q[layer].data_ptr(), g, pb, pe, sm, d_out.data_ptr(), d_lse.data_ptr())
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("SPECKV_ATTEND_SPLITS", None)
+            set_tuning("attend_splits", 0)
         want, wlse, mag, delta = oracle_attention(oracle, recs, q[layer], T, layer, pb, pe, sm, g)
         check(d_out.cpu().numpy(), d_lse.cpu().numpy(), want, wlse, mag, delta, (g, layer, pb, pe, splits))
     # sharp softmax (large scale): the running-max rescale path
@@ -183,12 +183,12 @@ def test_mx4_fused_attention(eng, oracle, g):
     want, _, mag, delta = oracle_attention(oracle, recs, q[1], T, 1, 30, 512, sm, g)
     check(d_out.cpu().numpy(), None, want, None, mag, delta, (g, "table tail"))
     # ... and SPECKV_ATTEND_GENERAL forces it for a whole range
-    os.environ["SPECKV_ATTEND_GENERAL"] = "1"
+    set_tuning("attend_general", "1")
     try:
         lib.attend_mx4(h, 2, 1, d_q[2].data_ptr(), g, 0, T, sm, d_out.data_ptr())
         torch.cuda.synchronize()
     finally:
-        os.environ.pop("SPECKV_ATTEND_GENERAL", None)
+        set_tuning("attend_general", 0)
     want, _, mag, delta = oracle_attention(oracle, recs, q[2], T, 2, 0, T, sm, g)
     check(d_out.cpu().numpy(), None, want, None, mag, delta, (g, "table whole"))
     # empty range: zeros
@@ -255,7 +255,7 @@ def test_mx4_batch_and_planned_forms(eng, oracle, g):
     sm = 1.0 / np.sqrt(D)
     st = torch.cuda.Stream()
     for layer, tps in ((1, None), (0, "4")):
-        if tps: os.environ["SPECKV_ATTEND_TILES_PER_SPLIT"] = tps
+        if tps: set_tuning("attend_tiles_per_split", tps)
         try:
             out = torch.full((n_seq, H, g, D), float("nan"), dtype=torch.float32, device="cuda")
             lse = torch.full((n_seq, H, g), float("nan"), dtype=torch.float32, device="cuda")
@@ -269,7 +269,7 @@ def test_mx4_batch_and_planned_forms(eng, oracle, g):
             lib.attend_planned(5, plan.data_ptr(), n_seq, layer, q.data_ptr(), g, T, sm, out2.data_ptr(), lse2.data_ptr(), st.cuda_stream)
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("SPECKV_ATTEND_TILES_PER_SPLIT", None)
+            set_tuning("attend_tiles_per_split", 0)
         one = torch.empty((H, g, D), dtype=torch.float32, device="cuda")
         one_lse = torch.empty((H, g), dtype=torch.float32, device="cuda")
         for i in range(n_seq):

@@ -18,7 +18,7 @@ import pytest
 
 import cxl_speckv_amd as pkg
 from cxl_speckv_amd.speckv_ctypes import SpeckvError
-from tests._gpu import N, assert_same_float_bits, dev_to_host, graph_capture, torch_mod
+from tests._gpu import N, assert_same_float_bits, dev_to_host, graph_capture, torch_mod, set_tuning
 from tests.test_gpu_engine import synth
 
 pytestmark = pytest.mark.gpu
@@ -431,8 +431,8 @@ def test_planned_batch_attention_replays_under_a_graph(scheme):
         plan = torch.zeros(plan_bytes, dtype=torch.uint8, device="cuda")
         s = torch.cuda.Stream()
         for tps in (None, "8", "64"):                 # the rule's geometry, one with real splits, one without any (no merge launch)
-            if tps is None: os.environ.pop("SPECKV_ATTEND_TILES_PER_SPLIT", None)
-            else: os.environ["SPECKV_ATTEND_TILES_PER_SPLIT"] = tps
+            if tps is None: set_tuning("attend_tiles_per_split", 0)
+            else: set_tuning("attend_tiles_per_split", tps)
             try:
                 def run_layers():
                     for layer in range(L):
@@ -480,7 +480,7 @@ def test_planned_batch_attention_replays_under_a_graph(scheme):
                     lib.attend_batch_plan(handles, [T] * n_seq, T - 2, plan.data_ptr(), plan_bytes, s.cuda_stream)
                 del g
             finally:
-                os.environ.pop("SPECKV_ATTEND_TILES_PER_SPLIT", None)
+                set_tuning("attend_tiles_per_split", 0)
         for h in handles:
             lib.free(h)
     finally:

@@ -10,7 +10,7 @@ import pytest
 
 import cxl_speckv_amd as pkg
 from cxl_speckv_amd.speckv_ctypes import SpeckvError, SpeckvLib
-from tests._gpu import N, assert_same_float_bits, dev_to_host, torch_mod
+from tests._gpu import N, assert_same_float_bits, dev_to_host, torch_mod, set_tuning
 
 pytestmark = pytest.mark.gpu
 PAGE = 4096
@@ -310,14 +310,14 @@ def test_fused_attention_over_a_regularly_striped_pool_computes_its_addresses(or
             attend = lib.attend_int4 if scheme == 3 else lib.attend_fp8
 
             def run(pb, pe, general=False, layer0=0, nl=L):
-                if general: os.environ["SPECKV_ATTEND_GENERAL"] = "1"
+                if general: set_tuning("attend_general", "1")
                 try:
                     out = torch.full((nl, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
                     lse = torch.full((nl, H, G), float("nan"), dtype=torch.float32, device="cuda")
                     attend(h, layer0, nl, d_q[layer0:layer0 + nl].data_ptr(), G, pb, pe, sm, out.data_ptr(), lse.data_ptr())
                     torch.cuda.synchronize()
                 finally:
-                    os.environ.pop("SPECKV_ATTEND_GENERAL", None)
+                    set_tuning("attend_general", 0)
                 return out.cpu().numpy(), lse.cpu().numpy()
 
             results[name] = {"full": run(0, T), "part": run(64, T - 26, layer0=1, nl=2)}
@@ -411,7 +411,7 @@ def test_real_lstm_cell_predictor_matches_torch_nn_lstm():
 def test_small_prediction_path_equals_the_batch_path(oracle, vocab):
     """One to four requests take two launches (k_predict_small: the logits of a workgroup's 128 rows reduced on the spot, no
     logits in memory; k_predict_small_merge) instead of the batch path's four.  Both paths on the same weights and histories
-    (SPECKV_PREDICT_BATCH_PATH, read at every call): the same tokens, confidences within 2e-5 (the dot products add in a
+    (speckv_ext_set_tuning: predict_batch_path): the same tokens, confidences within 2e-5 (the dot products add in a
     different order), for the reference's degenerate cell -- also against the oracle -- and for the real LSTM cell with an
     output bias."""
     torch = torch_mod()
@@ -430,11 +430,11 @@ def test_small_prediction_path_equals_the_batch_path(oracle, vocab):
 
         def both(n, k, H):
             small = run(n, k, H)
-            os.environ["SPECKV_PREDICT_BATCH_PATH"] = "1"
+            set_tuning("predict_batch_path", "1")
             try:
                 batch = run(n, k, H)
             finally:
-                os.environ.pop("SPECKV_PREDICT_BATCH_PATH")
+                set_tuning("predict_batch_path", 0)
             return small, batch
 
         lib.predictor_load(emb.ctypes.data, wout.ctypes.data, vocab, False)
@@ -471,8 +471,8 @@ def test_small_prediction_path_equals_the_batch_path(oracle, vocab):
 @pytest.mark.parametrize("n_req", [5, 64, 200])
 def test_one_workgroup_flush_equals_the_four_launch_pipeline(oracle, n_req):
     """Small flushes run the device-side pipeline (candidates, first-occurrence dedupe, ring run, ordered placement) as phases
-    of one workgroup (k_flush_small) instead of four launches.  Same requests through both forms (SPECKV_FLUSH_NO_SMALL /
-    SPECKV_FLUSH_SMALL_WORDS, read at every flush), each in a fresh engine: the same pages become resident, in the SAME ring
+    of one workgroup (k_flush_small) instead of four launches.  Same requests through both forms (speckv_ext_set_tuning: flush_no_small /
+    flush_small_words), each in a fresh engine: the same pages become resident, in the SAME ring
     slots (entry order is part of the contract: the host derives residency from the slot's sequence number), with the same
     bytes; and the set of pages is the oracle's.  Requests repeat pages (dedupe) and some name pages already resident."""
     T, L, H, D, bpe = 512, 4, 8, 128, 2
@@ -485,9 +485,9 @@ def test_one_workgroup_flush_equals_the_four_launch_pipeline(oracle, n_req):
     depth = np.full(n_req, 4, np.uint32)
     x = (rng.standard_normal((n_pages, N)) * 0.5).astype(np.float16)
     seen = {}
-    for form, env in (("one workgroup", {"SPECKV_FLUSH_SMALL_WORDS": 16384}), ("four launches", {"SPECKV_FLUSH_NO_SMALL": 1})):
+    for form, env in (("one workgroup", {"flush_small_words": 16384}), ("four launches", {"flush_no_small": 1})):
         for k_, v_ in env.items():
-            os.environ[k_] = str(v_)
+            set_tuning(k_, v_)
         try:
             lib = SpeckvLib(pkg.library_path(), "hip:0")
             try:
@@ -508,7 +508,7 @@ def test_one_workgroup_flush_equals_the_four_launch_pipeline(oracle, n_req):
                 lib.finalize()
         finally:
             for k_ in env:
-                os.environ.pop(k_, None)
+                set_tuning(k_, 0)
     a, b = seen["one workgroup"], seen["four launches"]
     base = lambda res: min(addr for addr, _ in res.values())
     rel = lambda res: {p: (addr - base(res), f) for p, (addr, f) in res.items()}
@@ -1072,7 +1072,7 @@ def test_vllm_connector_prefix_hit_chunked_prefill_and_separate_roles():
             assert torch.equal(prefix[li][:, res_slots], truth[li][:, :matched]), li
         # ... and a hit that no entry of the step's output carries is an error, not a silent drop
         sched.update_state_after_alloc(req, NS(get_block_ids=lambda: [res_blk]), matched)
-        with pytest.raises(RuntimeError, match="never being filled"):
+        with pytest.raises(RuntimeError, match="without ever being filled"):
             sched.build_connector_meta(NS(scheduled_new_reqs=[], num_scheduled_tokens={}))
         assert sched.build_connector_meta(NS(scheduled_new_reqs=[])).requests == []         # (the state was reset)
 
