@@ -1631,10 +1631,22 @@ def run_extras(torch, pkg, lib, src, dst, n_blocks, sp):
         hint_ms = timed(dec_hint)
         comp = int(lens.to(torch.int64).sum().item())
         dec_bytes = comp + n_blocks * (4 + PAGE)
+        # ... and through the ENGINE with no hint from anybody: speckv_ext_fetch_range over an allocation that was written with this
+        # data -- the compress kernel's own record-length samples pick the flat-run decoder
+        eng_ms = None
+        try:
+            lib.set_compression_scheme(2)
+            he = lib.alloc(n_blocks * PAGE)
+            lib.write(he, 0, data.data_ptr(), data.numel() * 2, True)
+            eng_ms = timed(lambda: lib.fetch_range(he, 0, n_blocks, dst.data_ptr(), False, sp))
+            lib.free(he)
+        except Exception as e:
+            eng_ms = None
         ex[name] = {"decompress_blocks_per_s": round(n_blocks / (dec_ms * 1e-3), 1),
                     "decompress_GBps": round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1),
                     "decompress_frac_hbm": round(dec_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                     "decompress_frac_hbm_structured_hint": round(dec_bytes / (hint_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    "engine_fetch_range_frac_hbm_no_hint_given": round(dec_bytes / (eng_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if eng_ms else None,
                     "compress_blocks_per_s": round(n_blocks / (enc_ms * 1e-3), 1),
                     "record_bytes_per_block": round(comp / n_blocks, 1)}
     return ex

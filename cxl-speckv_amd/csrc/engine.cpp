@@ -376,12 +376,14 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
                      hipMemsetAsync(a->d_slot, 0xFF, a->n_pages * sizeof(uint32_t), stream_) == hipSuccess &&
                      hipMemsetAsync(a->d_stamp, 0, a->n_pages * sizeof(uint32_t), stream_) == hipSuccess;
             }
-            if (ok) ok = hipHostMalloc(&a->pinned, a->n_pages * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocPortable) == hipSuccess;
+            if (ok) ok = hipHostMalloc(&a->pinned, (a->n_pages + kLenSamples) * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocPortable) == hipSuccess;      // + the record-length samples (Allocation::len_samples)
             if (ok) {
                 a->host_flags.assign(a->n_pages, 0u);
                 a->flags = a->host_flags.data();
                 a->slot = static_cast<uint32_t*>(a->pinned);
                 memset(a->slot, 0xFF, a->n_pages * sizeof(uint32_t));
+                a->len_samples = a->slot + a->n_pages;
+                memset(a->len_samples, 0, kLenSamples * sizeof(uint32_t));
             }
             if (ok) {
                 if (single_run)

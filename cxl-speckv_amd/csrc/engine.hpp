@@ -51,6 +51,7 @@ private:
     std::deque<uint8_t> hist_;   // window of 100 outcomes
 };
 
+constexpr uint32_t kLenSamples = 16;       // record-length samples per allocation (Allocation::len_samples)
 struct Allocation {
     uint64_t handle = 0;
     size_t size_bytes = 0;
@@ -64,7 +65,11 @@ struct Allocation {
     uint32_t* flags = nullptr;
     uint32_t* slot = nullptr;
     std::vector<uint32_t> host_flags;     // backing store of flags
-    void* pinned = nullptr;               // backing store of slot
+    void* pinned = nullptr;               // backing store of slot (+ kLenSamples words behind it)
+    // INT8_DELTA_RLE: record lengths of every 1024th page, stored by the compress kernel itself (CodecArgs::len_samples; host-visible
+    // memory, no copy back): looks_structured() = "the mean sample is under 512 B" picks the flat-run decoder for reads of an
+    // allocation that was never sealed.  0 = no sample yet.
+    uint32_t* len_samples = nullptr;
     std::vector<uint32_t> access_count;   // MemoryPage::access_count
     std::vector<uint32_t> stamp;          // dedupe epoch of access_batch
     uint32_t l1_pages = 0;

@@ -4,6 +4,29 @@
 
 namespace speckv {
 
+// device-visible address of an allocation's record-length samples (null where there are none: other schemes, the fake device)
+static uint32_t* len_samples_dev(const Allocation* a)
+{
+    if (!a->len_samples || a->scheme != SPECKV_COMP_INT8_DELTA_RLE) return nullptr;
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, a->len_samples, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return static_cast<uint32_t*>(dp);
+}
+// "this allocation holds data that compresses": the mean of the record lengths the compress kernel left behind (every 1024th
+// page) is under 512 B.  Read without any ordering -- samples of writes still in flight may be missing -- because it only picks
+// between two decoders that produce the same bytes.
+static bool looks_structured(const Allocation* a)
+{
+    if (!a->len_samples || a->scheme != SPECKV_COMP_INT8_DELTA_RLE) return false;
+    uint64_t sum = 0, cnt = 0;
+    for (uint32_t i = 0; i < kLenSamples; ++i) {
+        const uint32_t v = *const_cast<volatile uint32_t*>(a->len_samples + i);
+        if (v) { sum += v; ++cnt; }
+    }
+    return cnt && sum / cnt < 512u;
+}
+
+
 // -------------------------------------------------------------- data path
 int Engine::write(uint64_t handle, uint64_t off, const void* src, size_t len, bool on_device)
 {
@@ -28,6 +51,7 @@ int Engine::write(uint64_t handle, uint64_t off, const void* src, size_t len, bo
     CodecArgs c{};
     c.entries = a->d_entries;
     c.scale_tab = a->d_scale_tab;        // fused-attention scale table follows every write
+    c.len_samples = len_samples_dev(a);
     c.region_pages = a->region_pages;
     c.data_stride = kPageSize;
     c.scheme = a->scheme;
@@ -102,6 +126,7 @@ int Engine::write_strided(uint64_t handle, uint64_t first, uint64_t step, uint64
     CodecArgs c{};
     c.entries = a->d_entries;
     c.scale_tab = a->d_scale_tab;
+    c.len_samples = len_samples_dev(a);
     c.region_pages = a->region_pages;
     c.data_stride = kPageSize;
     c.scheme = a->scheme;
@@ -302,6 +327,13 @@ int Engine::read(uint64_t handle, uint64_t off, void* dst, size_t len, bool on_d
 // rotation: the copies of chunk c+1 overlap the decompression of chunk c.
 int Engine::fetch_range_copy_engine(Allocation* a, uint64_t first, uint64_t n, void* d_dst, bool f32, hipStream_t st)
 {
+    // data that compresses takes the flat-run decoder here too: a sealed allocation by its packed size, another by its length samples
+    int hint = 0;
+    if (a->scheme == SPECKV_COMP_INT8_DELTA_RLE && a->n_pages) {
+        if (a->packed) { uint64_t pk = 0; for (uint64_t b : a->packed_bytes) pk += b; hint = pk / a->n_pages < 512u ? 1 : 0; }
+        else hint = looks_structured(a) ? 1 : 0;
+    }
+    if (hint) st_.flat_decoder_fetches++;
     const uint32_t D = static_cast<uint32_t>(a->pool_of_residue.size());
     const bool packed = a->packed && a->packed_regular;
     if (D == 0 || D > 8 || !(a->regular || packed)) return SPECKV_ERR_INVAL;
@@ -346,6 +378,7 @@ int Engine::fetch_range_copy_engine(Allocation* a, uint64_t first, uint64_t n, v
         c.scheme = a->scheme;
         c.quant_mode = quant_mode_;
         c.out_f32 = f32 ? 1 : 0;
+        c.structured_hint = hint;                            // (the flat-run decoder also reads staged records: k_fetch_decompress_flat_staged)
         c.stripe_n = D;
         c.stripe_magic = (1ull << 35) / D + 1;
         for (uint32_t k = 0; k < D; ++k) {
@@ -435,7 +468,10 @@ int Engine::fetch_range(uint64_t handle, uint64_t first, uint64_t n, void* d_dst
             uint64_t packed = 0;
             for (uint64_t b : a->packed_bytes) packed += b;
             c.structured_hint = packed / a->n_pages < 512u ? 1 : 0;
+        } else {                                             // never sealed: the compress kernel's own length samples
+            c.structured_hint = looks_structured(a) ? 1 : 0;
         }
+        if (c.structured_hint) st_.flat_decoder_fetches++;
         HIP_TRY(launch_decompress(c, st));
     }
     note_use(a, s);

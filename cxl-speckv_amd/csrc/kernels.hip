@@ -729,6 +729,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))
 }
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void k_fetch_decompress_flat_f32(CodecArgs a) { fetch_decompress_body<kInt8DeltaRle, MODE, true, 0, true>(a); }
+// ... and for records the copy engines staged (EXT 1: a remote pool's allocation that compresses)
+template <int MODE>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fetch_decompress_flat_staged(CodecArgs a)
+{
+    fetch_decompress_body<kInt8DeltaRle, MODE, false, 1, true>(a);
+}
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void k_fetch_decompress_flat_f32_staged(CodecArgs a) { fetch_decompress_body<kInt8DeltaRle, MODE, true, 1, true>(a); }
 
 // ===================================================================
 // RLE encode of the delta stream (cache_engine.cpp:198-239)
@@ -1215,6 +1223,7 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
             if (entries) {
                 gstore<uint32_t>(&entries[page].rec_bytes, out_len);
                 gstore<float>(&entries[page].scale, scale);
+                if (SCHEME == kInt8DeltaRle && a.len_samples && (page & 1023u) == 0u) gstore<uint32_t>(&a.len_samples[(page >> 10) & 15u], out_len);
                 if (scale_tab) {
                     const uint32_t j = static_cast<uint32_t>(page % region_pages) & 15u;
                     gstore<float>(&scale_tab[page - j + attend_tile_slot(j)], scale);
@@ -2396,9 +2405,11 @@ hipError_t launch_dec2(const CodecArgs& a_in, hipStream_t s)
     if (ext == 3 && (a.out_f32 || a.alloc_list || a.ring_owner || a.stripe_n || !a.seq0_dev || !a.data_list)) return hipErrorInvalidValue;
 #define SPECKV_LAUNCH_DEC(F32, EXT) \
     hipLaunchKernelGGL((k_fetch_decompress<SCHEME, MODE, F32, EXT>), dim3(grid), dim3(kThreads), 0, s, a)
-    if (SCHEME == kInt8DeltaRle && a.structured_hint && ext == 0) {      // data known to compress: the FLAT instantiation (plain form only)
-        if (a.out_f32) hipLaunchKernelGGL((k_fetch_decompress_flat_f32<MODE>), dim3(grid), dim3(kThreads), 0, s, a);
-        else           hipLaunchKernelGGL((k_fetch_decompress_flat<MODE>), dim3(grid), dim3(kThreads), 0, s, a);
+    if (SCHEME == kInt8DeltaRle && a.structured_hint && ext <= 1) {      // data known to compress: the FLAT instantiation (plain and copy-engine-staged forms)
+        if (a.out_f32 && ext == 0) hipLaunchKernelGGL((k_fetch_decompress_flat_f32<MODE>), dim3(grid), dim3(kThreads), 0, s, a);
+        else if (a.out_f32)        hipLaunchKernelGGL((k_fetch_decompress_flat_f32_staged<MODE>), dim3(grid), dim3(kThreads), 0, s, a);
+        else if (ext == 0)         hipLaunchKernelGGL((k_fetch_decompress_flat<MODE>), dim3(grid), dim3(kThreads), 0, s, a);
+        else                       hipLaunchKernelGGL((k_fetch_decompress_flat_staged<MODE>), dim3(grid), dim3(kThreads), 0, s, a);
         return hipGetLastError();
     }
     if (a.out_f32) { if (ext == 2) SPECKV_LAUNCH_DEC(true, 2); else if (ext == 1) SPECKV_LAUNCH_DEC(true, 1); else SPECKV_LAUNCH_DEC(true, 0); }

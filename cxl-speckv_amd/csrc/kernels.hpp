@@ -103,6 +103,11 @@ struct CodecArgs {
     // (layer, kind) region of the shim layout, a multiple of 16
     float*          scale_tab;
     uint32_t        region_pages;
+    // compress only, INT8_DELTA_RLE: every 1024th page leaves its record length in len_samples[(page >> 10) & 15] -- 16 words of
+    // the allocation's host-visible memory, plain stores -- so that the host can tell, without a copy back, whether the
+    // allocation holds data that compresses (mean record well under 512 B: the flat-run decoder is then chosen for its reads;
+    // CodecArgs::structured_hint).  A hint only: either decoder gives the same bytes.  Null: no samples.
+    uint32_t*       len_samples;
     // compress only: blocks of several allocations in one launch -- block i belongs to groups[i / group_n] (device array)
     // as its page i % group_n; entries / scale_tab / region_pages / first / data above are then unused
     const CompressGroup* groups;

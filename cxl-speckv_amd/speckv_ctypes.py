@@ -41,7 +41,7 @@ class Stats(ctypes.Structure):
         [(n, c_uint32) for n in ("prefetch_depth", "compression_scheme", "quant_mode", "n_pool_devices")] + \
         [("pool_migrated_pages", c_uint64), ("prefetch_dropped", c_uint64), ("copy_engine_runs", c_uint64),
          ("copy_engine_bytes", c_uint64), ("pool_bytes_in_use", c_uint64), ("written_pages", c_uint64),
-         ("sealed_allocations", c_uint64), ("compactions", c_uint64)]
+         ("sealed_allocations", c_uint64), ("compactions", c_uint64), ("flat_decoder_fetches", c_uint64)]
 
 
 _u32p = ctypes.POINTER(c_uint32)
@@ -101,7 +101,7 @@ _EXT_SIGNATURES = {
 }
 
 
-EXT_ABI_VERSION = 4        # SPECKV_EXT_ABI_VERSION of include/speckv_ext.h
+EXT_ABI_VERSION = 5        # SPECKV_EXT_ABI_VERSION of include/speckv_ext.h
 
 
 def bind_ext(lib):

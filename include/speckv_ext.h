@@ -425,6 +425,7 @@ typedef struct {
     uint64_t written_pages;         /* pages of live allocations that hold a record */
     uint64_t sealed_allocations;    /* live allocations packed by speckv_ext_compact */
     uint64_t compactions;           /* speckv_ext_compact calls that packed an allocation */
+    uint64_t flat_decoder_fetches;  /* speckv_ext_fetch_range launches that took the flat-run decoder by themselves (sealed size or length samples) */
 } speckv_ext_stats_t;
 /* The struct only ever grows at its end.  speckv_ext_stats() writes sizeof(speckv_ext_stats_t) of THIS header: a caller
  * compiled against an older header must use the sized form, which writes min(out_size, the library's size) bytes (fields
@@ -433,7 +434,7 @@ typedef struct {
  * is SPECKV_ERR_INVAL.
  * SPECKV_EXT_ABI_VERSION is bumped whenever a struct of this header grows or an entry point changes meaning;
  * speckv_ext_abi_version() returns the library's value (the Python binding refuses a mismatch). */
-#define SPECKV_EXT_ABI_VERSION 4u
+#define SPECKV_EXT_ABI_VERSION 5u
 uint32_t        speckv_ext_abi_version(void);
 speckv_status_t speckv_ext_stats(speckv_ext_stats_t* out);
 speckv_status_t speckv_ext_stats_sized(void* out, size_t out_size, size_t* written);

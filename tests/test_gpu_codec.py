@@ -732,3 +732,45 @@ def test_tensor_codec_matches_oracle_over_sizes_and_structures(lib, oracle):
         want = oracle.decompress_f32(stream, 0.25, 0)
         y = gpu_decompress_tensor(lib, stream, 0.25, want.size + 3, 0, True)
         assert_same_float_bits(y, want, f"random stream {n_pairs}")
+
+
+def test_engine_picks_the_flat_run_decoder_by_itself(oracle):
+    """an allocation that holds data the reference's scheme compresses is read with the flat-run decoder without
+    anybody passing a hint -- the compress kernel leaves the record length of every 1024th page in host-visible memory and
+    speckv_ext_fetch_range looks at the mean (never-sealed allocations; sealed ones by their packed size, as before) -- through
+    the fused kernel AND through the copy engines (staged records: k_fetch_decompress_flat_staged).  The bytes are the
+    oracle's either way; speckv_ext_stats_t.flat_decoder_fetches shows which decoder ran."""
+    import os
+    import cxl_speckv_amd as pkg
+    from cxl_speckv_amd.speckv_ctypes import SpeckvLib
+    torch = __import__("torch")
+    os.environ["SPECKV_POOL_DEVICES"] = "0,0"
+    try:
+        lib = SpeckvLib(pkg.library_path(), "hip:0")
+    finally:
+        os.environ.pop("SPECKV_POOL_DEVICES", None)
+    try:
+        lib.set_compression_scheme(2)
+        n_pages = 4096
+        rng = np.random.default_rng(31)
+        flat = np.repeat(rng.standard_normal((n_pages, N // 32)), 32, axis=1).astype(np.float16)       # runs of 32: ~130-byte records
+        flat[7] = rng.standard_normal(N).astype(np.float16)                                            # one page that does not compress
+        noise = rng.standard_normal((n_pages, N)).astype(np.float16)
+        seen = {}
+        for name, x in (("flat", flat), ("noise", noise)):
+            h = lib.alloc(n_pages * 4096)
+            lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+            scales, lens, recs = oracle.compress_blocks_f16(x, 2, 0)
+            want = oracle.decompress_blocks_f16(recs, lens, scales, 2, 0)
+            before = lib.stats().flat_decoder_fetches
+            for engine in (1, 2):
+                out = torch.zeros((n_pages, N), dtype=torch.float16, device="cuda")
+                torch.cuda.synchronize()
+                lib.fetch_range(h, 0, n_pages, out.data_ptr(), False, torch.cuda.current_stream().cuda_stream, engine=engine)
+                torch.cuda.synchronize()
+                assert_same_float_bits(out.cpu().numpy(), want, f"{name} engine {engine}")
+            seen[name] = lib.stats().flat_decoder_fetches - before
+            lib.free(h)
+        assert seen == {"flat": 2, "noise": 0}, seen
+    finally:
+        lib.finalize()
