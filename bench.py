@@ -1140,14 +1140,16 @@ def connector_append_extra(torch, kv, n_seq=256, Lyr=80, T=64):
         kv.lib.set_compression_scheme(2)
 
 
-def connector_decode_extra(torch, kv, n_seq=256, Lyr=8, ctx=2048, T=4096):
+def connector_decode_extra(torch, kv, n_seq=256, Lyr=8, ctx=2048, T=4096, scheme="fp8"):
     """SURVEY 8f row N2 end to end: decode steps of a 256-sequence batch through the vLLM-shaped connector -- per step
     one look-ahead flush (begin_step), one fused attention call per layer for the whole batch, one batched append.  Only the
     KV side of a decode step (no model): what the drop-in costs per generated token at this batch and context."""
     from cxl_speckv_amd.kv_connector import SpeckvKVConnector
     conn = None
     try:
-        conn = SpeckvKVConnector(kv.lib, num_layers=Lyr, max_tokens=T, scheme="fp8")
+        conn = SpeckvKVConnector(kv.lib, num_layers=Lyr, max_tokens=T, scheme=scheme)
+        name = "connector_decode_step" if scheme == "fp8" else f"connector_decode_step_{scheme}"
+        rec_per_pos = {"fp8": 1024, "int4": 576, "mxfp4": 544}[scheme]
         ids = list(range(n_seq))
         g = torch.Generator(device="cuda"); g.manual_seed(2006)
         kp = torch.randn((Lyr, ctx, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
@@ -1173,16 +1175,16 @@ def connector_decode_extra(torch, kv, n_seq=256, Lyr=8, ctx=2048, T=4096):
                 times.append((time.perf_counter() - t0) * 1e3)
                 del keep, out
         ms = sum(times[2:]) / len(times[2:])                   # even and odd steps alternate (tail fold / pair append)
-        rec_bytes = n_seq * Lyr * 2 * ctx * 1024                  # FP8 records read per step (K and V, 1 KiB per position and kind)
-        return {"connector_decode_step": {"sequences": n_seq, "layers": Lyr, "context": ctx, "ms_per_step": round(ms, 3),
+        rec_bytes = n_seq * Lyr * 2 * ctx * rec_per_pos          # record bytes read per step (K and V; FP8 1 KiB per position and kind, MXFP4 544 B)
+        return {name: {"sequences": n_seq, "layers": Lyr, "context": ctx, "ms_per_step": round(ms, 3),
                                           "ms_fastest_step": round(min(times[2:]), 3), "ms_slowest_step": round(max(times[2:]), 3),
                                           "tokens_per_s_kv_side": round(n_seq / (ms * 1e-3), 1),
                                           "KV_record_GBps": round(rec_bytes / (ms * 1e-3) / 1e9, 1),
                                           "frac_hbm": round(rec_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                           "note": "begin_step (flush) + one batch attention call per layer + batched append (which plans the next step), wall time "
-                                                  "per step incl. the torch glue (tail fold, gathers); FP8 pool"}}
+                                                  "per step incl. the torch glue (tail fold, gathers); " + scheme + " pool"}}
     except Exception as e:
-        return {"connector_decode_step": {"error": repr(e)}}
+        return {"connector_decode_step" if scheme == "fp8" else f"connector_decode_step_{scheme}": {"error": repr(e)}}
     finally:
         if conn is not None:
             for r in list(conn.requests):
@@ -1559,6 +1561,7 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     ex.update(batch_attention_extra(torch, kv, scheme=5))
     ex.update(connector_append_extra(torch, kv))
     ex.update(connector_decode_extra(torch, kv))
+    ex.update(connector_decode_extra(torch, kv, scheme="mxfp4"))      # the same decode step over an MXFP4 pool (half the record bytes of FP8)
     ex.update(predictor_extra(torch, lib))
     ex.update(lstm_cell_extra(torch, lib))
     ex.update(compaction_extra(torch, kv))

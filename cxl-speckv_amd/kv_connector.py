@@ -23,7 +23,8 @@ from typing import Dict, List, Optional, Sequence
 from .speckv_ctypes import SpeckvLib
 
 PAGE = 4096
-SCHEMES = {"fp16": 0, "int8": 1, "int8_delta_rle": 2, "int4": 3, "fp8": 4}
+SCHEMES = {"fp16": 0, "int8": 1, "int8_delta_rle": 2, "int4": 3, "fp8": 4, "mxfp4": 5}
+FUSED = (3, 4, 5)              # schemes whose records the fused attention reads directly (speckv_ext_attend_{int4,fp8,mx4}_*)
 
 
 class _Request:
@@ -248,7 +249,7 @@ class SpeckvKVConnector:
         # running), so its handle look-ups and the upload of its descriptors cost the next step nothing.  On the stream the
         # step's attention ran on: the upload is ordered behind the launches that still read the current plan.
         st = self._plan_stream
-        if st is not None and self._arg_key is not None and self._arg_key[0][0] == tuple(req_ids) and self.scheme in (3, 4):
+        if st is not None and self._arg_key is not None and self._arg_key[0][0] == tuple(req_ids) and self.scheme in FUSED:
             # best effort: the append itself has taken effect (lengths, tails, pool write) -- a plan that cannot be made now (the
             # stream is capturing, or was destroyed by its owner) must not make the caller retry it; attend() plans again instead
             try:
@@ -331,8 +332,8 @@ class SpeckvKVConnector:
         head, GQA); returns [batch][heads][g][dim] fp32.  Stored positions come straight from the compressed records
         (one launch pair for the batch), the tail position is folded in with the log-sum-exp."""
         import torch
-        if self.scheme not in (3, 4):
-            raise ValueError("attend() needs an FP8 or INT4 pool; use block_table() / kv_rows() with the other schemes")
+        if self.scheme not in FUSED:
+            raise ValueError("attend() needs an FP8, INT4 or MXFP4 pool; use block_table() / kv_rows() with the other schemes")
         B, H, G, D = q.shape
         key, reqs, _ = self._batch(req_ids)
         q = q.contiguous()

@@ -536,13 +536,14 @@ def test_fold_tail_adds_one_position(subset):
         lib.finalize()
 
 
-@pytest.mark.parametrize("scheme", ["fp8", "int4"])
+@pytest.mark.parametrize("scheme", ["fp8", "int4", "mxfp4"])
 def test_kv_connector_toy_decode_loop(scheme):
     """a vLLM-shaped connector (one allocation per request, batched append / look-ahead / attention).
     A 2-layer toy decode loop over a batch of three requests: at every step the attention the connector computes
     straight from the compressed records (+ the fp16 tail position) equals torch attention over the pages fetched and
     decompressed from the same pool.  Tolerances as the per-sequence tests: INT4 2e-3 * sum p|v| (same arithmetic on
-    both sides up to summation order), FP8 10 % of the largest output (its query is quantised to e4m3 in the kernel)."""
+    both sides up to summation order), FP8 10 % of the largest output (its query is quantised to e4m3 in the kernel), MXFP4 the
+    FP8 bound (K / V values are exactly the decompressed ones, the query is quantised to MXFP8 in the kernel)."""
     torch = torch_mod()
     from cxl_speckv_amd.kv_connector import SpeckvKVConnector
     lib = open_lib()
