@@ -632,23 +632,74 @@ __device__ __forceinline__ BlockDesc load_desc(const CodecArgs& a, uint64_t i, u
 // "still in the ring" from it (Engine::l2_live), so evictions need no host-visible store.  (Every 4-byte store to pinned
 // memory is a PCIe transaction of its own: with slot, flags and the evicted page's flags stored per block, a flush of
 // 19 000 blocks ran at the link's transaction rate -- 70 us against 42 us without the stores, 47 us with one.)
-__device__ __forceinline__ void ring_note(const CodecArgs& a, const BlockDesc& d, uint32_t slot, uint32_t seq)
+//
+// In two halves, because a miss of one page is nothing but dependent round trips (profiles/r05_access_miss.txt: the kernel
+// was 6.3 us of a 12.5 us miss -- page entry, record, then owner word, owner's table row, owner's slot word, own table row,
+// one after another behind the decode).  ring_look reads what the bookkeeping needs BEFORE the block is decoded, in three
+// steps of wave-uniform loads: {page entry, the slot's previous owner}, {that owner's table row, this block's row}, {the
+// owner's slot word}; the last one is an ordinary load that the record's own loads follow without a wait in between.
+// ring_note (one lane, after the decode) only stores.  The first two steps are scalar loads written out by hand, each
+// statement ending in its own s_waitcnt: left to the compiler the chain becomes vector loads behind branches, every one
+// waited for before the next and before the record (the words are written by kernels, so it will not pick scalar loads
+// itself; the scalar cache is invalidated when a kernel starts, and within a launch a wave only reads words that no
+// other wave of the launch writes, the previous owner's slot word aside -- which is read by a coherent vector load).
+struct RingLook {
+    uint32_t* evict_flags;      // previous owner's flag word, or nullptr: nothing to evict
+    uint32_t  their_slot;       // previous owner's slot word (compared in ring_note: the load stays in flight over the decode)
+    uint32_t* d_flags;          // this block's allocation (nullptr: row freed meanwhile)
+    uint32_t* d_slot;
+    uint32_t* h_slot;
+};
+typedef uint32_t sgpr4 __attribute__((ext_vector_type(4)));
+typedef uint64_t sgpr8 __attribute__((ext_vector_type(4)));     // four pointers: entries, d_flags, d_slot, h_slot (DevAlloc)
+__device__ __forceinline__ BlockDesc load_desc_ring(const CodecArgs& a, uint64_t i, uint32_t slot0, RingLook& r)
 {
-    const uint64_t prev = a.ring_owner[slot];
+    BlockDesc d;
+    d.page = a.page_list ? a.page_list[i] : a.first + i;
+    d.row = a.alloc_idx;
+    const uint32_t slot = slot0 + static_cast<uint32_t>(i);
+    d.dst = a.ring_base + static_cast<uint64_t>(slot) * kPageSize;
     const uint64_t me = (static_cast<uint64_t>(d.row) << 32) | d.page;
-    if (prev != kNoOwner && prev != me) {
-        const DevAlloc t = a.tab[prev >> 32];
-        const uint32_t pp = static_cast<uint32_t>(prev);
-        // the row may have been recycled for a smaller allocation since the slot was filled
-        if (t.entries && pp < t.layout.alloc_pages && t.d_slot[pp] == slot)      // still pointing here: the page leaves L2
-            atomicAnd(&t.d_flags[pp], ~2u);
+    const uint64_t* owner_word = a.ring_owner + slot;
+    const DevAlloc* mine = a.tab + d.row;
+    uint64_t prev;
+    sgpr4 e = {0u, 0u, 0u, 0x3f800000u};
+    if (a.entries) {
+        const PageEntry* ep = a.entries + d.page;
+        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(e), "=&s"(prev) : "s"(ep), "s"(owner_word) : "memory");
+    } else {                                                 // a row freed meanwhile decodes as a never-written page
+        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(prev) : "s"(owner_word) : "memory");
     }
-    a.ring_owner[slot] = me;
-    const DevAlloc t = a.tab[d.row];
-    if (!t.entries) return;
-    t.d_slot[d.page] = slot;
-    t.h_slot[d.page] = seq;
-    atomicOr(&t.d_flags[d.page], 2u);
+    d.rec = reinterpret_cast<const uint8_t*>((static_cast<uint64_t>(e.y) << 32) | e.x);
+    d.len = e.z;
+    d.scale = __uint_as_float(e.w);
+    const bool other = prev != kNoOwner && prev != me;
+    const DevAlloc* theirs = other ? a.tab + (prev >> 32) : mine;
+    sgpr8 tp, mp;
+    uint64_t their_pages;
+    asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx2 %1, %3, %5\n\ts_load_dwordx8 %2, %4, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(tp), "=&s"(their_pages), "=&s"(mp) : "s"(theirs), "s"(mine),
+                   "i"(offsetof(DevAlloc, layout) + offsetof(Layout, alloc_pages)) : "memory");
+    const uint32_t pp = static_cast<uint32_t>(prev);
+    // the row may have been recycled for a smaller allocation since the slot was filled
+    const bool in_row = other && tp.x != 0 && pp < their_pages;
+    const uint32_t* word = in_row ? reinterpret_cast<const uint32_t*>(tp.z) + pp : reinterpret_cast<const uint32_t*>(owner_word);
+    r.their_slot = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.evict_flags = in_row ? reinterpret_cast<uint32_t*>(tp.y) + pp : nullptr;
+    r.d_flags = mp.x != 0 ? reinterpret_cast<uint32_t*>(mp.y) : nullptr;
+    r.d_slot = reinterpret_cast<uint32_t*>(mp.z);
+    r.h_slot = reinterpret_cast<uint32_t*>(mp.w);
+    return d;
+}
+__device__ __forceinline__ void ring_note(const CodecArgs& a, const BlockDesc& d, const RingLook& r, uint32_t slot, uint32_t seq)
+{
+    if (r.evict_flags && r.their_slot == slot) atomicAnd(r.evict_flags, ~2u);      // still pointing here: the page leaves L2
+    a.ring_owner[slot] = (static_cast<uint64_t>(d.row) << 32) | d.page;
+    if (!r.d_flags) return;
+    r.d_slot[d.page] = slot;
+    r.h_slot[d.page] = seq;
+    atomicOr(&r.d_flags[d.page], 2u);
 }
 
 template <int SCHEME, int MODE, bool F32, int EXT, bool FLAT>
@@ -674,12 +725,18 @@ __device__ __forceinline__ void fetch_decompress_body(const CodecArgs& a)
     uint64_t i = a.wave_step ? gw : gw * per_wave;
     uint64_t end = a.wave_step ? n : ((i + per_wave < n) ? i + per_wave : n);
     if (i >= n) return;
-    BlockDesc cur = load_desc<EXT>(a, i, slot0);
+    const bool ring = EXT == 2 && a.ring_owner;                          // (launch-uniform)
+    RingLook look{};
+    BlockDesc cur{};
+    if (!ring) cur = load_desc<EXT>(a, i, slot0);
     for (;;) {
-        // the next block's descriptor is fetched while this block is decoded
+        // the next block's descriptor is fetched while this block is decoded (ring form: in front of its own decode,
+        // these launches are short and wait on one block's chain of loads, not on throughput -- and inside the loop:
+        // a load issued in front of it is waited for there, whatever uses it)
+        if (ring) cur = load_desc_ring(a, i, slot0, look);
         const uint64_t nx = i + step;
         BlockDesc nxt = cur;
-        if (nx < end) nxt = load_desc<EXT>(a, nx, slot0);
+        if (nx < end && !ring) nxt = load_desc<EXT>(a, nx, slot0);
         uint32_t len = cur.len;
         if (SCHEME == kInt8DeltaRle) {
             if (len > 2u * kBlockElems) len = 2u * kBlockElems;
@@ -702,7 +759,7 @@ __device__ __forceinline__ void fetch_decompress_body(const CodecArgs& a)
             decode_fp16<F32>(cur.rec, len, cur.dst, lane);
         }
         if (lane == 0u) {
-            if (EXT == 2 && a.ring_owner) ring_note(a, cur, slot0 + static_cast<uint32_t>(i), seq0 + static_cast<uint32_t>(i));
+            if (ring) ring_note(a, cur, look, slot0 + static_cast<uint32_t>(i), seq0 + static_cast<uint32_t>(i));
             else if (EXT == 3) *a.host_words[i] = seq0 + static_cast<uint32_t>(i);
             else if (a.flags) atomicOr(&a.flags[cur.page], a.set_flags);   // neighbours belong to other waves / XCDs
         }
@@ -712,7 +769,9 @@ __device__ __forceinline__ void fetch_decompress_body(const CodecArgs& a)
     }
     if (EXT == 2 && a.done_flag) {                                      // (launch-uniform; one block per wave: n waves had work)
         __threadfence_system();                                          // the page, its residency words and the host-visible word are out
-        if (lane == 0u && atomicAdd(a.done_count, 1u) + 1u == static_cast<uint32_t>(n)) {
+        if (n == 1u) {                                                   // the lone wave has nobody to count
+            if (lane == 0u) __hip_atomic_store(a.done_flag, a.done_token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else if (lane == 0u && atomicAdd(a.done_count, 1u) + 1u == static_cast<uint32_t>(n)) {
             *a.done_count = 0u;
             __hip_atomic_store(a.done_flag, a.done_token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -2401,6 +2460,7 @@ hipError_t launch_dec2(const CodecArgs& a_in, hipStream_t s)
     a.wave_step = (round_strided() && a.per_wave > 1) ? static_cast<uint64_t>(grid) * kWaves : 0;
     const int ext = a.host_words ? 3 : (a.alloc_list || a.ring_owner) ? 2 : a.stripe_n ? 1 : 0;
     if (ext == 2 && a.stripe_n) return hipErrorInvalidValue;
+    if (a.ring_owner && a.alloc_list) return hipErrorInvalidValue;      // the ring form reads one allocation's row (load_desc_ring)
     if (a.done_flag && (ext != 2 || a.per_wave > 1 || a.n_dev || !a.done_count)) return hipErrorInvalidValue;
     if (ext == 3 && (a.out_f32 || a.alloc_list || a.ring_owner || a.stripe_n || !a.seq0_dev || !a.data_list)) return hipErrorInvalidValue;
 #define SPECKV_LAUNCH_DEC(F32, EXT) \
