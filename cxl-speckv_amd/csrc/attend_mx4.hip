@@ -341,9 +341,6 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
         auto tile_body = [&](uint32_t tile, auto buf_c) {
             constexpr uint32_t buf = decltype(buf_c)::value;
             const uint8_t* st = lptr + buf * kStage;
-#ifdef MX4_LOCKSTEP
-            __builtin_amdgcn_s_barrier();           // (experiment: the four waves of a workgroup ask for the same tile's pieces at the same time)
-#endif
             // ---- K of this tile has landed (younger requests: V of this tile, K and V of the next): both heads' blocks and codes
             // to registers, and the region goes straight back to the DMA for the next-but-one tile
             if (FORM != 2) wait_all_but<10u * kStages - 5u>();

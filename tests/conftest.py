@@ -37,3 +37,14 @@ def reference():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+# Seeds of the samples the full-size tests drew this run (tests/test_gpu_full_size.py: sample_seed): printed at the end of
+# EVERY run, passing or not, so that a run can be repeated with SPECKV_SAMPLE_SEED=<seed>.
+SAMPLE_SEEDS = []
+
+
+def pytest_terminal_summary(terminalreporter):
+    if SAMPLE_SEEDS:
+        terminalreporter.write_line("full-size sample seeds (SPECKV_SAMPLE_SEED=<seed> repeats one): "
+                                    + ", ".join(f"{name}={seed}" for name, seed in SAMPLE_SEEDS))

@@ -89,10 +89,14 @@ class HeadChecker:
 
 def sample_seed():
     """Which layers / heads / sequences the full-size tests check against the oracle rotates from run to run (the edge cases stay):
-    SPECKV_SAMPLE_SEED pins it; the seed in use is part of every assertion message of these tests."""
+    SPECKV_SAMPLE_SEED pins it; the seed in use is part of every assertion message of these tests and is printed in the
+    run's terminal summary whether the test passes or not (tests/conftest.py)."""
     import time
     env = os.environ.get("SPECKV_SAMPLE_SEED")
-    return int(env) if env else int(time.time_ns() // 1_000_000) % (2 ** 31)
+    seed = int(env) if env else int(time.time_ns() // 1_000_000) % (2 ** 31)
+    from conftest import SAMPLE_SEEDS
+    SAMPLE_SEEDS.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0], seed))
+    return seed
 
 
 @pytest.mark.parametrize("scheme", [3, 4])
