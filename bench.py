@@ -1591,14 +1591,14 @@ def run_extras(torch, pkg, lib, src, dst, n_blocks, sp):
         return a.elapsed_time(b) / reps
 
     for scheme, mode, name in ((0, 0, "fp16_copy"), (1, 0, "int8_ref_exact"), (2, 0, "rle_ref_exact"), (2, 1, "rle_intent"),
-                               (3, 0, "int4_g32"), (4, 0, "fp8_e4m3")):
-        stride = {1: 2048, 3: 1152, 4: 2048}.get(scheme, PAGE)
+                               (3, 0, "int4_g32"), (4, 0, "fp8_e4m3"), (5, 0, "mxfp4")):
+        stride = {1: 2048, 3: 1152, 4: 2048, 5: 1152}.get(scheme, PAGE)
         enc = lambda: raw.speckv_ext_codec_compress(src.data_ptr(), n_blocks, recs.data_ptr(), stride, lens.data_ptr(), scales.data_ptr(), scheme, mode, sp)
         dec = lambda: raw.speckv_ext_codec_decompress(recs.data_ptr(), stride, lens.data_ptr(), scales.data_ptr(), n_blocks, dst.data_ptr(), 0, scheme, mode, sp)
         enc_ms = timed(enc)
         dec_ms = timed(dec)
         comp = int(lens.to(torch.int64).sum().item())
-        dec_bytes = comp + n_blocks * ((0 if scheme == 3 else 4) + PAGE)
+        dec_bytes = comp + n_blocks * ((0 if scheme in (3, 5) else 4) + PAGE)
         enc_bytes = n_blocks * PAGE + comp + n_blocks * 8
         # the same blocks decoded to fp32, the reference's own output type (FPGACacheEngine::decompress returns floats): 8 KiB written per block
         if dst32 is not None:

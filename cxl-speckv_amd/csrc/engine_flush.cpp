@@ -283,7 +283,7 @@ int Engine::flush_group(int scheme, const uint32_t* const cols[5], uint32_t n, u
     for (int c = 0; c < 5; ++c) memcpy(static_cast<uint32_t*>(staged) + static_cast<size_t>(c) * n, cols[c], n * sizeof(uint32_t));
     // The columns are pulled over by a copy KERNEL on the flush's stream (16 bytes per lane from the pinned slot): a copy
     // engine's upload cost 9 us plus a 12 us cross-engine dependency in front of the first flush kernel -- 8 192 requests
-    // 0.102 -> 0.094 ms until landed, 20 480 requests unchanged (SPECKV_FLUSH_UPLOAD=copy for the A/B).
+    // 0.102 -> 0.094 ms until landed, 20 480 requests unchanged (the copy-engine form is gone: DESIGN_HISTORY.md).
     HIP_TRY(upload_pinned(buf, staged, up, stream_));
     HIP_TRY(hipEventRecord(req_stage_ev_[slot], stream_));
 

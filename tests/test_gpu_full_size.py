@@ -48,6 +48,9 @@ class HeadChecker:
         self.scales, self.lens, self.recs = oracle.compress_blocks_f16(region_pages16, scheme, 0)
         if scheme == 3:
             self.dec = oracle.decompress_blocks_f16(self.recs, self.lens, self.scales, 3, 0).reshape(-1, 2, H, D)
+        elif scheme == 5:
+            self.lut = np.array([oracle.lib.orc_e4m3_to_f32(b) for b in range(256)], np.float64)
+            self.lut[np.isnan(self.lut)] = 0.0
         else:
             self.lut = np.array([oracle.lib.orc_e4m3_to_f32(b) for b in range(256)], np.float32)
             self.lut[np.isnan(self.lut)] = 0.0
@@ -66,6 +69,17 @@ class HeadChecker:
             L.orc_attend_f16(_ptr(np.ascontiguousarray(q_head).view(np.uint16).reshape(-1), u16p), G, _ptr(k16.reshape(-1), u16p),
                              _ptr(v16.reshape(-1), u16p), npos, D, float(sm), _ptr(o, f32p), _ptr(l, f32p), _ptr(m, f32p))
             return o, l, m, 0.0
+        if self.scheme == 5:                                         # MXFP4: page rows of one head + their codes (tests/test_gpu_mx4.py)
+            from tests.test_gpu_mx4 import head_rows, dequant_rows
+            kr, kc = head_rows(self.recs, 0, npos, head)
+            vr, vc = head_rows(self.recs, hp, npos, head)
+            q8 = np.zeros((G, D), np.uint8); qc = np.zeros((G, D // 16), np.uint8)
+            L.orc_quantize_rows_mxfp8(_ptr(np.ascontiguousarray(q_head).view(np.uint16).reshape(-1), u16p), G, D, 16, _ptr(q8, u8p), _ptr(qc, u8p))
+            qd = self.lut[q8] * np.repeat(np.exp2(qc.astype(np.float64) - 127.0), 16, axis=1)
+            delta = 3e-5 * float((np.abs(qd) @ np.abs(dequant_rows(kr, kc, npos)).T).max()) * sm
+            L.orc_attend_mx4(_ptr(q8, u8p), _ptr(qc, u8p), 16, G, _ptr(kr, u8p), _ptr(kc, u8p), _ptr(vr, u8p), _ptr(vc, u8p), npos, D,
+                             float(sm), _ptr(o, f32p), _ptr(l, f32p), _ptr(m, f32p))
+            return o, l, m, delta
         r4 = self.recs[:, :N].reshape(-1, 2, H, D)
         krows = np.ascontiguousarray(r4[:hp, :, head, :].reshape(-1, D)[:npos])
         vrows = np.ascontiguousarray(r4[hp:2 * hp, :, head, :].reshape(-1, D)[:npos])
@@ -99,10 +113,10 @@ def sample_seed():
     return seed
 
 
-@pytest.mark.parametrize("scheme", [3, 4])
+@pytest.mark.parametrize("scheme", [3, 4, 5])
 def test_config5_70b_shaped_32k_context_at_full_size(eng, oracle, scheme):
-    """BASELINE configs[4]: 80 layers x 32 768 positions x 8 kv heads x 128 in INT4_G32 (3.0 GB of records) or
-    FP8_E4M3 (5.4 GB): one launch over all layers in the default geometry (the code that only runs at this size: 256-tile
+    """BASELINE configs[4]: 80 layers x 32 768 positions x 8 kv heads x 128 in INT4_G32 (3.0 GB of records),
+    FP8_E4M3 (5.4 GB) or MXFP4 (2.9 GB): one launch over all layers in the default geometry (the code that only runs at this size: 256-tile
     splits, split counts rounded to a multiple of 8, the merge over many splits), the page-table form of the same, a
     per-layer call, and sampled pages through fetch + decompress."""
     torch = torch_mod()
@@ -125,7 +139,7 @@ def test_config5_70b_shaped_32k_context_at_full_size(eng, oracle, scheme):
     q = (torch.randn((L, H, G, D), generator=gq, device="cuda") * 1.5).to(torch.float16)
     qh = q.cpu().numpy()
     sm = 1.0 / np.sqrt(D)
-    attend = lib.attend_int4 if scheme == 3 else lib.attend_fp8
+    attend = {3: lib.attend_int4, 4: lib.attend_fp8, 5: lib.attend_mx4}[scheme]
     checkers = {layer: HeadChecker(oracle, scheme, pages, T) for layer, pages in sampled.items()}
     mh = int(srng.integers(0, H))
     heads = {0: tuple(int(v) for v in srng.choice(H, 2, replace=False)), mid: (mh,), 79: (7, int(srng.integers(0, 7)))}
@@ -141,7 +155,7 @@ def test_config5_70b_shaped_32k_context_at_full_size(eng, oracle, scheme):
             set_tuning("attend_general", 0)
         return out.cpu().numpy(), lse.cpu().numpy()
 
-    for general in (0, 1, 2):
+    for general in ((0, 2) if scheme == 5 else (0, 1, 2)):          # MXFP4 has one page-table form
         out, lse = run(general)
         assert np.isfinite(out).all() and np.isfinite(lse).all()
         for layer, hs in heads.items():
@@ -174,7 +188,7 @@ def test_config5_70b_shaped_32k_context_at_full_size(eng, oracle, scheme):
     lib.free(h)
 
 
-@pytest.mark.parametrize("scheme", [3, 4])
+@pytest.mark.parametrize("scheme", [3, 4, 5])
 def test_config4_decode_step_256_sequences_8k_context(eng, oracle, scheme):
     """BASELINE configs[3]'s decode step on the config-5 formats: 256 sequences (one allocation each, 8 192 positions
     of two layers), lengths from empty to full, the batch form and the planned form of the fused attention against the
@@ -218,7 +232,7 @@ def test_config4_decode_step_256_sequences_8k_context(eng, oracle, scheme):
             for head in check_heads:
                 c.check(out[i, head], lse[i, head], qh[i, head], head, lens[i], sm, (what, i, head, "sample seed", seed))
 
-    batch = lib.attend_int4_batch if scheme == 3 else lib.attend_fp8_batch
+    batch = {3: lib.attend_int4_batch, 4: lib.attend_fp8_batch, 5: lib.attend_mx4_batch}[scheme]
     out = torch.full((NSEQ, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
     lse = torch.full((NSEQ, H, G), float("nan"), dtype=torch.float32, device="cuda")
     batch(handles, layer, q.data_ptr(), G, lens, sm, out.data_ptr(), lse.data_ptr())
@@ -240,7 +254,7 @@ def test_config4_decode_step_256_sequences_8k_context(eng, oracle, scheme):
 
 
 @pytest.mark.parametrize("T", [1024, 2048])
-@pytest.mark.parametrize("scheme", [3, 4])
+@pytest.mark.parametrize("scheme", [3, 4, 5])
 def test_short_context_decode_step_256_sequences(eng, oracle, scheme, T):
     """The same decode step at SHORT contexts (256 sequences x 1k / 2k positions, one layer each): the shapes where a launch's
     fixed part weighs most and the batch forms differ most from the long-context ones (INT4: the two-halves workgroups with 16- and
@@ -283,7 +297,7 @@ def test_short_context_decode_step_256_sequences(eng, oracle, scheme, T):
             for head in check_heads:
                 c.check(out[i, head], lse[i, head], qh[i, head], head, lens[i], sm, (what, T, i, head, "sample seed", seed))
 
-    batch = lib.attend_int4_batch if scheme == 3 else lib.attend_fp8_batch
+    batch = {3: lib.attend_int4_batch, 4: lib.attend_fp8_batch, 5: lib.attend_mx4_batch}[scheme]
     out = torch.full((NSEQ, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
     lse = torch.full((NSEQ, H, G), float("nan"), dtype=torch.float32, device="cuda")
     batch(handles, 0, q.data_ptr(), G, lens, sm, out.data_ptr(), lse.data_ptr())
