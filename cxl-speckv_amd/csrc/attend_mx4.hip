@@ -149,6 +149,10 @@ __device__ __forceinline__ float q_clean(uint32_t half_bits)
 // FORM 1: striped regularly over 2..8 pools (AttendArgs::stripe_bases)
 // FORM 2: no regular placement, or a last tile that would leave the layer's region: every record address from its page-table
 //         entry, clamped to the range (never-written pages read the zero page); staged through registers, one tile at a time
+// FORM 3: FORM 0 as a STREAM (AttendArgs::stream, many layers of one sequence; see k_attend_int4_wg8): the launch's tiles in
+//         layer-major order are cut into n_wgs equal pieces, one per workgroup = one per CU.  80 layers x 3 splits of the fixed
+//         grid fill 240 of 256 CUs; 256 pieces of 320 tiles fill them all.  Across a layer boundary the DMA pipeline goes on, the
+//         finished layer's partial is stored and the next layer's query rows are loaded.  grid (n_wgs, 1, query-row groups).
 // grid (splits, rows [, query-row groups of 8]); a workgroup = 4 waves = the 8 kv heads.
 template <int FORM>
 __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_eu(kStages > 2u ? 1 : 2, kStages > 2u ? 1 : 2))) void k_attend_mx4(AttendArgs a)
@@ -161,12 +165,25 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
     const uint32_t c = lane & 15u, kb = lane >> 4;
     const uint32_t w = c >> 3, ql = c & 7u;                              // this lane's column: position parity w, query row ql of the group
     const uint32_t q = blockIdx.z * 8u + ql;                             // query row inside the kv head's g rows
+    constexpr bool STREAM = FORM == 3;
     const uint32_t split = blockIdx.x;
     uint32_t layer = blockIdx.y;                                         // batch form: the sequence index
+    // stream form: this workgroup's piece = `count` tiles from tile `ct` of layer `layer` on; its partial of that layer is the
+    // layer's slot-th (slots count from the piece that holds the layer's first tile)
+    uint32_t ct = 0u, count = 0u, slot = 0u;
+    if (STREAM) {
+        const uint32_t nt = (a.n_pages + 15u) / 16u;
+        const uint64_t g0 = attend_stream_begin(blockIdx.x, a.stream.len, a.stream.rem), g1 = attend_stream_begin(blockIdx.x + 1u, a.stream.len, a.stream.rem);
+        layer = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(g0 / nt));                 // (the divisions run in the vector ALU)
+        ct = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(g0 - static_cast<uint64_t>(layer) * nt));
+        count = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(g1 - g0));
+        slot = __builtin_amdgcn_readfirstlane(blockIdx.x - attend_stream_wg_of(static_cast<uint64_t>(layer) * nt, a.stream.len, a.stream.rem));
+    }
     const uint32_t h0 = wave * 2u;                                       // first of this wave's two kv heads
-    const uint64_t row0 = static_cast<uint64_t>(layer) * a.heads + h0;   // query / output row block of head 0 (head 1: + 1)
+    uint64_t row0 = static_cast<uint64_t>(layer) * a.heads + h0;         // query / output row block of head 0 (head 1: + 1)
     uint64_t part0 = row0 * a.n_splits + split, part_step = a.n_splits;  // partials of head 0 | head 1: part0, part0 + part_step
     uint32_t my_splits = a.n_splits;
+    if (STREAM) { part0 = row0 * a.stream.max_slots + slot; part_step = a.stream.max_slots; my_splits = 0u; }      // (never the direct output)
     if (a.seqs) {                                                        // workgroup-uniform: per-sequence geometry
         const AttendSeq sq = a.seqs[layer];
         if (split >= sq.n_splits) {
@@ -200,14 +217,53 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
     }
 
     const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
-    const uint32_t t0 = split * a.tiles_per_split;
-    const uint32_t t1 = min(t0 + a.tiles_per_split, n_tiles);
+    const uint32_t t0 = STREAM ? 0u : split * a.tiles_per_split;         // (stream: positions in the piece, 0 .. count)
+    const uint32_t t1 = STREAM ? count : min(t0 + a.tiles_per_split, n_tiles);
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
     f32x4 acc[2][8];
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
         for (int s = 0; s < 8; ++s) acc[hh][s] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // ---- the two parities of a query row are added; the lanes of parity 0 write the partial (or, single split: the final) result
+    auto store_rows = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const float l_half = sum_over_kb(l_run[hh]);
+            const float l_tot = l_half + other_parity(l_half);
+            f32x4 o[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[s][r] = acc[hh][s][r] + other_parity(acc[hh][s][r]);
+            if (w != 0u || q >= a.g) continue;
+            const uint64_t row = row0 + hh;
+            if (a.direct_out && (!a.direct_per_seq || my_splits == 1u)) {
+                const float ws = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+                float* dst = a.direct_out + (row * a.g + q) * 128u + 32u * kb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    *reinterpret_cast<f32x4*>(dst + 8 * r) = f32x4{o[0][r], o[1][r], o[2][r], o[3][r]} * ws;
+                    *reinterpret_cast<f32x4*>(dst + 8 * r + 4) = f32x4{o[4][r], o[5][r], o[6][r], o[7][r]} * ws;
+                }
+                if (a.direct_lse && kb == 0)
+                    a.direct_lse[row * a.g + q] = l_tot > 0.0f ? (m_run[hh] + log2f(l_tot)) * 0.6931471805599453f : -INFINITY;
+                continue;
+            }
+            const uint64_t part = part0 + hh * part_step;
+            if (kb == 0) {
+                a.part_ml[part * 32u + q] = m_run[hh];
+                a.part_ml[part * 32u + 16u + q] = l_tot;
+            }
+            float* dst = a.part_acc + (part * 16u + q) * 128u + 32u * kb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                *reinterpret_cast<f32x4*>(dst + 8 * r) = f32x4{o[0][r], o[1][r], o[2][r], o[3][r]};
+                *reinterpret_cast<f32x4*>(dst + 8 * r + 4) = f32x4{o[4][r], o[5][r], o[6][r], o[7][r]};
+            }
+        }
+    };
 
     if (t0 < t1) {                                                       // wave-uniform
         const uint32_t lbase = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&lds[wave][0])));
@@ -227,13 +283,25 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
             const uint8_t* r = reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(e.x) | (static_cast<uint64_t>(e.y) << 32));
             return e.z >= kMx4RecBytes ? r : a.zero_page;
         };
+        // stream form: the next tile each region (K, V) will ask for -- its first page, its tile number in the layer, tiles left
+        // in the piece; the requests run ahead of the arithmetic across layer boundaries, a request past the piece repeats the last
+        uint32_t rq_page[2] = {kfirst + 16u * ct, vfirst + 16u * ct}, rq_ct[2] = {ct, ct}, rq_left[2] = {count, count};
+        const uint32_t layer_gap = static_cast<uint32_t>(a.layer_stride) - 16u * n_tiles;   // from the end of one layer's region to the next one's start
         // one region's share of a tile (rg = 0: K rows + K codes, 1: V rows + V codes) into stage `buf`: 5 DMA instructions
-        auto stage = [&](uint32_t tt, uint32_t buf, uint32_t rg) {
+        auto stage = [&](uint32_t tt, uint32_t buf, uint32_t rg) __attribute__((always_inline)) {
             const uint32_t tc = min(tt, last);
             const uint32_t dst = lbase + buf * kStage;
             const uint32_t first = rg ? vfirst : kfirst;
             const uint32_t drows = dst + (rg ? kStV : kStK), dcodes = dst + (rg ? kStVC : kStKC);
-            if (FORM == 0) {
+            if (STREAM) {
+                const uint8_t* rt = uniform_ptr(a.lin_base + static_cast<uint64_t>(rq_page[rg]) * kRec);    // (wave-uniform by construction)
+                dma_region(drows, dcodes, rt, goff, goffc);
+                if (rq_left[rg] > 1u) {
+                    --rq_left[rg];
+                    rq_page[rg] += 16u;
+                    if (++rq_ct[rg] == n_tiles) { rq_ct[rg] = 0u; rq_page[rg] += layer_gap; }
+                }
+            } else if (FORM == 0) {
                 const uint8_t* rt = a.lin_base + (static_cast<uint64_t>(first) + 16ull * tc) * kRec;      // (scalar)
                 dma_region(drows, dcodes, rt, goff, goffc);
             } else if (FORM == 1) {
@@ -266,7 +334,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
         // (gq = 0..3) of query row q of both heads; operand [head][half hf] bytes 0..15 <- gq = 2 hf, bytes 16..31 <- gq = 2 hf + 1
         v8i QB[2][2];
         int q_code[2][2];
-        {
+        auto load_query = [&]() __attribute__((always_inline)) {
             const bool live = q < a.g;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
@@ -317,7 +385,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
                     q_code[hh][hf] = static_cast<int>((kb >> 1) ? s1 : s0);
                 }
             }
-        }
+        };
+        load_query();
         // ---- where the lane reads its operands in a stage
         uint32_t rk[2][2], rkc[2][2], rv[2][4], rvc[2][4];
 #pragma unroll
@@ -338,7 +407,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
         const uint32_t n_pos = 2u * a.n_pages, skip_pos = 2u * a.skip_pages;
         const uint32_t wshift = 16u * w;
         // one tile out of stage BUF (a compile-time constant: the LDS reads then carry the stage as an immediate offset)
-        auto tile_body = [&](uint32_t tile, auto buf_c) {
+        auto tile_body = [&](uint32_t tile, auto buf_c) __attribute__((always_inline)) {
             constexpr uint32_t buf = decltype(buf_c)::value;
             const uint8_t* st = lptr + buf * kStage;
             // ---- K of this tile has landed (younger requests: V of this tile, K and V of the next): both heads' blocks and codes
@@ -444,6 +513,40 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
         if (FORM == 2) {
 #pragma unroll 1
             for (uint32_t tile = t0; tile < t1; ++tile) tile_body(tile, std::integral_constant<uint32_t, 0u>{});
+        } else if (STREAM) {
+            // the piece, tile by tile; at the end of a layer its partial goes out, the state starts over and the next layer's query
+            // rows come in (their loads are the compiler's: it waits for everything in flight once, a pipeline fill per boundary)
+            uint32_t done = 0u;
+            auto next = [&]() __attribute__((always_inline)) -> bool {
+                if (++done == count) return true;
+                if (++ct == n_tiles) {
+                    store_rows();
+                    ct = 0u;
+                    ++layer;
+                    row0 += a.heads;
+                    part0 = row0 * a.stream.max_slots;                    // this piece holds the new layer's first tile: slot 0
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        m_run[hh] = -INFINITY;
+                        l_run[hh] = 0.0f;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) acc[hh][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    }
+                    load_query();
+                }
+                return false;
+            };
+#pragma unroll 1
+            for (;;) {
+                tile_body(ct, std::integral_constant<uint32_t, 0u>{});
+                if (next()) break;
+                tile_body(ct, std::integral_constant<uint32_t, 1u>{});
+                if (next()) break;
+                if (kStages > 2u) {
+                    tile_body(ct, std::integral_constant<uint32_t, (kStages > 2u ? 2u : 0u)>{});
+                    if (next()) break;
+                }
+            }
         } else {
 #pragma unroll 1
             for (uint32_t tile = t0; tile < t1; tile += kStages) {
@@ -458,42 +561,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
         }
         if (FORM != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-requested tail tiles: nothing may land after the wave ends
     }
-    // ---- the two parities of a query row are added; the lanes of parity 0 write the partial (or, single split: the final) result
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        const float l_half = sum_over_kb(l_run[hh]);
-        const float l_tot = l_half + other_parity(l_half);
-        f32x4 o[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[s][r] = acc[hh][s][r] + other_parity(acc[hh][s][r]);
-        if (w != 0u || q >= a.g) continue;
-        const uint64_t row = row0 + hh;
-        if (a.direct_out && (!a.direct_per_seq || my_splits == 1u)) {
-            const float ws = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
-            float* dst = a.direct_out + (row * a.g + q) * 128u + 32u * kb;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                *reinterpret_cast<f32x4*>(dst + 8 * r) = f32x4{o[0][r], o[1][r], o[2][r], o[3][r]} * ws;
-                *reinterpret_cast<f32x4*>(dst + 8 * r + 4) = f32x4{o[4][r], o[5][r], o[6][r], o[7][r]} * ws;
-            }
-            if (a.direct_lse && kb == 0)
-                a.direct_lse[row * a.g + q] = l_tot > 0.0f ? (m_run[hh] + log2f(l_tot)) * 0.6931471805599453f : -INFINITY;
-            continue;
-        }
-        const uint64_t part = part0 + hh * part_step;
-        if (kb == 0) {
-            a.part_ml[part * 32u + q] = m_run[hh];
-            a.part_ml[part * 32u + 16u + q] = l_tot;
-        }
-        float* dst = a.part_acc + (part * 16u + q) * 128u + 32u * kb;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            *reinterpret_cast<f32x4*>(dst + 8 * r) = f32x4{o[0][r], o[1][r], o[2][r], o[3][r]};
-            *reinterpret_cast<f32x4*>(dst + 8 * r + 4) = f32x4{o[4][r], o[5][r], o[6][r], o[7][r]};
-        }
-    }
+    store_rows();
 }
 
 // a.lin_base set: linear form; else a.stripe_bases: striped; else a.table_form: page-table form.  Writes the final rows itself
@@ -502,19 +570,22 @@ hipError_t launch_attend_mx4(const AttendArgs& a, uint32_t n_rows, float* d_out,
 {
     if (n_rows == 0 || a.n_splits == 0 || a.heads != 8u) return a.heads != 8u ? hipErrorInvalidValue : hipSuccess;
     if (!a.seqs && a.n_pages == 0) return hipSuccess;
-    const int form = a.lin_base ? 0 : a.stripe_bases ? 1 : a.table_form ? 2 : -1;
-    if (form < 0) return hipErrorInvalidValue;
-    const dim3 grid(a.n_splits, n_rows, (a.g + 7u) / 8u), block(64 * kWavesPerWg);
+    const int form = a.lin_base ? (a.stream.n_wgs ? 3 : 0) : a.stripe_bases ? 1 : a.table_form ? 2 : -1;
+    if (form < 0 || (a.stream.n_wgs && (form != 3 || a.seqs || (a.n_pages & 15u) || a.skip_pages))) return hipErrorInvalidValue;
+    const dim3 grid = form == 3 ? dim3(a.stream.n_wgs, 1u, (a.g + 7u) / 8u) : dim3(a.n_splits, n_rows, (a.g + 7u) / 8u);
+    const dim3 block(64 * kWavesPerWg);
     constexpr size_t lds_bytes = static_cast<size_t>(kWavesPerWg) * kStages * kStage;
     static const hipError_t attr = [] {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         return e;
     }();
     if (attr != hipSuccess) return attr;
     if (form == 0) hipLaunchKernelGGL(k_attend_mx4<0>, grid, block, lds_bytes, s, a);
     else if (form == 1) hipLaunchKernelGGL(k_attend_mx4<1>, grid, block, lds_bytes, s, a);
+    else if (form == 3) hipLaunchKernelGGL(k_attend_mx4<3>, grid, block, lds_bytes, s, a);
     else hipLaunchKernelGGL(k_attend_mx4<2>, grid, block, lds_bytes, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

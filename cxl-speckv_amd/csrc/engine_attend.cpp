@@ -742,12 +742,28 @@ int Engine::attend_mx4(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     want = std::min(want, std::max(1u, n_tiles / min_tiles));
     if (tuning().attend_splits > 0) want = static_cast<uint32_t>(tuning().attend_splits);
     const EvenSplit es = even_split(n_tiles, std::max(1u, std::min(want, 2048u)));
-    const uint32_t n_splits = es.n_splits, tiles_per_split = es.tiles_per_split;
+    AttendArgs k{};
+    // several layers of one long sequence: the stream form -- all tiles of the call in layer-major order cut into one equal piece
+    // per CU (80 layers x 3 splits of the fixed grid occupy 240 CUs of 256; profiles/r05_mx4.txt)
+    const uint32_t zgroups = (g + 7u) / 8u;
+    const uint64_t total_tiles = static_cast<uint64_t>(n_layers) * n_tiles;
+    const int32_t stream_knob = tuning().attend_stream;                  // N > 0: that many pieces (tests cut small calls oddly), -1: never
+    const uint32_t stream_wgs = stream_knob > 0 ? static_cast<uint32_t>(stream_knob) : cus() / zgroups;
+    const bool stream = linear && n_layers >= 2u && (n_pages & 15u) == 0u && tuning().attend_splits <= 0 && stream_wgs >= 1u &&
+                        total_tiles >= stream_wgs && total_tiles / stream_wgs <= 0xFFFFFFFFull &&
+                        (stream_knob > 0 || (stream_knob == 0 && total_tiles >= 16ull * stream_wgs));
+    if (stream) {
+        k.stream.n_wgs = stream_wgs;
+        k.stream.len = static_cast<uint32_t>(total_tiles / stream_wgs);
+        k.stream.rem = static_cast<uint32_t>(total_tiles % stream_wgs);
+        k.stream.max_slots = 1;
+        for (uint32_t l = 0; l < n_layers; ++l) k.stream.max_slots = std::max(k.stream.max_slots, attend_stream_count(l, n_tiles, k.stream.len, k.stream.rem));
+    }
+    const uint32_t n_splits = stream ? k.stream.max_slots : es.n_splits, tiles_per_split = es.tiles_per_split;       // (stream: slots per row)
     const size_t acc_bytes = static_cast<size_t>(rows) * n_splits * 16 * 128 * sizeof(float);
     const size_t ml_bytes = static_cast<size_t>(rows) * n_splits * 32 * sizeof(float);
     uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes, s));
     if (!buf) return SPECKV_ERR_NOMEM;
-    AttendArgs k{};
     k.entries = a->d_entries;
     k.k_first = k_first;
     k.v_first = v_first;
@@ -769,7 +785,7 @@ int Engine::attend_mx4(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     k.zero_page = d_zero_page_;
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
-    if (n_splits == 1u) { k.direct_out = d_out; k.direct_lse = d_lse; }      // no merge launch
+    if (n_splits == 1u && !stream) { k.direct_out = d_out; k.direct_lse = d_lse; }      // no merge launch
     HIP_TRY(launch_attend_mx4(k, n_layers, d_out, d_lse, st));
     note_use(a, s);
     if (!s) RC_TRY(wait_stream());

@@ -13,6 +13,7 @@ const Key kKeys[] = {
     {"attend_splits", "SPECKV_ATTEND_SPLITS", &Tuning::attend_splits},
     {"attend_tiles_per_split", "SPECKV_ATTEND_TILES_PER_SPLIT", &Tuning::attend_tiles_per_split},
     {"attend_general", "SPECKV_ATTEND_GENERAL", &Tuning::attend_general},
+    {"attend_stream", "SPECKV_ATTEND_STREAM", &Tuning::attend_stream},
     {"tc_multipass", "SPECKV_TC_MULTIPASS", &Tuning::tc_multipass},
     {"tc_scan", "SPECKV_TC_SCAN", &Tuning::tc_scan},
     {"tc_no_pre", "SPECKV_TC_NO_PRE", &Tuning::tc_no_pre},

@@ -176,6 +176,31 @@ def test_mx4_fused_attention(eng, oracle, g):
     for layer in range(L):
         want, wlse, mag, delta = oracle_attention(oracle, recs, q[layer], T, layer, 0, T, sm, g)
         check(multi[layer].cpu().numpy(), mlse[layer].cpu().numpy(), want, wlse, mag, delta, (g, "multi", layer))
+    # the STREAM form of the same call (what 80 layers x 32k take by themselves): the 48 tiles of the three layers cut into 5, 7 and
+    # 48 pieces -- pieces that cross one and two layer boundaries, layers of 1 .. 16 partials -- and a range that does not start at 0
+    sout = torch.empty_like(multi); slse = torch.empty_like(mlse)
+    pout = torch.empty_like(multi); plse = torch.empty_like(mlse)
+    for pieces, (pb, pe) in ((5, (0, T)), (7, (0, T)), (48, (0, T)), (2, (0, T)), (5, (64, 512)), (3, (0, 64))):
+        set_tuning("attend_stream", pieces)
+        try:
+            sout.fill_(float("nan")); slse.fill_(float("nan"))
+            lib.attend_mx4(h, 0, L, d_q.data_ptr(), g, pb, pe, sm, sout.data_ptr(), slse.data_ptr())
+            torch.cuda.synchronize()
+        finally:
+            set_tuning("attend_stream", 0)
+        if (pb, pe) == (0, T):
+            for layer in range(L):
+                want, wlse, mag, delta = oracle_attention(oracle, recs, q[layer], T, layer, pb, pe, sm, g)
+                check(sout[layer].cpu().numpy(), slse[layer].cpu().numpy(), want, wlse, mag, delta, (g, "stream", pieces, pb, pe, layer))
+        else:
+            # other ranges: against the per-layer calls of the fixed-grid form (same arithmetic, another order of summation; the
+            # oracle's bound for the row with the 470 in it is met by a hair's breadth on ranges that leave out the first positions)
+            for layer in range(L):
+                lib.attend_mx4(h, layer, 1, d_q[layer].data_ptr(), g, pb, pe, sm, pout[layer].data_ptr(), plse[layer].data_ptr())
+            torch.cuda.synchronize()
+            a_, b_ = sout.cpu().numpy(), pout.cpu().numpy()
+            assert np.all(np.abs(a_ - b_) <= 2e-3 * np.abs(b_).max(axis=-1, keepdims=True) + 1e-6), (g, "stream vs per-layer", pieces, pb, pe)
+            assert np.all(np.abs(slse.cpu().numpy() - plse.cpu().numpy()) <= 1e-4), (g, "stream lse", pieces, pb, pe)
     # a range whose last 32-position tile would leave the layer's region takes the page-table form
     d_out = torch.empty((H, g, D), dtype=torch.float32, device="cuda")
     lib.attend_mx4(h, 1, 1, d_q[1].data_ptr(), g, 30, 512, sm, d_out.data_ptr())
