@@ -1449,7 +1449,8 @@ def striped_attention_extra(torch, pkg, T=32768, Lyr=80):
     tile ahead.  (The per-wave page-table kernels of rounds 1-3 are retired: INT4 has none left, FP8 keeps one for layouts
     without a scale table.)"""
     out = {}
-    for scheme, name, fn in ((3, "int4", int4_attention_extra), (4, "fp8", fp8_scores_extra)):
+    mx4 = lambda torch_, kv_, T_, L_: int4_attention_extra(torch_, kv_, T_, L_, scheme=5)
+    for scheme, name, fn in ((3, "int4", int4_attention_extra), (4, "fp8", fp8_scores_extra), (5, "mxfp4", mx4)):
         for label, general in (("computed_addresses", 0), ("table_form", 1)):
             os.environ["SPECKV_POOL_DEVICES"] = "0,0,0,0,0,0,0"
             if general:
@@ -1458,7 +1459,7 @@ def striped_attention_extra(torch, pkg, T=32768, Lyr=80):
                 kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), f"hip:{torch.cuda.current_device()}")
                 try:
                     r = fn(torch, kv, T, Lyr)
-                    r = r.get("int4_fused_attention") or r.get("fp8_fused_attention") or r
+                    r = r.get("int4_fused_attention") or r.get("fp8_fused_attention") or r.get("mxfp4_fused_attention") or r
                     out[f"{name}_{label}"] = {k: r.get(k) for k in ("ms_all_layers", "frac_hbm", "error") if k in r}
                 finally:
                     kv.close()

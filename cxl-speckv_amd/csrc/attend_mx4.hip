@@ -96,19 +96,6 @@ __device__ __forceinline__ void dma_region(uint32_t lds_rows, uint32_t lds_codes
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_rows), "s"(lds_codes), "v"(goff[0]), "v"(goff[1]), "v"(goff[2]), "v"(goff[3]), "v"(goffc), "s"(base) : "memory", "scc");
 }
-// the same with a full per-lane address (striped placements: the pages of one instruction sit in different runs)
-__device__ __forceinline__ void dma16_flat(uint32_t lds_dst, const uint8_t* addr)
-{
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_dst), "v"(addr) : "memory");
-}
-__device__ __forceinline__ void dma4_flat(uint32_t lds_dst, const uint8_t* addr)
-{
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_dst), "v"(addr) : "memory");
-}
 __device__ __forceinline__ float max_over_kb(float v)
 {
     const uint32_t u = __float_as_uint(v);
@@ -146,7 +133,14 @@ __device__ __forceinline__ float q_clean(uint32_t half_bits)
 } // namespace
 
 // FORM 0: records in one run (record p at lin_base + p * 1088; never-written records are zero bytes = zeros with code 0)
-// FORM 1: striped regularly over 2..8 pools (AttendArgs::stripe_bases)
+// FORM 1: striped regularly over 1..8 runs (AttendArgs::stripe_bases; the record of page p = bases[p % n] + (p / n) * 1152).  The
+//         range's pages are taken by residue CLASS (mx4_class_tiles): class c = the pages j of the range with j % n == c, every
+//         class in tiles of 16 -- a tile = 16 pages n apart = 16 CONSECUTIVE records of one run for K and of one run for V, so
+//         it is fetched exactly as in form 0 (one scalar base, the same ten instructions): attention does not care in which order
+//         it meets the positions.  (The first striped form took the pages in order and asked seven runs for two or three records
+//         each, per tile and region, with an address per lane: 0.64 of the roofline against 0.77 for form 0; this one 0.74:
+//         profiles/r05_mx4.txt.)  Every class gets the tile count of the largest; rows and tiles past a class's end are masked
+//         and fetch the class's last record again.
 // FORM 2: no regular placement, or a last tile that would leave the layer's region: every record address from its page-table
 //         entry, clamped to the range (never-written pages read the zero page); staged through registers, one tile at a time
 // FORM 3: FORM 0 as a STREAM (AttendArgs::stream, many layers of one sequence; see k_attend_int4_wg8): the launch's tiles in
@@ -165,7 +159,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
     const uint32_t c = lane & 15u, kb = lane >> 4;
     const uint32_t w = c >> 3, ql = c & 7u;                              // this lane's column: position parity w, query row ql of the group
     const uint32_t q = blockIdx.z * 8u + ql;                             // query row inside the kv head's g rows
-    constexpr bool STREAM = FORM == 3;
+    constexpr bool STREAM = FORM == 3, CLS = FORM == 1;
     const uint32_t split = blockIdx.x;
     uint32_t layer = blockIdx.y;                                         // batch form: the sequence index
     // stream form: this workgroup's piece = `count` tiles from tile `ct` of layer `layer` on; its partial of that layer is the
@@ -211,12 +205,14 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
         a.k_first += static_cast<uint64_t>(layer) * a.layer_stride;
         a.v_first += static_cast<uint64_t>(layer) * a.layer_stride;
     }
-    if (FORM == 1) {
+    if (CLS) {
         if (threadIdx.x < 8u) s_bases[threadIdx.x] = a.stripe_bases[threadIdx.x];
         __syncthreads();
     }
 
-    const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
+    const uint32_t cls_n = CLS ? a.stripe_n : 1u, cls_magic = CLS ? static_cast<uint32_t>(a.stripe_magic) : 0u, cls_pages = a.n_pages;
+    const uint32_t cls_m = CLS ? mx4_class_tiles(cls_pages, cls_n) : 0u;           // tiles per class
+    const uint32_t n_tiles = CLS ? cls_n * cls_m : (a.n_pages + 15u) / 16u;
     const uint32_t t0 = STREAM ? 0u : split * a.tiles_per_split;         // (stream: positions in the piece, 0 .. count)
     const uint32_t t1 = STREAM ? count : min(t0 + a.tiles_per_split, n_tiles);
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
@@ -277,8 +273,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
         const uint32_t goffc = (lane >> 2) * kRec + 1024u + h0 * 8u + (lane & 3u) * 4u;      // codes: lane l -> page l/4, dword l%4 of the two heads' 16
         const uint32_t kfirst = static_cast<uint32_t>(a.k_first), vfirst = static_cast<uint32_t>(a.v_first), last_pg = a.n_pages - 1u;
         const uint32_t last = t1 - 1u;
-        auto rec_of = [&](uint32_t first, uint32_t page_in_range) -> const uint8_t* {        // FORM 1 / 2: record of a page of the range
-            if (FORM == 1) return attend_stripe_rec(s_bases, first + page_in_range, a.stripe_n, a.stripe_magic, kRec);
+        auto rec_of = [&](uint32_t first, uint32_t page_in_range) -> const uint8_t* {        // FORM 2: record of a page of the range
             const u32x4 e = *MX_GP(u32x4, a.entries + (first + min(page_in_range, last_pg)));      // {address lo, hi, record bytes, scale}
             const uint8_t* r = reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(e.x) | (static_cast<uint64_t>(e.y) << 32));
             return e.z >= kMx4RecBytes ? r : a.zero_page;
@@ -287,13 +282,44 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
         // in the piece; the requests run ahead of the arithmetic across layer boundaries, a request past the piece repeats the last
         uint32_t rq_page[2] = {kfirst + 16u * ct, vfirst + 16u * ct}, rq_ct[2] = {ct, ct}, rq_left[2] = {count, count};
         const uint32_t layer_gap = static_cast<uint32_t>(a.layer_stride) - 16u * n_tiles;   // from the end of one layer's region to the next one's start
+        // class form: the next tile each region will ask for = (class, tile of the class), tiles left in the split
+        uint32_t cls0 = 0u, cq_cls[2] = {0u, 0u}, cq_m[2] = {0u, 0u}, cq_left[2] = {t1 - t0, t1 - t0};
+        const uint32_t jq = CLS ? cls_pages / cls_n : 0u, jr = CLS ? cls_pages - jq * cls_n : 0u;      // class c holds jq + (c < jr) pages
+        if (CLS) {
+            cls0 = __builtin_amdgcn_readfirstlane(t0 / cls_m);
+            cq_cls[0] = cq_cls[1] = cls0;
+            cq_m[0] = cq_m[1] = t0 - cls0 * cls_m;
+        }
         // one region's share of a tile (rg = 0: K rows + K codes, 1: V rows + V codes) into stage `buf`: 5 DMA instructions
         auto stage = [&](uint32_t tt, uint32_t buf, uint32_t rg) __attribute__((always_inline)) {
             const uint32_t tc = min(tt, last);
             const uint32_t dst = lbase + buf * kStage;
             const uint32_t first = rg ? vfirst : kfirst;
             const uint32_t drows = dst + (rg ? kStV : kStK), dcodes = dst + (rg ? kStVC : kStKC);
-            if (STREAM) {
+            if (CLS) {
+                uint32_t cls = cq_cls[rg];
+                const uint32_t m = cq_m[rg];
+                uint32_t cnt = jq + (cls < jr ? 1u : 0u);                         // pages of the class
+                if (cnt == 0u) { cls = 0u; cnt = 1u; }                            // (a range of fewer pages than runs: an empty class fetches the range's first record, all masked)
+                const uint32_t pg = first + cls;                                  // the class's first page: pool pg % n, record pg / n
+                const uint32_t rec0 = cls_n == 1u ? pg : __builtin_amdgcn_readfirstlane(__umulhi(pg, cls_magic)), pool = pg - rec0 * cls_n;     // (all wave-uniform)
+                const uint32_t mm = min(m, (cnt - 1u) >> 4);                      // a tile past the class's end fetches its last one (all masked)
+                const uint32_t imax = __builtin_amdgcn_readfirstlane(min(15u, cnt - 1u - 16u * mm));      // rows past the class's end fetch its last record
+                const uint64_t base = s_bases[pool];                              // (an LDS read: the compiler's wait for it leaves the DMA counter alone)
+                const uint8_t* rt = uniform_ptr(reinterpret_cast<const uint8_t*>(base) + static_cast<uint64_t>(rec0 + 16u * mm) * kRec);
+                if (imax == 15u) {
+                    dma_region(__builtin_amdgcn_readfirstlane(drows), __builtin_amdgcn_readfirstlane(dcodes), rt, goff, goffc);
+                } else {
+                    uint32_t gc[4];
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) gc[i] = min(4u * i + srow, imax) * kRec + h0 * 128u + ((sslot ^ ((4u * i + srow) & 15u)) * 16u);
+                    dma_region(__builtin_amdgcn_readfirstlane(drows), __builtin_amdgcn_readfirstlane(dcodes), rt, gc, min(lane >> 2, imax) * kRec + 1024u + h0 * 8u + (lane & 3u) * 4u);
+                }
+                if (cq_left[rg] > 1u) {
+                    --cq_left[rg];
+                    if (++cq_m[rg] == cls_m) { cq_m[rg] = 0u; ++cq_cls[rg]; }
+                }
+            } else if (STREAM) {
                 const uint8_t* rt = uniform_ptr(a.lin_base + static_cast<uint64_t>(rq_page[rg]) * kRec);    // (wave-uniform by construction)
                 dma_region(drows, dcodes, rt, goff, goffc);
                 if (rq_left[rg] > 1u) {
@@ -304,11 +330,6 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
             } else if (FORM == 0) {
                 const uint8_t* rt = a.lin_base + (static_cast<uint64_t>(first) + 16ull * tc) * kRec;      // (scalar)
                 dma_region(drows, dcodes, rt, goff, goffc);
-            } else if (FORM == 1) {
-#pragma unroll
-                for (uint32_t i = 0; i < 4; ++i)
-                    dma16_flat(drows + 1024u * i, rec_of(first, 16u * tc + 4u * i + srow) + h0 * 128u + ((sslot ^ ((4u * i + srow) & 15u)) * 16u));
-                dma4_flat(dcodes, rec_of(first, 16u * tc + (lane >> 2)) + 1024u + h0 * 8u + (lane & 3u) * 4u);
             } else {
                 // page-table form: through registers, synchronously (the slow path of odd ranges and migrated allocations)
                 uint8_t* d = const_cast<uint8_t*>(lptr) + buf * kStage;
@@ -405,6 +426,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
         }
         const bool ragged = (a.n_pages & 15u) != 0u;
         const uint32_t n_pos = 2u * a.n_pages, skip_pos = 2u * a.skip_pages;
+        uint32_t cc_cls = cls0, cc_m = t0 - cls0 * cls_m;                    // class form: the tile the arithmetic is at
         const uint32_t wshift = 16u * w;
         // one tile out of stage BUF (a compile-time constant: the LDS reads then carry the stage as an immediate offset)
         auto tile_body = [&](uint32_t tile, auto buf_c) __attribute__((always_inline)) {
@@ -439,7 +461,13 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
                 float sc[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sc[r] = s[r] * a.scale_log2e;
-                if ((ragged && tile + 1u == n_tiles) || (a.skip_pages && tile == 0u)) {         // wave-uniform: positions beyond / in front of the range
+                if (CLS) {
+                    if (cc_m + 1u == cls_m) {                                                   // wave-uniform: the class may end inside its last tile
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (cc_cls + cls_n * (16u * cc_m + 4u * kb + r) >= cls_pages) sc[r] = -INFINITY;
+                    }
+                } else if ((ragged && tile + 1u == n_tiles) || (a.skip_pages && tile == 0u)) {  // wave-uniform: positions beyond / in front of the range
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const uint32_t pos = tile * 32u + 2u * (4u * kb + r) + w;
@@ -504,6 +532,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
                 MX_PV(0, x, 0) MX_PV(1, x, 1) MX_PV(2, x, 2) MX_PV(3, x, 3) MX_PV(4, y, 0) MX_PV(5, y, 1) MX_PV(6, y, 2) MX_PV(7, y, 3)
 #undef MX_PV
             }
+            if (CLS && ++cc_m == cls_m) { cc_m = 0u; ++cc_cls; }
             if (FORM == 2 && tile + 1u < t1) {                                    // synchronous staging of the next tile
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 stage(tile + 1u, 0u, 0u);
@@ -571,6 +600,7 @@ hipError_t launch_attend_mx4(const AttendArgs& a, uint32_t n_rows, float* d_out,
     if (n_rows == 0 || a.n_splits == 0 || a.heads != 8u) return a.heads != 8u ? hipErrorInvalidValue : hipSuccess;
     if (!a.seqs && a.n_pages == 0) return hipSuccess;
     const int form = a.lin_base ? (a.stream.n_wgs ? 3 : 0) : a.stripe_bases ? 1 : a.table_form ? 2 : -1;
+    if (form == 1 && (a.skip_pages || (!a.seqs && (a.stripe_n < 1u || a.stripe_n > 8u)))) return hipErrorInvalidValue;
     if (form < 0 || (a.stream.n_wgs && (form != 3 || a.seqs || (a.n_pages & 15u) || a.skip_pages))) return hipErrorInvalidValue;
     const dim3 grid = form == 3 ? dim3(a.stream.n_wgs, 1u, (a.g + 7u) / 8u) : dim3(a.n_splits, n_rows, (a.g + 7u) / 8u);
     const dim3 block(64 * kWavesPerWg);

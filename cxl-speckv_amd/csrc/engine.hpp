@@ -339,7 +339,7 @@ private:
     Scratch s_attn_, s_attn_seq_;
     // pinned staging for the batch descriptors: 4 slots in rotation, each guarded by an event (no stream sync per call)
     struct PinnedRing { void* base = nullptr; size_t slot_bytes = 0; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; int next = 0; } seq_ring_, grp_ring_;
-    struct PlanInfo { uint32_t n_seq; int scheme; uint32_t n_layers, max_pos_end; bool striped, table; };
+    struct PlanInfo { uint32_t n_seq; int scheme; uint32_t n_layers, max_pos_end; bool striped, table; uint32_t mx4_stripe_n_max; };
     std::unordered_map<const void*, PlanInfo> plans_;      // device plan buffer -> what attend_batch_plan last wrote there
     CompressGroup* d_groups_ = nullptr;    // device twin of grp_ring_ (4 slots): descriptors of a grouped compress launch
     uint8_t* d_zero_page_ = nullptr;     // stands in for never-written pages in the fused attention

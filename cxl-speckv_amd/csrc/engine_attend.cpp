@@ -300,6 +300,10 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     // splits, 4k 0.60 / 0.52, 2k 0.58 / 0.43: single-split rows are final, no partials and no merge).
     if (any_table)                                           // (AttendSeq::lin_base carries the page table in table launches)
         for (uint32_t i = 0; i < n_seq; ++i) seqs[i].lin_base = reinterpret_cast<const uint8_t*>(ents[i]);
+    if (mx4 && any_striped && !any_table) {                  // the striped form of k_attend_mx4 counts its tiles by residue class
+        total_tiles = 0;
+        for (uint32_t i = 0; i < n_seq; ++i) { seqs[i].n_splits = mx4_striped_tiles(seqs[i].n_pages, seqs[i].stripe_n); total_tiles += seqs[i].n_splits; }
+    }
     uint32_t tiles_max = 0;
     for (uint32_t i = 0; i < n_seq; ++i) tiles_max = std::max(tiles_max, seqs[i].n_splits);
     const bool wg8 = !fp8 && !mx4 && !any_striped && !any_table && heads == 8u && true;
@@ -385,9 +389,10 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
 // of the caller; speckv_ext_attend_*_planned is kernel launches only: no handle look-ups, no staging, grid and scratch
 // sized from max_pos_end alone, so a captured launch stays valid for as long as the lengths stay within that bound.
 struct PlanGeometry { uint32_t tps, max_splits; uint64_t parts_bound; UnequalSplit unequal; };
-static PlanGeometry plan_geometry(bool fp8, uint32_t n_seq, uint32_t heads, uint32_t max_pos_end, uint32_t cus, bool mx4 = false)
+static PlanGeometry plan_geometry(bool fp8, uint32_t n_seq, uint32_t heads, uint32_t max_pos_end, uint32_t cus, bool mx4 = false, uint32_t mx4_stripe_n_max = 0)
 {
-    const uint32_t tiles_max = (max_pos_end / 2u + 15u) / 16u;
+    // (MXFP4 over striped pools counts tiles by residue class: at most ceil(pages / 16) + runs + 1 of them, whatever a member's run count)
+    const uint32_t tiles_max = (max_pos_end / 2u + 15u) / 16u + (mx4 && mx4_stripe_n_max >= 2u ? mx4_stripe_n_max + 1u : 0u);
     PlanGeometry g{};
     if (mx4) {
         g.unequal = UnequalSplit{false, 1.0};
@@ -455,7 +460,13 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
         seqs[i].n_pages = n_pages;
         seqs[i].n_splits = n_tiles;
     }
-    const PlanGeometry g = plan_geometry(scheme == SPECKV_COMP_FP8_E4M3, n_seq, heads, max_pos_end, cus(), scheme == SPECKV_COMP_MXFP4);
+    uint32_t stripe_n_max = 0;
+    if (scheme == SPECKV_COMP_MXFP4 && any_striped && !any_table)
+        for (uint32_t i = 0; i < n_seq; ++i) {
+            seqs[i].n_splits = mx4_striped_tiles(seqs[i].n_pages, seqs[i].stripe_n);
+            stripe_n_max = std::max(stripe_n_max, seqs[i].stripe_n);
+        }
+    const PlanGeometry g = plan_geometry(scheme == SPECKV_COMP_FP8_E4M3, n_seq, heads, max_pos_end, cus(), scheme == SPECKV_COMP_MXFP4, stripe_n_max);
     if (g.max_splits > 2048u) return SPECKV_ERR_INVAL;
     if (plans_.size() >= 64 && !plans_.count(d_plan)) plans_.clear();        // (buffers of long-gone steps)
     if (any_table)
@@ -465,7 +476,7 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
         HIP_TRY(hipMemset(d_zero_page_, 0, kPageSize));
     }
-    plans_[d_plan] = PlanInfo{n_seq, scheme, min_layers, max_pos_end, any_striped, any_table};
+    plans_[d_plan] = PlanInfo{n_seq, scheme, min_layers, max_pos_end, any_striped, any_table, stripe_n_max};
     uint64_t parts = 0;
     for (uint32_t i = 0; i < n_seq; ++i) {
         const uint32_t n_tiles = seqs[i].n_splits;
@@ -508,7 +519,7 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
         SPECKV_ERR("speckv_ext_attend_*_planned: no plan of this shape at %p (n_seq, format and max_pos_end as planned, layer inside every layout)", d_plan);
         return SPECKV_ERR_INVAL;
     }
-    const PlanGeometry pg = plan_geometry(fp8, n_seq, heads, max_pos_end, cus(), mx4);
+    const PlanGeometry pg = plan_geometry(fp8, n_seq, heads, max_pos_end, cus(), mx4, plan->second.mx4_stripe_n_max);
     DeviceScope device_scope(device_);
     const size_t acc_bytes = static_cast<size_t>(pg.parts_bound) * 16 * 128 * sizeof(float), ml_bytes = static_cast<size_t>(pg.parts_bound) * 32 * sizeof(float);
     uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes, s));      // (growth during a capture is refused: warm up once)
@@ -720,19 +731,22 @@ int Engine::attend_mx4(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     const uint64_t v_first = k_first + L.num_tokens / 2;
     const uint64_t layer_stride = static_cast<uint64_t>(L.num_tokens);
     if (v_first + (n_layers - 1) * layer_stride + n_pages > a->n_pages) return SPECKV_ERR_GENERAL;
-    const uint32_t n_tiles = (n_pages + 15u) / 16u;
+    uint32_t n_tiles = (n_pages + 15u) / 16u;
     // arithmetic addresses need every 32-position tile inside the layer's K / V region (the last one may be ragged); otherwise,
     // or without a regular placement, the page-table form: its look-ups are clamped to the range
     const bool fits = static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
     const bool general_env = tuning().attend_general != 0;
     const bool linear = a->linear_base && fits && !general_env;
-    const bool striped = !linear && a->stripe_n >= 2 && fits && !general_env;
+    // a pool striped over 2..8 runs: the range's pages by residue class of the page index (every tile 16 consecutive records of one
+    // run: the linear form's fetch), whatever the range -- rows past a class's end are masked, nothing needs to "fit"
+    const bool striped = !linear && a->stripe_n >= 2 && a->stripe_n <= 8 && !general_env;
     const bool table = !linear && !striped;
     if (table && !d_zero_page_) {
         if (is_capturing(s)) return SPECKV_ERR_INVAL;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
         HIP_TRY(hipMemset(d_zero_page_, 0, kPageSize));
     }
+    if (striped) n_tiles = mx4_striped_tiles(n_pages, a->stripe_n);
     // workgroups = splits x layers x query-row groups (each covers the 8 kv heads; one resident per CU): one round of the CUs,
     // rounded down -- 80 layers at 32k: 3 splits (240 workgroups) 0.765 of the HBM roofline, 6 splits 0.72-0.75 (profiles/r05_mx4.txt)
     const uint32_t rows = n_layers * L.num_heads;

@@ -313,6 +313,19 @@ __host__ __device__ inline uint32_t attend_stream_count(uint32_t layer, uint32_t
     const uint64_t g0 = static_cast<uint64_t>(layer) * n_tiles;
     return attend_stream_wg_of(g0 + n_tiles - 1u, len, rem) - attend_stream_wg_of(g0, len, rem) + 1u;
 }
+// MXFP4 over a striped pool (k_attend_mx4 form 1): the positions of the range are taken CLASS by class -- class c = the pages j
+// of the range with j % stripe_n == c, which are consecutive records of ONE run for K and of one run for V -- each class in
+// tiles of 16 pages; every class gets the tile count of the largest (trailing tiles of the others are masked).
+__host__ __device__ inline uint32_t mx4_class_tiles(uint32_t n_pages, uint32_t stripe_n)
+{
+    return ((n_pages + stripe_n - 1u) / stripe_n + 15u) / 16u;
+}
+// tiles of a range in that form (stripe_n = 1, a single run: the plain count)
+__host__ __device__ inline uint32_t mx4_striped_tiles(uint32_t n_pages, uint32_t stripe_n)
+{
+    const uint32_t n = stripe_n ? stripe_n : 1u;
+    return n_pages ? n * mx4_class_tiles(n_pages, n) : 0u;
+}
 #if defined(__HIPCC__)
 // record address of page p in the striped form; `bases` = the allocation's run bases copied to LDS
 __device__ __forceinline__ const uint8_t* attend_stripe_rec(const uint64_t* bases, uint32_t p, uint32_t n, uint32_t magic, uint32_t stride)

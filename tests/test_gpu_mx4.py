@@ -360,3 +360,96 @@ def test_mx4_striped_and_migrated_placements(oracle):
         assert_same_float_bits(dst.cpu().numpy(), want, "after migration")
     finally:
         kv.close()
+
+
+@pytest.mark.parametrize("pools", [2, 3, 7, 8])
+def test_mx4_striped_pool_by_residue_classes(oracle, pools):
+    """One sequence over a pool striped across 2 .. 8 runs (BASELINE configs[3]'s 1 + 7 layout; every 'peer' on this GPU): the
+    class form of the kernel (tiles = 16 pages `pools` apart = 16 consecutive records of one run) against the oracle -- ranges
+    whose classes are of unequal length, whose last tiles are ragged or empty, that do not start at 0, several layers in one
+    launch, forced split counts, ranges of fewer pages than runs; the batch and planned forms over allocations of ragged lengths."""
+    torch = torch_mod()
+    os.environ["SPECKV_POOL_DEVICES"] = ",".join(["0"] * pools)
+    try:
+        kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), "hip:0")
+    finally:
+        os.environ.pop("SPECKV_POOL_DEVICES", None)
+    try:
+        lib = kv.lib
+        lib.set_compression_scheme(5)
+        T, L, g = 1024, 3, 8
+        h = kv.allocate(T, L, H, D, 2)
+        n_pages = T * L * H * D * 2 * 2 // PAGE
+        rng = np.random.default_rng(170 + pools)
+        x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.1, 4.0, (n_pages, 1))).astype(np.float16)
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+        recs = oracle.compress_blocks_f16(x, 5, 0)[2]
+        qn = rng.standard_normal((L, H, g, D)).astype(np.float16)
+        q = torch.from_numpy(qn).cuda()
+        sm = 1.0 / np.sqrt(D)
+        out = torch.empty((L, H, g, D), dtype=torch.float32, device="cuda")
+        lse = torch.empty((L, H, g), dtype=torch.float32, device="cuda")
+        # (layer, layers, range, splits): 512 pages = full; 2 * 16 * pools + 2: classes of 33 and 32 pages (a ragged last tile in
+        # some, in the others an empty one); odd page counts; ranges off 0
+        cases = [(0, 1, (0, T), 0), (1, 1, (0, 2 * (16 * pools) + 4), 0), (2, 1, (64, 64 + 2 * (17 * pools + 1)), 0), (0, 3, (0, T), 0),
+                 (0, 3, (32, 32 + 2 * (40 * pools + 3)), 0), (1, 2, (0, 2 * (16 * pools + pools - 1)), 3), (0, 1, (0, T), 5), (2, 1, (2, T - 2), 2)]
+        for layer, nl, (pb, pe), splits in cases:
+            set_tuning("attend_splits", splits)
+            try:
+                out.fill_(float("nan")); lse.fill_(float("nan"))
+                lib.attend_mx4(h, layer, nl, q[layer].data_ptr(), g, pb, pe, sm, out.data_ptr(), lse.data_ptr())
+                torch.cuda.synchronize()
+            finally:
+                set_tuning("attend_splits", 0)
+            for i in range(nl):
+                want, wlse, mag, delta = oracle_attention(oracle, recs, qn[layer + i], T, layer + i, pb, pe, sm, g)
+                check(out[i].cpu().numpy(), lse[i].cpu().numpy(), want, wlse, mag, delta, (pools, layer + i, pb, pe, splits))
+        # ranges of fewer pages than a tile per class, or than runs (empty classes)
+        for pe in (64, 2 * pools - 2, 2, 2 * pools + 2):
+            lib.attend_mx4(h, 1, 1, q[1].data_ptr(), g, 0, pe, sm, out.data_ptr(), lse.data_ptr())
+            torch.cuda.synchronize()
+            want, wlse, mag, delta = oracle_attention(oracle, recs, qn[1], T, 1, 0, pe, sm, g)
+            check(out[0].cpu().numpy(), lse[0].cpu().numpy(), want, wlse, mag, delta, (pools, "short", pe))
+        # the batch and the planned forms over several striped allocations of ragged lengths (empty, shorter than the run count, full)
+        lens = [T, 0, 2, 2 * pools - 2, 34, 200, T - 2, 2 * (16 * pools) + 2]
+        hs, rs = [h], [recs]
+        for i in range(1, len(lens)):
+            hi = kv.allocate(T, L, H, D, 2)
+            xi = (rng.standard_normal((n_pages, N)) * rng.uniform(0.1, 4.0, (n_pages, 1))).astype(np.float16)
+            lib.write(hi, 0, xi.ctypes.data, xi.nbytes, False)
+            hs.append(hi); rs.append(oracle.compress_blocks_f16(xi, 5, 0)[2])
+        nb = len(lens)
+        qb = rng.standard_normal((nb, H, g, D)).astype(np.float16)
+        d_qb = torch.from_numpy(qb).cuda()
+        bout = torch.full((nb, H, g, D), float("nan"), dtype=torch.float32, device="cuda")
+        blse = torch.full((nb, H, g), float("nan"), dtype=torch.float32, device="cuda")
+
+        def check_batch(what, layer):
+            o, l_ = bout.cpu().numpy(), blse.cpu().numpy()
+            for i, n in enumerate(lens):
+                if n == 0:
+                    assert not o[i].any(), (what, i)
+                    continue
+                want, wlse, mag, delta = oracle_attention(oracle, rs[i], qb[i], T, layer, 0, n, sm, g)
+                check(o[i], l_[i], want, wlse, mag, delta, (pools, what, i, n))
+
+        for tps in (0, 2):
+            set_tuning("attend_tiles_per_split", tps)
+            try:
+                bout.fill_(float("nan")); blse.fill_(float("nan"))
+                lib.attend_mx4_batch(hs, 2, d_qb.data_ptr(), g, np.array(lens, np.uint32), sm, bout.data_ptr(), blse.data_ptr())
+                torch.cuda.synchronize()
+            finally:
+                set_tuning("attend_tiles_per_split", 0)
+            check_batch(("batch", tps), 2)
+        st = torch.cuda.Stream()
+        plan_bytes = lib.attend_plan_bytes(nb)
+        d_plan = torch.empty(plan_bytes, dtype=torch.uint8, device="cuda")
+        bout.fill_(float("nan")); blse.fill_(float("nan"))
+        torch.cuda.synchronize()
+        lib.attend_batch_plan(hs, lens, T, d_plan.data_ptr(), plan_bytes, st.cuda_stream)
+        lib.attend_planned(5, d_plan.data_ptr(), nb, 1, d_qb.data_ptr(), g, T, sm, bout.data_ptr(), blse.data_ptr(), st.cuda_stream)
+        torch.cuda.synchronize()
+        check_batch("planned", 1)
+    finally:
+        kv.close()
