@@ -149,10 +149,13 @@ __device__ __forceinline__ float q_clean(uint32_t half_bits)
 //         finished layer's partial is stored and the next layer's query rows are loaded.  grid (n_wgs, 1, query-row groups).
 // grid (splits, rows [, query-row groups of 8]); a workgroup = 4 waves = the 8 kv heads.
 template <int FORM>
-__global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_eu(kStages > 2u ? 1 : 2, kStages > 2u ? 1 : 2))) void k_attend_mx4(AttendArgs a)
+__global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_eu(FORM == 2 ? 2 : kStages > 2u ? 1 : 2, FORM == 2 ? 2 : kStages > 2u ? 1 : 2))) void k_attend_mx4(AttendArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];                  // kWavesPerWg x 2 stages (68 KiB: beyond the static limit)
-    uint8_t (*lds)[kStages * kStage] = reinterpret_cast<uint8_t (*)[kStages * kStage]>(lds_dyn);
+    // (the page-table form works on one tile at a time with nothing in flight: ONE stage per wave, and two workgroups per CU
+    // hide one another's round trips instead -- 0.33 of the HBM roofline with one workgroup per CU)
+    constexpr uint32_t kWaveLds = (FORM == 2 ? 1u : kStages) * kStage;
+    uint8_t (*lds)[kWaveLds] = reinterpret_cast<uint8_t (*)[kWaveLds]>(lds_dyn);
     __shared__ uint64_t s_bases[8];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -616,7 +619,7 @@ hipError_t launch_attend_mx4(const AttendArgs& a, uint32_t n_rows, float* d_out,
     if (form == 0) hipLaunchKernelGGL(k_attend_mx4<0>, grid, block, lds_bytes, s, a);
     else if (form == 1) hipLaunchKernelGGL(k_attend_mx4<1>, grid, block, lds_bytes, s, a);
     else if (form == 3) hipLaunchKernelGGL(k_attend_mx4<3>, grid, block, lds_bytes, s, a);
-    else hipLaunchKernelGGL(k_attend_mx4<2>, grid, block, lds_bytes, s, a);
+    else hipLaunchKernelGGL(k_attend_mx4<2>, grid, block, static_cast<size_t>(kWavesPerWg) * kStage, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const bool all_final = a.direct_out && (!a.direct_per_seq || a.direct_per_seq == 2u);

@@ -751,7 +751,7 @@ int Engine::attend_mx4(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     // rounded down -- 80 layers at 32k: 3 splits (240 workgroups) 0.765 of the HBM roofline, 6 splits 0.72-0.75 (profiles/r05_mx4.txt)
     const uint32_t rows = n_layers * L.num_heads;
     const uint32_t columns = n_layers * ((g + 7u) / 8u);
-    uint32_t want = std::max(1u, cus() / columns);
+    uint32_t want = std::max(1u, (table ? 2u : 1u) * cus() / columns);          // (the page-table form: two workgroups per CU)
     const uint32_t min_tiles = std::min(8u, std::max(2u, n_tiles / 64u));      // per-layer calls: see attend_fp8
     want = std::min(want, std::max(1u, n_tiles / min_tiles));
     if (tuning().attend_splits > 0) want = static_cast<uint32_t>(tuning().attend_splits);
