@@ -1468,6 +1468,20 @@ def striped_attention_extra(torch, pkg, T=32768, Lyr=80):
             finally:
                 os.environ.pop("SPECKV_POOL_DEVICES", None)
                 set_tuning("attend_general", 0)
+    # ... and BASELINE configs[3]'s decode step itself over that layout: 256 sequences x 8k, every sequence striped over the 7 pools
+    for scheme, name in ((4, "fp8"), (5, "mxfp4")):
+        os.environ["SPECKV_POOL_DEVICES"] = "0,0,0,0,0,0,0"
+        try:
+            kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), f"hip:{torch.cuda.current_device()}")
+            try:
+                r = list(batch_attention_extra(torch, kv, scheme=scheme).values())[0]
+                out[f"{name}_batch_256x8k"] = {k: r.get(k) for k in ("ms_per_layer", "frac_hbm", "error") if k in r}
+            finally:
+                kv.close()
+        except Exception as e:
+            out[f"{name}_batch_256x8k"] = {"error": repr(e)}
+        finally:
+            os.environ.pop("SPECKV_POOL_DEVICES", None)
     return {"fused_attention_striped_x7": out}
 
 
