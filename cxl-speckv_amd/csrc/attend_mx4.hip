@@ -35,6 +35,7 @@
 // 32-position tile of its two heads 4 for K, 4 for V, 1 + 1 for the codes -- 10 instructions for 8704 bytes -- two tiles deep per
 // wave; the operands are then read from LDS.  All vector-memory traffic of the loop is inline assembly with explicit counters.
 #include "kernels.hpp"
+#include <atomic>
 #include <type_traits>
 
 #ifndef MX4_CODES_POLICY
@@ -608,14 +609,18 @@ hipError_t launch_attend_mx4(const AttendArgs& a, uint32_t n_rows, float* d_out,
     const dim3 grid = form == 3 ? dim3(a.stream.n_wgs, 1u, (a.g + 7u) / 8u) : dim3(a.n_splits, n_rows, (a.g + 7u) / 8u);
     const dim3 block(64 * kWavesPerWg);
     constexpr size_t lds_bytes = static_cast<size_t>(kWavesPerWg) * kStages * kStage;
-    static const hipError_t attr = [] {
+    // more than 64 KiB of dynamic LDS has to be allowed per function AND per device: once for every device this process launches on
+    static std::atomic<uint64_t> allowed{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return hipErrorInvalidDevice;
+    if (!(allowed.load(std::memory_order_acquire) >> dev & 1ull)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        return e;
-    }();
-    if (attr != hipSuccess) return attr;
+        if (e != hipSuccess) return e;
+        allowed.fetch_or(1ull << dev, std::memory_order_release);
+    }
     if (form == 0) hipLaunchKernelGGL(k_attend_mx4<0>, grid, block, lds_bytes, s, a);
     else if (form == 1) hipLaunchKernelGGL(k_attend_mx4<1>, grid, block, lds_bytes, s, a);
     else if (form == 3) hipLaunchKernelGGL(k_attend_mx4<3>, grid, block, lds_bytes, s, a);
