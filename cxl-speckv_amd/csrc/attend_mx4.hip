@@ -63,7 +63,7 @@ constexpr uint32_t kStK = 0, kStV = 4096, kStKC = 8192, kStVC = 8448, kStage = 8
 #ifndef MX4_STAGES
 #define MX4_STAGES 3          // (2: two workgroups per CU fit; measured 0.71-0.75 of the HBM roofline against 0.73-0.77 with 3 and one workgroup per CU)
 #endif
-constexpr uint32_t kStages = MX4_STAGES;                     // tiles a wave keeps in LDS: the one it works on and kStages - 1 on their way
+constexpr uint32_t kStagesDefault = MX4_STAGES;              // tiles a wave keeps in LDS: the one it works on and kStages - 1 on their way
 
 template <typename T> __device__ __forceinline__ T* uniform_ptr(T* p)
 {
@@ -149,9 +149,15 @@ __device__ __forceinline__ float q_clean(uint32_t half_bits)
 //         grid fill 240 of 256 CUs; 256 pieces of 320 tiles fill them all.  Across a layer boundary the DMA pipeline goes on, the
 //         finished layer's partial is stored and the next layer's query rows are loaded.  grid (n_wgs, 1, query-row groups).
 // grid (splits, rows [, query-row groups of 8]); a workgroup = 4 waves = the 8 kv heads.
-template <int FORM>
-__global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_eu(FORM == 2 ? 2 : kStages > 2u ? 1 : 2, FORM == 2 ? 2 : kStages > 2u ? 1 : 2))) void k_attend_mx4(AttendArgs a)
+// HALVES = 2 (form 0, batches whose sequences are one split each and no more than the CUs): 8 waves -- the workgroup's run of tiles cut
+//         in two, waves 4..7 take the second half with stages of their own (two per wave: 136 KiB), and at the end their (m, l,
+//         accumulators) cross over through the LDS the stages no longer need and waves 0..3 store the merged rows.  A sequence of a
+//         batch then has two pipelines running and two fills overlapping instead of one -- what a short context is made of
+//         (256 x 1k: a third of the launch is fill and drain) -- and still needs no partials and no merge launch.
+template <int FORM, int HALVES = 1>
+__global__ __launch_bounds__(64 * kWavesPerWg * HALVES) __attribute__((amdgpu_waves_per_eu((FORM == 2 || HALVES == 2) ? 2 : kStagesDefault > 2u ? 1 : 2, (FORM == 2 || HALVES == 2) ? 2 : kStagesDefault > 2u ? 1 : 2))) void k_attend_mx4(AttendArgs a)
 {
+    constexpr uint32_t kStages = HALVES == 2 ? 2u : kStagesDefault;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];                  // kWavesPerWg x 2 stages (68 KiB: beyond the static limit)
     // (the page-table form works on one tile at a time with nothing in flight: ONE stage per wave, and two workgroups per CU
     // hide one another's round trips instead -- 0.33 of the HBM roofline with one workgroup per CU)
@@ -159,7 +165,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
     uint8_t (*lds)[kWaveLds] = reinterpret_cast<uint8_t (*)[kWaveLds]>(lds_dyn);
     __shared__ uint64_t s_bases[8];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wave = wave8 & 3u, half = wave8 >> 2;                 // (half: HALVES == 2 only)
     const uint32_t c = lane & 15u, kb = lane >> 4;
     const uint32_t w = c >> 3, ql = c & 7u;                              // this lane's column: position parity w, query row ql of the group
     const uint32_t q = blockIdx.z * 8u + ql;                             // query row inside the kv head's g rows
@@ -217,8 +224,12 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
     const uint32_t cls_n = CLS ? a.stripe_n : 1u, cls_magic = CLS ? static_cast<uint32_t>(a.stripe_magic) : 0u, cls_pages = a.n_pages;
     const uint32_t cls_m = CLS ? mx4_class_tiles(cls_pages, cls_n) : 0u;           // tiles per class
     const uint32_t n_tiles = CLS ? cls_n * cls_m : (a.n_pages + 15u) / 16u;
-    const uint32_t t0 = STREAM ? 0u : split * a.tiles_per_split;         // (stream: positions in the piece, 0 .. count)
-    const uint32_t t1 = STREAM ? count : min(t0 + a.tiles_per_split, n_tiles);
+    uint32_t t0 = STREAM ? 0u : split * a.tiles_per_split;               // (stream: positions in the piece, 0 .. count)
+    uint32_t t1 = STREAM ? count : min(t0 + a.tiles_per_split, n_tiles);
+    if (HALVES == 2) {                                                   // waves 0..3: the first half of the run, waves 4..7: the second
+        const uint32_t tm = t0 + (t1 - t0 + 1u) / 2u;
+        if (half) t0 = tm; else t1 = tm;
+    }
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
     f32x4 acc[2][8];
 #pragma unroll
@@ -266,8 +277,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
     };
 
     if (t0 < t1) {                                                       // wave-uniform
-        const uint32_t lbase = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&lds[wave][0])));
-        const uint8_t* const lptr = &lds[wave][0];
+        const uint32_t lbase = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&lds[HALVES == 2 ? wave8 : wave][0])));
+        const uint8_t* const lptr = &lds[HALVES == 2 ? wave8 : wave][0];
         // ---- staging: DMA instruction i (0..3) of a region fills page rows 4i .. 4i+3: lane l -> row 4i + l/16, 16-byte slot l%16,
         // which holds piece (slot ^ row) of the two heads' 256 bytes -- the XOR spreads the operand reads below over the banks
         const uint32_t srow = lane >> 4, sslot = lane & 15u;
@@ -594,6 +605,37 @@ __global__ __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_e
         }
         if (FORM != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-requested tail tiles: nothing may land after the wave ends
     }
+    if (HALVES == 2) {
+        // the second half's state crosses over: 68 registers per lane = exactly the 17 408 bytes of a wave's two stages, [register][lane]
+        float* xw = reinterpret_cast<float*>(&lds[4u + wave][0]);
+        __syncthreads();                                                 // (every wave's DMAs have landed: vmcnt(0) above)
+        if (half) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                xw[(2 * hh) * 64 + lane] = m_run[hh];
+                xw[(2 * hh + 1) * 64 + lane] = l_run[hh];
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xw[(4 + 32 * hh + 4 * t + r) * 64 + lane] = acc[hh][t][r];
+            }
+        }
+        __syncthreads();
+        if (half) return;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const float mb = xw[(2 * hh) * 64 + lane], lb = xw[(2 * hh + 1) * 64 + lane];
+            const float mn = fmaxf(m_run[hh], mb);
+            const float fa = (mn == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run[hh] - mn);      // (-inf - finite: 0)
+            const float fb = (mn == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(mb - mn);
+            m_run[hh] = mn;
+            l_run[hh] = l_run[hh] * fa + lb * fb;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[hh][t][r] = acc[hh][t][r] * fa + xw[(4 + 32 * hh + 4 * t + r) * 64 + lane] * fb;
+        }
+    }
     store_rows();
 }
 
@@ -608,7 +650,7 @@ hipError_t launch_attend_mx4(const AttendArgs& a, uint32_t n_rows, float* d_out,
     if (form < 0 || (a.stream.n_wgs && (form != 3 || a.seqs || (a.n_pages & 15u) || a.skip_pages))) return hipErrorInvalidValue;
     const dim3 grid = form == 3 ? dim3(a.stream.n_wgs, 1u, (a.g + 7u) / 8u) : dim3(a.n_splits, n_rows, (a.g + 7u) / 8u);
     const dim3 block(64 * kWavesPerWg);
-    constexpr size_t lds_bytes = static_cast<size_t>(kWavesPerWg) * kStages * kStage;
+    constexpr size_t lds_bytes = static_cast<size_t>(kWavesPerWg) * kStagesDefault * kStage;
     // more than 64 KiB of dynamic LDS has to be allowed per function AND per device: once for every device this process launches on
     static std::atomic<uint64_t> allowed{0};
     int dev = 0;
@@ -618,10 +660,12 @@ hipError_t launch_attend_mx4(const AttendArgs& a, uint32_t n_rows, float* d_out,
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<size_t>(2 * kWavesPerWg) * 2 * kStage);
         if (e != hipSuccess) return e;
         allowed.fetch_or(1ull << dev, std::memory_order_release);
     }
-    if (form == 0) hipLaunchKernelGGL(k_attend_mx4<0>, grid, block, lds_bytes, s, a);
+    if (form == 0 && a.mx4_halves) hipLaunchKernelGGL((k_attend_mx4<0, 2>), grid, dim3(128 * kWavesPerWg), static_cast<size_t>(2 * kWavesPerWg) * 2 * kStage, s, a);
+    else if (form == 0) hipLaunchKernelGGL(k_attend_mx4<0>, grid, block, lds_bytes, s, a);
     else if (form == 1) hipLaunchKernelGGL(k_attend_mx4<1>, grid, block, lds_bytes, s, a);
     else if (form == 3) hipLaunchKernelGGL(k_attend_mx4<3>, grid, block, lds_bytes, s, a);
     else hipLaunchKernelGGL(k_attend_mx4<2>, grid, block, static_cast<size_t>(kWavesPerWg) * kStage, s, a);

@@ -369,6 +369,8 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     bool one_split_each = true;                           // then the attention kernel writes the final rows itself
     for (uint32_t i = 0; i < n_seq; ++i) one_split_each = one_split_each && seqs[i].n_splits == 1u;
     if (one_split_each) { k.direct_out = d_out; k.direct_lse = d_lse; }
+    // MXFP4, whole sequences in single runs and a CU to each: 8-wave workgroups, the run cut in two (k_attend_mx4<0, 2>)
+    if (mx4 && one_split_each && !any_striped && !any_table && static_cast<uint64_t>(n_seq) * ((g + 7u) / 8u) <= cus() && tuning().attend_mx4_one_half == 0) k.mx4_halves = 1u;
     if (unequal.on) k.rows_first = 1u;
     if (wg8) k.wg8 = int4_wg8_form(n_seq, cus());
     if (fp8) {
@@ -544,6 +546,9 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
     k.direct_lse = d_lse;
     // ... decided per sequence on the device, the merge skips those; a geometry of one split at most needs no merge at all
     k.direct_per_seq = pg.max_splits == 1u ? 2u : 1u;
+    if (mx4 && pg.max_splits == 1u && !plan->second.striped && !plan->second.table && static_cast<uint64_t>(n_seq) * ((g + 7u) / 8u) <= cus() &&
+        tuning().attend_mx4_one_half == 0)
+        k.mx4_halves = 1u;                                     // (see attend_batch)
     if (pg.unequal.on) k.rows_first = 1u;
     if (fp8) {
         HIP_TRY(launch_attend_fp8_batch(k, n_seq, d_out, d_lse, s));

@@ -291,6 +291,7 @@ struct AttendArgs {
     // from the page-table entry, looked up one tile ahead of its request; never-written pages read zero_page
     uint32_t table_form;
     // INT4, linear form, 8 kv heads: the whole-record kernel (k_attend_int4_wg8: 8 waves = 8 heads, grid (splits, layers))
+    uint32_t mx4_halves;              // MXFP4, linear batch launches of single-split sequences: 8-wave workgroups, the run cut in two (k_attend_mx4<0, 2>)
     uint32_t wg8;                     // 1: the engine's choice of form; 2: workgroups of one run (8 waves) also for batches
     // ... and its STREAM form for many layers of one sequence (see k_attend_int4_wg8): n_wgs != 0 turns it on.  The rows'
     // partials then sit at (row * max_slots + slot) and the merge takes each row's count from attend_stream_count().

@@ -14,6 +14,7 @@ const Key kKeys[] = {
     {"attend_tiles_per_split", "SPECKV_ATTEND_TILES_PER_SPLIT", &Tuning::attend_tiles_per_split},
     {"attend_general", "SPECKV_ATTEND_GENERAL", &Tuning::attend_general},
     {"attend_stream", "SPECKV_ATTEND_STREAM", &Tuning::attend_stream},
+    {"attend_mx4_one_half", "SPECKV_ATTEND_MX4_ONE_HALF", &Tuning::attend_mx4_one_half},
     {"tc_multipass", "SPECKV_TC_MULTIPASS", &Tuning::tc_multipass},
     {"tc_scan", "SPECKV_TC_SCAN", &Tuning::tc_scan},
     {"tc_no_pre", "SPECKV_TC_NO_PRE", &Tuning::tc_no_pre},

@@ -13,6 +13,7 @@ struct Tuning {
     int32_t attend_splits = 0;              // SPECKV_ATTEND_SPLITS            single-sequence calls: splits per row
     int32_t attend_tiles_per_split = 0;     // SPECKV_ATTEND_TILES_PER_SPLIT   batch calls: tiles (32 positions) per split
     int32_t attend_stream = 0;              // SPECKV_ATTEND_STREAM            MXFP4, several layers of one sequence: N > 0 the stream form with N workgroups, -1 never, 0 by size
+    int32_t attend_mx4_one_half = 0;        // SPECKV_ATTEND_MX4_ONE_HALF      MXFP4 batches: 4-wave workgroups also where the two-halves form applies (A/B, tests)
     int32_t attend_general = 0;             // SPECKV_ATTEND_GENERAL           1: page-table forms even where an arithmetic form applies (tests)
     // whole-tensor codec: the multi-launch forms the one-pass kernels replaced, kept as cross-checks of each other (tests)
     int32_t tc_multipass = 0;               // SPECKV_TC_MULTIPASS
