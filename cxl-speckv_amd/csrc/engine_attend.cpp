@@ -325,9 +325,11 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     }
     const size_t acc_bytes = static_cast<size_t>(parts) * 16 * 128 * sizeof(float), ml_bytes = static_cast<size_t>(parts) * 32 * sizeof(float);
     uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes, s));
-    AttendSeq* d_seqs = static_cast<AttendSeq*>(scratch(s_attn_seq_, seqs.size() * sizeof(AttendSeq), s));
-    if (!buf || !d_seqs) return SPECKV_ERR_NOMEM;
-    // descriptors go through a pinned slot so the call can return without waiting for the copy
+    if (!buf) return SPECKV_ERR_NOMEM;
+    // The kernels read the descriptors IN PLACE from a pinned slot: each workgroup fetches its own 64 bytes over the host link when
+    // it starts (one round trip, all workgroups at once).  Copying the slot to the device first was a copy-engine operation in
+    // front of every launch, 7-8 us that the kernels waited for: 256 x 1k MXFP4 59.5 -> 53 us per call, FP8 96 -> 88
+    // (profiles/r05_mx4.txt; the planned form never had it).  A slot is reused once the launches that read it have finished.
     const size_t seq_bytes = seqs.size() * sizeof(AttendSeq);
     if (seq_ring_.slot_bytes < seq_bytes) {
         if (seq_ring_.base) { HIP_TRY(hipDeviceSynchronize()); (void)hipHostFree(seq_ring_.base); seq_ring_.base = nullptr; }
@@ -338,11 +340,11 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     }
     const int slot = seq_ring_.next;
     seq_ring_.next = (slot + 1) & 3;
-    HIP_TRY(hipEventSynchronize(seq_ring_.ev[slot]));          // the copy that last used this slot has finished
+    HIP_TRY(hipEventSynchronize(seq_ring_.ev[slot]));          // whatever last used this slot (a launch that read it in place, a plan's copy) has finished
     void* staged = static_cast<uint8_t*>(seq_ring_.base) + static_cast<size_t>(slot) * seq_ring_.slot_bytes;
     memcpy(staged, seqs.data(), seq_bytes);
-    HIP_TRY(hipMemcpyAsync(d_seqs, staged, seq_bytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipEventRecord(seq_ring_.ev[slot], st));
+    AttendSeq* d_seqs = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_seqs), staged, 0));
     // sequences without positions have no splits: their rows are written as zeros by the merge (L == 0)
     AttendArgs k{};
     k.heads = heads;
@@ -381,6 +383,7 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
         HIP_TRY(launch_attend_int4(k, n_seq, st));        // grid y = sequences x head groups, as for layers
         if (!k.direct_out) HIP_TRY(launch_attend_combine(k, n_seq, d_out, d_lse, st));
     }
+    HIP_TRY(hipEventRecord(seq_ring_.ev[slot], st));           // the slot's descriptors have been read when this point is reached
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
     return SPECKV_OK;
 }
