@@ -1053,6 +1053,8 @@ def batch_attention_extra(torch, kv, n_seq=256, T=8192, scheme=4):
     lib = kv.lib
     handles = []
     name = {4: "fp8_attention_batch_decode_step", 3: "int4_attention_batch_decode_step", 5: "mxfp4_attention_batch_decode_step"}[scheme]
+    if (n_seq, T) != (256, 8192):
+        name += f"_{n_seq}x{T}"
     rec = {4: 2048, 3: 1152, 5: 1088}[scheme]
     try:
         lib.set_compression_scheme(scheme)
@@ -1591,6 +1593,9 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     ex.update(batch_attention_extra(torch, kv))      # BASELINE configs[4] shape: 70B-shaped KV @ 32k context
     ex.update(batch_attention_extra(torch, kv, scheme=3))
     ex.update(batch_attention_extra(torch, kv, scheme=5))
+    for sch in (4, 3, 5):                                                 # short contexts: 256 x 1k and 256 x 2k, batch and planned forms
+        for T_short in (1024, 2048):
+            ex.update(batch_attention_extra(torch, kv, T=T_short, scheme=sch))
     ex.update(connector_append_extra(torch, kv))
     ex.update(connector_decode_extra(torch, kv))
     ex.update(connector_decode_extra(torch, kv, scheme="mxfp4"))      # the same decode step over an MXFP4 pool (half the record bytes of FP8)
