@@ -18,7 +18,7 @@ if what in ("single", "both"):
 if what in ("batch", "both"):
     for tps in os.environ.get("TPS", "0").split(","):
         bench.set_tuning("attend_tiles_per_split", int(tps))
-        r = bench.batch_attention_extra(torch, kv, n_seq=n_seq, T=T, scheme=5)["mxfp4_attention_batch_decode_step"]
+        r = list(bench.batch_attention_extra(torch, kv, n_seq=n_seq, T=T, scheme=5).values())[0]
         bench.set_tuning("attend_tiles_per_split", 0)
-        print(tag, f"batch {n_seq} x {T} tps", tps, r.get("ms_per_layer"), r.get("frac_hbm"), r.get("error"), flush=True)
+        print(tag, f"batch {n_seq} x {T} tps", tps, r.get("ms_per_layer"), r.get("frac_hbm"), "planned", r.get("planned_ms_per_layer"), r.get("planned_frac_hbm"), r.get("error"), flush=True)
 kv.close()
