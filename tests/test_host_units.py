@@ -412,3 +412,29 @@ def test_int4_batch_unequal_split_rule(rules):
             second = n_tiles - first
             assert 1 <= second <= first and -(-n_tiles // first) == 2      # what the kernel computes from tiles_per_split = first
 
+
+
+def test_mx4_class_enumeration_covers_every_page_once_and_stays_inside_the_planners_bound():
+    """k_attend_mx4's striped form takes the pages of a range by residue class (kernels.hpp: mx4_class_tiles, mx4_striped_tiles):
+    class c = pages j with j % n == c, in tiles of 16, every class with the tile count of the largest.  Restated here: every page
+    of the range appears in exactly one (class, tile, row), rows past a class's end are the masked ones, and the tile count stays
+    under the bound the planner sizes its splits with (engine_attend.cpp: plan_geometry, ceil(pages / 16) + runs + 1)."""
+    def class_tiles(n_pages, n):
+        return ((n_pages + n - 1) // n + 15) // 16
+
+    for n in range(1, 9):
+        for pages in list(range(1, 300)) + [511, 512, 513, 4095, 4096, 4097, 16384, 16385, 131071]:
+            m = class_tiles(pages, n)
+            total = n * m
+            assert total <= (pages + 15) // 16 + n + 1, (n, pages, total)
+            if pages > 2000:
+                continue
+            seen = set()
+            for t in range(total):
+                c, tm = divmod(t, m)
+                for row in range(16):
+                    j = c + n * (16 * tm + row)
+                    if j < pages:                                   # (the kernel's mask: j >= n_pages)
+                        assert j not in seen
+                        seen.add(j)
+            assert len(seen) == pages, (n, pages)
