@@ -188,6 +188,69 @@ def test_config5_70b_shaped_32k_context_at_full_size(eng, oracle, scheme):
     lib.free(h)
 
 
+def test_config4_layout_70b_shaped_32k_context_striped_over_7_pools_mxfp4(oracle):
+    """BASELINE configs[3]'s pool layout (1 compute + 7 pool GPUs; here seven runs on this GPU) at configs[4]'s size: 80 layers x 32 768
+    positions of MXFP4 KV striped page by page over the 7 runs -- the fused attention of all layers in one launch (the form that takes
+    the range's pages by residue class: classes of 2341 and 2340 pages, ragged last tiles), a per-layer call on a range that does
+    not start at 0, and sampled pages through fetch + decompress, against the oracle on sampled (layer, head) rows."""
+    torch = torch_mod()
+    os.environ["SPECKV_POOL_DEVICES"] = "0,0,0,0,0,0,0"
+    try:
+        kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), "hip:0")
+    finally:
+        os.environ.pop("SPECKV_POOL_DEVICES", None)
+    try:
+        lib = kv.lib
+        T, L, scheme = 32768, 80, 5
+        lib.set_compression_scheme(scheme)
+        h = kv.allocate(T, L, H, D, 2)
+        layer_pages = T
+        seed = sample_seed()
+        srng = np.random.default_rng(seed)
+        mid = int(srng.integers(1, L - 1))
+        sampled = {0: None, mid: None, 79: None}
+        for layer in range(L):
+            x = synth_pages(torch, 2006_000 + layer, layer_pages)
+            lib.write(h, layer * layer_pages * PAGE, x.data_ptr(), x.numel() * 2, True)
+            if layer in sampled:
+                sampled[layer] = x.cpu().numpy()
+            del x
+        assert {lib.translate(h, p * PAGE).pool_device for p in range(8)} == {0}        # (every "peer" is this GPU)
+        gq = torch.Generator(device="cuda"); gq.manual_seed(2006)
+        q = (torch.randn((L, H, G, D), generator=gq, device="cuda") * 1.5).to(torch.float16)
+        qh = q.cpu().numpy()
+        sm = 1.0 / np.sqrt(D)
+        checkers = {layer: HeadChecker(oracle, scheme, pages, T) for layer, pages in sampled.items()}
+        mh = int(srng.integers(0, H))
+        heads = {0: tuple(int(v) for v in srng.choice(H, 2, replace=False)), mid: (mh,), 79: (7, int(srng.integers(0, 7)))}
+        out = torch.full((L, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
+        lse = torch.full((L, H, G), float("nan"), dtype=torch.float32, device="cuda")
+        lib.attend_mx4(h, 0, L, q.data_ptr(), G, 0, T, sm, out.data_ptr(), lse.data_ptr())
+        torch.cuda.synchronize()
+        o, l_ = out.cpu().numpy(), lse.cpu().numpy()
+        assert np.isfinite(o).all() and np.isfinite(l_).all()
+        for layer, hs in heads.items():
+            for head in hs:
+                checkers[layer].check(o[layer, head], l_[layer, head], qh[layer, head], head, T, sm, ("striped x7, all layers", layer, head, "sample seed", seed))
+        # one layer by itself on a ragged range (32738 positions: classes of unequal length)
+        lib.attend_mx4(h, 79, 1, q[79].data_ptr(), G, 0, T - 30, sm, out.data_ptr(), lse.data_ptr())
+        torch.cuda.synchronize()
+        checkers[79].check(out[0, 7].cpu().numpy(), lse[0, 7].cpu().numpy(), qh[79, 7], 7, T - 30, sm, ("striped x7, layer 79, 32738 positions", "sample seed", seed))
+        rng = np.random.default_rng(seed)
+        for layer, pages16 in sampled.items():
+            idx = np.sort(rng.choice(layer_pages, 512, replace=False)).astype(np.uint32)
+            d_idx = torch.from_numpy((idx + layer * layer_pages).astype(np.int64)).to(torch.int32).cuda()
+            got = torch.empty((idx.size, N), dtype=torch.float16, device="cuda")
+            lib.fetch_list(h, d_idx.data_ptr(), idx.size, got.data_ptr(), False)
+            torch.cuda.synchronize()
+            c = checkers[layer]
+            want = oracle.decompress_blocks_f16(c.recs[idx], c.lens[idx], c.scales[idx], scheme, 0)
+            assert_same_float_bits(got.cpu().numpy(), want, f"striped x7, layer {layer} pages (sample seed {seed})")
+        lib.free(h)
+    finally:
+        kv.close()
+
+
 @pytest.mark.parametrize("scheme", [3, 4, 5])
 def test_config4_decode_step_256_sequences_8k_context(eng, oracle, scheme):
     """BASELINE configs[3]'s decode step on the config-5 formats: 256 sequences (one allocation each, 8 192 positions
