@@ -15,7 +15,7 @@ Two graphs exist (with and without the tail fold); both stay valid while the seq
 sized by a length bound and read the actual lengths from the plan on the device.  The result of every step is checked
 against the connector's eager path on a copy of the same state.
 
-    python examples/batch_decode_graph_example.py [--seqs 16] [--layers 4] [--prompt 96] [--steps 12] [--scheme fp8|int4]
+    python examples/batch_decode_graph_example.py [--seqs 16] [--layers 4] [--prompt 96] [--steps 12] [--scheme fp8|int4|mxfp4]
 """
 import argparse
 import ctypes
@@ -33,7 +33,7 @@ def run(seqs=16, layers=4, prompt=96, steps=12, scheme="fp8", max_tokens=512, ve
     from cxl_speckv_amd.kv_connector import SpeckvKVConnector
 
     H, D, G = 8, 128, 4
-    code = 4 if scheme == "fp8" else 3
+    code = {"fp8": 4, "int4": 3, "mxfp4": 5}[scheme]
     lib = pkg.SpeckvLib(pkg.library_path(), "hip:0")
     conn = None
     try:
@@ -132,6 +132,6 @@ if __name__ == "__main__":
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--prompt", type=int, default=96)
     ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--scheme", default="fp8", choices=["fp8", "int4"])
+    ap.add_argument("--scheme", default="fp8", choices=["fp8", "int4", "mxfp4"])
     a = ap.parse_args()
     run(a.seqs, a.layers, a.prompt, a.steps, a.scheme, max_tokens=(a.prompt + a.steps + 511) // 512 * 512)

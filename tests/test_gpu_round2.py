@@ -765,7 +765,7 @@ def test_write_strided_batch_equals_per_allocation_writes(scheme):
         lib.finalize()
 
 
-@pytest.mark.parametrize("scheme", ["fp8", "int4"])
+@pytest.mark.parametrize("scheme", ["fp8", "int4", "mxfp4"])
 def test_batch_decode_graph_example_runs(scheme):
     """examples/batch_decode_graph_example.py: a batch decode loop whose per-step attention (all layers, tail fold on odd
     steps) is one HIP graph replay, planned outside the graph; every step equals the connector's eager path."""
