@@ -613,7 +613,7 @@ def test_fused_attention_batch_of_sequences(eng, scheme):
     torch = torch_mod()
     lib = eng.lib
     lib.set_compression_scheme(scheme)
-    batch_fn, single_fn = (lib.attend_fp8_batch, lib.attend_fp8) if scheme == 4 else (lib.attend_int4_batch, lib.attend_int4)
+    batch_fn, single_fn = {4: (lib.attend_fp8_batch, lib.attend_fp8), 3: (lib.attend_int4_batch, lib.attend_int4), 5: (lib.attend_mx4_batch, lib.attend_mx4)}[scheme]
     T, L, H, D, G = 1024, 2, 8, 128, 8
     rng = np.random.default_rng(83)
     lens = [1024, 64, 0, 258, 1000, 32, 514, 2]
@@ -658,14 +658,14 @@ def test_fused_attention_batch_of_sequences(eng, scheme):
         lib.free(h)
 
 
-@pytest.mark.parametrize("scheme", [4, 3])
+@pytest.mark.parametrize("scheme", [4, 3, 5])
 def test_fused_attention_batch_larger_than_the_machine(eng, scheme):
     """More sequences than the GPU has CUs (INT4: the batch then runs on workgroups of one run each, two resident per CU,
     instead of the two-halves form): 272 short ragged sequences against the per-sequence entry point, batch and planned."""
     torch = torch_mod()
     lib = eng.lib
     lib.set_compression_scheme(scheme)
-    batch_fn, single_fn = (lib.attend_fp8_batch, lib.attend_fp8) if scheme == 4 else (lib.attend_int4_batch, lib.attend_int4)
+    batch_fn, single_fn = {4: (lib.attend_fp8_batch, lib.attend_fp8), 3: (lib.attend_int4_batch, lib.attend_int4), 5: (lib.attend_mx4_batch, lib.attend_mx4)}[scheme]
     T, L, H, D, G = 128, 1, 8, 128, 8
     rng = np.random.default_rng(97)
     n_seq = 272

@@ -191,7 +191,7 @@ def test_ring_wrap_and_eviction_by_the_fetch_kernel(oracle, seq_limit, host_word
         lib.finalize()
 
 
-@pytest.mark.parametrize("scheme", [2, 0, 4, 3])
+@pytest.mark.parametrize("scheme", [2, 0, 4, 3, 5])
 def test_copy_engine_fetch_equals_kernel_fetch(scheme):
     """speckv_ext_fetch_range_engine: engine 2 (coalesced hipMemcpyPeerAsync runs on per-peer streams into staging, local
     decompress, double-buffered) against engine 1 (fused peer-load kernel), pool striped over three peers."""
@@ -236,7 +236,7 @@ def test_copy_engine_fetch_equals_kernel_fetch(scheme):
         lib.finalize()
 
 
-@pytest.mark.parametrize("scheme", [4, 3, 1])
+@pytest.mark.parametrize("scheme", [4, 3, 1, 5])
 def test_migration_frees_exact_runs(scheme, oracle):
     """records are 2048 / 1152 B; migrating an odd number of pages out of a striped pool and then
     allocating and writing a second handle must leave every record of the first one intact."""
@@ -398,7 +398,7 @@ def test_batch_attention_refuses_stream_capture():
         lib.finalize()
 
 
-@pytest.mark.parametrize("scheme", [4, 3])
+@pytest.mark.parametrize("scheme", [4, 3, 5])
 def test_planned_batch_attention_replays_under_a_graph(scheme):
     """The planned form of the batch attention: speckv_ext_attend_batch_plan once per step outside the graph, the
     per-layer speckv_ext_attend_*_planned calls captured ONCE and replayed while the sequences grow.  Every replay must
@@ -409,7 +409,7 @@ def test_planned_batch_attention_replays_under_a_graph(scheme):
     lib = open_lib()
     try:
         lib.set_compression_scheme(scheme)
-        single_fn = lib.attend_fp8 if scheme == 4 else lib.attend_int4
+        single_fn = {4: lib.attend_fp8, 3: lib.attend_int4, 5: lib.attend_mx4}[scheme]
         T, L, H, D, G = 2048, 3, 8, 128, 4
         rng = np.random.default_rng(97)
         steps = [[64, 1024, 2, 600, 0], [66, 1026, 4, 602, 0], [512, 2048, 34, 1600, 2], [2048, 2048, 2048, 2048, 2048]]
@@ -448,7 +448,7 @@ def test_planned_batch_attention_replays_under_a_graph(scheme):
                 with pytest.raises(SpeckvError):
                     lib.attend_planned(scheme, plan.data_ptr(), n_seq, 0, q[0].data_ptr(), G, T - 2, sm, out[0].data_ptr(), None, s.cuda_stream)
                 with pytest.raises(SpeckvError):
-                    lib.attend_planned(7 - scheme, plan.data_ptr(), n_seq, 0, q[0].data_ptr(), G, T, sm, out[0].data_ptr(), None, s.cuda_stream)
+                    lib.attend_planned({4: 3, 3: 4, 5: 4}[scheme], plan.data_ptr(), n_seq, 0, q[0].data_ptr(), G, T, sm, out[0].data_ptr(), None, s.cuda_stream)     # another format than the plan's
                 run_layers()                              # warm-up: sizes the scratch
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
@@ -707,7 +707,7 @@ def test_int4_attention_with_group_scales_near_the_fp16_limit(oracle):
         lib.finalize()
 
 
-@pytest.mark.parametrize("scheme", [2, 3, 4])
+@pytest.mark.parametrize("scheme", [2, 3, 4, 5])
 def test_write_strided_batch_equals_per_allocation_writes(scheme):
     """speckv_ext_write_strided_batch (one launch for a batch of allocations: the append of a decode step) stores exactly
     what one speckv_ext_write_strided per allocation stores: record lengths, scales and decoded pages are identical; a page

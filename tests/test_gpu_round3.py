@@ -752,7 +752,7 @@ def test_compaction_packs_rle_records_and_frees_the_slots(oracle, pools):
         lib.finalize()
 
 
-@pytest.mark.parametrize("scheme", [3, 4])
+@pytest.mark.parametrize("scheme", [3, 4, 5])
 def test_batch_and_planned_attention_over_striped_pools(scheme):
     """A decode step of a batch whose sequences live in striped pools (the 1 + 7 layout of configs[3]): the batch and the
     planned forms used to refuse anything but single-run allocations.  Each sequence descriptor now carries its own run
@@ -773,11 +773,11 @@ def test_batch_and_planned_attention_over_striped_pools(scheme):
             x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.3, 2.0, (n_pages, 1))).astype(np.float16)
             lib.write(h, 0, x.ctypes.data, x.nbytes, False)
             handles.append(h)
-        assert lib.translate(handles[0], 0).pool_addr != lib.translate(handles[0], PAGE).pool_addr - (2048 if scheme == 4 else 1152)
+        assert lib.translate(handles[0], 0).pool_addr != lib.translate(handles[0], PAGE).pool_addr - (2048 if scheme == 4 else 1152)       # (INT4_G32 and MXFP4 slots: 1152 B)
         q = torch.from_numpy(rng.standard_normal((len(lens), H, G, D)).astype(np.float16)).cuda()
         sm = 1.0 / np.sqrt(D)
-        single = lib.attend_int4 if scheme == 3 else lib.attend_fp8
-        batch = lib.attend_int4_batch if scheme == 3 else lib.attend_fp8_batch
+        single = {3: lib.attend_int4, 4: lib.attend_fp8, 5: lib.attend_mx4}[scheme]
+        batch = {3: lib.attend_int4_batch, 4: lib.attend_fp8_batch, 5: lib.attend_mx4_batch}[scheme]
         st = torch.cuda.Stream()
         for layer in (0, 1):
             ref = torch.zeros((len(lens), H, G, D), dtype=torch.float32, device="cuda")
@@ -1096,7 +1096,7 @@ def test_vllm_connector_prefix_hit_chunked_prefill_and_separate_roles():
         lib.finalize()
 
 
-@pytest.mark.parametrize("scheme", [3, 4])
+@pytest.mark.parametrize("scheme", [3, 4, 5])
 def test_attention_calls_on_different_streams_share_the_scratch_safely(scheme):
     """The split partials of every fused-attention call live in ONE scratch buffer of the engine.  Calls issued back to back on
     different caller streams (no host synchronisation in between) used to be the caller's problem ("use one stream"); the
@@ -1110,7 +1110,7 @@ def test_attention_calls_on_different_streams_share_the_scratch_safely(scheme):
     lib = open_lib()
     try:
         lib.set_compression_scheme(scheme)
-        attend = lib.attend_int4 if scheme == 3 else lib.attend_fp8
+        attend = {3: lib.attend_int4, 4: lib.attend_fp8, 5: lib.attend_mx4}[scheme]
         rng = np.random.default_rng(900 + scheme)
         hs, qs = [], []
         for i in range(2):
