@@ -773,7 +773,7 @@ int Engine::attend_mx4(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     const uint32_t stream_wgs = stream_knob > 0 ? static_cast<uint32_t>(stream_knob) : cus() / zgroups;
     const bool stream = linear && n_layers >= 2u && (n_pages & 15u) == 0u && tuning().attend_splits <= 0 && stream_wgs >= 1u &&
                         total_tiles >= stream_wgs && total_tiles / stream_wgs <= 0xFFFFFFFFull &&
-                        (stream_knob > 0 || (stream_knob == 0 && total_tiles >= 16ull * stream_wgs));
+                        (stream_knob > 0 || (stream_knob == 0 && total_tiles >= 16ull * stream_wgs && es.n_splits > 1u));      // (a fixed grid of whole layers writes final rows: no partials, no merge)
     if (stream) {
         k.stream.n_wgs = stream_wgs;
         k.stream.len = static_cast<uint32_t>(total_tiles / stream_wgs);
