@@ -54,7 +54,11 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 namespace {
 
 #define MX_GP(T, p) ((const T __attribute__((address_space(1)))*)(reinterpret_cast<uintptr_t>(p)))
-constexpr uint32_t kRec = kMx4SlotBytes;                     // record stride: 1088 bytes of record in a slot of 9 lines
+// Records in the pool are tile-planar (kernels.hpp): 16 records of a run = 16 nibble rows (1024 B each) + 16 code rows (64 B each)
+// = 136 whole cache lines.  A 16-page tile of the kernel that starts at record R of its run reads rows R .. R+15; with R a multiple
+// of 16 (every tile-aligned range of a layout whose regions are multiples of 16 pages) that is ONE storage tile: the ten 1 KiB
+// requests below touch exactly its 136 lines, and nothing else (round 5's 1152-byte slots: 144).  Any other phase R % 16 works
+// too: rows past the storage tile's 16th continue in the next one (lane offsets + one tile's codes, tile_offsets).
 constexpr uint32_t kWavesPerWg = 4;                          // two heads per wave: a workgroup covers the 8 kv heads -- the four waves that read a
                                                              // record's 64 bytes of codes then sit on one CU (one L2): measured with two workgroups per
                                                              // record, each code line came from HBM up to four times (profiles/r05_mx4.txt)
@@ -133,8 +137,8 @@ __device__ __forceinline__ float q_clean(uint32_t half_bits)
 
 } // namespace
 
-// FORM 0: records in one run (record p at lin_base + p * 1088; never-written records are zero bytes = zeros with code 0)
-// FORM 1: striped regularly over 1..8 runs (AttendArgs::stripe_bases; the record of page p = bases[p % n] + (p / n) * 1152).  The
+// FORM 0: records in one run (record p = record p of the tile-planar run at lin_base; never-written records are zero bytes = zeros with code 0)
+// FORM 1: striped regularly over 1..8 runs (AttendArgs::stripe_bases; the record of page p = record p / n of the run bases[p % n]).  The
 //         range's pages are taken by residue CLASS (mx4_class_tiles): class c = the pages j of the range with j % n == c, every
 //         class in tiles of 16 -- a tile = 16 pages n apart = 16 CONSECUTIVE records of one run for K and of one run for V, so
 //         it is fetched exactly as in form 0 (one scalar base, the same ten instructions): attention does not care in which order
@@ -282,15 +286,37 @@ __global__ __launch_bounds__(64 * kWavesPerWg * HALVES) __attribute__((amdgpu_wa
         // ---- staging: DMA instruction i (0..3) of a region fills page rows 4i .. 4i+3: lane l -> row 4i + l/16, 16-byte slot l%16,
         // which holds piece (slot ^ row) of the two heads' 256 bytes -- the XOR spreads the operand reads below over the banks
         const uint32_t srow = lane >> 4, sslot = lane & 15u;
-        uint32_t goff[4];                                                // byte offset of the lane's piece from the tile's first record
+        // byte offset of the lane's piece from the nibble row of the tile's FIRST record (scalar base), for a tile that starts on a
+        // storage-tile boundary (phase 0): row r at r * 1024; its codes at 16384 + r * 64
+        uint32_t goff[4];
 #pragma unroll
-        for (uint32_t i = 0; i < 4; ++i) goff[i] = (4u * i + srow) * kRec + h0 * 128u + ((sslot ^ ((4u * i + srow) & 15u)) * 16u);
-        const uint32_t goffc = (lane >> 2) * kRec + 1024u + h0 * 8u + (lane & 3u) * 4u;      // codes: lane l -> page l/4, dword l%4 of the two heads' 16
+        for (uint32_t i = 0; i < 4; ++i) goff[i] = (4u * i + srow) * 1024u + h0 * 128u + ((sslot ^ ((4u * i + srow) & 15u)) * 16u);
+        const uint32_t goffc = kMx4CodePlane + (lane >> 2) * 64u + h0 * 8u + (lane & 3u) * 4u;      // codes: lane l -> page l/4, dword l%4 of the two heads' 16
+        // ... and for a tile whose first record is slot `ph` of its storage tile, rows clamped to imax (masked rows fetch a live one):
+        // rows with ph + r >= 16 lie in the next storage tile, 1024 bytes further on than r * 1024 says; a code row lies
+        // 16384 - 960 * slot behind its nibble row (mx4_code_delta)
+        auto issue = [&](uint32_t drows, uint32_t dcodes, const uint8_t* rt, uint32_t ph, uint32_t imax) __attribute__((always_inline)) {
+            if (ph == 0u && imax == 15u) {                                       // (wave-uniform)
+                dma_region(drows, dcodes, rt, goff, goffc);
+                return;
+            }
+            uint32_t gc[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t r = min(4u * i + srow, imax);
+                gc[i] = r * 1024u + (ph + r >= 16u ? 1024u : 0u) + h0 * 128u + ((sslot ^ ((4u * i + srow) & 15u)) * 16u);
+            }
+            const uint32_t rc = min(lane >> 2, imax);
+            const uint32_t gcc = (kMx4CodePlane - 960u * ph) + rc * 64u + (ph + rc >= 16u ? kMx4CodePlane : 0u) + h0 * 8u + (lane & 3u) * 4u;
+            dma_region(drows, dcodes, rt, gc, gcc);
+        };
         const uint32_t kfirst = static_cast<uint32_t>(a.k_first), vfirst = static_cast<uint32_t>(a.v_first), last_pg = a.n_pages - 1u;
         const uint32_t last = t1 - 1u;
-        auto rec_of = [&](uint32_t first, uint32_t page_in_range) -> const uint8_t* {        // FORM 2: record of a page of the range
-            const u32x4 e = *MX_GP(u32x4, a.entries + (first + min(page_in_range, last_pg)));      // {address lo, hi, record bytes, scale}
+        // FORM 2: record of a page of the range = {nibble row, its codes' distance behind it} (never-written pages: the zero page, 1024)
+        auto rec_of = [&](uint32_t first, uint32_t page_in_range, uint32_t& code_delta) -> const uint8_t* {
+            const u32x4 e = *MX_GP(u32x4, a.entries + (first + min(page_in_range, last_pg)));      // {address lo, hi, record bytes, code delta}
             const uint8_t* r = reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(e.x) | (static_cast<uint64_t>(e.y) << 32));
+            code_delta = e.z >= kMx4RecBytes ? e.w : 1024u;
             return e.z >= kMx4RecBytes ? r : a.zero_page;
         };
         // stream form: the next tile each region (K, V) will ask for -- its first page, its tile number in the layer, tiles left
@@ -321,41 +347,37 @@ __global__ __launch_bounds__(64 * kWavesPerWg * HALVES) __attribute__((amdgpu_wa
                 const uint32_t mm = min(m, (cnt - 1u) >> 4);                      // a tile past the class's end fetches its last one (all masked)
                 const uint32_t imax = __builtin_amdgcn_readfirstlane(min(15u, cnt - 1u - 16u * mm));      // rows past the class's end fetch its last record
                 const uint64_t base = s_bases[pool];                              // (an LDS read: the compiler's wait for it leaves the DMA counter alone)
-                const uint8_t* rt = uniform_ptr(reinterpret_cast<const uint8_t*>(base) + static_cast<uint64_t>(rec0 + 16u * mm) * kRec);
-                if (imax == 15u) {
-                    dma_region(__builtin_amdgcn_readfirstlane(drows), __builtin_amdgcn_readfirstlane(dcodes), rt, goff, goffc);
-                } else {
-                    uint32_t gc[4];
-#pragma unroll
-                    for (uint32_t i = 0; i < 4; ++i) gc[i] = min(4u * i + srow, imax) * kRec + h0 * 128u + ((sslot ^ ((4u * i + srow) & 15u)) * 16u);
-                    dma_region(__builtin_amdgcn_readfirstlane(drows), __builtin_amdgcn_readfirstlane(dcodes), rt, gc, min(lane >> 2, imax) * kRec + 1024u + h0 * 8u + (lane & 3u) * 4u);
-                }
+                const uint32_t R = rec0 + 16u * mm;                               // the tile's first record in its run
+                const uint8_t* rt = uniform_ptr(reinterpret_cast<const uint8_t*>(base) + mx4_nib_off(R));
+                issue(__builtin_amdgcn_readfirstlane(drows), __builtin_amdgcn_readfirstlane(dcodes), rt, R & 15u, imax);
                 if (cq_left[rg] > 1u) {
                     --cq_left[rg];
                     if (++cq_m[rg] == cls_m) { cq_m[rg] = 0u; ++cq_cls[rg]; }
                 }
             } else if (STREAM) {
-                const uint8_t* rt = uniform_ptr(a.lin_base + static_cast<uint64_t>(rq_page[rg]) * kRec);    // (wave-uniform by construction)
-                dma_region(drows, dcodes, rt, goff, goffc);
+                const uint8_t* rt = uniform_ptr(a.lin_base + mx4_nib_off(rq_page[rg]));    // (wave-uniform by construction)
+                issue(drows, dcodes, rt, rq_page[rg] & 15u, 15u);
                 if (rq_left[rg] > 1u) {
                     --rq_left[rg];
                     rq_page[rg] += 16u;
                     if (++rq_ct[rg] == n_tiles) { rq_ct[rg] = 0u; rq_page[rg] += layer_gap; }
                 }
             } else if (FORM == 0) {
-                const uint8_t* rt = a.lin_base + (static_cast<uint64_t>(first) + 16ull * tc) * kRec;      // (scalar)
-                dma_region(drows, dcodes, rt, goff, goffc);
+                const uint64_t R = static_cast<uint64_t>(first) + 16ull * tc;
+                const uint8_t* rt = a.lin_base + mx4_nib_off(R);                  // (scalar)
+                issue(drows, dcodes, rt, first & 15u, 15u);
             } else {
                 // page-table form: through registers, synchronously (the slow path of odd ranges and migrated allocations)
                 uint8_t* d = const_cast<uint8_t*>(lptr) + buf * kStage;
+                uint32_t cd;
 #pragma unroll
                 for (uint32_t i = 0; i < 4; ++i) {
-                    const uint8_t* r = rec_of(first, 16u * tc + 4u * i + srow);
+                    const uint8_t* r = rec_of(first, 16u * tc + 4u * i + srow, cd);
                     *reinterpret_cast<u32x4*>(d + (rg ? kStV : kStK) + 1024u * i + 16u * lane) =
                         *MX_GP(u32x4, r + h0 * 128u + ((sslot ^ ((4u * i + srow) & 15u)) * 16u));
                 }
-                const uint8_t* r = rec_of(first, 16u * tc + (lane >> 2));
-                *reinterpret_cast<uint32_t*>(d + (rg ? kStVC : kStKC) + 4u * lane) = *MX_GP(uint32_t, r + 1024u + h0 * 8u + (lane & 3u) * 4u);
+                const uint8_t* r = rec_of(first, 16u * tc + (lane >> 2), cd);
+                *reinterpret_cast<uint32_t*>(d + (rg ? kStVC : kStKC) + 4u * lane) = *MX_GP(uint32_t, r + cd + h0 * 8u + (lane & 3u) * 4u);
             }
         };
         // request order K(t), V(t), K(t+1), V(t+1), ...: five instructions each, so "all but the 15 youngest" is "this region has landed"

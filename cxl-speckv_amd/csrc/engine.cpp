@@ -335,14 +335,14 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
                 for (uint32_t k = 0; k < D && ok; ++k) {
                     const uint64_t np = shard_pages(a->n_pages, D, k);    // pages with page % D == k
                     if (np == 0) { a->extents.push_back({use[k], nullptr, 0, 0}); continue; }
-                    const size_t need = np * a->rec_stride;
+                    const size_t need = run_bytes_for(a->scheme, a->rec_stride, np);
                     void* base = pools_[use[k]]->alloc(need);
                     if (base) {
                         a->extents.push_back({use[k], base, need, np});
                         if (!single_run) {
                             if (host.empty()) host.resize(a->n_pages);
                             for (uint64_t j = 0; j < np; ++j)
-                                host[k + j * D] = PageEntry{reinterpret_cast<uint64_t>(base) + j * a->rec_stride, 0u, 1.0f};
+                                host[k + j * D] = entry_at(a->scheme, a->rec_stride, reinterpret_cast<uint64_t>(base), j);
                         }
                         continue;
                     }
@@ -352,12 +352,12 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
                     uint64_t placed = 0;
                     while (ok && placed < np) {
                         size_t got = 0;
-                        void* part = pools_[use[k]]->alloc_up_to((np - placed) * a->rec_stride, a->rec_stride, &got);
+                        void* part = pools_[use[k]]->alloc_up_to(run_bytes_for(a->scheme, a->rec_stride, np - placed), run_granule_for(a->scheme, a->rec_stride), &got);
                         if (!part) { ok = false; break; }
-                        const uint64_t cnt = got / a->rec_stride;
+                        const uint64_t cnt = std::min<uint64_t>(run_records_for(a->scheme, a->rec_stride, got), np - placed);
                         a->extents.push_back({use[k], part, got, cnt});
                         for (uint64_t j = 0; j < cnt; ++j)
-                            host[k + (placed + j) * D] = PageEntry{reinterpret_cast<uint64_t>(part) + j * a->rec_stride, 0u, 1.0f};
+                            host[k + (placed + j) * D] = entry_at(a->scheme, a->rec_stride, reinterpret_cast<uint64_t>(part), j);
                         placed += cnt;
                     }
                 }
@@ -365,8 +365,14 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
                 // out of pool memory with freed allocations still waiting for their streams: wait for them, retry
                 for (auto& ex : a->extents) if (ex.base) pools_[ex.pool]->free(ex.base, ex.bytes);
                 a->extents.clear();
+                a->mx4_vacated.clear();
                 drain_zombies(true);
             }
+            if (ok && planar_mx4(a->scheme))                  // the unused tail of every run's last tile holds no page
+                for (const auto& ex : a->extents)
+                    if (ex.base && ex.n_pages % kMx4TileRecs)
+                        a->mx4_vacated[reinterpret_cast<uint64_t>(ex.base) + ex.n_pages / kMx4TileRecs * kMx4TileBytes] =
+                            static_cast<uint16_t>(0xFFFFu << (ex.n_pages % kMx4TileRecs));
             uint32_t* dev3 = nullptr;
             if (ok) ok = hipMalloc(reinterpret_cast<void**>(&a->d_entries), a->n_pages * sizeof(PageEntry)) == hipSuccess;
             if (ok) ok = hipMalloc(reinterpret_cast<void**>(&dev3), 3 * a->n_pages * sizeof(uint32_t)) == hipSuccess;
@@ -388,7 +394,7 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
             if (ok) {
                 if (single_run)
                     ok = launch_init_entries(a->d_entries, a->n_pages, reinterpret_cast<uint64_t>(a->extents[0].base),
-                                             a->rec_stride, stream_) == hipSuccess;
+                                             planar_mx4(a->scheme) ? kPlanarMx4 : a->rec_stride, stream_) == hipSuccess;
                 else
                     ok = hipMemcpy(a->d_entries, host.data(), host.size() * sizeof(PageEntry), hipMemcpyHostToDevice) == hipSuccess;
             }
@@ -1113,8 +1119,9 @@ int Engine::translate(uint64_t handle, uint64_t off, speckv_ext_page_info_t* o)
     HIP_TRY(hipMemcpy(&e, a->d_entries + p, sizeof(e), hipMemcpyDeviceToHost));
     o->pool_device = pools_[a->page_pool[p]]->device();
     o->rec_bytes = e.rec_bytes;
-    o->scale = e.scale;
+    o->scale = planar_mx4(a->scheme) ? 1.0f : e.scale;
     o->pool_addr = e.pool_addr;
+    o->aux_offset = planar_mx4(a->scheme) ? float_bits(e.scale) : 0u;      // tile-planar MXFP4: the record's 64 codes lie this far behind its nibbles
     o->cache_addr = (res_flags(a, p) & 3u) ? reinterpret_cast<uint64_t>(slot_ptr(res_slot(a, p))) : 0;
     o->access_count = a->access_count[p];
     return SPECKV_OK;

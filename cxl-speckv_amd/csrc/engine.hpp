@@ -76,6 +76,10 @@ struct Allocation {
     // HIP mode
     struct Extent { int pool; void* base; size_t bytes; uint64_t n_pages; };
     std::vector<Extent> extents;
+    // tile-planar MXFP4 runs (kernels.hpp) are returned to the pool tile by tile: tile address -> record slots that hold no page
+    // of this allocation (the unused tail of a run's last tile, records that migrated away); a tile whose 16 slots are all
+    // vacated goes back (Engine::migrate).  Only tiles with at least one vacated slot are listed.
+    std::unordered_map<uint64_t, uint16_t> mx4_vacated;
     std::vector<int> pool_of_residue;     // pool index serving pages with page % D == k (at allocation)
     std::vector<uint8_t> page_pool;       // pool index holding each page's record now
     bool regular = false;                 // placement still is "page p = record p/D of the run on pool p%D"
@@ -403,6 +407,7 @@ private:
     int fetch_into_slot(Allocation* a, uint32_t page, uint32_t slot);
     int fetch_range_copy_engine(Allocation* a, uint64_t first, uint64_t n, void* d_dst, bool f32, hipStream_t st);
     bool infer_layout(Allocation* a);
+    int migrate_mx4(Allocation* a, uint64_t first, uint64_t n, uint32_t target_pool);      // tile-planar records (engine_relocate.cpp)
     int unpack(Allocation* a);                            // a compacted allocation back into fixed slots (before any write / migration)
     int settle_for_relocation(Allocation*& a, uint64_t handle);
     int write_groups(const uint64_t* handles, const uint64_t* firsts, const void* const* d_srcs, uint32_t n_groups, uint64_t step,

@@ -64,10 +64,28 @@ uint32_t stride_for(int scheme)
     case SPECKV_COMP_INT8: return 2048u;
     case SPECKV_COMP_FP8_E4M3: return 2048u;
     case SPECKV_COMP_INT4_G32: return kInt4RecBytes;      // 1152 B: the 4:1 format (3.56:1 with scales)
-    case SPECKV_COMP_MXFP4: return kMx4SlotBytes;         // 1088-byte records (3.76:1 of traffic) in line-aligned 1152-byte slots (3.56:1 of capacity)
+    case SPECKV_COMP_MXFP4: return kMx4RecBytes;          // 1088 B per record (3.76:1), but NOT a stride: the pool holds them tile-planar (kernels.hpp, planar_mx4)
     default: return kPageSize;
     }
 }
+
+// MXFP4 runs are tile-planar (kernels.hpp: 16 records = 16 nibble rows + 16 code rows = 136 lines): bytes of a run of `recs`
+// records, and the table entry of record r of the run at `base`
+bool planar_mx4(int scheme) { return scheme == SPECKV_COMP_MXFP4; }
+float bits_as_float(uint32_t u) { float f; memcpy(&f, &u, sizeof(f)); return f; }
+uint32_t float_bits(float f) { uint32_t u; memcpy(&u, &f, sizeof(u)); return u; }
+size_t run_bytes_for(int scheme, uint32_t stride, uint64_t recs)
+{
+    return planar_mx4(scheme) ? static_cast<size_t>(mx4_run_bytes(recs)) : static_cast<size_t>(recs) * stride;
+}
+PageEntry entry_at(int scheme, uint32_t stride, uint64_t base, uint64_t r)
+{
+    if (planar_mx4(scheme)) return PageEntry{base + mx4_nib_off(r), 0u, bits_as_float(mx4_code_delta(r))};
+    return PageEntry{base + r * stride, 0u, 1.0f};
+}
+// granule in which a fragmented pool serves such runs, and the records a piece of `bytes` holds
+size_t run_granule_for(int scheme, uint32_t stride) { return planar_mx4(scheme) ? kMx4TileBytes : stride; }
+uint64_t run_records_for(int scheme, uint32_t stride, size_t bytes) { return planar_mx4(scheme) ? bytes / kMx4TileBytes * kMx4TileRecs : bytes / stride; }
 
 int no_data_path(const char* what)
 {

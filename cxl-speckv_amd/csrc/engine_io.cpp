@@ -353,9 +353,12 @@ int Engine::fetch_range_copy_engine(Allocation* a, uint64_t first, uint64_t n, v
             for (auto& ev : lanes_[i].copied) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         }
     }
-    // records per pool and chunk: the staging buffer is cut into D equal regions
-    const uint64_t region = (stage_bytes_ / D) / stride * stride;
-    const uint64_t recs_per_region = region / stride;
+    // records per pool and chunk: the staging buffer is cut into D equal regions.  Tile-planar MXFP4 runs move as whole tiles
+    // (the staged copy keeps every record's place inside its tile, so "pool address + delta" still finds nibbles and codes):
+    // a chunk's records may begin and end inside a tile -- one tile of the region is kept for that
+    const bool planar = planar_mx4(a->scheme);
+    const uint64_t region = planar ? (stage_bytes_ / D) / kMx4TileBytes * kMx4TileBytes : (stage_bytes_ / D) / stride * stride;
+    const uint64_t recs_per_region = planar ? (region / kMx4TileBytes >= 2 ? (region / kMx4TileBytes - 1) * kMx4TileRecs : 0) : region / stride;
     if (recs_per_region == 0) return SPECKV_ERR_NOMEM;
     const uint64_t chunk_pages = recs_per_region * D;     // logical pages per chunk (each pool gets <= recs_per_region of them)
     // the source records must be in place: everything queued on the engine stream (writes are synchronous) and on
@@ -397,6 +400,10 @@ int Engine::fetch_range_copy_engine(Allocation* a, uint64_t first, uint64_t n, v
                 const uint64_t hi = p_next < a->n_pages ? static_cast<uint64_t>(a->packed_off128[p_next]) << 7 : a->packed_bytes[k];
                 src = static_cast<const uint8_t*>(a->extents[k].base) + lo;
                 run_bytes = static_cast<size_t>(hi - lo);
+            } else if (planar) {
+                const uint64_t t0 = rb / kMx4TileRecs, t1 = (rb + cnt + kMx4TileRecs - 1) / kMx4TileRecs;
+                src = static_cast<const uint8_t*>(a->extents[k].base) + t0 * kMx4TileBytes;
+                run_bytes = static_cast<size_t>(t1 - t0) * kMx4TileBytes;
             } else {
                 src = static_cast<const uint8_t*>(a->extents[k].base) + rb * stride;
                 run_bytes = cnt * stride;

@@ -27,6 +27,7 @@ int Engine::migrate(uint64_t handle, uint64_t first, uint64_t n, uint32_t target
         if (hipStreamSynchronize(us) != hipSuccess) (void)hipGetLastError();
     reap(false);
     if (!copy_stream_) HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    if (planar_mx4(a->scheme)) return migrate_mx4(a, first, n, target_pool);
     const size_t stride = a->rec_stride;
     uint8_t* dst = static_cast<uint8_t*>(pools_[target_pool]->alloc(n * stride));
     if (!dst) return SPECKV_ERR_NOMEM;
@@ -85,6 +86,121 @@ int Engine::migrate(uint64_t handle, uint64_t first, uint64_t n, uint32_t target
         a->regular = true;
         const bool fixed_fmt = a->scheme == SPECKV_COMP_FP8_E4M3 || a->scheme == SPECKV_COMP_INT4_G32 || a->scheme == SPECKV_COMP_MXFP4;
         if (fixed_fmt && a->d_stripe) {
+            uint64_t bases[8] = {reinterpret_cast<uint64_t>(dst), 0, 0, 0, 0, 0, 0, 0};
+            HIP_TRY(hipMemcpy(a->d_stripe, bases, sizeof(bases), hipMemcpyHostToDevice));
+            a->linear_base = dst;
+            a->stripe_n = 1;
+        }
+    }
+    return SPECKV_OK;
+}
+
+// The same for tile-planar MXFP4 records (kernels.hpp: 16 records = 16 nibble rows + 16 code rows, 136 whole lines).  A source
+// run = consecutive pages whose records are consecutive slots of one pool's run.  The destination is one new run, records
+// dense in page order -- except that a long source run (>= 32 records) starts at its source's slot phase (up to 15 slots of
+// padding), so that all its full tiles move as ONE hipMemcpyPeerAsync; everything else moves in pieces cut at the tile
+// boundaries of either side (a piece = its nibble rows + its code rows: two copies).  Old tiles go back to their pool when
+// their last record has left (Allocation::mx4_vacated).
+int Engine::migrate_mx4(Allocation* a, uint64_t first, uint64_t n, uint32_t target_pool)
+{
+    std::vector<PageEntry> cur(n);
+    HIP_TRY(hipMemcpy(cur.data(), a->d_entries + first, n * sizeof(PageEntry), hipMemcpyDeviceToHost));
+    struct Src { uint64_t i0, cnt, tile; uint32_t j0; int pool; uint64_t d0; };      // records i0 .. i0+cnt of the range: slot j0 of the tile at `tile` on
+    auto slot_of = [](const PageEntry& e) { return (kMx4CodePlane - float_bits(e.scale)) / 960u; };
+    std::vector<Src> runs;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t j = slot_of(cur[i]);
+        const uint64_t tile = cur[i].pool_addr - 1024ull * j;
+        const int pool = a->page_pool[first + i];
+        if (!runs.empty()) {
+            const Src& r = runs.back();
+            const uint64_t next = r.j0 + r.cnt;
+            if (r.pool == pool && tile == r.tile + next / kMx4TileRecs * kMx4TileBytes && j == next % kMx4TileRecs) { runs.back().cnt++; continue; }
+        }
+        runs.push_back({i, 1, tile, j, pool, 0});
+    }
+    uint64_t total = 0;
+    for (Src& r : runs) {
+        if (r.cnt >= 2 * kMx4TileRecs) total += (r.j0 + kMx4TileRecs - total % kMx4TileRecs) % kMx4TileRecs;      // the source's phase
+        r.d0 = total;
+        total += r.cnt;
+    }
+    const size_t dst_bytes = static_cast<size_t>(mx4_run_bytes(total));
+    uint8_t* dst = static_cast<uint8_t*>(pools_[target_pool]->alloc(dst_bytes));
+    if (!dst) return SPECKV_ERR_NOMEM;
+    struct PoolGuard {
+        SlabPool* pool; void* p; size_t bytes; bool keep = false;
+        ~PoolGuard() { if (!keep) pool->free(p, bytes); }
+    } guard{pools_[target_pool].get(), dst, dst_bytes};
+    const int dst_dev = pools_[target_pool]->device();
+    std::vector<uint16_t> used((total + kMx4TileRecs - 1) / kMx4TileRecs, 0);            // slots of the new run that hold a page
+    for (const Src& r : runs) {
+        const int src_dev = pools_[r.pool]->device();
+        const uint8_t* sb = reinterpret_cast<const uint8_t*>(r.tile);
+        uint64_t s = r.j0, t = r.d0, left = r.cnt;
+        while (left) {
+            if (s % kMx4TileRecs == 0 && t % kMx4TileRecs == 0 && left >= kMx4TileRecs) {
+                const uint64_t m = left / kMx4TileRecs;
+                HIP_TRY(hipMemcpyPeerAsync(dst + t / kMx4TileRecs * kMx4TileBytes, dst_dev, sb + s / kMx4TileRecs * kMx4TileBytes, src_dev,
+                                           static_cast<size_t>(m) * kMx4TileBytes, copy_stream_));
+                s += m * kMx4TileRecs; t += m * kMx4TileRecs; left -= m * kMx4TileRecs;
+                continue;
+            }
+            const uint64_t len = std::min<uint64_t>(left, std::min<uint64_t>(kMx4TileRecs - s % kMx4TileRecs, kMx4TileRecs - t % kMx4TileRecs));
+            HIP_TRY(hipMemcpyPeerAsync(dst + mx4_nib_off(t), dst_dev, sb + mx4_nib_off(s), src_dev, static_cast<size_t>(len) * 1024u, copy_stream_));
+            HIP_TRY(hipMemcpyPeerAsync(dst + mx4_nib_off(t) + mx4_code_delta(t), dst_dev, sb + mx4_nib_off(s) + mx4_code_delta(s), src_dev,
+                                       static_cast<size_t>(len) * 64u, copy_stream_));
+            s += len; t += len; left -= len;
+        }
+        for (uint64_t c = 0; c < r.cnt; ++c) {
+            used[(r.d0 + c) / kMx4TileRecs] |= static_cast<uint16_t>(1u << ((r.d0 + c) % kMx4TileRecs));
+            cur[r.i0 + c] = PageEntry{reinterpret_cast<uint64_t>(dst) + mx4_nib_off(r.d0 + c), cur[r.i0 + c].rec_bytes, bits_as_float(mx4_code_delta(r.d0 + c))};
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(copy_stream_));
+    HIP_TRY(hipMemcpy(a->d_entries + first, cur.data(), n * sizeof(PageEntry), hipMemcpyHostToDevice));
+    guard.keep = true;
+    // the slots the records left: a tile whose 16 slots are all vacated goes back to its pool, adjacent ones as one range
+    std::vector<std::pair<uint64_t, int>> gone;
+    for (const Src& r : runs)
+        for (uint64_t c = 0; c < r.cnt; ++c) {
+            const uint64_t tile = r.tile + (r.j0 + c) / kMx4TileRecs * kMx4TileBytes;
+            uint16_t& m = a->mx4_vacated[tile];
+            m |= static_cast<uint16_t>(1u << ((r.j0 + c) % kMx4TileRecs));
+            if (m == 0xFFFFu) { gone.push_back({tile, r.pool}); a->mx4_vacated.erase(tile); }
+        }
+    std::sort(gone.begin(), gone.end());
+    for (size_t g = 0; g < gone.size();) {
+        size_t h = g + 1;
+        while (h < gone.size() && gone[h].second == gone[g].second && gone[h].first == gone[h - 1].first + kMx4TileBytes) ++h;
+        const uint64_t addr = gone[g].first, bytes = (h - g) * static_cast<uint64_t>(kMx4TileBytes);
+        const int pool = gone[g].second;
+        // (adjacent tiles may still belong to two extents of a fragmented allocation: every extent gives up its share)
+        std::vector<Allocation::Extent> next;
+        for (const auto& ex : a->extents) {
+            const uint64_t lo = reinterpret_cast<uint64_t>(ex.base), hi = lo + ex.bytes;
+            if (!ex.base || ex.pool != pool || addr >= hi || addr + bytes <= lo) { next.push_back(ex); continue; }
+            const uint64_t f0 = std::max(lo, addr), f1 = std::min(hi, addr + bytes);
+            if (f0 > lo) next.push_back({ex.pool, ex.base, static_cast<size_t>(f0 - lo), (f0 - lo) / kMx4TileBytes * kMx4TileRecs});
+            if (f1 < hi) next.push_back({ex.pool, reinterpret_cast<void*>(f1), static_cast<size_t>(hi - f1), (hi - f1) / kMx4TileBytes * kMx4TileRecs});
+            pools_[pool]->free(reinterpret_cast<void*>(f0), static_cast<size_t>(f1 - f0));
+        }
+        a->extents.swap(next);
+        g = h;
+    }
+    a->extents.push_back({static_cast<int>(target_pool), dst, dst_bytes, total});
+    for (size_t t = 0; t < used.size(); ++t)
+        if (used[t] != 0xFFFFu) a->mx4_vacated[reinterpret_cast<uint64_t>(dst) + t * kMx4TileBytes] = static_cast<uint16_t>(~used[t]);
+    for (uint64_t i = 0; i < n; ++i) a->page_pool[first + i] = static_cast<uint8_t>(target_pool);
+    a->linear_base = nullptr;
+    a->regular = false;
+    a->stripe_n = 0;
+    st_.pool_migrated_pages += n;
+    if (first == 0 && n == a->n_pages && total == n) {
+        // the WHOLE allocation moved and landed dense (page p = record p of the new run): regular "over one pool" again
+        a->pool_of_residue.assign(1, static_cast<int>(target_pool));
+        a->regular = true;
+        if (a->d_stripe) {
             uint64_t bases[8] = {reinterpret_cast<uint64_t>(dst), 0, 0, 0, 0, 0, 0, 0};
             HIP_TRY(hipMemcpy(a->d_stripe, bases, sizeof(bases), hipMemcpyHostToDevice));
             a->linear_base = dst;

@@ -531,7 +531,7 @@ __device__ __forceinline__ void decode_int4(const uint8_t* __restrict__ rec, uin
 // [512 j + 8 l, + 8) for j = 0, 1 and their partners 1024 further on (j = 2, 3 of every other decoder's lane map).
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 template <bool F32>
-__device__ __forceinline__ void decode_mx4(const uint8_t* __restrict__ rec, uint32_t len,
+__device__ __forceinline__ void decode_mx4(const uint8_t* __restrict__ rec, const uint8_t* __restrict__ codes, uint32_t len,
                                            uint8_t* __restrict__ dst, uint32_t lane)
 {
     const bool ok = len >= kMx4RecBytes;                     // short record decodes to zeros
@@ -542,7 +542,7 @@ __device__ __forceinline__ void decode_mx4(const uint8_t* __restrict__ rec, uint
         uint32_t code = 127u;
         if (ok) {
             nib = gload_u2(rec + p0);
-            code = gload<uint8_t>(rec + 1024u + (p0 >> 4));
+            code = gload<uint8_t>(codes + (p0 >> 4));
         }
         const float s = __uint_as_float(code == 0u ? 0x00400000u : code == 255u ? 0x7FC00000u : code << 23);
         float y0[8], y1[8];
@@ -750,7 +750,8 @@ __device__ __forceinline__ void fetch_decompress_body(const CodecArgs& a)
         } else if (SCHEME == kInt4G32) {
             decode_int4<F32>(cur.rec, len, cur.dst, lane);
         } else if (SCHEME == kMxFp4) {
-            decode_mx4<F32>(cur.rec, len, cur.dst, lane);
+            // pool records are tile-planar: the codes lie mx4_code_delta behind the nibbles (the entry's scale word); raw records: 1024
+            decode_mx4<F32>(cur.rec, cur.rec + (a.recs ? 1024u : __float_as_uint(cur.scale)), len, cur.dst, lane);
         } else if (SCHEME == kFp8E4m3) {
             if (len > kBlockElems) len = kBlockElems;
             decode_fp8<F32>(cur.rec, len, cur.scale, cur.dst, lane);
@@ -987,6 +988,9 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
         }
         uint8_t* rec = entries ? reinterpret_cast<uint8_t*>(gload<uint64_t>(&entries[page].pool_addr))
                                : a.recs + page * a.rec_stride;
+        // MXFP4 in the pool is tile-planar (kernels.hpp): the codes go mx4_code_delta behind the nibbles -- the entry's scale word
+        uint8_t* rec_codes = rec + 1024u;
+        if (SCHEME == kMxFp4 && entries) rec_codes = rec + gload<uint32_t>(reinterpret_cast<const uint32_t*>(&entries[page].scale));
         uint32_t out_len;
         float scale = 1.0f;
 
@@ -1173,7 +1177,7 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                 uint8_t* wl = reinterpret_cast<uint8_t*>(lds) + wave * kMx4RecBytes;
                 wave_lds_fence();
                 enc_st16(rec + 16u * lane, *reinterpret_cast<const uint4*>(wl + 16u * lane));
-                if (lane < 4u) enc_st16(rec + 1024u + 16u * lane, *reinterpret_cast<const uint4*>(wl + 1024u + 16u * lane));
+                if (lane < 4u) enc_st16(rec_codes + 16u * lane, *reinterpret_cast<const uint4*>(wl + 1024u + 16u * lane));
                 wave_lds_fence();
             }
             out_len = kMx4RecBytes;
@@ -1281,7 +1285,7 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
         if (lane == 0u) {
             if (entries) {
                 gstore<uint32_t>(&entries[page].rec_bytes, out_len);
-                gstore<float>(&entries[page].scale, scale);
+                if (SCHEME != kMxFp4) gstore<float>(&entries[page].scale, scale);       // (MXFP4: the word holds the code delta)
                 if (SCHEME == kInt8DeltaRle && a.len_samples && (page & 1023u) == 0u) gstore<uint32_t>(&a.len_samples[(page >> 10) & 15u], out_len);
                 if (scale_tab) {
                     const uint32_t j = static_cast<uint32_t>(page % region_pages) & 15u;
@@ -1626,10 +1630,12 @@ __global__ void k_apply_updates(const DevAlloc* __restrict__ tab, const MirrorUp
     if (u.slot != kKeepSlot) t.d_slot[u.page] = u.slot;
 }
 
-__global__ void k_init_entries(PageEntry* e, uint64_t n, uint64_t base, uint64_t stride)
+__global__ void k_init_entries(PageEntry* e, uint64_t n, uint64_t base, uint64_t stride, uint64_t rec0)
 {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < n) { e[i].pool_addr = base + i * stride; e[i].rec_bytes = 0; e[i].scale = 1.0f; }
+    if (i >= n) return;
+    if (stride == kPlanarMx4) { e[i].pool_addr = base + mx4_nib_off(rec0 + i); e[i].rec_bytes = 0; e[i].scale = __uint_as_float(mx4_code_delta(rec0 + i)); }
+    else { e[i].pool_addr = base + i * stride; e[i].rec_bytes = 0; e[i].scale = 1.0f; }
 }
 
 // ===================================================================
@@ -2410,10 +2416,12 @@ __global__ __launch_bounds__(256) void k_repack(PageEntry* __restrict__ entries,
     if (lane == 0u) entries[p].pool_addr = new_addr[p];
 }
 
-__global__ void k_retarget_entries(PageEntry* e, uint64_t n, uint64_t base, uint64_t stride)
+__global__ void k_retarget_entries(PageEntry* e, uint64_t n, uint64_t base, uint64_t stride, uint64_t rec0)
 {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < n) e[i].pool_addr = base + i * stride;
+    if (i >= n) return;
+    if (stride == kPlanarMx4) { e[i].pool_addr = base + mx4_nib_off(rec0 + i); e[i].scale = __uint_as_float(mx4_code_delta(rec0 + i)); }
+    else e[i].pool_addr = base + i * stride;
 }
 
 int g_cus = 0;
@@ -2622,11 +2630,11 @@ hipError_t launch_repack(PageEntry* d_entries, const uint64_t* d_new_addr, uint6
     return hipGetLastError();
 }
 
-hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t base, uint64_t stride, hipStream_t s)
+hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t base, uint64_t stride, hipStream_t s, uint64_t rec0)
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_retarget_entries, dim3(static_cast<uint32_t>((n + 255u) / 256u)), dim3(256), 0, s,
-                       d_entries, n, base, stride);
+                       d_entries, n, base, stride, rec0);
     return hipGetLastError();
 }
 
@@ -2703,11 +2711,11 @@ hipError_t launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t s
 }
 
 hipError_t launch_init_entries(PageEntry* d_entries, uint64_t n, uint64_t base, uint64_t stride,
-                               hipStream_t s)
+                               hipStream_t s, uint64_t rec0)
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_init_entries, dim3(static_cast<uint32_t>((n + 255u) / 256u)), dim3(256), 0, s,
-                       d_entries, n, base, stride);
+                       d_entries, n, base, stride, rec0);
     return hipGetLastError();
 }
 

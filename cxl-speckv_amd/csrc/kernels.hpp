@@ -16,17 +16,27 @@ constexpr uint32_t kBlockElems = 2048;
 enum Scheme : int { kFp16 = 0, kInt8 = 1, kInt8DeltaRle = 2, kInt4G32 = 3, kFp8E4m3 = 4, kMxFp4 = 5 };
 constexpr uint32_t kInt4RecBytes = 128 + 1024;   // 64 fp16 group scales + 2048 nibbles
 constexpr uint32_t kMx4RecBytes = 1024 + 64;     // 2048 E2M1 nibbles + 64 E8M0 group scales (OCP MX v1.0 blocks of 32)
-// ... in a slot of 9 cache lines: at a stride of 1088 (8.5 lines) every other record starts in the middle of a line and a head
-// pair's 256 bytes span three lines instead of two -- measured on the attention kernel: 3.38 GB fetched for 2.85 GB of records,
-// the HBM side at 0.73 of its peak for 0.60 of useful bytes (profiles/r05_mx4.txt).  The 64 bytes behind a record are never read.
-constexpr uint32_t kMx4SlotBytes = 1152;
+// MXFP4 records in the POOL are tile-planar (round 6).  A record is 8.5 cache lines: at a stride of 1088 every other record starts
+// in the middle of a line (a head pair's 256 bytes then span three lines: 3.38 GB fetched for 2.85 GB of records, profiles/r05_mx4.txt),
+// and in line-aligned 1152-byte slots (round 5) the ninth line of every slot was fetched for half its bytes: 1.065 x the record bytes
+// from DRAM and 5.9 % of the pool's capacity (profiles/r05c_mx4_mem_pmc.json).  So 16 records of a run form a TILE of exactly
+// 136 lines: the 16 nibble rows (16 x 1024 B) followed by the 16 code rows (16 x 64 B, two records per line).  Record r of a
+// run (runs start on a tile boundary) has its nibbles at mx4_nib_off(r) and its codes mx4_code_delta(r) bytes behind them; the
+// record BYTES are the oracle's, only their placement differs.  The raw operators (speckv_ext_codec_*) keep contiguous records.
+constexpr uint32_t kMx4TileRecs = 16;
+constexpr uint32_t kMx4CodePlane = kMx4TileRecs * 1024u;                 // offset of the code rows inside a tile
+constexpr uint32_t kMx4TileBytes = kMx4TileRecs * kMx4RecBytes;          // 17 408 B = 136 lines
+__host__ __device__ inline uint64_t mx4_nib_off(uint64_t r) { return (r >> 4) * kMx4TileBytes + (r & 15u) * 1024u; }
+__host__ __device__ inline uint32_t mx4_code_delta(uint64_t r) { return kMx4CodePlane - 960u * static_cast<uint32_t>(r & 15u); }
+__host__ __device__ inline uint64_t mx4_run_bytes(uint64_t recs) { return (recs + 15u) / 16u * kMx4TileBytes; }
 enum QuantMode : int { kRefExact = 0, kIntent = 1 };
 
 // Device-resident page-table entry (16 B).
 struct PageEntry {
     uint64_t pool_addr;   // device address of the stored record (local or peer HBM)
     uint32_t rec_bytes;   // record length in bytes (0 = never written)
-    float    scale;       // per-block scale factor
+    float    scale;       // per-block scale factor; MXFP4 (no block scale): the BITS are mx4_code_delta of the record, set when
+                          // the entry is pointed at its place (k_init_entries / k_retarget_entries / the host) and kept by k_compress
 };
 
 // Shim layout (vllm_speckv_backend.py:87-100) of the allocation a lookup runs on.
@@ -212,9 +222,11 @@ hipError_t launch_flush_pipeline(const FlushArgs& a, hipStream_t s);
 // bytes rounded up to 16: both buffers must be 16-byte aligned and padded to a multiple of 16
 hipError_t launch_copy16(const void* src_host_mapped, void* dst, size_t bytes, hipStream_t s);
 
-// entries[first+i].pool_addr = base + i*stride ; rec_bytes = 0 ; scale = 1
+// entries[first+i].pool_addr = base + i*stride ; rec_bytes = 0 ; scale = 1.  stride == kPlanarMx4: entry i = record rec0 + i of
+// a tile-planar MXFP4 run at base (pool_addr = base + mx4_nib_off, scale bits = mx4_code_delta)
+constexpr uint64_t kPlanarMx4 = 0;
 hipError_t launch_init_entries(PageEntry* d_entries, uint64_t n, uint64_t base,
-                               uint64_t stride, hipStream_t s);
+                               uint64_t stride, hipStream_t s, uint64_t rec0 = 0);
 
 // Fused dequant-matvec of BASELINE config 5: q.K^T scores straight from FP8_E4M3
 // records with v_mfma_f32_16x16x32_fp8_fp8 (no fp16 K is ever materialised).
@@ -373,8 +385,10 @@ hipError_t launch_attend_fp8_batch(const AttendArgs& a, uint32_t n_seq, float* d
 
 // every page's record (rec_bytes rounded up to 16) copied to d_new_addr[page], then entries[page].pool_addr = d_new_addr[page]
 hipError_t launch_repack(PageEntry* d_entries, const uint64_t* d_new_addr, uint64_t n, hipStream_t s);
-// entries[i].pool_addr = base + i*stride (record bytes / scale untouched): after a migration
-hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t base, uint64_t stride, hipStream_t s);
+// entries[i].pool_addr = base + i*stride (record bytes / scale untouched): after a migration.  stride == kPlanarMx4: record
+// rec0 + i of the tile-planar run at base (address and code delta, record bytes untouched)
+hipError_t launch_retarget_entries(PageEntry* d_entries, uint64_t n, uint64_t base, uint64_t stride, hipStream_t s, uint64_t rec0 = 0);
+
 
 // Token predictor (lstm_predictor.cpp:40-188): n histories of 16 tokens -> top-k (k <= 8) tokens and
 // confidences.  d_emb [vocab][64], d_wout [vocab][128]; d_hid (n*128 floats) and d_logits (n*vocab

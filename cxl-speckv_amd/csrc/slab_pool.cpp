@@ -19,12 +19,11 @@ void slab_free(void* p) { (void)hipFree(p); }
 void use_device(int d) { (void)hipSetDevice(d); }
 int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 #endif
-// every record stride (4096, 2048, 1152, 1088) is a multiple of 64 B = half a cache line, one HBM burst: with this granule
-// a run of k records occupies exactly k*stride bytes, so any sub-run of records can be freed on its own (Engine::migrate)
-// without the freed range reaching into live neighbours.  (128 until the 1088-byte MXFP4 record arrived; runs still start
-// on 128-byte lines whenever their size is a multiple of 128, and a 16-byte load never straddles a 64-byte piece.)
-constexpr size_t kGranule = 64;
-constexpr size_t kLine = 128;
+// every unit the engine frees on its own is a multiple of one 128-byte cache line -- record strides 4096, 2048, 1152, packed
+// records (128-byte aligned) and the 17 408-byte tiles of MXFP4 runs (kernels.hpp: 16 records = 136 lines) -- so with this
+// granule a run of k units occupies exactly k units of bytes and any sub-run can go back to the pool (Engine::migrate) without
+// the freed range reaching into live neighbours; every run starts on a line.
+constexpr size_t kGranule = 128;
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }
 
@@ -84,8 +83,7 @@ void* SlabPool::alloc(size_t bytes)
 {
     if (bytes == 0) return nullptr;
     bytes = round_up(bytes, kGranule);
-    // runs of whole cache lines start on a line (a free block may begin 64 bytes into one behind a run of 1088-byte records)
-    const size_t align = bytes % kLine == 0 ? kLine : kGranule;
+    const size_t align = kGranule;
     for (int attempt = 0; attempt < 2; ++attempt) {
         for (auto it = free_.begin(); it != free_.end(); ++it) {
             const uintptr_t addr = round_up(it->first, align);
@@ -113,7 +111,7 @@ void* SlabPool::alloc_up_to(size_t want, size_t granule, size_t* got)
     for (int attempt = 0; attempt < 2; ++attempt) {
         auto best = free_.end();
         size_t best_len = 0;
-        const size_t align = granule % kLine == 0 ? kLine : kGranule;
+        const size_t align = kGranule;
         for (auto it = free_.begin(); it != free_.end(); ++it) {
             const size_t head = round_up(it->first, align) - it->first;
             if (it->second <= head) continue;

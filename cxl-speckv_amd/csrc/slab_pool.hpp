@@ -25,8 +25,8 @@ public:
     SlabPool(const SlabPool&) = delete;
     SlabPool& operator=(const SlabPool&) = delete;
 
-    // Contiguous run of `bytes` (rounded up to 64 B; a run of whole 128-byte cache lines starts on a line).  nullptr = out of
-    // memory.  free() takes any 64-B-granular sub-range of what alloc returned.
+    // Contiguous run of `bytes` (rounded up to whole 128-byte cache lines, starting on one).  nullptr = out of
+    // memory.  free() takes any line-granular sub-range of what alloc returned.
     void* alloc(size_t bytes);
     // Fragmented fallback: the largest free run that is a multiple of `granule`
     // and at most `want` bytes (grows by one slab when nothing is free).

@@ -22,7 +22,7 @@ class PageInfo(ctypes.Structure):
     _fields_ = [("virt_page_id", c_uint64), ("phys_page_id", c_uint64), ("page_size", c_uint32),
                 ("flags", c_uint32), ("pool_device", c_int32), ("scheme", c_uint32), ("rec_bytes", c_uint32),
                 ("scale", c_float), ("pool_addr", c_uint64), ("cache_addr", c_uint64),
-                ("access_count", c_uint32), ("reserved", c_uint32)]
+                ("access_count", c_uint32), ("aux_offset", c_uint32)]
 
 
 class DmaDesc(ctypes.Structure):
@@ -101,7 +101,7 @@ _EXT_SIGNATURES = {
 }
 
 
-EXT_ABI_VERSION = 5        # SPECKV_EXT_ABI_VERSION of include/speckv_ext.h
+EXT_ABI_VERSION = 6        # SPECKV_EXT_ABI_VERSION of include/speckv_ext.h
 
 
 def bind_ext(lib):

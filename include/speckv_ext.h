@@ -67,7 +67,9 @@ typedef struct {
     uint64_t pool_addr;      /* device address of the record in the pool */
     uint64_t cache_addr;     /* device address of the decompressed copy, 0 if not resident */
     uint32_t access_count;   /* MemoryPage::access_count, cxl_memory_manager.h:34 */
-    uint32_t reserved;
+    uint32_t aux_offset;     /* 0: the record's rec_bytes are contiguous at pool_addr.  MXFP4 (tile-planar pool, 16 records = 16 nibble
+                              * rows + 16 code rows = 136 whole cache lines): bytes 0..1023 at pool_addr, bytes 1024..1087 (the E8M0
+                              * codes) at pool_addr + aux_offset.  (The field was `reserved`, always 0, until ABI version 6.) */
 } speckv_ext_page_info_t;
 speckv_status_t speckv_ext_translate(speckv_handle_t handle, uint64_t offset_bytes,
                                      speckv_ext_page_info_t* out);
@@ -434,7 +436,7 @@ typedef struct {
  * is SPECKV_ERR_INVAL.
  * SPECKV_EXT_ABI_VERSION is bumped whenever a struct of this header grows or an entry point changes meaning;
  * speckv_ext_abi_version() returns the library's value (the Python binding refuses a mismatch). */
-#define SPECKV_EXT_ABI_VERSION 5u
+#define SPECKV_EXT_ABI_VERSION 6u
 uint32_t        speckv_ext_abi_version(void);
 speckv_status_t speckv_ext_stats(speckv_ext_stats_t* out);
 speckv_status_t speckv_ext_stats_sized(void* out, size_t out_size, size_t* written);

@@ -136,3 +136,12 @@ def dev_to_host(ptr, nbytes):
     rc = _hip_runtime().hipMemcpy(buf.ctypes.data, C.c_void_p(ptr), nbytes, 2)   # hipMemcpyDeviceToHost
     assert rc == 0, rc
     return buf
+
+
+def stored_record(info, nbytes):
+    """The first nbytes of a page's pool record as speckv_ext_translate describes it: contiguous at pool_addr, or -- tile-planar
+    MXFP4, aux_offset != 0 -- bytes 0..1023 there and the 64 codes aux_offset further on (include/speckv_ext.h)."""
+    nbytes = int(nbytes)
+    if not info.aux_offset or nbytes <= 1024:
+        return dev_to_host(info.pool_addr, nbytes)
+    return np.concatenate([dev_to_host(info.pool_addr, 1024), dev_to_host(info.pool_addr + info.aux_offset, nbytes - 1024)])

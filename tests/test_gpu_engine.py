@@ -10,7 +10,7 @@ import pytest
 
 import cxl_speckv_amd as pkg
 from cxl_speckv_amd.speckv_ctypes import SpeckvError
-from tests._gpu import N, assert_same_float_bits, dev_to_host, graph_capture, torch_mod, set_tuning
+from tests._gpu import N, assert_same_float_bits, dev_to_host, stored_record, graph_capture, torch_mod, set_tuning
 
 pytestmark = pytest.mark.gpu
 PAGE = 4096
@@ -52,7 +52,7 @@ def test_write_read_translate_parity(eng, oracle, scheme):
         assert info.rec_bytes == lens[p] and info.scheme == scheme and info.pool_device == 0
         assert np.float32(info.scale).tobytes() == scales[p].tobytes()
         assert info.flags == (4 if scheme else 0)            # bit2 = compressed, not resident yet
-        stored = dev_to_host(info.pool_addr, int(lens[p]))
+        stored = stored_record(info, lens[p])
         assert stored.tobytes() == recs[p, :lens[p]].tobytes()
     st = lib.stats()
     assert st.total_compressions == n_pages and st.compressed_bytes == int(lens.sum())
@@ -1259,7 +1259,7 @@ def test_striped_multi_pool_on_one_gpu(oracle):
 
 
 def stored_equal(info, rec, n):
-    return dev_to_host(info.pool_addr, int(n)).tobytes() == rec[:n].tobytes()
+    return stored_record(info, n).tobytes() == rec[:n].tobytes()
 
 
 def test_engine_random_operations_vs_model(oracle):

@@ -10,7 +10,7 @@ import pytest
 
 import cxl_speckv_amd as pkg
 from cxl_speckv_amd.speckv_ctypes import SpeckvError, SpeckvLib
-from tests._gpu import N, assert_same_float_bits, dev_to_host, torch_mod, set_tuning
+from tests._gpu import N, assert_same_float_bits, dev_to_host, stored_record, torch_mod, set_tuning
 
 pytestmark = pytest.mark.gpu
 PAGE = 4096
@@ -709,7 +709,7 @@ def test_compaction_packs_rle_records_and_frees_the_slots(oracle, pools):
         for p in (0, 1, 2, 5, 4095, n - 1):
             assert dev_to_host(lib.access(h, p * PAGE, PAGE), PAGE).tobytes() == want[p].tobytes(), p
             info = lib.translate(h, p * PAGE)
-            assert info.rec_bytes == ln[p] and dev_to_host(info.pool_addr, int(ln[p])).tobytes() == rc[p, :ln[p]].tobytes()
+            assert info.rec_bytes == ln[p] and stored_record(info, ln[p]).tobytes() == rc[p, :ln[p]].tobytes()
         # the freed slots are really back in the pool: a second allocation of the same size fits without growing it
         reserved = lib.stats().pool_bytes_reserved
         h2 = lib.alloc((n * PAGE - packed) // PAGE // 4 * PAGE)
@@ -773,7 +773,7 @@ def test_batch_and_planned_attention_over_striped_pools(scheme):
             x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.3, 2.0, (n_pages, 1))).astype(np.float16)
             lib.write(h, 0, x.ctypes.data, x.nbytes, False)
             handles.append(h)
-        assert lib.translate(handles[0], 0).pool_addr != lib.translate(handles[0], PAGE).pool_addr - (2048 if scheme == 4 else 1152)       # (INT4_G32 and MXFP4 slots: 1152 B)
+        assert lib.translate(handles[0], 0).pool_addr != lib.translate(handles[0], PAGE).pool_addr - {4: 2048, 3: 1152, 5: 1024}[scheme]       # (striped: page 1 is not the next record; MXFP4 runs are tile-planar, nibble rows 1024 B apart)
         q = torch.from_numpy(rng.standard_normal((len(lens), H, G, D)).astype(np.float16)).cuda()
         sm = 1.0 / np.sqrt(D)
         single = {3: lib.attend_int4, 4: lib.attend_fp8, 5: lib.attend_mx4}[scheme]
@@ -827,9 +827,11 @@ def test_batch_and_planned_attention_over_striped_pools(scheme):
         # ... but a sequence migrated AS A WHOLE (a hot one pulled onto one pool GPU) is one run again and qualifies for every
         # arithmetic-address path: same results, records at base + page * stride
         lib.migrate(handles[0], 0, n_pages, 5)
-        stride = 2048 if scheme == 4 else 1152
+        rec_off = (lambda p: (p >> 4) * 17408 + (p & 15) * 1024) if scheme == 5 else (lambda p: (2048 if scheme == 4 else 1152) * p)      # MXFP4: 16-record tiles of 136 lines
         base = lib.translate(handles[0], 0).pool_addr
-        assert [lib.translate(handles[0], p * PAGE).pool_addr - base for p in (1, 2, 77, n_pages - 1)] == [stride * p for p in (1, 2, 77, n_pages - 1)]
+        assert [lib.translate(handles[0], p * PAGE).pool_addr - base for p in (1, 2, 77, n_pages - 1)] == [rec_off(p) for p in (1, 2, 77, n_pages - 1)]
+        if scheme == 5:
+            assert [lib.translate(handles[0], p * PAGE).aux_offset for p in (0, 1, 15, 16, 77)] == [16384 - 960 * (p & 15) for p in (0, 1, 15, 16, 77)]
         out3 = torch.full_like(out, float("nan")); lse3 = torch.full_like(lse, float("nan"))
         batch(handles, 1, q.data_ptr(), G, lens, sm, out3.data_ptr(), lse3.data_ptr())
         torch.cuda.synchronize()

@@ -147,18 +147,18 @@ def slab():
     return lib
 
 
-@pytest.mark.parametrize("stride", [2048, 1152, 4096, 1088])
+@pytest.mark.parametrize("stride", [2048, 1152, 4096, 17408])            # (17 408: one tile of an MXFP4 run, 16 records)
 def test_slab_subrange_free_never_reaches_live_records(slab, stride):
     """freeing record 1 of a run of 64 and allocating again must not hand out bytes of record 2."""
-    p = slab.slabtest_new(1 << 20, 0)
+    p = slab.slabtest_new(2 << 20, 0)
     base = slab.slabtest_alloc(p, 64 * stride)
     assert base and slab.slabtest_used(p) == 64 * stride
     slab.slabtest_free(p, base + stride, stride)
     assert slab.slabtest_used(p) == 63 * stride
     again = slab.slabtest_alloc(p, min(stride, 4096))
     assert again == base + stride                                 # first fit: exactly the hole, nothing more
-    if stride < 4096:
-        nxt = slab.slabtest_alloc(p, 4096)
+    if stride != 4096:
+        nxt = slab.slabtest_alloc(p, max(4096, stride + 128))
         assert nxt >= base + 64 * stride                          # a bigger request cannot fit in the hole
     slab.slabtest_delete(p)
 
@@ -171,7 +171,7 @@ def test_slab_random_alloc_free_keeps_runs_disjoint(slab):
         if live and rng.random() < 0.45:
             i = int(rng.integers(0, len(live)))
             addr, n = live.pop(i)
-            stride = 128 * int(rng.integers(1, 9)) if n % 128 == 0 else 1088
+            stride = 128 * int(rng.integers(1, 9))
             if n > 2 * stride and rng.random() < 0.5:             # free a middle piece first, then the two rests
                 k = (n // stride) // 2 * stride
                 slab.slabtest_free(p, addr + k, stride)
@@ -190,21 +190,20 @@ def test_slab_random_alloc_free_keeps_runs_disjoint(slab):
                 a = slab.slabtest_alloc_up_to(p, want, 1152, C.byref(got))
                 n = got.value
                 assert a and n and n % 1152 == 0 and n <= want
-            elif kind < 0.4:                                       # runs of 1088-byte MXFP4 records: 64-byte granule
-                n = 1088 * int(rng.integers(1, 70))
+            elif kind < 0.4:                                       # runs of MXFP4 tiles (16 records = 17 408 bytes = 136 lines)
+                n = 17408 * int(rng.integers(1, 6))
                 if rng.random() < 0.5:
                     got = C.c_size_t()
-                    a = slab.slabtest_alloc_up_to(p, n, 1088, C.byref(got))
+                    a = slab.slabtest_alloc_up_to(p, n, 17408, C.byref(got))
                     n = got.value
-                    assert a and n and n % 1088 == 0
+                    assert a and n and n % 17408 == 0
                 else:
                     a = slab.slabtest_alloc(p, n)
                     assert a
             else:
                 a = slab.slabtest_alloc(p, n)
                 assert a
-            by_record_1088 = 0.2 <= kind < 0.4 and got.value == n if 0.2 <= kind < 0.4 else False
-            assert a % 64 == 0 and (n % 128 or by_record_1088 or a % 128 == 0)      # runs of whole cache lines start on a line
+            assert a % 128 == 0 and n % 128 == 0                  # whole cache lines, starting on one
             for b, m in live:
                 assert a + n <= b or b + m <= a, "overlapping live runs"
             live.append((a, n))
