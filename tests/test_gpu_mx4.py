@@ -453,3 +453,138 @@ def test_mx4_striped_pool_by_residue_classes(oracle, pools):
         check_batch("planned", 1)
     finally:
         kv.close()
+
+
+def _stored_mx4(lib, h, page):
+    """the 1088 record bytes of a page as they lie in the tile-planar pool (speckv_ext_translate: nibbles at pool_addr, codes aux_offset on)"""
+    from tests._gpu import stored_record
+    info = lib.translate(h, page * PAGE)
+    assert info.rec_bytes == REC and info.aux_offset and (16384 - info.aux_offset) % 960 == 0 and (16384 - info.aux_offset) // 960 < 16
+    return stored_record(info, REC), info
+
+
+def test_mx4_tile_planar_layout_capacity_and_phases(eng, oracle):
+    """Round 6: pool records are tile-planar -- 16 records of a run = 16 nibble rows + 16 code rows = 136 whole cache lines, 1088 B of
+    pool per page (3.76 : 1 on capacity too).  The record BYTES stay the oracle's.  A layout whose K / V regions are not multiples of
+    16 pages (T = 520: 260 pages) makes the attention's 16-page tiles start at every phase of the storage tiles: linear form, stream
+    form across layers (the phase changes at every layer boundary), ranges that start anywhere."""
+    torch = torch_mod()
+    lib = eng.lib
+    lib.set_compression_scheme(5)
+    in_use0 = lib.stats().pool_bytes_in_use
+    T, L, g = 520, 3, 8
+    h = eng.allocate(T, L, H, D, 2)
+    n_pages = T * L * H * D * 2 * 2 // PAGE                       # 1560 = 97.5 tiles
+    assert lib.stats().pool_bytes_in_use - in_use0 == (n_pages + 15) // 16 * 17408
+    rng = np.random.default_rng(606)
+    x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.1, 4.0, (n_pages, 1))).astype(np.float16)
+    lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+    recs = oracle.compress_blocks_f16(x, 5, 0)[2]
+    base = lib.translate(h, 0).pool_addr
+    assert base % 128 == 0
+    for p in (0, 1, 15, 16, 17, 259, 260, 777, n_pages - 1):
+        got, info = _stored_mx4(lib, h, p)
+        assert got.tobytes() == recs[p, :REC].tobytes(), p
+        assert info.pool_addr - base == (p >> 4) * 17408 + (p & 15) * 1024 and info.aux_offset == 16384 - 960 * (p & 15) and info.scale == 1.0
+    qn = rng.standard_normal((L, H, g, D)).astype(np.float16)
+    q = torch.from_numpy(qn).cuda()
+    sm = 1.0 / np.sqrt(D)
+    out = torch.empty((L, H, g, D), dtype=torch.float32, device="cuda")
+    lse = torch.empty((L, H, g), dtype=torch.float32, device="cuda")
+    # K of layer l starts at page 520 l (phases 0, 8, 0), V at 520 l + 260 (phases 4, 12, 4); ranges that start at pages 3, 7, 21
+    for layer, nl, (pb, pe), splits, stream in ((0, 1, (0, 512), 0, 0), (1, 1, (0, 512), 0, 0), (1, 1, (6, 390), 3, 0), (2, 1, (14, 46), 0, 0), (0, 1, (42, 512), 2, 0),
+                                                (0, 3, (0, 512), 0, 5), (0, 3, (0, 512), 0, 48), (1, 2, (0, 480), 0, 0), (0, 3, (0, 512), 2, 0)):
+        set_tuning("attend_splits", splits); set_tuning("attend_stream", stream)
+        try:
+            out.fill_(float("nan")); lse.fill_(float("nan"))
+            lib.attend_mx4(h, layer, nl, q[layer].data_ptr(), g, pb, pe, sm, out.data_ptr(), lse.data_ptr())
+            torch.cuda.synchronize()
+        finally:
+            set_tuning("attend_splits", 0); set_tuning("attend_stream", 0)
+        for i in range(nl):
+            want, wlse, mag, delta = oracle_attention(oracle, recs, qn[layer + i], T, layer + i, pb, pe, sm, g)
+            check(out[i].cpu().numpy(), lse[i].cpu().numpy(), want, wlse, mag, delta, ("phase", layer, nl, i, pb, pe, splits, stream))
+    # the batch and planned forms over the same layout (layer 1: K at phase 8, V at phase 12)
+    pos = np.array([512], np.uint32)
+    lib.attend_mx4_batch([h], 1, q[1].data_ptr(), g, pos, sm, out[0].data_ptr(), lse[0].data_ptr())
+    torch.cuda.synchronize()
+    want, wlse, mag, delta = oracle_attention(oracle, recs, qn[1], T, 1, 0, 512, sm, g)
+    check(out[0].cpu().numpy(), lse[0].cpu().numpy(), want, wlse, mag, delta, ("phase", "batch"))
+    lib.free(h)
+    lib.sync()
+    assert lib.stats().pool_bytes_in_use == in_use0
+
+
+def test_mx4_migration_moves_tiles_and_returns_them(oracle):
+    """Migration of tile-planar records: long runs keep their slot phase and move as whole tiles in one copy, short ones in pieces;
+    a tile goes back to its pool when its last record has left; the bytes every reader sees stay the oracle's; a whole-allocation
+    move lands dense (linear form again)."""
+    torch = torch_mod()
+    os.environ["SPECKV_POOL_DEVICES"] = "0,0,0"
+    os.environ["SPECKV_SLAB_MB"] = "8"
+    try:
+        kv = pkg.CxlSpeckvKVAllocator(pkg.library_path(), "hip:0")
+    finally:
+        os.environ.pop("SPECKV_POOL_DEVICES", None); os.environ.pop("SPECKV_SLAB_MB", None)
+    try:
+        lib = kv.lib
+        lib.set_compression_scheme(5)
+        T, L, g = 1024, 1, 8
+        n_pages = T * L * H * D * 2 * 2 // PAGE                   # 1024
+        h = lib.alloc(n_pages * PAGE, preferred_node=1)           # one run on pool 0
+        lib.set_layout(h, T, L, H, D, 2)
+        rng = np.random.default_rng(612)
+        x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.1, 4.0, (n_pages, 1))).astype(np.float16)
+        lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+        recs = oracle.compress_blocks_f16(x, 5, 0)[2]
+        want = oracle.decompress_blocks_f16(recs, np.full(n_pages, REC, np.uint32), np.ones(n_pages, np.float32), 5, 0)
+        tile = 17408
+        assert lib.stats().pool_bytes_in_use == n_pages // 16 * tile
+        dst = torch.empty((n_pages, N), dtype=torch.float16, device="cuda")
+
+        def readers_agree(what):
+            dst.fill_(float("nan"))
+            lib.fetch_range(h, 0, n_pages, dst.data_ptr(), False, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert_same_float_bits(dst.cpu().numpy(), want, what)
+            for p in (0, 36, 37, 47, 48, 536, 537, 600, 601, n_pages - 1):
+                got, _ = _stored_mx4(lib, h, p)
+                assert got.tobytes() == recs[p, :REC].tobytes(), (what, p)
+
+        # a long run that starts at slot 5 of its tile: 500 records to pool 1 -- 11 + 480 + 9: the 30 full tiles in one copy;
+        # the new run keeps the phase (5 slots of padding in front), source tiles 3 .. 32 are vacated entirely and go back
+        lib.migrate(h, 37, 500, 1)
+        a37 = lib.translate(h, 37 * PAGE)
+        assert lib.translate(h, 48 * PAGE).pool_addr - a37.pool_addr == 11 * 1024 + 1024      # slots 5 .. 15, then the next tile (its code rows in between)
+        assert lib.translate(h, 38 * PAGE).pool_addr - a37.pool_addr == 1024 and a37.aux_offset == 16384 - 960 * 5
+        assert lib.stats().pool_bytes_in_use == (n_pages // 16 - 30) * tile + 32 * tile       # 30 tiles back, 32 new (5 + 500 slots)
+        readers_agree("long run with a phase")
+        # short pieces: 3 pages, then the 11 records left in the old tile of page 37's neighbours (tile 2 loses its last records)
+        lib.migrate(h, 600, 3, 2)
+        lib.migrate(h, 32, 5, 2)                                  # slots 0 .. 4 of tile 2: with 37 .. 47 gone the tile is empty -> back
+        assert lib.stats().pool_bytes_in_use == (n_pages // 16 - 31) * tile + 32 * tile + 2 * tile
+        readers_agree("short pieces")
+        # the attention reads the migrated allocation through the page table
+        qn = rng.standard_normal((H, g, D)).astype(np.float16)
+        q = torch.from_numpy(qn).cuda()
+        sm = 1.0 / np.sqrt(D)
+        out = torch.empty((H, g, D), dtype=torch.float32, device="cuda"); lse = torch.empty((H, g), dtype=torch.float32, device="cuda")
+        lib.attend_mx4(h, 0, 1, q.data_ptr(), g, 0, T, sm, out.data_ptr(), lse.data_ptr())
+        torch.cuda.synchronize()
+        w, wl, mag, delta = oracle_attention(oracle, recs, qn, T, 0, 0, T, sm, g)
+        check(out.cpu().numpy(), lse.cpu().numpy(), w, wl, mag, delta, "migrated, page-table form")
+        # the whole allocation onto pool 2: every old tile goes back, the new run is dense (record p = page p) and linear again
+        lib.migrate(h, 0, n_pages, 2)
+        assert lib.stats().pool_bytes_in_use == n_pages // 16 * tile
+        b = lib.translate(h, 0).pool_addr
+        assert [lib.translate(h, p * PAGE).pool_addr - b for p in (1, 16, 37, 1023)] == [(p >> 4) * tile + (p & 15) * 1024 for p in (1, 16, 37, 1023)]
+        readers_agree("whole allocation")
+        out.fill_(float("nan"))
+        lib.attend_mx4(h, 0, 1, q.data_ptr(), g, 0, T, sm, out.data_ptr(), lse.data_ptr())
+        torch.cuda.synchronize()
+        check(out.cpu().numpy(), lse.cpu().numpy(), w, wl, mag, delta, "whole allocation, linear form")
+        lib.free(h)
+        lib.sync()
+        assert lib.stats().pool_bytes_in_use == 0
+    finally:
+        kv.close()
