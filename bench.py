@@ -1212,6 +1212,20 @@ def connector_decode_extra(torch, kv, n_seq=256, Lyr=8, ctx=2048, T=4096, scheme
         kv.lib.set_compression_scheme(2)
 
 
+def kv_accuracy_extra(torch, kv):
+    """What the pool formats cost in attention accuracy on KV-like data (outlier channels, RoPE pairs, heavy-tailed V; peaky / decode-like /
+    flat softmax) against float64 attention over the original fp16 K / V with the unquantised query: cxl-speckv_amd/kv_accuracy.py."""
+    try:
+        from cxl_speckv_amd.kv_accuracy import kv_format_accuracy
+        acc = kv_format_accuracy(kv)
+        acc["note"] = ("relative L2 error / cosine of the fused attention's output rows, top-1 agreement of the attention weights; format_rel_l2 = the "
+                       "format alone (float64 over the dequantised K / V, exact query), kernel_rel_l2 = what the kernel adds (query quantisation, f16 weights); "
+                       "'+kscale' = per-channel power-of-two pre-scale of K folded into the query (SpeckvKVConnector.set_k_channel_scale)")
+        return {"kv_format_accuracy": acc}
+    except Exception as e:                                               # noqa: BLE001
+        return {"kv_format_accuracy": {"error": repr(e)}}
+
+
 def footprint_extra(torch, kv, T, Lyr, seed, seconds=0.4):
     """The hot path at another footprint: one sequence of T positions x Lyr layers (8 kv heads x 128), INT8_DELTA_RLE,
     reference quantiser, one launch per pass, timed over >= `seconds` of back-to-back passes after a clock ramp."""
@@ -1599,6 +1613,7 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     ex.update(connector_append_extra(torch, kv))
     ex.update(connector_decode_extra(torch, kv))
     ex.update(connector_decode_extra(torch, kv, scheme="mxfp4"))      # the same decode step over an MXFP4 pool (half the record bytes of FP8)
+    ex.update(kv_accuracy_extra(torch, kv))
     ex.update(predictor_extra(torch, lib))
     ex.update(lstm_cell_extra(torch, lib))
     ex.update(compaction_extra(torch, kv))

@@ -506,7 +506,7 @@ def test_fp8_fused_attention(eng, oracle):
     lib.attend_fp8(h, 0, 1, d_q[0].data_ptr(), G, 0, T, sm, d_out.data_ptr())
     torch.cuda.synchronize()
     rel = np.abs(d_out.cpu().numpy() - ref).max() / np.abs(ref).max()
-    assert rel <= 0.15, rel
+    assert rel <= 0.14, rel              # measured 0.120 (largest deviation over the largest value; seeded data); per-regime bounds: tests/test_gpu_accuracy.py
     # empty range -> zeros; odd positions / wrong scheme -> INVAL
     lib.attend_fp8(h, 0, 1, d_q[0].data_ptr(), G, 8, 8, sm, d_out.data_ptr())
     torch.cuda.synchronize()
@@ -770,7 +770,7 @@ def test_int4_fused_attention(eng, oracle):
     p = np.exp(s_ - s_.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
     ref = np.einsum("hgt,thd->hgd", p, vfull)
     rel = np.linalg.norm(multi[0].cpu().numpy() - ref) / np.linalg.norm(ref)      # 4-bit KV under a peaky softmax: coarse
-    assert rel <= 0.5, rel
+    assert rel <= 0.31, rel              # measured 0.263 on this seeded data; per-regime bounds on KV-like data: tests/test_gpu_accuracy.py
     # a range whose last 32-position tile would leave the layer's region goes through the page table
     d_out = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
     lib.attend_int4(h, 1, 1, d_q[1].data_ptr(), G, 30, 512, sm, d_out.data_ptr())

@@ -228,7 +228,8 @@ def test_mx4_fused_attention(eng, oracle, g):
         p = np.exp(s_ - s_.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
         ref = np.einsum("hgt,thd->hgd", p, vfull)
         rel = np.linalg.norm(multi[0].cpu().numpy() - ref) / np.linalg.norm(ref)
-        assert rel <= 0.6, rel
+        assert rel <= 0.45, rel          # measured 0.391 on this seeded data (q = 2 N(0,1): a sharp softmax over pages of very different scale); what the
+                                         # formats cost on KV-like data, with bounds per regime: tests/test_gpu_accuracy.py
 
 
 def test_mx4_attention_unwritten_pages_count_as_zeros(eng, oracle):
