@@ -582,6 +582,17 @@ speckv_status_t speckv_ext_stats(speckv_ext_stats_t* out)
 
 uint32_t speckv_ext_abi_version(void) { return SPECKV_EXT_ABI_VERSION; }
 
+speckv_status_t speckv_ext_stream_is_capturing(void* stream, int* out_capturing)
+{
+    if (!out_capturing) return SPECKV_ERR_INVAL;
+    *out_capturing = 0;
+    if (!stream) return SPECKV_OK;                              // the NULL stream cannot be captured
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) != hipSuccess) { (void)hipGetLastError(); return SPECKV_ERR_DRIVER; }
+    *out_capturing = cs != hipStreamCaptureStatusNone ? 1 : 0;
+    return SPECKV_OK;
+}
+
 speckv_status_t speckv_ext_set_tuning(const char* key, long long value)
 {
     LOCK;

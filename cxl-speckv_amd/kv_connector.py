@@ -92,6 +92,29 @@ class SpeckvKVConnector:
         self._batch_cache = {}
         self._step_cols = {}
         self._plan_stream = None
+        self._kscale = self._kscale_inv = None               # set_k_channel_scale
+
+    def set_k_channel_scale(self, scale):
+        """Per-(layer, kv head, channel) pre-scale of K, folded into the query: K / scale goes into the pool, q * scale meets it, q.k is
+        unchanged.  `scale`: [layers][heads][dim] tensor of POWERS OF TWO (exact in fp16 both ways; kv_accuracy.pow2_channel_scales
+        calibrates them from a prompt's K: the channel's max|k| over the head's median channel), or None to switch it off.  What it buys:
+        an outlier channel of K no longer sets the block scale of the channels that share its quantisation group -- on KV-like data
+        INT4_G32 loses 0.33-0.42 of the attention output instead of 0.57-0.71 when the query weighs those channels (MXFP4, whose limit
+        there is the element's one mantissa bit, gains little): profiles/r06_kv_format_accuracy.txt, tests/test_gpu_accuracy.py.
+        Set it before the first write; rows read back through kv_rows() are scaled back."""
+        import torch
+        if any(r.length for r in self.requests.values()):
+            raise ValueError("set_k_channel_scale after positions were written: the pool would hold K in two scalings")
+        if scale is None:
+            self._kscale = self._kscale_inv = None
+            return
+        scale = torch.as_tensor(scale, dtype=torch.float32, device="cuda")
+        if tuple(scale.shape) != (self.L, self.H, self.D):
+            raise ValueError(f"k channel scale must be [layers][heads][dim] = {(self.L, self.H, self.D)}")
+        if not bool(torch.all(scale == torch.exp2(torch.round(torch.log2(scale))))):
+            raise ValueError("k channel scales must be powers of two (anything else rounds K and q a second time)")
+        self._kscale = scale.to(torch.float16).contiguous()
+        self._kscale_inv = (1.0 / scale).to(torch.float16).contiguous()
 
     # The library takes a hipStream_t and reads NULL as "the engine's own stream".  torch's default stream IS the NULL
     # stream, so work issued from it goes through a side stream that is ordered after it and that it then waits for.
@@ -175,6 +198,8 @@ class SpeckvKVConnector:
         if r.length:
             raise ValueError("write_prefill on a request that already has positions")
         even = n & ~1
+        if self._kscale_inv is not None:
+            k = k * self._kscale_inv[:, None]                  # [layers][tokens][heads][dim] / [layers][1][heads][dim]
         k = k.contiguous(); v = v.contiguous()
         if even:
             layer_bytes = n * self.H * self.D * 2
@@ -194,6 +219,8 @@ class SpeckvKVConnector:
         (speckv_ext_write_strided_batch); an odd one waits in the tail.  A handful of torch kernels per call, whatever
         the batch size: the tails of a step are kept as views of one gathered tensor."""
         import torch
+        if self._kscale_inv is not None:
+            k_new = k_new * self._kscale_inv[None]              # [batch][layers][heads][dim]
         pair_b, tail_b = [], []
         for b, rid in enumerate(req_ids):
             r = self.requests[rid]
@@ -252,14 +279,18 @@ class SpeckvKVConnector:
         if st is not None and self._arg_key is not None and self._arg_key[0][0] == tuple(req_ids) and self.scheme in FUSED:
             # best effort: the append itself has taken effect (lengths, tails, pool write) -- a plan that cannot be made now (the
             # stream is capturing, or was destroyed by its owner) must not make the caller retry it; attend() plans again instead
+            # (only those two cases are swallowed -- the capture status is asked of the stream the plan would go to, not
+            # of torch's current one -- a real failure of the plan, a bad layout or an exhausted pool, is the caller's to see)
+            from .speckv_ctypes import SpeckvError
             try:
-                import torch
-                if torch.cuda.is_current_stream_capturing():
-                    raise RuntimeError("capturing: no early plan")
-                self.plan_step(req_ids, st)
-            except Exception:
-                self._arg_key = None
-                self._plan_stream = None
+                if not self.lib.stream_is_capturing(st.cuda_stream):
+                    self.plan_step(req_ids, st)
+                else:
+                    self._arg_key = self._plan_stream = None
+            except SpeckvError as e:
+                self._arg_key = self._plan_stream = None
+                if e.status != -4:                             # SPECKV_ERR_INVAL: the stream cannot take the plan now (capturing / destroyed): attend() plans again
+                    raise
         return keep                                            # sources of the asynchronous writes: hold until the stream passed them
 
     # ------------------------------------------------------------------ reads
@@ -305,6 +336,8 @@ class SpeckvKVConnector:
                 self.lib.fetch_range(r.handle, self._page(layer, kind, lo), (hi - lo) // 2, out.data_ptr(), False, st.cuda_stream)
         if pos_end > even:                                               # the odd last position lives in the tail
             out[even - lo] = (r.tail_k if kind == 0 else r.tail_v)[layer]
+        if kind == 0 and self._kscale is not None:
+            out = out * self._kscale[layer][None]                        # back to the caller's scaling (exact: powers of two)
         return out[pos_begin - lo:pos_end - lo]
 
     PLAN_BUCKET = 512
@@ -336,6 +369,8 @@ class SpeckvKVConnector:
             raise ValueError("attend() needs an FP8, INT4 or MXFP4 pool; use block_table() / kv_rows() with the other schemes")
         B, H, G, D = q.shape
         key, reqs, _ = self._batch(req_ids)
+        if self._kscale is not None:
+            q = q * self._kscale[layer][None, :, None, :]
         q = q.contiguous()
         out = torch.empty((B, H, G, D), dtype=torch.float32, device="cuda")
         lse = torch.empty((B, H, G), dtype=torch.float32, device="cuda")

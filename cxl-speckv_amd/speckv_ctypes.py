@@ -48,6 +48,7 @@ _u32p = ctypes.POINTER(c_uint32)
 _u64p = ctypes.POINTER(c_uint64)
 
 _EXT_SIGNATURES = {
+    "speckv_ext_stream_is_capturing": [c_void_p, ctypes.POINTER(c_int)],
     "speckv_ext_set_quant_mode": [c_int],
     "speckv_ext_translate": [c_uint64, c_uint64, ctypes.POINTER(PageInfo)],
     "speckv_ext_fetch_desc": [c_uint64, c_uint64, ctypes.POINTER(DmaDesc)],
@@ -413,6 +414,12 @@ class SpeckvLib:
         pe = pos_end if isinstance(pos_end, ctypes.Array) else (c_uint32 * n)(*pos_end)
         self._ext("speckv_ext_attend_mx4_batch", n, hs, layer, c_void_p(d_q_f16), g, pe, ctypes.c_float(sm_scale),
                   c_void_p(d_out), c_void_p(d_lse or 0), c_void_p(stream or 0))
+
+    def stream_is_capturing(self, stream):
+        """True while `stream` (a hipStream_t value) is being captured into a HIP graph"""
+        out = ctypes.c_int(0)
+        self._ext("speckv_ext_stream_is_capturing", c_void_p(stream or 0), ctypes.byref(out))
+        return bool(out.value)
 
     def set_tuning(self, key, value):
         """A launch-form switch of the library (speckv_ext_set_tuning: the environment is read once per process)."""

@@ -502,6 +502,11 @@ double speckv_ext_codec_model_throughput_gbps(uint32_t num_engines, double clock
  * SPECKV_ERR_INVAL for an unknown key.  Works without speckv_init.  (INTEGRATION.md lists what each one does.) */
 speckv_status_t speckv_ext_set_tuning(const char* key, long long value);
 
+/* Is `stream` (a hipStream_t) being captured into a HIP graph right now?  The batch entry points and speckv_ext_attend_batch_plan
+ * refuse such a stream; a caller that plans ahead (SpeckvKVConnector.append) asks first.  *out_capturing = 0 for the NULL stream.
+ * SPECKV_ERR_DRIVER when the runtime does not know the stream (destroyed by its owner).  Works without speckv_init. */
+speckv_status_t speckv_ext_stream_is_capturing(void* stream, int* out_capturing);
+
 /* library identity: "hip" when built with the HIP data path */
 const char* speckv_ext_backend(void);
 

@@ -58,3 +58,46 @@ def test_formats_rank_as_their_bits_say(acc):
             assert abs(t["int4_g32"][regime]["rel_l2"] - t["mxfp4"][regime]["rel_l2"]) <= 0.03, (seed, regime)
         assert t["int4_g32+kscale"]["decode"]["rel_l2"] < 0.75 * t["mxfp4"]["decode"]["rel_l2"], seed
         assert t["int4_g32+kscale"]["decode"]["rel_l2"] < 0.8 * t["int4_g32"]["decode"]["rel_l2"], seed
+
+
+def test_connector_k_channel_scale_on_an_int4_pool():
+    """SpeckvKVConnector.set_k_channel_scale: K / s into the pool, q * s to meet it (powers of two, calibrated from the prompt).  A decode
+    loop over an INT4_G32 pool on KV-like data: prefill, appended positions (pairs and the odd tail), attention -- with the pre-scale the
+    output is closer to float64 attention over the original K / V where the query weighs K's outlier channels, and kv_rows() hands
+    back K in the caller's scaling."""
+    import torch
+    from cxl_speckv_amd.kv_connector import SpeckvKVConnector
+    from cxl_speckv_amd.speckv_ctypes import SpeckvLib
+    T, g, n_prompt, n_steps = 1024, 8, 601, 5
+    K, V, qs, _ = synth_kv(T, g, 7005)
+    sm = 1.0 / np.sqrt(D)
+    lib = SpeckvLib(pkg.library_path(), "hip:0")
+    try:
+        err = {}
+        for scaled in (False, True):
+            conn = SpeckvKVConnector(lib, num_layers=1, num_kv_heads=8, head_dim=D, max_tokens=T, scheme="int4")
+            if scaled:
+                conn.set_k_channel_scale(torch.from_numpy(pow2_channel_scales(K[:n_prompt])[None]))      # calibrated on the prompt only
+            conn.add_request(1)
+            kd, vd = torch.from_numpy(K).cuda(), torch.from_numpy(V).cuda()
+            keep = conn.write_prefill(1, kd[None, :n_prompt], vd[None, :n_prompt])
+            for t in range(n_prompt, n_prompt + n_steps):
+                keep += conn.append([1], kd[t][None, None], vd[t][None, None])
+            n = n_prompt + n_steps
+            assert conn.length(1) == n
+            out = conn.attend(0, [1], torch.from_numpy(qs["decode"]).cuda()[None], sm)
+            torch.cuda.synchronize()
+            ref = attention_f64(K[:n], V[:n], qs["decode"], sm)[0]
+            o = out[0].cpu().numpy().astype(np.float64)
+            err[scaled] = float(np.sqrt(((o - ref) ** 2).sum() / (ref ** 2).sum()))
+            rows = conn.kv_rows(1, 0, 0).cpu().numpy()
+            assert rows.shape == (n, 8, D)
+            # what comes back is INT4-quantised K in the caller's scaling: close to K channel by channel (a forgotten scale-back would be off by 2x .. 16x)
+            assert np.abs(rows.astype(np.float32) - K[:n].astype(np.float32)).max() <= 0.16 * np.abs(K[:n].astype(np.float32)).max()
+            conn.free_request(1)
+        assert err[True] < 0.8 * err[False] and err[True] <= 0.55, err
+        with pytest.raises(ValueError):
+            c2 = SpeckvKVConnector(lib, num_layers=1, max_tokens=T, scheme="int4")
+            c2.set_k_channel_scale(torch.full((1, 8, D), 3.0))                                              # not a power of two
+    finally:
+        lib.finalize()
