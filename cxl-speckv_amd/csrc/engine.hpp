@@ -341,8 +341,15 @@ private:
     std::vector<float*> lstm_bufs_;
     Scratch s_hid_, s_logits_, s_predict_ws_, s_hist_, s_pred_;
     Scratch s_attn_, s_attn_seq_;
-    // pinned staging for the batch descriptors: 4 slots in rotation, each guarded by an event (no stream sync per call)
-    struct PinnedRing { void* base = nullptr; size_t slot_bytes = 0; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; int next = 0; } seq_ring_, grp_ring_;
+    // pinned staging for the batch descriptors: slots in rotation, each guarded by an event (no stream sync per call).
+    // The batch attention kernels read their slot IN PLACE, so its guard is passed only when the launches of the call that
+    // last used it have finished: the ring is sized for the calls a caller runs ahead of the GPU -- one decode step of an
+    // 80-layer model and some (with 4 slots the host, holding the ABI lock, waited for the kernels of the call four
+    // layers back at every layer).  A 97th call in flight waits, under the lock, for the oldest.
+    static constexpr int kSeqRingSlots = 96;
+    template <int N> struct PinnedRingT { void* base = nullptr; size_t slot_bytes = 0; hipEvent_t ev[N] = {}; int next = 0; };
+    PinnedRingT<kSeqRingSlots> seq_ring_;
+    PinnedRingT<4> grp_ring_;
     struct PlanInfo { uint32_t n_seq; int scheme; uint32_t n_layers, max_pos_end; bool striped, table; uint32_t mx4_stripe_n_max; };
     std::unordered_map<const void*, PlanInfo> plans_;      // device plan buffer -> what attend_batch_plan last wrote there
     CompressGroup* d_groups_ = nullptr;    // device twin of grp_ring_ (4 slots): descriptors of a grouped compress launch

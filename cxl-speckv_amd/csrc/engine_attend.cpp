@@ -306,7 +306,7 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     }
     uint32_t tiles_max = 0;
     for (uint32_t i = 0; i < n_seq; ++i) tiles_max = std::max(tiles_max, seqs[i].n_splits);
-    const bool wg8 = !fp8 && !mx4 && !any_striped && !any_table && heads == 8u && true;
+    const bool wg8 = !fp8 && !mx4 && !any_striped && !any_table && heads == 8u;
     const uint32_t tps = mx4 ? mx4_batch_tps(n_seq, tiles_max, cus()) : wg8 ? int4_wg8_batch_tps(n_seq, tiles_max, cus()) : batch_tiles_per_split(fp8, n_seq, heads, total_tiles, seqs.data(), 0);
     const UnequalSplit unequal = (fp8 || mx4 || wg8) ? UnequalSplit{false, 1.0} : int4_unequal_split(n_seq, heads / 4u, tiles_max);
     uint32_t max_splits = 0;
@@ -334,12 +334,12 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     if (seq_ring_.slot_bytes < seq_bytes) {
         if (seq_ring_.base) { HIP_TRY(hipDeviceSynchronize()); (void)hipHostFree(seq_ring_.base); seq_ring_.base = nullptr; }
         seq_ring_.slot_bytes = std::max<size_t>(seq_bytes * 2, 16384);
-        HIP_TRY(hipHostMalloc(&seq_ring_.base, seq_ring_.slot_bytes * 4, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&seq_ring_.base, seq_ring_.slot_bytes * kSeqRingSlots, hipHostMallocDefault));
         for (auto& ev : seq_ring_.ev)
             if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     const int slot = seq_ring_.next;
-    seq_ring_.next = (slot + 1) & 3;
+    seq_ring_.next = (slot + 1) % kSeqRingSlots;
     HIP_TRY(hipEventSynchronize(seq_ring_.ev[slot]));          // whatever last used this slot (a launch that read it in place, a plan's copy) has finished
     void* staged = static_cast<uint8_t*>(seq_ring_.base) + static_cast<size_t>(slot) * seq_ring_.slot_bytes;
     memcpy(staged, seqs.data(), seq_bytes);
@@ -375,6 +375,13 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     if (mx4 && one_split_each && !any_striped && !any_table && static_cast<uint64_t>(n_seq) * ((g + 7u) / 8u) <= cus() && tuning().attend_mx4_one_half == 0) k.mx4_halves = 1u;
     if (unequal.on) k.rows_first = 1u;
     if (wg8) k.wg8 = int4_wg8_form(n_seq, cus());
+    // The kernels read the slot's descriptors in place: whatever was launched must have passed before the slot is written again.
+    // The guard event is recorded on EVERY way out from here on (a merge launch that fails behind an attention launch
+    // that went through used to leave the slot unguarded under a kernel still fetching from it).
+    struct SlotGuard {
+        hipEvent_t ev; hipStream_t st;
+        ~SlotGuard() { if (hipEventRecord(ev, st) != hipSuccess) (void)hipGetLastError(); }
+    } slot_guard{seq_ring_.ev[slot], st};
     if (fp8) {
         HIP_TRY(launch_attend_fp8_batch(k, n_seq, d_out, d_lse, st));
     } else if (mx4) {
@@ -383,7 +390,6 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
         HIP_TRY(launch_attend_int4(k, n_seq, st));        // grid y = sequences x head groups, as for layers
         if (!k.direct_out) HIP_TRY(launch_attend_combine(k, n_seq, d_out, d_lse, st));
     }
-    HIP_TRY(hipEventRecord(seq_ring_.ev[slot], st));           // the slot's descriptors have been read when this point is reached
     if (!s) HIP_TRY(hipStreamSynchronize(stream_));
     return SPECKV_OK;
 }
@@ -406,7 +412,7 @@ static PlanGeometry plan_geometry(bool fp8, uint32_t n_seq, uint32_t heads, uint
         g.parts_bound = static_cast<uint64_t>(n_seq) * heads * g.max_splits;
         return g;
     }
-    if (!fp8 && heads == 8u && true) {            // the whole-record kernel's geometry (a striped / table launch runs it on the 4-head kernels)
+    if (!fp8 && heads == 8u) {            // the whole-record kernel's geometry (a striped / table launch runs it on the 4-head kernels)
         g.unequal = UnequalSplit{false, 1.0};
         g.tps = int4_wg8_batch_tps(n_seq, tiles_max, cus);
         g.max_splits = std::max(1u, (tiles_max + g.tps - 1u) / g.tps);
@@ -496,12 +502,12 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
     if (seq_ring_.slot_bytes < seq_bytes) {
         if (seq_ring_.base) { HIP_TRY(hipDeviceSynchronize()); (void)hipHostFree(seq_ring_.base); seq_ring_.base = nullptr; }
         seq_ring_.slot_bytes = std::max<size_t>(seq_bytes * 2, 16384);
-        HIP_TRY(hipHostMalloc(&seq_ring_.base, seq_ring_.slot_bytes * 4, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&seq_ring_.base, seq_ring_.slot_bytes * kSeqRingSlots, hipHostMallocDefault));
         for (auto& ev : seq_ring_.ev)
             if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     const int slot = seq_ring_.next;
-    seq_ring_.next = (slot + 1) & 3;
+    seq_ring_.next = (slot + 1) % kSeqRingSlots;
     HIP_TRY(hipEventSynchronize(seq_ring_.ev[slot]));
     void* staged = static_cast<uint8_t*>(seq_ring_.base) + static_cast<size_t>(slot) * seq_ring_.slot_bytes;
     memcpy(staged, seqs.data(), seq_bytes);
@@ -540,7 +546,7 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
     k.scale_log2e = sm_scale * 1.4426950408889634f;
     if (plan->second.table) { k.table_form = 1u; k.zero_page = d_zero_page_; }           // a member without a regular placement: addresses from the page tables
     else if (plan->second.striped) k.stripe_bases = reinterpret_cast<const uint64_t*>(1);     // striped launch: every descriptor brings its table
-    else { k.lin_base = reinterpret_cast<const uint8_t*>(1); if (!fp8 && !mx4 && true) k.wg8 = int4_wg8_form(n_seq, cus()); }     // non-null: linear form (the real base comes from the descriptor)
+    else { k.lin_base = reinterpret_cast<const uint8_t*>(1); if (!fp8 && !mx4) k.wg8 = int4_wg8_form(n_seq, cus()); }     // non-null: linear form (the real base comes from the descriptor)
     k.seqs = static_cast<const AttendSeq*>(d_plan);
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);

@@ -652,6 +652,16 @@ struct RingLook {
 };
 typedef uint32_t sgpr4 __attribute__((ext_vector_type(4)));
 typedef uint64_t sgpr8 __attribute__((ext_vector_type(4)));     // four pointers: entries, d_flags, d_slot, h_slot (DevAlloc)
+// load_desc_ring reads these structs with hand-written scalar loads: one s_load_dwordx4 = a PageEntry {address, bytes, scale}, one
+// s_load_dwordx8 = the first four pointers of a DevAlloc row, one s_load_dwordx2 = Layout::alloc_pages.  A reordered or resized
+// field would silently defeat the `pp < their_pages` bound and send the atomicAnd on d_flags out of bounds: the layout
+// the assembly assumes is pinned here.  (-DSPECKV_RING_VECTOR_LOADS builds the same function from plain loads, for debugging.)
+static_assert(sizeof(PageEntry) == 16 && offsetof(PageEntry, pool_addr) == 0 && offsetof(PageEntry, rec_bytes) == 8 && offsetof(PageEntry, scale) == 12,
+              "load_desc_ring: s_load_dwordx4 of a PageEntry");
+static_assert(offsetof(DevAlloc, entries) == 0 && offsetof(DevAlloc, d_flags) == 8 && offsetof(DevAlloc, d_slot) == 16 && offsetof(DevAlloc, h_slot) == 24,
+              "load_desc_ring: s_load_dwordx8 of a DevAlloc row = {entries, d_flags, d_slot, h_slot}");
+static_assert(sizeof(Layout::alloc_pages) == 8 && (offsetof(DevAlloc, layout) + offsetof(Layout, alloc_pages)) % 8 == 0,
+              "load_desc_ring: s_load_dwordx2 of Layout::alloc_pages");
 __device__ __forceinline__ BlockDesc load_desc_ring(const CodecArgs& a, uint64_t i, uint32_t slot0, RingLook& r)
 {
     BlockDesc d;
@@ -664,6 +674,10 @@ __device__ __forceinline__ BlockDesc load_desc_ring(const CodecArgs& a, uint64_t
     const DevAlloc* mine = a.tab + d.row;
     uint64_t prev;
     sgpr4 e = {0u, 0u, 0u, 0x3f800000u};
+#ifdef SPECKV_RING_VECTOR_LOADS
+    if (a.entries) { const PageEntry pe = a.entries[d.page]; e = sgpr4{static_cast<uint32_t>(pe.pool_addr), static_cast<uint32_t>(pe.pool_addr >> 32), pe.rec_bytes, __float_as_uint(pe.scale)}; }
+    prev = __hip_atomic_load(owner_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
     if (a.entries) {
         const PageEntry* ep = a.entries + d.page;
         asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
@@ -671,6 +685,7 @@ __device__ __forceinline__ BlockDesc load_desc_ring(const CodecArgs& a, uint64_t
     } else {                                                 // a row freed meanwhile decodes as a never-written page
         asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(prev) : "s"(owner_word) : "memory");
     }
+#endif
     d.rec = reinterpret_cast<const uint8_t*>((static_cast<uint64_t>(e.y) << 32) | e.x);
     d.len = e.z;
     d.scale = __uint_as_float(e.w);
@@ -678,9 +693,15 @@ __device__ __forceinline__ BlockDesc load_desc_ring(const CodecArgs& a, uint64_t
     const DevAlloc* theirs = other ? a.tab + (prev >> 32) : mine;
     sgpr8 tp, mp;
     uint64_t their_pages;
+#ifdef SPECKV_RING_VECTOR_LOADS
+    tp = sgpr8{reinterpret_cast<uint64_t>(theirs->entries), reinterpret_cast<uint64_t>(theirs->d_flags), reinterpret_cast<uint64_t>(theirs->d_slot), reinterpret_cast<uint64_t>(theirs->h_slot)};
+    mp = sgpr8{reinterpret_cast<uint64_t>(mine->entries), reinterpret_cast<uint64_t>(mine->d_flags), reinterpret_cast<uint64_t>(mine->d_slot), reinterpret_cast<uint64_t>(mine->h_slot)};
+    their_pages = theirs->layout.alloc_pages;
+#else
     asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx2 %1, %3, %5\n\ts_load_dwordx8 %2, %4, 0x0\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(tp), "=&s"(their_pages), "=&s"(mp) : "s"(theirs), "s"(mine),
                    "i"(offsetof(DevAlloc, layout) + offsetof(Layout, alloc_pages)) : "memory");
+#endif
     const uint32_t pp = static_cast<uint32_t>(prev);
     // the row may have been recycled for a smaller allocation since the slot was filled
     const bool in_row = other && tp.x != 0 && pp < their_pages;

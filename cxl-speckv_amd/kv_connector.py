@@ -294,11 +294,15 @@ class SpeckvKVConnector:
         return keep                                            # sources of the asynchronous writes: hold until the stream passed them
 
     # ------------------------------------------------------------------ reads
-    def begin_step(self, req_ids: Sequence[int], depth_k: int = 0) -> Optional[int]:
+    def begin_step(self, req_ids: Sequence[int], depth_k: int = 0, force: bool = False) -> Optional[int]:
         """Speculative look-ahead of the next positions of every (request, layer): one prefetch batch, one flush.
-        Meaningful for pools whose pages are consumed decompressed (fp16 / int8 schemes); the fused attention of the
-        FP8 / INT4 pools reads the records themselves."""
+        For pools whose pages are consumed decompressed (fp16 / int8 schemes).  The fused attention of the FP8 / INT4 / MXFP4
+        pools reads the records themselves and never looks into the ring of decoded pages, so for those pools the call does
+        nothing (it used to decode 4 positions x layers x requests per step that nobody read: 0.09 ms of a 1 ms decode step,
+        profiles/r06_connector_step.txt) unless `force` says that block_table() / access() consumers exist beside it."""
         import numpy as np
+        if self.scheme in FUSED and not force:
+            return None
         key, robjs, _ = self._batch(req_ids)
         cols = self._step_cols.get((key, depth_k))            # request / layer / depth columns: constants of the batch
         if cols is None:

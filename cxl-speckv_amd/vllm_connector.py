@@ -155,6 +155,7 @@ class SpeckvVllmConnector:
                 blk, first, n = self._to_load.pop(rid)
                 use = blk or list(new_blocks)
                 if len(use) * self.block_size < first + n:
+                    self._pending_free = meta.free_engine_ids + self._pending_free      # this metadata is never delivered: its frees stay pending
                     raise RuntimeError(f"request {rid!r}: a pool hit of tokens [{first}, {first + n}) but only {len(use)} blocks to load it into")
                 meta.requests.append(ReqMeta(rid, self._engine_id(rid), slot_mapping_for(use, self.block_size, n, first), first, n, is_store=False))
                 continue
@@ -172,6 +173,9 @@ class SpeckvVllmConnector:
             # tokens as computed although nothing fills their blocks -- never drop that silently
             lost = sorted(self._to_load)
             self._to_load.clear()
+            # (the metadata object dies with this exception -- the engine-side frees it had taken over go back to the
+            # pending list, so a caller that survives the error does not leak their pool allocations)
+            self._pending_free = meta.free_engine_ids + self._pending_free
             raise RuntimeError(f"pool hits recorded for {lost} but the scheduler output schedules none of them (neither as a new nor "
                                "as a cached / resumed request): their blocks would be attended without ever being filled")
         return meta

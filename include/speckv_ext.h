@@ -327,13 +327,18 @@ speckv_status_t speckv_ext_attend_int4_batch(uint32_t n_seq, const speckv_handle
 
 /* speckv_ext_attend_mx4: the same attention over SPECKV_COMP_MXFP4 records -- the 4:1 format gfx950's matrix cores read
  * natively (OCP Microscaling Formats v1.0: FP4 E2M1 elements, one E8M0 power-of-two scale per 32 elements; record = 1024 B of
- * nibbles, element 2i in the low half of byte i, then the 64 scale codes: 1088 B per 4 KiB block, 3.76 : 1).
+ * nibbles -- byte i = element i in the low half, element 1024 + i in the high half: the two positions of a page interleaved --
+ * then the 64 scale codes, one per 16 bytes: 1088 B per 4 KiB block, 3.76 : 1.  In the POOL the records of a run lie
+ * tile-planar: 16 records = their 16 nibble rows followed by their 16 code rows = 136 whole cache lines, so the pool spends
+ * 1088 B per page and the attention fetches nothing but record bytes; speckv_ext_translate reports a page's two pieces,
+ * speckv_ext_page_info_t::aux_offset.  The raw operators speckv_ext_codec_* keep contiguous records).
  * q.K^T runs on v_mfma_scale_f32_16x16x128_f8f6f4: one instruction contracts the whole head dimension, K nibbles and scale
  * codes go in as they lie in the record, the block scales are applied by the hardware; the query is quantised to MXFP8
  * (e4m3 elements, E8M0 per 32: emax 8, saturating) on the device.  V is widened to f16 WITH its block scale by one
  * v_cvt_scalef32_pk_f16_fp4 per element pair and meets the f16 softmax weights on v_mfma_f32_16x16x32_f16, fp32 accumulation.
- * Any placement is served (one run, regular striping, page-table addresses).  g <= 16 query rows per kv head; waves take
- * 16 / g' heads at once (g' = g rounded up to 4, 8 or 16) so that every column of the score MFMA is a live query row.
+ * Any placement is served (one run, regular striping, page-table addresses).  g <= 16 query rows per kv head, taken in groups
+ * of 8 (a second set of workgroups for rows 8 .. 15): the 16 columns of a score MFMA are 8 query rows x the 2 positions of a
+ * page, so with g = 8 (GQA 8) every column is live, with g = 4 half of them are masked.
  * (oracle: orc_attend_mx4; arguments as speckv_ext_attend_int4.) */
 speckv_status_t speckv_ext_attend_mx4(speckv_handle_t handle, uint32_t layer_begin, uint32_t n_layers,
                                       const void* d_q_f16, uint32_t g, uint32_t pos_begin, uint32_t pos_end,
@@ -498,7 +503,9 @@ double speckv_ext_codec_model_throughput_gbps(uint32_t num_engines, double clock
  * call of the process; after that a form is changed by this call only.  Keys (= the SPECKV_<KEY> environment names, lower case):
  * attend_splits, attend_tiles_per_split, attend_general, tc_multipass, tc_scan (1 one workgroup, 2 one wave), tc_no_pre,
  * tc_no_split_tiles, td_one_pass, td_expand_per_element, flush_no_small, flush_small_words, predict_batch_path, wgs_per_cu,
- * rounds_consecutive, remote_engine (1 kernel, 2 copy engines), copy_min_run_kb.  0 restores the library's own rule.
+ * rounds_consecutive, remote_engine (1 kernel, 2 copy engines), copy_min_run_kb, attend_stream (MXFP4, several layers of one
+ * sequence: N > 0 the stream form with N workgroups, -1 never), attend_mx4_one_half (MXFP4 batches: 4-wave workgroups also where
+ * the two-halves form applies).  0 restores the library's own rule.
  * SPECKV_ERR_INVAL for an unknown key.  Works without speckv_init.  (INTEGRATION.md lists what each one does.) */
 speckv_status_t speckv_ext_set_tuning(const char* key, long long value);
 

@@ -1,6 +1,6 @@
 """Where a connector decode step spends its time: host time of each phase (no sync inside), device time of the step, and
 the same attention layers replayed from a HIP graph (plan_step outside, planned launches captured).
-Run on the GPU box:  python profiles/tools/conn_step.py"""
+Run on the GPU box:  python profiles/tools/conn_step.py [fp8|int4|mxfp4]"""
 import os, sys, time, gc
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -9,7 +9,11 @@ from cxl_speckv_amd.kv_connector import SpeckvKVConnector
 
 n_seq, Lyr, ctx, T = 256, 8, 2048, 4096
 lib = pkg.SpeckvLib(pkg.library_path(), "hip:0")
-conn = SpeckvKVConnector(lib, num_layers=Lyr, max_tokens=T, scheme="fp8")
+SCH = sys.argv[1] if len(sys.argv) > 1 else "fp8"
+SID = {"fp8": 4, "int4": 3, "mxfp4": 5}[SCH]
+REC = {"fp8": 1024, "int4": 576, "mxfp4": 544}[SCH]          # record bytes per position and kind
+conn = SpeckvKVConnector(lib, num_layers=Lyr, max_tokens=T, scheme=SCH)
+print("pool format:", SCH)
 ids = list(range(n_seq))
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 kp = torch.randn((Lyr, ctx, 8, 128), generator=g, device="cuda").to(torch.float16)
@@ -47,7 +51,7 @@ lse = torch.empty((Lyr, n_seq, 8, 8), dtype=torch.float32, device="cuda")
 bound = conn.plan_step(ids, s)
 def layers():
     for layer in range(Lyr):
-        lib.attend_planned(4, conn._plan.data_ptr(), n_seq, layer, q.data_ptr(), 8, bound, 0.0884, out[layer].data_ptr(), lse[layer].data_ptr(), s.cuda_stream)
+        lib.attend_planned(SID, conn._plan.data_ptr(), n_seq, layer, q.data_ptr(), 8, bound, 0.0884, out[layer].data_ptr(), lse[layer].data_ptr(), s.cuda_stream)
 layers(); torch.cuda.synchronize()
 gr = torch.cuda.CUDAGraph()
 gc.collect(); gc.disable()
@@ -64,7 +68,7 @@ for name, fn in (("eager planned x%d" % Lyr, layers), ("graph replay", gr.replay
         host = (time.perf_counter() - t0) / 50 * 1e3
         b.record(s); torch.cuda.synchronize()
         ms = a.elapsed_time(b) / 50
-    gb = n_seq * Lyr * 2 * ctx * 1024 / 1e9
+    gb = n_seq * Lyr * 2 * ctx * REC / 1e9
     print("%-18s host %.3f ms  device %.3f ms  %.0f GB/s (%.3f of 8 TB/s)" % (name, host, ms, gb / (ms * 1e-3), gb / (ms * 1e-3) / 8000))
 t0 = time.perf_counter()
 for _ in range(50): conn.plan_step(ids, s)

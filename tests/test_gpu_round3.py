@@ -1074,9 +1074,12 @@ def test_vllm_connector_prefix_hit_chunked_prefill_and_separate_roles():
             assert torch.equal(prefix[li][:, res_slots], truth[li][:, :matched]), li
         # ... and a hit that no entry of the step's output carries is an error, not a silent drop
         sched.update_state_after_alloc(req, NS(get_block_ids=lambda: [res_blk]), matched)
+        sched._pending_free.append(4242)                                              # a free waiting for this step's metadata ...
         with pytest.raises(RuntimeError, match="without ever being filled"):
             sched.build_connector_meta(NS(scheduled_new_reqs=[], num_scheduled_tokens={}))
-        assert sched.build_connector_meta(NS(scheduled_new_reqs=[])).requests == []         # (the state was reset)
+        after = sched.build_connector_meta(NS(scheduled_new_reqs=[]))
+        assert after.requests == []                                                     # (the state was reset)
+        assert after.free_engine_ids == [4242]                                          # ... survives the metadata that died with the error
 
         # ---- a load for a request this worker never saved fails with a clear error, not a KeyError
         bad = sched.build_connector_meta(NS(scheduled_new_reqs=[]))
