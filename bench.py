@@ -93,6 +93,25 @@ def parse_args():
 # --------------------------------------------------------------------------
 # CPU baseline (checker code, used here ONLY as the thing timed beside the GPU)
 # --------------------------------------------------------------------------
+def host_cpu_info():
+    """(model string, physical cores, logical CPUs) of this host from /proc/cpuinfo (BASELINE.md section 3 asks for both)."""
+    model, cores = None, set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model is None: model = v
+            elif k == "physical id": phys = v
+            elif k == "core id": core = v
+            elif not k and phys is not None:
+                cores.add((phys, core)); phys = core = None
+        if phys is not None: cores.add((phys, core))
+    except OSError:
+        pass
+    return model or "unknown", len(cores) or None, os.cpu_count() or 1
+
+
 def cpu_baseline(seconds, sample_blocks=None, seed=2001):
     """The CPU path timed beside the GPU figure, on this host's cores, on a bounded sample of the same workload.
     `kind: "reference"`: the reference's own FPGACacheEngine::decompress (oracle/_ref, compiled from /root/reference in the
@@ -136,12 +155,16 @@ def cpu_baseline(seconds, sample_blocks=None, seed=2001):
         return round(sum(d for d, _ in outs) / max(e for _, e in outs), 1), round(v1, 1)
 
     pv, pv1 = timed(port_work)
+    cpu_model, physical, logical = host_cpu_info()
+    host = {"cpu_model": cpu_model, "physical_cores": physical, "logical_cpus": logical,
+            "cores_note": "`cores` = the threads that ran (one per logical CPU); physical_cores from /proc/cpuinfo"}
     port = {"value": pv, "value_1thread": pv1, "unit": "blocks/s", "cores": n_threads,
-            "what": "oracle/speckv_oracle.c (C restatement), INT8_DELTA_RLE decompress to fp16"}
+            "what": "oracle/speckv_oracle.c (C restatement), INT8_DELTA_RLE decompress to fp16 -- through a bit-by-bit software float -> half "
+                    "conversion per element (no F16C intrinsics in a C99 checker), which is most of its distance to the reference's fp32 output"}
     sample = (f"{sample_blocks} N(0,1) fp16 blocks (seed {seed}), INT8_DELTA_RLE decompress, looped ~{leg_s:.0f}s per leg; "
               f"1 thread and {n_threads} threads (one engine each)")
     if not have_reference():
-        return {"value": pv, "unit": "blocks/s", "cores": n_threads, "kind": "port", "value_1thread": pv1, "sample": sample, "port": port}
+        return {"value": pv, "unit": "blocks/s", "cores": n_threads, "kind": "port", "value_1thread": pv1, "sample": sample, "port": port, **host}
     ref = Reference()
     L = ref.lib
     x32 = x.astype(np.float32)
@@ -164,7 +187,7 @@ def cpu_baseline(seconds, sample_blocks=None, seed=2001):
 
     rv, rv1 = timed(ref_work)
     return {"value": rv, "unit": "blocks/s", "cores": n_threads, "kind": "reference", "value_1thread": rv1,
-            "sample": sample + "; reference = FPGACacheEngine::decompress to fp32", "port": port}
+            "sample": sample + "; reference = FPGACacheEngine::decompress to fp32", "port": port, **host}
 
 
 # --------------------------------------------------------------------------
@@ -505,6 +528,9 @@ def main():
                     out["roofline"]["xgmi"]["one_gpu_dry_run"] = "every 'peer' is the same GPU: no link was crossed, the fraction means nothing"
                 # `value` at N > 1 is replica weak scaling of the LOCAL path (every rank decodes its own pool); north_star's
                 # remote fetch is a different figure and stands beside it at the top level so that nobody mistakes one for the other
+                out["north_star_fields"] = {"xgmi_remote_fetch_at_N_gpus": "value_remote_fetch_GBps_inbound (and roofline.xgmi.frac: target >= 0.60)",
+                                            "hbm_local_decompress": "roofline.frac (target >= 0.70)",
+                                            "not_a_north_star_figure": "value at N > 1 (replica weak scaling of the local path)"}
                 out["value_remote_fetch_blocks_per_s"] = rx.get("blocks_per_s")
                 out["value_remote_fetch_GBps_inbound"] = rx["achieved"]
                 out["value_note"] = ("`value` = blocks/s of the local fetch+decompress path summed over ranks (replicas, no exchange: linear by "
@@ -643,6 +669,29 @@ def xgmi_sets_for(n_pool_gpus, set_bytes, single_gpu_test):
     return max(1, -(-21 * MALL_BYTES * n_pool_gpus // (2 * max(set_bytes, 1))))      # 10.5x: records are a little smaller than their 4 KiB pages
 
 
+def xgmi_mode_plan(mode, rank, world, set_bytes, single_gpu_test, device_count):
+    """What `rank` does in remote-fetch mode `mode` -- a pure function of its arguments, so that the branch a real 8-GPU node
+    takes can be asserted on a machine without one (tests/test_multirank_cpu.py runs it for every rank of world 8 with
+    device_count = 8): which GPUs hold its pool, the SPECKV_POOL_DEVICES value it opens the engine with, how many allocations of
+    the 8B-shaped set make the remote working set (>= 10 x the Infinity Cache per pool GPU), the per-peer copy streams the copy
+    engine will use (one per pool GPU), and a pessimistic wall-time estimate of the mode (every byte at 40 GB/s per link:
+    one compressing write of the set + 10 timed passes x 2 engines x {records, fp16 pages})."""
+    pools = pool_devices_for(mode, rank, world)
+    links = len(pool_devices_for(mode, 0, world))
+    n_sets = xgmi_sets_for(links, set_bytes, single_gpu_test)
+    plan = {"active": pools is not None, "pools": pools, "links": links, "n_sets": n_sets, "error": None,
+            "working_set_bytes": n_sets * set_bytes, "working_set_bytes_per_pool_gpu": n_sets * set_bytes // max(links, 1),
+            "peer_streams": len(pools) if pools else 0, "pool_devices_env": None}
+    if pools is not None:
+        if not single_gpu_test and device_count < world:
+            plan["error"] = f"only {device_count} devices visible to this rank"
+        else:
+            plan["pool_devices_env"] = ",".join(str(d) for d in ([0] * len(pools) if single_gpu_test else pools))
+    passes = 1 + 10 * 2 * 2
+    plan["expected_wall_s_at_40GBps_per_link"] = round(plan["working_set_bytes"] * passes / (40e9 * max(links, 1)) + 20.0, 1)
+    return plan
+
+
 def xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream, red_dev="cuda", single_gpu_test=False, state=None):
     """Remote fetch over xGMI in the three shapes of pool_devices_for(), each with both fetch engines: the fused
     peer-load + decompress kernel (engine 1) and the copy engines (engine 2: one hipMemcpyPeerAsync per pool GPU and
@@ -676,18 +725,16 @@ def xgmi_phase(args, torch, pkg, dist, rank, local_rank, world, src, dst, stream
         if mode == "cfg4" and world == 2:
             result[mode] = {"same_as": "cfg3", "note": "with 2 GPUs the striped pool has one peer"}
             continue
-        pools = pool_devices_for(mode, rank, world)
-        active = pools is not None
-        links = len(pool_devices_for(mode, 0, world))
-        info = {"compute_ranks": world if mode == "symmetric" else 1, "pool_gpus_per_compute_gpu": links, "links": links}
+        plan = xgmi_mode_plan(mode, rank, world, n_blocks * PAGE, single_gpu_test, torch.cuda.device_count())
+        pools, active, links, n_sets = plan["pools"], plan["active"], plan["links"], plan["n_sets"]
+        info = {"compute_ranks": world if mode == "symmetric" else 1, "pool_gpus_per_compute_gpu": links, "links": links,
+                "expected_wall_s_at_40GBps_per_link": plan["expected_wall_s_at_40GBps_per_link"]}
         kv2, err, rec_bytes, handles = None, None, 0, []
-        n_sets = xgmi_sets_for(links, n_blocks * PAGE, single_gpu_test)
         try:
             if active:
-                dev_list = [0] * len(pools) if single_gpu_test else pools
-                if not single_gpu_test and torch.cuda.device_count() < world:
-                    raise RuntimeError(f"only {torch.cuda.device_count()} devices visible to this rank")
-                os.environ["SPECKV_POOL_DEVICES"] = ",".join(str(d) for d in dev_list)
+                if plan["error"]:
+                    raise RuntimeError(plan["error"])
+                os.environ["SPECKV_POOL_DEVICES"] = plan["pool_devices_env"]
                 kv2 = pkg.CxlSpeckvKVAllocator(pkg.library_path(), f"hip:{local_rank}")
                 lib = kv2.lib
                 lib.set_compression_scheme(args.scheme)
@@ -1200,7 +1247,7 @@ def connector_decode_extra(torch, kv, n_seq=256, Lyr=8, ctx=2048, T=4096, scheme
                                           "tokens_per_s_kv_side": round(n_seq / (ms * 1e-3), 1),
                                           "KV_record_GBps": round(rec_bytes / (ms * 1e-3) / 1e9, 1),
                                           "frac_hbm": round(rec_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                          "note": "begin_step (flush) + one batch attention call per layer + batched append (which plans the next step), wall time "
+                                          "note": "begin_step (a no-op for fused pools since round 6) + one batch attention call per layer + batched append (which plans the next step), wall time "
                                                   "per step incl. the torch glue (tail fold, gathers); " + scheme + " pool"}}
     except Exception as e:
         return {"connector_decode_step" if scheme == "fp8" else f"connector_decode_step_{scheme}": {"error": repr(e)}}

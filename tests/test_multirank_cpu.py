@@ -284,3 +284,43 @@ def test_committed_bench_line_has_the_contract_fields():
     for variant in ("as_called", "ramped", "sustained"):
         assert abs(s[variant]["trace_vs_hip_events"]) < 0.02, (variant, s[variant])
         assert abs(s[variant]["frac_from_trace"] - s[variant]["bench_frac_hbm"]) < 0.01
+
+
+def test_real_8_gpu_branch_of_the_remote_phase_by_rank():
+    """VERDICT r5 #8 (first-contact readiness): the branch of bench.py's remote phase that a REAL 8-GPU node takes (not the
+    SPECKV_BENCH_SINGLE_GPU_TEST dry run) as a pure function, asserted for every rank with 8 devices visible: the pool list each
+    engine is opened with, the copy engine's per-peer streams, the working set (>= 10 x the 256 MiB Infinity Cache on
+    every pool GPU) and a pessimistic wall-time estimate that must stay far inside the driver's 1 800 s."""
+    sys.path.insert(0, ROOT)
+    import bench
+    world, set_bytes = 8, 131072 * 4096
+    for rank in range(world):
+        plans = {m: bench.xgmi_mode_plan(m, rank, world, set_bytes, False, 8) for m in bench.XGMI_MODES}
+        others = [d for d in range(world) if d != rank]
+        # configs[2]: rank 0 computes, pool on GPU 1; configs[3]: rank 0 computes, pool striped page % 7 over GPUs 1..7; the rest idle
+        if rank == 0:
+            assert plans["cfg3"]["pool_devices_env"] == "1" and plans["cfg3"]["peer_streams"] == 1
+            assert plans["cfg4"]["pool_devices_env"] == "1,2,3,4,5,6,7" and plans["cfg4"]["peer_streams"] == 7
+        else:
+            assert not plans["cfg3"]["active"] and not plans["cfg4"]["active"] and plans["cfg4"]["pool_devices_env"] is None
+        assert plans["symmetric"]["active"] and plans["symmetric"]["pool_devices_env"] == ",".join(map(str, others)) and plans["symmetric"]["peer_streams"] == 7
+        assert all(p["error"] is None for p in plans.values())
+        # every rank agrees on the shape of a mode (the barriers and reductions of the phase depend on it)
+        assert [plans[m]["links"] for m in bench.XGMI_MODES] == [1, 7, 7]
+        assert plans["cfg4"]["n_sets"] == 37 and plans["cfg4"]["working_set_bytes"] == 37 * 512 * 2**20       # 18.5 GiB, 2.64 GiB per pool GPU
+        assert plans["cfg3"]["n_sets"] == 6
+        for m in bench.XGMI_MODES:
+            assert plans[m]["working_set_bytes_per_pool_gpu"] * (4080 / 4096) >= 10 * bench.MALL_BYTES
+            assert plans[m]["expected_wall_s_at_40GBps_per_link"] < 300.0                                       # three modes: well inside the driver's 1 800 s
+    # a rank that sees fewer devices than the world says so instead of opening a pool on a GPU that is not there
+    assert "only 4 devices" in bench.xgmi_mode_plan("cfg4", 0, 8, set_bytes, False, 4)["error"]
+    # ... and the one-GPU dry run keeps every "peer" on GPU 0 with a small working set
+    dry = bench.xgmi_mode_plan("cfg4", 0, 8, set_bytes, True, 1)
+    assert dry["pool_devices_env"] == "0,0,0,0,0,0,0" and dry["n_sets"] == 2 and dry["error"] is None
+
+
+def test_host_cpu_info_reads_model_and_physical_cores():
+    sys.path.insert(0, ROOT)
+    import bench
+    model, physical, logical = bench.host_cpu_info()
+    assert isinstance(model, str) and model and logical >= 1 and (physical is None or 1 <= physical <= logical)
