@@ -1470,6 +1470,68 @@ def tensor_codec_extra(torch, lib, n=131072 * 256):
         return {"tensor_codec_whole_tensor": {"error": repr(e)}}
 
 
+def tensor_codec_batch_extra(torch, lib, n_tensors=4096, n=131072):
+    """The reference's codec at the reference's own call size (VERDICT r5 missing #4): FPGACacheEngine::compress(data, n) is called per KV
+    tile -- 1024 x 128 = 131 072 elements, hardware/rtl/kv_compress.v:5-11 -- so the shape is MANY tensors of that size, not one giant
+    one.  speckv_ext_codec_compress_tensors / _decompress_tensors: one workgroup per tensor, one launch each way; fp32 in and out as
+    the reference takes and returns them, and the fp16 forms beside."""
+    import ctypes as C
+    try:
+        raw = lib.lib
+        raw.speckv_ext_codec_compress_tensors.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        raw.speckv_ext_codec_decompress_tensors.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        g = torch.Generator(device="cuda"); g.manual_seed(2007)
+        x32 = torch.randn((n_tensors, n), generator=g, device="cuda", dtype=torch.float32)
+        x32 *= torch.rand((n_tensors, 1), generator=g, device="cuda") * 4 + 0.25          # every tensor its own scale
+        x16 = x32.to(torch.float16)
+        cap = 2 * n + 16
+        rle = torch.empty((n_tensors, cap), dtype=torch.uint8, device="cuda")
+        y32 = torch.empty((n_tensors, n), dtype=torch.float32, device="cuda")
+        sizes = torch.zeros(n_tensors, dtype=torch.int64, device="cuda")
+        scales = torch.zeros(n_tensors, dtype=torch.float32, device="cuda")
+        nout = torch.zeros(n_tensors, dtype=torch.int64, device="cuda")
+        s = torch.cuda.Stream()
+
+        def descs(data, esz):
+            d = np.zeros((n_tensors, 4), np.uint64)
+            d[:, 0] = data.data_ptr() + np.arange(n_tensors, dtype=np.uint64) * np.uint64(n * esz)
+            d[:, 1] = n
+            d[:, 2] = rle.data_ptr() + np.arange(n_tensors, dtype=np.uint64) * np.uint64(cap)
+            d[:, 3] = cap
+            return torch.from_numpy(d.view(np.int64)).cuda()
+        out = {"tensors": n_tensors, "elements_each": n}
+        for tag, src, esz, f32 in (("fp32", x32, 4, 1), ("fp16", x16, 2, 0)):
+            dst = y32 if f32 else y32.view(torch.float16)[:, :n]
+            if not f32:
+                dst = torch.empty((n_tensors, n), dtype=torch.float16, device="cuda")
+            dc, dd = descs(src, esz), descs(dst, esz)
+            enc = lambda: raw.speckv_ext_codec_compress_tensors(n_tensors, dc.data_ptr(), f32, sizes.data_ptr(), scales.data_ptr(), 0, s.cuda_stream)
+            dec = lambda: raw.speckv_ext_codec_decompress_tensors(n_tensors, dd.data_ptr(), sizes.data_ptr(), scales.data_ptr(), f32, nout.data_ptr(), 0, s.cuda_stream)
+            assert enc() == 0 and dec() == 0
+            torch.cuda.synchronize()
+            comp = int(sizes.sum().item())
+            assert int(nout.min().item()) == n and int(nout.max().item()) == n
+            # (REF_EXACT reproduces the reference's double scaling and int8 wrap, cache_engine.cpp:190-192: its round trip is not close
+            #  to the input by design; what the streams must be is pinned per tensor in tests/test_gpu_codec.py)
+            for name, fn, byt in (("compress", enc, esz * n * n_tensors + comp), ("decompress", dec, comp + esz * n * n_tensors)):
+                ramp(lambda: fn(), torch.cuda.synchronize, EXTRAS_RAMP_MS)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(s)
+                for _ in range(5):
+                    fn()
+                b.record(s); torch.cuda.synchronize()
+                ms = a.elapsed_time(b) / 5
+                out[f"{name}_{tag}"] = {"ms": round(ms, 4), "tensors_per_s": round(n_tensors / (ms * 1e-3), 1), "algorithmic_GBps": round(byt / (ms * 1e-3) / 1e9, 1),
+                                        "frac_hbm": round(byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+            out[f"compressed_bytes_{tag}"] = comp
+            del dc, dd
+        out["note"] = ("one workgroup per tensor: max|x| by the workgroup itself (first pass, 512 KiB of fp32 per tensor), then the encode in rounds of 16 tiles "
+                       "(second pass: out of the L2 / Infinity Cache), chains carried in LDS; algorithmic bytes = source once + stream (compress), stream + output (decompress)")
+        return {"tensor_codec_batched_131072": out}
+    except Exception as e:                                               # noqa: BLE001
+        return {"tensor_codec_batched_131072": {"error": repr(e)}}
+
+
 def compaction_extra(torch, kv, n_pages=131072):
     """speckv_ext_compact on the structured data SURVEY 8(d) names (a third runs of 32, a third zeros, a third N(0,1)):
     pool bytes before / after, i.e. the capacity the reference's scheme really buys once records are packed."""
@@ -1664,6 +1726,7 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     ex.update(predictor_extra(torch, lib))
     ex.update(lstm_cell_extra(torch, lib))
     ex.update(compaction_extra(torch, kv))
+    ex.update(tensor_codec_batch_extra(torch, lib))                    # the reference's call size: 4096 tensors of 131 072 elements, one launch each way
     ex.update(tensor_codec_extra(torch, lib))
     ex.update(tensor_codec_extra(torch, lib, n=1280 * 2**20))          # a 2.5 GiB source: ten times the Infinity Cache
     return ex

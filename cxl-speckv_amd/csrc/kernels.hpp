@@ -169,6 +169,14 @@ hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, u
 hipError_t launch_tensor_decompress(const uint8_t* d_rle, uint64_t rle_bytes, float scale, void* d_dst, uint64_t dst_cap, bool out_f32,
                                     uint64_t* d_n_out, void* d_ws, size_t ws_bytes, int quant_mode, hipStream_t s);
 
+// The same over MANY tensors in one launch each way, one workgroup per tensor, no workspace (tensor_codec.hip: k_tcb_fused /
+// k_tdb_fused).  TensorDesc = speckv_ext_tensor_t: {data (compress: the source; decompress: the destination), n (elements;
+// decompress: room), rle (the stream, 16-byte aligned), rle_cap}.
+struct TensorDesc { void* data; uint64_t n; uint8_t* rle; uint64_t rle_cap; };
+hipError_t launch_tensors_compress(uint32_t n_tensors, const TensorDesc* d_desc, bool src_f32, uint64_t* d_rle_bytes, float* d_scales, int quant_mode, hipStream_t s);
+hipError_t launch_tensors_decompress(uint32_t n_tensors, const TensorDesc* d_desc, const uint64_t* d_rle_bytes, const float* d_scales, bool out_f32,
+                                     uint64_t* d_n_out, int quant_mode, hipStream_t s);
+
 // Prefetch lookup: 3 kernels (mask+count, scan, scatter) -> compacted page list
 // in request order.  scratch must hold (2*n + 2) uint32.
 hipError_t launch_prefetch_lookup(const Layout& lay, uint32_t n,

@@ -59,16 +59,18 @@ __device__ __forceinline__ float tc_load(const void* src, uint64_t p)
 // max|x| over the tensor as fp32 bits (non-negative floats order like their bit patterns); a NaN never wins
 // (cache_engine.cpp:176-180: `if (abs > max_val)`).  16 bytes per lane and step where the source allows it (the elements in
 // front of the first 16-byte boundary and behind the last one are taken one by one).
-template <bool F32>
-__global__ __launch_bounds__(1024) void k_tc_absmax(const void* __restrict__ src, uint64_t n, uint32_t* __restrict__ out_bits)
+// one thread's share (thread `tid` of `nthr`) of that maximum: fp32 sources |x| bits, fp16 sources |x| half bits (converted by the
+// caller at the end).  NT: non-temporal loads (a pass that nobody re-reads); the batched kernel below keeps the default policy --
+// its second pass over the same 512 KiB comes out of the L2 / Infinity Cache.
+template <bool F32, bool NT>
+__device__ __forceinline__ uint32_t tc_absmax_thread(const void* __restrict__ src, uint64_t n, uint64_t tid, uint64_t nthr)
 {
     constexpr uint32_t kPer = F32 ? 4u : 8u, kEsz = F32 ? 4u : 2u;
-    const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x, nthr = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     const uintptr_t addr = reinterpret_cast<uintptr_t>(src);
     uint64_t head = ((16u - (addr & 15u)) & 15u) / kEsz;
     if ((addr & (kEsz - 1u)) != 0u || head > n) head = n;            // (a source that is not even element-aligned: all scalar)
     const uint64_t nvec = (n - head) / kPer;
-    uint32_t m = 0;                                                  // fp32: |x| bits; fp16: |x| half bits (converted at the end)
+    uint32_t m = 0;
     auto one = [&](uint64_t p) {
         if (F32) { const uint32_t a = static_cast<const uint32_t*>(src)[p] & 0x7FFFFFFFu; if (a <= 0x7F800000u) m = umax(m, a); }
         else     { const uint32_t a = static_cast<const uint16_t*>(src)[p] & 0x7FFFu;     if (a <= 0x7C00u) m = umax(m, a); }
@@ -87,15 +89,23 @@ __global__ __launch_bounds__(1024) void k_tc_absmax(const void* __restrict__ src
             }
         }
     };
+    auto ld = [&](const u32x4* p) { return NT ? __builtin_nontemporal_load(p) : *p; };
     // four 16-byte loads in flight per lane (the pass is a pure read: it ran at 5.7 TB/s with one, the chip reads at 7)
     uint64_t v = tid;
     for (; v + 3u * nthr < nvec; v += 4u * nthr) {
-        const u32x4 x0 = __builtin_nontemporal_load(vsrc + v), x1 = __builtin_nontemporal_load(vsrc + v + nthr);
-        const u32x4 x2 = __builtin_nontemporal_load(vsrc + v + 2u * nthr), x3 = __builtin_nontemporal_load(vsrc + v + 3u * nthr);
+        const u32x4 x0 = ld(vsrc + v), x1 = ld(vsrc + v + nthr);
+        const u32x4 x2 = ld(vsrc + v + 2u * nthr), x3 = ld(vsrc + v + 3u * nthr);
         take(x0); take(x1); take(x2); take(x3);
     }
-    for (; v < nvec; v += nthr) take(__builtin_nontemporal_load(vsrc + v));
+    for (; v < nvec; v += nthr) take(ld(vsrc + v));
     for (uint64_t p = head + nvec * kPer + tid; p < n; p += nthr) one(p);
+    return m;
+}
+template <bool F32>
+__global__ __launch_bounds__(1024) void k_tc_absmax(const void* __restrict__ src, uint64_t n, uint32_t* __restrict__ out_bits)
+{
+    const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x, nthr = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    uint32_t m = tc_absmax_thread<F32, true>(src, n, tid, nthr);
     // one atomic per workgroup of 1024 threads, one workgroup per CU: same-address atomics take ~12 ns each one after the other
     // (16 384 of them, one per wave of a 4096-block grid, 190 us by themselves; 1024, one per 256-thread workgroup, still 12 of
     // the kernel's 22 us)
@@ -1268,27 +1278,30 @@ __device__ __forceinline__ uint64_t tc_look_back(const uint64_t* status, uint64_
 
 // (amdgpu_waves_per_eu: with the out-of-line SPLIT tile path in it the kernel ran a quarter slower on tensors that never call it
 //  -- same instructions, other registers -- until the compiler was told to aim at 8 waves per SIMD: two workgroups per CU)
-template <int MODE, bool F32>
-__global__ __launch_bounds__(64 * kTfWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tc_fused(const void* __restrict__ src, uint64_t n, const uint32_t* __restrict__ absmax_bits,
-                                                            uint64_t n_tiles, uint64_t* __restrict__ w1, uint64_t* __restrict__ w2,
-                                                            uint32_t* __restrict__ ticket, uint8_t* __restrict__ out,
-                                                            float* __restrict__ out_scale, uint64_t* __restrict__ out_bytes, uint32_t no_split)
+// BATCH (speckv_ext_codec_compress_tensors: many tensors per launch, ONE workgroup per tensor): the workgroup walks its tensor in
+// rounds of kTfWaves tiles, and what enters a round from the left is what the previous round left in LDS -- no status words, no
+// look-back, no ticket: thousands of independent chains of a few rounds each instead of one chain over the whole launch.
+template <int MODE, bool F32, bool BATCH>
+__device__ __forceinline__ void tc_fused_body(const void* __restrict__ src, uint64_t n, float scale, uint64_t n_tiles, uint64_t wg0,
+                                              uint64_t* __restrict__ w1, uint64_t* __restrict__ w2, uint8_t* __restrict__ out,
+                                              float* __restrict__ out_scale, uint64_t* __restrict__ out_bytes, uint32_t no_split)
 {
     constexpr uint32_t kSlot = kTcLead + 2 * kTile + 16;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kTfWaves * kSlot];
-    __shared__ uint32_t s_ticket;
     __shared__ uint64_t s_ss[kTfWaves];                                  // last stretch start of the tile (absolute + 1, 0 = none)
     __shared__ uint32_t s_runs[kTfWaves];
     __shared__ uint64_t s_ss_in, s_run_base;
+    __shared__ uint64_t s_carry_ss, s_carry_runs;                       // BATCH: the two chains across the rounds of the workgroup
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0u) s_ticket = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const uint64_t wg = s_ticket;
+    if (BATCH && threadIdx.x == 0u) { s_carry_ss = 0ull; s_carry_runs = 0ull; }      // (published by the first barrier of round 0)
+    const uint64_t n_rounds = BATCH ? (n_tiles + kTfWaves - 1u) / kTfWaves : 1u;
+#pragma unroll 1
+    for (uint64_t round = 0; round < n_rounds; ++round) {
+    const uint64_t wg = BATCH ? round : wg0;
     const uint64_t tile = wg * kTfWaves + wave;
     const bool valid = tile < n_tiles;                                  // (waves behind the last tile only keep the barriers company)
     const uint64_t t0 = tile * kTile;
     const uint32_t len = valid ? static_cast<uint32_t>((n - t0 < kTile) ? (n - t0) : kTile) : 0u;
-    const float scale = tc_scale(*absmax_bits);
     if (tile == 0u && lane == 0u) *out_scale = scale;
     // the two elements in front of the tile give q[t0-1] and d[t0-1]
     uint32_t qtail0 = 0, dtail0 = 0;
@@ -1369,11 +1382,13 @@ __global__ __launch_bounds__(64 * kTfWaves) __attribute__((amdgpu_waves_per_eu(8
     if (wave == 0u) {
         uint64_t mine = 0;
         for (uint32_t i = 0; i < kTfWaves; ++i) mine = s_ss[i] ? s_ss[i] : mine;       // (ascending positions: the last one that has any)
-        if (lane == 0u && wg != 0u) tc_lb_store(w1 + wg, mine ? 2ull : 1ull, mine);
+        if (!BATCH && lane == 0u && wg != 0u) tc_lb_store(w1 + wg, mine ? 2ull : 1ull, mine);
         uint64_t in = 0;
-        if (wg != 0u) in = tc_look_back<false>(w1, wg, lane);
+        if (BATCH) in = s_carry_ss;
+        else if (wg != 0u) in = tc_look_back<false>(w1, wg, lane);
         if (lane == 0u) {
-            if (wg == 0u) tc_lb_store(w1, 2ull, mine);                   // (tile 0 always has position 0)
+            if (BATCH) s_carry_ss = mine ? mine : in;
+            else if (wg == 0u) tc_lb_store(w1, 2ull, mine);              // (tile 0 always has position 0)
             else if (!mine) tc_lb_store(w1 + wg, 2ull, in);
             s_ss_in = in;
         }
@@ -1407,7 +1422,8 @@ __global__ __launch_bounds__(64 * kTfWaves) __attribute__((amdgpu_waves_per_eu(8
         uint32_t total = 0;
         for (uint32_t i = 0; i < kTfWaves; ++i) total += s_runs[i];
         uint64_t base = 0;
-        if (wg == 0u) { if (lane == 0u) tc_lb_store(w2, 2ull, total); }
+        if (BATCH) { base = s_carry_runs; if (lane == 0u) s_carry_runs = base + total; }
+        else if (wg == 0u) { if (lane == 0u) tc_lb_store(w2, 2ull, total); }
         else {
             if (lane == 0u) tc_lb_store(w2 + wg, 1ull, total);
             base = tc_look_back<true>(w2, wg, lane);
@@ -1416,7 +1432,7 @@ __global__ __launch_bounds__(64 * kTfWaves) __attribute__((amdgpu_waves_per_eu(8
         if (lane == 0u) s_run_base = base;
     }
     __syncthreads();
-    if (!valid) return;                                                 // (no barrier behind this point)
+    if (!valid) continue;                                               // (no barrier behind this point in the round)
     uint64_t run_base = s_run_base;
     for (uint32_t i = 0; i < wave; ++i) run_base += s_runs[i];
     // ---- count bytes at the seams.  The byte in front of this tile's pairs closes the last pair of its left neighbours: it ends
@@ -1442,7 +1458,7 @@ __global__ __launch_bounds__(64 * kTfWaves) __attribute__((amdgpu_waves_per_eu(8
     const bool lead_out = run_base != 0u && (n_runs != 0u || is_last);
     const uint64_t g_begin = 2u * run_base - (lead_out ? 1u : 0u);
     const uint64_t g_end = 2u * (run_base + n_runs) - ((is_last || n_runs == 0u) ? 0u : 1u);
-    if (g_end <= g_begin) return;
+    if (g_end <= g_begin) continue;
     const uint32_t l_begin = kTcLead - (lead_out ? 1u : 0u);             // LDS offset (in wl) of the byte that goes to g_begin
     const uintptr_t gaddr = reinterpret_cast<uintptr_t>(out) + g_begin, gend = reinterpret_cast<uintptr_t>(out) + g_end;
     const uintptr_t a0 = gaddr & ~static_cast<uintptr_t>(15);
@@ -1482,6 +1498,47 @@ __global__ __launch_bounds__(64 * kTfWaves) __attribute__((amdgpu_waves_per_eu(8
             }
         }
     }
+    }   // rounds
+}
+
+// (amdgpu_waves_per_eu: see above.)  One tensor: ticket order, chains through status words.
+template <int MODE, bool F32>
+__global__ __launch_bounds__(64 * kTfWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tc_fused(const void* __restrict__ src, uint64_t n, const uint32_t* __restrict__ absmax_bits,
+                                                            uint64_t n_tiles, uint64_t* __restrict__ w1, uint64_t* __restrict__ w2,
+                                                            uint32_t* __restrict__ ticket, uint8_t* __restrict__ out,
+                                                            float* __restrict__ out_scale, uint64_t* __restrict__ out_bytes, uint32_t no_split)
+{
+    __shared__ uint32_t s_ticket;
+    if (threadIdx.x == 0u) s_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    tc_fused_body<MODE, F32, false>(src, n, tc_scale(*absmax_bits), n_tiles, s_ticket, w1, w2, out, out_scale, out_bytes, no_split);
+}
+
+// Many tensors, one workgroup each (speckv_ext_codec_compress_tensors; the reference's compress(data, n) is called per KV tile --
+// cache_engine.cpp:40-82, RTL tile 1024 x 128 = 131 072 elements, hardware/rtl/kv_compress.v:5-11 -- and at that size the
+// single-tensor launch pair is all fixed cost: 64 tiles = 4 workgroups and two launches).  The workgroup finds its tensor's
+// max|x| itself (first pass over the source, default cache policy), then encodes it in rounds (second pass: the same bytes out of
+// the L2 / Infinity Cache, so the HBM sees the source once).  Any length works; a tensor is walked by ONE workgroup, so tensors of
+// many millions of elements belong to speckv_ext_codec_compress_tensor.
+struct TcbDesc { void* data; uint64_t n; uint8_t* rle; uint64_t rle_cap; };        // = speckv_ext_tensor_t (include/speckv_ext.h)
+template <int MODE, bool F32>
+__global__ __launch_bounds__(64 * kTfWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tcb_fused(const TcbDesc* __restrict__ desc, float* __restrict__ out_scale,
+                                                            uint64_t* __restrict__ out_bytes, uint32_t no_split)
+{
+    __shared__ uint32_t s_am[kTfWaves];
+    const TcbDesc d = desc[blockIdx.x];
+    out_scale += blockIdx.x; out_bytes += blockIdx.x;
+    if (d.n == 0u) {                                                     // compress(data, 0): an empty stream, scale 1 (cache_engine.cpp:172-183)
+        if (threadIdx.x == 0u) { *out_bytes = 0ull; *out_scale = 1.0f; }
+        return;
+    }
+    uint32_t m = lane63(wave_incl_max(tc_absmax_thread<F32, false>(d.data, d.n, threadIdx.x, 64u * kTfWaves)));
+    if ((threadIdx.x & 63u) == 0u) s_am[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = 0;
+    for (uint32_t w = 0; w < kTfWaves; ++w) m = umax(m, s_am[w]);
+    if (!F32) m = __float_as_uint(half_bits_to_float(m));
+    tc_fused_body<MODE, F32, true>(d.data, d.n, tc_scale(m), (d.n + kTile - 1u) / kTile, 0ull, nullptr, nullptr, d.rle, out_scale, out_bytes, no_split);
 }
 
 // ---------------------------------------------------------------- decompress in ONE pass over the stream
@@ -1829,21 +1886,25 @@ __device__ __noinline__ void td_windows_behind_the_first(const uint8_t* __restri
     }
 }
 
-template <int MODE, bool F32>
-__global__ __launch_bounds__(64 * kTdfWaves) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k_td_fused(const uint8_t* __restrict__ rle, uint64_t n_pairs, uint64_t n_chunks, uint64_t* __restrict__ status, uint32_t* __restrict__ ticket,
-                uint64_t cap, uint64_t* __restrict__ out_n, float scale, uint8_t* __restrict__ dst)
+// BATCH (speckv_ext_codec_decompress_tensors): one workgroup per stream, rounds of kTdfChunks chunks, the prefix in front of a
+// round carried in LDS (see tc_fused_body).
+template <int MODE, bool F32, bool BATCH>
+__device__ __forceinline__ void td_fused_body(const uint8_t* __restrict__ rle, uint64_t n_pairs, uint64_t n_chunks, uint64_t wg0, uint64_t* __restrict__ status,
+                                              uint64_t cap, uint64_t* __restrict__ out_n, float scale, uint8_t* __restrict__ dst)
 {
     constexpr uint32_t kFront = 16;           // bytes in front of a wave's table (the store pass may read up to 7 of them: never used)
     __shared__ __attribute__((aligned(16))) uint8_t tabs[kTdfWaves][kFront + kTdfWin + 16];      // (+16 behind: written, never used)
-    __shared__ uint32_t s_ticket;
     __shared__ uint32_t s_tot[kTdfWaves];
     __shared__ uint64_t s_start[kTdfWaves];
     __shared__ uint32_t s_qp[kTdfWaves];
+    __shared__ uint64_t s_carry_before;                                 // BATCH: elements / int8 prefix in front of the round
+    __shared__ uint32_t s_carry_q;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0u) s_ticket = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const uint64_t wg = s_ticket;
+    if (BATCH && threadIdx.x == 0u) { s_carry_before = 0ull; s_carry_q = 0u; }       // (published by the first barrier of round 0)
+    const uint64_t n_rounds = BATCH ? (n_chunks + kTdfChunks - 1u) / kTdfChunks : 1u;
+#pragma unroll 1
+    for (uint64_t round = 0; round < n_rounds; ++round) {
+    const uint64_t wg = BATCH ? round : wg0;
     const uint64_t chunk = wg * kTdfChunks + wave - kTdfLbWave;
     const bool live = wave >= kTdfLbWave && chunk < n_chunks;           // (waves behind the last chunk only keep the barriers company)
     const uint64_t p0 = chunk * kTile;
@@ -1859,7 +1920,7 @@ void k_td_fused(const uint8_t* __restrict__ rle, uint64_t n_pairs, uint64_t n_ch
     if (wave == 0u) {
         const uint32_t wt = lane < kTdfWaves ? s_tot[lane] : 0u;
         const uint32_t agg_c = lane63(wave_incl_add(wt & 0xFFFFFFu)), agg_v = lane63(wave_incl_add(wt >> 24)) & 0xFFu;      // < 2^24 x 16
-        if (lane == 0u) tc_lb_store(status + wg, wg == 0u ? 2ull : 1ull, (static_cast<uint64_t>(agg_v) << 54) | agg_c);
+        if (!BATCH && lane == 0u) tc_lb_store(status + wg, wg == 0u ? 2ull : 1ull, (static_cast<uint64_t>(agg_v) << 54) | agg_c);
     }
     // ---- the first window's values: nothing in them needs the look-back, which they therefore hide
     uint8_t* tab = tabs[wave] + kFront;
@@ -1872,7 +1933,10 @@ void k_td_fused(const uint8_t* __restrict__ rle, uint64_t n_pairs, uint64_t n_ch
         const uint32_t agg_c = lane63(wic), agg_v = lane63(wiv) & 0xFFu;
         uint64_t before = 0;
         uint32_t qb = 0;
-        if (wg != 0u) {
+        if (BATCH) {
+            before = s_carry_before; qb = s_carry_q;
+            if (lane == 0u) { s_carry_before = before + agg_c; s_carry_q = (qb + agg_v) & 0xFFu; }
+        } else if (wg != 0u) {
 #ifdef SPECKV_TD_NO_LB
             before = wg * kTdfChunks * 2048ull;                         // (timing builds only: wrong output)
 #else
@@ -1888,14 +1952,41 @@ void k_td_fused(const uint8_t* __restrict__ rle, uint64_t n_pairs, uint64_t n_ch
         if (lane == 0u && (wg + 1u) * kTdfChunks >= n_chunks) { const uint64_t total = before + agg_c; *out_n = total < cap ? total : cap; }
     }
     __syncthreads();
-    if (!live) return;
+    if (!live) continue;
     const uint64_t start = s_start[wave];
     const uint32_t qp = s_qp[wave];
     const uint64_t end = (start + tot_c < cap) ? start + tot_c : cap;
-    if (start >= end) return;
-    if (has_zero) { td_chunk_general<MODE, F32>(rle, p0, n_pairs, start, end, qp, scale, dst, lane); return; }
+    if (start >= end) continue;
+    if (has_zero) { td_chunk_general<MODE, F32>(rle, p0, n_pairs, start, end, qp, scale, dst, lane); continue; }
     td_window_store<MODE, F32>(tab, 0u, start, end, qp, scale, dst, lane);
     if (start + kTdfWin < end) td_windows_behind_the_first<MODE, F32>(rle, p0, n_pairs, start, end, qp, tot_c, c1, c2, tab, scale, dst, lane);
+    }   // rounds
+}
+
+template <int MODE, bool F32>
+__global__ __launch_bounds__(64 * kTdfWaves) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_td_fused(const uint8_t* __restrict__ rle, uint64_t n_pairs, uint64_t n_chunks, uint64_t* __restrict__ status, uint32_t* __restrict__ ticket,
+                uint64_t cap, uint64_t* __restrict__ out_n, float scale, uint8_t* __restrict__ dst)
+{
+    __shared__ uint32_t s_ticket;
+    if (threadIdx.x == 0u) s_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    td_fused_body<MODE, F32, false>(rle, n_pairs, n_chunks, s_ticket, status, cap, out_n, scale, dst);
+}
+
+// Many streams, one workgroup each (speckv_ext_codec_decompress_tensors): stream i = desc[i].rle, rle_bytes[i] bytes, scale
+// scales[i], decoded into desc[i].data (room for desc[i].n elements); n_out[i] = elements the stream holds, clipped to the room.
+template <int MODE, bool F32>
+__global__ __launch_bounds__(64 * kTdfWaves) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_tdb_fused(const TcbDesc* __restrict__ desc, const uint64_t* __restrict__ rle_bytes, const float* __restrict__ scales, uint64_t* __restrict__ n_out)
+{
+    __shared__ uint64_t s_none;
+    const TcbDesc d = desc[blockIdx.x];
+    const uint64_t n_pairs = rle_bytes[blockIdx.x] >> 1;                 // an odd trailing byte is dropped (cache_engine.cpp:245)
+    const uint64_t chunks = (n_pairs + kTile - 1u) / kTile;
+    uint64_t* on = n_out ? n_out + blockIdx.x : &s_none;
+    if (chunks == 0u || d.n == 0u) { if (threadIdx.x == 0u) *on = 0ull; return; }
+    td_fused_body<MODE, F32, true>(d.rle, n_pairs, chunks, 0ull, nullptr, d.n, on, scales[blockIdx.x], static_cast<uint8_t*>(d.data));
 }
 
 // ---------------------------------------------------------------- output-centric expand with the run scatter (multi-launch form)
@@ -2218,6 +2309,32 @@ hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, u
     }
 #undef SPECKV_TC2
 #undef SPECKV_TC
+    return hipGetLastError();
+}
+
+// One workgroup per tensor, no workspace: d_desc[i] = {source, elements, stream, room} (device array, kernels.hpp TensorDesc)
+hipError_t launch_tensors_compress(uint32_t n_tensors, const TensorDesc* d_desc, bool src_f32, uint64_t* d_rle_bytes, float* d_scales, int quant_mode, hipStream_t s)
+{
+    static_assert(sizeof(TcbDesc) == sizeof(TensorDesc) && sizeof(TensorDesc) == 32, "descriptor layout");
+    if (n_tensors == 0) return hipSuccess;
+    const uint32_t no_split = tuning().tc_no_split_tiles ? 1u : 0u;
+    const TcbDesc* dd = reinterpret_cast<const TcbDesc*>(d_desc);
+#define SPECKV_TCB(MODE, F32) hipLaunchKernelGGL((k_tcb_fused<MODE, F32>), dim3(n_tensors), dim3(64 * kTfWaves), 0, s, dd, d_scales, d_rle_bytes, no_split)
+    if (quant_mode == kIntent) { if (src_f32) SPECKV_TCB(kIntent, true); else SPECKV_TCB(kIntent, false); }
+    else                       { if (src_f32) SPECKV_TCB(kRefExact, true); else SPECKV_TCB(kRefExact, false); }
+#undef SPECKV_TCB
+    return hipGetLastError();
+}
+
+hipError_t launch_tensors_decompress(uint32_t n_tensors, const TensorDesc* d_desc, const uint64_t* d_rle_bytes, const float* d_scales, bool out_f32,
+                                     uint64_t* d_n_out, int quant_mode, hipStream_t s)
+{
+    if (n_tensors == 0) return hipSuccess;
+    const TcbDesc* dd = reinterpret_cast<const TcbDesc*>(d_desc);
+#define SPECKV_TDB(MODE, F32) hipLaunchKernelGGL((k_tdb_fused<MODE, F32>), dim3(n_tensors), dim3(64 * kTdfWaves), 0, s, dd, d_rle_bytes, d_scales, d_n_out)
+    if (quant_mode == kIntent) { if (out_f32) SPECKV_TDB(kIntent, true); else SPECKV_TDB(kIntent, false); }
+    else                       { if (out_f32) SPECKV_TDB(kRefExact, true); else SPECKV_TDB(kRefExact, false); }
+#undef SPECKV_TDB
     return hipGetLastError();
 }
 

@@ -257,6 +257,32 @@ speckv_status_t speckv_ext_codec_decompress_tensor(const void* d_rle, uint64_t r
                                                    uint64_t dst_cap_elems, int out_f32, uint64_t* d_n_out,
                                                    void* d_workspace, size_t workspace_bytes, int quant_mode, void* stream);
 
+/* The same codec over MANY tensors per launch (round 6).  The reference calls FPGACacheEngine::compress(data, n) once per KV tile
+ * (cache_engine.cpp:40-82; the RTL's tile is 1024 x 128 = 131 072 elements, hardware/rtl/kv_compress.v:5-11): at that size one
+ * tensor is 64 tiles of work and the single-tensor entry point above is all fixed cost (two launches, a look-back chain that has
+ * barely started when it ends).  Here ONE workgroup takes one tensor -- its own scale (it finds max|x| itself; the second pass
+ * over the source comes out of the L2 / Infinity Cache), its own delta chain, its own run-length stream, carried from round to
+ * round in LDS -- and one launch takes thousands of them; no workspace.  Streams and scales are bit-identical to the
+ * single-tensor entry point's and to the reference's, per tensor.  Any length works, but a tensor is walked by one workgroup:
+ * tensors of many millions of elements belong to speckv_ext_codec_compress_tensor.
+ *   d_tensors  DEVICE array of n_tensors descriptors
+ *   compress:   data = the source (fp16, or fp32 with src_f32), n = its elements, rle = where the stream goes (16-byte aligned),
+ *               rle_cap >= 2 n rounded up to 16 (not checked); d_rle_bytes[i] / d_scales[i] receive the stream length / the scale
+ *   decompress: data = the destination (16-byte aligned; fp16, or fp32 with out_f32), n = its room in elements, rle = the stream,
+ *               d_rle_bytes[i] / d_scales[i] as compress left them; d_n_out[i] (may be NULL) = elements decoded, clipped to the room
+ * Asynchronous on `stream`; no engine needed. */
+typedef struct {
+    void*    data;
+    uint64_t n;
+    void*    rle;
+    uint64_t rle_cap;
+} speckv_ext_tensor_t;       /* 32 bytes */
+speckv_status_t speckv_ext_codec_compress_tensors(uint32_t n_tensors, const speckv_ext_tensor_t* d_tensors, int src_f32,
+                                                  uint64_t* d_rle_bytes, float* d_scales, int quant_mode, void* stream);
+speckv_status_t speckv_ext_codec_decompress_tensors(uint32_t n_tensors, const speckv_ext_tensor_t* d_tensors,
+                                                    const uint64_t* d_rle_bytes, const float* d_scales, int out_f32,
+                                                    uint64_t* d_n_out, int quant_mode, void* stream);
+
 /* ---- 4:1 / 2:1 formats + fused dequant-matvec (BASELINE config 5; SURVEY 8a row
  *      A22: no reference counterpart, parity is against oracle/ only) -----------
  * SPECKV_COMP_INT4_G32: record 1152 B = 64 fp16 group scales + 2048 nibbles.

@@ -774,3 +774,125 @@ def test_engine_picks_the_flat_run_decoder_by_itself(oracle):
         assert seen == {"flat": 2, "noise": 0}, seen
     finally:
         lib.finalize()
+
+
+# ---- many tensors per launch, one workgroup per tensor (speckv_ext_codec_compress_tensors / _decompress_tensors, round 6) ----
+def gpu_codec_tensors(lib, xs, mode=0, out_f32=True, misalign=0, room_extra=3):
+    """xs: list of 1-d numpy arrays of ONE dtype (float32 or float16), any lengths.  One compress launch and one decompress launch over
+    all of them.  Returns [(scale f32, rle bytes, decoded)] per tensor."""
+    import ctypes as C
+    torch = torch_mod()
+    f32 = xs[0].dtype == np.float32
+    esz = 4 if f32 else 2
+    lib.speckv_ext_codec_compress_tensors.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.speckv_ext_codec_decompress_tensors.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    nt = len(xs)
+    # sources back to back (each start 16-byte aligned + `misalign` elements), streams and outputs 16-byte aligned with guard bytes between
+    src_off, rle_off, out_off = [], [], []
+    so = ro = oo = 0
+    osz = 4 if out_f32 else 2
+    for x in xs:
+        so = (so + 15) // 16 * 16 + misalign * esz; src_off.append(so); so += x.size * esz
+        ro = (ro + 15) // 16 * 16; rle_off.append(ro); ro += (2 * x.size + 15) // 16 * 16 + 16
+        oo = (oo + 15) // 16 * 16; out_off.append(oo); oo += (x.size + room_extra) * osz + 32
+    h_src = np.zeros(so + 16, np.uint8)
+    for x, o in zip(xs, src_off):
+        h_src[o:o + x.size * esz] = np.ascontiguousarray(x).view(np.uint8)
+    d_src = torch.from_numpy(h_src).cuda()
+    d_rle = torch.full((ro + 16,), 0xA5, dtype=torch.uint8, device="cuda")
+    d_out = torch.full((oo + 16,), 0xFF, dtype=torch.uint8, device="cuda")                  # (0xFFFF / 0xFFFFFFFF: NaN patterns)
+    desc_c = np.zeros((nt, 4), np.uint64); desc_d = np.zeros((nt, 4), np.uint64)
+    for i, x in enumerate(xs):
+        desc_c[i] = (d_src.data_ptr() + src_off[i], x.size, d_rle.data_ptr() + rle_off[i], (2 * x.size + 15) // 16 * 16)
+        desc_d[i] = (d_out.data_ptr() + out_off[i], x.size + room_extra, d_rle.data_ptr() + rle_off[i], 0)
+    d_desc_c = torch.from_numpy(desc_c.view(np.int64)).cuda(); d_desc_d = torch.from_numpy(desc_d.view(np.int64)).cuda()
+    d_bytes = torch.full((nt,), -1, dtype=torch.int64, device="cuda")
+    d_scales = torch.full((nt,), float("nan"), dtype=torch.float32, device="cuda")
+    d_nout = torch.full((nt,), -1, dtype=torch.int64, device="cuda")
+    assert lib.speckv_ext_codec_compress_tensors(nt, d_desc_c.data_ptr(), int(f32), d_bytes.data_ptr(), d_scales.data_ptr(), mode, stream_ptr()) == 0
+    assert lib.speckv_ext_codec_decompress_tensors(nt, d_desc_d.data_ptr(), d_bytes.data_ptr(), d_scales.data_ptr(), int(out_f32), d_nout.data_ptr(), mode, stream_ptr()) == 0
+    torch.cuda.synchronize()
+    sizes, scales, nout = d_bytes.cpu().numpy(), d_scales.cpu().numpy(), d_nout.cpu().numpy()
+    rle, out = d_rle.cpu().numpy(), d_out.cpu().numpy()
+    res = []
+    for i, x in enumerate(xs):
+        assert 0 <= sizes[i] <= 2 * x.size, (i, sizes[i])
+        r = rle[rle_off[i]:rle_off[i] + sizes[i]].copy()
+        guard = rle[rle_off[i] + (2 * x.size + 15) // 16 * 16:rle_off[i] + (2 * x.size + 15) // 16 * 16 + 16]
+        assert (guard == 0xA5).all(), f"tensor {i}: its stream ran over its room"
+        assert nout[i] == x.size, (i, nout[i], x.size)
+        y = out[out_off[i]:out_off[i] + x.size * osz].view(np.float32 if out_f32 else np.float16).copy()
+        behind = out[out_off[i] + x.size * osz:out_off[i] + (x.size + room_extra) * osz + 32]
+        assert (behind == 0xFF).all(), f"tensor {i}: something was written behind its last element"
+        res.append((np.float32(scales[i]), r, y))
+    return res
+
+
+def test_tensors_batch_golden_reference_vectors(lib, golden_dir):
+    """Every reference-generated codec vector as ONE batched launch each way (kat n = 11 beside short_257 beside the 2048-element blocks
+    beside the 131 072-element `big` -- the reference's own call size): per tensor the stream's bytes, the scale's bits and every
+    decoded fp32 bit are the reference's."""
+    g = np.load(os.path.join(golden_dir, "codec_vectors.npz"))
+    names = [k[:-2] for k in g.files if k.endswith(".x")]
+    xs = [g[f"{nm}.x"].astype(np.float32) for nm in names]
+    n_big = int(g["big.n"][0])
+    xs.append(np.random.default_rng(int(g["big.seed"][0])).standard_normal(n_big).astype(np.float32))
+    res = gpu_codec_tensors(lib, xs, 0, True)
+    for nm, (scale, rle, y) in zip(names, res):
+        assert scale.tobytes() == g[f"{nm}.scale"][0].tobytes(), nm
+        assert rle.tobytes() == g[f"{nm}.rle"].tobytes(), nm
+        assert_same_float_bits(y, g[f"{nm}.y"], nm)
+    scale, rle, y = res[-1]
+    assert scale.tobytes() == g["big.scale"][0].tobytes() and rle.size == int(g["big.compressed_size"][0])
+    assert int(np.bitwise_xor.reduce(rle.astype(np.uint64) * (np.arange(rle.size, dtype=np.uint64) % 251 + 1))) == int(g["big.rle_crc"][0])
+    assert int(y.view(np.uint32).astype(np.uint64).sum()) == int(g["big.y_sum_bits"][0])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_tensors_batch_matches_oracle_over_sizes_and_structures(lib, oracle, dtype):
+    """The batched form against the oracle, per tensor: lengths 0, 1, below / at / just over a tile, a round (16 tiles) and several
+    rounds with ragged ends; noise, long flat stretches that cross tiles and rounds (255-splits, the delta chain and both carried
+    chains), all zeros, inf / NaN; both quantiser modes; sources off their 16-byte alignment; fp16 and fp32 outputs."""
+    rng = np.random.default_rng(61 if dtype == np.float32 else 62)
+    lens = [0, 1, 7, 2047, 2048, 2049, 5000, 16 * 2048 - 1, 16 * 2048, 16 * 2048 + 1, 131072, 131072 + 77, 3 * 32768 + 2048 * 5 + 3, 300001]
+    xs = []
+    for n in lens:
+        x = rng.standard_normal(n).astype(np.float32)
+        for _ in range(3 if n > 2048 else 0):
+            a = int(rng.integers(0, n)); b = min(n, a + int(rng.integers(1, max(2, n))))
+            x[a:b] = np.float32(rng.standard_normal())
+        xs.append(x.astype(dtype))
+    xs.append(np.zeros(40000, dtype))                                              # all zeros: scale 1, one run per 255
+    z = rng.standard_normal(70000).astype(dtype); z[5] = np.inf; z[40000] = np.nan; z[69999] = -np.inf
+    xs.append(z)
+    xs.append(np.repeat(rng.standard_normal(300).astype(dtype), 700))              # runs of 700: every one split at 255, across tiles and rounds
+    for mode in MODES:
+        for misalign, out_f32 in ((0, True), (3, False)):
+            res = gpu_codec_tensors(lib, xs, mode, out_f32, misalign)
+            for i, (x, (scale, rle, y)) in enumerate(zip(xs, res)):
+                o_scale, o_rle = oracle.compress_f32(x.astype(np.float32), mode)
+                assert np.float32(scale).tobytes() == np.float32(o_scale).tobytes(), (i, x.size, mode, misalign)
+                assert rle.tobytes() == o_rle.tobytes(), (i, x.size, mode, misalign)
+                want = oracle.decompress_f32(o_rle, o_scale, mode)
+                if out_f32:
+                    assert_same_float_bits(y, want, f"tensor {i} n={x.size} mode={mode}")
+                else:
+                    assert_same_float_bits(y, want.astype(np.float16), f"tensor {i} n={x.size} mode={mode} fp16 out")
+
+
+def test_tensors_batch_equals_the_single_tensor_entry_point(lib):
+    """4 x 64 tensors of 131 072 elements (the reference's call size) in one launch: every stream equals the one the single-tensor
+    entry point produces for the same tensor (which the tests above pin to the oracle and the reference)."""
+    rng = np.random.default_rng(63)
+    base = [rng.standard_normal(131072).astype(np.float32) * np.float32(rng.uniform(0.1, 30)) for _ in range(4)]
+    xs = [base[i % 4] if i % 8 < 4 else np.roll(base[i % 4], i) for i in range(256)]
+    res = gpu_codec_tensors(lib, xs, 0, True)
+    single = {}
+    for i in (0, 1, 2, 3, 5, 130, 255):
+        scale, rle = gpu_compress_tensor(lib, xs[i], 0)
+        assert res[i][0].tobytes() == scale.tobytes() and res[i][1].tobytes() == rle.tobytes(), i
+        y = gpu_decompress_tensor(lib, rle, scale, xs[i].size, 0, True)
+        assert_same_float_bits(res[i][2], y, f"tensor {i}")
+    for i in range(256):                                                            # the same tensor always gives the same stream
+        if i % 8 < 4:
+            assert res[i][1].tobytes() == res[i % 4][1].tobytes(), i
