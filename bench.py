@@ -1478,8 +1478,12 @@ def tensor_codec_batch_extra(torch, lib, n_tensors=4096, n=131072):
     import ctypes as C
     try:
         raw = lib.lib
-        raw.speckv_ext_codec_compress_tensors.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
-        raw.speckv_ext_codec_decompress_tensors.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        raw.speckv_ext_codec_tensors_workspace_bytes.argtypes = [C.c_uint32, C.c_uint64]; raw.speckv_ext_codec_tensors_workspace_bytes.restype = C.c_size_t
+        raw.speckv_ext_codec_compress_tensors.argtypes = [C.c_uint32, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        raw.speckv_ext_codec_decompress_tensors.argtypes = [C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        ws_bytes = int(raw.speckv_ext_codec_tensors_workspace_bytes(n_tensors, n))
+        ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device="cuda")
+        wsp = (ws.data_ptr() + 255) & ~255
         g = torch.Generator(device="cuda"); g.manual_seed(2007)
         x32 = torch.randn((n_tensors, n), generator=g, device="cuda", dtype=torch.float32)
         x32 *= torch.rand((n_tensors, 1), generator=g, device="cuda") * 4 + 0.25          # every tensor its own scale
@@ -1505,8 +1509,8 @@ def tensor_codec_batch_extra(torch, lib, n_tensors=4096, n=131072):
             if not f32:
                 dst = torch.empty((n_tensors, n), dtype=torch.float16, device="cuda")
             dc, dd = descs(src, esz), descs(dst, esz)
-            enc = lambda: raw.speckv_ext_codec_compress_tensors(n_tensors, dc.data_ptr(), f32, sizes.data_ptr(), scales.data_ptr(), 0, s.cuda_stream)
-            dec = lambda: raw.speckv_ext_codec_decompress_tensors(n_tensors, dd.data_ptr(), sizes.data_ptr(), scales.data_ptr(), f32, nout.data_ptr(), 0, s.cuda_stream)
+            enc = lambda: raw.speckv_ext_codec_compress_tensors(n_tensors, dc.data_ptr(), n, f32, sizes.data_ptr(), scales.data_ptr(), wsp, ws_bytes, 0, s.cuda_stream)
+            dec = lambda: raw.speckv_ext_codec_decompress_tensors(n_tensors, dd.data_ptr(), n, sizes.data_ptr(), scales.data_ptr(), f32, nout.data_ptr(), wsp, ws_bytes, 0, s.cuda_stream)
             assert enc() == 0 and dec() == 0
             torch.cuda.synchronize()
             comp = int(sizes.sum().item())
@@ -1525,8 +1529,8 @@ def tensor_codec_batch_extra(torch, lib, n_tensors=4096, n=131072):
                                         "frac_hbm": round(byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
             out[f"compressed_bytes_{tag}"] = comp
             del dc, dd
-        out["note"] = ("one workgroup per tensor: max|x| by the workgroup itself (first pass, 512 KiB of fp32 per tensor), then the encode in rounds of 16 tiles "
-                       "(second pass: out of the L2 / Infinity Cache), chains carried in LDS; algorithmic bytes = source once + stream (compress), stream + output (decompress)")
+        out["note"] = ("four workgroups per tensor (16 tiles each): max|x| by a rendezvous of the tensor's workgroups, the chains by look-back over the tensor's own "
+                       "status words, the second read of the source out of the L2 / Infinity Cache; algorithmic bytes = source once + stream (compress), stream + output (decompress)")
         return {"tensor_codec_batched_131072": out}
     except Exception as e:                                               # noqa: BLE001
         return {"tensor_codec_batched_131072": {"error": repr(e)}}

@@ -390,34 +390,41 @@ speckv_status_t speckv_ext_codec_decompress_tensor(const void* d_rle, uint64_t r
     return SPECKV_OK;
 }
 
-// ... and over MANY tensors per launch, one workgroup per tensor (the reference calls compress(data, n) per KV tile: 131 072 elements)
-speckv_status_t speckv_ext_codec_compress_tensors(uint32_t n_tensors, const speckv_ext_tensor_t* d_tensors, int src_f32, uint64_t* d_rle_bytes,
-                                                  float* d_scales, int quant_mode, void* stream)
+// ... and over MANY tensors per launch (the reference calls compress(data, n) per KV tile: 131 072 elements)
+size_t speckv_ext_codec_tensors_workspace_bytes(uint32_t n_tensors, uint64_t max_elems) { return speckv::tensors_workspace_bytes(n_tensors, max_elems); }
+
+speckv_status_t speckv_ext_codec_compress_tensors(uint32_t n_tensors, const speckv_ext_tensor_t* d_tensors, uint64_t max_elems, int src_f32,
+                                                  uint64_t* d_rle_bytes, float* d_scales, void* d_workspace, size_t workspace_bytes, int quant_mode, void* stream)
 {
     static_assert(sizeof(speckv_ext_tensor_t) == sizeof(speckv::TensorDesc), "speckv_ext_tensor_t is the kernels' descriptor");
     if (quant_mode < 0 || quant_mode > 1) return SPECKV_ERR_INVAL;
     if (n_tensors && (!d_tensors || !d_rle_bytes || !d_scales)) return SPECKV_ERR_INVAL;
-    const hipError_t e = speckv::launch_tensors_compress(n_tensors, reinterpret_cast<const speckv::TensorDesc*>(d_tensors), src_f32 != 0, d_rle_bytes, d_scales,
-                                                         quant_mode, static_cast<hipStream_t>(stream));
+    if (n_tensors && (!d_workspace || (reinterpret_cast<uintptr_t>(d_workspace) & 255u) || workspace_bytes < speckv::tensors_workspace_bytes(n_tensors, max_elems)))
+        return SPECKV_ERR_INVAL;
+    const hipError_t e = speckv::launch_tensors_compress(n_tensors, reinterpret_cast<const speckv::TensorDesc*>(d_tensors), max_elems, src_f32 != 0, d_rle_bytes, d_scales,
+                                                         d_workspace, workspace_bytes, quant_mode, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) {
         fprintf(stderr, "[libcxlspeckv] speckv_ext_codec_compress_tensors: %s\n", hipGetErrorString(e));
         (void)hipGetLastError();
-        return SPECKV_ERR_DRIVER;
+        return e == hipErrorInvalidValue ? SPECKV_ERR_INVAL : SPECKV_ERR_DRIVER;
     }
     return SPECKV_OK;
 }
 
-speckv_status_t speckv_ext_codec_decompress_tensors(uint32_t n_tensors, const speckv_ext_tensor_t* d_tensors, const uint64_t* d_rle_bytes,
-                                                    const float* d_scales, int out_f32, uint64_t* d_n_out, int quant_mode, void* stream)
+speckv_status_t speckv_ext_codec_decompress_tensors(uint32_t n_tensors, const speckv_ext_tensor_t* d_tensors, uint64_t max_elems, const uint64_t* d_rle_bytes,
+                                                    const float* d_scales, int out_f32, uint64_t* d_n_out, void* d_workspace, size_t workspace_bytes,
+                                                    int quant_mode, void* stream)
 {
     if (quant_mode < 0 || quant_mode > 1) return SPECKV_ERR_INVAL;
     if (n_tensors && (!d_tensors || !d_rle_bytes || !d_scales)) return SPECKV_ERR_INVAL;
-    const hipError_t e = speckv::launch_tensors_decompress(n_tensors, reinterpret_cast<const speckv::TensorDesc*>(d_tensors), d_rle_bytes, d_scales,
-                                                           out_f32 != 0, d_n_out, quant_mode, static_cast<hipStream_t>(stream));
+    if (n_tensors && (!d_workspace || (reinterpret_cast<uintptr_t>(d_workspace) & 255u) || workspace_bytes < speckv::tensors_workspace_bytes(n_tensors, max_elems)))
+        return SPECKV_ERR_INVAL;
+    const hipError_t e = speckv::launch_tensors_decompress(n_tensors, reinterpret_cast<const speckv::TensorDesc*>(d_tensors), max_elems, d_rle_bytes, d_scales,
+                                                           out_f32 != 0, d_n_out, d_workspace, workspace_bytes, quant_mode, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) {
         fprintf(stderr, "[libcxlspeckv] speckv_ext_codec_decompress_tensors: %s\n", hipGetErrorString(e));
         (void)hipGetLastError();
-        return SPECKV_ERR_DRIVER;
+        return e == hipErrorInvalidValue ? SPECKV_ERR_INVAL : SPECKV_ERR_DRIVER;
     }
     return SPECKV_OK;
 }

@@ -169,13 +169,17 @@ hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, u
 hipError_t launch_tensor_decompress(const uint8_t* d_rle, uint64_t rle_bytes, float scale, void* d_dst, uint64_t dst_cap, bool out_f32,
                                     uint64_t* d_n_out, void* d_ws, size_t ws_bytes, int quant_mode, hipStream_t s);
 
-// The same over MANY tensors in one launch each way, one workgroup per tensor, no workspace (tensor_codec.hip: k_tcb_fused /
-// k_tdb_fused).  TensorDesc = speckv_ext_tensor_t: {data (compress: the source; decompress: the destination), n (elements;
-// decompress: room), rle (the stream, 16-byte aligned), rle_cap}.
+// The same over MANY tensors in one launch each way (tensor_codec.hip: k_tcm_fused / k_tdm_fused -- several workgroups per tensor,
+// tensor-local look-back, max|x| by rendezvous; tensors of at most 16 tiles: k_tcb_fused / k_tdb_fused, one workgroup each).
+// TensorDesc = speckv_ext_tensor_t: {data (compress: the source; decompress: the destination), n (elements; decompress: room),
+// rle (the stream, 16-byte aligned), rle_cap}.  max_elems: the host's bound on n (sizes the grid); d_ws: 256-byte aligned,
+// tensors_workspace_bytes(n_tensors, max_elems) bytes.
 struct TensorDesc { void* data; uint64_t n; uint8_t* rle; uint64_t rle_cap; };
-hipError_t launch_tensors_compress(uint32_t n_tensors, const TensorDesc* d_desc, bool src_f32, uint64_t* d_rle_bytes, float* d_scales, int quant_mode, hipStream_t s);
-hipError_t launch_tensors_decompress(uint32_t n_tensors, const TensorDesc* d_desc, const uint64_t* d_rle_bytes, const float* d_scales, bool out_f32,
-                                     uint64_t* d_n_out, int quant_mode, hipStream_t s);
+size_t tensors_workspace_bytes(uint32_t n_tensors, uint64_t max_elems);
+hipError_t launch_tensors_compress(uint32_t n_tensors, const TensorDesc* d_desc, uint64_t max_elems, bool src_f32, uint64_t* d_rle_bytes, float* d_scales,
+                                   void* d_ws, size_t ws_bytes, int quant_mode, hipStream_t s);
+hipError_t launch_tensors_decompress(uint32_t n_tensors, const TensorDesc* d_desc, uint64_t max_elems, const uint64_t* d_rle_bytes, const float* d_scales, bool out_f32,
+                                     uint64_t* d_n_out, void* d_ws, size_t ws_bytes, int quant_mode, hipStream_t s);
 
 // Prefetch lookup: 3 kernels (mask+count, scan, scatter) -> compacted page list
 // in request order.  scratch must hold (2*n + 2) uint32.

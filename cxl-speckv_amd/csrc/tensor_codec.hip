@@ -1541,6 +1541,62 @@ __global__ __launch_bounds__(64 * kTfWaves) __attribute__((amdgpu_waves_per_eu(8
     tc_fused_body<MODE, F32, true>(d.data, d.n, tc_scale(m), (d.n + kTile - 1u) / kTile, 0ull, nullptr, nullptr, d.rle, out_scale, out_bytes, no_split);
 }
 
+// The same launch shape with SEVERAL workgroups per tensor (`wpt` = workgroups of the largest tensor; tensor t = ticket / wpt,
+// its workgroup ticket % wpt takes 16 tiles as in k_tc_fused).  One workgroup per tensor (above) leaves a tensor's 64 tiles to
+// four strictly serial rounds between barriers: 0.31 of the roofline at 4096 x 131 072.  Here the tiles of a tensor are encoded
+// side by side, the chains are k_tc_fused's look-back over the tensor's OWN status words (at most wpt - 1 predecessors: one
+// window, mostly answered at once), and the max|x| comes from a rendezvous of the tensor's workgroups: each publishes the maximum
+// of its 16 tiles as a tagged word and reads the others'.  Tickets make that safe: the workgroups of a tensor hold consecutive
+// tickets, every earlier ticket has started, and at most wpt - 1 workgroups ever wait for a ticket that has not (they are
+// resident and the rest of the chip is not waiting for them).  A workgroup re-reads the 128 KiB it has just taken the maximum
+// of: about 500 workgroups = 64 MiB are in flight at a time, so that second read is served by the L2 / Infinity Cache.
+template <int MODE, bool F32>
+__global__ __launch_bounds__(64 * kTfWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tcm_fused(const TcbDesc* __restrict__ desc, uint32_t wpt, uint32_t* __restrict__ ticket,
+                                                            uint64_t* __restrict__ amax_words, uint64_t* __restrict__ w1, uint64_t* __restrict__ w2,
+                                                            float* __restrict__ out_scale, uint64_t* __restrict__ out_bytes, uint32_t no_split)
+{
+    __shared__ uint32_t s_ticket, s_bits;
+    __shared__ uint32_t s_am[kTfWaves];
+    if (threadIdx.x == 0u) s_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t t = s_ticket / wpt, l = s_ticket - t * wpt;
+    const TcbDesc d = desc[t];
+    const uint64_t n_tiles = (d.n + kTile - 1u) / kTile;
+    const uint32_t my_wgs = static_cast<uint32_t>((n_tiles + kTfWaves - 1u) / kTfWaves);
+    if (l >= my_wgs) {                                                   // (a shorter tensor than the largest; an empty one: scale 1, no stream)
+        if (l == 0u && threadIdx.x == 0u) { out_bytes[t] = 0ull; out_scale[t] = 1.0f; }
+        return;
+    }
+    constexpr uint64_t kWgElems = static_cast<uint64_t>(kTfWaves) * kTile;
+    const uint64_t e0 = l * kWgElems, cnt = d.n - e0 < kWgElems ? d.n - e0 : kWgElems;
+    uint32_t m = lane63(wave_incl_max(tc_absmax_thread<F32, false>(static_cast<const uint8_t*>(d.data) + e0 * (F32 ? 4u : 2u), cnt, threadIdx.x, 64u * kTfWaves)));
+    if ((threadIdx.x & 63u) == 0u) s_am[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x < 64u) {
+        const uint32_t lane = threadIdx.x;
+        m = 0;
+        for (uint32_t w = 0; w < kTfWaves; ++w) m = umax(m, s_am[w]);
+        if (!F32) m = __float_as_uint(half_bits_to_float(m));
+        uint64_t* words = amax_words + static_cast<uint64_t>(t) * wpt;
+        if (lane == 0u) tc_lb_store(words + l, 1ull, m);                 // the value IS the word: nothing to fence
+        uint32_t all = 0;
+        for (uint32_t b = 0; b < my_wgs; b += 64u) {                     // the others' (and mine), 64 at a time
+            const bool have = b + lane < my_wgs;
+            uint64_t w;
+            for (;;) {
+                w = have ? tc_lb_load(words + b + lane) : (1ull << 62);
+                if (__ballot((w >> 62) == 0ull) == 0ull) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            all = umax(all, lane63(wave_incl_max(have ? static_cast<uint32_t>(w) : 0u)));
+        }
+        if (lane == 0u) s_bits = all;
+    }
+    __syncthreads();
+    tc_fused_body<MODE, F32, false>(d.data, d.n, tc_scale(s_bits), n_tiles, l, w1 + static_cast<uint64_t>(t) * wpt, w2 + static_cast<uint64_t>(t) * wpt, d.rle,
+                                    out_scale + t, out_bytes + t, no_split);
+}
+
 // ---------------------------------------------------------------- decompress in ONE pass over the stream
 // The three launches above read the stream twice (summary, expand), and their expand loop takes a lane's 8 pairs one after the
 // other with a byte store per ELEMENT.  This form reads the stream once and expands the way the block decoder of the pool does
@@ -1989,6 +2045,30 @@ void k_tdb_fused(const TcbDesc* __restrict__ desc, const uint64_t* __restrict__ 
     td_fused_body<MODE, F32, true>(d.rle, n_pairs, chunks, 0ull, nullptr, d.n, on, scales[blockIdx.x], static_cast<uint8_t*>(d.data));
 }
 
+// ... and with several workgroups per stream (see k_tcm_fused): stream t = ticket / wpt, its workgroup ticket % wpt takes 16 chunks of
+// 2048 pairs, the prefix in front of it by look-back over the stream's own status words.
+template <int MODE, bool F32>
+__global__ __launch_bounds__(64 * kTdfWaves) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_tdm_fused(const TcbDesc* __restrict__ desc, uint32_t wpt, uint32_t* __restrict__ ticket, uint64_t* __restrict__ status,
+                 const uint64_t* __restrict__ rle_bytes, const float* __restrict__ scales, uint64_t* __restrict__ n_out)
+{
+    __shared__ uint32_t s_ticket;
+    __shared__ uint64_t s_none;
+    if (threadIdx.x == 0u) s_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t t = s_ticket / wpt, l = s_ticket - t * wpt;
+    const TcbDesc d = desc[t];
+    const uint64_t n_pairs = rle_bytes[t] >> 1;                           // an odd trailing byte is dropped (cache_engine.cpp:245)
+    const uint64_t chunks = (n_pairs + kTile - 1u) / kTile;
+    const uint64_t my_wgs = (chunks + kTdfChunks - 1u) / kTdfChunks;
+    uint64_t* on = n_out ? n_out + t : &s_none;
+    if (l >= my_wgs || d.n == 0u) {
+        if (l == 0u && threadIdx.x == 0u) *on = 0ull;
+        return;
+    }
+    td_fused_body<MODE, F32, false>(d.rle, n_pairs, chunks, l, status + static_cast<uint64_t>(t) * wpt, d.n, on, scales[t], static_cast<uint8_t*>(d.data));
+}
+
 // ---------------------------------------------------------------- output-centric expand with the run scatter (multi-launch form)
 // k_td_expand above lets a lane write the part of its run that falls into the tile element by element: a tile covered by three
 // runs of 700 elements is three lanes storing 700 bytes each.  On tensors that compress (long runs, few pairs) BOTH decoders
@@ -2312,29 +2392,69 @@ hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, u
     return hipGetLastError();
 }
 
-// One workgroup per tensor, no workspace: d_desc[i] = {source, elements, stream, room} (device array, kernels.hpp TensorDesc)
-hipError_t launch_tensors_compress(uint32_t n_tensors, const TensorDesc* d_desc, bool src_f32, uint64_t* d_rle_bytes, float* d_scales, int quant_mode, hipStream_t s)
+// Many tensors per launch.  d_desc[i] = {source, elements, stream, room} (device array, kernels.hpp TensorDesc); max_elems = the
+// largest tensor (the host's bound: it sizes the grid, wpt workgroups per tensor).  Workspace: ticket (256 B) | max|x| words | chain 1 |
+// chain 2, one 8-byte word per (tensor, workgroup) each; cleared here.  wpt == 1 (tensors of at most 16 tiles) and SPECKV_TC_BATCH_ONE_WG:
+// the one-workgroup-per-tensor kernels (chains in LDS, no workspace words).
+size_t tensors_workspace_bytes(uint32_t n_tensors, uint64_t max_elems)
+{
+    const uint64_t wpt = std::max<uint64_t>(1, (max_elems + static_cast<uint64_t>(kTfWaves) * kTile - 1) / (static_cast<uint64_t>(kTfWaves) * kTile));
+    return 256 + 3ull * n_tensors * wpt * 8ull;
+}
+hipError_t launch_tensors_compress(uint32_t n_tensors, const TensorDesc* d_desc, uint64_t max_elems, bool src_f32, uint64_t* d_rle_bytes, float* d_scales,
+                                   void* d_ws, size_t ws_bytes, int quant_mode, hipStream_t s)
 {
     static_assert(sizeof(TcbDesc) == sizeof(TensorDesc) && sizeof(TensorDesc) == 32, "descriptor layout");
+    static_assert(kTfWaves == kTdfChunks, "one workgroup count per tensor serves both directions");
     if (n_tensors == 0) return hipSuccess;
     const uint32_t no_split = tuning().tc_no_split_tiles ? 1u : 0u;
     const TcbDesc* dd = reinterpret_cast<const TcbDesc*>(d_desc);
+    const uint64_t wpt = std::max<uint64_t>(1, (max_elems + static_cast<uint64_t>(kTfWaves) * kTile - 1) / (static_cast<uint64_t>(kTfWaves) * kTile));
+    if (wpt == 1 || tuning().tc_batch_one_wg) {
 #define SPECKV_TCB(MODE, F32) hipLaunchKernelGGL((k_tcb_fused<MODE, F32>), dim3(n_tensors), dim3(64 * kTfWaves), 0, s, dd, d_scales, d_rle_bytes, no_split)
-    if (quant_mode == kIntent) { if (src_f32) SPECKV_TCB(kIntent, true); else SPECKV_TCB(kIntent, false); }
-    else                       { if (src_f32) SPECKV_TCB(kRefExact, true); else SPECKV_TCB(kRefExact, false); }
+        if (quant_mode == kIntent) { if (src_f32) SPECKV_TCB(kIntent, true); else SPECKV_TCB(kIntent, false); }
+        else                       { if (src_f32) SPECKV_TCB(kRefExact, true); else SPECKV_TCB(kRefExact, false); }
 #undef SPECKV_TCB
+        return hipGetLastError();
+    }
+    if (!d_ws || ws_bytes < tensors_workspace_bytes(n_tensors, max_elems) || (reinterpret_cast<uintptr_t>(d_ws) & 255u) || n_tensors * wpt > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const hipError_t e = hipMemsetAsync(d_ws, 0, tensors_workspace_bytes(n_tensors, max_elems), s);
+    if (e != hipSuccess) return e;
+    uint32_t* ticket = static_cast<uint32_t*>(d_ws);
+    uint64_t* amax = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(d_ws) + 256);
+    uint64_t* w1 = amax + n_tensors * wpt;
+    uint64_t* w2 = w1 + n_tensors * wpt;
+    const uint32_t g = static_cast<uint32_t>(n_tensors * wpt), w = static_cast<uint32_t>(wpt);
+#define SPECKV_TCM(MODE, F32) hipLaunchKernelGGL((k_tcm_fused<MODE, F32>), dim3(g), dim3(64 * kTfWaves), 0, s, dd, w, ticket, amax, w1, w2, d_scales, d_rle_bytes, no_split)
+    if (quant_mode == kIntent) { if (src_f32) SPECKV_TCM(kIntent, true); else SPECKV_TCM(kIntent, false); }
+    else                       { if (src_f32) SPECKV_TCM(kRefExact, true); else SPECKV_TCM(kRefExact, false); }
+#undef SPECKV_TCM
     return hipGetLastError();
 }
 
-hipError_t launch_tensors_decompress(uint32_t n_tensors, const TensorDesc* d_desc, const uint64_t* d_rle_bytes, const float* d_scales, bool out_f32,
-                                     uint64_t* d_n_out, int quant_mode, hipStream_t s)
+hipError_t launch_tensors_decompress(uint32_t n_tensors, const TensorDesc* d_desc, uint64_t max_elems, const uint64_t* d_rle_bytes, const float* d_scales, bool out_f32,
+                                     uint64_t* d_n_out, void* d_ws, size_t ws_bytes, int quant_mode, hipStream_t s)
 {
     if (n_tensors == 0) return hipSuccess;
     const TcbDesc* dd = reinterpret_cast<const TcbDesc*>(d_desc);
+    const uint64_t wpt = std::max<uint64_t>(1, (max_elems + static_cast<uint64_t>(kTfWaves) * kTile - 1) / (static_cast<uint64_t>(kTfWaves) * kTile));
+    if (wpt == 1 || tuning().tc_batch_one_wg) {
 #define SPECKV_TDB(MODE, F32) hipLaunchKernelGGL((k_tdb_fused<MODE, F32>), dim3(n_tensors), dim3(64 * kTdfWaves), 0, s, dd, d_rle_bytes, d_scales, d_n_out)
-    if (quant_mode == kIntent) { if (out_f32) SPECKV_TDB(kIntent, true); else SPECKV_TDB(kIntent, false); }
-    else                       { if (out_f32) SPECKV_TDB(kRefExact, true); else SPECKV_TDB(kRefExact, false); }
+        if (quant_mode == kIntent) { if (out_f32) SPECKV_TDB(kIntent, true); else SPECKV_TDB(kIntent, false); }
+        else                       { if (out_f32) SPECKV_TDB(kRefExact, true); else SPECKV_TDB(kRefExact, false); }
 #undef SPECKV_TDB
+        return hipGetLastError();
+    }
+    if (!d_ws || ws_bytes < tensors_workspace_bytes(n_tensors, max_elems) || (reinterpret_cast<uintptr_t>(d_ws) & 255u) || n_tensors * wpt > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const hipError_t e = hipMemsetAsync(d_ws, 0, 256 + n_tensors * wpt * 8ull, s);
+    if (e != hipSuccess) return e;
+    uint32_t* ticket = static_cast<uint32_t*>(d_ws);
+    uint64_t* status = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(d_ws) + 256);
+    const uint32_t g = static_cast<uint32_t>(n_tensors * wpt), w = static_cast<uint32_t>(wpt);
+#define SPECKV_TDM(MODE, F32) hipLaunchKernelGGL((k_tdm_fused<MODE, F32>), dim3(g), dim3(64 * kTdfWaves), 0, s, dd, w, ticket, status, d_rle_bytes, d_scales, d_n_out)
+    if (quant_mode == kIntent) { if (out_f32) SPECKV_TDM(kIntent, true); else SPECKV_TDM(kIntent, false); }
+    else                       { if (out_f32) SPECKV_TDM(kRefExact, true); else SPECKV_TDM(kRefExact, false); }
+#undef SPECKV_TDM
     return hipGetLastError();
 }
 

@@ -21,6 +21,7 @@ const Key kKeys[] = {
     {"tc_no_split_tiles", "SPECKV_TC_NO_SPLIT_TILES", &Tuning::tc_no_split_tiles},
     {"td_one_pass", "SPECKV_TD_ONE_PASS", &Tuning::td_one_pass},
     {"td_expand_per_element", "SPECKV_TD_EXPAND_PER_ELEMENT", &Tuning::td_expand_per_element},
+    {"tc_batch_one_wg", "SPECKV_TC_BATCH_ONE_WG", &Tuning::tc_batch_one_wg},
     {"flush_no_small", "SPECKV_FLUSH_NO_SMALL", &Tuning::flush_no_small},
     {"flush_small_words", "SPECKV_FLUSH_SMALL_WORDS", &Tuning::flush_small_words},
     {"predict_batch_path", "SPECKV_PREDICT_BATCH_PATH", &Tuning::predict_batch_path},

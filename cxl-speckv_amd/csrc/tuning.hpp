@@ -22,6 +22,7 @@ struct Tuning {
     int32_t tc_no_split_tiles = 0;          // SPECKV_TC_NO_SPLIT_TILES        element-wise loop for long stretches
     int32_t td_one_pass = 0;                // SPECKV_TD_ONE_PASS              one-pass decoder also for streams of few pairs
     int32_t td_expand_per_element = 0;      // SPECKV_TD_EXPAND_PER_ELEMENT    the expand loop of rounds 2-3
+    int32_t tc_batch_one_wg = 0;            // SPECKV_TC_BATCH_ONE_WG          many-tensor launches: one workgroup per tensor whatever its size (chains in LDS; tests, A/B)
     // prefetch flush / predictor forms (tests compare them)
     int32_t flush_no_small = 0;             // SPECKV_FLUSH_NO_SMALL           always the four-launch pipeline
     int32_t flush_small_words = 0;          // SPECKV_FLUSH_SMALL_WORDS        candidate words up to which one workgroup flushes (0: default)

@@ -260,16 +260,18 @@ speckv_status_t speckv_ext_codec_decompress_tensor(const void* d_rle, uint64_t r
 /* The same codec over MANY tensors per launch (round 6).  The reference calls FPGACacheEngine::compress(data, n) once per KV tile
  * (cache_engine.cpp:40-82; the RTL's tile is 1024 x 128 = 131 072 elements, hardware/rtl/kv_compress.v:5-11): at that size one
  * tensor is 64 tiles of work and the single-tensor entry point above is all fixed cost (two launches, a look-back chain that has
- * barely started when it ends).  Here ONE workgroup takes one tensor -- its own scale (it finds max|x| itself; the second pass
- * over the source comes out of the L2 / Infinity Cache), its own delta chain, its own run-length stream, carried from round to
- * round in LDS -- and one launch takes thousands of them; no workspace.  Streams and scales are bit-identical to the
- * single-tensor entry point's and to the reference's, per tensor.  Any length works, but a tensor is walked by one workgroup:
- * tensors of many millions of elements belong to speckv_ext_codec_compress_tensor.
+ * barely started when it ends).  Here one launch takes thousands of tensors: every tensor its own scale, its own delta chain, its
+ * own run-length stream; a tensor's workgroups (16 tiles each) find its max|x| by a rendezvous among themselves and hand their
+ * chains on by look-back over the tensor's own status words; each workgroup reads the source twice, the second time out of the
+ * L2 / Infinity Cache.  Streams and scales are bit-identical to the single-tensor entry point's and to the reference's, per tensor.
  *   d_tensors  DEVICE array of n_tensors descriptors
+ *   max_elems  the host's upper bound on the tensors' lengths (sizes the grid and the workspace; a tensor may be shorter, or empty)
  *   compress:   data = the source (fp16, or fp32 with src_f32), n = its elements, rle = where the stream goes (16-byte aligned),
  *               rle_cap >= 2 n rounded up to 16 (not checked); d_rle_bytes[i] / d_scales[i] receive the stream length / the scale
- *   decompress: data = the destination (16-byte aligned; fp16, or fp32 with out_f32), n = its room in elements, rle = the stream,
- *               d_rle_bytes[i] / d_scales[i] as compress left them; d_n_out[i] (may be NULL) = elements decoded, clipped to the room
+ *   decompress: data = the destination (16-byte aligned; fp16, or fp32 with out_f32), n = its room in elements (<= max_elems),
+ *               rle = the stream (2 max_elems bytes at most), d_rle_bytes[i] / d_scales[i] as compress left them; d_n_out[i] (may be
+ *               NULL) = elements decoded, clipped to the room
+ *   d_workspace  256-byte aligned, speckv_ext_codec_tensors_workspace_bytes(n_tensors, max_elems) bytes (cleared by the call)
  * Asynchronous on `stream`; no engine needed. */
 typedef struct {
     void*    data;
@@ -277,11 +279,14 @@ typedef struct {
     void*    rle;
     uint64_t rle_cap;
 } speckv_ext_tensor_t;       /* 32 bytes */
-speckv_status_t speckv_ext_codec_compress_tensors(uint32_t n_tensors, const speckv_ext_tensor_t* d_tensors, int src_f32,
-                                                  uint64_t* d_rle_bytes, float* d_scales, int quant_mode, void* stream);
-speckv_status_t speckv_ext_codec_decompress_tensors(uint32_t n_tensors, const speckv_ext_tensor_t* d_tensors,
+size_t speckv_ext_codec_tensors_workspace_bytes(uint32_t n_tensors, uint64_t max_elems);
+speckv_status_t speckv_ext_codec_compress_tensors(uint32_t n_tensors, const speckv_ext_tensor_t* d_tensors, uint64_t max_elems,
+                                                  int src_f32, uint64_t* d_rle_bytes, float* d_scales, void* d_workspace,
+                                                  size_t workspace_bytes, int quant_mode, void* stream);
+speckv_status_t speckv_ext_codec_decompress_tensors(uint32_t n_tensors, const speckv_ext_tensor_t* d_tensors, uint64_t max_elems,
                                                     const uint64_t* d_rle_bytes, const float* d_scales, int out_f32,
-                                                    uint64_t* d_n_out, int quant_mode, void* stream);
+                                                    uint64_t* d_n_out, void* d_workspace, size_t workspace_bytes,
+                                                    int quant_mode, void* stream);
 
 /* ---- 4:1 / 2:1 formats + fused dequant-matvec (BASELINE config 5; SURVEY 8a row
  *      A22: no reference counterpart, parity is against oracle/ only) -----------
@@ -528,7 +533,7 @@ double speckv_ext_codec_model_throughput_gbps(uint32_t num_engines, double clock
 /* Launch-form switches (tests, measurement runs): the library reads its environment ONCE, at the first speckv_init / raw codec
  * call of the process; after that a form is changed by this call only.  Keys (= the SPECKV_<KEY> environment names, lower case):
  * attend_splits, attend_tiles_per_split, attend_general, tc_multipass, tc_scan (1 one workgroup, 2 one wave), tc_no_pre,
- * tc_no_split_tiles, td_one_pass, td_expand_per_element, flush_no_small, flush_small_words, predict_batch_path, wgs_per_cu,
+ * tc_no_split_tiles, td_one_pass, td_expand_per_element, flush_no_small, flush_small_words, predict_batch_path, wgs_per_cu, tc_batch_one_wg (many-tensor launches: one workgroup per tensor),
  * rounds_consecutive, remote_engine (1 kernel, 2 copy engines), copy_min_run_kb, attend_stream (MXFP4, several layers of one
  * sequence: N > 0 the stream form with N workgroups, -1 never), attend_mx4_one_half (MXFP4 batches: 4-wave workgroups also where
  * the two-halves form applies).  0 restores the library's own rule.

@@ -784,9 +784,14 @@ def gpu_codec_tensors(lib, xs, mode=0, out_f32=True, misalign=0, room_extra=3):
     torch = torch_mod()
     f32 = xs[0].dtype == np.float32
     esz = 4 if f32 else 2
-    lib.speckv_ext_codec_compress_tensors.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
-    lib.speckv_ext_codec_decompress_tensors.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    lib.speckv_ext_codec_tensors_workspace_bytes.argtypes = [C.c_uint32, C.c_uint64]; lib.speckv_ext_codec_tensors_workspace_bytes.restype = C.c_size_t
+    lib.speckv_ext_codec_compress_tensors.argtypes = [C.c_uint32, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    lib.speckv_ext_codec_decompress_tensors.argtypes = [C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     nt = len(xs)
+    max_elems = max(x.size for x in xs) + room_extra
+    ws_bytes = lib.speckv_ext_codec_tensors_workspace_bytes(nt, max_elems)
+    d_ws = torch.full((ws_bytes + 256,), 0x5A, dtype=torch.uint8, device="cuda")               # (dirty: the call clears what it uses)
+    ws_ptr = (d_ws.data_ptr() + 255) & ~255
     # sources back to back (each start 16-byte aligned + `misalign` elements), streams and outputs 16-byte aligned with guard bytes between
     src_off, rle_off, out_off = [], [], []
     so = ro = oo = 0
@@ -809,8 +814,9 @@ def gpu_codec_tensors(lib, xs, mode=0, out_f32=True, misalign=0, room_extra=3):
     d_bytes = torch.full((nt,), -1, dtype=torch.int64, device="cuda")
     d_scales = torch.full((nt,), float("nan"), dtype=torch.float32, device="cuda")
     d_nout = torch.full((nt,), -1, dtype=torch.int64, device="cuda")
-    assert lib.speckv_ext_codec_compress_tensors(nt, d_desc_c.data_ptr(), int(f32), d_bytes.data_ptr(), d_scales.data_ptr(), mode, stream_ptr()) == 0
-    assert lib.speckv_ext_codec_decompress_tensors(nt, d_desc_d.data_ptr(), d_bytes.data_ptr(), d_scales.data_ptr(), int(out_f32), d_nout.data_ptr(), mode, stream_ptr()) == 0
+    assert lib.speckv_ext_codec_compress_tensors(nt, d_desc_c.data_ptr(), max_elems, int(f32), d_bytes.data_ptr(), d_scales.data_ptr(), ws_ptr, ws_bytes, mode, stream_ptr()) == 0
+    assert lib.speckv_ext_codec_decompress_tensors(nt, d_desc_d.data_ptr(), max_elems, d_bytes.data_ptr(), d_scales.data_ptr(), int(out_f32), d_nout.data_ptr(), ws_ptr, ws_bytes, mode,
+                                                   stream_ptr()) == 0
     torch.cuda.synchronize()
     sizes, scales, nout = d_bytes.cpu().numpy(), d_scales.cpu().numpy(), d_nout.cpu().numpy()
     rle, out = d_rle.cpu().numpy(), d_out.cpu().numpy()
@@ -848,8 +854,9 @@ def test_tensors_batch_golden_reference_vectors(lib, golden_dir):
     assert int(y.view(np.uint32).astype(np.uint64).sum()) == int(g["big.y_sum_bits"][0])
 
 
+@pytest.mark.parametrize("one_wg", [0, 1])
 @pytest.mark.parametrize("dtype", [np.float32, np.float16])
-def test_tensors_batch_matches_oracle_over_sizes_and_structures(lib, oracle, dtype):
+def test_tensors_batch_matches_oracle_over_sizes_and_structures(lib, oracle, dtype, one_wg):
     """The batched form against the oracle, per tensor: lengths 0, 1, below / at / just over a tile, a round (16 tiles) and several
     rounds with ragged ends; noise, long flat stretches that cross tiles and rounds (255-splits, the delta chain and both carried
     chains), all zeros, inf / NaN; both quantiser modes; sources off their 16-byte alignment; fp16 and fp32 outputs."""
@@ -866,6 +873,16 @@ def test_tensors_batch_matches_oracle_over_sizes_and_structures(lib, oracle, dty
     z = rng.standard_normal(70000).astype(dtype); z[5] = np.inf; z[40000] = np.nan; z[69999] = -np.inf
     xs.append(z)
     xs.append(np.repeat(rng.standard_normal(300).astype(dtype), 700))              # runs of 700: every one split at 255, across tiles and rounds
+    # both forms: several workgroups per tensor (look-back over the tensor's own words, max|x| by rendezvous) and one workgroup per tensor
+    # (chains carried in LDS: what launches of tensors of at most 16 tiles take by themselves)
+    set_tuning("tc_batch_one_wg", one_wg)
+    try:
+        _tensors_batch_against_oracle(lib, oracle, xs)
+    finally:
+        set_tuning("tc_batch_one_wg", 0)
+
+
+def _tensors_batch_against_oracle(lib, oracle, xs):
     for mode in MODES:
         for misalign, out_f32 in ((0, True), (3, False)):
             res = gpu_codec_tensors(lib, xs, mode, out_f32, misalign)
