@@ -1228,27 +1228,36 @@ def connector_decode_extra(torch, kv, n_seq=256, Lyr=8, ctx=2048, T=4096, scheme
         k = torch.randn((n_seq, Lyr, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
         v = torch.randn((n_seq, Lyr, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
         s = torch.cuda.Stream()
-        times = []
+        times, times_all = [], []
+        qall = q[None].expand(Lyr, -1, -1, -1, -1).contiguous()
         with torch.cuda.stream(s):
-            for step in range(8):
+            for step in range(16):
+                all_layers = step >= 8                              # steps 8..15: the layers' attention as ONE library call (attend_layers)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 conn.begin_step(ids, depth_k=0)
-                for layer in range(Lyr):
-                    out = conn.attend(layer, ids, q, 0.08838834764831845, stream=s)
+                if all_layers:
+                    out = conn.attend_layers(0, Lyr, ids, qall, 0.08838834764831845, stream=s)
+                else:
+                    for layer in range(Lyr):
+                        out = conn.attend(layer, ids, q, 0.08838834764831845, stream=s)
                 keep = conn.append(ids, k, v, stream=s)
                 torch.cuda.synchronize()
-                times.append((time.perf_counter() - t0) * 1e3)
+                (times_all if all_layers else times).append((time.perf_counter() - t0) * 1e3)
                 del keep, out
+        ms_all = sum(times_all[2:]) / len(times_all[2:])
         ms = sum(times[2:]) / len(times[2:])                   # even and odd steps alternate (tail fold / pair append)
         rec_bytes = n_seq * Lyr * 2 * ctx * rec_per_pos          # record bytes read per step (K and V; FP8 1 KiB per position and kind, MXFP4 544 B)
         return {name: {"sequences": n_seq, "layers": Lyr, "context": ctx, "ms_per_step": round(ms, 3),
                                           "ms_fastest_step": round(min(times[2:]), 3), "ms_slowest_step": round(max(times[2:]), 3),
+                                          "ms_per_step_layers_in_one_call": round(ms_all, 3), "frac_hbm_layers_in_one_call": round(rec_bytes / (ms_all * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                           "tokens_per_s_kv_side": round(n_seq / (ms * 1e-3), 1),
                                           "KV_record_GBps": round(rec_bytes / (ms * 1e-3) / 1e9, 1),
                                           "frac_hbm": round(rec_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                          "note": "begin_step (a no-op for fused pools since round 6) + one batch attention call per layer + batched append (which plans the next step), wall time "
-                                                  "per step incl. the torch glue (tail fold, gathers); " + scheme + " pool"}}
+                                          "note": "begin_step (a no-op for fused pools since round 6) + one batch attention call per layer (the tail position goes along in the call) + batched "
+                                                  "append (which plans the next step), wall time per step incl. the torch glue; ms_per_step_layers_in_one_call: the same step with the "
+                                                  "layers' attention as ONE call (SpeckvKVConnector.attend_layers: for callers that have several layers' query rows at once; over an "
+                                                  "MXFP4 pool one launch); " + scheme + " pool"}}
     except Exception as e:
         return {"connector_decode_step" if scheme == "fp8" else f"connector_decode_step_{scheme}": {"error": repr(e)}}
     finally:

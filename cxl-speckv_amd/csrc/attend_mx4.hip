@@ -193,8 +193,16 @@ __global__ __launch_bounds__(64 * kWavesPerWg * HALVES) __attribute__((amdgpu_wa
     uint64_t part0 = row0 * a.n_splits + split, part_step = a.n_splits;  // partials of head 0 | head 1: part0, part0 + part_step
     uint32_t my_splits = a.n_splits;
     if (STREAM) { part0 = row0 * a.stream.max_slots + slot; part_step = a.stream.max_slots; my_splits = 0u; }      // (never the direct output)
+    int32_t tail = -1;                                                   // this sequence's row in the tail arrays (split 0 folds it in)
     if (a.seqs) {                                                        // workgroup-uniform: per-sequence geometry
-        const AttendSeq sq = a.seqs[layer];
+        uint32_t seq = layer;
+        if (a.batch_n_seq) {                                             // several layers in one launch: y = layer x sequence
+            const uint32_t li = layer / a.batch_n_seq;
+            seq = layer - li * a.batch_n_seq;
+            a.batch_layer += li;
+        }
+        if (a.tail_k && split == 0u) tail = a.tail_idx ? a.tail_idx[seq] : static_cast<int32_t>(seq);
+        const AttendSeq sq = a.seqs[seq];
         if (split >= sq.n_splits) {
             if (sq.n_splits == 0u && split == 0u && blockIdx.z == 0u && a.direct_out && a.direct_per_seq == 2u) {
                 attend_zero_rows(a.direct_out, a.direct_lse, a.g, row0, lane);
@@ -241,17 +249,40 @@ __global__ __launch_bounds__(64 * kWavesPerWg * HALVES) __attribute__((amdgpu_wa
 #pragma unroll
         for (int s = 0; s < 8; ++s) acc[hh][s] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
+    // the tail position (AttendArgs::tail_k): per head its score in the kernel's log2 units and the lane's 32 V values (channels
+    // 32 kb .. + 31 of the head, fp16 pairs) -- fetched beside the query rows, so that the epilogue waits for nothing
+    float tail_sc[2] = {-INFINITY, -INFINITY};
+    u32x4 tail_v[2][4];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tail_v[hh][j] = u32x4{0u, 0u, 0u, 0u};
     // ---- the two parities of a query row are added; the lanes of parity 0 write the partial (or, single split: the final) result
     auto store_rows = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const float l_half = sum_over_kb(l_run[hh]);
-            const float l_tot = l_half + other_parity(l_half);
+            float l_tot = l_half + other_parity(l_half);
             f32x4 o[8];
 #pragma unroll
             for (int s = 0; s < 8; ++s)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[s][r] = acc[hh][s][r] + other_parity(acc[hh][s][r]);
+            if (tail >= 0) {                                             // (workgroup-uniform) one more position: its score and V row were fetched beside the query
+                const float m_new = fmaxf(m_run[hh], tail_sc[hh]);
+                const float fa = (m_run[hh] == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(m_run[hh] - m_new), fb = __builtin_amdgcn_exp2f(tail_sc[hh] - m_new);
+                m_run[hh] = m_new;
+                l_tot = l_tot * fa + fb;
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // o[s][r] is output channel 32 kb + 8 r + s: half (8 r + s) of the lane's 32 V values = word r of piece r' ... packed two per dword
+                        const uint32_t wd = tail_v[hh][r][s >> 1];
+                        const float vch = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>((s & 1) ? (wd >> 16) : (wd & 0xFFFFu))));
+                        o[s][r] = o[s][r] * fa + fb * vch;
+                    }
+            }
             if (w != 0u || q >= a.g) continue;
             const uint64_t row = row0 + hh;
             if (a.direct_out && (!a.direct_per_seq || my_splits == 1u)) {
@@ -445,6 +476,28 @@ __global__ __launch_bounds__(64 * kWavesPerWg * HALVES) __attribute__((amdgpu_wa
             }
         };
         load_query();
+        if (tail >= 0) {                                                     // (workgroup-uniform; split 0 of a sequence that keeps a position outside the pool)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                // the lane holds output channels 32 kb + 8 r + s of query row ql: the same 32 channels of q and k make its share of q.k
+                const uint64_t trow = static_cast<uint64_t>(tail) * a.tail_stride + (static_cast<uint64_t>(a.batch_layer) * a.heads + h0 + hh) * 128u + 32u * kb;
+                const uint16_t* qp = a.q16 + ((row0 + hh) * a.g + min(q, a.g - 1u)) * 128u + 32u * kb;
+                float dot = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32x4 qw = *MX_GP(u32x4, qp + 8 * j), kw = *MX_GP(u32x4, a.tail_k + trow + 8 * j);
+                    tail_v[hh][j] = *MX_GP(u32x4, a.tail_v + trow + 8 * j);
+                    const uint32_t qq[4] = {qw.x, qw.y, qw.z, qw.w}, kk[4] = {kw.x, kw.y, kw.z, kw.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f16x2 q2 = __builtin_bit_cast(f16x2, qq[e]), k2 = __builtin_bit_cast(f16x2, kk[e]);
+                        dot = __builtin_fmaf(static_cast<float>(q2.x), static_cast<float>(k2.x), dot);
+                        dot = __builtin_fmaf(static_cast<float>(q2.y), static_cast<float>(k2.y), dot);
+                    }
+                }
+                tail_sc[hh] = sum_over_kb(dot) * a.scale_log2e;
+            }
+        }
         // ---- where the lane reads its operands in a stage
         uint32_t rk[2][2], rkc[2][2], rv[2][4], rvc[2][4];
 #pragma unroll

@@ -567,6 +567,35 @@ speckv_status_t speckv_ext_attend_mx4_planned(const void* d_plan, uint32_t n_seq
     });
 }
 
+speckv_status_t speckv_ext_attend_planned_tail(int scheme, const void* d_plan, uint32_t n_seq, uint32_t layer, const void* d_q_f16, uint32_t g,
+                                               uint32_t max_pos_end, float sm_scale, float* d_out, float* d_lse, uint32_t n_tail,
+                                               const uint32_t* d_tail_rows, const int32_t* d_tail_idx, const void* d_k_tail, const void* d_v_tail,
+                                               uint64_t tail_stride_elems, void* stream)
+{
+    LOCK; NEED_INIT;
+    if (scheme != SPECKV_COMP_FP8_E4M3 && scheme != SPECKV_COMP_INT4_G32 && scheme != SPECKV_COMP_MXFP4) return SPECKV_ERR_INVAL;
+    if (n_tail > n_seq || (n_tail && n_tail < n_seq && !d_tail_rows)) return SPECKV_ERR_INVAL;
+    return guarded([&] {
+        const Engine::TailArgs t{n_tail, d_tail_rows, d_tail_idx, d_k_tail, d_v_tail, tail_stride_elems};
+        return g_engine->attend_planned(scheme, d_plan, n_seq, layer, d_q_f16, g, max_pos_end, sm_scale, d_out, d_lse, static_cast<hipStream_t>(stream), &t);
+    });
+}
+
+speckv_status_t speckv_ext_attend_planned_layers(int scheme, const void* d_plan, uint32_t n_seq, uint32_t layer_begin, uint32_t n_layers, const void* d_q_f16,
+                                                 uint32_t g, uint32_t max_pos_end, float sm_scale, float* d_out, float* d_lse, uint32_t n_tail,
+                                                 const uint32_t* d_tail_rows, const int32_t* d_tail_idx, const void* d_k_tail, const void* d_v_tail,
+                                                 uint64_t tail_stride_elems, void* stream)
+{
+    LOCK; NEED_INIT;
+    if (scheme != SPECKV_COMP_FP8_E4M3 && scheme != SPECKV_COMP_INT4_G32 && scheme != SPECKV_COMP_MXFP4) return SPECKV_ERR_INVAL;
+    if (n_tail > n_seq || (n_tail && n_tail < n_seq && !d_tail_rows)) return SPECKV_ERR_INVAL;
+    return guarded([&] {
+        const Engine::TailArgs t{n_tail, d_tail_rows, d_tail_idx, d_k_tail, d_v_tail, tail_stride_elems};
+        return g_engine->attend_planned_layers(scheme, d_plan, n_seq, layer_begin, n_layers, d_q_f16, g, max_pos_end, sm_scale, d_out, d_lse,
+                                               static_cast<hipStream_t>(stream), n_tail ? &t : nullptr);
+    });
+}
+
 speckv_status_t speckv_ext_promote_to_l1(speckv_handle_t handle, uint64_t offset_bytes)
 {
     LOCK; NEED_INIT;

@@ -145,8 +145,12 @@ public:
     hipError_t upload_pinned(void* dst, const void* staged, size_t bytes, hipStream_t s);
     int attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uint32_t* pos_end, uint32_t max_pos_end, void* d_plan,
                           size_t plan_bytes, hipStream_t s);
+    // the position a caller still keeps outside the pool (speckv_ext_attend_planned_tail): fp16 rows [n_tail][layers][heads][128]
+    struct TailArgs { uint32_t n_tail; const uint32_t* d_tail_rows; const int32_t* d_tail_idx; const void* d_k_tail; const void* d_v_tail; uint64_t stride_elems; };
     int attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint32_t layer, const void* d_q_f16, uint32_t g,
-                       uint32_t max_pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
+                       uint32_t max_pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s, const TailArgs* tail = nullptr, uint32_t n_layers = 1);
+    int attend_planned_layers(int scheme, const void* d_plan, uint32_t n_seq, uint32_t layer_begin, uint32_t n_layers, const void* d_q_f16, uint32_t g,
+                              uint32_t max_pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s, const TailArgs* tail = nullptr);
     int attend_fold_tail(uint32_t n_rows, const uint32_t* d_rows, uint32_t heads, uint32_t g, const void* d_q_f16, const void* d_k_tail,
                          const void* d_v_tail, uint64_t tail_stride_elems, float sm_scale, float* d_out, float* d_lse, hipStream_t s);
     int write_strided_batch(const uint64_t* handles, const uint64_t* firsts, const void* const* d_srcs, uint32_t n_alloc, uint64_t step,
@@ -350,7 +354,7 @@ private:
     template <int N> struct PinnedRingT { void* base = nullptr; size_t slot_bytes = 0; hipEvent_t ev[N] = {}; int next = 0; };
     PinnedRingT<kSeqRingSlots> seq_ring_;
     PinnedRingT<4> grp_ring_;
-    struct PlanInfo { uint32_t n_seq; int scheme; uint32_t n_layers, max_pos_end; bool striped, table; uint32_t mx4_stripe_n_max; };
+    struct PlanInfo { uint32_t n_seq; int scheme; uint32_t n_layers, max_pos_end; bool striped, table; uint32_t mx4_stripe_n_max; bool any_empty; };
     std::unordered_map<const void*, PlanInfo> plans_;      // device plan buffer -> what attend_batch_plan last wrote there
     CompressGroup* d_groups_ = nullptr;    // device twin of grp_ring_ (4 slots): descriptors of a grouped compress launch
     uint8_t* d_zero_page_ = nullptr;     // stands in for never-written pages in the fused attention

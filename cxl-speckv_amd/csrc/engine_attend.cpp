@@ -487,7 +487,9 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_zero_page_), kPageSize));
         HIP_TRY(hipMemset(d_zero_page_, 0, kPageSize));
     }
-    plans_[d_plan] = PlanInfo{n_seq, scheme, min_layers, max_pos_end, any_striped, any_table, stripe_n_max};
+    bool any_empty = false;
+    for (uint32_t i = 0; i < n_seq; ++i) any_empty = any_empty || pos_end[i] == 0u;
+    plans_[d_plan] = PlanInfo{n_seq, scheme, min_layers, max_pos_end, any_striped, any_table, stripe_n_max, any_empty};
     uint64_t parts = 0;
     for (uint32_t i = 0; i < n_seq; ++i) {
         const uint32_t n_tiles = seqs[i].n_splits;
@@ -516,8 +518,30 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
     return SPECKV_OK;
 }
 
+// Several layers of a planned batch in one call (speckv_ext_attend_planned_layers): d_q_f16 [n_layers][n_seq][heads][g][128], d_out /
+// d_lse likewise.  MXFP4 with a geometry of one split per sequence: ONE launch over layers x sequences (the workgroups of the next
+// layer start while the last of this one drain: a batch of 256 x 2k is eight launches of 92 us, each a third fill and drain --
+// or one of 0.68 ms); anything else: the per-layer launches, from one call.
+int Engine::attend_planned_layers(int scheme, const void* d_plan, uint32_t n_seq, uint32_t layer_begin, uint32_t n_layers, const void* d_q_f16, uint32_t g,
+                                  uint32_t max_pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s, const TailArgs* tail)
+{
+    if (n_layers == 0 || n_seq == 0) return SPECKV_OK;
+    if (n_layers == 1) return attend_planned(scheme, d_plan, n_seq, layer_begin, d_q_f16, g, max_pos_end, sm_scale, d_out, d_lse, s, tail);
+    if (g == 0 || g > 16) return SPECKV_ERR_INVAL;
+    const auto plan = plans_.find(d_plan);
+    const bool one_launch = scheme == SPECKV_COMP_MXFP4 && plan != plans_.end() && layer_begin + n_layers <= plan->second.n_layers &&
+                            static_cast<uint64_t>(n_seq) * n_layers <= 65535u && tuning().attend_layers_loop == 0 &&
+                            plan_geometry(false, n_seq, 8, max_pos_end, cus(), true, plan->second.mx4_stripe_n_max).max_splits == 1u;
+    if (one_launch) return attend_planned(scheme, d_plan, n_seq, layer_begin, d_q_f16, g, max_pos_end, sm_scale, d_out, d_lse, s, tail, n_layers);
+    const size_t rows = static_cast<size_t>(n_seq) * 8u * g;
+    for (uint32_t l = 0; l < n_layers; ++l)
+        RC_TRY(attend_planned(scheme, d_plan, n_seq, layer_begin + l, static_cast<const uint16_t*>(d_q_f16) + l * rows * 128u, g, max_pos_end, sm_scale,
+                              d_out + l * rows * 128u, d_lse ? d_lse + l * rows : nullptr, s, tail));
+    return SPECKV_OK;
+}
+
 int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint32_t layer, const void* d_q_f16, uint32_t g,
-                           uint32_t max_pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
+                           uint32_t max_pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s, const TailArgs* tail, uint32_t n_layers)
 {
     const bool fp8 = scheme == SPECKV_COMP_FP8_E4M3, mx4 = scheme == SPECKV_COMP_MXFP4;
     if (null_) return no_data_path("speckv_ext_attend_*_planned");
@@ -526,7 +550,7 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
     const uint32_t heads = 8;                                  // the page-wise layout: 8 kv heads x 128
     const auto plan = plans_.find(d_plan);                     // what speckv_ext_attend_batch_plan last wrote there
     if (plan == plans_.end() || plan->second.n_seq != n_seq || plan->second.scheme != scheme || plan->second.max_pos_end != max_pos_end ||
-        layer >= plan->second.n_layers) {
+        layer >= plan->second.n_layers || n_layers == 0 || n_layers > plan->second.n_layers - layer) {
         SPECKV_ERR("speckv_ext_attend_*_planned: no plan of this shape at %p (n_seq, format and max_pos_end as planned, layer inside every layout)", d_plan);
         return SPECKV_ERR_INVAL;
     }
@@ -559,13 +583,40 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
         tuning().attend_mx4_one_half == 0)
         k.mx4_halves = 1u;                                     // (see attend_batch)
     if (pg.unequal.on) k.rows_first = 1u;
+    // The position the caller still holds outside the pool (TailArgs: a connector's odd last position).  MXFP4: folded in by the
+    // attention kernel's own epilogue (split 0 of every sequence) -- needs a lse to be of use to nobody else, a batch without an
+    // empty member (an empty sequence has no split to fold into) and the tail index by sequence; otherwise, and for the other
+    // formats, one k_attend_fold_tail launch behind the attention, as the connector used to issue itself.
+    const bool have_tail = tail && tail->n_tail != 0u;
+    if (have_tail && (!tail->d_k_tail || !tail->d_v_tail || !d_lse || tail->stride_elems % 8u || tail->stride_elems < static_cast<uint64_t>(layer + 1u) * heads * 128u))
+        return SPECKV_ERR_INVAL;
+    const bool fold_in_kernel = have_tail && mx4 && !plan->second.any_empty && (tail->d_tail_idx || tail->n_tail == n_seq) && tuning().attend_fold_launch == 0;
+    if (n_layers > 1u) {                                       // (attend_planned_layers checked the geometry: MXFP4, one split per sequence)
+        if (!mx4 || pg.max_splits != 1u) return SPECKV_ERR_INVAL;
+        k.batch_n_seq = n_seq;
+    }
+    if (fold_in_kernel) {
+        k.tail_k = static_cast<const uint16_t*>(tail->d_k_tail);
+        k.tail_v = static_cast<const uint16_t*>(tail->d_v_tail);
+        k.tail_idx = tail->n_tail == n_seq && !tail->d_tail_idx ? nullptr : tail->d_tail_idx;
+        k.tail_stride = tail->stride_elems;
+    }
     if (fp8) {
         HIP_TRY(launch_attend_fp8_batch(k, n_seq, d_out, d_lse, s));
     } else if (mx4) {
-        HIP_TRY(launch_attend_mx4(k, n_seq, d_out, d_lse, s));
+        HIP_TRY(launch_attend_mx4(k, n_seq * n_layers, d_out, d_lse, s));
     } else {
         HIP_TRY(launch_attend_int4(k, n_seq, s));
         if (k.direct_per_seq != 2u) HIP_TRY(launch_attend_combine(k, n_seq, d_out, d_lse, s));
+    }
+    if (have_tail && !fold_in_kernel) {
+        const size_t rows = static_cast<size_t>(n_seq) * heads * g;
+        for (uint32_t l = 0; l < n_layers; ++l) {
+            const uint64_t off = static_cast<uint64_t>(layer + l) * heads * 128u;
+            HIP_TRY(launch_attend_fold_tail(tail->n_tail, tail->n_tail == n_seq ? nullptr : tail->d_tail_rows, heads, g, static_cast<const uint16_t*>(d_q_f16) + l * rows * 128u,
+                                            static_cast<const uint16_t*>(tail->d_k_tail) + off, static_cast<const uint16_t*>(tail->d_v_tail) + off, tail->stride_elems,
+                                            sm_scale, d_out + l * rows * 128u, d_lse + l * rows, s));
+        }
     }
     return SPECKV_OK;
 }

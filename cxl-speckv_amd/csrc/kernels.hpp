@@ -299,6 +299,10 @@ struct AttendArgs {
     // positions are zeroed by the attention kernel itself (attend_zero_rows)
     uint32_t batch_layer;
     uint32_t direct_per_seq;
+    // ... and SEVERAL layers of the planned batch in one launch (speckv_ext_attend_planned_layers: callers that have the query rows of
+    // several layers at once): batch_n_seq != 0 -> grid y = layer x sequence, row block y of q / out / lse = [layer][sequence], layer
+    // batch_layer + y / batch_n_seq.  Only launches whose geometry has one split per sequence (direct_per_seq == 2: no merge behind).
+    uint32_t batch_n_seq;
     // striped form (lin_base == nullptr, stripe_bases != nullptr): the allocation still has the regular placement over
     // 2..8 pools -- the record of page p is stripe_bases[p % stripe_n] + (p / stripe_n) * record stride (placement.hpp),
     // never-written records zero bytes -- so every address is arithmetic here too; stripe_magic = floor(2^32 / n) + 1:
@@ -320,6 +324,15 @@ struct AttendArgs {
     // ... and its STREAM form for many layers of one sequence (see k_attend_int4_wg8): n_wgs != 0 turns it on.  The rows'
     // partials then sit at (row * max_slots + slot) and the merge takes each row's count from attend_stream_count().
     struct Stream { uint32_t len, rem, n_wgs, max_slots; } stream;
+    // planned batches, MXFP4: the position a sequence still keeps OUTSIDE the pool (the connector's odd last position, fp16 rows
+    // [tail][layers][heads][128], tail_stride elements apart) is folded in by the attention kernel itself -- by the workgroup of
+    // split 0, into its partial or final state, in the epilogue -- instead of by a launch of its own behind every layer's attention.
+    // tail_idx[sequence] = index of its tail rows, < 0: none; null with tail_k set: sequence i has tail i.  Every sequence of such a
+    // launch has at least one split (the engine sends batches with an empty member through k_attend_fold_tail as before).
+    const uint16_t* tail_k;
+    const uint16_t* tail_v;
+    const int32_t* tail_idx;
+    uint64_t tail_stride;
 };
 // The stream partition: `total` tiles in layer-major order cut into n_wgs contiguous pieces, the first `rem` one longer
 // (len = total / n_wgs >= 1, rem = total % n_wgs).  begin(w) = first tile of piece w; wg_of(G) = the piece tile G is in.

@@ -13,6 +13,8 @@ const Key kKeys[] = {
     {"attend_splits", "SPECKV_ATTEND_SPLITS", &Tuning::attend_splits},
     {"attend_tiles_per_split", "SPECKV_ATTEND_TILES_PER_SPLIT", &Tuning::attend_tiles_per_split},
     {"attend_general", "SPECKV_ATTEND_GENERAL", &Tuning::attend_general},
+    {"attend_fold_launch", "SPECKV_ATTEND_FOLD_LAUNCH", &Tuning::attend_fold_launch},
+    {"attend_layers_loop", "SPECKV_ATTEND_LAYERS_LOOP", &Tuning::attend_layers_loop},
     {"attend_stream", "SPECKV_ATTEND_STREAM", &Tuning::attend_stream},
     {"attend_mx4_one_half", "SPECKV_ATTEND_MX4_ONE_HALF", &Tuning::attend_mx4_one_half},
     {"tc_multipass", "SPECKV_TC_MULTIPASS", &Tuning::tc_multipass},

@@ -82,7 +82,7 @@ class SpeckvKVConnector:
         self._fold_key = self._arg_key = None
         self._plan = None                                     # device buffer of the step's attention plan
         self._plan_bound = 0
-        self._fold_rows = self._fold_k = self._fold_v = None
+        self._fold_rows = self._fold_idx = self._fold_k = self._fold_v = None
         self._fold_n = 0
         # host-side bookkeeping of a decode loop is per STEP, not per layer: `_epoch` moves whenever a length or the set of
         # requests changes, and everything derived from (batch, lengths) -- the attention plan, the fold rows, the ctypes
@@ -285,6 +285,8 @@ class SpeckvKVConnector:
             try:
                 if not self.lib.stream_is_capturing(st.cuda_stream):
                     self.plan_step(req_ids, st)
+                    key, reqs, _ = self._batch(req_ids)
+                    self._prepare_tails(req_ids, key, reqs, st)   # (and which rows carry a tail into the next step: 40 us of host time off its start)
                 else:
                     self._arg_key = self._plan_stream = None
             except SpeckvError as e:
@@ -364,22 +366,57 @@ class SpeckvKVConnector:
         self._plan_bound = bound
         return bound
 
+    def _prepare_tails(self, req_ids, key, reqs, st):
+        """Which sequences of the batch keep a position outside the pool, and their fp16 rows as one tensor per kind: the same for every
+        layer of a step, so it is set up once per (batch, epoch) -- by append(), while the host is ahead of the GPU, for the step that
+        follows; by the first attend() otherwise."""
+        import torch
+        akey = (key, self._epoch)
+        if self._fold_key == akey:
+            return
+        B = len(reqs)
+        odd = [b for b, r in enumerate(reqs) if r.length & 1]
+        self._fold_key, self._fold_n = akey, len(odd)
+        self._fold_rows = self._fold_idx = self._fold_k = self._fold_v = None
+        if odd:
+            with torch.cuda.stream(st):
+                if len(odd) != B:
+                    self._fold_rows = _device_index(odd)
+                    inv = [-1] * B
+                    for i, b in enumerate(odd):
+                        inv[b] = i
+                    self._fold_idx = _device_index(inv)
+                if tuple(req_ids[b] for b in odd) == self._tail_ids:
+                    self._fold_k, self._fold_v = self._tail_k, self._tail_v                 # [n][layers][heads][dim]
+                else:
+                    self._fold_k = torch.stack([reqs[b].tail_k for b in odd]).contiguous()
+                    self._fold_v = torch.stack([reqs[b].tail_v for b in odd]).contiguous()
+
     def attend(self, layer: int, req_ids: Sequence[int], q, sm_scale: float, stream=None):
         """softmax(q.K^T * sm_scale).V of one layer for the batch.  q: [batch][heads][g][dim] fp16 (g query rows per kv
         head, GQA); returns [batch][heads][g][dim] fp32.  Stored positions come straight from the compressed records
-        (one launch pair for the batch), the tail position is folded in with the log-sum-exp."""
+        (one launch pair for the batch); the position still waiting for its partner goes along in the same call
+        (speckv_ext_attend_planned_tail: folded in by the MXFP4 kernel itself, by one launch inside the call otherwise)."""
+        return self.attend_layers(layer, 1, req_ids, q[None], sm_scale, stream)[0]
+
+    def attend_layers(self, layer_begin: int, n_layers: int, req_ids: Sequence[int], q, sm_scale: float, stream=None):
+        """The same for n_layers consecutive layers whose query rows exist at once (speckv_ext_attend_planned_layers): q
+        [n_layers][batch][heads][g][dim] fp16, returns [n_layers][batch][heads][g][dim] fp32.  One library call; over an MXFP4 pool
+        with a batch that fills the chip, one launch."""
         import torch
         if self.scheme not in FUSED:
             raise ValueError("attend() needs an FP8, INT4 or MXFP4 pool; use block_table() / kv_rows() with the other schemes")
-        B, H, G, D = q.shape
+        NL, B, H, G, D = q.shape
+        if NL != n_layers:
+            raise ValueError("q must be [n_layers][batch][heads][g][dim]")
         key, reqs, _ = self._batch(req_ids)
         if self._kscale is not None:
-            q = q * self._kscale[layer][None, :, None, :]
+            q = q * self._kscale[layer_begin:layer_begin + n_layers][:, None, :, None, :]
         q = q.contiguous()
-        out = torch.empty((B, H, G, D), dtype=torch.float32, device="cuda")
-        lse = torch.empty((B, H, G), dtype=torch.float32, device="cuda")
+        out = torch.empty((NL, B, H, G, D), dtype=torch.float32, device="cuda")
+        lse = torch.empty((NL, B, H, G), dtype=torch.float32, device="cuda")
         # One plan per decode step (speckv_ext_attend_batch_plan: handle look-ups and descriptors once, resident on the
-        # device), then one launch-only call per layer (speckv_ext_attend_*_planned).  The length bound moves in steps of
+        # device), then launch-only calls (speckv_ext_attend_*_planned*).  The length bound moves in steps of
         # PLAN_BUCKET positions, so a caller that captures its per-layer calls into a HIP graph can replay that graph for
         # PLAN_BUCKET decode steps (plan_step() outside the graph, then the replay).
         akey = (key, self._epoch)
@@ -387,26 +424,19 @@ class SpeckvKVConnector:
             if self._arg_key != (akey, st.cuda_stream):
                 self.plan_step(req_ids, st)
             self._plan_stream = st
-            self.lib.attend_planned(self.scheme, self._plan.data_ptr(), B, layer, q.data_ptr(), G, self._plan_bound, sm_scale,
-                                    out.data_ptr(), lse.data_ptr(), st.cuda_stream)
-            # the position still waiting for its partner: folded into out / lse by one launch for the batch
-            # (speckv_ext_attend_fold_tail).  Which rows have a tail is the same for every layer of the step.
-            if self._fold_key != akey:
-                odd = [b for b, r in enumerate(reqs) if r.length & 1]
-                self._fold_key, self._fold_n = akey, len(odd)
-                self._fold_rows = self._fold_k = self._fold_v = None
-                if odd:
-                    with torch.cuda.stream(st):
-                        self._fold_rows = None if len(odd) == B else _device_index(odd)
-                        if tuple(req_ids[b] for b in odd) == self._tail_ids:
-                            self._fold_k, self._fold_v = self._tail_k, self._tail_v                 # [n][layers][heads][dim]
-                        else:
-                            self._fold_k = torch.stack([reqs[b].tail_k for b in odd]).contiguous()
-                            self._fold_v = torch.stack([reqs[b].tail_v for b in odd]).contiguous()
-            if self._fold_n:
-                row_bytes = self.H * self.D * 2
-                self.lib.attend_fold_tail(self._fold_n, self._fold_rows.data_ptr() if self._fold_rows is not None else 0, H, G,
-                                          q.data_ptr(), self._fold_k.data_ptr() + layer * row_bytes,
-                                          self._fold_v.data_ptr() + layer * row_bytes, self.L * self.H * self.D, sm_scale,
-                                          out.data_ptr(), lse.data_ptr(), st.cuda_stream)
+            self._prepare_tails(req_ids, key, reqs, st)
+            n_tail = self._fold_n
+            rows = self._fold_rows.data_ptr() if n_tail and self._fold_rows is not None else 0
+            idx = self._fold_idx.data_ptr() if n_tail and self._fold_idx is not None else 0
+            kt = self._fold_k.data_ptr() if n_tail else 0
+            vt = self._fold_v.data_ptr() if n_tail else 0
+            if n_layers == 1 and not n_tail:
+                self.lib.attend_planned(self.scheme, self._plan.data_ptr(), B, layer_begin, q.data_ptr(), G, self._plan_bound, sm_scale,
+                                        out.data_ptr(), lse.data_ptr(), st.cuda_stream)
+            elif n_layers == 1:
+                self.lib.attend_planned_tail(self.scheme, self._plan.data_ptr(), B, layer_begin, q.data_ptr(), G, self._plan_bound, sm_scale,
+                                             out.data_ptr(), lse.data_ptr(), n_tail, rows, idx, kt, vt, self.L * self.H * self.D, st.cuda_stream)
+            else:
+                self.lib.attend_planned_layers(self.scheme, self._plan.data_ptr(), B, layer_begin, n_layers, q.data_ptr(), G, self._plan_bound, sm_scale,
+                                               out.data_ptr(), lse.data_ptr(), st.cuda_stream, n_tail, rows, idx, kt, vt, self.L * self.H * self.D)
         return out

@@ -90,6 +90,10 @@ _EXT_SIGNATURES = {
     "speckv_ext_attend_mx4": [c_uint64, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, c_uint32, ctypes.c_float, c_void_p, c_void_p, c_void_p],
     "speckv_ext_attend_mx4_batch": [c_uint32, ctypes.POINTER(c_uint64), c_uint32, c_void_p, c_uint32, _u32p, ctypes.c_float, c_void_p, c_void_p, c_void_p],
     "speckv_ext_attend_mx4_planned": [c_void_p, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, ctypes.c_float, c_void_p, c_void_p, c_void_p],
+    "speckv_ext_attend_planned_layers": [c_int, c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, ctypes.c_float, c_void_p, c_void_p, c_uint32,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p],
+    "speckv_ext_attend_planned_tail": [c_int, c_void_p, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, ctypes.c_float, c_void_p, c_void_p, c_uint32,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p],
     "speckv_ext_promote_to_l1": [c_uint64, c_uint64],
     "speckv_ext_demote_to_l3": [c_uint64, c_uint64],
     "speckv_ext_migrate": [c_uint64, c_uint64, c_uint64, c_uint32],
@@ -397,6 +401,21 @@ class SpeckvLib:
         name = {4: "speckv_ext_attend_fp8_planned", 3: "speckv_ext_attend_int4_planned", 5: "speckv_ext_attend_mx4_planned"}[scheme]
         self._ext(name, c_void_p(d_plan), n_seq, layer, c_void_p(d_q_f16), g, max_pos_end, ctypes.c_float(sm_scale),
                   c_void_p(d_out), c_void_p(d_lse or 0), c_void_p(stream))
+
+    def attend_planned_layers(self, scheme, d_plan, n_seq, layer_begin, n_layers, d_q_f16, g, max_pos_end, sm_scale, d_out, d_lse, stream, n_tail=0,
+                              d_tail_rows=0, d_tail_idx=0, d_k_tail=0, d_v_tail=0, tail_stride_elems=0):
+        """Several layers of a planned batch in one call: q [n_layers][n_seq][heads][g][128], out / lse likewise."""
+        self._ext("speckv_ext_attend_planned_layers", scheme, c_void_p(d_plan), n_seq, layer_begin, n_layers, c_void_p(d_q_f16), g, max_pos_end,
+                  ctypes.c_float(sm_scale), c_void_p(d_out), c_void_p(d_lse or 0), n_tail, c_void_p(d_tail_rows or 0), c_void_p(d_tail_idx or 0),
+                  c_void_p(d_k_tail or 0), c_void_p(d_v_tail or 0), tail_stride_elems, c_void_p(stream))
+
+    def attend_planned_tail(self, scheme, d_plan, n_seq, layer, d_q_f16, g, max_pos_end, sm_scale, d_out, d_lse, n_tail, d_tail_rows, d_tail_idx,
+                            d_k_tail, d_v_tail, tail_stride_elems, stream):
+        """attend_planned + the position still held outside the pool (fp16 rows [n_tail][layers][heads][128]) in one call: folded in by
+        the MXFP4 attention kernel itself, by one fold launch inside the call for the other formats."""
+        self._ext("speckv_ext_attend_planned_tail", scheme, c_void_p(d_plan), n_seq, layer, c_void_p(d_q_f16), g, max_pos_end, ctypes.c_float(sm_scale),
+                  c_void_p(d_out), c_void_p(d_lse), n_tail, c_void_p(d_tail_rows or 0), c_void_p(d_tail_idx or 0), c_void_p(d_k_tail or 0),
+                  c_void_p(d_v_tail or 0), tail_stride_elems, c_void_p(stream))
 
     def attend_int4(self, handle, layer_begin, n_layers, d_q_f16, g, pos_begin, pos_end, sm_scale, d_out, d_lse=None,
                     stream=None):

@@ -405,6 +405,33 @@ speckv_status_t speckv_ext_attend_int4_planned(const void* d_plan, uint32_t n_se
                                                uint32_t g, uint32_t max_pos_end, float sm_scale, float* d_out,
                                                float* d_lse, void* stream);
 
+/* A planned layer AND the position the caller still holds outside the pool, in one call (round 6: the connector used to issue
+ * speckv_ext_attend_fold_tail behind every layer's attention -- eight dependent launches of a few microseconds in an 8-layer step).
+ *   scheme        SPECKV_COMP_FP8_E4M3 / _INT4_G32 / _MXFP4 (the plan's)
+ *   n_tail        sequences of the batch that have such a position (0: exactly speckv_ext_attend_*_planned)
+ *   d_tail_rows   device array [n_tail] of their indices in the batch (NULL when n_tail == n_seq: tail i belongs to sequence i)
+ *   d_tail_idx    device array [n_seq]: index of the sequence's tail rows, < 0 = none (the inverse of d_tail_rows; may be NULL when
+ *                 n_tail == n_seq, or altogether -- then the fold is a launch of its own, below)
+ *   d_k_tail, d_v_tail  fp16 [n_tail][layers][heads][128] (the BASE of the arrays: `layer` selects the row), tails
+ *                 tail_stride_elems (a multiple of 8, >= layers * heads * 128) apart;  d_lse is required
+ * MXFP4 with d_tail_idx (or n_tail == n_seq) and no empty sequence in the plan: the attention kernel folds the position in itself,
+ * in the epilogue of each sequence's first split -- no launch behind it.  Otherwise one k_attend_fold_tail launch follows inside the
+ * call.  Either way the result is speckv_ext_attend_*_planned followed by speckv_ext_attend_fold_tail.  Capturable. */
+speckv_status_t speckv_ext_attend_planned_tail(int scheme, const void* d_plan, uint32_t n_seq, uint32_t layer, const void* d_q_f16,
+                                               uint32_t g, uint32_t max_pos_end, float sm_scale, float* d_out, float* d_lse,
+                                               uint32_t n_tail, const uint32_t* d_tail_rows, const int32_t* d_tail_idx,
+                                               const void* d_k_tail, const void* d_v_tail, uint64_t tail_stride_elems, void* stream);
+
+/* SEVERAL layers of a planned batch in one call, for callers that have the query rows of several layers at once (a draft model's
+ * layers, a benchmark, layers whose attention inputs do not depend on each other): d_q_f16 [n_layers][n_seq][heads][g][128], d_out and
+ * d_lse likewise; the tail arguments as speckv_ext_attend_planned_tail (n_tail == 0: none).  MXFP4 with a launch geometry of one split
+ * per sequence (a batch that fills the chip by itself): ONE launch over layers x sequences -- the next layer's workgroups start while
+ * the last of this one drain; everything else: the per-layer launches, issued from this one call.  Results equal the per-layer calls. */
+speckv_status_t speckv_ext_attend_planned_layers(int scheme, const void* d_plan, uint32_t n_seq, uint32_t layer_begin, uint32_t n_layers,
+                                                 const void* d_q_f16, uint32_t g, uint32_t max_pos_end, float sm_scale, float* d_out,
+                                                 float* d_lse, uint32_t n_tail, const uint32_t* d_tail_rows, const int32_t* d_tail_idx,
+                                                 const void* d_k_tail, const void* d_v_tail, uint64_t tail_stride_elems, void* stream);
+
 /* speckv_ext_attend_fold_tail: one more position for rows that already hold an attention result and its log-sum-exp
  * (speckv_ext_attend_* with d_lse) -- the fp16 K / V row a decode step produced but has not stored yet (pages hold
  * position PAIRS; a connector keeps the odd position until its partner arrives):
@@ -536,7 +563,8 @@ double speckv_ext_codec_model_throughput_gbps(uint32_t num_engines, double clock
  * tc_no_split_tiles, td_one_pass, td_expand_per_element, flush_no_small, flush_small_words, predict_batch_path, wgs_per_cu, tc_batch_one_wg (many-tensor launches: one workgroup per tensor),
  * rounds_consecutive, remote_engine (1 kernel, 2 copy engines), copy_min_run_kb, attend_stream (MXFP4, several layers of one
  * sequence: N > 0 the stream form with N workgroups, -1 never), attend_mx4_one_half (MXFP4 batches: 4-wave workgroups also where
- * the two-halves form applies).  0 restores the library's own rule.
+ * the two-halves form applies), attend_fold_launch (speckv_ext_attend_planned_tail: the fold always as a launch of its own), attend_layers_loop
+ * (speckv_ext_attend_planned_layers: always per-layer launches).  0 restores the library's own rule.
  * SPECKV_ERR_INVAL for an unknown key.  Works without speckv_init.  (INTEGRATION.md lists what each one does.) */
 speckv_status_t speckv_ext_set_tuning(const char* key, long long value);
 

@@ -839,3 +839,143 @@ def test_flush_of_a_256_sequence_decode_step_at_full_size(oracle):
         assert lib.prefetch_flush() == 0
     finally:
         lib.finalize()
+
+
+@pytest.mark.parametrize("scheme", [5, 4, 3])
+def test_planned_layer_with_the_tail_position_in_one_call(scheme):
+    """speckv_ext_attend_planned_tail = the planned layer followed by speckv_ext_attend_fold_tail, in one call: MXFP4 folds the position
+    in the attention kernel's own epilogue (single-split sequences: into the final rows; with real splits: into split 0's partial, in
+    front of the merge), the other formats by one fold launch inside the call.  Tails on some sequences only (index by sequence),
+    on all of them (no index needed), on none; a batch with an empty member takes the launch form; as a HIP graph."""
+    torch = torch_mod()
+    lib = open_lib()
+    try:
+        lib.set_compression_scheme(scheme)
+        T, L, H, D, G = 1024, 2, 8, 128, 8
+        rng = np.random.default_rng(300 + scheme)
+        lens_list = ([64, 1024, 34, 600], [64, 1024, 0, 600])
+        n_seq = 4
+        handles = []
+        for _ in range(n_seq):
+            h = lib.alloc(T * L * H * D * 2 * 2)
+            lib.set_layout(h, T, L, H, D, 2)
+            n_pages = T * L * H * D * 2 * 2 // PAGE
+            x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.2, 2.0, (n_pages, 1))).astype(np.float16)
+            lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+            handles.append(h)
+        sm = 1.0 / np.sqrt(D)
+        q = torch.from_numpy(rng.standard_normal((L, n_seq, H, G, D)).astype(np.float16)).cuda()
+        kt = torch.from_numpy((rng.standard_normal((n_seq, L, H, D)) * 1.5).astype(np.float16)).cuda()
+        vt = torch.from_numpy(rng.standard_normal((n_seq, L, H, D)).astype(np.float16)).cuda()
+        plan_bytes = lib.attend_plan_bytes(n_seq)
+        plan = torch.zeros(plan_bytes, dtype=torch.uint8, device="cuda")
+        s = torch.cuda.Stream()
+        stride = L * H * D
+
+        def both(layer, lens, rows, tps):
+            """(separate calls, one call) for tails on the sequences `rows`"""
+            set_tuning("attend_tiles_per_split", tps)
+            try:
+                lib.attend_batch_plan(handles, lens, T, plan.data_ptr(), plan_bytes, s.cuda_stream)
+                res = []
+                n_tail = len(rows)
+                d_rows = torch.tensor(rows, dtype=torch.int32).cuda() if 0 < n_tail < n_seq else None
+                inv = [-1] * n_seq
+                for i, b in enumerate(rows): inv[b] = i
+                d_idx = torch.tensor(inv, dtype=torch.int32).cuda() if 0 < n_tail < n_seq else None
+                kk = kt[rows].contiguous() if n_tail else kt; vv = vt[rows].contiguous() if n_tail else vt
+                for one_call in (False, True):
+                    out = torch.full((n_seq, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
+                    lse = torch.full((n_seq, H, G), float("nan"), dtype=torch.float32, device="cuda")
+                    if one_call:
+                        lib.attend_planned_tail(scheme, plan.data_ptr(), n_seq, layer, q[layer].data_ptr(), G, T, sm, out.data_ptr(), lse.data_ptr(), n_tail,
+                                                d_rows.data_ptr() if d_rows is not None else 0, d_idx.data_ptr() if d_idx is not None else 0,
+                                                kk.data_ptr(), vv.data_ptr(), stride, s.cuda_stream)
+                    else:
+                        lib.attend_planned(scheme, plan.data_ptr(), n_seq, layer, q[layer].data_ptr(), G, T, sm, out.data_ptr(), lse.data_ptr(), s.cuda_stream)
+                        if n_tail:
+                            lib.attend_fold_tail(n_tail, d_rows.data_ptr() if d_rows is not None else 0, H, G, q[layer].data_ptr(),
+                                                 kk.data_ptr() + layer * H * D * 2, vv.data_ptr() + layer * H * D * 2, stride, sm, out.data_ptr(), lse.data_ptr(),
+                                                 s.cuda_stream)
+                    s.synchronize()
+                    res.append((out.cpu().numpy(), lse.cpu().numpy()))
+                return res
+            finally:
+                set_tuning("attend_tiles_per_split", 0)
+
+        for lens in lens_list:
+            for rows in ([0, 1, 2, 3], [1, 3], [2], []):
+                for tps in (0, 4):                                  # the rule's geometry (one split each here), and real splits with a merge behind
+                    for layer in range(L):
+                        (o0, l0), (o1, l1) = both(layer, lens, rows, tps)
+                        assert np.isfinite(o1).all() and not np.isnan(l1).any()
+                        scale = np.abs(o0).max(axis=-1, keepdims=True) + 1e-6
+                        assert np.all(np.abs(o1 - o0) <= 2e-3 * scale + 1e-6), (scheme, lens, rows, tps, layer, float(np.abs(o1 - o0).max()))
+                        fin = np.isfinite(l0)
+                        assert np.array_equal(fin, np.isfinite(l1)) and np.all(np.abs(l1[fin] - l0[fin]) <= 2e-3), (scheme, lens, rows, tps, layer)
+        # the launch form on request gives the same again (what the one call does for FP8 / INT4 anyway)
+        set_tuning("attend_fold_launch", 1)
+        try:
+            (o0, l0), (o1, l1) = both(1, lens_list[0], [1, 3], 0)
+            assert np.allclose(o0, o1, rtol=0, atol=1e-6) and np.allclose(l0, l1, rtol=0, atol=1e-6)
+        finally:
+            set_tuning("attend_fold_launch", 0)
+        # captured: the one call replays with the tail rows read at replay time
+        lib.attend_batch_plan(handles, lens_list[0], T, plan.data_ptr(), plan_bytes, s.cuda_stream)
+        out = torch.zeros((n_seq, H, G, D), dtype=torch.float32, device="cuda"); lse = torch.zeros((n_seq, H, G), dtype=torch.float32, device="cuda")
+        call = lambda: lib.attend_planned_tail(scheme, plan.data_ptr(), n_seq, 0, q[0].data_ptr(), G, T, sm, out.data_ptr(), lse.data_ptr(), n_seq, 0, 0,
+                                               kt.data_ptr(), vt.data_ptr(), stride, s.cuda_stream)
+        call(); s.synchronize()
+        want = out.clone()
+        g = torch.cuda.CUDAGraph()
+        with graph_capture(g, s):
+            call()
+        out.zero_()
+        g.replay(); torch.cuda.synchronize()
+        assert torch.equal(out, want)
+    finally:
+        lib.finalize()
+
+
+@pytest.mark.parametrize("scheme", ["mxfp4", "fp8", "int4"])
+def test_connector_layers_in_one_call_equal_the_per_layer_calls(scheme):
+    """SpeckvKVConnector.attend_layers (speckv_ext_attend_planned_layers): all layers of a step in one library call -- over an MXFP4 pool
+    with one split per sequence ONE launch over layers x sequences, tails folded in by the kernel; per-layer launches from the one call
+    otherwise -- equals attend() layer by layer: even and odd lengths (some sequences with a tail, all, none), bit for bit where the
+    same kernels run (the loop form), within the tolerance of another summation order nowhere (the one-launch form runs the same
+    workgroups on the same data)."""
+    torch = torch_mod()
+    from cxl_speckv_amd.kv_connector import SpeckvKVConnector
+    lib = open_lib()
+    try:
+        L, H, D, G, T = 3, 8, 128, 8, 512
+        conn = SpeckvKVConnector(lib, num_layers=L, num_kv_heads=H, head_dim=D, max_tokens=T, scheme=scheme)
+        gen = torch.Generator(device="cuda"); gen.manual_seed(15)
+        rnd = lambda *s: torch.randn(s, generator=gen, device="cuda", dtype=torch.float32).to(torch.float16)
+        rids, prompt = [3, 4, 5, 6], [37, 64, 130, 2]
+        for rid, n in zip(rids, prompt):
+            conn.add_request(rid)
+            conn.write_prefill(rid, rnd(L, n, H, D), rnd(L, n, H, D))
+        sm = 1.0 / np.sqrt(D)
+        keep = []
+        for step in range(4):
+            q = rnd(L, len(rids), H, G, D)
+            for loop in (0, 1):
+                set_tuning("attend_layers_loop", loop)
+                try:
+                    got = conn.attend_layers(0, L, rids, q, sm)
+                finally:
+                    set_tuning("attend_layers_loop", 0)
+                torch.cuda.synchronize()
+                for layer in range(L):
+                    one = conn.attend(layer, rids, q[layer], sm)
+                    torch.cuda.synchronize()
+                    assert torch.equal(got[layer], one), (scheme, step, loop, layer, float((got[layer] - one).abs().max()))
+            part = conn.attend_layers(1, 2, rids, q[1:], sm)                   # a sub-range of the layers
+            torch.cuda.synchronize()
+            assert torch.equal(part[1], conn.attend(2, rids, q[2], sm))
+            keep += conn.append(rids, rnd(len(rids), L, H, D), rnd(len(rids), L, H, D))
+        for rid in rids:
+            conn.free_request(rid)
+    finally:
+        lib.finalize()
