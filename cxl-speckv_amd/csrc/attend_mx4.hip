@@ -68,6 +68,7 @@ constexpr uint32_t kStK = 0, kStV = 4096, kStKC = 8192, kStVC = 8448, kStage = 8
 #define MX4_STAGES 3          // (2: two workgroups per CU fit; measured 0.71-0.75 of the HBM roofline against 0.73-0.77 with 3 and one workgroup per CU)
 #endif
 constexpr uint32_t kStagesDefault = MX4_STAGES;              // tiles a wave keeps in LDS: the one it works on and kStages - 1 on their way
+constexpr uint32_t kTabEnt = 2u * 512u;                      // page-table form: the 32 entries (16 K pages, 16 V pages) of a tile, for the two tiles ahead
 
 template <typename T> __device__ __forceinline__ T* uniform_ptr(T* p)
 {
@@ -87,6 +88,19 @@ __device__ __forceinline__ void dma4(uint32_t lds_dst, const uint8_t* base, uint
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3 nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(base) : "memory");
+}
+// the same with a full address per lane (page-table form: every row of a tile may lie anywhere)
+__device__ __forceinline__ void dma16v(uint32_t lds_dst, const uint8_t* addr)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(addr) : "memory");
+}
+__device__ __forceinline__ void dma4v(uint32_t lds_dst, const uint8_t* addr)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(addr) : "memory");
 }
 // a region's share of a tile in one statement: four 1 KiB pieces of rows + the codes; M0 saved and restored once
 __device__ __forceinline__ void dma_region(uint32_t lds_rows, uint32_t lds_codes, const uint8_t* base, const uint32_t (&goff)[4], uint32_t goffc)
@@ -163,9 +177,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg * HALVES) __attribute__((amdgpu_wa
 {
     constexpr uint32_t kStages = HALVES == 2 ? 2u : kStagesDefault;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];                  // kWavesPerWg x 2 stages (68 KiB: beyond the static limit)
-    // (the page-table form works on one tile at a time with nothing in flight: ONE stage per wave, and two workgroups per CU
-    // hide one another's round trips instead -- 0.33 of the HBM roofline with one workgroup per CU)
-    constexpr uint32_t kWaveLds = (FORM == 2 ? 1u : kStages) * kStage;
+    // (the page-table form: two stages per wave + two small buffers of page-table entries, two workgroups per CU: below)
+    constexpr uint32_t kWaveLds = FORM == 2 ? 2u * kStage + kTabEnt : kStages * kStage;
     uint8_t (*lds)[kWaveLds] = reinterpret_cast<uint8_t (*)[kWaveLds]>(lds_dyn);
     __shared__ uint64_t s_bases[8];
     const uint32_t lane = threadIdx.x & 63u;
@@ -201,7 +214,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg * HALVES) __attribute__((amdgpu_wa
             seq = layer - li * a.batch_n_seq;
             a.batch_layer += li;
         }
-        if (a.tail_k && split == 0u) tail = a.tail_idx ? a.tail_idx[seq] : static_cast<int32_t>(seq);
+        // (not the page-table form: it sits at the register limit of two waves per SIMD; the engine sends its tails through k_attend_fold_tail)
+        if (FORM != 2 && a.tail_k && split == 0u) tail = a.tail_idx ? a.tail_idx[seq] : static_cast<int32_t>(seq);
         const AttendSeq sq = a.seqs[seq];
         if (split >= sq.n_splits) {
             if (sq.n_splits == 0u && split == 0u && blockIdx.z == 0u && a.direct_out && a.direct_per_seq == 2u) {
@@ -343,12 +357,40 @@ __global__ __launch_bounds__(64 * kWavesPerWg * HALVES) __attribute__((amdgpu_wa
         };
         const uint32_t kfirst = static_cast<uint32_t>(a.k_first), vfirst = static_cast<uint32_t>(a.v_first), last_pg = a.n_pages - 1u;
         const uint32_t last = t1 - 1u;
-        // FORM 2: record of a page of the range = {nibble row, its codes' distance behind it} (never-written pages: the zero page, 1024)
-        auto rec_of = [&](uint32_t first, uint32_t page_in_range, uint32_t& code_delta) -> const uint8_t* {
-            const u32x4 e = *MX_GP(u32x4, a.entries + (first + min(page_in_range, last_pg)));      // {address lo, hi, record bytes, code delta}
-            const uint8_t* r = reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(e.x) | (static_cast<uint64_t>(e.y) << 32));
-            code_delta = e.z >= kMx4RecBytes ? e.w : 1024u;
-            return e.z >= kMx4RecBytes ? r : a.zero_page;
+        // FORM 2 (page table): the 32 entries of a tile -- lane l < 16: K page l of the tile, lanes 16 .. 31: V page l - 16 -- are fetched
+        // two tiles ahead with one load per wave, parked in LDS, and read back from there by the lanes that need them when the tile's
+        // ten LDS-DMAs go out (one tile ahead, a full address per lane).  The entry load is inline assembly and waited for by hand
+        // at the END of a tile's arithmetic, together with the next tile's DMAs: nothing of this is the compiler's to count.
+        const uint32_t ent_lds = lbase + 2u * kStage;
+        auto ent_fetch = [&](uint32_t tt) -> u32x4 {
+            const uint32_t idx = lane & 31u, pg = min(16u * min(tt, last) + (idx & 15u), last_pg);
+            const PageEntry* ep = a.entries + ((idx < 16u ? kfirst : vfirst) + pg);
+            u32x4 e;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(e) : "v"(ep) : "memory");
+            return e;
+        };
+        auto ent_store = [&](uint32_t eb, const u32x4 e) {                                 // (lanes 32 .. 63 repeat lanes 0 .. 31: same bytes)
+            asm volatile("ds_write_b128 %0, %1" :: "v"(ent_lds + eb * 512u + (lane & 31u) * 16u), "v"(e) : "memory");
+        };
+        auto issue_table_tile = [&](uint32_t sbuf, uint32_t eb) __attribute__((always_inline)) {
+            const uint8_t* eb_ptr = lptr + 2u * kStage + eb * 512u;
+            const uint32_t dst = lbase + sbuf * kStage;
+            // (rolled: unrolled, the ten entries were all read up front -- 40 registers on top of a kernel that sits at the 256 of two
+            //  waves per SIMD)
+#pragma unroll 1
+            for (uint32_t rg = 0; rg < 2u; ++rg) {
+#pragma unroll 1
+                for (uint32_t i = 0; i < 4u; ++i) {
+                    const u32x4 e = *reinterpret_cast<const u32x4*>(eb_ptr + (rg * 16u + 4u * i + srow) * 16u);      // {address lo, hi, record bytes, code delta}
+                    const uint8_t* r = reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(e.x) | (static_cast<uint64_t>(e.y) << 32));
+                    r = e.z >= kMx4RecBytes ? r : a.zero_page;                                                       // never written: zeros
+                    dma16v(dst + (rg ? kStV : kStK) + 1024u * i, r + h0 * 128u + ((sslot ^ ((4u * i + srow) & 15u)) * 16u));
+                }
+                const u32x4 e = *reinterpret_cast<const u32x4*>(eb_ptr + (rg * 16u + (lane >> 2)) * 16u);
+                const bool ok = e.z >= kMx4RecBytes;
+                const uint8_t* r = ok ? reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(e.x) | (static_cast<uint64_t>(e.y) << 32)) : a.zero_page;
+                dma4v(dst + (rg ? kStVC : kStKC), r + (ok ? e.w : 1024u) + h0 * 8u + (lane & 3u) * 4u);
+            }
         };
         // stream form: the next tile each region (K, V) will ask for -- its first page, its tile number in the layer, tiles left
         // in the piece; the requests run ahead of the arithmetic across layer boundaries, a request past the piece repeats the last
@@ -397,26 +439,21 @@ __global__ __launch_bounds__(64 * kWavesPerWg * HALVES) __attribute__((amdgpu_wa
                 const uint64_t R = static_cast<uint64_t>(first) + 16ull * tc;
                 const uint8_t* rt = a.lin_base + mx4_nib_off(R);                  // (scalar)
                 issue(drows, dcodes, rt, first & 15u, 15u);
-            } else {
-                // page-table form: through registers, synchronously (the slow path of odd ranges and migrated allocations)
-                uint8_t* d = const_cast<uint8_t*>(lptr) + buf * kStage;
-                uint32_t cd;
-#pragma unroll
-                for (uint32_t i = 0; i < 4; ++i) {
-                    const uint8_t* r = rec_of(first, 16u * tc + 4u * i + srow, cd);
-                    *reinterpret_cast<u32x4*>(d + (rg ? kStV : kStK) + 1024u * i + 16u * lane) =
-                        *MX_GP(u32x4, r + h0 * 128u + ((sslot ^ ((4u * i + srow) & 15u)) * 16u));
-                }
-                const uint8_t* r = rec_of(first, 16u * tc + (lane >> 2), cd);
-                *reinterpret_cast<uint32_t*>(d + (rg ? kStVC : kStKC) + 4u * lane) = *MX_GP(uint32_t, r + cd + h0 * 8u + (lane & 3u) * 4u);
             }
         };
         // request order K(t), V(t), K(t+1), V(t+1), ...: five instructions each, so "all but the 15 youngest" is "this region has landed"
-        stage(t0, 0u, 0u);
-        stage(t0, 0u, 1u);
         if (FORM != 2) {
+            stage(t0, 0u, 0u);
+            stage(t0, 0u, 1u);
 #pragma unroll
             for (uint32_t sg = 1; sg < kStages; ++sg) { stage(t0 + sg, sg, 0u); stage(t0 + sg, sg, 1u); }
+        } else {
+            u32x4 e0 = ent_fetch(t0), e1 = ent_fetch(t0 + 1u);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(e0), "+v"(e1) :: "memory");
+            ent_store(0u, e0);
+            ent_store(1u, e1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue_table_tile(0u, 0u);
         }
 
         // ---- query operands (MXFP8, blocks of 16 channels, zero-interleaved): lane (c = 8w + q, kb) takes channels 8kb + 32 gq + 0..7
@@ -520,7 +557,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg * HALVES) __attribute__((amdgpu_wa
         const uint32_t wshift = 16u * w;
         // one tile out of stage BUF (a compile-time constant: the LDS reads then carry the stage as an immediate offset)
         auto tile_body = [&](uint32_t tile, auto buf_c) __attribute__((always_inline)) {
-            constexpr uint32_t buf = decltype(buf_c)::value;
+            const uint32_t buf = buf_c;                                   // (an integral_constant: folded; the page-table form passes a variable)
             const uint8_t* st = lptr + buf * kStage;
             // ---- K of this tile has landed (younger requests: V of this tile, K and V of the next): both heads' blocks and codes
             // to registers, and the region goes straight back to the DMA for the next-but-one tile
@@ -623,15 +660,24 @@ __global__ __launch_bounds__(64 * kWavesPerWg * HALVES) __attribute__((amdgpu_wa
 #undef MX_PV
             }
             if (CLS && ++cc_m == cls_m) { cc_m = 0u; ++cc_cls; }
-            if (FORM == 2 && tile + 1u < t1) {                                    // synchronous staging of the next tile
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                stage(tile + 1u, 0u, 0u);
-                stage(tile + 1u, 0u, 1u);
-            }
         };
         if (FORM == 2) {
+            // tile in stage buf: its DMAs have landed; the next tile's go out (its entries are in LDS), the entries of the tile after that
+            // are asked for; the arithmetic; then ONE wait for both, and the entries move into the LDS buffer this tile's had.
+            // (ONE copy of the tile's arithmetic with the stage as a variable: two copies with constant stages left the scheduler room to
+            //  overlap them, and the kernel -- at the 256 registers of two waves per SIMD -- spilled)
+            uint32_t tbuf = 0u;
 #pragma unroll 1
-            for (uint32_t tile = t0; tile < t1; ++tile) tile_body(tile, std::integral_constant<uint32_t, 0u>{});
+            for (uint32_t tile = t0; tile < t1; ++tile) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (tile + 1u < t1) issue_table_tile(tbuf ^ 1u, tbuf ^ 1u);
+                u32x4 e2 = ent_fetch(tile + 2u);
+                tile_body(tile, tbuf);
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" : "+v"(e2) :: "memory");
+                ent_store(tbuf, e2);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                tbuf ^= 1u;
+            }
         } else if (STREAM) {
             // the piece, tile by tile; at the end of a layer its partial goes out, the state starts over and the next layer's query
             // rows come in (their loads are the compiler's: it waits for everything in flight once, a pipeline fill per boundary)
@@ -733,7 +779,7 @@ hipError_t launch_attend_mx4(const AttendArgs& a, uint32_t n_rows, float* d_out,
     if (!(allowed.load(std::memory_order_acquire) >> dev & 1ull)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<size_t>(kWavesPerWg) * (2u * kStage + kTabEnt));
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attend_mx4<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<size_t>(2 * kWavesPerWg) * 2 * kStage);
         if (e != hipSuccess) return e;
@@ -743,7 +789,7 @@ hipError_t launch_attend_mx4(const AttendArgs& a, uint32_t n_rows, float* d_out,
     else if (form == 0) hipLaunchKernelGGL(k_attend_mx4<0>, grid, block, lds_bytes, s, a);
     else if (form == 1) hipLaunchKernelGGL(k_attend_mx4<1>, grid, block, lds_bytes, s, a);
     else if (form == 3) hipLaunchKernelGGL(k_attend_mx4<3>, grid, block, lds_bytes, s, a);
-    else hipLaunchKernelGGL(k_attend_mx4<2>, grid, block, static_cast<size_t>(kWavesPerWg) * kStage, s, a);
+    else hipLaunchKernelGGL(k_attend_mx4<2>, grid, block, static_cast<size_t>(kWavesPerWg) * (2u * kStage + kTabEnt), s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const bool all_final = a.direct_out && (!a.direct_per_seq || a.direct_per_seq == 2u);

@@ -590,7 +590,7 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
     const bool have_tail = tail && tail->n_tail != 0u;
     if (have_tail && (!tail->d_k_tail || !tail->d_v_tail || !d_lse || tail->stride_elems % 8u || tail->stride_elems < static_cast<uint64_t>(layer + 1u) * heads * 128u))
         return SPECKV_ERR_INVAL;
-    const bool fold_in_kernel = have_tail && mx4 && !plan->second.any_empty && (tail->d_tail_idx || tail->n_tail == n_seq) && tuning().attend_fold_launch == 0;
+    const bool fold_in_kernel = have_tail && mx4 && !plan->second.any_empty && !plan->second.table && (tail->d_tail_idx || tail->n_tail == n_seq) && tuning().attend_fold_launch == 0;
     if (n_layers > 1u) {                                       // (attend_planned_layers checked the geometry: MXFP4, one split per sequence)
         if (!mx4 || pg.max_splits != 1u) return SPECKV_ERR_INVAL;
         k.batch_n_seq = n_seq;

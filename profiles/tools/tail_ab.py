@@ -6,7 +6,7 @@ import cxl_speckv_amd as pkg
 from cxl_speckv_amd.kv_connector import SpeckvKVConnector
 SCH = sys.argv[1] if len(sys.argv) > 1 else "mxfp4"
 SID = {"fp8": 4, "int4": 3, "mxfp4": 5}[SCH]
-n_seq, Lyr, ctx, T = 256, 8, 2048, 4096
+n_seq, Lyr, ctx, T = 256, 8, 2048, int(os.environ.get("TMAX", "4096"))
 lib = pkg.SpeckvLib(pkg.library_path(), "hip:0")
 conn = SpeckvKVConnector(lib, num_layers=Lyr, max_tokens=T, scheme=SCH)
 ids = list(range(n_seq))
@@ -35,3 +35,19 @@ for name, fn in (("planned", plain), ("planned_tail", tail), ("planned", plain),
             for l in range(Lyr): fn(l)
         b.record(s); torch.cuda.synchronize()
     print(SCH, name, "us per layer", round(a.elapsed_time(b) / 20 / Lyr * 1e3, 2))
+# all layers in one call (MXFP4: one launch over layers x sequences), with the two-halves workgroups and without
+import bench
+qall = q[None].expand(Lyr, -1, -1, -1, -1).contiguous()
+outall = torch.empty((Lyr, n_seq, 8, 8, 128), dtype=torch.float32, device="cuda"); lseall = torch.empty((Lyr, n_seq, 8, 8), dtype=torch.float32, device="cuda")
+alll = lambda: lib.attend_planned_layers(SID, conn._plan.data_ptr(), n_seq, 0, Lyr, qall.data_ptr(), 8, bound, 0.0884, outall.data_ptr(), lseall.data_ptr(), s.cuda_stream)
+for half in (0, 1, 0, 1):
+    bench.set_tuning("attend_mx4_one_half", half)
+    with torch.cuda.stream(s):
+        for _ in range(5): alll()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s)
+        for _ in range(20): alll()
+        b.record(s); torch.cuda.synchronize()
+    print(SCH, "layers in one call, one_half =", half, "us per layer", round(a.elapsed_time(b) / 20 / Lyr * 1e3, 2))
+bench.set_tuning("attend_mx4_one_half", 0)
