@@ -25,6 +25,7 @@
 //           (4 consecutive d of one position) and splits them with v_perm_b32.
 //           -> lane (c, kb) holds out[query row c][64blk + 16kb + 4i + t].
 #include "kernels.hpp"
+#include "tuning.hpp"
 #include "codec_device.hpp"          // the exact reciprocal divide of the codecs (div_by_scale and friends)
 #include <cstdlib>
 
@@ -720,6 +721,13 @@ __device__ __forceinline__ void fd_dma16(uint32_t lds_dst, const uint8_t* base, 
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(base) : "memory");
 }
+// the same with a full address per lane (TABLE form: every page of a tile may lie anywhere)
+__device__ __forceinline__ void fd_dma16v(uint32_t lds_dst, const uint8_t* addr)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(addr) : "memory");
+}
 __device__ __forceinline__ void fd_dma4(uint32_t lds_dst, const uint8_t* base, uint32_t voff)      // active lanes only
 {
     uint32_t keep;
@@ -727,24 +735,29 @@ __device__ __forceinline__ void fd_dma4(uint32_t lds_dst, const uint8_t* base, u
                  : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(base) : "memory");
 }
 // all but the 13 youngest DMAs have landed (V of this tile: 4, the next tile: 9): K operand of both blocks + the scales
+// (N: the TABLE form has a page-table load per tile in its queue: 14)
+template <int N = 13>
 __device__ __forceinline__ void fd_take_k(uint32_t rd0, uint32_t rd1, uint32_t rs, u32x4 (&k)[4], f32x4& ks, f32x4& vs)
 {
-    asm volatile("s_waitcnt vmcnt(13)\n\t"
+    static_assert(N == 13 || N == 14, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%9)\n\t"
                  "ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %6 offset:2048\n\tds_read_b128 %3, %7 offset:2048\n\t"
                  "ds_read_b128 %4, %8\n\tds_read_b128 %5, %8 offset:64\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(k[0]), "=&v"(k[1]), "=&v"(k[2]), "=&v"(k[3]), "=&v"(ks), "=&v"(vs) : "v"(rd0), "v"(rd1), "v"(rs) : "memory");
+                 : "=&v"(k[0]), "=&v"(k[1]), "=&v"(k[2]), "=&v"(k[3]), "=&v"(ks), "=&v"(vs) : "v"(rd0), "v"(rd1), "v"(rs), "n"(N) : "memory");
 }
 // V of this tile has landed (younger: the next tile 9, K + scales of the one after 5)
 typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+template <int N = 14>
 __device__ __forceinline__ void fd_take_v(const uint32_t (&rd)[4], u32x2v (&v)[8])
 {
-    asm volatile("s_waitcnt vmcnt(14)\n\t"
+    static_assert(N == 14 || N == 16, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%12)\n\t"
                  "ds_read_b64 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %10\n\tds_read_b64 %3, %11\n\t"
                  "ds_read_b64 %4, %8 offset:2048\n\tds_read_b64 %5, %9 offset:2048\n\tds_read_b64 %6, %10 offset:2048\n\tds_read_b64 %7, %11 offset:2048\n\t"
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-                 : "v"(rd[0]), "v"(rd[1]), "v"(rd[2]), "v"(rd[3]) : "memory");
+                 : "v"(rd[0]), "v"(rd[1]), "v"(rd[2]), "v"(rd[3]), "n"(N) : "memory");
 }
 __device__ __forceinline__ uint32_t fd_row_slot(uint32_t r) { return r ^ ((r >> 2) & 1u); }
 __device__ __forceinline__ uint32_t fd_piece_xor(uint32_t r) { return (r >> 1) & 7u; }
@@ -754,9 +767,19 @@ __device__ __forceinline__ uint32_t fd_piece_xor(uint32_t r) { return (r >> 1) &
 #define SPECKV_FP8_WG_HEADS 4
 #endif
 constexpr uint32_t kFdHeads = SPECKV_FP8_WG_HEADS;          // kv heads (= waves) per workgroup
+// TABLE (round 6): the same pipeline for allocations whose records do NOT lie in one run -- striped regularly over several pools
+// (BASELINE configs[3]: page % 7) or moved page by page.  Every page's record address comes from its page-table entry: the 32
+// entries of a tile (16 K pages, 16 V pages) are fetched FOUR tiles ahead with one load per wave (two register sets in rotation),
+// parked in LDS when the tile's requests are due, and read back from there by the lanes that need them: a request is an LDS-DMA
+// with a full address per lane (a lane's rows of one instruction belong to four pages).  Pages stay in page order, so the scale
+// table's tile order holds as it is.  The queue of an iteration is K(t+2) 5, entries(t+4) 1, V(t+2) 4: "all but the 14 youngest"
+// = K(t) and entries(t+2) have landed, "all but the 16 youngest" = V(t) has.  (The register-staged k_attend_fp8_linear<STRIPED / TABLE> computed or chased an address
+// per page and request: 0.67-0.69 of the roofline over a pool striped x7 against 0.78 for this pipeline on one run.)
+constexpr uint32_t kFdEnt = 512u;                           // the 32 page-table entries of the tile being requested
+template <bool TABLE>
 __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_attend_fp8_dma(AttendArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kFdHeads][2 * kFdBuf];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kFdHeads][2 * kFdBuf + (TABLE ? kFdEnt : 0u)];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t c = lane & 15u, kb = lane >> 4;
@@ -784,6 +807,7 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
         my_splits = sq.n_splits;
         part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
         layer = 0;
+        if (TABLE) a.entries = reinterpret_cast<const PageEntry*>(sq.lin_base);      // (table launches: the descriptor carries the page table)
     }
     uint32_t qd[8];
     float qscale = 1.0f;
@@ -827,6 +851,48 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i) fd_dma16(dst + 1024u * i, src, g[i]);
         };
+        // ---- TABLE: entries two tiles ahead (lane l < 16: K page l of the tile, 16 .. 31: V page l - 16), the tile's DMAs one ahead
+        const uint32_t kfirst = static_cast<uint32_t>(a.k_first + layer * a.layer_stride), vfirst = static_cast<uint32_t>(a.v_first + layer * a.layer_stride);
+        const uint32_t last_pg = a.n_pages - 1u;
+        const uint32_t ent_lds = lbase + 2u * kFdBuf;
+        auto ent_fetch = [&](uint32_t tt) -> u32x4 {
+            const uint32_t idx = lane & 31u, pg = min(16u * min(tt, last) + (idx & 15u), last_pg);
+            const PageEntry* ep = a.entries + ((idx < 16u ? kfirst : vfirst) + pg);
+            u32x4 e;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(e) : "v"(ep) : "memory");
+            return e;
+        };
+        auto ent_store = [&](const u32x4 e) {                                             // (lanes 32 .. 63 repeat lanes 0 .. 31: same bytes)
+            asm volatile("ds_write_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(ent_lds + (lane & 31u) * 16u), "v"(e) : "memory");
+        };
+        // the lane's eight request addresses of a tile (K rows of its four instructions, then V) from the entries parked in LDS: one
+        // LDS round trip per tile; the V addresses wait in registers for their turn
+        typedef const uint8_t* addr8[8];
+        auto table_addrs = [&](addr8& ad) __attribute__((always_inline)) {
+            const uint8_t* eb_ptr = &lds[wave][0] + 2u * kFdBuf;
+            u32x4 e[8];
+            uint32_t rr[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) {
+                rr[i] = fd_row_slot(8u * i + (lane >> 3));                                                      // position row of the tile: page r / 2, position r % 2
+                e[i] = *reinterpret_cast<const u32x4*>(eb_ptr + (rr[i] >> 1) * 16u);                            // {address lo, hi, record bytes, scale}
+                e[4 + i] = *reinterpret_cast<const u32x4*>(eb_ptr + (16u + (rr[i] >> 1)) * 16u);
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) {
+                const uint32_t r = rr[j & 3u];
+                const uint8_t* rec = reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(e[j].x) | (static_cast<uint64_t>(e[j].y) << 32));
+                rec = e[j].z >= 2048u ? rec : a.zero_page;                                                      // never written: zeros (its table scale is 0)
+                ad[j] = rec + (r & 1u) * 1024u + head * 128u + (((lane & 7u) ^ fd_piece_xor(r)) * 16u);
+            }
+        };
+        // the K (rg = 0: + the 32 page scales) or V requests of tile tt into stage sbuf
+        auto issue_table = [&](const addr8& ad, uint32_t tt, uint32_t sbuf, uint32_t rg) __attribute__((always_inline)) {
+            const uint32_t dst = lbase + sbuf * kFdBuf + (rg ? kFdV : 0u);
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) fd_dma16v(__builtin_amdgcn_readfirstlane(dst + 1024u * i), ad[4u * rg + i]);
+            if (rg == 0u && lane < 32u) fd_dma4(__builtin_amdgcn_readfirstlane(lbase + sbuf * kFdBuf + kFdS), reinterpret_cast<const uint8_t*>(a.scale_tab), gsc + min(tt, last) * 64u);
+        };
         // reader addresses inside buffer 0
         const uint32_t kslot = fd_row_slot(c), kx_ = fd_piece_xor(c);
         const uint32_t rdk0 = lbase + kslot * 128u + ((kb ^ kx_) * 16u);
@@ -842,7 +908,17 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
         // scores: two round trips, not three), by inline assembly like the DMAs: the compiler neither counts these loads nor waits
         // for them.  One wait with the row's registers as operands: all but the 13 youngest requests (V of tile 0, tile 1) have
         // landed -- the count fd_take_k uses at the head of every iteration.
-        issue_k(t0, 0u);
+        u32x4 eA, eB;                                                     // TABLE: entries of the tile two ahead of an even / odd iteration
+        addr8 tad;                                                        // ... and the request addresses of the tile being asked for
+        if (TABLE) {
+            eA = ent_fetch(t0); eB = ent_fetch(t0 + 1u);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(eA), "+v"(eB) :: "memory");
+            ent_store(eA);
+            table_addrs(tad);
+            issue_table(tad, t0, 0u, 0u);
+        } else {
+            issue_k(t0, 0u);
+        }
         u32x4 qw[4];
         {
             const uint16_t* qsrc = a.q16 + (row * a.g + min(c, a.g - 1u)) * 128u + kb * 16u;
@@ -850,21 +926,35 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
                          "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:144"
                          : "=&v"(qw[0]), "=&v"(qw[1]), "=&v"(qw[2]), "=&v"(qw[3]) : "v"(qsrc) : "memory");
         }
-        issue_v(t0, 0u);
-        issue_k(t0 + 1u, 1u);
-        issue_v(t0 + 1u, 1u);
-        asm volatile("s_waitcnt vmcnt(13)" : "+v"(qw[0]), "+v"(qw[1]), "+v"(qw[2]), "+v"(qw[3]) :: "memory");
+        if (TABLE) {
+            issue_table(tad, t0, 0u, 1u);
+            ent_store(eB);
+            table_addrs(tad);
+            issue_table(tad, t0 + 1u, 1u, 0u);
+            issue_table(tad, t0 + 1u, 1u, 1u);
+            eA = ent_fetch(t0 + 2u); eB = ent_fetch(t0 + 3u);
+            // (everything in flight, once per workgroup: the loop's counts hold from the third tile on, the first two find all landed)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(qw[0]), "+v"(qw[1]), "+v"(qw[2]), "+v"(qw[3]), "+v"(eA), "+v"(eB) :: "memory");
+        } else {
+            issue_v(t0, 0u);
+            issue_k(t0 + 1u, 1u);
+            issue_v(t0 + 1u, 1u);
+            asm volatile("s_waitcnt vmcnt(13)" : "+v"(qw[0]), "+v"(qw[1]), "+v"(qw[2]), "+v"(qw[3]) :: "memory");
+        }
         quantize_query_rows(qw, c < a.g, qd, qscale);
         qscale *= a.scale_log2e;
         const bool ragged = (a.n_pages & 15u) != 0u;
-#pragma unroll 1
-        for (uint32_t tile = t0; tile < t1; ++tile) {
-            const uint32_t buf = (tile - t0) & 1u;
+        auto tile_step = [&](uint32_t tile, uint32_t buf, u32x4& et) __attribute__((always_inline)) {
             const uint32_t bo = buf * kFdBuf;
             u32x4 kx[4];
             f32x4 ks4, vs4;
-            fd_take_k(rdk0 + bo, rdk1 + bo, rsc + bo, kx, ks4, vs4);
-            issue_k(tile + 2u, buf);
+            if (TABLE) {
+                fd_take_k<14>(rdk0 + bo, rdk1 + bo, rsc + bo, kx, ks4, vs4);       // K of this tile and the entries of tile + 2 have landed
+                asm volatile("" : "+v"(et));
+            } else {
+                fd_take_k(rdk0 + bo, rdk1 + bo, rsc + bo, kx, ks4, vs4);
+                issue_k(tile + 2u, buf);
+            }
             // ---- scores
             float sc[8];
 #pragma unroll
@@ -876,6 +966,14 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
                     s = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(kd[2 * st], kd[2 * st + 1]), pack64(qd[2 * st], qd[2 * st + 1]), s, 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sc[4 * b + i] = s[i] * (ks4[2 * b + (i >> 1)] * qscale);
+            }
+            if (TABLE) {
+                // behind the score MFMAs (they run while the entries make their way through LDS): the entries of tile + 2 are parked,
+                // its eight request addresses formed, its K requests go out; the entries of tile + 4 are asked for
+                ent_store(et);
+                table_addrs(tad);
+                issue_table(tad, tile + 2u, buf, 0u);
+                et = ent_fetch(tile + 4u);
             }
             if ((ragged && tile + 1u == n_tiles) || (a.skip_pages && tile == 0u)) {     // wave-uniform: positions beyond / in front of the range
 #pragma unroll
@@ -910,8 +1008,8 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
             // ---- V pieces, then the next-but-one tile's V is requested into the buffer they came from
             u32x2v vx[8];
             const uint32_t rdvb[4] = {rdv[0] + bo, rdv[1] + bo, rdv[2] + bo, rdv[3] + bo};
-            fd_take_v(rdvb, vx);
-            issue_v(tile + 2u, buf);
+            if (TABLE) { fd_take_v<16>(rdvb, vx); issue_table(tad, tile + 2u, buf, 1u); }
+            else { fd_take_v(rdvb, vx); issue_v(tile + 2u, buf); }
             // ---- out^T += V^T . P^T, accumulated in place
             uint32_t w[4][4];                                             // [row pair][byte pair of the 8 d]
 #pragma unroll
@@ -933,6 +1031,17 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
                 }
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t] * fa, 0, 0, 0);
             }
+        };
+        if (TABLE) {
+#pragma unroll 1
+            for (uint32_t tile = t0; tile < t1; tile += 2u) {             // (two steps per trip: the entry registers of even and odd tiles are fixed)
+                tile_step(tile, 0u, eA);
+                if (tile + 1u >= t1) break;
+                tile_step(tile + 1u, 1u, eB);
+            }
+        } else {
+#pragma unroll 1
+            for (uint32_t tile = t0; tile < t1; ++tile) tile_step(tile, (tile - t0) & 1u, eA);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the re-requested tail tiles: nothing may land after the wave ends
     }
@@ -1263,7 +1372,9 @@ hipError_t launch_attend_fp8_batch(const AttendArgs& a, uint32_t n_seq, float* d
     // the batch form keeps the register-staged kernel: 256 sequences x 8k context, one layer: 0.69 of HBM peak against 0.67
     // with the LDS-DMA kernel (many short splits: 4 waves/SIMD hide more than two tiles per wave at 2 waves/SIMD); the
     // single-sequence form below is the other way round (8k x 80 layers: 0.61 against 0.55; 32k x 80: 0.70 both)
-    if (a.table_form) hipLaunchKernelGGL((k_attend_fp8_linear<false, true>), dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
+    if (a.table_form && tuning().attend_fp8_table_regs == 0)            // striped / moved placements: the DMA pipeline with addresses from the page tables
+        hipLaunchKernelGGL(k_attend_fp8_dma<true>, dim3(a.n_splits, n_seq * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
+    else if (a.table_form) hipLaunchKernelGGL((k_attend_fp8_linear<false, true>), dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
     else if (a.stripe_bases) hipLaunchKernelGGL(k_attend_fp8_linear<true>, dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
     else     hipLaunchKernelGGL(k_attend_fp8_linear<false>, dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
@@ -1287,8 +1398,11 @@ hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_ou
     // 1 split 0.58 / 0.73; 8k: 1 split DMA 0.69, 8 splits 0.63 / 0.62
     // (launches with few workgroup columns -- the per-layer calls of one sequence -- are latency-bound either way: DMA kernel,
     // 13.8 against 15.5 us at 8k context)
-    if (a.lin_base && (a.n_splits == 1u || n_layers * (a.heads / 4u) < 128u))
-        hipLaunchKernelGGL(k_attend_fp8_dma, dim3(a.n_splits, n_layers * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
+    const bool dma_table = !a.lin_base && (a.stripe_bases || a.table_form) && a.scale_tab && a.entries && !a.skip_pages && tuning().attend_fp8_table_regs == 0;
+    if (dma_table)                                                       // striped or moved page by page: the DMA pipeline with addresses from the page table
+        hipLaunchKernelGGL(k_attend_fp8_dma<true>, dim3(a.n_splits, n_layers * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
+    else if (a.lin_base && (a.n_splits == 1u || n_layers * (a.heads / 4u) < 128u))
+        hipLaunchKernelGGL(k_attend_fp8_dma<false>, dim3(a.n_splits, n_layers * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
     else if (a.lin_base)
         hipLaunchKernelGGL(k_attend_fp8_linear<false>, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
     else if (a.stripe_bases)

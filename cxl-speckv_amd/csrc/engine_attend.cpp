@@ -123,7 +123,10 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     const bool table = fits && !lin_base && !striped;
     // (the page-table form has nothing to gain from whole rows: it hides its look-ups behind other waves and always
     // goes through the merge -- 80 layers x 8k: one split 0.13 of HBM peak, eight 0.18+)
-    uint32_t want = (lin_base && rows / 4u >= 128u && n_tiles < 768u) ? 1u : (5120u + rows - 1u) / rows;     // (32k and beyond: 8 splits, below)
+    // (striped / moved placements run the same DMA pipeline with their addresses from the page table, k_attend_fp8_dma<TABLE>: the
+    //  same rule; the register-staged kernels of rounds 2-5 -- a range that starts inside a tile, or on request -- want the splits)
+    const bool dma_table = (striped || table) && skip_pages == 0 && tuning().attend_fp8_table_regs == 0;
+    uint32_t want = ((lin_base || dma_table) && rows / 4u >= 128u && n_tiles < 768u) ? 1u : (5120u + rows - 1u) / rows;     // (32k and beyond: 8 splits, below)
     // per-layer calls are latency-bound: short contexts want short splits (measured best: 2 tiles per split at 2k
     // context, 4 at 8k, 8 at 32k), long multi-layer launches are bounded by `want` above
     const uint32_t min_tiles = std::min(8u, std::max(2u, n_tiles / 64u));
@@ -298,6 +301,8 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     // INT4 (arithmetic-bound kernel): splits longer than 256 tiles stop paying (256 sequences x 32k: 256 tiles per split
     // 0.67, 512: 0.65, 1024 = no split: 0.60), shorter sequences are best left whole (8k 0.63 against 0.59 in two
     // splits, 4k 0.60 / 0.52, 2k 0.58 / 0.43: single-split rows are final, no partials and no merge).
+    // FP8 over striped pools: the DMA pipeline takes its addresses from the page tables (k_attend_fp8_dma<TABLE>), in page order
+    if (fp8 && any_striped && tuning().attend_fp8_table_regs == 0) any_table = true;
     if (any_table)                                           // (AttendSeq::lin_base carries the page table in table launches)
         for (uint32_t i = 0; i < n_seq; ++i) seqs[i].lin_base = reinterpret_cast<const uint8_t*>(ents[i]);
     if (mx4 && any_striped && !any_table) {                  // the striped form of k_attend_mx4 counts its tiles by residue class
@@ -471,6 +476,7 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
         seqs[i].n_pages = n_pages;
         seqs[i].n_splits = n_tiles;
     }
+    if (scheme == SPECKV_COMP_FP8_E4M3 && any_striped && tuning().attend_fp8_table_regs == 0) any_table = true;       // (see attend_batch)
     uint32_t stripe_n_max = 0;
     if (scheme == SPECKV_COMP_MXFP4 && any_striped && !any_table)
         for (uint32_t i = 0; i < n_seq; ++i) {
