@@ -1307,7 +1307,7 @@ hipError_t launch_attend_combine(const AttendArgs& a, uint32_t n_layers, float* 
 {
     if (n_layers == 0) return hipSuccess;
     const uint32_t splits = a.stream.n_wgs ? a.stream.max_slots : a.n_splits;      // most partials a row can have
-    const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
+    const uint32_t n_tiles = a.stream.tiles ? a.stream.tiles : (a.n_pages + 15u) / 16u;
     if (splits > kMaxSplits) return hipErrorInvalidValue;
     if (splits <= kSmallCombineSplits) {
         const uint32_t n_rows = n_layers * a.heads;

@@ -669,19 +669,33 @@ __device__ __forceinline__ void w8_take_v(const uint32_t (&rd)[4], uint32_t rs, 
 #ifndef SPECKV_INT4_W8_WAVES
 #define SPECKV_INT4_W8_WAVES 4
 #endif
+__device__ __forceinline__ const uint8_t* w8_uniform_ptr(const uint8_t* p)
+{
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+    return reinterpret_cast<const uint8_t*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
 // HALVES = 2 (fixed-grid and batch launches): 16 waves, the workgroup's run of tiles cut in two, waves 8..15 take the second
 // half with LDS stages of their own; at the end their (m, l, accumulators) cross over through LDS and waves 0..7 store the
 // merged result -- a row that fits one workgroup needs no partials and no merge launch, and a batch of 256 sequences fills
 // 256 CUs with 16 waves each.  One workgroup per CU then (144 KiB of LDS).  The stream form keeps HALVES = 1, two per CU.
-template <int HALVES>
+// CLS (round 6): an allocation striped regularly over 2..8 pools (AttendArgs::stripe_bases; BASELINE configs[3]: page % 7).  The
+// range's pages are taken by residue CLASS, as k_attend_mx4's striped form does: class c = the pages j of the range with j % n == c
+// -- consecutive records of ONE run for K and of one run for V -- every class in tiles of 16, every class with the tile count of the
+// largest (mx4_class_tiles); the run of tiles is class-major.  A tile is then fetched exactly as in the linear form, from a base
+// that is recomputed per tile instead of advanced; rows past a class's end are masked (their fetch stays inside the run: the
+// engine allocates INT4 runs with 15 records of slack), a tile past a class's end fetches the class's last one.  Attention does
+// not care in which order it meets the positions.  Fixed-grid and batch launches (no stream form).
+template <int HALVES, bool CLS = false>
 __global__ __launch_bounds__(512 * HALVES) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4_W8_WAVES, SPECKV_INT4_W8_WAVES))) void k_attend_int4_wg8(AttendArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[HALVES * 2 * kW8Stage];
+    __shared__ uint64_t s_bases[8];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t head = wave & 7u, half = wave >> 3;                   // wave = kv head (x half of the run)
     const uint32_t c = lane & 15u, kb = lane >> 4;
-    const uint32_t n_tiles = (a.n_pages + 15u) / 16u;                    // (batch form: set per sequence below)
+    const uint32_t n_tiles = CLS ? mx4_striped_tiles(a.n_pages, a.stripe_n) : (a.n_pages + 15u) / 16u;       // (batch form: set per sequence below)
     // ---- this workgroup's run of tiles: `count` tiles from tile `ct` of layer `cl` on, in layer-major order
     uint32_t cl, ct, count, slot = 0u, my_splits = a.n_splits;
     uint64_t part = 0u;
@@ -714,9 +728,15 @@ __global__ __launch_bounds__(512 * HALVES) __attribute__((amdgpu_waves_per_eu(SP
             my_splits = sq.n_splits;
             part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
             tiles_in_layer = (sq.n_pages + 15u) / 16u;
+            if (CLS) { a.stripe_bases = sq.stripe_bases; a.stripe_n = sq.stripe_n; }
         }
+        if (CLS) tiles_in_layer = mx4_striped_tiles(a.n_pages, a.stripe_n);
         ct = split * a.tiles_per_split;
         count = ct < tiles_in_layer ? min(a.tiles_per_split, tiles_in_layer - ct) : 0u;
+    }
+    if (CLS) {
+        if (threadIdx.x < 8u) s_bases[threadIdx.x] = a.stripe_bases[threadIdx.x];
+        __syncthreads();
     }
     const uint32_t out_row0 = cl;                                        // (batch form: the row index is the sequence, the addresses use layer 0)
     // every wave runs `iters` iterations (the barriers are the workgroup's); this half's own tiles are the first `count` of them
@@ -752,6 +772,20 @@ __global__ __launch_bounds__(512 * HALVES) __attribute__((amdgpu_waves_per_eu(SP
         const uint8_t* kptr = a.lin_base + (a.k_first + addr_layer * a.layer_stride) * kInt4RecBytes + static_cast<uint64_t>(ct) * tile_bytes;
         const uint8_t* vptr = a.lin_base + (a.v_first + addr_layer * a.layer_stride) * kInt4RecBytes + static_cast<uint64_t>(ct) * tile_bytes;
         uint32_t itile = ct;
+        // class form: pages per class (class c holds jq + (c < jr) of the range's pages), tiles per class, the next tile to request as
+        // (class, tile of the class) and the tile the arithmetic is at
+        const uint32_t cls_n = CLS ? (a.stripe_n ? a.stripe_n : 1u) : 1u, cls_m = CLS ? mx4_class_tiles(a.n_pages, cls_n) : 1u;
+        const uint32_t jq = a.n_pages / cls_n, jr = a.n_pages - jq * cls_n;
+        uint32_t kpage0 = static_cast<uint32_t>(a.k_first + addr_layer * a.layer_stride), vpage0 = static_cast<uint32_t>(a.v_first + addr_layer * a.layer_stride);      // (the layer the requests are at)
+        uint32_t iq_cls = CLS ? ct / cls_m : 0u, iq_m = CLS ? ct - iq_cls * cls_m : 0u;
+        uint32_t cc_cls = iq_cls, cc_m = iq_m;
+        auto cls_base = [&](uint32_t page0, uint32_t cls, uint32_t m) -> const uint8_t* {       // first record of tile m of class cls (clamped to the class's last tile)
+            uint32_t cnt = jq + (cls < jr ? 1u : 0u);
+            if (cnt == 0u) { cls = 0u; cnt = 1u; }                        // (fewer pages than runs: an empty class fetches the range's first record, all masked)
+            const uint32_t pg = page0 + cls, rec0 = pg / cls_n, pool = pg - rec0 * cls_n;
+            const uint32_t mm = min(m, (cnt - 1u) >> 4);
+            return reinterpret_cast<const uint8_t*>(s_bases[pool]) + static_cast<uint64_t>(rec0 + 16u * mm) * kInt4RecBytes;
+        };
         // ---- this wave's share of the fetch.  Nibbles: pages 2w and 2w+1 of K and of V, one instruction per page: lanes
         // 0..31 -> the page's slot 0 (row 4w or 4w+2), lanes 32..63 -> slot 1; LDS piece y of row r holds source piece y ^ (r & 15)
         const uint32_t pslot = lane >> 5, y = lane & 31u;
@@ -765,11 +799,24 @@ __global__ __launch_bounds__(512 * HALVES) __attribute__((amdgpu_waves_per_eu(SP
         const uint32_t dn = 4u * head * 512u, dsl = ((head < 4u) ? kW8Ks : kW8Vs) + 4u * (head & 3u) * 128u;    // destinations inside a stage
         auto issue = [&](uint32_t stage_off) {
             const uint32_t dst = lbase + stage_off;
+            if (CLS) {                                                   // the tile's bases from its (class, tile of the class); wave-uniform
+                const uint32_t ic = min(iq_cls, cls_n - 1u);
+                kptr = w8_uniform_ptr(cls_base(kpage0, ic, iq_m));
+                vptr = w8_uniform_ptr(cls_base(vpage0, ic, iq_m));
+                if (++iq_m == cls_m) {
+                    iq_m = 0u;
+                    if (++iq_cls == cls_n && stream) {                    // (stream form: on into the next layer's regions)
+                        iq_cls = 0u;
+                        kpage0 += static_cast<uint32_t>(a.layer_stride); vpage0 += static_cast<uint32_t>(a.layer_stride);
+                    }
+                }
+            }
             dma16(dst + dn, kptr, ga);
             dma16(dst + dn + 1024u, kptr, gb);
             dma16(dst + kW8V + dn, vptr, ga);
             dma16(dst + kW8V + dn + 1024u, vptr, gb);
             if (lane < 32u) dma16(dst + dsl, (head < 4u) ? kptr : vptr, gs);
+            if (CLS) return;
             kptr += tile_bytes; vptr += tile_bytes;
             if (++itile == tiles_in_layer) {                             // (stream form: on into the next layer's regions)
                 itile = 0u;
@@ -805,7 +852,7 @@ __global__ __launch_bounds__(512 * HALVES) __attribute__((amdgpu_waves_per_eu(SP
             asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
                          "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
                          : "=&v"(tq0), "=&v"(tq1), "=&v"(tq2), "=&v"(tq3) : "v"(q16) : "memory");
-            if (count == 1u) { kptr = k0p; vptr = v0p; itile = t0i; }
+            if (count == 1u) { kptr = k0p; vptr = v0p; itile = t0i; if (CLS) { iq_cls = cc_cls; iq_m = cc_m; } }
             issue(kW8Stage);
             asm volatile("s_waitcnt vmcnt(5)" : "+v"(tq0), "+v"(tq1), "+v"(tq2), "+v"(tq3) :: "memory");
             const bool qlive = c < a.g;
@@ -840,7 +887,17 @@ __global__ __launch_bounds__(512 * HALVES) __attribute__((amdgpu_waves_per_eu(SP
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { sc[j] = s0[j]; sc[4 + j] = s1[j]; }
             }
-            if (ragged && ct + 1u == tiles_in_layer) {                    // workgroup-uniform: positions beyond the range
+            if (CLS) {
+                const uint32_t cnt = cc_cls < cls_n ? jq + (cc_cls < jr ? 1u : 0u) : 0u;
+                if (16u * (cc_m + 1u) > cnt) {                            // workgroup-uniform: the class ends inside (or in front of) this tile
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t pi = 16u * cc_m + ((j >> 1) < 2 ? 2u * kb + (j >> 1) : 8u + 2u * kb + ((j >> 1) - 2));
+                        if (pi >= cnt) sc[j] = -INFINITY;
+                    }
+                }
+                if (++cc_m == cls_m) { cc_m = 0u; if (++cc_cls == cls_n && stream) cc_cls = 0u; }
+            } else if (ragged && ct + 1u == tiles_in_layer) {             // workgroup-uniform: positions beyond the range
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const uint32_t pg = ct * 16u + ((j >> 1) < 2 ? 2u * kb + (j >> 1) : 8u + 2u * kb + ((j >> 1) - 2));
@@ -906,6 +963,12 @@ hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_
     if ((a.n_pages == 0 && !a.seqs) || n_layers == 0 || a.n_splits == 0) return hipSuccess;   // batch form: geometry per sequence
     const dim3 wg_grid = a.rows_first ? dim3(n_layers * (a.heads / 4u), a.n_splits) : dim3(a.n_splits, n_layers * (a.heads / 4u));
     if (a.table_form) { hipLaunchKernelGGL((k_attend_int4_wg<false, true>), wg_grid, dim3(256), 0, s, a); return hipGetLastError(); }
+    if (a.wg8 && !a.lin_base && a.stripe_bases && a.heads == 8u) {       // striped regularly: the same kernel over residue classes
+        const dim3 grid8 = a.stream.n_wgs ? dim3(a.stream.n_wgs) : a.rows_first ? dim3(n_layers, a.n_splits) : dim3(a.n_splits, n_layers);
+        if (a.stream.n_wgs || a.wg8 == 2u) hipLaunchKernelGGL((k_attend_int4_wg8<1, true>), grid8, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((k_attend_int4_wg8<2, true>), grid8, dim3(1024), 0, s, a);
+        return hipGetLastError();
+    }
     if (a.wg8 && a.lin_base && a.heads == 8u) {                          // whole records per workgroup: one workgroup per (layer | sequence, split)
         const dim3 grid8 = a.stream.n_wgs ? dim3(a.stream.n_wgs) : a.rows_first ? dim3(n_layers, a.n_splits) : dim3(a.n_splits, n_layers);
         if (a.stream.n_wgs || a.wg8 == 2u) hipLaunchKernelGGL(k_attend_int4_wg8<1>, grid8, dim3(512), 0, s, a);

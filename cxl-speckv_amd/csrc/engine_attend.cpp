@@ -305,13 +305,15 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     if (fp8 && any_striped && tuning().attend_fp8_table_regs == 0) any_table = true;
     if (any_table)                                           // (AttendSeq::lin_base carries the page table in table launches)
         for (uint32_t i = 0; i < n_seq; ++i) seqs[i].lin_base = reinterpret_cast<const uint8_t*>(ents[i]);
-    if (mx4 && any_striped && !any_table) {                  // the striped form of k_attend_mx4 counts its tiles by residue class
+    // INT4_G32, 8 kv heads, every member placed regularly (one run = "striped over 1"): the whole-record kernel by residue classes
+    const bool int4_cls = !fp8 && !mx4 && any_striped && !any_table && heads == 8u && tuning().attend_int4_striped_wg == 0;
+    if ((mx4 || int4_cls) && any_striped && !any_table) {    // the striped forms of k_attend_mx4 / k_attend_int4_wg8 count their tiles by residue class
         total_tiles = 0;
         for (uint32_t i = 0; i < n_seq; ++i) { seqs[i].n_splits = mx4_striped_tiles(seqs[i].n_pages, seqs[i].stripe_n); total_tiles += seqs[i].n_splits; }
     }
     uint32_t tiles_max = 0;
     for (uint32_t i = 0; i < n_seq; ++i) tiles_max = std::max(tiles_max, seqs[i].n_splits);
-    const bool wg8 = !fp8 && !mx4 && !any_striped && !any_table && heads == 8u;
+    const bool wg8 = !fp8 && !mx4 && (!any_striped || int4_cls) && !any_table && heads == 8u;
     const uint32_t tps = mx4 ? mx4_batch_tps(n_seq, tiles_max, cus()) : wg8 ? int4_wg8_batch_tps(n_seq, tiles_max, cus()) : batch_tiles_per_split(fp8, n_seq, heads, total_tiles, seqs.data(), 0);
     const UnequalSplit unequal = (fp8 || mx4 || wg8) ? UnequalSplit{false, 1.0} : int4_unequal_split(n_seq, heads / 4u, tiles_max);
     uint32_t max_splits = 0;
@@ -407,8 +409,9 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
 struct PlanGeometry { uint32_t tps, max_splits; uint64_t parts_bound; UnequalSplit unequal; };
 static PlanGeometry plan_geometry(bool fp8, uint32_t n_seq, uint32_t heads, uint32_t max_pos_end, uint32_t cus, bool mx4 = false, uint32_t mx4_stripe_n_max = 0)
 {
-    // (MXFP4 over striped pools counts tiles by residue class: at most ceil(pages / 16) + runs + 1 of them, whatever a member's run count)
-    const uint32_t tiles_max = (max_pos_end / 2u + 15u) / 16u + (mx4 && mx4_stripe_n_max >= 2u ? mx4_stripe_n_max + 1u : 0u);
+    // (MXFP4 -- and INT4_G32 on the whole-record kernel -- over striped pools count tiles by residue class: at most ceil(pages / 16) +
+    //  runs + 1 of them, whatever a member's run count; mx4_stripe_n_max is the largest run count of such a plan, 0 otherwise)
+    const uint32_t tiles_max = (max_pos_end / 2u + 15u) / 16u + (!fp8 && mx4_stripe_n_max >= 2u ? mx4_stripe_n_max + 1u : 0u);
     PlanGeometry g{};
     if (mx4) {
         g.unequal = UnequalSplit{false, 1.0};
@@ -478,7 +481,8 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
     }
     if (scheme == SPECKV_COMP_FP8_E4M3 && any_striped && tuning().attend_fp8_table_regs == 0) any_table = true;       // (see attend_batch)
     uint32_t stripe_n_max = 0;
-    if (scheme == SPECKV_COMP_MXFP4 && any_striped && !any_table)
+    const bool int4_cls = scheme == SPECKV_COMP_INT4_G32 && any_striped && !any_table && heads == 8u && tuning().attend_int4_striped_wg == 0;
+    if ((scheme == SPECKV_COMP_MXFP4 || int4_cls) && any_striped && !any_table)
         for (uint32_t i = 0; i < n_seq; ++i) {
             seqs[i].n_splits = mx4_striped_tiles(seqs[i].n_pages, seqs[i].stripe_n);
             stripe_n_max = std::max(stripe_n_max, seqs[i].stripe_n);
@@ -575,7 +579,10 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
     k.q8 = static_cast<const uint8_t*>(d_q_f16);
     k.scale_log2e = sm_scale * 1.4426950408889634f;
     if (plan->second.table) { k.table_form = 1u; k.zero_page = d_zero_page_; }           // a member without a regular placement: addresses from the page tables
-    else if (plan->second.striped) k.stripe_bases = reinterpret_cast<const uint64_t*>(1);     // striped launch: every descriptor brings its table
+    else if (plan->second.striped) {                           // striped launch: every descriptor brings its table
+        k.stripe_bases = reinterpret_cast<const uint64_t*>(1);
+        if (!fp8 && !mx4 && plan->second.mx4_stripe_n_max) k.wg8 = int4_wg8_form(n_seq, cus());      // (planned by residue classes: the whole-record kernel)
+    }
     else { k.lin_base = reinterpret_cast<const uint8_t*>(1); if (!fp8 && !mx4) k.wg8 = int4_wg8_form(n_seq, cus()); }     // non-null: linear form (the real base comes from the descriptor)
     k.seqs = static_cast<const AttendSeq*>(d_plan);
     k.part_acc = reinterpret_cast<float*>(buf);
@@ -702,13 +709,17 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     const uint64_t v_first = k_first + L.num_tokens / 2;
     const uint64_t layer_stride = static_cast<uint64_t>(L.num_tokens);
     if (v_first + (n_layers - 1) * layer_stride + n_pages > a->n_pages) return SPECKV_ERR_GENERAL;
-    const uint32_t n_tiles = (n_pages + 15u) / 16u;
+    uint32_t n_tiles = (n_pages + 15u) / 16u;
     // linear form: records in one local run and every 32-position tile inside the layer's K / V region; otherwise the
     // page-table form of the same kernel
     const bool fits = static_cast<uint64_t>(pos_begin) + static_cast<uint64_t>(n_tiles) * 32u <= L.num_tokens;
     const bool general_env = tuning().attend_general != 0;
     const bool linear = a->linear_base && fits && !general_env;
     const bool striped = !linear && a->stripe_n >= 2 && fits && !general_env;
+    // a pool striped over 2..8 runs, 8 kv heads: the whole-record kernel over the range's pages by residue class (every tile 16
+    // consecutive records of one run: the linear form's fetch; k_attend_int4_wg8<.., CLS>)
+    const bool cls = striped && L.num_heads == 8 && a->stripe_n <= 8 && tuning().attend_int4_striped_wg == 0;
+    if (cls) n_tiles = mx4_striped_tiles(n_pages, a->stripe_n);
     // everything else -- no regular placement, a last tile that would leave the region, SPECKV_ATTEND_GENERAL (measurements,
     // tests) -- takes the workgroup kernel with its record addresses from the page table: its look-ups are clamped to the
     // range, so a ragged last tile never reads a record it has no business with.  (The per-wave page-table kernel of rounds
@@ -728,7 +739,7 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
     // to each other (measured at 32k x 80 layers: 8 splits 0.598, 10 or 12 splits 0.56, 16 splits 0.595)
     if (want > 8u) want &= ~7u;
     // whole-record kernel (8 waves = 8 heads, one workgroup per CU): workgroups = splits x layers, in whole rounds of the CUs
-    const bool wg8 = linear && L.num_heads == 8;
+    const bool wg8 = (linear || cls) && L.num_heads == 8;
     if (wg8) want = int4_wg8_splits(n_layers, n_tiles, cus());
     const bool forced_splits = tuning().attend_splits > 0;
     if (forced_splits) want = static_cast<uint32_t>(tuning().attend_splits);
@@ -737,6 +748,7 @@ int Engine::attend_int4(uint64_t handle, uint32_t layer, uint32_t n_layers, cons
         es = even_split(n_tiles, es.n_splits & ~7u);
     AttendArgs k{};
     const bool stream = wg8 && !forced_splits && int4_wg8_stream(n_layers, n_tiles, cus(), &k.stream);
+    if (stream && cls) k.stream.tiles = n_tiles;                   // (the merge counts a layer's partials from the same tile count)
     const uint32_t n_splits = stream ? k.stream.max_slots : es.n_splits, tiles_per_split = es.tiles_per_split;      // (stream: slots per row)
     const size_t acc_bytes = static_cast<size_t>(rows) * n_splits * 16 * 128 * sizeof(float);
     const size_t ml_bytes = static_cast<size_t>(rows) * n_splits * 32 * sizeof(float);

@@ -323,7 +323,7 @@ struct AttendArgs {
     uint32_t wg8;                     // 1: the engine's choice of form; 2: workgroups of one run (8 waves) also for batches
     // ... and its STREAM form for many layers of one sequence (see k_attend_int4_wg8): n_wgs != 0 turns it on.  The rows'
     // partials then sit at (row * max_slots + slot) and the merge takes each row's count from attend_stream_count().
-    struct Stream { uint32_t len, rem, n_wgs, max_slots; } stream;
+    struct Stream { uint32_t len, rem, n_wgs, max_slots, tiles; } stream;      // tiles: per layer, 0 = ceil(n_pages / 16) (the class form of INT4_G32 over a striped pool counts by residue class)
     // planned batches, MXFP4: the position a sequence still keeps OUTSIDE the pool (the connector's odd last position, fp16 rows
     // [tail][layers][heads][128], tail_stride elements apart) is folded in by the attention kernel itself -- by the workgroup of
     // split 0, into its partial or final state, in the epilogue -- instead of by a launch of its own behind every layer's attention.

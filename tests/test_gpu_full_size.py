@@ -188,9 +188,10 @@ def test_config5_70b_shaped_32k_context_at_full_size(eng, oracle, scheme):
     lib.free(h)
 
 
-def test_config4_layout_70b_shaped_32k_context_striped_over_7_pools_mxfp4(oracle):
+@pytest.mark.parametrize("scheme", [5, 3])
+def test_config4_layout_70b_shaped_32k_context_striped_over_7_pools(oracle, scheme):
     """BASELINE configs[3]'s pool layout (1 compute + 7 pool GPUs; here seven runs on this GPU) at configs[4]'s size: 80 layers x 32 768
-    positions of MXFP4 KV striped page by page over the 7 runs -- the fused attention of all layers in one launch (the form that takes
+    positions of MXFP4 (or INT4_G32) KV striped page by page over the 7 runs -- the fused attention of all layers in one launch (the form that takes
     the range's pages by residue class: classes of 2341 and 2340 pages, ragged last tiles), a per-layer call on a range that does
     not start at 0, and sampled pages through fetch + decompress, against the oracle on sampled (layer, head) rows."""
     torch = torch_mod()
@@ -201,7 +202,8 @@ def test_config4_layout_70b_shaped_32k_context_striped_over_7_pools_mxfp4(oracle
         os.environ.pop("SPECKV_POOL_DEVICES", None)
     try:
         lib = kv.lib
-        T, L, scheme = 32768, 80, 5
+        T, L = 32768, 80
+        attend = {3: lib.attend_int4, 5: lib.attend_mx4}[scheme]
         lib.set_compression_scheme(scheme)
         h = kv.allocate(T, L, H, D, 2)
         layer_pages = T
@@ -225,7 +227,7 @@ def test_config4_layout_70b_shaped_32k_context_striped_over_7_pools_mxfp4(oracle
         heads = {0: tuple(int(v) for v in srng.choice(H, 2, replace=False)), mid: (mh,), 79: (7, int(srng.integers(0, 7)))}
         out = torch.full((L, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
         lse = torch.full((L, H, G), float("nan"), dtype=torch.float32, device="cuda")
-        lib.attend_mx4(h, 0, L, q.data_ptr(), G, 0, T, sm, out.data_ptr(), lse.data_ptr())
+        attend(h, 0, L, q.data_ptr(), G, 0, T, sm, out.data_ptr(), lse.data_ptr())
         torch.cuda.synchronize()
         o, l_ = out.cpu().numpy(), lse.cpu().numpy()
         assert np.isfinite(o).all() and np.isfinite(l_).all()
@@ -233,7 +235,7 @@ def test_config4_layout_70b_shaped_32k_context_striped_over_7_pools_mxfp4(oracle
             for head in hs:
                 checkers[layer].check(o[layer, head], l_[layer, head], qh[layer, head], head, T, sm, ("striped x7, all layers", layer, head, "sample seed", seed))
         # one layer by itself on a ragged range (32738 positions: classes of unequal length)
-        lib.attend_mx4(h, 79, 1, q[79].data_ptr(), G, 0, T - 30, sm, out.data_ptr(), lse.data_ptr())
+        attend(h, 79, 1, q[79].data_ptr(), G, 0, T - 30, sm, out.data_ptr(), lse.data_ptr())
         torch.cuda.synchronize()
         checkers[79].check(out[0, 7].cpu().numpy(), lse[0, 7].cpu().numpy(), qh[79, 7], 7, T - 30, sm, ("striped x7, layer 79, 32738 positions", "sample seed", seed))
         rng = np.random.default_rng(seed)
