@@ -735,7 +735,7 @@ __global__ __launch_bounds__(512 * HALVES) __attribute__((amdgpu_waves_per_eu(SP
         count = ct < tiles_in_layer ? min(a.tiles_per_split, tiles_in_layer - ct) : 0u;
     }
     if (CLS) {
-        if (threadIdx.x < 8u) s_bases[threadIdx.x] = a.stripe_bases[threadIdx.x];
+        if (threadIdx.x < 8u) s_bases[threadIdx.x] = ldg_small<uint64_t>(reinterpret_cast<const uint8_t*>(a.stripe_bases + threadIdx.x));
         __syncthreads();
     }
     const uint32_t out_row0 = cl;                                        // (batch form: the row index is the sequence, the addresses use layer 0)
