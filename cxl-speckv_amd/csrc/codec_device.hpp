@@ -100,6 +100,29 @@ __device__ __forceinline__ float div_by_scale(float x, float s, float r)
     return __builtin_fmaf(e, r, q0);
 }
 
+// x / s for fp32 x (the tensor codec's fp32 sources: any finite bit pattern, not an fp16 value): r = RN(1/s), then the two
+// quotient refinements of the IEEE divide's own expansion -- q0 = x r, twice { e = fma(-s, q, x); q = fma(e, r, q) } -- without
+// its per-element v_div_scale / v_rcp / v_div_fixup (5 full-rate instructions instead of 10 + a quarter-rate reciprocal).  With a
+// correctly rounded reciprocal and a faithful q the last step rounds correctly (Markstein); what the scaling instructions
+// protect against -- exponents near the ends of the range -- is excluded by the caller (scale_in_fast_div_range: 2^-60 <= s
+// <= 2^60, |x| <= 127 s (1 + 2^-22)); quotients so small that an intermediate underflows (|x / s| < 2^-40) may differ in their
+// last bits and round to the same stored byte 0.  Checked on the device over EVERY fp32 bit pattern of x against divisors with
+// random and extreme significands (all ones, 1.0) at both ends and the middle of the exponent range:
+// tests/test_gpu_codec.py::test_fast_fp32_division_is_exact via k_debug_divcheck_f32.
+__device__ __forceinline__ float div_f32_by_scale(float x, float s, float r)
+{
+    const float q0 = x * r;
+    const float e0 = __builtin_fmaf(-s, q0, x);
+    const float q1 = __builtin_fmaf(e0, r, q0);
+    const float e1 = __builtin_fmaf(-s, q1, x);
+    return __builtin_fmaf(e1, r, q1);
+}
+__device__ __forceinline__ bool scale_in_fast_div_range(float s)
+{
+    const uint32_t e = (__float_as_uint(s) >> 23) & 0xFFu;              // (sign bit ignored: scales are positive)
+    return e - 67u <= 120u;                                             // 2^-60 .. 2^60 (exclusive of the next binade)
+}
+
 // m / 7.0f for a non-negative finite fp16 VALUE m (the INT4_G32 group scale before its rounding to fp16), correctly rounded, in two
 // operations instead of the IEEE divide's ten: fma(m, hi, m*lo) with hi = fl(1/7), lo = fl(1/7 - hi).  m has 11 significant bits and
 // m/7 never comes within 2^-27 (relative) of a rounding boundary of fp32, the pair (hi, lo) carries 1/7 to 2^-50.  Checked
@@ -156,6 +179,14 @@ __device__ __forceinline__ uint32_t quantize(float x, float scale)
 __device__ __forceinline__ int round_to_int(float y)
 {
     return static_cast<int>(y + __builtin_copysignf(0.5f, y));
+}
+// The same for ANY fp32 y (the tensor codec's fp32 sources): with 0.5 the sum of y = pred(0.5) rounds up to 1.0 (the one value
+// where y + 0.5 leaves y's binade for a coarser one and lands on a tie); with pred(0.5) it does not, and every half-integer
+// still reaches the next integer (n + 0.5 + pred(0.5) is within a quarter ulp of n + 1).  Checked over every fp32 quotient
+// next to the divide (k_debug_divcheck_f32).
+__device__ __forceinline__ int round_to_int_f32(float y)
+{
+    return static_cast<int>(y + __builtin_copysignf(0x1.fffffep-2f, y));
 }
 template <int MODE>
 __device__ __forceinline__ uint32_t quantize_finite(float x, float scale, float rcp)

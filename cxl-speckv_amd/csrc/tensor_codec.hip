@@ -37,6 +37,11 @@ constexpr bool kTcNoFast = true;             // (A/B builds: the element-wise ti
 #else
 constexpr bool kTcNoFast = false;
 #endif
+#ifdef SPECKV_TC_PRE_RELOAD
+constexpr bool kTcPreRegs = false;           // (A/B builds: fp16 tiles read again behind the rendezvous, like fp32 ones)
+#else
+constexpr bool kTcPreRegs = true;
+#endif
 constexpr uint32_t kTcLead = 16;            // bytes in front of a wave's pair buffer: "count of the pair before the first" lands here
 
 struct TcSummary {                          // what a tile knows without its left neighbours (positions tile-relative, +1; 0 = none)
@@ -139,55 +144,69 @@ __device__ __forceinline__ float tc_scale(uint32_t absmax_bits)
 // per lane and step -- two 16-byte loads -- with the IEEE divide of quantize<MODE> (the reciprocal short cut of quantize8 is
 // exact for fp16-valued operands only).  Such tiles took the element-wise loop before: a 256 Mi-element fp32 tensor compressed
 // in 1.54 ms against 0.47 ms for the same values as fp16.
-template <int MODE>
-__device__ __forceinline__ void quantize8_f32(const u32x4 a, const u32x4 b, float scale, uint32_t (&q)[8])
+template <int MODE, bool FASTDIV>
+__device__ __forceinline__ void quantize8_f32(const u32x4 a, const u32x4 b, float scale, float rcp, uint32_t (&q)[8])
 {
     const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         f32x2 y;
-        y.x = __uint_as_float(w[2 * t]) / scale;                     // (correctly rounded: no fast-math in this build)
-        y.y = __uint_as_float(w[2 * t + 1]) / scale;
+        if (FASTDIV) {                                               // (the scale is inside 2^-60 .. 2^60: codec_device.hpp, div_f32_by_scale)
+            y.x = div_f32_by_scale(__uint_as_float(w[2 * t]), scale, rcp);
+            y.y = div_f32_by_scale(__uint_as_float(w[2 * t + 1]), scale, rcp);
+        } else {
+            y.x = __uint_as_float(w[2 * t]) / scale;                 // (correctly rounded: no fast-math in this build)
+            y.y = __uint_as_float(w[2 * t + 1]) / scale;
+        }
         if (MODE == kRefExact) { const f32x2 k127 = {127.0f, 127.0f}; y = y * k127; }      // cache_engine.cpp:190-191
         f32x2 h;
-        h.x = __builtin_copysignf(0.5f, y.x);
-        h.y = __builtin_copysignf(0.5f, y.y);
-        const f32x2 r = y + h;                                       // round half away from zero = truncate(y + copysign(0.5, y))
+        h.x = __builtin_copysignf(0x1.fffffep-2f, y.x);              // (round_to_int_f32: pred(0.5), exact for every fp32 y)
+        h.y = __builtin_copysignf(0x1.fffffep-2f, y.y);
+        const f32x2 r = y + h;                                       // round half away from zero = truncate(y + copysign(pred(0.5), y))
         int i0 = static_cast<int>(r.x), i1 = static_cast<int>(r.y);
         if (MODE != kRefExact) { i0 = min(max(i0, -127), 127); i1 = min(max(i1, -127), 127); }
         q[2 * t] = static_cast<uint32_t>(i0);
         q[2 * t + 1] = static_cast<uint32_t>(i1);
     }
 }
-template <int MODE, bool EMIT, bool SRC32 = false>
+//   PRE (k_tcm_fused took the tile's max|x| itself): fp16 -- the tile's 4 KiB are in registers already and known to be finite; fp32 -- known
+//   to be finite, loaded again (out of the L2: holding 32 registers across the rendezvous spilled 20 of the kernel's 64).
+template <int MODE, bool EMIT, bool SRC32 = false, bool PRE = false>
 __device__ __forceinline__ bool tc_tile_fast(const uint8_t* tsrc, float scale, float rcp, uint32_t qtail, uint32_t dtail, uint32_t pair_m1,
-                                             uint32_t lane, uint32_t& first_ss, uint32_t& last_ss, uint32_t& n_starts)
+                                             uint32_t lane, uint32_t& first_ss, uint32_t& last_ss, uint32_t& n_starts, const u32x4* pre = nullptr)
 {
     uint4 raw[4];
     u32x4 rf[SRC32 ? 8 : 1];
-    if (SRC32) {
+    if (PRE && !SRC32 && kTcPreRegs) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) raw[j] = make_uint4(pre[j].x, pre[j].y, pre[j].z, pre[j].w);
+    } else if (SRC32) {
         uint32_t m = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             rf[j] = __builtin_nontemporal_load((const u32x4 __attribute__((address_space(1)))*)(reinterpret_cast<uintptr_t>(tsrc + 4ull * (512u * (j >> 1) + 8u * lane) + 16u * (j & 1))));
-            m = umax(m, umax(umax(rf[j].x & 0x7FFFFFFFu, rf[j].y & 0x7FFFFFFFu), umax(rf[j].z & 0x7FFFFFFFu, rf[j].w & 0x7FFFFFFFu)));
+            if (!PRE) m = umax(m, umax(umax(rf[j].x & 0x7FFFFFFFu, rf[j].y & 0x7FFFFFFFu), umax(rf[j].z & 0x7FFFFFFFu, rf[j].w & 0x7FFFFFFFu)));
         }
-        if (lane63(wave_incl_max(m)) >= 0x7F800000u) return false;  // wave-uniform: inf / NaN in the tile
+        if (!PRE && lane63(wave_incl_max(m)) >= 0x7F800000u) return false;  // wave-uniform: inf / NaN in the tile
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const u32x4 v = __builtin_nontemporal_load((const u32x4 __attribute__((address_space(1)))*)(reinterpret_cast<uintptr_t>(tsrc + 2ull * (512u * j + 8u * lane))));
             raw[j] = make_uint4(v.x, v.y, v.z, v.w);
         }
-        if (absmax_bits(raw) >= 0x7C00u) return false;              // wave-uniform
+        if (!PRE && absmax_bits(raw) >= 0x7C00u) return false;      // wave-uniform
     }
     uint32_t mcarry = 0, icarry = 0, first = 0;
     bool prev_sparse = false, failed = false;
+    const bool fast_div = SRC32 && __builtin_amdgcn_readfirstlane(scale_in_fast_div_range(scale) ? 1u : 0u) != 0u;      // (one scale per tensor)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t p0 = 512u * j + 8u * lane;
         uint32_t q[8];
-        if (SRC32) quantize8_f32<MODE>(rf[SRC32 ? 2 * j : 0], rf[SRC32 ? 2 * j + 1 : 0], scale, q);
+        if (SRC32) {
+            if (fast_div) quantize8_f32<MODE, true>(rf[SRC32 ? 2 * j : 0], rf[SRC32 ? 2 * j + 1 : 0], scale, rcp, q);
+            else          quantize8_f32<MODE, false>(rf[SRC32 ? 2 * j : 0], rf[SRC32 ? 2 * j + 1 : 0], scale, rcp, q);
+        }
         else       quantize8<MODE>(raw[j], scale, rcp, q);
         const uint32_t prevq = wave_shr1(q[7], qtail);
         qtail = lane63(q[7]);
@@ -1281,10 +1300,11 @@ __device__ __forceinline__ uint64_t tc_look_back(const uint64_t* status, uint64_
 // BATCH (speckv_ext_codec_compress_tensors: many tensors per launch, ONE workgroup per tensor): the workgroup walks its tensor in
 // rounds of kTfWaves tiles, and what enters a round from the left is what the previous round left in LDS -- no status words, no
 // look-back, no ticket: thousands of independent chains of a few rounds each instead of one chain over the whole launch.
-template <int MODE, bool F32, bool BATCH>
+template <int MODE, bool F32, bool BATCH, bool PRE = false>
 __device__ __forceinline__ void tc_fused_body(const void* __restrict__ src, uint64_t n, float scale, uint64_t n_tiles, uint64_t wg0,
                                               uint64_t* __restrict__ w1, uint64_t* __restrict__ w2, uint8_t* __restrict__ out,
-                                              float* __restrict__ out_scale, uint64_t* __restrict__ out_bytes, uint32_t no_split)
+                                              float* __restrict__ out_scale, uint64_t* __restrict__ out_bytes, uint32_t no_split,
+                                              const u32x4* pre = nullptr, bool pre_ok = false)
 {
     constexpr uint32_t kSlot = kTcLead + 2 * kTile + 16;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kTfWaves * kSlot];
@@ -1356,10 +1376,10 @@ __device__ __forceinline__ void tc_fused_body(const void* __restrict__ src, uint
     const bool tile_fast_ok = len == kTile && ((reinterpret_cast<uintptr_t>(src) + (F32 ? 4ull : 2ull) * t0) & 15u) == 0u && !kTcNoFast;
     const bool getenv_no_split = no_split != 0u;                        // (tuning.hpp tc_no_split_tiles: the element-wise loop for long stretches, tests)
     if (valid) {
-        if (tile_fast_ok) {
+        if (PRE ? pre_ok : tile_fast_ok) {                              // (PRE: the wave's tile is whole, aligned, finite and in registers)
             uint32_t f_first = 0, f_last = 0, f_n = 0;
-            if (tc_tile_fast<MODE, true, F32>(static_cast<const uint8_t*>(src) + (F32 ? 4ull : 2ull) * t0, scale, 1.0f / scale, qtail0, t0 == 0u ? 0x100u : dtail0, pair_addr - 1u, lane,
-                                              f_first, f_last, f_n)) {
+            if (tc_tile_fast<MODE, true, F32, PRE>(static_cast<const uint8_t*>(src) + (F32 ? 4ull : 2ull) * t0, scale, 1.0f / scale, qtail0, t0 == 0u ? 0x100u : dtail0, pair_addr - 1u, lane,
+                                                   f_first, f_last, f_n, pre)) {
                 first_ss = f_first; scarry = f_last; mcarry = f_last; own_runs = f_n;
                 fast = true;
             }
@@ -1461,42 +1481,47 @@ __device__ __forceinline__ void tc_fused_body(const void* __restrict__ src, uint
     if (g_end <= g_begin) continue;
     const uint32_t l_begin = kTcLead - (lead_out ? 1u : 0u);             // LDS offset (in wl) of the byte that goes to g_begin
     const uintptr_t gaddr = reinterpret_cast<uintptr_t>(out) + g_begin, gend = reinterpret_cast<uintptr_t>(out) + g_end;
-    const uintptr_t a0 = gaddr & ~static_cast<uintptr_t>(15);
-    // LDS byte offset of global address a: l_begin + (a - gaddr).  For 16-byte aligned a the offset modulo 4 is one value (sh).
+    const uintptr_t a0v = gaddr & ~static_cast<uintptr_t>(15);
+    // Everything about the stretch is the same for the 64 lanes: said so (SGPRs), and as 32-bit offsets from a0 -- the loop below
+    // was 53 vector instructions per KiB of stream on 64-bit addresses (a fifth of the kernel's: PMC, round 6).
+    // (the builtin returns a signed int: through uint32_t, or a low half with bit 31 set sign-extends over the high one)
+    const uintptr_t a0 = static_cast<uintptr_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a0v)))) |
+                         (static_cast<uintptr_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a0v >> 32)))) << 32);
+    const uint32_t first = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(gaddr - a0v));       // bytes of a0's 16 that are the left neighbour's
+    const uint32_t total = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(gend - a0v));         // the stretch ends `total` bytes behind a0
+    // LDS offset (in wl) of global address a0 + x: delta + x (delta >= 0: the lead is 16 bytes).  For x a multiple of 16 the offset
+    // modulo 16 is one value: sh = byte shift inside a dword, dsel = which five of eight dwords
+    const uint32_t delta = __builtin_amdgcn_readfirstlane(l_begin - first);
     const uint32_t wl_addr = pair_addr - kTcLead;
-    const int32_t delta = static_cast<int32_t>(l_begin) - static_cast<int32_t>(gaddr - a0);       // LDS offset of a0 (>= 0: the lead is 16 bytes)
-    const uint32_t sh = static_cast<uint32_t>(delta) & 3u;
+    const uint32_t sh = delta & 3u, dsel = (delta >> 2) & 3u;
+    const uint32_t full_begin = first ? 16u : 0u, full_end = total & ~15u;      // whole 16-byte pieces: [full_begin, full_end)
+    typedef u32x4 __attribute__((address_space(1)))* g_u32x4_p;        // (global address space spelled out: a pointer made from an
+    typedef uint8_t __attribute__((address_space(1)))* g_u8_p;          //  integer is a FLAT pointer to the compiler, and flat stores count in lgkmcnt beside the LDS reads of the next piece)
+    typedef const u32x4 __attribute__((address_space(3)))* l_u32x4_p;
+    // the 20 bytes around a piece as two ALIGNED 16-byte reads (lanes 16 bytes apart: conflict-free); which five of the eight
+    // dwords are wanted is wave-uniform: one loop per value
+    auto pieces = [&](auto ds_c) {
+        constexpr uint32_t ds = decltype(ds_c)::value;
 #pragma unroll 1
-    for (uintptr_t a = a0 + 16u * lane; a < gend; a += 1024u) {
-        const int32_t lo = delta + static_cast<int32_t>(a - a0);          // LDS offset of the chunk's first byte
-        if (a >= gaddr && a + 16u <= gend) {
-            // the 20 bytes around the piece as two ALIGNED 16-byte reads (lanes 16 bytes apart: conflict-free) instead of five dword
-            // reads at a 16-byte lane stride (each a 4-way bank conflict: 305 M of the kernel's 472 M LDS-active cycles, PMC of round
-            // 4); which five of the eight dwords are wanted is the same for every lane ((lo >> 2) & 3 = (delta >> 2) & 3)
-            const uint32_t base = wl_addr + static_cast<uint32_t>(lo & ~15);
-            typedef const u32x4 __attribute__((address_space(3)))* l_u32x4_p;
+        for (uint32_t x = full_begin + 16u * lane; x < full_end; x += 1024u) {
+            const uint32_t base = wl_addr + ((delta + x) & ~15u);
             const u32x4 q0 = *(l_u32x4_p)(static_cast<uintptr_t>(base)), q1 = *(l_u32x4_p)(static_cast<uintptr_t>(base + 16u));
             const uint32_t e8[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-            uint32_t d[5];
-            const uint32_t dsel = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(delta) >> 2) & 3u;      // (wave-uniform)
-            if (dsel == 0u)      { d[0] = e8[0]; d[1] = e8[1]; d[2] = e8[2]; d[3] = e8[3]; d[4] = e8[4]; }
-            else if (dsel == 1u) { d[0] = e8[1]; d[1] = e8[2]; d[2] = e8[3]; d[3] = e8[4]; d[4] = e8[5]; }
-            else if (dsel == 2u) { d[0] = e8[2]; d[1] = e8[3]; d[2] = e8[4]; d[3] = e8[5]; d[4] = e8[6]; }
-            else                 { d[0] = e8[3]; d[1] = e8[4]; d[2] = e8[5]; d[3] = e8[6]; d[4] = e8[7]; }
             u32x4 v;
-            v.x = __builtin_amdgcn_alignbyte(d[1], d[0], sh); v.y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
-            v.z = __builtin_amdgcn_alignbyte(d[3], d[2], sh); v.w = __builtin_amdgcn_alignbyte(d[4], d[3], sh);
-            // (global address space spelled out: a pointer made from an integer is a FLAT pointer to the compiler, and flat stores
-            //  count in lgkmcnt beside the LDS reads of the next piece)
-            typedef u32x4 __attribute__((address_space(1)))* g_u32x4_p;
-            __builtin_nontemporal_store(v, (g_u32x4_p)(a));
-        } else {                                                        // a ragged piece at one end of the tile's stretch of the stream
-            typedef uint8_t __attribute__((address_space(1)))* g_u8_p;
-            for (uint32_t b = 0; b < 16u; ++b) {
-                const uintptr_t g = a + b;
-                if (g >= gaddr && g < gend) *(g_u8_p)(g) = wl[lo + static_cast<int32_t>(b)];
-            }
+            v.x = __builtin_amdgcn_alignbyte(e8[ds + 1], e8[ds], sh); v.y = __builtin_amdgcn_alignbyte(e8[ds + 2], e8[ds + 1], sh);
+            v.z = __builtin_amdgcn_alignbyte(e8[ds + 3], e8[ds + 2], sh); v.w = __builtin_amdgcn_alignbyte(e8[ds + 4], e8[ds + 3], sh);
+            __builtin_nontemporal_store(v, (g_u32x4_p)(a0 + x));
         }
+    };
+    if (dsel == 0u)      pieces(std::integral_constant<uint32_t, 0u>{});
+    else if (dsel == 1u) pieces(std::integral_constant<uint32_t, 1u>{});
+    else if (dsel == 2u) pieces(std::integral_constant<uint32_t, 2u>{});
+    else                 pieces(std::integral_constant<uint32_t, 3u>{});
+    // the ragged pieces at the two ends of the stretch, a byte per lane: lanes 0-15 the first piece, 16-31 the last
+    if (lane < 32u) {
+        const uint32_t piece = lane >> 4, x = (piece ? full_end : 0u) + (lane & 15u);
+        const bool want = piece ? (full_end < total && full_end >= full_begin) : (first != 0u);
+        if (want && x >= first && x < total) *(g_u8_p)(a0 + x) = wl[delta + x];
     }
     }   // rounds
 }
@@ -1567,9 +1592,44 @@ __global__ __launch_bounds__(64 * kTfWaves) __attribute__((amdgpu_waves_per_eu(8
         if (l == 0u && threadIdx.x == 0u) { out_bytes[t] = 0ull; out_scale[t] = 1.0f; }
         return;
     }
-    constexpr uint64_t kWgElems = static_cast<uint64_t>(kTfWaves) * kTile;
-    const uint64_t e0 = l * kWgElems, cnt = d.n - e0 < kWgElems ? d.n - e0 : kWgElems;
-    uint32_t m = lane63(wave_incl_max(tc_absmax_thread<F32, false>(static_cast<const uint8_t*>(d.data) + e0 * (F32 ? 4u : 2u), cnt, threadIdx.x, 64u * kTfWaves)));
+    // max|x| of this wave's OWN tile, in the layout tc_tile_fast encodes from (round 6; before, the workgroup took the maximum of
+    // its 16 tiles thread by thread with a compare and a select per element, and tc_tile_fast tested its tile for inf / NaN once
+    // more: 160 + 64 vector instructions of the wave's 1300, here 48).  fp32: one shift per word puts |x| in front (order kept),
+    // inf / NaN are the values >= 0xFF000000 of that; fp16: the block encoder's packed maximum, and the tile stays in registers
+    // (16 per lane; fp32's 32 did not fit beside the rendezvous and are read again, out of the L2).  A tile that holds an inf or a
+    // NaN takes the element rule (a NaN never wins, cache_engine.cpp:176-180) and the element-wise encoder, as before.
+    const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
+    const uint64_t my_tile = static_cast<uint64_t>(l) * kTfWaves + wv, my_t0 = my_tile * kTile;
+    const bool tile_valid = my_tile < n_tiles;
+    const uint32_t my_len = tile_valid ? static_cast<uint32_t>((d.n - my_t0 < kTile) ? (d.n - my_t0) : kTile) : 0u;
+    const uint8_t* tsrc = static_cast<const uint8_t*>(d.data) + my_t0 * (F32 ? 4u : 2u);
+    bool pre_ok = tile_valid && my_len == kTile && (reinterpret_cast<uintptr_t>(tsrc) & 15u) == 0u && !kTcNoFast;       // wave-uniform
+    u32x4 pre[4];                                                       // (fp16 sources: the tile; fp32 sources read theirs again, out of the L2)
+    uint32_t m = 0;
+    if (pre_ok) {
+        typedef const u32x4 __attribute__((address_space(1)))* g_u32x4_cp;
+        if (F32) {
+            uint32_t mm = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const u32x4 x = *(g_u32x4_cp)(reinterpret_cast<uintptr_t>(tsrc + 4ull * (512u * (j >> 1) + 8u * ln) + 16u * (j & 1)));
+                mm = umax(umax(mm, x.x << 1), x.y << 1);                 // (v_max3_u32)
+                mm = umax(umax(mm, x.z << 1), x.w << 1);
+            }
+            mm = lane63(wave_incl_max(mm));
+            if (mm >= 0xFF000000u) pre_ok = false; else m = mm >> 1;
+        } else {
+            uint4 raw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pre[j] = __builtin_nontemporal_load((g_u32x4_cp)(reinterpret_cast<uintptr_t>(tsrc + 2ull * (512u * j + 8u * ln))));
+                raw[j] = make_uint4(pre[j].x, pre[j].y, pre[j].z, pre[j].w);
+            }
+            const uint32_t mm = absmax_bits(raw);
+            if (mm >= 0x7C00u) pre_ok = false; else m = mm;
+        }
+    }
+    if (!pre_ok && tile_valid) m = lane63(wave_incl_max(tc_absmax_thread<F32, false>(tsrc, my_len, ln, 64u)));
     if ((threadIdx.x & 63u) == 0u) s_am[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x < 64u) {
@@ -1593,8 +1653,8 @@ __global__ __launch_bounds__(64 * kTfWaves) __attribute__((amdgpu_waves_per_eu(8
         if (lane == 0u) s_bits = all;
     }
     __syncthreads();
-    tc_fused_body<MODE, F32, false>(d.data, d.n, tc_scale(s_bits), n_tiles, l, w1 + static_cast<uint64_t>(t) * wpt, w2 + static_cast<uint64_t>(t) * wpt, d.rle,
-                                    out_scale + t, out_bytes + t, no_split);
+    tc_fused_body<MODE, F32, false, true>(d.data, d.n, tc_scale(s_bits), n_tiles, l, w1 + static_cast<uint64_t>(t) * wpt, w2 + static_cast<uint64_t>(t) * wpt, d.rle,
+                                          out_scale + t, out_bytes + t, no_split, pre, pre_ok);
 }
 
 // ---------------------------------------------------------------- decompress in ONE pass over the stream

@@ -52,6 +52,36 @@ __global__ void k_debug_divcheck(float den, unsigned long long* counters)
     if (badr) atomicAdd(&counters[2], badr);
 }
 
+// div_f32_by_scale (codec_device.hpp; the tensor codec's fp32 sources) against the IEEE divide over EVERY fp32 bit pattern of x
+// with |x| <= 127 s (what a tensor whose abs-max gave the scale s = mx / 127 can hold): counters[0] quotients that differ
+// in their bits where |x / s| >= 2^-40, [1] stored bytes that differ in REF_EXACT (round(x / s * 127) & 0xFF), [2] in the
+// saturating mode (clamp(round(x / s), -127, 127)), [3] elements checked.  One launch per divisor: 2^32 threads.
+__global__ void k_debug_divcheck_f32(float s, unsigned long long* counters)
+{
+    unsigned long long bad = 0, bad_exact = 0, bad_sat = 0, n = 0;
+    for (uint32_t sign = 0; sign < 2u; ++sign) {                        // (a grid holds fewer than 2^32 threads: both signs per thread)
+    const uint32_t xb = (blockIdx.x * blockDim.x + threadIdx.x) | (sign << 31);
+    const float x = __uint_as_float(xb);
+    if ((xb & 0x7F800000u) != 0x7F800000u && fabsf(x) <= 127.0f * s * 1.0000002f) {
+        const float r = 1.0f / s;
+        const float a = x / s, b = div_f32_by_scale(x, s, r);
+        n += 1;
+        if (fabsf(a) >= 0x1p-40f) bad += (__float_as_uint(a) != __float_as_uint(b)) ? 1ull : 0ull;
+        bad_exact += ((static_cast<uint32_t>(static_cast<int>(roundf(a * 127.0f))) & 0xFFu) != (static_cast<uint32_t>(round_to_int_f32(b * 127.0f)) & 0xFFu)) ? 1ull : 0ull;
+        const int sa = static_cast<int>(fminf(fmaxf(roundf(a), -127.0f), 127.0f)), sb = min(max(round_to_int_f32(b), -127), 127);
+        bad_sat += (sa != sb) ? 1ull : 0ull;
+    }
+    }
+    // one atomic per wave
+    for (int off = 32; off; off >>= 1) { bad += __shfl_xor(bad, off); bad_exact += __shfl_xor(bad_exact, off); bad_sat += __shfl_xor(bad_sat, off); n += __shfl_xor(n, off); }
+    if ((threadIdx.x & 63u) == 0u) {
+        if (bad) atomicAdd(&counters[0], bad);
+        if (bad_exact) atomicAdd(&counters[1], bad_exact);
+        if (bad_sat) atomicAdd(&counters[2], bad_sat);
+        if (n) atomicAdd(&counters[3], n);
+    }
+}
+
 // self-test of the wave primitives (tests/test_gpu_codec.py::test_wave_primitives)
 __global__ void k_debug_dpp(const uint32_t* in, uint32_t* out)
 {
@@ -76,6 +106,12 @@ extern "C" {
 int speckv_debug_divcheck(float den, unsigned long long* d_counters, void* stream)
 {
     hipLaunchKernelGGL(speckv::k_debug_divcheck, dim3((0x7BFFu + 255u) / 256u), dim3(256), 0, static_cast<hipStream_t>(stream), den, d_counters);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int speckv_debug_divcheck_f32(float s, unsigned long long* d_counters, void* stream)
+{
+    hipLaunchKernelGGL(speckv::k_debug_divcheck_f32, dim3(1u << 23), dim3(256), 0, static_cast<hipStream_t>(stream), s, d_counters);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -477,6 +477,34 @@ def test_fast_division_is_exact():
         assert cnt.tolist() == [0, 0, 0, 0], (den, cnt.tolist())
 
 
+def test_fast_fp32_division_is_exact():
+    """The tensor codec divides fp32 sources by the tensor's scale through one reciprocal and two refinements
+    (codec_device.hpp: div_f32_by_scale) while the scale lies in 2^-60 .. 2^60.  Device check over EVERY fp32 bit pattern of the
+    dividend a tensor with that scale can hold, per divisor: same quotient bits as the IEEE divide, same stored byte in both
+    modes.  Divisors: significands all ones / 1.0 / random, at both ends and the middle of the admitted exponent range, and
+    mx / 127 for round and random mx."""
+    import ctypes as C
+    import torch
+    lib = load_debug_lib()
+    lib.speckv_debug_divcheck_f32.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(20261004)
+    scales = []
+    for e in (-60, -59, -17, -1, 0, 1, 9, 59, 60):
+        for mant in (0, 0x7FFFFF, 0x400000, 1, int(rng.integers(1, 0x7FFFFF)), int(rng.integers(1, 0x7FFFFF))):
+            scales.append(np.uint32(((e + 127) << 23) | mant).view(np.float32))
+    for mx in (1.0, 3.0, 127.0, 4.75, 65504.0, float(np.float32(rng.uniform(0.1, 20.0))), float(np.float32(rng.lognormal(0.0, 4.0)))):
+        scales.append(np.float32(mx) / np.float32(127.0))
+    checked = 0
+    for s in scales:
+        cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
+        assert lib.speckv_debug_divcheck_f32(float(s), cnt.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        c = cnt.tolist()
+        assert c[:3] == [0, 0, 0] and c[3] > 2 ** 30, (float(s), hex(int(np.float32(s).view(np.uint32))), c)
+        checked += c[3]
+    assert checked > len(scales) * 2 ** 30
+
+
 def test_wave_primitives():
     """DPP scans / shifts on the hardware (the folded wave_shr form once miscompiled)."""
     import ctypes as C
@@ -682,6 +710,19 @@ def test_tensor_codec_matches_oracle_over_sizes_and_structures(lib, oracle):
     cases.append(("sparse", sp))
     wide = rng.standard_normal(5000).astype(np.float32); wide[17] = np.inf; wide[99] = np.nan; wide[4000] = -3e38
     cases.append(("nonfinite", wide))
+    # fp32 quotients on and beside the quantiser's rounding boundaries (n + 0.5, its two neighbours; the same over 127 for
+    # REF_EXACT), for scales inside the range of the reciprocal short cut (div_f32_by_scale: 2^-60 .. 2^60), at its ends, outside
+    # it (the IEEE divide) and with a full significand
+    for e, mant in ((0, 0), (-60, 0), (60, 0x7FFFFF), (-61, 0x7FFFFF), (61, 0), (-100, 0x123456), (90, 0x7FFFFF), (3, 0x7FFFFF), (-7, 0x2AAAAA)):
+        sc = np.uint32(((e + 127) << 23) | mant).view(np.float32)
+        halves = np.arange(0, 127, dtype=np.float32) + np.float32(0.5)
+        qs = np.concatenate([halves, np.nextafter(halves, np.float32(0)), np.nextafter(halves, np.float32(200)),
+                             halves / np.float32(127), np.nextafter(halves / np.float32(127), np.float32(0)), np.nextafter(halves / np.float32(127), np.float32(2))]).astype(np.float32)
+        qs = np.concatenate([qs, -qs, rng.uniform(-127, 127, 8192 - 2 * qs.size - 1).astype(np.float32)])
+        with np.errstate(over="ignore", under="ignore"):
+            xb = np.concatenate([[np.float32(127) * sc], rng.permutation(qs) * sc]).astype(np.float32)
+        if np.isfinite(xb).all():
+            cases.append((f"boundaries 2^{e} {mant:#x}", xb))
     for name, x in cases:
         for mode in MODES:
             o_scale, o_rle = oracle.compress_f32(x, mode)
