@@ -1906,80 +1906,63 @@ __device__ __forceinline__ void td_window_values(const uint32_t (&w)[4][4], cons
     }
     wave_lds_fence();
 }
-// ... and out: groups of 8 elements aligned in the OUTPUT (16-byte stores) from a table that is aligned to the chunk: bytes
-// re-aligned with v_alignbyte from three aligned dwords; group G of the window covers table bytes [8 G - al, 8 G - al + 8), al =
-// start mod 8.  The groups at the window's two ends that hold fewer than 8 of its elements go element by element (the others
-// belong to the neighbouring chunk's wave, or to the window before / behind).
+// ... and out (round 6): groups of one 16-byte store -- 4 fp32 / 8 fp16 elements -- aligned in the OUTPUT, from a table that is
+// aligned to the chunk: the group's bytes re-aligned with v_alignbyte from aligned dwords (group G of the window covers table
+// bytes [g G - al, g G - al + g), al = start mod g), and every byte turned into its output value by ONE LDS read: `lut_q` = LDS
+// address of entry qp of the workgroup's 512-entry table, entry i = the output bits of int8(i & 0xFF) under the tensor's scale
+// (dequant<MODE>, converted once; the table byte is q - qp mod 256, so byte + qp < 512 needs no wrap).  Before: byte extract, add,
+// sign extension, conversion, the exact division by 127 and the scale per element, and for fp32 a lane's 8 elements exchanged
+// inside the quad so that a store instruction writes whole sectors -- 92 vector instructions per 8 elements, a third of the
+// kernel's; now a lane takes 4 consecutive fp32 elements per store (lanes 16 bytes apart: a contiguous KiB per instruction).
+// The groups at the window's two ends that hold fewer of its elements than a whole group go element by element (the others belong
+// to the neighbouring chunk's wave, or to the window before / behind).
+template <bool F32>
+__device__ __forceinline__ uint32_t td_lut_entry(uint32_t lut_q, uint32_t bytes, int k)
+{
+    typedef const uint32_t __attribute__((address_space(3)))* l_u32_p;
+    return *(l_u32_p)(static_cast<uintptr_t>(lut_q + (((bytes >> (8 * k)) & 0xFFu) << 2)));
+}
 template <int MODE, bool F32>
-__device__ __forceinline__ void td_window_store(const uint8_t* tab, uint32_t wo, uint64_t start, uint64_t end, uint32_t qp, float scale,
+__device__ __forceinline__ void td_window_store(const uint8_t* tab, uint32_t wo, uint64_t start, uint64_t end, uint32_t lut_q,
                                                 uint8_t* __restrict__ dst, uint32_t lane)
 {
-#ifdef SPECKV_TD_UNALIGNED
-    const uint32_t al = 0u;
-    const uint64_t obase = start + wo;
-#else
-    const uint32_t al = static_cast<uint32_t>(start) & 7u;
-    const uint64_t obase = (start & ~7ull) + wo;                        // output position of group 0's first element
-#endif
+    constexpr uint32_t kG = F32 ? 4u : 8u;                              // elements per 16-byte store
+    const uint32_t al = static_cast<uint32_t>(start) & (kG - 1u);
+    const uint64_t obase = (start & ~static_cast<uint64_t>(kG - 1u)) + wo;      // output position of group 0's first element
     const int32_t lo_i = static_cast<int32_t>(al);                      // group-relative bounds of what this window stores
     const uint64_t wend = start + wo + kTdfWin < end ? start + wo + kTdfWin : end;
     const int32_t hi_i = static_cast<int32_t>(wend - obase);
+    const uint32_t tab_addr = lds_addr_of(tab);
+    typedef const uint32_t __attribute__((address_space(3)))* l_u32_p;
+    typedef u32x4 __attribute__((address_space(1)))* g_u32x4_p;
+    const uint32_t sh = (0u - al) & 3u;                                 // (table byte of a group's first element) mod 4: the same for every group
 #pragma unroll 1
     for (uint32_t g0 = 0; static_cast<int32_t>(g0) < hi_i; g0 += 512u) {
-        const int32_t q0 = static_cast<int32_t>(g0 + 8u * lane);         // group-relative element index of the lane's group
-        if (q0 + 8 <= lo_i || q0 >= hi_i) continue;
-        const int32_t tb = q0 - static_cast<int32_t>(al);                // table byte of its first element (>= -7)
-        const uint32_t* dw = reinterpret_cast<const uint32_t*>(tab + ((tb >> 2) << 2));           // (arithmetic shift: -1 -> the dword in front)
-        const uint32_t a0 = dw[0], a1 = dw[1], a2 = dw[2];
-        const uint32_t sh = static_cast<uint32_t>(tb) & 3u;
-        const uint32_t lo4 = __builtin_amdgcn_alignbyte(a1, a0, sh), hi4 = __builtin_amdgcn_alignbyte(a2, a1, sh);
-        float y[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const uint32_t b = (((e < 4 ? lo4 : hi4) >> ((e & 3) * 8)) + qp) & 0xFFu;
-            y[e] = dequant<MODE>(static_cast<int>(static_cast<int8_t>(b)), scale);
-        }
-        const uint64_t o = obase + static_cast<uint64_t>(q0);
-#ifndef SPECKV_TD_F32_PER_LANE
-        if (F32) {
-            // fp32: a lane's group is 32 bytes, so stores from the lane write half of every 64-byte sector per instruction
-            // (kernels.hip store8_f32).  The four lanes of a quad hold 128 contiguous bytes: exchanged inside the quad (DPP
-            // quad_perm, no LDS -- this kernel has none to spare) so that each of the two store instructions writes a whole sector.
-            const int32_t qb = static_cast<int32_t>(g0 + 8u * (lane & ~3u));     // the quad's first element, group-relative
-            if (qb >= lo_i && qb + 32 <= hi_i) {                            // (uniform within the quad: all four groups are whole)
-                const bool odd = (lane & 1u) != 0u;
-                typedef float f32x4v __attribute__((ext_vector_type(4)));
-                f32x4v s1, s2;
+        for (uint32_t part = 0; part < (F32 ? 2u : 1u); ++part) {
+            const int32_t q0 = static_cast<int32_t>(g0 + (F32 ? 256u * part + 4u * lane : 8u * lane));     // group-relative element index of the lane's group
+            if (q0 + static_cast<int32_t>(kG) <= lo_i || q0 >= hi_i) continue;
+            const int32_t tb = q0 - static_cast<int32_t>(al);            // table byte of its first element (>= 1 - kG)
+            const uint32_t da = tab_addr + static_cast<uint32_t>((tb >> 2) << 2);      // (arithmetic shift: -1 -> the dword in front)
+            const uint32_t a0 = *(l_u32_p)(static_cast<uintptr_t>(da)), a1 = *(l_u32_p)(static_cast<uintptr_t>(da + 4u));
+            const uint32_t lo4 = __builtin_amdgcn_alignbyte(a1, a0, sh);
+            uint32_t hi4 = 0u;
+            if (!F32) { const uint32_t a2 = *(l_u32_p)(static_cast<uintptr_t>(da + 8u)); hi4 = __builtin_amdgcn_alignbyte(a2, a1, sh); }
+            uint32_t y[8];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t lo_b = __float_as_uint(y[k]), hi_b = __float_as_uint(y[4 + k]);
-                    const uint32_t a1 = dpp<0x50>(0u, lo_b), b1 = dpp<0x50>(0u, hi_b);          // quad_perm [0,0,1,1]
-                    const uint32_t a2 = dpp<0xFA>(0u, lo_b), b2 = dpp<0xFA>(0u, hi_b);          // quad_perm [2,2,3,3]
-                    s1[k] = __uint_as_float(odd ? b1 : a1);
-                    s2[k] = __uint_as_float(odd ? b2 : a2);
-                }
-                float* qa = reinterpret_cast<float*>(dst) + obase + static_cast<uint64_t>(qb) + 4u * (lane & 3u);
-                __builtin_nontemporal_store(s1, reinterpret_cast<f32x4v*>(qa));
-                __builtin_nontemporal_store(s2, reinterpret_cast<f32x4v*>(qa + 16));
-                continue;
-            }
-        }
-#endif
-        if (q0 >= lo_i && q0 + 8 <= hi_i) {
-            if (F32) {
-                float* op = reinterpret_cast<float*>(dst) + o;
-                typedef float f32x4v __attribute__((ext_vector_type(4)));
-                __builtin_nontemporal_store(f32x4v{y[0], y[1], y[2], y[3]}, reinterpret_cast<f32x4v*>(op));
-                __builtin_nontemporal_store(f32x4v{y[4], y[5], y[6], y[7]}, reinterpret_cast<f32x4v*>(op + 4));
+            for (int e = 0; e < static_cast<int>(kG); ++e) y[e] = td_lut_entry<F32>(lut_q, e < 4 ? lo4 : hi4, e & 3);
+            const uint64_t o = obase + static_cast<uint64_t>(q0);
+            if (q0 >= lo_i && q0 + static_cast<int32_t>(kG) <= hi_i) {
+                u32x4 v;
+                if (F32) { v.x = y[0]; v.y = y[1]; v.z = y[2]; v.w = y[3]; }
+                else { v.x = y[0] | (y[1] << 16); v.y = y[2] | (y[3] << 16); v.z = y[4] | (y[5] << 16); v.w = y[6] | (y[7] << 16); }
+                __builtin_nontemporal_store(v, (g_u32x4_p)(reinterpret_cast<uintptr_t>(dst) + (F32 ? 4ull : 2ull) * o));
             } else {
-                const u32x4 pk = {pack_half2(y[0], y[1]), pack_half2(y[2], y[3]), pack_half2(y[4], y[5]), pack_half2(y[6], y[7])};
-                __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(dst) + o));
-            }
-        } else {
-            for (int e = 0; e < 8; ++e) {
-                if (q0 + e < lo_i || q0 + e >= hi_i) continue;
-                if (F32) reinterpret_cast<float*>(dst)[o + e] = y[e];
-                else { float a = y[e], z = 0.0f; reinterpret_cast<uint16_t*>(dst)[o + e] = static_cast<uint16_t>(pack_half2(a, z) & 0xFFFFu); }
+                for (int e = 0; e < static_cast<int>(kG); ++e) {
+                    if (q0 + e < lo_i || q0 + e >= hi_i) continue;
+                    if (F32) reinterpret_cast<uint32_t*>(dst)[o + e] = y[e];
+                    else reinterpret_cast<uint16_t*>(dst)[o + e] = static_cast<uint16_t>(y[e]);
+                }
             }
         }
     }
@@ -1989,8 +1972,8 @@ __device__ __forceinline__ void td_window_store(const uint8_t* tab, uint32_t wo,
 // they would cost the kernel a workgroup per CU).  Out of line: data that does not compress never gets here.
 template <int MODE, bool F32>
 __device__ __noinline__ void td_windows_behind_the_first(const uint8_t* __restrict__ rle, uint64_t p0, uint64_t n_pairs, uint64_t start,
-                                                         uint64_t end, uint32_t qp, uint32_t tot_c, uint32_t c1, uint32_t c2, uint8_t* tab,
-                                                         float scale, uint8_t* __restrict__ dst, uint32_t lane)
+                                                         uint64_t end, uint32_t lut_q, uint32_t tot_c, uint32_t c1, uint32_t c2, uint8_t* tab,
+                                                         uint8_t* __restrict__ dst, uint32_t lane)
 {
     uint32_t w[4][4], ex[4], st[4], mn = 255u;
     td_load_pairs(rle, p0, n_pairs, true, lane, w, mn);
@@ -1998,7 +1981,7 @@ __device__ __noinline__ void td_windows_behind_the_first(const uint8_t* __restri
 #pragma unroll 1
     for (uint32_t wo = kTdfWin; start + wo < end; wo += kTdfWin) {
         td_window_values(w, ex, st, wo, tot_c, tab, lane, c1, c2);
-        td_window_store<MODE, F32>(tab, wo, start, end, qp, scale, dst, lane);
+        td_window_store<MODE, F32>(tab, wo, start, end, lut_q, dst, lane);
     }
 }
 
@@ -2015,7 +1998,13 @@ __device__ __forceinline__ void td_fused_body(const uint8_t* __restrict__ rle, u
     __shared__ uint32_t s_qp[kTdfWaves];
     __shared__ uint64_t s_carry_before;                                 // BATCH: elements / int8 prefix in front of the round
     __shared__ uint32_t s_carry_q;
+    __shared__ uint32_t s_lut[512];                                     // output bits of int8(i & 0xFF) under this tensor's scale (td_window_store)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t i = threadIdx.x; i < 512u; i += 64u * kTdfWaves) {    // (published by the first barrier of round 0)
+        const float y = dequant<MODE>(static_cast<int>(static_cast<int8_t>(i & 0xFFu)), scale);
+        float a = y, z = 0.0f;
+        s_lut[i] = F32 ? __float_as_uint(y) : (pack_half2(a, z) & 0xFFFFu);
+    }
     if (BATCH && threadIdx.x == 0u) { s_carry_before = 0ull; s_carry_q = 0u; }       // (published by the first barrier of round 0)
     const uint64_t n_rounds = BATCH ? (n_chunks + kTdfChunks - 1u) / kTdfChunks : 1u;
 #pragma unroll 1
@@ -2074,8 +2063,9 @@ __device__ __forceinline__ void td_fused_body(const uint8_t* __restrict__ rle, u
     const uint64_t end = (start + tot_c < cap) ? start + tot_c : cap;
     if (start >= end) continue;
     if (has_zero) { td_chunk_general<MODE, F32>(rle, p0, n_pairs, start, end, qp, scale, dst, lane); continue; }
-    td_window_store<MODE, F32>(tab, 0u, start, end, qp, scale, dst, lane);
-    if (start + kTdfWin < end) td_windows_behind_the_first<MODE, F32>(rle, p0, n_pairs, start, end, qp, tot_c, c1, c2, tab, scale, dst, lane);
+    const uint32_t lut_q = lds_addr_of(reinterpret_cast<const uint8_t*>(s_lut)) + 4u * qp;
+    td_window_store<MODE, F32>(tab, 0u, start, end, lut_q, dst, lane);
+    if (start + kTdfWin < end) td_windows_behind_the_first<MODE, F32>(rle, p0, n_pairs, start, end, lut_q, tot_c, c1, c2, tab, dst, lane);
     }   // rounds
 }
 
