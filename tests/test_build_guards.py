@@ -157,3 +157,37 @@ def test_no_environment_walks_behind_the_entry_points():
     assert "getenv" not in text[end_of_open:], "engine.cpp reads the environment outside Engine::open / Engine::init_hip"
     # the header documents the entry point tests use instead
     assert "speckv_ext_set_tuning" in open(os.path.join(ROOT, "include", "speckv_ext.h")).read()
+
+
+HEADLINE = r"k_fetch_decompressILi2ELi0ELb0ELi0E"                     # k_fetch_decompress<INT8_DELTA_RLE, REF_EXACT, fp16 out, EXT 0>: bench.py's dominant kernel
+
+
+def headline_kernel_hash():
+    """(mangled name, SHA-256 of its instructions one per line without addresses / encodings, instruction count) of the headline
+    kernel as built.  profiles/publish_r06.py writes it into <tag>_pmc.json beside the PMC traffic measured on that build."""
+    import hashlib
+    funcs = _function_text("kernels.o", HEADLINE)
+    assert len(funcs) == 1, list(funcs)
+    (name, lines), = funcs.items()
+    return name, hashlib.sha256("\n".join(lines).encode()).hexdigest(), len(lines)
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump of the ROCm toolchain not found")
+def test_committed_pmc_traffic_belongs_to_the_headline_kernel_as_built():
+    """bench.py's roofline.traffic is a constant read from the newest profiles/r*_pmc.json -- PMC cannot be
+    read from inside the run.  That file names the kernel it was measured on and the hash of its instructions; a build whose
+    headline kernel differs (any change to k_fetch_decompress<2, 0, false, 0>) fails here until the PMC passes are collected
+    again (profiles/tools/r6_final.sh + profiles/publish_r06.py), so the figure cannot go stale silently."""
+    import glob
+    import json
+    import __graft_entry__ as entry
+    if not os.path.exists(os.path.join(OBJ, "kernels.o")):
+        entry.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import bench
+    traffic, src = bench.pmc_traffic(2, 0)
+    assert traffic and src, "no committed PMC file with the headline kernel's traffic"
+    d = json.load(open(os.path.join(root, src)))
+    name, sha, n = headline_kernel_hash()
+    assert d.get("kernel") == name, (src, d.get("kernel"), name)
+    assert d.get("kernel_instructions_sha256") == sha, f"{src} was measured on another build of {name} ({d.get('kernel_instructions')} instructions then, {n} now): collect the PMC passes again"
