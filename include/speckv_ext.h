@@ -262,8 +262,8 @@ speckv_status_t speckv_ext_codec_decompress_tensor(const void* d_rle, uint64_t r
  * tensor is 64 tiles of work and the single-tensor entry point above is all fixed cost (two launches, a look-back chain that has
  * barely started when it ends).  Here one launch takes thousands of tensors: every tensor its own scale, its own delta chain, its
  * own run-length stream; a tensor's workgroups (16 tiles each) find its max|x| by a rendezvous among themselves and hand their
- * chains on by look-back over the tensor's own status words; each workgroup reads the source twice, the second time out of the
- * L2 / Infinity Cache.  Streams and scales are bit-identical to the single-tensor entry point's and to the reference's, per tensor.
+ * chains on by look-back over the tensor's own status words; a wave takes max|x| from its own tile (fp16 tiles stay in registers for
+ * the encode, fp32 tiles are read again out of the L2 / Infinity Cache).  Streams and scales are bit-identical to the single-tensor entry point's and to the reference's, per tensor.
  *   d_tensors  DEVICE array of n_tensors descriptors
  *   max_elems  the host's upper bound on the tensors' lengths (sizes the grid and the workspace; a tensor may be shorter, or empty)
  *   compress:   data = the source (fp16, or fp32 with src_f32), n = its elements, rle = where the stream goes (16-byte aligned),
