@@ -776,10 +776,19 @@ constexpr uint32_t kFdHeads = SPECKV_FP8_WG_HEADS;          // kv heads (= waves
 // = K(t) and entries(t+2) have landed, "all but the 16 youngest" = V(t) has.  (The register-staged k_attend_fp8_linear<STRIPED / TABLE> computed or chased an address
 // per page and request: 0.67-0.69 of the roofline over a pool striped x7 against 0.78 for this pipeline on one run.)
 constexpr uint32_t kFdEnt = 512u;                           // the 32 page-table entries of the tile being requested
-template <bool TABLE>
+// FORM 2, CLS (round 6, after the table form): an allocation striped REGULARLY over 2..8 runs (page p = record p / D of run p % D) needs no
+// page table at all if the range's pages are taken by residue class, as k_attend_mx4 and k_attend_int4_wg8 take them: the pages
+// j = c, c + D, c + 2 D ... of the range are consecutive records of ONE run for K and of one for V, so a tile of 16 of them is
+// 32 KiB in one piece and is fetched exactly like the linear form's (one SGPR base + a lane offset per request: the table form's
+// address per lane is what costs it 5 points of the roofline on any layout).  Attention does not care in which order it meets
+// positions; the scale table keeps its page order and is read with a stride of D pages; pages past a class's end are masked
+// (every class gets the tile count of the largest; FP8 runs carry 15 records of slack so that a ragged last tile stays inside).
+template <int FORM>
 __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_attend_fp8_dma(AttendArgs a)
 {
+    constexpr bool TABLE = FORM == 1, CLS = FORM == 2;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kFdHeads][2 * kFdBuf + (TABLE ? kFdEnt : 0u)];
+    __shared__ uint64_t s_bases[CLS ? 8 : 1];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t c = lane & 15u, kb = lane >> 4;
@@ -808,11 +817,16 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
         part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
         layer = 0;
         if (TABLE) a.entries = reinterpret_cast<const PageEntry*>(sq.lin_base);      // (table launches: the descriptor carries the page table)
+        if (CLS) { a.stripe_bases = sq.stripe_bases; a.stripe_n = sq.stripe_n; }
+    }
+    if (CLS) {                                                           // (workgroup-uniform up to here: every wave gets to the barrier)
+        if (threadIdx.x < 8u) s_bases[threadIdx.x] = *reinterpret_cast<const uint64_t __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(a.stripe_bases + threadIdx.x));
+        __syncthreads();
     }
     uint32_t qd[8];
     float qscale = 1.0f;
 
-    const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
+    const uint32_t n_tiles = CLS ? mx4_striped_tiles(a.n_pages, a.stripe_n) : (a.n_pages + 15u) / 16u;
     const uint32_t t0 = split * a.tiles_per_split;
     const uint32_t t1 = min(t0 + a.tiles_per_split, n_tiles);
     float m_run = -INFINITY, l_run = 0.0f, vref = 1.0f;
@@ -835,18 +849,44 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
         }
         const uint32_t lbase = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&lds[wave][0])));
         const uint32_t last = t1 - 1u;
+        // CLS: the request cursor (class, tile of the class) and what it last resolved to -- the K / V bases of its tile (scalar) and
+        // the lane's scale-table offset; class c holds jq + (c < jr) of the range's pages
+        const uint32_t cls_n = CLS ? (a.stripe_n ? a.stripe_n : 1u) : 1u, cls_m = CLS ? mx4_class_tiles(a.n_pages, cls_n) : 1u;
+        const uint32_t jq = a.n_pages / cls_n, jr = a.n_pages - jq * cls_n;
+        const uint32_t kpage0 = static_cast<uint32_t>(a.k_first + layer * a.layer_stride), vpage0 = static_cast<uint32_t>(a.v_first + layer * a.layer_stride);
+        uint32_t iq_cls = CLS ? t0 / cls_m : 0u, iq_m = CLS ? t0 - iq_cls * cls_m : 0u;
+        const uint8_t* ksrc_c = nullptr; const uint8_t* vsrc_c = nullptr;
+        uint32_t gsc_c = 0u;
+        // (tried: every workgroup row starting on another class, so that the launch does not walk the runs in step -- no difference)
+        auto cls_next = [&]() {
+            uint32_t ic = min(iq_cls, cls_n - 1u);
+            uint32_t cnt = jq + (ic < jr ? 1u : 0u);
+            if (cnt == 0u) { ic = 0u; cnt = 1u; }                            // (fewer pages than runs: an empty class asks for the range's first records, all masked)
+            const uint32_t mm = min(iq_m, (cnt - 1u) >> 4);
+            const uint32_t pk = kpage0 + ic, pv = vpage0 + ic;
+            const uint32_t rk = pk / cls_n, rv = pv / cls_n;                      // (wave-uniform, twice per tile)
+            ksrc_c = uniform_ptr(reinterpret_cast<const uint8_t*>(s_bases[pk - rk * cls_n]) + static_cast<uint64_t>(rk + 16u * mm) * 2048u + head * 128u);
+            vsrc_c = uniform_ptr(reinterpret_cast<const uint8_t*>(s_bases[pv - rv * cls_n]) + static_cast<uint64_t>(rv + 16u * mm) * 2048u + head * 128u);
+            // the lane's scale: LDS slot (lane & 15) = [kb][r] holds the tile's page 2 kb + r (r < 2) or 8 + 2 kb + r - 2 (the order the
+            // readers want: attend_tile_slot); the table keeps every aligned group of 16 pages of a region in that order too
+            const uint32_t sl = lane & 15u, pgi = (sl & 2u) * 4u + (sl >> 2) * 2u + (sl & 1u);
+            const uint32_t rel = ic + cls_n * min(16u * mm + pgi, cnt - 1u), j = rel & 15u;       // page of the range (its first page starts a group)
+            gsc_c = ((lane < 16u ? kpage0 : vpage0) + rel - j + attend_tile_slot(j)) * 4u;
+            if (++iq_m == cls_m) { iq_m = 0u; ++iq_cls; }
+        };
         auto issue_k = [&](uint32_t tt, uint32_t buf) {
             const uint32_t tc = min(tt, last);
-            const uint8_t* src = kreg + static_cast<uint64_t>(tc) * 32768u;
+            if (CLS && tt <= last) cls_next();                               // (behind the split's last tile: that tile again)
+            const uint8_t* src = CLS ? ksrc_c : kreg + static_cast<uint64_t>(tc) * 32768u;
             const uint32_t dst = lbase + buf * kFdBuf;
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i) fd_dma16(dst + 1024u * i, src, g[i]);
             // one instruction for the 32 page scales of the tile: lanes 0..15 from the K table, 16..31 from the V table
             if (lane < 32u)
-                fd_dma4(dst + kFdS, reinterpret_cast<const uint8_t*>(a.scale_tab), gsc + tc * 64u);
+                fd_dma4(dst + kFdS, reinterpret_cast<const uint8_t*>(a.scale_tab), CLS ? gsc_c : gsc + tc * 64u);
         };
-        auto issue_v = [&](uint32_t tt, uint32_t buf) {
-            const uint8_t* src = vreg + static_cast<uint64_t>(min(tt, last)) * 32768u;
+        auto issue_v = [&](uint32_t tt, uint32_t buf) {                     // (CLS: always the tile issue_k has just resolved)
+            const uint8_t* src = CLS ? vsrc_c : vreg + static_cast<uint64_t>(min(tt, last)) * 32768u;
             const uint32_t dst = lbase + buf * kFdBuf + kFdV;
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i) fd_dma16(dst + 1024u * i, src, g[i]);
@@ -944,6 +984,7 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
         quantize_query_rows(qw, c < a.g, qd, qscale);
         qscale *= a.scale_log2e;
         const bool ragged = (a.n_pages & 15u) != 0u;
+        uint32_t cc_cls = CLS ? t0 / cls_m : 0u, cc_m = CLS ? t0 - cc_cls * cls_m : 0u;      // CLS: (class, tile of the class) the arithmetic is at
         auto tile_step = [&](uint32_t tile, uint32_t buf, u32x4& et) __attribute__((always_inline)) {
             const uint32_t bo = buf * kFdBuf;
             u32x4 kx[4];
@@ -975,6 +1016,18 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
                 issue_table(tad, tile + 2u, buf, 0u);
                 et = ent_fetch(tile + 4u);
             }
+            if (CLS) {                                                       // pages of this tile past the end of its class
+                const uint32_t cnt = jq + (cc_cls < jr ? 1u : 0u);
+                const uint32_t have = cnt > 16u * cc_m ? cnt - 16u * cc_m : 0u;          // wave-uniform
+                if (have < 16u) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t pg = (j >> 1) < 2 ? 2u * kb + (j >> 1) : 8u + 2u * kb + ((j >> 1) - 2);
+                        if (pg >= have) sc[j] = -INFINITY;
+                    }
+                }
+                if (++cc_m == cls_m) { cc_m = 0u; ++cc_cls; }
+            } else
             if ((ragged && tile + 1u == n_tiles) || (a.skip_pages && tile == 0u)) {     // wave-uniform: positions beyond / in front of the range
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -1373,7 +1426,7 @@ hipError_t launch_attend_fp8_batch(const AttendArgs& a, uint32_t n_seq, float* d
     // with the LDS-DMA kernel (many short splits: 4 waves/SIMD hide more than two tiles per wave at 2 waves/SIMD); the
     // single-sequence form below is the other way round (8k x 80 layers: 0.61 against 0.55; 32k x 80: 0.70 both)
     if (a.table_form && tuning().attend_fp8_table_regs == 0)            // striped / moved placements: the DMA pipeline with addresses from the page tables
-        hipLaunchKernelGGL(k_attend_fp8_dma<true>, dim3(a.n_splits, n_seq * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
+        hipLaunchKernelGGL(k_attend_fp8_dma<1>, dim3(a.n_splits, n_seq * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
     else if (a.table_form) hipLaunchKernelGGL((k_attend_fp8_linear<false, true>), dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
     else if (a.stripe_bases) hipLaunchKernelGGL(k_attend_fp8_linear<true>, dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
     else     hipLaunchKernelGGL(k_attend_fp8_linear<false>, dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
@@ -1399,10 +1452,12 @@ hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_ou
     // (launches with few workgroup columns -- the per-layer calls of one sequence -- are latency-bound either way: DMA kernel,
     // 13.8 against 15.5 us at 8k context)
     const bool dma_table = !a.lin_base && (a.stripe_bases || a.table_form) && a.scale_tab && a.entries && !a.skip_pages && tuning().attend_fp8_table_regs == 0;
-    if (dma_table)                                                       // striped or moved page by page: the DMA pipeline with addresses from the page table
-        hipLaunchKernelGGL(k_attend_fp8_dma<true>, dim3(a.n_splits, n_layers * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
+    if (a.fp8_cls && a.stripe_bases && a.scale_tab && !a.skip_pages)     // striped regularly: the linear pipeline over residue classes
+        hipLaunchKernelGGL(k_attend_fp8_dma<2>, dim3(a.n_splits, n_layers * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
+    else if (dma_table)                                                  // moved page by page (or striped, on request): the DMA pipeline with addresses from the page table
+        hipLaunchKernelGGL(k_attend_fp8_dma<1>, dim3(a.n_splits, n_layers * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
     else if (a.lin_base && (a.n_splits == 1u || n_layers * (a.heads / 4u) < 128u))
-        hipLaunchKernelGGL(k_attend_fp8_dma<false>, dim3(a.n_splits, n_layers * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
+        hipLaunchKernelGGL(k_attend_fp8_dma<0>, dim3(a.n_splits, n_layers * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
     else if (a.lin_base)
         hipLaunchKernelGGL(k_attend_fp8_linear<false>, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
     else if (a.stripe_bases)

@@ -335,9 +335,10 @@ int Engine::alloc(size_t bytes, const speckv_alloc_hint_t* hint, uint64_t* out)
                 for (uint32_t k = 0; k < D && ok; ++k) {
                     const uint64_t np = shard_pages(a->n_pages, D, k);    // pages with page % D == k
                     if (np == 0) { a->extents.push_back({use[k], nullptr, 0, 0}); continue; }
-                    // (INT4_G32 runs carry 15 records of slack: the class form of the fused attention over a striped pool fetches whole
-                    //  16-record tiles, and the tile that holds a class's last record may reach past the run's -- k_attend_int4_wg8<.., CLS>)
-                    const size_t need = run_bytes_for(a->scheme, a->rec_stride, np) + (a->scheme == SPECKV_COMP_INT4_G32 ? 15u * a->rec_stride : 0u);
+                    // (INT4_G32 runs, and FP8 runs of a striped allocation, carry 15 records of slack: the class forms of the fused attention over
+                    //  a striped pool fetch whole 16-record tiles, and the tile that holds a class's last record may reach past the run's --
+                    //  k_attend_int4_wg8<.., CLS>, k_attend_fp8_dma<2>)
+                    const size_t need = run_bytes_for(a->scheme, a->rec_stride, np) + ((a->scheme == SPECKV_COMP_INT4_G32 || (a->scheme == SPECKV_COMP_FP8_E4M3 && D > 1)) ? 15u * a->rec_stride : 0u);
                     void* base = pools_[use[k]]->alloc(need);
                     if (base) {
                         a->extents.push_back({use[k], base, need, np});

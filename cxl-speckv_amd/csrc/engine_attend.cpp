@@ -108,7 +108,7 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     // A launch that already has 128+ workgroup columns (layers x head quads) is best left unsplit: each workgroup then
     // streams one long run, the rows are final (no partials, no merge launch) -- 80 layers: 1 split 0.73 / 0.70 / 0.64 of
     // HBM peak at 32k / 8k / 2k context against 0.71 / 0.62 / 0.48 with 8 splits.
-    const uint32_t n_tiles = (n_pages + 15u) / 16u;
+    uint32_t n_tiles = (n_pages + 15u) / 16u;
     const uint32_t rows = n_layers * L.num_heads;
     // linear form: records in one run, scale table present, tiles aligned with the table's (pos_begin a multiple of 32),
     // and the last (possibly ragged) 32-position tile must not read past the K / V region of its layer
@@ -126,6 +126,9 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     // (striped / moved placements run the same DMA pipeline with their addresses from the page table, k_attend_fp8_dma<TABLE>: the
     //  same rule; the register-staged kernels of rounds 2-5 -- a range that starts inside a tile, or on request -- want the splits)
     const bool dma_table = (striped || table) && skip_pages == 0 && tuning().attend_fp8_table_regs == 0;
+    // striped regularly: the linear pipeline over the range's pages by residue class (k_attend_fp8_dma<2>): the tiles are then counted per class
+    const bool cls = striped && dma_table && a->stripe_n <= 8 && tuning().attend_fp8_striped_table == 0;
+    if (cls) n_tiles = mx4_striped_tiles(n_pages, a->stripe_n);
     uint32_t want = ((lin_base || dma_table) && rows / 4u >= 128u && n_tiles < 768u) ? 1u : (5120u + rows - 1u) / rows;     // (32k and beyond: 8 splits, below)
     // per-layer calls are latency-bound: short contexts want short splits (measured best: 2 tiles per split at 2k
     // context, 4 at 8k, 8 at 32k), long multi-layer launches are bounded by `want` above
@@ -164,6 +167,7 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     }
     k.part_acc = reinterpret_cast<float*>(buf + q_bytes + qs_bytes);
     k.part_ml = reinterpret_cast<float*>(buf + q_bytes + qs_bytes + acc_bytes);
+    if (cls) k.fp8_cls = 1u;
     if (table) { k.table_form = 1u; k.lin_base = nullptr; k.stripe_bases = nullptr; }
     if (!k.lin_base && !striped && !table)         // the linear / striped / table forms quantise the query in their own prologue
         HIP_TRY(launch_quantize_q_e4m3(d_q_f16, rows, g, L.head_dim, buf, reinterpret_cast<float*>(buf + q_bytes), st));

@@ -323,6 +323,7 @@ struct AttendArgs {
     uint32_t wg8;                     // 1: the engine's choice of form; 2: workgroups of one run (8 waves) also for batches
     // ... and its STREAM form for many layers of one sequence (see k_attend_int4_wg8): n_wgs != 0 turns it on.  The rows'
     // partials then sit at (row * max_slots + slot) and the merge takes each row's count from attend_stream_count().
+    uint32_t fp8_cls = 0;            // FP8 over a regularly striped pool: k_attend_fp8_dma<2>, pages by residue class (n_splits / tiles_per_split count class-major tiles)
     struct Stream { uint32_t len, rem, n_wgs, max_slots, tiles; } stream;      // tiles: per layer, 0 = ceil(n_pages / 16) (the class form of INT4_G32 over a striped pool counts by residue class)
     // planned batches, MXFP4: the position a sequence still keeps OUTSIDE the pool (the connector's odd last position, fp16 rows
     // [tail][layers][heads][128], tail_stride elements apart) is folded in by the attention kernel itself -- by the workgroup of

@@ -564,7 +564,8 @@ double speckv_ext_codec_model_throughput_gbps(uint32_t num_engines, double clock
  * rounds_consecutive, remote_engine (1 kernel, 2 copy engines), copy_min_run_kb, attend_stream (MXFP4, several layers of one
  * sequence: N > 0 the stream form with N workgroups, -1 never), attend_mx4_one_half (MXFP4 batches: 4-wave workgroups also where
  * the two-halves form applies), attend_fold_launch (speckv_ext_attend_planned_tail: the fold always as a launch of its own), attend_layers_loop
- * (speckv_ext_attend_planned_layers: always per-layer launches).  0 restores the library's own rule.
+ * (speckv_ext_attend_planned_layers: always per-layer launches), attend_fp8_table_regs / attend_fp8_striped_table / attend_int4_striped_wg
+ * (striped and migrated pools: the earlier kernel forms, kept as A/B partners and test coverage).  0 restores the library's own rule.
  * SPECKV_ERR_INVAL for an unknown key.  Works without speckv_init.  (INTEGRATION.md lists what each one does.) */
 speckv_status_t speckv_ext_set_tuning(const char* key, long long value);
 

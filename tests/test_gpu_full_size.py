@@ -188,10 +188,10 @@ def test_config5_70b_shaped_32k_context_at_full_size(eng, oracle, scheme):
     lib.free(h)
 
 
-@pytest.mark.parametrize("scheme", [5, 3])
+@pytest.mark.parametrize("scheme", [5, 3, 4])
 def test_config4_layout_70b_shaped_32k_context_striped_over_7_pools(oracle, scheme):
     """BASELINE configs[3]'s pool layout (1 compute + 7 pool GPUs; here seven runs on this GPU) at configs[4]'s size: 80 layers x 32 768
-    positions of MXFP4 (or INT4_G32) KV striped page by page over the 7 runs -- the fused attention of all layers in one launch (the form that takes
+    positions of MXFP4 (or INT4_G32, or FP8_E4M3) KV striped page by page over the 7 runs -- the fused attention of all layers in one launch (the form that takes
     the range's pages by residue class: classes of 2341 and 2340 pages, ragged last tiles), a per-layer call on a range that does
     not start at 0, and sampled pages through fetch + decompress, against the oracle on sampled (layer, head) rows."""
     torch = torch_mod()
@@ -203,7 +203,7 @@ def test_config4_layout_70b_shaped_32k_context_striped_over_7_pools(oracle, sche
     try:
         lib = kv.lib
         T, L = 32768, 80
-        attend = {3: lib.attend_int4, 5: lib.attend_mx4}[scheme]
+        attend = {3: lib.attend_int4, 4: lib.attend_fp8, 5: lib.attend_mx4}[scheme]
         lib.set_compression_scheme(scheme)
         h = kv.allocate(T, L, H, D, 2)
         layer_pages = T
