@@ -1683,6 +1683,13 @@ constexpr uint32_t kTdfWaves = SPECKV_TDF_WAVES;
 #endif
 constexpr uint32_t kTdfLbWave = SPECKV_TDF_LB_WAVE;   // 1: wave 0 of a workgroup takes no chunk, it only looks back (kTdfWaves - 1 chunks per workgroup)
 constexpr uint32_t kTdfChunks = kTdfWaves - kTdfLbWave;
+// The many-streams kernels (k_tdm_fused / k_tdb_fused) take 8-wave workgroups: four of them per CU wait less at their barriers than
+// two of 16 waves (4096 x 131 072 to fp32 0.63 -> 0.65, to fp16 0.56 -> 0.59); ONE long stream wants the 16 -- half as many status
+// words to look back over (32 Mi elements: 0.37 against 0.30 with 8).
+#ifndef SPECKV_TDM_WAVES
+#define SPECKV_TDM_WAVES 8
+#endif
+constexpr uint32_t kTdmWaves = SPECKV_TDM_WAVES, kTdmChunks = kTdmWaves - kTdfLbWave;
 constexpr uint32_t kTdfWin = 4096;           // elements per window
 #define SPECKV_TD_SDWA2(NAME, OP, S0, S1)                                                       \
     __device__ __forceinline__ uint32_t NAME(uint32_t a, uint32_t b)                            \
@@ -1987,30 +1994,30 @@ __device__ __noinline__ void td_windows_behind_the_first(const uint8_t* __restri
 
 // BATCH (speckv_ext_codec_decompress_tensors): one workgroup per stream, rounds of kTdfChunks chunks, the prefix in front of a
 // round carried in LDS (see tc_fused_body).
-template <int MODE, bool F32, bool BATCH>
+template <int MODE, bool F32, bool BATCH, uint32_t WAVES = kTdfWaves>
 __device__ __forceinline__ void td_fused_body(const uint8_t* __restrict__ rle, uint64_t n_pairs, uint64_t n_chunks, uint64_t wg0, uint64_t* __restrict__ status,
                                               uint64_t cap, uint64_t* __restrict__ out_n, float scale, uint8_t* __restrict__ dst)
 {
     constexpr uint32_t kFront = 16;           // bytes in front of a wave's table (the store pass may read up to 7 of them: never used)
-    __shared__ __attribute__((aligned(16))) uint8_t tabs[kTdfWaves][kFront + kTdfWin + 16];      // (+16 behind: written, never used)
-    __shared__ uint32_t s_tot[kTdfWaves];
-    __shared__ uint64_t s_start[kTdfWaves];
-    __shared__ uint32_t s_qp[kTdfWaves];
+    __shared__ __attribute__((aligned(16))) uint8_t tabs[WAVES][kFront + kTdfWin + 16];      // (+16 behind: written, never used)
+    __shared__ uint32_t s_tot[WAVES];
+    __shared__ uint64_t s_start[WAVES];
+    __shared__ uint32_t s_qp[WAVES];
     __shared__ uint64_t s_carry_before;                                 // BATCH: elements / int8 prefix in front of the round
     __shared__ uint32_t s_carry_q;
     __shared__ uint32_t s_lut[512];                                     // output bits of int8(i & 0xFF) under this tensor's scale (td_window_store)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t i = threadIdx.x; i < 512u; i += 64u * kTdfWaves) {    // (published by the first barrier of round 0)
+    for (uint32_t i = threadIdx.x; i < 512u; i += 64u * WAVES) {    // (published by the first barrier of round 0)
         const float y = dequant<MODE>(static_cast<int>(static_cast<int8_t>(i & 0xFFu)), scale);
         float a = y, z = 0.0f;
         s_lut[i] = F32 ? __float_as_uint(y) : (pack_half2(a, z) & 0xFFFFu);
     }
     if (BATCH && threadIdx.x == 0u) { s_carry_before = 0ull; s_carry_q = 0u; }       // (published by the first barrier of round 0)
-    const uint64_t n_rounds = BATCH ? (n_chunks + kTdfChunks - 1u) / kTdfChunks : 1u;
+    const uint64_t n_rounds = BATCH ? (n_chunks + (WAVES - kTdfLbWave) - 1u) / (WAVES - kTdfLbWave) : 1u;
 #pragma unroll 1
     for (uint64_t round = 0; round < n_rounds; ++round) {
     const uint64_t wg = BATCH ? round : wg0;
-    const uint64_t chunk = wg * kTdfChunks + wave - kTdfLbWave;
+    const uint64_t chunk = wg * (WAVES - kTdfLbWave) + wave - kTdfLbWave;
     const bool live = wave >= kTdfLbWave && chunk < n_chunks;           // (waves behind the last chunk only keep the barriers company)
     const uint64_t p0 = chunk * kTile;
     uint32_t w[4][4], ex[4], st[4], mn = 255u;
@@ -2023,7 +2030,7 @@ __device__ __forceinline__ void td_fused_body(const uint8_t* __restrict__ rle, u
     __syncthreads();
     // ---- wave 0: the workgroup's aggregate goes out at once (nobody in front of it is needed for that)
     if (wave == 0u) {
-        const uint32_t wt = lane < kTdfWaves ? s_tot[lane] : 0u;
+        const uint32_t wt = lane < WAVES ? s_tot[lane] : 0u;
         const uint32_t agg_c = lane63(wave_incl_add(wt & 0xFFFFFFu)), agg_v = lane63(wave_incl_add(wt >> 24)) & 0xFFu;      // < 2^24 x 16
         if (!BATCH && lane == 0u) tc_lb_store(status + wg, wg == 0u ? 2ull : 1ull, (static_cast<uint64_t>(agg_v) << 54) | agg_c);
     }
@@ -2033,7 +2040,7 @@ __device__ __forceinline__ void td_fused_body(const uint8_t* __restrict__ rle, u
     if (live && tot_c != 0u && !has_zero) td_window_values(w, ex, st, 0u, tot_c, tab, lane, c1, c2);
     // ---- wave 0: the prefix in front of the workgroup by look-back, every wave's own start; then everybody knows where it writes
     if (wave == 0u) {
-        const uint32_t wt = lane < kTdfWaves ? s_tot[lane] : 0u;         // (again: cheaper than keeping them over the window)
+        const uint32_t wt = lane < WAVES ? s_tot[lane] : 0u;         // (again: cheaper than keeping them over the window)
         const uint32_t wic = wave_incl_add(wt & 0xFFFFFFu), wiv = wave_incl_add(wt >> 24);
         const uint32_t agg_c = lane63(wic), agg_v = lane63(wiv) & 0xFFu;
         uint64_t before = 0;
@@ -2043,18 +2050,18 @@ __device__ __forceinline__ void td_fused_body(const uint8_t* __restrict__ rle, u
             if (lane == 0u) { s_carry_before = before + agg_c; s_carry_q = (qb + agg_v) & 0xFFu; }
         } else if (wg != 0u) {
 #ifdef SPECKV_TD_NO_LB
-            before = wg * kTdfChunks * 2048ull;                         // (timing builds only: wrong output)
+            before = wg * (WAVES - kTdfLbWave) * 2048ull;                         // (timing builds only: wrong output)
 #else
             td_look_back(status, wg, lane, before, qb);
 #endif
             qb &= 0xFFu;
             if (lane == 0u) tc_lb_store(status + wg, 2ull, (static_cast<uint64_t>((qb + agg_v) & 0xFFu) << 54) | (before + agg_c));
         }
-        if (lane < kTdfWaves) {
+        if (lane < WAVES) {
             s_start[lane] = before + (wic - (wt & 0xFFFFFFu));
             s_qp[lane] = (qb + wiv - (wt >> 24)) & 0xFFu;
         }
-        if (lane == 0u && (wg + 1u) * kTdfChunks >= n_chunks) { const uint64_t total = before + agg_c; *out_n = total < cap ? total : cap; }
+        if (lane == 0u && (wg + 1u) * (WAVES - kTdfLbWave) >= n_chunks) { const uint64_t total = before + agg_c; *out_n = total < cap ? total : cap; }
     }
     __syncthreads();
     if (!live) continue;
@@ -2083,7 +2090,7 @@ void k_td_fused(const uint8_t* __restrict__ rle, uint64_t n_pairs, uint64_t n_ch
 // Many streams, one workgroup each (speckv_ext_codec_decompress_tensors): stream i = desc[i].rle, rle_bytes[i] bytes, scale
 // scales[i], decoded into desc[i].data (room for desc[i].n elements); n_out[i] = elements the stream holds, clipped to the room.
 template <int MODE, bool F32>
-__global__ __launch_bounds__(64 * kTdfWaves) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ __launch_bounds__(64 * kTdmWaves) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_tdb_fused(const TcbDesc* __restrict__ desc, const uint64_t* __restrict__ rle_bytes, const float* __restrict__ scales, uint64_t* __restrict__ n_out)
 {
     __shared__ uint64_t s_none;
@@ -2092,13 +2099,13 @@ void k_tdb_fused(const TcbDesc* __restrict__ desc, const uint64_t* __restrict__ 
     const uint64_t chunks = (n_pairs + kTile - 1u) / kTile;
     uint64_t* on = n_out ? n_out + blockIdx.x : &s_none;
     if (chunks == 0u || d.n == 0u) { if (threadIdx.x == 0u) *on = 0ull; return; }
-    td_fused_body<MODE, F32, true>(d.rle, n_pairs, chunks, 0ull, nullptr, d.n, on, scales[blockIdx.x], static_cast<uint8_t*>(d.data));
+    td_fused_body<MODE, F32, true, kTdmWaves>(d.rle, n_pairs, chunks, 0ull, nullptr, d.n, on, scales[blockIdx.x], static_cast<uint8_t*>(d.data));
 }
 
 // ... and with several workgroups per stream (see k_tcm_fused): stream t = ticket / wpt, its workgroup ticket % wpt takes 16 chunks of
 // 2048 pairs, the prefix in front of it by look-back over the stream's own status words.
 template <int MODE, bool F32>
-__global__ __launch_bounds__(64 * kTdfWaves) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ __launch_bounds__(64 * kTdmWaves) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_tdm_fused(const TcbDesc* __restrict__ desc, uint32_t wpt, uint32_t* __restrict__ ticket, uint64_t* __restrict__ status,
                  const uint64_t* __restrict__ rle_bytes, const float* __restrict__ scales, uint64_t* __restrict__ n_out)
 {
@@ -2110,13 +2117,13 @@ void k_tdm_fused(const TcbDesc* __restrict__ desc, uint32_t wpt, uint32_t* __res
     const TcbDesc d = desc[t];
     const uint64_t n_pairs = rle_bytes[t] >> 1;                           // an odd trailing byte is dropped (cache_engine.cpp:245)
     const uint64_t chunks = (n_pairs + kTile - 1u) / kTile;
-    const uint64_t my_wgs = (chunks + kTdfChunks - 1u) / kTdfChunks;
+    const uint64_t my_wgs = (chunks + kTdmChunks - 1u) / kTdmChunks;
     uint64_t* on = n_out ? n_out + t : &s_none;
     if (l >= my_wgs || d.n == 0u) {
         if (l == 0u && threadIdx.x == 0u) *on = 0ull;
         return;
     }
-    td_fused_body<MODE, F32, false>(d.rle, n_pairs, chunks, l, status + static_cast<uint64_t>(t) * wpt, d.n, on, scales[t], static_cast<uint8_t*>(d.data));
+    td_fused_body<MODE, F32, false, kTdmWaves>(d.rle, n_pairs, chunks, l, status + static_cast<uint64_t>(t) * wpt, d.n, on, scales[t], static_cast<uint8_t*>(d.data));
 }
 
 // ---------------------------------------------------------------- output-centric expand with the run scatter (multi-launch form)
@@ -2446,20 +2453,23 @@ hipError_t launch_tensor_compress(const void* d_src, uint64_t n, bool src_f32, u
 // largest tensor (the host's bound: it sizes the grid, wpt workgroups per tensor).  Workspace: ticket (256 B) | max|x| words | chain 1 |
 // chain 2, one 8-byte word per (tensor, workgroup) each; cleared here.  wpt == 1 (tensors of at most 16 tiles) and SPECKV_TC_BATCH_ONE_WG:
 // the one-workgroup-per-tensor kernels (chains in LDS, no workspace words).
+// (the two directions cut a tensor into workgroups of their own size: kTfWaves tiles to compress, kTdmChunks chunks to decompress)
+static uint64_t tensors_wpt(uint64_t max_elems, uint32_t per_wg)
+{
+    return std::max<uint64_t>(1, (max_elems + static_cast<uint64_t>(per_wg) * kTile - 1) / (static_cast<uint64_t>(per_wg) * kTile));
+}
 size_t tensors_workspace_bytes(uint32_t n_tensors, uint64_t max_elems)
 {
-    const uint64_t wpt = std::max<uint64_t>(1, (max_elems + static_cast<uint64_t>(kTfWaves) * kTile - 1) / (static_cast<uint64_t>(kTfWaves) * kTile));
-    return 256 + 3ull * n_tensors * wpt * 8ull;
+    return 256 + 8ull * n_tensors * std::max<uint64_t>(3ull * tensors_wpt(max_elems, kTfWaves), tensors_wpt(max_elems, kTdmChunks));
 }
 hipError_t launch_tensors_compress(uint32_t n_tensors, const TensorDesc* d_desc, uint64_t max_elems, bool src_f32, uint64_t* d_rle_bytes, float* d_scales,
                                    void* d_ws, size_t ws_bytes, int quant_mode, hipStream_t s)
 {
     static_assert(sizeof(TcbDesc) == sizeof(TensorDesc) && sizeof(TensorDesc) == 32, "descriptor layout");
-    static_assert(kTfWaves == kTdfChunks, "one workgroup count per tensor serves both directions");
     if (n_tensors == 0) return hipSuccess;
     const uint32_t no_split = tuning().tc_no_split_tiles ? 1u : 0u;
     const TcbDesc* dd = reinterpret_cast<const TcbDesc*>(d_desc);
-    const uint64_t wpt = std::max<uint64_t>(1, (max_elems + static_cast<uint64_t>(kTfWaves) * kTile - 1) / (static_cast<uint64_t>(kTfWaves) * kTile));
+    const uint64_t wpt = tensors_wpt(max_elems, kTfWaves);
     if (wpt == 1 || tuning().tc_batch_one_wg) {
 #define SPECKV_TCB(MODE, F32) hipLaunchKernelGGL((k_tcb_fused<MODE, F32>), dim3(n_tensors), dim3(64 * kTfWaves), 0, s, dd, d_scales, d_rle_bytes, no_split)
         if (quant_mode == kIntent) { if (src_f32) SPECKV_TCB(kIntent, true); else SPECKV_TCB(kIntent, false); }
@@ -2468,7 +2478,7 @@ hipError_t launch_tensors_compress(uint32_t n_tensors, const TensorDesc* d_desc,
         return hipGetLastError();
     }
     if (!d_ws || ws_bytes < tensors_workspace_bytes(n_tensors, max_elems) || (reinterpret_cast<uintptr_t>(d_ws) & 255u) || n_tensors * wpt > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const hipError_t e = hipMemsetAsync(d_ws, 0, tensors_workspace_bytes(n_tensors, max_elems), s);
+    const hipError_t e = hipMemsetAsync(d_ws, 0, 256 + 3ull * n_tensors * wpt * 8ull, s);
     if (e != hipSuccess) return e;
     uint32_t* ticket = static_cast<uint32_t*>(d_ws);
     uint64_t* amax = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(d_ws) + 256);
@@ -2487,9 +2497,9 @@ hipError_t launch_tensors_decompress(uint32_t n_tensors, const TensorDesc* d_des
 {
     if (n_tensors == 0) return hipSuccess;
     const TcbDesc* dd = reinterpret_cast<const TcbDesc*>(d_desc);
-    const uint64_t wpt = std::max<uint64_t>(1, (max_elems + static_cast<uint64_t>(kTfWaves) * kTile - 1) / (static_cast<uint64_t>(kTfWaves) * kTile));
+    const uint64_t wpt = tensors_wpt(max_elems, kTdmChunks);
     if (wpt == 1 || tuning().tc_batch_one_wg) {
-#define SPECKV_TDB(MODE, F32) hipLaunchKernelGGL((k_tdb_fused<MODE, F32>), dim3(n_tensors), dim3(64 * kTdfWaves), 0, s, dd, d_rle_bytes, d_scales, d_n_out)
+#define SPECKV_TDB(MODE, F32) hipLaunchKernelGGL((k_tdb_fused<MODE, F32>), dim3(n_tensors), dim3(64 * kTdmWaves), 0, s, dd, d_rle_bytes, d_scales, d_n_out)
         if (quant_mode == kIntent) { if (out_f32) SPECKV_TDB(kIntent, true); else SPECKV_TDB(kIntent, false); }
         else                       { if (out_f32) SPECKV_TDB(kRefExact, true); else SPECKV_TDB(kRefExact, false); }
 #undef SPECKV_TDB
@@ -2501,7 +2511,7 @@ hipError_t launch_tensors_decompress(uint32_t n_tensors, const TensorDesc* d_des
     uint32_t* ticket = static_cast<uint32_t*>(d_ws);
     uint64_t* status = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(d_ws) + 256);
     const uint32_t g = static_cast<uint32_t>(n_tensors * wpt), w = static_cast<uint32_t>(wpt);
-#define SPECKV_TDM(MODE, F32) hipLaunchKernelGGL((k_tdm_fused<MODE, F32>), dim3(g), dim3(64 * kTdfWaves), 0, s, dd, w, ticket, status, d_rle_bytes, d_scales, d_n_out)
+#define SPECKV_TDM(MODE, F32) hipLaunchKernelGGL((k_tdm_fused<MODE, F32>), dim3(g), dim3(64 * kTdmWaves), 0, s, dd, w, ticket, status, d_rle_bytes, d_scales, d_n_out)
     if (quant_mode == kIntent) { if (out_f32) SPECKV_TDM(kIntent, true); else SPECKV_TDM(kIntent, false); }
     else                       { if (out_f32) SPECKV_TDM(kRefExact, true); else SPECKV_TDM(kRefExact, false); }
 #undef SPECKV_TDM

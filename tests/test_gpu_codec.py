@@ -902,7 +902,7 @@ def test_tensors_batch_matches_oracle_over_sizes_and_structures(lib, oracle, dty
     rounds with ragged ends; noise, long flat stretches that cross tiles and rounds (255-splits, the delta chain and both carried
     chains), all zeros, inf / NaN; both quantiser modes; sources off their 16-byte alignment; fp16 and fp32 outputs."""
     rng = np.random.default_rng(61 if dtype == np.float32 else 62)
-    lens = [0, 1, 7, 2047, 2048, 2049, 5000, 16 * 2048 - 1, 16 * 2048, 16 * 2048 + 1, 131072, 131072 + 77, 3 * 32768 + 2048 * 5 + 3, 300001]
+    lens = [0, 1, 7, 2047, 2048, 2049, 5000, 8 * 2048 - 1, 8 * 2048, 8 * 2048 + 1, 16 * 2048 - 1, 16 * 2048, 16 * 2048 + 1, 131072, 131072 + 77, 3 * 32768 + 2048 * 5 + 3, 300001]      # (workgroups take 16 tiles to compress, 8 chunks to decompress)
     xs = []
     for n in lens:
         x = rng.standard_normal(n).astype(np.float32)
