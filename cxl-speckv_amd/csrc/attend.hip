@@ -1378,17 +1378,24 @@ hipError_t launch_attend_combine(const AttendArgs& a, uint32_t n_layers, float* 
 //   s = q.k * sm_scale;  new = logaddexp(lse, s);  out = out * exp(lse - new) + v * exp(s - new);  lse = new
 // One wave per (row, kv head, query row), a lane holds two of the 128 dimensions.  A row without stored positions comes
 // in as out = 0, lse = -inf and leaves as out = v, lse = s.
+// Several layers in one launch (round 6; a planned step whose attention runs layer by layer folds all its layers at the end):
+// waves_per_layer != 0 -> wave w belongs to layer w / waves_per_layer, whose q / out / lse rows start layer_rows row blocks further on
+// and whose tail rows lie heads x 128 elements further on ([tail][layers][heads][128]).
 __global__ __launch_bounds__(256) void k_attend_fold_tail(uint32_t n_waves, const uint32_t* __restrict__ rows, uint32_t heads, uint32_t g,
                                                           const f16x2* __restrict__ q, const f16x2* __restrict__ k_tail,
                                                           const f16x2* __restrict__ v_tail, uint64_t tail_stride_h2, float sm_scale,
-                                                          float2* __restrict__ out, float* __restrict__ lse)
+                                                          float2* __restrict__ out, float* __restrict__ lse, uint32_t waves_per_layer, uint32_t layer_rows)
 {
-    const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
     if (w >= n_waves) return;
+    uint32_t l = 0;
+    if (waves_per_layer) { l = w / waves_per_layer; w -= l * waves_per_layer; }
     const uint32_t m = w % g, head = (w / g) % heads, i = w / (g * heads);
-    const uint32_t b = rows ? rows[i] : i;
+    const uint32_t b = (rows ? rows[i] : i) + l * layer_rows;
     const uint64_t row = (static_cast<uint64_t>(b) * heads + head) * g + m;
-    const f16x2 qh = q[row * 64u + lane], kh = k_tail[i * tail_stride_h2 + head * 64u + lane], vh = v_tail[i * tail_stride_h2 + head * 64u + lane];
+    const uint64_t t_at = i * tail_stride_h2 + (static_cast<uint64_t>(l) * heads + head) * 64u + lane;
+    const f16x2 qh = q[row * 64u + lane], kh = k_tail[t_at], vh = v_tail[t_at];
     const float2 qv = make_float2(static_cast<float>(qh.x), static_cast<float>(qh.y));
     const float2 kv = make_float2(static_cast<float>(kh.x), static_cast<float>(kh.y));
     const float2 vv = make_float2(static_cast<float>(vh.x), static_cast<float>(vh.y));
@@ -1408,14 +1415,15 @@ __global__ __launch_bounds__(256) void k_attend_fold_tail(uint32_t n_waves, cons
 
 hipError_t launch_attend_fold_tail(uint32_t n_rows, const uint32_t* d_rows, uint32_t heads, uint32_t g, const void* d_q_f16,
                                    const void* d_k_tail, const void* d_v_tail, uint64_t tail_stride_elems, float sm_scale,
-                                   float* d_out, float* d_lse, hipStream_t s)
+                                   float* d_out, float* d_lse, hipStream_t s, uint32_t n_layers, uint32_t layer_rows)
 {
-    const uint64_t n_waves = static_cast<uint64_t>(n_rows) * heads * g;
+    const uint64_t per_layer = static_cast<uint64_t>(n_rows) * heads * g, n_waves = per_layer * n_layers;
     if (n_waves == 0) return hipSuccess;
     if (n_waves > 0xFFFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_attend_fold_tail, dim3(static_cast<uint32_t>((n_waves + 3u) / 4u)), dim3(256), 0, s, static_cast<uint32_t>(n_waves),
                        d_rows, heads, g, static_cast<const f16x2*>(d_q_f16), static_cast<const f16x2*>(d_k_tail),
-                       static_cast<const f16x2*>(d_v_tail), tail_stride_elems / 2u, sm_scale, reinterpret_cast<float2*>(d_out), d_lse);
+                       static_cast<const f16x2*>(d_v_tail), tail_stride_elems / 2u, sm_scale, reinterpret_cast<float2*>(d_out), d_lse,
+                       n_layers > 1u ? static_cast<uint32_t>(per_layer) : 0u, layer_rows);
     return hipGetLastError();
 }
 

@@ -547,10 +547,22 @@ int Engine::attend_planned_layers(int scheme, const void* d_plan, uint32_t n_seq
                             static_cast<uint64_t>(n_seq) * n_layers <= 65535u && tuning().attend_layers_loop == 0 &&
                             plan_geometry(false, n_seq, 8, max_pos_end, cus(), true, plan->second.mx4_stripe_n_max).max_splits == 1u;
     if (one_launch) return attend_planned(scheme, d_plan, n_seq, layer_begin, d_q_f16, g, max_pos_end, sm_scale, d_out, d_lse, s, tail, n_layers);
+    // layer by layer; the position the caller still holds outside the pool is folded into ALL layers by one launch at the end (the
+    // attention launches of the step then stand back to back: 8 layers of FP8, 256 x 2k, 7 fold launches and their gaps less)
     const size_t rows = static_cast<size_t>(n_seq) * 8u * g;
+    const bool have_tail = tail && tail->n_tail != 0u;
+    const bool fold_once = have_tail && scheme != SPECKV_COMP_MXFP4 && d_lse && tail->d_k_tail && tail->d_v_tail && tuning().attend_fold_launch == 0;     // (MXFP4 folds inside its kernel)
+    if (have_tail && fold_once && (tail->stride_elems % 8u || tail->stride_elems < static_cast<uint64_t>(layer_begin + n_layers) * 8u * 128u)) return SPECKV_ERR_INVAL;
     for (uint32_t l = 0; l < n_layers; ++l)
         RC_TRY(attend_planned(scheme, d_plan, n_seq, layer_begin + l, static_cast<const uint16_t*>(d_q_f16) + l * rows * 128u, g, max_pos_end, sm_scale,
-                              d_out + l * rows * 128u, d_lse ? d_lse + l * rows : nullptr, s, tail));
+                              d_out + l * rows * 128u, d_lse ? d_lse + l * rows : nullptr, s, fold_once ? nullptr : tail));
+    if (fold_once) {
+        DeviceScope device_scope(device_);
+        const uint64_t off = static_cast<uint64_t>(layer_begin) * 8u * 128u;
+        HIP_TRY(launch_attend_fold_tail(tail->n_tail, tail->n_tail == n_seq ? nullptr : tail->d_tail_rows, 8u, g, d_q_f16,
+                                        static_cast<const uint16_t*>(tail->d_k_tail) + off, static_cast<const uint16_t*>(tail->d_v_tail) + off, tail->stride_elems,
+                                        sm_scale, d_out, d_lse, s, n_layers, n_seq));
+    }
     return SPECKV_OK;
 }
 

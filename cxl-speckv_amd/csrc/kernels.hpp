@@ -388,7 +388,9 @@ __device__ __forceinline__ void attend_zero_rows(float* direct_out, float* direc
 // (consecutive i tail_stride_elems apart); see k_attend_fold_tail
 hipError_t launch_attend_fold_tail(uint32_t n_rows, const uint32_t* d_rows, uint32_t heads, uint32_t g, const void* d_q_f16,
                                    const void* d_k_tail, const void* d_v_tail, uint64_t tail_stride_elems, float sm_scale,
-                                   float* d_out, float* d_lse, hipStream_t s);
+                                   float* d_out, float* d_lse, hipStream_t s, uint32_t n_layers = 1, uint32_t layer_rows = 0);
+// (n_layers > 1: the same rows for n_layers consecutive layers in one launch -- layer l's q / out / lse row blocks start l * layer_rows
+//  row blocks further on, its tail rows l * heads * 128 elements further on)
 // a.lin_base set: linear form (a.scale_tab, a.q16); else page-table form (a.q8 / a.qs from launch_quantize_q_e4m3)
 hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s);
 // scale_tab[tile order of p] = entries[p].rec_bytes >= 2048 ? entries[p].scale : 0 for every page (set_layout time)
