@@ -100,7 +100,7 @@ class SpeckvKVConnector:
         calibrates them from a prompt's K: the channel's max|k| over the head's median channel), or None to switch it off.  What it buys:
         an outlier channel of K no longer sets the block scale of the channels that share its quantisation group -- on KV-like data
         INT4_G32 loses 0.33-0.42 of the attention output instead of 0.57-0.71 when the query weighs those channels (MXFP4, whose limit
-        there is the element's one mantissa bit, gains little): profiles/r06_kv_format_accuracy.txt, tests/test_gpu_accuracy.py.
+        there is the element's one mantissa bit, gains little): profiles/r06a_kv_format_accuracy.txt, tests/test_gpu_accuracy.py.
         Set it before the first write; rows read back through kv_rows() are scaled back."""
         import torch
         if any(r.length for r in self.requests.values()):
@@ -115,6 +115,20 @@ class SpeckvKVConnector:
             raise ValueError("k channel scales must be powers of two (anything else rounds K and q a second time)")
         self._kscale = scale.to(torch.float16).contiguous()
         self._kscale_inv = (1.0 / scale).to(torch.float16).contiguous()
+
+    def calibrate_k_channel_scale(self, k):
+        """set_k_channel_scale from a sample of K ([layers][tokens][heads][dim], e.g. a first prompt): per (layer, head, channel) the
+        channel's max|k| over the head's median channel, rounded to a power of two (kv_accuracy.pow2_channel_scales, here on the device).
+        Returns the scales it set."""
+        import torch
+        k = torch.as_tensor(k, device="cuda")
+        if k.dim() != 4 or tuple(k.shape[0:1] + k.shape[2:]) != (self.L, self.H, self.D) or k.shape[1] == 0:
+            raise ValueError(f"k sample must be [layers][tokens][heads][dim] = ({self.L}, n, {self.H}, {self.D})")
+        amax = k.abs().to(torch.float32).amax(dim=1)                                 # [layers][heads][dim]
+        med = torch.quantile(amax, 0.5, dim=-1, keepdim=True).clamp_min(1e-9)        # (the mean of the two middle channels, as numpy's median)
+        scale = torch.exp2(torch.round(torch.log2((amax / med).clamp_min(1e-9)))).clamp(2.0 ** -14, 2.0 ** 14)      # (exact in fp16 both ways)
+        self.set_k_channel_scale(scale)
+        return scale
 
     # The library takes a hipStream_t and reads NULL as "the engine's own stream".  torch's default stream IS the NULL
     # stream, so work issued from it goes through a side stream that is ordered after it and that it then waits for.

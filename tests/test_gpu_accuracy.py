@@ -77,7 +77,9 @@ def test_connector_k_channel_scale_on_an_int4_pool():
         for scaled in (False, True):
             conn = SpeckvKVConnector(lib, num_layers=1, num_kv_heads=8, head_dim=D, max_tokens=T, scheme="int4")
             if scaled:
-                conn.set_k_channel_scale(torch.from_numpy(pow2_channel_scales(K[:n_prompt])[None]))      # calibrated on the prompt only
+                want = pow2_channel_scales(K[:n_prompt])[None]                                          # calibrated on the prompt only
+                got = conn.calibrate_k_channel_scale(torch.from_numpy(K[None, :n_prompt]))            # ... by the connector itself, on the device
+                assert np.array_equal(got.cpu().numpy(), want)
             conn.add_request(1)
             kd, vd = torch.from_numpy(K).cuda(), torch.from_numpy(V).cuda()
             keep = conn.write_prefill(1, kd[None, :n_prompt], vd[None, :n_prompt])
