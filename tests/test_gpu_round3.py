@@ -280,6 +280,49 @@ def test_decode_loop_does_not_accumulate_flights_or_events(oracle):
         lib.finalize()
 
 
+@pytest.mark.parametrize("scheme", [3, 4, 5])
+def test_residue_class_forms_on_short_and_ragged_ranges(scheme):
+    """The residue-class forms of the fused attention over a pool striped x7 (k_attend_int4_wg8<.., CLS>, k_attend_fp8_dma<2>,
+    k_attend_mx4<1>) at the small end: ranges with fewer pages than runs (empty classes), with one page per class, with classes of
+    unequal length, a range that starts inside the region, several layers -- against a one-pool engine on the same data (other
+    split boundaries: the tolerance of another summation order)."""
+    torch = torch_mod()
+    from tests.test_gpu_full_size import H, D, G
+    T, L = 128, 3
+    n_pages = T * L * H * D * 2 * 2 // PAGE
+    rng = np.random.default_rng(310 + scheme)
+    x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.3, 2.0, (n_pages, 1))).astype(np.float16)
+    q = (rng.standard_normal((L, H, G, D)) * 1.5).astype(np.float16)
+    sm = 1.0 / np.sqrt(D)
+    ranges = [(0, 2), (0, 8), (0, 14), (0, 16), (0, 30), (32, 64), (32, 46), (0, 128), (64, 126)]
+    results = {}
+    for name, env in (("one pool", {}), ("striped", {"SPECKV_POOL_DEVICES": "0,0,0,0,0,0,0"})):
+        lib = open_lib(**env)
+        try:
+            lib.set_compression_scheme(scheme)
+            h = lib.alloc(n_pages * PAGE)
+            lib.set_layout(h, T, L, H, D, 2)
+            lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+            d_q = torch.from_numpy(q.view(np.int16)).cuda()
+            attend = {3: lib.attend_int4, 4: lib.attend_fp8, 5: lib.attend_mx4}[scheme]
+            res = []
+            for pb, pe in ranges:
+                for layer0, nl in ((0, L), (1, 1)):
+                    out = torch.full((nl, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
+                    lse = torch.full((nl, H, G), float("nan"), dtype=torch.float32, device="cuda")
+                    attend(h, layer0, nl, d_q[layer0:layer0 + nl].data_ptr(), G, pb, pe, sm, out.data_ptr(), lse.data_ptr())
+                    torch.cuda.synchronize()
+                    res.append((out.cpu().numpy(), lse.cpu().numpy()))
+            results[name] = res
+        finally:
+            lib.finalize()
+    for i, ((o_s, l_s), (o_o, l_o)) in enumerate(zip(results["striped"], results["one pool"])):
+        assert np.isfinite(o_s).all() and np.isfinite(l_s).all(), (scheme, ranges[i // 2])
+        scale = float(np.abs(o_o).max())
+        assert float(np.abs(o_s - o_o).max()) <= 1e-3 * scale, (scheme, ranges[i // 2], i % 2)
+        assert float(np.abs(l_s - l_o).max()) <= 2e-4, (scheme, ranges[i // 2], i % 2)
+
+
 @pytest.mark.parametrize("pools", ["0,0,0", "0,0,0,0,0,0,0"])
 @pytest.mark.parametrize("scheme", [3, 4])
 def test_fused_attention_over_a_regularly_striped_pool_computes_its_addresses(oracle, scheme, pools):
