@@ -408,7 +408,10 @@ __global__ __launch_bounds__(256) void k_build_scale_tab(const PageEntry* __rest
 // TABLE: the same loop for an allocation without a regular placement (AttendArgs::table_form): the six record addresses come
 // from the page-table entries, looked up ONE REQUEST AHEAD (a request is then one round trip, not an entry and the record
 // behind it); never-written pages read the zero page.  Single-sequence form only.
-template <bool STRIPED, bool TABLE = false>
+// CLS (round 6): regular striping taken by residue class (see k_attend_fp8_dma<2>): the pages j = c, c + D, ... of the range are
+// consecutive records of one run, so the lane's pointers advance through a class exactly as through a linear region and are set
+// anew only where the requests enter the next class; the four page scales of a lane group come from table entries D pages apart.
+template <bool STRIPED, bool TABLE = false, bool CLS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 : 4, TABLE ? 3 : 4))) void k_attend_fp8_linear(AttendArgs a)
 {
     __shared__ uint64_t s_bases[8];
@@ -440,13 +443,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
         part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
         layer = 0;
         if (TABLE) a.entries = reinterpret_cast<const PageEntry*>(sq.lin_base);
-        if (STRIPED) {                                                   // the sequence's own placement
+        if (STRIPED || CLS) {                                            // the sequence's own placement
             a.stripe_bases = sq.stripe_bases;
             a.stripe_n = sq.stripe_n;
             a.stripe_magic = sq.stripe_n > 1u ? static_cast<uint32_t>((1ull << 32) / sq.stripe_n + 1u) : 0u;
         }
     }
-    if (STRIPED) {
+    if (STRIPED || CLS) {
         if (threadIdx.x < 8u) s_bases[threadIdx.x] = a.stripe_bases[threadIdx.x];
         __syncthreads();
     }
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
         qscale = (live ? sc : 1.0f) * a.scale_log2e;
     };
 
-    const uint32_t n_tiles = (a.n_pages + 15u) / 16u;
+    const uint32_t n_tiles = CLS ? mx4_striped_tiles(a.n_pages, a.stripe_n) : (a.n_pages + 15u) / 16u;
     const uint32_t t0 = split * a.tiles_per_split;
     const uint32_t t1 = min(t0 + a.tiles_per_split, n_tiles);
     float m_run = -INFINITY, l_run = 0.0f, vref = 1.0f;
@@ -505,7 +508,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
         // running pointers of the tile being requested
         const uint8_t* kp = nullptr;
         const uint8_t* vp = nullptr;
-        if (!STRIPED && !TABLE) {
+        // CLS: the K and the V requests each walk (class, tile of the class); class c holds jq + (c < jr) of the range's pages
+        const uint32_t cls_n = CLS ? (a.stripe_n ? a.stripe_n : 1u) : 1u, cls_m = CLS ? mx4_class_tiles(a.n_pages, cls_n) : 1u;
+        const uint32_t jq = a.n_pages / cls_n, jr = a.n_pages - jq * cls_n;
+        const uint32_t kfirst32 = static_cast<uint32_t>(a.k_first + layer * a.layer_stride), vfirst32 = static_cast<uint32_t>(a.v_first + layer * a.layer_stride);
+        uint32_t qk_cls = CLS ? t0 / cls_m : 0u, qk_m = CLS ? t0 - qk_cls * cls_m : 0u, qv_cls = qk_cls, qv_m = qk_m, cc_cls = qk_cls, cc_m = qk_m;
+        uint32_t qk_ic = 0u, qk_cnt = 1u, qv_ic = 0u, qv_cnt = 1u;
+        const uint8_t* kp_c = nullptr; const uint8_t* vp_c = nullptr;      // the lane's row pointers in tile 0 of the class the requests are in
+        auto cls_enter = [&](uint32_t cls_i, uint32_t first32, uint32_t lane_off, const uint8_t*& p_c, uint32_t& ic_o, uint32_t& cnt_o) {
+            uint32_t ic = min(cls_i, cls_n - 1u);
+            uint32_t cnt = jq + (ic < jr ? 1u : 0u);
+            if (cnt == 0u) { ic = 0u; cnt = 1u; }                        // (fewer pages than runs: an empty class asks for the range's first records, all masked)
+            const uint32_t pg = first32 + ic, rc = pg / cls_n;             // the class's first page: record rc of run pg % D (wave-uniform)
+            p_c = reinterpret_cast<const uint8_t*>(s_bases[pg - rc * cls_n]) + static_cast<uint64_t>(rc) * 2048u + lane_off;
+            ic_o = ic; cnt_o = cnt;
+        };
+        // the page scales of tile mm of class ic, ONE load per wave (this kernel is bound by its load instructions: 14 per tile and wave,
+        // and four scalar loads per lane group in place of the linear form's one 16-byte load made it 20): lane l takes the scale of
+        // slot l & 15 = the tile's page 2 kb' + r (r < 2) / 8 + 2 kb' + r - 2 -- table entries D pages apart (the table keeps every
+        // aligned group of 16 pages of a region in slot order: attend_tile_slot) -- and the lane groups pick theirs across the wave
+        auto cls_scale_raw = [&](uint32_t first32, uint32_t ic, uint32_t cnt, uint32_t mm) -> float {
+            const uint32_t sl = lane & 15u, pgi = (sl & 2u) * 4u + (sl >> 2) * 2u + (sl & 1u);
+            const uint32_t rel = ic + cls_n * min(16u * mm + pgi, cnt - 1u), j = rel & 15u;
+            return *reinterpret_cast<const float __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(a.scale_tab + (first32 + rel - j + attend_tile_slot(j))));
+        };
+        auto cls_scales4 = [&](float raw) -> f32x4 {
+            f32x4 r4;
+#pragma unroll
+            for (uint32_t r = 0; r < 4u; ++r) r4[r] = __shfl(raw, static_cast<int>(4u * kb + r));
+            return r4;
+        };
+        float ks_raw = 0.0f, vs_raw = 0.0f;
+        if (CLS) {
+            cls_enter(qk_cls, kfirst32, head * 128u + kb * 16u + c * 1024u, kp_c, qk_ic, qk_cnt);
+            cls_enter(qv_cls, vfirst32, head * 128u + 8u * c + 4u * kb * 1024u, vp_c, qv_ic, qv_cnt);
+        }
+        if (!STRIPED && !TABLE && !CLS) {
             kp = a.lin_base + (a.k_first + layer * a.layer_stride) * 2048ull + head * 128u + kb * 16u
                  + (static_cast<uint64_t>(t0) * 32u + c) * 1024u;            // block b: + b*16 KiB; second half of the row: + 64
             vp = a.lin_base + (a.v_first + layer * a.layer_stride) * 2048ull + head * 128u + 8u * c
@@ -545,12 +583,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
         uint2 vx[8];
         f32x4 ks4, vs4;
         auto issue_k = [&]() {
+            const uint32_t kmm = CLS ? min(qk_m, (qk_cnt - 1u) >> 4) : 0u;   // (a tile past the class's end: its last one again, all masked)
+            if (CLS) kp = kp_c + static_cast<uint64_t>(kmm) * 32768u;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 const uint8_t* src = TABLE ? kbase[b] + koff : STRIPED ? rec(kpage0 + tile_k * 16u + 8u * b) + koff : kp + 16384 * b;
                 kx[b][0] = ldg16(src); kx[b][1] = ldg16(src + 64);
             }
-            ks4 = ldg_f4(kt);
+            if (CLS) ks_raw = cls_scale_raw(kfirst32, qk_ic, qk_cnt, kmm); else ks4 = ldg_f4(kt);
             if (TABLE) lookup_k(tile_k + 1u);
         };
         auto issue_v = [&]() {
@@ -563,8 +603,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
                 }
                 if (TABLE) lookup_v(tile_v + 1u);
             } else {
+                const uint32_t vmm = CLS ? min(qv_m, (qv_cnt - 1u) >> 4) : 0u;
+                if (CLS) vp = vp_c + static_cast<uint64_t>(vmm) * 32768u;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) vx[j] = ldg8(vp + 1024 * (j & 3) + 16384 * (j >> 2));
+                if (CLS) { vs_raw = cls_scale_raw(vfirst32, qv_ic, qv_cnt, vmm); return; }
             }
             vs4 = ldg_f4(vt);
         };
@@ -585,6 +628,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
             // during the next scores).  The refills are unconditional -- the last iteration re-requests its own
             // tile -- so the loop body is one basic block and the compiler's s_waitcnt vmcnt(N) counts are exact.
             const uint32_t step = (tile + 1u < t1) ? 1u : 0u;            // scalar
+            if (CLS) ks4 = cls_scales4(ks_raw);
             // ---- scores
             float sc[8];
 #pragma unroll
@@ -597,15 +641,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sc[4 * b + i] = s[i] * (ks4[2 * b + (i >> 1)] * qscale);
             }
-            if ((ragged && tile + 1u == n_tiles) || (a.skip_pages && tile == 0u)) {     // wave-uniform: positions beyond / in front of the range
+            if (!CLS && ((ragged && tile + 1u == n_tiles) || (a.skip_pages && tile == 0u))) {     // wave-uniform: positions beyond / in front of the range
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const uint32_t pg = tile * 16u + ((j >> 1) < 2 ? 2u * kb + (j >> 1) : 8u + 2u * kb + ((j >> 1) - 2));
                     if (pg >= a.n_pages || pg < a.skip_pages) sc[j] = -INFINITY;
                 }
             }
+            if (CLS) {                                                       // pages of this tile past the end of its class
+                const uint32_t cnt = jq + (cc_cls < jr ? 1u : 0u);
+                const uint32_t have = cnt > 16u * cc_m ? cnt - 16u * cc_m : 0u;          // wave-uniform
+                if (have < 16u) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t pg = (j >> 1) < 2 ? 2u * kb + (j >> 1) : 8u + 2u * kb + ((j >> 1) - 2);
+                        if (pg >= have) sc[j] = -INFINITY;
+                    }
+                }
+                if (++cc_m == cls_m) { cc_m = 0u; ++cc_cls; }
+            }
             __builtin_amdgcn_sched_barrier(0);
-            kp += step * 32768u; kt += step * 16u; tile_k += step;
+            if (CLS) {
+                if (step && ++qk_m == cls_m) { qk_m = 0u; ++qk_cls; cls_enter(qk_cls, kfirst32, head * 128u + kb * 16u + c * 1024u, kp_c, qk_ic, qk_cnt); }
+            } else { kp += step * 32768u; kt += step * 16u; tile_k += step; }
             issue_k();
             __builtin_amdgcn_sched_barrier(0);
             // ---- online softmax of query row c
@@ -617,6 +675,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
             const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;
             const float f = __builtin_amdgcn_exp2f(m_run - m_use);
             m_run = m_new;
+            if (CLS) vs4 = cls_scales4(vs_raw);
             // the tile's V reference scale (its largest V page scale) and the weights in units of it
             const float vmx = max_over_kb(fmaxf(fmaxf(vs4[0], vs4[1]), fmaxf(vs4[2], vs4[3])));
             const float vref_t = vmx > 0.0f ? vmx : vref;
@@ -654,7 +713,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(V, P, acc[t] * fa, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            vp += step * 32768u; vt += step * 16u; tile_v += step;
+            if (CLS) {
+                if (step && ++qv_m == cls_m) { qv_m = 0u; ++qv_cls; cls_enter(qv_cls, vfirst32, head * 128u + 8u * c + 4u * kb * 1024u, vp_c, qv_ic, qv_cnt); }
+            } else { vp += step * 32768u; vt += step * 16u; tile_v += step; }
             issue_v();
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -858,21 +919,33 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
         const uint8_t* ksrc_c = nullptr; const uint8_t* vsrc_c = nullptr;
         uint32_t gsc_c = 0u;
         // (tried: every workgroup row starting on another class, so that the launch does not walk the runs in step -- no difference)
-        auto cls_next = [&]() {
+        // what the class the requests are in resolves to -- the K / V rows of its first page, its page count -- looked up when the
+        // requests ENTER a class, not per tile (two divisions, two LDS reads and the wait behind them in front of every request cost
+        // the class forms 3-4 points of the roofline: attend_mx4.hip)
+        const uint8_t* cls_k0 = nullptr; const uint8_t* cls_v0 = nullptr;
+        uint32_t cls_ic = 0u, cls_cnt = 1u;
+        auto cls_enter = [&]() {
             uint32_t ic = min(iq_cls, cls_n - 1u);
             uint32_t cnt = jq + (ic < jr ? 1u : 0u);
             if (cnt == 0u) { ic = 0u; cnt = 1u; }                            // (fewer pages than runs: an empty class asks for the range's first records, all masked)
-            const uint32_t mm = min(iq_m, (cnt - 1u) >> 4);
             const uint32_t pk = kpage0 + ic, pv = vpage0 + ic;
-            const uint32_t rk = pk / cls_n, rv = pv / cls_n;                      // (wave-uniform, twice per tile)
-            ksrc_c = uniform_ptr(reinterpret_cast<const uint8_t*>(s_bases[pk - rk * cls_n]) + static_cast<uint64_t>(rk + 16u * mm) * 2048u + head * 128u);
-            vsrc_c = uniform_ptr(reinterpret_cast<const uint8_t*>(s_bases[pv - rv * cls_n]) + static_cast<uint64_t>(rv + 16u * mm) * 2048u + head * 128u);
+            const uint32_t rk = pk / cls_n, rv = pv / cls_n;                      // (wave-uniform)
+            cls_k0 = uniform_ptr(reinterpret_cast<const uint8_t*>(s_bases[pk - rk * cls_n]) + static_cast<uint64_t>(rk) * 2048u + head * 128u);
+            cls_v0 = uniform_ptr(reinterpret_cast<const uint8_t*>(s_bases[pv - rv * cls_n]) + static_cast<uint64_t>(rv) * 2048u + head * 128u);
+            cls_ic = __builtin_amdgcn_readfirstlane(ic); cls_cnt = __builtin_amdgcn_readfirstlane(cnt);
+        };
+        if (CLS) cls_enter();
+        auto cls_next = [&]() {
+            const uint32_t ic = cls_ic, cnt = cls_cnt;
+            const uint32_t mm = min(iq_m, (cnt - 1u) >> 4);
+            ksrc_c = uniform_ptr(cls_k0 + static_cast<uint64_t>(mm) * 32768u);
+            vsrc_c = uniform_ptr(cls_v0 + static_cast<uint64_t>(mm) * 32768u);
             // the lane's scale: LDS slot (lane & 15) = [kb][r] holds the tile's page 2 kb + r (r < 2) or 8 + 2 kb + r - 2 (the order the
             // readers want: attend_tile_slot); the table keeps every aligned group of 16 pages of a region in that order too
             const uint32_t sl = lane & 15u, pgi = (sl & 2u) * 4u + (sl >> 2) * 2u + (sl & 1u);
             const uint32_t rel = ic + cls_n * min(16u * mm + pgi, cnt - 1u), j = rel & 15u;       // page of the range (its first page starts a group)
             gsc_c = ((lane < 16u ? kpage0 : vpage0) + rel - j + attend_tile_slot(j)) * 4u;
-            if (++iq_m == cls_m) { iq_m = 0u; ++iq_cls; }
+            if (++iq_m == cls_m) { iq_m = 0u; ++iq_cls; cls_enter(); }
         };
         auto issue_k = [&](uint32_t tt, uint32_t buf) {
             const uint32_t tc = min(tt, last);
@@ -1433,7 +1506,9 @@ hipError_t launch_attend_fp8_batch(const AttendArgs& a, uint32_t n_seq, float* d
     // the batch form keeps the register-staged kernel: 256 sequences x 8k context, one layer: 0.69 of HBM peak against 0.67
     // with the LDS-DMA kernel (many short splits: 4 waves/SIMD hide more than two tiles per wave at 2 waves/SIMD); the
     // single-sequence form below is the other way round (8k x 80 layers: 0.61 against 0.55; 32k x 80: 0.70 both)
-    if (a.table_form && tuning().attend_fp8_table_regs == 0)            // striped / moved placements: the DMA pipeline with addresses from the page tables
+    if (a.fp8_cls && a.stripe_bases && !a.table_form)                   // every member placed regularly: pages by residue class
+        hipLaunchKernelGGL((k_attend_fp8_linear<false, false, true>), dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
+    else if (a.table_form && tuning().attend_fp8_table_regs == 0)       // striped / moved placements: the DMA pipeline with addresses from the page tables
         hipLaunchKernelGGL(k_attend_fp8_dma<1>, dim3(a.n_splits, n_seq * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
     else if (a.table_form) hipLaunchKernelGGL((k_attend_fp8_linear<false, true>), dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
     else if (a.stripe_bases) hipLaunchKernelGGL(k_attend_fp8_linear<true>, dim3(a.n_splits, n_seq * (a.heads / 4u)), dim3(256), 0, s, a);
@@ -1460,8 +1535,12 @@ hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_ou
     // (launches with few workgroup columns -- the per-layer calls of one sequence -- are latency-bound either way: DMA kernel,
     // 13.8 against 15.5 us at 8k context)
     const bool dma_table = !a.lin_base && (a.stripe_bases || a.table_form) && a.scale_tab && a.entries && !a.skip_pages && tuning().attend_fp8_table_regs == 0;
-    if (a.fp8_cls && a.stripe_bases && a.scale_tab && !a.skip_pages)     // striped regularly: the linear pipeline over residue classes
-        hipLaunchKernelGGL(k_attend_fp8_dma<2>, dim3(a.n_splits, n_layers * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
+    if (a.fp8_cls && a.stripe_bases && a.scale_tab && !a.skip_pages) {   // striped regularly: the linear kernels over residue classes, by the linear forms' rule
+        if (a.n_splits == 1u || n_layers * (a.heads / 4u) < 128u)
+            hipLaunchKernelGGL(k_attend_fp8_dma<2>, dim3(a.n_splits, n_layers * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
+        else
+            hipLaunchKernelGGL((k_attend_fp8_linear<false, false, true>), dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);
+    }
     else if (dma_table)                                                  // moved page by page (or striped, on request): the DMA pipeline with addresses from the page table
         hipLaunchKernelGGL(k_attend_fp8_dma<1>, dim3(a.n_splits, n_layers * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
     else if (a.lin_base && (a.n_splits == 1u || n_layers * (a.heads / 4u) < 128u))

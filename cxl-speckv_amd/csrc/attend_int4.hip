@@ -779,13 +779,21 @@ __global__ __launch_bounds__(512 * HALVES) __attribute__((amdgpu_waves_per_eu(SP
         uint32_t kpage0 = static_cast<uint32_t>(a.k_first + addr_layer * a.layer_stride), vpage0 = static_cast<uint32_t>(a.v_first + addr_layer * a.layer_stride);      // (the layer the requests are at)
         uint32_t iq_cls = CLS ? ct / cls_m : 0u, iq_m = CLS ? ct - iq_cls * cls_m : 0u;
         uint32_t cc_cls = iq_cls, cc_m = iq_m;
-        auto cls_base = [&](uint32_t page0, uint32_t cls, uint32_t m) -> const uint8_t* {       // first record of tile m of class cls (clamped to the class's last tile)
+        // what the class the requests are in resolves to -- the K / V records of its first page, its page count -- looked up when the
+        // requests ENTER a class, not per tile (a division, an LDS read and the wait behind it in front of every request cost the
+        // class forms 3-4 points of the roofline: attend_mx4.hip)
+        const uint8_t* cls_k0 = nullptr; const uint8_t* cls_v0 = nullptr;
+        uint32_t cls_last_tile = 0u;
+        auto cls_enter = [&]() {
+            uint32_t cls = min(iq_cls, cls_n - 1u);
             uint32_t cnt = jq + (cls < jr ? 1u : 0u);
             if (cnt == 0u) { cls = 0u; cnt = 1u; }                        // (fewer pages than runs: an empty class fetches the range's first record, all masked)
-            const uint32_t pg = page0 + cls, rec0 = pg / cls_n, pool = pg - rec0 * cls_n;
-            const uint32_t mm = min(m, (cnt - 1u) >> 4);
-            return reinterpret_cast<const uint8_t*>(s_bases[pool]) + static_cast<uint64_t>(rec0 + 16u * mm) * kInt4RecBytes;
+            const uint32_t pk = kpage0 + cls, rk = pk / cls_n, pv = vpage0 + cls, rv = pv / cls_n;
+            cls_k0 = w8_uniform_ptr(reinterpret_cast<const uint8_t*>(s_bases[pk - rk * cls_n]) + static_cast<uint64_t>(rk) * kInt4RecBytes);
+            cls_v0 = w8_uniform_ptr(reinterpret_cast<const uint8_t*>(s_bases[pv - rv * cls_n]) + static_cast<uint64_t>(rv) * kInt4RecBytes);
+            cls_last_tile = __builtin_amdgcn_readfirstlane((cnt - 1u) >> 4);
         };
+        if (CLS) cls_enter();
         // ---- this wave's share of the fetch.  Nibbles: pages 2w and 2w+1 of K and of V, one instruction per page: lanes
         // 0..31 -> the page's slot 0 (row 4w or 4w+2), lanes 32..63 -> slot 1; LDS piece y of row r holds source piece y ^ (r & 15)
         const uint32_t pslot = lane >> 5, y = lane & 31u;
@@ -800,15 +808,16 @@ __global__ __launch_bounds__(512 * HALVES) __attribute__((amdgpu_waves_per_eu(SP
         auto issue = [&](uint32_t stage_off) {
             const uint32_t dst = lbase + stage_off;
             if (CLS) {                                                   // the tile's bases from its (class, tile of the class); wave-uniform
-                const uint32_t ic = min(iq_cls, cls_n - 1u);
-                kptr = w8_uniform_ptr(cls_base(kpage0, ic, iq_m));
-                vptr = w8_uniform_ptr(cls_base(vpage0, ic, iq_m));
+                const uint64_t toff = static_cast<uint64_t>(min(iq_m, cls_last_tile)) * tile_bytes;      // (a tile past the class's end: its last one again, all masked)
+                kptr = w8_uniform_ptr(cls_k0 + toff);
+                vptr = w8_uniform_ptr(cls_v0 + toff);
                 if (++iq_m == cls_m) {
                     iq_m = 0u;
                     if (++iq_cls == cls_n && stream) {                    // (stream form: on into the next layer's regions)
                         iq_cls = 0u;
                         kpage0 += static_cast<uint32_t>(a.layer_stride); vpage0 += static_cast<uint32_t>(a.layer_stride);
                     }
+                    cls_enter();
                 }
             }
             dma16(dst + dn, kptr, ga);

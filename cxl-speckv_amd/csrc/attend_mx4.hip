@@ -399,10 +399,36 @@ __global__ __launch_bounds__(64 * kWavesPerWg * HALVES) __attribute__((amdgpu_wa
         // class form: the next tile each region will ask for = (class, tile of the class), tiles left in the split
         uint32_t cls0 = 0u, cq_cls[2] = {0u, 0u}, cq_m[2] = {0u, 0u}, cq_left[2] = {t1 - t0, t1 - t0};
         const uint32_t jq = CLS ? cls_pages / cls_n : 0u, jr = CLS ? cls_pages - jq * cls_n : 0u;      // class c holds jq + (c < jr) pages
+        // ... and what the class a region is in resolves to -- its run's base, its first record there, its page count -- looked up when the
+        // region ENTERS a class (147 tiles apart at 32k x 7 runs), not per request: an LDS read of the run base, the wait the compiler
+        // puts behind it (which also waits for the tile's operand reads) and a handful of vector-to-scalar moves in front of every
+        // request cost the class form 3-4 points of the roofline with one wave per SIMD to hide nothing behind (round 6)
+        const uint8_t* cq_base[2] = {nullptr, nullptr};
+        uint32_t cq_rec0[2] = {0u, 0u}, cq_cnt[2] = {1u, 1u};
+        uint32_t cq_g[2][4], cq_gc[2];                                           // the lane's request offsets at the class's phase (whole tiles: imax = 15)
+        auto cls_enter = [&](uint32_t rg) __attribute__((always_inline)) {
+            uint32_t cls = min(cq_cls[rg], cls_n - 1u);
+            uint32_t cnt = jq + (cls < jr ? 1u : 0u);                             // pages of the class
+            if (cnt == 0u) { cls = 0u; cnt = 1u; }                                // (a range of fewer pages than runs: an empty class fetches the range's first record, all masked)
+            const uint32_t pg = (rg ? vfirst : kfirst) + cls;                     // the class's first page: pool pg % n, record pg / n
+            const uint32_t rec0 = cls_n == 1u ? pg : __builtin_amdgcn_readfirstlane(__umulhi(pg, cls_magic)), pool = pg - rec0 * cls_n;     // (all wave-uniform)
+            cq_base[rg] = uniform_ptr(reinterpret_cast<const uint8_t*>(s_bases[pool]));
+            cq_rec0[rg] = rec0;
+            cq_cnt[rg] = __builtin_amdgcn_readfirstlane(cnt);
+            const uint32_t ph = rec0 & 15u;                                       // every tile of the class starts in this slot of its storage tile
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t r = 4u * i + srow;
+                cq_g[rg][i] = r * 1024u + (ph + r >= 16u ? 1024u : 0u) + h0 * 128u + ((sslot ^ (r & 15u)) * 16u);
+            }
+            const uint32_t rc = lane >> 2;
+            cq_gc[rg] = (kMx4CodePlane - 960u * ph) + rc * 64u + (ph + rc >= 16u ? kMx4CodePlane : 0u) + h0 * 8u + (lane & 3u) * 4u;
+        };
         if (CLS) {
             cls0 = __builtin_amdgcn_readfirstlane(t0 / cls_m);
             cq_cls[0] = cq_cls[1] = cls0;
             cq_m[0] = cq_m[1] = t0 - cls0 * cls_m;
+            cls_enter(0u); cls_enter(1u);
         }
         // one region's share of a tile (rg = 0: K rows + K codes, 1: V rows + V codes) into stage `buf`: 5 DMA instructions
         auto stage = [&](uint32_t tt, uint32_t buf, uint32_t rg) __attribute__((always_inline)) {
@@ -411,21 +437,16 @@ __global__ __launch_bounds__(64 * kWavesPerWg * HALVES) __attribute__((amdgpu_wa
             const uint32_t first = rg ? vfirst : kfirst;
             const uint32_t drows = dst + (rg ? kStV : kStK), dcodes = dst + (rg ? kStVC : kStKC);
             if (CLS) {
-                uint32_t cls = cq_cls[rg];
-                const uint32_t m = cq_m[rg];
-                uint32_t cnt = jq + (cls < jr ? 1u : 0u);                         // pages of the class
-                if (cnt == 0u) { cls = 0u; cnt = 1u; }                            // (a range of fewer pages than runs: an empty class fetches the range's first record, all masked)
-                const uint32_t pg = first + cls;                                  // the class's first page: pool pg % n, record pg / n
-                const uint32_t rec0 = cls_n == 1u ? pg : __builtin_amdgcn_readfirstlane(__umulhi(pg, cls_magic)), pool = pg - rec0 * cls_n;     // (all wave-uniform)
-                const uint32_t mm = min(m, (cnt - 1u) >> 4);                      // a tile past the class's end fetches its last one (all masked)
-                const uint32_t imax = __builtin_amdgcn_readfirstlane(min(15u, cnt - 1u - 16u * mm));      // rows past the class's end fetch its last record
-                const uint64_t base = s_bases[pool];                              // (an LDS read: the compiler's wait for it leaves the DMA counter alone)
-                const uint32_t R = rec0 + 16u * mm;                               // the tile's first record in its run
-                const uint8_t* rt = uniform_ptr(reinterpret_cast<const uint8_t*>(base) + mx4_nib_off(R));
-                issue(__builtin_amdgcn_readfirstlane(drows), __builtin_amdgcn_readfirstlane(dcodes), rt, R & 15u, imax);
+                const uint32_t cnt = cq_cnt[rg];
+                const uint32_t mm = min(cq_m[rg], (cnt - 1u) >> 4);               // a tile past the class's end fetches its last one (all masked)
+                const uint32_t imax = min(15u, cnt - 1u - 16u * mm);              // rows past the class's end fetch its last record
+                const uint32_t R = cq_rec0[rg] + 16u * mm;                        // the tile's first record in its run
+                const uint8_t* rt = cq_base[rg] + mx4_nib_off(R);                 // (scalar: the cursor is)
+                if (imax == 15u) dma_region(__builtin_amdgcn_readfirstlane(drows), __builtin_amdgcn_readfirstlane(dcodes), rt, cq_g[rg], cq_gc[rg]);      // (wave-uniform)
+                else issue(__builtin_amdgcn_readfirstlane(drows), __builtin_amdgcn_readfirstlane(dcodes), rt, R & 15u, imax);
                 if (cq_left[rg] > 1u) {
                     --cq_left[rg];
-                    if (++cq_m[rg] == cls_m) { cq_m[rg] = 0u; ++cq_cls[rg]; }
+                    if (++cq_m[rg] == cls_m) { cq_m[rg] = 0u; ++cq_cls[rg]; cls_enter(rg); }
                 }
             } else if (STREAM) {
                 const uint8_t* rt = uniform_ptr(a.lin_base + mx4_nib_off(rq_page[rg]));    // (wave-uniform by construction)

@@ -305,13 +305,17 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     // INT4 (arithmetic-bound kernel): splits longer than 256 tiles stop paying (256 sequences x 32k: 256 tiles per split
     // 0.67, 512: 0.65, 1024 = no split: 0.60), shorter sequences are best left whole (8k 0.63 against 0.59 in two
     // splits, 4k 0.60 / 0.52, 2k 0.58 / 0.43: single-split rows are final, no partials and no merge).
-    // FP8 over striped pools: the DMA pipeline takes its addresses from the page tables (k_attend_fp8_dma<TABLE>), in page order
-    if (fp8 && any_striped && tuning().attend_fp8_table_regs == 0) any_table = true;
+    // FP8 over striped pools, every member placed regularly: the register-staged kernel by residue classes (k_attend_fp8_linear<.., CLS>);
+    // on request (tests, A/B) the DMA pipeline with its addresses from the page tables (k_attend_fp8_dma<1>), in page order
+    // (measured: batches of 256 x 8k over 7 runs 0.70-0.71 by residue classes against 0.71-0.73 through the page tables -- the table form
+    //  stays the default for batches; attend_fp8_striped_table = -1 takes the class form: tests, A/B)
+    const bool fp8_cls = fp8 && any_striped && !any_table && tuning().attend_fp8_table_regs == 0 && tuning().attend_fp8_striped_table < 0;
+    if (fp8 && any_striped && tuning().attend_fp8_table_regs == 0 && !fp8_cls) any_table = true;
     if (any_table)                                           // (AttendSeq::lin_base carries the page table in table launches)
         for (uint32_t i = 0; i < n_seq; ++i) seqs[i].lin_base = reinterpret_cast<const uint8_t*>(ents[i]);
     // INT4_G32, 8 kv heads, every member placed regularly (one run = "striped over 1"): the whole-record kernel by residue classes
     const bool int4_cls = !fp8 && !mx4 && any_striped && !any_table && heads == 8u && tuning().attend_int4_striped_wg == 0;
-    if ((mx4 || int4_cls) && any_striped && !any_table) {    // the striped forms of k_attend_mx4 / k_attend_int4_wg8 count their tiles by residue class
+    if ((mx4 || int4_cls || fp8_cls) && any_striped && !any_table) {    // the striped forms of k_attend_mx4 / k_attend_int4_wg8 / k_attend_fp8_linear count their tiles by residue class
         total_tiles = 0;
         for (uint32_t i = 0; i < n_seq; ++i) { seqs[i].n_splits = mx4_striped_tiles(seqs[i].n_pages, seqs[i].stripe_n); total_tiles += seqs[i].n_splits; }
     }
@@ -368,6 +372,7 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     k.scale_log2e = sm_scale * 1.4426950408889634f;
     k.lin_base = (any_striped || any_table) ? nullptr : seqs[0].lin_base;           // (overridden per sequence)
     if (any_striped) k.stripe_bases = seqs[0].stripe_bases;          // marks a striped launch (each sequence brings its own table)
+    if (fp8_cls) k.fp8_cls = 1u;
     if (any_table) {
         k.table_form = 1u; k.lin_base = nullptr; k.stripe_bases = nullptr;
         if (!d_zero_page_) {
@@ -415,7 +420,7 @@ static PlanGeometry plan_geometry(bool fp8, uint32_t n_seq, uint32_t heads, uint
 {
     // (MXFP4 -- and INT4_G32 on the whole-record kernel -- over striped pools count tiles by residue class: at most ceil(pages / 16) +
     //  runs + 1 of them, whatever a member's run count; mx4_stripe_n_max is the largest run count of such a plan, 0 otherwise)
-    const uint32_t tiles_max = (max_pos_end / 2u + 15u) / 16u + (!fp8 && mx4_stripe_n_max >= 2u ? mx4_stripe_n_max + 1u : 0u);
+    const uint32_t tiles_max = (max_pos_end / 2u + 15u) / 16u + (mx4_stripe_n_max >= 2u ? mx4_stripe_n_max + 1u : 0u);
     PlanGeometry g{};
     if (mx4) {
         g.unequal = UnequalSplit{false, 1.0};
@@ -483,10 +488,11 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
         seqs[i].n_pages = n_pages;
         seqs[i].n_splits = n_tiles;
     }
-    if (scheme == SPECKV_COMP_FP8_E4M3 && any_striped && tuning().attend_fp8_table_regs == 0) any_table = true;       // (see attend_batch)
+    const bool fp8_cls = scheme == SPECKV_COMP_FP8_E4M3 && any_striped && !any_table && tuning().attend_fp8_table_regs == 0 && tuning().attend_fp8_striped_table < 0;      // (see attend_batch)
+    if (scheme == SPECKV_COMP_FP8_E4M3 && any_striped && tuning().attend_fp8_table_regs == 0 && !fp8_cls) any_table = true;
     uint32_t stripe_n_max = 0;
     const bool int4_cls = scheme == SPECKV_COMP_INT4_G32 && any_striped && !any_table && heads == 8u && tuning().attend_int4_striped_wg == 0;
-    if ((scheme == SPECKV_COMP_MXFP4 || int4_cls) && any_striped && !any_table)
+    if ((scheme == SPECKV_COMP_MXFP4 || int4_cls || fp8_cls) && any_striped && !any_table)
         for (uint32_t i = 0; i < n_seq; ++i) {
             seqs[i].n_splits = mx4_striped_tiles(seqs[i].n_pages, seqs[i].stripe_n);
             stripe_n_max = std::max(stripe_n_max, seqs[i].stripe_n);
@@ -598,6 +604,7 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
     else if (plan->second.striped) {                           // striped launch: every descriptor brings its table
         k.stripe_bases = reinterpret_cast<const uint64_t*>(1);
         if (!fp8 && !mx4 && plan->second.mx4_stripe_n_max) k.wg8 = int4_wg8_form(n_seq, cus());      // (planned by residue classes: the whole-record kernel)
+        if (fp8 && plan->second.mx4_stripe_n_max) k.fp8_cls = 1u;                                   // (... the register-staged kernel by residue classes)
     }
     else { k.lin_base = reinterpret_cast<const uint8_t*>(1); if (!fp8 && !mx4) k.wg8 = int4_wg8_form(n_seq, cus()); }     // non-null: linear form (the real base comes from the descriptor)
     k.seqs = static_cast<const AttendSeq*>(d_plan);

@@ -849,6 +849,27 @@ def test_batch_and_planned_attention_over_striped_pools(scheme):
                     scale = float(ref[i].abs().max()) + 1e-6
                     assert float((got[i] - ref[i]).abs().max()) <= 1e-3 * scale, (what, layer, i)
                     assert float((got_lse[i] - ref_lse[i]).abs().max()) <= 2e-4, (what, layer, i)
+        if scheme == 4:
+            # FP8 batches take the page tables by default; the residue-class form of the register-staged kernel on request (layer 1: `ref`)
+            set_tuning("attend_fp8_striped_table", -1)
+            try:
+                out6 = torch.full_like(out, float("nan")); lse6 = torch.full_like(lse, float("nan"))
+                batch(handles, 1, q.data_ptr(), G, lens, sm, out6.data_ptr(), lse6.data_ptr())
+                out7 = torch.full_like(out, float("nan")); lse7 = torch.full_like(lse, float("nan"))
+                torch.cuda.synchronize()
+                lib.attend_batch_plan(handles, lens, T, d_plan.data_ptr(), plan_bytes, st.cuda_stream)
+                lib.attend_planned(scheme, d_plan.data_ptr(), len(lens), 1, q.data_ptr(), G, T, sm, out7.data_ptr(), lse7.data_ptr(), st.cuda_stream)
+                torch.cuda.synchronize()
+            finally:
+                set_tuning("attend_fp8_striped_table", 0)
+            for got, got_lse, what in ((out6, lse6, "batch, class form"), (out7, lse7, "planned, class form")):
+                for i, n in enumerate(lens):
+                    if n == 0:
+                        assert float(got[i].abs().max()) == 0.0
+                        continue
+                    scale = float(ref[i].abs().max()) + 1e-6
+                    assert float((got[i] - ref[i]).abs().max()) <= 1e-3 * scale, (what, i)
+                    assert float((got_lse[i] - ref_lse[i]).abs().max()) <= 2e-4, (what, i)
         # a partly migrated sequence no longer has an arithmetic placement: the whole launch then reads its record addresses from
         # the page tables (the table forms of the kernels) -- batch and planned, same numbers as before the migration (layer 1: `ref`)
         lib.migrate(handles[0], 4, 8, 2)
