@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
         }
     }
     if (STRIPED || CLS) {
-        if (threadIdx.x < 8u) s_bases[threadIdx.x] = a.stripe_bases[threadIdx.x];
+        if (threadIdx.x < 8u) s_bases[threadIdx.x] = *reinterpret_cast<const uint64_t __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(a.stripe_bases + threadIdx.x));
         __syncthreads();
     }
 

@@ -25,8 +25,8 @@ HOT = [
     ("kernels.o", r"k_fetch_decompress_flat", 0),                           # the kernel of launches hinted "structured" (fp16 and fp32 outputs)
     ("kernels.o", r"k_compressILi[0134]ELi\dE", 0),
     ("kernels.o", r"k_compressILi2ELi\dE", 1),                              # (one tail store of the RLE record)
-    ("attend.o", r"k_attend_fp8_linearILb0E", 0),
-    ("attend.o", r"k_attend_fp8_linearILb1E", 1),                           # (the run-base table is read once per workgroup)
+    ("attend.o", r"k_attend_fp8_linearILb0E", 0),                           # linear, table and residue-class forms
+    ("attend.o", r"k_attend_fp8_linearILb1E", 0),                           # striped, address per page (the run-base table through the global address space since round 6)
     ("attend.o", r"k_attend_fp8ENS", 0),
     ("attend.o", r"k_attend_fp8_dma", 0),
     ("attend.o", r"k_qk_scores_fp8_linear", 0),
