@@ -127,7 +127,7 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     //  same rule; the register-staged kernels of rounds 2-5 -- a range that starts inside a tile, or on request -- want the splits)
     const bool dma_table = (striped || table) && skip_pages == 0 && tuning().attend_fp8_table_regs == 0;
     // striped regularly: the linear pipeline over the range's pages by residue class (k_attend_fp8_dma<2>): the tiles are then counted per class
-    const bool cls = striped && dma_table && a->stripe_n <= 8 && tuning().attend_fp8_striped_table == 0;
+    const bool cls = striped && dma_table && a->stripe_n <= 8 && tuning().attend_fp8_striped_table <= 0;
     if (cls) n_tiles = mx4_striped_tiles(n_pages, a->stripe_n);
     uint32_t want = ((lin_base || dma_table) && rows / 4u >= 128u && n_tiles < 768u) ? 1u : (5120u + rows - 1u) / rows;     // (32k and beyond: 8 splits, below)
     // per-layer calls are latency-bound: short contexts want short splits (measured best: 2 tiles per split at 2k
