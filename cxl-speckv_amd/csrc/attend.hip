@@ -530,6 +530,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
         auto cls_scale_raw = [&](uint32_t first32, uint32_t ic, uint32_t cnt, uint32_t mm) -> float {
             const uint32_t sl = lane & 15u, pgi = (sl & 2u) * 4u + (sl >> 2) * 2u + (sl & 1u);
             const uint32_t rel = ic + cls_n * min(16u * mm + pgi, cnt - 1u), j = rel & 15u;
+#ifdef SPECKV_FP8_CLS_FAKE_SCALES                                          // (timing builds only, wrong results: the scales of a class tile from ONE line, as if the table were laid out by class)
+            return *reinterpret_cast<const float __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(a.scale_tab + (first32 + 16u * (ic * cls_m + mm) % (a.n_pages & ~15u) + sl)));
+#endif
             return *reinterpret_cast<const float __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(a.scale_tab + (first32 + rel - j + attend_tile_slot(j))));
         };
         auto cls_scales4 = [&](float raw) -> f32x4 {
