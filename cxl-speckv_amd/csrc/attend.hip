@@ -1546,7 +1546,7 @@ hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_ou
     }
     else if (dma_table)                                                  // moved page by page (or striped, on request): the DMA pipeline with addresses from the page table
         hipLaunchKernelGGL(k_attend_fp8_dma<1>, dim3(a.n_splits, n_layers * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
-    else if (a.lin_base && (a.n_splits == 1u || n_layers * (a.heads / 4u) < 128u))
+    else if (a.lin_base && tuning().attend_fp8_dma >= 0 && (a.n_splits == 1u || n_layers * (a.heads / 4u) < 128u || tuning().attend_fp8_dma > 0))
         hipLaunchKernelGGL(k_attend_fp8_dma<0>, dim3(a.n_splits, n_layers * (a.heads / kFdHeads)), dim3(64 * kFdHeads), 0, s, a);
     else if (a.lin_base)
         hipLaunchKernelGGL(k_attend_fp8_linear<false>, dim3(a.n_splits, n_layers * (a.heads / 4u)), dim3(256), 0, s, a);

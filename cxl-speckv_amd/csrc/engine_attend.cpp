@@ -134,6 +134,27 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     // context, 4 at 8k, 8 at 32k), long multi-layer launches are bounded by `want` above
     const uint32_t min_tiles = std::min(8u, std::max(2u, n_tiles / 64u));
     want = std::min(want, std::max(1u, n_tiles / min_tiles));
+    // Launches of many rows (several layers of one sequence): every workgroup resident at once and the CUs evenly loaded counts for
+    // more than the split length -- 80 layers = 160 workgroup rows: 3 splits = 480 workgroups (15 of 16 CUs hold two) 0.777 of the
+    // roofline at 32k and 0.738 at 8k, 5 splits = 800 (some CUs four, some three) 0.67, 8 = 1280 (a second round) 0.765, one split
+    // (the DMA kernel, 160 of 256 CUs busy) 0.73 / 0.70; 32 layers x 32k: 4 splits = 256 workgroups 0.734, 20 splits 0.72.
+    // So: the split count whose workgroups fill whole rounds of the CUs best, one round at most, splits of 64 tiles or more.
+    // (A stream form as the INT4 / MXFP4 kernels have it -- the launch's rows x tiles in one equal piece per resident workgroup --
+    //  was built for k_attend_fp8_linear and dropped: at the kernel's 128 registers the row-boundary path spilled, and the extra
+    //  partials cost the short contexts more than the balance gave: 32k x 80 0.7635 against 0.7745, 8k 0.66 / 0.74, 128k 0.794 / 0.783.)
+    if ((lin_base || cls) && rows / 4u >= 32u) {
+        const uint32_t wg_rows = rows / 4u, n_cu = cus();
+        uint32_t best_s = 1;
+        double best = -1.0;
+        for (uint32_t sp = 1; sp <= 16u; ++sp) {
+            if (sp > 1u && n_tiles / sp < 64u) break;
+            const uint64_t wgs = static_cast<uint64_t>(wg_rows) * sp, cap = static_cast<uint64_t>(sp == 1u ? 2u : 4u) * n_cu;      // (resident: DMA kernel 2 per CU, register-staged 4)
+            if (wgs > cap && sp > 1u) break;
+            const double per_cu = static_cast<double>(wgs) / n_cu, score = per_cu / std::ceil(per_cu);
+            if (score > best + 1e-9) { best = score; best_s = sp; }
+        }
+        want = best_s;
+    }
     if (tuning().attend_splits > 0) want = static_cast<uint32_t>(tuning().attend_splits);
     const EvenSplit es = even_split(n_tiles, std::max(1u, std::min(want, 2048u)));
     const uint32_t n_splits = es.n_splits, tiles_per_split = es.tiles_per_split;

@@ -15,6 +15,7 @@ const Key kKeys[] = {
     {"attend_general", "SPECKV_ATTEND_GENERAL", &Tuning::attend_general},
     {"attend_fold_launch", "SPECKV_ATTEND_FOLD_LAUNCH", &Tuning::attend_fold_launch},
     {"attend_layers_loop", "SPECKV_ATTEND_LAYERS_LOOP", &Tuning::attend_layers_loop},
+    {"attend_fp8_dma", "SPECKV_ATTEND_FP8_DMA", &Tuning::attend_fp8_dma},
     {"attend_fp8_striped_table", "SPECKV_ATTEND_FP8_STRIPED_TABLE", &Tuning::attend_fp8_striped_table},
     {"attend_int4_striped_wg", "SPECKV_ATTEND_INT4_STRIPED_WG", &Tuning::attend_int4_striped_wg},
     {"attend_fp8_table_regs", "SPECKV_ATTEND_FP8_TABLE_REGS", &Tuning::attend_fp8_table_regs},

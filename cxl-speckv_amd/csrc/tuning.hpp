@@ -16,6 +16,7 @@ struct Tuning {
     int32_t attend_mx4_one_half = 0;        // SPECKV_ATTEND_MX4_ONE_HALF      MXFP4 batches: 4-wave workgroups also where the two-halves form applies (A/B, tests)
     int32_t attend_general = 0;             // SPECKV_ATTEND_GENERAL           1: page-table forms even where an arithmetic form applies (tests)
     int32_t attend_fp8_table_regs = 0;      // SPECKV_ATTEND_FP8_TABLE_REGS    FP8 over striped / moved placements: the register-staged kernels of rounds 2-5 instead of the DMA pipeline (tests, A/B)
+    int32_t attend_fp8_dma = 0;             // SPECKV_ATTEND_FP8_DMA           FP8, one sequence: 1 = the LDS-DMA kernel whatever the split count, -1 = the register-staged one (tests, A/B)
     int32_t attend_fp8_striped_table = 0;   // SPECKV_ATTEND_FP8_STRIPED_TABLE FP8 over regularly striped pools: 1 = single-sequence calls through the page table (k_attend_fp8_dma<1>) instead of residue classes; -1 = batches / plans by residue classes instead of the page tables (tests, A/B)
     int32_t attend_int4_striped_wg = 0;     // SPECKV_ATTEND_INT4_STRIPED_WG   INT4_G32 over striped pools: the 4-head kernel with an address per lane (rounds 2-5) instead of the whole-record kernel by residue classes (tests, A/B)
     int32_t attend_layers_loop = 0;         // SPECKV_ATTEND_LAYERS_LOOP       planned_layers: per-layer launches also where one launch could take them all (tests, A/B)
