@@ -393,13 +393,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // scales of its four slot pages with one 16-byte load.  k_compress keeps it current (CodecArgs::scale_tab); this kernel
 // (re)builds it from the page table when the layout becomes known.  Never-written pages hold 0.
 __global__ __launch_bounds__(256) void k_build_scale_tab(const PageEntry* __restrict__ entries, uint64_t n_pages,
-                                                         uint32_t region_pages, float* __restrict__ tab)
+                                                         uint32_t region_pages, float* __restrict__ tab, uint32_t scale_run)
 {
     const uint64_t p = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
     if (p >= n_pages) return;
     const PageEntry e = entries[p];
     const uint32_t j = static_cast<uint32_t>(p % region_pages) & 15u;
-    tab[p - j + attend_tile_slot(j)] = e.rec_bytes >= kBlockElems ? e.scale : 0.0f;
+    const float sc = e.rec_bytes >= kBlockElems ? e.scale : 0.0f;
+    tab[p - j + attend_tile_slot(j)] = sc;
+    if (scale_run) tab[scale_run_index(p, scale_run)] = sc;             // (the run-order part in front of the table: CodecArgs::scale_run)
 }
 
 // STRIPED: the same loop for an allocation striped regularly over several pools (AttendArgs::stripe_bases): the six record
@@ -515,20 +517,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
         uint32_t qk_cls = CLS ? t0 / cls_m : 0u, qk_m = CLS ? t0 - qk_cls * cls_m : 0u, qv_cls = qk_cls, qv_m = qk_m, cc_cls = qk_cls, cc_m = qk_m;
         uint32_t qk_ic = 0u, qk_cnt = 1u, qv_ic = 0u, qv_cnt = 1u;
         const uint8_t* kp_c = nullptr; const uint8_t* vp_c = nullptr;      // the lane's row pointers in tile 0 of the class the requests are in
-        auto cls_enter = [&](uint32_t cls_i, uint32_t first32, uint32_t lane_off, const uint8_t*& p_c, uint32_t& ic_o, uint32_t& cnt_o) {
+        uint32_t qk_run = 0u, qv_run = 0u;                                 // (the class's first entry in the run-order scale table: AttendArgs::scale_run)
+        const uint32_t run_cap = a.scale_run >> 4;
+        auto cls_enter = [&](uint32_t cls_i, uint32_t first32, uint32_t lane_off, const uint8_t*& p_c, uint32_t& ic_o, uint32_t& cnt_o, uint32_t& run_o) {
             uint32_t ic = min(cls_i, cls_n - 1u);
             uint32_t cnt = jq + (ic < jr ? 1u : 0u);
             if (cnt == 0u) { ic = 0u; cnt = 1u; }                        // (fewer pages than runs: an empty class asks for the range's first records, all masked)
             const uint32_t pg = first32 + ic, rc = pg / cls_n;             // the class's first page: record rc of run pg % D (wave-uniform)
             p_c = reinterpret_cast<const uint8_t*>(s_bases[pg - rc * cls_n]) + static_cast<uint64_t>(rc) * 2048u + lane_off;
-            ic_o = ic; cnt_o = cnt;
+            ic_o = ic; cnt_o = cnt; run_o = (pg - rc * cls_n) * run_cap + rc;
         };
         // the page scales of tile mm of class ic, ONE load per wave (this kernel is bound by its load instructions: 14 per tile and wave,
         // and four scalar loads per lane group in place of the linear form's one 16-byte load made it 20): lane l takes the scale of
         // slot l & 15 = the tile's page 2 kb' + r (r < 2) / 8 + 2 kb' + r - 2 -- table entries D pages apart (the table keeps every
         // aligned group of 16 pages of a region in slot order: attend_tile_slot) -- and the lane groups pick theirs across the wave
-        auto cls_scale_raw = [&](uint32_t first32, uint32_t ic, uint32_t cnt, uint32_t mm) -> float {
+        auto cls_scale_raw = [&](uint32_t first32, uint32_t ic, uint32_t cnt, uint32_t mm, uint32_t run0) -> float {
             const uint32_t sl = lane & 15u, pgi = (sl & 2u) * 4u + (sl >> 2) * 2u + (sl & 1u);
+            if (a.scale_run)                                                 // run order: the tile's 16 scales are consecutive entries
+                return *reinterpret_cast<const float __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(a.scale_tab) - static_cast<uint64_t>(cls_n) * run_cap * 4u +
+                                                                                          static_cast<uint64_t>(run0 + min(16u * mm + pgi, cnt - 1u)) * 4u);
             const uint32_t rel = ic + cls_n * min(16u * mm + pgi, cnt - 1u), j = rel & 15u;
 #ifdef SPECKV_FP8_CLS_FAKE_SCALES                                          // (timing builds only, wrong results: the scales of a class tile from ONE line, as if the table were laid out by class)
             return *reinterpret_cast<const float __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(a.scale_tab + (first32 + 16u * (ic * cls_m + mm) % (a.n_pages & ~15u) + sl)));
@@ -543,8 +550,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
         };
         float ks_raw = 0.0f, vs_raw = 0.0f;
         if (CLS) {
-            cls_enter(qk_cls, kfirst32, head * 128u + kb * 16u + c * 1024u, kp_c, qk_ic, qk_cnt);
-            cls_enter(qv_cls, vfirst32, head * 128u + 8u * c + 4u * kb * 1024u, vp_c, qv_ic, qv_cnt);
+            cls_enter(qk_cls, kfirst32, head * 128u + kb * 16u + c * 1024u, kp_c, qk_ic, qk_cnt, qk_run);
+            cls_enter(qv_cls, vfirst32, head * 128u + 8u * c + 4u * kb * 1024u, vp_c, qv_ic, qv_cnt, qv_run);
         }
         if (!STRIPED && !TABLE && !CLS) {
             kp = a.lin_base + (a.k_first + layer * a.layer_stride) * 2048ull + head * 128u + kb * 16u
@@ -593,7 +600,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
                 const uint8_t* src = TABLE ? kbase[b] + koff : STRIPED ? rec(kpage0 + tile_k * 16u + 8u * b) + koff : kp + 16384 * b;
                 kx[b][0] = ldg16(src); kx[b][1] = ldg16(src + 64);
             }
-            if (CLS) ks_raw = cls_scale_raw(kfirst32, qk_ic, qk_cnt, kmm); else ks4 = ldg_f4(kt);
+            if (CLS) ks_raw = cls_scale_raw(kfirst32, qk_ic, qk_cnt, kmm, qk_run); else ks4 = ldg_f4(kt);
             if (TABLE) lookup_k(tile_k + 1u);
         };
         auto issue_v = [&]() {
@@ -610,7 +617,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
                 if (CLS) vp = vp_c + static_cast<uint64_t>(vmm) * 32768u;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) vx[j] = ldg8(vp + 1024 * (j & 3) + 16384 * (j >> 2));
-                if (CLS) { vs_raw = cls_scale_raw(vfirst32, qv_ic, qv_cnt, vmm); return; }
+                if (CLS) { vs_raw = cls_scale_raw(vfirst32, qv_ic, qv_cnt, vmm, qv_run); return; }
             }
             vs4 = ldg_f4(vt);
         };
@@ -665,7 +672,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
             }
             __builtin_amdgcn_sched_barrier(0);
             if (CLS) {
-                if (step && ++qk_m == cls_m) { qk_m = 0u; ++qk_cls; cls_enter(qk_cls, kfirst32, head * 128u + kb * 16u + c * 1024u, kp_c, qk_ic, qk_cnt); }
+                if (step && ++qk_m == cls_m) { qk_m = 0u; ++qk_cls; cls_enter(qk_cls, kfirst32, head * 128u + kb * 16u + c * 1024u, kp_c, qk_ic, qk_cnt, qk_run); }
             } else { kp += step * 32768u; kt += step * 16u; tile_k += step; }
             issue_k();
             __builtin_amdgcn_sched_barrier(0);
@@ -717,7 +724,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
             }
             __builtin_amdgcn_sched_barrier(0);
             if (CLS) {
-                if (step && ++qv_m == cls_m) { qv_m = 0u; ++qv_cls; cls_enter(qv_cls, vfirst32, head * 128u + 8u * c + 4u * kb * 1024u, vp_c, qv_ic, qv_cnt); }
+                if (step && ++qv_m == cls_m) { qv_m = 0u; ++qv_cls; cls_enter(qv_cls, vfirst32, head * 128u + 8u * c + 4u * kb * 1024u, vp_c, qv_ic, qv_cnt, qv_run); }
             } else { vp += step * 32768u; vt += step * 16u; tile_v += step; }
             issue_v();
             __builtin_amdgcn_sched_barrier(0);
@@ -881,7 +888,7 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
         part = sq.part_base + static_cast<uint64_t>(head) * sq.n_splits + split;
         layer = 0;
         if (TABLE) a.entries = reinterpret_cast<const PageEntry*>(sq.lin_base);      // (table launches: the descriptor carries the page table)
-        if (CLS) { a.stripe_bases = sq.stripe_bases; a.stripe_n = sq.stripe_n; }
+        if (CLS) { a.stripe_bases = sq.stripe_bases; a.stripe_n = sq.stripe_n; a.scale_run = 0u; }      // (descriptors carry no run-order table: gather)
     }
     if (CLS) {                                                           // (workgroup-uniform up to here: every wave gets to the barrier)
         if (threadIdx.x < 8u) s_bases[threadIdx.x] = *reinterpret_cast<const uint64_t __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(a.stripe_bases + threadIdx.x));
@@ -926,7 +933,10 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
         // requests ENTER a class, not per tile (two divisions, two LDS reads and the wait behind them in front of every request cost
         // the class forms 3-4 points of the roofline: attend_mx4.hip)
         const uint8_t* cls_k0 = nullptr; const uint8_t* cls_v0 = nullptr;
-        uint32_t cls_ic = 0u, cls_cnt = 1u;
+        uint32_t cls_ic = 0u, cls_cnt = 1u, cls_krun = 0u, cls_vrun = 0u;
+        // (the allocation's scales in run order, AttendArgs::scale_run: entry p / D of run p % D, in front of the page-order table)
+        const uint32_t run_cap = CLS ? a.scale_run >> 4 : 0u;
+        const uint8_t* sc_base = reinterpret_cast<const uint8_t*>(a.scale_tab) - (CLS && a.scale_run ? static_cast<uint64_t>(cls_n) * run_cap * 4u : 0ull);
         auto cls_enter = [&]() {
             uint32_t ic = min(iq_cls, cls_n - 1u);
             uint32_t cnt = jq + (ic < jr ? 1u : 0u);
@@ -936,6 +946,7 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
             cls_k0 = uniform_ptr(reinterpret_cast<const uint8_t*>(s_bases[pk - rk * cls_n]) + static_cast<uint64_t>(rk) * 2048u + head * 128u);
             cls_v0 = uniform_ptr(reinterpret_cast<const uint8_t*>(s_bases[pv - rv * cls_n]) + static_cast<uint64_t>(rv) * 2048u + head * 128u);
             cls_ic = __builtin_amdgcn_readfirstlane(ic); cls_cnt = __builtin_amdgcn_readfirstlane(cnt);
+            cls_krun = __builtin_amdgcn_readfirstlane((pk - rk * cls_n) * run_cap + rk); cls_vrun = __builtin_amdgcn_readfirstlane((pv - rv * cls_n) * run_cap + rv);
         };
         if (CLS) cls_enter();
         auto cls_next = [&]() {
@@ -948,6 +959,7 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
             const uint32_t sl = lane & 15u, pgi = (sl & 2u) * 4u + (sl >> 2) * 2u + (sl & 1u);
             const uint32_t rel = ic + cls_n * min(16u * mm + pgi, cnt - 1u), j = rel & 15u;       // page of the range (its first page starts a group)
             gsc_c = ((lane < 16u ? kpage0 : vpage0) + rel - j + attend_tile_slot(j)) * 4u;
+            if (a.scale_run) gsc_c = ((lane < 16u ? cls_krun : cls_vrun) + min(16u * mm + pgi, cnt - 1u)) * 4u;      // (run order: 16 consecutive entries)
             if (++iq_m == cls_m) { iq_m = 0u; ++iq_cls; cls_enter(); }
         };
         auto issue_k = [&](uint32_t tt, uint32_t buf) {
@@ -959,7 +971,7 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
             for (uint32_t i = 0; i < 4; ++i) fd_dma16(dst + 1024u * i, src, g[i]);
             // one instruction for the 32 page scales of the tile: lanes 0..15 from the K table, 16..31 from the V table
             if (lane < 32u)
-                fd_dma4(dst + kFdS, reinterpret_cast<const uint8_t*>(a.scale_tab), CLS ? gsc_c : gsc + tc * 64u);
+                fd_dma4(dst + kFdS, CLS ? sc_base : reinterpret_cast<const uint8_t*>(a.scale_tab), CLS ? gsc_c : gsc + tc * 64u);
         };
         auto issue_v = [&](uint32_t tt, uint32_t buf) {                     // (CLS: always the tile issue_k has just resolved)
             const uint8_t* src = CLS ? vsrc_c : vreg + static_cast<uint64_t>(min(tt, last)) * 32768u;
@@ -1521,11 +1533,11 @@ hipError_t launch_attend_fp8_batch(const AttendArgs& a, uint32_t n_seq, float* d
     return launch_attend_combine(a, n_seq, d_out, d_lse, s);
 }
 
-hipError_t launch_build_scale_tab(const PageEntry* d_entries, uint64_t n_pages, uint32_t region_pages, float* d_scale_tab, hipStream_t s)
+hipError_t launch_build_scale_tab(const PageEntry* d_entries, uint64_t n_pages, uint32_t region_pages, float* d_scale_tab, hipStream_t s, uint32_t scale_run)
 {
     if (n_pages == 0) return hipSuccess;
     hipLaunchKernelGGL(k_build_scale_tab, dim3(static_cast<uint32_t>((n_pages + 255u) / 256u)), dim3(256), 0, s, d_entries, n_pages,
-                       region_pages, d_scale_tab);
+                       region_pages, d_scale_tab, scale_run);
     return hipGetLastError();
 }
 

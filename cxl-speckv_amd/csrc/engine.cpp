@@ -484,7 +484,7 @@ void Engine::release_allocation(Allocation* a)
     a->extents.clear();
     if (a->d_entries) (void)hipFree(a->d_entries);
     if (a->d_flags) (void)hipFree(a->d_flags);            // flags, slots and stamps are one block
-    if (a->d_scale_tab) { (void)hipFree(a->d_scale_tab); a->d_scale_tab = nullptr; }
+    if (a->d_scale_tab) { (void)hipFree(a->d_scale_tab_base); a->d_scale_tab = a->d_scale_tab_base = nullptr; a->scale_run = 0; }
     if (a->d_stripe) { (void)hipFree(a->d_stripe); a->d_stripe = nullptr; a->stripe_n = 0; }
     if (a->pinned) { (void)hipHostFree(a->pinned); a->pinned = nullptr; }
     a->d_entries = nullptr;
@@ -1082,14 +1082,24 @@ int Engine::set_layout(uint64_t handle, uint32_t T, uint32_t L, uint32_t H, uint
     RC_TRY(publish_row(a));
     // fused-attention scale table (FP8 records, 2 positions per page, regions aligned to 16-page tiles)
     if (a->scheme == SPECKV_COMP_FP8_E4M3 && static_cast<uint64_t>(H) * D * bpe == 2048u && T % 32u == 0u) {
-        if (!a->d_scale_tab) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&a->d_scale_tab), a->n_pages * sizeof(float)));
+        if (!a->d_scale_tab) {
+            // a regularly striped allocation keeps the scales a second time, in run order (entry p / D of run p % D, like the records),
+            // in front of the table: the residue-class forms of the attention then find a class tile's 16 scales in one line
+            const uint32_t Dn = a->regular ? a->stripe_n : 0u;
+            const uint64_t cap = Dn >= 2u ? (a->n_pages + Dn - 1u) / Dn : 0u;
+            a->scale_run = (Dn >= 2u && Dn <= 8u && cap < (1ull << 28)) ? (Dn | static_cast<uint32_t>(cap << 4)) : 0u;
+            const size_t front = a->scale_run ? static_cast<size_t>(Dn) * cap : 0u;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&a->d_scale_tab_base), (front + a->n_pages) * sizeof(float)));
+            a->d_scale_tab = a->d_scale_tab_base + front;
+        }
         a->region_pages = T / 2u;
-        HIP_TRY(launch_build_scale_tab(a->d_entries, a->n_pages, a->region_pages, a->d_scale_tab, stream_));
+        HIP_TRY(launch_build_scale_tab(a->d_entries, a->n_pages, a->region_pages, a->d_scale_tab, stream_, a->scale_run));
         HIP_TRY(hipStreamSynchronize(stream_));
     } else if (a->d_scale_tab) {
         HIP_TRY(hipDeviceSynchronize());
-        (void)hipFree(a->d_scale_tab);
-        a->d_scale_tab = nullptr;
+        (void)hipFree(a->d_scale_tab_base);
+        a->d_scale_tab = a->d_scale_tab_base = nullptr;
+        a->scale_run = 0;
         a->region_pages = 0;
     }
     return SPECKV_OK;

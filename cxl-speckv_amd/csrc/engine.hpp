@@ -103,6 +103,8 @@ struct Allocation {
     uint32_t stripe_n = 0;
     // FP8 allocations with a known layout: block scales in the fused attention's tile order (attend.hip), n_pages floats
     float* d_scale_tab = nullptr;
+    float* d_scale_tab_base = nullptr;    // what was allocated: a striped FP8 allocation keeps its scales in run order in front of the table
+    uint32_t scale_run = 0;               // ... CodecArgs::scale_run (D | cap << 4), 0 = no run-order part
     uint32_t region_pages = 0;
     bool has_layout = false;
     bool layout_inferred = false;

@@ -188,7 +188,7 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     }
     k.part_acc = reinterpret_cast<float*>(buf + q_bytes + qs_bytes);
     k.part_ml = reinterpret_cast<float*>(buf + q_bytes + qs_bytes + acc_bytes);
-    if (cls) k.fp8_cls = 1u;
+    if (cls) { k.fp8_cls = 1u; k.scale_run = a->scale_run; }
     if (table) { k.table_form = 1u; k.lin_base = nullptr; k.stripe_bases = nullptr; }
     if (!k.lin_base && !striped && !table)         // the linear / striped / table forms quantise the query in their own prologue
         HIP_TRY(launch_quantize_q_e4m3(d_q_f16, rows, g, L.head_dim, buf, reinterpret_cast<float*>(buf + q_bytes), st));

@@ -51,6 +51,7 @@ int Engine::write(uint64_t handle, uint64_t off, const void* src, size_t len, bo
     CodecArgs c{};
     c.entries = a->d_entries;
     c.scale_tab = a->d_scale_tab;        // fused-attention scale table follows every write
+    c.scale_run = a->scale_run;
     c.len_samples = len_samples_dev(a);
     c.region_pages = a->region_pages;
     c.data_stride = kPageSize;
@@ -126,6 +127,7 @@ int Engine::write_strided(uint64_t handle, uint64_t first, uint64_t step, uint64
     CodecArgs c{};
     c.entries = a->d_entries;
     c.scale_tab = a->d_scale_tab;
+    c.scale_run = a->scale_run;
     c.len_samples = len_samples_dev(a);
     c.region_pages = a->region_pages;
     c.data_stride = kPageSize;
@@ -231,7 +233,7 @@ int Engine::write_groups(const uint64_t* handles, const uint64_t* firsts, const 
     CompressGroup* d_slot = reinterpret_cast<CompressGroup*>(reinterpret_cast<uint8_t*>(d_groups_) + static_cast<size_t>(slot) * grp_ring_.slot_bytes);
     for (uint32_t i = 0; i < n_groups; ++i) {
         const Allocation* a = as[i];
-        staged[i] = CompressGroup{a->d_entries, a->d_scale_tab, a->region_pages, 0u, firsts[i],
+        staged[i] = CompressGroup{a->d_entries, a->d_scale_tab, a->region_pages, a->scale_run, firsts[i],
                                   static_cast<const uint8_t*>(d_srcs[i])};
     }
     HIP_TRY(hipMemcpyAsync(d_slot, staged, bytes, hipMemcpyHostToDevice, s));

@@ -999,11 +999,11 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                                          : a.data + i * a.data_stride;
         PageEntry* entries = a.entries;
         float* scale_tab = a.scale_tab;
-        uint32_t region_pages = a.region_pages;
+        uint32_t region_pages = a.region_pages, scale_run = a.scale_run;
         if (a.groups) {                                              // wave-uniform: this block's allocation
             const uint64_t gi = i / a.group_n, j = i - gi * a.group_n;
             const CompressGroup g = a.groups[gi];
-            entries = g.entries; scale_tab = g.scale_tab; region_pages = g.region_pages;
+            entries = g.entries; scale_tab = g.scale_tab; region_pages = g.region_pages; scale_run = g.scale_run;
             page = g.first + j * (a.page_step ? a.page_step : 1);
             src = g.data + j * a.data_stride;
         }
@@ -1311,6 +1311,7 @@ __global__ __launch_bounds__(kThreads) void k_compress(CodecArgs a)
                 if (scale_tab) {
                     const uint32_t j = static_cast<uint32_t>(page % region_pages) & 15u;
                     gstore<float>(&scale_tab[page - j + attend_tile_slot(j)], scale);
+                    if (scale_run) gstore<float>(scale_tab + scale_run_index(page, scale_run), scale);
                 }
             } else {
                 a.rec_bytes[page] = out_len;

@@ -69,7 +69,7 @@ struct CompressGroup {
     PageEntry*     entries;
     float*         scale_tab;
     uint32_t       region_pages;
-    uint32_t       pad;
+    uint32_t       scale_run;         // CodecArgs::scale_run of this allocation
     uint64_t       first;
     const uint8_t* data;
 };
@@ -113,6 +113,10 @@ struct CodecArgs {
     // (layer, kind) region of the shim layout, a multiple of 16
     float*          scale_tab;
     uint32_t        region_pages;
+    // ... and, for an allocation striped regularly over D >= 2 runs (round 6), ALSO in run order -- the scale of page p at
+    // scale_tab[-D * cap + (p % D) * cap + p / D], D = scale_run & 15, cap = scale_run >> 4 (0: no such table) -- where the
+    // residue-class forms of the FP8 attention find the 16 scales of a class tile in one line (scale_run_index)
+    uint32_t        scale_run;
     // compress only, INT8_DELTA_RLE: every 1024th page leaves its record length in len_samples[(page >> 10) & 15] -- 16 words of
     // the allocation's host-visible memory, plain stores -- so that the host can tell, without a copy back, whether the
     // allocation holds data that compresses (mean record well under 512 B: the flat-run decoder is then chosen for its reads;
@@ -323,6 +327,7 @@ struct AttendArgs {
     uint32_t wg8;                     // 1: the engine's choice of form; 2: workgroups of one run (8 waves) also for batches
     // ... and its STREAM form for many layers of one sequence (see k_attend_int4_wg8): n_wgs != 0 turns it on.  The rows'
     // partials then sit at (row * max_slots + slot) and the merge takes each row's count from attend_stream_count().
+    uint32_t scale_run = 0;          // FP8 class forms: the allocation's run-order scale table (CodecArgs::scale_run), 0 = none (gather from the page-order table)
     uint32_t fp8_cls = 0;            // FP8 over a regularly striped pool: k_attend_fp8_dma<2>, pages by residue class (n_splits / tiles_per_split count class-major tiles)
     struct Stream { uint32_t len, rem, n_wgs, max_slots, tiles; } stream;      // tiles: per layer, 0 = ceil(n_pages / 16) (the class form of INT4_G32 over a striped pool counts by residue class)
     // planned batches, MXFP4: the position a sequence still keeps OUTSIDE the pool (the connector's odd last position, fp16 rows
@@ -394,7 +399,13 @@ hipError_t launch_attend_fold_tail(uint32_t n_rows, const uint32_t* d_rows, uint
 // a.lin_base set: linear form (a.scale_tab, a.q16); else page-table form (a.q8 / a.qs from launch_quantize_q_e4m3)
 hipError_t launch_attend_fp8(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s);
 // scale_tab[tile order of p] = entries[p].rec_bytes >= 2048 ? entries[p].scale : 0 for every page (set_layout time)
-hipError_t launch_build_scale_tab(const PageEntry* d_entries, uint64_t n_pages, uint32_t region_pages, float* d_scale_tab, hipStream_t s);
+hipError_t launch_build_scale_tab(const PageEntry* d_entries, uint64_t n_pages, uint32_t region_pages, float* d_scale_tab, hipStream_t s, uint32_t scale_run = 0);
+// the run-order part of a scale table (CodecArgs::scale_run): index of page p relative to scale_tab
+__host__ __device__ inline int64_t scale_run_index(uint64_t p, uint32_t scale_run)
+{
+    const uint32_t D = scale_run & 15u, cap = scale_run >> 4;
+    return -static_cast<int64_t>(D) * cap + static_cast<int64_t>(p % D) * cap + static_cast<int64_t>(p / D);
+}
 // position of page-in-tile j (0..15) in the tile order [kb][r]: pages 2kb, 2kb+1, 8+2kb, 9+2kb of lane group kb
 __host__ __device__ inline uint32_t attend_tile_slot(uint32_t j) { return j < 8u ? ((j >> 1) << 2) + (j & 1u) : (((j - 8u) >> 1) << 2) + 2u + (j & 1u); }
 // INT4_G32 records (attend_int4.hip; a.lin_base set: linear form, else page-table form with a.entries / a.zero_page;
