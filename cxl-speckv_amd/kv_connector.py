@@ -100,7 +100,7 @@ class SpeckvKVConnector:
         calibrates them from a prompt's K: the channel's max|k| over the head's median channel), or None to switch it off.  What it buys:
         an outlier channel of K no longer sets the block scale of the channels that share its quantisation group -- on KV-like data
         INT4_G32 loses 0.33-0.42 of the attention output instead of 0.57-0.71 when the query weighs those channels (MXFP4, whose limit
-        there is the element's one mantissa bit, gains little): profiles/r06c_kv_format_accuracy.txt, tests/test_gpu_accuracy.py.
+        there is the element's one mantissa bit, gains little): profiles/r06d_kv_format_accuracy.txt, tests/test_gpu_accuracy.py.
         Set it before the first write; rows read back through kv_rows() are scaled back."""
         import torch
         if any(r.length for r in self.requests.values()):
