@@ -1724,6 +1724,7 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
         ex["prefetch_flush_small"] = {"error": repr(e)}
     ex.update(seq70b_extra(torch, kv))
     ex.update(fp8_scores_extra(torch, kv, 32768, 80))
+    ex.update({k + "_8k_context": v for k, v in fp8_scores_extra(torch, kv, 8192, 80).items()})      # the same 80 layers at 8k (the split count by CU balance: round 6)
     ex.update(int4_attention_extra(torch, kv, 32768, 80))
     ex.update(int4_attention_extra(torch, kv, 32768, 80, scheme=5))      # the same on MXFP4 records (block-scaled matrix instruction)
     ex.update(batch_attention_extra(torch, kv))      # BASELINE configs[4] shape: 70B-shaped KV @ 32k context
