@@ -658,15 +658,16 @@ def test_fused_attention_batch_of_sequences(eng, scheme):
         lib.free(h)
 
 
-@pytest.mark.parametrize("scheme", [4, 3, 5])
-def test_fused_attention_batch_larger_than_the_machine(eng, scheme):
+@pytest.mark.parametrize("scheme,T", [(4, 128), (3, 128), (5, 128), (5, 2048)])
+def test_fused_attention_batch_larger_than_the_machine(eng, scheme, T):
     """More sequences than the GPU has CUs (INT4: the batch then runs on workgroups of one run each, two resident per CU,
-    instead of the two-halves form): 272 short ragged sequences against the per-sequence entry point, batch and planned."""
+    instead of the two-halves form; MXFP4 at 64 tiles and more: the sequences cut into the pieces that balance the last round
+    of workgroups -- mx4_balanced_splits): 272 ragged sequences against the per-sequence entry point."""
     torch = torch_mod()
     lib = eng.lib
     lib.set_compression_scheme(scheme)
     batch_fn, single_fn = {4: (lib.attend_fp8_batch, lib.attend_fp8), 3: (lib.attend_int4_batch, lib.attend_int4), 5: (lib.attend_mx4_batch, lib.attend_mx4)}[scheme]
-    T, L, H, D, G = 128, 1, 8, 128, 8
+    L, H, D, G = 1, 8, 128, 8
     rng = np.random.default_rng(97)
     n_seq = 272
     lens = [int(v) * 2 for v in rng.integers(0, T // 2 + 1, n_seq)]
