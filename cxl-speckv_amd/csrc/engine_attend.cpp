@@ -246,6 +246,9 @@ static uint32_t int4_wg8_batch_tps(uint32_t n_seq, uint32_t tiles_max, uint32_t 
     if (tuning().attend_tiles_per_split > 0) return static_cast<uint32_t>(tuning().attend_tiles_per_split);      // (tests, measurement runs)
     const uint32_t resident = cus;                                        // 16-wave workgroups (two halves each), one per CU
     const uint32_t splits = std::max(1u, resident / std::max(1u, n_seq));
+    // more sequences than CUs: the pieces that balance the last round (ring_rule.hpp balanced_tiles_per_piece; 260 x 8k 0.45 -> 0.61
+    // of the HBM roofline, 300 0.52 -> 0.67, 340 0.58 -> 0.70, 384 0.63 -> 0.71)
+    if (n_seq > resident && tiles_max >= 64u) return balanced_tiles_per_piece(nullptr, n_seq, tiles_max, 1u, resident, kPiecesInt4Wg8);
     return std::max(32u, (tiles_max + splits - 1u) / splits);
 }
 
@@ -254,33 +257,14 @@ static uint32_t int4_wg8_batch_tps(uint32_t n_seq, uint32_t tiles_max, uint32_t 
 // workgroups) 0.77 of the HBM roofline, two splits each 0.73 (profiles/r05_mx4.txt) -- never under 8 tiles a split; a whole
 // sequence is final (no partials, no merge launch).
 //
-// More sequences than CUs, fewer than twice as many (round 6): whole sequences would be one full round and a thin one -- and a
-// thin round is slow, a workgroup alone on the machine runs only twice as fast as one among 256 (260 x 8k: 0.51 ms where
-// 256 x 8k take 0.335).  Cut into s pieces the sequences make W = n s workgroups of 1/s the length: F = W / CUs full rounds
-// and a last one of r = W % CUs, which costs max(0.5, 1.1 r / CUs) of a full one; pieces cost a merge launch and their own
-// ramps, (6 + 1.9 s) % over whole sequences.  The cheapest s of 1 .. 8, pieces of 24 tiles and more -- the model against
-// profiles/r06_mx4_batch_splits.txt: 260 x 8k -> 5 pieces (0.57 -> 0.69 of the HBM roofline), 300 -> 3 (0.65 -> 0.74), 340 -> 2 (0.72 -> 0.78),
-// 360 and up -> whole sequences (384: 0.78, 448: 0.835); 260 x 2k -> 2 pieces (0.475 -> 0.51).
-static uint32_t mx4_balanced_splits(uint32_t n_seq, uint32_t tiles_max, uint32_t cus)
-{
-    uint32_t best = 1u;
-    double best_cost = 0.0;
-    for (uint32_t sp = 1u; sp <= 8u && (sp == 1u || tiles_max / sp >= 24u); ++sp) {
-        const uint64_t w = static_cast<uint64_t>(n_seq) * sp;
-        const double full = static_cast<double>(w / cus), rest = static_cast<double>(w % cus) / cus;
-        const double rounds = full + (rest > 0.0 ? std::max(0.5, 1.1 * rest) : 0.0);
-        const double cost = rounds / sp * (sp == 1u ? 1.0 : 1.06 + 0.019 * sp);
-        if (sp == 1u || cost < best_cost) { best = sp; best_cost = cost; }
-    }
-    return best;
-}
-
+// More sequences than CUs (round 6): the pieces per sequence that balance the last round of workgroups (ring_rule.hpp
+// balanced_tiles_per_piece: 260 x 8k 0.57 -> 0.69 of the HBM roofline, 300 0.65 -> 0.74, 340 0.72 -> 0.78; 360 and up stay whole).
 static uint32_t mx4_batch_tps(uint32_t n_seq, uint32_t tiles_max, uint32_t cus)
 {
     if (tuning().attend_tiles_per_split > 0) return static_cast<uint32_t>(tuning().attend_tiles_per_split);      // (tests, measurement runs)
     const uint32_t resident = cus;
-    uint32_t splits = std::max(1u, resident / std::max(1u, n_seq));
-    if (n_seq > resident && n_seq < 2u * resident && tiles_max >= 64u) splits = mx4_balanced_splits(n_seq, tiles_max, resident);
+    const uint32_t splits = std::max(1u, resident / std::max(1u, n_seq));
+    if (n_seq > resident && tiles_max >= 64u) return balanced_tiles_per_piece(nullptr, n_seq, tiles_max, 1u, resident, kPiecesMx4);
     return std::max(8u, (tiles_max + splits - 1u) / splits);
 }
 

@@ -71,6 +71,44 @@ inline EvenSplit unequal_pieces(const UnequalFraction& u, uint32_t n_tiles)
     return EvenSplit{first, 2u};
 }
 
+// Batch attention launches of MORE workgroup columns than the machine takes in whole rounds (round 6; profiles/r06_batch_over_cus.txt).
+// Whole sequences make W = columns workgroups: F = W / CUs full rounds and a last one of the fraction r = (W % CUs) / CUs, and the
+// last round is not cheap -- a CU that holds one workgroup more than its neighbours runs all of them slower (FP8, INT4: the CU's
+// rate is shared), a workgroup alone on a CU is only about twice as fast as one among 256 (MXFP4) -- 260 sequences x 8k ran at
+// 0.59 / 0.45 / 0.57 of the HBM roofline (FP8 / INT4 / MXFP4) where 256 run at 0.80 / 0.69 / 0.85.  Cut into s pieces the
+// sequences make s times the workgroups of 1/s the length, and the launch costs, in tiles of one workgroup column,
+//     (F + last(r)) x tiles per piece x pieces(s),    last(r) = max(last_min, last_base + last_slope r) for r > 0,
+//                                                     pieces(s) = piece_base + piece_step s for s > 1 (merge launch, ramps), 1 whole
+// -- fitted per kernel to sweeps of s = 1 .. 8 at 260 / 300 / 340 / 384 / 448 sequences x 8k (within 3 % of every point).  The
+// cheapest s of 1 .. 8 is taken if it beats whole sequences by 3 % or more.  Returns the tiles per piece.
+struct PieceModel { double last_min, last_base, last_slope, piece_base, piece_step; uint32_t min_tiles; };
+constexpr PieceModel kPiecesMx4{0.5, 0.48, 0.36, 1.04, 0.022, 24u};         // k_attend_mx4: one workgroup column per sequence, one workgroup per CU
+constexpr PieceModel kPiecesFp8{0.75, 0.75, 0.25, 0.98, 0.02, 32u};       // k_attend_fp8_*: kv heads / 4 columns per sequence, up to four workgroups per CU
+constexpr PieceModel kPiecesInt4Wg8{0.55, 0.3, 0.6, 1.0, 0.008, 32u};     // k_attend_int4_wg8<1>: one column per sequence, two workgroups per CU
+inline uint32_t balanced_tiles_per_piece(const uint32_t* tiles, uint32_t n_seq, uint32_t uniform_tiles, uint32_t columns_per_seq,
+                                         uint32_t n_cus, const PieceModel& m)
+{
+    uint32_t n_max = tiles ? 0u : uniform_tiles;
+    if (tiles) for (uint32_t i = 0; i < n_seq; ++i) n_max = tiles[i] > n_max ? tiles[i] : n_max;
+    if (n_max == 0 || n_seq == 0 || columns_per_seq == 0 || n_cus == 0) return n_max ? n_max : 8u;
+    double whole_cost = 0.0, best_cost = 0.0;
+    uint32_t best = n_max;
+    for (uint32_t sp = 1u; sp <= 8u; ++sp) {
+        const uint32_t tps = (n_max + sp - 1u) / sp;
+        if (sp > 1u && tps < m.min_tiles) break;
+        uint64_t w = 0;
+        if (tiles) for (uint32_t i = 0; i < n_seq; ++i) w += (tiles[i] + tps - 1u) / tps;
+        else w = static_cast<uint64_t>(n_seq) * ((uniform_tiles + tps - 1u) / tps);
+        w *= columns_per_seq;
+        const double full = static_cast<double>(w / n_cus), rest = static_cast<double>(w % n_cus) / n_cus;
+        const double last = rest > 0.0 ? (m.last_base + m.last_slope * rest > m.last_min ? m.last_base + m.last_slope * rest : m.last_min) : 0.0;
+        const double cost = (full + last) * tps * (sp == 1u ? 1.0 : m.piece_base + m.piece_step * sp);
+        if (sp == 1u) { whole_cost = best_cost = cost; continue; }
+        if (cost < best_cost && cost <= 0.97 * whole_cost) { best_cost = cost; best = tps; }
+    }
+    return best;
+}
+
 // Split length (tiles) of an FP8 batch attention launch.  tiles[i] = tiles of sequence i (null: n_seq sequences of
 // uniform_tiles each); columns_per_seq = workgroup columns one sequence contributes (kv heads / 4).  The four workgroups a
 // CU can hold share its rate, so a launch takes about  ceil(workgroups / 256) x (tiles per split + 3)  tile times, plus
@@ -84,6 +122,9 @@ inline uint32_t fp8_batch_tiles_per_split(const uint32_t* tiles, uint32_t n_seq,
     if (tiles) for (uint32_t i = 0; i < n_seq; ++i) n_max = tiles[i] > n_max ? tiles[i] : n_max;
     if (n_max == 0 || n_seq == 0 || columns_per_seq == 0) return 8u;
     const uint64_t columns = static_cast<uint64_t>(n_seq) * columns_per_seq;
+    if (columns > 2ull * n_cus && n_max >= 128u)                 // more than two rounds of whole sequences, 4k context and up (at 2k pieces gave nothing:
+                                                                 // 300 x 2k whole 0.66, two pieces 0.62): the pieces that balance the last round (above)
+        return balanced_tiles_per_piece(tiles, n_seq, uniform_tiles, columns_per_seq, n_cus, kPiecesFp8);
     uint64_t best_cost = UINT64_MAX;
     uint32_t best = n_max;
     for (uint32_t r = 0; r <= 4u; ++r) {

@@ -658,11 +658,11 @@ def test_fused_attention_batch_of_sequences(eng, scheme):
         lib.free(h)
 
 
-@pytest.mark.parametrize("scheme,T", [(4, 128), (3, 128), (5, 128), (5, 2048)])
+@pytest.mark.parametrize("scheme,T", [(4, 128), (3, 128), (5, 128), (5, 2048), (3, 2048), (4, 4096)])
 def test_fused_attention_batch_larger_than_the_machine(eng, scheme, T):
     """More sequences than the GPU has CUs (INT4: the batch then runs on workgroups of one run each, two resident per CU,
-    instead of the two-halves form; MXFP4 at 64 tiles and more: the sequences cut into the pieces that balance the last round
-    of workgroups -- mx4_balanced_splits): 272 ragged sequences against the per-sequence entry point."""
+    instead of the two-halves form; at 64 tiles and more -- FP8: 128 -- the sequences are cut into the pieces that balance the
+    last round of workgroups: ring_rule.hpp balanced_tiles_per_piece): 272 ragged sequences against the per-sequence entry point."""
     torch = torch_mod()
     lib = eng.lib
     lib.set_compression_scheme(scheme)

@@ -263,6 +263,8 @@ def rules():
     lib.rules_int4_unequal.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.rules_fp8_batch_tiles_per_split.restype = C.c_uint32
     lib.rules_fp8_batch_tiles_per_split.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.rules_balanced_tiles_per_piece.restype = C.c_uint32
+    lib.rules_balanced_tiles_per_piece.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     return lib
 
 
@@ -357,7 +359,11 @@ def test_fp8_batch_split_rule(rules):
     assert uniform(32, 128) == 32 and uniform(16, 256) == 32      # 256 workgroups
     assert uniform(32, 1024) == 256 and uniform(4, 4096) == 128   # 256 workgroups
     assert uniform(48, 512) == 64                                 # 8 splits: 768 workgroups = three per CU (288 would be 0.50 of peak)
-    assert uniform(300, 128) == 128                               # 600 columns: splitting only unbalances them
+    assert uniform(300, 64) == 64                                 # 600 columns x 2k: pieces gave nothing (whole 0.66 of HBM peak, two pieces 0.62)
+    # more than two rounds of whole sequences, 4k context and up: the pieces that balance the last round (balanced_tiles_per_piece,
+    # profiles/r06_batch_over_cus.txt: 260 x 8k 0.59 -> 0.70 of HBM peak, 300 0.68 -> 0.74, 340 0.73 -> 0.78, 448 0.72 -> 0.76)
+    assert uniform(260, 256) == 64 and uniform(300, 256) == 128 and uniform(340, 256) == 86 and uniform(448, 256) == 128
+    assert uniform(384, 256) == 256 and uniform(480, 256) == 256 and uniform(512, 256) == 256      # whole rounds, or near enough: whole sequences
     assert uniform(100, 128) == 26                                # 200 columns x 5 splits = 1000 workgroups (measured 0.61 of HBM peak, whole 0.54) since the merge is one wave per row
     rng = np.random.default_rng(5)
     for _ in range(400):
@@ -367,6 +373,9 @@ def test_fp8_batch_split_rule(rules):
         splits = -(-tiles // tps)
         wgs = n_seq * hq * splits
         assert 1 <= tps <= tiles and (splits == 1 or tps >= 8) and splits <= 2048
+        if n_seq * hq > 512 and tiles >= 128:                     # the balanced-pieces rule: at most 8 pieces of 32 tiles or more
+            assert splits <= 8 and (splits == 1 or tps >= 32)
+            continue
         if n_seq * hq >= 256:
             assert splits == 1 or wgs <= 1024                     # a batch that covers the chip is split only inside one residency
         if splits > 1:                                            # priced below whole sequences by the rule's own cost
@@ -379,6 +388,47 @@ def test_fp8_batch_split_rule(rules):
         assert tps >= 1 and (t.max() == 0 or tps <= max(int(t.max()), 8))
         assert int(np.max(-(-t.astype(np.int64) // tps))) <= 2048
     assert f(None, 0, 100, hq) == 8 and f(None, 10, 0, hq) == 8  # nothing to do: any legal length
+
+
+def test_balanced_pieces_rule_for_batches_over_the_cu_count(rules):
+    """ring_rule.hpp::balanced_tiles_per_piece (batch attention of more workgroup columns than whole rounds of the machine take, round 6,
+    profiles/r06_batch_over_cus.txt): the measured shapes get pieces within 3 % of the best measured, batches that fill whole rounds stay
+    whole, a piece is never shorter than the model's minimum, at most 8 pieces, the pieces cover the longest sequence, the answer for a
+    uniform batch is the same from a list and from a bound, and it never prices pieces above whole sequences."""
+    f = rules.rules_balanced_tiles_per_piece
+    MX4, FP8, INT4 = 0, 1, 2
+
+    def uniform(n_seq, tiles, cols, model, cus=256):
+        a = f(None, n_seq, tiles, cols, cus, model)
+        b = f((C.c_uint32 * n_seq)(*([tiles] * n_seq)), n_seq, 0, cols, cus, model)
+        assert a == b
+        return a
+
+    # 8k context = 256 tiles; (sequences -> tiles per piece) as measured best or within 3 % of it
+    assert [uniform(n, 256, 1, MX4) for n in (260, 300, 340, 384, 448, 512)] == [64, 64, 86, 256, 256, 256]
+    assert [uniform(n, 256, 2, FP8) for n in (260, 300, 340, 384, 448, 480, 512)] == [64, 128, 86, 256, 128, 256, 256]
+    assert [uniform(n, 256, 1, INT4) for n in (260, 300, 340, 384, 448, 512)] == [32, 64, 86, 128, 256, 256]
+    assert uniform(260, 64, 1, MX4) == 32 and uniform(260, 64, 1, INT4) == 32          # 2k context: two pieces (0.48 -> 0.51, 0.36 -> 0.45 of HBM peak)
+    min_tiles = {MX4: 24, FP8: 32, INT4: 32}
+    rng = np.random.default_rng(23)
+    for _ in range(600):
+        model = int(rng.integers(0, 3))
+        cols = 2 if model == FP8 else 1
+        n_seq = int(rng.integers(1, 1500))
+        tiles = int(rng.integers(1, 3000))
+        cus = int(rng.choice([256, 304, 64]))
+        tps = uniform(n_seq, tiles, cols, model, cus)
+        pieces = -(-tiles // tps)
+        assert 1 <= tps <= tiles and pieces <= 8 and (pieces == 1 or tps >= min_tiles[model])
+        if (n_seq * cols) % cus == 0:
+            assert pieces == 1                                    # whole rounds of whole sequences: nothing to balance
+    for _ in range(200):                                          # ragged batches: priced on their real workgroup count
+        n_seq = int(rng.integers(1, 600))
+        t = rng.integers(0, 2000, n_seq).astype(np.uint32)
+        tps = f(t.ctypes.data_as(C.POINTER(C.c_uint32)), n_seq, 0, 1, 256, MX4)
+        assert tps >= 1 and (t.max() == 0 or tps <= int(t.max()))
+        assert int(np.max(-(-t.astype(np.int64) // tps))) <= 8
+    assert f(None, 0, 100, 1, 256, MX4) == 100 and f(None, 10, 0, 1, 256, MX4) == 8     # nothing to do: any legal length
 
 
 def test_int4_batch_unequal_split_rule(rules):
