@@ -249,6 +249,8 @@ static uint32_t int4_wg8_batch_tps(uint32_t n_seq, uint32_t tiles_max, uint32_t 
     // more sequences than CUs: the pieces that balance the last round (ring_rule.hpp balanced_tiles_per_piece; 260 x 8k 0.45 -> 0.61
     // of the HBM roofline, 300 0.52 -> 0.67, 340 0.58 -> 0.70, 384 0.63 -> 0.71)
     if (n_seq > resident && tiles_max >= 64u) return balanced_tiles_per_piece(nullptr, n_seq, tiles_max, 1u, resident, kPiecesInt4Wg8);
+    // between half a machine and a whole one (the 16-wave form): 130 x 8k 0.43 -> 0.57, 160 0.53 -> 0.64, 200 and up stay whole
+    if (2u * n_seq > resident && tiles_max >= 64u) return balanced_tiles_per_piece(nullptr, n_seq, tiles_max, 1u, resident, kPiecesInt4Halves);
     return std::max(32u, (tiles_max + splits - 1u) / splits);
 }
 
@@ -257,14 +259,15 @@ static uint32_t int4_wg8_batch_tps(uint32_t n_seq, uint32_t tiles_max, uint32_t 
 // workgroups) 0.77 of the HBM roofline, two splits each 0.73 (profiles/r05_mx4.txt) -- never under 8 tiles a split; a whole
 // sequence is final (no partials, no merge launch).
 //
-// More sequences than CUs (round 6): the pieces per sequence that balance the last round of workgroups (ring_rule.hpp
+// More sequences than half the CUs (round 6): the pieces per sequence that balance the last round of workgroups (ring_rule.hpp
 // balanced_tiles_per_piece: 260 x 8k 0.57 -> 0.69 of the HBM roofline, 300 0.65 -> 0.74, 340 0.72 -> 0.78; 360 and up stay whole).
 static uint32_t mx4_batch_tps(uint32_t n_seq, uint32_t tiles_max, uint32_t cus)
 {
     if (tuning().attend_tiles_per_split > 0) return static_cast<uint32_t>(tuning().attend_tiles_per_split);      // (tests, measurement runs)
     const uint32_t resident = cus;
     const uint32_t splits = std::max(1u, resident / std::max(1u, n_seq));
-    if (n_seq > resident && tiles_max >= 64u) return balanced_tiles_per_piece(nullptr, n_seq, tiles_max, 1u, resident, kPiecesMx4);
+    // (up to CUs sequences whole ones run on the 8-wave halves form: pieces pay from 8k context -- 130 x 8k 0.63 -> 0.65, 160 0.71 -> 0.76; 4k: 0.63 -> 0.61, 0.73 -> 0.70)
+    if ((n_seq > resident && tiles_max >= 64u) || (2u * n_seq > resident && tiles_max >= 256u)) return balanced_tiles_per_piece(nullptr, n_seq, tiles_max, 1u, resident, kPiecesMx4);
     return std::max(8u, (tiles_max + splits - 1u) / splits);
 }
 

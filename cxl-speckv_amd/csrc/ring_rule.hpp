@@ -81,10 +81,14 @@ inline EvenSplit unequal_pieces(const UnequalFraction& u, uint32_t n_tiles)
 //                                                     pieces(s) = piece_base + piece_step s for s > 1 (merge launch, ramps), 1 whole
 // -- fitted per kernel to sweeps of s = 1 .. 8 at 260 / 300 / 340 / 384 / 448 sequences x 8k (within 3 % of every point).  The
 // cheapest s of 1 .. 8 is taken if it beats whole sequences by 3 % or more.  Returns the tiles per piece.
+// The same holds between half a machine and a whole one (130 x 8k whole: FP8 0.46, INT4 0.43, MXFP4 0.63 of the roofline; 160: 0.56 /
+// 0.53 / 0.71): the rule is applied from CUs / 2 sequences (FP8: more than CUs columns) up -- 130 -> 0.64 / 0.57 / 0.66, 160 -> 0.72 / 0.64 / 0.76.
 struct PieceModel { double last_min, last_base, last_slope, piece_base, piece_step; uint32_t min_tiles; };
 constexpr PieceModel kPiecesMx4{0.5, 0.48, 0.36, 1.04, 0.022, 24u};         // k_attend_mx4: one workgroup column per sequence, one workgroup per CU
 constexpr PieceModel kPiecesFp8{0.75, 0.75, 0.25, 0.98, 0.02, 32u};       // k_attend_fp8_*: kv heads / 4 columns per sequence, up to four workgroups per CU
 constexpr PieceModel kPiecesInt4Wg8{0.55, 0.3, 0.6, 1.0, 0.008, 32u};     // k_attend_int4_wg8<1>: one column per sequence, two workgroups per CU
+constexpr PieceModel kPiecesInt4Halves{0.8, 0.62, 0.31, 1.0, 0.012, 32u}; // k_attend_int4_wg8<2> (batches of at most CUs sequences): 16-wave workgroups, one per CU -- and
+                                                                         // a workgroup alone on its CU is hardly faster than one among 256 (the kernel is bound by instruction issue)
 inline uint32_t balanced_tiles_per_piece(const uint32_t* tiles, uint32_t n_seq, uint32_t uniform_tiles, uint32_t columns_per_seq,
                                          uint32_t n_cus, const PieceModel& m)
 {
@@ -122,7 +126,7 @@ inline uint32_t fp8_batch_tiles_per_split(const uint32_t* tiles, uint32_t n_seq,
     if (tiles) for (uint32_t i = 0; i < n_seq; ++i) n_max = tiles[i] > n_max ? tiles[i] : n_max;
     if (n_max == 0 || n_seq == 0 || columns_per_seq == 0) return 8u;
     const uint64_t columns = static_cast<uint64_t>(n_seq) * columns_per_seq;
-    if (columns > 2ull * n_cus && n_max >= 128u)                 // more than two rounds of whole sequences, 4k context and up (at 2k pieces gave nothing:
+    if (columns > n_cus && n_max >= 128u)                        // more than one round of whole sequences, 4k context and up (at 2k pieces gave nothing:
                                                                  // 300 x 2k whole 0.66, two pieces 0.62): the pieces that balance the last round (above)
         return balanced_tiles_per_piece(tiles, n_seq, uniform_tiles, columns_per_seq, n_cus, kPiecesFp8);
     uint64_t best_cost = UINT64_MAX;

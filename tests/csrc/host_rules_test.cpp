@@ -18,10 +18,10 @@ uint32_t rules_fp8_batch_tiles_per_split(const uint32_t* tiles, uint32_t n_seq, 
 {
     return speckv::fp8_batch_tiles_per_split(tiles, n_seq, uniform_tiles, columns_per_seq);
 }
-// model: 0 = MXFP4 (k_attend_mx4), 1 = FP8, 2 = INT4 on the whole-record kernel
+// model: 0 = MXFP4 (k_attend_mx4), 1 = FP8, 2 = INT4 on the whole-record kernel (one-run workgroups), 3 = the same, 16-wave form
 uint32_t rules_balanced_tiles_per_piece(const uint32_t* tiles, uint32_t n_seq, uint32_t uniform_tiles, uint32_t columns_per_seq, uint32_t n_cus, uint32_t model)
 {
-    const speckv::PieceModel& m = model == 0u ? speckv::kPiecesMx4 : model == 1u ? speckv::kPiecesFp8 : speckv::kPiecesInt4Wg8;
+    const speckv::PieceModel& m = model == 0u ? speckv::kPiecesMx4 : model == 1u ? speckv::kPiecesFp8 : model == 2u ? speckv::kPiecesInt4Wg8 : speckv::kPiecesInt4Halves;
     return speckv::balanced_tiles_per_piece(tiles, n_seq, uniform_tiles, columns_per_seq, n_cus, m);
 }
 // {on, first piece, pieces} of a sequence of n_tiles in an INT4 batch of `columns` workgroup columns whose longest member has tiles_max

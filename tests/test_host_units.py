@@ -364,6 +364,8 @@ def test_fp8_batch_split_rule(rules):
     # profiles/r06_batch_over_cus.txt: 260 x 8k 0.59 -> 0.70 of HBM peak, 300 0.68 -> 0.74, 340 0.73 -> 0.78, 448 0.72 -> 0.76)
     assert uniform(260, 256) == 64 and uniform(300, 256) == 128 and uniform(340, 256) == 86 and uniform(448, 256) == 128
     assert uniform(384, 256) == 256 and uniform(480, 256) == 256 and uniform(512, 256) == 256      # whole rounds, or near enough: whole sequences
+    # ... and between one round and two (130 x 8k: 0.62 -> 0.64, 200 x 8k: 0.69 -> 0.73)
+    assert uniform(130, 256) == 32 and uniform(160, 256) == 64 and uniform(200, 256) == 86 and uniform(230, 256) == 256
     assert uniform(100, 128) == 26                                # 200 columns x 5 splits = 1000 workgroups (measured 0.61 of HBM peak, whole 0.54) since the merge is one wave per row
     rng = np.random.default_rng(5)
     for _ in range(400):
@@ -373,7 +375,7 @@ def test_fp8_batch_split_rule(rules):
         splits = -(-tiles // tps)
         wgs = n_seq * hq * splits
         assert 1 <= tps <= tiles and (splits == 1 or tps >= 8) and splits <= 2048
-        if n_seq * hq > 512 and tiles >= 128:                     # the balanced-pieces rule: at most 8 pieces of 32 tiles or more
+        if n_seq * hq > 256 and tiles >= 128:                     # the balanced-pieces rule: at most 8 pieces of 32 tiles or more
             assert splits <= 8 and (splits == 1 or tps >= 32)
             continue
         if n_seq * hq >= 256:
@@ -409,10 +411,13 @@ def test_balanced_pieces_rule_for_batches_over_the_cu_count(rules):
     assert [uniform(n, 256, 2, FP8) for n in (260, 300, 340, 384, 448, 480, 512)] == [64, 128, 86, 256, 128, 256, 256]
     assert [uniform(n, 256, 1, INT4) for n in (260, 300, 340, 384, 448, 512)] == [32, 64, 86, 128, 256, 256]
     assert uniform(260, 64, 1, MX4) == 32 and uniform(260, 64, 1, INT4) == 32          # 2k context: two pieces (0.48 -> 0.51, 0.36 -> 0.45 of HBM peak)
-    min_tiles = {MX4: 24, FP8: 32, INT4: 32}
+    HALVES = 3                                                    # INT4, at most CUs sequences: the 16-wave form
+    assert [uniform(n, 256, 1, HALVES) for n in (130, 160, 200, 230, 256)] == [37, 86, 256, 256, 256]
+    assert [uniform(n, 256, 1, MX4) for n in (130, 160, 200, 230, 256)] == [86, 86, 256, 256, 256]
+    min_tiles = {MX4: 24, FP8: 32, INT4: 32, HALVES: 32}
     rng = np.random.default_rng(23)
     for _ in range(600):
-        model = int(rng.integers(0, 3))
+        model = int(rng.integers(0, 4))
         cols = 2 if model == FP8 else 1
         n_seq = int(rng.integers(1, 1500))
         tiles = int(rng.integers(1, 3000))
