@@ -236,7 +236,7 @@ static uint32_t batch_tiles_per_split(bool fp8, uint32_t n_seq, uint32_t heads, 
 
 // INT4 batches on the whole-record kernel (k_attend_int4_wg8<2>: workgroups = sequences x splits, one 16-wave workgroup per
 // CU resident, its two halves merged in LDS): one round of resident workgroups when the batch is smaller than that, whole
-// sequences otherwise (a whole sequence is final: no partials, no merge launch); never under 32 tiles a split.
+// sequences otherwise (a whole sequence is final: no partials, no merge launch); never under 8 tiles a split.
 // More sequences than CUs: workgroups of one run (8 waves, two resident per CU) -- a finishing workgroup's successor starts
 // under its neighbour's stream, where a second round of 16-wave workgroups would wait for the whole CU (512 x 1k 0.52 -> 0.54,
 // 1024 x 1k 0.56 -> 0.595: profiles/r04_batch_short.txt); AttendArgs::wg8 = 2.
@@ -251,7 +251,9 @@ static uint32_t int4_wg8_batch_tps(uint32_t n_seq, uint32_t tiles_max, uint32_t 
     if (n_seq > resident && tiles_max >= 64u) return balanced_tiles_per_piece(nullptr, n_seq, tiles_max, 1u, resident, kPiecesInt4Wg8);
     // between half a machine and a whole one (the 16-wave form): 130 x 8k 0.43 -> 0.57, 160 0.53 -> 0.64, 200 and up stay whole
     if (2u * n_seq > resident && tiles_max >= 64u) return balanced_tiles_per_piece(nullptr, n_seq, tiles_max, 1u, resident, kPiecesInt4Halves);
-    return std::max(32u, (tiles_max + splits - 1u) / splits);
+    // (the floor was 32 tiles until round 6: with few sequences that left most of the machine idle -- 8 x 8k: 64 workgroups 0.16 of the HBM
+    //  roofline, 256 workgroups of 8 tiles 0.34; 16 x 8k 0.32 -> 0.49; 4 x 8k 0.08 -> 0.21)
+    return std::max(8u, (tiles_max + splits - 1u) / splits);
 }
 
 // MXFP4 batches (k_attend_mx4: one workgroup of 4 waves = the 8 kv heads per (sequence, split), three tiles deep in LDS: ONE
