@@ -1290,7 +1290,12 @@ __global__ __launch_bounds__(512) void k_attend_combine(const float* __restrict_
 // lane (c, kb) = query row c, dimensions 32 kb .. 32 kb + 31 -- the layout the partials are stored in, so every access is a
 // 16-byte one.  (The general kernel above spends a 512-thread workgroup per query row: 16 384 workgroups for a batch of 256
 // sequences, more than the merge is worth when there are two partials to add.)
+// WPR = 4 (round 6; launches of few rows -- batches of some tens of sequences cut into pieces): the four waves of a workgroup share ONE row, wave w
+// takes dimensions 8 w .. 8 w + 7 of every lane's 32 (two of its eight 16-byte pieces), all splits in the same order -- bit for bit the sums of
+// WPR = 1, a quarter of the dependent loads per wave and four times the waves (32 sequences x 8 splits: 8.6 -> 4.6 us; one wave per CU was
+// the whole launch).
 constexpr uint32_t kSmallCombineSplits = 8;
+template <int WPR>
 __global__ __launch_bounds__(256) void k_attend_combine_small(const float* __restrict__ part_acc, const float* __restrict__ part_ml,
                                                               uint32_t g, uint32_t n_splits, float* __restrict__ out,
                                                               float* __restrict__ lse, const AttendSeq* __restrict__ seqs,
@@ -1298,7 +1303,9 @@ __global__ __launch_bounds__(256) void k_attend_combine_small(const float* __res
 {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const uint32_t lane = threadIdx.x & 63u, c = lane & 15u, kb = lane >> 4;
-    const uint32_t rowq = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t rowq = WPR == 1 ? blockIdx.x * 4u + (threadIdx.x >> 6) : blockIdx.x;
+    constexpr int kI0 = 0, kIn = WPR == 1 ? 8 : 2;                     // this wave's 16-byte pieces of a lane's eight: [i0, i0 + kIn)
+    const int i0 = WPR == 1 ? kI0 : 2 * static_cast<int>(threadIdx.x >> 6);
     if (rowq >= n_rows) return;
     uint64_t part0 = static_cast<uint64_t>(rowq) * n_splits;
     if (seqs) {
@@ -1322,10 +1329,10 @@ __global__ __launch_bounds__(256) void k_attend_combine_small(const float* __res
     }
     const float Mu = (M == -INFINITY) ? 0.0f : M;
     float L = 0.0f;
-    v4f o[8];
+    v4f o[kIn];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    const float* src = part_acc + (part0 * 16u + c) * 128u + 32u * kb;
+    for (int i = 0; i < kIn; ++i) o[i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    const float* src = part_acc + (part0 * 16u + c) * 128u + 32u * kb + 4 * i0;
 #pragma unroll
     for (uint32_t s = 0; s < kSmallCombineSplits; ++s) {
         if (s < n_splits) {                                          // wave-uniform
@@ -1333,15 +1340,15 @@ __global__ __launch_bounds__(256) void k_attend_combine_small(const float* __res
             L += w * l[s];
             if (c < g) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] += *reinterpret_cast<const v4f*>(src + static_cast<uint64_t>(s) * 2048u + 4 * i) * w;
+                for (int i = 0; i < kIn; ++i) o[i] += *reinterpret_cast<const v4f*>(src + static_cast<uint64_t>(s) * 2048u + 4 * i) * w;
             }
         }
     }
     if (c < g) {
-        float* dst = out + (static_cast<uint64_t>(rowq) * g + c) * 128u + 32u * kb;
+        float* dst = out + (static_cast<uint64_t>(rowq) * g + c) * 128u + 32u * kb + 4 * i0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<v4f*>(dst + 4 * i) = L > 0.0f ? o[i] / L : v4f{0.0f, 0.0f, 0.0f, 0.0f};
-        if (lse && kb == 0u) lse[static_cast<uint64_t>(rowq) * g + c] = L > 0.0f ? (M + log2f(L)) * 0.6931471805599453f : -INFINITY;
+        for (int i = 0; i < kIn; ++i) *reinterpret_cast<v4f*>(dst + 4 * i) = L > 0.0f ? o[i] / L : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        if (lse && kb == 0u && i0 == 0) lse[static_cast<uint64_t>(rowq) * g + c] = L > 0.0f ? (M + log2f(L)) * 0.6931471805599453f : -INFINITY;
     }
 }
 
@@ -1444,6 +1451,7 @@ hipError_t launch_qk_scores_fp8_linear(const AttendArgs& a, uint32_t n_layers, f
     return hipGetLastError();
 }
 
+constexpr uint32_t kSmallCombineRowsShared = 8192;     // rows up to which the small merge spends a workgroup per row (k_attend_combine_small<4>)
 hipError_t launch_attend_combine(const AttendArgs& a, uint32_t n_layers, float* d_out, float* d_lse, hipStream_t s)
 {
     if (n_layers == 0) return hipSuccess;
@@ -1452,8 +1460,12 @@ hipError_t launch_attend_combine(const AttendArgs& a, uint32_t n_layers, float* 
     if (splits > kMaxSplits) return hipErrorInvalidValue;
     if (splits <= kSmallCombineSplits) {
         const uint32_t n_rows = n_layers * a.heads;
-        hipLaunchKernelGGL(k_attend_combine_small, dim3((n_rows + 3u) / 4u), dim3(256), 0, s, a.part_acc, a.part_ml, a.g,
-                           a.n_splits, d_out, d_lse, a.seqs, a.heads, (a.direct_out && a.direct_per_seq) ? 1u : 0u, n_rows, a.stream, n_tiles);
+        if (n_rows <= kSmallCombineRowsShared)
+            hipLaunchKernelGGL(k_attend_combine_small<4>, dim3(n_rows), dim3(256), 0, s, a.part_acc, a.part_ml, a.g,
+                               a.n_splits, d_out, d_lse, a.seqs, a.heads, (a.direct_out && a.direct_per_seq) ? 1u : 0u, n_rows, a.stream, n_tiles);
+        else
+            hipLaunchKernelGGL(k_attend_combine_small<1>, dim3((n_rows + 3u) / 4u), dim3(256), 0, s, a.part_acc, a.part_ml, a.g,
+                               a.n_splits, d_out, d_lse, a.seqs, a.heads, (a.direct_out && a.direct_per_seq) ? 1u : 0u, n_rows, a.stream, n_tiles);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_attend_combine, dim3(n_layers * a.heads * a.g), dim3(512), 0, s, a.part_acc, a.part_ml, a.g,
