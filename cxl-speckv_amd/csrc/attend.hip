@@ -1292,7 +1292,7 @@ __global__ __launch_bounds__(512) void k_attend_combine(const float* __restrict_
 // sequences, more than the merge is worth when there are two partials to add.)
 // WPR = 4 (round 6; launches of few rows -- batches of some tens of sequences cut into pieces): the four waves of a workgroup share ONE row, wave w
 // takes dimensions 8 w .. 8 w + 7 of every lane's 32 (two of its eight 16-byte pieces), all splits in the same order -- bit for bit the sums of
-// WPR = 1, a quarter of the dependent loads per wave and four times the waves (32 sequences x 8 splits: 8.6 -> 4.6 us; one wave per CU was
+// WPR = 1, a quarter of the dependent loads per wave and four times the waves (32 sequences x 8 splits: 8.6 -> 5.6 us; one wave per CU was
 // the whole launch).
 constexpr uint32_t kSmallCombineSplits = 8;
 template <int WPR>
