@@ -147,7 +147,9 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
         uint32_t best_s = 1;
         double best = -1.0;
         for (uint32_t sp = 1; sp <= 16u; ++sp) {
-            if (sp > 1u && n_tiles / sp < 64u) break;
+            // (pieces under 64 tiles -- never under 16 -- only while the launch has not filled one round: 32 layers x 2k were 64 workgroups 0.36 of the
+            //  roofline, 8 pieces 0.56; 4k: 128 workgroups 0.64, 8 pieces 0.685)
+            if (sp > 1u && (n_tiles / sp < 16u || (n_tiles / sp < 64u && static_cast<uint64_t>(wg_rows) * (sp - 1u) >= n_cu))) break;
             const uint64_t wgs = static_cast<uint64_t>(wg_rows) * sp, cap = static_cast<uint64_t>(sp == 1u ? 2u : 4u) * n_cu;      // (resident: DMA kernel 2 per CU, register-staged 4)
             if (wgs > cap && sp > 1u) break;
             const double per_cu = static_cast<double>(wgs) / n_cu, score = per_cu / std::ceil(per_cu);
@@ -711,11 +713,15 @@ int Engine::attend_fold_tail(uint32_t n_rows, const uint32_t* d_rows, uint32_t h
 // Stream form (many layers of one sequence): the launch's n_layers x n_tiles tiles, layer-major, in as many equal pieces as
 // workgroups are resident at once -- one pipeline fill per workgroup, no partial last round, few partials per layer.  Worth
 // it when a piece is long enough to amortise its fill (>= 16 tiles); *max_slots = most pieces any layer is cut into.
+constexpr uint32_t kStreamMinTiles = 896;            // context (tiles of 32 positions) from which several layers of one sequence take the stream form
 static bool int4_wg8_stream(uint32_t n_layers, uint32_t n_tiles, uint32_t cus, AttendArgs::Stream* out)
 {
     const uint64_t total = static_cast<uint64_t>(n_layers) * n_tiles;
     uint64_t wgs = 2ull * static_cast<uint64_t>(cus);
-    if (n_layers < 2 || total < 16u * wgs) return false;
+    // (round 6: from 28k context only.  Below it the fixed grid of ONE round -- layers x splits <= CUs, whole-layer rows final or merged --
+    //  is faster: 80 layers x 4k 0.515 (stream) against 0.567, 8k 0.60 / 0.63, 16k 0.64 / 0.66, 24k 0.667 / 0.66, 32k 0.70 / 0.67, 64k 0.71 / 0.69;
+    //  70 layers x 4k 0.46 / 0.55; profiles/r06_layers_by_context.txt)
+    if (n_layers < 2 || total < 16u * wgs || n_tiles < kStreamMinTiles) return false;
     out->n_wgs = static_cast<uint32_t>(wgs);
     out->len = static_cast<uint32_t>(total / wgs);
     out->rem = static_cast<uint32_t>(total % wgs);
@@ -730,9 +736,10 @@ static uint32_t int4_wg8_splits(uint32_t n_layers, uint32_t n_tiles, uint32_t cu
     const uint64_t resident = static_cast<uint64_t>(cus);                 // (16-wave workgroups, two halves each: one per CU)
     const uint64_t total = static_cast<uint64_t>(n_layers) * n_tiles;
     uint64_t wgs = std::max<uint64_t>(1, total / 64u);
-    if (wgs >= resident) wgs = (wgs + resident / 2u) / resident * resident;       // whole rounds
+    if (wgs >= resident && n_layers >= 2u) wgs = resident;                        // several layers: ONE round (80 layers x 16k: 3 splits 0.65, 6: 0.63, 10: 0.54)
+    else if (wgs >= resident) wgs = (wgs + resident / 2u) / resident * resident;  // whole rounds
     else wgs = std::min<uint64_t>(resident, std::max<uint64_t>(wgs, total / 8u));
-    const uint64_t per_layer = std::max<uint64_t>(1, (wgs + n_layers / 2u) / n_layers);
+    const uint64_t per_layer = std::max<uint64_t>(1, n_layers >= 2u ? wgs / n_layers : (wgs + n_layers / 2u) / n_layers);
     return static_cast<uint32_t>(std::min<uint64_t>(per_layer, std::max<uint32_t>(1u, n_tiles / 4u)));
 }
 
@@ -897,14 +904,16 @@ int Engine::attend_mx4(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     const EvenSplit es = even_split(n_tiles, std::max(1u, std::min(want, 2048u)));
     AttendArgs k{};
     // several layers of one long sequence: the stream form -- all tiles of the call in layer-major order cut into one equal piece
-    // per CU (80 layers x 3 splits of the fixed grid occupy 240 CUs of 256; profiles/r05_mx4.txt)
+    // per CU (80 layers x 3 splits of the fixed grid occupy 240 CUs of 256; profiles/r05_mx4.txt) -- from 28k context (round 6: below it
+    // the fixed grid is ahead, 80 layers x 2k 0.48 (stream) against 0.55, 4k 0.61 / 0.66, 12k 0.77 / 0.83, 24k 0.81 / 0.82, 32k 0.83 / 0.80,
+    // 64k 0.84 / 0.75; 70 layers x 4k 0.56 / 0.66, 100 layers x 4k 0.65 / 0.72; profiles/r06_layers_by_context.txt)
     const uint32_t zgroups = (g + 7u) / 8u;
     const uint64_t total_tiles = static_cast<uint64_t>(n_layers) * n_tiles;
     const int32_t stream_knob = tuning().attend_stream;                  // N > 0: that many pieces (tests cut small calls oddly), -1: never
     const uint32_t stream_wgs = stream_knob > 0 ? static_cast<uint32_t>(stream_knob) : cus() / zgroups;
     const bool stream = linear && n_layers >= 2u && (n_pages & 15u) == 0u && tuning().attend_splits <= 0 && stream_wgs >= 1u &&
                         total_tiles >= stream_wgs && total_tiles / stream_wgs <= 0xFFFFFFFFull &&
-                        (stream_knob > 0 || (stream_knob == 0 && total_tiles >= 16ull * stream_wgs && es.n_splits > 1u));      // (a fixed grid of whole layers writes final rows: no partials, no merge)
+                        (stream_knob > 0 || (stream_knob == 0 && total_tiles >= 16ull * stream_wgs && es.n_splits > 1u && n_tiles >= kStreamMinTiles));      // (a fixed grid of whole layers writes final rows: no partials, no merge)
     if (stream) {
         k.stream.n_wgs = stream_wgs;
         k.stream.len = static_cast<uint32_t>(total_tiles / stream_wgs);
