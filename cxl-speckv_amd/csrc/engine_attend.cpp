@@ -134,6 +134,9 @@ int Engine::attend_fp8(uint64_t handle, uint32_t layer, uint32_t n_layers, const
     // context, 4 at 8k, 8 at 32k), long multi-layer launches are bounded by `want` above
     const uint32_t min_tiles = std::min(8u, std::max(2u, n_tiles / 64u));
     want = std::min(want, std::max(1u, n_tiles / min_tiles));
+    // ... and never more than ONE round of workgroups (round 6, profiles/r06_layers_by_context.txt: one layer x 128k took 512 splits = 1024
+    // workgroups 0.55 of the roofline, 128 splits = 256 workgroups 0.68; 4 layers x 32k 0.65 -> 0.74, 8 x 32k 0.59 -> 0.68, 12 x 16k 0.56 -> 0.65)
+    if (lin_base || dma_table) want = std::min(want, std::max(1u, cus() / std::max(1u, rows / 4u)));
     // Launches of many rows (several layers of one sequence): every workgroup resident at once and the CUs evenly loaded counts for
     // more than the split length -- 80 layers = 160 workgroup rows: 3 splits = 480 workgroups (15 of 16 CUs hold two) 0.777 of the
     // roofline at 32k and 0.738 at 8k, 5 splits = 800 (some CUs four, some three) 0.67, 8 = 1280 (a second round) 0.765, one split
