@@ -1733,6 +1733,21 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     for sch in (4, 3, 5):                                                 # short contexts: 256 x 1k and 256 x 2k, batch and planned forms
         for T_short in (1024, 2048):
             ex.update(batch_attention_extra(torch, kv, T=T_short, scheme=sch))
+    # batches that do not fill whole rounds of the CUs (round 6: the pieces per sequence by ring_rule.hpp balanced_tiles_per_piece; the merge of few rows
+    # by a workgroup per row) and the 70B-shaped sequence at 4k context (the fixed grid below 28k, the stream form above)
+    off = {}
+    try:
+        for sch, nm in ((4, "fp8"), (3, "int4_g32"), (5, "mxfp4")):
+            for n_off in (32, 160, 300):
+                r = list(batch_attention_extra(torch, kv, n_seq=n_off, scheme=sch).values())[0]
+                off[f"{nm}_{n_off}x8k"] = {k: r.get(k) for k in ("ms_per_layer", "frac_hbm", "planned_ms_per_layer", "planned_frac_hbm", "error") if k in r}
+            r = (fp8_scores_extra(torch, kv, 4096, 80) if sch == 4 else int4_attention_extra(torch, kv, 4096, 80, scheme=sch))
+            r = next(v for k, v in r.items() if "fused_attention" in k)
+            off[f"{nm}_one_sequence_80_layers_4k"] = {k: r.get(k) for k in ("ms_all_layers", "frac_hbm", "error") if k in r}
+    except Exception as e:                                               # noqa: BLE001
+        off["error"] = repr(e)
+    ex["attention_off_round_sizes"] = dict(off, note="256 x 8k / 32k x 80 layers are the figures above; here: 32, 160 and 300 sequences x 8k (one layer per call, batch and planned "
+                                                      "entries) and one sequence x 80 layers x 4k; fraction of 8 TB/s in record bytes")
     ex.update(connector_append_extra(torch, kv))
     ex.update(connector_decode_extra(torch, kv))
     ex.update(connector_decode_extra(torch, kv, scheme="mxfp4"))      # the same decode step over an MXFP4 pool (half the record bytes of FP8)
