@@ -423,6 +423,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
     const uint32_t split = blockIdx.x;
     const uint32_t hq = a.heads / 4u;
     uint32_t layer = blockIdx.y / hq;                                    // batch form: the sequence index
+    if (a.seqs && a.order) layer = a.order[layer];                       // (workgroup-uniform)
     const uint32_t head = (blockIdx.y % hq) * 4u + wave;
     const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;  // query / output row block
     uint64_t part = row * a.n_splits + split;
@@ -866,6 +867,7 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
     const uint32_t split = blockIdx.x;
     const uint32_t hq = a.heads / kFdHeads;
     uint32_t layer = blockIdx.y / hq;                                    // batch form: the sequence index
+    if (a.seqs && a.order) layer = a.order[layer];                       // (workgroup-uniform)
     const uint32_t head = (blockIdx.y % hq) * kFdHeads + wave;
     const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;  // query / output row block
     uint64_t part = row * a.n_splits + split;

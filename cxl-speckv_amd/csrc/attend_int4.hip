@@ -344,6 +344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
     const uint32_t split = a.rows_first ? blockIdx.y : blockIdx.x, by = a.rows_first ? blockIdx.x : blockIdx.y;
     const uint32_t hq = a.heads / 4u;
     uint32_t layer = by / hq;                                            // batch form: the sequence index
+    if (a.seqs && a.order) layer = a.order[layer];                       // (workgroup-uniform)
     const uint32_t head0 = (by % hq) * 4u;                               // first head of the workgroup
     const uint32_t head = head0 + wave;
     const uint64_t row = static_cast<uint64_t>(layer) * a.heads + head;
@@ -711,6 +712,7 @@ __global__ __launch_bounds__(512 * HALVES) __attribute__((amdgpu_waves_per_eu(SP
     } else {
         const uint32_t split = a.rows_first ? blockIdx.y : blockIdx.x;
         cl = a.rows_first ? blockIdx.x : blockIdx.y;                      // batch form: the sequence index
+        if (a.seqs && a.order) cl = a.order[cl];                          // (workgroup-uniform)
         part = (static_cast<uint64_t>(cl) * 8u + head) * a.n_splits + split;
         if (a.seqs) {                                                    // workgroup-uniform: per-sequence geometry
             const AttendSeq sq = a.seqs[cl];

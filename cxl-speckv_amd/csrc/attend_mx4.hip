@@ -190,6 +190,10 @@ __global__ __launch_bounds__(64 * kWavesPerWg * HALVES) __attribute__((amdgpu_wa
     constexpr bool STREAM = FORM == 3, CLS = FORM == 1;
     const uint32_t split = blockIdx.x;
     uint32_t layer = blockIdx.y;                                         // batch form: the sequence index
+    if (a.seqs && a.order) {                                             // (workgroup-uniform; several layers in one launch: y = layer x sequence)
+        const uint32_t li = a.batch_n_seq ? layer / a.batch_n_seq : 0u;
+        layer = li * a.batch_n_seq + a.order[layer - li * a.batch_n_seq];
+    }
     // stream form: this workgroup's piece = `count` tiles from tile `ct` of layer `layer` on; its partial of that layer is the
     // layer's slot-th (slots count from the piece that holds the layer's first tile)
     uint32_t ct = 0u, count = 0u, slot = 0u;

@@ -491,7 +491,8 @@ speckv_status_t speckv_ext_attend_batch_plan(uint32_t n_seq, const speckv_handle
     });
 }
 
-size_t speckv_ext_attend_plan_bytes(uint32_t n_seq) { return static_cast<size_t>(n_seq) * sizeof(speckv::AttendSeq); }
+// one descriptor per sequence, then the dispatch order (one index per sequence: Engine::attend_batch_plan)
+size_t speckv_ext_attend_plan_bytes(uint32_t n_seq) { return static_cast<size_t>(n_seq) * (sizeof(speckv::AttendSeq) + sizeof(uint32_t)); }
 
 speckv_status_t speckv_ext_attend_fp8_planned(const void* d_plan, uint32_t n_seq, uint32_t layer, const void* d_q_f16, uint32_t g,
                                               uint32_t max_pos_end, float sm_scale, float* d_out, float* d_lse, void* stream)

@@ -278,6 +278,28 @@ static uint32_t mx4_batch_tps(uint32_t n_seq, uint32_t tiles_max, uint32_t cus)
     return std::max(8u, (tiles_max + splits - 1u) / splits);
 }
 
+// Sequences of different lengths (round 6, profiles/r06_ragged_batches.txt): the order their workgroups are dispatched in decides how evenly the
+// CUs are loaded -- a CU receives workgroups i, i + CUs, i + 2 CUs, ... of the launch.  Kernels that keep several workgroups resident per
+// CU (FP8: 4; INT4 on one-run workgroups: 2) get the sequences sorted by length and laid out as a serpentine over rounds of `round`
+// sequences (one round = the sequences whose workgroups cover the CUs once): a CU then holds a long one with a short one -- 256 sequences
+// of 1k .. 16k, FP8: 0.54 of the HBM roofline as given, 0.63 sorted, 0.78 as a serpentine; 512: 0.535 -> 0.79, INT4 0.48 -> 0.67.
+// round = 0 (MXFP4, one workgroup per CU): longest first, the short ones fill the tail (512 sequences 0.62 -> 0.84).
+// Returns false (order as given) when the lengths do not differ by more than a tile in eight.
+static bool attend_dispatch_order(const AttendSeq* seqs, uint32_t n_seq, uint32_t round, uint32_t* order)
+{
+    std::vector<uint32_t> len(n_seq);
+    for (uint32_t i = 0; i < n_seq; ++i) len[i] = seqs[i].n_pages;
+    return dispatch_order_by_length(len.data(), n_seq, round, order);           // ring_rule.hpp
+}
+// sequences per round of the CUs for the kernel a batch of this format runs on (0: longest first)
+static uint32_t attend_order_round(bool fp8, bool mx4, uint32_t heads, uint32_t n_seq, uint32_t cus)
+{
+    if (mx4) return 0u;
+    if (fp8) return std::max(1u, cus / std::max(1u, heads / 4u));
+    if (heads == 8u) return cus;                               // whole-record kernel (one column per sequence)
+    return std::max(1u, cus / std::max(1u, heads / 4u));
+}
+
 int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, uint32_t layer, const void* d_q_f16, uint32_t g,
                          const uint32_t* pos_end, float sm_scale, float* d_out, float* d_lse, hipStream_t s)
 {
@@ -383,7 +405,7 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     // it starts (one round trip, all workgroups at once).  Copying the slot to the device first was a copy-engine operation in
     // front of every launch, 7-8 us that the kernels waited for: 256 x 1k MXFP4 59.5 -> 53 us per call, FP8 96 -> 88
     // (profiles/r05_mx4.txt; the planned form never had it).  A slot is reused once the launches that read it have finished.
-    const size_t seq_bytes = seqs.size() * sizeof(AttendSeq);
+    const size_t desc_bytes = seqs.size() * sizeof(AttendSeq), seq_bytes = desc_bytes + seqs.size() * sizeof(uint32_t);      // descriptors, then the dispatch order
     if (seq_ring_.slot_bytes < seq_bytes) {
         if (seq_ring_.base) { HIP_TRY(hipDeviceSynchronize()); (void)hipHostFree(seq_ring_.base); seq_ring_.base = nullptr; }
         seq_ring_.slot_bytes = std::max<size_t>(seq_bytes * 2, 16384);
@@ -395,7 +417,9 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     seq_ring_.next = (slot + 1) % kSeqRingSlots;
     HIP_TRY(hipEventSynchronize(seq_ring_.ev[slot]));          // whatever last used this slot (a launch that read it in place, a plan's copy) has finished
     void* staged = static_cast<uint8_t*>(seq_ring_.base) + static_cast<size_t>(slot) * seq_ring_.slot_bytes;
-    memcpy(staged, seqs.data(), seq_bytes);
+    memcpy(staged, seqs.data(), desc_bytes);
+    const bool ordered = tuning().attend_order_as_given == 0 &&
+                         attend_dispatch_order(seqs.data(), n_seq, attend_order_round(fp8, mx4, heads, n_seq, cus()), reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(staged) + desc_bytes));
     AttendSeq* d_seqs = nullptr;
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_seqs), staged, 0));
     // sequences without positions have no splits: their rows are written as zeros by the merge (L == 0)
@@ -420,6 +444,7 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
         k.zero_page = d_zero_page_;
     }
     k.seqs = d_seqs;
+    if (ordered) k.order = reinterpret_cast<const uint32_t*>(d_seqs + n_seq);
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
     bool one_split_each = true;                           // then the attention kernel writes the final rows itself
@@ -547,7 +572,14 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
     }
     bool any_empty = false;
     for (uint32_t i = 0; i < n_seq; ++i) any_empty = any_empty || pos_end[i] == 0u;
-    plans_[d_plan] = PlanInfo{n_seq, scheme, min_layers, max_pos_end, any_striped, any_table, stripe_n_max, any_empty};
+    // the dispatch order behind the descriptors, where the caller's buffer has the room (speckv_ext_attend_plan_bytes says so since round 6)
+    std::vector<uint32_t> order(n_seq);
+    // (always written when there is room -- the order as given for sequences of one length: a graph captured over this plan keeps reading it as the lengths change)
+    const bool ordered = plan_bytes >= n_seq * (sizeof(AttendSeq) + sizeof(uint32_t));
+    if (ordered && (tuning().attend_order_as_given != 0 ||
+                    !attend_dispatch_order(seqs.data(), n_seq, attend_order_round(scheme == SPECKV_COMP_FP8_E4M3, scheme == SPECKV_COMP_MXFP4, heads, n_seq, cus()), order.data())))
+        for (uint32_t i = 0; i < n_seq; ++i) order[i] = i;
+    plans_[d_plan] = PlanInfo{n_seq, scheme, min_layers, max_pos_end, any_striped, any_table, stripe_n_max, any_empty, ordered};
     uint64_t parts = 0;
     for (uint32_t i = 0; i < n_seq; ++i) {
         const uint32_t n_tiles = seqs[i].n_splits;
@@ -558,7 +590,7 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
         parts += static_cast<uint64_t>(heads) * seqs[i].n_splits;
     }
     DeviceScope device_scope(device_);
-    const size_t seq_bytes = seqs.size() * sizeof(AttendSeq);
+    const size_t desc_bytes = seqs.size() * sizeof(AttendSeq), seq_bytes = desc_bytes + (ordered ? seqs.size() * sizeof(uint32_t) : 0u);
     if (seq_ring_.slot_bytes < seq_bytes) {
         if (seq_ring_.base) { HIP_TRY(hipDeviceSynchronize()); (void)hipHostFree(seq_ring_.base); seq_ring_.base = nullptr; }
         seq_ring_.slot_bytes = std::max<size_t>(seq_bytes * 2, 16384);
@@ -570,7 +602,8 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
     seq_ring_.next = (slot + 1) % kSeqRingSlots;
     HIP_TRY(hipEventSynchronize(seq_ring_.ev[slot]));
     void* staged = static_cast<uint8_t*>(seq_ring_.base) + static_cast<size_t>(slot) * seq_ring_.slot_bytes;
-    memcpy(staged, seqs.data(), seq_bytes);
+    memcpy(staged, seqs.data(), desc_bytes);
+    if (ordered) memcpy(static_cast<uint8_t*>(staged) + desc_bytes, order.data(), n_seq * sizeof(uint32_t));
     HIP_TRY(hipMemcpyAsync(d_plan, staged, seq_bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(seq_ring_.ev[slot], s));
     return SPECKV_OK;
@@ -646,6 +679,7 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
     }
     else { k.lin_base = reinterpret_cast<const uint8_t*>(1); if (!fp8 && !mx4) k.wg8 = int4_wg8_form(n_seq, cus()); }     // non-null: linear form (the real base comes from the descriptor)
     k.seqs = static_cast<const AttendSeq*>(d_plan);
+    if (plan->second.ordered) k.order = reinterpret_cast<const uint32_t*>(static_cast<const AttendSeq*>(d_plan) + n_seq);
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
     k.batch_layer = layer;

@@ -291,6 +291,8 @@ struct AttendArgs {
     const float* scale_tab;           // linear form: page scales of the whole allocation in tile order (attend.hip)
     const uint16_t* q16;              // linear form: the fp16 query rows [layers][heads][g][128] (quantised in the kernel)
     const struct AttendSeq* seqs;     // batch form: one descriptor per sequence (blockIdx.y / (heads/4)), else null
+    const uint32_t* order;            // batch form, sequences of different lengths (round 6): order[i] = the sequence whose workgroups are dispatched i-th (the
+                                      // engine orders them by length so that the CUs' shares even out: attend_dispatch_order), or null = as given
     float* part_acc;                  // [layers][heads][splits][16][128]
     float* part_ml;                   // [layers][heads][splits][2][16]
     // every row has exactly ONE split (set by the engine then): the attention kernel normalises and writes the final

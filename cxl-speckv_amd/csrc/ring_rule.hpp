@@ -7,6 +7,7 @@
 // the lap is skipped.  (Reference: the FIFO prefetch buffer of cxl_memory_manager.cpp:196-221 / prefetch_core.v:210-216,
 // which moves nothing; here slots hold decompressed pages.)
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #ifndef __host__
 #define __host__
@@ -128,7 +129,7 @@ inline uint32_t fp8_batch_tiles_per_split(const uint32_t* tiles, uint32_t n_seq,
     const uint64_t columns = static_cast<uint64_t>(n_seq) * columns_per_seq;
     if (columns > n_cus && n_max >= 128u)                        // more than one round of whole sequences, 4k context and up (at 2k pieces gave nothing:
                                                                  // 300 x 2k whole 0.66, two pieces 0.62): the pieces that balance the last round (above)
-        return balanced_tiles_per_piece(tiles, n_seq, uniform_tiles, columns_per_seq, n_cus, kPiecesFp8);
+        return balanced_tiles_per_piece(nullptr, n_seq, n_max, columns_per_seq, n_cus, kPiecesFp8);      // (priced on the longest member: equal pieces; the engine's dispatch order evens out the rest)
     uint64_t best_cost = UINT64_MAX;
     uint32_t best = n_max;
     for (uint32_t r = 0; r <= 4u; ++r) {
@@ -147,6 +148,24 @@ inline uint32_t fp8_batch_tiles_per_split(const uint32_t* tiles, uint32_t n_seq,
         if (cost < best_cost) { best_cost = cost; best = tps; }
     }
     return best;
+}
+
+// The order in which a batch's sequences are dispatched (Engine::attend_batch / attend_batch_plan; AttendArgs::order): by length, longest
+// first, and -- round != 0 -- as a serpentine over rounds of `round` sequences (every second round reversed), so that the workgroups a
+// CU receives from consecutive rounds are a long one and a short one.  False (nothing written) when the lengths differ by no more
+// than an eighth of the longest: the order as given.
+inline bool dispatch_order_by_length(const uint32_t* len, uint32_t n, uint32_t round, uint32_t* order)
+{
+    uint32_t lo = UINT32_MAX, hi = 0;
+    for (uint32_t i = 0; i < n; ++i) { lo = len[i] < lo ? len[i] : lo; hi = len[i] > hi ? len[i] : hi; }
+    if (n < 2u || hi - lo <= hi / 8u) return false;
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order, order + n, [len](uint32_t x, uint32_t y) { return len[x] > len[y]; });
+    if (round)
+        for (uint32_t k = round; k < n; k += 2u * round) {
+            std::reverse(order + k, order + (k + round < n ? k + round : n));
+        }
+    return true;
 }
 
 } // namespace speckv

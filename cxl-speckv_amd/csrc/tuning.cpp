@@ -21,6 +21,7 @@ const Key kKeys[] = {
     {"attend_fp8_table_regs", "SPECKV_ATTEND_FP8_TABLE_REGS", &Tuning::attend_fp8_table_regs},
     {"attend_stream", "SPECKV_ATTEND_STREAM", &Tuning::attend_stream},
     {"attend_mx4_one_half", "SPECKV_ATTEND_MX4_ONE_HALF", &Tuning::attend_mx4_one_half},
+    {"attend_order_as_given", "SPECKV_ATTEND_ORDER_AS_GIVEN", &Tuning::attend_order_as_given},
     {"tc_multipass", "SPECKV_TC_MULTIPASS", &Tuning::tc_multipass},
     {"tc_scan", "SPECKV_TC_SCAN", &Tuning::tc_scan},
     {"tc_no_pre", "SPECKV_TC_NO_PRE", &Tuning::tc_no_pre},

@@ -14,6 +14,7 @@ struct Tuning {
     int32_t attend_tiles_per_split = 0;     // SPECKV_ATTEND_TILES_PER_SPLIT   batch calls: tiles (32 positions) per split
     int32_t attend_stream = 0;              // SPECKV_ATTEND_STREAM            MXFP4, several layers of one sequence: N > 0 the stream form with N workgroups, -1 never, 0 by size
     int32_t attend_mx4_one_half = 0;        // SPECKV_ATTEND_MX4_ONE_HALF      MXFP4 batches: 4-wave workgroups also where the two-halves form applies (A/B, tests)
+    int32_t attend_order_as_given = 0;      // SPECKV_ATTEND_ORDER_AS_GIVEN    batches of different lengths: dispatch the sequences in the caller's order (A/B, tests)
     int32_t attend_general = 0;             // SPECKV_ATTEND_GENERAL           1: page-table forms even where an arithmetic form applies (tests)
     int32_t attend_fp8_table_regs = 0;      // SPECKV_ATTEND_FP8_TABLE_REGS    FP8 over striped / moved placements: the register-staged kernels of rounds 2-5 instead of the DMA pipeline (tests, A/B)
     int32_t attend_fp8_dma = 0;             // SPECKV_ATTEND_FP8_DMA           FP8, one sequence: 1 = the LDS-DMA kernel whatever the split count, -1 = the register-staged one (tests, A/B)

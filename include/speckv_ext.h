@@ -387,7 +387,10 @@ speckv_status_t speckv_ext_attend_mx4_planned(const void* d_plan, uint32_t n_seq
  * splits them in two:
  *   speckv_ext_attend_batch_plan   once per decode step, OUTSIDE any capture: looks the n_seq allocations up and writes
  *       one descriptor per sequence -- valid for every layer -- into the caller's device buffer d_plan
- *       (speckv_ext_attend_plan_bytes(n_seq) bytes; the copy is ordered on `stream`).
+ *       (speckv_ext_attend_plan_bytes(n_seq) bytes; the copy is ordered on `stream`), and behind them the order in which
+ *       the launches take the sequences: batches whose members differ in length are dispatched by length (a long member
+ *       beside a short one on every CU) -- rows of q / out / lse stay in the caller's order.  A buffer of n_seq x 64 bytes
+ *       (what the size was before) still works, in the caller's order.
  *   speckv_ext_attend_{fp8,int4}_planned   one layer of the batch: kernel launches only (no look-ups, no staging,
  *       nothing allocated once the scratch is warm), so the per-layer calls of a step can be captured once and replayed
  *       for as long as every pos_end stays <= max_pos_end: grid, split length and scratch are functions of

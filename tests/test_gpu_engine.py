@@ -701,6 +701,69 @@ def test_fused_attention_batch_larger_than_the_machine(eng, scheme, T):
         lib.free(h)
 
 
+@pytest.mark.parametrize("scheme", [4, 3, 5])
+def test_batches_of_different_lengths_are_dispatched_by_length(eng, scheme):
+    """AttendArgs::order (round 6): a batch whose members differ in length is dispatched longest first / as a serpentine over rounds of the
+    CUs (ring_rule.hpp dispatch_order_by_length) -- only the ORDER of the workgroups changes: the rows must equal, bit for bit, those of
+    the same call dispatched in the caller's order (attend_order_as_given), for the batch entry and for the planned one, and lie in the
+    caller's order in q / out / lse (checked against the per-sequence entry point)."""
+    torch = torch_mod()
+    lib = eng.lib
+    lib.set_compression_scheme(scheme)
+    batch_fn, single_fn = {4: (lib.attend_fp8_batch, lib.attend_fp8), 3: (lib.attend_int4_batch, lib.attend_int4), 5: (lib.attend_mx4_batch, lib.attend_mx4)}[scheme]
+    T, L, H, D, G = 1024, 2, 8, 128, 8
+    rng = np.random.default_rng(131)
+    n_seq = 41
+    lens = [int(v) * 2 for v in rng.integers(1, T // 2 + 1, n_seq)]
+    lens[0], lens[5], lens[40] = 2, T, 0
+    n_pages = T * L * H * D * 2 * 2 // PAGE
+    xs = [(rng.standard_normal((n_pages, N)) * rng.uniform(0.2, 2.0, (n_pages, 1))).astype(np.float16) for _ in range(3)]
+    handles = []
+    for i in range(n_seq):
+        h = lib.alloc(T * L * H * D * 2 * 2)
+        lib.set_layout(h, T, L, H, D, 2)
+        lib.write(h, 0, xs[i % 3].ctypes.data, xs[i % 3].nbytes, False)
+        handles.append(h)
+    q = torch.from_numpy(rng.standard_normal((n_seq, H, G, D)).astype(np.float16)).cuda()
+    sm = 1.0 / np.sqrt(D)
+    s = torch.cuda.Stream()
+    plan_bytes = lib.attend_plan_bytes(n_seq)
+    d_plan = torch.empty(plan_bytes, dtype=torch.uint8, device="cuda")
+    res = {}
+    try:
+        for given in (0, 1):
+            set_tuning("attend_order_as_given", given)
+            for entry in ("batch", "planned"):
+                out = torch.full((n_seq, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
+                lse = torch.full((n_seq, H, G), float("nan"), dtype=torch.float32, device="cuda")
+                if entry == "batch":
+                    batch_fn(handles, 1, q.data_ptr(), G, lens, sm, out.data_ptr(), lse.data_ptr(), s.cuda_stream)
+                else:
+                    lib.attend_batch_plan(handles, lens, T, d_plan.data_ptr(), plan_bytes, s.cuda_stream)
+                    lib.attend_planned(scheme, d_plan.data_ptr(), n_seq, 1, q.data_ptr(), G, T, sm, out.data_ptr(), lse.data_ptr(), s.cuda_stream)
+                torch.cuda.synchronize()
+                res[(given, entry)] = (out.cpu().numpy(), lse.cpu().numpy())
+    finally:
+        set_tuning("attend_order_as_given", 0)
+    for entry in ("batch", "planned"):
+        assert np.array_equal(res[(0, entry)][0], res[(1, entry)][0], equal_nan=True), entry
+        assert np.array_equal(res[(0, entry)][1], res[(1, entry)][1], equal_nan=True), entry
+    one = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
+    one_lse = torch.empty((H, G), dtype=torch.float32, device="cuda")
+    got, got_lse = res[(0, "planned")]
+    for i in (0, 1, 5, 17, 39, 40):
+        if lens[i] == 0:
+            assert float(np.abs(got[i]).max()) == 0.0
+            continue
+        single_fn(handles[i], 1, 1, q[i].data_ptr(), G, 0, lens[i], sm, one.data_ptr(), one_lse.data_ptr())
+        torch.cuda.synchronize()
+        ref = one.cpu().numpy()
+        assert float(np.abs(got[i] - ref).max()) <= 1e-3 * (float(np.abs(ref).max()) + 1e-6), (i, lens[i])
+        assert float(np.abs(got_lse[i] - one_lse.cpu().numpy()).max()) <= 1e-4, (i, lens[i])
+    for h in handles:
+        lib.free(h)
+
+
 def test_int4_fused_attention(eng, oracle):
     """The 4:1 format of BASELINE config 5: softmax(q.K^T).V straight from INT4_G32 records
     (speckv_ext_attend_int4) against the oracle's double-precision attention over the pages as

@@ -427,7 +427,7 @@ def test_planned_batch_attention_replays_under_a_graph(scheme):
         out = torch.zeros((L, n_seq, H, G, D), dtype=torch.float32, device="cuda")
         lse = torch.zeros((L, n_seq, H, G), dtype=torch.float32, device="cuda")
         plan_bytes = lib.attend_plan_bytes(n_seq)
-        assert plan_bytes == n_seq * 64
+        assert plan_bytes == n_seq * (64 + 4)              # one descriptor and one dispatch-order index per sequence
         plan = torch.zeros(plan_bytes, dtype=torch.uint8, device="cuda")
         s = torch.cuda.Stream()
         for tps in (None, "8", "64"):                 # the rule's geometry, one with real splits, one without any (no merge launch)

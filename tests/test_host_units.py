@@ -436,6 +436,34 @@ def test_balanced_pieces_rule_for_batches_over_the_cu_count(rules):
     assert f(None, 0, 100, 1, 256, MX4) == 100 and f(None, 10, 0, 1, 256, MX4) == 8     # nothing to do: any legal length
 
 
+def test_dispatch_order_of_ragged_batches(rules):
+    """ring_rule.hpp::dispatch_order_by_length (AttendArgs::order, round 6): a permutation; longest first; with rounds, every second round
+    reversed, so that position p of round 2k and position p of round 2k + 1 hold a long and a short sequence (their sums even out);
+    sequences of (nearly) one length keep the caller's order."""
+    f = rules.rules_dispatch_order
+    f.restype = C.c_int
+    f.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    rng = np.random.default_rng(31)
+    for n, rnd in ((256, 128), (512, 128), (512, 256), (300, 0), (7, 2), (2, 1), (1000, 128)):
+        ln = rng.integers(32, 8192, n).astype(np.uint32)
+        order = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+        assert f(ln.ctypes.data_as(C.POINTER(C.c_uint32)), n, rnd, order.ctypes.data_as(C.POINTER(C.c_uint32))) == 1
+        assert sorted(order.tolist()) == list(range(n))
+        got = ln[order].astype(np.int64)
+        if rnd == 0:
+            assert np.all(np.diff(got) <= 0)                        # longest first
+        else:
+            for k in range(0, n, rnd):
+                d = np.diff(got[k:k + rnd])
+                assert np.all(d <= 0) if (k // rnd) % 2 == 0 else np.all(d >= 0)
+            if n >= 2 * rnd:                                        # a CU's pair from rounds 0 and 1: sums within the spread of neighbouring ranks
+                sums = got[:rnd] + got[rnd:2 * rnd]
+                assert sums.max() - sums.min() <= 0.35 * sums.mean(), (n, rnd, sums.min(), sums.max())
+    same = np.full(64, 4096, dtype=np.uint32); same[3] = 4000
+    order = np.zeros(64, dtype=np.uint32)
+    assert f(same.ctypes.data_as(C.POINTER(C.c_uint32)), 64, 16, order.ctypes.data_as(C.POINTER(C.c_uint32))) == 0      # one length: as given
+
+
 def test_int4_batch_unequal_split_rule(rules):
     """The INT4 batch attention's two-pieces rule (ring_rule.hpp::int4_unequal_fraction / unequal_pieces, measured in
     profiles/r03_int4_batch_split_sweep.txt): only batches that fill between half and the whole machine with workgroup columns,
