@@ -382,7 +382,16 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     uint32_t tiles_max = 0;
     for (uint32_t i = 0; i < n_seq; ++i) tiles_max = std::max(tiles_max, seqs[i].n_splits);
     const bool wg8 = !fp8 && !mx4 && (!any_striped || int4_cls) && !any_table && heads == 8u;
-    const uint32_t tps = mx4 ? mx4_batch_tps(n_seq, tiles_max, cus()) : wg8 ? int4_wg8_batch_tps(n_seq, tiles_max, cus()) : batch_tiles_per_split(fp8, n_seq, heads, total_tiles, seqs.data(), 0);
+    uint32_t tps = mx4 ? mx4_batch_tps(n_seq, tiles_max, cus()) : wg8 ? int4_wg8_batch_tps(n_seq, tiles_max, cus()) : batch_tiles_per_split(fp8, n_seq, heads, total_tiles, seqs.data(), 0);
+    // members of different lengths on the one-workgroup-per-CU kernels: the piece length whose workgroups just fill whole rounds (ring_rule.hpp
+    // ragged_tiles_per_piece; this entry knows the lengths -- a plan's geometry is a function of its bound alone).  256 x 1k .. 16k: INT4 0.48 -> 0.61, MXFP4 0.65 -> 0.72
+    // (from a machine's worth of members up: below that the rule for equal lengths already cuts pieces and did better -- 128 members: INT4 0.47 against 0.44, MXFP4 0.62 / 0.53)
+    if ((mx4 || wg8) && n_seq >= cus() && tuning().attend_tiles_per_split <= 0 && tuning().attend_order_as_given == 0) {
+        std::vector<uint32_t> tl(n_seq);
+        for (uint32_t i = 0; i < n_seq; ++i) tl[i] = seqs[i].n_splits;
+        const uint32_t r = ragged_tiles_per_piece(tl.data(), n_seq, cus(), mx4 ? kPiecesMx4 : n_seq > cus() ? kPiecesInt4Wg8 : kPiecesInt4Halves);
+        if (r) tps = r;
+    }
     const UnequalSplit unequal = (fp8 || mx4 || wg8) ? UnequalSplit{false, 1.0} : int4_unequal_split(n_seq, heads / 4u, tiles_max);
     uint32_t max_splits = 0;
     uint64_t parts = 0;

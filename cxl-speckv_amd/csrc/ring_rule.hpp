@@ -150,6 +150,45 @@ inline uint32_t fp8_batch_tiles_per_split(const uint32_t* tiles, uint32_t n_seq,
     return best;
 }
 
+// Sequences of DIFFERENT lengths on the kernels that run one workgroup per CU (MXFP4, INT4 whole-record): whole sequences make the longest
+// member the launch (256 x 1k .. 16k: INT4 0.48, MXFP4 0.66 of the HBM roofline where 256 x 8k run at 0.69 / 0.85).  With the sequences
+// dispatched longest first (dispatch_order_by_length) pieces pay where their number just fills whole rounds of the CUs: the same batch by
+// piece length, INT4 / MXFP4 -- 384 tiles 0.49 / 0.64, 256 (392 workgroups) 0.55 / 0.65, 192 (495 workgroups: two rounds) 0.62 / 0.73,
+// 128 (670) 0.51 / 0.62 (profiles/r06_ragged_batches.txt).  So: for 1, 2, 3 rounds the shortest piece length whose workgroup count stays
+// within the rounds, priced as  max(0.75 x longest piece, (F + last(r)) x mean piece x pieces(s))  with the kernel's PieceModel, against
+// whole sequences priced the same way; 0 = leave it to the rule for equal lengths (lengths within a quarter of their mean, or nothing gained).
+inline uint32_t ragged_tiles_per_piece(const uint32_t* tiles, uint32_t n_seq, uint32_t n_cus, const PieceModel& m)
+{
+    uint64_t total = 0;
+    uint32_t n_max = 0;
+    for (uint32_t i = 0; i < n_seq; ++i) { total += tiles[i]; n_max = tiles[i] > n_max ? tiles[i] : n_max; }
+    if (n_seq < 2u || n_cus == 0u || total == 0u || n_max < 2u * m.min_tiles) return 0u;
+    const double mean = static_cast<double>(total) / n_seq;
+    if (n_max <= 1.25 * mean) return 0u;
+    auto count = [&](uint32_t tps) { uint64_t w = 0; for (uint32_t i = 0; i < n_seq; ++i) w += (tiles[i] + tps - 1u) / tps; return w; };
+    auto cost = [&](uint32_t tps) {
+        const uint64_t w = count(tps);
+        const uint32_t sp = (n_max + tps - 1u) / tps;
+        const double full = static_cast<double>(w / n_cus), rest = static_cast<double>(w % n_cus) / n_cus;
+        const double last = rest > 0.0 ? (m.last_base + m.last_slope * rest > m.last_min ? m.last_base + m.last_slope * rest : m.last_min) : 0.0;
+        const double longest = static_cast<double>((n_max + sp - 1u) / sp);           // (a sequence's pieces are evened out: even_split)
+        const double rounds = (full + last) * (static_cast<double>(total) / static_cast<double>(w)) * (sp == 1u ? 1.0 : m.piece_base + m.piece_step * sp);
+        return rounds > 0.75 * longest ? rounds : 0.75 * longest;
+    };
+    const double whole = cost(n_max);
+    double best_cost = whole;
+    uint32_t best = 0u;
+    for (uint32_t k = 1u; k <= 3u; ++k) {
+        if (count(n_max) > static_cast<uint64_t>(k) * n_cus) continue;               // whole sequences already exceed k rounds
+        uint32_t lo = m.min_tiles, hi = n_max;                                        // smallest piece length with count <= k rounds (count falls as tps grows)
+        while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2u; if (count(mid) <= static_cast<uint64_t>(k) * n_cus) hi = mid; else lo = mid + 1u; }
+        if ((n_max + lo - 1u) / lo > 8u || lo >= n_max) continue;
+        const double c = cost(lo);
+        if (c < best_cost && c <= 0.95 * whole) { best_cost = c; best = lo; }
+    }
+    return best;
+}
+
 // The order in which a batch's sequences are dispatched (Engine::attend_batch / attend_batch_plan; AttendArgs::order): by length, longest
 // first, and -- round != 0 -- as a serpentine over rounds of `round` sequences (every second round reversed), so that the workgroups a
 // CU receives from consecutive rounds are a long one and a short one.  False (nothing written) when the lengths differ by no more

@@ -24,6 +24,11 @@ uint32_t rules_balanced_tiles_per_piece(const uint32_t* tiles, uint32_t n_seq, u
     const speckv::PieceModel& m = model == 0u ? speckv::kPiecesMx4 : model == 1u ? speckv::kPiecesFp8 : model == 2u ? speckv::kPiecesInt4Wg8 : speckv::kPiecesInt4Halves;
     return speckv::balanced_tiles_per_piece(tiles, n_seq, uniform_tiles, columns_per_seq, n_cus, m);
 }
+uint32_t rules_ragged_tiles_per_piece(const uint32_t* tiles, uint32_t n_seq, uint32_t n_cus, uint32_t model)
+{
+    const speckv::PieceModel& m = model == 0u ? speckv::kPiecesMx4 : model == 1u ? speckv::kPiecesFp8 : model == 2u ? speckv::kPiecesInt4Wg8 : speckv::kPiecesInt4Halves;
+    return speckv::ragged_tiles_per_piece(tiles, n_seq, n_cus, m);
+}
 int rules_dispatch_order(const uint32_t* len, uint32_t n, uint32_t round, uint32_t* order) { return speckv::dispatch_order_by_length(len, n, round, order) ? 1 : 0; }
 // {on, first piece, pieces} of a sequence of n_tiles in an INT4 batch of `columns` workgroup columns whose longest member has tiles_max
 void rules_int4_unequal(uint32_t columns, uint32_t tiles_max, uint32_t n_tiles, uint32_t* out3)

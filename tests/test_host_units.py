@@ -464,6 +464,31 @@ def test_dispatch_order_of_ragged_batches(rules):
     assert f(same.ctypes.data_as(C.POINTER(C.c_uint32)), 64, 16, order.ctypes.data_as(C.POINTER(C.c_uint32))) == 0      # one length: as given
 
 
+def test_ragged_piece_length_rule(rules):
+    """ring_rule.hpp::ragged_tiles_per_piece (batch entry, members of different lengths on the one-workgroup-per-CU kernels): nothing for members of
+    one length or for batches that already fill their rounds; otherwise a piece length between the model's minimum and the longest member, at most 8
+    pieces for the longest, and a workgroup count within one, two or three rounds of the CUs; the measured batch (256 x 1k .. 16k) gets ~190 tiles."""
+    f = rules.rules_ragged_tiles_per_piece
+    f.restype = C.c_uint32
+    f.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32]
+    ptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
+    rng = np.random.default_rng(7)
+    t = rng.integers(32, 513, 256).astype(np.uint32)
+    for model in (0, 3):
+        tps = f(ptr(t), 256, 256, model)
+        assert 170 <= tps <= 200, tps                           # measured best of the sweep: 192 (495 workgroups: two rounds)
+    same = np.full(256, 256, dtype=np.uint32)
+    assert f(ptr(same), 256, 256, 0) == 0
+    for _ in range(300):
+        n = int(rng.integers(2, 700)); cus = int(rng.choice([256, 304, 64])); model = int(rng.choice([0, 2, 3]))
+        t = rng.integers(0, int(rng.integers(2, 2000)), n).astype(np.uint32)
+        tps = f(ptr(t), n, cus, model)
+        if tps == 0: continue
+        w = int(np.sum(-(-t.astype(np.int64) // tps)))
+        assert {0: 24, 2: 32, 3: 32}[model] <= tps < int(t.max()) and -(-int(t.max()) // tps) <= 8
+        assert w <= 3 * cus and w > int(np.count_nonzero(t))    # within three rounds, and something was cut
+
+
 def test_int4_batch_unequal_split_rule(rules):
     """The INT4 batch attention's two-pieces rule (ring_rule.hpp::int4_unequal_fraction / unequal_pieces, measured in
     profiles/r03_int4_batch_split_sweep.txt): only batches that fill between half and the whole machine with workgroup columns,
