@@ -1093,6 +1093,58 @@ def int4_attention_extra(torch, kv, T, Lyr, scheme=3):
         lib.set_compression_scheme(2)
 
 
+def ragged_batch_extra(torch, kv, scheme=4, n_seq=256, lo=1024, hi=16384):
+    """One decode step's attention of ONE layer for a batch whose members DIFFER in length (uniform in lo .. hi positions, seeded): what a serving
+    batch looks like.  The engine dispatches such a batch by length (AttendArgs::order); `as_given` is the same call with the caller's order."""
+    import numpy as np
+    lib = kv.lib
+    name = {4: "fp8", 3: "int4_g32", 5: "mxfp4"}[scheme] + f"_{n_seq}_sequences_{lo}_to_{hi}"
+    rec = {4: 2048, 3: 1152, 5: 1088}[scheme]
+    handles = []
+    try:
+        lib.set_compression_scheme(scheme)
+        lens = [int(v) * 32 for v in np.random.default_rng(7).integers(lo // 32, hi // 32 + 1, n_seq)]
+        g = torch.Generator(device="cuda"); g.manual_seed(2004)
+        n_pages = hi * 8 * 128 * 2 * 2 // PAGE
+        x = torch.randn((n_pages, BLOCK_ELEMS), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+        for _ in range(n_seq):
+            h = lib.alloc(n_pages * PAGE)
+            lib.set_layout(h, hi, 1, 8, 128, 2)
+            lib.write(h, 0, x.data_ptr(), x.numel() * 2, True)
+            handles.append(h)
+        q = torch.randn((n_seq, 8, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+        o = torch.empty((n_seq, 8, 8, 128), dtype=torch.float32, device="cuda")
+        lse = torch.empty((n_seq, 8, 8), dtype=torch.float32, device="cuda")
+        s = torch.cuda.Stream()
+        plan_bytes = lib.attend_plan_bytes(n_seq)
+        d_plan = torch.empty(plan_bytes, dtype=torch.uint8, device="cuda")
+        out = {"sequences": n_seq, "positions": f"{lo}..{hi} (mean {sum(lens) // n_seq})"}
+        for key, given in (("planned", 0), ("planned_as_given", 1)):
+            set_tuning("attend_order_as_given", given)
+            lib.attend_batch_plan(handles, lens, hi, d_plan.data_ptr(), plan_bytes, s.cuda_stream)
+            def step():
+                lib.attend_planned(scheme, d_plan.data_ptr(), n_seq, 0, q.data_ptr(), 8, hi, 0.08838834764831845, o.data_ptr(), lse.data_ptr(), s.cuda_stream)
+            step(); torch.cuda.synchronize()
+            ramp(step, torch.cuda.synchronize, EXTRAS_RAMP_MS)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(s)
+            for _ in range(10):
+                step()
+            b.record(s); torch.cuda.synchronize()
+            ms = a.elapsed_time(b) / 10
+            out[key + "_ms_per_layer"] = round(ms, 4)
+            out[key + "_frac_hbm"] = round(sum(lens) * rec / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        return {name: out}
+    except Exception as e:                                               # noqa: BLE001
+        return {name: {"error": repr(e)}}
+    finally:
+        try: set_tuning("attend_order_as_given", 0)
+        except Exception: pass                                           # noqa: BLE001
+        for h in handles:
+            try: lib.free(h)
+            except Exception: pass                                       # noqa: BLE001
+
+
 def batch_attention_extra(torch, kv, n_seq=256, T=8192, scheme=4):
     """BASELINE configs[3] shape on one GPU: one decode step's attention of ONE layer for a batch of 256 sequences at
     8k context (8 kv heads x 128, 8 query rows per kv head), FP8 (scheme 4) or INT4 (3) records, one launch pair for the
@@ -1744,6 +1796,8 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
             r = (fp8_scores_extra(torch, kv, 4096, 80) if sch == 4 else int4_attention_extra(torch, kv, 4096, 80, scheme=sch))
             r = next(v for k, v in r.items() if "fused_attention" in k)
             off[f"{nm}_one_sequence_80_layers_4k"] = {k: r.get(k) for k in ("ms_all_layers", "frac_hbm", "error") if k in r}
+        off.update(ragged_batch_extra(torch, kv, scheme=4))            # members of different lengths: dispatched by length (round 6)
+        off.update(ragged_batch_extra(torch, kv, scheme=5, n_seq=512))
     except Exception as e:                                               # noqa: BLE001
         off["error"] = repr(e)
     ex["attention_off_round_sizes"] = dict(off, note="256 x 8k / 32k x 80 layers are the figures above; here: 32, 160 and 300 sequences x 8k (one layer per call, batch and planned "
