@@ -566,7 +566,7 @@ double speckv_ext_codec_model_throughput_gbps(uint32_t num_engines, double clock
  * tc_no_split_tiles, td_one_pass, td_expand_per_element, flush_no_small, flush_small_words, predict_batch_path, wgs_per_cu, tc_batch_one_wg (many-tensor launches: one workgroup per tensor),
  * rounds_consecutive, remote_engine (1 kernel, 2 copy engines), copy_min_run_kb, attend_stream (MXFP4, several layers of one
  * sequence: N > 0 the stream form with N workgroups, -1 never), attend_mx4_one_half (MXFP4 batches: 4-wave workgroups also where
- * the two-halves form applies), attend_fold_launch (speckv_ext_attend_planned_tail: the fold always as a launch of its own), attend_layers_loop
+ * the two-halves form applies), attend_order_as_given (batches of members of different lengths: the caller's dispatch order), attend_fold_launch (speckv_ext_attend_planned_tail: the fold always as a launch of its own), attend_layers_loop
  * (speckv_ext_attend_planned_layers: always per-layer launches), attend_fp8_table_regs / attend_fp8_striped_table / attend_int4_striped_wg
  * (striped and migrated pools: the earlier kernel forms, kept as A/B partners and test coverage).  0 restores the library's own rule.
  * SPECKV_ERR_INVAL for an unknown key.  Works without speckv_init.  (INTEGRATION.md lists what each one does.) */
