@@ -748,6 +748,19 @@ def test_batches_of_different_lengths_are_dispatched_by_length(eng, scheme):
     for entry in ("batch", "planned"):
         assert np.array_equal(res[(0, entry)][0], res[(1, entry)][0], equal_nan=True), entry
         assert np.array_equal(res[(0, entry)][1], res[(1, entry)][1], equal_nan=True), entry
+    # both layers of the planned batch in one call (MXFP4: one launch over layers x sequences, the order applied inside every layer): the per-layer rows
+    q2 = torch.from_numpy(rng.standard_normal((L, n_seq, H, G, D)).astype(np.float16)).cuda()
+    out2 = torch.full((L, n_seq, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
+    lse2 = torch.full((L, n_seq, H, G), float("nan"), dtype=torch.float32, device="cuda")
+    lib.attend_batch_plan(handles, lens, T, d_plan.data_ptr(), plan_bytes, s.cuda_stream)
+    lib.attend_planned_layers(scheme, d_plan.data_ptr(), n_seq, 0, L, q2.data_ptr(), G, T, sm, out2.data_ptr(), lse2.data_ptr(), s.cuda_stream)
+    torch.cuda.synchronize()
+    for l in range(L):
+        o1 = torch.full((n_seq, H, G, D), float("nan"), dtype=torch.float32, device="cuda")
+        l1 = torch.full((n_seq, H, G), float("nan"), dtype=torch.float32, device="cuda")
+        lib.attend_planned(scheme, d_plan.data_ptr(), n_seq, l, q2[l].data_ptr(), G, T, sm, o1.data_ptr(), l1.data_ptr(), s.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(out2[l], o1) and torch.equal(lse2[l], l1), l
     one = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
     one_lse = torch.empty((H, G), dtype=torch.float32, device="cuda")
     got, got_lse = res[(0, "planned")]
