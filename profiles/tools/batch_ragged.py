@@ -13,6 +13,8 @@ lib = kv.lib
 PAGE, BLOCK = 4096, 2048
 rng = np.random.default_rng(7)
 lens = [int(v) * 32 for v in rng.integers(lo // 32, hi // 32 + 1, n_seq)]
+if os.environ.get('DIST') == 'tail':                                 # heavy tail: one member in 16 at `hi`, the others uniform in lo .. hi / 8
+    lens = [hi if i % 16 == 5 else int(v) * 32 for i, v in enumerate(rng.integers(lo // 32, max(lo // 32 + 1, hi // 256 + 1), n_seq))]
 if os.environ.get('SORT') == '1': lens.sort(reverse=True)          # longest first: what an ordering by length inside the engine would give
 if os.environ.get('SORT') == '2': lens.sort()
 if os.environ.get('SORT', '').startswith('3'):                     # serpentine by rounds of R sequences: position p of round k holds rank p (k even) or the round's mirror (k odd)
