@@ -356,7 +356,8 @@ private:
     template <int N> struct PinnedRingT { void* base = nullptr; size_t slot_bytes = 0; hipEvent_t ev[N] = {}; int next = 0; };
     PinnedRingT<kSeqRingSlots> seq_ring_;
     PinnedRingT<4> grp_ring_;
-    struct PlanInfo { uint32_t n_seq; int scheme; uint32_t n_layers, max_pos_end; bool striped, table; uint32_t mx4_stripe_n_max; bool any_empty; bool ordered; };
+    struct PlanInfo { uint32_t n_seq; int scheme; uint32_t n_layers, max_pos_end; bool striped, table; uint32_t mx4_stripe_n_max; bool any_empty; bool ordered;
+                      uint32_t max_splits; bool rows_first; uint32_t rule_tps, rule_splits; };      // (the launch geometry the FIRST plan of this shape in this buffer chose: attend_batch_plan)
     std::unordered_map<const void*, PlanInfo> plans_;      // device plan buffer -> what attend_batch_plan last wrote there
     CompressGroup* d_groups_ = nullptr;    // device twin of grp_ring_ (4 slots): descriptors of a grouped compress launch
     uint8_t* d_zero_page_ = nullptr;     // stands in for never-written pages in the fused attention

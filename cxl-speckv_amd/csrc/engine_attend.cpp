@@ -383,14 +383,12 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     for (uint32_t i = 0; i < n_seq; ++i) tiles_max = std::max(tiles_max, seqs[i].n_splits);
     const bool wg8 = !fp8 && !mx4 && (!any_striped || int4_cls) && !any_table && heads == 8u;
     uint32_t tps = mx4 ? mx4_batch_tps(n_seq, tiles_max, cus()) : wg8 ? int4_wg8_batch_tps(n_seq, tiles_max, cus()) : batch_tiles_per_split(fp8, n_seq, heads, total_tiles, seqs.data(), 0);
-    // members of different lengths on the one-workgroup-per-CU kernels: the piece length whose workgroups just fill whole rounds (ring_rule.hpp
-    // ragged_tiles_per_piece; this entry knows the lengths -- a plan's geometry is a function of its bound alone).  256 x 1k .. 16k: INT4 0.48 -> 0.61, MXFP4 0.65 -> 0.72
-    // (from a machine's worth of members up: below that the rule for equal lengths already cuts pieces and did better -- 128 members: INT4 0.47 against 0.44, MXFP4 0.62 / 0.53)
-    if ((mx4 || wg8) && n_seq >= cus() && tuning().attend_tiles_per_split <= 0 && tuning().attend_order_as_given == 0) {
+    // members of different lengths: pieces on account of the lengths (ring_rule.hpp ragged_tiles_per_piece), dispatched by length and rows first (below)
+    if ((fp8 || mx4 || wg8) && tuning().attend_tiles_per_split <= 0 && tuning().attend_order_as_given == 0) {
         std::vector<uint32_t> tl(n_seq);
         for (uint32_t i = 0; i < n_seq; ++i) tl[i] = seqs[i].n_splits;
-        const uint32_t r = ragged_tiles_per_piece(tl.data(), n_seq, cus(), mx4 ? kPiecesMx4 : n_seq > cus() ? kPiecesInt4Wg8 : kPiecesInt4Halves);
-        if (r) tps = r;
+        const uint32_t r = ragged_tiles_per_piece(tl.data(), n_seq, cus(), fp8 ? heads / 4u : 1u);
+        if (r && r < tps) tps = r;
     }
     const UnequalSplit unequal = (fp8 || mx4 || wg8) ? UnequalSplit{false, 1.0} : int4_unequal_split(n_seq, heads / 4u, tiles_max);
     uint32_t max_splits = 0;
@@ -454,6 +452,7 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     }
     k.seqs = d_seqs;
     if (ordered) k.order = reinterpret_cast<const uint32_t*>(d_seqs + n_seq);
+    if (ordered && max_splits > 1u) k.rows_first = 1u;                 // (members of different lengths with pieces: see launch_attend_fp8_batch)
     k.part_acc = reinterpret_cast<float*>(buf);
     k.part_ml = reinterpret_cast<float*>(buf + acc_bytes);
     bool one_split_each = true;                           // then the attention kernel writes the final rows itself
@@ -569,9 +568,36 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
             seqs[i].n_splits = mx4_striped_tiles(seqs[i].n_pages, seqs[i].stripe_n);
             stripe_n_max = std::max(stripe_n_max, seqs[i].stripe_n);
         }
-    const PlanGeometry g = plan_geometry(scheme == SPECKV_COMP_FP8_E4M3, n_seq, heads, max_pos_end, cus(), scheme == SPECKV_COMP_MXFP4, stripe_n_max);
+    PlanGeometry g = plan_geometry(scheme == SPECKV_COMP_FP8_E4M3, n_seq, heads, max_pos_end, cus(), scheme == SPECKV_COMP_MXFP4, stripe_n_max);
     if (g.max_splits > 2048u) return SPECKV_ERR_INVAL;
-    if (plans_.size() >= 64 && !plans_.count(d_plan)) plans_.clear();        // (buffers of long-gone steps)
+    const uint32_t rule_tps = g.tps, rule_splits = g.max_splits;
+    // The launches of a plan may sit in a captured graph: their grid (pieces per member at most) and the presence of the merge launch must not change under
+    // it.  So the FIRST plan of a shape (members, format, bound) in a buffer fixes them -- from the lengths it sees: members of different lengths get room
+    // for pieces (ragged_tiles_per_piece) and the rows-first grid -- and every later plan of that shape in that buffer keeps them (a later batch that wants
+    // more pieces than there is room for gets longer ones).  A new shape (the caller captures anew for it anyway) decides anew.
+    uint32_t plan_tps = g.tps;
+    bool plan_rows_first = g.unequal.on, plan_sticky = false;
+    {
+        const auto old = plans_.find(d_plan);
+        const bool same_shape = old != plans_.end() && old->second.n_seq == n_seq && old->second.scheme == scheme && old->second.max_pos_end == max_pos_end &&
+                                old->second.rule_tps == g.tps && old->second.rule_splits == g.max_splits;      // (... and the same rule for equal lengths: the tuning keys move it)
+        uint32_t r = 0, n_max = 0;
+        if (!g.unequal.on && tuning().attend_order_as_given == 0 && tuning().attend_tiles_per_split <= 0 && (scheme != SPECKV_COMP_INT4_G32 || heads == 8u)) {
+            std::vector<uint32_t> tl(n_seq);
+            for (uint32_t i = 0; i < n_seq; ++i) { tl[i] = seqs[i].n_splits; n_max = std::max(n_max, tl[i]); }
+            r = ragged_tiles_per_piece(tl.data(), n_seq, cus(), scheme == SPECKV_COMP_FP8_E4M3 ? heads / 4u : 1u);
+        }
+        if (same_shape) {
+            plan_sticky = true;
+            g.max_splits = old->second.max_splits;
+            plan_rows_first = old->second.rows_first;
+        } else if (r && r < g.tps) {
+            g.max_splits = std::max(g.max_splits, std::min(16u, (n_max + r - 1u) / r));      // (16 pieces at most: the launches' scratch is sized for members x room)
+            plan_rows_first = true;
+        }
+        if (r && r < g.tps && g.max_splits > 1u) plan_tps = std::max(r, (n_max + g.max_splits - 1u) / g.max_splits);      // (pieces on account of the lengths, as many as there is room for)
+    }
+    if (plans_.size() >= 4096 && !plans_.count(d_plan)) plans_.clear();      // (buffers of long-gone steps; a graph captured over one of them must be captured anew after this)
     if (any_table)
         for (uint32_t i = 0; i < n_seq; ++i) seqs[i].lin_base = reinterpret_cast<const uint8_t*>(ents[i]);
     if (any_table && !d_zero_page_) {
@@ -585,15 +611,18 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
     std::vector<uint32_t> order(n_seq);
     // (always written when there is room -- the order as given for sequences of one length: a graph captured over this plan keeps reading it as the lengths change)
     const bool ordered = plan_bytes >= n_seq * (sizeof(AttendSeq) + sizeof(uint32_t));
-    if (ordered && (tuning().attend_order_as_given != 0 ||
-                    !attend_dispatch_order(seqs.data(), n_seq, attend_order_round(scheme == SPECKV_COMP_FP8_E4M3, scheme == SPECKV_COMP_MXFP4, heads, n_seq, cus()), order.data())))
+    const bool by_length = ordered && tuning().attend_order_as_given == 0 &&
+                           attend_dispatch_order(seqs.data(), n_seq, attend_order_round(scheme == SPECKV_COMP_FP8_E4M3, scheme == SPECKV_COMP_MXFP4, heads, n_seq, cus()), order.data());
+    if (ordered && !by_length)
         for (uint32_t i = 0; i < n_seq; ++i) order[i] = i;
-    plans_[d_plan] = PlanInfo{n_seq, scheme, min_layers, max_pos_end, any_striped, any_table, stripe_n_max, any_empty, ordered};
+    // (a first plan whose members differ in length and have pieces -- by whichever rule -- takes the rows-first grid, as the batch entry does)
+    if (!plan_sticky && by_length && g.max_splits > 1u) plan_rows_first = true;
+    plans_[d_plan] = PlanInfo{n_seq, scheme, min_layers, max_pos_end, any_striped, any_table, stripe_n_max, any_empty, ordered, g.max_splits, plan_rows_first, rule_tps, rule_splits};
     uint64_t parts = 0;
     for (uint32_t i = 0; i < n_seq; ++i) {
         const uint32_t n_tiles = seqs[i].n_splits;
-        const EvenSplit es = g.unequal.on ? unequal_pieces(g.unequal, n_tiles) : even_split(n_tiles, (n_tiles + g.tps - 1u) / g.tps);
-        seqs[i].tiles_per_split = n_tiles ? es.tiles_per_split : g.tps;
+        const EvenSplit es = g.unequal.on ? unequal_pieces(g.unequal, n_tiles) : even_split(n_tiles, (n_tiles + plan_tps - 1u) / plan_tps);
+        seqs[i].tiles_per_split = n_tiles ? es.tiles_per_split : plan_tps;
         seqs[i].n_splits = es.n_splits;
         seqs[i].part_base = static_cast<uint32_t>(parts);
         parts += static_cast<uint64_t>(heads) * seqs[i].n_splits;
@@ -631,7 +660,7 @@ int Engine::attend_planned_layers(int scheme, const void* d_plan, uint32_t n_seq
     const auto plan = plans_.find(d_plan);
     const bool one_launch = scheme == SPECKV_COMP_MXFP4 && plan != plans_.end() && layer_begin + n_layers <= plan->second.n_layers &&
                             static_cast<uint64_t>(n_seq) * n_layers <= 65535u && tuning().attend_layers_loop == 0 &&
-                            plan_geometry(false, n_seq, 8, max_pos_end, cus(), true, plan->second.mx4_stripe_n_max).max_splits == 1u;
+                            plan->second.max_splits == 1u;
     if (one_launch) return attend_planned(scheme, d_plan, n_seq, layer_begin, d_q_f16, g, max_pos_end, sm_scale, d_out, d_lse, s, tail, n_layers);
     // layer by layer; the position the caller still holds outside the pool is folded into ALL layers by one launch at the end (the
     // attention launches of the step then stand back to back: 8 layers of FP8, 256 x 2k, 7 fold launches and their gaps less)
@@ -666,7 +695,9 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
         SPECKV_ERR("speckv_ext_attend_*_planned: no plan of this shape at %p (n_seq, format and max_pos_end as planned, layer inside every layout)", d_plan);
         return SPECKV_ERR_INVAL;
     }
-    const PlanGeometry pg = plan_geometry(fp8, n_seq, heads, max_pos_end, cus(), mx4, plan->second.mx4_stripe_n_max);
+    PlanGeometry pg = plan_geometry(fp8, n_seq, heads, max_pos_end, cus(), mx4, plan->second.mx4_stripe_n_max);
+    pg.max_splits = plan->second.max_splits;                   // (what the first plan of this shape in this buffer fixed: attend_batch_plan)
+    pg.parts_bound = static_cast<uint64_t>(n_seq) * heads * pg.max_splits;
     DeviceScope device_scope(device_);
     const size_t acc_bytes = static_cast<size_t>(pg.parts_bound) * 16 * 128 * sizeof(float), ml_bytes = static_cast<size_t>(pg.parts_bound) * 32 * sizeof(float);
     uint8_t* buf = static_cast<uint8_t*>(scratch(s_attn_, acc_bytes + ml_bytes, s));      // (growth during a capture is refused: warm up once)
@@ -699,7 +730,7 @@ int Engine::attend_planned(int scheme, const void* d_plan, uint32_t n_seq, uint3
     if (mx4 && pg.max_splits == 1u && !plan->second.striped && !plan->second.table && static_cast<uint64_t>(n_seq) * ((g + 7u) / 8u) <= cus() &&
         tuning().attend_mx4_one_half == 0)
         k.mx4_halves = 1u;                                     // (see attend_batch)
-    if (pg.unequal.on) k.rows_first = 1u;
+    if (pg.unequal.on || plan->second.rows_first) k.rows_first = 1u;
     // The position the caller still holds outside the pool (TailArgs: a connector's odd last position).  MXFP4: folded in by the
     // attention kernel's own epilogue (split 0 of every sequence) -- needs a lse to be of use to nobody else, a batch without an
     // empty member (an empty sequence has no split to fold into) and the tail index by sequence; otherwise, and for the other

@@ -150,43 +150,28 @@ inline uint32_t fp8_batch_tiles_per_split(const uint32_t* tiles, uint32_t n_seq,
     return best;
 }
 
-// Sequences of DIFFERENT lengths on the kernels that run one workgroup per CU (MXFP4, INT4 whole-record): whole sequences make the longest
-// member the launch (256 x 1k .. 16k: INT4 0.48, MXFP4 0.66 of the HBM roofline where 256 x 8k run at 0.69 / 0.85).  With the sequences
-// dispatched longest first (dispatch_order_by_length) pieces pay where their number just fills whole rounds of the CUs: the same batch by
-// piece length, INT4 / MXFP4 -- 384 tiles 0.49 / 0.64, 256 (392 workgroups) 0.55 / 0.65, 192 (495 workgroups: two rounds) 0.62 / 0.73,
-// 128 (670) 0.51 / 0.62 (profiles/r06_ragged_batches.txt).  So: for 1, 2, 3 rounds the shortest piece length whose workgroup count stays
-// within the rounds, priced as  max(0.75 x longest piece, (F + last(r)) x mean piece x pieces(s))  with the kernel's PieceModel, against
-// whole sequences priced the same way; 0 = leave it to the rule for equal lengths (lengths within a quarter of their mean, or nothing gained).
-inline uint32_t ragged_tiles_per_piece(const uint32_t* tiles, uint32_t n_seq, uint32_t n_cus, const PieceModel& m)
+// Members of DIFFERENT lengths: whole sequences make the longest member the launch -- 256 members of 1k .. 16k on the one-workgroup-per-CU kernels: INT4 0.48,
+// MXFP4 0.66 of the HBM roofline where 256 x 8k run at 0.69 / 0.85; with a heavy tail (one member in 16 at 32k, the others 1k .. 4k) every format collapses: FP8 0.26,
+// INT4 0.12, MXFP4 0.20.  Dispatched by length (dispatch_order_by_length) and ROWS FIRST (every member's first piece, then the second pieces ...: with the
+// splits-first grid a batch in which few members have several pieces puts its real workgroups on one or two XCDs -- linear id = piece + pieces x member) pieces
+// pay as soon as the longest member exceeds a CU's fair share of the launch, share = tiles x workgroup columns per member / CUs (profiles/r06_ragged_batches.txt):
+//   256 x 1k .. 16k   share 272 (one column) -- INT4 0.48 -> 0.60, MXFP4 0.66 -> 0.71 with pieces of 128;  FP8 (two columns: share 544 >= the longest) whole 0.78, pieces 0.69-0.76
+//   512 x 1k .. 16k   share 534: whole sequences in order 0.70 / 0.80, pieces 0.68 / 0.73
+//   256, heavy tail   share 139 / 278 -- FP8 0.26 -> 0.53-0.58 (pieces of 128 / 64), INT4 0.12 -> 0.41 / 0.38, MXFP4 0.20 -> 0.49 / 0.44
+// -> pieces of a share's worth of tiles, 128 at most (32 at least, half the longest member at most) when the longest member is over 1.25 x share; 0 = no pieces on
+//    account of the lengths.
+inline uint32_t ragged_tiles_per_piece(const uint32_t* tiles, uint32_t n_seq, uint32_t n_cus, uint32_t columns_per_seq)
 {
     uint64_t total = 0;
     uint32_t n_max = 0;
     for (uint32_t i = 0; i < n_seq; ++i) { total += tiles[i]; n_max = tiles[i] > n_max ? tiles[i] : n_max; }
-    if (n_seq < 2u || n_cus == 0u || total == 0u || n_max < 2u * m.min_tiles) return 0u;
-    const double mean = static_cast<double>(total) / n_seq;
-    if (n_max <= 1.25 * mean) return 0u;
-    auto count = [&](uint32_t tps) { uint64_t w = 0; for (uint32_t i = 0; i < n_seq; ++i) w += (tiles[i] + tps - 1u) / tps; return w; };
-    auto cost = [&](uint32_t tps) {
-        const uint64_t w = count(tps);
-        const uint32_t sp = (n_max + tps - 1u) / tps;
-        const double full = static_cast<double>(w / n_cus), rest = static_cast<double>(w % n_cus) / n_cus;
-        const double last = rest > 0.0 ? (m.last_base + m.last_slope * rest > m.last_min ? m.last_base + m.last_slope * rest : m.last_min) : 0.0;
-        const double longest = static_cast<double>((n_max + sp - 1u) / sp);           // (a sequence's pieces are evened out: even_split)
-        const double rounds = (full + last) * (static_cast<double>(total) / static_cast<double>(w)) * (sp == 1u ? 1.0 : m.piece_base + m.piece_step * sp);
-        return rounds > 0.75 * longest ? rounds : 0.75 * longest;
-    };
-    const double whole = cost(n_max);
-    double best_cost = whole;
-    uint32_t best = 0u;
-    for (uint32_t k = 1u; k <= 3u; ++k) {
-        if (count(n_max) > static_cast<uint64_t>(k) * n_cus) continue;               // whole sequences already exceed k rounds
-        uint32_t lo = m.min_tiles, hi = n_max;                                        // smallest piece length with count <= k rounds (count falls as tps grows)
-        while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2u; if (count(mid) <= static_cast<uint64_t>(k) * n_cus) hi = mid; else lo = mid + 1u; }
-        if ((n_max + lo - 1u) / lo > 8u || lo >= n_max) continue;
-        const double c = cost(lo);
-        if (c < best_cost && c <= 0.95 * whole) { best_cost = c; best = lo; }
-    }
-    return best;
+    if (n_seq < 2u || n_cus == 0u || total == 0u || n_max < 64u) return 0u;
+    const double share = static_cast<double>(total) * columns_per_seq / n_cus;
+    if (n_max <= 1.25 * share) return 0u;
+    uint32_t tps = share >= 128.0 ? 128u : static_cast<uint32_t>(share + 0.5);      // (a share's worth, 128 tiles at most: 192 and 163 measured 10 % behind 128)
+    if (tps > n_max / 2u) tps = n_max / 2u;
+    if (tps < 32u) tps = 32u;
+    return (n_max + tps - 1u) / tps > 2048u ? (n_max + 2047u) / 2048u : tps;
 }
 
 // The order in which a batch's sequences are dispatched (Engine::attend_batch / attend_batch_plan; AttendArgs::order): by length, longest

@@ -393,8 +393,11 @@ speckv_status_t speckv_ext_attend_mx4_planned(const void* d_plan, uint32_t n_seq
  *       (what the size was before) still works, in the caller's order.
  *   speckv_ext_attend_{fp8,int4}_planned   one layer of the batch: kernel launches only (no look-ups, no staging,
  *       nothing allocated once the scratch is warm), so the per-layer calls of a step can be captured once and replayed
- *       for as long as every pos_end stays <= max_pos_end: grid, split length and scratch are functions of
- *       (n_seq, max_pos_end) alone; the lengths themselves are read from the plan on the device.
+ *       for as long as every pos_end stays <= max_pos_end: grid and scratch are functions of (n_seq, max_pos_end) and of
+ *       what the FIRST plan of that shape written into that buffer saw (a batch whose members differ much in length gets
+ *       room for pieces per member and a merge launch; every later plan of the shape in the buffer keeps that room, so the
+ *       captured launches stay valid); the lengths and piece lengths themselves are read from the plan on the device.
+ *       Capture AFTER the first plan of a shape, as before.
  * Arguments as for the batch calls; max_pos_end (even) must be the value given to the plan.  `stream` must not be NULL.
  * Run each shape once outside the capture first (scratch growth during a capture is refused with SPECKV_ERR_INVAL).
  * A plan names record addresses: plan again after an allocation of the batch was freed, re-created or migrated. */

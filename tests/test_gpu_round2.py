@@ -487,6 +487,75 @@ def test_planned_batch_attention_replays_under_a_graph(scheme):
         lib.finalize()
 
 
+@pytest.mark.parametrize("scheme", [4, 3, 5])
+@pytest.mark.parametrize("first", ["tail", "equal"])
+def test_a_plans_first_batch_fixes_the_room_for_pieces_under_a_graph(scheme, first):
+    """Members of different lengths get pieces on account of the lengths (ring_rule.hpp ragged_tiles_per_piece) and the rows-first grid -- decided by
+    the FIRST plan of a shape in a buffer, kept by every later plan of that shape there, because the launches may sit in a captured graph.  Capture
+    once behind the first plan, then replay behind plans of other length sets (a heavy tail, nearly equal lengths, a tail elsewhere, empty members):
+    every replay equals the per-sequence entry point.  `first` = what the first plan sees: a heavy tail (room for pieces, merge launch in the graph)
+    or equal lengths (no room: later tails run as whole sequences)."""
+    torch = torch_mod()
+    lib = open_lib()
+    try:
+        lib.set_compression_scheme(scheme)
+        single_fn = {4: lib.attend_fp8, 3: lib.attend_int4, 5: lib.attend_mx4}[scheme]
+        T, L, H, D, G = 4096, 1, 8, 128, 8
+        rng = np.random.default_rng(211)
+        n_seq = 24
+        tail = [int(v) * 2 for v in rng.integers(16, 200, n_seq)]
+        tail[3], tail[17] = T, T - 64                          # 128 tiles against ~7: far over a CU's share
+        equal = [2048 + 2 * i for i in range(n_seq)]
+        tail2 = [int(v) * 2 for v in rng.integers(1, 100, n_seq)]
+        tail2[0], tail2[23], tail2[7] = T, 0, 2
+        order = ([tail, equal, tail2, tail] if first == "tail" else [equal, tail, tail2, equal])
+        n_pages = T * L * H * D * 2 * 2 // PAGE
+        x = (rng.standard_normal((n_pages, N)) * rng.uniform(0.2, 2.0, (n_pages, 1))).astype(np.float16)
+        handles = []
+        for _ in range(n_seq):
+            h = lib.alloc(T * L * H * D * 2 * 2)
+            lib.set_layout(h, T, L, H, D, 2)
+            lib.write(h, 0, x.ctypes.data, x.nbytes, False)
+            handles.append(h)
+        sm = 1.0 / np.sqrt(D)
+        q = torch.from_numpy(rng.standard_normal((n_seq, H, G, D)).astype(np.float16)).cuda()
+        out = torch.zeros((n_seq, H, G, D), dtype=torch.float32, device="cuda")
+        lse = torch.zeros((n_seq, H, G), dtype=torch.float32, device="cuda")
+        plan_bytes = lib.attend_plan_bytes(n_seq)
+        plan = torch.zeros(plan_bytes, dtype=torch.uint8, device="cuda")
+        s = torch.cuda.Stream()
+        def run():
+            lib.attend_planned(scheme, plan.data_ptr(), n_seq, 0, q.data_ptr(), G, T, sm, out.data_ptr(), lse.data_ptr(), s.cuda_stream)
+        lib.attend_batch_plan(handles, order[0], T, plan.data_ptr(), plan_bytes, s.cuda_stream)
+        run(); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with graph_capture(g, s):
+            run()
+        one = torch.empty((H, G, D), dtype=torch.float32, device="cuda")
+        one_lse = torch.empty((H, G), dtype=torch.float32, device="cuda")
+        for lens in order:
+            lib.attend_batch_plan(handles, lens, T, plan.data_ptr(), plan_bytes, s.cuda_stream)
+            s.synchronize()
+            out.fill_(float("nan")); lse.fill_(float("nan"))
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            for i, (h, n) in enumerate(zip(handles, lens)):
+                if n == 0:
+                    assert float(out[i].abs().max()) == 0.0
+                    continue
+                single_fn(h, 0, 1, q[i].data_ptr(), G, 0, n, sm, one.data_ptr(), one_lse.data_ptr())
+                torch.cuda.synchronize()
+                scale = float(one.abs().max()) + 1e-6
+                assert float((out[i] - one).abs().max()) <= 1e-3 * scale, (first, i, n)
+                assert float((lse[i] - one_lse).abs().max()) <= 1e-4, (first, i, n)
+        del g
+        for h in handles:
+            lib.free(h)
+    finally:
+        lib.finalize()
+
+
 @pytest.mark.parametrize("subset", [False, True])
 def test_fold_tail_adds_one_position(subset):
     """speckv_ext_attend_fold_tail against the same three lines in float64: rows chosen by an index list or all of them,
