@@ -1093,17 +1093,20 @@ def int4_attention_extra(torch, kv, T, Lyr, scheme=3):
         lib.set_compression_scheme(2)
 
 
-def ragged_batch_extra(torch, kv, scheme=4, n_seq=256, lo=1024, hi=16384):
+def ragged_batch_extra(torch, kv, scheme=4, n_seq=256, lo=1024, hi=16384, tail=False):
     """One decode step's attention of ONE layer for a batch whose members DIFFER in length (uniform in lo .. hi positions, seeded): what a serving
-    batch looks like.  The engine dispatches such a batch by length (AttendArgs::order); `as_given` is the same call with the caller's order."""
+    batch looks like.  The engine dispatches such a batch by length (AttendArgs::order) and cuts members far over a CU's share into pieces
+    (ring_rule.hpp ragged_tiles_per_piece); `as_given` is the same call in the caller's order, whole sequences."""
     import numpy as np
     lib = kv.lib
-    name = {4: "fp8", 3: "int4_g32", 5: "mxfp4"}[scheme] + f"_{n_seq}_sequences_{lo}_to_{hi}"
+    name = {4: "fp8", 3: "int4_g32", 5: "mxfp4"}[scheme] + (f"_{n_seq}_sequences_one_in_16_at_{hi}_others_{lo}_to_{hi // 8}" if tail else f"_{n_seq}_sequences_{lo}_to_{hi}")
     rec = {4: 2048, 3: 1152, 5: 1088}[scheme]
     handles = []
     try:
         lib.set_compression_scheme(scheme)
         lens = [int(v) * 32 for v in np.random.default_rng(7).integers(lo // 32, hi // 32 + 1, n_seq)]
+        if tail:                                                         # a heavy tail: one member in 16 at `hi`, the others uniform in lo .. hi / 8
+            lens = [hi if i % 16 == 5 else int(v) * 32 for i, v in enumerate(np.random.default_rng(7).integers(lo // 32, max(lo // 32 + 1, hi // 256 + 1), n_seq))]
         g = torch.Generator(device="cuda"); g.manual_seed(2004)
         n_pages = hi * 8 * 128 * 2 * 2 // PAGE
         x = torch.randn((n_pages, BLOCK_ELEMS), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
@@ -1798,6 +1801,7 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
             off[f"{nm}_one_sequence_80_layers_4k"] = {k: r.get(k) for k in ("ms_all_layers", "frac_hbm", "error") if k in r}
         off.update(ragged_batch_extra(torch, kv, scheme=4))            # members of different lengths: dispatched by length (round 6)
         off.update(ragged_batch_extra(torch, kv, scheme=5, n_seq=512))
+        off.update(ragged_batch_extra(torch, kv, scheme=4, hi=32768, tail=True))      # ... with a heavy tail: pieces of a CU's share, the grid rows first
     except Exception as e:                                               # noqa: BLE001
         off["error"] = repr(e)
     ex["attention_off_round_sizes"] = dict(off, note="256 x 8k / 32k x 80 layers are the figures above; here: 32, 160 and 300 sequences x 8k (one layer per call, batch and planned "
