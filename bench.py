@@ -1122,8 +1122,10 @@ def ragged_batch_extra(torch, kv, scheme=4, n_seq=256, lo=1024, hi=16384, tail=F
         plan_bytes = lib.attend_plan_bytes(n_seq)
         d_plan = torch.empty(plan_bytes, dtype=torch.uint8, device="cuda")
         out = {"sequences": n_seq, "positions": f"{lo}..{hi} (mean {sum(lens) // n_seq})"}
+        plans = []
         for key, given in (("planned", 0), ("planned_as_given", 1)):
             set_tuning("attend_order_as_given", given)
+            d_plan = torch.empty(plan_bytes, dtype=torch.uint8, device="cuda"); plans.append(d_plan)      # (a buffer each: a plan's first batch fixes its launch geometry)
             lib.attend_batch_plan(handles, lens, hi, d_plan.data_ptr(), plan_bytes, s.cuda_stream)
             def step():
                 lib.attend_planned(scheme, d_plan.data_ptr(), n_seq, 0, q.data_ptr(), 8, hi, 0.08838834764831845, o.data_ptr(), lse.data_ptr(), s.cuda_stream)
