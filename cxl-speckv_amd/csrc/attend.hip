@@ -421,6 +421,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TABLE ? 3 :
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t c = lane & 15u, kb = lane >> 4;
     const uint32_t split = a.rows_first ? blockIdx.y : blockIdx.x, by = a.rows_first ? blockIdx.x : blockIdx.y;     // (rows_first: batches of members of different lengths)
+    if (a.rows_first && by >= a.rows_real) return;                      // (padding row: see AttendArgs::rows_real)
     const uint32_t hq = a.heads / 4u;
     uint32_t layer = by / hq;                                            // batch form: the sequence index
     if (a.seqs && a.order) layer = a.order[layer];                       // (workgroup-uniform)
@@ -865,6 +866,7 @@ __global__ __launch_bounds__(64 * SPECKV_FP8_WG_HEADS) __attribute__((amdgpu_wav
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t c = lane & 15u, kb = lane >> 4;
     const uint32_t split = a.rows_first ? blockIdx.y : blockIdx.x, by = a.rows_first ? blockIdx.x : blockIdx.y;
+    if (a.rows_first && by >= a.rows_real) return;                      // (padding row: see AttendArgs::rows_real)
     const uint32_t hq = a.heads / kFdHeads;
     uint32_t layer = by / hq;                                            // batch form: the sequence index
     if (a.seqs && a.order) layer = a.order[layer];                       // (workgroup-uniform)
@@ -1534,17 +1536,18 @@ hipError_t launch_attend_fp8_batch(const AttendArgs& a, uint32_t n_seq, float* d
     if (n_seq == 0 || a.n_splits == 0) return hipSuccess;
     // (rows_first: the sequences' first pieces side by side, then their second ones ...: a batch in which few members have several pieces would otherwise
     //  put every real workgroup on the same XCDs -- linear ids x + splits * y with most x > 0 empty)
-    auto grid_of = [&](uint32_t hq) { return a.rows_first ? dim3(n_seq * hq, a.n_splits) : dim3(a.n_splits, n_seq * hq); };
+    AttendArgs ar = a;
+    auto grid_of = [&](uint32_t hq) { ar.rows_real = n_seq * hq; return a.rows_first ? dim3((n_seq * hq) | 1u, a.n_splits) : dim3(a.n_splits, n_seq * hq); };
     // the batch form keeps the register-staged kernel: 256 sequences x 8k context, one layer: 0.69 of HBM peak against 0.67
     // with the LDS-DMA kernel (many short splits: 4 waves/SIMD hide more than two tiles per wave at 2 waves/SIMD); the
     // single-sequence form below is the other way round (8k x 80 layers: 0.61 against 0.55; 32k x 80: 0.70 both)
     if (a.fp8_cls && a.stripe_bases && !a.table_form)                   // every member placed regularly: pages by residue class
-        hipLaunchKernelGGL((k_attend_fp8_linear<false, false, true>), grid_of(a.heads / 4u), dim3(256), 0, s, a);
+        { const dim3 gr = grid_of(a.heads / 4u); hipLaunchKernelGGL((k_attend_fp8_linear<false, false, true>), gr, dim3(256), 0, s, ar); }
     else if (a.table_form && tuning().attend_fp8_table_regs == 0)       // striped / moved placements: the DMA pipeline with addresses from the page tables
-        hipLaunchKernelGGL(k_attend_fp8_dma<1>, grid_of(a.heads / kFdHeads), dim3(64 * kFdHeads), 0, s, a);
-    else if (a.table_form) hipLaunchKernelGGL((k_attend_fp8_linear<false, true>), grid_of(a.heads / 4u), dim3(256), 0, s, a);
-    else if (a.stripe_bases) hipLaunchKernelGGL(k_attend_fp8_linear<true>, grid_of(a.heads / 4u), dim3(256), 0, s, a);
-    else     hipLaunchKernelGGL(k_attend_fp8_linear<false>, grid_of(a.heads / 4u), dim3(256), 0, s, a);
+        { const dim3 gr = grid_of(a.heads / kFdHeads); hipLaunchKernelGGL(k_attend_fp8_dma<1>, gr, dim3(64 * kFdHeads), 0, s, ar); }
+    else if (a.table_form) { const dim3 gr = grid_of(a.heads / 4u); hipLaunchKernelGGL((k_attend_fp8_linear<false, true>), gr, dim3(256), 0, s, ar); }
+    else if (a.stripe_bases) { const dim3 gr = grid_of(a.heads / 4u); hipLaunchKernelGGL(k_attend_fp8_linear<true>, gr, dim3(256), 0, s, ar); }
+    else     { const dim3 gr = grid_of(a.heads / 4u); hipLaunchKernelGGL(k_attend_fp8_linear<false>, gr, dim3(256), 0, s, ar); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || (a.direct_out && a.direct_per_seq != 1u)) return e;      // every row final: no merge
     return launch_attend_combine(a, n_seq, d_out, d_lse, s);

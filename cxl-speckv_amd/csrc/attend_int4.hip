@@ -342,6 +342,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPECKV_INT4
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t c = lane & 15u, kb = lane >> 4;
     const uint32_t split = a.rows_first ? blockIdx.y : blockIdx.x, by = a.rows_first ? blockIdx.x : blockIdx.y;
+    if (a.rows_first && by >= a.rows_real) return;                      // (padding row: see AttendArgs::rows_real)
     const uint32_t hq = a.heads / 4u;
     uint32_t layer = by / hq;                                            // batch form: the sequence index
     if (a.seqs && a.order) layer = a.order[layer];                       // (workgroup-uniform)
@@ -712,6 +713,7 @@ __global__ __launch_bounds__(512 * HALVES) __attribute__((amdgpu_waves_per_eu(SP
     } else {
         const uint32_t split = a.rows_first ? blockIdx.y : blockIdx.x;
         cl = a.rows_first ? blockIdx.x : blockIdx.y;                      // batch form: the sequence index
+        if (a.rows_first && cl >= a.rows_real) return;                    // (padding row: see AttendArgs::rows_real)
         if (a.seqs && a.order) cl = a.order[cl];                          // (workgroup-uniform)
         part = (static_cast<uint64_t>(cl) * 8u + head) * a.n_splits + split;
         if (a.seqs) {                                                    // workgroup-uniform: per-sequence geometry
@@ -969,19 +971,22 @@ __global__ __launch_bounds__(512 * HALVES) __attribute__((amdgpu_waves_per_eu(SP
     store_partial(a, part, static_cast<uint64_t>(stream ? cl : out_row0) * 8u + head, my_splits, c, kb, m_run, l_run, acc);
 }
 
-hipError_t launch_attend_int4(const AttendArgs& a, uint32_t n_layers, hipStream_t s)
+hipError_t launch_attend_int4(const AttendArgs& a_in, uint32_t n_layers, hipStream_t s)
 {
+    AttendArgs a = a_in;
     if ((a.n_pages == 0 && !a.seqs) || n_layers == 0 || a.n_splits == 0) return hipSuccess;   // batch form: geometry per sequence
-    const dim3 wg_grid = a.rows_first ? dim3(n_layers * (a.heads / 4u), a.n_splits) : dim3(a.n_splits, n_layers * (a.heads / 4u));
+    const bool w8 = a.wg8 && a.heads == 8u && !a.table_form && (a.lin_base || a.stripe_bases);
+    a.rows_real = w8 ? n_layers : n_layers * (a.heads / 4u);            // (rows-first grids are padded to an odd number of rows: AttendArgs::rows_real)
+    const dim3 wg_grid = a.rows_first ? dim3((n_layers * (a.heads / 4u)) | 1u, a.n_splits) : dim3(a.n_splits, n_layers * (a.heads / 4u));
     if (a.table_form) { hipLaunchKernelGGL((k_attend_int4_wg<false, true>), wg_grid, dim3(256), 0, s, a); return hipGetLastError(); }
     if (a.wg8 && !a.lin_base && a.stripe_bases && a.heads == 8u) {       // striped regularly: the same kernel over residue classes
-        const dim3 grid8 = a.stream.n_wgs ? dim3(a.stream.n_wgs) : a.rows_first ? dim3(n_layers, a.n_splits) : dim3(a.n_splits, n_layers);
+        const dim3 grid8 = a.stream.n_wgs ? dim3(a.stream.n_wgs) : a.rows_first ? dim3(n_layers | 1u, a.n_splits) : dim3(a.n_splits, n_layers);
         if (a.stream.n_wgs || a.wg8 == 2u) hipLaunchKernelGGL((k_attend_int4_wg8<1, true>), grid8, dim3(512), 0, s, a);
         else hipLaunchKernelGGL((k_attend_int4_wg8<2, true>), grid8, dim3(1024), 0, s, a);
         return hipGetLastError();
     }
     if (a.wg8 && a.lin_base && a.heads == 8u) {                          // whole records per workgroup: one workgroup per (layer | sequence, split)
-        const dim3 grid8 = a.stream.n_wgs ? dim3(a.stream.n_wgs) : a.rows_first ? dim3(n_layers, a.n_splits) : dim3(a.n_splits, n_layers);
+        const dim3 grid8 = a.stream.n_wgs ? dim3(a.stream.n_wgs) : a.rows_first ? dim3(n_layers | 1u, a.n_splits) : dim3(a.n_splits, n_layers);
         if (a.stream.n_wgs || a.wg8 == 2u) hipLaunchKernelGGL(k_attend_int4_wg8<1>, grid8, dim3(512), 0, s, a);
         else hipLaunchKernelGGL(k_attend_int4_wg8<2>, grid8, dim3(1024), 0, s, a);
         return hipGetLastError();

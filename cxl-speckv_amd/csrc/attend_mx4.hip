@@ -190,6 +190,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg * HALVES) __attribute__((amdgpu_wa
     constexpr bool STREAM = FORM == 3, CLS = FORM == 1;
     const uint32_t split = a.rows_first ? blockIdx.y : blockIdx.x;       // (rows_first: batches of members of different lengths, see launch_attend_fp8_batch)
     uint32_t layer = a.rows_first ? blockIdx.x : blockIdx.y;             // batch form: the sequence index
+    if (a.rows_first && layer >= a.rows_real) return;                    // (padding row: see AttendArgs::rows_real)
     if (a.seqs && a.order) {                                             // (workgroup-uniform; several layers in one launch: y = layer x sequence)
         const uint32_t li = a.batch_n_seq ? layer / a.batch_n_seq : 0u;
         layer = li * a.batch_n_seq + a.order[layer - li * a.batch_n_seq];
@@ -798,14 +799,16 @@ __global__ __launch_bounds__(64 * kWavesPerWg * HALVES) __attribute__((amdgpu_wa
 
 // a.lin_base set: linear form; else a.stripe_bases: striped; else a.table_form: page-table form.  Writes the final rows itself
 // when a.direct_out allows it, else the split partials followed by launch_attend_combine.
-hipError_t launch_attend_mx4(const AttendArgs& a, uint32_t n_rows, float* d_out, float* d_lse, hipStream_t s)
+hipError_t launch_attend_mx4(const AttendArgs& a_in, uint32_t n_rows, float* d_out, float* d_lse, hipStream_t s)
 {
+    AttendArgs a = a_in;
+    a.rows_real = n_rows;
     if (n_rows == 0 || a.n_splits == 0 || a.heads != 8u) return a.heads != 8u ? hipErrorInvalidValue : hipSuccess;
     if (!a.seqs && a.n_pages == 0) return hipSuccess;
     const int form = a.lin_base ? (a.stream.n_wgs ? 3 : 0) : a.stripe_bases ? 1 : a.table_form ? 2 : -1;
     if (form == 1 && (a.skip_pages || (!a.seqs && (a.stripe_n < 1u || a.stripe_n > 8u)))) return hipErrorInvalidValue;
     if (form < 0 || (a.stream.n_wgs && (form != 3 || a.seqs || (a.n_pages & 15u) || a.skip_pages))) return hipErrorInvalidValue;
-    const dim3 grid = form == 3 ? dim3(a.stream.n_wgs, 1u, (a.g + 7u) / 8u) : a.rows_first ? dim3(n_rows, a.n_splits, (a.g + 7u) / 8u) : dim3(a.n_splits, n_rows, (a.g + 7u) / 8u);
+    const dim3 grid = form == 3 ? dim3(a.stream.n_wgs, 1u, (a.g + 7u) / 8u) : a.rows_first ? dim3(n_rows | 1u, a.n_splits, (a.g + 7u) / 8u) : dim3(a.n_splits, n_rows, (a.g + 7u) / 8u);
     const dim3 block(64 * kWavesPerWg);
     constexpr size_t lds_bytes = static_cast<size_t>(kWavesPerWg) * kStagesDefault * kStage;
     // more than 64 KiB of dynamic LDS has to be allowed per function AND per device: once for every device this process launches on

@@ -387,7 +387,7 @@ int Engine::attend_batch(int scheme, uint32_t n_seq, const uint64_t* handles, ui
     if ((fp8 || mx4 || wg8) && tuning().attend_tiles_per_split <= 0 && tuning().attend_order_as_given == 0) {
         std::vector<uint32_t> tl(n_seq);
         for (uint32_t i = 0; i < n_seq; ++i) tl[i] = seqs[i].n_splits;
-        const uint32_t r = ragged_tiles_per_piece(tl.data(), n_seq, cus(), fp8 ? heads / 4u : 1u);
+        const uint32_t r = ragged_tiles_per_piece(tl.data(), n_seq, cus(), fp8 ? heads / 4u : 1u, fp8 ? 4u : 1u);
         if (r && r < tps) tps = r;
     }
     const UnequalSplit unequal = (fp8 || mx4 || wg8) ? UnequalSplit{false, 1.0} : int4_unequal_split(n_seq, heads / 4u, tiles_max);
@@ -585,14 +585,16 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
         if (!g.unequal.on && tuning().attend_order_as_given == 0 && tuning().attend_tiles_per_split <= 0 && (scheme != SPECKV_COMP_INT4_G32 || heads == 8u)) {
             std::vector<uint32_t> tl(n_seq);
             for (uint32_t i = 0; i < n_seq; ++i) { tl[i] = seqs[i].n_splits; n_max = std::max(n_max, tl[i]); }
-            r = ragged_tiles_per_piece(tl.data(), n_seq, cus(), scheme == SPECKV_COMP_FP8_E4M3 ? heads / 4u : 1u);
+            r = ragged_tiles_per_piece(tl.data(), n_seq, cus(), scheme == SPECKV_COMP_FP8_E4M3 ? heads / 4u : 1u, scheme == SPECKV_COMP_FP8_E4M3 ? 4u : 1u);
         }
         if (same_shape) {
             plan_sticky = true;
             g.max_splits = old->second.max_splits;
             plan_rows_first = old->second.rows_first;
         } else if (r && r < g.tps) {
-            g.max_splits = std::max(g.max_splits, std::min(16u, (n_max + r - 1u) / r));      // (16 pieces at most: the launches' scratch is sized for members x room)
+            // (the launches' scratch is sized for members x heads x room: 32 768 partials = 270 MB at most, 8 pieces at least)
+            const uint32_t room = std::max(8u, 32768u / std::max(1u, n_seq * heads));
+            g.max_splits = std::max(g.max_splits, std::min(room, (n_max + r - 1u) / r));
             plan_rows_first = true;
         }
         if (r && r < g.tps && g.max_splits > 1u) plan_tps = std::max(r, (n_max + g.max_splits - 1u) / g.max_splits);      // (pieces on account of the lengths, as many as there is room for)

@@ -320,6 +320,8 @@ struct AttendArgs {
     // split -- split 0 of every row first.  With a long split 0 and a short split 1 per row the long pieces all start at
     // once and the short ones fill the remaining workgroup slots in turns (engine_attend.cpp: int4_unequal_split)
     uint32_t rows_first;
+    uint32_t rows_real;               // rows-first batch launches of the FP8 / MXFP4 kernels: grid x is padded to an ODD number of rows, so that the pieces of one member go round
+                                      // the XCDs (workgroup id % 8) instead of all landing on one; rows >= rows_real are padding and return at once
     // table form of the fast kernels (single-sequence form; lin_base and stripe_bases null): an allocation whose placement
     // is no longer regular (pages migrated one by one) but whose range is tile-aligned -- every record address comes
     // from the page-table entry, looked up one tile ahead of its request; never-written pages read zero_page

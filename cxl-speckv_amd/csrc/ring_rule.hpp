@@ -160,7 +160,9 @@ inline uint32_t fp8_batch_tiles_per_split(const uint32_t* tiles, uint32_t n_seq,
 //   256, heavy tail   share 139 / 278 -- FP8 0.26 -> 0.53-0.58 (pieces of 128 / 64), INT4 0.12 -> 0.41 / 0.38, MXFP4 0.20 -> 0.49 / 0.44
 // -> pieces of a share's worth of tiles, 128 at most (32 at least, half the longest member at most) when the longest member is over 1.25 x share; 0 = no pieces on
 //    account of the lengths.
-inline uint32_t ragged_tiles_per_piece(const uint32_t* tiles, uint32_t n_seq, uint32_t n_cus, uint32_t columns_per_seq)
+// slots_per_cu: workgroups the kernel needs resident per CU to run at its rate (FP8's register-staged batch kernel: 4 -- one alone on a CU reads at a third of its
+// share of the machine's rate: 64 members with a heavy tail, 300 workgroups of 70 tiles: 293 us for 0.57 GB; the LDS-DMA kernels: 1): the piece length aims at that many.
+inline uint32_t ragged_tiles_per_piece(const uint32_t* tiles, uint32_t n_seq, uint32_t n_cus, uint32_t columns_per_seq, uint32_t slots_per_cu = 1u)
 {
     uint64_t total = 0;
     uint32_t n_max = 0;
@@ -168,9 +170,11 @@ inline uint32_t ragged_tiles_per_piece(const uint32_t* tiles, uint32_t n_seq, ui
     if (n_seq < 2u || n_cus == 0u || total == 0u || n_max < 64u) return 0u;
     const double share = static_cast<double>(total) * columns_per_seq / n_cus;
     if (n_max <= 1.25 * share) return 0u;
-    uint32_t tps = share >= 128.0 ? 128u : static_cast<uint32_t>(share + 0.5);      // (a share's worth, 128 tiles at most: 192 and 163 measured 10 % behind 128)
+    const double per_slot = share / (slots_per_cu ? slots_per_cu : 1u);
+    uint32_t tps = per_slot >= 128.0 ? 128u : static_cast<uint32_t>(per_slot + 0.5);      // (a slot's worth, 128 tiles at most: 192 and 163 measured 10 % behind 128)
     if (tps > n_max / 2u) tps = n_max / 2u;
-    if (tps < 32u) tps = 32u;
+    const uint32_t floor_tiles = slots_per_cu > 1u ? 16u : 32u;
+    if (tps < floor_tiles) tps = floor_tiles;
     return (n_max + tps - 1u) / tps > 2048u ? (n_max + 2047u) / 2048u : tps;
 }
 

@@ -26,7 +26,7 @@ uint32_t rules_balanced_tiles_per_piece(const uint32_t* tiles, uint32_t n_seq, u
 }
 uint32_t rules_ragged_tiles_per_piece(const uint32_t* tiles, uint32_t n_seq, uint32_t n_cus, uint32_t model)
 {
-    return speckv::ragged_tiles_per_piece(tiles, n_seq, n_cus, model == 1u ? 2u : 1u);          // (model 1 = FP8 with 8 kv heads: two workgroup columns per member)
+    return speckv::ragged_tiles_per_piece(tiles, n_seq, n_cus, model == 1u ? 2u : 1u, model == 1u ? 4u : 1u);          // (model 1 = FP8 with 8 kv heads: two workgroup columns per member)
 }
 int rules_dispatch_order(const uint32_t* len, uint32_t n, uint32_t round, uint32_t* order) { return speckv::dispatch_order_by_length(len, n, round, order) ? 1 : 0; }
 // {on, first piece, pieces} of a sequence of n_tiles in an INT4 batch of `columns` workgroup columns whose longest member has tiles_max

@@ -477,7 +477,7 @@ def test_ragged_piece_length_rule(rules):
     t2 = rng.integers(32, 513, 512).astype(np.uint32)
     assert f(ptr(t2), 512, 256, 0) == 0                            # two machines' worth: whole sequences, longest first
     tail = rng.integers(32, 129, 256).astype(np.uint32); tail[5::16] = 1024
-    assert 100 <= f(ptr(tail), 256, 256, 0) <= 128 and f(ptr(tail), 256, 256, 1) == 128
+    assert 100 <= f(ptr(tail), 256, 256, 0) <= 128 and 55 <= f(ptr(tail), 256, 256, 1) <= 80       # FP8: a quarter of its share (four workgroups per CU)
     assert 32 <= f(ptr(tail[:64].copy()), 64, 256, 0) <= 40        # few members: short pieces, so that the long members spread over the machine
     same = np.full(256, 256, dtype=np.uint32)
     assert f(ptr(same), 256, 256, 0) == 0 and f(ptr(same[:1].copy()), 1, 256, 0) == 0
@@ -486,7 +486,7 @@ def test_ragged_piece_length_rule(rules):
         t = rng.integers(0, int(rng.integers(2, 3000)), n).astype(np.uint32)
         tps = f(ptr(t), n, 256, model)
         if tps:
-            assert 32 <= tps <= max(32, int(t.max()) // 2) and -(-int(t.max()) // tps) <= 2048
+            assert (16 if model == 1 else 32) <= tps <= max(32, int(t.max()) // 2) and -(-int(t.max()) // tps) <= 2048
 
 
 def test_int4_batch_unequal_split_rule(rules):
