@@ -170,6 +170,7 @@ inline uint32_t ragged_tiles_per_piece(const uint32_t* tiles, uint32_t n_seq, ui
     if (n_seq < 2u || n_cus == 0u || total == 0u || n_max < 64u) return 0u;
     const double share = static_cast<double>(total) * columns_per_seq / n_cus;
     if (n_max <= 1.25 * share) return 0u;
+    if (n_max <= 1.25 * (static_cast<double>(total) / n_seq)) return 0u;           // members of (nearly) one length: the rules for equal lengths (few of them are over a CU's share too)
     const double per_slot = share / (slots_per_cu ? slots_per_cu : 1u);
     uint32_t tps = per_slot >= 128.0 ? 128u : static_cast<uint32_t>(per_slot + 0.5);      // (a slot's worth, 128 tiles at most: 192 and 163 measured 10 % behind 128)
     if (tps > n_max / 2u) tps = n_max / 2u;

@@ -481,6 +481,7 @@ def test_ragged_piece_length_rule(rules):
     assert 32 <= f(ptr(tail[:64].copy()), 64, 256, 0) <= 40        # few members: short pieces, so that the long members spread over the machine
     same = np.full(256, 256, dtype=np.uint32)
     assert f(ptr(same), 256, 256, 0) == 0 and f(ptr(same[:1].copy()), 1, 256, 0) == 0
+    assert f(ptr(same[:32].copy()), 32, 256, 1) == 0 and f(ptr(same[:8].copy()), 8, 256, 0) == 0      # few members of one length are over a CU's share too: not this rule's business
     for _ in range(300):
         n = int(rng.integers(1, 700)); model = int(rng.choice([0, 1, 3]))
         t = rng.integers(0, int(rng.integers(2, 3000)), n).astype(np.uint32)
