@@ -210,13 +210,13 @@ def test_bench_gpus_2_starts_its_own_ranks():
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    """The bench line committed with the round's profile (profiles/r06e_bench.json = stdout of `python bench.py` on the
+    """The bench line committed with the round's profile (profiles/r06f_bench.json = stdout of `python bench.py` on the
     MI355X box) carries every field of the driver's contract, with the tier's meaning: metric and config from
     BASELINE.json, roofline and cpu_baseline objects, no model keys; `value` is the W + K region at steady clocks (ramped), the cold
     as-called figure and a sustained one stand beside it."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r06e_bench.json")))
+    d = json.load(open(os.path.join(root, "profiles", "r06f_bench.json")))
     base = json.load(open(os.path.join(root, "BASELINE.json")))
     assert d["metric"] in base["metric"] and d["unit"] == "blocks/s"
     for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
@@ -245,7 +245,7 @@ def test_committed_bench_line_has_the_contract_fields():
     f = d["extras"]["prefetch_flush"]
     assert f["requests"] == 8192 and f["pages_issued"] > 10000 and f["submit_ms"] < 0.1 and f["ms"] < 0.2
     # the 2-rank run on one GPU shows the three remote shapes with both engines
-    d2 = json.load(open(os.path.join(root, "profiles", "r06e_bench_2ranks_one_gpu.json")))       # started by bench.py itself: `python bench.py --gpus 2`
+    d2 = json.load(open(os.path.join(root, "profiles", "r06f_bench_2ranks_one_gpu.json")))       # started by bench.py itself: `python bench.py --gpus 2`
     assert d2["n_gpus"] == 2
     x = d2["xgmi"]
     assert set(x) >= {"cfg3", "cfg4", "symmetric", "accounting"}
@@ -254,7 +254,7 @@ def test_committed_bench_line_has_the_contract_fields():
     # ... and the 8-rank run on one GPU executes the 1 + 7 layout for real (7-way striping, D = 7 in the fetch kernel), with
     # the prefetch-flush leg of configs[2], the working-set statement, the copy engines' actual link bytes, and the top-level
     # remote roofline object of the rank-0 line
-    d8 = json.load(open(os.path.join(root, "profiles", "r06e_bench_8ranks_one_gpu.json")))
+    d8 = json.load(open(os.path.join(root, "profiles", "r06f_bench_8ranks_one_gpu.json")))
     assert d8["n_gpus"] == 8 and "watchdog_fired" not in d8
     x8 = d8["xgmi"]
     for mode in ("cfg3", "cfg4", "symmetric"):
@@ -280,7 +280,7 @@ def test_committed_bench_line_has_the_contract_fields():
     for mode in ("cfg3", "cfg4", "symmetric"):
         assert x8[mode]["engines_bit_identical"] is True, mode
     # the headline's evidence: the per-dispatch trace of the driver's command agrees with the bench's own HIP events
-    s = json.load(open(os.path.join(root, "profiles", "r06e_summary.json")))["traced_run"]
+    s = json.load(open(os.path.join(root, "profiles", "r06f_summary.json")))["traced_run"]
     for variant in ("as_called", "ramped", "sustained"):
         assert abs(s[variant]["trace_vs_hip_events"]) < 0.02, (variant, s[variant])
         assert abs(s[variant]["frac_from_trace"] - s[variant]["bench_frac_hbm"]) < 0.01
