@@ -34,6 +34,8 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <array>
+#include <map>
 #include <unordered_map>
 #include <vector>
 
@@ -359,6 +361,9 @@ private:
     struct PlanInfo { uint32_t n_seq; int scheme; uint32_t n_layers, max_pos_end; bool striped, table; uint32_t mx4_stripe_n_max; bool any_empty; bool ordered;
                       uint32_t max_splits; bool rows_first; uint32_t rule_tps, rule_splits; };      // (the launch geometry the FIRST plan of this shape in this buffer chose: attend_batch_plan)
     std::unordered_map<const void*, PlanInfo> plans_;      // device plan buffer -> what attend_batch_plan last wrote there
+    // (buffer, members | format, bound | rule's piece length, rule's pieces) -> {room for pieces, rows-first grid}: what the FIRST plan of that shape in that
+    // buffer chose -- kept per shape, so that a buffer that alternates between shapes keeps every shape's captured launches valid
+    std::map<std::array<uint64_t, 4>, std::pair<uint32_t, bool>> plan_rooms_;
     CompressGroup* d_groups_ = nullptr;    // device twin of grp_ring_ (4 slots): descriptors of a grouped compress launch
     uint8_t* d_zero_page_ = nullptr;     // stands in for never-written pages in the fused attention
     std::unordered_map<uint32_t, std::vector<int32_t>> hist_;

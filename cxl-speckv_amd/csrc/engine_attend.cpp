@@ -578,9 +578,9 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
     uint32_t plan_tps = g.tps;
     bool plan_rows_first = g.unequal.on, plan_sticky = false;
     {
-        const auto old = plans_.find(d_plan);
-        const bool same_shape = old != plans_.end() && old->second.n_seq == n_seq && old->second.scheme == scheme && old->second.max_pos_end == max_pos_end &&
-                                old->second.rule_tps == g.tps && old->second.rule_splits == g.max_splits;      // (... and the same rule for equal lengths: the tuning keys move it)
+        const std::array<uint64_t, 4> room_key{reinterpret_cast<uintptr_t>(d_plan), n_seq | (static_cast<uint64_t>(scheme) << 32), max_pos_end | (static_cast<uint64_t>(g.tps) << 32), g.max_splits};
+        const auto old = plan_rooms_.find(room_key);               // (... the rule for equal lengths is part of the shape: the tuning keys move it)
+        const bool same_shape = old != plan_rooms_.end();
         uint32_t r = 0, n_max = 0;
         if (!g.unequal.on && tuning().attend_order_as_given == 0 && tuning().attend_tiles_per_split <= 0 && (scheme != SPECKV_COMP_INT4_G32 || heads == 8u)) {
             std::vector<uint32_t> tl(n_seq);
@@ -589,8 +589,8 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
         }
         if (same_shape) {
             plan_sticky = true;
-            g.max_splits = old->second.max_splits;
-            plan_rows_first = old->second.rows_first;
+            g.max_splits = old->second.first;
+            plan_rows_first = old->second.second;
         } else if (r && r < g.tps) {
             // (the launches' scratch is sized for members x heads x room: 32 768 partials = 270 MB at most, 8 pieces at least)
             const uint32_t room = std::max(8u, 32768u / std::max(1u, n_seq * heads));
@@ -599,7 +599,7 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
         }
         if (r && r < g.tps && g.max_splits > 1u) plan_tps = std::max(r, (n_max + g.max_splits - 1u) / g.max_splits);      // (pieces on account of the lengths, as many as there is room for)
     }
-    if (plans_.size() >= 4096 && !plans_.count(d_plan)) plans_.clear();      // (buffers of long-gone steps; a graph captured over one of them must be captured anew after this)
+    if (plans_.size() >= 64 && !plans_.count(d_plan)) plans_.clear();        // (buffers of long-gone steps)
     if (any_table)
         for (uint32_t i = 0; i < n_seq; ++i) seqs[i].lin_base = reinterpret_cast<const uint8_t*>(ents[i]);
     if (any_table && !d_zero_page_) {
@@ -619,6 +619,10 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
         for (uint32_t i = 0; i < n_seq; ++i) order[i] = i;
     // (a first plan whose members differ in length and have pieces -- by whichever rule -- takes the rows-first grid, as the batch entry does)
     if (!plan_sticky && by_length && g.max_splits > 1u) plan_rows_first = true;
+    if (!plan_sticky) {
+        if (plan_rooms_.size() >= 4096) plan_rooms_.clear();   // (graphs captured over plans older than this must be captured anew: not a working set anyone has)
+        plan_rooms_[{reinterpret_cast<uintptr_t>(d_plan), n_seq | (static_cast<uint64_t>(scheme) << 32), max_pos_end | (static_cast<uint64_t>(rule_tps) << 32), rule_splits}] = {g.max_splits, plan_rows_first};
+    }
     plans_[d_plan] = PlanInfo{n_seq, scheme, min_layers, max_pos_end, any_striped, any_table, stripe_n_max, any_empty, ordered, g.max_splits, plan_rows_first, rule_tps, rule_splits};
     uint64_t parts = 0;
     for (uint32_t i = 0; i < n_seq; ++i) {
