@@ -1263,7 +1263,7 @@ def connector_append_extra(torch, kv, n_seq=256, Lyr=80, T=64):
         kv.lib.set_compression_scheme(2)
 
 
-def connector_decode_extra(torch, kv, n_seq=256, Lyr=8, ctx=2048, T=4096, scheme="fp8"):
+def connector_decode_extra(torch, kv, n_seq=256, Lyr=8, ctx=2048, T=4096, scheme="fp8", tail=False):
     """SURVEY 8f row N2 end to end: decode steps of a 256-sequence batch through the vLLM-shaped connector -- per step
     one look-ahead flush (begin_step), one fused attention call per layer for the whole batch, one batched append.  Only the
     KV side of a decode step (no model): what the drop-in costs per generated token at this batch and context."""
@@ -1271,16 +1271,21 @@ def connector_decode_extra(torch, kv, n_seq=256, Lyr=8, ctx=2048, T=4096, scheme
     conn = None
     try:
         conn = SpeckvKVConnector(kv.lib, num_layers=Lyr, max_tokens=T, scheme=scheme)
-        name = "connector_decode_step" if scheme == "fp8" else f"connector_decode_step_{scheme}"
+        name = ("connector_decode_step" if scheme == "fp8" else f"connector_decode_step_{scheme}") + ("_heavy_tail" if tail else "")
         rec_per_pos = {"fp8": 1024, "int4": 576, "mxfp4": 544}[scheme]
         ids = list(range(n_seq))
         g = torch.Generator(device="cuda"); g.manual_seed(2006)
         kp = torch.randn((Lyr, ctx, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
         vp = torch.randn((Lyr, ctx, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+        # tail: the prompts differ in length -- one request in 16 has ctx positions, the others ctx / 32 .. ctx / 8 (seeded): what a serving batch looks like
+        import numpy as np
+        lens = [ctx] * n_seq if not tail else [ctx if i % 16 == 5 else int(v) * 32 for i, v in enumerate(np.random.default_rng(11).integers(ctx // 1024, ctx // 256 + 1, n_seq))]
+        held = []
         for r in ids:
             conn.add_request(r)
-            conn.write_prefill(r, kp, vp)                     # same synthetic prompt KV in every sequence
-        del kp, vp
+            held.append(conn.write_prefill(r, kp[:, :lens[r]], vp[:, :lens[r]]))      # the same synthetic prompt KV (a prefix of it) in every sequence
+        torch.cuda.synchronize()                               # (the launches read the tensors they were given: held until they have run)
+        del kp, vp, held
         q = torch.randn((n_seq, 8, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
         k = torch.randn((n_seq, Lyr, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
         v = torch.randn((n_seq, Lyr, 8, 128), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
@@ -1304,8 +1309,8 @@ def connector_decode_extra(torch, kv, n_seq=256, Lyr=8, ctx=2048, T=4096, scheme
                 del keep, out
         ms_all = sum(times_all[2:]) / len(times_all[2:])
         ms = sum(times[2:]) / len(times[2:])                   # even and odd steps alternate (tail fold / pair append)
-        rec_bytes = n_seq * Lyr * 2 * ctx * rec_per_pos          # record bytes read per step (K and V; FP8 1 KiB per position and kind, MXFP4 544 B)
-        return {name: {"sequences": n_seq, "layers": Lyr, "context": ctx, "ms_per_step": round(ms, 3),
+        rec_bytes = Lyr * 2 * sum(lens) * rec_per_pos            # record bytes read per step (K and V; FP8 1 KiB per position and kind, MXFP4 544 B)
+        return {name: {"sequences": n_seq, "layers": Lyr, "context": ctx if not tail else f"one in 16 at {ctx}, the others {ctx // 32}..{ctx // 8} (mean {sum(lens) // n_seq})", "ms_per_step": round(ms, 3),
                                           "ms_fastest_step": round(min(times[2:]), 3), "ms_slowest_step": round(max(times[2:]), 3),
                                           "ms_per_step_layers_in_one_call": round(ms_all, 3), "frac_hbm_layers_in_one_call": round(rec_bytes / (ms_all * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                           "tokens_per_s_kv_side": round(n_seq / (ms * 1e-3), 1),
@@ -1316,7 +1321,7 @@ def connector_decode_extra(torch, kv, n_seq=256, Lyr=8, ctx=2048, T=4096, scheme
                                                   "layers' attention as ONE call (SpeckvKVConnector.attend_layers: for callers that have several layers' query rows at once; over an "
                                                   "MXFP4 pool one launch); " + scheme + " pool"}}
     except Exception as e:
-        return {"connector_decode_step" if scheme == "fp8" else f"connector_decode_step_{scheme}": {"error": repr(e)}}
+        return {("connector_decode_step" if scheme == "fp8" else f"connector_decode_step_{scheme}") + ("_heavy_tail" if tail else ""): {"error": repr(e)}}
     finally:
         if conn is not None:
             for r in list(conn.requests):
@@ -1811,6 +1816,7 @@ def run_engine_extras(torch, kv, handle, n_blocks, T, Lyr):
     ex.update(connector_append_extra(torch, kv))
     ex.update(connector_decode_extra(torch, kv))
     ex.update(connector_decode_extra(torch, kv, scheme="mxfp4"))      # the same decode step over an MXFP4 pool (half the record bytes of FP8)
+    ex.update(connector_decode_extra(torch, kv, ctx=16384, T=16384 + 64, scheme="fp8", tail=True))      # prompts of very different lengths (round 6: pieces, dispatch order)
     ex.update(kv_accuracy_extra(torch, kv))
     ex.update(predictor_extra(torch, lib))
     ex.update(lstm_cell_extra(torch, lib))
