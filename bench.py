@@ -1307,8 +1307,13 @@ def connector_decode_extra(torch, kv, n_seq=256, Lyr=8, ctx=2048, T=4096, scheme
                 torch.cuda.synchronize()
                 (times_all if all_layers else times).append((time.perf_counter() - t0) * 1e3)
                 del keep, out
-        ms_all = sum(times_all[2:]) / len(times_all[2:])
-        ms = sum(times[2:]) / len(times[2:])                   # even and odd steps alternate (tail fold / pair append)
+        # the median of the steps (even and odd steps alternate -- tail fold / pair append -- so of six steps the mean of the middle two): one stalled step of
+        # 11 ms (seen once, in both FP8 loops of one process, never again) no longer doubles the figure; fastest and slowest stand beside it
+        def med(v):
+            v = sorted(v); n = len(v)
+            return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+        ms_all = med(times_all[2:])
+        ms = med(times[2:])
         rec_bytes = Lyr * 2 * sum(lens) * rec_per_pos            # record bytes read per step (K and V; FP8 1 KiB per position and kind, MXFP4 544 B)
         return {name: {"sequences": n_seq, "layers": Lyr, "context": ctx if not tail else f"one in 16 at {ctx}, the others {ctx // 32}..{ctx // 8} (mean {sum(lens) // n_seq})", "ms_per_step": round(ms, 3),
                                           "ms_fastest_step": round(min(times[2:]), 3), "ms_slowest_step": round(max(times[2:]), 3),
@@ -1317,7 +1322,7 @@ def connector_decode_extra(torch, kv, n_seq=256, Lyr=8, ctx=2048, T=4096, scheme
                                           "KV_record_GBps": round(rec_bytes / (ms * 1e-3) / 1e9, 1),
                                           "frac_hbm": round(rec_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                           "note": "begin_step (a no-op for fused pools since round 6) + one batch attention call per layer (the tail position goes along in the call) + batched "
-                                                  "append (which plans the next step), wall time per step incl. the torch glue; ms_per_step_layers_in_one_call: the same step with the "
+                                                  "append (which plans the next step), wall time per step incl. the torch glue (median of the steps); ms_per_step_layers_in_one_call: the same step with the "
                                                   "layers' attention as ONE call (SpeckvKVConnector.attend_layers: for callers that have several layers' query rows at once; over an "
                                                   "MXFP4 pool one launch); " + scheme + " pool"}}
     except Exception as e:
