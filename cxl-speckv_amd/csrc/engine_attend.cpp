@@ -582,7 +582,9 @@ int Engine::attend_batch_plan(uint32_t n_seq, const uint64_t* handles, const uin
         const auto old = plan_rooms_.find(room_key);               // (... the rule for equal lengths is part of the shape: the tuning keys move it)
         const bool same_shape = old != plan_rooms_.end();
         uint32_t r = 0, n_max = 0;
-        if (!g.unequal.on && tuning().attend_order_as_given == 0 && tuning().attend_tiles_per_split <= 0 && (scheme != SPECKV_COMP_INT4_G32 || heads == 8u)) {
+        // (INT4: on the whole-record kernel only, as in attend_batch)
+        const bool int4_wg8 = scheme == SPECKV_COMP_INT4_G32 && heads == 8u && (!any_striped || int4_cls) && !any_table;
+        if (!g.unequal.on && tuning().attend_order_as_given == 0 && tuning().attend_tiles_per_split <= 0 && (scheme != SPECKV_COMP_INT4_G32 || int4_wg8)) {
             std::vector<uint32_t> tl(n_seq);
             for (uint32_t i = 0; i < n_seq; ++i) { tl[i] = seqs[i].n_splits; n_max = std::max(n_max, tl[i]); }
             r = ragged_tiles_per_piece(tl.data(), n_seq, cus(), scheme == SPECKV_COMP_FP8_E4M3 ? heads / 4u : 1u, scheme == SPECKV_COMP_FP8_E4M3 ? 4u : 1u);
